@@ -1,0 +1,169 @@
+/* recengine — C-ABI of the MI355X-native sparse-embedding + feature-interaction engine that
+ * stands in for the Paddle ops on the hot path of PaddleRec's models/rank CTR stack.
+ *
+ * The reference has no FFI seam of its own: the seam is the Paddle operator API used inside
+ * net.py.  Each entry point below names the reference call site whose Paddle
+ * ops it replaces; a Paddle custom-op shim (PD_BUILD_OP) or the ctypes/torch
+ * adapter in paddlerec_amd/ binds exactly these symbols.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless marked "host".
+ *   - the caller owns every buffer (tables, outputs, workspace); nothing is retained.
+ *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*); no internal sync.
+ *   - return 0 on success or a negative rec_status; rec_last_error() gives thread-local text.
+ *   - `status` arguments are device int32 words the kernels OR error bits into
+ *     (REC_FLAG_*), so out-of-range indices are reported without a host sync.
+ *   - tables are row-major f32 [num_rows, row_stride] with row_stride >= emb_dim (floats).
+ */
+#ifndef RECENGINE_H_
+#define RECENGINE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  REC_OK = 0,
+  REC_EINVAL = -1,     /* null pointer / negative size / unsupported combination */
+  REC_ESHAPE = -2,     /* dimension outside what the kernels are built for */
+  REC_EWORKSPACE = -3, /* workspace too small (query *_workspace_bytes first) */
+  REC_EHIP = -4,       /* HIP runtime error at launch */
+  REC_ENCCL = -5
+} rec_status;
+
+/* bits OR-ed into a device status word */
+#define REC_FLAG_INDEX_OOB 1 /* an id was < 0 or >= num_rows (Paddle raises on OOB [EXT]) */
+
+const char* rec_last_error(void); /* host; thread-local */
+int rec_version(void);            /* host */
+
+/* ------------------------------------------------------------------------------------------
+ * DeepFM: embedding lookup + FM first/second order, fused.
+ * Replaces concat + Embedding x2 + multiply/unsqueeze/sum/square/concat of
+ *   models/rank/deepfm/net.py:105-139 (FM.forward).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t batch;       /* B */
+  int32_t num_slots;   /* S  (26) : sparse fields, one id each */
+  int32_t num_dense;   /* Dn (13) : dense fields, <= 16 */
+  int32_t emb_dim;     /* D  <= 256 */
+  int32_t row_stride;  /* floats between consecutive rows of W (>= D); W1 has stride 1 */
+  int64_t num_rows;    /* N rows in W / W1 (after slot offsets) */
+  int64_t padding_idx; /* id that yields a zero row and no gradient; < 0 = none */
+} rec_deepfm_desc;
+
+/* ids [B,S] i64 (= paddle.concat(sparse_inputs,1), net.py:107); dense [B,Dn] f32;
+ * W [N,stride], W1 [N]; dense_w [Dn,D]; dense_w_one [Dn];
+ * slot_offset [S] i64 or NULL: row = id + slot_offset[s] (26 tables laid out as one);
+ * outputs y1,y2 [B]; feat [B,S+Dn,D] (= feat_embeddings, net.py:120);
+ * sum_emb [B,D] (= summed_features_emb, net.py:124; kept for backward). */
+int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids, const float* dense,
+                      const float* W, const float* W1, const float* dense_w,
+                      const float* dense_w_one, const int64_t* slot_offset, float* y1, float* y2,
+                      float* feat, float* sum_emb, int32_t* status, void* stream);
+
+/* Backward of the block above (what loss.backward(), tools/trainer.py:151, runs for net.py:105-139).
+ * In : dense, feat, sum_emb (saved by fwd), d_feat_dnn [B,S+Dn,D], dy1, dy2 [B].
+ * Out: row_grad [B*S, D]  — SelectedRows.value of `embedding` (rows = flattened ids, unmerged);
+ *      d_dense_w [Dn,D], d_dense_w_one [Dn] — batch sums, reduced in a fixed order (deterministic).
+ *      The SelectedRows.value of `embedding_one` is dy1[b] for every (b,s); it is not
+ *      materialised — rec_sparse_adam_rows reads dy1 through grad_div = S. */
+int rec_deepfm_fm_bwd_workspace_bytes(const rec_deepfm_desc* desc, size_t* bytes);
+int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense, const float* feat,
+                      const float* sum_emb, const float* d_feat_dnn, const float* dy1,
+                      const float* dy2, float* row_grad, float* d_dense_w, float* d_dense_w_one,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Plain lookup and LoD sum-pool.
+ *   rec_emb_gather         : nn.Embedding forward (deepfm/net.py:108,117; dcn_v2/net.py:93-96;
+ *                            din/net.py:141-147).  out[i,:] = id==padding_idx ? 0 : W[id,:]
+ *   rec_emb_gather_sumpool : sparse_embedding + sequence_pool('sum')
+ *                            (models/rank/slot_dnn/net.py:63-75; dnn/static_model_lod.py:70-97).
+ *                            out[b,:] = sum_{k in [lod[b],lod[b+1])} W[ids[k],:], padding ids skipped;
+ *                            counts[b] = number of non-padding ids pooled (bit-exact).
+ * ---------------------------------------------------------------------------------------- */
+int rec_emb_gather(int64_t n, int32_t emb_dim, int32_t row_stride, int64_t num_rows,
+                   int64_t padding_idx, const int64_t* ids, const float* W, float* out,
+                   int32_t* status, void* stream);
+int rec_emb_gather_sumpool(int64_t batch, int32_t emb_dim, int32_t row_stride, int64_t num_rows,
+                           int64_t padding_idx, const int64_t* ids, const int64_t* lod /*[B+1]*/,
+                           const float* W, float* out, int32_t* counts, int32_t* status,
+                           void* stream);
+/* backward of the sum-pool: SelectedRows.value[k,:] = d_out[sample(k),:]  (rows = ids). */
+int rec_emb_sumpool_bwd(int64_t batch, int32_t emb_dim, const int64_t* lod, const float* d_out,
+                        float* row_grad, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SelectedRows merge (MergeAdd [EXT]) — integer part: group the n = B*S lookups by row.
+ * Replaces the duplicate-row merge every consumer of a sparse=True embedding gradient performs
+ * (deepfm/net.py:62-70,80 `sparse=use_sparse`).
+ *   sorted_pos [n] i32 : positions (b*S+s) stably sorted by row; padding hits are dropped
+ *   uniq_rows  [n] i64 : first n_uniq entries = distinct rows, ascending
+ *   seg_offset [n+1] i32: sorted_pos[seg_offset[u] .. seg_offset[u+1]) belong to uniq_rows[u]
+ *   n_uniq     [2] i32 : {number of distinct rows, number of non-padding positions}
+ * All four are bit-exact targets.
+ * ---------------------------------------------------------------------------------------- */
+int rec_ids_group_workspace_bytes(int64_t n, int64_t num_rows, size_t* bytes);
+int rec_ids_group(int64_t n, int32_t num_slots, int64_t num_rows, int64_t padding_idx,
+                  const int64_t* ids, const int64_t* slot_offset, int32_t* sorted_pos,
+                  int64_t* uniq_rows, int32_t* seg_offset, int32_t* n_uniq, int32_t* status,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizers.  paddle.optimizer.Adam [EXT] (deepfm/dygraph_model.py:61-65, static_model.py:83-84):
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m = b1*m+(1-b1)*g;  v = b2*v+(1-b2)*g*g;
+ *   p -= lr_t * m / (sqrt(v) + eps*sqrt(1-b2^t))
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  float lr, beta1, beta2, eps;
+  int64_t step; /* t, 1-based */
+} rec_adam_hyper;
+
+/* lazy_mode=True Adam on the rows of a merged SelectedRows gradient, merge fused in:
+ *   g[u,:] = sum_{k in seg(u)} grad[(sorted_pos[k] / grad_div) * D .. +D]   (ascending position order)
+ * then Adam on rows uniq_rows[u] of P/M/V ([num_rows,row_stride]).  n_uniq is read on the device.
+ * grad_div = 1 with grad = row_grad [n,D];  grad_div = S, D = 1 with grad = dy1 [B] updates W1. */
+int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride, const int32_t* n_uniq,
+                         const int64_t* uniq_rows, const int32_t* seg_offset,
+                         const int32_t* sorted_pos, const float* grad, int32_t grad_div, float* P,
+                         float* M, float* V, const rec_adam_hyper* hyper, void* stream);
+
+/* dense Adam over a flat buffer (MLP + FM dense weights). */
+int rec_adam_dense(int64_t n, float* p, float* m, float* v, const float* g,
+                   const rec_adam_hyper* hyper, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss head: predict = sigmoid(y1+y2+y_dnn) (deepfm/net.py:47);
+ *            cost = log_loss(pred,label,eps=1e-4); avg = mean(cost) (deepfm/dygraph_model.py:53-58)
+ * and its gradient dz = d avg / d z.  loss_out[0] = avg (reduced in a fixed order).
+ * y2 / y_dnn may be NULL (treated as 0).  workspace >= rec_logloss_workspace_bytes(B).
+ * ---------------------------------------------------------------------------------------- */
+int rec_logloss_workspace_bytes(int64_t batch, size_t* bytes);
+int rec_sigmoid_logloss(int64_t batch, const float* y1, const float* y2, const float* y_dnn,
+                        const int64_t* label, float eps, float* pred, float* dz, float* loss_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* paddle.metric.Auc("ROC").update [EXT] (deepfm/dygraph_model.py:69-73,83-84):
+ *   bucket = int(pred*num_thresholds); stat_pos[bucket] += label!=0; stat_neg[bucket] += label==0.
+ * stat_pos/stat_neg are i64 [num_thresholds+1], accumulated (not cleared). */
+int rec_auc_histogram(int64_t batch, const float* pred, const int64_t* label,
+                      int32_t num_thresholds, int64_t* stat_pos, int64_t* stat_neg, void* stream);
+
+/* Row H — feature hash, HOST function: xxh32(str(field_idx)+value) % hash_dim
+ * (models/rank/dnn/benchmark_reader.py:52).  `bytes` = the concatenated string. */
+uint32_t rec_xxh32(const void* bytes, size_t len, uint32_t seed);
+int rec_xxh32_hash_mod(const char* const* strings, const int32_t* field_idx, int64_t n,
+                       uint32_t hash_dim, int64_t* out);
+
+/* Fills buf[i] = i-th value of a counter-based generator, uniform in [lo,hi) — used to initialise
+ * multi-GB tables on the device without a host round trip. */
+int rec_fill_uniform(int64_t n, float* buf, float lo, float hi, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECENGINE_H_ */

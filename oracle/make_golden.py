@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by executing the reference's UNMODIFIED net.py files.
+
+Runs only in the build container (needs /root/reference); the GPU box uses the committed
+fixtures.  `paddle` resolves to oracle/paddle_shim (torch-CPU stand-in), so
+what is pinned is the reference's own graph code — op order, shapes, padding handling, the DIN
+duplicate-sublayer quirk — not Paddle's kernels (those are [EXT], not installable here).
+
+    python oracle/make_golden.py            # rewrites tests/golden/*.npz deterministically
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get("PADDLEREC_REF", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, os.path.join(HERE, "paddle_shim"))
+
+
+def load_ref_module(rel, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def make_ids(rng, B, S, N, pad_frac=0.1, dup=True):
+    ids = rng.integers(1, N, size=(B, S), dtype=np.int64)
+    if dup:  # force duplicate rows inside the batch (SelectedRows merge path)
+        ids[1::2, : S // 2] = ids[0::2, : S // 2][: ids[1::2].shape[0]]
+    ids[rng.random((B, S)) < pad_frac] = 0
+    return ids
+
+
+def golden_deepfm(D, seed):
+    """models/rank/deepfm/net.py:21-174 + dygraph_model.py:53-58 (loss)."""
+    import paddle  # the shim
+    net = load_ref_module("models/rank/deepfm/net.py", "ref_deepfm_net")
+    rng = np.random.default_rng(seed)
+    N, S, Dn, B, fc = 1001, 26, 13, 12, [32, 16]
+    torch.manual_seed(seed)
+    model = net.DeepFMLayer(N, D, Dn, S, fc)
+    ids = make_ids(rng, B, S, N)
+    dense = rng.random((B, Dn), dtype=np.float32)
+    label = (rng.random((B, 1)) < 0.3).astype(np.int64)
+    sparse_inputs = [paddle.to_tensor(ids[:, s:s + 1]) for s in range(S)]   # list of [B,1] int64
+    pred = model.forward(sparse_inputs, paddle.to_tensor(dense))
+    # deepfm/dygraph_model.py:53-58
+    cost = paddle.nn.functional.log_loss(input=pred, label=paddle.cast(paddle.to_tensor(label),
+                                                                        dtype="float32"))
+    loss = paddle.mean(x=cost)
+    y1, y2, feat = model.fm.forward(sparse_inputs, paddle.to_tensor(dense))
+    loss.backward()
+    g = dict(
+        ids=ids, dense=dense, label=label, D=np.int64(D),
+        W=npy(model.fm.embedding.weight), W1=npy(model.fm.embedding_one.weight),
+        dense_w=npy(model.fm.dense_w), dense_w_one=npy(model.fm.dense_w_one),
+        pred=npy(pred), loss=npy(loss), y1=npy(y1), y2=npy(y2), feat=npy(feat),
+        gW=npy(model.fm.embedding.weight.grad), gW1=npy(model.fm.embedding_one.weight.grad),
+        g_dense_w=npy(model.fm.dense_w.grad), g_dense_w_one=npy(model.fm.dense_w_one.grad),
+    )
+    lin = [m for m in model.dnn._mlp_layers if hasattr(m, "weight")]
+    for i, l in enumerate(lin):
+        g[f"mlp_w{i}"], g[f"mlp_b{i}"] = npy(l.weight), npy(l.bias)
+        g[f"g_mlp_w{i}"], g[f"g_mlp_b{i}"] = npy(l.weight.grad), npy(l.bias.grad)
+    g["n_mlp"] = np.int64(len(lin))
+    np.savez_compressed(os.path.join(OUT, f"deepfm_D{D}.npz"), **g)
+    print("deepfm D=%d loss=%.6f" % (D, float(loss)))
+
+
+def golden_dcn_v2(mix, seed):
+    """models/rank/dcn_v2/net.py:20-320 in eval() mode (Dropout off — Appendix B-10)."""
+    import paddle
+    net = load_ref_module("models/rank/dcn_v2/net.py", "ref_dcn_net")
+    rng = np.random.default_rng(seed)
+    N, S, Dn, B, D, fc = 501, 26, 13, 6, 4, [24, 16]
+    torch.manual_seed(seed)
+    model = net.DCN_V2Layer(N, D, Dn, S, fc, cross_num=3 if not mix else 2, is_Stacked=True,
+                            use_low_rank_mixture=mix, low_rank=8, num_experts=4)
+    model.eval()
+    # give the zero-initialised biases some signal so a bias bug cannot hide
+    with torch.no_grad():
+        for p_name, p in model.named_parameters():
+            if "bias" in p_name:
+                p.copy_(torch.from_numpy(rng.standard_normal(tuple(p.shape)).astype(np.float32) * 0.1))
+    ids = make_ids(rng, B, S, N)
+    dense = np.log(rng.random((B, Dn), dtype=np.float32) * 50 + 1).astype(np.float32)  # reader.py:63-64
+    sparse_inputs = [paddle.to_tensor(ids[:, s:s + 1]) for s in range(S)]
+    pred = model.forward(sparse_inputs, paddle.to_tensor(dense))
+    emb = model.embedding(paddle.concat(sparse_inputs, axis=1))
+    feat = paddle.concat([paddle.reshape(emb, [-1, S * D]), model.dense_emb(paddle.to_tensor(dense))], 1)
+    cross = model.DeepCrossLayer_(feat)
+    pred.sum().backward()
+    g = dict(ids=ids, dense=dense, pred=npy(pred), feat=npy(feat), cross=npy(cross),
+             mix=np.int64(mix))
+    for k, v in model.state_dict().items():
+        g["p." + k] = npy(v)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            g["g." + k] = npy(p.grad)
+    np.savez_compressed(os.path.join(OUT, f"dcn_v2_{'mix' if mix else 'v2'}.npz"), **g)
+    print("dcn_v2 mix=%d pred[0]=%.6f" % (mix, float(pred[0])))
+
+
+def golden_din(seed):
+    """models/rank/din/net.py:20-184 + mask construction of din/dinReader.py:81-99."""
+    import paddle
+    net = load_ref_module("models/rank/din/net.py", "ref_din_net")
+    rng = np.random.default_rng(seed)
+    B, T, item_count, cat_count, E = 5, 7, 301, 41, 8
+    torch.manual_seed(seed)
+    model = net.DINLayer(E, E, "sigmoid", False, True, item_count, cat_count)
+    with torch.no_grad():
+        model.item_b_attr.weight.copy_(torch.from_numpy(
+            rng.standard_normal((item_count, 1)).astype(np.float32) * 0.1))
+    lens = np.array([7, 3, 1, 5, 7])
+    hist_item = np.zeros((B, T), np.int64)
+    hist_cat = np.zeros((B, T), np.int64)
+    mask = np.zeros((B, T, 1), np.float32)
+    for b in range(B):
+        hist_item[b, : lens[b]] = rng.integers(1, item_count, lens[b])
+        hist_cat[b, : lens[b]] = rng.integers(1, cat_count, lens[b])
+        mask[b, lens[b]:, 0] = -1e9                       # dinReader.py:81-84
+    mask_i64 = mask.astype(np.int64)                      # dinReader.py:99  (cast to int64)
+    target_item = rng.integers(1, item_count, B).astype(np.int64)
+    target_cat = rng.integers(1, cat_count, B).astype(np.int64)
+    target_item_seq = np.repeat(target_item[:, None], T, 1)
+    target_cat_seq = np.repeat(target_cat[:, None], T, 1)
+    label = (rng.random((B, 1)) < 0.5).astype(np.float32)
+    tt = paddle.to_tensor
+    logit = model.forward(tt(hist_item), tt(hist_cat), tt(target_item), tt(target_cat), tt(label),
+                          tt(mask_i64), tt(target_item_seq), tt(target_cat_seq))
+    loss = paddle.nn.functional.binary_cross_entropy_with_logits(logit, tt(label))  # dygraph_model.py:58-61
+    loss.backward()
+    g = dict(hist_item=hist_item, hist_cat=hist_cat, target_item=target_item, target_cat=target_cat,
+             mask=mask_i64, lens=lens, label=label, logit=npy(logit), loss=npy(loss))
+    for k, v in model.state_dict().items():
+        g["p." + k] = npy(v)
+    for i, l in enumerate([m for m in model.attention_layer if hasattr(m, "weight")]):
+        g[f"att_w{i}"], g[f"att_b{i}"] = npy(l.weight), npy(l.bias)   # NOT in state_dict (App. B-9)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            g["g." + k] = npy(p.grad)
+    g["registered"] = np.array(sorted(k for k, _ in model.named_parameters()))
+    np.savez_compressed(os.path.join(OUT, "din.npz"), **g)
+    print("din loss=%.6f" % float(loss))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    golden_deepfm(9, 20250404)
+    golden_deepfm(16, 20250405)
+    golden_dcn_v2(False, 20250406)
+    golden_dcn_v2(True, 20250407)
+    golden_din(20250408)

@@ -1,0 +1,86 @@
+import math as _m
+import torch as _t
+from . import functional, initializer  # noqa: F401
+
+
+class Layer(_t.nn.Module):
+    def add_sublayer(self, name, layer):
+        # paddle semantics: same-name registration replaces the earlier entry (Appendix B-9)
+        self._modules[name] = layer
+        return layer
+
+    def sublayers(self):
+        return list(self.modules())[1:]
+
+
+class LayerList(_t.nn.ModuleList):
+    def __init__(self, layers=None):
+        super().__init__(list(layers) if layers is not None else None)
+
+
+class ParameterList(_t.nn.ParameterList):
+    def __init__(self, params=None):
+        super().__init__(list(params) if params is not None else None)
+
+
+def _init_from(attr, p, default):
+    init = getattr(attr, "initializer", None) if attr is not None else None
+    with _t.no_grad():
+        (init or default)(p)
+
+
+class Embedding(Layer):
+    """out = 0 where id == padding_idx, else weight[id]; padding row gets no grad (App. B-1)."""
+
+    def __init__(self, num_embeddings, embedding_dim, padding_idx=None, sparse=False,
+                 weight_attr=None, name=None):
+        super().__init__()
+        self.padding_idx = padding_idx
+        self.weight = _t.nn.Parameter(_t.empty(num_embeddings, embedding_dim))
+        _init_from(weight_attr, self.weight, initializer.XavierUniform())
+        if padding_idx is not None:
+            with _t.no_grad():
+                self.weight[padding_idx].zero_()
+
+    def forward(self, ids):
+        out = self.weight[ids]
+        if self.padding_idx is not None:
+            out = out * (ids != self.padding_idx).unsqueeze(-1).to(out.dtype)
+        return out
+
+
+class Linear(Layer):
+    """y = x @ W + b with W [in, out] (App. B-2)."""
+
+    def __init__(self, in_features, out_features, weight_attr=None, bias_attr=None, name=None):
+        super().__init__()
+        self.weight = _t.nn.Parameter(_t.empty(in_features, out_features))
+        self.bias = _t.nn.Parameter(_t.zeros(out_features))
+        _init_from(weight_attr, self.weight, initializer.XavierUniform())
+        _init_from(bias_attr, self.bias, initializer.Constant(0.0))
+
+    def forward(self, x):
+        return _t.matmul(x, self.weight) + self.bias
+
+
+class ReLU(Layer):
+    def forward(self, x):
+        return _t.relu(x)
+
+
+class Sigmoid(Layer):
+    def forward(self, x):
+        return _t.sigmoid(x)
+
+
+class Dropout(Layer):
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        return _t.nn.functional.dropout(x, self.p, self.training)
+
+
+class Conv1D(Layer):  # imported by din/net.py:13, never used
+    pass

@@ -1,0 +1,78 @@
+"""ctypes binding of librecengine.so — the only door from Python into the HIP kernels.
+
+There is no CPU fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librecengine.so")
+
+REC_FLAG_INDEX_OOB = 1
+
+
+class RecError(RuntimeError):
+    pass
+
+
+class DeepFMDesc(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("num_slots", C.c_int32), ("num_dense", C.c_int32),
+                ("emb_dim", C.c_int32), ("row_stride", C.c_int32), ("num_rows", C.c_int64),
+                ("padding_idx", C.c_int64)]
+
+
+class AdamHyper(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("step", C.c_int64)]
+
+
+_P = C.c_void_p
+_I64, _I32, _F, _SZ = C.c_int64, C.c_int32, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/recengine.h declares
+SIGNATURES = {
+    "rec_last_error": (C.c_char_p, []),
+    "rec_version": (C.c_int, []),
+    "rec_deepfm_fm_fwd": (C.c_int, [C.POINTER(DeepFMDesc)] + [_P] * 13),
+    "rec_deepfm_fm_bwd_workspace_bytes": (C.c_int, [C.POINTER(DeepFMDesc), C.POINTER(_SZ)]),
+    "rec_deepfm_fm_bwd": (C.c_int, [C.POINTER(DeepFMDesc)] + [_P] * 10 + [_SZ, _P]),
+    "rec_emb_gather": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, _P, _P, _P]),
+    "rec_emb_gather_sumpool": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "rec_emb_sumpool_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _P]),
+    "rec_ids_group_workspace_bytes": (C.c_int, [_I64, _I64, C.POINTER(_SZ)]),
+    "rec_ids_group": (C.c_int, [_I64, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "rec_sparse_adam_rows": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P,
+                                       C.POINTER(AdamHyper), _P]),
+    "rec_adam_dense": (C.c_int, [_I64, _P, _P, _P, _P, C.POINTER(AdamHyper), _P]),
+    "rec_logloss_workspace_bytes": (C.c_int, [_I64, C.POINTER(_SZ)]),
+    "rec_sigmoid_logloss": (C.c_int, [_I64, _P, _P, _P, _P, _F, _P, _P, _P, _P, _SZ, _P]),
+    "rec_auc_histogram": (C.c_int, [_I64, _P, _P, _I32, _P, _P, _P]),
+    "rec_xxh32": (C.c_uint32, [C.c_char_p, _SZ, C.c_uint32]),
+    "rec_xxh32_hash_mod": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(_I32), _I64, C.c_uint32,
+                                     C.POINTER(_I64)]),
+    "rec_fill_uniform": (C.c_int, [_I64, _P, _F, _F, C.c_uint64, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load librecengine.so (once).  Raises RecError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RecError(
+                "librecengine.so not found at %s — run `python -m paddlerec_amd.build` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().rec_last_error().decode("utf-8", "replace")
+        raise RecError("%s failed (rc=%d): %s" % (what or "recengine call", rc, msg))

@@ -1,0 +1,76 @@
+"""In-tree build of librecengine.so (hipcc, gfx950 only).
+
+    python -m paddlerec_amd.build            # incremental
+    python -m paddlerec_amd.build --force
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
+paddlerec_amd/librecengine.so is git-ignored but travels to the GPU box with the snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
+LIB = os.path.join(HERE, "librecengine.so")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"),
+         "-I" + CSRC, "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _newer(a, b):
+    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(REPO, "include", "recengine.h"))
+    jobs = []
+    for s in sources():
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + ".o")
+        if force or _newer(src, obj) or any(_newer(h, obj) for h in headers):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        return src
+
+    if jobs:
+        if verbose:
+            print("[build] hipcc %s: %s" % (ARCH, ", ".join(os.path.basename(j[0]) for j in jobs)),
+                  flush=True)
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(cc, jobs))
+    objs = [os.path.join(OBJ, s[:-4] + ".o") for s in sources()]
+    if jobs or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+        if verbose:
+            print("[build] linked", LIB, flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,151 @@
+// Plain embedding gather and LoD multi-slot gather + sum-pool (gfx950).
+//
+//   rec_emb_gather         <- paddle.nn.Embedding forward
+//                             (/root/reference/models/rank/deepfm/net.py:108,117;
+//                              dcn_v2/net.py:93-96; din/net.py:141-147)
+//   rec_emb_gather_sumpool <- paddle.static.nn.sparse_embedding + sequence_pool('sum')
+//                             (/root/reference/models/rank/slot_dnn/net.py:63-75;
+//                              dnn/static_model_lod.py:70-97)
+// Row groups of LANES lanes, VEC floats per lane (see deepfm_fm.hip).  The sum-pool walks a
+// sample's LoD segment CH ids at a time so CH row gathers are in flight per group; the pooled
+// count of non-padding ids is an integer output (bit-exact target).
+#include "rec_common.h"
+
+namespace rec {
+
+template <int VEC, int LANES>
+__global__ __launch_bounds__(kBlock) void emb_gather_kernel(
+    int64_t n, int D, int stride, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
+    const float* __restrict__ W, float* __restrict__ out, int32_t* __restrict__ status) {
+  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
+  const int lg = threadIdx.x % LANES;
+  const int d0 = lg * VEC;
+  if (i >= n || d0 >= D) return;
+  const int64_t id = ids[i];
+  float e[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) e[v] = 0.f;
+  if (id != pad || pad < 0) {
+    if (id >= 0 && id < N) vload<VEC>(e, W + id * stride + d0);
+    else if (lg == 0) atomicOr(status, REC_FLAG_INDEX_OOB);
+  }
+  vstore<VEC>(out + i * D + d0, e);
+}
+
+constexpr int kPoolCH = 8;
+
+template <int VEC, int LANES>
+__global__ __launch_bounds__(kBlock) void emb_sumpool_kernel(
+    int64_t B, int D, int stride, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
+    const int64_t* __restrict__ lod, const float* __restrict__ W, float* __restrict__ out,
+    int32_t* __restrict__ counts, int32_t* __restrict__ status) {
+  const int64_t b = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
+  const int lg = threadIdx.x % LANES;
+  const int d0 = lg * VEC;
+  if (b >= B) return;
+  const bool dvalid = d0 < D;
+  const int64_t beg = lod[b], end = lod[b + 1];
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  int cnt = 0;
+  for (int64_t k0 = beg; k0 < end; k0 += kPoolCH) {
+    int64_t row[kPoolCH];
+#pragma unroll
+    for (int c = 0; c < kPoolCH; ++c) {
+      row[c] = -1;
+      if (k0 + c < end) {
+        const int64_t id = ids[k0 + c];
+        if (id != pad || pad < 0) {
+          if (id >= 0 && id < N) { row[c] = id; ++cnt; }
+          else if (lg == 0) atomicOr(status, REC_FLAG_INDEX_OOB);
+        }
+      }
+    }
+    float e[kPoolCH][VEC];
+#pragma unroll
+    for (int c = 0; c < kPoolCH; ++c) {
+      if (dvalid && row[c] >= 0) vload<VEC>(e[c], W + row[c] * stride + d0);
+      else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) e[c][v] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kPoolCH; ++c) {  // ascending-k order, same as the oracle
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += e[c][v];
+    }
+  }
+  if (dvalid) vstore<VEC>(out + b * D + d0, acc);
+  if (lg == 0 && counts) counts[b] = cnt;
+}
+
+template <int VEC, int LANES>
+__global__ __launch_bounds__(kBlock) void emb_sumpool_bwd_kernel(
+    int64_t B, int D, const int64_t* __restrict__ lod, const float* __restrict__ d_out,
+    float* __restrict__ row_grad) {
+  const int64_t b = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
+  const int d0 = (threadIdx.x % LANES) * VEC;
+  if (b >= B || d0 >= D) return;
+  float g[VEC];
+  vload<VEC>(g, d_out + b * D + d0);
+  for (int64_t k = lod[b]; k < lod[b + 1]; ++k) vstore<VEC>(row_grad + k * D + d0, g);
+}
+
+}  // namespace rec
+
+using namespace rec;
+
+extern "C" int rec_emb_gather(int64_t n, int32_t emb_dim, int32_t row_stride, int64_t num_rows,
+                              int64_t padding_idx, const int64_t* ids, const float* W, float* out,
+                              int32_t* status, void* stream) {
+  REC_REQUIRE(n >= 0 && emb_dim > 0 && row_stride >= emb_dim && num_rows > 0, REC_EINVAL,
+              "bad sizes");
+  if (n == 0) return REC_OK;
+  REC_REQUIRE(ids && W && out && status, REC_EINVAL, "null pointer argument");
+  // output rows are written with stride emb_dim: vector width must divide it
+  return dispatch_row_shape(emb_dim, row_stride, [&](auto vec, auto lanes) -> int {
+    constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
+    const int64_t grid = (n * LANES + kBlock - 1) / kBlock;
+    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "n too large");
+    hipLaunchKernelGGL((emb_gather_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock), 0,
+                       (hipStream_t)stream, n, emb_dim, row_stride, num_rows, padding_idx, ids, W,
+                       out, status);
+    return check_launch("rec_emb_gather");
+  });
+}
+
+extern "C" int rec_emb_gather_sumpool(int64_t batch, int32_t emb_dim, int32_t row_stride,
+                                      int64_t num_rows, int64_t padding_idx, const int64_t* ids,
+                                      const int64_t* lod, const float* W, float* out,
+                                      int32_t* counts, int32_t* status, void* stream) {
+  REC_REQUIRE(batch >= 0 && emb_dim > 0 && row_stride >= emb_dim && num_rows > 0, REC_EINVAL,
+              "bad sizes");
+  if (batch == 0) return REC_OK;
+  REC_REQUIRE(lod && W && out && status, REC_EINVAL, "null pointer argument");
+  return dispatch_row_shape(emb_dim, row_stride, [&](auto vec, auto lanes) -> int {
+    constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
+    const int64_t grid = (batch * LANES + kBlock - 1) / kBlock;
+    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "batch too large");
+    hipLaunchKernelGGL((emb_sumpool_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock), 0,
+                       (hipStream_t)stream, batch, emb_dim, row_stride, num_rows, padding_idx, ids,
+                       lod, W, out, counts, status);
+    return check_launch("rec_emb_gather_sumpool");
+  });
+}
+
+extern "C" int rec_emb_sumpool_bwd(int64_t batch, int32_t emb_dim, const int64_t* lod,
+                                   const float* d_out, float* row_grad, void* stream) {
+  REC_REQUIRE(batch >= 0 && emb_dim > 0, REC_EINVAL, "bad sizes");
+  if (batch == 0) return REC_OK;
+  REC_REQUIRE(lod && d_out && row_grad, REC_EINVAL, "null pointer argument");
+  return dispatch_row_shape(emb_dim, emb_dim, [&](auto vec, auto lanes) -> int {
+    constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
+    const int64_t grid = (batch * LANES + kBlock - 1) / kBlock;
+    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "batch too large");
+    hipLaunchKernelGGL((emb_sumpool_bwd_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock), 0,
+                       (hipStream_t)stream, batch, emb_dim, lod, d_out, row_grad);
+    return check_launch("rec_emb_sumpool_bwd");
+  });
+}

@@ -1,0 +1,212 @@
+// Loss head, AUC histogram, table fill, host-side feature hash and error plumbing (gfx950).
+//
+//   rec_sigmoid_logloss <- F.sigmoid (/root/reference/models/rank/deepfm/net.py:47) +
+//                          log_loss/mean (deepfm/dygraph_model.py:53-58), forward value and dz
+//   rec_auc_histogram   <- paddle.metric.Auc.update [EXT] (deepfm/dygraph_model.py:69-73,83-84),
+//                          bucket arithmetic as tools/utils/utils_single.py:160-206 consumes it
+//   rec_xxh32*          <- xxhash.xxh32(str(idx)+feat).intdigest() % hash_dim
+//                          (models/rank/dnn/benchmark_reader.py:52) — XXH32 per its published spec
+#include <stdarg.h>
+#include <string.h>
+
+#include <string>
+
+#include "rec_common.h"
+
+namespace rec {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+constexpr int kLossBlocks = 1024;
+
+__global__ __launch_bounds__(kBlock) void sigmoid_logloss_kernel(
+    int64_t B, const float* __restrict__ y1, const float* __restrict__ y2,
+    const float* __restrict__ y3, const int64_t* __restrict__ label, float eps,
+    float* __restrict__ pred, float* __restrict__ dz, float* __restrict__ partial) {
+  __shared__ float red[kBlock / kWave];
+  float local = 0.f;
+  const float invB = 1.f / (float)B;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B;
+       i += (int64_t)gridDim.x * kBlock) {
+    float z = y1[i];
+    if (y2) z += y2[i];
+    if (y3) z += y3[i];
+    const float p = 1.f / (1.f + expf(-z));
+    const float t = (float)label[i];
+    const float cost = -t * logf(p + eps) - (1.f - t) * logf(1.f - p + eps);
+    local += cost;
+    if (pred) pred[i] = p;
+    if (dz) dz[i] = (-t / (p + eps) + (1.f - t) / (1.f - p + eps)) * invB * (p * (1.f - p));
+  }
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) local += __shfl_xor(local, o, kWave);
+  if (threadIdx.x % kWave == 0) red[threadIdx.x / kWave] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kBlock / kWave; ++w) t += red[w];
+    partial[blockIdx.x] = t;
+  }
+}
+
+__global__ void fold_loss_kernel(const float* __restrict__ partial, int n, float invB,
+                                 float* __restrict__ out) {
+  __shared__ float red[kBlock];
+  float t = 0.f;
+  for (int i = threadIdx.x; i < n; i += kBlock) t += partial[i];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * invB;
+}
+
+// per-block LDS histograms (int32), flushed with 64-bit integer atomics: exact for any order
+__global__ __launch_bounds__(kBlock) void auc_hist_kernel(
+    int64_t B, const float* __restrict__ pred, const int64_t* __restrict__ label, int T,
+    unsigned long long* __restrict__ pos, unsigned long long* __restrict__ neg) {
+  extern __shared__ int sh[];  // [2][T+1]
+  const int nb = T + 1;
+  for (int i = threadIdx.x; i < 2 * nb; i += kBlock) sh[i] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B;
+       i += (int64_t)gridDim.x * kBlock) {
+    int bucket = (int)(pred[i] * (float)T);
+    bucket = bucket < 0 ? 0 : (bucket > T ? T : bucket);
+    atomicAdd(&sh[(label[i] != 0 ? 0 : nb) + bucket], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += kBlock) {
+    if (sh[i]) atomicAdd(&pos[i], (unsigned long long)sh[i]);
+    if (sh[nb + i]) atomicAdd(&neg[i], (unsigned long long)sh[nb + i]);
+  }
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ void fill_uniform_kernel(int64_t n, float* __restrict__ buf, float lo, float hi,
+                                    uint64_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = splitmix64(seed ^ splitmix64((uint64_t)i));
+    const float u = (float)(r >> 40) * (1.0f / 16777216.0f);  // 24 random bits -> [0,1)
+    buf[i] = lo + (hi - lo) * u;
+  }
+}
+
+}  // namespace rec
+
+using namespace rec;
+
+extern "C" const char* rec_last_error(void) { return rec::g_err; }
+extern "C" int rec_version(void) { return 100; }
+
+extern "C" int rec_logloss_workspace_bytes(int64_t batch, size_t* bytes) {
+  REC_REQUIRE(bytes && batch >= 0, REC_EINVAL, "bad arguments");
+  *bytes = kLossBlocks * sizeof(float);
+  return REC_OK;
+}
+
+extern "C" int rec_sigmoid_logloss(int64_t batch, const float* y1, const float* y2,
+                                   const float* y_dnn, const int64_t* label, float eps,
+                                   float* pred, float* dz, float* loss_out, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  REC_REQUIRE(batch > 0 && y1 && label && loss_out, REC_EINVAL, "bad arguments");
+  REC_REQUIRE(workspace && workspace_bytes >= kLossBlocks * sizeof(float), REC_EWORKSPACE,
+              "workspace too small");
+  int64_t grid = (batch + kBlock - 1) / kBlock;
+  if (grid > kLossBlocks) grid = kLossBlocks;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sigmoid_logloss_kernel, dim3((unsigned)grid), dim3(kBlock), 0, st, batch, y1,
+                     y2, y_dnn, label, eps, pred, dz, (float*)workspace);
+  hipLaunchKernelGGL(fold_loss_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)workspace,
+                     (int)grid, 1.f / (float)batch, loss_out);
+  return check_launch("rec_sigmoid_logloss");
+}
+
+extern "C" int rec_auc_histogram(int64_t batch, const float* pred, const int64_t* label,
+                                 int32_t num_thresholds, int64_t* stat_pos, int64_t* stat_neg,
+                                 void* stream) {
+  REC_REQUIRE(batch >= 0 && num_thresholds > 0 && num_thresholds < 16000, REC_EINVAL,
+              "bad arguments");
+  if (batch == 0) return REC_OK;
+  REC_REQUIRE(pred && label && stat_pos && stat_neg, REC_EINVAL, "null pointer argument");
+  int64_t grid = (batch + kBlock * 16 - 1) / (kBlock * 16);
+  if (grid > kNumCU * 2) grid = kNumCU * 2;
+  const size_t shmem = 2 * (size_t)(num_thresholds + 1) * sizeof(int);
+  hipLaunchKernelGGL(auc_hist_kernel, dim3((unsigned)grid), dim3(kBlock), shmem,
+                     (hipStream_t)stream, batch, pred, label, num_thresholds,
+                     (unsigned long long*)stat_pos, (unsigned long long*)stat_neg);
+  return check_launch("rec_auc_histogram");
+}
+
+extern "C" int rec_fill_uniform(int64_t n, float* buf, float lo, float hi, uint64_t seed,
+                                void* stream) {
+  REC_REQUIRE(n >= 0 && (n == 0 || buf), REC_EINVAL, "bad arguments");
+  if (n == 0) return REC_OK;
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(kNumCU * 8), dim3(kBlock), 0, (hipStream_t)stream,
+                     n, buf, lo, hi, seed);
+  return check_launch("rec_fill_uniform");
+}
+
+// ------------------------------------------------------------------ XXH32 (host), published spec
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+extern "C" uint32_t rec_xxh32(const void* bytes, size_t len, uint32_t seed) {
+  const uint32_t P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u,
+                 P5 = 374761393u;
+  const uint8_t* p = (const uint8_t*)bytes;
+  const uint8_t* const end = p + len;
+  uint32_t h;
+  if (len >= 16) {
+    uint32_t v[4] = {seed + P1 + P2, seed + P2, seed, seed - P1};
+    for (; p + 16 <= end; p += 16) {
+      uint32_t w[4];
+      memcpy(w, p, 16);
+      for (int i = 0; i < 4; ++i) v[i] = rotl32(v[i] + w[i] * P2, 13) * P1;
+    }
+    h = rotl32(v[0], 1) + rotl32(v[1], 7) + rotl32(v[2], 12) + rotl32(v[3], 18);
+  } else {
+    h = seed + P5;
+  }
+  h += (uint32_t)len;
+  for (; p + 4 <= end; p += 4) {
+    uint32_t w;
+    memcpy(&w, p, 4);
+    h = rotl32(h + w * P3, 17) * P4;
+  }
+  for (; p < end; ++p) h = rotl32(h + (*p) * P5, 11) * P1;
+  h ^= h >> 15;
+  h *= P2;
+  h ^= h >> 13;
+  h *= P3;
+  h ^= h >> 16;
+  return h;
+}
+
+extern "C" int rec_xxh32_hash_mod(const char* const* strings, const int32_t* field_idx, int64_t n,
+                                  uint32_t hash_dim, int64_t* out) {
+  REC_REQUIRE(n >= 0 && hash_dim > 0 && (n == 0 || (strings && field_idx && out)), REC_EINVAL,
+              "bad arguments");
+  std::string buf;
+  for (int64_t i = 0; i < n; ++i) {
+    buf = std::to_string(field_idx[i]);  // str(idx) + features[idx]
+    buf += strings[i];
+    out[i] = (int64_t)(rec_xxh32(buf.data(), buf.size(), 0) % hash_dim);
+  }
+  return REC_OK;
+}

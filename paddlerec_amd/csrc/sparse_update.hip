@@ -1,0 +1,280 @@
+// SelectedRows merge (integer grouping) + lazy sparse Adam + dense Adam (gfx950).
+//
+// Reference behaviour replaced (all inside Paddle core [EXT], driven from
+// /root/reference/models/rank/deepfm/net.py:62-70,80 `sparse=True` and
+// deepfm/dygraph_model.py:61-65 / static_model.py:83-84 paddle.optimizer.Adam):
+//   lookup_table_v2_grad -> SelectedRows{rows=ids, value} -> MergeAdd -> adam (lazy rows).
+// Here: one stable key sort of the B*S lookups by row (integer, bit-exact, hidden behind the
+// top-MLP GEMMs on a side stream), then ONE kernel that sums each row's duplicate gradients in
+// ascending-position order (deterministic, unlike atomics) and applies Adam to P/M/V in place —
+// the merged [U,D] gradient never goes to HBM.
+#include <string.h>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <cmath>
+
+#include "rec_common.h"
+
+namespace rec {
+
+// ------------------------------------------------------------------------------- ids grouping
+template <class KeyT>
+__global__ void make_keys_kernel(int64_t n, int S, int64_t N, int64_t pad,
+                                 const int64_t* __restrict__ ids,
+                                 const int64_t* __restrict__ slot_off, KeyT* __restrict__ keys,
+                                 int32_t* __restrict__ vals, int32_t* __restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = ids[i];
+  KeyT k = (KeyT)N;  // sentinel: sorts behind every real row
+  if (id != pad || pad < 0) {
+    const int64_t r = slot_off ? id + slot_off[i % S] : id;
+    if (r >= 0 && r < N) k = (KeyT)r; else atomicOr(status, REC_FLAG_INDEX_OOB);
+  }
+  keys[i] = k;
+  vals[i] = (int32_t)i;
+}
+
+template <class KeyT>
+__global__ void mark_heads_kernel(int64_t n, KeyT sentinel, const KeyT* __restrict__ keys,
+                                  int32_t* __restrict__ heads) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const KeyT k = keys[i];
+  heads[i] = (k != sentinel && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
+}
+
+template <class KeyT>
+__global__ void emit_segments_kernel(int64_t n, KeyT sentinel, const KeyT* __restrict__ keys,
+                                     const int32_t* __restrict__ heads,
+                                     const int32_t* __restrict__ incl, int64_t* __restrict__ uniq,
+                                     int32_t* __restrict__ seg_off, int32_t* __restrict__ n_uniq) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const KeyT k = keys[i];
+  if (heads[i]) {
+    const int u = incl[i] - 1;
+    uniq[u] = (int64_t)k;
+    seg_off[u] = (int32_t)i;
+  }
+  if (k != sentinel && (i == n - 1 || keys[i + 1] == sentinel)) {  // last real position
+    seg_off[incl[i]] = (int32_t)(i + 1);
+    n_uniq[0] = incl[i];
+    n_uniq[1] = (int32_t)(i + 1);
+  }
+  if (i == 0 && k == sentinel) {  // nothing but padding
+    seg_off[0] = 0;
+    n_uniq[0] = 0;
+    n_uniq[1] = 0;
+  }
+}
+
+static int key_bits(int64_t N) {
+  int b = 1;
+  while (b < 63 && (1ll << b) <= N) ++b;  // keys take values 0..N (N = sentinel)
+  return b;
+}
+
+template <class KeyT>
+struct GroupPlan {
+  size_t off_keys_in, off_keys_out, off_vals_in, off_heads, off_incl, off_temp, temp_bytes, total;
+};
+
+template <class KeyT>
+static int plan_group(int64_t n, int64_t N, GroupPlan<KeyT>* p) {
+  size_t sort_tmp = 0, scan_tmp = 0;
+  hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, KeyT*, KeyT*, int32_t*,
+                                           int32_t*>(nullptr, sort_tmp, nullptr, nullptr, nullptr,
+                                                     nullptr, (size_t)n, 0, key_bits(N));
+  if (e != hipSuccess) { set_error("radix_sort_pairs size query: %s", hipGetErrorString(e)); return REC_EHIP; }
+  e = rocprim::inclusive_scan<rocprim::default_config, int32_t*, int32_t*>(
+      nullptr, scan_tmp, nullptr, nullptr, (size_t)n, rocprim::plus<int32_t>());
+  if (e != hipSuccess) { set_error("inclusive_scan size query: %s", hipGetErrorString(e)); return REC_EHIP; }
+  size_t o = 0;
+  p->off_keys_in = o;  o += align_up((size_t)n * sizeof(KeyT), 256);
+  p->off_keys_out = o; o += align_up((size_t)n * sizeof(KeyT), 256);
+  p->off_vals_in = o;  o += align_up((size_t)n * sizeof(int32_t), 256);
+  p->off_heads = o;    o += align_up((size_t)n * sizeof(int32_t), 256);
+  p->off_incl = o;     o += align_up((size_t)n * sizeof(int32_t), 256);
+  p->off_temp = o;
+  p->temp_bytes = align_up(sort_tmp > scan_tmp ? sort_tmp : scan_tmp, 256);
+  p->total = o + p->temp_bytes;
+  return REC_OK;
+}
+
+template <class KeyT>
+static int run_group(int64_t n, int S, int64_t N, int64_t pad, const int64_t* ids,
+                     const int64_t* slot_off, int32_t* sorted_pos, int64_t* uniq,
+                     int32_t* seg_off, int32_t* n_uniq, int32_t* status, void* ws, size_t ws_bytes,
+                     hipStream_t st) {
+  GroupPlan<KeyT> p;
+  if (int rc = plan_group<KeyT>(n, N, &p)) return rc;
+  REC_REQUIRE(ws && ws_bytes >= p.total, REC_EWORKSPACE, "workspace %zu < %zu", ws_bytes, p.total);
+  char* base = (char*)ws;
+  KeyT* keys_in = (KeyT*)(base + p.off_keys_in);
+  KeyT* keys_out = (KeyT*)(base + p.off_keys_out);
+  int32_t* vals_in = (int32_t*)(base + p.off_vals_in);
+  int32_t* heads = (int32_t*)(base + p.off_heads);
+  int32_t* incl = (int32_t*)(base + p.off_incl);
+  void* temp = base + p.off_temp;
+  const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(make_keys_kernel<KeyT>, dim3(grid), dim3(kBlock), 0, st, n, S, N, pad, ids,
+                     slot_off, keys_in, vals_in, status);
+  size_t tb = p.temp_bytes;
+  hipError_t e = rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, vals_in, sorted_pos,
+                                           (size_t)n, 0, key_bits(N), st);
+  if (e != hipSuccess) { set_error("radix_sort_pairs: %s", hipGetErrorString(e)); return REC_EHIP; }
+  hipLaunchKernelGGL(mark_heads_kernel<KeyT>, dim3(grid), dim3(kBlock), 0, st, n, (KeyT)N,
+                     keys_out, heads);
+  tb = p.temp_bytes;
+  e = rocprim::inclusive_scan(temp, tb, heads, incl, (size_t)n, rocprim::plus<int32_t>(), st);
+  if (e != hipSuccess) { set_error("inclusive_scan: %s", hipGetErrorString(e)); return REC_EHIP; }
+  hipLaunchKernelGGL(emit_segments_kernel<KeyT>, dim3(grid), dim3(kBlock), 0, st, n, (KeyT)N,
+                     keys_out, heads, incl, uniq, seg_off, n_uniq);
+  return check_launch("rec_ids_group");
+}
+
+// --------------------------------------------------------------------------- lazy sparse Adam
+template <int VEC, int LANES>
+__global__ __launch_bounds__(kBlock) void sparse_adam_rows_kernel(
+    int D, int stride, const int32_t* __restrict__ n_uniq, const int64_t* __restrict__ uniq,
+    const int32_t* __restrict__ seg_off, const int32_t* __restrict__ spos,
+    const float* __restrict__ grad, int grad_div, float* __restrict__ P, float* __restrict__ M,
+    float* __restrict__ V, float lr_t, float eps_t, float b1, float b2) {
+  const int64_t u = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
+  const int d0 = (threadIdx.x % LANES) * VEC;
+  if (u >= n_uniq[0] || d0 >= D) return;
+  const int64_t row = uniq[u];
+  const int beg = seg_off[u], end = seg_off[u + 1];
+  float p[VEC], m[VEC], v[VEC], g[VEC];
+  const int64_t ro = row * stride + d0;
+  vload<VEC>(p, P + ro);
+  vload<VEC>(m, M + ro);
+  vload<VEC>(v, V + ro);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+  for (int k = beg; k < end; ++k) {
+    int pos = spos[k];
+    if (grad_div != 1) pos /= grad_div;
+    float t[VEC];
+    vload<VEC>(t, grad + (int64_t)pos * D + d0);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] += t[i];
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    m[i] = b1 * m[i] + (1.f - b1) * g[i];
+    v[i] = b2 * v[i] + (1.f - b2) * g[i] * g[i];
+    p[i] = p[i] - lr_t * (m[i] / (sqrtf(v[i]) + eps_t));
+  }
+  vstore<VEC>(P + ro, p);
+  vstore<VEC>(M + ro, m);
+  vstore<VEC>(V + ro, v);
+}
+
+__global__ void adam_dense_kernel(int64_t n, float* __restrict__ p, float* __restrict__ m,
+                                  float* __restrict__ v, const float* __restrict__ g, float lr_t,
+                                  float eps_t, float b1, float b2) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr_t * (mi / (sqrtf(vi) + eps_t));
+  }
+}
+
+static void adam_scalars(const rec_adam_hyper* h, float* lr_t, float* eps_t) {
+  const float b1p = powf(h->beta1, (float)h->step), b2p = powf(h->beta2, (float)h->step);
+  *lr_t = h->lr * sqrtf(1.f - b2p) / (1.f - b1p);
+  *eps_t = h->eps * sqrtf(1.f - b2p);
+}
+
+}  // namespace rec
+
+using namespace rec;
+
+static bool use_u32_keys(int64_t N) { return N < 0xFFFFFFFFll; }
+
+extern "C" int rec_ids_group_workspace_bytes(int64_t n, int64_t num_rows, size_t* bytes) {
+  REC_REQUIRE(bytes && n >= 0 && num_rows > 0, REC_EINVAL, "bad arguments");
+  REC_REQUIRE(n < (1ll << 31) - 1, REC_ESHAPE, "n too large for int32 positions");
+  if (n == 0) { *bytes = 256; return REC_OK; }
+  if (use_u32_keys(num_rows)) {
+    GroupPlan<uint32_t> p;
+    if (int rc = plan_group<uint32_t>(n, num_rows, &p)) return rc;
+    *bytes = p.total;
+  } else {
+    GroupPlan<uint64_t> p;
+    if (int rc = plan_group<uint64_t>(n, num_rows, &p)) return rc;
+    *bytes = p.total;
+  }
+  return REC_OK;
+}
+
+extern "C" int rec_ids_group(int64_t n, int32_t num_slots, int64_t num_rows, int64_t padding_idx,
+                             const int64_t* ids, const int64_t* slot_offset, int32_t* sorted_pos,
+                             int64_t* uniq_rows, int32_t* seg_offset, int32_t* n_uniq,
+                             int32_t* status, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  REC_REQUIRE(n >= 0 && num_slots > 0 && num_rows > 0, REC_EINVAL, "bad sizes");
+  REC_REQUIRE(n < (1ll << 31) - 1, REC_ESHAPE, "n too large for int32 positions");
+  REC_REQUIRE(sorted_pos && uniq_rows && seg_offset && n_uniq && status, REC_EINVAL,
+              "null pointer argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    (void)hipMemsetAsync(n_uniq, 0, 2 * sizeof(int32_t), st);
+    (void)hipMemsetAsync(seg_offset, 0, sizeof(int32_t), st);
+    return REC_OK;
+  }
+  REC_REQUIRE(ids, REC_EINVAL, "ids is NULL");
+  if (use_u32_keys(num_rows))
+    return run_group<uint32_t>(n, num_slots, num_rows, padding_idx, ids, slot_offset, sorted_pos,
+                               uniq_rows, seg_offset, n_uniq, status, workspace, workspace_bytes,
+                               st);
+  return run_group<uint64_t>(n, num_slots, num_rows, padding_idx, ids, slot_offset, sorted_pos,
+                             uniq_rows, seg_offset, n_uniq, status, workspace, workspace_bytes, st);
+}
+
+extern "C" int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride,
+                                    const int32_t* n_uniq, const int64_t* uniq_rows,
+                                    const int32_t* seg_offset, const int32_t* sorted_pos,
+                                    const float* grad, int32_t grad_div, float* P, float* M,
+                                    float* V, const rec_adam_hyper* hyper, void* stream) {
+  REC_REQUIRE(n_max >= 0 && emb_dim > 0 && row_stride >= emb_dim && grad_div >= 1, REC_EINVAL,
+              "bad sizes");
+  REC_REQUIRE(n_uniq && uniq_rows && seg_offset && sorted_pos && grad && P && M && V && hyper,
+              REC_EINVAL, "null pointer argument");
+  REC_REQUIRE(hyper->step >= 1, REC_EINVAL, "Adam step must be >= 1");
+  if (n_max == 0) return REC_OK;
+  float lr_t, eps_t;
+  adam_scalars(hyper, &lr_t, &eps_t);
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_row_shape(emb_dim, row_stride, [&](auto vec, auto lanes) -> int {
+    constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
+    const int64_t grid = (n_max * LANES + kBlock - 1) / kBlock;
+    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");
+    hipLaunchKernelGGL((sparse_adam_rows_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock),
+                       0, st, emb_dim, row_stride, n_uniq, uniq_rows, seg_offset, sorted_pos, grad,
+                       grad_div, P, M, V, lr_t, eps_t, hyper->beta1, hyper->beta2);
+    return check_launch("rec_sparse_adam_rows");
+  });
+}
+
+extern "C" int rec_adam_dense(int64_t n, float* p, float* m, float* v, const float* g,
+                              const rec_adam_hyper* hyper, void* stream) {
+  REC_REQUIRE(n >= 0 && p && m && v && g && hyper, REC_EINVAL, "bad arguments");
+  REC_REQUIRE(hyper->step >= 1, REC_EINVAL, "Adam step must be >= 1");
+  if (n == 0) return REC_OK;
+  float lr_t, eps_t;
+  adam_scalars(hyper, &lr_t, &eps_t);
+  int64_t grid = (n + kBlock - 1) / kBlock;
+  if (grid > kNumCU * 8) grid = kNumCU * 8;
+  hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)grid), dim3(kBlock), 0,
+                     (hipStream_t)stream, n, p, m, v, g, lr_t, eps_t, hyper->beta1, hyper->beta2);
+  return check_launch("rec_adam_dense");
+}

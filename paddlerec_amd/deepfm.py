@@ -1,0 +1,275 @@
+"""Host-side mirror of the reference's DeepFM plugin, running on the recengine HIP kernels.
+
+Mirrors (same class names, constructor arguments, parameter names and forward signature):
+    /root/reference/models/rank/deepfm/net.py:21-174        DeepFMLayer / FM / DNN
+    /root/reference/models/rank/deepfm/dygraph_model.py     DygraphModel (create_model, create_loss,
+                                                            create_optimizer, train_forward, ...)
+The embedding lookups, FM block, loss head, SelectedRows merge, sparse/dense Adam and the AUC
+histogram are hand-written HIP kernels behind the C-ABI (include/recengine.h); the top-MLP GEMMs go
+to the MFMA units through the vendor GEMM (torch.mm -> hipBLASLt), as the north star prescribes.
+There is no autograd tape and no CPU fallback: backward is the explicit chain the reference's
+`loss.backward()` (tools/trainer.py:151) implies.
+"""
+import math
+
+import torch
+
+from . import ops
+
+NUM_THRESHOLDS = 4095  # paddle.metric.Auc default [EXT]
+
+
+# ----------------------------------------------------------------------------------------------
+# top MLP (net.py:142-174): pure tensor algebra, device agnostic — GEMMs only, no custom kernels
+# ----------------------------------------------------------------------------------------------
+def mlp_forward(x, weights, biases):
+    """Linear(+bias)->ReLU ... ->Linear with Paddle-layout weights [in,out].
+    Returns (y, acts) where acts[i] is the input of layer i."""
+    acts = []
+    n = len(weights)
+    for i in range(n):
+        acts.append(x)
+        x = torch.addmm(biases[i], x, weights[i])
+        if i < n - 1:
+            x = torch.relu_(x)
+    return x, acts + [x]
+
+
+def mlp_backward(dy, acts, weights, dws, dbs):
+    """Writes dW_i into dws[i], db_i into dbs[i] (preallocated views); returns d(input)."""
+    n = len(weights)
+    g = dy
+    for i in reversed(range(n)):
+        if i < n - 1:
+            g = g * (acts[i + 1] > 0).to(g.dtype)      # ReLU'
+        torch.mm(acts[i].t(), g, out=dws[i])
+        torch.sum(g, dim=0, out=dbs[i])
+        g = torch.mm(g, weights[i].t())
+    return g
+
+
+class _FlatParams:
+    """All dense parameters in ONE flat f32 buffer (+ grad, Adam m/v): one optimizer launch and one
+    all-reduce bucket per step instead of one per tensor."""
+
+    def __init__(self, shapes, device):
+        self.names = [n for n, _ in shapes]
+        self.shapes = dict(shapes)
+        total = sum(math.prod(s) for _, s in shapes)
+        self.data = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros_like(self.data)
+        self.m = torch.zeros_like(self.data)
+        self.v = torch.zeros_like(self.data)
+        self.p, self.g = {}, {}
+        o = 0
+        for n, s in shapes:
+            k = math.prod(s)
+            self.p[n] = self.data[o:o + k].view(s)
+            self.g[n] = self.grad[o:o + k].view(s)
+            o += k
+
+
+class FM:
+    """net.py:52-139.  Holds embedding_one [N,1], embedding [N,D]; dense_w_one/dense_w live in the
+    flat dense buffer of the owning DeepFMLayer."""
+
+    def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim,
+                 sparse_num_field, device, slot_offset=None):
+        self.sparse_feature_number = sparse_feature_number
+        self.sparse_feature_dim = sparse_feature_dim
+        self.dense_feature_dim = dense_feature_dim
+        self.dense_emb_dim = sparse_feature_dim
+        self.sparse_num_field = sparse_num_field
+        self.init_value_ = 0.1
+        self.padding_idx = 0                                   # net.py:69,81
+        std = self.init_value_ / math.sqrt(float(sparse_feature_dim))
+        N, D = sparse_feature_number, sparse_feature_dim
+        self.embedding_one = torch.empty(N, 1, dtype=torch.float32, device=device)
+        self.embedding = torch.empty(N, D, dtype=torch.float32, device=device)
+        for t in (self.embedding_one, self.embedding):        # TruncatedNormal(0,std) net.py:72-75
+            torch.nn.init.trunc_normal_(t, 0.0, std, -2 * std, 2 * std)
+            if slot_offset is None:
+                t[self.padding_idx].zero_()                    # padding row zeroed at construction [EXT]
+        self.slot_offset = slot_offset
+
+
+class DeepFMLayer:
+    """net.py:21-49.  forward(sparse_inputs, dense_inputs) -> predict [B,1]."""
+
+    def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim,
+                 sparse_num_field, layer_sizes, device="cuda", slot_offset=None):
+        self.device = torch.device(device)
+        self.sparse_feature_number = sparse_feature_number
+        self.sparse_feature_dim = sparse_feature_dim
+        self.dense_feature_dim = dense_feature_dim
+        self.sparse_num_field = sparse_num_field
+        self.layer_sizes = list(layer_sizes)
+        if slot_offset is not None:
+            slot_offset = torch.as_tensor(slot_offset, dtype=torch.int64, device=self.device)
+        self.fm = FM(sparse_feature_number, sparse_feature_dim, dense_feature_dim, sparse_num_field,
+                     self.device, slot_offset)
+        D, Dn = sparse_feature_dim, dense_feature_dim
+        self.num_field = Dn + sparse_num_field
+        sizes = [D * self.num_field] + self.layer_sizes + [1]               # net.py:150
+        shapes = [("fm.dense_w_one", (Dn,)), ("fm.dense_w", (1, Dn, D))]
+        for i in range(len(sizes) - 1):
+            shapes += [("dnn.linear_%d.weight" % i, (sizes[i], sizes[i + 1])),
+                       ("dnn.linear_%d.bias" % i, (sizes[i + 1],))]
+        shapes.append(("bias", (1,)))       # created, never used in forward (net.py:36-39; App. B-14)
+        self.dense = _FlatParams(shapes, self.device)
+        std = 0.1 / math.sqrt(float(D))
+        for n in ("fm.dense_w_one", "fm.dense_w"):                          # net.py:89-103
+            torch.nn.init.trunc_normal_(self.dense.p[n], 0.0, std, -2 * std, 2 * std)
+        self.n_linear = len(sizes) - 1
+        for i in range(self.n_linear):                                      # net.py:155-160
+            self.dense.p["dnn.linear_%d.weight" % i].normal_(0.0, 1.0 / math.sqrt(sizes[i]))
+        self.mlp_w = [self.dense.p["dnn.linear_%d.weight" % i] for i in range(self.n_linear)]
+        self.mlp_b = [self.dense.p["dnn.linear_%d.bias" % i] for i in range(self.n_linear)]
+        self.mlp_dw = [self.dense.g["dnn.linear_%d.weight" % i] for i in range(self.n_linear)]
+        self.mlp_db = [self.dense.g["dnn.linear_%d.bias" % i] for i in range(self.n_linear)]
+        # sparse Adam state (lazy rows) + bookkeeping
+        self.sparse_state = None
+        self.ws = ops.Workspace(self.device)
+        self.ws_group = ops.Workspace(self.device)
+        self.status = ops.new_status(self.device)
+        self.step_count = 0
+        self._side = None
+
+    # -- parameters under the reference's state_dict keys (Appendix C) -------------------------
+    def state_dict(self):
+        sd = {"fm.embedding_one.weight": self.fm.embedding_one, "fm.embedding.weight": self.fm.embedding}
+        sd.update(self.dense.p)
+        return sd
+
+    def set_dict(self, sd):
+        for k, v in sd.items():
+            dst = self.state_dict()[k]
+            dst.copy_(torch.as_tensor(v).to(dst.device).reshape(dst.shape))
+
+    def parameters(self):
+        return list(self.state_dict().values())
+
+    # -- forward (net.py:41-49) -----------------------------------------------------------------
+    @staticmethod
+    def _concat_ids(sparse_inputs):
+        if isinstance(sparse_inputs, (list, tuple)):
+            return torch.cat(list(sparse_inputs), dim=1).contiguous()       # net.py:107
+        return sparse_inputs
+
+    def _fm_fwd(self, ids, dense_inputs):
+        return ops.deepfm_fm_fwd(ids, dense_inputs, self.fm.embedding, self.fm.embedding_one,
+                                 self.dense.p["fm.dense_w"], self.dense.p["fm.dense_w_one"],
+                                 self.fm.padding_idx, self.fm.slot_offset, self.status)
+
+    def forward(self, sparse_inputs, dense_inputs):
+        ids = self._concat_ids(sparse_inputs)
+        y1, y2, feat, _, _ = self._fm_fwd(ids, dense_inputs)
+        y_dnn, _ = mlp_forward(feat.view(feat.shape[0], -1), self.mlp_w, self.mlp_b)
+        return torch.sigmoid(y1 + y2 + y_dnn)
+
+    __call__ = forward
+
+    # -- one full training step: train_forward + backward + optimizer.step ----------------------
+    def _ensure_sparse_state(self):
+        if self.sparse_state is None:
+            self.sparse_state = dict(
+                m=torch.zeros_like(self.fm.embedding), v=torch.zeros_like(self.fm.embedding),
+                m1=torch.zeros_like(self.fm.embedding_one), v1=torch.zeros_like(self.fm.embedding_one))
+
+    def train_step(self, sparse_inputs, dense_inputs, label, lr=1e-3, auc_stats=None,
+                   allreduce=None):
+        """dygraph_model.py:76-88 train_forward + tools/trainer.py:151-152 backward/step.
+        label [B,1] int64.  Returns (loss [1] device tensor, pred [B,1])."""
+        ids = self._concat_ids(sparse_inputs)
+        B, S = ids.shape
+        self._ensure_sparse_state()
+        self.step_count += 1
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        # SelectedRows merge keys only depend on ids: sort them on a side stream, hidden behind the GEMMs
+        self._side.wait_stream(cur)
+        groups = getattr(self, "_groups", None)          # persistent: the wait_stream above orders reuse
+        if groups is None or groups.n != B * S:
+            groups = self._groups = ops.IdGroups(B * S, self.device)
+        with torch.cuda.stream(self._side):
+            ops.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
+                          self.fm.slot_offset, self.status, groups)
+        y1, y2, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
+        y_dnn, acts = mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b)
+        pred, dz, loss = ops.sigmoid_logloss(y1, y2, y_dnn, label, self.ws)
+        if auc_stats is not None:
+            ops.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
+        d_flat = mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db)
+        row_grad, _, _ = ops.deepfm_fm_bwd(
+            dense_inputs, feat, sum_emb, d_flat.view(B, self.num_field, -1), dz, dz, S, self.ws,
+            out=(self._row_grad_buf(B * S), self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
+                 self.dense.g["fm.dense_w_one"]))
+        if allreduce is not None:
+            allreduce(self.dense.grad)
+        t = self.step_count
+        ops.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
+        cur.wait_stream(self._side)
+        st = self.sparse_state
+        ops.sparse_adam_rows(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr)
+        ops.sparse_adam_rows(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
+        return loss, pred
+
+    def _row_grad_buf(self, n):
+        b = getattr(self, "_rg", None)
+        if b is None or b.shape[0] != n:
+            self._rg = torch.empty(n, self.sparse_feature_dim, dtype=torch.float32, device=self.device)
+        return self._rg
+
+
+class DygraphModel:
+    """deepfm/dygraph_model.py:23-98 — same method names; tensors are torch device tensors."""
+
+    def create_model(self, config, device="cuda"):
+        return DeepFMLayer(config.get("hyper_parameters.sparse_feature_number"),
+                           config.get("hyper_parameters.sparse_feature_dim"),
+                           config.get("hyper_parameters.dense_input_dim"),
+                           config.get("hyper_parameters.sparse_inputs_slots") - 1,
+                           config.get("hyper_parameters.fc_sizes"), device=device)
+
+    def create_feeds(self, batch_data, config, device="cuda"):
+        dn = config.get("hyper_parameters.dense_input_dim")
+        sparse = [torch.as_tensor(b).to(torch.int64).reshape(-1, 1).to(device) for b in batch_data[:-1]]
+        dense = torch.as_tensor(batch_data[-1]).to(torch.float32).reshape(-1, dn).to(device)
+        return sparse[0], sparse[1:], dense
+
+    def create_metrics(self, device="cuda"):
+        stats = (torch.zeros(NUM_THRESHOLDS + 1, dtype=torch.int64, device=device),
+                 torch.zeros(NUM_THRESHOLDS + 1, dtype=torch.int64, device=device))
+        return [stats], ["auc"]
+
+    def train_forward(self, dy_model, metrics_list, batch_data, config, lr=None):
+        label, sparse, dense = self.create_feeds(batch_data, config, dy_model.device)
+        lr = lr if lr is not None else config.get("hyper_parameters.optimizer.learning_rate", 0.001)
+        loss, _ = dy_model.train_step(sparse, dense, label, lr, metrics_list[0] if metrics_list else None)
+        return loss, metrics_list, {"loss": loss}
+
+    def infer_forward(self, dy_model, metrics_list, batch_data, config):
+        label, sparse, dense = self.create_feeds(batch_data, config, dy_model.device)
+        pred = dy_model.forward(sparse, dense)
+        if metrics_list:
+            ops.auc_histogram(pred.contiguous(), label.contiguous(), metrics_list[0][0],
+                              metrics_list[0][1], NUM_THRESHOLDS)
+        return metrics_list, None
+
+
+def auc_from_buckets(stat_pos, stat_neg):
+    """tools/utils/utils_single.py:183-204 — trapezoid sweep from the top bucket (host, fp64)."""
+    pos_l = stat_pos.tolist()
+    neg_l = stat_neg.tolist()
+    area = pos = neg = 0.0
+    total = 0
+    for idx in range(len(pos_l) - 1, -1, -1):
+        new_pos = pos + pos_l[idx]
+        new_neg = neg + neg_l[idx]
+        total += pos_l[idx] + neg_l[idx]
+        area += (new_neg - neg) * (pos + new_pos) / 2
+        pos, neg = new_pos, new_neg
+    if pos * neg == 0 or total == 0:
+        return 0.5
+    return area / (pos * neg)

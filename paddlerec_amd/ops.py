@@ -1,0 +1,281 @@
+"""Operator layer: torch tensors in, C-ABI calls out.
+
+torch is plumbing here (device memory, streams); every op below is a hand-written HIP kernel in
+librecengine.so.  Tensors must live on a ROCm device — there is deliberately no CPU path.
+Reference call sites are cited in include/recengine.h next to each entry point.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import AdamHyper, DeepFMDesc, RecError, check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(t, dtype, name, shape=None):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RecError("%s must be a device tensor (no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise RecError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RecError("%s must be contiguous" % name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RecError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+
+
+def new_status(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def raise_on_status(status, what="lookup"):
+    """Host sync: raises if a kernel flagged an out-of-range id (Paddle raises on OOB [EXT])."""
+    s = int(status.item())
+    if s & _lib.REC_FLAG_INDEX_OOB:
+        raise RecError("%s: index out of range [0, num_rows)" % what)
+
+
+class Workspace:
+    """Grow-only device scratch owned by the caller of the C-ABI (the engine never allocates)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def make_desc(B, S, Dn, D, num_rows, padding_idx, row_stride=None):
+    return DeepFMDesc(int(B), int(S), int(Dn), int(D), int(row_stride or D), int(num_rows),
+                      -1 if padding_idx is None else int(padding_idx))
+
+
+# ------------------------------------------------------------------ DeepFM FM block
+def deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, padding_idx=0, slot_offset=None,
+                  status=None, out=None):
+    """ids [B,S] i64, dense [B,Dn] f32, W [N,D], W1 [N,1]|[N], dense_w [Dn,D]|[1,Dn,D], dense_w_one [Dn]
+    -> y1 [B,1], y2 [B,1], feat [B,S+Dn,D], sum_emb [B,D], status"""
+    B, S = ids.shape
+    Dn = dense.shape[1]
+    N, D = W.shape
+    dev = ids.device
+    _chk(ids, torch.int64, "ids")
+    _chk(dense, torch.float32, "dense", (B, Dn))
+    _chk(W, torch.float32, "W")
+    _chk(W1, torch.float32, "W1")
+    _chk(dense_w, torch.float32, "dense_w")
+    _chk(dense_w_one, torch.float32, "dense_w_one", (Dn,))
+    _chk(slot_offset, torch.int64, "slot_offset", (S,))
+    if W1.numel() != N or dense_w.numel() != Dn * D:
+        raise RecError("W1 / dense_w shape mismatch")
+    if out is None:
+        y1 = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        y2 = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        feat = torch.empty(B, S + Dn, D, dtype=torch.float32, device=dev)
+        sum_emb = torch.empty(B, D, dtype=torch.float32, device=dev)
+    else:
+        y1, y2, feat, sum_emb = out
+    if status is None:
+        status = new_status(dev)
+    desc = make_desc(B, S, Dn, D, N, padding_idx, W.stride(0))
+    check(lib().rec_deepfm_fm_fwd(C.byref(desc), _p(ids), _p(dense), _p(W), _p(W1), _p(dense_w),
+                                  _p(dense_w_one), _p(slot_offset), _p(y1), _p(y2), _p(feat),
+                                  _p(sum_emb), _p(status), _stream()), "rec_deepfm_fm_fwd")
+    return y1, y2, feat, sum_emb, status
+
+
+def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None):
+    """-> row_grad [B*S,D], d_dense_w [Dn,D], d_dense_w_one [Dn]"""
+    B, F, D = feat.shape
+    Dn = F - S
+    dev = feat.device
+    for t, n in ((dense, "dense"), (feat, "feat"), (sum_emb, "sum_emb"), (d_feat_dnn, "d_feat_dnn"),
+                 (dy1, "dy1"), (dy2, "dy2")):
+        _chk(t, torch.float32, n)
+    if d_feat_dnn.numel() != feat.numel() or dy1.numel() != B or dy2.numel() != B:
+        raise RecError("gradient shape mismatch")
+    if out is None:
+        row_grad = torch.empty(B * S, D, dtype=torch.float32, device=dev)
+        d_dense_w = torch.empty(Dn, D, dtype=torch.float32, device=dev)
+        d_dense_w_one = torch.empty(Dn, dtype=torch.float32, device=dev)
+    else:
+        row_grad, d_dense_w, d_dense_w_one = out
+    desc = make_desc(B, S, Dn, D, 1, None)
+    nbytes = C.c_size_t(0)
+    check(lib().rec_deepfm_fm_bwd_workspace_bytes(C.byref(desc), C.byref(nbytes)))
+    w = ws.get(nbytes.value)
+    check(lib().rec_deepfm_fm_bwd(C.byref(desc), _p(dense), _p(feat), _p(sum_emb), _p(d_feat_dnn),
+                                  _p(dy1), _p(dy2), _p(row_grad), _p(d_dense_w), _p(d_dense_w_one),
+                                  _p(w), C.c_size_t(w.numel()), _stream()), "rec_deepfm_fm_bwd")
+    return row_grad, d_dense_w, d_dense_w_one
+
+
+# ------------------------------------------------------------------ lookups
+def emb_gather(ids, W, padding_idx=None, status=None):
+    _chk(ids, torch.int64, "ids")
+    _chk(W, torch.float32, "W")
+    N, D = W.shape
+    out = torch.empty(*ids.shape, D, dtype=torch.float32, device=ids.device)
+    if status is None:
+        status = new_status(ids.device)
+    check(lib().rec_emb_gather(ids.numel(), D, W.stride(0), N,
+                               -1 if padding_idx is None else padding_idx, _p(ids), _p(W), _p(out),
+                               _p(status), _stream()), "rec_emb_gather")
+    return out, status
+
+
+def emb_gather_sumpool(ids, lod, W, padding_idx=0, status=None):
+    """ids [nnz] i64, lod [B+1] i64 -> (bow [B,D], counts [B] i32, status)"""
+    _chk(ids, torch.int64, "ids")
+    _chk(lod, torch.int64, "lod")
+    _chk(W, torch.float32, "W")
+    N, D = W.shape
+    B = lod.numel() - 1
+    out = torch.empty(B, D, dtype=torch.float32, device=W.device)
+    counts = torch.empty(B, dtype=torch.int32, device=W.device)
+    if status is None:
+        status = new_status(W.device)
+    check(lib().rec_emb_gather_sumpool(B, D, W.stride(0), N,
+                                       -1 if padding_idx is None else padding_idx, _p(ids), _p(lod),
+                                       _p(W), _p(out), _p(counts), _p(status), _stream()),
+          "rec_emb_gather_sumpool")
+    return out, counts, status
+
+
+def emb_sumpool_bwd(lod, d_out, nnz):
+    _chk(lod, torch.int64, "lod")
+    _chk(d_out, torch.float32, "d_out")
+    B, D = d_out.shape
+    row_grad = torch.empty(nnz, D, dtype=torch.float32, device=d_out.device)
+    check(lib().rec_emb_sumpool_bwd(B, D, _p(lod), _p(d_out), _p(row_grad), _stream()),
+          "rec_emb_sumpool_bwd")
+    return row_grad
+
+
+# ------------------------------------------------------------------ SelectedRows merge + optimizers
+class IdGroups:
+    """Result buffers of rec_ids_group (device)."""
+
+    def __init__(self, n, device):
+        self.n = n
+        self.sorted_pos = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+        self.uniq_rows = torch.empty(max(n, 1), dtype=torch.int64, device=device)
+        self.seg_offset = torch.empty(n + 1, dtype=torch.int32, device=device)
+        self.n_uniq = torch.zeros(2, dtype=torch.int32, device=device)
+
+    def host(self):
+        """(sorted_pos[:n_valid], uniq_rows[:U], seg_offset[:U+1]) on the CPU — host sync."""
+        U, nv = (int(x) for x in self.n_uniq.tolist())
+        return (self.sorted_pos[:nv].cpu().numpy(), self.uniq_rows[:U].cpu().numpy(),
+                self.seg_offset[:U + 1].cpu().numpy())
+
+
+def ids_group(ids, num_rows, padding_idx, ws, slot_offset=None, status=None, groups=None):
+    _chk(ids, torch.int64, "ids")
+    n = ids.numel()
+    S = ids.shape[-1] if ids.dim() > 1 else 1
+    dev = ids.device
+    if groups is None:
+        groups = IdGroups(n, dev)
+    if status is None:
+        status = new_status(dev)
+    nbytes = C.c_size_t(0)
+    check(lib().rec_ids_group_workspace_bytes(n, num_rows, C.byref(nbytes)))
+    w = ws.get(nbytes.value)
+    check(lib().rec_ids_group(n, S, num_rows, -1 if padding_idx is None else padding_idx, _p(ids),
+                              _p(slot_offset), _p(groups.sorted_pos), _p(groups.uniq_rows),
+                              _p(groups.seg_offset), _p(groups.n_uniq), _p(status), _p(w),
+                              C.c_size_t(w.numel()), _stream()), "rec_ids_group")
+    return groups, status
+
+
+def _hyper(lr, beta1, beta2, eps, step):
+    return AdamHyper(float(lr), float(beta1), float(beta2), float(eps), int(step))
+
+
+def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999,
+                     eps=1e-8):
+    for t, n in ((grad, "grad"), (P, "P"), (M, "M"), (V, "V")):
+        _chk(t, torch.float32, n)
+    D = P.shape[1] if P.dim() > 1 else 1
+    stride = P.stride(0) if P.dim() > 1 else 1
+    h = _hyper(lr, beta1, beta2, eps, step)
+    check(lib().rec_sparse_adam_rows(groups.n, D, stride, _p(groups.n_uniq), _p(groups.uniq_rows),
+                                     _p(groups.seg_offset), _p(groups.sorted_pos), _p(grad),
+                                     int(grad_div), _p(P), _p(M), _p(V), C.byref(h), _stream()),
+          "rec_sparse_adam_rows")
+
+
+def adam_dense(p, m, v, g, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    for t, n in ((p, "p"), (m, "m"), (v, "v"), (g, "g")):
+        _chk(t, torch.float32, n)
+    h = _hyper(lr, beta1, beta2, eps, step)
+    check(lib().rec_adam_dense(p.numel(), _p(p), _p(m), _p(v), _p(g), C.byref(h), _stream()),
+          "rec_adam_dense")
+
+
+# ------------------------------------------------------------------ loss head / metric
+def sigmoid_logloss(y1, y2, y_dnn, label, ws, eps=1e-4, want_dz=True, out=None):
+    """-> pred [B,1], dz [B,1] (or None), loss [1]"""
+    B = y1.numel()
+    dev = y1.device
+    _chk(y1, torch.float32, "y1")
+    _chk(y2, torch.float32, "y2")
+    _chk(y_dnn, torch.float32, "y_dnn")
+    _chk(label, torch.int64, "label")
+    if out is None:
+        pred = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        dz = torch.empty(B, 1, dtype=torch.float32, device=dev) if want_dz else None
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+    else:
+        pred, dz, loss = out
+    nbytes = C.c_size_t(0)
+    check(lib().rec_logloss_workspace_bytes(B, C.byref(nbytes)))
+    w = ws.get(nbytes.value)
+    check(lib().rec_sigmoid_logloss(B, _p(y1), _p(y2), _p(y_dnn), _p(label), float(eps), _p(pred),
+                                    _p(dz), _p(loss), _p(w), C.c_size_t(w.numel()), _stream()),
+          "rec_sigmoid_logloss")
+    return pred, dz, loss
+
+
+def auc_histogram(pred, label, stat_pos, stat_neg, num_thresholds=4095):
+    _chk(pred, torch.float32, "pred")
+    _chk(label, torch.int64, "label")
+    _chk(stat_pos, torch.int64, "stat_pos", (num_thresholds + 1,))
+    _chk(stat_neg, torch.int64, "stat_neg", (num_thresholds + 1,))
+    check(lib().rec_auc_histogram(pred.numel(), _p(pred), _p(label), num_thresholds, _p(stat_pos),
+                                  _p(stat_neg), _stream()), "rec_auc_histogram")
+
+
+def fill_uniform(buf, lo, hi, seed):
+    _chk(buf, torch.float32, "buf")
+    check(lib().rec_fill_uniform(buf.numel(), _p(buf), float(lo), float(hi), int(seed), _stream()),
+          "rec_fill_uniform")
+    return buf
+
+
+# ------------------------------------------------------------------ host: feature hash
+def xxh32(data: bytes, seed: int = 0) -> int:
+    return int(lib().rec_xxh32(data, len(data), seed))
+
+
+def hash_features(field_idx, values, hash_dim=1000001):
+    """xxh32(str(idx)+value) % hash_dim for each (idx, value) — dnn/benchmark_reader.py:52."""
+    n = len(values)
+    arr = (C.c_char_p * n)(*[v.encode("utf-8") for v in values])
+    idx = (C.c_int32 * n)(*[int(i) for i in field_idx])
+    out = (C.c_int64 * n)()
+    check(lib().rec_xxh32_hash_mod(arr, idx, n, hash_dim, out), "rec_xxh32_hash_mod")
+    return list(out)

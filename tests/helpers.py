@@ -1,0 +1,90 @@
+"""Shared test helpers: golden loading, seeded synthetic DeepFM problems, C-oracle wrappers."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def deepfm_params_from_golden(g):
+    n = int(g["n_mlp"])
+    return dict(W=g["W"], W1=g["W1"], dense_w=g["dense_w"], dense_w_one=g["dense_w_one"],
+                mlp_w=[g["mlp_w%d" % i] for i in range(n)], mlp_b=[g["mlp_b%d" % i] for i in range(n)])
+
+
+def make_deepfm_problem(B, S=26, Dn=13, D=16, N=5000, fc=(64, 32), seed=0, pad_frac=0.03,
+                        zipf=False, tables=False, dtype=np.float32):
+    """Synthetic batch + weights, SURVEY.md §8(d) recipe (uniform or Zipf ids, 3 % padding)."""
+    rng = np.random.default_rng(seed)
+    if zipf:
+        ranks = np.minimum(rng.zipf(1.05, size=(B, S)), N - 1)
+        perm = rng.permutation(N)
+        ids = np.clip(perm[ranks], 1, N - 1).astype(np.int64)
+    else:
+        ids = rng.integers(1, N, size=(B, S), dtype=np.int64)
+    ids[rng.random((B, S)) < pad_frac] = 0
+    slot_offsets = (np.arange(S, dtype=np.int64) * N) if tables else None
+    rows_total = N * S if tables else N
+    dense = rng.random((B, Dn), dtype=np.float32)
+    label = (rng.random((B, 1)) < 0.25).astype(np.int64)
+    std = 0.1 / np.sqrt(D)
+    tn = lambda *s: np.clip(rng.standard_normal(s) * std, -2 * std, 2 * std).astype(dtype)
+    sizes = [(S + Dn) * D] + list(fc) + [1]
+    params = dict(
+        W=tn(rows_total, D), W1=tn(rows_total, 1), dense_w=tn(1, Dn, D), dense_w_one=tn(Dn),
+        mlp_w=[(rng.standard_normal((sizes[i], sizes[i + 1])) / np.sqrt(sizes[i])).astype(dtype)
+               for i in range(len(sizes) - 1)],
+        mlp_b=[(rng.standard_normal(sizes[i + 1]) * 0.01).astype(dtype) for i in range(len(sizes) - 1)])
+    return dict(ids=ids, dense=dense, label=label, params=params, slot_offsets=slot_offsets,
+                N=rows_total, S=S, Dn=Dn, D=D, fc=list(fc))
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def c_fm_fwd(lib, ids, dense, W, W1, dense_w, dense_w_one, pad=0, slot_off=None):
+    B, S = ids.shape
+    Dn = dense.shape[1]
+    D = W.shape[1]
+    y1 = np.empty(B, np.float32)
+    y2 = np.empty(B, np.float32)
+    feat = np.empty((B, S + Dn, D), np.float32)
+    sum_emb = np.empty((B, D), np.float32)
+    lib.oracle_fm_fwd.restype = None
+    lib.oracle_fm_fwd(C.c_int64(B), C.c_int(S), C.c_int(Dn), C.c_int(D), fptr(ids), fptr(dense),
+                      fptr(W), fptr(np.ascontiguousarray(W1.reshape(-1))),
+                      fptr(np.ascontiguousarray(dense_w.reshape(Dn, D))), fptr(dense_w_one),
+                      C.c_int64(pad), fptr(slot_off) if slot_off is not None else None,
+                      fptr(y1), fptr(y2), fptr(feat), fptr(sum_emb))
+    return y1, y2, feat, sum_emb
+
+
+def c_fm_bwd(lib, S, dense, feat, sum_emb, d_feat, dy1, dy2):
+    B, F, D = feat.shape
+    Dn = F - S
+    row_grad = np.empty((B * S, D), np.float32)
+    row_grad1 = np.empty(B * S, np.float32)
+    ddw = np.empty((Dn, D), np.float32)
+    ddw1 = np.empty(Dn, np.float32)
+    lib.oracle_fm_bwd.restype = None
+    lib.oracle_fm_bwd(C.c_int64(B), C.c_int(S), C.c_int(Dn), C.c_int(D), fptr(dense), fptr(feat),
+                      fptr(sum_emb), fptr(np.ascontiguousarray(d_feat)),
+                      fptr(np.ascontiguousarray(dy1.reshape(-1))),
+                      fptr(np.ascontiguousarray(dy2.reshape(-1))), fptr(row_grad), fptr(row_grad1),
+                      fptr(ddw), fptr(ddw1))
+    return row_grad, row_grad1, ddw, ddw1
+
+
+def c_adam_rows(lib, uniq, seg_off, spos, row_grad, P, M, V, step, lr=1e-3, b1=0.9, b2=0.999,
+                eps=1e-8):
+    lib.oracle_adam_rows.restype = None
+    D = P.shape[1]
+    lib.oracle_adam_rows(C.c_int64(len(uniq)), C.c_int(D), fptr(uniq), fptr(seg_off), fptr(spos),
+                         fptr(row_grad), fptr(P), fptr(M), fptr(V), C.c_float(lr), C.c_float(b1),
+                         C.c_float(b2), C.c_float(eps), C.c_int64(step))
