@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Criteo DeepFM training step, bs=65536 per GPU, on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 26 sparse slots x 1M rows x dim 16 (one 26M-row table with
+slot offsets), 13 dense fields, top MLP 400-400-400 (config_bigdata.yaml:47), fp32, batch 65536.
+One "step" = train_forward + backward + optimizer of the reference graph
+(deepfm/dygraph_model.py:76-88, tools/trainer.py:148-152) on a device-resident synthetic batch:
+fused embedding+FM forward, MLP GEMMs, loss head, MLP backward, FM backward, SelectedRows merge,
+lazy sparse Adam on both tables, dense Adam.  Lazy Adam is the reference's static-graph optimizer
+(deepfm/static_model.py:83-84) and the only one that scales to the 10B-row table of configs[4].
+
+N>1: weak scaling — every rank keeps batch 65536 and 26M/N... see DESIGN.md §multi-GPU: table rows
+are sharded row-wise (row r on rank r % N), ids/rows/grads exchanged by RCCL all-to-all, dense
+gradients all-reduced.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+# cpu_baseline mixes an OpenMP C oracle with BLAS threads: spinning idle workers would starve each other
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP32_MFMA_PEAK_TF = 157.3   # dense f32 MFMA peak
+
+
+def algorithmic_bytes(B, S, Dn, D):
+    """DeepFM embedding + FM forward/backward bytes per step."""
+    F = S + Dn
+    fwd = B * S * 8 + B * S * D * 4 + B * S * 4 + B * Dn * 4 + B * F * D * 4 + B * 8
+    bwd = B * S * 8 + B * F * D * 4 + B * 4 + B * S * D * 4 + B * S * D * 4 + B * S * 4
+    return fwd, bwd
+
+
+def mlp_flops(B, sizes):
+    return sum(2 * B * sizes[i] * sizes[i + 1] for i in range(len(sizes) - 1))
+
+
+def make_batches(n, B, S, Dn, rows_per_table, device, seed):
+    """Device-resident synthetic Criteo-shaped batches: uniform ids in [1,rows), 3 % padding (id 0)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = []
+    for _ in range(n):
+        ids = torch.randint(1, rows_per_table, (B, S), device=device, generator=g, dtype=torch.int64)
+        ids[torch.rand(B, S, device=device, generator=g) < 0.03] = 0
+        dense = torch.rand(B, Dn, device=device, generator=g)
+        label = (torch.rand(B, 1, device=device, generator=g) < 0.25).to(torch.int64)
+        out.append((ids, dense, label))
+    return out
+
+
+def cpu_baseline(B, S, Dn, D, fc, rows_per_table, budget_s=20.0):
+    """Times the ORACLE (C restatement for embedding+FM+sparse Adam, NumPy GEMMs for the MLP) on this
+    host's cores, on a bounded sample of the same workload: whole steps of batch B until ~budget_s."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from helpers import c_adam_rows, c_fm_bwd, c_fm_fwd
+    from oracle import deepfm_ref as R
+    lib = C.CDLL(os.path.join(REPO, "oracle", "_build", "liboracle.so"))
+    lib.oracle_num_threads.restype = C.c_int
+    cores = lib.oracle_num_threads()
+    rng = np.random.default_rng(20250404)
+    N = rows_per_table * S
+    std = 0.1 / np.sqrt(D)
+    W = (rng.standard_normal((N, D), dtype=np.float32) * std)
+    W1 = (rng.standard_normal((N, 1), dtype=np.float32) * std)
+    M, V = np.zeros_like(W), np.zeros_like(W)
+    dw = (rng.standard_normal((1, Dn, D), dtype=np.float32) * std)
+    dw1 = (rng.standard_normal(Dn, dtype=np.float32) * std)
+    sizes = [(S + Dn) * D] + list(fc) + [1]
+    mw = [(rng.standard_normal((sizes[i], sizes[i + 1]), dtype=np.float32) / np.sqrt(sizes[i]))
+          for i in range(len(sizes) - 1)]
+    mb = [np.zeros(sizes[i + 1], np.float32) for i in range(len(sizes) - 1)]
+    so = (np.arange(S, dtype=np.int64) * rows_per_table)
+    ids = rng.integers(1, rows_per_table, (B, S), dtype=np.int64)
+    ids[rng.random((B, S)) < 0.03] = 0
+    dense = rng.random((B, Dn), dtype=np.float32)
+    label = (rng.random((B, 1)) < 0.25).astype(np.int64)
+    steps, t_total = 0, 0.0
+    while True:
+        t0 = time.perf_counter()
+        y1, y2, feat, sum_emb = c_fm_fwd(lib, ids, dense, W, W1, dw, dw1, 0, so)
+        y_dnn, acts = R.dnn_forward(feat, mw, mb, return_acts=True)
+        pred = R.sigmoid(y1[:, None] + y2[:, None] + y_dnn)
+        dz = R.log_loss_mean_grad_z(pred, label).astype(np.float32)
+        dflat, dws, dbs = R.dnn_backward(dz, acts, mw)
+        rg, rg1, ddw, ddw1 = c_fm_bwd(lib, S, dense, feat, sum_emb, dflat.reshape(feat.shape), dz, dz)
+        rows, valid = R.effective_rows(ids, 0, so)
+        spos, uniq, offs = R.group_ids(rows.reshape(-1), valid.reshape(-1))
+        c_adam_rows(lib, uniq, offs, spos, rg, W, M, V, steps + 1)
+        t_total += time.perf_counter() - t0
+        steps += 1
+        if t_total > budget_s or steps >= 8:
+            break
+    return {"value": B * steps / t_total, "unit": "samples/s", "cores": int(cores), "kind": "port",
+            "sample": "%d full steps of batch %d (oracle: C embedding+FM fwd/bwd+lazy Adam on the "
+                      "embedding table, NumPy/BLAS MLP; first-order table + dense Adam omitted), "
+                      "%.1f s" % (steps, B, t_total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--dim", type=int, default=16)
+    ap.add_argument("--rows-per-table", type=int, default=1_000_000)
+    ap.add_argument("--fc", type=str, default="400,400,400")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from paddlerec_amd import _lib
+    _lib.lib()                                   # fail loudly if the HIP library is not built
+    B, S, Dn, D = args.batch, 26, 13, args.dim
+    fc = [int(x) for x in args.fc.split(",")]
+    N = args.rows_per_table * S
+    so = torch.arange(S, dtype=torch.int64, device=dev) * args.rows_per_table
+    if world == 1:
+        from paddlerec_amd.deepfm import DeepFMLayer
+        model = DeepFMLayer(N, D, Dn, S, fc, device=dev, slot_offset=so)
+        parallelism = "single"
+    else:
+        from paddlerec_amd.sharded import ShardedDeepFMLayer
+        model = ShardedDeepFMLayer(N, D, Dn, S, fc, device=dev, slot_offset=so, group=dist.group.WORLD)
+        parallelism = "rowshard%d+dp%d" % (world, world)
+    batches = make_batches(4, B, S, Dn, args.rows_per_table, dev, 20250404 + rank)
+
+    def step(i):
+        ids, dense, label = batches[i % len(batches)]
+        return model.train_step(ids, dense, label, lr=1e-3)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    model.timers = {}
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = 1e3 * dt / args.steps
+    loss_v = float(loss.item())
+    oob = int(model.status.item())
+
+    def avg_ms(name):
+        ev = model.timers.get(name, [])
+        return sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+
+    k_ms = {k: avg_ms(k) for k in model.timers}
+    fwd_b, bwd_b = algorithmic_bytes(B, S, Dn, D)
+    t_pair = (k_ms.get("fm_fwd", 0) + k_ms.get("fm_bwd", 0)) * 1e-3
+    achieved = (fwd_b + bwd_b) / t_pair / 1e9 if t_pair > 0 else 0.0
+    sizes = [(S + Dn) * D] + fc + [1]
+    gemm_tf = 3 * mlp_flops(B, sizes) / ((k_ms.get("mlp_fwd", 0) + k_ms.get("mlp_bwd", 0)) * 1e-3) / 1e12 \
+        if k_ms.get("mlp_fwd") else 0.0
+    out = {
+        "metric": "CTR samples/sec, Criteo DeepFM bs=65536 (train step: fwd+bwd+optimizer)",
+        "value": world * B * args.steps / dt, "unit": "samples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "DeepFM full Criteo: 26 sparse slots x %d rows x dim %d, 13 dense, "
+                               "MLP %s, batch %d per GPU, lazy Adam" % (args.rows_per_table, D, args.fc, B),
+                   "global_batch": world * B, "parallelism": parallelism,
+                   "table_rows_total": N, "loss": loss_v, "index_oob_flag": oob},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "fm_fwd_kernel + fm_bwd_kernel (embedding+FM fwd+bwd, SURVEY §8(d) bytes: "
+                               "%d B/sample)" % ((fwd_b + bwd_b) // B),
+                     "fm_fwd_ms": k_ms.get("fm_fwd"), "fm_bwd_ms": k_ms.get("fm_bwd"),
+                     "fm_fwd_GBs": fwd_b / (k_ms["fm_fwd"] * 1e-3) / 1e9 if k_ms.get("fm_fwd") else None,
+                     "fm_bwd_GBs": bwd_b / (k_ms["fm_bwd"] * 1e-3) / 1e9 if k_ms.get("fm_bwd") else None},
+        "kernels_ms": k_ms,
+        "mlp_gemm": {"bound": "mfma", "achieved": gemm_tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": gemm_tf / FP32_MFMA_PEAK_TF},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(B, S, Dn, D, fc, args.rows_per_table, args.cpu_budget)
+            except Exception as e:  # the oracle .so is test infrastructure; report, do not hide
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,24 @@ class _FlatParams:
             o += k
 
 
+class _Timed:
+    """Brackets a region with HIP events on the current stream when a timers dict is installed."""
+
+    def __init__(self, timers, name):
+        self.timers, self.name = timers, name
+
+    def __enter__(self):
+        if self.timers is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.timers is not None:
+            self.e1.record()
+            self.timers.setdefault(self.name, []).append((self.e0, self.e1))
+
+
 class FM:
     """net.py:52-139.  Holds embedding_one [N,1], embedding [N,D]; dense_w_one/dense_w live in the
     flat dense buffer of the owning DeepFMLayer."""
@@ -134,6 +152,7 @@ class DeepFMLayer:
         self.status = ops.new_status(self.device)
         self.step_count = 0
         self._side = None
+        self.timers = None      # bench.py: dict name -> list of (start,end) torch.cuda.Event pairs
 
     # -- parameters under the reference's state_dict keys (Appendix C) -------------------------
     def state_dict(self):
@@ -195,25 +214,34 @@ class DeepFMLayer:
         with torch.cuda.stream(self._side):
             ops.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
                           self.fm.slot_offset, self.status, groups)
-        y1, y2, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
-        y_dnn, acts = mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b)
+        with self._timed("fm_fwd"):
+            y1, y2, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
+        with self._timed("mlp_fwd"):
+            y_dnn, acts = mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b)
         pred, dz, loss = ops.sigmoid_logloss(y1, y2, y_dnn, label, self.ws)
         if auc_stats is not None:
             ops.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
-        d_flat = mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db)
-        row_grad, _, _ = ops.deepfm_fm_bwd(
-            dense_inputs, feat, sum_emb, d_flat.view(B, self.num_field, -1), dz, dz, S, self.ws,
-            out=(self._row_grad_buf(B * S), self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
-                 self.dense.g["fm.dense_w_one"]))
+        with self._timed("mlp_bwd"):
+            d_flat = mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db)
+        with self._timed("fm_bwd"):
+            row_grad, _, _ = ops.deepfm_fm_bwd(
+                dense_inputs, feat, sum_emb, d_flat.view(B, self.num_field, -1), dz, dz, S, self.ws,
+                out=(self._row_grad_buf(B * S),
+                     self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
+                     self.dense.g["fm.dense_w_one"]))
         if allreduce is not None:
             allreduce(self.dense.grad)
         t = self.step_count
         ops.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
         cur.wait_stream(self._side)
         st = self.sparse_state
-        ops.sparse_adam_rows(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr)
-        ops.sparse_adam_rows(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
+        with self._timed("sparse_adam"):
+            ops.sparse_adam_rows(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr)
+            ops.sparse_adam_rows(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
         return loss, pred
+
+    def _timed(self, name):
+        return _Timed(self.timers, name)
 
     def _row_grad_buf(self, n):
         b = getattr(self, "_rg", None)

@@ -1,0 +1,448 @@
+"""GPU parity tests: every HIP kernel on the DeepFM path, called through the C-ABI, against the
+oracle (oracle/deepfm_ref.py, oracle/deepfm_oracle.c) and the golden fixtures.
+
+Bars (north star): indices / pooling counts / histograms bit-exact; fp32 within 1e-5 relative.
+`ATOL` bounds the fp32 summation-order noise of values that are sums of O(40..1e5) terms of
+magnitude <= ~0.1 (measured against the float64 oracle in test_fp32_noise_floor).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import deepfm_params_from_golden, load_golden, make_deepfm_problem
+from oracle import deepfm_ref as R
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+ATOL = 2e-7
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops(engine_lib):
+    from paddlerec_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+def T(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+def run_fm_fwd(ops, pr):
+    p = pr["params"]
+    so = T(pr["slot_offsets"]) if pr.get("slot_offsets") is not None else None
+    y1, y2, feat, sum_emb, status = ops.deepfm_fm_fwd(
+        T(pr["ids"]), T(pr["dense"]), T(p["W"]), T(p["W1"]), T(p["dense_w"]), T(p["dense_w_one"]),
+        0, so)
+    assert int(status.item()) == 0
+    return y1, y2, feat, sum_emb
+
+
+# ------------------------------------------------------------------------------ forward
+@pytest.mark.parametrize("name", ["deepfm_D9", "deepfm_D16"])
+def test_fm_fwd_golden(ops, name):
+    g = load_golden(name)
+    pr = dict(ids=g["ids"], dense=g["dense"], params=deepfm_params_from_golden(g))
+    y1, y2, feat, sum_emb = run_fm_fwd(ops, pr)
+    assert np.array_equal(N_(feat), g["feat"])                      # gather + multiply: bit-exact
+    np.testing.assert_allclose(N_(y1), g["y1"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(N_(y2), g["y2"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(N_(sum_emb), g["feat"].sum(1), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("B,D,zipf,tables", [
+    (1, 16, False, False), (63, 16, False, False), (1000, 16, True, False), (513, 16, False, True),
+    (257, 9, False, False), (300, 10, True, False), (130, 40, False, False), (65, 64, False, False),
+    (70, 7, False, False), (40, 128, False, False)])
+def test_fm_fwd_vs_oracle(ops, B, D, zipf, tables):
+    pr = make_deepfm_problem(B=B, D=D, N=3000, seed=B + D, zipf=zipf, tables=tables)
+    p = pr["params"]
+    y1, y2, feat, sum_emb = run_fm_fwd(ops, pr)
+    ry1, ry2, rfeat = R.fm_forward(pr["ids"], pr["dense"], p["W1"], p["W"], p["dense_w_one"],
+                                   p["dense_w"], 0, pr["slot_offsets"])
+    assert np.array_equal(N_(feat), rfeat)
+    np.testing.assert_allclose(N_(y1), ry1, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(N_(y2), ry2, rtol=RTOL, atol=ATOL * D)
+    np.testing.assert_allclose(N_(sum_emb), rfeat.sum(1), rtol=RTOL, atol=ATOL)
+
+
+def test_fm_fwd_edge_cases(ops):
+    # all-padding batch: zero sparse rows, y1/y2 come from the dense fields only
+    pr = make_deepfm_problem(B=32, N=100, seed=1)
+    pr["ids"][:] = 0
+    y1, y2, feat, _ = run_fm_fwd(ops, pr)
+    assert np.all(N_(feat)[:, :26] == 0)
+    ry1, ry2, _ = R.fm_forward(pr["ids"], pr["dense"], pr["params"]["W1"], pr["params"]["W"],
+                               pr["params"]["dense_w_one"], pr["params"]["dense_w"])
+    np.testing.assert_allclose(N_(y1), ry1, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(N_(y2), ry2, rtol=RTOL, atol=ATOL)
+    # empty batch is a no-op
+    e = ops.deepfm_fm_fwd(torch.zeros(0, 26, dtype=torch.int64, device=DEV),
+                          torch.zeros(0, 13, device=DEV), T(pr["params"]["W"]), T(pr["params"]["W1"]),
+                          T(pr["params"]["dense_w"]), T(pr["params"]["dense_w_one"]))
+    assert e[2].shape == (0, 39, 16)
+    # out-of-range id: flagged in the device status word, row treated as zero, no crash
+    pr2 = make_deepfm_problem(B=8, N=100, seed=2)
+    pr2["ids"][3, 5] = 100
+    pr2["ids"][4, 6] = -7
+    p = pr2["params"]
+    _, _, feat2, _, status = ops.deepfm_fm_fwd(T(pr2["ids"]), T(pr2["dense"]), T(p["W"]), T(p["W1"]),
+                                               T(p["dense_w"]), T(p["dense_w_one"]))
+    assert int(status.item()) & 1
+    assert np.all(N_(feat2)[3, 5] == 0) and np.all(N_(feat2)[4, 6] == 0)
+    with pytest.raises(Exception):
+        ops.raise_on_status(status)
+
+
+def test_no_cpu_fallback(ops):
+    pr = make_deepfm_problem(B=4, N=50, seed=0)
+    p = pr["params"]
+    with pytest.raises(Exception, match="device tensor"):
+        ops.deepfm_fm_fwd(torch.as_tensor(pr["ids"]), torch.as_tensor(pr["dense"]),
+                          torch.as_tensor(p["W"]), torch.as_tensor(p["W1"]),
+                          torch.as_tensor(p["dense_w"]), torch.as_tensor(p["dense_w_one"]))
+
+
+def test_fp32_noise_floor():
+    """Justifies ATOL: float32 oracle vs float64 oracle on the same inputs."""
+    pr = make_deepfm_problem(B=512, N=3000, seed=77)
+    p = pr["params"]
+    p64 = {k: (v.astype(np.float64) if not isinstance(v, list) else [x.astype(np.float64) for x in v])
+           for k, v in p.items()}
+    y1, y2, _ = R.fm_forward(pr["ids"], pr["dense"], p["W1"], p["W"], p["dense_w_one"], p["dense_w"])
+    z1, z2, _ = R.fm_forward(pr["ids"], pr["dense"].astype(np.float64), p64["W1"], p64["W"],
+                             p64["dense_w_one"], p64["dense_w"])
+    assert np.abs(y1 - z1).max() < ATOL and np.abs(y2 - z2).max() < ATOL * 16
+
+
+# ------------------------------------------------------------------------------ backward
+@pytest.mark.parametrize("B,D,tables", [(1, 16, False), (777, 16, False), (2100, 16, True),
+                                        (257, 9, False), (129, 40, False)])
+def test_fm_bwd_vs_oracle(ops, oracle_lib, B, D, tables):
+    from helpers import c_fm_bwd
+    pr = make_deepfm_problem(B=B, D=D, N=3000, seed=B, tables=tables)
+    y1, y2, feat, sum_emb = run_fm_fwd(ops, pr)
+    rng = np.random.default_rng(B)
+    dfeat = (rng.standard_normal(feat.shape) * 1e-3).astype(np.float32)
+    dz = (rng.standard_normal((B, 1)) * 1e-3).astype(np.float32)
+    ws = ops.Workspace(DEV)
+    rg, ddw, ddw1 = ops.deepfm_fm_bwd(T(pr["dense"]), feat, sum_emb, T(dfeat), T(dz), T(dz), 26, ws)
+    ref = R.fm_backward(pr["ids"], pr["dense"], N_(feat), dfeat, dz, dz, 0, pr["slot_offsets"])
+    np.testing.assert_allclose(N_(rg), ref["row_grad"], rtol=RTOL, atol=1e-9)
+    # batch sums: compare against the float64 oracle (summation-order independent truth)
+    ref64 = R.fm_backward(pr["ids"], pr["dense"].astype(np.float64), N_(feat).astype(np.float64),
+                          dfeat.astype(np.float64), dz.astype(np.float64), dz.astype(np.float64))
+    scale = np.abs(ref64["d_dense_w"]).max()
+    np.testing.assert_allclose(N_(ddw), ref64["d_dense_w"][0], rtol=RTOL, atol=RTOL * scale)
+    np.testing.assert_allclose(N_(ddw1), ref64["d_dense_w_one"], rtol=RTOL,
+                               atol=RTOL * np.abs(ref64["d_dense_w_one"]).max())
+    # C oracle agrees as well (independent restatement)
+    crg, _, cddw, _ = c_fm_bwd(oracle_lib, 26, pr["dense"], N_(feat), N_(sum_emb), dfeat, dz, dz)
+    np.testing.assert_allclose(N_(rg), crg, rtol=RTOL, atol=1e-9)
+    # deterministic: same bits on a second run
+    rg2, ddw2, _ = ops.deepfm_fm_bwd(T(pr["dense"]), feat, sum_emb, T(dfeat), T(dz), T(dz), 26, ws)
+    assert torch.equal(rg, rg2) and torch.equal(ddw, ddw2)
+
+
+# ------------------------------------------------------------------------------ ids grouping
+@pytest.mark.parametrize("B,N,pad_frac,zipf,tables", [
+    (1, 50, 0.0, False, False), (64, 50, 0.2, False, False), (1000, 100000, 0.03, True, False),
+    (4096, 1000, 0.03, False, True), (333, 7, 0.5, False, False)])
+def test_ids_group_bit_exact(ops, B, N, pad_frac, zipf, tables):
+    pr = make_deepfm_problem(B=B, N=N, seed=B, pad_frac=pad_frac, zipf=zipf, tables=tables)
+    so = T(pr["slot_offsets"]) if tables else None
+    ws = ops.Workspace(DEV)
+    groups, status = ops.ids_group(T(pr["ids"]), pr["N"], 0, ws, so)
+    spos, uniq, offs = groups.host()
+    rows, valid = R.effective_rows(pr["ids"], 0, pr["slot_offsets"])
+    rspos, runiq, roffs = R.group_ids(rows.reshape(-1), valid.reshape(-1))
+    assert int(status.item()) == 0
+    assert np.array_equal(spos, rspos) and np.array_equal(uniq, runiq) and np.array_equal(offs, roffs)
+
+
+def test_ids_group_edge_cases(ops):
+    ws = ops.Workspace(DEV)
+    ids = torch.zeros(16, 26, dtype=torch.int64, device=DEV)          # nothing but padding
+    groups, _ = ops.ids_group(ids, 100, 0, ws)
+    assert groups.n_uniq.tolist() == [0, 0]
+    groups, _ = ops.ids_group(torch.zeros(0, 26, dtype=torch.int64, device=DEV), 100, 0, ws)
+    assert groups.n_uniq.tolist() == [0, 0]
+    ids = torch.full((5, 26), 7, dtype=torch.int64, device=DEV)       # one row, 130 duplicates
+    groups, _ = ops.ids_group(ids, 100, 0, ws)
+    spos, uniq, offs = groups.host()
+    assert uniq.tolist() == [7] and offs.tolist() == [0, 130] and spos.tolist() == list(range(130))
+    ids[2, 3] = 1000                                                   # out of range -> flagged, dropped
+    groups, status = ops.ids_group(ids, 100, 0, ws)
+    assert int(status.item()) & 1 and groups.n_uniq.tolist() == [1, 129]
+    big = torch.randint(1, 3_000_000_000, (64, 26), dtype=torch.int64, device=DEV)   # 64-bit key path
+    groups, _ = ops.ids_group(big, 5_000_000_000, 0, ws)
+    spos, uniq, offs = groups.host()
+    rspos, runiq, roffs = R.group_ids(N_(big).reshape(-1), np.ones(64 * 26, bool))
+    assert np.array_equal(spos, rspos) and np.array_equal(uniq, runiq) and np.array_equal(offs, roffs)
+
+
+# ------------------------------------------------------------------------------ optimizers
+@pytest.mark.parametrize("D,zipf", [(16, False), (16, True), (9, False), (1, False), (40, True)])
+def test_sparse_adam_rows_vs_oracle(ops, D, zipf):
+    B, S, N = 600, 26, 500
+    pr = make_deepfm_problem(B=B, N=N, D=max(D, 2), seed=D, zipf=zipf, pad_frac=0.05)
+    rng = np.random.default_rng(D)
+    rows, valid = R.effective_rows(pr["ids"])
+    P = (rng.standard_normal((N, D)) * 0.1).astype(np.float32)
+    M = (rng.standard_normal((N, D)) * 0.01).astype(np.float32)
+    V = (np.abs(rng.standard_normal((N, D))) * 1e-4).astype(np.float32)
+    grad = (rng.standard_normal((B * S, D)) * 1e-2).astype(np.float32)
+    ws = ops.Workspace(DEV)
+    groups, _ = ops.ids_group(T(pr["ids"]), N, 0, ws)
+    tP, tM, tV = T(P), T(M), T(V)
+    uniq, merged, _ = R.merge_rows(rows.reshape(-1), valid.reshape(-1), grad)
+    for step in (1, 2, 7):
+        ops.sparse_adam_rows(groups, T(grad), 1, tP, tM, tV, step, lr=1e-3)
+        R.adam_update_rows(P, M, V, uniq, merged, step, lr=1e-3)
+    # atol: M ~ 1e-2 and V ~ 1e-4 are sums of opposite-sign terms; 1e-5 of their scale
+    np.testing.assert_allclose(N_(tM), M, rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(N_(tV), V, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(N_(tP), P, rtol=RTOL, atol=1e-6)
+    untouched = np.setdiff1d(np.arange(N), uniq)
+    assert np.array_equal(N_(tP)[untouched], P[untouched])            # lazy: other rows untouched
+
+
+def test_sparse_adam_first_order_via_grad_div(ops):
+    """embedding_one: SelectedRows.value is dy1[b] for all S slots of sample b (grad_div = S)."""
+    B, S, N = 300, 26, 200
+    pr = make_deepfm_problem(B=B, N=N, seed=4, pad_frac=0.1)
+    rng = np.random.default_rng(4)
+    dz = (rng.standard_normal((B, 1)) * 1e-2).astype(np.float32)
+    rows, valid = R.effective_rows(pr["ids"])
+    P = (rng.standard_normal((N, 1)) * 0.1).astype(np.float32)
+    M, V = np.zeros_like(P), np.zeros_like(P)
+    ws = ops.Workspace(DEV)
+    groups, _ = ops.ids_group(T(pr["ids"]), N, 0, ws)
+    tP, tM, tV = T(P), T(M), T(V)
+    ops.sparse_adam_rows(groups, T(dz), S, tP, tM, tV, 1)
+    uniq, merged, _ = R.merge_rows(rows.reshape(-1), valid.reshape(-1), np.repeat(dz, S, 1).reshape(-1, 1))
+    R.adam_update_rows(P, M, V, uniq, merged, 1)
+    np.testing.assert_allclose(N_(tP), P, rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(N_(tM), M, rtol=RTOL, atol=1e-10)
+
+
+def test_adam_dense_vs_oracle(ops):
+    rng = np.random.default_rng(0)
+    n = 100003
+    p = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    tp, tm, tv = T(p), T(m), T(v)
+    for step in range(1, 5):
+        g = (rng.standard_normal(n) * 0.1).astype(np.float32)
+        ops.adam_dense(tp, tm, tv, T(g), step)
+        R.adam_update(p, m, v, g, step)
+    np.testing.assert_allclose(N_(tp), p, rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(N_(tv), v, rtol=RTOL, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------ loss head / AUC
+def test_sigmoid_logloss_and_auc(ops):
+    rng = np.random.default_rng(3)
+    B = 10007
+    y1, y2, y3 = [(rng.standard_normal((B, 1)) * 2).astype(np.float32) for _ in range(3)]
+    y1[:3] = [[40.0], [-40.0], [0.0]]                                   # saturated logits
+    y2[:3] = 0; y3[:3] = 0
+    label = (rng.random((B, 1)) < 0.3).astype(np.int64)
+    ws = ops.Workspace(DEV)
+    pred, dz, loss = ops.sigmoid_logloss(T(y1), T(y2), T(y3), T(label), ws)
+    z = (y1 + y2 + y3).astype(np.float64)
+    p64 = R.sigmoid(z)
+    np.testing.assert_allclose(N_(pred), p64, rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(N_(loss)[0], R.log_loss_mean(p64, label), rtol=RTOL)
+    # dz is evaluated from the float32 pred, as the reference does (sigmoid output feeds log_loss):
+    # compare on the SAME float32 pred so the (1-p) cancellation is identical on both sides
+    np.testing.assert_allclose(N_(dz), R.log_loss_mean_grad_z(N_(pred), label), rtol=2e-5, atol=1e-10)
+    ok = np.abs(z) < 4                      # away from saturation the float64 truth agrees too
+    np.testing.assert_allclose(N_(dz)[ok], R.log_loss_mean_grad_z(p64, label)[ok], rtol=1e-4, atol=1e-10)
+    # AUC histogram: integer counts, bit-exact against the oracle on the SAME float32 predictions
+    pos = torch.zeros(4096, dtype=torch.int64, device=DEV)
+    neg = torch.zeros(4096, dtype=torch.int64, device=DEV)
+    ops.auc_histogram(pred, T(label), pos, neg)
+    ops.auc_histogram(pred, T(label), pos, neg)                         # accumulates
+    rpos, rneg = R.auc_histogram(N_(pred), label)
+    assert np.array_equal(N_(pos), 2 * rpos) and np.array_equal(N_(neg), 2 * rneg)
+    from paddlerec_amd.deepfm import auc_from_buckets
+    assert auc_from_buckets(N_(pos), N_(neg)) == R.auc_from_buckets(2 * rpos, 2 * rneg)
+
+
+# ------------------------------------------------------------------------------ gather / sum-pool
+@pytest.mark.parametrize("D", [9, 16, 64])
+def test_gather_and_sumpool(ops, D):
+    rng = np.random.default_rng(D)
+    N, B = 1000, 300
+    W = rng.standard_normal((N, D)).astype(np.float32)
+    lens = rng.integers(0, 20, B)
+    lens[0] = 0; lens[1] = 150                                          # empty and long segments
+    lod = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ids = rng.integers(0, N, lod[-1], dtype=np.int64)                   # id 0 = padding, occurs
+    out, counts, status = ops.emb_gather_sumpool(T(ids), T(lod), T(W), 0)
+    rout, rcnt = R.sequence_pool_sum(W, ids, lod)
+    assert int(status.item()) == 0
+    assert np.array_equal(N_(counts), rcnt)                             # pooling counts bit-exact
+    assert np.array_equal(N_(out), rout)                                # same ascending-k order
+    g, _ = ops.emb_gather(T(ids), T(W), 0)
+    assert np.array_equal(N_(g), R.embedding_lookup(W, ids, 0))
+    d_out = rng.standard_normal((B, D)).astype(np.float32)
+    rg = ops.emb_sumpool_bwd(T(lod), T(d_out), int(lod[-1]))
+    assert np.array_equal(N_(rg), np.repeat(d_out, lens, axis=0))
+
+
+# ------------------------------------------------------------------------------ end to end
+@pytest.mark.parametrize("name", ["deepfm_D9", "deepfm_D16"])
+def test_deepfm_layer_forward_and_grads_golden(ops, name):
+    """Host mirror + kernels reproduce the reference net.py outputs and autograd gradients."""
+    from paddlerec_amd.deepfm import DeepFMLayer
+    g = load_golden(name)
+    D = int(g["D"])
+    m = DeepFMLayer(1001, D, 13, 26, [32, 16], device=DEV)
+    sd = {"fm.embedding.weight": g["W"], "fm.embedding_one.weight": g["W1"],
+          "fm.dense_w": g["dense_w"], "fm.dense_w_one": g["dense_w_one"]}
+    for i in range(int(g["n_mlp"])):
+        sd["dnn.linear_%d.weight" % i] = g["mlp_w%d" % i]
+        sd["dnn.linear_%d.bias" % i] = g["mlp_b%d" % i]
+    m.set_dict(sd)
+    sparse_inputs = [T(g["ids"][:, s:s + 1]) for s in range(26)]        # list of [B,1], as the reader feeds
+    pred = m.forward(sparse_inputs, T(g["dense"]))
+    np.testing.assert_allclose(N_(pred), g["pred"], rtol=RTOL, atol=ATOL)
+    W0 = g["W"].copy()
+    loss, _ = m.train_step(sparse_inputs, T(g["dense"]), T(g["label"]), lr=1e-3)
+    np.testing.assert_allclose(N_(loss)[0], g["loss"], rtol=RTOL)
+    for i in range(int(g["n_mlp"])):
+        np.testing.assert_allclose(N_(m.dense.g["dnn.linear_%d.weight" % i]), g["g_mlp_w%d" % i],
+                                   rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(N_(m.dense.g["fm.dense_w"]), g["g_dense_w"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(N_(m.dense.g["fm.dense_w_one"]), g["g_dense_w_one"], rtol=1e-4, atol=1e-8)
+    # first Adam step moves each touched row by -lr*sign(g) (m/(sqrt(v)+eps) = sign at t=1)
+    moved = N_(m.fm.embedding) - W0
+    touched = np.abs(g["gW"]) > 1e-4                 # update = lr*g/(|g|+eps): eps=1e-8 matters for tiny g
+    np.testing.assert_allclose(moved[touched], -1e-3 * np.sign(g["gW"][touched]), rtol=1e-3)
+    assert np.all(moved[g["gW"] == 0] == 0)
+
+
+def test_train_steps_vs_oracle(ops):
+    """3 full steps (fwd + bwd + lazy Adam on tables + dense Adam) against the NumPy oracle."""
+    from paddlerec_amd.deepfm import DeepFMLayer
+    B, N, D, fc = 256, 400, 16, [32, 16]
+    pr = make_deepfm_problem(B=B, N=N, D=D, fc=fc, seed=11, pad_frac=0.05)
+    p = pr["params"]
+    m = DeepFMLayer(N, D, 13, 26, fc, device=DEV)
+    sd = {"fm.embedding.weight": p["W"], "fm.embedding_one.weight": p["W1"],
+          "fm.dense_w": p["dense_w"], "fm.dense_w_one": p["dense_w_one"]}
+    for i in range(len(fc) + 1):
+        sd["dnn.linear_%d.weight" % i] = p["mlp_w"][i]
+        sd["dnn.linear_%d.bias" % i] = p["mlp_b"][i]
+    m.set_dict(sd)
+    # oracle state
+    op = {k: (v.copy() if not isinstance(v, list) else [x.copy() for x in v]) for k, v in p.items()}
+    st = {k: np.zeros_like(v) for k, v in (("mW", p["W"]), ("vW", p["W"]), ("mW1", p["W1"]), ("vW1", p["W1"]))}
+    dstate = {}
+    rng = np.random.default_rng(5)
+    for step in (1, 2, 3):
+        ids = rng.integers(0, N, (B, 26), dtype=np.int64)
+        dense = rng.random((B, 13), dtype=np.float32)
+        label = (rng.random((B, 1)) < 0.3).astype(np.int64)
+        loss, pred = m.train_step(T(ids), T(dense), T(label), lr=1e-2)
+        o = R.deepfm_loss_and_grads(ids, dense, label, op)
+        np.testing.assert_allclose(N_(loss)[0], o["loss"], rtol=RTOL)
+        np.testing.assert_allclose(N_(pred), o["pred"], rtol=RTOL, atol=ATOL)
+        uniq, merged, _ = R.merge_rows(o["rows"], o["row_valid"], o["row_grad"])
+        R.adam_update_rows(op["W"], st["mW"], st["vW"], uniq, merged, step, lr=1e-2)
+        uniq1, merged1, _ = R.merge_rows(o["rows"], o["row_valid"], o["row_grad1"])
+        R.adam_update_rows(op["W1"], st["mW1"], st["vW1"], uniq1, merged1, step, lr=1e-2)
+        dense_pairs = [("dense_w", o["d_dense_w"]), ("dense_w_one", o["d_dense_w_one"])]
+        for i in range(len(fc) + 1):
+            dense_pairs += [(("mlp_w", i), o["mlp_dw"][i]), (("mlp_b", i), o["mlp_db"][i])]
+        for key, gr in dense_pairs:
+            arr = op[key] if not isinstance(key, tuple) else op[key[0]][key[1]]
+            mm, vv = dstate.setdefault(key, (np.zeros_like(arr), np.zeros_like(arr)))
+            R.adam_update(arr, mm, vv, gr.reshape(arr.shape).astype(arr.dtype), step, lr=1e-2)
+    assert int(m.status.item()) == 0
+    # after 3 Adam steps at lr=1e-2 weights moved by ~3e-2; agreement well inside 1e-4 absolute
+    np.testing.assert_allclose(N_(m.fm.embedding), op["W"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(N_(m.fm.embedding_one), op["W1"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(N_(m.dense.p["dnn.linear_0.weight"]), op["mlp_w"][0], rtol=1e-3, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------ full size (BASELINE config 2)
+def test_full_size_properties(ops):
+    """B=65536, 26 tables x 1M rows x D=16: size-independent properties instead of an oracle run."""
+    from paddlerec_amd.deepfm import DeepFMLayer
+    B, S, D, NT = 65536, 26, 16, 1_000_000
+    N = NT * S
+    gen = torch.Generator(device=DEV).manual_seed(20250404)
+    W = (torch.randn(N, D, device=DEV, generator=gen) * 0.025)
+    W1 = (torch.randn(N, 1, device=DEV, generator=gen) * 0.025)
+    dw = torch.randn(1, 13, D, device=DEV, generator=gen) * 0.025
+    dw1 = torch.randn(13, device=DEV, generator=gen) * 0.025
+    ids = torch.randint(1, NT, (B, S), device=DEV, generator=gen)
+    ids[torch.rand(B, S, device=DEV, generator=gen) < 0.03] = 0
+    dense = torch.rand(B, 13, device=DEV, generator=gen)
+    so = torch.arange(S, device=DEV, dtype=torch.int64) * NT
+    y1, y2, feat, sum_emb, status = ops.deepfm_fm_fwd(ids, dense, W, W1, dw, dw1, 0, so)
+    assert int(status.item()) == 0
+    # (1) feat is exactly the gathered rows / dense products
+    rows = ids + so[None, :]
+    want = W[rows] * (ids != 0).unsqueeze(-1)
+    assert torch.equal(feat[:, :S], want)
+    assert torch.equal(feat[:, S:], dense.unsqueeze(2) * dw)
+    # (2) FM identity in float64 from the kernel's own feat
+    f64 = feat.double()
+    y2_64 = 0.5 * (f64.sum(1) ** 2 - (f64 ** 2).sum(1)).sum(1, keepdim=True)
+    torch.testing.assert_close(y2.double(), y2_64, rtol=RTOL, atol=1e-6)
+    y1_64 = (W1[rows].double() * (ids != 0).unsqueeze(-1)).sum(1) + (dense.double() * dw1.double()).sum(1, keepdim=True)
+    torch.testing.assert_close(y1.double(), y1_64, rtol=RTOL, atol=1e-6)
+    # (3) grouping invariants: permutation of the non-padding positions, sorted rows, counts add up
+    ws = ops.Workspace(DEV)
+    groups, _ = ops.ids_group(ids, N, 0, ws, so)
+    U, nv = groups.n_uniq.tolist()
+    assert nv == int((ids != 0).sum())
+    spos = groups.sorted_pos[:nv].long()
+    assert torch.equal(torch.sort(spos).values, torch.nonzero((ids != 0).reshape(-1)).reshape(-1))
+    srows = rows.reshape(-1)[spos]
+    assert bool((srows[1:] >= srows[:-1]).all())
+    uniq = groups.uniq_rows[:U]
+    assert torch.equal(uniq, torch.unique(srows))
+    offs = groups.seg_offset[:U + 1].long()
+    assert int(offs[0]) == 0 and int(offs[-1]) == nv and bool((offs[1:] > offs[:-1]).all())
+    assert torch.equal(srows[offs[:-1]], uniq)
+    # (4) backward is linear in the incoming gradients; merged row-gradient mass is conserved
+    dfeat = torch.randn(B, S + 13, D, device=DEV, generator=gen) * 1e-3
+    dz = torch.randn(B, 1, device=DEV, generator=gen) * 1e-3
+    rg1, ddw_a, _ = ops.deepfm_fm_bwd(dense, feat, sum_emb, dfeat, dz, dz, S, ws)
+    rg1 = rg1.clone(); ddw_a = ddw_a.clone()
+    rg2, ddw_b, _ = ops.deepfm_fm_bwd(dense, feat, sum_emb, 2 * dfeat, 2 * dz, 2 * dz, S, ws)
+    torch.testing.assert_close(rg2, 2 * rg1, rtol=1e-6, atol=1e-12)
+    torch.testing.assert_close(ddw_b, 2 * ddw_a, rtol=1e-5, atol=1e-9)
+    want_rg = dfeat[:, :S] + dz.unsqueeze(2) * (sum_emb.unsqueeze(1) - feat[:, :S])
+    torch.testing.assert_close(rg1.view(B, S, D), want_rg, rtol=1e-5, atol=1e-9)
+    # (5) lazy Adam at t=1 from zero moments moves exactly the touched rows, by lr*sign(merged grad)
+    M = torch.zeros_like(W); V = torch.zeros_like(W); P = W.clone()
+    ops.sparse_adam_rows(groups, rg1, 1, P, M, V, 1, lr=1e-3)
+    delta = P - W
+    touched = torch.zeros(N, dtype=torch.bool, device=DEV); touched[uniq] = True
+    assert bool((delta[~touched] == 0).all())
+    merged = torch.zeros(N, D, device=DEV, dtype=torch.float64)
+    merged.index_add_(0, rows.reshape(-1)[(ids != 0).reshape(-1)], rg1.double()[(ids != 0).reshape(-1)])
+    torch.testing.assert_close(M[uniq].double(), 0.1 * merged[uniq], rtol=1e-4, atol=1e-10)
+    big = merged[uniq].abs() > 1e-6
+    torch.testing.assert_close(delta[uniq][big].double(), (-1e-3 * torch.sign(merged[uniq]))[big],
+                               rtol=2e-2, atol=0)
+    del W, P, M, V, merged
+    torch.cuda.empty_cache()
+    # (6) the host mirror runs a whole step at this size and the loss is finite and decreases
+    m = DeepFMLayer(N, D, 13, S, [400, 400, 400], device=DEV, slot_offset=so)
+    label = (torch.rand(B, 1, device=DEV, generator=gen) < 0.25).long()
+    losses = [float(m.train_step(ids, dense, label, lr=1e-3)[0].item()) for _ in range(4)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert int(m.status.item()) == 0
