@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--rows-per-table", type=int, default=1_000_000)
     ap.add_argument("--fc", type=str, default="400,400,400")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the row-sharded path (RCCL all-to-all) even with one rank")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -132,18 +134,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from paddlerec_amd import _lib
     _lib.lib()                                   # fail loudly if the HIP library is not built
     B, S, Dn, D = args.batch, 26, 13, args.dim
     fc = [int(x) for x in args.fc.split(",")]
-    N = args.rows_per_table * S
-    so = torch.arange(S, dtype=torch.int64, device=dev) * args.rows_per_table
-    if world == 1:
+    # weak scaling: every GPU holds 26 x rows_per_table rows; the global table grows with the world
+    N = args.rows_per_table * S * world
+    so = torch.arange(S, dtype=torch.int64, device=dev) * (args.rows_per_table * world)
+    if dist is None:
         from paddlerec_amd.deepfm import DeepFMLayer
         model = DeepFMLayer(N, D, Dn, S, fc, device=dev, slot_offset=so)
         parallelism = "single"
@@ -151,7 +155,7 @@ def main():
         from paddlerec_amd.sharded import ShardedDeepFMLayer
         model = ShardedDeepFMLayer(N, D, Dn, S, fc, device=dev, slot_offset=so, group=dist.group.WORLD)
         parallelism = "rowshard%d+dp%d" % (world, world)
-    batches = make_batches(4, B, S, Dn, args.rows_per_table, dev, 20250404 + rank)
+    batches = make_batches(4, B, S, Dn, args.rows_per_table * world, dev, 20250404 + rank)
 
     def step(i):
         ids, dense, label = batches[i % len(batches)]

@@ -141,9 +141,12 @@ int rec_adam_dense(int64_t n, float* p, float* m, float* v, const float* g,
  *            cost = log_loss(pred,label,eps=1e-4); avg = mean(cost) (deepfm/dygraph_model.py:53-58)
  * and its gradient dz = d avg / d z.  loss_out[0] = avg (reduced in a fixed order).
  * y2 / y_dnn may be NULL (treated as 0).  workspace >= rec_logloss_workspace_bytes(B).
+ * mean_over = denominator of the mean (0 -> batch).  Data-parallel ranks pass the GLOBAL batch so
+ * that summing gradients over ranks reproduces one step on the concatenated batch.
  * ---------------------------------------------------------------------------------------- */
 int rec_logloss_workspace_bytes(int64_t batch, size_t* bytes);
-int rec_sigmoid_logloss(int64_t batch, const float* y1, const float* y2, const float* y_dnn,
+int rec_sigmoid_logloss(int64_t batch, int64_t mean_over, const float* y1, const float* y2,
+                        const float* y_dnn,
                         const int64_t* label, float eps, float* pred, float* dz, float* loss_out,
                         void* workspace, size_t workspace_bytes, void* stream);
 
@@ -152,6 +155,28 @@ int rec_sigmoid_logloss(int64_t batch, const float* y1, const float* y2, const f
  * stat_pos/stat_neg are i64 [num_thresholds+1], accumulated (not cleared). */
 int rec_auc_histogram(int64_t batch, const float* pred, const int64_t* label,
                       int32_t num_thresholds, int64_t* stat_pos, int64_t* stat_neg, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row-sharded tables: owner(r) = r mod G, local row = r div G.
+ * Stands in for the key-sharded pull/push of core.PSGPU inside exe.train_from_dataset
+ * (tools/static_gpubox_trainer.py:152-160,256; models/rank/dnn/net.py:71-79) [HeterPS is EXT].
+ * One stable partition of the n = B*S lookups by owner:
+ *   send_local_row [n] i64 : local rows grouped by owner (ascending position inside a group) —
+ *                            the message of the ids all-to-all; first sum(send_counts[0..G)) valid
+ *   send_pos       [n] i64 : position b*S+s of each entry (row-grad gather for the bwd exchange)
+ *   send_sample    [n] i64 : b of each entry (dy1 gather for the first-order table)
+ *   slot_of_pos    [n] i64 : 1 + index of a position in send order, 0 for padding — the reply of
+ *                            the rows all-to-all arrives in send order, so this is the `ids` that
+ *                            rec_deepfm_fm_fwd reads the reply buffer with (row 0 = zero row)
+ *   send_counts  [G+1] i64 : entries per owner; [G] = dropped (padding / out-of-range) positions
+ * All outputs are bit-exact targets.
+ * ---------------------------------------------------------------------------------------- */
+int rec_shard_route_workspace_bytes(int64_t n, int32_t num_shards, size_t* bytes);
+int rec_shard_route(int64_t n, int32_t num_slots, int64_t num_rows, int64_t padding_idx,
+                    int32_t num_shards, const int64_t* ids, const int64_t* slot_offset,
+                    int64_t* send_local_row, int64_t* send_pos, int64_t* send_sample,
+                    int64_t* slot_of_pos, int64_t* send_counts, int32_t* status, void* workspace,
+                    size_t workspace_bytes, void* stream);
 
 /* Row H — feature hash, HOST function: xxh32(str(field_idx)+value) % hash_dim
  * (models/rank/dnn/benchmark_reader.py:52).  `bytes` = the concatenated string. */

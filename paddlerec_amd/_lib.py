@@ -45,8 +45,10 @@ SIGNATURES = {
                                        C.POINTER(AdamHyper), _P]),
     "rec_adam_dense": (C.c_int, [_I64, _P, _P, _P, _P, C.POINTER(AdamHyper), _P]),
     "rec_logloss_workspace_bytes": (C.c_int, [_I64, C.POINTER(_SZ)]),
-    "rec_sigmoid_logloss": (C.c_int, [_I64, _P, _P, _P, _P, _F, _P, _P, _P, _P, _SZ, _P]),
+    "rec_sigmoid_logloss": (C.c_int, [_I64, _I64, _P, _P, _P, _P, _F, _P, _P, _P, _P, _SZ, _P]),
     "rec_auc_histogram": (C.c_int, [_I64, _P, _P, _I32, _P, _P, _P]),
+    "rec_shard_route_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(_SZ)]),
+    "rec_shard_route": (C.c_int, [_I64, _I32, _I64, _I64, _I32] + [_P] * 9 + [_SZ, _P]),
     "rec_xxh32": (C.c_uint32, [C.c_char_p, _SZ, C.c_uint32]),
     "rec_xxh32_hash_mod": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(_I32), _I64, C.c_uint32,
                                      C.POINTER(_I64)]),

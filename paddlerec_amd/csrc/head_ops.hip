@@ -27,12 +27,11 @@ void set_error(const char* fmt, ...) {
 constexpr int kLossBlocks = 1024;
 
 __global__ __launch_bounds__(kBlock) void sigmoid_logloss_kernel(
-    int64_t B, const float* __restrict__ y1, const float* __restrict__ y2,
+    int64_t B, float invB, const float* __restrict__ y1, const float* __restrict__ y2,
     const float* __restrict__ y3, const int64_t* __restrict__ label, float eps,
     float* __restrict__ pred, float* __restrict__ dz, float* __restrict__ partial) {
   __shared__ float red[kBlock / kWave];
   float local = 0.f;
-  const float invB = 1.f / (float)B;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B;
        i += (int64_t)gridDim.x * kBlock) {
     float z = y1[i];
@@ -121,20 +120,23 @@ extern "C" int rec_logloss_workspace_bytes(int64_t batch, size_t* bytes) {
   return REC_OK;
 }
 
-extern "C" int rec_sigmoid_logloss(int64_t batch, const float* y1, const float* y2,
-                                   const float* y_dnn, const int64_t* label, float eps,
+extern "C" int rec_sigmoid_logloss(int64_t batch, int64_t mean_over, const float* y1,
+                                   const float* y2, const float* y_dnn, const int64_t* label,
+                                   float eps,
                                    float* pred, float* dz, float* loss_out, void* workspace,
                                    size_t workspace_bytes, void* stream) {
-  REC_REQUIRE(batch > 0 && y1 && label && loss_out, REC_EINVAL, "bad arguments");
+  REC_REQUIRE(batch > 0 && mean_over >= 0 && y1 && label && loss_out, REC_EINVAL,
+              "bad arguments");
+  const float inv = 1.f / (float)(mean_over > 0 ? mean_over : batch);
   REC_REQUIRE(workspace && workspace_bytes >= kLossBlocks * sizeof(float), REC_EWORKSPACE,
               "workspace too small");
   int64_t grid = (batch + kBlock - 1) / kBlock;
   if (grid > kLossBlocks) grid = kLossBlocks;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(sigmoid_logloss_kernel, dim3((unsigned)grid), dim3(kBlock), 0, st, batch, y1,
-                     y2, y_dnn, label, eps, pred, dz, (float*)workspace);
+  hipLaunchKernelGGL(sigmoid_logloss_kernel, dim3((unsigned)grid), dim3(kBlock), 0, st, batch, inv,
+                     y1, y2, y_dnn, label, eps, pred, dz, (float*)workspace);
   hipLaunchKernelGGL(fold_loss_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)workspace,
-                     (int)grid, 1.f / (float)batch, loss_out);
+                     (int)grid, inv, loss_out);
   return check_launch("rec_sigmoid_logloss");
 }
 

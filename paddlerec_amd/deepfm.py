@@ -92,7 +92,7 @@ class FM:
     flat dense buffer of the owning DeepFMLayer."""
 
     def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim,
-                 sparse_num_field, device, slot_offset=None):
+                 sparse_num_field, device, slot_offset=None, zero_padding_row=True):
         self.sparse_feature_number = sparse_feature_number
         self.sparse_feature_dim = sparse_feature_dim
         self.dense_feature_dim = dense_feature_dim
@@ -106,7 +106,7 @@ class FM:
         self.embedding = torch.empty(N, D, dtype=torch.float32, device=device)
         for t in (self.embedding_one, self.embedding):        # TruncatedNormal(0,std) net.py:72-75
             torch.nn.init.trunc_normal_(t, 0.0, std, -2 * std, 2 * std)
-            if slot_offset is None:
+            if slot_offset is None and zero_padding_row:
                 t[self.padding_idx].zero_()                    # padding row zeroed at construction [EXT]
         self.slot_offset = slot_offset
 
@@ -115,8 +115,14 @@ class DeepFMLayer:
     """net.py:21-49.  forward(sparse_inputs, dense_inputs) -> predict [B,1]."""
 
     def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim,
-                 sparse_num_field, layer_sizes, device="cuda", slot_offset=None):
+                 sparse_num_field, layer_sizes, device="cuda", slot_offset=None, table_rows=None,
+                 zero_padding_row=True, kernels=None, extra_dense=()):
+        """table_rows: rows actually allocated on this device (row-sharded subclass: ceil(N/G));
+        kernels: operator backend (default: the HIP kernels of paddlerec_amd.ops — tests/ may inject
+        a stand-in to exercise host orchestration without a GPU; the product never does);
+        extra_dense: extra (name, shape) entries appended to the flat dense buffer."""
         self.device = torch.device(device)
+        self.k = kernels if kernels is not None else ops
         self.sparse_feature_number = sparse_feature_number
         self.sparse_feature_dim = sparse_feature_dim
         self.dense_feature_dim = dense_feature_dim
@@ -124,8 +130,9 @@ class DeepFMLayer:
         self.layer_sizes = list(layer_sizes)
         if slot_offset is not None:
             slot_offset = torch.as_tensor(slot_offset, dtype=torch.int64, device=self.device)
-        self.fm = FM(sparse_feature_number, sparse_feature_dim, dense_feature_dim, sparse_num_field,
-                     self.device, slot_offset)
+        self.fm = FM(table_rows if table_rows is not None else sparse_feature_number,
+                     sparse_feature_dim, dense_feature_dim, sparse_num_field, self.device,
+                     slot_offset, zero_padding_row)
         D, Dn = sparse_feature_dim, dense_feature_dim
         self.num_field = Dn + sparse_num_field
         sizes = [D * self.num_field] + self.layer_sizes + [1]               # net.py:150
@@ -134,6 +141,7 @@ class DeepFMLayer:
             shapes += [("dnn.linear_%d.weight" % i, (sizes[i], sizes[i + 1])),
                        ("dnn.linear_%d.bias" % i, (sizes[i + 1],))]
         shapes.append(("bias", (1,)))       # created, never used in forward (net.py:36-39; App. B-14)
+        shapes += list(extra_dense)
         self.dense = _FlatParams(shapes, self.device)
         std = 0.1 / math.sqrt(float(D))
         for n in ("fm.dense_w_one", "fm.dense_w"):                          # net.py:89-103
@@ -147,9 +155,9 @@ class DeepFMLayer:
         self.mlp_db = [self.dense.g["dnn.linear_%d.bias" % i] for i in range(self.n_linear)]
         # sparse Adam state (lazy rows) + bookkeeping
         self.sparse_state = None
-        self.ws = ops.Workspace(self.device)
-        self.ws_group = ops.Workspace(self.device)
-        self.status = ops.new_status(self.device)
+        self.ws = self.k.Workspace(self.device)
+        self.ws_group = self.k.Workspace(self.device)
+        self.status = self.k.new_status(self.device)
         self.step_count = 0
         self._side = None
         self.timers = None      # bench.py: dict name -> list of (start,end) torch.cuda.Event pairs
@@ -157,7 +165,7 @@ class DeepFMLayer:
     # -- parameters under the reference's state_dict keys (Appendix C) -------------------------
     def state_dict(self):
         sd = {"fm.embedding_one.weight": self.fm.embedding_one, "fm.embedding.weight": self.fm.embedding}
-        sd.update(self.dense.p)
+        sd.update({k: v for k, v in self.dense.p.items() if not k.startswith("__")})
         return sd
 
     def set_dict(self, sd):
@@ -176,7 +184,7 @@ class DeepFMLayer:
         return sparse_inputs
 
     def _fm_fwd(self, ids, dense_inputs):
-        return ops.deepfm_fm_fwd(ids, dense_inputs, self.fm.embedding, self.fm.embedding_one,
+        return self.k.deepfm_fm_fwd(ids, dense_inputs, self.fm.embedding, self.fm.embedding_one,
                                  self.dense.p["fm.dense_w"], self.dense.p["fm.dense_w_one"],
                                  self.fm.padding_idx, self.fm.slot_offset, self.status)
 
@@ -210,21 +218,21 @@ class DeepFMLayer:
         self._side.wait_stream(cur)
         groups = getattr(self, "_groups", None)          # persistent: the wait_stream above orders reuse
         if groups is None or groups.n != B * S:
-            groups = self._groups = ops.IdGroups(B * S, self.device)
+            groups = self._groups = self.k.IdGroups(B * S, self.device)
         with torch.cuda.stream(self._side):
-            ops.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
+            self.k.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
                           self.fm.slot_offset, self.status, groups)
         with self._timed("fm_fwd"):
             y1, y2, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
         with self._timed("mlp_fwd"):
             y_dnn, acts = mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b)
-        pred, dz, loss = ops.sigmoid_logloss(y1, y2, y_dnn, label, self.ws)
+        pred, dz, loss = self.k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws)
         if auc_stats is not None:
-            ops.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
+            self.k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         with self._timed("mlp_bwd"):
             d_flat = mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db)
         with self._timed("fm_bwd"):
-            row_grad, _, _ = ops.deepfm_fm_bwd(
+            row_grad, _, _ = self.k.deepfm_fm_bwd(
                 dense_inputs, feat, sum_emb, d_flat.view(B, self.num_field, -1), dz, dz, S, self.ws,
                 out=(self._row_grad_buf(B * S),
                      self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
@@ -232,12 +240,12 @@ class DeepFMLayer:
         if allreduce is not None:
             allreduce(self.dense.grad)
         t = self.step_count
-        ops.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
+        self.k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
         cur.wait_stream(self._side)
         st = self.sparse_state
         with self._timed("sparse_adam"):
-            ops.sparse_adam_rows(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr)
-            ops.sparse_adam_rows(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
+            self.k.sparse_adam_rows(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr)
+            self.k.sparse_adam_rows(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
         return loss, pred
 
     def _timed(self, name):

@@ -123,11 +123,17 @@ def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None):
 
 
 # ------------------------------------------------------------------ lookups
-def emb_gather(ids, W, padding_idx=None, status=None):
+def emb_gather(ids, W, padding_idx=None, status=None, out=None):
+    """out[i,:] = W[ids[i],:] (zero row where ids[i]==padding_idx).  W [N,D] f32."""
     _chk(ids, torch.int64, "ids")
     _chk(W, torch.float32, "W")
     N, D = W.shape
-    out = torch.empty(*ids.shape, D, dtype=torch.float32, device=ids.device)
+    if out is None:
+        out = torch.empty(*ids.shape, D, dtype=torch.float32, device=ids.device)
+    else:
+        _chk(out, torch.float32, "out")
+        if out.numel() != ids.numel() * D:
+            raise RecError("out has %d elements, expected %d" % (out.numel(), ids.numel() * D))
     if status is None:
         status = new_status(ids.device)
     check(lib().rec_emb_gather(ids.numel(), D, W.stride(0), N,
@@ -226,9 +232,45 @@ def adam_dense(p, m, v, g, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
           "rec_adam_dense")
 
 
+# ------------------------------------------------------------------ row-sharded tables
+class ShardRoute:
+    """Result buffers of rec_shard_route (device)."""
+
+    def __init__(self, n, num_shards, device):
+        self.n, self.num_shards = n, num_shards
+        i64 = dict(dtype=torch.int64, device=device)
+        self.send_local_row = torch.empty(max(n, 1), **i64)
+        self.send_pos = torch.empty(max(n, 1), **i64)
+        self.send_sample = torch.empty(max(n, 1), **i64)
+        self.slot_of_pos = torch.empty(max(n, 1), **i64)
+        self.send_counts = torch.zeros(num_shards + 1, **i64)
+
+
+def shard_route(ids, num_rows, padding_idx, num_shards, ws, slot_offset=None, status=None,
+                route=None):
+    """Partition the lookups by owner shard (row % num_shards).  -> (ShardRoute, status)"""
+    _chk(ids, torch.int64, "ids")
+    n = ids.numel()
+    S = ids.shape[-1] if ids.dim() > 1 else 1
+    dev = ids.device
+    if route is None:
+        route = ShardRoute(n, num_shards, dev)
+    if status is None:
+        status = new_status(dev)
+    nbytes = C.c_size_t(0)
+    check(lib().rec_shard_route_workspace_bytes(n, num_shards, C.byref(nbytes)))
+    w = ws.get(nbytes.value)
+    check(lib().rec_shard_route(n, S, num_rows, -1 if padding_idx is None else padding_idx,
+                                num_shards, _p(ids), _p(slot_offset), _p(route.send_local_row),
+                                _p(route.send_pos), _p(route.send_sample), _p(route.slot_of_pos),
+                                _p(route.send_counts), _p(status), _p(w), C.c_size_t(w.numel()),
+                                _stream()), "rec_shard_route")
+    return route, status
+
+
 # ------------------------------------------------------------------ loss head / metric
-def sigmoid_logloss(y1, y2, y_dnn, label, ws, eps=1e-4, want_dz=True, out=None):
-    """-> pred [B,1], dz [B,1] (or None), loss [1]"""
+def sigmoid_logloss(y1, y2, y_dnn, label, ws, eps=1e-4, want_dz=True, out=None, mean_over=0):
+    """-> pred [B,1], dz [B,1] (or None), loss [1].  mean_over: denominator of the mean (0 -> B)."""
     B = y1.numel()
     dev = y1.device
     _chk(y1, torch.float32, "y1")
@@ -244,7 +286,7 @@ def sigmoid_logloss(y1, y2, y_dnn, label, ws, eps=1e-4, want_dz=True, out=None):
     nbytes = C.c_size_t(0)
     check(lib().rec_logloss_workspace_bytes(B, C.byref(nbytes)))
     w = ws.get(nbytes.value)
-    check(lib().rec_sigmoid_logloss(B, _p(y1), _p(y2), _p(y_dnn), _p(label), float(eps), _p(pred),
+    check(lib().rec_sigmoid_logloss(B, int(mean_over), _p(y1), _p(y2), _p(y_dnn), _p(label), float(eps), _p(pred),
                                     _p(dz), _p(loss), _p(w), C.c_size_t(w.numel()), _stream()),
           "rec_sigmoid_logloss")
     return pred, dz, loss

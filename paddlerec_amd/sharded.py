@@ -1,0 +1,226 @@
+"""Row-sharded DeepFM: one process per GPU, table rows split row-wise, exchanges by all-to-all.
+
+Reference counterpart: the gpubox path — `core.PSGPU` pull/push inside `exe.train_from_dataset`
+(/root/reference/tools/static_gpubox_trainer.py:152-160,244,256; models/rank/dnn/net.py:67-79), where
+one trainer process drives 8 GPUs and the HeterPS hash table shards keys across them [EXT].  Here
+(SURVEY.md §8(e)): owner(r) = r mod G, local row = r div G; every rank keeps its own batch of B samples
+(data parallel) and ceil(N/G) rows of both tables plus their Adam state (model parallel).
+
+One training step = three exchange rounds over RCCL (xGMI is fully connected, so all-to-all drives all
+7 links of a GPU at once):
+    ids  : all-to-all(v) of local row ids, grouped by owner            (int64)
+    rows : owners gather W / W1 rows, all-to-all(v) back in send order  (f32 x D, f32 x 1)
+    grads: row-grads / dy1 gathered into send order, all-to-all(v) to owners, merged + lazy Adam there
+plus ONE all-reduce of the flat dense-gradient bucket (MLP + FM dense weights + the loss scalar).
+The loss is the mean over the GLOBAL batch (G*B), so a sharded step is arithmetically one step of the
+unsharded model on the concatenated batch (tests/test_sharded*.py check exactly that).
+"""
+import torch
+
+from . import ops
+from .deepfm import NUM_THRESHOLDS, DeepFMLayer, mlp_backward, mlp_forward
+
+
+class Comm:
+    """The collectives a step needs, over a torch.distributed process group.
+    backend nccl (= RCCL on ROCm): device buffers go straight to the collective.
+    backend gloo: device buffers are staged through host memory (used by the CPU / single-GPU tests;
+    a transport detail — compute never leaves the HIP kernels)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group if group is not None else dist.group.WORLD
+        self.rank = dist.get_rank(self.group)
+        self.world = dist.get_world_size(self.group)
+        self.staged = dist.get_backend(self.group) != "nccl"
+
+    def exchange_counts(self, send_counts):
+        """send_counts[d] = entries this rank sends to d  ->  recv_counts[s] = entries s sends here."""
+        dev = "cpu" if self.staged else torch.device("cuda", torch.cuda.current_device())
+        t_in = torch.tensor(list(send_counts), dtype=torch.int64, device=dev)
+        t_out = torch.empty_like(t_in)
+        self.dist.all_to_all_single(t_out, t_in, group=self.group)
+        return [int(x) for x in t_out.tolist()]
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        """Rows (dim 0) of `inp` split by in_splits go to the ranks; `out` receives out_splits rows."""
+        if self.staged and out.is_cuda:
+            h_in = inp.cpu()
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_to_all_single(h_out, h_in, list(out_splits), list(in_splits), group=self.group)
+            out.copy_(h_out)
+        else:
+            self.dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=self.group)
+        return out
+
+    def all_reduce_sum(self, t):
+        if self.staged and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, group=self.group)
+        return t
+
+
+class _Lookup:
+    """Everything one routed lookup leaves behind for the backward exchange."""
+    __slots__ = ("route", "send_splits", "recv_splits", "n_send", "n_recv", "recv_rows", "reply",
+                 "reply1")
+
+
+class ShardedDeepFMLayer(DeepFMLayer):
+    """DeepFMLayer (deepfm/net.py:21-49) with both embedding tables row-sharded over `group`.
+    sparse_feature_number is the GLOBAL row count (after slot offsets)."""
+
+    def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim,
+                 sparse_num_field, layer_sizes, device="cuda", slot_offset=None, group=None,
+                 comm=None, kernels=None):
+        self.comm = comm if comm is not None else Comm(group)
+        G = self.comm.world
+        self.global_rows = int(sparse_feature_number)
+        self.local_rows = (self.global_rows + G - 1) // G
+        # global padding row 0 lives on rank 0 as local row 0 (only meaningful without slot offsets)
+        super().__init__(sparse_feature_number, sparse_feature_dim, dense_feature_dim,
+                         sparse_num_field, layer_sizes, device=device, slot_offset=slot_offset,
+                         table_rows=self.local_rows, zero_padding_row=(self.comm.rank == 0),
+                         kernels=kernels, extra_dense=(("__loss__", (1,)),))
+        self.ws_route = self.k.Workspace(self.device)
+        self._route = None
+        self._groups = None
+        self._reply = None
+
+    # -- parameters: global <-> shard --------------------------------------------------------------
+    def set_dict(self, sd):
+        """Accepts GLOBAL tables ([N,D] / [N,1]); keeps rows r with r % G == rank."""
+        sd = dict(sd)
+        G, r = self.comm.world, self.comm.rank
+        for key, dst in (("fm.embedding.weight", self.fm.embedding),
+                         ("fm.embedding_one.weight", self.fm.embedding_one)):
+            if key in sd:
+                src = torch.as_tensor(sd.pop(key)).reshape(self.global_rows, -1)[r::G]
+                dst[: src.shape[0]].copy_(src.to(dst.device))
+        super().set_dict(sd)
+
+    def gather_global_tables(self):
+        """(W [N,D], W1 [N,1]) assembled on every rank — checkpoint export / tests."""
+        G = self.comm.world
+        out = []
+        for t in (self.fm.embedding, self.fm.embedding_one):
+            full = torch.zeros(G * self.local_rows, t.shape[1], dtype=t.dtype, device=t.device)
+            parts = full.view(self.local_rows, G, t.shape[1])     # row r = local*G + owner
+            mine = torch.zeros_like(parts)
+            mine[:, self.comm.rank] = t
+            self.comm.all_reduce_sum(mine)
+            out.append(mine.reshape(G * self.local_rows, -1)[: self.global_rows])
+        return out
+
+    # -- routed lookup (ids exchange + rows exchange) ----------------------------------------------
+    def _lookup(self, ids):
+        B, S = ids.shape
+        n, G, D = B * S, self.comm.world, self.sparse_feature_dim
+        k = self.k
+        if self._route is None or self._route.n != n:
+            self._route = k.ShardRoute(n, G, self.device)
+        route, _ = k.shard_route(ids, self.global_rows, self.fm.padding_idx, G, self.ws_route,
+                                 self.fm.slot_offset, self.status, self._route)
+        L = _Lookup()
+        L.route = route
+        L.send_splits = [int(x) for x in route.send_counts[:G].tolist()]       # host sync (G ints)
+        L.recv_splits = self.comm.exchange_counts(L.send_splits)
+        L.n_send, L.n_recv = sum(L.send_splits), sum(L.recv_splits)
+        i64 = dict(dtype=torch.int64, device=self.device)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        L.recv_rows = torch.empty(L.n_recv, **i64)
+        self.comm.all_to_all(L.recv_rows, route.send_local_row[: L.n_send], L.recv_splits, L.send_splits)
+        g_rows = torch.empty(L.n_recv, D, **f32)
+        g_w1 = torch.empty(L.n_recv, 1, **f32)
+        if L.n_recv:
+            k.emb_gather(L.recv_rows, self.fm.embedding, None, self.status, out=g_rows)
+            k.emb_gather(L.recv_rows, self.fm.embedding_one, None, self.status, out=g_w1)
+        if self._reply is None or self._reply[0].shape[0] != n + 1:
+            self._reply = (torch.zeros(n + 1, D, **f32), torch.zeros(n + 1, 1, **f32))  # row 0 stays 0
+        L.reply, L.reply1 = self._reply
+        self.comm.all_to_all(L.reply[1:1 + L.n_send], g_rows, L.send_splits, L.recv_splits)
+        self.comm.all_to_all(L.reply1[1:1 + L.n_send], g_w1, L.send_splits, L.recv_splits)
+        return L
+
+    def _fm_fwd_routed(self, L, B, S, dense_inputs):
+        # the reply buffer is a (n+1)-row table read through slot_of_pos; 0 = padding -> zero row
+        return self.k.deepfm_fm_fwd(L.route.slot_of_pos.view(B, S), dense_inputs, L.reply, L.reply1,
+                                    self.dense.p["fm.dense_w"], self.dense.p["fm.dense_w_one"], 0, None,
+                                    self.status)
+
+    def forward(self, sparse_inputs, dense_inputs):
+        ids = self._concat_ids(sparse_inputs)
+        B, S = ids.shape
+        L = self._lookup(ids)
+        y1, y2, feat, _, _ = self._fm_fwd_routed(L, B, S, dense_inputs)
+        y_dnn, _ = mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b)
+        return torch.sigmoid(y1 + y2 + y_dnn)
+
+    __call__ = forward
+
+    # -- one full training step --------------------------------------------------------------------
+    def train_step(self, sparse_inputs, dense_inputs, label, lr=1e-3, auc_stats=None):
+        """Returns (loss [1] = mean over the GLOBAL batch, pred [B,1] of the local samples)."""
+        k = self.k
+        ids = self._concat_ids(sparse_inputs)
+        B, S = ids.shape
+        G, D = self.comm.world, self.sparse_feature_dim
+        self._ensure_sparse_state()
+        self.step_count += 1
+        t = self.step_count
+        with self._timed("lookup_exchange"):
+            L = self._lookup(ids)
+        with self._timed("fm_fwd"):
+            y1, y2, feat, sum_emb, _ = self._fm_fwd_routed(L, B, S, dense_inputs)
+        with self._timed("mlp_fwd"):
+            y_dnn, acts = mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b)
+        loss_slot = self.dense.g["__loss__"]
+        pred, dz, _ = k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws, mean_over=G * B,
+                                        out=(self._buf("pred", (B, 1)), self._buf("dz", (B, 1)),
+                                             loss_slot))
+        if auc_stats is not None:
+            k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
+        with self._timed("mlp_bwd"):
+            d_flat = mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db)
+        with self._timed("fm_bwd"):
+            row_grad, _, _ = k.deepfm_fm_bwd(
+                dense_inputs, feat, sum_emb, d_flat.view(B, self.num_field, -1), dz, dz, S, self.ws,
+                out=(self._row_grad_buf(B * S),
+                     self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
+                     self.dense.g["fm.dense_w_one"]))
+        with self._timed("grad_exchange"):
+            f32 = dict(dtype=torch.float32, device=self.device)
+            send_g = torch.empty(L.n_send, D, **f32)
+            send_g1 = torch.empty(L.n_send, 1, **f32)
+            if L.n_send:
+                k.emb_gather(L.route.send_pos[: L.n_send], row_grad, None, self.status, out=send_g)
+                k.emb_gather(L.route.send_sample[: L.n_send], dz, None, self.status, out=send_g1)
+            recv_g = torch.empty(max(L.n_recv, 1), D, **f32)
+            recv_g1 = torch.empty(max(L.n_recv, 1), 1, **f32)
+            self.comm.all_to_all(recv_g[: L.n_recv], send_g, L.recv_splits, L.send_splits)
+            self.comm.all_to_all(recv_g1[: L.n_recv], send_g1, L.recv_splits, L.send_splits)
+            self.comm.all_reduce_sum(self.dense.grad)            # one bucket: dense grads + loss
+        loss = loss_slot.clone()
+        loss_slot.zero_()                                         # not a parameter: keep Adam off it
+        k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
+        with self._timed("sparse_adam"):
+            if L.n_recv:
+                if self._groups is None or self._groups.n < L.n_recv:
+                    self._groups = k.IdGroups(L.n_recv + L.n_recv // 8, self.device)
+                groups, _ = k.ids_group(L.recv_rows, self.local_rows, None, self.ws_group, None,
+                                        self.status, self._groups)
+                st = self.sparse_state
+                k.sparse_adam_rows(groups, recv_g, 1, self.fm.embedding, st["m"], st["v"], t, lr)
+                k.sparse_adam_rows(groups, recv_g1, 1, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
+        return loss, pred
+
+    def _buf(self, name, shape):
+        b = getattr(self, "_b_" + name, None)
+        if b is None or tuple(b.shape) != tuple(shape):
+            b = torch.empty(*shape, dtype=torch.float32, device=self.device)
+            setattr(self, "_b_" + name, b)
+        return b

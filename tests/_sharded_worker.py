@@ -1,0 +1,71 @@
+"""One rank of a sharded DeepFM run (spawned by tests/test_sharded*.py).
+
+    python tests/_sharded_worker.py <rank> <world> <port> <cpu|gpu> <outdir> [tables]
+
+cpu : gloo, CPU tensors, operator backend = tests/cpu_kernels.py (oracle) — exercises the host
+      orchestration only.
+gpu : gloo with host staging, all ranks on cuda:0, operator backend = the HIP kernels.
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from helpers import deepfm_state_dict, make_deepfm_problem  # noqa: E402
+
+CFG = dict(B=48, N=257, D=16, fc=(32, 16), seed=77, pad_frac=0.08, steps=2, lr=1e-2)
+
+
+def main():
+    rank, world, port, mode, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    tables = len(sys.argv) > 6 and sys.argv[6] == "tables"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from paddlerec_amd.sharded import Comm, ShardedDeepFMLayer
+    if mode == "cpu":
+        import cpu_kernels
+        dev, kernels = "cpu", cpu_kernels
+    else:
+        dev, kernels = "cuda:0", None
+    c = CFG
+    pr = make_deepfm_problem(B=c["B"] * world, N=c["N"], D=c["D"], fc=c["fc"], seed=c["seed"],
+                             pad_frac=c["pad_frac"], tables=tables)
+    so = pr["slot_offsets"]
+    m = ShardedDeepFMLayer(pr["N"], c["D"], 13, 26, list(c["fc"]), device=dev,
+                           slot_offset=None if so is None else torch.as_tensor(so),
+                           comm=Comm(), kernels=kernels)
+    m.set_dict(deepfm_state_dict(pr["params"], len(c["fc"]) + 1))
+    rng = np.random.default_rng(c["seed"] + 1)
+    out = {}
+    lo, hi = rank * c["B"], (rank + 1) * c["B"]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(dev)
+    for step in range(c["steps"]):
+        if step == 0:
+            ids, dense, label = pr["ids"], pr["dense"], pr["label"]
+        else:      # later steps: fresh global batch, same on every rank
+            ids = rng.integers(0, c["N"], (c["B"] * world, 26), dtype=np.int64)
+            dense = rng.random((c["B"] * world, 13), dtype=np.float32)
+            label = (rng.random((c["B"] * world, 1)) < 0.3).astype(np.int64)
+        loss, pred = m.train_step(t(ids[lo:hi]), t(dense[lo:hi]), t(label[lo:hi]), lr=c["lr"])
+        out["loss%d" % step] = loss.cpu().numpy().copy()
+        out["pred%d" % step] = pred.cpu().numpy().copy()   # pred is a reused buffer
+    pred_eval = m.forward(t(pr["ids"][lo:hi]), t(pr["dense"][lo:hi]))
+    out["pred_eval"] = pred_eval.cpu().numpy()
+    W, W1 = m.gather_global_tables()
+    out["W"], out["W1"] = W.cpu().numpy(), W1.cpu().numpy()
+    out["mlp_w0"] = m.dense.p["dnn.linear_0.weight"].cpu().numpy()
+    out["dense_w"] = m.dense.p["fm.dense_w"].cpu().numpy()
+    out["status"] = m.status.cpu().numpy()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,3 +88,43 @@ def c_adam_rows(lib, uniq, seg_off, spos, row_grad, P, M, V, step, lr=1e-3, b1=0
     lib.oracle_adam_rows(C.c_int64(len(uniq)), C.c_int(D), fptr(uniq), fptr(seg_off), fptr(spos),
                          fptr(row_grad), fptr(P), fptr(M), fptr(V), C.c_float(lr), C.c_float(b1),
                          C.c_float(b2), C.c_float(eps), C.c_int64(step))
+
+
+def deepfm_state_dict(p, n_mlp):
+    sd = {"fm.embedding.weight": p["W"], "fm.embedding_one.weight": p["W1"],
+          "fm.dense_w": p["dense_w"], "fm.dense_w_one": p["dense_w_one"]}
+    for i in range(n_mlp):
+        sd["dnn.linear_%d.weight" % i] = p["mlp_w"][i]
+        sd["dnn.linear_%d.bias" % i] = p["mlp_b"][i]
+    return sd
+
+
+class OracleTrainer:
+    """Unsharded DeepFM training on the NumPy oracle: fwd + bwd + lazy Adam (tables) + Adam (dense)."""
+
+    def __init__(self, params, slot_offsets=None, lr=1e-2):
+        from oracle import deepfm_ref as R
+        self.R = R
+        self.p = {k: (v.copy() if not isinstance(v, list) else [x.copy() for x in v])
+                  for k, v in params.items()}
+        self.so, self.lr, self.step = slot_offsets, lr, 0
+        self.st = {k: np.zeros_like(params[t]) for k, t in
+                   (("mW", "W"), ("vW", "W"), ("mW1", "W1"), ("vW1", "W1"))}
+        self.dstate = {}
+
+    def train_step(self, ids, dense, label):
+        R, op, st = self.R, self.p, self.st
+        self.step += 1
+        o = R.deepfm_loss_and_grads(ids, dense, label, op, slot_offsets=self.so)
+        uniq, merged, _ = R.merge_rows(o["rows"], o["row_valid"], o["row_grad"])
+        R.adam_update_rows(op["W"], st["mW"], st["vW"], uniq, merged, self.step, lr=self.lr)
+        uniq1, merged1, _ = R.merge_rows(o["rows"], o["row_valid"], o["row_grad1"])
+        R.adam_update_rows(op["W1"], st["mW1"], st["vW1"], uniq1, merged1, self.step, lr=self.lr)
+        pairs = [("dense_w", o["d_dense_w"]), ("dense_w_one", o["d_dense_w_one"])]
+        for i in range(len(op["mlp_w"])):
+            pairs += [(("mlp_w", i), o["mlp_dw"][i]), (("mlp_b", i), o["mlp_db"][i])]
+        for key, gr in pairs:
+            arr = op[key] if not isinstance(key, tuple) else op[key[0]][key[1]]
+            mm, vv = self.dstate.setdefault(key, (np.zeros_like(arr), np.zeros_like(arr)))
+            R.adam_update(arr, mm, vv, gr.reshape(arr.shape).astype(arr.dtype), self.step, lr=self.lr)
+        return o["loss"], o["pred"]

@@ -1,0 +1,160 @@
+"""Row-sharded DeepFM (paddlerec_amd/sharded.py): a G-rank sharded run must equal ONE unsharded
+oracle run on the concatenated batch.
+
+  * test_shard_route_oracle_*      : the routing contract itself (CPU, NumPy oracle).
+  * test_sharded_orchestration_cpu : world_size-2 gloo on CPU, operator backend = oracle stand-in —
+                                     checks split bookkeeping / exchange order / unscrambling.
+  * test_shard_route_gpu, test_sharded_two_ranks_one_gpu (gpu): the HIP partition kernel bit-exact
+    against the oracle, and 2 processes sharing cuda:0 running the real kernels end to end.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from helpers import OracleTrainer, make_deepfm_problem
+from oracle import shard_ref
+
+WORKER = os.path.join(REPO, "tests", "_sharded_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return str(p)
+
+
+def _run_world(world, mode, outdir, tables=False):
+    port = _free_port()
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), port, mode, str(outdir)]
+                              + (["tables"] if tables else []), env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode("utf-8", "replace"))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+    return [dict(np.load(os.path.join(outdir, "rank%d.npz" % r))) for r in range(world)]
+
+
+def _expected(world, tables):
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from _sharded_worker import CFG as c
+    pr = make_deepfm_problem(B=c["B"] * world, N=c["N"], D=c["D"], fc=c["fc"], seed=c["seed"],
+                             pad_frac=c["pad_frac"], tables=tables)
+    tr = OracleTrainer(pr["params"], pr["slot_offsets"], lr=c["lr"])
+    rng = np.random.default_rng(c["seed"] + 1)
+    res = []
+    for step in range(c["steps"]):
+        if step == 0:
+            ids, dense, label = pr["ids"], pr["dense"], pr["label"]
+        else:
+            ids = rng.integers(0, c["N"], (c["B"] * world, 26), dtype=np.int64)
+            dense = rng.random((c["B"] * world, 13), dtype=np.float32)
+            label = (rng.random((c["B"] * world, 1)) < 0.3).astype(np.int64)
+        res.append(tr.train_step(ids, dense, label))
+    from oracle import deepfm_ref as R
+    pred_eval, _, _ = R.deepfm_forward(pr["ids"], pr["dense"], tr.p, slot_offsets=pr["slot_offsets"])
+    return c, tr, res, pred_eval
+
+
+def _check(world, ranks, tables):
+    c, tr, res, pred_eval = _expected(world, tables)
+    B = c["B"]
+    for r, out in enumerate(ranks):
+        assert int(out["status"][0]) == 0
+        for step, (loss, pred) in enumerate(res):
+            np.testing.assert_allclose(out["loss%d" % step][0], loss, rtol=2e-5)
+            np.testing.assert_allclose(out["pred%d" % step], pred[r * B:(r + 1) * B], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(out["pred_eval"], pred_eval[r * B:(r + 1) * B], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out["W"], tr.p["W"], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(out["W1"], tr.p["W1"], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(out["mlp_w0"], tr.p["mlp_w"][0], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(out["dense_w"], tr.p["dense_w"], rtol=1e-3, atol=2e-4)
+    # every rank holds the same replicated dense parameters and sees the same global tables
+    for out in ranks[1:]:
+        assert np.array_equal(out["mlp_w0"], ranks[0]["mlp_w0"])
+        assert np.array_equal(out["W"], ranks[0]["W"])
+
+
+# ------------------------------------------------------------------------------ routing contract (CPU)
+@pytest.mark.parametrize("G", [1, 2, 3, 8])
+def test_shard_route_oracle_properties(G):
+    pr = make_deepfm_problem(B=37, N=101, seed=G, pad_frac=0.1, tables=(G == 3))
+    r = shard_ref.shard_route(pr["ids"], G, 0, pr["slot_offsets"])
+    ids = pr["ids"].reshape(-1)
+    n = ids.size
+    nv = int((ids != 0).sum())
+    assert r["send_counts"][:G].sum() == nv and r["send_counts"][G] == n - nv
+    rows = (pr["ids"] + (pr["slot_offsets"][None] if pr["slot_offsets"] is not None else 0)).reshape(-1)
+    # send order: grouped by owner, ascending position inside a group
+    owner = rows[r["send_pos"]] % G
+    assert np.all(np.diff(owner) >= 0)
+    for d in range(G):
+        assert np.all(np.diff(r["send_pos"][owner == d]) > 0)
+    assert np.array_equal(r["send_local_row"] * G + owner, rows[r["send_pos"]])
+    assert np.array_equal(r["send_sample"], r["send_pos"] // 26)
+    # slot_of_pos inverts send order and is 0 exactly on padding
+    assert np.array_equal(r["slot_of_pos"][r["send_pos"]], np.arange(1, nv + 1))
+    assert np.array_equal(r["slot_of_pos"] == 0, ids == 0)
+
+
+@pytest.mark.parametrize("tables", [False, True])
+def test_sharded_orchestration_cpu(tmp_path, tables):
+    _check(2, _run_world(2, "cpu", tmp_path, tables), tables)
+
+
+def test_sharded_orchestration_cpu_world3(tmp_path):
+    _check(3, _run_world(3, "cpu", tmp_path), False)
+
+
+# ------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,G,pad,tables", [(1, 50, 2, 0.0, False), (300, 1000, 8, 0.05, False),
+                                               (1000, 5000, 3, 0.03, True), (64, 10, 2, 1.0, False),
+                                               (4096, 100000, 8, 0.03, True), (100, 7, 64, 0.2, False)])
+def test_shard_route_gpu(engine_lib, B, N, G, pad, tables):
+    import torch
+    from paddlerec_amd import ops
+    pr = make_deepfm_problem(B=B, N=N, seed=B + G, pad_frac=pad, tables=tables)
+    want = shard_ref.shard_route(pr["ids"], G, 0, pr["slot_offsets"])
+    dev = "cuda"
+    so = None if pr["slot_offsets"] is None else torch.as_tensor(pr["slot_offsets"]).to(dev)
+    route, status = ops.shard_route(torch.as_tensor(pr["ids"]).to(dev), pr["N"], 0, G, ops.Workspace(dev), so)
+    assert int(status.item()) == 0
+    k = len(want["send_pos"])
+    assert np.array_equal(route.send_counts.cpu().numpy(), want["send_counts"])
+    assert np.array_equal(route.send_local_row[:k].cpu().numpy(), want["send_local_row"])
+    assert np.array_equal(route.send_pos[:k].cpu().numpy(), want["send_pos"])
+    assert np.array_equal(route.send_sample[:k].cpu().numpy(), want["send_sample"])
+    assert np.array_equal(route.slot_of_pos[:B * 26].cpu().numpy(), want["slot_of_pos"])
+
+
+@pytest.mark.gpu
+def test_shard_route_flags_out_of_range(engine_lib):
+    import torch
+    from paddlerec_amd import ops
+    ids = torch.tensor([[1, 2, 99, -3]], dtype=torch.int64, device="cuda")
+    route, status = ops.shard_route(ids, 10, 0, 2, ops.Workspace("cuda"))
+    assert int(status.item()) & 1
+    assert route.send_counts.tolist() == [1, 1, 2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,tables", [(2, False), (2, True), (1, False)])
+def test_sharded_ranks_share_one_gpu(engine_lib, tmp_path, world, tables):
+    """2 processes on cuda:0 (gloo transport, host-staged) running the real HIP kernels."""
+    _check(world, _run_world(world, "gpu", tmp_path, tables), tables)
