@@ -50,9 +50,14 @@ typedef struct {
   int32_t num_slots;   /* S  (26) : sparse fields, one id each */
   int32_t num_dense;   /* Dn (13) : dense fields, <= 16 */
   int32_t emb_dim;     /* D  <= 256 */
-  int32_t row_stride;  /* floats between consecutive rows of W (>= D); W1 has stride 1 */
+  int32_t row_stride;  /* floats between consecutive rows of W (>= D) */
   int64_t num_rows;    /* N rows in W / W1 (after slot offsets) */
   int64_t padding_idx; /* id that yields a zero row and no gradient; < 0 = none */
+  int32_t w1_stride;   /* floats between consecutive entries of W1; 0 or 1 = dense [N] array.
+                          HBM fetches whole 128-B lines: a table kept as 32-float records
+                          [W(16) | W1 | ...] (W1 = W + 16, both strides 32) costs ONE line per
+                          lookup instead of two (see DESIGN.md "table layout"). */
+  int32_t reserved;
 } rec_deepfm_desc;
 
 /* ids [B,S] i64 (= paddle.concat(sparse_inputs,1), net.py:107); dense [B,Dn] f32;
@@ -66,7 +71,9 @@ int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids, const flo
                       float* feat, float* sum_emb, int32_t* status, void* stream);
 
 /* Backward of the block above (what loss.backward(), tools/trainer.py:151, runs for net.py:105-139).
- * In : dense, feat, sum_emb (saved by fwd), d_feat_dnn [B,S+Dn,D], dy1, dy2 [B].
+ * In : dense, feat, sum_emb (saved by fwd), d_feat_dnn [B,S+Dn,D], dy1, dy2 [B];
+ *      dense_w [Dn,D] or NULL: when given, the dense part of feat is recomputed as
+ *      dense[b,j]*dense_w[j,:] (bit-identical to what fwd stored) instead of re-read.
  * Out: row_grad [B*S, D]  — SelectedRows.value of `embedding` (rows = flattened ids, unmerged);
  *      d_dense_w [Dn,D], d_dense_w_one [Dn] — batch sums, reduced in a fixed order (deterministic).
  *      The SelectedRows.value of `embedding_one` is dy1[b] for every (b,s); it is not
@@ -74,8 +81,8 @@ int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids, const flo
 int rec_deepfm_fm_bwd_workspace_bytes(const rec_deepfm_desc* desc, size_t* bytes);
 int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense, const float* feat,
                       const float* sum_emb, const float* d_feat_dnn, const float* dy1,
-                      const float* dy2, float* row_grad, float* d_dense_w, float* d_dense_w_one,
-                      void* workspace, size_t workspace_bytes, void* stream);
+                      const float* dy2, const float* dense_w, float* row_grad, float* d_dense_w,
+                      float* d_dense_w_one, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Plain lookup and LoD sum-pool.

@@ -12,26 +12,46 @@
 // that every wave-wide load/store of feat covers FS*D*4 contiguous bytes per sample
 // (D=16: 2 samples x 8 fields = 2 x 512 B) — full cache lines, no half-used 128-B lines.
 // A lane walks fields f = it*FS + fs; the FM sums over fields are lane-local partials folded with
-// log2(FS) xor-shuffles at the end.  In the backward the same walk makes the dense-field index of a
-// lane fixed across samples, so the batch reductions d_dense_w / d_dense_w_one accumulate in
-// registers over a persistent grid-stride loop and are folded in a fixed order (deterministic).
+// log2(FS) xor-shuffles at the end.
+//
+// Both kernels are persistent (grid <= 8 blocks per CU, waves stride over tiles of SPW samples) and
+// free of data-dependent branches in the load path, so every gather of a tile is issued back to back:
+//   fwd: the ids / dense values of the NEXT tile are fetched (coalesced, one load per lane) while the
+//        current tile's rows are gathered; they reach the lanes that need them through a per-wave LDS
+//        staging area.  Invalid lookups (padding, out of range, dense slots) read row 0 and are
+//        zeroed with selects; the out-of-range flag is raised once per wave at the end.
+//   bwd: the dense-field index of a lane is fixed across samples, so the batch reductions
+//        d_dense_w / d_dense_w_one accumulate in registers over the persistent loop and are folded
+//        in a fixed order (deterministic); the dense part of feat is recomputed as x * dense_w
+//        instead of re-read when dense_w is supplied.
 #include "rec_common.h"
 
 namespace rec {
 
 constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxBlocks = kNumCU * 8;
 
 template <int LANES>
 constexpr int fs_for() {  // fields per sample per wave instruction
   return (kWave / LANES) < 8 ? (kWave / LANES) : 8;
 }
 
+// acquire/release at wavefront scope: orders a wave's own LDS writes and reads for the compiler
+// (the LDS unit executes one wave's instructions in order); no cross-wave traffic goes through it.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------------------------------ fwd
 constexpr int kFwdUnroll = 4;
+constexpr int kDnMax = 16;
+constexpr int kDenseCh = 2;  // ceil(SPW_max * kDnMax / 64) = 8*16/64
 
-template <int VEC, int LANES>
+template <int VEC, int LANES, int IDCH>
 __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
-    int64_t B, int S, int Dn, int D, int stride, int64_t N, int64_t pad,
+    int64_t B, int S, int Dn, int D, int stride, int w1_stride, int64_t N, int64_t pad,
     const int64_t* __restrict__ ids, const float* __restrict__ dense, const float* __restrict__ W,
     const float* __restrict__ W1, const float* __restrict__ dense_w,
     const float* __restrict__ dense_w_one, const int64_t* __restrict__ slot_off,
@@ -39,118 +59,183 @@ __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
     float* __restrict__ sum_emb, int32_t* __restrict__ status) {
   constexpr int FS = fs_for<LANES>();
   constexpr int SPW = kWave / (LANES * FS);  // samples per wave
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_dw = smem;            // [Dn*D]
-  float* s_dw1 = smem + Dn * D;  // [Dn]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // [Dn*D] dense_w | [Dn] dense_w_one | [S] slot offsets | per wave: [SPW*S] ids, [SPW*Dn] dense
+  float* s_dw = reinterpret_cast<float*>(smem_raw);
+  float* s_dw1 = s_dw + Dn * D;
+  const int hdr = ((Dn * D + Dn) * 4 + 15) & ~15;
+  int64_t* s_off = reinterpret_cast<int64_t*>(smem_raw + hdr);
+  const int ids_per_tile = SPW * S, dense_per_tile = SPW * Dn;
+  const int wave_bytes = (ids_per_tile * 8 + dense_per_tile * 4 + 15) & ~15;
+  const int lane = threadIdx.x % kWave;
+  const int wave = threadIdx.x / kWave;
+  unsigned char* wbase = smem_raw + hdr + S * 8 + wave * wave_bytes;
+  int64_t* w_ids = reinterpret_cast<int64_t*>(wbase);
+  float* w_dense = reinterpret_cast<float*>(wbase + ids_per_tile * 8);
+
   for (int i = threadIdx.x; i < Dn * D; i += kBlock) s_dw[i] = dense_w[i];
   for (int i = threadIdx.x; i < Dn; i += kBlock) s_dw1[i] = dense_w_one[i];
+  for (int i = threadIdx.x; i < S; i += kBlock) s_off[i] = slot_off ? slot_off[i] : 0;
   __syncthreads();
 
-  const int lane = threadIdx.x % kWave;
   const int lg = lane % LANES;
   const int fs = (lane / LANES) % FS;
   const int sp = lane / (LANES * FS);
-  const int64_t wv = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
-  const int64_t b = wv * SPW + sp;
-  const bool active = b < B;
   const int d0 = lg * VEC;
-  const bool dvalid = active && d0 < D;
   const int F = S + Dn;
   const int NIT = (F + FS - 1) / FS;
+  const int64_t ntiles = (B + SPW - 1) / SPW;
+  const int64_t tstride = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t n_ids = B * S, n_dense = B * Dn;
+  int oob = 0;
 
-  float s[VEC], q[VEC];
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) s[v] = q[v] = 0.f;
-  float first = 0.f;
-  const int64_t* idp = ids + b * S;
-  float* fb = feat + (b * F) * (int64_t)D + d0;
+  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (tile >= ntiles) return;
 
-  for (int it0 = 0; it0 < NIT; it0 += kFwdUnroll) {
-    int64_t row[kFwdUnroll];
-    int f[kFwdUnroll];
+  // prefetch registers: the wave's slice of ids / dense for the tile it will work on next
+  int64_t pre_ids[IDCH];
+  float pre_dense[kDenseCh];
+  auto prefetch = [&](int64_t t) {
 #pragma unroll
-    for (int u = 0; u < kFwdUnroll; ++u) {
-      f[u] = (it0 + u) * FS + fs;
-      row[u] = -1;
-      if (active && f[u] < S) {
-        const int64_t id = idp[f[u]];
-        if (id != pad || pad < 0) {
-          const int64_t r = slot_off ? id + slot_off[f[u]] : id;
-          if (r >= 0 && r < N) {
-            row[u] = r;
-          } else if (lg == 0) {
-            atomicOr(status, REC_FLAG_INDEX_OOB);
+    for (int c = 0; c < IDCH; ++c) {
+      int64_t gi = t * ids_per_tile + c * kWave + lane;
+      gi = gi < n_ids ? gi : n_ids - 1;  // clamped: value unused where out of range
+      pre_ids[c] = ids[gi];
+    }
+    if (Dn > 0) {
+#pragma unroll
+      for (int c = 0; c < kDenseCh; ++c) {
+        int64_t gi = t * dense_per_tile + c * kWave + lane;
+        gi = gi < n_dense ? gi : n_dense - 1;
+        pre_dense[c] = dense[gi];
+      }
+    }
+  };
+  prefetch(tile);
+
+  for (; tile < ntiles; tile += tstride) {
+    // stage this tile's ids / dense values for the lanes that consume them
+#pragma unroll
+    for (int c = 0; c < IDCH; ++c) {
+      const int i = c * kWave + lane;
+      if (i < ids_per_tile) w_ids[i] = pre_ids[c];
+    }
+    if (Dn > 0) {
+#pragma unroll
+      for (int c = 0; c < kDenseCh; ++c) {
+        const int i = c * kWave + lane;
+        if (i < dense_per_tile) w_dense[i] = pre_dense[c];
+      }
+    }
+    wave_lds_fence();
+    {  // next tile's ids are in flight while this tile gathers (clamped: the last one re-reads)
+      const int64_t nxt = tile + tstride;
+      prefetch(nxt < ntiles ? nxt : ntiles - 1);
+    }
+
+    const int64_t b = tile * SPW + sp;
+    const bool active = b < B;
+    const bool dvalid = active && d0 < D;
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[v] = q[v] = 0.f;
+    float first = 0.f;
+    float* fb = feat + (b * F) * (int64_t)D + d0;
+
+    for (int it0 = 0; it0 < NIT; it0 += kFwdUnroll) {
+      int f[kFwdUnroll];
+      int64_t row[kFwdUnroll];
+      bool hit[kFwdUnroll];
+#pragma unroll
+      for (int u = 0; u < kFwdUnroll; ++u) {
+        f[u] = (it0 + u) * FS + fs;
+        const bool sparse = f[u] < S;
+        const int fi = sparse ? f[u] : 0;
+        const int64_t id = w_ids[sp * S + fi];
+        const int64_t r = id + s_off[fi];
+        const bool live = sparse && active && (id != pad || pad < 0);
+        const bool inr = r >= 0 && r < N;
+        oob |= (live && !inr) ? 1 : 0;
+        hit[u] = live && inr;
+        row[u] = hit[u] ? r : 0;
+      }
+      float e[kFwdUnroll][VEC];
+      float one[kFwdUnroll];
+#pragma unroll
+      for (int u = 0; u < kFwdUnroll; ++u) {
+        // wave-uniform skip of iterations that hold no sparse field at all
+        if ((it0 + u) * FS < S) {
+          if (d0 < D) vload<VEC>(e[u], W + row[u] * stride + d0);    // net.py:117
+          else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) e[u][v] = 0.f;
           }
+          one[u] = W1[row[u] * w1_stride];                                     // net.py:108
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) e[u][v] = 0.f;
+          one[u] = 0.f;
         }
       }
-    }
-    float e[kFwdUnroll][VEC];
-    float one[kFwdUnroll];
 #pragma unroll
-    for (int u = 0; u < kFwdUnroll; ++u) {
-      one[u] = 0.f;
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) e[u][v] = 0.f;
-      if (row[u] >= 0) {                               // sparse field: gather (net.py:108,117)
-        if (dvalid) vload<VEC>(e[u], W + row[u] * stride + d0);
-        if (lg == 0) one[u] = W1[row[u]];
-      } else if (active && f[u] >= S && f[u] < F) {    // dense field: x * dense_w (net.py:110-119)
-        const int j = f[u] - S;
-        const float x = dense[b * Dn + j];
-        if (lg == 0) one[u] = x * s_dw1[j];
-        if (dvalid) {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) e[u][v] = x * s_dw[j * D + d0 + v];
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kFwdUnroll; ++u) {
-      first += one[u];
-      if (dvalid && f[u] < F) {
+      for (int u = 0; u < kFwdUnroll; ++u) {
+        const bool isdense = f[u] >= S && f[u] < F;
+        const int j = isdense ? f[u] - S : 0;
+        const float x = (isdense && Dn > 0) ? w_dense[sp * Dn + j] : 0.f;   // net.py:110-119
+        float o1 = hit[u] ? one[u] : 0.f;
+        o1 = isdense ? x * s_dw1[j] : o1;
+        first += (lg == 0) ? o1 : 0.f;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          s[v] += e[u][v];
-          q[v] += e[u][v] * e[u][v];
+          float ev = hit[u] ? e[u][v] : 0.f;
+          if (isdense && d0 + v < D) ev = x * s_dw[j * D + d0 + v];
+          e[u][v] = ev;
         }
-        vstore<VEC>(fb + (int64_t)f[u] * D, e[u]);
+        if (dvalid && f[u] < F) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            s[v] += e[u][v];
+            q[v] += e[u][v] * e[u][v];
+          }
+          vstore<VEC>(fb + (int64_t)f[u] * D, e[u]);
+        }
       }
     }
-  }
-  // fold the FS field slots of a sample (lanes that differ only in fs)
+    // fold the FS field slots of a sample (lanes that differ only in fs)
 #pragma unroll
-  for (int o = LANES; o < LANES * FS; o <<= 1) {
+    for (int o = LANES; o < LANES * FS; o <<= 1) {
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      s[v] += __shfl_xor(s[v], o, kWave);
-      q[v] += __shfl_xor(q[v], o, kWave);
+      for (int v = 0; v < VEC; ++v) {
+        s[v] += __shfl_xor(s[v], o, kWave);
+        q[v] += __shfl_xor(q[v], o, kWave);
+      }
     }
-  }
-  float part = 0.f;
+    float part = 0.f;
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) part += s[v] * s[v] - q[v];   // net.py:135-136
-  if (!dvalid) part = 0.f;
-  const float tot2 = group_sum<LANES>(part);
-  const float tot1 = group_sum<LANES * FS>(active ? first : 0.f);
-  if (dvalid && fs == 0 && sum_emb) vstore<VEC>(sum_emb + b * D + d0, s);
-  if (active && fs == 0 && lg == 0) {
-    y1[b] = tot1;          // net.py:113-114
-    y2[b] = 0.5f * tot2;   // net.py:135
+    for (int v = 0; v < VEC; ++v) part += s[v] * s[v] - q[v];   // net.py:135-136
+    if (!dvalid) part = 0.f;
+    const float tot2 = group_sum<LANES>(part);
+    const float tot1 = group_sum<LANES * FS>(active ? first : 0.f);
+    if (dvalid && fs == 0 && sum_emb) vstore<VEC>(sum_emb + b * D + d0, s);
+    if (active && fs == 0 && lg == 0) {
+      y1[b] = tot1;          // net.py:113-114
+      y2[b] = 0.5f * tot2;   // net.py:135
+    }
+    wave_lds_fence();  // staging area is rewritten at the top of the next iteration
   }
+  if (oob) atomicOr(status, REC_FLAG_INDEX_OOB);
 }
 
 // ------------------------------------------------------------------------------------------ bwd
-constexpr int kDnMax = 16;
 constexpr int kBwdUnroll = 4;
 constexpr int kMaxDenseIters = 8;   // wave iterations that may contain dense fields
-constexpr int kBwdMaxBlocks = kNumCU * 8;
 
-template <int VEC, int LANES>
+template <int VEC, int LANES, int NDI>
 __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
     int64_t B, int S, int Dn, int D, const float* __restrict__ dense,
     const float* __restrict__ feat, const float* __restrict__ sum_emb,
     const float* __restrict__ dfeat, const float* __restrict__ dy1, const float* __restrict__ dy2,
-    float* __restrict__ row_grad, float* __restrict__ partial) {
+    const float* __restrict__ dense_w, float* __restrict__ row_grad, float* __restrict__ partial) {
   constexpr int FS = fs_for<LANES>();
   constexpr int SPW = kWave / (LANES * FS);
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [waves][Dn*D + Dn]
@@ -163,16 +248,22 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
   const int F = S + Dn;
   const int NIT = (F + FS - 1) / FS;
   const int it_d0 = S / FS;        // first wave iteration that can contain a dense field
-  const int nd = NIT - it_d0;      // <= kMaxDenseIters (checked on the host)
+  const int nd = NIT - it_d0;      // <= NDI (dispatched on the host)
   const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
 
-  float acc[kMaxDenseIters][VEC];
-  float acc1[kMaxDenseIters];
+  float acc[NDI][VEC];
+  float acc1[NDI];
+  float dwr[NDI][VEC];             // this lane's slice of dense_w for its dense field of iteration k
 #pragma unroll
-  for (int k = 0; k < kMaxDenseIters; ++k) {
+  for (int k = 0; k < NDI; ++k) {
     acc1[k] = 0.f;
+    const int f = (it_d0 + k) * FS + fs;
+    const bool isd = k < nd && f >= S && f < F;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[k][v] = 0.f;
+    for (int v = 0; v < VEC; ++v) {
+      acc[k][v] = 0.f;
+      dwr[k][v] = (dense_w && isd && d0 + v < D) ? dense_w[(f - S) * D + d0 + v] : 0.f;
+    }
   }
 
   for (int64_t wv = (int64_t)blockIdx.x * kWavesPerBlock + wave; wv * SPW < B; wv += nwaves) {
@@ -190,6 +281,21 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
     const float* fb = feat + (b * F) * (int64_t)D + d0;
     const float* gb = dfeat + (b * F) * (int64_t)D + d0;
     float* rg = row_grad + (b * S) * (int64_t)D + d0;
+    // wave iterations that (may) hold dense fields first: their loads are the irregular ones
+    float ed[NDI][VEC], gd[NDI][VEC], xd[NDI];
+#pragma unroll
+    for (int k = 0; k < NDI; ++k) {
+      const int f = (it_d0 + k) * FS + fs;
+      const bool ok = k < nd && dvalid && f < F;
+      xd[k] = 0.f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) ed[k][v] = gd[k][v] = 0.f;
+      if (ok) {
+        vload<VEC>(gd[k], gb + (int64_t)f * D);
+        if (f >= S) xd[k] = dense[b * Dn + (f - S)];
+        if (f < S || !dense_w) vload<VEC>(ed[k], fb + (int64_t)f * D);
+      }
+    }
     // wave iterations holding sparse fields only: d row = d_dnn + dy2 * (sum_emb - feat)
     for (int it0 = 0; it0 < it_d0; it0 += kBwdUnroll) {
       float e[kBwdUnroll][VEC], g[kBwdUnroll][VEC];
@@ -212,25 +318,23 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
         }
       }
     }
-    // wave iterations that (may) hold dense fields: the (field, dims) of a lane is loop invariant
 #pragma unroll
-    for (int k = 0; k < kMaxDenseIters; ++k) {
-      if (k < nd) {
-        const int f = (it_d0 + k) * FS + fs;
-        if (dvalid && f < F) {
-          float e[VEC], g[VEC], de[VEC];
-          vload<VEC>(e, fb + (int64_t)f * D);
-          vload<VEC>(g, gb + (int64_t)f * D);
+    for (int k = 0; k < NDI; ++k) {
+      const int f = (it_d0 + k) * FS + fs;
+      if (k < nd && dvalid && f < F) {
+        float de[VEC];
+        const bool isd = f >= S;
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) de[v] = g[v] + g2 * (sb[v] - e[v]);
-          if (f < S) {
-            vstore<VEC>(rg + (int64_t)f * D, de);
-          } else {
-            const float x = dense[b * Dn + (f - S)];
+        for (int v = 0; v < VEC; ++v) {
+          const float e = (isd && dense_w) ? xd[k] * dwr[k][v] : ed[k][v];
+          de[v] = gd[k][v] + g2 * (sb[v] - e);
+        }
+        if (!isd) {
+          vstore<VEC>(rg + (int64_t)f * D, de);
+        } else {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[k][v] += x * de[v];
-            if (lg == 0) acc1[k] += g1 * x;
-          }
+          for (int v = 0; v < VEC; ++v) acc[k][v] += xd[k] * de[v];
+          if (lg == 0) acc1[k] += g1 * xd[k];
         }
       }
     }
@@ -238,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
 
   // fold the SPW samples of the wave, then the waves of the block (fixed order)
 #pragma unroll
-  for (int k = 0; k < kMaxDenseIters; ++k) {
+  for (int k = 0; k < NDI; ++k) {
 #pragma unroll
     for (int o = LANES * FS; o < kWave; o <<= 1) {
 #pragma unroll
@@ -250,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
   float* sw = smem + wave * K;
   if (sp == 0 && d0 < D) {
 #pragma unroll
-    for (int k = 0; k < kMaxDenseIters; ++k) {
+    for (int k = 0; k < NDI; ++k) {
       const int f = (it_d0 + k) * FS + fs;
       if (k < nd && f >= S && f < F) {
         const int j = f - S;
@@ -301,16 +405,6 @@ static int check_desc(const rec_deepfm_desc* d) {
   return REC_OK;
 }
 
-template <int LANES>
-static int bwd_shape_ok(int S, int Dn) {
-  constexpr int FS = fs_for<LANES>();
-  const int nit = (S + Dn + FS - 1) / FS;
-  REC_REQUIRE(nit - S / FS <= kMaxDenseIters, REC_ESHAPE,
-              "num_dense %d spans more than %d wave iterations at this emb_dim", Dn,
-              kMaxDenseIters);
-  return REC_OK;
-}
-
 }  // namespace rec
 
 using namespace rec;
@@ -326,18 +420,33 @@ extern "C" int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids
   REC_REQUIRE(desc->num_dense == 0 || (dense && dense_w && dense_w_one), REC_EINVAL,
               "dense inputs missing");
   const int S = desc->num_slots, Dn = desc->num_dense, D = desc->emb_dim;
-  const size_t shmem = (size_t)(Dn * D + Dn + 4) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+  const int w1_stride = desc->w1_stride > 0 ? desc->w1_stride : 1;
   return dispatch_row_shape(D, desc->row_stride, [&](auto vec, auto lanes) -> int {
     constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
     constexpr int SPW = kWave / (LANES * fs_for<LANES>());
-    const int64_t spb = (int64_t)SPW * kWavesPerBlock;  // samples per block
-    const int64_t grid = (desc->batch + spb - 1) / spb;
-    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "batch too large");
-    hipLaunchKernelGGL((fm_fwd_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock), shmem, st,
-                       desc->batch, S, Dn, D, desc->row_stride, desc->num_rows, desc->padding_idx,
-                       ids, dense, W, W1, dense_w, dense_w_one, slot_offset, y1, y2, feat, sum_emb,
-                       status);
+    const int idch = (SPW * S + kWave - 1) / kWave;  // id loads per lane per tile
+    REC_REQUIRE(idch <= 8, REC_ESHAPE, "num_slots %d too large at emb_dim %d (limit %d)", S, D,
+                8 * kWave / SPW);
+    const size_t hdr = ((size_t)(Dn * D + Dn) * 4 + 15) & ~(size_t)15;
+    const size_t wave_bytes = ((size_t)SPW * S * 8 + (size_t)SPW * Dn * 4 + 15) & ~(size_t)15;
+    const size_t shmem = hdr + (size_t)S * 8 + kWavesPerBlock * wave_bytes;
+    REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "LDS staging %zu B too large", shmem);
+    const int64_t ntiles = (desc->batch + SPW - 1) / SPW;
+    const int64_t want = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+#define REC_FWD_LAUNCH(IDCH)                                                                      \
+  int64_t grid = resident_blocks(fm_fwd_kernel<VEC, LANES, IDCH>, kBlock, shmem);                 \
+  if (grid > want) grid = want;                                                                   \
+  if (grid > kMaxBlocks) grid = kMaxBlocks;                                                       \
+  hipLaunchKernelGGL((fm_fwd_kernel<VEC, LANES, IDCH>), dim3((unsigned)grid), dim3(kBlock), shmem, \
+                     st, desc->batch, S, Dn, D, desc->row_stride, w1_stride, desc->num_rows,       \
+                     desc->padding_idx, ids, dense, W, W1, dense_w, dense_w_one, slot_offset, y1,  \
+                     y2, feat, sum_emb, status)
+    if (idch <= 1) { REC_FWD_LAUNCH(1); }
+    else if (idch <= 2) { REC_FWD_LAUNCH(2); }
+    else if (idch <= 4) { REC_FWD_LAUNCH(4); }
+    else { REC_FWD_LAUNCH(8); }
+#undef REC_FWD_LAUNCH
     return check_launch("rec_deepfm_fm_fwd");
   });
 }
@@ -346,15 +455,15 @@ extern "C" int rec_deepfm_fm_bwd_workspace_bytes(const rec_deepfm_desc* desc, si
   if (int rc = check_desc(desc)) return rc;
   REC_REQUIRE(bytes, REC_EINVAL, "bytes is NULL");
   const int K = desc->num_dense * desc->emb_dim + desc->num_dense;
-  *bytes = align_up((size_t)kBwdMaxBlocks * (K > 0 ? K : 1) * sizeof(float), 256);
+  *bytes = align_up((size_t)kMaxBlocks * (K > 0 ? K : 1) * sizeof(float), 256);
   return REC_OK;
 }
 
 extern "C" int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense,
                                  const float* feat, const float* sum_emb, const float* d_feat_dnn,
-                                 const float* dy1, const float* dy2, float* row_grad,
-                                 float* d_dense_w, float* d_dense_w_one, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+                                 const float* dy1, const float* dy2, const float* dense_w,
+                                 float* row_grad, float* d_dense_w, float* d_dense_w_one,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_desc(desc)) return rc;
   const int S = desc->num_slots, Dn = desc->num_dense, D = desc->emb_dim;
   REC_REQUIRE(Dn == 0 || (d_dense_w && d_dense_w_one), REC_EINVAL, "dense args missing");
@@ -376,16 +485,33 @@ extern "C" int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense
   }
   return dispatch_row_shape(D, D, [&](auto vec, auto lanes) -> int {
     constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
-    constexpr int SPW = kWave / (LANES * fs_for<LANES>());
-    if (int rc = bwd_shape_ok<LANES>(S, Dn)) return rc;
+    constexpr int FS = fs_for<LANES>();
+    constexpr int SPW = kWave / (LANES * FS);
+    const int nit = (S + Dn + FS - 1) / FS;
+    const int nd = nit - S / FS;
+    REC_REQUIRE(nd <= kMaxDenseIters, REC_ESHAPE,
+                "num_dense %d spans more than %d wave iterations at this emb_dim", Dn,
+                kMaxDenseIters);
     const int64_t spb = (int64_t)SPW * kWavesPerBlock;
-    int64_t need_blocks = (desc->batch + spb - 1) / spb;
-    const int grid = (int)(need_blocks < kBwdMaxBlocks ? need_blocks : kBwdMaxBlocks);
+    const int64_t need_blocks = (desc->batch + spb - 1) / spb;
     const size_t shmem = (size_t)kWavesPerBlock * (K > 0 ? K : 1) * sizeof(float);
     float* partial = (float*)workspace;
-    hipLaunchKernelGGL((fm_bwd_kernel<VEC, LANES>), dim3(grid), dim3(kBlock), shmem, st,
-                       desc->batch, S, Dn, D, dense, feat, sum_emb, d_feat_dnn, dy1, dy2,
-                       row_grad, partial);
+    int grid = 1;
+#define REC_BWD_LAUNCH(NDI)                                                                       \
+  {                                                                                               \
+    int64_t g = resident_blocks(fm_bwd_kernel<VEC, LANES, NDI>, kBlock, shmem);                   \
+    if (g > need_blocks) g = need_blocks;                                                         \
+    if (g > kMaxBlocks) g = kMaxBlocks;                                                           \
+    grid = (int)g;                                                                                \
+  }                                                                                               \
+  hipLaunchKernelGGL((fm_bwd_kernel<VEC, LANES, NDI>), dim3(grid), dim3(kBlock), shmem, st,       \
+                     desc->batch, S, Dn, D, dense, feat, sum_emb, d_feat_dnn, dy1, dy2, dense_w,  \
+                     row_grad, partial)
+    if (nd <= 1) { REC_BWD_LAUNCH(1); }
+    else if (nd <= 2) { REC_BWD_LAUNCH(2); }
+    else if (nd <= 4) { REC_BWD_LAUNCH(4); }
+    else { REC_BWD_LAUNCH(8); }
+#undef REC_BWD_LAUNCH
     if (K > 0) {
       hipLaunchKernelGGL(fold_partials_kernel, dim3(K), dim3(kBlock), 0, st, partial, grid, Dn * D,
                          d_dense_w, d_dense_w_one);

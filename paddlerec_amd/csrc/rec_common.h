@@ -34,6 +34,26 @@ inline int check_launch(const char* what) {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Grid of a persistent kernel: as many blocks as are co-resident on the chip (occupancy query x CU
+// count), so that no block waits for a slot — a second, partly filled dispatch round is pure tail.
+// Only speed depends on it (no inter-block waits anywhere), so an optimistic answer is harmless.
+template <class Kernel>
+inline int64_t resident_blocks(Kernel kernel, int block_threads, size_t dyn_lds) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, dyn_lds) !=
+          hipSuccess || per_cu < 1) {
+    (void)hipGetLastError();
+    per_cu = 2;
+  }
+  int dev = 0, cus = kNumCU;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+  }
+  return (int64_t)per_cu * cus;
+}
+
 // Lanes that cooperate on one embedding row: each lane owns VEC consecutive floats.
 // D % 4 == 0 && stride % 4 == 0 -> float4 per lane; otherwise one float per lane.
 inline int pow2_ceil(int x) {

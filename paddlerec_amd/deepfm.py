@@ -87,6 +87,10 @@ class _Timed:
             self.timers.setdefault(self.name, []).append((self.e0, self.e1))
 
 
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
 class FM:
     """net.py:52-139.  Holds embedding_one [N,1], embedding [N,D]; dense_w_one/dense_w live in the
     flat dense buffer of the owning DeepFMLayer."""
@@ -102,8 +106,15 @@ class FM:
         self.padding_idx = 0                                   # net.py:69,81
         std = self.init_value_ / math.sqrt(float(sparse_feature_dim))
         N, D = sparse_feature_number, sparse_feature_dim
-        self.embedding_one = torch.empty(N, 1, dtype=torch.float32, device=device)
-        self.embedding = torch.empty(N, D, dtype=torch.float32, device=device)
+        # Table layout (DESIGN.md "table layout"): HBM is fetched in whole 128-B lines, so both
+        # embeddings of a row live in ONE line-aligned record  [W(D) | W1 | m1 | v1 | pad]  and a
+        # lookup costs one line instead of two; the second-order Adam moments sit in a second
+        # record buffer [m(D) | v(D)] that only the optimizer touches.  The reference's two
+        # parameters are views: embedding = rec[:, :D], embedding_one = rec[:, D:D+1].
+        self.rec_width = _round_up(D + 3, 32)
+        self.rec = torch.zeros(N, self.rec_width, dtype=torch.float32, device=device)
+        self.embedding = self.rec[:, :D]
+        self.embedding_one = self.rec[:, D:D + 1]
         for t in (self.embedding_one, self.embedding):        # TruncatedNormal(0,std) net.py:72-75
             torch.nn.init.trunc_normal_(t, 0.0, std, -2 * std, 2 * std)
             if slot_offset is None and zero_padding_row:
@@ -199,9 +210,12 @@ class DeepFMLayer:
     # -- one full training step: train_forward + backward + optimizer.step ----------------------
     def _ensure_sparse_state(self):
         if self.sparse_state is None:
-            self.sparse_state = dict(
-                m=torch.zeros_like(self.fm.embedding), v=torch.zeros_like(self.fm.embedding),
-                m1=torch.zeros_like(self.fm.embedding_one), v1=torch.zeros_like(self.fm.embedding_one))
+            D = self.sparse_feature_dim
+            Dp = _round_up(D, 4)
+            mv = torch.zeros(self.fm.rec.shape[0], _round_up(2 * Dp, 32), dtype=torch.float32,
+                             device=self.device)
+            self.sparse_state = dict(mv=mv, m=mv[:, :D], v=mv[:, Dp:Dp + D],
+                                     m1=self.fm.rec[:, D + 1:D + 2], v1=self.fm.rec[:, D + 2:D + 3])
 
     def train_step(self, sparse_inputs, dense_inputs, label, lr=1e-3, auc_stats=None,
                    allreduce=None):
@@ -214,16 +228,17 @@ class DeepFMLayer:
         cur = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-        # SelectedRows merge keys only depend on ids: sort them on a side stream, hidden behind the GEMMs
-        self._side.wait_stream(cur)
-        groups = getattr(self, "_groups", None)          # persistent: the wait_stream above orders reuse
+        groups = getattr(self, "_groups", None)          # persistent: the wait_stream below orders reuse
         if groups is None or groups.n != B * S:
             groups = self._groups = self.k.IdGroups(B * S, self.device)
+        with self._timed("fm_fwd"):
+            y1, y2, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
+        # SelectedRows merge keys only depend on ids: sort them on a side stream, hidden behind the
+        # MFMA-bound GEMMs (started after the HBM-bound lookup so the two do not fight for bandwidth)
+        self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             self.k.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
                           self.fm.slot_offset, self.status, groups)
-        with self._timed("fm_fwd"):
-            y1, y2, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
         with self._timed("mlp_fwd"):
             y_dnn, acts = mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b)
         pred, dz, loss = self.k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws)
@@ -236,7 +251,8 @@ class DeepFMLayer:
                 dense_inputs, feat, sum_emb, d_flat.view(B, self.num_field, -1), dz, dz, S, self.ws,
                 out=(self._row_grad_buf(B * S),
                      self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
-                     self.dense.g["fm.dense_w_one"]))
+                     self.dense.g["fm.dense_w_one"]),
+                dense_w=self.dense.p["fm.dense_w"])
         if allreduce is not None:
             allreduce(self.dense.grad)
         t = self.step_count

@@ -33,6 +33,25 @@ def _chk(t, dtype, name, shape=None):
         raise RecError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
 
 
+def _chk_table(t, name):
+    """A table is f32 [N,D] (or [N]) on the device with unit column stride; rows may be strided
+    (a column slice of a wider record buffer).  Returns (D, row_stride)."""
+    if not t.is_cuda:
+        raise RecError("%s must be a device tensor (no CPU fallback)" % name)
+    if t.dtype != torch.float32:
+        raise RecError("%s must be float32, got %s" % (name, t.dtype))
+    if t.dim() == 1:
+        return 1, (t.stride(0) if t.numel() > 1 else 1)
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise RecError("%s must be [N,D] with unit column stride" % name)
+    D, rs = t.shape[1], (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+    if rs < D:
+        raise RecError("%s: row stride %d < D %d" % (name, rs, D))
+    if D % 4 == 0 and rs % 4 == 0 and t.data_ptr() % 16 != 0:
+        raise RecError("%s: rows must be 16-byte aligned" % name)
+    return D, rs
+
+
 def new_status(device):
     return torch.zeros(1, dtype=torch.int32, device=device)
 
@@ -57,9 +76,9 @@ class Workspace:
         return self.buf
 
 
-def make_desc(B, S, Dn, D, num_rows, padding_idx, row_stride=None):
+def make_desc(B, S, Dn, D, num_rows, padding_idx, row_stride=None, w1_stride=1):
     return DeepFMDesc(int(B), int(S), int(Dn), int(D), int(row_stride or D), int(num_rows),
-                      -1 if padding_idx is None else int(padding_idx))
+                      -1 if padding_idx is None else int(padding_idx), int(w1_stride), 0)
 
 
 # ------------------------------------------------------------------ DeepFM FM block
@@ -73,8 +92,8 @@ def deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, padding_idx=0, slot_o
     dev = ids.device
     _chk(ids, torch.int64, "ids")
     _chk(dense, torch.float32, "dense", (B, Dn))
-    _chk(W, torch.float32, "W")
-    _chk(W1, torch.float32, "W1")
+    _, w_stride = _chk_table(W, "W")
+    _, w1_stride = _chk_table(W1, "W1")
     _chk(dense_w, torch.float32, "dense_w")
     _chk(dense_w_one, torch.float32, "dense_w_one", (Dn,))
     _chk(slot_offset, torch.int64, "slot_offset", (S,))
@@ -89,15 +108,16 @@ def deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, padding_idx=0, slot_o
         y1, y2, feat, sum_emb = out
     if status is None:
         status = new_status(dev)
-    desc = make_desc(B, S, Dn, D, N, padding_idx, W.stride(0))
+    desc = make_desc(B, S, Dn, D, N, padding_idx, w_stride, w1_stride)
     check(lib().rec_deepfm_fm_fwd(C.byref(desc), _p(ids), _p(dense), _p(W), _p(W1), _p(dense_w),
                                   _p(dense_w_one), _p(slot_offset), _p(y1), _p(y2), _p(feat),
                                   _p(sum_emb), _p(status), _stream()), "rec_deepfm_fm_fwd")
     return y1, y2, feat, sum_emb, status
 
 
-def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None):
-    """-> row_grad [B*S,D], d_dense_w [Dn,D], d_dense_w_one [Dn]"""
+def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, dense_w=None):
+    """-> row_grad [B*S,D], d_dense_w [Dn,D], d_dense_w_one [Dn].
+    dense_w ([Dn,D] / [1,Dn,D], optional): recompute the dense part of feat instead of re-reading it."""
     B, F, D = feat.shape
     Dn = F - S
     dev = feat.device
@@ -106,6 +126,10 @@ def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None):
         _chk(t, torch.float32, n)
     if d_feat_dnn.numel() != feat.numel() or dy1.numel() != B or dy2.numel() != B:
         raise RecError("gradient shape mismatch")
+    if dense_w is not None:
+        _chk(dense_w, torch.float32, "dense_w")
+        if dense_w.numel() != Dn * D:
+            raise RecError("dense_w shape mismatch")
     if out is None:
         row_grad = torch.empty(B * S, D, dtype=torch.float32, device=dev)
         d_dense_w = torch.empty(Dn, D, dtype=torch.float32, device=dev)
@@ -117,7 +141,8 @@ def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None):
     check(lib().rec_deepfm_fm_bwd_workspace_bytes(C.byref(desc), C.byref(nbytes)))
     w = ws.get(nbytes.value)
     check(lib().rec_deepfm_fm_bwd(C.byref(desc), _p(dense), _p(feat), _p(sum_emb), _p(d_feat_dnn),
-                                  _p(dy1), _p(dy2), _p(row_grad), _p(d_dense_w), _p(d_dense_w_one),
+                                  _p(dy1), _p(dy2), _p(dense_w), _p(row_grad), _p(d_dense_w),
+                                  _p(d_dense_w_one),
                                   _p(w), C.c_size_t(w.numel()), _stream()), "rec_deepfm_fm_bwd")
     return row_grad, d_dense_w, d_dense_w_one
 
@@ -126,7 +151,7 @@ def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None):
 def emb_gather(ids, W, padding_idx=None, status=None, out=None):
     """out[i,:] = W[ids[i],:] (zero row where ids[i]==padding_idx).  W [N,D] f32."""
     _chk(ids, torch.int64, "ids")
-    _chk(W, torch.float32, "W")
+    _, w_stride = _chk_table(W, "W")
     N, D = W.shape
     if out is None:
         out = torch.empty(*ids.shape, D, dtype=torch.float32, device=ids.device)
@@ -136,7 +161,7 @@ def emb_gather(ids, W, padding_idx=None, status=None, out=None):
             raise RecError("out has %d elements, expected %d" % (out.numel(), ids.numel() * D))
     if status is None:
         status = new_status(ids.device)
-    check(lib().rec_emb_gather(ids.numel(), D, W.stride(0), N,
+    check(lib().rec_emb_gather(ids.numel(), D, w_stride, N,
                                -1 if padding_idx is None else padding_idx, _p(ids), _p(W), _p(out),
                                _p(status), _stream()), "rec_emb_gather")
     return out, status
@@ -213,10 +238,11 @@ def _hyper(lr, beta1, beta2, eps, step):
 
 def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999,
                      eps=1e-8):
-    for t, n in ((grad, "grad"), (P, "P"), (M, "M"), (V, "V")):
-        _chk(t, torch.float32, n)
-    D = P.shape[1] if P.dim() > 1 else 1
-    stride = P.stride(0) if P.dim() > 1 else 1
+    _chk(grad, torch.float32, "grad")
+    D, stride = _chk_table(P, "P")
+    for t, n in ((M, "M"), (V, "V")):
+        if _chk_table(t, n) != (D, stride):
+            raise RecError("%s must have the shape and row stride of P" % n)
     h = _hyper(lr, beta1, beta2, eps, step)
     check(lib().rec_sparse_adam_rows(groups.n, D, stride, _p(groups.n_uniq), _p(groups.uniq_rows),
                                      _p(groups.seg_offset), _p(groups.sorted_pos), _p(grad),

@@ -191,7 +191,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
                 dense_inputs, feat, sum_emb, d_flat.view(B, self.num_field, -1), dz, dz, S, self.ws,
                 out=(self._row_grad_buf(B * S),
                      self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
-                     self.dense.g["fm.dense_w_one"]))
+                     self.dense.g["fm.dense_w_one"]),
+                dense_w=self.dense.p["fm.dense_w"])
         with self._timed("grad_exchange"):
             f32 = dict(dtype=torch.float32, device=self.device)
             send_g = torch.empty(L.n_send, D, **f32)

@@ -62,7 +62,7 @@ def deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, padding_idx=0, slot_o
     return f(y1), f(y2), f(feat), f(sum_emb), status
 
 
-def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None):
+def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, dense_w=None):
     B, F, D = feat.shape
     ids = np.ones((B, S), np.int64)     # padding handling happens at the merge, not here
     g = R.fm_backward(ids, _n(dense), _n(feat), _n(d_feat_dnn).reshape(B, F, D), _n(dy1).reshape(B, 1),

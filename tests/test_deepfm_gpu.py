@@ -147,6 +147,10 @@ def test_fm_bwd_vs_oracle(ops, oracle_lib, B, D, tables):
     # deterministic: same bits on a second run
     rg2, ddw2, _ = ops.deepfm_fm_bwd(T(pr["dense"]), feat, sum_emb, T(dfeat), T(dz), T(dz), 26, ws)
     assert torch.equal(rg, rg2) and torch.equal(ddw, ddw2)
+    # recomputing the dense part of feat from dense_w instead of re-reading it: same bits
+    rg3, ddw3, ddw13 = ops.deepfm_fm_bwd(T(pr["dense"]), feat, sum_emb, T(dfeat), T(dz), T(dz), 26, ws,
+                                         dense_w=T(pr["params"]["dense_w"]))
+    assert torch.equal(rg, rg3) and torch.equal(ddw, ddw3) and torch.equal(ddw1, ddw13)
 
 
 # ------------------------------------------------------------------------------ ids grouping

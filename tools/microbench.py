@@ -58,6 +58,15 @@ def main():
         bwd_b = B * S * 8 + B * F * D * 4 + B * 4 + B * S * D * 4 + B * S * D * 4 + B * S * 4
         out = ops.deepfm_fm_fwd(ids, dense, W, W1, dw, dw1, 0, so)
         y1, y2, feat, sum_emb, status = out
+        # record layout: one 128-B line per row holds W and W1
+        rec = torch.zeros(N, 32, device=DEV)
+        rec[:, :D] = W
+        rec[:, D:D + 1] = W1
+        med, mn = timeit(lambda: ops.deepfm_fm_fwd(ids, dense, rec[:, :D], rec[:, D:D + 1], dw, dw1, 0, so,
+                                                   status, (y1, y2, feat, sum_emb)))
+        print("N=%d: fm_fwd[record layout] %.1f us (min %.1f) => %.0f GB/s algorithmic"
+              % (N, med, mn, fwd_b / med / 1e3))
+        mv = torch.zeros(N, 32, device=DEV)
         med, mn = timeit(lambda: ops.deepfm_fm_fwd(ids, dense, W, W1, dw, dw1, 0, so, status,
                                                    (y1, y2, feat, sum_emb)))
         print("N=%d (%.2f GB): fm_fwd %.1f us (min %.1f) => %.0f GB/s algorithmic"
@@ -74,6 +83,8 @@ def main():
         o = ops.deepfm_fm_bwd(dense, feat, sum_emb, dfeat, dz, dz, S, ws)
         med, mn = timeit(lambda: ops.deepfm_fm_bwd(dense, feat, sum_emb, dfeat, dz, dz, S, ws, o))
         print("   fm_bwd %.1f us (min %.1f) => %.0f GB/s algorithmic" % (med, mn, bwd_b / med / 1e3))
+        med, mn = timeit(lambda: ops.deepfm_fm_bwd(dense, feat, sum_emb, dfeat, dz, dz, S, ws, o, dense_w=dw))
+        print("   fm_bwd(recompute dense) %.1f us (min %.1f) => %.0f GB/s algorithmic" % (med, mn, bwd_b / med / 1e3))
         groups, _ = ops.ids_group(ids, N, 0, ws, so)
         med, mn = timeit(lambda: ops.ids_group(ids, N, 0, ws, so, status, groups))
         print("   ids_group %.1f us; uniq=%s" % (med, groups.n_uniq.tolist()))
@@ -87,7 +98,12 @@ def main():
         V1 = torch.zeros_like(W1)
         med, mn = timeit(lambda: ops.sparse_adam_rows(groups, dz, S, W1, M1, V1, 1))
         print("   sparse_adam_rows D=1: %.1f us" % med)
-        del W, W1, M, V, M1, V1
+        g2, _ = ops.ids_group(ids, N, 0, ws, so)
+        med, mn = timeit(lambda: ops.sparse_adam_rows(g2, o[0], 1, rec[:, :D], mv[:, :D], mv[:, D:2 * D], 1))
+        med1, _ = timeit(lambda: ops.sparse_adam_rows(g2, dz, S, rec[:, D:D + 1], rec[:, D + 1:D + 2],
+                                                      rec[:, D + 2:D + 3], 1))
+        print("   sparse_adam_rows[record layout] D=16: %.1f us, D=1: %.1f us" % (med, med1))
+        del W, W1, M, V, M1, V1, rec, mv
         torch.cuda.empty_cache()
 
 
