@@ -144,6 +144,50 @@ int rec_adam_dense(int64_t n, float* p, float* m, float* v, const float* g,
                    const rec_adam_hyper* hyper, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * f32 GEMM on the matrix cores with fused epilogues: C[M,N] = epi(op(A)[M,K] @ op(B)[K,N]).
+ * Replaces paddle.nn.Linear / paddle.matmul (+ the elementwise ops around them) on the hot path:
+ *   top MLP fwd/bwd  deepfm/net.py:142-174, dcn_v2/net.py:140-184, din/net.py:104-137,175-181
+ *   CrossNetV2       dcn_v2/net.py:214-226 : REC_EPI_CROSS computes X_l + X_0*(X_l W + b) in place
+ *   CrossNetMix      dcn_v2/net.py:278-320 : REC_EPI_BIAS_TANH for the low-rank projections
+ * Row-major everywhere; Paddle's Linear.weight is [in,out] = B[K,N].
+ *   trans_a: A is stored [K,M] (dW = X^T G);  trans_b: B is stored [N,K] (dX = G W^T).
+ * Exact f32 (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain).  split_k: 0 = automatic, partial
+ * sums are reduced in a fixed order (deterministic).
+ * ---------------------------------------------------------------------------------------- */
+typedef enum {
+  REC_EPI_NONE = 0,
+  REC_EPI_BIAS = 1,         /* acc + bias[j] */
+  REC_EPI_BIAS_RELU = 2,    /* max(acc + bias[j], 0) */
+  REC_EPI_RELU_MASK = 3,    /* aux0[i,j] > 0 ? acc : 0          (ReLU backward on dX) */
+  REC_EPI_CROSS = 4,        /* aux1[i,j] + aux0[i,j] * (acc + bias[j])   (aux0 = X_0, aux1 = X_l) */
+  REC_EPI_BIAS_SIGMOID = 5, /* sigmoid(acc + bias[j]) */
+  REC_EPI_BIAS_TANH = 6,    /* tanh(acc + bias[j]); bias may be NULL */
+  REC_EPI_ADD = 7           /* acc + aux1[i,j] */
+} rec_epilogue;
+
+typedef struct {
+  int64_t m;
+  int32_t n, k;
+  int32_t lda, ldb, ldc; /* leading dimensions in floats, of the arrays as stored */
+  int32_t trans_a, trans_b;
+  int32_t epilogue;      /* rec_epilogue */
+  int32_t split_k;       /* 0 = automatic */
+} rec_gemm_desc;
+
+int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* bytes);
+int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const float* B, float* C,
+                 const float* bias, const float* aux0, int32_t ld_aux0, const float* aux1,
+                 int32_t ld_aux1, float* b_colsum, void* workspace, size_t workspace_bytes,
+                 void* stream);
+/* b_colsum ([N] or NULL): also return the column sums of op(B) over K — the bias gradient when the
+ * call computes dW = X^T dY (B = dY), at no extra pass over dY. */
+
+/* out[j] = sum_i G[i,j] (bias gradient of a Linear), fixed reduction order. */
+int rec_colsum_workspace_bytes(int64_t m, int32_t n, size_t* bytes);
+int rec_colsum(int64_t m, int32_t n, int32_t ld, const float* G, float* out, void* workspace,
+               size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Loss head: predict = sigmoid(y1+y2+y_dnn) (deepfm/net.py:47);
  *            cost = log_loss(pred,label,eps=1e-4); avg = mean(cost) (deepfm/dygraph_model.py:53-58)
  * and its gradient dz = d avg / d z.  loss_out[0] = avg (reduced in a fixed order).

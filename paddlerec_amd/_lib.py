@@ -26,6 +26,14 @@ class AdamHyper(C.Structure):
                 ("step", C.c_int64)]
 
 
+class GemmDesc(C.Structure):
+    _fields_ = [("m", C.c_int64), ("n", C.c_int32), ("k", C.c_int32), ("lda", C.c_int32),
+                ("ldb", C.c_int32), ("ldc", C.c_int32), ("trans_a", C.c_int32),
+                ("trans_b", C.c_int32), ("epilogue", C.c_int32), ("split_k", C.c_int32)]
+
+
+EPI = dict(none=0, bias=1, bias_relu=2, relu_mask=3, cross=4, bias_sigmoid=5, bias_tanh=6, add=7)
+
 _P = C.c_void_p
 _I64, _I32, _F, _SZ = C.c_int64, C.c_int32, C.c_float, C.c_size_t
 
@@ -49,6 +57,10 @@ SIGNATURES = {
     "rec_auc_histogram": (C.c_int, [_I64, _P, _P, _I32, _P, _P, _P]),
     "rec_shard_route_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(_SZ)]),
     "rec_shard_route": (C.c_int, [_I64, _I32, _I64, _I64, _I32] + [_P] * 9 + [_SZ, _P]),
+    "rec_gemm_f32_workspace_bytes": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(_SZ)]),
+    "rec_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _I32, _P, _I32, _P, _P, _SZ, _P]),
+    "rec_colsum_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(_SZ)]),
+    "rec_colsum": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _SZ, _P]),
     "rec_xxh32": (C.c_uint32, [C.c_char_p, _SZ, C.c_uint32]),
     "rec_xxh32_hash_mod": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(_I32), _I64, C.c_uint32,
                                      C.POINTER(_I64)]),

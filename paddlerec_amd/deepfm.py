@@ -5,8 +5,8 @@ Mirrors (same class names, constructor arguments, parameter names and forward si
     /root/reference/models/rank/deepfm/dygraph_model.py     DygraphModel (create_model, create_loss,
                                                             create_optimizer, train_forward, ...)
 The embedding lookups, FM block, loss head, SelectedRows merge, sparse/dense Adam and the AUC
-histogram are hand-written HIP kernels behind the C-ABI (include/recengine.h); the top-MLP GEMMs go
-to the MFMA units through the vendor GEMM (torch.mm -> hipBLASLt), as the north star prescribes.
+histogram are hand-written HIP kernels behind the C-ABI (include/recengine.h); the top-MLP GEMMs run on the
+MFMA units through rec_gemm_f32 (exact-f32 v_mfma_f32_16x16x4, bias/ReLU/ReLU' fused in the epilogue).
 There is no autograd tape and no CPU fallback: backward is the explicit chain the reference's
 `loss.backward()` (tools/trainer.py:151) implies.
 """
@@ -17,35 +17,6 @@ import torch
 from . import ops
 
 NUM_THRESHOLDS = 4095  # paddle.metric.Auc default [EXT]
-
-
-# ----------------------------------------------------------------------------------------------
-# top MLP (net.py:142-174): pure tensor algebra, device agnostic — GEMMs only, no custom kernels
-# ----------------------------------------------------------------------------------------------
-def mlp_forward(x, weights, biases):
-    """Linear(+bias)->ReLU ... ->Linear with Paddle-layout weights [in,out].
-    Returns (y, acts) where acts[i] is the input of layer i."""
-    acts = []
-    n = len(weights)
-    for i in range(n):
-        acts.append(x)
-        x = torch.addmm(biases[i], x, weights[i])
-        if i < n - 1:
-            x = torch.relu_(x)
-    return x, acts + [x]
-
-
-def mlp_backward(dy, acts, weights, dws, dbs):
-    """Writes dW_i into dws[i], db_i into dbs[i] (preallocated views); returns d(input)."""
-    n = len(weights)
-    g = dy
-    for i in reversed(range(n)):
-        if i < n - 1:
-            g = g * (acts[i + 1] > 0).to(g.dtype)      # ReLU'
-        torch.mm(acts[i].t(), g, out=dws[i])
-        torch.sum(g, dim=0, out=dbs[i])
-        g = torch.mm(g, weights[i].t())
-    return g
 
 
 class _FlatParams:
@@ -168,6 +139,7 @@ class DeepFMLayer:
         self.sparse_state = None
         self.ws = self.k.Workspace(self.device)
         self.ws_group = self.k.Workspace(self.device)
+        self.ws_mlp = self.k.Workspace(self.device)
         self.status = self.k.new_status(self.device)
         self.step_count = 0
         self._side = None
@@ -202,7 +174,7 @@ class DeepFMLayer:
     def forward(self, sparse_inputs, dense_inputs):
         ids = self._concat_ids(sparse_inputs)
         y1, y2, feat, _, _ = self._fm_fwd(ids, dense_inputs)
-        y_dnn, _ = mlp_forward(feat.view(feat.shape[0], -1), self.mlp_w, self.mlp_b)
+        y_dnn, _ = self.k.mlp_forward(feat.view(feat.shape[0], -1), self.mlp_w, self.mlp_b, self.ws_mlp)
         return torch.sigmoid(y1 + y2 + y_dnn)
 
     __call__ = forward
@@ -240,12 +212,12 @@ class DeepFMLayer:
             self.k.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
                           self.fm.slot_offset, self.status, groups)
         with self._timed("mlp_fwd"):
-            y_dnn, acts = mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b)
+            y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b, self.ws_mlp)
         pred, dz, loss = self.k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws)
         if auc_stats is not None:
             self.k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         with self._timed("mlp_bwd"):
-            d_flat = mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db)
+            d_flat = self.k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp)
         with self._timed("fm_bwd"):
             row_grad, _, _ = self.k.deepfm_fm_bwd(
                 dense_inputs, feat, sum_emb, d_flat.view(B, self.num_field, -1), dz, dz, S, self.ws,

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import AdamHyper, DeepFMDesc, RecError, check, lib
+from ._lib import EPI, AdamHyper, DeepFMDesc, GemmDesc, RecError, check, lib
 
 
 def _stream():
@@ -292,6 +292,92 @@ def shard_route(ids, num_rows, padding_idx, num_shards, ws, slot_offset=None, st
                                 _p(route.send_counts), _p(status), _p(w), C.c_size_t(w.numel()),
                                 _stream()), "rec_shard_route")
     return route, status
+
+
+# ------------------------------------------------------------------ f32 MFMA GEMM
+def _chk_mat(t, name):
+    if not t.is_cuda:
+        raise RecError("%s must be a device tensor (no CPU fallback)" % name)
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise RecError("%s must be a 2-D float32 tensor" % name)
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise RecError("%s must have unit column stride" % name)
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux0=None, aux1=None,
+         out=None, split_k=0, b_colsum=None):
+    """out[M,N] = epi(op(A) @ op(B)); A/B/out row-major (row strides allowed).
+    trans_a: A is given as [K,M]; trans_b: B is given as [N,K] (a torch Linear.weight, or W for dX)."""
+    lda, ldb = _chk_mat(A, "A"), _chk_mat(B, "B")
+    K, M = (A.shape if trans_a else A.shape[::-1])
+    N, K2 = (B.shape if trans_b else B.shape[::-1])
+    if K != K2:
+        raise RecError("inner dimensions differ: %d vs %d" % (K, K2))
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    ldc = _chk_mat(out, "out")
+    if tuple(out.shape) != (M, N):
+        raise RecError("out has shape %s, expected %s" % (tuple(out.shape), (M, N)))
+    ld0 = ld1 = 0
+    if aux0 is not None:
+        ld0 = _chk_mat(aux0, "aux0")
+    if aux1 is not None:
+        ld1 = _chk_mat(aux1, "aux1")
+    if bias is not None:
+        _chk(bias, torch.float32, "bias")
+        if bias.numel() != N:
+            raise RecError("bias must have N elements")
+    if b_colsum is not None:
+        _chk(b_colsum, torch.float32, "b_colsum")
+        if b_colsum.numel() != N:
+            raise RecError("b_colsum must have N elements")
+    d = GemmDesc(M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), EPI[epilogue], int(split_k))
+    nbytes = C.c_size_t(0)
+    check(lib().rec_gemm_f32_workspace_bytes(C.byref(d), C.byref(nbytes)))
+    w = ws.get(nbytes.value)
+    check(lib().rec_gemm_f32(C.byref(d), _p(A), _p(B), _p(out), _p(bias), _p(aux0), ld0, _p(aux1), ld1,
+                             _p(b_colsum), _p(w), C.c_size_t(w.numel()), _stream()), "rec_gemm_f32")
+    return out
+
+
+def colsum(G, ws, out=None):
+    ld = _chk_mat(G, "G")
+    M, N = G.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=G.device)
+    nbytes = C.c_size_t(0)
+    check(lib().rec_colsum_workspace_bytes(M, N, C.byref(nbytes)))
+    w = ws.get(nbytes.value)
+    check(lib().rec_colsum(M, N, ld, _p(G), _p(out), _p(w), C.c_size_t(w.numel()), _stream()),
+          "rec_colsum")
+    return out
+
+
+# ------------------------------------------------------------------ top MLP on the GEMM above
+def mlp_forward(x, weights, biases, ws):
+    """Linear(+bias)->ReLU ... ->Linear (deepfm/net.py:142-174) with Paddle-layout weights [in,out];
+    bias and ReLU run in the GEMM epilogue.  Returns (y, acts): acts[i] = input of layer i."""
+    acts = []
+    n = len(weights)
+    for i in range(n):
+        acts.append(x)
+        x = gemm(x, weights[i], ws, epilogue="bias_relu" if i < n - 1 else "bias", bias=biases[i])
+    return x, acts + [x]
+
+
+def mlp_backward(dy, acts, weights, dws, dbs, ws):
+    """Backward of mlp_forward: dW_i -> dws[i], db_i -> dbs[i] (preallocated views); returns d(input).
+    ReLU' is applied in the epilogue of the dX GEMM (mask = layer input > 0)."""
+    n = len(weights)
+    g = dy
+    for i in reversed(range(n)):
+        gemm(acts[i], g, ws, trans_a=True, out=dws[i], b_colsum=dbs[i])    # dW = X^T G, db = colsum(G)
+        if i > 0:
+            g = gemm(g, weights[i], ws, trans_b=True, epilogue="relu_mask", aux0=acts[i])
+        else:
+            g = gemm(g, weights[i], ws, trans_b=True)
+    return g
 
 
 # ------------------------------------------------------------------ loss head / metric

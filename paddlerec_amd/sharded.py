@@ -18,7 +18,7 @@ unsharded model on the concatenated batch (tests/test_sharded*.py check exactly 
 import torch
 
 from . import ops
-from .deepfm import NUM_THRESHOLDS, DeepFMLayer, mlp_backward, mlp_forward
+from .deepfm import NUM_THRESHOLDS, DeepFMLayer
 
 
 class Comm:
@@ -157,7 +157,7 @@ class ShardedDeepFMLayer(DeepFMLayer):
         B, S = ids.shape
         L = self._lookup(ids)
         y1, y2, feat, _, _ = self._fm_fwd_routed(L, B, S, dense_inputs)
-        y_dnn, _ = mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b)
+        y_dnn, _ = self.k.mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b, self.ws_mlp)
         return torch.sigmoid(y1 + y2 + y_dnn)
 
     __call__ = forward
@@ -177,7 +177,7 @@ class ShardedDeepFMLayer(DeepFMLayer):
         with self._timed("fm_fwd"):
             y1, y2, feat, sum_emb, _ = self._fm_fwd_routed(L, B, S, dense_inputs)
         with self._timed("mlp_fwd"):
-            y_dnn, acts = mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b)
+            y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b, self.ws_mlp)
         loss_slot = self.dense.g["__loss__"]
         pred, dz, _ = k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws, mean_over=G * B,
                                         out=(self._buf("pred", (B, 1)), self._buf("dz", (B, 1)),
@@ -185,7 +185,7 @@ class ShardedDeepFMLayer(DeepFMLayer):
         if auc_stats is not None:
             k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         with self._timed("mlp_bwd"):
-            d_flat = mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db)
+            d_flat = self.k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp)
         with self._timed("fm_bwd"):
             row_grad, _, _ = k.deepfm_fm_bwd(
                 dense_inputs, feat, sum_emb, d_flat.view(B, self.num_field, -1), dz, dz, S, self.ws,

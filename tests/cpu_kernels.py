@@ -120,3 +120,26 @@ def auc_histogram(pred, label, stat_pos, stat_neg, num_thresholds=4095):
     pos, neg = R.auc_histogram(pred.numpy(), label.numpy(), num_thresholds)
     stat_pos += torch.from_numpy(pos)
     stat_neg += torch.from_numpy(neg)
+
+
+def mlp_forward(x, weights, biases, ws):
+    acts = []
+    n = len(weights)
+    for i in range(n):
+        acts.append(x)
+        x = torch.addmm(biases[i], x, weights[i])
+        if i < n - 1:
+            x = torch.relu_(x)
+    return x, acts + [x]
+
+
+def mlp_backward(dy, acts, weights, dws, dbs, ws):
+    n = len(weights)
+    g = dy
+    for i in reversed(range(n)):
+        if i < n - 1:
+            g = g * (acts[i + 1] > 0).to(g.dtype)
+        torch.mm(acts[i].t(), g, out=dws[i])
+        torch.sum(g, dim=0, out=dbs[i])
+        g = torch.mm(g, weights[i].t())
+    return g

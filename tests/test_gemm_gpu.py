@@ -1,0 +1,138 @@
+"""f32 MFMA GEMM (rec_gemm_f32) and column sums against float64 NumPy.
+
+The instruction is an exact k-ordered f32 fmaf chain; against float64 the error is f32 round-off of a
+K-term dot product, bounded here by 4e-7 * sum_k |a_ik||b_kj| (the guide measures 0.75-1.5e-7 at K<=1024).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops(engine_lib):
+    from paddlerec_amd import ops as o
+    return o
+
+
+def _mk(rng, *shape):
+    return rng.uniform(-1, 1, size=shape).astype(np.float32)
+
+
+def _check(C, want, bound):
+    err = np.abs(C.astype(np.float64) - want)
+    assert np.all(err <= bound + 1e-30), "max err %.3e, bound %.3e" % (err.max(), bound.max())
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [
+    (128, 128, 16, False, False), (256, 400, 624, False, False), (1000, 400, 400, False, False),
+    (300, 1, 400, False, False), (129, 81, 17, False, False), (1, 5, 3, False, False),
+    (624, 400, 3000, True, False), (400, 1, 999, True, False), (513, 624, 400, False, True),
+    (200, 1560, 1560, False, False), (77, 130, 50, True, True), (64, 256, 40, False, True)])
+def test_gemm_plain(ops, M, N, K, ta, tb):
+    # A=I-style asymmetry is covered by random asymmetric operands: a row/col swap cannot pass
+    rng = np.random.default_rng(M + N + K)
+    A, B = _mk(rng, M, K), _mk(rng, K, N)
+    At = torch.as_tensor(np.ascontiguousarray(A.T if ta else A)).to(DEV)
+    Bt = torch.as_tensor(np.ascontiguousarray(B.T if tb else B)).to(DEV)
+    ws = ops.Workspace(DEV)
+    C = ops.gemm(At, Bt, ws, trans_a=ta, trans_b=tb).cpu().numpy()
+    want = A.astype(np.float64) @ B.astype(np.float64)
+    bound = 4e-7 * (np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64))
+    _check(C, want, bound)
+    # deterministic (split-K partials are reduced in a fixed order)
+    C2 = ops.gemm(At, Bt, ws, trans_a=ta, trans_b=tb).cpu().numpy()
+    assert np.array_equal(C, C2)
+
+
+@pytest.mark.parametrize("split", [1, 2, 7, 64])
+def test_gemm_split_k(ops, split):
+    rng = np.random.default_rng(split)
+    M, N, K = 100, 90, 2000
+    A, B = _mk(rng, K, M), _mk(rng, K, N)          # trans_a form: dW = X^T G
+    ws = ops.Workspace(DEV)
+    C = ops.gemm(torch.as_tensor(A).to(DEV), torch.as_tensor(B).to(DEV), ws, trans_a=True,
+                 split_k=split).cpu().numpy()
+    want = A.astype(np.float64).T @ B.astype(np.float64)
+    _check(C, want, 4e-7 * (np.abs(A).astype(np.float64).T @ np.abs(B).astype(np.float64)))
+
+
+def test_gemm_epilogues(ops):
+    rng = np.random.default_rng(3)
+    M, N, K = 300, 400, 200
+    A, B, bias = _mk(rng, M, K), _mk(rng, K, N) * 0.1, _mk(rng, N)
+    X0, Xl = _mk(rng, M, N), _mk(rng, M, N)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    ws = ops.Workspace(DEV)
+    acc = A.astype(np.float64) @ B.astype(np.float64)
+    tol = dict(rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(ops.gemm(t(A), t(B), ws, epilogue="bias", bias=t(bias)).cpu().numpy(),
+                               acc + bias, **tol)
+    np.testing.assert_allclose(ops.gemm(t(A), t(B), ws, epilogue="bias_relu", bias=t(bias)).cpu().numpy(),
+                               np.maximum(acc + bias, 0), **tol)
+    np.testing.assert_allclose(ops.gemm(t(A), t(B), ws, epilogue="relu_mask", aux0=t(X0)).cpu().numpy(),
+                               np.where(X0 > 0, acc, 0), **tol)
+    np.testing.assert_allclose(                                   # dcn_v2/net.py:225
+        ops.gemm(t(A), t(B), ws, epilogue="cross", bias=t(bias), aux0=t(X0), aux1=t(Xl)).cpu().numpy(),
+        Xl + X0 * (acc + bias), **tol)
+    np.testing.assert_allclose(ops.gemm(t(A), t(B), ws, epilogue="bias_sigmoid", bias=t(bias)).cpu().numpy(),
+                               1 / (1 + np.exp(-(acc + bias))), **tol)
+    np.testing.assert_allclose(ops.gemm(t(A), t(B), ws, epilogue="bias_tanh", bias=t(bias)).cpu().numpy(),
+                               np.tanh(acc + bias), **tol)
+    np.testing.assert_allclose(ops.gemm(t(A), t(B), ws, epilogue="add", aux1=t(Xl)).cpu().numpy(),
+                               acc + Xl, **tol)
+    # epilogue after a split-K reduction
+    np.testing.assert_allclose(
+        ops.gemm(t(A), t(B), ws, epilogue="bias_relu", bias=t(bias), split_k=4).cpu().numpy(),
+        np.maximum(acc + bias, 0), **tol)
+
+
+def test_gemm_strided_views_and_inplace_out(ops):
+    rng = np.random.default_rng(4)
+    big = torch.as_tensor(_mk(rng, 200, 96)).to(DEV)
+    A = big[:, 8:72]                                   # row stride 96, 16-B aligned start
+    A1 = big[:, 1:65]                                  # unaligned start -> scalar load path
+    B = torch.as_tensor(_mk(rng, 64, 48)).to(DEV)
+    ws = ops.Workspace(DEV)
+    outbuf = torch.zeros(200, 64, device=DEV)
+    for a in (A, A1):
+        C = ops.gemm(a, B, ws, out=outbuf[:, :48])
+        want = a.double().cpu().numpy() @ B.double().cpu().numpy()
+        np.testing.assert_allclose(C.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+    assert float(outbuf[:, 48:].abs().max()) == 0.0   # nothing written outside the N columns
+
+
+def test_gemm_fused_colsum(ops):
+    """dW = X^T G with db = colsum(G) from the same pass (bias gradient of a Linear)."""
+    rng = np.random.default_rng(6)
+    for Bsz, nin, nout in ((3000, 624, 400), (777, 40, 1), (5000, 130, 200), (100, 400, 400)):
+        X, G = _mk(rng, Bsz, nin), _mk(rng, Bsz, nout)
+        ws = ops.Workspace(DEV)
+        db = torch.empty(nout, device=DEV)
+        dW = ops.gemm(torch.as_tensor(X).to(DEV), torch.as_tensor(G).to(DEV), ws, trans_a=True, b_colsum=db)
+        np.testing.assert_allclose(dW.cpu().numpy(), X.astype(np.float64).T @ G.astype(np.float64),
+                                   rtol=2e-5, atol=2e-4)
+        np.testing.assert_allclose(db.cpu().numpy(), G.astype(np.float64).sum(0), rtol=1e-5,
+                                   atol=1e-6 * np.abs(G).sum(0).max())
+
+
+def test_colsum(ops):
+    rng = np.random.default_rng(5)
+    for M, N in ((1, 3), (513, 400), (70000, 400), (1000, 1)):
+        G = _mk(rng, M, N)
+        got = ops.colsum(torch.as_tensor(G).to(DEV), ops.Workspace(DEV)).cpu().numpy()
+        np.testing.assert_allclose(got, G.astype(np.float64).sum(0), rtol=1e-5,
+                                   atol=1e-6 * np.abs(G).sum(0).max())
+
+
+def test_gemm_argument_errors(ops):
+    ws = ops.Workspace(DEV)
+    a = torch.zeros(4, 5, device=DEV)
+    with pytest.raises(Exception, match="inner"):
+        ops.gemm(a, torch.zeros(6, 3, device=DEV), ws)
+    with pytest.raises(Exception, match="bias"):
+        ops.gemm(a, torch.zeros(5, 3, device=DEV), ws, epilogue="bias")
+    with pytest.raises(Exception, match="device tensor"):
+        ops.gemm(torch.zeros(4, 5), torch.zeros(5, 3), ws)

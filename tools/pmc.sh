@@ -1,28 +1,33 @@
 #!/bin/bash
-# usage: tools/pmc.sh <outdir-under-gpurun_out> <kernel-name-regex> -- <command...>
-# One rocprofv3 --pmc pass per counter group (never combined with tracing), results summarised per kernel.
+# usage: tools/pmc.sh <outdir-under-gpurun_out> <kernel-name-regex> <group-set: mem|compute> -- <command...>
+# One rocprofv3 --pmc pass per counter group (never combined with tracing; each pass under its own
+# timeout), results summarised per kernel into gpurun_out/<outdir>/summary.txt.
 set -u
-out=$1; shift; regex=$1; shift; shift
+out=$1; shift; regex=$1; shift; set_=$1; shift; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $root/gpurun_out/$out
 cd /tmp && export TMPDIR=/tmp
+if [ "$set_" = "mem" ]; then
 groups=(
- "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
- "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INSTS_VALU"
- "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCR_TCP_STALL_CYCLES_sum"
- "TCP_TCC_WRITE_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum"
+ "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU"
  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum"
- "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum"
- "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_TAG_STALL_sum"
- "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_BUSY_sum TCC_REQ_sum"
- "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum"
- "GRBM_GUI_ACTIVE GRBM_TA_BUSY GRBM_TC_BUSY GRBM_EA_BUSY"
+ "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum"
  "FETCH_SIZE"
  "WRITE_SIZE"
 )
+else
+groups=(
+ "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA"
+ "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+ "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"
+ "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"
+ "GRBM_GUI_ACTIVE"
+)
+fi
 i=0
 for g in "${groups[@]}"; do
-  rocprofv3 --pmc $g -d $root/gpurun_out/$out/p$i -o p --output-format csv -- "$@" > $root/gpurun_out/$out/p$i.log 2>&1
+  timeout 90 rocprofv3 --pmc $g -d $root/gpurun_out/$out/p$i -o p --output-format csv -- "$@" > $root/gpurun_out/$out/p$i.log 2>&1
+  echo "pass $i rc=$?"
   i=$((i+1))
 done
 python3 - "$root/gpurun_out/$out" "$regex" <<'PY'
@@ -33,7 +38,7 @@ for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
         if rx.search(k):
-            acc[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[k[:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(root + "/summary.txt", "w") as out:
     for k, d in acc.items():
         out.write("kernel %s\n" % k)
