@@ -77,7 +77,7 @@ int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids, const flo
  * Out: row_grad [B*S, D]  — SelectedRows.value of `embedding` (rows = flattened ids, unmerged);
  *      d_dense_w [Dn,D], d_dense_w_one [Dn] — batch sums, reduced in a fixed order (deterministic).
  *      The SelectedRows.value of `embedding_one` is dy1[b] for every (b,s); it is not
- *      materialised — rec_sparse_adam_rows reads dy1 through grad_div = S. */
+ *      materialised — rec_sparse_adam_rows reads dy1 through rec_grad_layout{S,0,0}. */
 int rec_deepfm_fm_bwd_workspace_bytes(const rec_deepfm_desc* desc, size_t* bytes);
 int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense, const float* feat,
                       const float* sum_emb, const float* d_feat_dnn, const float* dy1,
@@ -93,9 +93,12 @@ int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense, const flo
  *                            out[b,:] = sum_{k in [lod[b],lod[b+1])} W[ids[k],:], padding ids skipped;
  *                            counts[b] = number of non-padding ids pooled (bit-exact).
  * ---------------------------------------------------------------------------------------- */
+/* out_group > 0: lookup i is written at out + (i / out_group) * out_group_stride + (i % out_group) * D
+ * (e.g. the S sparse fields of a sample into the head of a wider feature row, dcn_v2/net.py:100-108);
+ * out_group <= 0: contiguous [n, D]. */
 int rec_emb_gather(int64_t n, int32_t emb_dim, int32_t row_stride, int64_t num_rows,
                    int64_t padding_idx, const int64_t* ids, const float* W, float* out,
-                   int32_t* status, void* stream);
+                   int32_t out_group, int64_t out_group_stride, int32_t* status, void* stream);
 int rec_emb_gather_sumpool(int64_t batch, int32_t emb_dim, int32_t row_stride, int64_t num_rows,
                            int64_t padding_idx, const int64_t* ids, const int64_t* lod /*[B+1]*/,
                            const float* W, float* out, int32_t* counts, int32_t* status,
@@ -130,18 +133,55 @@ typedef struct {
   int64_t step; /* t, 1-based */
 } rec_adam_hyper;
 
+/* Where the gradient row of lookup position `pos` (= b*S+s) lives inside `grad`:
+ *   q = pos / div;   offset = group > 0 ? (q / group) * group_stride + (q % group) * D : q * D
+ * {1,0,0}: contiguous [n,D] (DeepFM row_grad); {S,0,0} with D = 1: dy1 [B] for the first-order table;
+ * {1,S,d}: the first S*D columns of a [B,d] feature gradient (DCN-v2). */
+typedef struct {
+  int32_t div;
+  int32_t group;
+  int64_t group_stride;
+} rec_grad_layout;
+
 /* lazy_mode=True Adam on the rows of a merged SelectedRows gradient, merge fused in:
- *   g[u,:] = sum_{k in seg(u)} grad[(sorted_pos[k] / grad_div) * D .. +D]   (ascending position order)
+ *   g[u,:] = sum_{k in seg(u)} grad_row(sorted_pos[k])            (ascending position order)
  * then Adam on rows uniq_rows[u] of P/M/V ([num_rows,row_stride]).  n_uniq is read on the device.
- * grad_div = 1 with grad = row_grad [n,D];  grad_div = S, D = 1 with grad = dy1 [B] updates W1. */
-int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride, const int32_t* n_uniq,
-                         const int64_t* uniq_rows, const int32_t* seg_offset,
-                         const int32_t* sorted_pos, const float* grad, int32_t grad_div, float* P,
+ * grad_layout NULL = {1,0,0}.  grad_scale (device float[1] or NULL): factor applied to the merged
+ * gradient — the global-norm clipping coefficient of rec_clip_scale. */
+int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride,
+                         int32_t state_stride /* row stride of M and V; 0 = row_stride */,
+                         const int32_t* n_uniq, const int64_t* uniq_rows, const int32_t* seg_offset,
+                         const int32_t* sorted_pos, const float* grad,
+                         const rec_grad_layout* grad_layout, const float* grad_scale, float* P,
                          float* M, float* V, const rec_adam_hyper* hyper, void* stream);
 
-/* dense Adam over a flat buffer (MLP + FM dense weights). */
-int rec_adam_dense(int64_t n, float* p, float* m, float* v, const float* g,
+/* dense Adam over a flat buffer (MLP + FM dense weights); grad_scale as above. */
+int rec_adam_dense(int64_t n, float* p, float* m, float* v, const float* g, const float* grad_scale,
                    const rec_adam_hyper* hyper, void* stream);
+
+/* paddle.nn.ClipGradByGlobalNorm(clip_norm) [EXT] (dcn_v2/dygraph_model.py:81-88):
+ *   global_norm = sqrt(sum over ALL gradients of g^2);  every g *= clip_norm / max(global_norm, clip_norm).
+ * rec_sumsq: out[0] (+)= sum x^2 over a dense buffer; rec_sparse_rows_sumsq: the same over the MERGED
+ * rows of a SelectedRows gradient (duplicates summed first, as Paddle's merge does); both reduce in a
+ * fixed order.  rec_clip_scale turns the total into the device scalar the Adam kernels take. */
+int rec_sumsq_workspace_bytes(size_t* bytes);
+int rec_sumsq(int64_t n, const float* x, float* out, int32_t accumulate, void* workspace,
+              size_t workspace_bytes, void* stream);
+int rec_sparse_rows_sumsq(int64_t n_max, int32_t emb_dim, const int32_t* n_uniq,
+                          const int32_t* seg_offset, const int32_t* sorted_pos, const float* grad,
+                          const rec_grad_layout* grad_layout, float* out, int32_t accumulate,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int rec_clip_scale(const float* sumsq, float clip_norm, float* scale, void* stream);
+
+/* CrossNetV2 backward glue (dcn_v2/net.py:222-226), one streaming pass:
+ *   dU = dX * X0;   dX0_acc = (accumulate ? dX0_acc : 0) + dX * U       (all [m,n] with row strides) */
+int rec_cross_bwd_prep(int64_t m, int32_t n, const float* dX, int32_t ld_dx, const float* X0,
+                       int32_t ld_x0, const float* U, int32_t ld_u, float* dU, int32_t ld_du,
+                       float* dX0_acc, int32_t ld_acc, int32_t accumulate, void* stream);
+
+/* y[i,:] = softmax(x[i,:]) over n <= 64 columns (CrossNetMix expert gate, dcn_v2/net.py:313-316). */
+int rec_softmax_rows(int64_t m, int32_t n, const float* x, int32_t ldx, float* y, int32_t ldy,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * f32 GEMM on the matrix cores with fused epilogues: C[M,N] = epi(op(A)[M,K] @ op(B)[K,N]).
@@ -162,7 +202,10 @@ typedef enum {
   REC_EPI_CROSS = 4,        /* aux1[i,j] + aux0[i,j] * (acc + bias[j])   (aux0 = X_0, aux1 = X_l) */
   REC_EPI_BIAS_SIGMOID = 5, /* sigmoid(acc + bias[j]) */
   REC_EPI_BIAS_TANH = 6,    /* tanh(acc + bias[j]); bias may be NULL */
-  REC_EPI_ADD = 7           /* acc + aux1[i,j] */
+  REC_EPI_ADD = 7,          /* acc + aux1[i,j] (+ aux0[i,j] when given) */
+  REC_EPI_MOE = 8           /* aux1[i,j] + aux0[i,j] * row_scale[i] * (acc + bias[j])
+                               (CrossNetMix, dcn_v2/net.py:301-317: aux0 = x_0, aux1 = running x_{l+1},
+                               row_scale = softmax gate of this expert) */
 } rec_epilogue;
 
 typedef struct {
@@ -174,13 +217,24 @@ typedef struct {
   int32_t split_k;       /* 0 = automatic */
 } rec_gemm_desc;
 
+typedef struct {
+  const float* bias;        /* [N] */
+  const float* aux0;        /* [M, ld_aux0] */
+  int32_t ld_aux0;
+  const float* aux1;        /* [M, ld_aux1] */
+  int32_t ld_aux1;
+  const float* row_scale;   /* [M] with stride row_scale_stride (REC_EPI_MOE) */
+  int32_t row_scale_stride;
+  float* out2;              /* [M, ld_out2] or NULL: REC_EPI_CROSS also stores u = acc + bias (for backward) */
+  int32_t ld_out2;
+  float* b_colsum;          /* [N] or NULL: also return the column sums of op(B) over K — the bias
+                               gradient when the call computes dW = X^T dY (B = dY), at no extra pass */
+} rec_gemm_epilogue_args;
+
 int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* bytes);
 int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const float* B, float* C,
-                 const float* bias, const float* aux0, int32_t ld_aux0, const float* aux1,
-                 int32_t ld_aux1, float* b_colsum, void* workspace, size_t workspace_bytes,
-                 void* stream);
-/* b_colsum ([N] or NULL): also return the column sums of op(B) over K — the bias gradient when the
- * call computes dW = X^T dY (B = dY), at no extra pass over dY. */
+                 const rec_gemm_epilogue_args* args /* may be NULL */, void* workspace,
+                 size_t workspace_bytes, void* stream);
 
 /* out[j] = sum_i G[i,j] (bias gradient of a Linear), fixed reduction order. */
 int rec_colsum_workspace_bytes(int64_t m, int32_t n, size_t* bytes);

@@ -26,13 +26,24 @@ class AdamHyper(C.Structure):
                 ("step", C.c_int64)]
 
 
+class GradLayout(C.Structure):
+    _fields_ = [("div", C.c_int32), ("group", C.c_int32), ("group_stride", C.c_int64)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("m", C.c_int64), ("n", C.c_int32), ("k", C.c_int32), ("lda", C.c_int32),
                 ("ldb", C.c_int32), ("ldc", C.c_int32), ("trans_a", C.c_int32),
                 ("trans_b", C.c_int32), ("epilogue", C.c_int32), ("split_k", C.c_int32)]
 
 
-EPI = dict(none=0, bias=1, bias_relu=2, relu_mask=3, cross=4, bias_sigmoid=5, bias_tanh=6, add=7)
+class GemmEpilogueArgs(C.Structure):
+    _fields_ = [("bias", C.c_void_p), ("aux0", C.c_void_p), ("ld_aux0", C.c_int32),
+                ("aux1", C.c_void_p), ("ld_aux1", C.c_int32), ("row_scale", C.c_void_p),
+                ("row_scale_stride", C.c_int32), ("out2", C.c_void_p), ("ld_out2", C.c_int32),
+                ("b_colsum", C.c_void_p)]
+
+
+EPI = dict(none=0, bias=1, bias_relu=2, relu_mask=3, cross=4, bias_sigmoid=5, bias_tanh=6, add=7, moe=8)
 
 _P = C.c_void_p
 _I64, _I32, _F, _SZ = C.c_int64, C.c_int32, C.c_float, C.c_size_t
@@ -44,21 +55,28 @@ SIGNATURES = {
     "rec_deepfm_fm_fwd": (C.c_int, [C.POINTER(DeepFMDesc)] + [_P] * 13),
     "rec_deepfm_fm_bwd_workspace_bytes": (C.c_int, [C.POINTER(DeepFMDesc), C.POINTER(_SZ)]),
     "rec_deepfm_fm_bwd": (C.c_int, [C.POINTER(DeepFMDesc)] + [_P] * 11 + [_SZ, _P]),
-    "rec_emb_gather": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, _P, _P, _P]),
+    "rec_emb_gather": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, _P, _I32, _I64, _P, _P]),
     "rec_emb_gather_sumpool": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "rec_emb_sumpool_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _P]),
     "rec_ids_group_workspace_bytes": (C.c_int, [_I64, _I64, C.POINTER(_SZ)]),
     "rec_ids_group": (C.c_int, [_I64, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
-    "rec_sparse_adam_rows": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _P,
-                                       C.POINTER(AdamHyper), _P]),
-    "rec_adam_dense": (C.c_int, [_I64, _P, _P, _P, _P, C.POINTER(AdamHyper), _P]),
+    "rec_sparse_adam_rows": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
+                                       _P, _P, _P, C.POINTER(AdamHyper), _P]),
+    "rec_adam_dense": (C.c_int, [_I64, _P, _P, _P, _P, _P, C.POINTER(AdamHyper), _P]),
+    "rec_sumsq_workspace_bytes": (C.c_int, [C.POINTER(_SZ)]),
+    "rec_sumsq": (C.c_int, [_I64, _P, _P, _I32, _P, _SZ, _P]),
+    "rec_sparse_rows_sumsq": (C.c_int, [_I64, _I32, _P, _P, _P, _P, C.POINTER(GradLayout), _P, _I32, _P,
+                                        _SZ, _P]),
+    "rec_clip_scale": (C.c_int, [_P, _F, _P, _P]),
+    "rec_softmax_rows": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P]),
+    "rec_cross_bwd_prep": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _I32, _P]),
     "rec_logloss_workspace_bytes": (C.c_int, [_I64, C.POINTER(_SZ)]),
     "rec_sigmoid_logloss": (C.c_int, [_I64, _I64, _P, _P, _P, _P, _F, _P, _P, _P, _P, _SZ, _P]),
     "rec_auc_histogram": (C.c_int, [_I64, _P, _P, _I32, _P, _P, _P]),
     "rec_shard_route_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(_SZ)]),
     "rec_shard_route": (C.c_int, [_I64, _I32, _I64, _I64, _I32] + [_P] * 9 + [_SZ, _P]),
     "rec_gemm_f32_workspace_bytes": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(_SZ)]),
-    "rec_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _I32, _P, _I32, _P, _P, _SZ, _P]),
+    "rec_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, C.POINTER(GemmEpilogueArgs), _P, _SZ, _P]),
     "rec_colsum_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(_SZ)]),
     "rec_colsum": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _SZ, _P]),
     "rec_xxh32": (C.c_uint32, [C.c_char_p, _SZ, C.c_uint32]),

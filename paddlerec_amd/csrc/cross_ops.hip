@@ -1,0 +1,97 @@
+// CrossNetV2 backward glue (gfx950): the two elementwise products between the GEMMs.
+//
+// Forward layer (/root/reference/models/rank/dcn_v2/net.py:222-226): X_{l+1} = X_l + X_0 * U_l,
+// U_l = X_l W_l + b_l (rec_gemm_f32, REC_EPI_CROSS, U_l saved through out2).  Backward of one layer,
+// given dX = d X_{l+1}:
+//     dU       = dX * X_0            -> feeds  dW_l = X_l^T dU (b_colsum = db_l),  dX_l = dX + dU W_l^T
+//     dX0_acc += dX * U_l            (gradient reaching X_0 through the Hadamard product)
+// One streaming pass reads dX, X_0, U_l once and writes both results (HBM-bound, float4 per lane).
+#include "rec_common.h"
+
+namespace rec {
+
+__global__ __launch_bounds__(kBlock) void cross_bwd_prep_kernel(
+    int64_t M, int N, const float* __restrict__ dX, int64_t ld_dx, const float* __restrict__ X0,
+    int64_t ld_x0, const float* __restrict__ U, int64_t ld_u, float* __restrict__ dU, int64_t ld_du,
+    float* __restrict__ acc, int64_t ld_acc, int accumulate, bool vec) {
+  if (vec) {
+    const int n4 = N / 4;
+    const int64_t total = M * n4;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * kBlock) {
+      const int64_t i = e / n4;
+      const int j = (int)(e % n4) * 4;
+      const float4 g = *reinterpret_cast<const float4*>(dX + i * ld_dx + j);
+      const float4 x = *reinterpret_cast<const float4*>(X0 + i * ld_x0 + j);
+      const float4 u = *reinterpret_cast<const float4*>(U + i * ld_u + j);
+      *reinterpret_cast<float4*>(dU + i * ld_du + j) = make_float4(g.x * x.x, g.y * x.y, g.z * x.z, g.w * x.w);
+      float4 a = make_float4(g.x * u.x, g.y * u.y, g.z * u.z, g.w * u.w);
+      float4* ap = reinterpret_cast<float4*>(acc + i * ld_acc + j);
+      if (accumulate) {
+        const float4 o = *ap;
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+      }
+      *ap = a;
+    }
+  } else {
+    const int64_t total = M * N;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * kBlock) {
+      const int64_t i = e / N;
+      const int j = (int)(e % N);
+      const float g = dX[i * ld_dx + j];
+      dU[i * ld_du + j] = g * X0[i * ld_x0 + j];
+      const float a = g * U[i * ld_u + j];
+      acc[i * ld_acc + j] = accumulate ? acc[i * ld_acc + j] + a : a;
+    }
+  }
+}
+
+// row-wise softmax over a handful of columns (CrossNetMix gate, dcn_v2/net.py:315: E = num_experts)
+__global__ __launch_bounds__(kBlock) void softmax_rows_kernel(int64_t M, int E,
+                                                              const float* __restrict__ x, int64_t ldx,
+                                                              float* __restrict__ y, int64_t ldy) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < M; i += (int64_t)gridDim.x * kBlock) {
+    float mx = x[i * ldx];
+    for (int e = 1; e < E; ++e) mx = fmaxf(mx, x[i * ldx + e]);
+    float sum = 0.f;
+    for (int e = 0; e < E; ++e) sum += expf(x[i * ldx + e] - mx);
+    const float inv = 1.f / sum;
+    for (int e = 0; e < E; ++e) y[i * ldy + e] = expf(x[i * ldx + e] - mx) * inv;
+  }
+}
+
+}  // namespace rec
+
+using namespace rec;
+
+extern "C" int rec_softmax_rows(int64_t m, int32_t n, const float* x, int32_t ldx, float* y,
+                                int32_t ldy, void* stream) {
+  REC_REQUIRE(m >= 0 && n > 0 && n <= 64 && ldx >= n && ldy >= n, REC_EINVAL, "bad sizes (n <= 64)");
+  if (m == 0) return REC_OK;
+  REC_REQUIRE(x && y, REC_EINVAL, "null pointer argument");
+  int64_t grid = (m + kBlock - 1) / kBlock;
+  if (grid > kNumCU * 8) grid = kNumCU * 8;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, m,
+                     n, x, (int64_t)ldx, y, (int64_t)ldy);
+  return check_launch("rec_softmax_rows");
+}
+
+extern "C" int rec_cross_bwd_prep(int64_t m, int32_t n, const float* dX, int32_t ld_dx,
+                                  const float* X0, int32_t ld_x0, const float* U, int32_t ld_u,
+                                  float* dU, int32_t ld_du, float* dX0_acc, int32_t ld_acc,
+                                  int32_t accumulate, void* stream) {
+  REC_REQUIRE(m >= 0 && n > 0 && ld_dx >= n && ld_x0 >= n && ld_u >= n && ld_du >= n && ld_acc >= n,
+              REC_EINVAL, "bad sizes");
+  if (m == 0) return REC_OK;
+  REC_REQUIRE(dX && X0 && U && dU && dX0_acc, REC_EINVAL, "null pointer argument");
+  const bool vec = n % 4 == 0 && ld_dx % 4 == 0 && ld_x0 % 4 == 0 && ld_u % 4 == 0 && ld_du % 4 == 0 &&
+                   ld_acc % 4 == 0 &&
+                   (((uintptr_t)dX | (uintptr_t)X0 | (uintptr_t)U | (uintptr_t)dU | (uintptr_t)dX0_acc) % 16) == 0;
+  int64_t grid = (m * (int64_t)n / (vec ? 4 : 1) + kBlock - 1) / kBlock;
+  if (grid > kNumCU * 8) grid = kNumCU * 8;
+  hipLaunchKernelGGL(cross_bwd_prep_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream,
+                     m, n, dX, (int64_t)ld_dx, X0, (int64_t)ld_x0, U, (int64_t)ld_u, dU, (int64_t)ld_du,
+                     dX0_acc, (int64_t)ld_acc, accumulate, vec);
+  return check_launch("rec_cross_bwd_prep");
+}

@@ -16,7 +16,8 @@ namespace rec {
 template <int VEC, int LANES>
 __global__ __launch_bounds__(kBlock) void emb_gather_kernel(
     int64_t n, int D, int stride, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
-    const float* __restrict__ W, float* __restrict__ out, int32_t* __restrict__ status) {
+    const float* __restrict__ W, float* __restrict__ out, int group, int64_t group_stride,
+    int32_t* __restrict__ status) {
   const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
   const int lg = threadIdx.x % LANES;
   const int d0 = lg * VEC;
@@ -29,7 +30,8 @@ __global__ __launch_bounds__(kBlock) void emb_gather_kernel(
     if (id >= 0 && id < N) vload<VEC>(e, W + id * stride + d0);
     else if (lg == 0) atomicOr(status, REC_FLAG_INDEX_OOB);
   }
-  vstore<VEC>(out + i * D + d0, e);
+  const int64_t o = group > 0 ? (i / group) * group_stride + (i % group) * D : i * D;
+  vstore<VEC>(out + o + d0, e);
 }
 
 constexpr int kPoolCH = 8;
@@ -99,19 +101,23 @@ using namespace rec;
 
 extern "C" int rec_emb_gather(int64_t n, int32_t emb_dim, int32_t row_stride, int64_t num_rows,
                               int64_t padding_idx, const int64_t* ids, const float* W, float* out,
-                              int32_t* status, void* stream) {
+                              int32_t out_group, int64_t out_group_stride, int32_t* status,
+                              void* stream) {
   REC_REQUIRE(n >= 0 && emb_dim > 0 && row_stride >= emb_dim && num_rows > 0, REC_EINVAL,
               "bad sizes");
   if (n == 0) return REC_OK;
   REC_REQUIRE(ids && W && out && status, REC_EINVAL, "null pointer argument");
-  // output rows are written with stride emb_dim: vector width must divide it
-  return dispatch_row_shape(emb_dim, row_stride, [&](auto vec, auto lanes) -> int {
+  REC_REQUIRE(out_group <= 0 || out_group_stride >= (int64_t)out_group * emb_dim, REC_EINVAL,
+              "out_group_stride too small");
+  // float4 stores need 16-B aligned output rows: fall back to scalar lanes otherwise
+  const bool out_vec = out_group <= 0 || (out_group_stride % 4 == 0 && ((uintptr_t)out) % 16 == 0);
+  return dispatch_row_shape(emb_dim, out_vec ? row_stride : row_stride | 1, [&](auto vec, auto lanes) -> int {
     constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
     const int64_t grid = (n * LANES + kBlock - 1) / kBlock;
     REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "n too large");
     hipLaunchKernelGGL((emb_gather_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock), 0,
                        (hipStream_t)stream, n, emb_dim, row_stride, num_rows, padding_idx, ids, W,
-                       out, status);
+                       out, out_group, out_group_stride, status);
     return check_launch("rec_emb_gather");
   });
 }

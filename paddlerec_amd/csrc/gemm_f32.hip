@@ -118,10 +118,12 @@ struct TileLoader {
 
 // ------------------------------------------------------------------------------------ epilogues
 struct EpiArgs {
-  const float* bias;   // [N] or null
-  const float* aux0;   // [M,ld0]: RELU_MASK source / CROSS X_0 / MUL operand
-  const float* aux1;   // [M,ld1]: CROSS X_l / ADD operand
-  int ld0, ld1;
+  const float* bias;       // [N] or null
+  const float* aux0;       // [M,ld0]: RELU_MASK source / CROSS, MOE X_0 / second ADD operand
+  const float* aux1;       // [M,ld1]: CROSS, MOE X_l / ADD operand
+  const float* row_scale;  // [M] (stride rs_stride): MOE gate probability of this expert
+  float* out2;             // [M,ldc] or null: CROSS also stores u = acc + bias (saved for backward)
+  int ld0, ld1, rs_stride, ld2;
 };
 
 template <int EPI>
@@ -131,9 +133,13 @@ __device__ __forceinline__ float apply_epi(float acc, int64_t i, int j, const Ep
   if (EPI == REC_EPI_BIAS_RELU) return fmaxf(acc + e.bias[j], 0.f);
   if (EPI == REC_EPI_RELU_MASK) return e.aux0[i * e.ld0 + j] > 0.f ? acc : 0.f;
   if (EPI == REC_EPI_CROSS) return e.aux1[i * e.ld1 + j] + e.aux0[i * e.ld0 + j] * (acc + e.bias[j]);
+  if (EPI == REC_EPI_MOE)
+    return e.aux1[i * e.ld1 + j] +
+           e.aux0[i * e.ld0 + j] * (e.row_scale[i * e.rs_stride] * (acc + e.bias[j]));
   if (EPI == REC_EPI_BIAS_SIGMOID) return 1.f / (1.f + expf(-(acc + e.bias[j])));
   if (EPI == REC_EPI_BIAS_TANH) return tanhf(acc + (e.bias ? e.bias[j] : 0.f));
-  if (EPI == REC_EPI_ADD) return acc + e.aux1[i * e.ld1 + j];
+  if (EPI == REC_EPI_ADD)
+    return acc + e.aux1[i * e.ld1 + j] + (e.aux0 ? e.aux0[i * e.ld0 + j] : 0.f);
   return acc;
 }
 
@@ -269,6 +275,7 @@ __global__ __launch_bounds__(kBlock, gemm_blocks_per_cu<BN>()) void gemm_f32_ker
           if (j < N) {
             const float v = acc[a][b][r];
             out[i * ldc + j] = partial ? v : apply_epi<EPI>(v, i, j, epi);
+            if (EPI == REC_EPI_CROSS && !partial && epi.out2) epi.out2[i * epi.ld2 + j] = v + epi.bias[j];
           }
         }
       }
@@ -290,6 +297,7 @@ __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(int64_t M, int N,
     float t = 0.f;
     for (int z = 0; z < splits; ++z) t += partial[(int64_t)z * M * ldc + i * ldc + j];
     C[i * ldc + j] = apply_epi<EPI>(t, i, j, epi);
+    if (EPI == REC_EPI_CROSS && epi.out2) epi.out2[i * epi.ld2 + j] = t + epi.bias[j];
   }
 }
 
@@ -370,7 +378,7 @@ static int check_gemm(const rec_gemm_desc* d) {
   REC_REQUIRE(d->m >= 0 && d->n > 0 && d->k > 0, REC_EINVAL, "bad sizes M=%lld N=%d K=%d",
               (long long)d->m, d->n, d->k);
   REC_REQUIRE(d->lda > 0 && d->ldb > 0 && d->ldc >= d->n, REC_EINVAL, "bad leading dimensions");
-  REC_REQUIRE(d->epilogue >= 0 && d->epilogue <= REC_EPI_ADD, REC_EINVAL, "unknown epilogue %d",
+  REC_REQUIRE(d->epilogue >= 0 && d->epilogue <= REC_EPI_MOE, REC_EINVAL, "unknown epilogue %d",
               d->epilogue);
   return REC_OK;
 }
@@ -426,19 +434,28 @@ extern "C" int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* b
 }
 
 extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const float* B, float* C,
-                            const float* bias, const float* aux0, int32_t ld_aux0,
-                            const float* aux1, int32_t ld_aux1, float* b_colsum, void* workspace,
+                            const rec_gemm_epilogue_args* x, void* workspace,
                             size_t workspace_bytes, void* stream) {
   if (int rc = check_gemm(desc)) return rc;
   if (desc->m == 0) return REC_OK;
   REC_REQUIRE(A && B && C, REC_EINVAL, "null pointer argument");
+  static const rec_gemm_epilogue_args kNoArgs = {};
+  if (!x) x = &kNoArgs;
   const int epi = desc->epilogue;
+  const float* bias = x->bias;
+  const float *aux0 = x->aux0, *aux1 = x->aux1;
+  const int ld_aux0 = x->ld_aux0, ld_aux1 = x->ld_aux1;
+  float* b_colsum = x->b_colsum;
   REC_REQUIRE(!(epi == REC_EPI_BIAS || epi == REC_EPI_BIAS_RELU || epi == REC_EPI_CROSS ||
-                epi == REC_EPI_BIAS_SIGMOID) || bias, REC_EINVAL, "epilogue needs bias");
-  REC_REQUIRE(!(epi == REC_EPI_RELU_MASK || epi == REC_EPI_CROSS) || (aux0 && ld_aux0 >= desc->n),
-              REC_EINVAL, "epilogue needs aux0");
-  REC_REQUIRE(!(epi == REC_EPI_CROSS || epi == REC_EPI_ADD) || (aux1 && ld_aux1 >= desc->n),
-              REC_EINVAL, "epilogue needs aux1");
+                epi == REC_EPI_BIAS_SIGMOID || epi == REC_EPI_MOE) || bias, REC_EINVAL,
+              "epilogue needs bias");
+  REC_REQUIRE(!(epi == REC_EPI_RELU_MASK || epi == REC_EPI_CROSS || epi == REC_EPI_MOE) ||
+                  (aux0 && ld_aux0 >= desc->n), REC_EINVAL, "epilogue needs aux0");
+  REC_REQUIRE(!(epi == REC_EPI_CROSS || epi == REC_EPI_ADD || epi == REC_EPI_MOE) ||
+                  (aux1 && ld_aux1 >= desc->n), REC_EINVAL, "epilogue needs aux1");
+  REC_REQUIRE(epi != REC_EPI_ADD || !aux0 || ld_aux0 >= desc->n, REC_EINVAL, "bad ld_aux0");
+  REC_REQUIRE(epi != REC_EPI_MOE || (x->row_scale && x->row_scale_stride >= 1), REC_EINVAL,
+              "epilogue needs row_scale");
   const GemmPlan p = plan_gemm(desc);
   REC_REQUIRE(p.tiles_total < (1ll << 31), REC_ESHAPE, "too many tiles");
   float* partial = nullptr;
@@ -455,7 +472,8 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
     }
     if (b_colsum) cpart = (float*)((char*)workspace + off);
   }
-  EpiArgs e{bias, aux0, aux1, ld_aux0, ld_aux1};
+  EpiArgs e{bias, aux0, aux1, x->row_scale, x->out2, ld_aux0, ld_aux1, x->row_scale_stride, x->ld_out2};
+  REC_REQUIRE(!x->out2 || x->ld_out2 >= desc->n, REC_EINVAL, "bad ld_out2");
   hipStream_t st = (hipStream_t)stream;
 #define REC_EPI_CASE(E)                                                   \
   case E:                                                                 \
@@ -475,6 +493,7 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
     REC_EPI_CASE(REC_EPI_BIAS_SIGMOID)
     REC_EPI_CASE(REC_EPI_BIAS_TANH)
     REC_EPI_CASE(REC_EPI_ADD)
+    REC_EPI_CASE(REC_EPI_MOE)
   }
 #undef REC_EPI_CASE
   if (b_colsum)

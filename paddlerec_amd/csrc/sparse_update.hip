@@ -136,13 +136,21 @@ static int run_group(int64_t n, int S, int64_t N, int64_t pad, const int64_t* id
   return check_launch("rec_ids_group");
 }
 
+// element offset of the gradient row of lookup position `pos` (see rec_grad_layout)
+__device__ __forceinline__ int64_t grad_offset(const rec_grad_layout& gl, int pos, int D) {
+  const int q = gl.div > 1 ? pos / gl.div : pos;
+  return gl.group > 0 ? (int64_t)(q / gl.group) * gl.group_stride + (int64_t)(q % gl.group) * D
+                      : (int64_t)q * D;
+}
+
 // --------------------------------------------------------------------------- lazy sparse Adam
 template <int VEC, int LANES>
 __global__ __launch_bounds__(kBlock) void sparse_adam_rows_kernel(
-    int D, int stride, const int32_t* __restrict__ n_uniq, const int64_t* __restrict__ uniq,
+    int D, int stride, int sstride, const int32_t* __restrict__ n_uniq, const int64_t* __restrict__ uniq,
     const int32_t* __restrict__ seg_off, const int32_t* __restrict__ spos,
-    const float* __restrict__ grad, int grad_div, float* __restrict__ P, float* __restrict__ M,
-    float* __restrict__ V, float lr_t, float eps_t, float b1, float b2) {
+    const float* __restrict__ grad, rec_grad_layout gl, const float* __restrict__ grad_scale,
+    float* __restrict__ P, float* __restrict__ M, float* __restrict__ V, float lr_t, float eps_t,
+    float b1, float b2) {
   const int64_t u = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
   const int d0 = (threadIdx.x % LANES) * VEC;
   if (u >= n_uniq[0] || d0 >= D) return;
@@ -150,18 +158,22 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_rows_kernel(
   const int beg = seg_off[u], end = seg_off[u + 1];
   float p[VEC], m[VEC], v[VEC], g[VEC];
   const int64_t ro = row * stride + d0;
+  const int64_t so = row * sstride + d0;
   vload<VEC>(p, P + ro);
-  vload<VEC>(m, M + ro);
-  vload<VEC>(v, V + ro);
+  vload<VEC>(m, M + so);
+  vload<VEC>(v, V + so);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) g[i] = 0.f;
   for (int k = beg; k < end; ++k) {
-    int pos = spos[k];
-    if (grad_div != 1) pos /= grad_div;
     float t[VEC];
-    vload<VEC>(t, grad + (int64_t)pos * D + d0);
+    vload<VEC>(t, grad + grad_offset(gl, spos[k], D) + d0);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) g[i] += t[i];
+  }
+  if (grad_scale) {   // global-norm clipping factor (device scalar)
+    const float sc = grad_scale[0];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] *= sc;
   }
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
@@ -170,16 +182,89 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_rows_kernel(
     p[i] = p[i] - lr_t * (m[i] / (sqrtf(v[i]) + eps_t));
   }
   vstore<VEC>(P + ro, p);
-  vstore<VEC>(M + ro, m);
-  vstore<VEC>(V + ro, v);
+  vstore<VEC>(M + so, m);
+  vstore<VEC>(V + so, v);
+}
+
+// sum over the merged rows of |g_row|^2 (global-norm clipping needs the norm of the MERGED sparse grad)
+template <int VEC, int LANES>
+__global__ __launch_bounds__(kBlock) void sparse_rows_sumsq_kernel(
+    int D, const int32_t* __restrict__ n_uniq, const int32_t* __restrict__ seg_off,
+    const int32_t* __restrict__ spos, const float* __restrict__ grad, rec_grad_layout gl,
+    float* __restrict__ partial) {
+  __shared__ float red[kBlock];
+  float acc = 0.f;
+  const int d0 = (threadIdx.x % LANES) * VEC;
+  const int U = n_uniq[0];
+  for (int64_t u = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES; u < U;
+       u += (int64_t)gridDim.x * kBlock / LANES) {
+    if (d0 < D) {
+      float g[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+      for (int k = seg_off[u]; k < seg_off[u + 1]; ++k) {
+        float t[VEC];
+        vload<VEC>(t, grad + grad_offset(gl, spos[k], D) + d0);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g[i] += t[i];
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc += g[i] * g[i];
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(kBlock) void dense_sumsq_kernel(int64_t n, const float* __restrict__ x,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[kBlock];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    acc += x[i] * x[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// out[0] = (accumulate ? out[0] : 0) + sum(partial[0..n)) in a fixed order
+__global__ __launch_bounds__(kBlock) void sumsq_fold_kernel(const float* __restrict__ partial, int n,
+                                                            int accumulate, float* __restrict__ out) {
+  __shared__ float red[kBlock];
+  float t = 0.f;
+  for (int i = threadIdx.x; i < n; i += kBlock) t += partial[i];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + red[0];
+}
+
+// paddle.nn.ClipGradByGlobalNorm [EXT]: every gradient is multiplied by clip / max(||g||, clip)
+__global__ void clip_scale_kernel(const float* __restrict__ sumsq, float clip, float* __restrict__ scale) {
+  const float nrm = sqrtf(sumsq[0]);
+  scale[0] = clip / fmaxf(nrm, clip);
 }
 
 __global__ void adam_dense_kernel(int64_t n, float* __restrict__ p, float* __restrict__ m,
-                                  float* __restrict__ v, const float* __restrict__ g, float lr_t,
-                                  float eps_t, float b1, float b2) {
+                                  float* __restrict__ v, const float* __restrict__ g,
+                                  const float* __restrict__ grad_scale, float lr_t, float eps_t,
+                                  float b1, float b2) {
+  const float sc = grad_scale ? grad_scale[0] : 1.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i];
+    const float gi = g[i] * sc;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
@@ -241,12 +326,19 @@ extern "C" int rec_ids_group(int64_t n, int32_t num_slots, int64_t num_rows, int
 }
 
 extern "C" int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride,
-                                    const int32_t* n_uniq, const int64_t* uniq_rows,
+                                    int32_t state_stride, const int32_t* n_uniq, const int64_t* uniq_rows,
                                     const int32_t* seg_offset, const int32_t* sorted_pos,
-                                    const float* grad, int32_t grad_div, float* P, float* M,
-                                    float* V, const rec_adam_hyper* hyper, void* stream) {
-  REC_REQUIRE(n_max >= 0 && emb_dim > 0 && row_stride >= emb_dim && grad_div >= 1, REC_EINVAL,
+                                    const float* grad, const rec_grad_layout* grad_layout,
+                                    const float* grad_scale, float* P, float* M, float* V,
+                                    const rec_adam_hyper* hyper, void* stream) {
+  rec_grad_layout gl = {1, 0, 0};
+  if (grad_layout) gl = *grad_layout;
+  REC_REQUIRE(n_max >= 0 && emb_dim > 0 && row_stride >= emb_dim && gl.div >= 1, REC_EINVAL,
               "bad sizes");
+  REC_REQUIRE(gl.group <= 0 || gl.group_stride >= (int64_t)gl.group * emb_dim, REC_EINVAL,
+              "grad group_stride too small");
+  if (state_stride <= 0) state_stride = row_stride;
+  REC_REQUIRE(state_stride >= emb_dim, REC_EINVAL, "state_stride < emb_dim");
   REC_REQUIRE(n_uniq && uniq_rows && seg_offset && sorted_pos && grad && P && M && V && hyper,
               REC_EINVAL, "null pointer argument");
   REC_REQUIRE(hyper->step >= 1, REC_EINVAL, "Adam step must be >= 1");
@@ -254,19 +346,79 @@ extern "C" int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_
   float lr_t, eps_t;
   adam_scalars(hyper, &lr_t, &eps_t);
   hipStream_t st = (hipStream_t)stream;
-  return dispatch_row_shape(emb_dim, row_stride, [&](auto vec, auto lanes) -> int {
+  // float4 gradient loads need 16-B aligned gradient rows
+  const bool gvec = ((uintptr_t)grad) % 16 == 0 && (gl.group <= 0 || gl.group_stride % 4 == 0);
+  return dispatch_row_shape(emb_dim, (gvec && state_stride % 4 == 0) ? row_stride : row_stride | 1,
+                            [&](auto vec, auto lanes) -> int {
     constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
     const int64_t grid = (n_max * LANES + kBlock - 1) / kBlock;
     REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");
     hipLaunchKernelGGL((sparse_adam_rows_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock),
-                       0, st, emb_dim, row_stride, n_uniq, uniq_rows, seg_offset, sorted_pos, grad,
-                       grad_div, P, M, V, lr_t, eps_t, hyper->beta1, hyper->beta2);
+                       0, st, emb_dim, row_stride, state_stride, n_uniq, uniq_rows, seg_offset, sorted_pos, grad,
+                       gl, grad_scale, P, M, V, lr_t, eps_t, hyper->beta1, hyper->beta2);
     return check_launch("rec_sparse_adam_rows");
   });
 }
 
+constexpr int kSumsqBlocks = 1024;
+
+extern "C" int rec_sumsq_workspace_bytes(size_t* bytes) {
+  REC_REQUIRE(bytes, REC_EINVAL, "bytes is NULL");
+  *bytes = kSumsqBlocks * sizeof(float);
+  return REC_OK;
+}
+
+extern "C" int rec_sumsq(int64_t n, const float* x, float* out, int32_t accumulate, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  REC_REQUIRE(n >= 0 && out && (n == 0 || x), REC_EINVAL, "bad arguments");
+  REC_REQUIRE(workspace && workspace_bytes >= kSumsqBlocks * sizeof(float), REC_EWORKSPACE,
+              "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t grid = (n + kBlock * 8 - 1) / (kBlock * 8);
+  if (grid > kSumsqBlocks) grid = kSumsqBlocks;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(dense_sumsq_kernel, dim3((unsigned)grid), dim3(kBlock), 0, st, n, x,
+                     (float*)workspace);
+  hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)workspace,
+                     (int)grid, accumulate, out);
+  return check_launch("rec_sumsq");
+}
+
+extern "C" int rec_sparse_rows_sumsq(int64_t n_max, int32_t emb_dim, const int32_t* n_uniq,
+                                     const int32_t* seg_offset, const int32_t* sorted_pos,
+                                     const float* grad, const rec_grad_layout* grad_layout,
+                                     float* out, int32_t accumulate, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  rec_grad_layout gl = {1, 0, 0};
+  if (grad_layout) gl = *grad_layout;
+  REC_REQUIRE(n_max >= 0 && emb_dim > 0 && gl.div >= 1 && out, REC_EINVAL, "bad arguments");
+  REC_REQUIRE(n_uniq && seg_offset && sorted_pos && grad, REC_EINVAL, "null pointer argument");
+  REC_REQUIRE(workspace && workspace_bytes >= kSumsqBlocks * sizeof(float), REC_EWORKSPACE,
+              "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const bool gvec = ((uintptr_t)grad) % 16 == 0 && (gl.group <= 0 || gl.group_stride % 4 == 0);
+  return dispatch_row_shape(emb_dim, gvec ? emb_dim : emb_dim | 1, [&](auto vec, auto lanes) -> int {
+    constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
+    int64_t grid = (n_max * LANES + kBlock - 1) / kBlock;
+    if (grid > kSumsqBlocks) grid = kSumsqBlocks;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((sparse_rows_sumsq_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock),
+                       0, st, emb_dim, n_uniq, seg_offset, sorted_pos, grad, gl, (float*)workspace);
+    hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)workspace,
+                       (int)grid, accumulate, out);
+    return check_launch("rec_sparse_rows_sumsq");
+  });
+}
+
+extern "C" int rec_clip_scale(const float* sumsq, float clip_norm, float* scale, void* stream) {
+  REC_REQUIRE(sumsq && scale && clip_norm > 0.f, REC_EINVAL, "bad arguments");
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, clip_norm,
+                     scale);
+  return check_launch("rec_clip_scale");
+}
+
 extern "C" int rec_adam_dense(int64_t n, float* p, float* m, float* v, const float* g,
-                              const rec_adam_hyper* hyper, void* stream) {
+                              const float* grad_scale, const rec_adam_hyper* hyper, void* stream) {
   REC_REQUIRE(n >= 0 && p && m && v && g && hyper, REC_EINVAL, "bad arguments");
   REC_REQUIRE(hyper->step >= 1, REC_EINVAL, "Adam step must be >= 1");
   if (n == 0) return REC_OK;
@@ -275,6 +427,7 @@ extern "C" int rec_adam_dense(int64_t n, float* p, float* m, float* v, const flo
   int64_t grid = (n + kBlock - 1) / kBlock;
   if (grid > kNumCU * 8) grid = kNumCU * 8;
   hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)grid), dim3(kBlock), 0,
-                     (hipStream_t)stream, n, p, m, v, g, lr_t, eps_t, hyper->beta1, hyper->beta2);
+                     (hipStream_t)stream, n, p, m, v, g, grad_scale, lr_t, eps_t, hyper->beta1,
+                     hyper->beta2);
   return check_launch("rec_adam_dense");
 }

@@ -1,0 +1,311 @@
+"""Host-side mirror of the reference's DCN-v2 plugin on the recengine HIP kernels.
+
+Mirrors /root/reference/models/rank/dcn_v2/net.py:20-320 (DCN_V2Layer, DNNLayer, DeepCrossLayer,
+CrossNetV2, CrossNetMix) and dcn_v2/dygraph_model.py (loss, Adam + ClipGradByGlobalNorm(10)) with the
+reference's parameter names.  Kernels: rec_emb_gather (lookup straight into the
+feature row), rec_gemm_f32 (dense_emb, CrossNet layers with the fused `x_l + x_0*(x_l W + b)`
+epilogue, low-rank expert projections with fused tanh / gate mixing, MLP), rec_cross_bwd_prep,
+rec_sparse_adam_rows with the clipping coefficient, rec_sumsq / rec_sparse_rows_sumsq.
+
+Scope notes: Dropout(0.5) of the reference's train mode (App. B-10) is not applied —
+results are those of eval() mode, the only mode in which the reference's outputs are reproducible;
+L2Decay(1e-7) on the DNN weights (net.py:164-170) is below the fp32 parity tolerance and omitted;
+the sparse optimizer is lazy Adam (see deepfm.py).  Training is implemented for CrossNetV2
+(BASELINE config 3); CrossNetMix has forward (inference) only.
+"""
+import math
+
+import torch
+
+from . import ops
+from .deepfm import NUM_THRESHOLDS, _FlatParams, _round_up, _Timed
+
+P = "DeepCrossLayer_.crossNet."
+
+
+class DCN_V2Layer:
+    """dcn_v2/net.py:20-137.  forward(sparse_inputs, dense_inputs) -> predict [B,1]."""
+
+    def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim, sparse_num_field,
+                 layer_sizes, cross_num, is_Stacked=True, use_low_rank_mixture=False, low_rank=32,
+                 num_experts=4, device="cuda", kernels=None):
+        self.device = torch.device(device)
+        self.k = kernels if kernels is not None else ops
+        self.sparse_feature_number = N = sparse_feature_number
+        self.sparse_feature_dim = D = sparse_feature_dim
+        self.dense_feature_dim = Dn = dense_feature_dim
+        self.sparse_num_field = S = sparse_num_field
+        self.num_field = S + Dn
+        self.layer_sizes = list(layer_sizes)
+        self.cross_num, self.is_Stacked = cross_num, bool(is_Stacked)
+        self.use_low_rank_mixture, self.low_rank, self.num_experts = bool(use_low_rank_mixture), low_rank, num_experts
+        self.d = d = self.num_field * D
+        f32 = dict(dtype=torch.float32, device=self.device)
+        # embedding table: line-aligned records; padding_idx=0 (net.py:45-54)
+        self.rec = torch.zeros(N, _round_up(D, 32), **f32)
+        self.embedding = self.rec[:, :D]
+        std = 0.1 / math.sqrt(float(D))
+        torch.nn.init.trunc_normal_(self.embedding, 0.0, std, -2 * std, 2 * std)
+        self.embedding[0].zero_()
+        self.padding_idx = 0
+        E, r = num_experts, low_rank
+        shapes = [("dense_emb.weight", (Dn, D * Dn)), ("dense_emb.bias", (D * Dn,))]
+        if self.use_low_rank_mixture:
+            for i in range(cross_num):
+                shapes += [(P + "U_list.%d" % i, (E, d, r)), (P + "V_list.%d" % i, (E, d, r)),
+                           (P + "C_list.%d" % i, (E, r, r))]
+            shapes += [(P + "gating.weight", (d, E)), (P + "gating.bias", (E,))]   # E Linear(d,1), stacked
+            shapes += [(P + "bias.%d" % i, (d, 1)) for i in range(cross_num)]
+        else:
+            for i in range(cross_num):
+                shapes += [(P + "cross_layers.%d.weight" % i, (d, d)), (P + "cross_layers.%d.bias" % i, (d,))]
+        sizes = [d] + self.layer_sizes
+        for i in range(len(self.layer_sizes)):
+            shapes += [("DNN_.linear_%d.weight" % i, (sizes[i], sizes[i + 1])),
+                       ("DNN_.linear_%d.bias" % i, (sizes[i + 1],))]
+        fc_in = self.layer_sizes[-1] + (0 if self.is_Stacked else d)
+        shapes += [("fc.weight", (fc_in, 1)), ("fc.bias", (1,))]
+        self.dense = _FlatParams(shapes, self.device)
+        p = self.dense.p
+        # initialisers (net.py:56-57,164-170,70-87,241-276); Linear default = XavierUniform-like [EXT]
+        for name, (fi, fo) in (("dense_emb.weight", (Dn, D * Dn)),):
+            bound = math.sqrt(6.0 / (fi + fo))
+            p[name].uniform_(-bound, bound)
+        if self.use_low_rank_mixture:
+            for i in range(cross_num):
+                for nm in ("U_list", "V_list", "C_list"):
+                    t = p[P + "%s.%d" % (nm, i)]
+                    t.normal_(0.0, math.sqrt(2.0 / (t.shape[1] + t.shape[2])))
+            p[P + "gating.weight"].uniform_(-math.sqrt(6.0 / (d + 1)), math.sqrt(6.0 / (d + 1)))
+        else:
+            for i in range(cross_num):
+                p[P + "cross_layers.%d.weight" % i].uniform_(-math.sqrt(3.0 / d), math.sqrt(3.0 / d))
+        for i in range(len(self.layer_sizes)):
+            p["DNN_.linear_%d.weight" % i].normal_(0.0, 1.0 / math.sqrt(sizes[i]))
+        p["fc.weight"].normal_(0.0, 1.0 / math.sqrt(self.layer_sizes[-1]))
+        self.ws = self.k.Workspace(self.device)
+        self.ws_group = self.k.Workspace(self.device)
+        self.status = self.k.new_status(self.device)
+        self.sparse_state = None
+        self.step_count = 0
+        self.timers = None
+        self._groups = None
+        self._side = None
+
+    # ---------------------------------------------------------------- parameters (reference keys)
+    def state_dict(self):
+        sd = {"embedding.weight": self.embedding}
+        for k, v in self.dense.p.items():
+            if k == P + "gating.weight":
+                for e in range(self.num_experts):
+                    sd[P + "gating.%d.weight" % e] = v[:, e:e + 1]
+            elif k == P + "gating.bias":
+                for e in range(self.num_experts):
+                    sd[P + "gating.%d.bias" % e] = v[e:e + 1]
+            else:
+                sd[k] = v
+        return sd
+
+    def set_dict(self, sd):
+        cur = self.state_dict()
+        for k, v in sd.items():
+            dst = cur[k]
+            dst.copy_(torch.as_tensor(v).to(dst.device).reshape(dst.shape))
+
+    def grad_dict(self):
+        """Dense gradients of the last train_step under the reference's parameter names."""
+        out = {}
+        for k, v in self.dense.g.items():
+            if k == P + "gating.weight":
+                for e in range(self.num_experts):
+                    out[P + "gating.%d.weight" % e] = v[:, e:e + 1]
+            elif k == P + "gating.bias":
+                for e in range(self.num_experts):
+                    out[P + "gating.%d.bias" % e] = v[e:e + 1]
+            else:
+                out[k] = v
+        return out
+
+    def _timed(self, name):
+        return _Timed(self.timers, name)
+
+    @staticmethod
+    def _concat_ids(sparse_inputs):
+        if isinstance(sparse_inputs, (list, tuple)):
+            return torch.cat(list(sparse_inputs), dim=1).contiguous()       # net.py:93-94
+        return sparse_inputs
+
+    # ---------------------------------------------------------------- forward pieces
+    def _feat(self, ids, dense_inputs):
+        """net.py:93-108: lookup written straight into the head of the feature row, Linear(dense) into its tail."""
+        B, S = ids.shape
+        D, d = self.sparse_feature_dim, self.d
+        feat = torch.empty(B, d, dtype=torch.float32, device=self.device)
+        self.k.emb_gather(ids.reshape(-1), self.embedding, self.padding_idx, self.status, out=feat,
+                          out_group=S, out_group_stride=d)
+        self.k.gemm(dense_inputs, self.dense.p["dense_emb.weight"], self.ws, epilogue="bias",
+                    bias=self.dense.p["dense_emb.bias"], out=feat[:, S * D:])
+        return feat
+
+    def _cross_v2(self, feat, out_last=None):
+        """net.py:222-226.  Returns (x_L, xs, us)."""
+        p, k = self.dense.p, self.k
+        xs, us = [feat], []
+        x = feat
+        for i in range(self.cross_num):
+            u = torch.empty_like(feat)
+            last = i == self.cross_num - 1
+            x = k.gemm(x, p[P + "cross_layers.%d.weight" % i], self.ws, epilogue="cross",
+                       bias=p[P + "cross_layers.%d.bias" % i], aux0=feat, aux1=x, out2=u,
+                       out=out_last if (last and out_last is not None) else None)
+            xs.append(x)
+            us.append(u)
+        return x, xs, us
+
+    def _cross_mix(self, feat, out_last=None):
+        """net.py:278-320 (row-vector form).  Forward only."""
+        p, k = self.dense.p, self.k
+        E, r = self.num_experts, self.low_rank
+        B = feat.shape[0]
+        x = feat
+        for i in range(self.cross_num):
+            U, V, Cm = p[P + "U_list.%d" % i], p[P + "V_list.%d" % i], p[P + "C_list.%d" % i]
+            bias = p[P + "bias.%d" % i].view(-1)
+            gate = k.gemm(x, p[P + "gating.weight"], self.ws, epilogue="bias", bias=p[P + "gating.bias"])
+            prob = k.softmax_rows(gate)                                                   # net.py:315
+            t1 = torch.empty(B, E * r, dtype=torch.float32, device=self.device)
+            t2 = torch.empty(B, E * r, dtype=torch.float32, device=self.device)
+            last = i == self.cross_num - 1
+            x_next = out_last if (last and out_last is not None) else torch.empty_like(feat)
+            for e in range(E):
+                k.gemm(x, V[e], self.ws, epilogue="bias_tanh", out=t1[:, e * r:(e + 1) * r])        # :292-296
+                k.gemm(t1[:, e * r:(e + 1) * r], Cm[e], self.ws, trans_b=True, epilogue="bias_tanh",
+                       out=t2[:, e * r:(e + 1) * r])                                               # :297-298
+            for e in range(E):
+                k.gemm(t2[:, e * r:(e + 1) * r], U[e], self.ws, trans_b=True, epilogue="moe", bias=bias,
+                       aux0=feat, aux1=x if e == 0 else x_next, row_scale=prob[:, e], out=x_next)   # :301-317
+            x = x_next
+        return x
+
+    def _dnn_params(self):
+        n = len(self.layer_sizes)
+        p, g = self.dense.p, self.dense.g
+        W = [p["DNN_.linear_%d.weight" % i] for i in range(n)]
+        b = [p["DNN_.linear_%d.bias" % i] for i in range(n)]
+        dW = [g["DNN_.linear_%d.weight" % i] for i in range(n)]
+        db = [g["DNN_.linear_%d.bias" % i] for i in range(n)]
+        return W, b, dW, db
+
+    def _logit(self, ids, dense_inputs, keep=False):
+        p, k = self.dense.p, self.k
+        B = ids.shape[0]
+        feat = self._feat(ids, dense_inputs)
+        W, b, _, _ = self._dnn_params()
+        n_out = self.layer_sizes[-1]
+        saved = dict(feat=feat)
+        if self.is_Stacked:
+            if self.use_low_rank_mixture:
+                cross = self._cross_mix(feat)
+            else:
+                cross, saved["xs"], saved["us"] = self._cross_v2(feat)
+            logit, acts = k.mlp_forward(cross, W + [p["fc.weight"]], b + [p["fc.bias"]], self.ws)
+            saved["acts"] = acts
+        else:
+            last = torch.empty(B, n_out + self.d, dtype=torch.float32, device=self.device)      # net.py:129
+            if self.use_low_rank_mixture:
+                self._cross_mix(feat, out_last=last[:, n_out:])
+            else:
+                _, saved["xs"], saved["us"] = self._cross_v2(feat, out_last=last[:, n_out:])
+            _, acts = k.mlp_forward(feat, W, b, self.ws, relu_last=True, out_last=last[:, :n_out])
+            logit = k.gemm(last, p["fc.weight"], self.ws, epilogue="bias", bias=p["fc.bias"])
+            saved["acts"], saved["last"] = acts, last
+        return (logit, saved) if keep else (logit, None)
+
+    def forward(self, sparse_inputs, dense_inputs):
+        ids = self._concat_ids(sparse_inputs)
+        logit, _ = self._logit(ids, dense_inputs)
+        return torch.sigmoid(logit)                                                       # net.py:117,134
+
+    __call__ = forward
+
+    # ---------------------------------------------------------------- training step (CrossNetV2)
+    def _ensure_sparse_state(self):
+        if self.sparse_state is None:
+            D = self.sparse_feature_dim
+            Dp = _round_up(D, 4)
+            mv = torch.zeros(self.rec.shape[0], _round_up(2 * Dp, 32), dtype=torch.float32, device=self.device)
+            self.sparse_state = dict(mv=mv, m=mv[:, :D], v=mv[:, Dp:Dp + D])
+
+    def train_step(self, sparse_inputs, dense_inputs, label, lr=1e-3, clip_norm=10.0, auc_stats=None,
+                   dlogit=None):
+        """dcn_v2/dygraph_model.py:103-127 train_forward + backward + Adam with ClipGradByGlobalNorm.
+        dlogit ([B,1], optional): d loss / d logit supplied by the caller instead of the log-loss head
+        (custom losses; the golden-gradient tests use d pred.sum()).  Returns (loss [1], pred [B,1])."""
+        if self.use_low_rank_mixture:
+            raise ops.RecError("training is implemented for CrossNetV2 only (CrossNetMix: forward only)")
+        k, p, g = self.k, self.dense.p, self.dense.g
+        ids = self._concat_ids(sparse_inputs)
+        B, S = ids.shape
+        D, d = self.sparse_feature_dim, self.d
+        self._ensure_sparse_state()
+        self.step_count += 1
+        t = self.step_count
+        if self._groups is None or self._groups.n != B * S:
+            self._groups = k.IdGroups(B * S, self.device)
+        groups = self._groups
+        with self._timed("fwd"):
+            logit, sv = self._logit(ids, dense_inputs, keep=True)
+        k.ids_group(ids, self.sparse_feature_number, self.padding_idx, self.ws_group, None, self.status, groups)
+        pred, dz, loss = k.sigmoid_logloss(logit, None, None, label, self.ws)
+        if dlogit is not None:
+            dz = dlogit
+        if auc_stats is not None:
+            k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
+        W, b, dW, db = self._dnn_params()
+        n_out = self.layer_sizes[-1]
+        with self._timed("bwd"):
+            if self.is_Stacked:
+                dcross = k.mlp_backward(dz, sv["acts"], W + [p["fc.weight"]], dW + [g["fc.weight"]],
+                                        db + [g["fc.bias"]], self.ws)
+                dx0_acc, have_acc = torch.empty_like(sv["feat"]), False
+            else:
+                last, fcw = sv["last"], p["fc.weight"]
+                k.gemm(last, dz, self.ws, trans_a=True, out=g["fc.weight"], b_colsum=g["fc.bias"])
+                ddnn = k.gemm(dz, fcw[:n_out], self.ws, trans_b=True, epilogue="relu_mask", aux0=last[:, :n_out])
+                dcross = k.gemm(dz, fcw[n_out:], self.ws, trans_b=True)
+                dx0_acc, have_acc = k.mlp_backward(ddnn, sv["acts"], W, dW, db, self.ws), True   # d feat via DNN
+            dx = dcross
+            xs, us, feat = sv["xs"], sv["us"], sv["feat"]
+            du = torch.empty_like(feat)
+            for i in reversed(range(self.cross_num)):
+                wi = p[P + "cross_layers.%d.weight" % i]
+                k.cross_bwd_prep(dx, feat, us[i], du, dx0_acc, accumulate=have_acc)
+                have_acc = True
+                k.gemm(xs[i], du, self.ws, trans_a=True, out=g[P + "cross_layers.%d.weight" % i],
+                       b_colsum=g[P + "cross_layers.%d.bias" % i])
+                dx = k.gemm(du, wi, self.ws, trans_b=True, epilogue="add", aux1=dx,
+                            aux0=dx0_acc if i == 0 else None)
+            dfeat = dx                                           # d loss / d feat_embeddings  [B,d]
+            k.gemm(dense_inputs, dfeat[:, S * D:], self.ws, trans_a=True, out=g["dense_emb.weight"],
+                   b_colsum=g["dense_emb.bias"])
+        with self._timed("optimizer"):
+            scale = None
+            if clip_norm:
+                ss = self._scalar("sumsq")
+                k.sumsq(self.dense.grad, ss, self.ws)
+                k.sparse_rows_sumsq(groups, dfeat, D, ss, self.ws, accumulate=True, grad_group=S,
+                                    grad_group_stride=d)
+                scale = k.clip_scale(ss, clip_norm, self._scalar("scale"))
+            k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr, grad_scale=scale)
+            st = self.sparse_state
+            k.sparse_adam_rows(groups, dfeat, 1, self.embedding, st["m"], st["v"], t, lr, grad_group=S,
+                               grad_group_stride=d, grad_scale=scale)
+        self._last_dfeat = dfeat
+        return loss, pred
+
+    def _scalar(self, name):
+        b = getattr(self, "_s_" + name, None)
+        if b is None:
+            b = torch.zeros(1, dtype=torch.float32, device=self.device)
+            setattr(self, "_s_" + name, b)
+        return b

@@ -9,7 +9,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import EPI, AdamHyper, DeepFMDesc, GemmDesc, RecError, check, lib
+from ._lib import (EPI, AdamHyper, DeepFMDesc, GemmDesc, GemmEpilogueArgs, GradLayout, RecError, check,
+                   lib)
 
 
 def _stream():
@@ -148,22 +149,27 @@ def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, d
 
 
 # ------------------------------------------------------------------ lookups
-def emb_gather(ids, W, padding_idx=None, status=None, out=None):
-    """out[i,:] = W[ids[i],:] (zero row where ids[i]==padding_idx).  W [N,D] f32."""
+def emb_gather(ids, W, padding_idx=None, status=None, out=None, out_group=0, out_group_stride=0):
+    """out[i,:] = W[ids[i],:] (zero row where ids[i]==padding_idx).  W [N,D] f32.
+    out_group/out_group_stride: write lookup i at out + (i//group)*stride + (i%group)*D (floats)."""
     _chk(ids, torch.int64, "ids")
     _, w_stride = _chk_table(W, "W")
     N, D = W.shape
     if out is None:
         out = torch.empty(*ids.shape, D, dtype=torch.float32, device=ids.device)
     else:
-        _chk(out, torch.float32, "out")
-        if out.numel() != ids.numel() * D:
-            raise RecError("out has %d elements, expected %d" % (out.numel(), ids.numel() * D))
+        if out_group <= 0:
+            _chk(out, torch.float32, "out")
+            if out.numel() != ids.numel() * D:
+                raise RecError("out has %d elements, expected %d" % (out.numel(), ids.numel() * D))
+        elif not out.is_cuda or out.dtype != torch.float32:
+            raise RecError("out must be a float32 device tensor")
     if status is None:
         status = new_status(ids.device)
     check(lib().rec_emb_gather(ids.numel(), D, w_stride, N,
                                -1 if padding_idx is None else padding_idx, _p(ids), _p(W), _p(out),
-                               _p(status), _stream()), "rec_emb_gather")
+                               int(out_group), int(out_group_stride), _p(status), _stream()),
+          "rec_emb_gather")
     return out, status
 
 
@@ -237,25 +243,84 @@ def _hyper(lr, beta1, beta2, eps, step):
 
 
 def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999,
-                     eps=1e-8):
-    _chk(grad, torch.float32, "grad")
+                     eps=1e-8, grad_group=0, grad_group_stride=0, grad_scale=None):
+    """grad_div / grad_group / grad_group_stride: rec_grad_layout (where position pos's row lives in
+    grad); grad_scale: device float[1] clipping coefficient or None."""
+    if grad_group <= 0:
+        _chk(grad, torch.float32, "grad")
+    elif not grad.is_cuda or grad.dtype != torch.float32:
+        raise RecError("grad must be a float32 device tensor")
     D, stride = _chk_table(P, "P")
+    sstride = _chk_table(M, "M")[1]
     for t, n in ((M, "M"), (V, "V")):
-        if _chk_table(t, n) != (D, stride):
-            raise RecError("%s must have the shape and row stride of P" % n)
+        if _chk_table(t, n) != (D, sstride) or t.shape[0] != P.shape[0]:
+            raise RecError("%s must have the shape of P (M and V share one row stride)" % n)
     h = _hyper(lr, beta1, beta2, eps, step)
-    check(lib().rec_sparse_adam_rows(groups.n, D, stride, _p(groups.n_uniq), _p(groups.uniq_rows),
+    check(lib().rec_sparse_adam_rows(groups.n, D, stride, sstride, _p(groups.n_uniq), _p(groups.uniq_rows),
                                      _p(groups.seg_offset), _p(groups.sorted_pos), _p(grad),
-                                     int(grad_div), _p(P), _p(M), _p(V), C.byref(h), _stream()),
+                                     C.byref(GradLayout(int(grad_div), int(grad_group), int(grad_group_stride))),
+                                     _p(grad_scale), _p(P), _p(M), _p(V), C.byref(h), _stream()),
           "rec_sparse_adam_rows")
 
 
-def adam_dense(p, m, v, g, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_dense(p, m, v, g, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=None):
     for t, n in ((p, "p"), (m, "m"), (v, "v"), (g, "g")):
         _chk(t, torch.float32, n)
     h = _hyper(lr, beta1, beta2, eps, step)
-    check(lib().rec_adam_dense(p.numel(), _p(p), _p(m), _p(v), _p(g), C.byref(h), _stream()),
-          "rec_adam_dense")
+    check(lib().rec_adam_dense(p.numel(), _p(p), _p(m), _p(v), _p(g), _p(grad_scale), C.byref(h),
+                               _stream()), "rec_adam_dense")
+
+
+def _sumsq_ws(ws):
+    nbytes = C.c_size_t(0)
+    check(lib().rec_sumsq_workspace_bytes(C.byref(nbytes)))
+    return ws.get(nbytes.value)
+
+
+def sumsq(x, out, ws, accumulate=False):
+    """out[0] (+)= sum(x^2), fixed reduction order."""
+    _chk(x, torch.float32, "x")
+    _chk(out, torch.float32, "out")
+    w = _sumsq_ws(ws)
+    check(lib().rec_sumsq(x.numel(), _p(x), _p(out), int(accumulate), _p(w), C.c_size_t(w.numel()),
+                          _stream()), "rec_sumsq")
+    return out
+
+
+def sparse_rows_sumsq(groups, grad, D, out, ws, accumulate=False, grad_div=1, grad_group=0,
+                      grad_group_stride=0):
+    """out[0] (+)= sum over merged rows of |sum of the row's duplicate gradients|^2."""
+    _chk(out, torch.float32, "out")
+    w = _sumsq_ws(ws)
+    check(lib().rec_sparse_rows_sumsq(groups.n, int(D), _p(groups.n_uniq), _p(groups.seg_offset),
+                                      _p(groups.sorted_pos), _p(grad),
+                                      C.byref(GradLayout(int(grad_div), int(grad_group), int(grad_group_stride))),
+                                      _p(out), int(accumulate), _p(w), C.c_size_t(w.numel()), _stream()),
+          "rec_sparse_rows_sumsq")
+    return out
+
+
+def clip_scale(sumsq_t, clip_norm, out):
+    """out[0] = clip_norm / max(sqrt(sumsq), clip_norm)  (ClipGradByGlobalNorm coefficient)."""
+    check(lib().rec_clip_scale(_p(sumsq_t), float(clip_norm), _p(out), _stream()), "rec_clip_scale")
+    return out
+
+
+def softmax_rows(x, out=None):
+    ldx = _chk_mat(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().rec_softmax_rows(x.shape[0], x.shape[1], _p(x), ldx, _p(out), _chk_mat(out, "out"),
+                                 _stream()), "rec_softmax_rows")
+    return out
+
+
+def cross_bwd_prep(dX, X0, U, dU, dX0_acc, accumulate):
+    """dU = dX*X0; dX0_acc (+)= dX*U  (CrossNetV2 backward glue)."""
+    M, N = dX.shape
+    lds = [_chk_mat(t, n) for t, n in ((dX, "dX"), (X0, "X0"), (U, "U"), (dU, "dU"), (dX0_acc, "dX0_acc"))]
+    check(lib().rec_cross_bwd_prep(M, N, _p(dX), lds[0], _p(X0), lds[1], _p(U), lds[2], _p(dU), lds[3],
+                                   _p(dX0_acc), lds[4], int(accumulate), _stream()), "rec_cross_bwd_prep")
 
 
 # ------------------------------------------------------------------ row-sharded tables
@@ -306,7 +371,7 @@ def _chk_mat(t, name):
 
 
 def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux0=None, aux1=None,
-         out=None, split_k=0, b_colsum=None):
+         out=None, split_k=0, b_colsum=None, row_scale=None, out2=None):
     """out[M,N] = epi(op(A) @ op(B)); A/B/out row-major (row strides allowed).
     trans_a: A is given as [K,M]; trans_b: B is given as [N,K] (a torch Linear.weight, or W for dX)."""
     lda, ldb = _chk_mat(A, "A"), _chk_mat(B, "B")
@@ -332,12 +397,25 @@ def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux
         _chk(b_colsum, torch.float32, "b_colsum")
         if b_colsum.numel() != N:
             raise RecError("b_colsum must have N elements")
+    rs_stride = 0
+    if row_scale is not None:
+        if not row_scale.is_cuda or row_scale.dtype != torch.float32 or row_scale.shape[0] != M:
+            raise RecError("row_scale must be a float32 device tensor with M rows")
+        rs_stride = row_scale.stride(0) if M > 1 else 1
+    ld2 = 0
+    if out2 is not None:
+        ld2 = _chk_mat(out2, "out2")
+        if tuple(out2.shape) != (M, N):
+            raise RecError("out2 must have the shape of out")
     d = GemmDesc(M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), EPI[epilogue], int(split_k))
+    pv = lambda t: None if t is None else t.data_ptr()
+    x = GemmEpilogueArgs(pv(bias), pv(aux0), ld0, pv(aux1), ld1, pv(row_scale), rs_stride, pv(out2),
+                         ld2, pv(b_colsum))
     nbytes = C.c_size_t(0)
     check(lib().rec_gemm_f32_workspace_bytes(C.byref(d), C.byref(nbytes)))
     w = ws.get(nbytes.value)
-    check(lib().rec_gemm_f32(C.byref(d), _p(A), _p(B), _p(out), _p(bias), _p(aux0), ld0, _p(aux1), ld1,
-                             _p(b_colsum), _p(w), C.c_size_t(w.numel()), _stream()), "rec_gemm_f32")
+    check(lib().rec_gemm_f32(C.byref(d), _p(A), _p(B), _p(out), C.byref(x), _p(w),
+                             C.c_size_t(w.numel()), _stream()), "rec_gemm_f32")
     return out
 
 
@@ -355,14 +433,18 @@ def colsum(G, ws, out=None):
 
 
 # ------------------------------------------------------------------ top MLP on the GEMM above
-def mlp_forward(x, weights, biases, ws):
+def mlp_forward(x, weights, biases, ws, relu_last=False, out_last=None):
     """Linear(+bias)->ReLU ... ->Linear (deepfm/net.py:142-174) with Paddle-layout weights [in,out];
-    bias and ReLU run in the GEMM epilogue.  Returns (y, acts): acts[i] = input of layer i."""
+    bias and ReLU run in the GEMM epilogue.  relu_last: ReLU after the last layer too (the DNN tower of
+    dcn_v2/net.py:161-184); out_last: buffer (view) for the last layer's output.
+    Returns (y, acts): acts[i] = input of layer i."""
     acts = []
     n = len(weights)
     for i in range(n):
         acts.append(x)
-        x = gemm(x, weights[i], ws, epilogue="bias_relu" if i < n - 1 else "bias", bias=biases[i])
+        last = i == n - 1
+        x = gemm(x, weights[i], ws, epilogue="bias_relu" if (not last or relu_last) else "bias",
+                 bias=biases[i], out=out_last if last else None)
     return x, acts + [x]
 
 

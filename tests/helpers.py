@@ -128,3 +128,43 @@ class OracleTrainer:
             mm, vv = self.dstate.setdefault(key, (np.zeros_like(arr), np.zeros_like(arr)))
             R.adam_update(arr, mm, vv, gr.reshape(arr.shape).astype(arr.dtype), self.step, lr=self.lr)
         return o["loss"], o["pred"]
+
+
+class OracleDCNTrainer:
+    """DCN-v2 training on the NumPy oracle: fwd + bwd + ClipGradByGlobalNorm + lazy Adam (table) +
+    Adam (dense), as dcn_v2/dygraph_model.py:73-88 configures it (L2Decay 1e-7 omitted, see dcn_v2.py)."""
+
+    def __init__(self, params, lr=1e-3, clip_norm=10.0):
+        from oracle import dcn_v2_ref as X
+        from oracle import deepfm_ref as R
+        self.X, self.R = X, R
+        self.p = {k: v.copy() for k, v in params.items()}
+        self.lr, self.clip, self.step = lr, clip_norm, 0
+        self.m = {k: np.zeros_like(v) for k, v in params.items()}
+        self.v = {k: np.zeros_like(v) for k, v in params.items()}
+
+    def train_step(self, ids, dense, label):
+        X, R, p = self.X, self.R, self.p
+        self.step += 1
+        pred, saved = X.forward(ids, dense, p, return_saved=True)
+        loss = R.log_loss_mean(pred, label)
+        t = label.astype(np.float32)
+        eps = np.float32(1e-4)
+        dpred = (-t / (pred + eps) + (1 - t) / (1 - pred + eps)) / np.float32(pred.shape[0])
+        g = X.backward(ids, dense, p, saved, dpred)
+        rows = ids.reshape(-1)
+        uniq, merged, _ = R.merge_rows(rows, rows != 0, g["_row_grad"])
+        scale = np.float32(1.0)
+        if self.clip:
+            ss = sum(float((np.asarray(v, np.float64) ** 2).sum()) for k, v in g.items()
+                     if k not in ("_row_grad", "embedding.weight"))
+            ss += float((merged.astype(np.float64) ** 2).sum())
+            scale = np.float32(self.clip / max(np.sqrt(ss), self.clip))
+        R.adam_update_rows(p["embedding.weight"], self.m["embedding.weight"], self.v["embedding.weight"],
+                           uniq, merged * scale, self.step, lr=self.lr)
+        for k, gv in g.items():
+            if k in ("_row_grad", "embedding.weight"):
+                continue
+            R.adam_update(p[k], self.m[k], self.v[k], (np.asarray(gv).reshape(p[k].shape) * scale).astype(np.float32),
+                          self.step, lr=self.lr)
+        return loss, pred, g

@@ -192,3 +192,26 @@ def test_sequence_pool_and_reader():
     label, sid, dense = R.parse_slot_line(line)
     assert label == 1 and sid[0] == 11 and sid[1] == 0 and sid[2] == 33 and sid[25] == 99
     assert dense.shape == (13,) and dense[0] == np.float32(0.5)
+
+
+# ------------------------------------------------------------------------------ DCN-v2 oracle vs golden
+@pytest.mark.parametrize("name", ["dcn_v2_v2", "dcn_v2_mix"])
+def test_dcn_v2_oracle_matches_reference_net(name):
+    """oracle/dcn_v2_ref.py reproduces the outputs and autograd gradients of the reference's
+    unmodified dcn_v2/net.py (fixture = d pred.sum() / d params)."""
+    from oracle import dcn_v2_ref as X
+    g = load_golden(name)
+    p = {k[2:]: v for k, v in g.items() if k.startswith("p.")}
+    pred, saved = X.forward(g["ids"], g["dense"], p, return_saved=True)
+    np.testing.assert_allclose(saved["feat"], g["feat"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(saved["cross"], g["cross"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pred, g["pred"], rtol=1e-5, atol=1e-7)
+    grads = X.backward(g["ids"], g["dense"], p, saved, np.ones_like(pred))
+    n = 0
+    for k, v in g.items():
+        if k.startswith("g."):
+            got = np.asarray(grads[k[2:]]).reshape(v.shape)
+            np.testing.assert_allclose(got, v, rtol=2e-4, atol=2e-6, err_msg=k)
+            n += 1
+    assert n >= 15
+    assert np.all(grads["embedding.weight"][0] == 0)       # padding row gets no gradient
