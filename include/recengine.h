@@ -179,6 +179,34 @@ int rec_cross_bwd_prep(int64_t m, int32_t n, const float* dX, int32_t ld_dx, con
                        int32_t ld_x0, const float* U, int32_t ld_u, float* dU, int32_t ld_du,
                        float* dX0_acc, int32_t ld_acc, int32_t accumulate, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * DIN attention-pool, fused: 4 lookups -> [h, q, h-q, h*q] -> Linear/Sigmoid x2 -> Linear -> + mask ->
+ * * E^-0.5 -> softmax over T -> weights @ h.   Replaces din/net.py:141-173; the [B,T,4E] concat and the
+ * hidden activations never reach HBM (one block per sample, 32-position tiles, online softmax).
+ *   hist_item/hist_cat/tgt_item_seq/tgt_cat_seq [B,T] i64 (no padding_idx: id 0 is a real row, App. B-11)
+ *   mask [B,T] i64: 0 valid, -1e9 padding (din/dinReader.py:81-84,99)
+ *   tables f32 [rows, stride]; hist and target tables are independent parameters (App. C)
+ *   att_w1 [4E,H1] (Paddle [in,out]), att_b1 [H1], att_w2 [H1,H2], att_b2 [H2], att_w3 [H2], att_b3 [1]
+ *   out [B,E];  att_weight [B,T] or NULL: the softmax weights (saved for the backward)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t batch;      /* B */
+  int32_t max_len;    /* T (padded history length of this batch) */
+  int32_t item_dim, cat_dim;   /* E = item_dim + cat_dim <= 256, both multiples of 4 */
+  int32_t hidden1, hidden2;    /* 80, 40 */
+  int64_t item_rows, cat_rows;
+  int32_t item_stride, cat_stride;
+} rec_din_desc;
+
+int rec_din_attention_pool_fwd(const rec_din_desc* desc, const int64_t* hist_item,
+                               const int64_t* hist_cat, const int64_t* tgt_item_seq,
+                               const int64_t* tgt_cat_seq, const int64_t* mask,
+                               const float* w_hist_item, const float* w_hist_cat,
+                               const float* w_tgt_item_seq, const float* w_tgt_cat_seq,
+                               const float* att_w1, const float* att_b1, const float* att_w2,
+                               const float* att_b2, const float* att_w3, const float* att_b3,
+                               float* out, float* att_weight, int32_t* status, void* stream);
+
 /* y[i,:] = softmax(x[i,:]) over n <= 64 columns (CrossNetMix expert gate, dcn_v2/net.py:313-316). */
 int rec_softmax_rows(int64_t m, int32_t n, const float* x, int32_t ldx, float* y, int32_t ldy,
                      void* stream);
@@ -202,7 +230,7 @@ typedef enum {
   REC_EPI_CROSS = 4,        /* aux1[i,j] + aux0[i,j] * (acc + bias[j])   (aux0 = X_0, aux1 = X_l) */
   REC_EPI_BIAS_SIGMOID = 5, /* sigmoid(acc + bias[j]) */
   REC_EPI_BIAS_TANH = 6,    /* tanh(acc + bias[j]); bias may be NULL */
-  REC_EPI_ADD = 7,          /* acc + aux1[i,j] (+ aux0[i,j] when given) */
+  REC_EPI_ADD = 7,          /* acc + aux1[i,j] (+ bias[j], + aux0[i,j] when given) */
   REC_EPI_MOE = 8           /* aux1[i,j] + aux0[i,j] * row_scale[i] * (acc + bias[j])
                                (CrossNetMix, dcn_v2/net.py:301-317: aux0 = x_0, aux1 = running x_{l+1},
                                row_scale = softmax gate of this expert) */

@@ -30,6 +30,13 @@ class GradLayout(C.Structure):
     _fields_ = [("div", C.c_int32), ("group", C.c_int32), ("group_stride", C.c_int64)]
 
 
+class DinDesc(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("max_len", C.c_int32), ("item_dim", C.c_int32),
+                ("cat_dim", C.c_int32), ("hidden1", C.c_int32), ("hidden2", C.c_int32),
+                ("item_rows", C.c_int64), ("cat_rows", C.c_int64), ("item_stride", C.c_int32),
+                ("cat_stride", C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("m", C.c_int64), ("n", C.c_int32), ("k", C.c_int32), ("lda", C.c_int32),
                 ("ldb", C.c_int32), ("ldc", C.c_int32), ("trans_a", C.c_int32),
@@ -68,6 +75,7 @@ SIGNATURES = {
     "rec_sparse_rows_sumsq": (C.c_int, [_I64, _I32, _P, _P, _P, _P, C.POINTER(GradLayout), _P, _I32, _P,
                                         _SZ, _P]),
     "rec_clip_scale": (C.c_int, [_P, _F, _P, _P]),
+    "rec_din_attention_pool_fwd": (C.c_int, [C.POINTER(DinDesc)] + [_P] * 19),
     "rec_softmax_rows": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P]),
     "rec_cross_bwd_prep": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _I32, _P]),
     "rec_logloss_workspace_bytes": (C.c_int, [_I64, C.POINTER(_SZ)]),

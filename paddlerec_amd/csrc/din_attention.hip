@@ -1,0 +1,221 @@
+// DIN attention-pool, fused (gfx950): gather -> attention MLP -> masked softmax over T -> weighted sum.
+//
+// Replaces /root/reference/models/rank/din/net.py:141-173
+//   4 Embedding lookups -> concat [h, q, h-q, h*q] ([B,T,4E] in HBM) -> Linear/Sigmoid x2 -> Linear ->
+//   + mask -> transpose -> scale(E^-0.5) -> softmax -> matmul(weight, h)
+// with ONE kernel that never materialises the [B,T,4E] concat or the [B,T,80]/[B,T,40] activations:
+// a block owns a sample and walks its history in tiles of 32 positions, flash-attention style
+// (running max / running sum / running weighted sum of h, rescaled per tile), so the softmax over a
+// variable-length history needs no second pass over HBM.  Per tile:
+//   gather  h = [item_emb(hist_item), cat_emb(hist_cat)], q = [.. target seq ..] into LDS (float4, coalesced per row)
+//   layer 1 thread (j, pg) owns hidden unit j for positions pg, pg+PG, ..:   acc += h*w_a + q*w_b + (h-q)*w_c + (h*q)*w_d
+//           (the four E-row blocks of W1 are walked together, so the concat exists only as 4 FMAs)
+//   layer 2 / layer 3 from LDS, sigmoid in registers
+//   logits  s = (s + mask) * E^-0.5  kept in LDS for the whole history (softmax weights for the backward)
+// Padded positions (mask = -1e9) get weight exp(-8.8e7 - m) = 0 exactly in fp32, as in the reference
+// (SURVEY App. B-11); they are computed, not skipped, so an all-padding history still reproduces it.
+#include "rec_common.h"
+
+namespace rec {
+
+constexpr int kDinTP = 32;       // positions per tile
+constexpr int kDinNP1 = 16;      // max positions per thread in layer 1 (PG >= 2)
+constexpr int kDinNP2 = 16;
+
+struct DinArgs {
+  int64_t B;
+  int T, Ei, Ec, H1, H2;
+  int64_t n_item, n_cat;
+  int ld_item, ld_cat;
+  const int64_t *hist_item, *hist_cat, *tgt_item, *tgt_cat, *mask;
+  const float *w_hist_item, *w_hist_cat, *w_tgt_item, *w_tgt_cat;
+  const float *w1, *b1, *w2, *b2, *w3, *b3;
+  float *out, *att_weight;
+  int32_t* status;
+};
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+
+__global__ __launch_bounds__(kBlock) void din_attention_fwd_kernel(DinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int E = a.Ei + a.Ec, H1 = a.H1, H2 = a.H2, T = a.T;
+  float* hs = smem;                    // [TP][E]
+  float* qs = hs + kDinTP * E;         // [TP][E]
+  float* a1 = qs + kDinTP * E;         // [TP][H1]
+  float* a2 = a1 + kDinTP * H1;        // [TP][H2]
+  float* w2s = a2 + kDinTP * H2;       // [H1][H2]
+  float* w3s = w2s + H1 * H2;          // [H2]
+  float* b1s = w3s + H2;               // [H1]
+  float* b2s = b1s + H1;               // [H2]
+  float* sall = b2s + H2;              // [T] scaled logits of the whole history
+  const int tid = threadIdx.x;
+  for (int i = tid; i < H1 * H2; i += kBlock) w2s[i] = a.w2[i];
+  for (int i = tid; i < H2; i += kBlock) { w3s[i] = a.w3[i]; b2s[i] = a.b2[i]; }
+  for (int i = tid; i < H1; i += kBlock) b1s[i] = a.b1[i];
+  const float b3 = a.b3[0];
+  const float scale = 1.f / sqrtf((float)E);          // net.py:168  firInDim ** -0.5
+  const int j1 = tid % H1, pg1 = tid / H1, PG1 = kBlock / H1;
+  const int NP1 = (kDinTP + PG1 - 1) / PG1;
+  const bool on1 = pg1 < PG1;
+  const int j2 = tid % H2, pg2 = tid / H2, PG2 = kBlock / H2;
+  const int NP2 = (kDinTP + PG2 - 1) / PG2;
+  const bool on2 = pg2 < PG2;
+  const int e4 = E / 4;
+  int oob = 0;
+  __syncthreads();
+
+  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+    float m_run = -INFINITY, l_run = 0.f, acc = 0.f;   // acc: thread d < E owns out[b][d]
+    for (int t0 = 0; t0 < T; t0 += kDinTP) {
+      // ---- gather h and q rows of this tile into LDS (net.py:141-151)
+      for (int v = tid; v < kDinTP * e4; v += kBlock) {
+        const int p = v / e4, c4 = (v % e4) * 4;
+        const int t = t0 + p;
+        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f), qv = hv;
+        if (t < T) {
+          const bool item = c4 < a.Ei;
+          const int64_t hid = item ? a.hist_item[b * T + t] : a.hist_cat[b * T + t];
+          const int64_t qid = item ? a.tgt_item[b * T + t] : a.tgt_cat[b * T + t];
+          const int64_t nrow = item ? a.n_item : a.n_cat;
+          const int ld = item ? a.ld_item : a.ld_cat;
+          const int c = item ? c4 : c4 - a.Ei;
+          const float* wh = item ? a.w_hist_item : a.w_hist_cat;
+          const float* wq = item ? a.w_tgt_item : a.w_tgt_cat;
+          if (hid >= 0 && hid < nrow) hv = *reinterpret_cast<const float4*>(wh + hid * ld + c); else oob = 1;
+          if (qid >= 0 && qid < nrow) qv = *reinterpret_cast<const float4*>(wq + qid * ld + c); else oob = 1;
+        }
+        *reinterpret_cast<float4*>(hs + p * E + c4) = hv;
+        *reinterpret_cast<float4*>(qs + p * E + c4) = qv;
+      }
+      __syncthreads();
+      // ---- attention layer 1: [h, q, h-q, h*q] @ W1 + b1, sigmoid (net.py:155-164)
+      if (on1) {
+        float s1[kDinNP1];
+#pragma unroll
+        for (int i = 0; i < kDinNP1; ++i) s1[i] = 0.f;
+        const float* w = a.w1 + j1;
+        for (int kk = 0; kk < E; ++kk) {
+          const float wa = w[(int64_t)kk * H1], wb = w[(int64_t)(E + kk) * H1];
+          const float wc = w[(int64_t)(2 * E + kk) * H1], wd = w[(int64_t)(3 * E + kk) * H1];
+#pragma unroll
+          for (int i = 0; i < kDinNP1; ++i) {
+            const int p = pg1 + i * PG1;
+            if (i < NP1 && p < kDinTP) {
+              const float hv = hs[p * E + kk], qv = qs[p * E + kk];
+              s1[i] += hv * wa + qv * wb + (hv - qv) * wc + (hv * qv) * wd;
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < kDinNP1; ++i) {
+          const int p = pg1 + i * PG1;
+          if (i < NP1 && p < kDinTP) a1[p * H1 + j1] = sigmoidf_(s1[i] + b1s[j1]);
+        }
+      }
+      __syncthreads();
+      // ---- layer 2
+      if (on2) {
+        float s2[kDinNP2];
+#pragma unroll
+        for (int i = 0; i < kDinNP2; ++i) s2[i] = 0.f;
+        for (int k = 0; k < H1; ++k) {
+          const float wv = w2s[k * H2 + j2];
+#pragma unroll
+          for (int i = 0; i < kDinNP2; ++i) {
+            const int p = pg2 + i * PG2;
+            if (i < NP2 && p < kDinTP) s2[i] += a1[p * H1 + k] * wv;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < kDinNP2; ++i) {
+          const int p = pg2 + i * PG2;
+          if (i < NP2 && p < kDinTP) a2[p * H2 + j2] = sigmoidf_(s2[i] + b2s[j2]);
+        }
+      }
+      __syncthreads();
+      // ---- layer 3 + mask + scale (net.py:166-168)
+      if (tid < kDinTP) {
+        const int t = t0 + tid;
+        float s = -INFINITY;
+        if (t < T) {
+          s = b3;
+          for (int k = 0; k < H2; ++k) s += a2[tid * H2 + k] * w3s[k];
+          s = (s + (float)a.mask[b * T + t]) * scale;
+          sall[t] = s;
+        }
+        a2[tid * H2] = s;   // a2[p][0] doubles as the tile's logit slot (layer 2 output no longer needed)
+      }
+      __syncthreads();
+      // ---- online softmax + weighted sum of h (net.py:169-171)
+      float mt = -INFINITY;
+      for (int p = 0; p < kDinTP; ++p) mt = fmaxf(mt, a2[p * H2]);
+      const float m_new = fmaxf(m_run, mt);
+      const float f = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+      float lsum = 0.f, asum = 0.f;
+      for (int p = 0; p < kDinTP; ++p) {
+        const float sp = a2[p * H2];
+        const float e = (sp == -INFINITY) ? 0.f : expf(sp - m_new);
+        lsum += e;
+        if (tid < E) asum += e * hs[p * E + tid];
+      }
+      l_run = l_run * f + lsum;
+      acc = acc * f + asum;
+      m_run = m_new;
+      __syncthreads();   // hs/qs/a2 are rewritten by the next tile
+    }
+    if (tid < E) a.out[b * E + tid] = acc / l_run;
+    if (a.att_weight) {
+      for (int t = tid; t < T; t += kBlock) a.att_weight[b * T + t] = expf(sall[t] - m_run) / l_run;
+    }
+    __syncthreads();
+  }
+  if (oob) atomicOr(a.status, REC_FLAG_INDEX_OOB);
+}
+
+}  // namespace rec
+
+using namespace rec;
+
+extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* hist_item,
+                                          const int64_t* hist_cat, const int64_t* tgt_item_seq,
+                                          const int64_t* tgt_cat_seq, const int64_t* mask,
+                                          const float* w_hist_item, const float* w_hist_cat,
+                                          const float* w_tgt_item_seq, const float* w_tgt_cat_seq,
+                                          const float* att_w1, const float* att_b1,
+                                          const float* att_w2, const float* att_b2,
+                                          const float* att_w3, const float* att_b3, float* out,
+                                          float* att_weight, int32_t* status, void* stream) {
+  REC_REQUIRE(d, REC_EINVAL, "desc is NULL");
+  const int E = d->item_dim + d->cat_dim;
+  REC_REQUIRE(d->batch >= 0 && d->max_len > 0 && d->item_dim > 0 && d->cat_dim > 0 && d->hidden1 > 0 &&
+                  d->hidden2 > 0 && d->item_rows > 0 && d->cat_rows > 0, REC_EINVAL, "bad sizes");
+  REC_REQUIRE(d->item_dim % 4 == 0 && d->cat_dim % 4 == 0 && E <= kBlock, REC_ESHAPE,
+              "item_dim/cat_dim must be multiples of 4 with item_dim+cat_dim <= %d", kBlock);
+  REC_REQUIRE(d->hidden1 <= kBlock / 2 && d->hidden2 <= kBlock / 2, REC_ESHAPE, "hidden sizes must be <= %d",
+              kBlock / 2);
+  REC_REQUIRE((kDinTP + kBlock / d->hidden1 - 1) / (kBlock / d->hidden1) <= kDinNP1 &&
+                  (kDinTP + kBlock / d->hidden2 - 1) / (kBlock / d->hidden2) <= kDinNP2, REC_ESHAPE,
+              "hidden sizes too large for the tile");
+  REC_REQUIRE(d->item_stride >= d->item_dim && d->cat_stride >= d->cat_dim && d->item_stride % 4 == 0 &&
+                  d->cat_stride % 4 == 0, REC_EINVAL, "table strides must be multiples of 4 and >= dims");
+  if (d->batch == 0) return REC_OK;
+  REC_REQUIRE(hist_item && hist_cat && tgt_item_seq && tgt_cat_seq && mask && w_hist_item && w_hist_cat &&
+                  w_tgt_item_seq && w_tgt_cat_seq && att_w1 && att_b1 && att_w2 && att_b2 && att_w3 &&
+                  att_b3 && out && status, REC_EINVAL, "null pointer argument");
+  const int H1 = d->hidden1, H2 = d->hidden2;
+  const size_t shmem = sizeof(float) * ((size_t)2 * kDinTP * E + (size_t)kDinTP * (H1 + H2) + (size_t)H1 * H2 +
+                                        2 * H2 + H1 + (size_t)d->max_len);
+  REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "history too long for the LDS logit buffer (%zu B)", shmem);
+  DinArgs a;
+  a.B = d->batch; a.T = d->max_len; a.Ei = d->item_dim; a.Ec = d->cat_dim; a.H1 = H1; a.H2 = H2;
+  a.n_item = d->item_rows; a.n_cat = d->cat_rows; a.ld_item = d->item_stride; a.ld_cat = d->cat_stride;
+  a.hist_item = hist_item; a.hist_cat = hist_cat; a.tgt_item = tgt_item_seq; a.tgt_cat = tgt_cat_seq;
+  a.mask = mask; a.w_hist_item = w_hist_item; a.w_hist_cat = w_hist_cat; a.w_tgt_item = w_tgt_item_seq;
+  a.w_tgt_cat = w_tgt_cat_seq; a.w1 = att_w1; a.b1 = att_b1; a.w2 = att_w2; a.b2 = att_b2; a.w3 = att_w3;
+  a.b3 = att_b3; a.out = out; a.att_weight = att_weight; a.status = status;
+  int64_t grid = resident_blocks(din_attention_fwd_kernel, kBlock, shmem);
+  if (grid > d->batch) grid = d->batch;
+  hipLaunchKernelGGL(din_attention_fwd_kernel, dim3((unsigned)grid), dim3(kBlock), shmem,
+                     (hipStream_t)stream, a);
+  return check_launch("rec_din_attention_pool_fwd");
+}

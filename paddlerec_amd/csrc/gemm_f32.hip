@@ -139,7 +139,8 @@ __device__ __forceinline__ float apply_epi(float acc, int64_t i, int j, const Ep
   if (EPI == REC_EPI_BIAS_SIGMOID) return 1.f / (1.f + expf(-(acc + e.bias[j])));
   if (EPI == REC_EPI_BIAS_TANH) return tanhf(acc + (e.bias ? e.bias[j] : 0.f));
   if (EPI == REC_EPI_ADD)
-    return acc + e.aux1[i * e.ld1 + j] + (e.aux0 ? e.aux0[i * e.ld0 + j] : 0.f);
+    return acc + (e.bias ? e.bias[j] : 0.f) + e.aux1[i * e.ld1 + j] +
+           (e.aux0 ? e.aux0[i * e.ld0 + j] : 0.f);
   return acc;
 }
 

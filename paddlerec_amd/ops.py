@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI, AdamHyper, DeepFMDesc, GemmDesc, GemmEpilogueArgs, GradLayout, RecError, check,
+from ._lib import (EPI, AdamHyper, DeepFMDesc, DinDesc, GemmDesc, GemmEpilogueArgs, GradLayout, RecError, check,
                    lib)
 
 
@@ -304,6 +304,37 @@ def clip_scale(sumsq_t, clip_norm, out):
     """out[0] = clip_norm / max(sqrt(sumsq), clip_norm)  (ClipGradByGlobalNorm coefficient)."""
     check(lib().rec_clip_scale(_p(sumsq_t), float(clip_norm), _p(out), _stream()), "rec_clip_scale")
     return out
+
+
+def din_attention_pool(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, mask, w_hist_item, w_hist_cat,
+                       w_tgt_item_seq, w_tgt_cat_seq, att_w, att_b, status=None, want_weights=True):
+    """Fused DIN attention-pool forward (din/net.py:141-173).  ids/mask [B,T] i64; att_w/att_b: the three
+    attention Linear layers ([4E,H1],[H1,H2],[H2,1] / biases).  -> (out [B,E], att_weight [B,T] | None, status)"""
+    B, T = hist_item.shape
+    for t, n in ((hist_item, "hist_item"), (hist_cat, "hist_cat"), (tgt_item_seq, "tgt_item_seq"),
+                 (tgt_cat_seq, "tgt_cat_seq"), (mask, "mask")):
+        _chk(t, torch.int64, n, (B, T))
+    Ei, ldi = _chk_table(w_hist_item, "w_hist_item")
+    Ec, ldc = _chk_table(w_hist_cat, "w_hist_cat")
+    if _chk_table(w_tgt_item_seq, "w_tgt_item_seq") != (Ei, ldi) or _chk_table(w_tgt_cat_seq, "w_tgt_cat_seq") != (Ec, ldc):
+        raise RecError("target tables must have the shape/stride of the history tables")
+    E, H1, H2 = Ei + Ec, att_w[0].shape[1], att_w[1].shape[1]
+    _chk(att_w[0], torch.float32, "att_w1", (4 * E, H1))
+    _chk(att_w[1], torch.float32, "att_w2", (H1, H2))
+    for t, n in ((att_w[2], "att_w3"), (att_b[0], "att_b1"), (att_b[1], "att_b2"), (att_b[2], "att_b3")):
+        _chk(t, torch.float32, n)
+    dev = hist_item.device
+    out = torch.empty(B, E, dtype=torch.float32, device=dev)
+    attw = torch.empty(B, T, dtype=torch.float32, device=dev) if want_weights else None
+    if status is None:
+        status = new_status(dev)
+    d = DinDesc(B, T, Ei, Ec, H1, H2, w_hist_item.shape[0], w_hist_cat.shape[0], ldi, ldc)
+    check(lib().rec_din_attention_pool_fwd(
+        C.byref(d), _p(hist_item), _p(hist_cat), _p(tgt_item_seq), _p(tgt_cat_seq), _p(mask),
+        _p(w_hist_item), _p(w_hist_cat), _p(w_tgt_item_seq), _p(w_tgt_cat_seq), _p(att_w[0]), _p(att_b[0]),
+        _p(att_w[1]), _p(att_b[1]), _p(att_w[2]), _p(att_b[2]), _p(out), _p(attw), _p(status), _stream()),
+        "rec_din_attention_pool_fwd")
+    return out, attw, status
 
 
 def softmax_rows(x, out=None):

@@ -1,0 +1,88 @@
+"""DIN on the HIP kernels: fused attention-pool and the full DINLayer forward against the golden fixture of
+the reference's unmodified din/net.py and the NumPy oracle (oracle/din_ref.py)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+from oracle import din_ref as Dn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+def test_din_layer_forward_golden(engine_lib):
+    from paddlerec_amd.din import DINLayer
+    g = load_golden("din")
+    p = {k[2:]: v for k, v in g.items() if k.startswith("p.")}
+    m = DINLayer(8, 8, "sigmoid", False, True, 301, 41, device=DEV)
+    m.set_dict(p)
+    m.set_attention([g["att_w%d" % i] for i in range(3)], [g["att_b%d" % i] for i in range(3)])
+    B, Tn = g["hist_item"].shape
+    tis = np.repeat(g["target_item"][:, None], Tn, 1)
+    tcs = np.repeat(g["target_cat"][:, None], Tn, 1)
+    logit = m.forward(T(g["hist_item"]), T(g["hist_cat"]), T(g["target_item"]), T(g["target_cat"]),
+                      T(g["label"]), T(g["mask"]), T(tis), T(tcs))
+    np.testing.assert_allclose(N_(logit), g["logit"], rtol=1e-5, atol=1e-6)
+    assert int(m.status.item()) == 0
+
+
+@pytest.mark.parametrize("B,Tn,Ei,Ec", [(1, 1, 8, 8), (32, 152, 64, 64), (7, 33, 64, 64), (5, 64, 32, 96),
+                                        (300, 40, 64, 64)])
+def test_attention_pool_vs_oracle(engine_lib, B, Tn, Ei, Ec):
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(B + Tn)
+    ni, nc, E = 500, 41, Ei + Ec
+    tabs = [rng.uniform(-0.3, 0.3, (n, d)).astype(np.float32) for n, d in ((ni, Ei), (nc, Ec), (ni, Ei), (nc, Ec))]
+    lens = rng.integers(1, Tn + 1, B)
+    lens[0] = Tn
+    hi = np.zeros((B, Tn), np.int64); hc = np.zeros((B, Tn), np.int64)
+    for b in range(B):
+        hi[b, :lens[b]] = rng.integers(1, ni, lens[b]); hc[b, :lens[b]] = rng.integers(1, nc, lens[b])
+    mask = np.where(np.arange(Tn)[None] < lens[:, None], 0, -1000000000).astype(np.int64)
+    ti = np.repeat(rng.integers(1, ni, B)[:, None], Tn, 1); tc = np.repeat(rng.integers(1, nc, B)[:, None], Tn, 1)
+    aw = [rng.uniform(-0.2, 0.2, s).astype(np.float32) for s in ((4 * E, 80), (80, 40), (40, 1))]
+    ab = [rng.uniform(-0.1, 0.1, s).astype(np.float32) for s in ((80,), (40,), (1,))]
+    out, attw, status = ops.din_attention_pool(T(hi), T(hc), T(ti), T(tc), T(mask), *[T(t) for t in tabs],
+                                               [T(w) for w in aw], [T(b) for b in ab])
+    assert int(status.item()) == 0
+    h = np.concatenate([tabs[0][hi], tabs[1][hc]], 2)
+    q = np.concatenate([tabs[2][ti], tabs[3][tc]], 2)
+    want, wts = Dn.attention_pool(h, q, mask.astype(np.float32), aw, ab, return_weights=True)
+    np.testing.assert_allclose(N_(out), want, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(N_(attw), wts, rtol=1e-4, atol=1e-7)
+    # padded positions carry exactly zero weight; weights of a sample sum to 1
+    assert np.all(N_(attw)[mask != 0] == 0.0)
+    np.testing.assert_allclose(N_(attw).sum(1), 1.0, rtol=1e-5)
+
+
+def test_attention_pool_known_answers(engine_lib):
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(1)
+    B, Tn, Ei, Ec = 4, 70, 8, 8
+    E = Ei + Ec
+    tabs = [rng.standard_normal((50, 8)).astype(np.float32) for _ in range(4)]
+    hi = rng.integers(0, 50, (B, Tn)); hc = rng.integers(0, 50, (B, Tn))
+    lens = np.array([70, 33, 1, 64])
+    mask = np.where(np.arange(Tn)[None] < lens[:, None], 0, -1000000000).astype(np.int64)
+    mask[3, :] = -1000000000                      # all-padding history: uniform weights, as the reference
+    zw = [np.zeros((4 * E, 80), np.float32), np.zeros((80, 40), np.float32), np.zeros((40, 1), np.float32)]
+    zb = [np.zeros(80, np.float32), np.zeros(40, np.float32), np.zeros(1, np.float32)]
+    out, attw, _ = ops.din_attention_pool(T(hi), T(hc), T(hi), T(hc), T(mask), *[T(t) for t in tabs],
+                                          [T(w) for w in zw], [T(b) for b in zb])
+    h = np.concatenate([tabs[0][hi], tabs[1][hc]], 2)
+    for b, n in enumerate([70, 33, 1, 70]):       # equal logits => mean-pool over the valid positions
+        np.testing.assert_allclose(N_(out)[b], h[b, :n].mean(0), rtol=1e-5, atol=1e-6)
+    # out-of-range id: flagged, row read as zero
+    hi2 = hi.copy(); hi2[0, 0] = 50
+    _, _, status = ops.din_attention_pool(T(hi2), T(hc), T(hi), T(hc), T(mask), *[T(t) for t in tabs],
+                                          [T(w) for w in zw], [T(b) for b in zb])
+    assert int(status.item()) & 1

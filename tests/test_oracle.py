@@ -215,3 +215,28 @@ def test_dcn_v2_oracle_matches_reference_net(name):
             n += 1
     assert n >= 15
     assert np.all(grads["embedding.weight"][0] == 0)       # padding row gets no gradient
+
+
+def test_din_oracle_matches_reference_net():
+    from oracle import din_ref as Dn
+    g = load_golden("din")
+    p = {k[2:]: v for k, v in g.items() if k.startswith("p.")}
+    att = ([g["att_w%d" % i] for i in range(3)], [g["att_b%d" % i] for i in range(3)])
+    logit = Dn.forward(p, att, g["hist_item"], g["hist_cat"], g["target_item"], g["target_cat"],
+                       g["mask"][:, :, 0])
+    np.testing.assert_allclose(logit, g["logit"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(Dn.bce_with_logits_mean(logit, g["label"]), g["loss"], rtol=1e-6)
+    # App. B-9: the attention MLP is not among the registered parameters, the top MLP reuses its names
+    assert "linear_0.weight" in p and p["linear_0.weight"].shape == (32, 80) and g["att_w0"].shape == (64, 80)
+    # known-answer property: equal logits => mean-pool over the valid positions
+    B, T, E = 3, 6, 4
+    rng = np.random.default_rng(0)
+    h = rng.standard_normal((B, T, E)).astype(np.float32)
+    q = rng.standard_normal((B, T, E)).astype(np.float32)
+    lens = np.array([6, 2, 1])
+    mask = np.where(np.arange(T)[None] < lens[:, None], 0.0, -1e9).astype(np.float32)
+    zero_w = [np.zeros((4 * E, 80), np.float32), np.zeros((80, 40), np.float32), np.zeros((40, 1), np.float32)]
+    zero_b = [np.zeros(80, np.float32), np.zeros(40, np.float32), np.zeros(1, np.float32)]
+    out = Dn.attention_pool(h, q, mask, zero_w, zero_b)
+    want = np.stack([h[b, :lens[b]].mean(0) for b in range(B)])
+    np.testing.assert_allclose(out, want, rtol=1e-6, atol=1e-7)
