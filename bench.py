@@ -45,6 +45,24 @@ def algorithmic_bytes(B, S, Dn, D):
     return fwd, bwd
 
 
+def pmc_traffic(B, D):
+    """HBM bytes per launch (fm_fwd + fm_bwd) from the committed rocprofv3 --pmc passes of this same command
+    (tools/profile_bench.sh -> profiles/*_pmc_traffic.json: TCC_EA0_RDREQ_{32,64,128}B / WRREQ{,_64B} request
+    counters x their sizes, i.e. already in bytes — not the FETCH_SIZE KB figure that needs the x2 gfx950
+    correction).  Only valid for the profiled shape; None otherwise."""
+    if B != 65536 or D != 16:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        t = json.load(open(files[-1]))
+        return float(t["fm_fwd_kernel"]["hbm_bytes"] + t["fm_bwd_kernel"]["hbm_bytes"])
+    except Exception:
+        return None
+
+
 def mlp_flops(B, sizes):
     return sum(2 * B * sizes[i] * sizes[i + 1] for i in range(len(sizes) - 1))
 
@@ -205,7 +223,8 @@ def main():
                    "global_batch": world * B, "parallelism": parallelism,
                    "table_rows_total": N, "loss": loss_v, "index_oob_flag": oob},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(B, D),
+                     "algorithmic_bytes": fwd_b + bwd_b,
                      "kernel": "fm_fwd_kernel + fm_bwd_kernel (embedding+FM fwd+bwd, SURVEY §8(d) bytes: "
                                "%d B/sample)" % ((fwd_b + bwd_b) // B),
                      "fm_fwd_ms": k_ms.get("fm_fwd"), "fm_bwd_ms": k_ms.get("fm_bwd"),

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""L-step / L-kernel numbers for the DCN-v2 and DIN rows of SURVEY.md §8 (BASELINE configs[2], configs[3]).
+Not part of bench.py's contract; results are copied into profiles/."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from paddlerec_amd import ops  # noqa: E402
+from paddlerec_amd.dcn_v2 import DCN_V2Layer  # noqa: E402
+
+DEV = "cuda"
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return ts[len(ts) // 2]
+
+
+g = torch.Generator(device=DEV).manual_seed(3)
+# ---- DCN-v2, datasets/criteo_dcn_v2 shapes: N 1 100 001, D 40, d 1560, fc [768,768] (dcn_v2/config.yaml:42-58)
+for B, mix, depth in ((65536, False, 3), (512, False, 3), (65536, True, 2)):
+    m = DCN_V2Layer(1100001, 40, 13, 26, [768, 768], depth, is_Stacked=True, use_low_rank_mixture=mix,
+                    low_rank=256, num_experts=4, device=DEV)
+    ids = torch.randint(1, 1100001, (B, 26), device=DEV, generator=g)
+    dense = torch.rand(B, 13, device=DEV, generator=g)
+    label = (torch.rand(B, 1, device=DEV, generator=g) < 0.25).long()
+    t_f = timeit(lambda: m.forward(ids, dense))
+    d = 1560
+    if mix:
+        fl = depth * (2.0 * B * d * 256 * 4 * 2 + 2.0 * B * 256 * 256 * 4 + 2.0 * B * d * 4) + 2.0 * B * (d * 768 + 768 * 768 + 768)
+        print("DCN-v2 CrossNetMix r256 E4 depth%d B=%d: forward %.2f ms  (%.1f TF, %.2f M samples/s)" %
+              (depth, B, t_f, fl / t_f / 1e9, B / t_f / 1e3))
+    else:
+        fl_f = depth * 2.0 * B * d * d + 2.0 * B * (d * 768 + 768 * 768 + 768) + 2.0 * B * 13 * 520
+        t_s = timeit(lambda: m.train_step(ids, dense, label, lr=1e-3))
+        print("DCN-v2 CrossNetV2 depth%d B=%d: forward %.2f ms (%.1f TF)  train step %.2f ms (%.1f TF, %.2f M samples/s)" %
+              (depth, B, t_f, fl_f / t_f / 1e9, t_s, 3 * fl_f / t_s / 1e9, B / t_s / 1e3))
+    del m
+    torch.cuda.empty_cache()
+
+# ---- DIN attention-pool, amazonElec shapes: item 63001 x 64, cat 801 x 64 (din/config.yaml:38-44)
+for B, T in ((32, 152), (4096, 100), (4096, 512)):
+    tabs = [torch.randn(n, 64, device=DEV, generator=g) * 0.05 for n in (63001, 801, 63001, 801)]
+    hi = torch.randint(0, 63001, (B, T), device=DEV, generator=g)
+    hc = torch.randint(0, 801, (B, T), device=DEV, generator=g)
+    lens = torch.randint(1, T + 1, (B, 1), device=DEV, generator=g)
+    mask = torch.where(torch.arange(T, device=DEV)[None] < lens, 0, -1000000000).long()
+    aw = [torch.randn(s, device=DEV, generator=g) * 0.05 for s in ((512, 80), (80, 40), (40, 1))]
+    ab = [torch.zeros(s, device=DEV) for s in (80, 40, 1)]
+    st = ops.new_status(DEV)
+    t = timeit(lambda: ops.din_attention_pool(hi, hc, hi, hc, mask, *tabs, aw, ab, st))
+    fl = 2.0 * B * T * (512 * 80 + 80 * 40 + 40 + 128)
+    by = B * T * (4 * 8 + 8 + 4 * 256)          # ids + mask + 4 rows of 256 B (algorithmic, rows hit L2)
+    print("DIN attention-pool B=%d T=%d: %.3f ms  (%.1f M positions/s, %.2f TF, %.0f GB/s algorithmic)" %
+          (B, T, t, B * T / t / 1e3, fl / t / 1e9, by / t / 1e6))
