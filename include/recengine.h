@@ -317,6 +317,23 @@ uint32_t rec_xxh32(const void* bytes, size_t len, uint32_t seed);
 int rec_xxh32_hash_mod(const char* const* strings, const int32_t* field_idx, int64_t n,
                        uint32_t hash_dim, int64_t* out);
 
+/* Rows R and H — input pipeline, HOST functions (no device code; outputs are caller-owned, ideally pinned).
+ * rec_parse_slot_text : models/rank/deepfm/criteo_reader.py:61-103 (and dcn_v2/reader.py:41-89 with
+ *   log1p_dense = 1): "click:L dense_feature:v x13 1:id ... 26:id" per line; missing sparse slot -> id 0,
+ *   missing dense slot -> zeros, first value of a repeated slot wins.  label [n], ids [n,n_sparse] i64,
+ *   dense [n,n_dense] f32 (parsed as double, then cast — as float() / np.float32 do).
+ * rec_parse_criteo_tsv: models/rank/dnn/benchmark_reader.py:39-54: "label \t 13 ints \t 26 strings";
+ *   dense = (x - cont_min[j]) / cont_diff[j] ("" -> 0), ids = xxh32(str(field_idx)+string) % hash_dim with
+ *   field_idx = 14..39 (the column index, as the reference hashes it).
+ * threads <= 0: one per host core (capped at 32).  *n_lines = lines parsed (<= max_lines). */
+int rec_parse_slot_text(const char* buf, size_t len, int32_t n_sparse, int32_t n_dense,
+                        int32_t log1p_dense, int64_t max_lines, int32_t threads, int64_t* label,
+                        int64_t* ids, float* dense, int64_t* n_lines);
+int rec_parse_criteo_tsv(const char* buf, size_t len, int32_t n_dense, int32_t n_sparse,
+                         const float* cont_min, const float* cont_diff, uint32_t hash_dim,
+                         int64_t max_lines, int32_t threads, int64_t* label, int64_t* ids, float* dense,
+                         int64_t* n_lines);
+
 /* Fills buf[i] = i-th value of a counter-based generator, uniform in [lo,hi) — used to initialise
  * multi-GB tables on the device without a host round trip. */
 int rec_fill_uniform(int64_t n, float* buf, float lo, float hi, uint64_t seed, void* stream);

@@ -57,3 +57,22 @@ def xxh32(data: bytes, seed: int = 0) -> int:
 def hash_feature(field_idx: int, value: str, hash_dim: int = 1000001) -> int:
     """benchmark_reader.py:52 — xxh32(str(idx)+feat) % hash_dim."""
     return xxh32((str(field_idx) + value).encode("utf-8")) % hash_dim
+
+
+# benchmark_reader.py:23-26
+CONT_MIN = [0, -3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+CONT_DIFF = [20, 603, 100, 50, 64000, 500, 100, 50, 500, 10, 10, 10, 50]
+
+
+def criteo_tsv_line(line: str, hash_dim: int = 1000001):
+    """models/rank/dnn/benchmark_reader.py:39-54 line_process -> (label, ids[26], dense[13] as float32)."""
+    import numpy as np
+    features = line.rstrip("\n").split("\t")
+    dense = []
+    for idx in range(1, 14):
+        if features[idx] == "":
+            dense.append(0.0)
+        else:
+            dense.append((float(features[idx]) - CONT_MIN[idx - 1]) / CONT_DIFF[idx - 1])
+    ids = [hash_feature(idx, features[idx], hash_dim) for idx in range(14, 40)]
+    return int(features[0]), np.asarray(ids, np.int64), np.asarray(dense, np.float64).astype(np.float32)

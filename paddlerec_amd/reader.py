@@ -1,0 +1,98 @@
+"""Input pipeline on the engine's host parser: text files -> device batches.
+
+Mirrors the reference's RecDataset readers (same constructor shape: file_list, config) for
+  models/rank/deepfm/criteo_reader.py:21-103 / dcn_v2/reader.py  (slot text)   -> SlotTextReader
+  models/rank/dnn/benchmark_reader.py:35-54                       (raw Criteo)  -> CriteoTsvReader
+but parses whole files in C++ (librecengine.so, multi-threaded) into pinned host buffers and ships each
+batch with one async copy, instead of a Python loop per line + a 28-array collate per sample.
+Batches have the layout the kernels take: label [B,1] i64, ids [B,26] i64 (= concat(sparse_inputs,1)),
+dense [B,13] f32.  drop_last=True as tools/utils/utils_single.py:104-110 builds the DataLoader.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+
+CONT_MIN = [0, -3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]                      # benchmark_reader.py:23
+CONT_DIFF = [20, 603, 100, 50, 64000, 500, 100, 50, 500, 10, 10, 10, 50]  # benchmark_reader.py:25
+HASH_DIM = 1000001                                                        # benchmark_reader.py:26
+
+
+def _alloc(n, S, Dn, pinned):
+    pin = pinned and torch.cuda.is_available()
+    label = torch.empty(n, dtype=torch.int64, pin_memory=pin)
+    ids = torch.empty(n, S, dtype=torch.int64, pin_memory=pin)
+    dense = torch.empty(n, max(Dn, 1), dtype=torch.float32, pin_memory=pin)
+    return label, ids, dense
+
+
+def parse_slot_text(data: bytes, n_sparse=26, n_dense=13, log1p_dense=False, threads=0, pinned=False):
+    """-> (label [n] i64, ids [n,S] i64, dense [n,Dn] f32) host tensors."""
+    cap = data.count(b"\n") + 1
+    label, ids, dense = _alloc(cap, n_sparse, n_dense, pinned)
+    n = C.c_int64(0)
+    check(lib().rec_parse_slot_text(data, len(data), n_sparse, n_dense, int(log1p_dense), cap, threads,
+                                    C.c_void_p(label.data_ptr()), C.c_void_p(ids.data_ptr()),
+                                    C.c_void_p(dense.data_ptr()), C.byref(n)), "rec_parse_slot_text")
+    return label[: n.value], ids[: n.value], dense[: n.value, :n_dense]
+
+
+def parse_criteo_tsv(data: bytes, n_dense=13, n_sparse=26, hash_dim=HASH_DIM, threads=0, pinned=False):
+    cap = data.count(b"\n") + 1
+    label, ids, dense = _alloc(cap, n_sparse, n_dense, pinned)
+    cmin = np.asarray(CONT_MIN[:n_dense], np.float32)
+    cdiff = np.asarray(CONT_DIFF[:n_dense], np.float32)
+    n = C.c_int64(0)
+    check(lib().rec_parse_criteo_tsv(data, len(data), n_dense, n_sparse, cmin.ctypes.data_as(C.c_void_p),
+                                     cdiff.ctypes.data_as(C.c_void_p), hash_dim, cap, threads,
+                                     C.c_void_p(label.data_ptr()), C.c_void_p(ids.data_ptr()),
+                                     C.c_void_p(dense.data_ptr()), C.byref(n)), "rec_parse_criteo_tsv")
+    return label[: n.value], ids[: n.value], dense[: n.value, :n_dense]
+
+
+class _FileBatches:
+    def __init__(self, file_list, batch_size, device, parse, shard=None):
+        self.file_list = list(file_list)
+        if shard is not None:                      # criteo_reader.py:30-43: files split by worker
+            rank, world = shard
+            if len(self.file_list) < world:
+                raise ValueError("The number of data files is less than the number of workers")
+            blk = len(self.file_list) // world
+            mine = self.file_list[rank * blk:(rank + 1) * blk]
+            if rank < len(self.file_list) - blk * world:
+                mine.append(self.file_list[-(rank + 1)])
+            self.file_list = mine
+        self.batch_size, self.device, self.parse = batch_size, device, parse
+
+    def __iter__(self):
+        B = self.batch_size
+        carry = None
+        for path in self.file_list:
+            with open(path, "rb") as f:
+                label, ids, dense = self.parse(f.read())
+            if carry is not None:
+                label, ids, dense = (torch.cat([c, x]) for c, x in zip(carry, (label, ids, dense)))
+            n = label.shape[0]
+            for lo in range(0, n - B + 1, B):
+                yield tuple(t[lo:lo + B].to(self.device, non_blocking=True) for t in
+                            (label.view(-1, 1), ids, dense))
+            rem = n % B
+            carry = (label[n - rem:], ids[n - rem:], dense[n - rem:]) if rem else None
+
+
+class SlotTextReader(_FileBatches):
+    """criteo_reader.py RecDataset: yields (label [B,1], ids [B,26], dense [B,13]) on `device`."""
+
+    def __init__(self, file_list, batch_size, device="cuda", log1p_dense=False, shard=None, threads=0):
+        super().__init__(file_list, batch_size, device,
+                         lambda data: parse_slot_text(data, 26, 13, log1p_dense, threads, pinned=True), shard)
+
+
+class CriteoTsvReader(_FileBatches):
+    """benchmark_reader.py Reader: raw Criteo TSV, min-max dense scaling, xxh32 feature hashing."""
+
+    def __init__(self, file_list, batch_size, device="cuda", hash_dim=HASH_DIM, shard=None, threads=0):
+        super().__init__(file_list, batch_size, device,
+                         lambda data: parse_criteo_tsv(data, 13, 26, hash_dim, threads, pinned=True), shard)
