@@ -211,8 +211,8 @@ def main():
     t_pair = (k_ms.get("fm_fwd", 0) + k_ms.get("fm_bwd", 0)) * 1e-3
     achieved = (fwd_b + bwd_b) / t_pair / 1e9 if t_pair > 0 else 0.0
     sizes = [(S + Dn) * D] + fc + [1]
-    gemm_tf = 3 * mlp_flops(B, sizes) / ((k_ms.get("mlp_fwd", 0) + k_ms.get("mlp_bwd", 0)) * 1e-3) / 1e12 \
-        if k_ms.get("mlp_fwd") else 0.0
+    t_gemm = (k_ms.get("mlp_fwd", 0) + k_ms.get("mlp_bwd", 0) + k_ms.get("mlp_bwd_dw0", 0)) * 1e-3
+    gemm_tf = 3 * mlp_flops(B, sizes) / t_gemm / 1e12 if k_ms.get("mlp_fwd") else 0.0
     out = {
         "metric": "CTR samples/sec, Criteo DeepFM bs=65536 (train step: fwd+bwd+optimizer)",
         "value": world * B * args.steps / dt, "unit": "samples/s", "n_gpus": world,

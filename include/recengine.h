@@ -155,6 +155,25 @@ int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride,
                          const rec_grad_layout* grad_layout, const float* grad_scale, float* P,
                          float* M, float* V, const rec_adam_hyper* hyper, void* stream);
 
+/* PS / gpubox accessor rule — "SparseAdaGradSGDRule" + show/click counters (models/rank/slot_dnn/
+ * config_online.yaml:57-79; dnn/net.py:71-79 feature value [show, click, embed_w, embedx(D-1)];
+ * formula per SURVEY.md App. B-13 [EXT]: the rule itself lives in the un-vendored Paddle PS code):
+ *   scale = sqrt(initial_g2sum / (initial_g2sum + g2sum));  w = clip(w - lr*g*scale, bounds);
+ *   g2sum += mean(g^2) per part (embed_w = first weight, embedx = the other D-1);
+ *   show += lookups of the row in this batch, click += sum of their labels (label [B] i64 or NULL).
+ * rec: record table [num_rows, row_stride], row = [show | click | g2sum_w | g2sum_x | W(D) | pad];
+ * the lookup table of rec_emb_gather / rec_emb_gather_sumpool is W = rec + 4 with the same stride
+ * (continuous_value_model(use_cvm=False) = "return the embedding without the CVM columns").  num_slots maps a lookup
+ * position to its sample (b = pos / num_slots) for the click counter. */
+typedef struct {
+  float lr, initial_g2sum, min_bound, max_bound;
+} rec_adagrad_hyper;
+int rec_sparse_adagrad_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride, int32_t num_slots,
+                            const int32_t* n_uniq, const int64_t* uniq_rows,
+                            const int32_t* seg_offset, const int32_t* sorted_pos, const float* grad,
+                            const rec_grad_layout* grad_layout, const int64_t* label, float* rec,
+                            const rec_adagrad_hyper* hyper, void* stream);
+
 /* dense Adam over a flat buffer (MLP + FM dense weights); grad_scale as above. */
 int rec_adam_dense(int64_t n, float* p, float* m, float* v, const float* g, const float* grad_scale,
                    const rec_adam_hyper* hyper, void* stream);

@@ -26,6 +26,11 @@ class AdamHyper(C.Structure):
                 ("step", C.c_int64)]
 
 
+class AdagradHyper(C.Structure):
+    _fields_ = [("lr", C.c_float), ("initial_g2sum", C.c_float), ("min_bound", C.c_float),
+                ("max_bound", C.c_float)]
+
+
 class GradLayout(C.Structure):
     _fields_ = [("div", C.c_int32), ("group", C.c_int32), ("group_stride", C.c_int64)]
 
@@ -69,6 +74,8 @@ SIGNATURES = {
     "rec_ids_group": (C.c_int, [_I64, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rec_sparse_adam_rows": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
                                        _P, _P, _P, C.POINTER(AdamHyper), _P]),
+    "rec_sparse_adagrad_rows": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
+                                          _P, C.POINTER(AdagradHyper), _P]),
     "rec_adam_dense": (C.c_int, [_I64, _P, _P, _P, _P, _P, C.POINTER(AdamHyper), _P]),
     "rec_sumsq_workspace_bytes": (C.c_int, [C.POINTER(_SZ)]),
     "rec_sumsq": (C.c_int, [_I64, _P, _P, _I32, _P, _SZ, _P]),

@@ -295,8 +295,16 @@ __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(int64_t M, int N,
        e += (int64_t)gridDim.x * kBlock) {
     const int64_t i = e / N;
     const int j = (int)(e % N);
-    float t = 0.f;
-    for (int z = 0; z < splits; ++z) t += partial[(int64_t)z * M * ldc + i * ldc + j];
+    const float* pp = partial + i * ldc + j;
+    const int64_t zs = M * ldc;
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // 8 loads in flight; fixed fold order below
+    int z = 0;
+    for (; z + 8 <= splits; z += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += pp[(int64_t)(z + u) * zs];
+    }
+    for (; z < splits; ++z) a8[z & 7] += pp[(int64_t)z * zs];
+    const float t = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     C[i * ldc + j] = apply_epi<EPI>(t, i, j, epi);
     if (EPI == REC_EPI_CROSS && epi.out2) epi.out2[i * epi.ld2 + j] = t + epi.bias[j];
   }
@@ -307,9 +315,14 @@ __global__ __launch_bounds__(kBlock) void colsum_reduce_kernel(int N, int splits
                                                                float* __restrict__ out) {
   const int j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= N) return;
-  float t = 0.f;
-  for (int z = 0; z < splits; ++z) t += partial[(int64_t)z * N + j];
-  out[j] = t;
+  float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int z = 0;
+  for (; z + 8 <= splits; z += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a8[u] += partial[(int64_t)(z + u) * N + j];
+  }
+  for (; z < splits; ++z) a8[z & 7] += partial[(int64_t)z * N + j];
+  out[j] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
 }
 
 // column sums of G [M,N] (bias gradients): deterministic two-level reduction

@@ -360,7 +360,69 @@ extern "C" int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_
   });
 }
 
+// ---------------------------------------------------------------------------------------------
+// PS / gpubox accessor rule (slot_dnn/config_online.yaml:57-79): a feature value is
+//   [show, click, embed_w, embedx(D-1)]  (dnn/net.py:71-79: sparse_embedding(size=[N, D+2]) + CVM strips 2)
+// with ONE AdaGrad scalar g2sum per part (embed_w / embedx) — D+4 floats per row instead of Adam's 3D:
+//   scale = sqrt(initial_g2sum / (initial_g2sum + g2sum));  w -= lr * g * scale, clipped to the bounds;
+//   g2sum += mean(g^2) over the part;  show += occurrences, click += sum of their labels.
+// Record (one 128-B line for D <= 28): [show | click | g2sum_w | g2sum_x | W(D) | pad] — W starts 16-B
+// aligned so the lookup kernels keep their float4 path.  One thread per
+// touched row; the duplicate gradients of the row are summed in ascending-position order first.
+__global__ __launch_bounds__(kBlock) void sparse_adagrad_rows_kernel(
+    int D, int stride, int S, const int32_t* __restrict__ n_uniq, const int64_t* __restrict__ uniq,
+    const int32_t* __restrict__ seg_off, const int32_t* __restrict__ spos,
+    const float* __restrict__ grad, rec_grad_layout gl, const int64_t* __restrict__ label,
+    float* __restrict__ rec, rec_adagrad_hyper h) {
+  const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (u >= n_uniq[0]) return;
+  float* r = rec + uniq[u] * stride;
+  const int beg = seg_off[u], end = seg_off[u + 1];
+  float clicks = 0.f;
+  if (label)
+    for (int k = beg; k < end; ++k) clicks += (float)label[spos[k] / S];
+  r[0] += (float)(end - beg);   // show: every lookup of the row is one impression (dnn/static_model.py:86-94)
+  r[1] += clicks;
+  const float g2w = r[2], g2x = r[3];
+  const float sw = sqrtf(h.initial_g2sum / (h.initial_g2sum + g2w));
+  const float sx = sqrtf(h.initial_g2sum / (h.initial_g2sum + g2x));
+  float addw = 0.f, addx = 0.f;
+  for (int d = 0; d < D; ++d) {
+    float g = 0.f;
+    for (int k = beg; k < end; ++k) g += grad[grad_offset(gl, spos[k], D) + d];
+    float w = r[4 + d] - h.lr * g * (d == 0 ? sw : sx);
+    w = fminf(fmaxf(w, h.min_bound), h.max_bound);
+    r[4 + d] = w;
+    if (d == 0) addw = g * g; else addx += g * g;
+  }
+  r[2] = g2w + addw;
+  if (D > 1) r[3] = g2x + addx / (float)(D - 1);
+}
+
 constexpr int kSumsqBlocks = 1024;
+
+extern "C" int rec_sparse_adagrad_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride,
+                                       int32_t num_slots, const int32_t* n_uniq,
+                                       const int64_t* uniq_rows, const int32_t* seg_offset,
+                                       const int32_t* sorted_pos, const float* grad,
+                                       const rec_grad_layout* grad_layout, const int64_t* label,
+                                       float* rec, const rec_adagrad_hyper* hyper, void* stream) {
+  rec_grad_layout gl = {1, 0, 0};
+  if (grad_layout) gl = *grad_layout;
+  REC_REQUIRE(n_max >= 0 && emb_dim > 0 && row_stride >= emb_dim + 4 && num_slots > 0 && gl.div >= 1,
+              REC_EINVAL, "bad sizes (row_stride must hold show, click, D weights and 2 g2sum)");
+  REC_REQUIRE(n_uniq && uniq_rows && seg_offset && sorted_pos && grad && rec && hyper, REC_EINVAL,
+              "null pointer argument");
+  REC_REQUIRE(hyper->initial_g2sum > 0.f && hyper->min_bound <= hyper->max_bound, REC_EINVAL,
+              "bad hyper-parameters");
+  if (n_max == 0) return REC_OK;
+  const int64_t grid = (n_max + kBlock - 1) / kBlock;
+  REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");
+  hipLaunchKernelGGL(sparse_adagrad_rows_kernel, dim3((unsigned)grid), dim3(kBlock), 0,
+                     (hipStream_t)stream, emb_dim, row_stride, num_slots, n_uniq, uniq_rows, seg_offset,
+                     sorted_pos, grad, gl, label, rec, *hyper);
+  return check_launch("rec_sparse_adagrad_rows");
+}
 
 extern "C" int rec_sumsq_workspace_bytes(size_t* bytes) {
   REC_REQUIRE(bytes, REC_EINVAL, "bytes is NULL");

@@ -217,7 +217,8 @@ class DeepFMLayer:
         if auc_stats is not None:
             self.k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         with self._timed("mlp_bwd"):
-            d_flat = self.k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp)
+            d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db,
+                                                     self.ws_mlp, defer_first=True)
         with self._timed("fm_bwd"):
             row_grad, _, _ = self.k.deepfm_fm_bwd(
                 dense_inputs, feat, sum_emb, d_flat.view(B, self.num_field, -1), dz, dz, S, self.ws,
@@ -225,15 +226,21 @@ class DeepFMLayer:
                      self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
                      self.dense.g["fm.dense_w_one"]),
                 dense_w=self.dense.p["fm.dense_w"])
+        # The lazy sparse optimizer (HBM-bound) runs on the side stream underneath the MFMA-bound
+        # dW_0 GEMM; it needs row_grad / dz and the merge keys (sorted on that same stream earlier).
+        t = self.step_count
+        st = self.sparse_state
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            with self._timed("sparse_adam"):
+                self.k.sparse_adam_rows(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr)
+                self.k.sparse_adam_rows(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
+        with self._timed("mlp_bwd_dw0"):
+            finish_dw0()
         if allreduce is not None:
             allreduce(self.dense.grad)
-        t = self.step_count
         self.k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
         cur.wait_stream(self._side)
-        st = self.sparse_state
-        with self._timed("sparse_adam"):
-            self.k.sparse_adam_rows(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr)
-            self.k.sparse_adam_rows(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
         return loss, pred
 
     def _timed(self, name):

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI, AdamHyper, DeepFMDesc, DinDesc, GemmDesc, GemmEpilogueArgs, GradLayout, RecError, check,
+from ._lib import (EPI, AdagradHyper, AdamHyper, DeepFMDesc, DinDesc, GemmDesc, GemmEpilogueArgs, GradLayout, RecError, check,
                    lib)
 
 
@@ -263,6 +263,22 @@ def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, 
           "rec_sparse_adam_rows")
 
 
+def sparse_adagrad_rows(groups, grad, rec, emb_dim, num_slots, label=None, lr=0.05, initial_g2sum=3.0,
+                        bounds=(-10.0, 10.0), grad_div=1, grad_group=0, grad_group_stride=0):
+    """PS accessor rule (SparseAdaGradSGDRule + show/click) on the touched rows of a record table
+    rec [N, stride] = [show | click | g2sum_w | g2sum_x | W(D) | pad]."""
+    if rec.dim() != 2 or rec.dtype != torch.float32 or not rec.is_cuda or rec.stride(1) != 1:
+        raise RecError("rec must be a 2-D float32 device tensor with unit column stride")
+    if label is not None:
+        _chk(label, torch.int64, "label")
+    h = AdagradHyper(float(lr), float(initial_g2sum), float(bounds[0]), float(bounds[1]))
+    check(lib().rec_sparse_adagrad_rows(groups.n, int(emb_dim), rec.stride(0), int(num_slots), _p(groups.n_uniq),
+                                        _p(groups.uniq_rows), _p(groups.seg_offset), _p(groups.sorted_pos),
+                                        _p(grad), C.byref(GradLayout(int(grad_div), int(grad_group),
+                                                                     int(grad_group_stride))),
+                                        _p(label), _p(rec), C.byref(h), _stream()), "rec_sparse_adagrad_rows")
+
+
 def adam_dense(p, m, v, g, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=None):
     for t, n in ((p, "p"), (m, "m"), (v, "v"), (g, "g")):
         _chk(t, torch.float32, n)
@@ -479,12 +495,19 @@ def mlp_forward(x, weights, biases, ws, relu_last=False, out_last=None):
     return x, acts + [x]
 
 
-def mlp_backward(dy, acts, weights, dws, dbs, ws):
+def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False):
     """Backward of mlp_forward: dW_i -> dws[i], db_i -> dbs[i] (preallocated views); returns d(input).
-    ReLU' is applied in the epilogue of the dX GEMM (mask = layer input > 0)."""
+    ReLU' is applied in the epilogue of the dX GEMM (mask = layer input > 0).
+    defer_first: compute d(input) BEFORE dW_0 and return (d_input, finish) where finish() launches the
+    dW_0 / db_0 GEMM — lets the caller start the HBM-bound consumers of d(input) on another stream
+    underneath that MFMA-bound GEMM."""
     n = len(weights)
     g = dy
     for i in reversed(range(n)):
+        if i == 0 and defer_first:
+            g0 = g
+            d_in = gemm(g0, weights[0], ws, trans_b=True)
+            return d_in, (lambda: gemm(acts[0], g0, ws, trans_a=True, out=dws[0], b_colsum=dbs[0]))
         gemm(acts[i], g, ws, trans_a=True, out=dws[i], b_colsum=dbs[i])    # dW = X^T G, db = colsum(G)
         if i > 0:
             g = gemm(g, weights[i], ws, trans_b=True, epilogue="relu_mask", aux0=acts[i])

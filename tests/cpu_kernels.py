@@ -133,7 +133,9 @@ def mlp_forward(x, weights, biases, ws):
     return x, acts + [x]
 
 
-def mlp_backward(dy, acts, weights, dws, dbs, ws):
+def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False):
+    if defer_first:
+        return mlp_backward(dy, acts, weights, dws, dbs, ws), (lambda: None)
     n = len(weights)
     g = dy
     for i in reversed(range(n)):
