@@ -174,6 +174,14 @@ int rec_sparse_adagrad_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride, 
                             const rec_grad_layout* grad_layout, const int64_t* label, float* rec,
                             const rec_adagrad_hyper* hyper, void* stream);
 
+/* paddle.optimizer.SGD [EXT] (din/dygraph_model.py:64-73): p -= lr * g.  Rows whose gradient is zero do
+ * not move, so updating the merged rows of a SelectedRows gradient equals the dense update. */
+int rec_sparse_sgd_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride, const int32_t* n_uniq,
+                        const int64_t* uniq_rows, const int32_t* seg_offset, const int32_t* sorted_pos,
+                        const float* grad, const rec_grad_layout* grad_layout, float* P, float lr,
+                        void* stream);
+int rec_sgd_dense(int64_t n, float* p, const float* g, float lr, void* stream);
+
 /* dense Adam over a flat buffer (MLP + FM dense weights); grad_scale as above. */
 int rec_adam_dense(int64_t n, float* p, float* m, float* v, const float* g, const float* grad_scale,
                    const rec_adam_hyper* hyper, void* stream);
@@ -226,6 +234,21 @@ int rec_din_attention_pool_fwd(const rec_din_desc* desc, const int64_t* hist_ite
                                const float* att_b2, const float* att_w3, const float* att_b3,
                                float* out, float* att_weight, int32_t* status, void* stream);
 
+/* Backward of the block above w.r.t. the gathered rows (what loss.backward() computes for net.py:141-173):
+ *   d_hist [B,T,E] = gradient of [hist_item_emb | hist_cat_emb] per position, d_tgt_seq [B,T,E] likewise
+ *   for the target-seq tables; their row-wise merge (rec_ids_group + rec_sparse_sgd_rows) is the
+ *   embedding gradient.  att_weight = the forward's softmax weights; att_w1_t = att_w1 transposed
+ *   [H1,4E].  Hidden activations are recomputed.  The attention MLP's own weight gradients are not
+ *   produced (not registered parameters in dygraph mode). */
+int rec_din_attention_pool_bwd(const rec_din_desc* desc, const int64_t* hist_item,
+                               const int64_t* hist_cat, const int64_t* tgt_item_seq,
+                               const int64_t* tgt_cat_seq, const float* w_hist_item,
+                               const float* w_hist_cat, const float* w_tgt_item_seq,
+                               const float* w_tgt_cat_seq, const float* att_w1,
+                               const float* att_w1_t, const float* att_b1, const float* att_w2,
+                               const float* att_b2, const float* att_w3, const float* att_weight,
+                               const float* d_out, float* d_hist, float* d_tgt_seq, void* stream);
+
 /* y[i,:] = softmax(x[i,:]) over n <= 64 columns (CrossNetMix expert gate, dcn_v2/net.py:313-316). */
 int rec_softmax_rows(int64_t m, int32_t n, const float* x, int32_t ldx, float* y, int32_t ldy,
                      void* stream);
@@ -250,6 +273,7 @@ typedef enum {
   REC_EPI_BIAS_SIGMOID = 5, /* sigmoid(acc + bias[j]) */
   REC_EPI_BIAS_TANH = 6,    /* tanh(acc + bias[j]); bias may be NULL */
   REC_EPI_ADD = 7,          /* acc + aux1[i,j] (+ bias[j], + aux0[i,j] when given) */
+  REC_EPI_DSIGMOID = 9,     /* acc * aux0[i,j] * (1 - aux0[i,j])   (sigmoid backward on dX, din/net.py MLPs) */
   REC_EPI_MOE = 8           /* aux1[i,j] + aux0[i,j] * row_scale[i] * (acc + bias[j])
                                (CrossNetMix, dcn_v2/net.py:301-317: aux0 = x_0, aux1 = running x_{l+1},
                                row_scale = softmax gate of this expert) */
@@ -301,6 +325,13 @@ int rec_sigmoid_logloss(int64_t batch, int64_t mean_over, const float* y1, const
                         const float* y_dnn,
                         const int64_t* label, float eps, float* pred, float* dz, float* loss_out,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* binary_cross_entropy_with_logits(reduction='mean') [EXT] (din/dygraph_model.py:58-61): loss_out[0] = mean,
+ * pred = sigmoid(logit), dz = (pred - label) / mean_over (0 -> batch).  label is float32 as the DIN reader
+ * feeds it.  workspace >= rec_logloss_workspace_bytes(batch). */
+int rec_bce_with_logits(int64_t batch, int64_t mean_over, const float* logit, const float* label,
+                        float* pred, float* dz, float* loss_out, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /* paddle.metric.Auc("ROC").update [EXT] (deepfm/dygraph_model.py:69-73,83-84):
  *   bucket = int(pred*num_thresholds); stat_pos[bucket] += label!=0; stat_neg[bucket] += label==0.

@@ -58,3 +58,80 @@ def bce_with_logits_mean(logit, label):
     """paddle.nn.functional.binary_cross_entropy_with_logits(reduction='mean') (din/dygraph_model.py:58-61)."""
     z, t = logit.astype(np.float64), label.astype(np.float64)
     return np.mean(np.maximum(z, 0) - z * t + np.log1p(np.exp(-np.abs(z))))
+
+
+# --------------------------------------------------------------------------
+# backward (what loss.backward() computes for din/net.py:139-184)
+# --------------------------------------------------------------------------
+def attention_pool_backward(h, q, mask, att_w, att_b, dout):
+    """Gradients of attention_pool w.r.t. h and q (and the attention MLP parameters).
+    Returns dict(dh [B,T,E], dq [B,T,E], dW=[...], db=[...])."""
+    B, T, E = h.shape
+    x = np.concatenate([h, q, h - q, h * q], axis=2)
+    a1 = sigmoid(x @ att_w[0] + att_b[0])
+    a2 = sigmoid(a1 @ att_w[1] + att_b[1])
+    c = np.asarray(E ** -0.5, dtype=h.dtype)
+    s = ((a2 @ att_w[2] + att_b[2])[..., 0] + mask.astype(h.dtype)) * c
+    s = s - s.max(axis=1, keepdims=True)
+    p = np.exp(s)
+    p = p / p.sum(axis=1, keepdims=True)                    # [B,T]
+    dp = (h * dout[:, None, :]).sum(axis=2)                 # [B,T]
+    dh = p[..., None] * dout[:, None, :]
+    ds = p * (dp - (p * dp).sum(axis=1, keepdims=True))
+    dl = (ds * c)[..., None]                                # [B,T,1]
+    dz2 = (dl @ att_w[2].T) * a2 * (1 - a2)
+    dz1 = (dz2 @ att_w[1].T) * a1 * (1 - a1)
+    dx = dz1 @ att_w[0].T                                   # [B,T,4E]
+    dh = dh + dx[..., :E] + dx[..., 2 * E:3 * E] + dx[..., 3 * E:] * q
+    dq = dx[..., E:2 * E] - dx[..., 2 * E:3 * E] + dx[..., 3 * E:] * h
+    dW = [np.einsum("btk,btj->kj", x, dz1), np.einsum("btk,btj->kj", a1, dz2), np.einsum("btk,btj->kj", a2, dl)]
+    db = [dz1.sum((0, 1)), dz2.sum((0, 1)), dl.sum((0, 1))]
+    return dict(dh=dh, dq=dq, dW=dW, db=db, p=p)
+
+
+def backward(p, att, hist_item, hist_cat, target_item, target_cat, mask, label):
+    """Gradients of mean BCE-with-logits (din/dygraph_model.py:58-61) w.r.t. the REGISTERED parameters
+    (embedding gradients returned dense, as Paddle does for is_sparse=False)."""
+    B, T = hist_item.shape
+    tis = np.repeat(target_item[:, None], T, 1)
+    tcs = np.repeat(target_cat[:, None], T, 1)
+    h = np.concatenate([p["hist_item_emb_attr.weight"][hist_item], p["hist_cat_emb_attr.weight"][hist_cat]], 2)
+    q = np.concatenate([p["target_item_seq_emb_attr.weight"][tis], p["target_cat_seq_emb_attr.weight"][tcs]], 2)
+    tc = np.concatenate([p["target_item_emb_attr.weight"][target_item], p["target_cat_emb_attr.weight"][target_cat]], 1)
+    m2 = mask.reshape(B, T)
+    pooled = attention_pool(h, q, m2, att[0], att[1])
+    c = pooled @ p["linearCon.weight"] + p["linearCon.bias"]
+    e0 = np.concatenate([c, tc], axis=1)
+    e1 = sigmoid(e0 @ p["linear_0.weight"] + p["linear_0.bias"])
+    e2 = sigmoid(e1 @ p["linear_1.weight"] + p["linear_1.bias"])
+    logit = e2 @ p["linear_2.weight"] + p["linear_2.bias"] + p["item_b_attr.weight"][target_item]
+    g = {}
+    dlogit = (sigmoid(logit) - label) / np.asarray(B, dtype=logit.dtype)
+    g["linear_2.weight"], g["linear_2.bias"] = e2.T @ dlogit, dlogit.sum(0)
+    d2 = (dlogit @ p["linear_2.weight"].T) * e2 * (1 - e2)
+    g["linear_1.weight"], g["linear_1.bias"] = e1.T @ d2, d2.sum(0)
+    d1 = (d2 @ p["linear_1.weight"].T) * e1 * (1 - e1)
+    g["linear_0.weight"], g["linear_0.bias"] = e0.T @ d1, d1.sum(0)
+    de0 = d1 @ p["linear_0.weight"].T
+    E = h.shape[2]
+    dc, dtc = de0[:, :E], de0[:, E:]
+    g["linearCon.weight"], g["linearCon.bias"] = pooled.T @ dc, dc.sum(0)
+    dpooled = dc @ p["linearCon.weight"].T
+    ab = attention_pool_backward(h, q, m2, att[0], att[1], dpooled)
+    Ei = p["hist_item_emb_attr.weight"].shape[1]
+
+    def scatter(name, ids, vals):
+        out = np.zeros_like(p[name])
+        np.add.at(out, ids.reshape(-1), vals.reshape(-1, vals.shape[-1]))
+        g[name] = out
+
+    scatter("hist_item_emb_attr.weight", hist_item, ab["dh"][..., :Ei])
+    scatter("hist_cat_emb_attr.weight", hist_cat, ab["dh"][..., Ei:])
+    scatter("target_item_seq_emb_attr.weight", tis, ab["dq"][..., :Ei])
+    scatter("target_cat_seq_emb_attr.weight", tcs, ab["dq"][..., Ei:])
+    scatter("target_item_emb_attr.weight", target_item, dtc[:, :Ei])
+    scatter("target_cat_emb_attr.weight", target_cat, dtc[:, Ei:])
+    scatter("item_b_attr.weight", target_item, dlogit)
+    g["_att"] = ab
+    g["_logit"] = logit
+    return g

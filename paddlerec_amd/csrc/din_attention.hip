@@ -35,6 +35,7 @@ struct DinArgs {
 };
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+__device__ __forceinline__ float dout_k_of(const float* dout, int64_t b, int E, int k) { return dout[b * E + k]; }
 
 __global__ __launch_bounds__(kBlock) void din_attention_fwd_kernel(DinArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -172,6 +173,226 @@ __global__ __launch_bounds__(kBlock) void din_attention_fwd_kernel(DinArgs a) {
   if (oob) atomicOr(a.status, REC_FLAG_INDEX_OOB);
 }
 
+// ------------------------------------------------------------------------------------------ backward
+// Gradient of the attention-pool w.r.t. the gathered rows: dh [B,T,E] (history item|cat), dq [B,T,E]
+// (target seq item|cat) — the per-position values whose row-wise merge is the embedding gradient.
+// Same tiling as the forward; the hidden activations are recomputed per tile instead of stored.
+//   pass 1 over the history: dp_t = dout . h_t,  sdp = sum_t p_t dp_t        (softmax backward needs it)
+//   pass 2 per tile: a1, a2 (recomputed) -> dl_t = p_t (dp_t - sdp) E^-0.5 -> dz2 = dl w3 * a2(1-a2)
+//                    -> dz1 = (dz2 W2^T) * a1(1-a1) -> dx = dz1 W1^T (W1 passed transposed: coalesced)
+//                    dh = p_t dout + dx_a + dx_c + dx_d*q ;  dq = dx_b - dx_c + dx_d*h
+// The attention MLP's own weight gradients are not produced: in the dygraph mode tools/trainer.py runs,
+// those layers are not registered parameters and stay frozen.
+struct DinBwdArgs {
+  DinArgs f;
+  const float* w1t;        // [H1][4E]  (att_w1 transposed)
+  const float* att_weight; // [B,T] softmax weights saved by the forward
+  const float* dout;       // [B,E]
+  float *dh, *dq;          // [B,T,E]
+};
+
+__global__ __launch_bounds__(kBlock) void din_attention_bwd_kernel(DinBwdArgs g) {
+  const DinArgs& a = g.f;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int E = a.Ei + a.Ec, H1 = a.H1, H2 = a.H2, T = a.T;
+  float* hs = smem;                    // [TP][E]
+  float* qs = hs + kDinTP * E;         // [TP][E]
+  float* a1 = qs + kDinTP * E;         // [TP][H1]   activations, then dz1 in place
+  float* a2 = a1 + kDinTP * H1;        // [TP][H2]   activations, then dz2 in place
+  float* w2s = a2 + kDinTP * H2;       // [H1][H2]
+  float* w3s = w2s + H1 * H2;          // [H2]
+  float* b1s = w3s + H2;               // [H1]
+  float* b2s = b1s + H1;               // [H2]
+  float* dls = b2s + H2;               // [TP] dl of the tile
+  float* red = dls + kDinTP;           // [kBlock/64] block reduction scratch
+  float* dps = red + kBlock / kWave;   // [T] dp_t of the whole history
+  const int tid = threadIdx.x;
+  for (int i = tid; i < H1 * H2; i += kBlock) w2s[i] = a.w2[i];
+  for (int i = tid; i < H2; i += kBlock) { w3s[i] = a.w3[i]; b2s[i] = a.b2[i]; }
+  for (int i = tid; i < H1; i += kBlock) b1s[i] = a.b1[i];
+  const float scale = 1.f / sqrtf((float)E);
+  const int j1 = tid % H1, pg1 = tid / H1, PG1 = kBlock / H1;
+  const int NP1 = (kDinTP + PG1 - 1) / PG1;
+  const bool on1 = pg1 < PG1;
+  const int j2 = tid % H2, pg2 = tid / H2, PG2 = kBlock / H2;
+  const int NP2 = (kDinTP + PG2 - 1) / PG2;
+  const bool on2 = pg2 < PG2;
+  const int e4 = E / 4;
+  // dx mapping: thread (kk, pgx) owns embedding dim kk for positions pgx, pgx+PGX, ...
+  const int kkx = tid % E, pgx = tid / E, PGX = kBlock / E;
+  const int NPX = (kDinTP + PGX - 1) / PGX;
+  const bool onx = pgx < PGX;
+  __syncthreads();
+
+  auto gather_tile = [&](int64_t b, int t0, bool with_q) {
+    for (int v = tid; v < kDinTP * e4; v += kBlock) {
+      const int p = v / e4, c4 = (v % e4) * 4;
+      const int t = t0 + p;
+      float4 hv = make_float4(0.f, 0.f, 0.f, 0.f), qv = hv;
+      if (t < T) {
+        const bool item = c4 < a.Ei;
+        const int64_t hid = item ? a.hist_item[b * T + t] : a.hist_cat[b * T + t];
+        const int64_t nrow = item ? a.n_item : a.n_cat;
+        const int ld = item ? a.ld_item : a.ld_cat;
+        const int c = item ? c4 : c4 - a.Ei;
+        const float* wh = item ? a.w_hist_item : a.w_hist_cat;
+        if (hid >= 0 && hid < nrow) hv = *reinterpret_cast<const float4*>(wh + hid * ld + c);
+        if (with_q) {
+          const int64_t qid = item ? a.tgt_item[b * T + t] : a.tgt_cat[b * T + t];
+          const float* wq = item ? a.w_tgt_item : a.w_tgt_cat;
+          if (qid >= 0 && qid < nrow) qv = *reinterpret_cast<const float4*>(wq + qid * ld + c);
+        }
+      }
+      *reinterpret_cast<float4*>(hs + p * E + c4) = hv;
+      if (with_q) *reinterpret_cast<float4*>(qs + p * E + c4) = qv;
+    }
+  };
+
+  for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const float dout_k = (tid < E) ? g.dout[b * E + tid] : 0.f;
+    // ---- pass 1: dp_t and sdp = sum_t p_t dp_t
+    float sdp_part = 0.f;
+    for (int t0 = 0; t0 < T; t0 += kDinTP) {
+      gather_tile(b, t0, false);
+      __syncthreads();
+      if (tid < kDinTP && t0 + tid < T) {
+        float dp = 0.f;
+        for (int k = 0; k < E; ++k) dp += g.dout[b * E + k] * hs[tid * E + k];
+        dps[t0 + tid] = dp;
+        sdp_part += g.att_weight[b * T + t0 + tid] * dp;
+      }
+      __syncthreads();
+    }
+    // block reduction of sdp_part (only threads < TP hold something): fixed order
+    {
+      float v = sdp_part;
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+      if (tid % kWave == 0) red[tid / kWave] = v;
+      __syncthreads();
+    }
+    float sdp = 0.f;
+    for (int w = 0; w < kBlock / kWave; ++w) sdp += red[w];
+    __syncthreads();
+
+    // ---- pass 2
+    for (int t0 = 0; t0 < T; t0 += kDinTP) {
+      gather_tile(b, t0, true);
+      __syncthreads();
+      if (on1) {   // recompute layer 1
+        float s1[kDinNP1];
+#pragma unroll
+        for (int i = 0; i < kDinNP1; ++i) s1[i] = 0.f;
+        const float* w = a.w1 + j1;
+        for (int kk = 0; kk < E; ++kk) {
+          const float wa = w[(int64_t)kk * H1], wb = w[(int64_t)(E + kk) * H1];
+          const float wc = w[(int64_t)(2 * E + kk) * H1], wd = w[(int64_t)(3 * E + kk) * H1];
+#pragma unroll
+          for (int i = 0; i < kDinNP1; ++i) {
+            const int p = pg1 + i * PG1;
+            if (i < NP1 && p < kDinTP) {
+              const float hv = hs[p * E + kk], qv = qs[p * E + kk];
+              s1[i] += hv * wa + qv * wb + (hv - qv) * wc + (hv * qv) * wd;
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < kDinNP1; ++i) {
+          const int p = pg1 + i * PG1;
+          if (i < NP1 && p < kDinTP) a1[p * H1 + j1] = sigmoidf_(s1[i] + b1s[j1]);
+        }
+      }
+      __syncthreads();
+      if (on2) {   // recompute layer 2
+        float s2[kDinNP2];
+#pragma unroll
+        for (int i = 0; i < kDinNP2; ++i) s2[i] = 0.f;
+        for (int k = 0; k < H1; ++k) {
+          const float wv = w2s[k * H2 + j2];
+#pragma unroll
+          for (int i = 0; i < kDinNP2; ++i) {
+            const int p = pg2 + i * PG2;
+            if (i < NP2 && p < kDinTP) s2[i] += a1[p * H1 + k] * wv;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < kDinNP2; ++i) {
+          const int p = pg2 + i * PG2;
+          if (i < NP2 && p < kDinTP) a2[p * H2 + j2] = sigmoidf_(s2[i] + b2s[j2]);
+        }
+      }
+      if (tid < kDinTP) {   // dl_t (softmax backward + scale)
+        const int t = t0 + tid;
+        dls[tid] = (t < T) ? g.att_weight[b * T + t] * (dps[t] - sdp) * scale : 0.f;
+      }
+      __syncthreads();
+      if (on2) {   // dz2 = dl * w3 * a2 (1 - a2), in place
+#pragma unroll
+        for (int i = 0; i < kDinNP2; ++i) {
+          const int p = pg2 + i * PG2;
+          if (i < NP2 && p < kDinTP) {
+            const float av = a2[p * H2 + j2];
+            a2[p * H2 + j2] = dls[p] * w3s[j2] * av * (1.f - av);
+          }
+        }
+      }
+      __syncthreads();
+      if (on1) {   // dz1 = (dz2 W2^T) * a1 (1 - a1), in place (each thread rewrites only its own slots)
+        float d1[kDinNP1];
+#pragma unroll
+        for (int i = 0; i < kDinNP1; ++i) d1[i] = 0.f;
+        for (int k = 0; k < H2; ++k) {
+          const float wv = w2s[j1 * H2 + k];
+#pragma unroll
+          for (int i = 0; i < kDinNP1; ++i) {
+            const int p = pg1 + i * PG1;
+            if (i < NP1 && p < kDinTP) d1[i] += a2[p * H2 + k] * wv;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < kDinNP1; ++i) {
+          const int p = pg1 + i * PG1;
+          if (i < NP1 && p < kDinTP) {
+            const float av = a1[p * H1 + j1];
+            a1[p * H1 + j1] = d1[i] * av * (1.f - av);
+          }
+        }
+      }
+      __syncthreads();
+      if (onx) {   // dx = dz1 W1^T, folded straight into dh / dq
+        float xa[kDinNP1], xb[kDinNP1], xc[kDinNP1], xd[kDinNP1];
+#pragma unroll
+        for (int i = 0; i < kDinNP1; ++i) xa[i] = xb[i] = xc[i] = xd[i] = 0.f;
+        for (int j = 0; j < H1; ++j) {
+          const float* wt = g.w1t + (int64_t)j * 4 * E + kkx;
+          const float wa = wt[0], wb = wt[E], wc = wt[2 * E], wd = wt[3 * E];
+#pragma unroll
+          for (int i = 0; i < kDinNP1; ++i) {
+            const int p = pgx + i * PGX;
+            if (i < NPX && p < kDinTP) {
+              const float dz = a1[p * H1 + j];
+              xa[i] += dz * wa; xb[i] += dz * wb; xc[i] += dz * wc; xd[i] += dz * wd;
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < kDinNP1; ++i) {
+          const int p = pgx + i * PGX;
+          const int t = t0 + p;
+          if (i < NPX && p < kDinTP && t < T) {
+            const float hv = hs[p * E + kkx], qv = qs[p * E + kkx];
+            const float pw = g.att_weight[b * T + t];
+            g.dh[(b * T + t) * (int64_t)E + kkx] = pw * dout_k_of(g.dout, b, E, kkx) + xa[i] + xc[i] + xd[i] * qv;
+            g.dq[(b * T + t) * (int64_t)E + kkx] = xb[i] - xc[i] + xd[i] * hv;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    (void)dout_k;
+  }
+}
+
 }  // namespace rec
 
 using namespace rec;
@@ -218,4 +439,48 @@ extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* 
   hipLaunchKernelGGL(din_attention_fwd_kernel, dim3((unsigned)grid), dim3(kBlock), shmem,
                      (hipStream_t)stream, a);
   return check_launch("rec_din_attention_pool_fwd");
+}
+
+extern "C" int rec_din_attention_pool_bwd(const rec_din_desc* d, const int64_t* hist_item,
+                                          const int64_t* hist_cat, const int64_t* tgt_item_seq,
+                                          const int64_t* tgt_cat_seq, const float* w_hist_item,
+                                          const float* w_hist_cat, const float* w_tgt_item_seq,
+                                          const float* w_tgt_cat_seq, const float* att_w1,
+                                          const float* att_w1_t, const float* att_b1,
+                                          const float* att_w2, const float* att_b2,
+                                          const float* att_w3, const float* att_weight,
+                                          const float* d_out, float* d_hist, float* d_tgt_seq,
+                                          void* stream) {
+  REC_REQUIRE(d, REC_EINVAL, "desc is NULL");
+  const int E = d->item_dim + d->cat_dim;
+  REC_REQUIRE(d->batch >= 0 && d->max_len > 0 && d->item_dim > 0 && d->cat_dim > 0 && d->hidden1 > 0 &&
+                  d->hidden2 > 0 && d->item_rows > 0 && d->cat_rows > 0, REC_EINVAL, "bad sizes");
+  REC_REQUIRE(d->item_dim % 4 == 0 && d->cat_dim % 4 == 0 && E <= kBlock / 2, REC_ESHAPE,
+              "item_dim/cat_dim must be multiples of 4 with item_dim+cat_dim <= %d", kBlock / 2);
+  REC_REQUIRE(d->hidden1 <= kBlock / 2 && d->hidden2 <= kBlock / 2, REC_ESHAPE, "hidden sizes must be <= %d",
+              kBlock / 2);
+  REC_REQUIRE(d->item_stride >= d->item_dim && d->cat_stride >= d->cat_dim && d->item_stride % 4 == 0 &&
+                  d->cat_stride % 4 == 0, REC_EINVAL, "table strides must be multiples of 4 and >= dims");
+  if (d->batch == 0) return REC_OK;
+  REC_REQUIRE(hist_item && hist_cat && tgt_item_seq && tgt_cat_seq && w_hist_item && w_hist_cat &&
+                  w_tgt_item_seq && w_tgt_cat_seq && att_w1 && att_w1_t && att_b1 && att_w2 && att_b2 &&
+                  att_w3 && att_weight && d_out && d_hist && d_tgt_seq, REC_EINVAL, "null pointer argument");
+  const int H1 = d->hidden1, H2 = d->hidden2;
+  const size_t shmem = sizeof(float) * ((size_t)2 * kDinTP * E + (size_t)kDinTP * (H1 + H2) + (size_t)H1 * H2 +
+                                        2 * H2 + H1 + kDinTP + kBlock / kWave + (size_t)d->max_len);
+  REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "history too long for the LDS buffers (%zu B)", shmem);
+  DinBwdArgs g;
+  DinArgs& a = g.f;
+  a.B = d->batch; a.T = d->max_len; a.Ei = d->item_dim; a.Ec = d->cat_dim; a.H1 = H1; a.H2 = H2;
+  a.n_item = d->item_rows; a.n_cat = d->cat_rows; a.ld_item = d->item_stride; a.ld_cat = d->cat_stride;
+  a.hist_item = hist_item; a.hist_cat = hist_cat; a.tgt_item = tgt_item_seq; a.tgt_cat = tgt_cat_seq;
+  a.mask = nullptr; a.w_hist_item = w_hist_item; a.w_hist_cat = w_hist_cat; a.w_tgt_item = w_tgt_item_seq;
+  a.w_tgt_cat = w_tgt_cat_seq; a.w1 = att_w1; a.b1 = att_b1; a.w2 = att_w2; a.b2 = att_b2; a.w3 = att_w3;
+  a.b3 = nullptr; a.out = nullptr; a.att_weight = nullptr; a.status = nullptr;
+  g.w1t = att_w1_t; g.att_weight = att_weight; g.dout = d_out; g.dh = d_hist; g.dq = d_tgt_seq;
+  int64_t grid = resident_blocks(din_attention_bwd_kernel, kBlock, shmem);
+  if (grid > d->batch) grid = d->batch;
+  hipLaunchKernelGGL(din_attention_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), shmem,
+                     (hipStream_t)stream, g);
+  return check_launch("rec_din_attention_pool_bwd");
 }

@@ -69,6 +69,33 @@ __global__ void fold_loss_kernel(const float* __restrict__ partial, int n, float
   if (threadIdx.x == 0) out[0] = red[0] * invB;
 }
 
+// binary_cross_entropy_with_logits(reduction='mean') [EXT] (din/dygraph_model.py:58-61) and its gradient:
+//   cost = max(z,0) - z*t + log1p(exp(-|z|));   d mean / dz = (sigmoid(z) - t) / B
+__global__ __launch_bounds__(kBlock) void bce_logits_kernel(int64_t B, float invB,
+                                                            const float* __restrict__ z,
+                                                            const float* __restrict__ label,
+                                                            float* __restrict__ pred, float* __restrict__ dz,
+                                                            float* __restrict__ partial) {
+  __shared__ float red[kBlock / kWave];
+  float local = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kBlock) {
+    const float zi = z[i], t = label[i];
+    local += fmaxf(zi, 0.f) - zi * t + log1pf(expf(-fabsf(zi)));
+    const float p = 1.f / (1.f + expf(-zi));
+    if (pred) pred[i] = p;
+    if (dz) dz[i] = (p - t) * invB;
+  }
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) local += __shfl_xor(local, o, kWave);
+  if (threadIdx.x % kWave == 0) red[threadIdx.x / kWave] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kBlock / kWave; ++w) t += red[w];
+    partial[blockIdx.x] = t;
+  }
+}
+
 // per-block LDS histograms (int32), flushed with 64-bit integer atomics: exact for any order
 __global__ __launch_bounds__(kBlock) void auc_hist_kernel(
     int64_t B, const float* __restrict__ pred, const int64_t* __restrict__ label, int T,
@@ -138,6 +165,23 @@ extern "C" int rec_sigmoid_logloss(int64_t batch, int64_t mean_over, const float
   hipLaunchKernelGGL(fold_loss_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)workspace,
                      (int)grid, inv, loss_out);
   return check_launch("rec_sigmoid_logloss");
+}
+
+extern "C" int rec_bce_with_logits(int64_t batch, int64_t mean_over, const float* logit,
+                                   const float* label, float* pred, float* dz, float* loss_out,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  REC_REQUIRE(batch > 0 && mean_over >= 0 && logit && label && loss_out, REC_EINVAL, "bad arguments");
+  REC_REQUIRE(workspace && workspace_bytes >= kLossBlocks * sizeof(float), REC_EWORKSPACE,
+              "workspace too small");
+  const float inv = 1.f / (float)(mean_over > 0 ? mean_over : batch);
+  int64_t grid = (batch + kBlock - 1) / kBlock;
+  if (grid > kLossBlocks) grid = kLossBlocks;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bce_logits_kernel, dim3((unsigned)grid), dim3(kBlock), 0, st, batch, inv, logit, label,
+                     pred, dz, (float*)workspace);
+  hipLaunchKernelGGL(fold_loss_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)workspace, (int)grid, inv,
+                     loss_out);
+  return check_launch("rec_bce_with_logits");
 }
 
 extern "C" int rec_auc_histogram(int64_t batch, const float* pred, const int64_t* label,

@@ -186,6 +186,37 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_rows_kernel(
   vstore<VEC>(V + so, v);
 }
 
+// paddle.optimizer.SGD on the touched rows (din/dygraph_model.py:64-73; rows with zero gradient do not move,
+// so updating only the merged rows IS dense SGD): p -= lr * sum of the row's duplicate gradients
+template <int VEC, int LANES>
+__global__ __launch_bounds__(kBlock) void sparse_sgd_rows_kernel(
+    int D, int stride, const int32_t* __restrict__ n_uniq, const int64_t* __restrict__ uniq,
+    const int32_t* __restrict__ seg_off, const int32_t* __restrict__ spos,
+    const float* __restrict__ grad, rec_grad_layout gl, float* __restrict__ P, float lr) {
+  const int64_t u = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
+  const int d0 = (threadIdx.x % LANES) * VEC;
+  if (u >= n_uniq[0] || d0 >= D) return;
+  float p[VEC], g[VEC];
+  const int64_t ro = uniq[u] * stride + d0;
+  vload<VEC>(p, P + ro);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+  for (int k = seg_off[u]; k < seg_off[u + 1]; ++k) {
+    float t[VEC];
+    vload<VEC>(t, grad + grad_offset(gl, spos[k], D) + d0);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] += t[i];
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) p[i] -= lr * g[i];
+  vstore<VEC>(P + ro, p);
+}
+
+__global__ void sgd_dense_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float lr) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] -= lr * g[i];
+}
+
 // sum over the merged rows of |g_row|^2 (global-norm clipping needs the norm of the MERGED sparse grad)
 template <int VEC, int LANES>
 __global__ __launch_bounds__(kBlock) void sparse_rows_sumsq_kernel(
@@ -492,4 +523,39 @@ extern "C" int rec_adam_dense(int64_t n, float* p, float* m, float* v, const flo
                      (hipStream_t)stream, n, p, m, v, g, grad_scale, lr_t, eps_t, hyper->beta1,
                      hyper->beta2);
   return check_launch("rec_adam_dense");
+}
+
+extern "C" int rec_sparse_sgd_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride,
+                                   const int32_t* n_uniq, const int64_t* uniq_rows,
+                                   const int32_t* seg_offset, const int32_t* sorted_pos,
+                                   const float* grad, const rec_grad_layout* grad_layout, float* P,
+                                   float lr, void* stream) {
+  rec_grad_layout gl = {1, 0, 0};
+  if (grad_layout) gl = *grad_layout;
+  REC_REQUIRE(n_max >= 0 && emb_dim > 0 && row_stride >= emb_dim && gl.div >= 1, REC_EINVAL, "bad sizes");
+  REC_REQUIRE(gl.group <= 0 || gl.group_stride >= (int64_t)gl.group * emb_dim, REC_EINVAL,
+              "grad group_stride too small");
+  REC_REQUIRE(n_uniq && uniq_rows && seg_offset && sorted_pos && grad && P, REC_EINVAL,
+              "null pointer argument");
+  if (n_max == 0) return REC_OK;
+  const bool gvec = ((uintptr_t)grad) % 16 == 0 && (gl.group <= 0 || gl.group_stride % 4 == 0) &&
+                    ((uintptr_t)P) % 16 == 0;
+  return dispatch_row_shape(emb_dim, gvec ? row_stride : row_stride | 1, [&](auto vec, auto lanes) -> int {
+    constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
+    const int64_t grid = (n_max * LANES + kBlock - 1) / kBlock;
+    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");
+    hipLaunchKernelGGL((sparse_sgd_rows_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock), 0,
+                       (hipStream_t)stream, emb_dim, row_stride, n_uniq, uniq_rows, seg_offset, sorted_pos,
+                       grad, gl, P, lr);
+    return check_launch("rec_sparse_sgd_rows");
+  });
+}
+
+extern "C" int rec_sgd_dense(int64_t n, float* p, const float* g, float lr, void* stream) {
+  REC_REQUIRE(n >= 0 && (n == 0 || (p && g)), REC_EINVAL, "bad arguments");
+  if (n == 0) return REC_OK;
+  int64_t grid = (n + kBlock - 1) / kBlock;
+  if (grid > kNumCU * 8) grid = kNumCU * 8;
+  hipLaunchKernelGGL(sgd_dense_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, n, p, g, lr);
+  return check_launch("rec_sgd_dense");
 }

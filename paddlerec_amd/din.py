@@ -5,7 +5,12 @@ Mirrors /root/reference/models/rank/din/net.py:20-184 (DINLayer) with the refere
 `attention_layer`, NOT in state_dict — App. B-9), linearCon and the top MLP `linear_{0,1,2}`.
 The attention-pool (net.py:141-173) is ONE fused kernel (rec_din_attention_pool_fwd); linearCon and the
 top MLP run on rec_gemm_f32 with the sigmoid in the epilogue; `logit + item_b` is the last GEMM's
-epilogue.  Training (backward of the attention-pool) is not built yet — see DESIGN.md.
+epilogue.  train_step adds the explicit backward chain (sigmoid' fused in the dX GEMMs, bias gradients
+from the dW GEMMs, rec_din_attention_pool_bwd for the rows) and the reference's optimizer: SGD with
+PiecewiseDecay([410000], [base_lr, 0.2]) (din/dygraph_model.py:64-73) — embedding rows through the
+merge-fused rec_sparse_sgd_rows (rows with zero gradient do not move under SGD, so this IS the dense
+update Paddle performs for is_sparse=False).  As in the reference's dygraph mode the attention MLP is
+not optimised (App. B-9).
 """
 import math
 
@@ -66,15 +71,15 @@ class DINLayer:
             dst.copy_(torch.as_tensor(src).to(self.device).reshape(dst.shape))
 
     def forward(self, hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq,
-                target_cat_seq):
+                target_cat_seq, _keep=None):
         p, E = self.params, self.firInDim
         B, T = hist_item_seq.shape
         mask2 = mask.reshape(B, T).contiguous()
-        pooled, _, _ = ops.din_attention_pool(
+        pooled, attw, _ = ops.din_attention_pool(
             hist_item_seq, hist_cat_seq, target_item_seq, target_cat_seq, mask2,
             p["hist_item_emb_attr.weight"], p["hist_cat_emb_attr.weight"],
             p["target_item_seq_emb_attr.weight"], p["target_cat_seq_emb_attr.weight"],
-            self.attention_w, self.attention_b, self.status, want_weights=False)       # net.py:141-173
+            self.attention_w, self.attention_b, self.status, want_weights=_keep is not None)  # net.py:141-173
         emb = torch.empty(B, 2 * E, dtype=torch.float32, device=self.device)           # net.py:178
         ops.gemm(pooled, p["linearCon.weight"], self.ws, epilogue="bias", bias=p["linearCon.bias"],
                  out=emb[:, :E])                                                         # net.py:175-176
@@ -84,9 +89,83 @@ class DINLayer:
         ops.emb_gather(tc, p["target_cat_emb_attr.weight"], None, self.status,
                        out=emb[:, E + self.item_emb_size:], out_group=1, out_group_stride=2 * E)
         item_b, _ = ops.emb_gather(ti, p["item_b_attr.weight"], None, self.status)      # net.py:147
-        x = ops.gemm(emb, p["linear_0.weight"], self.ws, epilogue="bias_sigmoid", bias=p["linear_0.bias"])
-        x = ops.gemm(x, p["linear_1.weight"], self.ws, epilogue="bias_sigmoid", bias=p["linear_1.bias"])
-        return ops.gemm(x, p["linear_2.weight"], self.ws, epilogue="add", bias=p["linear_2.bias"],
-                        aux1=item_b)                                                     # net.py:180-183
+        x1 = ops.gemm(emb, p["linear_0.weight"], self.ws, epilogue="bias_sigmoid", bias=p["linear_0.bias"])
+        x2 = ops.gemm(x1, p["linear_1.weight"], self.ws, epilogue="bias_sigmoid", bias=p["linear_1.bias"])
+        logit = ops.gemm(x2, p["linear_2.weight"], self.ws, epilogue="add", bias=p["linear_2.bias"],
+                         aux1=item_b)                                                    # net.py:180-183
+        if _keep is not None:
+            _keep.update(attw=attw, pooled=pooled, emb=emb, x1=x1, x2=x2, ti=ti, tc=tc)
+        return logit
 
     __call__ = forward
+
+    # ---------------------------------------------------------------- training
+    @staticmethod
+    def learning_rate(step, base_lr):
+        """paddle.optimizer.lr.PiecewiseDecay(boundaries=[410000], values=[base_lr, 0.2]) (dygraph_model.py:65-70)."""
+        return base_lr if step < 410000 else 0.2
+
+    def _sgd_rows(self, ids, grad_view, table, lr, row_stride_floats):
+        n = ids.numel()
+        key = n
+        grp = self._groups.get(key)
+        if grp is None:
+            grp = self._groups[key] = ops.IdGroups(n, self.device)
+        ops.ids_group(ids.reshape(-1), table.shape[0], None, self.ws_group, None, self.status, grp)
+        ops.sparse_sgd_rows(grp, grad_view, table, lr, grad_group=1, grad_group_stride=row_stride_floats)
+
+    def train_step(self, hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq,
+                   target_cat_seq, base_lr=0.85):
+        """din/dygraph_model.py:85-100 train_forward + backward + SGD step.  label float32 [B,1].
+        Returns (loss [1], pred [B,1])."""
+        if not hasattr(self, "_groups"):
+            self._groups, self.ws_group, self.step_count = {}, ops.Workspace(self.device), 0
+        p, E, Ei = self.params, self.firInDim, self.item_emb_size
+        B, T = hist_item_seq.shape
+        lr = self.learning_rate(self.step_count, base_lr)
+        self.step_count += 1
+        sv = {}
+        logit = self.forward(hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask,
+                             target_item_seq, target_cat_seq, _keep=sv)
+        pred, dz, loss = ops.bce_with_logits(logit, label.reshape(B, 1).contiguous(), self.ws)
+        g = {}
+        ws = self.ws
+
+        def lin_bwd(name, x, dy, act=None):
+            """dW, db of Linear `name` (input x, output-gradient dy); returns d x (sigmoid' of x fused when act)."""
+            g[name + ".weight"] = ops.gemm(x, dy, ws, trans_a=True, b_colsum=self._gbuf(name + ".bias"))
+            g[name + ".bias"] = self._gbuf(name + ".bias")
+            if act is None:
+                return ops.gemm(dy, p[name + ".weight"], ws, trans_b=True)
+            return ops.gemm(dy, p[name + ".weight"], ws, trans_b=True, epilogue="dsigmoid", aux0=act)
+
+        d2 = lin_bwd("linear_2", sv["x2"], dz, act=sv["x2"])
+        d1 = lin_bwd("linear_1", sv["x1"], d2, act=sv["x1"])
+        de0 = lin_bwd("linear_0", sv["emb"], d1)                       # [B, 2E] = [d linearCon out | d target_concat]
+        dpooled = lin_bwd("linearCon", sv["pooled"], de0[:, :E])
+        dh, dq = ops.din_attention_pool_bwd(
+            hist_item_seq, hist_cat_seq, target_item_seq, target_cat_seq,
+            p["hist_item_emb_attr.weight"], p["hist_cat_emb_attr.weight"],
+            p["target_item_seq_emb_attr.weight"], p["target_cat_seq_emb_attr.weight"],
+            self.attention_w, self.attention_b, sv["attw"], dpooled)
+        self._last = dict(dh=dh, dq=dq, de0=de0, dz=dz, dense=g)
+        # ---- SGD (dygraph_model.py:64-73).  Embedding tables: merged rows; dense: in place.
+        self._sgd_rows(hist_item_seq, dh, p["hist_item_emb_attr.weight"], lr, E)
+        self._sgd_rows(hist_cat_seq, dh[:, :, Ei:], p["hist_cat_emb_attr.weight"], lr, E)
+        self._sgd_rows(target_item_seq, dq, p["target_item_seq_emb_attr.weight"], lr, E)
+        self._sgd_rows(target_cat_seq, dq[:, :, Ei:], p["target_cat_seq_emb_attr.weight"], lr, E)
+        self._sgd_rows(sv["ti"], de0[:, E:], p["target_item_emb_attr.weight"], lr, 2 * E)
+        self._sgd_rows(sv["tc"], de0[:, E + Ei:], p["target_cat_emb_attr.weight"], lr, 2 * E)
+        self._sgd_rows(sv["ti"], dz, p["item_b_attr.weight"], lr, 1)
+        for name in ("linear_0", "linear_1", "linear_2", "linearCon"):
+            ops.sgd_dense(p[name + ".weight"], g[name + ".weight"], lr)
+            ops.sgd_dense(p[name + ".bias"], g[name + ".bias"], lr)
+        return loss, pred
+
+    def _gbuf(self, name):
+        if not hasattr(self, "_gb"):
+            self._gb = {}
+        b = self._gb.get(name)
+        if b is None:
+            b = self._gb[name] = torch.empty_like(self.params[name])
+        return b

@@ -353,6 +353,59 @@ def din_attention_pool(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, mask, w_h
     return out, attw, status
 
 
+def din_attention_pool_bwd(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_hist_item, w_hist_cat,
+                           w_tgt_item_seq, w_tgt_cat_seq, att_w, att_b, att_weight, d_out):
+    """-> (d_hist [B,T,E], d_tgt_seq [B,T,E]): per-position gradients of the gathered rows."""
+    B, T = hist_item.shape
+    Ei, ldi = _chk_table(w_hist_item, "w_hist_item")
+    Ec, ldc = _chk_table(w_hist_cat, "w_hist_cat")
+    E, H1, H2 = Ei + Ec, att_w[0].shape[1], att_w[1].shape[1]
+    _chk(att_weight, torch.float32, "att_weight", (B, T))
+    _chk(d_out, torch.float32, "d_out", (B, E))
+    w1t = att_w[0].t().contiguous()
+    dev = hist_item.device
+    dh = torch.empty(B, T, E, dtype=torch.float32, device=dev)
+    dq = torch.empty(B, T, E, dtype=torch.float32, device=dev)
+    d = DinDesc(B, T, Ei, Ec, H1, H2, w_hist_item.shape[0], w_hist_cat.shape[0], ldi, ldc)
+    check(lib().rec_din_attention_pool_bwd(
+        C.byref(d), _p(hist_item), _p(hist_cat), _p(tgt_item_seq), _p(tgt_cat_seq), _p(w_hist_item),
+        _p(w_hist_cat), _p(w_tgt_item_seq), _p(w_tgt_cat_seq), _p(att_w[0]), _p(w1t), _p(att_b[0]),
+        _p(att_w[1]), _p(att_b[1]), _p(att_w[2]), _p(att_weight), _p(d_out), _p(dh), _p(dq), _stream()),
+        "rec_din_attention_pool_bwd")
+    return dh, dq
+
+
+def sparse_sgd_rows(groups, grad, P, lr, grad_div=1, grad_group=0, grad_group_stride=0):
+    D, stride = _chk_table(P, "P")
+    check(lib().rec_sparse_sgd_rows(groups.n, D, stride, _p(groups.n_uniq), _p(groups.uniq_rows),
+                                    _p(groups.seg_offset), _p(groups.sorted_pos), _p(grad),
+                                    C.byref(GradLayout(int(grad_div), int(grad_group), int(grad_group_stride))),
+                                    _p(P), float(lr), _stream()), "rec_sparse_sgd_rows")
+
+
+def sgd_dense(p, g, lr):
+    _chk(p, torch.float32, "p")
+    _chk(g, torch.float32, "g")
+    check(lib().rec_sgd_dense(p.numel(), _p(p), _p(g), float(lr), _stream()), "rec_sgd_dense")
+
+
+def bce_with_logits(logit, label, ws, mean_over=0):
+    """-> pred [B,1], dz [B,1], loss [1]   (label float32 [B,1])"""
+    B = logit.numel()
+    _chk(logit, torch.float32, "logit")
+    _chk(label, torch.float32, "label")
+    dev = logit.device
+    pred = torch.empty(B, 1, dtype=torch.float32, device=dev)
+    dz = torch.empty(B, 1, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    nbytes = C.c_size_t(0)
+    check(lib().rec_logloss_workspace_bytes(B, C.byref(nbytes)))
+    w = ws.get(nbytes.value)
+    check(lib().rec_bce_with_logits(B, int(mean_over), _p(logit), _p(label), _p(pred), _p(dz), _p(loss), _p(w),
+                                    C.c_size_t(w.numel()), _stream()), "rec_bce_with_logits")
+    return pred, dz, loss
+
+
 def softmax_rows(x, out=None):
     ldx = _chk_mat(x, "x")
     if out is None:

@@ -86,3 +86,89 @@ def test_attention_pool_known_answers(engine_lib):
     _, _, status = ops.din_attention_pool(T(hi2), T(hc), T(hi), T(hc), T(mask), *[T(t) for t in tabs],
                                           [T(w) for w in zw], [T(b) for b in zb])
     assert int(status.item()) & 1
+
+
+def _din_problem(rng, B, Tn, ni, nc):
+    lens = rng.integers(1, Tn + 1, B)
+    lens[0] = Tn
+    hi = np.zeros((B, Tn), np.int64); hc = np.zeros((B, Tn), np.int64)
+    for b in range(B):
+        hi[b, :lens[b]] = rng.integers(1, ni, lens[b]); hc[b, :lens[b]] = rng.integers(1, nc, lens[b])
+    mask = np.where(np.arange(Tn)[None] < lens[:, None], 0, -1000000000).astype(np.int64)
+    ti = rng.integers(1, ni, B).astype(np.int64); tc = rng.integers(1, nc, B).astype(np.int64)
+    label = (rng.random((B, 1)) < 0.5).astype(np.float32)
+    return hi, hc, ti, tc, mask, label
+
+
+@pytest.mark.parametrize("B,Tn,Ei,Ec", [(5, 7, 8, 8), (40, 70, 64, 64), (3, 33, 32, 96)])
+def test_attention_pool_bwd_vs_oracle(engine_lib, B, Tn, Ei, Ec):
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(B * Tn)
+    ni, nc, E = 200, 41, Ei + Ec
+    tabs = [rng.uniform(-0.3, 0.3, (n, d)).astype(np.float32) for n, d in ((ni, Ei), (nc, Ec), (ni, Ei), (nc, Ec))]
+    hi, hc, ti, tc, mask, _ = _din_problem(rng, B, Tn, ni, nc)
+    tis, tcs = np.repeat(ti[:, None], Tn, 1), np.repeat(tc[:, None], Tn, 1)
+    aw = [rng.uniform(-0.3, 0.3, s).astype(np.float32) for s in ((4 * E, 80), (80, 40), (40, 1))]
+    ab = [rng.uniform(-0.1, 0.1, s).astype(np.float32) for s in ((80,), (40,), (1,))]
+    dout = rng.standard_normal((B, E)).astype(np.float32)
+    taw, tab, tt = [T(w) for w in aw], [T(b) for b in ab], [T(t) for t in tabs]
+    out, attw, _ = ops.din_attention_pool(T(hi), T(hc), T(tis), T(tcs), T(mask), *tt, taw, tab)
+    dh, dq = ops.din_attention_pool_bwd(T(hi), T(hc), T(tis), T(tcs), *tt, taw, tab, attw, T(dout))
+    h = np.concatenate([tabs[0][hi], tabs[1][hc]], 2)
+    q = np.concatenate([tabs[2][tis], tabs[3][tcs]], 2)
+    ref = Dn.attention_pool_backward(h.astype(np.float64), q.astype(np.float64), mask.astype(np.float64),
+                                     [w.astype(np.float64) for w in aw], [b.astype(np.float64) for b in ab],
+                                     dout.astype(np.float64))
+    scale = np.abs(ref["dh"]).max()
+    np.testing.assert_allclose(N_(dh), ref["dh"], rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(N_(dq), ref["dq"], rtol=1e-4, atol=1e-5 * scale)
+    assert np.all(N_(dh)[mask != 0] == 0.0) and np.all(N_(dq)[mask != 0] == 0.0)   # padding: exactly zero
+
+
+def test_din_train_step_golden_grads_and_sgd(engine_lib):
+    """Gradients of every registered parameter vs the reference's autograd (golden), then the SGD step."""
+    from paddlerec_amd.din import DINLayer
+    g = load_golden("din")
+    p = {k[2:]: v for k, v in g.items() if k.startswith("p.")}
+    m = DINLayer(8, 8, "sigmoid", False, True, 301, 41, device=DEV)
+    m.set_dict(p)
+    m.set_attention([g["att_w%d" % i] for i in range(3)], [g["att_b%d" % i] for i in range(3)])
+    B, Tn = g["hist_item"].shape
+    tis = np.repeat(g["target_item"][:, None], Tn, 1); tcs = np.repeat(g["target_cat"][:, None], Tn, 1)
+    lr = 0.85
+    loss, pred = m.train_step(T(g["hist_item"]), T(g["hist_cat"]), T(g["target_item"]), T(g["target_cat"]),
+                              T(g["label"]), T(g["mask"]), T(tis), T(tcs), base_lr=lr)
+    np.testing.assert_allclose(N_(loss)[0], g["loss"], rtol=1e-5)
+    for name in ("linear_0", "linear_1", "linear_2", "linearCon"):
+        for part in ("weight", "bias"):
+            k = "%s.%s" % (name, part)
+            np.testing.assert_allclose(N_(m._last["dense"][k]).reshape(g["g." + k].shape), g["g." + k],
+                                       rtol=3e-4, atol=3e-7, err_msg=k)
+    # after one SGD step every registered parameter equals p - lr * golden gradient
+    sd = m.state_dict()
+    for k, v in g.items():
+        if k.startswith("g."):
+            np.testing.assert_allclose(N_(sd[k[2:]]), p[k[2:]] - lr * v, rtol=2e-4, atol=2e-6, err_msg=k)
+    assert int(m.status.item()) == 0
+
+
+def test_din_train_steps_vs_oracle(engine_lib):
+    from paddlerec_amd.din import DINLayer
+    rng = np.random.default_rng(9)
+    ni, nc, B, Tn = 120, 30, 48, 40
+    m = DINLayer(16, 16, "sigmoid", False, True, ni, nc, device=DEV)
+    with torch.no_grad():
+        m.params["item_b_attr.weight"].copy_(T((rng.standard_normal((ni, 1)) * 0.1).astype(np.float32)))
+    p = {k: N_(v).copy() for k, v in m.state_dict().items()}
+    att = ([N_(w).copy() for w in m.attention_w], [N_(b).copy() for b in m.attention_b])
+    lr = 0.5
+    for step in range(2):
+        hi, hc, ti, tc, mask, label = _din_problem(rng, B, Tn, ni, nc)
+        tis, tcs = np.repeat(ti[:, None], Tn, 1), np.repeat(tc[:, None], Tn, 1)
+        loss, pred = m.train_step(T(hi), T(hc), T(ti), T(tc), T(label), T(mask), T(tis), T(tcs), base_lr=lr)
+        grads = Dn.backward(p, att, hi, hc, ti, tc, mask, label)
+        np.testing.assert_allclose(N_(loss)[0], Dn.bce_with_logits_mean(grads["_logit"], label), rtol=2e-5)
+        for k in p:
+            p[k] = (p[k] - lr * np.asarray(grads[k]).reshape(p[k].shape)).astype(np.float32)
+    for k, v in m.state_dict().items():
+        np.testing.assert_allclose(N_(v), p[k], rtol=2e-4, atol=3e-6, err_msg=k)

@@ -240,3 +240,18 @@ def test_din_oracle_matches_reference_net():
     out = Dn.attention_pool(h, q, mask, zero_w, zero_b)
     want = np.stack([h[b, :lens[b]].mean(0) for b in range(B)])
     np.testing.assert_allclose(out, want, rtol=1e-6, atol=1e-7)
+
+
+def test_din_oracle_backward_matches_reference_autograd():
+    from oracle import din_ref as Dn
+    g = load_golden("din")
+    p = {k[2:]: v for k, v in g.items() if k.startswith("p.")}
+    att = ([g["att_w%d" % i] for i in range(3)], [g["att_b%d" % i] for i in range(3)])
+    grads = Dn.backward(p, att, g["hist_item"], g["hist_cat"], g["target_item"], g["target_cat"],
+                        g["mask"][:, :, 0], g["label"])
+    n = 0
+    for k, v in g.items():
+        if k.startswith("g."):
+            np.testing.assert_allclose(np.asarray(grads[k[2:]]).reshape(v.shape), v, rtol=3e-4, atol=3e-7, err_msg=k)
+            n += 1
+    assert n == 15
