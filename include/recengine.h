@@ -249,6 +249,16 @@ int rec_din_attention_pool_bwd(const rec_din_desc* desc, const int64_t* hist_ite
                                const float* att_b2, const float* att_w3, const float* att_weight,
                                const float* d_out, float* d_hist, float* d_tgt_seq, void* stream);
 
+/* CrossNetMix backward glue for one expert (dcn_v2/net.py:301-317), one pass over [m,n]:
+ *   dU = dX*X0*p_e;  dX0_acc (+)= dX*p_e*U;  dp[i] = sum_j dX*X0*U      (p_e = prob[i*prob_stride])
+ * and the softmax backward of the gate: dz = p * (dp - sum_e p_e dp_e) over n <= 64 columns. */
+int rec_moe_bwd_prep(int64_t m, int32_t n, const float* dX, int32_t ld_dx, const float* X0,
+                     int32_t ld_x0, const float* U, int32_t ld_u, const float* prob, int32_t prob_stride,
+                     float* dU, int32_t ld_du, float* dX0_acc, int32_t ld_acc, int32_t accumulate,
+                     float* dp, int32_t dp_stride, void* stream);
+int rec_softmax_rows_bwd(int64_t m, int32_t n, const float* p, int32_t ldp, const float* dp,
+                         int32_t lddp, float* dz, int32_t lddz, void* stream);
+
 /* y[i,:] = softmax(x[i,:]) over n <= 64 columns (CrossNetMix expert gate, dcn_v2/net.py:313-316). */
 int rec_softmax_rows(int64_t m, int32_t n, const float* x, int32_t ldx, float* y, int32_t ldy,
                      void* stream);
@@ -273,6 +283,7 @@ typedef enum {
   REC_EPI_BIAS_SIGMOID = 5, /* sigmoid(acc + bias[j]) */
   REC_EPI_BIAS_TANH = 6,    /* tanh(acc + bias[j]); bias may be NULL */
   REC_EPI_ADD = 7,          /* acc + aux1[i,j] (+ bias[j], + aux0[i,j] when given) */
+  REC_EPI_DTANH = 10,       /* acc * (1 - aux0[i,j]^2)             (tanh backward on dX, CrossNetMix) */
   REC_EPI_DSIGMOID = 9,     /* acc * aux0[i,j] * (1 - aux0[i,j])   (sigmoid backward on dX, din/net.py MLPs) */
   REC_EPI_MOE = 8           /* aux1[i,j] + aux0[i,j] * row_scale[i] * (acc + bias[j])
                                (CrossNetMix, dcn_v2/net.py:301-317: aux0 = x_0, aux1 = running x_{l+1},

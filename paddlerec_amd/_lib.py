@@ -56,7 +56,7 @@ class GemmEpilogueArgs(C.Structure):
 
 
 EPI = dict(none=0, bias=1, bias_relu=2, relu_mask=3, cross=4, bias_sigmoid=5, bias_tanh=6, add=7, moe=8,
-           dsigmoid=9)
+           dsigmoid=9, dtanh=10)
 
 _P = C.c_void_p
 _I64, _I32, _F, _SZ = C.c_int64, C.c_int32, C.c_float, C.c_size_t
@@ -88,6 +88,9 @@ SIGNATURES = {
     "rec_sparse_sgd_rows": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P, _F, _P]),
     "rec_sgd_dense": (C.c_int, [_I64, _P, _P, _F, _P]),
     "rec_bce_with_logits": (C.c_int, [_I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "rec_moe_bwd_prep": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _I32,
+                                   _P, _I32, _P]),
+    "rec_softmax_rows_bwd": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P, _I32, _P]),
     "rec_softmax_rows": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P]),
     "rec_cross_bwd_prep": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _I32, _P]),
     "rec_logloss_workspace_bytes": (C.c_int, [_I64, C.POINTER(_SZ)]),

@@ -47,6 +47,45 @@ __global__ __launch_bounds__(kBlock) void cross_bwd_prep_kernel(
   }
 }
 
+// CrossNetMix backward glue for one expert (dcn_v2/net.py:301-317), one wave per row, float4 lanes:
+//   du  = dX * x0 * p_e            (gradient of u_e = U_e v + bias)
+//   acc = (accumulate ? acc : 0) + dX * p_e * u_e      (gradient reaching x_0 through the Hadamard product)
+//   dp_e[i] = sum_j dX * x0 * u_e                       (gradient of the gate probability)
+__global__ __launch_bounds__(kBlock) void moe_bwd_prep_kernel(
+    int64_t M, int N, const float* __restrict__ dX, int64_t ld_dx, const float* __restrict__ X0,
+    int64_t ld_x0, const float* __restrict__ U, int64_t ld_u, const float* __restrict__ prob,
+    int64_t prob_stride, float* __restrict__ dU, int64_t ld_du, float* __restrict__ acc, int64_t ld_acc,
+    int accumulate, float* __restrict__ dp, int64_t dp_stride) {
+  const int lane = threadIdx.x % kWave;
+  const int64_t wpb = kBlock / kWave;
+  for (int64_t i = (int64_t)blockIdx.x * wpb + threadIdx.x / kWave; i < M; i += (int64_t)gridDim.x * wpb) {
+    const float pe = prob[i * prob_stride];
+    float dot = 0.f;
+    for (int j = lane; j < N; j += kWave) {
+      const float g = dX[i * ld_dx + j], x = X0[i * ld_x0 + j], u = U[i * ld_u + j];
+      dU[i * ld_du + j] = g * x * pe;
+      const float a = g * pe * u;
+      acc[i * ld_acc + j] = accumulate ? acc[i * ld_acc + j] + a : a;
+      dot += g * x * u;
+    }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, kWave);
+    if (lane == 0) dp[i * dp_stride] = dot;
+  }
+}
+
+// softmax backward over a handful of columns: dz = p * (dp - sum_e p_e dp_e)
+__global__ __launch_bounds__(kBlock) void softmax_rows_bwd_kernel(int64_t M, int E, const float* __restrict__ p,
+                                                                  int64_t ldp, const float* __restrict__ dp,
+                                                                  int64_t lddp, float* __restrict__ dz,
+                                                                  int64_t lddz) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < M; i += (int64_t)gridDim.x * kBlock) {
+    float s = 0.f;
+    for (int e = 0; e < E; ++e) s += p[i * ldp + e] * dp[i * lddp + e];
+    for (int e = 0; e < E; ++e) dz[i * lddz + e] = p[i * ldp + e] * (dp[i * lddp + e] - s);
+  }
+}
+
 // row-wise softmax over a handful of columns (CrossNetMix gate, dcn_v2/net.py:315: E = num_experts)
 __global__ __launch_bounds__(kBlock) void softmax_rows_kernel(int64_t M, int E,
                                                               const float* __restrict__ x, int64_t ldx,
@@ -94,4 +133,33 @@ extern "C" int rec_cross_bwd_prep(int64_t m, int32_t n, const float* dX, int32_t
                      m, n, dX, (int64_t)ld_dx, X0, (int64_t)ld_x0, U, (int64_t)ld_u, dU, (int64_t)ld_du,
                      dX0_acc, (int64_t)ld_acc, accumulate, vec);
   return check_launch("rec_cross_bwd_prep");
+}
+
+extern "C" int rec_moe_bwd_prep(int64_t m, int32_t n, const float* dX, int32_t ld_dx, const float* X0,
+                                int32_t ld_x0, const float* U, int32_t ld_u, const float* prob,
+                                int32_t prob_stride, float* dU, int32_t ld_du, float* dX0_acc,
+                                int32_t ld_acc, int32_t accumulate, float* dp, int32_t dp_stride,
+                                void* stream) {
+  REC_REQUIRE(m >= 0 && n > 0 && ld_dx >= n && ld_x0 >= n && ld_u >= n && ld_du >= n && ld_acc >= n &&
+                  prob_stride >= 1 && dp_stride >= 1, REC_EINVAL, "bad sizes");
+  if (m == 0) return REC_OK;
+  REC_REQUIRE(dX && X0 && U && prob && dU && dX0_acc && dp, REC_EINVAL, "null pointer argument");
+  int64_t grid = (m + kBlock / kWave - 1) / (kBlock / kWave);
+  if (grid > kNumCU * 8) grid = kNumCU * 8;
+  hipLaunchKernelGGL(moe_bwd_prep_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, m, n,
+                     dX, (int64_t)ld_dx, X0, (int64_t)ld_x0, U, (int64_t)ld_u, prob, (int64_t)prob_stride, dU,
+                     (int64_t)ld_du, dX0_acc, (int64_t)ld_acc, accumulate, dp, (int64_t)dp_stride);
+  return check_launch("rec_moe_bwd_prep");
+}
+
+extern "C" int rec_softmax_rows_bwd(int64_t m, int32_t n, const float* p, int32_t ldp, const float* dp,
+                                    int32_t lddp, float* dz, int32_t lddz, void* stream) {
+  REC_REQUIRE(m >= 0 && n > 0 && n <= 64 && ldp >= n && lddp >= n && lddz >= n, REC_EINVAL, "bad sizes");
+  if (m == 0) return REC_OK;
+  REC_REQUIRE(p && dp && dz, REC_EINVAL, "null pointer argument");
+  int64_t grid = (m + kBlock - 1) / kBlock;
+  if (grid > kNumCU * 8) grid = kNumCU * 8;
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, m, n,
+                     p, (int64_t)ldp, dp, (int64_t)lddp, dz, (int64_t)lddz);
+  return check_launch("rec_softmax_rows_bwd");
 }

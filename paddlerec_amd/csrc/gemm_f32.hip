@@ -133,6 +133,10 @@ __device__ __forceinline__ float apply_epi(float acc, int64_t i, int j, const Ep
   if (EPI == REC_EPI_BIAS_RELU) return fmaxf(acc + e.bias[j], 0.f);
   if (EPI == REC_EPI_RELU_MASK) return e.aux0[i * e.ld0 + j] > 0.f ? acc : 0.f;
   if (EPI == REC_EPI_CROSS) return e.aux1[i * e.ld1 + j] + e.aux0[i * e.ld0 + j] * (acc + e.bias[j]);
+  if (EPI == REC_EPI_DTANH) {
+    const float a = e.aux0[i * e.ld0 + j];
+    return acc * (1.f - a * a);
+  }
   if (EPI == REC_EPI_DSIGMOID) {
     const float a = e.aux0[i * e.ld0 + j];
     return acc * a * (1.f - a);
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void colsum_reduce_kernel(int N, int splits
 }
 
 // column sums of G [M,N] (bias gradients): deterministic two-level reduction
-constexpr int kColsumRows = 512;
+constexpr int kColsumRows = 64;
 __global__ __launch_bounds__(kBlock) void colsum_partial_kernel(int64_t M, int N, int64_t ld,
                                                                 const float* __restrict__ G,
                                                                 float* __restrict__ partial) {
@@ -396,7 +400,7 @@ static int check_gemm(const rec_gemm_desc* d) {
   REC_REQUIRE(d->m >= 0 && d->n > 0 && d->k > 0, REC_EINVAL, "bad sizes M=%lld N=%d K=%d",
               (long long)d->m, d->n, d->k);
   REC_REQUIRE(d->lda > 0 && d->ldb > 0 && d->ldc >= d->n, REC_EINVAL, "bad leading dimensions");
-  REC_REQUIRE(d->epilogue >= 0 && d->epilogue <= REC_EPI_DSIGMOID, REC_EINVAL, "unknown epilogue %d",
+  REC_REQUIRE(d->epilogue >= 0 && d->epilogue <= REC_EPI_DTANH, REC_EINVAL, "unknown epilogue %d",
               d->epilogue);
   return REC_OK;
 }
@@ -468,7 +472,7 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
                 epi == REC_EPI_BIAS_SIGMOID || epi == REC_EPI_MOE) || bias, REC_EINVAL,
               "epilogue needs bias");
   REC_REQUIRE(!(epi == REC_EPI_RELU_MASK || epi == REC_EPI_CROSS || epi == REC_EPI_MOE ||
-                epi == REC_EPI_DSIGMOID) ||
+                epi == REC_EPI_DSIGMOID || epi == REC_EPI_DTANH) ||
                   (aux0 && ld_aux0 >= desc->n), REC_EINVAL, "epilogue needs aux0");
   REC_REQUIRE(!(epi == REC_EPI_CROSS || epi == REC_EPI_ADD || epi == REC_EPI_MOE) ||
                   (aux1 && ld_aux1 >= desc->n), REC_EINVAL, "epilogue needs aux1");
@@ -514,6 +518,7 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
     REC_EPI_CASE(REC_EPI_ADD)
     REC_EPI_CASE(REC_EPI_MOE)
     REC_EPI_CASE(REC_EPI_DSIGMOID)
+    REC_EPI_CASE(REC_EPI_DTANH)
   }
 #undef REC_EPI_CASE
   if (b_colsum)

@@ -10,8 +10,8 @@ rec_sparse_adam_rows with the clipping coefficient, rec_sumsq / rec_sparse_rows_
 Scope notes: Dropout(0.5) of the reference's train mode (App. B-10) is not applied —
 results are those of eval() mode, the only mode in which the reference's outputs are reproducible;
 L2Decay(1e-7) on the DNN weights (net.py:164-170) is below the fp32 parity tolerance and omitted;
-the sparse optimizer is lazy Adam (see deepfm.py).  Training is implemented for CrossNetV2
-(BASELINE config 3); CrossNetMix has forward (inference) only.
+the sparse optimizer is lazy Adam (see deepfm.py).  Training covers both cross networks: CrossNetV2
+(BASELINE config 3) and the shipped CrossNetMix (low-rank mixture of experts).
 """
 import math
 
@@ -162,8 +162,8 @@ class DCN_V2Layer:
             us.append(u)
         return x, xs, us
 
-    def _cross_mix(self, feat, out_last=None):
-        """net.py:278-320 (row-vector form).  Forward only."""
+    def _cross_mix(self, feat, out_last=None, saved=None):
+        """net.py:278-320 (row-vector form).  saved (list, optional): per layer (x_l, t1, t2, prob)."""
         p, k = self.dense.p, self.k
         E, r = self.num_experts, self.low_rank
         B = feat.shape[0]
@@ -184,6 +184,8 @@ class DCN_V2Layer:
             for e in range(E):
                 k.gemm(t2[:, e * r:(e + 1) * r], U[e], self.ws, trans_b=True, epilogue="moe", bias=bias,
                        aux0=feat, aux1=x if e == 0 else x_next, row_scale=prob[:, e], out=x_next)   # :301-317
+            if saved is not None:
+                saved.append((x, t1, t2, prob))
             x = x_next
         return x
 
@@ -205,7 +207,8 @@ class DCN_V2Layer:
         saved = dict(feat=feat)
         if self.is_Stacked:
             if self.use_low_rank_mixture:
-                cross = self._cross_mix(feat)
+                saved["mix"] = []
+                cross = self._cross_mix(feat, saved=saved["mix"] if keep else None)
             else:
                 cross, saved["xs"], saved["us"] = self._cross_v2(feat)
             logit, acts = k.mlp_forward(cross, W + [p["fc.weight"]], b + [p["fc.bias"]], self.ws)
@@ -213,7 +216,8 @@ class DCN_V2Layer:
         else:
             last = torch.empty(B, n_out + self.d, dtype=torch.float32, device=self.device)      # net.py:129
             if self.use_low_rank_mixture:
-                self._cross_mix(feat, out_last=last[:, n_out:])
+                saved["mix"] = []
+                self._cross_mix(feat, out_last=last[:, n_out:], saved=saved["mix"] if keep else None)
             else:
                 _, saved["xs"], saved["us"] = self._cross_v2(feat, out_last=last[:, n_out:])
             _, acts = k.mlp_forward(feat, W, b, self.ws, relu_last=True, out_last=last[:, :n_out])
@@ -241,8 +245,6 @@ class DCN_V2Layer:
         """dcn_v2/dygraph_model.py:103-127 train_forward + backward + Adam with ClipGradByGlobalNorm.
         dlogit ([B,1], optional): d loss / d logit supplied by the caller instead of the log-loss head
         (custom losses; the golden-gradient tests use d pred.sum()).  Returns (loss [1], pred [B,1])."""
-        if self.use_low_rank_mixture:
-            raise ops.RecError("training is implemented for CrossNetV2 only (CrossNetMix: forward only)")
         k, p, g = self.k, self.dense.p, self.dense.g
         ids = self._concat_ids(sparse_inputs)
         B, S = ids.shape
@@ -274,17 +276,21 @@ class DCN_V2Layer:
                 ddnn = k.gemm(dz, fcw[:n_out], self.ws, trans_b=True, epilogue="relu_mask", aux0=last[:, :n_out])
                 dcross = k.gemm(dz, fcw[n_out:], self.ws, trans_b=True)
                 dx0_acc, have_acc = k.mlp_backward(ddnn, sv["acts"], W, dW, db, self.ws), True   # d feat via DNN
-            dx = dcross
-            xs, us, feat = sv["xs"], sv["us"], sv["feat"]
-            du = torch.empty_like(feat)
-            for i in reversed(range(self.cross_num)):
-                wi = p[P + "cross_layers.%d.weight" % i]
-                k.cross_bwd_prep(dx, feat, us[i], du, dx0_acc, accumulate=have_acc)
-                have_acc = True
-                k.gemm(xs[i], du, self.ws, trans_a=True, out=g[P + "cross_layers.%d.weight" % i],
-                       b_colsum=g[P + "cross_layers.%d.bias" % i])
-                dx = k.gemm(du, wi, self.ws, trans_b=True, epilogue="add", aux1=dx,
-                            aux0=dx0_acc if i == 0 else None)
+            feat = sv["feat"]
+            if self.use_low_rank_mixture:
+                dx = self._cross_mix_backward(dcross, feat, sv["mix"], dx0_acc, have_acc)
+            else:
+                dx = dcross
+                xs, us = sv["xs"], sv["us"]
+                du = torch.empty_like(feat)
+                for i in reversed(range(self.cross_num)):
+                    wi = p[P + "cross_layers.%d.weight" % i]
+                    k.cross_bwd_prep(dx, feat, us[i], du, dx0_acc, accumulate=have_acc)
+                    have_acc = True
+                    k.gemm(xs[i], du, self.ws, trans_a=True, out=g[P + "cross_layers.%d.weight" % i],
+                           b_colsum=g[P + "cross_layers.%d.bias" % i])
+                    dx = k.gemm(du, wi, self.ws, trans_b=True, epilogue="add", aux1=dx,
+                                aux0=dx0_acc if i == 0 else None)
             dfeat = dx                                           # d loss / d feat_embeddings  [B,d]
             k.gemm(dense_inputs, dfeat[:, S * D:], self.ws, trans_a=True, out=g["dense_emb.weight"],
                    b_colsum=g["dense_emb.bias"])
@@ -302,6 +308,56 @@ class DCN_V2Layer:
                                grad_group_stride=d, grad_scale=scale)
         self._last_dfeat = dfeat
         return loss, pred
+
+    def _cross_mix_backward(self, dout, feat, saved, dx0_acc, have_acc):
+        """Backward of _cross_mix (oracle: oracle/dcn_v2_ref.py cross_mix_backward).  Returns d feat."""
+        p, g, k = self.dense.p, self.dense.g, self.k
+        E, r = self.num_experts, self.low_rank
+        B = feat.shape[0]
+        f32 = dict(dtype=torch.float32, device=self.device)
+        u = torch.empty_like(feat)
+        du = torch.empty_like(feat)
+        dp = torch.empty(B, E, **f32)
+        dc = torch.empty(B, r, **f32)
+        da = torch.empty(B, r, **f32)
+        dbias_e = torch.empty(self.d, **f32)
+        g[P + "gating.weight"].zero_()
+        g[P + "gating.bias"].zero_()
+        dx = dout
+        for i in reversed(range(self.cross_num)):
+            xl, t1, t2, prob = saved[i]
+            U, V, Cm = p[P + "U_list.%d" % i], p[P + "V_list.%d" % i], p[P + "C_list.%d" % i]
+            gU, gV, gC = g[P + "U_list.%d" % i], g[P + "V_list.%d" % i], g[P + "C_list.%d" % i]
+            bias = p[P + "bias.%d" % i].view(-1)
+            gbias = g[P + "bias.%d" % i].view(-1)
+            dxl = torch.empty_like(feat)
+            first = True
+            for e in range(E):
+                t1e, t2e = t1[:, e * r:(e + 1) * r], t2[:, e * r:(e + 1) * r]
+                k.gemm(t2e, U[e], self.ws, trans_b=True, epilogue="bias", bias=bias, out=u)       # recompute u_e
+                k.moe_bwd_prep(dx, feat, u, prob[:, e], du, dx0_acc, have_acc, dp[:, e])
+                have_acc = True
+                k.colsum(du, self.ws, out=dbias_e)
+                if e == 0:
+                    gbias.copy_(dbias_e)
+                else:
+                    gbias.add_(dbias_e)
+                k.gemm(du, t2e, self.ws, trans_a=True, out=gU[e])                                  # dU_e = du^T t2
+                k.gemm(du, U[e], self.ws, epilogue="dtanh", aux0=t2e, out=dc)                      # dc = (du U)*(1-t2^2)
+                k.gemm(dc, t1e, self.ws, trans_a=True, out=gC[e])                                  # dC_e = dc^T t1
+                k.gemm(dc, Cm[e], self.ws, epilogue="dtanh", aux0=t1e, out=da)                     # da = (dc C)*(1-t1^2)
+                k.gemm(xl, da, self.ws, trans_a=True, out=gV[e])                                   # dV_e = x_l^T da
+                k.gemm(da, V[e], self.ws, trans_b=True, epilogue="add", aux1=dx if first else dxl, out=dxl)
+                first = False
+            dgate = k.softmax_rows_bwd(prob, dp)
+            # gating Linear layers are shared by all cross layers (net.py:267-268): accumulate
+            gw = k.gemm(xl, dgate, self.ws, trans_a=True)
+            g[P + "gating.weight"].add_(gw)
+            g[P + "gating.bias"].add_(k.colsum(dgate, self.ws))
+            k.gemm(dgate, p[P + "gating.weight"], self.ws, trans_b=True, epilogue="add", aux1=dxl, out=dxl,
+                   aux0=dx0_acc if i == 0 else None)
+            dx = dxl
+        return dx
 
     def _scalar(self, name):
         b = getattr(self, "_s_" + name, None)

@@ -415,6 +415,24 @@ def softmax_rows(x, out=None):
     return out
 
 
+def moe_bwd_prep(dX, X0, U, prob_e, dU, dX0_acc, accumulate, dp_e):
+    """CrossNetMix backward glue for one expert: dU = dX*X0*p_e; dX0_acc (+)= dX*p_e*U; dp_e = rowsum(dX*X0*U)."""
+    M, N = dX.shape
+    lds = [_chk_mat(t, n) for t, n in ((dX, "dX"), (X0, "X0"), (U, "U"), (dU, "dU"), (dX0_acc, "dX0_acc"))]
+    check(lib().rec_moe_bwd_prep(M, N, _p(dX), lds[0], _p(X0), lds[1], _p(U), lds[2], _p(prob_e),
+                                 prob_e.stride(0) if M > 1 else 1, _p(dU), lds[3], _p(dX0_acc), lds[4],
+                                 int(accumulate), _p(dp_e), dp_e.stride(0) if M > 1 else 1, _stream()),
+          "rec_moe_bwd_prep")
+
+
+def softmax_rows_bwd(p, dp, out=None):
+    if out is None:
+        out = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+    check(lib().rec_softmax_rows_bwd(p.shape[0], p.shape[1], _p(p), _chk_mat(p, "p"), _p(dp), _chk_mat(dp, "dp"),
+                                     _p(out), _chk_mat(out, "out"), _stream()), "rec_softmax_rows_bwd")
+    return out
+
+
 def cross_bwd_prep(dX, X0, U, dU, dX0_acc, accumulate):
     """dU = dX*X0; dX0_acc (+)= dX*U  (CrossNetV2 backward glue)."""
     M, N = dX.shape

@@ -98,12 +98,54 @@ def test_v2_train_steps_vs_oracle(engine_lib, stacked, D, B):
         np.testing.assert_allclose(N_(sd[k]), tr.p[k], rtol=1e-3, atol=3e-4, err_msg=k)
 
 
-def test_mix_training_is_refused(engine_lib):
+def test_mix_gradients_golden(engine_lib):
+    """CrossNetMix backward (experts, tanh chain, softmax gate shared across layers) vs the reference autograd."""
+    g = load_golden("dcn_v2_mix")
+    p = {k[2:]: v for k, v in g.items() if k.startswith("p.")}
+    m = _model_from(p)
+    pred = g["pred"]
+    dlogit = (pred * (1 - pred)).astype(np.float32)
+    label = torch.zeros(len(pred), 1, dtype=torch.int64, device=DEV)
+    m.train_step(T(g["ids"]), T(g["dense"]), label, lr=0.0, clip_norm=None, dlogit=T(dlogit))
+    got = m.grad_dict()
+    n = 0
+    for k, v in g.items():
+        if k.startswith("g.") and k[2:] in got:
+            np.testing.assert_allclose(N_(got[k[2:]]).reshape(v.shape), v, rtol=3e-4, atol=3e-6, err_msg=k)
+            n += 1
+    assert n >= 24
+    dfeat = N_(m._last_dfeat)[:, :26 * 4].reshape(-1, 4)
+    gW = np.zeros_like(g["g.embedding.weight"])
+    rows = g["ids"].reshape(-1)
+    np.add.at(gW, rows[rows != 0], dfeat[rows != 0])
+    np.testing.assert_allclose(gW, g["g.embedding.weight"], rtol=3e-4, atol=3e-6)
+
+
+@pytest.mark.parametrize("stacked", [True, False])
+def test_mix_train_steps_vs_oracle(engine_lib, stacked):
     from paddlerec_amd.dcn_v2 import DCN_V2Layer
-    m = DCN_V2Layer(50, 4, 13, 26, [8], 1, use_low_rank_mixture=True, low_rank=4, device=DEV)
-    with pytest.raises(Exception, match="CrossNetV2 only"):
-        m.train_step(torch.zeros(2, 26, dtype=torch.int64, device=DEV), torch.zeros(2, 13, device=DEV),
-                     torch.zeros(2, 1, dtype=torch.int64, device=DEV))
+    rng = np.random.default_rng(17 + stacked)
+    N, D, B, fc = 200, 8, 96, [32, 16]
+    m = DCN_V2Layer(N, D, 13, 26, fc, 2, is_Stacked=stacked, use_low_rank_mixture=True, low_rank=16,
+                    num_experts=4, device=DEV)
+    with torch.no_grad():
+        for k, v in m.dense.p.items():
+            if "bias" in k:
+                v.copy_(T((rng.standard_normal(tuple(v.shape)) * 0.05).astype(np.float32)))
+    p = {k: N_(v).copy() for k, v in m.state_dict().items()}
+    tr = OracleDCNTrainer(p, lr=1e-2, clip_norm=0.05)
+    for step in range(2):
+        ids = rng.integers(0, N, (B, 26), dtype=np.int64)
+        dense = np.log(rng.random((B, 13), dtype=np.float32) * 50 + 1).astype(np.float32)
+        label = (rng.random((B, 1)) < 0.3).astype(np.int64)
+        loss, pred = m.train_step(T(ids), T(dense), T(label), lr=1e-2, clip_norm=0.05)
+        oloss, opred, _ = tr.train_step(ids, dense, label)
+        np.testing.assert_allclose(N_(loss)[0], oloss, rtol=2e-5)
+        np.testing.assert_allclose(N_(pred), opred, rtol=2e-5, atol=1e-6)
+    sd = m.state_dict()
+    for k in ("embedding.weight", X.P + "U_list.0", X.P + "V_list.1", X.P + "C_list.0", X.P + "gating.2.weight",
+              X.P + "gating.0.bias", X.P + "bias.1", "DNN_.linear_0.weight", "fc.weight"):
+        np.testing.assert_allclose(N_(sd[k]), tr.p[k], rtol=1e-3, atol=3e-4, err_msg=k)
 
 
 def test_emb_gather_grouped_output(engine_lib):
