@@ -182,6 +182,15 @@ int rec_sparse_sgd_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride, cons
                         void* stream);
 int rec_sgd_dense(int64_t n, float* p, const float* g, float lr, void* stream);
 
+/* lazy_mode=False Adam on a SelectedRows gradient — the dygraph default (deepfm/dygraph_model.py:61-65,
+ * SURVEY.md App. B-3): every one of the num_rows rows is updated, rows absent from the merged gradient with
+ * g = 0.  Same arguments as rec_sparse_adam_rows; streams the whole table (6*N*D*4 B per step). */
+int rec_adam_rows_all(int64_t num_rows, int32_t emb_dim, int32_t row_stride, int32_t state_stride,
+                      const int32_t* n_uniq, const int64_t* uniq_rows, const int32_t* seg_offset,
+                      const int32_t* sorted_pos, const float* grad, const rec_grad_layout* grad_layout,
+                      const float* grad_scale, float* P, float* M, float* V, const rec_adam_hyper* hyper,
+                      void* stream);
+
 /* dense Adam over a flat buffer (MLP + FM dense weights); grad_scale as above. */
 int rec_adam_dense(int64_t n, float* p, float* m, float* v, const float* g, const float* grad_scale,
                    const rec_adam_hyper* hyper, void* stream);

@@ -77,6 +77,8 @@ SIGNATURES = {
                                        _P, _P, _P, C.POINTER(AdamHyper), _P]),
     "rec_sparse_adagrad_rows": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
                                           _P, C.POINTER(AdagradHyper), _P]),
+    "rec_adam_rows_all": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
+                                    _P, _P, _P, C.POINTER(AdamHyper), _P]),
     "rec_adam_dense": (C.c_int, [_I64, _P, _P, _P, _P, _P, C.POINTER(AdamHyper), _P]),
     "rec_sumsq_workspace_bytes": (C.c_int, [C.POINTER(_SZ)]),
     "rec_sumsq": (C.c_int, [_I64, _P, _P, _I32, _P, _SZ, _P]),

@@ -333,6 +333,116 @@ __global__ __launch_bounds__(kBlock) void colsum_reduce_kernel(int N, int splits
   out[j] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
 }
 
+// ------------------------------------------------------------------------------- skinny shapes (N <= 4)
+// The last Linear of a CTR tower has one output (deepfm/net.py:150 sizes[-1] = 1): as a tiled GEMM it would
+// use 1/80 of every MFMA; it is a streaming HBM-bound pass instead.
+constexpr int kSkinnyN = 4;
+
+// C[M,N] = epi(A[M,K] @ op(B)):  one wave per row, lanes stride K with float4 loads, xor-shuffle fold.
+template <int EPI>
+__global__ __launch_bounds__(kBlock) void gemv_rows_kernel(int64_t M, int N, int K, const float* __restrict__ A,
+                                                           int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                           bool trans_b, float* __restrict__ C, int64_t ldc,
+                                                           EpiArgs epi, bool vec_a) {
+  extern __shared__ __attribute__((aligned(16))) float bs[];   // [N][K] (k contiguous)
+  for (int i = threadIdx.x; i < N * K; i += kBlock) {
+    const int n = i / K, k = i % K;
+    bs[i] = trans_b ? B[(int64_t)n * ldb + k] : B[(int64_t)k * ldb + n];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x % kWave;
+  const int64_t wpb = kBlock / kWave;
+  for (int64_t i = (int64_t)blockIdx.x * wpb + threadIdx.x / kWave; i < M; i += (int64_t)gridDim.x * wpb) {
+    float acc[kSkinnyN] = {0.f, 0.f, 0.f, 0.f};
+    const float* a = A + i * lda;
+    if (vec_a) {
+      for (int k = lane * 4; k + 3 < K; k += kWave * 4) {
+        const float4 x = *reinterpret_cast<const float4*>(a + k);
+#pragma unroll
+        for (int n = 0; n < kSkinnyN; ++n)
+          if (n < N) {
+            const float4 w = *reinterpret_cast<const float4*>(bs + n * K + k);
+            acc[n] += x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
+          }
+      }
+      for (int k = (K / 4) * 4 + lane; k < K; k += kWave)
+#pragma unroll
+        for (int n = 0; n < kSkinnyN; ++n)
+          if (n < N) acc[n] += a[k] * bs[n * K + k];
+    } else {
+      for (int k = lane; k < K; k += kWave)
+#pragma unroll
+        for (int n = 0; n < kSkinnyN; ++n)
+          if (n < N) acc[n] += a[k] * bs[n * K + k];
+    }
+#pragma unroll
+    for (int n = 0; n < kSkinnyN; ++n)
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) acc[n] += __shfl_xor(acc[n], o, kWave);
+    if (lane == 0)
+#pragma unroll
+      for (int n = 0; n < kSkinnyN; ++n)
+        if (n < N) {
+          C[i * ldc + n] = apply_epi<EPI>(acc[n], i, n, epi);
+          if (EPI == REC_EPI_CROSS && epi.out2) epi.out2[i * epi.ld2 + n] = acc[n] + epi.bias[n];
+        }
+  }
+}
+
+// partial[z][m][n] = sum over the K-chunk z of A[k,m] * B[k,n]   (A stored [K,M]: dW of a 1-output Linear),
+// colsum_partial[z][n] = sum_k B[k,n].  Thread t owns columns m = t, t+256, ...; reduced by splitk_reduce.
+constexpr int kSkinnyKC = 128;   // k rows per block
+constexpr int kSkinnyMT = 4;     // columns per thread (M <= 1024)
+__global__ __launch_bounds__(kBlock) void skinny_dw_kernel(int M, int N, int64_t K, const float* __restrict__ A,
+                                                           int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                           int64_t ldc, float* __restrict__ partial,
+                                                           float* __restrict__ colsum_partial) {
+  __shared__ float bs[kSkinnyKC * kSkinnyN];
+  const int64_t k0 = (int64_t)blockIdx.x * kSkinnyKC;
+  const int kc = (int)((K - k0 < kSkinnyKC) ? K - k0 : kSkinnyKC);
+  for (int i = threadIdx.x; i < kc * N; i += kBlock) bs[(i / N) * kSkinnyN + i % N] = B[(k0 + i / N) * ldb + i % N];
+  __syncthreads();
+  float acc[kSkinnyMT][kSkinnyN];
+#pragma unroll
+  for (int c = 0; c < kSkinnyMT; ++c)
+#pragma unroll
+    for (int n = 0; n < kSkinnyN; ++n) acc[c][n] = 0.f;
+  // 8 rows of A in flight per thread before any FMA (the loop is pure streaming: latency, not ALU, sets it)
+  for (int kb = 0; kb < kc; kb += 8) {
+    float x[8][kSkinnyMT];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* a = A + (k0 + kb + u) * lda;
+#pragma unroll
+      for (int c = 0; c < kSkinnyMT; ++c) {
+        const int m = threadIdx.x + c * kBlock;
+        x[u][c] = (kb + u < kc && m < M) ? a[m] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int c = 0; c < kSkinnyMT; ++c)
+#pragma unroll
+        for (int n = 0; n < kSkinnyN; ++n)
+          if (n < N) acc[c][n] += x[u][c] * ((kb + u < kc) ? bs[(kb + u) * kSkinnyN + n] : 0.f);
+  }
+  float* out = partial + (int64_t)blockIdx.x * M * ldc;
+#pragma unroll
+  for (int c = 0; c < kSkinnyMT; ++c) {
+    const int m = threadIdx.x + c * kBlock;
+    if (m < M)
+#pragma unroll
+      for (int n = 0; n < kSkinnyN; ++n)
+        if (n < N) out[(int64_t)m * ldc + n] = acc[c][n];
+  }
+  if (colsum_partial && (int)threadIdx.x < N) {
+    float t = 0.f;
+    for (int k = 0; k < kc; ++k) t += bs[k * kSkinnyN + threadIdx.x];
+    colsum_partial[(int64_t)blockIdx.x * N + threadIdx.x] = t;
+  }
+}
+
 // column sums of G [M,N] (bias gradients): deterministic two-level reduction
 constexpr int kColsumRows = 64;
 __global__ __launch_bounds__(kBlock) void colsum_partial_kernel(int64_t M, int N, int64_t ld,
@@ -342,9 +452,14 @@ __global__ __launch_bounds__(kBlock) void colsum_partial_kernel(int64_t M, int N
   const int64_t r0 = (int64_t)blockIdx.x * kColsumRows;
   const int64_t r1 = r0 + kColsumRows < M ? r0 + kColsumRows : M;
   for (int j = threadIdx.x; j < N; j += kBlock) {
-    float t = 0.f;
-    for (int64_t r = r0; r < r1; ++r) t += G[r * ld + j];
-    partial[(int64_t)blockIdx.x * N + j] = t;
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // 8 loads in flight, fixed fold order
+    int64_t r = r0;
+    for (; r + 8 <= r1; r += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += G[(r + u) * ld + j];
+    }
+    for (; r < r1; ++r) a8[(r - r0) & 7] += G[r * ld + j];
+    partial[(int64_t)blockIdx.x * N + j] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
   }
 }
 __global__ __launch_bounds__(kBlock) void colsum_final_kernel(int nblk, int N,
@@ -352,9 +467,14 @@ __global__ __launch_bounds__(kBlock) void colsum_final_kernel(int nblk, int N,
                                                               float* __restrict__ out) {
   const int j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= N) return;
-  float t = 0.f;
-  for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * N + j];
-  out[j] = t;
+  float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int b = 0;
+  for (; b + 8 <= nblk; b += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a8[u] += partial[(int64_t)(b + u) * N + j];
+  }
+  for (; b < nblk; ++b) a8[b & 7] += partial[(int64_t)b * N + j];
+  out[j] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
 }
 
 struct GemmPlan {
@@ -363,6 +483,13 @@ struct GemmPlan {
   int64_t tiles_m, tiles_total;
   int splits, k_chunk;
 };
+
+static bool skinny_rows(const rec_gemm_desc* d) {   // C = A @ B with N <= 4, A row-major
+  return d->n <= kSkinnyN && !d->trans_a && (size_t)d->n * d->k * sizeof(float) <= 48 * 1024;
+}
+static bool skinny_dw(const rec_gemm_desc* d) {     // C[M<=1024, N<=4] = A^T B over a long K
+  return d->n <= kSkinnyN && d->trans_a && !d->trans_b && d->m <= kSkinnyMT * kBlock && d->k >= 1024;
+}
 
 static GemmPlan plan_gemm(const rec_gemm_desc* d) {
   GemmPlan p;
@@ -448,6 +575,11 @@ using namespace rec;
 extern "C" int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* bytes) {
   if (int rc = check_gemm(desc)) return rc;
   REC_REQUIRE(bytes, REC_EINVAL, "bytes is NULL");
+  if (skinny_dw(desc)) {
+    const size_t z = (size_t)((desc->k + kSkinnyKC - 1) / kSkinnyKC);
+    *bytes = align_up(z * desc->m * desc->ldc * sizeof(float), 256) + align_up(z * desc->n * sizeof(float), 256);
+    return REC_OK;
+  }
   const GemmPlan p = plan_gemm(desc);
   // [splits][M][ldc] partial tiles (split-K only) + [splits][N] partial column sums
   *bytes = (p.splits > 1 ? align_up((size_t)p.splits * desc->m * desc->ldc * sizeof(float), 256) : 0) +
@@ -479,6 +611,47 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
   REC_REQUIRE(epi != REC_EPI_ADD || !aux0 || ld_aux0 >= desc->n, REC_EINVAL, "bad ld_aux0");
   REC_REQUIRE(epi != REC_EPI_MOE || (x->row_scale && x->row_scale_stride >= 1), REC_EINVAL,
               "epilogue needs row_scale");
+  hipStream_t st = (hipStream_t)stream;
+  EpiArgs e{bias, aux0, aux1, x->row_scale, x->out2, ld_aux0, ld_aux1, x->row_scale_stride, x->ld_out2};
+  REC_REQUIRE(!x->out2 || x->ld_out2 >= desc->n, REC_EINVAL, "bad ld_out2");
+  if (skinny_rows(desc) && !b_colsum) {
+    const bool vec_a = desc->lda % 4 == 0 && ((uintptr_t)A) % 16 == 0 && desc->k % 4 == 0;
+    int64_t grid = (desc->m + kBlock / kWave - 1) / (kBlock / kWave);
+    if (grid > kNumCU * 8) grid = kNumCU * 8;
+    const size_t shmem = (size_t)desc->n * desc->k * sizeof(float);
+#define REC_GEMV_CASE(E)                                                                                   \
+  case E:                                                                                                  \
+    hipLaunchKernelGGL(gemv_rows_kernel<E>, dim3((unsigned)grid), dim3(kBlock), shmem, st, desc->m, desc->n, \
+                       desc->k, A, (int64_t)desc->lda, B, (int64_t)desc->ldb, desc->trans_b != 0, C,       \
+                       (int64_t)desc->ldc, e, vec_a);                                                      \
+    break;
+    switch (epi) {
+      REC_GEMV_CASE(REC_EPI_NONE) REC_GEMV_CASE(REC_EPI_BIAS) REC_GEMV_CASE(REC_EPI_BIAS_RELU)
+      REC_GEMV_CASE(REC_EPI_RELU_MASK) REC_GEMV_CASE(REC_EPI_CROSS) REC_GEMV_CASE(REC_EPI_BIAS_SIGMOID)
+      REC_GEMV_CASE(REC_EPI_BIAS_TANH) REC_GEMV_CASE(REC_EPI_ADD) REC_GEMV_CASE(REC_EPI_MOE)
+      REC_GEMV_CASE(REC_EPI_DSIGMOID) REC_GEMV_CASE(REC_EPI_DTANH)
+    }
+#undef REC_GEMV_CASE
+    return check_launch("rec_gemm_f32 (skinny rows)");
+  }
+  if (skinny_dw(desc) && epi == REC_EPI_NONE) {
+    size_t need = 0;
+    rec_gemm_f32_workspace_bytes(desc, &need);
+    REC_REQUIRE(workspace && workspace_bytes >= need, REC_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
+    const int z = (int)((desc->k + kSkinnyKC - 1) / kSkinnyKC);
+    float* part = (float*)workspace;
+    float* cpart2 = (float*)((char*)workspace + align_up((size_t)z * desc->m * desc->ldc * sizeof(float), 256));
+    hipLaunchKernelGGL(skinny_dw_kernel, dim3(z), dim3(kBlock), 0, st, (int)desc->m, desc->n, (int64_t)desc->k, A,
+                       (int64_t)desc->lda, B, (int64_t)desc->ldb, (int64_t)desc->ldc, part,
+                       b_colsum ? cpart2 : nullptr);
+    GemmPlan sp;
+    sp.splits = z;
+    launch_reduce<REC_EPI_NONE>(desc, sp, part, C, e, st);
+    if (b_colsum)
+      hipLaunchKernelGGL(colsum_reduce_kernel, dim3((desc->n + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                         desc->n, z, (const float*)cpart2, b_colsum);
+    return check_launch("rec_gemm_f32 (skinny dW)");
+  }
   const GemmPlan p = plan_gemm(desc);
   REC_REQUIRE(p.tiles_total < (1ll << 31), REC_ESHAPE, "too many tiles");
   float* partial = nullptr;
@@ -495,9 +668,6 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
     }
     if (b_colsum) cpart = (float*)((char*)workspace + off);
   }
-  EpiArgs e{bias, aux0, aux1, x->row_scale, x->out2, ld_aux0, ld_aux1, x->row_scale_stride, x->ld_out2};
-  REC_REQUIRE(!x->out2 || x->ld_out2 >= desc->n, REC_EINVAL, "bad ld_out2");
-  hipStream_t st = (hipStream_t)stream;
 #define REC_EPI_CASE(E)                                                   \
   case E:                                                                 \
     if (partial) {                                                        \

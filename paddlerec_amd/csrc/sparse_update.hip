@@ -186,6 +186,71 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_rows_kernel(
   vstore<VEC>(V + so, v);
 }
 
+// paddle.optimizer.Adam with lazy_mode=False on a SelectedRows gradient (the dygraph default,
+// deepfm/dygraph_model.py:61-65): EVERY row's moments decay and every row moves, rows absent
+// from the merged gradient use g = 0.  One pass over the whole table (6*N*D*4 B of traffic — the reason the
+// engine defaults to the lazy variant); a block owns kBlock/LANES consecutive rows, finds the slice of the
+// sorted unique-row list that falls inside with two binary searches and spreads it into an LDS slot map.
+template <int VEC, int LANES>
+__global__ __launch_bounds__(kBlock) void adam_rows_all_kernel(
+    int64_t N, int D, int stride, int sstride, const int32_t* __restrict__ n_uniq,
+    const int64_t* __restrict__ uniq, const int32_t* __restrict__ seg_off,
+    const int32_t* __restrict__ spos, const float* __restrict__ grad, rec_grad_layout gl,
+    const float* __restrict__ grad_scale, float* __restrict__ P, float* __restrict__ M,
+    float* __restrict__ V, float lr_t, float eps_t, float b1, float b2) {
+  constexpr int RB = kBlock / LANES;
+  __shared__ int slot[RB];
+  __shared__ int range[2];
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+  for (int i = threadIdx.x; i < RB; i += kBlock) slot[i] = -1;
+  if (threadIdx.x < 2) {
+    const int64_t key = r0 + (threadIdx.x ? RB : 0);
+    int lo = 0, hi = n_uniq[0];
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (uniq[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    range[threadIdx.x] = lo;
+  }
+  __syncthreads();
+  for (int u = range[0] + threadIdx.x; u < range[1]; u += kBlock) slot[(int)(uniq[u] - r0)] = u;
+  __syncthreads();
+  const int lr_ = threadIdx.x / LANES;
+  const int64_t row = r0 + lr_;
+  const int d0 = (threadIdx.x % LANES) * VEC;
+  if (row >= N || d0 >= D) return;
+  float p[VEC], m[VEC], v[VEC], g[VEC];
+  const int64_t ro = row * stride + d0, so = row * sstride + d0;
+  vload<VEC>(p, P + ro);
+  vload<VEC>(m, M + so);
+  vload<VEC>(v, V + so);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+  const int u = slot[lr_];
+  if (u >= 0) {
+    for (int k = seg_off[u]; k < seg_off[u + 1]; ++k) {
+      float t[VEC];
+      vload<VEC>(t, grad + grad_offset(gl, spos[k], D) + d0);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) g[i] += t[i];
+    }
+    if (grad_scale) {
+      const float sc = grad_scale[0];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) g[i] *= sc;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    m[i] = b1 * m[i] + (1.f - b1) * g[i];
+    v[i] = b2 * v[i] + (1.f - b2) * g[i] * g[i];
+    p[i] = p[i] - lr_t * (m[i] / (sqrtf(v[i]) + eps_t));
+  }
+  vstore<VEC>(P + ro, p);
+  vstore<VEC>(M + so, m);
+  vstore<VEC>(V + so, v);
+}
+
 // paddle.optimizer.SGD on the touched rows (din/dygraph_model.py:64-73; rows with zero gradient do not move,
 // so updating only the merged rows IS dense SGD): p -= lr * sum of the row's duplicate gradients
 template <int VEC, int LANES>
@@ -558,4 +623,35 @@ extern "C" int rec_sgd_dense(int64_t n, float* p, const float* g, float lr, void
   if (grid > kNumCU * 8) grid = kNumCU * 8;
   hipLaunchKernelGGL(sgd_dense_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, n, p, g, lr);
   return check_launch("rec_sgd_dense");
+}
+
+extern "C" int rec_adam_rows_all(int64_t num_rows, int32_t emb_dim, int32_t row_stride,
+                                 int32_t state_stride, const int32_t* n_uniq, const int64_t* uniq_rows,
+                                 const int32_t* seg_offset, const int32_t* sorted_pos, const float* grad,
+                                 const rec_grad_layout* grad_layout, const float* grad_scale, float* P,
+                                 float* M, float* V, const rec_adam_hyper* hyper, void* stream) {
+  rec_grad_layout gl = {1, 0, 0};
+  if (grad_layout) gl = *grad_layout;
+  REC_REQUIRE(num_rows >= 0 && emb_dim > 0 && row_stride >= emb_dim && gl.div >= 1, REC_EINVAL, "bad sizes");
+  if (state_stride <= 0) state_stride = row_stride;
+  REC_REQUIRE(state_stride >= emb_dim, REC_EINVAL, "state_stride < emb_dim");
+  REC_REQUIRE(n_uniq && uniq_rows && seg_offset && sorted_pos && grad && P && M && V && hyper, REC_EINVAL,
+              "null pointer argument");
+  REC_REQUIRE(hyper->step >= 1, REC_EINVAL, "Adam step must be >= 1");
+  if (num_rows == 0) return REC_OK;
+  float lr_t, eps_t;
+  adam_scalars(hyper, &lr_t, &eps_t);
+  const bool gvec = ((uintptr_t)grad) % 16 == 0 && (gl.group <= 0 || gl.group_stride % 4 == 0) &&
+                    state_stride % 4 == 0;
+  return dispatch_row_shape(emb_dim, gvec ? row_stride : row_stride | 1, [&](auto vec, auto lanes) -> int {
+    constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
+    constexpr int RB = kBlock / LANES;
+    const int64_t grid = (num_rows + RB - 1) / RB;
+    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");
+    hipLaunchKernelGGL((adam_rows_all_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock), 0,
+                       (hipStream_t)stream, num_rows, emb_dim, row_stride, state_stride, n_uniq, uniq_rows,
+                       seg_offset, sorted_pos, grad, gl, grad_scale, P, M, V, lr_t, eps_t, hyper->beta1,
+                       hyper->beta2);
+    return check_launch("rec_adam_rows_all");
+  });
 }

@@ -189,6 +189,8 @@ class DeepFMLayer:
             self.sparse_state = dict(mv=mv, m=mv[:, :D], v=mv[:, Dp:Dp + D],
                                      m1=self.fm.rec[:, D + 1:D + 2], v1=self.fm.rec[:, D + 2:D + 3])
 
+    lazy_mode = True   # False = the dygraph default (every row decays each step, 6*N*(D+1)*4 B of traffic)
+
     def train_step(self, sparse_inputs, dense_inputs, label, lr=1e-3, auc_stats=None,
                    allreduce=None):
         """dygraph_model.py:76-88 train_forward + tools/trainer.py:151-152 backward/step.
@@ -233,8 +235,9 @@ class DeepFMLayer:
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             with self._timed("sparse_adam"):
-                self.k.sparse_adam_rows(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr)
-                self.k.sparse_adam_rows(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
+                upd = self.k.sparse_adam_rows if self.lazy_mode else self.k.adam_rows_all
+                upd(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr)
+                upd(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
         with self._timed("mlp_bwd_dw0"):
             finish_dw0()
         if allreduce is not None:

@@ -263,6 +263,22 @@ def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, 
           "rec_sparse_adam_rows")
 
 
+def adam_rows_all(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                  grad_group=0, grad_group_stride=0, grad_scale=None):
+    """lazy_mode=False Adam (dygraph default): every row of P/M/V moves, absent rows with g = 0."""
+    D, stride = _chk_table(P, "P")
+    sstride = _chk_table(M, "M")[1]
+    for t, n in ((M, "M"), (V, "V")):
+        if _chk_table(t, n) != (D, sstride) or t.shape[0] != P.shape[0]:
+            raise RecError("%s must have the shape of P (M and V share one row stride)" % n)
+    h = _hyper(lr, beta1, beta2, eps, step)
+    check(lib().rec_adam_rows_all(P.shape[0], D, stride, sstride, _p(groups.n_uniq), _p(groups.uniq_rows),
+                                  _p(groups.seg_offset), _p(groups.sorted_pos), _p(grad),
+                                  C.byref(GradLayout(int(grad_div), int(grad_group), int(grad_group_stride))),
+                                  _p(grad_scale), _p(P), _p(M), _p(V), C.byref(h), _stream()),
+          "rec_adam_rows_all")
+
+
 def sparse_adagrad_rows(groups, grad, rec, emb_dim, num_slots, label=None, lr=0.05, initial_g2sum=3.0,
                         bounds=(-10.0, 10.0), grad_div=1, grad_group=0, grad_group_stride=0):
     """PS accessor rule (SparseAdaGradSGDRule + show/click) on the touched rows of a record table

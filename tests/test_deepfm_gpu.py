@@ -235,6 +235,28 @@ def test_sparse_adam_first_order_via_grad_div(ops):
     np.testing.assert_allclose(N_(tM), M, rtol=RTOL, atol=1e-10)
 
 
+@pytest.mark.parametrize("D", [16, 9, 1])
+def test_adam_rows_all_nonlazy_vs_oracle(ops, D):
+    """lazy_mode=False (dygraph default, App. B-3): absent rows decay too — oracle adam_update_dense_equivalent."""
+    pr = make_deepfm_problem(B=300, N=700, D=D, seed=D + 3, pad_frac=0.1)
+    rng = np.random.default_rng(D)
+    n = pr["ids"].size
+    grad = (rng.standard_normal((n, D)) * 1e-2).astype(np.float32)
+    P = pr["params"]["W"].copy()
+    M = (rng.standard_normal(P.shape) * 1e-3).astype(np.float32)
+    V = (rng.random(P.shape) * 1e-5).astype(np.float32)
+    tp, tm, tv = T(P), T(M), T(V)
+    ws = ops.Workspace(DEV)
+    groups, _ = ops.ids_group(T(pr["ids"]), 700, 0, ws)
+    ops.adam_rows_all(groups, T(grad), 1, tp, tm, tv, 3, lr=1e-2)
+    rows, valid = R.effective_rows(pr["ids"], 0)
+    uniq, merged, _ = R.merge_rows(rows.reshape(-1), valid.reshape(-1), grad)
+    R.adam_update_dense_equivalent(P, M, V, uniq, merged, 3, lr=1e-2)
+    np.testing.assert_allclose(N_(tp), P, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(N_(tm), M, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(N_(tv), V, rtol=1e-5, atol=1e-12)
+
+
 def test_adam_dense_vs_oracle(ops):
     rng = np.random.default_rng(0)
     n = 100003

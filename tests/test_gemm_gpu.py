@@ -30,7 +30,9 @@ def _check(C, want, bound):
     (128, 128, 16, False, False), (256, 400, 624, False, False), (1000, 400, 400, False, False),
     (300, 1, 400, False, False), (129, 81, 17, False, False), (1, 5, 3, False, False),
     (624, 400, 3000, True, False), (400, 1, 999, True, False), (513, 624, 400, False, True),
-    (200, 1560, 1560, False, False), (77, 130, 50, True, True), (64, 256, 40, False, True)])
+    (200, 1560, 1560, False, False), (77, 130, 50, True, True), (64, 256, 40, False, True),
+    (5000, 1, 400, False, False), (777, 3, 401, False, True), (400, 1, 5000, True, False),
+    (1000, 4, 3000, True, False), (33, 2, 7, False, False)])
 def test_gemm_plain(ops, M, N, K, ta, tb):
     # A=I-style asymmetry is covered by random asymmetric operands: a row/col swap cannot pass
     rng = np.random.default_rng(M + N + K)
@@ -87,6 +89,31 @@ def test_gemm_epilogues(ops):
     np.testing.assert_allclose(
         ops.gemm(t(A), t(B), ws, epilogue="bias_relu", bias=t(bias), split_k=4).cpu().numpy(),
         np.maximum(acc + bias, 0), **tol)
+
+
+def test_gemm_skinny_paths(ops):
+    """One-output Linear layers (N <= 4) take the streaming kernels: forward with epilogues, dW with the fused
+    bias gradient."""
+    rng = np.random.default_rng(8)
+    M, K = 3000, 400
+    A, w, b = _mk(rng, M, K), _mk(rng, K, 1) * 0.1, _mk(rng, 1)
+    item_b = _mk(rng, M, 1)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    ws = ops.Workspace(DEV)
+    acc = A.astype(np.float64) @ w.astype(np.float64)
+    tol = dict(rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(ops.gemm(t(A), t(w), ws, epilogue="bias", bias=t(b)).cpu().numpy(), acc + b, **tol)
+    np.testing.assert_allclose(ops.gemm(t(A), t(w), ws, epilogue="add", bias=t(b), aux1=t(item_b)).cpu().numpy(),
+                               acc + b + item_b, **tol)
+    np.testing.assert_allclose(ops.gemm(t(A), t(w), ws, epilogue="bias_sigmoid", bias=t(b)).cpu().numpy(),
+                               1 / (1 + np.exp(-(acc + b))), **tol)
+    G = _mk(rng, M, 1)
+    db = torch.empty(1, device=DEV)
+    dW = ops.gemm(t(A), t(G), ws, trans_a=True, b_colsum=db)
+    np.testing.assert_allclose(dW.cpu().numpy(), A.astype(np.float64).T @ G.astype(np.float64), rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), G.astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
+    dW2 = ops.gemm(t(A), t(G), ws, trans_a=True, b_colsum=db)
+    assert torch.equal(dW, dW2)
 
 
 def test_gemm_strided_views_and_inplace_out(ops):
