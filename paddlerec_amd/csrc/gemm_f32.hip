@@ -19,6 +19,9 @@
 // tile is fetched from HBM once and re-read from that XCD's L2).
 // Split-K (trans_a GEMMs with K = batch): partial tiles go to the workspace and are summed in a
 // fixed order by a second kernel (deterministic).
+// Tried and dropped (measured on MI355X, [65536x624]x[624x400]): a barrier-free variant in which every wave
+// stages its own A/B K-slices (76 TF vs 96 TF — the 4x re-read of B costs more than the barriers), static
+// s_setprio staggering of co-resident blocks (no effect).
 #include "rec_common.h"
 
 namespace rec {
@@ -34,11 +37,13 @@ constexpr int kLdsPadB = 4;   // B_lds[BK][BN+4]  : (BN+4) % 8 == 4 -> the two 3
 // along R ("T": element (r,c) at p[c*ld + r]).  LDS keeps it as [R][LDS_LD] — or, with LDST, as
 // [C][LDS_LD] (the memory order of a "T" tile, so its float4s are stored whole instead of being
 // scattered across LDS rows, which costs 16-way bank conflicts for R = 128).
-template <int R, int C, int LDS_LD, bool MEMT, bool LDST = false>
+template <int R, int C, int LDS_LD, bool MEMT, bool LDST = false, int NTHR = kBlock>
 struct TileLoader {
   static constexpr int kVecs = R * C / 4;
-  static constexpr int kPerThread = (kVecs + kBlock - 1) / kBlock;
+  static constexpr int kPerThread = (kVecs + NTHR - 1) / NTHR;
   float4 stage[kPerThread];
+  int tid;   // index of this thread among the NTHR cooperating ones
+  __device__ __forceinline__ explicit TileLoader(int t) : tid(t) {}
 
   // FAST: the tile is fully inside the matrix and 16-B aligned — straight float4 loads, no checks
   template <bool FAST>
@@ -46,10 +51,10 @@ struct TileLoader {
                                        int64_t c0, int64_t rmax, int64_t cmax, bool vec_ok) {
 #pragma unroll
     for (int it = 0; it < kPerThread; ++it) {
-      const int v = threadIdx.x + it * kBlock;
+      const int v = tid + it * NTHR;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
       if (FAST) {
-        if (kVecs % kBlock == 0 || v < kVecs) {
+        if (kVecs % NTHR == 0 || v < kVecs) {
           if (!MEMT) {
             const int r = v / (C / 4), c4 = (v % (C / 4)) * 4;
             x = *reinterpret_cast<const float4*>(p + (r0 + r) * ld + (c0 + c4));
@@ -58,7 +63,7 @@ struct TileLoader {
             x = *reinterpret_cast<const float4*>(p + (c0 + c) * ld + (r0 + r4));
           }
         }
-      } else if (kVecs % kBlock == 0 || v < kVecs) {
+      } else if (kVecs % NTHR == 0 || v < kVecs) {
         if (!MEMT) {
           const int r = v / (C / 4), c4 = (v % (C / 4)) * 4;
           const int64_t gr = r0 + r, gc = c0 + c4;
@@ -96,8 +101,8 @@ struct TileLoader {
   __device__ __forceinline__ void store(float* __restrict__ lds) const {
 #pragma unroll
     for (int it = 0; it < kPerThread; ++it) {
-      const int v = threadIdx.x + it * kBlock;
-      if (kVecs % kBlock == 0 || v < kVecs) {
+      const int v = tid + it * NTHR;
+      if (kVecs % NTHR == 0 || v < kVecs) {
         if (!MEMT) {
           const int r = v / (C / 4), c4 = (v % (C / 4)) * 4;
           *reinterpret_cast<float4*>(lds + r * LDS_LD + c4) = stage[it];
@@ -191,8 +196,8 @@ __global__ __launch_bounds__(kBlock, gemm_blocks_per_cu<BN>()) void gemm_f32_ker
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 15, g = lane >> 4;
 
-  TileLoader<BM, kBK, LDA_S, TA, TA> la;
-  TileLoader<kBK, BN, LDB_S, TB> lb;
+  TileLoader<BM, kBK, LDA_S, TA, TA> la(threadIdx.x);
+  TileLoader<kBK, BN, LDB_S, TB> lb(threadIdx.x);
 
   f32x4_t acc[MT][NT];
 #pragma unroll

@@ -212,7 +212,7 @@ class DeepFMLayer:
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             self.k.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
-                          self.fm.slot_offset, self.status, groups)
+                             self.fm.slot_offset, self.status, groups)
         with self._timed("mlp_fwd"):
             y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b, self.ws_mlp)
         pred, dz, loss = self.k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws)
