@@ -177,6 +177,8 @@ def main():
 
     def step(i):
         ids, dense, label = batches[i % len(batches)]
+        if dist is not None:      # the sharded layer routes the next batch's ids a step ahead
+            return model.train_step(ids, dense, label, lr=1e-3, next_sparse_inputs=batches[(i + 1) % len(batches)][0])
         return model.train_step(ids, dense, label, lr=1e-3)
 
     def barrier():

@@ -43,6 +43,12 @@ class Comm:
         self.dist.all_to_all_single(t_out, t_in, group=self.group)
         return [int(x) for x in t_out.tolist()]
 
+    def exchange_counts_device(self, send_counts_dev):
+        """Device-side variant for backend nccl: no host sync here; returns the receive counts (device)."""
+        out = torch.empty_like(send_counts_dev)
+        self.dist.all_to_all_single(out, send_counts_dev.contiguous(), group=self.group)
+        return out
+
     def all_to_all(self, out, inp, out_splits, in_splits):
         """Rows (dim 0) of `inp` split by in_splits go to the ranks; `out` receives out_splits rows."""
         if self.staged and out.is_cuda:
@@ -87,7 +93,7 @@ class ShardedDeepFMLayer(DeepFMLayer):
                          table_rows=self.local_rows, zero_padding_row=(self.comm.rank == 0),
                          kernels=kernels, extra_dense=(("__loss__", (1,)),))
         self.ws_route = self.k.Workspace(self.device)
-        self._route = None
+        self._routes, self._route_flip, self._pending = [], 0, None
         self._groups = None
         self._reply = None
 
@@ -117,18 +123,48 @@ class ShardedDeepFMLayer(DeepFMLayer):
         return out
 
     # -- routed lookup (ids exchange + rows exchange) ----------------------------------------------
+    def _route_async(self, ids):
+        """Partition `ids` by owner and start moving the per-owner counts to the host WITHOUT waiting:
+        the routing of the next batch depends on its ids only, so it can be issued a step ahead
+        (train_step(next_sparse_inputs=...)) and the lookup that consumes it never stalls on a host sync."""
+        B, S = ids.shape
+        n, G = B * S, self.comm.world
+        k = self.k
+        if not self._routes or self._routes[0].n != n:
+            self._routes = [k.ShardRoute(n, G, self.device), k.ShardRoute(n, G, self.device)]
+        self._route_flip ^= 1
+        route = self._routes[self._route_flip]       # double-buffered: the previous one is still in use
+        k.shard_route(ids, self.global_rows, self.fm.padding_idx, G, self.ws_route, self.fm.slot_offset,
+                      self.status, route)
+        pend = dict(ids=ids, route=route, host=None, ev=None)
+        if self.device.type == "cuda" and not self.comm.staged:
+            recv_dev = self.comm.exchange_counts_device(route.send_counts[:G])
+            host = torch.empty(2, G, dtype=torch.int64, pin_memory=True)
+            host[0].copy_(route.send_counts[:G], non_blocking=True)
+            host[1].copy_(recv_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            pend.update(host=host, ev=ev, keep=recv_dev)
+        return pend
+
     def _lookup(self, ids):
         B, S = ids.shape
         n, G, D = B * S, self.comm.world, self.sparse_feature_dim
         k = self.k
-        if self._route is None or self._route.n != n:
-            self._route = k.ShardRoute(n, G, self.device)
-        route, _ = k.shard_route(ids, self.global_rows, self.fm.padding_idx, G, self.ws_route,
-                                 self.fm.slot_offset, self.status, self._route)
+        pend = self._pending
+        self._pending = None
+        if pend is None or pend["ids"] is not ids:
+            pend = self._route_async(ids)
+        route = pend["route"]
         L = _Lookup()
         L.route = route
-        L.send_splits = [int(x) for x in route.send_counts[:G].tolist()]       # host sync (G ints)
-        L.recv_splits = self.comm.exchange_counts(L.send_splits)
+        if pend["ev"] is not None:
+            pend["ev"].synchronize()                  # normally long since complete (issued a step ahead)
+            L.send_splits = [int(x) for x in pend["host"][0].tolist()]
+            L.recv_splits = [int(x) for x in pend["host"][1].tolist()]
+        else:
+            L.send_splits = [int(x) for x in route.send_counts[:G].tolist()]       # host sync (G ints)
+            L.recv_splits = self.comm.exchange_counts(L.send_splits)
         L.n_send, L.n_recv = sum(L.send_splits), sum(L.recv_splits)
         i64 = dict(dtype=torch.int64, device=self.device)
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -163,8 +199,11 @@ class ShardedDeepFMLayer(DeepFMLayer):
     __call__ = forward
 
     # -- one full training step --------------------------------------------------------------------
-    def train_step(self, sparse_inputs, dense_inputs, label, lr=1e-3, auc_stats=None):
-        """Returns (loss [1] = mean over the GLOBAL batch, pred [B,1] of the local samples)."""
+    def train_step(self, sparse_inputs, dense_inputs, label, lr=1e-3, auc_stats=None,
+                   next_sparse_inputs=None):
+        """Returns (loss [1] = mean over the GLOBAL batch, pred [B,1] of the local samples).
+        next_sparse_inputs: ids of the NEXT batch (the same tensor object must be passed to the next call):
+        its routing is issued now, under this step's GEMMs."""
         k = self.k
         ids = self._concat_ids(sparse_inputs)
         B, S = ids.shape
@@ -172,8 +211,35 @@ class ShardedDeepFMLayer(DeepFMLayer):
         self._ensure_sparse_state()
         self.step_count += 1
         t = self.step_count
+        on_gpu = self.device.type == "cuda"
+        cur = torch.cuda.current_stream() if on_gpu else None
+        if on_gpu and self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+
+        class _Side:          # "with side:" = run on the side stream after everything issued so far (GPU only)
+            def __enter__(s_):
+                if on_gpu:
+                    self._side.wait_stream(cur)
+                    s_.ctx = torch.cuda.stream(self._side)
+                    s_.ctx.__enter__()
+
+            def __exit__(s_, *a):
+                if on_gpu:
+                    s_.ctx.__exit__(*a)
+
         with self._timed("lookup_exchange"):
             L = self._lookup(ids)
+        groups = None
+        if L.n_recv:
+            # merge keys of the rows this rank owns: sorted on the side stream under the forward GEMMs
+            if self._groups is None or self._groups.n < L.n_recv:
+                self._groups = k.IdGroups(L.n_recv + L.n_recv // 8, self.device)
+            with _Side():
+                groups, _ = k.ids_group(L.recv_rows, self.local_rows, None, self.ws_group, None,
+                                        self.status, self._groups)
+        if next_sparse_inputs is not None:
+            with _Side():
+                self._pending = self._route_async(self._concat_ids(next_sparse_inputs))
         with self._timed("fm_fwd"):
             y1, y2, feat, sum_emb, _ = self._fm_fwd_routed(L, B, S, dense_inputs)
         with self._timed("mlp_fwd"):
@@ -185,7 +251,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
         if auc_stats is not None:
             k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         with self._timed("mlp_bwd"):
-            d_flat = self.k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp)
+            d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db,
+                                                     self.ws_mlp, defer_first=True)
         with self._timed("fm_bwd"):
             row_grad, _, _ = k.deepfm_fm_bwd(
                 dense_inputs, feat, sum_emb, d_flat.view(B, self.num_field, -1), dz, dz, S, self.ws,
@@ -193,30 +260,33 @@ class ShardedDeepFMLayer(DeepFMLayer):
                      self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
                      self.dense.g["fm.dense_w_one"]),
                 dense_w=self.dense.p["fm.dense_w"])
-        with self._timed("grad_exchange"):
-            f32 = dict(dtype=torch.float32, device=self.device)
-            send_g = torch.empty(L.n_send, D, **f32)
-            send_g1 = torch.empty(L.n_send, 1, **f32)
-            if L.n_send:
-                k.emb_gather(L.route.send_pos[: L.n_send], row_grad, None, self.status, out=send_g)
-                k.emb_gather(L.route.send_sample[: L.n_send], dz, None, self.status, out=send_g1)
-            recv_g = torch.empty(max(L.n_recv, 1), D, **f32)
-            recv_g1 = torch.empty(max(L.n_recv, 1), 1, **f32)
-            self.comm.all_to_all(recv_g[: L.n_recv], send_g, L.recv_splits, L.send_splits)
-            self.comm.all_to_all(recv_g1[: L.n_recv], send_g1, L.recv_splits, L.send_splits)
-            self.comm.all_reduce_sum(self.dense.grad)            # one bucket: dense grads + loss
+        # row-gradient exchange + lazy sparse optimizer (xGMI / HBM bound) on the side stream, underneath
+        # the MFMA-bound dW_0 GEMM and the dense all-reduce on the main stream
+        with _Side():
+            with self._timed("grad_exchange"):
+                f32 = dict(dtype=torch.float32, device=self.device)
+                send_g = torch.empty(L.n_send, D, **f32)
+                send_g1 = torch.empty(L.n_send, 1, **f32)
+                if L.n_send:
+                    k.emb_gather(L.route.send_pos[: L.n_send], row_grad, None, self.status, out=send_g)
+                    k.emb_gather(L.route.send_sample[: L.n_send], dz, None, self.status, out=send_g1)
+                recv_g = torch.empty(max(L.n_recv, 1), D, **f32)
+                recv_g1 = torch.empty(max(L.n_recv, 1), 1, **f32)
+                self.comm.all_to_all(recv_g[: L.n_recv], send_g, L.recv_splits, L.send_splits)
+                self.comm.all_to_all(recv_g1[: L.n_recv], send_g1, L.recv_splits, L.send_splits)
+            with self._timed("sparse_adam"):
+                if L.n_recv:
+                    st = self.sparse_state
+                    k.sparse_adam_rows(groups, recv_g, 1, self.fm.embedding, st["m"], st["v"], t, lr)
+                    k.sparse_adam_rows(groups, recv_g1, 1, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
+        with self._timed("mlp_bwd_dw0"):
+            finish_dw0()
+        self.comm.all_reduce_sum(self.dense.grad)                # one bucket: dense grads + loss
         loss = loss_slot.clone()
         loss_slot.zero_()                                         # not a parameter: keep Adam off it
         k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
-        with self._timed("sparse_adam"):
-            if L.n_recv:
-                if self._groups is None or self._groups.n < L.n_recv:
-                    self._groups = k.IdGroups(L.n_recv + L.n_recv // 8, self.device)
-                groups, _ = k.ids_group(L.recv_rows, self.local_rows, None, self.ws_group, None,
-                                        self.status, self._groups)
-                st = self.sparse_state
-                k.sparse_adam_rows(groups, recv_g, 1, self.fm.embedding, st["m"], st["v"], t, lr)
-                k.sparse_adam_rows(groups, recv_g1, 1, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
+        if on_gpu:
+            cur.wait_stream(self._side)
         return loss, pred
 
     def _buf(self, name, shape):

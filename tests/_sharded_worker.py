@@ -45,6 +45,7 @@ def main():
     out = {}
     lo, hi = rank * c["B"], (rank + 1) * c["B"]
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(dev)
+    batches = []
     for step in range(c["steps"]):
         if step == 0:
             ids, dense, label = pr["ids"], pr["dense"], pr["label"]
@@ -52,7 +53,10 @@ def main():
             ids = rng.integers(0, c["N"], (c["B"] * world, 26), dtype=np.int64)
             dense = rng.random((c["B"] * world, 13), dtype=np.float32)
             label = (rng.random((c["B"] * world, 1)) < 0.3).astype(np.int64)
-        loss, pred = m.train_step(t(ids[lo:hi]), t(dense[lo:hi]), t(label[lo:hi]), lr=c["lr"])
+        batches.append((t(ids[lo:hi]), t(dense[lo:hi]), t(label[lo:hi])))
+    for step, (ids_t, dense_t, label_t) in enumerate(batches):
+        nxt = batches[step + 1][0] if step + 1 < len(batches) else None     # routed a step ahead
+        loss, pred = m.train_step(ids_t, dense_t, label_t, lr=c["lr"], next_sparse_inputs=nxt)
         out["loss%d" % step] = loss.cpu().numpy().copy()
         out["pred%d" % step] = pred.cpu().numpy().copy()   # pred is a reused buffer
     pred_eval = m.forward(t(pr["ids"][lo:hi]), t(pr["dense"][lo:hi]))
