@@ -37,12 +37,94 @@ struct DinArgs {
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
 __device__ __forceinline__ float dout_k_of(const float* dout, int64_t b, int E, int k) { return dout[b * E + k]; }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kDinNT1 = 5;   // hidden1 <= 80 on the MFMA path (5 column tiles of 16)
+
+// Attention layer 1 on the matrix cores: z1[32, H1] = [h, q, h-q, h*q][32, 4E] @ W1[4E, H1] + b1, sigmoid.
+// The block's 4 waves split K by SEGMENT of the concat (wave w owns rows w*E..(w+1)*E of W1), so every wave
+// builds its A fragments with one fixed formula and the concat never exists anywhere; v_mfma_f32_16x16x4_f32
+// with 2 x 5 accumulator tiles per wave.  The four partial sums are added into a1 in wave order (fixed
+// order -> deterministic), then the sigmoid is applied in place.  Needs E % 16 == 0, H1 % 16 == 0, H1 <= 80.
+__device__ __forceinline__ void din_layer1_mfma(const float* __restrict__ hs, const float* __restrict__ qs,
+                                                int EP, const float* __restrict__ w1, const float* __restrict__ b1s,
+                                                float* __restrict__ a1, int E, int H1) {
+  const int lane = threadIdx.x % kWave, seg = threadIdx.x / kWave;
+  const int li = lane & 15, g = lane >> 4;
+  const int nt = H1 / 16;
+  f32x4_t acc[2][kDinNT1];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < kDinNT1; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // W1 fragments come from L2 (the 4E x H1 matrix does not fit beside the tiles in LDS): the loads of the
+  // next K block are issued before this block's MFMAs (register double buffering) to cover their latency.
+  const int nkb = E / 16;
+  float bf[2][kDinNT1][4];
+  auto load_b = [&](int kb, float (&dst)[kDinNT1][4]) {
+    const float* wrow = w1 + ((int64_t)(seg * E + kb * 16 + 4 * g)) * H1 + li;
+#pragma unroll
+    for (int b = 0; b < kDinNT1; ++b)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dst[b][s] = (b < nt) ? wrow[(int64_t)s * H1 + b * 16] : 0.f;
+  };
+  load_b(0, bf[0]);
+  for (int kb0 = 0; kb0 < nkb; kb0 += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int kb = kb0 + half;
+      if (kb < nkb) {
+        if (kb + 1 < nkb) load_b(kb + 1, bf[half ^ 1]);
+        float av[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int off = (a * 16 + li) * EP + kb * 16 + 4 * g;
+          const float4 hv = *reinterpret_cast<const float4*>(hs + off);
+          const float4 qv = *reinterpret_cast<const float4*>(qs + off);
+          const float h4[4] = {hv.x, hv.y, hv.z, hv.w}, q4[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            av[a][s] = seg == 0 ? h4[s] : seg == 1 ? q4[s] : seg == 2 ? h4[s] - q4[s] : h4[s] * q4[s];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < kDinNT1; ++b)
+              if (b < nt)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][s], bf[half][b][s], acc[a][b], 0, 0, 0);
+      }
+    }
+  }
+  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+  for (int w0 = 0; w0 < kBlock / kWave; ++w0) {
+    if (seg == w0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < kDinNT1; ++b)
+          if (b < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int p = a * 16 + g * 4 + r, j = b * 16 + li;
+              const float base = (w0 == 0) ? b1s[j] : a1[p * H1 + j];
+              a1[p * H1 + j] = base + acc[a][b][r];
+            }
+          }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < kDinTP * H1; i += kBlock) a1[i] = sigmoidf_(a1[i]);
+}
+
 __global__ __launch_bounds__(kBlock) void din_attention_fwd_kernel(DinArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int E = a.Ei + a.Ec, H1 = a.H1, H2 = a.H2, T = a.T;
-  float* hs = smem;                    // [TP][E]
-  float* qs = hs + kDinTP * E;         // [TP][E]
-  float* a1 = qs + kDinTP * E;         // [TP][H1]
+  const int EP = E + 4;                // LDS row stride of h/q: +4 floats so the 16 rows of an MFMA
+                                       // A-fragment read (one b128 per lane) fall on different banks
+  float* hs = smem;                    // [TP][EP]
+  float* qs = hs + kDinTP * EP;        // [TP][EP]
+  float* a1 = qs + kDinTP * EP;        // [TP][H1]
   float* a2 = a1 + kDinTP * H1;        // [TP][H2]
   float* w2s = a2 + kDinTP * H2;       // [H1][H2]
   float* w3s = w2s + H1 * H2;          // [H2]
@@ -62,6 +144,7 @@ __global__ __launch_bounds__(kBlock) void din_attention_fwd_kernel(DinArgs a) {
   const int NP2 = (kDinTP + PG2 - 1) / PG2;
   const bool on2 = pg2 < PG2;
   const int e4 = E / 4;
+  const bool use_mfma = (E % 16 == 0) && (H1 % 16 == 0) && H1 <= 16 * kDinNT1;   // block-uniform
   int oob = 0;
   __syncthreads();
 
@@ -85,12 +168,14 @@ __global__ __launch_bounds__(kBlock) void din_attention_fwd_kernel(DinArgs a) {
           if (hid >= 0 && hid < nrow) hv = *reinterpret_cast<const float4*>(wh + hid * ld + c); else oob = 1;
           if (qid >= 0 && qid < nrow) qv = *reinterpret_cast<const float4*>(wq + qid * ld + c); else oob = 1;
         }
-        *reinterpret_cast<float4*>(hs + p * E + c4) = hv;
-        *reinterpret_cast<float4*>(qs + p * E + c4) = qv;
+        *reinterpret_cast<float4*>(hs + p * EP + c4) = hv;
+        *reinterpret_cast<float4*>(qs + p * EP + c4) = qv;
       }
       __syncthreads();
       // ---- attention layer 1: [h, q, h-q, h*q] @ W1 + b1, sigmoid (net.py:155-164)
-      if (on1) {
+      if (use_mfma) {
+        din_layer1_mfma(hs, qs, EP, a.w1, b1s, a1, E, H1);
+      } else if (on1) {
         float s1[kDinNP1];
 #pragma unroll
         for (int i = 0; i < kDinNP1; ++i) s1[i] = 0.f;
@@ -102,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void din_attention_fwd_kernel(DinArgs a) {
           for (int i = 0; i < kDinNP1; ++i) {
             const int p = pg1 + i * PG1;
             if (i < NP1 && p < kDinTP) {
-              const float hv = hs[p * E + kk], qv = qs[p * E + kk];
+              const float hv = hs[p * EP + kk], qv = qs[p * EP + kk];
               s1[i] += hv * wa + qv * wb + (hv - qv) * wc + (hv * qv) * wd;
             }
           }
@@ -147,17 +232,23 @@ __global__ __launch_bounds__(kBlock) void din_attention_fwd_kernel(DinArgs a) {
         a2[tid * H2] = s;   // a2[p][0] doubles as the tile's logit slot (layer 2 output no longer needed)
       }
       __syncthreads();
-      // ---- online softmax + weighted sum of h (net.py:169-171)
+      // ---- online softmax + weighted sum of h (net.py:169-171).  The 32 exponentials of the tile are
+      // computed once (threads 0..31) and shared through LDS instead of once per thread.
       float mt = -INFINITY;
       for (int p = 0; p < kDinTP; ++p) mt = fmaxf(mt, a2[p * H2]);
       const float m_new = fmaxf(m_run, mt);
       const float f = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+      __syncthreads();                       // everyone has read the logits before they are replaced
+      if (tid < kDinTP) {
+        const float sp = a2[tid * H2];
+        a2[tid * H2] = (sp == -INFINITY) ? 0.f : expf(sp - m_new);
+      }
+      __syncthreads();
       float lsum = 0.f, asum = 0.f;
       for (int p = 0; p < kDinTP; ++p) {
-        const float sp = a2[p * H2];
-        const float e = (sp == -INFINITY) ? 0.f : expf(sp - m_new);
+        const float e = a2[p * H2];
         lsum += e;
-        if (tid < E) asum += e * hs[p * E + tid];
+        if (tid < E) asum += e * hs[p * EP + tid];
       }
       l_run = l_run * f + lsum;
       acc = acc * f + asum;
@@ -222,6 +313,7 @@ __global__ __launch_bounds__(kBlock) void din_attention_bwd_kernel(DinBwdArgs g)
   const int kkx = tid % E, pgx = tid / E, PGX = kBlock / E;
   const int NPX = (kDinTP + PGX - 1) / PGX;
   const bool onx = pgx < PGX;
+  const bool use_mfma = (E % 16 == 0) && (H1 % 16 == 0) && H1 <= 16 * kDinNT1;
   __syncthreads();
 
   auto gather_tile = [&](int64_t b, int t0, bool with_q) {
@@ -279,7 +371,9 @@ __global__ __launch_bounds__(kBlock) void din_attention_bwd_kernel(DinBwdArgs g)
     for (int t0 = 0; t0 < T; t0 += kDinTP) {
       gather_tile(b, t0, true);
       __syncthreads();
-      if (on1) {   // recompute layer 1
+      if (use_mfma) {   // recompute layer 1 on the matrix cores (same routine as the forward)
+        din_layer1_mfma(hs, qs, E, a.w1, b1s, a1, E, H1);
+      } else if (on1) {   // recompute layer 1
         float s1[kDinNP1];
 #pragma unroll
         for (int i = 0; i < kDinNP1; ++i) s1[i] = 0.f;
@@ -424,8 +518,8 @@ extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* 
                   w_tgt_item_seq && w_tgt_cat_seq && att_w1 && att_b1 && att_w2 && att_b2 && att_w3 &&
                   att_b3 && out && status, REC_EINVAL, "null pointer argument");
   const int H1 = d->hidden1, H2 = d->hidden2;
-  const size_t shmem = sizeof(float) * ((size_t)2 * kDinTP * E + (size_t)kDinTP * (H1 + H2) + (size_t)H1 * H2 +
-                                        2 * H2 + H1 + (size_t)d->max_len);
+  const size_t shmem = sizeof(float) * ((size_t)2 * kDinTP * (E + 4) + (size_t)kDinTP * (H1 + H2) +
+                                        (size_t)H1 * H2 + 2 * H2 + H1 + (size_t)d->max_len);
   REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "history too long for the LDS logit buffer (%zu B)", shmem);
   DinArgs a;
   a.B = d->batch; a.T = d->max_len; a.Ei = d->item_dim; a.Ec = d->cat_dim; a.H1 = H1; a.H2 = H2;
