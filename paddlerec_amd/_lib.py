@@ -125,6 +125,10 @@ def lib():
             raise RecError(
                 "librecengine.so not found at %s — run `python -m paddlerec_amd.build` "
                 "(there is no CPU fallback)" % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own libamdhip64; it must be the HIP runtime of the process.  If
+        # librecengine.so were loaded first it would pull in /opt/rocm's copy and the process would end up
+        # with two runtimes ("no ROCm-capable device is detected" on the first launch) — so torch goes first.
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError if the symbol is missing
