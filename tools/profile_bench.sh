@@ -24,8 +24,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
-        for tag in ("fm_fwd_kernel", "fm_bwd_kernel", "sparse_adam_rows_kernel", "gemm_f32_kernel"):
-            if tag in k:
+        for tag, pat in (("fm_fwd_kernel", "fm_fwd_"), ("fm_bwd_kernel", "fm_bwd_kernel"), ("sparse_adam_rows_kernel", "sparse_adam_rows_kernel"), ("gemm_f32_kernel", "gemm_f32_kernel")):
+            if pat in k:
                 acc[tag][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in acc.items():
