@@ -135,3 +135,49 @@ def backward(p, att, hist_item, hist_cat, target_item, target_cat, mask, label):
     g["_att"] = ab
     g["_logit"] = logit
     return g
+
+
+# --------------------------------------------------------------------------
+# reader                                              models/rank/din/dinReader.py:46-147
+# --------------------------------------------------------------------------
+def reader_batches(lines, batch_size):
+    """dinReader.py restated as plain loops: groups of 20*batch_size lines are sorted by history length
+    (stable), cut into batches, padded with id 0 to the batch's longest history; mask = 0 / -1e9 (cast to
+    int64 as dinReader.py:99 does); the last group drops its incomplete batch.
+    Yields dicts of arrays for whole batches (the per-sample `yield res` + DataLoader collate of the
+    reference regroup exactly these)."""
+    res0 = []
+    for line in lines:
+        line = line.strip().split(";")
+        if len(line) < 5:
+            continue
+        res0.append([line[0].split(), line[1].split(), line[2], line[3], float(line[4])])
+    group_size = batch_size * 20
+    out = []
+
+    def emit(group, upto):
+        sortb = sorted(group, key=lambda x: len(x[0]))
+        for i in range(0, upto, batch_size):
+            b = sortb[i:i + batch_size]
+            max_len = max(len(x[0]) for x in b)
+            item = np.array([x[0] + [0] * (max_len - len(x[0])) for x in b]).astype("int64").reshape([-1, max_len])
+            cat = np.array([x[1] + [0] * (max_len - len(x[1])) for x in b]).astype("int64").reshape([-1, max_len])
+            mask = np.array([[0] * len(x[0]) + [-1e9] * (max_len - len(x[0])) for x in b]).reshape([-1, max_len, 1])
+            out.append(dict(
+                hist_item=item, hist_cat=cat,
+                target_item=np.array([x[2] for x in b]).astype("int64"),
+                target_cat=np.array([x[3] for x in b]).astype("int64"),
+                label=np.array([x[4] for x in b]).astype("float32").reshape(-1, 1),
+                mask=mask.astype("int64"),
+                target_item_seq=np.array([[x[2]] * max_len for x in b]).astype("int64").reshape([-1, max_len]),
+                target_cat_seq=np.array([[x[3]] * max_len for x in b]).astype("int64").reshape([-1, max_len])))
+
+    bg = []
+    for rec in res0:
+        bg.append(rec)
+        if len(bg) == group_size:
+            emit(bg, group_size)
+            bg = []
+    if bg:
+        emit(bg, len(bg) - len(bg) % batch_size)
+    return out

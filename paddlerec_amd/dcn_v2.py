@@ -365,3 +365,41 @@ class DCN_V2Layer:
             b = torch.zeros(1, dtype=torch.float32, device=self.device)
             setattr(self, "_s_" + name, b)
         return b
+
+
+class DygraphModel:
+    """dcn_v2/dygraph_model.py:24-140 — same method names; tensors are torch device tensors."""
+
+    def create_model(self, config, device="cuda"):
+        g = config.get
+        return DCN_V2Layer(g("hyper_parameters.sparse_feature_number"), g("hyper_parameters.sparse_feature_dim"),
+                           g("hyper_parameters.dense_input_dim"), g("hyper_parameters.sparse_inputs_slots") - 1,
+                           g("hyper_parameters.fc_sizes"), g("hyper_parameters.cross_num"),
+                           g("hyper_parameters.is_Stacked", None), g("hyper_parameters.use_low_rank_mixture", None),
+                           g("hyper_parameters.low_rank", 32), g("hyper_parameters.num_experts", 4), device=device)
+
+    def create_feeds(self, batch_data, config, device="cuda"):
+        dn = config.get("hyper_parameters.dense_input_dim")
+        sparse = [torch.as_tensor(b).to(torch.int64).reshape(-1, 1).to(device) for b in batch_data[:-1]]
+        dense = torch.as_tensor(batch_data[-1]).to(torch.float32).reshape(-1, dn).to(device)
+        return sparse[0], sparse[1:], dense
+
+    def create_metrics(self, device="cuda"):
+        stats = (torch.zeros(NUM_THRESHOLDS + 1, dtype=torch.int64, device=device),
+                 torch.zeros(NUM_THRESHOLDS + 1, dtype=torch.int64, device=device))
+        return [stats], ["auc"]
+
+    def train_forward(self, dy_model, metrics_list, batch_data, config):
+        label, sparse, dense = self.create_feeds(batch_data, config, dy_model.device)
+        lr = config.get("hyper_parameters.optimizer.learning_rate", 0.001)
+        clip = config.get("hyper_parameters.optimizer.clip_by_norm", 10.0)        # dygraph_model.py:83-85
+        loss, _ = dy_model.train_step(sparse, dense, label, lr, clip, metrics_list[0] if metrics_list else None)
+        return loss, metrics_list, {"log_loss": loss}
+
+    def infer_forward(self, dy_model, metrics_list, batch_data, config):
+        label, sparse, dense = self.create_feeds(batch_data, config, dy_model.device)
+        pred = dy_model.forward(sparse, dense)
+        if metrics_list:
+            ops.auc_histogram(pred.contiguous(), label.contiguous(), metrics_list[0][0], metrics_list[0][1],
+                              NUM_THRESHOLDS)
+        return metrics_list, None

@@ -169,3 +169,45 @@ class DINLayer:
         if b is None:
             b = self._gb[name] = torch.empty_like(self.params[name])
         return b
+
+
+NUM_THRESHOLDS = 4095  # paddle.metric.Auc default [EXT]
+
+
+class DygraphModel:
+    """din/dygraph_model.py:21-113 — same method names; tensors are torch device tensors."""
+
+    def create_model(self, config, device="cuda"):
+        g = config.get
+        return DINLayer(g("hyper_parameters.item_emb_size", 64), g("hyper_parameters.cat_emb_size", 64),
+                        g("hyper_parameters.act", "sigmoid"), g("hyper_parameters.is_sparse", False),
+                        g("hyper_parameters.use_DataLoader", False), g("hyper_parameters.item_count", 63001),
+                        g("hyper_parameters.cat_count", 801), device=device)
+
+    def create_feeds(self, batch, config, device="cuda"):
+        t = [torch.as_tensor(x).to(device) for x in batch]
+        label = t[4].to(torch.float32).reshape(-1, 1)                                  # dygraph_model.py:52
+        return t[0], t[1], t[2], t[3], label, t[5], t[6], t[7]
+
+    def create_metrics(self, device="cuda"):
+        stats = (torch.zeros(NUM_THRESHOLDS + 1, dtype=torch.int64, device=device),
+                 torch.zeros(NUM_THRESHOLDS + 1, dtype=torch.int64, device=device))
+        return [stats], ["auc"]
+
+    def _auc(self, metrics_list, pred, label):
+        if metrics_list:
+            ops.auc_histogram(pred.contiguous(), label.to(torch.int64).contiguous(), metrics_list[0][0],
+                              metrics_list[0][1], NUM_THRESHOLDS)
+
+    def train_forward(self, dy_model, metrics_list, batch_data, config):
+        feeds = self.create_feeds(batch_data, config, dy_model.device)
+        base_lr = config.get("hyper_parameters.optimizer.learning_rate_base_lr")
+        loss, pred = dy_model.train_step(*feeds, base_lr=base_lr)
+        self._auc(metrics_list, pred, feeds[4])
+        return loss, metrics_list, {"loss": loss}
+
+    def infer_forward(self, dy_model, metrics_list, batch_data, config):
+        feeds = self.create_feeds(batch_data, config, dy_model.device)
+        pred = torch.sigmoid(dy_model.forward(*feeds))
+        self._auc(metrics_list, pred, feeds[4])
+        return metrics_list, None

@@ -96,3 +96,51 @@ class CriteoTsvReader(_FileBatches):
     def __init__(self, file_list, batch_size, device="cuda", hash_dim=HASH_DIM, shard=None, threads=0):
         super().__init__(file_list, batch_size, device,
                          lambda data: parse_criteo_tsv(data, 13, 26, hash_dim, threads, pinned=True), shard)
+
+
+class DinReader:
+    """models/rank/din/dinReader.py RecDataset: lines "hist items;hist cats;target item;target cat;label".
+    Groups of 20*batch_size samples are sorted by history length (stable) and cut into batches padded to the
+    batch's longest history; yields (hist_item [B,T], hist_cat [B,T], target_item [B], target_cat [B],
+    label [B,1] f32, mask [B,T,1] i64 (0 / -1e9), target_item_seq [B,T], target_cat_seq [B,T]) on `device` —
+    the eight feeds of din/dygraph_model.py:47-56.  (The reference also scans the files for the longest
+    history and writes it to ./tmp.txt, dinReader.py:29-43 — an unused side effect that is not reproduced.)"""
+
+    def __init__(self, file_list, batch_size, device="cuda"):
+        self.file_list, self.batch_size, self.device = list(file_list), int(batch_size), device
+
+    def _emit(self, group, upto):
+        B = self.batch_size
+        lens = np.fromiter((len(g[0]) for g in group), dtype=np.int64, count=len(group))
+        order = np.argsort(lens, kind="stable")
+        for i in range(0, upto, B):
+            idx = order[i:i + B]
+            T = int(lens[idx].max())
+            item = np.zeros((len(idx), T), np.int64)
+            cat = np.zeros((len(idx), T), np.int64)
+            for r, k in enumerate(idx):
+                item[r, :lens[k]] = group[k][0]
+                cat[r, :lens[k]] = group[k][1]
+            ti = np.array([group[k][2] for k in idx], np.int64)
+            tc = np.array([group[k][3] for k in idx], np.int64)
+            label = np.array([group[k][4] for k in idx], np.float32).reshape(-1, 1)
+            mask = np.where(np.arange(T)[None, :] < lens[idx][:, None], 0, -1000000000).astype(np.int64)
+            arrs = (item, cat, ti, tc, label, mask.reshape(-1, T, 1), np.repeat(ti[:, None], T, 1),
+                    np.repeat(tc[:, None], T, 1))
+            yield tuple(torch.from_numpy(np.ascontiguousarray(a)).to(self.device, non_blocking=True) for a in arrs)
+
+    def __iter__(self):
+        group, gsz = [], self.batch_size * 20
+        for path in self.file_list:
+            with open(path, "r") as f:
+                for line in f:
+                    parts = line.strip().split(";")
+                    if len(parts) < 5:
+                        continue
+                    group.append((np.array(parts[0].split(), np.int64), np.array(parts[1].split(), np.int64),
+                                  int(parts[2]), int(parts[3]), float(parts[4])))
+                    if len(group) == gsz:
+                        yield from self._emit(group, gsz)
+                        group = []
+        if group:
+            yield from self._emit(group, len(group) - len(group) % self.batch_size)

@@ -120,3 +120,20 @@ def test_file_batches_drop_last(reader, tmp_path):
     ol, oi, _ = _oracle_slot(lines + lines)
     assert np.array_equal(lab, ol[:48])
     assert np.array_equal(np.concatenate([b[1].numpy() for b in batches]), oi[:48])
+
+
+@pytest.mark.parametrize("bs", [4, 1, 7])
+def test_din_reader_matches_reference_restatement(reader, bs):
+    """Sorting by history length inside 20*bs groups, padding, mask, repeated target — vs oracle/din_ref.py
+    on the first 40 lines of the reference's own sample file."""
+    from oracle import din_ref
+    path = os.path.join(GOLDEN, "din_sample.txt")
+    lines = open(path).read().strip().split("\n")
+    want = din_ref.reader_batches(lines, bs)
+    got = list(reader.DinReader([path], bs, device="cpu"))
+    assert len(got) == len(want) and len(got) == (len(lines) // (bs * 20)) * 20 + (len(lines) % (bs * 20)) // bs
+    keys = ("hist_item", "hist_cat", "target_item", "target_cat", "label", "mask", "target_item_seq", "target_cat_seq")
+    for g, w in zip(got, want):
+        for t, k in zip(g, keys):
+            assert np.array_equal(t.numpy(), w[k]), k
+            assert t.numpy().dtype == w[k].dtype, k
