@@ -57,7 +57,14 @@ typedef struct {
                           HBM fetches whole 128-B lines: a table kept as 32-float records
                           [W(16) | W1 | ...] (W1 = W + 16, both strides 32) costs ONE line per
                           lookup instead of two (see DESIGN.md "table layout"). */
-  int32_t reserved;
+  int32_t compact_dense; /* 0: feat = [B, S+Dn, D] (= feat_embeddings, net.py:120).
+                            1: feat = [B, S+1, D]: the S embedding rows plus ONE row holding the Dn raw dense
+                            values (zero padded to D; needs Dn <= D).  The dense "embeddings" x_j*dense_w[j,:]
+                            are never materialised: the FM sums still include them (computed in registers),
+                            and the top MLP's first layer sees them through folded weights
+                            (rec_dense_fold_fwd): feat'[B,(S+1)D] @ [W0_sparse; M; 0] == feat[B,(S+Dn)D] @ W0.
+                            In this mode rec_deepfm_fm_bwd takes d_feat_dnn in the same [B,S+1,D] layout and
+                            its d_dense_w holds the FM part only (the MLP part comes from rec_dense_fold_bwd). */
 } rec_deepfm_desc;
 
 /* ids [B,S] i64 (= paddle.concat(sparse_inputs,1), net.py:107); dense [B,Dn] f32;
@@ -83,6 +90,19 @@ int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense, const flo
                       const float* sum_emb, const float* d_feat_dnn, const float* dy1,
                       const float* dy2, const float* dense_w, float* row_grad, float* d_dense_w,
                       float* d_dense_w_one, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Folding the dense "embeddings" into the first MLP layer (compact_dense = 1 above).
+ *   fwd: M[j,n] = sum_d dense_w[j,d] * W0[(S+j)*D + d, n]                    -> M [Dn, n_out]
+ *        so that  sum_j x_j * (dense_w[j,:] @ W0_rows(j))  ==  x @ M   (net.py:110-119,170-171 re-associated)
+ *   bwd: given dM [Dn, n_out] (rows S*D .. S*D+Dn-1 of feat'^T dZ0):
+ *        dW0[(S+j)*D + d, n] = dense_w[j,d] * dM[j,n];   d_dense_w[j,d] (+)= sum_n dM[j,n] * W0[(S+j)*D+d, n]
+ * W0 is the layer's weight [ (S+Dn)*D, n_out ] (Paddle [in,out]); dW0 its gradient buffer (only the dense rows
+ * are written). */
+int rec_dense_fold_fwd(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out,
+                       const float* dense_w, const float* W0, float* M, void* stream);
+int rec_dense_fold_bwd(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out,
+                       const float* dense_w, const float* W0, const float* dM, float* dW0,
+                       float* d_dense_w, int32_t accumulate_ddw, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Plain lookup and LoD sum-pool.

@@ -18,7 +18,7 @@ class RecError(RuntimeError):
 class DeepFMDesc(C.Structure):
     _fields_ = [("batch", C.c_int64), ("num_slots", C.c_int32), ("num_dense", C.c_int32),
                 ("emb_dim", C.c_int32), ("row_stride", C.c_int32), ("num_rows", C.c_int64),
-                ("padding_idx", C.c_int64), ("w1_stride", C.c_int32), ("reserved", C.c_int32)]
+                ("padding_idx", C.c_int64), ("w1_stride", C.c_int32), ("compact_dense", C.c_int32)]
 
 
 class AdamHyper(C.Structure):
@@ -68,6 +68,8 @@ SIGNATURES = {
     "rec_deepfm_fm_fwd": (C.c_int, [C.POINTER(DeepFMDesc)] + [_P] * 13),
     "rec_deepfm_fm_bwd_workspace_bytes": (C.c_int, [C.POINTER(DeepFMDesc), C.POINTER(_SZ)]),
     "rec_deepfm_fm_bwd": (C.c_int, [C.POINTER(DeepFMDesc)] + [_P] * 11 + [_SZ, _P]),
+    "rec_dense_fold_fwd": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "rec_dense_fold_bwd": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "rec_emb_gather": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, _P, _I32, _I64, _P, _P]),
     "rec_emb_gather_sumpool": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "rec_emb_sumpool_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _P]),

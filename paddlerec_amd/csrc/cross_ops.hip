@@ -163,3 +163,69 @@ extern "C" int rec_softmax_rows_bwd(int64_t m, int32_t n, const float* p, int32_
                      p, (int64_t)ldp, dp, (int64_t)lddp, dz, (int64_t)lddz);
   return check_launch("rec_softmax_rows_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Dense-field folding for the DeepFM top MLP (rec_deepfm_desc.compact_dense): tiny parameter-space kernels.
+namespace rec {
+__global__ __launch_bounds__(kBlock) void dense_fold_fwd_kernel(int S, int Dn, int D, int NO,
+                                                                const float* __restrict__ dw,
+                                                                const float* __restrict__ W0,
+                                                                float* __restrict__ M) {
+  for (int e = blockIdx.x * kBlock + threadIdx.x; e < Dn * NO; e += gridDim.x * kBlock) {
+    const int j = e / NO, n = e % NO;
+    float t = 0.f;
+    for (int d = 0; d < D; ++d) t += dw[j * D + d] * W0[(int64_t)((S + j) * D + d) * NO + n];
+    M[e] = t;
+  }
+}
+__global__ __launch_bounds__(kBlock) void dense_fold_bwd_w_kernel(int S, int Dn, int D, int NO,
+                                                                  const float* __restrict__ dw,
+                                                                  const float* __restrict__ dM,
+                                                                  float* __restrict__ dW0) {
+  for (int e = blockIdx.x * kBlock + threadIdx.x; e < Dn * D * NO; e += gridDim.x * kBlock) {
+    const int n = e % NO, jd = e / NO, j = jd / D;
+    dW0[(int64_t)(S * D + jd) * NO + n] = dw[jd] * dM[j * NO + n];
+  }
+}
+// one block per (j,d): d_dense_w[j,d] (+)= sum_n dM[j,n] * W0[(S+j)*D+d, n]   (fixed-order tree)
+__global__ __launch_bounds__(kBlock) void dense_fold_bwd_dw_kernel(int S, int D, int NO,
+                                                                   const float* __restrict__ W0,
+                                                                   const float* __restrict__ dM,
+                                                                   float* __restrict__ ddw, int accumulate) {
+  __shared__ float red[kBlock];
+  const int jd = blockIdx.x, j = jd / D;
+  float t = 0.f;
+  for (int n = threadIdx.x; n < NO; n += kBlock) t += dM[j * NO + n] * W0[(int64_t)(S * D + jd) * NO + n];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ddw[jd] = (accumulate ? ddw[jd] : 0.f) + red[0];
+}
+}  // namespace rec
+
+extern "C" int rec_dense_fold_fwd(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out,
+                                  const float* dense_w, const float* W0, float* M, void* stream) {
+  REC_REQUIRE(num_slots > 0 && num_dense > 0 && emb_dim > 0 && n_out > 0 && dense_w && W0 && M, REC_EINVAL,
+              "bad arguments");
+  const int total = num_dense * n_out;
+  hipLaunchKernelGGL(rec::dense_fold_fwd_kernel, dim3((total + rec::kBlock - 1) / rec::kBlock), dim3(rec::kBlock),
+                     0, (hipStream_t)stream, num_slots, num_dense, emb_dim, n_out, dense_w, W0, M);
+  return rec::check_launch("rec_dense_fold_fwd");
+}
+
+extern "C" int rec_dense_fold_bwd(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out,
+                                  const float* dense_w, const float* W0, const float* dM, float* dW0,
+                                  float* d_dense_w, int32_t accumulate_ddw, void* stream) {
+  REC_REQUIRE(num_slots > 0 && num_dense > 0 && emb_dim > 0 && n_out > 0 && dense_w && W0 && dM && dW0 &&
+                  d_dense_w, REC_EINVAL, "bad arguments");
+  const int total = num_dense * emb_dim * n_out;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rec::dense_fold_bwd_w_kernel, dim3((total + rec::kBlock - 1) / rec::kBlock),
+                     dim3(rec::kBlock), 0, st, num_slots, num_dense, emb_dim, n_out, dense_w, dM, dW0);
+  hipLaunchKernelGGL(rec::dense_fold_bwd_dw_kernel, dim3(num_dense * emb_dim), dim3(rec::kBlock), 0, st,
+                     num_slots, emb_dim, n_out, W0, dM, d_dense_w, accumulate_ddw);
+  return rec::check_launch("rec_dense_fold_bwd");
+}

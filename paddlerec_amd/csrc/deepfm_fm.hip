@@ -20,6 +20,8 @@
 //        current tile's rows are gathered; they reach the lanes that need them through a per-wave LDS
 //        staging area.  Invalid lookups (padding, out of range, dense slots) read row 0 and are
 //        zeroed with selects; the out-of-range flag is raised once per wave at the end.
+//        (A software-pipelined variant holding two tiles in registers was measured and dropped: 128 VGPRs with
+//        spills, 78.8 us vs 72.4 us for this kernel on the Criteo shape.)
 //   bwd: the dense-field index of a lane is fixed across samples, so the batch reductions
 //        d_dense_w / d_dense_w_one accumulate in registers over the persistent loop and are folded
 //        in a fixed order (deterministic); the dense part of feat is recomputed as x * dense_w
@@ -51,7 +53,7 @@ constexpr int kDenseCh = 2;  // ceil(SPW_max * kDnMax / 64) = 8*16/64
 
 template <int VEC, int LANES, int IDCH>
 __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
-    int64_t B, int S, int Dn, int D, int stride, int w1_stride, int64_t N, int64_t pad,
+    int64_t B, int S, int Dn, int D, int FP, int stride, int w1_stride, int64_t N, int64_t pad,
     const int64_t* __restrict__ ids, const float* __restrict__ dense, const float* __restrict__ W,
     const float* __restrict__ W1, const float* __restrict__ dense_w,
     const float* __restrict__ dense_w_one, const int64_t* __restrict__ slot_off,
@@ -140,7 +142,8 @@ __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
 #pragma unroll
     for (int v = 0; v < VEC; ++v) s[v] = q[v] = 0.f;
     float first = 0.f;
-    float* fb = feat + (b * F) * (int64_t)D + d0;
+    float* fb = feat + (b * FP) * (int64_t)D + d0;
+    const bool compact = FP != F;   // feat = S embedding rows + ONE row of raw dense values (see header)
 
     for (int it0 = 0; it0 < NIT; it0 += kFwdUnroll) {
       int f[kFwdUnroll];
@@ -197,7 +200,13 @@ __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
             s[v] += e[u][v];
             q[v] += e[u][v] * e[u][v];
           }
-          vstore<VEC>(fb + (int64_t)f[u] * D, e[u]);
+          if (!compact || f[u] < S) vstore<VEC>(fb + (int64_t)f[u] * D, e[u]);
+          if (compact && f[u] == S) {
+            float xr[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) xr[v] = (d0 + v < Dn) ? w_dense[sp * Dn + d0 + v] : 0.f;
+            vstore<VEC>(fb + (int64_t)S * D, xr);
+          }
         }
       }
     }
@@ -226,210 +235,13 @@ __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
   if (oob) atomicOr(status, REC_FLAG_INDEX_OOB);
 }
 
-// ------------------------------------------------------------------------- fwd, software-pipelined
-// Same arithmetic and data layout as fm_fwd_kernel, but a wave keeps TWO tiles in registers: while the rows
-// of tile i+1 are being gathered, tile i is reduced and stored — the gather phase and the store phase of one
-// wave overlap instead of alternating (measured: gather-only 58 us, store-only 44 us, alternating 84 us).
-// The wave-iteration structure is fixed at compile time (NIT iterations, the first NSP of which may hold
-// sparse fields) so everything stays in registers; the host dispatches here for the shapes it is built for
-// (Criteo DeepFM: S=26, Dn=13, D=16 -> NIT=5, NSP=4) and to fm_fwd_kernel otherwise.
-template <int VEC, int NSP, int NIT>
-struct FwdTile {
-  float e[NSP][VEC];
-  float one[NSP];
-  float xd[NIT];
-  unsigned hit;
-  int64_t b;
-  bool active;
-};
-
-template <int VEC, int LANES, int NSP, int NIT>
-__global__ __launch_bounds__(kBlock, 4) void fm_fwd_pipe_kernel(
-    int64_t B, int S, int Dn, int D, int stride, int w1_stride, int64_t N, int64_t pad,
-    const int64_t* __restrict__ ids, const float* __restrict__ dense, const float* __restrict__ W,
-    const float* __restrict__ W1, const float* __restrict__ dense_w,
-    const float* __restrict__ dense_w_one, const int64_t* __restrict__ slot_off,
-    float* __restrict__ y1, float* __restrict__ y2, float* __restrict__ feat,
-    float* __restrict__ sum_emb, int32_t* __restrict__ status) {
-  constexpr int FS = fs_for<LANES>();
-  constexpr int SPW = kWave / (LANES * FS);
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* s_dw = reinterpret_cast<float*>(smem_raw);
-  float* s_dw1 = s_dw + Dn * D;
-  const int hdr = ((Dn * D + Dn) * 4 + 15) & ~15;
-  int64_t* s_off = reinterpret_cast<int64_t*>(smem_raw + hdr);
-  const int ids_per_tile = SPW * S, dense_per_tile = SPW * Dn;   // <= 64 / <= 128 (checked on the host)
-  const int wave_bytes = (ids_per_tile * 8 + dense_per_tile * 4 + 15) & ~15;
-  const int lane = threadIdx.x % kWave;
-  const int wave = threadIdx.x / kWave;
-  unsigned char* wbase = smem_raw + hdr + S * 8 + wave * wave_bytes;
-  int64_t* w_ids = reinterpret_cast<int64_t*>(wbase);
-  float* w_dense = reinterpret_cast<float*>(wbase + ids_per_tile * 8);
-  for (int i = threadIdx.x; i < Dn * D; i += kBlock) s_dw[i] = dense_w[i];
-  for (int i = threadIdx.x; i < Dn; i += kBlock) s_dw1[i] = dense_w_one[i];
-  for (int i = threadIdx.x; i < S; i += kBlock) s_off[i] = slot_off ? slot_off[i] : 0;
-  __syncthreads();
-
-  const int lg = lane % LANES;
-  const int fs = (lane / LANES) % FS;
-  const int sp = lane / (LANES * FS);
-  const int d0 = lg * VEC;
-  const int F = S + Dn;
-  const int64_t ntiles = (B + SPW - 1) / SPW;
-  const int64_t tstride = (int64_t)gridDim.x * kWavesPerBlock;
-  const int64_t n_ids = B * S, n_dense = B * Dn;
-  int oob = 0;
-  int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  if (tile >= ntiles) return;
-
-  int64_t pre_id;
-  float pre_dense[kDenseCh];
-  auto prefetch = [&](int64_t t) {
-    int64_t gi = t * ids_per_tile + lane;
-    gi = gi < n_ids ? gi : n_ids - 1;
-    pre_id = ids[gi];
-    if (Dn > 0) {
-#pragma unroll
-      for (int c = 0; c < kDenseCh; ++c) {
-        int64_t gd = t * dense_per_tile + c * kWave + lane;
-        gd = gd < n_dense ? gd : n_dense - 1;
-        pre_dense[c] = dense[gd];
-      }
-    }
-  };
-  auto stage = [&]() {
-    if (lane < ids_per_tile) w_ids[lane] = pre_id;
-    if (Dn > 0) {
-#pragma unroll
-      for (int c = 0; c < kDenseCh; ++c) {
-        const int i = c * kWave + lane;
-        if (i < dense_per_tile) w_dense[i] = pre_dense[c];
-      }
-    }
-    wave_lds_fence();
-  };
-  using Tile = FwdTile<VEC, NSP, NIT>;
-  auto issue = [&](Tile& t, int64_t tl) {   // gathers of tile tl (its ids / dense are staged in LDS)
-    t.b = tl * SPW + sp;
-    t.active = t.b < B;
-    t.hit = 0;
-    int64_t row[NSP];
-#pragma unroll
-    for (int u = 0; u < NSP; ++u) {
-      const int f = u * FS + fs;
-      const bool sparse = f < S;
-      const int fi = sparse ? f : 0;
-      const int64_t id = w_ids[sp * S + fi];
-      const int64_t r = id + s_off[fi];
-      const bool live = sparse && t.active && (id != pad || pad < 0);
-      const bool inr = r >= 0 && r < N;
-      oob |= (live && !inr) ? 1 : 0;
-      const bool h = live && inr;
-      t.hit |= h ? (1u << u) : 0u;
-      row[u] = h ? r : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < NIT; ++u) {
-      const int f = u * FS + fs;
-      const bool isdense = f >= S && f < F;
-      t.xd[u] = (isdense && Dn > 0) ? w_dense[sp * Dn + (isdense ? f - S : 0)] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < NSP; ++u) {
-      if (d0 < D) vload<VEC>(t.e[u], W + row[u] * stride + d0);
-      else {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) t.e[u][v] = 0.f;
-      }
-      t.one[u] = W1[row[u] * w1_stride];
-    }
-  };
-  auto consume = [&](const Tile& t) {
-    const bool dvalid = t.active && d0 < D;
-    float s[VEC], q[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) s[v] = q[v] = 0.f;
-    float first = 0.f;
-    float* fb = feat + (t.b * F) * (int64_t)D + d0;
-#pragma unroll
-    for (int u = 0; u < NIT; ++u) {
-      const int f = u * FS + fs;
-      const bool isdense = f >= S && f < F;
-      const int j = isdense ? f - S : 0;
-      const bool h = (u < NSP) && ((t.hit >> u) & 1u);
-      const float x = t.xd[u];
-      float o1 = h ? t.one[u < NSP ? u : 0] : 0.f;
-      o1 = isdense ? x * s_dw1[j] : o1;
-      first += (lg == 0) ? o1 : 0.f;
-      float ev[VEC];
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        float val = h ? t.e[u < NSP ? u : 0][v] : 0.f;
-        if (isdense && d0 + v < D) val = x * s_dw[j * D + d0 + v];
-        ev[v] = val;
-      }
-      if (dvalid && f < F) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          s[v] += ev[v];
-          q[v] += ev[v] * ev[v];
-        }
-        vstore<VEC>(fb + (int64_t)f * D, ev);
-      }
-    }
-#pragma unroll
-    for (int o = LANES; o < LANES * FS; o <<= 1) {
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        s[v] += __shfl_xor(s[v], o, kWave);
-        q[v] += __shfl_xor(q[v], o, kWave);
-      }
-    }
-    float part = 0.f;
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) part += s[v] * s[v] - q[v];
-    if (!dvalid) part = 0.f;
-    const float tot2 = group_sum<LANES>(part);
-    const float tot1 = group_sum<LANES * FS>(t.active ? first : 0.f);
-    if (dvalid && fs == 0 && sum_emb) vstore<VEC>(sum_emb + t.b * D + d0, s);
-    if (t.active && fs == 0 && lg == 0) {
-      y1[t.b] = tot1;
-      y2[t.b] = 0.5f * tot2;
-    }
-  };
-
-  Tile cur, nxt;
-  prefetch(tile);
-  stage();
-  {
-    const int64_t t2 = tile + tstride;
-    prefetch(t2 < ntiles ? t2 : ntiles - 1);
-  }
-  issue(cur, tile);
-  for (;;) {
-    const int64_t nt = tile + tstride;
-    const bool more = nt < ntiles;
-    if (more) {                       // wave-uniform
-      stage();
-      const int64_t t3 = nt + tstride;
-      prefetch(t3 < ntiles ? t3 : ntiles - 1);
-      issue(nxt, nt);
-    }
-    consume(cur);
-    if (!more) break;
-    cur = nxt;
-    tile = nt;
-  }
-  if (oob) atomicOr(status, REC_FLAG_INDEX_OOB);
-}
-
 // ------------------------------------------------------------------------------------------ bwd
 constexpr int kBwdUnroll = 4;
 constexpr int kMaxDenseIters = 8;   // wave iterations that may contain dense fields
 
 template <int VEC, int LANES, int NDI>
 __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
-    int64_t B, int S, int Dn, int D, const float* __restrict__ dense,
+    int64_t B, int S, int Dn, int D, int FP, const float* __restrict__ dense,
     const float* __restrict__ feat, const float* __restrict__ sum_emb,
     const float* __restrict__ dfeat, const float* __restrict__ dy1, const float* __restrict__ dy2,
     const float* __restrict__ dense_w, float* __restrict__ row_grad, float* __restrict__ partial) {
@@ -475,8 +287,10 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
       g1 = dy1[b];
       g2 = dy2[b];
     }
-    const float* fb = feat + (b * F) * (int64_t)D + d0;
-    const float* gb = dfeat + (b * F) * (int64_t)D + d0;
+    const float* fb = feat + (b * FP) * (int64_t)D + d0;
+    const float* gb = dfeat + (b * FP) * (int64_t)D + d0;
+    const bool compact = FP != F;   // dense fields have no rows in feat / dfeat: their d_dnn part is handled
+                                    // by the caller through the folded layer-0 weights (see header)
     float* rg = row_grad + (b * S) * (int64_t)D + d0;
     // wave iterations that (may) hold dense fields first: their loads are the irregular ones
     float ed[NDI][VEC], gd[NDI][VEC], xd[NDI];
@@ -488,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
 #pragma unroll
       for (int v = 0; v < VEC; ++v) ed[k][v] = gd[k][v] = 0.f;
       if (ok) {
-        vload<VEC>(gd[k], gb + (int64_t)f * D);
+        if (!(compact && f >= S)) vload<VEC>(gd[k], gb + (int64_t)f * D);
         if (f >= S) xd[k] = dense[b * Dn + (f - S)];
         if (f < S || !dense_w) vload<VEC>(ed[k], fb + (int64_t)f * D);
       }
@@ -619,6 +433,9 @@ extern "C" int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids
   const int S = desc->num_slots, Dn = desc->num_dense, D = desc->emb_dim;
   hipStream_t st = (hipStream_t)stream;
   const int w1_stride = desc->w1_stride > 0 ? desc->w1_stride : 1;
+  REC_REQUIRE(!desc->compact_dense || (Dn > 0 && Dn <= D), REC_ESHAPE,
+              "compact_dense needs 0 < num_dense <= emb_dim");
+  const int FP = desc->compact_dense ? S + 1 : S + Dn;
   return dispatch_row_shape(D, desc->row_stride, [&](auto vec, auto lanes) -> int {
     constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
     constexpr int SPW = kWave / (LANES * fs_for<LANES>());
@@ -631,28 +448,12 @@ extern "C" int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids
     REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "LDS staging %zu B too large", shmem);
     const int64_t ntiles = (desc->batch + SPW - 1) / SPW;
     const int64_t want = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    {   // software-pipelined kernel for the shapes it is instantiated for
-      constexpr int FS = fs_for<LANES>();
-      const int nit = (S + Dn + FS - 1) / FS, nsp = (S + FS - 1) / FS;
-      static const bool no_pipe = getenv("REC_FM_NOPIPE") != nullptr;
-      if (!no_pipe && VEC == 4 && LANES == 4 && idch == 1 && SPW * Dn <= kDenseCh * kWave && nit == 5 &&
-          nsp == 4) {
-        auto kern = fm_fwd_pipe_kernel<4, 4, 4, 5>;
-        int64_t grid = resident_blocks(kern, kBlock, shmem);
-        if (grid > want) grid = want;
-        if (grid > kMaxBlocks) grid = kMaxBlocks;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), shmem, st, desc->batch, S, Dn, D,
-                           desc->row_stride, w1_stride, desc->num_rows, desc->padding_idx, ids, dense, W, W1,
-                           dense_w, dense_w_one, slot_offset, y1, y2, feat, sum_emb, status);
-        return check_launch("rec_deepfm_fm_fwd");
-      }
-    }
 #define REC_FWD_LAUNCH(IDCH)                                                                      \
   int64_t grid = resident_blocks(fm_fwd_kernel<VEC, LANES, IDCH>, kBlock, shmem);                 \
   if (grid > want) grid = want;                                                                   \
   if (grid > kMaxBlocks) grid = kMaxBlocks;                                                       \
   hipLaunchKernelGGL((fm_fwd_kernel<VEC, LANES, IDCH>), dim3((unsigned)grid), dim3(kBlock), shmem, \
-                     st, desc->batch, S, Dn, D, desc->row_stride, w1_stride, desc->num_rows,       \
+                     st, desc->batch, S, Dn, D, FP, desc->row_stride, w1_stride, desc->num_rows,   \
                      desc->padding_idx, ids, dense, W, W1, dense_w, dense_w_one, slot_offset, y1,  \
                      y2, feat, sum_emb, status)
     if (idch <= 1) { REC_FWD_LAUNCH(1); }
@@ -689,6 +490,9 @@ extern "C" int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense
               workspace_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   const int K = Dn * D + Dn;
+  REC_REQUIRE(!desc->compact_dense || (Dn > 0 && Dn <= D && dense_w), REC_ESHAPE,
+              "compact_dense needs 0 < num_dense <= emb_dim and dense_w");
+  const int FP = desc->compact_dense ? S + 1 : S + Dn;
   if (desc->batch == 0) {
     if (K) {
       (void)hipMemsetAsync(d_dense_w, 0, (size_t)Dn * D * sizeof(float), st);
@@ -718,7 +522,7 @@ extern "C" int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense
     grid = (int)g;                                                                                \
   }                                                                                               \
   hipLaunchKernelGGL((fm_bwd_kernel<VEC, LANES, NDI>), dim3(grid), dim3(kBlock), shmem, st,       \
-                     desc->batch, S, Dn, D, dense, feat, sum_emb, d_feat_dnn, dy1, dy2, dense_w,  \
+                     desc->batch, S, Dn, D, FP, dense, feat, sum_emb, d_feat_dnn, dy1, dy2, dense_w, \
                      row_grad, partial)
     if (nd <= 1) { REC_BWD_LAUNCH(1); }
     else if (nd <= 2) { REC_BWD_LAUNCH(2); }

@@ -137,6 +137,14 @@ class DeepFMLayer:
         self.mlp_db = [self.dense.g["dnn.linear_%d.bias" % i] for i in range(self.n_linear)]
         # sparse Adam state (lazy rows) + bookkeeping
         self.sparse_state = None
+        # Dense "embeddings" x_j * dense_w[j,:] are never materialised (DESIGN.md §3 "compact feat"): feat keeps
+        # the S embedding rows + one row of raw dense values, and layer 0 runs on folded weights
+        #   W0' = [ W0[:S*D] ; M ; 0 ],  M[j,:] = dense_w[j,:] @ W0[(S+j)*D:(S+j+1)*D, :]   (rebuilt every step)
+        self.compact = 0 < Dn <= D
+        self.fp = (sparse_num_field + 1) if self.compact else self.num_field      # fields per sample in feat
+        if self.compact:
+            self._w0p = torch.zeros(self.fp * D, sizes[1], dtype=torch.float32, device=self.device)
+            self._dm = torch.zeros(Dn, sizes[1], dtype=torch.float32, device=self.device)
         self.ws = self.k.Workspace(self.device)
         self.ws_group = self.k.Workspace(self.device)
         self.ws_mlp = self.k.Workspace(self.device)
@@ -168,13 +176,35 @@ class DeepFMLayer:
 
     def _fm_fwd(self, ids, dense_inputs):
         return self.k.deepfm_fm_fwd(ids, dense_inputs, self.fm.embedding, self.fm.embedding_one,
-                                 self.dense.p["fm.dense_w"], self.dense.p["fm.dense_w_one"],
-                                 self.fm.padding_idx, self.fm.slot_offset, self.status)
+                                    self.dense.p["fm.dense_w"], self.dense.p["fm.dense_w_one"],
+                                    self.fm.padding_idx, self.fm.slot_offset, self.status,
+                                    compact=self.compact)
+
+    # -- layer 0 on folded weights ------------------------------------------------------------------
+    def _mlp_weights(self):
+        """(weights, weight-grad views) of the top MLP as the GEMMs see them this step."""
+        if not self.compact:
+            return self.mlp_w, self.mlp_dw
+        S, D, Dn = self.sparse_num_field, self.sparse_feature_dim, self.dense_feature_dim
+        w0 = self.mlp_w[0]
+        self._w0p[: S * D].copy_(w0[: S * D])
+        self.k.dense_fold_fwd(S, self.dense.p["fm.dense_w"].view(Dn, D), w0, self._w0p[S * D: S * D + Dn])
+        return [self._w0p] + self.mlp_w[1:], [self.mlp_dw[0][: self.fp * D]] + self.mlp_dw[1:]
+
+    def _fold_backward(self):
+        """After dW0' = feat'^T dZ0 landed in the first (S+1)*D rows of the layer-0 gradient buffer: turn its
+        dense rows (= dM) into the gradients of the real parameters (W0 dense rows, dense_w MLP part)."""
+        if not self.compact:
+            return
+        S, D, Dn = self.sparse_num_field, self.sparse_feature_dim, self.dense_feature_dim
+        self._dm.copy_(self.mlp_dw[0][S * D: S * D + Dn])
+        self.k.dense_fold_bwd(S, self.dense.p["fm.dense_w"].view(Dn, D), self.mlp_w[0], self._dm, self.mlp_dw[0],
+                              self.dense.g["fm.dense_w"].view(Dn, D), accumulate=True)
 
     def forward(self, sparse_inputs, dense_inputs):
         ids = self._concat_ids(sparse_inputs)
         y1, y2, feat, _, _ = self._fm_fwd(ids, dense_inputs)
-        y_dnn, _ = self.k.mlp_forward(feat.view(feat.shape[0], -1), self.mlp_w, self.mlp_b, self.ws_mlp)
+        y_dnn, _ = self.k.mlp_forward(feat.view(feat.shape[0], -1), self._mlp_weights()[0], self.mlp_b, self.ws_mlp)
         return torch.sigmoid(y1 + y2 + y_dnn)
 
     __call__ = forward
@@ -213,21 +243,22 @@ class DeepFMLayer:
         with torch.cuda.stream(self._side):
             self.k.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
                              self.fm.slot_offset, self.status, groups)
+        mlp_w, mlp_dw = self._mlp_weights()
         with self._timed("mlp_fwd"):
-            y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b, self.ws_mlp)
+            y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), mlp_w, self.mlp_b, self.ws_mlp)
         pred, dz, loss = self.k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws)
         if auc_stats is not None:
             self.k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         with self._timed("mlp_bwd"):
-            d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db,
+            d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db,
                                                      self.ws_mlp, defer_first=True)
         with self._timed("fm_bwd"):
             row_grad, _, _ = self.k.deepfm_fm_bwd(
-                dense_inputs, feat, sum_emb, d_flat.view(B, self.num_field, -1), dz, dz, S, self.ws,
+                dense_inputs, feat, sum_emb, d_flat.view(B, self.fp, -1), dz, dz, S, self.ws,
                 out=(self._row_grad_buf(B * S),
                      self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
                      self.dense.g["fm.dense_w_one"]),
-                dense_w=self.dense.p["fm.dense_w"])
+                dense_w=self.dense.p["fm.dense_w"], compact=self.compact)
         # The lazy sparse optimizer (HBM-bound) runs on the side stream underneath the MFMA-bound
         # dW_0 GEMM; it needs row_grad / dz and the merge keys (sorted on that same stream earlier).
         t = self.step_count
@@ -240,6 +271,7 @@ class DeepFMLayer:
                 upd(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
         with self._timed("mlp_bwd_dw0"):
             finish_dw0()
+            self._fold_backward()
         if allreduce is not None:
             allreduce(self.dense.grad)
         self.k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)

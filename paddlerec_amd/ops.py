@@ -77,16 +77,17 @@ class Workspace:
         return self.buf
 
 
-def make_desc(B, S, Dn, D, num_rows, padding_idx, row_stride=None, w1_stride=1):
+def make_desc(B, S, Dn, D, num_rows, padding_idx, row_stride=None, w1_stride=1, compact=False):
     return DeepFMDesc(int(B), int(S), int(Dn), int(D), int(row_stride or D), int(num_rows),
-                      -1 if padding_idx is None else int(padding_idx), int(w1_stride), 0)
+                      -1 if padding_idx is None else int(padding_idx), int(w1_stride), int(bool(compact)))
 
 
 # ------------------------------------------------------------------ DeepFM FM block
 def deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, padding_idx=0, slot_offset=None,
-                  status=None, out=None):
+                  status=None, out=None, compact=False):
     """ids [B,S] i64, dense [B,Dn] f32, W [N,D], W1 [N,1]|[N], dense_w [Dn,D]|[1,Dn,D], dense_w_one [Dn]
-    -> y1 [B,1], y2 [B,1], feat [B,S+Dn,D], sum_emb [B,D], status"""
+    -> y1 [B,1], y2 [B,1], feat [B,S+Dn,D], sum_emb [B,D], status
+    compact: feat is [B,S+1,D] — S embedding rows + one row of the raw dense values (rec_deepfm_desc.compact_dense)."""
     B, S = ids.shape
     Dn = dense.shape[1]
     N, D = W.shape
@@ -103,24 +104,25 @@ def deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, padding_idx=0, slot_o
     if out is None:
         y1 = torch.empty(B, 1, dtype=torch.float32, device=dev)
         y2 = torch.empty(B, 1, dtype=torch.float32, device=dev)
-        feat = torch.empty(B, S + Dn, D, dtype=torch.float32, device=dev)
+        feat = torch.empty(B, S + 1 if compact else S + Dn, D, dtype=torch.float32, device=dev)
         sum_emb = torch.empty(B, D, dtype=torch.float32, device=dev)
     else:
         y1, y2, feat, sum_emb = out
     if status is None:
         status = new_status(dev)
-    desc = make_desc(B, S, Dn, D, N, padding_idx, w_stride, w1_stride)
+    desc = make_desc(B, S, Dn, D, N, padding_idx, w_stride, w1_stride, compact)
     check(lib().rec_deepfm_fm_fwd(C.byref(desc), _p(ids), _p(dense), _p(W), _p(W1), _p(dense_w),
                                   _p(dense_w_one), _p(slot_offset), _p(y1), _p(y2), _p(feat),
                                   _p(sum_emb), _p(status), _stream()), "rec_deepfm_fm_fwd")
     return y1, y2, feat, sum_emb, status
 
 
-def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, dense_w=None):
+def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, dense_w=None, compact=False):
     """-> row_grad [B*S,D], d_dense_w [Dn,D], d_dense_w_one [Dn].
-    dense_w ([Dn,D] / [1,Dn,D], optional): recompute the dense part of feat instead of re-reading it."""
+    dense_w ([Dn,D] / [1,Dn,D], optional): recompute the dense part of feat instead of re-reading it.
+    compact: feat / d_feat_dnn are [B,S+1,D] and d_dense_w is the FM part only (see deepfm_fm_fwd)."""
     B, F, D = feat.shape
-    Dn = F - S
+    Dn = dense.shape[1] if compact else F - S
     dev = feat.device
     for t, n in ((dense, "dense"), (feat, "feat"), (sum_emb, "sum_emb"), (d_feat_dnn, "d_feat_dnn"),
                  (dy1, "dy1"), (dy2, "dy2")):
@@ -137,7 +139,7 @@ def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, d
         d_dense_w_one = torch.empty(Dn, dtype=torch.float32, device=dev)
     else:
         row_grad, d_dense_w, d_dense_w_one = out
-    desc = make_desc(B, S, Dn, D, 1, None)
+    desc = make_desc(B, S, Dn, D, 1, None, compact=compact)
     nbytes = C.c_size_t(0)
     check(lib().rec_deepfm_fm_bwd_workspace_bytes(C.byref(desc), C.byref(nbytes)))
     w = ws.get(nbytes.value)
@@ -146,6 +148,27 @@ def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, d
                                   _p(d_dense_w_one),
                                   _p(w), C.c_size_t(w.numel()), _stream()), "rec_deepfm_fm_bwd")
     return row_grad, d_dense_w, d_dense_w_one
+
+
+def dense_fold_fwd(S, dense_w, W0, M):
+    """M[j,:] = dense_w[j,:] @ W0[(S+j)*D:(S+j+1)*D, :]   (dense embeddings folded into MLP layer 0)."""
+    Dn, D = dense_w.shape[-2], dense_w.shape[-1]
+    for t, n in ((dense_w, "dense_w"), (W0, "W0")):
+        _chk(t, torch.float32, n)
+    if not M.is_cuda or M.dtype != torch.float32 or not M.is_contiguous() or tuple(M.shape) != (Dn, W0.shape[1]):
+        raise RecError("M must be a contiguous float32 device tensor [Dn, n_out]")
+    check(lib().rec_dense_fold_fwd(int(S), Dn, D, W0.shape[1], _p(dense_w), _p(W0), _p(M), _stream()),
+          "rec_dense_fold_fwd")
+    return M
+
+
+def dense_fold_bwd(S, dense_w, W0, dM, dW0, d_dense_w, accumulate=True):
+    """dW0 dense rows = dense_w (x) dM;  d_dense_w (+)= dM @ W0_dense^T."""
+    Dn, D = dense_w.shape[-2], dense_w.shape[-1]
+    for t, n in ((dense_w, "dense_w"), (W0, "W0"), (dM, "dM"), (dW0, "dW0"), (d_dense_w, "d_dense_w")):
+        _chk(t, torch.float32, n)
+    check(lib().rec_dense_fold_bwd(int(S), Dn, D, W0.shape[1], _p(dense_w), _p(W0), _p(dM), _p(dW0),
+                                   _p(d_dense_w), int(accumulate), _stream()), "rec_dense_fold_bwd")
 
 
 # ------------------------------------------------------------------ lookups

@@ -186,14 +186,14 @@ class ShardedDeepFMLayer(DeepFMLayer):
         # the reply buffer is a (n+1)-row table read through slot_of_pos; 0 = padding -> zero row
         return self.k.deepfm_fm_fwd(L.route.slot_of_pos.view(B, S), dense_inputs, L.reply, L.reply1,
                                     self.dense.p["fm.dense_w"], self.dense.p["fm.dense_w_one"], 0, None,
-                                    self.status)
+                                    self.status, compact=self.compact)
 
     def forward(self, sparse_inputs, dense_inputs):
         ids = self._concat_ids(sparse_inputs)
         B, S = ids.shape
         L = self._lookup(ids)
         y1, y2, feat, _, _ = self._fm_fwd_routed(L, B, S, dense_inputs)
-        y_dnn, _ = self.k.mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b, self.ws_mlp)
+        y_dnn, _ = self.k.mlp_forward(feat.view(B, -1), self._mlp_weights()[0], self.mlp_b, self.ws_mlp)
         return torch.sigmoid(y1 + y2 + y_dnn)
 
     __call__ = forward
@@ -242,8 +242,9 @@ class ShardedDeepFMLayer(DeepFMLayer):
                 self._pending = self._route_async(self._concat_ids(next_sparse_inputs))
         with self._timed("fm_fwd"):
             y1, y2, feat, sum_emb, _ = self._fm_fwd_routed(L, B, S, dense_inputs)
+        mlp_w, mlp_dw = self._mlp_weights()
         with self._timed("mlp_fwd"):
-            y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b, self.ws_mlp)
+            y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), mlp_w, self.mlp_b, self.ws_mlp)
         loss_slot = self.dense.g["__loss__"]
         pred, dz, _ = k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws, mean_over=G * B,
                                         out=(self._buf("pred", (B, 1)), self._buf("dz", (B, 1)),
@@ -251,15 +252,15 @@ class ShardedDeepFMLayer(DeepFMLayer):
         if auc_stats is not None:
             k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         with self._timed("mlp_bwd"):
-            d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db,
+            d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db,
                                                      self.ws_mlp, defer_first=True)
         with self._timed("fm_bwd"):
             row_grad, _, _ = k.deepfm_fm_bwd(
-                dense_inputs, feat, sum_emb, d_flat.view(B, self.num_field, -1), dz, dz, S, self.ws,
+                dense_inputs, feat, sum_emb, d_flat.view(B, self.fp, -1), dz, dz, S, self.ws,
                 out=(self._row_grad_buf(B * S),
                      self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
                      self.dense.g["fm.dense_w_one"]),
-                dense_w=self.dense.p["fm.dense_w"])
+                dense_w=self.dense.p["fm.dense_w"], compact=self.compact)
         # row-gradient exchange + lazy sparse optimizer (xGMI / HBM bound) on the side stream, underneath
         # the MFMA-bound dW_0 GEMM and the dense all-reduce on the main stream
         with _Side():
@@ -281,6 +282,7 @@ class ShardedDeepFMLayer(DeepFMLayer):
                     k.sparse_adam_rows(groups, recv_g1, 1, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
         with self._timed("mlp_bwd_dw0"):
             finish_dw0()
+            self._fold_backward()
         self.comm.all_reduce_sum(self.dense.grad)                # one bucket: dense grads + loss
         loss = loss_slot.clone()
         loss_slot.zero_()                                         # not a parameter: keep Adam off it

@@ -54,19 +54,30 @@ def emb_gather(ids, W, padding_idx=None, status=None, out=None):
 
 
 def deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, padding_idx=0, slot_offset=None,
-                  status=None, out=None):
+                  status=None, out=None, compact=False):
     y1, y2, feat = R.fm_forward(_n(ids), _n(dense), _n(W1).reshape(-1, 1), _n(W), _n(dense_w_one),
                                 _n(dense_w).reshape(1, dense.shape[1], -1), padding_idx, _n(slot_offset))
     sum_emb = feat.sum(axis=1, dtype=np.float32)
+    if compact:
+        B, S = ids.shape
+        D, Dn = feat.shape[2], dense.shape[1]
+        packed = np.zeros((B, 1, D), np.float32)
+        packed[:, 0, :Dn] = _n(dense)
+        feat = np.concatenate([feat[:, :S], packed], axis=1)
     f = torch.from_numpy
-    return f(y1), f(y2), f(feat), f(sum_emb), status
+    return f(y1), f(y2), f(np.ascontiguousarray(feat)), f(sum_emb), status
 
 
-def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, dense_w=None):
+def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, dense_w=None, compact=False):
     B, F, D = feat.shape
     ids = np.ones((B, S), np.int64)     # padding handling happens at the merge, not here
-    g = R.fm_backward(ids, _n(dense), _n(feat), _n(d_feat_dnn).reshape(B, F, D), _n(dy1).reshape(B, 1),
-                      _n(dy2).reshape(B, 1), None)
+    featn, dfn = _n(feat), _n(d_feat_dnn).reshape(B, F, D)
+    if compact:      # rebuild the full tensors: dense embeddings recomputed, their d_dnn part is zero here
+        Dn = dense.shape[1]
+        de = _n(dense)[:, :, None] * _n(dense_w).reshape(1, Dn, D)
+        featn = np.concatenate([featn[:, :S], de.astype(np.float32)], axis=1)
+        dfn = np.concatenate([dfn[:, :S], np.zeros((B, Dn, D), np.float32)], axis=1)
+    g = R.fm_backward(ids, _n(dense), featn, dfn, _n(dy1).reshape(B, 1), _n(dy2).reshape(B, 1), None)
     row_grad, ddw, ddw1 = out
     row_grad.copy_(torch.from_numpy(g["row_grad"]))
     ddw.copy_(torch.from_numpy(g["d_dense_w"][0]))
@@ -145,3 +156,22 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False):
         torch.sum(g, dim=0, out=dbs[i])
         g = torch.mm(g, weights[i].t())
     return g
+
+
+def dense_fold_fwd(S, dense_w, W0, M):
+    dw = dense_w.numpy().reshape(-1, dense_w.shape[-1])
+    Dn, D = dw.shape
+    w = W0.numpy()[S * D:(S + Dn) * D].reshape(Dn, D, -1)
+    M.copy_(torch.from_numpy(np.einsum("jd,jdn->jn", dw, w).astype(np.float32)))
+    return M
+
+
+def dense_fold_bwd(S, dense_w, W0, dM, dW0, d_dense_w, accumulate=True):
+    dw = dense_w.numpy().reshape(-1, dense_w.shape[-1])
+    Dn, D = dw.shape
+    w = W0.numpy()[S * D:(S + Dn) * D].reshape(Dn, D, -1)
+    dm = dM.numpy()
+    dW0.numpy()[S * D:(S + Dn) * D] = (dw[:, :, None] * dm[:, None, :]).reshape(Dn * D, -1)
+    add = np.einsum("jn,jdn->jd", dm, w).astype(np.float32)
+    tgt = d_dense_w.numpy().reshape(Dn, D)
+    tgt[...] = (tgt + add) if accumulate else add

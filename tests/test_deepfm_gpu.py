@@ -153,6 +153,58 @@ def test_fm_bwd_vs_oracle(ops, oracle_lib, B, D, tables):
     assert torch.equal(rg, rg3) and torch.equal(ddw, ddw3) and torch.equal(ddw1, ddw13)
 
 
+@pytest.mark.parametrize("B,D,tables", [(1, 16, False), (515, 16, True), (130, 40, False), (77, 13, False)])
+def test_compact_dense_mode(ops, B, D, tables):
+    """compact feat = S embedding rows + one row of raw dense values; FM outputs unchanged; the backward takes
+    d_feat_dnn in the same layout and returns the FM part of d_dense_w; the folded layer-0 weights reproduce
+    feat @ W0 and its gradients."""
+    pr = make_deepfm_problem(B=B, D=D, N=2000, seed=B + D, tables=tables)
+    p = pr["params"]
+    so = T(pr["slot_offsets"]) if tables else None
+    args = (T(pr["ids"]), T(pr["dense"]), T(p["W"]), T(p["W1"]), T(p["dense_w"]), T(p["dense_w_one"]), 0, so)
+    y1, y2, feat, sum_emb, st = ops.deepfm_fm_fwd(*args)
+    c1, c2, cfeat, csum, st2 = ops.deepfm_fm_fwd(*args, compact=True)
+    assert int(st2.item()) == 0 and cfeat.shape == (B, 27, D)
+    assert torch.equal(y1, c1) and torch.equal(y2, c2) and torch.equal(sum_emb, csum)
+    assert torch.equal(cfeat[:, :26], feat[:, :26])
+    assert np.array_equal(N_(cfeat[:, 26, :13]), pr["dense"]) and float(cfeat[:, 26, 13:].abs().sum()) == 0.0
+    # folded layer 0: feat' @ [W0_sparse; M; 0] == feat @ W0
+    rng = np.random.default_rng(B)
+    n_out = 48
+    W0 = (rng.standard_normal((39 * D, n_out)) / np.sqrt(39 * D)).astype(np.float32)
+    M = torch.zeros(13, n_out, device=DEV)
+    ops.dense_fold_fwd(26, T(p["dense_w"]).view(13, D), T(W0), M)
+    np.testing.assert_allclose(N_(M), np.einsum("jd,jdn->jn", p["dense_w"][0], W0[26 * D:].reshape(13, D, n_out)),
+                               rtol=1e-5, atol=1e-7)
+    W0p = np.zeros((27 * D, n_out), np.float32)
+    W0p[:26 * D] = W0[:26 * D]
+    W0p[26 * D:26 * D + 13] = N_(M)
+    np.testing.assert_allclose(N_(cfeat).reshape(B, -1).astype(np.float64) @ W0p,
+                               N_(feat).reshape(B, -1).astype(np.float64) @ W0, rtol=1e-5, atol=1e-6)
+    # backward: same row gradients when the dnn gradient of the dense fields is zero; d_dense_w = FM part
+    dfeat = (rng.standard_normal((B, 39, D)) * 1e-3).astype(np.float32)
+    dfeat[:, 26:] = 0
+    dz = (rng.standard_normal((B, 1)) * 1e-3).astype(np.float32)
+    ws = ops.Workspace(DEV)
+    rg, ddw, ddw1 = ops.deepfm_fm_bwd(T(pr["dense"]), feat, sum_emb, T(dfeat), T(dz), T(dz), 26, ws)
+    rg, ddw, ddw1 = rg.clone(), ddw.clone(), ddw1.clone()
+    cd = np.zeros((B, 27, D), np.float32)
+    cd[:, :26] = dfeat[:, :26]
+    crg, cddw, cddw1 = ops.deepfm_fm_bwd(T(pr["dense"]), cfeat, csum, T(cd), T(dz), T(dz), 26, ws,
+                                         dense_w=T(p["dense_w"]), compact=True)
+    assert torch.equal(rg, crg) and torch.equal(ddw, cddw) and torch.equal(ddw1, cddw1)
+    # fold backward vs NumPy
+    dM = (rng.standard_normal((13, n_out)) * 1e-2).astype(np.float32)
+    dW0 = torch.zeros(39 * D, n_out, device=DEV)
+    gdw = torch.ones(13, D, device=DEV)
+    ops.dense_fold_bwd(26, T(p["dense_w"]).view(13, D), T(W0), T(dM), dW0, gdw, accumulate=True)
+    np.testing.assert_allclose(N_(dW0)[26 * D:], (p["dense_w"][0][:, :, None] * dM[:, None, :]).reshape(13 * D, n_out),
+                               rtol=1e-6, atol=1e-9)
+    assert float(dW0[:26 * D].abs().max()) == 0.0
+    np.testing.assert_allclose(N_(gdw), 1 + np.einsum("jn,jdn->jd", dM, W0[26 * D:].reshape(13, D, n_out)),
+                               rtol=1e-5, atol=1e-7)
+
+
 # ------------------------------------------------------------------------------ ids grouping
 @pytest.mark.parametrize("B,N,pad_frac,zipf,tables", [
     (1, 50, 0.0, False, False), (64, 50, 0.2, False, False), (1000, 100000, 0.03, True, False),

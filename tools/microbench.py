@@ -66,6 +66,11 @@ def main():
                                                    status, (y1, y2, feat, sum_emb)))
         print("N=%d: fm_fwd[record layout] %.1f us (min %.1f) => %.0f GB/s algorithmic"
               % (N, med, mn, fwd_b / med / 1e3))
+        cfeat = torch.empty(B, S + 1, D, device=DEV)
+        med, mn = timeit(lambda: ops.deepfm_fm_fwd(ids, dense, rec[:, :D], rec[:, D:D + 1], dw, dw1, 0, so,
+                                                   status, (y1, y2, cfeat, sum_emb), compact=True))
+        print("N=%d: fm_fwd[record layout, compact feat] %.1f us (min %.1f) => %.0f GB/s algorithmic"
+              % (N, med, mn, fwd_b / med / 1e3))
         mv = torch.zeros(N, 32, device=DEV)
         med, mn = timeit(lambda: ops.deepfm_fm_fwd(ids, dense, W, W1, dw, dw1, 0, so, status,
                                                    (y1, y2, feat, sum_emb)))
