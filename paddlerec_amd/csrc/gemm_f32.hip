@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock, gemm_blocks_per_cu<BN>()) void gemm_f32_ker
     int64_t M, int N, int K, const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
     int64_t ldb, float* __restrict__ C, int64_t ldc, EpiArgs epi, int tiles_n, int64_t tiles_total,
     int k_chunk, bool vec_a, bool vec_b, float* __restrict__ partial,
-    float* __restrict__ colsum_partial) {
+    float* __restrict__ colsum_partial, int splits_in_x) {
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MT = WTM / 16, NT = WTN / 16;
   // A in LDS: [BM][BK+4] (b128 fragment reads) — or k-major [BK][BM+4] when A is stored [K,M]
@@ -177,9 +177,19 @@ __global__ __launch_bounds__(kBlock, gemm_blocks_per_cu<BN>()) void gemm_f32_ker
   __shared__ __attribute__((aligned(16))) float As[2][A_ELEMS];
   __shared__ __attribute__((aligned(16))) float Bs[2][kBK * LDB_S];
 
-  // XCD-aware numbering: block b runs on XCD b % 8; give every XCD a contiguous range of tiles
+  // XCD-aware numbering (block b runs on XCD b % 8, each XCD has its own L2):
+  //  * no split-K: every XCD gets a contiguous range of tiles, so the N-tiles that share an A tile run on the
+  //    same XCD back to back;
+  //  * split-K (grid.y = 1, grid.x = tiles * splits, splits % 8 == 0): ALL tiles of one K-slice run on one XCD
+  //    back to back — the slice of A and B (a few MB) is fetched from HBM once into that L2 instead of once
+  //    per XCD that happens to hold one of its tiles.
   int64_t w = blockIdx.x;
-  {
+  int kz = blockIdx.y;
+  if (splits_in_x > 1) {
+    const int64_t xcd = w % 8, slot = w / 8;
+    kz = (int)(xcd + 8 * (slot / tiles_total));
+    w = slot % tiles_total;
+  } else {
     const int64_t per = tiles_total / 8;
     if (w < per * 8) w = (w % 8) * per + w / 8;
   }
@@ -187,7 +197,6 @@ __global__ __launch_bounds__(kBlock, gemm_blocks_per_cu<BN>()) void gemm_f32_ker
   const int tn = (int)(w % tiles_n);
   const int64_t m0 = tm * BM;
   const int n0 = tn * BN;
-  const int kz = blockIdx.y;
   const int k_begin = kz * k_chunk;
   const int k_end = (k_begin + k_chunk < K) ? k_begin + k_chunk : K;
 
@@ -516,6 +525,7 @@ static GemmPlan plan_gemm(const rec_gemm_desc* d) {
       int64_t want = capacity / p.tiles_total;
       if (want > nkt / 8) want = nkt / 8;   // keep >= 8 K-tiles (128 k) per split
       if (want > 512) want = 512;
+      if (want >= 8) want -= want % 8;      // multiples of 8: one K-slice per XCD at a time (see the kernel)
       splits = want < 1 ? 1 : (int)want;
     }
   }
@@ -542,10 +552,13 @@ static void launch_one(const rec_gemm_desc* d, const GemmPlan& p, const float* A
                        float* C, const EpiArgs& e, float* partial, float* cpart, hipStream_t st) {
   const bool vec_a = (d->lda % 4 == 0) && (((uintptr_t)A) % 16 == 0);
   const bool vec_b = (d->ldb % 4 == 0) && (((uintptr_t)B) % 16 == 0);
-  dim3 grid((unsigned)p.tiles_total, (unsigned)p.splits);
+  const bool fold = p.splits >= 8 && p.splits % 8 == 0 && p.tiles_total * p.splits < (1ll << 31);
+  dim3 grid(fold ? (unsigned)(p.tiles_total * p.splits) : (unsigned)p.tiles_total,
+            fold ? 1u : (unsigned)p.splits);
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM_, WN_, TA, TB, EPI>), grid, dim3(kBlock), 0, st,
                      d->m, d->n, d->k, A, (int64_t)d->lda, B, (int64_t)d->ldb, C, (int64_t)d->ldc,
-                     e, p.tiles_n, p.tiles_total, p.k_chunk, vec_a, vec_b, partial, cpart);
+                     e, p.tiles_n, p.tiles_total, p.k_chunk, vec_a, vec_b, partial, cpart,
+                     fold ? p.splits : 1);
 }
 
 template <bool TA, bool TB, int EPI>

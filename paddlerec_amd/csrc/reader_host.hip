@@ -24,39 +24,79 @@ namespace rec {
 
 struct LineSpan { const char* b; const char* e; };
 
-static void split_lines(const char* buf, size_t len, int64_t max_lines, std::vector<LineSpan>* out) {
-  const char* p = buf;
-  const char* end = buf + len;
-  while (p < end && (int64_t)out->size() < max_lines) {
-    const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-    const char* e = nl ? nl : end;
-    const char* te = e;
-    while (te > p && (te[-1] == '\r' || te[-1] == ' ' || te[-1] == '\t')) --te;   // l.strip() (right side)
-    const char* tb = p;
-    while (tb < te && (*tb == ' ' || *tb == '\t')) ++tb;                           // l.strip() (left side)
-    if (te > tb || nl) out->push_back({tb, te});   // python iterates every line, blank ones too
-    p = nl ? nl + 1 : end;
-  }
-}
+// Splits [buf, buf+len) into T byte ranges that end on line boundaries; range t holds lines
+// [first_line[t], first_line[t+1]).  Counting and (later) parsing both run one thread per range, so the
+// whole pipeline scales with the host cores (no serial line index).
+struct Chunks {
+  std::vector<const char*> begin;     // T+1 pointers
+  std::vector<int64_t> first_line;    // T+1 line numbers
+};
 
 template <class F>
-static void parallel_lines(int64_t n, int threads, F&& f) {
-  if (threads <= 1 || n < 256) { f(0, n); return; }
+static void run_threads(int T, F&& f) {
+  if (T <= 1) { f(0); return; }
   std::vector<std::thread> pool;
-  const int64_t per = (n + threads - 1) / threads;
-  for (int t = 0; t < threads; ++t) {
-    const int64_t lo = t * per, hi = lo + per < n ? lo + per : n;
-    if (lo >= hi) break;
-    pool.emplace_back([=, &f]() { f(lo, hi); });
-  }
+  for (int t = 0; t < T; ++t) pool.emplace_back([=, &f]() { f(t); });
   for (auto& th : pool) th.join();
+}
+
+static Chunks make_chunks(const char* buf, size_t len, int T) {
+  Chunks c;
+  const char* end = buf + len;
+  if (len < (size_t)T * 4096) T = 1;
+  c.begin.resize(T + 1);
+  c.begin[0] = buf;
+  for (int t = 1; t < T; ++t) {
+    const char* p = buf + len / T * t;
+    if (p < c.begin[t - 1]) p = c.begin[t - 1];
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+    c.begin[t] = nl ? nl + 1 : end;
+  }
+  c.begin[T] = end;
+  std::vector<int64_t> cnt((size_t)T, 0);
+  run_threads(T, [&](int t) {
+    int64_t n = 0;
+    const char* p = c.begin[t];
+    const char* e = c.begin[t + 1];
+    while (p < e) {
+      const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+      ++n;                              // a trailing fragment without '\n' is a line too
+      p = nl ? nl + 1 : e;
+    }
+    cnt[t] = n;
+  });
+  c.first_line.resize(T + 1);
+  c.first_line[0] = 0;
+  for (int t = 0; t < T; ++t) c.first_line[t + 1] = c.first_line[t] + cnt[t];
+  return c;
+}
+
+// calls f(line_index, LineSpan) for every line (raw: [p, newline) without trimming), in parallel
+template <class F>
+static int64_t for_each_line(const char* buf, size_t len, int64_t max_lines, int threads, F&& f) {
+  const Chunks c = make_chunks(buf, len, threads);
+  const int T = (int)c.begin.size() - 1;
+  run_threads(T, [&](int t) {
+    int64_t i = c.first_line[t];
+    const char* p = c.begin[t];
+    const char* e = c.begin[t + 1];
+    while (p < e && i < max_lines) {
+      const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+      const char* le = nl ? nl : e;
+      f(i, LineSpan{p, le});
+      ++i;
+      p = nl ? nl + 1 : e;
+    }
+  });
+  const int64_t total = c.first_line[T];
+  return total < max_lines ? total : max_lines;
 }
 
 static int host_threads(int requested) {
   if (requested > 0) return requested;
   unsigned hc = std::thread::hardware_concurrency();
   int t = hc ? (int)hc : 4;
-  return t > 32 ? 32 : t;
+  return t > 64 ? 64 : t;
 }
 
 static void parse_slot_line(LineSpan ln, int S, int Dn, bool log1p_dense, int64_t* label, int64_t* ids,
@@ -110,15 +150,12 @@ extern "C" int rec_parse_slot_text(const char* buf, size_t len, int32_t n_sparse
   REC_REQUIRE(len == 0 || buf, REC_EINVAL, "buf is NULL");
   REC_REQUIRE(max_lines == 0 || (label && ids && (n_dense == 0 || dense)), REC_EINVAL,
               "null output pointer");
-  std::vector<LineSpan> lines;
-  split_lines(buf, len, max_lines, &lines);
-  const int64_t n = (int64_t)lines.size();
-  parallel_lines(n, host_threads(threads), [&](int64_t lo, int64_t hi) {
-    for (int64_t i = lo; i < hi; ++i)
-      parse_slot_line(lines[i], n_sparse, n_dense, log1p_dense != 0, label + i, ids + i * n_sparse,
-                      dense + i * n_dense);
+  *n_lines = for_each_line(buf, len, max_lines, host_threads(threads), [&](int64_t i, LineSpan ln) {
+    while (ln.e > ln.b && (ln.e[-1] == '\r' || ln.e[-1] == ' ' || ln.e[-1] == '\t')) --ln.e;   // l.strip()
+    while (ln.b < ln.e && (*ln.b == ' ' || *ln.b == '\t')) ++ln.b;
+    parse_slot_line(ln, n_sparse, n_dense, log1p_dense != 0, label + i, ids + i * n_sparse,
+                    dense + i * n_dense);
   });
-  *n_lines = n;
   return REC_OK;
 }
 
@@ -133,23 +170,11 @@ extern "C" int rec_parse_criteo_tsv(const char* buf, size_t len, int32_t n_dense
   REC_REQUIRE(max_lines == 0 || (label && ids && (n_dense == 0 || dense)), REC_EINVAL,
               "null output pointer");
   // lines are split on '\n' only: fields may be empty and are tab separated (line.rstrip('\n').split('\t'))
-  std::vector<LineSpan> lines;
-  {
-    const char* p = buf;
-    const char* end = buf + len;
-    while (p < end && (int64_t)lines.size() < max_lines) {
-      const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-      const char* e = nl ? nl : end;
-      lines.push_back({p, e});
-      p = nl ? nl + 1 : end;
-    }
-  }
-  const int64_t n = (int64_t)lines.size();
-  parallel_lines(n, host_threads(threads), [&](int64_t lo, int64_t hi) {
-    std::string key;
-    for (int64_t i = lo; i < hi; ++i) {
-      const char* p = lines[i].b;
-      const char* e = lines[i].e;
+  *n_lines = for_each_line(buf, len, max_lines, host_threads(threads), [&](int64_t i, LineSpan ln) {
+    thread_local std::string key;
+    {
+      const char* p = ln.b;
+      const char* e = ln.e;
       for (int f = 0; f < 1 + n_dense + n_sparse; ++f) {
         const char* te = (p <= e) ? (const char*)memchr(p, '\t', (size_t)(e - p)) : nullptr;
         if (!te) te = e;
@@ -171,6 +196,5 @@ extern "C" int rec_parse_criteo_tsv(const char* buf, size_t len, int32_t n_dense
       }
     }
   });
-  *n_lines = n;
   return REC_OK;
 }
