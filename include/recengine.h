@@ -416,6 +416,7 @@ int rec_xxh32_hash_mod(const char* const* strings, const int32_t* field_idx, int
  *   dense = (x - cont_min[j]) / cont_diff[j] ("" -> 0), ids = xxh32(str(field_idx)+string) % hash_dim with
  *   field_idx = 14..39 (the column index, as the reference hashes it).
  * threads <= 0: one per host core (capped at 64).  *n_lines = lines parsed (<= max_lines). */
+int rec_count_lines(const char* buf, size_t len, int32_t threads, int64_t* n_lines); /* to size the outputs */
 int rec_parse_slot_text(const char* buf, size_t len, int32_t n_sparse, int32_t n_dense,
                         int32_t log1p_dense, int64_t max_lines, int32_t threads, int64_t* label,
                         int64_t* ids, float* dense, int64_t* n_lines);

@@ -143,6 +143,13 @@ static void parse_slot_line(LineSpan ln, int S, int Dn, bool log1p_dense, int64_
 
 using namespace rec;
 
+extern "C" int rec_count_lines(const char* buf, size_t len, int32_t threads, int64_t* n_lines) {
+  REC_REQUIRE(n_lines && (len == 0 || buf), REC_EINVAL, "bad arguments");
+  const Chunks c = make_chunks(buf, len, host_threads(threads));
+  *n_lines = c.first_line.back();
+  return REC_OK;
+}
+
 extern "C" int rec_parse_slot_text(const char* buf, size_t len, int32_t n_sparse, int32_t n_dense,
                                    int32_t log1p_dense, int64_t max_lines, int32_t threads,
                                    int64_t* label, int64_t* ids, float* dense, int64_t* n_lines) {

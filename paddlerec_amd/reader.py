@@ -28,9 +28,15 @@ def _alloc(n, S, Dn, pinned):
     return label, ids, dense
 
 
+def _count_lines(data, threads):
+    n = C.c_int64(0)
+    check(lib().rec_count_lines(data, len(data), threads, C.byref(n)), "rec_count_lines")
+    return max(int(n.value), 1)
+
+
 def parse_slot_text(data: bytes, n_sparse=26, n_dense=13, log1p_dense=False, threads=0, pinned=False):
     """-> (label [n] i64, ids [n,S] i64, dense [n,Dn] f32) host tensors."""
-    cap = data.count(b"\n") + 1
+    cap = _count_lines(data, threads)
     label, ids, dense = _alloc(cap, n_sparse, n_dense, pinned)
     n = C.c_int64(0)
     check(lib().rec_parse_slot_text(data, len(data), n_sparse, n_dense, int(log1p_dense), cap, threads,
@@ -40,7 +46,7 @@ def parse_slot_text(data: bytes, n_sparse=26, n_dense=13, log1p_dense=False, thr
 
 
 def parse_criteo_tsv(data: bytes, n_dense=13, n_sparse=26, hash_dim=HASH_DIM, threads=0, pinned=False):
-    cap = data.count(b"\n") + 1
+    cap = _count_lines(data, threads)
     label, ids, dense = _alloc(cap, n_sparse, n_dense, pinned)
     cmin = np.asarray(CONT_MIN[:n_dense], np.float32)
     cdiff = np.asarray(CONT_DIFF[:n_dense], np.float32)
