@@ -161,7 +161,21 @@ typedef struct {
   int32_t div;
   int32_t group;
   int64_t group_stride;
+  const float* partials; /* device, from rec_segment_partials for THIS grad + grouping, or NULL */
 } rec_grad_layout;
+
+/* Hot rows.  With Zipf-distributed ids one row can own tens of thousands of the n lookups; the per-row
+ * duplicate sum of the consumers below would then be a serial chain of that many reads.  rec_segment_partials
+ * pre-reduces, per tile of REC_SEG_TILE sorted positions, the pieces of every segment of >= REC_SEG_LONG
+ * positions into partials [ceil(n_max/REC_SEG_TILE), 2, emb_dim] (fixed summation tree: deterministic); a
+ * consumer given grad_layout.partials adds one partial per tile for such rows.  Optional: with partials =
+ * NULL every consumer sums position by position.  grad_layout->partials is ignored on input here. */
+#define REC_SEG_TILE 64
+#define REC_SEG_LONG 128
+int rec_segment_partials_bytes(int64_t n_max, int32_t emb_dim, size_t* bytes);
+int rec_segment_partials(int64_t n_max, int32_t emb_dim, const int32_t* n_uniq,
+                         const int32_t* seg_offset, const int32_t* sorted_pos, const float* grad,
+                         const rec_grad_layout* grad_layout, float* partials, void* stream);
 
 /* lazy_mode=True Adam on the rows of a merged SelectedRows gradient, merge fused in:
  *   g[u,:] = sum_{k in seg(u)} grad_row(sorted_pos[k])            (ascending position order)

@@ -32,7 +32,8 @@ class AdagradHyper(C.Structure):
 
 
 class GradLayout(C.Structure):
-    _fields_ = [("div", C.c_int32), ("group", C.c_int32), ("group_stride", C.c_int64)]
+    _fields_ = [("div", C.c_int32), ("group", C.c_int32), ("group_stride", C.c_int64),
+                ("partials", C.c_void_p)]
 
 
 class DinDesc(C.Structure):
@@ -75,6 +76,8 @@ SIGNATURES = {
     "rec_emb_sumpool_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _P]),
     "rec_ids_group_workspace_bytes": (C.c_int, [_I64, _I64, C.POINTER(_SZ)]),
     "rec_ids_group": (C.c_int, [_I64, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "rec_segment_partials_bytes": (C.c_int, [_I64, _I32, C.POINTER(C.c_size_t)]),
+    "rec_segment_partials": (C.c_int, [_I64, _I32, _P, _P, _P, _P, C.POINTER(GradLayout), _P, _P]),
     "rec_sparse_adam_rows": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
                                        _P, _P, _P, C.POINTER(AdamHyper), _P]),
     "rec_sparse_adagrad_rows": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,

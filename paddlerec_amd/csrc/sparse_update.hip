@@ -143,6 +143,120 @@ __device__ __forceinline__ int64_t grad_offset(const rec_grad_layout& gl, int po
                       : (int64_t)q * D;
 }
 
+
+// ---------------------------------------------------------------- long-segment partial sums
+// A hot row (Zipf-distributed ids: one row can own tens of thousands of the B*S lookups) would turn
+// the per-row duplicate loop below into a serial chain of that many dependent HBM/L2 reads.
+// rec_segment_partials pre-reduces, one wave per tile of REC_SEG_TILE sorted positions, the pieces of
+// every segment of >= REC_SEG_LONG positions; the per-row loops then add one partial per tile instead
+// of one gradient row per position.  partials[(tile*2 + slot)*D ..]: slot 0 = the piece of the long
+// segment that contains the tile's first position, slot 1 = the piece of a different long segment
+// that contains its last position (a long segment spans >= 2 tiles, so no tile holds a third piece).
+constexpr int kSegTile = REC_SEG_TILE, kSegLong = REC_SEG_LONG;
+
+template <int VEC, int LANES>
+__global__ __launch_bounds__(kBlock) void segment_partials_kernel(
+    int D, const int32_t* __restrict__ n_uniq, const int32_t* __restrict__ seg_off,
+    const int32_t* __restrict__ spos, const float* __restrict__ grad, rec_grad_layout gl,
+    float* __restrict__ partials) {
+  static_assert(kSegTile == 64, "one wave per tile");
+  constexpr int G = 64 / LANES;  // row groups per wave
+  const int lane = threadIdx.x % 64;
+  const int64_t tile = (int64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+  const int U = n_uniq[0];
+  if (U <= 0) return;
+  const int nvalid = seg_off[U];
+  const int64_t s64 = tile * kSegTile;
+  if (s64 >= nvalid) return;
+  const int s = (int)s64, e = min(s + kSegTile, nvalid);
+  auto find = [&](int x) {  // the segment that holds sorted position x: 64-ary search, one probe per lane
+    int lo = 0, hi = U;     // invariant: seg_off[lo] <= x < seg_off[hi]
+    while (hi - lo > 1) {
+      const int step = (hi - lo + 63) / 64;
+      const int idx = lo + lane * step;
+      const bool le = idx < hi && seg_off[idx] <= x;      // monotone over the lanes, lane 0 always true
+      const int c = __popcll(__ballot(le));
+      lo += (c - 1) * step;
+      hi = min(lo + step, hi);
+    }
+    return lo;
+  };
+  const int grp = lane / LANES, d0 = (lane % LANES) * VEC;
+  auto piece = [&](int a, int b, int slot) {
+    float g[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+    if (d0 < D)
+      for (int k = a + grp; k < b; k += G) {
+        float t[VEC];
+        vload<VEC>(t, grad + grad_offset(gl, spos[k], D) + d0);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g[i] += t[i];
+      }
+#pragma unroll
+    for (int off = LANES; off < 64; off <<= 1)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) g[i] += __shfl_xor(g[i], off, 64);
+    if (grp == 0 && d0 < D) vstore<VEC>(partials + (tile * 2 + slot) * D + d0, g);
+  };
+  const int u0 = find(s);
+  const int b0 = seg_off[u0], e0 = seg_off[u0 + 1];
+  if (e0 - b0 >= kSegLong) piece(s, min(e, e0), 0);
+  if (e0 < e) {
+    const int u1 = find(e - 1);
+    const int b1 = seg_off[u1];
+    if (seg_off[u1 + 1] - b1 >= kSegLong) piece(b1, e, 1);
+  }
+}
+
+// g += the gradient rows of sorted positions [beg,end) (ascending; four loads in flight), through the
+// tile partials when the segment is long and the caller supplied them
+template <int VEC>
+__device__ __forceinline__ void segment_sum(float (&g)[VEC], int beg, int end,
+                                            const int32_t* __restrict__ spos,
+                                            const float* __restrict__ grad,
+                                            const rec_grad_layout& gl, int D, int d0) {
+  if (gl.partials && end - beg >= kSegLong) {
+    const float* __restrict__ pp = gl.partials;
+    const int t1 = (end - 1) / kSegTile;
+    int t = beg / kSegTile;
+    auto at = [&](int tt) {
+      return pp + ((int64_t)tt * 2 + (beg <= tt * kSegTile ? 0 : 1)) * D + d0;
+    };
+    for (; t + 4 <= t1 + 1; t += 4) {
+      float a[VEC], b[VEC], c[VEC], d[VEC];
+      vload<VEC>(a, at(t)); vload<VEC>(b, at(t + 1)); vload<VEC>(c, at(t + 2)); vload<VEC>(d, at(t + 3));
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) g[i] = (((g[i] + a[i]) + b[i]) + c[i]) + d[i];
+    }
+    for (; t <= t1; ++t) {
+      float a[VEC];
+      vload<VEC>(a, at(t));
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) g[i] += a[i];
+    }
+    return;
+  }
+  int k = beg;
+  if (end - beg >= 8)   // short rows (the common case) stay on the plain loop: no divergence inside a wave
+  for (; k + 4 <= end; k += 4) {
+    float a[VEC], b[VEC], c[VEC], d[VEC];
+    const int p0 = spos[k], p1 = spos[k + 1], p2 = spos[k + 2], p3 = spos[k + 3];
+    vload<VEC>(a, grad + grad_offset(gl, p0, D) + d0);
+    vload<VEC>(b, grad + grad_offset(gl, p1, D) + d0);
+    vload<VEC>(c, grad + grad_offset(gl, p2, D) + d0);
+    vload<VEC>(d, grad + grad_offset(gl, p3, D) + d0);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] = (((g[i] + a[i]) + b[i]) + c[i]) + d[i];
+  }
+  for (; k < end; ++k) {
+    float a[VEC];
+    vload<VEC>(a, grad + grad_offset(gl, spos[k], D) + d0);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] += a[i];
+  }
+}
+
 // --------------------------------------------------------------------------- lazy sparse Adam
 template <int VEC, int LANES>
 __global__ __launch_bounds__(kBlock) void sparse_adam_rows_kernel(
@@ -164,12 +278,7 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_rows_kernel(
   vload<VEC>(v, V + so);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) g[i] = 0.f;
-  for (int k = beg; k < end; ++k) {
-    float t[VEC];
-    vload<VEC>(t, grad + grad_offset(gl, spos[k], D) + d0);
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) g[i] += t[i];
-  }
+  segment_sum<VEC>(g, beg, end, spos, grad, gl, D, d0);
   if (grad_scale) {   // global-norm clipping factor (device scalar)
     const float sc = grad_scale[0];
 #pragma unroll
@@ -228,12 +337,7 @@ __global__ __launch_bounds__(kBlock) void adam_rows_all_kernel(
   for (int i = 0; i < VEC; ++i) g[i] = 0.f;
   const int u = slot[lr_];
   if (u >= 0) {
-    for (int k = seg_off[u]; k < seg_off[u + 1]; ++k) {
-      float t[VEC];
-      vload<VEC>(t, grad + grad_offset(gl, spos[k], D) + d0);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) g[i] += t[i];
-    }
+    segment_sum<VEC>(g, seg_off[u], seg_off[u + 1], spos, grad, gl, D, d0);
     if (grad_scale) {
       const float sc = grad_scale[0];
 #pragma unroll
@@ -266,12 +370,7 @@ __global__ __launch_bounds__(kBlock) void sparse_sgd_rows_kernel(
   vload<VEC>(p, P + ro);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) g[i] = 0.f;
-  for (int k = seg_off[u]; k < seg_off[u + 1]; ++k) {
-    float t[VEC];
-    vload<VEC>(t, grad + grad_offset(gl, spos[k], D) + d0);
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) g[i] += t[i];
-  }
+  segment_sum<VEC>(g, seg_off[u], seg_off[u + 1], spos, grad, gl, D, d0);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) p[i] -= lr * g[i];
   vstore<VEC>(P + ro, p);
@@ -298,12 +397,7 @@ __global__ __launch_bounds__(kBlock) void sparse_rows_sumsq_kernel(
       float g[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) g[i] = 0.f;
-      for (int k = seg_off[u]; k < seg_off[u + 1]; ++k) {
-        float t[VEC];
-        vload<VEC>(t, grad + grad_offset(gl, spos[k], D) + d0);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) g[i] += t[i];
-      }
+      segment_sum<VEC>(g, seg_off[u], seg_off[u + 1], spos, grad, gl, D, d0);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc += g[i] * g[i];
     }
@@ -421,18 +515,52 @@ extern "C" int rec_ids_group(int64_t n, int32_t num_slots, int64_t num_rows, int
                              uniq_rows, seg_offset, n_uniq, status, workspace, workspace_bytes, st);
 }
 
+extern "C" int rec_segment_partials_bytes(int64_t n_max, int32_t emb_dim, size_t* bytes) {
+  REC_REQUIRE(n_max >= 0 && emb_dim > 0 && bytes, REC_EINVAL, "bad arguments");
+  *bytes = (size_t)((n_max + kSegTile - 1) / kSegTile) * 2 * (size_t)emb_dim * sizeof(float);
+  return REC_OK;
+}
+
+extern "C" int rec_segment_partials(int64_t n_max, int32_t emb_dim, const int32_t* n_uniq,
+                                    const int32_t* seg_offset, const int32_t* sorted_pos,
+                                    const float* grad, const rec_grad_layout* grad_layout,
+                                    float* partials, void* stream) {
+  rec_grad_layout gl = {1, 0, 0, nullptr};
+  if (grad_layout) gl = *grad_layout;
+  gl.partials = nullptr;
+  REC_REQUIRE(n_max >= 0 && emb_dim > 0 && gl.div >= 1, REC_EINVAL, "bad sizes");
+  REC_REQUIRE(gl.group <= 0 || gl.group_stride >= (int64_t)gl.group * emb_dim, REC_EINVAL,
+              "grad group_stride too small");
+  REC_REQUIRE(((uintptr_t)gl.partials) % 16 == 0, REC_EINVAL, "grad_layout.partials must be 16-byte aligned");
+  REC_REQUIRE(n_uniq && seg_offset && sorted_pos && grad && partials, REC_EINVAL,
+              "null pointer argument");
+  if (n_max == 0) return REC_OK;
+  REC_REQUIRE(((uintptr_t)partials) % 16 == 0, REC_EINVAL, "partials must be 16-byte aligned");
+  const bool gvec = ((uintptr_t)grad) % 16 == 0 && (gl.group <= 0 || gl.group_stride % 4 == 0);
+  return dispatch_row_shape(emb_dim, gvec ? 4 : 1, [&](auto vec, auto lanes) -> int {
+    constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
+    const int64_t tiles = (n_max + kSegTile - 1) / kSegTile;
+    const int64_t grid = (tiles + kBlock / 64 - 1) / (kBlock / 64);
+    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many positions");
+    hipLaunchKernelGGL((segment_partials_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock), 0,
+                       (hipStream_t)stream, emb_dim, n_uniq, seg_offset, sorted_pos, grad, gl, partials);
+    return check_launch("rec_segment_partials");
+  });
+}
+
 extern "C" int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride,
                                     int32_t state_stride, const int32_t* n_uniq, const int64_t* uniq_rows,
                                     const int32_t* seg_offset, const int32_t* sorted_pos,
                                     const float* grad, const rec_grad_layout* grad_layout,
                                     const float* grad_scale, float* P, float* M, float* V,
                                     const rec_adam_hyper* hyper, void* stream) {
-  rec_grad_layout gl = {1, 0, 0};
+  rec_grad_layout gl = {1, 0, 0, nullptr};
   if (grad_layout) gl = *grad_layout;
   REC_REQUIRE(n_max >= 0 && emb_dim > 0 && row_stride >= emb_dim && gl.div >= 1, REC_EINVAL,
               "bad sizes");
   REC_REQUIRE(gl.group <= 0 || gl.group_stride >= (int64_t)gl.group * emb_dim, REC_EINVAL,
               "grad group_stride too small");
+  REC_REQUIRE(((uintptr_t)gl.partials) % 16 == 0, REC_EINVAL, "grad_layout.partials must be 16-byte aligned");
   if (state_stride <= 0) state_stride = row_stride;
   REC_REQUIRE(state_stride >= emb_dim, REC_EINVAL, "state_stride < emb_dim");
   REC_REQUIRE(n_uniq && uniq_rows && seg_offset && sorted_pos && grad && P && M && V && hyper,
@@ -475,8 +603,15 @@ __global__ __launch_bounds__(kBlock) void sparse_adagrad_rows_kernel(
   float* r = rec + uniq[u] * stride;
   const int beg = seg_off[u], end = seg_off[u + 1];
   float clicks = 0.f;
-  if (label)
-    for (int k = beg; k < end; ++k) clicks += (float)label[spos[k] / S];
+  if (label) {
+    int k = beg;
+    for (; k + 4 <= end; k += 4) {   // four independent loads in flight
+      const int64_t l0 = label[spos[k] / S], l1 = label[spos[k + 1] / S], l2 = label[spos[k + 2] / S],
+                    l3 = label[spos[k + 3] / S];
+      clicks += (float)(l0 + l1 + l2 + l3);
+    }
+    for (; k < end; ++k) clicks += (float)label[spos[k] / S];
+  }
   r[0] += (float)(end - beg);   // show: every lookup of the row is one impression (dnn/static_model.py:86-94)
   r[1] += clicks;
   const float g2w = r[2], g2x = r[3];
@@ -484,8 +619,9 @@ __global__ __launch_bounds__(kBlock) void sparse_adagrad_rows_kernel(
   const float sx = sqrtf(h.initial_g2sum / (h.initial_g2sum + g2x));
   float addw = 0.f, addx = 0.f;
   for (int d = 0; d < D; ++d) {
-    float g = 0.f;
-    for (int k = beg; k < end; ++k) g += grad[grad_offset(gl, spos[k], D) + d];
+    float gv[1] = {0.f};
+    segment_sum<1>(gv, beg, end, spos, grad, gl, D, d);
+    const float g = gv[0];
     float w = r[4 + d] - h.lr * g * (d == 0 ? sw : sx);
     w = fminf(fmaxf(w, h.min_bound), h.max_bound);
     r[4 + d] = w;
@@ -503,7 +639,7 @@ extern "C" int rec_sparse_adagrad_rows(int64_t n_max, int32_t emb_dim, int32_t r
                                        const int32_t* sorted_pos, const float* grad,
                                        const rec_grad_layout* grad_layout, const int64_t* label,
                                        float* rec, const rec_adagrad_hyper* hyper, void* stream) {
-  rec_grad_layout gl = {1, 0, 0};
+  rec_grad_layout gl = {1, 0, 0, nullptr};
   if (grad_layout) gl = *grad_layout;
   REC_REQUIRE(n_max >= 0 && emb_dim > 0 && row_stride >= emb_dim + 4 && num_slots > 0 && gl.div >= 1,
               REC_EINVAL, "bad sizes (row_stride must hold show, click, D weights and 2 g2sum)");
@@ -547,7 +683,7 @@ extern "C" int rec_sparse_rows_sumsq(int64_t n_max, int32_t emb_dim, const int32
                                      const float* grad, const rec_grad_layout* grad_layout,
                                      float* out, int32_t accumulate, void* workspace,
                                      size_t workspace_bytes, void* stream) {
-  rec_grad_layout gl = {1, 0, 0};
+  rec_grad_layout gl = {1, 0, 0, nullptr};
   if (grad_layout) gl = *grad_layout;
   REC_REQUIRE(n_max >= 0 && emb_dim > 0 && gl.div >= 1 && out, REC_EINVAL, "bad arguments");
   REC_REQUIRE(n_uniq && seg_offset && sorted_pos && grad, REC_EINVAL, "null pointer argument");
@@ -595,11 +731,12 @@ extern "C" int rec_sparse_sgd_rows(int64_t n_max, int32_t emb_dim, int32_t row_s
                                    const int32_t* seg_offset, const int32_t* sorted_pos,
                                    const float* grad, const rec_grad_layout* grad_layout, float* P,
                                    float lr, void* stream) {
-  rec_grad_layout gl = {1, 0, 0};
+  rec_grad_layout gl = {1, 0, 0, nullptr};
   if (grad_layout) gl = *grad_layout;
   REC_REQUIRE(n_max >= 0 && emb_dim > 0 && row_stride >= emb_dim && gl.div >= 1, REC_EINVAL, "bad sizes");
   REC_REQUIRE(gl.group <= 0 || gl.group_stride >= (int64_t)gl.group * emb_dim, REC_EINVAL,
               "grad group_stride too small");
+  REC_REQUIRE(((uintptr_t)gl.partials) % 16 == 0, REC_EINVAL, "grad_layout.partials must be 16-byte aligned");
   REC_REQUIRE(n_uniq && uniq_rows && seg_offset && sorted_pos && grad && P, REC_EINVAL,
               "null pointer argument");
   if (n_max == 0) return REC_OK;
@@ -630,7 +767,7 @@ extern "C" int rec_adam_rows_all(int64_t num_rows, int32_t emb_dim, int32_t row_
                                  const int32_t* seg_offset, const int32_t* sorted_pos, const float* grad,
                                  const rec_grad_layout* grad_layout, const float* grad_scale, float* P,
                                  float* M, float* V, const rec_adam_hyper* hyper, void* stream) {
-  rec_grad_layout gl = {1, 0, 0};
+  rec_grad_layout gl = {1, 0, 0, nullptr};
   if (grad_layout) gl = *grad_layout;
   REC_REQUIRE(num_rows >= 0 && emb_dim > 0 && row_stride >= emb_dim && gl.div >= 1, REC_EINVAL, "bad sizes");
   if (state_stride <= 0) state_stride = row_stride;

@@ -296,16 +296,18 @@ class DCN_V2Layer:
                    b_colsum=g["dense_emb.bias"])
         with self._timed("optimizer"):
             scale = None
+            pp = self._pp = k.segment_partials(groups, dfeat, D, grad_group=S, grad_group_stride=d,
+                                               out=getattr(self, "_pp", None))   # hot rows, shared by both consumers
             if clip_norm:
                 ss = self._scalar("sumsq")
                 k.sumsq(self.dense.grad, ss, self.ws)
                 k.sparse_rows_sumsq(groups, dfeat, D, ss, self.ws, accumulate=True, grad_group=S,
-                                    grad_group_stride=d)
+                                    grad_group_stride=d, partials=pp)
                 scale = k.clip_scale(ss, clip_norm, self._scalar("scale"))
             k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr, grad_scale=scale)
             st = self.sparse_state
             k.sparse_adam_rows(groups, dfeat, 1, self.embedding, st["m"], st["v"], t, lr, grad_group=S,
-                               grad_group_stride=d, grad_scale=scale)
+                               grad_group_stride=d, grad_scale=scale, partials=pp)
         self._last_dfeat = dfeat
         return loss, pred
 

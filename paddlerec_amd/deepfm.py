@@ -267,8 +267,11 @@ class DeepFMLayer:
         with torch.cuda.stream(self._side):
             with self._timed("sparse_adam"):
                 upd = self.k.sparse_adam_rows if self.lazy_mode else self.k.adam_rows_all
-                upd(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr)
-                upd(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
+                # hot rows (Zipf ids): long duplicate runs are pre-reduced per 64-position tile
+                pp = self._pp = self.k.segment_partials(groups, row_grad, row_grad.shape[1], out=getattr(self, "_pp", None))
+                pp1 = self._pp1 = self.k.segment_partials(groups, dz, 1, grad_div=S, out=getattr(self, "_pp1", None))
+                upd(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr, partials=pp)
+                upd(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr, partials=pp1)
         with self._timed("mlp_bwd_dw0"):
             finish_dw0()
             self._fold_backward()

@@ -112,14 +112,18 @@ class DINLayer:
         if grp is None:
             grp = self._groups[key] = ops.IdGroups(n, self.device)
         ops.ids_group(ids.reshape(-1), table.shape[0], None, self.ws_group, None, self.status, grp)
-        ops.sparse_sgd_rows(grp, grad_view, table, lr, grad_group=1, grad_group_stride=row_stride_floats)
+        pp = self._partials[key, table.shape[1]] = ops.segment_partials(grp, grad_view, table.shape[1], grad_group=1,
+                                                        grad_group_stride=row_stride_floats,
+                                                        out=self._partials.get((key, table.shape[1])))   # popular items: hot rows
+        ops.sparse_sgd_rows(grp, grad_view, table, lr, grad_group=1, grad_group_stride=row_stride_floats,
+                            partials=pp)
 
     def train_step(self, hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq,
                    target_cat_seq, base_lr=0.85):
         """din/dygraph_model.py:85-100 train_forward + backward + SGD step.  label float32 [B,1].
         Returns (loss [1], pred [B,1])."""
         if not hasattr(self, "_groups"):
-            self._groups, self.ws_group, self.step_count = {}, ops.Workspace(self.device), 0
+            self._groups, self._partials, self.ws_group, self.step_count = {}, {}, ops.Workspace(self.device), 0
         p, E, Ei = self.params, self.firInDim, self.item_emb_size
         B, T = hist_item_seq.shape
         lr = self.learning_rate(self.step_count, base_lr)

@@ -261,12 +261,31 @@ def ids_group(ids, num_rows, padding_idx, ws, slot_offset=None, status=None, gro
     return groups, status
 
 
+def _gl(div, group, group_stride, partials=None):
+    return GradLayout(int(div), int(group), int(group_stride), partials.data_ptr() if partials is not None else None)
+
+
+def segment_partials(groups, grad, D, grad_div=1, grad_group=0, grad_group_stride=0, out=None):
+    """Tile partial sums of the long segments (hot rows) of `grad` under `groups` -> tensor to pass as
+    `partials=` to the row-update ops together with the SAME grad and layout."""
+    nbytes = C.c_size_t(0)
+    check(lib().rec_segment_partials_bytes(groups.n, int(D), C.byref(nbytes)))
+    need = max(nbytes.value // 4, 1)
+    if out is None or out.numel() < need:
+        out = torch.empty(need, dtype=torch.float32, device=grad.device)
+    check(lib().rec_segment_partials(groups.n, int(D), _p(groups.n_uniq), _p(groups.seg_offset),
+                                     _p(groups.sorted_pos), _p(grad),
+                                     C.byref(_gl(grad_div, grad_group, grad_group_stride)), _p(out), _stream()),
+          "rec_segment_partials")
+    return out
+
+
 def _hyper(lr, beta1, beta2, eps, step):
     return AdamHyper(float(lr), float(beta1), float(beta2), float(eps), int(step))
 
 
 def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999,
-                     eps=1e-8, grad_group=0, grad_group_stride=0, grad_scale=None):
+                     eps=1e-8, grad_group=0, grad_group_stride=0, grad_scale=None, partials=None):
     """grad_div / grad_group / grad_group_stride: rec_grad_layout (where position pos's row lives in
     grad); grad_scale: device float[1] clipping coefficient or None."""
     if grad_group <= 0:
@@ -281,13 +300,13 @@ def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, 
     h = _hyper(lr, beta1, beta2, eps, step)
     check(lib().rec_sparse_adam_rows(groups.n, D, stride, sstride, _p(groups.n_uniq), _p(groups.uniq_rows),
                                      _p(groups.seg_offset), _p(groups.sorted_pos), _p(grad),
-                                     C.byref(GradLayout(int(grad_div), int(grad_group), int(grad_group_stride))),
+                                     C.byref(_gl(grad_div, grad_group, grad_group_stride, partials)),
                                      _p(grad_scale), _p(P), _p(M), _p(V), C.byref(h), _stream()),
           "rec_sparse_adam_rows")
 
 
 def adam_rows_all(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
-                  grad_group=0, grad_group_stride=0, grad_scale=None):
+                  grad_group=0, grad_group_stride=0, grad_scale=None, partials=None):
     """lazy_mode=False Adam (dygraph default): every row of P/M/V moves, absent rows with g = 0."""
     D, stride = _chk_table(P, "P")
     sstride = _chk_table(M, "M")[1]
@@ -297,13 +316,13 @@ def adam_rows_all(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, bet
     h = _hyper(lr, beta1, beta2, eps, step)
     check(lib().rec_adam_rows_all(P.shape[0], D, stride, sstride, _p(groups.n_uniq), _p(groups.uniq_rows),
                                   _p(groups.seg_offset), _p(groups.sorted_pos), _p(grad),
-                                  C.byref(GradLayout(int(grad_div), int(grad_group), int(grad_group_stride))),
+                                  C.byref(_gl(grad_div, grad_group, grad_group_stride, partials)),
                                   _p(grad_scale), _p(P), _p(M), _p(V), C.byref(h), _stream()),
           "rec_adam_rows_all")
 
 
 def sparse_adagrad_rows(groups, grad, rec, emb_dim, num_slots, label=None, lr=0.05, initial_g2sum=3.0,
-                        bounds=(-10.0, 10.0), grad_div=1, grad_group=0, grad_group_stride=0):
+                        bounds=(-10.0, 10.0), grad_div=1, grad_group=0, grad_group_stride=0, partials=None):
     """PS accessor rule (SparseAdaGradSGDRule + show/click) on the touched rows of a record table
     rec [N, stride] = [show | click | g2sum_w | g2sum_x | W(D) | pad]."""
     if rec.dim() != 2 or rec.dtype != torch.float32 or not rec.is_cuda or rec.stride(1) != 1:
@@ -313,8 +332,7 @@ def sparse_adagrad_rows(groups, grad, rec, emb_dim, num_slots, label=None, lr=0.
     h = AdagradHyper(float(lr), float(initial_g2sum), float(bounds[0]), float(bounds[1]))
     check(lib().rec_sparse_adagrad_rows(groups.n, int(emb_dim), rec.stride(0), int(num_slots), _p(groups.n_uniq),
                                         _p(groups.uniq_rows), _p(groups.seg_offset), _p(groups.sorted_pos),
-                                        _p(grad), C.byref(GradLayout(int(grad_div), int(grad_group),
-                                                                     int(grad_group_stride))),
+                                        _p(grad), C.byref(_gl(grad_div, grad_group, grad_group_stride, partials)),
                                         _p(label), _p(rec), C.byref(h), _stream()), "rec_sparse_adagrad_rows")
 
 
@@ -343,13 +361,13 @@ def sumsq(x, out, ws, accumulate=False):
 
 
 def sparse_rows_sumsq(groups, grad, D, out, ws, accumulate=False, grad_div=1, grad_group=0,
-                      grad_group_stride=0):
+                      grad_group_stride=0, partials=None):
     """out[0] (+)= sum over merged rows of |sum of the row's duplicate gradients|^2."""
     _chk(out, torch.float32, "out")
     w = _sumsq_ws(ws)
     check(lib().rec_sparse_rows_sumsq(groups.n, int(D), _p(groups.n_uniq), _p(groups.seg_offset),
                                       _p(groups.sorted_pos), _p(grad),
-                                      C.byref(GradLayout(int(grad_div), int(grad_group), int(grad_group_stride))),
+                                      C.byref(_gl(grad_div, grad_group, grad_group_stride, partials)),
                                       _p(out), int(accumulate), _p(w), C.c_size_t(w.numel()), _stream()),
           "rec_sparse_rows_sumsq")
     return out
@@ -414,11 +432,11 @@ def din_attention_pool_bwd(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_his
     return dh, dq
 
 
-def sparse_sgd_rows(groups, grad, P, lr, grad_div=1, grad_group=0, grad_group_stride=0):
+def sparse_sgd_rows(groups, grad, P, lr, grad_div=1, grad_group=0, grad_group_stride=0, partials=None):
     D, stride = _chk_table(P, "P")
     check(lib().rec_sparse_sgd_rows(groups.n, D, stride, _p(groups.n_uniq), _p(groups.uniq_rows),
                                     _p(groups.seg_offset), _p(groups.sorted_pos), _p(grad),
-                                    C.byref(GradLayout(int(grad_div), int(grad_group), int(grad_group_stride))),
+                                    C.byref(_gl(grad_div, grad_group, grad_group_stride, partials)),
                                     _p(P), float(lr), _stream()), "rec_sparse_sgd_rows")
 
 

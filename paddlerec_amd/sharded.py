@@ -278,8 +278,11 @@ class ShardedDeepFMLayer(DeepFMLayer):
             with self._timed("sparse_adam"):
                 if L.n_recv:
                     st = self.sparse_state
-                    k.sparse_adam_rows(groups, recv_g, 1, self.fm.embedding, st["m"], st["v"], t, lr)
-                    k.sparse_adam_rows(groups, recv_g1, 1, self.fm.embedding_one, st["m1"], st["v1"], t, lr)
+                    pp = self._pp = k.segment_partials(groups, recv_g, D, out=getattr(self, "_pp", None))
+                    pp1 = self._pp1 = k.segment_partials(groups, recv_g1, 1, out=getattr(self, "_pp1", None))
+                    k.sparse_adam_rows(groups, recv_g, 1, self.fm.embedding, st["m"], st["v"], t, lr, partials=pp)
+                    k.sparse_adam_rows(groups, recv_g1, 1, self.fm.embedding_one, st["m1"], st["v1"], t, lr,
+                                       partials=pp1)
         with self._timed("mlp_bwd_dw0"):
             finish_dw0()
             self._fold_backward()

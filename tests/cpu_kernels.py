@@ -115,7 +115,12 @@ def ids_group(ids, num_rows, padding_idx, ws, slot_offset=None, status=None, gro
     return groups, status
 
 
-def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+def segment_partials(groups, grad, D, grad_div=1, grad_group=0, grad_group_stride=0, out=None):
+    return None     # a pure speed-up of the device kernels (hot rows); the merge below is position by position
+
+
+def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                     partials=None):
     g = grad.numpy().reshape(-1, P.shape[1])
     merged = np.zeros((len(groups.uniq), P.shape[1]), np.float32)
     for u in range(len(groups.uniq)):

@@ -268,6 +268,71 @@ def test_sparse_adam_rows_vs_oracle(ops, D, zipf):
     assert np.array_equal(N_(tP)[untouched], P[untouched])            # lazy: other rows untouched
 
 
+def _hot_row_ids(rng, pad=37):
+    """Flattened ids whose sorted segments hit every tile case of rec_segment_partials (REC_SEG_TILE = 64,
+    REC_SEG_LONG = 128): long segments that start / end on and off tile boundaries, a 127-long (short) one,
+    long-short-long inside neighbouring tiles, a ragged tail, padding ids in between."""
+    lens = [5, 128, 59, 128, 1, 127, 300, 64, 1000, 2, 2500, 17, 129, 3, 640, 1]
+    ids = np.concatenate([np.full(L, r + 1, np.int64) for r, L in enumerate(lens)] + [np.zeros(pad, np.int64)])
+    return rng.permutation(ids), len(lens) + 1
+
+
+@pytest.mark.parametrize("D,layout", [(16, "rows"), (1, "div"), (9, "rows"), (40, "group"), (64, "rows")])
+def test_hot_rows_segment_partials(ops, D, layout):
+    """Merged gradient through the tile partials == position-by-position merge == float64 sum (1e-5)."""
+    rng = np.random.default_rng(D)
+    ids, N = _hot_row_ids(rng)
+    n = ids.size
+    S = 3 if layout == "div" else 1
+    if layout == "div":
+        ids = ids[: n // S * S]                                   # gradient row of position p is grad[p // S]
+        n = ids.size
+        grad = rng.standard_normal((n // S, 1)).astype(np.float32)
+        kw = dict(grad_div=S)
+        rows_of = lambda g: np.repeat(g, S, 0)
+    elif layout == "group":
+        stride = D + 24
+        buf = rng.standard_normal((n, stride)).astype(np.float32)
+        grad, kw = buf, dict(grad_group=1, grad_group_stride=stride)
+        rows_of = lambda g: g[:, :D]
+    else:
+        grad, kw = rng.standard_normal((n, D)).astype(np.float32), {}
+        rows_of = lambda g: g
+    ws = ops.Workspace(DEV)
+    groups, _ = ops.ids_group(T(ids.reshape(-1, 1)), N, 0, ws)
+    tg = T(grad)
+    pp = ops.segment_partials(groups, tg, D, **kw)
+    out = []
+    for partials in (None, pp):
+        P = torch.zeros(N, D, dtype=torch.float32, device=DEV)
+        ops.sparse_sgd_rows(groups, tg, P, -1.0, partials=partials, **kw)      # P = merged gradient
+        out.append(N_(P))
+    ref = np.zeros((N, D), np.float64)
+    np.add.at(ref, ids[ids != 0], rows_of(grad).astype(np.float64)[ids != 0])
+    mag = np.zeros((N, D), np.float64)
+    np.add.at(mag, ids[ids != 0], np.abs(rows_of(grad).astype(np.float64))[ids != 0])
+    for got in out:
+        assert np.all(np.abs(got - ref) <= 1e-6 * mag + 1e-6)                # fp32 summation bound, any order
+        assert np.array_equal(got[0], np.zeros(D, np.float32))
+    # the other consumers take the same partials: Adam (lazy + all rows) and the clipping norm agree both ways
+    res = []
+    for partials in (None, pp):
+        Pm = [torch.zeros(N, D, dtype=torch.float32, device=DEV) for _ in range(3)]
+        ops.sparse_adam_rows(groups, tg, kw.get("grad_div", 1), *Pm, 1, lr=1e-3, partials=partials,
+                             **{k_: v for k_, v in kw.items() if k_ != "grad_div"})
+        Pa = [torch.zeros(N, D, dtype=torch.float32, device=DEV) for _ in range(3)]
+        ops.adam_rows_all(groups, tg, kw.get("grad_div", 1), *Pa, 1, lr=1e-3, partials=partials,
+                          **{k_: v for k_, v in kw.items() if k_ != "grad_div"})
+        ss = torch.zeros(1, dtype=torch.float32, device=DEV)
+        ops.sparse_rows_sumsq(groups, tg, D, ss, ws, partials=partials, **kw)
+        res.append((N_(Pm[1]), N_(Pa[1]), float(ss.item())))
+    for j in (0, 1):                                                           # first moment = 0.1 * merged g
+        assert np.all(np.abs(res[1][j] - res[0][j]) <= 1e-7 * mag + 1e-7)
+        assert np.all(np.abs(res[1][j] - 0.1 * ref) <= 1e-7 * mag + 1e-7)
+    assert abs(res[1][2] - res[0][2]) <= 1e-5 * res[0][2]
+    np.testing.assert_allclose(res[1][2], float((ref ** 2).sum()), rtol=1e-5)
+
+
 def test_sparse_adam_first_order_via_grad_div(ops):
     """embedding_one: SelectedRows.value is dy1[b] for all S slots of sample b (grad_div = S)."""
     B, S, N = 300, 26, 200
