@@ -67,12 +67,19 @@ def mlp_flops(B, sizes):
     return sum(2 * B * sizes[i] * sizes[i + 1] for i in range(len(sizes) - 1))
 
 
-def make_batches(n, B, S, Dn, rows_per_table, device, seed):
-    """Device-resident synthetic Criteo-shaped batches: uniform ids in [1,rows), 3 % padding (id 0)."""
+def make_batches(n, B, S, Dn, rows_per_table, device, seed, dist="uniform"):
+    """Device-resident synthetic Criteo-shaped batches, 3 % padding (id 0).  ids: (U) uniform in [1,rows) or
+    (Z) Zipf(1.05) ranks through a fixed random permutation, clipped to [1,rows-1]: hot rows."""
     g = torch.Generator(device=device).manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    perm = torch.as_tensor(rng.permutation(rows_per_table)).to(device) if dist == "zipf" else None
     out = []
     for _ in range(n):
-        ids = torch.randint(1, rows_per_table, (B, S), device=device, generator=g, dtype=torch.int64)
+        if dist == "zipf":
+            rank = np.minimum(rng.zipf(1.05, size=(B, S)), rows_per_table - 1)
+            ids = perm[torch.as_tensor(rank).to(device)].clamp_(1, rows_per_table - 1)
+        else:
+            ids = torch.randint(1, rows_per_table, (B, S), device=device, generator=g, dtype=torch.int64)
         ids[torch.rand(B, S, device=device, generator=g) < 0.03] = 0
         dense = torch.rand(B, Dn, device=device, generator=g)
         label = (torch.rand(B, 1, device=device, generator=g) < 0.25).to(torch.int64)
@@ -138,6 +145,8 @@ def main():
     ap.add_argument("--dim", type=int, default=16)
     ap.add_argument("--rows-per-table", type=int, default=1_000_000)
     ap.add_argument("--fc", type=str, default="400,400,400")
+    ap.add_argument("--ids", choices=("uniform", "zipf"), default="uniform",
+                    help="id distribution of SURVEY.md §8(d): (U) uniform [default] or (Z) Zipf 1.05 (hot rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the row-sharded path (RCCL all-to-all) even with one rank")
@@ -165,6 +174,7 @@ def main():
     # weak scaling: every GPU holds 26 x rows_per_table rows; the global table grows with the world
     N = args.rows_per_table * S * world
     so = torch.arange(S, dtype=torch.int64, device=dev) * (args.rows_per_table * world)
+    torch.manual_seed(20250404)                  # same random-init dense weights on every run (and rank)
     if dist is None:
         from paddlerec_amd.deepfm import DeepFMLayer
         model = DeepFMLayer(N, D, Dn, S, fc, device=dev, slot_offset=so)
@@ -173,7 +183,7 @@ def main():
         from paddlerec_amd.sharded import ShardedDeepFMLayer
         model = ShardedDeepFMLayer(N, D, Dn, S, fc, device=dev, slot_offset=so, group=dist.group.WORLD)
         parallelism = "rowshard%d+dp%d" % (world, world)
-    batches = make_batches(4, B, S, Dn, args.rows_per_table * world, dev, 20250404 + rank)
+    batches = make_batches(4, B, S, Dn, args.rows_per_table * world, dev, 20250404 + rank, args.ids)
 
     def step(i):
         ids, dense, label = batches[i % len(batches)]
@@ -192,8 +202,11 @@ def main():
     model.timers = {}
     barrier()
     t0 = time.perf_counter()
+    host_issue = 0.0
     for i in range(args.steps):
+        h0 = time.perf_counter()
         loss, _ = step(args.warmup + i)
+        host_issue += time.perf_counter() - h0
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -208,7 +221,9 @@ def main():
         ev = model.timers.get(name, [])
         return sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
 
-    k_ms = {k: avg_ms(k) for k in model.timers}
+    k_ms = {k: avg_ms(k) for k in model.timers if not k.endswith("@host")}
+    host_ms = {k[:-5]: 1e3 * sum(v) / max(len(v), 1) for k, v in model.timers.items() if k.endswith("@host")}
+    host_ms["step_issue_total"] = 1e3 * host_issue / args.steps     # host time inside train_step (no device sync)
     fwd_b, bwd_b = algorithmic_bytes(B, S, Dn, D)
     t_pair = (k_ms.get("fm_fwd", 0) + k_ms.get("fm_bwd", 0)) * 1e-3
     achieved = (fwd_b + bwd_b) / t_pair / 1e9 if t_pair > 0 else 0.0
@@ -221,7 +236,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "DeepFM full Criteo: 26 sparse slots x %d rows x dim %d, 13 dense, "
-                               "MLP %s, batch %d per GPU, lazy Adam" % (args.rows_per_table, D, args.fc, B),
+                               "MLP %s, batch %d per GPU, lazy Adam, %s ids" % (args.rows_per_table, D, args.fc, B, args.ids),
                    "global_batch": world * B, "parallelism": parallelism,
                    "table_rows_total": N, "loss": loss_v, "index_oob_flag": oob},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -232,7 +247,7 @@ def main():
                      "fm_fwd_ms": k_ms.get("fm_fwd"), "fm_bwd_ms": k_ms.get("fm_bwd"),
                      "fm_fwd_GBs": fwd_b / (k_ms["fm_fwd"] * 1e-3) / 1e9 if k_ms.get("fm_fwd") else None,
                      "fm_bwd_GBs": bwd_b / (k_ms["fm_bwd"] * 1e-3) / 1e9 if k_ms.get("fm_bwd") else None},
-        "kernels_ms": k_ms,
+        "kernels_ms": k_ms, "host_issue_ms": host_ms,
         "mlp_gemm": {"bound": "mfma", "achieved": gemm_tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": gemm_tf / FP32_MFMA_PEAK_TF},
     }

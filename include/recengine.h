@@ -357,6 +357,10 @@ typedef struct {
 } rec_gemm_epilogue_args;
 
 int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* bytes);
+/* Host query: the split-K factor the planner picks for `desc` (its split_k ignored) when the GEMM may use
+ * num_cus compute units (<= 0: the whole chip) — one resident round of blocks.  A caller that runs the GEMM on
+ * a CU-restricted stream (rec_stream_create_cu_range) passes the result as desc->split_k. */
+int rec_gemm_plan_splits(const rec_gemm_desc* desc, int32_t num_cus, int32_t* splits);
 int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const float* B, float* C,
                  const rec_gemm_epilogue_args* args /* may be NULL */, void* workspace,
                  size_t workspace_bytes, void* stream);
@@ -442,6 +446,20 @@ int rec_parse_criteo_tsv(const char* buf, size_t len, int32_t n_dense, int32_t n
 /* Fills buf[i] = i-th value of a counter-based generator, uniform in [lo,hi) — used to initialise
  * multi-GB tables on the device without a host round trip. */
 int rec_fill_uniform(int64_t n, float* buf, float lo, float hi, uint64_t seed, void* stream);
+
+/* One wave busy-waits `micros` microseconds on `stream`.  Host-side stream probe: HIP maps streams onto a
+ * few hardware queues and kernels of two streams that share a queue run strictly one after the other, so a
+ * caller that wants its HBM-bound side stream to run underneath the GEMMs of its main stream spins both and
+ * checks with events that the two spins overlapped (paddlerec_amd/ops.py: concurrent_stream). */
+int rec_stream_spin(int32_t micros, void* stream);
+
+/* Streams confined to the compute units [cu_begin, cu_end) of the current device (bit i of the HSA CU mask;
+ * gfx950 has 256).  The row-sharded step partitions the chip for its tail: the HBM / xGMI bound chain (gradient
+ * all-to-all, sparse Adam, next lookup) on a few CUs, the MFMA-bound dW GEMMs on the rest — two kernels that
+ * merely share all CUs do not co-schedule (the GEMM's long-lived blocks hold every wave slot).  The stream is a
+ * plain hipStream_t owned by the caller: rec_stream_destroy when done. */
+int rec_stream_create_cu_range(int32_t cu_begin, int32_t cu_end, void** stream);
+int rec_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

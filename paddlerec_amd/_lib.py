@@ -106,6 +106,7 @@ SIGNATURES = {
     "rec_shard_route_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(_SZ)]),
     "rec_shard_route": (C.c_int, [_I64, _I32, _I64, _I64, _I32] + [_P] * 9 + [_SZ, _P]),
     "rec_gemm_f32_workspace_bytes": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(_SZ)]),
+    "rec_gemm_plan_splits": (C.c_int, [C.POINTER(GemmDesc), _I32, C.POINTER(_I32)]),
     "rec_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, C.POINTER(GemmEpilogueArgs), _P, _SZ, _P]),
     "rec_colsum_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(_SZ)]),
     "rec_colsum": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _SZ, _P]),
@@ -118,6 +119,9 @@ SIGNATURES = {
     "rec_parse_criteo_tsv": (C.c_int, [C.c_char_p, _SZ, _I32, _I32, _P, _P, C.c_uint32, _I64, _I32, _P, _P, _P,
                                        C.POINTER(_I64)]),
     "rec_fill_uniform": (C.c_int, [_I64, _P, _F, _F, C.c_uint64, _P]),
+    "rec_stream_spin": (C.c_int, [_I32, _P]),
+    "rec_stream_create_cu_range": (C.c_int, [_I32, _I32, C.POINTER(C.c_void_p)]),
+    "rec_stream_destroy": (C.c_int, [_P]),
 }
 
 _lib = None

@@ -505,7 +505,7 @@ static bool skinny_dw(const rec_gemm_desc* d) {     // C[M<=1024, N<=4] = A^T B 
   return d->n <= kSkinnyN && d->trans_a && !d->trans_b && d->m <= kSkinnyMT * kBlock && d->k >= 1024;
 }
 
-static GemmPlan plan_gemm(const rec_gemm_desc* d) {
+static GemmPlan plan_gemm(const rec_gemm_desc* d, int num_cus = kNumCU) {
   GemmPlan p;
   const int N = d->n;
   // 128x80 when it wastes fewer columns than 128x128 (N = 400 -> 5 x 80 exactly)
@@ -519,7 +519,7 @@ static GemmPlan plan_gemm(const rec_gemm_desc* d) {
   const int nkt = (d->k + kBK - 1) / kBK;
   if (splits <= 0) {  // auto: split K when the output alone cannot fill the chip
     splits = 1;
-    const int64_t capacity = (int64_t)kNumCU * (p.narrow ? gemm_blocks_per_cu<80>() : gemm_blocks_per_cu<128>());
+    const int64_t capacity = (int64_t)num_cus * (p.narrow ? gemm_blocks_per_cu<80>() : gemm_blocks_per_cu<128>());
     if (p.tiles_total * 2 <= capacity) {
       // as many splits as still fit in ONE resident round (one block more would double the time)
       int64_t want = capacity / p.tiles_total;
@@ -602,6 +602,15 @@ extern "C" int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* b
   // [splits][M][ldc] partial tiles (split-K only) + [splits][N] partial column sums
   *bytes = (p.splits > 1 ? align_up((size_t)p.splits * desc->m * desc->ldc * sizeof(float), 256) : 0) +
            align_up((size_t)p.splits * desc->n * sizeof(float), 256);
+  return REC_OK;
+}
+
+extern "C" int rec_gemm_plan_splits(const rec_gemm_desc* desc, int32_t num_cus, int32_t* splits) {
+  if (int rc = check_gemm(desc)) return rc;
+  REC_REQUIRE(splits && num_cus <= kNumCU, REC_EINVAL, "bad arguments");
+  rec_gemm_desc d = *desc;
+  d.split_k = 0;
+  *splits = plan_gemm(&d, num_cus > 0 ? num_cus : kNumCU).splits;
   return REC_OK;
 }
 

@@ -200,6 +200,46 @@ extern "C" int rec_auc_histogram(int64_t batch, const float* pred, const int64_t
   return check_launch("rec_auc_histogram");
 }
 
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+extern "C" int rec_stream_spin(int32_t micros, void* stream) {
+  REC_REQUIRE(micros >= 0 && micros <= 1000000, REC_EINVAL, "micros out of range");
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+    khz = 100000;   // gfx9 constant 100 MHz counter
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     (long long)micros * khz / 1000);
+  return check_launch("rec_stream_spin");
+}
+
+extern "C" int rec_stream_create_cu_range(int32_t cu_begin, int32_t cu_end, void** stream) {
+  REC_REQUIRE(stream && cu_begin >= 0 && cu_end > cu_begin && cu_end <= 1024, REC_EINVAL, "bad CU range");
+  uint32_t mask[32] = {0};
+  for (int i = cu_begin; i < cu_end; ++i) mask[i / 32] |= 1u << (i % 32);
+  hipStream_t s = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)((cu_end + 31) / 32), mask);
+  if (e != hipSuccess) {
+    set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    return REC_EHIP;
+  }
+  *stream = (void*)s;
+  return REC_OK;
+}
+
+extern "C" int rec_stream_destroy(void* stream) {
+  if (!stream) return REC_OK;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) {
+    set_error("hipStreamDestroy: %s", hipGetErrorString(e));
+    return REC_EHIP;
+  }
+  return REC_OK;
+}
+
 extern "C" int rec_fill_uniform(int64_t n, float* buf, float lo, float hi, uint64_t seed,
                                 void* stream) {
   REC_REQUIRE(n >= 0 && (n == 0 || buf), REC_EINVAL, "bad arguments");

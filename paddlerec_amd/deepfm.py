@@ -12,6 +12,8 @@ There is no autograd tape and no CPU fallback: backward is the explicit chain th
 """
 import math
 
+import time
+
 import torch
 
 from . import ops
@@ -48,6 +50,7 @@ class _Timed:
 
     def __enter__(self):
         if self.timers is not None:
+            self.h0 = time.perf_counter()
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
@@ -56,6 +59,8 @@ class _Timed:
         if self.timers is not None:
             self.e1.record()
             self.timers.setdefault(self.name, []).append((self.e0, self.e1))
+            # host time spent ISSUING the region (launch overhead, host syncs) under "<name>@host"
+            self.timers.setdefault(self.name + "@host", []).append(time.perf_counter() - self.h0)
 
 
 def _round_up(x, m):
@@ -231,7 +236,7 @@ class DeepFMLayer:
         self.step_count += 1
         cur = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = self.k.concurrent_stream(self.device)   # verified to overlap with the main stream
         groups = getattr(self, "_groups", None)          # persistent: the wait_stream below orders reuse
         if groups is None or groups.n != B * S:
             groups = self._groups = self.k.IdGroups(B * S, self.device)

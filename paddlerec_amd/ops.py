@@ -5,6 +5,7 @@ librecengine.so.  Tensors must live on a ROCm device — there is deliberately n
 Reference call sites are cited in include/recengine.h next to each entry point.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -546,9 +547,11 @@ def _chk_mat(t, name):
 
 
 def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux0=None, aux1=None,
-         out=None, split_k=0, b_colsum=None, row_scale=None, out2=None):
+         out=None, split_k=0, b_colsum=None, row_scale=None, out2=None, num_cus=0):
     """out[M,N] = epi(op(A) @ op(B)); A/B/out row-major (row strides allowed).
-    trans_a: A is given as [K,M]; trans_b: B is given as [N,K] (a torch Linear.weight, or W for dX)."""
+    trans_a: A is given as [K,M]; trans_b: B is given as [N,K] (a torch Linear.weight, or W for dX).
+    num_cus > 0: the current stream is confined to that many compute units (cu_range_stream) — size the
+    split-K for them instead of the whole chip."""
     lda, ldb = _chk_mat(A, "A"), _chk_mat(B, "B")
     K, M = (A.shape if trans_a else A.shape[::-1])
     N, K2 = (B.shape if trans_b else B.shape[::-1])
@@ -583,6 +586,10 @@ def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux
         if tuple(out2.shape) != (M, N):
             raise RecError("out2 must have the shape of out")
     d = GemmDesc(M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), EPI[epilogue], int(split_k))
+    if num_cus > 0 and split_k <= 0:
+        sp = C.c_int32(0)
+        check(lib().rec_gemm_plan_splits(C.byref(d), int(num_cus), C.byref(sp)), "rec_gemm_plan_splits")
+        d.split_k = sp.value
     pv = lambda t: None if t is None else t.data_ptr()
     x = GemmEpilogueArgs(pv(bias), pv(aux0), ld0, pv(aux1), ld1, pv(row_scale), rs_stride, pv(out2),
                          ld2, pv(b_colsum))
@@ -623,14 +630,26 @@ def mlp_forward(x, weights, biases, ws, relu_last=False, out_last=None):
     return x, acts + [x]
 
 
-def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False):
+def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=False):
     """Backward of mlp_forward: dW_i -> dws[i], db_i -> dbs[i] (preallocated views); returns d(input).
     ReLU' is applied in the epilogue of the dX GEMM (mask = layer input > 0).
     defer_first: compute d(input) BEFORE dW_0 and return (d_input, finish) where finish() launches the
     dW_0 / db_0 GEMM — lets the caller start the HBM-bound consumers of d(input) on another stream
-    underneath that MFMA-bound GEMM."""
+    underneath that MFMA-bound GEMM.
+    defer_all: run the whole dX chain first and return (d_input, finish) with EVERY dW / db GEMM in finish()
+    — the row-sharded step hides its gradient exchange, sparse optimizer and the next batch's lookup under them."""
     n = len(weights)
     g = dy
+    if defer_all:
+        gs = [None] * n
+        for i in reversed(range(n)):
+            gs[i] = g
+            g = gemm(g, weights[i], ws, trans_b=True, **(dict(epilogue="relu_mask", aux0=acts[i]) if i > 0 else {}))
+
+        def finish(num_cus=0):
+            for i in reversed(range(n)):
+                gemm(acts[i], gs[i], ws, trans_a=True, out=dws[i], b_colsum=dbs[i], num_cus=num_cus)
+        return g, finish
     for i in reversed(range(n)):
         if i == 0 and defer_first:
             g0 = g
@@ -682,6 +701,58 @@ def fill_uniform(buf, lo, hi, seed):
     check(lib().rec_fill_uniform(buf.numel(), _p(buf), float(lo), float(hi), int(seed), _stream()),
           "rec_fill_uniform")
     return buf
+
+
+_SIDE_STREAMS = {}
+
+
+def concurrent_stream(device, tries=8, micros=200, priority=None):
+    """A side stream whose kernels really run CONCURRENTLY with the current stream's.  HIP multiplexes streams
+    onto a few hardware queues (4 by default, shared with the streams RCCL and rocPRIM create); two streams on
+    one queue execute strictly in submission order, which silently turns 'sparse optimizer underneath the dW
+    GEMM' into 'after it'.  Probe: spin `micros` on a candidate, then on the current stream, and accept the
+    candidate if the second spin did not have to wait for the first (events).  Cached per (device, main stream)."""
+    device = torch.device(device)
+    main = torch.cuda.current_stream(device)
+    if priority is None:
+        priority = int(os.environ.get("REC_SIDE_PRIORITY", "0"))      # -1 = high priority queue (measured: no effect)
+    key = (device.index, main.cuda_stream, priority)
+    if key in _SIDE_STREAMS:
+        return _SIDE_STREAMS[key]
+    s = None
+    with torch.cuda.device(device):
+        for _ in range(tries):
+            s = torch.cuda.Stream(device=device, priority=priority)
+            for st in (s, main):                                  # first use of a stream binds its queue
+                check(lib().rec_stream_spin(1, C.c_void_p(st.cuda_stream)), "rec_stream_spin")
+            torch.cuda.synchronize(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+            check(lib().rec_stream_spin(micros, C.c_void_p(s.cuda_stream)), "rec_stream_spin")
+            check(lib().rec_stream_spin(micros, C.c_void_p(main.cuda_stream)), "rec_stream_spin")
+            e1.record(main)
+            torch.cuda.synchronize(device)
+            if e0.elapsed_time(e1) * 1e3 < 1.5 * micros:
+                break
+    _SIDE_STREAMS[key] = s
+    return s
+
+
+_CU_STREAMS = {}
+
+
+def cu_range_stream(device, cu_begin, cu_end):
+    """torch stream (ExternalStream over rec_stream_create_cu_range) whose kernels only run on compute units
+    [cu_begin, cu_end).  Cached for the life of the process."""
+    device = torch.device(device)
+    key = (device.index, int(cu_begin), int(cu_end))
+    if key not in _CU_STREAMS:
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            check(lib().rec_stream_create_cu_range(int(cu_begin), int(cu_end), C.byref(h)),
+                  "rec_stream_create_cu_range")
+        _CU_STREAMS[key] = torch.cuda.ExternalStream(h.value, device=device)
+    return _CU_STREAMS[key]
 
 
 # ------------------------------------------------------------------ host: feature hash

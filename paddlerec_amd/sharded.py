@@ -15,6 +15,8 @@ plus ONE all-reduce of the flat dense-gradient bucket (MLP + FM dense weights + 
 The loss is the mean over the GLOBAL batch (G*B), so a sharded step is arithmetically one step of the
 unsharded model on the concatenated batch (tests/test_sharded*.py check exactly that).
 """
+import os
+
 import torch
 
 from . import ops
@@ -60,6 +62,15 @@ class Comm:
             self.dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=self.group)
         return out
 
+    def broadcast(self, t, src=0):
+        if self.staged and t.is_cuda:
+            h = t.cpu()
+            self.dist.broadcast(h, src=self.dist.get_global_rank(self.group, src), group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, src), group=self.group)
+        return t
+
     def all_reduce_sum(self, t):
         if self.staged and t.is_cuda:
             h = t.cpu()
@@ -92,15 +103,26 @@ class ShardedDeepFMLayer(DeepFMLayer):
                          sparse_num_field, layer_sizes, device=device, slot_offset=slot_offset,
                          table_rows=self.local_rows, zero_padding_row=(self.comm.rank == 0),
                          kernels=kernels, extra_dense=(("__loss__", (1,)),))
+        # data-parallel replicas of the dense parameters (MLP, FM dense weights) must start identical: every rank
+        # drew its own random initialisation, rank 0's wins (one flat buffer, one broadcast)
+        if G > 1:
+            self.comm.broadcast(self.dense.data, src=0)
         self.ws_route = self.k.Workspace(self.device)
         self._routes, self._route_flip, self._pending = [], 0, None
         self._groups = None
-        self._reply = None
+        self._replies, self._reply_flip = [None, None], 0
+        # how the tail of a step (exchange chain vs dW GEMMs) shares the chip: "overlap" two streams on all CUs,
+        # "serial" chain then GEMMs, "partition" disjoint CU ranges (side_cus for the chain)
+        self.tail_mode = os.environ.get("REC_SHARD_TAIL", "overlap")
+        self.side_cus = int(os.environ.get("REC_SHARD_SIDE_CUS", "64"))
+        self._gemm_stream, self._gemm_cus = None, 0
+        self._next_lookup = None
 
     # -- parameters: global <-> shard --------------------------------------------------------------
     def set_dict(self, sd):
         """Accepts GLOBAL tables ([N,D] / [N,1]); keeps rows r with r % G == rank."""
         sd = dict(sd)
+        self._next_lookup = None          # a prefetched lookup holds rows of the old tables
         G, r = self.comm.world, self.comm.rank
         for key, dst in (("fm.embedding.weight", self.fm.embedding),
                          ("fm.embedding_one.weight", self.fm.embedding_one)):
@@ -175,9 +197,12 @@ class ShardedDeepFMLayer(DeepFMLayer):
         if L.n_recv:
             k.emb_gather(L.recv_rows, self.fm.embedding, None, self.status, out=g_rows)
             k.emb_gather(L.recv_rows, self.fm.embedding_one, None, self.status, out=g_w1)
-        if self._reply is None or self._reply[0].shape[0] != n + 1:
-            self._reply = (torch.zeros(n + 1, D, **f32), torch.zeros(n + 1, 1, **f32))  # row 0 stays 0
-        L.reply, L.reply1 = self._reply
+        self._reply_flip ^= 1            # double-buffered: the next batch's lookup may be issued during this step
+        rep = self._replies[self._reply_flip]
+        if rep is None or rep[0].shape[0] != n + 1:
+            rep = self._replies[self._reply_flip] = (torch.zeros(n + 1, D, **f32),
+                                                     torch.zeros(n + 1, 1, **f32))  # row 0 stays 0
+        L.reply, L.reply1 = rep
         self.comm.all_to_all(L.reply[1:1 + L.n_send], g_rows, L.send_splits, L.recv_splits)
         self.comm.all_to_all(L.reply1[1:1 + L.n_send], g_w1, L.send_splits, L.recv_splits)
         return L
@@ -213,8 +238,16 @@ class ShardedDeepFMLayer(DeepFMLayer):
         t = self.step_count
         on_gpu = self.device.type == "cuda"
         cur = torch.cuda.current_stream() if on_gpu else None
+        mode = self.tail_mode if on_gpu else "overlap"
         if on_gpu and self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            if mode == "partition":
+                # the chip is split for the tail of the step: HBM/xGMI-bound chain on the first side_cus compute
+                # units, dW GEMMs on the others (two kernels sharing all CUs do not co-schedule)
+                ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+                self._side = k.cu_range_stream(self.device, 0, self.side_cus)
+                self._gemm_stream, self._gemm_cus = k.cu_range_stream(self.device, self.side_cus, ncu), ncu - self.side_cus
+            else:
+                self._side = k.concurrent_stream(self.device)   # verified to overlap with the main stream
 
         class _Side:          # "with side:" = run on the side stream after everything issued so far (GPU only)
             def __enter__(s_):
@@ -228,7 +261,9 @@ class ShardedDeepFMLayer(DeepFMLayer):
                     s_.ctx.__exit__(*a)
 
         with self._timed("lookup_exchange"):
-            L = self._lookup(ids)
+            nl, self._next_lookup = self._next_lookup, None
+            # prefetched behind the previous step's sparse Adam (see the end of this function)
+            L = nl[1] if nl is not None and nl[0] is ids else self._lookup(ids)
         groups = None
         if L.n_recv:
             # merge keys of the rows this rank owns: sorted on the side stream under the forward GEMMs
@@ -252,8 +287,10 @@ class ShardedDeepFMLayer(DeepFMLayer):
         if auc_stats is not None:
             k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         with self._timed("mlp_bwd"):
+            # dX chain only; every dW / db GEMM is deferred to the tail so that the exchange-bound work
+            # (gradient all-to-all, sparse Adam, next batch's lookup) has ~1.2 ms of MFMA work to hide under
             d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db,
-                                                     self.ws_mlp, defer_first=True)
+                                                     self.ws_mlp, defer_all=True)
         with self._timed("fm_bwd"):
             row_grad, _, _ = k.deepfm_fm_bwd(
                 dense_inputs, feat, sum_emb, d_flat.view(B, self.fp, -1), dz, dz, S, self.ws,
@@ -261,8 +298,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
                      self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
                      self.dense.g["fm.dense_w_one"]),
                 dense_w=self.dense.p["fm.dense_w"], compact=self.compact)
-        # row-gradient exchange + lazy sparse optimizer (xGMI / HBM bound) on the side stream, underneath
-        # the MFMA-bound dW_0 GEMM and the dense all-reduce on the main stream
+        # row-gradient exchange + lazy sparse optimizer + next lookup (xGMI / HBM bound) on the side stream,
+        # underneath the MFMA-bound dW GEMMs and the dense all-reduce on the main stream
         with _Side():
             with self._timed("grad_exchange"):
                 f32 = dict(dtype=torch.float32, device=self.device)
@@ -283,9 +320,26 @@ class ShardedDeepFMLayer(DeepFMLayer):
                     k.sparse_adam_rows(groups, recv_g, 1, self.fm.embedding, st["m"], st["v"], t, lr, partials=pp)
                     k.sparse_adam_rows(groups, recv_g1, 1, self.fm.embedding_one, st["m1"], st["v1"], t, lr,
                                        partials=pp1)
-        with self._timed("mlp_bwd_dw0"):
-            finish_dw0()
-            self._fold_backward()
+            # The next batch's lookup needs nothing of this step but the table rows the sparse optimizer just
+            # wrote: it goes on the same side stream right behind it — ids / rows exchange over xGMI while the
+            # main stream runs the dW GEMMs, the dense all-reduce and the dense Adam.
+            if self._pending is not None and next_sparse_inputs is not None:
+                with self._timed("next_lookup"):
+                    nids = self._pending["ids"]
+                    self._next_lookup = (nids, self._lookup(nids))
+        if mode == "serial":
+            cur.wait_stream(self._side)                          # exchange chain first, GEMMs after it
+        if mode == "partition":
+            self._gemm_stream.wait_stream(cur)
+            with torch.cuda.stream(self._gemm_stream):
+                with self._timed("mlp_bwd_dw0"):
+                    finish_dw0(num_cus=self._gemm_cus)
+                    self._fold_backward()
+            cur.wait_stream(self._gemm_stream)
+        else:
+            with self._timed("mlp_bwd_dw0"):
+                finish_dw0()
+                self._fold_backward()
         self.comm.all_reduce_sum(self.dense.grad)                # one bucket: dense grads + loss
         loss = loss_slot.clone()
         loss_slot.zero_()                                         # not a parameter: keep Adam off it

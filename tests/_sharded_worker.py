@@ -37,9 +37,15 @@ def main():
     pr = make_deepfm_problem(B=c["B"] * world, N=c["N"], D=c["D"], fc=c["fc"], seed=c["seed"],
                              pad_frac=c["pad_frac"], tables=tables)
     so = pr["slot_offsets"]
+    torch.manual_seed(1000 + rank)          # every rank draws a DIFFERENT random init ...
     m = ShardedDeepFMLayer(pr["N"], c["D"], 13, 26, list(c["fc"]), device=dev,
                            slot_offset=None if so is None else torch.as_tensor(so),
                            comm=Comm(), kernels=kernels)
+    # ... and the constructor must have replaced the dense replica by rank 0's (data-parallel invariant)
+    mine = m.dense.data.detach().cpu().clone()
+    ref0 = mine.clone()
+    dist.broadcast(ref0, src=0)
+    assert torch.equal(mine, ref0), "dense parameters differ across ranks after construction"
     m.set_dict(deepfm_state_dict(pr["params"], len(c["fc"]) + 1))
     rng = np.random.default_rng(c["seed"] + 1)
     out = {}

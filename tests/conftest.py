@@ -24,6 +24,15 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _seed_everything():
+    """Models draw their initial weights from torch's global generator: pin it so that every test sees the same
+    parameters on every run (a parity failure must be reproducible, not a draw of the initialisation)."""
+    import torch
+    torch.manual_seed(20250404)
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     """ctypes handle of oracle/_build/liboracle.so (built on demand with gcc)."""

@@ -149,8 +149,8 @@ def mlp_forward(x, weights, biases, ws):
     return x, acts + [x]
 
 
-def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False):
-    if defer_first:
+def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=False):
+    if defer_first or defer_all:
         return mlp_backward(dy, acts, weights, dws, dbs, ws), (lambda: None)
     n = len(weights)
     g = dy

@@ -95,7 +95,9 @@ def test_v2_train_steps_vs_oracle(engine_lib, stacked, D, B):
     sd = m.state_dict()
     for k in ("embedding.weight", "dense_emb.weight", X.P + "cross_layers.1.weight", "DNN_.linear_0.weight",
               "fc.weight", "fc.bias"):
-        np.testing.assert_allclose(N_(sd[k]), tr.p[k], rtol=1e-3, atol=3e-4, err_msg=k)
+        # three Adam steps at lr 1e-2: an entry whose gradient is ~eps-sized moves by lr * g/(|g|+eps), which
+        # amplifies fp32 summation-order noise in g to <= ~1e-4 per step; a wrong update is off by >= lr
+        np.testing.assert_allclose(N_(sd[k]), tr.p[k], rtol=1e-3, atol=1e-3, err_msg=k)
 
 
 def test_mix_gradients_golden(engine_lib):
