@@ -116,6 +116,7 @@ class ShardedDeepFMLayer(DeepFMLayer):
         self.tail_mode = os.environ.get("REC_SHARD_TAIL", "overlap")
         self.side_cus = int(os.environ.get("REC_SHARD_SIDE_CUS", "64"))
         self._gemm_stream, self._gemm_cus = None, 0
+        self._xbuf, self._pinned = {}, [None, None]
         self._next_lookup = None
 
     # -- parameters: global <-> shard --------------------------------------------------------------
@@ -161,7 +162,9 @@ class ShardedDeepFMLayer(DeepFMLayer):
         pend = dict(ids=ids, route=route, host=None, ev=None)
         if self.device.type == "cuda" and not self.comm.staged:
             recv_dev = self.comm.exchange_counts_device(route.send_counts[:G])
-            host = torch.empty(2, G, dtype=torch.int64, pin_memory=True)
+            host = self._pinned[self._route_flip]           # persistent pinned staging, one per route buffer
+            if host is None or host.shape[1] != G:
+                host = self._pinned[self._route_flip] = torch.empty(2, G, dtype=torch.int64, pin_memory=True)
             host[0].copy_(route.send_counts[:G], non_blocking=True)
             host[1].copy_(recv_dev, non_blocking=True)
             ev = torch.cuda.Event()
@@ -188,12 +191,13 @@ class ShardedDeepFMLayer(DeepFMLayer):
             L.send_splits = [int(x) for x in route.send_counts[:G].tolist()]       # host sync (G ints)
             L.recv_splits = self.comm.exchange_counts(L.send_splits)
         L.n_send, L.n_recv = sum(L.send_splits), sum(L.recv_splits)
-        i64 = dict(dtype=torch.int64, device=self.device)
         f32 = dict(dtype=torch.float32, device=self.device)
-        L.recv_rows = torch.empty(L.n_recv, **i64)
+        # exchange buffers are persistent (grown with slack, never allocated per step): no allocator traffic and
+        # no cross-stream block recycling on the exchange path
+        L.recv_rows = self._fit("recv_rows%d" % (self._reply_flip ^ 1), L.n_recv, 0, torch.int64)
         self.comm.all_to_all(L.recv_rows, route.send_local_row[: L.n_send], L.recv_splits, L.send_splits)
-        g_rows = torch.empty(L.n_recv, D, **f32)
-        g_w1 = torch.empty(L.n_recv, 1, **f32)
+        g_rows = self._fit("g_rows", L.n_recv, D)
+        g_w1 = self._fit("g_w1", L.n_recv, 1)
         if L.n_recv:
             k.emb_gather(L.recv_rows, self.fm.embedding, None, self.status, out=g_rows)
             k.emb_gather(L.recv_rows, self.fm.embedding_one, None, self.status, out=g_w1)
@@ -303,13 +307,13 @@ class ShardedDeepFMLayer(DeepFMLayer):
         with _Side():
             with self._timed("grad_exchange"):
                 f32 = dict(dtype=torch.float32, device=self.device)
-                send_g = torch.empty(L.n_send, D, **f32)
-                send_g1 = torch.empty(L.n_send, 1, **f32)
+                send_g = self._fit("send_g", L.n_send, D)
+                send_g1 = self._fit("send_g1", L.n_send, 1)
                 if L.n_send:
                     k.emb_gather(L.route.send_pos[: L.n_send], row_grad, None, self.status, out=send_g)
                     k.emb_gather(L.route.send_sample[: L.n_send], dz, None, self.status, out=send_g1)
-                recv_g = torch.empty(max(L.n_recv, 1), D, **f32)
-                recv_g1 = torch.empty(max(L.n_recv, 1), 1, **f32)
+                recv_g = self._fit("recv_g", max(L.n_recv, 1), D)
+                recv_g1 = self._fit("recv_g1", max(L.n_recv, 1), 1)
                 self.comm.all_to_all(recv_g[: L.n_recv], send_g, L.recv_splits, L.send_splits)
                 self.comm.all_to_all(recv_g1[: L.n_recv], send_g1, L.recv_splits, L.send_splits)
             with self._timed("sparse_adam"):
@@ -347,6 +351,14 @@ class ShardedDeepFMLayer(DeepFMLayer):
         if on_gpu:
             cur.wait_stream(self._side)
         return loss, pred
+
+    def _fit(self, name, rows, cols, dtype=torch.float32):
+        """Persistent exchange buffer `name`, first `rows` rows (cols = 0: 1-D)."""
+        b = self._xbuf.get(name)
+        if b is None or b.shape[0] < rows:
+            cap = rows + rows // 8 + 1
+            b = self._xbuf[name] = torch.empty((cap, cols) if cols else (cap,), dtype=dtype, device=self.device)
+        return b[:rows]
 
     def _buf(self, name, shape):
         b = getattr(self, "_b_" + name, None)
