@@ -46,3 +46,58 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "liboracle" not in txt, f
+
+
+def test_host_planning_queries(engine_lib):
+    """Pure host logic behind the boundary: split-K planning for a CU budget, partial-sum buffer sizing."""
+    import ctypes as C
+    from paddlerec_amd import _lib
+    sp = C.c_int32(0)
+    # dW of the 400x400 MLP layers at batch 65536: 4 x 5 tiles of 128x80, 5 blocks per CU
+    d = _lib.GemmDesc(400, 400, 65536, 400, 400, 400, 1, 0, 0, 0)
+    assert engine_lib.rec_gemm_plan_splits(C.byref(d), 0, C.byref(sp)) == 0
+    full = sp.value
+    assert full == 64 and full % 8 == 0                      # 256 CUs * 5 / 20 tiles = one resident round
+    assert engine_lib.rec_gemm_plan_splits(C.byref(d), 192, C.byref(sp)) == 0
+    assert sp.value == 48                                    # 192 CUs * 5 / 20
+    assert engine_lib.rec_gemm_plan_splits(C.byref(d), 8, C.byref(sp)) == 0 and sp.value == 2
+    # forward GEMM [65536 x 400] = 2560 tiles: fills the chip without splitting K
+    f = _lib.GemmDesc(65536, 400, 432, 432, 400, 400, 0, 0, 0, 0)
+    assert engine_lib.rec_gemm_plan_splits(C.byref(f), 0, C.byref(sp)) == 0 and sp.value == 1
+    # an explicit split_k in the descriptor is ignored by the query
+    d.split_k = 7
+    assert engine_lib.rec_gemm_plan_splits(C.byref(d), 0, C.byref(sp)) == 0 and sp.value == full
+    assert engine_lib.rec_gemm_plan_splits(C.byref(d), 100000, C.byref(sp)) == -1
+    bad = _lib.GemmDesc(4, 0, 4, 4, 4, 4, 0, 0, 0, 0)
+    assert engine_lib.rec_gemm_plan_splits(C.byref(bad), 0, C.byref(sp)) == -1
+    n = C.c_size_t(0)
+    assert engine_lib.rec_segment_partials_bytes(65536 * 26, 16, C.byref(n)) == 0
+    assert n.value == (65536 * 26 // 64) * 2 * 16 * 4          # [tiles, 2, D] floats, REC_SEG_TILE = 64
+    assert engine_lib.rec_segment_partials_bytes(65, 1, C.byref(n)) == 0 and n.value == 2 * 2 * 4
+    assert engine_lib.rec_segment_partials_bytes(-1, 16, C.byref(n)) == -1
+
+
+def test_more_argument_validation_without_gpu(engine_lib):
+    """Every entry point rejects null pointers / bad sizes before it touches the device."""
+    import ctypes as C
+    from paddlerec_amd import _lib
+    L = engine_lib
+    gl = _lib.GradLayout(1, 0, 0, None)
+    h = _lib.AdamHyper(1e-3, 0.9, 0.999, 1e-8, 1)
+    assert L.rec_segment_partials(10, 16, None, None, None, None, C.byref(gl), None, None) == -1
+    assert L.rec_segment_partials(0, 0, None, None, None, None, None, None, None) == -1
+    assert L.rec_sparse_adam_rows(10, 16, 8, 0, None, None, None, None, None, None, None, None, None, None,
+                                  C.byref(h), None) == -1              # row_stride < emb_dim
+    assert b"bad sizes" in L.rec_last_error()
+    assert L.rec_sparse_sgd_rows(10, 16, 16, None, None, None, None, None, None, None, 0.1, None) == -1
+    assert L.rec_stream_spin(-1, None) == -1
+    out = C.c_void_p()
+    assert L.rec_stream_create_cu_range(5, 5, C.byref(out)) == -1
+    assert L.rec_stream_create_cu_range(0, 64, None) == -1
+    assert L.rec_stream_destroy(None) == 0
+    d = _lib.GemmDesc(4, 4, 4, 4, 4, 4, 0, 0, 99, 0)
+    assert L.rec_gemm_f32(C.byref(d), None, None, None, None, None, 0, None) == -1
+    assert b"epilogue" in L.rec_last_error()
+    nl = C.c_int64(0)
+    assert L.rec_count_lines(None, 10, 1, C.byref(nl)) == -1
+    assert L.rec_count_lines(b"a\nb\nc", 5, 4, C.byref(nl)) == 0 and nl.value == 3
