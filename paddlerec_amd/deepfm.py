@@ -63,6 +63,24 @@ class _Timed:
             self.timers.setdefault(self.name + "@host", []).append(time.perf_counter() - self.h0)
 
 
+class _OnSide:
+    """`with _OnSide(side, cur):` — issue on the side stream, ordered after everything issued so far on `cur`.
+    side None (a CPU device: orchestration tests with an injected operator backend) makes it a no-op."""
+
+    def __init__(self, side, cur):
+        self.side, self.cur = side, cur
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(self.cur)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.side is not None:
+            self.ctx.__exit__(*a)
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -234,9 +252,11 @@ class DeepFMLayer:
         B, S = ids.shape
         self._ensure_sparse_state()
         self.step_count += 1
-        cur = torch.cuda.current_stream()
-        if self._side is None:
+        on_gpu = self.device.type == "cuda"
+        cur = torch.cuda.current_stream() if on_gpu else None
+        if on_gpu and self._side is None:
             self._side = self.k.concurrent_stream(self.device)   # verified to overlap with the main stream
+        side = self._side if on_gpu else None
         groups = getattr(self, "_groups", None)          # persistent: the wait_stream below orders reuse
         if groups is None or groups.n != B * S:
             groups = self._groups = self.k.IdGroups(B * S, self.device)
@@ -244,8 +264,7 @@ class DeepFMLayer:
             y1, y2, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
         # SelectedRows merge keys only depend on ids: sort them on a side stream, hidden behind the
         # MFMA-bound GEMMs (started after the HBM-bound lookup so the two do not fight for bandwidth)
-        self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side):
+        with _OnSide(side, cur):
             self.k.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
                              self.fm.slot_offset, self.status, groups)
         mlp_w, mlp_dw = self._mlp_weights()
@@ -268,8 +287,7 @@ class DeepFMLayer:
         # dW_0 GEMM; it needs row_grad / dz and the merge keys (sorted on that same stream earlier).
         t = self.step_count
         st = self.sparse_state
-        self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side):
+        with _OnSide(side, cur):
             with self._timed("sparse_adam"):
                 upd = self.k.sparse_adam_rows if self.lazy_mode else self.k.adam_rows_all
                 # hot rows (Zipf ids): long duplicate runs are pre-reduced per 64-position tile
@@ -283,7 +301,8 @@ class DeepFMLayer:
         if allreduce is not None:
             allreduce(self.dense.grad)
         self.k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
-        cur.wait_stream(self._side)
+        if on_gpu:
+            cur.wait_stream(self._side)
         return loss, pred
 
     def _timed(self, name):
@@ -299,14 +318,20 @@ class DeepFMLayer:
 class DygraphModel:
     """deepfm/dygraph_model.py:23-98 — same method names; tensors are torch device tensors."""
 
-    def create_model(self, config, device="cuda"):
+    def create_model(self, config, device="cuda", kernels=None):
         return DeepFMLayer(config.get("hyper_parameters.sparse_feature_number"),
                            config.get("hyper_parameters.sparse_feature_dim"),
                            config.get("hyper_parameters.dense_input_dim"),
                            config.get("hyper_parameters.sparse_inputs_slots") - 1,
-                           config.get("hyper_parameters.fc_sizes"), device=device)
+                           config.get("hyper_parameters.fc_sizes"), device=device, kernels=kernels)
 
     def create_feeds(self, batch_data, config, device="cuda"):
+        """batch_data: the reference's 28 arrays [label, C1..C26, dense] (dygraph_model.py:41-51) or the
+        (label [B,1], ids [B,26], dense [B,13]) device tensors of paddlerec_amd.reader (no per-slot split)."""
+        if len(batch_data) == 3 and torch.is_tensor(batch_data[1]) and batch_data[1].dim() == 2 \
+                and batch_data[1].shape[1] > 1:
+            label, ids, dense = batch_data
+            return label.to(device), ids.to(device), dense.to(device)
         dn = config.get("hyper_parameters.dense_input_dim")
         sparse = [torch.as_tensor(b).to(torch.int64).reshape(-1, 1).to(device) for b in batch_data[:-1]]
         dense = torch.as_tensor(batch_data[-1]).to(torch.float32).reshape(-1, dn).to(device)
@@ -327,8 +352,8 @@ class DygraphModel:
         label, sparse, dense = self.create_feeds(batch_data, config, dy_model.device)
         pred = dy_model.forward(sparse, dense)
         if metrics_list:
-            ops.auc_histogram(pred.contiguous(), label.contiguous(), metrics_list[0][0],
-                              metrics_list[0][1], NUM_THRESHOLDS)
+            dy_model.k.auc_histogram(pred.contiguous(), label.contiguous(), metrics_list[0][0],
+                                     metrics_list[0][1], NUM_THRESHOLDS)
         return metrics_list, None
 
 

@@ -93,7 +93,7 @@ def sigmoid_logloss(y1, y2, y_dnn, label, ws, eps=1e-4, want_dz=True, out=None, 
     den = np.float32(mean_over if mean_over else B)
     cost = -t * np.log(p + np.float32(eps)) - (1 - t) * np.log(1 - p + np.float32(eps))
     dz = ((-t / (p + np.float32(eps)) + (1 - t) / (1 - p + np.float32(eps))) / den) * (p * (1 - p))
-    pred, dzo, loss = out
+    pred, dzo, loss = out if out is not None else (torch.empty(B, 1), torch.empty(B, 1), torch.empty(1))
     pred.copy_(torch.from_numpy(p))
     dzo.copy_(torch.from_numpy(dz.astype(np.float32)))
     loss.copy_(torch.tensor([cost.sum(dtype=np.float32) / den]))

@@ -1,0 +1,192 @@
+"""Train / infer loops (paddlerec_amd/trainer.py; reference: tools/trainer.py:40-223, tools/infer.py) on
+BASELINE configs[0]: DeepFM, the reference's own 80-line Criteo sample, small batches.
+
+Host-logic tests run here on the CPU with the oracle-backed operator backend (tests/cpu_kernels.py) injected
+through `kernels=` — config handling, the reader, the epoch loop, AUC accumulation, checkpoints per epoch and
+the per-epoch infer loop are exactly the product code; the `-m gpu` test runs the same thing on the HIP kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from helpers import OracleTrainer
+
+YAML = """
+runner:
+  train_data_dir: "data/train"
+  train_reader_path: "criteo_reader" # importlib format
+  use_gpu: False
+  use_auc: True
+  train_batch_size: 16
+  epochs: 2
+  print_interval: 2
+  model_save_path: "{out}"
+  test_data_dir: "data/train"
+  infer_batch_size: 20
+  infer_load_path: "{out}"
+  infer_start_epoch: 0
+  infer_end_epoch: 2
+hyper_parameters:
+  optimizer:
+    class: Adam
+    learning_rate: 0.01
+    strategy: async
+  sparse_inputs_slots: 27
+  sparse_feature_number: 1000001
+  sparse_feature_dim: 9
+  dense_input_dim: 13
+  fc_sizes: [16, 8]
+  distributed_embedding: 0
+"""
+
+
+def _sample_lines(n=80, seed=7):
+    """Slot-text lines in the format of models/rank/deepfm/data/sample_data/train/sample_train.txt (the golden
+    fixture holds its first 6 lines; the other 74 are synthetic: a small id range so that rows repeat across
+    batches and Adam's moments matter, a few missing slots -> padding id 0, criteo_reader.py:80-91)."""
+    rng = np.random.default_rng(seed)
+    lines = open(os.path.join(GOLDEN, "criteo_slot_sample.txt")).read().strip().split("\n")
+    while len(lines) < n:
+        parts = ["click:%d" % int(rng.random() < 0.3)]
+        parts += ["dense_feature:%s" % repr(round(float(rng.random()), 6)) for _ in range(13)]
+        for slot in range(1, 27):
+            if rng.random() < 0.04:
+                continue
+            parts.append("%d:%d" % (slot, int(rng.integers(1, 400)) + 1000 * slot))
+        lines.append(" ".join(parts))
+    return lines
+
+
+@pytest.fixture()
+def workdir(tmp_path):
+    d = tmp_path / "models" / "rank" / "deepfm"
+    (d / "data" / "train").mkdir(parents=True)
+    (d / "data" / "train" / "sample_train.txt").write_text("\n".join(_sample_lines()) + "\n")
+    (d / "config.yaml").write_text(YAML.format(out=str(tmp_path / "output_model_deepfm")))
+    return d
+
+
+def test_load_yaml_flattens_and_overrides(workdir):
+    from paddlerec_amd import trainer
+    cfg = trainer.load_yaml(str(workdir / "config.yaml"),
+                            ["runner.epochs=5", "runner.use_auc=false", "hyper_parameters.optimizer.learning_rate=0.5",
+                             "runner.model_save_path=elsewhere"])
+    assert cfg["runner.train_batch_size"] == 16 and cfg["hyper_parameters.fc_sizes"] == [16, 8]
+    assert cfg["hyper_parameters.optimizer.class"] == "Adam"
+    assert cfg["runner.epochs"] == 5 and cfg["runner.use_auc"] is False          # coerced to the old value's type
+    assert cfg["hyper_parameters.optimizer.learning_rate"] == 0.5 and cfg["runner.model_save_path"] == "elsewhere"
+    assert cfg["config_abs_dir"] == str(workdir)
+    assert trainer.guess_model(str(workdir / "config.yaml")) == "deepfm"
+    with pytest.raises(ValueError):
+        trainer.create_data_loader({"runner.train_data_dir": "nope", "config_abs_dir": str(workdir),
+                                    "runner.train_batch_size": 2}, "deepfm", "cpu")
+
+
+def _oracle_params(sd, n_mlp):
+    p = {"W": sd["fm.embedding.weight"], "W1": sd["fm.embedding_one.weight"], "dense_w": sd["fm.dense_w"],
+         "dense_w_one": sd["fm.dense_w_one"], "mlp_w": [sd["dnn.linear_%d.weight" % i] for i in range(n_mlp)],
+         "mlp_b": [sd["dnn.linear_%d.bias" % i] for i in range(n_mlp)]}
+    return p
+
+
+def _hist_auc(R, preds, labels):
+    pos, neg = np.zeros(4096, np.int64), np.zeros(4096, np.int64)
+    for p, t in zip(preds, labels):
+        dp, dn = R.auc_histogram(p, t)
+        pos += dp
+        neg += dn
+    return R.auc_from_buckets(pos, neg)
+
+
+def _run(workdir, device, kernels, tol):
+    """tol = (loss rtol, AUC atol, max |param diff|, mean |param diff|)"""
+    l_rtol, auc_atol, p_max, p_mean = tol
+    from oracle import deepfm_ref as R
+    from paddlerec_amd import trainer
+    from paddlerec_amd.deepfm import DygraphModel
+    cfg = trainer.load_yaml(str(workdir / "config.yaml"))
+    # the same initial parameters train() will draw (runner.seed default 12345, trainer.py:83-84)
+    torch.manual_seed(12345)
+    m0 = DygraphModel().create_model(cfg, device, **({"kernels": kernels} if kernels else {}))
+    sd0 = {k: v.detach().cpu().numpy().copy() for k, v in m0.state_dict().items()}
+    del m0
+    summaries, model = trainer.train(cfg, "deepfm", device, kernels)
+    # oracle: the same 2 x 5 batches of 16 in file order (drop_last: 80 = 5 * 16)
+    parsed = [R.parse_slot_line(ln) for ln in _sample_lines()]
+    lab = np.asarray([a for a, _, _ in parsed], np.int64).reshape(-1, 1)
+    ids = np.stack([b for _, b, _ in parsed])
+    dense = np.stack([c for _, _, c in parsed])
+    tr = OracleTrainer(_oracle_params(sd0, 3), lr=0.01)
+    snaps, aucs, losses = [], [], []
+    for _ in range(2):
+        preds = []
+        for lo in range(0, 80, 16):
+            loss, pred = tr.train_step(ids[lo:lo + 16], dense[lo:lo + 16], lab[lo:lo + 16])
+            preds.append(pred)
+        losses.append(float(loss))
+        aucs.append(_hist_auc(R, preds, [lab[lo:lo + 16] for lo in range(0, 80, 16)]))
+        snaps.append({k: (v.copy() if not isinstance(v, list) else [x.copy() for x in v]) for k, v in tr.p.items()})
+    assert [s["epoch"] for s in summaries] == [0, 1] and all(s["batches"] == 5 and s["samples"] == 80 for s in summaries)
+    for s, ol, oa in zip(summaries, losses, aucs):
+        np.testing.assert_allclose(s["loss"], ol, rtol=l_rtol)
+        np.testing.assert_allclose(s["auc"], oa, rtol=1e-9, atol=auc_atol)   # integer buckets: equal unless a pred sits on an edge
+        assert os.path.exists(os.path.join(s["model_dir"], "rec.pdparams"))
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    touched = np.unique(ids)
+    for got, want in ((sd["fm.embedding.weight"][touched], tr.p["W"][touched]),
+                      (sd["dnn.linear_0.weight"], tr.p["mlp_w"][0])):
+        d = np.abs(got - want)          # 10 Adam steps at lr 1e-2: parameters moved by up to 0.1
+        assert d.max() <= p_max and d.mean() <= p_mean, (d.max(), d.mean())
+    untouched = np.setdiff1d(np.arange(0, 5000), touched)
+    assert np.array_equal(sd["fm.embedding.weight"][untouched], sd0["fm.embedding.weight"][untouched])   # lazy rows
+    # infer loop: checkpoint of each epoch -> AUC over the test set in batches of 20
+    res = trainer.infer(cfg, "deepfm", device, kernels)
+    assert [r["epoch"] for r in res] == [0, 1] and all(r["batches"] == 4 and r["samples"] == 80 for r in res)
+    for r, snap in zip(res, snaps):
+        preds = [R.deepfm_forward(ids[lo:lo + 20], dense[lo:lo + 20], snap)[0] for lo in range(0, 80, 20)]
+        np.testing.assert_allclose(r["auc"], _hist_auc(R, preds, [lab[lo:lo + 20] for lo in range(0, 80, 20)]),
+                                   rtol=1e-9, atol=auc_atol)
+    # resume: model_init_path + last_epoch continue from the epoch-0 checkpoint and reproduce epoch 1
+    cfg2 = dict(cfg)
+    cfg2["runner.model_init_path"] = summaries[0]["model_dir"]
+    cfg2["last_epoch"] = 0
+    cfg2["runner.model_save_path"] = str(workdir / "resumed")
+    s2, _ = trainer.train(cfg2, "deepfm", device, kernels)
+    assert [s["epoch"] for s in s2] == [1]
+    np.testing.assert_allclose(s2[0]["loss"], summaries[1]["loss"], rtol=1e-6)
+    np.testing.assert_allclose(s2[0]["auc"], summaries[1]["auc"], rtol=1e-9)
+
+
+def test_train_infer_resume_cpu_backend(workdir):
+    import cpu_kernels
+    _run(workdir, "cpu", cpu_kernels, (2e-5, 1e-12, 1e-4, 1e-6))
+
+
+@pytest.mark.gpu
+def test_train_infer_resume_gpu(workdir, engine_lib):
+    # fp32 kernels vs the NumPy oracle over 10 optimizer steps: a prediction next to a bucket edge may move one
+    # AUC bucket, an entry with an ~eps-sized gradient may take a different Adam step (see test_dcn_v2_gpu.py)
+    _run(workdir, "cuda", None, (1e-3, 5e-3, 2e-2, 1e-4))
+
+
+REF_YAML = "/root/reference/models/rank/deepfm/config.yaml"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_YAML), reason="reference tree not mounted (only in the build container)")
+def test_reference_yaml_and_sample_data_run_unchanged(tmp_path):
+    """BASELINE configs[0]: the reference's own models/rank/deepfm/config.yaml (bs 2, 80-line sample, D 9,
+    fc 512-256-128-32) drives the loop as is — only the output directory is redirected."""
+    import cpu_kernels
+    from paddlerec_amd import trainer
+    cfg = trainer.load_yaml(REF_YAML, ["runner.epochs=1", "runner.model_save_path=" + str(tmp_path / "out"),
+                                       "runner.infer_load_path=" + str(tmp_path / "out"),
+                                       "runner.infer_end_epoch=1"])
+    assert cfg["runner.train_batch_size"] == 2 and cfg["hyper_parameters.sparse_feature_dim"] == 9
+    s, model = trainer.train(cfg, trainer.guess_model(REF_YAML), "cpu", cpu_kernels)
+    assert len(s) == 1 and s[0]["samples"] == 80 and s[0]["batches"] == 40
+    assert np.isfinite(s[0]["loss"]) and 0.0 <= s[0]["auc"] <= 1.0
+    assert int(model.status.item()) == 0                       # no id of the sample file is out of range
+    r = trainer.infer(cfg, "deepfm", "cpu", cpu_kernels)
+    assert r[0]["samples"] == 80 and r[0]["batches"] == 16 and 0.0 <= r[0]["auc"] <= 1.0
