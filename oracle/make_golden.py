@@ -6,7 +6,7 @@ fixtures.  `paddle` resolves to oracle/paddle_shim (torch-CPU stand-in, SURVEY.m
 what is pinned is the reference's own graph code — op order, shapes, padding handling, the DIN
 duplicate-sublayer quirk — not Paddle's kernels (those are [EXT], not installable here).
 
-    python oracle/make_golden.py            # rewrites tests/golden/*.npz deterministically
+    python oracle/make_golden.py [name ...]  # rewrites tests/golden/*.npz (all, or the named ones) deterministically
 """
 import importlib.util
 import os
@@ -75,6 +75,40 @@ def golden_deepfm(D, seed):
     g["n_mlp"] = np.int64(len(lin))
     np.savez_compressed(os.path.join(OUT, f"deepfm_D{D}.npz"), **g)
     print("deepfm D=%d loss=%.6f" % (D, float(loss)))
+
+
+def golden_fm(D, seed):
+    """models/rank/fm/net.py:20-124 + fm/dygraph_model.py:53-58 (loss)."""
+    import paddle  # the shim
+    net = load_ref_module("models/rank/fm/net.py", "ref_fm_net")
+    rng = np.random.default_rng(seed)
+    N, S, Dn, B = 1001, 26, 13, 12
+    torch.manual_seed(seed)
+    model = net.FMLayer(N, D, Dn, S)
+    with torch.no_grad():
+        # the Constant(1.0) dense weights saturate the sigmoid on [0,1) dense inputs (y2 ~ 200: every gradient is
+        # exactly 0) and, being all equal, would hide a swapped or dropped weight; Constant(0.0) bias likewise
+        model.fm.dense_w_one.copy_(torch.as_tensor(0.2 * (1.0 + 0.5 * rng.standard_normal(Dn)).astype(np.float32)))
+        model.fm.dense_w.copy_(torch.as_tensor(0.05 * (1.0 + 0.5 * rng.standard_normal((1, Dn, D))).astype(np.float32)))
+        model.bias.copy_(torch.as_tensor(np.asarray([0.37], np.float32)))
+    ids = make_ids(rng, B, S, N)
+    dense = rng.random((B, Dn), dtype=np.float32)
+    label = (rng.random((B, 1)) < 0.3).astype(np.int64)
+    sparse_inputs = [paddle.to_tensor(ids[:, s:s + 1]) for s in range(S)]
+    pred = model.forward(sparse_inputs, paddle.to_tensor(dense))
+    cost = paddle.nn.functional.log_loss(input=pred, label=paddle.cast(paddle.to_tensor(label), dtype="float32"))
+    loss = paddle.mean(x=cost)
+    y1, y2 = model.fm.forward(sparse_inputs, paddle.to_tensor(dense))
+    loss.backward()
+    g = dict(ids=ids, dense=dense, label=label, D=np.int64(D),
+             W=npy(model.fm.embedding.weight), W1=npy(model.fm.embedding_one.weight),
+             dense_w=npy(model.fm.dense_w), dense_w_one=npy(model.fm.dense_w_one), bias=npy(model.bias),
+             pred=npy(pred), loss=npy(loss), y1=npy(y1), y2=npy(y2),
+             gW=npy(model.fm.embedding.weight.grad), gW1=npy(model.fm.embedding_one.weight.grad),
+             g_dense_w=npy(model.fm.dense_w.grad), g_dense_w_one=npy(model.fm.dense_w_one.grad),
+             g_bias=npy(model.bias.grad))
+    np.savez_compressed(os.path.join(OUT, f"fm_D{D}.npz"), **g)
+    print("fm D=%d loss=%.6f" % (D, float(loss.detach())))
 
 
 def golden_dcn_v2(mix, seed):
@@ -157,8 +191,8 @@ def golden_din(seed):
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    golden_deepfm(9, 20250404)
-    golden_deepfm(16, 20250405)
-    golden_dcn_v2(False, 20250406)
-    golden_dcn_v2(True, 20250407)
-    golden_din(20250408)
+    jobs = {"deepfm_D9": lambda: golden_deepfm(9, 20250404), "deepfm_D16": lambda: golden_deepfm(16, 20250405),
+            "dcn_v2_v2": lambda: golden_dcn_v2(False, 20250406), "dcn_v2_mix": lambda: golden_dcn_v2(True, 20250407),
+            "din": lambda: golden_din(20250408), "fm_D9": lambda: golden_fm(9, 20250409)}
+    for name in (sys.argv[1:] or list(jobs)):      # optional: only the named fixtures
+        jobs[name]()

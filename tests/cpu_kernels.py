@@ -100,6 +100,11 @@ def sigmoid_logloss(y1, y2, y_dnn, label, ws, eps=1e-4, want_dz=True, out=None, 
     return pred, dzo, loss
 
 
+def colsum(G, ws, out=None):
+    r = torch.from_numpy(_n(G).sum(axis=0, dtype=np.float32))
+    return r if out is None else out.copy_(r.reshape(out.shape))
+
+
 def adam_dense(p, m, v, g, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
     R.adam_update(p.numpy(), m.numpy(), v.numpy(), g.numpy(), step, lr, beta1, beta2, eps)
 
