@@ -111,6 +111,39 @@ def golden_fm(D, seed):
     print("fm D=%d loss=%.6f" % (D, float(loss.detach())))
 
 
+def golden_wide_deep(D, seed):
+    """models/rank/wide_deep/net.py:20-104 + wide_deep/dygraph_model.py:54-59 (loss)."""
+    import paddle  # the shim
+    net = load_ref_module("models/rank/wide_deep/net.py", "ref_wide_deep_net")
+    rng = np.random.default_rng(seed)
+    N, S, Dn, B, fc = 1001, 26, 13, 12, [32, 16]
+    torch.manual_seed(seed)
+    model = net.WideDeepLayer(N, D, Dn, S, fc)
+    with torch.no_grad():       # Uniform(-1,1) rows x 26 slots would saturate a 2-layer toy MLP; biases away from 0
+        model.embedding.weight.mul_(0.2)
+        for m in [model.wide_part] + [l for l in model._mlp_layers if hasattr(l, "weight")]:
+            m.bias.copy_(torch.as_tensor((0.05 * rng.standard_normal(tuple(m.bias.shape))).astype(np.float32)))
+    ids = make_ids(rng, B, S, N)
+    dense = rng.random((B, Dn), dtype=np.float32)
+    label = (rng.random((B, 1)) < 0.3).astype(np.int64)
+    sparse_inputs = [paddle.to_tensor(ids[:, s:s + 1]) for s in range(S)]
+    pred = model.forward(sparse_inputs, paddle.to_tensor(dense))
+    cost = paddle.nn.functional.log_loss(input=pred, label=paddle.cast(paddle.to_tensor(label), dtype="float32"))
+    loss = paddle.mean(x=cost)
+    loss.backward()
+    g = dict(ids=ids, dense=dense, label=label, D=np.int64(D), W=npy(model.embedding.weight),
+             wide_w=npy(model.wide_part.weight), wide_b=npy(model.wide_part.bias), pred=npy(pred), loss=npy(loss),
+             gW=npy(model.embedding.weight.grad), g_wide_w=npy(model.wide_part.weight.grad),
+             g_wide_b=npy(model.wide_part.bias.grad))
+    lin = [m for m in model._mlp_layers if hasattr(m, "weight")]
+    for i, l in enumerate(lin):
+        g[f"mlp_w{i}"], g[f"mlp_b{i}"] = npy(l.weight), npy(l.bias)
+        g[f"g_mlp_w{i}"], g[f"g_mlp_b{i}"] = npy(l.weight.grad), npy(l.bias.grad)
+    g["n_mlp"] = np.int64(len(lin))
+    np.savez_compressed(os.path.join(OUT, f"wide_deep_D{D}.npz"), **g)
+    print("wide_deep D=%d loss=%.6f" % (D, float(loss.detach())))
+
+
 def golden_dcn_v2(mix, seed):
     """models/rank/dcn_v2/net.py:20-320 in eval() mode (Dropout off — Appendix B-10)."""
     import paddle
@@ -193,6 +226,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     jobs = {"deepfm_D9": lambda: golden_deepfm(9, 20250404), "deepfm_D16": lambda: golden_deepfm(16, 20250405),
             "dcn_v2_v2": lambda: golden_dcn_v2(False, 20250406), "dcn_v2_mix": lambda: golden_dcn_v2(True, 20250407),
-            "din": lambda: golden_din(20250408), "fm_D9": lambda: golden_fm(9, 20250409)}
+            "din": lambda: golden_din(20250408), "fm_D9": lambda: golden_fm(9, 20250409),
+            "wide_deep_D9": lambda: golden_wide_deep(9, 20250410)}
     for name in (sys.argv[1:] or list(jobs)):      # optional: only the named fixtures
         jobs[name]()

@@ -44,3 +44,13 @@ class XavierNormal:
     def __call__(self, p):
         fi, fo = _fans(p)
         p.normal_(0.0, _m.sqrt(2.0 / (fi + fo)))
+
+
+class Uniform:
+    """paddle.nn.initializer.Uniform(low=-1.0, high=1.0) [EXT defaults]."""
+
+    def __init__(self, low=-1.0, high=1.0):
+        self.low, self.high = low, high
+
+    def __call__(self, p):
+        p.uniform_(self.low, self.high)

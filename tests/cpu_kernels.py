@@ -45,12 +45,33 @@ def shard_route(ids, num_rows, padding_idx, num_shards, ws, slot_offset=None, st
     return route, status
 
 
-def emb_gather(ids, W, padding_idx=None, status=None, out=None):
+def emb_gather(ids, W, padding_idx=None, status=None, out=None, out_group=0, out_group_stride=0):
     res = torch.from_numpy(R.embedding_lookup(_n(W), _n(ids).reshape(-1, 1), padding_idx)[:, 0, :])
     if out is None:
         return res, status
+    if out_group > 0:          # lookup i -> out + (i // group) * stride + (i % group) * D
+        n, D = res.shape
+        out.view(-1, out_group_stride)[:, : out_group * D].copy_(res.reshape(n // out_group, out_group * D))
+        return out, status
     out.view(res.shape).copy_(res)
     return out, status
+
+
+def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux0=None, aux1=None, out=None,
+         split_k=0, b_colsum=None, row_scale=None, out2=None, num_cus=0):
+    a = _n(A).T if trans_a else _n(A)
+    b = _n(B).T if trans_b else _n(B)
+    c = a @ b
+    if epilogue in ("bias", "bias_relu"):
+        c = c + _n(bias).reshape(1, -1)
+        if epilogue == "bias_relu":
+            c = np.maximum(c, 0)
+    elif epilogue != "none":
+        raise NotImplementedError(epilogue)
+    if b_colsum is not None:
+        b_colsum.copy_(torch.from_numpy(_n(B).sum(axis=0, dtype=np.float32)).reshape(b_colsum.shape))
+    r = torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32))
+    return r if out is None else out.copy_(r)
 
 
 def deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, padding_idx=0, slot_offset=None,
@@ -125,8 +146,12 @@ def segment_partials(groups, grad, D, grad_div=1, grad_group=0, grad_group_strid
 
 
 def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
-                     partials=None):
-    g = grad.numpy().reshape(-1, P.shape[1])
+                     partials=None, grad_group=0, grad_group_stride=0, grad_scale=None):
+    D = P.shape[1]
+    if grad_group > 0:     # rec_grad_layout{1, group, stride}: the first group*D columns of a [B, stride] buffer
+        g = np.ascontiguousarray(grad.numpy().reshape(-1, grad_group_stride)[:, : grad_group * D]).reshape(-1, D)
+    else:
+        g = grad.numpy().reshape(-1, D)
     merged = np.zeros((len(groups.uniq), P.shape[1]), np.float32)
     for u in range(len(groups.uniq)):
         acc = np.zeros(P.shape[1], np.float32)
