@@ -443,6 +443,21 @@ int rec_parse_criteo_tsv(const char* buf, size_t len, int32_t n_dense, int32_t n
                          int64_t max_lines, int32_t threads, int64_t* label, int64_t* ids, float* dense,
                          int64_t* n_lines);
 
+/* Host parser of multi-value slot lines (models/rank/slot_dnn/queuedataset_reader.py:56-82): a line is
+ * "feasign:slot feasign:slot ..." with uint64 feasigns and any number of values per slot.  Slots outside
+ * [first_slot, first_slot + num_slots) are dropped; a slot that does not occur in a line gets the single padding
+ * id 0 (line_process, :75-80).  Output = the layout rec_emb_gather_sumpool consumes, slot-major CSR:
+ *   values[slot_base[s] + lod[s*(max_lines+1) + b] + j] = j-th value of slot s in line b      (token order)
+ *   lod [num_slots, max_lines+1] (row s: offsets of slot s over the lines), slot_base [num_slots+1]
+ * hash_rows = 0: values are the raw uint64 bit patterns (what the reference feeds its PS hash map);
+ * hash_rows >= 2: rows of a hashed table, 0 -> 0 (padding row), f -> 1 + f % (hash_rows-1).
+ * REC_EWORKSPACE (with *n_values = the size needed) when max_values is too small.  Multi-threaded, results do
+ * not depend on the thread count. */
+int rec_parse_feasign_slots(const char* buf, size_t len, int32_t first_slot, int32_t num_slots,
+                            uint64_t hash_rows, int64_t max_lines, int64_t max_values, int32_t threads,
+                            int64_t* values, int64_t* lod, int64_t* slot_base, int64_t* n_lines,
+                            int64_t* n_values);
+
 /* Fills buf[i] = i-th value of a counter-based generator, uniform in [lo,hi) — used to initialise
  * multi-GB tables on the device without a host round trip. */
 int rec_fill_uniform(int64_t n, float* buf, float lo, float hi, uint64_t seed, void* stream);

@@ -324,3 +324,30 @@ def parse_slot_line(line, n_sparse=26, n_dense=13, padding=0):
         dense = [padding] * n_dense
     ids = np.array([s[0] if s else padding for s in sparse], dtype=np.int64)
     return np.int64(label[0]), ids, np.array(dense, dtype=np.float32)
+
+
+# --------------------------------------------------------------------------
+# R/P — multi-value slot reader               models/rank/slot_dnn/queuedataset_reader.py:56-82
+# --------------------------------------------------------------------------
+def parse_feasign_line(line, first_slot=1, num_slots=301, padding=0):
+    """'feasign:slot feasign:slot ...' -> list over the slots first_slot .. first_slot+num_slots-1 of the slot's
+    feasigns in token order (line_process, :56-82: `slots` = "1".."slot_num+1", :39-50); a slot that does not occur
+    holds [padding]; tokens of other slots are dropped.  Feasigns are uint64 (returned as Python ints).  The
+    constant show slot ("0", [1]) the reference prepends (:81) is not part of the output."""
+    out = [[] for _ in range(num_slots)]
+    for tok in line.strip().split(" "):
+        if not tok:
+            continue
+        fs, _, slot = tok.partition(":")
+        if not slot.isdigit() or not fs.isdigit():
+            continue
+        s = int(slot) - first_slot
+        if 0 <= s < num_slots:
+            out[s].append(int(fs))
+    return [v if v else [padding] for v in out]
+
+
+def feasign_row(f, hash_rows):
+    """Row of a hashed table with `hash_rows` rows: 0 stays the padding row, any other feasign lands in [1, rows)
+    (engine convention — the reference's PS table is an exact hash map keyed by the feasign [EXT])."""
+    return 0 if f == 0 else 1 + f % (hash_rows - 1)

@@ -118,6 +118,8 @@ SIGNATURES = {
                                       C.POINTER(_I64)]),
     "rec_parse_criteo_tsv": (C.c_int, [C.c_char_p, _SZ, _I32, _I32, _P, _P, C.c_uint32, _I64, _I32, _P, _P, _P,
                                        C.POINTER(_I64)]),
+    "rec_parse_feasign_slots": (C.c_int, [C.c_char_p, _SZ, _I32, _I32, C.c_uint64, _I64, _I64, _I32, _P, _P, _P,
+                                          C.POINTER(_I64), C.POINTER(_I64)]),
     "rec_fill_uniform": (C.c_int, [_I64, _P, _F, _F, C.c_uint64, _P]),
     "rec_stream_spin": (C.c_int, [_I32, _P]),
     "rec_stream_create_cu_range": (C.c_int, [_I32, _I32, C.POINTER(C.c_void_p)]),

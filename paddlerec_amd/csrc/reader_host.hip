@@ -205,3 +205,111 @@ extern "C" int rec_parse_criteo_tsv(const char* buf, size_t len, int32_t n_dense
   });
   return REC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Multi-value slot lines — models/rank/slot_dnn/queuedataset_reader.py:56-82 (Reader.line_process): a line is
+// "feasign:slot feasign:slot ..." with uint64 feasigns and any number of values per slot; slots outside
+// [first_slot, first_slot + num_slots) are dropped, a slot that never shows up gets the single padding id 0.
+// Output = what the sum-pool lookup (rec_emb_gather_sumpool, one launch per slot) consumes: slot-major CSR
+//   values[slot_base[s] + lod[s][b] + j]   (j-th value of slot s in line b),   lod[s][0..n_lines]
+// in two parallel passes over the lines (count, then fill) around one prefix sum per slot.
+namespace rec {
+
+// calls f(slot_index, feasign) for every "feasign:slot" token of the line whose slot is in range
+template <class F>
+static void scan_feasign_line(LineSpan ln, int first_slot, int num_slots, F&& f) {
+  const char* p = ln.b;
+  while (p < ln.e) {
+    while (p < ln.e && *p == ' ') ++p;
+    if (p >= ln.e) break;
+    const char* te = (const char*)memchr(p, ' ', (size_t)(ln.e - p));
+    if (!te) te = ln.e;
+    const char* colon = (const char*)memchr(p, ':', (size_t)(te - p));
+    if (colon && colon + 1 < te) {
+      uint64_t fs = 0;
+      bool ok = colon > p;
+      for (const char* q = p; q < colon; ++q) {
+        if (*q < '0' || *q > '9') { ok = false; break; }
+        fs = fs * 10u + (uint64_t)(*q - '0');
+      }
+      long slot = 0;
+      bool sok = true;
+      for (const char* q = colon + 1; q < te; ++q) {
+        if (*q < '0' || *q > '9') { sok = false; break; }
+        slot = slot * 10 + (*q - '0');
+        if (slot > (1l << 30)) { sok = false; break; }
+      }
+      if (ok && sok && slot >= first_slot && slot < (long)first_slot + num_slots) f((int)(slot - first_slot), fs);
+    }
+    p = te;
+  }
+}
+
+static inline void strip_line(LineSpan& ln) {
+  while (ln.e > ln.b && (ln.e[-1] == '\r' || ln.e[-1] == ' ' || ln.e[-1] == '\t')) --ln.e;
+  while (ln.b < ln.e && (*ln.b == ' ' || *ln.b == '\t')) ++ln.b;
+}
+
+}  // namespace rec
+
+extern "C" int rec_parse_feasign_slots(const char* buf, size_t len, int32_t first_slot, int32_t num_slots,
+                                       uint64_t hash_rows, int64_t max_lines, int64_t max_values,
+                                       int32_t threads, int64_t* values, int64_t* lod, int64_t* slot_base,
+                                       int64_t* n_lines, int64_t* n_values) {
+  REC_REQUIRE(num_slots > 0 && first_slot >= 0 && max_lines >= 0 && max_values >= 0 && n_lines && n_values,
+              REC_EINVAL, "bad arguments");
+  REC_REQUIRE(hash_rows == 0 || hash_rows >= 2, REC_EINVAL, "hash_rows must be 0 (raw feasigns) or >= 2");
+  REC_REQUIRE(len == 0 || buf, REC_EINVAL, "buf is NULL");
+  REC_REQUIRE(max_lines == 0 || (lod && slot_base), REC_EINVAL, "null output pointer");
+  const int T = host_threads(threads);
+  const int S = num_slots;
+  // pass 1: values per (line, slot); a slot without a token holds the one padding id
+  std::vector<int32_t> cnt((size_t)max_lines * S, 0);
+  const int64_t n = for_each_line(buf, len, max_lines, T, [&](int64_t i, LineSpan ln) {
+    strip_line(ln);
+    int32_t* c = cnt.data() + (size_t)i * S;
+    scan_feasign_line(ln, first_slot, S, [&](int s, uint64_t) { ++c[s]; });
+    for (int s = 0; s < S; ++s)
+      if (c[s] == 0) c[s] = -1;            // -1 = padded (one value, id 0)
+  });
+  *n_lines = n;
+  // per-slot offsets over the lines (parallel over slots), then the slot bases
+  std::vector<int64_t> tot((size_t)S, 0);
+  run_threads(T < S ? T : S, [&](int t) {
+    const int TT = T < S ? T : S;
+    for (int s = t; s < S; s += TT) {
+      int64_t acc = 0;
+      int64_t* l = lod + (size_t)s * (max_lines + 1);
+      l[0] = 0;
+      for (int64_t b = 0; b < n; ++b) {
+        const int32_t c = cnt[(size_t)b * S + s];
+        acc += c < 0 ? 1 : c;
+        l[b + 1] = acc;
+      }
+      tot[s] = acc;
+    }
+  });
+  int64_t total = 0;
+  for (int s = 0; s < S; ++s) { slot_base[s] = total; total += tot[s]; }
+  slot_base[S] = total;
+  *n_values = total;
+  REC_REQUIRE(total <= max_values, REC_EWORKSPACE, "values buffer holds %lld ids, %lld needed",
+              (long long)max_values, (long long)total);
+  if (total == 0) return REC_OK;
+  REC_REQUIRE(values, REC_EINVAL, "values is NULL");
+  // pass 2: fill
+  for_each_line(buf, len, n, T, [&](int64_t i, LineSpan ln) {
+    strip_line(ln);
+    std::vector<int32_t> cur((size_t)S, 0);
+    scan_feasign_line(ln, first_slot, S, [&](int s, uint64_t fs) {
+      const int64_t at = slot_base[s] + lod[(size_t)s * (max_lines + 1) + i] + cur[s]++;
+      // hashed table: row 0 stays the padding row, every other feasign lands in [1, hash_rows)
+      const uint64_t row = hash_rows == 0 ? fs : (fs == 0 ? 0 : 1 + fs % (hash_rows - 1));
+      values[at] = (int64_t)row;             // raw mode: the uint64 bit pattern, as the reference feeds int64
+    });
+    const int32_t* c = cnt.data() + (size_t)i * S;
+    for (int s = 0; s < S; ++s)
+      if (c[s] < 0) values[slot_base[s] + lod[(size_t)s * (max_lines + 1) + i]] = 0;
+  });
+  return REC_OK;
+}

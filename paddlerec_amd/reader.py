@@ -58,6 +58,44 @@ def parse_criteo_tsv(data: bytes, n_dense=13, n_sparse=26, hash_dim=HASH_DIM, th
     return label[: n.value], ids[: n.value], dense[: n.value, :n_dense]
 
 
+def parse_feasign_slots(data: bytes, first_slot=1, num_slots=301, hash_rows=0, threads=0):
+    """Multi-value slot lines (slot_dnn/queuedataset_reader.py:56-82) -> slot-major CSR, host tensors:
+    (values [total] i64, lod [num_slots, n+1] i64, slot_base [num_slots+1] i64, n lines) — slot s of line b is
+    values[slot_base[s] + lod[s,b] : slot_base[s] + lod[s,b+1]]; with hash_rows > 0 the values are table rows."""
+    cap = _count_lines(data, threads)
+    bound = data.count(b":") + cap * num_slots          # every token + one padding id per (line, slot)
+    values = torch.empty(max(bound, 1), dtype=torch.int64)
+    lod = torch.zeros(num_slots, cap + 1, dtype=torch.int64)
+    base = torch.zeros(num_slots + 1, dtype=torch.int64)
+    n, nv = C.c_int64(0), C.c_int64(0)
+    check(lib().rec_parse_feasign_slots(data, len(data), int(first_slot), int(num_slots), int(hash_rows), cap,
+                                        values.numel(), threads, C.c_void_p(values.data_ptr()),
+                                        C.c_void_p(lod.data_ptr()), C.c_void_p(base.data_ptr()), C.byref(n),
+                                        C.byref(nv)), "rec_parse_feasign_slots")
+    return values[: nv.value], lod[:, : n.value + 1], base, int(n.value)
+
+
+class FeasignSlotReader:
+    """slot_dnn/queuedataset_reader.py Reader over a file list: yields, per batch of `batch_size` lines (drop_last),
+    (values, lod [num_slots, B+1], slot_base [num_slots+1]) on `device` — slot s of the batch feeds one
+    rec_emb_gather_sumpool launch: ids = values[slot_base[s]:slot_base[s+1]], lod = lod[s]."""
+
+    def __init__(self, file_list, batch_size, device="cuda", first_slot=1, num_slots=301, hash_rows=0, threads=0):
+        self.file_list, self.batch_size, self.device = list(file_list), batch_size, device
+        self.kw = dict(first_slot=first_slot, num_slots=num_slots, hash_rows=hash_rows, threads=threads)
+
+    def __iter__(self):
+        B = self.batch_size
+        pending = []
+        for path in self.file_list:
+            with open(path, "rb") as f:
+                pending += [ln for ln in f.read().split(b"\n") if ln.strip()]
+            while len(pending) >= B:
+                chunk, pending = pending[:B], pending[B:]
+                values, lod, base, _ = parse_feasign_slots(b"\n".join(chunk) + b"\n", **self.kw)
+                yield tuple(t.to(self.device, non_blocking=True) for t in (values, lod.contiguous(), base))
+
+
 class _FileBatches:
     def __init__(self, file_list, batch_size, device, parse, shard=None):
         self.file_list = list(file_list)

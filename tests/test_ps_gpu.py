@@ -47,3 +47,29 @@ def test_cvm_lookup_and_adagrad_rule(engine_lib, D, B, N):
     untouched = np.setdiff1d(np.arange(N), uniq)
     assert np.array_equal(got[untouched], rec[untouched])
     assert np.all(np.abs(got[:, 4:4 + D]) <= 10.0)
+
+
+def test_multi_value_slots_file_to_sum_pool(engine_lib):
+    """Row P end to end on the reference's own multi-value fixture (first lines of slot_dnn/data/demo_10):
+    host parser (queuedataset_reader.py:56-82) -> hashed rows -> one rec_emb_gather_sumpool launch per slot
+    == sparse_embedding(padding_idx=0) + sequence_pool('sum') of slot_dnn/net.py:63-75 (oracle), counts bit-exact."""
+    import os
+    from conftest import GOLDEN
+    from paddlerec_amd import ops, reader
+    data = open(os.path.join(GOLDEN, "slot_dnn_demo_4.txt"), "rb").read()
+    N, D = 100003, 9
+    values, lod, base, n = reader.parse_feasign_slots(data, 2, 300, N)            # slots "2".."301" (slot "1" = click)
+    rng = np.random.default_rng(1)
+    W = rng.standard_normal((N, D)).astype(np.float32)
+    W[0] = 0
+    tW, tv, tl = T(W), T(values.numpy()), T(lod.numpy())
+    nnz_per_slot = (base[1:] - base[:-1]).numpy()
+    picked = list(np.argsort(-nnz_per_slot)[:6]) + [0, 5, 299]                     # the fattest slots + some thin ones
+    for s in picked:
+        ids = tv[int(base[s]): int(base[s + 1])]
+        out, counts, status = ops.emb_gather_sumpool(ids.contiguous(), tl[s].contiguous(), tW, 0)
+        want, wcnt = R.sequence_pool_sum(W, values.numpy()[int(base[s]): int(base[s + 1])], lod.numpy()[s], 0)
+        assert np.array_equal(counts.cpu().numpy(), wcnt.astype(np.int32))
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+        assert int(status.item()) == 0
+    assert nnz_per_slot.max() > 4                                                  # really multi-valued

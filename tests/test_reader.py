@@ -137,3 +137,72 @@ def test_din_reader_matches_reference_restatement(reader, bs):
         for t, k in zip(g, keys):
             assert np.array_equal(t.numpy(), w[k]), k
             assert t.numpy().dtype == w[k].dtype, k
+
+
+# ------------------------------------------------------------------------------ multi-value slot lines (row P)
+def _oracle_csr(lines, first_slot, num_slots, hash_rows):
+    per_line = [R.parse_feasign_line(ln, first_slot, num_slots) for ln in lines]
+    values, lod, base = [], np.zeros((num_slots, len(lines) + 1), np.int64), np.zeros(num_slots + 1, np.int64)
+    for s in range(num_slots):
+        base[s] = len(values)
+        for b, pl in enumerate(per_line):
+            vals = pl[s]
+            if hash_rows:
+                vals = [R.feasign_row(f, hash_rows) for f in vals]
+            values += vals
+            lod[s, b + 1] = lod[s, b] + len(vals)
+    base[num_slots] = len(values)
+    as_i64 = np.asarray([v - (1 << 64) if v >= (1 << 63) else v for v in values], dtype=np.int64)  # bit pattern
+    return as_i64, lod, base
+
+
+@pytest.mark.parametrize("threads,hash_rows", [(1, 0), (5, 0), (3, 1000003)])
+def test_feasign_slots_reference_demo(reader, threads, hash_rows):
+    """First 4 lines of the reference's models/rank/slot_dnn/data/demo_10 (uint64 feasigns > 2^63, multi-value
+    slots, 271 distinct slots) against the restatement of queuedataset_reader.py line_process."""
+    data = open(os.path.join(GOLDEN, "slot_dnn_demo_4.txt"), "rb").read()
+    lines = data.decode().strip().split("\n")
+    values, lod, base, n = reader.parse_feasign_slots(data, 1, 301, hash_rows, threads)
+    ov, ol, ob = _oracle_csr(lines, 1, 301, hash_rows)
+    assert n == 4 and np.array_equal(base.numpy(), ob) and np.array_equal(lod.numpy(), ol)
+    assert np.array_equal(values.numpy(), ov)
+    if not hash_rows:
+        assert (values.numpy() < 0).any()                       # feasigns above 2^63 kept as int64 bit patterns
+    else:
+        assert values.min() >= 0 and values.max() < hash_rows
+    # slot "1" is the click label (first token of every line is "<0|1>:1")
+    assert [int(values[base[0] + lod[0, b]]) for b in range(4)] == [int(ln.split(":")[0]) for ln in lines]
+    # every (line, slot) holds at least one id: absent slots are padded with a single 0
+    assert int((lod[:, 1:] - lod[:, :-1]).min()) == 1
+
+
+def test_feasign_slots_edge_cases(reader):
+    import ctypes as C
+    from paddlerec_amd._lib import lib
+    data = b"7:2 9:2 5:9  18446744073709551615:3 x:3 4: :5 11:77\n\n3:3\r\n8:2"
+    values, lod, base, n = reader.parse_feasign_slots(data, 2, 3, 0, 2)          # slots 2, 3, 4
+    assert n == 4
+    v = values.numpy().tolist()
+    seg = lambda s, b: v[base[s] + lod[s, b]: base[s] + lod[s, b + 1]]
+    assert seg(0, 0) == [7, 9] and seg(1, 0) == [-1] and seg(2, 0) == [0]        # 2^64-1 -> bit pattern -1; pad
+    assert seg(0, 1) == [0] and seg(1, 1) == [0] and seg(2, 1) == [0]            # empty line: every slot padded
+    assert seg(1, 2) == [3] and seg(0, 3) == [8]
+    assert int(base[-1]) == len(v) == 13
+    nl, nv = C.c_int64(0), C.c_int64(0)
+    rc = lib().rec_parse_feasign_slots(data, len(data), 2, 3, 0, 4, 5, 1, None, lod.data_ptr(), base.data_ptr(),
+                                       C.byref(nl), C.byref(nv))
+    assert rc == -3 and nv.value == 13                                            # REC_EWORKSPACE reports the size
+    assert lib().rec_parse_feasign_slots(data, len(data), 2, 3, 1, 4, 99, 1, None, None, None, C.byref(nl),
+                                         C.byref(nv)) == -1                       # hash_rows = 1 is meaningless
+
+
+def test_feasign_slot_reader_batches(reader, tmp_path):
+    data = open(os.path.join(GOLDEN, "slot_dnn_demo_4.txt"), "rb").read()
+    p = tmp_path / "part-0"
+    p.write_bytes(data + data[: data.index(b"\n") + 1])                           # 5 lines -> 2 batches of 2
+    got = list(reader.FeasignSlotReader([str(p)], 2, device="cpu", hash_rows=1000003))
+    assert len(got) == 2
+    lines = data.decode().strip().split("\n")
+    for i, (values, lod, base) in enumerate(got):
+        ov, ol, ob = _oracle_csr(lines[2 * i: 2 * i + 2], 1, 301, 1000003)
+        assert np.array_equal(values.numpy(), ov) and np.array_equal(lod.numpy(), ol) and np.array_equal(base.numpy(), ob)
