@@ -163,3 +163,30 @@ def test_gemm_argument_errors(ops):
         ops.gemm(a, torch.zeros(5, 3, device=DEV), ws, epilogue="bias")
     with pytest.raises(Exception, match="device tensor"):
         ops.gemm(torch.zeros(4, 5), torch.zeros(5, 3), ws)
+
+
+def test_stream_helpers(ops):
+    """rec_stream_spin / concurrent_stream / cu_range_stream: the helpers the train steps place their side work with."""
+    import ctypes as C
+    import time
+    from paddlerec_amd._lib import lib
+    main = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    assert lib().rec_stream_spin(2000, C.c_void_p(main.cuda_stream)) == 0
+    e1.record()
+    torch.cuda.synchronize()
+    assert 0.2 <= e0.elapsed_time(e1) <= 200.0                   # the spin really holds the stream (~2 ms)
+    s = ops.concurrent_stream(DEV)
+    assert isinstance(s, torch.cuda.Stream) and s.cuda_stream != main.cuda_stream
+    assert ops.concurrent_stream(DEV) is s                       # probed once per (device, main stream)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cs = ops.cu_range_stream(dev, 0, 64)
+    assert ops.cu_range_stream(dev, 0, 64) is cs
+    with torch.cuda.stream(cs):                                  # kernels run (and finish) on a CU-restricted stream
+        a = torch.ones(1 << 20, device=DEV)
+        out = ops.colsum(a.view(-1, 1), ops.Workspace(DEV))
+    cs.synchronize()
+    assert float(out.item()) == float(1 << 20)
+    sp = ops.gemm(torch.ones(8, 4, device=DEV), torch.ones(8, 3, device=DEV), ops.Workspace(DEV), trans_a=True, num_cus=64)
+    assert torch.equal(sp.cpu(), torch.full((4, 3), 8.0))
