@@ -315,6 +315,28 @@ class DeepFMLayer:
         return self._rg
 
 
+def slot_feeds(batch_data, config, device):
+    """create_feeds of the Criteo slot models (deepfm/dygraph_model.py:41-51, same code in fm / wide_deep / dcn_v2):
+    -> (label [B,1] i64, sparse, dense [B,Dn] f32) on `device`.  batch_data is either the reference's 28 arrays
+    [label, C1..C26, dense] (sparse = list of 26 [B,1] tensors) or the (label [B,1], ids [B,26], dense [B,13]) device
+    tensors of paddlerec_amd.reader (sparse = the [B,26] tensor: no per-slot split and re-concat)."""
+    if len(batch_data) == 3 and torch.is_tensor(batch_data[1]) and batch_data[1].dim() == 2 \
+            and batch_data[1].shape[1] > 1:
+        label, ids, dense = batch_data
+        return label.to(device), ids.to(device), dense.to(device)
+    dn = config.get("hyper_parameters.dense_input_dim")
+    sparse = [torch.as_tensor(b).to(torch.int64).reshape(-1, 1).to(device) for b in batch_data[:-1]]
+    dense = torch.as_tensor(batch_data[-1]).to(torch.float32).reshape(-1, dn).to(device)
+    return sparse[0], sparse[1:], dense
+
+
+def auc_metrics(device):
+    """create_metrics: paddle.metric.Auc("ROC") = the two int64 bucket arrays of rec_auc_histogram, on the device."""
+    stats = (torch.zeros(NUM_THRESHOLDS + 1, dtype=torch.int64, device=device),
+             torch.zeros(NUM_THRESHOLDS + 1, dtype=torch.int64, device=device))
+    return [stats], ["auc"]
+
+
 class DygraphModel:
     """deepfm/dygraph_model.py:23-98 — same method names; tensors are torch device tensors."""
 
@@ -326,21 +348,10 @@ class DygraphModel:
                            config.get("hyper_parameters.fc_sizes"), device=device, kernels=kernels)
 
     def create_feeds(self, batch_data, config, device="cuda"):
-        """batch_data: the reference's 28 arrays [label, C1..C26, dense] (dygraph_model.py:41-51) or the
-        (label [B,1], ids [B,26], dense [B,13]) device tensors of paddlerec_amd.reader (no per-slot split)."""
-        if len(batch_data) == 3 and torch.is_tensor(batch_data[1]) and batch_data[1].dim() == 2 \
-                and batch_data[1].shape[1] > 1:
-            label, ids, dense = batch_data
-            return label.to(device), ids.to(device), dense.to(device)
-        dn = config.get("hyper_parameters.dense_input_dim")
-        sparse = [torch.as_tensor(b).to(torch.int64).reshape(-1, 1).to(device) for b in batch_data[:-1]]
-        dense = torch.as_tensor(batch_data[-1]).to(torch.float32).reshape(-1, dn).to(device)
-        return sparse[0], sparse[1:], dense
+        return slot_feeds(batch_data, config, device)
 
     def create_metrics(self, device="cuda"):
-        stats = (torch.zeros(NUM_THRESHOLDS + 1, dtype=torch.int64, device=device),
-                 torch.zeros(NUM_THRESHOLDS + 1, dtype=torch.int64, device=device))
-        return [stats], ["auc"]
+        return auc_metrics(device)
 
     def train_forward(self, dy_model, metrics_list, batch_data, config, lr=None):
         label, sparse, dense = self.create_feeds(batch_data, config, dy_model.device)

@@ -11,7 +11,7 @@ There is no autograd tape and no CPU fallback.
 import torch
 
 from . import ops
-from .deepfm import FM, NUM_THRESHOLDS, _FlatParams, _OnSide
+from .deepfm import FM, NUM_THRESHOLDS, _FlatParams, _OnSide, auc_metrics, slot_feeds
 
 
 class FMLayer:
@@ -144,19 +144,10 @@ class DygraphModel:
                        config.get("hyper_parameters.sparse_inputs_slots") - 1, device=device, kernels=kernels)
 
     def create_feeds(self, batch_data, config, device="cuda"):
-        if len(batch_data) == 3 and torch.is_tensor(batch_data[1]) and batch_data[1].dim() == 2 \
-                and batch_data[1].shape[1] > 1:            # (label, ids [B,26], dense) from paddlerec_amd.reader
-            label, ids, dense = batch_data
-            return label.to(device), ids.to(device), dense.to(device)
-        dn = config.get("hyper_parameters.dense_input_dim")
-        sparse = [torch.as_tensor(b).to(torch.int64).reshape(-1, 1).to(device) for b in batch_data[:-1]]
-        dense = torch.as_tensor(batch_data[-1]).to(torch.float32).reshape(-1, dn).to(device)
-        return sparse[0], sparse[1:], dense
+        return slot_feeds(batch_data, config, device)
 
     def create_metrics(self, device="cuda"):
-        stats = (torch.zeros(NUM_THRESHOLDS + 1, dtype=torch.int64, device=device),
-                 torch.zeros(NUM_THRESHOLDS + 1, dtype=torch.int64, device=device))
-        return [stats], ["auc"]
+        return auc_metrics(device)
 
     def train_forward(self, dy_model, metrics_list, batch_data, config):
         label, sparse, dense = self.create_feeds(batch_data, config, dy_model.device)
