@@ -26,8 +26,7 @@ def _np(t):
 
 
 def _mkdir_if_not_exist(path):
-    if not os.path.exists(path):
-        os.makedirs(path)
+    os.makedirs(path, exist_ok=True)         # every rank of a sharded run creates the same epoch directory
 
 
 def optimizer_state(net):

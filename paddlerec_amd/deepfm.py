@@ -340,12 +340,15 @@ def auc_metrics(device):
 class DygraphModel:
     """deepfm/dygraph_model.py:23-98 — same method names; tensors are torch device tensors."""
 
-    def create_model(self, config, device="cuda", kernels=None):
-        return DeepFMLayer(config.get("hyper_parameters.sparse_feature_number"),
-                           config.get("hyper_parameters.sparse_feature_dim"),
-                           config.get("hyper_parameters.dense_input_dim"),
-                           config.get("hyper_parameters.sparse_inputs_slots") - 1,
-                           config.get("hyper_parameters.fc_sizes"), device=device, kernels=kernels)
+    def create_model(self, config, device="cuda", kernels=None, comm=None):
+        """comm (paddlerec_amd.sharded.Comm, world > 1): the row-sharded layer of the collective mode."""
+        args = (config.get("hyper_parameters.sparse_feature_number"), config.get("hyper_parameters.sparse_feature_dim"),
+                config.get("hyper_parameters.dense_input_dim"), config.get("hyper_parameters.sparse_inputs_slots") - 1,
+                config.get("hyper_parameters.fc_sizes"))
+        if comm is not None and comm.world > 1:
+            from .sharded import ShardedDeepFMLayer
+            return ShardedDeepFMLayer(*args, device=device, comm=comm, kernels=kernels)
+        return DeepFMLayer(*args, device=device, kernels=kernels)
 
     def create_feeds(self, batch_data, config, device="cuda"):
         return slot_feeds(batch_data, config, device)
@@ -353,10 +356,14 @@ class DygraphModel:
     def create_metrics(self, device="cuda"):
         return auc_metrics(device)
 
-    def train_forward(self, dy_model, metrics_list, batch_data, config, lr=None):
+    def train_forward(self, dy_model, metrics_list, batch_data, config, lr=None, next_batch=None):
+        """next_batch (row-sharded layer only): the batch the next call will get — its ids are routed a step ahead."""
         label, sparse, dense = self.create_feeds(batch_data, config, dy_model.device)
         lr = lr if lr is not None else config.get("hyper_parameters.optimizer.learning_rate", 0.001)
-        loss, _ = dy_model.train_step(sparse, dense, label, lr, metrics_list[0] if metrics_list else None)
+        kw = {}
+        if next_batch is not None and hasattr(dy_model, "comm"):
+            kw["next_sparse_inputs"] = self.create_feeds(next_batch, config, dy_model.device)[1]
+        loss, _ = dy_model.train_step(sparse, dense, label, lr, metrics_list[0] if metrics_list else None, **kw)
         return loss, metrics_list, {"loss": loss}
 
     def infer_forward(self, dy_model, metrics_list, batch_data, config):

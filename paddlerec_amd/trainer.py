@@ -11,6 +11,7 @@ What differs by construction: a batch never becomes 28 per-sample NumPy arrays (
 host mirrors, and the AUC buckets stay on the device (read back only when a log line prints them).
 
     python -m paddlerec_amd.trainer -m <config.yaml> [--model deepfm|fm|wide_deep|dcn_v2|din] [-o runner.epochs=1 ...] [--infer]
+    python -m torch.distributed.run --nproc-per-node G -m paddlerec_amd.trainer -m <config.yaml>     # collective mode
 """
 import argparse
 import logging
@@ -118,6 +119,50 @@ def _metric_values(dy_model_class, metric_list, metric_names):
     return {n: auc_from_buckets(m[0], m[1]) for n, m in zip(metric_names, metric_list)}
 
 
+def _global_metric_values(dy_model_class, metric_list, metric_names, comm):
+    """Global AUC of a data-parallel run: the integer buckets of all ranks are summed (one all-reduce of a copy, only
+    where a value is printed) — what the reference's fleet metrics do for its static AUC (utils_single.py:143-158)."""
+    if comm is None or comm.world == 1:
+        return _metric_values(dy_model_class, metric_list, metric_names)
+    summed = [tuple(comm.all_reduce_sum(t.clone()) for t in m) for m in metric_list]
+    return _metric_values(dy_model_class, summed, metric_names)
+
+
+def _local_batches(config, mode, shard, batch_size):
+    """Batches this rank's files hold (drop_last over the concatenation of its files, as the readers batch)."""
+    from . import reader
+    from .reader import _FileBatches
+    files = _FileBatches(_data_files(config, "runner.train_data_dir" if mode == "train" else "runner.test_data_dir"),
+                         batch_size, "cpu", None, shard).file_list
+    lines = 0
+    for path in files:
+        with open(path, "rb") as f:
+            lines += reader._count_lines(f.read(), 0) if os.path.getsize(path) else 0
+    return lines // batch_size
+
+
+def _agreed_batches(config, mode, comm, batch_size):
+    """Every rank must issue the same number of steps (each step holds collectives): the minimum over the ranks."""
+    n = _local_batches(config, mode, (comm.rank, comm.world), batch_size)
+    t = torch.tensor([-n], dtype=torch.int64, device="cpu" if comm.staged else torch.device("cuda", torch.cuda.current_device()))
+    comm.dist.all_reduce(t, op=comm.dist.ReduceOp.MAX, group=comm.group)         # max of -n = -min n
+    return int(-t.item())
+
+
+def _lookahead(it, limit=None):
+    """(batch, next batch or None) pairs — the row-sharded step routes the next batch a step ahead."""
+    prev, n = None, 0
+    for cur in it:
+        if prev is not None:
+            yield prev, cur
+            n += 1
+            if limit is not None and n >= limit:
+                return
+        prev = cur
+    if prev is not None and (limit is None or n < limit):
+        yield prev, None
+
+
 def _reset(metric_list):
     for m in metric_list:
         m[0].zero_()
@@ -125,12 +170,20 @@ def _reset(metric_list):
 
 
 # -------------------------------------------------------------------------------------------- train
-def train(config, model, device="cuda", kernels=None):
+def train(config, model, device="cuda", kernels=None, comm=None):
     """tools/trainer.py main(): returns one summary dict per epoch
-    {"epoch", "batches", "samples", "loss", "ips", <metric name>: value, "model_dir"}."""
+    {"epoch", "batches", "samples", "loss", "ips", <metric name>: value, "model_dir"}.
+    comm (paddlerec_amd.sharded.Comm, world > 1): the `use_fleet` collective mode of trainer.py:113-119 — one process
+    per GPU, the files of train_data_dir split over the ranks (criteo_reader.py:30-43), the embedding tables
+    row-sharded (deepfm only), loss / AUC / samples reported for the GLOBAL batch, one checkpoint shard per rank."""
     torch.manual_seed(config.get("runner.seed", 12345))
     dy_model_class = _dygraph_model(model)
     kw = {"kernels": kernels} if kernels is not None else {}
+    world = comm.world if comm is not None else 1
+    if world > 1:
+        if model != "deepfm":
+            raise ValueError("the row-sharded collective mode is built for deepfm only")
+        kw["comm"] = comm
     dy_model = dy_model_class.create_model(config, device, **kw)
     if config.get("runner.model_init_path"):
         checkpoint.load_model(config["runner.model_init_path"], dy_model)
@@ -138,7 +191,9 @@ def train(config, model, device="cuda", kernels=None):
     print_interval = max(int(config.get("runner.print_interval", 1) or 1), 1)
     save_path = config.get("runner.model_save_path", "model_output")
     use_auc = config.get("runner.use_auc", False)
-    loader = create_data_loader(config, model, dy_model.device, "train")
+    shard = (comm.rank, comm.world) if world > 1 else None
+    loader = create_data_loader(config, model, dy_model.device, "train", shard)
+    limit = _agreed_batches(config, "train", comm, config.get("runner.train_batch_size")) if world > 1 else None
     summaries = []
     for epoch_id in range(config.get("last_epoch", -1) + 1, epochs):
         metric_list, metric_names = dy_model_class.create_metrics(dy_model.device)
@@ -147,17 +202,18 @@ def train(config, model, device="cuda", kernels=None):
         interval_samples = total_samples = n_batches = 0
         loss = None
         reader_start = time.time()
-        for batch_id, batch in enumerate(loader()):
+        for batch_id, (batch, nxt) in enumerate(_lookahead(loader(), limit)):
             reader_cost += time.time() - reader_start
             t0 = time.time()
-            loss, metric_list, _ = dy_model_class.train_forward(dy_model, metric_list, batch, config)
+            fkw = {"next_batch": nxt} if world > 1 else {}
+            loss, metric_list, _ = dy_model_class.train_forward(dy_model, metric_list, batch, config, **fkw)
             run_cost += time.time() - t0
-            bs = _batch_size(batch)
+            bs = _batch_size(batch) * world
             interval_samples += bs
             total_samples += bs
             n_batches += 1
             if batch_id % print_interval == 0:        # the only place the device is read back
-                vals = _metric_values(dy_model_class, metric_list, metric_names)
+                vals = _global_metric_values(dy_model_class, metric_list, metric_names, comm)
                 logger.info("epoch: %d, batch_id: %d, %sloss: %.6f, avg_reader_cost: %.5f sec, avg_batch_cost: "
                             "%.5f sec, avg_samples: %.5f, ips: %.5f ins/s", epoch_id, batch_id,
                             "".join("%s:%.6f, " % kv for kv in vals.items()), float(loss.reshape(-1)[0].item()),
@@ -172,7 +228,7 @@ def train(config, model, device="cuda", kernels=None):
         if dy_model.device.type == "cuda":
             torch.cuda.synchronize(dy_model.device)
         elapsed = time.time() - epoch_begin
-        vals = _metric_values(dy_model_class, metric_list, metric_names)
+        vals = _global_metric_values(dy_model_class, metric_list, metric_names, comm)
         if use_auc:
             _reset(metric_list)
         model_dir = checkpoint.save_model(dy_model, None, save_path, epoch_id, prefix="rec")
@@ -185,27 +241,33 @@ def train(config, model, device="cuda", kernels=None):
 
 
 # -------------------------------------------------------------------------------------------- infer
-def infer(config, model, device="cuda", kernels=None):
+def infer(config, model, device="cuda", kernels=None, comm=None):
     """tools/infer.py main(): for every saved epoch in [infer_start_epoch, infer_end_epoch) load the checkpoint
-    and run the test set; returns one dict per epoch {"epoch", "batches", "samples", <metric>: value}."""
+    and run the test set; returns one dict per epoch {"epoch", "batches", "samples", <metric>: value}.
+    comm: as in train() — test files split over the ranks, sharded lookup, global AUC."""
     dy_model_class = _dygraph_model(model)
     kw = {"kernels": kernels} if kernels is not None else {}
+    world = comm.world if comm is not None else 1
+    if world > 1:
+        kw["comm"] = comm
     dy_model = dy_model_class.create_model(config, device, **kw)
     load_path = config.get("runner.infer_load_path", "model_output")
-    loader = create_data_loader(config, model, dy_model.device, "test")
+    shard = (comm.rank, comm.world) if world > 1 else None
+    loader = create_data_loader(config, model, dy_model.device, "test", shard)
+    limit = _agreed_batches(config, "test", comm, config.get("runner.infer_batch_size")) if world > 1 else None
     use_auc = config.get("runner.use_auc", False)
     metric_list, metric_names = dy_model_class.create_metrics(dy_model.device)
     out = []
     for epoch_id in range(config.get("runner.infer_start_epoch", 0), config.get("runner.infer_end_epoch", 1)):
         checkpoint.load_model(os.path.join(load_path, str(epoch_id)), dy_model, load_optimizer=False)
         n_batches = samples = 0
-        for batch in loader():
+        for batch, _ in _lookahead(loader(), limit):
             metric_list, _ = dy_model_class.infer_forward(dy_model, metric_list, batch, config)
             n_batches += 1
-            samples += _batch_size(batch)
+            samples += _batch_size(batch) * world
         if n_batches == 0:
             raise ValueError("test_dataloader is null, please ensure batch size < dataset size!")
-        vals = _metric_values(dy_model_class, metric_list, metric_names)
+        vals = _global_metric_values(dy_model_class, metric_list, metric_names, comm)
         if use_auc:
             _reset(metric_list)
         logger.info("epoch: %d done, %s", epoch_id, "".join("%s: %.6f," % kv for kv in vals.items()))
@@ -226,12 +288,25 @@ def main(argv=None):
     model = args.model or guess_model(args.config_yaml)
     if model is None:
         raise SystemExit("cannot tell the model from the path of %s: pass --model" % args.config_yaml)
-    if args.infer:
-        for s in infer(config, model, args.device):
+    comm, device = None, args.device
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:          # launched by torch.distributed.run: one process per GPU (runner.use_fleet of the reference)
+        import torch.distributed as dist
+        from .sharded import Comm
+        if device.startswith("cuda"):
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(local)
+            device = "cuda:%d" % local
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group("gloo")
+        comm = Comm()
+    run = infer if args.infer else (lambda *a: train(*a)[0])
+    for s in run(config, model, device, None, comm):
+        if comm is None or comm.rank == 0:
             print(s)
-    else:
-        for s in train(config, model, args.device)[0]:
-            print(s)
+    if comm is not None:
+        comm.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

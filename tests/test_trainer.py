@@ -220,3 +220,67 @@ def test_other_mirrors_through_the_loops_gpu(model, tmp_path, engine_lib):
     assert all(os.path.exists(os.path.join(x["model_dir"], "rec.pdparams")) for x in s)
     r = trainer.infer(cfg, model, "cuda")
     assert [x["epoch"] for x in r] == [0, 1] and all(0.0 <= x["auc"] <= 1.0 and x["samples"] > 0 for x in r)
+
+
+def test_collective_mode_two_ranks_gloo(tmp_path):
+    """tools/trainer.py `use_fleet` mode on the engine: 2 processes (gloo), the data files split over the ranks, tables
+    row-sharded, routing prefetched a step ahead, global loss / AUC, one checkpoint shard per rank, sharded infer —
+    equal to ONE oracle run on the concatenated batches."""
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    from oracle import deepfm_ref as R
+    world, B = 2, 8
+    d = tmp_path / "deepfm"
+    (d / "data" / "train").mkdir(parents=True)
+    lines = _sample_lines(80)
+    for r in range(world):                                         # rank r reads file r (criteo_reader.py:30-43)
+        (d / "data" / "train" / ("part-%d" % r)).write_text("\n".join(lines[r * 40:(r + 1) * 40]) + "\n")
+    (d / "config.yaml").write_text(YAML.format(out=str(tmp_path / "out")).replace("train_batch_size: 16", "train_batch_size: %d" % B)
+                                   .replace("infer_batch_size: 20", "infer_batch_size: 10"))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    worker = os.path.join(REPO, "tests", "_trainer_dist_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), port, str(d)], env=dict(os.environ, OMP_NUM_THREADS="2"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode("utf-8", "replace") for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+    ranks = [dict(np.load(str(d / ("rank%d.npz" % r)))) for r in range(world)]
+    # both ranks report the same GLOBAL numbers
+    for k in ("loss", "auc", "samples", "batches", "infer_auc", "W", "mlp_w0"):
+        assert np.array_equal(ranks[0][k], ranks[1][k]), k
+    assert ranks[0]["samples"].tolist() == [80, 80] and ranks[0]["batches"].tolist() == [5, 5]
+    assert ranks[0]["shard_files"].all() and ranks[1]["shard_files"].all()
+    # oracle: one unsharded run, step i = rank 0's batch i followed by rank 1's batch i
+    g = ranks[0]
+    p = {"W": g["init.W"].copy(), "W1": g["init.W1"].copy(), "dense_w": g["init.fm.dense_w"].copy(),
+         "dense_w_one": g["init.fm.dense_w_one"].copy(),
+         "mlp_w": [g["init.dnn.linear_%d.weight" % i].copy() for i in range(3)],
+         "mlp_b": [g["init.dnn.linear_%d.bias" % i].copy() for i in range(3)]}
+    parsed = [R.parse_slot_line(ln) for ln in lines]
+    lab = np.asarray([a for a, _, _ in parsed], np.int64).reshape(-1, 1)
+    ids = np.stack([b for _, b, _ in parsed])
+    dense = np.stack([c for _, _, c in parsed])
+    tr = OracleTrainer(p, lr=0.01)
+    losses, aucs = [], []
+    for _ in range(2):
+        preds, labs = [], []
+        for i in range(5):
+            sel = np.concatenate([np.arange(r * 40 + i * B, r * 40 + (i + 1) * B) for r in range(world)])
+            loss, pred = tr.train_step(ids[sel], dense[sel], lab[sel])
+            preds.append(pred)
+            labs.append(lab[sel])
+        losses.append(float(loss))
+        aucs.append(_hist_auc(R, preds, labs))
+    np.testing.assert_allclose(g["loss"], losses, rtol=2e-5)
+    np.testing.assert_allclose(g["auc"], aucs, rtol=1e-9, atol=1e-12)
+    touched = np.unique(ids)
+    assert np.abs(g["W"][touched] - tr.p["W"][touched]).max() <= 1e-4
+    assert np.abs(g["mlp_w0"] - tr.p["mlp_w"][0]).max() <= 1e-4
+    assert g["infer_samples"].tolist() == [80, 80]
+    final_pred = R.deepfm_forward(ids, dense, tr.p)[0]
+    np.testing.assert_allclose(g["infer_auc"][-1], _hist_auc(R, [final_pred], [lab]), rtol=1e-9, atol=1e-12)
