@@ -36,6 +36,14 @@ class Comm:
         self.rank = dist.get_rank(self.group)
         self.world = dist.get_world_size(self.group)
         self.staged = dist.get_backend(self.group) != "nccl"
+        # The dense all-reduce (main stream) runs concurrently with the exchange all-to-alls (side stream).  RCCL
+        # collectives of ONE communicator must execute in the same order on every rank, which two streams do not
+        # guarantee (torch issues a blocking collective on the caller's current stream) — so the dense collectives
+        # get a communicator of their own.  new_group is itself collective: every rank constructs its Comm at the
+        # same point of the program.
+        self.dense_group = self.group
+        if self.world > 1:
+            self.dense_group = dist.new_group(ranks=dist.get_process_group_ranks(self.group))
 
     def exchange_counts(self, send_counts):
         """send_counts[d] = entries this rank sends to d  ->  recv_counts[s] = entries s sends here."""
@@ -63,21 +71,23 @@ class Comm:
         return out
 
     def broadcast(self, t, src=0):
+        g = self.dense_group
         if self.staged and t.is_cuda:
             h = t.cpu()
-            self.dist.broadcast(h, src=self.dist.get_global_rank(self.group, src), group=self.group)
+            self.dist.broadcast(h, src=self.dist.get_global_rank(g, src), group=g)
             t.copy_(h)
         else:
-            self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, src), group=self.group)
+            self.dist.broadcast(t, src=self.dist.get_global_rank(g, src), group=g)
         return t
 
     def all_reduce_sum(self, t):
+        g = self.dense_group
         if self.staged and t.is_cuda:
             h = t.cpu()
-            self.dist.all_reduce(h, group=self.group)
+            self.dist.all_reduce(h, group=g)
             t.copy_(h)
         else:
-            self.dist.all_reduce(t, group=self.group)
+            self.dist.all_reduce(t, group=g)
         return t
 
 
