@@ -36,14 +36,9 @@ class Comm:
         self.rank = dist.get_rank(self.group)
         self.world = dist.get_world_size(self.group)
         self.staged = dist.get_backend(self.group) != "nccl"
-        # The dense all-reduce (main stream) runs concurrently with the exchange all-to-alls (side stream).  RCCL
-        # collectives of ONE communicator must execute in the same order on every rank, which two streams do not
-        # guarantee (torch issues a blocking collective on the caller's current stream) — so the dense collectives
-        # get a communicator of their own.  new_group is itself collective: every rank constructs its Comm at the
-        # same point of the program.
-        self.dense_group = self.group
-        if self.world > 1:
-            self.dense_group = dist.new_group(ranks=dist.get_process_group_ranks(self.group))
+        # ONE communicator: RCCL collectives of a communicator must execute in the same order on every rank, and
+        # torch issues a blocking collective on the caller's current stream — so every collective of a training
+        # step is issued on ONE stream (the side stream) or behind a stream wait on it (see train_step).
 
     def exchange_counts(self, send_counts):
         """send_counts[d] = entries this rank sends to d  ->  recv_counts[s] = entries s sends here."""
@@ -71,7 +66,7 @@ class Comm:
         return out
 
     def broadcast(self, t, src=0):
-        g = self.dense_group
+        g = self.group
         if self.staged and t.is_cuda:
             h = t.cpu()
             self.dist.broadcast(h, src=self.dist.get_global_rank(g, src), group=g)
@@ -81,7 +76,7 @@ class Comm:
         return t
 
     def all_reduce_sum(self, t):
-        g = self.dense_group
+        g = self.group
         if self.staged and t.is_cuda:
             h = t.cpu()
             self.dist.all_reduce(h, group=g)
@@ -354,7 +349,15 @@ class ShardedDeepFMLayer(DeepFMLayer):
             with self._timed("mlp_bwd_dw0"):
                 finish_dw0()
                 self._fold_backward()
-        self.comm.all_reduce_sum(self.dense.grad)                # one bucket: dense grads + loss
+        # one bucket: dense grads + loss.  Issued on the side stream, behind the exchange all-to-alls already queued
+        # there and behind the dW GEMMs of the main stream: all collectives of the step stay totally ordered.
+        if on_gpu:
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                self.comm.all_reduce_sum(self.dense.grad)
+            cur.wait_stream(self._side)
+        else:
+            self.comm.all_reduce_sum(self.dense.grad)
         loss = loss_slot.clone()
         loss_slot.zero_()                                         # not a parameter: keep Adam off it
         k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
