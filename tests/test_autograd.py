@@ -1,0 +1,52 @@
+"""torch.autograd adapter (paddlerec_amd/autograd.py): the fused FM block inside a torch autograd graph reproduces
+the reference's own autograd gradients (tests/golden/deepfm_D*.npz = unmodified deepfm/net.py over the paddle shim),
+including the SelectedRows-style sparse table gradients.  CPU: oracle-backed operator stand-in (plumbing only);
+`-m gpu`: the HIP kernels."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+
+
+def _run(name, device, kernels, rtol, atol):
+    from paddlerec_amd.autograd import deepfm_fm
+    g = load_golden(name)
+    T = lambda a, grad=False: torch.as_tensor(np.ascontiguousarray(a)).to(device).requires_grad_(grad)
+    W, W1 = T(g["W"], True), T(g["W1"], True)
+    dense_w, dense_w_one = T(g["dense_w"], True), T(g["dense_w_one"], True)
+    n = int(g["n_mlp"])
+    mw = [T(g["mlp_w%d" % i], True) for i in range(n)]
+    mb = [T(g["mlp_b%d" % i], True) for i in range(n)]
+    y1, y2, feat = deepfm_fm(T(g["ids"]), T(g["dense"]), W, W1, dense_w, dense_w_one, 0, kernels)
+    x = feat.flatten(1)
+    for i in range(n):                                   # deepfm/net.py:142-174 (Paddle Linear: x @ W[in,out] + b)
+        x = x @ mw[i] + mb[i]
+        if i < n - 1:
+            x = torch.relu(x)
+    pred = torch.sigmoid(y1 + y2 + x)
+    t = T(g["label"]).to(torch.float32)
+    eps = 1e-4                                           # paddle.nn.functional.log_loss default epsilon (App. B-4)
+    loss = (-t * torch.log(pred + eps) - (1 - t) * torch.log(1 - pred + eps)).mean()
+    loss.backward()
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["pred"], rtol=rtol)
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=rtol)
+    assert W.grad.is_sparse and W1.grad.is_sparse        # SelectedRows, not a dense [N,D] gradient
+    assert W.grad._nnz() == int((g["ids"] != 0).sum())   # unmerged: one row per non-padding lookup
+    for got, want in ((W.grad.coalesce().to_dense(), g["gW"]), (W1.grad.coalesce().to_dense(), g["gW1"]),
+                      (dense_w.grad, g["g_dense_w"]), (dense_w_one.grad, g["g_dense_w_one"]),
+                      (mw[0].grad, g["g_mlp_w0"]), (mb[n - 1].grad, g["g_mlp_b%d" % (n - 1)])):
+        np.testing.assert_allclose(got.cpu().numpy().reshape(want.shape), want, rtol=rtol, atol=atol)
+    assert float(W.grad.coalesce().to_dense()[0].abs().max()) == 0.0       # padding row gets no gradient
+
+
+@pytest.mark.parametrize("name", ["deepfm_D9", "deepfm_D16"])
+def test_autograd_adapter_plumbing_cpu_backend(name):
+    import cpu_kernels
+    _run(name, "cpu", cpu_kernels, 2e-6, 1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["deepfm_D9", "deepfm_D16"])
+def test_autograd_adapter_gpu(name, engine_lib):
+    _run(name, "cuda", None, 2e-5, 2e-7)
