@@ -59,19 +59,105 @@ def emb_gather(ids, W, padding_idx=None, status=None, out=None, out_group=0, out
 
 def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux0=None, aux1=None, out=None,
          split_k=0, b_colsum=None, row_scale=None, out2=None, num_cus=0):
+    """NumPy statement of rec_gemm_f32 and its epilogues (include/recengine.h: rec_epilogue)."""
     a = _n(A).T if trans_a else _n(A)
     b = _n(B).T if trans_b else _n(B)
-    c = a @ b
-    if epilogue in ("bias", "bias_relu"):
-        c = c + _n(bias).reshape(1, -1)
-        if epilogue == "bias_relu":
-            c = np.maximum(c, 0)
-    elif epilogue != "none":
+    acc = (a.astype(np.float64) @ b.astype(np.float64)).astype(np.float32)
+    bv = _n(bias).reshape(1, -1) if bias is not None else np.float32(0)
+    a0 = _n(aux0) if aux0 is not None else None
+    a1 = _n(aux1) if aux1 is not None else None
+    if epilogue == "none":
+        c = acc
+    elif epilogue == "bias":
+        c = acc + bv
+    elif epilogue == "bias_relu":
+        c = np.maximum(acc + bv, 0)
+    elif epilogue == "relu_mask":
+        c = np.where(a0 > 0, acc, 0)
+    elif epilogue == "cross":
+        u = acc + bv
+        c = a1 + a0 * u
+        if out2 is not None:
+            out2.copy_(torch.from_numpy(np.ascontiguousarray(u, dtype=np.float32)))
+    elif epilogue == "bias_sigmoid":
+        c = R.sigmoid(acc + bv)
+    elif epilogue == "bias_tanh":
+        c = np.tanh(acc + bv)
+    elif epilogue == "add":
+        c = acc + a1 + bv + (a0 if a0 is not None else 0)
+    elif epilogue == "dtanh":
+        c = acc * (1 - a0 * a0)
+    elif epilogue == "dsigmoid":
+        c = acc * a0 * (1 - a0)
+    elif epilogue == "moe":
+        c = a1 + a0 * _n(row_scale).reshape(-1, 1) * (acc + bv)
+    else:
         raise NotImplementedError(epilogue)
     if b_colsum is not None:
-        b_colsum.copy_(torch.from_numpy(_n(B).sum(axis=0, dtype=np.float32)).reshape(b_colsum.shape))
+        b_colsum.copy_(torch.from_numpy(b.sum(axis=0, dtype=np.float32)).reshape(b_colsum.shape))
     r = torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32))
     return r if out is None else out.copy_(r)
+
+
+def cross_bwd_prep(dX, X0, U, dU, dX0_acc, accumulate):
+    dx, x0, u = _n(dX), _n(X0), _n(U)
+    dU.copy_(torch.from_numpy(dx * x0))
+    acc = _n(dX0_acc).copy() if accumulate else 0
+    dX0_acc.copy_(torch.from_numpy((acc + dx * u).astype(np.float32)))
+
+
+def moe_bwd_prep(dX, X0, U, prob_e, dU, dX0_acc, accumulate, dp_e):
+    dx, x0, u, pe = _n(dX), _n(X0), _n(U), _n(prob_e).reshape(-1, 1)
+    dU.copy_(torch.from_numpy(dx * x0 * pe))
+    acc = _n(dX0_acc).copy() if accumulate else 0
+    dX0_acc.copy_(torch.from_numpy((acc + dx * pe * u).astype(np.float32)))
+    dp_e.copy_(torch.from_numpy((dx * x0 * u).sum(axis=1, dtype=np.float32)))
+
+
+def softmax_rows(x, out=None):
+    z = _n(x)
+    e = np.exp(z - z.max(axis=1, keepdims=True))
+    r = torch.from_numpy((e / e.sum(axis=1, keepdims=True)).astype(np.float32))
+    return r if out is None else out.copy_(r)
+
+
+def softmax_rows_bwd(p, dp, out=None):
+    pn, dpn = _n(p), _n(dp)
+    r = torch.from_numpy((pn * (dpn - (pn * dpn).sum(axis=1, keepdims=True))).astype(np.float32))
+    return r if out is None else out.copy_(r)
+
+
+def sumsq(x, out, ws, accumulate=False):
+    v = np.float32((_n(x).astype(np.float64) ** 2).sum())
+    out.copy_(torch.tensor([v + (float(out[0]) if accumulate else 0.0)], dtype=torch.float32))
+    return out
+
+
+def _merged_rows(groups, grad, D, grad_div=1, grad_group=0, grad_group_stride=0):
+    if grad_group > 0:
+        g = np.ascontiguousarray(grad.numpy().reshape(-1, grad_group_stride)[:, : grad_group * D]).reshape(-1, D)
+    else:
+        g = grad.numpy().reshape(-1, D)
+    merged = np.zeros((len(groups.uniq), D), np.float32)
+    for u in range(len(groups.uniq)):
+        acc = np.zeros(D, np.float32)
+        for kk in range(groups.offs[u], groups.offs[u + 1]):
+            acc = acc + g[groups.spos[kk] // grad_div]
+        merged[u] = acc
+    return merged
+
+
+def sparse_rows_sumsq(groups, grad, D, out, ws, accumulate=False, grad_div=1, grad_group=0, grad_group_stride=0,
+                      partials=None):
+    m = _merged_rows(groups, grad, D, grad_div, grad_group, grad_group_stride)
+    v = np.float32((m.astype(np.float64) ** 2).sum())
+    out.copy_(torch.tensor([v + (float(out[0]) if accumulate else 0.0)], dtype=torch.float32))
+    return out
+
+
+def clip_scale(sumsq_t, clip_norm, out):
+    out.copy_(torch.tensor([clip_norm / max(float(np.sqrt(float(sumsq_t[0]))), clip_norm)], dtype=torch.float32))
+    return out
 
 
 def deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, padding_idx=0, slot_offset=None,
@@ -107,7 +193,7 @@ def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, d
 
 
 def sigmoid_logloss(y1, y2, y_dnn, label, ws, eps=1e-4, want_dz=True, out=None, mean_over=0):
-    z = _n(y1) + _n(y2) + _n(y_dnn)
+    z = sum(_n(t) for t in (y1, y2, y_dnn) if t is not None)         # NULL addends are allowed by the entry point
     p = R.sigmoid(z).astype(np.float32)
     t = _n(label).astype(np.float32)
     B = p.shape[0]
@@ -126,8 +212,9 @@ def colsum(G, ws, out=None):
     return r if out is None else out.copy_(r.reshape(out.shape))
 
 
-def adam_dense(p, m, v, g, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
-    R.adam_update(p.numpy(), m.numpy(), v.numpy(), g.numpy(), step, lr, beta1, beta2, eps)
+def adam_dense(p, m, v, g, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=None):
+    gn = g.numpy() if grad_scale is None else g.numpy() * np.float32(float(grad_scale[0]))
+    R.adam_update(p.numpy(), m.numpy(), v.numpy(), gn, step, lr, beta1, beta2, eps)
 
 
 class IdGroups:
@@ -147,17 +234,9 @@ def segment_partials(groups, grad, D, grad_div=1, grad_group=0, grad_group_strid
 
 def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
                      partials=None, grad_group=0, grad_group_stride=0, grad_scale=None):
-    D = P.shape[1]
-    if grad_group > 0:     # rec_grad_layout{1, group, stride}: the first group*D columns of a [B, stride] buffer
-        g = np.ascontiguousarray(grad.numpy().reshape(-1, grad_group_stride)[:, : grad_group * D]).reshape(-1, D)
-    else:
-        g = grad.numpy().reshape(-1, D)
-    merged = np.zeros((len(groups.uniq), P.shape[1]), np.float32)
-    for u in range(len(groups.uniq)):
-        acc = np.zeros(P.shape[1], np.float32)
-        for kk in range(groups.offs[u], groups.offs[u + 1]):
-            acc = acc + g[groups.spos[kk] // grad_div]
-        merged[u] = acc
+    merged = _merged_rows(groups, grad, P.shape[1], grad_div, grad_group, grad_group_stride)
+    if grad_scale is not None:
+        merged = merged * np.float32(float(grad_scale[0]))
     R.adam_update_rows(P.numpy(), M.numpy(), V.numpy(), groups.uniq, merged, step, lr=lr, beta1=beta1,
                        beta2=beta2, eps=eps)
 
@@ -168,14 +247,16 @@ def auc_histogram(pred, label, stat_pos, stat_neg, num_thresholds=4095):
     stat_neg += torch.from_numpy(neg)
 
 
-def mlp_forward(x, weights, biases, ws):
+def mlp_forward(x, weights, biases, ws, relu_last=False, out_last=None):
     acts = []
     n = len(weights)
     for i in range(n):
         acts.append(x)
         x = torch.addmm(biases[i], x, weights[i])
-        if i < n - 1:
+        if i < n - 1 or relu_last:
             x = torch.relu_(x)
+        if i == n - 1 and out_last is not None:
+            x = out_last.copy_(x)
     return x, acts + [x]
 
 
