@@ -372,13 +372,14 @@ class DCN_V2Layer:
 class DygraphModel:
     """dcn_v2/dygraph_model.py:24-140 — same method names; tensors are torch device tensors."""
 
-    def create_model(self, config, device="cuda"):
+    def create_model(self, config, device="cuda", kernels=None):
         g = config.get
         return DCN_V2Layer(g("hyper_parameters.sparse_feature_number"), g("hyper_parameters.sparse_feature_dim"),
                            g("hyper_parameters.dense_input_dim"), g("hyper_parameters.sparse_inputs_slots") - 1,
                            g("hyper_parameters.fc_sizes"), g("hyper_parameters.cross_num"),
                            g("hyper_parameters.is_Stacked", None), g("hyper_parameters.use_low_rank_mixture", None),
-                           g("hyper_parameters.low_rank", 32), g("hyper_parameters.num_experts", 4), device=device)
+                           g("hyper_parameters.low_rank", 32), g("hyper_parameters.num_experts", 4), device=device,
+                           kernels=kernels)
 
     def create_feeds(self, batch_data, config, device="cuda"):
         return slot_feeds(batch_data, config, device)
@@ -397,6 +398,6 @@ class DygraphModel:
         label, sparse, dense = self.create_feeds(batch_data, config, dy_model.device)
         pred = dy_model.forward(sparse, dense)
         if metrics_list:
-            ops.auc_histogram(pred.contiguous(), label.contiguous(), metrics_list[0][0], metrics_list[0][1],
-                              NUM_THRESHOLDS)
+            dy_model.k.auc_histogram(pred.contiguous(), label.contiguous(), metrics_list[0][0], metrics_list[0][1],
+                                     NUM_THRESHOLDS)
         return metrics_list, None

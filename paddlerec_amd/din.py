@@ -28,8 +28,9 @@ class DINLayer:
     """din/net.py:20-184.  forward(...) -> logit [B,1]."""
 
     def __init__(self, item_emb_size, cat_emb_size, act, is_sparse, use_DataLoader, item_count, cat_count,
-                 device="cuda"):
+                 device="cuda", kernels=None):
         self.device = torch.device(device)
+        self.k = kernels if kernels is not None else ops     # tests may inject a stand-in backend (host logic only)
         self.item_emb_size, self.cat_emb_size = item_emb_size, cat_emb_size
         self.item_count, self.cat_count = item_count, cat_count
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -56,8 +57,8 @@ class DINLayer:
             self.params["linear_%d.weight" % i] = _xavier_uniform_(torch.empty(con[i], con[i + 1], **f32),
                                                                    con[i], con[i + 1])
             self.params["linear_%d.bias" % i] = torch.zeros(con[i + 1], **f32)
-        self.ws = ops.Workspace(self.device)
-        self.status = ops.new_status(self.device)
+        self.ws = self.k.Workspace(self.device)
+        self.status = self.k.new_status(self.device)
 
     def state_dict(self):
         return dict(self.params)
@@ -75,23 +76,23 @@ class DINLayer:
         p, E = self.params, self.firInDim
         B, T = hist_item_seq.shape
         mask2 = mask.reshape(B, T).contiguous()
-        pooled, attw, _ = ops.din_attention_pool(
+        pooled, attw, _ = self.k.din_attention_pool(
             hist_item_seq, hist_cat_seq, target_item_seq, target_cat_seq, mask2,
             p["hist_item_emb_attr.weight"], p["hist_cat_emb_attr.weight"],
             p["target_item_seq_emb_attr.weight"], p["target_cat_seq_emb_attr.weight"],
             self.attention_w, self.attention_b, self.status, want_weights=_keep is not None)  # net.py:141-173
         emb = torch.empty(B, 2 * E, dtype=torch.float32, device=self.device)           # net.py:178
-        ops.gemm(pooled, p["linearCon.weight"], self.ws, epilogue="bias", bias=p["linearCon.bias"],
+        self.k.gemm(pooled, p["linearCon.weight"], self.ws, epilogue="bias", bias=p["linearCon.bias"],
                  out=emb[:, :E])                                                         # net.py:175-176
         ti, tc = target_item.reshape(-1).contiguous(), target_cat.reshape(-1).contiguous()
-        ops.emb_gather(ti, p["target_item_emb_attr.weight"], None, self.status, out=emb[:, E:],
+        self.k.emb_gather(ti, p["target_item_emb_attr.weight"], None, self.status, out=emb[:, E:],
                        out_group=1, out_group_stride=2 * E)                              # net.py:143,152
-        ops.emb_gather(tc, p["target_cat_emb_attr.weight"], None, self.status,
+        self.k.emb_gather(tc, p["target_cat_emb_attr.weight"], None, self.status,
                        out=emb[:, E + self.item_emb_size:], out_group=1, out_group_stride=2 * E)
-        item_b, _ = ops.emb_gather(ti, p["item_b_attr.weight"], None, self.status)      # net.py:147
-        x1 = ops.gemm(emb, p["linear_0.weight"], self.ws, epilogue="bias_sigmoid", bias=p["linear_0.bias"])
-        x2 = ops.gemm(x1, p["linear_1.weight"], self.ws, epilogue="bias_sigmoid", bias=p["linear_1.bias"])
-        logit = ops.gemm(x2, p["linear_2.weight"], self.ws, epilogue="add", bias=p["linear_2.bias"],
+        item_b, _ = self.k.emb_gather(ti, p["item_b_attr.weight"], None, self.status)      # net.py:147
+        x1 = self.k.gemm(emb, p["linear_0.weight"], self.ws, epilogue="bias_sigmoid", bias=p["linear_0.bias"])
+        x2 = self.k.gemm(x1, p["linear_1.weight"], self.ws, epilogue="bias_sigmoid", bias=p["linear_1.bias"])
+        logit = self.k.gemm(x2, p["linear_2.weight"], self.ws, epilogue="add", bias=p["linear_2.bias"],
                          aux1=item_b)                                                    # net.py:180-183
         if _keep is not None:
             _keep.update(attw=attw, pooled=pooled, emb=emb, x1=x1, x2=x2, ti=ti, tc=tc)
@@ -110,12 +111,12 @@ class DINLayer:
         key = n
         grp = self._groups.get(key)
         if grp is None:
-            grp = self._groups[key] = ops.IdGroups(n, self.device)
-        ops.ids_group(ids.reshape(-1), table.shape[0], None, self.ws_group, None, self.status, grp)
-        pp = self._partials[key, table.shape[1]] = ops.segment_partials(grp, grad_view, table.shape[1], grad_group=1,
+            grp = self._groups[key] = self.k.IdGroups(n, self.device)
+        self.k.ids_group(ids.reshape(-1), table.shape[0], None, self.ws_group, None, self.status, grp)
+        pp = self._partials[key, table.shape[1]] = self.k.segment_partials(grp, grad_view, table.shape[1], grad_group=1,
                                                         grad_group_stride=row_stride_floats,
                                                         out=self._partials.get((key, table.shape[1])))   # popular items: hot rows
-        ops.sparse_sgd_rows(grp, grad_view, table, lr, grad_group=1, grad_group_stride=row_stride_floats,
+        self.k.sparse_sgd_rows(grp, grad_view, table, lr, grad_group=1, grad_group_stride=row_stride_floats,
                             partials=pp)
 
     def train_step(self, hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq,
@@ -123,7 +124,7 @@ class DINLayer:
         """din/dygraph_model.py:85-100 train_forward + backward + SGD step.  label float32 [B,1].
         Returns (loss [1], pred [B,1])."""
         if not hasattr(self, "_groups"):
-            self._groups, self._partials, self.ws_group, self.step_count = {}, {}, ops.Workspace(self.device), 0
+            self._groups, self._partials, self.ws_group, self.step_count = {}, {}, self.k.Workspace(self.device), 0
         p, E, Ei = self.params, self.firInDim, self.item_emb_size
         B, T = hist_item_seq.shape
         lr = self.learning_rate(self.step_count, base_lr)
@@ -131,23 +132,23 @@ class DINLayer:
         sv = {}
         logit = self.forward(hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask,
                              target_item_seq, target_cat_seq, _keep=sv)
-        pred, dz, loss = ops.bce_with_logits(logit, label.reshape(B, 1).contiguous(), self.ws)
+        pred, dz, loss = self.k.bce_with_logits(logit, label.reshape(B, 1).contiguous(), self.ws)
         g = {}
         ws = self.ws
 
         def lin_bwd(name, x, dy, act=None):
             """dW, db of Linear `name` (input x, output-gradient dy); returns d x (sigmoid' of x fused when act)."""
-            g[name + ".weight"] = ops.gemm(x, dy, ws, trans_a=True, b_colsum=self._gbuf(name + ".bias"))
+            g[name + ".weight"] = self.k.gemm(x, dy, ws, trans_a=True, b_colsum=self._gbuf(name + ".bias"))
             g[name + ".bias"] = self._gbuf(name + ".bias")
             if act is None:
-                return ops.gemm(dy, p[name + ".weight"], ws, trans_b=True)
-            return ops.gemm(dy, p[name + ".weight"], ws, trans_b=True, epilogue="dsigmoid", aux0=act)
+                return self.k.gemm(dy, p[name + ".weight"], ws, trans_b=True)
+            return self.k.gemm(dy, p[name + ".weight"], ws, trans_b=True, epilogue="dsigmoid", aux0=act)
 
         d2 = lin_bwd("linear_2", sv["x2"], dz, act=sv["x2"])
         d1 = lin_bwd("linear_1", sv["x1"], d2, act=sv["x1"])
         de0 = lin_bwd("linear_0", sv["emb"], d1)                       # [B, 2E] = [d linearCon out | d target_concat]
         dpooled = lin_bwd("linearCon", sv["pooled"], de0[:, :E])
-        dh, dq = ops.din_attention_pool_bwd(
+        dh, dq = self.k.din_attention_pool_bwd(
             hist_item_seq, hist_cat_seq, target_item_seq, target_cat_seq,
             p["hist_item_emb_attr.weight"], p["hist_cat_emb_attr.weight"],
             p["target_item_seq_emb_attr.weight"], p["target_cat_seq_emb_attr.weight"],
@@ -162,8 +163,8 @@ class DINLayer:
         self._sgd_rows(sv["tc"], de0[:, E + Ei:], p["target_cat_emb_attr.weight"], lr, 2 * E)
         self._sgd_rows(sv["ti"], dz, p["item_b_attr.weight"], lr, 1)
         for name in ("linear_0", "linear_1", "linear_2", "linearCon"):
-            ops.sgd_dense(p[name + ".weight"], g[name + ".weight"], lr)
-            ops.sgd_dense(p[name + ".bias"], g[name + ".bias"], lr)
+            self.k.sgd_dense(p[name + ".weight"], g[name + ".weight"], lr)
+            self.k.sgd_dense(p[name + ".bias"], g[name + ".bias"], lr)
         return loss, pred
 
     def _gbuf(self, name):
@@ -181,12 +182,12 @@ NUM_THRESHOLDS = 4095  # paddle.metric.Auc default [EXT]
 class DygraphModel:
     """din/dygraph_model.py:21-113 — same method names; tensors are torch device tensors."""
 
-    def create_model(self, config, device="cuda"):
+    def create_model(self, config, device="cuda", kernels=None):
         g = config.get
         return DINLayer(g("hyper_parameters.item_emb_size", 64), g("hyper_parameters.cat_emb_size", 64),
                         g("hyper_parameters.act", "sigmoid"), g("hyper_parameters.is_sparse", False),
                         g("hyper_parameters.use_DataLoader", False), g("hyper_parameters.item_count", 63001),
-                        g("hyper_parameters.cat_count", 801), device=device)
+                        g("hyper_parameters.cat_count", 801), device=device, kernels=kernels)
 
     def create_feeds(self, batch, config, device="cuda"):
         t = [torch.as_tensor(x).to(device) for x in batch]
@@ -198,20 +199,20 @@ class DygraphModel:
                  torch.zeros(NUM_THRESHOLDS + 1, dtype=torch.int64, device=device))
         return [stats], ["auc"]
 
-    def _auc(self, metrics_list, pred, label):
+    def _auc(self, dy_model, metrics_list, pred, label):
         if metrics_list:
-            ops.auc_histogram(pred.contiguous(), label.to(torch.int64).contiguous(), metrics_list[0][0],
+            dy_model.k.auc_histogram(pred.contiguous(), label.to(torch.int64).contiguous(), metrics_list[0][0],
                               metrics_list[0][1], NUM_THRESHOLDS)
 
     def train_forward(self, dy_model, metrics_list, batch_data, config):
         feeds = self.create_feeds(batch_data, config, dy_model.device)
         base_lr = config.get("hyper_parameters.optimizer.learning_rate_base_lr")
         loss, pred = dy_model.train_step(*feeds, base_lr=base_lr)
-        self._auc(metrics_list, pred, feeds[4])
+        self._auc(dy_model, metrics_list, pred, feeds[4])
         return loss, metrics_list, {"loss": loss}
 
     def infer_forward(self, dy_model, metrics_list, batch_data, config):
         feeds = self.create_feeds(batch_data, config, dy_model.device)
         pred = torch.sigmoid(dy_model.forward(*feeds))
-        self._auc(metrics_list, pred, feeds[4])
+        self._auc(dy_model, metrics_list, pred, feeds[4])
         return metrics_list, None

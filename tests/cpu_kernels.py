@@ -49,9 +49,10 @@ def emb_gather(ids, W, padding_idx=None, status=None, out=None, out_group=0, out
     res = torch.from_numpy(R.embedding_lookup(_n(W), _n(ids).reshape(-1, 1), padding_idx)[:, 0, :])
     if out is None:
         return res, status
-    if out_group > 0:          # lookup i -> out + (i // group) * stride + (i % group) * D
+    if out_group > 0:          # lookup i -> out + (i // group) * stride + (i % group) * D  (out may be a strided view)
         n, D = res.shape
-        out.view(-1, out_group_stride)[:, : out_group * D].copy_(res.reshape(n // out_group, out_group * D))
+        torch.as_strided(out, (n // out_group, out_group * D), (out_group_stride, 1), out.storage_offset()) \
+            .copy_(res.reshape(n // out_group, out_group * D))
         return out, status
     out.view(res.shape).copy_(res)
     return out, status
@@ -134,17 +135,86 @@ def sumsq(x, out, ws, accumulate=False):
 
 
 def _merged_rows(groups, grad, D, grad_div=1, grad_group=0, grad_group_stride=0):
+    """Sum of the duplicate gradient rows of every unique id, rows addressed through rec_grad_layout: position pos ->
+    q = pos // div; offset = group > 0 ? (q // group) * stride + (q % group) * D : q * D (from the view's first element)."""
     if grad_group > 0:
-        g = np.ascontiguousarray(grad.numpy().reshape(-1, grad_group_stride)[:, : grad_group * D]).reshape(-1, D)
+        base = grad.storage_offset()
+        flat = torch.as_strided(grad, (grad.untyped_storage().nbytes() // 4 - base,), (1,), base).numpy()
+        row = lambda q: flat[(q // grad_group) * grad_group_stride + (q % grad_group) * D:][:D]
     else:
         g = grad.numpy().reshape(-1, D)
+        row = lambda q: g[q]
     merged = np.zeros((len(groups.uniq), D), np.float32)
     for u in range(len(groups.uniq)):
         acc = np.zeros(D, np.float32)
         for kk in range(groups.offs[u], groups.offs[u + 1]):
-            acc = acc + g[groups.spos[kk] // grad_div]
+            acc = acc + row(int(groups.spos[kk]) // grad_div)
         merged[u] = acc
     return merged
+
+
+def sparse_sgd_rows(groups, grad, P, lr, grad_div=1, grad_group=0, grad_group_stride=0, partials=None):
+    merged = _merged_rows(groups, grad, P.shape[1], grad_div, grad_group, grad_group_stride)
+    Pn = P.numpy()
+    Pn[groups.uniq] = Pn[groups.uniq] - np.float32(lr) * merged
+
+
+def sgd_dense(p, g, lr):
+    p.sub_(g.reshape(p.shape) * float(lr))
+
+
+def bce_with_logits(logit, label, ws):
+    """binary_cross_entropy_with_logits(reduction='mean') (din/dygraph_model.py:58-61) -> (pred, dz, loss)."""
+    from oracle import din_ref
+    z, t = _n(logit).astype(np.float32), _n(label).astype(np.float32)
+    pred = din_ref.sigmoid(z).astype(np.float32)
+    dz = ((pred - t) / np.float32(z.shape[0])).astype(np.float32)
+    loss = np.float32(din_ref.bce_with_logits_mean(z, t))
+    f = torch.from_numpy
+    return f(pred), f(dz), torch.tensor([loss], dtype=torch.float32)
+
+
+def _din_hq(hist_item, hist_cat, tis, tcs, w_hi, w_hc, w_ti, w_tc):
+    h = np.concatenate([_n(w_hi)[_n(hist_item)], _n(w_hc)[_n(hist_cat)]], axis=2)
+    q = np.concatenate([_n(w_ti)[_n(tis)], _n(w_tc)[_n(tcs)]], axis=2)
+    return h, q
+
+
+def din_attention_pool(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, mask, w_hist_item, w_hist_cat,
+                       w_tgt_item_seq, w_tgt_cat_seq, att_w, att_b, status=None, want_weights=True):
+    from oracle import din_ref
+    h, q = _din_hq(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_hist_item, w_hist_cat, w_tgt_item_seq,
+                   w_tgt_cat_seq)
+    out, w = din_ref.attention_pool(h, q, _n(mask).astype(np.float32), [_n(x) for x in att_w], [_n(x) for x in att_b],
+                                    return_weights=True)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return f(out), (f(w) if want_weights else None), status
+
+
+def din_attention_pool_bwd(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_hist_item, w_hist_cat, w_tgt_item_seq,
+                           w_tgt_cat_seq, att_w, att_b, att_weight, d_out):
+    """d h, d q of the attention-pool given the forward's softmax weights (oracle/din_ref.py:66-90 with p = att_weight;
+    the attention MLP's own gradients are not produced, App. B-9)."""
+    from oracle import din_ref
+    h, q = _din_hq(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_hist_item, w_hist_cat, w_tgt_item_seq,
+                   w_tgt_cat_seq)
+    aw, ab = [_n(x) for x in att_w], [_n(x) for x in att_b]
+    E = h.shape[2]
+    x = np.concatenate([h, q, h - q, h * q], axis=2)
+    a1 = din_ref.sigmoid(x @ aw[0] + ab[0])
+    a2 = din_ref.sigmoid(a1 @ aw[1] + ab[1])
+    pw, dout = _n(att_weight), _n(d_out)
+    dp = (h * dout[:, None, :]).sum(axis=2)
+    dh = pw[..., None] * dout[:, None, :]
+    ds = pw * (dp - (pw * dp).sum(axis=1, keepdims=True))
+    dl = (ds * np.float32(E ** -0.5))[..., None]
+    dz2 = (dl @ aw[2].T) * a2 * (1 - a2)
+    dz1 = (dz2 @ aw[1].T) * a1 * (1 - a1)
+    dx = dz1 @ aw[0].T
+    dh = dh + dx[..., :E] + dx[..., 2 * E:3 * E] + dx[..., 3 * E:] * q
+    dq = dx[..., E:2 * E] - dx[..., 2 * E:3 * E] + dx[..., 3 * E:] * h
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return f(dh), f(dq)
 
 
 def sparse_rows_sumsq(groups, grad, D, out, ws, accumulate=False, grad_div=1, grad_group=0, grad_group_stride=0,

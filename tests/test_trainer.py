@@ -192,11 +192,7 @@ def test_reference_yaml_and_sample_data_run_unchanged(tmp_path):
     assert r[0]["samples"] == 80 and r[0]["batches"] == 16 and 0.0 <= r[0]["auc"] <= 1.0
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("model", ["dcn_v2", "din"])
-def test_other_mirrors_through_the_loops_gpu(model, tmp_path, engine_lib):
-    """DCN-v2 (slot text, log1p dense, ClipGradByGlobalNorm) and DIN (dinReader format, SGD) through the same
-    train / checkpoint / infer loops on the reference's own sample lines (tests/golden)."""
+def _other_mirrors(model, tmp_path, device, kernels):
     import shutil
     from paddlerec_amd import trainer
     d = tmp_path / "models" / "rank" / model
@@ -215,11 +211,32 @@ def test_other_mirrors_through_the_loops_gpu(model, tmp_path, engine_lib):
            "hyper_parameters.item_emb_size": 64, "hyper_parameters.cat_emb_size": 64,
            "hyper_parameters.item_count": 63001, "hyper_parameters.cat_count": 801,
            "hyper_parameters.optimizer.learning_rate_base_lr": 0.85}
-    s, net = trainer.train(cfg, model, "cuda")
+    s, net = trainer.train(cfg, model, device, kernels)
     assert [x["epoch"] for x in s] == [0, 1] and all(np.isfinite(x["loss"]) and x["batches"] >= 3 for x in s)
     assert all(os.path.exists(os.path.join(x["model_dir"], "rec.pdparams")) for x in s)
-    r = trainer.infer(cfg, model, "cuda")
+    r = trainer.infer(cfg, model, device, kernels)
     assert [x["epoch"] for x in r] == [0, 1] and all(0.0 <= x["auc"] <= 1.0 and x["samples"] > 0 for x in r)
+    # the epoch-1 checkpoint holds the trained parameters: a fresh model loaded from it predicts like `net`
+    from paddlerec_amd import checkpoint
+    dm = trainer._dygraph_model(model)
+    fresh = dm.create_model(cfg, device, **({"kernels": kernels} if kernels is not None else {}))
+    checkpoint.load_model(s[-1]["model_dir"], fresh, load_optimizer=False)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v.detach().cpu(), fresh.state_dict()[k].detach().cpu()), k
+
+
+@pytest.mark.parametrize("model", ["dcn_v2", "din"])
+def test_other_mirrors_through_the_loops_cpu_backend(model, tmp_path):
+    """DCN-v2 (slot text, log1p dense, ClipGradByGlobalNorm) and DIN (dinReader format, SGD) through the same
+    train / checkpoint / infer loops on the reference's own sample lines (tests/golden), host logic only."""
+    import cpu_kernels
+    _other_mirrors(model, tmp_path, "cpu", cpu_kernels)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["dcn_v2", "din"])
+def test_other_mirrors_through_the_loops_gpu(model, tmp_path, engine_lib):
+    _other_mirrors(model, tmp_path, "cuda", None)
 
 
 def test_collective_mode_two_ranks_gloo(tmp_path):
