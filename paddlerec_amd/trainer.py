@@ -154,9 +154,10 @@ def _lookahead(it, limit=None):
     prev, n = None, 0
     for cur in it:
         if prev is not None:
-            yield prev, cur
+            last = limit is not None and n + 1 >= limit      # the agreed last step: no rank may prefetch beyond it
+            yield prev, (None if last else cur)              # (a prefetch holds collectives — all ranks or none)
             n += 1
-            if limit is not None and n >= limit:
+            if last:
                 return
         prev = cur
     if prev is not None and (limit is None or n < limit):

@@ -251,9 +251,11 @@ def test_collective_mode_two_ranks_gloo(tmp_path):
     world, B = 2, 8
     d = tmp_path / "deepfm"
     (d / "data" / "train").mkdir(parents=True)
-    lines = _sample_lines(80)
+    lines = _sample_lines(96)
     for r in range(world):                                         # rank r reads file r (criteo_reader.py:30-43)
-        (d / "data" / "train" / ("part-%d" % r)).write_text("\n".join(lines[r * 40:(r + 1) * 40]) + "\n")
+        mine = lines[r * 40:(r + 1) * 40] + (lines[80:] if r == 1 else [])     # rank 1 holds 2 more batches: unused,
+        (d / "data" / "train" / ("part-%d" % r)).write_text("\n".join(mine) + "\n")   # every rank runs min = 5 steps
+    lines = lines[:80]
     (d / "config.yaml").write_text(YAML.format(out=str(tmp_path / "out")).replace("train_batch_size: 16", "train_batch_size: %d" % B)
                                    .replace("infer_batch_size: 20", "infer_batch_size: 10"))
     s = socket.socket()
