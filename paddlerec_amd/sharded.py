@@ -36,12 +36,14 @@ class Comm:
         self.rank = dist.get_rank(self.group)
         self.world = dist.get_world_size(self.group)
         self.staged = dist.get_backend(self.group) != "nccl"
+        self.trace = None       # tests set this to a list: the sequence of collectives this rank issued
         # ONE communicator: RCCL collectives of a communicator must execute in the same order on every rank, and
         # torch issues a blocking collective on the caller's current stream — so every collective of a training
         # step is issued on ONE stream (the side stream) or behind a stream wait on it (see train_step).
 
     def exchange_counts(self, send_counts):
         """send_counts[d] = entries this rank sends to d  ->  recv_counts[s] = entries s sends here."""
+        self._log("all_to_all:counts")
         dev = "cpu" if self.staged else torch.device("cuda", torch.cuda.current_device())
         t_in = torch.tensor(list(send_counts), dtype=torch.int64, device=dev)
         t_out = torch.empty_like(t_in)
@@ -50,12 +52,14 @@ class Comm:
 
     def exchange_counts_device(self, send_counts_dev):
         """Device-side variant for backend nccl: no host sync here; returns the receive counts (device)."""
+        self._log("all_to_all:counts")
         out = torch.empty_like(send_counts_dev)
         self.dist.all_to_all_single(out, send_counts_dev.contiguous(), group=self.group)
         return out
 
     def all_to_all(self, out, inp, out_splits, in_splits):
         """Rows (dim 0) of `inp` split by in_splits go to the ranks; `out` receives out_splits rows."""
+        self._log("all_to_all:%s x%d" % (str(inp.dtype).replace("torch.", ""), inp.shape[1] if inp.dim() > 1 else 1))
         if self.staged and out.is_cuda:
             h_in = inp.cpu()
             h_out = torch.empty(out.shape, dtype=out.dtype)
@@ -65,7 +69,12 @@ class Comm:
             self.dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=self.group)
         return out
 
+    def _log(self, what):
+        if self.trace is not None:
+            self.trace.append(what)
+
     def broadcast(self, t, src=0):
+        self._log("broadcast")
         g = self.group
         if self.staged and t.is_cuda:
             h = t.cpu()
@@ -76,6 +85,7 @@ class Comm:
         return t
 
     def all_reduce_sum(self, t):
+        self._log("all_reduce")
         g = self.group
         if self.staged and t.is_cuda:
             h = t.cpu()

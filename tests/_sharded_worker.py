@@ -37,10 +37,12 @@ def main():
     pr = make_deepfm_problem(B=c["B"] * world, N=c["N"], D=c["D"], fc=c["fc"], seed=c["seed"],
                              pad_frac=c["pad_frac"], tables=tables)
     so = pr["slot_offsets"]
+    comm = Comm()
+    comm.trace = []
     torch.manual_seed(1000 + rank)          # every rank draws a DIFFERENT random init ...
     m = ShardedDeepFMLayer(pr["N"], c["D"], 13, 26, list(c["fc"]), device=dev,
                            slot_offset=None if so is None else torch.as_tensor(so),
-                           comm=Comm(), kernels=kernels)
+                           comm=comm, kernels=kernels)
     # ... and the constructor must have replaced the dense replica by rank 0's (data-parallel invariant)
     mine = m.dense.data.detach().cpu().clone()
     ref0 = mine.clone()
@@ -72,6 +74,7 @@ def main():
     out["mlp_w0"] = m.dense.p["dnn.linear_0.weight"].cpu().numpy()
     out["dense_w"] = m.dense.p["fm.dense_w"].cpu().numpy()
     out["status"] = m.status.cpu().numpy()
+    out["trace"] = np.asarray(m.comm.trace)
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
     dist.barrier()
     dist.destroy_process_group()

@@ -21,6 +21,7 @@ def main():
     from paddlerec_amd import trainer
     from paddlerec_amd.sharded import Comm
     comm = Comm()
+    comm.trace = []
     cfg = trainer.load_yaml(os.path.join(workdir, "config.yaml"))
     out = {}
     # the initial parameters: the same seed path with zero epochs
@@ -45,6 +46,7 @@ def main():
     res = trainer.infer(cfg, "deepfm", "cpu", cpu_kernels, comm)
     out["infer_auc"] = np.asarray([r["auc"] for r in res])
     out["infer_samples"] = np.asarray([r["samples"] for r in res])
+    out["trace"] = np.asarray(comm.trace)
     np.savez(os.path.join(workdir, "rank%d.npz" % rank), **out)
     dist.barrier()
     dist.destroy_process_group()

@@ -76,6 +76,8 @@ def _check(world, ranks, tables):
     B = c["B"]
     for r, out in enumerate(ranks):
         assert int(out["status"][0]) == 0
+        # one communicator: every rank must issue the same sequence of collectives (a divergence hangs on real GPUs)
+        assert out["trace"].tolist() == ranks[0]["trace"].tolist() and len(out["trace"]) > 10
         for step, (loss, pred) in enumerate(res):
             np.testing.assert_allclose(out["loss%d" % step][0], loss, rtol=2e-5)
             np.testing.assert_allclose(out["pred%d" % step], pred[r * B:(r + 1) * B], rtol=2e-5, atol=1e-6)

@@ -269,6 +269,8 @@ def test_collective_mode_two_ranks_gloo(tmp_path):
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
     ranks = [dict(np.load(str(d / ("rank%d.npz" % r)))) for r in range(world)]
+    # every rank issued the same sequence of collectives (one communicator: any divergence is a hang on real GPUs)
+    assert ranks[0]["trace"].tolist() == ranks[1]["trace"].tolist() and len(ranks[0]["trace"]) > 50
     # both ranks report the same GLOBAL numbers
     for k in ("loss", "auc", "samples", "batches", "infer_auc", "W", "mlp_w0"):
         assert np.array_equal(ranks[0][k], ranks[1][k]), k
