@@ -144,6 +144,36 @@ def golden_wide_deep(D, seed):
     print("wide_deep D=%d loss=%.6f" % (D, float(loss.detach())))
 
 
+def golden_dnn(D, seed):
+    """models/rank/dnn/net.py:20-95 (DNNLayer) + dnn/dygraph_model.py:53-58 (softmax cross-entropy, mean)."""
+    import paddle  # the shim
+    net = load_ref_module("models/rank/dnn/net.py", "ref_dnn_net")
+    rng = np.random.default_rng(seed)
+    N, S, Dn, B, fc = 1001, 26, 13, 12, [32, 16]
+    torch.manual_seed(seed)
+    model = net.DNNLayer(N, D, Dn, S, fc)
+    with torch.no_grad():       # as for wide_deep: Uniform(-1,1) rows saturate a toy MLP; biases away from 0
+        model.embedding.weight.mul_(0.2)
+        for m in [l for l in model._mlp_layers if hasattr(l, "weight")]:
+            m.bias.copy_(torch.as_tensor((0.05 * rng.standard_normal(tuple(m.bias.shape))).astype(np.float32)))
+    ids = make_ids(rng, B, S, N)
+    dense = rng.random((B, Dn), dtype=np.float32)
+    label = (rng.random((B, 1)) < 0.4).astype(np.int64)
+    raw = model.forward([paddle.to_tensor(ids[:, s:s + 1]) for s in range(S)], paddle.to_tensor(dense))
+    # paddle.nn.functional.cross_entropy(input, label [B,1] int64): softmax inside, hard labels, reduction 'mean' [EXT]
+    loss = torch.nn.functional.cross_entropy(raw, torch.as_tensor(label).reshape(-1))
+    loss.backward()
+    g = dict(ids=ids, dense=dense, label=label, D=np.int64(D), W=npy(model.embedding.weight), raw=npy(raw),
+             loss=npy(loss), gW=npy(model.embedding.weight.grad))
+    lin = [m for m in model._mlp_layers if hasattr(m, "weight")]
+    for i, l in enumerate(lin):
+        g[f"mlp_w{i}"], g[f"mlp_b{i}"] = npy(l.weight), npy(l.bias)
+        g[f"g_mlp_w{i}"], g[f"g_mlp_b{i}"] = npy(l.weight.grad), npy(l.bias.grad)
+    g["n_mlp"] = np.int64(len(lin))
+    np.savez_compressed(os.path.join(OUT, f"dnn_D{D}.npz"), **g)
+    print("dnn D=%d loss=%.6f" % (D, float(loss.detach())))
+
+
 def golden_dcn_v2(mix, seed):
     """models/rank/dcn_v2/net.py:20-320 in eval() mode (Dropout off — Appendix B-10)."""
     import paddle
@@ -227,6 +257,6 @@ if __name__ == "__main__":
     jobs = {"deepfm_D9": lambda: golden_deepfm(9, 20250404), "deepfm_D16": lambda: golden_deepfm(16, 20250405),
             "dcn_v2_v2": lambda: golden_dcn_v2(False, 20250406), "dcn_v2_mix": lambda: golden_dcn_v2(True, 20250407),
             "din": lambda: golden_din(20250408), "fm_D9": lambda: golden_fm(9, 20250409),
-            "wide_deep_D9": lambda: golden_wide_deep(9, 20250410)}
+            "wide_deep_D9": lambda: golden_wide_deep(9, 20250410), "dnn_D9": lambda: golden_dnn(9, 20250411)}
     for name in (sys.argv[1:] or list(jobs)):      # optional: only the named fixtures
         jobs[name]()

@@ -10,7 +10,7 @@ What differs by construction: a batch never becomes 28 per-sample NumPy arrays (
 [B,26] / [B,13] device tensors), `loss.backward(); optimizer.step()` is the explicit `train_step` chain of the
 host mirrors, and the AUC buckets stay on the device (read back only when a log line prints them).
 
-    python -m paddlerec_amd.trainer -m <config.yaml> [--model deepfm|fm|wide_deep|dcn_v2|din] [-o runner.epochs=1 ...] [--infer]
+    python -m paddlerec_amd.trainer -m <config.yaml> [--model deepfm|fm|wide_deep|dnn|dcn_v2|din] [-o runner.epochs=1 ...] [--infer]
     python -m torch.distributed.run --nproc-per-node G -m paddlerec_amd.trainer -m <config.yaml>     # collective mode
 """
 import argparse
@@ -24,7 +24,7 @@ from . import checkpoint
 
 logger = logging.getLogger("paddlerec_amd.trainer")
 
-MODELS = ("deepfm", "fm", "wide_deep", "dcn_v2", "din")
+MODELS = ("deepfm", "fm", "wide_deep", "dnn", "dcn_v2", "din")
 
 
 # ------------------------------------------------------------------------------------ configuration
@@ -77,6 +77,8 @@ def _dygraph_model(name):
         from .fm import DygraphModel
     elif name == "wide_deep":
         from .wide_deep import DygraphModel
+    elif name == "dnn":
+        from .dnn import DygraphModel
     elif name == "dcn_v2":
         from .dcn_v2 import DygraphModel
     elif name == "din":

@@ -20,11 +20,13 @@ from . import ops
 from .deepfm import NUM_THRESHOLDS, _FlatParams, _OnSide, _round_up, auc_metrics, slot_feeds
 
 
-class WideDeepLayer:
-    """wide_deep/net.py:20-104.  forward(sparse_inputs, dense_inputs) -> predict [B,1]."""
+class SlotMLPBase:
+    """What rank/wide_deep and rank/dnn share (wide_deep/net.py:43-99 == dnn/net.py:38-95): one Uniform-initialised
+    embedding table without padding_idx, x = concat(rows of the slots, dense), an MLP of Linear+ReLU ... Linear(n_out),
+    lazy Adam on the touched rows read through rec_grad_layout, dense Adam on one flat buffer."""
 
-    def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim, num_field, layer_sizes,
-                 device="cuda", kernels=None):
+    def _build(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim, num_field, layer_sizes, n_out,
+               extra_shapes, device, kernels):
         self.device = torch.device(device)
         self.k = kernels if kernels is not None else ops     # tests may inject a stand-in backend (host logic only)
         self.sparse_feature_number = N = sparse_feature_number
@@ -36,13 +38,11 @@ class WideDeepLayer:
         self.rec = torch.zeros(N, _round_up(D, 32), dtype=torch.float32, device=self.device)   # line-aligned rows
         self.embedding = self.rec[:, :D]
         self.embedding.uniform_(-1.0, 1.0)                                        # net.py:48-54 Uniform() [EXT -1..1]
-        sizes = [self.width] + self.layer_sizes + [1]
-        shapes = [("wide_part.weight", (Dn, 1)), ("wide_part.bias", (1,))]
+        sizes = [self.width] + self.layer_sizes + [n_out]
+        shapes = list(extra_shapes)
         for i in range(len(sizes) - 1):
             shapes += [("linear_%d.weight" % i, (sizes[i], sizes[i + 1])), ("linear_%d.bias" % i, (sizes[i + 1],))]
         self.dense = _FlatParams(shapes, self.device)
-        std = 1.0 / math.sqrt(Dn)                                                 # net.py:36-41
-        torch.nn.init.trunc_normal_(self.dense.p["wide_part.weight"], 0.0, std, -2 * std, 2 * std)
         self.n_linear = len(sizes) - 1
         for i in range(self.n_linear):                                            # net.py:60-66
             self.dense.p["linear_%d.weight" % i].normal_(0.0, 1.0 / math.sqrt(sizes[i]))
@@ -92,6 +92,52 @@ class WideDeepLayer:
         x[:, S * D:].copy_(dense_inputs)
         return x
 
+    def _ensure_sparse_state(self):
+        if self.sparse_state is None:
+            D = self.sparse_feature_dim
+            Dp = _round_up(D, 4)
+            mv = torch.zeros(self.rec.shape[0], _round_up(2 * Dp, 32), dtype=torch.float32, device=self.device)
+            self.sparse_state = dict(mv=mv, m=mv[:, :D], v=mv[:, Dp:Dp + D])
+
+    def _begin_step(self, ids):
+        """Bookkeeping every train_step starts with -> (t, on_gpu, cur, side, groups)."""
+        k = self.k
+        B, S = ids.shape
+        self._ensure_sparse_state()
+        self.step_count += 1
+        on_gpu = self.device.type == "cuda"
+        cur = torch.cuda.current_stream() if on_gpu else None
+        if on_gpu and self._side is None:
+            self._side = k.concurrent_stream(self.device)
+        if self._groups is None or self._groups.n != B * S:
+            self._groups = k.IdGroups(B * S, self.device)
+        return self.step_count, on_gpu, cur, (self._side if on_gpu else None), self._groups
+
+    def _finish_step(self, groups, dx, S, t, lr, on_gpu, cur, side):
+        """Lazy Adam on the touched embedding rows (SelectedRows.value = the first S*D columns of d x, read in place,
+        on the side stream) + dense Adam."""
+        k, D, st = self.k, self.sparse_feature_dim, self.sparse_state
+        with _OnSide(side, cur):
+            pp = self._pp = k.segment_partials(groups, dx, D, grad_group=S, grad_group_stride=self.width,
+                                               out=getattr(self, "_pp", None))
+            k.sparse_adam_rows(groups, dx, 1, self.embedding, st["m"], st["v"], t, lr, grad_group=S,
+                               grad_group_stride=self.width, partials=pp)
+        k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
+        if on_gpu:
+            cur.wait_stream(self._side)
+
+
+class WideDeepLayer(SlotMLPBase):
+    """wide_deep/net.py:20-104.  forward(sparse_inputs, dense_inputs) -> predict [B,1]."""
+
+    def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim, num_field, layer_sizes,
+                 device="cuda", kernels=None):
+        Dn = dense_feature_dim
+        self._build(sparse_feature_number, sparse_feature_dim, dense_feature_dim, num_field, layer_sizes, 1,
+                    [("wide_part.weight", (Dn, 1)), ("wide_part.bias", (1,))], device, kernels)
+        std = 1.0 / math.sqrt(Dn)                                                 # net.py:36-41
+        torch.nn.init.trunc_normal_(self.dense.p["wide_part.weight"], 0.0, std, -2 * std, 2 * std)
+
     def _wide(self, dense_inputs):
         return self.k.gemm(dense_inputs, self.dense.p["wide_part.weight"], self.ws, epilogue="bias",
                            bias=self.dense.p["wide_part.bias"])
@@ -104,13 +150,6 @@ class WideDeepLayer:
 
     __call__ = forward
 
-    def _ensure_sparse_state(self):
-        if self.sparse_state is None:
-            D = self.sparse_feature_dim
-            Dp = _round_up(D, 4)
-            mv = torch.zeros(self.rec.shape[0], _round_up(2 * Dp, 32), dtype=torch.float32, device=self.device)
-            self.sparse_state = dict(mv=mv, m=mv[:, :D], v=mv[:, Dp:Dp + D])
-
     # -- one full training step: train_forward + backward + optimizer.step ----------------------
     def train_step(self, sparse_inputs, dense_inputs, label, lr=1e-3, auc_stats=None):
         """wide_deep/dygraph_model.py:73-85 + tools/trainer.py:148-152.  label [B,1] int64.
@@ -118,18 +157,7 @@ class WideDeepLayer:
         k = self.k
         ids = self._concat_ids(sparse_inputs)
         B, S = ids.shape
-        D = self.sparse_feature_dim
-        self._ensure_sparse_state()
-        self.step_count += 1
-        t = self.step_count
-        on_gpu = self.device.type == "cuda"
-        cur = torch.cuda.current_stream() if on_gpu else None
-        if on_gpu and self._side is None:
-            self._side = k.concurrent_stream(self.device)
-        side = self._side if on_gpu else None
-        if self._groups is None or self._groups.n != B * S:
-            self._groups = k.IdGroups(B * S, self.device)
-        groups = self._groups
+        t, on_gpu, cur, side, groups = self._begin_step(ids)
         x = self._features(ids, dense_inputs)
         with _OnSide(side, cur):                                   # merge keys depend on the ids only
             k.ids_group(ids, self.sparse_feature_number, None, self.ws_group, None, self.status, groups)
@@ -143,16 +171,7 @@ class WideDeepLayer:
         dx = k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp)  # [B, width]
         k.gemm(dense_inputs, dz, self.ws, trans_a=True, out=self.dense.g["wide_part.weight"],
                b_colsum=self.dense.g["wide_part.bias"])                                # wide part: dW, db
-        st = self.sparse_state
-        with _OnSide(side, cur):
-            # SelectedRows.value of `embedding` = the first S*D columns of d x, read in place
-            pp = self._pp = k.segment_partials(groups, dx, D, grad_group=S, grad_group_stride=self.width,
-                                               out=getattr(self, "_pp", None))
-            k.sparse_adam_rows(groups, dx, 1, self.embedding, st["m"], st["v"], t, lr, grad_group=S,
-                               grad_group_stride=self.width, partials=pp)
-        k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
-        if on_gpu:
-            cur.wait_stream(self._side)
+        self._finish_step(groups, dx, S, t, lr, on_gpu, cur, side)
         return loss, pred
 
 

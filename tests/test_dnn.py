@@ -1,0 +1,118 @@
+"""rank/dnn sibling net (paddlerec_amd/dnn.py; reference: models/rank/dnn/net.py DNNLayer, dnn/dygraph_model.py).
+
+Oracle (oracle/dnn_ref.py) pinned to tests/golden/dnn_D9.npz = the reference's unmodified net.py executed over the
+paddle shim; the two-class softmax cross-entropy is served by the BCE-with-logits head through an exact identity, which
+the oracle test checks.  Host mirror: oracle-backed operator backend on the CPU, HIP kernels under `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+from oracle import deepfm_ref as R
+from oracle import dnn_ref as DN
+
+
+def _params(g):
+    n = int(g["n_mlp"])
+    return dict(W=g["W"].copy(), mlp_w=[g["mlp_w%d" % i].copy() for i in range(n)],
+                mlp_b=[g["mlp_b%d" % i].copy() for i in range(n)])
+
+
+def _state_dict(p):
+    sd = {"embedding.weight": p["W"]}
+    for i, (w, b) in enumerate(zip(p["mlp_w"], p["mlp_b"])):
+        sd["linear_%d.weight" % i], sd["linear_%d.bias" % i] = w, b
+    return sd
+
+
+def test_oracle_matches_reference_golden_and_the_two_class_identity():
+    g = load_golden("dnn_D9")
+    o = DN.loss_and_grads(g["ids"], g["dense"], g["label"], _params(g))
+    np.testing.assert_allclose(o["raw"], g["raw"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(o["loss"], g["loss"], rtol=1e-6)
+    for i in range(int(g["n_mlp"])):
+        np.testing.assert_allclose(o["mlp_dw"][i], g["g_mlp_w%d" % i], rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(o["mlp_db"][i], g["g_mlp_b%d" % i], rtol=1e-5, atol=1e-8)
+    uniq, merged, _ = R.merge_rows(o["rows"], o["row_valid"], o["row_grad"])
+    gW = np.zeros_like(g["gW"])
+    gW[uniq] = merged
+    np.testing.assert_allclose(gW, g["gW"], rtol=1e-5, atol=1e-8)
+    # softmax CE over two classes == BCE with logits on the score difference; P(class 1) == sigmoid(difference)
+    r64 = g["raw"].astype(np.float64)
+    d = r64[:, 1:2] - r64[:, 0:1]
+    t = g["label"].astype(np.float64)
+    bce = np.mean(np.maximum(d, 0) - d * t + np.log1p(np.exp(-np.abs(d))))
+    np.testing.assert_allclose(bce, float(g["loss"]), rtol=1e-6)
+    np.testing.assert_allclose(1 / (1 + np.exp(-d)), DN.softmax(r64)[:, 1:2], rtol=1e-12)
+
+
+class _OracleTrainer:
+    def __init__(self, p, lr):
+        self.p = {k: (v.copy() if not isinstance(v, list) else [x.copy() for x in v]) for k, v in p.items()}
+        self.lr, self.step, self.st = lr, 0, {}
+
+    def _adam(self, key, arr, grad):
+        m, v = self.st.setdefault(key, (np.zeros_like(arr), np.zeros_like(arr)))
+        R.adam_update(arr, m, v, grad.reshape(arr.shape).astype(arr.dtype), self.step, lr=self.lr)
+
+    def train_step(self, ids, dense, label):
+        self.step += 1
+        o = DN.loss_and_grads(ids, dense, label, self.p)
+        uniq, merged, _ = R.merge_rows(o["rows"], o["row_valid"], o["row_grad"])
+        m, v = self.st.setdefault("W", (np.zeros_like(self.p["W"]), np.zeros_like(self.p["W"])))
+        R.adam_update_rows(self.p["W"], m, v, uniq, merged, self.step, lr=self.lr)
+        for i in range(len(self.p["mlp_w"])):
+            self._adam(("w", i), self.p["mlp_w"][i], o["mlp_dw"][i])
+            self._adam(("b", i), self.p["mlp_b"][i], o["mlp_db"][i])
+        return o["loss"], o["pred"]
+
+
+def _check_layer(device, kernels, tol):
+    from paddlerec_amd.dnn import DNNLayer, DygraphModel
+    rtol, p_atol = tol
+    g = load_golden("dnn_D9")
+    N, D = g["W"].shape
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(device)
+    m = DNNLayer(N, D, 13, 26, [32, 16], device=device, kernels=kernels)
+    assert set(m.state_dict()) == set(_state_dict(_params(g)))
+    m.set_dict(_state_dict(_params(g)))
+    raw = m.forward([T(g["ids"][:, s:s + 1]) for s in range(26)], T(g["dense"]))
+    np.testing.assert_allclose(raw.cpu().numpy(), g["raw"], rtol=rtol, atol=1e-6)
+    np.testing.assert_allclose(m.predict(raw).cpu().numpy(), DN.softmax(g["raw"])[:, 1:2], rtol=rtol)
+    tr = _OracleTrainer(_params(g), lr=1e-2)
+    rng = np.random.default_rng(6)
+    for step in range(3):
+        ids = rng.integers(0, N, (64, 26), dtype=np.int64)
+        ids[:, 7] = 0                                                             # row 0 is an ordinary, hot row
+        dense = rng.random((64, 13), dtype=np.float32)
+        label = (rng.random((64, 1)) < 0.4).astype(np.int64)
+        loss, pred = m.train_step(T(ids), T(dense), T(label), lr=1e-2)
+        ol, op = tr.train_step(ids, dense, label)
+        np.testing.assert_allclose(loss.cpu().numpy()[0], ol, rtol=rtol)
+        np.testing.assert_allclose(pred.cpu().numpy(), op, rtol=rtol, atol=1e-6)
+    assert int(m.status.item()) == 0
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    want = _state_dict(tr.p)
+    for k in sd:
+        np.testing.assert_allclose(sd[k], want[k].reshape(sd[k].shape), rtol=1e-3, atol=p_atol, err_msg=k)
+    dm = DygraphModel()
+    cfg = {"hyper_parameters.sparse_feature_number": N, "hyper_parameters.sparse_feature_dim": D,
+           "hyper_parameters.dense_input_dim": 13, "hyper_parameters.sparse_inputs_slots": 27,
+           "hyper_parameters.fc_sizes": [32, 16], "hyper_parameters.optimizer.learning_rate": 0.001}
+    net = dm.create_model(cfg, device, kernels=kernels)
+    metrics, names = dm.create_metrics(device)
+    batch = [g["label"]] + [g["ids"][:, s:s + 1] for s in range(26)] + [g["dense"]]
+    loss, metrics, _ = dm.train_forward(net, metrics, batch, cfg)
+    dm.infer_forward(net, metrics, batch, cfg)
+    assert np.isfinite(float(loss.reshape(-1)[0])) and names == ["auc"]
+    assert int(metrics[0][0].sum() + metrics[0][1].sum()) == 2 * len(g["label"])
+
+
+def test_dnn_layer_host_logic_cpu_backend():
+    import cpu_kernels
+    _check_layer("cpu", cpu_kernels, (2e-6, 1e-6))
+
+
+@pytest.mark.gpu
+def test_dnn_layer_gpu(engine_lib):
+    _check_layer("cuda", None, (2e-5, 2e-4))
