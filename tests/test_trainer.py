@@ -171,25 +171,32 @@ def test_train_infer_resume_gpu(workdir, engine_lib):
     _run(workdir, "cuda", None, (1e-3, 5e-3, 2e-2, 1e-4))
 
 
-REF_YAML = "/root/reference/models/rank/deepfm/config.yaml"
+REF_RANK = "/root/reference/models/rank"
 
 
-@pytest.mark.skipif(not os.path.exists(REF_YAML), reason="reference tree not mounted (only in the build container)")
-def test_reference_yaml_and_sample_data_run_unchanged(tmp_path):
-    """BASELINE configs[0]: the reference's own models/rank/deepfm/config.yaml (bs 2, 80-line sample, D 9,
-    fc 512-256-128-32) drives the loop as is — only the output directory is redirected."""
+@pytest.mark.skipif(not os.path.isdir(REF_RANK), reason="reference tree not mounted (only in the build container)")
+@pytest.mark.parametrize("model,samples,batches", [("deepfm", 80, 40), ("fm", None, None), ("wide_deep", None, None),
+                                                    ("dnn", None, None), ("dcn_v2", None, None), ("din", None, None)])
+def test_reference_yaml_and_sample_data_run_unchanged(model, samples, batches, tmp_path):
+    """BASELINE configs[0] and its siblings: the reference's OWN models/rank/<model>/config.yaml and sample data
+    directory drive the loops as they are (deepfm: bs 2, 80 lines, D 9, fc 512-256-128-32; dcn_v2: D 40, CrossNetMix
+    with 4 experts; din: bs 32, 100 lines) — only the output directory and the number of epochs are redirected."""
     import cpu_kernels
     from paddlerec_amd import trainer
-    cfg = trainer.load_yaml(REF_YAML, ["runner.epochs=1", "runner.model_save_path=" + str(tmp_path / "out"),
-                                       "runner.infer_load_path=" + str(tmp_path / "out"),
-                                       "runner.infer_end_epoch=1"])
-    assert cfg["runner.train_batch_size"] == 2 and cfg["hyper_parameters.sparse_feature_dim"] == 9
-    s, model = trainer.train(cfg, trainer.guess_model(REF_YAML), "cpu", cpu_kernels)
-    assert len(s) == 1 and s[0]["samples"] == 80 and s[0]["batches"] == 40
-    assert np.isfinite(s[0]["loss"]) and 0.0 <= s[0]["auc"] <= 1.0
-    assert int(model.status.item()) == 0                       # no id of the sample file is out of range
-    r = trainer.infer(cfg, "deepfm", "cpu", cpu_kernels)
-    assert r[0]["samples"] == 80 and r[0]["batches"] == 16 and 0.0 <= r[0]["auc"] <= 1.0
+    yaml_path = os.path.join(REF_RANK, model, "config.yaml")
+    cfg = trainer.load_yaml(yaml_path, ["runner.epochs=1", "runner.model_save_path=" + str(tmp_path / "out"),
+                                        "runner.infer_load_path=" + str(tmp_path / "out"),
+                                        "runner.infer_start_epoch=0", "runner.infer_end_epoch=1"])
+    assert trainer.guess_model(yaml_path) == model
+    s, net = trainer.train(cfg, model, "cpu", cpu_kernels)
+    assert len(s) == 1 and np.isfinite(s[0]["loss"]) and 0.0 <= s[0]["auc"] <= 1.0
+    if samples is not None:
+        assert s[0]["samples"] == samples and s[0]["batches"] == batches
+    else:
+        assert s[0]["samples"] > 0 and s[0]["samples"] % cfg["runner.train_batch_size"] == 0
+    assert int(net.status.item()) == 0                          # no id of the sample files is out of range
+    r = trainer.infer(cfg, model, "cpu", cpu_kernels)
+    assert r[0]["samples"] > 0 and 0.0 <= r[0]["auc"] <= 1.0
 
 
 def _other_mirrors(model, tmp_path, device, kernels):
