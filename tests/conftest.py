@@ -12,10 +12,20 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "first_hw_run: written while no GPU time was left — has not run on hardware yet; "
+                                       "collected AFTER the tests that have (drop the mark once it has passed there)")
 
 
 def pytest_collection_modifyitems(config, items):
     import torch
+    # tests that have never run on hardware go last: with `-x` a surprise in one of them must not hide the others
+    # (among themselves: the ones built from already-verified entry points first)
+    order = ["test_multi_value_slots_file_to_sum_pool", "test_fm_layer_gpu", "test_wide_deep_layer_gpu",
+             "test_dnn_layer_gpu", "test_autograd_adapter_gpu", "test_other_mirrors_through_the_loops_gpu",
+             "test_train_infer_resume_gpu", "test_stream_helpers"]
+    rank = {n: i + 1 for i, n in enumerate(order)}
+    items.sort(key=lambda it: (rank.get(it.originalname or it.name, len(order) + 1) if "first_hw_run" in it.keywords
+                               else 0))
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
