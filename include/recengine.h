@@ -128,6 +128,52 @@ int rec_emb_sumpool_bwd(int64_t batch, int32_t emb_dim, const int64_t* lod, cons
                         float* row_grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ALL slots of a batch in one launch: the `for s_input in slot_inputs: sparse_embedding(...,
+ * padding_idx=0, entry=ShowClickEntry) -> sequence_pool('sum')` loop + concat(axis=1) of
+ * models/rank/slot_dnn/net.py:63-77 (408 slots x D 9) and dnn/static_model_lod.py:70-97.
+ * Input = the slot-major CSR of rec_parse_feasign_slots, resident on the device:
+ *   values [nnz]; ids of (slot s, sample b) = values[slot_base[s] + lod[s*lod_stride + b] ..
+ *                                                    slot_base[s] + lod[s*lod_stride + b + 1])
+ * key_mode 0: values are table rows (checked against [0,num_rows), REC_FLAG_INDEX_OOB otherwise);
+ * key_mode 1: values are uint64 feasign bit patterns (what the reference feeds its PS hash map,
+ *             queuedataset_reader.py:56-82); row = rec_feasign_rows' hash, 0 stays the padding row.
+ * padding_idx is compared with the VALUE (before hashing); < 0 = no padding id.
+ * Outputs: out [B, out_stride] with out[b, s*D:(s+1)*D] = sum of the segment's rows (padding skipped);
+ *   counts [B,S] i32 (or NULL) = ids pooled per segment — bit-exact target;
+ *   seg_of_value [nnz] i32 (or NULL) = b*S+s of every value: rec_grad_layout.index for the backward;
+ *   rows_out [nnz] i64 (or NULL) = table row of every value (dropped ones -> the padding row): the `ids`
+ *   of rec_ids_group(n = nnz, num_slots = 1) for the SelectedRows merge of the backward.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t batch;
+  int32_t num_slots;
+  int32_t emb_dim;
+  int32_t row_stride;  /* floats between rows of W */
+  int32_t key_mode;    /* 0 rows, 1 uint64 feasigns */
+  int64_t num_rows;
+  int64_t padding_idx;
+  int64_t lod_stride;  /* elements between slot rows of lod; 0 = batch + 1 */
+  int64_t out_stride;  /* floats between samples of out; 0 = num_slots * emb_dim */
+  /* PS tables create a feature at its first pull (MemorySparseTable + SparseAdaGradSGDRule::InitValue [EXT],
+   * slot_dnn/config_online.yaml:66-79 initial_range): init_range > 0 makes a row whose state float
+   * W[row*row_stride + state_offset] is 0 read as its creation values — element d < init_dims =
+   * uniform(+-init_range) keyed by (init_seed, row, d), the rest 0 — without writing the table
+   * (rec_ps_push_rows gives birth with the same values).  init_range <= 0: off. */
+  int32_t state_offset;
+  int32_t init_dims;
+  float init_range;
+  uint64_t init_seed;
+} rec_multislot_desc;
+int rec_multislot_sumpool_fwd(const rec_multislot_desc* desc, const int64_t* values, const int64_t* lod,
+                              const int64_t* slot_base, const float* W, float* out, int32_t* counts,
+                              int32_t* seg_of_value, int64_t* rows_out, int32_t* status, void* stream);
+/* Row of a feasign in a hashed table of num_rows (>= 2) rows: 0 -> 0 (padding row), f -> 1 + mix64(f) %
+ * (num_rows - 1) with mix64 = the murmur3 64-bit finaliser (SURVEY §8(d) cfg5 "64-bit mix % N").  Device
+ * (keys/rows device pointers) and host variants, bit-identical. */
+int rec_feasign_rows(int64_t n, int64_t num_rows, const int64_t* keys, int64_t* rows, void* stream);
+int rec_feasign_rows_host(int64_t n, int64_t num_rows, const uint64_t* keys, int64_t* rows);
+
+/* ------------------------------------------------------------------------------------------
  * SelectedRows merge (MergeAdd [EXT]) — integer part: group the n = B*S lookups by row.
  * Replaces the duplicate-row merge every consumer of a sparse=True embedding gradient performs
  * (deepfm/net.py:62-70,80 `sparse=use_sparse`).
@@ -154,14 +200,19 @@ typedef struct {
 } rec_adam_hyper;
 
 /* Where the gradient row of lookup position `pos` (= b*S+s) lives inside `grad`:
- *   q = pos / div;   offset = group > 0 ? (q / group) * group_stride + (q % group) * D : q * D
+ *   p = index ? index[pos] : pos;  q = p / div;
+ *   offset = group > 0 ? (q / group) * group_stride + (q % group) * D : q * D
  * {1,0,0}: contiguous [n,D] (DeepFM row_grad); {S,0,0} with D = 1: dy1 [B] for the first-order table;
- * {1,S,d}: the first S*D columns of a [B,d] feature gradient (DCN-v2). */
+ * {1,S,d}: the first S*D columns of a [B,d] feature gradient (DCN-v2);
+ * index = seg_of_value of rec_multislot_sumpool_fwd: every id of a pooled (sample, slot) segment reads the ONE
+ * gradient row of that segment, d_out[b, s*D:(s+1)*D] — the backward of sequence_pool('sum') without a
+ * materialised [nnz, D] row-gradient tensor (slot_dnn/net.py:73). */
 typedef struct {
   int32_t div;
   int32_t group;
   int64_t group_stride;
   const float* partials; /* device, from rec_segment_partials for THIS grad + grouping, or NULL */
+  const int32_t* index;  /* device [n] or NULL: lookup position -> gradient position */
 } rec_grad_layout;
 
 /* Hot rows.  With Zipf-distributed ids one row can own tens of thousands of the n lookups; the per-row
@@ -189,6 +240,18 @@ int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride,
                          const rec_grad_layout* grad_layout, const float* grad_scale, float* P,
                          float* M, float* V, const rec_adam_hyper* hyper, void* stream);
 
+/* Both embeddings of a DeepFM row (deepfm/net.py:62-86: `embedding` [N,D] and `embedding_one` [N,1]) in one
+ * pass over the record layout  rec [N, rec_stride] = W(D) | W1 | m1 | v1 | pad,  MV [N, state_stride] = m(D) at
+ * 0 | v(D) at v_offset:  W/m/v from (grad, grad_layout), W1/m1/v1 from (grad1, grad1_layout) — for DeepFM
+ * grad1 = dz [B] with layout {S,0,0}.  Same arithmetic as two rec_sparse_adam_rows calls; one record line and
+ * one state line are read and written per touched row instead of the record line twice. */
+int rec_sparse_adam_record(int64_t n_max, int32_t emb_dim, int32_t rec_stride, int32_t state_stride,
+                           int32_t v_offset, const int32_t* n_uniq, const int64_t* uniq_rows,
+                           const int32_t* seg_offset, const int32_t* sorted_pos, const float* grad,
+                           const rec_grad_layout* grad_layout, const float* grad1,
+                           const rec_grad_layout* grad1_layout, const float* grad_scale, float* rec,
+                           float* MV, const rec_adam_hyper* hyper, void* stream);
+
 /* PS / gpubox accessor rule — "SparseAdaGradSGDRule" + show/click counters (models/rank/slot_dnn/
  * config_online.yaml:57-79; dnn/net.py:71-79 feature value [show, click, embed_w, embedx(D-1)];
  * formula per SURVEY.md App. B-13 [EXT]: the rule itself lives in the un-vendored Paddle PS code):
@@ -207,6 +270,47 @@ int rec_sparse_adagrad_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride, 
                             const int32_t* seg_offset, const int32_t* sorted_pos, const float* grad,
                             const rec_grad_layout* grad_layout, const int64_t* label, float* rec,
                             const rec_adagrad_hyper* hyper, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The full table accessor of the PS / gpubox mode (slot_dnn/config_online.yaml:57-89: SparseAccessor with
+ * embedx_threshold, SparseAdaGradSGDRule for embed_w and embedx, ctr_accessor_param; slot_dnn/net.py:61-62
+ * ShowClickEntry; tools/static_gpubox_trainer.py:152-160).  A feature value lives in one record row; the
+ * layout says where its parts are (floats from the row start), so DeepFM (embedx = the 16-dim embedding at 0,
+ * embed_w = the first-order weight behind it) and slot_dnn (W = [embed_w, embedx(8)]) use the same kernels:
+ *   stat_off: show, click, embed_g2sum, embedx_g2sum, state   (5 consecutive floats;
+ *             state 0 = unborn (zeroed memory), 1 = embed_w exists, 2 = embedx exists too)
+ * rec_ps_push_rows = CtrCommonAccessor::Update [EXT] on the touched rows (merge of duplicate gradients fused in,
+ * ascending position order): counters, AdaGrad rule per part, lazy birth (uniform(+-initial_range), a pure
+ * function of (seed,row,element): the same values rec_multislot_sumpool_fwd shows for an unborn row), embedx
+ * creation once (show-click)*nonclk_coeff + click*click_coeff >= embedx_threshold (its gradient is dropped
+ * until then).  show / click: per-SAMPLE int64 [B] (NULL: 1 per occurrence / 0); num_slots maps a lookup
+ * position to its sample.  rec_ps_shrink_rows = the end-of-pass Shrink: counters decay, rows whose score fell
+ * below delete_threshold are zeroed (unborn again); n_deleted (device int64 or NULL) counts them.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  float lr, initial_g2sum, min_bound, max_bound; /* SparseAdaGradSGDRule (embed and embedx share them) */
+  float initial_range;
+  float embedx_threshold, nonclk_coeff, click_coeff;
+  uint64_t seed;
+} rec_ps_accessor;
+typedef struct {
+  int32_t row_stride, embed_off, embedx_off, embedx_dim, stat_off;
+} rec_ps_layout;
+typedef struct {
+  const float* grad;       /* element (pos, c) at grad + offset(layout, pos, pitch) + col + c */
+  rec_grad_layout layout;
+  int32_t pitch;           /* the D of rec_grad_layout's offset formula for this source */
+  int32_t col;
+} rec_grad_src;
+int rec_ps_push_rows(int64_t n_max, int32_t num_slots, const rec_ps_layout* layout, const int32_t* n_uniq,
+                     const int64_t* uniq_rows, const int32_t* seg_offset, const int32_t* sorted_pos,
+                     const rec_grad_src* grad_embedx, const rec_grad_src* grad_embed, const int64_t* show,
+                     const int64_t* click, float* rec, const rec_ps_accessor* accessor, void* stream);
+/* host: the creation value of element `element` (0 = embed_w, 1+j = embedx[j]) of feature `row` */
+float rec_ps_init_value_host(uint64_t seed, int64_t row, int32_t element, float initial_range);
+int rec_ps_shrink_rows(int64_t num_rows, const rec_ps_layout* layout, float* rec, float show_click_decay_rate,
+                       float delete_threshold, const rec_ps_accessor* accessor, int64_t* n_deleted,
+                       void* stream);
 
 /* paddle.optimizer.SGD [EXT] (din/dygraph_model.py:64-73): p -= lr * g.  Rows whose gradient is zero do
  * not move, so updating the merged rows of a SelectedRows gradient equals the dense update. */
@@ -377,12 +481,14 @@ int rec_colsum(int64_t m, int32_t n, int32_t ld, const float* G, float* out, voi
  * y2 / y_dnn may be NULL (treated as 0).  workspace >= rec_logloss_workspace_bytes(B).
  * mean_over = denominator of the mean (0 -> batch).  Data-parallel ranks pass the GLOBAL batch so
  * that summing gradients over ranks reproduces one step on the concatenated batch.
+ * clip_lo < clip_hi: the logit goes through paddle.clip(z, clip_lo, clip_hi) first (slot_dnn/net.py:84,
+ * `F.sigmoid(paddle.clip(y_dnn, min=-15.0, max=15.0))`), dz = 0 outside the open interval; clip_lo >= clip_hi: off.
  * ---------------------------------------------------------------------------------------- */
 int rec_logloss_workspace_bytes(int64_t batch, size_t* bytes);
 int rec_sigmoid_logloss(int64_t batch, int64_t mean_over, const float* y1, const float* y2,
                         const float* y_dnn,
-                        const int64_t* label, float eps, float* pred, float* dz, float* loss_out,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        const int64_t* label, float eps, float clip_lo, float clip_hi, float* pred,
+                        float* dz, float* loss_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* binary_cross_entropy_with_logits(reduction='mean') [EXT] (din/dygraph_model.py:58-61): loss_out[0] = mean,
  * pred = sigmoid(logit), dz = (pred - label) / mean_over (0 -> batch).  label is float32 as the DIN reader

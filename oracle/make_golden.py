@@ -252,11 +252,76 @@ def golden_din(seed):
     print("din loss=%.6f" % float(loss))
 
 
+def golden_slot_dnn(D, seed):
+    """models/rank/slot_dnn/net.py:21-85 (BenchmarkDNNLayer) + static_model.py:104-108 (loss): multi-value slots over
+    ONE shared table, sum-pooled per slot, concat, MLP, sigmoid(clip(+-15))."""
+    import paddle  # the shim
+    from paddle.static import nn as snn
+    net = load_ref_module("models/rank/slot_dnn/net.py", "ref_slot_dnn_net")
+    rng = np.random.default_rng(seed)
+    N, S, B, fc = 503, 12, 9, [32, 16]
+    torch.manual_seed(seed)
+    snn.PARAMS.clear()
+    model = net.BenchmarkDNNLayer(N, D, S, fc)
+    # per (sample, slot): 0..4 ids, an absent slot holds the single padding id 0 (queuedataset_reader.py:75-80);
+    # duplicates inside a segment and across samples are forced (SelectedRows merge path)
+    samples = []
+    for b in range(B):
+        row = []
+        for s in range(S):
+            k = int(rng.integers(0, 5))
+            v = [int(x) for x in rng.integers(1, N, size=k)] if k else [0]
+            if k >= 2 and rng.random() < 0.5:
+                v[1] = v[0]
+            if b % 2 == 1 and s < S // 2:
+                v = list(samples[b - 1][s])
+            if len(v) >= 3 and rng.random() < 0.3:
+                v[2] = 0                                  # an explicit padding id inside a longer segment
+            row.append(v)
+        samples.append(row)
+    label = (rng.random((B, 1)) < 0.4).astype(np.int64)
+    slot_inputs = []
+    for s in range(S):
+        vals, lod = [], [0]
+        for b in range(B):
+            vals.extend(samples[b][s])
+            lod.append(len(vals))
+        slot_inputs.append(paddle.LoDTensor(paddle.to_tensor(np.asarray(vals, np.int64).reshape(-1, 1)), lod, str(s + 2)))
+    show = paddle.LoDTensor(paddle.to_tensor(np.ones((B, 1), np.int64)), list(range(B + 1)), "show")
+    click = paddle.LoDTensor(paddle.to_tensor(label), list(range(B + 1)), "click")
+    # the table parameter is created by the first sparse_embedding call: run once, then set seeded weights
+    model.forward(show, click, slot_inputs)
+    W = snn.PARAMS["embedding"]
+    with torch.no_grad():
+        W.copy_(torch.as_tensor((rng.standard_normal((N, D)) * 0.3).astype(np.float32)))
+        lin = [m for m in model._mlp_layers if hasattr(m, "weight")]
+        lin[-1].bias.fill_(0.1)
+        for l in lin:                     # spread the logits so that some samples sit outside the +-15 clip
+            l.weight.mul_(24.0)
+    pred = model.forward(show, click, slot_inputs)
+    cost = paddle.nn.functional.log_loss(input=pred, label=paddle.cast(paddle.to_tensor(label), "float32"))
+    loss = paddle.mean(x=cost)
+    loss.backward()
+    pooled = model.all_vars[S]           # concat of the S bows (net.py:77-78)
+    logits = model.all_vars[-2]
+    g = dict(D=np.int64(D), N=np.int64(N), S=np.int64(S), label=label,
+             samples=np.array([[",".join(str(x) for x in v) for v in r] for r in samples]),
+             W=npy(W), gW=npy(W.grad), pred=npy(pred), loss=npy(loss), pooled=npy(pooled), logits=npy(logits),
+             n_clipped=np.int64(int((npy(logits).__abs__() >= 15).sum())))
+    for i, l in enumerate(lin):
+        g[f"mlp_w{i}"], g[f"mlp_b{i}"] = npy(l.weight), npy(l.bias)
+        g[f"g_mlp_w{i}"], g[f"g_mlp_b{i}"] = npy(l.weight.grad), npy(l.bias.grad)
+    g["n_mlp"] = np.int64(len(lin))
+    np.savez_compressed(os.path.join(OUT, f"slot_dnn_D{D}.npz"), **g)
+    print("slot_dnn D=%d loss=%.6f clipped=%d" % (D, float(loss), int(g["n_clipped"])))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     jobs = {"deepfm_D9": lambda: golden_deepfm(9, 20250404), "deepfm_D16": lambda: golden_deepfm(16, 20250405),
             "dcn_v2_v2": lambda: golden_dcn_v2(False, 20250406), "dcn_v2_mix": lambda: golden_dcn_v2(True, 20250407),
             "din": lambda: golden_din(20250408), "fm_D9": lambda: golden_fm(9, 20250409),
-            "wide_deep_D9": lambda: golden_wide_deep(9, 20250410), "dnn_D9": lambda: golden_dnn(9, 20250411)}
+            "wide_deep_D9": lambda: golden_wide_deep(9, 20250410), "dnn_D9": lambda: golden_dnn(9, 20250411),
+            "slot_dnn_D9": lambda: golden_slot_dnn(9, 20250412)}
     for name in (sys.argv[1:] or list(jobs)):      # optional: only the named fixtures
         jobs[name]()

@@ -9,7 +9,7 @@ behaviour).  It is never imported by paddlerec_amd/.
 import numpy as _np
 import torch as _t
 
-from . import nn, framework, regularizer  # noqa: F401
+from . import nn, framework, regularizer, static, distributed  # noqa: F401
 from .framework import ParamAttr  # noqa: F401
 
 Tensor = _t.Tensor
@@ -40,8 +40,24 @@ def to_tensor(x, dtype=None):
     return t.to(_dtype(dtype)) if dtype is not None else t
 
 
+class LoDTensor:
+    """lod_level=1 feed: values [nnz, ...] + offsets [B+1] (what paddle.static.data(..., lod_level=1) carries)."""
+    _n = 0
+
+    def __init__(self, values, lod, name=None):
+        self.values, self.lod = values, lod
+        LoDTensor._n += 1
+        self.name = name or "lod_%d" % LoDTensor._n
+
+
 def cast(x, dtype):
+    if isinstance(x, LoDTensor):
+        return LoDTensor(x.values.to(_dtype(dtype)), x.lod, x.name + ".cast")
     return x.to(_dtype(dtype))
+
+
+def clip(x, min=None, max=None):  # noqa: A002
+    return _t.clamp(x, min=min, max=max)
 
 
 def concat(x, axis=0):

@@ -33,7 +33,30 @@ class AdagradHyper(C.Structure):
 
 class GradLayout(C.Structure):
     _fields_ = [("div", C.c_int32), ("group", C.c_int32), ("group_stride", C.c_int64),
-                ("partials", C.c_void_p)]
+                ("partials", C.c_void_p), ("index", C.c_void_p)]
+
+
+class PsAccessor(C.Structure):
+    _fields_ = [("lr", C.c_float), ("initial_g2sum", C.c_float), ("min_bound", C.c_float), ("max_bound", C.c_float),
+                ("initial_range", C.c_float), ("embedx_threshold", C.c_float), ("nonclk_coeff", C.c_float),
+                ("click_coeff", C.c_float), ("seed", C.c_uint64)]
+
+
+class PsLayout(C.Structure):
+    _fields_ = [("row_stride", C.c_int32), ("embed_off", C.c_int32), ("embedx_off", C.c_int32),
+                ("embedx_dim", C.c_int32), ("stat_off", C.c_int32)]
+
+
+class GradSrc(C.Structure):
+    _fields_ = [("grad", C.c_void_p), ("layout", GradLayout), ("pitch", C.c_int32), ("col", C.c_int32)]
+
+
+class MultislotDesc(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("num_slots", C.c_int32), ("emb_dim", C.c_int32),
+                ("row_stride", C.c_int32), ("key_mode", C.c_int32), ("num_rows", C.c_int64),
+                ("padding_idx", C.c_int64), ("lod_stride", C.c_int64), ("out_stride", C.c_int64),
+                ("state_offset", C.c_int32), ("init_dims", C.c_int32), ("init_range", C.c_float),
+                ("init_seed", C.c_uint64)]
 
 
 class DinDesc(C.Structure):
@@ -80,6 +103,15 @@ SIGNATURES = {
     "rec_segment_partials": (C.c_int, [_I64, _I32, _P, _P, _P, _P, C.POINTER(GradLayout), _P, _P]),
     "rec_sparse_adam_rows": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
                                        _P, _P, _P, C.POINTER(AdamHyper), _P]),
+    "rec_sparse_adam_record": (C.c_int, [_I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
+                                         C.POINTER(GradLayout), _P, _P, _P, C.POINTER(AdamHyper), _P]),
+    "rec_multislot_sumpool_fwd": (C.c_int, [C.POINTER(MultislotDesc)] + [_P] * 10),
+    "rec_feasign_rows": (C.c_int, [_I64, _I64, _P, _P, _P]),
+    "rec_feasign_rows_host": (C.c_int, [_I64, _I64, _P, _P]),
+    "rec_ps_push_rows": (C.c_int, [_I64, _I32, C.POINTER(PsLayout), _P, _P, _P, _P, C.POINTER(GradSrc),
+                                   C.POINTER(GradSrc), _P, _P, _P, C.POINTER(PsAccessor), _P]),
+    "rec_ps_init_value_host": (C.c_float, [C.c_uint64, _I64, _I32, _F]),
+    "rec_ps_shrink_rows": (C.c_int, [_I64, C.POINTER(PsLayout), _P, _F, _F, C.POINTER(PsAccessor), _P, _P]),
     "rec_sparse_adagrad_rows": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
                                           _P, C.POINTER(AdagradHyper), _P]),
     "rec_adam_rows_all": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
@@ -101,7 +133,7 @@ SIGNATURES = {
     "rec_softmax_rows": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P]),
     "rec_cross_bwd_prep": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _I32, _P]),
     "rec_logloss_workspace_bytes": (C.c_int, [_I64, C.POINTER(_SZ)]),
-    "rec_sigmoid_logloss": (C.c_int, [_I64, _I64, _P, _P, _P, _P, _F, _P, _P, _P, _P, _SZ, _P]),
+    "rec_sigmoid_logloss": (C.c_int, [_I64, _I64, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _SZ, _P]),
     "rec_auc_histogram": (C.c_int, [_I64, _P, _P, _I32, _P, _P, _P]),
     "rec_shard_route_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(_SZ)]),
     "rec_shard_route": (C.c_int, [_I64, _I32, _I64, _I64, _I32] + [_P] * 9 + [_SZ, _P]),

@@ -28,8 +28,8 @@ constexpr int kLossBlocks = 1024;
 
 __global__ __launch_bounds__(kBlock) void sigmoid_logloss_kernel(
     int64_t B, float invB, const float* __restrict__ y1, const float* __restrict__ y2,
-    const float* __restrict__ y3, const int64_t* __restrict__ label, float eps,
-    float* __restrict__ pred, float* __restrict__ dz, float* __restrict__ partial) {
+    const float* __restrict__ y3, const int64_t* __restrict__ label, float eps, float clip_lo,
+    float clip_hi, float* __restrict__ pred, float* __restrict__ dz, float* __restrict__ partial) {
   __shared__ float red[kBlock / kWave];
   float local = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B;
@@ -37,12 +37,17 @@ __global__ __launch_bounds__(kBlock) void sigmoid_logloss_kernel(
     float z = y1[i];
     if (y2) z += y2[i];
     if (y3) z += y3[i];
+    // paddle.clip(y, min, max) in front of the sigmoid (slot_dnn/net.py:84); its gradient is 1 strictly
+    // inside the interval, 0 elsewhere [EXT ClipGradFunctor]
+    const bool clipped = clip_lo < clip_hi;
+    const float open = (!clipped || (z > clip_lo && z < clip_hi)) ? 1.f : 0.f;
+    if (clipped) z = fminf(fmaxf(z, clip_lo), clip_hi);
     const float p = 1.f / (1.f + expf(-z));
     const float t = (float)label[i];
     const float cost = -t * logf(p + eps) - (1.f - t) * logf(1.f - p + eps);
     local += cost;
     if (pred) pred[i] = p;
-    if (dz) dz[i] = (-t / (p + eps) + (1.f - t) / (1.f - p + eps)) * invB * (p * (1.f - p));
+    if (dz) dz[i] = (-t / (p + eps) + (1.f - t) / (1.f - p + eps)) * invB * (p * (1.f - p)) * open;
   }
 #pragma unroll
   for (int o = kWave / 2; o > 0; o >>= 1) local += __shfl_xor(local, o, kWave);
@@ -149,7 +154,7 @@ extern "C" int rec_logloss_workspace_bytes(int64_t batch, size_t* bytes) {
 
 extern "C" int rec_sigmoid_logloss(int64_t batch, int64_t mean_over, const float* y1,
                                    const float* y2, const float* y_dnn, const int64_t* label,
-                                   float eps,
+                                   float eps, float clip_lo, float clip_hi,
                                    float* pred, float* dz, float* loss_out, void* workspace,
                                    size_t workspace_bytes, void* stream) {
   REC_REQUIRE(batch > 0 && mean_over >= 0 && y1 && label && loss_out, REC_EINVAL,
@@ -161,7 +166,7 @@ extern "C" int rec_sigmoid_logloss(int64_t batch, int64_t mean_over, const float
   if (grid > kLossBlocks) grid = kLossBlocks;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(sigmoid_logloss_kernel, dim3((unsigned)grid), dim3(kBlock), 0, st, batch, inv,
-                     y1, y2, y_dnn, label, eps, pred, dz, (float*)workspace);
+                     y1, y2, y_dnn, label, eps, clip_lo, clip_hi, pred, dz, (float*)workspace);
   hipLaunchKernelGGL(fold_loss_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)workspace,
                      (int)grid, inv, loss_out);
   return check_launch("rec_sigmoid_logloss");

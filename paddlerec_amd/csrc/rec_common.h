@@ -119,6 +119,30 @@ __device__ __forceinline__ float group_sum(float x) {
   return x;
 }
 
+// murmur3 fmix64: the 64-bit finaliser (public domain, Austin Appleby) — the "64-bit mix" of SURVEY §8(d) cfg5
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return k;
+}
+
+// feasign -> row of a hashed table with N rows: 0 stays the padding row, everything else lands in [1, N)
+__host__ __device__ __forceinline__ int64_t feasign_row(uint64_t f, int64_t N) {
+  return f == 0 ? 0 : (int64_t)(1 + mix64(f) % (uint64_t)(N - 1));
+}
+
+// Value a PS feature is created with (SparseAdaGradSGDRule::InitValue [EXT]: uniform(-range, range)): a pure
+// function of (seed, row, element) so that a row can be born lazily, on the rank that owns it, at its first
+// pull OR push, with the same value — no init pass over a table that is mostly never touched.
+__host__ __device__ __forceinline__ float ps_init_value(uint64_t seed, int64_t row, int d, float range) {
+  const uint64_t h = mix64(seed ^ mix64((uint64_t)row * 0x9E3779B97F4A7C15ull + (uint64_t)(d + 1)));
+  const float u = (float)(h >> 40) * (1.0f / 16777216.0f);   // 24 bits -> [0,1)
+  return (2.f * u - 1.f) * range;
+}
+
 // Dispatch on (emb_dim,row_stride) -> <VEC,LANES>.  F is a generic lambda taking
 // std::integral_constant<int,VEC>, std::integral_constant<int,LANES>.
 template <class F>

@@ -138,7 +138,8 @@ static int run_group(int64_t n, int S, int64_t N, int64_t pad, const int64_t* id
 
 // element offset of the gradient row of lookup position `pos` (see rec_grad_layout)
 __device__ __forceinline__ int64_t grad_offset(const rec_grad_layout& gl, int pos, int D) {
-  const int q = gl.div > 1 ? pos / gl.div : pos;
+  const int p = gl.index ? gl.index[pos] : pos;   // multi-slot CSR: value k -> its (sample, slot) segment
+  const int q = gl.div > 1 ? p / gl.div : p;
   return gl.group > 0 ? (int64_t)(q / gl.group) * gl.group_stride + (int64_t)(q % gl.group) * D
                       : (int64_t)q * D;
 }
@@ -293,6 +294,59 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_rows_kernel(
   vstore<VEC>(P + ro, p);
   vstore<VEC>(M + so, m);
   vstore<VEC>(V + so, v);
+}
+
+// Both embeddings of a DeepFM row in ONE pass (DESIGN.md "table layout"): the record line holds
+//   rec [N, stride] = W(D) | W1 | m1 | v1 | pad      and      mv [N, sstride] = m(D) | v(D)
+// so the first-order table (deepfm/net.py:62-70 `embedding_one`) costs no extra HBM line: the row group that
+// updates W/m/v also updates W1/m1/v1 (lane 0 of the group, same 128-B record line) from the first-order
+// gradient dz[pos / S].  Replaces two launches of sparse_adam_rows_kernel (the second one re-read and re-wrote
+// the record line for 12 useful bytes).
+template <int VEC, int LANES>
+__global__ __launch_bounds__(kBlock) void sparse_adam_record_kernel(
+    int D, int stride, int sstride, int v_off, const int32_t* __restrict__ n_uniq,
+    const int64_t* __restrict__ uniq, const int32_t* __restrict__ seg_off,
+    const int32_t* __restrict__ spos, const float* __restrict__ grad, rec_grad_layout gl,
+    const float* __restrict__ grad1, rec_grad_layout gl1, const float* __restrict__ grad_scale,
+    float* __restrict__ rec, float* __restrict__ MV, float lr_t, float eps_t, float b1, float b2) {
+  const int64_t u = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
+  const int lg = threadIdx.x % LANES;
+  const int d0 = lg * VEC;
+  if (u >= n_uniq[0]) return;
+  const int64_t row = uniq[u];
+  const int beg = seg_off[u], end = seg_off[u + 1];
+  const float sc = grad_scale ? grad_scale[0] : 1.f;
+  float* r = rec + row * stride;
+  if (d0 < D) {
+    float p[VEC], m[VEC], v[VEC], g[VEC];
+    float* mv = MV + row * sstride;
+    vload<VEC>(p, r + d0);
+    vload<VEC>(m, mv + d0);
+    vload<VEC>(v, mv + v_off + d0);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+    segment_sum<VEC>(g, beg, end, spos, grad, gl, D, d0);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      g[i] *= sc;
+      m[i] = b1 * m[i] + (1.f - b1) * g[i];
+      v[i] = b2 * v[i] + (1.f - b2) * g[i] * g[i];
+      p[i] = p[i] - lr_t * (m[i] / (sqrtf(v[i]) + eps_t));
+    }
+    vstore<VEC>(r + d0, p);
+    vstore<VEC>(mv + d0, m);
+    vstore<VEC>(mv + v_off + d0, v);
+  }
+  if (lg == 0) {   // first-order weight + its moments: rec[D], rec[D+1], rec[D+2]
+    float p1 = r[D], m1 = r[D + 1], v1 = r[D + 2];
+    float g1[1] = {0.f};
+    segment_sum<1>(g1, beg, end, spos, grad1, gl1, 1, 0);
+    const float g = g1[0] * sc;
+    m1 = b1 * m1 + (1.f - b1) * g;
+    v1 = b2 * v1 + (1.f - b2) * g * g;
+    p1 = p1 - lr_t * (m1 / (sqrtf(v1) + eps_t));
+    r[D] = p1; r[D + 1] = m1; r[D + 2] = v1;
+  }
 }
 
 // paddle.optimizer.Adam with lazy_mode=False on a SelectedRows gradient (the dygraph default,
@@ -525,7 +579,7 @@ extern "C" int rec_segment_partials(int64_t n_max, int32_t emb_dim, const int32_
                                     const int32_t* seg_offset, const int32_t* sorted_pos,
                                     const float* grad, const rec_grad_layout* grad_layout,
                                     float* partials, void* stream) {
-  rec_grad_layout gl = {1, 0, 0, nullptr};
+  rec_grad_layout gl = {1, 0, 0, nullptr, nullptr};
   if (grad_layout) gl = *grad_layout;
   gl.partials = nullptr;
   REC_REQUIRE(n_max >= 0 && emb_dim > 0 && gl.div >= 1, REC_EINVAL, "bad sizes");
@@ -554,7 +608,7 @@ extern "C" int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_
                                     const float* grad, const rec_grad_layout* grad_layout,
                                     const float* grad_scale, float* P, float* M, float* V,
                                     const rec_adam_hyper* hyper, void* stream) {
-  rec_grad_layout gl = {1, 0, 0, nullptr};
+  rec_grad_layout gl = {1, 0, 0, nullptr, nullptr};
   if (grad_layout) gl = *grad_layout;
   REC_REQUIRE(n_max >= 0 && emb_dim > 0 && row_stride >= emb_dim && gl.div >= 1, REC_EINVAL,
               "bad sizes");
@@ -584,6 +638,45 @@ extern "C" int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_
   });
 }
 
+extern "C" int rec_sparse_adam_record(int64_t n_max, int32_t emb_dim, int32_t rec_stride,
+                                      int32_t state_stride, int32_t v_offset, const int32_t* n_uniq,
+                                      const int64_t* uniq_rows, const int32_t* seg_offset,
+                                      const int32_t* sorted_pos, const float* grad,
+                                      const rec_grad_layout* grad_layout, const float* grad1,
+                                      const rec_grad_layout* grad1_layout, const float* grad_scale,
+                                      float* rec, float* MV, const rec_adam_hyper* hyper, void* stream) {
+  rec_grad_layout gl = {1, 0, 0, nullptr, nullptr}, gl1 = {1, 0, 0, nullptr, nullptr};
+  if (grad_layout) gl = *grad_layout;
+  if (grad1_layout) gl1 = *grad1_layout;
+  REC_REQUIRE(n_max >= 0 && emb_dim > 0 && rec_stride >= emb_dim + 3 && gl.div >= 1 && gl1.div >= 1,
+              REC_EINVAL, "bad sizes (the record holds W(D) | W1 | m1 | v1)");
+  REC_REQUIRE(v_offset >= emb_dim && state_stride >= v_offset + emb_dim, REC_EINVAL,
+              "state line must hold m(D) at 0 and v(D) at v_offset");
+  REC_REQUIRE(gl.group <= 0 || gl.group_stride >= (int64_t)gl.group * emb_dim, REC_EINVAL,
+              "grad group_stride too small");
+  REC_REQUIRE(((uintptr_t)gl.partials) % 16 == 0 && ((uintptr_t)gl1.partials) % 4 == 0, REC_EINVAL,
+              "grad_layout.partials must be 16-byte aligned");
+  REC_REQUIRE(n_uniq && uniq_rows && seg_offset && sorted_pos && grad && grad1 && rec && MV && hyper,
+              REC_EINVAL, "null pointer argument");
+  REC_REQUIRE(hyper->step >= 1, REC_EINVAL, "Adam step must be >= 1");
+  if (n_max == 0) return REC_OK;
+  float lr_t, eps_t;
+  adam_scalars(hyper, &lr_t, &eps_t);
+  const bool vec = ((uintptr_t)grad) % 16 == 0 && (gl.group <= 0 || gl.group_stride % 4 == 0) &&
+                   state_stride % 4 == 0 && v_offset % 4 == 0 && ((uintptr_t)rec) % 16 == 0 &&
+                   ((uintptr_t)MV) % 16 == 0;
+  return dispatch_row_shape(emb_dim, vec ? rec_stride : rec_stride | 1, [&](auto vec_, auto lanes) -> int {
+    constexpr int VEC = decltype(vec_)::value, LANES = decltype(lanes)::value;
+    const int64_t grid = (n_max * LANES + kBlock - 1) / kBlock;
+    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");
+    hipLaunchKernelGGL((sparse_adam_record_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock), 0,
+                       (hipStream_t)stream, emb_dim, rec_stride, state_stride, v_offset, n_uniq, uniq_rows,
+                       seg_offset, sorted_pos, grad, gl, grad1, gl1, grad_scale, rec, MV, lr_t, eps_t,
+                       hyper->beta1, hyper->beta2);
+    return check_launch("rec_sparse_adam_record");
+  });
+}
+
 // ---------------------------------------------------------------------------------------------
 // PS / gpubox accessor rule (slot_dnn/config_online.yaml:57-79): a feature value is
 //   [show, click, embed_w, embedx(D-1)]  (dnn/net.py:71-79: sparse_embedding(size=[N, D+2]) + CVM strips 2)
@@ -603,14 +696,15 @@ __global__ __launch_bounds__(kBlock) void sparse_adagrad_rows_kernel(
   float* r = rec + uniq[u] * stride;
   const int beg = seg_off[u], end = seg_off[u + 1];
   float clicks = 0.f;
+  auto smp = [&](int pos) { return (gl.index ? gl.index[pos] : pos) / S; };   // sample of a lookup position
   if (label) {
     int k = beg;
     for (; k + 4 <= end; k += 4) {   // four independent loads in flight
-      const int64_t l0 = label[spos[k] / S], l1 = label[spos[k + 1] / S], l2 = label[spos[k + 2] / S],
-                    l3 = label[spos[k + 3] / S];
+      const int64_t l0 = label[smp(spos[k])], l1 = label[smp(spos[k + 1])], l2 = label[smp(spos[k + 2])],
+                    l3 = label[smp(spos[k + 3])];
       clicks += (float)(l0 + l1 + l2 + l3);
     }
-    for (; k < end; ++k) clicks += (float)label[spos[k] / S];
+    for (; k < end; ++k) clicks += (float)label[smp(spos[k])];
   }
   r[0] += (float)(end - beg);   // show: every lookup of the row is one impression (dnn/static_model.py:86-94)
   r[1] += clicks;
@@ -639,7 +733,7 @@ extern "C" int rec_sparse_adagrad_rows(int64_t n_max, int32_t emb_dim, int32_t r
                                        const int32_t* sorted_pos, const float* grad,
                                        const rec_grad_layout* grad_layout, const int64_t* label,
                                        float* rec, const rec_adagrad_hyper* hyper, void* stream) {
-  rec_grad_layout gl = {1, 0, 0, nullptr};
+  rec_grad_layout gl = {1, 0, 0, nullptr, nullptr};
   if (grad_layout) gl = *grad_layout;
   REC_REQUIRE(n_max >= 0 && emb_dim > 0 && row_stride >= emb_dim + 4 && num_slots > 0 && gl.div >= 1,
               REC_EINVAL, "bad sizes (row_stride must hold show, click, D weights and 2 g2sum)");
@@ -683,7 +777,7 @@ extern "C" int rec_sparse_rows_sumsq(int64_t n_max, int32_t emb_dim, const int32
                                      const float* grad, const rec_grad_layout* grad_layout,
                                      float* out, int32_t accumulate, void* workspace,
                                      size_t workspace_bytes, void* stream) {
-  rec_grad_layout gl = {1, 0, 0, nullptr};
+  rec_grad_layout gl = {1, 0, 0, nullptr, nullptr};
   if (grad_layout) gl = *grad_layout;
   REC_REQUIRE(n_max >= 0 && emb_dim > 0 && gl.div >= 1 && out, REC_EINVAL, "bad arguments");
   REC_REQUIRE(n_uniq && seg_offset && sorted_pos && grad, REC_EINVAL, "null pointer argument");
@@ -731,7 +825,7 @@ extern "C" int rec_sparse_sgd_rows(int64_t n_max, int32_t emb_dim, int32_t row_s
                                    const int32_t* seg_offset, const int32_t* sorted_pos,
                                    const float* grad, const rec_grad_layout* grad_layout, float* P,
                                    float lr, void* stream) {
-  rec_grad_layout gl = {1, 0, 0, nullptr};
+  rec_grad_layout gl = {1, 0, 0, nullptr, nullptr};
   if (grad_layout) gl = *grad_layout;
   REC_REQUIRE(n_max >= 0 && emb_dim > 0 && row_stride >= emb_dim && gl.div >= 1, REC_EINVAL, "bad sizes");
   REC_REQUIRE(gl.group <= 0 || gl.group_stride >= (int64_t)gl.group * emb_dim, REC_EINVAL,
@@ -767,7 +861,7 @@ extern "C" int rec_adam_rows_all(int64_t num_rows, int32_t emb_dim, int32_t row_
                                  const int32_t* seg_offset, const int32_t* sorted_pos, const float* grad,
                                  const rec_grad_layout* grad_layout, const float* grad_scale, float* P,
                                  float* M, float* V, const rec_adam_hyper* hyper, void* stream) {
-  rec_grad_layout gl = {1, 0, 0, nullptr};
+  rec_grad_layout gl = {1, 0, 0, nullptr, nullptr};
   if (grad_layout) gl = *grad_layout;
   REC_REQUIRE(num_rows >= 0 && emb_dim > 0 && row_stride >= emb_dim && gl.div >= 1, REC_EINVAL, "bad sizes");
   if (state_stride <= 0) state_stride = row_stride;

@@ -10,8 +10,8 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (EPI, AdagradHyper, AdamHyper, DeepFMDesc, DinDesc, GemmDesc, GemmEpilogueArgs, GradLayout, RecError, check,
-                   lib)
+from ._lib import (EPI, AdagradHyper, AdamHyper, DeepFMDesc, DinDesc, GemmDesc, GemmEpilogueArgs, GradLayout,
+                   GradSrc, MultislotDesc, PsAccessor, PsLayout, RecError, check, lib)
 
 
 def _stream():
@@ -225,6 +225,69 @@ def emb_sumpool_bwd(lod, d_out, nnz):
     return row_grad
 
 
+class MultislotBatch:
+    """Device-resident slot-major CSR of one batch (the layout rec_parse_feasign_slots writes):
+    values [nnz] i64, lod [S, B+1] i64, slot_base [S+1] i64."""
+
+    def __init__(self, values, lod, slot_base):
+        _chk(values, torch.int64, "values")
+        _chk(lod, torch.int64, "lod")
+        _chk(slot_base, torch.int64, "slot_base")
+        if lod.dim() != 2 or slot_base.numel() != lod.shape[0] + 1:
+            raise RecError("lod must be [S, B+1] and slot_base [S+1]")
+        self.values, self.lod, self.slot_base = values, lod, slot_base
+        self.num_slots, self.batch = lod.shape[0], lod.shape[1] - 1
+        self.nnz = values.numel()
+
+
+def multislot_sumpool(mb, W, num_rows=None, padding_idx=0, key_mode=0, status=None, out=None, want_counts=True,
+                      want_backward=True, lazy_init=None):
+    """All slots of a batch in one launch (slot_dnn/net.py:63-77): -> (out [B, S*D], counts [B,S] i32 | None,
+    seg_of_value [nnz] i32 | None, rows [nnz] i64 | None, status).  W [N,D] table view (row stride allowed);
+    key_mode 1: values are uint64 feasigns hashed to rows on the device (feasign_rows).
+    lazy_init = (state_offset, init_dims, init_range, seed): PS rows are born at their first pull (PsTable.lazy_init)."""
+    D, stride = _chk_table(W, "W")
+    N = int(num_rows if num_rows is not None else W.shape[0])
+    B, S = mb.batch, mb.num_slots
+    dev = W.device
+    if B * S >= 2 ** 31:
+        raise RecError("batch x slots must stay below 2^31")
+    if out is None:
+        out = torch.empty(B, S * D, dtype=torch.float32, device=dev)
+    else:
+        _chk(out, torch.float32, "out", (B, S * D))
+    counts = torch.empty(B, S, dtype=torch.int32, device=dev) if want_counts else None
+    seg = torch.empty(max(mb.nnz, 1), dtype=torch.int32, device=dev) if want_backward else None
+    rows = torch.empty(max(mb.nnz, 1), dtype=torch.int64, device=dev) if want_backward else None
+    if status is None:
+        status = new_status(dev)
+    d = MultislotDesc(B, S, D, stride, int(key_mode), N, -1 if padding_idx is None else int(padding_idx),
+                      mb.lod.stride(0), 0, *(lazy_init if lazy_init is not None else (0, 0, 0.0, 0)))
+    check(lib().rec_multislot_sumpool_fwd(C.byref(d), _p(mb.values), _p(mb.lod), _p(mb.slot_base), _p(W), _p(out),
+                                          _p(counts), _p(seg), _p(rows), _p(status), _stream()),
+          "rec_multislot_sumpool_fwd")
+    return out, counts, seg, rows, status
+
+
+def feasign_rows(keys, num_rows, out=None):
+    """uint64 feasign bit patterns (int64 tensor) -> rows of a hashed table: 0 -> 0, f -> 1 + mix64(f) % (N-1)."""
+    _chk(keys, torch.int64, "keys")
+    if out is None:
+        out = torch.empty_like(keys)
+    check(lib().rec_feasign_rows(keys.numel(), int(num_rows), _p(keys), _p(out), _stream()), "rec_feasign_rows")
+    return out
+
+
+def feasign_rows_host(keys, num_rows):
+    """Host variant over a numpy uint64 array (bit-identical to the device kernel)."""
+    import numpy as np
+    k = np.ascontiguousarray(keys, dtype=np.uint64)
+    out = np.empty(k.shape, np.int64)
+    check(lib().rec_feasign_rows_host(k.size, int(num_rows), k.ctypes.data_as(C.c_void_p),
+                                      out.ctypes.data_as(C.c_void_p)), "rec_feasign_rows_host")
+    return out
+
+
 # ------------------------------------------------------------------ SelectedRows merge + optimizers
 class IdGroups:
     """Result buffers of rec_ids_group (device)."""
@@ -262,11 +325,14 @@ def ids_group(ids, num_rows, padding_idx, ws, slot_offset=None, status=None, gro
     return groups, status
 
 
-def _gl(div, group, group_stride, partials=None):
-    return GradLayout(int(div), int(group), int(group_stride), partials.data_ptr() if partials is not None else None)
+def _gl(div, group, group_stride, partials=None, index=None):
+    if index is not None:
+        _chk(index, torch.int32, "grad index")
+    return GradLayout(int(div), int(group), int(group_stride), partials.data_ptr() if partials is not None else None,
+                      index.data_ptr() if index is not None else None)
 
 
-def segment_partials(groups, grad, D, grad_div=1, grad_group=0, grad_group_stride=0, out=None):
+def segment_partials(groups, grad, D, grad_div=1, grad_group=0, grad_group_stride=0, out=None, grad_index=None):
     """Tile partial sums of the long segments (hot rows) of `grad` under `groups` -> tensor to pass as
     `partials=` to the row-update ops together with the SAME grad and layout."""
     nbytes = C.c_size_t(0)
@@ -276,7 +342,8 @@ def segment_partials(groups, grad, D, grad_div=1, grad_group=0, grad_group_strid
         out = torch.empty(need, dtype=torch.float32, device=grad.device)
     check(lib().rec_segment_partials(groups.n, int(D), _p(groups.n_uniq), _p(groups.seg_offset),
                                      _p(groups.sorted_pos), _p(grad),
-                                     C.byref(_gl(grad_div, grad_group, grad_group_stride)), _p(out), _stream()),
+                                     C.byref(_gl(grad_div, grad_group, grad_group_stride, None, grad_index)), _p(out),
+                                     _stream()),
           "rec_segment_partials")
     return out
 
@@ -286,7 +353,7 @@ def _hyper(lr, beta1, beta2, eps, step):
 
 
 def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999,
-                     eps=1e-8, grad_group=0, grad_group_stride=0, grad_scale=None, partials=None):
+                     eps=1e-8, grad_group=0, grad_group_stride=0, grad_scale=None, partials=None, grad_index=None):
     """grad_div / grad_group / grad_group_stride: rec_grad_layout (where position pos's row lives in
     grad); grad_scale: device float[1] clipping coefficient or None."""
     if grad_group <= 0:
@@ -301,9 +368,30 @@ def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, 
     h = _hyper(lr, beta1, beta2, eps, step)
     check(lib().rec_sparse_adam_rows(groups.n, D, stride, sstride, _p(groups.n_uniq), _p(groups.uniq_rows),
                                      _p(groups.seg_offset), _p(groups.sorted_pos), _p(grad),
-                                     C.byref(_gl(grad_div, grad_group, grad_group_stride, partials)),
+                                     C.byref(_gl(grad_div, grad_group, grad_group_stride, partials, grad_index)),
                                      _p(grad_scale), _p(P), _p(M), _p(V), C.byref(h), _stream()),
           "rec_sparse_adam_rows")
+
+
+def sparse_adam_record(groups, grad, grad1, grad1_div, rec, mv, D, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                       v_offset=None, grad_scale=None, partials=None, partials1=None):
+    """Lazy Adam on BOTH embeddings of a DeepFM row in one pass: rec [N, stride] = W(D) | W1 | m1 | v1 | pad,
+    mv [N, sstride] = m(D) | v(D) at v_offset.  grad [n,D] row gradients, grad1 = dz with layout {grad1_div,0,0}."""
+    _chk(grad, torch.float32, "grad")
+    _chk(grad1, torch.float32, "grad1")
+    for t, n in ((rec, "rec"), (mv, "mv")):
+        if t.dim() != 2 or t.dtype != torch.float32 or not t.is_cuda or t.stride(1) != 1:
+            raise RecError("%s must be a 2-D float32 device tensor with unit column stride" % n)
+    if mv.shape[0] != rec.shape[0]:
+        raise RecError("rec and mv must have the same number of rows")
+    if v_offset is None:
+        v_offset = (D + 3) // 4 * 4
+    h = _hyper(lr, beta1, beta2, eps, step)
+    check(lib().rec_sparse_adam_record(groups.n, int(D), rec.stride(0), mv.stride(0), int(v_offset),
+                                       _p(groups.n_uniq), _p(groups.uniq_rows), _p(groups.seg_offset),
+                                       _p(groups.sorted_pos), _p(grad), C.byref(_gl(1, 0, 0, partials)), _p(grad1),
+                                       C.byref(_gl(grad1_div, 0, 0, partials1)), _p(grad_scale), _p(rec), _p(mv),
+                                       C.byref(h), _stream()), "rec_sparse_adam_record")
 
 
 def adam_rows_all(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
@@ -323,7 +411,8 @@ def adam_rows_all(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, bet
 
 
 def sparse_adagrad_rows(groups, grad, rec, emb_dim, num_slots, label=None, lr=0.05, initial_g2sum=3.0,
-                        bounds=(-10.0, 10.0), grad_div=1, grad_group=0, grad_group_stride=0, partials=None):
+                        bounds=(-10.0, 10.0), grad_div=1, grad_group=0, grad_group_stride=0, partials=None,
+                        grad_index=None):
     """PS accessor rule (SparseAdaGradSGDRule + show/click) on the touched rows of a record table
     rec [N, stride] = [show | click | g2sum_w | g2sum_x | W(D) | pad]."""
     if rec.dim() != 2 or rec.dtype != torch.float32 or not rec.is_cuda or rec.stride(1) != 1:
@@ -333,8 +422,85 @@ def sparse_adagrad_rows(groups, grad, rec, emb_dim, num_slots, label=None, lr=0.
     h = AdagradHyper(float(lr), float(initial_g2sum), float(bounds[0]), float(bounds[1]))
     check(lib().rec_sparse_adagrad_rows(groups.n, int(emb_dim), rec.stride(0), int(num_slots), _p(groups.n_uniq),
                                         _p(groups.uniq_rows), _p(groups.seg_offset), _p(groups.sorted_pos),
-                                        _p(grad), C.byref(_gl(grad_div, grad_group, grad_group_stride, partials)),
+                                        _p(grad),
+                                        C.byref(_gl(grad_div, grad_group, grad_group_stride, partials, grad_index)),
                                         _p(label), _p(rec), C.byref(h), _stream()), "rec_sparse_adagrad_rows")
+
+
+class PsTable:
+    """A PS / gpubox sparse table on the device: record rows + the accessor parameters
+    (slot_dnn/config_online.yaml:57-89).  kind "slot": W = [embed_w, embedx(D-1)] (slot_dnn / dnn: the looked-up
+    vector is the whole W); kind "deepfm": embedx = the D-dim embedding at 0, embed_w = the first-order weight
+    behind it.  Rows are zero memory until they are born (state float)."""
+
+    def __init__(self, num_rows, emb_dim, device, kind="slot", lr=0.05, initial_g2sum=3.0, bounds=(-10.0, 10.0),
+                 initial_range=1e-4, embedx_threshold=10.0, nonclk_coeff=0.1, click_coeff=1.0, seed=2025,
+                 row_stride=None):
+        D = int(emb_dim)
+        if kind == "slot":      # [W(D) | show | click | g2w | g2x | state]: D = 9 -> 14 floats in a 64-B half line
+            need = D + 5
+            stride = int(row_stride or (16 if need <= 16 else (need + 31) // 32 * 32))
+            self.layout = PsLayout(stride, 0, 1, D - 1, D)
+            self.w_cols = slice(0, D)
+            self.stat = slice(D, D + 4)
+            self.state_col = D + 4
+        elif kind == "deepfm":  # [W(D) | W1 | show | click | g2w | g2x | state | pad]
+            need = D + 6
+            stride = int(row_stride or (need + 31) // 32 * 32)
+            self.layout = PsLayout(stride, D, 0, D, D + 1)
+            self.w_cols = slice(0, D)
+            self.stat = slice(D + 1, D + 5)
+            self.state_col = D + 5
+        else:
+            raise RecError("kind must be 'slot' or 'deepfm'")
+        if stride < need:
+            raise RecError("row_stride %d < %d" % (stride, need))
+        self.kind, self.emb_dim, self.num_rows = kind, D, int(num_rows)
+        self.rec = torch.zeros(int(num_rows), stride, dtype=torch.float32, device=device)
+        self.W = self.rec[:, self.w_cols]
+        self.accessor = PsAccessor(float(lr), float(initial_g2sum), float(bounds[0]), float(bounds[1]),
+                                   float(initial_range), float(embedx_threshold), float(nonclk_coeff),
+                                   float(click_coeff), int(seed))
+
+    @property
+    def lazy_init(self):
+        """(state_offset, init_dims, init_range, seed) for the lookups: what an unborn row reads as.  The looked-up
+        vector starts at embed_w for kind 'slot' (element d of W = accessor element d)."""
+        a = self.accessor
+        dims = self.emb_dim if a.embedx_threshold <= 0 else 1
+        return (self.state_col - self.w_cols.start, dims, a.initial_range, a.seed)
+
+
+def ps_push_rows(table, groups, grad, num_slots, grad_pitch=None, grad_index=None, grad1=None, grad1_div=1,
+                 show=None, click=None):
+    """CtrCommonAccessor::Update on the touched rows of `table` (PsTable).  kind 'slot': grad rows [*, D] hold
+    [g_embed_w, g_embedx...]; kind 'deepfm': grad = the D-dim row gradients, grad1 = dz [B] (layout {grad1_div})."""
+    D = table.emb_dim
+    pitch = int(grad_pitch or D)
+    if table.kind == "slot":
+        gx = GradSrc(grad.data_ptr(), _gl(1, 0, 0, None, grad_index), pitch, 1)
+        gw = GradSrc(grad.data_ptr(), _gl(1, 0, 0, None, grad_index), pitch, 0)
+    else:
+        if grad1 is None:
+            raise RecError("kind 'deepfm' needs grad1 (the first-order gradient)")
+        gx = GradSrc(grad.data_ptr(), _gl(1, 0, 0, None, grad_index), pitch, 0)
+        gw = GradSrc(grad1.data_ptr(), _gl(grad1_div, 0, 0, None, None), 1, 0)
+    for t, n in ((show, "show"), (click, "click")):
+        if t is not None:
+            _chk(t, torch.int64, n)
+    check(lib().rec_ps_push_rows(groups.n, int(num_slots), C.byref(table.layout), _p(groups.n_uniq),
+                                 _p(groups.uniq_rows), _p(groups.seg_offset), _p(groups.sorted_pos), C.byref(gx),
+                                 C.byref(gw), _p(show), _p(click), _p(table.rec), C.byref(table.accessor), _stream()),
+          "rec_ps_push_rows")
+
+
+def ps_shrink_rows(table, decay=0.98, delete_threshold=0.8):
+    """End-of-pass shrink: counters decay, rows below delete_threshold are deleted.  -> number deleted (host sync)."""
+    n = torch.zeros(1, dtype=torch.int64, device=table.rec.device)
+    check(lib().rec_ps_shrink_rows(table.num_rows, C.byref(table.layout), _p(table.rec), float(decay),
+                                   float(delete_threshold), C.byref(table.accessor), _p(n), _stream()),
+          "rec_ps_shrink_rows")
+    return int(n.item())
 
 
 def adam_dense(p, m, v, g, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=None):
@@ -664,14 +830,17 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
 
 
 # ------------------------------------------------------------------ loss head / metric
-def sigmoid_logloss(y1, y2, y_dnn, label, ws, eps=1e-4, want_dz=True, out=None, mean_over=0):
-    """-> pred [B,1], dz [B,1] (or None), loss [1].  mean_over: denominator of the mean (0 -> B)."""
+def sigmoid_logloss(y1, y2, y_dnn, label, ws, eps=1e-4, want_dz=True, out=None, mean_over=0, clip=None):
+    """-> pred [B,1], dz [B,1] (or None), loss [1].  mean_over: denominator of the mean (0 -> B).
+    clip = (lo, hi): paddle.clip on the logit in front of the sigmoid (slot_dnn/net.py:84)."""
     B = y1.numel()
     dev = y1.device
     _chk(y1, torch.float32, "y1")
     _chk(y2, torch.float32, "y2")
     _chk(y_dnn, torch.float32, "y_dnn")
     _chk(label, torch.int64, "label")
+    if clip is not None and not clip[0] < clip[1]:
+        raise RecError("clip must be (lo, hi) with lo < hi")
     if out is None:
         pred = torch.empty(B, 1, dtype=torch.float32, device=dev)
         dz = torch.empty(B, 1, dtype=torch.float32, device=dev) if want_dz else None
@@ -681,8 +850,9 @@ def sigmoid_logloss(y1, y2, y_dnn, label, ws, eps=1e-4, want_dz=True, out=None, 
     nbytes = C.c_size_t(0)
     check(lib().rec_logloss_workspace_bytes(B, C.byref(nbytes)))
     w = ws.get(nbytes.value)
-    check(lib().rec_sigmoid_logloss(B, int(mean_over), _p(y1), _p(y2), _p(y_dnn), _p(label), float(eps), _p(pred),
-                                    _p(dz), _p(loss), _p(w), C.c_size_t(w.numel()), _stream()),
+    lo, hi = (float(clip[0]), float(clip[1])) if clip is not None else (0.0, 0.0)
+    check(lib().rec_sigmoid_logloss(B, int(mean_over), _p(y1), _p(y2), _p(y_dnn), _p(label), float(eps), lo, hi,
+                                    _p(pred), _p(dz), _p(loss), _p(w), C.c_size_t(w.numel()), _stream()),
           "rec_sigmoid_logloss")
     return pred, dz, loss
 

@@ -1,0 +1,201 @@
+"""rank/slot_dnn on the engine — the multi-slot sum-pool net the PS / gpubox benchmarks train.
+
+Host mirror of /root/reference/models/rank/slot_dnn/net.py (`BenchmarkDNNLayer`) and static_model.py:
+    for every slot: sparse_embedding(padding_idx=0, ONE shared table, entry=ShowClickEntry)   net.py:61-69
+                    sequence_pool('sum')                                                       net.py:73
+    y = concat(bows, axis=1)  ->  Linear+ReLU ... Linear(1)                                   net.py:77-82
+    predict = sigmoid(clip(y, -15, 15))                                                        net.py:84
+    cost = mean(log_loss(predict, click))                                                      static_model.py:104-108
+All 408 slots of a batch go through ONE launch of rec_multislot_sumpool_fwd (slot-major CSR straight from the host
+parser, uint64 feasigns hashed to table rows on the device); the backward reads every id's gradient row in place
+from d y (rec_grad_layout.index) — no [nnz, D] tensors in either direction.  Sparse optimizer:
+    "adam"  lazy Adam on the touched rows (static_model.py:110-112 `Adam(lazy_mode=True)`)
+    "ps"    the table accessor of the PS / gpubox mode (config_online.yaml:57-89): AdaGrad rule, show/click counters
+            fed from the show / click inputs (ShowClickEntry), embedx_threshold, lazy feature creation
+Parameter keys: embedding (the shared table), linear_i.{weight,bias}.
+"""
+import math
+
+import torch
+
+from . import ops
+from .deepfm import NUM_THRESHOLDS, _FlatParams, _OnSide, _round_up, auc_metrics
+
+CLIP = (-15.0, 15.0)      # net.py:84
+
+
+class BenchmarkDNNLayer:
+    """net.py:21-85.  forward(batch) -> predict [B,1]; batch = ops.MultislotBatch (values | lod [S,B+1] | slot_base)."""
+
+    def __init__(self, dict_dim, emb_dim, slot_num, layer_sizes, device="cuda", kernels=None, sparse_optimizer="adam",
+                 key_mode=1, accessor=None):
+        """key_mode 1: batch values are uint64 feasign bit patterns (what queuedataset_reader.py feeds), hashed into
+        dict_dim rows on the device; 0: values are rows.  accessor: kwargs of ops.PsTable for sparse_optimizer='ps'."""
+        self.device = torch.device(device)
+        self.k = kernels if kernels is not None else ops
+        self.dict_dim, self.emb_dim, self.slot_num = int(dict_dim), int(emb_dim), int(slot_num)
+        self.layer_sizes = list(layer_sizes)
+        self.key_mode = int(key_mode)
+        self.sparse_optimizer = sparse_optimizer
+        N, D = self.dict_dim, self.emb_dim
+        if sparse_optimizer == "ps":
+            self.table = self.k.PsTable(N, D, self.device, kind="slot", **(accessor or {}))
+            self.rec = self.table.rec
+            self.embedding = self.table.W
+        elif sparse_optimizer == "adam":
+            self.table = None
+            self.rec = torch.zeros(N, _round_up(D, 16), dtype=torch.float32, device=self.device)  # 64-B aligned rows
+            self.embedding = self.rec[:, :D]
+            self.embedding.uniform_(-1e-4, 1e-4)
+            self.embedding[0].zero_()                                    # padding row
+        else:
+            raise ValueError("sparse_optimizer must be 'adam' or 'ps'")
+        sizes = [D * self.slot_num] + self.layer_sizes + [1]                        # net.py:36
+        shapes = []
+        for i in range(len(sizes) - 1):
+            shapes += [("linear_%d.weight" % i, (sizes[i], sizes[i + 1])), ("linear_%d.bias" % i, (sizes[i + 1],))]
+        self.dense = _FlatParams(shapes, self.device)
+        self.n_linear = len(sizes) - 1
+        for i in range(self.n_linear):                                              # net.py:38-46: Normal(std=0.2/sqrt(in))
+            self.dense.p["linear_%d.weight" % i].normal_(0.0, 0.2 / math.sqrt(sizes[i]))
+        p, g = self.dense.p, self.dense.g
+        self.mlp_w = [p["linear_%d.weight" % i] for i in range(self.n_linear)]
+        self.mlp_b = [p["linear_%d.bias" % i] for i in range(self.n_linear)]
+        self.mlp_dw = [g["linear_%d.weight" % i] for i in range(self.n_linear)]
+        self.mlp_db = [g["linear_%d.bias" % i] for i in range(self.n_linear)]
+        self.sparse_state = None
+        self.ws = self.k.Workspace(self.device)
+        self.ws_group = self.k.Workspace(self.device)
+        self.ws_mlp = self.k.Workspace(self.device)
+        self.status = self.k.new_status(self.device)
+        self.step_count = 0
+        self._side = None
+        self._groups = None
+        self.timers = None
+
+    # -- parameters ------------------------------------------------------------------------------
+    def state_dict(self):
+        sd = {"embedding": self.embedding}
+        sd.update(self.dense.p)
+        return sd
+
+    def set_dict(self, sd):
+        cur = self.state_dict()
+        for k, v in sd.items():
+            cur[k].copy_(torch.as_tensor(v).to(self.device).reshape(cur[k].shape))
+        if self.table is not None and "embedding" in sd:        # explicitly set rows exist: state = embedx created
+            self.rec[:, self.table.state_col] = 2.0
+
+    def parameters(self):
+        return list(self.state_dict().values())
+
+    # -- forward ---------------------------------------------------------------------------------
+    def _pool(self, mb, want_backward):
+        lazy = self.table.lazy_init if self.table is not None else None
+        return self.k.multislot_sumpool(mb, self.embedding, self.dict_dim, 0, self.key_mode, self.status,
+                                        want_backward=want_backward, lazy_init=lazy)
+
+    def forward(self, mb):
+        x, _, _, _, _ = self._pool(mb, False)
+        y, _ = self.k.mlp_forward(x, self.mlp_w, self.mlp_b, self.ws_mlp)
+        return torch.sigmoid(torch.clamp(y, CLIP[0], CLIP[1]))
+
+    __call__ = forward
+
+    def _ensure_sparse_state(self):
+        if self.sparse_state is None and self.table is None:
+            D = self.emb_dim
+            Dp = _round_up(D, 4)
+            mv = torch.zeros(self.rec.shape[0], _round_up(2 * Dp, 16), dtype=torch.float32, device=self.device)
+            self.sparse_state = dict(mv=mv, m=mv[:, :D], v=mv[:, Dp:Dp + D])
+
+    def _timed(self, name):
+        from .deepfm import _Timed
+        return _Timed(self.timers, name)
+
+    # -- one full training step ----------------------------------------------------------------------
+    def train_step(self, mb, label, lr=1e-3, auc_stats=None, show=None):
+        """static_model.py:104-112 + the trainer's backward / optimizer step.  label = the click input [B,1] int64;
+        show [B] int64 (None: 1 per sample, the reader's constant show slot).  Returns (loss [1], pred [B,1])."""
+        k, D, S = self.k, self.emb_dim, self.slot_num
+        if mb.num_slots != S:
+            raise ops.RecError("batch has %d slots, the net %d" % (mb.num_slots, S))
+        self._ensure_sparse_state()
+        self.step_count += 1
+        t = self.step_count
+        on_gpu = self.device.type == "cuda"
+        cur = torch.cuda.current_stream() if on_gpu else None
+        if on_gpu and self._side is None:
+            self._side = k.concurrent_stream(self.device)
+        side = self._side if on_gpu else None
+        if self._groups is None or self._groups.n < mb.nnz:
+            self._groups = k.IdGroups(int(mb.nnz * 1.25) + 1, self.device)
+        groups = self._groups
+        with self._timed("pool_fwd"):
+            x, counts, seg, rows, _ = self._pool(mb, True)
+        self.last_counts = counts
+        with _OnSide(side, cur):            # SelectedRows merge keys: the rows the pooling kernel resolved
+            k.ids_group(rows[: mb.nnz], self.dict_dim, 0, self.ws_group, None, self.status, groups)
+        with self._timed("mlp_fwd"):
+            y, acts = k.mlp_forward(x, self.mlp_w, self.mlp_b, self.ws_mlp)
+        pred, dz, loss = k.sigmoid_logloss(y, None, None, label, self.ws, clip=CLIP)
+        if auc_stats is not None:
+            k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
+        with self._timed("mlp_bwd"):
+            dx = k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp)      # [B, S*D]
+        with _OnSide(side, cur):
+            with self._timed("sparse_update"):
+                idx = seg[: mb.nnz]
+                if self.table is not None:
+                    k.ps_push_rows(self.table, groups, dx, S, grad_index=idx, show=show, click=label.reshape(-1))
+                else:
+                    st = self.sparse_state
+                    pp = self._pp = k.segment_partials(groups, dx, D, out=getattr(self, "_pp", None), grad_index=idx)
+                    k.sparse_adam_rows(groups, dx, 1, self.embedding, st["m"], st["v"], t, lr, partials=pp,
+                                       grad_index=idx)
+        k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
+        if on_gpu:
+            cur.wait_stream(self._side)
+        return loss, pred
+
+
+class StaticModel:
+    """slot_dnn/static_model.py:23-118 — the method names of the reference's model class over the engine layer."""
+
+    def __init__(self, config):
+        self.config = config
+        g = config.get
+        self.dict_dim = g("hyper_parameters.dict_dim")
+        self.emb_dim = g("hyper_parameters.emb_dim")
+        self.slot_num = g("hyper_parameters.slot_num")
+        self.layer_sizes = g("hyper_parameters.layer_sizes")
+        self.learning_rate = g("hyper_parameters.optimizer.learning_rate", 0.001)
+
+    def create_model(self, device="cuda", kernels=None, sparse_optimizer=None):
+        tp = self.config.get("table_parameters.embedding.accessor", None)
+        acc = None
+        if sparse_optimizer is None:
+            sparse_optimizer = "ps" if tp else "adam"
+        if tp and sparse_optimizer == "ps":          # config_online.yaml:57-89
+            rule = tp.get("embedx_sgd_param", {}).get("adagrad", {})
+            ctr = tp.get("ctr_accessor_param", {})
+            acc = dict(lr=rule.get("learning_rate", 0.05), initial_g2sum=rule.get("initial_g2sum", 3.0),
+                       bounds=tuple(rule.get("weight_bounds", (-10.0, 10.0))),
+                       initial_range=rule.get("initial_range", 1e-4), embedx_threshold=tp.get("embedx_threshold", 10),
+                       nonclk_coeff=ctr.get("nonclk_coeff", 0.1), click_coeff=ctr.get("click_coeff", 1.0))
+        return BenchmarkDNNLayer(self.dict_dim, self.emb_dim, self.slot_num, self.layer_sizes, device=device,
+                                 kernels=kernels, sparse_optimizer=sparse_optimizer, accessor=acc)
+
+    def create_metrics(self, device="cuda"):
+        return auc_metrics(device)
+
+    def train_forward(self, model, metrics_list, mb, label, show=None):
+        loss, _ = model.train_step(mb, label, self.learning_rate, metrics_list[0] if metrics_list else None, show=show)
+        return loss, metrics_list, {"cost": loss}
+
+    def infer_forward(self, model, metrics_list, mb, label):
+        pred = model.forward(mb)
+        if metrics_list:
+            model.k.auc_histogram(pred.contiguous(), label.contiguous(), metrics_list[0][0], metrics_list[0][1],
+                                  NUM_THRESHOLDS)
+        return metrics_list, None

@@ -1,0 +1,362 @@
+"""Row P — the multi-slot sum-pool kernel and the BenchmarkDNNLayer net built on it (paddlerec_amd/slot_dnn.py;
+reference: models/rank/slot_dnn/net.py:55-85, static_model.py:104-112, queuedataset_reader.py:56-82).
+
+Oracle (oracle/slot_dnn_ref.py) pinned to tests/golden/slot_dnn_D9.npz = the reference's unmodified net.py executed
+over the paddle shim (sparse_embedding + sequence_pool + clip).  CPU: oracle vs golden, host logic of the mirror with
+the oracle-backed operator backend, the feasign hash (C host restatement vs oracle).  `-m gpu`: the HIP kernels
+through the C-ABI — pooled sums within 1e-5, counts / segment ids / rows bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from helpers import load_golden
+from oracle import deepfm_ref as R
+from oracle import slot_dnn_ref as M
+
+DEV = "cuda"
+
+
+def T(a, dev=DEV):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dev)
+
+
+def _golden_problem():
+    g = load_golden("slot_dnn_D9")
+    S = int(g["S"])
+    samples = [[[int(x) for x in cell.split(",")] for cell in row] for row in g["samples"]]
+    values, lod, base = M.csr_from_samples(samples, S)
+    n = int(g["n_mlp"])
+    return g, samples, values, lod, base, [g["mlp_w%d" % i].copy() for i in range(n)], \
+        [g["mlp_b%d" % i].copy() for i in range(n)]
+
+
+def test_oracle_matches_reference_golden():
+    g, _, values, lod, base, mw, mb = _golden_problem()
+    o = M.loss_and_grads(values, lod, base, g["label"], g["W"], mw, mb, padding_idx=0, key_mode=0)
+    np.testing.assert_allclose(o["pool"], g["pooled"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(o["pred"], g["pred"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(o["loss"], g["loss"], rtol=1e-6)
+    assert int(g["n_clipped"]) >= 1                                   # the +-15 clip and its zero gradient are exercised
+    for i in range(int(g["n_mlp"])):
+        # atol = fp32 summation noise of O(0.1..1) gradients (the x24 weights of the fixture): NumPy and torch
+        # reduce in different orders
+        np.testing.assert_allclose(o["dws"][i], g["g_mlp_w%d" % i], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(o["dbs"][i], g["g_mlp_b%d" % i], rtol=1e-5, atol=1e-6)
+    gW = np.zeros_like(g["gW"])
+    gW[o["uniq"]] = o["merged"]
+    np.testing.assert_allclose(gW, g["gW"], rtol=1e-5, atol=1e-6)
+    assert np.all(g["gW"][0] == 0)                                    # padding row: no gradient
+
+
+def test_feasign_hash_host_restatement_matches_oracle(engine_lib):
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(7)
+    keys = rng.integers(0, 2 ** 64, size=4000, dtype=np.uint64)
+    keys[:6] = [0, 1, 2 ** 63, 2 ** 64 - 1, 2 ** 63 + 5, 12345678901234567890]   # > 2^63 feasigns occur
+    for N in (2, 1000, 1_000_003, 10 ** 10):
+        got = ops.feasign_rows_host(keys, N)
+        assert np.array_equal(got, M.feasign_rows(keys, N))
+        assert got[0] == 0 and got[1:].min() >= 1 and got.max() < N
+    assert M.mix64(1) == 0xB456BCFC34C2CB2C                           # murmur3 fmix64(1), published vector
+
+
+def test_ps_init_value_host_matches_oracle(engine_lib):
+    from oracle import ps_ref
+    for seed, row, d in [(2025, 0, 0), (2025, 17, 3), (1, 10 ** 10 - 1, 16), (2 ** 63 + 9, 123456789, 8)]:
+        got = engine_lib.rec_ps_init_value_host(seed, row, d, 1e-4)
+        assert np.float32(got) == ps_ref.init_value(seed, row, d, 1e-4)
+        assert abs(got) <= 1e-4
+
+
+def _random_problem(rng, B, S, N, max_len=6, empty_frac=0.2, pad_frac=0.1, feasigns=False):
+    samples = []
+    for b in range(B):
+        row = []
+        for s in range(S):
+            k = int(rng.integers(0, max_len + 1))
+            if rng.random() < empty_frac:
+                k = 0
+            if feasigns:
+                v = [int(x) for x in rng.integers(1, 2 ** 64, size=k, dtype=np.uint64)]
+            else:
+                v = [int(x) for x in rng.integers(1, N, size=k)]
+            v = [0 if rng.random() < pad_frac else x for x in v]
+            row.append(v)                                              # may be EMPTY: lod[b] == lod[b+1]
+        samples.append(row)
+    return samples
+
+
+def _layer_from_golden(g, mw, mb, device, kernels=None, **kw):
+    from paddlerec_amd.slot_dnn import BenchmarkDNNLayer
+    m = BenchmarkDNNLayer(int(g["N"]), int(g["D"]), int(g["S"]), [w.shape[1] for w in mw[:-1]], device=device,
+                          kernels=kernels, key_mode=0, **kw)
+    sd = {"embedding": g["W"]}
+    for i, (w, b) in enumerate(zip(mw, mb)):
+        sd["linear_%d.weight" % i], sd["linear_%d.bias" % i] = w, b
+    m.set_dict(sd)
+    return m
+
+
+def _check_layer_step(device, kernels, Batch):
+    g, _, values, lod, base, mw, mb = _golden_problem()
+    m = _layer_from_golden(g, mw, mb, device, kernels)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(device)
+    mbatch = Batch(t(values), t(lod), t(base))
+    pred0 = m.forward(mbatch)
+    np.testing.assert_allclose(pred0.cpu().numpy(), g["pred"], rtol=1e-5, atol=1e-6)
+    W0 = g["W"].copy()
+    loss, pred = m.train_step(mbatch, t(g["label"]), lr=1e-3)
+    np.testing.assert_allclose(loss.cpu().numpy()[0], g["loss"], rtol=1e-5)
+    for i in range(int(g["n_mlp"])):
+        np.testing.assert_allclose(m.mlp_dw[i].cpu().numpy(), g["g_mlp_w%d" % i], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(m.mlp_db[i].cpu().numpy(), g["g_mlp_b%d" % i], rtol=1e-4, atol=1e-6)
+    # lazy Adam, step 1, on exactly the rows the reference's sparse gradient touches
+    o = M.loss_and_grads(values, lod, base, g["label"], W0, mw, mb, 0, 0)
+    Wn, Mn, Vn = W0.copy(), np.zeros_like(W0), np.zeros_like(W0)
+    R.adam_update_rows(Wn, Mn, Vn, o["uniq"], o["merged"], 1, lr=1e-3)
+    got = m.embedding.cpu().numpy()
+    np.testing.assert_allclose(m.sparse_state["m"].cpu().numpy(), Mn, rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(got, Wn, rtol=1e-5, atol=2e-6)
+    untouched = np.setdiff1d(np.arange(W0.shape[0]), o["uniq"])
+    assert np.array_equal(got[untouched], W0[untouched])
+    assert np.array_equal(m.last_counts.cpu().numpy(), o["counts"])
+    assert int(m.status.item()) == 0
+
+
+def test_layer_host_logic_on_cpu_backend():
+    """Orchestration of the mirror (buffers, grad-index plumbing, optimizer bookkeeping) with the oracle-backed
+    operator stand-in — no GPU, no HIP kernel."""
+    import cpu_kernels
+    _check_layer_step("cpu", cpu_kernels, cpu_kernels.MultislotBatch)
+
+
+def test_layer_ps_accessor_host_logic_on_cpu_backend():
+    import cpu_kernels
+    _check_ps_layer("cpu", cpu_kernels, cpu_kernels.MultislotBatch)
+
+
+def _check_ps_layer(device, kernels, Batch):
+    """sparse_optimizer='ps': lazy birth at the first pull, AdaGrad rule per part, show/click from the inputs,
+    embedx created only once the score reaches embedx_threshold — three steps against oracle/ps_ref.py."""
+    from oracle import ps_ref
+    from paddlerec_amd.slot_dnn import BenchmarkDNNLayer
+    g, _, values, lod, base, mw, mb = _golden_problem()
+    N, D, S = int(g["N"]), int(g["D"]), int(g["S"])
+    accp = dict(lr=0.05, initial_g2sum=3.0, bounds=(-10.0, 10.0), initial_range=1e-2, embedx_threshold=1.5,
+                nonclk_coeff=0.1, click_coeff=1.0, seed=99)
+    m = BenchmarkDNNLayer(N, D, S, [w.shape[1] for w in mw[:-1]], device=device, kernels=kernels, key_mode=0,
+                          sparse_optimizer="ps", accessor=accp)
+    sd = {}
+    for i, (w, b) in enumerate(zip(mw, mb)):
+        sd["linear_%d.weight" % i], sd["linear_%d.bias" % i] = w / 24.0, b     # un-saturate: real gradients flow
+    m.set_dict(sd)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(device)
+    mbatch = Batch(t(values), t(lod), t(base))
+    L = m.table.layout
+    lay = dict(embed_off=L.embed_off, embedx_off=L.embedx_off, embedx_dim=L.embedx_dim, stat_off=L.stat_off)
+    rec = np.zeros((N, L.row_stride), np.float32)
+    mwn = [w / 24.0 for w in mw]
+    label = g["label"]
+    live = values != 0
+    for step in range(3):
+        # what the pull shows: born rows their weights, unborn rows their creation values
+        Wv = np.stack([ps_ref.pull_value(rec, lay, r, accp, D) for r in range(N)])
+        o = M.loss_and_grads(values, lod, base, label, Wv, mwn, mb, 0, 0)
+        loss, _ = m.train_step(mbatch, t(label), lr=1e-3)
+        np.testing.assert_allclose(loss.cpu().numpy()[0], o["loss"], rtol=2e-5)
+        U = len(o["uniq"])
+        dshow, dclick = np.zeros(U), np.zeros(U)
+        pos = {int(r): i for i, r in enumerate(o["uniq"])}
+        for k in np.nonzero(live)[0]:
+            dshow[pos[int(o["rows"][k])]] += 1
+            dclick[pos[int(o["rows"][k])]] += int(label[o["seg"][k] // S, 0])
+        ps_ref.push_rows(rec, lay, o["uniq"], o["merged"][:, 0], o["merged"][:, 1:], dshow, dclick, accp)
+        got = m.rec.cpu().numpy()
+        so = L.stat_off
+        assert np.array_equal(got[:, so:so + 2], rec[:, so:so + 2]), "show / click counters"
+        assert np.array_equal(got[:, so + 4], rec[:, so + 4]), "feature states"
+        np.testing.assert_allclose(got[:, :D], rec[:, :D], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(got[:, so + 2:so + 4], rec[:, so + 2:so + 4], rtol=1e-4, atol=1e-12)
+        # the MLP's dense Adam moved the weights: mirror it for the next step's oracle forward
+        mwn = [m.mlp_w[i].cpu().numpy().copy() for i in range(len(mwn))]
+        mb = [m.mlp_b[i].cpu().numpy().copy() for i in range(len(mb))]
+    st = rec[:, L.stat_off + 4]
+    assert (st == 0).any() and (st == 1).any() and (st == 2).any()    # unborn, embed-only and full features all occur
+
+
+# ----------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,stride,B,S,N", [(9, 16, 130, 21, 4001), (9, 9, 70, 5, 300), (16, 16, 64, 8, 1000),
+                                            (4, 4, 200, 3, 50), (1, 1, 33, 2, 20), (8, 8, 65, 17, 500),
+                                            (40, 40, 50, 3, 200), (64, 64, 20, 2, 100), (10, 12, 128, 16, 999)])
+def test_multislot_sumpool_vs_oracle(engine_lib, D, stride, B, S, N):
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(D * 1000 + B)
+    samples = _random_problem(rng, B, S, N)
+    values, lod, base = M.csr_from_samples(samples, S)
+    Wfull = rng.standard_normal((N, stride)).astype(np.float32)
+    W = Wfull[:, :D]
+    tW = T(Wfull)[:, :D]
+    mbatch = ops.MultislotBatch(T(values), T(lod), T(base))
+    out, counts, seg, rows, status = ops.multislot_sumpool(mbatch, tW, N, 0, 0)
+    want, wcnt, wseg, wrows = M.multislot_sumpool(values, lod, base, W, 0, 0)
+    assert np.array_equal(counts.cpu().numpy(), wcnt)
+    assert np.array_equal(seg.cpu().numpy()[: len(values)], wseg)
+    assert np.array_equal(rows.cpu().numpy()[: len(values)], wrows)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    assert int(status.item()) == 0
+
+
+@pytest.mark.gpu
+def test_multislot_feasign_keys_oob_and_long_segments(engine_lib):
+    from paddlerec_amd import _lib, ops
+    rng = np.random.default_rng(5)
+    B, S, N, D = 100, 6, 777, 9
+    samples = _random_problem(rng, B, S, N, max_len=40, feasigns=True)      # segments far longer than a sub-step
+    values, lod, base = M.csr_from_samples(samples, S)
+    Wfull = rng.standard_normal((N, 16)).astype(np.float32)
+    mbatch = ops.MultislotBatch(T(values), T(lod), T(base))
+    out, counts, seg, rows, status = ops.multislot_sumpool(mbatch, T(Wfull)[:, :D], N, 0, 1)
+    want, wcnt, wseg, wrows = M.multislot_sumpool(values, lod, base, Wfull[:, :D], 0, 1, N)
+    assert np.array_equal(counts.cpu().numpy(), wcnt) and np.array_equal(rows.cpu().numpy()[: len(values)], wrows)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
+    assert np.array_equal(ops.feasign_rows(T(values), N).cpu().numpy(), M.feasign_rows(values.astype(np.uint64), N))
+    assert int(status.item()) == 0
+    # key_mode 0 with an id outside the table: defined behaviour = skipped + flagged (Paddle raises [EXT])
+    bad = np.array([1, N + 5, 2, -3], np.int64)
+    mb2 = ops.MultislotBatch(T(bad), T(np.array([[0, 2, 4]], np.int64)), T(np.array([0, 4], np.int64)))
+    out2, c2, _, _, st2 = ops.multislot_sumpool(mb2, T(Wfull)[:, :D], N, 0, 0)
+    assert int(st2.item()) & _lib.REC_FLAG_INDEX_OOB
+    assert np.array_equal(c2.cpu().numpy(), [[1], [1]])
+    np.testing.assert_allclose(out2.cpu().numpy(), Wfull[[1, 2], :D], rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_reference_demo_file_through_parser_and_one_launch(engine_lib):
+    """The reference's own multi-value fixture (first lines of slot_dnn/data/demo_10): host parser -> device CSR ->
+    ONE launch for the 300 slots == the per-slot sparse_embedding + sequence_pool of slot_dnn/net.py:63-75."""
+    from paddlerec_amd import ops, reader
+    data = open(os.path.join(GOLDEN, "slot_dnn_demo_4.txt"), "rb").read()
+    N, D = 100003, 9
+    values, lod, base, n = reader.parse_feasign_slots(data, 2, 300, 0)     # hash_rows 0: raw uint64 bit patterns
+    rng = np.random.default_rng(1)
+    Wfull = rng.standard_normal((N, 16)).astype(np.float32)
+    Wfull[0] = 0
+    mbatch = ops.MultislotBatch(T(values.numpy()), T(lod.numpy()), T(base.numpy()))
+    out, counts, seg, rows, status = ops.multislot_sumpool(mbatch, T(Wfull)[:, :D], N, 0, 1)
+    want, wcnt, _, wrows = M.multislot_sumpool(values.numpy(), lod.numpy(), base.numpy(), Wfull[:, :D], 0, 1, N)
+    assert np.array_equal(counts.cpu().numpy(), wcnt)
+    assert np.array_equal(rows.cpu().numpy()[: len(wrows)], wrows)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
+    assert int(counts.max().item()) > 4 and int(status.item()) == 0
+
+
+@pytest.mark.gpu
+def test_multislot_full_size_properties(engine_lib):
+    """B = 65536 x 408 slots x D 9 (the slot_dnn benchmark shape): size-independent properties — pooled counts sum to
+    the number of non-padding ids, every segment equals a torch index_add of the same rows on the same device,
+    seg/rows consistent with the CSR."""
+    from paddlerec_amd import ops
+    B, S, D, N = 65536, 408, 9, 1_000_003
+    g = torch.Generator(device=DEV).manual_seed(3)
+    lens = torch.randint(1, 3, (S, B), device=DEV, generator=g)                    # 1-2 ids per (slot, sample)
+    lod = torch.zeros(S, B + 1, dtype=torch.int64, device=DEV)
+    lod[:, 1:] = torch.cumsum(lens, dim=1)
+    per_slot = lod[:, -1]
+    base = torch.zeros(S + 1, dtype=torch.int64, device=DEV)
+    base[1:] = torch.cumsum(per_slot, 0)
+    nnz = int(base[-1].item())
+    values = torch.randint(1, N, (nnz,), device=DEV, generator=g, dtype=torch.int64)
+    values[torch.rand(nnz, device=DEV, generator=g) < 0.2] = 0
+    rec = torch.randn(N, 16, device=DEV, generator=g)
+    mbatch = ops.MultislotBatch(values, lod, base)
+    out, counts, seg, rows, status = ops.multislot_sumpool(mbatch, rec[:, :D], N, 0, 0)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    assert int(counts.sum().item()) == int((values != 0).sum().item())
+    # reference on the same device: segment id of every value from the CSR, index_add of the gathered rows
+    sl = torch.repeat_interleave(torch.arange(S, device=DEV), per_slot)
+    within = torch.arange(nnz, device=DEV) - base[sl]
+    samp = torch.searchsorted(lod, within.view(S, -1) if False else within.unsqueeze(0).expand(1, -1).contiguous()
+                              .view(-1, 1).squeeze(1).unsqueeze(0), right=True) if False else None
+    # (per-slot searchsorted: rows of lod are the sorted offset tables)
+    samp = torch.empty(nnz, dtype=torch.int64, device=DEV)
+    for s in range(S):
+        a, b = int(base[s].item()), int(base[s + 1].item())
+        samp[a:b] = torch.searchsorted(lod[s], torch.arange(b - a, device=DEV), right=True) - 1
+    want_seg = (samp * S + sl).to(torch.int32)
+    assert torch.equal(seg[:nnz], want_seg)
+    assert torch.equal(rows[:nnz], values)
+    ref = torch.zeros(B * S, D, device=DEV)
+    live = values != 0
+    ref.index_add_(0, want_seg[live].long(), rec[values[live], :D])
+    torch.testing.assert_close(out.view(B * S, D), ref, rtol=1e-5, atol=1e-5)
+    cref = torch.zeros(B * S, dtype=torch.int32, device=DEV)
+    cref.index_add_(0, want_seg[live].long(), torch.ones(int(live.sum()), dtype=torch.int32, device=DEV))
+    assert torch.equal(counts.view(-1), cref)
+
+
+@pytest.mark.gpu
+def test_layer_gpu_vs_golden_and_oracle(engine_lib):
+    from paddlerec_amd import ops
+    _check_layer_step(DEV, None, ops.MultislotBatch)
+
+
+@pytest.mark.gpu
+def test_layer_ps_accessor_gpu(engine_lib):
+    from paddlerec_amd import ops
+    _check_ps_layer(DEV, None, ops.MultislotBatch)
+
+
+@pytest.mark.gpu
+def test_ps_shrink_rows(engine_lib):
+    from oracle import ps_ref
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(11)
+    N, D = 500, 9
+    tbl = ops.PsTable(N, D, DEV, kind="slot")
+    L = tbl.layout
+    rec = np.zeros((N, L.row_stride), np.float32)
+    born = rng.random(N) < 0.7
+    rec[born, :D] = rng.standard_normal((int(born.sum()), D))
+    rec[born, L.stat_off] = rng.integers(1, 30, int(born.sum()))
+    rec[born, L.stat_off + 1] = np.minimum(rec[born, L.stat_off], rng.integers(0, 3, int(born.sum())))
+    rec[born, L.stat_off + 4] = rng.integers(1, 3, int(born.sum()))
+    tbl.rec.copy_(T(rec))
+    deleted = ops.ps_shrink_rows(tbl, 0.98, 0.8)
+    lay = dict(embed_off=L.embed_off, embedx_off=L.embedx_off, embedx_dim=L.embedx_dim, stat_off=L.stat_off)
+    want = rec.copy()
+    wdel = ps_ref.shrink_rows(want, lay, dict(nonclk_coeff=0.1, click_coeff=1.0), 0.98, 0.8)
+    assert deleted == wdel and wdel > 0
+    np.testing.assert_allclose(tbl.rec.cpu().numpy(), want, rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_sparse_adam_record_equals_two_row_passes(engine_lib):
+    """rec_sparse_adam_record == rec_sparse_adam_rows on W + rec_sparse_adam_rows on W1, bit for bit."""
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(2)
+    B, S, N, D = 3000, 26, 5000, 16
+    ids = rng.integers(0, N, (B, S), dtype=np.int64)
+    ids[:, :3] = rng.integers(1, 20, (B, 3))                      # hot rows: long segments through the partials path
+    grad = (rng.standard_normal((B * S, D)) * 0.1).astype(np.float32)
+    dz = (rng.standard_normal((B, 1)) * 0.1).astype(np.float32)
+    rec0 = rng.standard_normal((N, 32)).astype(np.float32) * 0.1
+    rec0[:, D + 2] = np.abs(rec0[:, D + 2])                       # v1 >= 0
+    mv0 = np.abs(rng.standard_normal((N, 32)).astype(np.float32)) * 0.01
+    ws = ops.Workspace(DEV)
+    groups, _ = ops.ids_group(T(ids), N, 0, ws)
+    tg, tdz = T(grad), T(dz)
+    pp = ops.segment_partials(groups, tg, D)
+    pp1 = ops.segment_partials(groups, tdz, 1, grad_div=S)
+    a_rec, a_mv = T(rec0), T(mv0)
+    ops.sparse_adam_rows(groups, tg, 1, a_rec[:, :D], a_mv[:, :D], a_mv[:, D:2 * D], 3, 1e-3, partials=pp)
+    ops.sparse_adam_rows(groups, tdz, S, a_rec[:, D:D + 1], a_rec[:, D + 1:D + 2], a_rec[:, D + 2:D + 3], 3, 1e-3,
+                         partials=pp1)
+    b_rec, b_mv = T(rec0), T(mv0)
+    ops.sparse_adam_record(groups, tg, tdz, S, b_rec, b_mv, D, 3, 1e-3, partials=pp, partials1=pp1)
+    assert torch.equal(a_rec, b_rec) and torch.equal(a_mv, b_mv)
+    assert not torch.equal(b_rec, T(rec0))
