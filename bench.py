@@ -45,22 +45,35 @@ def algorithmic_bytes(B, S, Dn, D):
     return fwd, bwd
 
 
+def designed_bytes(B, S, Dn, D):
+    """Bytes the two kernels are DESIGNED to move per launch: one 128-B record line per lookup
+    (64 B of it useful), compact feat [B,S+1,D] instead of [B,S+Dn,D] — what the PMC counters should show if
+    nothing is re-read.  fwd: ids + lines + dense + feat' + sum_emb + y1,y2;  bwd: feat' + d_feat' + sum_emb + dy +
+    dense (reads), row_grad (write)."""
+    F = S + 1
+    fwd = B * S * 8 + B * S * 128 + B * Dn * 4 + B * F * D * 4 + B * D * 4 + B * 8
+    bwd = 2 * B * F * D * 4 + B * D * 4 + B * 8 + B * Dn * 4 + B * S * D * 4
+    return fwd, bwd
+
+
 def pmc_traffic(B, D):
-    """HBM bytes per launch (fm_fwd + fm_bwd) from the committed rocprofv3 --pmc passes of this same command
+    """HBM bytes per launch of (fm_fwd, fm_bwd) from the COMMITTED rocprofv3 --pmc passes of this same command
     (tools/profile_bench.sh -> profiles/*_pmc_traffic.json: TCC_EA0_RDREQ_{32,64,128}B / WRREQ{,_64B} request
     counters x their sizes, i.e. already in bytes — not the FETCH_SIZE KB figure that needs the x2 gfx950
-    correction).  Only valid for the profiled shape; None otherwise."""
+    correction).  NOT measured in this run (PMC needs rocprofv3 around the process): a cross-reference, returned
+    with the file it came from.  Only valid for the profiled shape; None otherwise."""
     if B != 65536 or D != 16:
-        return None
+        return None, None, None
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, None, None
     try:
         t = json.load(open(files[-1]))
-        return float(t["fm_fwd_kernel"]["hbm_bytes"] + t["fm_bwd_kernel"]["hbm_bytes"])
+        return (float(t["fm_fwd_kernel"]["hbm_bytes"]), float(t["fm_bwd_kernel"]["hbm_bytes"]),
+                os.path.relpath(files[-1], REPO))
     except Exception:
-        return None
+        return None, None, None
 
 
 def mlp_flops(B, sizes):
@@ -135,7 +148,8 @@ def cpu_baseline(B, S, Dn, D, fc, rows_per_table, budget_s=20.0):
         steps += 1
         if t_total > budget_s or steps >= 8:
             break
-    return {"value": B * steps / t_total, "unit": "samples/s", "cores": int(cores), "kind": "port",
+    return {"value": B * steps / t_total, "unit": "samples/s", "cores": int(cores), "host_cores": os.cpu_count(),
+            "kind": "port",
             "sample": "%d full steps of batch %d (oracle: C embedding+FM fwd/bwd + lazy Adam on both tables, "
                       "NumPy/BLAS MLP fwd/bwd + dense Adam), %.1f s" % (steps, B, t_total)}
 
@@ -226,14 +240,31 @@ def main():
         return sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
 
     k_ms = {k: avg_ms(k) for k in model.timers if not k.endswith("@host")}
+    # The roofline kernels once more, the way rocprofv3's kernel trace sees them: back-to-back launches between
+    # one pair of HIP events (no event markers / stream joins between the launches), on the step's own buffers.
+    pair_us = None
+    if dist is None and hasattr(model, "time_fm_pair"):
+        model.timers = None
+        pair_us = model.time_fm_pair([(b[0], b[1]) for b in batches], repeats=20, rounds=3)
     host_ms = {k[:-5]: 1e3 * sum(v) / max(len(v), 1) for k, v in model.timers.items() if k.endswith("@host")}
     host_ms["step_issue_total"] = 1e3 * host_issue / args.steps     # host time inside train_step (no device sync)
     fwd_b, bwd_b = algorithmic_bytes(B, S, Dn, D)
-    t_pair = (k_ms.get("fm_fwd", 0) + k_ms.get("fm_bwd", 0)) * 1e-3
-    achieved = (fwd_b + bwd_b) / t_pair / 1e9 if t_pair > 0 else 0.0
-    sizes = [(S + Dn) * D] + fc + [1]
+    dfwd_b, dbwd_b = designed_bytes(B, S, Dn, D)
+    t_step_pair = (k_ms.get("fm_fwd", 0) + k_ms.get("fm_bwd", 0)) * 1e-3
+    in_step = (fwd_b + bwd_b) / t_step_pair / 1e9 if t_step_pair > 0 else 0.0
+    if pair_us is not None:
+        fwd_s, bwd_s = pair_us[0] * 1e-6, pair_us[1] * 1e-6
+        timing = "%d back-to-back launches per HIP-event pair, median of 3 (agrees with rocprofv3 kernel durations)" % 20
+    else:       # sharded path: only the in-step brackets exist
+        fwd_s, bwd_s = k_ms.get("fm_fwd", 0) * 1e-3, k_ms.get("fm_bwd", 0) * 1e-3
+        timing = "in-step HIP-event brackets"
+    achieved = (fwd_b + bwd_b) / (fwd_s + bwd_s) / 1e9 if fwd_s + bwd_s > 0 else 0.0
+    # flops EXECUTED: layer 0 runs on the folded [B,(S+1)D] input, not on the [B,(S+Dn)D] graph
+    model_compact = getattr(model, "compact", False)
+    sizes = [((S + 1) if model_compact else (S + Dn)) * D] + fc + [1]
     t_gemm = (k_ms.get("mlp_fwd", 0) + k_ms.get("mlp_bwd", 0) + k_ms.get("mlp_bwd_dw0", 0)) * 1e-3
     gemm_tf = 3 * mlp_flops(B, sizes) / t_gemm / 1e12 if k_ms.get("mlp_fwd") else 0.0
+    tr_f, tr_b, tr_src = pmc_traffic(B, D)
     out = {
         "metric": "CTR samples/sec, Criteo DeepFM bs=65536 (train step: fwd+bwd+optimizer)",
         "value": world * B * args.steps / dt, "unit": "samples/s", "n_gpus": world,
@@ -244,16 +275,28 @@ def main():
                    "global_batch": world * B, "parallelism": parallelism,
                    "table_rows_total": N, "loss": loss_v, "index_oob_flag": oob},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(B, D),
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": (tr_f + tr_b) if tr_f is not None else None,
+                     "traffic_source": tr_src,       # committed PMC passes of this command, NOT this run's counters
                      "algorithmic_bytes": fwd_b + bwd_b,
                      "kernel": "fm_fwd_kernel + fm_bwd_kernel (embedding+FM fwd+bwd, SURVEY §8(d) bytes: "
                                "%d B/sample)" % ((fwd_b + bwd_b) // B),
-                     "fm_fwd_ms": k_ms.get("fm_fwd"), "fm_bwd_ms": k_ms.get("fm_bwd"),
-                     "fm_fwd_GBs": fwd_b / (k_ms["fm_fwd"] * 1e-3) / 1e9 if k_ms.get("fm_fwd") else None,
-                     "fm_bwd_GBs": bwd_b / (k_ms["fm_bwd"] * 1e-3) / 1e9 if k_ms.get("fm_bwd") else None},
+                     "timing": timing,
+                     "per_kernel": {
+                         "fm_fwd": {"us": fwd_s * 1e6, "algorithmic_bytes": fwd_b, "designed_bytes": dfwd_b,
+                                    "GBs_algorithmic": fwd_b / fwd_s / 1e9 if fwd_s else None,
+                                    "GBs_designed": dfwd_b / fwd_s / 1e9 if fwd_s else None, "pmc_bytes": tr_f},
+                         "fm_bwd": {"us": bwd_s * 1e6, "algorithmic_bytes": bwd_b, "designed_bytes": dbwd_b,
+                                    "GBs_algorithmic": bwd_b / bwd_s / 1e9 if bwd_s else None,
+                                    "GBs_designed": dbwd_b / bwd_s / 1e9 if bwd_s else None, "pmc_bytes": tr_b}},
+                     # the same pair as bracketed INSIDE a step (event marker + join overhead included)
+                     "in_step_event": {"fm_fwd_ms": k_ms.get("fm_fwd"), "fm_bwd_ms": k_ms.get("fm_bwd"),
+                                       "achieved": in_step, "frac": in_step / HBM_PEAK_GBS},
+                     "frac_designed_bytes": ((dfwd_b + dbwd_b) / (fwd_s + bwd_s) / 1e9 / HBM_PEAK_GBS)
+                     if fwd_s + bwd_s > 0 else None},
         "kernels_ms": k_ms, "host_issue_ms": host_ms,
         "mlp_gemm": {"bound": "mfma", "achieved": gemm_tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": gemm_tf / FP32_MFMA_PEAK_TF},
+                     "frac": gemm_tf / FP32_MFMA_PEAK_TF, "flops_executed_per_step": 3 * mlp_flops(B, sizes)},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

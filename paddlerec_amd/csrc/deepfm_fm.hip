@@ -26,6 +26,8 @@
 //        d_dense_w / d_dense_w_one accumulate in registers over the persistent loop and are folded
 //        in a fixed order (deterministic); the dense part of feat is recomputed as x * dense_w
 //        instead of re-read when dense_w is supplied.
+#include <stdlib.h>
+
 #include "rec_common.h"
 
 namespace rec {
@@ -51,7 +53,7 @@ constexpr int kFwdUnroll = 4;
 constexpr int kDnMax = 16;
 constexpr int kDenseCh = 2;  // ceil(SPW_max * kDnMax / 64) = 8*16/64
 
-template <int VEC, int LANES, int IDCH>
+template <int VEC, int LANES, int IDCH, bool NT>
 __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
     int64_t B, int S, int Dn, int D, int FP, int stride, int w1_stride, int64_t N, int64_t pad,
     const int64_t* __restrict__ ids, const float* __restrict__ dense, const float* __restrict__ W,
@@ -200,7 +202,9 @@ __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
             s[v] += e[u][v];
             q[v] += e[u][v] * e[u][v];
           }
-          if (!compact || f[u] < S) vstore<VEC>(fb + (int64_t)f[u] * D, e[u]);
+          if (!compact || f[u] < S) {
+            if (NT) vstore_nt<VEC>(fb + (int64_t)f[u] * D, e[u]); else vstore<VEC>(fb + (int64_t)f[u] * D, e[u]);
+          }
           if (compact && f[u] == S) {
             float xr[VEC];
 #pragma unroll
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
 constexpr int kBwdUnroll = 4;
 constexpr int kMaxDenseIters = 8;   // wave iterations that may contain dense fields
 
-template <int VEC, int LANES, int NDI>
+template <int VEC, int LANES, int NDI, bool NT>
 __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
     int64_t B, int S, int Dn, int D, int FP, const float* __restrict__ dense,
     const float* __restrict__ feat, const float* __restrict__ sum_emb,
@@ -314,8 +318,13 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
       for (int u = 0; u < kBwdUnroll; ++u) {
         if (dvalid && it0 + u < it_d0) {
           const int f = (it0 + u) * FS + fs;
-          vload<VEC>(e[u], fb + (int64_t)f * D);
-          vload<VEC>(g[u], gb + (int64_t)f * D);
+          if (NT) {   // read-once streams: do not displace the table lines other kernels will want in L2
+            vload_nt<VEC>(e[u], fb + (int64_t)f * D);
+            vload_nt<VEC>(g[u], gb + (int64_t)f * D);
+          } else {
+            vload<VEC>(e[u], fb + (int64_t)f * D);
+            vload<VEC>(g[u], gb + (int64_t)f * D);
+          }
         }
       }
 #pragma unroll
@@ -404,6 +413,23 @@ __global__ __launch_bounds__(kBlock) void fold_partials_kernel(const float* __re
   }
 }
 
+// Launch-geometry knobs, read once from the environment (tools/fm_sweep.py measures them; the defaults below are
+// the measured best on MI355X): REC_FM_FWD_BPC / REC_FM_BWD_BPC = cap on resident blocks per CU (0 = occupancy
+// limit), REC_FM_NT = 1 streams feat / d_feat with non-temporal accesses.
+struct FmTune {
+  int fwd_bpc, bwd_bpc, nt;
+};
+static const FmTune& tune() {
+  static const FmTune t = [] {
+    auto geti = [](const char* k, int dflt) {
+      const char* v = getenv(k);
+      return v && *v ? atoi(v) : dflt;
+    };
+    return FmTune{geti("REC_FM_FWD_BPC", 0), geti("REC_FM_BWD_BPC", 0), geti("REC_FM_NT", 0)};
+  }();
+  return t;
+}
+
 static int check_desc(const rec_deepfm_desc* d) {
   REC_REQUIRE(d, REC_EINVAL, "desc is NULL");
   REC_REQUIRE(d->batch >= 0 && d->num_slots > 0 && d->num_dense >= 0 && d->emb_dim > 0,
@@ -448,19 +474,24 @@ extern "C" int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids
     REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "LDS staging %zu B too large", shmem);
     const int64_t ntiles = (desc->batch + SPW - 1) / SPW;
     const int64_t want = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
-#define REC_FWD_LAUNCH(IDCH)                                                                      \
-  int64_t grid = resident_blocks(fm_fwd_kernel<VEC, LANES, IDCH>, kBlock, shmem);                 \
-  if (grid > want) grid = want;                                                                   \
-  if (grid > kMaxBlocks) grid = kMaxBlocks;                                                       \
-  hipLaunchKernelGGL((fm_fwd_kernel<VEC, LANES, IDCH>), dim3((unsigned)grid), dim3(kBlock), shmem, \
-                     st, desc->batch, S, Dn, D, FP, desc->row_stride, w1_stride, desc->num_rows,   \
-                     desc->padding_idx, ids, dense, W, W1, dense_w, dense_w_one, slot_offset, y1,  \
-                     y2, feat, sum_emb, status)
+#define REC_FWD_LAUNCH2(IDCH, NT_)                                                                \
+  {                                                                                               \
+    int64_t grid = resident_blocks(fm_fwd_kernel<VEC, LANES, IDCH, NT_>, kBlock, shmem);          \
+    if (tune().fwd_bpc > 0 && grid > (int64_t)tune().fwd_bpc * kNumCU) grid = (int64_t)tune().fwd_bpc * kNumCU; \
+    if (grid > want) grid = want;                                                                 \
+    if (grid > kMaxBlocks) grid = kMaxBlocks;                                                     \
+    hipLaunchKernelGGL((fm_fwd_kernel<VEC, LANES, IDCH, NT_>), dim3((unsigned)grid), dim3(kBlock), \
+                       shmem, st, desc->batch, S, Dn, D, FP, desc->row_stride, w1_stride,          \
+                       desc->num_rows, desc->padding_idx, ids, dense, W, W1, dense_w, dense_w_one, \
+                       slot_offset, y1, y2, feat, sum_emb, status);                                \
+  }
+#define REC_FWD_LAUNCH(IDCH) if (tune().nt) REC_FWD_LAUNCH2(IDCH, true) else REC_FWD_LAUNCH2(IDCH, false)
     if (idch <= 1) { REC_FWD_LAUNCH(1); }
     else if (idch <= 2) { REC_FWD_LAUNCH(2); }
     else if (idch <= 4) { REC_FWD_LAUNCH(4); }
     else { REC_FWD_LAUNCH(8); }
 #undef REC_FWD_LAUNCH
+#undef REC_FWD_LAUNCH2
     return check_launch("rec_deepfm_fm_fwd");
   });
 }
@@ -514,21 +545,24 @@ extern "C" int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense
     const size_t shmem = (size_t)kWavesPerBlock * (K > 0 ? K : 1) * sizeof(float);
     float* partial = (float*)workspace;
     int grid = 1;
-#define REC_BWD_LAUNCH(NDI)                                                                       \
+#define REC_BWD_LAUNCH2(NDI, NT_)                                                                 \
   {                                                                                               \
-    int64_t g = resident_blocks(fm_bwd_kernel<VEC, LANES, NDI>, kBlock, shmem);                   \
+    int64_t g = resident_blocks(fm_bwd_kernel<VEC, LANES, NDI, NT_>, kBlock, shmem);              \
+    if (tune().bwd_bpc > 0 && g > (int64_t)tune().bwd_bpc * kNumCU) g = (int64_t)tune().bwd_bpc * kNumCU; \
     if (g > need_blocks) g = need_blocks;                                                         \
     if (g > kMaxBlocks) g = kMaxBlocks;                                                           \
     grid = (int)g;                                                                                \
-  }                                                                                               \
-  hipLaunchKernelGGL((fm_bwd_kernel<VEC, LANES, NDI>), dim3(grid), dim3(kBlock), shmem, st,       \
-                     desc->batch, S, Dn, D, FP, dense, feat, sum_emb, d_feat_dnn, dy1, dy2, dense_w, \
-                     row_grad, partial)
+    hipLaunchKernelGGL((fm_bwd_kernel<VEC, LANES, NDI, NT_>), dim3(grid), dim3(kBlock), shmem, st, \
+                       desc->batch, S, Dn, D, FP, dense, feat, sum_emb, d_feat_dnn, dy1, dy2,      \
+                       dense_w, row_grad, partial);                                                \
+  }
+#define REC_BWD_LAUNCH(NDI) if (tune().nt) REC_BWD_LAUNCH2(NDI, true) else REC_BWD_LAUNCH2(NDI, false)
     if (nd <= 1) { REC_BWD_LAUNCH(1); }
     else if (nd <= 2) { REC_BWD_LAUNCH(2); }
     else if (nd <= 4) { REC_BWD_LAUNCH(4); }
     else { REC_BWD_LAUNCH(8); }
 #undef REC_BWD_LAUNCH
+#undef REC_BWD_LAUNCH2
     if (K > 0) {
       hipLaunchKernelGGL(fold_partials_kernel, dim3(K), dim3(kBlock), 0, st, partial, grid, Dn * D,
                          d_dense_w, d_dense_w_one);

@@ -293,8 +293,14 @@ class DeepFMLayer:
                 # hot rows (Zipf ids): long duplicate runs are pre-reduced per 64-position tile
                 pp = self._pp = self.k.segment_partials(groups, row_grad, row_grad.shape[1], out=getattr(self, "_pp", None))
                 pp1 = self._pp1 = self.k.segment_partials(groups, dz, 1, grad_div=S, out=getattr(self, "_pp1", None))
-                upd(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr, partials=pp)
-                upd(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr, partials=pp1)
+                if self.lazy_mode:
+                    # W, m, v and W1, m1, v1 of a row in ONE pass: W1 / m1 / v1 share the record line with W
+                    D = self.sparse_feature_dim
+                    self.k.sparse_adam_record(groups, row_grad, dz, S, self.fm.rec, st["mv"], D, t, lr,
+                                              v_offset=_round_up(D, 4), partials=pp, partials1=pp1)
+                else:
+                    upd(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr, partials=pp)
+                    upd(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr, partials=pp1)
         with self._timed("mlp_bwd_dw0"):
             finish_dw0()
             self._fold_backward()
@@ -307,6 +313,46 @@ class DeepFMLayer:
 
     def _timed(self, name):
         return _Timed(self.timers, name)
+
+    def time_fm_pair(self, batches, repeats=20, rounds=3):
+        """MEASUREMENT ONLY (bench.py): the two FM kernels of a step, each launched `repeats` times back to back
+        between ONE pair of HIP events on the current stream — the per-launch duration rocprofv3's kernel trace
+        reports (plus the launch boundary), without the event markers and stream joins that bracket a kernel inside
+        a step.  batches: list of (ids, dense); cycled so that a launch never re-reads the previous launch's table
+        lines from cache.  Uses the step's own buffers (feat, d_feat, row_grad).  -> (fwd_us, bwd_us), medians."""
+        ids0, dense0 = batches[0]
+        ids0 = self._concat_ids(ids0)
+        B, S = ids0.shape
+        D = self.sparse_feature_dim
+        y1, y2, feat, sum_emb, _ = self._fm_fwd(ids0, dense0)
+        dfeat = torch.randn(B, self.fp, D, device=self.device) * 1e-3
+        dz = torch.randn(B, 1, device=self.device) * 1e-3
+        out = (self._row_grad_buf(B * S), torch.empty(self.dense_feature_dim, D, device=self.device),
+               torch.empty(self.dense_feature_dim, device=self.device))
+
+        def fwd(i):
+            ids, dense = batches[i % len(batches)]
+            self.k.deepfm_fm_fwd(self._concat_ids(ids), dense, self.fm.embedding, self.fm.embedding_one,
+                                 self.dense.p["fm.dense_w"], self.dense.p["fm.dense_w_one"], self.fm.padding_idx,
+                                 self.fm.slot_offset, self.status, (y1, y2, feat, sum_emb), compact=self.compact)
+
+        def bwd(i):
+            self.k.deepfm_fm_bwd(dense0, feat, sum_emb, dfeat, dz, dz, S, self.ws, out=out,
+                                 dense_w=self.dense.p["fm.dense_w"], compact=self.compact)
+
+        def run(fn):
+            ts = []
+            for _ in range(rounds):
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for i in range(repeats):
+                    fn(i)
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) * 1e3 / repeats)
+            return sorted(ts)[len(ts) // 2]
+        return run(fwd), run(bwd)
 
     def _row_grad_buf(self, n):
         b = getattr(self, "_rg", None)

@@ -336,9 +336,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
                     st = self.sparse_state
                     pp = self._pp = k.segment_partials(groups, recv_g, D, out=getattr(self, "_pp", None))
                     pp1 = self._pp1 = k.segment_partials(groups, recv_g1, 1, out=getattr(self, "_pp1", None))
-                    k.sparse_adam_rows(groups, recv_g, 1, self.fm.embedding, st["m"], st["v"], t, lr, partials=pp)
-                    k.sparse_adam_rows(groups, recv_g1, 1, self.fm.embedding_one, st["m1"], st["v1"], t, lr,
-                                       partials=pp1)
+                    k.sparse_adam_record(groups, recv_g, recv_g1, 1, self.fm.rec, st["mv"], D, t, lr,
+                                         v_offset=(D + 3) // 4 * 4, partials=pp, partials1=pp1)
             # The next batch's lookup needs nothing of this step but the table rows the sparse optimizer just
             # wrote: it goes on the same side stream right behind it — ids / rows exchange over xGMI while the
             # main stream runs the dW GEMMs, the dense all-reduce and the dense Adam.
