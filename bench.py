@@ -240,14 +240,14 @@ def main():
         return sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
 
     k_ms = {k: avg_ms(k) for k in model.timers if not k.endswith("@host")}
+    host_ms = {k[:-5]: 1e3 * sum(v) / max(len(v), 1) for k, v in model.timers.items() if k.endswith("@host")}
+    host_ms["step_issue_total"] = 1e3 * host_issue / args.steps     # host time inside train_step (no device sync)
     # The roofline kernels once more, the way rocprofv3's kernel trace sees them: back-to-back launches between
     # one pair of HIP events (no event markers / stream joins between the launches), on the step's own buffers.
     pair_us = None
     if dist is None and hasattr(model, "time_fm_pair"):
         model.timers = None
         pair_us = model.time_fm_pair([(b[0], b[1]) for b in batches], repeats=20, rounds=3)
-    host_ms = {k[:-5]: 1e3 * sum(v) / max(len(v), 1) for k, v in model.timers.items() if k.endswith("@host")}
-    host_ms["step_issue_total"] = 1e3 * host_issue / args.steps     # host time inside train_step (no device sync)
     fwd_b, bwd_b = algorithmic_bytes(B, S, Dn, D)
     dfwd_b, dbwd_b = designed_bytes(B, S, Dn, D)
     t_step_pair = (k_ms.get("fm_fwd", 0) + k_ms.get("fm_bwd", 0)) * 1e-3

@@ -414,8 +414,9 @@ __global__ __launch_bounds__(kBlock) void fold_partials_kernel(const float* __re
 }
 
 // Launch-geometry knobs, read once from the environment (tools/fm_sweep.py measures them; the defaults below are
-// the measured best on MI355X): REC_FM_FWD_BPC / REC_FM_BWD_BPC = cap on resident blocks per CU (0 = occupancy
-// limit), REC_FM_NT = 1 streams feat / d_feat with non-temporal accesses.
+// the measured best on MI355X, profiles/r02a_fm_sweep.txt): REC_FM_FWD_BPC / REC_FM_BWD_BPC = cap on resident
+// blocks per CU (0 = occupancy limit; 2 and 3 measured slower), REC_FM_NT = 1 streams feat / d_feat with
+// non-temporal accesses (fm_bwd 71.3 -> 64.5 us, fm_fwd 73.8 -> 72.9 us).
 struct FmTune {
   int fwd_bpc, bwd_bpc, nt;
 };
@@ -425,7 +426,7 @@ static const FmTune& tune() {
       const char* v = getenv(k);
       return v && *v ? atoi(v) : dflt;
     };
-    return FmTune{geti("REC_FM_FWD_BPC", 0), geti("REC_FM_BWD_BPC", 0), geti("REC_FM_NT", 0)};
+    return FmTune{geti("REC_FM_FWD_BPC", 0), geti("REC_FM_BWD_BPC", 0), geti("REC_FM_NT", 1)};
   }();
   return t;
 }

@@ -8,20 +8,28 @@
 // Exact f32: v_mfma_f32_16x16x4_f32 is bit-for-bit a k-ordered fmaf chain (157 TF peak, no
 // xf32/TF32 on gfx950), which is what the 1e-5 logit tolerance of the north star needs.
 //
-// Tiling: 256 threads = 4 waves per block; block tile BM x BN, K step 16 through double-buffered
-// LDS (global -> registers -> LDS, next tile's global loads issued before this tile's MFMAs).
-// A wave owns MT x NT MFMA tiles of 16x16; per K step it reads MT A-fragments with one
-// ds_read_b128 each (lane group g = lane>>4 takes k = 4g..4g+3, so MFMA step s multiplies the
-// k = 4g+s slices — every k exactly once, in a fixed order) and NT*4 B values with ds_read_b32.
-//   config "128x128": waves 2x2, wave tile 64x64  (general shapes)
-//   config "128x80" : waves 4x1, wave tile 32x80  (N = 400: the DeepFM MLP width, no column waste)
+// Tiling (measured on MI355X with tools/gemm_lab, profiles/r02b_gemm_lab.txt): block tile BM x BN, K step 16
+// through double-buffered LDS (global -> registers -> LDS, next tile's global loads issued before this tile's
+// MFMAs).  A wave owns MT x NT MFMA tiles of 16x16; per K step it reads its fragments as lane (i = lane & 15,
+// g = lane >> 4) -> k = 4g..4g+3, so MFMA step s multiplies the k = 4g+s slices — every k exactly once, in a
+// fixed order.  LDS images: an operand stored k-contiguous in memory (A row-major) keeps that order, rows padded
+// by 4 floats, fragments by ds_read_b128; B always ends up [k][n] (a [N,K] operand is transposed by the store
+// pass: +33 % on the dX GEMMs against b128 reads of an [n][k] image), fragments by ds_read_b32.
+//   "128x80"   4 waves (4x1), 5 blocks/CU: N = 400, the DeepFM MLP width (no column waste)
+//   "256x80"   8 waves (8x1), 2 blocks/CU: narrow N whose tile count does not fill whole rounds of 128x80
+//   "256x128"  8 waves (4x2), 2 blocks/CU: wide N, many rows (CrossNet 1560^2: 88 -> 117 TF; slot_dnn layer 0)
+//   "128x128"  4 waves (2x2), 4 blocks/CU: general
+//   "80x80"    5 waves (5x1), 4 blocks/CU: the weight-gradient GEMMs (M, N = 400: no padding rows; 64 -> 98 TF)
+//   "64x80"    4 waves (4x1), 6 blocks/CU
 // Blocks are numbered so that the N-tiles of one M-tile run on the same XCD back to back (its A
 // tile is fetched from HBM once and re-read from that XCD's L2).
 // Split-K (trans_a GEMMs with K = batch): partial tiles go to the workspace and are summed in a
-// fixed order by a second kernel (deterministic).
-// Tried and dropped (measured on MI355X, [65536x624]x[624x400]): a barrier-free variant in which every wave
-// stages its own A/B K-slices (76 TF vs 96 TF — the 4x re-read of B costs more than the barriers), static
-// s_setprio staggering of co-resident blocks (no effect).
+// fixed order by a second kernel (deterministic); the split count fills ONE resident round of the config.
+// Tried and dropped (measured on MI355X): a barrier-free variant in which every wave stages its own A/B
+// K-slices (76 TF vs 96 TF), static s_setprio staggering of co-resident blocks (no effect), K step 32 (-20 %:
+// fewer resident blocks), v_mfma_f32_32x32x2_f32 (equal or slower at every tile), XOR-swizzled A rows (equal).
+#include <stdlib.h>
+
 #include "rec_common.h"
 
 namespace rec {
@@ -29,68 +37,56 @@ namespace rec {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kBK = 16;
-constexpr int kLdsPadA = 4;   // A_lds[BM][BK+4]  : 80-B rows, 16-B aligned
-constexpr int kLdsPadB = 4;   // B_lds[BK][BN+4]  : (BN+4) % 8 == 4 -> the two 32-lane halves hit disjoint banks
 
 // ---------------------------------------------------------------------------------- tile loader
-// Logical tile T[R][C].  Memory is either contiguous along C ("N": element (r,c) at p[r*ld + c]) or
-// along R ("T": element (r,c) at p[c*ld + r]).  LDS keeps it as [R][LDS_LD] — or, with LDST, as
-// [C][LDS_LD] (the memory order of a "T" tile, so its float4s are stored whole instead of being
-// scattered across LDS rows, which costs 16-way bank conflicts for R = 128).
-template <int R, int C, int LDS_LD, bool MEMT, bool LDST = false, int NTHR = kBlock>
+// Logical tile T[R][C] of a matrix; MEMT: memory is contiguous along R (element (r,c) at p[c*ld + r]).
+// load(): the thread's float4s of the tile (zeros outside [rmax, cmax)); vec_ok = 16-B aligned rows.
+// store<TRANSPOSE>(): LDS image in memory order, [OUTER][INNER+4] — or transposed, [INNER][OUTER+4].
+template <int R, int C, bool MEMT, int NTHR>
 struct TileLoader {
+  static constexpr int INNER = MEMT ? R : C, OUTER = MEMT ? C : R;
   static constexpr int kVecs = R * C / 4;
   static constexpr int kPerThread = (kVecs + NTHR - 1) / NTHR;
   float4 stage[kPerThread];
-  int tid;   // index of this thread among the NTHR cooperating ones
-  __device__ __forceinline__ explicit TileLoader(int t) : tid(t) {}
 
-  // FAST: the tile is fully inside the matrix and 16-B aligned — straight float4 loads, no checks
-  template <bool FAST>
-  __device__ __forceinline__ void load(const float* __restrict__ p, int64_t ld, int64_t r0,
-                                       int64_t c0, int64_t rmax, int64_t cmax, bool vec_ok) {
+  // MODE 0: the tile is known to be inside the matrix (interior block, full K tile) — straight float4 loads.
+  // MODE 1: branch-free edge handling — the address of a float4 outside [rmax, cmax) is clamped to a valid one
+  //         and the value zeroed by a select.  Needs 16-B aligned rows and contiguous extents that are multiples
+  //         of 4 (a float4 is then either inside or outside).
+  // MODE 2: element-wise bounds checks (the K tail tile, unaligned operands).
+  // Modes 0/1 keep a tile's loads back to back and in flight under the MFMAs; a branchy loader in the steady-state
+  // loop makes the compiler wait vmcnt(0) before the first MFMA (measured: 78 vs 110 TF).
+  template <int MODE>
+  __device__ __forceinline__ void load(const float* __restrict__ p, int64_t ld, int64_t r0, int64_t c0,
+                                       int64_t rmax, int64_t cmax, bool vec_ok, int tid) {
 #pragma unroll
     for (int it = 0; it < kPerThread; ++it) {
-      const int v = tid + it * NTHR;
+      // threads beyond the tile's last float4 re-load that one (unconditional loads: no exec-mask branch, no
+      // vmcnt(0) in front of the MFMAs); only their LDS store is skipped
+      const int v0 = tid + it * NTHR;
+      const int v = (kVecs % NTHR == 0 || v0 < kVecs) ? v0 : kVecs - 1;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (FAST) {
-        if (kVecs % NTHR == 0 || v < kVecs) {
-          if (!MEMT) {
-            const int r = v / (C / 4), c4 = (v % (C / 4)) * 4;
-            x = *reinterpret_cast<const float4*>(p + (r0 + r) * ld + (c0 + c4));
+      {
+        const int o = v / (INNER / 4), i4 = (v % (INNER / 4)) * 4;
+        const int64_t go = (MEMT ? c0 : r0) + o, gi = (MEMT ? r0 : c0) + i4;
+        const int64_t omax = MEMT ? cmax : rmax, imax = MEMT ? rmax : cmax;
+        if (MODE == 0) {
+          x = *reinterpret_cast<const float4*>(p + go * ld + gi);
+        } else if (MODE == 1) {
+          const bool ok = go < omax && gi + 3 < imax;
+          const int64_t go_c = go < omax ? go : omax - 1;
+          const int64_t gi_c = gi + 3 < imax ? gi : 0;
+          const float4 t = *reinterpret_cast<const float4*>(p + go_c * ld + gi_c);
+          x.x = ok ? t.x : 0.f; x.y = ok ? t.y : 0.f; x.z = ok ? t.z : 0.f; x.w = ok ? t.w : 0.f;
+        } else if (go < omax) {
+          const float* q = p + go * ld + gi;
+          if (vec_ok && gi + 3 < imax) {
+            x = *reinterpret_cast<const float4*>(q);
           } else {
-            const int c = v / (R / 4), r4 = (v % (R / 4)) * 4;
-            x = *reinterpret_cast<const float4*>(p + (c0 + c) * ld + (r0 + r4));
-          }
-        }
-      } else if (kVecs % NTHR == 0 || v < kVecs) {
-        if (!MEMT) {
-          const int r = v / (C / 4), c4 = (v % (C / 4)) * 4;
-          const int64_t gr = r0 + r, gc = c0 + c4;
-          if (gr < rmax) {
-            const float* q = p + gr * ld + gc;
-            if (vec_ok && gc + 3 < cmax) {
-              x = *reinterpret_cast<const float4*>(q);
-            } else {
-              if (gc + 0 < cmax) x.x = q[0];
-              if (gc + 1 < cmax) x.y = q[1];
-              if (gc + 2 < cmax) x.z = q[2];
-              if (gc + 3 < cmax) x.w = q[3];
-            }
-          }
-        } else {
-          const int c = v / (R / 4), r4 = (v % (R / 4)) * 4;
-          const int64_t gr = r0 + r4, gc = c0 + c;
-          if (gc < cmax) {
-            const float* q = p + gc * ld + gr;
-            if (vec_ok && gr + 3 < rmax) {
-              x = *reinterpret_cast<const float4*>(q);
-            } else {
-              if (gr + 0 < rmax) x.x = q[0];
-              if (gr + 1 < rmax) x.y = q[1];
-              if (gr + 2 < rmax) x.z = q[2];
-              if (gr + 3 < rmax) x.w = q[3];
-            }
+            if (gi + 0 < imax) x.x = q[0];
+            if (gi + 1 < imax) x.y = q[1];
+            if (gi + 2 < imax) x.z = q[2];
+            if (gi + 3 < imax) x.w = q[3];
           }
         }
       }
@@ -98,23 +94,20 @@ struct TileLoader {
     }
   }
 
-  __device__ __forceinline__ void store(float* __restrict__ lds) const {
+  template <bool TRANSPOSE>
+  __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
 #pragma unroll
     for (int it = 0; it < kPerThread; ++it) {
       const int v = tid + it * NTHR;
       if (kVecs % NTHR == 0 || v < kVecs) {
-        if (!MEMT) {
-          const int r = v / (C / 4), c4 = (v % (C / 4)) * 4;
-          *reinterpret_cast<float4*>(lds + r * LDS_LD + c4) = stage[it];
-        } else if (LDST) {
-          const int c = v / (R / 4), r4 = (v % (R / 4)) * 4;
-          *reinterpret_cast<float4*>(lds + c * LDS_LD + r4) = stage[it];
+        const int o = v / (INNER / 4), i4 = (v % (INNER / 4)) * 4;
+        if (!TRANSPOSE) {
+          *reinterpret_cast<float4*>(lds + o * (INNER + 4) + i4) = stage[it];
         } else {
-          const int c = v / (R / 4), r4 = (v % (R / 4)) * 4;
-          lds[(r4 + 0) * LDS_LD + c] = stage[it].x;
-          lds[(r4 + 1) * LDS_LD + c] = stage[it].y;
-          lds[(r4 + 2) * LDS_LD + c] = stage[it].z;
-          lds[(r4 + 3) * LDS_LD + c] = stage[it].w;
+          lds[(i4 + 0) * (OUTER + 4) + o] = stage[it].x;
+          lds[(i4 + 1) * (OUTER + 4) + o] = stage[it].y;
+          lds[(i4 + 2) * (OUTER + 4) + o] = stage[it].z;
+          lds[(i4 + 3) * (OUTER + 4) + o] = stage[it].w;
         }
       }
     }
@@ -158,24 +151,23 @@ __device__ __forceinline__ float apply_epi(float acc, int64_t i, int j, const Ep
 }
 
 // --------------------------------------------------------------------------------------- kernel
-// Blocks per CU each config is built for (launch bound = waves per SIMD for 256-thread blocks): the
-// narrow config at 5 makes the 2560 tiles of a [65536 x 400] product exactly two full rounds.
-template <int BN>
-constexpr int gemm_blocks_per_cu() { return BN == 80 ? 5 : 4; }
-
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(kBlock, gemm_blocks_per_cu<BN>()) void gemm_f32_kernel(
+// OCC = blocks per CU the config is built for (launch bound = waves per SIMD).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OCC, bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N + 3) / 4) void gemm_f32_kernel(
     int64_t M, int N, int K, const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
     int64_t ldb, float* __restrict__ C, int64_t ldc, EpiArgs epi, int tiles_n, int64_t tiles_total,
-    int k_chunk, bool vec_a, bool vec_b, float* __restrict__ partial,
+    int k_chunk, bool vec_a, bool vec_b, bool fast, float* __restrict__ partial,
     float* __restrict__ colsum_partial, int splits_in_x) {
+  constexpr int NTHR = WAVES_M * WAVES_N * kWave;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MT = WTM / 16, NT = WTN / 16;
-  // A in LDS: [BM][BK+4] (b128 fragment reads) — or k-major [BK][BM+4] when A is stored [K,M]
-  constexpr int LDA_S = TA ? BM + kLdsPadB : kBK + kLdsPadA, LDB_S = BN + kLdsPadB;
-  constexpr int A_ELEMS = TA ? kBK * LDA_S : BM * LDA_S;
-  __shared__ __attribute__((aligned(16))) float As[2][A_ELEMS];
-  __shared__ __attribute__((aligned(16))) float Bs[2][kBK * LDB_S];
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of the 16x16 MFMA tile");
+  // A in LDS: [BM][BK+4] (b128 fragment reads) — or k-major [BK][BM+4] when A is stored [K,M];  B: [BK][BN+4]
+  constexpr int LDA_S = TA ? BM + 4 : kBK + 4, LDB_S = BN + 4;
+  constexpr int A_ELEMS = TA ? kBK * LDA_S : BM * LDA_S, B_ELEMS = kBK * LDB_S;
+  extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+  float* As = gemm_smem;                  // [2][A_ELEMS]
+  float* Bs = gemm_smem + 2 * A_ELEMS;    // [2][B_ELEMS]
 
   // XCD-aware numbering (block b runs on XCD b % 8, each XCD has its own L2):
   //  * no split-K: every XCD gets a contiguous range of tiles, so the N-tiles that share an A tile run on the
@@ -200,13 +192,13 @@ __global__ __launch_bounds__(kBlock, gemm_blocks_per_cu<BN>()) void gemm_f32_ker
   const int k_begin = kz * k_chunk;
   const int k_end = (k_begin + k_chunk < K) ? k_begin + k_chunk : K;
 
-  const int lane = threadIdx.x % kWave;
-  const int wave = threadIdx.x / kWave;
+  const int tid = threadIdx.x;
+  const int lane = tid % kWave, wave = tid / kWave;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 15, g = lane >> 4;
 
-  TileLoader<BM, kBK, LDA_S, TA, TA> la(threadIdx.x);
-  TileLoader<kBK, BN, LDB_S, TB> lb(threadIdx.x);
+  TileLoader<BM, kBK, TA, NTHR> la;
+  TileLoader<kBK, BN, TB, NTHR> lb;
 
   f32x4_t acc[MT][NT];
 #pragma unroll
@@ -220,69 +212,88 @@ __global__ __launch_bounds__(kBlock, gemm_blocks_per_cu<BN>()) void gemm_f32_ker
   float csum = 0.f;
 
   const int nkt = (k_end - k_begin + kBK - 1) / kBK;
-  // interior blocks (tile fully inside, K range a multiple of 16, aligned operands) take the
-  // check-free loader; edge blocks the predicated one.  The choice is block-uniform.
-  const bool interior = vec_a && vec_b && m0 + BM <= M && n0 + BN <= N &&
-                        (k_end - k_begin) % kBK == 0;
-  auto mainloop = [&](auto fast_tag) {
-    constexpr bool FAST = decltype(fast_tag)::value;
-  if (nkt > 0) {
-    la.template load<FAST>(A, lda, m0, k_begin, M, k_end, vec_a);
-    lb.template load<FAST>(B, ldb, k_begin, n0, k_end, N, vec_b);
-    la.store(As[0]);
-    lb.store(Bs[0]);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) {   // next tile's global loads fly under this tile's MFMAs
-      const int k0 = k_begin + (kt + 1) * kBK;
-      la.template load<FAST>(A, lda, m0, k0, M, k_end, vec_a);
-      lb.template load<FAST>(B, ldb, k0, n0, k_end, N, vec_b);
-    }
-    const float* bs = Bs[cur] + (g * 4) * LDB_S + wn * WTN + li;
-    float4 af[MT];
-    float bf[NT][4];
-    if (TA) {
-      const float* as = As[cur] + (g * 4) * LDA_S + wm * WTM + li;
+  // The K range splits into tiles loaded branch-free (every full tile, if the operands allow it: `fast`) and, at
+  // most, one checked tail tile.
+  const bool tail = !fast || (k_end - k_begin) % kBK != 0;
+  const int n_fast = fast ? (tail ? nkt - 1 : nkt) : 0;
+
+  auto load_tile = [&](int kt, auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    const int k0 = k_begin + kt * kBK;
+    la.template load<MODE>(A, lda, m0, k0, M, k_end, vec_a, tid);
+    lb.template load<MODE>(B, ldb, k0, n0, k_end, N, vec_b, tid);
+  };
+  auto store_tile = [&](int buf) {
+    la.template store<false>(As + buf * A_ELEMS, tid);
+    lb.template store<TB>(Bs + buf * B_ELEMS, tid);
+  };
+  auto compute = [&](int cur) {
+    const float* as = As + cur * A_ELEMS;
+    const float* bs = Bs + cur * B_ELEMS;
+    float af[MT][4], bf[NT][4];
 #pragma unroll
-      for (int a = 0; a < MT; ++a)
-        af[a] = make_float4(as[a * 16], as[LDA_S + a * 16], as[2 * LDA_S + a * 16],
-                            as[3 * LDA_S + a * 16]);
-    } else {
-      const float* as = As[cur] + (wm * WTM + li) * LDA_S + g * 4;
+    for (int a = 0; a < MT; ++a) {
+      const int row = wm * WTM + a * 16 + li;
+      if (!TA) {
+        const float4 t = *reinterpret_cast<const float4*>(as + row * LDA_S + g * 4);
+        af[a][0] = t.x; af[a][1] = t.y; af[a][2] = t.z; af[a][3] = t.w;
+      } else {
 #pragma unroll
-      for (int a = 0; a < MT; ++a) af[a] = *reinterpret_cast<const float4*>(as + a * 16 * LDA_S);
-    }
-#pragma unroll
-    for (int b = 0; b < NT; ++b)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) bf[b][s] = bs[s * LDB_S + b * 16];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int a = 0; a < MT; ++a) {
-        const float av = s == 0 ? af[a].x : s == 1 ? af[a].y : s == 2 ? af[a].z : af[a].w;
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[b][s], acc[a][b], 0, 0, 0);
+        for (int s_ = 0; s_ < 4; ++s_) af[a][s_] = as[(g * 4 + s_) * LDA_S + row];
       }
     }
-    if (do_colsum && threadIdx.x < BN) {
 #pragma unroll
-      for (int kk = 0; kk < kBK; ++kk) csum += Bs[cur][kk * LDB_S + threadIdx.x];
+    for (int b = 0; b < NT; ++b) {
+      const int col = wn * WTN + b * 16 + li;
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) bf[b][s_] = bs[(g * 4 + s_) * LDB_S + col];
     }
-    if (kt + 1 < nkt) {
-      la.store(As[cur ^ 1]);
-      lb.store(Bs[cur ^ 1]);
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][s_], bf[b][s_], acc[a][b], 0, 0, 0);
+    if (do_colsum && tid < BN) {
+#pragma unroll
+      for (int kk = 0; kk < kBK; ++kk) csum += bs[kk * LDB_S + tid];
     }
+  };
+  using Checked = std::integral_constant<int, 2>;
+  // steady state over the branch-free tiles: next tile's loads are issued first and fly under this tile's MFMAs
+  auto steady = [&](auto mode_tag) {
+    load_tile(0, mode_tag);
+    store_tile(0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < n_fast; ++kt) {
+      load_tile(kt + 1, mode_tag);
+      __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMAs
+      compute(kt & 1);
+      store_tile((kt + 1) & 1);
+      __syncthreads();
+    }
+    return kt;
+  };
+  int kt = 0;
+  if (n_fast > 0) {
+    const bool interior = m0 + BM <= M && n0 + BN <= N;   // block-uniform
+    kt = interior ? steady(std::integral_constant<int, 0>{}) : steady(std::integral_constant<int, 1>{});
+  } else if (nkt > 0) {
+    load_tile(0, Checked{});
+    store_tile(0);
     __syncthreads();
   }
-  };
-  if (interior) mainloop(std::integral_constant<bool, true>{});
-  else mainloop(std::integral_constant<bool, false>{});
-  if (do_colsum && threadIdx.x < BN && n0 + (int)threadIdx.x < N)
-    colsum_partial[(int64_t)kz * N + n0 + threadIdx.x] = csum;
+  for (; kt < nkt; ++kt) {                 // last branch-free tile and/or the checked tail tile(s)
+    const bool next = kt + 1 < nkt;
+    if (next) load_tile(kt + 1, Checked{});
+    compute(kt & 1);
+    if (next) store_tile((kt + 1) & 1);
+    __syncthreads();
+  }
+  if (do_colsum && tid < BN && n0 + tid < N)
+    colsum_partial[(int64_t)kz * N + n0 + tid] = csum;
 
   // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
   float* out = partial ? partial + (int64_t)kz * M * ldc : C;
@@ -491,8 +502,20 @@ __global__ __launch_bounds__(kBlock) void colsum_final_kernel(int nblk, int N,
   out[j] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
 }
 
+// ------------------------------------------------------------------------------- config selection
+enum GemmCfg { CFG_128x80 = 0, CFG_256x80, CFG_256x128, CFG_128x128, CFG_80x80, CFG_64x80, CFG_128x80_O4, CFG_COUNT };
+struct CfgInfo {
+  int bm, bn, threads, occ;
+  float eff;   // relative throughput of a full tile of this config (tools/gemm_lab measurements)
+};
+static const CfgInfo kCfg[CFG_COUNT] = {
+    {128, 80, 256, 5, 1.00f},  {256, 80, 512, 2, 0.97f}, {256, 128, 512, 2, 1.08f},
+    {128, 128, 256, 4, 1.00f}, {80, 80, 320, 4, 0.98f},  {64, 80, 256, 6, 0.97f},
+    {128, 80, 256, 4, 1.00f},   // 128x80 built for 4 blocks/CU (128 VGPRs: no spills) — experiment
+};
+
 struct GemmPlan {
-  bool narrow;      // 128x80 config
+  int cfg;
   int tiles_n;
   int64_t tiles_m, tiles_total;
   int splits, k_chunk;
@@ -505,21 +528,39 @@ static bool skinny_dw(const rec_gemm_desc* d) {     // C[M<=1024, N<=4] = A^T B 
   return d->n <= kSkinnyN && d->trans_a && !d->trans_b && d->m <= kSkinnyMT * kBlock && d->k >= 1024;
 }
 
+static int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Config choice from the measurements of profiles/r02b_gemm_*.txt (MI355X, f32):
+//   few output rows (weight gradients, K = batch): 80x80 — M, N = 400 tile exactly, 90 vs 67 TF for 128x128;
+//   many rows: the tile width that wastes fewer columns (80 vs 128), on 256-row / 8-wave blocks when there are
+//   enough rows (256x80: 100-105 TF on N = 400/432 and 121 TF on N = 1560, 256x128: 123-131 TF on N = 512 / 1560 /
+//   4096); the 4-wave versions (128x80, 128x128) for short matrices.
 static GemmPlan plan_gemm(const rec_gemm_desc* d, int num_cus = kNumCU) {
   GemmPlan p;
-  const int N = d->n;
-  // 128x80 when it wastes fewer columns than 128x128 (N = 400 -> 5 x 80 exactly)
-  const int w128 = (N + 127) / 128 * 128 - N, w80 = (N + 79) / 80 * 80 - N;
-  p.narrow = w80 < w128;
-  const int bn = p.narrow ? 80 : 128;
-  p.tiles_n = (N + bn - 1) / bn;
-  p.tiles_m = (d->m + 127) / 128;
+  const int nkt = (d->k + kBK - 1) / kBK;
+  int best;
+  if (d->m < 2048) {
+    const int64_t a80 = ceil_div64(d->m, 80) * 80 * ceil_div64(d->n, 80) * 80;
+    const int64_t a128 = ceil_div64(d->m, 128) * 128 * ceil_div64(d->n, 128) * 128;
+    best = a80 <= a128 + a128 / 16 ? CFG_80x80 : CFG_128x128;
+  } else {
+    const int64_t w80 = ceil_div64(d->n, 80) * 80 - d->n, w128 = ceil_div64(d->n, 128) * 128 - d->n;
+    const bool tall = d->m >= 8192;
+    best = w80 < w128 ? (tall ? CFG_256x80 : CFG_128x80) : (tall ? CFG_256x128 : CFG_128x128);
+  }
+  {   // experiments: REC_GEMM_FORCE_CFG=<index> overrides the choice (tools/gemm_lab)
+    static const int forced = [] { const char* v = getenv("REC_GEMM_FORCE_CFG"); return v && *v ? atoi(v) : -1; }();
+    if (forced >= 0 && forced < CFG_COUNT) best = forced;
+  }
+  p.cfg = best;
+  const CfgInfo& f = kCfg[best];
+  p.tiles_n = (int)ceil_div64(d->n, f.bn);
+  p.tiles_m = ceil_div64(d->m, f.bm);
   p.tiles_total = p.tiles_m * p.tiles_n;
   int splits = d->split_k;
-  const int nkt = (d->k + kBK - 1) / kBK;
   if (splits <= 0) {  // auto: split K when the output alone cannot fill the chip
     splits = 1;
-    const int64_t capacity = (int64_t)num_cus * (p.narrow ? gemm_blocks_per_cu<80>() : gemm_blocks_per_cu<128>());
+    const int64_t capacity = (int64_t)num_cus * f.occ;
     if (p.tiles_total * 2 <= capacity) {
       // as many splits as still fit in ONE resident round (one block more would double the time)
       int64_t want = capacity / p.tiles_total;
@@ -547,25 +588,39 @@ static int check_gemm(const rec_gemm_desc* d) {
   return REC_OK;
 }
 
-template <int BM, int BN, int WM_, int WN_, bool TA, bool TB, int EPI>
+template <int BM, int BN, int WM_, int WN_, int OCC, bool TA, bool TB, int EPI>
 static void launch_one(const rec_gemm_desc* d, const GemmPlan& p, const float* A, const float* B,
                        float* C, const EpiArgs& e, float* partial, float* cpart, hipStream_t st) {
   const bool vec_a = (d->lda % 4 == 0) && (((uintptr_t)A) % 16 == 0);
   const bool vec_b = (d->ldb % 4 == 0) && (((uintptr_t)B) % 16 == 0);
+  // branch-free tile loads: aligned operands whose contiguous extents are multiples of 4 (a float4 is then either
+  // inside or outside the matrix) and hold at least one float4
+  const int64_t a_inner = TA ? d->m : d->k, b_inner = TB ? d->k : d->n;
+  const bool fast = vec_a && vec_b && a_inner % 4 == 0 && b_inner % 4 == 0 && a_inner >= 4 && b_inner >= 4;
   const bool fold = p.splits >= 8 && p.splits % 8 == 0 && p.tiles_total * p.splits < (1ll << 31);
   dim3 grid(fold ? (unsigned)(p.tiles_total * p.splits) : (unsigned)p.tiles_total,
             fold ? 1u : (unsigned)p.splits);
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM_, WN_, TA, TB, EPI>), grid, dim3(kBlock), 0, st,
-                     d->m, d->n, d->k, A, (int64_t)d->lda, B, (int64_t)d->ldb, C, (int64_t)d->ldc,
-                     e, p.tiles_n, p.tiles_total, p.k_chunk, vec_a, vec_b, partial, cpart,
+  constexpr int A_ELEMS = TA ? kBK * (BM + 4) : BM * (kBK + 4), B_ELEMS = kBK * (BN + 4);
+  constexpr size_t shmem = 2 * (size_t)(A_ELEMS + B_ELEMS) * sizeof(float);
+  static_assert(shmem <= 64 * 1024, "LDS tile too large");
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM_, WN_, OCC, TA, TB, EPI>), grid, dim3(WM_ * WN_ * kWave),
+                     shmem, st, d->m, d->n, d->k, A, (int64_t)d->lda, B, (int64_t)d->ldb, C,
+                     (int64_t)d->ldc, e, p.tiles_n, p.tiles_total, p.k_chunk, vec_a, vec_b, fast, partial, cpart,
                      fold ? p.splits : 1);
 }
 
 template <bool TA, bool TB, int EPI>
 static void launch_cfg(const rec_gemm_desc* d, const GemmPlan& p, const float* A, const float* B,
                        float* C, const EpiArgs& e, float* partial, float* cpart, hipStream_t st) {
-  if (p.narrow) launch_one<128, 80, 4, 1, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st);
-  else launch_one<128, 128, 2, 2, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st);
+  switch (p.cfg) {
+    case CFG_128x80: launch_one<128, 80, 4, 1, 5, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st); break;
+    case CFG_256x80: launch_one<256, 80, 8, 1, 2, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st); break;
+    case CFG_256x128: launch_one<256, 128, 4, 2, 2, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st); break;
+    case CFG_80x80: launch_one<80, 80, 5, 1, 4, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st); break;
+    case CFG_64x80: launch_one<64, 80, 4, 1, 6, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st); break;
+    case CFG_128x80_O4: launch_one<128, 80, 4, 1, 4, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st); break;
+    default: launch_one<128, 128, 2, 2, 4, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st); break;
+  }
 }
 
 template <int EPI>

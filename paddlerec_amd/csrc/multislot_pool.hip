@@ -12,15 +12,18 @@
 // offsets with one coalesced load per lane and its ids in 512-B runs.
 //
 // Work decomposition (HBM-bound integer/byte work, no MFMA):
-//   block = 4 waves = tile of TS = 64 samples x SS = 4*NSW slots; wave w owns NSW slots of the tile.
-//   per slot:  offsets -> per-wave LDS (the segment table of the tile)
-//              ids, 64 per step, one per lane (coalesced); lane -> segment by binary search in the LDS table
-//              rows gathered G = 64/LANES at a time (row group = LANES lanes x float4), all sub-steps of a
-//              64-id step issued back to back (16 x LANES/4 rows in flight per wave)
-//              WAVE-LEVEL SEGMENTED REDUCTION: the G row groups of a sub-step hold G consecutive ids; a
-//              log2(G)-step segmented scan with shuffles (ids of one sample are adjacent) leaves each run's sum
-//              in its last group, which adds it to the block's LDS output tile (one lane per address: no
-//              conflicts between waves - they own different slots - and program order inside a wave)
+//   block = 8 waves = tile of TS = 64 samples x SS = 8*NSW slots; wave w owns NSW slots of the tile.
+//   per slot:  offsets -> per-wave LDS; every lane (= sample) stamps its run into a per-wave byte table of
+//              segment ids (LDS-staged segment table; binary search in the offsets if a run table would overflow)
+//              ids, 64 per step, one per lane (coalesced) -> hash -> row; the LIVE ids (not padding, in range)
+//              are compacted through LDS in id order, so padding costs no gather slot
+//              rows gathered G = 64/LANES at a time (row group = LANES lanes x float4, lane = slice * G + group),
+//              all sub-steps of a 64-id step issued back to back
+//              WAVE-LEVEL SEGMENTED REDUCTION: the G row groups of a sub-step hold G consecutive live ids; a
+//              segmented scan over the groups (DPP row shifts: no LDS traffic; steps skipped once no run reaches
+//              that far) leaves each run's sum in its last group, which adds it to the block's LDS output tile
+//              (one lane per address: no conflicts between waves - they own different slots - and program order
+//              inside a wave)
 //   the LDS tile [TS][SS*D] is written out once, in SS*D*4-byte runs per sample (concat(axis=1) layout), and
 //   the pooled-id counts [TS][SS] likewise — a per-slot launch would write D*4 = 36-byte pieces.
 // Work is proportional to the number of ids, not to B x S x longest segment: load balance does not depend on
@@ -31,7 +34,8 @@
 namespace rec {
 
 constexpr int kMsTS = 64;     // samples per tile (one offset per lane)
-constexpr int kMsWaves = kBlock / kWave;
+// waves per block W: 8 (512 threads) for D <= 20 — the LDS output tile is then shared by 8 waves and three resident
+// blocks give 24 waves per CU (the kernel is latency-, not ALU-bound); 4 for wider rows (the tile grows with D)
 
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -39,40 +43,75 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int VEC, int LANES, int NSW>
-__global__ __launch_bounds__(kBlock) void multislot_sumpool_kernel(
+// x % d for a divisor fixed per launch: q = mulhi(x, floor(2^64 / d)) is floor(x / d) or one less, so at most two
+// conditional subtractions finish it — ~20 instructions instead of the ~150 of a generic 64-bit remainder
+// (the hash runs once per id: 40 M times per batch on the slot_dnn shape).
+struct FastMod {
+  uint64_t d, magic;
+};
+__device__ __forceinline__ uint64_t fast_mod(uint64_t x, const FastMod& f) {
+  const uint64_t q = __umul64hi(x, f.magic);
+  uint64_t r = x - q * f.d;
+  r = r >= f.d ? r - f.d : r;
+  r = r >= f.d ? r - f.d : r;
+  return r;
+}
+
+// lane shift inside a 16-lane row without touching the LDS crossbar (DPP row_shr); lanes whose source would be
+// outside the row keep `old`
+template <int O>
+__device__ __forceinline__ int row_shr_i(int old, int x) {
+  return __builtin_amdgcn_update_dpp(old, x, 0x110 | O, 0xF, 0xF, false);
+}
+template <int O>
+__device__ __forceinline__ float row_shr_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x110 | O, 0xF, 0xF, false));
+}
+
+constexpr int kSegCap = 512;    // ids of (one slot, 64 samples) whose segment ids fit the per-wave byte table
+
+// Lane layout inside a wave: lane = lg * G + g — the G row groups sit side by side (g), the LANES slices of a row
+// are G lanes apart (lg).  With G <= 16 the segmented scan over g never leaves a 16-lane DPP row.
+template <int VEC, int LANES, int NSW, int kMsWaves>
+__global__ __launch_bounds__(kMsWaves * kWave, kMsWaves == 8 ? 6 : 3) void multislot_sumpool_kernel(
     int64_t B, int S, int D, int stride, int key_mode, int64_t N, int64_t pad, int64_t lod_stride,
     int64_t out_stride, int nbt, int pitch, int state_off, float init_range, int init_dims, uint64_t seed,
-    const int64_t* __restrict__ values,
+    FastMod fm, const int64_t* __restrict__ values,
     const int64_t* __restrict__ lod, const int64_t* __restrict__ slot_base,
     const float* __restrict__ W, float* __restrict__ out, int32_t* __restrict__ counts,
     int32_t* __restrict__ seg_of_value, int64_t* __restrict__ rows_out,
     int32_t* __restrict__ status) {
+  constexpr int kMsBlock = kMsWaves * kWave;
   constexpr int G = kWave / LANES;        // row groups per wave instruction
   constexpr int SS = kMsWaves * NSW;      // slots per tile
   constexpr int U = (kWave / G) < 4 ? (kWave / G) : 4;  // sub-steps gathered back to back (<= a 64-id step)
+  constexpr bool DPP = G <= 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* tile = reinterpret_cast<float*>(smem_raw);                 // [TS][pitch]
   int* cnt = reinterpret_cast<int*>(tile + kMsTS * pitch);          // [TS][SS]
-  int* offs = cnt + kMsTS * SS;                                     // [waves][NSW][TS+1]
+  int64_t* crow = reinterpret_cast<int64_t*>(cnt + kMsTS * SS);     // [waves][64]
+  int* cseg = reinterpret_cast<int*>(crow + kMsWaves * kWave);      // [waves][64]
+  unsigned char* segtab = reinterpret_cast<unsigned char*>(cseg + kMsWaves * kWave);   // [waves][kSegCap]
   const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
   const int64_t b0 = (int64_t)(blockIdx.x % nbt) * kMsTS;
   const int s0 = (int)(blockIdx.x / nbt) * SS;
   const int ns_tile = min(SS, S - s0);
 
-  for (int i = threadIdx.x; i < kMsTS * pitch; i += kBlock) tile[i] = 0.f;
-  for (int i = threadIdx.x; i < kMsTS * SS; i += kBlock) cnt[i] = 0;
+  for (int i = threadIdx.x; i < kMsTS * pitch; i += kMsBlock) tile[i] = 0.f;
+  for (int i = threadIdx.x; i < kMsTS * SS; i += kMsBlock) cnt[i] = 0;
   __syncthreads();
 
   // ---- phase A: the tile's offsets of every slot this wave owns (2 coalesced loads per lane and slot)
   int64_t k0[NSW], base[NSW];
-  int n[NSW];
-  int64_t idv[NSW];
-  int* woffs = offs + wave * NSW * (kMsTS + 1);
+  int n[NSW], len[NSW], so_l[NSW];
+  int64_t idv[NSW], idv2[NSW];
+  int64_t* wrow = crow + wave * kWave;
+  int* wseg = cseg + wave * kWave;
+  unsigned char* wtab = segtab + wave * kSegCap;
 #pragma unroll
   for (int i = 0; i < NSW; ++i) {
     const int sl = wave * NSW + i;
-    n[i] = 0; k0[i] = 0; base[i] = 0;
+    n[i] = 0; k0[i] = 0; base[i] = 0; len[i] = 0; so_l[i] = 0;
     if (sl < ns_tile) {
       const int64_t* l = lod + (int64_t)(s0 + sl) * lod_stride;
       const int64_t ba = min(b0 + lane, B), bb = min(b0 + lane + 1, B);
@@ -81,65 +120,81 @@ __global__ __launch_bounds__(kBlock) void multislot_sumpool_kernel(
       const int64_t kend = __shfl(hi, kWave - 1, kWave);
       n[i] = (int)(kend - k0[i]);
       base[i] = slot_base[s0 + sl];
-      woffs[i * (kMsTS + 1) + lane] = (int)(lo - k0[i]);
-      if (lane == kWave - 1) woffs[i * (kMsTS + 1) + kMsTS] = n[i];
+      so_l[i] = (int)(lo - k0[i]);
+      len[i] = (int)(hi - lo);
     }
   }
   // ---- phase B: first 64 ids of every slot (in flight together)
 #pragma unroll
-  for (int i = 0; i < NSW; ++i) idv[i] = lane < n[i] ? values[base[i] + k0[i] + lane] : 0;
+  for (int i = 0; i < NSW; ++i) {
+    idv[i] = lane < n[i] ? values[base[i] + k0[i] + lane] : 0;
+    idv2[i] = kWave + lane < n[i] ? values[base[i] + k0[i] + kWave + lane] : 0;
+  }
   wave_fence();
 
-  const int lg = lane % LANES, g = lane / LANES;
+  const int lg = lane / G, g = lane % G;
   const int d0 = lg * VEC;
   int oob = 0;
 #pragma unroll
   for (int i = 0; i < NSW; ++i) {
     const int sl = wave * NSW + i;
-    const int* so = woffs + i * (kMsTS + 1);
+    // segment id of every id of this (slot, 64 samples): each lane (= sample) stamps its own run into the byte
+    // table; runs are short (<= 15 in the reference's data), so this is a couple of LDS stores per lane
+    const bool tab = n[i] <= kSegCap;
+    if (tab) {
+      for (int j = 0; __ballot(j < len[i]) != 0; ++j)
+        if (j < len[i]) wtab[so_l[i] + j] = (unsigned char)lane;
+    }
+    wave_fence();
     for (int c0 = 0; c0 < n[i]; c0 += kWave) {
       const int kk = c0 + lane;
       const bool in = kk < n[i];
-      const int64_t id = c0 == 0 ? idv[i] : (in ? values[base[i] + k0[i] + kk] : 0);
+      const int64_t id = c0 == 0 ? idv[i] : c0 == kWave ? idv2[i] : (in ? values[base[i] + k0[i] + kk] : 0);
       const bool live = in && (id != pad || pad < 0);
-      const int64_t r = key_mode ? feasign_row((uint64_t)id, N) : id;
+      const int64_t r = key_mode ? (id == 0 ? 0 : (int64_t)(1 + fast_mod(mix64((uint64_t)id), fm))) : id;
       const bool inr = r >= 0 && r < N;
       oob |= (live && !inr) ? 1 : 0;
       const bool hit = live && inr;
-      // segment (sample of the tile) of id kk: the last t with so[t] <= kk
-      int lo = 0, hi = kMsTS;   // invariant so[lo] <= kk < so[hi] (so[0] = 0, so[TS] = n)
+      int seg = -1;
+      if (tab) {
+        if (in) seg = wtab[kk];
+      } else {   // oversized run table: binary search in the lanes' offsets (the last t with so[t] <= kk)
+        int lo = 0, hi = kMsTS;
 #pragma unroll
-      for (int it = 0; it < 6; ++it) {
-        const int mid = (lo + hi) >> 1;
-        const bool le = so[mid] <= kk;
-        lo = le ? mid : lo;
-        hi = le ? hi : mid;
+        for (int it = 0; it < 6; ++it) {
+          const int mid = (lo + hi) >> 1;
+          const bool le = __shfl(so_l[i], mid, kWave) <= kk;
+          lo = le ? mid : lo;
+          hi = le ? hi : mid;
+        }
+        seg = in ? lo : -1;
       }
-      const int seg = in ? lo : -1;
       if (in) {
         const int64_t gk = base[i] + k0[i] + kk;
         if (seg_of_value) seg_of_value[gk] = (int32_t)((b0 + seg) * S + s0 + sl);
         if (rows_out) rows_out[gk] = hit ? r : (pad >= 0 ? (key_mode ? 0 : pad) : r);
       }
       if (hit) atomicAdd(&cnt[seg * SS + sl], 1);   // LDS integer add: exact, order-free
-      const int64_t row = hit ? r : 0;
-      const int nsub = (min(kWave, n[i] - c0) + G - 1) / G;
+      // compaction: only the live ids are gathered; they stay in id order, so runs stay contiguous
+      const unsigned long long hm = __ballot(hit);
+      const int nlive = __popcll(hm);
+      const int cpos = __popcll(hm & ((1ull << lane) - 1ull));
+      if (hit) { wrow[cpos] = r; wseg[cpos] = seg; }
+      wave_fence();
+      const int nsub = (nlive + G - 1) / G;
       for (int j0 = 0; j0 < nsub; j0 += U) {
         float e[U][VEC];
         int sg[U], sgn[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int src = (j0 + u) * G + g;       // lane that holds this group's id
-          const int64_t rr = __shfl(row, src & 63, kWave);
-          const int hh = __shfl((int)hit, src & 63, kWave);
-          sg[u] = __shfl(seg, src & 63, kWave);
-          sgn[u] = __shfl(seg, (src + 1) & 63, kWave);
-          const bool ok = (j0 + u) < nsub && hh && d0 < D;
-          if (g == G - 1) sgn[u] = -2;            // last group of the sub-step always flushes
-          if ((j0 + u) >= nsub) sg[u] = -1;
+          const int q = (j0 + u) * G + g;          // compacted id this row group sums
+          const bool ok = q < nlive;
+          const int64_t rr = ok ? wrow[q] : 0;
+          sg[u] = ok ? wseg[q] : -1;
+          sgn[u] = (q + 1 < nlive && g != G - 1) ? wseg[q + 1] : -2;   // last group of a sub-step always flushes
 #pragma unroll
           for (int v = 0; v < VEC; ++v) e[u][v] = 0.f;
-          if (ok) {
+          if (ok && d0 < D) {
             vload<VEC>(e[u], W + rr * stride + d0);
             // PS rows are born lazily: an unborn row (state 0, zero memory) reads as its creation values
             if (state_off >= 0 && W[rr * stride + state_off] == 0.f) {
@@ -152,17 +207,27 @@ __global__ __launch_bounds__(kBlock) void multislot_sumpool_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if ((j0 + u) < nsub) {                  // wave-uniform
-            // segmented inclusive scan over the G groups (runs of equal seg are contiguous)
-#pragma unroll
-            for (int o = 1; o < G; o <<= 1) {
-              const int so_ = __shfl_up(sg[u], o * LANES, kWave);
-              const bool take = g >= o && so_ == sg[u];
-#pragma unroll
-              for (int v = 0; v < VEC; ++v) {
-                const float t = __shfl_up(e[u][v], o * LANES, kWave);
-                e[u][v] += take ? t : 0.f;
-              }
-            }
+            // segmented inclusive scan over the G groups (runs of equal seg are contiguous); a step is skipped
+            // once no run reaches that far back (wave-uniform)
+#define REC_SCAN_STEP(O)                                                                      \
+  if (O < G && more) {                                                                        \
+    int so_;                                                                                  \
+    float t[VEC];                                                                             \
+    if (DPP) {                                                                                \
+      so_ = row_shr_i<O>(-3, sg[u]);                                                          \
+      _Pragma("unroll") for (int v = 0; v < VEC; ++v) t[v] = row_shr_f<O>(e[u][v]);           \
+    } else {                                                                                  \
+      so_ = __shfl_up(sg[u], O, kWave);                                                       \
+      _Pragma("unroll") for (int v = 0; v < VEC; ++v) t[v] = __shfl_up(e[u][v], O, kWave);    \
+    }                                                                                         \
+    const bool take = g >= O && so_ == sg[u] && sg[u] >= 0;                                   \
+    more = __ballot(take) != 0;                                                               \
+    _Pragma("unroll") for (int v = 0; v < VEC; ++v) e[u][v] += take ? t[v] : 0.f;             \
+  }
+            bool more = true;
+            REC_SCAN_STEP(1) REC_SCAN_STEP(2) REC_SCAN_STEP(4) REC_SCAN_STEP(8)
+            REC_SCAN_STEP(16) REC_SCAN_STEP(32)
+#undef REC_SCAN_STEP
             if (sg[u] >= 0 && sgn[u] != sg[u]) {  // tail of a run: its sum goes to the output tile
               float* dst = tile + sg[u] * pitch + sl * D + d0;
 #pragma unroll
@@ -172,23 +237,26 @@ __global__ __launch_bounds__(kBlock) void multislot_sumpool_kernel(
           }
         }
       }
+      wave_fence();   // the compaction scratch is rewritten by the next 64-id step
     }
   }
   if (oob) atomicOr(status, REC_FLAG_INDEX_OOB);
   __syncthreads();
 
-  // ---- the tile goes out in ns_tile*D-float runs per sample (concat(axis=1) layout)
+  // ---- the tile goes out in ns_tile*D-float runs per sample (concat(axis=1) layout); a wave per sample row,
+  // lanes along the run (no integer division in the loop)
   const int run = ns_tile * D;
   const int nsamp = (int)min((int64_t)kMsTS, B - b0);
-  for (int i = threadIdx.x; i < nsamp * run; i += kBlock) {
-    const int smp = i / run, c = i - smp * run;
-    out[(b0 + smp) * out_stride + (int64_t)s0 * D + c] = tile[smp * pitch + c];
+  for (int smp = wave; smp < nsamp; smp += kMsWaves) {
+    float* dst = out + (b0 + smp) * out_stride + (int64_t)s0 * D;
+    const float* src = tile + smp * pitch;
+    for (int c = lane; c < run; c += kWave) dst[c] = src[c];
   }
   if (counts) {
-    for (int i = threadIdx.x; i < nsamp * ns_tile; i += kBlock) {
-      const int smp = i / ns_tile, c = i - smp * ns_tile;
-      counts[(b0 + smp) * S + s0 + c] = cnt[smp * SS + c];
-    }
+    constexpr int SPW = kWave / SS > 0 ? kWave / SS : 1;   // samples per wave instruction (SS is a power of two <= 64)
+    const int c = lane % SS, so = lane / SS;
+    for (int smp = wave * SPW + so; smp < nsamp; smp += kMsWaves * SPW)
+      if (c < ns_tile && so < SPW) counts[(b0 + smp) * S + s0 + c] = cnt[smp * SS + c];
   }
 }
 
@@ -248,42 +316,53 @@ extern "C" int rec_multislot_sumpool_fwd(const rec_multislot_desc* d, const int6
   REC_REQUIRE(d->init_range <= 0.f || (d->state_offset >= D && d->state_offset < d->row_stride &&
                                         d->init_dims >= 0 && d->init_dims <= D),
               REC_EINVAL, "lazy creation needs the state float inside the row, behind the weights");
+  FastMod fmod = {1, 0};
+  if (d->key_mode == 1) {
+    fmod.d = (uint64_t)(d->num_rows - 1);
+    fmod.magic = fmod.d > 1 ? (uint64_t)((((unsigned __int128)1) << 64) / fmod.d) : 0;   // d == 1: x % 1 == 0 either way
+  }
   hipStream_t st = (hipStream_t)stream;
-#define REC_MS_LAUNCH(V, L, NSW_)                                                                       \
+#define REC_MS_LAUNCH(V, L, NSW_, W_)                                                                   \
   {                                                                                                     \
+    constexpr int kMsWaves = W_;                                                                        \
+    constexpr int kMsBlock = W_ * kWave;                                                                \
     constexpr int SS = kMsWaves * NSW_;                                                                 \
     const int pitch = (SS * D) | 1;                                                                     \
-    const size_t shmem = ((size_t)kMsTS * pitch + (size_t)kMsTS * SS +                                  \
-                          (size_t)kMsWaves * NSW_ * (kMsTS + 1)) * 4;                                   \
+    const size_t shmem = ((size_t)kMsTS * pitch + (size_t)kMsTS * SS) * 4 +                             \
+                         (size_t)kMsWaves * kWave * 12 + (size_t)kMsWaves * kSegCap;                    \
     const int64_t grid = (int64_t)nbt * ((S + SS - 1) / SS);                                            \
     REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many tiles");                                      \
-    hipLaunchKernelGGL((multislot_sumpool_kernel<V, L, NSW_>), dim3((unsigned)grid), dim3(kBlock),      \
+    REC_REQUIRE(shmem <= 160 * 1024, REC_ESHAPE, "LDS tile %zu B too large", shmem);                    \
+    auto kern = multislot_sumpool_kernel<V, L, NSW_, W_>;                                               \
+    if (shmem > 64 * 1024)                                                                              \
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kMsBlock),                                      \
                        shmem, st, d->batch, S, D, d->row_stride, d->key_mode, d->num_rows,              \
                        d->padding_idx, lod_stride, out_stride, nbt, pitch, state_off, d->init_range,    \
-                       d->init_dims, d->init_seed, values, lod, slot_base, W,                           \
+                       d->init_dims, d->init_seed, fmod, values, lod, slot_base, W,                     \
                        out, counts, seg_of_value, rows_out, status);                                    \
     return check_launch("rec_multislot_sumpool_fwd");                                                   \
   }
 #define REC_MS_NSW(V, L)                                                                                \
   {                                                                                                     \
-    if (D <= 10 && S > 8) REC_MS_LAUNCH(V, L, 4)                                                        \
-    else if (D <= 20 && S > 4) REC_MS_LAUNCH(V, L, 2)                                                   \
-    else REC_MS_LAUNCH(V, L, 1)                                                                         \
+    if (D <= 10 && S > 8) REC_MS_LAUNCH(V, L, 2, 8)                                                     \
+    else if (D <= 20 && S > 4) REC_MS_LAUNCH(V, L, 1, 8)                                                \
+    else REC_MS_LAUNCH(V, L, 1, 4)                                                                      \
   }
   if (v4) {
     if (lanes == 1) REC_MS_NSW(4, 1)
     if (lanes == 2) REC_MS_NSW(4, 2)
     if (lanes == 4) REC_MS_NSW(4, 4)
-    if (lanes == 8) REC_MS_LAUNCH(4, 8, 1)
-    if (lanes == 16) REC_MS_LAUNCH(4, 16, 1)
+    if (lanes == 8) REC_MS_LAUNCH(4, 8, 1, 4)
+    if (lanes == 16) REC_MS_LAUNCH(4, 16, 1, 4)
   } else {
     if (lanes == 1) REC_MS_NSW(1, 1)
     if (lanes == 2) REC_MS_NSW(1, 2)
     if (lanes == 4) REC_MS_NSW(1, 4)
     if (lanes == 8) REC_MS_NSW(1, 8)
     if (lanes == 16) REC_MS_NSW(1, 16)
-    if (lanes == 32) REC_MS_LAUNCH(1, 32, 1)
-    if (lanes == 64) REC_MS_LAUNCH(1, 64, 1)
+    if (lanes == 32) REC_MS_LAUNCH(1, 32, 1, 4)
+    if (lanes == 64) REC_MS_LAUNCH(1, 64, 1, 4)
   }
 #undef REC_MS_NSW
 #undef REC_MS_LAUNCH

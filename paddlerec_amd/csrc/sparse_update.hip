@@ -258,6 +258,28 @@ __device__ __forceinline__ void segment_sum(float (&g)[VEC], int beg, int end,
   }
 }
 
+// One Adam element update with the rounding points pinned (no compiler-chosen fma contraction): every Adam kernel
+// of this file goes through it, so rec_sparse_adam_record is bit-identical to two rec_sparse_adam_rows passes and
+// rec_adam_rows_all to the lazy kernel on the touched rows.
+__device__ __forceinline__ float scale_grad(float g, float sc) {
+#pragma clang fp contract(off)
+  return g * sc;
+}
+
+__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, float lr_t, float eps_t,
+                                          float b1, float b2) {
+#pragma clang fp contract(off)
+  const float m1 = b1 * m;
+  const float m2 = (1.f - b1) * g;
+  const float v1 = b2 * v;
+  const float v2 = ((1.f - b2) * g) * g;
+  m = m1 + m2;
+  v = v1 + v2;
+  const float den = sqrtf(v) + eps_t;
+  const float step = lr_t * (m / den);
+  p = p - step;
+}
+
 // --------------------------------------------------------------------------- lazy sparse Adam
 template <int VEC, int LANES>
 __global__ __launch_bounds__(kBlock) void sparse_adam_rows_kernel(
@@ -283,14 +305,10 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_rows_kernel(
   if (grad_scale) {   // global-norm clipping factor (device scalar)
     const float sc = grad_scale[0];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) g[i] *= sc;
+    for (int i = 0; i < VEC; ++i) g[i] = scale_grad(g[i], sc);
   }
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    m[i] = b1 * m[i] + (1.f - b1) * g[i];
-    v[i] = b2 * v[i] + (1.f - b2) * g[i] * g[i];
-    p[i] = p[i] - lr_t * (m[i] / (sqrtf(v[i]) + eps_t));
-  }
+  for (int i = 0; i < VEC; ++i) adam_elem(p[i], m[i], v[i], g[i], lr_t, eps_t, b1, b2);
   vstore<VEC>(P + ro, p);
   vstore<VEC>(M + so, m);
   vstore<VEC>(V + so, v);
@@ -328,10 +346,8 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_record_kernel(
     segment_sum<VEC>(g, beg, end, spos, grad, gl, D, d0);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      g[i] *= sc;
-      m[i] = b1 * m[i] + (1.f - b1) * g[i];
-      v[i] = b2 * v[i] + (1.f - b2) * g[i] * g[i];
-      p[i] = p[i] - lr_t * (m[i] / (sqrtf(v[i]) + eps_t));
+      if (grad_scale) g[i] = scale_grad(g[i], sc);
+      adam_elem(p[i], m[i], v[i], g[i], lr_t, eps_t, b1, b2);
     }
     vstore<VEC>(r + d0, p);
     vstore<VEC>(mv + d0, m);
@@ -341,10 +357,8 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_record_kernel(
     float p1 = r[D], m1 = r[D + 1], v1 = r[D + 2];
     float g1[1] = {0.f};
     segment_sum<1>(g1, beg, end, spos, grad1, gl1, 1, 0);
-    const float g = g1[0] * sc;
-    m1 = b1 * m1 + (1.f - b1) * g;
-    v1 = b2 * v1 + (1.f - b2) * g * g;
-    p1 = p1 - lr_t * (m1 / (sqrtf(v1) + eps_t));
+    const float g = grad_scale ? scale_grad(g1[0], sc) : g1[0];
+    adam_elem(p1, m1, v1, g, lr_t, eps_t, b1, b2);
     r[D] = p1; r[D + 1] = m1; r[D + 2] = v1;
   }
 }
@@ -399,11 +413,7 @@ __global__ __launch_bounds__(kBlock) void adam_rows_all_kernel(
     }
   }
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    m[i] = b1 * m[i] + (1.f - b1) * g[i];
-    v[i] = b2 * v[i] + (1.f - b2) * g[i] * g[i];
-    p[i] = p[i] - lr_t * (m[i] / (sqrtf(v[i]) + eps_t));
-  }
+  for (int i = 0; i < VEC; ++i) adam_elem(p[i], m[i], v[i], g[i], lr_t, eps_t, b1, b2);
   vstore<VEC>(P + ro, p);
   vstore<VEC>(M + so, m);
   vstore<VEC>(V + so, v);

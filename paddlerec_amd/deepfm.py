@@ -11,7 +11,7 @@ There is no autograd tape and no CPU fallback: backward is the explicit chain th
 `loss.backward()` (tools/trainer.py:151) implies.
 """
 import math
-
+import os
 import time
 
 import torch
@@ -254,9 +254,10 @@ class DeepFMLayer:
         self.step_count += 1
         on_gpu = self.device.type == "cuda"
         cur = torch.cuda.current_stream() if on_gpu else None
-        if on_gpu and self._side is None:
+        overlap = on_gpu and os.environ.get("REC_DEEPFM_OVERLAP", "1") != "0"
+        if overlap and self._side is None:
             self._side = self.k.concurrent_stream(self.device)   # verified to overlap with the main stream
-        side = self._side if on_gpu else None
+        side = self._side if overlap else None
         groups = getattr(self, "_groups", None)          # persistent: the wait_stream below orders reuse
         if groups is None or groups.n != B * S:
             groups = self._groups = self.k.IdGroups(B * S, self.device)
@@ -307,7 +308,7 @@ class DeepFMLayer:
         if allreduce is not None:
             allreduce(self.dense.grad)
         self.k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
-        if on_gpu:
+        if side is not None:
             cur.wait_stream(self._side)
         return loss, pred
 

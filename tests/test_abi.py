@@ -53,14 +53,14 @@ def test_host_planning_queries(engine_lib):
     import ctypes as C
     from paddlerec_amd import _lib
     sp = C.c_int32(0)
-    # dW of the 400x400 MLP layers at batch 65536: 4 x 5 tiles of 128x80, 5 blocks per CU
+    # dW of the 400x400 MLP layers at batch 65536: 5 x 5 tiles of 80x80 (no padding rows), 4 blocks per CU
     d = _lib.GemmDesc(400, 400, 65536, 400, 400, 400, 1, 0, 0, 0)
     assert engine_lib.rec_gemm_plan_splits(C.byref(d), 0, C.byref(sp)) == 0
     full = sp.value
-    assert full == 64 and full % 8 == 0                      # 256 CUs * 5 / 20 tiles = one resident round
+    assert full == 40 and full % 8 == 0                      # 256 CUs * 4 / 25 tiles = one resident round
     assert engine_lib.rec_gemm_plan_splits(C.byref(d), 192, C.byref(sp)) == 0
-    assert sp.value == 48                                    # 192 CUs * 5 / 20
-    assert engine_lib.rec_gemm_plan_splits(C.byref(d), 8, C.byref(sp)) == 0 and sp.value == 2
+    assert sp.value == 24                                    # 192 CUs * 4 / 25 = 30 -> multiple of 8
+    assert engine_lib.rec_gemm_plan_splits(C.byref(d), 8, C.byref(sp)) == 0 and sp.value == 1
     # forward GEMM [65536 x 400] = 2560 tiles: fills the chip without splitting K
     f = _lib.GemmDesc(65536, 400, 432, 432, 400, 400, 0, 0, 0, 0)
     assert engine_lib.rec_gemm_plan_splits(C.byref(f), 0, C.byref(sp)) == 0 and sp.value == 1
@@ -82,7 +82,7 @@ def test_more_argument_validation_without_gpu(engine_lib):
     import ctypes as C
     from paddlerec_amd import _lib
     L = engine_lib
-    gl = _lib.GradLayout(1, 0, 0, None)
+    gl = _lib.GradLayout(1, 0, 0, None, None)
     h = _lib.AdamHyper(1e-3, 0.9, 0.999, 1e-8, 1)
     assert L.rec_segment_partials(10, 16, None, None, None, None, C.byref(gl), None, None) == -1
     assert L.rec_segment_partials(0, 0, None, None, None, None, None, None, None) == -1

@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--extra-p", type=float, default=0.6)
     ap.add_argument("--opt", default="adam")
     ap.add_argument("--layers", default="512,256,128,128,128")
+    ap.add_argument("--pool-only", type=int, default=0, help="only loop the pooling kernel this many times (profiling)")
     args = ap.parse_args()
     B, S, D, N = args.batch, args.slots, args.dim, args.rows
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -79,6 +80,12 @@ def main():
     W = model.embedding
     out = torch.empty(B, S * D, device=DEV)
     lazy = model.table.lazy_init if model.table is not None else None
+    if args.pool_only:
+        for i in range(args.pool_only):
+            ops.multislot_sumpool(batches[i % 2][0], W, N, 0, 1, model.status, out=out, lazy_init=lazy)
+        torch.cuda.synchronize()
+        print("pool-only done")
+        return
     ms_pool = timeit(lambda i: ops.multislot_sumpool(batches[i % 2][0], W, N, 0, 1, model.status, out=out,
                                                      lazy_init=lazy))
     nnz = mb.nnz
