@@ -180,7 +180,8 @@ int rec_feasign_rows_host(int64_t n, int64_t num_rows, const uint64_t* keys, int
  *   sorted_pos [n] i32 : positions (b*S+s) stably sorted by row; padding hits are dropped
  *   uniq_rows  [n] i64 : first n_uniq entries = distinct rows, ascending
  *   seg_offset [n+1] i32: sorted_pos[seg_offset[u] .. seg_offset[u+1]) belong to uniq_rows[u]
- *   n_uniq     [2] i32 : {number of distinct rows, number of non-padding positions}
+ *   n_uniq     [4] i32 : {number of distinct rows, number of non-padding positions, 1 if some row owns >=
+ *                         REC_SEG_LONG positions else 0, 0}
  * All four are bit-exact targets.
  * ---------------------------------------------------------------------------------------- */
 int rec_ids_group_workspace_bytes(int64_t n, int64_t num_rows, size_t* bytes);

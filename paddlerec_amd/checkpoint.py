@@ -80,26 +80,54 @@ def save_model(net, optimizer, model_path, epoch_id, prefix="rec"):
     return model_path
 
 
-def _load_global(model_prefix):
-    """Reads either the single file or all rank shards and returns the GLOBAL state dict."""
-    single = model_prefix + ".pdparams"
-    if os.path.exists(single):
-        with open(single, "rb") as f:
-            return pickle.load(f)
+def _shard_files(model_prefix, ext=".pdparams"):
     d = os.path.dirname(model_prefix)
     base = os.path.basename(model_prefix)
-    shards = sorted(f for f in os.listdir(d) if f.startswith(base + ".shard") and f.endswith(".pdparams"))
-    if not shards:
-        raise FileNotFoundError(single)
+    if not os.path.isdir(d):
+        return []
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.startswith(base + ".shard") and f.endswith(ext))
+
+
+def _pick_source(model_prefix):
+    """-> ("single", path) or ("shards", [paths]).  A directory that holds BOTH a single-process file and rank shards
+    (a sharded run saved over an older single-process one, or the reverse) is ambiguous: the newer set wins and the
+    stale one is named in a warning instead of silently shadowing it."""
+    import logging
+    single = model_prefix + ".pdparams"
+    shards = _shard_files(model_prefix)
+    if os.path.exists(single) and shards:
+        newest_shard = max(os.path.getmtime(f) for f in shards)
+        use_single = os.path.getmtime(single) >= newest_shard
+        logging.getLogger(__name__).warning(
+            "%s holds both %s and %d rank shards: loading the newer %s, ignoring the stale other",
+            os.path.dirname(model_prefix), os.path.basename(single), len(shards), "single file" if use_single else "shards")
+        return ("single", single) if use_single else ("shards", shards)
+    if os.path.exists(single):
+        return "single", single
+    if shards:
+        return "shards", shards
+    raise FileNotFoundError(single)
+
+
+def _read_shards(paths):
     parts = []
-    for fn in shards:
-        with open(os.path.join(d, fn), "rb") as f:
+    for fn in paths:
+        with open(fn, "rb") as f:
             parts.append(pickle.load(f))
     world = int(parts[0]["__shard__"][1])
     if len(parts) != world:
         raise ValueError("checkpoint has %d of %d shards" % (len(parts), world))
     parts.sort(key=lambda p: int(p["__shard__"][0]))
-    n_rows = int(parts[0]["__shard__"][2])
+    return parts, world, int(parts[0]["__shard__"][2])
+
+
+def _load_global(model_prefix):
+    """Reads either the single file or all rank shards and returns the GLOBAL state dict (single-process nets)."""
+    kind, src = _pick_source(model_prefix)
+    if kind == "single":
+        with open(src, "rb") as f:
+            return pickle.load(f)
+    parts, world, n_rows = _read_shards(src)
     out = {k: v for k, v in parts[0].items() if k != "__shard__" and k not in TABLE_KEYS}
     for key in TABLE_KEYS:
         if key in parts[0]:
@@ -111,12 +139,79 @@ def _load_global(model_prefix):
     return out
 
 
+def _reshard_rows(old_rank, old_world, n_local_old, new_rank, new_world, n_rows):
+    """Rows of old shard `old_rank` that the new rank owns: (indices into the old shard, local rows in the new one)."""
+    g = old_rank + np.arange(n_local_old, dtype=np.int64) * old_world        # global rows the old shard holds
+    keep = (g < n_rows) & (g % new_world == new_rank)
+    return np.nonzero(keep)[0], g[keep] // new_world
+
+
+def _load_sharded(net, model_prefix, shard_paths, load_optimizer):
+    """A row-sharded net resumes from rank shards WITHOUT assembling the global table: with the same world size a
+    rank reads its own file; otherwise it walks the old shards one at a time and keeps the rows it owns now.  The
+    per-rank optimizer shards (step, dense and sparse Adam moments) are restored the same way."""
+    from .deepfm import DeepFMLayer
+    comm = net.comm
+    heads = []
+    for fn in shard_paths:                      # headers only decide the plan; the payload is read shard by shard
+        with open(fn, "rb") as f:
+            heads.append((fn, pickle.load(f)))
+    heads.sort(key=lambda t: int(t[1]["__shard__"][0]))
+    old_world, n_rows = int(heads[0][1]["__shard__"][1]), int(heads[0][1]["__shard__"][2])
+    if len(heads) != old_world:
+        raise ValueError("checkpoint has %d of %d shards" % (len(heads), old_world))
+    if n_rows != net.global_rows:
+        raise ValueError("checkpoint table has %d rows, the model %d" % (n_rows, net.global_rows))
+    net._next_lookup = None
+    local = net.state_dict()
+    dense = {k: v for k, v in heads[0][1].items() if k != "__shard__" and k not in TABLE_KEYS}
+    DeepFMLayer.set_dict(net, dense)
+    opt_parts = []
+    if load_optimizer:
+        for fn, _ in heads:
+            of = fn[: -len(".pdparams")] + ".pdopt"
+            if os.path.exists(of):
+                with open(of, "rb") as f:
+                    opt_parts.append(pickle.load(f))
+        if len(opt_parts) != old_world:
+            opt_parts = []
+    if opt_parts:
+        set_optimizer_state(net, {k: v for k, v in opt_parts[0].items() if not k.startswith("sparse.")})
+        net._ensure_sparse_state()
+    for r_old, (fn, sd) in enumerate(heads):
+        for key in TABLE_KEYS:
+            if key not in sd:
+                continue
+            src_idx, dst_idx = _reshard_rows(r_old, old_world, sd[key].shape[0], comm.rank, comm.world, n_rows)
+            if len(src_idx) == 0:
+                continue
+            dst = local[key]
+            di = torch.as_tensor(dst_idx, device=dst.device)
+            dst[di] = torch.as_tensor(sd[key][src_idx]).to(dst.device).reshape(len(src_idx), -1)
+        if opt_parts:
+            for k in ("m", "v", "m1", "v1"):
+                arr = opt_parts[r_old].get("sparse." + k)
+                if arr is None or k not in net.sparse_state:
+                    continue
+                src_idx, dst_idx = _reshard_rows(r_old, old_world, arr.shape[0], comm.rank, comm.world, n_rows)
+                if len(src_idx):
+                    dst = net.sparse_state[k]
+                    di = torch.as_tensor(dst_idx, device=dst.device)
+                    dst[di] = torch.as_tensor(arr[src_idx]).to(dst.device).reshape(len(src_idx), -1)
+
+
 def load_model(model_path, net, prefix="rec", load_optimizer=True):
     """tools/utils/save_load.py:42-46 (+ optimizer state when present and the layout matches)."""
     model_prefix = os.path.join(model_path, prefix)
+    comm = getattr(net, "comm", None)
+    if comm is not None and comm.world > 1:
+        kind, src = _pick_source(model_prefix)
+        if kind == "shards":
+            _load_sharded(net, model_prefix, src, load_optimizer)
+            return net
     net.set_dict(_load_global(model_prefix))
     opt_file = model_prefix + ".pdopt"
-    if load_optimizer and os.path.exists(opt_file) and getattr(net, "comm", None) is None:
+    if load_optimizer and os.path.exists(opt_file) and comm is None:
         with open(opt_file, "rb") as f:
             set_optimizer_state(net, pickle.load(f))
     return net

@@ -14,8 +14,7 @@
 #include <string.h>
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
-
+#include "radix_sort.h"
 #include "rec_common.h"
 
 namespace rec {
@@ -72,23 +71,22 @@ static int route_bits(int G) {
 }
 
 struct RoutePlan {
-  size_t off_keys_in, off_keys_out, off_vals_in, off_vals_out, off_temp, temp_bytes, total;
+  rsort::Plan sort;
+  size_t off_keys_in, off_keys_out, off_vals_in, off_vals_out, off_keys_tmp, off_vals_tmp, off_hist, off_totals, total;
 };
 
 static int plan_route(int64_t n, int G, RoutePlan* p) {
-  size_t sort_tmp = 0;
-  hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, uint32_t*, uint32_t*, int32_t*,
-                                           int32_t*>(nullptr, sort_tmp, nullptr, nullptr, nullptr,
-                                                     nullptr, (size_t)n, 0, route_bits(G));
-  if (e != hipSuccess) { set_error("radix_sort_pairs size query: %s", hipGetErrorString(e)); return REC_EHIP; }
+  p->sort = rsort::make_plan(n, route_bits(G));     // G <= 1024: one pass
   size_t o = 0;
   p->off_keys_in = o;  o += align_up((size_t)n * 4, 256);
   p->off_keys_out = o; o += align_up((size_t)n * 4, 256);
   p->off_vals_in = o;  o += align_up((size_t)n * 4, 256);
   p->off_vals_out = o; o += align_up((size_t)n * 4, 256);
-  p->off_temp = o;
-  p->temp_bytes = align_up(sort_tmp, 256);
-  p->total = o + p->temp_bytes;
+  p->off_keys_tmp = o; o += p->sort.passes > 1 ? align_up((size_t)n * 4, 256) : 0;
+  p->off_vals_tmp = o; o += p->sort.passes > 1 ? align_up((size_t)n * 4, 256) : 0;
+  p->off_hist = o;     o += p->sort.hist_bytes;
+  p->off_totals = o;   o += p->sort.totals_bytes;
+  p->total = o;
   return REC_OK;
 }
 
@@ -139,10 +137,12 @@ extern "C" int rec_shard_route(int64_t n, int32_t num_slots, int64_t num_rows, i
   hipLaunchKernelGGL(route_keys_kernel, dim3((unsigned)grid), dim3(kBlock),
                      (size_t)(G + 1) * sizeof(int), st, n, num_slots, num_rows, padding_idx, G, ids,
                      slot_offset, keys_in, vals_in, (unsigned long long*)send_counts, status);
-  size_t tb = p.temp_bytes;
-  hipError_t e = rocprim::radix_sort_pairs(base + p.off_temp, tb, keys_in, keys_out, vals_in,
-                                           vals_out, (size_t)n, 0, route_bits(G), st);
-  if (e != hipSuccess) { set_error("radix_sort_pairs: %s", hipGetErrorString(e)); return REC_EHIP; }
+  // stable partition by owner: one radix pass over the owner key (hand-written, csrc/radix_sort.h)
+  rsort::BufSrc<uint32_t> src{keys_in, vals_in};
+  if (int rc = rsort::sort_pairs<uint32_t>(n, p.sort, src, (uint32_t*)(base + p.off_keys_tmp),
+                                           (int32_t*)(base + p.off_vals_tmp), keys_out, vals_out,
+                                           base + p.off_hist, base + p.off_totals, st))
+    return rc;
   const unsigned g2 = (unsigned)((n + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(route_emit_kernel, dim3(g2), dim3(kBlock), 0, st, n, num_slots, G, ids,
                      slot_offset, keys_out, vals_out, send_local_row, send_pos, send_sample,

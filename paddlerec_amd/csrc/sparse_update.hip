@@ -11,63 +11,160 @@
 #include <string.h>
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
-
 #include <cmath>
 
+#include "radix_sort.h"
 #include "rec_common.h"
 
 namespace rec {
 
+constexpr int kSegTile = REC_SEG_TILE, kSegLong = REC_SEG_LONG;
+
 // ------------------------------------------------------------------------------- ids grouping
+// keys of the B*S lookups, computed on the fly by the first radix pass (no key materialisation pass):
+// row = id + slot_offset[pos % S]; padding and out-of-range lookups get the sentinel N (sorts behind every row)
 template <class KeyT>
-__global__ void make_keys_kernel(int64_t n, int S, int64_t N, int64_t pad,
-                                 const int64_t* __restrict__ ids,
-                                 const int64_t* __restrict__ slot_off, KeyT* __restrict__ keys,
-                                 int32_t* __restrict__ vals, int32_t* __restrict__ status) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t id = ids[i];
-  KeyT k = (KeyT)N;  // sentinel: sorts behind every real row
-  if (id != pad || pad < 0) {
-    const int64_t r = slot_off ? id + slot_off[i % S] : id;
-    if (r >= 0 && r < N) k = (KeyT)r; else atomicOr(status, REC_FLAG_INDEX_OOB);
+struct IdsSrc {
+  const int64_t* ids;
+  const int64_t* slot_off;
+  int S;
+  int64_t N, pad;
+  int32_t* status;
+  __device__ __forceinline__ KeyT key(int64_t i) const {
+    const int64_t id = ids[i];
+    KeyT k = (KeyT)N;
+    if (id != pad || pad < 0) {
+      const int64_t r = slot_off ? id + slot_off[(int)i % S] : id;
+      if (r >= 0 && r < N) k = (KeyT)r; else atomicOr(status, REC_FLAG_INDEX_OOB);
+    }
+    return k;
   }
-  keys[i] = k;
-  vals[i] = (int32_t)i;
+  __device__ __forceinline__ int32_t val(int64_t i) const { return (int32_t)i; }
+};
+
+// Heads of the sorted key runs.  A block owns a tile of kHeadsTile consecutive sorted positions, a wave walks it
+// in 64-position chunks (coalesced): head flags by comparing with the left neighbour (shuffle; lane 0 reads one key
+// more), counted / ranked with ballots — no per-thread serial scans.
+constexpr int kHeadsChunks = 8;                                            // chunks per wave
+constexpr int kHeadsWaves = rsort::kThreads / kWave;
+constexpr int kHeadsTile = kHeadsWaves * kHeadsChunks * kWave;             // 2048 positions per block
+
+template <class KeyT>
+__device__ __forceinline__ unsigned long long head_mask(int64_t n, KeyT sentinel, const KeyT* __restrict__ keys,
+                                                        int64_t i, int lane, bool* valid, KeyT* key_out) {
+  const bool in = i < n;
+  const KeyT k = in ? keys[i] : sentinel;
+  KeyT left = __shfl_up(k, 1, kWave);
+  if (lane == 0) left = (i > 0 && i <= n) ? keys[i - 1] : sentinel;
+  const bool v = in && k != sentinel;
+  *valid = v;
+  *key_out = k;
+  return __ballot(v && (i == 0 || k != left));
+}
+
+// per tile: {number of heads, number of valid positions}; also raises n_uniq[2] when some row owns >= REC_SEG_LONG
+// positions (keys[i] == keys[i + REC_SEG_LONG - 1]) — the hot-row partial sums are skipped when none does
+template <class KeyT>
+__global__ __launch_bounds__(rsort::kThreads) void heads_count_kernel(int64_t n, KeyT sentinel,
+                                                                      const KeyT* __restrict__ keys,
+                                                                      int32_t* __restrict__ cnt,
+                                                                      int32_t* __restrict__ n_uniq) {
+  __shared__ int red[2][kHeadsWaves];
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+  const int64_t base = (int64_t)blockIdx.x * kHeadsTile;
+  int heads = 0, valid = 0, has_long = 0;
+#pragma unroll
+  for (int c = 0; c < kHeadsChunks; ++c) {
+    const int64_t i = base + (int64_t)(c * kHeadsWaves + wave) * kWave + lane;
+    bool v;
+    KeyT k;
+    const unsigned long long hm = head_mask<KeyT>(n, sentinel, keys, i, lane, &v, &k);
+    heads += __popcll(hm);
+    valid += __popcll(__ballot(v));
+    if (v && i + kSegLong - 1 < n && keys[i + kSegLong - 1] == k) has_long = 1;
+  }
+  if (__ballot(has_long) != 0 && lane == 0) atomicOr(&n_uniq[2], 1);
+  if (lane == 0) { red[0][wave] = heads; red[1][wave] = valid; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int h = 0, v = 0;
+    for (int w = 0; w < kHeadsWaves; ++w) { h += red[0][w]; v += red[1][w]; }
+    cnt[blockIdx.x * 2] = h;
+    cnt[blockIdx.x * 2 + 1] = v;
+  }
+}
+
+// one block: exclusive scan of the per-tile head counts (in place, cnt[2*blk]); n_uniq[0..1] = {U, n_valid};
+// seg_off[U] = n_valid (the end of the last segment)
+__global__ __launch_bounds__(rsort::kThreads) void heads_scan_kernel(int nblk, int32_t* __restrict__ cnt,
+                                                                     int32_t* __restrict__ seg_off,
+                                                                     int32_t* __restrict__ n_uniq) {
+  __shared__ int part[rsort::kThreads], vpart[rsort::kThreads];
+  const int per = (nblk + rsort::kThreads - 1) / rsort::kThreads;
+  const int lo = threadIdx.x * per, hi = min(lo + per, nblk);
+  int s = 0, v = 0;
+  for (int i = lo; i < hi; ++i) { s += cnt[2 * i]; v += cnt[2 * i + 1]; }
+  part[threadIdx.x] = s;
+  vpart[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 1; o < rsort::kThreads; o <<= 1) {
+    const int a = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    const int b = (int)threadIdx.x >= o ? vpart[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += a;
+    vpart[threadIdx.x] += b;
+    __syncthreads();
+  }
+  int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+  for (int i = lo; i < hi; ++i) {
+    const int t = cnt[2 * i];
+    cnt[2 * i] = run;
+    run += t;
+  }
+  if (threadIdx.x == rsort::kThreads - 1) {
+    const int U = part[rsort::kThreads - 1], nv = vpart[rsort::kThreads - 1];
+    n_uniq[0] = U;
+    n_uniq[1] = nv;
+    seg_off[U] = nv;
+  }
 }
 
 template <class KeyT>
-__global__ void mark_heads_kernel(int64_t n, KeyT sentinel, const KeyT* __restrict__ keys,
-                                  int32_t* __restrict__ heads) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const KeyT k = keys[i];
-  heads[i] = (k != sentinel && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
-}
-
-template <class KeyT>
-__global__ void emit_segments_kernel(int64_t n, KeyT sentinel, const KeyT* __restrict__ keys,
-                                     const int32_t* __restrict__ heads,
-                                     const int32_t* __restrict__ incl, int64_t* __restrict__ uniq,
-                                     int32_t* __restrict__ seg_off, int32_t* __restrict__ n_uniq) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const KeyT k = keys[i];
-  if (heads[i]) {
-    const int u = incl[i] - 1;
-    uniq[u] = (int64_t)k;
-    seg_off[u] = (int32_t)i;
+__global__ __launch_bounds__(rsort::kThreads) void heads_emit_kernel(int64_t n, KeyT sentinel,
+                                                                     const KeyT* __restrict__ keys,
+                                                                     const int32_t* __restrict__ cnt,
+                                                                     int64_t* __restrict__ uniq,
+                                                                     int32_t* __restrict__ seg_off) {
+  __shared__ int ccnt[kHeadsChunks * kHeadsWaves];
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+  const int64_t base = (int64_t)blockIdx.x * kHeadsTile;
+  unsigned long long hm[kHeadsChunks];
+  KeyT kk[kHeadsChunks];
+#pragma unroll
+  for (int c = 0; c < kHeadsChunks; ++c) {
+    const int64_t i = base + (int64_t)(c * kHeadsWaves + wave) * kWave + lane;
+    bool v;
+    hm[c] = head_mask<KeyT>(n, sentinel, keys, i, lane, &v, &kk[c]);
+    if (lane == 0) ccnt[c * kHeadsWaves + wave] = __popcll(hm[c]);
   }
-  if (k != sentinel && (i == n - 1 || keys[i + 1] == sentinel)) {  // last real position
-    seg_off[incl[i]] = (int32_t)(i + 1);
-    n_uniq[0] = incl[i];
-    n_uniq[1] = (int32_t)(i + 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {   // exclusive scan over the tile's 32 chunks (in position order)
+    int run = cnt[blockIdx.x * 2];
+    for (int q = 0; q < kHeadsChunks * kHeadsWaves; ++q) {
+      const int t = ccnt[q];
+      ccnt[q] = run;
+      run += t;
+    }
   }
-  if (i == 0 && k == sentinel) {  // nothing but padding
-    seg_off[0] = 0;
-    n_uniq[0] = 0;
-    n_uniq[1] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < kHeadsChunks; ++c) {
+    if ((hm[c] >> lane) & 1ull) {
+      const int64_t i = base + (int64_t)(c * kHeadsWaves + wave) * kWave + lane;
+      const int u = ccnt[c * kHeadsWaves + wave] + __popcll(hm[c] & ((1ull << lane) - 1ull));
+      uniq[u] = (int64_t)kk[c];
+      seg_off[u] = (int32_t)i;
+    }
   }
 }
 
@@ -79,28 +176,21 @@ static int key_bits(int64_t N) {
 
 template <class KeyT>
 struct GroupPlan {
-  size_t off_keys_in, off_keys_out, off_vals_in, off_heads, off_incl, off_temp, temp_bytes, total;
+  rsort::Plan sort;
+  size_t off_keys_tmp, off_keys_dst, off_vals_tmp, off_hist, off_totals, off_cnt, total;
 };
 
 template <class KeyT>
 static int plan_group(int64_t n, int64_t N, GroupPlan<KeyT>* p) {
-  size_t sort_tmp = 0, scan_tmp = 0;
-  hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, KeyT*, KeyT*, int32_t*,
-                                           int32_t*>(nullptr, sort_tmp, nullptr, nullptr, nullptr,
-                                                     nullptr, (size_t)n, 0, key_bits(N));
-  if (e != hipSuccess) { set_error("radix_sort_pairs size query: %s", hipGetErrorString(e)); return REC_EHIP; }
-  e = rocprim::inclusive_scan<rocprim::default_config, int32_t*, int32_t*>(
-      nullptr, scan_tmp, nullptr, nullptr, (size_t)n, rocprim::plus<int32_t>());
-  if (e != hipSuccess) { set_error("inclusive_scan size query: %s", hipGetErrorString(e)); return REC_EHIP; }
+  p->sort = rsort::make_plan(n, key_bits(N));
   size_t o = 0;
-  p->off_keys_in = o;  o += align_up((size_t)n * sizeof(KeyT), 256);
-  p->off_keys_out = o; o += align_up((size_t)n * sizeof(KeyT), 256);
-  p->off_vals_in = o;  o += align_up((size_t)n * sizeof(int32_t), 256);
-  p->off_heads = o;    o += align_up((size_t)n * sizeof(int32_t), 256);
-  p->off_incl = o;     o += align_up((size_t)n * sizeof(int32_t), 256);
-  p->off_temp = o;
-  p->temp_bytes = align_up(sort_tmp > scan_tmp ? sort_tmp : scan_tmp, 256);
-  p->total = o + p->temp_bytes;
+  p->off_keys_tmp = o; o += align_up((size_t)n * sizeof(KeyT), 256);
+  p->off_keys_dst = o; o += align_up((size_t)n * sizeof(KeyT), 256);
+  p->off_vals_tmp = o; o += align_up((size_t)n * sizeof(int32_t), 256);
+  p->off_hist = o;     o += p->sort.hist_bytes;
+  p->off_totals = o;   o += p->sort.totals_bytes;
+  p->off_cnt = o;      o += align_up((size_t)((n + kHeadsTile - 1) / kHeadsTile + 1) * 2 * sizeof(int32_t), 256);
+  p->total = o;
   return REC_OK;
 }
 
@@ -113,26 +203,21 @@ static int run_group(int64_t n, int S, int64_t N, int64_t pad, const int64_t* id
   if (int rc = plan_group<KeyT>(n, N, &p)) return rc;
   REC_REQUIRE(ws && ws_bytes >= p.total, REC_EWORKSPACE, "workspace %zu < %zu", ws_bytes, p.total);
   char* base = (char*)ws;
-  KeyT* keys_in = (KeyT*)(base + p.off_keys_in);
-  KeyT* keys_out = (KeyT*)(base + p.off_keys_out);
-  int32_t* vals_in = (int32_t*)(base + p.off_vals_in);
-  int32_t* heads = (int32_t*)(base + p.off_heads);
-  int32_t* incl = (int32_t*)(base + p.off_incl);
-  void* temp = base + p.off_temp;
-  const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(make_keys_kernel<KeyT>, dim3(grid), dim3(kBlock), 0, st, n, S, N, pad, ids,
-                     slot_off, keys_in, vals_in, status);
-  size_t tb = p.temp_bytes;
-  hipError_t e = rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, vals_in, sorted_pos,
-                                           (size_t)n, 0, key_bits(N), st);
-  if (e != hipSuccess) { set_error("radix_sort_pairs: %s", hipGetErrorString(e)); return REC_EHIP; }
-  hipLaunchKernelGGL(mark_heads_kernel<KeyT>, dim3(grid), dim3(kBlock), 0, st, n, (KeyT)N,
-                     keys_out, heads);
-  tb = p.temp_bytes;
-  e = rocprim::inclusive_scan(temp, tb, heads, incl, (size_t)n, rocprim::plus<int32_t>(), st);
-  if (e != hipSuccess) { set_error("inclusive_scan: %s", hipGetErrorString(e)); return REC_EHIP; }
-  hipLaunchKernelGGL(emit_segments_kernel<KeyT>, dim3(grid), dim3(kBlock), 0, st, n, (KeyT)N,
-                     keys_out, heads, incl, uniq, seg_off, n_uniq);
+  KeyT* keys_tmp = (KeyT*)(base + p.off_keys_tmp);
+  KeyT* keys_dst = (KeyT*)(base + p.off_keys_dst);
+  int32_t* vals_tmp = (int32_t*)(base + p.off_vals_tmp);
+  int32_t* cnt = (int32_t*)(base + p.off_cnt);
+  IdsSrc<KeyT> src{ids, slot_off, S, N, pad, status};
+  if (int rc = rsort::sort_pairs<KeyT>(n, p.sort, src, keys_tmp, vals_tmp, keys_dst, sorted_pos,
+                                       base + p.off_hist, base + p.off_totals, st))
+    return rc;
+  const int nblk = (int)((n + kHeadsTile - 1) / kHeadsTile);
+  (void)hipMemsetAsync(n_uniq + 2, 0, 2 * sizeof(int32_t), st);
+  hipLaunchKernelGGL(heads_count_kernel<KeyT>, dim3(nblk), dim3(rsort::kThreads), 0, st, n, (KeyT)N, keys_dst, cnt,
+                     n_uniq);
+  hipLaunchKernelGGL(heads_scan_kernel, dim3(1), dim3(rsort::kThreads), 0, st, nblk, cnt, seg_off, n_uniq);
+  hipLaunchKernelGGL(heads_emit_kernel<KeyT>, dim3(nblk), dim3(rsort::kThreads), 0, st, n, (KeyT)N, keys_dst, cnt,
+                     uniq, seg_off);
   return check_launch("rec_ids_group");
 }
 
@@ -153,7 +238,6 @@ __device__ __forceinline__ int64_t grad_offset(const rec_grad_layout& gl, int po
 // of one gradient row per position.  partials[(tile*2 + slot)*D ..]: slot 0 = the piece of the long
 // segment that contains the tile's first position, slot 1 = the piece of a different long segment
 // that contains its last position (a long segment spans >= 2 tiles, so no tile holds a third piece).
-constexpr int kSegTile = REC_SEG_TILE, kSegLong = REC_SEG_LONG;
 
 template <int VEC, int LANES>
 __global__ __launch_bounds__(kBlock) void segment_partials_kernel(
@@ -165,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void segment_partials_kernel(
   const int lane = threadIdx.x % 64;
   const int64_t tile = (int64_t)blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
   const int U = n_uniq[0];
-  if (U <= 0) return;
+  if (U <= 0 || n_uniq[2] == 0) return;   // no long segment in this batch: nothing to pre-reduce
   const int nvalid = seg_off[U];
   const int64_t s64 = tile * kSegTile;
   if (s64 >= nvalid) return;
@@ -566,7 +650,7 @@ extern "C" int rec_ids_group(int64_t n, int32_t num_slots, int64_t num_rows, int
               "null pointer argument");
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) {
-    (void)hipMemsetAsync(n_uniq, 0, 2 * sizeof(int32_t), st);
+    (void)hipMemsetAsync(n_uniq, 0, 4 * sizeof(int32_t), st);
     (void)hipMemsetAsync(seg_offset, 0, sizeof(int32_t), st);
     return REC_OK;
   }

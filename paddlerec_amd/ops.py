@@ -297,11 +297,11 @@ class IdGroups:
         self.sorted_pos = torch.empty(max(n, 1), dtype=torch.int32, device=device)
         self.uniq_rows = torch.empty(max(n, 1), dtype=torch.int64, device=device)
         self.seg_offset = torch.empty(n + 1, dtype=torch.int32, device=device)
-        self.n_uniq = torch.zeros(2, dtype=torch.int32, device=device)
+        self.n_uniq = torch.zeros(4, dtype=torch.int32, device=device)
 
     def host(self):
         """(sorted_pos[:n_valid], uniq_rows[:U], seg_offset[:U+1]) on the CPU — host sync."""
-        U, nv = (int(x) for x in self.n_uniq.tolist())
+        U, nv = (int(x) for x in self.n_uniq.tolist()[:2])
         return (self.sorted_pos[:nv].cpu().numpy(), self.uniq_rows[:U].cpu().numpy(),
                 self.seg_offset[:U + 1].cpu().numpy())
 

@@ -113,11 +113,19 @@ class ShardedDeepFMLayer(DeepFMLayer):
         G = self.comm.world
         self.global_rows = int(sparse_feature_number)
         self.local_rows = (self.global_rows + G - 1) // G
-        # global padding row 0 lives on rank 0 as local row 0 (only meaningful without slot offsets)
-        super().__init__(sparse_feature_number, sparse_feature_dim, dense_feature_dim,
-                         sparse_num_field, layer_sizes, device=device, slot_offset=slot_offset,
-                         table_rows=self.local_rows, zero_padding_row=(self.comm.rank == 0),
-                         kernels=kernels, extra_dense=(("__loss__", (1,)),))
+        # Every rank draws ITS shard from its own generator state (seed + a function of the rank): with the launcher
+        # seeding all ranks alike, the shards would otherwise be bit-identical copies — global rows i*G .. i*G+G-1
+        # all starting from the same values instead of an i.i.d. table.  (The dense parameters drawn here too are
+        # replaced by rank 0's below.)
+        dev = torch.device(device)
+        base_seed = torch.initial_seed()
+        with torch.random.fork_rng(devices=[dev] if dev.type == "cuda" else []):
+            torch.manual_seed((base_seed + 1000003 * (self.comm.rank + 1)) % (2 ** 63 - 1))
+            # global padding row 0 lives on rank 0 as local row 0 (only meaningful without slot offsets)
+            super().__init__(sparse_feature_number, sparse_feature_dim, dense_feature_dim,
+                             sparse_num_field, layer_sizes, device=device, slot_offset=slot_offset,
+                             table_rows=self.local_rows, zero_padding_row=(self.comm.rank == 0),
+                             kernels=kernels, extra_dense=(("__loss__", (1,)),))
         # data-parallel replicas of the dense parameters (MLP, FM dense weights) must start identical: every rank
         # drew its own random initialisation, rank 0's wins (one flat buffer, one broadcast)
         if G > 1:

@@ -154,6 +154,8 @@ def _agreed_batches(config, mode, comm, batch_size):
 def _lookahead(it, limit=None):
     """(batch, next batch or None) pairs — the row-sharded step routes the next batch a step ahead."""
     prev, n = None, 0
+    if limit is not None and limit <= 0:
+        return
     for cur in it:
         if prev is not None:
             last = limit is not None and n + 1 >= limit      # the agreed last step: no rank may prefetch beyond it
@@ -164,6 +166,41 @@ def _lookahead(it, limit=None):
         prev = cur
     if prev is not None and (limit is None or n < limit):
         yield prev, None
+
+
+def _check_status(dy_model, comm, what):
+    """Paddle's lookup raises on an id outside the table [EXT]; the engine's kernels flag it in a device status word
+    instead (no sync on the hot path).  Read it wherever the device is read back anyway — every rank raises together
+    in collective mode (the flag is summed over the ranks first)."""
+    st = getattr(dy_model, "status", None)
+    if st is None:
+        return
+    flag = st.clone()
+    if comm is not None and comm.world > 1:
+        comm.all_reduce_sum(flag)
+    if int(flag.item()) != 0:
+        from ._lib import RecError
+        raise RecError("%s: an id was outside [0, sparse_feature_number) — check the dataset against the config "
+                       "(hyper_parameters.sparse_feature_number)" % what)
+
+
+def _apply_optimizer_config(config, model, dy_model):
+    """hyper_parameters.optimizer.lazy_mode (default False = the reference's dygraph Adam, dygraph_model.py:61-65:
+    every row's moments decay each step) for the nets that implement both variants; the deviations of the others
+    from the reference's dygraph semantics are logged once, loudly."""
+    lazy = bool(config.get("hyper_parameters.optimizer.lazy_mode", False))
+    if hasattr(type(dy_model), "lazy_mode"):
+        dy_model.lazy_mode = lazy
+        logger.info("sparse optimizer: Adam lazy_mode=%s%s", lazy,
+                    "" if lazy else " (dygraph default: the whole table is streamed every step)")
+    elif model in ("wide_deep", "dnn", "dcn_v2"):
+        logger.warning("DEVIATION from the reference's dygraph run: %s updates only the rows a batch touches "
+                       "(Adam lazy_mode=True); the reference's dygraph Adam also decays the moments of every "
+                       "other row each step", model)
+    if model == "dcn_v2":
+        logger.warning("DEVIATION from the reference's dygraph run: dcn_v2 trains WITHOUT the train-mode "
+                       "Dropout(0.5) of its DNN tower (RNG-dependent, dcn_v2/net.py:161-176) and without "
+                       "L2Decay(1e-7); loss / AUC trajectories differ from the reference's")
 
 
 def _reset(metric_list):
@@ -190,6 +227,7 @@ def train(config, model, device="cuda", kernels=None, comm=None):
     dy_model = dy_model_class.create_model(config, device, **kw)
     if config.get("runner.model_init_path"):
         checkpoint.load_model(config["runner.model_init_path"], dy_model)
+    _apply_optimizer_config(config, model, dy_model)
     epochs = config.get("runner.epochs", 1)
     print_interval = max(int(config.get("runner.print_interval", 1) or 1), 1)
     save_path = config.get("runner.model_save_path", "model_output")
@@ -197,6 +235,9 @@ def train(config, model, device="cuda", kernels=None, comm=None):
     shard = (comm.rank, comm.world) if world > 1 else None
     loader = create_data_loader(config, model, dy_model.device, "train", shard)
     limit = _agreed_batches(config, "train", comm, config.get("runner.train_batch_size")) if world > 1 else None
+    if limit is not None and limit <= 0:       # some rank holds less than one batch: every rank raises (no hang)
+        raise ValueError("train_dataloader is null on at least one rank, please ensure batch size < dataset size "
+                         "of every rank's file split!")
     summaries = []
     for epoch_id in range(config.get("last_epoch", -1) + 1, epochs):
         metric_list, metric_names = dy_model_class.create_metrics(dy_model.device)
@@ -216,6 +257,7 @@ def train(config, model, device="cuda", kernels=None, comm=None):
             total_samples += bs
             n_batches += 1
             if batch_id % print_interval == 0:        # the only place the device is read back
+                _check_status(dy_model, comm, "train")
                 vals = _global_metric_values(dy_model_class, metric_list, metric_names, comm)
                 logger.info("epoch: %d, batch_id: %d, %sloss: %.6f, avg_reader_cost: %.5f sec, avg_batch_cost: "
                             "%.5f sec, avg_samples: %.5f, ips: %.5f ins/s", epoch_id, batch_id,
@@ -231,6 +273,7 @@ def train(config, model, device="cuda", kernels=None, comm=None):
         if dy_model.device.type == "cuda":
             torch.cuda.synchronize(dy_model.device)
         elapsed = time.time() - epoch_begin
+        _check_status(dy_model, comm, "train")
         vals = _global_metric_values(dy_model_class, metric_list, metric_names, comm)
         if use_auc:
             _reset(metric_list)
@@ -258,6 +301,8 @@ def infer(config, model, device="cuda", kernels=None, comm=None):
     shard = (comm.rank, comm.world) if world > 1 else None
     loader = create_data_loader(config, model, dy_model.device, "test", shard)
     limit = _agreed_batches(config, "test", comm, config.get("runner.infer_batch_size")) if world > 1 else None
+    if limit is not None and limit <= 0:
+        raise ValueError("test_dataloader is null on at least one rank, please ensure batch size < dataset size!")
     use_auc = config.get("runner.use_auc", False)
     metric_list, metric_names = dy_model_class.create_metrics(dy_model.device)
     out = []
@@ -270,6 +315,7 @@ def infer(config, model, device="cuda", kernels=None, comm=None):
             samples += _batch_size(batch) * world
         if n_batches == 0:
             raise ValueError("test_dataloader is null, please ensure batch size < dataset size!")
+        _check_status(dy_model, comm, "infer")
         vals = _global_metric_values(dy_model_class, metric_list, metric_names, comm)
         if use_auc:
             _reset(metric_list)

@@ -430,3 +430,14 @@ def ps_push_rows(table, groups, grad, num_slots, grad_pitch=None, grad_index=Non
                initial_range=A.initial_range, embedx_threshold=A.embedx_threshold, nonclk_coeff=A.nonclk_coeff,
                click_coeff=A.click_coeff, seed=A.seed)
     ps_ref.push_rows(table.rec.numpy(), lay, groups.uniq, g_w, g_x, dshow, dclick, acc)
+
+
+def adam_rows_all(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                  grad_group=0, grad_group_stride=0, grad_scale=None, partials=None):
+    """rec_adam_rows_all: lazy_mode=False Adam — every row moves, rows absent from the merged gradient with g = 0."""
+    merged = _merged_rows(groups, grad, P.shape[1], grad_div, grad_group, grad_group_stride)
+    if grad_scale is not None:
+        merged = merged * np.float32(float(grad_scale[0]))
+    Pn, Mn, Vn = P.numpy().copy(), M.numpy().copy(), V.numpy().copy()      # strided views: work on copies
+    R.adam_update_dense_equivalent(Pn, Mn, Vn, groups.uniq, merged, step, lr=lr, beta1=beta1, beta2=beta2, eps=eps)
+    P.copy_(torch.from_numpy(Pn)); M.copy_(torch.from_numpy(Mn)); V.copy_(torch.from_numpy(Vn))

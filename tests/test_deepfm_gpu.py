@@ -225,16 +225,16 @@ def test_ids_group_edge_cases(ops):
     ws = ops.Workspace(DEV)
     ids = torch.zeros(16, 26, dtype=torch.int64, device=DEV)          # nothing but padding
     groups, _ = ops.ids_group(ids, 100, 0, ws)
-    assert groups.n_uniq.tolist() == [0, 0]
+    assert groups.n_uniq.tolist() == [0, 0, 0, 0]                      # {rows, positions, has a long segment, -}
     groups, _ = ops.ids_group(torch.zeros(0, 26, dtype=torch.int64, device=DEV), 100, 0, ws)
-    assert groups.n_uniq.tolist() == [0, 0]
+    assert groups.n_uniq.tolist() == [0, 0, 0, 0]
     ids = torch.full((5, 26), 7, dtype=torch.int64, device=DEV)       # one row, 130 duplicates
     groups, _ = ops.ids_group(ids, 100, 0, ws)
     spos, uniq, offs = groups.host()
     assert uniq.tolist() == [7] and offs.tolist() == [0, 130] and spos.tolist() == list(range(130))
     ids[2, 3] = 1000                                                   # out of range -> flagged, dropped
     groups, status = ops.ids_group(ids, 100, 0, ws)
-    assert int(status.item()) & 1 and groups.n_uniq.tolist() == [1, 129]
+    assert int(status.item()) & 1 and groups.n_uniq.tolist() == [1, 129, 1, 0]
     big = torch.randint(1, 3_000_000_000, (64, 26), dtype=torch.int64, device=DEV)   # 64-bit key path
     groups, _ = ops.ids_group(big, 5_000_000_000, 0, ws)
     spos, uniq, offs = groups.host()

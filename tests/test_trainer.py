@@ -33,6 +33,7 @@ hyper_parameters:
     class: Adam
     learning_rate: 0.01
     strategy: async
+    lazy_mode: True     # engine key: the static-graph optimizer (deepfm/static_model.py:101-107); default False = dygraph Adam
   sparse_inputs_slots: 27
   sparse_feature_number: 1000001
   sparse_feature_dim: 9
