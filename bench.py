@@ -169,6 +169,11 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the row-sharded path (RCCL all-to-all) even with one rank")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--table", choices=("adam", "ps"), default="adam",
+                    help="ps = BASELINE configs[4]: the hashed gpubox table (uint64 feasigns -> mix64 %% N rows on the "
+                         "device, AdaGrad accessor record, rows born lazily), row-sharded; implies the sharded path")
+    ap.add_argument("--hashed-rows", type=int, default=1_250_000_000,
+                    help="--table ps: table rows PER GPU (10^10 / 8 = 1.25e9 = 160 GB of 128-B records)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,7 +184,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or args.force_sharded:
+    if world > 1 or args.force_sharded or args.table == "ps":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -197,11 +202,25 @@ def main():
         from paddlerec_amd.deepfm import DeepFMLayer
         model = DeepFMLayer(N, D, Dn, S, fc, device=dev, slot_offset=so)
         parallelism = "single"
+    elif args.table == "ps":
+        from paddlerec_amd.sharded import ShardedDeepFMLayer
+        N = args.hashed_rows * world
+        # embedx_threshold 0: a feature is created whole at its first pull (the full-work regime; the shipped
+        # config_online.yaml gates embedx behind 10 shows)
+        model = ShardedDeepFMLayer(N, D, Dn, S, fc, device=dev, group=dist.group.WORLD, table="ps",
+                                   accessor=dict(embedx_threshold=0.0), hash_keys=True)
+        parallelism = "rowshard%d+dp%d (PS accessor table, hashed uint64 keys)" % (world, world)
     else:
         from paddlerec_amd.sharded import ShardedDeepFMLayer
         model = ShardedDeepFMLayer(N, D, Dn, S, fc, device=dev, slot_offset=so, group=dist.group.WORLD)
         parallelism = "rowshard%d+dp%d" % (world, world)
     batches = make_batches(4, B, S, Dn, args.rows_per_table * world, dev, 20250404 + rank, args.ids)
+    if args.table == "ps":      # raw uint64 feasigns (as int64 bit patterns), 3 % padding id 0
+        g = torch.Generator(device=dev).manual_seed(99 + rank)
+        for i, (ids, dense, label) in enumerate(batches):
+            keys = torch.randint(-2 ** 63, 2 ** 63 - 1, ids.shape, device=dev, generator=g, dtype=torch.int64)
+            keys[ids == 0] = 0
+            batches[i] = (keys, dense, label)
 
     def step(i):
         ids, dense, label = batches[i % len(batches)]
@@ -271,7 +290,11 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "DeepFM full Criteo: 26 sparse slots x %d rows x dim %d, 13 dense, "
-                               "MLP %s, batch %d per GPU, lazy Adam, %s ids" % (args.rows_per_table, D, args.fc, B, args.ids),
+                               "MLP %s, batch %d per GPU, lazy Adam, %s ids" % (args.rows_per_table, D, args.fc, B, args.ids)
+                   if args.table != "ps" else
+                   "DeepFM on the hashed gpubox table (configs[4]): %d rows per GPU x %d GPUs x dim %d (one 128-B "
+                   "accessor record per row, born lazily), 26 slots of uint64 feasigns hashed on the device, 13 dense, "
+                   "MLP %s, batch %d per GPU, AdaGrad accessor push" % (args.hashed_rows, world, D, args.fc, B),
                    "global_batch": world * B, "parallelism": parallelism,
                    "table_rows_total": N, "loss": loss_v, "index_oob_flag": oob},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -123,6 +123,23 @@ int rec_emb_gather_sumpool(int64_t batch, int32_t emb_dim, int32_t row_stride, i
                            int64_t padding_idx, const int64_t* ids, const int64_t* lod /*[B+1]*/,
                            const float* W, float* out, int32_t* counts, int32_t* status,
                            void* stream);
+/* What an unborn row of a lazily created PS table reads as (rec_ps_push_rows gives birth with the same values):
+ * element 0 (embed_w) always, elements 1.. (embedx) when init_dims > 1; keyed by (seed, row*row_mul+row_add, d).
+ * init_range <= 0: rows are plain memory. */
+typedef struct {
+  int32_t state_offset; /* floats from the row start to the state float (0 = unborn) */
+  int32_t init_dims;
+  float init_range;
+  uint64_t seed;
+  int64_t row_mul, row_add;
+} rec_lazy_init;
+/* Owner-side lookup of a row-sharded DeepFM table (tools/static_gpubox_trainer.py:152-160: the pull of the GPU
+ * parameter server): out_w[i,:] = rec[rows[i], 0:D], out_w1[i] = rec[rows[i], D] — both embeddings of
+ * deepfm/net.py:62-86 from the one record line of a row.  lazy may be NULL. */
+int rec_record_gather(int64_t n, int32_t emb_dim, int32_t rec_stride, int64_t num_rows, const int64_t* rows,
+                      const float* rec, float* out_w, float* out_w1, const rec_lazy_init* lazy,
+                      int32_t* status, void* stream);
+
 /* backward of the sum-pool: SelectedRows.value[k,:] = d_out[sample(k),:]  (rows = ids). */
 int rec_emb_sumpool_bwd(int64_t batch, int32_t emb_dim, const int64_t* lod, const float* d_out,
                         float* row_grad, void* stream);
@@ -293,6 +310,9 @@ typedef struct {
   float initial_range;
   float embedx_threshold, nonclk_coeff, click_coeff;
   uint64_t seed;
+  int64_t row_mul, row_add; /* identity of table row r in the creation values: r * row_mul + row_add (a shard
+                               passes {world, rank}: a feature is born with the same values however the table
+                               is sharded); {1, 0} for an unsharded table */
 } rec_ps_accessor;
 typedef struct {
   int32_t row_stride, embed_off, embedx_off, embedx_dim, stat_off;
@@ -525,6 +545,23 @@ int rec_shard_route(int64_t n, int32_t num_slots, int64_t num_rows, int64_t padd
                     int64_t* send_local_row, int64_t* send_pos, int64_t* send_sample,
                     int64_t* slot_of_pos, int64_t* send_counts, int32_t* status, void* workspace,
                     size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Exchange layer of the row-sharded table (reference: the inter-GPU pull / push of
+ * core.PSGPU, tools/static_gpubox_trainer.py:152-160,256 [EXT HeterPS]).  `comm` is an RCCL ncclComm_t — created
+ * by rec_comm_init (one per process; rank 0 makes the id with rec_comm_unique_id and distributes its 128 bytes by
+ * any means) or owned by the framework.  RCCL is bound at run time; REC_ENCCL when it is missing or fails.
+ *   rec_alltoall_exchange: all-to-all(v) of rows of row_bytes bytes — send is grouped by destination rank
+ *     (send_counts[d] rows, HOST array of `world` entries), recv by source rank; asynchronous on `stream`.
+ *     A sharded step issues it three times: ids to owners, rows back, row-gradients to owners.
+ *   rec_allreduce_sum_f32: the flat dense-gradient bucket.
+ * ---------------------------------------------------------------------------------------- */
+int rec_comm_unique_id(void* id128);
+int rec_comm_init(const void* id128, int32_t world, int32_t rank, void** comm);
+int rec_comm_destroy(void* comm);
+int rec_alltoall_exchange(void* comm, const void* send, const int64_t* send_counts, void* recv,
+                          const int64_t* recv_counts, int32_t row_bytes, void* stream);
+int rec_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);
 
 /* Row H — feature hash, HOST function: xxh32(str(field_idx)+value) % hash_dim
  * (models/rank/dnn/benchmark_reader.py:52).  `bytes` = the concatenated string. */

@@ -73,8 +73,10 @@ def push_rows(rec, lay, uniq, g_embed, g_embedx, dshow, dclick, acc):
     Dx, eo, xo, so = lay["embedx_dim"], lay["embed_off"], lay["embedx_off"], lay["stat_off"]
     g0, lr = f(acc["initial_g2sum"]), f(acc["lr"])
     lo, hi = f(acc["bounds"][0]), f(acc["bounds"][1])
+    mul, add = int(acc.get("row_mul", 1)), int(acc.get("row_add", 0))   # identity of a shard's row: row*mul + add
     for u, row in enumerate(uniq):
         r = rec[row]
+        row = int(row) * mul + add
         show0, click0, g2w, g2x, state = r[so], r[so + 1], r[so + 2], r[so + 3], r[so + 4]
         score0 = (show0 - click0) * f(acc["nonclk_coeff"]) + click0 * f(acc["click_coeff"])
         unborn = state == 0
@@ -109,6 +111,7 @@ def pull_value(rec, lay, row, acc, D_lookup):
     r = rec[row]
     if r[lay["stat_off"] + 4] != 0:
         return r[lay["embed_off"]:lay["embed_off"] + D_lookup].copy()
+    row = int(row) * int(acc.get("row_mul", 1)) + int(acc.get("row_add", 0))
     dims = D_lookup if acc["embedx_threshold"] <= 0 else 1
     return np.array([init_value(acc["seed"], row, d, acc["initial_range"]) if d < dims else np.float32(0)
                      for d in range(D_lookup)], np.float32)
@@ -133,3 +136,22 @@ def shrink_rows(rec, lay, acc, decay, delete_threshold):
         else:
             r[so], r[so + 1] = show, click
     return deleted
+
+
+def pull_deepfm(rec, lay, rows, acc):
+    """Lookup of the 'deepfm' record layout (embedx = the D-dim embedding, embed_w = the first-order weight):
+    -> (W [n, Dx], W1 [n]); unborn rows read as their creation values."""
+    Dx, eo, xo, so = lay["embedx_dim"], lay["embed_off"], lay["embedx_off"], lay["stat_off"]
+    mul, add = int(acc.get("row_mul", 1)), int(acc.get("row_add", 0))
+    W = np.zeros((len(rows), Dx), np.float32)
+    W1 = np.zeros(len(rows), np.float32)
+    for i, row in enumerate(rows):
+        r = rec[int(row)]
+        if r[so + 4] != 0:
+            W[i], W1[i] = r[xo:xo + Dx], r[eo]
+        else:
+            g = int(row) * mul + add
+            W1[i] = init_value(acc["seed"], g, 0, acc["initial_range"])
+            if acc["embedx_threshold"] <= 0:
+                W[i] = [init_value(acc["seed"], g, 1 + j, acc["initial_range"]) for j in range(Dx)]
+    return W, W1

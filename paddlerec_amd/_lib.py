@@ -39,7 +39,12 @@ class GradLayout(C.Structure):
 class PsAccessor(C.Structure):
     _fields_ = [("lr", C.c_float), ("initial_g2sum", C.c_float), ("min_bound", C.c_float), ("max_bound", C.c_float),
                 ("initial_range", C.c_float), ("embedx_threshold", C.c_float), ("nonclk_coeff", C.c_float),
-                ("click_coeff", C.c_float), ("seed", C.c_uint64)]
+                ("click_coeff", C.c_float), ("seed", C.c_uint64), ("row_mul", C.c_int64), ("row_add", C.c_int64)]
+
+
+class LazyInit(C.Structure):
+    _fields_ = [("state_offset", C.c_int32), ("init_dims", C.c_int32), ("init_range", C.c_float),
+                ("seed", C.c_uint64), ("row_mul", C.c_int64), ("row_add", C.c_int64)]
 
 
 class PsLayout(C.Structure):
@@ -108,6 +113,12 @@ SIGNATURES = {
     "rec_multislot_sumpool_fwd": (C.c_int, [C.POINTER(MultislotDesc)] + [_P] * 10),
     "rec_feasign_rows": (C.c_int, [_I64, _I64, _P, _P, _P]),
     "rec_feasign_rows_host": (C.c_int, [_I64, _I64, _P, _P]),
+    "rec_record_gather": (C.c_int, [_I64, _I32, _I32, _I64, _P, _P, _P, _P, C.POINTER(LazyInit), _P, _P]),
+    "rec_comm_unique_id": (C.c_int, [_P]),
+    "rec_comm_init": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),
+    "rec_comm_destroy": (C.c_int, [_P]),
+    "rec_alltoall_exchange": (C.c_int, [_P, _P, C.POINTER(_I64), _P, C.POINTER(_I64), _I32, _P]),
+    "rec_allreduce_sum_f32": (C.c_int, [_P, _P, _I64, _P]),
     "rec_ps_push_rows": (C.c_int, [_I64, _I32, C.POINTER(PsLayout), _P, _P, _P, _P, C.POINTER(GradSrc),
                                    C.POINTER(GradSrc), _P, _P, _P, C.POINTER(PsAccessor), _P]),
     "rec_ps_init_value_host": (C.c_float, [C.c_uint64, _I64, _I32, _F]),

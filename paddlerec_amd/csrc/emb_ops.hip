@@ -34,6 +34,44 @@ __global__ __launch_bounds__(kBlock) void emb_gather_kernel(
   vstore<VEC>(out + o + d0, e);
 }
 
+// Owner-side lookup of a row-sharded DeepFM table: BOTH embeddings of a row from its ONE record line
+//   rec [N, stride] = W(D) | W1 | ...   ->  out_w [n, D], out_w1 [n]
+// (two rec_emb_gather launches read every line twice).  PS tables are born lazily: with init_range > 0 a row whose
+// state float rec[row*stride + state_off] is 0 reads as its creation values — embed_w (= W1, element 0) always,
+// embedx (= W, element 1+d) only when init_embedx — keyed by the GLOBAL row = row * row_mul + row_add.
+template <int VEC, int LANES>
+__global__ __launch_bounds__(kBlock) void record_gather_kernel(
+    int64_t n, int D, int stride, int64_t N, const int64_t* __restrict__ rows, const float* __restrict__ rec,
+    float* __restrict__ out_w, float* __restrict__ out_w1, int state_off, float init_range, int init_embedx,
+    uint64_t seed, int64_t row_mul, int64_t row_add, int32_t* __restrict__ status) {
+  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
+  const int lg = threadIdx.x % LANES;
+  const int d0 = lg * VEC;
+  if (i >= n) return;
+  const int64_t row = rows[i];
+  const bool ok = row >= 0 && row < N;
+  if (!ok && lg == 0) atomicOr(status, REC_FLAG_INDEX_OOB);
+  const float* r = rec + (ok ? row : 0) * stride;
+  const bool unborn = ok && state_off >= 0 && r[state_off] == 0.f;
+  const int64_t grow = row * row_mul + row_add;
+  if (d0 < D) {
+    float e[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) e[v] = 0.f;
+    if (ok) {
+      if (unborn) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+          e[v] = (init_embedx && d0 + v < D) ? ps_init_value(seed, grow, 1 + d0 + v, init_range) : 0.f;
+      } else {
+        vload<VEC>(e, r + d0);
+      }
+    }
+    vstore<VEC>(out_w + i * D + d0, e);
+  }
+  if (lg == 0) out_w1[i] = !ok ? 0.f : (unborn ? ps_init_value(seed, grow, 0, init_range) : r[D]);
+}
+
 constexpr int kPoolCH = 8;
 
 template <int VEC, int LANES>
@@ -153,5 +191,29 @@ extern "C" int rec_emb_sumpool_bwd(int64_t batch, int32_t emb_dim, const int64_t
     hipLaunchKernelGGL((emb_sumpool_bwd_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock), 0,
                        (hipStream_t)stream, batch, emb_dim, lod, d_out, row_grad);
     return check_launch("rec_emb_sumpool_bwd");
+  });
+}
+
+extern "C" int rec_record_gather(int64_t n, int32_t emb_dim, int32_t rec_stride, int64_t num_rows,
+                                 const int64_t* rows, const float* rec, float* out_w, float* out_w1,
+                                 const rec_lazy_init* lazy, int32_t* status, void* stream) {
+  REC_REQUIRE(n >= 0 && emb_dim > 0 && rec_stride > emb_dim && num_rows > 0, REC_EINVAL,
+              "bad sizes (the record holds W(D) | W1 | ...)");
+  if (n == 0) return REC_OK;
+  REC_REQUIRE(rows && rec && out_w && out_w1 && status, REC_EINVAL, "null pointer argument");
+  rec_lazy_init lz = {-1, 0, 0.f, 0, 1, 0};
+  if (lazy && lazy->init_range > 0.f) lz = *lazy;
+  REC_REQUIRE(lz.state_offset < rec_stride && (lz.state_offset < 0 || lz.state_offset > emb_dim), REC_EINVAL,
+              "state float must sit behind W | W1 inside the record");
+  const bool vec = ((uintptr_t)rec) % 16 == 0 && ((uintptr_t)out_w) % 16 == 0;
+  return dispatch_row_shape(emb_dim, vec ? rec_stride : rec_stride | 1, [&](auto vec_, auto lanes) -> int {
+    constexpr int VEC = decltype(vec_)::value, LANES = decltype(lanes)::value;
+    const int64_t grid = (n * LANES + kBlock - 1) / kBlock;
+    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "n too large");
+    hipLaunchKernelGGL((record_gather_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock), 0,
+                       (hipStream_t)stream, n, emb_dim, rec_stride, num_rows, rows, rec, out_w, out_w1,
+                       lz.state_offset, lz.init_range, lz.init_dims > 1 ? 1 : 0, lz.seed, lz.row_mul, lz.row_add,
+                       status);
+    return check_launch("rec_record_gather");
   });
 }

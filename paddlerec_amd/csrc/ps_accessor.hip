@@ -80,6 +80,7 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
   const int beg = rowok ? seg_off[u] : 0, end = rowok ? seg_off[u + 1] : 0;
   float* r = rec + row * (int64_t)L.row_stride;
   float* st = r + L.stat_off;            // show, click, g2sum_w, g2sum_x, state
+  const int64_t grow = row * A.row_mul + A.row_add;   // identity of the feature across shards (creation values)
   const int Dx = L.embedx_dim;
   const bool xlane = rowok && d0 < Dx;
 
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
     if (unborn) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i)
-        w[i] = (has_x && d0 + i < Dx) ? ps_init_value(A.seed, row, 1 + d0 + i, A.initial_range) : 0.f;
+        w[i] = (has_x && d0 + i < Dx) ? ps_init_value(A.seed, grow, 1 + d0 + i, A.initial_range) : 0.f;
     } else {
       vload<VEC>(w, r + L.embedx_off + d0);
     }
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
     if (create_x) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i)
-        w[i] = d0 + i < Dx ? ps_init_value(A.seed, row, 1 + d0 + i, A.initial_range) : 0.f;
+        w[i] = d0 + i < Dx ? ps_init_value(A.seed, grow, 1 + d0 + i, A.initial_range) : 0.f;
     }
     if (has_x || create_x || unborn) {
       if (VEC == 1 || d0 + VEC <= Dx) {
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
   }
   // ---- embed_w + counters
   if (rowok && lg == 0) {
-    float ew = unborn ? ps_init_value(A.seed, row, 0, A.initial_range) : r[L.embed_off];
+    float ew = unborn ? ps_init_value(A.seed, grow, 0, A.initial_range) : r[L.embed_off];
     float gwv[1] = {0.f};
     ps_segment_sum<1>(gwv, beg, end, spos, gw, gw.col);
     const float sc = sqrtf(A.initial_g2sum / (A.initial_g2sum + g2w));
@@ -228,7 +229,7 @@ extern "C" int rec_ps_push_rows(int64_t n_max, int32_t num_slots, const rec_ps_l
               "embedx gradient missing");
   REC_REQUIRE(n_uniq && uniq_rows && seg_offset && sorted_pos && rec, REC_EINVAL, "null pointer argument");
   REC_REQUIRE(accessor->initial_g2sum > 0.f && accessor->min_bound <= accessor->max_bound &&
-                  accessor->initial_range >= 0.f,
+                  accessor->initial_range >= 0.f && accessor->row_mul >= 1 && accessor->row_add >= 0,
               REC_EINVAL, "bad accessor parameters");
   if (n_max == 0) return REC_OK;
   GradSrc gw = {grad_embed->grad, grad_embed->layout, grad_embed->pitch, grad_embed->col};

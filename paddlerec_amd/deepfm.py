@@ -90,7 +90,9 @@ class FM:
     flat dense buffer of the owning DeepFMLayer."""
 
     def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim,
-                 sparse_num_field, device, slot_offset=None, zero_padding_row=True):
+                 sparse_num_field, device, slot_offset=None, zero_padding_row=True, rec=None):
+        """rec: an existing record buffer [N, >= D+3] to use as the table WITHOUT initialising it (the PS table of
+        the gpubox mode: rows are born lazily, a 160 GB shard is never swept by an init pass)."""
         self.sparse_feature_number = sparse_feature_number
         self.sparse_feature_dim = sparse_feature_dim
         self.dense_feature_dim = dense_feature_dim
@@ -105,6 +107,12 @@ class FM:
         # lookup costs one line instead of two; the second-order Adam moments sit in a second
         # record buffer [m(D) | v(D)] that only the optimizer touches.  The reference's two
         # parameters are views: embedding = rec[:, :D], embedding_one = rec[:, D:D+1].
+        self.slot_offset = slot_offset
+        if rec is not None:
+            self.rec, self.rec_width = rec, rec.shape[1]
+            self.embedding = self.rec[:, :D]
+            self.embedding_one = self.rec[:, D:D + 1]
+            return
         self.rec_width = _round_up(D + 3, 32)
         self.rec = torch.zeros(N, self.rec_width, dtype=torch.float32, device=device)
         self.embedding = self.rec[:, :D]
@@ -113,7 +121,6 @@ class FM:
             torch.nn.init.trunc_normal_(t, 0.0, std, -2 * std, 2 * std)
             if slot_offset is None and zero_padding_row:
                 t[self.padding_idx].zero_()                    # padding row zeroed at construction [EXT]
-        self.slot_offset = slot_offset
 
 
 class DeepFMLayer:
@@ -121,7 +128,7 @@ class DeepFMLayer:
 
     def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim,
                  sparse_num_field, layer_sizes, device="cuda", slot_offset=None, table_rows=None,
-                 zero_padding_row=True, kernels=None, extra_dense=()):
+                 zero_padding_row=True, kernels=None, extra_dense=(), table_rec=None):
         """table_rows: rows actually allocated on this device (row-sharded subclass: ceil(N/G));
         kernels: operator backend (default: the HIP kernels of paddlerec_amd.ops — tests/ may inject
         a stand-in to exercise host orchestration without a GPU; the product never does);
@@ -137,7 +144,7 @@ class DeepFMLayer:
             slot_offset = torch.as_tensor(slot_offset, dtype=torch.int64, device=self.device)
         self.fm = FM(table_rows if table_rows is not None else sparse_feature_number,
                      sparse_feature_dim, dense_feature_dim, sparse_num_field, self.device,
-                     slot_offset, zero_padding_row)
+                     slot_offset, zero_padding_row, rec=table_rec)
         D, Dn = sparse_feature_dim, dense_feature_dim
         self.num_field = Dn + sparse_num_field
         sizes = [D * self.num_field] + self.layer_sizes + [1]               # net.py:150

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (EPI, AdagradHyper, AdamHyper, DeepFMDesc, DinDesc, GemmDesc, GemmEpilogueArgs, GradLayout,
-                   GradSrc, MultislotDesc, PsAccessor, PsLayout, RecError, check, lib)
+                   GradSrc, LazyInit, MultislotDesc, PsAccessor, PsLayout, RecError, check, lib)
 
 
 def _stream():
@@ -435,7 +435,7 @@ class PsTable:
 
     def __init__(self, num_rows, emb_dim, device, kind="slot", lr=0.05, initial_g2sum=3.0, bounds=(-10.0, 10.0),
                  initial_range=1e-4, embedx_threshold=10.0, nonclk_coeff=0.1, click_coeff=1.0, seed=2025,
-                 row_stride=None):
+                 row_stride=None, row_mul=1, row_add=0):
         D = int(emb_dim)
         if kind == "slot":      # [W(D) | show | click | g2w | g2x | state]: D = 9 -> 14 floats in a 64-B half line
             need = D + 5
@@ -460,7 +460,7 @@ class PsTable:
         self.W = self.rec[:, self.w_cols]
         self.accessor = PsAccessor(float(lr), float(initial_g2sum), float(bounds[0]), float(bounds[1]),
                                    float(initial_range), float(embedx_threshold), float(nonclk_coeff),
-                                   float(click_coeff), int(seed))
+                                   float(click_coeff), int(seed), int(row_mul), int(row_add))
 
     @property
     def lazy_init(self):
@@ -471,8 +471,26 @@ class PsTable:
         return (self.state_col - self.w_cols.start, dims, a.initial_range, a.seed)
 
 
+def record_gather(rows, rec, D, out_w, out_w1, status, table=None):
+    """Owner-side lookup: both embeddings of every row from its one record line (rec [N, stride] = W(D) | W1 | ...).
+    table (PsTable, kind 'deepfm'): unborn rows read as their creation values."""
+    _chk(rows, torch.int64, "rows")
+    if rec.dim() != 2 or rec.dtype != torch.float32 or not rec.is_cuda or rec.stride(1) != 1:
+        raise RecError("rec must be a 2-D float32 device tensor with unit column stride")
+    n = rows.numel()
+    lz = None
+    if table is not None and table.accessor.initial_range > 0:
+        a = table.accessor
+        lz = LazyInit(table.state_col, (D + 1) if a.embedx_threshold <= 0 else 1, a.initial_range, a.seed,
+                      a.row_mul, a.row_add)
+    check(lib().rec_record_gather(n, int(D), rec.stride(0), rec.shape[0], _p(rows), _p(rec), _p(out_w), _p(out_w1),
+                                  C.byref(lz) if lz is not None else None, _p(status), _stream()),
+          "rec_record_gather")
+    return out_w, out_w1
+
+
 def ps_push_rows(table, groups, grad, num_slots, grad_pitch=None, grad_index=None, grad1=None, grad1_div=1,
-                 show=None, click=None):
+                 show=None, click=None, grad1_pitch=1):
     """CtrCommonAccessor::Update on the touched rows of `table` (PsTable).  kind 'slot': grad rows [*, D] hold
     [g_embed_w, g_embedx...]; kind 'deepfm': grad = the D-dim row gradients, grad1 = dz [B] (layout {grad1_div})."""
     D = table.emb_dim
@@ -484,7 +502,7 @@ def ps_push_rows(table, groups, grad, num_slots, grad_pitch=None, grad_index=Non
         if grad1 is None:
             raise RecError("kind 'deepfm' needs grad1 (the first-order gradient)")
         gx = GradSrc(grad.data_ptr(), _gl(1, 0, 0, None, grad_index), pitch, 0)
-        gw = GradSrc(grad1.data_ptr(), _gl(grad1_div, 0, 0, None, None), 1, 0)
+        gw = GradSrc(grad1.data_ptr(), _gl(grad1_div, 0, 0, None, None), int(grad1_pitch), 0)
     for t, n in ((show, "show"), (click, "click")):
         if t is not None:
             _chk(t, torch.int64, n)

@@ -37,9 +37,43 @@ class Comm:
         self.world = dist.get_world_size(self.group)
         self.staged = dist.get_backend(self.group) != "nccl"
         self.trace = None       # tests set this to a list: the sequence of collectives this rank issued
+        # backend nccl: the data-path collectives go through the engine's own C-ABI exchange layer
+        # (rec_alltoall_exchange / rec_allreduce_sum_f32 over an RCCL communicator created here) — what a Paddle-side
+        # binder gets; torch.distributed only carries the 128-byte communicator id and the small int64 metric sums.
+        self.native = None
+        if not self.staged and os.environ.get("REC_NATIVE_EXCHANGE", "1") != "0":
+            self._init_native()
         # ONE communicator: RCCL collectives of a communicator must execute in the same order on every rank, and
         # torch issues a blocking collective on the caller's current stream — so every collective of a training
         # step is issued on ONE stream (the side stream) or behind a stream wait on it (see train_step).
+
+    def _init_native(self):
+        import ctypes as C
+        from ._lib import check, lib
+        dev = torch.device("cuda", torch.cuda.current_device())
+        idbuf = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if self.rank == 0:
+            raw = (C.c_char * 128)()
+            check(lib().rec_comm_unique_id(C.cast(raw, C.c_void_p)), "rec_comm_unique_id")
+            idbuf.copy_(torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8))
+        self.dist.broadcast(idbuf, src=self.dist.get_global_rank(self.group, 0), group=self.group)
+        raw = bytes(idbuf.cpu().numpy().tobytes())
+        h = C.c_void_p()
+        check(lib().rec_comm_init(raw, self.world, self.rank, C.byref(h)), "rec_comm_init")
+        self.native = h
+
+    def _native_a2a(self, out, inp, out_splits, in_splits):
+        import ctypes as C
+        from ._lib import check, lib
+        G = self.world
+        row_bytes = inp.element_size() * (inp.shape[1] if inp.dim() > 1 else 1)
+        sc = (C.c_int64 * G)(*[int(x) for x in in_splits])
+        rc = (C.c_int64 * G)(*[int(x) for x in out_splits])
+        check(lib().rec_alltoall_exchange(self.native, C.c_void_p(inp.data_ptr() if inp.numel() else 0), sc,
+                                          C.c_void_p(out.data_ptr() if out.numel() else 0), rc, int(row_bytes),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "rec_alltoall_exchange")
+        return out
 
     def exchange_counts(self, send_counts):
         """send_counts[d] = entries this rank sends to d  ->  recv_counts[s] = entries s sends here."""
@@ -54,12 +88,18 @@ class Comm:
         """Device-side variant for backend nccl: no host sync here; returns the receive counts (device)."""
         self._log("all_to_all:counts")
         out = torch.empty_like(send_counts_dev)
+        if self.native is not None:
+            return self._native_a2a(out, send_counts_dev.contiguous(), [1] * self.world, [1] * self.world)
         self.dist.all_to_all_single(out, send_counts_dev.contiguous(), group=self.group)
         return out
 
     def all_to_all(self, out, inp, out_splits, in_splits):
         """Rows (dim 0) of `inp` split by in_splits go to the ranks; `out` receives out_splits rows."""
         self._log("all_to_all:%s x%d" % (str(inp.dtype).replace("torch.", ""), inp.shape[1] if inp.dim() > 1 else 1))
+        if self.native is not None and out.is_cuda:
+            if not (inp.is_contiguous() and out.is_contiguous()):
+                raise ops.RecError("exchange buffers must be contiguous")
+            return self._native_a2a(out, inp, out_splits, in_splits)
         if self.staged and out.is_cuda:
             h_in = inp.cpu()
             h_out = torch.empty(out.shape, dtype=out.dtype)
@@ -87,6 +127,13 @@ class Comm:
     def all_reduce_sum(self, t):
         self._log("all_reduce")
         g = self.group
+        if self.native is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+            import ctypes as C
+            from ._lib import check, lib
+            check(lib().rec_allreduce_sum_f32(self.native, C.c_void_p(t.data_ptr()), t.numel(),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                  "rec_allreduce_sum_f32")
+            return t
         if self.staged and t.is_cuda:
             h = t.cpu()
             self.dist.all_reduce(h, group=g)
@@ -108,11 +155,24 @@ class ShardedDeepFMLayer(DeepFMLayer):
 
     def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim,
                  sparse_num_field, layer_sizes, device="cuda", slot_offset=None, group=None,
-                 comm=None, kernels=None):
+                 comm=None, kernels=None, table="adam", accessor=None, hash_keys=False):
+        """table 'adam': the record layout + lazy Adam of the unsharded layer.  table 'ps': the gpubox feature value
+        (tools/static_gpubox_trainer.py:152-160; accessor = slot_dnn/config_online.yaml:57-89) — ONE 128-B record
+        line per row [W(16) | W1 | show | click | g2sum_w | g2sum_x | state], no second optimizer-state line, rows
+        born lazily from zeroed memory: 10^10 rows are 160 GB per GPU on 8 GPUs.  accessor: kwargs of ops.PsTable.
+        hash_keys: the ids are uint64 feasigns, hashed to rows [1, N) on the device (row = 1 + mix64(f) % (N-1))."""
         self.comm = comm if comm is not None else Comm(group)
         G = self.comm.world
         self.global_rows = int(sparse_feature_number)
         self.local_rows = (self.global_rows + G - 1) // G
+        self.hash_keys = bool(hash_keys)
+        self.ps = None
+        kk = kernels if kernels is not None else ops
+        if table == "ps":
+            self.ps = kk.PsTable(self.local_rows, sparse_feature_dim, torch.device(device), kind="deepfm",
+                                 row_mul=G, row_add=self.comm.rank, **(accessor or {}))
+        elif table != "adam":
+            raise ValueError("table must be 'adam' or 'ps'")
         # Every rank draws ITS shard from its own generator state (seed + a function of the rank): with the launcher
         # seeding all ranks alike, the shards would otherwise be bit-identical copies — global rows i*G .. i*G+G-1
         # all starting from the same values instead of an i.i.d. table.  (The dense parameters drawn here too are
@@ -125,7 +185,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
             super().__init__(sparse_feature_number, sparse_feature_dim, dense_feature_dim,
                              sparse_num_field, layer_sizes, device=device, slot_offset=slot_offset,
                              table_rows=self.local_rows, zero_padding_row=(self.comm.rank == 0),
-                             kernels=kernels, extra_dense=(("__loss__", (1,)),))
+                             kernels=kernels, extra_dense=(("__loss__", (1,)),),
+                             table_rec=self.ps.rec if self.ps is not None else None)
         # data-parallel replicas of the dense parameters (MLP, FM dense weights) must start identical: every rank
         # drew its own random initialisation, rank 0's wins (one flat buffer, one broadcast)
         if G > 1:
@@ -176,13 +237,17 @@ class ShardedDeepFMLayer(DeepFMLayer):
         B, S = ids.shape
         n, G = B * S, self.comm.world
         k = self.k
+        ids_key = ids                                # identity of the batch (the prefetch is matched by object)
         if not self._routes or self._routes[0].n != n:
             self._routes = [k.ShardRoute(n, G, self.device), k.ShardRoute(n, G, self.device)]
         self._route_flip ^= 1
         route = self._routes[self._route_flip]       # double-buffered: the previous one is still in use
+        if self.hash_keys:                           # uint64 feasigns -> rows of the hashed global table (device)
+            ids = k.feasign_rows(ids, self.global_rows, out=self._fit("hashed_ids%d" % self._route_flip, n, 0,
+                                                                      torch.int64).view(B, S))
         k.shard_route(ids, self.global_rows, self.fm.padding_idx, G, self.ws_route, self.fm.slot_offset,
                       self.status, route)
-        pend = dict(ids=ids, route=route, host=None, ev=None)
+        pend = dict(ids=ids_key, route=route, host=None, ev=None)
         if self.device.type == "cuda" and not self.comm.staged:
             recv_dev = self.comm.exchange_counts_device(route.send_counts[:G])
             host = self._pinned[self._route_flip]           # persistent pinned staging, one per route buffer
@@ -221,9 +286,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
         self.comm.all_to_all(L.recv_rows, route.send_local_row[: L.n_send], L.recv_splits, L.send_splits)
         g_rows = self._fit("g_rows", L.n_recv, D)
         g_w1 = self._fit("g_w1", L.n_recv, 1)
-        if L.n_recv:
-            k.emb_gather(L.recv_rows, self.fm.embedding, None, self.status, out=g_rows)
-            k.emb_gather(L.recv_rows, self.fm.embedding_one, None, self.status, out=g_w1)
+        if L.n_recv:       # both embeddings of a row from its one record line (unborn PS rows: creation values)
+            k.record_gather(L.recv_rows, self.fm.rec, D, g_rows, g_w1, self.status, table=self.ps)
         self._reply_flip ^= 1            # double-buffered: the next batch's lookup may be issued during this step
         rep = self._replies[self._reply_flip]
         if rep is None or rep[0].shape[0] != n + 1:
@@ -260,7 +324,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
         ids = self._concat_ids(sparse_inputs)
         B, S = ids.shape
         G, D = self.comm.world, self.sparse_feature_dim
-        self._ensure_sparse_state()
+        if self.ps is None:
+            self._ensure_sparse_state()
         self.step_count += 1
         t = self.step_count
         on_gpu = self.device.type == "cuda"
@@ -330,17 +395,26 @@ class ShardedDeepFMLayer(DeepFMLayer):
         with _Side():
             with self._timed("grad_exchange"):
                 f32 = dict(dtype=torch.float32, device=self.device)
+                C1 = 2 if self.ps is not None else 1     # PS: the label rides with dz (click counter of the accessor)
                 send_g = self._fit("send_g", L.n_send, D)
-                send_g1 = self._fit("send_g1", L.n_send, 1)
+                send_g1 = self._fit("send_g1", L.n_send, C1)
                 if L.n_send:
                     k.emb_gather(L.route.send_pos[: L.n_send], row_grad, None, self.status, out=send_g)
-                    k.emb_gather(L.route.send_sample[: L.n_send], dz, None, self.status, out=send_g1)
+                    k.emb_gather(L.route.send_sample[: L.n_send], dz, None, self.status, out=send_g1,
+                                 out_group=1, out_group_stride=C1)
+                    if C1 == 2:
+                        k.emb_gather(L.route.send_sample[: L.n_send], label.to(torch.float32), None, self.status,
+                                     out=send_g1[:, 1:], out_group=1, out_group_stride=C1)
                 recv_g = self._fit("recv_g", max(L.n_recv, 1), D)
-                recv_g1 = self._fit("recv_g1", max(L.n_recv, 1), 1)
+                recv_g1 = self._fit("recv_g1", max(L.n_recv, 1), C1)
                 self.comm.all_to_all(recv_g[: L.n_recv], send_g, L.recv_splits, L.send_splits)
                 self.comm.all_to_all(recv_g1[: L.n_recv], send_g1, L.recv_splits, L.send_splits)
             with self._timed("sparse_adam"):
-                if L.n_recv:
+                if L.n_recv and self.ps is not None:
+                    # the accessor's push: counters, AdaGrad rule per part, lazy birth / embedx creation
+                    click = recv_g1[: L.n_recv, 1].contiguous().to(torch.int64)
+                    k.ps_push_rows(self.ps, groups, recv_g, 1, grad1=recv_g1, grad1_pitch=2, click=click)
+                elif L.n_recv:
                     st = self.sparse_state
                     pp = self._pp = k.segment_partials(groups, recv_g, D, out=getattr(self, "_pp", None))
                     pp1 = self._pp1 = k.segment_partials(groups, recv_g1, 1, out=getattr(self, "_pp1", None))

@@ -406,8 +406,38 @@ def multislot_sumpool(mb, W, num_rows=None, padding_idx=0, key_mode=0, status=No
 from paddlerec_amd.ops import PsTable  # noqa: E402,F401  (ctypes structs + a torch buffer: no kernel involved)
 
 
+def _acc_dict(table):
+    A = table.accessor
+    return dict(lr=A.lr, initial_g2sum=A.initial_g2sum, bounds=(A.min_bound, A.max_bound),
+                initial_range=A.initial_range, embedx_threshold=A.embedx_threshold, nonclk_coeff=A.nonclk_coeff,
+                click_coeff=A.click_coeff, seed=A.seed, row_mul=A.row_mul, row_add=A.row_add)
+
+
+def _lay_dict(table):
+    L = table.layout
+    return dict(embed_off=L.embed_off, embedx_off=L.embedx_off, embedx_dim=L.embedx_dim, stat_off=L.stat_off)
+
+
+def record_gather(rows, rec, D, out_w, out_w1, status, table=None):
+    from oracle import ps_ref
+    r = _n(rows)
+    if table is not None and table.accessor.initial_range > 0:
+        W, W1 = ps_ref.pull_deepfm(rec.numpy(), _lay_dict(table), r, _acc_dict(table))
+    else:
+        W, W1 = rec.numpy()[r, :D], rec.numpy()[r, D]
+    out_w.copy_(torch.from_numpy(np.ascontiguousarray(W)).reshape(out_w.shape))
+    out_w1.copy_(torch.from_numpy(np.ascontiguousarray(W1)).reshape(out_w1.shape))
+    return out_w, out_w1
+
+
+def feasign_rows(keys, num_rows, out=None):
+    from oracle import slot_dnn_ref
+    r = torch.from_numpy(slot_dnn_ref.feasign_rows(_n(keys).astype(np.uint64), num_rows))
+    return r if out is None else out.copy_(r.reshape(out.shape))
+
+
 def ps_push_rows(table, groups, grad, num_slots, grad_pitch=None, grad_index=None, grad1=None, grad1_div=1,
-                 show=None, click=None):
+                 show=None, click=None, grad1_pitch=1):
     from oracle import ps_ref
     D, L, A = table.emb_dim, table.layout, table.accessor
     gi = _n(grad_index) if grad_index is not None else None
@@ -416,7 +446,8 @@ def ps_push_rows(table, groups, grad, num_slots, grad_pitch=None, grad_index=Non
         g_w, g_x = full[:, 0], full[:, 1:D]
     else:
         g_x = full[:, :D]
-        g_w = _merged_rows(groups, grad1.reshape(-1, 1), 1, grad_div=grad1_div)[:, 0]
+        g1 = grad1.reshape(-1, int(grad1_pitch))[:, :1].contiguous()
+        g_w = _merged_rows(groups, g1, 1, grad_div=grad1_div)[:, 0]
     U = len(groups.uniq)
     dshow, dclick = np.zeros(U), np.zeros(U)
     for u in range(U):
@@ -425,10 +456,7 @@ def ps_push_rows(table, groups, grad, num_slots, grad_pitch=None, grad_index=Non
             smp = (int(gi[pos]) if gi is not None else pos) // num_slots
             dshow[u] += float(show[smp]) if show is not None else 1.0
             dclick[u] += float(click[smp]) if click is not None else 0.0
-    lay = dict(embed_off=L.embed_off, embedx_off=L.embedx_off, embedx_dim=L.embedx_dim, stat_off=L.stat_off)
-    acc = dict(lr=A.lr, initial_g2sum=A.initial_g2sum, bounds=(A.min_bound, A.max_bound),
-               initial_range=A.initial_range, embedx_threshold=A.embedx_threshold, nonclk_coeff=A.nonclk_coeff,
-               click_coeff=A.click_coeff, seed=A.seed)
+    lay, acc = _lay_dict(table), _acc_dict(table)
     ps_ref.push_rows(table.rec.numpy(), lay, groups.uniq, g_w, g_x, dshow, dclick, acc)
 
 

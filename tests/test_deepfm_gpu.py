@@ -548,7 +548,7 @@ def test_full_size_properties(ops):
     # (3) grouping invariants: permutation of the non-padding positions, sorted rows, counts add up
     ws = ops.Workspace(DEV)
     groups, _ = ops.ids_group(ids, N, 0, ws, so)
-    U, nv = groups.n_uniq.tolist()
+    U, nv = groups.n_uniq.tolist()[:2]
     assert nv == int((ids != 0).sum())
     spos = groups.sorted_pos[:nv].long()
     assert torch.equal(torch.sort(spos).values, torch.nonzero((ids != 0).reshape(-1)).reshape(-1))

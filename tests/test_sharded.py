@@ -30,10 +30,10 @@ def _free_port():
     return str(p)
 
 
-def _run_world(world, mode, outdir, tables=False):
+def _run_world(world, mode, outdir, tables=False, worker=None):
     port = _free_port()
     env = dict(os.environ, OMP_NUM_THREADS="2")
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), port, mode, str(outdir)]
+    procs = [subprocess.Popen([sys.executable, worker or WORKER, str(r), str(world), port, mode, str(outdir)]
                               + (["tables"] if tables else []), env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
@@ -160,3 +160,73 @@ def test_shard_route_flags_out_of_range(engine_lib):
 def test_sharded_ranks_share_one_gpu(engine_lib, tmp_path, world, tables):
     """2 processes on cuda:0 (gloo transport, host-staged) running the real HIP kernels."""
     _check(world, _run_world(world, "gpu", tmp_path, tables), tables)
+
+
+# ------------------------------------------------------------------------------- PS / gpubox table (configs[4])
+def _expected_ps(world):
+    """ONE unsharded run on the concatenated batches: hashed rows, lazily born accessor table, AdaGrad push."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from _sharded_ps_worker import CFG as c, make_batches
+    from oracle import deepfm_ref as R
+    from oracle import ps_ref
+    from oracle import slot_dnn_ref
+    D, N = c["D"], c["N"]
+    pr = make_deepfm_problem(B=4, N=N, D=D, fc=c["fc"], seed=c["seed"])
+    p = {k: (v.copy() if not isinstance(v, list) else [x.copy() for x in v]) for k, v in pr["params"].items()}
+    acc = dict(c["accessor"])
+    lay = dict(embed_off=D, embedx_off=0, embedx_dim=D, stat_off=D + 1)
+    rec = np.zeros((N, 32), np.float32)
+    dstate, losses = {}, []
+    for step, (keys, dense, label) in enumerate(make_batches(world)):
+        rows = slot_dnn_ref.feasign_rows(keys.astype(np.uint64), N)
+        p["W"], w1 = ps_ref.pull_deepfm(rec, lay, np.arange(N), acc)
+        p["W1"] = w1.reshape(-1, 1)
+        o = R.deepfm_loss_and_grads(rows, dense, label, p)
+        losses.append(float(o["loss"]))
+        uniq, merged, counts = R.merge_rows(o["rows"], o["row_valid"], o["row_grad"])
+        _, merged1, _ = R.merge_rows(o["rows"], o["row_valid"], o["row_grad1"])
+        lab = np.repeat(label.reshape(-1), rows.shape[1])
+        flat = o["rows"].reshape(-1)
+        clicks = np.array([lab[(flat == u) & o["row_valid"].reshape(-1)].sum() for u in uniq], np.float64)
+        ps_ref.push_rows(rec, lay, uniq, merged1[:, 0], merged, counts, clicks, acc)
+        pairs = [("dense_w", o["d_dense_w"]), ("dense_w_one", o["d_dense_w_one"])]
+        for i in range(len(p["mlp_w"])):
+            pairs += [(("mlp_w", i), o["mlp_dw"][i]), (("mlp_b", i), o["mlp_db"][i])]
+        for key, gr in pairs:
+            arr = p[key] if not isinstance(key, tuple) else p[key[0]][key[1]]
+            mm, vv = dstate.setdefault(key, (np.zeros_like(arr), np.zeros_like(arr)))
+            R.adam_update(arr, mm, vv, gr.reshape(arr.shape).astype(arr.dtype), step + 1, lr=c["lr"])
+    return c, rec, losses, p
+
+
+def _check_ps(world, ranks):
+    c, rec, losses, p = _expected_ps(world)
+    D = c["D"]
+    for r, out in enumerate(ranks):
+        assert int(out["status"][0]) == 0
+        assert out["trace"].tolist() == ranks[0]["trace"].tolist()
+        for s, want in enumerate(losses):
+            np.testing.assert_allclose(out["loss%d" % s][0], want, rtol=2e-5)
+        mine = rec[r::world]                                    # owner(row) = row % world, local = row // world
+        got = out["rec"][: mine.shape[0]]
+        so = D + 1
+        assert np.array_equal(got[:, so:so + 2], mine[:, so:so + 2]), "show / click counters of rank %d" % r
+        assert np.array_equal(got[:, so + 4], mine[:, so + 4]), "feature states of rank %d" % r
+        np.testing.assert_allclose(got[:, :D + 1], mine[:, :D + 1], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(got[:, so + 2:so + 4], mine[:, so + 2:so + 4], rtol=1e-4, atol=1e-12)
+        np.testing.assert_allclose(out["mlp_w0"], p["mlp_w"][0], rtol=1e-3, atol=2e-5)
+    st = rec[:, D + 5]
+    assert (st == 0).any() and (st == 1).any() and (st == 2).any()       # unborn, embed-only and full features occur
+
+
+def test_sharded_ps_table_world2_cpu(tmp_path):
+    """configs[4] in miniature: uint64 feasigns hashed on the device, the AdaGrad accessor table row-sharded over 2
+    gloo ranks == one unsharded oracle run on the concatenated batch (rows born with the same values on either)."""
+    worker = os.path.join(REPO, "tests", "_sharded_ps_worker.py")
+    _check_ps(2, _run_world(2, "cpu", tmp_path, worker=worker))
+
+
+@pytest.mark.gpu
+def test_sharded_ps_table_two_ranks_one_gpu(tmp_path):
+    worker = os.path.join(REPO, "tests", "_sharded_ps_worker.py")
+    _check_ps(2, _run_world(2, "gpu", tmp_path, worker=worker))
