@@ -1,0 +1,170 @@
+"""paddle.* — see paddlerec_amd/compat/__init__.py.  Symbol list: SURVEY.md Appendix A.1; semantics: Appendix B [EXT]."""
+import pickle as _pickle
+
+import numpy as _np
+import torch as _t
+
+from . import _backend
+from . import nn, optimizer, metric, io, distributed, static, regularizer, framework, jit  # noqa: F401
+from .framework import ParamAttr  # noqa: F401
+
+Tensor = _t.Tensor
+_DT = {"float32": _t.float32, "float64": _t.float64, "int64": _t.int64, "int32": _t.int32, "bool": _t.bool}
+
+
+def _dtype(d):
+    if isinstance(d, _t.dtype):
+        return d
+    return _DT[str(d).replace("paddle.", "")]
+
+
+# Tensor method spellings that differ from torch (the reference calls them on batch fields and predictions)
+_t.Tensor.astype = lambda self, d: self.to(_dtype(d))
+_torch_numpy = _t.Tensor.numpy
+_t.Tensor.numpy = lambda self, *a, **k: _torch_numpy(self.detach().cpu(), *a, **k)
+
+
+def seed(s):
+    _t.manual_seed(int(s))
+
+
+def set_device(name):
+    return _backend.set_device(name)
+
+
+def get_device():
+    d = _backend.device()
+    return "gpu:%d" % (d.index or 0) if d.type == "cuda" else "cpu"
+
+
+def is_compiled_with_custom_device(name):
+    return False
+
+
+def is_compiled_with_cuda():
+    return _t.cuda.is_available()
+
+
+class CPUPlace:
+    pass
+
+
+class CUDAPlace:
+    def __init__(self, idx=0):
+        self.idx = idx
+
+
+def to_tensor(x, dtype=None, place=None, stop_gradient=True):
+    if isinstance(x, _t.Tensor):
+        t = x
+    else:
+        t = _t.as_tensor(_np.asarray(x))
+    t = t.to(_backend.device())
+    return t.to(_dtype(dtype)) if dtype is not None else t
+
+
+def cast(x, dtype):
+    return x.to(_dtype(dtype))
+
+
+def concat(x, axis=0):
+    return _t.cat(list(x), dim=int(axis))
+
+
+def stack(x, axis=0):
+    return _t.stack(list(x), dim=int(axis))
+
+
+def reshape(x, shape):
+    shape = [x.shape[i] if s == 0 else s for i, s in enumerate(shape)]  # 0 = copy input dim
+    return x.reshape(shape)
+
+
+def sum(x, axis=None, dtype=None, keepdim=False):  # noqa: A001
+    if axis is None:
+        return x.sum()
+    return x.sum(dim=axis, keepdim=keepdim)
+
+
+def mean(x, axis=None, keepdim=False):
+    return x.mean() if axis is None else x.mean(dim=axis, keepdim=keepdim)
+
+
+def square(x):
+    return x * x
+
+
+def multiply(x, y):
+    return x * y
+
+
+def add(x, y):
+    return x + y
+
+
+def unsqueeze(x, axis):
+    return x.unsqueeze(axis)
+
+
+def squeeze(x, axis=None):
+    return x.squeeze() if axis is None else x.squeeze(axis)
+
+
+def matmul(x, y, transpose_x=False, transpose_y=False):
+    if transpose_x:
+        x = x.transpose(-1, -2)
+    if transpose_y:
+        y = y.transpose(-1, -2)
+    return _t.matmul(x, y)
+
+
+def transpose(x, perm):
+    return x.permute(*perm)
+
+
+def scale(x, scale=1.0, bias=0.0):  # noqa: A001
+    return x * scale + bias
+
+
+def tanh(x):
+    return _t.tanh(x)
+
+
+def clip(x, min=None, max=None):  # noqa: A002
+    return _t.clamp(x, min=min, max=max)
+
+
+def zeros(shape, dtype="float32"):
+    return _t.zeros(list(shape), dtype=_dtype(dtype), device=_backend.device())
+
+
+def ones(shape, dtype="float32"):
+    return _t.ones(list(shape), dtype=_dtype(dtype), device=_backend.device())
+
+
+def create_parameter(shape, dtype="float32", default_initializer=None, attr=None, is_bias=False):
+    p = _t.nn.Parameter(_t.zeros(list(shape), dtype=_dtype(dtype), device=_backend.device()))
+    init = default_initializer or (attr.initializer if attr is not None else None)
+    if init is not None:
+        with _t.no_grad():
+            init(p)
+    return p
+
+
+def save(obj, path):
+    """paddle.save(state_dict, path): a pickled {name -> ndarray} dict (nested dicts of tensors are converted)."""
+    def conv(o):
+        if isinstance(o, _t.Tensor):
+            return o.detach().cpu().numpy()
+        if isinstance(o, dict):
+            return {k: conv(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [conv(v) for v in o]
+        return o
+    with open(path, "wb") as f:
+        _pickle.dump(conv(obj), f, protocol=4)
+
+
+def load(path):
+    with open(path, "rb") as f:
+        return _pickle.load(f)

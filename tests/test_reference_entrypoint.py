@@ -1,0 +1,94 @@
+"""The reference's OWN driver, unmodified (row N1): `tools/trainer.py -m models/rank/deepfm/config.yaml` executed through
+paddlerec_amd.run_reference over the product `paddle` compat namespace (paddlerec_amd/compat) — build container only
+(needs /root/reference).  Here: no GPU, so the operator backend is the oracle-backed stand-in (REC_COMPAT_KERNELS);
+the loss lines the reference prints and the checkpoint it writes must equal the oracle's trajectory from the same
+initial parameters (dygraph Adam, lazy_mode=False: every row decays each step)."""
+import os
+import pickle
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+REF = os.environ.get("PADDLEREC_REF", "/root/reference")
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "tools")), reason="reference tree not present")
+
+INIT_SCRIPT = r"""
+import os, sys, pickle
+sys.path.insert(0, os.path.join(%(repo)r, "paddlerec_amd", "compat"))
+sys.path.insert(0, %(repo)r)
+sys.path.insert(0, os.path.join(%(ref)r, "models", "rank", "deepfm"))
+import paddle
+paddle.seed(12345)
+paddle.set_device("cpu")
+import net
+m = net.DeepFMLayer(1000001, 9, 13, 26, [512, 256, 128, 32])
+pickle.dump({k: v.detach().numpy() for k, v in m.state_dict().items()}, open(sys.argv[1], "wb"))
+"""
+
+
+def _env():
+    env = dict(os.environ, REC_COMPAT_KERNELS="cpu_kernels", OMP_NUM_THREADS="4")
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(REPO, "tests"), REPO, env.get("PYTHONPATH", "")])
+    return env
+
+
+def test_reference_trainer_runs_unmodified_and_matches_oracle(tmp_path):
+    from oracle import deepfm_ref as R
+    out_dir = tmp_path / "ckpt"
+    cmd = [sys.executable, "-m", "paddlerec_amd.run_reference", os.path.join(REF, "tools", "trainer.py"),
+           "-m", os.path.join(REF, "models", "rank", "deepfm", "config.yaml"),
+           "-o", "runner.epochs=1", "runner.print_interval=5", "runner.model_save_path=%s" % out_dir]
+    r = subprocess.run(cmd, cwd=REF, env=_env(), capture_output=True, text=True, timeout=900)
+    log = r.stdout + r.stderr
+    assert r.returncode == 0, log[-3000:]
+    printed = [(int(m.group(1)), float(m.group(2))) for m in
+               re.finditer(r"batch_id: (\d+), auc:[0-9.]+, loss:\s*([0-9.eE+-]+),", log)]
+    assert len(printed) == 8 and printed[0][0] == 0 and printed[-1][0] == 35, log[-2000:]       # 40 batches of 2
+    ips = re.findall(r"ips: ([0-9.]+) ins/s", log)
+    assert ips, "the reference's own ips line is missing"
+    # the same initial parameters: the reference's net.py constructed over the compat namespace with the trainer's seed
+    init_file = tmp_path / "init.pkl"
+    r2 = subprocess.run([sys.executable, "-c", INIT_SCRIPT % dict(repo=REPO, ref=REF), str(init_file)], env=_env(),
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    sd = pickle.load(open(init_file, "rb"))
+    n_mlp = 5
+    p = {"W": sd["fm.embedding.weight"].copy(), "W1": sd["fm.embedding_one.weight"].copy(),
+         "dense_w": sd["fm.dense_w"].copy(), "dense_w_one": sd["fm.dense_w_one"].copy(),
+         "mlp_w": [sd["dnn.linear_%d.weight" % i].copy() for i in range(n_mlp)],
+         "mlp_b": [sd["dnn.linear_%d.bias" % i].copy() for i in range(n_mlp)]}
+    lines = open(os.path.join(REF, "models/rank/deepfm/data/sample_data/train/sample_train.txt")).read().strip().split("\n")
+    parsed = [R.parse_slot_line(ln) for ln in lines]
+    lab = np.asarray([a for a, _, _ in parsed], np.int64).reshape(-1, 1)
+    ids = np.stack([b for _, b, _ in parsed])
+    dense = np.stack([c for _, _, c in parsed])
+    st = {k: np.zeros_like(p[t]) for k, t in (("mW", "W"), ("vW", "W"), ("mW1", "W1"), ("vW1", "W1"))}
+    dstate, want = {}, {}
+    for step in range(40):
+        lo = step * 2
+        o = R.deepfm_loss_and_grads(ids[lo:lo + 2], dense[lo:lo + 2], lab[lo:lo + 2], p)
+        want[step] = float(o["loss"])
+        t = step + 1
+        uniq, merged, _ = R.merge_rows(o["rows"], o["row_valid"], o["row_grad"])
+        R.adam_update_dense_equivalent(p["W"], st["mW"], st["vW"], uniq, merged, t, lr=0.001)
+        uniq1, merged1, _ = R.merge_rows(o["rows"], o["row_valid"], o["row_grad1"])
+        R.adam_update_dense_equivalent(p["W1"], st["mW1"], st["vW1"], uniq1, merged1, t, lr=0.001)
+        pairs = [("dense_w", o["d_dense_w"]), ("dense_w_one", o["d_dense_w_one"])]
+        for i in range(n_mlp):
+            pairs += [(("mlp_w", i), o["mlp_dw"][i]), (("mlp_b", i), o["mlp_db"][i])]
+        for key, gr in pairs:
+            arr = p[key] if not isinstance(key, tuple) else p[key[0]][key[1]]
+            mm, vv = dstate.setdefault(key, (np.zeros_like(arr), np.zeros_like(arr)))
+            R.adam_update(arr, mm, vv, gr.reshape(arr.shape).astype(arr.dtype), t, lr=0.001)
+    for batch_id, loss in printed:
+        np.testing.assert_allclose(loss, want[batch_id], rtol=2e-4, atol=1e-6)       # the log prints 6-8 digits
+    saved = pickle.load(open(out_dir / "0" / "rec.pdparams", "rb"))
+    np.testing.assert_allclose(saved["dnn.linear_4.weight"], p["mlp_w"][4], rtol=1e-3, atol=1e-5)
+    touched = np.unique(ids)
+    np.testing.assert_allclose(saved["fm.embedding.weight"][touched], p["W"][touched], rtol=1e-3, atol=2e-5)
+    assert os.path.exists(out_dir / "0" / "rec.pdopt")
