@@ -169,6 +169,9 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the row-sharded path (RCCL all-to-all) even with one rank")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--shared-table", action="store_true",
+                    help="layout (2b) of SURVEY §8(d), the reference's own: ONE table of rows-per-table (+1) rows shared "
+                         "by the 26 slots (deepfm/config.yaml:48-50 with --dim 9, benchmark.yaml:21 with --dim 10)")
     ap.add_argument("--table", choices=("adam", "ps"), default="adam",
                     help="ps = BASELINE configs[4]: the hashed gpubox table (uint64 feasigns -> mix64 %% N rows on the "
                          "device, AdaGrad accessor record, rows born lazily), row-sharded; implies the sharded path")
@@ -197,6 +200,8 @@ def main():
     # weak scaling: every GPU holds 26 x rows_per_table rows; the global table grows with the world
     N = args.rows_per_table * S * world
     so = torch.arange(S, dtype=torch.int64, device=dev) * (args.rows_per_table * world)
+    if args.shared_table:
+        N, so = args.rows_per_table * world, None
     torch.manual_seed(20250404)                  # same random-init dense weights on every run (and rank)
     if dist is None:
         from paddlerec_amd.deepfm import DeepFMLayer
@@ -291,6 +296,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "DeepFM full Criteo: 26 sparse slots x %d rows x dim %d, 13 dense, "
                                "MLP %s, batch %d per GPU, lazy Adam, %s ids" % (args.rows_per_table, D, args.fc, B, args.ids)
+                   + (" [ONE shared table: the reference's layout]" if args.shared_table else "")
                    if args.table != "ps" else
                    "DeepFM on the hashed gpubox table (configs[4]): %d rows per GPU x %d GPUs x dim %d (one 128-B "
                    "accessor record per row, born lazily), 26 slots of uint64 feasigns hashed on the device, 13 dense, "

@@ -14,6 +14,9 @@
 //   logits  s = (s + mask) * E^-0.5  kept in LDS for the whole history (softmax weights for the backward)
 // Padded positions (mask = -1e9) get weight exp(-8.8e7 - m) = 0 exactly in fp32, as in the reference
 // (SURVEY App. B-11); they are computed, not skipped, so an all-padding history still reproduces it.
+#include <stdlib.h>
+#include <string.h>
+
 #include "rec_common.h"
 
 namespace rec {
@@ -21,6 +24,7 @@ namespace rec {
 constexpr int kDinTP = 32;       // positions per tile
 constexpr int kDinNP1 = 16;      // max positions per thread in layer 1 (PG >= 2)
 constexpr int kDinNP2 = 16;
+constexpr size_t kDinCtLdsMax = 160 * 1024;   // LDS of a gfx950 CU; two blocks are resident below half of it
 
 struct DinArgs {
   int64_t B;
@@ -117,6 +121,41 @@ __device__ __forceinline__ void din_layer1_mfma(const float* __restrict__ hs, co
   for (int i = threadIdx.x; i < kDinTP * H1; i += kBlock) a1[i] = sigmoidf_(a1[i]);
 }
 
+// Attention layer 2 on the matrix cores: a2[32, H2] = sigmoid(a1[32, H1] @ W2[H1, H2] + b2) — 2 row tiles x
+// ceil(H2/16) column tiles of 16x16, dealt round-robin to the block's 4 waves (whole K per tile: no partial sums to
+// combine); A fragments by ds_read_b128 from a1, B fragments from the LDS copy of W2.  On the VALU this layer cost
+// 5 k instructions per wave and tile (runtime-shaped loops over the position groups) against 320 MFMAs of layer 1.
+// Needs H1 % 16 == 0; columns >= H2 of the last tile are computed on zeros and dropped.
+__device__ __forceinline__ void din_layer2_mfma(const float* __restrict__ a1, const float* __restrict__ w2s,
+                                                const float* __restrict__ b2s, float* __restrict__ a2, int H1,
+                                                int H2) {
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+  const int li = lane & 15, g = lane >> 4;
+  const int nt = (H2 + 15) / 16;
+  const int nkb = H1 / 16;
+  for (int t = wave; t < 2 * nt; t += kBlock / kWave) {
+    const int m = t & 1, n = t >> 1;
+    const int col = n * 16 + li;
+    const bool cok = col < H2;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < nkb; ++kb) {
+      const int k0 = kb * 16 + 4 * g;
+      const float4 av = *reinterpret_cast<const float4*>(a1 + (m * 16 + li) * H1 + k0);
+      const float a4[4] = {av.x, av.y, av.z, av.w};
+      float b4[4];
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) b4[s_] = cok ? w2s[(k0 + s_) * H2 + col] : 0.f;
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s_], b4[s_], acc, 0, 0, 0);
+    }
+    if (cok) {
+      const float bias = b2s[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a2[(m * 16 + g * 4 + r) * H2 + col] = sigmoidf_(acc[r] + bias);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void din_attention_fwd_kernel(DinArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int E = a.Ei + a.Ec, H1 = a.H1, H2 = a.H2, T = a.T;
@@ -145,6 +184,7 @@ __global__ __launch_bounds__(kBlock) void din_attention_fwd_kernel(DinArgs a) {
   const bool on2 = pg2 < PG2;
   const int e4 = E / 4;
   const bool use_mfma = (E % 16 == 0) && (H1 % 16 == 0) && H1 <= 16 * kDinNT1;   // block-uniform
+  const bool use_mfma2 = H1 % 16 == 0;
   int oob = 0;
   __syncthreads();
 
@@ -200,7 +240,9 @@ __global__ __launch_bounds__(kBlock) void din_attention_fwd_kernel(DinArgs a) {
       }
       __syncthreads();
       // ---- layer 2
-      if (on2) {
+      if (use_mfma2) {
+        din_layer2_mfma(a1, w2s, b2s, a2, H1, H2);
+      } else if (on2) {
         float s2[kDinNP2];
 #pragma unroll
         for (int i = 0; i < kDinNP2; ++i) s2[i] = 0.f;
@@ -264,6 +306,327 @@ __global__ __launch_bounds__(kBlock) void din_attention_fwd_kernel(DinArgs a) {
   if (oob) atomicOr(a.status, REC_FLAG_INDEX_OOB);
 }
 
+// ------------------------------------------------------------------------- forward, compile-time shapes
+// The same attention-pool for shapes known at compile time (the reference net: E = 128, attention MLP 80-40-1,
+// din/net.py:60-75).  What changes against the runtime-shaped kernel above, all of it to keep the matrix cores fed:
+//   * the wave's K-segment of W1 ([E, H1] of the [4E, H1] matrix) lives in registers for the life of the block
+//     (E/16 x H1/16 x 4 = 160 VGPRs at 128/80): no W1 traffic and no address arithmetic inside the tile loop;
+//   * <= 256 VGPRs and < 80 KB LDS, so TWO blocks are resident per CU and one block's gathers / barriers overlap
+//     the other's MFMAs (the runtime-shaped kernel sits at one wave per SIMD and waits 63 % of its cycles);
+//   * the ids and mask of tile k+1 are fetched during tile k's layer 1, so the row gather at the end of tile k is one
+//     HBM round trip, not a dependent id -> row chain (fetching the rows themselves a phase earlier, template
+//     parameter PF, costs 40 more spilled registers than it hides latency: measured slower);
+//   * the four K-segment partial sums are combined as a two-level tree (2 barriers instead of 4), layer 3 is folded
+//     into layer 2's epilogue (a 16-lane reduction of sigmoid(z2) * w3), and the softmax bookkeeping is done once by
+//     wave 0 instead of by every thread.
+// Summation order differs from the kernel above only inside layer 3 and the final pool (both within fp32 rounding
+// of the same values); every order is fixed, so results are reproducible run to run.
+template <int E, int H1, int H2>
+struct DinCt {
+  static_assert(E % 32 == 0 && kBlock % E == 0 && H1 % 16 == 0 && H1 % 4 == 0, "unsupported compile-time shape");
+  static constexpr int EP = E + 4;                       // row stride of hs / qs   (== 4 mod 8: conflict-free b128)
+  static constexpr int H1P = H1 + 4;                     // row stride of X / Y
+  static constexpr int H2C = ((H2 + 15) / 16) * 16;      // layer-2 columns padded to whole MFMA tiles (zeros)
+  static constexpr int W2P = H2C + 4;                    // row stride of the LDS copy of W2
+  static constexpr int NKB = E / 16, NT1 = H1 / 16, NT2 = H2C / 16;
+  static constexpr int E4 = E / 4, NIT = kDinTP * E4 / kBlock, PSTEP = kBlock / E4;
+  static constexpr int NPART = kBlock / E, PPART = kDinTP / NPART;
+  static constexpr int kHs = 0;
+  static constexpr int kQs = kHs + kDinTP * EP;
+  static constexpr int kX = kQs + kDinTP * EP;
+  static constexpr int kY = kX + kDinTP * H1P;
+  static constexpr int kW2 = kY + kDinTP * H1P;
+  static constexpr int kW3 = kW2 + H1 * W2P;
+  static constexpr int kB1 = kW3 + H2C;
+  static constexpr int kB2 = kB1 + H1;
+  static constexpr int kLp = kB2 + H2C;                  // [NT2][32] layer-3 partial dots
+  static constexpr int kEs = kLp + NT2 * kDinTP;         // [32] exp weights of the tile, [32] f, [33] l_run, [34] m_run
+  static constexpr int kRed = kEs + 40;                  // [NPART][E] end-of-sample combine
+  static constexpr int kIds = (kRed + NPART * E + 1) & ~1;   // int64 [2][5][32]: ids + mask of this / the next tile
+  static constexpr int kSall = kIds + 2 * 2 * 5 * kDinTP;
+  static size_t lds_bytes(int T) { return sizeof(float) * ((size_t)kSall + (size_t)T); }
+};
+
+template <int SEG, int E, int H1>
+__device__ __forceinline__ void din_l1_segment(const float* __restrict__ hs, const float* __restrict__ qs,
+                                               const float (&bf)[E / 16][H1 / 16][4],
+                                               f32x4_t (&acc)[2][H1 / 16], int li, int g) {
+  constexpr int EP = E + 4, NKB = E / 16;
+  // A fragments: lane (li, g) holds row a*16 + li, k = kb*16 + 4g .. +3 of the segment's operand
+  auto load_a = [&](int kb, float (&av)[2][4]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int off = (a * 16 + li) * EP + kb * 16 + 4 * g;
+      float4 hv, qv;
+      if (SEG != 1) hv = *reinterpret_cast<const float4*>(hs + off);
+      if (SEG != 0) qv = *reinterpret_cast<const float4*>(qs + off);
+      if (SEG == 0) { av[a][0] = hv.x; av[a][1] = hv.y; av[a][2] = hv.z; av[a][3] = hv.w; }
+      if (SEG == 1) { av[a][0] = qv.x; av[a][1] = qv.y; av[a][2] = qv.z; av[a][3] = qv.w; }
+      if (SEG == 2) { av[a][0] = hv.x - qv.x; av[a][1] = hv.y - qv.y; av[a][2] = hv.z - qv.z; av[a][3] = hv.w - qv.w; }
+      if (SEG == 3) { av[a][0] = hv.x * qv.x; av[a][1] = hv.y * qv.y; av[a][2] = hv.z * qv.z; av[a][3] = hv.w * qv.w; }
+    }
+  };
+  // one K block ahead in registers; the scheduling fences keep the compiler from hoisting all E/16 blocks' LDS
+  // reads to the top (64 more live registers - the W1 fragments would spill)
+  float av[2][2][4];
+  load_a(0, av[0]);
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    if (kb + 1 < NKB) load_a(kb + 1, av[(kb + 1) & 1]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < H1 / 16; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb & 1][a][s], bf[kb][b][s], acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int E, int H1, int H2, bool PF, int OCC>
+__global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinArgs a) {
+  using S = DinCt<E, H1, H2>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* hs = smem + S::kHs;
+  float* qs = smem + S::kQs;
+  float* X = smem + S::kX;
+  float* Y = smem + S::kY;
+  float* w2s = smem + S::kW2;
+  float* w3s = smem + S::kW3;
+  float* b1s = smem + S::kB1;
+  float* b2s = smem + S::kB2;
+  float* lp = smem + S::kLp;
+  float* es = smem + S::kEs;
+  float* red = smem + S::kRed;
+  int64_t* idbuf = reinterpret_cast<int64_t*>(smem + S::kIds);
+  float* sall = smem + S::kSall;
+  const int tid = threadIdx.x, lane = tid % kWave;
+  const int seg = __builtin_amdgcn_readfirstlane(tid / kWave);   // wave index == K segment of the concat
+  const int li = lane & 15, g = lane >> 4;
+  const int T = a.T;
+  for (int i = tid; i < H1 * S::W2P; i += kBlock) {
+    const int k = i / S::W2P, c = i % S::W2P;
+    w2s[i] = c < H2 ? a.w2[k * H2 + c] : 0.f;
+  }
+  for (int i = tid; i < S::H2C; i += kBlock) {
+    w3s[i] = i < H2 ? a.w3[i] : 0.f;
+    b2s[i] = i < H2 ? a.b2[i] : 0.f;
+  }
+  for (int i = tid; i < H1; i += kBlock) b1s[i] = a.b1[i];
+  const float b3 = a.b3[0];
+  const float scale = 1.f / sqrtf((float)E);          // net.py:168  firInDim ** -0.5
+  // this wave's segment of W1 as MFMA B fragments: bf[kb][b][s] = W1[seg*E + kb*16 + 4g + s][b*16 + li]
+  float bf[S::NKB][S::NT1][4];
+#pragma unroll
+  for (int kb = 0; kb < S::NKB; ++kb)
+#pragma unroll
+    for (int b = 0; b < S::NT1; ++b)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        bf[kb][b][s] = a.w1[(int64_t)(seg * E + kb * 16 + 4 * g + s) * H1 + b * 16 + li];
+
+  // gather geometry: a thread always fetches the same 4 columns, of rows p0, p0 + PSTEP, ...
+  const int c4 = (tid % S::E4) * 4, p0 = tid / S::E4;
+  const bool item = c4 < a.Ei;
+  const float* wh = item ? a.w_hist_item : a.w_hist_cat;
+  const float* wq = item ? a.w_tgt_item : a.w_tgt_cat;
+  const int64_t nrow = item ? a.n_item : a.n_cat;
+  const int ld = item ? a.ld_item : a.ld_cat;
+  const int col = item ? c4 : c4 - a.Ei;
+  const int ih = item ? 0 : 1, iq = item ? 2 : 3;
+  // id prefetch geometry: threads 0..159 = 5 arrays x 32 positions
+  const int id_arr = tid >> 5, id_p = tid & 31;
+  const int64_t* id_ptr = id_arr == 0 ? a.hist_item : id_arr == 1 ? a.hist_cat : id_arr == 2 ? a.tgt_item
+                          : id_arr == 3 ? a.tgt_cat : a.mask;
+  int oob = 0;
+
+  auto ids_issue = [&](int64_t b, int t0) -> int64_t {
+    const int t = t0 + id_p;
+    return (id_arr < 5 && t < T) ? id_ptr[b * T + t] : (int64_t)0;
+  };
+  auto ids_store = [&](int buf, int64_t v) {
+    if (id_arr < 5) idbuf[(buf * 5 + id_arr) * kDinTP + id_p] = v;
+  };
+  auto rows_issue = [&](int buf, int t0, float4 (&ph)[S::NIT], float4 (&pq)[S::NIT]) {
+#pragma unroll
+    for (int it = 0; it < S::NIT; ++it) {
+      const int p = p0 + it * S::PSTEP;
+      ph[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pq[it] = ph[it];
+      if (t0 + p < T) {
+        const int64_t hid = idbuf[(buf * 5 + ih) * kDinTP + p], qid = idbuf[(buf * 5 + iq) * kDinTP + p];
+        if (hid >= 0 && hid < nrow) ph[it] = *reinterpret_cast<const float4*>(wh + hid * ld + col); else oob = 1;
+        if (qid >= 0 && qid < nrow) pq[it] = *reinterpret_cast<const float4*>(wq + qid * ld + col); else oob = 1;
+      }
+    }
+  };
+  auto rows_store = [&](const float4 (&ph)[S::NIT], const float4 (&pq)[S::NIT]) {
+#pragma unroll
+    for (int it = 0; it < S::NIT; ++it) {
+      const int p = p0 + it * S::PSTEP;
+      *reinterpret_cast<float4*>(hs + p * S::EP + c4) = ph[it];
+      *reinterpret_cast<float4*>(qs + p * S::EP + c4) = pq[it];
+    }
+  };
+
+  int64_t b = blockIdx.x;
+  if (b >= a.B) return;
+  int t0 = 0, buf = 0;
+  float4 ph[S::NIT], pq[S::NIT];
+  ids_store(0, ids_issue(b, 0));
+  __syncthreads();
+  rows_issue(0, 0, ph, pq);
+  rows_store(ph, pq);
+  __syncthreads();
+  float m_run = -INFINITY, l_run = 0.f;     // live in wave 0
+  float pool = 0.f;                         // thread (part, d): partial of out[b][d] over its positions
+  const int pd = tid % E, part = tid / E;
+
+  while (true) {
+    int64_t nb = b;
+    int nt0 = t0 + kDinTP;
+    const bool last_tile = nt0 >= T;
+    if (last_tile) { nb = b + gridDim.x; nt0 = 0; }
+    const bool has_next = nb < a.B;
+    int64_t idv = 0;
+    if (has_next) idv = ids_issue(nb, nt0);
+
+    // ---- layer 1: this wave's K segment of [h, q, h-q, h*q] @ W1 (net.py:155-164)
+    f32x4_t acc[2][S::NT1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < S::NT1; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (seg == 0) din_l1_segment<0, E, H1>(hs, qs, bf, acc, li, g);
+    else if (seg == 1) din_l1_segment<1, E, H1>(hs, qs, bf, acc, li, g);
+    else if (seg == 2) din_l1_segment<2, E, H1>(hs, qs, bf, acc, li, g);
+    else din_l1_segment<3, E, H1>(hs, qs, bf, acc, li, g);
+    if (has_next) ids_store(buf ^ 1, idv);
+    // partial sums, two-level tree in a fixed order: X = (b1 + P0) + P2, Y = P1 + P3, z1 = X + Y.
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+    {
+      float* dst = (seg & 1) ? Y : X;
+      if (seg < 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < S::NT1; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int p = i * 16 + g * 4 + r, c = j * 16 + li;
+              dst[p * S::H1P + c] = (seg == 0 ? b1s[c] : 0.f) + acc[i][j][r];
+            }
+      }
+      __syncthreads();
+      if (seg >= 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < S::NT1; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int p = i * 16 + g * 4 + r, c = j * 16 + li;
+              dst[p * S::H1P + c] += acc[i][j][r];
+            }
+      }
+      __syncthreads();
+    }
+    // embedding rows of the next tile: in flight during layers 2/3 and the softmax of this one
+    if (PF && has_next) rows_issue(buf ^ 1, nt0, ph, pq);
+    for (int v = tid; v < kDinTP * (H1 / 4); v += kBlock) {
+      const int p = v / (H1 / 4), c = (v % (H1 / 4)) * 4;
+      const float4 x = *reinterpret_cast<const float4*>(X + p * S::H1P + c);
+      const float4 y = *reinterpret_cast<const float4*>(Y + p * S::H1P + c);
+      float4 z;
+      z.x = sigmoidf_(x.x + y.x); z.y = sigmoidf_(x.y + y.y); z.z = sigmoidf_(x.z + y.z); z.w = sigmoidf_(x.w + y.w);
+      *reinterpret_cast<float4*>(X + p * S::H1P + c) = z;
+    }
+    __syncthreads();
+    // ---- layer 2 on the matrix cores, layer 3 folded into its epilogue: lp[n][p] = sum_{c in tile n} a2[p][c] w3[c]
+    for (int t = seg; t < 2 * S::NT2; t += kBlock / kWave) {
+      const int m = t & 1, n = t >> 1;
+      const int c = n * 16 + li;
+      f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < S::NT1; ++kb) {
+        const int k0 = kb * 16 + 4 * g;
+        const float4 av = *reinterpret_cast<const float4*>(X + (m * 16 + li) * S::H1P + k0);
+        const float a4[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          z = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], w2s[(k0 + s) * S::W2P + c], z, 0, 0, 0);
+      }
+      const float bias = b2s[c], w3c = w3s[c];      // columns >= H2 carry w3 = 0
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = sigmoidf_(z[r] + bias) * w3c;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+        if (li == 0) lp[n * kDinTP + m * 16 + g * 4 + r] = v;
+      }
+    }
+    __syncthreads();
+    // ---- logits + online softmax bookkeeping, wave 0 (net.py:166-170)
+    if (seg == 0) {
+      const int p = lane & 31, t = t0 + p;
+      float s = -INFINITY;
+      if (t < T) {
+        s = b3;
+#pragma unroll
+        for (int n = 0; n < S::NT2; ++n) s += lp[n * kDinTP + p];
+        s = (s + (float)idbuf[(buf * 5 + 4) * kDinTP + p]) * scale;
+        if (lane < 32) sall[t] = s;
+      }
+      float mt = s;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) mt = fmaxf(mt, __shfl_xor(mt, o, kWave));
+      const float m_new = fmaxf(m_run, mt);
+      const float f = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+      const float e = (s == -INFINITY) ? 0.f : expf(s - m_new);
+      float lsum = e;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, kWave);
+      l_run = l_run * f + lsum;
+      m_run = m_new;
+      if (lane < 32) es[p] = e;
+      if (lane == 0) { es[32] = f; es[33] = l_run; es[34] = m_run; }
+      if (last_tile) { m_run = -INFINITY; l_run = 0.f; }
+    }
+    __syncthreads();
+    // ---- weighted sum of h (net.py:171): thread (part, d) covers PPART positions of column d
+    {
+      const float f = es[32];
+      float asum = 0.f;
+#pragma unroll
+      for (int i = 0; i < S::PPART; ++i) {
+        const int p = part * S::PPART + i;
+        asum += es[p] * hs[p * S::EP + pd];
+      }
+      pool = pool * f + asum;
+      if (last_tile) { red[part * E + pd] = pool; pool = 0.f; }
+    }
+    __syncthreads();
+    if (last_tile) {
+      const float l_fin = es[33], m_fin = es[34];
+      if (tid < E) {
+        float o = 0.f;
+#pragma unroll
+        for (int q = 0; q < S::NPART; ++q) o += red[q * E + tid];
+        a.out[b * E + tid] = o / l_fin;
+      }
+      if (a.att_weight)
+        for (int t = tid; t < T; t += kBlock) a.att_weight[b * T + t] = expf(sall[t] - m_fin) / l_fin;
+    }
+    if (!has_next) break;
+    if (!PF) rows_issue(buf ^ 1, nt0, ph, pq);
+    rows_store(ph, pq);
+    __syncthreads();
+    b = nb; t0 = nt0; buf ^= 1;
+  }
+  if (oob) atomicOr(a.status, REC_FLAG_INDEX_OOB);
+}
+
 // ------------------------------------------------------------------------------------------ backward
 // Gradient of the attention-pool w.r.t. the gathered rows: dh [B,T,E] (history item|cat), dq [B,T,E]
 // (target seq item|cat) — the per-position values whose row-wise merge is the embedding gradient.
@@ -314,6 +677,7 @@ __global__ __launch_bounds__(kBlock) void din_attention_bwd_kernel(DinBwdArgs g)
   const int NPX = (kDinTP + PGX - 1) / PGX;
   const bool onx = pgx < PGX;
   const bool use_mfma = (E % 16 == 0) && (H1 % 16 == 0) && H1 <= 16 * kDinNT1;
+  const bool use_mfma2 = H1 % 16 == 0;
   __syncthreads();
 
   auto gather_tile = [&](int64_t b, int t0, bool with_q) {
@@ -397,7 +761,9 @@ __global__ __launch_bounds__(kBlock) void din_attention_bwd_kernel(DinBwdArgs g)
         }
       }
       __syncthreads();
-      if (on2) {   // recompute layer 2
+      if (use_mfma2) {   // recompute layer 2
+        din_layer2_mfma(a1, w2s, b2s, a2, H1, H2);
+      } else if (on2) {
         float s2[kDinNP2];
 #pragma unroll
         for (int i = 0; i < kDinNP2; ++i) s2[i] = 0.f;
@@ -518,9 +884,14 @@ extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* 
                   w_tgt_item_seq && w_tgt_cat_seq && att_w1 && att_b1 && att_w2 && att_b2 && att_w3 &&
                   att_b3 && out && status, REC_EINVAL, "null pointer argument");
   const int H1 = d->hidden1, H2 = d->hidden2;
-  const size_t shmem = sizeof(float) * ((size_t)2 * kDinTP * (E + 4) + (size_t)kDinTP * (H1 + H2) +
-                                        (size_t)H1 * H2 + 2 * H2 + H1 + (size_t)d->max_len);
-  REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "history too long for the LDS logit buffer (%zu B)", shmem);
+  size_t shmem = sizeof(float) * ((size_t)2 * kDinTP * (E + 4) + (size_t)kDinTP * (H1 + H2) +
+                                  (size_t)H1 * H2 + 2 * H2 + H1 + (size_t)d->max_len);
+  // the reference net's own shape (E 128, attention MLP 80-40-1) runs the compile-time-shaped kernel
+  using Ct = DinCt<128, 80, 40>;
+  static const bool force_generic = getenv("REC_DIN_FWD_GENERIC") != nullptr;
+  const bool ct = !force_generic && E == 128 && H1 == 80 && H2 == 40 && Ct::lds_bytes(d->max_len) <= kDinCtLdsMax;
+  if (ct) shmem = Ct::lds_bytes(d->max_len);
+  else REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "history too long for the LDS logit buffer (%zu B)", shmem);
   DinArgs a;
   a.B = d->batch; a.T = d->max_len; a.Ei = d->item_dim; a.Ec = d->cat_dim; a.H1 = H1; a.H2 = H2;
   a.n_item = d->item_rows; a.n_cat = d->cat_rows; a.ld_item = d->item_stride; a.ld_cat = d->cat_stride;
@@ -528,6 +899,29 @@ extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* 
   a.mask = mask; a.w_hist_item = w_hist_item; a.w_hist_cat = w_hist_cat; a.w_tgt_item = w_tgt_item_seq;
   a.w_tgt_cat = w_tgt_cat_seq; a.w1 = att_w1; a.b1 = att_b1; a.w2 = att_w2; a.b2 = att_b2; a.w3 = att_w3;
   a.b3 = att_b3; a.out = out; a.att_weight = att_weight; a.status = status;
+  if (ct) {
+    // REC_DIN_FWD_VARIANT: measurement knob.  Measured at B 4096, T 512 (profiles/r02_din_variants.txt):
+    //   nopf2 (default; rows fetched at the end of the tile, 2 blocks/CU, 36 spilled VGPRs)  2.74 ms  68.0 TF
+    //   pf2   (rows prefetched into registers during layers 2/3, 76 spilled VGPRs)            3.25 ms  57.3 TF
+    //   pf1   (prefetch, 345 VGPRs, 1 block/CU, no spills)                                    3.36 ms  55.4 TF
+    // the runtime-shaped kernel: 6.81 ms, 27.3 TF.
+    static const int variant = [] {
+      const char* v = getenv("REC_DIN_FWD_VARIANT");
+      return !v ? 1 : !strcmp(v, "pf2") ? 0 : !strcmp(v, "pf1") ? 2 : 1;
+    }();
+    void (*kern)(DinArgs) = variant == 1   ? din_attention_fwd_ct_kernel<128, 80, 40, false, 2>
+                            : variant == 2 ? din_attention_fwd_ct_kernel<128, 80, 40, true, 1>
+                                           : din_attention_fwd_ct_kernel<128, 80, 40, true, 2>;
+    static bool attr_set[3] = {false, false, false};
+    if (!attr_set[variant]) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDinCtLdsMax);
+      attr_set[variant] = true;
+    }
+    int64_t grid = resident_blocks(kern, kBlock, shmem);
+    if (grid > d->batch) grid = d->batch;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), shmem, (hipStream_t)stream, a);
+    return check_launch("rec_din_attention_pool_fwd");
+  }
   int64_t grid = resident_blocks(din_attention_fwd_kernel, kBlock, shmem);
   if (grid > d->batch) grid = d->batch;
   hipLaunchKernelGGL(din_attention_fwd_kernel, dim3((unsigned)grid), dim3(kBlock), shmem,

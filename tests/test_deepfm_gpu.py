@@ -18,6 +18,13 @@ ATOL = 2e-7
 DEV = "cuda"
 
 
+def assert_close_scaled(got, want, rel=1e-5):
+    """1e-5 relative, with the absolute floor tied to the TENSOR's scale (1e-5 x max|want|): elements that are sums
+    of opposite-sign terms carry the fp32 summation noise of the terms, not of the (cancelled) result."""
+    want = np.asarray(want)
+    np.testing.assert_allclose(got, want, rtol=rel, atol=rel * float(np.abs(want).max()))
+
+
 @pytest.fixture(scope="module")
 def ops(engine_lib):
     from paddlerec_amd import ops as o
@@ -462,10 +469,9 @@ def test_deepfm_layer_forward_and_grads_golden(ops, name):
     loss, _ = m.train_step(sparse_inputs, T(g["dense"]), T(g["label"]), lr=1e-3)
     np.testing.assert_allclose(N_(loss)[0], g["loss"], rtol=RTOL)
     for i in range(int(g["n_mlp"])):
-        np.testing.assert_allclose(N_(m.dense.g["dnn.linear_%d.weight" % i]), g["g_mlp_w%d" % i],
-                                   rtol=1e-4, atol=1e-8)
-    np.testing.assert_allclose(N_(m.dense.g["fm.dense_w"]), g["g_dense_w"], rtol=1e-4, atol=1e-8)
-    np.testing.assert_allclose(N_(m.dense.g["fm.dense_w_one"]), g["g_dense_w_one"], rtol=1e-4, atol=1e-8)
+        assert_close_scaled(N_(m.dense.g["dnn.linear_%d.weight" % i]), g["g_mlp_w%d" % i])
+    assert_close_scaled(N_(m.dense.g["fm.dense_w"]).reshape(g["g_dense_w"].shape), g["g_dense_w"])
+    assert_close_scaled(N_(m.dense.g["fm.dense_w_one"]), g["g_dense_w_one"])
     # first Adam step moves each touched row by -lr*sign(g) (m/(sqrt(v)+eps) = sign at t=1)
     moved = N_(m.fm.embedding) - W0
     touched = np.abs(g["gW"]) > 1e-4                 # update = lr*g/(|g|+eps): eps=1e-8 matters for tiny g
@@ -511,10 +517,53 @@ def test_train_steps_vs_oracle(ops):
             mm, vv = dstate.setdefault(key, (np.zeros_like(arr), np.zeros_like(arr)))
             R.adam_update(arr, mm, vv, gr.reshape(arr.shape).astype(arr.dtype), step, lr=1e-2)
     assert int(m.status.item()) == 0
-    # after 3 Adam steps at lr=1e-2 weights moved by ~3e-2; agreement well inside 1e-4 absolute
-    np.testing.assert_allclose(N_(m.fm.embedding), op["W"], rtol=1e-3, atol=2e-4)
-    np.testing.assert_allclose(N_(m.fm.embedding_one), op["W1"], rtol=1e-3, atol=2e-4)
-    np.testing.assert_allclose(N_(m.dense.p["dnn.linear_0.weight"]), op["mlp_w"][0], rtol=1e-3, atol=2e-4)
+    # The Adam MOMENTS are linear (m) / quadratic (v) in the gradients: they must agree at the 1e-5 bar.
+    m._ensure_sparse_state()
+    assert_close_scaled(N_(m.sparse_state["m"]), st["mW"])
+    assert_close_scaled(N_(m.sparse_state["v"]), st["vW"])
+    assert_close_scaled(N_(m.sparse_state["m1"]), st["mW1"])
+    assert_close_scaled(N_(m.sparse_state["v1"]), st["vW1"])
+    off = 0
+    for name in m.dense.names:                      # dense moments live in the flat buffer, in declaration order
+        k = int(np.prod(m.dense.shapes[name]))
+        if name == "dnn.linear_0.weight":
+            assert_close_scaled(N_(m.dense.m[off:off + k]).reshape(op["mlp_w"][0].shape), dstate[("mlp_w", 0)][0])
+            assert_close_scaled(N_(m.dense.v[off:off + k]).reshape(op["mlp_w"][0].shape), dstate[("mlp_w", 0)][1])
+        off += k
+    # The WEIGHTS go through m / (sqrt(v) + eps): where a gradient is ~0 the ratio amplifies fp32 noise up to a sign
+    # flip, i.e. up to lr per step for a handful of elements — so: all but a vanishing fraction agree at 1e-6
+    # absolute, and nothing moved further than the 3 steps allow.
+    for got, want in ((N_(m.fm.embedding), op["W"]), (N_(m.fm.embedding_one), op["W1"]),
+                      (N_(m.dense.p["dnn.linear_0.weight"]), op["mlp_w"][0])):
+        d = np.abs(got - want)
+        assert d.max() <= 3 * 1e-2 and (d > 2e-6).mean() < 2e-3, (d.max(), (d > 2e-6).mean())
+
+
+def test_bench_batch_loss_vs_c_oracle(ops, oracle_lib):
+    """The bench's batch size against the ORACLE (not torch-on-the-same-GPU): B = 65536, the bench's MLP, 26 slot
+    tables (50 k rows each keeps the host side small; the reduction over 65536 samples is what is being checked):
+    loss and predictions of one train step == C oracle (embedding + FM) + NumPy MLP."""
+    from helpers import c_fm_fwd
+    from paddlerec_amd.deepfm import DeepFMLayer
+    B, S, D, NT, fc = 65536, 26, 16, 50_000, [400, 400, 400]
+    pr = make_deepfm_problem(B=B, N=NT, D=D, fc=fc, seed=20250404, pad_frac=0.03, tables=True)
+    p = pr["params"]
+    so = pr["slot_offsets"]
+    m = DeepFMLayer(NT * S, D, 13, S, fc, device=DEV, slot_offset=T(so))
+    sd = {"fm.embedding.weight": p["W"], "fm.embedding_one.weight": p["W1"],
+          "fm.dense_w": p["dense_w"], "fm.dense_w_one": p["dense_w_one"]}
+    for i in range(len(fc) + 1):
+        sd["dnn.linear_%d.weight" % i] = p["mlp_w"][i]
+        sd["dnn.linear_%d.bias" % i] = p["mlp_b"][i]
+    m.set_dict(sd)
+    loss, pred = m.train_step(T(pr["ids"]), T(pr["dense"]), T(pr["label"]), lr=1e-3)
+    y1, y2, feat, _ = c_fm_fwd(oracle_lib, pr["ids"], pr["dense"], p["W"], p["W1"], p["dense_w"], p["dense_w_one"], 0, so)
+    y_dnn = R.dnn_forward(feat, p["mlp_w"], p["mlp_b"])
+    want_pred = R.sigmoid(y1[:, None] + y2[:, None] + y_dnn).astype(np.float32)
+    want_loss = R.log_loss_mean(want_pred, pr["label"])
+    np.testing.assert_allclose(N_(loss)[0], want_loss, rtol=RTOL)
+    np.testing.assert_allclose(N_(pred), want_pred, rtol=RTOL, atol=ATOL)
+    assert int(m.status.item()) == 0
 
 
 # ------------------------------------------------------------------------------ full size (BASELINE config 2)

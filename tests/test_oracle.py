@@ -255,3 +255,38 @@ def test_din_oracle_backward_matches_reference_autograd():
             np.testing.assert_allclose(np.asarray(grads[k[2:]]).reshape(v.shape), v, rtol=3e-4, atol=3e-7, err_msg=k)
             n += 1
     assert n == 15
+
+
+def test_adam_restatement_vs_torch_optim_adam():
+    """Rows O / PS are pinned to a restatement (SURVEY App. B-3 [EXT]): a SECOND, independent implementation must
+    agree.  torch.optim.Adam computes p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps), which is algebraically
+    Paddle's lr_t * m / (sqrt(v) + eps*sqrt(1-b2^t)) with lr_t = lr*sqrt(1-b2^t)/(1-b1^t)."""
+    import torch
+    rng = np.random.default_rng(3)
+    p0 = rng.standard_normal((37, 16)).astype(np.float32)
+    grads = [(rng.standard_normal(p0.shape) * 10.0 ** rng.integers(-4, 1)).astype(np.float32) for _ in range(6)]
+    p, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    tp = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([tp], lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    for t, g in enumerate(grads, 1):
+        R.adam_update(p, m, v, g, t, lr=1e-2)
+        tp.grad = torch.from_numpy(g.copy())
+        opt.step()
+        np.testing.assert_allclose(p, tp.detach().numpy(), rtol=2e-6, atol=2e-7)
+    st = opt.state[tp]
+    # the restatement forms 1 - beta in float32 like Paddle's kernel (1 - 0.999f = 0.00100005): 4.7e-5 relative on
+    # the increment of v against torch's double-precision 0.001 — the moments agree to that, the weights to 2e-6
+    np.testing.assert_allclose(m, st["exp_avg"].numpy(), rtol=2e-6, atol=2e-7 * float(np.abs(m).max()))
+    np.testing.assert_allclose(v, st["exp_avg_sq"].numpy(), rtol=6e-5, atol=1e-12)
+    # lazy rows == torch.optim.SparseAdam semantics on the touched rows (untouched rows keep p, m, v)
+    P, M, V = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    rows = np.array([3, 7, 20])
+    gr = rng.standard_normal((3, 16)).astype(np.float32)
+    R.adam_update_rows(P, M, V, rows, gr, 1, lr=1e-2)
+    sp = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    sopt = torch.optim.SparseAdam([sp], lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    sp.grad = torch.sparse_coo_tensor(torch.from_numpy(rows).unsqueeze(0), torch.from_numpy(gr), p0.shape)
+    sopt.step()
+    np.testing.assert_allclose(P, sp.detach().numpy(), rtol=2e-6, atol=2e-7)
+    untouched = np.setdiff1d(np.arange(37), rows)
+    assert np.array_equal(P[untouched], p0[untouched]) and not M[untouched].any()

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """L-step / L-kernel numbers for the DCN-v2 and DIN rows of SURVEY.md §8 (BASELINE configs[2], configs[3]).
-Not part of bench.py's contract; results are copied into profiles/."""
+Not part of bench.py's contract; results are copied into profiles/.  Besides the readable lines, ONE JSON line per
+configuration with a `roofline` object (MFMA for the cross / attention GEMM work, HBM for the DIN gather part)."""
+import json
 import os
 import sys
 
@@ -25,6 +27,20 @@ def timeit(fn, iters=5, warm=2):
     return ts[len(ts) // 2]
 
 
+JSON = []
+PEAK_TF, PEAK_GBS = 157.3, 8000.0
+
+
+def record(config, workload, ms, flops, samples, extra=None):
+    tf = flops / ms / 1e9
+    d = {"config": config, "workload": workload, "ms": ms, "samples_per_s": samples / ms * 1e3, "dtype": "f32",
+         "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TF, "unit": "TFLOP/s", "frac": tf / PEAK_TF,
+                      "flops": flops}}
+    if extra:
+        d.update(extra)
+    JSON.append(d)
+
+
 g = torch.Generator(device=DEV).manual_seed(3)
 # ---- DCN-v2, datasets/criteo_dcn_v2 shapes: N 1 100 001, D 40, d 1560, fc [768,768] (dcn_v2/config.yaml:42-58)
 for B, mix, depth in ((65536, False, 3), (512, False, 3), (65536, True, 2)):
@@ -39,11 +55,15 @@ for B, mix, depth in ((65536, False, 3), (512, False, 3), (65536, True, 2)):
         fl = depth * (2.0 * B * d * 256 * 4 * 2 + 2.0 * B * 256 * 256 * 4 + 2.0 * B * d * 4) + 2.0 * B * (d * 768 + 768 * 768 + 768)
         print("DCN-v2 CrossNetMix r256 E4 depth%d B=%d: forward %.2f ms  (%.1f TF, %.2f M samples/s)" %
               (depth, B, t_f, fl / t_f / 1e9, B / t_f / 1e3))
+        record("configs[2] (shipped CrossNetMix)", "DCN-v2 CrossNetMix r256 E4 depth %d, d 1560, B %d: forward" % (depth, B),
+               t_f, fl, B)
     else:
         fl_f = depth * 2.0 * B * d * d + 2.0 * B * (d * 768 + 768 * 768 + 768) + 2.0 * B * 13 * 520
         t_s = timeit(lambda: m.train_step(ids, dense, label, lr=1e-3))
         print("DCN-v2 CrossNetV2 depth%d B=%d: forward %.2f ms (%.1f TF)  train step %.2f ms (%.1f TF, %.2f M samples/s)" %
               (depth, B, t_f, fl_f / t_f / 1e9, t_s, 3 * fl_f / t_s / 1e9, B / t_s / 1e3))
+        record("configs[2]", "DCN-v2 CrossNetV2 depth %d, d 1560, DNN 768-768, B %d: train step (fwd + bwd + clip + "
+               "Adam)" % (depth, B), t_s, 3 * fl_f, B, {"forward_ms": t_f, "forward_tflops": fl_f / t_f / 1e9})
     del m
     torch.cuda.empty_cache()
 
@@ -62,3 +82,11 @@ for B, T in ((32, 152), (4096, 100), (4096, 512)):
     by = B * T * (4 * 8 + 8 + 4 * 256)          # ids + mask + 4 rows of 256 B (algorithmic, rows hit L2)
     print("DIN attention-pool B=%d T=%d: %.3f ms  (%.1f M positions/s, %.2f TF, %.0f GB/s algorithmic)" %
           (B, T, t, B * T / t / 1e3, fl / t / 1e9, by / t / 1e6))
+    record("configs[3]", "DIN attention-pool forward (4 gathers + 512-80-40-1 MLP + masked softmax + pool), B %d, "
+           "T %d" % (B, T), t, fl, B,
+           {"positions_per_s": B * T / t * 1e3,
+            "gather_roofline": {"bound": "hbm", "achieved": by / t / 1e6, "peak": PEAK_GBS, "unit": "GB/s",
+                                "frac": by / t / 1e6 / PEAK_GBS, "bytes": by}})
+
+for d in JSON:
+    print(json.dumps(d))
