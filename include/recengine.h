@@ -393,6 +393,10 @@ typedef struct {
   int32_t item_stride, cat_stride;
 } rec_din_desc;
 
+/* act1 [B,T,H1] or NULL: layer-1 activations for the backward.  Written only when rec_din_saves_act1(desc)
+ * returns 1 (the reference net's own shape: E 128, attention MLP 80-40-1); otherwise left untouched and the
+ * backward must be given NULL for act1_saved. */
+int rec_din_saves_act1(const rec_din_desc* desc);
 int rec_din_attention_pool_fwd(const rec_din_desc* desc, const int64_t* hist_item,
                                const int64_t* hist_cat, const int64_t* tgt_item_seq,
                                const int64_t* tgt_cat_seq, const int64_t* mask,
@@ -400,13 +404,16 @@ int rec_din_attention_pool_fwd(const rec_din_desc* desc, const int64_t* hist_ite
                                const float* w_tgt_item_seq, const float* w_tgt_cat_seq,
                                const float* att_w1, const float* att_b1, const float* att_w2,
                                const float* att_b2, const float* att_w3, const float* att_b3,
-                               float* out, float* att_weight, int32_t* status, void* stream);
+                               float* out, float* att_weight, float* act1, int32_t* status, void* stream);
 
 /* Backward of the block above w.r.t. the gathered rows (what loss.backward() computes for net.py:141-173):
  *   d_hist [B,T,E] = gradient of [hist_item_emb | hist_cat_emb] per position, d_tgt_seq [B,T,E] likewise
  *   for the target-seq tables; their row-wise merge (rec_ids_group + rec_sparse_sgd_rows) is the
  *   embedding gradient.  att_weight = the forward's softmax weights; att_w1_t = att_w1 transposed
- *   [H1,4E].  Hidden activations are recomputed.  The attention MLP's own weight gradients are not
+ *   [H1,4E].  out_saved [B,E] / act1_saved [B,T,H1] (both nullable): the forward's output and the layer-1
+ *   activations it wrote when its `act1` argument was non-null and rec_din_saves_act1(desc) == 1 (NULL here
+ *   otherwise).  With both, the backward runs on the saved activations (dz1 W1^T on the matrix cores, W1^T in
+ *   registers); without, hidden activations are recomputed.  The attention MLP's own weight gradients are not
  *   produced (not registered parameters in dygraph mode). */
 int rec_din_attention_pool_bwd(const rec_din_desc* desc, const int64_t* hist_item,
                                const int64_t* hist_cat, const int64_t* tgt_item_seq,
@@ -415,6 +422,7 @@ int rec_din_attention_pool_bwd(const rec_din_desc* desc, const int64_t* hist_ite
                                const float* w_tgt_cat_seq, const float* att_w1,
                                const float* att_w1_t, const float* att_b1, const float* att_w2,
                                const float* att_b2, const float* att_w3, const float* att_weight,
+                               const float* out_saved, const float* act1_saved,
                                const float* d_out, float* d_hist, float* d_tgt_seq, void* stream);
 
 /* CrossNetMix backward glue for one expert (dcn_v2/net.py:301-317), one pass over [m,n]:

@@ -133,8 +133,9 @@ SIGNATURES = {
     "rec_sparse_rows_sumsq": (C.c_int, [_I64, _I32, _P, _P, _P, _P, C.POINTER(GradLayout), _P, _I32, _P,
                                         _SZ, _P]),
     "rec_clip_scale": (C.c_int, [_P, _F, _P, _P]),
-    "rec_din_attention_pool_fwd": (C.c_int, [C.POINTER(DinDesc)] + [_P] * 19),
-    "rec_din_attention_pool_bwd": (C.c_int, [C.POINTER(DinDesc)] + [_P] * 19),
+    "rec_din_saves_act1": (C.c_int, [C.POINTER(DinDesc)]),
+    "rec_din_attention_pool_fwd": (C.c_int, [C.POINTER(DinDesc)] + [_P] * 20),
+    "rec_din_attention_pool_bwd": (C.c_int, [C.POINTER(DinDesc)] + [_P] * 21),
     "rec_sparse_sgd_rows": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P, _F, _P]),
     "rec_sgd_dense": (C.c_int, [_I64, _P, _P, _F, _P]),
     "rec_bce_with_logits": (C.c_int, [_I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),

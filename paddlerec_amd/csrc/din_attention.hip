@@ -35,6 +35,7 @@ struct DinArgs {
   const float *w_hist_item, *w_hist_cat, *w_tgt_item, *w_tgt_cat;
   const float *w1, *b1, *w2, *b2, *w3, *b3;
   float *out, *att_weight;
+  float* act1;             // [B,T,H1] layer-1 activations, saved for the backward when non-null
   int32_t* status;
 };
 
@@ -541,6 +542,7 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
       float4 z;
       z.x = sigmoidf_(x.x + y.x); z.y = sigmoidf_(x.y + y.y); z.z = sigmoidf_(x.z + y.z); z.w = sigmoidf_(x.w + y.w);
       *reinterpret_cast<float4*>(X + p * S::H1P + c) = z;
+      if (a.act1 && t0 + p < T) *reinterpret_cast<float4*>(a.act1 + ((int64_t)b * T + t0 + p) * H1 + c) = z;
     }
     __syncthreads();
     // ---- layer 2 on the matrix cores, layer 3 folded into its epilogue: lp[n][p] = sum_{c in tile n} a2[p][c] w3[c]
@@ -642,6 +644,8 @@ struct DinBwdArgs {
   const float* w1t;        // [H1][4E]  (att_w1 transposed)
   const float* att_weight; // [B,T] softmax weights saved by the forward
   const float* dout;       // [B,E]
+  const float* out_saved;  // [B,E]    forward output        } both non-null: the compile-time-shaped kernel runs
+  const float* act1;       // [B,T,H1] forward layer-1 acts  } on saved activations instead of recomputing them
   float *dh, *dq;          // [B,T,E]
 };
 
@@ -853,9 +857,295 @@ __global__ __launch_bounds__(kBlock) void din_attention_bwd_kernel(DinBwdArgs g)
   }
 }
 
+// ------------------------------------------------------------------------ backward, compile-time shapes
+// Backward on the activations the forward saved (act1 [B,T,H1], out [B,E]) instead of recomputing layer 1:
+//   * sdp = sum_t p_t (dout . h_t) = dout . out — the first pass over the history of the kernel above disappears;
+//   * a2 is recomputed from a1 (one small MFMA GEMM), dz2 / dz1 are MFMA GEMMs against the LDS copy of W2;
+//   * dx = dz1 W1^T — as large as layer 1 — runs on the matrix cores with W1^T fragments resident in registers.
+//     Wave w owns columns [w*E/4, (w+1)*E/4) of ALL FOUR concat segments, so dx_a, dx_b, dx_c, dx_d of an (p, e)
+//     sit in the same lane and   dh = p_t dout + dx_a + dx_c + dx_d*q,   dq = dx_b - dx_c + dx_d*h
+//     are formed in registers and stored straight to HBM: no partial sums, no LDS round trip for the result.
+// Saving a1 costs B*T*H1*4 bytes written once and read once (0.67 GB at B 4096, T 512: ~0.3 ms of HBM time)
+// against 2.7 ms of recomputed layer-1 MFMA work.
+template <int E, int H1, int H2>
+struct DinBwdCt {
+  static_assert(E % 64 == 0 && kBlock % E == 0 && H1 % 16 == 0, "unsupported compile-time shape");
+  static constexpr int EP = E + 4, H1P = H1 + 4;
+  static constexpr int H2C = ((H2 + 15) / 16) * 16, W2P = H2C + 4, Z2P = H2C + 4;
+  static constexpr int NJB = H1 / 16, NCB = H2C / 16;
+  static constexpr int EW = E / 4, NH = EW / 16;         // columns of each segment owned by a wave, in MFMA tiles
+  static constexpr int E4 = E / 4, NIT = kDinTP * E4 / kBlock, PSTEP = kBlock / E4;
+  static constexpr int kHs = 0;
+  static constexpr int kQs = kHs + kDinTP * EP;
+  static constexpr int kX = kQs + kDinTP * EP;           // a1 of the tile
+  static constexpr int kY = kX + kDinTP * H1P;           // dz1
+  static constexpr int kZ2 = kY + kDinTP * H1P;          // dz2
+  static constexpr int kW2 = kZ2 + kDinTP * Z2P;
+  static constexpr int kW3 = kW2 + H1 * W2P;
+  static constexpr int kB2 = kW3 + H2C;
+  static constexpr int kDl = kB2 + H2C;                  // [32] dl of the tile
+  static constexpr int kPw = kDl + kDinTP;               // [2][32] softmax weights of this / the next tile
+  static constexpr int kDout = kPw + 2 * kDinTP;         // [E] dout of the sample, [E] sdp
+  static constexpr int kIds = (kDout + E + 2 + 1) & ~1;  // int64 [4][32]: ids of the NEXT tile (this tile's are spent)
+  static constexpr int kEnd = kIds + 2 * 4 * kDinTP;
+  static_assert(2 * sizeof(float) * kEnd <= 160 * 1024 || E > 128, "two blocks per CU no longer fit the LDS");
+  static constexpr size_t lds_bytes = sizeof(float) * (size_t)kEnd;
+};
+
+template <int E, int H1, int H2>
+__global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdArgs gb) {
+  using S = DinBwdCt<E, H1, H2>;
+  const DinArgs& a = gb.f;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* hs = smem + S::kHs;
+  float* qs = smem + S::kQs;
+  float* X = smem + S::kX;
+  float* Y = smem + S::kY;
+  float* Z2 = smem + S::kZ2;
+  float* w2s = smem + S::kW2;
+  float* w3s = smem + S::kW3;
+  float* b2s = smem + S::kB2;
+  float* dls = smem + S::kDl;
+  float* pws = smem + S::kPw;
+  float* douts = smem + S::kDout;
+  int64_t* idbuf = reinterpret_cast<int64_t*>(smem + S::kIds);
+  const int tid = threadIdx.x, lane = tid % kWave;
+  const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int li = lane & 15, g = lane >> 4;
+  const int T = a.T;
+  for (int i = tid; i < H1 * S::W2P; i += kBlock) {
+    const int k = i / S::W2P, c = i % S::W2P;
+    w2s[i] = c < H2 ? a.w2[k * H2 + c] : 0.f;
+  }
+  for (int i = tid; i < S::H2C; i += kBlock) {
+    w3s[i] = i < H2 ? a.w3[i] : 0.f;
+    b2s[i] = i < H2 ? a.b2[i] : 0.f;
+  }
+  const float scale = 1.f / sqrtf((float)E);
+  // W1^T as MFMA B fragments of dx[p][n] = sum_j dz1[p][j] W1[n][j]:
+  //   bt[sg][nh][jb][s] = W1[sg*E + wv*EW + nh*16 + li][jb*16 + 4g + s]
+  float bt[4][S::NH][S::NJB][4];
+#pragma unroll
+  for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+    for (int nh = 0; nh < S::NH; ++nh)
+#pragma unroll
+      for (int jb = 0; jb < S::NJB; ++jb) {
+        const float4 w = *reinterpret_cast<const float4*>(
+            a.w1 + (int64_t)(sg * E + wv * S::EW + nh * 16 + li) * H1 + jb * 16 + 4 * g);
+        bt[sg][nh][jb][0] = w.x; bt[sg][nh][jb][1] = w.y; bt[sg][nh][jb][2] = w.z; bt[sg][nh][jb][3] = w.w;
+      }
+
+  const int c4 = (tid % S::E4) * 4, p0 = tid / S::E4;
+  const bool item = c4 < a.Ei;
+  const float* wh = item ? a.w_hist_item : a.w_hist_cat;
+  const float* wq = item ? a.w_tgt_item : a.w_tgt_cat;
+  const int64_t nrow = item ? a.n_item : a.n_cat;
+  const int ld = item ? a.ld_item : a.ld_cat;
+  const int col = item ? c4 : c4 - a.Ei;
+  const int ih = item ? 0 : 1, iq = item ? 2 : 3;
+  const int id_arr = tid >> 5, id_p = tid & 31;     // threads 0..127: ids; 128..159: softmax weights
+  const int64_t* id_ptr = id_arr == 0 ? a.hist_item : id_arr == 1 ? a.hist_cat : id_arr == 2 ? a.tgt_item : a.tgt_cat;
+
+  auto ids_issue = [&](int64_t b, int t0, int64_t& idv, float& pwv) {
+    const int t = t0 + id_p;
+    idv = 0; pwv = 0.f;
+    if (t < T) {
+      if (id_arr < 4) idv = id_ptr[b * T + t];
+      else if (id_arr == 4) pwv = gb.att_weight[b * T + t];
+    }
+  };
+  auto ids_store = [&](int buf, int64_t idv, float pwv) {
+    if (id_arr < 4) idbuf[id_arr * kDinTP + id_p] = idv;
+    else if (id_arr == 4) pws[buf * kDinTP + id_p] = pwv;
+  };
+  // gathers h, q rows and the saved a1 rows of a tile into LDS
+  auto tile_load = [&](int buf, int64_t b, int t0) {
+    float4 ph[S::NIT], pq[S::NIT];
+#pragma unroll
+    for (int it = 0; it < S::NIT; ++it) {
+      const int p = p0 + it * S::PSTEP;
+      ph[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pq[it] = ph[it];
+      if (t0 + p < T) {
+        const int64_t hid = idbuf[ih * kDinTP + p], qid = idbuf[iq * kDinTP + p];
+        if (hid >= 0 && hid < nrow) ph[it] = *reinterpret_cast<const float4*>(wh + hid * ld + col);
+        if (qid >= 0 && qid < nrow) pq[it] = *reinterpret_cast<const float4*>(wq + qid * ld + col);
+      }
+    }
+    constexpr int NV = kDinTP * (H1 / 4), NA = (NV + kBlock - 1) / kBlock;
+    float4 pa[NA];
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int v = tid + it * kBlock;
+      const int p = v / (H1 / 4), c = (v % (H1 / 4)) * 4;
+      pa[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v < NV && t0 + p < T) pa[it] = *reinterpret_cast<const float4*>(gb.act1 + (b * T + t0 + p) * H1 + c);
+    }
+#pragma unroll
+    for (int it = 0; it < S::NIT; ++it) {
+      const int p = p0 + it * S::PSTEP;
+      *reinterpret_cast<float4*>(hs + p * S::EP + c4) = ph[it];
+      *reinterpret_cast<float4*>(qs + p * S::EP + c4) = pq[it];
+    }
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int v = tid + it * kBlock;
+      const int p = v / (H1 / 4), c = (v % (H1 / 4)) * 4;
+      if (v < NV) *reinterpret_cast<float4*>(X + p * S::H1P + c) = pa[it];
+    }
+  };
+  // dout of a sample and sdp = dout . out (softmax backward), by wave 0 and threads < E
+  auto sample_load = [&](int64_t b) {
+    if (tid < E) douts[tid] = gb.dout[b * E + tid];
+    if (wv == 0) {
+      float v = 0.f;
+      for (int k = lane; k < E; k += kWave) v += gb.dout[b * E + k] * gb.out_saved[b * E + k];
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+      if (lane == 0) douts[E] = v;
+    }
+  };
+
+  int64_t b = blockIdx.x;
+  if (b >= a.B) return;
+  int t0 = 0, buf = 0;
+  {
+    int64_t idv; float pwv;
+    ids_issue(b, 0, idv, pwv);
+    ids_store(0, idv, pwv);
+    sample_load(b);
+  }
+  __syncthreads();
+  tile_load(0, b, 0);
+  __syncthreads();
+
+  while (true) {
+    int64_t nb = b;
+    int nt0 = t0 + kDinTP;
+    if (nt0 >= T) { nb = b + gridDim.x; nt0 = 0; }
+    const bool has_next = nb < a.B;
+    int64_t idv = 0;
+    float pwv = 0.f;
+    if (has_next) ids_issue(nb, nt0, idv, pwv);
+    // ---- dl_t = p_t (dout . h_t - sdp) E^-0.5 : 8 threads per position
+    {
+      const int p = tid >> 3, sub = tid & 7;
+      float dp = 0.f;
+#pragma unroll
+      for (int i = 0; i < E / 32; ++i) {
+        const int k = (i * 8 + sub) * 4;
+        const float4 hv = *reinterpret_cast<const float4*>(hs + p * S::EP + k);
+        const float4 dv = *reinterpret_cast<const float4*>(douts + k);
+        dp += hv.x * dv.x + hv.y * dv.y + hv.z * dv.z + hv.w * dv.w;
+      }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) dp += __shfl_xor(dp, o, 8);
+      if (sub == 0) dls[p] = pws[buf * kDinTP + p] * (dp - douts[E]) * scale;   // padded positions: p_t = 0
+    }
+    __syncthreads();
+    // ---- a2 = sigmoid(a1 W2 + b2) recomputed on the matrix cores; dz2 = dl w3 a2 (1 - a2) in the epilogue
+    for (int t = wv; t < 2 * S::NCB; t += kBlock / kWave) {
+      const int m = t & 1, n = t >> 1;
+      const int c = n * 16 + li;
+      f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < S::NJB; ++kb) {
+        const int k0 = kb * 16 + 4 * g;
+        const float4 av = *reinterpret_cast<const float4*>(X + (m * 16 + li) * S::H1P + k0);
+        const float a4[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          z = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], w2s[(k0 + s) * S::W2P + c], z, 0, 0, 0);
+      }
+      const float bias = b2s[c], w3c = w3s[c];      // columns >= H2: w3 = 0 -> dz2 = 0
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = m * 16 + g * 4 + r;
+        const float a2v = sigmoidf_(z[r] + bias);
+        Z2[p * S::Z2P + c] = dls[p] * w3c * a2v * (1.f - a2v);
+      }
+    }
+    __syncthreads();
+    // ---- dz1 = (dz2 W2^T) a1 (1 - a1)
+    for (int t = wv; t < 2 * S::NJB; t += kBlock / kWave) {
+      const int m = t & 1, n = t >> 1;
+      f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cb = 0; cb < S::NCB; ++cb) {
+        const int k0 = cb * 16 + 4 * g;
+        const float4 av = *reinterpret_cast<const float4*>(Z2 + (m * 16 + li) * S::Z2P + k0);
+        const float4 bv = *reinterpret_cast<const float4*>(w2s + (n * 16 + li) * S::W2P + k0);
+        z = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, z, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = m * 16 + g * 4 + r, j = n * 16 + li;
+        const float a1v = X[p * S::H1P + j];
+        Y[p * S::H1P + j] = z[r] * a1v * (1.f - a1v);
+      }
+    }
+    if (has_next) ids_store(buf ^ 1, idv, pwv);
+    __syncthreads();
+    // ---- dx = dz1 W1^T for this wave's columns of the four segments, folded into dh / dq (16 positions a pass)
+#pragma unroll 1
+    for (int m = 0; m < 2; ++m) {
+      f32x4_t acc[4][S::NH];
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+        for (int nh = 0; nh < S::NH; ++nh) acc[sg][nh] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jb = 0; jb < S::NJB; ++jb) {
+        const float4 av = *reinterpret_cast<const float4*>(Y + (m * 16 + li) * S::H1P + jb * 16 + 4 * g);
+        const float a4[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+            for (int nh = 0; nh < S::NH; ++nh)
+              acc[sg][nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], bt[sg][nh][jb][s], acc[sg][nh], 0, 0, 0);
+      }
+#pragma unroll
+      for (int nh = 0; nh < S::NH; ++nh) {
+        const int e = wv * S::EW + nh * 16 + li;
+        const float de = douts[e];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = m * 16 + g * 4 + r, t = t0 + p;
+          if (t < T) {
+            const float hv = hs[p * S::EP + e], qv = qs[p * S::EP + e];
+            const float xa = acc[0][nh][r], xb = acc[1][nh][r], xc = acc[2][nh][r], xd = acc[3][nh][r];
+            gb.dh[(b * T + t) * (int64_t)E + e] = pws[buf * kDinTP + p] * de + xa + xc + xd * qv;
+            gb.dq[(b * T + t) * (int64_t)E + e] = xb - xc + xd * hv;
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    __syncthreads();            // hs / qs / X / douts are rewritten for the next tile
+    if (nt0 == 0) sample_load(nb);
+    tile_load(buf ^ 1, nb, nt0);
+    __syncthreads();
+    b = nb; t0 = nt0; buf ^= 1;
+  }
+}
+
 }  // namespace rec
 
 using namespace rec;
+
+// 1 when the forward for this shape writes `act1` (and the backward can consume it), else 0
+extern "C" int rec_din_saves_act1(const rec_din_desc* d) {
+  if (!d) return 0;
+  using Ct = DinCt<128, 80, 40>;
+  return d->item_dim + d->cat_dim == 128 && d->hidden1 == 80 && d->hidden2 == 40 && d->max_len > 0 &&
+         Ct::lds_bytes(d->max_len) <= kDinCtLdsMax && getenv("REC_DIN_FWD_GENERIC") == nullptr;
+}
 
 extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* hist_item,
                                           const int64_t* hist_cat, const int64_t* tgt_item_seq,
@@ -865,7 +1155,7 @@ extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* 
                                           const float* att_w1, const float* att_b1,
                                           const float* att_w2, const float* att_b2,
                                           const float* att_w3, const float* att_b3, float* out,
-                                          float* att_weight, int32_t* status, void* stream) {
+                                          float* att_weight, float* act1, int32_t* status, void* stream) {
   REC_REQUIRE(d, REC_EINVAL, "desc is NULL");
   const int E = d->item_dim + d->cat_dim;
   REC_REQUIRE(d->batch >= 0 && d->max_len > 0 && d->item_dim > 0 && d->cat_dim > 0 && d->hidden1 > 0 &&
@@ -899,6 +1189,7 @@ extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* 
   a.mask = mask; a.w_hist_item = w_hist_item; a.w_hist_cat = w_hist_cat; a.w_tgt_item = w_tgt_item_seq;
   a.w_tgt_cat = w_tgt_cat_seq; a.w1 = att_w1; a.b1 = att_b1; a.w2 = att_w2; a.b2 = att_b2; a.w3 = att_w3;
   a.b3 = att_b3; a.out = out; a.att_weight = att_weight; a.status = status;
+  a.act1 = ct ? act1 : nullptr;       // only the compile-time-shaped pair saves / consumes layer-1 activations
   if (ct) {
     // REC_DIN_FWD_VARIANT: measurement knob.  Measured at B 4096, T 512 (profiles/r02_din_variants.txt):
     //   nopf2 (default; rows fetched at the end of the tile, 2 blocks/CU, 36 spilled VGPRs)  2.74 ms  68.0 TF
@@ -937,6 +1228,7 @@ extern "C" int rec_din_attention_pool_bwd(const rec_din_desc* d, const int64_t* 
                                           const float* att_w1_t, const float* att_b1,
                                           const float* att_w2, const float* att_b2,
                                           const float* att_w3, const float* att_weight,
+                                          const float* out_saved, const float* act1_saved,
                                           const float* d_out, float* d_hist, float* d_tgt_seq,
                                           void* stream) {
   REC_REQUIRE(d, REC_EINVAL, "desc is NULL");
@@ -956,7 +1248,6 @@ extern "C" int rec_din_attention_pool_bwd(const rec_din_desc* d, const int64_t* 
   const int H1 = d->hidden1, H2 = d->hidden2;
   const size_t shmem = sizeof(float) * ((size_t)2 * kDinTP * E + (size_t)kDinTP * (H1 + H2) + (size_t)H1 * H2 +
                                         2 * H2 + H1 + kDinTP + kBlock / kWave + (size_t)d->max_len);
-  REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "history too long for the LDS buffers (%zu B)", shmem);
   DinBwdArgs g;
   DinArgs& a = g.f;
   a.B = d->batch; a.T = d->max_len; a.Ei = d->item_dim; a.Ec = d->cat_dim; a.H1 = H1; a.H2 = H2;
@@ -964,8 +1255,22 @@ extern "C" int rec_din_attention_pool_bwd(const rec_din_desc* d, const int64_t* 
   a.hist_item = hist_item; a.hist_cat = hist_cat; a.tgt_item = tgt_item_seq; a.tgt_cat = tgt_cat_seq;
   a.mask = nullptr; a.w_hist_item = w_hist_item; a.w_hist_cat = w_hist_cat; a.w_tgt_item = w_tgt_item_seq;
   a.w_tgt_cat = w_tgt_cat_seq; a.w1 = att_w1; a.b1 = att_b1; a.w2 = att_w2; a.b2 = att_b2; a.w3 = att_w3;
-  a.b3 = nullptr; a.out = nullptr; a.att_weight = nullptr; a.status = nullptr;
+  a.b3 = nullptr; a.out = nullptr; a.att_weight = nullptr; a.status = nullptr; a.act1 = nullptr;
   g.w1t = att_w1_t; g.att_weight = att_weight; g.dout = d_out; g.dh = d_hist; g.dq = d_tgt_seq;
+  g.out_saved = out_saved; g.act1 = act1_saved;
+  static const bool force_generic = getenv("REC_DIN_BWD_GENERIC") != nullptr;
+  if (!force_generic && out_saved && act1_saved && E == 128 && H1 == 80 && H2 == 40) {
+    using Ct = DinBwdCt<128, 80, 40>;
+    auto kern = din_attention_bwd_ct_kernel<128, 80, 40>;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)kDinCtLdsMax);
+    (void)attr;
+    int64_t grid = resident_blocks(kern, kBlock, Ct::lds_bytes);
+    if (grid > d->batch) grid = d->batch;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), Ct::lds_bytes, (hipStream_t)stream, g);
+    return check_launch("rec_din_attention_pool_bwd");
+  }
+  REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "history too long for the LDS buffers (%zu B)", shmem);
   int64_t grid = resident_blocks(din_attention_bwd_kernel, kBlock, shmem);
   if (grid > d->batch) grid = d->batch;
   hipLaunchKernelGGL(din_attention_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), shmem,

@@ -59,6 +59,7 @@ class DINLayer:
             self.params["linear_%d.bias" % i] = torch.zeros(con[i + 1], **f32)
         self.ws = self.k.Workspace(self.device)
         self.status = self.k.new_status(self.device)
+        self._att_saved = {}     # what the attention-pool forward keeps for its backward (buffers reused per step)
 
     def state_dict(self):
         return dict(self.params)
@@ -80,7 +81,8 @@ class DINLayer:
             hist_item_seq, hist_cat_seq, target_item_seq, target_cat_seq, mask2,
             p["hist_item_emb_attr.weight"], p["hist_cat_emb_attr.weight"],
             p["target_item_seq_emb_attr.weight"], p["target_cat_seq_emb_attr.weight"],
-            self.attention_w, self.attention_b, self.status, want_weights=_keep is not None)  # net.py:141-173
+            self.attention_w, self.attention_b, self.status, want_weights=_keep is not None,
+            saved=self._att_saved if _keep is not None else None)                            # net.py:141-173
         emb = torch.empty(B, 2 * E, dtype=torch.float32, device=self.device)           # net.py:178
         self.k.gemm(pooled, p["linearCon.weight"], self.ws, epilogue="bias", bias=p["linearCon.bias"],
                  out=emb[:, :E])                                                         # net.py:175-176
@@ -152,7 +154,7 @@ class DINLayer:
             hist_item_seq, hist_cat_seq, target_item_seq, target_cat_seq,
             p["hist_item_emb_attr.weight"], p["hist_cat_emb_attr.weight"],
             p["target_item_seq_emb_attr.weight"], p["target_cat_seq_emb_attr.weight"],
-            self.attention_w, self.attention_b, sv["attw"], dpooled)
+            self.attention_w, self.attention_b, sv["attw"], dpooled, saved=self._att_saved)
         self._last = dict(dh=dh, dq=dq, de0=de0, dz=dz, dense=g)
         # ---- SGD (dygraph_model.py:64-73).  Embedding tables: merged rows; dense: in place.
         self._sgd_rows(hist_item_seq, dh, p["hist_item_emb_attr.weight"], lr, E)

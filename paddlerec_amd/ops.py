@@ -565,9 +565,11 @@ def clip_scale(sumsq_t, clip_norm, out):
 
 
 def din_attention_pool(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, mask, w_hist_item, w_hist_cat,
-                       w_tgt_item_seq, w_tgt_cat_seq, att_w, att_b, status=None, want_weights=True):
+                       w_tgt_item_seq, w_tgt_cat_seq, att_w, att_b, status=None, want_weights=True, saved=None):
     """Fused DIN attention-pool forward (din/net.py:141-173).  ids/mask [B,T] i64; att_w/att_b: the three
-    attention Linear layers ([4E,H1],[H1,H2],[H2,1] / biases).  -> (out [B,E], att_weight [B,T] | None, status)"""
+    attention Linear layers ([4E,H1],[H1,H2],[H2,1] / biases).  -> (out [B,E], att_weight [B,T] | None, status)
+    saved: a dict the training caller hands in; it receives what the backward can reuse ("out", and "act1"
+    [B,T,H1] when the engine saves layer-1 activations for this shape) — pass it on to din_attention_pool_bwd."""
     B, T = hist_item.shape
     for t, n in ((hist_item, "hist_item"), (hist_cat, "hist_cat"), (tgt_item_seq, "tgt_item_seq"),
                  (tgt_cat_seq, "tgt_cat_seq"), (mask, "mask")):
@@ -587,17 +589,25 @@ def din_attention_pool(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, mask, w_h
     if status is None:
         status = new_status(dev)
     d = DinDesc(B, T, Ei, Ec, H1, H2, w_hist_item.shape[0], w_hist_cat.shape[0], ldi, ldc)
+    act1 = None
+    if saved is not None and lib().rec_din_saves_act1(C.byref(d)):
+        act1 = saved.get("act1")
+        if act1 is None or act1.shape != (B, T, H1) or act1.device != dev:
+            act1 = torch.empty(B, T, H1, dtype=torch.float32, device=dev)
     check(lib().rec_din_attention_pool_fwd(
         C.byref(d), _p(hist_item), _p(hist_cat), _p(tgt_item_seq), _p(tgt_cat_seq), _p(mask),
         _p(w_hist_item), _p(w_hist_cat), _p(w_tgt_item_seq), _p(w_tgt_cat_seq), _p(att_w[0]), _p(att_b[0]),
-        _p(att_w[1]), _p(att_b[1]), _p(att_w[2]), _p(att_b[2]), _p(out), _p(attw), _p(status), _stream()),
+        _p(att_w[1]), _p(att_b[1]), _p(att_w[2]), _p(att_b[2]), _p(out), _p(attw), _p(act1), _p(status), _stream()),
         "rec_din_attention_pool_fwd")
+    if saved is not None:
+        saved["out"], saved["act1"] = out, act1
     return out, attw, status
 
 
 def din_attention_pool_bwd(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_hist_item, w_hist_cat,
-                           w_tgt_item_seq, w_tgt_cat_seq, att_w, att_b, att_weight, d_out):
-    """-> (d_hist [B,T,E], d_tgt_seq [B,T,E]): per-position gradients of the gathered rows."""
+                           w_tgt_item_seq, w_tgt_cat_seq, att_w, att_b, att_weight, d_out, saved=None):
+    """-> (d_hist [B,T,E], d_tgt_seq [B,T,E]): per-position gradients of the gathered rows.
+    saved: the dict the forward filled (optional; without it the hidden activations are recomputed)."""
     B, T = hist_item.shape
     Ei, ldi = _chk_table(w_hist_item, "w_hist_item")
     Ec, ldc = _chk_table(w_hist_cat, "w_hist_cat")
@@ -609,11 +619,16 @@ def din_attention_pool_bwd(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_his
     dh = torch.empty(B, T, E, dtype=torch.float32, device=dev)
     dq = torch.empty(B, T, E, dtype=torch.float32, device=dev)
     d = DinDesc(B, T, Ei, Ec, H1, H2, w_hist_item.shape[0], w_hist_cat.shape[0], ldi, ldc)
+    out_s = act1_s = None
+    if saved is not None and saved.get("act1") is not None and saved.get("out") is not None:
+        out_s, act1_s = saved["out"], saved["act1"]
+        _chk(out_s, torch.float32, "saved out", (B, E))
+        _chk(act1_s, torch.float32, "saved act1", (B, T, H1))
     check(lib().rec_din_attention_pool_bwd(
         C.byref(d), _p(hist_item), _p(hist_cat), _p(tgt_item_seq), _p(tgt_cat_seq), _p(w_hist_item),
         _p(w_hist_cat), _p(w_tgt_item_seq), _p(w_tgt_cat_seq), _p(att_w[0]), _p(w1t), _p(att_b[0]),
-        _p(att_w[1]), _p(att_b[1]), _p(att_w[2]), _p(att_weight), _p(d_out), _p(dh), _p(dq), _stream()),
-        "rec_din_attention_pool_bwd")
+        _p(att_w[1]), _p(att_b[1]), _p(att_w[2]), _p(att_weight), _p(out_s), _p(act1_s), _p(d_out), _p(dh), _p(dq),
+        _stream()), "rec_din_attention_pool_bwd")
     return dh, dq
 
 

@@ -184,7 +184,7 @@ def _din_hq(hist_item, hist_cat, tis, tcs, w_hi, w_hc, w_ti, w_tc):
 
 
 def din_attention_pool(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, mask, w_hist_item, w_hist_cat,
-                       w_tgt_item_seq, w_tgt_cat_seq, att_w, att_b, status=None, want_weights=True):
+                       w_tgt_item_seq, w_tgt_cat_seq, att_w, att_b, status=None, want_weights=True, saved=None):
     from oracle import din_ref
     h, q = _din_hq(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_hist_item, w_hist_cat, w_tgt_item_seq,
                    w_tgt_cat_seq)
@@ -195,7 +195,7 @@ def din_attention_pool(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, mask, w_h
 
 
 def din_attention_pool_bwd(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_hist_item, w_hist_cat, w_tgt_item_seq,
-                           w_tgt_cat_seq, att_w, att_b, att_weight, d_out):
+                           w_tgt_cat_seq, att_w, att_b, att_weight, d_out, saved=None):
     """d h, d q of the attention-pool given the forward's softmax weights (oracle/din_ref.py:66-90 with p = att_weight;
     the attention MLP's own gradients are not produced, App. B-9)."""
     from oracle import din_ref

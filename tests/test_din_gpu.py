@@ -100,8 +100,12 @@ def _din_problem(rng, B, Tn, ni, nc):
     return hi, hc, ti, tc, mask, label
 
 
-@pytest.mark.parametrize("B,Tn,Ei,Ec", [(5, 7, 8, 8), (40, 70, 64, 64), (3, 33, 32, 96)])
-def test_attention_pool_bwd_vs_oracle(engine_lib, B, Tn, Ei, Ec):
+@pytest.mark.parametrize("use_saved", [False, True])
+@pytest.mark.parametrize("B,Tn,Ei,Ec", [(5, 7, 8, 8), (40, 70, 64, 64), (3, 33, 32, 96), (300, 64, 64, 64),
+                                        (2, 1, 64, 64)])
+def test_attention_pool_bwd_vs_oracle(engine_lib, B, Tn, Ei, Ec, use_saved):
+    """use_saved: the backward runs on the forward's saved output and layer-1 activations (the compile-time-shaped
+    kernel pair for E 128 / 80-40-1; other shapes save nothing and recompute), else it recomputes everything."""
     from paddlerec_amd import ops
     rng = np.random.default_rng(B * Tn)
     ni, nc, E = 200, 41, Ei + Ec
@@ -112,8 +116,11 @@ def test_attention_pool_bwd_vs_oracle(engine_lib, B, Tn, Ei, Ec):
     ab = [rng.uniform(-0.1, 0.1, s).astype(np.float32) for s in ((80,), (40,), (1,))]
     dout = rng.standard_normal((B, E)).astype(np.float32)
     taw, tab, tt = [T(w) for w in aw], [T(b) for b in ab], [T(t) for t in tabs]
-    out, attw, _ = ops.din_attention_pool(T(hi), T(hc), T(tis), T(tcs), T(mask), *tt, taw, tab)
-    dh, dq = ops.din_attention_pool_bwd(T(hi), T(hc), T(tis), T(tcs), *tt, taw, tab, attw, T(dout))
+    saved = {} if use_saved else None
+    out, attw, _ = ops.din_attention_pool(T(hi), T(hc), T(tis), T(tcs), T(mask), *tt, taw, tab, saved=saved)
+    if use_saved:
+        assert (saved["act1"] is not None) == (E == 128)
+    dh, dq = ops.din_attention_pool_bwd(T(hi), T(hc), T(tis), T(tcs), *tt, taw, tab, attw, T(dout), saved=saved)
     h = np.concatenate([tabs[0][hi], tabs[1][hc]], 2)
     q = np.concatenate([tabs[2][tis], tabs[3][tcs]], 2)
     ref = Dn.attention_pool_backward(h.astype(np.float64), q.astype(np.float64), mask.astype(np.float64),

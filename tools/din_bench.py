@@ -65,7 +65,8 @@ def main():
         aw = [torch.randn(s, device=DEV, generator=g) * 0.2 for s in ((512, 80), (80, 40), (40, 1))]
         ab = [torch.randn(s, device=DEV, generator=g) * 0.1 for s in (80, 40, 1)]
         st = ops.new_status(DEV)
-        out, attw, _ = ops.din_attention_pool(hi, hc, ti, tc, mask, *tabs, aw, ab, st)
+        saved = {}
+        out, attw, _ = ops.din_attention_pool(hi, hc, ti, tc, mask, *tabs, aw, ab, st, saved=saved)
         n = min(B, 16)
         d_out = torch.randn(B, 128, device=DEV, generator=g)
         ref = torch_ref(n, hi, hc, ti, tc, mask, tabs, aw, ab, d_out if args.bwd else None)
@@ -73,15 +74,20 @@ def main():
         e_w = float((attw[:n].double() - ref[1]).abs().max())
         assert int(st.item()) == 0, "status flags %d" % int(st.item())
         t = timeit(lambda: ops.din_attention_pool(hi, hc, ti, tc, mask, *tabs, aw, ab, st), args.iters)
+        t_s = timeit(lambda: ops.din_attention_pool(hi, hc, ti, tc, mask, *tabs, aw, ab, st, saved=saved), args.iters)
         fl = 2.0 * B * T * (512 * 80 + 80 * 40 + 40 + 128)
-        print("[%s] fwd B=%d T=%d: %.3f ms  %.2f TF  %.1f M positions/s   (err out %.1e, weights %.1e)"
-              % (tag, B, T, t, fl / t / 1e9, B * T / t / 1e3, e_out, e_w), flush=True)
+        print("[%s] fwd B=%d T=%d: %.3f ms  %.2f TF  %.1f M positions/s  (saving act1: %.3f ms)  (err out %.1e, weights %.1e)"
+              % (tag, B, T, t, fl / t / 1e9, B * T / t / 1e3, t_s, e_out, e_w), flush=True)
         if args.bwd:
-            dh, dq = ops.din_attention_pool_bwd(hi, hc, ti, tc, *tabs, aw, ab, attw, d_out)
+            dh, dq = ops.din_attention_pool_bwd(hi, hc, ti, tc, *tabs, aw, ab, attw, d_out, saved=saved)
             e_h = float((dh[:n].double() - ref[2]).abs().max() / ref[2].abs().max())
             e_q = float((dq[:n].double() - ref[3]).abs().max() / ref[3].abs().max())
-            t = timeit(lambda: ops.din_attention_pool_bwd(hi, hc, ti, tc, *tabs, aw, ab, attw, d_out), args.iters)
-            flb = 2.0 * B * T * (2 * 512 * 80 + 3 * 80 * 40 + 2 * 40 + 2 * 128)   # recompute + dz1 W1^T, dz2 W2^T
+            t = timeit(lambda: ops.din_attention_pool_bwd(hi, hc, ti, tc, *tabs, aw, ab, attw, d_out, saved=saved),
+                       args.iters)
+            on_saved = saved.get("act1") is not None and "REC_DIN_BWD_GENERIC" not in os.environ
+            # executed: dz1 W1^T, a2 recompute, dz2 W2^T, dout . h  (+ the layer-1 recompute and the first pass over the
+            # history when the activations were not saved)
+            flb = 2.0 * B * T * (512 * 80 + 2 * 80 * 40 + 128 + (0 if on_saved else 512 * 80 + 128))
             print("[%s] bwd B=%d T=%d: %.3f ms  %.2f TF executed  (err dh %.1e, dq %.1e)"
                   % (tag, B, T, t, flb / t / 1e9, e_h, e_q), flush=True)
 
