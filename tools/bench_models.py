@@ -88,5 +88,27 @@ for B, T in ((32, 152), (4096, 100), (4096, 512)):
             "gather_roofline": {"bound": "hbm", "achieved": by / t / 1e6, "peak": PEAK_GBS, "unit": "GB/s",
                                 "frac": by / t / 1e6 / PEAK_GBS, "bytes": by}})
 
+# ---- DIN full train step (din/dygraph_model.py:85-100): attention-pool fwd + bwd, the concat MLP, 7 row-merged SGDs
+from paddlerec_amd.din import DINLayer  # noqa: E402
+
+for B, T in ((32, 152), (4096, 100), (4096, 512)):
+    m = DINLayer(64, 64, "sigmoid", False, True, 63001, 801, device=DEV)
+    hi = torch.randint(0, 63001, (B, T), device=DEV, generator=g)
+    hc = torch.randint(0, 801, (B, T), device=DEV, generator=g)
+    ti = torch.randint(0, 63001, (B, 1), device=DEV, generator=g)
+    tc = torch.randint(0, 801, (B, 1), device=DEV, generator=g)
+    lens = torch.randint(1, T + 1, (B, 1), device=DEV, generator=g)
+    mask = torch.where(torch.arange(T, device=DEV)[None] < lens, 0, -1000000000).long()
+    label = (torch.rand(B, 1, device=DEV, generator=g) < 0.5).float()
+    tis, tcs = ti.expand(B, T).contiguous(), tc.expand(B, T).contiguous()
+    t = timeit(lambda: m.train_step(hi, hc, ti, tc, label, mask, tis, tcs))
+    fl = 2.0 * B * T * (512 * 80 + 80 * 40 + 40 + 128) + 2.0 * B * T * (512 * 80 + 2 * 80 * 40 + 128)
+    print("DIN train step B=%d T=%d: %.3f ms  (%.1f k samples/s, %.1f M positions/s, attention fwd+bwd %.1f TF executed)"
+          % (B, T, t, B / t, B * T / t / 1e3, fl / t / 1e9))
+    record("configs[3]", "DIN train step (attention-pool fwd + bwd on saved activations, concat MLP, row-merged SGD on "
+           "7 tables), B %d, T %d" % (B, T), t, fl, B, {"positions_per_s": B * T / t * 1e3})
+    del m
+    torch.cuda.empty_cache()
+
 for d in JSON:
     print(json.dumps(d))
