@@ -440,6 +440,39 @@ int rec_softmax_rows(int64_t m, int32_t n, const float* x, int32_t ldx, float* y
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * xDeepFM Compressed Interaction Network (models/rank/xdeepfm/net.py:155-202), the passes around the GEMM.
+ * Every X_k (k >= 1) is kept d-major, XT[(b,d), c] (row = b*D + d), so the reference's 1x1 Conv2D over the F*S
+ * interaction channels (net.py:176-190) is one row-major GEMM  XT_{k+1} = Z @ Wc^T  with M = B*D, K = F*S, N = C
+ * (rec_gemm_f32; Wc^T is the conv weight [C, F*S, 1, 1] viewed [C, F*S], passed with trans_b).
+ *   rec_cin_view: element (b, j, d) of a feature tensor sits at base + b*stride_b + j*stride_j + d*stride_d
+ *                 floats — feat_embeddings [B,F,D] is {F*D, D, 1}; an XT [B*D, ld] is {D*ld, 1, ld}.
+ *   rec_cin_outer_fwd : Z[(b,d), f*S + s] = X0[b,f,d] * Xk[b,s,d]                    net.py:163-175
+ *   rec_cin_outer_bwd : dX0[b,f,d] (+)= sum_s dZ[(b,d), f*S+s] Xk[b,s,d]
+ *                       dXk[b,s,d] (+)= sum_f dZ[(b,d), f*S+s] X0[b,f,d]  (+ dpool[b,s]: the gradient of the
+ *                       sum-pooled features of that layer, every d row gets it).  dX0 and dXk may alias
+ *                       (layer 1, Xk = X0: pass both accumulate flags).
+ *   rec_cin_sumpool(_bwd): pooled[b,c] = sum_d XT[(b,d), c]  (net.py:195-198) and its broadcast backward.
+ * Z for a whole batch is B*D*F*S floats (11.8 GB at B 65536, D 9, 39 x 128): callers walk the batch in chunks.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t stride_b;
+  int32_t stride_j, stride_d;
+} rec_cin_view;
+
+int rec_cin_outer_fwd(int64_t batch, int32_t emb_dim, int32_t F, int32_t S, const float* X0,
+                      const rec_cin_view* v0, const float* Xk, const rec_cin_view* vk, float* Z, int64_t ldz,
+                      void* stream);
+int rec_cin_outer_bwd(int64_t batch, int32_t emb_dim, int32_t F, int32_t S, const float* dZ, int64_t ldz,
+                      const float* X0, const rec_cin_view* v0, const float* Xk, const rec_cin_view* vk,
+                      float* dX0, const rec_cin_view* dv0, int32_t accumulate_dx0, float* dXk,
+                      const rec_cin_view* dvk, int32_t accumulate_dxk, const float* dpool, int64_t ld_dpool,
+                      void* stream);
+int rec_cin_sumpool(int64_t batch, int32_t emb_dim, int32_t C, const float* XT, int64_t ldx, float* out,
+                    int64_t ldo, void* stream);
+int rec_cin_sumpool_bwd(int64_t batch, int32_t emb_dim, int32_t C, const float* dpool, int64_t ldp,
+                        float* dXT, int64_t ldx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * f32 GEMM on the matrix cores with fused epilogues: C[M,N] = epi(op(A)[M,K] @ op(B)[K,N]).
  * Replaces paddle.nn.Linear / paddle.matmul (+ the elementwise ops around them) on the hot path:
  *   top MLP fwd/bwd  deepfm/net.py:142-174, dcn_v2/net.py:140-184, din/net.py:104-137,175-181

@@ -252,6 +252,60 @@ def golden_din(seed):
     print("din loss=%.6f" % float(loss))
 
 
+def golden_xdeepfm(D, seed):
+    """models/rank/xdeepfm/net.py:23-242 + xdeepfm/dygraph_model.py:53-58 (loss).  Two CIN layers so that the second
+    one consumes a d-major X_k, a DNN of two hidden layers."""
+    import paddle  # the shim
+    net = load_ref_module("models/rank/xdeepfm/net.py", "ref_xdeepfm_net")
+    rng = np.random.default_rng(seed)
+    N, S, Dn, B, cin, dnn = 1001, 26, 13, 12, [8, 4], [32, 16]
+    torch.manual_seed(seed)
+    model = net.xDeepFMLayer(N, D, Dn, S, cin, dnn)
+    with torch.no_grad():
+        # Constant(1.0) dense weights are all equal (would hide a swapped weight) and the tiny initial CIN / DNN
+        # weights make those branches vanish beside y_linear: rescale so every branch moves the logit
+        model.fm.dense_w_one.copy_(torch.as_tensor(0.2 * (1.0 + 0.5 * rng.standard_normal(Dn)).astype(np.float32)))
+        model.fm.dense_w.copy_(torch.as_tensor(0.5 * (1.0 + 0.5 * rng.standard_normal((1, Dn, D))).astype(np.float32)))
+        model.fm.embedding.weight.mul_(12.0)
+        model.bias.copy_(torch.as_tensor(np.asarray([0.21], np.float32)))
+        model.cin.cin_linear.weight.mul_(16.0)
+        model.cin.cin_linear.bias.copy_(torch.as_tensor(np.asarray([-0.13], np.float32)))
+        for lin in model.dnn._mlp_layers:
+            if hasattr(lin, "weight"):
+                lin.weight.mul_(10.0)
+                lin.bias.copy_(torch.as_tensor(0.1 * rng.standard_normal(lin.bias.shape[0]).astype(np.float32)))
+    ids = make_ids(rng, B, S, N)
+    dense = rng.random((B, Dn), dtype=np.float32)
+    label = (rng.random((B, 1)) < 0.3).astype(np.int64)
+    sparse_inputs = [paddle.to_tensor(ids[:, s:s + 1]) for s in range(S)]
+    pred = model.forward(sparse_inputs, paddle.to_tensor(dense))
+    cost = paddle.nn.functional.log_loss(input=pred, label=paddle.cast(paddle.to_tensor(label), dtype="float32"))
+    loss = paddle.mean(x=cost)
+    y_linear, feat = model.fm.forward(sparse_inputs, paddle.to_tensor(dense))
+    y_cin, y_dnn = model.cin.forward(feat), model.dnn.forward(feat)
+    loss.backward()
+    lins = [l for l in model.dnn._mlp_layers if hasattr(l, "weight")]
+    g = dict(ids=ids, dense=dense, label=label, D=np.int64(D),
+             W=npy(model.fm.embedding.weight), W1=npy(model.fm.embedding_one.weight),
+             dense_w=npy(model.fm.dense_w), dense_w_one=npy(model.fm.dense_w_one), bias=npy(model.bias),
+             fc_w=npy(model.cin.cin_linear.weight), fc_b=npy(model.cin.cin_linear.bias),
+             pred=npy(pred), loss=npy(loss), y1=npy(y_linear), feat=npy(feat), y_cin=npy(y_cin), y_dnn=npy(y_dnn),
+             gW=npy(model.fm.embedding.weight.grad), gW1=npy(model.fm.embedding_one.weight.grad),
+             g_dense_w=npy(model.fm.dense_w.grad), g_dense_w_one=npy(model.fm.dense_w_one.grad),
+             g_bias=npy(model.bias.grad), g_fc_w=npy(model.cin.cin_linear.weight.grad),
+             g_fc_b=npy(model.cin.cin_linear.bias.grad), n_cin=np.int64(len(cin)), n_mlp=np.int64(len(lins)),
+             state_keys=np.array(sorted(model.state_dict().keys())))
+    for i, conv in enumerate(model.cin.cnn_layers):
+        g["cin_w%d" % i], g["g_cin_w%d" % i] = npy(conv.weight), npy(conv.weight.grad)
+    for i, lin in enumerate(lins):
+        g["mlp_w%d" % i], g["mlp_b%d" % i] = npy(lin.weight), npy(lin.bias)
+        g["g_mlp_w%d" % i], g["g_mlp_b%d" % i] = npy(lin.weight.grad), npy(lin.bias.grad)
+    np.savez_compressed(os.path.join(OUT, f"xdeepfm_D{D}.npz"), **g)
+    print("xdeepfm D=%d loss=%.6f pred range %.3f..%.3f  y1 %.2f y_cin %.2f y_dnn %.2f (abs means)" % (
+        D, float(loss.detach()), float(pred.detach().min()), float(pred.detach().max()), float(y_linear.detach().abs().mean()),
+        float(y_cin.detach().abs().mean()), float(y_dnn.detach().abs().mean())))
+
+
 def golden_slot_dnn(D, seed):
     """models/rank/slot_dnn/net.py:21-85 (BenchmarkDNNLayer) + static_model.py:104-108 (loss): multi-value slots over
     ONE shared table, sum-pooled per slot, concat, MLP, sigmoid(clip(+-15))."""
@@ -322,6 +376,6 @@ if __name__ == "__main__":
             "dcn_v2_v2": lambda: golden_dcn_v2(False, 20250406), "dcn_v2_mix": lambda: golden_dcn_v2(True, 20250407),
             "din": lambda: golden_din(20250408), "fm_D9": lambda: golden_fm(9, 20250409),
             "wide_deep_D9": lambda: golden_wide_deep(9, 20250410), "dnn_D9": lambda: golden_dnn(9, 20250411),
-            "slot_dnn_D9": lambda: golden_slot_dnn(9, 20250412)}
+            "slot_dnn_D9": lambda: golden_slot_dnn(9, 20250412), "xdeepfm_D9": lambda: golden_xdeepfm(9, 20250413)}
     for name in (sys.argv[1:] or list(jobs)):      # optional: only the named fixtures
         jobs[name]()

@@ -84,3 +84,20 @@ class Dropout(Layer):
 
 class Conv1D(Layer):  # imported by din/net.py:13, never used
     pass
+
+
+class Conv2D(Layer):
+    """NCHW convolution, weight [out, in, kh, kw] (xdeepfm/net.py:133-143 uses 1x1, bias_attr=False)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, weight_attr=None, bias_attr=None, name=None):
+        super().__init__()
+        kh, kw = (kernel_size, kernel_size) if isinstance(kernel_size, int) else kernel_size
+        self.weight = _t.nn.Parameter(_t.empty(out_channels, in_channels, kh, kw))
+        _init_from(weight_attr, self.weight, initializer.XavierUniform())
+        self.bias = None
+        if bias_attr is not False:
+            self.bias = _t.nn.Parameter(_t.zeros(out_channels))
+            _init_from(bias_attr, self.bias, initializer.Constant(0.0))
+
+    def forward(self, x):
+        return _t.nn.functional.conv2d(x, self.weight, self.bias)

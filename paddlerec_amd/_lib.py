@@ -36,6 +36,10 @@ class GradLayout(C.Structure):
                 ("partials", C.c_void_p), ("index", C.c_void_p)]
 
 
+class CinView(C.Structure):
+    _fields_ = [("stride_b", C.c_int64), ("stride_j", C.c_int32), ("stride_d", C.c_int32)]
+
+
 class PsAccessor(C.Structure):
     _fields_ = [("lr", C.c_float), ("initial_g2sum", C.c_float), ("min_bound", C.c_float), ("max_bound", C.c_float),
                 ("initial_range", C.c_float), ("embedx_threshold", C.c_float), ("nonclk_coeff", C.c_float),
@@ -143,6 +147,11 @@ SIGNATURES = {
                                    _P, _I32, _P]),
     "rec_softmax_rows_bwd": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P, _I32, _P]),
     "rec_softmax_rows": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P]),
+    "rec_cin_outer_fwd": (C.c_int, [_I64, _I32, _I32, _I32, _P, C.POINTER(CinView), _P, C.POINTER(CinView), _P, _I64, _P]),
+    "rec_cin_outer_bwd": (C.c_int, [_I64, _I32, _I32, _I32, _P, _I64, _P, C.POINTER(CinView), _P, C.POINTER(CinView),
+                                    _P, C.POINTER(CinView), _I32, _P, C.POINTER(CinView), _I32, _P, _I64, _P]),
+    "rec_cin_sumpool": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _I64, _P]),
+    "rec_cin_sumpool_bwd": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _I64, _P]),
     "rec_cross_bwd_prep": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _I32, _P]),
     "rec_logloss_workspace_bytes": (C.c_int, [_I64, C.POINTER(_SZ)]),
     "rec_sigmoid_logloss": (C.c_int, [_I64, _I64, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _SZ, _P]),

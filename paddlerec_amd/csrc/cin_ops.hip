@@ -1,0 +1,175 @@
+// xDeepFM's Compressed Interaction Network around the GEMM (gfx950).
+//
+// Reference: /root/reference/models/rank/xdeepfm/net.py:155-202 — per layer
+//   Z[b,d,f,s] = X0[b,f,d] * Xk[b,s,d]          (matmul of a [F,1] by a [1,S] per (b,d))   net.py:163-173
+//   X_{k+1}[b,c,d] = sum_{f,s} Wc[c, f*S+s] Z[b,d,f,s]   (1x1 Conv2D over F*S channels)    net.py:176-190
+//   pooled[b, c] = sum_d X_{k+1}[b,c,d]                                                     net.py:195-198
+// Here every X_k (k >= 1) is kept "d-major", XT[(b,d), c], so that the compression is ONE row-major GEMM
+//   XT_{k+1}[(b,d), :] = Z[(b,d), :] @ Wc^T          M = B*D, K = F*S, N = C           (rec_gemm_f32)
+// and these kernels are the HBM-bound passes either side of it: the outer-product rows Z (written once, read by
+// the GEMM; batch-chunked by the caller), its backward (dZ read once -> dX0, dXk), the sum over d and its broadcast.
+// No reshapes / transposes of [B,F,D] tensors exist anywhere: X0 = feat_embeddings is read through a strided view.
+#include "rec_common.h"
+
+namespace rec {
+namespace {
+
+struct View { int64_t sb; int sj, sd; };
+__device__ __forceinline__ int64_t at(const View& v, int64_t b, int j, int d) { return b * v.sb + (int64_t)j * v.sj + (int64_t)d * v.sd; }
+
+// One block walks rows (b,d); thread (fr, sc): columns [sc*VEC, sc*VEC+VEC) of Z's f-rows fr, fr+FR, ...
+// Its Xk values are loaded once per row; X0[f] is a broadcast load per f (L1-resident: F floats per row).
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void cin_outer_fwd_kernel(int64_t rows, int D, int F, int S, const float* __restrict__ X0,
+                                                               View v0, const float* __restrict__ Xk, View vk,
+                                                               float* __restrict__ Z, int64_t ldz, int tpr) {
+  const int sc = threadIdx.x % tpr, fr = threadIdx.x / tpr, FR = kBlock / tpr;
+  const int s0 = sc * VEC;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int64_t b = r / D;
+    const int d = (int)(r - b * D);
+    if (s0 >= S) continue;
+    float kv[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) kv[i] = Xk[at(vk, b, s0 + i, d)];
+    float* zrow = Z + r * ldz + s0;
+    for (int f = fr; f < F; f += FR) {
+      const float x = X0[at(v0, b, f, d)];
+      float o[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] = x * kv[i];
+      vstore<VEC>(zrow + (int64_t)f * S, o);
+    }
+  }
+}
+
+// One block per row (b,d): the dZ row (F x S) staged in LDS (pitch S+1), then
+//   dXk[s] = sum_f dZ[f,s] X0[f]  (+ dpool[b,s])      dX0[f] = sum_s dZ[f,s] Xk[s]
+// element e of either output is always produced by thread e % kBlock, so the two may alias (layer 1: Xk == X0).
+__global__ __launch_bounds__(kBlock) void cin_outer_bwd_kernel(int64_t rows, int D, int F, int S, const float* __restrict__ dZ,
+                                                               int64_t ldz, const float* __restrict__ X0, View v0,
+                                                               const float* __restrict__ Xk, View vk, float* dX0,
+                                                               View dv0, int acc0, float* dXk, View dvk, int acck,
+                                                               const float* __restrict__ dpool, int64_t ldp) {
+  extern __shared__ float smem[];
+  const int SP = S + 1;
+  float* dz = smem;             // [F][SP]
+  float* x0s = dz + F * SP;     // [F]
+  float* xks = x0s + F;         // [S]
+  const int tid = threadIdx.x;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int64_t b = r / D;
+    const int d = (int)(r - b * D);
+    const float* zrow = dZ + r * ldz;
+    for (int i = tid; i < F * S; i += kBlock) {
+      const int f = i / S, s = i - f * S;
+      dz[f * SP + s] = zrow[i];
+    }
+    for (int f = tid; f < F; f += kBlock) x0s[f] = X0[at(v0, b, f, d)];
+    for (int s = tid; s < S; s += kBlock) xks[s] = Xk[at(vk, b, s, d)];
+    __syncthreads();
+    for (int f = tid; f < F; f += kBlock) {
+      float a = 0.f;
+      for (int s = 0; s < S; ++s) a += dz[f * SP + s] * xks[s];
+      float* o = dX0 + at(dv0, b, f, d);
+      *o = (acc0 ? *o : 0.f) + a;
+    }
+    for (int s = tid; s < S; s += kBlock) {
+      float a = 0.f;
+      for (int f = 0; f < F; ++f) a += dz[f * SP + s] * x0s[f];
+      if (dpool) a += dpool[b * ldp + s];
+      float* o = dXk + at(dvk, b, s, d);
+      *o = (acck ? *o : 0.f) + a;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cin_sumpool_kernel(int64_t B, int D, int C, const float* __restrict__ XT, int64_t ldx,
+                                                             float* __restrict__ out, int64_t ldo) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B * C) return;
+  const int64_t b = i / C;
+  const int c = (int)(i - b * C);
+  float a = 0.f;
+  for (int d = 0; d < D; ++d) a += XT[(b * D + d) * ldx + c];     // fixed order over d
+  out[b * ldo + c] = a;
+}
+
+__global__ __launch_bounds__(kBlock) void cin_sumpool_bwd_kernel(int64_t B, int D, int C, const float* __restrict__ dpool,
+                                                                 int64_t ldp, float* __restrict__ dXT, int64_t ldx) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= B * D * C) return;
+  const int64_t r = i / C;
+  const int c = (int)(i - r * C);
+  dXT[r * ldx + c] = dpool[(r / D) * ldp + c];
+}
+
+View view_of(const rec_cin_view* v) { return View{v->stride_b, v->stride_j, v->stride_d}; }
+
+}  // namespace
+}  // namespace rec
+
+using namespace rec;
+
+extern "C" int rec_cin_outer_fwd(int64_t batch, int32_t emb_dim, int32_t F, int32_t S, const float* X0,
+                                 const rec_cin_view* v0, const float* Xk, const rec_cin_view* vk, float* Z,
+                                 int64_t ldz, void* stream) {
+  REC_REQUIRE(batch >= 0 && emb_dim > 0 && F > 0 && S > 0 && ldz >= (int64_t)F * S, REC_EINVAL, "bad sizes");
+  if (batch == 0) return REC_OK;
+  REC_REQUIRE(X0 && Xk && Z && v0 && vk, REC_EINVAL, "null pointer argument");
+  const int64_t rows = batch * emb_dim;
+  const bool vec = S % 4 == 0 && ldz % 4 == 0 && ((uintptr_t)Z % 16) == 0;
+  const int cols = vec ? S / 4 : S;
+  REC_REQUIRE(cols <= kBlock, REC_ESHAPE, "previous CIN layer too wide (%d)", S);
+  const int tpr = pow2_ceil(cols);
+  const int64_t grid = rows < 64 * 1024 ? rows : 64 * 1024;
+  if (vec)
+    hipLaunchKernelGGL(cin_outer_fwd_kernel<4>, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, rows,
+                       emb_dim, F, S, X0, view_of(v0), Xk, view_of(vk), Z, ldz, tpr);
+  else
+    hipLaunchKernelGGL(cin_outer_fwd_kernel<1>, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, rows,
+                       emb_dim, F, S, X0, view_of(v0), Xk, view_of(vk), Z, ldz, tpr);
+  return check_launch("rec_cin_outer_fwd");
+}
+
+extern "C" int rec_cin_outer_bwd(int64_t batch, int32_t emb_dim, int32_t F, int32_t S, const float* dZ, int64_t ldz,
+                                 const float* X0, const rec_cin_view* v0, const float* Xk, const rec_cin_view* vk,
+                                 float* dX0, const rec_cin_view* dv0, int32_t accumulate_dx0, float* dXk,
+                                 const rec_cin_view* dvk, int32_t accumulate_dxk, const float* dpool,
+                                 int64_t ld_dpool, void* stream) {
+  REC_REQUIRE(batch >= 0 && emb_dim > 0 && F > 0 && S > 0 && ldz >= (int64_t)F * S, REC_EINVAL, "bad sizes");
+  if (batch == 0) return REC_OK;
+  REC_REQUIRE(dZ && X0 && Xk && dX0 && dXk && v0 && vk && dv0 && dvk, REC_EINVAL, "null pointer argument");
+  const size_t shmem = sizeof(float) * ((size_t)F * (S + 1) + F + S);
+  REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "CIN row of %d x %d does not fit the LDS stage", F, S);
+  const int64_t rows = batch * emb_dim;
+  int64_t grid = resident_blocks(cin_outer_bwd_kernel, kBlock, shmem);
+  if (grid > rows) grid = rows;
+  hipLaunchKernelGGL(cin_outer_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), shmem, (hipStream_t)stream, rows,
+                     emb_dim, F, S, dZ, ldz, X0, view_of(v0), Xk, view_of(vk), dX0, view_of(dv0), accumulate_dx0, dXk,
+                     view_of(dvk), accumulate_dxk, dpool, ld_dpool);
+  return check_launch("rec_cin_outer_bwd");
+}
+
+extern "C" int rec_cin_sumpool(int64_t batch, int32_t emb_dim, int32_t C, const float* XT, int64_t ldx, float* out,
+                               int64_t ldo, void* stream) {
+  REC_REQUIRE(batch >= 0 && emb_dim > 0 && C > 0 && ldx >= C && ldo >= C, REC_EINVAL, "bad sizes");
+  if (batch == 0) return REC_OK;
+  REC_REQUIRE(XT && out, REC_EINVAL, "null pointer argument");
+  const int64_t n = batch * C;
+  hipLaunchKernelGGL(cin_sumpool_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, batch, emb_dim, C, XT, ldx, out, ldo);
+  return check_launch("rec_cin_sumpool");
+}
+
+extern "C" int rec_cin_sumpool_bwd(int64_t batch, int32_t emb_dim, int32_t C, const float* dpool, int64_t ldp,
+                                   float* dXT, int64_t ldx, void* stream) {
+  REC_REQUIRE(batch >= 0 && emb_dim > 0 && C > 0 && ldx >= C && ldp >= C, REC_EINVAL, "bad sizes");
+  if (batch == 0) return REC_OK;
+  REC_REQUIRE(dpool && dXT, REC_EINVAL, "null pointer argument");
+  const int64_t n = batch * emb_dim * C;
+  hipLaunchKernelGGL(cin_sumpool_bwd_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, batch, emb_dim, C, dpool, ldp, dXT, ldx);
+  return check_launch("rec_cin_sumpool_bwd");
+}

@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (EPI, AdagradHyper, AdamHyper, DeepFMDesc, DinDesc, GemmDesc, GemmEpilogueArgs, GradLayout,
+from ._lib import (EPI, AdagradHyper, AdamHyper, CinView, DeepFMDesc, DinDesc, GemmDesc, GemmEpilogueArgs, GradLayout,
                    GradSrc, LazyInit, MultislotDesc, PsAccessor, PsLayout, RecError, check, lib)
 
 
@@ -630,6 +630,73 @@ def din_attention_pool_bwd(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_his
         _p(att_w[1]), _p(att_b[1]), _p(att_w[2]), _p(att_weight), _p(out_s), _p(act1_s), _p(d_out), _p(dh), _p(dq),
         _stream()), "rec_din_attention_pool_bwd")
     return dh, dq
+
+
+# ------------------------------------------------------------------ xDeepFM CIN (the passes around the GEMM)
+def _chk_f32(t, name):
+    if not t.is_cuda:
+        raise RecError("%s must be a device tensor (no CPU fallback)" % name)
+    if t.dtype != torch.float32:
+        raise RecError("%s must be float32, got %s" % (name, t.dtype))
+
+
+def cin_view(t, kind):
+    """rec_cin_view of a feature tensor: kind "bfd" = [B,F,D] (feat_embeddings, any strides), "xt" = (tensor [B*D, C],
+    D): a CIN layer's d-major GEMM output (row stride allowed, unit column stride)."""
+    if kind == "bfd":
+        _chk_f32(t, "feature tensor")
+        return CinView(t.stride(0), t.stride(1), t.stride(2))
+    x, D = t
+    return CinView(D * _chk_mat(x, "XT"), 1, _chk_mat(x, "XT"))
+
+
+def cin_outer_fwd(B, D, F, S, X0, v0, Xk, vk, Z):
+    """Z[(b,d), f*S+s] = X0[b,f,d] * Xk[b,s,d]   (xdeepfm/net.py:163-175).  Z [B*D, F*S] f32."""
+    _chk_f32(X0, "X0")
+    _chk_f32(Xk, "Xk")
+    ldz = _chk_mat(Z, "Z")
+    if tuple(Z.shape) != (B * D, F * S):
+        raise RecError("Z must be [B*D, F*S]")
+    check(lib().rec_cin_outer_fwd(B, D, F, S, _p(X0), C.byref(v0), _p(Xk), C.byref(vk), _p(Z), ldz, _stream()),
+          "rec_cin_outer_fwd")
+    return Z
+
+
+def cin_outer_bwd(B, D, F, S, dZ, X0, v0, Xk, vk, dX0, dv0, acc0, dXk, dvk, acck, dpool=None):
+    """dX0 (+)= dZ . Xk over s;  dXk (+)= dZ . X0 over f (+ dpool[b,s] on every d row)."""
+    for t, n in ((X0, "X0"), (Xk, "Xk"), (dX0, "dX0"), (dXk, "dXk")):
+        _chk_f32(t, n)
+    ldz = _chk_mat(dZ, "dZ")
+    if tuple(dZ.shape) != (B * D, F * S):
+        raise RecError("dZ must be [B*D, F*S]")
+    ldp = 0
+    if dpool is not None:
+        ldp = _chk_mat(dpool, "dpool")
+        if tuple(dpool.shape) != (B, S):
+            raise RecError("dpool must be [B, S]")
+    check(lib().rec_cin_outer_bwd(B, D, F, S, _p(dZ), ldz, _p(X0), C.byref(v0), _p(Xk), C.byref(vk), _p(dX0),
+                                  C.byref(dv0), int(acc0), _p(dXk), C.byref(dvk), int(acck), _p(dpool), ldp, _stream()),
+          "rec_cin_outer_bwd")
+
+
+def cin_sumpool(B, D, XT, out):
+    """out[b,c] = sum_d XT[(b,d), c]   (net.py:195-198); out may be a column window of the pooled-feature row."""
+    ldx, ldo = _chk_mat(XT, "XT"), _chk_mat(out, "out")
+    Cc = XT.shape[1]
+    if XT.shape[0] != B * D or tuple(out.shape) != (B, Cc):
+        raise RecError("XT must be [B*D, C] and out [B, C]")
+    check(lib().rec_cin_sumpool(B, D, Cc, _p(XT), ldx, _p(out), ldo, _stream()), "rec_cin_sumpool")
+    return out
+
+
+def cin_sumpool_bwd(B, D, dpool, dXT):
+    """dXT[(b,d), c] = dpool[b,c]."""
+    ldp, ldx = _chk_mat(dpool, "dpool"), _chk_mat(dXT, "dXT")
+    Cc = dpool.shape[1]
+    if tuple(dXT.shape) != (B * D, Cc) or dpool.shape[0] != B:
+        raise RecError("dXT must be [B*D, C] and dpool [B, C]")
+    check(lib().rec_cin_sumpool_bwd(B, D, Cc, _p(dpool), ldp, _p(dXT), ldx, _stream()), "rec_cin_sumpool_bwd")
+    return dXT
 
 
 def sparse_sgd_rows(groups, grad, P, lr, grad_div=1, grad_group=0, grad_group_stride=0, partials=None):

@@ -10,7 +10,7 @@ What differs by construction: a batch never becomes 28 per-sample NumPy arrays (
 [B,26] / [B,13] device tensors), `loss.backward(); optimizer.step()` is the explicit `train_step` chain of the
 host mirrors, and the AUC buckets stay on the device (read back only when a log line prints them).
 
-    python -m paddlerec_amd.trainer -m <config.yaml> [--model deepfm|fm|wide_deep|dnn|dcn_v2|din] [-o runner.epochs=1 ...] [--infer]
+    python -m paddlerec_amd.trainer -m <config.yaml> [--model deepfm|fm|wide_deep|dnn|dcn_v2|din|xdeepfm] [-o runner.epochs=1 ...] [--infer]
     python -m torch.distributed.run --nproc-per-node G -m paddlerec_amd.trainer -m <config.yaml>     # collective mode
 """
 import argparse
@@ -24,7 +24,7 @@ from . import checkpoint
 
 logger = logging.getLogger("paddlerec_amd.trainer")
 
-MODELS = ("deepfm", "fm", "wide_deep", "dnn", "dcn_v2", "din")
+MODELS = ("deepfm", "fm", "wide_deep", "dnn", "dcn_v2", "din", "xdeepfm")
 
 
 # ------------------------------------------------------------------------------------ configuration
@@ -83,6 +83,8 @@ def _dygraph_model(name):
         from .dcn_v2 import DygraphModel
     elif name == "din":
         from .din import DygraphModel
+    elif name == "xdeepfm":
+        from .xdeepfm import DygraphModel
     else:
         raise ValueError("unknown model %r (known: %s)" % (name, ", ".join(MODELS)))
     return DygraphModel()
@@ -189,7 +191,9 @@ def _apply_optimizer_config(config, model, dy_model):
     every row's moments decay each step) for the nets that implement both variants; the deviations of the others
     from the reference's dygraph semantics are logged once, loudly."""
     lazy = bool(config.get("hyper_parameters.optimizer.lazy_mode", False))
-    if hasattr(type(dy_model), "lazy_mode"):
+    if model == "xdeepfm":       # its create_optimizer asks for Adam(lazy_mode=True) itself (xdeepfm/dygraph_model.py:66-67)
+        logger.info("sparse optimizer: Adam lazy_mode=True (the reference's own setting for xdeepfm)")
+    elif hasattr(type(dy_model), "lazy_mode"):
         dy_model.lazy_mode = lazy
         logger.info("sparse optimizer: Adam lazy_mode=%s%s", lazy,
                     "" if lazy else " (dygraph default: the whole table is streamed every step)")

@@ -1,0 +1,241 @@
+"""rank/xdeepfm on the engine (the CIN sibling of DeepFM).
+
+Host mirror of /root/reference/models/rank/xdeepfm/net.py (`xDeepFMLayer` :23-55, `Linear` :58-124, `CIN` :127-202,
+`DNN` :205-242) and xdeepfm/dygraph_model.py (`DygraphModel`).
+
+    y_linear, feat = Linear(ids, dense)      net.py:104-124  == DeepFM's first-order term and feat_embeddings:
+                                             rec_deepfm_fm_fwd with padding_idx = none (its y2 is ignored)
+    y_cin  = CIN(feat)                       net.py:155-202  per layer  Z = X0 (x) Xk  (rec_cin_outer_fwd, batch chunks)
+                                             XT_{k+1} = Z @ Wc^T (rec_gemm_f32, M = B*D)   pooled += sum_d (rec_cin_sumpool)
+                                             y_cin = pooled @ cnn_fc.weight + cnn_fc.bias
+    y_dnn  = DNN(feat.reshape(B, F*D))       net.py:235-242  Linear+ReLU ... Linear(1)  (rec_gemm_f32 epilogues)
+    pred   = sigmoid(y_linear + bias + y_cin + y_dnn)        net.py:54
+Backward is the explicit chain (CIN: dZ = dXT @ Wc, dWc = dXT^T @ Z with Z recomputed per chunk, rec_cin_outer_bwd into
+d feat), L2Decay(1e-4) on the CIN / cnn_fc / DNN weights (net.py:139,150,219) added to their gradients, then the
+reference's optimizer: Adam(lazy_mode=True) (dygraph_model.py:60-64) — lazy rows fused per record, dense flat Adam.
+Parameter keys follow the reference's sublayer names; `cin.cin_linear.*` and `cin.cnn_fc.*` are the same tensors (the
+reference registers that Linear twice, net.py:146-153).
+"""
+import math
+
+import torch
+
+from .deepfm import NUM_THRESHOLDS, DeepFMLayer, _OnSide, _round_up, auc_metrics, slot_feeds
+
+L2_COEFF = 1e-4            # net.py:139,150,219
+Z_CHUNK_BYTES = 1 << 30    # the outer-product rows Z of a batch chunk stay under this
+
+
+class xDeepFMLayer(DeepFMLayer):
+    """xdeepfm/net.py:23-55.  forward(sparse_inputs, dense_inputs) -> predict [B,1]."""
+
+    def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim, sparse_num_field,
+                 layer_sizes_cin, layer_sizes_dnn, device="cuda", kernels=None):
+        F = dense_feature_dim + sparse_num_field
+        self.layer_sizes_cin = list(layer_sizes_cin)
+        extra, last = [], F
+        for i, c in enumerate(self.layer_sizes_cin):
+            extra.append(("cin.cnn_%d.weight" % i, (c, last * F, 1, 1)))          # Conv2D weight [out, in, 1, 1]
+            last = c
+        self.cin_total = sum(self.layer_sizes_cin)
+        extra += [("cin.cnn_fc.weight", (self.cin_total, 1)), ("cin.cnn_fc.bias", (1,))]
+        super().__init__(sparse_feature_number, sparse_feature_dim, dense_feature_dim, sparse_num_field,
+                         layer_sizes_dnn, device=device, zero_padding_row=False, kernels=kernels, extra_dense=extra)
+        self.fm.padding_idx = None                      # net.py:75-93: the Embeddings have no padding_idx
+        self.compact = False                            # the CIN reads every field of feat_embeddings, dense ones too
+        self.fp = self.num_field
+        p = self.dense.p
+        p["fm.dense_w_one"].fill_(1.0)                  # net.py:96-104 Constant(1.0)
+        p["fm.dense_w"].fill_(1.0)
+        D = sparse_feature_dim
+        sizes = [D * F] + self.layer_sizes + [1]
+        for i in range(self.n_linear):                  # net.py:216-221 Normal(std = 0.1 / sqrt(in))
+            p["dnn.linear_%d.weight" % i].normal_(0.0, 0.1 / math.sqrt(sizes[i]))
+        last = F
+        for i, c in enumerate(self.layer_sizes_cin):    # net.py:137-142 Normal(std = 1 / sqrt(last_s * num_field))
+            p["cin.cnn_%d.weight" % i].normal_(0.0, 1.0 / math.sqrt(last * F))
+            last = c
+        p["cin.cnn_fc.weight"].normal_(0.0, 0.1 / math.sqrt(self.cin_total))      # net.py:147-153
+        self.cin_w = [p["cin.cnn_%d.weight" % i].view(c, -1) for i, c in enumerate(self.layer_sizes_cin)]   # [C, F*S]
+        self.cin_dw = [self.dense.g["cin.cnn_%d.weight" % i].view(c, -1) for i, c in enumerate(self.layer_sizes_cin)]
+        self._decayed = ["cin.cnn_%d.weight" % i for i in range(len(self.layer_sizes_cin))] + ["cin.cnn_fc.weight"] + \
+                        ["dnn.linear_%d.weight" % i for i in range(self.n_linear)]
+        self._zbuf = None
+        self._bias_sum = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._zeros = None
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["cin.cin_linear.weight"], sd["cin.cin_linear.bias"] = sd["cin.cnn_fc.weight"], sd["cin.cnn_fc.bias"]
+        return sd
+
+    # -- CIN ----------------------------------------------------------------------------------------
+    def _chunks(self, B, K):
+        D = self.sparse_feature_dim
+        per = max(1, Z_CHUNK_BYTES // (4 * D * K))
+        return [(b0, min(B, b0 + per)) for b0 in range(0, B, per)]
+
+    def _z(self, rows, K):
+        """Grow-only scratch for the outer-product rows of one batch chunk (Z forward, dZ backward)."""
+        if self._zbuf is None or self._zbuf.numel() < rows * K:
+            self._zbuf = torch.empty(rows * K, dtype=torch.float32, device=self.device)
+        return self._zbuf[: rows * K].view(rows, K)
+
+    def _layer_inputs(self, feat, xts, i):
+        """(tensor, view maker) of X_i: feat_embeddings for layer 0, the previous layer's d-major output after."""
+        k, D = self.k, self.sparse_feature_dim
+        if i == 0:
+            return feat, (lambda t: k.cin_view(t, "bfd"))
+        return xts[i - 1], (lambda t: k.cin_view((t, D), "xt"))
+
+    def _cin_forward(self, feat):
+        """-> (pooled [B, sum C], [XT_1 .. XT_L])   XT_k [B*D, C_k] d-major."""
+        k, D = self.k, self.sparse_feature_dim
+        B, F, _ = feat.shape
+        pooled = torch.empty(B, self.cin_total, dtype=torch.float32, device=self.device)
+        xts, off, S = [], 0, F
+        for i, Cn in enumerate(self.layer_sizes_cin):
+            xk, mk = self._layer_inputs(feat, xts, i)
+            xt = torch.empty(B * D, Cn, dtype=torch.float32, device=self.device)
+            for b0, b1 in self._chunks(B, F * S):
+                n = b1 - b0
+                z = self._z(n * D, F * S)
+                xk_c = xk[b0:b1] if i == 0 else xk[b0 * D:b1 * D]
+                k.cin_outer_fwd(n, D, F, S, feat[b0:b1], k.cin_view(feat, "bfd"), xk_c, mk(xk_c), z)
+                k.gemm(z, self.cin_w[i], self.ws, trans_b=True, out=xt[b0 * D:b1 * D])        # net.py:190 (1x1 conv)
+            k.cin_sumpool(B, D, xt, pooled[:, off:off + Cn])                                   # net.py:195-198
+            xts.append(xt)
+            off, S = off + Cn, Cn
+        return pooled, xts
+
+    def _cin_backward(self, feat, xts, dpooled, dfeat):
+        """Accumulates the CIN's gradient w.r.t. feat_embeddings into dfeat [B,F,D]; writes the conv weight gradients."""
+        k, D = self.k, self.sparse_feature_dim
+        B, F, _ = feat.shape
+        L = len(self.layer_sizes_cin)
+        offs = [sum(self.layer_sizes_cin[:i]) for i in range(L)]
+        dxt = torch.empty(B * D, self.layer_sizes_cin[-1], dtype=torch.float32, device=self.device)
+        k.cin_sumpool_bwd(B, D, dpooled[:, offs[-1]:offs[-1] + self.layer_sizes_cin[-1]], dxt)
+        for i in reversed(range(L)):
+            Cn = self.layer_sizes_cin[i]
+            S = F if i == 0 else self.layer_sizes_cin[i - 1]
+            xk, mk = self._layer_inputs(feat, xts, i)
+            dxk = dfeat if i == 0 else torch.empty(B * D, S, dtype=torch.float32, device=self.device)
+            for ci, (b0, b1) in enumerate(self._chunks(B, F * S)):
+                n = b1 - b0
+                z = self._z(n * D, F * S)
+                xk_c = xk[b0:b1] if i == 0 else xk[b0 * D:b1 * D]
+                dxk_c = dxk[b0:b1] if i == 0 else dxk[b0 * D:b1 * D]
+                g = dxt[b0 * D:b1 * D]
+                k.cin_outer_fwd(n, D, F, S, feat[b0:b1], k.cin_view(feat, "bfd"), xk_c, mk(xk_c), z)      # recomputed
+                k.gemm(g, z, self.ws, trans_a=True, out=self.cin_dw[i],
+                       **(dict(epilogue="add", aux1=self.cin_dw[i]) if ci > 0 else {}))                   # dWc
+                k.gemm(g, self.cin_w[i], self.ws, out=z)                                                  # dZ (in place of Z)
+                dpool = None if i == 0 else dpooled[b0:b1, offs[i - 1]:offs[i - 1] + S]
+                k.cin_outer_bwd(n, D, F, S, z, feat[b0:b1], k.cin_view(feat, "bfd"), xk_c, mk(xk_c),
+                                dfeat[b0:b1], k.cin_view(dfeat, "bfd"), True, dxk_c, mk(dxk_c), i == 0, dpool)
+            dxt = dxk
+
+    def _logit_parts(self, ids, dense_inputs, keep=None):
+        k = self.k
+        y1, _, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
+        B = feat.shape[0]
+        pooled, xts = self._cin_forward(feat)
+        p = self.dense.p
+        self._bias_sum.copy_(p["cin.cnn_fc.bias"])
+        k.sgd_dense(self._bias_sum, p["bias"], -1.0)                      # cnn_fc.bias + bias (net.py:54)
+        y_cin = k.gemm(pooled, p["cin.cnn_fc.weight"], self.ws, epilogue="bias", bias=self._bias_sum)
+        y_dnn, acts = k.mlp_forward(feat.view(B, -1), self.mlp_w, self.mlp_b, self.ws_mlp)
+        if keep is not None:
+            keep.update(feat=feat, sum_emb=sum_emb, pooled=pooled, xts=xts, acts=acts)
+        return y1, y_cin, y_dnn
+
+    def forward(self, sparse_inputs, dense_inputs):
+        y1, y_cin, y_dnn = self._logit_parts(self._concat_ids(sparse_inputs), dense_inputs)
+        return torch.sigmoid(y1 + y_cin + y_dnn)
+
+    __call__ = forward
+
+    def train_step(self, sparse_inputs, dense_inputs, label, lr=1e-3, auc_stats=None, allreduce=None):
+        """xdeepfm/dygraph_model.py:77-90 train_forward + tools/trainer.py:151-152 backward / step.
+        label [B,1] int64.  Returns (loss [1] device tensor, pred [B,1])."""
+        k = self.k
+        ids = self._concat_ids(sparse_inputs)
+        B, S = ids.shape
+        D, Dn = self.sparse_feature_dim, self.dense_feature_dim
+        self._ensure_sparse_state()
+        self.step_count += 1
+        on_gpu = self.device.type == "cuda"
+        cur = torch.cuda.current_stream() if on_gpu else None
+        if on_gpu and self._side is None:
+            self._side = k.concurrent_stream(self.device)
+        side = self._side if on_gpu else None
+        groups = getattr(self, "_groups", None)
+        if groups is None or groups.n != B * S:
+            groups = self._groups = k.IdGroups(B * S, self.device)
+        sv = {}
+        y1, y_cin, y_dnn = self._logit_parts(ids, dense_inputs, keep=sv)
+        with _OnSide(side, cur):                                   # merge keys depend on the ids only
+            k.ids_group(ids, self.sparse_feature_number, None, self.ws_group, None, self.status, groups)
+        pred, dz, loss = k.sigmoid_logloss(y1, y_cin, y_dnn, label, self.ws)
+        if auc_stats is not None:
+            k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
+        p, g = self.dense.p, self.dense.g
+        # heads: y_cin = pooled @ w_fc + (b_fc + bias)
+        k.gemm(sv["pooled"], dz, self.ws, trans_a=True, out=g["cin.cnn_fc.weight"], b_colsum=g["cin.cnn_fc.bias"])
+        g["bias"].copy_(g["cin.cnn_fc.bias"])
+        dpooled = k.gemm(dz, p["cin.cnn_fc.weight"], self.ws, trans_b=True)
+        d_flat = k.mlp_backward(dz, sv["acts"], self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp)   # [B, F*D]
+        dfeat = d_flat.view(B, self.num_field, D)
+        self._cin_backward(sv["feat"], sv["xts"], dpooled, dfeat)
+        if self._zeros is None or self._zeros.shape[0] != B:
+            self._zeros = torch.zeros(B, 1, dtype=torch.float32, device=self.device)
+        row_grad, _, _ = k.deepfm_fm_bwd(dense_inputs, sv["feat"], sv["sum_emb"], dfeat, dz, self._zeros, S, self.ws,
+                                         out=(self._row_grad_buf(B * S), g["fm.dense_w"].view(Dn, -1),
+                                              g["fm.dense_w_one"]),
+                                         dense_w=p["fm.dense_w"], compact=False)
+        for name in self._decayed:                                  # L2Decay: grad += coeff * w
+            k.sgd_dense(g[name], p[name], -L2_COEFF)
+        t, st = self.step_count, self.sparse_state
+        with _OnSide(side, cur):
+            pp = self._pp = k.segment_partials(groups, row_grad, D, out=getattr(self, "_pp", None))
+            pp1 = self._pp1 = k.segment_partials(groups, dz, 1, grad_div=S, out=getattr(self, "_pp1", None))
+            k.sparse_adam_record(groups, row_grad, dz, S, self.fm.rec, st["mv"], D, t, lr,
+                                 v_offset=_round_up(D, 4), partials=pp, partials1=pp1)
+        if allreduce is not None:
+            allreduce(self.dense.grad)
+        k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
+        if side is not None:
+            cur.wait_stream(self._side)
+        return loss, pred
+
+
+class DygraphModel:
+    """xdeepfm/dygraph_model.py:23-104 — same method names; tensors are torch device tensors."""
+
+    def create_model(self, config, device="cuda", kernels=None):
+        g = config.get
+        return xDeepFMLayer(g("hyper_parameters.sparse_feature_number"), g("hyper_parameters.sparse_feature_dim"),
+                            g("hyper_parameters.dense_input_dim"), g("hyper_parameters.sparse_inputs_slots") - 1,
+                            g("hyper_parameters.layer_sizes_cin"), g("hyper_parameters.layer_sizes_dnn"),
+                            device=device, kernels=kernels)
+
+    def create_feeds(self, batch_data, config, device="cuda"):
+        return slot_feeds(batch_data, config, device)
+
+    def create_metrics(self, device="cuda"):
+        return auc_metrics(device)
+
+    def train_forward(self, dy_model, metrics_list, batch_data, config):
+        label, sparse, dense = self.create_feeds(batch_data, config, dy_model.device)
+        lr = config.get("hyper_parameters.optimizer.learning_rate", 0.001)
+        loss, _ = dy_model.train_step(sparse, dense, label, lr, metrics_list[0] if metrics_list else None)
+        return loss, metrics_list, None
+
+    def infer_forward(self, dy_model, metrics_list, batch_data, config):
+        label, sparse, dense = self.create_feeds(batch_data, config, dy_model.device)
+        pred = dy_model.forward(sparse, dense)
+        if metrics_list:
+            dy_model.k.auc_histogram(pred.contiguous(), label.contiguous(), metrics_list[0][0], metrics_list[0][1],
+                                     NUM_THRESHOLDS)
+        return metrics_list, None

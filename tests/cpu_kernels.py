@@ -469,3 +469,46 @@ def adam_rows_all(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, bet
     Pn, Mn, Vn = P.numpy().copy(), M.numpy().copy(), V.numpy().copy()      # strided views: work on copies
     R.adam_update_dense_equivalent(Pn, Mn, Vn, groups.uniq, merged, step, lr=lr, beta1=beta1, beta2=beta2, eps=eps)
     P.copy_(torch.from_numpy(Pn)); M.copy_(torch.from_numpy(Mn)); V.copy_(torch.from_numpy(Vn))
+
+
+# ------------------------------------------------------------------ xDeepFM CIN (include/recengine.h: rec_cin_*)
+def cin_view(t, kind):
+    return ("bfd", None) if kind == "bfd" else ("xt", t[1])
+
+
+def _cin_bsd(t, view, B, D):
+    """any feature tensor as a numpy [B, J, D] VIEW (writes go through)."""
+    a = _n(t)
+    if view[0] == "bfd":
+        return a
+    return a.reshape(B, D, a.shape[1]).transpose(0, 2, 1)
+
+
+def cin_outer_fwd(B, D, F, S, X0, v0, Xk, vk, Z):
+    x0, xk = _cin_bsd(X0, v0, B, D), _cin_bsd(Xk, vk, B, D)
+    z = np.einsum("bfd,bsd->bdfs", x0, xk).reshape(B * D, F * S)
+    Z.copy_(torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32)))
+    return Z
+
+
+def cin_outer_bwd(B, D, F, S, dZ, X0, v0, Xk, vk, dX0, dv0, acc0, dXk, dvk, acck, dpool=None):
+    x0, xk = _cin_bsd(X0, v0, B, D), _cin_bsd(Xk, vk, B, D)
+    dz = _n(dZ).reshape(B, D, F, S)
+    a = np.einsum("bdfs,bsd->bfd", dz, xk).astype(np.float32)
+    bk = np.einsum("bdfs,bfd->bsd", dz, x0).astype(np.float32)
+    if dpool is not None:
+        bk = bk + _n(dpool)[:, :, None]
+    o0, ok = _cin_bsd(dX0, dv0, B, D), _cin_bsd(dXk, dvk, B, D)
+    o0[...] = (o0 if acc0 else 0) + a
+    ok[...] = (ok if acck else 0) + bk
+
+
+def cin_sumpool(B, D, XT, out):
+    x = _n(XT)
+    out.copy_(torch.from_numpy(x.reshape(B, D, -1).sum(axis=1, dtype=np.float32)))
+    return out
+
+
+def cin_sumpool_bwd(B, D, dpool, dXT):
+    dXT.copy_(torch.from_numpy(np.repeat(_n(dpool)[:, None, :], D, axis=1).reshape(B * D, -1).copy()))
+    return dXT

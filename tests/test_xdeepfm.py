@@ -1,0 +1,226 @@
+"""rank/xdeepfm sibling net (paddlerec_amd/xdeepfm.py + csrc/cin_ops.hip; reference: models/rank/xdeepfm/net.py,
+dygraph_model.py).
+
+Oracle (oracle/xdeepfm_ref.py) pinned to tests/golden/xdeepfm_D9.npz = the reference's unmodified net.py executed over
+the paddle shim (forward pieces + every autograd gradient).  The host mirror is checked against golden + oracle with the
+oracle-backed operator backend on the CPU (orchestration only) and with the HIP kernels (`-m gpu`); the CIN kernels
+themselves against numpy on both their column paths (float4 when S % 4 == 0, scalar otherwise) and through strided views."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+from oracle import deepfm_ref as R
+from oracle import xdeepfm_ref as X
+
+
+def _params(g):
+    n, nc = int(g["n_mlp"]), int(g["n_cin"])
+    return dict(W=g["W"].copy(), W1=g["W1"].copy(), dense_w=g["dense_w"].copy(), dense_w_one=g["dense_w_one"].copy(),
+                bias=g["bias"].copy(), fc_w=g["fc_w"].copy(), fc_b=g["fc_b"].copy(),
+                cin_w=[g["cin_w%d" % i].reshape(g["cin_w%d" % i].shape[0], -1).copy() for i in range(nc)],
+                mlp_w=[g["mlp_w%d" % i].copy() for i in range(n)], mlp_b=[g["mlp_b%d" % i].copy() for i in range(n)])
+
+
+def _state_dict(p):
+    sd = {"fm.embedding.weight": p["W"], "fm.embedding_one.weight": p["W1"], "fm.dense_w": p["dense_w"],
+          "fm.dense_w_one": p["dense_w_one"], "bias": p["bias"], "cin.cnn_fc.weight": p["fc_w"],
+          "cin.cnn_fc.bias": p["fc_b"]}
+    for i, w in enumerate(p["cin_w"]):
+        sd["cin.cnn_%d.weight" % i] = w
+    for i, (w, b) in enumerate(zip(p["mlp_w"], p["mlp_b"])):
+        sd["dnn.linear_%d.weight" % i], sd["dnn.linear_%d.bias" % i] = w, b
+    return sd
+
+
+def test_oracle_matches_reference_golden():
+    g = load_golden("xdeepfm_D9")
+    p = _params(g)
+    o = X.loss_and_grads(g["ids"], g["dense"], g["label"], p)
+    for k, want in (("pred", "pred"), ("loss", "loss"), ("y1", "y1"), ("feat", "feat"), ("y_cin", "y_cin"),
+                    ("y_dnn", "y_dnn")):
+        np.testing.assert_allclose(o[k], g[want], rtol=1e-5, atol=1e-6, err_msg=k)   # fp32 einsum vs conv2d summation order
+    tol = dict(rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(o["d_fc_w"], g["g_fc_w"], **tol)
+    np.testing.assert_allclose(o["d_fc_b"], g["g_fc_b"], **tol)
+    np.testing.assert_allclose(o["d_bias"], g["g_bias"], **tol)
+    for i in range(int(g["n_cin"])):
+        np.testing.assert_allclose(o["d_cin_w"][i], g["g_cin_w%d" % i].reshape(o["d_cin_w"][i].shape), rtol=1e-5,
+                                   atol=1e-7, err_msg="cin %d" % i)
+    for i in range(int(g["n_mlp"])):
+        np.testing.assert_allclose(o["mlp_dw"][i], g["g_mlp_w%d" % i], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(o["mlp_db"][i], g["g_mlp_b%d" % i], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(o["d_dense_w"], g["g_dense_w"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(o["d_dense_w_one"], g["g_dense_w_one"], **tol)
+    for key, val, want in (("row_grad", o["row_grad"], g["gW"]), ("row_grad1", o["row_grad1"], g["gW1"])):
+        uniq, merged, _ = R.merge_rows(o["rows"], o["row_valid"], val)
+        full = np.zeros_like(want)
+        full[uniq] = merged
+        np.testing.assert_allclose(full, want, rtol=1e-5, atol=1e-7, err_msg=key)
+    assert np.abs(g["gW"][0]).max() > 0          # net.py:75-93: no padding_idx — row 0 is looked up and trained
+    assert max(np.abs(g["g_cin_w1"]).max(), np.abs(g["g_cin_w0"]).max()) > 1e-4     # the CIN branch is live
+
+
+class _OracleTrainer:
+    """Adam(lazy_mode=True) on the gradients + L2Decay terms (dygraph_model.py:60-64, net.py:139,150,219)."""
+
+    def __init__(self, p, lr):
+        self.p = {k: (v.copy() if not isinstance(v, list) else [x.copy() for x in v]) for k, v in p.items()}
+        self.lr, self.step, self.st = lr, 0, {}
+
+    def _adam(self, key, arr, grad):
+        m, v = self.st.setdefault(key, (np.zeros_like(arr), np.zeros_like(arr)))
+        R.adam_update(arr, m, v, grad.reshape(arr.shape).astype(arr.dtype), self.step, lr=self.lr)
+
+    def train_step(self, ids, dense, label):
+        self.step += 1
+        p = self.p
+        o = X.l2_decay_grads(X.loss_and_grads(ids, dense, label, p), p)
+        for key, val in (("W", o["row_grad"]), ("W1", o["row_grad1"])):
+            uniq, merged, _ = R.merge_rows(o["rows"], o["row_valid"], val)
+            m, v = self.st.setdefault(key, (np.zeros_like(p[key]), np.zeros_like(p[key])))
+            R.adam_update_rows(p[key], m, v, uniq, merged, self.step, lr=self.lr)
+        for key, grad in (("dense_w", o["d_dense_w"]), ("dense_w_one", o["d_dense_w_one"]), ("bias", o["d_bias"]),
+                          ("fc_w", o["d_fc_w"]), ("fc_b", o["d_fc_b"])):
+            self._adam(key, p[key], grad)
+        for i in range(len(p["cin_w"])):
+            self._adam(("c", i), p["cin_w"][i], o["d_cin_w"][i])
+        for i in range(len(p["mlp_w"])):
+            self._adam(("w", i), p["mlp_w"][i], o["mlp_dw"][i])
+            self._adam(("b", i), p["mlp_b"][i], o["mlp_db"][i])
+        return o["loss"], o["pred"]
+
+
+def _check_layer(device, kernels, tol, chunk_bytes=None):
+    from paddlerec_amd import xdeepfm as XM
+    rtol, p_atol = tol
+    g = load_golden("xdeepfm_D9")
+    N, D = g["W"].shape
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(device)
+    if chunk_bytes:
+        XM.Z_CHUNK_BYTES = chunk_bytes                   # several batch chunks per CIN layer (dWc accumulates)
+    try:
+        m = XM.xDeepFMLayer(N, D, 13, 26, [8, 4], [32, 16], device=device, kernels=kernels)
+        assert set(m.state_dict()) == set(str(k) for k in g["state_keys"])          # the reference's own key set
+        m.set_dict(_state_dict(_params(g)))
+        pred = m.forward([T(g["ids"][:, s:s + 1]) for s in range(26)], T(g["dense"]))  # the reference's list of [B,1]
+        np.testing.assert_allclose(pred.cpu().numpy(), g["pred"], rtol=rtol)
+        # one step on the golden batch: the gradient buffers before Adam consumed them = autograd + L2Decay
+        loss, _ = m.train_step(T(g["ids"]), T(g["dense"]), T(g["label"]), lr=0.0)
+        np.testing.assert_allclose(loss.cpu().numpy()[0], g["loss"], rtol=rtol)
+        p0 = _params(g)
+        G = m.dense.g
+        for i in range(int(g["n_cin"])):
+            want = g["g_cin_w%d" % i].reshape(p0["cin_w"][i].shape) + X.L2_COEFF * p0["cin_w"][i]
+            got = G["cin.cnn_%d.weight" % i].cpu().numpy().reshape(want.shape)
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * np.abs(want).max(), err_msg="cin %d" % i)
+        np.testing.assert_allclose(G["fm.dense_w"].cpu().numpy(), g["g_dense_w"], rtol=1e-4,
+                                   atol=1e-5 * np.abs(g["g_dense_w"]).max())
+        np.testing.assert_allclose(G["bias"].cpu().numpy(), g["g_bias"], rtol=1e-4, atol=1e-7)
+        m.set_dict(_state_dict(_params(g)))
+        m.step_count, m.sparse_state = 0, None
+        m.dense.m.zero_(); m.dense.v.zero_()
+        m.fm.rec[:, D + 1:D + 3].zero_()                 # the first-order moments live in the record line
+        tr = _OracleTrainer(_params(g), lr=1e-2)
+        rng = np.random.default_rng(4)
+        for step in range(3):
+            ids = rng.integers(0, N, (40, 26), dtype=np.int64)
+            ids[:, 3] = 0                                                             # heavy duplicates on row 0
+            dense = rng.random((40, 13), dtype=np.float32)
+            label = (rng.random((40, 1)) < 0.3).astype(np.int64)
+            loss, pred = m.train_step(T(ids), T(dense), T(label), lr=1e-2)
+            ol, op = tr.train_step(ids, dense, label)
+            np.testing.assert_allclose(loss.cpu().numpy()[0], ol, rtol=rtol)
+            np.testing.assert_allclose(pred.cpu().numpy(), op, rtol=rtol, atol=1e-6)
+        assert int(m.status.item()) == 0
+        sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        want = _state_dict(tr.p)
+        for k in want:
+            np.testing.assert_allclose(sd[k], want[k].reshape(sd[k].shape), rtol=1e-3, atol=p_atol, err_msg=k)
+        dm = XM.DygraphModel()
+        cfg = {"hyper_parameters.sparse_feature_number": N, "hyper_parameters.sparse_feature_dim": D,
+               "hyper_parameters.dense_input_dim": 13, "hyper_parameters.sparse_inputs_slots": 27,
+               "hyper_parameters.layer_sizes_cin": [8, 4], "hyper_parameters.layer_sizes_dnn": [32, 16],
+               "hyper_parameters.optimizer.learning_rate": 0.001}
+        net = dm.create_model(cfg, device, kernels=kernels)
+        metrics, names = dm.create_metrics(device)
+        batch = [g["label"]] + [g["ids"][:, s:s + 1] for s in range(26)] + [g["dense"]]
+        loss, metrics, _ = dm.train_forward(net, metrics, batch, cfg)
+        dm.infer_forward(net, metrics, batch, cfg)
+        assert np.isfinite(float(loss.reshape(-1)[0])) and names == ["auc"]
+        assert int(metrics[0][0].sum() + metrics[0][1].sum()) == 2 * len(g["label"])
+    finally:
+        XM.Z_CHUNK_BYTES = 1 << 30
+
+
+def test_xdeepfm_layer_host_logic_cpu_backend():
+    import cpu_kernels
+    _check_layer("cpu", cpu_kernels, (2e-6, 2e-6))
+
+
+def test_xdeepfm_layer_host_logic_chunked_cpu_backend():
+    import cpu_kernels
+    _check_layer("cpu", cpu_kernels, (2e-6, 2e-6), chunk_bytes=9 * 1521 * 4 * 5)    # 5 samples per chunk
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,D,F,S,layer0", [(7, 9, 39, 39, True), (5, 9, 39, 128, False), (3, 16, 27, 32, False),
+                                            (1, 4, 3, 5, False), (33, 9, 39, 200, False)])
+def test_cin_kernels_vs_numpy(engine_lib, B, D, F, S, layer0):
+    """Z = X0 (x) Xk and its backward, sum over d and its broadcast — exact products, sums within fp32 rounding."""
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(B * 100 + S)
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    feat_wide = rng.standard_normal((B, F, D + 3)).astype(np.float32)         # feat as a strided window
+    tw = T(feat_wide)
+    tf = tw[:, :, 1:1 + D]
+    feat = feat_wide[:, :, 1:1 + D]
+    if layer0:
+        xk_t, xk, vk = tf, feat, ops.cin_view(tf, "bfd")
+    else:
+        xt_wide = rng.standard_normal((B * D, S + 4)).astype(np.float32)      # XT with a row stride
+        tx = T(xt_wide)
+        xk_t = tx[:, :S]
+        xk = xt_wide[:, :S].reshape(B, D, S).transpose(0, 2, 1)               # [B,S,D]
+        vk = ops.cin_view((xk_t, D), "xt")
+    v0 = ops.cin_view(tf, "bfd")
+    Z = torch.empty(B * D, F * S, device="cuda")
+    ops.cin_outer_fwd(B, D, F, S, tf, v0, xk_t, vk, Z)
+    want = np.einsum("bfd,bsd->bdfs", feat, xk).reshape(B * D, F * S)
+    np.testing.assert_array_equal(Z.cpu().numpy(), want)                      # one multiply each: bit-exact
+    dZ = rng.standard_normal((B * D, F * S)).astype(np.float32)
+    dpool = rng.standard_normal((B, S + 2)).astype(np.float32)
+    tdp = T(dpool)[:, 1:1 + S]
+    d0 = rng.standard_normal((B, F, D)).astype(np.float32)
+    td0 = T(d0)
+    dz4 = dZ.reshape(B, D, F, S).astype(np.float64)
+    a = np.einsum("bdfs,bsd->bfd", dz4, xk.astype(np.float64))
+    bk = np.einsum("bdfs,bfd->bsd", dz4, feat.astype(np.float64))
+    if layer0:                                                                # dXk aliases dX0, both accumulate
+        ops.cin_outer_bwd(B, D, F, S, T(dZ), tf, v0, xk_t, vk, td0, ops.cin_view(td0, "bfd"), True, td0,
+                          ops.cin_view(td0, "bfd"), True, None)
+        np.testing.assert_allclose(td0.cpu().numpy(), d0 + a + bk, rtol=1e-5, atol=1e-5)
+    else:
+        tdk = torch.full((B * D, S), 7.0, device="cuda")
+        ops.cin_outer_bwd(B, D, F, S, T(dZ), tf, v0, xk_t, vk, td0, ops.cin_view(td0, "bfd"), True, tdk,
+                          ops.cin_view((tdk, D), "xt"), False, tdp)
+        np.testing.assert_allclose(td0.cpu().numpy(), d0 + a, rtol=1e-5, atol=1e-5)
+        wantk = (bk + dpool[:, 1:1 + S, None]).transpose(0, 2, 1).reshape(B * D, S)
+        np.testing.assert_allclose(tdk.cpu().numpy(), wantk, rtol=1e-5, atol=1e-5)
+        pooled = torch.zeros(B, S + 3, device="cuda")
+        ops.cin_sumpool(B, D, xk_t, pooled[:, 2:2 + S])
+        np.testing.assert_allclose(pooled.cpu().numpy()[:, 2:2 + S], xk.sum(axis=2), rtol=1e-6, atol=1e-6)
+        assert np.all(pooled.cpu().numpy()[:, :2] == 0) and np.all(pooled.cpu().numpy()[:, 2 + S:] == 0)
+        dxt = torch.empty(B * D, S, device="cuda")
+        ops.cin_sumpool_bwd(B, D, tdp, dxt)
+        np.testing.assert_array_equal(dxt.cpu().numpy(), np.repeat(dpool[:, None, 1:1 + S], D, axis=1).reshape(B * D, S))
+
+
+@pytest.mark.gpu
+def test_xdeepfm_layer_gpu(engine_lib):
+    _check_layer("cuda", None, (2e-5, 2e-4))
+
+
+@pytest.mark.gpu
+def test_xdeepfm_layer_chunked_gpu(engine_lib):
+    _check_layer("cuda", None, (2e-5, 2e-4), chunk_bytes=9 * 1521 * 4 * 5)
