@@ -512,3 +512,8 @@ def cin_sumpool(B, D, XT, out):
 def cin_sumpool_bwd(B, D, dpool, dXT):
     dXT.copy_(torch.from_numpy(np.repeat(_n(dpool)[:, None, :], D, axis=1).reshape(B * D, -1).copy()))
     return dXT
+
+
+def ps_shrink_rows(table, decay=0.98, delete_threshold=0.8):
+    from oracle import ps_ref
+    return ps_ref.shrink_rows(table.rec.numpy(), _lay_dict(table), _acc_dict(table), decay, delete_threshold)

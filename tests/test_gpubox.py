@@ -1,0 +1,120 @@
+"""The gpubox pass loop (paddlerec_amd/gpubox.py; reference: tools/static_gpubox_trainer.py:85-260 with the PSGPU
+begin_pass / train_from_dataset / end_pass surface) on the reference's own multi-value fixture (the first lines of
+models/rank/slot_dnn/data/demo_10) with the accessor of slot_dnn/config_online.yaml:57-89.
+
+Checked against a straight replay of the same passes with the oracle (oracle/slot_dnn_ref.py + oracle/ps_ref.py):
+per-pass loss, AUC buckets, the table after every end_pass (shrink: decay + delete), the pass checkpoint round trip."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import deepfm_ref as R
+from oracle import ps_ref
+from oracle import slot_dnn_ref as M
+
+SLOTS, N, D = 300, 20011, 9
+
+
+def _config(tmp_path, epochs=2):
+    d = tmp_path / "slot_dnn"
+    (d / "data").mkdir(parents=True, exist_ok=True)
+    shutil.copy(os.path.join(GOLDEN, "slot_dnn_demo_4.txt"), d / "data" / "part-0")
+    acc = {"embedx_threshold": 0.5,      # low enough that some features grow their embedx within two passes
+           "embedx_sgd_param": {"adagrad": {"learning_rate": 0.05, "initial_g2sum": 3.0, "initial_range": 1e-2,
+                                            "weight_bounds": [-10.0, 10.0]}},
+           "ctr_accessor_param": {"nonclk_coeff": 0.1, "click_coeff": 1.0, "show_click_decay_rate": 0.98,
+                                  "delete_threshold": 0.15}}
+    return {"config_abs_dir": str(d), "runner.train_data_dir": "data", "runner.train_batch_size": 2,
+            "runner.epochs": epochs, "runner.use_auc": True, "runner.model_save_path": str(tmp_path / "out"),
+            "hyper_parameters.dict_dim": N, "hyper_parameters.emb_dim": D, "hyper_parameters.slot_num": SLOTS,
+            "hyper_parameters.layer_sizes": [16, 8], "hyper_parameters.optimizer.learning_rate": 1e-3,
+            "table_parameters.embedding.accessor": acc}
+
+
+def _run(tmp_path, device, kernels):
+    from paddlerec_amd import gpubox, reader
+    cfg = _config(tmp_path)
+    torch.manual_seed(7)
+    main = gpubox.Main(cfg, device, kernels)
+    with pytest.raises(RuntimeError):
+        gpubox.PSGPU(main.k).begin_pass()                       # begin_pass before init_gpu_ps / bind
+    res = main.run_worker()
+    net, L = main.net, main.net.table.layout
+    assert len(res["loss"]) == 2 and all(np.isfinite(x) for x in res["loss"]) and len(res["auc"]) == 2
+    assert main.PSGPU.passes == 2 and main.PSGPU.device_pass is None
+    # ---- replay with the oracle: same initial dense weights, same accessor, same passes
+    acc = dict(lr=0.05, initial_g2sum=3.0, bounds=(-10.0, 10.0), initial_range=1e-2, embedx_threshold=0.5,
+               nonclk_coeff=0.1, click_coeff=1.0, seed=net.table.accessor.seed)
+    lay = dict(embed_off=L.embed_off, embedx_off=L.embedx_off, embedx_dim=L.embedx_dim, stat_off=L.stat_off)
+    torch.manual_seed(7)
+    fresh = gpubox.Main(cfg, "cpu", __import__("cpu_kernels"))
+    fresh.network()
+    mw = [w.numpy().copy() for w in fresh.net.mlp_w]
+    mb = [b.numpy().copy() for b in fresh.net.mlp_b]
+    st = [[np.zeros_like(w), np.zeros_like(w)] for w in mw], [[np.zeros_like(b), np.zeros_like(b)] for b in mb]
+    rec = np.zeros((N, L.row_stride), np.float32)
+    data = open(os.path.join(GOLDEN, "slot_dnn_demo_4.txt"), "rb").read().split(b"\n")
+    lines = [ln for ln in data if ln.strip()]
+    step, want_loss, want_deleted = 0, [], []
+    for epoch in range(2):
+        losses = []
+        for b0 in range(0, len(lines) - 1, 2):
+            chunk = b"\n".join(lines[b0:b0 + 2]) + b"\n"
+            values, lod, base, n = reader.parse_feasign_slots(chunk, 2, SLOTS, 0)
+            lv, llod, _, _ = reader.parse_feasign_slots(chunk, 1, 1, 0)
+            label = lv[llod[0, :-1]].reshape(n, 1).clamp(0, 1).numpy()
+            values, lod, base = values.numpy(), lod.numpy(), base.numpy()
+            rows_all = np.array([R.feasign_row(int(v) & 0xFFFFFFFFFFFFFFFF, N) for v in values], np.int64)
+            touched = np.unique(rows_all)
+            Wv = np.zeros((N, D), np.float32)
+            for r in touched:
+                Wv[r] = ps_ref.pull_value(rec, lay, int(r), acc, D)
+            Wv[0] = 0
+            o = M.loss_and_grads(values, lod, base, label, Wv, mw, mb, 0, 1, N)
+            losses.append(float(o["loss"]))
+            U = len(o["uniq"])
+            dshow, dclick = np.zeros(U), np.zeros(U)
+            pos = {int(r): i for i, r in enumerate(o["uniq"])}
+            for k in np.nonzero(values != 0)[0]:
+                dshow[pos[int(o["rows"][k])]] += 1
+                dclick[pos[int(o["rows"][k])]] += int(label[o["seg"][k] // SLOTS, 0])
+            ps_ref.push_rows(rec, lay, o["uniq"], o["merged"][:, 0], o["merged"][:, 1:], dshow, dclick, acc)
+            step += 1
+            for i in range(len(mw)):
+                R.adam_update(mw[i], st[0][i][0], st[0][i][1], o["dws"][i], step, lr=1e-3)
+                R.adam_update(mb[i], st[1][i][0], st[1][i][1], o["dbs"][i], step, lr=1e-3)
+        want_loss.append(float(np.mean(losses)))
+        want_deleted.append(ps_ref.shrink_rows(rec, lay, acc, 0.98, 0.15))
+    np.testing.assert_allclose(res["loss"], want_loss, rtol=2e-5)
+    assert res["deleted"] == want_deleted and want_deleted[0] > 0            # the shrink really deletes rows
+    got = net.rec.cpu().numpy()
+    so = L.stat_off
+    assert np.array_equal(got[:, so + 4], rec[:, so + 4]), "feature states after two passes"
+    np.testing.assert_allclose(got[:, so:so + 2], rec[:, so:so + 2], rtol=1e-6, atol=0)
+    # weights ~1e-2: the dense Adam of the MLP turns fp32 noise of ~eps-sized gradients into lr-sized steps, which reach
+    # the embedding gradients of later steps (tests/test_slot_dnn.py re-syncs the MLP every step for that reason)
+    np.testing.assert_allclose(got[:, :D], rec[:, :D], rtol=1e-3, atol=5e-5)
+    states = rec[:, so + 4]
+    assert (states == 1).any() and (states == 2).any()
+    # ---- pass checkpoint: born rows only, round trip
+    z = np.load(os.path.join(cfg["runner.model_save_path"], "1", "rec_gpubox.npz"))
+    assert 0 < len(z["rows"]) < N // 2
+    before = net.rec.clone()
+    net.rec.zero_()
+    main.load_pass(os.path.join(cfg["runner.model_save_path"], "1"))
+    # the checkpoint of epoch 1 is written after that epoch's end_pass: identical table
+    assert torch.equal(before, net.rec)
+
+
+def test_gpubox_pass_loop_cpu_backend(tmp_path):
+    import cpu_kernels
+    _run(tmp_path, "cpu", cpu_kernels)
+
+
+@pytest.mark.gpu
+def test_gpubox_pass_loop_gpu(tmp_path, engine_lib):
+    _run(tmp_path, "cuda", None)
