@@ -473,6 +473,36 @@ int rec_cin_sumpool_bwd(int64_t batch, int32_t emb_dim, int32_t C, const float* 
                         float* dXT, int64_t ldx, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * DLRM (models/rank/dlrm/net.py): BatchNorm1D over the batch, the pairwise dot interaction, accuracy counts.
+ *   rec_batchnorm_fwd : nn.BatchNorm1D on X [m, n] (net.py:151-153, after every Linear -> ReLU).  training != 0:
+ *                       batch mean and BIASED batch variance, running = momentum*running + (1-momentum)*batch
+ *                       (Paddle: momentum 0.9, epsilon 1e-5) [EXT]; training == 0: the running statistics.
+ *                       save_mean / save_invstd [n] are kept for the backward.  Column sums in a fixed order.
+ *   rec_batchnorm_bwd : dX, dgamma [n], dbeta [n];  relu_mask != 0: X was a ReLU output — dX is zeroed where
+ *                       X <= 0 (the ReLU backward folded in), so dX is the gradient of the Linear's output.
+ *   rec_dot_interact_fwd : T [batch, F, D] (sample stride ldt) = [emb_1 .. emb_{F-1}, x] ->
+ *                       R [batch, D + F(F-1)/2] = [ x | <T_i, T_j> for i < j in row-major order ]   (net.py:96-123:
+ *                       bmm + triu + masked_select + concat)
+ *   rec_dot_interact_bwd : dT[b,i,:] = sum_{j != i} dZ(i,j) T[b,j,:]  (+ dR[b,:D] for the last field)
+ *   rec_accuracy_count : paddle.metric.Accuracy top-1 of softmax(raw) for two classes: counts[0] += #(pred > 0.5
+ *                       == label != 0), counts[1] += n   (int64, exact)          dygraph_model.py:58-63,79-81
+ * ---------------------------------------------------------------------------------------- */
+int rec_batchnorm_workspace_bytes(int64_t m, int32_t n, size_t* bytes);
+int rec_batchnorm_fwd(int64_t m, int32_t n, const float* X, int64_t ldx, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, int32_t training,
+                      float* Y, int64_t ldy, float* save_mean, float* save_invstd, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int rec_batchnorm_bwd(int64_t m, int32_t n, const float* X, int64_t ldx, const float* dY, int64_t lddy,
+                      const float* gamma, const float* save_mean, const float* save_invstd, int32_t relu_mask,
+                      float* dX, int64_t lddx, float* dgamma, float* dbeta, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int rec_dot_interact_fwd(int64_t batch, int32_t F, int32_t D, const float* T, int64_t ldt, float* R, int64_t ldr,
+                         void* stream);
+int rec_dot_interact_bwd(int64_t batch, int32_t F, int32_t D, const float* T, int64_t ldt, const float* dR,
+                         int64_t ldr, float* dT, int64_t lddt, void* stream);
+int rec_accuracy_count(int64_t n, const float* pred, const int64_t* label, int64_t* counts, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * f32 GEMM on the matrix cores with fused epilogues: C[M,N] = epi(op(A)[M,K] @ op(B)[K,N]).
  * Replaces paddle.nn.Linear / paddle.matmul (+ the elementwise ops around them) on the hot path:
  *   top MLP fwd/bwd  deepfm/net.py:142-174, dcn_v2/net.py:140-184, din/net.py:104-137,175-181

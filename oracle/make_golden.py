@@ -306,6 +306,58 @@ def golden_xdeepfm(D, seed):
         float(y_cin.detach().abs().mean()), float(y_dnn.detach().abs().mean())))
 
 
+def golden_dlrm(D, seed):
+    """models/rank/dlrm/net.py:23-178 + dlrm/dygraph_model.py:53-57 (loss), train mode (BatchNorm on batch statistics)."""
+    import paddle  # the shim
+    net = load_ref_module("models/rank/dlrm/net.py", "ref_dlrm_net")
+    rng = np.random.default_rng(seed)
+    N, S, Dn, B, bot, top = 1001, 26, 13, 24, [32, D], [48, 2]
+    torch.manual_seed(seed)
+    model = net.DLRMLayer(dense_feature_dim=Dn, bot_layer_sizes=bot, sparse_feature_number=N, sparse_feature_dim=D,
+                          top_layer_sizes=top, num_field=S, self_interaction=False)
+    model.train()
+    norms = [m for m in model.modules() if isinstance(m, paddle.nn.BatchNorm1D)]
+    with torch.no_grad():
+        model.embedding.weight.mul_(0.3)                       # TruncatedNormal() std 1: dots of 16-vectors would swamp x
+        for bn in norms:                                       # non-trivial affine parameters and running statistics
+            bn.weight.copy_(torch.as_tensor((1.0 + 0.3 * rng.standard_normal(bn.weight.shape[0])).astype(np.float32)))
+            bn.bias.copy_(torch.as_tensor((0.2 * rng.standard_normal(bn.bias.shape[0])).astype(np.float32)))
+            bn._mean.copy_(torch.as_tensor((0.1 * rng.standard_normal(bn.bias.shape[0])).astype(np.float32)))
+            bn._variance.copy_(torch.as_tensor((1.0 + 0.2 * rng.random(bn.bias.shape[0])).astype(np.float32)))
+    run0 = [(npy(bn._mean), npy(bn._variance)) for bn in norms]
+    ids = make_ids(rng, B, S, N, pad_frac=0.0)
+    ids[:3, :4] = 0                                            # id 0 is an ordinary row here (no padding_idx)
+    dense = rng.random((B, Dn), dtype=np.float32)
+    label = (rng.random((B, 1)) < 0.4).astype(np.int64)
+    sparse_inputs = [paddle.to_tensor(ids[:, s:s + 1]) for s in range(S)]
+    raw = model.forward(sparse_inputs, paddle.to_tensor(dense))
+    cost = paddle.nn.functional.cross_entropy(input=raw, label=paddle.to_tensor(label))
+    loss = paddle.mean(x=cost)
+    loss.backward()
+    g = dict(ids=ids, dense=dense, label=label, D=np.int64(D), W=npy(model.embedding.weight),
+             gW=npy(model.embedding.weight.grad), raw=npy(raw), loss=npy(loss),
+             state_keys=np.array(sorted(model.state_dict().keys())))
+    for name, mlp in (("bot", model.bot_mlp), ("top", model.top_mlp)):
+        lins = [l for l in mlp.mlp if isinstance(l, paddle.nn.Linear)]
+        bns = [l for l in mlp.mlp if isinstance(l, paddle.nn.BatchNorm1D)]
+        assert len(lins) == len(bns)                           # net.py:145: every layer carries ReLU + BatchNorm
+        g["n_" + name] = np.int64(len(lins))
+        for i, (lin, bn) in enumerate(zip(lins, bns)):
+            k = "%s%d_" % (name, i)
+            j = norms.index(bn)
+            g[k + "w"], g[k + "b"], g[k + "gamma"], g[k + "beta"] = npy(lin.weight), npy(lin.bias), npy(bn.weight), npy(bn.bias)
+            g[k + "mean0"], g[k + "var0"] = run0[j]
+            g[k + "mean1"], g[k + "var1"] = npy(bn._mean), npy(bn._variance)      # after this training forward
+            g[k + "gw"], g[k + "gb"] = npy(lin.weight.grad), npy(lin.bias.grad)
+            g[k + "ggamma"], g[k + "gbeta"] = npy(bn.weight.grad), npy(bn.bias.grad)
+    model.eval()
+    with torch.no_grad():
+        g["raw_eval"] = npy(model.forward(sparse_inputs, paddle.to_tensor(dense)))
+    np.savez_compressed(os.path.join(OUT, f"dlrm_D{D}.npz"), **g)
+    print("dlrm D=%d loss=%.6f raw range %.3f..%.3f" % (D, float(loss.detach()), float(raw.detach().min()),
+                                                       float(raw.detach().max())))
+
+
 def golden_slot_dnn(D, seed):
     """models/rank/slot_dnn/net.py:21-85 (BenchmarkDNNLayer) + static_model.py:104-108 (loss): multi-value slots over
     ONE shared table, sum-pooled per slot, concat, MLP, sigmoid(clip(+-15))."""
@@ -376,6 +428,7 @@ if __name__ == "__main__":
             "dcn_v2_v2": lambda: golden_dcn_v2(False, 20250406), "dcn_v2_mix": lambda: golden_dcn_v2(True, 20250407),
             "din": lambda: golden_din(20250408), "fm_D9": lambda: golden_fm(9, 20250409),
             "wide_deep_D9": lambda: golden_wide_deep(9, 20250410), "dnn_D9": lambda: golden_dnn(9, 20250411),
-            "slot_dnn_D9": lambda: golden_slot_dnn(9, 20250412), "xdeepfm_D9": lambda: golden_xdeepfm(9, 20250413)}
+            "slot_dnn_D9": lambda: golden_slot_dnn(9, 20250412), "xdeepfm_D9": lambda: golden_xdeepfm(9, 20250413),
+            "dlrm_D16": lambda: golden_dlrm(16, 20250414)}
     for name in (sys.argv[1:] or list(jobs)):      # optional: only the named fixtures
         jobs[name]()

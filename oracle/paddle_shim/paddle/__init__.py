@@ -126,3 +126,27 @@ def create_parameter(shape, dtype="float32", default_initializer=None, attr=None
 
 def add(x, y):
     return x + y
+
+
+def bmm(x, y):
+    return _t.bmm(x, y)
+
+
+def triu(x, diagonal=0):
+    return _t.triu(x, diagonal)
+
+
+def tril(x, diagonal=0):
+    return _t.tril(x, diagonal)
+
+
+def ones_like(x, dtype=None):
+    return _t.ones_like(x) if dtype is None else _t.ones_like(x, dtype=_dtype(dtype))
+
+
+def greater_than(x, y):
+    return x > y
+
+
+def masked_select(x, mask):
+    return _t.masked_select(x, mask)

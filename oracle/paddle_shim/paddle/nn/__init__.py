@@ -101,3 +101,27 @@ class Conv2D(Layer):
 
     def forward(self, x):
         return _t.nn.functional.conv2d(x, self.weight, self.bias)
+
+
+class BatchNorm1D(Layer):
+    """[EXT Paddle batch_norm] momentum 0.9, epsilon 1e-5; training: batch mean / BIASED batch variance, running stats
+    moved by (1 - momentum) towards them (biased variance there too); parameters weight, bias, _mean, _variance."""
+
+    def __init__(self, num_features, momentum=0.9, epsilon=1e-05, weight_attr=None, bias_attr=None, name=None):
+        super().__init__()
+        self.momentum, self.epsilon = momentum, epsilon
+        self.weight = _t.nn.Parameter(_t.ones(num_features))
+        self.bias = _t.nn.Parameter(_t.zeros(num_features))
+        self.register_buffer("_mean", _t.zeros(num_features))
+        self.register_buffer("_variance", _t.ones(num_features))
+
+    def forward(self, x):
+        if self.training:
+            mean = x.mean(dim=0)
+            var = ((x - mean) ** 2).mean(dim=0)
+            with _t.no_grad():
+                self._mean.mul_(self.momentum).add_((1 - self.momentum) * mean)
+                self._variance.mul_(self.momentum).add_((1 - self.momentum) * var)
+        else:
+            mean, var = self._mean, self._variance
+        return (x - mean) / _t.sqrt(var + self.epsilon) * self.weight + self.bias

@@ -147,6 +147,12 @@ SIGNATURES = {
                                    _P, _I32, _P]),
     "rec_softmax_rows_bwd": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P, _I32, _P]),
     "rec_softmax_rows": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P]),
+    "rec_batchnorm_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(_SZ)]),
+    "rec_batchnorm_fwd": (C.c_int, [_I64, _I32, _P, _I64, _P, _P, _P, _P, _F, _F, _I32, _P, _I64, _P, _P, _P, _SZ, _P]),
+    "rec_batchnorm_bwd": (C.c_int, [_I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _I32, _P, _I64, _P, _P, _P, _SZ, _P]),
+    "rec_dot_interact_fwd": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _I64, _P]),
+    "rec_dot_interact_bwd": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _I64, _P, _I64, _P]),
+    "rec_accuracy_count": (C.c_int, [_I64, _P, _P, _P, _P]),
     "rec_cin_outer_fwd": (C.c_int, [_I64, _I32, _I32, _I32, _P, C.POINTER(CinView), _P, C.POINTER(CinView), _P, _I64, _P]),
     "rec_cin_outer_bwd": (C.c_int, [_I64, _I32, _I32, _I32, _P, _I64, _P, C.POINTER(CinView), _P, C.POINTER(CinView),
                                     _P, C.POINTER(CinView), _I32, _P, C.POINTER(CinView), _I32, _P, _I64, _P]),

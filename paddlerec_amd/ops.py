@@ -699,6 +699,85 @@ def cin_sumpool_bwd(B, D, dpool, dXT):
     return dXT
 
 
+# ------------------------------------------------------------------ DLRM: BatchNorm1D, dot interaction, accuracy
+def batchnorm_fwd(X, gamma, beta, running_mean, running_var, ws, training=True, momentum=0.9, eps=1e-5, out=None):
+    """nn.BatchNorm1D on X [m, n] (dlrm/net.py:151-153).  -> (Y, save_mean [n], save_invstd [n]); the running
+    statistics are updated in place when training."""
+    ldx = _chk_mat(X, "X")
+    m, n = X.shape
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        _chk(t, torch.float32, nm, (n,))
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=X.device)
+    ldy = _chk_mat(out, "out")
+    sm = torch.empty(n, dtype=torch.float32, device=X.device)
+    si = torch.empty(n, dtype=torch.float32, device=X.device)
+    nbytes = C.c_size_t(0)
+    check(lib().rec_batchnorm_workspace_bytes(m, n, C.byref(nbytes)))
+    w = ws.get(nbytes.value)
+    check(lib().rec_batchnorm_fwd(m, n, _p(X), ldx, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                  float(momentum), float(eps), int(bool(training)), _p(out), ldy, _p(sm), _p(si), _p(w),
+                                  C.c_size_t(w.numel()), _stream()), "rec_batchnorm_fwd")
+    return out, sm, si
+
+
+def batchnorm_bwd(X, dY, gamma, save_mean, save_invstd, ws, relu_mask=False, dgamma=None, dbeta=None, out=None):
+    """-> (dX, dgamma, dbeta).  relu_mask: X was a ReLU output — dX is zeroed where X <= 0."""
+    ldx, lddy = _chk_mat(X, "X"), _chk_mat(dY, "dY")
+    m, n = X.shape
+    dev = X.device
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=dev)
+    if dgamma is None:
+        dgamma = torch.empty(n, dtype=torch.float32, device=dev)
+    if dbeta is None:
+        dbeta = torch.empty(n, dtype=torch.float32, device=dev)
+    for t, nm in ((gamma, "gamma"), (save_mean, "save_mean"), (save_invstd, "save_invstd"), (dgamma, "dgamma"),
+                  (dbeta, "dbeta")):
+        _chk(t, torch.float32, nm, (n,))
+    nbytes = C.c_size_t(0)
+    check(lib().rec_batchnorm_workspace_bytes(m, n, C.byref(nbytes)))
+    w = ws.get(nbytes.value)
+    check(lib().rec_batchnorm_bwd(m, n, _p(X), ldx, _p(dY), lddy, _p(gamma), _p(save_mean), _p(save_invstd),
+                                  int(bool(relu_mask)), _p(out), _chk_mat(out, "dX"), _p(dgamma), _p(dbeta), _p(w),
+                                  C.c_size_t(w.numel()), _stream()), "rec_batchnorm_bwd")
+    return out, dgamma, dbeta
+
+
+def dot_interact_fwd(T, out=None):
+    """T [B,F,D] = [emb_1 .. emb_{F-1}, x]  ->  R [B, D + F(F-1)/2] = [x | strictly-upper-triangle dots, row-major]
+    (dlrm/net.py:96-123)."""
+    _chk(T, torch.float32, "T")
+    B, F, D = T.shape
+    P = F * (F - 1) // 2
+    if out is None:
+        out = torch.empty(B, D + P, dtype=torch.float32, device=T.device)
+    check(lib().rec_dot_interact_fwd(B, F, D, _p(T), F * D, _p(out), _chk_mat(out, "R"), _stream()),
+          "rec_dot_interact_fwd")
+    return out
+
+
+def dot_interact_bwd(T, dR, out=None):
+    _chk(T, torch.float32, "T")
+    B, F, D = T.shape
+    ldr = _chk_mat(dR, "dR")
+    if out is None:
+        out = torch.empty(B, F, D, dtype=torch.float32, device=T.device)
+    _chk(out, torch.float32, "dT", (B, F, D))
+    check(lib().rec_dot_interact_bwd(B, F, D, _p(T), F * D, _p(dR), ldr, _p(out), F * D, _stream()),
+          "rec_dot_interact_bwd")
+    return out
+
+
+def accuracy_count(pred, label, counts):
+    """counts [2] int64: += (#correct top-1 of two classes, n)   (paddle.metric.Accuracy)."""
+    _chk(pred, torch.float32, "pred")
+    _chk(label, torch.int64, "label")
+    _chk(counts, torch.int64, "counts", (2,))
+    check(lib().rec_accuracy_count(pred.numel(), _p(pred), _p(label), _p(counts), _stream()), "rec_accuracy_count")
+    return counts
+
+
 def sparse_sgd_rows(groups, grad, P, lr, grad_div=1, grad_group=0, grad_group_stride=0, partials=None):
     D, stride = _chk_table(P, "P")
     check(lib().rec_sparse_sgd_rows(groups.n, D, stride, _p(groups.n_uniq), _p(groups.uniq_rows),

@@ -10,7 +10,7 @@ What differs by construction: a batch never becomes 28 per-sample NumPy arrays (
 [B,26] / [B,13] device tensors), `loss.backward(); optimizer.step()` is the explicit `train_step` chain of the
 host mirrors, and the AUC buckets stay on the device (read back only when a log line prints them).
 
-    python -m paddlerec_amd.trainer -m <config.yaml> [--model deepfm|fm|wide_deep|dnn|dcn_v2|din|xdeepfm] [-o runner.epochs=1 ...] [--infer]
+    python -m paddlerec_amd.trainer -m <config.yaml> [--model deepfm|fm|wide_deep|dnn|dcn_v2|din|xdeepfm|dlrm] [-o runner.epochs=1 ...] [--infer]
     python -m torch.distributed.run --nproc-per-node G -m paddlerec_amd.trainer -m <config.yaml>     # collective mode
 """
 import argparse
@@ -24,7 +24,7 @@ from . import checkpoint
 
 logger = logging.getLogger("paddlerec_amd.trainer")
 
-MODELS = ("deepfm", "fm", "wide_deep", "dnn", "dcn_v2", "din", "xdeepfm")
+MODELS = ("deepfm", "fm", "wide_deep", "dnn", "dcn_v2", "din", "xdeepfm", "dlrm")
 
 
 # ------------------------------------------------------------------------------------ configuration
@@ -85,6 +85,8 @@ def _dygraph_model(name):
         from .din import DygraphModel
     elif name == "xdeepfm":
         from .xdeepfm import DygraphModel
+    elif name == "dlrm":
+        from .dlrm import DygraphModel
     else:
         raise ValueError("unknown model %r (known: %s)" % (name, ", ".join(MODELS)))
     return DygraphModel()
@@ -120,6 +122,9 @@ def _batch_size(batch):
 
 def _metric_values(dy_model_class, metric_list, metric_names):
     from .deepfm import auc_from_buckets
+    fn = getattr(dy_model_class, "metric_value", None)        # models with metrics other than AUC bucket pairs (dlrm)
+    if fn is not None:
+        return {n: fn(n, m) for n, m in zip(metric_names, metric_list)}
     return {n: auc_from_buckets(m[0], m[1]) for n, m in zip(metric_names, metric_list)}
 
 

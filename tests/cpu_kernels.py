@@ -517,3 +517,43 @@ def cin_sumpool_bwd(B, D, dpool, dXT):
 def ps_shrink_rows(table, decay=0.98, delete_threshold=0.8):
     from oracle import ps_ref
     return ps_ref.shrink_rows(table.rec.numpy(), _lay_dict(table), _acc_dict(table), decay, delete_threshold)
+
+
+# ------------------------------------------------------------------ DLRM (include/recengine.h: rec_batchnorm_*, rec_dot_interact_*)
+def batchnorm_fwd(X, gamma, beta, running_mean, running_var, ws, training=True, momentum=0.9, eps=1e-5, out=None):
+    from oracle import dlrm_ref
+    y, mean, invstd = dlrm_ref.batchnorm_forward(_n(X), _n(gamma), _n(beta), running_mean.numpy(), running_var.numpy(),
+                                                 training, momentum, eps)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    y = f(y)
+    return (y if out is None else out.copy_(y)), f(mean), f(invstd)
+
+
+def batchnorm_bwd(X, dY, gamma, save_mean, save_invstd, ws, relu_mask=False, dgamma=None, dbeta=None, out=None):
+    from oracle import dlrm_ref
+    dx, dg, db = dlrm_ref.batchnorm_backward(_n(X), _n(dY), _n(gamma), _n(save_mean), _n(save_invstd))
+    if relu_mask:
+        dx = dx * (_n(X) > 0)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    dx, dg, db = f(dx), f(dg), f(db)
+    return (dx if out is None else out.copy_(dx)), (dg if dgamma is None else dgamma.copy_(dg)), \
+        (db if dbeta is None else dbeta.copy_(db))
+
+
+def dot_interact_fwd(T, out=None):
+    from oracle import dlrm_ref
+    r = torch.from_numpy(dlrm_ref.dot_interact(_n(T)))
+    return r if out is None else out.copy_(r)
+
+
+def dot_interact_bwd(T, dR, out=None):
+    from oracle import dlrm_ref
+    r = torch.from_numpy(dlrm_ref.dot_interact_backward(_n(T), _n(dR)))
+    return r if out is None else out.copy_(r)
+
+
+def accuracy_count(pred, label, counts):
+    ok = ((_n(pred).reshape(-1) > 0.5) == (_n(label).reshape(-1) != 0)).sum()
+    counts[0] += int(ok)
+    counts[1] += int(pred.numel())
+    return counts

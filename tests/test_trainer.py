@@ -179,7 +179,7 @@ REF_RANK = "/root/reference/models/rank"
 @pytest.mark.skipif(not os.path.isdir(REF_RANK), reason="reference tree not mounted (only in the build container)")
 @pytest.mark.parametrize("model,samples,batches", [("deepfm", 80, 40), ("fm", None, None), ("wide_deep", None, None),
                                                     ("dnn", None, None), ("dcn_v2", None, None), ("din", None, None),
-                                                    ("xdeepfm", None, None)])
+                                                    ("xdeepfm", None, None), ("dlrm", None, None)])
 def test_reference_yaml_and_sample_data_run_unchanged(model, samples, batches, tmp_path):
     """BASELINE configs[0] and its siblings: the reference's OWN models/rank/<model>/config.yaml and sample data
     directory drive the loops as they are (deepfm: bs 2, 80 lines, D 9, fc 512-256-128-32; dcn_v2: D 40, CrossNetMix
