@@ -149,7 +149,8 @@ class Main:
 
     def run_worker(self):
         cfg = self.config
-        self.network()
+        if not hasattr(self, "net"):
+            self.network()
         self.init_reader()
         epochs = int(cfg.get("runner.epochs", 1))
         use_auc = bool(cfg.get("runner.use_auc", True))

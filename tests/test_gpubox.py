@@ -42,19 +42,17 @@ def _run(tmp_path, device, kernels):
     main = gpubox.Main(cfg, device, kernels)
     with pytest.raises(RuntimeError):
         gpubox.PSGPU(main.k).begin_pass()                       # begin_pass before init_gpu_ps / bind
+    main.network()
+    mw = [w.cpu().numpy().copy() for w in main.net.mlp_w]      # the initial dense weights the replay starts from
+    mb = [b.cpu().numpy().copy() for b in main.net.mlp_b]
     res = main.run_worker()
     net, L = main.net, main.net.table.layout
     assert len(res["loss"]) == 2 and all(np.isfinite(x) for x in res["loss"]) and len(res["auc"]) == 2
     assert main.PSGPU.passes == 2 and main.PSGPU.device_pass is None
-    # ---- replay with the oracle: same initial dense weights, same accessor, same passes
+    # ---- replay with the oracle: the same initial dense weights, the same accessor, the same passes
     acc = dict(lr=0.05, initial_g2sum=3.0, bounds=(-10.0, 10.0), initial_range=1e-2, embedx_threshold=0.5,
                nonclk_coeff=0.1, click_coeff=1.0, seed=net.table.accessor.seed)
     lay = dict(embed_off=L.embed_off, embedx_off=L.embedx_off, embedx_dim=L.embedx_dim, stat_off=L.stat_off)
-    torch.manual_seed(7)
-    fresh = gpubox.Main(cfg, "cpu", __import__("cpu_kernels"))
-    fresh.network()
-    mw = [w.numpy().copy() for w in fresh.net.mlp_w]
-    mb = [b.numpy().copy() for b in fresh.net.mlp_b]
     st = [[np.zeros_like(w), np.zeros_like(w)] for w in mw], [[np.zeros_like(b), np.zeros_like(b)] for b in mb]
     rec = np.zeros((N, L.row_stride), np.float32)
     data = open(os.path.join(GOLDEN, "slot_dnn_demo_4.txt"), "rb").read().split(b"\n")
