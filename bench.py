@@ -154,6 +154,23 @@ def cpu_baseline(B, S, Dn, D, fc, rows_per_table, budget_s=20.0):
                       "NumPy/BLAS MLP fwd/bwd + dense Adam), %.1f s" % (steps, B, t_total)}
 
 
+class _QuietStdout:
+    """fd 1 -> fd 2 for a region, C stdio flushed before it is restored."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *a):
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +208,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        # RCCL prints a version banner on the C-level stdout when a communicator is created (flushed at exit, i.e.
+        # AFTER the result): stdout is pointed at stderr until the warm-up has created every communicator, so that
+        # this program's stdout stays the ONE JSON line of the contract
+        quiet = _QuietStdout()
+        quiet.__enter__()
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from paddlerec_amd import _lib
@@ -243,13 +265,19 @@ def main():
         step(i)
     model.timers = {}
     barrier()
+    if dist is not None:
+        quiet.__exit__()
     t0 = time.perf_counter()
     host_issue = 0.0
+    step_host = []
     for i in range(args.steps):
         h0 = time.perf_counter()
         loss, _ = step(args.warmup + i)
-        host_issue += time.perf_counter() - h0
+        step_host.append(time.perf_counter() - h0)
+        host_issue += step_host[-1]
     barrier()
+    if os.environ.get("REC_BENCH_STEP_TIMES"):       # diagnosis: host time of every step (ms) on stderr
+        print("host ms per step: " + " ".join("%.2f" % (1e3 * x) for x in step_host), file=sys.stderr)
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

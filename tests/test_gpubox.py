@@ -35,7 +35,7 @@ def _config(tmp_path, epochs=2):
             "table_parameters.embedding.accessor": acc}
 
 
-def _run(tmp_path, device, kernels):
+def _run(tmp_path, device, kernels, loss_rtol=2e-5):
     from paddlerec_amd import gpubox, reader
     cfg = _config(tmp_path)
     torch.manual_seed(7)
@@ -87,7 +87,7 @@ def _run(tmp_path, device, kernels):
                 R.adam_update(mb[i], st[1][i][0], st[1][i][1], o["dbs"][i], step, lr=1e-3)
         want_loss.append(float(np.mean(losses)))
         want_deleted.append(ps_ref.shrink_rows(rec, lay, acc, 0.98, 0.15))
-    np.testing.assert_allclose(res["loss"], want_loss, rtol=2e-5)
+    np.testing.assert_allclose(res["loss"], want_loss, rtol=loss_rtol)
     assert res["deleted"] == want_deleted and want_deleted[0] > 0            # the shrink really deletes rows
     got = net.rec.cpu().numpy()
     so = L.stat_off
@@ -115,4 +115,6 @@ def test_gpubox_pass_loop_cpu_backend(tmp_path):
 
 @pytest.mark.gpu
 def test_gpubox_pass_loop_gpu(tmp_path, engine_lib):
-    _run(tmp_path, "cuda", None)
+    # pass 0 agrees to 2e-5; pass 1 runs on MLP weights that took Adam's lr-sized steps on ~eps-sized gradients (sign
+    # noise of the fp32 summation order), see the comment at the weight check
+    _run(tmp_path, "cuda", None, loss_rtol=2e-4)
