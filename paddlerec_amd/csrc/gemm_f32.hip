@@ -124,30 +124,44 @@ struct EpiArgs {
   int ld0, ld1, rs_stride, ld2;
 };
 
+// which per-element operands an epilogue reads besides the accumulator
 template <int EPI>
-__device__ __forceinline__ float apply_epi(float acc, int64_t i, int j, const EpiArgs& e) {
+struct EpiUses {
+  static constexpr bool aux0 = EPI == REC_EPI_RELU_MASK || EPI == REC_EPI_CROSS || EPI == REC_EPI_DTANH ||
+                               EPI == REC_EPI_DSIGMOID || EPI == REC_EPI_MOE || EPI == REC_EPI_ADD;
+  static constexpr bool aux1 = EPI == REC_EPI_CROSS || EPI == REC_EPI_MOE || EPI == REC_EPI_ADD;
+};
+template <int EPI>
+__device__ __forceinline__ float load_aux0(int64_t i, int j, const EpiArgs& e) {
+  if (EPI == REC_EPI_ADD) return e.aux0 ? e.aux0[i * e.ld0 + j] : 0.f;
+  return EpiUses<EPI>::aux0 ? e.aux0[i * e.ld0 + j] : 0.f;
+}
+template <int EPI>
+__device__ __forceinline__ float load_aux1(int64_t i, int j, const EpiArgs& e) {
+  return EpiUses<EPI>::aux1 ? e.aux1[i * e.ld1 + j] : 0.f;
+}
+
+// the epilogue on operands already in registers (x0 = aux0[i,j], x1 = aux1[i,j]): the tile store below first issues
+// every aux load of the tile and only then starts storing — C may alias nothing the compiler can prove, so loads
+// interleaved with the stores would each wait for the store in front of them (measured: 44 us of a 221 us dX GEMM)
+template <int EPI>
+__device__ __forceinline__ float apply_epi(float acc, float x0, float x1, int64_t i, int j, const EpiArgs& e) {
   if (EPI == REC_EPI_NONE) return acc;
   if (EPI == REC_EPI_BIAS) return acc + e.bias[j];
   if (EPI == REC_EPI_BIAS_RELU) return fmaxf(acc + e.bias[j], 0.f);
-  if (EPI == REC_EPI_RELU_MASK) return e.aux0[i * e.ld0 + j] > 0.f ? acc : 0.f;
-  if (EPI == REC_EPI_CROSS) return e.aux1[i * e.ld1 + j] + e.aux0[i * e.ld0 + j] * (acc + e.bias[j]);
-  if (EPI == REC_EPI_DTANH) {
-    const float a = e.aux0[i * e.ld0 + j];
-    return acc * (1.f - a * a);
-  }
-  if (EPI == REC_EPI_DSIGMOID) {
-    const float a = e.aux0[i * e.ld0 + j];
-    return acc * a * (1.f - a);
-  }
-  if (EPI == REC_EPI_MOE)
-    return e.aux1[i * e.ld1 + j] +
-           e.aux0[i * e.ld0 + j] * (e.row_scale[i * e.rs_stride] * (acc + e.bias[j]));
+  if (EPI == REC_EPI_RELU_MASK) return x0 > 0.f ? acc : 0.f;
+  if (EPI == REC_EPI_CROSS) return x1 + x0 * (acc + e.bias[j]);
+  if (EPI == REC_EPI_DTANH) return acc * (1.f - x0 * x0);
+  if (EPI == REC_EPI_DSIGMOID) return acc * x0 * (1.f - x0);
+  if (EPI == REC_EPI_MOE) return x1 + x0 * (e.row_scale[i * e.rs_stride] * (acc + e.bias[j]));
   if (EPI == REC_EPI_BIAS_SIGMOID) return 1.f / (1.f + expf(-(acc + e.bias[j])));
   if (EPI == REC_EPI_BIAS_TANH) return tanhf(acc + (e.bias ? e.bias[j] : 0.f));
-  if (EPI == REC_EPI_ADD)
-    return acc + (e.bias ? e.bias[j] : 0.f) + e.aux1[i * e.ld1 + j] +
-           (e.aux0 ? e.aux0[i * e.ld0 + j] : 0.f);
+  if (EPI == REC_EPI_ADD) return acc + (e.bias ? e.bias[j] : 0.f) + x1 + x0;
   return acc;
+}
+template <int EPI>
+__device__ __forceinline__ float apply_epi(float acc, int64_t i, int j, const EpiArgs& e) {
+  return apply_epi<EPI>(acc, load_aux0<EPI>(i, j, e), load_aux1<EPI>(i, j, e), i, j, e);
 }
 
 // --------------------------------------------------------------------------------------- kernel
@@ -297,8 +311,23 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N +
 
   // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
   float* out = partial ? partial + (int64_t)kz * M * ldc : C;
+  // one M-tile row block (16 rows x the wave's columns) at a time: all of its aux loads first, then its stores
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
+    float x0[4][NT], x1[4][NT];
+    if ((EpiUses<EPI>::aux0 || EpiUses<EPI>::aux1) && !partial) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t i = m0 + wm * WTM + a * 16 + g * 4 + r;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+          const int j = n0 + wn * WTN + b * 16 + li;
+          const bool ok = i < M && j < N;
+          x0[r][b] = ok ? load_aux0<EPI>(i, j, epi) : 0.f;
+          x1[r][b] = ok ? load_aux1<EPI>(i, j, epi) : 0.f;
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t i = m0 + wm * WTM + a * 16 + g * 4 + r;
@@ -308,7 +337,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N +
           const int j = n0 + wn * WTN + b * 16 + li;
           if (j < N) {
             const float v = acc[a][b][r];
-            out[i * ldc + j] = partial ? v : apply_epi<EPI>(v, i, j, epi);
+            out[i * ldc + j] = partial ? v : apply_epi<EPI>(v, x0[r][b], x1[r][b], i, j, epi);
             if (EPI == REC_EPI_CROSS && !partial && epi.out2) epi.out2[i * epi.ld2 + j] = v + epi.bias[j];
           }
         }
