@@ -110,5 +110,33 @@ for B, T in ((32, 152), (4096, 100), (4096, 512)):
     del m
     torch.cuda.empty_cache()
 
+# ---- sibling nets: xDeepFM (config.yaml: D 9, CIN 128-32, DNN 512-256-128) and DLRM (D 16, bot 512-256-64-16, top 512-256-2)
+from paddlerec_amd.dlrm import DLRMLayer  # noqa: E402
+from paddlerec_amd.xdeepfm import xDeepFMLayer  # noqa: E402
+
+for B in (4096, 65536):
+    ids = torch.randint(0, 1000001, (B, 26), device=DEV, generator=g)
+    dense = torch.rand(B, 13, device=DEV, generator=g)
+    label = (torch.rand(B, 1, device=DEV, generator=g) < 0.25).long()
+    m = xDeepFMLayer(1000001, 9, 13, 26, [128, 32], [512, 256, 128], device=DEV)
+    t = timeit(lambda: m.train_step(ids, dense, label, lr=1e-3), iters=3, warm=1)
+    fl_cin = 2.0 * B * 9 * (39 * 39 * 128 + 39 * 128 * 32)
+    fl_dnn = 2.0 * B * (351 * 512 + 512 * 256 + 256 * 128 + 128)
+    print("xDeepFM train step B=%d: %.2f ms  (%.2f M samples/s; CIN + DNN GEMMs %.1f TF executed, fwd + 2x bwd)"
+          % (B, t, B / t / 1e3, 3 * (fl_cin + fl_dnn) / t / 1e9))
+    record("sibling net", "xDeepFM (CIN 128-32 over 39 fields x D 9, DNN 512-256-128) train step, B %d; the CIN's "
+           "outer-product rows go through HBM in 1-GB chunks" % B, t, 3 * (fl_cin + fl_dnn), B)
+    del m
+    torch.cuda.empty_cache()
+    m = DLRMLayer(13, [512, 256, 64, 16], 1000001, 16, [512, 256, 2], 26, device=DEV)
+    t = timeit(lambda: m.train_step(ids, dense, label, lr=1e-3), iters=3, warm=1)
+    fl = 2.0 * B * (13 * 512 + 512 * 256 + 256 * 64 + 64 * 16 + 367 * 512 + 512 * 256 + 256 * 2 + 27 * 27 * 16)
+    print("DLRM train step B=%d: %.2f ms  (%.2f M samples/s; non-lazy Adam sweeps the 1M x 16 table every step)"
+          % (B, t, B / t / 1e3))
+    record("sibling net", "DLRM (bot 512-256-64-16, top 512-256-2, BatchNorm after every layer, 27 x 27 dot "
+           "interaction) train step with non-lazy Adam, B %d" % B, t, 3 * fl, B)
+    del m
+    torch.cuda.empty_cache()
+
 for d in JSON:
     print(json.dumps(d))
