@@ -330,6 +330,8 @@ def main():
                    "accessor record per row, born lazily), 26 slots of uint64 feasigns hashed on the device, 13 dense, "
                    "MLP %s, batch %d per GPU, AdaGrad accessor push" % (args.hashed_rows, world, D, args.fc, B),
                    "global_batch": world * B, "parallelism": parallelism,
+                   **({"exchange": "rec_alltoall_exchange (C-ABI, RCCL)" if model.comm.native is not None
+                       else "torch.distributed (RCCL)"} if dist is not None else {}),
                    "table_rows_total": N, "loss": loss_v, "index_oob_flag": oob},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,

@@ -61,6 +61,36 @@ class Comm:
         h = C.c_void_p()
         check(lib().rec_comm_init(raw, self.world, self.rank, C.byref(h)), "rec_comm_init")
         self.native = h
+        try:
+            self._selftest_native(dev)
+        except Exception as e:   # a broken exchange must not take the step down with it: RCCL through torch instead
+            import sys
+            print("[recengine] rank %d: native RCCL exchange self-test FAILED (%s) - using torch.distributed's RCCL "
+                  "collectives for the exchange" % (self.rank, e), file=sys.stderr, flush=True)
+            self.native = None
+        ok = torch.tensor([1 if self.native is not None else 0], dtype=torch.int64, device=dev)
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)    # every rank takes the same path
+        if int(ok.item()) == 0:
+            self.native = None
+
+    def _selftest_native(self, dev):
+        """One all-to-all (one int64 per peer, value = 1000*src + dst) and one all-reduce over the new communicator,
+        checked on the host, before any training data depends on it."""
+        G, r = self.world, self.rank
+        send = torch.tensor([1000 * r + d for d in range(G)], dtype=torch.int64, device=dev)
+        recv = torch.full((G,), -1, dtype=torch.int64, device=dev)
+        self._native_a2a(recv, send, [1] * G, [1] * G)
+        one = torch.ones(3, dtype=torch.float32, device=dev)
+        import ctypes as C
+        from ._lib import check, lib
+        check(lib().rec_allreduce_sum_f32(self.native, C.c_void_p(one.data_ptr()), one.numel(),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rec_allreduce_sum_f32")
+        torch.cuda.synchronize()
+        want = [1000 * s_ + r for s_ in range(G)]
+        if recv.tolist() != want:
+            raise RuntimeError("all-to-all returned %s, expected %s" % (recv.tolist(), want))
+        if one.tolist() != [float(G)] * 3:
+            raise RuntimeError("all-reduce returned %s, expected %d" % (one.tolist(), G))
 
     def _native_a2a(self, out, inp, out_splits, in_splits):
         import ctypes as C
