@@ -270,15 +270,24 @@ class DeepFMLayer:
             groups = self._groups = self.k.IdGroups(B * S, self.device)
         with self._timed("fm_fwd"):
             y1, y2, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
-        # SelectedRows merge keys only depend on ids: sort them on a side stream, hidden behind the
-        # MFMA-bound GEMMs (started after the HBM-bound lookup so the two do not fight for bandwidth)
-        with _OnSide(side, cur):
-            self.k.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
-                             self.fm.slot_offset, self.status, groups)
+        # SelectedRows merge keys only depend on ids: sort them on a side stream, hidden behind the MFMA-bound GEMMs.
+        # REC_DEEPFM_GROUP_AT (measurement knob): "bwd" = under the dX chain (default: 2.83 ms/step), "fwd" = under
+        # the forward GEMMs (2.875 ms; gpurun call 25) — the sort costs the GEMMs it runs beside about its own time
+        # either way, the backward chain absorbs it slightly better
+        group_at = os.environ.get("REC_DEEPFM_GROUP_AT", "bwd")
+
+        def issue_group():
+            with _OnSide(side, cur):
+                self.k.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
+                                 self.fm.slot_offset, self.status, groups)
+        if group_at == "fwd":
+            issue_group()
         mlp_w, mlp_dw = self._mlp_weights()
         with self._timed("mlp_fwd"):
             y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), mlp_w, self.mlp_b, self.ws_mlp)
         pred, dz, loss = self.k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws)
+        if group_at != "fwd":
+            issue_group()
         if auc_stats is not None:
             self.k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         with self._timed("mlp_bwd"):

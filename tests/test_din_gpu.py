@@ -64,12 +64,13 @@ def test_attention_pool_vs_oracle(engine_lib, B, Tn, Ei, Ec):
     np.testing.assert_allclose(N_(attw).sum(1), 1.0, rtol=1e-5)
 
 
-def test_attention_pool_known_answers(engine_lib):
+@pytest.mark.parametrize("Ei,Ec", [(8, 8), (64, 64)])      # runtime-shaped kernel / the compile-time-shaped one (E 128)
+def test_attention_pool_known_answers(engine_lib, Ei, Ec):
     from paddlerec_amd import ops
     rng = np.random.default_rng(1)
-    B, Tn, Ei, Ec = 4, 70, 8, 8
+    B, Tn = 4, 70
     E = Ei + Ec
-    tabs = [rng.standard_normal((50, 8)).astype(np.float32) for _ in range(4)]
+    tabs = [rng.standard_normal((50, d)).astype(np.float32) for d in (Ei, Ec, Ei, Ec)]
     hi = rng.integers(0, 50, (B, Tn)); hc = rng.integers(0, 50, (B, Tn))
     lens = np.array([70, 33, 1, 64])
     mask = np.where(np.arange(Tn)[None] < lens[:, None], 0, -1000000000).astype(np.int64)
@@ -83,9 +84,20 @@ def test_attention_pool_known_answers(engine_lib):
         np.testing.assert_allclose(N_(out)[b], h[b, :n].mean(0), rtol=1e-5, atol=1e-6)
     # out-of-range id: flagged, row read as zero
     hi2 = hi.copy(); hi2[0, 0] = 50
-    _, _, status = ops.din_attention_pool(T(hi2), T(hc), T(hi), T(hc), T(mask), *[T(t) for t in tabs],
-                                          [T(w) for w in zw], [T(b) for b in zb])
+    out2, _, status = ops.din_attention_pool(T(hi2), T(hc), T(hi), T(hc), T(mask), *[T(t) for t in tabs],
+                                             [T(w) for w in zw], [T(b) for b in zb])
     assert int(status.item()) & 1
+    h2 = h.copy()
+    h2[0, 0, :Ei] = 0
+    np.testing.assert_allclose(N_(out2)[0], h2[0].mean(0), rtol=1e-5, atol=1e-6)
+    # negative id in the last tile of a sample, on the category table
+    hc2 = hc.copy(); hc2[1, 32] = -7
+    out3, _, status = ops.din_attention_pool(T(hi), T(hc2), T(hi), T(hc), T(mask), *[T(t) for t in tabs],
+                                             [T(w) for w in zw], [T(b) for b in zb])
+    assert int(status.item()) & 1
+    h3 = h.copy()
+    h3[1, 32, Ei:] = 0
+    np.testing.assert_allclose(N_(out3)[1], h3[1, :33].mean(0), rtol=1e-5, atol=1e-6)
 
 
 def _din_problem(rng, B, Tn, ni, nc):
