@@ -286,13 +286,14 @@ class DeepFMLayer:
         with self._timed("mlp_fwd"):
             y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), mlp_w, self.mlp_b, self.ws_mlp)
         pred, dz, loss = self.k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws)
-        if group_at != "fwd":
+        if group_at == "bwd":
             issue_group()
         if auc_stats is not None:
             self.k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
+        defer_all = os.environ.get("REC_DEEPFM_DEFER_ALL", "0") == "1"   # measurement knob: every dW GEMM in the tail
         with self._timed("mlp_bwd"):
-            d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db,
-                                                     self.ws_mlp, defer_first=True)
+            d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db, self.ws_mlp,
+                                                     **(dict(defer_all=True) if defer_all else dict(defer_first=True)))
         with self._timed("fm_bwd"):
             row_grad, _, _ = self.k.deepfm_fm_bwd(
                 dense_inputs, feat, sum_emb, d_flat.view(B, self.fp, -1), dz, dz, S, self.ws,
@@ -304,6 +305,8 @@ class DeepFMLayer:
         # dW_0 GEMM; it needs row_grad / dz and the merge keys (sorted on that same stream earlier).
         t = self.step_count
         st = self.sparse_state
+        if group_at == "tail":
+            issue_group()
         with _OnSide(side, cur):
             with self._timed("sparse_adam"):
                 upd = self.k.sparse_adam_rows if self.lazy_mode else self.k.adam_rows_all
