@@ -13,9 +13,11 @@ fused embedding+FM forward, MLP GEMMs, loss head, MLP backward, FM backward, Sel
 lazy sparse Adam on both tables, dense Adam.  Lazy Adam is the reference's static-graph optimizer
 (deepfm/static_model.py:83-84) and the only one that scales to the 10B-row table of configs[4].
 
-N>1: weak scaling — every rank keeps batch 65536 and 26M/N... see DESIGN.md §multi-GPU: table rows
-are sharded row-wise (row r on rank r % N), ids/rows/grads exchanged by RCCL all-to-all, dense
-gradients all-reduced.
+N>1 (BASELINE.json configs[4]): weak scaling on the hashed gpubox table — every rank keeps batch 65536 and owns
+1.25e9 rows (one 128-B record each, 160 GB) of a table that grows with N: 10^10 rows at 8 GPUs.  uint64 feasigns are
+hashed to rows on the device, rows are sharded row-wise (row r on rank r % N) and born at their first pull, ids / rows /
+gradients are exchanged by RCCL all-to-all over xGMI, the PS accessor (AdaGrad rule, show / click) updates the touched
+rows, dense gradients are all-reduced.  `--table adam` keeps the lazy-Adam record table of N = 1 (26M rows per GPU).
 
 Prints ONE JSON line (rank 0).
 """
@@ -189,14 +191,18 @@ def main():
     ap.add_argument("--shared-table", action="store_true",
                     help="layout (2b) of SURVEY §8(d), the reference's own: ONE table of rows-per-table (+1) rows shared "
                          "by the 26 slots (deepfm/config.yaml:48-50 with --dim 9, benchmark.yaml:21 with --dim 10)")
-    ap.add_argument("--table", choices=("adam", "ps"), default="adam",
+    ap.add_argument("--table", choices=("auto", "adam", "ps"), default="auto",
                     help="ps = BASELINE configs[4]: the hashed gpubox table (uint64 feasigns -> mix64 %% N rows on the "
-                         "device, AdaGrad accessor record, rows born lazily), row-sharded; implies the sharded path")
+                         "device, AdaGrad accessor record, rows born lazily), row-sharded; implies the sharded path.  "
+                         "auto (default): adam on one GPU (configs[1]), ps on N > 1 GPUs — 1.25e9 rows per GPU, i.e. "
+                         "the 10^10-row table of configs[4] at 8 GPUs (weak scaling: the table grows with N)")
     ap.add_argument("--hashed-rows", type=int, default=1_250_000_000,
                     help="--table ps: table rows PER GPU (10^10 / 8 = 1.25e9 = 160 GB of 128-B records)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.table == "auto":
+        args.table = "ps" if world > 1 else "adam"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
