@@ -260,10 +260,22 @@ __global__ __launch_bounds__(kMsWaves * kWave, kMsWaves == 8 ? 6 : 3) void multi
   }
 }
 
-__global__ void feasign_rows_kernel(int64_t n, int64_t N, const int64_t* __restrict__ keys,
+// the same multiply-high modulo as the pool kernel's fused hash (one implementation, one test surface)
+__global__ void feasign_rows_kernel(int64_t n, FastMod fm, const int64_t* __restrict__ keys,
                                     int64_t* __restrict__ rows) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) rows[i] = feasign_row((uint64_t)keys[i], N);
+  if (i < n) {
+    const uint64_t k = (uint64_t)keys[i];
+    rows[i] = k == 0 ? 0 : (int64_t)(1 + fast_mod(mix64(k), fm));
+  }
+}
+
+// magic = floor(2^64 / d); d == 1 (a two-row table): 2^64 - 1 makes the estimate x - 1 and the correction step lands on 0
+inline FastMod make_fastmod(uint64_t d) {
+  FastMod f;
+  f.d = d;
+  f.magic = d > 1 ? (uint64_t)((((unsigned __int128)1) << 64) / d) : ~0ull;
+  return f;
 }
 
 }  // namespace rec
@@ -283,7 +295,7 @@ extern "C" int rec_feasign_rows(int64_t n, int64_t num_rows, const int64_t* keys
   const int64_t grid = (n + kBlock - 1) / kBlock;
   REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "n too large");
   hipLaunchKernelGGL(feasign_rows_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, n,
-                     num_rows, keys, rows);
+                     make_fastmod((uint64_t)(num_rows - 1)), keys, rows);
   return check_launch("rec_feasign_rows");
 }
 
@@ -316,11 +328,8 @@ extern "C" int rec_multislot_sumpool_fwd(const rec_multislot_desc* d, const int6
   REC_REQUIRE(d->init_range <= 0.f || (d->state_offset >= D && d->state_offset < d->row_stride &&
                                         d->init_dims >= 0 && d->init_dims <= D),
               REC_EINVAL, "lazy creation needs the state float inside the row, behind the weights");
-  FastMod fmod = {1, 0};
-  if (d->key_mode == 1) {
-    fmod.d = (uint64_t)(d->num_rows - 1);
-    fmod.magic = fmod.d > 1 ? (uint64_t)((((unsigned __int128)1) << 64) / fmod.d) : 0;   // d == 1: x % 1 == 0 either way
-  }
+  FastMod fmod = make_fastmod(1);
+  if (d->key_mode == 1) fmod = make_fastmod((uint64_t)(d->num_rows - 1));
   hipStream_t st = (hipStream_t)stream;
 #define REC_MS_LAUNCH(V, L, NSW_, W_)                                                                   \
   {                                                                                                     \

@@ -211,6 +211,20 @@ def test_multislot_sumpool_vs_oracle(engine_lib, D, stride, B, S, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [2, 1_000_003, 1_250_000_000, 2 ** 32 + 7, 10 ** 10, 2 ** 62 + 1])
+def test_feasign_rows_device_matches_oracle_at_configs4_sizes(engine_lib, N):
+    """uint64 feasign -> row of the hashed table on the device (multiply-high exact modulo), bit-exact against the
+    oracle for divisors below and above 2^32 — 10^10 rows is BASELINE configs[4]'s table, 1.25e9 one GPU's share."""
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(N % 1000)
+    keys = rng.integers(0, 2 ** 64, size=20011, dtype=np.uint64)
+    keys[:8] = [0, 1, 2 ** 63, 2 ** 64 - 1, 2 ** 63 + 5, 12345678901234567890, N, N - 1]
+    got = ops.feasign_rows(T(keys.view(np.int64)), N).cpu().numpy()
+    assert np.array_equal(got, M.feasign_rows(keys, N))
+    assert got[0] == 0 and got[1:].min() >= 1 and got.max() < N
+
+
+@pytest.mark.gpu
 def test_multislot_feasign_keys_oob_and_long_segments(engine_lib):
     from paddlerec_amd import _lib, ops
     rng = np.random.default_rng(5)
