@@ -467,6 +467,16 @@ int rec_cin_outer_bwd(int64_t batch, int32_t emb_dim, int32_t F, int32_t S, cons
                       float* dX0, const rec_cin_view* dv0, int32_t accumulate_dx0, float* dXk,
                       const rec_cin_view* dvk, int32_t accumulate_dxk, const float* dpool, int64_t ld_dpool,
                       void* stream);
+/* The other association of a layer, chosen when C < S (then Y is smaller than Z and its GEMM better shaped):
+ *   Y = Xk @ W'^T  with W' = the same conv weight viewed [C*F, S]   (rec_gemm_f32, trans_b; M = B*D, K = S, N = C*F)
+ *   rec_cin_contract_fwd : XT_{k+1}[(b,d), c] = sum_f X0[b,f,d] * Y[(b,d), c*F + f]
+ *   rec_cin_contract_bwd : dY[(b,d), c*F+f] = dXT[(b,d), c] * X0[b,f,d];  dX0[b,f,d] (+)= sum_c dXT[(b,d),c] Y[(b,d), c*F+f]
+ *   (then dW' = dY^T @ Xk and dXk = dY @ W' are plain GEMMs). */
+int rec_cin_contract_fwd(int64_t batch, int32_t emb_dim, int32_t F, int32_t C, const float* Y, int64_t ldy,
+                         const float* X0, const rec_cin_view* v0, float* XT, int64_t ldx, void* stream);
+int rec_cin_contract_bwd(int64_t batch, int32_t emb_dim, int32_t F, int32_t C, const float* Y, int64_t ldy,
+                         const float* dXT, int64_t ldx, const float* X0, const rec_cin_view* v0, float* dY,
+                         int64_t lddy, float* dX0, const rec_cin_view* dv0, int32_t accumulate_dx0, void* stream);
 int rec_cin_sumpool(int64_t batch, int32_t emb_dim, int32_t C, const float* XT, int64_t ldx, float* out,
                     int64_t ldo, void* stream);
 int rec_cin_sumpool_bwd(int64_t batch, int32_t emb_dim, int32_t C, const float* dpool, int64_t ldp,

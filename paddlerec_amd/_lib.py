@@ -156,6 +156,9 @@ SIGNATURES = {
     "rec_cin_outer_fwd": (C.c_int, [_I64, _I32, _I32, _I32, _P, C.POINTER(CinView), _P, C.POINTER(CinView), _P, _I64, _P]),
     "rec_cin_outer_bwd": (C.c_int, [_I64, _I32, _I32, _I32, _P, _I64, _P, C.POINTER(CinView), _P, C.POINTER(CinView),
                                     _P, C.POINTER(CinView), _I32, _P, C.POINTER(CinView), _I32, _P, _I64, _P]),
+    "rec_cin_contract_fwd": (C.c_int, [_I64, _I32, _I32, _I32, _P, _I64, _P, C.POINTER(CinView), _P, _I64, _P]),
+    "rec_cin_contract_bwd": (C.c_int, [_I64, _I32, _I32, _I32, _P, _I64, _P, _I64, _P, C.POINTER(CinView), _P, _I64,
+                                       _P, C.POINTER(CinView), _I32, _P]),
     "rec_cin_sumpool": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _I64, _P]),
     "rec_cin_sumpool_bwd": (C.c_int, [_I64, _I32, _I32, _P, _I64, _P, _I64, _P]),
     "rec_cross_bwd_prep": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _I32, _P]),

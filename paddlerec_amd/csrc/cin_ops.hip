@@ -105,6 +105,71 @@ __global__ __launch_bounds__(kBlock) void cin_sumpool_bwd_kernel(int64_t B, int 
   dXT[r * ldx + c] = dpool[(r / D) * ldp + c];
 }
 
+// ---- the other association of a CIN layer:  X_{k+1}[m,c] = sum_f X0[m,f] * Y[m, c*F + f],   Y = Xk @ W'^T  with
+// W' = the conv weight viewed [C*F, S].  Y is B*D*C*F floats where Z is B*D*F*S: the smaller one goes through HBM
+// (layer 2 of the reference config: C 32 < S 128 -> Y is a quarter of Z, and its GEMM is K 128 x N 1248 instead of
+// K 4992 x N 32).  One wave per row (b,d): the Y row staged in LDS, lane c walks its F consecutive values.
+__global__ __launch_bounds__(kBlock) void cin_contract_fwd_kernel(int64_t rows, int D, int F, int C, const float* __restrict__ Y,
+                                                                  int64_t ldy, const float* __restrict__ X0, View v0,
+                                                                  float* __restrict__ XT, int64_t ldx) {
+  extern __shared__ float smem[];
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int CF = C * F;
+  float* ys = smem + (size_t)wave * (CF + F);
+  float* xs = ys + CF;
+  for (int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + wave; r < rows; r += (int64_t)gridDim.x * (kBlock / kWave)) {
+    const int64_t b = r / D;
+    const int d = (int)(r - b * D);
+    const float* yrow = Y + r * ldy;
+    for (int i = lane; i < CF; i += kWave) ys[i] = yrow[i];
+    for (int f = lane; f < F; f += kWave) xs[f] = X0[at(v0, b, f, d)];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < C; c += kWave) {
+      float a = 0.f;
+      for (int f = 0; f < F; ++f) a += xs[f] * ys[c * F + f];          // fixed order over f
+      XT[r * ldx + c] = a;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// dY[m, c*F+f] = dXT[m,c] * X0[m,f];   dX0[m,f] (+)= sum_c dXT[m,c] * Y[m, c*F+f]
+__global__ __launch_bounds__(kBlock) void cin_contract_bwd_kernel(int64_t rows, int D, int F, int C, const float* __restrict__ Y,
+                                                                  int64_t ldy, const float* __restrict__ dXT, int64_t ldx,
+                                                                  const float* __restrict__ X0, View v0,
+                                                                  float* __restrict__ dY, int64_t lddy, float* dX0,
+                                                                  View dv0, int acc0) {
+  extern __shared__ float smem[];
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int CF = C * F;
+  float* ys = smem + (size_t)wave * (CF + F + C);
+  float* xs = ys + CF;
+  float* gs = xs + F;
+  for (int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + wave; r < rows; r += (int64_t)gridDim.x * (kBlock / kWave)) {
+    const int64_t b = r / D;
+    const int d = (int)(r - b * D);
+    const float* yrow = Y + r * ldy;
+    for (int i = lane; i < CF; i += kWave) ys[i] = yrow[i];
+    for (int f = lane; f < F; f += kWave) xs[f] = X0[at(v0, b, f, d)];
+    for (int c = lane; c < C; c += kWave) gs[c] = dXT[r * ldx + c];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    float* dyrow = dY + r * lddy;
+    for (int c = 0; c < C; ++c) {
+      const float g = gs[c];
+      for (int f = lane; f < F; f += kWave) dyrow[c * F + f] = g * xs[f];
+    }
+    for (int f = lane; f < F; f += kWave) {
+      float a = 0.f;
+      for (int c = 0; c < C; ++c) a += gs[c] * ys[c * F + f];          // fixed order over c
+      float* o = dX0 + at(dv0, b, f, d);
+      *o = (acc0 ? *o : 0.f) + a;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 View view_of(const rec_cin_view* v) { return View{v->stride_b, v->stride_j, v->stride_d}; }
 
 }  // namespace
@@ -172,4 +237,37 @@ extern "C" int rec_cin_sumpool_bwd(int64_t batch, int32_t emb_dim, int32_t C, co
   hipLaunchKernelGGL(cin_sumpool_bwd_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                      (hipStream_t)stream, batch, emb_dim, C, dpool, ldp, dXT, ldx);
   return check_launch("rec_cin_sumpool_bwd");
+}
+
+extern "C" int rec_cin_contract_fwd(int64_t batch, int32_t emb_dim, int32_t F, int32_t C, const float* Y, int64_t ldy,
+                                    const float* X0, const rec_cin_view* v0, float* XT, int64_t ldx, void* stream) {
+  REC_REQUIRE(batch >= 0 && emb_dim > 0 && F > 0 && C > 0 && ldy >= (int64_t)C * F && ldx >= C, REC_EINVAL, "bad sizes");
+  if (batch == 0) return REC_OK;
+  REC_REQUIRE(Y && X0 && XT && v0, REC_EINVAL, "null pointer argument");
+  const size_t shmem = sizeof(float) * (kBlock / kWave) * ((size_t)C * F + F);
+  REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "CIN row of %d x %d does not fit the LDS stage", C, F);
+  const int64_t rows = batch * emb_dim;
+  int64_t grid = (rows + kBlock / kWave - 1) / (kBlock / kWave);
+  if (grid > 32 * kNumCU) grid = 32 * kNumCU;
+  hipLaunchKernelGGL(cin_contract_fwd_kernel, dim3((unsigned)grid), dim3(kBlock), shmem, (hipStream_t)stream, rows,
+                     emb_dim, F, C, Y, ldy, X0, view_of(v0), XT, ldx);
+  return check_launch("rec_cin_contract_fwd");
+}
+
+extern "C" int rec_cin_contract_bwd(int64_t batch, int32_t emb_dim, int32_t F, int32_t C, const float* Y, int64_t ldy,
+                                    const float* dXT, int64_t ldx, const float* X0, const rec_cin_view* v0, float* dY,
+                                    int64_t lddy, float* dX0, const rec_cin_view* dv0, int32_t accumulate_dx0,
+                                    void* stream) {
+  REC_REQUIRE(batch >= 0 && emb_dim > 0 && F > 0 && C > 0 && ldy >= (int64_t)C * F && lddy >= (int64_t)C * F &&
+                  ldx >= C, REC_EINVAL, "bad sizes");
+  if (batch == 0) return REC_OK;
+  REC_REQUIRE(Y && dXT && X0 && dY && dX0 && v0 && dv0, REC_EINVAL, "null pointer argument");
+  const size_t shmem = sizeof(float) * (kBlock / kWave) * ((size_t)C * F + F + C);
+  REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "CIN row of %d x %d does not fit the LDS stage", C, F);
+  const int64_t rows = batch * emb_dim;
+  int64_t grid = (rows + kBlock / kWave - 1) / (kBlock / kWave);
+  if (grid > 32 * kNumCU) grid = 32 * kNumCU;
+  hipLaunchKernelGGL(cin_contract_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), shmem, (hipStream_t)stream, rows,
+                     emb_dim, F, C, Y, ldy, dXT, ldx, X0, view_of(v0), dY, lddy, dX0, view_of(dv0), accumulate_dx0);
+  return check_launch("rec_cin_contract_bwd");
 }

@@ -679,6 +679,30 @@ def cin_outer_bwd(B, D, F, S, dZ, X0, v0, Xk, vk, dX0, dv0, acc0, dXk, dvk, acck
           "rec_cin_outer_bwd")
 
 
+def cin_contract_fwd(B, D, F, Y, X0, v0, XT):
+    """XT[(b,d), c] = sum_f X0[b,f,d] * Y[(b,d), c*F+f]   (the C < S association of a CIN layer)."""
+    _chk_f32(X0, "X0")
+    ldy, ldx = _chk_mat(Y, "Y"), _chk_mat(XT, "XT")
+    Cc = XT.shape[1]
+    if tuple(Y.shape) != (B * D, Cc * F) or XT.shape[0] != B * D:
+        raise RecError("Y must be [B*D, C*F] and XT [B*D, C]")
+    check(lib().rec_cin_contract_fwd(B, D, F, Cc, _p(Y), ldy, _p(X0), C.byref(v0), _p(XT), ldx, _stream()),
+          "rec_cin_contract_fwd")
+    return XT
+
+
+def cin_contract_bwd(B, D, F, Y, dXT, X0, v0, dY, dX0, dv0, acc0):
+    """dY = dXT (x) X0;  dX0 (+)= sum_c dXT[.,c] * Y[., c*F+f]."""
+    for t, n in ((X0, "X0"), (dX0, "dX0")):
+        _chk_f32(t, n)
+    ldy, ldx, lddy = _chk_mat(Y, "Y"), _chk_mat(dXT, "dXT"), _chk_mat(dY, "dY")
+    Cc = dXT.shape[1]
+    if tuple(Y.shape) != (B * D, Cc * F) or tuple(dY.shape) != (B * D, Cc * F) or dXT.shape[0] != B * D:
+        raise RecError("Y / dY must be [B*D, C*F] and dXT [B*D, C]")
+    check(lib().rec_cin_contract_bwd(B, D, F, Cc, _p(Y), ldy, _p(dXT), ldx, _p(X0), C.byref(v0), _p(dY), lddy,
+                                     _p(dX0), C.byref(dv0), int(acc0), _stream()), "rec_cin_contract_bwd")
+
+
 def cin_sumpool(B, D, XT, out):
     """out[b,c] = sum_d XT[(b,d), c]   (net.py:195-198); out may be a column window of the pooled-feature row."""
     ldx, ldo = _chk_mat(XT, "XT"), _chk_mat(out, "out")

@@ -75,6 +75,12 @@ class xDeepFMLayer(DeepFMLayer):
         per = max(1, Z_CHUNK_BYTES // (4 * D * K))
         return [(b0, min(B, b0 + per)) for b0 in range(0, B, per)]
 
+    @staticmethod
+    def _use_y(i, S, Cn):
+        """Which association a CIN layer takes: Y = Xk W'^T (C*F columns) when it is smaller than Z (F*S columns); layer 0
+        always takes Z (its Xk is feat_embeddings, not a d-major matrix)."""
+        return i > 0 and Cn < S
+
     def _z(self, rows, K):
         """Grow-only scratch for the outer-product rows of one batch chunk (Z forward, dZ backward)."""
         if self._zbuf is None or self._zbuf.numel() < rows * K:
@@ -97,7 +103,13 @@ class xDeepFMLayer(DeepFMLayer):
         for i, Cn in enumerate(self.layer_sizes_cin):
             xk, mk = self._layer_inputs(feat, xts, i)
             xt = torch.empty(B * D, Cn, dtype=torch.float32, device=self.device)
-            for b0, b1 in self._chunks(B, F * S):
+            if self._use_y(i, S, Cn):       # C < S: Y = Xk @ W'^T [., C*F] is smaller than Z [., F*S] and better shaped
+                for b0, b1 in self._chunks(B, F * Cn):
+                    n = b1 - b0
+                    y = self._z(n * D, Cn * F)
+                    k.gemm(xk[b0 * D:b1 * D], self.cin_w[i].view(Cn * F, S), self.ws, trans_b=True, out=y)
+                    k.cin_contract_fwd(n, D, F, y, feat[b0:b1], k.cin_view(feat, "bfd"), xt[b0 * D:b1 * D])
+            for b0, b1 in ([] if self._use_y(i, S, Cn) else self._chunks(B, F * S)):
                 n = b1 - b0
                 z = self._z(n * D, F * S)
                 xk_c = xk[b0:b1] if i == 0 else xk[b0 * D:b1 * D]
@@ -121,7 +133,24 @@ class xDeepFMLayer(DeepFMLayer):
             S = F if i == 0 else self.layer_sizes_cin[i - 1]
             xk, mk = self._layer_inputs(feat, xts, i)
             dxk = dfeat if i == 0 else torch.empty(B * D, S, dtype=torch.float32, device=self.device)
-            for ci, (b0, b1) in enumerate(self._chunks(B, F * S)):
+            use_y = self._use_y(i, S, Cn)
+            if use_y:
+                w2 = self.cin_w[i].view(Cn * F, S)
+                dw2 = self.cin_dw[i].view(Cn * F, S)
+                k.cin_sumpool_bwd(B, D, dpooled[:, offs[i - 1]:offs[i - 1] + S], dxk)       # the pooled-feature gradient
+                for ci, (b0, b1) in enumerate(self._chunks(B, 2 * F * Cn)):
+                    n = b1 - b0
+                    both = self._z(2 * n * D, Cn * F)
+                    y, dy = both[: n * D], both[n * D:]
+                    xk_c, g = xk[b0 * D:b1 * D], dxt[b0 * D:b1 * D]
+                    k.gemm(xk_c, w2, self.ws, trans_b=True, out=y)                            # Y recomputed
+                    k.cin_contract_bwd(n, D, F, y, g, feat[b0:b1], k.cin_view(feat, "bfd"), dy, dfeat[b0:b1],
+                                       k.cin_view(dfeat, "bfd"), True)
+                    k.gemm(dy, xk_c, self.ws, trans_a=True, out=dw2,
+                           **(dict(epilogue="add", aux1=dw2) if ci > 0 else {}))              # dW' = dY^T Xk
+                    dxk_c = dxk[b0 * D:b1 * D]
+                    k.gemm(dy, w2, self.ws, epilogue="add", aux1=dxk_c, out=dxk_c)            # dXk = dY W' + pooled grad
+            for ci, (b0, b1) in enumerate([] if use_y else self._chunks(B, F * S)):
                 n = b1 - b0
                 z = self._z(n * D, F * S)
                 xk_c = xk[b0:b1] if i == 0 else xk[b0 * D:b1 * D]

@@ -503,6 +503,23 @@ def cin_outer_bwd(B, D, F, S, dZ, X0, v0, Xk, vk, dX0, dv0, acc0, dXk, dvk, acck
     ok[...] = (ok if acck else 0) + bk
 
 
+def cin_contract_fwd(B, D, F, Y, X0, v0, XT):
+    x0 = _cin_bsd(X0, v0, B, D)                                    # [B,F,D]
+    y = _n(Y).reshape(B, D, -1, F)                                 # [B,D,C,F]
+    XT.copy_(torch.from_numpy(np.einsum("bfd,bdcf->bdc", x0, y).reshape(B * D, -1).astype(np.float32)))
+    return XT
+
+
+def cin_contract_bwd(B, D, F, Y, dXT, X0, v0, dY, dX0, dv0, acc0):
+    x0 = _cin_bsd(X0, v0, B, D)
+    y = _n(Y).reshape(B, D, -1, F)
+    g = _n(dXT).reshape(B, D, -1)
+    dY.copy_(torch.from_numpy(np.einsum("bdc,bfd->bdcf", g, x0).reshape(B * D, -1).astype(np.float32)))
+    a = np.einsum("bdc,bdcf->bfd", g, y).astype(np.float32)
+    o0 = _cin_bsd(dX0, dv0, B, D)
+    o0[...] = (o0 if acc0 else 0) + a
+
+
 def cin_sumpool(B, D, XT, out):
     x = _n(XT)
     out.copy_(torch.from_numpy(x.reshape(B, D, -1).sum(axis=1, dtype=np.float32)))

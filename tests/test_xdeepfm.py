@@ -217,6 +217,34 @@ def test_cin_kernels_vs_numpy(engine_lib, B, D, F, S, layer0):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,D,F,C", [(5, 9, 39, 32), (3, 16, 27, 7), (1, 4, 3, 1), (40, 9, 39, 4), (2, 9, 40, 64)])
+def test_cin_contract_kernels_vs_numpy(engine_lib, B, D, F, C):
+    """The C < S association: XT = sum_f X0 * Y and its backward (dY, dX0), through strided views."""
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(B * 10 + C)
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    feat_wide = rng.standard_normal((B, F, D + 2)).astype(np.float32)
+    tf = T(feat_wide)[:, :, 1:1 + D]
+    feat = feat_wide[:, :, 1:1 + D]
+    y_wide = rng.standard_normal((B * D, C * F + 3)).astype(np.float32)
+    ty = T(y_wide)[:, :C * F]
+    y4 = y_wide[:, :C * F].reshape(B, D, C, F).astype(np.float64)
+    xt = torch.zeros(B * D, C + 1, device="cuda")
+    ops.cin_contract_fwd(B, D, F, ty, tf, ops.cin_view(tf, "bfd"), xt[:, :C])
+    want = np.einsum("bfd,bdcf->bdc", feat.astype(np.float64), y4).reshape(B * D, C)
+    np.testing.assert_allclose(xt.cpu().numpy()[:, :C], want, rtol=1e-5, atol=1e-5)
+    assert float(xt[:, C].abs().max()) == 0
+    g = rng.standard_normal((B * D, C)).astype(np.float32)
+    d0 = rng.standard_normal((B, F, D)).astype(np.float32)
+    td0 = T(d0)
+    dy = torch.empty(B * D, C * F, device="cuda")
+    ops.cin_contract_bwd(B, D, F, ty, T(g), tf, ops.cin_view(tf, "bfd"), dy, td0, ops.cin_view(td0, "bfd"), True)
+    g3 = g.reshape(B, D, C).astype(np.float64)
+    np.testing.assert_array_equal(dy.cpu().numpy(), np.einsum("bdc,bfd->bdcf", g.reshape(B, D, C), feat).reshape(B * D, -1))
+    np.testing.assert_allclose(td0.cpu().numpy(), d0 + np.einsum("bdc,bdcf->bfd", g3, y4), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
 def test_xdeepfm_layer_gpu(engine_lib):
     _check_layer("cuda", None, (2e-5, 2e-4))
 
