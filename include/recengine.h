@@ -558,8 +558,8 @@ typedef struct {
   int32_t row_scale_stride;
   float* out2;              /* [M, ld_out2] or NULL: REC_EPI_CROSS also stores u = acc + bias (for backward) */
   int32_t ld_out2;
-  float* b_colsum;          /* [N] or NULL: also return the column sums of op(B) over K — the bias
-                               gradient when the call computes dW = X^T dY (B = dY), at no extra pass */
+  float* b_colsum;          /* [N] or NULL (trans_a calls only): also return the column sums of B over K — the
+                               bias gradient when the call computes dW = X^T dY (B = dY), at no extra pass */
 } rec_gemm_epilogue_args;
 
 int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* bytes);

@@ -144,24 +144,33 @@ __device__ __forceinline__ float load_aux1(int64_t i, int j, const EpiArgs& e) {
 // the epilogue on operands already in registers (x0 = aux0[i,j], x1 = aux1[i,j]): the tile store below first issues
 // every aux load of the tile and only then starts storing — C may alias nothing the compiler can prove, so loads
 // interleaved with the stores would each wait for the store in front of them (measured: 44 us of a 221 us dX GEMM)
+// bias[j] (0 where the epilogue has none / the pointer is null): like the aux operands, loaded ahead of the stores
 template <int EPI>
-__device__ __forceinline__ float apply_epi(float acc, float x0, float x1, int64_t i, int j, const EpiArgs& e) {
+__device__ __forceinline__ float load_bias(int j, const EpiArgs& e) {
+  if (EPI == REC_EPI_BIAS || EPI == REC_EPI_BIAS_RELU || EPI == REC_EPI_CROSS || EPI == REC_EPI_MOE ||
+      EPI == REC_EPI_BIAS_SIGMOID)
+    return e.bias[j];
+  if (EPI == REC_EPI_BIAS_TANH || EPI == REC_EPI_ADD) return e.bias ? e.bias[j] : 0.f;
+  return 0.f;
+}
+template <int EPI>
+__device__ __forceinline__ float apply_epi(float acc, float x0, float x1, float bj, int64_t i, const EpiArgs& e) {
   if (EPI == REC_EPI_NONE) return acc;
-  if (EPI == REC_EPI_BIAS) return acc + e.bias[j];
-  if (EPI == REC_EPI_BIAS_RELU) return fmaxf(acc + e.bias[j], 0.f);
+  if (EPI == REC_EPI_BIAS) return acc + bj;
+  if (EPI == REC_EPI_BIAS_RELU) return fmaxf(acc + bj, 0.f);
   if (EPI == REC_EPI_RELU_MASK) return x0 > 0.f ? acc : 0.f;
-  if (EPI == REC_EPI_CROSS) return x1 + x0 * (acc + e.bias[j]);
+  if (EPI == REC_EPI_CROSS) return x1 + x0 * (acc + bj);
   if (EPI == REC_EPI_DTANH) return acc * (1.f - x0 * x0);
   if (EPI == REC_EPI_DSIGMOID) return acc * x0 * (1.f - x0);
-  if (EPI == REC_EPI_MOE) return x1 + x0 * (e.row_scale[i * e.rs_stride] * (acc + e.bias[j]));
-  if (EPI == REC_EPI_BIAS_SIGMOID) return 1.f / (1.f + expf(-(acc + e.bias[j])));
-  if (EPI == REC_EPI_BIAS_TANH) return tanhf(acc + (e.bias ? e.bias[j] : 0.f));
-  if (EPI == REC_EPI_ADD) return acc + (e.bias ? e.bias[j] : 0.f) + x1 + x0;
+  if (EPI == REC_EPI_MOE) return x1 + x0 * (e.row_scale[i * e.rs_stride] * (acc + bj));
+  if (EPI == REC_EPI_BIAS_SIGMOID) return 1.f / (1.f + expf(-(acc + bj)));
+  if (EPI == REC_EPI_BIAS_TANH) return tanhf(acc + bj);
+  if (EPI == REC_EPI_ADD) return acc + bj + x1 + x0;
   return acc;
 }
 template <int EPI>
 __device__ __forceinline__ float apply_epi(float acc, int64_t i, int j, const EpiArgs& e) {
-  return apply_epi<EPI>(acc, load_aux0<EPI>(i, j, e), load_aux1<EPI>(i, j, e), i, j, e);
+  return apply_epi<EPI>(acc, load_aux0<EPI>(i, j, e), load_aux1<EPI>(i, j, e), load_bias<EPI>(j, e), i, e);
 }
 
 // --------------------------------------------------------------------------------------- kernel
@@ -222,7 +231,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N +
 
   // column sums of op(B) over this block's K range (bias gradient when B = dY): the blocks of the
   // first M-tile add up the B tiles they stage anyway
-  const bool do_colsum = colsum_partial != nullptr && tm == 0;
+  // (only the trans_a instantiations carry the code: in the others the unused, predicated adds cost 32 VALU and 8 LDS
+  // instructions per K step beside 40 MFMAs)
+  const bool do_colsum = TA && colsum_partial != nullptr && tm == 0;
   float csum = 0.f;
 
   const int nkt = (k_end - k_begin + kBK - 1) / kBK;
@@ -269,9 +280,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N +
 #pragma unroll
         for (int b = 0; b < NT; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][s_], bf[b][s_], acc[a][b], 0, 0, 0);
-    if (do_colsum && tid < BN) {
+    if constexpr (TA) {
+      if (do_colsum && tid < BN) {
 #pragma unroll
-      for (int kk = 0; kk < kBK; ++kk) csum += bs[kk * LDB_S + tid];
+        for (int kk = 0; kk < kBK; ++kk) csum += bs[kk * LDB_S + tid];
+      }
     }
   };
   using Checked = std::integral_constant<int, 2>;
@@ -285,6 +298,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N +
       load_tile(kt + 1, mode_tag);
       __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMAs
       compute(kt & 1);
+      // ... and the LDS stores of the loaded tile behind ALL of them: hoisted into the MFMA stream, their
+      // s_waitcnt vmcnt stalls the wave on the global loads after a third of the MFMAs (seen in the ISA)
+      __builtin_amdgcn_sched_barrier(0);
       store_tile((kt + 1) & 1);
       __syncthreads();
     }
@@ -303,6 +319,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N +
     const bool next = kt + 1 < nkt;
     if (next) load_tile(kt + 1, Checked{});
     compute(kt & 1);
+    __builtin_amdgcn_sched_barrier(0);
     if (next) store_tile((kt + 1) & 1);
     __syncthreads();
   }
@@ -311,6 +328,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N +
 
   // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
   float* out = partial ? partial + (int64_t)kz * M * ldc : C;
+  float bj[NT];                     // this lane's NT bias values, read once ahead of every store of the tile
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    const int j = n0 + wn * WTN + b * 16 + li;
+    bj[b] = (!partial && j < N) ? load_bias<EPI>(j, epi) : 0.f;
+  }
   // one M-tile row block (16 rows x the wave's columns) at a time: all of its aux loads first, then its stores
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
@@ -337,8 +360,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N +
           const int j = n0 + wn * WTN + b * 16 + li;
           if (j < N) {
             const float v = acc[a][b][r];
-            out[i * ldc + j] = partial ? v : apply_epi<EPI>(v, x0[r][b], x1[r][b], i, j, epi);
-            if (EPI == REC_EPI_CROSS && !partial && epi.out2) epi.out2[i * epi.ld2 + j] = v + epi.bias[j];
+            out[i * ldc + j] = partial ? v : apply_epi<EPI>(v, x0[r][b], x1[r][b], bj[b], i, epi);
+            if (EPI == REC_EPI_CROSS && !partial && epi.out2) epi.out2[i * epi.ld2 + j] = v + bj[b];
           }
         }
       }
@@ -711,6 +734,8 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
   const float *aux0 = x->aux0, *aux1 = x->aux1;
   const int ld_aux0 = x->ld_aux0, ld_aux1 = x->ld_aux1;
   float* b_colsum = x->b_colsum;
+  REC_REQUIRE(!b_colsum || desc->trans_a, REC_EINVAL,
+              "b_colsum (the bias gradient) is produced by the trans_a form dW = X^T dY only");
   REC_REQUIRE(!(epi == REC_EPI_BIAS || epi == REC_EPI_BIAS_RELU || epi == REC_EPI_CROSS ||
                 epi == REC_EPI_BIAS_SIGMOID || epi == REC_EPI_MOE) || bias, REC_EINVAL,
               "epilogue needs bias");

@@ -291,9 +291,13 @@ class DeepFMLayer:
         if auc_stats is not None:
             self.k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         defer_all = os.environ.get("REC_DEEPFM_DEFER_ALL", "0") == "1"   # measurement knob: every dW GEMM in the tail
+        kw = dict(defer_all=True) if defer_all else dict(defer_first=True)
+        if on_gpu and os.environ.get("REC_MLP_DW_STREAM", "0") == "1":     # measurement knob: dW GEMMs on a third stream
+            if getattr(self, "_dw_stream", None) is None:
+                self._dw_stream, self._ws_dw = self.k.concurrent_stream(self.device), self.k.Workspace(self.device)
+            kw.update(dw_stream=self._dw_stream, dw_ws=self._ws_dw)
         with self._timed("mlp_bwd"):
-            d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db, self.ws_mlp,
-                                                     **(dict(defer_all=True) if defer_all else dict(defer_first=True)))
+            d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db, self.ws_mlp, **kw)
         with self._timed("fm_bwd"):
             row_grad, _, _ = self.k.deepfm_fm_bwd(
                 dense_inputs, feat, sum_emb, d_flat.view(B, self.fp, -1), dz, dz, S, self.ws,

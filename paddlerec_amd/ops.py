@@ -999,7 +999,7 @@ def mlp_forward(x, weights, biases, ws, relu_last=False, out_last=None):
     return x, acts + [x]
 
 
-def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=False):
+def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=False, dw_stream=None, dw_ws=None):
     """Backward of mlp_forward: dW_i -> dws[i], db_i -> dbs[i] (preallocated views); returns d(input).
     ReLU' is applied in the epilogue of the dX GEMM (mask = layer input > 0).
     defer_first: compute d(input) BEFORE dW_0 and return (d_input, finish) where finish() launches the
@@ -1019,16 +1019,33 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
             for i in reversed(range(n)):
                 gemm(acts[i], gs[i], ws, trans_a=True, out=dws[i], b_colsum=dbs[i], num_cus=num_cus)
         return g, finish
+    cur = torch.cuda.current_stream() if dw_stream is not None else None
+    keep = []          # dw_stream: tensors the other stream still reads (the caching allocator must not recycle them)
+
+    def join():
+        if dw_stream is not None:
+            cur.wait_stream(dw_stream)
+            keep.clear()
     for i in reversed(range(n)):
         if i == 0 and defer_first:
             g0 = g
             d_in = gemm(g0, weights[0], ws, trans_b=True)
+            join()
             return d_in, (lambda: gemm(acts[0], g0, ws, trans_a=True, out=dws[0], b_colsum=dbs[0]))
-        gemm(acts[i], g, ws, trans_a=True, out=dws[i], b_colsum=dbs[i])    # dW = X^T G, db = colsum(G)
+        if dw_stream is not None:
+            # dW_i and dX_i both consume g_i and nothing of each other: two streams, so that the half-empty last
+            # round of blocks of one GEMM is filled by the other
+            dw_stream.wait_stream(cur)
+            keep.append(g)
+            with torch.cuda.stream(dw_stream):
+                gemm(acts[i], g, dw_ws if dw_ws is not None else ws, trans_a=True, out=dws[i], b_colsum=dbs[i])
+        else:
+            gemm(acts[i], g, ws, trans_a=True, out=dws[i], b_colsum=dbs[i])    # dW = X^T G, db = colsum(G)
         if i > 0:
             g = gemm(g, weights[i], ws, trans_b=True, epilogue="relu_mask", aux0=acts[i])
         else:
             g = gemm(g, weights[i], ws, trans_b=True)
+    join()
     return g
 
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One rec_gemm_f32 shape in a loop (for rocprofv3): python tools/gemm_loop.py fwd0|dx0|dw0|cross [iters]"""
+"""Three launches each of the bench's forward GEMM (65536 x 400 x 400, bias + ReLU), its dX (ReLU mask) and its dW, for
+a rocprofv3 --pmc pass (tools/pmc.sh)."""
 import os
 import sys
 
@@ -8,17 +9,18 @@ import torch  # noqa: E402
 
 from paddlerec_amd import ops  # noqa: E402
 
-which = sys.argv[1] if len(sys.argv) > 1 else "fwd0"
-iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-DEV, B = "cuda", 65536
-cfg = {"fwd0": (B, 400, 624, False, False), "dx0": (B, 624, 400, False, True),
-       "dw0": (624, 400, B, True, False), "cross": (B, 1560, 1560, False, False)}[which]
-M, N, K, ta, tb = cfg
-A = torch.randn((K, M) if ta else (M, K), device=DEV)
-Bm = torch.randn((N, K) if tb else (K, N), device=DEV)
-out = torch.empty(M, N, device=DEV)
+DEV = "cuda"
+g = torch.Generator(device=DEV).manual_seed(3)
+B = 65536
+x = torch.randn(B, 400, device=DEV, generator=g)
+w = torch.randn(400, 400, device=DEV, generator=g) * 0.05
+b = torch.zeros(400, device=DEV)
+gg = torch.randn(B, 400, device=DEV, generator=g)
+dw, db = torch.empty_like(w), torch.empty_like(b)
 ws = ops.Workspace(DEV)
-for _ in range(iters):
-    ops.gemm(A, Bm, ws, trans_a=ta, trans_b=tb, out=out)
+for _ in range(3):
+    ops.gemm(x, w, ws, epilogue="bias_relu", bias=b)
+    ops.gemm(gg, w, ws, trans_b=True, epilogue="relu_mask", aux0=x)
+    ops.gemm(x, gg, ws, trans_a=True, out=dw, b_colsum=db)
 torch.cuda.synchronize()
 print("done")
