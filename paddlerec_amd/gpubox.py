@@ -231,3 +231,36 @@ class Main:
             n += label.shape[0]
         mean = float(torch.stack([l.reshape(()) for l in losses]).mean()) if losses else float("nan")
         return n, mean
+
+
+def load_config(path, overrides=()):
+    """The reference's gpubox / online YAML (runner + hyper_parameters flattened as in paddlerec_amd.trainer, plus the
+    nested table_parameters.embedding.accessor block, slot_dnn/config_online.yaml:57-89)."""
+    import yaml
+    from .trainer import load_yaml
+    cfg = load_yaml(path, overrides)
+    with open(path, "r") as f:
+        doc = yaml.safe_load(f) or {}
+    acc = ((doc.get("table_parameters") or {}).get("embedding") or {}).get("accessor")
+    if acc:
+        cfg["table_parameters.embedding.accessor"] = acc
+    cfg.setdefault("runner.epochs", 1)
+    return cfg
+
+
+def main(argv=None):
+    """python -m paddlerec_amd.gpubox -m <PaddleRec>/models/rank/slot_dnn/config_online.yaml [-o key=value ...]"""
+    import argparse
+    ap = argparse.ArgumentParser(description="the gpubox pass loop (tools/static_gpubox_trainer.py) on the recengine")
+    ap.add_argument("-m", "--config_yaml", required=True)
+    ap.add_argument("-o", "--opt", nargs="*", default=[], help="key=value overrides, e.g. runner.epochs=2")
+    ap.add_argument("--device", default="cuda")
+    args = ap.parse_args(argv)
+    logging.basicConfig(format="%(asctime)s - %(levelname)s - %(message)s", level=logging.INFO)
+    res = Main(load_config(args.config_yaml, args.opt), args.device).run_worker()
+    print(res)
+    return res
+
+
+if __name__ == "__main__":
+    main()

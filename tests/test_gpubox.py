@@ -118,3 +118,24 @@ def test_gpubox_pass_loop_gpu(tmp_path, engine_lib):
     # pass 0 agrees to 2e-5; pass 1 runs on MLP weights that took Adam's lr-sized steps on ~eps-sized gradients (sign
     # noise of the fp32 summation order), see the comment at the weight check
     _run(tmp_path, "cuda", None, loss_rtol=2e-4)
+
+
+REF_CFG = "/root/reference/models/rank/slot_dnn/config_online.yaml"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason="reference tree not mounted (only in the build container)")
+def test_reference_online_yaml_and_data_run_unchanged(tmp_path):
+    """The reference's OWN slot_dnn/config_online.yaml (300 slots, D 9, accessor block :57-89) and its data directory
+    (demo_10) through the pass loop — only the batch size (its 32 exceeds the 10 demo lines), the pass count and the
+    output directory are overridden."""
+    import cpu_kernels
+    from paddlerec_amd import gpubox
+    cfg = gpubox.load_config(REF_CFG, ["runner.train_batch_size=5", "runner.epochs=2",
+                                       "runner.model_save_path=" + str(tmp_path / "out")])
+    acc = cfg["table_parameters.embedding.accessor"]
+    assert acc["embedx_threshold"] == 10 and acc["ctr_accessor_param"]["show_click_decay_rate"] == 0.98
+    main = gpubox.Main(cfg, "cpu", cpu_kernels)
+    res = main.run_worker()
+    assert len(res["loss"]) == 2 and all(np.isfinite(x) for x in res["loss"]) and all(0 <= a <= 1 for a in res["auc"])
+    assert main.net.slot_num == 300 and main.net.emb_dim == 9 and main.net.table.accessor.embedx_threshold == 10
+    assert os.path.exists(tmp_path / "out" / "1" / "rec_gpubox.npz")
