@@ -29,6 +29,8 @@
 // Work is proportional to the number of ids, not to B x S x longest segment: load balance does not depend on
 // the segment-length distribution.  Fixed summation order (tree inside a sub-step, ascending across): results
 // do not depend on the launch geometry.
+#include <stdlib.h>
+
 #include "rec_common.h"
 
 namespace rec {
@@ -73,7 +75,7 @@ constexpr int kSegCap = 512;    // ids of (one slot, 64 samples) whose segment i
 // Lane layout inside a wave: lane = lg * G + g — the G row groups sit side by side (g), the LANES slices of a row
 // are G lanes apart (lg).  With G <= 16 the segmented scan over g never leaves a 16-lane DPP row.
 template <int VEC, int LANES, int NSW, int kMsWaves>
-__global__ __launch_bounds__(kMsWaves * kWave, kMsWaves == 8 ? 6 : 3) void multislot_sumpool_kernel(
+__global__ __launch_bounds__(kMsWaves * kWave, (kMsWaves == 8 || NSW >= 2) ? 6 : 3) void multislot_sumpool_kernel(
     int64_t B, int S, int D, int stride, int key_mode, int64_t N, int64_t pad, int64_t lod_stride,
     int64_t out_stride, int nbt, int pitch, int state_off, float init_range, int init_dims, uint64_t seed,
     FastMod fm, const int64_t* __restrict__ values,
@@ -331,6 +333,7 @@ extern "C" int rec_multislot_sumpool_fwd(const rec_multislot_desc* d, const int6
   FastMod fmod = make_fastmod(1);
   if (d->key_mode == 1) fmod = make_fastmod((uint64_t)(d->num_rows - 1));
   hipStream_t st = (hipStream_t)stream;
+  static const int ms_cfg = [] { const char* v = getenv("REC_MS_CFG"); return v && *v ? atoi(v) : 0; }();
 #define REC_MS_LAUNCH(V, L, NSW_, W_)                                                                   \
   {                                                                                                     \
     constexpr int kMsWaves = W_;                                                                        \
@@ -354,7 +357,11 @@ extern "C" int rec_multislot_sumpool_fwd(const rec_multislot_desc* d, const int6
   }
 #define REC_MS_NSW(V, L)                                                                                \
   {                                                                                                     \
-    if (D <= 10 && S > 8) REC_MS_LAUNCH(V, L, 2, 8)                                                     \
+    if (D <= 10 && S > 8 && ms_cfg == 1) REC_MS_LAUNCH(V, L, 2, 4)                                      \
+    else if (D <= 10 && S > 8 && ms_cfg == 2) REC_MS_LAUNCH(V, L, 4, 4)                                 \
+    else if (D <= 10 && S > 8 && ms_cfg == 3) REC_MS_LAUNCH(V, L, 1, 8)                                 \
+    else if (D <= 10 && S > 8 && ms_cfg == 4) REC_MS_LAUNCH(V, L, 4, 8)                                 \
+    else if (D <= 10 && S > 8) REC_MS_LAUNCH(V, L, 2, 8)                                                \
     else if (D <= 20 && S > 4) REC_MS_LAUNCH(V, L, 1, 8)                                                \
     else REC_MS_LAUNCH(V, L, 1, 4)                                                                      \
   }

@@ -24,6 +24,8 @@
 //   shrink (end of a pass / day): show *= decay, click *= decay; features whose score fell below delete_threshold
 //   are deleted (row zeroed: unborn again).  unseen_days / delta_score bookkeeping (SSD tiering, delta saves) is
 //   storage-engine state outside this path.
+#include <stdlib.h>
+
 #include "rec_common.h"
 
 namespace rec {
@@ -175,6 +177,96 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
   }
 }
 
+// Narrow features without float4 row groups (slot_dnn: embedx_dim 8 at record offset 1, gradient rows of 9 floats):
+// the kernel above then runs 8 lanes per feature = 8 features per wave, each walking uniq -> seg_off -> sorted_pos
+// -> grad_index -> gradient row -> record one dependent round trip after the other (4.2 ms for 9 M features).
+// Here ONE LANE owns a feature: 64 features per wave in flight, the index chain coalesced across lanes, the 64-B
+// record the lane's private line.  Same rule, same ascending-position summation.
+template <int DX>   // embedx floats held in registers (>= embedx_dim)
+__global__ __launch_bounds__(kBlock) void ps_push_rows_narrow_kernel(
+    rec_ps_layout L, int S, const int32_t* __restrict__ n_uniq, const int64_t* __restrict__ uniq,
+    const int32_t* __restrict__ seg_off, const int32_t* __restrict__ spos, GradSrc gx, GradSrc gw,
+    const int64_t* __restrict__ show, const int64_t* __restrict__ click, float* __restrict__ rec,
+    rec_ps_accessor A) {
+  const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (u >= n_uniq[0]) return;
+  const int64_t row = uniq[u];
+  const int beg = seg_off[u], end = seg_off[u + 1];
+  float* r = rec + row * (int64_t)L.row_stride;
+  float* st = r + L.stat_off;            // show, click, g2sum_w, g2sum_x, state
+  const int64_t grow = row * A.row_mul + A.row_add;
+  const int Dx = L.embedx_dim;
+  const float show0 = st[0], click0 = st[1], g2w = st[2], g2x = st[3], state = st[4];
+  const bool unborn = state == 0.f;
+  float w[DX];
+#pragma unroll
+  for (int d = 0; d < DX; ++d) w[d] = (!unborn && d < Dx) ? r[L.embedx_off + d] : 0.f;
+  float ew = unborn ? 0.f : r[L.embed_off];
+
+  // ---- one walk over the feature's occurrences: counters, embed_w gradient, embedx gradient
+  const float score0 = (show0 - click0) * A.nonclk_coeff + click0 * A.click_coeff;
+  const bool has_x = state >= 2.f || (unborn && score0 >= A.embedx_threshold);
+  float dshow = show ? 0.f : (float)(end - beg), dclick = 0.f, gwv = 0.f;
+  float g[DX];
+#pragma unroll
+  for (int d = 0; d < DX; ++d) g[d] = 0.f;
+  int64_t lsum = 0;
+  for (int k = beg; k < end; ++k) {
+    const int pos = spos[k];
+    if (show || click) {
+      const int smp = (gx.gl.index ? gx.gl.index[pos] : pos) / S;
+      if (show) dshow += (float)show[smp];
+      if (click) lsum += click[smp];
+    }
+    gwv += gw.grad[ps_grad_offset(gw.gl, pos, gw.pitch) + gw.col];
+    if (has_x) {
+      const float* a = gx.grad + ps_grad_offset(gx.gl, pos, gx.pitch) + gx.col;
+#pragma unroll
+      for (int d = 0; d < DX; ++d) g[d] += d < Dx ? a[d] : 0.f;
+    }
+  }
+  // (the wide kernel adds the labels four at a time as integers, then to float: any grouping of integer partial
+  // sums below 2^24 gives the same float)
+  dclick = (float)lsum;
+
+  float sq = 0.f;
+  if (unborn) {
+#pragma unroll
+    for (int d = 0; d < DX; ++d) w[d] = (has_x && d < Dx) ? ps_init_value(A.seed, grow, 1 + d, A.initial_range) : 0.f;
+    ew = ps_init_value(A.seed, grow, 0, A.initial_range);
+  }
+  if (has_x) {
+    const float sc = sqrtf(A.initial_g2sum / (A.initial_g2sum + g2x));
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+      if (d < Dx) {
+        w[d] = fminf(fmaxf(w[d] - A.lr * g[d] * sc, A.min_bound), A.max_bound);
+        sq += g[d] * g[d];
+      }
+    }
+  }
+  const float show1 = show0 + dshow, click1 = click0 + dclick;
+  const float score1 = (show1 - click1) * A.nonclk_coeff + click1 * A.click_coeff;
+  const bool create_x = !has_x && score1 >= A.embedx_threshold;   // what the NEXT pull would do
+  if (create_x) {
+#pragma unroll
+    for (int d = 0; d < DX; ++d) w[d] = d < Dx ? ps_init_value(A.seed, grow, 1 + d, A.initial_range) : 0.f;
+  }
+  if (has_x || create_x || unborn) {
+#pragma unroll
+    for (int d = 0; d < DX; ++d)
+      if (d < Dx) r[L.embedx_off + d] = w[d];
+  }
+  const float scw = sqrtf(A.initial_g2sum / (A.initial_g2sum + g2w));
+  ew = fminf(fmaxf(ew - A.lr * gwv * scw, A.min_bound), A.max_bound);
+  r[L.embed_off] = ew;
+  st[0] = show1;
+  st[1] = click1;
+  st[2] = g2w + gwv * gwv;
+  if (has_x) st[3] = g2x + sq / (float)Dx;
+  st[4] = (has_x || create_x) ? 2.f : 1.f;
+}
+
 __global__ __launch_bounds__(kBlock) void ps_shrink_rows_kernel(int64_t N, rec_ps_layout L,
                                                                  float* __restrict__ rec, float decay,
                                                                  float delete_threshold, float nonclk,
@@ -245,6 +337,18 @@ extern "C" int rec_ps_push_rows(int64_t n_max, int32_t num_slots, const rec_ps_l
   const int lanes = pow2_ceil(vec ? (Dx + 3) / 4 : Dx);
   REC_REQUIRE(lanes <= 64, REC_ESHAPE, "embedx_dim %d too large", Dx);
   hipStream_t st = (hipStream_t)stream;
+  static const bool narrow_ok = [] { const char* v = getenv("REC_NARROW_ROWS"); return !(v && *v == '0'); }();
+  if (!vec && Dx <= 16 && narrow_ok) {   // no float4 row groups: one lane per feature
+    const int64_t grid = (n_max + kBlock - 1) / kBlock;
+    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");
+#define REC_PS_NARROW(DX_)                                                                               \
+  hipLaunchKernelGGL((ps_push_rows_narrow_kernel<DX_>), dim3((unsigned)grid), dim3(kBlock), 0, st, *layout, \
+                     num_slots, n_uniq, uniq_rows, seg_offset, sorted_pos, gx, gw, show, click, rec, *accessor)
+    if (Dx <= 4) REC_PS_NARROW(4); else if (Dx <= 8) REC_PS_NARROW(8);
+    else if (Dx <= 12) REC_PS_NARROW(12); else REC_PS_NARROW(16);
+#undef REC_PS_NARROW
+    return check_launch("rec_ps_push_rows (narrow)");
+  }
 #define REC_PS_CASE(V, L_)                                                                             \
   if (lanes == L_) {                                                                                   \
     const int64_t grid = (n_max * L_ + kBlock - 1) / kBlock;                                           \

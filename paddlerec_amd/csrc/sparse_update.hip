@@ -14,6 +14,8 @@
 #include <cmath>
 
 #include "radix_sort.h"
+#include <stdlib.h>
+
 #include "rec_common.h"
 
 namespace rec {
@@ -398,6 +400,106 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_rows_kernel(
   vstore<VEC>(V + so, v);
 }
 
+// ------------------------------------------------------------- narrow rows: one LANE per touched row
+// Rows whose width is not a multiple of 4 floats (slot_dnn: D 9, deepfm/config.yaml: D 9 / 10) have no float4 row
+// groups: the kernel above then spends 16 lanes on a 9-float row — 4 rows per wave — and each wave walks the chain
+// uniq -> seg_off -> sorted_pos -> grad_index -> gradient row -> P, M, V -> store one dependent memory round trip
+// after the other: 9 M touched rows took 3.1 ms (profiles/r02c_slot_dnn_kernel_stats.csv), five times the time of
+// their bytes.  Here a lane owns a whole row (<= 16 floats in registers): 64 rows per wave are in flight, the index
+// chain is read coalesced across the lanes, and the row's own 36-64 bytes are the lane's private line.  Same
+// arithmetic (adam_elem), same ascending-position summation order.
+template <int NV, bool V4>
+__device__ __forceinline__ void narrow_load(float (&x)[NV * 4], const float* __restrict__ p, int D) {
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    if (V4 && c * 4 + 4 <= D) {
+      const float4 t = *reinterpret_cast<const float4*>(p + c * 4);
+      x[c * 4] = t.x; x[c * 4 + 1] = t.y; x[c * 4 + 2] = t.z; x[c * 4 + 3] = t.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[c * 4 + i] = c * 4 + i < D ? p[c * 4 + i] : 0.f;
+    }
+  }
+}
+template <int NV, bool V4>
+__device__ __forceinline__ void narrow_store(float* __restrict__ p, const float (&x)[NV * 4], int D) {
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    if (V4 && c * 4 + 4 <= D) {
+      *reinterpret_cast<float4*>(p + c * 4) = make_float4(x[c * 4], x[c * 4 + 1], x[c * 4 + 2], x[c * 4 + 3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (c * 4 + i < D) p[c * 4 + i] = x[c * 4 + i];
+    }
+  }
+}
+
+// g[0..D) += the gradient rows of sorted positions [beg,end), ascending (two positions in flight); long segments
+// through the tile partials as segment_sum does
+template <int NV>
+__device__ __forceinline__ void narrow_segment_sum(float (&g)[NV * 4], int beg, int end,
+                                                   const int32_t* __restrict__ spos,
+                                                   const float* __restrict__ grad, const rec_grad_layout& gl,
+                                                   int D) {
+  if (gl.partials && end - beg >= kSegLong) {
+    const float* __restrict__ pp = gl.partials;
+    const int t1 = (end - 1) / kSegTile;
+    for (int t = beg / kSegTile; t <= t1; ++t) {
+      const float* a = pp + ((int64_t)t * 2 + (beg <= t * kSegTile ? 0 : 1)) * D;
+#pragma unroll
+      for (int d = 0; d < NV * 4; ++d) g[d] += d < D ? a[d] : 0.f;
+    }
+    return;
+  }
+  int k = beg;
+  for (; k + 2 <= end; k += 2) {
+    const float* a = grad + grad_offset(gl, spos[k], D);
+    const float* b = grad + grad_offset(gl, spos[k + 1], D);
+    float x[NV * 4], y[NV * 4];
+#pragma unroll
+    for (int d = 0; d < NV * 4; ++d) { x[d] = d < D ? a[d] : 0.f; y[d] = d < D ? b[d] : 0.f; }
+#pragma unroll
+    for (int d = 0; d < NV * 4; ++d) g[d] = (g[d] + x[d]) + y[d];
+  }
+  if (k < end) {
+    const float* a = grad + grad_offset(gl, spos[k], D);
+#pragma unroll
+    for (int d = 0; d < NV * 4; ++d) g[d] += d < D ? a[d] : 0.f;
+  }
+}
+
+template <int NV, bool V4>
+__global__ __launch_bounds__(kBlock) void sparse_adam_rows_narrow_kernel(
+    int D, int stride, int sstride, const int32_t* __restrict__ n_uniq, const int64_t* __restrict__ uniq,
+    const int32_t* __restrict__ seg_off, const int32_t* __restrict__ spos,
+    const float* __restrict__ grad, rec_grad_layout gl, const float* __restrict__ grad_scale,
+    float* __restrict__ P, float* __restrict__ M, float* __restrict__ V, float lr_t, float eps_t,
+    float b1, float b2) {
+  const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (u >= n_uniq[0]) return;
+  const int64_t row = uniq[u];
+  const int beg = seg_off[u], end = seg_off[u + 1];
+  float p[NV * 4], m[NV * 4], v[NV * 4], g[NV * 4];
+  narrow_load<NV, V4>(p, P + row * stride, D);
+  narrow_load<NV, V4>(m, M + row * sstride, D);
+  narrow_load<NV, V4>(v, V + row * sstride, D);
+#pragma unroll
+  for (int d = 0; d < NV * 4; ++d) g[d] = 0.f;
+  narrow_segment_sum<NV>(g, beg, end, spos, grad, gl, D);
+  const float sc = grad_scale ? grad_scale[0] : 1.f;
+#pragma unroll
+  for (int d = 0; d < NV * 4; ++d) {
+    if (d < D) {
+      if (grad_scale) g[d] = scale_grad(g[d], sc);
+      adam_elem(p[d], m[d], v[d], g[d], lr_t, eps_t, b1, b2);
+    }
+  }
+  narrow_store<NV, V4>(P + row * stride, p, D);
+  narrow_store<NV, V4>(M + row * sstride, m, D);
+  narrow_store<NV, V4>(V + row * sstride, v, D);
+}
+
 // Both embeddings of a DeepFM row in ONE pass (DESIGN.md "table layout"): the record line holds
 //   rec [N, stride] = W(D) | W1 | m1 | v1 | pad      and      mv [N, sstride] = m(D) | v(D)
 // so the first-order table (deepfm/net.py:62-70 `embedding_one`) costs no extra HBM line: the row group that
@@ -720,6 +822,28 @@ extern "C" int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_
   hipStream_t st = (hipStream_t)stream;
   // float4 gradient loads need 16-B aligned gradient rows
   const bool gvec = ((uintptr_t)grad) % 16 == 0 && (gl.group <= 0 || gl.group_stride % 4 == 0);
+  const bool rows4 = emb_dim % 4 == 0 && row_stride % 4 == 0 && gvec && state_stride % 4 == 0;
+  static const bool narrow_ok = [] { const char* v = getenv("REC_NARROW_ROWS"); return !(v && *v == '0'); }();
+  if (!rows4 && emb_dim <= 16 && narrow_ok) {   // no float4 row groups: one lane per row (see the narrow kernel)
+    const bool v4 = row_stride % 4 == 0 && state_stride % 4 == 0 && ((uintptr_t)P) % 16 == 0 &&
+                    ((uintptr_t)M) % 16 == 0 && ((uintptr_t)V) % 16 == 0;
+    const int64_t grid = (n_max + kBlock - 1) / kBlock;
+    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");
+    const int nv = (emb_dim + 3) / 4;
+#define REC_NARROW(NV_, V4_)                                                                                 \
+  hipLaunchKernelGGL((sparse_adam_rows_narrow_kernel<NV_, V4_>), dim3((unsigned)grid), dim3(kBlock), 0, st,   \
+                     emb_dim, row_stride, state_stride, n_uniq, uniq_rows, seg_offset, sorted_pos, grad, gl,   \
+                     grad_scale, P, M, V, lr_t, eps_t, hyper->beta1, hyper->beta2)
+    if (v4) {
+      if (nv == 1) REC_NARROW(1, true); else if (nv == 2) REC_NARROW(2, true);
+      else if (nv == 3) REC_NARROW(3, true); else REC_NARROW(4, true);
+    } else {
+      if (nv == 1) REC_NARROW(1, false); else if (nv == 2) REC_NARROW(2, false);
+      else if (nv == 3) REC_NARROW(3, false); else REC_NARROW(4, false);
+    }
+#undef REC_NARROW
+    return check_launch("rec_sparse_adam_rows (narrow)");
+  }
   return dispatch_row_shape(emb_dim, (gvec && state_stride % 4 == 0) ? row_stride : row_stride | 1,
                             [&](auto vec, auto lanes) -> int {
     constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;

@@ -211,6 +211,29 @@ def test_multislot_sumpool_vs_oracle(engine_lib, D, stride, B, S, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("max_len,D,stride", [(12, 9, 16), (16, 9, 16), (17, 9, 16), (16, 12, 12), (16, 16, 16),
+                                               (15, 5, 5), (16, 20, 20)])
+def test_multislot_run_lengths_around_a_substep(engine_lib, max_len, D, stride):
+    """Run lengths around the 16 row groups of one gather sub-step and pieces of (slot, 64 samples) around 320 and 512
+    ids (the per-wave segment table holds 512), 30 % empty segments, feasign keys, padding ids; widths with 1-5 float4
+    or scalar lanes per row."""
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(max_len * 31 + D)
+    B, S, N = 150, 19, 5003
+    samples = _random_problem(rng, B, S, N, max_len=max_len, empty_frac=0.3, feasigns=True)
+    values, lod, base = M.csr_from_samples(samples, S)
+    Wfull = rng.standard_normal((N, stride)).astype(np.float32)
+    mbatch = ops.MultislotBatch(T(values), T(lod), T(base))
+    out, counts, seg, rows, status = ops.multislot_sumpool(mbatch, T(Wfull)[:, :D], N, 0, 1)
+    want, wcnt, wseg, wrows = M.multislot_sumpool(values, lod, base, Wfull[:, :D], 0, 1, N)
+    assert np.array_equal(counts.cpu().numpy(), wcnt)
+    assert np.array_equal(seg.cpu().numpy()[: len(values)], wseg)
+    assert np.array_equal(rows.cpu().numpy()[: len(values)], wrows)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
+    assert int(status.item()) == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N", [2, 1_000_003, 1_250_000_000, 2 ** 32 + 7, 10 ** 10, 2 ** 62 + 1])
 def test_feasign_rows_device_matches_oracle_at_configs4_sizes(engine_lib, N):
     """uint64 feasign -> row of the hashed table on the device (multiply-high exact modulo), bit-exact against the

@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--extra-p", type=float, default=0.6)
     ap.add_argument("--opt", default="adam")
     ap.add_argument("--layers", default="512,256,128,128,128")
+    ap.add_argument("--pool-bench", type=int, default=0, help="time only the pooling kernel and print its line")
     ap.add_argument("--pool-only", type=int, default=0, help="only loop the pooling kernel this many times (profiling)")
     args = ap.parse_args()
     B, S, D, N = args.batch, args.slots, args.dim, args.rows
@@ -89,6 +90,9 @@ def main():
     ms_pool = timeit(lambda i: ops.multislot_sumpool(batches[i % 2][0], W, N, 0, 1, model.status, out=out,
                                                      lazy_init=lazy))
     nnz = mb.nnz
+    if args.pool_bench:
+        print("pool_fwd_ms %.4f  (ids %d, live %d, rows %d)" % (ms_pool, nnz, live, N))
+        return
     alg = nnz * 8 + S * (B + 1) * 8 + live * D * 4 + B * S * D * 4 + B * S * 4 + nnz * 4 + nnz * 8
     designed = alg - live * D * 4 + live * 64
     for i in range(2):
