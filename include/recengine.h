@@ -206,6 +206,15 @@ int rec_ids_group(int64_t n, int32_t num_slots, int64_t num_rows, int64_t paddin
                   const int64_t* ids, const int64_t* slot_offset, int32_t* sorted_pos,
                   int64_t* uniq_rows, int32_t* seg_offset, int32_t* n_uniq, int32_t* status,
                   void* workspace, size_t workspace_bytes, void* stream);
+/* The same grouping with a caller-chosen 32-bit payload travelling with every lookup instead of its position:
+ * sorted_pos[k] = payload[position].  The multi-slot CSR path (slot_dnn/net.py:63-75) passes the (sample, slot)
+ * segment of every value (rec_multislot_sumpool_fwd's seg_of_value), so the row-update kernels find a position's
+ * gradient row without the random read of rec_grad_layout.index that sorting positions would need (22.7 M
+ * 4-byte reads, a memory line each, on the slot_dnn benchmark shape).  Stable in the positions, as above. */
+int rec_ids_group_payload(int64_t n, int32_t num_slots, int64_t num_rows, int64_t padding_idx,
+                          const int64_t* ids, const int64_t* slot_offset, const int32_t* payload,
+                          int32_t* sorted_pos, int64_t* uniq_rows, int32_t* seg_offset, int32_t* n_uniq,
+                          int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizers.  paddle.optimizer.Adam [EXT] (deepfm/dygraph_model.py:61-65, static_model.py:83-84):

@@ -108,6 +108,7 @@ SIGNATURES = {
     "rec_emb_sumpool_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _P]),
     "rec_ids_group_workspace_bytes": (C.c_int, [_I64, _I64, C.POINTER(_SZ)]),
     "rec_ids_group": (C.c_int, [_I64, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "rec_ids_group_payload": (C.c_int, [_I64, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rec_segment_partials_bytes": (C.c_int, [_I64, _I32, C.POINTER(C.c_size_t)]),
     "rec_segment_partials": (C.c_int, [_I64, _I32, _P, _P, _P, _P, C.POINTER(GradLayout), _P, _P]),
     "rec_sparse_adam_rows": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,

@@ -32,6 +32,7 @@ struct IdsSrc {
   int S;
   int64_t N, pad;
   int32_t* status;
+  const int32_t* payload;   // what travels with the key: payload[i], or the position i itself when null
   __device__ __forceinline__ KeyT key(int64_t i) const {
     const int64_t id = ids[i];
     KeyT k = (KeyT)N;
@@ -41,7 +42,7 @@ struct IdsSrc {
     }
     return k;
   }
-  __device__ __forceinline__ int32_t val(int64_t i) const { return (int32_t)i; }
+  __device__ __forceinline__ int32_t val(int64_t i) const { return payload ? payload[i] : (int32_t)i; }
 };
 
 // Heads of the sorted key runs.  A block owns a tile of kHeadsTile consecutive sorted positions, a wave walks it
@@ -198,7 +199,7 @@ static int plan_group(int64_t n, int64_t N, GroupPlan<KeyT>* p) {
 
 template <class KeyT>
 static int run_group(int64_t n, int S, int64_t N, int64_t pad, const int64_t* ids,
-                     const int64_t* slot_off, int32_t* sorted_pos, int64_t* uniq,
+                     const int64_t* slot_off, const int32_t* payload, int32_t* sorted_pos, int64_t* uniq,
                      int32_t* seg_off, int32_t* n_uniq, int32_t* status, void* ws, size_t ws_bytes,
                      hipStream_t st) {
   GroupPlan<KeyT> p;
@@ -209,7 +210,7 @@ static int run_group(int64_t n, int S, int64_t N, int64_t pad, const int64_t* id
   KeyT* keys_dst = (KeyT*)(base + p.off_keys_dst);
   int32_t* vals_tmp = (int32_t*)(base + p.off_vals_tmp);
   int32_t* cnt = (int32_t*)(base + p.off_cnt);
-  IdsSrc<KeyT> src{ids, slot_off, S, N, pad, status};
+  IdsSrc<KeyT> src{ids, slot_off, S, N, pad, status, payload};
   if (int rc = rsort::sort_pairs<KeyT>(n, p.sort, src, keys_tmp, vals_tmp, keys_dst, sorted_pos,
                                        base + p.off_hist, base + p.off_totals, st))
     return rc;
@@ -741,11 +742,11 @@ extern "C" int rec_ids_group_workspace_bytes(int64_t n, int64_t num_rows, size_t
   return REC_OK;
 }
 
-extern "C" int rec_ids_group(int64_t n, int32_t num_slots, int64_t num_rows, int64_t padding_idx,
-                             const int64_t* ids, const int64_t* slot_offset, int32_t* sorted_pos,
-                             int64_t* uniq_rows, int32_t* seg_offset, int32_t* n_uniq,
-                             int32_t* status, void* workspace, size_t workspace_bytes,
-                             void* stream) {
+extern "C" int rec_ids_group_payload(int64_t n, int32_t num_slots, int64_t num_rows, int64_t padding_idx,
+                                     const int64_t* ids, const int64_t* slot_offset, const int32_t* payload,
+                                     int32_t* sorted_pos, int64_t* uniq_rows, int32_t* seg_offset,
+                                     int32_t* n_uniq, int32_t* status, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
   REC_REQUIRE(n >= 0 && num_slots > 0 && num_rows > 0, REC_EINVAL, "bad sizes");
   REC_REQUIRE(n < (1ll << 31) - 1, REC_ESHAPE, "n too large for int32 positions");
   REC_REQUIRE(sorted_pos && uniq_rows && seg_offset && n_uniq && status, REC_EINVAL,
@@ -758,11 +759,20 @@ extern "C" int rec_ids_group(int64_t n, int32_t num_slots, int64_t num_rows, int
   }
   REC_REQUIRE(ids, REC_EINVAL, "ids is NULL");
   if (use_u32_keys(num_rows))
-    return run_group<uint32_t>(n, num_slots, num_rows, padding_idx, ids, slot_offset, sorted_pos,
+    return run_group<uint32_t>(n, num_slots, num_rows, padding_idx, ids, slot_offset, payload, sorted_pos,
                                uniq_rows, seg_offset, n_uniq, status, workspace, workspace_bytes,
                                st);
-  return run_group<uint64_t>(n, num_slots, num_rows, padding_idx, ids, slot_offset, sorted_pos,
+  return run_group<uint64_t>(n, num_slots, num_rows, padding_idx, ids, slot_offset, payload, sorted_pos,
                              uniq_rows, seg_offset, n_uniq, status, workspace, workspace_bytes, st);
+}
+
+extern "C" int rec_ids_group(int64_t n, int32_t num_slots, int64_t num_rows, int64_t padding_idx,
+                             const int64_t* ids, const int64_t* slot_offset, int32_t* sorted_pos,
+                             int64_t* uniq_rows, int32_t* seg_offset, int32_t* n_uniq,
+                             int32_t* status, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  return rec_ids_group_payload(n, num_slots, num_rows, padding_idx, ids, slot_offset, nullptr, sorted_pos,
+                               uniq_rows, seg_offset, n_uniq, status, workspace, workspace_bytes, stream);
 }
 
 extern "C" int rec_segment_partials_bytes(int64_t n_max, int32_t emb_dim, size_t* bytes) {

@@ -306,8 +306,14 @@ class IdGroups:
                 self.seg_offset[:U + 1].cpu().numpy())
 
 
-def ids_group(ids, num_rows, padding_idx, ws, slot_offset=None, status=None, groups=None):
+def ids_group(ids, num_rows, padding_idx, ws, slot_offset=None, status=None, groups=None, payload=None):
+    """payload [n] int32 (or None): what groups.sorted_pos holds for every lookup instead of its position
+    (rec_ids_group_payload) — the multi-slot path passes the (sample, slot) segment of every value."""
     _chk(ids, torch.int64, "ids")
+    if payload is not None:
+        _chk(payload, torch.int32, "payload")
+        if payload.numel() < ids.numel():
+            raise RecError("payload shorter than ids")
     n = ids.numel()
     S = ids.shape[-1] if ids.dim() > 1 else 1
     dev = ids.device
@@ -318,10 +324,10 @@ def ids_group(ids, num_rows, padding_idx, ws, slot_offset=None, status=None, gro
     nbytes = C.c_size_t(0)
     check(lib().rec_ids_group_workspace_bytes(n, num_rows, C.byref(nbytes)))
     w = ws.get(nbytes.value)
-    check(lib().rec_ids_group(n, S, num_rows, -1 if padding_idx is None else padding_idx, _p(ids),
-                              _p(slot_offset), _p(groups.sorted_pos), _p(groups.uniq_rows),
-                              _p(groups.seg_offset), _p(groups.n_uniq), _p(status), _p(w),
-                              C.c_size_t(w.numel()), _stream()), "rec_ids_group")
+    check(lib().rec_ids_group_payload(n, S, num_rows, -1 if padding_idx is None else padding_idx, _p(ids),
+                                      _p(slot_offset), _p(payload), _p(groups.sorted_pos), _p(groups.uniq_rows),
+                                      _p(groups.seg_offset), _p(groups.n_uniq), _p(status), _p(w),
+                                      C.c_size_t(w.numel()), _stream()), "rec_ids_group_payload")
     return groups, status
 
 

@@ -134,8 +134,10 @@ class BenchmarkDNNLayer:
         with self._timed("pool_fwd"):
             x, counts, seg, rows, _ = self._pool(mb, True)
         self.last_counts = counts
-        with _OnSide(side, cur):            # SelectedRows merge keys: the rows the pooling kernel resolved
-            k.ids_group(rows[: mb.nnz], self.dict_dim, 0, self.ws_group, None, self.status, groups)
+        with _OnSide(side, cur):            # SelectedRows merge keys: the rows the pooling kernel resolved; every
+            # value carries its (sample, slot) segment = its gradient row in dx through the sort (no index indirection)
+            k.ids_group(rows[: mb.nnz], self.dict_dim, 0, self.ws_group, None, self.status, groups,
+                        payload=seg[: mb.nnz])
         with self._timed("mlp_fwd"):
             y, acts = k.mlp_forward(x, self.mlp_w, self.mlp_b, self.ws_mlp)
         pred, dz, loss = k.sigmoid_logloss(y, None, None, label, self.ws, clip=CLIP)
@@ -145,14 +147,12 @@ class BenchmarkDNNLayer:
             dx = k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp)      # [B, S*D]
         with _OnSide(side, cur):
             with self._timed("sparse_update"):
-                idx = seg[: mb.nnz]
                 if self.table is not None:
-                    k.ps_push_rows(self.table, groups, dx, S, grad_index=idx, show=show, click=label.reshape(-1))
+                    k.ps_push_rows(self.table, groups, dx, S, show=show, click=label.reshape(-1))
                 else:
                     st = self.sparse_state
-                    pp = self._pp = k.segment_partials(groups, dx, D, out=getattr(self, "_pp", None), grad_index=idx)
-                    k.sparse_adam_rows(groups, dx, 1, self.embedding, st["m"], st["v"], t, lr, partials=pp,
-                                       grad_index=idx)
+                    pp = self._pp = k.segment_partials(groups, dx, D, out=getattr(self, "_pp", None))
+                    k.sparse_adam_rows(groups, dx, 1, self.embedding, st["m"], st["v"], t, lr, partials=pp)
         k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
         if on_gpu:
             cur.wait_stream(self._side)

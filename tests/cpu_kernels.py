@@ -299,9 +299,11 @@ class IdGroups:
         self.n = n
 
 
-def ids_group(ids, num_rows, padding_idx, ws, slot_offset=None, status=None, groups=None):
+def ids_group(ids, num_rows, padding_idx, ws, slot_offset=None, status=None, groups=None, payload=None):
     rows, valid = R.effective_rows(_n(ids).reshape(-1, 1), padding_idx, None)
     groups.spos, groups.uniq, groups.offs = R.group_ids(rows.reshape(-1), valid.reshape(-1))
+    if payload is not None:             # rec_ids_group_payload: the payload travels instead of the position
+        groups.spos = _n(payload).astype(np.int64)[groups.spos]
     return groups, status
 
 

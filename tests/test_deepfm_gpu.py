@@ -228,6 +228,26 @@ def test_ids_group_bit_exact(ops, B, N, pad_frac, zipf, tables):
     assert np.array_equal(spos, rspos) and np.array_equal(uniq, runiq) and np.array_equal(offs, roffs)
 
 
+@pytest.mark.parametrize("N", [3000, 5_000_000_000])
+def test_ids_group_payload_travels_with_the_lookup(ops, N):
+    """rec_ids_group_payload: sorted_pos[k] = payload[position] — same rows, same segments, stable in the positions
+    (32- and 64-bit key paths)."""
+    rng = np.random.default_rng(17)
+    n = 20011
+    ids = rng.integers(0, min(N, 4000), size=n).astype(np.int64)            # ~15 % duplicates per row, some padding 0
+    payload = rng.integers(0, 2 ** 31 - 1, size=n).astype(np.int32)
+    ws = ops.Workspace(DEV)
+    g0, _ = ops.ids_group(T(ids), N, 0, ws)
+    spos0, uniq0, offs0 = g0.host()
+    g1, st = ops.ids_group(T(ids), N, 0, ws, payload=T(payload))
+    spos1, uniq1, offs1 = g1.host()
+    assert int(st.item()) == 0
+    assert np.array_equal(uniq0, uniq1) and np.array_equal(offs0, offs1)
+    assert np.array_equal(spos1, payload[spos0])
+    rspos, runiq, roffs = R.group_ids(ids, ids != 0)
+    assert np.array_equal(spos0, rspos) and np.array_equal(uniq0, runiq) and np.array_equal(offs0, roffs)
+
+
 def test_ids_group_edge_cases(ops):
     ws = ops.Workspace(DEV)
     ids = torch.zeros(16, 26, dtype=torch.int64, device=DEV)          # nothing but padding
