@@ -188,14 +188,15 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_narrow_kernel(
     const int32_t* __restrict__ seg_off, const int32_t* __restrict__ spos, GradSrc gx, GradSrc gw,
     const int64_t* __restrict__ show, const int64_t* __restrict__ click, float* __restrict__ rec,
     rec_ps_accessor A) {
-  const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (u >= n_uniq[0]) return;
+  // n_max is a capacity (the number of touched features is only known on the device): capped grid, strided loop
+  const int nu = n_uniq[0];
+  const int Dx = L.embedx_dim;
+  for (int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x; u < nu; u += (int64_t)gridDim.x * kBlock) {
   const int64_t row = uniq[u];
   const int beg = seg_off[u], end = seg_off[u + 1];
   float* r = rec + row * (int64_t)L.row_stride;
   float* st = r + L.stat_off;            // show, click, g2sum_w, g2sum_x, state
   const int64_t grow = row * A.row_mul + A.row_add;
-  const int Dx = L.embedx_dim;
   const float show0 = st[0], click0 = st[1], g2w = st[2], g2x = st[3], state = st[4];
   const bool unborn = state == 0.f;
   float w[DX];
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_narrow_kernel(
   st[2] = g2w + gwv * gwv;
   if (has_x) st[3] = g2x + sq / (float)Dx;
   st[4] = (has_x || create_x) ? 2.f : 1.f;
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void ps_shrink_rows_kernel(int64_t N, rec_ps_layout L,
@@ -339,8 +341,8 @@ extern "C" int rec_ps_push_rows(int64_t n_max, int32_t num_slots, const rec_ps_l
   hipStream_t st = (hipStream_t)stream;
   static const bool narrow_ok = [] { const char* v = getenv("REC_NARROW_ROWS"); return !(v && *v == '0'); }();
   if (!vec && Dx <= 16 && narrow_ok) {   // no float4 row groups: one lane per feature
-    const int64_t grid = (n_max + kBlock - 1) / kBlock;
-    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");
+    int64_t grid = (n_max + kBlock - 1) / kBlock;
+    if (grid > (int64_t)kNumCU * 32) grid = (int64_t)kNumCU * 32;   // grid-stride loop in the kernel
 #define REC_PS_NARROW(DX_)                                                                               \
   hipLaunchKernelGGL((ps_push_rows_narrow_kernel<DX_>), dim3((unsigned)grid), dim3(kBlock), 0, st, *layout, \
                      num_slots, n_uniq, uniq_rows, seg_offset, sorted_pos, gx, gw, show, click, rec, *accessor)

@@ -477,8 +477,10 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_rows_narrow_kernel(
     const float* __restrict__ grad, rec_grad_layout gl, const float* __restrict__ grad_scale,
     float* __restrict__ P, float* __restrict__ M, float* __restrict__ V, float lr_t, float eps_t,
     float b1, float b2) {
-  const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (u >= n_uniq[0]) return;
+  // the launch is sized for n_max (a capacity: the number of distinct rows is only known on the device), so the
+  // grid is capped at a few resident rounds and strides over the rows that exist
+  const int nu = n_uniq[0];
+  for (int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x; u < nu; u += (int64_t)gridDim.x * kBlock) {
   const int64_t row = uniq[u];
   const int beg = seg_off[u], end = seg_off[u + 1];
   float p[NV * 4], m[NV * 4], v[NV * 4], g[NV * 4];
@@ -499,6 +501,7 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_rows_narrow_kernel(
   narrow_store<NV, V4>(P + row * stride, p, D);
   narrow_store<NV, V4>(M + row * sstride, m, D);
   narrow_store<NV, V4>(V + row * sstride, v, D);
+  }
 }
 
 // Both embeddings of a DeepFM row in ONE pass (DESIGN.md "table layout"): the record line holds
@@ -837,8 +840,8 @@ extern "C" int rec_sparse_adam_rows(int64_t n_max, int32_t emb_dim, int32_t row_
   if (!rows4 && emb_dim <= 16 && narrow_ok) {   // no float4 row groups: one lane per row (see the narrow kernel)
     const bool v4 = row_stride % 4 == 0 && state_stride % 4 == 0 && ((uintptr_t)P) % 16 == 0 &&
                     ((uintptr_t)M) % 16 == 0 && ((uintptr_t)V) % 16 == 0;
-    const int64_t grid = (n_max + kBlock - 1) / kBlock;
-    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");
+    int64_t grid = (n_max + kBlock - 1) / kBlock;
+    if (grid > (int64_t)kNumCU * 32) grid = (int64_t)kNumCU * 32;   // grid-stride loop in the kernel
     const int nv = (emb_dim + 3) / 4;
 #define REC_NARROW(NV_, V4_)                                                                                 \
   hipLaunchKernelGGL((sparse_adam_rows_narrow_kernel<NV_, V4_>), dim3((unsigned)grid), dim3(kBlock), 0, st,   \

@@ -143,8 +143,10 @@ class BenchmarkDNNLayer:
         pred, dz, loss = k.sigmoid_logloss(y, None, None, label, self.ws, clip=CLIP)
         if auc_stats is not None:
             k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
-        with self._timed("mlp_bwd"):
-            dx = k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp)      # [B, S*D]
+        with self._timed("mlp_bwd"):      # dX of layer 0 BEFORE its dW: the HBM-bound sparse update below runs on the
+            # side stream underneath that MFMA-bound GEMM (the largest of the step: S*D x 512 x B)
+            dx, finish_dw0 = k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp,
+                                            defer_first=True)                                     # [B, S*D]
         with _OnSide(side, cur):
             with self._timed("sparse_update"):
                 if self.table is not None:
@@ -153,6 +155,8 @@ class BenchmarkDNNLayer:
                     st = self.sparse_state
                     pp = self._pp = k.segment_partials(groups, dx, D, out=getattr(self, "_pp", None))
                     k.sparse_adam_rows(groups, dx, 1, self.embedding, st["m"], st["v"], t, lr, partials=pp)
+        with self._timed("mlp_bwd_dw0"):
+            finish_dw0()
         k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
         if on_gpu:
             cur.wait_stream(self._side)

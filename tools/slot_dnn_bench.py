@@ -109,7 +109,7 @@ def main():
                      "frac": alg / ms_pool / 1e6 / 8000.0, "GBs_designed": designed / ms_pool / 1e6,
                      "kernel": "multislot_sumpool_kernel"},
         "train_step_ms": ms_step, "samples_per_s": B / ms_step * 1e3, "kernels_ms": ev,
-        "mlp_tflops_in_step": flops / ((ev.get("mlp_fwd", 0) + ev.get("mlp_bwd", 0)) * 1e-3) / 1e12
+        "mlp_tflops_in_step": flops / ((ev.get("mlp_fwd", 0) + ev.get("mlp_bwd", 0) + ev.get("mlp_bwd_dw0", 0)) * 1e-3) / 1e12
         if ev.get("mlp_fwd") else None,
         "index_oob_flag": int(model.status.item())}))
 
