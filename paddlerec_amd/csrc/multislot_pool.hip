@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kMsWaves * kWave, (kMsWaves == 8 || NSW >= 2) ? 6 :
       wave_fence();
       const int nsub = (nlive + G - 1) / G;
       for (int j0 = 0; j0 < nsub; j0 += U) {
-        float e[U][VEC];
+        float e[U][VEC], stf[U];
         int sg[U], sgn[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -196,19 +196,23 @@ __global__ __launch_bounds__(kMsWaves * kWave, (kMsWaves == 8 || NSW >= 2) ? 6 :
           sgn[u] = (q + 1 < nlive && g != G - 1) ? wseg[q + 1] : -2;   // last group of a sub-step always flushes
 #pragma unroll
           for (int v = 0; v < VEC; ++v) e[u][v] = 0.f;
+          stf[u] = 1.f;
           if (ok && d0 < D) {
             vload<VEC>(e[u], W + rr * stride + d0);
-            // PS rows are born lazily: an unborn row (state 0, zero memory) reads as its creation values
-            if (state_off >= 0 && W[rr * stride + state_off] == 0.f) {
-#pragma unroll
-              for (int v = 0; v < VEC; ++v)
-                e[u][v] = d0 + v < init_dims ? ps_init_value(seed, rr, d0 + v, init_range) : 0.f;
-            }
+            // PS rows are born lazily; the state float is only LOADED here (same record line as the weights) and
+            // looked at below, so the gathers of all U sub-steps are in flight before the first wait
+            if (state_off >= 0) stf[u] = W[rr * stride + state_off];
           }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if ((j0 + u) < nsub) {                  // wave-uniform
+            if (state_off >= 0 && stf[u] == 0.f) {   // an unborn row (state 0, zero memory) reads as its creation values
+              const int64_t rr = wrow[(j0 + u) * G + g];   // (stf is 1 where the group holds no row)
+#pragma unroll
+              for (int v = 0; v < VEC; ++v)
+                e[u][v] = d0 + v < init_dims ? ps_init_value(seed, rr, d0 + v, init_range) : 0.f;
+            }
             // segmented inclusive scan over the G groups (runs of equal seg are contiguous); a step is skipped
             // once no run reaches that far back (wave-uniform)
 #define REC_SCAN_STEP(O)                                                                      \
