@@ -292,7 +292,10 @@ class DeepFMLayer:
             self.k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         defer_all = os.environ.get("REC_DEEPFM_DEFER_ALL", "0") == "1"   # measurement knob: every dW GEMM in the tail
         kw = dict(defer_all=True) if defer_all else dict(defer_first=True)
-        if on_gpu and os.environ.get("REC_MLP_DW_STREAM", "0") == "1":     # measurement knob: dW GEMMs on a third stream
+        # dW_i on a third stream beside dX_i (both consume g_i, neither the other): the half-empty last round of
+        # blocks of one GEMM is filled by the other — 2.77-2.84 -> 2.70-2.81 ms per step in five A/B pairs on two boxes
+        # (profiles/r02f_dw_stream_ab.txt); REC_MLP_DW_STREAM=0 puts them back on one stream
+        if on_gpu and not defer_all and os.environ.get("REC_MLP_DW_STREAM", "1") == "1":
             if getattr(self, "_dw_stream", None) is None:
                 self._dw_stream, self._ws_dw = self.k.concurrent_stream(self.device), self.k.Workspace(self.device)
             kw.update(dw_stream=self._dw_stream, dw_ws=self._ws_dw)
