@@ -349,6 +349,16 @@ int rec_sparse_sgd_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride, cons
                         const float* grad, const rec_grad_layout* grad_layout, float* P, float lr,
                         void* stream);
 int rec_sgd_dense(int64_t n, float* p, const float* g, float lr, void* stream);
+/* The merge and the SGD row update of a SMALL SelectedRows gradient in one launch (n <= 15360 lookups,
+ * emb_dim <= 256): at the reference's own batch size (din/config.yaml: batch_size 32, ~5 k lookups per table) the
+ * sort-based rec_ids_group + rec_segment_partials + rec_sparse_sgd_rows are 12-13 launches per table whose launch
+ * latency, not work, is the step time.  A wave per lookup finds the occurrences of its row with ballots over the id
+ * list; the first occurrence's wave adds the gradient rows in ascending position (the SelectedRows merge order)
+ * and applies p -= lr * g.  ids [n] i64 rows (padding_idx < 0: none); out-of-range ids are skipped and flagged in
+ * status; grad / grad_layout as for rec_sparse_sgd_rows (partials ignored). */
+int rec_sparse_sgd_small(int64_t n, int32_t emb_dim, int32_t row_stride, int64_t num_rows, int64_t padding_idx,
+                         const int64_t* ids, const float* grad, const rec_grad_layout* grad_layout, float* P,
+                         float lr, int32_t* status, void* stream);
 
 /* lazy_mode=False Adam on a SelectedRows gradient — the dygraph default (deepfm/dygraph_model.py:61-65,
  * SURVEY.md App. B-3): every one of the num_rows rows is updated, rows absent from the merged gradient with

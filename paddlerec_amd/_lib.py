@@ -143,6 +143,7 @@ SIGNATURES = {
     "rec_din_attention_pool_bwd": (C.c_int, [C.POINTER(DinDesc)] + [_P] * 21),
     "rec_sparse_sgd_rows": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P, _F, _P]),
     "rec_sgd_dense": (C.c_int, [_I64, _P, _P, _F, _P]),
+    "rec_sparse_sgd_small": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, C.POINTER(GradLayout), _P, _F, _P, _P]),
     "rec_bce_with_logits": (C.c_int, [_I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rec_moe_bwd_prep": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _I32,
                                    _P, _I32, _P]),

@@ -635,6 +635,111 @@ __global__ void sgd_dense_kernel(int64_t n, float* __restrict__ p, const float* 
     p[i] -= lr * g[i];
 }
 
+// ------------------------------------------------------------------ small batches: merge + SGD in ONE launch
+// At the reference's own batch size (din/config.yaml: 32 samples x ~150 history positions = ~5 k lookups per table)
+// the grouping sort + hot-row partials + row update of one table are 12-13 launches of a few microseconds each,
+// seven tables per step: ~90 of the ~120 launches of a DIN train step, and the launches — not the work — are the
+// step time (0.70 ms; replaying the same launches from a hipGraph: 0.60 ms).  For n this small the merge needs no
+// sort: a wave per lookup compares its id with all n ids 64 at a time (ballots over the id list, which sits in L2);
+// the wave of a row's FIRST occurrence adds the gradient rows of every occurrence in ascending position (the
+// SelectedRows merge order) and applies p -= lr * g.  O(n^2 / 64) wave steps: 12 us at n = 8192.
+constexpr int kSmallMergeMax = 15360;   // ids + per-wave lists stay inside the default 64 KB of LDS
+constexpr int kSmallWaves = 16;        // lookups per block; the block stages the whole id list in LDS once (4 B per id)
+constexpr int kSmallList = 32;         // occurrences of a row collected before their gradient rows are fetched together
+
+template <int NACC>   // floats per lane: D <= 64 * NACC
+__global__ __launch_bounds__(kSmallWaves* kWave) void sparse_sgd_small_kernel(
+    int n, int D, int stride, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
+    const float* __restrict__ grad, rec_grad_layout gl, float* __restrict__ P, float lr,
+    int32_t* __restrict__ status) {
+  constexpr int FLY = kSmallList / NACC;   // gradient rows in flight per wave (32 / 16 / 8 rows of 64 / 128 / 256 floats)
+  extern __shared__ int small_lds[];
+  int* wlists = small_lds;                               // [waves][kSmallList] positions of collected occurrences
+  int* small_ids = small_lds + kSmallWaves * kSmallList; // [n] rows as int32, -1 = padding / out of range (never matches)
+  int oob = 0;
+  for (int i = threadIdx.x; i < n; i += kSmallWaves * kWave) {
+    const int64_t id = ids[i];
+    const bool isp = pad >= 0 && id == pad;
+    const bool inr = id >= 0 && id < N;
+    oob |= (!isp && !inr) ? 1 : 0;
+    small_ids[i] = (!isp && inr) ? (int)id : -1;
+  }
+  if (oob) atomicOr(status, REC_FLAG_INDEX_OOB);
+  __syncthreads();
+  const int lane = threadIdx.x % kWave;
+  const int pos = blockIdx.x * kSmallWaves + threadIdx.x / kWave;
+  if (pos >= n) return;
+  const int my = small_ids[pos];
+  if (my < 0) return;
+  // an earlier occurrence owns the row (four 64-id chunks per trip: the LDS reads of a trip are in flight together)
+  for (int c0 = 0; c0 < pos; c0 += 4 * kWave) {
+    bool hit = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = c0 + u * kWave + lane;
+      hit |= j < pos && small_ids[j] == my;
+    }
+    if (__ballot(hit) != 0) return;
+  }
+  // The occurrences (ascending) are collected FLY at a time across the 64-id chunks and their gradient rows fetched
+  // together: a row with a handful of scattered duplicates costs one memory round trip, a hot row (the target item
+  // of a sample: one occurrence per history position) ceil(occurrences / FLY).
+  int* wl = wlists + (threadIdx.x / kWave) * kSmallList;
+  float acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) acc[a] = 0.f;
+  int cnt = 0;
+  const bool plain = gl.group == 1 && gl.div == 1 && gl.index == nullptr;
+  auto flush = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float x[FLY][NACC];
+#pragma unroll
+    for (int u = 0; u < FLY; ++u) {
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) x[u][a] = 0.f;
+      if (u < cnt) {                                   // wave-uniform: unused slots cost nothing
+        const int q = wl[u];
+        // (one gradient row per position at a fixed pitch is the common layout: no integer division)
+        const float* g = grad + (plain ? (int64_t)q * gl.group_stride : grad_offset(gl, q, D));
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+          const int d = lane + a * kWave;
+          if (d < D) x[u][a] = g[d];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < FLY; ++u)
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) acc[a] += x[u][a];
+    cnt = 0;
+    __builtin_amdgcn_wave_barrier();     // the list is rewritten only after every lane has read it
+  };
+  for (int c = pos / kWave; c * kWave < n; ++c) {
+    const int j = c * kWave + lane;
+    bool mine = j >= pos && j < n && small_ids[j] == my;
+    unsigned long long m = __ballot(mine);
+    while (m) {
+      const int rank = __popcll(m & ((1ull << lane) - 1ull));
+      const int take = min((int)__popcll(m), FLY - cnt);
+      if (mine && rank < take) wl[cnt + rank] = j;
+      cnt += take;
+      mine = mine && rank >= take;
+      m = __ballot(mine);
+      if (cnt == FLY) flush();
+    }
+  }
+  if (cnt > 0) flush();
+  float* p = P + (int64_t)my * stride;
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int d = lane + a * kWave;
+    if (d < D) p[d] -= lr * acc[a];
+  }
+}
+
 // sum over the merged rows of |g_row|^2 (global-norm clipping needs the norm of the MERGED sparse grad)
 template <int VEC, int LANES>
 __global__ __launch_bounds__(kBlock) void sparse_rows_sumsq_kernel(
@@ -1076,6 +1181,34 @@ extern "C" int rec_sparse_sgd_rows(int64_t n_max, int32_t emb_dim, int32_t row_s
                        grad, gl, P, lr);
     return check_launch("rec_sparse_sgd_rows");
   });
+}
+
+extern "C" int rec_sparse_sgd_small(int64_t n, int32_t emb_dim, int32_t row_stride, int64_t num_rows,
+                                    int64_t padding_idx, const int64_t* ids, const float* grad,
+                                    const rec_grad_layout* grad_layout, float* P, float lr, int32_t* status,
+                                    void* stream) {
+  rec_grad_layout gl = {1, 0, 0, nullptr, nullptr};
+  if (grad_layout) gl = *grad_layout;
+  gl.partials = nullptr;
+  REC_REQUIRE(n >= 0 && emb_dim > 0 && row_stride >= emb_dim && num_rows > 0 && gl.div >= 1, REC_EINVAL, "bad sizes");
+  REC_REQUIRE(n <= kSmallMergeMax, REC_ESHAPE, "n %lld > %d: use rec_ids_group + rec_sparse_sgd_rows", (long long)n,
+              kSmallMergeMax);
+  REC_REQUIRE(emb_dim <= 4 * kWave, REC_ESHAPE, "emb_dim %d > %d unsupported by the one-launch merge", emb_dim,
+              4 * kWave);
+  REC_REQUIRE(gl.group <= 0 || gl.group_stride >= (int64_t)gl.group * emb_dim, REC_EINVAL,
+              "grad group_stride too small");
+  if (n == 0) return REC_OK;
+  REC_REQUIRE(ids && grad && P && status, REC_EINVAL, "null pointer argument");
+  REC_REQUIRE(num_rows < (1ll << 31), REC_ESHAPE, "num_rows too large for the one-launch merge");
+  const unsigned grid = (unsigned)((n + kSmallWaves - 1) / kSmallWaves);
+  const size_t shmem = ((size_t)n + kSmallWaves * kSmallList) * sizeof(int);       // <= 66 KB
+  hipStream_t st = (hipStream_t)stream;
+#define REC_SMALL(NACC_)                                                                                       \
+  hipLaunchKernelGGL((sparse_sgd_small_kernel<NACC_>), dim3(grid), dim3(kSmallWaves * kWave), shmem, st, (int)n, \
+                     emb_dim, row_stride, num_rows, padding_idx, ids, grad, gl, P, lr, status)
+  if (emb_dim <= kWave) REC_SMALL(1); else if (emb_dim <= 2 * kWave) REC_SMALL(2); else REC_SMALL(4);
+#undef REC_SMALL
+  return check_launch("rec_sparse_sgd_small");
 }
 
 extern "C" int rec_sgd_dense(int64_t n, float* p, const float* g, float lr, void* stream) {

@@ -24,6 +24,16 @@ def _xavier_uniform_(t, fan_in, fan_out):
     return t.uniform_(-b, b)
 
 
+class _StepBuffers:
+    """The reusable device buffers of one train step: GEMM / grouping workspaces, what the attention forward saves
+    for its backward, the SelectedRows grouping outputs and hot-row partial sums per (lookup count, width).  The eager
+    step owns one set; under train_step_graphed every input signature owns its own (a hipGraph holds addresses)."""
+
+    def __init__(self, k, device):
+        self.ws, self.ws_group = k.Workspace(device), k.Workspace(device)
+        self.att_saved, self.groups, self.partials = {}, {}, {}
+
+
 class DINLayer:
     """din/net.py:20-184.  forward(...) -> logit [B,1]."""
 
@@ -50,16 +60,28 @@ class DINLayer:
         self.attention_w = [_xavier_uniform_(torch.empty(sizes[i], sizes[i + 1], **f32), sizes[i], sizes[i + 1])
                             for i in range(3)]
         self.attention_b = [torch.zeros(sizes[i + 1], **f32) for i in range(3)]
-        self.params["linearCon.weight"] = _xavier_uniform_(torch.empty(E, E, **f32), E, E)  # net.py:109-117
-        self.params["linearCon.bias"] = torch.zeros(E, **f32)
+        # the dense parameters (linearCon, linear_0..2) are views of ONE flat buffer, their gradients of another:
+        # one SGD launch per step instead of eight
         con = [2 * E, 80, 40, 1]                                                         # net.py:119-137
+        shapes = [("linearCon.weight", (E, E)), ("linearCon.bias", (E,))]               # net.py:109-117
         for i in range(3):
-            self.params["linear_%d.weight" % i] = _xavier_uniform_(torch.empty(con[i], con[i + 1], **f32),
-                                                                   con[i], con[i + 1])
-            self.params["linear_%d.bias" % i] = torch.zeros(con[i + 1], **f32)
+            shapes += [("linear_%d.weight" % i, (con[i], con[i + 1])), ("linear_%d.bias" % i, (con[i + 1],))]
+        self._dense = torch.zeros(sum(math.prod(sh) for _, sh in shapes), **f32)
+        self._dense_grad = torch.zeros_like(self._dense)
+        self._gb, o = {}, 0
+        for name, sh in shapes:
+            k_ = math.prod(sh)
+            self.params[name] = self._dense[o:o + k_].view(sh)
+            self._gb[name] = self._dense_grad[o:o + k_].view(sh)
+            o += k_
+            if name.endswith(".weight"):
+                _xavier_uniform_(self.params[name], sh[0], sh[1])
         self.ws = self.k.Workspace(self.device)
         self.status = self.k.new_status(self.device)
         self._att_saved = {}     # what the attention-pool forward keeps for its backward (buffers reused per step)
+        self._bufs = None        # the eager train step's reusable buffers (_StepBuffers)
+        self._graph = None       # StepGraph of train_step_graphed
+        self.step_count = 0
 
     def state_dict(self):
         return dict(self.params)
@@ -73,18 +95,20 @@ class DINLayer:
             dst.copy_(torch.as_tensor(src).to(self.device).reshape(dst.shape))
 
     def forward(self, hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq,
-                target_cat_seq, _keep=None):
+                target_cat_seq, _keep=None, _bufs=None):
         p, E = self.params, self.firInDim
         B, T = hist_item_seq.shape
+        ws = _bufs.ws if _bufs is not None else self.ws
+        att_saved = _bufs.att_saved if _bufs is not None else self._att_saved
         mask2 = mask.reshape(B, T).contiguous()
         pooled, attw, _ = self.k.din_attention_pool(
             hist_item_seq, hist_cat_seq, target_item_seq, target_cat_seq, mask2,
             p["hist_item_emb_attr.weight"], p["hist_cat_emb_attr.weight"],
             p["target_item_seq_emb_attr.weight"], p["target_cat_seq_emb_attr.weight"],
             self.attention_w, self.attention_b, self.status, want_weights=_keep is not None,
-            saved=self._att_saved if _keep is not None else None)                            # net.py:141-173
+            saved=att_saved if _keep is not None else None)                            # net.py:141-173
         emb = torch.empty(B, 2 * E, dtype=torch.float32, device=self.device)           # net.py:178
-        self.k.gemm(pooled, p["linearCon.weight"], self.ws, epilogue="bias", bias=p["linearCon.bias"],
+        self.k.gemm(pooled, p["linearCon.weight"], ws, epilogue="bias", bias=p["linearCon.bias"],
                  out=emb[:, :E])                                                         # net.py:175-176
         ti, tc = target_item.reshape(-1).contiguous(), target_cat.reshape(-1).contiguous()
         self.k.emb_gather(ti, p["target_item_emb_attr.weight"], None, self.status, out=emb[:, E:],
@@ -92,9 +116,9 @@ class DINLayer:
         self.k.emb_gather(tc, p["target_cat_emb_attr.weight"], None, self.status,
                        out=emb[:, E + self.item_emb_size:], out_group=1, out_group_stride=2 * E)
         item_b, _ = self.k.emb_gather(ti, p["item_b_attr.weight"], None, self.status)      # net.py:147
-        x1 = self.k.gemm(emb, p["linear_0.weight"], self.ws, epilogue="bias_sigmoid", bias=p["linear_0.bias"])
-        x2 = self.k.gemm(x1, p["linear_1.weight"], self.ws, epilogue="bias_sigmoid", bias=p["linear_1.bias"])
-        logit = self.k.gemm(x2, p["linear_2.weight"], self.ws, epilogue="add", bias=p["linear_2.bias"],
+        x1 = self.k.gemm(emb, p["linear_0.weight"], ws, epilogue="bias_sigmoid", bias=p["linear_0.bias"])
+        x2 = self.k.gemm(x1, p["linear_1.weight"], ws, epilogue="bias_sigmoid", bias=p["linear_1.bias"])
+        logit = self.k.gemm(x2, p["linear_2.weight"], ws, epilogue="add", bias=p["linear_2.bias"],
                          aux1=item_b)                                                    # net.py:180-183
         if _keep is not None:
             _keep.update(attw=attw, pooled=pooled, emb=emb, x1=x1, x2=x2, ti=ti, tc=tc)
@@ -108,16 +132,22 @@ class DINLayer:
         """paddle.optimizer.lr.PiecewiseDecay(boundaries=[410000], values=[base_lr, 0.2]) (dygraph_model.py:65-70)."""
         return base_lr if step < 410000 else 0.2
 
-    def _sgd_rows(self, ids, grad_view, table, lr, row_stride_floats):
+    def _sgd_rows(self, bufs, ids, grad_view, table, lr, row_stride_floats):
         n = ids.numel()
+        if n <= getattr(self.k, "SMALL_MERGE_MAX", 0) and table.shape[1] <= 256:
+            # the shipped batch size (32 x ~150 positions): merge + update in ONE launch instead of the 12-13 of
+            # sort + partials + row update — the launches, not the work, are the step time there
+            self.k.sparse_sgd_small(ids.reshape(-1), grad_view, table, lr, None, self.status, grad_group=1,
+                                    grad_group_stride=row_stride_floats)
+            return
         key = n
-        grp = self._groups.get(key)
+        grp = bufs.groups.get(key)
         if grp is None:
-            grp = self._groups[key] = self.k.IdGroups(n, self.device)
-        self.k.ids_group(ids.reshape(-1), table.shape[0], None, self.ws_group, None, self.status, grp)
-        pp = self._partials[key, table.shape[1]] = self.k.segment_partials(grp, grad_view, table.shape[1], grad_group=1,
+            grp = bufs.groups[key] = self.k.IdGroups(n, self.device)
+        self.k.ids_group(ids.reshape(-1), table.shape[0], None, bufs.ws_group, None, self.status, grp)
+        pp = bufs.partials[key, table.shape[1]] = self.k.segment_partials(grp, grad_view, table.shape[1], grad_group=1,
                                                         grad_group_stride=row_stride_floats,
-                                                        out=self._partials.get((key, table.shape[1])))   # popular items: hot rows
+                                                        out=bufs.partials.get((key, table.shape[1])))   # popular items: hot rows
         self.k.sparse_sgd_rows(grp, grad_view, table, lr, grad_group=1, grad_group_stride=row_stride_floats,
                             partials=pp)
 
@@ -125,23 +155,46 @@ class DINLayer:
                    target_cat_seq, base_lr=0.85):
         """din/dygraph_model.py:85-100 train_forward + backward + SGD step.  label float32 [B,1].
         Returns (loss [1], pred [B,1])."""
-        if not hasattr(self, "_groups"):
-            self._groups, self._partials, self.ws_group, self.step_count = {}, {}, self.k.Workspace(self.device), 0
-        p, E, Ei = self.params, self.firInDim, self.item_emb_size
-        B, T = hist_item_seq.shape
+        if self._bufs is None:
+            self._bufs = _StepBuffers(self.k, self.device)
         lr = self.learning_rate(self.step_count, base_lr)
         self.step_count += 1
+        return self._step(self._bufs, hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask,
+                          target_item_seq, target_cat_seq, lr=lr)
+
+    def train_step_graphed(self, hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq,
+                           target_cat_seq, base_lr=0.85):
+        """train_step replayed from a hipGraph per input signature (paddlerec_amd/graph.py): at the shipped batch size
+        (din/config.yaml: 32) the step is ~120 launches of a few microseconds and the host's launch path is the step
+        time.  Same arithmetic, same kernels, same order; the returned (loss, pred) are the graph's static outputs,
+        overwritten by the next step of the same signature."""
+        if self._graph is None:
+            import weakref
+            from .graph import StepGraph
+            me = weakref.ref(self)                          # no cycle model <-> graph: see graph.py
+            self._graph = StepGraph(lambda st, *a, **kw: me()._step(st, *a, **kw),
+                                    state_factory=lambda: _StepBuffers(me().k, me().device))
+        lr = self.learning_rate(self.step_count, base_lr)     # host scalar baked into the launches: part of the key
+        self.step_count += 1
+        return self._graph(hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq,
+                           target_cat_seq, lr=lr)
+
+    def _step(self, bufs, hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq,
+              target_cat_seq, lr):
+        p, E, Ei = self.params, self.firInDim, self.item_emb_size
+        B, T = hist_item_seq.shape
         sv = {}
         logit = self.forward(hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask,
-                             target_item_seq, target_cat_seq, _keep=sv)
-        pred, dz, loss = self.k.bce_with_logits(logit, label.reshape(B, 1).contiguous(), self.ws)
+                             target_item_seq, target_cat_seq, _keep=sv, _bufs=bufs)
+        pred, dz, loss = self.k.bce_with_logits(logit, label.reshape(B, 1).contiguous(), bufs.ws)
         g = {}
-        ws = self.ws
+        ws = bufs.ws
 
         def lin_bwd(name, x, dy, act=None):
             """dW, db of Linear `name` (input x, output-gradient dy); returns d x (sigmoid' of x fused when act)."""
-            g[name + ".weight"] = self.k.gemm(x, dy, ws, trans_a=True, b_colsum=self._gbuf(name + ".bias"))
-            g[name + ".bias"] = self._gbuf(name + ".bias")
+            g[name + ".weight"] = self.k.gemm(x, dy, ws, trans_a=True, out=self._gb[name + ".weight"],
+                                              b_colsum=self._gb[name + ".bias"])
+            g[name + ".bias"] = self._gb[name + ".bias"]
             if act is None:
                 return self.k.gemm(dy, p[name + ".weight"], ws, trans_b=True)
             return self.k.gemm(dy, p[name + ".weight"], ws, trans_b=True, epilogue="dsigmoid", aux0=act)
@@ -154,28 +207,18 @@ class DINLayer:
             hist_item_seq, hist_cat_seq, target_item_seq, target_cat_seq,
             p["hist_item_emb_attr.weight"], p["hist_cat_emb_attr.weight"],
             p["target_item_seq_emb_attr.weight"], p["target_cat_seq_emb_attr.weight"],
-            self.attention_w, self.attention_b, sv["attw"], dpooled, saved=self._att_saved)
+            self.attention_w, self.attention_b, sv["attw"], dpooled, saved=bufs.att_saved)
         self._last = dict(dh=dh, dq=dq, de0=de0, dz=dz, dense=g)
         # ---- SGD (dygraph_model.py:64-73).  Embedding tables: merged rows; dense: in place.
-        self._sgd_rows(hist_item_seq, dh, p["hist_item_emb_attr.weight"], lr, E)
-        self._sgd_rows(hist_cat_seq, dh[:, :, Ei:], p["hist_cat_emb_attr.weight"], lr, E)
-        self._sgd_rows(target_item_seq, dq, p["target_item_seq_emb_attr.weight"], lr, E)
-        self._sgd_rows(target_cat_seq, dq[:, :, Ei:], p["target_cat_seq_emb_attr.weight"], lr, E)
-        self._sgd_rows(sv["ti"], de0[:, E:], p["target_item_emb_attr.weight"], lr, 2 * E)
-        self._sgd_rows(sv["tc"], de0[:, E + Ei:], p["target_cat_emb_attr.weight"], lr, 2 * E)
-        self._sgd_rows(sv["ti"], dz, p["item_b_attr.weight"], lr, 1)
-        for name in ("linear_0", "linear_1", "linear_2", "linearCon"):
-            self.k.sgd_dense(p[name + ".weight"], g[name + ".weight"], lr)
-            self.k.sgd_dense(p[name + ".bias"], g[name + ".bias"], lr)
+        self._sgd_rows(bufs, hist_item_seq, dh, p["hist_item_emb_attr.weight"], lr, E)
+        self._sgd_rows(bufs, hist_cat_seq, dh[:, :, Ei:], p["hist_cat_emb_attr.weight"], lr, E)
+        self._sgd_rows(bufs, target_item_seq, dq, p["target_item_seq_emb_attr.weight"], lr, E)
+        self._sgd_rows(bufs, target_cat_seq, dq[:, :, Ei:], p["target_cat_seq_emb_attr.weight"], lr, E)
+        self._sgd_rows(bufs, sv["ti"], de0[:, E:], p["target_item_emb_attr.weight"], lr, 2 * E)
+        self._sgd_rows(bufs, sv["tc"], de0[:, E + Ei:], p["target_cat_emb_attr.weight"], lr, 2 * E)
+        self._sgd_rows(bufs, sv["ti"], dz, p["item_b_attr.weight"], lr, 1)
+        self.k.sgd_dense(self._dense, self._dense_grad, lr)      # all four Linear layers (every gradient was written above)
         return loss, pred
-
-    def _gbuf(self, name):
-        if not hasattr(self, "_gb"):
-            self._gb = {}
-        b = self._gb.get(name)
-        if b is None:
-            b = self._gb[name] = torch.empty_like(self.params[name])
-        return b
 
 
 NUM_THRESHOLDS = 4095  # paddle.metric.Auc default [EXT]

@@ -816,6 +816,22 @@ def sparse_sgd_rows(groups, grad, P, lr, grad_div=1, grad_group=0, grad_group_st
                                     _p(P), float(lr), _stream()), "rec_sparse_sgd_rows")
 
 
+SMALL_MERGE_MAX = 15360     # rec_sparse_sgd_small: lookups per call
+
+
+def sparse_sgd_small(ids, grad, P, lr, padding_idx=None, status=None, grad_div=1, grad_group=0, grad_group_stride=0):
+    """Merge + SGD row update of a small SelectedRows gradient in ONE launch (ids.numel() <= SMALL_MERGE_MAX,
+    emb_dim <= 256): P[row] -= lr * (sum of the row's gradient rows, ascending position)."""
+    _chk(ids, torch.int64, "ids")
+    D, stride = _chk_table(P, "P")
+    if status is None:
+        status = new_status(ids.device)
+    check(lib().rec_sparse_sgd_small(ids.numel(), D, stride, P.shape[0], -1 if padding_idx is None else padding_idx,
+                                     _p(ids), _p(grad), C.byref(_gl(grad_div, grad_group, grad_group_stride)), _p(P),
+                                     float(lr), _p(status), _stream()), "rec_sparse_sgd_small")
+    return status
+
+
 def sgd_dense(p, g, lr):
     _chk(p, torch.float32, "p")
     _chk(g, torch.float32, "g")

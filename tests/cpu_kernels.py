@@ -162,6 +162,16 @@ def sparse_sgd_rows(groups, grad, P, lr, grad_div=1, grad_group=0, grad_group_st
     Pn[groups.uniq] = Pn[groups.uniq] - np.float32(lr) * merged
 
 
+SMALL_MERGE_MAX = 15360
+
+
+def sparse_sgd_small(ids, grad, P, lr, padding_idx=None, status=None, grad_div=1, grad_group=0, grad_group_stride=0):
+    g = IdGroups(ids.numel(), "cpu")
+    ids_group(ids.reshape(-1), P.shape[0], padding_idx, None, None, status, g)
+    sparse_sgd_rows(g, grad, P, lr, grad_div, grad_group, grad_group_stride)
+    return status
+
+
 def sgd_dense(p, g, lr):
     p.sub_(g.reshape(p.shape) * float(lr))
 

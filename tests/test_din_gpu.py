@@ -191,3 +191,67 @@ def test_din_train_steps_vs_oracle(engine_lib):
             p[k] = (p[k] - lr * np.asarray(grads[k]).reshape(p[k].shape)).astype(np.float32)
     for k, v in m.state_dict().items():
         np.testing.assert_allclose(N_(v), p[k], rtol=2e-4, atol=3e-6, err_msg=k)
+
+
+def test_din_train_step_graphed_equals_eager(engine_lib):
+    """train_step_graphed (hipGraph replay per input signature, paddlerec_amd/graph.py) runs the same launches in the
+    same order as train_step: after a sequence of batches with TWO padded lengths (two signatures, first sight eager,
+    second sight captured, then replays) every parameter and every loss is bit-identical, and no step ran twice."""
+    from paddlerec_amd.din import DINLayer
+    rng = np.random.default_rng(21)
+    ni, nc, B = 150, 30, 32
+    a = DINLayer(64, 64, "sigmoid", False, True, ni, nc, device=DEV)
+    b = DINLayer(64, 64, "sigmoid", False, True, ni, nc, device=DEV)
+    b.set_dict({k: v.clone() for k, v in a.state_dict().items()})
+    b.set_attention([w.clone() for w in a.attention_w], [x.clone() for x in a.attention_b])
+    batches = []
+    for Tn in (40, 24, 40, 40, 24, 40, 24, 24):
+        hi, hc, ti, tc, mask, label = _din_problem(rng, B, Tn, ni, nc)
+        tis, tcs = np.repeat(ti[:, None], Tn, 1), np.repeat(tc[:, None], Tn, 1)
+        batches.append([T(x) for x in (hi, hc, ti, tc, label, mask, tis, tcs)])
+    for bt in batches:
+        la, _ = a.train_step(*bt, base_lr=0.5)
+        lb, _ = b.train_step_graphed(*bt, base_lr=0.5)
+        assert torch.equal(la, lb)
+    g = b._graph
+    assert (g.eager, g.captures, g.replays) == (2, 2, 6)          # one eager + one capture per signature, 6 replays
+    assert a.step_count == b.step_count == len(batches)
+    for k, v in a.state_dict().items():
+        assert torch.equal(v, b.state_dict()[k]), k
+    assert int(a.status.item()) == 0 and int(b.status.item()) == 0
+
+
+@pytest.mark.parametrize("n,D,N,hot", [(4864, 128, 63001, True), (32, 64, 801, False), (1, 1, 5, False),
+                                        (15360, 200, 3000, True), (777, 1, 100, False), (5000, 256, 50, True)])
+def test_sparse_sgd_small_equals_group_then_rows(engine_lib, n, D, N, hot):
+    """rec_sparse_sgd_small (merge + SGD in one launch, the bs-32 path) == rec_ids_group + rec_sparse_sgd_rows on the
+    same lookups (same ascending-position sums), with a strided gradient view, hot rows, an out-of-range id."""
+    from paddlerec_amd import _lib, ops
+    rng = np.random.default_rng(n + D)
+    ids = rng.integers(0, N, size=n).astype(np.int64)
+    if hot and n > 300:
+        ids[rng.integers(0, n, size=n // 3)] = ids[0]                   # one row with ~n/3 occurrences
+    pitch = D + 8
+    gfull = rng.standard_normal((n, pitch)).astype(np.float32)
+    P0 = rng.standard_normal((N, D)).astype(np.float32)
+    tg = T(gfull)
+    Pa, Pb = T(P0), T(P0)
+    st = ops.sparse_sgd_small(T(ids), tg[:, 4:4 + D], Pa, 0.37, grad_group=1, grad_group_stride=pitch)
+    ws = ops.Workspace(DEV)
+    grp, _ = ops.ids_group(T(ids), N, None, ws)
+    ops.sparse_sgd_rows(grp, tg[:, 4:4 + D], Pb, 0.37, grad_group=1, grad_group_stride=pitch)
+    assert int(st.item()) == 0
+    np.testing.assert_allclose(N_(Pa), N_(Pb), rtol=2e-6, atol=1e-6)
+    # oracle: float64 merge
+    want = P0.astype(np.float64)
+    np.subtract.at(want, ids, 0.37 * gfull[:, 4:4 + D].astype(np.float64))
+    np.testing.assert_allclose(N_(Pa), want, rtol=1e-4, atol=1e-4 if hot else 2e-5)
+    if n >= 32:        # padding id skipped, out-of-range id skipped + flagged
+        ids2 = ids.copy(); ids2[5] = N + 3; ids2[7] = 0
+        Pc = T(P0)
+        st2 = ops.sparse_sgd_small(T(ids2), tg[:, 4:4 + D], Pc, 0.37, padding_idx=0, grad_group=1, grad_group_stride=pitch)
+        assert int(st2.item()) & _lib.REC_FLAG_INDEX_OOB
+        keep = (ids2 != 0) & (ids2 < N)
+        want2 = P0.astype(np.float64)
+        np.subtract.at(want2, ids2[keep], 0.37 * gfull[keep, 4:4 + D].astype(np.float64))
+        np.testing.assert_allclose(N_(Pc), want2, rtol=1e-4, atol=1e-4 if hot else 2e-5)

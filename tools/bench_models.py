@@ -107,6 +107,12 @@ for B, T in ((32, 152), (4096, 100), (4096, 512)):
           % (B, T, t, B / t, B * T / t / 1e3, fl / t / 1e9))
     record("configs[3]", "DIN train step (attention-pool fwd + bwd on saved activations, concat MLP, row-merged SGD on "
            "7 tables), B %d, T %d" % (B, T), t, fl, B, {"positions_per_s": B * T / t * 1e3})
+    if B == 32:     # the same step replayed from a hipGraph (paddlerec_amd/graph.py): the launch-bound shape
+        tg = timeit(lambda: m.train_step_graphed(hi, hc, ti, tc, label, mask, tis, tcs))
+        print("DIN train step B=%d T=%d, hipGraph replay: %.3f ms  (%.1f k samples/s; eager %.3f ms)"
+              % (B, T, tg, B / tg, t))
+        record("configs[3]", "DIN train step replayed from a hipGraph (same launches), B %d, T %d" % (B, T), tg, fl, B,
+               {"positions_per_s": B * T / tg * 1e3, "eager_ms": t})
     del m
     torch.cuda.empty_cache()
 
