@@ -596,6 +596,57 @@ int rec_colsum(int64_t m, int32_t n, int32_t ld, const float* G, float* out, voi
                size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * CrossNet layers as ONE entry point per layer and direction (SURVEY.md §8(b) `crossnet_v2_layer`,
+ * `crossnet_mix_layer`): what a Paddle custom op (PD_BUILD_OP / PD_BUILD_GRAD_OP) binds for
+ *   dcn_v2/net.py:214-226  CrossNetV2:  x_{l+1} = x_l + x_0 * (x_l W_l + b_l)
+ *   dcn_v2/net.py:278-320  CrossNetMix: x_{l+1} = x_l + sum_e p_e * x_0 * (tanh(tanh(x_l V_e) C_e^T) U_e^T + b_l),
+ *                                       p = softmax_e(x_l gate_w + gate_b)
+ * They launch the GEMMs (rec_gemm_f32 epilogues) and streaming glue passes declared above in a fixed order; no
+ * kernel of their own.  Row strides (ld_*) in floats, 0 = d.  Workspace: query the _workspace_bytes function
+ * (GEMM split-K partials + the layer's scratch tensors).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t batch;
+  int32_t d;                            /* feature width: num_field * emb_dim */
+  int32_t ld_x0, ld_xl, ld_out, ld_u;   /* X_0, X_l, X_{l+1}, saved U_l */
+} rec_crossnet_v2_desc;
+int rec_crossnet_v2_layer_workspace_bytes(const rec_crossnet_v2_desc* desc, size_t* fwd_bytes, size_t* bwd_bytes);
+/* W [d,d] (Paddle [in,out]), bias [d]; U_saved [B, ld_u] (or NULL) receives u = x_l W + b for the backward. */
+int rec_crossnet_v2_layer_fwd(const rec_crossnet_v2_desc* desc, const float* X0, const float* Xl, const float* W,
+                              const float* bias, float* Xnext, float* U_saved, void* workspace,
+                              size_t workspace_bytes, void* stream);
+/* Given dXnext = d x_{l+1}:  dW [d,d], db [d], dXl = d x_l (may alias dXnext);  dX0_acc (+)= dXnext * U_l
+ * (accumulate_dx0 = 0: overwritten);  fold_dx0 != 0: dXl also receives dX0_acc (the first layer, x_l = x_0). */
+int rec_crossnet_v2_layer_bwd(const rec_crossnet_v2_desc* desc, const float* X0, const float* Xl, const float* W,
+                              const float* U_saved, const float* dXnext, int32_t ld_dxnext, float* dX0_acc,
+                              int32_t ld_acc, int32_t accumulate_dx0, int32_t fold_dx0, float* dXl,
+                              int32_t ld_dxl, float* dW, float* db, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
+typedef struct {
+  int64_t batch;
+  int32_t d, rank, experts;             /* experts <= 64 */
+  int32_t ld_x0, ld_xl, ld_out;
+} rec_crossnet_mix_desc;
+int rec_crossnet_mix_layer_workspace_bytes(const rec_crossnet_mix_desc* desc, size_t* fwd_bytes, size_t* bwd_bytes);
+/* U, V [E,d,r], C [E,r,r], bias [d], gate_w [d,E] (the E Linear(d,1) stacked), gate_b [E].
+ * Saved for the backward: t1 = tanh(x_l V_e), t2 = tanh(t1 C_e^T), both [B, E*r]; prob [B,E]. */
+int rec_crossnet_mix_layer_fwd(const rec_crossnet_mix_desc* desc, const float* X0, const float* Xl, const float* U,
+                               const float* V, const float* C, const float* bias, const float* gate_w,
+                               const float* gate_b, float* Xnext, float* t1, float* t2, float* prob,
+                               void* workspace, size_t workspace_bytes, void* stream);
+/* gU, gV [E,d,r], gC [E,r,r], gbias [d] are written; the gating layers are shared by all cross layers
+ * (net.py:267-268): g_gate_w [d,E] / g_gate_b [E] are overwritten when accumulate_gate == 0, added to otherwise.
+ * dXl must not alias dXnext.  dX0_acc / fold_dx0 as above. */
+int rec_crossnet_mix_layer_bwd(const rec_crossnet_mix_desc* desc, const float* X0, const float* Xl, const float* U,
+                               const float* V, const float* C, const float* bias, const float* gate_w,
+                               const float* t1, const float* t2, const float* prob, const float* dXnext,
+                               int32_t ld_dxnext, float* dX0_acc, int32_t ld_acc, int32_t accumulate_dx0,
+                               int32_t fold_dx0, float* dXl, int32_t ld_dxl, float* gU, float* gV, float* gC,
+                               float* gbias, float* g_gate_w, float* g_gate_b, int32_t accumulate_gate,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Loss head: predict = sigmoid(y1+y2+y_dnn) (deepfm/net.py:47);
  *            cost = log_loss(pred,label,eps=1e-4); avg = mean(cost) (deepfm/dygraph_model.py:53-58)
  * and its gradient dz = d avg / d z.  loss_out[0] = avg (reduced in a fixed order).

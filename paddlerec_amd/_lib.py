@@ -75,6 +75,16 @@ class DinDesc(C.Structure):
                 ("cat_stride", C.c_int32)]
 
 
+class CrossV2Desc(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("d", C.c_int32), ("ld_x0", C.c_int32), ("ld_xl", C.c_int32),
+                ("ld_out", C.c_int32), ("ld_u", C.c_int32)]
+
+
+class CrossMixDesc(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("d", C.c_int32), ("rank", C.c_int32), ("experts", C.c_int32),
+                ("ld_x0", C.c_int32), ("ld_xl", C.c_int32), ("ld_out", C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("m", C.c_int64), ("n", C.c_int32), ("k", C.c_int32), ("lda", C.c_int32),
                 ("ldb", C.c_int32), ("ldc", C.c_int32), ("trans_a", C.c_int32),
@@ -143,6 +153,14 @@ SIGNATURES = {
     "rec_din_attention_pool_bwd": (C.c_int, [C.POINTER(DinDesc)] + [_P] * 21),
     "rec_sparse_sgd_rows": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P, _F, _P]),
     "rec_sgd_dense": (C.c_int, [_I64, _P, _P, _F, _P]),
+    "rec_crossnet_v2_layer_workspace_bytes": (C.c_int, [C.POINTER(CrossV2Desc), C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "rec_crossnet_v2_layer_fwd": (C.c_int, [C.POINTER(CrossV2Desc), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "rec_crossnet_v2_layer_bwd": (C.c_int, [C.POINTER(CrossV2Desc), _P, _P, _P, _P, _P, _I32, _P, _I32, _I32, _I32, _P,
+                                            _I32, _P, _P, _P, _SZ, _P]),
+    "rec_crossnet_mix_layer_workspace_bytes": (C.c_int, [C.POINTER(CrossMixDesc), C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "rec_crossnet_mix_layer_fwd": (C.c_int, [C.POINTER(CrossMixDesc)] + [_P] * 13 + [_SZ, _P]),
+    "rec_crossnet_mix_layer_bwd": (C.c_int, [C.POINTER(CrossMixDesc)] + [_P] * 11 + [_I32, _P, _I32, _I32, _I32, _P, _I32]
+                                   + [_P] * 6 + [_I32, _P, _SZ, _P]),
     "rec_sparse_sgd_small": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, C.POINTER(GradLayout), _P, _F, _P, _P]),
     "rec_bce_with_logits": (C.c_int, [_I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rec_moe_bwd_prep": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _I32,

@@ -148,42 +148,31 @@ class DCN_V2Layer:
         return feat
 
     def _cross_v2(self, feat, out_last=None):
-        """net.py:222-226.  Returns (x_L, xs, us)."""
+        """net.py:222-226: one rec_crossnet_v2_layer_fwd per layer.  Returns (x_L, xs, us)."""
         p, k = self.dense.p, self.k
         xs, us = [feat], []
         x = feat
         for i in range(self.cross_num):
             u = torch.empty_like(feat)
             last = i == self.cross_num - 1
-            x = k.gemm(x, p[P + "cross_layers.%d.weight" % i], self.ws, epilogue="cross",
-                       bias=p[P + "cross_layers.%d.bias" % i], aux0=feat, aux1=x, out2=u,
-                       out=out_last if (last and out_last is not None) else None)
+            x = k.crossnet_v2_layer_fwd(feat, x, p[P + "cross_layers.%d.weight" % i],
+                                        p[P + "cross_layers.%d.bias" % i], self.ws,
+                                        out=out_last if (last and out_last is not None) else None, u=u)
             xs.append(x)
             us.append(u)
         return x, xs, us
 
     def _cross_mix(self, feat, out_last=None, saved=None):
-        """net.py:278-320 (row-vector form).  saved (list, optional): per layer (x_l, t1, t2, prob)."""
+        """net.py:278-320 (row-vector form): one rec_crossnet_mix_layer_fwd per layer.
+        saved (list, optional): per layer (x_l, t1, t2, prob)."""
         p, k = self.dense.p, self.k
-        E, r = self.num_experts, self.low_rank
-        B = feat.shape[0]
         x = feat
         for i in range(self.cross_num):
-            U, V, Cm = p[P + "U_list.%d" % i], p[P + "V_list.%d" % i], p[P + "C_list.%d" % i]
-            bias = p[P + "bias.%d" % i].view(-1)
-            gate = k.gemm(x, p[P + "gating.weight"], self.ws, epilogue="bias", bias=p[P + "gating.bias"])
-            prob = k.softmax_rows(gate)                                                   # net.py:315
-            t1 = torch.empty(B, E * r, dtype=torch.float32, device=self.device)
-            t2 = torch.empty(B, E * r, dtype=torch.float32, device=self.device)
             last = i == self.cross_num - 1
-            x_next = out_last if (last and out_last is not None) else torch.empty_like(feat)
-            for e in range(E):
-                k.gemm(x, V[e], self.ws, epilogue="bias_tanh", out=t1[:, e * r:(e + 1) * r])        # :292-296
-                k.gemm(t1[:, e * r:(e + 1) * r], Cm[e], self.ws, trans_b=True, epilogue="bias_tanh",
-                       out=t2[:, e * r:(e + 1) * r])                                               # :297-298
-            for e in range(E):
-                k.gemm(t2[:, e * r:(e + 1) * r], U[e], self.ws, trans_b=True, epilogue="moe", bias=bias,
-                       aux0=feat, aux1=x if e == 0 else x_next, row_scale=prob[:, e], out=x_next)   # :301-317
+            x_next, t1, t2, prob = k.crossnet_mix_layer_fwd(
+                feat, x, p[P + "U_list.%d" % i], p[P + "V_list.%d" % i], p[P + "C_list.%d" % i],
+                p[P + "bias.%d" % i].view(-1), p[P + "gating.weight"], p[P + "gating.bias"], self.ws,
+                out=out_last if (last and out_last is not None) else None)
             if saved is not None:
                 saved.append((x, t1, t2, prob))
             x = x_next
@@ -282,15 +271,11 @@ class DCN_V2Layer:
             else:
                 dx = dcross
                 xs, us = sv["xs"], sv["us"]
-                du = torch.empty_like(feat)
-                for i in reversed(range(self.cross_num)):
-                    wi = p[P + "cross_layers.%d.weight" % i]
-                    k.cross_bwd_prep(dx, feat, us[i], du, dx0_acc, accumulate=have_acc)
+                for i in reversed(range(self.cross_num)):       # one rec_crossnet_v2_layer_bwd per layer
+                    dx = k.crossnet_v2_layer_bwd(feat, xs[i], p[P + "cross_layers.%d.weight" % i], us[i], dx, dx0_acc,
+                                                 have_acc, i == 0, g[P + "cross_layers.%d.weight" % i],
+                                                 g[P + "cross_layers.%d.bias" % i], self.ws)
                     have_acc = True
-                    k.gemm(xs[i], du, self.ws, trans_a=True, out=g[P + "cross_layers.%d.weight" % i],
-                           b_colsum=g[P + "cross_layers.%d.bias" % i])
-                    dx = k.gemm(du, wi, self.ws, trans_b=True, epilogue="add", aux1=dx,
-                                aux0=dx0_acc if i == 0 else None)
             dfeat = dx                                           # d loss / d feat_embeddings  [B,d]
             k.gemm(dense_inputs, dfeat[:, S * D:], self.ws, trans_a=True, out=g["dense_emb.weight"],
                    b_colsum=g["dense_emb.bias"])
@@ -312,53 +297,19 @@ class DCN_V2Layer:
         return loss, pred
 
     def _cross_mix_backward(self, dout, feat, saved, dx0_acc, have_acc):
-        """Backward of _cross_mix (oracle: oracle/dcn_v2_ref.py cross_mix_backward).  Returns d feat."""
+        """Backward of _cross_mix (oracle: oracle/dcn_v2_ref.py cross_mix_backward): one rec_crossnet_mix_layer_bwd
+        per layer; the gating Linear layers are shared by all cross layers (net.py:267-268), so their gradients are
+        written by the first layer processed and accumulated by the others.  Returns d feat."""
         p, g, k = self.dense.p, self.dense.g, self.k
-        E, r = self.num_experts, self.low_rank
-        B = feat.shape[0]
-        f32 = dict(dtype=torch.float32, device=self.device)
-        u = torch.empty_like(feat)
-        du = torch.empty_like(feat)
-        dp = torch.empty(B, E, **f32)
-        dc = torch.empty(B, r, **f32)
-        da = torch.empty(B, r, **f32)
-        dbias_e = torch.empty(self.d, **f32)
-        g[P + "gating.weight"].zero_()
-        g[P + "gating.bias"].zero_()
         dx = dout
         for i in reversed(range(self.cross_num)):
             xl, t1, t2, prob = saved[i]
-            U, V, Cm = p[P + "U_list.%d" % i], p[P + "V_list.%d" % i], p[P + "C_list.%d" % i]
-            gU, gV, gC = g[P + "U_list.%d" % i], g[P + "V_list.%d" % i], g[P + "C_list.%d" % i]
-            bias = p[P + "bias.%d" % i].view(-1)
-            gbias = g[P + "bias.%d" % i].view(-1)
-            dxl = torch.empty_like(feat)
-            first = True
-            for e in range(E):
-                t1e, t2e = t1[:, e * r:(e + 1) * r], t2[:, e * r:(e + 1) * r]
-                k.gemm(t2e, U[e], self.ws, trans_b=True, epilogue="bias", bias=bias, out=u)       # recompute u_e
-                k.moe_bwd_prep(dx, feat, u, prob[:, e], du, dx0_acc, have_acc, dp[:, e])
-                have_acc = True
-                k.colsum(du, self.ws, out=dbias_e)
-                if e == 0:
-                    gbias.copy_(dbias_e)
-                else:
-                    gbias.add_(dbias_e)
-                k.gemm(du, t2e, self.ws, trans_a=True, out=gU[e])                                  # dU_e = du^T t2
-                k.gemm(du, U[e], self.ws, epilogue="dtanh", aux0=t2e, out=dc)                      # dc = (du U)*(1-t2^2)
-                k.gemm(dc, t1e, self.ws, trans_a=True, out=gC[e])                                  # dC_e = dc^T t1
-                k.gemm(dc, Cm[e], self.ws, epilogue="dtanh", aux0=t1e, out=da)                     # da = (dc C)*(1-t1^2)
-                k.gemm(xl, da, self.ws, trans_a=True, out=gV[e])                                   # dV_e = x_l^T da
-                k.gemm(da, V[e], self.ws, trans_b=True, epilogue="add", aux1=dx if first else dxl, out=dxl)
-                first = False
-            dgate = k.softmax_rows_bwd(prob, dp)
-            # gating Linear layers are shared by all cross layers (net.py:267-268): accumulate
-            gw = k.gemm(xl, dgate, self.ws, trans_a=True)
-            g[P + "gating.weight"].add_(gw)
-            g[P + "gating.bias"].add_(k.colsum(dgate, self.ws))
-            k.gemm(dgate, p[P + "gating.weight"], self.ws, trans_b=True, epilogue="add", aux1=dxl, out=dxl,
-                   aux0=dx0_acc if i == 0 else None)
-            dx = dxl
+            dx = k.crossnet_mix_layer_bwd(
+                feat, xl, p[P + "U_list.%d" % i], p[P + "V_list.%d" % i], p[P + "C_list.%d" % i],
+                p[P + "bias.%d" % i].view(-1), p[P + "gating.weight"], t1, t2, prob, dx, dx0_acc, have_acc, i == 0,
+                g[P + "U_list.%d" % i], g[P + "V_list.%d" % i], g[P + "C_list.%d" % i], g[P + "bias.%d" % i].view(-1),
+                g[P + "gating.weight"], g[P + "gating.bias"], i != self.cross_num - 1, self.ws)
+            have_acc = True
         return dx
 
     def _scalar(self, name):

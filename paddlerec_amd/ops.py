@@ -890,6 +890,82 @@ def cross_bwd_prep(dX, X0, U, dU, dX0_acc, accumulate):
                                    _p(dX0_acc), lds[4], int(accumulate), _stream()), "rec_cross_bwd_prep")
 
 
+# ------------------------------------------------------------------ CrossNet layers (one C-ABI call per layer)
+def _ld(t, name):
+    return _chk_mat(t, name)
+
+
+def crossnet_v2_layer_fwd(x0, xl, W, bias, ws, out=None, u=None):
+    """x_{l+1} = x_l + x_0 * (x_l W + b) (dcn_v2/net.py:222-226) -> out; u (optional) receives x_l W + b."""
+    B, d = xl.shape
+    if out is None:
+        out = torch.empty(B, d, dtype=torch.float32, device=xl.device)
+    desc = _lib.CrossV2Desc(B, d, _ld(x0, "x0"), _ld(xl, "xl"), _ld(out, "out"), _ld(u, "u") if u is not None else d)
+    nb = C.c_size_t(0)
+    check(lib().rec_crossnet_v2_layer_workspace_bytes(C.byref(desc), C.byref(nb), None))
+    w = ws.get(nb.value)
+    check(lib().rec_crossnet_v2_layer_fwd(C.byref(desc), _p(x0), _p(xl), _p(W), _p(bias), _p(out), _p(u), _p(w),
+                                          C.c_size_t(w.numel()), _stream()), "rec_crossnet_v2_layer_fwd")
+    return out
+
+
+def crossnet_v2_layer_bwd(x0, xl, W, u, dxnext, dx0_acc, accumulate_dx0, fold_dx0, dW, db, ws, out=None):
+    """-> d x_l ([B,d]); dW, db written; dx0_acc (+)= dxnext * u."""
+    B, d = xl.shape
+    if out is None:
+        out = torch.empty(B, d, dtype=torch.float32, device=xl.device)
+    desc = _lib.CrossV2Desc(B, d, _ld(x0, "x0"), _ld(xl, "xl"), d, _ld(u, "u"))
+    nb = C.c_size_t(0)
+    check(lib().rec_crossnet_v2_layer_workspace_bytes(C.byref(desc), None, C.byref(nb)))
+    w = ws.get(nb.value)
+    check(lib().rec_crossnet_v2_layer_bwd(C.byref(desc), _p(x0), _p(xl), _p(W), _p(u), _p(dxnext), _ld(dxnext, "dxnext"),
+                                          _p(dx0_acc), _ld(dx0_acc, "dx0_acc"), int(accumulate_dx0), int(fold_dx0),
+                                          _p(out), _ld(out, "out"), _p(dW), _p(db), _p(w), C.c_size_t(w.numel()),
+                                          _stream()), "rec_crossnet_v2_layer_bwd")
+    return out
+
+
+def crossnet_mix_layer_fwd(x0, xl, U, V, Cm, bias, gate_w, gate_b, ws, out=None):
+    """One CrossNetMix layer (dcn_v2/net.py:278-320) -> (x_next, t1, t2, prob); t1 / t2 / prob are what the backward
+    needs."""
+    B, d = xl.shape
+    E, _, r = U.shape
+    dev = xl.device
+    if out is None:
+        out = torch.empty(B, d, dtype=torch.float32, device=dev)
+    t1 = torch.empty(B, E * r, dtype=torch.float32, device=dev)
+    t2 = torch.empty(B, E * r, dtype=torch.float32, device=dev)
+    prob = torch.empty(B, E, dtype=torch.float32, device=dev)
+    desc = _lib.CrossMixDesc(B, d, r, E, _ld(x0, "x0"), _ld(xl, "xl"), _ld(out, "out"))
+    nb = C.c_size_t(0)
+    check(lib().rec_crossnet_mix_layer_workspace_bytes(C.byref(desc), C.byref(nb), None))
+    w = ws.get(nb.value)
+    check(lib().rec_crossnet_mix_layer_fwd(C.byref(desc), _p(x0), _p(xl), _p(U), _p(V), _p(Cm), _p(bias), _p(gate_w),
+                                           _p(gate_b), _p(out), _p(t1), _p(t2), _p(prob), _p(w),
+                                           C.c_size_t(w.numel()), _stream()), "rec_crossnet_mix_layer_fwd")
+    return out, t1, t2, prob
+
+
+def crossnet_mix_layer_bwd(x0, xl, U, V, Cm, bias, gate_w, t1, t2, prob, dxnext, dx0_acc, accumulate_dx0, fold_dx0,
+                           gU, gV, gC, gbias, g_gate_w, g_gate_b, accumulate_gate, ws, out=None):
+    """-> d x_l; gU / gV / gC / gbias written, the shared gating gradients written or accumulated."""
+    B, d = xl.shape
+    E, _, r = U.shape
+    if out is None:
+        out = torch.empty(B, d, dtype=torch.float32, device=xl.device)
+    desc = _lib.CrossMixDesc(B, d, r, E, _ld(x0, "x0"), _ld(xl, "xl"), d)
+    nb = C.c_size_t(0)
+    check(lib().rec_crossnet_mix_layer_workspace_bytes(C.byref(desc), None, C.byref(nb)))
+    w = ws.get(nb.value)
+    check(lib().rec_crossnet_mix_layer_bwd(C.byref(desc), _p(x0), _p(xl), _p(U), _p(V), _p(Cm), _p(bias), _p(gate_w),
+                                           _p(t1), _p(t2), _p(prob), _p(dxnext), _ld(dxnext, "dxnext"), _p(dx0_acc),
+                                           _ld(dx0_acc, "dx0_acc"), int(accumulate_dx0), int(fold_dx0), _p(out),
+                                           _ld(out, "out"), _p(gU), _p(gV), _p(gC), _p(gbias), _p(g_gate_w),
+                                           _p(g_gate_b), int(accumulate_gate), _p(w), C.c_size_t(w.numel()),
+                                           _stream()), "rec_crossnet_mix_layer_bwd")
+    return out
+
+
 # ------------------------------------------------------------------ row-sharded tables
 class ShardRoute:
     """Result buffers of rec_shard_route (device)."""

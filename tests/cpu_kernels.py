@@ -586,3 +586,72 @@ def accuracy_count(pred, label, counts):
     counts[0] += int(ok)
     counts[1] += int(pred.numel())
     return counts
+
+
+# ------------------------------------------------------------------ CrossNet layers (rec_crossnet_*_layer_*)
+def crossnet_v2_layer_fwd(x0, xl, W, bias, ws, out=None, u=None):
+    return gemm(xl, W, ws, epilogue="cross", bias=bias, aux0=x0, aux1=xl, out2=u, out=out)
+
+
+def crossnet_v2_layer_bwd(x0, xl, W, u, dxnext, dx0_acc, accumulate_dx0, fold_dx0, dW, db, ws, out=None):
+    du = torch.empty(xl.shape, dtype=torch.float32)
+    cross_bwd_prep(dxnext, x0, u, du, dx0_acc, accumulate=accumulate_dx0)
+    gemm(xl, du, ws, trans_a=True, out=dW, b_colsum=db)
+    return gemm(du, W, ws, trans_b=True, epilogue="add", aux1=dxnext, aux0=dx0_acc if fold_dx0 else None, out=out)
+
+
+def crossnet_mix_layer_fwd(x0, xl, U, V, Cm, bias, gate_w, gate_b, ws, out=None):
+    B, d = xl.shape
+    E, _, r = U.shape
+    gate = gemm(xl, gate_w, ws, epilogue="bias", bias=gate_b)
+    prob = softmax_rows(gate)
+    t1 = torch.empty(B, E * r, dtype=torch.float32)
+    t2 = torch.empty(B, E * r, dtype=torch.float32)
+    x_next = out if out is not None else torch.empty(B, d, dtype=torch.float32)
+    for e in range(E):
+        gemm(xl, V[e], ws, epilogue="bias_tanh", out=t1[:, e * r:(e + 1) * r])
+        gemm(t1[:, e * r:(e + 1) * r], Cm[e], ws, trans_b=True, epilogue="bias_tanh", out=t2[:, e * r:(e + 1) * r])
+    for e in range(E):
+        gemm(t2[:, e * r:(e + 1) * r], U[e], ws, trans_b=True, epilogue="moe", bias=bias, aux0=x0,
+             aux1=xl if e == 0 else x_next, row_scale=prob[:, e], out=x_next)
+    return x_next, t1, t2, prob
+
+
+def crossnet_mix_layer_bwd(x0, xl, U, V, Cm, bias, gate_w, t1, t2, prob, dxnext, dx0_acc, accumulate_dx0, fold_dx0,
+                           gU, gV, gC, gbias, g_gate_w, g_gate_b, accumulate_gate, ws, out=None):
+    B, d = xl.shape
+    E, _, r = U.shape
+    u = torch.empty(B, d, dtype=torch.float32)
+    du = torch.empty(B, d, dtype=torch.float32)
+    dp = torch.empty(B, E, dtype=torch.float32)
+    dc = torch.empty(B, r, dtype=torch.float32)
+    da = torch.empty(B, r, dtype=torch.float32)
+    dxl = out if out is not None else torch.empty(B, d, dtype=torch.float32)
+    acc = accumulate_dx0
+    for e in range(E):
+        t1e, t2e = t1[:, e * r:(e + 1) * r], t2[:, e * r:(e + 1) * r]
+        gemm(t2e, U[e], ws, trans_b=True, epilogue="bias", bias=bias, out=u)
+        moe_bwd_prep(dxnext, x0, u, prob[:, e], du, dx0_acc, acc, dp[:, e])
+        acc = True
+        dbias_e = colsum(du, ws)
+        if e == 0:
+            gbias.copy_(dbias_e)
+        else:
+            gbias.add_(dbias_e)
+        gemm(du, t2e, ws, trans_a=True, out=gU[e])
+        gemm(du, U[e], ws, epilogue="dtanh", aux0=t2e, out=dc)
+        gemm(dc, t1e, ws, trans_a=True, out=gC[e])
+        gemm(dc, Cm[e], ws, epilogue="dtanh", aux0=t1e, out=da)
+        gemm(xl, da, ws, trans_a=True, out=gV[e])
+        gemm(da, V[e], ws, trans_b=True, epilogue="add", aux1=dxnext if e == 0 else dxl, out=dxl)
+    dgate = softmax_rows_bwd(prob, dp)
+    gw = gemm(xl, dgate, ws, trans_a=True)
+    gb = colsum(dgate, ws)
+    if accumulate_gate:
+        g_gate_w.add_(gw)
+        g_gate_b.add_(gb)
+    else:
+        g_gate_w.copy_(gw)
+        g_gate_b.copy_(gb)
+    gemm(dgate, gate_w, ws, trans_b=True, epilogue="add", aux1=dxl, out=dxl, aux0=dx0_acc if fold_dx0 else None)
+    return dxl
