@@ -9,6 +9,10 @@ Batches have the layout the kernels take: label [B,1] i64, ids [B,26] i64 (= con
 dense [B,13] f32.  drop_last=True as tools/utils/utils_single.py:104-110 builds the DataLoader.
 """
 import ctypes as C
+import mmap
+import os
+import queue
+import threading
 
 import numpy as np
 import torch
@@ -28,9 +32,19 @@ def _alloc(n, S, Dn, pinned):
     return label, ids, dense
 
 
+def _buf(data):
+    """(char pointer, length, keep-alive) of the text: a bytes object, or any buffer — the readers hand in an mmap of
+    the file, so the parser threads read the page cache directly and no copy of the text is made."""
+    if isinstance(data, bytes):
+        return data, len(data), data
+    arr = np.frombuffer(data, np.uint8)
+    return C.c_char_p(arr.ctypes.data), arr.size, arr
+
+
 def _count_lines(data, threads):
     n = C.c_int64(0)
-    check(lib().rec_count_lines(data, len(data), threads, C.byref(n)), "rec_count_lines")
+    ptr, ln, _keep = _buf(data)
+    check(lib().rec_count_lines(ptr, ln, threads, C.byref(n)), "rec_count_lines")
     return max(int(n.value), 1)
 
 
@@ -39,7 +53,8 @@ def parse_slot_text(data: bytes, n_sparse=26, n_dense=13, log1p_dense=False, thr
     cap = _count_lines(data, threads)
     label, ids, dense = _alloc(cap, n_sparse, n_dense, pinned)
     n = C.c_int64(0)
-    check(lib().rec_parse_slot_text(data, len(data), n_sparse, n_dense, int(log1p_dense), cap, threads,
+    ptr, ln, _keep = _buf(data)
+    check(lib().rec_parse_slot_text(ptr, ln, n_sparse, n_dense, int(log1p_dense), cap, threads,
                                     C.c_void_p(label.data_ptr()), C.c_void_p(ids.data_ptr()),
                                     C.c_void_p(dense.data_ptr()), C.byref(n)), "rec_parse_slot_text")
     return label[: n.value], ids[: n.value], dense[: n.value, :n_dense]
@@ -51,7 +66,8 @@ def parse_criteo_tsv(data: bytes, n_dense=13, n_sparse=26, hash_dim=HASH_DIM, th
     cmin = np.asarray(CONT_MIN[:n_dense], np.float32)
     cdiff = np.asarray(CONT_DIFF[:n_dense], np.float32)
     n = C.c_int64(0)
-    check(lib().rec_parse_criteo_tsv(data, len(data), n_dense, n_sparse, cmin.ctypes.data_as(C.c_void_p),
+    ptr, ln, _keep = _buf(data)
+    check(lib().rec_parse_criteo_tsv(ptr, ln, n_dense, n_sparse, cmin.ctypes.data_as(C.c_void_p),
                                      cdiff.ctypes.data_as(C.c_void_p), hash_dim, cap, threads,
                                      C.c_void_p(label.data_ptr()), C.c_void_p(ids.data_ptr()),
                                      C.c_void_p(dense.data_ptr()), C.byref(n)), "rec_parse_criteo_tsv")
@@ -110,12 +126,64 @@ class _FileBatches:
             self.file_list = mine
         self.batch_size, self.device, self.parse = batch_size, device, parse
 
+    def _load(self, path):
+        """One file -> host tensors.  The text is mmap'ed, not read(): the parser's threads walk the page cache
+        directly (a read() of the file alone was 51 ms per 277 MB, four times the 12 ms the parse takes)."""
+        with open(path, "rb") as f:
+            size = os.fstat(f.fileno()).st_size
+            if size == 0:
+                return self.parse(b"")
+            mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+            try:
+                return self.parse(mm)
+            finally:
+                mm.close()
+
+    def _files(self):
+        """Parsed files in order; the NEXT file is read and parsed by a background thread (the parser is a C call that
+        releases the GIL) while the caller trains on the current one."""
+        q = queue.Queue(maxsize=1)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                for path in self.file_list:
+                    item = self._load(path)
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            pass
+                    if stop.is_set():
+                        return
+                item = None
+            except BaseException as e:           # surfaces in the consumer
+                item = e
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    break
+                except queue.Full:
+                    pass
+
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+
     def __iter__(self):
         B = self.batch_size
         carry = None
-        for path in self.file_list:
-            with open(path, "rb") as f:
-                label, ids, dense = self.parse(f.read())
+        for label, ids, dense in self._files():
             if carry is not None:
                 label, ids, dense = (torch.cat([c, x]) for c, x in zip(carry, (label, ids, dense)))
             n = label.shape[0]
