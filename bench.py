@@ -305,12 +305,15 @@ def main():
     loss_v = float(loss.item())
     oob = int(model.status.item())
 
+    def med(v):         # median over the bracketed steps: the first of them can carry a one-off host stall of tens of ms
+        v = sorted(v)   # (event pools / allocator growth when the brackets switch on) that lands in whichever region
+        return v[len(v) // 2] if v else 0.0   # it happens to hit and would dominate a mean over ten steps
+
     def avg_ms(name):
-        ev = model.timers.get(name, [])
-        return sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        return med([a.elapsed_time(b) for a, b in model.timers.get(name, [])])
 
     k_ms = {k: avg_ms(k) for k in model.timers if not k.endswith("@host")}
-    host_ms = {k[:-5]: 1e3 * sum(v) / max(len(v), 1) for k, v in model.timers.items() if k.endswith("@host")}
+    host_ms = {k[:-5]: 1e3 * med(v) for k, v in model.timers.items() if k.endswith("@host")}
     host_ms["step_issue_total"] = 1e3 * host_issue / args.steps     # host time inside train_step (no device sync)
     # The roofline kernels once more, the way rocprofv3's kernel trace sees them: back-to-back launches between
     # one pair of HIP events (no event markers / stream joins between the launches), on the step's own buffers.
