@@ -76,3 +76,33 @@ def test_train_steps_vs_oracle():
             p[k] = (p[k] - lr * np.asarray(grads[k]).reshape(p[k].shape)).astype(np.float32)
     for k, v in m.state_dict().items():
         np.testing.assert_allclose(N_(v), p[k], rtol=2e-4, atol=3e-6, err_msg=k)
+
+
+def test_train_step_graphed_on_the_cpu_backend_is_the_eager_step():
+    """paddlerec_amd/graph.py host logic: with host tensors (the operator stand-in) StepGraph runs the step eagerly on
+    one shared buffer set; the step counter and the piecewise learning rate advance per call either way."""
+    g, p, m, feeds = _golden_model()
+    _, _, m2, _ = _golden_model()
+    for _ in range(3):
+        la, _ = m.train_step(*feeds, base_lr=0.85)
+        lb, _ = m2.train_step_graphed(*feeds, base_lr=0.85)
+        assert torch.equal(la, lb)
+    assert m.step_count == m2.step_count == 3
+    assert (m2._graph.eager, m2._graph.captures, m2._graph.replays) == (3, 0, 0)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    assert m.learning_rate(409999, 0.85) == 0.85 and m.learning_rate(410000, 0.85) == 0.2
+
+
+def test_step_graph_signature_and_eviction_logic():
+    """StepGraph bookkeeping without a GPU: signatures are (shape, dtype, stride) per tensor + the keyword constants."""
+    from paddlerec_amd.graph import StepGraph
+    a, b = torch.zeros(3, 4), torch.zeros(3, 5)
+    s1 = StepGraph._signature((a, b), {"lr": 0.1})
+    assert s1 == StepGraph._signature((torch.ones(3, 4), torch.ones(3, 5)), {"lr": 0.1})
+    assert s1 != StepGraph._signature((a, b), {"lr": 0.2})
+    assert s1 != StepGraph._signature((a.t().contiguous().t(), b), {"lr": 0.1})        # same shape, other strides
+    calls = []
+    sg = StepGraph(lambda st, x, lr: calls.append((st, lr)) or x + lr, state_factory=lambda: "bufs")
+    out = sg(a, lr=1.0)
+    assert torch.equal(out, a + 1.0) and calls == [("bufs", 1.0)] and sg.eager == 1
