@@ -613,7 +613,10 @@ static GemmPlan plan_gemm(const rec_gemm_desc* d, int num_cus = kNumCU) {
   if (splits <= 0) {  // auto: split K when the output alone cannot fill the chip
     splits = 1;
     const int64_t capacity = (int64_t)num_cus * f.occ;
-    if (p.tiles_total * 2 <= capacity) {
+    // a GEMM this small runs for a few microseconds split or not, and a split adds a reduce LAUNCH (4-5 us on the
+    // GPU, ~10 us of host time in a launch-bound step: the reference's own batch size of 512 splits every MLP GEMM)
+    const bool tiny = (double)d->m * d->n * d->k < 1.5e8;
+    if (p.tiles_total * 2 <= capacity && !tiny) {
       // as many splits as still fit in ONE resident round (one block more would double the time)
       int64_t want = capacity / p.tiles_total;
       if (want > nkt / 8) want = nkt / 8;   // keep >= 8 K-tiles (128 k) per split
