@@ -207,6 +207,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # diagnostics on a one-GPU box: REC_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and REC_BENCH_BACKEND=gloo swaps the
+    # transport (RCCL refuses two ranks on one device) — the N > 1 code path of this file with the real kernels; the
+    # numbers of such a run mean nothing
+    if os.environ.get("REC_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("REC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -219,7 +225,10 @@ def main():
         # this program's stdout stays the ONE JSON line of the contract
         quiet = _QuietStdout()
         quiet.__enter__()
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from paddlerec_amd import _lib
     _lib.lib()                                   # fail loudly if the HIP library is not built
