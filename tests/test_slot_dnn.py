@@ -397,3 +397,104 @@ def test_sparse_adam_record_equals_two_row_passes(engine_lib):
     ops.sparse_adam_record(groups, tg, tdz, S, b_rec, b_mv, D, 3, 1e-3, partials=pp, partials1=pp1)
     assert torch.equal(a_rec, b_rec) and torch.equal(a_mv, b_mv)
     assert not torch.equal(b_rec, T(rec0))
+
+
+@pytest.mark.gpu
+def test_ps_pull_group_push_full_size_properties(engine_lib):
+    """configs[4]'s model shape at full size (B 65536 x 408 slots x D 9, ~40 M values, lazily born accessor table):
+    pull (one-launch pool on unborn rows) -> grouping with the segment payload -> lane-per-row accessor push, checked
+    against torch on the same device: show / click counters bit-exact per row (bincount), merged gradients and the
+    AdaGrad step of every touched row (index_add), rows born with exactly the values the pull showed, untouched rows
+    still zero memory."""
+    from paddlerec_amd import ops
+    B, S, D, N = 65536, 408, 9, 3_000_017
+    g = torch.Generator(device=DEV).manual_seed(11)
+    lens = torch.randint(1, 3, (S, B), device=DEV, generator=g)                    # 1-2 ids per (slot, sample)
+    lod = torch.zeros(S, B + 1, dtype=torch.int64, device=DEV)
+    lod[:, 1:] = torch.cumsum(lens, dim=1)
+    base = torch.zeros(S + 1, dtype=torch.int64, device=DEV)
+    base[1:] = torch.cumsum(lod[:, -1], 0)
+    nnz = int(base[-1].item())
+    values = torch.randint(1, N, (nnz,), device=DEV, generator=g, dtype=torch.int64)
+    values[torch.rand(nnz, device=DEV, generator=g) < 0.3] = 0
+    table = ops.PsTable(N, D, DEV, kind="slot", embedx_threshold=0.0, initial_range=1e-2)
+    mbatch = ops.MultislotBatch(values, lod, base)
+    status = ops.new_status(DEV)
+    out, counts, seg, rows, _ = ops.multislot_sumpool(mbatch, table.W, N, 0, 0, status, lazy_init=table.lazy_init)
+    # creation values of every row, as a pull shows them: N samples x 1 slot, one id each, on an untouched table
+    fresh = ops.PsTable(N, D, DEV, kind="slot", embedx_threshold=0.0, initial_range=1e-2)
+    allrows = torch.arange(N, device=DEV)
+    one = ops.MultislotBatch(allrows, torch.arange(N + 1, device=DEV).view(1, -1).contiguous(),
+                             torch.tensor([0, N], device=DEV))
+    init, _, _, _, _ = ops.multislot_sumpool(one, fresh.W, N, None, 0, status, lazy_init=fresh.lazy_init,
+                                             want_backward=False, want_counts=False)
+    assert float(init.abs().max().item()) <= 1e-2 and float(init[1:].abs().min().item()) >= 0.0
+    live = values != 0
+    r, sg = values[live], seg[:nnz][live].long()
+    # the pooled output IS the sum of creation values of the live ids of a cell
+    ref_out = torch.zeros(B * S, D, device=DEV)
+    ref_out.index_add_(0, sg, init[r])
+    torch.testing.assert_close(out.view(B * S, D), ref_out, rtol=1e-5, atol=1e-7)
+    groups = ops.IdGroups(nnz, DEV)
+    ops.ids_group(rows[:nnz], N, 0, ops.Workspace(DEV), None, status, groups, payload=seg[:nnz])
+    dx = torch.randn(B, S * D, device=DEV, generator=g) * 1e-3
+    label = torch.randint(0, 2, (B,), device=DEV, generator=g)
+    ops.ps_push_rows(table, groups, dx, S, click=label)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    rec = table.rec
+    L = table.layout
+    show = torch.bincount(r, minlength=N)
+    click = torch.bincount(r, weights=label[sg // S].double(), minlength=N)
+    assert torch.equal(rec[:, L.stat_off].long(), show)
+    assert torch.equal(rec[:, L.stat_off + 1].double(), click)
+    touched = show > 0
+    assert torch.equal(rec[:, L.stat_off + 4], torch.where(touched, 2.0, 0.0).float())      # born with embedx / unborn
+    assert bool((rec[~touched] == 0).all())                                                 # still zero memory
+    gsum = torch.zeros(N, D, device=DEV, dtype=torch.float64)
+    gsum.index_add_(0, r, dx.view(B * S, D)[sg].double())
+    a = table.accessor
+    want = (init.double() - a.lr * gsum).clamp(a.min_bound, a.max_bound)                     # g2sum = 0: scale 1
+    torch.testing.assert_close(rec[touched][:, :D].double(), want[touched], rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(rec[touched][:, L.stat_off + 2].double(), (gsum[touched][:, 0] ** 2), rtol=1e-4,
+                               atol=1e-12)
+    torch.testing.assert_close(rec[touched][:, L.stat_off + 3].double(), (gsum[touched][:, 1:] ** 2).mean(1),
+                               rtol=1e-4, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_narrow_row_adam_full_size_against_torch(engine_lib):
+    """The lane-per-row lazy Adam (rows of 9 floats in 16-float records, moments in a second record) on ~20 M lookups of
+    2 M rows with the segment payload: step 3 of Adam on every touched row against torch on the merged (index_add)
+    gradients; untouched rows bit-identical."""
+    from paddlerec_amd import ops
+    n, N, D, C_ = 20_000_000, 2_000_003, 9, 5_000_000
+    g = torch.Generator(device=DEV).manual_seed(12)
+    ids = torch.randint(0, N, (n,), device=DEV, generator=g, dtype=torch.int64)             # 0 = padding
+    cell = torch.randint(0, C_, (n,), device=DEV, generator=g, dtype=torch.int32)           # the payload: gradient row
+    grad = torch.randn(C_, D, device=DEV, generator=g) * 1e-2
+    rec = torch.randn(N, 16, device=DEV, generator=g) * 0.1
+    mv = torch.rand(N, 32, device=DEV, generator=g) * 1e-3
+    P, M, V = rec[:, :D], mv[:, :D], mv[:, 12:12 + D]
+    P0, M0, V0 = P.clone(), M.clone(), V.clone()
+    status = ops.new_status(DEV)
+    groups = ops.IdGroups(n, DEV)
+    ops.ids_group(ids, N, 0, ops.Workspace(DEV), None, status, groups, payload=cell)
+    pp = ops.segment_partials(groups, grad, D)
+    ops.sparse_adam_rows(groups, grad, 1, P, M, V, 3, lr=1e-3, partials=pp)
+    torch.cuda.synchronize()
+    live = ids != 0
+    gs = torch.zeros(N, D, device=DEV, dtype=torch.float64)
+    gs.index_add_(0, ids[live], grad[cell[live].long()].double())
+    touched = torch.bincount(ids[live], minlength=N) > 0
+    b1, b2, eps, t = 0.9, 0.999, 1e-8, 3
+    m1 = b1 * M0.double() + (1 - b1) * gs
+    v1 = b2 * V0.double() + (1 - b2) * gs * gs
+    lr_t = 1e-3 * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
+    p1 = P0.double() - lr_t * m1 / (v1.sqrt() + eps * (1 - b2 ** t) ** 0.5)
+    # 1e-5 of each tensor's scale (an element of m that cancels to ~0 has no relative accuracy to speak of)
+    for got, want_ in ((M, m1), (V, v1), (P, p1)):
+        torch.testing.assert_close(got[touched].double(), want_[touched], rtol=1e-5,
+                                   atol=1e-5 * float(want_[touched].abs().max().item()))
+    assert torch.equal(P[~touched], P0[~touched]) and torch.equal(M[~touched], M0[~touched])
+    assert torch.equal(rec[:, D:], rec[:, D:]) and int(status.item()) == 0
