@@ -730,6 +730,12 @@ int rec_xxh32_hash_mod(const char* const* strings, const int32_t* field_idx, int
  *   field_idx = 14..39 (the column index, as the reference hashes it).
  * threads <= 0: one per host core (capped at 64).  *n_lines = lines parsed (<= max_lines). */
 int rec_count_lines(const char* buf, size_t len, int32_t threads, int64_t* n_lines); /* to size the outputs */
+/* Indices (ascending) of the lines made of blanks only — the parsers above count them as lines; a loader that cuts
+ * batches from a whole-file parse skips them like the reference's `for line in f` readers do.  *n_blank = how many
+ * there are (may exceed max_out: only the first max_out are written). */
+int rec_blank_lines(const char* buf, size_t len, int32_t threads, int64_t max_out, int64_t* idx, int64_t* n_blank);
+/* Occurrences of one byte value, multi-threaded (the ':' count bounds the values of rec_parse_feasign_slots). */
+int rec_count_byte(const char* buf, size_t len, int32_t byte, int32_t threads, int64_t* n);
 int rec_parse_slot_text(const char* buf, size_t len, int32_t n_sparse, int32_t n_dense,
                         int32_t log1p_dense, int64_t max_lines, int32_t threads, int64_t* label,
                         int64_t* ids, float* dense, int64_t* n_lines);

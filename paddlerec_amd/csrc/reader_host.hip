@@ -150,6 +150,65 @@ extern "C" int rec_count_lines(const char* buf, size_t len, int32_t threads, int
   return REC_OK;
 }
 
+// occurrences of one byte value (the ':' of every `feasign:slot` token bounds the value count of a multi-value parse)
+extern "C" int rec_count_byte(const char* buf, size_t len, int32_t byte, int32_t threads, int64_t* n) {
+  REC_REQUIRE(n && (len == 0 || buf) && byte >= 0 && byte < 256, REC_EINVAL, "bad arguments");
+  const int T = host_threads(threads);
+  std::vector<int64_t> cnt((size_t)T, 0);
+  const size_t per = (len + (size_t)T - 1) / (size_t)T;
+  run_threads(T, [&](int t) {
+    const size_t a = (size_t)t * per, z = a + per < len ? a + per : len;
+    int64_t c = 0;
+    const char* p = a < len ? buf + a : nullptr;
+    const char* e = buf + z;
+    while (p && p < e) {
+      p = (const char*)memchr(p, byte, (size_t)(e - p));
+      if (!p) break;
+      ++c;
+      ++p;
+    }
+    cnt[(size_t)t] = c;
+  });
+  int64_t tot = 0;
+  for (int64_t c : cnt) tot += c;
+  *n = tot;
+  return REC_OK;
+}
+
+// indices (ascending) of the lines that hold nothing but blanks: the reference's readers iterate `for line in f` and
+// the loaders built on the whole-file parsers skip such lines instead of treating them as samples
+extern "C" int rec_blank_lines(const char* buf, size_t len, int32_t threads, int64_t max_out, int64_t* idx,
+                               int64_t* n_blank) {
+  REC_REQUIRE(n_blank && max_out >= 0 && (len == 0 || buf) && (max_out == 0 || idx), REC_EINVAL, "bad arguments");
+  const int T = host_threads(threads);
+  std::vector<std::vector<int64_t>> found((size_t)T + 1);
+  const Chunks c = make_chunks(buf, len, T);
+  const int nt = (int)c.begin.size() - 1;
+  run_threads(nt, [&](int t) {
+    int64_t i = c.first_line[t];
+    const char* p = c.begin[t];
+    const char* e = c.begin[t + 1];
+    while (p < e) {
+      const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+      const char* le = nl ? nl : e;
+      bool blank = true;
+      for (const char* q = p; q < le; ++q)
+        if (*q != ' ' && *q != '\t' && *q != '\r') { blank = false; break; }
+      if (blank) found[(size_t)t].push_back(i);
+      ++i;
+      p = nl ? nl + 1 : e;
+    }
+  });
+  int64_t n = 0;
+  for (int t = 0; t < nt; ++t)
+    for (int64_t v : found[(size_t)t]) {
+      if (n < max_out) idx[n] = v;
+      ++n;
+    }
+  *n_blank = n;
+  return REC_OK;
+}
+
 extern "C" int rec_parse_slot_text(const char* buf, size_t len, int32_t n_sparse, int32_t n_dense,
                                    int32_t log1p_dense, int64_t max_lines, int32_t threads,
                                    int64_t* label, int64_t* ids, float* dense, int64_t* n_lines) {

@@ -48,6 +48,18 @@ def _count_lines(data, threads):
     return max(int(n.value), 1)
 
 
+def blank_lines(data, threads=0):
+    """Indices of the whitespace-only lines of the text (sorted numpy int64 array; usually empty)."""
+    ptr, ln, _keep = _buf(data)
+    n = C.c_int64(0)
+    check(lib().rec_blank_lines(ptr, ln, threads, 0, None, C.byref(n)), "rec_blank_lines")
+    out = np.empty(max(int(n.value), 1), np.int64)
+    if n.value:
+        check(lib().rec_blank_lines(ptr, ln, threads, int(n.value), out.ctypes.data_as(C.c_void_p), C.byref(n)),
+              "rec_blank_lines")
+    return out[: int(n.value)]
+
+
 def parse_slot_text(data: bytes, n_sparse=26, n_dense=13, log1p_dense=False, threads=0, pinned=False):
     """-> (label [n] i64, ids [n,S] i64, dense [n,Dn] f32) host tensors."""
     cap = _count_lines(data, threads)
@@ -79,12 +91,15 @@ def parse_feasign_slots(data: bytes, first_slot=1, num_slots=301, hash_rows=0, t
     (values [total] i64, lod [num_slots, n+1] i64, slot_base [num_slots+1] i64, n lines) — slot s of line b is
     values[slot_base[s] + lod[s,b] : slot_base[s] + lod[s,b+1]]; with hash_rows > 0 the values are table rows."""
     cap = _count_lines(data, threads)
-    bound = data.count(b":") + cap * num_slots          # every token + one padding id per (line, slot)
+    ptr, ln, _keep = _buf(data)
+    nc = C.c_int64(0)
+    check(lib().rec_count_byte(ptr, ln, ord(":"), threads, C.byref(nc)), "rec_count_byte")
+    bound = int(nc.value) + cap * num_slots             # every token + one padding id per (line, slot)
     values = torch.empty(max(bound, 1), dtype=torch.int64)
     lod = torch.zeros(num_slots, cap + 1, dtype=torch.int64)
     base = torch.zeros(num_slots + 1, dtype=torch.int64)
     n, nv = C.c_int64(0), C.c_int64(0)
-    check(lib().rec_parse_feasign_slots(data, len(data), int(first_slot), int(num_slots), int(hash_rows), cap,
+    check(lib().rec_parse_feasign_slots(ptr, ln, int(first_slot), int(num_slots), int(hash_rows), cap,
                                         values.numel(), threads, C.c_void_p(values.data_ptr()),
                                         C.c_void_p(lod.data_ptr()), C.c_void_p(base.data_ptr()), C.byref(n),
                                         C.byref(nv)), "rec_parse_feasign_slots")

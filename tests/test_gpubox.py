@@ -139,3 +139,36 @@ def test_reference_online_yaml_and_data_run_unchanged(tmp_path):
     assert len(res["loss"]) == 2 and all(np.isfinite(x) for x in res["loss"]) and all(0 <= a <= 1 for a in res["auc"])
     assert main.net.slot_num == 300 and main.net.emb_dim == 9 and main.net.table.accessor.embedx_threshold == 10
     assert os.path.exists(tmp_path / "out" / "1" / "rec_gpubox.npz")
+
+
+def test_in_memory_reader_cuts_the_batches_a_per_batch_parse_gives(tmp_path):
+    """InMemoryReader.load_into_memory parses each file once (whole, mmap'ed) and cuts batches by index arithmetic:
+    every batch equals what rec_parse_feasign_slots gives for exactly those lines parsed on their own — across file
+    boundaries, with blank lines, an empty file, and batch sizes that do / do not divide the line count (drop_last)."""
+    import random
+    from paddlerec_amd import gpubox, reader as rd
+    lines = [ln for ln in open(os.path.join(GOLDEN, "slot_dnn_demo_4.txt"), "rb").read().split(b"\n") if ln.strip()]
+    random.seed(1)
+    pool = []
+    for k in range(11):                     # 11 lines with 50..420 feasigns each, labels alternating
+        feat = lines[k % 4].split(b" ")[1:]
+        random.shuffle(feat)
+        feat = sorted(feat[: 50 + 37 * k], key=lambda t: int(t.split(b":")[1]))
+        pool.append(b" ".join([b"%d:1" % (k % 2)] + feat))
+    files = []
+    for i, (a, z) in enumerate(((0, 3), (3, 4), (4, 9), (9, 11))):
+        p = tmp_path / ("part-%d" % i)
+        p.write_bytes(b"\n".join(pool[a:z]) + (b"\n \n\n" if i % 2 else b"\n"))      # blank lines after odd files
+        files.append(str(p))
+    (tmp_path / "empty").write_bytes(b"")
+    files.insert(2, str(tmp_path / "empty"))
+    assert rd.blank_lines(b"a:1\n\n \t\nb:2\n").tolist() == [1, 2]
+    for B in (1, 2, 3, 4, 5, 11, 12):
+        r = gpubox.InMemoryReader(files, B, 300)
+        assert r.load_into_memory() == 11 // B
+        for i, (values, lod, base, label) in enumerate(r.batches):
+            data = b"\n".join(pool[i * B:(i + 1) * B]) + b"\n"
+            v2, l2, b2, n = rd.parse_feasign_slots(data, 2, 300, 0, 0)
+            lv, llod, _, _ = rd.parse_feasign_slots(data, 1, 1, 0, 0)
+            assert torch.equal(values, v2) and torch.equal(lod, l2) and torch.equal(base, b2), (B, i)
+            assert torch.equal(label, lv[llod[0, :-1]].reshape(n, 1).clamp_(0, 1)), (B, i)
