@@ -359,6 +359,18 @@ int rec_sgd_dense(int64_t n, float* p, const float* g, float lr, void* stream);
 int rec_sparse_sgd_small(int64_t n, int32_t emb_dim, int32_t row_stride, int64_t num_rows, int64_t padding_idx,
                          const int64_t* ids, const float* grad, const rec_grad_layout* grad_layout, float* P,
                          float lr, int32_t* status, void* stream);
+/* The same one-launch merge with the lazy Adam update of BOTH embeddings of a DeepFM record (the arithmetic of
+ * rec_sparse_adam_record: W, m, v and W1, m1, v1 of a touched row in one pass) — the reference's bigdata batch size
+ * (deepfm/config_bigdata.yaml: 512 x 26 slots = 13312 lookups) replaces grouping sort + two partial passes + record
+ * update, 12 launches, by one.  ids [n] (n = B * num_slots, row = id + slot_offset[pos % num_slots] when
+ * slot_offset is given); grad: one emb_dim-wide row per position (grad_layout as rec_sparse_adam_record), grad1:
+ * the first-order gradient source with its layout (dz with {div = num_slots}). */
+int rec_sparse_adam_record_small(int64_t n, int32_t num_slots, int32_t emb_dim, int32_t rec_stride,
+                                 int32_t state_stride, int32_t v_offset, int64_t num_rows, int64_t padding_idx,
+                                 const int64_t* ids, const int64_t* slot_offset, const float* grad,
+                                 const rec_grad_layout* grad_layout, const float* grad1,
+                                 const rec_grad_layout* grad1_layout, const float* grad_scale, float* rec, float* MV,
+                                 const rec_adam_hyper* hyper, int32_t* status, void* stream);
 
 /* lazy_mode=False Adam on a SelectedRows gradient — the dygraph default (deepfm/dygraph_model.py:61-65,
  * SURVEY.md App. B-3): every one of the num_rows rows is updated, rows absent from the merged gradient with

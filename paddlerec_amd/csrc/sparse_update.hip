@@ -15,6 +15,7 @@
 
 #include "radix_sort.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #include "rec_common.h"
 
@@ -647,11 +648,29 @@ constexpr int kSmallMergeMax = 15360;   // ids + per-wave lists stay inside the 
 constexpr int kSmallWaves = 16;        // lookups per block; the block stages the whole id list in LDS once (4 B per id)
 constexpr int kSmallList = 32;         // occurrences of a row collected before their gradient rows are fetched together
 
-template <int NACC>   // floats per lane: D <= 64 * NACC
-__global__ __launch_bounds__(kSmallWaves* kWave) void sparse_sgd_small_kernel(
-    int n, int D, int stride, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
-    const float* __restrict__ grad, rec_grad_layout gl, float* __restrict__ P, float lr,
+// What the wave of a row's first occurrence does with the merged gradient: SGD on the row, or lazy Adam on BOTH
+// embeddings of a DeepFM record (W, m, v and W1, m1, v1 — the record kernel's arithmetic, adam_elem).
+struct SmallSgd {
+  float* P;
+  int stride;
+  float lr;
+};
+struct SmallAdamRecord {
+  float* rec;      // [N, stride]  = W(D) | W1 | m1 | v1 | pad
+  float* MV;       // [N, sstride] = m(D) at 0, v(D) at v_off
+  int stride, sstride, v_off;
+  const float* grad1;          // first-order gradient source (dz), layout gl1
+  rec_grad_layout gl1;
+  const float* grad_scale;     // device scalar or null
+  float lr_t, eps_t, b1, b2;
+};
+
+template <int NACC, class Update>   // floats per lane: D <= 64 * NACC
+__global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_kernel(
+    int n, int D, int S, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
+    const int64_t* __restrict__ slot_off, const float* __restrict__ grad, rec_grad_layout gl, Update up,
     int32_t* __restrict__ status) {
+  constexpr bool kRecord = std::is_same<Update, SmallAdamRecord>::value;
   constexpr int FLY = kSmallList / NACC;   // gradient rows in flight per wave (32 / 16 / 8 rows of 64 / 128 / 256 floats)
   extern __shared__ int small_lds[];
   int* wlists = small_lds;                               // [waves][kSmallList] positions of collected occurrences
@@ -660,9 +679,10 @@ __global__ __launch_bounds__(kSmallWaves* kWave) void sparse_sgd_small_kernel(
   for (int i = threadIdx.x; i < n; i += kSmallWaves * kWave) {
     const int64_t id = ids[i];
     const bool isp = pad >= 0 && id == pad;
-    const bool inr = id >= 0 && id < N;
+    const int64_t r = slot_off ? id + slot_off[i % S] : id;     // 26 tables as one: row = id + slot offset
+    const bool inr = r >= 0 && r < N;
     oob |= (!isp && !inr) ? 1 : 0;
-    small_ids[i] = (!isp && inr) ? (int)id : -1;
+    small_ids[i] = (!isp && inr) ? (int)r : -1;
   }
   if (oob) atomicOr(status, REC_FLAG_INDEX_OOB);
   __syncthreads();
@@ -688,17 +708,19 @@ __global__ __launch_bounds__(kSmallWaves* kWave) void sparse_sgd_small_kernel(
   float acc[NACC];
 #pragma unroll
   for (int a = 0; a < NACC; ++a) acc[a] = 0.f;
+  float acc1 = 0.f;                                      // first-order gradient of the row (record update)
   int cnt = 0;
   const bool plain = gl.group == 1 && gl.div == 1 && gl.index == nullptr;
   auto flush = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float x[FLY][NACC];
+    float x[FLY][NACC], x1[FLY];
 #pragma unroll
     for (int u = 0; u < FLY; ++u) {
 #pragma unroll
       for (int a = 0; a < NACC; ++a) x[u][a] = 0.f;
+      x1[u] = 0.f;
       if (u < cnt) {                                   // wave-uniform: unused slots cost nothing
         const int q = wl[u];
         // (one gradient row per position at a fixed pitch is the common layout: no integer division)
@@ -708,35 +730,72 @@ __global__ __launch_bounds__(kSmallWaves* kWave) void sparse_sgd_small_kernel(
           const int d = lane + a * kWave;
           if (d < D) x[u][a] = g[d];
         }
+        if constexpr (kRecord) x1[u] = up.grad1[grad_offset(up.gl1, q, 1)];
       }
     }
 #pragma unroll
-    for (int u = 0; u < FLY; ++u)
+    for (int u = 0; u < FLY; ++u) {
 #pragma unroll
       for (int a = 0; a < NACC; ++a) acc[a] += x[u][a];
+      acc1 += x1[u];
+    }
     cnt = 0;
     __builtin_amdgcn_wave_barrier();     // the list is rewritten only after every lane has read it
   };
-  for (int c = pos / kWave; c * kWave < n; ++c) {
-    const int j = c * kWave + lane;
-    bool mine = j >= pos && j < n && small_ids[j] == my;
-    unsigned long long m = __ballot(mine);
-    while (m) {
-      const int rank = __popcll(m & ((1ull << lane) - 1ull));
-      const int take = min((int)__popcll(m), FLY - cnt);
-      if (mine && rank < take) wl[cnt + rank] = j;
-      cnt += take;
-      mine = mine && rank >= take;
-      m = __ballot(mine);
-      if (cnt == FLY) flush();
+  // (four chunks per trip, like the search above: most rows have no second occurrence, and a trip without a match
+  // is four LDS reads in flight, one ballot)
+  for (int c0 = (pos / kWave) * kWave; c0 < n; c0 += 4 * kWave) {
+    bool mk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = c0 + u * kWave + lane;
+      mk[u] = j >= pos && j < n && small_ids[j] == my;
+    }
+    if (__ballot(mk[0] || mk[1] || mk[2] || mk[3]) == 0) continue;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = c0 + u * kWave + lane;
+      bool mine = mk[u];
+      unsigned long long m = __ballot(mine);
+      while (m) {
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        const int take = min((int)__popcll(m), FLY - cnt);
+        if (mine && rank < take) wl[cnt + rank] = j;
+        cnt += take;
+        mine = mine && rank >= take;
+        m = __ballot(mine);
+        if (cnt == FLY) flush();
+      }
     }
   }
   if (cnt > 0) flush();
-  float* p = P + (int64_t)my * stride;
+  if constexpr (!kRecord) {
+    float* p = up.P + (int64_t)my * up.stride;
 #pragma unroll
-  for (int a = 0; a < NACC; ++a) {
-    const int d = lane + a * kWave;
-    if (d < D) p[d] -= lr * acc[a];
+    for (int a = 0; a < NACC; ++a) {
+      const int d = lane + a * kWave;
+      if (d < D) p[d] -= up.lr * acc[a];
+    }
+  } else {
+    float* r = up.rec + (int64_t)my * up.stride;
+    float* mv = up.MV + (int64_t)my * up.sstride;
+    const float sc = up.grad_scale ? up.grad_scale[0] : 1.f;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      const int d = lane + a * kWave;
+      if (d < D) {
+        float p = r[d], m_ = mv[d], v_ = mv[up.v_off + d];
+        const float g = up.grad_scale ? scale_grad(acc[a], sc) : acc[a];
+        adam_elem(p, m_, v_, g, up.lr_t, up.eps_t, up.b1, up.b2);
+        r[d] = p; mv[d] = m_; mv[up.v_off + d] = v_;
+      }
+    }
+    if (lane == 0) {   // first-order weight + its moments: rec[D], rec[D+1], rec[D+2]
+      float p1 = r[D], m1 = r[D + 1], v1 = r[D + 2];
+      const float g = up.grad_scale ? scale_grad(acc1, sc) : acc1;
+      adam_elem(p1, m1, v1, g, up.lr_t, up.eps_t, up.b1, up.b2);
+      r[D] = p1; r[D + 1] = m1; r[D + 2] = v1;
+    }
   }
 }
 
@@ -1203,12 +1262,53 @@ extern "C" int rec_sparse_sgd_small(int64_t n, int32_t emb_dim, int32_t row_stri
   const unsigned grid = (unsigned)((n + kSmallWaves - 1) / kSmallWaves);
   const size_t shmem = ((size_t)n + kSmallWaves * kSmallList) * sizeof(int);       // <= 66 KB
   hipStream_t st = (hipStream_t)stream;
-#define REC_SMALL(NACC_)                                                                                       \
-  hipLaunchKernelGGL((sparse_sgd_small_kernel<NACC_>), dim3(grid), dim3(kSmallWaves * kWave), shmem, st, (int)n, \
-                     emb_dim, row_stride, num_rows, padding_idx, ids, grad, gl, P, lr, status)
+  const SmallSgd up{P, row_stride, lr};
+#define REC_SMALL(NACC_)                                                                                        \
+  hipLaunchKernelGGL((sparse_small_kernel<NACC_, SmallSgd>), dim3(grid), dim3(kSmallWaves * kWave), shmem, st,   \
+                     (int)n, emb_dim, 1, num_rows, padding_idx, ids, (const int64_t*)nullptr, grad, gl, up, status)
   if (emb_dim <= kWave) REC_SMALL(1); else if (emb_dim <= 2 * kWave) REC_SMALL(2); else REC_SMALL(4);
 #undef REC_SMALL
   return check_launch("rec_sparse_sgd_small");
+}
+
+extern "C" int rec_sparse_adam_record_small(int64_t n, int32_t num_slots, int32_t emb_dim, int32_t rec_stride,
+                                            int32_t state_stride, int32_t v_offset, int64_t num_rows,
+                                            int64_t padding_idx, const int64_t* ids, const int64_t* slot_offset,
+                                            const float* grad, const rec_grad_layout* grad_layout,
+                                            const float* grad1, const rec_grad_layout* grad1_layout,
+                                            const float* grad_scale, float* rec, float* MV,
+                                            const rec_adam_hyper* hyper, int32_t* status, void* stream) {
+  rec_grad_layout gl = {1, 0, 0, nullptr, nullptr}, gl1 = {1, 0, 0, nullptr, nullptr};
+  if (grad_layout) gl = *grad_layout;
+  if (grad1_layout) gl1 = *grad1_layout;
+  gl.partials = gl1.partials = nullptr;
+  REC_REQUIRE(n >= 0 && num_slots > 0 && emb_dim > 0 && rec_stride >= emb_dim + 3 && num_rows > 0 && gl.div >= 1 &&
+                  gl1.div >= 1, REC_EINVAL, "bad sizes (the record holds W(D) | W1 | m1 | v1)");
+  REC_REQUIRE(v_offset >= emb_dim && state_stride >= v_offset + emb_dim, REC_EINVAL,
+              "state line must hold m(D) at 0 and v(D) at v_offset");
+  REC_REQUIRE(n <= kSmallMergeMax, REC_ESHAPE, "n %lld > %d: use rec_ids_group + rec_sparse_adam_record",
+              (long long)n, kSmallMergeMax);
+  REC_REQUIRE(emb_dim <= 4 * kWave && num_rows < (1ll << 31), REC_ESHAPE, "shape unsupported by the one-launch merge");
+  REC_REQUIRE(gl.group <= 0 || gl.group_stride >= (int64_t)gl.group * emb_dim, REC_EINVAL,
+              "grad group_stride too small");
+  if (n == 0) return REC_OK;
+  REC_REQUIRE(ids && grad && grad1 && rec && MV && hyper && status, REC_EINVAL, "null pointer argument");
+  REC_REQUIRE(hyper->step >= 1, REC_EINVAL, "Adam step must be >= 1");
+  SmallAdamRecord up;
+  up.rec = rec; up.MV = MV; up.stride = rec_stride; up.sstride = state_stride; up.v_off = v_offset;
+  up.grad1 = grad1; up.gl1 = gl1; up.grad_scale = grad_scale;
+  adam_scalars(hyper, &up.lr_t, &up.eps_t);
+  up.b1 = hyper->beta1; up.b2 = hyper->beta2;
+  if (gl.group <= 0) { gl.group = 1; gl.group_stride = emb_dim; }   // one D-wide row per position
+  const unsigned grid = (unsigned)((n + kSmallWaves - 1) / kSmallWaves);
+  const size_t shmem = ((size_t)n + kSmallWaves * kSmallList) * sizeof(int);
+  hipStream_t st = (hipStream_t)stream;
+#define REC_SMALL(NACC_)                                                                                           \
+  hipLaunchKernelGGL((sparse_small_kernel<NACC_, SmallAdamRecord>), dim3(grid), dim3(kSmallWaves * kWave), shmem,   \
+                     st, (int)n, emb_dim, num_slots, num_rows, padding_idx, ids, slot_offset, grad, gl, up, status)
+  if (emb_dim <= kWave) REC_SMALL(1); else if (emb_dim <= 2 * kWave) REC_SMALL(2); else REC_SMALL(4);
+#undef REC_SMALL
+  return check_launch("rec_sparse_adam_record_small");
 }
 
 extern "C" int rec_sgd_dense(int64_t n, float* p, const float* g, float lr, void* stream) {

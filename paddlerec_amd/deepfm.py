@@ -276,7 +276,15 @@ class DeepFMLayer:
         # either way, the backward chain absorbs it slightly better
         group_at = os.environ.get("REC_DEEPFM_GROUP_AT", "bwd")
 
+        # the reference's own batch sizes (config_bigdata.yaml: 512 x 26 = 13312 lookups): the merge happens inside the
+        # ONE launch of the record update — no grouping sort, no hot-row partial passes (12 launches less per step)
+        small = (self.lazy_mode and B * S <= getattr(self.k, "SMALL_MERGE_MAX", 0)
+                 and hasattr(self.k, "sparse_adam_record_small")
+                 and os.environ.get("REC_SMALL_MERGE", "1") != "0")
+
         def issue_group():
+            if small:
+                return
             with _OnSide(side, cur):
                 self.k.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
                                  self.fm.slot_offset, self.status, groups)
@@ -317,10 +325,20 @@ class DeepFMLayer:
         with _OnSide(side, cur):
             with self._timed("sparse_adam"):
                 upd = self.k.sparse_adam_rows if self.lazy_mode else self.k.adam_rows_all
-                # hot rows (Zipf ids): long duplicate runs are pre-reduced per 64-position tile
-                pp = self._pp = self.k.segment_partials(groups, row_grad, row_grad.shape[1], out=getattr(self, "_pp", None))
-                pp1 = self._pp1 = self.k.segment_partials(groups, dz, 1, grad_div=S, out=getattr(self, "_pp1", None))
-                if self.lazy_mode:
+                if small:
+                    D = self.sparse_feature_dim
+                    self.k.sparse_adam_record_small(ids, self.fm.slot_offset, self.fm.padding_idx, row_grad, dz, S,
+                                                    self.fm.rec, st["mv"], D, t, lr, v_offset=_round_up(D, 4),
+                                                    status=self.status)
+                    pp = pp1 = None
+                else:
+                    # hot rows (Zipf ids): long duplicate runs are pre-reduced per 64-position tile
+                    pp = self._pp = self.k.segment_partials(groups, row_grad, row_grad.shape[1],
+                                                            out=getattr(self, "_pp", None))
+                    pp1 = self._pp1 = self.k.segment_partials(groups, dz, 1, grad_div=S, out=getattr(self, "_pp1", None))
+                if small:
+                    pass
+                elif self.lazy_mode:
                     # W, m, v and W1, m1, v1 of a row in ONE pass: W1 / m1 / v1 share the record line with W
                     D = self.sparse_feature_dim
                     self.k.sparse_adam_record(groups, row_grad, dz, S, self.fm.rec, st["mv"], D, t, lr,

@@ -840,6 +840,27 @@ def sparse_sgd_small(ids, grad, P, lr, padding_idx=None, status=None, grad_div=1
     return status
 
 
+def sparse_adam_record_small(ids, slot_offset, padding_idx, grad, grad1, grad1_div, rec, mv, D, step, lr=1e-3,
+                             beta1=0.9, beta2=0.999, eps=1e-8, v_offset=None, grad_scale=None, status=None):
+    """sparse_adam_record with the SelectedRows merge done inside the launch (ids.numel() <= SMALL_MERGE_MAX): ids
+    [B,S] (or flat [B*S]), row = id + slot_offset[s]; grad [B*S, D] row gradients; grad1 = dz with layout {grad1_div}."""
+    _chk(ids, torch.int64, "ids")
+    _chk(grad, torch.float32, "grad")
+    _chk(grad1, torch.float32, "grad1")
+    S = ids.shape[-1] if ids.dim() > 1 else 1
+    if v_offset is None:
+        v_offset = (D + 3) // 4 * 4
+    if status is None:
+        status = new_status(ids.device)
+    h = _hyper(lr, beta1, beta2, eps, step)
+    check(lib().rec_sparse_adam_record_small(ids.numel(), S, int(D), rec.stride(0), mv.stride(0), int(v_offset),
+                                             rec.shape[0], -1 if padding_idx is None else int(padding_idx), _p(ids),
+                                             _p(slot_offset), _p(grad), C.byref(_gl(1, 0, 0)), _p(grad1),
+                                             C.byref(_gl(grad1_div, 0, 0)), _p(grad_scale), _p(rec), _p(mv),
+                                             C.byref(h), _p(status), _stream()), "rec_sparse_adam_record_small")
+    return status
+
+
 def sgd_dense(p, g, lr):
     _chk(p, torch.float32, "p")
     _chk(g, torch.float32, "g")

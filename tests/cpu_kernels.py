@@ -392,6 +392,14 @@ def sparse_adam_record(groups, grad, grad1, grad1_div, rec, mv, D, step, lr=1e-3
     sparse_adam_rows(groups, grad1, grad1_div, rec[:, D:D + 1], rec[:, D + 1:D + 2], rec[:, D + 2:D + 3], step, **kw)
 
 
+def sparse_adam_record_small(ids, slot_offset, padding_idx, grad, grad1, grad1_div, rec, mv, D, step, lr=1e-3,
+                             beta1=0.9, beta2=0.999, eps=1e-8, v_offset=None, grad_scale=None, status=None):
+    g = IdGroups(ids.numel(), "cpu")
+    ids_group(ids, rec.shape[0], padding_idx, None, slot_offset, status, g)
+    sparse_adam_record(g, grad, grad1, grad1_div, rec, mv, D, step, lr, beta1, beta2, eps, v_offset, grad_scale)
+    return status
+
+
 class MultislotBatch:
     def __init__(self, values, lod, slot_base):
         self.values, self.lod, self.slot_base = values, lod, slot_base

@@ -658,3 +658,41 @@ def test_full_size_properties(ops):
     losses = [float(m.train_step(ids, dense, label, lr=1e-3)[0].item()) for _ in range(4)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     assert int(m.status.item()) == 0
+
+
+@pytest.mark.parametrize("zipf,tables", [(False, False), (False, True), (True, False)])
+def test_small_merge_step_equals_sorted_merge_step(ops, monkeypatch, zipf, tables):
+    """At the reference's batch size (config_bigdata.yaml: 512 x 26 lookups) the record update merges the duplicate rows
+    inside its one launch (rec_sparse_adam_record_small); REC_SMALL_MERGE=0 keeps the grouping sort + partials + record
+    update.  Three steps of two identical layers: with uniform ids both sum a row's gradients in ascending position,
+    so every parameter and moment is bit-identical; with Zipf ids the sorted path pre-reduces its hot rows per 64-position
+    tile (another association): equal at 1e-5 of each tensor's scale."""
+    from paddlerec_amd.deepfm import DeepFMLayer
+    B, N, D, fc = 512, 3000, 16, [64, 32]
+    pr = make_deepfm_problem(B=B, N=N, D=D, fc=fc, seed=3, zipf=zipf, tables=tables)
+    so = pr["slot_offsets"]
+    a = DeepFMLayer(pr["N"], D, 13, 26, fc, device=DEV, slot_offset=so)
+    b = DeepFMLayer(pr["N"], D, 13, 26, fc, device=DEV, slot_offset=so)
+    b.fm.rec.copy_(a.fm.rec)
+    b.dense.data.copy_(a.dense.data)
+    rng = np.random.default_rng(8)
+    for step in range(3):
+        pb = make_deepfm_problem(B=B, N=N, D=D, fc=fc, seed=100 + step, zipf=zipf, tables=tables)
+        ids, dense = T(pb["ids"]), T(pb["dense"])
+        label = T((rng.random((B, 1)) < 0.3).astype(np.int64))
+        monkeypatch.setenv("REC_SMALL_MERGE", "1")
+        la, _ = a.train_step(ids, dense, label, lr=1e-2)
+        monkeypatch.setenv("REC_SMALL_MERGE", "0")
+        lb, _ = b.train_step(ids, dense, label, lr=1e-2)
+        if not zipf:
+            assert torch.equal(la, lb)
+        else:
+            np.testing.assert_allclose(N_(la), N_(lb), rtol=1e-5)
+    pairs = [(a.fm.rec, b.fm.rec), (a.sparse_state["mv"], b.sparse_state["mv"]), (a.dense.data, b.dense.data)]
+    if not zipf:
+        for x, y in pairs:
+            assert torch.equal(x, y)
+    else:       # (after the first step the tables differ in the last bits, so everything downstream does too)
+        assert_close_scaled(N_(a.sparse_state["mv"]), N_(b.sparse_state["mv"]))
+        assert_close_scaled(N_(a.dense.m), N_(b.dense.m))
+    assert int(a.status.item()) == 0 and int(b.status.item()) == 0
