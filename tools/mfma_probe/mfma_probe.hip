@@ -73,13 +73,56 @@ extern "C" __global__ __launch_bounds__(256) void mfma_lds_probe_kernel(int iter
   if (t == 12345.678f) out[0] = t;
 }
 
+// ... and with HBM traffic beside it: every trip each lane also streams 16 bytes from a buffer far larger than the
+// caches (1 KB per wave per 32 MFMAs = ~2.3 TB/s over the chip at one wave per SIMD) — the third thing a GEMM keeps busy.
+extern "C" __global__ __launch_bounds__(256) void mfma_mem_probe_kernel(int iters, int mode, float* out,
+                                                                        const float4* __restrict__ big, long n4) {
+  __shared__ float lds[4096];
+  const int lane = threadIdx.x;
+  uint32_t s = 0x9E3779B9u * (blockIdx.x * 256 + lane + 1);
+  auto rnd = [&]() {
+    s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+    return ((float)(s >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.25f;
+  };
+  for (int i = lane; i < 4096; i += 256) lds[i] = mode == 0 ? 0.f : rnd();
+  __syncthreads();
+  f32x4 acc[NACC];
+  for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int w = lane & 63;
+  long at = ((long)blockIdx.x * 256 + lane) % n4;
+  const long stride = (long)gridDim.x * 256;
+  float4 sink = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int it = 0; it < iters; ++it) {
+    const float4 x = __builtin_nontemporal_load(&big[at]);
+    at += stride;
+    if (at >= n4) at -= n4;
+    const int base = (it & 7) * 512;
+    const float4 a4 = *reinterpret_cast<const float4*>(&lds[base + w * 4]);
+    float b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = lds[base + 256 + k * 64 + w];
+    const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[k], acc[i], 0, 0, 0);
+    sink.x += x.x; sink.y += x.y; sink.z += x.z; sink.w += x.w;
+  }
+  float t = sink.x + sink.y + sink.z + sink.w;
+  for (int i = 0; i < NACC; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (t == 12345.678f) out[0] = t;
+}
+
 // launches `blocks` blocks of 4 waves; returns milliseconds of the launch (HIP events)
-extern "C" float mfma_probe(int blocks, int iters, int mode, float* out, void* stream, int with_lds) {
+extern "C" float mfma_probe(int blocks, int iters, int mode, float* out, void* stream, int with_lds,
+                            const void* big, long n4) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   hipStream_t st = (hipStream_t)stream;
   (void)hipEventRecord(e0, st);
-  if (with_lds) hipLaunchKernelGGL(mfma_lds_probe_kernel, dim3(blocks), dim3(256), 0, st, iters, mode, out);
+  if (with_lds == 2)
+    hipLaunchKernelGGL(mfma_mem_probe_kernel, dim3(blocks), dim3(256), 0, st, iters, mode, out, (const float4*)big, n4);
+  else if (with_lds) hipLaunchKernelGGL(mfma_lds_probe_kernel, dim3(blocks), dim3(256), 0, st, iters, mode, out);
   else hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, st, iters, mode, out);
   (void)hipEventRecord(e1, st);
   (void)hipEventSynchronize(e1);
