@@ -746,6 +746,13 @@ int rec_count_lines(const char* buf, size_t len, int32_t threads, int64_t* n_lin
  * batches from a whole-file parse skips them like the reference's `for line in f` readers do.  *n_blank = how many
  * there are (may exceed max_out: only the first max_out are written). */
 int rec_blank_lines(const char* buf, size_t len, int32_t threads, int64_t max_out, int64_t* idx, int64_t* n_blank);
+/* One batch cut out of whole-file parses by line range (the in-memory pass of the gpubox loop): piece p = lines
+ * [l0[p], l1[p]) of a rec_parse_feasign_slots result (values[p], lod[p] with row stride lod_stride[p], base[p]); the
+ * batch's slot s holds its ids of piece 0, then of piece 1, ... — the CSR a parse of exactly those lines gives.
+ * out_lod [num_slots, lines + 1], out_base [num_slots + 1], out_values [max_values >= total ids]. */
+int rec_csr_cut(int32_t num_slots, int32_t n_pieces, const int64_t* const* values, const int64_t* const* lod,
+                const int64_t* lod_stride, const int64_t* const* base, const int64_t* l0, const int64_t* l1,
+                int32_t threads, int64_t* out_values, int64_t max_values, int64_t* out_lod, int64_t* out_base);
 /* Occurrences of one byte value, multi-threaded (the ':' count bounds the values of rec_parse_feasign_slots). */
 int rec_count_byte(const char* buf, size_t len, int32_t byte, int32_t threads, int64_t* n);
 int rec_parse_slot_text(const char* buf, size_t len, int32_t n_sparse, int32_t n_dense,

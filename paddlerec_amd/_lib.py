@@ -200,6 +200,7 @@ SIGNATURES = {
     "rec_count_lines": (C.c_int, [C.c_char_p, _SZ, _I32, C.POINTER(_I64)]),
     "rec_blank_lines": (C.c_int, [C.c_char_p, _SZ, _I32, _I64, _P, C.POINTER(_I64)]),
     "rec_count_byte": (C.c_int, [C.c_char_p, _SZ, _I32, _I32, C.POINTER(_I64)]),
+    "rec_csr_cut": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _I64, _P, _P]),
     "rec_parse_slot_text": (C.c_int, [C.c_char_p, _SZ, _I32, _I32, _I32, _I64, _I32, _P, _P, _P,
                                       C.POINTER(_I64)]),
     "rec_parse_criteo_tsv": (C.c_int, [C.c_char_p, _SZ, _I32, _I32, _P, _P, C.c_uint32, _I64, _I32, _P, _P, _P,

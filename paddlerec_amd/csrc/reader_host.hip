@@ -150,6 +150,54 @@ extern "C" int rec_count_lines(const char* buf, size_t len, int32_t threads, int
   return REC_OK;
 }
 
+// One batch cut out of whole-file parses (rec_parse_feasign_slots outputs): pieces = consecutive line ranges
+// [l0, l1) of parsed files; the batch's slot s holds its ids of piece 0, then of piece 1, ... — exactly the
+// slot-major CSR a parse of those lines on their own would give.  out_lod [num_slots, n_lines + 1],
+// out_base [num_slots + 1], out_values [sum of the ranges] (the caller sizes it from the lod differences).
+extern "C" int rec_csr_cut(int32_t num_slots, int32_t n_pieces, const int64_t* const* values,
+                           const int64_t* const* lod, const int64_t* lod_stride, const int64_t* const* base,
+                           const int64_t* l0, const int64_t* l1, int32_t threads, int64_t* out_values,
+                           int64_t max_values, int64_t* out_lod, int64_t* out_base) {
+  REC_REQUIRE(num_slots > 0 && n_pieces > 0 && values && lod && lod_stride && base && l0 && l1 && out_values &&
+                  out_lod && out_base, REC_EINVAL, "bad arguments");
+  const int S = num_slots, P = n_pieces;
+  int64_t nl = 0;
+  for (int p = 0; p < P; ++p) {
+    REC_REQUIRE(l1[p] >= l0[p] && l0[p] >= 0, REC_EINVAL, "bad line range of piece %d", p);
+    nl += l1[p] - l0[p];
+  }
+  // slot bases of the batch
+  int64_t tot = 0;
+  for (int s = 0; s < S; ++s) {
+    out_base[s] = tot;
+    for (int p = 0; p < P; ++p) {
+      const int64_t* l = lod[p] + (size_t)s * lod_stride[p];
+      tot += l[l1[p]] - l[l0[p]];
+    }
+  }
+  out_base[S] = tot;
+  REC_REQUIRE(tot <= max_values, REC_EWORKSPACE, "values buffer holds %lld ids, %lld needed", (long long)max_values,
+              (long long)tot);
+  const int T = tot < 200000 ? 1 : host_threads(threads);     // a small batch is copied faster than threads start
+  run_threads(T < S ? T : S, [&](int t) {
+    const int TT = T < S ? T : S;
+    for (int s = t; s < S; s += TT) {
+      int64_t* ol = out_lod + (size_t)s * (nl + 1);
+      int64_t* ov = out_values + out_base[s];
+      int64_t line = 0, at = 0;
+      ol[0] = 0;
+      for (int p = 0; p < P; ++p) {
+        const int64_t* l = lod[p] + (size_t)s * lod_stride[p];
+        const int64_t b0 = l[l0[p]], b1 = l[l1[p]];
+        memcpy(ov + at, values[p] + base[p][s] + b0, (size_t)(b1 - b0) * sizeof(int64_t));
+        for (int64_t i = l0[p]; i < l1[p]; ++i) ol[++line] = at + (l[i + 1] - b0);
+        at += b1 - b0;
+      }
+    }
+  });
+  return REC_OK;
+}
+
 // occurrences of one byte value (the ':' of every `feasign:slot` token bounds the value count of a multi-value parse)
 extern "C" int rec_count_byte(const char* buf, size_t len, int32_t byte, int32_t threads, int64_t* n) {
   REC_REQUIRE(n && (len == 0 || buf) && byte >= 0 && byte < 256, REC_EINVAL, "bad arguments");

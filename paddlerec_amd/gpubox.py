@@ -135,32 +135,10 @@ class InMemoryReader:
 def _cut_batch(pieces, S):
     """One batch from consecutive line ranges of parsed files: pieces = [(values, lod [S+1, n+1], base [S+2], l0, l1)]
     with slot 0 = the label slot.  -> (values, lod [S, B+1], slot_base [S+1], label [B,1]) in the slot-major layout
-    rec_parse_feasign_slots gives a batch parsed on its own: slot s holds its ids of piece 0, then of piece 1, ..."""
-    starts = torch.stack([base[:-1] + lod[:, l0] for _, lod, base, l0, _ in pieces], 1)        # [S+1, P]
-    lens = torch.stack([lod[:, l1] - lod[:, l0] for _, lod, _, l0, l1 in pieces], 1)           # [S+1, P]
-    offs, tot = [0], 0
-    for v, _, _, _, _ in pieces:                 # the pieces' value arrays behind one another
-        tot += v.numel()
-        offs.append(tot)
-    allv = pieces[0][0] if len(pieces) == 1 else torch.cat([v for v, _, _, _, _ in pieces])
-    src0 = (starts + torch.tensor(offs[:-1], dtype=torch.int64)).reshape(-1)                   # slot-major, piece-minor
-    flat = lens.reshape(-1)
-    dst0 = torch.cumsum(flat, 0) - flat
-    idx = torch.arange(int(flat.sum())) + torch.repeat_interleave(src0 - dst0, flat)
-    vals = allv[idx]
-    per_slot = lens.sum(1)
-    base_b = torch.zeros(S + 2, dtype=torch.int64)
-    base_b[1:] = torch.cumsum(per_slot, 0)
-    # per-slot offsets of the batch's lines: piece p's lines continue where piece p-1's ids of that slot ended
-    rows, carry = [], torch.zeros(S + 1, 1, dtype=torch.int64)
-    for (_, lod, _, l0, l1), p in zip(pieces, range(len(pieces))):
-        rel = lod[:, l0:l1 + 1] - lod[:, l0:l0 + 1] + carry
-        rows.append(rel if p == len(pieces) - 1 else rel[:, :-1])
-        carry = rel[:, -1:]
-    lod_b = torch.cat(rows, 1)
-    nlab = int(per_slot[0])
-    lab_first = vals[:nlab][lod_b[0, :-1]]                                                       # first value of slot "1"
-    label = lab_first.reshape(-1, 1).clamp_(0, 1).contiguous()
+    rec_parse_feasign_slots gives a batch parsed on its own (rec_csr_cut: threaded copies, no python per line)."""
+    vals, lod_b, base_b = rd.csr_cut(pieces, S + 1)
+    nlab = int(base_b[1])
+    label = vals[:nlab][lod_b[0, :-1]].reshape(-1, 1).clamp_(0, 1).contiguous()      # first value of slot "1"
     return vals[nlab:].contiguous(), lod_b[1:].contiguous(), (base_b[1:] - base_b[1]).contiguous(), label
 
 

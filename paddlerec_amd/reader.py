@@ -60,6 +60,25 @@ def blank_lines(data, threads=0):
     return out[: int(n.value)]
 
 
+def csr_cut(pieces, num_slots, threads=0):
+    """One batch from consecutive line ranges of parse_feasign_slots results: pieces = [(values, lod, base, l0, l1)].
+    -> (values, lod [num_slots, lines + 1], base [num_slots + 1]) host tensors (rec_csr_cut)."""
+    P = len(pieces)
+    nl = sum(l1 - l0 for _, _, _, l0, l1 in pieces)
+    total = sum(int((lod[:, l1] - lod[:, l0]).sum()) for _, lod, _, l0, l1 in pieces)
+    out_v = torch.empty(max(total, 1), dtype=torch.int64)
+    out_l = torch.empty(num_slots, nl + 1, dtype=torch.int64)
+    out_b = torch.empty(num_slots + 1, dtype=torch.int64)
+    arr = lambda xs: (C.c_void_p * P)(*xs)
+    i64 = lambda xs: (C.c_int64 * P)(*xs)
+    check(lib().rec_csr_cut(num_slots, P, arr([v.data_ptr() for v, _, _, _, _ in pieces]),
+                            arr([l.data_ptr() for _, l, _, _, _ in pieces]), i64([l.stride(0) for _, l, _, _, _ in pieces]),
+                            arr([b.data_ptr() for _, _, b, _, _ in pieces]), i64([p[3] for p in pieces]),
+                            i64([p[4] for p in pieces]), threads, C.c_void_p(out_v.data_ptr()), out_v.numel(),
+                            C.c_void_p(out_l.data_ptr()), C.c_void_p(out_b.data_ptr())), "rec_csr_cut")
+    return out_v[:total], out_l, out_b
+
+
 def parse_slot_text(data: bytes, n_sparse=26, n_dense=13, log1p_dense=False, threads=0, pinned=False):
     """-> (label [n] i64, ids [n,S] i64, dense [n,Dn] f32) host tensors."""
     cap = _count_lines(data, threads)
@@ -96,7 +115,7 @@ def parse_feasign_slots(data: bytes, first_slot=1, num_slots=301, hash_rows=0, t
     check(lib().rec_count_byte(ptr, ln, ord(":"), threads, C.byref(nc)), "rec_count_byte")
     bound = int(nc.value) + cap * num_slots             # every token + one padding id per (line, slot)
     values = torch.empty(max(bound, 1), dtype=torch.int64)
-    lod = torch.zeros(num_slots, cap + 1, dtype=torch.int64)
+    lod = torch.empty(num_slots, cap + 1, dtype=torch.int64)       # the parser writes every offset of the n lines
     base = torch.zeros(num_slots + 1, dtype=torch.int64)
     n, nv = C.c_int64(0), C.c_int64(0)
     check(lib().rec_parse_feasign_slots(ptr, ln, int(first_slot), int(num_slots), int(hash_rows), cap,
