@@ -19,7 +19,6 @@ buckets at the end of a pass, `ips` as the reference logs it (:181-203).  Paddle
 parameter servers behind HeterPS and `fleet.save_inference_model` are not mirrored.
 """
 import logging
-import mmap
 import os
 import time
 
@@ -95,51 +94,20 @@ class InMemoryReader:
         self.batches = []
 
     def load_into_memory(self):
-        """Every file is parsed ONCE, whole, by the C parser (mmap'ed text, all threads; label slot and feature slots in
-        one pass) into a slot-major CSR; batches are cut from it by index arithmetic on the host tensors.  Lines are
-        never split or re-joined in Python (the line-list version copied a pass's text three times at ~1 GB/s; a
-        65536-line batch of this format is ~650 MB of text).  Batching is the reference's: lines accumulate across
-        files, the last partial batch is dropped."""
-        B, S, out = self.batch_size, self.slot_num, []
-        pieces, have = [], 0                     # (values, lod [S+1, n+1], base [S+2], first line, end line) not yet batched
-        for path in self.file_list:
-            size = os.path.getsize(path)
-            if size == 0:
-                continue
-            with open(path, "rb") as f:
-                mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
-                try:     # slot "1" = click (label), slots "2".."slot_num+1" = features (queuedataset_reader.py:45-56)
-                    values, lod, base, n = rd.parse_feasign_slots(mm, 1, S + 1, 0, self.threads)
-                    blank = rd.blank_lines(mm, self.threads).tolist()
-                finally:
-                    mm.close()
-            # runs of real lines between the (rare) blank ones
-            edges = [-1] + [b for b in blank if b < n] + [n]
-            for a, z in zip(edges[:-1], edges[1:]):
-                lo = a + 1
-                while have + (z - lo) >= B:
-                    take = B - have
-                    pieces.append((values, lod, base, lo, lo + take))
-                    out.append(_cut_batch(pieces, S))
-                    pieces, have, lo = [], 0, lo + take
-                if lo < z:
-                    pieces.append((values, lod, base, lo, z))
-                    have += z - lo
+        """The pass's files -> host batches through reader.feasign_batches (every file parsed once, whole, by the C
+        parser; batches cut by rec_csr_cut: lines are never split or re-joined in python — a 65536-line batch of this
+        format is ~650 MB of text).  Slot "1" = click (label), slots "2".."slot_num+1" = features
+        (queuedataset_reader.py:45-56): parsed in one pass, the label slot peeled off here."""
+        S, out = self.slot_num, []
+        for vals, lod_b, base_b in rd.feasign_batches(self.file_list, self.batch_size, 1, S + 1, 0, self.threads):
+            nlab = int(base_b[1])
+            label = vals[:nlab][lod_b[0, :-1]].reshape(-1, 1).clamp_(0, 1).contiguous()      # first value of slot "1"
+            out.append((vals[nlab:].contiguous(), lod_b[1:].contiguous(), (base_b[1:] - base_b[1]).contiguous(), label))
         self.batches = out
         return len(out)
 
     def release_memory(self):
         self.batches = []
-
-
-def _cut_batch(pieces, S):
-    """One batch from consecutive line ranges of parsed files: pieces = [(values, lod [S+1, n+1], base [S+2], l0, l1)]
-    with slot 0 = the label slot.  -> (values, lod [S, B+1], slot_base [S+1], label [B,1]) in the slot-major layout
-    rec_parse_feasign_slots gives a batch parsed on its own (rec_csr_cut: threaded copies, no python per line)."""
-    vals, lod_b, base_b = rd.csr_cut(pieces, S + 1)
-    nlab = int(base_b[1])
-    label = vals[:nlab][lod_b[0, :-1]].reshape(-1, 1).clamp_(0, 1).contiguous()      # first value of slot "1"
-    return vals[nlab:].contiguous(), lod_b[1:].contiguous(), (base_b[1:] - base_b[1]).contiguous(), label
 
 
 def _data_files(config, key):

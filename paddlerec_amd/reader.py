@@ -135,15 +135,38 @@ class FeasignSlotReader:
         self.kw = dict(first_slot=first_slot, num_slots=num_slots, hash_rows=hash_rows, threads=threads)
 
     def __iter__(self):
-        B = self.batch_size
-        pending = []
-        for path in self.file_list:
-            with open(path, "rb") as f:
-                pending += [ln for ln in f.read().split(b"\n") if ln.strip()]
-            while len(pending) >= B:
-                chunk, pending = pending[:B], pending[B:]
-                values, lod, base, _ = parse_feasign_slots(b"\n".join(chunk) + b"\n", **self.kw)
-                yield tuple(t.to(self.device, non_blocking=True) for t in (values, lod.contiguous(), base))
+        for values, lod, base in feasign_batches(self.file_list, self.batch_size, **self.kw):
+            yield tuple(t.to(self.device, non_blocking=True) for t in (values, lod, base))
+
+
+def feasign_batches(file_list, batch_size, first_slot=1, num_slots=301, hash_rows=0, threads=0):
+    """Host batches (values, lod [num_slots, B+1], slot_base) of `batch_size` lines over a file list in the multi-value
+    `feasign:slot` format: every file is parsed ONCE, whole (mmap'ed text, all threads), and the batches are cut from
+    the parse by rec_csr_cut — lines are never split or re-joined in python.  Batching as the reference's datasets do
+    it: lines accumulate across files, whitespace-only lines are skipped, the last partial batch is dropped."""
+    B = batch_size
+    pieces, have = [], 0              # (values, lod, base, first line, end line) ranges not yet batched
+    for path in file_list:
+        if os.path.getsize(path) == 0:
+            continue
+        with open(path, "rb") as f:
+            mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+            try:
+                values, lod, base, n = parse_feasign_slots(mm, first_slot, num_slots, hash_rows, threads)
+                blank = blank_lines(mm, threads).tolist()
+            finally:
+                mm.close()
+        edges = [-1] + [b for b in blank if b < n] + [n]       # runs of real lines between the (rare) blank ones
+        for a, z in zip(edges[:-1], edges[1:]):
+            lo = a + 1
+            while have + (z - lo) >= B:
+                take = B - have
+                pieces.append((values, lod, base, lo, lo + take))
+                yield csr_cut(pieces, num_slots, threads)
+                pieces, have, lo = [], 0, lo + take
+            if lo < z:
+                pieces.append((values, lod, base, lo, z))
+                have += z - lo
 
 
 class _FileBatches:
