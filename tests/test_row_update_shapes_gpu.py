@@ -1,0 +1,122 @@
+"""Seeded shape sweep of the row-update kernels added in round 2 against torch on the same device: the lane-per-row lazy
+Adam (rows without float4 groups: every width 1..16, aligned and unaligned strides, views with offsets), the one-launch
+merge + SGD / record-Adam (any n up to the limit, widths up to 256, strided gradient views, duplicates from none to
+one row owning most lookups).  The kernels' own oracle tests use a few shapes; this walks the corners."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _adam_ref(P, M, V, rows, g, t, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """float64 lazy Adam on the merged gradient g [U, D] of rows [U] (Paddle's epsilon placement)."""
+    lr_t = lr * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
+    m = b1 * M[rows].double() + (1 - b1) * g
+    v = b2 * V[rows].double() + (1 - b2) * g * g
+    p = P[rows].double() - lr_t * m / (v.sqrt() + eps * (1 - b2 ** t) ** 0.5)
+    return p, m, v
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_narrow_adam_rows_shape_sweep(engine_lib, seed):
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.integers(1, 17))
+    N = int(rng.integers(50, 4000))
+    n = int(rng.integers(1, 30000))
+    stride = D + int(rng.integers(0, 9))
+    sstride = D + int(rng.integers(0, 9))
+    if rng.random() < 0.5:                                  # record-like: 16-B aligned strides
+        stride, sstride = (stride + 3) // 4 * 4, (sstride + 3) // 4 * 4
+    off = int(rng.integers(0, 3)) * (4 if stride % 4 == 0 else 1)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    Pbuf = torch.randn(N, stride + off, device=DEV, generator=g)
+    Mbuf = torch.randn(N, sstride, device=DEV, generator=g) * 1e-2
+    Vbuf = torch.rand(N, sstride, device=DEV, generator=g) * 1e-3
+    P, M, V = Pbuf[:, off:off + D], Mbuf[:, :D], Vbuf[:, :D]
+    P0, M0, V0 = P.clone(), M.clone(), V.clone()
+    hot = rng.random() < 0.3
+    ids = torch.from_numpy(rng.integers(0, N, size=n)).to(DEV)
+    if hot:
+        ids[torch.rand(n, device=DEV, generator=g) < 0.6] = int(rng.integers(1, N))
+    pitch = D + int(rng.integers(0, 5))
+    grad_full = torch.randn(n, pitch, device=DEV, generator=g) * 1e-2
+    grad = grad_full[:, :D]
+    t = int(rng.integers(1, 50))
+    ws = ops.Workspace(DEV)
+    groups, status = ops.ids_group(ids, N, 0, ws)
+    pp = ops.segment_partials(groups, grad, D, grad_group=1, grad_group_stride=pitch)
+    ops.sparse_adam_rows(groups, grad, 1, P, M, V, t, lr=1e-2, grad_group=1, grad_group_stride=pitch, partials=pp)
+    live = ids != 0
+    gs = torch.zeros(N, D, device=DEV, dtype=torch.float64)
+    gs.index_add_(0, ids[live], grad[live].double())
+    rows = torch.nonzero(torch.bincount(ids[live], minlength=N) > 0).reshape(-1)
+    p, m, v = _adam_ref(P0, M0, V0, rows, gs[rows], t, 1e-2)
+    for got, want, full in ((M, m, M0), (V, v, V0), (P, p, P0)):
+        torch.testing.assert_close(got[rows].double(), want, rtol=2e-5,
+                                   atol=2e-5 * float(want.abs().max().item()) if rows.numel() else 0.0)
+        mask = torch.ones(N, dtype=torch.bool, device=DEV)
+        mask[rows] = False
+        assert torch.equal(got[mask], full[mask])           # untouched rows bit-identical
+    if off or stride + off > D:                             # nothing outside the D columns was written
+        ref = torch.randn(N, stride + off, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+        assert torch.equal(Pbuf[:, :off], ref[:, :off]) and torch.equal(Pbuf[:, off + D:], ref[:, off + D:])
+    assert int(status.item()) == 0
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_small_merge_shape_sweep(engine_lib, seed):
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(2000 + seed)
+    D = int(rng.choice([1, 3, 16, 17, 64, 65, 128, 200, 256]))
+    N = int(rng.integers(2, 5000))
+    n = int(rng.choice([1, 63, 64, 65, 1000, 4864, 13312, 15360]))
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    ids = torch.from_numpy(rng.integers(0, N, size=n)).to(DEV)
+    if rng.random() < 0.4 and n > 10:
+        ids[torch.rand(n, device=DEV, generator=g) < 0.7] = int(rng.integers(0, N))
+    pitch = D + int(rng.integers(0, 4)) * 4
+    grad = torch.randn(n, pitch, device=DEV, generator=g)[:, :D]
+    pad = 0 if rng.random() < 0.5 else None
+    P = torch.randn(N, D, device=DEV, generator=g)
+    P0 = P.clone()
+    st = ops.sparse_sgd_small(ids, grad, P, 0.25, padding_idx=pad, grad_group=1, grad_group_stride=pitch)
+    live = (ids != 0) if pad == 0 else torch.ones_like(ids, dtype=torch.bool)
+    want = P0.double()
+    want.index_add_(0, ids[live], -0.25 * grad[live].double())
+    torch.testing.assert_close(P.double(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max().item()))
+    assert int(st.item()) == 0
+    if D <= 64:            # the record form: W | W1 | m1 | v1 in one line, moments in a second
+        S = int(rng.choice([1, 2, 13, 26]))
+        S = S if n >= S else 1
+        B = n // S
+        ids2 = ids[: B * S].reshape(B, S).contiguous()
+        rec = torch.randn(N, (D + 3 + 31) // 32 * 32, device=DEV, generator=g) * 0.1
+        Dp = (D + 3) // 4 * 4
+        mv = torch.rand(N, (2 * Dp + 31) // 32 * 32, device=DEV, generator=g) * 1e-3
+        rec[:, D + 2].abs_()
+        rec0, mv0 = rec.clone(), mv.clone()
+        rg = torch.randn(B * S, D, device=DEV, generator=g) * 1e-2
+        dz = torch.randn(B, device=DEV, generator=g) * 1e-2
+        t = int(rng.integers(1, 20))
+        st2 = ops.sparse_adam_record_small(ids2, None, 0, rg, dz, S, rec, mv, D, t, lr=1e-2, v_offset=Dp)
+        flat = ids2.reshape(-1)
+        lv = flat != 0
+        gs = torch.zeros(N, D, device=DEV, dtype=torch.float64)
+        gs.index_add_(0, flat[lv], rg[lv].double())
+        g1 = torch.zeros(N, 1, device=DEV, dtype=torch.float64)
+        g1.index_add_(0, flat[lv], dz.repeat_interleave(S)[lv].double().unsqueeze(1))
+        rows = torch.nonzero(torch.bincount(flat[lv], minlength=N) > 0).reshape(-1)
+        p, m, v = _adam_ref(rec0[:, :D], mv0[:, :D], mv0[:, Dp:Dp + D], rows, gs[rows], t, 1e-2)
+        p1, m1, v1 = _adam_ref(rec0[:, D:D + 1], rec0[:, D + 1:D + 2], rec0[:, D + 2:D + 3], rows, g1[rows], t, 1e-2)
+        for got, want_ in ((rec[:, :D], p), (mv[:, :D], m), (mv[:, Dp:Dp + D], v), (rec[:, D:D + 1], p1),
+                           (rec[:, D + 1:D + 2], m1), (rec[:, D + 2:D + 3], v1)):
+            if rows.numel():
+                torch.testing.assert_close(got[rows].double(), want_, rtol=2e-5,
+                                           atol=2e-5 * float(want_.abs().max().item()))
+        mask = torch.ones(N, dtype=torch.bool, device=DEV)
+        mask[rows] = False
+        assert torch.equal(rec[mask], rec0[mask]) and torch.equal(mv[mask], mv0[mask])
+        assert int(st2.item()) == 0
