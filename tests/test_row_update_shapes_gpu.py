@@ -120,3 +120,64 @@ def test_small_merge_shape_sweep(engine_lib, seed):
         mask[rows] = False
         assert torch.equal(rec[mask], rec0[mask]) and torch.equal(mv[mask], mv0[mask])
         assert int(st2.item()) == 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_ps_push_narrow_shape_sweep(engine_lib, seed):
+    """rec_ps_push_rows on narrow features (lane-per-feature kernel: embedx_dim 1..15 at record offset 1) against the
+    accessor oracle: tables holding unborn / embed-only / full features, thresholds that let some features be born
+    with and some without their embedx part, show and click inputs, duplicates and padding."""
+    from oracle import deepfm_ref as R
+    from oracle import ps_ref
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(3000 + seed)
+    D = int(rng.integers(2, 17))                       # looked-up width: embed_w + embedx(D-1)
+    N = int(rng.integers(20, 300))
+    S = int(rng.integers(1, 5))
+    B = int(rng.integers(4, 120))
+    thr = float(rng.choice([0.0, 1.5, 10.0]))
+    table = ops.PsTable(N, D, DEV, kind="slot", embedx_threshold=thr, initial_range=1e-2, seed=77 + seed)
+    L = table.layout
+    lay = dict(embed_off=L.embed_off, embedx_off=L.embedx_off, embedx_dim=L.embedx_dim, stat_off=L.stat_off)
+    a = table.accessor
+    acc = dict(lr=a.lr, initial_g2sum=a.initial_g2sum, bounds=(a.min_bound, a.max_bound), initial_range=a.initial_range,
+               embedx_threshold=a.embedx_threshold, nonclk_coeff=a.nonclk_coeff, click_coeff=a.click_coeff, seed=a.seed)
+    rec = np.zeros((N, L.row_stride), np.float32)
+    for r in range(1, N):                              # a table with history: a third unborn, a third embed-only, a third full
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            continue
+        rec[r, L.embed_off] = rng.standard_normal() * 0.1
+        rec[r, L.stat_off:L.stat_off + 4] = [rng.integers(0, 30), rng.integers(0, 3), rng.random() * 0.5, rng.random() * 0.5]
+        rec[r, L.stat_off + 1] = min(rec[r, L.stat_off + 1], rec[r, L.stat_off])
+        rec[r, L.stat_off + 4] = kind
+        if kind == 2:
+            rec[r, L.embedx_off:L.embedx_off + D - 1] = rng.standard_normal(D - 1) * 0.1
+    table.rec.copy_(torch.from_numpy(rec))
+    ids = rng.integers(0, N, size=(B, S)).astype(np.int64)
+    ids[rng.random((B, S)) < 0.2] = ids[0, 0]          # a popular feature
+    grad = (rng.standard_normal((B * S, D)) * 0.05).astype(np.float32)
+    show = rng.integers(1, 4, size=B).astype(np.int64)
+    click = (rng.random(B) < 0.4).astype(np.int64)
+    tids = torch.from_numpy(ids).to(DEV)
+    groups, status = ops.ids_group(tids, N, 0, ops.Workspace(DEV))
+    ops.ps_push_rows(table, groups, torch.from_numpy(grad).to(DEV), S, show=torch.from_numpy(show).to(DEV),
+                     click=torch.from_numpy(click).to(DEV))
+    rows = ids.reshape(-1)
+    valid = rows != 0
+    uniq, merged, _ = R.merge_rows(rows, valid, grad)
+    pos_s = np.repeat(show, S).astype(np.float64)
+    pos_c = np.repeat(click, S).astype(np.float64)
+    dshow = np.array([pos_s[(rows == u) & valid].sum() for u in uniq])
+    dclick = np.array([pos_c[(rows == u) & valid].sum() for u in uniq])
+    want = rec.copy()
+    ps_ref.push_rows(want, lay, uniq, merged[:, 0], merged[:, 1:], dshow, dclick, acc)
+    got = table.rec.cpu().numpy()
+    so = L.stat_off
+    assert np.array_equal(got[:, so:so + 2], want[:, so:so + 2])            # show / click: exact
+    assert np.array_equal(got[:, so + 4], want[:, so + 4])                  # feature states: exact
+    np.testing.assert_allclose(got[:, :D], want[:, :D], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(got[:, so + 2:so + 4], want[:, so + 2:so + 4], rtol=1e-4, atol=1e-9)
+    untouched = np.setdiff1d(np.arange(N), uniq)
+    assert np.array_equal(got[untouched], rec[untouched])
+    assert int(status.item()) == 0
