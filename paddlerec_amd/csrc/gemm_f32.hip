@@ -583,7 +583,10 @@ static bool skinny_dw(const rec_gemm_desc* d) {     // C[M<=1024, N<=4] = A^T B 
 static int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Config choice from the measurements of profiles/r02b_gemm_*.txt (MI355X, f32):
-//   few output rows (weight gradients, K = batch): 80x80 — M, N = 400 tile exactly, 90 vs 67 TF for 128x128;
+//   few output rows (weight gradients, K = batch): 80x80 when it pads at least a fifth less than 128x128 — M, N = 400
+//   tile exactly, 93 vs 70 TF — and 128x128 otherwise: a full 128x128 tile does ~1.3x the work per cycle of an
+//   80x80 one (64x64 against 16x80 per wave), 103 vs 72 TF on the 1560^2 weight gradients of DCN-v2
+//   (profiles/r02f_dw_cfg_probe.txt);
 //   many rows: the tile width that wastes fewer columns (80 vs 128), on 256-row / 8-wave blocks when there are
 //   enough rows (256x80: 100-105 TF on N = 400/432 and 121 TF on N = 1560, 256x128: 123-131 TF on N = 512 / 1560 /
 //   4096); the 4-wave versions (128x80, 128x128) for short matrices.
@@ -594,7 +597,7 @@ static GemmPlan plan_gemm(const rec_gemm_desc* d, int num_cus = kNumCU) {
   if (d->m < 2048) {
     const int64_t a80 = ceil_div64(d->m, 80) * 80 * ceil_div64(d->n, 80) * 80;
     const int64_t a128 = ceil_div64(d->m, 128) * 128 * ceil_div64(d->n, 128) * 128;
-    best = a80 <= a128 + a128 / 16 ? CFG_80x80 : CFG_128x128;
+    best = a80 * 5 <= a128 * 4 ? CFG_80x80 : CFG_128x128;
   } else {
     const int64_t w80 = ceil_div64(d->n, 80) * 80 - d->n, w128 = ceil_div64(d->n, 128) * 128 - d->n;
     const bool tall = d->m >= 8192;
