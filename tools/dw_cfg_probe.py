@@ -8,6 +8,8 @@ NAMES = {-1: "planner", 0: "128x80", 1: "256x80", 2: "256x128", 3: "128x128", 4:
 DW = [(1560, 1560, 65536), (3672, 512, 65536), (768, 768, 65536), (1560, 768, 65536), (400, 400, 65536), (416, 400, 65536)]
 FWD = [(65536, 1560, 1560), (65536, 768, 1560), (65536, 512, 3672), (65536, 400, 416), (65536, 256, 512)]
 SHAPES = [s + (True,) for s in DW] + [s + (False,) for s in FWD]
+if os.environ.get("PROBE_ONLY"):       # e.g. PROBE_ONLY=400x400x65536 under rocprofv3
+    SHAPES = [s for s in SHAPES if "%dx%dx%d" % s[:3] == os.environ["PROBE_ONLY"]]
 if len(sys.argv) > 1:
     import torch
     from paddlerec_amd import ops
