@@ -11,6 +11,7 @@
 // tools/utils/static_ps/reader_helper.py:283-308); outputs are written in line order, so results do not
 // depend on the thread count.  No device code here: the caller copies the batch with hipMemcpyAsync.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -99,25 +100,99 @@ static int host_threads(int requested) {
   return t > 64 ? 64 : t;
 }
 
+// ---- number fields: a bounded fast path for the forms the datasets hold, the C library for everything else.
+// Both see exactly [p, e): the fallbacks run on a NUL-terminated copy (the input may be an mmap that ends without one).
+static double strtod_span(const char* p, const char* e) {
+  char tmp[96];
+  const size_t n = (size_t)(e - p);
+  if (n < sizeof(tmp)) {
+    memcpy(tmp, p, n);
+    tmp[n] = 0;
+    return strtod(tmp, nullptr);
+  }
+  return strtod(std::string(p, n).c_str(), nullptr);
+}
+static long long strtoll_span(const char* p, const char* e) {
+  char tmp[96];
+  const size_t n = (size_t)(e - p);
+  if (n < sizeof(tmp)) {
+    memcpy(tmp, p, n);
+    tmp[n] = 0;
+    return strtoll(tmp, nullptr, 10);
+  }
+  return strtoll(std::string(p, n).c_str(), nullptr, 10);
+}
+// "[-]digits[.digits]" with at most 15 significant digits: the integer of all digits and the power of ten are both
+// exact doubles, so ONE division gives the correctly rounded value — the same double strtod returns (Clinger's fast
+// path).  Anything else (exponents, inf/nan, 16+ digits, trailing characters) goes to strtod.
+static inline double parse_double(const char* p, const char* e) {
+  static const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                    1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  const char* q = p;
+  bool neg = false;
+  if (q < e && *q == '-') { neg = true; ++q; }
+  uint64_t w = 0;
+  int sig = 0, frac = 0, digits = 0;
+  for (; q < e; ++q) {
+    const unsigned d = (unsigned)(*q - '0');
+    if (d > 9) break;
+    w = w * 10 + d;
+    sig += (sig > 0 || d != 0);
+    ++digits;
+  }
+  if (q < e && *q == '.') {
+    for (++q; q < e; ++q) {
+      const unsigned d = (unsigned)(*q - '0');
+      if (d > 9) break;
+      w = w * 10 + d;
+      sig += (sig > 0 || d != 0);
+      ++digits;
+      ++frac;
+    }
+  }
+  if (q != e || digits == 0 || sig > 15 || frac > 22 || digits > 19) return strtod_span(p, e);
+  const double v = (double)w / kPow10[frac];
+  return neg ? -v : v;
+}
+// "[-]digits", at most 18 of them
+static inline long long parse_int(const char* p, const char* e) {
+  const char* q = p;
+  bool neg = false;
+  if (q < e && *q == '-') { neg = true; ++q; }
+  const size_t n = (size_t)(e - q);
+  if (n == 0 || n > 18) return strtoll_span(p, e);
+  long long v = 0;
+  for (; q < e; ++q) {
+    const unsigned d = (unsigned)(*q - '0');
+    if (d > 9) return strtoll_span(p, e);
+    v = v * 10 + d;
+  }
+  return neg ? -v : v;
+}
+
 static void parse_slot_line(LineSpan ln, int S, int Dn, bool log1p_dense, int64_t* label, int64_t* ids,
                             float* dense) {
   bool have_label = false;
   int n_dense = 0;
   for (int s = 0; s < S; ++s) ids[s] = 0;       // padding for slots that never show up
-  std::vector<char> seen((size_t)S, 0);
+  uint64_t seen_bits = 0;                        // slots 1..64; beyond that (no such config) a heap bitmap
+  std::vector<char> seen_more;
+  if (S > 64) seen_more.assign((size_t)S, 0);
   *label = 0;
   const char* p = ln.b;
   while (p < ln.e) {
-    const char* te = (const char*)memchr(p, ' ', (size_t)(ln.e - p));
-    if (!te) te = ln.e;
-    const char* colon = (const char*)memchr(p, ':', (size_t)(te - p));
+    // one pass over the token: its end and its first ':'
+    const char* te = p;
+    const char* colon = nullptr;
+    for (; te < ln.e && *te != ' '; ++te)
+      if (*te == ':' && !colon) colon = te;
     if (colon) {
       const size_t nl = (size_t)(colon - p);
       if (nl == 5 && memcmp(p, "click", 5) == 0) {
-        if (!have_label) { *label = strtoll(colon + 1, nullptr, 10); have_label = true; }
+        if (!have_label) { *label = parse_int(colon + 1, te); have_label = true; }
       } else if (nl == 13 && memcmp(p, "dense_feature", 13) == 0) {
         if (n_dense < Dn) {
-          double v = strtod(colon + 1, nullptr);
+          double v = parse_double(colon + 1, te);
           if (log1p_dense) v = log(v + 1.0);          // dcn_v2/reader.py:63-64  np.log(feasign + 1)
           dense[n_dense++] = (float)v;
         }
@@ -128,9 +203,13 @@ static void parse_slot_line(LineSpan ln, int S, int Dn, bool log1p_dense, int64_
           if (p[i] < '0' || p[i] > '9') { digits = false; break; }
           slot = slot * 10 + (p[i] - '0');
         }
-        if (digits && slot >= 1 && slot <= S && !seen[slot - 1]) {   // first value of the slot
-          ids[slot - 1] = strtoll(colon + 1, nullptr, 10);
-          seen[slot - 1] = 1;
+        if (digits && slot >= 1 && slot <= S) {
+          const bool seen = S > 64 ? seen_more[(size_t)slot - 1] != 0 : ((seen_bits >> (slot - 1)) & 1) != 0;
+          if (!seen) {                                                   // first value of the slot
+            ids[slot - 1] = parse_int(colon + 1, te);
+            if (S > 64) seen_more[(size_t)slot - 1] = 1;
+            else seen_bits |= 1ull << (slot - 1);
+          }
         }
       }
     }
@@ -284,30 +363,43 @@ extern "C" int rec_parse_criteo_tsv(const char* buf, size_t len, int32_t n_dense
   REC_REQUIRE(max_lines == 0 || (label && ids && (n_dense == 0 || dense)), REC_EINVAL,
               "null output pointer");
   // lines are split on '\n' only: fields may be empty and are tab separated (line.rstrip('\n').split('\t'))
+  // str(idx) of every field index, once per call
+  const int n_fields = 1 + n_dense + n_sparse;
+  std::vector<char> prefix((size_t)n_fields * 12);
+  std::vector<int> prefix_len((size_t)n_fields);
+  for (int f = 0; f < n_fields; ++f)
+    prefix_len[(size_t)f] = snprintf(&prefix[(size_t)f * 12], 12, "%d", f);
   *n_lines = for_each_line(buf, len, max_lines, host_threads(threads), [&](int64_t i, LineSpan ln) {
-    thread_local std::string key;
-    {
-      const char* p = ln.b;
-      const char* e = ln.e;
-      for (int f = 0; f < 1 + n_dense + n_sparse; ++f) {
-        const char* te = (p <= e) ? (const char*)memchr(p, '\t', (size_t)(e - p)) : nullptr;
-        if (!te) te = e;
-        const size_t fl = p <= e ? (size_t)(te - p) : 0;
-        if (f == 0) {
-          label[i] = fl ? strtoll(p, nullptr, 10) : 0;
-        } else if (f <= n_dense) {
-          const int j = f - 1;     // benchmark_reader.py:44-49: "" -> 0.0 else (float(x) - min) / diff
-          double v = 0.0;
-          if (fl) v = (strtod(std::string(p, fl).c_str(), nullptr) - (double)cont_min[j]) / (double)cont_diff[j];
-          dense[i * n_dense + j] = (float)v;
+    const char* p = ln.b;
+    const char* e = ln.e;
+    for (int f = 0; f < n_fields; ++f) {
+      const char* te = p;                    // fields are a few bytes long: a byte loop beats a memchr call
+      if (p <= e) while (te < e && *te != '\t') ++te;
+      const size_t fl = p <= e ? (size_t)(te - p) : 0;
+      if (f == 0) {
+        label[i] = fl ? strtoll_span(p, te) : 0;       // int(features[0]): leading blanks and '+' allowed
+      } else if (f <= n_dense) {
+        const int j = f - 1;     // benchmark_reader.py:44-49: "" -> 0.0 else (float(x) - min) / diff
+        double v = 0.0;
+        if (fl) v = (parse_double(p, te) - (double)cont_min[j]) / (double)cont_diff[j];
+        dense[i * n_dense + j] = (float)v;
+      } else {
+        const int s = f - 1 - n_dense;   // benchmark_reader.py:50-53: xxh32(str(idx) + features[idx]) % hash_dim
+        char key[128];
+        const int pl = prefix_len[(size_t)f];
+        uint32_t h;
+        if (fl + (size_t)pl <= sizeof(key)) {
+          memcpy(key, &prefix[(size_t)f * 12], (size_t)pl);
+          memcpy(key + pl, p, fl);
+          h = rec_xxh32(key, (size_t)pl + fl, 0);
         } else {
-          const int s = f - 1 - n_dense;   // benchmark_reader.py:50-53: xxh32(str(idx) + features[idx]) % hash_dim
-          key = std::to_string(f);
-          key.append(p, fl);
-          ids[i * n_sparse + s] = (int64_t)(rec_xxh32(key.data(), key.size(), 0) % hash_dim);
+          std::string k(&prefix[(size_t)f * 12], (size_t)pl);
+          k.append(p, fl);
+          h = rec_xxh32(k.data(), k.size(), 0);
         }
-        p = te + 1;
+        ids[i * n_sparse + s] = (int64_t)(h % hash_dim);
       }
+      p = te + 1;
     }
   });
   return REC_OK;

@@ -79,6 +79,56 @@ def test_slot_text_edge_cases(reader):
     assert dense[2].tolist() == [0.5] + [0.0] * 12
 
 
+def test_number_forms_match_python(reader):
+    """The parsers' bounded fast path for "[-]digits[.digits]" and their C-library fallback give float(x) / int(x) of the
+    reference's readers for every form a field can take: short and 15/16/17-digit decimals, long fractions, exponents,
+    signs, leading zeros, '.5' / '5.', inf / nan, 18/19-digit integers — as the last token of an unterminated buffer too."""
+    rng = np.random.default_rng(5)
+    vals = ["0.0", "0.05", "0.00497512437811", "0.207421875", "94.864944714", "7.884e-06", "4.535E-05", "1e3", "-0", "-0.0",
+            ".5", "5.", "-.25", "+3.5", "00012.50", "123456789012345", "1234567890123456", "12345678901234567",
+            "0.1234567890123456789", "0.000000000000000000012345", "9007199254740993", "0.3", "2.675", "1e22", "1e23",
+            "123456789012345678901234567890", "inf", "-inf", "nan", "1.7976931348623157e308", "4.9e-324", "0.1e-1"]
+    for _ in range(400):
+        sig = int(rng.integers(1, 17))
+        digs = "".join(str(d) for d in rng.integers(0, 10, sig))
+        cut = int(rng.integers(0, sig + 1))
+        v = ("-" if rng.random() < 0.3 else "") + digs[:cut] + ("." + digs[cut:] if rng.random() < 0.8 or cut == 0 else "")
+        if v not in ("-", "", "."):
+            vals.append(v if any(c.isdigit() for c in v) else "0")
+    ints = ["0", "7", "-5", "+5", "007", "737395", "123456789012345678", "-123456789012345678", "9223372036854775807",
+            "-9223372036854775808", "1234567890123456789"]
+    lines = []
+    for i in range(0, len(vals), 13):
+        chunk = vals[i:i + 13]
+        lines.append("click:%s " % ints[(i // 13) % len(ints)] + " ".join("dense_feature:" + v for v in chunk) +
+                     " 1:" + ints[(i // 13 + 3) % len(ints)])
+    for data in (("\n".join(lines) + "\n").encode(), "\n".join(lines).encode()):      # with and without a final newline
+        buf = np.frombuffer(data, np.uint8).copy()        # exactly len(data) bytes: nothing readable behind the last token
+        label, ids, dense = reader.parse_slot_text(buf, n_sparse=1, n_dense=13, threads=2)
+        assert label.shape[0] == len(lines)
+        for r, i in enumerate(range(0, len(vals), 13)):
+            chunk = vals[i:i + 13]
+            with np.errstate(over="ignore"):
+                want = np.asarray([float(v) for v in chunk], np.float64).astype(np.float32)
+            got = dense[r, :len(chunk)].numpy()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) or \
+                np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)]), \
+                (chunk, got, want)
+            assert int(label[r]) == int(ints[(i // 13) % len(ints)])
+            assert int(ids[r, 0]) == int(ints[(i // 13 + 3) % len(ints)])
+    # the TSV parser shares the number code: dense fields through (x - min) / diff in float64, then float32
+    from paddlerec_amd.reader import CONT_MIN, CONT_DIFF
+    tsv = []
+    for i in range(0, len(vals) - 13, 13):
+        tsv.append("\t".join(["1"] + vals[i:i + 13] + ["ab%02d" % j for j in range(26)]))
+    label, ids, dense = reader.parse_criteo_tsv(np.frombuffer("\n".join(tsv).encode(), np.uint8).copy(), threads=2)
+    for r, ln in enumerate(tsv):
+        ol, oi, od = hash_ref.criteo_tsv_line(ln)
+        assert int(label[r]) == ol and np.array_equal(ids[r].numpy(), oi)
+        g, w = dense[r].numpy(), np.asarray(od, np.float32)
+        assert np.array_equal(np.isnan(g), np.isnan(w)) and np.array_equal(g[~np.isnan(g)], w[~np.isnan(w)]), ln
+
+
 def _synthetic_tsv(n, seed):
     rng = np.random.default_rng(seed)
     lines = []
