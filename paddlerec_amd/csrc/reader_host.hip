@@ -418,29 +418,33 @@ namespace rec {
 template <class F>
 static void scan_feasign_line(LineSpan ln, int first_slot, int num_slots, F&& f) {
   const char* p = ln.b;
-  while (p < ln.e) {
-    while (p < ln.e && *p == ' ') ++p;
-    if (p >= ln.e) break;
-    const char* te = (const char*)memchr(p, ' ', (size_t)(ln.e - p));
-    if (!te) te = ln.e;
-    const char* colon = (const char*)memchr(p, ':', (size_t)(te - p));
-    if (colon && colon + 1 < te) {
-      uint64_t fs = 0;
-      bool ok = colon > p;
-      for (const char* q = p; q < colon; ++q) {
-        if (*q < '0' || *q > '9') { ok = false; break; }
-        fs = fs * 10u + (uint64_t)(*q - '0');
-      }
-      long slot = 0;
-      bool sok = true;
-      for (const char* q = colon + 1; q < te; ++q) {
-        if (*q < '0' || *q > '9') { sok = false; break; }
-        slot = slot * 10 + (*q - '0');
-        if (slot > (1l << 30)) { sok = false; break; }
-      }
-      if (ok && sok && slot >= first_slot && slot < (long)first_slot + num_slots) f((int)(slot - first_slot), fs);
+  const char* const e = ln.e;
+  const long lo = first_slot, hi = (long)first_slot + num_slots;
+  while (p < e) {
+    if (*p == ' ') { ++p; continue; }
+    // one pass over the token; the only accepted form is digits ':' digits up to the next blank
+    const char* q = p;
+    uint64_t fs = 0;
+    for (; q < e; ++q) {
+      const unsigned d = (unsigned)(*q - '0');
+      if (d > 9) break;
+      fs = fs * 10u + d;
     }
-    p = te;
+    bool ok = q > p && q < e && *q == ':';
+    long slot = 0;
+    if (ok) {
+      const char* const r = ++q;
+      for (; q < e; ++q) {
+        const unsigned d = (unsigned)(*q - '0');
+        if (d > 9) break;
+        slot = slot * 10 + (long)d;
+        if (slot > (1l << 30)) { ok = false; break; }
+      }
+      ok = ok && q > r && (q == e || *q == ' ');
+    }
+    while (q < e && *q != ' ') ++q;        // the rest of a malformed token
+    if (ok && slot >= lo && slot < hi) f((int)(slot - lo), fs);
+    p = q;
   }
 }
 
@@ -499,7 +503,8 @@ extern "C" int rec_parse_feasign_slots(const char* buf, size_t len, int32_t firs
   // pass 2: fill
   for_each_line(buf, len, n, T, [&](int64_t i, LineSpan ln) {
     strip_line(ln);
-    std::vector<int32_t> cur((size_t)S, 0);
+    thread_local std::vector<int32_t> cur;        // values of this line already placed, per slot
+    cur.assign((size_t)S, 0);
     scan_feasign_line(ln, first_slot, S, [&](int s, uint64_t fs) {
       const int64_t at = slot_base[s] + lod[(size_t)s * (max_lines + 1) + i] + cur[s]++;
       // hashed table: row 0 stays the padding row, every other feasign lands in [1, hash_rows)
