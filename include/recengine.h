@@ -737,6 +737,9 @@ int rec_xxh32_hash_mod(const char* const* strings, const int32_t* field_idx, int
  *   log1p_dense = 1): "click:L dense_feature:v x13 1:id ... 26:id" per line; missing sparse slot -> id 0,
  *   missing dense slot -> zeros, first value of a repeated slot wins.  label [n], ids [n,n_sparse] i64,
  *   dense [n,n_dense] f32 (parsed as double, then cast — as float() / np.float32 do).
+ *   Number fields: "[-]digits[.digits]" with <= 15 significant digits is read as integer / 10^k (correctly rounded, the
+ *   value strtod returns), "[-]digits" ids / labels of <= 18 digits by a digit loop; every other form goes to strtod /
+ *   strtoll on a NUL-terminated copy of the field.  Only buf[0 .. len) is ever read (an mmap without a final newline is fine).
  * rec_parse_criteo_tsv: models/rank/dnn/benchmark_reader.py:39-54: "label \t 13 ints \t 26 strings";
  *   dense = (x - cont_min[j]) / cont_diff[j] ("" -> 0), ids = xxh32(str(field_idx)+string) % hash_dim with
  *   field_idx = 14..39 (the column index, as the reference hashes it).
