@@ -107,8 +107,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (OCC * WAVES_M * WAVES_N + 3
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float sink = 0.f;
-  float af[MT][4], bf[NT][4];
-  auto frags = [&](int cur) {
+  float af_keep[MT][4], bf_keep[NT][4];      // ABL 5 / 7 only: the first tile's fragments, multiplied every time
+  auto frags = [&](int cur, float (&af)[MT][4], float (&bf)[NT][4]) {
     const float* as = As + cur * A_ELEMS;
     const float* bs = Bs + cur * B_ELEMS;
 #pragma unroll
@@ -129,8 +129,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (OCC * WAVES_M * WAVES_N + 3
       for (int s_ = 0; s_ < 4; ++s_) bf[b][s_] = bs[(g * 4 + s_) * LDB_S + col];
     }
   };
-  auto compute = [&](int cur) {
-    if (!NO_FRAG) frags(cur);
+  auto mfmas = [&](float (&af)[MT][4], float (&bf)[NT][4]) {
 #pragma unroll
     for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
@@ -139,12 +138,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (OCC * WAVES_M * WAVES_N + 3
         for (int b = 0; b < NT; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][s_], bf[b][s_], acc[a][b], 0, 0, 0);
   };
+  auto compute = [&](int cur) {
+    if constexpr (NO_FRAG) {
+      mfmas(af_keep, bf_keep);
+    } else {                                   // fragments local to the tile, as in the engine's loop
+      float af[MT][4], bf[NT][4];
+      frags(cur, af, bf);
+      mfmas(af, bf);
+    }
+  };
   la.load(A, lda, lm0, k_begin, tid);
   lb.load(B, ldb, k_begin, ln0, tid);
   la.template store<false>(As, tid);
   lb.template store<TB>(Bs, tid);
   __syncthreads();
-  if (NO_FRAG) frags(0);
+  if (NO_FRAG) frags(0, af_keep, bf_keep);
   int kt = 0;
   for (; kt + 1 < nkt; ++kt) {
     if (!NO_LOAD) {
