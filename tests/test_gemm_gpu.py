@@ -191,3 +191,16 @@ def test_stream_helpers(ops):
     assert float(out.item()) == float(1 << 20)
     sp = ops.gemm(torch.ones(8, 4, device=DEV), torch.ones(8, 3, device=DEV), ops.Workspace(DEV), trans_a=True, num_cus=64)
     assert torch.equal(sp.cpu(), torch.full((4, 3), 8.0))
+
+
+def test_gemm_pipe_kernel():
+    """The opt-in interior-only kernel (REC_GEMM_PIPE=1, read once per process -> a subprocess): whole-tile shapes of the
+    256x80 and 80x80 tiles, the four epilogues it is built for, split-K and column sums, against float64."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, REC_GEMM_PIPE="1")
+    r = subprocess.run([sys.executable, os.path.join(here, "_gemm_pipe_check.py")], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "ok worst relative error" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
