@@ -246,6 +246,32 @@ def test_feasign_slots_edge_cases(reader):
                                          C.byref(nv)) == -1                       # hash_rows = 1 is meaningless
 
 
+def test_feasign_token_cache_equals_second_tokenize(reader, monkeypatch):
+    """rec_parse_feasign_slots keeps pass 1's (slot, feasign) pairs for pass 2 unless the text is huge; with the cache
+    switched off (the > 1 GiB path) it tokenizes twice.  Same values / lod / bases, any thread count, hashed or raw."""
+    rng = np.random.default_rng(12)
+    lines = []
+    for i in range(700):
+        toks = ["%d:1" % (i & 1)]
+        for s in rng.choice(np.arange(2, 40), size=int(rng.integers(0, 20)), replace=False):
+            toks += ["%d:%d" % (int(rng.integers(0, 2 ** 63)), s) for _ in range(int(rng.integers(1, 5)))]
+        if i % 50 == 7:
+            toks += ["junk", "12:", ":3", "5:x", "9:2:1", ""]
+        rng.shuffle(toks)
+        lines.append(" ".join(toks))
+    lines[100] = ""
+    data = ("\n".join(lines)).encode()
+    for threads in (1, 3):
+        for hash_rows in (0, 1000003):
+            monkeypatch.delenv("REC_FEASIGN_CACHE", raising=False)
+            a = reader.parse_feasign_slots(data, 1, 39, hash_rows, threads)
+            monkeypatch.setenv("REC_FEASIGN_CACHE", "0")
+            b = reader.parse_feasign_slots(data, 1, 39, hash_rows, threads)
+            assert a[3] == b[3] == len(lines)
+            for x, y in zip(a[:3], b[:3]):
+                assert np.array_equal(x.numpy(), y.numpy())
+
+
 def test_feasign_slot_reader_batches(reader, tmp_path):
     data = open(os.path.join(GOLDEN, "slot_dnn_demo_4.txt"), "rb").read()
     p = tmp_path / "part-0"
