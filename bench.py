@@ -173,6 +173,27 @@ class _QuietStdout:
         os.close(self.saved)
 
 
+def self_spawn(n):
+    """`python bench.py --gpus N` called plainly (no WORLD_SIZE in the environment): re-execute this same command
+    line as N ranks, one per GPU, under torch.distributed.run on 127.0.0.1 with a free port — the counterpart of the
+    reference's one-command 8-GPU launch (tools/run_gpubox.sh:21, tools/static_gpubox_trainer.py:152-160).  The
+    children inherit stdout: rank 0 prints the ONE JSON line.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["REC_BENCH_SELF_SPAWNED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,21 +221,40 @@ def main():
                     help="--table ps: table rows PER GPU (10^10 / 8 = 1.25e9 = 160 GB of 128-B records)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_spawn(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.table == "auto":
         args.table = "ps" if world > 1 else "adam"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch as `python bench.py --gpus N` (spawns its own ranks) or "
+                         "under torch.distributed.run --nproc-per-node N" % (args.gpus, world))
     # diagnostics on a one-GPU box: REC_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and REC_BENCH_BACKEND=gloo swaps the
     # transport (RCCL refuses two ranks on one device) — the N > 1 code path of this file with the real kernels; the
     # numbers of such a run mean nothing
     if os.environ.get("REC_BENCH_SHARE_GPU") == "1":
         local_rank = 0
     backend = os.environ.get("REC_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # REC_BENCH_STANDIN=1 (tests/test_bench_cli.py only): this file's launch / rank / collective logic on a box
+    # without a GPU — CPU tensors, gloo, and the tests' oracle-backed operator stand-in injected through the layer's
+    # `kernels=` argument.  The line it prints says so ("data": "cpu-standin ...") and is not a measurement.
+    standin = os.environ.get("REC_BENCH_STANDIN") == "1"
+    kernels = None
+    if standin:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        import cpu_kernels as kernels
+        backend = "gloo"
+        dev = torch.device("cpu")
+        sync = lambda: None
+    else:
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("rank %d: no GPU %d on this box (%d visible)" % (rank, local_rank,
+                                                                             torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
     dist = None
     if world > 1 or args.force_sharded or args.table == "ps":
         import torch.distributed as dist
@@ -230,8 +270,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from paddlerec_amd import _lib
-    _lib.lib()                                   # fail loudly if the HIP library is not built
+    if not standin:
+        from paddlerec_amd import _lib
+        _lib.lib()                               # fail loudly if the HIP library is not built
     B, S, Dn, D = args.batch, 26, 13, args.dim
     fc = [int(x) for x in args.fc.split(",")]
     # weak scaling: every GPU holds 26 x rows_per_table rows; the global table grows with the world
@@ -242,7 +283,7 @@ def main():
     torch.manual_seed(20250404)                  # same random-init dense weights on every run (and rank)
     if dist is None:
         from paddlerec_amd.deepfm import DeepFMLayer
-        model = DeepFMLayer(N, D, Dn, S, fc, device=dev, slot_offset=so)
+        model = DeepFMLayer(N, D, Dn, S, fc, device=dev, slot_offset=so, kernels=kernels)
         parallelism = "single"
     elif args.table == "ps":
         from paddlerec_amd.sharded import ShardedDeepFMLayer
@@ -250,11 +291,12 @@ def main():
         # embedx_threshold 0: a feature is created whole at its first pull (the full-work regime; the shipped
         # config_online.yaml gates embedx behind 10 shows)
         model = ShardedDeepFMLayer(N, D, Dn, S, fc, device=dev, group=dist.group.WORLD, table="ps",
-                                   accessor=dict(embedx_threshold=0.0), hash_keys=True)
+                                   accessor=dict(embedx_threshold=0.0), hash_keys=True, kernels=kernels)
         parallelism = "rowshard%d+dp%d (PS accessor table, hashed uint64 keys)" % (world, world)
     else:
         from paddlerec_amd.sharded import ShardedDeepFMLayer
-        model = ShardedDeepFMLayer(N, D, Dn, S, fc, device=dev, slot_offset=so, group=dist.group.WORLD)
+        model = ShardedDeepFMLayer(N, D, Dn, S, fc, device=dev, slot_offset=so, group=dist.group.WORLD,
+                                   kernels=kernels)
         parallelism = "rowshard%d+dp%d" % (world, world)
     batches = make_batches(4, B, S, Dn, args.rows_per_table * world, dev, 20250404 + rank, args.ids)
     if args.table == "ps":      # raw uint64 feasigns (as int64 bit patterns), 3 % padding id 0
@@ -271,10 +313,10 @@ def main():
         return model.train_step(ids, dense, label, lr=1e-3)
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     for i in range(args.warmup):
         step(i)
@@ -302,10 +344,12 @@ def main():
         print("host ms per step: " + " ".join("%.2f" % (1e3 * x) for x in step_host), file=sys.stderr)
     # per-region HIP-event timings (kernels_ms / host_issue_ms / in_step_event) come from a few MORE steps with the
     # event brackets switched on — outside the timed region, which therefore carries no measurement markers
-    model.timers = {}
-    for i in range(min(args.steps, 10)):
+    model.timers = None if standin else {}
+    for i in range(0 if standin else min(args.steps, 10)):
         step(first + args.steps + i)
-    torch.cuda.synchronize()
+    sync()
+    if standin:
+        model.timers = {}
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -327,7 +371,7 @@ def main():
     # The roofline kernels once more, the way rocprofv3's kernel trace sees them: back-to-back launches between
     # one pair of HIP events (no event markers / stream joins between the launches), on the step's own buffers.
     pair_us = None
-    if dist is None and hasattr(model, "time_fm_pair"):
+    if dist is None and hasattr(model, "time_fm_pair") and not standin:
         model.timers = None
         pair_us = model.time_fm_pair([(b[0], b[1]) for b in batches], repeats=20, rounds=3)
     fwd_b, bwd_b = algorithmic_bytes(B, S, Dn, D)
@@ -351,7 +395,9 @@ def main():
         "metric": "CTR samples/sec, Criteo DeepFM bs=65536 (train step: fwd+bwd+optimizer)",
         "value": world * B * args.steps / dt, "unit": "samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" if not standin else "cpu-standin (REC_BENCH_STANDIN=1: host-logic test of this file's "
+                                                "launch path on the tests' operator stand-in; NOT a measurement)",
         "config": {"workload": "DeepFM full Criteo: 26 sparse slots x %d rows x dim %d, 13 dense, "
                                "MLP %s, batch %d per GPU, lazy Adam, %s ids" % (args.rows_per_table, D, args.fc, B, args.ids)
                    + (" [ONE shared table: the reference's layout]" if args.shared_table else "")
@@ -361,7 +407,8 @@ def main():
                    "MLP %s, batch %d per GPU, AdaGrad accessor push" % (args.hashed_rows, world, D, args.fc, B),
                    "global_batch": world * B, "parallelism": parallelism, "untimed_settle_steps": settle,
                    **({"exchange": "rec_alltoall_exchange (C-ABI, RCCL)" if model.comm.native is not None
-                       else "torch.distributed (RCCL)"} if dist is not None else {}),
+                       else "torch.distributed (%s)" % ("RCCL" if backend == "nccl" else backend),
+                       "rccl_ranks": model.comm.native_ranks} if dist is not None else {}),
                    "table_rows_total": N, "loss": loss_v, "index_oob_flag": oob},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,

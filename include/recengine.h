@@ -722,6 +722,11 @@ int rec_shard_route(int64_t n, int32_t num_slots, int64_t num_rows, int64_t padd
 int rec_comm_unique_id(void* id128);
 int rec_comm_init(const void* id128, int32_t world, int32_t rank, void** comm);
 int rec_comm_destroy(void* comm);
+/* ranks of the communicator as RCCL reports them (ncclCommCount) */
+int rec_comm_size(void* comm, int32_t* world);
+/* 1 when RCCL's entry points resolve in this process (so that every rank can AGREE on the native exchange before
+ * any of them enters ncclCommInitRank), else 0; never fails */
+int rec_comm_available(void);
 int rec_alltoall_exchange(void* comm, const void* send, const int64_t* send_counts, void* recv,
                           const int64_t* recv_counts, int32_t row_bytes, void* stream);
 int rec_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);

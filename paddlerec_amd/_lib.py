@@ -132,6 +132,8 @@ SIGNATURES = {
     "rec_comm_unique_id": (C.c_int, [_P]),
     "rec_comm_init": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),
     "rec_comm_destroy": (C.c_int, [_P]),
+    "rec_comm_size": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "rec_comm_available": (C.c_int, []),
     "rec_alltoall_exchange": (C.c_int, [_P, _P, C.POINTER(_I64), _P, C.POINTER(_I64), _I32, _P]),
     "rec_allreduce_sum_f32": (C.c_int, [_P, _P, _I64, _P]),
     "rec_ps_push_rows": (C.c_int, [_I64, _I32, C.POINTER(PsLayout), _P, _P, _P, _P, C.POINTER(GradSrc),

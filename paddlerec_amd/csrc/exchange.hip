@@ -109,6 +109,20 @@ extern "C" int rec_comm_destroy(void* comm) {
   return REC_OK;
 }
 
+// Number of ranks of the communicator, as RCCL itself reports it (ncclCommCount).
+extern "C" int rec_comm_size(void* comm, int32_t* world) {
+  REC_REQUIRE(comm && world, REC_EINVAL, "bad arguments");
+  const Rccl& r = rccl();
+  REC_REQUIRE(r.ok, REC_ENCCL, "RCCL is not available in this process");
+  int w = 0;
+  if (int rc = r.comm_count(comm, &w)) return nccl_fail("ncclCommCount", rc);
+  *world = w;
+  return REC_OK;
+}
+
+// 1 when RCCL's entry points resolve in this process (rec_comm_* usable), else 0.  Never fails.
+extern "C" int rec_comm_available(void) { return rccl().ok ? 1 : 0; }
+
 // send: rows grouped by destination rank (send_counts[d] rows to rank d, ascending d); recv: rows grouped by source.
 // Counts are HOST arrays of `world` entries, in rows of row_bytes bytes.
 extern "C" int rec_alltoall_exchange(void* comm, const void* send, const int64_t* send_counts, void* recv,

@@ -41,6 +41,7 @@ class Comm:
         # (rec_alltoall_exchange / rec_allreduce_sum_f32 over an RCCL communicator created here) — what a Paddle-side
         # binder gets; torch.distributed only carries the 128-byte communicator id and the small int64 metric sums.
         self.native = None
+        self.native_ranks = 0   # ncclCommCount of the C-ABI communicator (0: exchange carried by torch.distributed)
         if not self.staged and os.environ.get("REC_NATIVE_EXCHANGE", "1") != "0":
             self._init_native()
         # ONE communicator: RCCL collectives of a communicator must execute in the same order on every rank, and
@@ -48,29 +49,61 @@ class Comm:
         # step is issued on ONE stream (the side stream) or behind a stream wait on it (see train_step).
 
     def _init_native(self):
+        """Creates the RCCL communicator of the C-ABI exchange.  Every step that can fail on ONE rank alone (RCCL not
+        resolvable by dlsym, ncclGetUniqueId) happens BEFORE an agreed all-reduce(MIN) over torch.distributed, so that
+        no rank enters ncclCommInitRank (which blocks for its peers) unless all of them will; a failure after that
+        point (communicator init, self-test) is agreed on the same way."""
         import ctypes as C
+        import sys
         from ._lib import check, lib
         dev = torch.device("cuda", torch.cuda.current_device())
+
+        def agree(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+            return int(t.item()) == 1
+
+        def warn(what, e):
+            print("[recengine] rank %d: native RCCL exchange %s FAILED (%s) - using torch.distributed's RCCL "
+                  "collectives for the exchange" % (self.rank, what, e), file=sys.stderr, flush=True)
+
         idbuf = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if self.rank == 0:
-            raw = (C.c_char * 128)()
-            check(lib().rec_comm_unique_id(C.cast(raw, C.c_void_p)), "rec_comm_unique_id")
-            idbuf.copy_(torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8))
+        ok = True
+        try:
+            if not lib().rec_comm_available():
+                raise RuntimeError("RCCL entry points do not resolve in this process")
+            if self.rank == 0:
+                raw = (C.c_char * 128)()
+                check(lib().rec_comm_unique_id(C.cast(raw, C.c_void_p)), "rec_comm_unique_id")
+                idbuf.copy_(torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8))
+        except Exception as e:
+            warn("set-up", e)
+            ok = False
+        if not agree(ok):
+            return
         self.dist.broadcast(idbuf, src=self.dist.get_global_rank(self.group, 0), group=self.group)
         raw = bytes(idbuf.cpu().numpy().tobytes())
         h = C.c_void_p()
-        check(lib().rec_comm_init(raw, self.world, self.rank, C.byref(h)), "rec_comm_init")
-        self.native = h
+        try:
+            check(lib().rec_comm_init(raw, self.world, self.rank, C.byref(h)), "rec_comm_init")
+            self.native = h
+            n = C.c_int32(0)
+            check(lib().rec_comm_size(h, C.byref(n)), "rec_comm_size")
+            self.native_ranks = int(n.value)
+            if self.native_ranks != self.world:
+                raise RuntimeError("communicator has %d ranks, group has %d" % (self.native_ranks, self.world))
+        except Exception as e:
+            warn("communicator init", e)
+            ok = False
+        if not agree(ok):       # a rank whose ncclCommInitRank failed makes every rank fall back together
+            self.native = None
+            return
         try:
             self._selftest_native(dev)
         except Exception as e:   # a broken exchange must not take the step down with it: RCCL through torch instead
-            import sys
-            print("[recengine] rank %d: native RCCL exchange self-test FAILED (%s) - using torch.distributed's RCCL "
-                  "collectives for the exchange" % (self.rank, e), file=sys.stderr, flush=True)
-            self.native = None
-        ok = torch.tensor([1 if self.native is not None else 0], dtype=torch.int64, device=dev)
-        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)    # every rank takes the same path
-        if int(ok.item()) == 0:
+            warn("self-test", e)
+            ok = False
+        if not agree(ok):
             self.native = None
 
     def _selftest_native(self, dev):

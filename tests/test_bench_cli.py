@@ -1,0 +1,65 @@
+"""bench.py's command line as the DRIVER calls it: `python bench.py --gpus N` with no
+WORLD_SIZE in the environment must spawn its own N ranks (the reference launches its 8-GPU run with one command,
+/root/reference/tools/run_gpubox.sh:21) and rank 0 must print exactly ONE JSON line with n_gpus = N.
+
+No GPU here: REC_BENCH_STANDIN=1 runs the same file on CPU tensors over gloo with the tests' operator stand-in — the
+launch, rendezvous, rank / table selection (configs[4]: the hashed PS table, row-sharded), collective order and JSON
+assembly are the code under test, not the numbers."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, extra_env=None, timeout=600):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(REC_BENCH_STANDIN="1", OMP_NUM_THREADS="1")
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must be ONE JSON line, got:\n" + r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+SMALL = ["--steps", "2", "--warmup", "1", "--batch", "64", "--fc", "16,8", "--no-cpu-baseline"]
+
+
+def test_plain_command_line_spawns_two_ranks_on_the_ps_table():
+    d = _run(["--gpus", "2"] + SMALL + ["--hashed-rows", "5000"])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["config"]["global_batch"] == 128
+    assert d["config"]["table_rows_total"] == 10000          # weak scaling: rows per GPU x world
+    assert "configs[4]" in d["config"]["workload"] and "rowshard2+dp2" in d["config"]["parallelism"]
+    assert d["config"]["exchange"].startswith("torch.distributed")      # gloo here; RCCL C-ABI on the GPU
+    assert d["config"]["index_oob_flag"] == 0
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["unit"] == "samples/s"
+    assert d["value"] > 0 and d["data"].startswith("cpu-standin")
+    assert 0.0 < d["config"]["loss"] < 5.0
+
+
+def test_plain_command_line_adam_table_two_ranks():
+    d = _run(["--gpus", "2", "--table", "adam", "--rows-per-table", "300"] + SMALL)
+    assert d["n_gpus"] == 2 and d["config"]["table_rows_total"] == 300 * 26 * 2
+    assert d["config"]["parallelism"] == "rowshard2+dp2"
+
+
+def test_single_rank_line_and_contract_keys():
+    d = _run(["--rows-per-table", "300"] + SMALL)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32"
+
+
+def test_world_size_mismatch_is_refused():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", REC_BENCH_STANDIN="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
