@@ -376,8 +376,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N +
 // unrolled by two, per-thread global and LDS offsets fixed before the loop) and the LDS stores of tile kt+1 pinned
 // inside the MFMA stream of tile kt, one ds_write per four MFMAs.  Same LDS images, fragment reads, MFMA order (every k
 // once, ascending) and epilogue as gemm_f32_kernel: results are bit-identical.
-// NOT the default: selected with REC_GEMM_PIPE=1 until the full GPU suite and the bench have run on it (a first
-// attempt that bent gemm_f32_kernel's own loop into this schedule lost the gain — tools/gemm_lab/generic_pipe.patch).
+// The default for the problems it covers since r03 (full GPU suite green with it, bench 2.82 / 2.80 -> 2.79 / 2.78 ms
+// in two alternating pairs: profiles/r03_pipe_default_ab.txt); REC_GEMM_PIPE=0 switches it off.  (A first attempt
+// that bent gemm_f32_kernel's own loop into this schedule lost the gain — tools/gemm_lab/generic_pipe.patch.)
 template <int BM, int BN, int WAVES_M, int WAVES_N, int OCC, bool TA, bool TB, int EPI>
 __global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N + 3) / 4) void gemm_f32_pipe_kernel(
     int64_t M, int N, int K, const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
@@ -893,7 +894,7 @@ static void launch_one(const rec_gemm_desc* d, const GemmPlan& p, const float* A
                             (EPI == REC_EPI_NONE || EPI == REC_EPI_BIAS || EPI == REC_EPI_BIAS_RELU ||
                              EPI == REC_EPI_RELU_MASK);
   if constexpr (kPipeCfg) {
-    static const bool pipe_env = [] { const char* v = getenv("REC_GEMM_PIPE"); return v && *v == '1'; }();
+    static const bool pipe_env = [] { const char* v = getenv("REC_GEMM_PIPE"); return !(v && *v == '0'); }();
     if (pipe_env && fast && d->m % BM == 0 && d->n % BN == 0 && d->k % kBK == 0 && d->lda < (1 << 23) &&
         d->ldb < (1 << 23)) {
       hipLaunchKernelGGL((gemm_f32_pipe_kernel<BM, BN, WM_, WN_, OCC, TA, TB, EPI>), grid, dim3(WM_ * WN_ * kWave), shmem,

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_record_kernel(
     const int64_t* __restrict__ uniq, const int32_t* __restrict__ seg_off,
     const int32_t* __restrict__ spos, const float* __restrict__ grad, rec_grad_layout gl,
     const float* __restrict__ grad1, rec_grad_layout gl1, const float* __restrict__ grad_scale,
-    float* __restrict__ rec, float* __restrict__ MV, float lr_t, float eps_t, float b1, float b2) {
+    float* __restrict__ rec, float* __restrict__ MV, float lr_t, float eps_t, float b1, float b2, int nt) {
   const int64_t u = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
   const int lg = threadIdx.x % LANES;
   const int d0 = lg * VEC;
@@ -540,9 +540,17 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_record_kernel(
       if (grad_scale) g[i] = scale_grad(g[i], sc);
       adam_elem(p[i], m[i], v[i], g[i], lr_t, eps_t, b1, b2);
     }
-    vstore<VEC>(r + d0, p);
-    vstore<VEC>(mv + d0, m);
-    vstore<VEC>(mv + v_off + d0, v);
+    // nt: the updated lines are not wanted in L2 / Infinity Cache (the next reader is some later step's gather
+    // of a random subset) — streamed out, the next kernel does not pay for evicting them (profiles/r03_fm_instep.txt)
+    if (nt) {
+      vstore_nt<VEC>(r + d0, p);
+      vstore_nt<VEC>(mv + d0, m);
+      vstore_nt<VEC>(mv + v_off + d0, v);
+    } else {
+      vstore<VEC>(r + d0, p);
+      vstore<VEC>(mv + d0, m);
+      vstore<VEC>(mv + v_off + d0, v);
+    }
   }
   if (lg == 0) {   // first-order weight + its moments: rec[D], rec[D+1], rec[D+2]
     float p1 = r[D], m1 = r[D + 1], v1 = r[D + 2];
@@ -1060,6 +1068,7 @@ extern "C" int rec_sparse_adam_record(int64_t n_max, int32_t emb_dim, int32_t re
   const bool vec = ((uintptr_t)grad) % 16 == 0 && (gl.group <= 0 || gl.group_stride % 4 == 0) &&
                    state_stride % 4 == 0 && v_offset % 4 == 0 && ((uintptr_t)rec) % 16 == 0 &&
                    ((uintptr_t)MV) % 16 == 0;
+  static const int sparse_nt = [] { const char* v = getenv("REC_SPARSE_NT"); return (v && *v) ? atoi(v) : 1; }();
   return dispatch_row_shape(emb_dim, vec ? rec_stride : rec_stride | 1, [&](auto vec_, auto lanes) -> int {
     constexpr int VEC = decltype(vec_)::value, LANES = decltype(lanes)::value;
     const int64_t grid = (n_max * LANES + kBlock - 1) / kBlock;
@@ -1067,7 +1076,7 @@ extern "C" int rec_sparse_adam_record(int64_t n_max, int32_t emb_dim, int32_t re
     hipLaunchKernelGGL((sparse_adam_record_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock), 0,
                        (hipStream_t)stream, emb_dim, rec_stride, state_stride, v_offset, n_uniq, uniq_rows,
                        seg_offset, sorted_pos, grad, gl, grad1, gl1, grad_scale, rec, MV, lr_t, eps_t,
-                       hyper->beta1, hyper->beta2);
+                       hyper->beta1, hyper->beta2, sparse_nt);
     return check_launch("rec_sparse_adam_record");
   });
 }
