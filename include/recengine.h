@@ -123,9 +123,10 @@ int rec_emb_gather_sumpool(int64_t batch, int32_t emb_dim, int32_t row_stride, i
                            int64_t padding_idx, const int64_t* ids, const int64_t* lod /*[B+1]*/,
                            const float* W, float* out, int32_t* counts, int32_t* status,
                            void* stream);
-/* What an unborn row of a lazily created PS table reads as (rec_ps_push_rows gives birth with the same values):
- * element 0 (embed_w) always, elements 1.. (embedx) when init_dims > 1; keyed by (seed, row*row_mul+row_add, d).
- * init_range <= 0: rows are plain memory. */
+/* What an unborn row of a lazily created PS table reads as when the accessor does NOT zero-initialise embed_w
+ * (rec_ps_accessor.embed_zero_init = 0; rec_ps_push_rows gives birth with the same values): element 0 (embed_w)
+ * always, elements 1.. when init_dims > 1; keyed by (seed, row*row_mul+row_add, d).
+ * init_range <= 0 (Paddle's default, zero_init): rows are plain memory — an unborn row reads as zeros. */
 typedef struct {
   int32_t state_offset; /* floats from the row start to the state float (0 = unborn) */
   int32_t init_dims;
@@ -301,23 +302,42 @@ int rec_sparse_adagrad_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride, 
 /* ------------------------------------------------------------------------------------------
  * The full table accessor of the PS / gpubox mode (slot_dnn/config_online.yaml:57-89: SparseAccessor with
  * embedx_threshold, SparseAdaGradSGDRule for embed_w and embedx, ctr_accessor_param; slot_dnn/net.py:61-62
- * ShowClickEntry; tools/static_gpubox_trainer.py:152-160).  A feature value lives in one record row; the
- * layout says where its parts are (floats from the row start), so DeepFM (embedx = the 16-dim embedding at 0,
- * embed_w = the first-order weight behind it) and slot_dnn (W = [embed_w, embedx(8)]) use the same kernels:
- *   stat_off: show, click, embed_g2sum, embedx_g2sum, state   (5 consecutive floats;
- *             state 0 = unborn (zeroed memory), 1 = embed_w exists, 2 = embedx exists too)
- * rec_ps_push_rows = CtrCommonAccessor::Update [EXT] on the touched rows (merge of duplicate gradients fused in,
- * ascending position order): counters, AdaGrad rule per part, lazy birth (uniform(+-initial_range), a pure
- * function of (seed,row,element): the same values rec_multislot_sumpool_fwd shows for an unborn row), embedx
- * creation once (show-click)*nonclk_coeff + click*click_coeff >= embedx_threshold (its gradient is dropped
- * until then).  show / click: per-SAMPLE int64 [B] (NULL: 1 per occurrence / 0); num_slots maps a lookup
- * position to its sample.  rec_ps_shrink_rows = the end-of-pass Shrink: counters decay, rows whose score fell
- * below delete_threshold are zeroed (unborn again); n_deleted (device int64 or NULL) counts them.
+ * ShowClickEntry; tools/static_gpubox_trainer.py:152-160).  The arithmetic follows the published source of
+ * PaddlePaddle release/2.4 [EXT] — paddle/fluid/distributed/ps/table/{sparse_sgd_rule.cc, ctr_accessor.cc,
+ * memory_sparse_table.cc} and framework/fleet/heter_ps/optimizer.cuh.h — quoted in oracle/ps_ref.py.
+ * A feature value lives in one record row; the layout says where its parts are (floats from the row start), so
+ * DeepFM (embedx = the 16-dim embedding at 0, embed_w = the first-order weight behind it) and slot_dnn
+ * (W = [embed_w, embedx(8)]) use the same kernels:
+ *   stat_off: show, click, embed_g2sum, embedx_g2sum, state, delta_score, unseen_days   (7 consecutive floats;
+ *             state 0 = no such key (zeroed memory: reads as embed_w = 0, embedx = 0, what PullSparse returns
+ *             for a missing key), 1 = value without its embedx part, 2 = embedx exists)
+ * rec_ps_push_rows = MemorySparseTable::PushSparse + CtrCommonAccessor::Update on the touched rows (merge of
+ *   duplicate gradients fused in, ascending position order): a new key is created without embedx (embed_w = 0 when
+ *   embed_zero_init, else uniform(+-initial_range)); show / click / delta_score / unseen_days; then
+ *   SparseAdaGradSGDRule::UpdateValueWork on embed_w and (if it exists) embedx:
+ *       double scaled = g * grad_scale / (show_scale ? pushed_show : 1);
+ *       w = clip(float(w - lr * scaled * sqrtf(g0 / (g0 + g2sum))));  g2sum = float(g2sum + sum(scaled^2) / n)
+ *   a value without embedx drops its embedx gradient and is extended (uniform(+-x_initial_range), a pure function
+ *   of (seed,row,element); embedx_g2sum = 0) at the end of the push after which
+ *   (show-click)*nonclk_coeff + click*click_coeff >= embedx_threshold (NeedExtendMF on the updated counters).
+ *   show / click: per-SAMPLE int64 [B] (NULL: 1 per occurrence / 0); num_slots maps a lookup position to its
+ *   sample.
+ * rec_ps_shrink_rows = CtrCommonAccessor::Shrink over the table: counters decay, values whose score fell below
+ *   delete_threshold or with unseen_days > delete_after_unseen_days are zeroed (the key is gone); n_deleted
+ *   (device int64 or NULL) counts them.
+ * rec_ps_save_select = Save(value, param) + UpdateStatAfterSave(value, param) for every row: selected[row]
+ *   (device bytes or NULL) = 1 if a save of kind param writes the value — 0: all; 1 (delta) / 2 (base): score >=
+ *   base_threshold && delta_score >= delta_threshold (0 for base) && unseen_days <= delta_keep_days, delta_score of
+ *   the selected values reset; 3: all, and unseen_days += 1 (a day passes).
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
-  float lr, initial_g2sum, min_bound, max_bound; /* SparseAdaGradSGDRule (embed and embedx share them) */
-  float initial_range;
+  float lr, initial_g2sum, min_bound, max_bound, initial_range;           /* embed_sgd_param  (embed_w)  */
+  float x_lr, x_initial_g2sum, x_min_bound, x_max_bound, x_initial_range; /* embedx_sgd_param (embedx)   */
   float embedx_threshold, nonclk_coeff, click_coeff;
+  float grad_scale;        /* pushed gradient = merged gradient * grad_scale (Paddle pushes the gradient of the SUMMED
+                              loss: scale_sparse_gradient_with_batch_size / PushCopy's `* bs`); 1 = as given */
+  int32_t show_scale;      /* 1 (Paddle's default): the rule divides the pushed gradient by the pushed show */
+  int32_t embed_zero_init; /* 1 (Paddle's default): embed_w of a new value is 0; 0: uniform(+-initial_range) */
   uint64_t seed;
   int64_t row_mul, row_add; /* identity of table row r in the creation values: r * row_mul + row_add (a shard
                                passes {world, rank}: a feature is born with the same values however the table
@@ -339,8 +359,11 @@ int rec_ps_push_rows(int64_t n_max, int32_t num_slots, const rec_ps_layout* layo
 /* host: the creation value of element `element` (0 = embed_w, 1+j = embedx[j]) of feature `row` */
 float rec_ps_init_value_host(uint64_t seed, int64_t row, int32_t element, float initial_range);
 int rec_ps_shrink_rows(int64_t num_rows, const rec_ps_layout* layout, float* rec, float show_click_decay_rate,
-                       float delete_threshold, const rec_ps_accessor* accessor, int64_t* n_deleted,
-                       void* stream);
+                       float delete_threshold, float delete_after_unseen_days, const rec_ps_accessor* accessor,
+                       int64_t* n_deleted, void* stream);
+int rec_ps_save_select(int64_t num_rows, const rec_ps_layout* layout, float* rec, int32_t param,
+                       float base_threshold, float delta_threshold, float delta_keep_days,
+                       const rec_ps_accessor* accessor, uint8_t* selected, int64_t* n_selected, void* stream);
 
 /* paddle.optimizer.SGD [EXT] (din/dygraph_model.py:64-73): p -= lr * g.  Rows whose gradient is zero do
  * not move, so updating the merged rows of a SelectedRows gradient equals the dense update. */

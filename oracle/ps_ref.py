@@ -1,12 +1,72 @@
-"""NumPy restatement of the PS / gpubox sparse path (oracle — test infrastructure only).
+"""NumPy restatement of the PS / gpubox sparse table accessor (oracle — test infrastructure only).
 
-Reference call sites: models/rank/dnn/net.py:67-82 (sparse_embedding(size=[N, D+2]) +
-continuous_value_model(emb, show_click, use_cvm=False)), dnn/static_model.py:86-94 (show = ones, click =
-label), slot_dnn/config_online.yaml:57-79 (SparseAdaGradSGDRule lr 0.05, initial_g2sum 3.0, bounds +-10).
-The accessor arithmetic itself is in the un-vendored PaddlePaddle PS code — **parity unpinned**; the
-formula is the one fixed by SURVEY.md App. B-13.
+Reference call sites in /root/reference (configuration only — the arithmetic is NOT in that tree):
+  models/rank/slot_dnn/config_online.yaml:57-89   accessor_class "SparseAccessor", fea_dim 11, embedx_dim 8,
+      embedx_threshold 10, embed_sgd_param / embedx_sgd_param "SparseAdaGradSGDRule" (learning_rate 0.05,
+      initial_g2sum 3.0, initial_range 1e-4, weight_bounds +-10), ctr_accessor_param (nonclk_coeff 0.1, click_coeff 1,
+      base_threshold 1.5, delta_threshold 0.25, delta_keep_days 16, show_click_decay_rate 0.98, delete_threshold 0.8,
+      delete_after_unseen_days 30)
+  models/rank/dnn/net.py:67-82, dnn/static_model.py:86-94   sparse_embedding(size=[N, D+2]) + continuous_value_model,
+      show = ones, click = label
+  tools/static_gpubox_trainer.py:152-160,256       the table lives in the GPU parameter server (core.PSGPU)
+
+The accessor itself is third-party code of the un-vendored dependency **PaddlePaddle** (README_EN.md:46,55 pins only
+">= 2.0"; the PS classes named by the YAML exist from release/2.3 on).  This file restates the PUBLISHED source of
+PaddlePaddle release/2.4 (github.com/PaddlePaddle/Paddle, tag v2.4.2):
+  paddle/fluid/distributed/ps/table/sparse_sgd_rule.cc
+      SparseAdaGradSGDRule::UpdateValueWork(w, sgd, grad, scale):
+          float& g2sum = sgd[G2SumIndex()];  double add_g2sum = 0;
+          for i < dim:  double scaled_grad = grad[i] / scale;
+                        w[i] -= learning_rate_ * scaled_grad * sqrt(_initial_g2sum / (_initial_g2sum + g2sum));
+                        BoundValue(w[i]);  add_g2sum += scaled_grad * scaled_grad;
+          g2sum += add_g2sum / dim;
+      SparseAdaGradSGDRule::InitValueWork(value, sgd, zero_init):
+          value[i] = zero_init ? 0 : (uniform_real<double>() * 2 - 1) * _initial_range;  BoundValue;  sgd[g2sum] = 0
+  paddle/fluid/distributed/ps/table/ctr_accessor.cc  (sparse_accessor.cc: the same Create / Update / Shrink / Save with
+      its own value struct)
+      Create:  unseen_days = delta_score = show = click = 0, slot = -1,
+               _embed_sgd_rule->InitValue(embed_w, embed_g2sum)  [zero_init defaults to true: embed_w = 0],
+               _embedx_sgd_rule->InitValue(embedx_w, embedx_g2sum, false)  [uniform(+-initial_range)]
+      Update:  show += push_show; click += push_click; slot = push_slot;
+               delta_score += (push_show - push_click) * nonclk_coeff + push_click * click_coeff;  unseen_days = 0;
+               _embed_sgd_rule->UpdateValue(embed_w, embed_g2sum, push_embed_g, push_show)      [show_scale]
+               _embedx_sgd_rule->UpdateValue(embedx_w, embedx_g2sum, push_embedx_g, push_show)
+      NeedExtendMF:  (show - click) * nonclk_coeff + click * click_coeff >= embedx_threshold
+      Shrink:  show *= show_click_decay_rate; click *= decay;
+               delete if ShowClickScore(show, click) < delete_threshold || unseen_days > delete_after_unseen_days
+      Save(param): 0 all; 1 (delta) / 2 (base): ShowClickScore >= base_threshold && delta_score >= delta_threshold
+               (0 for param 2) && unseen_days <= delta_keep_days; 3 all
+      UpdateStatAfterSave(param): 1: delta_score = 0 on the rows Save(1) selected; 3: unseen_days++
+  paddle/fluid/distributed/ps/table/memory_sparse_table.cc
+      PullSparse: a missing key is created WITHOUT its embedx part and reads as embed_w = 0, embedx = 0;
+      PushSparse: a value without embedx is updated (its embedx gradient is dropped), then extended
+               (embedx = uniform, embedx_g2sum = 0) when NeedExtendMF holds on the UPDATED counters.
+  paddle/fluid/framework/fleet/heter_ps/optimizer.cuh.h  (the gpubox path of tools/static_gpubox_trainer.py):
+      SparseAdagradOptimizer::update_value_work / dy_mf_update_value — the same rule (double scaled_grad = g / g_show,
+      ratio = lr * sqrt(g0 / (g0 + g2sum)), bounds, g2sum += add / n), embedx created inside the push once the score
+      reaches mf_create_thresholds.
+  The pushed gradient is the gradient of the SUMMED loss: the trainer multiplies by the batch size before the push
+  (heter_ps feature_value.cu PushCopy: `* -1. * bs`; CPU workers: scale_sparse_gradient_with_batch_size = true) —
+  `grad_scale` below — and the rule divides it by the pushed show (= occurrences of the key in the batch).
+
+**Parity unpinned**: Paddle is not installable here and /root/reference holds no expected values for this path, so
+this restatement is anchored on the published source text above and on hand-computed known answers
+(tests/test_ps_accessor_kat.py), not on outputs of the reference.  Deliberate, stated differences:
+  * creation values are a counter-based function of (seed, row, element) instead of Paddle's unseeded thread-local
+    engine (not reproducible between two Paddle runs either); distribution uniform(+-initial_range) as in
+    sparse_sgd_rule.cc (heter_ps draws curand_uniform * range, i.e. (0, range]);
+  * `slot` (an annotation for the save converter, no arithmetic) is not stored;
+  * push_show = 0 (cannot happen: every occurrence carries show >= 1) divides by 1 instead of 0.
+Arithmetic: exactly the typed evaluation of the C++ text — `_initial_g2sum / (_initial_g2sum + g2sum)` and its sqrt in
+float (all operands are float), scaled_grad, the product with the learning rate and add_g2sum in double, `w[i] -=` and
+`g2sum +=` rounded to float on store.
 """
 import numpy as np
+
+# statistics of a feature value, consecutive floats at lay["stat_off"]
+SHOW, CLICK, G2SUM_W, G2SUM_X, STATE, DELTA_SCORE, UNSEEN_DAYS = range(7)
+NUM_STATS = 7
+# STATE: 0 = no such key (zero memory), 1 = value without its embedx part, 2 = embedx exists
 
 
 def cvm_lookup(rec, ids, D, padding_idx=None):
@@ -18,7 +78,8 @@ def cvm_lookup(rec, ids, D, padding_idx=None):
 
 
 def adagrad_rows(rec, D, uniq, merged, shows, clicks, lr=0.05, initial_g2sum=3.0, bounds=(-10.0, 10.0)):
-    """In place on rec [N, stride] rows `uniq` with merged gradients [U,D], show/click increments [U]."""
+    """rec_sparse_adagrad_rows (the r01 CVM-record rule, kept for its kernel): in place on rec [N, stride] rows `uniq`
+    with merged gradients [U,D], show/click increments [U]; float arithmetic, no show scaling."""
     f = np.float32
     for u, row in enumerate(uniq):
         r = rec[row]
@@ -39,11 +100,6 @@ def adagrad_rows(rec, D, uniq, merged, shows, clicks, lr=0.05, initial_g2sum=3.0
             r[3] = g2x + acc / f(D - 1)
 
 
-# ------------------------------------------------------------------------------------------------
-# The full accessor (slot_dnn/config_online.yaml:57-89): lazy birth, embedx_threshold, shrink.
-# Restated from the published behaviour of Paddle's CtrCommonAccessor / SparseAdaGradSGDRule [EXT] — parity
-# unpinned (no reference source or vector exists in /root/reference); the engine's kernels are held to THIS text.
-# ------------------------------------------------------------------------------------------------
 _M64 = (1 << 64) - 1
 
 
@@ -58,100 +114,151 @@ def _mix64(k):
 
 
 def init_value(seed, row, d, rng_range):
-    """Creation value of element d of feature `row` (uniform(+-range), counter based): element 0 = embed_w,
-    element 1+j = embedx[j]."""
+    """Creation value of element d of feature `row` (uniform(+-range), counter based): element 0 = embed_w (used only
+    when the accessor is configured with embed_zero_init = False), element 1+j = embedx[j]."""
     h = _mix64(seed ^ _mix64((int(row) * 0x9E3779B97F4A7C15 + (d + 1)) & _M64))
     u = np.float32(h >> 40) * np.float32(1.0 / 16777216.0)
     return (np.float32(2.0) * u - np.float32(1.0)) * np.float32(rng_range)
 
 
+def _rule(acc, part):
+    """(lr, initial_g2sum, lo, hi, initial_range) of embed_sgd_param / embedx_sgd_param; embedx_* keys default to the
+    embed ones (config_online.yaml gives both rules the same numbers)."""
+    p = "embedx_" if part == "embedx" else ""
+    g = lambda k: acc.get(p + k, acc[k])
+    b = g("bounds")
+    return np.float32(g("lr")), np.float32(g("initial_g2sum")), np.float32(b[0]), np.float32(b[1]), g("initial_range")
+
+
+def update_value_work(w, g2sum, grad, scale, lr, g0, lo, hi):
+    """SparseAdaGradSGDRule::UpdateValueWork.  w: float32 array (updated in place); g2sum: float32 scalar;
+    grad: the pushed gradient (float32); scale: the pushed show.  -> new g2sum (float32)."""
+    ratio = np.float64(np.sqrt(np.float32(g0) / (np.float32(g0) + np.float32(g2sum))))     # float expression
+    add = np.float64(0.0)
+    for i in range(len(w)):
+        sg = np.float64(grad[i]) / np.float64(scale)
+        w[i] = np.float32(np.float64(w[i]) - np.float64(lr) * sg * ratio)
+        w[i] = min(max(w[i], lo), hi)
+        add += sg * sg
+    return np.float32(np.float64(g2sum) + add / np.float64(len(w)))
+
+
+def score(show, click, acc):
+    f = np.float32
+    return (f(show) - f(click)) * f(acc["nonclk_coeff"]) + f(click) * f(acc["click_coeff"])
+
+
 def push_rows(rec, lay, uniq, g_embed, g_embedx, dshow, dclick, acc):
-    """CtrCommonAccessor::Update on rows `uniq` of rec [N, stride] (in place).
+    """MemorySparseTable::PushSparse + CtrCommonAccessor::Update on rows `uniq` of rec [N, stride] (in place).
     lay = dict(embed_off, embedx_off, embedx_dim, stat_off); acc = dict(lr, initial_g2sum, bounds, initial_range,
-    embedx_threshold, nonclk_coeff, click_coeff, seed); g_embed [U], g_embedx [U, Dx] merged gradients."""
+    [embedx_lr, embedx_initial_g2sum, embedx_bounds, embedx_initial_range,] embedx_threshold, nonclk_coeff,
+    click_coeff, seed, [show_scale = True, grad_scale = 1.0, embed_zero_init = True, row_mul, row_add]);
+    g_embed [U], g_embedx [U, Dx]: gradients merged over the key's occurrences (float32 sums in ascending position);
+    dshow / dclick [U]: pushed show / click."""
     f = np.float32
     Dx, eo, xo, so = lay["embedx_dim"], lay["embed_off"], lay["embedx_off"], lay["stat_off"]
-    g0, lr = f(acc["initial_g2sum"]), f(acc["lr"])
-    lo, hi = f(acc["bounds"][0]), f(acc["bounds"][1])
+    lr_w, g0_w, lo_w, hi_w, range_w = _rule(acc, "embed")
+    lr_x, g0_x, lo_x, hi_x, range_x = _rule(acc, "embedx")
     mul, add = int(acc.get("row_mul", 1)), int(acc.get("row_add", 0))   # identity of a shard's row: row*mul + add
+    gs = np.float64(acc.get("grad_scale", 1.0))
     for u, row in enumerate(uniq):
         r = rec[row]
-        row = int(row) * mul + add
-        show0, click0, g2w, g2x, state = r[so], r[so + 1], r[so + 2], r[so + 3], r[so + 4]
-        score0 = (show0 - click0) * f(acc["nonclk_coeff"]) + click0 * f(acc["click_coeff"])
-        unborn = state == 0
-        has_x = state >= 2 or (unborn and score0 >= f(acc["embedx_threshold"]))
-        if unborn:                                    # the pull of this step created the feature
-            r[eo] = init_value(acc["seed"], row, 0, acc["initial_range"])
+        grow = int(row) * mul + add
+        st = r[so:so + NUM_STATS]
+        if st[STATE] == 0:                       # Create: a value without embedx; counters, g2sums, embedx stay 0
+            r[eo] = f(0) if acc.get("embed_zero_init", True) else init_value(acc["seed"], grow, 0, range_w)
+            st[STATE] = f(1)
+        push_show, push_click = f(dshow[u]), f(dclick[u])
+        st[SHOW] += push_show
+        st[CLICK] += push_click
+        st[DELTA_SCORE] += (push_show - push_click) * f(acc["nonclk_coeff"]) + push_click * f(acc["click_coeff"])
+        st[UNSEEN_DAYS] = f(0)
+        scale = np.float64(push_show) if (acc.get("show_scale", True) and push_show > 0) else np.float64(1.0)
+        # the pushed gradient = merged gradient x grad_scale (the batch size: gradient of the SUMMED loss), kept in
+        # double: scaled_grad = g * grad_scale / push_show
+        ew = r[eo:eo + 1]
+        st[G2SUM_W] = update_value_work(ew, st[G2SUM_W], [np.float64(g_embed[u]) * gs], scale, lr_w, g0_w, lo_w, hi_w)
+        if st[STATE] >= 2:
+            gx = np.asarray(g_embedx[u], np.float64) * gs
+            xw = r[xo:xo + Dx]
+            st[G2SUM_X] = update_value_work(xw, st[G2SUM_X], gx, scale, lr_x, g0_x, lo_x, hi_x)
+        elif Dx > 0 and score(st[SHOW], st[CLICK], acc) >= f(acc["embedx_threshold"]):   # NeedExtendMF on the UPDATED value
             for j in range(Dx):
-                r[xo + j] = init_value(acc["seed"], row, 1 + j, acc["initial_range"]) if has_x else f(0)
-        show1, click1 = show0 + f(dshow[u]), click0 + f(dclick[u])
-        gw = f(g_embed[u])
-        r[eo] = np.clip(r[eo] - lr * gw * np.sqrt(g0 / (g0 + g2w)), lo, hi)
-        r[so + 2] = g2w + gw * gw
-        if has_x:
-            gx = g_embedx[u].astype(f)
-            r[xo:xo + Dx] = np.clip(r[xo:xo + Dx] - lr * gx * np.sqrt(g0 / (g0 + g2x)), lo, hi)
-            acc_sq = f(0)
-            for j in range(Dx):
-                acc_sq = acc_sq + gx[j] * gx[j]
-            r[so + 3] = g2x + acc_sq / f(Dx)
-        r[so], r[so + 1] = show1, click1
-        score1 = (show1 - click1) * f(acc["nonclk_coeff"]) + click1 * f(acc["click_coeff"])
-        if not has_x and score1 >= f(acc["embedx_threshold"]):   # the next pull would extend the value
-            for j in range(Dx):
-                r[xo + j] = init_value(acc["seed"], row, 1 + j, acc["initial_range"])
-            has_x = True
-        r[so + 4] = f(2.0) if has_x else f(1.0)
+                r[xo + j] = min(max(init_value(acc["seed"], grow, 1 + j, range_x), lo_x), hi_x)
+            st[G2SUM_X] = f(0)
+            st[STATE] = f(2)
 
 
 def pull_value(rec, lay, row, acc, D_lookup):
-    """What a lookup of `row` returns for the slot layout (W = [embed_w, embedx...]): an unborn row reads as its
-    creation values (embedx only if the threshold allows creation at score 0)."""
+    """What a lookup of `row` returns for the slot layout (W = [embed_w, embedx...]) — PullSparse + Select: the stored
+    floats; a missing key reads as zeros (embed_zero_init = False: embed_w reads as its creation value, which the
+    first push then stores)."""
     r = rec[row]
-    if r[lay["stat_off"] + 4] != 0:
-        return r[lay["embed_off"]:lay["embed_off"] + D_lookup].copy()
-    row = int(row) * int(acc.get("row_mul", 1)) + int(acc.get("row_add", 0))
-    dims = D_lookup if acc["embedx_threshold"] <= 0 else 1
-    return np.array([init_value(acc["seed"], row, d, acc["initial_range"]) if d < dims else np.float32(0)
-                     for d in range(D_lookup)], np.float32)
-
-
-def shrink_rows(rec, lay, acc, decay, delete_threshold):
-    """Shrink: decay the counters of every born row; delete (zero) rows whose score fell below the threshold."""
-    f = np.float32
-    so = lay["stat_off"]
-    deleted = 0
-    for row in range(rec.shape[0]):
-        r = rec[row]
-        if r[so + 4] == 0:
-            continue
-        show, click = r[so] * f(decay), r[so + 1] * f(decay)
-        score = (show - click) * f(acc["nonclk_coeff"]) + click * f(acc["click_coeff"])
-        if score < f(delete_threshold):
-            r[lay["embed_off"]] = 0
-            r[lay["embedx_off"]:lay["embedx_off"] + lay["embedx_dim"]] = 0
-            r[so:so + 5] = 0
-            deleted += 1
-        else:
-            r[so], r[so + 1] = show, click
-    return deleted
+    out = r[lay["embed_off"]:lay["embed_off"] + D_lookup].copy()
+    if r[lay["stat_off"] + STATE] == 0 and not acc.get("embed_zero_init", True):
+        g = int(row) * int(acc.get("row_mul", 1)) + int(acc.get("row_add", 0))
+        out[0] = init_value(acc["seed"], g, 0, _rule(acc, "embed")[4])
+    return out
 
 
 def pull_deepfm(rec, lay, rows, acc):
     """Lookup of the 'deepfm' record layout (embedx = the D-dim embedding, embed_w = the first-order weight):
-    -> (W [n, Dx], W1 [n]); unborn rows read as their creation values."""
+    -> (W [n, Dx], W1 [n])."""
     Dx, eo, xo, so = lay["embedx_dim"], lay["embed_off"], lay["embedx_off"], lay["stat_off"]
     mul, add = int(acc.get("row_mul", 1)), int(acc.get("row_add", 0))
     W = np.zeros((len(rows), Dx), np.float32)
     W1 = np.zeros(len(rows), np.float32)
     for i, row in enumerate(rows):
         r = rec[int(row)]
-        if r[so + 4] != 0:
-            W[i], W1[i] = r[xo:xo + Dx], r[eo]
-        else:
-            g = int(row) * mul + add
-            W1[i] = init_value(acc["seed"], g, 0, acc["initial_range"])
-            if acc["embedx_threshold"] <= 0:
-                W[i] = [init_value(acc["seed"], g, 1 + j, acc["initial_range"]) for j in range(Dx)]
+        W[i], W1[i] = r[xo:xo + Dx], r[eo]
+        if r[so + STATE] == 0 and not acc.get("embed_zero_init", True):
+            W1[i] = init_value(acc["seed"], int(row) * mul + add, 0, _rule(acc, "embed")[4])
     return W, W1
+
+
+def shrink_rows(rec, lay, acc, decay, delete_threshold, delete_after_unseen_days=np.inf):
+    """CtrCommonAccessor::Shrink over the table: decay the counters of every existing value; delete (zero) those whose
+    score fell below delete_threshold or that were not seen for more than delete_after_unseen_days.  -> number deleted."""
+    f = np.float32
+    so = lay["stat_off"]
+    deleted = 0
+    for row in range(rec.shape[0]):
+        r = rec[row]
+        st = r[so:so + NUM_STATS]
+        if st[STATE] == 0:
+            continue
+        show, click = st[SHOW] * f(decay), st[CLICK] * f(decay)
+        if score(show, click, acc) < f(delete_threshold) or st[UNSEEN_DAYS] > f(delete_after_unseen_days):
+            r[lay["embed_off"]] = 0
+            r[lay["embedx_off"]:lay["embedx_off"] + lay["embedx_dim"]] = 0
+            st[:] = 0
+            deleted += 1
+        else:
+            st[SHOW], st[CLICK] = show, click
+    return deleted
+
+
+def save_select(rec, lay, acc, param, base_threshold=1.5, delta_threshold=0.25, delta_keep_days=16.0):
+    """CtrCommonAccessor::Save(value, param) for every row -> bool mask of the rows a save of this kind writes, then
+    UpdateStatAfterSave(value, param) applied in place (1: delta_score = 0 on the selected rows; 2: delta_score = 0 on
+    the selected rows [done by Save itself in the C++]; 3: unseen_days += 1 on every existing row)."""
+    f = np.float32
+    so = lay["stat_off"]
+    N = rec.shape[0]
+    mask = np.zeros(N, bool)
+    for row in range(N):
+        st = rec[row, so:so + NUM_STATS]
+        if st[STATE] == 0:
+            continue
+        if param in (1, 2):
+            dth = f(0) if param == 2 else f(delta_threshold)
+            ok = (score(st[SHOW], st[CLICK], acc) >= f(base_threshold) and st[DELTA_SCORE] >= dth
+                  and st[UNSEEN_DAYS] <= f(delta_keep_days))
+            mask[row] = ok
+            if ok:
+                st[DELTA_SCORE] = f(0)
+        else:
+            mask[row] = True
+            if param == 3:
+                st[UNSEEN_DAYS] += f(1)
+    return mask

@@ -42,8 +42,12 @@ class CinView(C.Structure):
 
 class PsAccessor(C.Structure):
     _fields_ = [("lr", C.c_float), ("initial_g2sum", C.c_float), ("min_bound", C.c_float), ("max_bound", C.c_float),
-                ("initial_range", C.c_float), ("embedx_threshold", C.c_float), ("nonclk_coeff", C.c_float),
-                ("click_coeff", C.c_float), ("seed", C.c_uint64), ("row_mul", C.c_int64), ("row_add", C.c_int64)]
+                ("initial_range", C.c_float),
+                ("x_lr", C.c_float), ("x_initial_g2sum", C.c_float), ("x_min_bound", C.c_float),
+                ("x_max_bound", C.c_float), ("x_initial_range", C.c_float),
+                ("embedx_threshold", C.c_float), ("nonclk_coeff", C.c_float), ("click_coeff", C.c_float),
+                ("grad_scale", C.c_float), ("show_scale", C.c_int32), ("embed_zero_init", C.c_int32),
+                ("seed", C.c_uint64), ("row_mul", C.c_int64), ("row_add", C.c_int64)]
 
 
 class LazyInit(C.Structure):
@@ -139,7 +143,9 @@ SIGNATURES = {
     "rec_ps_push_rows": (C.c_int, [_I64, _I32, C.POINTER(PsLayout), _P, _P, _P, _P, C.POINTER(GradSrc),
                                    C.POINTER(GradSrc), _P, _P, _P, C.POINTER(PsAccessor), _P]),
     "rec_ps_init_value_host": (C.c_float, [C.c_uint64, _I64, _I32, _F]),
-    "rec_ps_shrink_rows": (C.c_int, [_I64, C.POINTER(PsLayout), _P, _F, _F, C.POINTER(PsAccessor), _P, _P]),
+    "rec_ps_shrink_rows": (C.c_int, [_I64, C.POINTER(PsLayout), _P, _F, _F, _F, C.POINTER(PsAccessor), _P, _P]),
+    "rec_ps_save_select": (C.c_int, [_I64, C.POINTER(PsLayout), _P, _I32, _F, _F, _F, C.POINTER(PsAccessor), _P, _P,
+                                     _P]),
     "rec_sparse_adagrad_rows": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
                                           _P, C.POINTER(AdagradHyper), _P]),
     "rec_adam_rows_all": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,

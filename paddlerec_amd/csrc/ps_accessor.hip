@@ -1,29 +1,31 @@
-// PS / gpubox table accessor on the device (gfx950): push (update) and shrink of CTR feature values.
+// PS / gpubox table accessor on the device (gfx950): push (Update), Shrink, Save selection of CTR feature values.
 //
-// Reference (the rule is configured in the repo, its arithmetic lives in the un-vendored Paddle PS code [EXT]):
+// Reference configuration (the arithmetic lives in the un-vendored PaddlePaddle PS code [EXT]):
 //   /root/reference/models/rank/slot_dnn/config_online.yaml:57-89
 //       accessor_class SparseAccessor, fea_dim 11 = show, click, embed_w + embedx(8), embedx_threshold 10,
 //       embed_sgd_param / embedx_sgd_param = SparseAdaGradSGDRule(lr 0.05, initial_g2sum 3, initial_range 1e-4,
-//       weight_bounds +-10), ctr_accessor_param(nonclk_coeff 0.1, click_coeff 1.0, show_click_decay_rate 0.98,
-//       delete_threshold 0.8, ...)
+//       weight_bounds +-10), ctr_accessor_param(nonclk_coeff 0.1, click_coeff 1.0, base_threshold 1.5, delta_threshold
+//       0.25, delta_keep_days 16, show_click_decay_rate 0.98, delete_threshold 0.8, delete_after_unseen_days 30)
 //   /root/reference/models/rank/slot_dnn/net.py:61-62  ShowClickEntry(show, click): the per-sample show / click
 //       values a push adds to the feature's counters
 //   /root/reference/tools/static_gpubox_trainer.py:152-160,256  the table lives in the GPU parameter server
-// Semantics restated (CtrCommonAccessor::Update / NeedExtendMF / Shrink, SparseAdaGradSGDRule::UpdateValueWork):
-//   push of a feature with merged gradient g and batch counters (dshow, dclick):
-//     show += dshow; click += dclick
-//     embed_w  -= lr * g_w * sqrt(g0 / (g0 + g2sum_w)), clipped to the bounds;  g2sum_w += g_w^2
-//     if the feature HAS its embedx part:
-//       embedx_w -= lr * g_x * sqrt(g0 / (g0 + g2sum_x)), clipped;  g2sum_x += sum(g_x^2) / embedx_dim
-//   the embedx part is created (uniform(+-initial_range)) by the first pull that finds
-//     (show - click) * nonclk_coeff + click * click_coeff >= embedx_threshold;   before that it reads as zeros and
-//     its gradient is dropped.  Here the creation is done at the END of the push that crosses the threshold — the
-//     same table state the next pull would produce.
-//   a feature itself is created at its first pull (embed_w = uniform(+-initial_range), counters 0): rows are born
-//   lazily from zeroed memory, with values that are a pure function of (seed, row, element) — see ps_init_value.
-//   shrink (end of a pass / day): show *= decay, click *= decay; features whose score fell below delete_threshold
-//   are deleted (row zeroed: unborn again).  unseen_days / delta_score bookkeeping (SSD tiering, delta saves) is
-//   storage-engine state outside this path.
+// Semantics = the published source of PaddlePaddle release/2.4 (tag v2.4.2), restated in oracle/ps_ref.py with the
+// C++ text quoted there: paddle/fluid/distributed/ps/table/{sparse_sgd_rule.cc (SparseAdaGradSGDRule::UpdateValueWork,
+// InitValueWork), ctr_accessor.cc (Create, Update, NeedExtendMF, Shrink, Save, UpdateStatAfterSave),
+// memory_sparse_table.cc (PullSparse / PushSparse: when the embedx part is created)} and the gpubox twin
+// paddle/fluid/framework/fleet/heter_ps/optimizer.cuh.h.  Push of a key with merged gradient g, pushed show / click:
+//     new key:  value created WITHOUT embedx: embed_w = 0 (zero_init, Paddle's default; uniform(+-range) if switched
+//               off), counters and g2sums 0
+//     show += push_show; click += push_click; delta_score += (push_show - push_click)*nonclk + push_click*clk;
+//     unseen_days = 0
+//     rule(w, g2sum, g, scale = push_show):  double scaled = g * grad_scale / scale;
+//               w = float(w - lr * scaled * sqrtf(g0 / (g0 + g2sum))), clipped;  g2sum = float(g2sum + sum(scaled^2)/n)
+//         on embed_w (n = 1) and, if the value HAS its embedx part, on embedx (n = embedx_dim)
+//     a value without embedx drops its embedx gradient and is extended (embedx = uniform(+-range), embedx_g2sum = 0)
+//     at the end of the push that makes (show - click)*nonclk + click*clk >= embedx_threshold
+// A key that was never pushed is zero memory: it reads as embed_w = 0, embedx = 0 — exactly what PullSparse returns
+// for a missing key — so a 160 GB shard needs no init pass.  Creation values are a pure function of
+// (seed, row, element) (ps_init_value) instead of Paddle's unseeded thread-local engine.
 #include <stdlib.h>
 
 #include "rec_common.h"
@@ -65,8 +67,29 @@ __device__ __forceinline__ void ps_segment_sum(float (&g)[VEC], int beg, int end
   }
 }
 
+// SparseAdaGradSGDRule::UpdateValueWork on one element: typed evaluation of the C++ text (ratio in float, the
+// rest in double, float on store).  inv = grad_scale / scale (double).  Returns scaled_grad^2.
+struct PsRule {
+  float lr, g0, lo, hi;
+};
+__device__ __forceinline__ double ps_rule_elem(float& w, float g, double inv, float ratio, const PsRule& R) {
+  const double sg = (double)g * inv;
+  float nw = (float)((double)w - (double)R.lr * sg * (double)ratio);
+  w = fminf(fmaxf(nw, R.lo), R.hi);
+  return sg * sg;
+}
+
+template <int LANES>
+__device__ __forceinline__ double group_sum_f64(double x) {
+#pragma unroll
+  for (int o = LANES / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, kWave);
+  return x;
+}
+
+constexpr int kStShow = 0, kStClick = 1, kStG2w = 2, kStG2x = 3, kStState = 4, kStDelta = 5, kStUnseen = 6;
+
 // One row group of LANES lanes per touched feature: the lanes own VEC-float slices of the embedx part, lane 0 of
-// the group also owns embed_w and the counters (same record line).
+// the group also owns embed_w and the statistics (same record line).
 template <int VEC, int LANES>
 __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
     rec_ps_layout L, int S, const int32_t* __restrict__ n_uniq, const int64_t* __restrict__ uniq,
@@ -81,12 +104,12 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
   const int64_t row = rowok ? uniq[u] : 0;
   const int beg = rowok ? seg_off[u] : 0, end = rowok ? seg_off[u + 1] : 0;
   float* r = rec + row * (int64_t)L.row_stride;
-  float* st = r + L.stat_off;            // show, click, g2sum_w, g2sum_x, state
+  float* st = r + L.stat_off;            // show, click, g2sum_w, g2sum_x, state, delta_score, unseen_days
   const int64_t grow = row * A.row_mul + A.row_add;   // identity of the feature across shards (creation values)
   const int Dx = L.embedx_dim;
   const bool xlane = rowok && d0 < Dx;
 
-  // ---- counters of the batch (lane 0 of the group), shared with the group
+  // ---- pushed show / click of the key (lane 0 of the group), shared with the group
   float dshow = 0.f, dclick = 0.f;
   if (rowok && lg == 0) {
     auto smp = [&](int pos) { return (gx.gl.index ? gx.gl.index[pos] : pos) / S; };
@@ -109,49 +132,41 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
   dshow = __shfl(dshow, head, kWave);
   dclick = __shfl(dclick, head, kWave);
 
-  float show0 = 0.f, click0 = 0.f, g2w = 0.f, g2x = 0.f, state = 0.f;
-  if (rowok) { show0 = st[0]; click0 = st[1]; g2w = st[2]; g2x = st[3]; state = st[4]; }
-  const float score0 = (show0 - click0) * A.nonclk_coeff + click0 * A.click_coeff;
-  // birth (what the pull of this step did in the reference): embed_w always, embedx if the score allows it
+  float show0 = 0.f, click0 = 0.f, g2w = 0.f, g2x = 0.f, state = 0.f, delta0 = 0.f;
+  if (rowok) {
+    show0 = st[kStShow]; click0 = st[kStClick]; g2w = st[kStG2w]; g2x = st[kStG2x]; state = st[kStState];
+    delta0 = st[kStDelta];
+  }
   const bool unborn = state == 0.f;
-  bool has_x = state >= 2.f || (unborn && score0 >= A.embedx_threshold);
+  const bool has_x = state >= 2.f;
+  const float show1 = show0 + dshow, click1 = click0 + dclick;
+  const float score1 = (show1 - click1) * A.nonclk_coeff + click1 * A.click_coeff;
+  const double inv = (double)A.grad_scale / ((A.show_scale && dshow > 0.f) ? (double)dshow : 1.0);
 
   // ---- embedx part
   float w[VEC], g[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { w[i] = 0.f; g[i] = 0.f; }
-  float sq = 0.f;
-  if (xlane) {
-    if (unborn) {
+  double sq = 0.0;
+  const PsRule RX = {A.x_lr, A.x_initial_g2sum, A.x_min_bound, A.x_max_bound};
+  if (xlane && has_x) {
+    vload<VEC>(w, r + L.embedx_off + d0);
+    ps_segment_sum<VEC>(g, beg, end, spos, gx, gx.col + d0);
+    const float ratio = sqrtf(RX.g0 / (RX.g0 + g2x));
 #pragma unroll
-      for (int i = 0; i < VEC; ++i)
-        w[i] = (has_x && d0 + i < Dx) ? ps_init_value(A.seed, grow, 1 + d0 + i, A.initial_range) : 0.f;
-    } else {
-      vload<VEC>(w, r + L.embedx_off + d0);
-    }
-    if (has_x) {
-      ps_segment_sum<VEC>(g, beg, end, spos, gx, gx.col + d0);
-      const float sc = sqrtf(A.initial_g2sum / (A.initial_g2sum + g2x));
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        if (d0 + i < Dx) {
-          w[i] = fminf(fmaxf(w[i] - A.lr * g[i] * sc, A.min_bound), A.max_bound);
-          sq += g[i] * g[i];
-        }
-      }
-    }
+    for (int i = 0; i < VEC; ++i)
+      if (d0 + i < Dx) sq += ps_rule_elem(w[i], g[i], inv, ratio, RX);
   }
-  sq = group_sum<LANES>(sq);
-  const float show1 = show0 + dshow, click1 = click0 + dclick;
-  const float score1 = (show1 - click1) * A.nonclk_coeff + click1 * A.click_coeff;
-  const bool create_x = !has_x && score1 >= A.embedx_threshold;   // what the NEXT pull would do
+  sq = group_sum_f64<LANES>(sq);   // (0 everywhere for a value without embedx)
+  const bool create_x = !has_x && Dx > 0 && score1 >= A.embedx_threshold;   // NeedExtendMF on the updated counters
   if (xlane) {
     if (create_x) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i)
-        w[i] = d0 + i < Dx ? ps_init_value(A.seed, grow, 1 + d0 + i, A.initial_range) : 0.f;
+        w[i] = d0 + i < Dx ? fminf(fmaxf(ps_init_value(A.seed, grow, 1 + d0 + i, A.x_initial_range), RX.lo), RX.hi)
+                           : 0.f;
     }
-    if (has_x || create_x || unborn) {
+    if (has_x || create_x) {
       if (VEC == 1 || d0 + VEC <= Dx) {
         vstore<VEC>(r + L.embedx_off + d0, w);
       } else {
@@ -161,19 +176,22 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
       }
     }
   }
-  // ---- embed_w + counters
+  // ---- embed_w + statistics
   if (rowok && lg == 0) {
-    float ew = unborn ? ps_init_value(A.seed, grow, 0, A.initial_range) : r[L.embed_off];
+    float ew = unborn ? (A.embed_zero_init ? 0.f : ps_init_value(A.seed, grow, 0, A.initial_range)) : r[L.embed_off];
     float gwv[1] = {0.f};
     ps_segment_sum<1>(gwv, beg, end, spos, gw, gw.col);
-    const float sc = sqrtf(A.initial_g2sum / (A.initial_g2sum + g2w));
-    ew = fminf(fmaxf(ew - A.lr * gwv[0] * sc, A.min_bound), A.max_bound);
+    const PsRule RW = {A.lr, A.initial_g2sum, A.min_bound, A.max_bound};
+    const double sqw = ps_rule_elem(ew, gwv[0], inv, sqrtf(RW.g0 / (RW.g0 + g2w)), RW);
     r[L.embed_off] = ew;
-    st[0] = show1;
-    st[1] = click1;
-    st[2] = g2w + gwv[0] * gwv[0];
-    if (has_x) st[3] = g2x + sq / (float)Dx;
-    st[4] = (has_x || create_x) ? 2.f : 1.f;
+    st[kStShow] = show1;
+    st[kStClick] = click1;
+    st[kStG2w] = (float)((double)g2w + sqw);
+    if (has_x) st[kStG2x] = (float)((double)g2x + sq / (double)Dx);
+    else if (create_x) st[kStG2x] = 0.f;
+    st[kStState] = (has_x || create_x) ? 2.f : 1.f;
+    st[kStDelta] = delta0 + ((dshow - dclick) * A.nonclk_coeff + dclick * A.click_coeff);
+    st[kStUnseen] = 0.f;
   }
 }
 
@@ -191,22 +209,24 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_narrow_kernel(
   // n_max is a capacity (the number of touched features is only known on the device): capped grid, strided loop
   const int nu = n_uniq[0];
   const int Dx = L.embedx_dim;
+  const PsRule RW = {A.lr, A.initial_g2sum, A.min_bound, A.max_bound};
+  const PsRule RX = {A.x_lr, A.x_initial_g2sum, A.x_min_bound, A.x_max_bound};
   for (int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x; u < nu; u += (int64_t)gridDim.x * kBlock) {
   const int64_t row = uniq[u];
   const int beg = seg_off[u], end = seg_off[u + 1];
   float* r = rec + row * (int64_t)L.row_stride;
-  float* st = r + L.stat_off;            // show, click, g2sum_w, g2sum_x, state
+  float* st = r + L.stat_off;            // show, click, g2sum_w, g2sum_x, state, delta_score, unseen_days
   const int64_t grow = row * A.row_mul + A.row_add;
-  const float show0 = st[0], click0 = st[1], g2w = st[2], g2x = st[3], state = st[4];
+  const float show0 = st[kStShow], click0 = st[kStClick], g2w = st[kStG2w], g2x = st[kStG2x], state = st[kStState],
+              delta0 = st[kStDelta];
   const bool unborn = state == 0.f;
+  const bool has_x = state >= 2.f;
   float w[DX];
 #pragma unroll
-  for (int d = 0; d < DX; ++d) w[d] = (!unborn && d < Dx) ? r[L.embedx_off + d] : 0.f;
-  float ew = unborn ? 0.f : r[L.embed_off];
+  for (int d = 0; d < DX; ++d) w[d] = (has_x && d < Dx) ? r[L.embedx_off + d] : 0.f;
+  float ew = unborn ? (A.embed_zero_init ? 0.f : ps_init_value(A.seed, grow, 0, A.initial_range)) : r[L.embed_off];
 
   // ---- one walk over the feature's occurrences: counters, embed_w gradient, embedx gradient
-  const float score0 = (show0 - click0) * A.nonclk_coeff + click0 * A.click_coeff;
-  const bool has_x = state >= 2.f || (unborn && score0 >= A.embedx_threshold);
   float dshow = show ? 0.f : (float)(end - beg), dclick = 0.f, gwv = 0.f;
   float g[DX];
 #pragma unroll
@@ -229,66 +249,91 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_narrow_kernel(
   // (the wide kernel adds the labels four at a time as integers, then to float: any grouping of integer partial
   // sums below 2^24 gives the same float)
   dclick = (float)lsum;
-
-  float sq = 0.f;
-  if (unborn) {
-#pragma unroll
-    for (int d = 0; d < DX; ++d) w[d] = (has_x && d < Dx) ? ps_init_value(A.seed, grow, 1 + d, A.initial_range) : 0.f;
-    ew = ps_init_value(A.seed, grow, 0, A.initial_range);
-  }
-  if (has_x) {
-    const float sc = sqrtf(A.initial_g2sum / (A.initial_g2sum + g2x));
-#pragma unroll
-    for (int d = 0; d < DX; ++d) {
-      if (d < Dx) {
-        w[d] = fminf(fmaxf(w[d] - A.lr * g[d] * sc, A.min_bound), A.max_bound);
-        sq += g[d] * g[d];
-      }
-    }
-  }
   const float show1 = show0 + dshow, click1 = click0 + dclick;
   const float score1 = (show1 - click1) * A.nonclk_coeff + click1 * A.click_coeff;
-  const bool create_x = !has_x && score1 >= A.embedx_threshold;   // what the NEXT pull would do
+  const double inv = (double)A.grad_scale / ((A.show_scale && dshow > 0.f) ? (double)dshow : 1.0);
+
+  double sq = 0.0;
+  if (has_x) {
+    const float ratio = sqrtf(RX.g0 / (RX.g0 + g2x));
+#pragma unroll
+    for (int d = 0; d < DX; ++d)
+      if (d < Dx) sq += ps_rule_elem(w[d], g[d], inv, ratio, RX);
+  }
+  const bool create_x = !has_x && Dx > 0 && score1 >= A.embedx_threshold;   // NeedExtendMF on the updated counters
   if (create_x) {
 #pragma unroll
-    for (int d = 0; d < DX; ++d) w[d] = d < Dx ? ps_init_value(A.seed, grow, 1 + d, A.initial_range) : 0.f;
+    for (int d = 0; d < DX; ++d)
+      w[d] = d < Dx ? fminf(fmaxf(ps_init_value(A.seed, grow, 1 + d, A.x_initial_range), RX.lo), RX.hi) : 0.f;
   }
-  if (has_x || create_x || unborn) {
+  if (has_x || create_x) {
 #pragma unroll
     for (int d = 0; d < DX; ++d)
       if (d < Dx) r[L.embedx_off + d] = w[d];
   }
-  const float scw = sqrtf(A.initial_g2sum / (A.initial_g2sum + g2w));
-  ew = fminf(fmaxf(ew - A.lr * gwv * scw, A.min_bound), A.max_bound);
+  const double sqw = ps_rule_elem(ew, gwv, inv, sqrtf(RW.g0 / (RW.g0 + g2w)), RW);
   r[L.embed_off] = ew;
-  st[0] = show1;
-  st[1] = click1;
-  st[2] = g2w + gwv * gwv;
-  if (has_x) st[3] = g2x + sq / (float)Dx;
-  st[4] = (has_x || create_x) ? 2.f : 1.f;
+  st[kStShow] = show1;
+  st[kStClick] = click1;
+  st[kStG2w] = (float)((double)g2w + sqw);
+  if (has_x) st[kStG2x] = (float)((double)g2x + sq / (double)Dx);
+  else if (create_x) st[kStG2x] = 0.f;
+  st[kStState] = (has_x || create_x) ? 2.f : 1.f;
+  st[kStDelta] = delta0 + ((dshow - dclick) * A.nonclk_coeff + dclick * A.click_coeff);
+  st[kStUnseen] = 0.f;
   }
 }
 
 __global__ __launch_bounds__(kBlock) void ps_shrink_rows_kernel(int64_t N, rec_ps_layout L,
                                                                  float* __restrict__ rec, float decay,
-                                                                 float delete_threshold, float nonclk,
-                                                                 float clk, int64_t* __restrict__ n_deleted) {
+                                                                 float delete_threshold, float delete_after_unseen_days,
+                                                                 float nonclk, float clk,
+                                                                 int64_t* __restrict__ n_deleted) {
   const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (row >= N) return;
   float* r = rec + row * (int64_t)L.row_stride;
   float* st = r + L.stat_off;
-  if (st[4] == 0.f) return;                       // unborn rows stay untouched (zero memory)
-  const float show = st[0] * decay, click = st[1] * decay;
+  if (st[kStState] == 0.f) return;                // no such key: zero memory stays untouched
+  const float show = st[kStShow] * decay, click = st[kStClick] * decay;
   const float score = (show - click) * nonclk + click * clk;
-  if (score < delete_threshold) {                 // delete: the row is unborn again
+  if (score < delete_threshold || st[kStUnseen] > delete_after_unseen_days) {   // delete: the key is gone
     r[L.embed_off] = 0.f;
     for (int d = 0; d < L.embedx_dim; ++d) r[L.embedx_off + d] = 0.f;
-    st[0] = st[1] = st[2] = st[3] = st[4] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) st[i] = 0.f;
     if (n_deleted) atomicAdd((unsigned long long*)n_deleted, 1ull);
   } else {
-    st[0] = show;
-    st[1] = click;
+    st[kStShow] = show;
+    st[kStClick] = click;
   }
+}
+
+// CtrCommonAccessor::Save(value, param) + UpdateStatAfterSave(value, param) for every row of the table:
+// selected[row] = 1 if a save of kind `param` writes the value (0 all, 1 delta, 2 base, 3 all + a day passes).
+__global__ __launch_bounds__(kBlock) void ps_save_select_kernel(int64_t N, rec_ps_layout L, float* __restrict__ rec,
+                                                                 int param, float base_threshold,
+                                                                 float delta_threshold, float delta_keep_days,
+                                                                 float nonclk, float clk,
+                                                                 uint8_t* __restrict__ selected,
+                                                                 int64_t* __restrict__ n_selected) {
+  const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (row >= N) return;
+  float* st = rec + row * (int64_t)L.row_stride + L.stat_off;
+  bool sel = false;
+  if (st[kStState] != 0.f) {
+    if (param == 1 || param == 2) {
+      const float show = st[kStShow], click = st[kStClick];
+      const float score = (show - click) * nonclk + click * clk;
+      const float dth = param == 2 ? 0.f : delta_threshold;
+      sel = score >= base_threshold && st[kStDelta] >= dth && st[kStUnseen] <= delta_keep_days;
+      if (sel) st[kStDelta] = 0.f;
+    } else {
+      sel = true;
+      if (param == 3) st[kStUnseen] += 1.f;
+    }
+  }
+  if (selected) selected[row] = sel ? 1 : 0;
+  if (sel && n_selected) atomicAdd((unsigned long long*)n_selected, 1ull);
 }
 
 static int check_layout(const rec_ps_layout* L) {
@@ -297,11 +342,11 @@ static int check_layout(const rec_ps_layout* L) {
                   L->stat_off >= 0,
               REC_EINVAL, "bad record layout");
   REC_REQUIRE(L->embed_off < L->row_stride && L->embedx_off + L->embedx_dim <= L->row_stride &&
-                  L->stat_off + 5 <= L->row_stride,
+                  L->stat_off + 7 <= L->row_stride,
               REC_EINVAL, "record parts do not fit in row_stride %d", L->row_stride);
-  // the five statistics must not overlap the weights
-  const bool ov_x = L->stat_off < L->embedx_off + L->embedx_dim && L->embedx_off < L->stat_off + 5;
-  const bool ov_w = L->embed_off >= L->stat_off && L->embed_off < L->stat_off + 5;
+  // the seven statistics must not overlap the weights
+  const bool ov_x = L->stat_off < L->embedx_off + L->embedx_dim && L->embedx_off < L->stat_off + 7;
+  const bool ov_w = L->embed_off >= L->stat_off && L->embed_off < L->stat_off + 7;
   REC_REQUIRE(!(ov_x && L->embedx_dim > 0) && !ov_w, REC_EINVAL, "record parts overlap");
   return REC_OK;
 }
@@ -323,7 +368,9 @@ extern "C" int rec_ps_push_rows(int64_t n_max, int32_t num_slots, const rec_ps_l
               "embedx gradient missing");
   REC_REQUIRE(n_uniq && uniq_rows && seg_offset && sorted_pos && rec, REC_EINVAL, "null pointer argument");
   REC_REQUIRE(accessor->initial_g2sum > 0.f && accessor->min_bound <= accessor->max_bound &&
-                  accessor->initial_range >= 0.f && accessor->row_mul >= 1 && accessor->row_add >= 0,
+                  accessor->initial_range >= 0.f && accessor->x_initial_g2sum > 0.f &&
+                  accessor->x_min_bound <= accessor->x_max_bound && accessor->x_initial_range >= 0.f &&
+                  accessor->grad_scale > 0.f && accessor->row_mul >= 1 && accessor->row_add >= 0,
               REC_EINVAL, "bad accessor parameters");
   if (n_max == 0) return REC_OK;
   GradSrc gw = {grad_embed->grad, grad_embed->layout, grad_embed->pitch, grad_embed->col};
@@ -378,14 +425,30 @@ extern "C" float rec_ps_init_value_host(uint64_t seed, int64_t row, int32_t elem
 
 extern "C" int rec_ps_shrink_rows(int64_t num_rows, const rec_ps_layout* layout, float* rec,
                                   float show_click_decay_rate, float delete_threshold,
-                                  const rec_ps_accessor* accessor, int64_t* n_deleted, void* stream) {
+                                  float delete_after_unseen_days, const rec_ps_accessor* accessor,
+                                  int64_t* n_deleted, void* stream) {
   if (int rc = check_layout(layout)) return rc;
   REC_REQUIRE(num_rows >= 0 && rec && accessor && show_click_decay_rate >= 0.f, REC_EINVAL, "bad arguments");
   if (num_rows == 0) return REC_OK;
   const int64_t grid = (num_rows + kBlock - 1) / kBlock;
   REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");
   hipLaunchKernelGGL(ps_shrink_rows_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream,
-                     num_rows, *layout, rec, show_click_decay_rate, delete_threshold, accessor->nonclk_coeff,
-                     accessor->click_coeff, n_deleted);
+                     num_rows, *layout, rec, show_click_decay_rate, delete_threshold, delete_after_unseen_days,
+                     accessor->nonclk_coeff, accessor->click_coeff, n_deleted);
   return check_launch("rec_ps_shrink_rows");
+}
+
+extern "C" int rec_ps_save_select(int64_t num_rows, const rec_ps_layout* layout, float* rec, int32_t param,
+                                  float base_threshold, float delta_threshold, float delta_keep_days,
+                                  const rec_ps_accessor* accessor, uint8_t* selected, int64_t* n_selected,
+                                  void* stream) {
+  if (int rc = check_layout(layout)) return rc;
+  REC_REQUIRE(num_rows >= 0 && rec && accessor && param >= 0 && param <= 3, REC_EINVAL, "bad arguments");
+  if (num_rows == 0) return REC_OK;
+  const int64_t grid = (num_rows + kBlock - 1) / kBlock;
+  REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");
+  hipLaunchKernelGGL(ps_save_select_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, num_rows,
+                     *layout, rec, param, base_threshold, delta_threshold, delta_keep_days, accessor->nonclk_coeff,
+                     accessor->click_coeff, selected, n_selected);
+  return check_launch("rec_ps_save_select");
 }

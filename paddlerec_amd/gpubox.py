@@ -52,10 +52,11 @@ class PSGPU:
             raise ValueError("set_slot_vector / set_slot_dim_vector must be called first, with equal lengths")
         self.gpus = [int(g) for g in gpus]
 
-    def bind(self, table, decay=0.98, delete_threshold=0.8):
+    def bind(self, table, decay=0.98, delete_threshold=0.8, delete_after_unseen_days=float("inf")):
         """Not a PSGPU method: in the reference the table lives in the parameter servers PSGPU talks to; here the
-        layer owns it.  decay / delete_threshold: ctr_accessor_param (config_online.yaml:86-87)."""
-        self.table, self.shrink = table, (float(decay), float(delete_threshold))
+        layer owns it.  decay / delete_threshold / delete_after_unseen_days: ctr_accessor_param
+        (config_online.yaml:85-88)."""
+        self.table, self.shrink = table, (float(decay), float(delete_threshold), float(delete_after_unseen_days))
 
     def load_pass(self, batches):
         """The dataset's in-memory pass (what reader.load_into_memory() holds): host batches."""
@@ -157,7 +158,9 @@ class Main:
         self.PSGPU.set_slot_dim_vector([self.model.emb_dim - 1] * self.model.slot_num)       # :156-158 (embedx dim)
         gpus = os.environ.get("FLAGS_selected_gpus", "0")
         self.PSGPU.init_gpu_ps([int(s) for s in gpus.split(",")])                            # :159
-        self.PSGPU.bind(self.net.table, ctr.get("show_click_decay_rate", 0.98), ctr.get("delete_threshold", 0.8))
+        self.PSGPU.bind(self.net.table, ctr.get("show_click_decay_rate", 0.98), ctr.get("delete_threshold", 0.8),
+                        ctr.get("delete_after_unseen_days", float("inf")))
+        self.ctr = ctr
         save = cfg.get("runner.model_save_path")
         for epoch in range(epochs):
             t0 = time.time()
@@ -185,13 +188,20 @@ class Main:
         self.PSGPU.finalize()                                                                # :219
         return self.train_result_dict
 
-    def save_pass(self, model_dir):
-        """The pass checkpoint: the dense parameters and the BORN rows of the table only (index + record) — a 160-GB
-        shard with a few million live features is a few hundred MB on disk."""
+    def save_pass(self, model_dir, mode=0):
+        """The pass checkpoint: the dense parameters and the EXISTING values of the table only (index + record) — a
+        160-GB shard with a few million live features is a few hundred MB on disk.  mode = the `param` of the
+        accessor's Save / UpdateStatAfterSave [EXT ctr_accessor.cc]: 0 every value (default); 1 the delta save (values
+        with score >= base_threshold, delta_score >= delta_threshold, unseen_days <= delta_keep_days; their
+        delta_score restarts at 0); 2 the base save (the same without the delta_score bar); 3 every value, and a day
+        passes (unseen_days += 1: what delete_after_unseen_days counts)."""
         import numpy as np
         os.makedirs(model_dir, exist_ok=True)
         t = self.net.table
-        born = torch.nonzero(t.rec[:, t.state_col] != 0).reshape(-1)
+        ctr = getattr(self, "ctr", {}) or {}
+        sel = self.k.ps_save_select(t, int(mode), ctr.get("base_threshold", 1.5), ctr.get("delta_threshold", 0.25),
+                                    ctr.get("delta_keep_days", 16.0))
+        born = torch.nonzero(sel).reshape(-1)
         out = {"rows": born.cpu().numpy(), "records": t.rec[born].cpu().numpy(),
                "num_rows": np.int64(t.num_rows), "emb_dim": np.int64(t.emb_dim)}
         for k, v in self.net.state_dict().items():

@@ -443,46 +443,60 @@ def sparse_adagrad_rows(groups, grad, rec, emb_dim, num_slots, label=None, lr=0.
 
 class PsTable:
     """A PS / gpubox sparse table on the device: record rows + the accessor parameters
-    (slot_dnn/config_online.yaml:57-89).  kind "slot": W = [embed_w, embedx(D-1)] (slot_dnn / dnn: the looked-up
-    vector is the whole W); kind "deepfm": embedx = the D-dim embedding at 0, embed_w = the first-order weight
-    behind it.  Rows are zero memory until they are born (state float)."""
+    (slot_dnn/config_online.yaml:57-89; arithmetic = Paddle's published CtrCommonAccessor / SparseAdaGradSGDRule,
+    see include/recengine.h and oracle/ps_ref.py).  kind "slot": W = [embed_w, embedx(D-1)] (slot_dnn / dnn: the
+    looked-up vector is the whole W); kind "deepfm": embedx = the D-dim embedding at 0, embed_w = the first-order
+    weight behind it.  Rows are zero memory until their first push (state float); a key that does not exist reads as
+    zeros, as PullSparse returns it."""
+
+    NUM_STATS = 7   # show, click, g2sum_w, g2sum_x, state, delta_score, unseen_days
 
     def __init__(self, num_rows, emb_dim, device, kind="slot", lr=0.05, initial_g2sum=3.0, bounds=(-10.0, 10.0),
                  initial_range=1e-4, embedx_threshold=10.0, nonclk_coeff=0.1, click_coeff=1.0, seed=2025,
-                 row_stride=None, row_mul=1, row_add=0):
+                 row_stride=None, row_mul=1, row_add=0, embedx_lr=None, embedx_initial_g2sum=None,
+                 embedx_bounds=None, embedx_initial_range=None, grad_scale=1.0, show_scale=True,
+                 embed_zero_init=True):
         D = int(emb_dim)
-        if kind == "slot":      # [W(D) | show | click | g2w | g2x | state]: D = 9 -> 14 floats in a 64-B half line
-            need = D + 5
+        if kind == "slot":      # [W(D) | 7 statistics]: D = 9 -> 16 floats = one 64-B half line
+            need = D + self.NUM_STATS
             stride = int(row_stride or (16 if need <= 16 else (need + 31) // 32 * 32))
             self.layout = PsLayout(stride, 0, 1, D - 1, D)
             self.w_cols = slice(0, D)
-            self.stat = slice(D, D + 4)
-            self.state_col = D + 4
-        elif kind == "deepfm":  # [W(D) | W1 | show | click | g2w | g2x | state | pad]
-            need = D + 6
+            stat0 = D
+        elif kind == "deepfm":  # [W(D) | W1 | 7 statistics | pad]
+            need = D + 1 + self.NUM_STATS
             stride = int(row_stride or (need + 31) // 32 * 32)
             self.layout = PsLayout(stride, D, 0, D, D + 1)
             self.w_cols = slice(0, D)
-            self.stat = slice(D + 1, D + 5)
-            self.state_col = D + 5
+            stat0 = D + 1
         else:
             raise RecError("kind must be 'slot' or 'deepfm'")
         if stride < need:
             raise RecError("row_stride %d < %d" % (stride, need))
+        self.stat = slice(stat0, stat0 + 4)                  # show, click, g2sum_w, g2sum_x
+        self.stat_all = slice(stat0, stat0 + self.NUM_STATS)
+        self.state_col = stat0 + 4
+        self.delta_col, self.unseen_col = stat0 + 5, stat0 + 6
         self.kind, self.emb_dim, self.num_rows = kind, D, int(num_rows)
         self.rec = torch.zeros(int(num_rows), stride, dtype=torch.float32, device=device)
         self.W = self.rec[:, self.w_cols]
-        self.accessor = PsAccessor(float(lr), float(initial_g2sum), float(bounds[0]), float(bounds[1]),
-                                   float(initial_range), float(embedx_threshold), float(nonclk_coeff),
-                                   float(click_coeff), int(seed), int(row_mul), int(row_add))
+        xb = embedx_bounds if embedx_bounds is not None else bounds
+        self.accessor = PsAccessor(
+            float(lr), float(initial_g2sum), float(bounds[0]), float(bounds[1]), float(initial_range),
+            float(lr if embedx_lr is None else embedx_lr),
+            float(initial_g2sum if embedx_initial_g2sum is None else embedx_initial_g2sum), float(xb[0]), float(xb[1]),
+            float(initial_range if embedx_initial_range is None else embedx_initial_range),
+            float(embedx_threshold), float(nonclk_coeff), float(click_coeff), float(grad_scale),
+            1 if show_scale else 0, 1 if embed_zero_init else 0, int(seed), int(row_mul), int(row_add))
 
     @property
     def lazy_init(self):
-        """(state_offset, init_dims, init_range, seed) for the lookups: what an unborn row reads as.  The looked-up
-        vector starts at embed_w for kind 'slot' (element d of W = accessor element d)."""
+        """(state_offset, init_dims, init_range, seed) for the lookups: what a key that does not exist reads as.
+        Paddle's default (embed_zero_init): zeros = the memory itself, lazy init off (range 0).  Otherwise embed_w
+        (element 0 of a 'slot' vector) reads as its creation value, which the first push stores."""
         a = self.accessor
-        dims = self.emb_dim if a.embedx_threshold <= 0 else 1
-        return (self.state_col - self.w_cols.start, dims, a.initial_range, a.seed)
+        rng = 0.0 if a.embed_zero_init else a.initial_range
+        return (self.state_col - self.w_cols.start, 1, rng, a.seed)
 
 
 def record_gather(rows, rec, D, out_w, out_w1, status, table=None):
@@ -493,10 +507,9 @@ def record_gather(rows, rec, D, out_w, out_w1, status, table=None):
         raise RecError("rec must be a 2-D float32 device tensor with unit column stride")
     n = rows.numel()
     lz = None
-    if table is not None and table.accessor.initial_range > 0:
-        a = table.accessor
-        lz = LazyInit(table.state_col, (D + 1) if a.embedx_threshold <= 0 else 1, a.initial_range, a.seed,
-                      a.row_mul, a.row_add)
+    if table is not None and not table.accessor.embed_zero_init and table.accessor.initial_range > 0:
+        a = table.accessor      # embed_w (W1) of a key that does not exist yet reads as its creation value
+        lz = LazyInit(table.state_col, 1, a.initial_range, a.seed, a.row_mul, a.row_add)
     check(lib().rec_record_gather(n, int(D), rec.stride(0), rec.shape[0], _p(rows), _p(rec), _p(out_w), _p(out_w1),
                                   C.byref(lz) if lz is not None else None, _p(status), _stream()),
           "rec_record_gather")
@@ -526,13 +539,25 @@ def ps_push_rows(table, groups, grad, num_slots, grad_pitch=None, grad_index=Non
           "rec_ps_push_rows")
 
 
-def ps_shrink_rows(table, decay=0.98, delete_threshold=0.8):
-    """End-of-pass shrink: counters decay, rows below delete_threshold are deleted.  -> number deleted (host sync)."""
+def ps_shrink_rows(table, decay=0.98, delete_threshold=0.8, delete_after_unseen_days=float("inf")):
+    """CtrCommonAccessor::Shrink: counters decay; values below delete_threshold or unseen for more than
+    delete_after_unseen_days are deleted.  -> number deleted (host sync)."""
     n = torch.zeros(1, dtype=torch.int64, device=table.rec.device)
     check(lib().rec_ps_shrink_rows(table.num_rows, C.byref(table.layout), _p(table.rec), float(decay),
-                                   float(delete_threshold), C.byref(table.accessor), _p(n), _stream()),
+                                   float(delete_threshold), float(min(delete_after_unseen_days, 3.0e38)),
+                                   C.byref(table.accessor), _p(n), _stream()),
           "rec_ps_shrink_rows")
     return int(n.item())
+
+
+def ps_save_select(table, param, base_threshold=1.5, delta_threshold=0.25, delta_keep_days=16.0):
+    """CtrCommonAccessor::Save(param) + UpdateStatAfterSave(param) over the table -> bool [N] device mask of the rows a
+    save of this kind writes (0 all, 1 delta, 2 base, 3 all + unseen_days += 1)."""
+    sel = torch.zeros(table.num_rows, dtype=torch.uint8, device=table.rec.device)
+    check(lib().rec_ps_save_select(table.num_rows, C.byref(table.layout), _p(table.rec), int(param),
+                                   float(base_threshold), float(delta_threshold), float(delta_keep_days),
+                                   C.byref(table.accessor), _p(sel), None, _stream()), "rec_ps_save_select")
+    return sel.bool()
 
 
 def adam_dense(p, m, v, g, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=None):

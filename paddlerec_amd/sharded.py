@@ -218,17 +218,20 @@ class ShardedDeepFMLayer(DeepFMLayer):
 
     def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim,
                  sparse_num_field, layer_sizes, device="cuda", slot_offset=None, group=None,
-                 comm=None, kernels=None, table="adam", accessor=None, hash_keys=False):
+                 comm=None, kernels=None, table="adam", accessor=None, hash_keys=False, scale_sparse_grad=True):
         """table 'adam': the record layout + lazy Adam of the unsharded layer.  table 'ps': the gpubox feature value
         (tools/static_gpubox_trainer.py:152-160; accessor = slot_dnn/config_online.yaml:57-89) — ONE 128-B record
-        line per row [W(16) | W1 | show | click | g2sum_w | g2sum_x | state], no second optimizer-state line, rows
-        born lazily from zeroed memory: 10^10 rows are 160 GB per GPU on 8 GPUs.  accessor: kwargs of ops.PsTable.
+        line per row [W(16) | W1 | show | click | g2sum_w | g2sum_x | state | delta_score | unseen_days], no second
+        optimizer-state line, rows born lazily from zeroed memory: 10^10 rows are 160 GB per GPU on 8 GPUs.
+        accessor: kwargs of ops.PsTable.  scale_sparse_grad: the push carries the gradient of the SUMMED loss
+        (mean-loss gradient x GLOBAL batch), as Paddle's PS trainers do (scale_sparse_gradient_with_batch_size [EXT]).
         hash_keys: the ids are uint64 feasigns, hashed to rows [1, N) on the device (row = 1 + mix64(f) % (N-1))."""
         self.comm = comm if comm is not None else Comm(group)
         G = self.comm.world
         self.global_rows = int(sparse_feature_number)
         self.local_rows = (self.global_rows + G - 1) // G
         self.hash_keys = bool(hash_keys)
+        self.scale_sparse_grad = bool(scale_sparse_grad)
         self.ps = None
         kk = kernels if kernels is not None else ops
         if table == "ps":
@@ -476,6 +479,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
                 if L.n_recv and self.ps is not None:
                     # the accessor's push: counters, AdaGrad rule per part, lazy birth / embedx creation
                     click = recv_g1[: L.n_recv, 1].contiguous().to(torch.int64)
+                    if self.scale_sparse_grad:      # the loss is the mean over the GLOBAL batch
+                        self.ps.accessor.grad_scale = float(label.shape[0] * self.comm.world)
                     k.ps_push_rows(self.ps, groups, recv_g, 1, grad1=recv_g1, grad1_pitch=2, click=click)
                 elif L.n_recv:
                     st = self.sparse_state

@@ -28,9 +28,12 @@ class BenchmarkDNNLayer:
     """net.py:21-85.  forward(batch) -> predict [B,1]; batch = ops.MultislotBatch (values | lod [S,B+1] | slot_base)."""
 
     def __init__(self, dict_dim, emb_dim, slot_num, layer_sizes, device="cuda", kernels=None, sparse_optimizer="adam",
-                 key_mode=1, accessor=None):
+                 key_mode=1, accessor=None, scale_sparse_grad=True):
         """key_mode 1: batch values are uint64 feasign bit patterns (what queuedataset_reader.py feeds), hashed into
-        dict_dim rows on the device; 0: values are rows.  accessor: kwargs of ops.PsTable for sparse_optimizer='ps'."""
+        dict_dim rows on the device; 0: values are rows.  accessor: kwargs of ops.PsTable for sparse_optimizer='ps'.
+        scale_sparse_grad: the push carries the gradient of the SUMMED loss (mean-loss gradient x batch size), as
+        Paddle's PS trainers do (scale_sparse_gradient_with_batch_size, default true [EXT])."""
+        self.scale_sparse_grad = bool(scale_sparse_grad)
         self.device = torch.device(device)
         self.k = kernels if kernels is not None else ops
         self.dict_dim, self.emb_dim, self.slot_num = int(dict_dim), int(emb_dim), int(slot_num)
@@ -150,6 +153,10 @@ class BenchmarkDNNLayer:
         with _OnSide(side, cur):
             with self._timed("sparse_update"):
                 if self.table is not None:
+                    # the trainer pushes the gradient of the SUMMED loss (scale_sparse_gradient_with_batch_size [EXT];
+                    # heter_ps PushCopy `* bs`): the rule then divides it by the key's pushed show
+                    if self.scale_sparse_grad:
+                        self.table.accessor.grad_scale = float(label.shape[0])
                     k.ps_push_rows(self.table, groups, dx, S, show=show, click=label.reshape(-1))
                 else:
                     st = self.sparse_state
@@ -161,6 +168,21 @@ class BenchmarkDNNLayer:
         if on_gpu:
             cur.wait_stream(self._side)
         return loss, pred
+
+
+def accessor_kwargs(tp):
+    """table_parameters.embedding.accessor (slot_dnn/config_online.yaml:57-89) -> kwargs of ops.PsTable: both SGD rules
+    (embed_sgd_param for embed_w, embedx_sgd_param for embedx), embedx_threshold, the score coefficients."""
+    we = (tp.get("embed_sgd_param") or {}).get("adagrad", {})
+    wx = (tp.get("embedx_sgd_param") or {}).get("adagrad", {}) or we
+    we = we or wx
+    ctr = tp.get("ctr_accessor_param", {})
+    return dict(lr=we.get("learning_rate", 0.05), initial_g2sum=we.get("initial_g2sum", 3.0),
+                bounds=tuple(we.get("weight_bounds", (-10.0, 10.0))), initial_range=we.get("initial_range", 1e-4),
+                embedx_lr=wx.get("learning_rate", 0.05), embedx_initial_g2sum=wx.get("initial_g2sum", 3.0),
+                embedx_bounds=tuple(wx.get("weight_bounds", (-10.0, 10.0))),
+                embedx_initial_range=wx.get("initial_range", 1e-4), embedx_threshold=tp.get("embedx_threshold", 10),
+                nonclk_coeff=ctr.get("nonclk_coeff", 0.1), click_coeff=ctr.get("click_coeff", 1.0))
 
 
 class StaticModel:
@@ -181,12 +203,7 @@ class StaticModel:
         if sparse_optimizer is None:
             sparse_optimizer = "ps" if tp else "adam"
         if tp and sparse_optimizer == "ps":          # config_online.yaml:57-89
-            rule = tp.get("embedx_sgd_param", {}).get("adagrad", {})
-            ctr = tp.get("ctr_accessor_param", {})
-            acc = dict(lr=rule.get("learning_rate", 0.05), initial_g2sum=rule.get("initial_g2sum", 3.0),
-                       bounds=tuple(rule.get("weight_bounds", (-10.0, 10.0))),
-                       initial_range=rule.get("initial_range", 1e-4), embedx_threshold=tp.get("embedx_threshold", 10),
-                       nonclk_coeff=ctr.get("nonclk_coeff", 0.1), click_coeff=ctr.get("click_coeff", 1.0))
+            acc = accessor_kwargs(tp)
         return BenchmarkDNNLayer(self.dict_dim, self.emb_dim, self.slot_num, self.layer_sizes, device=device,
                                  kernels=kernels, sparse_optimizer=sparse_optimizer, accessor=acc)
 

@@ -429,8 +429,11 @@ from paddlerec_amd.ops import PsTable  # noqa: E402,F401  (ctypes structs + a to
 def _acc_dict(table):
     A = table.accessor
     return dict(lr=A.lr, initial_g2sum=A.initial_g2sum, bounds=(A.min_bound, A.max_bound),
-                initial_range=A.initial_range, embedx_threshold=A.embedx_threshold, nonclk_coeff=A.nonclk_coeff,
-                click_coeff=A.click_coeff, seed=A.seed, row_mul=A.row_mul, row_add=A.row_add)
+                initial_range=A.initial_range, embedx_lr=A.x_lr, embedx_initial_g2sum=A.x_initial_g2sum,
+                embedx_bounds=(A.x_min_bound, A.x_max_bound), embedx_initial_range=A.x_initial_range,
+                embedx_threshold=A.embedx_threshold, nonclk_coeff=A.nonclk_coeff,
+                click_coeff=A.click_coeff, grad_scale=A.grad_scale, show_scale=bool(A.show_scale),
+                embed_zero_init=bool(A.embed_zero_init), seed=A.seed, row_mul=A.row_mul, row_add=A.row_add)
 
 
 def _lay_dict(table):
@@ -441,7 +444,7 @@ def _lay_dict(table):
 def record_gather(rows, rec, D, out_w, out_w1, status, table=None):
     from oracle import ps_ref
     r = _n(rows)
-    if table is not None and table.accessor.initial_range > 0:
+    if table is not None:
         W, W1 = ps_ref.pull_deepfm(rec.numpy(), _lay_dict(table), r, _acc_dict(table))
     else:
         W, W1 = rec.numpy()[r, :D], rec.numpy()[r, D]
@@ -551,9 +554,16 @@ def cin_sumpool_bwd(B, D, dpool, dXT):
     return dXT
 
 
-def ps_shrink_rows(table, decay=0.98, delete_threshold=0.8):
+def ps_shrink_rows(table, decay=0.98, delete_threshold=0.8, delete_after_unseen_days=float("inf")):
     from oracle import ps_ref
-    return ps_ref.shrink_rows(table.rec.numpy(), _lay_dict(table), _acc_dict(table), decay, delete_threshold)
+    return ps_ref.shrink_rows(table.rec.numpy(), _lay_dict(table), _acc_dict(table), decay, delete_threshold,
+                              delete_after_unseen_days)
+
+
+def ps_save_select(table, param, base_threshold=1.5, delta_threshold=0.25, delta_keep_days=16.0):
+    from oracle import ps_ref
+    return torch.from_numpy(ps_ref.save_select(table.rec.numpy(), _lay_dict(table), _acc_dict(table), param,
+                                               base_threshold, delta_threshold, delta_keep_days))
 
 
 # ------------------------------------------------------------------ DLRM (include/recengine.h: rec_batchnorm_*, rec_dot_interact_*)

@@ -35,7 +35,7 @@ def _config(tmp_path, epochs=2):
             "table_parameters.embedding.accessor": acc}
 
 
-def _run(tmp_path, device, kernels, loss_rtol=2e-5):
+def _run(tmp_path, device, kernels, loss_rtol=1e-4):
     from paddlerec_amd import gpubox, reader
     cfg = _config(tmp_path)
     torch.manual_seed(7)
@@ -80,13 +80,18 @@ def _run(tmp_path, device, kernels, loss_rtol=2e-5):
             for k in np.nonzero(values != 0)[0]:
                 dshow[pos[int(o["rows"][k])]] += 1
                 dclick[pos[int(o["rows"][k])]] += int(label[o["seg"][k] // SLOTS, 0])
-            ps_ref.push_rows(rec, lay, o["uniq"], o["merged"][:, 0], o["merged"][:, 1:], dshow, dclick, acc)
+            ps_ref.push_rows(rec, lay, o["uniq"], o["merged"][:, 0], o["merged"][:, 1:], dshow, dclick,
+                             dict(acc, grad_scale=float(n)))      # the pushed gradient is that of the SUMMED loss
             step += 1
             for i in range(len(mw)):
                 R.adam_update(mw[i], st[0][i][0], st[0][i][1], o["dws"][i], step, lr=1e-3)
                 R.adam_update(mb[i], st[1][i][0], st[1][i][1], o["dbs"][i], step, lr=1e-3)
         want_loss.append(float(np.mean(losses)))
         want_deleted.append(ps_ref.shrink_rows(rec, lay, acc, 0.98, 0.15))
+    # pass 0 agrees to 1e-6; pass 1 runs on MLP weights that took Adam's lr-sized steps on ~eps-sized gradients (sign
+    # noise of the fp32 summation order) — see the comment at the weight check; tests/test_slot_dnn.py holds the layer
+    # to 2e-5 per step with the MLP re-synchronised
+    np.testing.assert_allclose(res["loss"][0], want_loss[0], rtol=2e-5)
     np.testing.assert_allclose(res["loss"], want_loss, rtol=loss_rtol)
     assert res["deleted"] == want_deleted and want_deleted[0] > 0            # the shrink really deletes rows
     got = net.rec.cpu().numpy()

@@ -136,12 +136,16 @@ def test_ps_push_narrow_shape_sweep(engine_lib, seed):
     S = int(rng.integers(1, 5))
     B = int(rng.integers(4, 120))
     thr = float(rng.choice([0.0, 1.5, 10.0]))
-    table = ops.PsTable(N, D, DEV, kind="slot", embedx_threshold=thr, initial_range=1e-2, seed=77 + seed)
+    # the two SGD rules differ (embed_sgd_param / embedx_sgd_param are separate blocks of the YAML), the pushed
+    # gradient is scaled (batch size), show scaling on / off, embed_w zero-initialised or not
+    kw = dict(embedx_threshold=thr, initial_range=1e-2, seed=77 + seed, lr=0.05, embedx_lr=float(rng.choice([0.05, 0.02])),
+              initial_g2sum=3.0, embedx_initial_g2sum=float(rng.choice([3.0, 1.0])), bounds=(-10.0, 10.0),
+              embedx_bounds=(-0.25, 0.25), embedx_initial_range=2e-2, grad_scale=float(rng.choice([1.0, 8.0])),
+              show_scale=bool(rng.integers(0, 2)), embed_zero_init=bool(rng.integers(0, 2)))
+    table = ops.PsTable(N, D, DEV, kind="slot", **kw)
     L = table.layout
     lay = dict(embed_off=L.embed_off, embedx_off=L.embedx_off, embedx_dim=L.embedx_dim, stat_off=L.stat_off)
-    a = table.accessor
-    acc = dict(lr=a.lr, initial_g2sum=a.initial_g2sum, bounds=(a.min_bound, a.max_bound), initial_range=a.initial_range,
-               embedx_threshold=a.embedx_threshold, nonclk_coeff=a.nonclk_coeff, click_coeff=a.click_coeff, seed=a.seed)
+    acc = dict(kw, nonclk_coeff=0.1, click_coeff=1.0)
     rec = np.zeros((N, L.row_stride), np.float32)
     for r in range(1, N):                              # a table with history: a third unborn, a third embed-only, a third full
         kind = rng.integers(0, 3)
@@ -151,6 +155,7 @@ def test_ps_push_narrow_shape_sweep(engine_lib, seed):
         rec[r, L.stat_off:L.stat_off + 4] = [rng.integers(0, 30), rng.integers(0, 3), rng.random() * 0.5, rng.random() * 0.5]
         rec[r, L.stat_off + 1] = min(rec[r, L.stat_off + 1], rec[r, L.stat_off])
         rec[r, L.stat_off + 4] = kind
+        rec[r, L.stat_off + 5:L.stat_off + 7] = [rng.random(), rng.integers(0, 9)]      # delta_score, unseen_days
         if kind == 2:
             rec[r, L.embedx_off:L.embedx_off + D - 1] = rng.standard_normal(D - 1) * 0.1
     table.rec.copy_(torch.from_numpy(rec))
@@ -176,8 +181,12 @@ def test_ps_push_narrow_shape_sweep(engine_lib, seed):
     so = L.stat_off
     assert np.array_equal(got[:, so:so + 2], want[:, so:so + 2])            # show / click: exact
     assert np.array_equal(got[:, so + 4], want[:, so + 4])                  # feature states: exact
-    np.testing.assert_allclose(got[:, :D], want[:, :D], rtol=2e-5, atol=1e-7)
-    np.testing.assert_allclose(got[:, so + 2:so + 4], want[:, so + 2:so + 4], rtol=1e-4, atol=1e-9)
+    assert np.array_equal(got[:, so + 6], want[:, so + 6])                  # unseen_days: exact
+    np.testing.assert_allclose(got[:, so + 5], want[:, so + 5], rtol=1e-6)  # delta_score
+    # weights / g2sums: the device merges duplicate gradients in the same ascending order as the oracle; what is left
+    # is the double -> float rounding of the rule (1 ulp)
+    np.testing.assert_allclose(got[:, :D], want[:, :D], rtol=2e-6, atol=1e-8)
+    np.testing.assert_allclose(got[:, so + 2:so + 4], want[:, so + 2:so + 4], rtol=2e-6, atol=1e-12)
     untouched = np.setdiff1d(np.arange(N), uniq)
     assert np.array_equal(got[untouched], rec[untouched])
     assert int(status.item()) == 0

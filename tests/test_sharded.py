@@ -188,7 +188,9 @@ def _expected_ps(world):
         lab = np.repeat(label.reshape(-1), rows.shape[1])
         flat = o["rows"].reshape(-1)
         clicks = np.array([lab[(flat == u) & o["row_valid"].reshape(-1)].sum() for u in uniq], np.float64)
-        ps_ref.push_rows(rec, lay, uniq, merged1[:, 0], merged, counts, clicks, acc)
+        # the layer pushes the gradient of the SUMMED loss: grad_scale = the global batch (scale_sparse_grad)
+        ps_ref.push_rows(rec, lay, uniq, merged1[:, 0], merged, counts, clicks,
+                         dict(acc, grad_scale=float(label.shape[0])))
         pairs = [("dense_w", o["d_dense_w"]), ("dense_w_one", o["d_dense_w_one"])]
         for i in range(len(p["mlp_w"])):
             pairs += [(("mlp_w", i), o["mlp_dw"][i]), (("mlp_b", i), o["mlp_db"][i])]
@@ -212,7 +214,10 @@ def _check_ps(world, ranks):
         so = D + 1
         assert np.array_equal(got[:, so:so + 2], mine[:, so:so + 2]), "show / click counters of rank %d" % r
         assert np.array_equal(got[:, so + 4], mine[:, so + 4]), "feature states of rank %d" % r
-        np.testing.assert_allclose(got[:, :D + 1], mine[:, :D + 1], rtol=1e-4, atol=1e-7)
+        assert np.array_equal(got[:, so + 6], mine[:, so + 6]), "unseen_days of rank %d" % r
+        np.testing.assert_allclose(got[:, so + 5], mine[:, so + 5], rtol=1e-6, err_msg="delta_score")
+        wscale = float(np.abs(rec[:, :D + 1]).max())
+        np.testing.assert_allclose(got[:, :D + 1], mine[:, :D + 1], rtol=1e-4, atol=1e-5 * wscale)
         np.testing.assert_allclose(got[:, so + 2:so + 4], mine[:, so + 2:so + 4], rtol=1e-4, atol=1e-12)
         np.testing.assert_allclose(out["mlp_w0"], p["mlp_w"][0], rtol=1e-3, atol=2e-5)
     st = rec[:, D + 5]

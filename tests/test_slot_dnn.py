@@ -173,13 +173,20 @@ def _check_ps_layer(device, kernels, Batch):
         for k in np.nonzero(live)[0]:
             dshow[pos[int(o["rows"][k])]] += 1
             dclick[pos[int(o["rows"][k])]] += int(label[o["seg"][k] // S, 0])
-        ps_ref.push_rows(rec, lay, o["uniq"], o["merged"][:, 0], o["merged"][:, 1:], dshow, dclick, accp)
+        # the layer pushes the gradient of the SUMMED loss (scale_sparse_grad): grad_scale = batch size
+        ps_ref.push_rows(rec, lay, o["uniq"], o["merged"][:, 0], o["merged"][:, 1:], dshow, dclick,
+                         dict(accp, grad_scale=float(label.shape[0])))
         got = m.rec.cpu().numpy()
         so = L.stat_off
         assert np.array_equal(got[:, so:so + 2], rec[:, so:so + 2]), "show / click counters"
         assert np.array_equal(got[:, so + 4], rec[:, so + 4]), "feature states"
-        np.testing.assert_allclose(got[:, :D], rec[:, :D], rtol=1e-4, atol=1e-7)
-        np.testing.assert_allclose(got[:, so + 2:so + 4], rec[:, so + 2:so + 4], rtol=1e-4, atol=1e-12)
+        assert np.array_equal(got[:, so + 6], rec[:, so + 6]), "unseen_days"
+        np.testing.assert_allclose(got[:, so + 5], rec[:, so + 5], rtol=1e-6, err_msg="delta_score")
+        # weights / g2sums: the merged gradient differs from the oracle's by float summation order (1e-6 of its
+        # scale); relative to the weight scale of the table
+        wscale = float(np.abs(rec[:, :D]).max())
+        np.testing.assert_allclose(got[:, :D], rec[:, :D], rtol=1e-5, atol=1e-5 * wscale)
+        np.testing.assert_allclose(got[:, so + 2:so + 4], rec[:, so + 2:so + 4], rtol=2e-5, atol=1e-12)
         # the MLP's dense Adam moved the weights: mirror it for the next step's oracle forward
         mwn = [m.mlp_w[i].cpu().numpy().copy() for i in range(len(mwn))]
         mb = [m.mlp_b[i].cpu().numpy().copy() for i in range(len(mb))]
@@ -362,13 +369,23 @@ def test_ps_shrink_rows(engine_lib):
     rec[born, L.stat_off] = rng.integers(1, 30, int(born.sum()))
     rec[born, L.stat_off + 1] = np.minimum(rec[born, L.stat_off], rng.integers(0, 3, int(born.sum())))
     rec[born, L.stat_off + 4] = rng.integers(1, 3, int(born.sum()))
+    rec[born, L.stat_off + 5] = rng.random(int(born.sum()))                       # delta_score
+    rec[born, L.stat_off + 6] = rng.integers(0, 40, int(born.sum()))              # unseen_days: some > 30
     tbl.rec.copy_(T(rec))
-    deleted = ops.ps_shrink_rows(tbl, 0.98, 0.8)
+    deleted = ops.ps_shrink_rows(tbl, 0.98, 0.8, 30.0)
     lay = dict(embed_off=L.embed_off, embedx_off=L.embedx_off, embedx_dim=L.embedx_dim, stat_off=L.stat_off)
+    acc = dict(nonclk_coeff=0.1, click_coeff=1.0)
     want = rec.copy()
-    wdel = ps_ref.shrink_rows(want, lay, dict(nonclk_coeff=0.1, click_coeff=1.0), 0.98, 0.8)
-    assert deleted == wdel and wdel > 0
+    wdel = ps_ref.shrink_rows(want, lay, acc, 0.98, 0.8, 30.0)
+    only_score = ps_ref.shrink_rows(rec.copy(), lay, acc, 0.98, 0.8)
+    assert deleted == wdel and wdel > only_score > 0            # both deletion causes occur
     np.testing.assert_allclose(tbl.rec.cpu().numpy(), want, rtol=1e-6)
+    # Save(param) + UpdateStatAfterSave(param): delta, base, daily — masks and statistics against the oracle
+    for param in (1, 2, 3, 0):
+        sel = ops.ps_save_select(tbl, param, 1.5, 0.25, 16.0).cpu().numpy()
+        wsel = ps_ref.save_select(want, lay, acc, param, 1.5, 0.25, 16.0)
+        assert np.array_equal(sel, wsel) and (param != 1 or 0 < wsel.sum() < (want[:, L.stat_off + 4] != 0).sum())
+        assert np.array_equal(tbl.rec.cpu().numpy(), want)
 
 
 @pytest.mark.gpu
@@ -417,18 +434,26 @@ def test_ps_pull_group_push_full_size_properties(engine_lib):
     nnz = int(base[-1].item())
     values = torch.randint(1, N, (nnz,), device=DEV, generator=g, dtype=torch.int64)
     values[torch.rand(nnz, device=DEV, generator=g) < 0.3] = 0
-    table = ops.PsTable(N, D, DEV, kind="slot", embedx_threshold=0.0, initial_range=1e-2)
+    # embed_zero_init off: a key that does not exist reads as its embed_w creation value (embedx as 0) without the
+    # table being written; the first push stores that embed_w and — threshold 0 — creates embedx at its end
+    table = ops.PsTable(N, D, DEV, kind="slot", embedx_threshold=0.0, initial_range=1e-2, embed_zero_init=False)
     mbatch = ops.MultislotBatch(values, lod, base)
     status = ops.new_status(DEV)
     out, counts, seg, rows, _ = ops.multislot_sumpool(mbatch, table.W, N, 0, 0, status, lazy_init=table.lazy_init)
     # creation values of every row, as a pull shows them: N samples x 1 slot, one id each, on an untouched table
-    fresh = ops.PsTable(N, D, DEV, kind="slot", embedx_threshold=0.0, initial_range=1e-2)
+    fresh = ops.PsTable(N, D, DEV, kind="slot", embedx_threshold=0.0, initial_range=1e-2, embed_zero_init=False)
     allrows = torch.arange(N, device=DEV)
     one = ops.MultislotBatch(allrows, torch.arange(N + 1, device=DEV).view(1, -1).contiguous(),
                              torch.tensor([0, N], device=DEV))
     init, _, _, _, _ = ops.multislot_sumpool(one, fresh.W, N, None, 0, status, lazy_init=fresh.lazy_init,
                                              want_backward=False, want_counts=False)
-    assert float(init.abs().max().item()) <= 1e-2 and float(init[1:].abs().min().item()) >= 0.0
+    assert float(init.abs().max().item()) <= 1e-2 and bool((init[:, 1:] == 0).all())
+    assert float(init[1:, 0].abs().max().item()) > 0
+    # Paddle's default (zero_init): the same pull on a table that does not exist yet returns zeros
+    ztab = ops.PsTable(N, D, DEV, kind="slot", embedx_threshold=0.0, initial_range=1e-2)
+    zout, _, _, _, _ = ops.multislot_sumpool(one, ztab.W, N, None, 0, status, lazy_init=ztab.lazy_init,
+                                             want_backward=False, want_counts=False)
+    assert not bool(zout.any())
     live = values != 0
     r, sg = values[live], seg[:nnz][live].long()
     # the pooled output IS the sum of creation values of the live ids of a cell
@@ -449,52 +474,20 @@ def test_ps_pull_group_push_full_size_properties(engine_lib):
     assert torch.equal(rec[:, L.stat_off].long(), show)
     assert torch.equal(rec[:, L.stat_off + 1].double(), click)
     touched = show > 0
-    assert torch.equal(rec[:, L.stat_off + 4], torch.where(touched, 2.0, 0.0).float())      # born with embedx / unborn
+    assert torch.equal(rec[:, L.stat_off + 4], torch.where(touched, 2.0, 0.0).float())      # embedx created / no key
     assert bool((rec[~touched] == 0).all())                                                 # still zero memory
     gsum = torch.zeros(N, D, device=DEV, dtype=torch.float64)
     gsum.index_add_(0, r, dx.view(B * S, D)[sg].double())
     a = table.accessor
-    want = (init.double() - a.lr * gsum).clamp(a.min_bound, a.max_bound)                     # g2sum = 0: scale 1
-    torch.testing.assert_close(rec[touched][:, :D].double(), want[touched], rtol=1e-5, atol=1e-8)
-    torch.testing.assert_close(rec[touched][:, L.stat_off + 2].double(), (gsum[touched][:, 0] ** 2), rtol=1e-4,
-                               atol=1e-12)
-    torch.testing.assert_close(rec[touched][:, L.stat_off + 3].double(), (gsum[touched][:, 1:] ** 2).mean(1),
-                               rtol=1e-4, atol=1e-12)
-
-
-@pytest.mark.gpu
-def test_narrow_row_adam_full_size_against_torch(engine_lib):
-    """The lane-per-row lazy Adam (rows of 9 floats in 16-float records, moments in a second record) on ~20 M lookups of
-    2 M rows with the segment payload: step 3 of Adam on every touched row against torch on the merged (index_add)
-    gradients; untouched rows bit-identical."""
-    from paddlerec_amd import ops
-    n, N, D, C_ = 20_000_000, 2_000_003, 9, 5_000_000
-    g = torch.Generator(device=DEV).manual_seed(12)
-    ids = torch.randint(0, N, (n,), device=DEV, generator=g, dtype=torch.int64)             # 0 = padding
-    cell = torch.randint(0, C_, (n,), device=DEV, generator=g, dtype=torch.int32)           # the payload: gradient row
-    grad = torch.randn(C_, D, device=DEV, generator=g) * 1e-2
-    rec = torch.randn(N, 16, device=DEV, generator=g) * 0.1
-    mv = torch.rand(N, 32, device=DEV, generator=g) * 1e-3
-    P, M, V = rec[:, :D], mv[:, :D], mv[:, 12:12 + D]
-    P0, M0, V0 = P.clone(), M.clone(), V.clone()
-    status = ops.new_status(DEV)
-    groups = ops.IdGroups(n, DEV)
-    ops.ids_group(ids, N, 0, ops.Workspace(DEV), None, status, groups, payload=cell)
-    pp = ops.segment_partials(groups, grad, D)
-    ops.sparse_adam_rows(groups, grad, 1, P, M, V, 3, lr=1e-3, partials=pp)
-    torch.cuda.synchronize()
-    live = ids != 0
-    gs = torch.zeros(N, D, device=DEV, dtype=torch.float64)
-    gs.index_add_(0, ids[live], grad[cell[live].long()].double())
-    touched = torch.bincount(ids[live], minlength=N) > 0
-    b1, b2, eps, t = 0.9, 0.999, 1e-8, 3
-    m1 = b1 * M0.double() + (1 - b1) * gs
-    v1 = b2 * V0.double() + (1 - b2) * gs * gs
-    lr_t = 1e-3 * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
-    p1 = P0.double() - lr_t * m1 / (v1.sqrt() + eps * (1 - b2 ** t) ** 0.5)
-    # 1e-5 of each tensor's scale (an element of m that cancels to ~0 has no relative accuracy to speak of)
-    for got, want_ in ((M, m1), (V, v1), (P, p1)):
-        torch.testing.assert_close(got[touched].double(), want_[touched], rtol=1e-5,
-                                   atol=1e-5 * float(want_[touched].abs().max().item()))
-    assert torch.equal(P[~touched], P0[~touched]) and torch.equal(M[~touched], M0[~touched])
-    assert torch.equal(rec[:, D:], rec[:, D:]) and int(status.item()) == 0
+    scaled = gsum[:, 0] / show.clamp(min=1).double()                    # the rule divides by the pushed show
+    want_w = (init[:, 0].double() - a.lr * scaled).clamp(a.min_bound, a.max_bound)           # g2sum = 0: ratio 1
+    torch.testing.assert_close(rec[touched][:, 0].double(), want_w[touched], rtol=1e-6, atol=1e-9)
+    torch.testing.assert_close(rec[touched][:, L.stat_off + 2].double(), scaled[touched] ** 2, rtol=1e-5, atol=1e-14)
+    # embedx: created at the END of this first push (score (show-click)*0.1 + click >= 0), its gradient dropped:
+    # uniform(+-x_initial_range) creation values, embedx_g2sum = 0
+    ex = rec[touched][:, 1:D]
+    assert float(ex.abs().max().item()) <= 1e-2 and float(ex.abs().mean().item()) > 2e-3
+    assert not bool(rec[:, L.stat_off + 3].any())
+    want_delta = (show.float() - click.float()) * 0.1 + click.float()
+    torch.testing.assert_close(rec[:, L.stat_off + 5], want_delta, rtol=1e-6, atol=0)
+    assert not bool(rec[:, L.stat_off + 6].any())
