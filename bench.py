@@ -156,6 +156,46 @@ def cpu_baseline(B, S, Dn, D, fc, rows_per_table, budget_s=20.0):
                       "NumPy/BLAS MLP fwd/bwd + dense Adam), %.1f s" % (steps, B, t_total)}
 
 
+def reference_trainer_baseline(budget_s=60.0):
+    """north_star / SURVEY §8(d) "CPU baseline (1)": the reference's OWN tools/trainer.py, unmodified, on its own
+    models/rank/deepfm/config.yaml (BASELINE configs[0]: sample data, bs 2, D 9, 1 000 001-row table, dygraph Adam
+    lazy_mode=False), run as a subprocess through paddlerec_amd.run_reference over the `paddle` compat namespace with
+    the ORACLE operator backend (tests/cpu_kernels.py), on this box's host cores, in this same bench run.  The value
+    is the reference's own `ips` log line (tools/trainer.py:179-186), mean over the printed intervals after the first.
+    Real PaddlePaddle CPU numbers cannot be produced (no Paddle wheel): this measures the reference's Python loop +
+    reader + the NumPy oracle.  The tree is oracle/_ref/PaddleRec (byte copies staged by oracle/make_ref_tree.py) or
+    /root/reference where that exists."""
+    import re
+    import subprocess
+    import tempfile
+    ref = next((d for d in (os.path.join(REPO, "oracle", "_ref", "PaddleRec"), "/root/reference")
+                if os.path.isdir(os.path.join(d, "tools"))), None)
+    if ref is None:
+        return {"error": "no reference tree (oracle/make_ref_tree.py stages it in the build container)"}
+    threads = min(os.cpu_count() or 1, 16)        # the NumPy oracle at bs 2 does not scale past a few threads
+    env = dict(os.environ, REC_COMPAT_KERNELS="cpu_kernels", OMP_NUM_THREADS=str(threads))
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(REPO, "tests"), REPO, env.get("PYTHONPATH", "")])
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [sys.executable, "-m", "paddlerec_amd.run_reference", os.path.join(ref, "tools", "trainer.py"),
+               "-m", os.path.join(ref, "models", "rank", "deepfm", "config.yaml"), "-o", "runner.epochs=1",
+               "runner.print_interval=5", "runner.use_gpu=False", "runner.model_save_path=%s" % os.path.join(tmp, "o")]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, cwd=ref, env=env, capture_output=True, text=True, timeout=budget_s)
+        except subprocess.TimeoutExpired:
+            return {"error": "reference trainer did not finish in %.0f s" % budget_s}
+        dt = time.perf_counter() - t0
+    log = r.stdout + r.stderr
+    ips = [float(x) for x in re.findall(r"ips: ([0-9.]+) ins/s", log)]
+    if r.returncode != 0 or len(ips) < 2:
+        return {"error": "reference trainer failed (rc %d): %s" % (r.returncode, log[-300:])}
+    return {"value": sum(ips[1:]) / len(ips[1:]), "unit": "samples/s", "cores": threads, "host_cores": os.cpu_count(),
+            "kind": "reference-trainer-over-shim",
+            "sample": "the reference's unmodified tools/trainer.py, 1 epoch of models/rank/deepfm/config.yaml "
+                      "(configs[0]: 80 sample lines, bs 2, D 9, N 1000001, non-lazy Adam) over the compat namespace "
+                      "with the NumPy oracle backend; its own ips lines (%d intervals), %.1f s wall" % (len(ips) - 1, dt)}
+
+
 class _QuietStdout:
     """fd 1 -> fd 2 for a region, C stdio flushed before it is restored."""
 
@@ -440,6 +480,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(B, S, Dn, D, fc, args.rows_per_table, args.cpu_budget)
             except Exception as e:  # the oracle .so is test infrastructure; report, do not hide
                 out["cpu_baseline"] = {"error": repr(e)}
+            try:    # the reference's own trainer loop on this box's cores, same run (its CPU-runnable config)
+                out["cpu_baseline"]["reference_trainer"] = reference_trainer_baseline()
+            except Exception as e:
+                out["cpu_baseline"]["reference_trainer"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -11,6 +11,11 @@ record layout never leaks: tables are exported as the reference'
 Row-sharded models (paddlerec_amd/sharded.py) write one file per rank, `rec.shard{r}of{G}.pdparams`, holding the
 rows r, r+G, r+2G, ... of each table plus the replicated dense parameters; `load_model` re-shards on load, so a
 checkpoint written by G ranks can be resumed by any G'.
+PS / gpubox tables (ops.PsTable: ShardedDeepFMLayer(table='ps'), BenchmarkDNNLayer(sparse_optimizer='ps')) are saved
+as the EXISTING feature values only — `ps.rows` (GLOBAL row ids) + `ps.records` (the whole accessor record: weights,
+show / click, g2sums, state, delta_score, unseen_days) — never as a dense [N,D] parameter: a 1.25e9-row shard with a few
+million live keys is a few hundred MB on disk, and a loaded value keeps its state (a dense export would come back as
+"no such key" and be overwritten by the first push).  There is no Adam row state for such a table.
 """
 import os
 import pickle
@@ -57,6 +62,43 @@ def set_optimizer_state(net, st):
                 dst.copy_(torch.as_tensor(st["sparse." + k]).to(dst.device).reshape(dst.shape))
 
 
+def _ps_table(net):
+    """The ops.PsTable of a net, or None."""
+    t = getattr(net, "ps", None)
+    return t if t is not None else getattr(net, "table", None)
+
+
+def _ps_export(net):
+    """{ps.rows: GLOBAL ids of the existing values, ps.records: their accessor records, ps.meta} of a PS table."""
+    t = _ps_table(net)
+    comm = getattr(net, "comm", None)
+    world, rank = (comm.world, comm.rank) if comm is not None else (1, 0)
+    live = torch.nonzero(t.rec[:, t.state_col] != 0).reshape(-1)
+    glob = getattr(net, "global_rows", t.num_rows)
+    return {"ps.rows": (live * world + rank).cpu().numpy().astype(np.int64), "ps.records": _np(t.rec[live]),
+            "ps.meta": np.asarray([glob, t.emb_dim, t.rec.shape[1], 1 if t.kind == "deepfm" else 0], np.int64)}
+
+
+def _ps_import(net, sd, zero_first=True):
+    """Writes the values of a ps.rows / ps.records pair this rank owns into its table (re-shards by global id)."""
+    t = _ps_table(net)
+    comm = getattr(net, "comm", None)
+    world, rank = (comm.world, comm.rank) if comm is not None else (1, 0)
+    meta = sd["ps.meta"]
+    glob = getattr(net, "global_rows", t.num_rows)
+    if int(meta[0]) != glob or int(meta[1]) != t.emb_dim or int(meta[2]) != t.rec.shape[1] or \
+            int(meta[3]) != (1 if t.kind == "deepfm" else 0):
+        raise ValueError("checkpoint holds a PS table %s, the model's is %s"
+                         % (meta.tolist(), [glob, t.emb_dim, t.rec.shape[1], 1 if t.kind == "deepfm" else 0]))
+    if zero_first:
+        t.rec.zero_()
+    rows = np.asarray(sd["ps.rows"], np.int64)
+    mine = np.nonzero(rows % world == rank)[0]
+    if len(mine):
+        di = torch.as_tensor(rows[mine] // world, device=t.rec.device)
+        t.rec[di] = torch.as_tensor(np.asarray(sd["ps.records"])[mine]).to(t.rec.device)
+
+
 def save_model(net, optimizer, model_path, epoch_id, prefix="rec"):
     """tools/utils/save_load.py:25-31.  `optimizer` may be None (state is read from the net) or a dict."""
     model_path = os.path.join(model_path, str(epoch_id))
@@ -64,6 +106,10 @@ def save_model(net, optimizer, model_path, epoch_id, prefix="rec"):
     model_prefix = os.path.join(model_path, prefix)
     comm = getattr(net, "comm", None)
     sd = {k: _np(v) for k, v in net.state_dict().items()}
+    if _ps_table(net) is not None:              # the accessor table: existing values only, whole records
+        for k in TABLE_KEYS + ("embedding",):
+            sd.pop(k, None)
+        sd.update(_ps_export(net))
     opt = optimizer if isinstance(optimizer, dict) else optimizer_state(net)
     if comm is not None and comm.world > 1:
         tag = ".shard%dof%d" % (comm.rank, comm.world)
@@ -128,7 +174,11 @@ def _load_global(model_prefix):
         with open(src, "rb") as f:
             return pickle.load(f)
     parts, world, n_rows = _read_shards(src)
-    out = {k: v for k, v in parts[0].items() if k != "__shard__" and k not in TABLE_KEYS}
+    out = {k: v for k, v in parts[0].items() if k != "__shard__" and k not in TABLE_KEYS and not k.startswith("ps.")}
+    if "ps.rows" in parts[0]:                   # a PS table: concatenate the shards' existing values
+        out["ps.rows"] = np.concatenate([p["ps.rows"] for p in parts])
+        out["ps.records"] = np.concatenate([p["ps.records"] for p in parts])
+        out["ps.meta"] = parts[0]["ps.meta"]
     for key in TABLE_KEYS:
         if key in parts[0]:
             local = parts[0][key].shape[0]
@@ -146,58 +196,76 @@ def _reshard_rows(old_rank, old_world, n_local_old, new_rank, new_world, n_rows)
     return np.nonzero(keep)[0], g[keep] // new_world
 
 
+def _shard_id(path):
+    """(rank, world) from the file name rec.shard{r}of{G}.pdparams — no unpickling."""
+    import re
+    m = re.search(r"\.shard(\d+)of(\d+)\.pd(?:params|opt)$", path)
+    if not m:
+        raise ValueError("not a shard file: %s" % path)
+    return int(m.group(1)), int(m.group(2))
+
+
 def _load_sharded(net, model_prefix, shard_paths, load_optimizer):
-    """A row-sharded net resumes from rank shards WITHOUT assembling the global table: with the same world size a
-    rank reads its own file; otherwise it walks the old shards one at a time and keeps the rows it owns now.  The
-    per-rank optimizer shards (step, dense and sparse Adam moments) are restored the same way."""
+    """A row-sharded net resumes from rank shards WITHOUT assembling the global table and without holding more than
+    ONE shard in host memory: the plan comes from the file names; with the same world size a rank opens only its own
+    file; otherwise it walks the old shards one at a time, keeps the rows it owns now and drops the shard before the
+    next.  The per-rank optimizer shards (step, dense and sparse Adam moments) are restored the same way."""
     from .deepfm import DeepFMLayer
     comm = net.comm
-    heads = []
-    for fn in shard_paths:                      # headers only decide the plan; the payload is read shard by shard
-        with open(fn, "rb") as f:
-            heads.append((fn, pickle.load(f)))
-    heads.sort(key=lambda t: int(t[1]["__shard__"][0]))
-    old_world, n_rows = int(heads[0][1]["__shard__"][1]), int(heads[0][1]["__shard__"][2])
-    if len(heads) != old_world:
-        raise ValueError("checkpoint has %d of %d shards" % (len(heads), old_world))
-    if n_rows != net.global_rows:
-        raise ValueError("checkpoint table has %d rows, the model %d" % (n_rows, net.global_rows))
+    files = sorted(shard_paths, key=lambda f: _shard_id(f)[0])
+    old_world = _shard_id(files[0])[1]
+    if len(files) != old_world or [_shard_id(f)[0] for f in files] != list(range(old_world)):
+        raise ValueError("checkpoint has %d of %d shards" % (len(files), old_world))
+    same = old_world == comm.world
+    todo = [files[comm.rank]] if same else files
+    ps = _ps_table(net) is not None
     net._next_lookup = None
     local = net.state_dict()
-    dense = {k: v for k, v in heads[0][1].items() if k != "__shard__" and k not in TABLE_KEYS}
-    DeepFMLayer.set_dict(net, dense)
-    opt_parts = []
-    if load_optimizer:
-        for fn, _ in heads:
-            of = fn[: -len(".pdparams")] + ".pdopt"
-            if os.path.exists(of):
-                with open(of, "rb") as f:
-                    opt_parts.append(pickle.load(f))
-        if len(opt_parts) != old_world:
-            opt_parts = []
-    if opt_parts:
-        set_optimizer_state(net, {k: v for k, v in opt_parts[0].items() if not k.startswith("sparse.")})
-        net._ensure_sparse_state()
-    for r_old, (fn, sd) in enumerate(heads):
-        for key in TABLE_KEYS:
-            if key not in sd:
-                continue
-            src_idx, dst_idx = _reshard_rows(r_old, old_world, sd[key].shape[0], comm.rank, comm.world, n_rows)
-            if len(src_idx) == 0:
-                continue
-            dst = local[key]
-            di = torch.as_tensor(dst_idx, device=dst.device)
-            dst[di] = torch.as_tensor(sd[key][src_idx]).to(dst.device).reshape(len(src_idx), -1)
-        if opt_parts:
-            for k in ("m", "v", "m1", "v1"):
-                arr = opt_parts[r_old].get("sparse." + k)
-                if arr is None or k not in net.sparse_state:
+    opt_ok = load_optimizer and all(os.path.exists(f[: -len(".pdparams")] + ".pdopt") for f in files)
+    first = True
+    for fn in todo:
+        with open(fn, "rb") as f:
+            sd = pickle.load(f)
+        r_old, n_rows = int(sd["__shard__"][0]), int(sd["__shard__"][2])
+        if n_rows != net.global_rows:
+            raise ValueError("checkpoint table has %d rows, the model %d" % (n_rows, net.global_rows))
+        opt = None
+        if opt_ok:
+            with open(fn[: -len(".pdparams")] + ".pdopt", "rb") as f:
+                opt = pickle.load(f)
+        if first:       # the replicated dense parameters / dense moments / step: any one shard holds them
+            DeepFMLayer.set_dict(net, {k: v for k, v in sd.items()
+                                       if k != "__shard__" and k not in TABLE_KEYS and not k.startswith("ps.")})
+            if opt is not None:
+                set_optimizer_state(net, {k: v for k, v in opt.items() if not k.startswith("sparse.")})
+                if not ps:
+                    net._ensure_sparse_state()          # (a PS table has no Adam row state: nothing to allocate)
+        if ps:
+            if "ps.rows" not in sd:
+                raise ValueError("%s holds no PS table (written by a table='adam' run?)" % fn)
+            _ps_import(net, sd, zero_first=first)
+        else:
+            for key in TABLE_KEYS:
+                if key not in sd:
                     continue
-                src_idx, dst_idx = _reshard_rows(r_old, old_world, arr.shape[0], comm.rank, comm.world, n_rows)
-                if len(src_idx):
-                    dst = net.sparse_state[k]
-                    di = torch.as_tensor(dst_idx, device=dst.device)
-                    dst[di] = torch.as_tensor(arr[src_idx]).to(dst.device).reshape(len(src_idx), -1)
+                src_idx, dst_idx = _reshard_rows(r_old, old_world, sd[key].shape[0], comm.rank, comm.world, n_rows)
+                if len(src_idx) == 0:
+                    continue
+                dst = local[key]
+                di = torch.as_tensor(dst_idx, device=dst.device)
+                dst[di] = torch.as_tensor(sd[key][src_idx]).to(dst.device).reshape(len(src_idx), -1)
+            if opt is not None:
+                for k in ("m", "v", "m1", "v1"):
+                    arr = opt.get("sparse." + k)
+                    if arr is None or k not in net.sparse_state:
+                        continue
+                    src_idx, dst_idx = _reshard_rows(r_old, old_world, arr.shape[0], comm.rank, comm.world, n_rows)
+                    if len(src_idx):
+                        dst = net.sparse_state[k]
+                        di = torch.as_tensor(dst_idx, device=dst.device)
+                        dst[di] = torch.as_tensor(arr[src_idx]).to(dst.device).reshape(len(src_idx), -1)
+        first = False
+        del sd, opt
 
 
 def load_model(model_path, net, prefix="rec", load_optimizer=True):
@@ -209,7 +277,13 @@ def load_model(model_path, net, prefix="rec", load_optimizer=True):
         if kind == "shards":
             _load_sharded(net, model_prefix, src, load_optimizer)
             return net
-    net.set_dict(_load_global(model_prefix))
+    sd = _load_global(model_prefix)
+    if "ps.rows" in sd:
+        if _ps_table(net) is None:
+            raise ValueError("the checkpoint holds a PS accessor table, the model does not")
+        _ps_import(net, sd)
+        sd = {k: v for k, v in sd.items() if not k.startswith("ps.")}
+    net.set_dict(sd)
     opt_file = model_prefix + ".pdopt"
     if load_optimizer and os.path.exists(opt_file) and comm is None:
         with open(opt_file, "rb") as f:

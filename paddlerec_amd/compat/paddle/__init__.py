@@ -148,6 +148,8 @@ def create_parameter(shape, dtype="float32", default_initializer=None, attr=None
     if init is not None:
         with _t.no_grad():
             init(p)
+    if attr is not None and getattr(attr, "regularizer", None) is not None:
+        p._regularizer = attr.regularizer
     return p
 
 

@@ -41,6 +41,9 @@ def _init_from(attr, p, default):
     init = getattr(attr, "initializer", None) if attr is not None else None
     with _t.no_grad():
         (init or default)(p)
+    reg = getattr(attr, "regularizer", None) if attr is not None else None
+    if reg is not None:           # ParamAttr(regularizer=L2Decay(c)): applied by the optimizer (dcn_v2/net.py:164-170)
+        p._regularizer = reg
 
 
 class _EmbeddingFn(_t.autograd.Function):
@@ -144,3 +147,11 @@ class Dropout(Layer):
 
 class Conv1D(Layer):  # imported by din/net.py:13, never used
     pass
+
+
+class ClipGradByGlobalNorm:
+    """paddle.nn.ClipGradByGlobalNorm(clip_norm) (dcn_v2/dygraph_model.py:81-88): passed to an optimizer as grad_clip;
+    the optimizer multiplies every gradient by clip_norm / max(global_norm, clip_norm) (paddle/optimizer.py here)."""
+
+    def __init__(self, clip_norm, group_name="default_group"):
+        self.clip_norm = float(clip_norm)

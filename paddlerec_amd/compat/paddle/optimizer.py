@@ -3,7 +3,14 @@
 Dense parameters: rec_adam_dense / rec_sgd_dense per parameter.  Embedding parameters arrive as SelectedRows gradients
 (ids + rows stashed by nn.Embedding's backward): merged with rec_ids_group and applied by rec_adam_rows_all (the dygraph
 default lazy_mode=False: every row's moments decay, deepfm/dygraph_model.py:61-65) or
-rec_sparse_adam_rows (lazy_mode=True) / rec_sparse_sgd_rows."""
+rec_sparse_adam_rows (lazy_mode=True) / rec_sparse_sgd_rows.
+
+weight_decay / ParamAttr(regularizer=L2Decay(c)) (dcn_v2/net.py:164-170: L2Decay(1e-7) on the DNN weights; xdeepfm:
+L2Decay(1e-4)): Paddle appends the regulariser to the GRADIENT before the optimizer rule [EXT append_regularization_ops]
+— g += c * w on dense parameters; a parameter's own regulariser wins over the optimizer's weight_decay.
+grad_clip = nn.ClipGradByGlobalNorm(clip_norm) (dcn_v2/dygraph_model.py:81-88): every gradient — the merged rows of
+SelectedRows gradients included — is multiplied by clip_norm / max(global_norm, clip_norm): rec_sumsq /
+rec_sparse_rows_sumsq / rec_clip_scale, the coefficient handed to the update kernels as a device scalar."""
 import torch as _t
 
 from . import _backend
@@ -13,6 +20,9 @@ class _Base:
     def __init__(self, learning_rate=0.001, parameters=None, weight_decay=None, grad_clip=None):
         self._lr = learning_rate
         self._params = [p for p in (parameters or [])]
+        self._weight_decay, self._grad_clip = weight_decay, grad_clip
+        if grad_clip is not None and not hasattr(grad_clip, "clip_norm"):
+            raise NotImplementedError("compat optimizer: grad_clip %r (only nn.ClipGradByGlobalNorm)" % (grad_clip,))
         self._step = 0
         self._state = {}
         self._ws = None
@@ -45,6 +55,45 @@ class _Base:
         K.ids_group(ids.contiguous(), p.shape[0], pad, self._ws, None, status, grp)
         return grp, rows
 
+    @staticmethod
+    def _coeff(reg):
+        if reg is None:
+            return 0.0
+        if isinstance(reg, (int, float)):
+            return float(reg)
+        if hasattr(reg, "coeff"):
+            return float(reg.coeff)
+        raise NotImplementedError("compat optimizer: regularizer %r (only L2Decay / a float)" % (reg,))
+
+    def _prepare(self):
+        """Regularisation into the dense gradients, then the global-norm clipping coefficient.
+        -> (sparse: {id(p): (groups, rows)}, scale: device float[1] or None)"""
+        K = _backend.kernels()
+        sparse = {}
+        for p in self._params:
+            if getattr(p, "_sparse_grads", None):
+                if self._coeff(getattr(p, "_regularizer", None)):
+                    raise NotImplementedError("compat optimizer: a regularizer on a sparse=True embedding")
+                sparse[id(p)] = self._merged_keys(p)
+            elif p.grad is not None:
+                c = self._coeff(getattr(p, "_regularizer", None) or self._weight_decay)
+                if c:
+                    p.grad = p.grad.add(p.detach(), alpha=c)
+        scale = None
+        if self._grad_clip is not None:
+            dev = self._params[0].device
+            if self._ws is None:
+                self._ws = K.Workspace(dev)
+            ss = _t.zeros(1, dtype=_t.float32, device=dev)
+            for p in self._params:
+                if id(p) in sparse:
+                    grp, rows = sparse[id(p)]
+                    K.sparse_rows_sumsq(grp, rows, rows.shape[1], ss, self._ws, accumulate=True)
+                elif p.grad is not None:
+                    K.sumsq(p.grad.contiguous().view(-1), ss, self._ws, accumulate=True)
+            scale = K.clip_scale(ss, float(self._grad_clip.clip_norm), _t.empty_like(ss))
+        return sparse, scale
+
     def state_dict(self):
         out = {"step": self._step}
         for i, p in enumerate(self._params):
@@ -65,13 +114,15 @@ class Adam(_Base):
         t, lr = self._step, self.get_lr()
         kw = dict(lr=lr, beta1=self._b1, beta2=self._b2, eps=self._eps)
         with _t.no_grad():
+            merged, scale = self._prepare()
+            kw["grad_scale"] = scale
             for p in self._params:
-                sparse = getattr(p, "_sparse_grads", None)
+                sparse = id(p) in merged
                 if not sparse and p.grad is None:
                     continue
                 st = self._state.setdefault(id(p), {"m": _t.zeros_like(p), "v": _t.zeros_like(p)})
                 if sparse:
-                    grp, rows = self._merged_keys(p)
+                    grp, rows = merged[id(p)]
                     upd = K.sparse_adam_rows if self._lazy else K.adam_rows_all
                     upd(grp, rows, 1, p.data, st["m"], st["v"], t, **kw)
                 else:
@@ -84,10 +135,11 @@ class SGD(_Base):
         self._step += 1
         lr = self.get_lr()
         with _t.no_grad():
+            merged, scale = self._prepare()
             for p in self._params:
-                sparse = getattr(p, "_sparse_grads", None)
-                if sparse:
-                    grp, rows = self._merged_keys(p)
-                    K.sparse_sgd_rows(grp, rows, p.data, lr)
+                if id(p) in merged:
+                    grp, rows = merged[id(p)]
+                    K.sparse_sgd_rows(grp, rows if scale is None else rows * scale, p.data, lr)
                 elif p.grad is not None:
-                    K.sgd_dense(p.data.view(-1), p.grad.contiguous().view(-1), lr)
+                    g = p.grad.contiguous().view(-1)
+                    K.sgd_dense(p.data.view(-1), g if scale is None else g * scale, lr)

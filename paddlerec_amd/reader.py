@@ -32,6 +32,16 @@ def _alloc(n, S, Dn, pinned):
     return label, ids, dense
 
 
+def _close_mmap(mm):
+    """Closes a text mapping.  If the parser raised, the traceback's frames may still hold the NumPy view _buf()
+    exported from it and mmap.close() raises BufferError('cannot close exported pointers exist') — which would mask
+    the parse error that matters.  Then the mapping is left to the garbage collector."""
+    try:
+        mm.close()
+    except BufferError:
+        pass
+
+
 def _buf(data):
     """(char pointer, length, keep-alive) of the text: a bytes object, or any buffer — the readers hand in an mmap of
     the file, so the parser threads read the page cache directly and no copy of the text is made."""
@@ -155,7 +165,7 @@ def feasign_batches(file_list, batch_size, first_slot=1, num_slots=301, hash_row
                 values, lod, base, n = parse_feasign_slots(mm, first_slot, num_slots, hash_rows, threads)
                 blank = blank_lines(mm, threads).tolist()
             finally:
-                mm.close()
+                _close_mmap(mm)
         edges = [-1] + [b for b in blank if b < n] + [n]       # runs of real lines between the (rare) blank ones
         for a, z in zip(edges[:-1], edges[1:]):
             lo = a + 1
@@ -194,7 +204,7 @@ class _FileBatches:
             try:
                 return self.parse(mm)
             finally:
-                mm.close()
+                _close_mmap(mm)
 
     def _files(self):
         """Parsed files in order; the NEXT file is read and parsed by a background thread (the parser is a C call that

@@ -280,6 +280,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
             if key in sd:
                 src = torch.as_tensor(sd.pop(key)).reshape(self.global_rows, -1)[r::G]
                 dst[: src.shape[0]].copy_(src.to(dst.device))
+                if self.ps is not None:     # explicitly set rows EXIST (with their embedx part): otherwise the first
+                    self.ps.rec[: src.shape[0], self.ps.state_col] = 2.0   # push would create them over the loaded values
         super().set_dict(sd)
 
     def gather_global_tables(self):

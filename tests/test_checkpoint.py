@@ -78,3 +78,81 @@ def test_deepfm_resume_continues_identically(engine_lib, tmp_path):
     assert torch.equal(loss_a, loss_b)
     for k, v in m.state_dict().items():
         assert torch.equal(v, m2.state_dict()[k]), k
+
+
+# --------------------------------------------------------------------------------------- PS / gpubox accessor tables
+class _FakeComm:
+    def __init__(self, r, w):
+        self.rank, self.world = r, w
+
+
+class _PsNet:
+    """A net with a row-sharded ops.PsTable ('deepfm' records) and one dense parameter — the surface checkpoint.py uses
+    of ShardedDeepFMLayer(table='ps'), without a process group."""
+
+    def __init__(self, rank, world, n_global=23, D=4):
+        from paddlerec_amd.ops import PsTable
+        self.comm, self.global_rows = _FakeComm(rank, world), n_global
+        self.ps = PsTable((n_global + world - 1) // world, D, "cpu", kind="deepfm", row_mul=world, row_add=rank)
+        self.dense_w = torch.zeros(3, 2)
+        self.step_count = 0
+        self.sparse_state = None
+
+    def state_dict(self):
+        D = self.ps.emb_dim
+        return {"fm.embedding.weight": self.ps.rec[:, :D], "fm.embedding_one.weight": self.ps.rec[:, D:D + 1],
+                "dnn.linear_0.weight": self.dense_w}
+
+    def set_dict(self, sd):
+        assert not any(k.startswith("fm.") or k.startswith("ps.") for k in sd), "tables must not come back dense"
+        for k, v in sd.items():
+            self.dense_w.copy_(torch.as_tensor(v))
+
+    def _ensure_sparse_state(self):
+        raise AssertionError("a PS table has no Adam row state: nothing must be allocated for it")
+
+
+def _fill(nets, seed=0):
+    """Some existing values (global rows 1, 4, 5, 9, 22) with recognisable records; the rest stays 'no such key'."""
+    world = len(nets)
+    g = torch.Generator().manual_seed(seed)
+    want = {}
+    for row in (1, 4, 5, 9, 22):
+        t = nets[row % world].ps
+        rec = torch.randn(t.rec.shape[1], generator=g)
+        rec[t.state_col] = 2.0 if row % 2 else 1.0
+        t.rec[row // world] = rec
+        want[row] = rec.clone()
+    for n in nets:
+        n.dense_w.fill_(3.5)
+        n.step_count = 11
+    return want
+
+
+@pytest.mark.parametrize("old_world,new_world", [(2, 2), (2, 3), (3, 1), (1, 2)])
+def test_ps_table_checkpoint_keeps_whole_records_and_reshards(tmp_path, old_world, new_world, monkeypatch):
+    """a PS table used to be saved through the dense fm.embedding views — show / click / g2sum / state were
+    lost and every loaded row came back as 'no such key'.  Now: existing values only, whole records, any world size."""
+    from paddlerec_amd.deepfm import DeepFMLayer
+    monkeypatch.setattr(DeepFMLayer, "set_dict", lambda self, sd: self.set_dict(sd), raising=False)
+    old = [_PsNet(r, old_world) for r in range(old_world)]
+    want = _fill(old)
+    for n in old:
+        d = ck.save_model(n, None, str(tmp_path), 0)
+    raw = pickle.load(open(os.path.join(d, "rec.pdparams" if old_world == 1 else "rec.shard0of%d.pdparams" % old_world), "rb"))
+    assert "fm.embedding.weight" not in raw and raw["ps.records"].shape[1] == old[0].ps.rec.shape[1]
+    assert set(int(x) for x in raw["ps.rows"]) == {r for r in want if r % old_world == 0}
+    new = [_PsNet(r, new_world) for r in range(new_world)]
+    for n in new:
+        n.ps.rec.fill_(9.0)                       # stale content must be gone after the load
+        if new_world == 1:
+            n.comm = None
+        ck.load_model(d, n)
+    for n in new:
+        assert float(n.dense_w[0, 0]) == 3.5
+    for row in range(23):
+        rec = new[row % new_world].ps.rec[row // new_world]
+        if row in want:
+            assert torch.equal(rec, want[row]), row
+        else:
+            assert not rec.any(), row

@@ -1,8 +1,12 @@
 """The reference's OWN driver, unmodified (row N1): `tools/trainer.py -m models/rank/deepfm/config.yaml` executed through
-paddlerec_amd.run_reference over the product `paddle` compat namespace (paddlerec_amd/compat) — build container only
-(needs /root/reference).  Here: no GPU, so the operator backend is the oracle-backed stand-in (REC_COMPAT_KERNELS);
-the loss lines the reference prints and the checkpoint it writes must equal the oracle's trajectory from the same
-initial parameters (dygraph Adam, lazy_mode=False: every row decays each step)."""
+paddlerec_amd.run_reference over the product `paddle` compat namespace (paddlerec_amd/compat).  The loss lines the
+reference prints and the checkpoint it writes must equal the oracle's trajectory from the same initial parameters
+(dygraph Adam, lazy_mode=False: every row decays each step).
+  * not gpu: the operator backend is the oracle-backed stand-in (REC_COMPAT_KERNELS) — the host logic of the namespace;
+  * -m gpu : `runner.use_gpu=True`, the HIP kernels behind the C-ABI carry the lookup, GEMMs, merge and optimizers.
+The reference tree is /root/reference in the build container; on the GPU box (no /root/reference) it is the byte copy
+of the needed files that oracle/make_ref_tree.py stages under oracle/_ref/PaddleRec (git-ignored, travels with the
+snapshot)."""
 import os
 import pickle
 import re
@@ -14,8 +18,10 @@ import pytest
 
 from conftest import REPO
 
-REF = os.environ.get("PADDLEREC_REF", "/root/reference")
-pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "tools")), reason="reference tree not present")
+STAGED = os.path.join(REPO, "oracle", "_ref", "PaddleRec")
+REF = os.environ.get("PADDLEREC_REF") or ("/root/reference" if os.path.isdir("/root/reference/tools") else STAGED)
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "tools")),
+                                reason="reference tree not present (run oracle/make_ref_tree.py in the build container)")
 
 INIT_SCRIPT = r"""
 import os, sys, pickle
@@ -24,26 +30,60 @@ sys.path.insert(0, %(repo)r)
 sys.path.insert(0, os.path.join(%(ref)r, "models", "rank", "deepfm"))
 import paddle
 paddle.seed(12345)
-paddle.set_device("cpu")
+paddle.set_device(%(dev)r)
 import net
 m = net.DeepFMLayer(1000001, 9, 13, 26, [512, 256, 128, 32])
 pickle.dump({k: v.detach().numpy() for k, v in m.state_dict().items()}, open(sys.argv[1], "wb"))
 """
 
 
-def _env():
-    env = dict(os.environ, REC_COMPAT_KERNELS="cpu_kernels", OMP_NUM_THREADS="4")
+def _env(gpu=False):
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    if not gpu:
+        env["REC_COMPAT_KERNELS"] = "cpu_kernels"
+    else:
+        env.pop("REC_COMPAT_KERNELS", None)
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(REPO, "tests"), REPO, env.get("PYTHONPATH", "")])
     return env
 
 
+def test_staged_tree_is_a_byte_copy():
+    """oracle/_ref/PaddleRec (what the GPU box runs) holds unmodified copies of the reference's files."""
+    if not (os.path.isdir("/root/reference/tools") and os.path.isdir(STAGED)):
+        pytest.skip("needs both /root/reference and the staged tree")
+    n = 0
+    for root, _, files in os.walk(STAGED):
+        for f in files:
+            if f == "STAGED_FROM" or f.endswith(".pyc") or "__pycache__" in root or f == "tmp.txt":
+                continue
+            rel = os.path.relpath(os.path.join(root, f), STAGED)
+            if rel.startswith("output_model") or "output_model" in rel:
+                continue
+            with open(os.path.join(root, f), "rb") as a, open(os.path.join("/root/reference", rel), "rb") as b:
+                assert a.read() == b.read(), rel
+            n += 1
+    assert n >= 30
+
+
 def test_reference_trainer_runs_unmodified_and_matches_oracle(tmp_path):
+    _run_trainer_and_check(tmp_path, gpu=False)
+
+
+@pytest.mark.gpu
+def test_reference_trainer_unmodified_on_the_hip_kernels(tmp_path, engine_lib):
+    """Row N1 on the GPU: the reference's own tools/trainer.py, its loop, reader, dygraph_model.py and net.py, with
+    `runner.use_gpu=True` — every paddle op of the step executes on the HIP kernels through the compat namespace."""
+    _run_trainer_and_check(tmp_path, gpu=True)
+
+
+def _run_trainer_and_check(tmp_path, gpu):
     from oracle import deepfm_ref as R
     out_dir = tmp_path / "ckpt"
     cmd = [sys.executable, "-m", "paddlerec_amd.run_reference", os.path.join(REF, "tools", "trainer.py"),
            "-m", os.path.join(REF, "models", "rank", "deepfm", "config.yaml"),
-           "-o", "runner.epochs=1", "runner.print_interval=5", "runner.model_save_path=%s" % out_dir]
-    r = subprocess.run(cmd, cwd=REF, env=_env(), capture_output=True, text=True, timeout=900)
+           "-o", "runner.epochs=1", "runner.print_interval=5", "runner.model_save_path=%s" % out_dir,
+           "runner.use_gpu=%s" % ("True" if gpu else "False")]
+    r = subprocess.run(cmd, cwd=REF, env=_env(gpu), capture_output=True, text=True, timeout=900)
     log = r.stdout + r.stderr
     assert r.returncode == 0, log[-3000:]
     printed = [(int(m.group(1)), float(m.group(2))) for m in
@@ -53,8 +93,8 @@ def test_reference_trainer_runs_unmodified_and_matches_oracle(tmp_path):
     assert ips, "the reference's own ips line is missing"
     # the same initial parameters: the reference's net.py constructed over the compat namespace with the trainer's seed
     init_file = tmp_path / "init.pkl"
-    r2 = subprocess.run([sys.executable, "-c", INIT_SCRIPT % dict(repo=REPO, ref=REF), str(init_file)], env=_env(),
-                        capture_output=True, text=True, timeout=300)
+    r2 = subprocess.run([sys.executable, "-c", INIT_SCRIPT % dict(repo=REPO, ref=REF, dev="gpu" if gpu else "cpu"),
+                         str(init_file)], env=_env(gpu), capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0, r2.stderr[-2000:]
     sd = pickle.load(open(init_file, "rb"))
     n_mlp = 5
