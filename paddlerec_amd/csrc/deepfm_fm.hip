@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
     int64_t B, int S, int Dn, int D, int FP, const float* __restrict__ dense,
     const float* __restrict__ feat, const float* __restrict__ sum_emb,
     const float* __restrict__ dfeat, const float* __restrict__ dy1, const float* __restrict__ dy2,
-    const float* __restrict__ dense_w, float* __restrict__ row_grad, float* __restrict__ partial) {
+    const float* __restrict__ dense_w, float* __restrict__ row_grad, float* __restrict__ partial, int rg_nt) {
   constexpr int FS = fs_for<LANES>();
   constexpr int SPW = kWave / (LANES * FS);
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [waves][Dn*D + Dn]
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
           float de[VEC];
 #pragma unroll
           for (int v = 0; v < VEC; ++v) de[v] = g[u][v] + g2 * (sb[v] - e[u][v]);
-          vstore<VEC>(rg + (int64_t)f * D, de);
+          if (rg_nt) vstore_nt<VEC>(rg + (int64_t)f * D, de); else vstore<VEC>(rg + (int64_t)f * D, de);
         }
       }
     }
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
           de[v] = gd[k][v] + g2 * (sb[v] - e);
         }
         if (!isd) {
-          vstore<VEC>(rg + (int64_t)f * D, de);
+          if (rg_nt) vstore_nt<VEC>(rg + (int64_t)f * D, de); else vstore<VEC>(rg + (int64_t)f * D, de);
         } else {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) acc[k][v] += xd[k] * de[v];
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void fold_partials_kernel(const float* __re
 // blocks per CU (0 = occupancy limit; 2 and 3 measured slower), REC_FM_NT = 1 streams feat / d_feat with
 // non-temporal accesses (fm_bwd 71.3 -> 64.5 us, fm_fwd 73.8 -> 72.9 us).
 struct FmTune {
-  int fwd_bpc, bwd_bpc, nt;
+  int fwd_bpc, bwd_bpc, nt, fwd_nt, rg_nt;
 };
 static const FmTune& tune() {
   static const FmTune t = [] {
@@ -426,7 +426,11 @@ static const FmTune& tune() {
       const char* v = getenv(k);
       return v && *v ? atoi(v) : dflt;
     };
-    return FmTune{geti("REC_FM_FWD_BPC", 0), geti("REC_FM_BWD_BPC", 0), geti("REC_FM_NT", 1)};
+    const int nt = geti("REC_FM_NT", 1);
+    // REC_FM_FWD_NT: feat stores of the forward streamed (1) or cached (0); REC_FM_BWD_RG_NT: the backward's row
+    // gradients streamed (1) or cached (0) — measured in-step, profiles/r03_fm_instep.txt
+    return FmTune{geti("REC_FM_FWD_BPC", 0), geti("REC_FM_BWD_BPC", 0), nt, geti("REC_FM_FWD_NT", nt),
+                  geti("REC_FM_BWD_RG_NT", 0)};
   }();
   return t;
 }
@@ -486,7 +490,7 @@ extern "C" int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids
                        desc->num_rows, desc->padding_idx, ids, dense, W, W1, dense_w, dense_w_one, \
                        slot_offset, y1, y2, feat, sum_emb, status);                                \
   }
-#define REC_FWD_LAUNCH(IDCH) if (tune().nt) REC_FWD_LAUNCH2(IDCH, true) else REC_FWD_LAUNCH2(IDCH, false)
+#define REC_FWD_LAUNCH(IDCH) if (tune().fwd_nt) REC_FWD_LAUNCH2(IDCH, true) else REC_FWD_LAUNCH2(IDCH, false)
     if (idch <= 1) { REC_FWD_LAUNCH(1); }
     else if (idch <= 2) { REC_FWD_LAUNCH(2); }
     else if (idch <= 4) { REC_FWD_LAUNCH(4); }
@@ -555,7 +559,7 @@ extern "C" int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense
     grid = (int)g;                                                                                \
     hipLaunchKernelGGL((fm_bwd_kernel<VEC, LANES, NDI, NT_>), dim3(grid), dim3(kBlock), shmem, st, \
                        desc->batch, S, Dn, D, FP, dense, feat, sum_emb, d_feat_dnn, dy1, dy2,      \
-                       dense_w, row_grad, partial);                                                \
+                       dense_w, row_grad, partial, tune().rg_nt);                                  \
   }
 #define REC_BWD_LAUNCH(NDI) if (tune().nt) REC_BWD_LAUNCH2(NDI, true) else REC_BWD_LAUNCH2(NDI, false)
     if (nd <= 1) { REC_BWD_LAUNCH(1); }

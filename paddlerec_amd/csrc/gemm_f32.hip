@@ -173,6 +173,10 @@ __device__ __forceinline__ float apply_epi(float acc, int64_t i, int j, const Ep
   return apply_epi<EPI>(acc, load_aux0<EPI>(i, j, e), load_aux1<EPI>(i, j, e), load_bias<EPI>(j, e), i, e);
 }
 
+}  // namespace rec
+#include "gemm_glds.h"
+namespace rec {
+
 // --------------------------------------------------------------------------------------- kernel
 // OCC = blocks per CU the config is built for (launch bound = waves per SIMD).
 template <int BM, int BN, int WAVES_M, int WAVES_N, int OCC, bool TA, bool TB, int EPI>
@@ -932,6 +936,72 @@ static void launch_epi(const rec_gemm_desc* d, const GemmPlan& p, const float* A
   else launch_cfg<true, true, EPI>(d, p, A, B, C, e, partial, cpart, st);
 }
 
+// The LDS-DMA kernel (gemm_glds.h) for the tall whole-tile problems of the MLP path: A row-major, many rows, N a
+// multiple of one of its two block widths, the four epilogues of the forward / dX chain.  REC_GEMM_GLDS=0 switches it
+// off (A/B measurements); -> false: not eligible, the caller takes the register-staged kernels.
+template <int BM, int BN, bool TB>
+static bool launch_glds_cfg(const rec_gemm_desc* d, const float* A, const float* B, float* C, const EpiArgs& e,
+                            hipStream_t st) {
+  const int tiles_n = d->n / BN;
+  const int64_t tiles_total = (d->m / BM) * tiles_n;
+  constexpr size_t shmem = (size_t)kGldsStages * (BM + BN) * 64;
+  static_assert(shmem <= 64 * 1024, "LDS ring too large for the default dynamic-LDS limit");
+  // persistent blocks: two per CU (63 KB of LDS each), a multiple of 8 (XCD-aware tile numbering)
+  static const int cus = [] {
+    int dev = 0, v = kNumCU;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    return v > 0 ? v : kNumCU;
+  }();
+  static const int bpc = [] { const char* v = getenv("REC_GEMM_GLDS_BPC"); return v && *v ? atoi(v) : 2; }();
+  static const int skew = [] { const char* v = getenv("REC_GEMM_GLDS_SKEW"); return v && *v ? atoi(v) : 0; }();
+  int64_t grid = (int64_t)cus * bpc;
+  grid -= grid % 8;
+  if (grid > tiles_total) grid = tiles_total;
+#define REC_GLDS_CASE(E)                                                                                         \
+  case E:                                                                                                        \
+    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, TB, E>), dim3((unsigned)grid), dim3(512), shmem, st,        \
+                       d->m, d->n, d->k, A, (int64_t)d->lda, B, (int64_t)d->ldb, C, (int64_t)d->ldc, e, tiles_n, \
+                       tiles_total, skew);                                                                       \
+    return true;
+  switch (d->epilogue) {
+    REC_GLDS_CASE(REC_EPI_NONE)
+    REC_GLDS_CASE(REC_EPI_BIAS)
+    REC_GLDS_CASE(REC_EPI_BIAS_RELU)
+    REC_GLDS_CASE(REC_EPI_RELU_MASK)
+  }
+#undef REC_GLDS_CASE
+  return false;
+}
+
+static bool launch_glds(const rec_gemm_desc* d, const float* A, const float* B, float* C, const EpiArgs& e,
+                        hipStream_t st) {
+  static const bool on = [] { const char* v = getenv("REC_GEMM_GLDS"); return !(v && *v == '0'); }();
+  if (!on || d->trans_a || d->split_k > 1 || d->m < 8192 || d->k % kBK != 0 || d->k < 2 * kBK) return false;
+  if (d->lda % 4 || d->ldb % 4 || ((uintptr_t)A) % 16 || ((uintptr_t)B) % 16) return false;
+  if (d->ldc % 4 || ((uintptr_t)C) % 16) return false;                       // float4 stores of C
+  if (d->epilogue == REC_EPI_RELU_MASK && (e.ld0 % 4 || ((uintptr_t)e.aux0) % 16)) return false;
+  const int e_ = d->epilogue;
+  if (!(e_ == REC_EPI_NONE || e_ == REC_EPI_BIAS || e_ == REC_EPI_BIAS_RELU || e_ == REC_EPI_RELU_MASK)) return false;
+  static const int bm128 = [] { const char* v = getenv("REC_GEMM_GLDS_BM"); return v && atoi(v) == 128; }();
+  if (bm128 && d->n % 80 == 0 && d->m % 128 == 0)
+    return d->trans_b ? launch_glds_cfg<128, 80, true>(d, A, B, C, e, st)
+                      : launch_glds_cfg<128, 80, false>(d, A, B, C, e, st);
+  // N a multiple of 80: gemm_f32_pipe_kernel is as fast or 3-5 % faster there (profiles/r03_gemm_glds.txt), so the
+  // ring takes these shapes only on request (REC_GEMM_GLDS_80=1: A/B runs, tests)
+  const char* v80 = getenv("REC_GEMM_GLDS_80");      // read per call (tests flip it inside one process)
+  const bool n80 = v80 && *v80 == '1';
+  if (n80 && d->n % 80 == 0 && d->m % 256 == 0 && (d->m / 256) * (int64_t)(d->n / 80) < (1ll << 31))
+    return d->trans_b ? launch_glds_cfg<256, 80, true>(d, A, B, C, e, st)
+                      : launch_glds_cfg<256, 80, false>(d, A, B, C, e, st);
+  if (d->n % 208 == 0 && d->m % 128 == 0 && (d->m / 128) * (int64_t)(d->n / 208) < (1ll << 31))
+    return d->trans_b ? launch_glds_cfg<128, 208, true>(d, A, B, C, e, st)
+                      : launch_glds_cfg<128, 208, false>(d, A, B, C, e, st);
+  if (d->n % 144 == 0 && d->m % 128 == 0 && (d->m / 128) * (int64_t)(d->n / 144) < (1ll << 31))   // 432 = 27 x 16
+    return d->trans_b ? launch_glds_cfg<128, 144, true>(d, A, B, C, e, st)
+                      : launch_glds_cfg<128, 144, false>(d, A, B, C, e, st);
+  return false;
+}
+
 template <int EPI>
 static void launch_reduce(const rec_gemm_desc* d, const GemmPlan& p, const float* partial, float* C,
                           const EpiArgs& e, hipStream_t st) {
@@ -1036,6 +1106,7 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
                          desc->n, z, (const float*)cpart2, b_colsum);
     return check_launch("rec_gemm_f32 (skinny dW)");
   }
+  if (!b_colsum && launch_glds(desc, A, B, C, e, st)) return check_launch("rec_gemm_f32 (glds)");
   const GemmPlan p = plan_gemm(desc);
   REC_REQUIRE(p.tiles_total < (1ll << 31), REC_ESHAPE, "too many tiles");
   float* partial = nullptr;

@@ -204,3 +204,36 @@ def test_gemm_pipe_kernel():
     r = subprocess.run([sys.executable, os.path.join(here, "_gemm_pipe_check.py")], env=env, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0 and "ok worst relative error" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("M,N,K,tb", [
+    (8192, 400, 416, False), (8192, 400, 400, True), (8192, 416, 400, True), (8448, 80, 32, False),
+    (8192, 416, 48, False), (16384, 160, 1008, True), (8192, 400, 16 * 3, False), (8192, 208, 32, True),
+    (8192, 432, 400, True), (8320, 144, 64, False), (66560, 432, 400, True)])
+def test_gemm_glds_kernel(ops, M, N, K, tb, monkeypatch):
+    """The LDS-DMA kernel (csrc/gemm_glds.h: 3-stage ring, counted vmcnt, one raw barrier per k-step) takes the tall
+    whole-tile problems of the MLP chain: both B forms ([K,N] rotated-row image, [N,K] swizzled b128 image), both block
+    shapes (256x80, 128x208), K from 2 to 63 tiles (ring wrap-around, 1-2 tile tails), the four epilogues — against
+    float64, and bit-identical across two launches and against REC_GEMM_GLDS=0 up to the fp32 bound."""
+    monkeypatch.setenv("REC_GEMM_GLDS_80", "1")       # the 256x80 configuration too (off by default: no faster)
+    rng = np.random.default_rng(M + N * 3 + K)
+    A, B = _mk(rng, M, K), _mk(rng, K, N)
+    bias, X0 = _mk(rng, N), _mk(rng, M, N)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    At, Bt = t(A), t(B.T if tb else B)
+    ws = ops.Workspace(DEV)
+    want = A.astype(np.float64) @ B.astype(np.float64)
+    bound = 4e-7 * (np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64))
+    C = ops.gemm(At, Bt, ws, trans_b=tb).cpu().numpy()
+    _check(C, want, bound)
+    assert np.array_equal(C, ops.gemm(At, Bt, ws, trans_b=tb).cpu().numpy())
+    Cb = ops.gemm(At, Bt, ws, trans_b=tb, epilogue="bias", bias=t(bias)).cpu().numpy()
+    _check(Cb, want + bias, bound + 1e-6)
+    Cr = ops.gemm(At, Bt, ws, trans_b=tb, epilogue="bias_relu", bias=t(bias)).cpu().numpy()
+    _check(Cr, np.maximum(want + bias, 0), bound + 1e-6)
+    Cm = ops.gemm(At, Bt, ws, trans_b=tb, epilogue="relu_mask", aux0=t(X0)).cpu().numpy()
+    _check(Cm, np.where(X0 > 0, want, 0), bound)
+    # strided views (row strides larger than the logical width) take the same kernel
+    wide = torch.zeros(M, K + 16, device=DEV)
+    wide[:, :K] = At
+    _check(ops.gemm(wide[:, :K], Bt, ws, trans_b=tb).cpu().numpy(), want, bound)
