@@ -72,6 +72,13 @@ def main():
     W, W1 = m.gather_global_tables()
     out["W"], out["W1"] = W.cpu().numpy(), W1.cpu().numpy()
     out["mlp_w0"] = m.dense.p["dnn.linear_0.weight"].cpu().numpy()
+    from helpers import layer_moments
+    mom = layer_moments(m)
+    out["m_mlp_w0"], out["v_mlp_w0"] = mom["dnn.linear_0.weight"]
+    out["m_dense_w"], out["v_dense_w"] = mom["fm.dense_w"]
+    # this rank's rows (r, r+G, ...) of the table moments
+    out["mW_local"] = m.sparse_state["m"].cpu().numpy()
+    out["vW_local"] = m.sparse_state["v"].cpu().numpy()
     out["dense_w"] = m.dense.p["fm.dense_w"].cpu().numpy()
     out["status"] = m.status.cpu().numpy()
     out["trace"] = np.asarray(m.comm.trace)

@@ -168,3 +168,87 @@ class OracleDCNTrainer:
             R.adam_update(p[k], self.m[k], self.v[k], (np.asarray(gv).reshape(p[k].shape) * scale).astype(np.float32),
                           self.step, lr=self.lr)
         return loss, pred, g
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The parity bar of the fp32 layers: 1e-5 relative to the TENSOR's scale.
+def assert_close_scaled(got, want, rel=1e-5, err_msg=""):
+    """|got - want| <= rel * (|want| + max|want|): elements that are sums of opposite-sign terms carry the fp32
+    summation noise of the terms, not of the (cancelled) result."""
+    got, want = np.asarray(got), np.asarray(want)
+    np.testing.assert_allclose(got.reshape(want.shape), want, rtol=rel, atol=rel * float(np.abs(want).max()),
+                               err_msg=err_msg)
+
+
+def layer_moments(layer):
+    """{dense parameter name: (m, v)} numpy views of a host mirror's flat Adam moments (paddlerec_amd.deepfm._FlatParams
+    keeps every dense parameter, its gradient and both moments in one buffer, in declaration order)."""
+    import math
+    out, o = {}, 0
+    m, v = layer.dense.m.detach().cpu().numpy(), layer.dense.v.detach().cpu().numpy()
+    for n in layer.dense.names:
+        shape = tuple(layer.dense.shapes[n])
+        k = math.prod(shape)
+        out[n] = (m[o:o + k].reshape(shape), v[o:o + k].reshape(shape))
+        o += k
+    return out
+
+
+def assert_moments_close(layer, want_m, want_v, names=None, rel=1e-5, rename=None):
+    """Adam's moments after a few steps against the oracle trainer's: m is linear and v quadratic in the gradients, so
+    both are held to the 1e-5-of-scale bar.  (Weights are NOT: a step is lr * m / (sqrt(v) + eps) — an entry whose
+    gradient is ~eps-sized moves by lr * sign(noise), which turns fp32 summation-order noise into lr-sized differences;
+    a wrong update rule shows up in the loss / prediction of the following steps, which the tests hold to 2e-5.)"""
+    got = layer_moments(layer)
+    n = 0
+    for k, (gm, gv) in got.items():
+        ok = (rename or {}).get(k, k)
+        if names is not None and ok not in names and k not in names:
+            continue
+        if ok not in want_m:
+            continue
+        assert_close_scaled(gm, want_m[ok], rel, err_msg="m of " + k)
+        assert_close_scaled(gv, want_v[ok], rel, err_msg="v of " + k)
+        n += 1
+    return n
+
+
+def assert_close_floor(got, want64, want32, rel=1e-5, err_msg="", scale=None):
+    """Against a float64 reference, with the fp32 noise floor MEASURED next to it: `want32` is the same computation
+    carried out in float32 (the oracle itself); the kernel may be off by 1e-5 of the tensor's scale or by 4x what fp32
+    round-off alone costs the oracle, whichever is larger — the floor is printed when it is the binding one."""
+    got, want64, want32 = np.asarray(got, np.float64), np.asarray(want64, np.float64), np.asarray(want32, np.float64)
+    scale = float(np.abs(want64).max()) if scale is None else float(scale)   # scale: of the terms the result cancels
+    floor = float(np.abs(want32 - want64).max())
+    bound = max(rel * scale, 4.0 * floor)
+    err = float(np.abs(got.reshape(want64.shape) - want64).max())
+    assert err <= bound, "%s max err %.3e > bound %.3e (1e-5 of scale %.3e, measured fp32 floor %.3e)" % (
+        err_msg, err, bound, rel * scale, floor)
+
+
+def assert_sibling_moments(layer, st, rel=1e-5):
+    """Adam moments of the sibling nets (dnn / wide_deep / fm / xdeepfm mirrors) against their test-local oracle
+    trainers, whose state is {key: (m, v)} with keys ("w", i) / ("b", i) for the MLP, "W" / "W1" for the tables and the
+    parameter's own name otherwise.  -> number of tensors compared."""
+    import re
+    want_m, want_v = {}, {}
+    for n in layer.dense.names:
+        mm = re.search(r"linear_(\d+)\.(weight|bias)$", n)
+        key = None
+        if mm and (("w" if mm.group(2) == "weight" else "b"), int(mm.group(1))) in st:
+            key = ("w" if mm.group(2) == "weight" else "b", int(mm.group(1)))
+        else:
+            for cand in (n, n.split(".", 1)[-1], n.replace(".", "_"), n.split(".", 1)[-1].replace(".", "_")):
+                if cand in st:
+                    key = cand
+                    break
+        if key is not None:
+            want_m[n], want_v[n] = st[key]
+    n = assert_moments_close(layer, want_m, want_v, rel=rel)
+    sp = getattr(layer, "sparse_state", None) or {}
+    for mk, vk, key in (("m", "v", "W"), ("m1", "v1", "W1")):
+        if mk in sp and key in st:
+            assert_close_scaled(sp[mk].detach().cpu().numpy(), st[key][0], rel, err_msg="m of " + key)
+            assert_close_scaled(sp[vk].detach().cpu().numpy(), st[key][1], rel, err_msg="v of " + key)
+            n += 1
+    return n

@@ -115,7 +115,9 @@ def _check_layer(device, kernels, tol):
                               ("norm_%d.bias", "gbeta")):
                 want = g[k + ref]
                 got = m.dense.g[key + "." + mine % i].cpu().numpy()
-                np.testing.assert_allclose(got, want, rtol=1e-3, atol=2e-5 * max(np.abs(want).max(), 1e-3),
+                # 2e-5 of the gradient tensor's scale (BatchNorm cancels a bias shift exactly: those entries are pure
+                # round-off around zero, which an element-wise rtol cannot describe)
+                np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * max(np.abs(want).max(), 1e-3),
                                            err_msg=k + ref)
             np.testing.assert_allclose(m.buffers["%s.norm_%d._mean" % (key, i)].cpu().numpy(), g[k + "mean1"],
                                        rtol=1e-5, atol=1e-6)
@@ -248,9 +250,9 @@ def test_batchnorm_kernels_vs_numpy(engine_lib, M, N, relu):
     if relu:
         wdx = wdx * (x > 0)
     scale = max(np.abs(wdx).max(), 1e-3)
-    np.testing.assert_allclose(dx.cpu().numpy(), wdx, rtol=1e-4, atol=2e-5 * scale)
-    np.testing.assert_allclose(dg.cpu().numpy(), wdg, rtol=1e-4, atol=1e-5 * max(np.abs(wdg).max(), 1))
-    np.testing.assert_allclose(db.cpu().numpy(), wdb, rtol=1e-4, atol=1e-5 * max(np.abs(wdb).max(), 1))
+    np.testing.assert_allclose(dx.cpu().numpy(), wdx, rtol=2e-5, atol=2e-5 * scale)      # float64 reference
+    np.testing.assert_allclose(dg.cpu().numpy(), wdg, rtol=2e-5, atol=1e-5 * max(np.abs(wdg).max(), 1))
+    np.testing.assert_allclose(db.cpu().numpy(), wdb, rtol=2e-5, atol=1e-5 * max(np.abs(wdb).max(), 1))
 
 
 @pytest.mark.gpu

@@ -95,6 +95,10 @@ def _check_layer(device, kernels, tol):
     want = _state_dict(tr.p)
     for k in sd:
         np.testing.assert_allclose(sd[k], want[k].reshape(sd[k].shape), rtol=1e-3, atol=p_atol, err_msg=k)
+    # ... and the optimizer state at the stated bar: Adam's moments within 1e-5 of their scale (the weights above carry
+    # lr-sized differences wherever a gradient is ~eps-sized: helpers.assert_moments_close)
+    from helpers import assert_sibling_moments
+    assert assert_sibling_moments(m, tr.st) >= 3
     dm = DygraphModel()
     cfg = {"hyper_parameters.sparse_feature_number": N, "hyper_parameters.sparse_feature_dim": D,
            "hyper_parameters.dense_input_dim": 13, "hyper_parameters.sparse_inputs_slots": 27,

@@ -86,6 +86,16 @@ def _check(world, ranks, tables):
         np.testing.assert_allclose(out["W1"], tr.p["W1"], rtol=1e-3, atol=2e-4)
         np.testing.assert_allclose(out["mlp_w0"], tr.p["mlp_w"][0], rtol=1e-3, atol=2e-4)
         np.testing.assert_allclose(out["dense_w"], tr.p["dense_w"], rtol=1e-3, atol=2e-4)
+        # the optimizer state at the stated bar: Adam's moments within 1e-5 of their scale (the weights above carry
+        # lr-sized differences where a gradient is ~eps-sized, helpers.assert_moments_close)
+        from helpers import assert_close_scaled
+        assert_close_scaled(out["m_mlp_w0"], tr.dstate[("mlp_w", 0)][0])
+        assert_close_scaled(out["v_mlp_w0"], tr.dstate[("mlp_w", 0)][1])
+        assert_close_scaled(out["m_dense_w"], tr.dstate["dense_w"][0])
+        assert_close_scaled(out["v_dense_w"], tr.dstate["dense_w"][1])
+        mine = tr.st["mW"][r::world]
+        assert_close_scaled(out["mW_local"][: mine.shape[0]], mine)
+        assert_close_scaled(out["vW_local"][: mine.shape[0]], tr.st["vW"][r::world])
     # every rank holds the same replicated dense parameters and sees the same global tables
     for out in ranks[1:]:
         assert np.array_equal(out["mlp_w0"], ranks[0]["mlp_w0"])
