@@ -35,7 +35,7 @@ def _config(tmp_path, epochs=2):
             "table_parameters.embedding.accessor": acc}
 
 
-def _run(tmp_path, device, kernels, loss_rtol=1e-4):
+def _run(tmp_path, device, kernels, loss_rtol=2e-5):
     from paddlerec_amd import gpubox, reader
     cfg = _config(tmp_path)
     torch.manual_seed(7)
@@ -66,11 +66,8 @@ def _run(tmp_path, device, kernels, loss_rtol=1e-4):
             lv, llod, _, _ = reader.parse_feasign_slots(chunk, 1, 1, 0)
             label = lv[llod[0, :-1]].reshape(n, 1).clamp(0, 1).numpy()
             values, lod, base = values.numpy(), lod.numpy(), base.numpy()
-            rows_all = np.array([R.feasign_row(int(v) & 0xFFFFFFFFFFFFFFFF, N) for v in values], np.int64)
-            touched = np.unique(rows_all)
-            Wv = np.zeros((N, D), np.float32)
-            for r in touched:
-                Wv[r] = ps_ref.pull_value(rec, lay, int(r), acc, D)
+            # what a pull shows (PullSparse + Select): the stored W of every key, zeros for keys that do not exist
+            Wv = np.stack([ps_ref.pull_value(rec, lay, r, acc, D) for r in range(N)])
             Wv[0] = 0
             o = M.loss_and_grads(values, lod, base, label, Wv, mw, mb, 0, 1, N)
             losses.append(float(o["loss"]))
@@ -100,7 +97,7 @@ def _run(tmp_path, device, kernels, loss_rtol=1e-4):
     np.testing.assert_allclose(got[:, so:so + 2], rec[:, so:so + 2], rtol=1e-6, atol=0)
     # weights ~1e-2: the dense Adam of the MLP turns fp32 noise of ~eps-sized gradients into lr-sized steps, which reach
     # the embedding gradients of later steps (tests/test_slot_dnn.py re-syncs the MLP every step for that reason)
-    np.testing.assert_allclose(got[:, :D], rec[:, :D], rtol=1e-3, atol=5e-5)
+    np.testing.assert_allclose(got[:, :D], rec[:, :D], rtol=1e-4, atol=1e-4 * float(np.abs(rec[:, :D]).max()))
     states = rec[:, so + 4]
     assert (states == 1).any() and (states == 2).any()
     # ---- pass checkpoint: born rows only, round trip
@@ -122,7 +119,7 @@ def test_gpubox_pass_loop_cpu_backend(tmp_path):
 def test_gpubox_pass_loop_gpu(tmp_path, engine_lib):
     # pass 0 agrees to 2e-5; pass 1 runs on MLP weights that took Adam's lr-sized steps on ~eps-sized gradients (sign
     # noise of the fp32 summation order), see the comment at the weight check
-    _run(tmp_path, "cuda", None, loss_rtol=2e-4)
+    _run(tmp_path, "cuda", None, loss_rtol=5e-5)
 
 
 REF_CFG = "/root/reference/models/rank/slot_dnn/config_online.yaml"
