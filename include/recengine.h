@@ -365,6 +365,18 @@ int rec_ps_save_select(int64_t num_rows, const rec_ps_layout* layout, float* rec
                        float base_threshold, float delta_threshold, float delta_keep_days,
                        const rec_ps_accessor* accessor, uint8_t* selected, int64_t* n_selected, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Train-mode Dropout and L2Decay of the DCN-v2 DNN tower (dcn_v2/net.py:158,164-170,181-183).
+ * rec_dropout: out[r,c] = keep ? in[r,c] / (1-p)^nmask : 0 over a [rows, cols] matrix (row strides ld_in / ld_out,
+ *   in place allowed).  keep is a pure function of (seed, stream id, r*cols + c) — no stored mask: the backward is the
+ *   same call on the gradient.  nmask 2 applies streams a AND b at once (the reference's two dropouts around a ReLU).
+ * rec_l2_decay_grad: grad += (coeff / grad_scale[0]) * w — L2Decay appended AFTER global-norm clipping [EXT]; the
+ *   Adam kernels multiply the whole gradient by the clipping coefficient, hence the pre-division (grad_scale NULL: 1).
+ * ---------------------------------------------------------------------------------------- */
+int rec_dropout(int64_t rows, int32_t cols, int64_t ld_in, int64_t ld_out, const float* in, float* out, float p,
+                uint64_t seed, uint64_t stream_a, uint64_t stream_b, int32_t nmask, void* stream);
+int rec_l2_decay_grad(int64_t n, float* grad, const float* w, float coeff, const float* grad_scale, void* stream);
+
 /* paddle.optimizer.SGD [EXT] (din/dygraph_model.py:64-73): p -= lr * g.  Rows whose gradient is zero do
  * not move, so updating the merged rows of a SelectedRows gradient equals the dense update. */
 int rec_sparse_sgd_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride, const int32_t* n_uniq,

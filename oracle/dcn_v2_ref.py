@@ -124,18 +124,59 @@ def cross_mix_backward(dout, x0, saved, p, layer_num, num_experts):
 # --------------------------------------------------------------------------
 # DNN + head                                          dcn_v2/net.py:110-137,140-184
 # --------------------------------------------------------------------------
-def dnn_forward(x, p, n_layers):
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix64(k):
+    k = k.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        k = k ^ (k >> np.uint64(33))
+        k = k * np.uint64(0xff51afd7ed558ccd)
+        k = k ^ (k >> np.uint64(33))
+        k = k * np.uint64(0xc4ceb9fe1a85ec53)
+        k = k ^ (k >> np.uint64(33))
+    return k
+
+
+def dropout_keep(shape, p, seed, stream):
+    """The engine's counter-based keep mask (csrc/cross_ops.hip dropout_kernel): element e of a [rows, cols] matrix is
+    kept when bits 32.. of mix64(seed ^ mix64(stream << 40 | e)) >= p * 2^32.  (Paddle's own masks come from the
+    device generator and cannot be reproduced from the reference; the distribution is the same Bernoulli(1 - p).)"""
+    n = int(np.prod(shape))
+    e = np.arange(n, dtype=np.uint64) | (np.uint64(stream) << np.uint64(40))
+    h = _mix64(np.uint64(seed) ^ _mix64(e))
+    return ((h >> np.uint64(32)) >= np.uint64(int(float(p) * 4294967296.0))).reshape(shape)
+
+
+def dnn_forward(x, p, n_layers, dropout=None):
+    """DNNLayer.forward (net.py:178-184).  dropout = None: eval mode.  dropout = (p, seed, step): train mode —
+    `y = drop_out(layer(y))` after the Linear AND after its ReLU (upscale_in_train [EXT]); mask stream of (layer i,
+    position j) = (step * n_layers + i) * 2 + j."""
     acts = [x]
     for i in range(n_layers):
-        x = np.maximum(_lin(x, p["DNN_.linear_%d.weight" % i], p["DNN_.linear_%d.bias" % i]), 0)
+        z = _lin(x, p["DNN_.linear_%d.weight" % i], p["DNN_.linear_%d.bias" % i])
+        if dropout is not None:
+            pr, seed, step = dropout
+            s = np.float32(1.0) / (np.float32(1.0) - np.float32(pr))
+            z = z * dropout_keep(z.shape, pr, seed, (step * n_layers + i) * 2) * s          # after the Linear
+            x = np.maximum(z, 0)
+            x = x * dropout_keep(x.shape, pr, seed, (step * n_layers + i) * 2 + 1) * s      # after the ReLU
+        else:
+            x = np.maximum(z, 0)
         acts.append(x)
     return x, acts
 
 
-def dnn_backward(dy, acts, p, n_layers):
+def dnn_backward(dy, acts, p, n_layers, dropout=None):
     g = {}
     d = dy
     for i in reversed(range(n_layers)):
+        if dropout is not None:       # through both dropouts and the ReLU between them
+            pr, seed, step = dropout
+            s = np.float32(1.0) / (np.float32(1.0) - np.float32(pr))
+            k = dropout_keep(d.shape, pr, seed, (step * n_layers + i) * 2) & \
+                dropout_keep(d.shape, pr, seed, (step * n_layers + i) * 2 + 1)
+            d = d * k * (s * s)
         d = d * (acts[i + 1] > 0)
         g["DNN_.linear_%d.weight" % i] = acts[i].T @ d
         g["DNN_.linear_%d.bias" % i] = d.sum(axis=0)
@@ -154,8 +195,8 @@ def config_of(p):
     return dict(mix=mix, n_cross=n_cross, n_dnn=n_dnn, n_exp=n_exp, d=d, stacked=stacked)
 
 
-def forward(ids, dense, p, return_saved=False):
-    """DCN_V2Layer.forward in eval mode (net.py:89-137) -> predict [B,1]."""
+def forward(ids, dense, p, return_saved=False, dropout=None):
+    """DCN_V2Layer.forward (net.py:89-137) -> predict [B,1]; eval mode, or train mode with dropout = (p, seed, step)."""
     c = config_of(p)
     feat = feat_embeddings(ids, dense, p)
     if c["mix"]:
@@ -163,12 +204,13 @@ def forward(ids, dense, p, return_saved=False):
     else:
         cross, csaved = cross_v2_forward(feat, p, c["n_cross"])
     dnn_in = cross if c["stacked"] else feat
-    dnn_out, acts = dnn_forward(dnn_in, p, c["n_dnn"])
+    dnn_out, acts = dnn_forward(dnn_in, p, c["n_dnn"], dropout)
     last = dnn_out if c["stacked"] else np.concatenate([dnn_out, cross], axis=1)   # net.py:129
     logit = _lin(last, p["fc.weight"], p["fc.bias"])
     pred = sigmoid(logit)
     if return_saved:
-        return pred, dict(feat=feat, cross=cross, csaved=csaved, acts=acts, last=last, logit=logit, cfg=c)
+        return pred, dict(feat=feat, cross=cross, csaved=csaved, acts=acts, last=last, logit=logit, cfg=c,
+                          dropout=dropout)
     return pred
 
 
@@ -183,7 +225,7 @@ def backward(ids, dense, p, saved, dpred):
     n_out = saved["acts"][-1].shape[1]
     ddnn = dlast[:, :n_out]
     dcross = None if c["stacked"] else dlast[:, n_out:]
-    d_in, gd = dnn_backward(ddnn, saved["acts"], p, c["n_dnn"])
+    d_in, gd = dnn_backward(ddnn, saved["acts"], p, c["n_dnn"], saved.get("dropout"))
     g.update(gd)
     if c["stacked"]:
         dcross, dfeat = d_in, 0

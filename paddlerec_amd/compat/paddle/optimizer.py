@@ -5,12 +5,13 @@ Dense parameters: rec_adam_dense / rec_sgd_dense per parameter.  Embedding param
 default lazy_mode=False: every row's moments decay, deepfm/dygraph_model.py:61-65) or
 rec_sparse_adam_rows (lazy_mode=True) / rec_sparse_sgd_rows.
 
-weight_decay / ParamAttr(regularizer=L2Decay(c)) (dcn_v2/net.py:164-170: L2Decay(1e-7) on the DNN weights; xdeepfm:
-L2Decay(1e-4)): Paddle appends the regulariser to the GRADIENT before the optimizer rule [EXT append_regularization_ops]
-— g += c * w on dense parameters; a parameter's own regulariser wins over the optimizer's weight_decay.
+Order [EXT Optimizer._apply_optimize]: gradient clipping FIRST, then the regulariser, then the rule.
 grad_clip = nn.ClipGradByGlobalNorm(clip_norm) (dcn_v2/dygraph_model.py:81-88): every gradient — the merged rows of
 SelectedRows gradients included — is multiplied by clip_norm / max(global_norm, clip_norm): rec_sumsq /
-rec_sparse_rows_sumsq / rec_clip_scale, the coefficient handed to the update kernels as a device scalar."""
+rec_sparse_rows_sumsq / rec_clip_scale, the coefficient handed to the update kernels as a device scalar.
+weight_decay / ParamAttr(regularizer=L2Decay(c)) (dcn_v2/net.py:164-170: L2Decay(1e-7) on the DNN weights; xdeepfm:
+L2Decay(1e-4)): appended to the (clipped) GRADIENT [EXT append_regularization_ops] — g = scale * g + c * w on dense
+parameters (rec_l2_decay_grad); a parameter's own regulariser wins over the optimizer's weight_decay."""
 import torch as _t
 
 from . import _backend
@@ -66,7 +67,8 @@ class _Base:
         raise NotImplementedError("compat optimizer: regularizer %r (only L2Decay / a float)" % (reg,))
 
     def _prepare(self):
-        """Regularisation into the dense gradients, then the global-norm clipping coefficient.
+        """The global-norm clipping coefficient over the raw gradients, then the regulariser appended to the dense
+        gradients (pre-divided by the coefficient, which the update kernels apply to the whole gradient).
         -> (sparse: {id(p): (groups, rows)}, scale: device float[1] or None)"""
         K = _backend.kernels()
         sparse = {}
@@ -75,10 +77,6 @@ class _Base:
                 if self._coeff(getattr(p, "_regularizer", None)):
                     raise NotImplementedError("compat optimizer: a regularizer on a sparse=True embedding")
                 sparse[id(p)] = self._merged_keys(p)
-            elif p.grad is not None:
-                c = self._coeff(getattr(p, "_regularizer", None) or self._weight_decay)
-                if c:
-                    p.grad = p.grad.add(p.detach(), alpha=c)
         scale = None
         if self._grad_clip is not None:
             dev = self._params[0].device
@@ -92,6 +90,13 @@ class _Base:
                 elif p.grad is not None:
                     K.sumsq(p.grad.contiguous().view(-1), ss, self._ws, accumulate=True)
             scale = K.clip_scale(ss, float(self._grad_clip.clip_norm), _t.empty_like(ss))
+        for p in self._params:
+            if id(p) not in sparse and p.grad is not None:
+                c = self._coeff(getattr(p, "_regularizer", None) or self._weight_decay)
+                if c:
+                    g = p.grad.contiguous()
+                    K.l2_decay_grad(g.view(-1), p.detach().contiguous().view(-1), c, scale)
+                    p.grad = g
         return sparse, scale
 
     def state_dict(self):

@@ -100,6 +100,41 @@ __global__ __launch_bounds__(kBlock) void softmax_rows_kernel(int64_t M, int E,
   }
 }
 
+
+// ------------------------------------------------------------------ train-mode Dropout + L2Decay (DCN-v2 DNN tower)
+// /root/reference/models/rank/dcn_v2/net.py:158,181-183: `y_dnn = self.drop_out(y_dnn)` after EVERY element of
+// _mlp_layers — after the Linear and again after its ReLU — paddle.nn.Dropout(p = 0.5), mode upscale_in_train [EXT]:
+// y = x * keep / (1 - p).  Paddle draws its masks from the device generator (not reproducible from the reference);
+// here keep(i) is a pure function of (seed, stream, element): bit 32.. of mix64(seed ^ mix64(stream << 40 | i))
+// against p * 2^32, so the forward, the backward (same kernel on the gradient) and the oracle agree without a stored
+// mask.  Up to two streams are applied at once (the two dropouts around a ReLU commute with it: relu(x * c) =
+// c * relu(x) for c >= 0): keep = keepA & keepB, scale = 1 / (1 - p)^nmask.
+__global__ __launch_bounds__(kBlock) void dropout_kernel(int64_t rows, int cols, int64_t ld_in, int64_t ld_out,
+                                                         const float* __restrict__ in, float* __restrict__ out,
+                                                         uint32_t thresh, float scale, uint64_t seed,
+                                                         uint64_t stream_a, uint64_t stream_b, int nmask) {
+  const int64_t n = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = e / cols;
+    const int c = (int)(e - r * cols);
+    bool keep = (uint32_t)(mix64(seed ^ mix64((stream_a << 40) | (uint64_t)e)) >> 32) >= thresh;
+    if (nmask > 1) keep = keep && (uint32_t)(mix64(seed ^ mix64((stream_b << 40) | (uint64_t)e)) >> 32) >= thresh;
+    const float x = in[r * ld_in + c];
+    out[r * ld_out + c] = keep ? x * scale : 0.f;
+  }
+}
+
+// grad += (coeff / grad_scale) * w : paddle.regularizer.L2Decay(coeff) (dcn_v2/net.py:164-170) appended to the
+// gradient AFTER gradient clipping [EXT Optimizer._apply_optimize: clip, then regularization] — the Adam kernels
+// multiply the whole gradient by the clipping coefficient, so the term is pre-divided by it.
+__global__ __launch_bounds__(kBlock) void l2_decay_grad_kernel(int64_t n, float* __restrict__ grad,
+                                                               const float* __restrict__ w, float coeff,
+                                                               const float* __restrict__ grad_scale) {
+  const float c = grad_scale ? coeff / grad_scale[0] : coeff;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    grad[i] += c * w[i];
+}
+
 }  // namespace rec
 
 using namespace rec;
@@ -228,4 +263,33 @@ extern "C" int rec_dense_fold_bwd(int32_t num_slots, int32_t num_dense, int32_t 
   hipLaunchKernelGGL(rec::dense_fold_bwd_dw_kernel, dim3(num_dense * emb_dim), dim3(rec::kBlock), 0, st,
                      num_slots, emb_dim, n_out, W0, dM, d_dense_w, accumulate_ddw);
   return rec::check_launch("rec_dense_fold_bwd");
+}
+
+extern "C" int rec_dropout(int64_t rows, int32_t cols, int64_t ld_in, int64_t ld_out, const float* in, float* out,
+                           float p, uint64_t seed, uint64_t stream_a, uint64_t stream_b, int32_t nmask,
+                           void* stream) {
+  REC_REQUIRE(rows >= 0 && cols > 0 && ld_in >= cols && ld_out >= cols && in && out, REC_EINVAL, "bad arguments");
+  REC_REQUIRE(p >= 0.f && p < 1.f && (nmask == 1 || nmask == 2), REC_EINVAL, "p must be in [0,1), nmask 1 or 2");
+  REC_REQUIRE(rows * (int64_t)cols < (1ll << 40) && stream_a < (1ull << 24) && stream_b < (1ull << 24), REC_ESHAPE,
+              "too many elements / stream id too large for the counter layout");
+  if (rows == 0) return REC_OK;
+  const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+  float scale = 1.f / (1.f - p);
+  if (nmask == 2) scale *= scale;
+  int64_t grid = (rows * cols + kBlock - 1) / kBlock;
+  if (grid > kNumCU * 16) grid = kNumCU * 16;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, rows, cols, ld_in,
+                     ld_out, in, out, thresh, scale, seed, stream_a, stream_b, nmask);
+  return check_launch("rec_dropout");
+}
+
+extern "C" int rec_l2_decay_grad(int64_t n, float* grad, const float* w, float coeff, const float* grad_scale,
+                                 void* stream) {
+  REC_REQUIRE(n >= 0 && grad && w && coeff >= 0.f, REC_EINVAL, "bad arguments");
+  if (n == 0 || coeff == 0.f) return REC_OK;
+  int64_t grid = (n + kBlock - 1) / kBlock;
+  if (grid > kNumCU * 16) grid = kNumCU * 16;
+  hipLaunchKernelGGL(l2_decay_grad_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, n, grad, w,
+                     coeff, grad_scale);
+  return check_launch("rec_l2_decay_grad");
 }

@@ -7,10 +7,13 @@ feature row), rec_gemm_f32 (dense_emb, CrossNet layers with the fused `x_l + x_0
 epilogue, low-rank expert projections with fused tanh / gate mixing, MLP), rec_cross_bwd_prep,
 rec_sparse_adam_rows with the clipping coefficient, rec_sumsq / rec_sparse_rows_sumsq.
 
-Scope notes: Dropout(0.5) of the reference's train mode (App. B-10) is not applied —
-results are those of eval() mode, the only mode in which the reference's outputs are reproducible;
-L2Decay(1e-7) on the DNN weights (net.py:164-170) is below the fp32 parity tolerance and omitted;
-the sparse optimizer is lazy Adam (see deepfm.py).  Training covers both cross networks: CrossNetV2
+Train mode (net.py:158,181-183; App. B-10): Dropout(dropout_rate) after EVERY element of the DNN tower's _mlp_layers —
+after each Linear and again after its ReLU — with masks from rec_dropout's counter-based generator (Paddle's own
+stream is not reproducible from the reference; the oracle restates the same generator), and L2Decay(l2_dnn) on the DNN
+weights appended after the global-norm clip (net.py:164-170).  The bare layer defaults to dropout_rate 0 / l2_dnn 0 =
+the reference's eval() arithmetic (what the golden fixtures hold); DygraphModel.create_model builds it with the
+reference's 0.5 / 1e-7, so the trainer runs the reference's train-mode graph.
+The sparse optimizer is lazy Adam (see deepfm.py).  Training covers both cross networks: CrossNetV2
 (BASELINE config 3) and the shipped CrossNetMix (low-rank mixture of experts).
 """
 import math
@@ -28,7 +31,8 @@ class DCN_V2Layer:
 
     def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim, sparse_num_field,
                  layer_sizes, cross_num, is_Stacked=True, use_low_rank_mixture=False, low_rank=32,
-                 num_experts=4, device="cuda", kernels=None):
+                 num_experts=4, device="cuda", kernels=None, dropout_rate=0.0, dropout_seed=2025, l2_dnn=0.0):
+        self.dropout_rate, self.dropout_seed, self.l2_dnn = float(dropout_rate), int(dropout_seed), float(l2_dnn)
         self.device = torch.device(device)
         self.k = kernels if kernels is not None else ops
         self.sparse_feature_number = N = sparse_feature_number
@@ -187,7 +191,31 @@ class DCN_V2Layer:
         db = [g["DNN_.linear_%d.bias" % i] for i in range(n)]
         return W, b, dW, db
 
-    def _logit(self, ids, dense_inputs, keep=False):
+    def _drop(self):
+        return self.dropout_rate > 0.0
+
+    def _dnn_tower(self, x, W, b, out_last=None, step=None):
+        """DNNLayer.forward (net.py:178-184): Linear(+bias) -> ReLU per layer.  Train mode (step given, dropout_rate > 0):
+        both dropouts of a layer in ONE pass behind the GEMM's bias+ReLU epilogue (they commute with the ReLU); mask
+        streams of layer i = (step * n + i) * 2 and + 1.  -> (output, acts): acts[i] = input of layer i, acts[n] = output."""
+        k, n = self.k, len(W)
+        if step is None or not self._drop():
+            return k.mlp_forward(x, W, b, self.ws, relu_last=True, out_last=out_last)
+        acts = []
+        for i in range(n):
+            acts.append(x)
+            x = k.gemm(x, W[i], self.ws, epilogue="bias_relu", bias=b[i], out=out_last if i == n - 1 else None)
+            st = (step * n + i) * 2
+            k.dropout(x, self.dropout_rate, self.dropout_seed, st, st + 1)
+        return x, acts + [x]
+
+    def _tower_grad_through_dropout(self, g, layer, n, step):
+        """d(loss)/d(output of DNN layer `layer`) after the dX GEMM's ReLU mask: the gradient also passes that layer's two
+        dropouts — the same rec_dropout call (keep mask redundant with the mask of the dropped output, scale 1/(1-p)^2)."""
+        st = (step * n + layer) * 2
+        return self.k.dropout(g, self.dropout_rate, self.dropout_seed, st, st + 1)
+
+    def _logit(self, ids, dense_inputs, keep=False, step=None):
         p, k = self.dense.p, self.k
         B = ids.shape[0]
         feat = self._feat(ids, dense_inputs)
@@ -200,7 +228,12 @@ class DCN_V2Layer:
                 cross = self._cross_mix(feat, saved=saved["mix"] if keep else None)
             else:
                 cross, saved["xs"], saved["us"] = self._cross_v2(feat)
-            logit, acts = k.mlp_forward(cross, W + [p["fc.weight"]], b + [p["fc.bias"]], self.ws)
+            if step is not None and self._drop():
+                h, acts = self._dnn_tower(cross, W, b, step=step)
+                logit = k.gemm(h, p["fc.weight"], self.ws, epilogue="bias", bias=p["fc.bias"])
+                acts = acts + [logit]
+            else:
+                logit, acts = k.mlp_forward(cross, W + [p["fc.weight"]], b + [p["fc.bias"]], self.ws)
             saved["acts"] = acts
         else:
             last = torch.empty(B, n_out + self.d, dtype=torch.float32, device=self.device)      # net.py:129
@@ -209,7 +242,7 @@ class DCN_V2Layer:
                 self._cross_mix(feat, out_last=last[:, n_out:], saved=saved["mix"] if keep else None)
             else:
                 _, saved["xs"], saved["us"] = self._cross_v2(feat, out_last=last[:, n_out:])
-            _, acts = k.mlp_forward(feat, W, b, self.ws, relu_last=True, out_last=last[:, :n_out])
+            _, acts = self._dnn_tower(feat, W, b, out_last=last[:, :n_out], step=step)
             logit = k.gemm(last, p["fc.weight"], self.ws, epilogue="bias", bias=p["fc.bias"])
             saved["acts"], saved["last"] = acts, last
         return (logit, saved) if keep else (logit, None)
@@ -244,8 +277,9 @@ class DCN_V2Layer:
         if self._groups is None or self._groups.n != B * S:
             self._groups = k.IdGroups(B * S, self.device)
         groups = self._groups
+        drop = self._drop()
         with self._timed("fwd"):
-            logit, sv = self._logit(ids, dense_inputs, keep=True)
+            logit, sv = self._logit(ids, dense_inputs, keep=True, step=t if drop else None)
         k.ids_group(ids, self.sparse_feature_number, self.padding_idx, self.ws_group, None, self.status, groups)
         pred, dz, loss = k.sigmoid_logloss(logit, None, None, label, self.ws)
         if dlogit is not None:
@@ -255,16 +289,40 @@ class DCN_V2Layer:
         W, b, dW, db = self._dnn_params()
         n_out = self.layer_sizes[-1]
         with self._timed("bwd"):
-            if self.is_Stacked:
+            n_dnn = len(W)
+
+            def tower_backward(gy, acts):
+                """d(input of the tower) from gy = d(output of its last layer) already masked by that layer's ReLU
+                and passed through its dropouts; dW / db of every layer on the way (train mode: net.py:181-183)."""
+                for i in reversed(range(n_dnn)):
+                    k.gemm(acts[i], gy, self.ws, trans_a=True, out=dW[i], b_colsum=db[i])
+                    if i > 0:
+                        gy = k.gemm(gy, W[i], self.ws, trans_b=True, epilogue="relu_mask", aux0=acts[i])
+                        gy = self._tower_grad_through_dropout(gy, i - 1, n_dnn, t)
+                    else:
+                        gy = k.gemm(gy, W[0], self.ws, trans_b=True)
+                return gy
+            if self.is_Stacked and not drop:
                 dcross = k.mlp_backward(dz, sv["acts"], W + [p["fc.weight"]], dW + [g["fc.weight"]],
                                         db + [g["fc.bias"]], self.ws)
+                dx0_acc, have_acc = torch.empty_like(sv["feat"]), False
+            elif self.is_Stacked:
+                acts = sv["acts"]                                  # [cross, y_0 .. y_{n-1}, logit]
+                k.gemm(acts[n_dnn], dz, self.ws, trans_a=True, out=g["fc.weight"], b_colsum=g["fc.bias"])
+                gy = k.gemm(dz, p["fc.weight"], self.ws, trans_b=True, epilogue="relu_mask", aux0=acts[n_dnn])
+                gy = self._tower_grad_through_dropout(gy, n_dnn - 1, n_dnn, t)
+                dcross = tower_backward(gy, acts)
                 dx0_acc, have_acc = torch.empty_like(sv["feat"]), False
             else:
                 last, fcw = sv["last"], p["fc.weight"]
                 k.gemm(last, dz, self.ws, trans_a=True, out=g["fc.weight"], b_colsum=g["fc.bias"])
                 ddnn = k.gemm(dz, fcw[:n_out], self.ws, trans_b=True, epilogue="relu_mask", aux0=last[:, :n_out])
                 dcross = k.gemm(dz, fcw[n_out:], self.ws, trans_b=True)
-                dx0_acc, have_acc = k.mlp_backward(ddnn, sv["acts"], W, dW, db, self.ws), True   # d feat via DNN
+                if drop:
+                    ddnn = self._tower_grad_through_dropout(ddnn, n_dnn - 1, n_dnn, t)
+                    dx0_acc, have_acc = tower_backward(ddnn, sv["acts"]), True
+                else:
+                    dx0_acc, have_acc = k.mlp_backward(ddnn, sv["acts"], W, dW, db, self.ws), True   # d feat via DNN
             feat = sv["feat"]
             if self.use_low_rank_mixture:
                 dx = self._cross_mix_backward(dcross, feat, sv["mix"], dx0_acc, have_acc)
@@ -289,6 +347,9 @@ class DCN_V2Layer:
                 k.sparse_rows_sumsq(groups, dfeat, D, ss, self.ws, accumulate=True, grad_group=S,
                                     grad_group_stride=d, partials=pp)
                 scale = k.clip_scale(ss, clip_norm, self._scalar("scale"))
+            if self.l2_dnn > 0.0:       # L2Decay on the DNN weights, appended AFTER the clip (net.py:164-170; [EXT] order)
+                for i in range(len(W)):
+                    k.l2_decay_grad(dW[i].reshape(-1), W[i].reshape(-1), self.l2_dnn, scale)
             k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr, grad_scale=scale)
             st = self.sparse_state
             k.sparse_adam_rows(groups, dfeat, 1, self.embedding, st["m"], st["v"], t, lr, grad_group=S,
@@ -330,7 +391,11 @@ class DygraphModel:
                            g("hyper_parameters.fc_sizes"), g("hyper_parameters.cross_num"),
                            g("hyper_parameters.is_Stacked", None), g("hyper_parameters.use_low_rank_mixture", None),
                            g("hyper_parameters.low_rank", 32), g("hyper_parameters.num_experts", 4), device=device,
-                           kernels=kernels)
+                           kernels=kernels,
+                           # the reference's train-mode graph: Dropout(0.5) in the DNN tower (net.py:146,158), L2Decay(1e-7)
+                           # on its weights (net.py:165); forward() / infer stay eval mode
+                           dropout_rate=g("hyper_parameters.dropout_rate", 0.5), l2_dnn=1e-7,
+                           dropout_seed=g("runner.seed", 12345))
 
     def create_feeds(self, batch_data, config, device="cuda"):
         return slot_feeds(batch_data, config, device)

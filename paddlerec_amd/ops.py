@@ -597,6 +597,28 @@ def sparse_rows_sumsq(groups, grad, D, out, ws, accumulate=False, grad_div=1, gr
     return out
 
 
+def dropout(x, p, seed, stream_a, stream_b=None, out=None):
+    """Train-mode Dropout (upscale_in_train) on a 2-D float32 matrix (row stride allowed), in place by default.
+    stream_b: a second mask stream applied in the same pass (keep = keepA & keepB, scale 1/(1-p)^2)."""
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda or x.stride(1) != 1:
+        raise RecError("x must be a 2-D float32 device tensor with unit column stride")
+    if out is None:
+        out = x
+    check(lib().rec_dropout(x.shape[0], x.shape[1], x.stride(0), out.stride(0), _p(x), _p(out), float(p), int(seed),
+                            int(stream_a), int(stream_b or 0), 2 if stream_b is not None else 1, _stream()),
+          "rec_dropout")
+    return out
+
+
+def l2_decay_grad(grad, w, coeff, grad_scale=None):
+    """grad += (coeff / grad_scale) * w  (L2Decay appended after clipping; grad / w contiguous float32 views)."""
+    _chk(grad, torch.float32, "grad")
+    _chk(w, torch.float32, "w")
+    check(lib().rec_l2_decay_grad(grad.numel(), _p(grad), _p(w), float(coeff), _p(grad_scale), _stream()),
+          "rec_l2_decay_grad")
+    return grad
+
+
 def clip_scale(sumsq_t, clip_norm, out):
     """out[0] = clip_norm / max(sqrt(sumsq), clip_norm)  (ClipGradByGlobalNorm coefficient)."""
     check(lib().rec_clip_scale(_p(sumsq_t), float(clip_norm), _p(out), _stream()), "rec_clip_scale")

@@ -207,9 +207,10 @@ def _apply_optimizer_config(config, model, dy_model):
                        "(Adam lazy_mode=True); the reference's dygraph Adam also decays the moments of every "
                        "other row each step", model)
     if model == "dcn_v2":
-        logger.warning("DEVIATION from the reference's dygraph run: dcn_v2 trains WITHOUT the train-mode "
-                       "Dropout(0.5) of its DNN tower (RNG-dependent, dcn_v2/net.py:161-176) and without "
-                       "L2Decay(1e-7); loss / AUC trajectories differ from the reference's")
+        logger.info("dcn_v2 train mode: Dropout(%.2f) after every element of the DNN tower (dcn_v2/net.py:181-183) with the "
+                    "engine's counter-based masks (seed %d; Paddle's own mask stream is not reproducible), L2Decay(%g) on "
+                    "its weights after the global-norm clip", getattr(dy_model, "dropout_rate", 0.0),
+                    getattr(dy_model, "dropout_seed", 0), getattr(dy_model, "l2_dnn", 0.0))
 
 
 def _reset(metric_list):

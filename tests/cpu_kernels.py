@@ -238,6 +238,25 @@ def sparse_rows_sumsq(groups, grad, D, out, ws, accumulate=False, grad_div=1, gr
     return out
 
 
+def dropout(x, p, seed, stream_a, stream_b=None, out=None):
+    from oracle import dcn_v2_ref as X
+    xn = _n(x)
+    keep = X.dropout_keep(xn.shape, p, seed, stream_a)
+    s = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    if stream_b is not None:
+        keep = keep & X.dropout_keep(xn.shape, p, seed, stream_b)
+        s = s * s
+    y = torch.from_numpy(np.where(keep, xn * s, np.float32(0)).astype(np.float32))
+    (x if out is None else out).copy_(y)
+    return x if out is None else out
+
+
+def l2_decay_grad(grad, w, coeff, grad_scale=None):
+    c = np.float32(coeff) / (np.float32(float(grad_scale[0])) if grad_scale is not None else np.float32(1))
+    grad.add_(w, alpha=float(c))
+    return grad
+
+
 def clip_scale(sumsq_t, clip_norm, out):
     out.copy_(torch.tensor([clip_norm / max(float(np.sqrt(float(sumsq_t[0]))), clip_norm)], dtype=torch.float32))
     return out

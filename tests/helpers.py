@@ -134,10 +134,13 @@ class OracleDCNTrainer:
     """DCN-v2 training on the NumPy oracle: fwd + bwd + ClipGradByGlobalNorm + lazy Adam (table) +
     Adam (dense), as dcn_v2/dygraph_model.py:73-88 configures it (L2Decay 1e-7 omitted, see dcn_v2.py)."""
 
-    def __init__(self, params, lr=1e-3, clip_norm=10.0):
+    def __init__(self, params, lr=1e-3, clip_norm=10.0, dropout=None, l2_dnn=0.0):
+        """dropout = (p, seed): train-mode Dropout of the DNN tower with the engine's counter-based masks; l2_dnn:
+        L2Decay on the DNN weights, appended after the clip ([EXT] Optimizer._apply_optimize order)."""
         from oracle import dcn_v2_ref as X
         from oracle import deepfm_ref as R
         self.X, self.R = X, R
+        self.dropout, self.l2_dnn = dropout, float(l2_dnn)
         self.p = {k: v.copy() for k, v in params.items()}
         self.lr, self.clip, self.step = lr, clip_norm, 0
         self.m = {k: np.zeros_like(v) for k, v in params.items()}
@@ -146,7 +149,8 @@ class OracleDCNTrainer:
     def train_step(self, ids, dense, label):
         X, R, p = self.X, self.R, self.p
         self.step += 1
-        pred, saved = X.forward(ids, dense, p, return_saved=True)
+        drop = None if self.dropout is None else (self.dropout[0], self.dropout[1], self.step)
+        pred, saved = X.forward(ids, dense, p, return_saved=True, dropout=drop)
         loss = R.log_loss_mean(pred, label)
         t = label.astype(np.float32)
         eps = np.float32(1e-4)
@@ -165,8 +169,10 @@ class OracleDCNTrainer:
         for k, gv in g.items():
             if k in ("_row_grad", "embedding.weight"):
                 continue
-            R.adam_update(p[k], self.m[k], self.v[k], (np.asarray(gv).reshape(p[k].shape) * scale).astype(np.float32),
-                          self.step, lr=self.lr)
+            gk = (np.asarray(gv).reshape(p[k].shape) * scale).astype(np.float32)
+            if self.l2_dnn and k.startswith("DNN_.linear_") and k.endswith(".weight"):
+                gk = (gk + np.float32(self.l2_dnn) * p[k]).astype(np.float32)
+            R.adam_update(p[k], self.m[k], self.v[k], gk, self.step, lr=self.lr)
         return loss, pred, g
 
 

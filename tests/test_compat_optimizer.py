@@ -2,8 +2,8 @@
 grad_clip=ClipGradByGlobalNorm are APPLIED (they used to be accepted and dropped, so dcn_v2 / xdeepfm
 configs trained with silently different semantics).  Runs in a subprocess (the namespace patches torch.Tensor); operator
 backend = the oracle-backed stand-in; expected values = plain torch autograd + a hand-written Adam with Paddle's
-epsilon placement, gradients regularised and clipped as Paddle does (regulariser first, then clip
-over dense gradients and MERGED SelectedRows rows)."""
+epsilon placement, gradients clipped and regularised in Paddle's order (clip over the raw dense
+gradients and the MERGED SelectedRows rows first, then the regulariser appended)."""
 import os
 import subprocess
 import sys
@@ -46,13 +46,12 @@ for step in range(1, 4):
     p = torch.sigmoid(torch.relu(e @ ref["l0.weight"] + ref["l0.bias"]) @ ref["l1.weight"] + ref["l1.bias"])
     rl = (-(y * torch.log(p + 1e-4) + (1 - y) * torch.log(1 - p + 1e-4))).mean() * 30.0
     gs = dict(zip(ref, torch.autograd.grad(rl, list(ref.values()))))
-    gs = {k: g + reg[k] * ref[k].detach() for k, g in gs.items()}
     norm = torch.sqrt(sum((g.double() ** 2).sum() for g in gs.values())).float()
     scale = CLIP / max(float(norm), CLIP)
     clipped += scale < 1
     with torch.no_grad():
         for k, w in ref.items():
-            g = gs[k] * scale
+            g = gs[k] * scale + reg[k] * w
             m, v = mom[k]
             m.mul_(0.9).add_(g, alpha=0.1); v.mul_(0.999).addcmul_(g, g, value=0.001)
             lr_t = LR * (1 - 0.999 ** step) ** 0.5 / (1 - 0.9 ** step)

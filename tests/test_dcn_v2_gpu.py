@@ -163,3 +163,69 @@ def test_emb_gather_grouped_output(engine_lib):
     want = W[ids] * (ids != 0)[..., None]
     assert np.array_equal(N_(out)[:, :40], want.reshape(7, 40))
     assert np.all(N_(out)[:, 40:] == -1.0)
+
+
+@pytest.mark.parametrize("stacked,mix", [(True, False), (False, False), (True, True)])
+def test_train_mode_dropout_and_l2_vs_oracle(engine_lib, stacked, mix):
+    """The reference's TRAIN-mode graph (net.py:181-183: Dropout(0.5) after every Linear and every ReLU of the DNN
+    tower; net.py:164-170: L2Decay on its weights; dygraph_model.py:81-88: clip then Adam) — three steps against the
+    oracle with the same counter-based masks: loss / pred per step, then every Adam moment at 1e-5 of its scale."""
+    _check_train_mode(DEV, None, stacked, mix)
+
+
+def test_dropout_kernel_matches_oracle_masks(engine_lib):
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((37, 50)).astype(np.float32)
+    wide = torch.zeros(37, 64, device=DEV)
+    wide[:, 3:53] = T(x)
+    for p, sa, sb in ((0.5, 7, None), (0.5, 7, 8), (0.3, 100000, 3), (0.0, 1, 2)):
+        y = ops.dropout(wide[:, 3:53].clone(), p, 99, sa, sb)
+        keep = X.dropout_keep(x.shape, p, 99, sa)
+        s = np.float32(1) / (np.float32(1) - np.float32(p))
+        if sb is not None:
+            keep, s = keep & X.dropout_keep(x.shape, p, 99, sb), s * s
+        np.testing.assert_allclose(N_(y), np.where(keep, x * s, 0), rtol=1e-6)
+        assert abs(keep.mean() - (1 - p) ** (2 if sb is not None else 1)) < 0.06
+    out = torch.full((37, 64), -1.0, device=DEV)
+    ops.dropout(wide[:, 3:53], 0.5, 99, 7, None, out=out[:, 10:60])       # strided in / out, not in place
+    assert np.all(N_(out)[:, :10] == -1) and np.all(N_(out)[:, 60:] == -1)
+    g = T(rng.standard_normal(1000).astype(np.float32))
+    w = T(rng.standard_normal(1000).astype(np.float32))
+    sc = T(np.float32([0.25]))
+    want = N_(g) + (np.float32(1e-3) / np.float32(0.25)) * N_(w)
+    np.testing.assert_allclose(N_(ops.l2_decay_grad(g, w, 1e-3, sc)), want, rtol=1e-6)
+
+
+def _check_train_mode(device, kernels, stacked, mix):
+    from paddlerec_amd.dcn_v2 import DCN_V2Layer
+    rng = np.random.default_rng(31 + stacked + 2 * mix)
+    N, D, B, fc = 200, 8, 64, [32, 16]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(device)
+    m = DCN_V2Layer(N, D, 13, 26, fc, 2, is_Stacked=stacked, use_low_rank_mixture=mix, low_rank=16, num_experts=4,
+                    device=device, kernels=kernels, dropout_rate=0.5, dropout_seed=4321, l2_dnn=1e-3)
+    with torch.no_grad():
+        for k, v in m.dense.p.items():
+            if "bias" in k:
+                v.copy_(t((rng.standard_normal(tuple(v.shape)) * 0.05).astype(np.float32)))
+    p = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    tr = OracleDCNTrainer(p, lr=1e-2, clip_norm=0.05, dropout=(0.5, 4321), l2_dnn=1e-3)
+    for step in range(3):
+        ids = rng.integers(0, N, (B, 26), dtype=np.int64)
+        dense = np.log(rng.random((B, 13), dtype=np.float32) * 50 + 1).astype(np.float32)
+        label = (rng.random((B, 1)) < 0.3).astype(np.int64)
+        loss, pred = m.train_step(t(ids), t(dense), t(label), lr=1e-2, clip_norm=0.05)
+        oloss, opred, _ = tr.train_step(ids, dense, label)
+        np.testing.assert_allclose(loss.cpu().numpy()[0], oloss, rtol=2e-5)
+        np.testing.assert_allclose(pred.cpu().numpy(), opred, rtol=2e-5, atol=1e-6)
+    # eval forward is untouched by the dropout settings
+    ev = m.forward(t(ids), t(dense)).cpu().numpy()
+    np.testing.assert_allclose(ev, X.forward(ids, dense, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}),
+                               rtol=2e-5, atol=1e-6)
+    want_m, want_v = dict(tr.m), dict(tr.v)
+    if mix:
+        for mv in (want_m, want_v):
+            mv[X.P + "gating.weight"] = np.concatenate([mv[X.P + "gating.%d.weight" % e] for e in range(4)], axis=1)
+            mv[X.P + "gating.bias"] = np.concatenate([mv[X.P + "gating.%d.bias" % e] for e in range(4)])
+    assert assert_moments_close(m, want_m, want_v) >= 8
+    assert_close_scaled(m.sparse_state["m"].cpu().numpy(), tr.m["embedding.weight"])

@@ -77,3 +77,12 @@ def test_train_steps_vs_oracle(mix, stacked):
     for k in tr.p:
         if k in sd:
             np.testing.assert_allclose(N_(sd[k]), tr.p[k].reshape(tuple(sd[k].shape)), rtol=1e-3, atol=1e-3, err_msg=k)
+
+
+@pytest.mark.parametrize("stacked,mix", [(True, False), (False, False), (False, True)])
+def test_train_mode_dropout_and_l2_host_logic(stacked, mix):
+    """tests/test_dcn_v2_gpu.py::_check_train_mode on the CPU operator stand-in: the train-mode orchestration (which
+    mask stream goes where, the gradient's way back through both dropouts, clip -> L2Decay -> Adam)."""
+    import cpu_kernels
+    import test_dcn_v2_gpu as G
+    G._check_train_mode("cpu", cpu_kernels, stacked, mix)
