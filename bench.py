@@ -173,7 +173,7 @@ def reference_trainer_baseline(budget_s=60.0):
     if ref is None:
         return {"error": "no reference tree (oracle/make_ref_tree.py stages it in the build container)"}
     threads = min(os.cpu_count() or 1, 16)        # the NumPy oracle at bs 2 does not scale past a few threads
-    env = dict(os.environ, REC_COMPAT_KERNELS="cpu_kernels", OMP_NUM_THREADS=str(threads))
+    env = dict(os.environ, REC_COMPAT_KERNELS="cpu_kernels", OMP_NUM_THREADS=str(threads), PYTHONDONTWRITEBYTECODE="1")
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(REPO, "tests"), REPO, env.get("PYTHONPATH", "")])
     with tempfile.TemporaryDirectory() as tmp:
         cmd = [sys.executable, "-m", "paddlerec_amd.run_reference", os.path.join(ref, "tools", "trainer.py"),

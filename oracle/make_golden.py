@@ -11,6 +11,7 @@ duplicate-sublayer quirk — not Paddle's kernels (those are [EXT], not installa
 import importlib.util
 import os
 import sys
+sys.dont_write_bytecode = True      # importing the reference's net.py files must not write __pycache__ next to them
 
 import numpy as np
 import torch

@@ -21,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEST = os.path.join(HERE, "_ref", "PaddleRec")
 
 FILES = [
-    "tools/trainer.py", "tools/infer.py", "tools/static_gpubox_trainer.py", "tools/run_gpubox.sh",
+    "tools/trainer.py", "tools/infer.py", "tools/static_gpubox_trainer.py", "tools/run_gpubox.sh", "tools/profiler.py",
     "tools/utils/__init__.py", "tools/utils/utils_single.py", "tools/utils/save_load.py", "tools/utils/envs.py",
     "tools/utils/static_ps/__init__.py", "tools/utils/static_ps/reader_helper.py",
     "tools/utils/static_ps/program_helper.py", "tools/utils/static_ps/common_ps.py",

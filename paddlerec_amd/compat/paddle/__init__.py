@@ -153,6 +153,41 @@ def create_parameter(shape, dtype="float32", default_initializer=None, attr=None
     return p
 
 
+def full_like(x, fill_value, dtype=None):
+    return _t.full_like(x, fill_value, dtype=_dtype(dtype) if dtype is not None else None)
+
+
+def enable_static():
+    """paddle.enable_static(): from here on `static.data` placeholders are recorded on the main program's tape
+    (compat/paddle/static/__init__.py)."""
+    _backend._state["static"] = True
+
+
+def disable_static():
+    _backend._state["static"] = False
+
+
+def in_dynamic_mode():
+    return not _backend.static_mode()
+
+
+def _ps_save(dirname, mode=0):
+    """fleet.save_inference_model in gpubox mode: dense parameters + the EXISTING values of every sparse table
+    (index + whole accessor record; Save(param = mode) decides which, UpdateStatAfterSave applied)."""
+    import os as _os
+    from . import static as _s
+    _os.makedirs(dirname, exist_ok=True)
+    prog = _s.default_main_program()
+    K = _backend.kernels()
+    out = {"dense.%d" % i: p.detach().cpu().numpy() for i, p in enumerate(prog.parameters())}
+    for name, tab in prog.tables.items():
+        sel = K.ps_save_select(tab.table, int(mode))
+        rows = _t.nonzero(sel).reshape(-1)
+        out["table.%s.rows" % name] = rows.cpu().numpy()
+        out["table.%s.records" % name] = tab.table.rec[rows].cpu().numpy()
+    _np.savez(_os.path.join(dirname, "rec_gpubox.npz"), **out)
+
+
 def save(obj, path):
     """paddle.save(state_dict, path): a pickled {name -> ndarray} dict (nested dicts of tensors are converted)."""
     def conv(o):
@@ -170,3 +205,21 @@ def save(obj, path):
 def load(path):
     with open(path, "rb") as f:
         return _pickle.load(f)
+
+
+# Every tensor function of the namespace becomes static-aware: a call that sees a static Var is recorded on the main
+# program's tape instead of executed (compat/paddle/static/__init__.py).
+def _make_static_aware():
+    import types
+    from .static import static_aware
+    from .nn import functional as _F
+    skip = {"seed", "set_device", "get_device", "save", "load", "enable_static", "disable_static", "in_dynamic_mode",
+            "is_compiled_with_custom_device", "is_compiled_with_cuda", "create_parameter", "to_tensor"}
+    for mod in (globals(), vars(_F)):
+        for name, fn in list(mod.items()):
+            if isinstance(fn, types.FunctionType) and not name.startswith("_") and name not in skip:
+                mod[name] = static_aware(fn)
+
+
+_make_static_aware()
+from . import incubate, utils  # noqa: E402,F401

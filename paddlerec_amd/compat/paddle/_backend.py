@@ -4,7 +4,11 @@ import os
 
 import torch
 
-_state = {"device": None, "kernels": None, "ws": None}
+_state = {"device": None, "kernels": None, "ws": None, "static": False}
+
+
+def static_mode():
+    return _state["static"]
 
 
 def kernels():

@@ -18,3 +18,108 @@ class ShowClickEntry:
 
     def __init__(self, show_name, click_name):
         self.show_name, self.click_name = show_name, click_name
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# InMemoryDataset / QueueDataset [EXT] (tools/utils/static_ps/reader_helper.py:211-316): the files of a pass go through
+# the reference's OWN pipe_command reader script (a subprocess per file, exactly as Paddle runs it) and the MultiSlot
+# text it prints is parsed back into one array per feed variable.
+class _PipeDataset:
+    def __init__(self):
+        self.use_var, self.pipe_command, self.batch_size, self.thread_num = None, None, 1, 1
+        self.filelist, self.samples = [], None
+
+    def init(self, use_var=None, pipe_command=None, batch_size=1, thread_num=1, fs_name="", fs_ugi="", **kw):
+        self.use_var, self.pipe_command = list(use_var), pipe_command
+        self.batch_size, self.thread_num = int(batch_size), int(thread_num)
+
+    def _set_use_ps_gpu(self, flag):
+        self.use_ps_gpu = bool(flag)
+
+    def update_settings(self, **kw):
+        self.settings = kw
+
+    def set_filelist(self, files):
+        self.filelist = list(files)
+
+    def _run_pipe(self, path):
+        import subprocess
+        import sys
+        compat = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # .../compat
+        repo = os.path.dirname(os.path.dirname(compat))
+        env = dict(os.environ)
+        env["PYTHONPATH"] = os.pathsep.join([compat, repo, env.get("PYTHONPATH", "")])
+        cmd = self.pipe_command
+        if cmd.startswith("python "):
+            cmd = sys.executable + cmd[len("python"):]
+        with open(path, "rb") as f:
+            r = subprocess.run(cmd, shell=True, stdin=f, capture_output=True, env=env)
+        if r.returncode != 0:
+            raise RuntimeError("pipe_command %r failed on %s:\n%s" % (self.pipe_command, path,
+                                                                      r.stderr.decode(errors="replace")[-2000:]))
+        return r.stdout.decode()
+
+    def _parse(self, text):
+        """MultiSlot lines -> per-variable lists of per-sample value lists (use_var order)."""
+        import numpy as np
+        nv = len(self.use_var)
+        cols = [[] for _ in range(nv)]
+        for line in text.splitlines():
+            tok = line.split()
+            if not tok:
+                continue
+            i = 0
+            for v in range(nv):
+                n = int(tok[i])
+                vals = tok[i + 1:i + 1 + n]
+                i += 1 + n
+                isint = "int" in str(self.use_var[v].dtype)
+                cols[v].append(np.asarray(vals, np.uint64).astype(np.int64) if isint else np.asarray(vals, np.float32))
+            if i != len(tok):
+                raise ValueError("MultiSlot line has %d tokens, the %d feed variables account for %d" % (len(tok), nv, i))
+        return cols
+
+    def load_into_memory(self):
+        cols = None
+        for path in self.filelist:
+            c = self._parse(self._run_pipe(path))
+            cols = c if cols is None else [a + b for a, b in zip(cols, c)]
+        self.samples = cols or [[] for _ in self.use_var]
+
+    def release_memory(self):
+        self.samples = None
+
+    def get_memory_data_size(self):
+        return len(self.samples[0]) if self.samples else 0
+
+    def local_shuffle(self):
+        pass
+
+    def global_shuffle(self, *a, **k):
+        pass
+
+    def _batches(self, device):
+        """{feed name: tensor [B, width]} per batch, in file order (the last batch may be short, as Paddle feeds it)."""
+        import numpy as np
+        import torch
+        if self.samples is None:
+            self.load_into_memory()
+        n = len(self.samples[0])
+        for lo in range(0, n, self.batch_size):
+            feed = {}
+            for v, col in zip(self.use_var, self.samples):
+                part = col[lo:lo + self.batch_size]
+                width = v.shape[-1] if len(v.shape) > 1 else 1
+                if any(len(x) != width for x in part):
+                    raise ValueError("feed %r: a sample holds %s values, the variable is [*, %d] (LoD feeds are served "
+                                     "by paddlerec_amd.gpubox)" % (v.name, sorted({len(x) for x in part}), width))
+                feed[v.name] = torch.as_tensor(np.stack(part)).to(device)
+            yield feed
+
+
+class InMemoryDataset(_PipeDataset):
+    pass
+
+
+class QueueDataset(_PipeDataset):
+    pass

@@ -1,0 +1,161 @@
+"""paddle.distributed.fleet — the worker-side surface of the reference's entry points.
+
+tools/trainer.py:113-119 (collective dygraph): distributed_optimizer / distributed_model are pass-through; the engine's
+own collective mode is the row-sharded trainer of paddlerec_amd.trainer (one process per GPU, torch.distributed.run).
+tools/static_gpubox_trainer.py:101-260 (parameter-server / gpubox mode): ONE worker process; the "servers" are the
+device tables of the main program (compat/paddle/static), so is_server() is False, init_worker / stop_worker /
+barrier_worker have nothing to contact, and DistributedStrategy is the attribute bag program_helper.get_strategy fills
+(its sparse_table_configs carry the accessor block of the YAML to the tables)."""
+import os
+import sys
+
+from . import base  # noqa: F401
+from .base import role_maker  # noqa: F401
+
+
+class DistributedStrategy:
+    def __init__(self):
+        self.a_sync = False
+        self.a_sync_configs = {}
+        self.trainer_desc_configs = {}
+        self.fs_client_param = {}
+        self.sparse_table_configs = {}
+        self.adam_d2sum = True
+        self.is_with_coordinator = False
+
+
+_state = {"init": False, "collective": False, "strategy": None}
+
+
+def init(role_maker=None, is_collective=False, strategy=None):  # noqa: A002
+    if is_collective:
+        raise NotImplementedError("runner.use_fleet (collective dygraph): run `python -m torch.distributed.run -m "
+                                  "paddlerec_amd.trainer ...` (row-sharded collective mode) instead")
+    _state.update(init=True, collective=False, strategy=strategy)
+
+
+def is_server():
+    return os.environ.get("TRAINING_ROLE", "TRAINER") == "PSERVER"
+
+
+def is_worker():
+    return not is_server()
+
+
+def is_first_worker():
+    return worker_index() == 0
+
+
+def worker_index():
+    return int(os.environ.get("PADDLE_TRAINER_ID", "0"))
+
+
+def worker_num():
+    return int(os.environ.get("PADDLE_TRAINERS_NUM", "1"))
+
+
+def init_server(*a, **k):
+    raise NotImplementedError("no parameter-server process exists: the table lives on the worker's GPU")
+
+
+def run_server():
+    raise NotImplementedError("no parameter-server process exists: the table lives on the worker's GPU")
+
+
+def init_worker():
+    pass
+
+
+def stop_worker():
+    pass
+
+
+def barrier_worker():
+    pass
+
+
+def save_inference_model(executor, dirname, feeded_var_names, target_vars, main_program=None, export_for_deployment=True,
+                         mode=0):
+    from ... import _ps_save
+    _ps_save(dirname, mode)
+
+
+class _StrategyOptimizer:
+    """fleet.distributed_optimizer(optimizer, strategy): minimize() also hands the strategy's sparse-table accessor
+    block (program_helper.py:81-90: table_parameters.* of the YAML) to the main program's tables."""
+
+    def __init__(self, optimizer, strategy):
+        self._opt, self._strategy = optimizer, strategy
+
+    def minimize(self, loss, *a, **k):
+        from ... import static
+        prog = static.default_main_program()
+        prog.strategy = self._strategy
+        return self._opt.minimize(loss, *a, **k)
+
+    def __getattr__(self, name):
+        return getattr(self._opt, name)
+
+
+def distributed_optimizer(optimizer, strategy=None):
+    if strategy is None:
+        return optimizer
+    return _StrategyOptimizer(optimizer, strategy)
+
+
+def distributed_model(model):
+    return model
+
+
+class _Util:
+    def all_reduce(self, x, mode="sum", comm_world="worker"):
+        return x              # one worker
+
+    def get_file_shard(self, files):
+        n, i = worker_num(), worker_index()
+        return [f for k, f in enumerate(sorted(files)) if k % n == i]
+
+    def barrier(self, *a, **k):
+        pass
+
+
+util = _Util()
+
+
+class MultiSlotDataGenerator:
+    """paddle.distributed.fleet.MultiSlotDataGenerator [EXT]: the base class of the reference's pipe_command readers
+    (dnn/queuedataset_reader.py:28, slot_dnn/queuedataset_reader.py): run_from_stdin() turns every input line into
+    the samples generate_sample(line)() yields and prints each as `len v ... len v ...` in slot order — the text
+    protocol InMemoryDataset / QueueDataset parse back (compat/paddle/distributed/__init__.py)."""
+
+    def _gen_str(self, sample):
+        parts = []
+        for name, values in sample:
+            if len(values) == 0:
+                raise ValueError("slot %r of a sample is empty: MultiSlot needs at least one value (pad it)" % (name,))
+            parts.append(str(len(values)))
+            parts.extend(str(v) for v in values)
+        return " ".join(parts) + "\n"
+
+    def generate_sample(self, line):
+        raise NotImplementedError
+
+    def generate_batch(self, samples):
+        def local_iter():
+            for s in samples:
+                yield s
+        return local_iter
+
+    def run_from_stdin(self):
+        out = sys.stdout
+        for line in sys.stdin:
+            for sample in self.generate_sample(line)():
+                if sample is None:
+                    continue
+                out.write(self._gen_str(sample))
+
+    def run_from_memory(self):
+        self.run_from_stdin()
+
+
+MultiSlotStringDataGenerator = MultiSlotDataGenerator

@@ -9,6 +9,14 @@ from .. import _backend
 
 
 class Layer(_t.nn.Module):
+    def __call__(self, *args, **kwargs):
+        # static graph: a layer applied to placeholder Vars is ONE recorded op (replayed on every batch)
+        if _backend.static_mode():
+            from ..static import has_var, record
+            if has_var(args, kwargs):
+                return record(super().__call__, args, kwargs)
+        return super().__call__(*args, **kwargs)
+
     def add_sublayer(self, name, layer):
         # paddle semantics: same-name registration replaces the earlier entry
         self._modules[name] = layer

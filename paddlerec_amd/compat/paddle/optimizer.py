@@ -29,6 +29,20 @@ class _Base:
         self._ws = None
         self._groups = {}
 
+    def minimize(self, loss, startup_program=None, parameters=None, no_grad_set=None):
+        """Static graph (dnn/static_model.py:121-127): the loss variable and this optimizer become the main program's
+        training target; Executor.train_from_dataset runs backward + step on every batch."""
+        from . import static as _s
+        if not isinstance(loss, _s.Var):
+            raise NotImplementedError("optimizer.minimize(): dygraph code calls loss.backward(); optimizer.step()")
+        _s.default_main_program().loss = loss
+        _s.default_main_program().optimizer = self
+        return None, None
+
+    def _bind(self, params):
+        if not self._params:
+            self._params = list(params)
+
     def get_lr(self):
         lr = self._lr
         return float(lr() if callable(lr) else getattr(lr, "last_lr", lr))

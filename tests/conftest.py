@@ -1,4 +1,10 @@
 import os
+import sys
+
+# tests execute files of /root/reference (read-only input): neither this process nor its children write __pycache__
+# next to them
+sys.dont_write_bytecode = True
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
 import subprocess
 import sys
 

@@ -19,7 +19,7 @@ import pytest
 from conftest import REPO
 
 STAGED = os.path.join(REPO, "oracle", "_ref", "PaddleRec")
-REF = os.environ.get("PADDLEREC_REF") or ("/root/reference" if os.path.isdir("/root/reference/tools") else STAGED)
+REF = os.environ.get("PADDLEREC_REF") or (STAGED if os.path.isdir(os.path.join(STAGED, "tools")) else "/root/reference")
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "tools")),
                                 reason="reference tree not present (run oracle/make_ref_tree.py in the build container)")
 
@@ -38,7 +38,7 @@ pickle.dump({k: v.detach().numpy() for k, v in m.state_dict().items()}, open(sys
 
 
 def _env(gpu=False):
-    env = dict(os.environ, OMP_NUM_THREADS="4")
+    env = dict(os.environ, OMP_NUM_THREADS="4", PYTHONDONTWRITEBYTECODE="1")      # nothing is written next to the reference's files
     if not gpu:
         env["REC_COMPAT_KERNELS"] = "cpu_kernels"
     else:
@@ -54,7 +54,8 @@ def test_staged_tree_is_a_byte_copy():
     n = 0
     for root, _, files in os.walk(STAGED):
         for f in files:
-            if f == "STAGED_FROM" or f.endswith(".pyc") or "__pycache__" in root or f == "tmp.txt":
+            if f in ("STAGED_FROM", "tmp.txt", "train_result_dict.txt") or f.endswith((".pyc", ".prototxt")) \
+                    or "__pycache__" in root:
                 continue
             rel = os.path.relpath(os.path.join(root, f), STAGED)
             if rel.startswith("output_model") or "output_model" in rel:
