@@ -366,6 +366,17 @@ int rec_ps_save_select(int64_t num_rows, const rec_ps_layout* layout, float* rec
                        const rec_ps_accessor* accessor, uint8_t* selected, int64_t* n_selected, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Backward of a ONE-logit head Linear(n -> 1) behind a ReLU (deepfm/net.py:169-174 and the sibling CTR MLPs), in one
+ * HBM-bound pass over the [batch, n] activation instead of a K = 1 dX GEMM plus a three-launch skinny dW path:
+ *   dx[b,j] = (relu == 0 || act[b,j] > 0) ? dz[b] * w[j] : 0;   dw[j] = sum_b act[b,j] * dz[b];   db[0] = sum_b dz[b]
+ * Fixed summation order (deterministic).  n % 4 == 0, n <= 512, 16-byte aligned rows.
+ * ---------------------------------------------------------------------------------------- */
+int rec_mlp_head_bwd_workspace_bytes(int64_t batch, int32_t n, size_t* bytes);
+int rec_mlp_head_bwd(int64_t batch, int32_t n, const float* act, int64_t ld_act, const float* dz, const float* w,
+                     int32_t relu, float* dx, int64_t ld_dx, float* dw, float* db, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Train-mode Dropout and L2Decay of the DCN-v2 DNN tower (dcn_v2/net.py:158,164-170,181-183).
  * rec_dropout: out[r,c] = keep ? in[r,c] / (1-p)^nmask : 0 over a [rows, cols] matrix (row strides ld_in / ld_out,
  *   in place allowed).  keep is a pure function of (seed, stream id, r*cols + c) — no stored mask: the backward is the

@@ -156,6 +156,8 @@ SIGNATURES = {
     "rec_sparse_rows_sumsq": (C.c_int, [_I64, _I32, _P, _P, _P, _P, C.POINTER(GradLayout), _P, _I32, _P,
                                         _SZ, _P]),
     "rec_clip_scale": (C.c_int, [_P, _F, _P, _P]),
+    "rec_mlp_head_bwd_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(C.c_size_t)]),
+    "rec_mlp_head_bwd": (C.c_int, [_I64, _I32, _P, _I64, _P, _P, _I32, _P, _I64, _P, _P, _P, _SZ, _P]),
     "rec_dropout": (C.c_int, [_I64, _I32, _I64, _I64, _P, _P, _F, C.c_uint64, C.c_uint64, C.c_uint64, _I32, _P]),
     "rec_l2_decay_grad": (C.c_int, [_I64, _P, _P, _F, _P, _P]),
     "rec_din_saves_act1": (C.c_int, [C.POINTER(DinDesc)]),

@@ -39,7 +39,7 @@ def optimizer_state(net):
     st = {"step": int(getattr(net, "step_count", 0))}
     dense = getattr(net, "dense", None)
     if dense is not None:
-        st["dense.m"], st["dense.v"] = _np(dense.m), _np(dense.v)
+        st["dense.m"], st["dense.v"] = _np(dense.packed(dense.m)), _np(dense.packed(dense.v))
     sp = getattr(net, "sparse_state", None)
     if sp:
         for k in ("m", "v", "m1", "v1"):
@@ -52,8 +52,8 @@ def set_optimizer_state(net, st):
     net.step_count = int(st.get("step", 0))
     dense = getattr(net, "dense", None)
     if dense is not None and "dense.m" in st:
-        dense.m.copy_(torch.as_tensor(st["dense.m"]).to(dense.m.device))
-        dense.v.copy_(torch.as_tensor(st["dense.v"]).to(dense.v.device))
+        dense.load_packed(dense.m, st["dense.m"])
+        dense.load_packed(dense.v, st["dense.v"])
     if any(k.startswith("sparse.") for k in st):
         net._ensure_sparse_state()
         for k in ("m", "v", "m1", "v1"):

@@ -785,6 +785,76 @@ __global__ __launch_bounds__(kBlock) void colsum_final_kernel(int nblk, int N,
   out[j] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
 }
 
+// ------------------------------------------------------------------------------- backward of a one-logit head
+// The last Linear of the CTR MLPs has ONE output (deepfm/net.py:169-174: 400 -> 1).  Its backward as two GEMMs is a
+// K = 1 "GEMM" for dX (a 256x80-tile MFMA kernel doing an outer product: 96 us for 210 MB in the DeepFM step) plus a
+// skinny dW path of three launches (skinny_dw + split-K reduce + column-sum reduce: 220 us of kernel time) — both
+// stream the same [B, N] activation.  One HBM-bound pass instead:
+//   dx[b, j] = act[b, j] > 0 ? dz[b] * w[j] : 0          (ReLU' fused: the layer in front ends in a ReLU)
+//   dW[j]    = sum_b act[b, j] * dz[b],   db = sum_b dz[b]
+// Thread t of a block owns float4 column chunk t % 128 (N <= 512) and row parity t / 128; per-thread partial sums over
+// its rows in ascending order, the two parities folded in LDS, one partial row [N + 1] per block, folded across blocks
+// by colsum_final_kernel in a fixed order: deterministic.
+constexpr int kHeadChunks = 128;
+__global__ __launch_bounds__(kBlock) void mlp_head_bwd_kernel(int64_t B, int N, const float* __restrict__ act,
+                                                              int64_t ld_act, const float* __restrict__ dz,
+                                                              const float* __restrict__ w, float* __restrict__ dx,
+                                                              int64_t ld_dx, int relu, float* __restrict__ partial) {
+  __shared__ float red[kHeadChunks * 4 + 1];
+  const int c = threadIdx.x % kHeadChunks, par = threadIdx.x / kHeadChunks;      // kBlock = 2 * kHeadChunks
+  const int j0 = c * 4;
+  const bool colok = j0 < N;
+  const int64_t rows_per = (B + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per;
+  const int64_t r1 = r0 + rows_per < B ? r0 + rows_per : B;
+  float wv[4] = {0.f, 0.f, 0.f, 0.f}, acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float accb = 0.f;
+  if (colok) vload<4>(wv, w + j0);
+  for (int64_t b = r0 + par; b < r1; b += 2) {
+    const float g = dz[b];
+    if (c == 0) accb += g;
+    if (colok) {
+      float a[4], o[4];
+      vload_nt<4>(a, act + b * ld_act + j0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        acc[v] += a[v] * g;
+        o[v] = (!relu || a[v] > 0.f) ? g * wv[v] : 0.f;
+      }
+      vstore<4>(dx + b * ld_dx + j0, o);
+    }
+  }
+  // fold the two row parities (even rows first), then one partial row per block
+  if (par == 1) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) red[c * 4 + v] = acc[v];
+    if (c == 0) red[kHeadChunks * 4] = accb;
+  }
+  __syncthreads();
+  if (par == 0) {
+    float* prow = partial + (int64_t)blockIdx.x * (N + 1);
+    if (colok) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) prow[j0 + v] = acc[v] + red[c * 4 + v];
+    }
+    if (c == 0) prow[N] = accb + red[kHeadChunks * 4];
+  }
+}
+
+// One wave per column folds the per-block partial rows of mlp_head_bwd_kernel: lane l sums rows l, l+64, ... in ascending
+// order, then a fixed xor-shuffle tree — deterministic; column N goes to db, the others to dw.
+__global__ __launch_bounds__(kBlock) void mlp_head_fold_kernel(int nblk, int N, const float* __restrict__ partial,
+                                                               float* __restrict__ dw, float* __restrict__ db) {
+  const int j = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  const int lane = threadIdx.x % kWave;
+  if (j > N) return;
+  float s = 0.f;
+  for (int r = lane; r < nblk; r += kWave) s += partial[(int64_t)r * (N + 1) + j];
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, kWave);
+  if (lane == 0) (j < N ? dw[j] : db[0]) = s;
+}
+
 // ------------------------------------------------------------------------------- config selection
 enum GemmCfg { CFG_128x80 = 0, CFG_256x80, CFG_256x128, CFG_128x128, CFG_80x80, CFG_64x80, CFG_128x80_O4, CFG_COUNT };
 struct CfgInfo {
@@ -1178,4 +1248,34 @@ extern "C" int rec_colsum(int64_t m, int32_t n, int32_t ld, const float* G, floa
   hipLaunchKernelGGL(colsum_final_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
                      nblk, n, (const float*)workspace, out);
   return check_launch("rec_colsum");
+}
+
+extern "C" int rec_mlp_head_bwd_workspace_bytes(int64_t batch, int32_t n, size_t* bytes) {
+  REC_REQUIRE(bytes && batch >= 0 && n > 0, REC_EINVAL, "bad arguments");
+  *bytes = align_up((size_t)kNumCU * 8 * (n + 1) * sizeof(float), 256);
+  return REC_OK;
+}
+
+extern "C" int rec_mlp_head_bwd(int64_t batch, int32_t n, const float* act, int64_t ld_act, const float* dz,
+                                const float* w, int32_t relu, float* dx, int64_t ld_dx, float* dw, float* db,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  REC_REQUIRE(batch >= 0 && n > 0 && n % 4 == 0 && n <= kHeadChunks * 4, REC_ESHAPE,
+              "rec_mlp_head_bwd: n must be a multiple of 4 and <= %d", kHeadChunks * 4);
+  REC_REQUIRE(act && dz && w && dx && dw && db && ld_act >= n && ld_dx >= n && ld_act % 4 == 0 && ld_dx % 4 == 0 &&
+                  ((uintptr_t)act) % 16 == 0 && ((uintptr_t)dx) % 16 == 0 && ((uintptr_t)w) % 16 == 0,
+              REC_EINVAL, "bad arguments (16-byte aligned rows required)");
+  size_t need = 0;
+  rec_mlp_head_bwd_workspace_bytes(batch, n, &need);
+  REC_REQUIRE(workspace && workspace_bytes >= need, REC_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  int64_t grid = (batch + 31) / 32;                 // >= 32 rows per block
+  if (grid > kNumCU * 8) grid = kNumCU * 8;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(mlp_head_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), 0, st, batch, n, act, ld_act, dz, w, dx,
+                     ld_dx, relu, partial);
+  const int cols_per_block = kBlock / kWave;
+  hipLaunchKernelGGL(mlp_head_fold_kernel, dim3((n + 1 + cols_per_block - 1) / cols_per_block), dim3(kBlock), 0, st,
+                     (int)grid, n, (const float*)partial, dw, db);
+  return check_launch("rec_mlp_head_bwd");
 }

@@ -23,22 +23,46 @@ NUM_THRESHOLDS = 4095  # paddle.metric.Auc default [EXT]
 
 class _FlatParams:
     """All dense parameters in ONE flat f32 buffer (+ grad, Adam m/v): one optimizer launch and one
-    all-reduce bucket per step instead of one per tensor."""
+    all-reduce bucket per step instead of one per tensor.  Every tensor starts on a 256-byte boundary (the gaps stay
+    zero in all four buffers): the GEMM loaders and the head kernels take 16-byte vector loads of the weights, and an
+    odd-sized tensor in front (fm.dense_w [13], a bias [1]) would otherwise push every later one off alignment and
+    silently onto the scalar-load variants.  `packed()` / `load_packed()` give the gap-free declaration-order image
+    checkpoints hold."""
+    ALIGN = 64          # floats
 
     def __init__(self, shapes, device):
         self.names = [n for n, _ in shapes]
         self.shapes = dict(shapes)
-        total = sum(math.prod(s) for _, s in shapes)
-        self.data = torch.zeros(total, dtype=torch.float32, device=device)
+        self.offsets, o = {}, 0
+        for n, s in shapes:
+            self.offsets[n] = o
+            o += -(-math.prod(s) // self.ALIGN) * self.ALIGN
+        self.data = torch.zeros(max(o, 1), dtype=torch.float32, device=device)
         self.grad = torch.zeros_like(self.data)
         self.m = torch.zeros_like(self.data)
         self.v = torch.zeros_like(self.data)
-        self.p, self.g = {}, {}
-        o = 0
+        self.p, self.g, self.pm, self.pv = {}, {}, {}, {}
         for n, s in shapes:
-            k = math.prod(s)
+            o, k = self.offsets[n], math.prod(s)
             self.p[n] = self.data[o:o + k].view(s)
             self.g[n] = self.grad[o:o + k].view(s)
+            self.pm[n] = self.m[o:o + k].view(s)
+            self.pv[n] = self.v[o:o + k].view(s)
+
+    def packed(self, buf):
+        """Gap-free image of one of the four buffers, tensors in declaration order."""
+        return torch.cat([buf[self.offsets[n]:self.offsets[n] + math.prod(self.shapes[n])] for n in self.names]) \
+            if self.names else buf[:0]
+
+    def load_packed(self, buf, flat):
+        flat = torch.as_tensor(flat).reshape(-1)
+        want = sum(math.prod(self.shapes[n]) for n in self.names)
+        if flat.numel() != want:
+            raise ValueError("packed dense image has %d floats, the parameters %d" % (flat.numel(), want))
+        o = 0
+        for n in self.names:
+            k = math.prod(self.shapes[n])
+            buf[self.offsets[n]:self.offsets[n] + k].copy_(flat[o:o + k].to(buf.device))
             o += k
 
 

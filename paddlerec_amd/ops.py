@@ -1180,6 +1180,28 @@ def mlp_forward(x, weights, biases, ws, relu_last=False, out_last=None):
     return x, acts + [x]
 
 
+def mlp_head_bwd(act, dz, w, ws, dw, db, relu=True, out=None):
+    """Backward of a one-logit head Linear(n -> 1) behind a ReLU in ONE pass over act [B, n]: -> dx [B, n]; dw [n] (or
+    [n,1]) and db [1] are written.  (rec_mlp_head_bwd)"""
+    B, n = act.shape
+    if out is None:
+        out = torch.empty(B, n, dtype=torch.float32, device=act.device)
+    nbytes = C.c_size_t(0)
+    check(lib().rec_mlp_head_bwd_workspace_bytes(B, n, C.byref(nbytes)))
+    wk = ws.get(nbytes.value)
+    check(lib().rec_mlp_head_bwd(B, n, _p(act), act.stride(0), _p(dz), _p(w), 1 if relu else 0, _p(out), out.stride(0),
+                                 _p(dw), _p(db), _p(wk), C.c_size_t(wk.numel()), _stream()), "rec_mlp_head_bwd")
+    return out
+
+
+def _head_ok(act, w, dw, db, dy):
+    """A one-logit head the fused backward takes: Linear(n -> 1), n % 4 == 0, n <= 512, aligned contiguous operands."""
+    return (os.environ.get("REC_MLP_HEAD_FUSED", "1") != "0" and w.dim() == 2 and w.shape[1] == 1 and
+            w.shape[0] % 4 == 0 and w.shape[0] <= 512 and act.dim() == 2 and act.stride(1) == 1 and
+            act.stride(0) % 4 == 0 and act.data_ptr() % 16 == 0 and w.is_contiguous() and w.data_ptr() % 16 == 0 and
+            dw.is_contiguous() and dy.is_contiguous() and dy.shape[-1] == 1 and act.shape[0] >= 64)
+
+
 def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=False, dw_stream=None, dw_ws=None):
     """Backward of mlp_forward: dW_i -> dws[i], db_i -> dbs[i] (preallocated views); returns d(input).
     ReLU' is applied in the epilogue of the dX GEMM (mask = layer input > 0).
@@ -1190,6 +1212,13 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
     — the row-sharded step hides its gradient exchange, sparse optimizer and the next batch's lookup under them."""
     n = len(weights)
     g = dy
+    head = n > 1 and _head_ok(acts[n - 1], weights[n - 1], dws[n - 1], dbs[n - 1], dy)
+    if head and not defer_all:
+        # the one-logit head: dX (with the ReLU mask of the layer in front), dW and db in ONE pass over its input
+        g = mlp_head_bwd(acts[n - 1], dy, weights[n - 1], ws, dws[n - 1], dbs[n - 1], relu=True)
+        n_run = n - 1
+    else:
+        n_run = n
     if defer_all:
         gs = [None] * n
         for i in reversed(range(n)):
@@ -1207,7 +1236,7 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
         if dw_stream is not None:
             cur.wait_stream(dw_stream)
             keep.clear()
-    for i in reversed(range(n)):
+    for i in reversed(range(n_run)):
         if i == 0 and defer_first:
             g0 = g
             d_in = gemm(g0, weights[0], ws, trans_b=True)

@@ -188,16 +188,9 @@ def assert_close_scaled(got, want, rel=1e-5, err_msg=""):
 
 def layer_moments(layer):
     """{dense parameter name: (m, v)} numpy views of a host mirror's flat Adam moments (paddlerec_amd.deepfm._FlatParams
-    keeps every dense parameter, its gradient and both moments in one buffer, in declaration order)."""
-    import math
-    out, o = {}, 0
-    m, v = layer.dense.m.detach().cpu().numpy(), layer.dense.v.detach().cpu().numpy()
-    for n in layer.dense.names:
-        shape = tuple(layer.dense.shapes[n])
-        k = math.prod(shape)
-        out[n] = (m[o:o + k].reshape(shape), v[o:o + k].reshape(shape))
-        o += k
-    return out
+    keeps every dense parameter, its gradient and both moments in flat buffers; .pm / .pv are the per-tensor views)."""
+    d = layer.dense
+    return {n: (d.pm[n].detach().cpu().numpy(), d.pv[n].detach().cpu().numpy()) for n in d.names}
 
 
 def assert_moments_close(layer, want_m, want_v, names=None, rel=1e-5, rename=None):

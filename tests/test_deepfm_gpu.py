@@ -543,13 +543,8 @@ def test_train_steps_vs_oracle(ops):
     assert_close_scaled(N_(m.sparse_state["v"]), st["vW"])
     assert_close_scaled(N_(m.sparse_state["m1"]), st["mW1"])
     assert_close_scaled(N_(m.sparse_state["v1"]), st["vW1"])
-    off = 0
-    for name in m.dense.names:                      # dense moments live in the flat buffer, in declaration order
-        k = int(np.prod(m.dense.shapes[name]))
-        if name == "dnn.linear_0.weight":
-            assert_close_scaled(N_(m.dense.m[off:off + k]).reshape(op["mlp_w"][0].shape), dstate[("mlp_w", 0)][0])
-            assert_close_scaled(N_(m.dense.v[off:off + k]).reshape(op["mlp_w"][0].shape), dstate[("mlp_w", 0)][1])
-        off += k
+    assert_close_scaled(N_(m.dense.pm["dnn.linear_0.weight"]), dstate[("mlp_w", 0)][0])
+    assert_close_scaled(N_(m.dense.pv["dnn.linear_0.weight"]), dstate[("mlp_w", 0)][1])
     # The WEIGHTS go through m / (sqrt(v) + eps): where a gradient is ~0 the ratio amplifies fp32 noise up to a sign
     # flip, i.e. up to lr per step for a handful of elements — so: all but a vanishing fraction agree at 1e-6
     # absolute, and nothing moved further than the 3 steps allow.

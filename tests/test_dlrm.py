@@ -175,19 +175,14 @@ def _check_layer(device, kernels, tol):
         tr.p = p2
         Dd = m.sparse_feature_dim
         tr.st = {"W": (m.sparse_state["m"].cpu().numpy().copy(), m.sparse_state["v"].cpu().numpy().copy())}
-        off = 0
-        flat_m, flat_v = m.dense.m.cpu().numpy(), m.dense.v.cpu().numpy()
         for nm in m.dense.names:
-            n_el = int(np.prod(m.dense.shapes[nm]))
             key, rest = nm.split(".", 1)
             kind, attr = rest.split(".")
             i = int(kind.split("_")[1])
             lk = {("dense", "weight"): "w", ("dense", "bias"): "b", ("norm", "weight"): "gamma",
                   ("norm", "bias"): "beta"}[(kind.split("_")[0], attr)]
-            shape = m.dense.shapes[nm]
-            tr.st[("bot" if key == "bot_mlp" else "top", i, lk)] = (flat_m[off:off + n_el].reshape(shape).copy(),
-                                                                    flat_v[off:off + n_el].reshape(shape).copy())
-            off += n_el
+            tr.st[("bot" if key == "bot_mlp" else "top", i, lk)] = (m.dense.pm[nm].cpu().numpy().copy(),
+                                                                    m.dense.pv[nm].cpu().numpy().copy())
     assert int(m.status.item()) == 0
     dm = DygraphModel()
     cfg = {"hyper_parameters.sparse_feature_number": N, "hyper_parameters.sparse_feature_dim": D,

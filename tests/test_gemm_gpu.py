@@ -237,3 +237,55 @@ def test_gemm_glds_kernel(ops, M, N, K, tb, monkeypatch):
     wide = torch.zeros(M, K + 16, device=DEV)
     wide[:, :K] = At
     _check(ops.gemm(wide[:, :K], Bt, ws, trans_b=tb).cpu().numpy(), want, bound)
+
+
+@pytest.mark.parametrize("B,N,ld", [(64, 400, 400), (1000, 400, 400), (65536, 400, 400), (4099, 16, 16),
+                                    (2048, 512, 512), (777, 128, 132)])
+def test_mlp_head_bwd(ops, B, N, ld):
+    """Fused backward of a one-logit head (rec_mlp_head_bwd) against float64, and bit-identical on a re-run."""
+    rng = np.random.default_rng(B + N)
+    act = np.maximum(_mk(rng, B, ld), 0)                       # a ReLU output: about half zeros
+    dz, w = _mk(rng, B, 1) * 1e-3, _mk(rng, N, 1)
+    ws = ops.Workspace(DEV)
+    a_t = torch.as_tensor(act).to(DEV)[:, :N]
+    dz_t, w_t = torch.as_tensor(dz).to(DEV), torch.as_tensor(w).to(DEV)
+    runs = []
+    for _ in range(2):
+        dw, db = torch.full((N, 1), 7.0, device=DEV), torch.full((1,), 7.0, device=DEV)
+        dx = ops.mlp_head_bwd(a_t, dz_t, w_t, ws, dw, db, relu=True)
+        runs.append((dx.cpu().numpy(), dw.cpu().numpy(), db.cpu().numpy()))
+    dx, dw, db = runs[0]
+    a64 = act[:, :N].astype(np.float64)
+    want_dx = (dz.astype(np.float32) * w.reshape(1, N).astype(np.float32)) * (act[:, :N] > 0)     # one fp32 product
+    np.testing.assert_array_equal(dx, want_dx.astype(np.float32))
+    want_dw = a64.T @ dz.astype(np.float64)
+    bound = 1e-6 * (np.abs(a64).T @ np.abs(dz.astype(np.float64))).max() + 1e-30
+    assert np.abs(dw - want_dw).max() <= bound
+    assert abs(db[0] - dz.astype(np.float64).sum()) <= 1e-6 * np.abs(dz).sum()
+    for x, y in zip(runs[0], runs[1]):
+        np.testing.assert_array_equal(x, y)
+    # relu = 0: no mask
+    dw, db = torch.empty(N, 1, device=DEV), torch.empty(1, device=DEV)
+    dx2 = ops.mlp_head_bwd(a_t, dz_t, w_t, ws, dw, db, relu=False).cpu().numpy()
+    np.testing.assert_array_equal(dx2, (dz * w.reshape(1, N)).astype(np.float32))
+
+
+def test_mlp_backward_head_path_matches_gemm_path(ops, monkeypatch):
+    """mlp_backward with the fused head and with the GEMM chain (REC_MLP_HEAD_FUSED=0): same gradients to 1e-5 of scale."""
+    rng = np.random.default_rng(11)
+    B, sizes = 4096, [208, 400, 400, 1]
+    ws = ops.Workspace(DEV)
+    Ws = [torch.as_tensor(_mk(rng, sizes[i], sizes[i + 1]) * 0.1).to(DEV) for i in range(3)]
+    bs = [torch.as_tensor(_mk(rng, sizes[i + 1]) * 0.1).to(DEV) for i in range(3)]
+    x = torch.as_tensor(_mk(rng, B, 208)).to(DEV)
+    dy = torch.as_tensor(_mk(rng, B, 1) * 1e-3).to(DEV)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("REC_MLP_HEAD_FUSED", flag)
+        _, acts = ops.mlp_forward(x, Ws, bs, ws)
+        dws = [torch.empty_like(w) for w in Ws]
+        dbs = [torch.empty_like(b) for b in bs]
+        dx = ops.mlp_backward(dy, acts, Ws, dws, dbs, ws)
+        outs.append([dx.cpu().numpy()] + [t.cpu().numpy() for t in dws + dbs])
+    for a, b in zip(*outs):
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
