@@ -266,6 +266,277 @@ __global__ __launch_bounds__(kMsWaves * kWave, (kMsWaves == 8 || NSW >= 2) ? 6 :
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Lane-per-id variant for narrow rows (D = 8..11 in 16-byte aligned records, tables below 2^32 rows, no lazy creation).
+//
+// The kernel above spends its time ISSUING VALU instructions (profiles/r02f_multislot_short_run_pmc.txt: 11.4 VALU
+// wave-instructions per id): with LANES lanes per row it gathers 64 / LANES ids per wave instruction, so the list reads,
+// the address arithmetic, the segmented scan and the flush run 64 / G times per 64 live ids, and every 64-id step of a
+// slot rounds its live ids up to a multiple of G on its own.  Here
+//   * a lane owns ONE id and holds the whole row in registers (D floats: ceil(D / 4) wide loads);
+//   * phase 1 (per 64 ids: hash -> row, segment id, side outputs, counts) runs for ALL ids of the wave's slots first
+//     and appends the live ones to a per-wave list (row as u32, offset in the block's output tile as u16);
+//   * phase 2 gathers the list 64 entries at a time, the loads of two gathers in flight before the first is reduced:
+//     a segmented scan over the 16-lane DPP rows (runs are contiguous in the list; shifts 1, 2, 4, 8, skipped once no
+//     run reaches that far), then the tail of each piece of a run puts its sum into the LDS tile — the FIRST piece of
+//     a run with plain stores (the tile is zero; one lane per address), a piece that continues a run from the DPP row
+//     or the drain before it with ds_add_f32, one DPP row per instruction (two such pieces can belong to one run),
+//     skipped when there is none.  Pieces go in ascending order, in program order: the summation order is a function
+//     of the input alone;
+//   * the tile goes out as float4 non-temporal stores (the output, the counts and the side outputs are written once and
+//     read by a later kernel; the table rows are what should stay in the caches).
+// Measured (profiles/r03_multislot_lane.txt): 0.77-0.83 of the row-group kernel's time on the slot_dnn shape; persistent
+// blocks with the next tile's offsets / ids requested a tile ahead were built and were SLOWER (the prefetched state
+// costs the registers of an occupancy step), as were plain read-add-write flushes and a scalar conflict-free write-out.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kLaneCap = 160;   // list entries per wave
+
+__device__ __forceinline__ int64_t uniform64(int64_t x) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+template <int DT, int NSW, int kMsWaves>
+__global__ __launch_bounds__(kMsWaves * kWave, 6) void multislot_sumpool_lane_kernel(
+    int64_t B, int S, int stride, int key_mode, int64_t N, int64_t pad, int64_t lod_stride, int64_t out_stride, int nsg,
+    int vec_out, FastMod fm, const int64_t* __restrict__ values, const int64_t* __restrict__ lod,
+    const int64_t* __restrict__ slot_base, const float* __restrict__ W, float* __restrict__ out,
+    int32_t* __restrict__ counts, int32_t* __restrict__ seg_of_value, int64_t* __restrict__ rows_out,
+    int32_t* __restrict__ status) {
+  constexpr int kMsBlock = kMsWaves * kWave;
+  constexpr int SS = kMsWaves * NSW;
+  constexpr int D = DT;
+  constexpr int pitch = (SS * D) | 1;
+  constexpr int NV4 = D / 4, REM = D % 4;                 // full float4 loads, leftover floats
+  constexpr int NE = REM == 1 ? D : (D + 3) / 4 * 4;      // floats held per lane (a 1-float tail is a dword load)
+  constexpr int TILE4 = (kMsTS * pitch + 3) / 4;          // the tile in float4 (16-byte aligned, padded)
+  static_assert(kMsTS * pitch < 65536, "tile offsets are 16-bit");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* tile = reinterpret_cast<float*>(smem_raw);                                   // [TS][pitch]
+  int* cnt = reinterpret_cast<int*>(tile + 4 * TILE4);                                // [TS][SS]
+  unsigned* lrow_all = reinterpret_cast<unsigned*>(cnt + kMsTS * SS);                 // [waves][kLaneCap]
+  unsigned short* ltoff_all = reinterpret_cast<unsigned short*>(lrow_all + kMsWaves * kLaneCap);   // [waves][kLaneCap + 32]
+  unsigned char* segtab = reinterpret_cast<unsigned char*>(ltoff_all + kMsWaves * (kLaneCap + 32));  // [waves][kSegCap]
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+  const int rpos = lane & 15, rowi = lane >> 4;
+  unsigned* lrow = lrow_all + wave * kLaneCap;
+  unsigned short* ltoff = ltoff_all + wave * (kLaneCap + 32);
+  unsigned char* wtab = segtab + wave * kSegCap;
+  // tile -> (64-sample piece, slot group): the slot groups of one piece are consecutive blocks
+  const int64_t b0 = (int64_t)(blockIdx.x / (unsigned)nsg) * kMsTS;
+  const int s0 = (int)(blockIdx.x % (unsigned)nsg) * SS;
+  const int ns_tile = min(SS, S - s0);
+
+  for (int i = threadIdx.x; i < TILE4 + kMsTS * SS / 4; i += kMsBlock)     // tile and counts are adjacent
+    reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // ---- offsets of the wave's slots, then the first 128 ids of each (all in flight together)
+  int64_t gk0[NSW];
+  int n[NSW], len[NSW], so_l[NSW];
+  int64_t idv[NSW], idv2[NSW];
+#pragma unroll
+  for (int i = 0; i < NSW; ++i) {
+    const int sl = wave * NSW + i;
+    n[i] = 0; gk0[i] = 0; len[i] = 0; so_l[i] = 0;
+    if (sl < ns_tile) {
+      const int64_t* l = lod + (int64_t)(s0 + sl) * lod_stride;
+      const int64_t lo = __builtin_nontemporal_load(l + min(b0 + lane, B));
+      const int64_t hi = __builtin_nontemporal_load(l + min(b0 + lane + 1, B));
+      const int64_t k0 = uniform64(lo);
+      const int64_t kend = uniform64(__shfl(hi, kWave - 1, kWave));
+      n[i] = (int)(kend - k0);
+      gk0[i] = slot_base[s0 + sl] + k0;
+      so_l[i] = (int)(lo - k0);
+      len[i] = (int)(hi - lo);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NSW; ++i) {
+    const int64_t* vp = values + gk0[i];
+    idv[i] = lane < n[i] ? __builtin_nontemporal_load(vp + lane) : 0;
+    idv2[i] = kWave + lane < n[i] ? __builtin_nontemporal_load(vp + kWave + lane) : 0;
+  }
+  __syncthreads();       // the zeroed tile
+
+  // phase 2 pieces: the rows of list entries [j0, j0 + 64) into registers / their segmented sums into the tile
+  auto load_rows = [&](int j0, int nl, float (&e)[NE]) {
+#pragma unroll
+    for (int v = 0; v < NE; ++v) e[v] = 0.f;
+    if (j0 + lane < nl) {
+      const float* p = W + (int64_t)lrow[j0 + lane] * stride;
+#pragma unroll
+      for (int c = 0; c < NV4; ++c) {
+        const float4 q = *reinterpret_cast<const float4*>(p + 4 * c);
+        e[4 * c] = q.x; e[4 * c + 1] = q.y; e[4 * c + 2] = q.z; e[4 * c + 3] = q.w;
+      }
+      if constexpr (REM == 1) {
+        e[4 * NV4] = p[4 * NV4];
+      } else if constexpr (REM > 1) {
+        const float4 q = *reinterpret_cast<const float4*>(p + 4 * NV4);
+        e[4 * NV4] = q.x; e[4 * NV4 + 1] = q.y; e[4 * NV4 + 2] = q.z; e[4 * NV4 + 3] = q.w;
+      }
+    }
+  };
+  // tile offset of the last entry of an overflow drain: its run may go on in the next list.  Never reset: a tile offset
+  // names one (sample, slot) cell and the ids of a cell are one run, so an entry that matches it IS the continuation
+  int carry = -1;
+  auto reduce_rows = [&](int j0, int nl, float (&e)[NE]) {
+    const int q = j0 + lane;
+    const bool ok = q < nl;
+    const int t = ok ? (int)ltoff[q] : -1 - lane;        // distinct negatives: never equal to a neighbour
+    const int tn = (q + 1 < nl) ? (int)ltoff[q + 1] : -1;
+    // a piece that starts a DPP row may continue a run of the row (or the drain) before it
+    const int tp = q > 0 ? (int)ltoff[q - 1] : carry;
+    const unsigned long long cm = __ballot(ok && rpos == 0 && tp == t);
+    int plen = 1;       // length of the piece that ends here (inclusive scan of ones)
+#define REC_LSCAN_STEP(O)                                                                   \
+  if (more) {                                                                               \
+    const int so_ = row_shr_i<O>(-3, t);                                                    \
+    const bool tk = rpos >= O && so_ == t;                                                  \
+    more = __ballot(tk) != 0;                                                               \
+    const int pl = row_shr_i<O>(0, plen);                                                   \
+    plen += tk ? pl : 0;                                                                    \
+    _Pragma("unroll") for (int v = 0; v < D; ++v) {                                         \
+      const float x = row_shr_f<O>(e[v]);                                                   \
+      e[v] += tk ? x : 0.f;                                                                 \
+    }                                                                                       \
+  }
+    bool more = true;
+    REC_LSCAN_STEP(1) REC_LSCAN_STEP(2) REC_LSCAN_STEP(4) REC_LSCAN_STEP(8)
+#undef REC_LSCAN_STEP
+    const bool tail = ok && (rpos == 15 || tn != t);
+    const bool cont = plen == rpos + 1 && ((cm >> (lane & 48)) & 1ull) != 0;
+    float* dst = tile + (t < 0 ? 0 : t);
+    if (tail && !cont) {
+#pragma unroll
+      for (int v = 0; v < D; ++v) dst[v] = e[v];
+    }
+    if (cm != 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        if (((cm >> (16 * ph)) & 1ull) != 0) {        // wave-uniform
+          if (tail && cont && rowi == ph) {
+#pragma unroll
+            for (int v = 0; v < D; ++v) atomicAdd(dst + v, e[v]);        // ds_add_f32, one lane per address
+          }
+        }
+      }
+    }
+  };
+  auto drain = [&](int nl) {
+    for (int j0 = 0; j0 < nl; j0 += 2 * kWave) {
+      float ea[NE], eb[NE];
+      load_rows(j0, nl, ea);
+      const bool two = j0 + kWave < nl;
+      if (two) load_rows(j0 + kWave, nl, eb);
+      reduce_rows(j0, nl, ea);
+      if (two) reduce_rows(j0 + kWave, nl, eb);
+    }
+  };
+
+  int oob = 0;
+  int nl = 0;     // live ids waiting in the list (wave-uniform)
+  // ---- phase 1
+#pragma unroll
+  for (int i = 0; i < NSW; ++i) {
+    const int sl = wave * NSW + i;
+    const bool tab = n[i] <= kSegCap;
+    if (tab) {
+      for (int j = 0; __ballot(j < len[i]) != 0; ++j)
+        if (j < len[i]) wtab[so_l[i] + j] = (unsigned char)lane;
+    }
+    wave_fence();
+    const int64_t* vp = values + gk0[i];
+    int32_t* svp = seg_of_value ? seg_of_value + gk0[i] : nullptr;
+    int64_t* rop = rows_out ? rows_out + gk0[i] : nullptr;
+    const int segbase = (int)(b0 * S) + s0 + sl;
+    for (int c0 = 0; c0 < n[i]; c0 += kWave) {
+      if (nl + kWave > kLaneCap) {      // the list could overflow: reduce what it holds (long pieces only)
+        wave_fence();
+        drain(nl);
+        carry = __builtin_amdgcn_readfirstlane((int)ltoff[nl - 1]);
+        nl = 0;
+        wave_fence();
+      }
+      const int kk = c0 + lane;
+      const bool in = kk < n[i];
+      const int64_t id = c0 == 0 ? idv[i] : c0 == kWave ? idv2[i] : (in ? __builtin_nontemporal_load(vp + kk) : 0);
+      const bool live = in && (id != pad || pad < 0);
+      const int64_t r = key_mode ? (id == 0 ? 0 : (int64_t)(1 + fast_mod(mix64((uint64_t)id), fm))) : id;
+      const bool inr = (uint64_t)r < (uint64_t)N;
+      oob |= (live && !inr) ? 1 : 0;
+      const bool hit = live && inr;
+      int seg = 0;
+      if (tab) {
+        if (in) seg = wtab[kk];
+      } else {   // oversized run table: binary search in the lanes' offsets (the last t with so[t] <= kk)
+        int lo = 0, hi = kMsTS;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+          const int mid = (lo + hi) >> 1;
+          const bool le = __shfl(so_l[i], mid, kWave) <= kk;
+          lo = le ? mid : lo;
+          hi = le ? hi : mid;
+        }
+        seg = lo;
+      }
+      if (in) {
+        if (svp) __builtin_nontemporal_store(segbase + seg * S, svp + kk);
+        if (rop) __builtin_nontemporal_store(hit ? r : (pad >= 0 ? (key_mode ? 0 : pad) : r), rop + kk);
+      }
+      if (hit) atomicAdd(&cnt[seg * SS + sl], 1);   // LDS integer add: exact, order-free
+      const unsigned long long hm = __ballot(hit);
+      const int cpos = nl + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0));
+      if (hit) { lrow[cpos] = (unsigned)r; ltoff[cpos] = (unsigned short)(seg * pitch + sl * D); }
+      nl += __popcll(hm);
+    }
+    wave_fence();      // wtab is restamped by the next slot
+  }
+  // ---- phase 2
+  drain(nl);
+  if (oob) atomicOr(status, REC_FLAG_INDEX_OOB);
+  __syncthreads();
+
+  // ---- write-out
+  const int nsamp = (int)min((int64_t)kMsTS, B - b0);
+  if (vec_out && ns_tile == SS) {       // whole tile, 16-byte aligned output rows: float4 stores
+    constexpr int RV = SS * D / 4;      // float4 per sample row (SS * D is a multiple of 4: SS is)
+    constexpr int TOT = kMsTS * RV;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int it = 0; it < (TOT + kMsBlock - 1) / kMsBlock; ++it) {
+      const int f = it * kMsBlock + threadIdx.x;
+      const int smp = f / RV, c4 = f - smp * RV;
+      if (f < TOT && smp < nsamp) {
+        const float* src = tile + smp * pitch + 4 * c4;
+        const f32x4 q = {src[0], src[1], src[2], src[3]};
+        __builtin_nontemporal_store(q, reinterpret_cast<f32x4*>(out + (b0 + smp) * out_stride + (int64_t)s0 * D + 4 * c4));
+      }
+    }
+    if (counts && threadIdx.x < kMsTS * SS / 4) {
+      const int smp = threadIdx.x / (SS / 4), c4 = threadIdx.x % (SS / 4);
+      const int4 q = *reinterpret_cast<const int4*>(cnt + smp * SS + 4 * c4);
+      const i32x4 qq = {q.x, q.y, q.z, q.w};
+      if (smp < nsamp) __builtin_nontemporal_store(qq, reinterpret_cast<i32x4*>(counts + (b0 + smp) * S + s0 + 4 * c4));
+    }
+  } else {
+    const int run = ns_tile * D;
+    for (int smp = wave; smp < nsamp; smp += kMsWaves) {
+      float* dst = out + (b0 + smp) * out_stride + (int64_t)s0 * D;
+      const float* src = tile + smp * pitch;
+      for (int c = lane; c < run; c += kWave) dst[c] = src[c];
+    }
+    if (counts) {
+      for (int i = threadIdx.x; i < kMsTS * SS; i += kMsBlock) {
+        const int smp = i / SS, c = i % SS;
+        if (c < ns_tile && smp < nsamp) counts[(b0 + smp) * S + s0 + c] = cnt[i];
+      }
+    }
+  }
+}
+
 // the same multiply-high modulo as the pool kernel's fused hash (one implementation, one test surface)
 __global__ void feasign_rows_kernel(int64_t n, FastMod fm, const int64_t* __restrict__ keys,
                                     int64_t* __restrict__ rows) {
@@ -337,6 +608,35 @@ extern "C" int rec_multislot_sumpool_fwd(const rec_multislot_desc* d, const int6
   FastMod fmod = make_fastmod(1);
   if (d->key_mode == 1) fmod = make_fastmod((uint64_t)(d->num_rows - 1));
   hipStream_t st = (hipStream_t)stream;
+  // narrow rows in 16-byte aligned records of a table below 2^32 rows: the lane-per-id kernel (REC_MS_LANE=0: off)
+  const char* lane_env = getenv("REC_MS_LANE");            // read per call: tests compare both kernels in one process
+  const bool lane_on = !(lane_env && *lane_env == '0');
+  if (lane_on && v4 && state_off < 0 && d->num_rows < (1ll << 32) && S > 8 && D >= 8 && D <= 11) {
+#define REC_MSL_LAUNCH(DT_)                                                                              \
+  case DT_: {                                                                                            \
+    constexpr int W_ = 8, NSW_ = 2, SS = W_ * NSW_;                                                      \
+    constexpr int pitch = (SS * DT_) | 1;                                                                \
+    constexpr size_t shmem = ((size_t)((kMsTS * pitch + 3) / 4 * 4) + (size_t)kMsTS * SS) * 4 +          \
+                             (size_t)W_ * kLaneCap * 4 + (size_t)W_ * (kLaneCap + 32) * 2 +              \
+                             (size_t)W_ * kSegCap;                                                       \
+    static_assert(shmem <= 64 * 1024, "LDS of the lane-per-id kernel");                                  \
+    const int nsg = (S + SS - 1) / SS;                                                                   \
+    const int64_t grid = (int64_t)nbt * nsg;                                                             \
+    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many tiles");                                       \
+    const int vec_out = out_stride % 4 == 0 && ((uintptr_t)out) % 16 == 0 && S % 4 == 0 &&               \
+                        (!counts || ((uintptr_t)counts) % 16 == 0);                                      \
+    hipLaunchKernelGGL((multislot_sumpool_lane_kernel<DT_, NSW_, W_>), dim3((unsigned)grid),             \
+                       dim3(W_ * kWave), shmem, st, d->batch, S, d->row_stride, d->key_mode,             \
+                       d->num_rows, d->padding_idx, lod_stride, out_stride, nsg, vec_out, fmod, values,  \
+                       lod, slot_base, W, out, counts, seg_of_value, rows_out, status);                  \
+    return check_launch("rec_multislot_sumpool_fwd (lane)");                                             \
+  }
+    switch (D) {
+      REC_MSL_LAUNCH(8) REC_MSL_LAUNCH(9) REC_MSL_LAUNCH(10) REC_MSL_LAUNCH(11)
+      default: break;
+    }
+#undef REC_MSL_LAUNCH
+  }
   static const int ms_cfg = [] { const char* v = getenv("REC_MS_CFG"); return v && *v ? atoi(v) : 0; }();
 #define REC_MS_LAUNCH(V, L, NSW_, W_)                                                                   \
   {                                                                                                     \

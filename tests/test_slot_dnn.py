@@ -241,6 +241,37 @@ def test_multislot_run_lengths_around_a_substep(engine_lib, max_len, D, stride):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("max_len,empty,D,stride,S", [(70, 0.0, 9, 16, 12), (3, 0.6, 9, 16, 33), (33, 0.2, 10, 12, 16),
+                                                      (200, 0.5, 8, 8, 9), (18, 0.1, 12, 12, 16), (5, 0.9, 11, 12, 40)])
+def test_multislot_lane_per_id_kernel(engine_lib, monkeypatch, max_len, empty, D, stride, S):
+    """The lane-per-id kernel (narrow rows) against the oracle AND the row-group kernel (REC_MS_LANE=0): runs that
+    cross DPP rows, cover whole rows (the four-pass flush), cross list drains and slots; mostly-empty slots."""
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(max_len * 7 + S)
+    B, N = 203, 6007
+    samples = _random_problem(rng, B, S, N, max_len=max_len, empty_frac=empty, feasigns=True)
+    values, lod, base = M.csr_from_samples(samples, S)
+    Wfull = rng.standard_normal((N, stride)).astype(np.float32)
+    mbatch = ops.MultislotBatch(T(values), T(lod), T(base))
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("REC_MS_LANE", flag)
+        out, counts, seg, rows, status = ops.multislot_sumpool(mbatch, T(Wfull)[:, :D], N, 0, 1)
+        res[flag] = (out.cpu().numpy(), counts.cpu().numpy(), seg.cpu().numpy(), rows.cpu().numpy(), int(status.item()))
+    want, wcnt, wseg, wrows = M.multislot_sumpool(values, lod, base, Wfull[:, :D], 0, 1, N)
+    for flag in ("1", "0"):
+        out, counts, seg, rows, st = res[flag]
+        assert np.array_equal(counts, wcnt) and st == 0
+        assert np.array_equal(seg[: len(values)], wseg) and np.array_equal(rows[: len(values)], wrows)
+        scale = np.abs(Wfull).max() * max(1, max_len) ** 0.5
+        np.testing.assert_allclose(out, want, rtol=1e-5, atol=2e-6 * scale)
+    # a second launch gives the same bits (fixed summation order)
+    monkeypatch.setenv("REC_MS_LANE", "1")
+    out2 = ops.multislot_sumpool(mbatch, T(Wfull)[:, :D], N, 0, 1)[0].cpu().numpy()
+    assert np.array_equal(out2, res["1"][0])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N", [2, 1_000_003, 1_250_000_000, 2 ** 32 + 7, 10 ** 10, 2 ** 62 + 1])
 def test_feasign_rows_device_matches_oracle_at_configs4_sizes(engine_lib, N):
     """uint64 feasign -> row of the hashed table on the device (multiply-high exact modulo), bit-exact against the
