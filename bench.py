@@ -420,7 +420,7 @@ def main():
     in_step = (fwd_b + bwd_b) / t_step_pair / 1e9 if t_step_pair > 0 else 0.0
     if pair_us is not None:
         fwd_s, bwd_s = pair_us[0] * 1e-6, pair_us[1] * 1e-6
-        timing = "%d back-to-back launches per HIP-event pair, median of 3 (agrees with rocprofv3 kernel durations)" % 20
+        timing = "%d back-to-back launches per HIP-event pair, median of 3 (= the back-to-back population of rocprofv3's kernel trace; the in-step launches are roofline.in_step_event)" % 20
     else:       # sharded path: only the in-step brackets exist
         fwd_s, bwd_s = k_ms.get("fm_fwd", 0) * 1e-3, k_ms.get("fm_bwd", 0) * 1e-3
         timing = "in-step HIP-event brackets"
