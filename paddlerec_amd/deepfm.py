@@ -309,6 +309,8 @@ class DeepFMLayer:
         def issue_group():
             if small:
                 return
+            if self.step_count > 3 and os.environ.get("REC_DEEPFM_SKIP_GROUP", "0") == "1":
+                return      # MEASUREMENT ONLY: the step without its grouping sort (stale groups: wrong results)
             with _OnSide(side, cur):
                 self.k.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
                                  self.fm.slot_offset, self.status, groups)

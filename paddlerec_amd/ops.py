@@ -1213,20 +1213,20 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
     n = len(weights)
     g = dy
     head = n > 1 and _head_ok(acts[n - 1], weights[n - 1], dws[n - 1], dbs[n - 1], dy)
-    if head and not defer_all:
+    if head:
         # the one-logit head: dX (with the ReLU mask of the layer in front), dW and db in ONE pass over its input
         g = mlp_head_bwd(acts[n - 1], dy, weights[n - 1], ws, dws[n - 1], dbs[n - 1], relu=True)
         n_run = n - 1
     else:
         n_run = n
     if defer_all:
-        gs = [None] * n
-        for i in reversed(range(n)):
+        gs = [None] * n_run
+        for i in reversed(range(n_run)):
             gs[i] = g
             g = gemm(g, weights[i], ws, trans_b=True, **(dict(epilogue="relu_mask", aux0=acts[i]) if i > 0 else {}))
 
         def finish(num_cus=0):
-            for i in reversed(range(n)):
+            for i in reversed(range(n_run)):
                 gemm(acts[i], gs[i], ws, trans_a=True, out=dws[i], b_colsum=dbs[i], num_cus=num_cus)
         return g, finish
     cur = torch.cuda.current_stream() if dw_stream is not None else None
