@@ -836,6 +836,11 @@ int rec_parse_feasign_slots(const char* buf, size_t len, int32_t first_slot, int
  * multi-GB tables on the device without a host round trip. */
 int rec_fill_uniform(int64_t n, float* buf, float lo, float hi, uint64_t seed, void* stream);
 
+/* Device-to-device copy on `stream` (hipMemcpyAsync).  The host mirrors copy parameter slices with it (the folded
+ * layer-0 weights of DeepFM) so that a training step consists of C-ABI calls only and can be replayed from a recorded
+ * call list (paddlerec_amd/plan.py). */
+int rec_copy_async(void* dst, const void* src, size_t bytes, void* stream);
+
 /* One wave busy-waits `micros` microseconds on `stream`.  Host-side stream probe: HIP maps streams onto a
  * few hardware queues and kernels of two streams that share a queue run strictly one after the other, so a
  * caller that wants its HBM-bound side stream to run underneath the GEMMs of its main stream spins both and

@@ -221,6 +221,7 @@ SIGNATURES = {
                                           C.POINTER(_I64), C.POINTER(_I64)]),
     "rec_fill_uniform": (C.c_int, [_I64, _P, _F, _F, C.c_uint64, _P]),
     "rec_stream_spin": (C.c_int, [_I32, _P]),
+    "rec_copy_async": (C.c_int, [_P, _P, _SZ, _P]),
     "rec_stream_create_cu_range": (C.c_int, [_I32, _I32, C.POINTER(C.c_void_p)]),
     "rec_stream_destroy": (C.c_int, [_P]),
 }

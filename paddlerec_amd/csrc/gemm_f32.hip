@@ -899,6 +899,12 @@ static GemmPlan plan_gemm(const rec_gemm_desc* d, int num_cus = kNumCU) {
     const int64_t a80 = ceil_div64(d->m, 80) * 80 * ceil_div64(d->n, 80) * 80;
     const int64_t a128 = ceil_div64(d->m, 128) * 128 * ceil_div64(d->n, 128) * 128;
     best = a80 * 5 <= a128 * 4 ? CFG_80x80 : CFG_128x128;
+    // few rows AND a short K (the reference's own batch sizes: 512 x 400 x 432): a 128x128 tile gives a wave 64 MFMAs
+    // per k-step and the problem 16 blocks — 47 us on 16 of 256 CUs.  64x80 tiles (20 MFMAs per wave and k-step, 2.5x
+    // the blocks) and a K split fill the chip: ~10 us incl. the reduce (profiles/r03_small_batch.txt)
+    if (!d->trans_a && d->m <= 1024 && d->k <= 4096 && best == CFG_128x128 &&
+        ceil_div64(d->m, 64) * 64 * ceil_div64(d->n, 80) * 80 * 4 <= a128 * 5)
+      best = CFG_64x80;
   } else {
     const int64_t w80 = ceil_div64(d->n, 80) * 80 - d->n, w128 = ceil_div64(d->n, 128) * 128 - d->n;
     const bool tall = d->m >= 8192;
@@ -919,11 +925,15 @@ static GemmPlan plan_gemm(const rec_gemm_desc* d, int num_cus = kNumCU) {
     const int64_t capacity = (int64_t)num_cus * f.occ;
     // a GEMM this small runs for a few microseconds split or not, and a split adds a reduce LAUNCH (4-5 us on the
     // GPU, ~10 us of host time in a launch-bound step: the reference's own batch size of 512 splits every MLP GEMM)
+    // round 3: they split again, with shorter slices — the reduce is issued by this same C call (~3 us of host time,
+    // not a python round trip) and a block that walks 27 dependent k-steps alone on its CU costs ten times that
     const bool tiny = (double)d->m * d->n * d->k < 1.5e8;
-    if (p.tiles_total * 2 <= capacity && !tiny) {
+    static const bool tiny_split = [] { const char* v = getenv("REC_GEMM_TINY_SPLIT"); return !(v && *v == '0'); }();
+    if (p.tiles_total * 2 <= capacity && (!tiny || (tiny_split && nkt >= 8))) {
       // as many splits as still fit in ONE resident round (one block more would double the time)
       int64_t want = capacity / p.tiles_total;
-      if (want > nkt / 8) want = nkt / 8;   // keep >= 8 K-tiles (128 k) per split
+      const int min_kt = tiny ? 4 : 8;      // keep >= 8 K-tiles (128 k) per split; 4 for the launch-bound sizes
+      if (want > nkt / min_kt) want = nkt / min_kt;
       if (want > 512) want = 512;
       if (want >= 8) want -= want % 8;      // multiples of 8: one K-slice per XCD at a time (see the kernel)
       splits = want < 1 ? 1 : (int)want;

@@ -221,6 +221,14 @@ extern "C" int rec_stream_spin(int32_t micros, void* stream) {
   return check_launch("rec_stream_spin");
 }
 
+extern "C" int rec_copy_async(void* dst, const void* src, size_t bytes, void* stream) {
+  REC_REQUIRE(bytes == 0 || (dst && src), REC_EINVAL, "null pointer argument");
+  if (bytes == 0) return REC_OK;
+  REC_REQUIRE(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess, REC_EHIP,
+              "hipMemcpyAsync failed");
+  return REC_OK;
+}
+
 extern "C" int rec_stream_create_cu_range(int32_t cu_begin, int32_t cu_end, void** stream) {
   REC_REQUIRE(stream && cu_begin >= 0 && cu_end > cu_begin && cu_end <= 1024, REC_EINVAL, "bad CU range");
   uint32_t mask[32] = {0};

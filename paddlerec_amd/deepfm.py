@@ -205,6 +205,7 @@ class DeepFMLayer:
         self.status = self.k.new_status(self.device)
         self.step_count = 0
         self._side = None
+        self._plans, self._recording = {}, False      # recorded call lists of launch-bound steps (plan.py)
         self.timers = None      # bench.py: dict name -> list of (start,end) torch.cuda.Event pairs
 
     # -- parameters under the reference's state_dict keys (Appendix C) -------------------------
@@ -241,9 +242,17 @@ class DeepFMLayer:
             return self.mlp_w, self.mlp_dw
         S, D, Dn = self.sparse_num_field, self.sparse_feature_dim, self.dense_feature_dim
         w0 = self.mlp_w[0]
-        self._w0p[: S * D].copy_(w0[: S * D])
+        self._copy(self._w0p[: S * D], w0[: S * D])
         self.k.dense_fold_fwd(S, self.dense.p["fm.dense_w"].view(Dn, D), w0, self._w0p[S * D: S * D + Dn])
         return [self._w0p] + self.mlp_w[1:], [self.mlp_dw[0][: self.fp * D]] + self.mlp_dw[1:]
+
+    def _copy(self, dst, src):
+        """Parameter-slice copy as a C-ABI call where the backend has one (a recorded step must not hide a torch kernel)."""
+        f = getattr(self.k, "copy_f32", None)
+        if f is not None and dst.is_cuda:
+            f(dst, src)
+        else:
+            dst.copy_(src)
 
     def _fold_backward(self):
         """After dW0' = feat'^T dZ0 landed in the first (S+1)*D rows of the layer-0 gradient buffer: turn its
@@ -251,7 +260,7 @@ class DeepFMLayer:
         if not self.compact:
             return
         S, D, Dn = self.sparse_num_field, self.sparse_feature_dim, self.dense_feature_dim
-        self._dm.copy_(self.mlp_dw[0][S * D: S * D + Dn])
+        self._copy(self._dm, self.mlp_dw[0][S * D: S * D + Dn])
         self.k.dense_fold_bwd(S, self.dense.p["fm.dense_w"].view(Dn, D), self.mlp_w[0], self._dm, self.mlp_dw[0],
                               self.dense.g["fm.dense_w"].view(Dn, D), accumulate=True)
 
@@ -275,17 +284,49 @@ class DeepFMLayer:
 
     lazy_mode = True   # False = the dygraph default (every row decays each step, 6*N*(D+1)*4 B of traffic)
 
+    # -- launch-bound batches: the step as a recorded call list (plan.py) ------------------------------------------
+    def _plan_eligible(self, sparse_inputs, dense_inputs, label, auc_stats, allreduce):
+        return (self.device.type == "cuda" and self.k is ops and torch.is_tensor(sparse_inputs)
+                and allreduce is None and self.timers is None and self.lazy_mode and not self._recording
+                and sparse_inputs.numel() <= getattr(self.k, "SMALL_MERGE_MAX", 0)
+                and hasattr(self.k, "sparse_adam_record_small")
+                and os.environ.get("REC_SMALL_MERGE", "1") != "0" and os.environ.get("REC_STEP_PLAN", "1") != "0")
+
+    def _train_step_planned(self, ids, dense_inputs, label, lr, auc_stats):
+        from .plan import CallPlan
+        inputs = [ids, dense_inputs, label]
+        key = (tuple(ids.shape), None if auc_stats is None else (auc_stats[0].data_ptr(), auc_stats[1].data_ptr()))
+        entry = self._plans.get(key)
+        if entry is None:                       # first sight of a signature: plain eager step (sizes its buffers)
+            self._plans[key] = "seen"
+            return None
+        if entry == "seen" or not entry.matches(inputs):
+            plan = CallPlan()
+            self._recording = True
+            try:                                # recorded on ONE stream: nothing to join, nothing torch would issue
+                out = plan.record(lambda: self.train_step(ids, dense_inputs, label, lr, auc_stats), inputs)
+            finally:
+                self._recording = False
+            self._plans[key] = plan
+            return out
+        self.step_count += 1
+        return entry.replay(inputs, self.step_count, float(lr))
+
     def train_step(self, sparse_inputs, dense_inputs, label, lr=1e-3, auc_stats=None,
                    allreduce=None):
         """dygraph_model.py:76-88 train_forward + tools/trainer.py:151-152 backward/step.
         label [B,1] int64.  Returns (loss [1] device tensor, pred [B,1])."""
+        if self._plan_eligible(sparse_inputs, dense_inputs, label, auc_stats, allreduce):
+            out = self._train_step_planned(sparse_inputs, dense_inputs, label, lr, auc_stats)
+            if out is not None:
+                return out
         ids = self._concat_ids(sparse_inputs)
         B, S = ids.shape
         self._ensure_sparse_state()
         self.step_count += 1
         on_gpu = self.device.type == "cuda"
         cur = torch.cuda.current_stream() if on_gpu else None
-        overlap = on_gpu and os.environ.get("REC_DEEPFM_OVERLAP", "1") != "0"
+        overlap = on_gpu and os.environ.get("REC_DEEPFM_OVERLAP", "1") != "0" and not self._recording
         if overlap and self._side is None:
             self._side = self.k.concurrent_stream(self.device)   # verified to overlap with the main stream
         side = self._side if overlap else None
@@ -329,7 +370,7 @@ class DeepFMLayer:
         # dW_i on a third stream beside dX_i (both consume g_i, neither the other): the half-empty last round of
         # blocks of one GEMM is filled by the other — 2.77-2.84 -> 2.70-2.81 ms per step in five A/B pairs on two boxes
         # (profiles/r02f_dw_stream_ab.txt); REC_MLP_DW_STREAM=0 puts them back on one stream
-        if on_gpu and not defer_all and os.environ.get("REC_MLP_DW_STREAM", "1") == "1":
+        if on_gpu and not defer_all and not self._recording and os.environ.get("REC_MLP_DW_STREAM", "1") == "1":
             if getattr(self, "_dw_stream", None) is None:
                 self._dw_stream, self._ws_dw = self.k.concurrent_stream(self.device), self.k.Workspace(self.device)
             kw.update(dw_stream=self._dw_stream, dw_ws=self._ws_dw)

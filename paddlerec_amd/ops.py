@@ -11,7 +11,15 @@ import torch
 
 from . import _lib
 from ._lib import (EPI, AdagradHyper, AdamHyper, CinView, DeepFMDesc, DinDesc, GemmDesc, GemmEpilogueArgs, GradLayout,
-                   GradSrc, LazyInit, MultislotDesc, PsAccessor, PsLayout, RecError, check, lib)
+                   GradSrc, LazyInit, MultislotDesc, PsAccessor, PsLayout, RecError, check)
+
+_recorder = None        # paddlerec_amd.plan.CallPlan while a step is being recorded
+
+
+def lib():
+    """The loaded library — or, while a step is recorded (plan.py), a proxy that also lists every call."""
+    h = _lib.lib()
+    return h if _recorder is None else _recorder.proxy(h)
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -27,7 +35,20 @@ def _stream():
 
 
 def _p(t):
-    return C.c_void_p(0 if t is None else t.data_ptr())
+    p = C.c_void_p(0 if t is None else t.data_ptr())
+    if _recorder is not None and t is not None:
+        _recorder.note_pointer(p, t)
+    return p
+
+
+def copy_f32(dst, src):
+    """dst[...] = src[...] (contiguous f32 device tensors of one size) as a C-ABI call (rec_copy_async)."""
+    _chk(dst, torch.float32, "dst")
+    _chk(src, torch.float32, "src")
+    if dst.numel() != src.numel():
+        raise RecError("copy_f32: %d != %d elements" % (dst.numel(), src.numel()))
+    check(lib().rec_copy_async(_p(dst), _p(src), C.c_size_t(dst.numel() * 4), _stream()), "rec_copy_async")
+    return dst
 
 
 def _chk(t, dtype, name, shape=None):
@@ -1139,6 +1160,8 @@ def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux
     pv = lambda t: None if t is None else t.data_ptr()
     x = GemmEpilogueArgs(pv(bias), pv(aux0), ld0, pv(aux1), ld1, pv(row_scale), rs_stride, pv(out2),
                          ld2, pv(b_colsum))
+    if _recorder is not None:      # a recorded step holds these addresses too
+        _recorder.keep.extend(t for t in (bias, aux0, aux1, row_scale, out2, b_colsum) if t is not None)
     key = (M, N, K, lda, ldb, ldc, d.trans_a, d.trans_b, d.epilogue, d.split_k)
     need = _gemm_ws_cache.get(key)
     if need is None:       # a pure function of the descriptor: one C call per distinct GEMM, not per launch

@@ -1,0 +1,89 @@
+"""Recorded call list of a launch-bound training step.
+
+At the reference's own batch sizes (deepfm / dcn_v2 `config_bigdata.yaml`: 512, din: 32) a train step is ~40 C-ABI calls
+of a few microseconds of GPU work each, and ~9 us of python + ctypes argument marshalling per call set the step time
+(DeepFM B 512: 0.35 ms of host time for 0.25 ms of GPU time, profiles/r03_small_batch.txt).  In the steady state those
+calls are IDENTICAL from step to step — same functions, same buffers, same sizes — except for the input pointers and
+Adam's step count.  `CallPlan` records them once (every `lib().rec_*` call an `ops` wrapper makes, with the ctypes
+argument objects it built) and replays the list: `fn(*args)` per call, the input pointers and the `rec_adam_hyper`
+structs patched in place.  This is the host half of what one "issue the whole step" C entry point would do, without
+stating the step's orchestration a second time in C++; a hipGraph of the same step replays no faster than the eager
+step on this ROCm, because the GPU-side cost per dependent kernel is what it is — the plan only
+removes the host's share.
+
+Rules for a recorded step (the mirrors obey them in their small-batch path): C-ABI calls only (a torch kernel would not
+be replayed — tests compare planned and eager steps bit for bit over several steps), one stream, no host read-back, no
+python control flow on device values; every tensor a call touches is kept alive by the plan."""
+import ctypes as C
+
+from . import _lib, ops
+
+_HOST_ONLY = ("rec_last_error", "rec_gemm_plan_splits", "rec_din_saves_act1", "rec_comm_available")
+
+
+class CallPlan:
+    def __init__(self):
+        self.calls = []          # (function, args tuple)
+        self.keep = []           # tensors whose addresses the calls hold
+        self.pointers = []       # (c_void_p object, address at record time)
+        self.hypers = []         # rec_adam_hyper structs passed by reference
+        self.input_slots = []    # (c_void_p object, input index)
+        self.stream = None
+        self.outputs = None
+
+    # -- recording ---------------------------------------------------------------------------------
+    def note_pointer(self, p, t):
+        self.keep.append(t)
+        self.pointers.append((p, t.data_ptr()))
+
+    def proxy(self, h):
+        plan = self
+
+        class _Proxy:
+            def __getattr__(self, name):
+                fn = getattr(h, name)
+                if name.endswith("_bytes") or name in _HOST_ONLY:      # host-side size queries: not part of the step
+                    return fn
+
+                def call(*args):
+                    plan.calls.append((fn, args))
+                    for a in args:
+                        obj = getattr(a, "_obj", None)                 # C.byref(struct)
+                        if isinstance(obj, _lib.AdamHyper):
+                            plan.hypers.append(obj)
+                    return fn(*args)
+                return call
+        return _Proxy()
+
+    def record(self, fn, inputs):
+        """Run fn() with every C-ABI call listed; inputs: the tensors whose pointers change from step to step."""
+        if ops._recorder is not None:
+            raise ops.RecError("a step is already being recorded")
+        self.stream = ops._stream().value
+        ops._recorder = self
+        try:
+            self.outputs = fn()
+        finally:
+            ops._recorder = None
+        addr = {t.data_ptr(): i for i, t in enumerate(inputs)}
+        self.input_slots = [(p, addr[a]) for p, a in self.pointers if a in addr]
+        self.input_sig = [(tuple(t.shape), t.dtype, t.stride()) for t in inputs]
+        self.pointers = None
+        return self.outputs
+
+    # -- replay ------------------------------------------------------------------------------------
+    def matches(self, inputs):
+        return (ops._stream().value == self.stream and
+                [(tuple(t.shape), t.dtype, t.stride()) for t in inputs] == self.input_sig)
+
+    def replay(self, inputs, step, lr):
+        for p, i in self.input_slots:
+            p.value = inputs[i].data_ptr()
+        for h in self.hypers:
+            h.step = step
+            h.lr = lr
+        for fn, args in self.calls:
+            rc = fn(*args)
+            if rc:
+                _lib.check(rc, "replayed call")
+        return self.outputs

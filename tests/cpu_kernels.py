@@ -368,6 +368,10 @@ def mlp_forward(x, weights, biases, ws, relu_last=False, out_last=None):
     return x, acts + [x]
 
 
+def copy_f32(dst, src):
+    return dst.copy_(src)
+
+
 def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=False, dw_stream=None, dw_ws=None):
     if defer_first or defer_all:
         return mlp_backward(dy, acts, weights, dws, dbs, ws), (lambda: None)

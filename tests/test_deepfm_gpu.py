@@ -691,3 +691,35 @@ def test_small_merge_step_equals_sorted_merge_step(ops, monkeypatch, zipf, table
         assert_close_scaled(N_(a.sparse_state["mv"]), N_(b.sparse_state["mv"]))
         assert_close_scaled(N_(a.dense.m), N_(b.dense.m))
     assert int(a.status.item()) == 0 and int(b.status.item()) == 0
+
+
+@pytest.mark.gpu
+def test_planned_step_equals_eager_step(engine_lib, monkeypatch):
+    """Launch-bound batches: the step replayed from its recorded call list (paddlerec_amd/plan.py) leaves the SAME bits
+    in every parameter, moment, loss and prediction as the eager step — over several steps with fresh inputs each (a
+    torch kernel hidden in the step, a stale pointer or a frozen Adam step count would all show)."""
+    from paddlerec_amd.deepfm import DeepFMLayer
+    B, N, D = 96, 5000, 16
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("REC_STEP_PLAN", mode)
+        torch.manual_seed(3)
+        m = DeepFMLayer(N, D, 13, 26, [64, 32], device=DEV)
+        auc = (torch.zeros(4096, dtype=torch.int64, device=DEV), torch.zeros(4096, dtype=torch.int64, device=DEV))
+        g = torch.Generator(device=DEV).manual_seed(11)
+        outs = []
+        for step in range(6):
+            ids = torch.randint(0, N, (B, 26), device=DEV, generator=g)
+            dense = torch.rand(B, 13, device=DEV, generator=g)
+            label = (torch.rand(B, 1, device=DEV, generator=g) < 0.3).to(torch.int64)
+            loss, pred = m.train_step(ids, dense, label, lr=1e-2 * (1 + step), auc_stats=auc)
+            outs.append((loss.cpu().numpy().copy(), pred.cpu().numpy().copy()))
+        runs[mode] = (outs, m.fm.rec.cpu().numpy(), m.sparse_state["mv"].cpu().numpy(), m.dense.data.cpu().numpy(),
+                      m.dense.m.cpu().numpy(), m.dense.v.cpu().numpy(), auc[0].cpu().numpy(), auc[1].cpu().numpy(),
+                      m.step_count, len(m._plans))
+    a, b = runs["1"], runs["0"]
+    assert a[-1] == 1 and b[-1] == 0 and a[-2] == b[-2] == 6          # the planned run really recorded a plan
+    for (la, pa), (lb, pb) in zip(a[0], b[0]):
+        assert np.array_equal(la, lb) and np.array_equal(pa, pb)
+    for x, y in zip(a[1:8], b[1:8]):
+        assert np.array_equal(x, y)
