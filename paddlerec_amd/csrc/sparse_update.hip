@@ -683,29 +683,38 @@ __global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_kernel(
   extern __shared__ int small_lds[];
   int* wlists = small_lds;                               // [waves][kSmallList] positions of collected occurrences
   int* small_ids = small_lds + kSmallWaves * kSmallList; // [n] rows as int32, -1 = padding / out of range (never matches)
-  int oob = 0;
+  int oob = 0, viol = 0;
   for (int i = threadIdx.x; i < n; i += kSmallWaves * kWave) {
     const int64_t id = ids[i];
     const bool isp = pad >= 0 && id == pad;
-    const int64_t r = slot_off ? id + slot_off[i % S] : id;     // 26 tables as one: row = id + slot offset
+    const int s = slot_off ? i % S : 0;
+    const int64_t r = slot_off ? id + slot_off[s] : id;     // 26 tables as one: row = id + slot offset
     const bool inr = r >= 0 && r < N;
     oob |= (!isp && !inr) ? 1 : 0;
+    // slots whose ids stay inside their own span of rows cannot share a row with another slot
+    if (slot_off && (id < 0 || (s + 1 < S && id >= slot_off[s + 1] - slot_off[s]))) viol = 1;
     small_ids[i] = (!isp && inr) ? (int)r : -1;
   }
   if (oob) atomicOr(status, REC_FLAG_INDEX_OOB);
-  __syncthreads();
+  // every block stages ALL ids, so every block takes the same decision: when no id leaves its slot's span, a lookup is
+  // compared with the lookups of ITS slot only (n / S of them: 512 instead of 13312 at the reference's batch size)
+  const bool by_slot = slot_off != nullptr && S > 1 && n % S == 0 && __syncthreads_or(viol) == 0;
+  if (!(slot_off != nullptr && S > 1 && n % S == 0)) __syncthreads();
   const int lane = threadIdx.x % kWave;
   const int pos = blockIdx.x * kSmallWaves + threadIdx.x / kWave;
   if (pos >= n) return;
   const int my = small_ids[pos];
   if (my < 0) return;
+  // logical index t of the list this lookup is compared with -> position in the id list
+  const int ts = by_slot ? S : 1, t0 = by_slot ? pos % S : 0;
+  const int tpos = by_slot ? pos / S : pos, tn = by_slot ? n / S : n;
   // an earlier occurrence owns the row (four 64-id chunks per trip: the LDS reads of a trip are in flight together)
-  for (int c0 = 0; c0 < pos; c0 += 4 * kWave) {
+  for (int c0 = 0; c0 < tpos; c0 += 4 * kWave) {
     bool hit = false;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = c0 + u * kWave + lane;
-      hit |= j < pos && small_ids[j] == my;
+      hit |= j < tpos && small_ids[t0 + j * ts] == my;
     }
     if (__ballot(hit) != 0) return;
   }
@@ -752,12 +761,12 @@ __global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_kernel(
   };
   // (four chunks per trip, like the search above: most rows have no second occurrence, and a trip without a match
   // is four LDS reads in flight, one ballot)
-  for (int c0 = (pos / kWave) * kWave; c0 < n; c0 += 4 * kWave) {
+  for (int c0 = (tpos / kWave) * kWave; c0 < tn; c0 += 4 * kWave) {
     bool mk[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = c0 + u * kWave + lane;
-      mk[u] = j >= pos && j < n && small_ids[j] == my;
+      mk[u] = j >= tpos && j < tn && small_ids[t0 + (j < tn ? j : 0) * ts] == my;
     }
     if (__ballot(mk[0] || mk[1] || mk[2] || mk[3]) == 0) continue;
 #pragma unroll
@@ -768,7 +777,7 @@ __global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_kernel(
       while (m) {
         const int rank = __popcll(m & ((1ull << lane) - 1ull));
         const int take = min((int)__popcll(m), FLY - cnt);
-        if (mine && rank < take) wl[cnt + rank] = j;
+        if (mine && rank < take) wl[cnt + rank] = t0 + j * ts;
         cnt += take;
         mine = mine && rank >= take;
         m = __ballot(mine);

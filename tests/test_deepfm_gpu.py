@@ -694,6 +694,36 @@ def test_small_merge_step_equals_sorted_merge_step(ops, monkeypatch, zipf, table
 
 
 @pytest.mark.gpu
+def test_small_merge_with_ids_outside_their_slot_span(ops, monkeypatch):
+    """The one-launch merge compares a lookup with the lookups of its own slot only — unless some id leaves its slot's
+    span of rows, where rows of different slots can coincide: slot offsets 100 apart, ids up to 300, so most rows are hit
+    from three slots.  Must equal the sort-based merge bit for bit (both add a row's gradients in ascending position)."""
+    from paddlerec_amd.deepfm import DeepFMLayer
+    B, D, S, fc = 320, 16, 26, [32, 16]
+    so = torch.arange(S, dtype=torch.int64) * 100
+    N = int(so[-1]) + 300
+    torch.manual_seed(5)
+    a = DeepFMLayer(N, D, 13, S, fc, device=DEV, slot_offset=so)
+    b = DeepFMLayer(N, D, 13, S, fc, device=DEV, slot_offset=so)
+    b.fm.rec.copy_(a.fm.rec)
+    b.dense.data.copy_(a.dense.data)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    for step in range(3):
+        ids = torch.randint(0, 300, (B, S), device=DEV, generator=g)
+        dense = torch.rand(B, 13, device=DEV, generator=g)
+        label = (torch.rand(B, 1, device=DEV, generator=g) < 0.3).to(torch.int64)
+        monkeypatch.setenv("REC_SMALL_MERGE", "1")
+        monkeypatch.setenv("REC_STEP_PLAN", "0")
+        la, _ = a.train_step(ids, dense, label, lr=1e-2)
+        monkeypatch.setenv("REC_SMALL_MERGE", "0")
+        lb, _ = b.train_step(ids, dense, label, lr=1e-2)
+        assert torch.equal(la, lb)
+    assert torch.equal(a.fm.rec, b.fm.rec) and torch.equal(a.sparse_state["mv"], b.sparse_state["mv"])
+    assert torch.equal(a.dense.data, b.dense.data)
+    assert int(a.status.item()) == 0 and int(b.status.item()) == 0
+
+
+@pytest.mark.gpu
 def test_planned_step_equals_eager_step(engine_lib, monkeypatch):
     """Launch-bound batches: the step replayed from its recorded call list (paddlerec_amd/plan.py) leaves the SAME bits
     in every parameter, moment, loss and prediction as the eager step — over several steps with fresh inputs each (a
