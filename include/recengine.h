@@ -405,6 +405,18 @@ int rec_sgd_dense(int64_t n, float* p, const float* g, float lr, void* stream);
 int rec_sparse_sgd_small(int64_t n, int32_t emb_dim, int32_t row_stride, int64_t num_rows, int64_t padding_idx,
                          const int64_t* ids, const float* grad, const rec_grad_layout* grad_layout, float* P,
                          float lr, int32_t* status, void* stream);
+/* The same for up to 8 tables in ONE launch (DIN updates seven embedding tables per step, din/dygraph_model.py:64-73:
+ * independent of each other, so their merges share the chip instead of running one after the other). */
+typedef struct {
+  int64_t n;              /* lookups of this table (<= 15360) */
+  int32_t emb_dim, row_stride;
+  int64_t num_rows, padding_idx;
+  const int64_t* ids;     /* [n] rows */
+  const float* grad;
+  rec_grad_layout grad_layout;
+  float* P;
+} rec_small_sgd_job;
+int rec_sparse_sgd_small_multi(int32_t count, const rec_small_sgd_job* jobs, float lr, int32_t* status, void* stream);
 /* The same one-launch merge with the lazy Adam update of BOTH embeddings of a DeepFM record (the arithmetic of
  * rec_sparse_adam_record: W, m, v and W1, m1, v1 of a touched row in one pass) — the reference's bigdata batch size
  * (deepfm/config_bigdata.yaml: 512 x 26 slots = 13312 lookups) replaces grouping sort + two partial passes + record

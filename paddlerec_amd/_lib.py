@@ -36,6 +36,12 @@ class GradLayout(C.Structure):
                 ("partials", C.c_void_p), ("index", C.c_void_p)]
 
 
+class SmallSgdJob(C.Structure):
+    _fields_ = [("n", C.c_int64), ("emb_dim", C.c_int32), ("row_stride", C.c_int32), ("num_rows", C.c_int64),
+                ("padding_idx", C.c_int64), ("ids", C.c_void_p), ("grad", C.c_void_p), ("grad_layout", GradLayout),
+                ("P", C.c_void_p)]
+
+
 class CinView(C.Structure):
     _fields_ = [("stride_b", C.c_int64), ("stride_j", C.c_int32), ("stride_d", C.c_int32)]
 
@@ -174,6 +180,7 @@ SIGNATURES = {
     "rec_crossnet_mix_layer_bwd": (C.c_int, [C.POINTER(CrossMixDesc)] + [_P] * 11 + [_I32, _P, _I32, _I32, _I32, _P, _I32]
                                    + [_P] * 6 + [_I32, _P, _SZ, _P]),
     "rec_sparse_sgd_small": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, C.POINTER(GradLayout), _P, _F, _P, _P]),
+    "rec_sparse_sgd_small_multi": (C.c_int, [_I32, C.POINTER(SmallSgdJob), _F, _P, _P]),
     "rec_sparse_adam_record_small": (C.c_int, [_I64, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _P, _P, _P, C.POINTER(GradLayout),
                                                _P, C.POINTER(GradLayout), _P, _P, _P, C.POINTER(AdamHyper), _P, _P]),
     "rec_bce_with_logits": (C.c_int, [_I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),

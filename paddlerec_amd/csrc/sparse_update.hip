@@ -674,8 +674,8 @@ struct SmallAdamRecord {
 };
 
 template <int NACC, class Update>   // floats per lane: D <= 64 * NACC
-__global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_kernel(
-    int n, int D, int S, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
+__device__ __forceinline__ void sparse_small_body(
+    int blk, int n, int D, int S, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
     const int64_t* __restrict__ slot_off, const float* __restrict__ grad, rec_grad_layout gl, Update up,
     int32_t* __restrict__ status) {
   constexpr bool kRecord = std::is_same<Update, SmallAdamRecord>::value;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_kernel(
   const bool by_slot = slot_off != nullptr && S > 1 && n % S == 0 && __syncthreads_or(viol) == 0;
   if (!(slot_off != nullptr && S > 1 && n % S == 0)) __syncthreads();
   const int lane = threadIdx.x % kWave;
-  const int pos = blockIdx.x * kSmallWaves + threadIdx.x / kWave;
+  const int pos = blk * kSmallWaves + threadIdx.x / kWave;
   if (pos >= n) return;
   const int my = small_ids[pos];
   if (my < 0) return;
@@ -814,6 +814,42 @@ __global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_kernel(
       r[D] = p1; r[D + 1] = m1; r[D + 2] = v1;
     }
   }
+}
+
+template <int NACC, class Update>
+__global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_kernel(
+    int n, int D, int S, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
+    const int64_t* __restrict__ slot_off, const float* __restrict__ grad, rec_grad_layout gl, Update up,
+    int32_t* __restrict__ status) {
+  sparse_small_body<NACC, Update>(blockIdx.x, n, D, S, N, pad, ids, slot_off, grad, gl, up, status);
+}
+
+// Several tables in ONE launch: DIN updates seven embedding tables per step (din/dygraph_model.py:64-73), independent of
+// each other; as seven launches on one stream they run one after the other, two of them 50 us long (the target tables:
+// one row per sample hit by all its ~150 history positions) — 150 of the 440 us of a batch-32 step.  A block finds its
+// table from the block ranges; the tables then share the chip.
+constexpr int kSmallJobsMax = 8;
+struct SmallJob {
+  int n, D, block0;
+  int64_t N, pad;
+  const int64_t* ids;
+  const float* grad;
+  rec_grad_layout gl;
+  SmallSgd up;
+};
+struct SmallJobs {
+  int count;
+  SmallJob j[kSmallJobsMax];
+};
+template <int NACC>
+__global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_multi_kernel(SmallJobs jobs, int32_t* __restrict__ status) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < kSmallJobsMax; ++i)
+    if (i < jobs.count && (int)blockIdx.x >= jobs.j[i].block0) k = i;
+  const SmallJob& jb = jobs.j[k];
+  sparse_small_body<NACC, SmallSgd>((int)blockIdx.x - jb.block0, jb.n, jb.D, 1, jb.N, jb.pad, jb.ids, nullptr, jb.grad, jb.gl,
+                                    jb.up, status);
 }
 
 // sum over the merged rows of |g_row|^2 (global-norm clipping needs the norm of the MERGED sparse grad)
@@ -1287,6 +1323,43 @@ extern "C" int rec_sparse_sgd_small(int64_t n, int32_t emb_dim, int32_t row_stri
   if (emb_dim <= kWave) REC_SMALL(1); else if (emb_dim <= 2 * kWave) REC_SMALL(2); else REC_SMALL(4);
 #undef REC_SMALL
   return check_launch("rec_sparse_sgd_small");
+}
+
+extern "C" int rec_sparse_sgd_small_multi(int32_t count, const rec_small_sgd_job* jobs, float lr, int32_t* status,
+                                          void* stream) {
+  REC_REQUIRE(count >= 0 && count <= kSmallJobsMax && (count == 0 || jobs) && status, REC_EINVAL,
+              "bad arguments (at most %d tables per call)", kSmallJobsMax);
+  SmallJobs js;
+  js.count = 0;
+  int blocks = 0, dmax = 0;
+  size_t nmax = 0;
+  for (int i = 0; i < count; ++i) {
+    const rec_small_sgd_job& a = jobs[i];
+    REC_REQUIRE(a.n >= 0 && a.emb_dim > 0 && a.row_stride >= a.emb_dim && a.num_rows > 0 && a.grad_layout.div >= 1,
+                REC_EINVAL, "job %d: bad sizes", i);
+    REC_REQUIRE(a.n <= kSmallMergeMax, REC_ESHAPE, "job %d: n %lld > %d", i, (long long)a.n, kSmallMergeMax);
+    REC_REQUIRE(a.emb_dim <= 4 * kWave && a.num_rows < (1ll << 31), REC_ESHAPE, "job %d: shape unsupported", i);
+    REC_REQUIRE(a.grad_layout.group <= 0 || a.grad_layout.group_stride >= (int64_t)a.grad_layout.group * a.emb_dim,
+                REC_EINVAL, "job %d: grad group_stride too small", i);
+    if (a.n == 0) continue;
+    REC_REQUIRE(a.ids && a.grad && a.P, REC_EINVAL, "job %d: null pointer argument", i);
+    SmallJob& j = js.j[js.count++];
+    j.n = (int)a.n; j.D = a.emb_dim; j.block0 = blocks; j.N = a.num_rows; j.pad = a.padding_idx;
+    j.ids = a.ids; j.grad = a.grad; j.gl = a.grad_layout; j.gl.partials = nullptr;
+    j.up = SmallSgd{a.P, a.row_stride, lr};
+    blocks += (int)((a.n + kSmallWaves - 1) / kSmallWaves);
+    dmax = a.emb_dim > dmax ? a.emb_dim : dmax;
+    nmax = (size_t)a.n > nmax ? (size_t)a.n : nmax;
+  }
+  if (js.count == 0) return REC_OK;
+  const size_t shmem = (nmax + kSmallWaves * kSmallList) * sizeof(int);
+  hipStream_t st = (hipStream_t)stream;
+#define REC_SMALLM(NACC_)                                                                                       \
+  hipLaunchKernelGGL((sparse_small_multi_kernel<NACC_>), dim3((unsigned)blocks), dim3(kSmallWaves * kWave), shmem, st, \
+                     js, status)
+  if (dmax <= kWave) REC_SMALLM(1); else if (dmax <= 2 * kWave) REC_SMALLM(2); else REC_SMALLM(4);
+#undef REC_SMALLM
+  return check_launch("rec_sparse_sgd_small_multi");
 }
 
 extern "C" int rec_sparse_adam_record_small(int64_t n, int32_t num_slots, int32_t emb_dim, int32_t rec_stride,

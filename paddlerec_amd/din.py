@@ -12,11 +12,14 @@ merge-fused rec_sparse_sgd_rows (rows with zero gradient do not move under SGD, 
 update Paddle performs for is_sparse=False).  As in the reference's dygraph mode the attention MLP is
 not optimised (App. B-9).
 """
+import collections
 import math
+import os
 
 import torch
 
 from . import ops
+from . import ops as _ops
 
 
 def _xavier_uniform_(t, fan_in, fan_out):
@@ -81,6 +84,7 @@ class DINLayer:
         self._att_saved = {}     # what the attention-pool forward keeps for its backward (buffers reused per step)
         self._bufs = None        # the eager train step's reusable buffers (_StepBuffers)
         self._graph = None       # StepGraph of train_step_graphed
+        self._plans, self._recording = collections.OrderedDict(), False    # recorded call lists (plan.py), per signature
         self.step_count = 0
 
     def state_dict(self):
@@ -91,6 +95,7 @@ class DINLayer:
             self.params[k].copy_(torch.as_tensor(v).to(self.device).reshape(self.params[k].shape))
 
     def set_attention(self, weights, biases):
+        self._plans.clear()          # a recorded step holds the address of the transposed copy of the old weights
         for dst, src in zip(self.attention_w + self.attention_b, list(weights) + list(biases)):
             dst.copy_(torch.as_tensor(src).to(self.device).reshape(dst.shape))
 
@@ -159,8 +164,33 @@ class DINLayer:
             self._bufs = _StepBuffers(self.k, self.device)
         lr = self.learning_rate(self.step_count, base_lr)
         self.step_count += 1
-        return self._step(self._bufs, hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask,
-                          target_item_seq, target_cat_seq, lr=lr)
+        inputs = [hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq, target_cat_seq]
+        run = lambda: self._step(self._bufs, *inputs, lr=lr)
+        # the shipped batch size (32 x ~150 positions) is launch-bound: from the third step of an input signature on the
+        # step is replayed from its recorded C-ABI call list (plan.py; bit-identical, tests/test_din_gpu.py)
+        small = getattr(self.k, "SMALL_MERGE_MAX", 0)
+        if (self.device.type == "cuda" and self.k is _ops and not self._recording and hist_item_seq.numel() <= small
+                and os.environ.get("REC_STEP_PLAN", "1") != "0"):
+            from .plan import CallPlan
+            key = (tuple(hist_item_seq.shape), float(lr))
+            entry = self._plans.get(key)
+            if entry is None:
+                self._plans[key] = "seen"
+                if len(self._plans) > 32:
+                    self._plans.popitem(last=False)
+            elif entry == "seen" or not entry.matches(inputs):
+                plan = CallPlan()
+                self._recording = True
+                try:
+                    out = plan.record(run, inputs)
+                finally:
+                    self._recording = False
+                self._plans[key] = plan
+                return out
+            else:
+                self._plans.move_to_end(key)
+                return entry.replay(inputs, 0, float(lr))
+        return run()
 
     def train_step_graphed(self, hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq,
                            target_cat_seq, base_lr=0.85):
@@ -210,13 +240,22 @@ class DINLayer:
             self.attention_w, self.attention_b, sv["attw"], dpooled, saved=bufs.att_saved)
         self._last = dict(dh=dh, dq=dq, de0=de0, dz=dz, dense=g)
         # ---- SGD (dygraph_model.py:64-73).  Embedding tables: merged rows; dense: in place.
-        self._sgd_rows(bufs, hist_item_seq, dh, p["hist_item_emb_attr.weight"], lr, E)
-        self._sgd_rows(bufs, hist_cat_seq, dh[:, :, Ei:], p["hist_cat_emb_attr.weight"], lr, E)
-        self._sgd_rows(bufs, target_item_seq, dq, p["target_item_seq_emb_attr.weight"], lr, E)
-        self._sgd_rows(bufs, target_cat_seq, dq[:, :, Ei:], p["target_cat_seq_emb_attr.weight"], lr, E)
-        self._sgd_rows(bufs, sv["ti"], de0[:, E:], p["target_item_emb_attr.weight"], lr, 2 * E)
-        self._sgd_rows(bufs, sv["tc"], de0[:, E + Ei:], p["target_cat_emb_attr.weight"], lr, 2 * E)
-        self._sgd_rows(bufs, sv["ti"], dz, p["item_b_attr.weight"], lr, 1)
+        jobs = [(hist_item_seq, dh, p["hist_item_emb_attr.weight"], E),
+                (hist_cat_seq, dh[:, :, Ei:], p["hist_cat_emb_attr.weight"], E),
+                (target_item_seq, dq, p["target_item_seq_emb_attr.weight"], E),
+                (target_cat_seq, dq[:, :, Ei:], p["target_cat_seq_emb_attr.weight"], E),
+                (sv["ti"], de0[:, E:], p["target_item_emb_attr.weight"], 2 * E),
+                (sv["tc"], de0[:, E + Ei:], p["target_cat_emb_attr.weight"], 2 * E),
+                (sv["ti"], dz, p["item_b_attr.weight"], 1)]
+        small = getattr(self.k, "SMALL_MERGE_MAX", 0)
+        if (hasattr(self.k, "sparse_sgd_small_multi") and os.environ.get("REC_SMALL_MULTI", "1") != "0"
+                and all(ids.numel() <= small and tab.shape[1] <= 256 for ids, _, tab, _ in jobs)):
+            # the shipped batch size: the seven independent merges share ONE launch (rec_sparse_sgd_small_multi)
+            self.k.sparse_sgd_small_multi([(ids.reshape(-1), gv, tab, 1, rs) for ids, gv, tab, rs in jobs], lr,
+                                          self.status)
+        else:
+            for ids, gv, tab, rs in jobs:
+                self._sgd_rows(bufs, ids, gv, tab, lr, rs)
         self.k.sgd_dense(self._dense, self._dense_grad, lr)      # all four Linear layers (every gradient was written above)
         return loss, pred
 

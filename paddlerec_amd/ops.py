@@ -41,6 +41,21 @@ def _p(t):
     return p
 
 
+_T_CACHE = {}
+
+
+def _transposed(w):
+    """w.t().contiguous(), kept while THIS tensor object is unchanged (the attention MLP is frozen in DIN's dygraph
+    mode: one transpose per set_attention instead of one torch kernel per step)."""
+    import weakref
+    hit = _T_CACHE.get(id(w))
+    if hit is None or hit[0]() is not w or hit[1] != w._version:
+        if len(_T_CACHE) > 64:
+            _T_CACHE.clear()
+        hit = _T_CACHE[id(w)] = (weakref.ref(w), w._version, w.t().contiguous())
+    return hit[2]
+
+
 def copy_f32(dst, src):
     """dst[...] = src[...] (contiguous f32 device tensors of one size) as a C-ABI call (rec_copy_async)."""
     _chk(dst, torch.float32, "dst")
@@ -696,7 +711,7 @@ def din_attention_pool_bwd(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_his
     E, H1, H2 = Ei + Ec, att_w[0].shape[1], att_w[1].shape[1]
     _chk(att_weight, torch.float32, "att_weight", (B, T))
     _chk(d_out, torch.float32, "d_out", (B, E))
-    w1t = att_w[0].t().contiguous()
+    w1t = _transposed(att_w[0])
     dev = hist_item.device
     dh = torch.empty(B, T, E, dtype=torch.float32, device=dev)
     dq = torch.empty(B, T, E, dtype=torch.float32, device=dev)
@@ -905,6 +920,24 @@ def sparse_sgd_small(ids, grad, P, lr, padding_idx=None, status=None, grad_div=1
     check(lib().rec_sparse_sgd_small(ids.numel(), D, stride, P.shape[0], -1 if padding_idx is None else padding_idx,
                                      _p(ids), _p(grad), C.byref(_gl(grad_div, grad_group, grad_group_stride)), _p(P),
                                      float(lr), _p(status), _stream()), "rec_sparse_sgd_small")
+    return status
+
+
+def sparse_sgd_small_multi(jobs, lr, status):
+    """Up to 8 sparse_sgd_small jobs in ONE launch: jobs = [(ids, grad, P, grad_group, grad_group_stride), ...] (tables
+    independent of each other: rec_sparse_sgd_small_multi)."""
+    arr = (_lib.SmallSgdJob * len(jobs))()
+    for a, (ids, grad, P, group, gstride) in zip(arr, jobs):
+        _chk(ids, torch.int64, "ids")
+        D, stride = _chk_table(P, "P")
+        a.n, a.emb_dim, a.row_stride, a.num_rows, a.padding_idx = ids.numel(), D, stride, P.shape[0], -1
+        a.ids, a.grad, a.P = ids.data_ptr(), grad.data_ptr(), P.data_ptr()
+        a.grad_layout = _gl(1, group, gstride)
+        if _recorder is not None:
+            _recorder.note_field(a, "ids", ids)
+            _recorder.keep.extend((ids, grad, P))
+    check(lib().rec_sparse_sgd_small_multi(len(jobs), arr, float(lr), _p(status), _stream()),
+          "rec_sparse_sgd_small_multi")
     return status
 
 

@@ -28,6 +28,8 @@ class CallPlan:
         self.pointers = []       # (c_void_p object, address at record time)
         self.hypers = []         # rec_adam_hyper structs passed by reference
         self.input_slots = []    # (c_void_p object, input index)
+        self.fields = []         # (struct, field name, address at record time): pointers inside descriptor arrays
+        self.field_slots = []    # (struct, field name, input index)
         self.stream = None
         self.outputs = None
 
@@ -35,6 +37,10 @@ class CallPlan:
     def note_pointer(self, p, t):
         self.keep.append(t)
         self.pointers.append((p, t.data_ptr()))
+
+    def note_field(self, obj, field, t):
+        self.keep.append(t)
+        self.fields.append((obj, field, t.data_ptr()))
 
     def proxy(self, h):
         plan = self
@@ -67,6 +73,8 @@ class CallPlan:
             ops._recorder = None
         addr = {t.data_ptr(): i for i, t in enumerate(inputs)}
         self.input_slots = [(p, addr[a]) for p, a in self.pointers if a in addr]
+        self.field_slots = [(o, f, addr[a]) for o, f, a in self.fields if a in addr]
+        self.fields = None
         self.input_sig = [(tuple(t.shape), t.dtype, t.stride()) for t in inputs]
         self.pointers = None
         return self.outputs
@@ -79,6 +87,8 @@ class CallPlan:
     def replay(self, inputs, step, lr):
         for p, i in self.input_slots:
             p.value = inputs[i].data_ptr()
+        for o, f, i in self.field_slots:
+            setattr(o, f, inputs[i].data_ptr())
         for h in self.hypers:
             h.step = step
             h.lr = lr

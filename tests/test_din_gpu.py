@@ -229,6 +229,33 @@ def test_din_train_step_graphed_equals_eager(engine_lib):
     assert int(a.status.item()) == 0 and int(b.status.item()) == 0
 
 
+def test_din_planned_step_equals_eager(engine_lib, monkeypatch):
+    """train_step replays a launch-bound step from its recorded C-ABI call list (paddlerec_amd/plan.py) from the third
+    sight of an input signature on: with two padded lengths, every loss, prediction and parameter is bit-identical to a
+    layer that never plans (REC_STEP_PLAN=0)."""
+    from paddlerec_amd.din import DINLayer
+    from paddlerec_amd.plan import CallPlan
+    rng = np.random.default_rng(22)
+    ni, nc, B = 150, 30, 32
+    a = DINLayer(64, 64, "sigmoid", False, True, ni, nc, device=DEV)
+    b = DINLayer(64, 64, "sigmoid", False, True, ni, nc, device=DEV)
+    b.set_dict({k: v.clone() for k, v in a.state_dict().items()})
+    b.set_attention([w.clone() for w in a.attention_w], [x.clone() for x in a.attention_b])
+    for Tn in (40, 24, 40, 40, 24, 40, 24, 24, 40):
+        hi, hc, ti, tc, mask, label = _din_problem(rng, B, Tn, ni, nc)
+        tis, tcs = np.repeat(ti[:, None], Tn, 1), np.repeat(tc[:, None], Tn, 1)
+        bt = [T(x) for x in (hi, hc, ti, tc, label, mask, tis, tcs)]
+        monkeypatch.setenv("REC_STEP_PLAN", "0")
+        la, pa = a.train_step(*bt, base_lr=0.5)
+        monkeypatch.setenv("REC_STEP_PLAN", "1")
+        lb, pb = b.train_step(*bt, base_lr=0.5)
+        assert torch.equal(la, lb) and torch.equal(pa, pb)
+    assert not a._plans and len(b._plans) == 2 and all(isinstance(p, CallPlan) for p in b._plans.values())
+    for k, v in a.state_dict().items():
+        assert torch.equal(v, b.state_dict()[k]), k
+    assert int(a.status.item()) == 0 and int(b.status.item()) == 0
+
+
 @pytest.mark.parametrize("n,D,N,hot", [(4864, 128, 63001, True), (32, 64, 801, False), (1, 1, 5, False),
                                         (15360, 200, 3000, True), (777, 1, 100, False), (5000, 256, 50, True)])
 def test_sparse_sgd_small_equals_group_then_rows(engine_lib, n, D, N, hot):
