@@ -288,9 +288,8 @@ class DeepFMLayer:
     def _plan_eligible(self, sparse_inputs, dense_inputs, label, auc_stats, allreduce):
         return (self.device.type == "cuda" and self.k is ops and torch.is_tensor(sparse_inputs)
                 and allreduce is None and self.timers is None and self.lazy_mode and not self._recording
-                and sparse_inputs.numel() <= getattr(self.k, "SMALL_MERGE_MAX", 0)
-                and hasattr(self.k, "sparse_adam_record_small")
-                and os.environ.get("REC_SMALL_MERGE", "1") != "0" and os.environ.get("REC_STEP_PLAN", "1") != "0")
+                and sparse_inputs.numel() <= int(os.environ.get("REC_STEP_PLAN_MAX", "65536"))
+                and os.environ.get("REC_STEP_PLAN", "1") != "0")
 
     def _train_step_planned(self, ids, dense_inputs, label, lr, auc_stats):
         from .plan import CallPlan

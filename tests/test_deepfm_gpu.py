@@ -724,12 +724,13 @@ def test_small_merge_with_ids_outside_their_slot_span(ops, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_planned_step_equals_eager_step(engine_lib, monkeypatch):
+@pytest.mark.parametrize("B", [96, 700])        # the one-launch merge / the grouping sort + record update (18200 lookups)
+def test_planned_step_equals_eager_step(engine_lib, monkeypatch, B):
     """Launch-bound batches: the step replayed from its recorded call list (paddlerec_amd/plan.py) leaves the SAME bits
     in every parameter, moment, loss and prediction as the eager step — over several steps with fresh inputs each (a
     torch kernel hidden in the step, a stale pointer or a frozen Adam step count would all show)."""
     from paddlerec_amd.deepfm import DeepFMLayer
-    B, N, D = 96, 5000, 16
+    N, D = 5000, 16
     runs = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("REC_STEP_PLAN", mode)
