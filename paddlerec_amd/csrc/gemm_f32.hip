@@ -1203,11 +1203,13 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
     }
     if (b_colsum) cpart = (float*)((char*)workspace + off);
   }
+  // MEASUREMENT ONLY (REC_GEMM_SKIP_REDUCE=1: wrong results): what the split-K reduce launches cost a step
+  static const bool skip_reduce = [] { const char* v = getenv("REC_GEMM_SKIP_REDUCE"); return v && *v == '1'; }();
 #define REC_EPI_CASE(E)                                                   \
   case E:                                                                 \
     if (partial) {                                                        \
       launch_epi<REC_EPI_NONE>(desc, p, A, B, C, e, partial, cpart, st);  \
-      launch_reduce<E>(desc, p, partial, C, e, st);                       \
+      if (!skip_reduce) launch_reduce<E>(desc, p, partial, C, e, st);     \
     } else {                                                              \
       launch_epi<E>(desc, p, A, B, C, e, nullptr, cpart, st);             \
     }                                                                     \
@@ -1226,7 +1228,7 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
     REC_EPI_CASE(REC_EPI_DTANH)
   }
 #undef REC_EPI_CASE
-  if (b_colsum)
+  if (b_colsum && !skip_reduce)
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((desc->n + kBlock - 1) / kBlock), dim3(kBlock), 0,
                        st, desc->n, p.splits, (const float*)cpart, b_colsum);
   return check_launch("rec_gemm_f32");
