@@ -9,6 +9,8 @@
 // and these kernels are the HBM-bound passes either side of it: the outer-product rows Z (written once, read by
 // the GEMM; batch-chunked by the caller), its backward (dZ read once -> dX0, dXk), the sum over d and its broadcast.
 // No reshapes / transposes of [B,F,D] tensors exist anywhere: X0 = feat_embeddings is read through a strided view.
+#include <stdlib.h>
+
 #include "rec_common.h"
 
 namespace rec {
@@ -82,6 +84,75 @@ __global__ __launch_bounds__(kBlock) void cin_outer_bwd_kernel(int64_t rows, int
       *o = (acck ? *o : 0.f) + a;
     }
     __syncthreads();
+  }
+}
+
+// ---- narrow layers (F, S <= 64: the first CIN layer, 39 x 39): ONE WAVE per row (b,d), no block barriers.
+// The block-per-row kernels above keep 39 of 256 threads busy in their reductions and store Z with scalar stores in
+// F separate runs: 4.2 ms (0.85 TB/s) and 1.3 ms (2.8 TB/s) per call at B 65536 (profiles/r03_xdeepfm.txt).
+//   forward : lane i, i + 64, ... of the row's F*S outputs, f = i / S by a multiply-shift: fully coalesced stores
+//   backward: the dZ row staged in the wave's LDS with coalesced loads; lanes over s sum over f (x0[f] by readlane),
+//             lanes over f sum over s (row reads at stride S: S odd -> conflict-free) — ascending order, as above.
+__global__ __launch_bounds__(kBlock) void cin_outer_fwd_wave_kernel(int64_t rows, int D, int F, int S, unsigned magic,
+                                                                    const float* __restrict__ X0, View v0,
+                                                                    const float* __restrict__ Xk, View vk,
+                                                                    float* __restrict__ Z, int64_t ldz) {
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int FS = F * S;
+  for (int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + wave; r < rows; r += (int64_t)gridDim.x * (kBlock / kWave)) {
+    const int64_t b = r / D;
+    const int d = (int)(r - b * D);
+    const float x0v = lane < F ? X0[at(v0, b, lane, d)] : 0.f;
+    const float xkv = lane < S ? Xk[at(vk, b, lane, d)] : 0.f;
+    float* zrow = Z + r * ldz;
+    for (int i0 = 0; i0 < FS; i0 += kWave) {      // wave-uniform trip count: every lane takes part in the shuffles
+      const int i = min(i0 + lane, FS - 1);
+      const int f = (int)(((uint64_t)(unsigned)i * magic) >> 32);      // i / S for i < 2^16 (magic = ceil(2^32 / S))
+      const int sc = i - f * S;
+      const float z = __shfl(x0v, f, kWave) * __shfl(xkv, sc, kWave);
+      if (i0 + lane < FS) zrow[i] = z;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cin_outer_bwd_wave_kernel(int64_t rows, int D, int F, int S, int rowf,
+                                                                    const float* __restrict__ dZ, int64_t ldz,
+                                                                    const float* __restrict__ X0, View v0,
+                                                                    const float* __restrict__ Xk, View vk, float* dX0,
+                                                                    View dv0, int acc0, float* dXk, View dvk, int acck,
+                                                                    const float* __restrict__ dpool, int64_t ldp) {
+  extern __shared__ float smem[];
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  float* dz = smem + (size_t)wave * rowf;      // [F][S]
+  const int FS = F * S;
+  for (int64_t r = (int64_t)blockIdx.x * (kBlock / kWave) + wave; r < rows; r += (int64_t)gridDim.x * (kBlock / kWave)) {
+    const int64_t b = r / D;
+    const int d = (int)(r - b * D);
+    const float* zrow = dZ + r * ldz;
+    for (int i = lane; i < FS; i += kWave) dz[i] = zrow[i];
+    const float x0v = lane < F ? X0[at(v0, b, lane, d)] : 0.f;
+    const float xkv = lane < S ? Xk[at(vk, b, lane, d)] : 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float a0 = 0.f, ak = 0.f;
+    // (v_readlane: a wave-uniform source lane, read whether or not that lane is active here)
+    const int fl = min(lane, F - 1), sl = min(lane, S - 1);
+    for (int sc = 0; sc < S; ++sc)        // dX0[f] = sum_s dZ[f,s] Xk[s]
+      a0 += dz[fl * S + sc] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xkv), sc));
+    for (int f = 0; f < F; ++f)           // dXk[s] = sum_f dZ[f,s] X0[f]
+      ak += dz[f * S + sl] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0v), f));
+    // lane j writes element j of both outputs, dX0 first: the two may alias (layer 1: Xk == X0)
+    if (lane < F) {
+      float* o = dX0 + at(dv0, b, lane, d);
+      *o = (acc0 ? *o : 0.f) + a0;
+    }
+    if (lane < S) {
+      if (dpool) ak += dpool[b * ldp + lane];
+      float* o = dXk + at(dvk, b, lane, d);
+      *o = (acck ? *o : 0.f) + ak;
+    }
+    __builtin_amdgcn_wave_barrier();      // the stage is rewritten by the next row
   }
 }
 
@@ -184,6 +255,14 @@ extern "C" int rec_cin_outer_fwd(int64_t batch, int32_t emb_dim, int32_t F, int3
   if (batch == 0) return REC_OK;
   REC_REQUIRE(X0 && Xk && Z && v0 && vk, REC_EINVAL, "null pointer argument");
   const int64_t rows = batch * emb_dim;
+  static const bool wave_on = [] { const char* v = getenv("REC_CIN_WAVE"); return !(v && *v == '0'); }();
+  if (wave_on && F <= kWave && S <= kWave && S % 4 != 0) {      // narrow layer, rows that float4 stores cannot take
+    const int64_t g = (rows + kBlock / kWave - 1) / (kBlock / kWave);
+    hipLaunchKernelGGL(cin_outer_fwd_wave_kernel, dim3((unsigned)(g < 16384 ? g : 16384)), dim3(kBlock), 0,
+                       (hipStream_t)stream, rows, emb_dim, F, S, (unsigned)((0x100000000ull + S - 1) / S), X0, view_of(v0),
+                       Xk, view_of(vk), Z, ldz);
+    return check_launch("rec_cin_outer_fwd (wave)");
+  }
   const bool vec = S % 4 == 0 && ldz % 4 == 0 && ((uintptr_t)Z % 16) == 0;
   const int cols = vec ? S / 4 : S;
   REC_REQUIRE(cols <= kBlock, REC_ESHAPE, "previous CIN layer too wide (%d)", S);
@@ -206,9 +285,23 @@ extern "C" int rec_cin_outer_bwd(int64_t batch, int32_t emb_dim, int32_t F, int3
   REC_REQUIRE(batch >= 0 && emb_dim > 0 && F > 0 && S > 0 && ldz >= (int64_t)F * S, REC_EINVAL, "bad sizes");
   if (batch == 0) return REC_OK;
   REC_REQUIRE(dZ && X0 && Xk && dX0 && dXk && v0 && vk && dv0 && dvk, REC_EINVAL, "null pointer argument");
+  const int64_t rows = batch * emb_dim;
+  static const bool wave_on = [] { const char* v = getenv("REC_CIN_WAVE"); return !(v && *v == '0'); }();
+  if (wave_on && F <= kWave && S <= kWave) {
+    const int rowf = (F * S + 3) & ~3;
+    const size_t sh = sizeof(float) * (size_t)rowf * (kBlock / kWave);
+    if (sh <= 64 * 1024) {
+      int64_t g = resident_blocks(cin_outer_bwd_wave_kernel, kBlock, sh);
+      const int64_t need = (rows + kBlock / kWave - 1) / (kBlock / kWave);
+      if (g > need) g = need;
+      hipLaunchKernelGGL(cin_outer_bwd_wave_kernel, dim3((unsigned)g), dim3(kBlock), sh, (hipStream_t)stream, rows, emb_dim,
+                         F, S, rowf, dZ, ldz, X0, view_of(v0), Xk, view_of(vk), dX0, view_of(dv0), accumulate_dx0, dXk,
+                         view_of(dvk), accumulate_dxk, dpool, ld_dpool);
+      return check_launch("rec_cin_outer_bwd (wave)");
+    }
+  }
   const size_t shmem = sizeof(float) * ((size_t)F * (S + 1) + F + S);
   REC_REQUIRE(shmem <= 64 * 1024, REC_ESHAPE, "CIN row of %d x %d does not fit the LDS stage", F, S);
-  const int64_t rows = batch * emb_dim;
   int64_t grid = resident_blocks(cin_outer_bwd_kernel, kBlock, shmem);
   if (grid > rows) grid = rows;
   hipLaunchKernelGGL(cin_outer_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), shmem, (hipStream_t)stream, rows,

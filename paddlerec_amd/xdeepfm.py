@@ -17,13 +17,17 @@ Parameter keys follow the reference's sublayer names; `cin.cin_linear.*` and `ci
 reference registers that Linear twice, net.py:146-153).
 """
 import math
+import os
 
 import torch
 
 from .deepfm import NUM_THRESHOLDS, DeepFMLayer, _OnSide, _round_up, auc_metrics, slot_feeds
 
 L2_COEFF = 1e-4            # net.py:139,150,219
-Z_CHUNK_BYTES = 1 << 30    # the outer-product rows Z of a batch chunk stay under this
+# bytes of the outer-product scratch (Z / Y) per batch chunk.  Small enough to stay in the 256 MB Infinity Cache between
+# the kernel that writes it and the GEMM that reads it — and to be overwritten there by the next chunk before it is ever
+# written back: REC_CIN_CHUNK_MB (default measured in profiles/r03_xdeepfm_chunk.txt)
+Z_CHUNK_BYTES = int(os.environ.get("REC_CIN_CHUNK_MB", "4096")) << 20
 
 
 class xDeepFMLayer(DeepFMLayer):
@@ -38,6 +42,7 @@ class xDeepFMLayer(DeepFMLayer):
             extra.append(("cin.cnn_%d.weight" % i, (c, last * F, 1, 1)))          # Conv2D weight [out, in, 1, 1]
             last = c
         self.cin_total = sum(self.layer_sizes_cin)
+        self._pad_bufs = {}
         extra += [("cin.cnn_fc.weight", (self.cin_total, 1)), ("cin.cnn_fc.bias", (1,))]
         super().__init__(sparse_feature_number, sparse_feature_dim, dense_feature_dim, sparse_num_field,
                          layer_sizes_dnn, device=device, zero_padding_row=False, kernels=kernels, extra_dense=extra)
@@ -87,6 +92,30 @@ class xDeepFMLayer(DeepFMLayer):
             self._zbuf = torch.empty(rows * K, dtype=torch.float32, device=self.device)
         return self._zbuf[: rows * K].view(rows, K)
 
+    def _scratch(self, name, shape):
+        b = self._pad_bufs.get(name)
+        if b is None or tuple(b.shape) != tuple(shape):
+            b = self._pad_bufs[name] = torch.zeros(*shape, dtype=torch.float32, device=self.device)
+        return b
+
+    def _padded_weight(self, i, K):
+        """(K rounded up to the GEMM's k-step, the conv weight of layer i with zero columns behind K): F*S = 39*39 = 1521
+        is odd, which keeps the layer-1 GEMMs (K or N = 1521, M = B*D) off the aligned tile loaders — 72 TF at K 1521
+        against 110+ at K 1536 (profiles/r03_xdeepfm.txt).  The zero columns meet zero columns of Z."""
+        KP = (K + 15) // 16 * 16
+        if KP == K or os.environ.get("REC_CIN_PAD", "1") == "0":
+            return K, self.cin_w[i]
+        w = self._scratch("cin_wz%d" % i, (self.cin_w[i].shape[0], KP))
+        w[:, :K].copy_(self.cin_w[i])
+        return KP, w
+
+    def _z_padded(self, rows, K, KP):
+        """-> (Z scratch [rows, KP], its [rows, K] view the outer-product kernels write); pad columns zeroed."""
+        zf = self._z(rows, KP)
+        if KP != K:
+            zf[:, K:].zero_()
+        return zf, zf[:, :K]
+
     def _layer_inputs(self, feat, xts, i):
         """(tensor, view maker) of X_i: feat_embeddings for layer 0, the previous layer's d-major output after."""
         k, D = self.k, self.sparse_feature_dim
@@ -109,12 +138,13 @@ class xDeepFMLayer(DeepFMLayer):
                     y = self._z(n * D, Cn * F)
                     k.gemm(xk[b0 * D:b1 * D], self.cin_w[i].view(Cn * F, S), self.ws, trans_b=True, out=y)
                     k.cin_contract_fwd(n, D, F, y, feat[b0:b1], k.cin_view(feat, "bfd"), xt[b0 * D:b1 * D])
-            for b0, b1 in ([] if self._use_y(i, S, Cn) else self._chunks(B, F * S)):
+            KP, wz = self._padded_weight(i, F * S)
+            for b0, b1 in ([] if self._use_y(i, S, Cn) else self._chunks(B, KP)):
                 n = b1 - b0
-                z = self._z(n * D, F * S)
+                zf, z = self._z_padded(n * D, F * S, KP)
                 xk_c = xk[b0:b1] if i == 0 else xk[b0 * D:b1 * D]
                 k.cin_outer_fwd(n, D, F, S, feat[b0:b1], k.cin_view(feat, "bfd"), xk_c, mk(xk_c), z)
-                k.gemm(z, self.cin_w[i], self.ws, trans_b=True, out=xt[b0 * D:b1 * D])        # net.py:190 (1x1 conv)
+                k.gemm(zf, wz, self.ws, trans_b=True, out=xt[b0 * D:b1 * D])                   # net.py:190 (1x1 conv)
             k.cin_sumpool(B, D, xt, pooled[:, off:off + Cn])                                   # net.py:195-198
             xts.append(xt)
             off, S = off + Cn, Cn
@@ -150,19 +180,23 @@ class xDeepFMLayer(DeepFMLayer):
                            **(dict(epilogue="add", aux1=dw2) if ci > 0 else {}))              # dW' = dY^T Xk
                     dxk_c = dxk[b0 * D:b1 * D]
                     k.gemm(dy, w2, self.ws, epilogue="add", aux1=dxk_c, out=dxk_c)            # dXk = dY W' + pooled grad
-            for ci, (b0, b1) in enumerate([] if use_y else self._chunks(B, F * S)):
+            KP, wz = (F * S, None) if use_y else self._padded_weight(i, F * S)
+            dwz = self.cin_dw[i] if KP == F * S else self._scratch("cin_dwz%d" % i, (Cn, KP))
+            for ci, (b0, b1) in enumerate([] if use_y else self._chunks(B, KP)):
                 n = b1 - b0
-                z = self._z(n * D, F * S)
+                zf, z = self._z_padded(n * D, F * S, KP)
                 xk_c = xk[b0:b1] if i == 0 else xk[b0 * D:b1 * D]
                 dxk_c = dxk[b0:b1] if i == 0 else dxk[b0 * D:b1 * D]
                 g = dxt[b0 * D:b1 * D]
                 k.cin_outer_fwd(n, D, F, S, feat[b0:b1], k.cin_view(feat, "bfd"), xk_c, mk(xk_c), z)      # recomputed
-                k.gemm(g, z, self.ws, trans_a=True, out=self.cin_dw[i],
-                       **(dict(epilogue="add", aux1=self.cin_dw[i]) if ci > 0 else {}))                   # dWc
-                k.gemm(g, self.cin_w[i], self.ws, out=z)                                                  # dZ (in place of Z)
+                k.gemm(g, zf, self.ws, trans_a=True, out=dwz,
+                       **(dict(epilogue="add", aux1=dwz) if ci > 0 else {}))                              # dWc
+                k.gemm(g, wz, self.ws, out=zf)                                                            # dZ (in place of Z)
                 dpool = None if i == 0 else dpooled[b0:b1, offs[i - 1]:offs[i - 1] + S]
                 k.cin_outer_bwd(n, D, F, S, z, feat[b0:b1], k.cin_view(feat, "bfd"), xk_c, mk(xk_c),
                                 dfeat[b0:b1], k.cin_view(dfeat, "bfd"), True, dxk_c, mk(dxk_c), i == 0, dpool)
+            if not use_y and KP != F * S:
+                self.cin_dw[i].copy_(dwz[:, : F * S])
             dxt = dxk
 
     def _logit_parts(self, ids, dense_inputs, keep=None):
