@@ -156,6 +156,46 @@ def cpu_baseline(B, S, Dn, D, fc, rows_per_table, budget_s=20.0):
                       "NumPy/BLAS MLP fwd/bwd + dense Adam), %.1f s" % (steps, B, t_total)}
 
 
+def other_configs(timeout_s=200):
+    """The other BASELINE configs measured in THIS run on THIS box (subprocesses of the repository's own tools, each under
+    its own timeout; a failure is reported, never hidden, and never touches the main line): configs[2] DCN-v2 and
+    configs[3] DIN train steps + the sibling nets (tools/bench_models.py), row P = the multi-slot pool kernel and the
+    gpubox model's train step on the PS accessor table (tools/slot_dnn_bench.py), configs[4] = one GPU's 1.25e9-row share
+    of the hashed table through the row-sharded code path (this script, world 1)."""
+    import subprocess
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    jobs = [("tools/bench_models.py", [sys.executable, os.path.join(REPO, "tools", "bench_models.py")]),
+            ("tools/slot_dnn_bench.py --opt ps", [sys.executable, os.path.join(REPO, "tools", "slot_dnn_bench.py"),
+                                                  "--opt", "ps"]),
+            ("bench.py --force-sharded --table ps --hashed-rows 1250000000",
+             [sys.executable, os.path.abspath(__file__), "--force-sharded", "--table", "ps", "--hashed-rows",
+              "1250000000", "--no-cpu-baseline", "--steps", "20", "--warmup", "5"])]
+    keep = ("config", "workload", "ms", "ms_per_step", "samples_per_s", "value", "unit", "roofline", "pool_fwd_ms",
+            "train_step_ms", "kernels_ms")
+    out = []
+    for name, cmd in jobs:
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout_s)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out.append({"command": name, "error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])})
+                continue
+            for ln in lines:
+                d = json.loads(ln)
+                e = {k: d[k] for k in keep if k in d}
+                if "config" in d and isinstance(d["config"], dict):      # a bench.py line: its config object names the workload
+                    e["workload"] = d["config"].get("workload")
+                    e["config"] = "configs[4] (one GPU's share, row-sharded path at world 1)"
+                    e["roofline"] = {k: d["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac")}
+                e["command"] = name
+                out.append(e)
+        except Exception as e:      # timeout, missing tool, bad JSON
+            out.append({"command": name, "error": repr(e)[:300]})
+        out[-1]["wall_s"] = round(time.time() - t0, 1)
+    return out
+
+
 def reference_trainer_baseline(budget_s=60.0):
     """north_star / SURVEY §8(d) "CPU baseline (1)": the reference's OWN tools/trainer.py, unmodified, on its own
     models/rank/deepfm/config.yaml (BASELINE configs[0]: sample data, bs 2, D 9, 1 000 001-row table, dygraph Adam
@@ -245,7 +285,10 @@ def main():
     ap.add_argument("--fc", type=str, default="400,400,400")
     ap.add_argument("--ids", choices=("uniform", "zipf"), default="uniform",
                     help="id distribution of SURVEY.md §8(d): (U) uniform [default] or (Z) Zipf 1.05 (hot rows)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the CPU baselines AND the other-configs section (quick runs, profiling)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the BASELINE configs[2]/[3]/[4] + row-P measurements appended to the line at N = 1")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the row-sharded path (RCCL all-to-all) even with one rank")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -484,6 +527,10 @@ def main():
                 out["cpu_baseline"]["reference_trainer"] = reference_trainer_baseline()
             except Exception as e:
                 out["cpu_baseline"]["reference_trainer"] = {"error": repr(e)}
+            if not args.no_other_configs and B == 65536 and not standin:
+                del model, batches          # the sub-benchmarks get the whole GPU
+                torch.cuda.empty_cache()
+                out["other_configs"] = other_configs()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
