@@ -131,7 +131,7 @@ for B in (4096, 65536):
     print("xDeepFM train step B=%d: %.2f ms  (%.2f M samples/s; CIN + DNN GEMMs %.1f TF executed, fwd + 2x bwd)"
           % (B, t, B / t / 1e3, 3 * (fl_cin + fl_dnn) / t / 1e9))
     record("sibling net", "xDeepFM (CIN 128-32 over 39 fields x D 9, DNN 512-256-128) train step, B %d; the CIN's "
-           "outer-product rows go through HBM in 1-GB chunks" % B, t, 3 * (fl_cin + fl_dnn), B)
+           "outer-product rows go through HBM (REC_CIN_CHUNK_MB scratch chunks)" % B, t, 3 * (fl_cin + fl_dnn), B)
     del m
     torch.cuda.empty_cache()
     m = DLRMLayer(13, [512, 256, 64, 16], 1000001, 16, [512, 256, 2], 26, device=DEV)
