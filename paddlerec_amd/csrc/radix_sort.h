@@ -28,14 +28,17 @@ struct BufSrc {
   const int32_t* vals;
   __device__ __forceinline__ KeyT key(int64_t i) const { return keys[i]; }
   __device__ __forceinline__ int32_t val(int64_t i) const { return vals[i]; }
+  __device__ __forceinline__ bool drop(KeyT) const { return false; }
 };
 
 // WAVES waves per block, tile = WAVES * 512 consecutive elements (2048 for small jobs: enough blocks to fill the
 // chip at n ~ 10^6; 8192 for large ones: a smaller histogram matrix)
 template <class KeyT, class Src, int WAVES>
 __global__ __launch_bounds__(WAVES* kWave) void hist_kernel(int64_t n, int shift, int bits, int nblk, Src src,
-                                                            int32_t* __restrict__ hist) {
+                                                            int32_t* __restrict__ hist,
+                                                            const int32_t* __restrict__ n_dev) {
   extern __shared__ int lh[];   // [1 << bits]
+  if (n_dev) n = min(n, (int64_t)n_dev[0]);      // an earlier pass dropped the invalid keys: fewer elements are left
   constexpr int NT = WAVES * kWave;
   const int nb = 1 << bits;
   for (int i = threadIdx.x; i < nb; i += NT) lh[i] = 0;
@@ -46,7 +49,11 @@ __global__ __launch_bounds__(WAVES* kWave) void hist_kernel(int64_t n, int shift
 #pragma unroll
   for (int j = 0; j < kChunks; ++j) {   // all loads first, then the LDS atomics
     const int64_t i = base + j * NT + threadIdx.x;
-    d[j] = i < n ? (int)((src.key(i) >> shift) & mask) : -1;
+    d[j] = -1;
+    if (i < n) {
+      const KeyT kk = src.key(i);
+      if (!src.drop(kk)) d[j] = (int)((kk >> shift) & mask);
+    }
   }
 #pragma unroll
   for (int j = 0; j < kChunks; ++j)
@@ -86,8 +93,11 @@ __global__ __launch_bounds__(WAVES* kWave) void scatter_kernel(int64_t n, int sh
                                                                const int32_t* __restrict__ hist,
                                                                const int32_t* __restrict__ totals,
                                                                KeyT* __restrict__ keys_out,
-                                                               int32_t* __restrict__ vals_out) {
-  extern __shared__ int sm[];   // [nb] bin bases | [WAVES][nb] per-wave counters -> running offsets | [NT] scan
+                                                               int32_t* __restrict__ vals_out,
+                                                               const int32_t* __restrict__ n_dev,
+                                                               int32_t* __restrict__ n_live_out) {
+  extern __shared__ int sm[];
+  if (n_dev) n = min(n, (int64_t)n_dev[0]);   // [nb] bin bases | [WAVES][nb] per-wave counters -> running offsets | [NT] scan
   constexpr int NT = WAVES * kWave;
   const int nb = 1 << bits;
   int* binbase = sm;
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(WAVES* kWave) void scatter_kernel(int64_t n, int sh
     const bool in = i < n;
     k[c] = in ? src.key(i) : (KeyT)0;
     v[c] = in ? src.val(i) : 0;
-    d[c] = in ? (int)((k[c] >> shift) & mask) : -1;
+    d[c] = (in && !src.drop(k[c])) ? (int)((k[c] >> shift) & mask) : -1;
   }
   // bin bases: exclusive scan of the totals (serial per thread + block scan)
   {
@@ -127,6 +137,8 @@ __global__ __launch_bounds__(WAVES* kWave) void scatter_kernel(int64_t n, int sh
       binbase[i] = run;
       run += totals[i];
     }
+    // the elements this pass keeps (all of them unless the source drops keys): what the later passes sort
+    if (n_live_out && blockIdx.x == 0 && threadIdx.x == NT - 1) n_live_out[0] = part[NT - 1];
   }
   for (int i = threadIdx.x; i < WAVES * nb; i += NT) whist[i] = 0;
   __syncthreads();
@@ -201,21 +213,33 @@ inline Plan make_plan(int64_t n, int key_bits_) {
 
 template <class KeyT, class Src, int WAVES>
 inline void run_pass(int64_t n, const Plan& p, int i, Src src, KeyT* ko, int32_t* vo, int32_t* hist,
-                     int32_t* totals, hipStream_t st) {
+                     int32_t* totals, hipStream_t st, const int32_t* n_dev = nullptr, int32_t* n_live_out = nullptr) {
   const int nb = 1 << p.bits[i];
   const size_t sm_scatter = (size_t)(nb + WAVES * nb + WAVES * kWave) * sizeof(int);
   hipLaunchKernelGGL((hist_kernel<KeyT, Src, WAVES>), dim3(p.nblk), dim3(WAVES * kWave), nb * sizeof(int), st, n,
-                     p.shift[i], p.bits[i], p.nblk, src, hist);
+                     p.shift[i], p.bits[i], p.nblk, src, hist, n_dev);
   hipLaunchKernelGGL(rowscan_kernel, dim3(nb), dim3(kThreads), 0, st, p.nblk, hist, totals);
   hipLaunchKernelGGL((scatter_kernel<KeyT, Src, WAVES>), dim3(p.nblk), dim3(WAVES * kWave), sm_scatter, st, n,
-                     p.shift[i], p.bits[i], p.nblk, src, hist, totals, ko, vo);
+                     p.shift[i], p.bits[i], p.nblk, src, hist, totals, ko, vo, n_dev, n_live_out);
+}
+
+// after a sort that dropped keys: positions [n_live, n) of the sorted keys read as `tail` (the callers' sentinel)
+template <class KeyT>
+__global__ void fill_tail_kernel(int64_t n, const int32_t* __restrict__ n_live, KeyT tail, KeyT* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && i >= n_live[0]) keys[i] = tail;
 }
 
 // Sorts n pairs by key bits [0, key_bits).  Pass 0 reads `first` (functor); later passes ping-pong between
 // (keys_tmp, vals_tmp) and (keys_dst, vals_dst) such that the last pass writes the *_dst buffers.
 template <class KeyT, class FirstSrc>
 inline int sort_pairs(int64_t n, const Plan& p, FirstSrc first, KeyT* keys_tmp, int32_t* vals_tmp, KeyT* keys_dst,
-                      int32_t* vals_dst, void* ws_hist, void* ws_totals, hipStream_t st) {
+                      int32_t* vals_dst, void* ws_hist, void* ws_totals, hipStream_t st, int32_t* n_live = nullptr,
+                      KeyT tail_key = 0) {
+  // n_live (device int, optional): the first pass leaves out the keys `first.drop()` names (padding / out-of-range
+  // lookups: 44 % of the ids of a multi-slot batch), writes how many it kept, the later passes sort only those, and the
+  // tail of keys_dst reads as tail_key — what the callers' sentinel-sorts-last convention produced, at a fraction of
+  // the traffic.  vals_dst behind the kept elements is unspecified.
   int32_t* hist = (int32_t*)ws_hist;
   int32_t* totals = (int32_t*)ws_totals;
   for (int i = 0; i < p.passes; ++i) {
@@ -223,14 +247,17 @@ inline int sort_pairs(int64_t n, const Plan& p, FirstSrc first, KeyT* keys_tmp, 
     KeyT* ko = to_dst ? keys_dst : keys_tmp;
     int32_t* vo = to_dst ? vals_dst : vals_tmp;
     if (i == 0) {
-      if (p.waves == 16) run_pass<KeyT, FirstSrc, 16>(n, p, i, first, ko, vo, hist, totals, st);
-      else run_pass<KeyT, FirstSrc, 4>(n, p, i, first, ko, vo, hist, totals, st);
+      if (p.waves == 16) run_pass<KeyT, FirstSrc, 16>(n, p, i, first, ko, vo, hist, totals, st, nullptr, n_live);
+      else run_pass<KeyT, FirstSrc, 4>(n, p, i, first, ko, vo, hist, totals, st, nullptr, n_live);
     } else {
       BufSrc<KeyT> src{to_dst ? keys_tmp : keys_dst, to_dst ? vals_tmp : vals_dst};
-      if (p.waves == 16) run_pass<KeyT, BufSrc<KeyT>, 16>(n, p, i, src, ko, vo, hist, totals, st);
-      else run_pass<KeyT, BufSrc<KeyT>, 4>(n, p, i, src, ko, vo, hist, totals, st);
+      if (p.waves == 16) run_pass<KeyT, BufSrc<KeyT>, 16>(n, p, i, src, ko, vo, hist, totals, st, n_live);
+      else run_pass<KeyT, BufSrc<KeyT>, 4>(n, p, i, src, ko, vo, hist, totals, st, n_live);
     }
   }
+  if (n_live)
+    hipLaunchKernelGGL(fill_tail_kernel<KeyT>, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, n,
+                       (const int32_t*)n_live, tail_key, keys_dst);
   return check_launch("radix sort");
 }
 

@@ -34,6 +34,8 @@ struct IdsSrc {
   int64_t N, pad;
   int32_t* status;
   const int32_t* payload;   // what travels with the key: payload[i], or the position i itself when null
+  bool drop_invalid;        // the sort leaves the sentinel keys out after its first pass (rsort::sort_pairs n_live)
+  __device__ __forceinline__ bool drop(KeyT k) const { return drop_invalid && k == (KeyT)N; }
   __device__ __forceinline__ KeyT key(int64_t i) const {
     const int64_t id = ids[i];
     KeyT k = (KeyT)N;
@@ -181,7 +183,7 @@ static int key_bits(int64_t N) {
 template <class KeyT>
 struct GroupPlan {
   rsort::Plan sort;
-  size_t off_keys_tmp, off_keys_dst, off_vals_tmp, off_hist, off_totals, off_cnt, total;
+  size_t off_keys_tmp, off_keys_dst, off_vals_tmp, off_hist, off_totals, off_nlive, off_cnt, total;
 };
 
 template <class KeyT>
@@ -193,6 +195,7 @@ static int plan_group(int64_t n, int64_t N, GroupPlan<KeyT>* p) {
   p->off_vals_tmp = o; o += align_up((size_t)n * sizeof(int32_t), 256);
   p->off_hist = o;     o += p->sort.hist_bytes;
   p->off_totals = o;   o += p->sort.totals_bytes;
+  p->off_nlive = o;    o += 256;
   p->off_cnt = o;      o += align_up((size_t)((n + kHeadsTile - 1) / kHeadsTile + 1) * 2 * sizeof(int32_t), 256);
   p->total = o;
   return REC_OK;
@@ -211,9 +214,13 @@ static int run_group(int64_t n, int S, int64_t N, int64_t pad, const int64_t* id
   KeyT* keys_dst = (KeyT*)(base + p.off_keys_dst);
   int32_t* vals_tmp = (int32_t*)(base + p.off_vals_tmp);
   int32_t* cnt = (int32_t*)(base + p.off_cnt);
-  IdsSrc<KeyT> src{ids, slot_off, S, N, pad, status, payload};
+  // padding and out-of-range lookups leave the sort after its first pass (REC_GROUP_DROP=0: carried through every pass)
+  static const bool drop = [] { const char* v = getenv("REC_GROUP_DROP"); return !(v && *v == '0'); }();
+  const bool dr = drop && n < (1ll << 31);
+  IdsSrc<KeyT> src{ids, slot_off, S, N, pad, status, payload, dr};
   if (int rc = rsort::sort_pairs<KeyT>(n, p.sort, src, keys_tmp, vals_tmp, keys_dst, sorted_pos,
-                                       base + p.off_hist, base + p.off_totals, st))
+                                       base + p.off_hist, base + p.off_totals, st,
+                                       dr ? (int32_t*)(base + p.off_nlive) : nullptr, (KeyT)N))
     return rc;
   const int nblk = (int)((n + kHeadsTile - 1) / kHeadsTile);
   (void)hipMemsetAsync(n_uniq + 2, 0, 2 * sizeof(int32_t), st);
