@@ -366,6 +366,10 @@ class DeepFMLayer:
             self.k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         defer_all = os.environ.get("REC_DEEPFM_DEFER_ALL", "0") == "1"   # measurement knob: every dW GEMM in the tail
         kw = dict(defer_all=True) if defer_all else dict(defer_first=True)
+        if overlap and not defer_all and not small and B >= 16384:
+            # dW_0 runs beside the sparse update: half a resident round of blocks (K split 16 instead of 32) leaves the
+            # HBM-bound kernel its wave slots — sparse_adam 404 -> 336 us, dW_0 unchanged (REC_DW0_SPLIT: 0 = planner's)
+            kw.update(defer_split=int(os.environ.get("REC_DW0_SPLIT", "16")))
         # dW_i on a third stream beside dX_i (both consume g_i, neither the other): the half-empty last round of
         # blocks of one GEMM is filled by the other — 2.77-2.84 -> 2.70-2.81 ms per step in five A/B pairs on two boxes
         # (profiles/r02f_dw_stream_ab.txt); REC_MLP_DW_STREAM=0 puts them back on one stream

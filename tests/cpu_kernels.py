@@ -372,7 +372,8 @@ def copy_f32(dst, src):
     return dst.copy_(src)
 
 
-def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=False, dw_stream=None, dw_ws=None):
+def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=False, dw_stream=None, dw_ws=None,
+                 defer_split=0):
     if defer_first or defer_all:
         return mlp_backward(dy, acts, weights, dws, dbs, ws), (lambda: None)
     n = len(weights)
