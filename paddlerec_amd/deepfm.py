@@ -338,7 +338,9 @@ class DeepFMLayer:
         # REC_DEEPFM_GROUP_AT (measurement knob): "bwd" = under the dX chain (default: 2.83 ms/step), "fwd" = under
         # the forward GEMMs (2.875 ms; gpurun call 25) — the sort costs the GEMMs it runs beside about its own time
         # either way, the backward chain absorbs it slightly better
-        group_at = os.environ.get("REC_DEEPFM_GROUP_AT", "bwd")
+        # (round 3, weights aligned and the pipe kernels in the step: under the forward GEMMs is now the better place —
+        # 2.311 against 2.32-2.34 ms in three A/B pairs on one box, profiles/r03_schedule_ab.txt)
+        group_at = os.environ.get("REC_DEEPFM_GROUP_AT", "fwd")
 
         # the reference's own batch sizes (config_bigdata.yaml: 512 x 26 = 13312 lookups): the merge happens inside the
         # ONE launch of the record update — no grouping sort, no hot-row partial passes (12 launches less per step)
@@ -373,7 +375,10 @@ class DeepFMLayer:
         # dW_i on a third stream beside dX_i (both consume g_i, neither the other): the half-empty last round of
         # blocks of one GEMM is filled by the other — 2.77-2.84 -> 2.70-2.81 ms per step in five A/B pairs on two boxes
         # (profiles/r02f_dw_stream_ab.txt); REC_MLP_DW_STREAM=0 puts them back on one stream
-        if on_gpu and not defer_all and not self._recording and os.environ.get("REC_MLP_DW_STREAM", "1") == "1":
+        # Round 3: with the MLP weights aligned (every GEMM on its fast variant) the two streams LOSE — a dX / dW pair
+        # takes 455 us side by side against 182 + 225 one after the other, 2.32-2.35 -> 2.27-2.32 ms per step — so one
+        # stream is the default again and REC_MLP_DW_STREAM=1 the switch
+        if on_gpu and not defer_all and not self._recording and os.environ.get("REC_MLP_DW_STREAM", "0") == "1":
             if getattr(self, "_dw_stream", None) is None:
                 self._dw_stream, self._ws_dw = self.k.concurrent_stream(self.device), self.k.Workspace(self.device)
             kw.update(dw_stream=self._dw_stream, dw_ws=self._ws_dw)
