@@ -1188,6 +1188,9 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
   }
   if (!b_colsum && launch_glds(desc, A, B, C, e, st)) return check_launch("rec_gemm_f32 (glds)");
   const GemmPlan p = plan_gemm(desc);
+  // (The half-empty last round of blocks — 65536 x 400 on 256x80 tiles is 2.5 rounds of the 512 resident blocks and
+  // costs three — was attacked in round 3 by giving the rows behind the whole rounds to a second launch on 64x80 tiles:
+  // 2.28 -> 2.38 ms per DeepFM step, i.e. worse; removed.  profiles/r03_schedule_ab.txt)
   REC_REQUIRE(p.tiles_total < (1ll << 31), REC_ESHAPE, "too many tiles");
   float* partial = nullptr;
   float* cpart = nullptr;
