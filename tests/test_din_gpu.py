@@ -229,6 +229,34 @@ def test_din_train_step_graphed_equals_eager(engine_lib):
     assert int(a.status.item()) == 0 and int(b.status.item()) == 0
 
 
+def test_sparse_sgd_small_multi_equals_single_calls(engine_lib):
+    """rec_sparse_sgd_small_multi (up to 8 independent tables in one launch) leaves the same bits as one
+    rec_sparse_sgd_small call per table: different sizes, widths 1 / 64 / 200, strided gradient views, a hot row, an
+    out-of-range id (flagged, skipped)."""
+    from paddlerec_amd import _lib, ops
+    rng = np.random.default_rng(77)
+    specs = [(4864, 64, 63001, 128), (32, 64, 801, 256), (32, 1, 63001, 1), (15360, 200, 3000, 208), (700, 64, 50, 64)]
+    tabs_a, tabs_b, jobs = [], [], []
+    for n, D, N, pitch in specs:
+        ids = rng.integers(0, N, size=n).astype(np.int64)
+        if n > 300:
+            ids[rng.integers(0, n, size=n // 4)] = ids[0]
+        if n == 700:
+            ids[5] = N + 3
+        g = rng.standard_normal((n, pitch)).astype(np.float32)
+        P0 = rng.standard_normal((N, D)).astype(np.float32)
+        tabs_a.append(T(P0.copy()))
+        tabs_b.append(T(P0.copy()))
+        jobs.append((T(ids), T(g)[:, :D] if pitch > D else T(g), pitch))
+    st_a, st_b = ops.new_status(DEV), ops.new_status(DEV)
+    ops.sparse_sgd_small_multi([(ids, gv, P, 1, pitch) for (ids, gv, pitch), P in zip(jobs, tabs_a)], 0.37, st_a)
+    for (ids, gv, pitch), P in zip(jobs, tabs_b):
+        ops.sparse_sgd_small(ids, gv, P, 0.37, None, st_b, grad_group=1, grad_group_stride=pitch)
+    for x, y in zip(tabs_a, tabs_b):
+        assert torch.equal(x, y)
+    assert int(st_a.item()) == int(st_b.item()) and int(st_a.item()) & _lib.REC_FLAG_INDEX_OOB
+
+
 def test_din_planned_step_equals_eager(engine_lib, monkeypatch):
     """train_step replays a launch-bound step from its recorded C-ABI call list (paddlerec_amd/plan.py) from the third
     sight of an input signature on: with two padded lengths, every loss, prediction and parameter is bit-identical to a
