@@ -16,6 +16,8 @@ Parameter keys: embedding (the shared table), linear_i.{weight,bias}.
 """
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -148,8 +150,15 @@ class BenchmarkDNNLayer:
             k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         with self._timed("mlp_bwd"):      # dX of layer 0 BEFORE its dW: the HBM-bound sparse update below runs on the
             # side stream underneath that MFMA-bound GEMM (the largest of the step: S*D x 512 x B)
+            # dW_0 runs beside the HBM-bound sparse update: half a resident round of blocks (K split 4 instead of the
+            # planner's 8) leaves that kernel its wave slots — sparse_update 3.30 -> 2.72 ms, dW_0 2.63 -> 2.72, the step
+            # 10.35 -> 9.75 ms on the benchmark shape (profiles/r03_schedule_ab.txt; REC_SLOT_DW0_SPLIT=0: planner's)
+            kw = {}
+            sk = int(os.environ.get("REC_SLOT_DW0_SPLIT", "4"))
+            if on_gpu and sk > 0 and label.shape[0] >= 16384:
+                kw = dict(defer_split=sk)
             dx, finish_dw0 = k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp,
-                                            defer_first=True)                                     # [B, S*D]
+                                            defer_first=True, **kw)                               # [B, S*D]
         with _OnSide(side, cur):
             with self._timed("sparse_update"):
                 if self.table is not None:
