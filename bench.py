@@ -156,6 +156,18 @@ def cpu_baseline(B, S, Dn, D, fc, rows_per_table, budget_s=20.0):
                       "NumPy/BLAS MLP fwd/bwd + dense Adam), %.1f s" % (steps, B, t_total)}
 
 
+def empty_bracket_us(dev, n=50):
+    """Median elapsed time between two torch timing events recorded back to back on the current stream (microseconds)."""
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    return sorted(ts)[len(ts) // 2]
+
+
 def other_configs(timeout_s=200):
     """The other BASELINE configs measured in THIS run on THIS box (subprocesses of the repository's own tools, each under
     its own timeout; a failure is reported, never hidden, and never touches the main line): configs[2] DCN-v2 and
@@ -510,7 +522,11 @@ def main():
                                     "GBs_designed": dbwd_b / bwd_s / 1e9 if bwd_s else None, "pmc_bytes": tr_b}},
                      # the same pair as bracketed INSIDE a step (event marker + join overhead included)
                      "in_step_event": {"fm_fwd_ms": k_ms.get("fm_fwd"), "fm_bwd_ms": k_ms.get("fm_bwd"),
-                                       "achieved": in_step, "frac": in_step / HBM_PEAK_GBS},
+                                       "achieved": in_step, "frac": in_step / HBM_PEAK_GBS,
+                                       # what a bracket measures around NOTHING (two event records back to back on the
+                                       # stream): the marker's own share of every bracketed region above — reported,
+                                       # not subtracted (profiles/*_bench_populations.txt holds rocprofv3's kernel clock)
+                                       "empty_bracket_us": empty_bracket_us(dev) if not standin else None},
                      "frac_designed_bytes": ((dfwd_b + dbwd_b) / (fwd_s + bwd_s) / 1e9 / HBM_PEAK_GBS)
                      if fwd_s + bwd_s > 0 else None},
         "kernels_ms": k_ms, "host_issue_ms": host_ms,
