@@ -17,10 +17,12 @@ The sparse optimizer is lazy Adam (see deepfm.py).  Training covers both cross n
 (BASELINE config 3) and the shipped CrossNetMix (low-rank mixture of experts).
 """
 import math
+import os
 
 import torch
 
 from . import ops
+from . import ops as _ops
 from .deepfm import NUM_THRESHOLDS, _FlatParams, _round_up, _Timed, auc_metrics, slot_feeds
 
 P = "DeepCrossLayer_.crossNet."
@@ -93,6 +95,7 @@ class DCN_V2Layer:
         self.sparse_state = None
         self.step_count = 0
         self.timers = None
+        self._plans, self._recording = {}, False          # recorded call lists of launch-bound steps (plan.py)
         self._groups = None
         self._side = None
 
@@ -206,14 +209,14 @@ class DCN_V2Layer:
             acts.append(x)
             x = k.gemm(x, W[i], self.ws, epilogue="bias_relu", bias=b[i], out=out_last if i == n - 1 else None)
             st = (step * n + i) * 2
-            k.dropout(x, self.dropout_rate, self.dropout_seed, st, st + 1)
+            k.dropout(x, self.dropout_rate, self.dropout_seed, st, st + 1, step_stride=2 * n)
         return x, acts + [x]
 
     def _tower_grad_through_dropout(self, g, layer, n, step):
         """d(loss)/d(output of DNN layer `layer`) after the dX GEMM's ReLU mask: the gradient also passes that layer's two
         dropouts — the same rec_dropout call (keep mask redundant with the mask of the dropped output, scale 1/(1-p)^2)."""
         st = (step * n + layer) * 2
-        return self.k.dropout(g, self.dropout_rate, self.dropout_seed, st, st + 1)
+        return self.k.dropout(g, self.dropout_rate, self.dropout_seed, st, st + 1, step_stride=2 * n)
 
     def _logit(self, ids, dense_inputs, keep=False, step=None):
         p, k = self.dense.p, self.k
@@ -267,6 +270,33 @@ class DCN_V2Layer:
         """dcn_v2/dygraph_model.py:103-127 train_forward + backward + Adam with ClipGradByGlobalNorm.
         dlogit ([B,1], optional): d loss / d logit supplied by the caller instead of the log-loss head
         (custom losses; the golden-gradient tests use d pred.sum()).  Returns (loss [1], pred [B,1])."""
+        # launch-bound batches (the reference's own: dcn_v2 config_bigdata.yaml batch_size 512): from the third sight of
+        # an input signature on the step is replayed from its recorded C-ABI call list (plan.py), the Adam step count and
+        # the dropout mask streams re-derived per replay; bit-identical (tests/test_dcn_v2_gpu.py)
+        if (self.device.type == "cuda" and self.k is _ops and torch.is_tensor(sparse_inputs) and dlogit is None
+                and self.timers is None and not self._recording and not self.use_low_rank_mixture
+                and sparse_inputs.numel() <= int(os.environ.get("REC_STEP_PLAN_MAX", "65536"))
+                and os.environ.get("REC_STEP_PLAN", "1") != "0"):
+            from .plan import CallPlan
+            inputs = [sparse_inputs, dense_inputs, label]
+            key = (tuple(sparse_inputs.shape), float(clip_norm or 0.0),
+                   None if auc_stats is None else (auc_stats[0].data_ptr(), auc_stats[1].data_ptr()))
+            entry = self._plans.get(key)
+            if entry is None:
+                self._plans[key] = "seen"
+            elif entry == "seen" or not entry.matches(inputs):
+                plan = CallPlan()
+                self._recording = True
+                try:
+                    out = plan.record(lambda: self.train_step(sparse_inputs, dense_inputs, label, lr, clip_norm,
+                                                              auc_stats), inputs, step0=self.step_count + 1)
+                finally:
+                    self._recording = False
+                self._plans[key] = plan
+                return out
+            else:
+                self.step_count += 1
+                return entry.replay(inputs, self.step_count, float(lr))
         k, p, g = self.k, self.dense.p, self.dense.g
         ids = self._concat_ids(sparse_inputs)
         B, S = ids.shape

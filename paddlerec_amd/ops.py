@@ -633,15 +633,23 @@ def sparse_rows_sumsq(groups, grad, D, out, ws, accumulate=False, grad_div=1, gr
     return out
 
 
-def dropout(x, p, seed, stream_a, stream_b=None, out=None):
+def dropout(x, p, seed, stream_a, stream_b=None, out=None, step_stride=0):
     """Train-mode Dropout (upscale_in_train) on a 2-D float32 matrix (row stride allowed), in place by default.
-    stream_b: a second mask stream applied in the same pass (keep = keepA & keepB, scale 1/(1-p)^2)."""
+    stream_b: a second mask stream applied in the same pass (keep = keepA & keepB, scale 1/(1-p)^2).
+    step_stride: by how much the caller's mask streams advance per training step (a recorded step re-derives them)."""
     if x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda or x.stride(1) != 1:
         raise RecError("x must be a 2-D float32 device tensor with unit column stride")
     if out is None:
         out = x
+    sa, sb = C.c_uint64(int(stream_a)), C.c_uint64(int(stream_b or 0))
+    if _recorder is not None:
+        if not step_stride:
+            raise RecError("dropout inside a recorded step needs step_stride")
+        _recorder.note_step_arg(sa, step_stride)
+        if stream_b is not None:
+            _recorder.note_step_arg(sb, step_stride)
     check(lib().rec_dropout(x.shape[0], x.shape[1], x.stride(0), out.stride(0), _p(x), _p(out), float(p), int(seed),
-                            int(stream_a), int(stream_b or 0), 2 if stream_b is not None else 1, _stream()),
+                            sa, sb, 2 if stream_b is not None else 1, _stream()),
           "rec_dropout")
     return out
 

@@ -30,6 +30,8 @@ class CallPlan:
         self.input_slots = []    # (c_void_p object, input index)
         self.fields = []         # (struct, field name, address at record time): pointers inside descriptor arrays
         self.field_slots = []    # (struct, field name, input index)
+        self.step_args = []      # (c_uint64 object, value at record time, increment per step): counters derived from the step
+        self.step0 = 0
         self.stream = None
         self.outputs = None
 
@@ -37,6 +39,10 @@ class CallPlan:
     def note_pointer(self, p, t):
         self.keep.append(t)
         self.pointers.append((p, t.data_ptr()))
+
+    def note_step_arg(self, obj, stride):
+        """obj (a ctypes integer passed by value) = a + stride * step for some a: re-derived on every replay."""
+        self.step_args.append((obj, int(obj.value), int(stride)))
 
     def note_field(self, obj, field, t):
         self.keep.append(t)
@@ -61,8 +67,10 @@ class CallPlan:
                 return call
         return _Proxy()
 
-    def record(self, fn, inputs):
-        """Run fn() with every C-ABI call listed; inputs: the tensors whose pointers change from step to step."""
+    def record(self, fn, inputs, step0=0):
+        """Run fn() with every C-ABI call listed; inputs: the tensors whose pointers change from step to step; step0: the
+        step count of the recorded step (for arguments registered with note_step_arg)."""
+        self.step0 = int(step0)
         if ops._recorder is not None:
             raise ops.RecError("a step is already being recorded")
         self.stream = ops._stream().value
@@ -92,6 +100,8 @@ class CallPlan:
         for h in self.hypers:
             h.step = step
             h.lr = lr
+        for o, base, stride in self.step_args:
+            o.value = base + (step - self.step0) * stride
         for fn, args in self.calls:
             rc = fn(*args)
             if rc:

@@ -238,7 +238,7 @@ def sparse_rows_sumsq(groups, grad, D, out, ws, accumulate=False, grad_div=1, gr
     return out
 
 
-def dropout(x, p, seed, stream_a, stream_b=None, out=None):
+def dropout(x, p, seed, stream_a, stream_b=None, out=None, step_stride=0):
     from oracle import dcn_v2_ref as X
     xn = _n(x)
     keep = X.dropout_keep(xn.shape, p, seed, stream_a)

@@ -173,6 +173,38 @@ def test_train_mode_dropout_and_l2_vs_oracle(engine_lib, stacked, mix):
     _check_train_mode(DEV, None, stacked, mix)
 
 
+@pytest.mark.parametrize("stacked,drop", [(True, 0.5), (False, 0.5), (True, 0.0)])
+def test_planned_step_equals_eager_step(engine_lib, monkeypatch, stacked, drop):
+    """The DCN-v2 train step replayed from its recorded call list (paddlerec_amd/plan.py: Adam step count AND the
+    per-step dropout mask streams re-derived on every replay) leaves the same bits as the eager step: six steps with
+    fresh inputs, train-mode dropout + L2Decay + clip."""
+    from paddlerec_amd.dcn_v2 import DCN_V2Layer
+    from paddlerec_amd.plan import CallPlan
+    N, D, B, fc = 300, 8, 96, [32, 16]
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("REC_STEP_PLAN", mode)
+        torch.manual_seed(5)
+        m = DCN_V2Layer(N, D, 13, 26, fc, 2, is_Stacked=stacked, device=DEV, dropout_rate=drop, dropout_seed=77,
+                        l2_dnn=1e-3)
+        g = torch.Generator(device=DEV).manual_seed(3)
+        outs = []
+        for step in range(6):
+            ids = torch.randint(0, N, (B, 26), device=DEV, generator=g)
+            dense = torch.rand(B, 13, device=DEV, generator=g)
+            label = (torch.rand(B, 1, device=DEV, generator=g) < 0.3).to(torch.int64)
+            loss, pred = m.train_step(ids, dense, label, lr=1e-2, clip_norm=0.05)
+            outs.append((N_(loss).copy(), N_(pred).copy()))
+        runs[mode] = (outs, N_(m.rec), N_(m.sparse_state["mv"]), N_(m.dense.data), N_(m.dense.m), N_(m.dense.v),
+                      [type(p_) for p_ in m._plans.values()])
+    a, b = runs["1"], runs["0"]
+    assert a[-1] == [CallPlan] and b[-1] == []
+    for (la, pa), (lb, pb) in zip(a[0], b[0]):
+        assert np.array_equal(la, lb) and np.array_equal(pa, pb)
+    for x, y in zip(a[1:6], b[1:6]):
+        assert np.array_equal(x, y)
+
+
 def test_dropout_kernel_matches_oracle_masks(engine_lib):
     from paddlerec_amd import ops
     rng = np.random.default_rng(1)

@@ -1,3 +1,2 @@
-timeout 900 python -m pytest tests/test_din_gpu.py -x -q -m gpu 2>&1 | tail -3
-timeout 300 python tools/din_small_bench.py 2>&1 | tail -3
-REC_DIN_HEAD_SMALL=0 timeout 300 python tools/din_small_bench.py 2>&1 | tail -3 | sed 's/^/HEAD_SMALL=0 /'
+timeout 900 python -m pytest tests/test_dcn_v2_gpu.py -x -q -m gpu 2>&1 | tail -3
+for f in 1 0; do REC_STEP_PLAN=$f timeout 300 python tools/bench_models.py 2>&1 | grep "DCN-v2 CrossNetV2 depth3 B=512" | sed "s/^/PLAN=$f /"; done
