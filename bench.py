@@ -168,7 +168,7 @@ def empty_bracket_us(dev, n=50):
     return sorted(ts)[len(ts) // 2]
 
 
-def other_configs(timeout_s=200):
+def other_configs(timeout_s=120):
     """The other BASELINE configs measured in THIS run on THIS box (subprocesses of the repository's own tools, each under
     its own timeout; a failure is reported, never hidden, and never touches the main line): configs[2] DCN-v2 and
     configs[3] DIN train steps + the sibling nets (tools/bench_models.py), row P = the multi-slot pool kernel and the
