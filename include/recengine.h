@@ -90,6 +90,14 @@ int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense, const flo
                       const float* sum_emb, const float* d_feat_dnn, const float* dy1,
                       const float* dy2, const float* dense_w, float* row_grad, float* d_dense_w,
                       float* d_dense_w_one, void* workspace, size_t workspace_bytes, void* stream);
+/* The same backward with the SelectedRows value written in SORTED order: the gradient row of lookup (b, s) goes to
+ * row_grad + row_rank[b*S+s] * D (row_rank from rec_ids_group_slots / rec_ids_rank; < 0 = padding, not written), so the
+ * merge + optimizer kernel reads every row's duplicates as consecutive rows (rec_grad_layout.sorted = 1). */
+int rec_deepfm_fm_bwd_sorted(const rec_deepfm_desc* desc, const float* dense, const float* feat,
+                             const float* sum_emb, const float* d_feat_dnn, const float* dy1,
+                             const float* dy2, const float* dense_w, const int32_t* row_rank, float* row_grad,
+                             float* d_dense_w, float* d_dense_w_one, void* workspace, size_t workspace_bytes,
+                             void* stream);
 
 /* Folding the dense "embeddings" into the first MLP layer (compact_dense = 1 above).
  *   fwd: M[j,n] = sum_d dense_w[j,d] * W0[(S+j)*D + d, n]                    -> M [Dn, n_out]
@@ -217,6 +225,24 @@ int rec_ids_group_payload(int64_t n, int32_t num_slots, int64_t num_rows, int64_
                           int32_t* sorted_pos, int64_t* uniq_rows, int32_t* seg_offset, int32_t* n_uniq,
                           int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same grouping for a [batch, num_slots] id batch whose slot s owns rows [s * slot_rows, (s + 1) * slot_rows) of the
+ * table (BASELINE configs[1]: 26 tables x 1 000 000 rows as one table; deepfm/net.py:62-86 with one nn.Embedding per
+ * slot) — i.e. rec_ids_group with slot_offset[s] = s * slot_rows and num_rows = num_slots * slot_rows, bit-identical
+ * outputs, except that an id outside [0, slot_rows) is flagged REC_FLAG_INDEX_OOB and dropped (with separate tables it
+ * IS out of range).  The slot digit of the key is free (column s of the batch is slot s), so the sort is num_slots
+ * independent two-digit sorts inside L2-resident 256 KB slices: 7 launches instead of 13 (csrc/ids_group_slots.hip);
+ * shapes that path does not cover (batch < 8192, slot_rows > 2^20, num_slots > 60) take the general sort.
+ *   rank [batch*num_slots] i32 or NULL: rank[pos] = k with sorted_pos[k] = pos, -1 for dropped lookups — where a
+ *   producer writes the gradient row of lookup pos so that the gradient buffer is in sorted order
+ *   (rec_grad_layout.sorted). */
+int rec_ids_group_slots_workspace_bytes(int64_t batch, int32_t num_slots, int64_t slot_rows, size_t* bytes);
+int rec_ids_group_slots(int64_t batch, int32_t num_slots, int64_t slot_rows, int64_t padding_idx, const int64_t* ids,
+                        int32_t* sorted_pos, int64_t* uniq_rows, int32_t* seg_offset, int32_t* n_uniq, int32_t* rank,
+                        int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+/* rank of any grouping whose sorted_pos holds positions (no payload): rank[0, n) = -1, then rank[sorted_pos[k]] = k for
+ * k < n_uniq[1]. */
+int rec_ids_rank(int64_t n, const int32_t* n_uniq, const int32_t* sorted_pos, int32_t* rank, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimizers.  paddle.optimizer.Adam [EXT] (deepfm/dygraph_model.py:61-65, static_model.py:83-84):
  *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m = b1*m+(1-b1)*g;  v = b2*v+(1-b2)*g*g;
@@ -241,6 +267,10 @@ typedef struct {
   int64_t group_stride;
   const float* partials; /* device, from rec_segment_partials for THIS grad + grouping, or NULL */
   const int32_t* index;  /* device [n] or NULL: lookup position -> gradient position */
+  int32_t sorted;        /* 1: grad is [n, D] in SORTED order — row k belongs to sorted position k (written through
+                          * the rank of rec_ids_group_slots / rec_ids_rank, e.g. by rec_deepfm_fm_bwd_sorted); div,
+                          * group, group_stride and index are then ignored.  A row's duplicate gradients are
+                          * consecutive rows: the update kernels stream them instead of chasing sorted_pos. */
 } rec_grad_layout;
 
 /* Hot rows.  With Zipf-distributed ids one row can own tens of thousands of the n lookups; the per-row
@@ -865,6 +895,10 @@ int rec_stream_spin(int32_t micros, void* stream);
  * merely share all CUs do not co-schedule (the GEMM's long-lived blocks hold every wave slot).  The stream is a
  * plain hipStream_t owned by the caller: rec_stream_destroy when done. */
 int rec_stream_create_cu_range(int32_t cu_begin, int32_t cu_end, void** stream);
+/* ... or to every `stride`-th compute unit starting at `first` (bits first, first + stride, ... < cu_total of the HSA CU
+ * mask): a share of the chip that takes the same number of CUs from every XCD whatever the bit -> XCD layout is
+ * (workgroup b runs on XCD b % 8, so a contiguous range would starve one XCD's share of every other kernel). */
+int rec_stream_create_cu_stride(int32_t first, int32_t stride, int32_t cu_total, void** stream);
 int rec_stream_destroy(void* stream);
 
 #ifdef __cplusplus

@@ -33,7 +33,7 @@ class AdagradHyper(C.Structure):
 
 class GradLayout(C.Structure):
     _fields_ = [("div", C.c_int32), ("group", C.c_int32), ("group_stride", C.c_int64),
-                ("partials", C.c_void_p), ("index", C.c_void_p)]
+                ("partials", C.c_void_p), ("index", C.c_void_p), ("sorted", C.c_int32)]
 
 
 class SmallSgdJob(C.Structure):
@@ -121,6 +121,7 @@ SIGNATURES = {
     "rec_deepfm_fm_fwd": (C.c_int, [C.POINTER(DeepFMDesc)] + [_P] * 13),
     "rec_deepfm_fm_bwd_workspace_bytes": (C.c_int, [C.POINTER(DeepFMDesc), C.POINTER(_SZ)]),
     "rec_deepfm_fm_bwd": (C.c_int, [C.POINTER(DeepFMDesc)] + [_P] * 11 + [_SZ, _P]),
+    "rec_deepfm_fm_bwd_sorted": (C.c_int, [C.POINTER(DeepFMDesc)] + [_P] * 12 + [_SZ, _P]),
     "rec_dense_fold_fwd": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "rec_dense_fold_bwd": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "rec_emb_gather": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, _P, _I32, _I64, _P, _P]),
@@ -129,6 +130,9 @@ SIGNATURES = {
     "rec_ids_group_workspace_bytes": (C.c_int, [_I64, _I64, C.POINTER(_SZ)]),
     "rec_ids_group": (C.c_int, [_I64, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rec_ids_group_payload": (C.c_int, [_I64, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "rec_ids_group_slots_workspace_bytes": (C.c_int, [_I64, _I32, _I64, C.POINTER(_SZ)]),
+    "rec_ids_group_slots": (C.c_int, [_I64, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "rec_ids_rank": (C.c_int, [_I64, _P, _P, _P, _P]),
     "rec_segment_partials_bytes": (C.c_int, [_I64, _I32, C.POINTER(C.c_size_t)]),
     "rec_segment_partials": (C.c_int, [_I64, _I32, _P, _P, _P, _P, C.POINTER(GradLayout), _P, _P]),
     "rec_sparse_adam_rows": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
@@ -230,6 +234,7 @@ SIGNATURES = {
     "rec_stream_spin": (C.c_int, [_I32, _P]),
     "rec_copy_async": (C.c_int, [_P, _P, _SZ, _P]),
     "rec_stream_create_cu_range": (C.c_int, [_I32, _I32, C.POINTER(C.c_void_p)]),
+    "rec_stream_create_cu_stride": (C.c_int, [_I32, _I32, _I32, C.POINTER(C.c_void_p)]),
     "rec_stream_destroy": (C.c_int, [_P]),
 }
 

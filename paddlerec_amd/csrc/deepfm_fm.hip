@@ -248,7 +248,10 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
     int64_t B, int S, int Dn, int D, int FP, const float* __restrict__ dense,
     const float* __restrict__ feat, const float* __restrict__ sum_emb,
     const float* __restrict__ dfeat, const float* __restrict__ dy1, const float* __restrict__ dy2,
-    const float* __restrict__ dense_w, float* __restrict__ row_grad, float* __restrict__ partial, int rg_nt) {
+    const float* __restrict__ dense_w, float* __restrict__ row_grad, float* __restrict__ partial, int rg_nt,
+    const int32_t* __restrict__ rank) {
+  // rank (or null): the row gradient of lookup (b, f) goes to row rank[b*S+f] of row_grad instead of row b*S+f — the
+  // SORTED order of the merge keys (rec_ids_group_slots), < 0 = a dropped lookup, not written
   constexpr int FS = fs_for<LANES>();
   constexpr int SPW = kWave / (LANES * FS);
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [waves][Dn*D + Dn]
@@ -296,16 +299,20 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
     const bool compact = FP != F;   // dense fields have no rows in feat / dfeat: their d_dnn part is handled
                                     // by the caller through the folded layer-0 weights (see header)
     float* rg = row_grad + (b * S) * (int64_t)D + d0;
+    const int32_t* rkb = rank ? rank + b * S : nullptr;
     // wave iterations that (may) hold dense fields first: their loads are the irregular ones
     float ed[NDI][VEC], gd[NDI][VEC], xd[NDI];
+    int rkd[NDI];
 #pragma unroll
     for (int k = 0; k < NDI; ++k) {
       const int f = (it_d0 + k) * FS + fs;
       const bool ok = k < nd && dvalid && f < F;
       xd[k] = 0.f;
+      rkd[k] = -1;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) ed[k][v] = gd[k][v] = 0.f;
       if (ok) {
+        if (rkb && f < S) rkd[k] = rkb[f];
         if (!(compact && f >= S)) vload<VEC>(gd[k], gb + (int64_t)f * D);
         if (f >= S) xd[k] = dense[b * Dn + (f - S)];
         if (f < S || !dense_w) vload<VEC>(ed[k], fb + (int64_t)f * D);
@@ -314,10 +321,13 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
     // wave iterations holding sparse fields only: d row = d_dnn + dy2 * (sum_emb - feat)
     for (int it0 = 0; it0 < it_d0; it0 += kBwdUnroll) {
       float e[kBwdUnroll][VEC], g[kBwdUnroll][VEC];
+      int rk[kBwdUnroll];
 #pragma unroll
       for (int u = 0; u < kBwdUnroll; ++u) {
+        rk[u] = -1;
         if (dvalid && it0 + u < it_d0) {
           const int f = (it0 + u) * FS + fs;
+          if (rkb) rk[u] = rkb[f];
           if (NT) {   // read-once streams: do not displace the table lines other kernels will want in L2
             vload_nt<VEC>(e[u], fb + (int64_t)f * D);
             vload_nt<VEC>(g[u], gb + (int64_t)f * D);
@@ -334,7 +344,12 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
           float de[VEC];
 #pragma unroll
           for (int v = 0; v < VEC; ++v) de[v] = g[u][v] + g2 * (sb[v] - e[u][v]);
-          if (rg_nt) vstore_nt<VEC>(rg + (int64_t)f * D, de); else vstore<VEC>(rg + (int64_t)f * D, de);
+          if (rkb) {
+            if (rk[u] >= 0) {
+              if (rg_nt) vstore_nt<VEC>(row_grad + (int64_t)rk[u] * D + d0, de);
+              else vstore<VEC>(row_grad + (int64_t)rk[u] * D + d0, de);
+            }
+          } else if (rg_nt) vstore_nt<VEC>(rg + (int64_t)f * D, de); else vstore<VEC>(rg + (int64_t)f * D, de);
         }
       }
     }
@@ -350,7 +365,12 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
           de[v] = gd[k][v] + g2 * (sb[v] - e);
         }
         if (!isd) {
-          if (rg_nt) vstore_nt<VEC>(rg + (int64_t)f * D, de); else vstore<VEC>(rg + (int64_t)f * D, de);
+          if (rkb) {
+            if (rkd[k] >= 0) {
+              if (rg_nt) vstore_nt<VEC>(row_grad + (int64_t)rkd[k] * D + d0, de);
+              else vstore<VEC>(row_grad + (int64_t)rkd[k] * D + d0, de);
+            }
+          } else if (rg_nt) vstore_nt<VEC>(rg + (int64_t)f * D, de); else vstore<VEC>(rg + (int64_t)f * D, de);
         } else {
 #pragma unroll
           for (int v = 0; v < VEC; ++v) acc[k][v] += xd[k] * de[v];
@@ -509,11 +529,34 @@ extern "C" int rec_deepfm_fm_bwd_workspace_bytes(const rec_deepfm_desc* desc, si
   return REC_OK;
 }
 
+static int fm_bwd_impl(const rec_deepfm_desc* desc, const float* dense, const float* feat, const float* sum_emb,
+                       const float* d_feat_dnn, const float* dy1, const float* dy2, const float* dense_w,
+                       const int32_t* row_rank, float* row_grad, float* d_dense_w, float* d_dense_w_one,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense,
                                  const float* feat, const float* sum_emb, const float* d_feat_dnn,
                                  const float* dy1, const float* dy2, const float* dense_w,
                                  float* row_grad, float* d_dense_w, float* d_dense_w_one,
                                  void* workspace, size_t workspace_bytes, void* stream) {
+  return fm_bwd_impl(desc, dense, feat, sum_emb, d_feat_dnn, dy1, dy2, dense_w, nullptr, row_grad, d_dense_w,
+                     d_dense_w_one, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rec_deepfm_fm_bwd_sorted(const rec_deepfm_desc* desc, const float* dense, const float* feat,
+                                        const float* sum_emb, const float* d_feat_dnn, const float* dy1,
+                                        const float* dy2, const float* dense_w, const int32_t* row_rank,
+                                        float* row_grad, float* d_dense_w, float* d_dense_w_one, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  REC_REQUIRE(row_rank || (desc && desc->batch == 0), REC_EINVAL, "row_rank is NULL");
+  return fm_bwd_impl(desc, dense, feat, sum_emb, d_feat_dnn, dy1, dy2, dense_w, row_rank, row_grad, d_dense_w,
+                     d_dense_w_one, workspace, workspace_bytes, stream);
+}
+
+static int fm_bwd_impl(const rec_deepfm_desc* desc, const float* dense, const float* feat, const float* sum_emb,
+                       const float* d_feat_dnn, const float* dy1, const float* dy2, const float* dense_w,
+                       const int32_t* row_rank, float* row_grad, float* d_dense_w, float* d_dense_w_one,
+                       void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_desc(desc)) return rc;
   const int S = desc->num_slots, Dn = desc->num_dense, D = desc->emb_dim;
   REC_REQUIRE(Dn == 0 || (d_dense_w && d_dense_w_one), REC_EINVAL, "dense args missing");
@@ -559,7 +602,7 @@ extern "C" int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense
     grid = (int)g;                                                                                \
     hipLaunchKernelGGL((fm_bwd_kernel<VEC, LANES, NDI, NT_>), dim3(grid), dim3(kBlock), shmem, st, \
                        desc->batch, S, Dn, D, FP, dense, feat, sum_emb, d_feat_dnn, dy1, dy2,      \
-                       dense_w, row_grad, partial, tune().rg_nt);                                  \
+                       dense_w, row_grad, partial, tune().rg_nt, row_rank);                        \
   }
 #define REC_BWD_LAUNCH(NDI) if (tune().nt) REC_BWD_LAUNCH2(NDI, true) else REC_BWD_LAUNCH2(NDI, false)
     if (nd <= 1) { REC_BWD_LAUNCH(1); }

@@ -856,7 +856,8 @@ __global__ __launch_bounds__(kBlock) void mlp_head_fold_kernel(int nblk, int N, 
 }
 
 // ------------------------------------------------------------------------------- config selection
-enum GemmCfg { CFG_128x80 = 0, CFG_256x80, CFG_256x128, CFG_128x128, CFG_80x80, CFG_64x80, CFG_128x80_O4, CFG_COUNT };
+enum GemmCfg { CFG_128x80 = 0, CFG_256x80, CFG_256x128, CFG_128x128, CFG_80x80, CFG_64x80, CFG_128x80_O4, CFG_144x80,
+               CFG_COUNT };
 struct CfgInfo {
   int bm, bn, threads, occ;
   float eff;   // relative throughput of a full tile of this config (tools/gemm_lab measurements)
@@ -865,6 +866,10 @@ static const CfgInfo kCfg[CFG_COUNT] = {
     {128, 80, 256, 5, 1.00f},  {256, 80, 512, 2, 0.97f}, {256, 128, 512, 2, 1.08f},
     {128, 128, 256, 4, 1.00f}, {80, 80, 320, 4, 0.98f},  {64, 80, 256, 6, 0.97f},
     {128, 80, 256, 4, 1.00f},   // 128x80 built for 4 blocks/CU (128 VGPRs: no spills) — experiment
+    // 9 waves x (16 x 80): the 80x80 weight-gradient tile with 144 rows — DeepFM's layer-0 weight gradient has M = 432 =
+    // 27 x 16 = 3 x 144 rows (26 embedding fields + the dense row, x 16), which 80-row tiles pad to 480 and keep off the
+    // whole-tile pipe kernel (64 TF, the long pole of the step's tail)
+    {144, 80, 576, 2, 0.98f},
 };
 
 struct GemmPlan {
@@ -899,6 +904,10 @@ static GemmPlan plan_gemm(const rec_gemm_desc* d, int num_cus = kNumCU) {
     const int64_t a80 = ceil_div64(d->m, 80) * 80 * ceil_div64(d->n, 80) * 80;
     const int64_t a128 = ceil_div64(d->m, 128) * 128 * ceil_div64(d->n, 128) * 128;
     best = a80 * 5 <= a128 * 4 ? CFG_80x80 : CFG_128x128;
+    static const bool cfg144 = [] { const char* v = getenv("REC_GEMM_144"); return !(v && *v == '0'); }();
+    if (cfg144 && best == CFG_80x80 && d->trans_a && !d->trans_b && d->epilogue == REC_EPI_NONE && d->m % 144 == 0 &&
+        d->m % 80 != 0 && d->n % 80 == 0)
+      best = CFG_144x80;
     // few rows AND a short K (the reference's own batch sizes: 512 x 400 x 432): a 128x128 tile gives a wave 64 MFMAs
     // per k-step and the problem 16 blocks — 47 us on 16 of 256 CUs.  64x80 tiles (20 MFMAs per wave and k-step, 2.5x
     // the blocks) and a K split fill the chip: ~10 us incl. the reduce (profiles/r03_small_batch.txt)
@@ -912,7 +921,7 @@ static GemmPlan plan_gemm(const rec_gemm_desc* d, int num_cus = kNumCU) {
   }
   {   // experiments: REC_GEMM_FORCE_CFG=<index> overrides the choice (tools/gemm_lab)
     static const int forced = [] { const char* v = getenv("REC_GEMM_FORCE_CFG"); return v && *v ? atoi(v) : -1; }();
-    if (forced >= 0 && forced < CFG_COUNT) best = forced;
+    if (forced >= 0 && forced < CFG_COUNT && forced != CFG_144x80) best = forced;
   }
   p.cfg = best;
   const CfgInfo& f = kCfg[best];
@@ -974,7 +983,8 @@ static void launch_one(const rec_gemm_desc* d, const GemmPlan& p, const float* A
   static_assert(shmem <= 64 * 1024, "LDS tile too large");
   // candidate schedule (see gemm_f32_pipe_kernel): whole-tile problems on the two tiles that have the registers for it,
   // epilogues of the MLP path; opt-in until it has been through the full GPU suite
-  constexpr bool kPipeCfg = ((BM == 256 && BN == 80 && WM_ == 8) || (BM == 80 && BN == 80 && WM_ == 5)) && !(TA && TB) &&
+  constexpr bool kPipeCfg = ((BM == 256 && BN == 80 && WM_ == 8) || (BM == 80 && BN == 80 && WM_ == 5) ||
+                             (BM == 144 && BN == 80 && WM_ == 9)) && !(TA && TB) &&
                             (EPI == REC_EPI_NONE || EPI == REC_EPI_BIAS || EPI == REC_EPI_BIAS_RELU ||
                              EPI == REC_EPI_RELU_MASK);
   if constexpr (kPipeCfg) {
@@ -1003,6 +1013,13 @@ static void launch_cfg(const rec_gemm_desc* d, const GemmPlan& p, const float* A
     case CFG_80x80: launch_one<80, 80, 5, 1, 4, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st); break;
     case CFG_64x80: launch_one<64, 80, 4, 1, 6, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st); break;
     case CFG_128x80_O4: launch_one<128, 80, 4, 1, 4, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st); break;
+    case CFG_144x80:     // planned only for dW = X^T G without an epilogue (plan_gemm)
+      if constexpr (TA && !TB && EPI == REC_EPI_NONE) {
+        launch_one<144, 80, 9, 1, 2, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st);
+      } else {
+        launch_one<80, 80, 5, 1, 4, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st);
+      }
+      break;
     default: launch_one<128, 128, 2, 2, 4, TA, TB, EPI>(d, p, A, B, C, e, partial, cpart, st); break;
   }
 }

@@ -243,6 +243,20 @@ extern "C" int rec_stream_create_cu_range(int32_t cu_begin, int32_t cu_end, void
   return REC_OK;
 }
 
+extern "C" int rec_stream_create_cu_stride(int32_t first, int32_t stride, int32_t cu_total, void** stream) {
+  REC_REQUIRE(stream && first >= 0 && stride >= 1 && cu_total > first && cu_total <= 1024, REC_EINVAL, "bad CU stride");
+  uint32_t mask[32] = {0};
+  for (int i = first; i < cu_total; i += stride) mask[i / 32] |= 1u << (i % 32);
+  hipStream_t s = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)((cu_total + 31) / 32), mask);
+  if (e != hipSuccess) {
+    set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    return REC_EHIP;
+  }
+  *stream = (void*)s;
+  return REC_OK;
+}
+
 extern "C" int rec_stream_destroy(void* stream) {
   if (!stream) return REC_OK;
   const hipError_t e = hipStreamDestroy((hipStream_t)stream);

@@ -14,6 +14,7 @@
 #include <cmath>
 
 #include "radix_sort.h"
+#include "slot_group.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -35,12 +36,14 @@ struct IdsSrc {
   int32_t* status;
   const int32_t* payload;   // what travels with the key: payload[i], or the position i itself when null
   bool drop_invalid;        // the sort leaves the sentinel keys out after its first pass (rsort::sort_pairs n_live)
+  int64_t slot_rows = 0;    // > 0 (rec_ids_group_slots): slot s owns rows [s * slot_rows, (s + 1) * slot_rows)
   __device__ __forceinline__ bool drop(KeyT k) const { return drop_invalid && k == (KeyT)N; }
   __device__ __forceinline__ KeyT key(int64_t i) const {
     const int64_t id = ids[i];
     KeyT k = (KeyT)N;
     if (id != pad || pad < 0) {
-      const int64_t r = slot_off ? id + slot_off[(int)i % S] : id;
+      int64_t r = slot_off ? id + slot_off[(int)i % S] : id;
+      if (slot_rows > 0) r = (id >= 0 && id < slot_rows) ? id + (int64_t)((int)i % S) * slot_rows : -1;
       if (r >= 0 && r < N) k = (KeyT)r; else atomicOr(status, REC_FLAG_INDEX_OOB);
     }
     return k;
@@ -205,7 +208,7 @@ template <class KeyT>
 static int run_group(int64_t n, int S, int64_t N, int64_t pad, const int64_t* ids,
                      const int64_t* slot_off, const int32_t* payload, int32_t* sorted_pos, int64_t* uniq,
                      int32_t* seg_off, int32_t* n_uniq, int32_t* status, void* ws, size_t ws_bytes,
-                     hipStream_t st) {
+                     hipStream_t st, int64_t slot_rows = 0) {
   GroupPlan<KeyT> p;
   if (int rc = plan_group<KeyT>(n, N, &p)) return rc;
   REC_REQUIRE(ws && ws_bytes >= p.total, REC_EWORKSPACE, "workspace %zu < %zu", ws_bytes, p.total);
@@ -217,7 +220,7 @@ static int run_group(int64_t n, int S, int64_t N, int64_t pad, const int64_t* id
   // padding and out-of-range lookups leave the sort after its first pass (REC_GROUP_DROP=0: carried through every pass)
   static const bool drop = [] { const char* v = getenv("REC_GROUP_DROP"); return !(v && *v == '0'); }();
   const bool dr = drop && n < (1ll << 31);
-  IdsSrc<KeyT> src{ids, slot_off, S, N, pad, status, payload, dr};
+  IdsSrc<KeyT> src{ids, slot_off, S, N, pad, status, payload, dr, slot_rows};
   if (int rc = rsort::sort_pairs<KeyT>(n, p.sort, src, keys_tmp, vals_tmp, keys_dst, sorted_pos,
                                        base + p.off_hist, base + p.off_totals, st,
                                        dr ? (int32_t*)(base + p.off_nlive) : nullptr, (KeyT)N))
@@ -238,6 +241,12 @@ __device__ __forceinline__ int64_t grad_offset(const rec_grad_layout& gl, int po
   const int q = gl.div > 1 ? p / gl.div : p;
   return gl.group > 0 ? (int64_t)(q / gl.group) * gl.group_stride + (int64_t)(q % gl.group) * D
                       : (int64_t)q * D;
+}
+// ... of SORTED position k: the k-th row of grad when the producer wrote its rows in sorted order (rec_grad_layout.sorted:
+// rec_deepfm_fm_bwd_sorted through the rank of rec_ids_group_slots) — consecutive segments then read consecutive
+// memory and the dependent sorted_pos read drops out of the chain
+__device__ __forceinline__ int64_t grad_at(const rec_grad_layout& gl, const int32_t* __restrict__ spos, int k, int D) {
+  return gl.sorted ? (int64_t)k * D : grad_offset(gl, spos[k], D);
 }
 
 
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void segment_partials_kernel(
     if (d0 < D)
       for (int k = a + grp; k < b; k += G) {
         float t[VEC];
-        vload<VEC>(t, grad + grad_offset(gl, spos[k], D) + d0);
+        vload<VEC>(t, grad + grad_at(gl, spos, k, D) + d0);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) g[i] += t[i];
       }
@@ -337,17 +346,16 @@ __device__ __forceinline__ void segment_sum(float (&g)[VEC], int beg, int end,
   if (end - beg >= 8)   // short rows (the common case) stay on the plain loop: no divergence inside a wave
   for (; k + 4 <= end; k += 4) {
     float a[VEC], b[VEC], c[VEC], d[VEC];
-    const int p0 = spos[k], p1 = spos[k + 1], p2 = spos[k + 2], p3 = spos[k + 3];
-    vload<VEC>(a, grad + grad_offset(gl, p0, D) + d0);
-    vload<VEC>(b, grad + grad_offset(gl, p1, D) + d0);
-    vload<VEC>(c, grad + grad_offset(gl, p2, D) + d0);
-    vload<VEC>(d, grad + grad_offset(gl, p3, D) + d0);
+    vload<VEC>(a, grad + grad_at(gl, spos, k, D) + d0);
+    vload<VEC>(b, grad + grad_at(gl, spos, k + 1, D) + d0);
+    vload<VEC>(c, grad + grad_at(gl, spos, k + 2, D) + d0);
+    vload<VEC>(d, grad + grad_at(gl, spos, k + 3, D) + d0);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) g[i] = (((g[i] + a[i]) + b[i]) + c[i]) + d[i];
   }
   for (; k < end; ++k) {
     float a[VEC];
-    vload<VEC>(a, grad + grad_offset(gl, spos[k], D) + d0);
+    vload<VEC>(a, grad + grad_at(gl, spos, k, D) + d0);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) g[i] += a[i];
   }
@@ -463,8 +471,8 @@ __device__ __forceinline__ void narrow_segment_sum(float (&g)[NV * 4], int beg, 
   }
   int k = beg;
   for (; k + 2 <= end; k += 2) {
-    const float* a = grad + grad_offset(gl, spos[k], D);
-    const float* b = grad + grad_offset(gl, spos[k + 1], D);
+    const float* a = grad + grad_at(gl, spos, k, D);
+    const float* b = grad + grad_at(gl, spos, k + 1, D);
     float x[NV * 4], y[NV * 4];
 #pragma unroll
     for (int d = 0; d < NV * 4; ++d) { x[d] = d < D ? a[d] : 0.f; y[d] = d < D ? b[d] : 0.f; }
@@ -472,7 +480,7 @@ __device__ __forceinline__ void narrow_segment_sum(float (&g)[NV * 4], int beg, 
     for (int d = 0; d < NV * 4; ++d) g[d] = (g[d] + x[d]) + y[d];
   }
   if (k < end) {
-    const float* a = grad + grad_offset(gl, spos[k], D);
+    const float* a = grad + grad_at(gl, spos, k, D);
 #pragma unroll
     for (int d = 0; d < NV * 4; ++d) g[d] += d < D ? a[d] : 0.f;
   }
@@ -1000,6 +1008,68 @@ extern "C" int rec_ids_group(int64_t n, int32_t num_slots, int64_t num_rows, int
                              void* stream) {
   return rec_ids_group_payload(n, num_slots, num_rows, padding_idx, ids, slot_offset, nullptr, sorted_pos,
                                uniq_rows, seg_offset, n_uniq, status, workspace, workspace_bytes, stream);
+}
+
+namespace rec {
+__global__ void rank_fill_kernel(int64_t n, int32_t* __restrict__ rank) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rank[i] = -1;
+}
+__global__ void rank_scatter_kernel(const int32_t* __restrict__ n_uniq, const int32_t* __restrict__ spos,
+                                    int32_t* __restrict__ rank) {
+  const int nv = n_uniq[1];
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nv; k += (int64_t)gridDim.x * blockDim.x)
+    rank[spos[k]] = (int32_t)k;
+}
+}  // namespace rec
+
+extern "C" int rec_ids_rank(int64_t n, const int32_t* n_uniq, const int32_t* sorted_pos, int32_t* rank, void* stream) {
+  REC_REQUIRE(n >= 0 && n < (1ll << 31) - 1, REC_EINVAL, "bad n");
+  if (n == 0) return REC_OK;
+  REC_REQUIRE(n_uniq && sorted_pos && rank, REC_EINVAL, "null pointer argument");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(rank_fill_kernel, dim3(grid), dim3(kBlock), 0, st, n, rank);
+  hipLaunchKernelGGL(rank_scatter_kernel, dim3(grid < 2048u ? grid : 2048u), dim3(kBlock), 0, st, n_uniq, sorted_pos, rank);
+  return check_launch("rec_ids_rank");
+}
+
+extern "C" int rec_ids_group_slots_workspace_bytes(int64_t batch, int32_t num_slots, int64_t slot_rows, size_t* bytes) {
+  REC_REQUIRE(bytes && batch >= 0 && num_slots > 0 && slot_rows > 0, REC_EINVAL, "bad arguments");
+  REC_REQUIRE(batch * num_slots < (1ll << 31) - 1, REC_ESHAPE, "batch x slots too large for int32 positions");
+  if (batch == 0) { *bytes = 256; return REC_OK; }
+  if (sg::eligible(batch, num_slots, slot_rows)) { *bytes = sg::workspace_bytes(batch, num_slots, slot_rows); return REC_OK; }
+  return rec_ids_group_workspace_bytes(batch * num_slots, slot_rows * num_slots, bytes);
+}
+
+extern "C" int rec_ids_group_slots(int64_t batch, int32_t num_slots, int64_t slot_rows, int64_t padding_idx,
+                                   const int64_t* ids, int32_t* sorted_pos, int64_t* uniq_rows, int32_t* seg_offset,
+                                   int32_t* n_uniq, int32_t* rank, int32_t* status, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  REC_REQUIRE(batch >= 0 && num_slots > 0 && slot_rows > 0, REC_EINVAL, "bad sizes");
+  const int64_t n = batch * num_slots;
+  REC_REQUIRE(n < (1ll << 31) - 1, REC_ESHAPE, "batch x slots too large for int32 positions");
+  REC_REQUIRE(sorted_pos && uniq_rows && seg_offset && n_uniq && status, REC_EINVAL, "null pointer argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    (void)hipMemsetAsync(n_uniq, 0, 4 * sizeof(int32_t), st);
+    (void)hipMemsetAsync(seg_offset, 0, sizeof(int32_t), st);
+    return REC_OK;
+  }
+  REC_REQUIRE(ids, REC_EINVAL, "ids is NULL");
+  if (sg::eligible(batch, num_slots, slot_rows))
+    return sg::run(batch, num_slots, slot_rows, padding_idx, ids, sorted_pos, uniq_rows, seg_offset, n_uniq, rank, status,
+                   workspace, workspace_bytes, st);
+  const int64_t N = slot_rows * num_slots;
+  int rc;
+  if (use_u32_keys(N))
+    rc = run_group<uint32_t>(n, num_slots, N, padding_idx, ids, nullptr, nullptr, sorted_pos, uniq_rows, seg_offset,
+                             n_uniq, status, workspace, workspace_bytes, st, slot_rows);
+  else
+    rc = run_group<uint64_t>(n, num_slots, N, padding_idx, ids, nullptr, nullptr, sorted_pos, uniq_rows, seg_offset,
+                             n_uniq, status, workspace, workspace_bytes, st, slot_rows);
+  if (rc != REC_OK || !rank) return rc;
+  return rec_ids_rank(n, n_uniq, sorted_pos, rank, stream);
 }
 
 extern "C" int rec_segment_partials_bytes(int64_t n_max, int32_t emb_dim, size_t* bytes) {

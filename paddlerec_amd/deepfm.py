@@ -164,7 +164,13 @@ class DeepFMLayer:
         self.dense_feature_dim = dense_feature_dim
         self.sparse_num_field = sparse_num_field
         self.layer_sizes = list(layer_sizes)
+        # slot s owning rows [s*R, (s+1)*R) (BASELINE configs[1]: 26 tables x 1M rows as one table): the merge keys are
+        # then sorted slot by slot (rec_ids_group_slots) and fm_bwd writes its row gradients in sorted order
+        self.slot_rows = None
         if slot_offset is not None:
+            so = [int(x) for x in torch.as_tensor(slot_offset).reshape(-1).tolist()]
+            if len(so) >= 2 and so[0] == 0 and so[1] > 0 and all(so[i] == i * so[1] for i in range(len(so))):
+                self.slot_rows = so[1]
             slot_offset = torch.as_tensor(slot_offset, dtype=torch.int64, device=self.device)
         self.fm = FM(table_rows if table_rows is not None else sparse_feature_number,
                      sparse_feature_dim, dense_feature_dim, sparse_num_field, self.device,
@@ -348,14 +354,38 @@ class DeepFMLayer:
                  and hasattr(self.k, "sparse_adam_record_small")
                  and os.environ.get("REC_SMALL_MERGE", "1") != "0")
 
+        # slot-local grouping + row gradients in sorted order (round 4): the update kernel streams its gradient rows
+        # instead of chasing sorted_pos into a 109 MB buffer (REC_DEEPFM_SORTED=0: the general sort, position order)
+        slot_sort = (not small and self.slot_rows is not None
+                     and hasattr(self.k, "group_slots_eligible") and self.k.group_slots_eligible(B, S, self.slot_rows)
+                     and os.environ.get("REC_DEEPFM_SORTED", "1") != "0")
+        # REC_DEEPFM_SORTED=2 (measurement): the slot-local sort without the rank, gradients in position order
+        sorted_rg = slot_sort and self.lazy_mode and os.environ.get("REC_DEEPFM_SORTED", "1") != "2"
+
+        # REC_DEEPFM_GROUP_CUS=<stride>[,range]: the grouping on its own stream confined to every stride-th CU ("k,r":
+        # the first r CUs) — the 256x80 GEMM blocks fill the VGPR file (4 waves x 128 per SIMD), so a sort block can
+        # only run where a GEMM block is not: confined to a few CUs it packs there instead of displacing GEMM blocks
+        # all over the chip
+        gspec = os.environ.get("REC_DEEPFM_GROUP_CUS", "")
+        gside = side
+        if gspec and side is not None and hasattr(self.k, "cu_stride_stream"):
+            if "," in gspec:
+                gside = self.k.cu_range_stream(self.device, 0, int(gspec.split(",")[1]))
+            else:
+                gside = self.k.cu_stride_stream(self.device, 0, int(gspec))
+
         def issue_group():
             if small:
                 return
             if self.step_count > 3 and os.environ.get("REC_DEEPFM_SKIP_GROUP", "0") == "1":
                 return      # MEASUREMENT ONLY: the step without its grouping sort (stale groups: wrong results)
-            with _OnSide(side, cur):
-                self.k.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
-                                 self.fm.slot_offset, self.status, groups)
+            with _OnSide(gside, cur):
+                if slot_sort:
+                    self.k.ids_group_slots(ids, self.slot_rows, self.fm.padding_idx, self.ws_group, self.status, groups,
+                                           want_rank=sorted_rg)
+                else:
+                    self.k.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
+                                     self.fm.slot_offset, self.status, groups)
         if group_at == "fwd":
             issue_group()
         mlp_w, mlp_dw = self._mlp_weights()
@@ -384,19 +414,25 @@ class DeepFMLayer:
             kw.update(dw_stream=self._dw_stream, dw_ws=self._ws_dw)
         with self._timed("mlp_bwd"):
             d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db, self.ws_mlp, **kw)
+        if group_at == "tail":
+            issue_group()
+        if sorted_rg and side is not None:
+            cur.wait_stream(gside)          # fm_bwd scatters through the rank the grouping (side stream) produced
         with self._timed("fm_bwd"):
             row_grad, _, _ = self.k.deepfm_fm_bwd(
                 dense_inputs, feat, sum_emb, d_flat.view(B, self.fp, -1), dz, dz, S, self.ws,
                 out=(self._row_grad_buf(B * S),
                      self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
                      self.dense.g["fm.dense_w_one"]),
-                dense_w=self.dense.p["fm.dense_w"], compact=self.compact)
+                dense_w=self.dense.p["fm.dense_w"], compact=self.compact,
+                **(dict(row_rank=groups.rank) if sorted_rg else {}))
         # The lazy sparse optimizer (HBM-bound) runs on the side stream underneath the MFMA-bound
         # dW_0 GEMM; it needs row_grad / dz and the merge keys (sorted on that same stream earlier).
         t = self.step_count
         st = self.sparse_state
-        if group_at == "tail":
-            issue_group()
+        skw = dict(grad_sorted=True) if sorted_rg else {}
+        if gside is not side and not sorted_rg:
+            cur.wait_stream(gside)
         with _OnSide(side, cur):
             with self._timed("sparse_adam"):
                 upd = self.k.sparse_adam_rows if self.lazy_mode else self.k.adam_rows_all
@@ -409,7 +445,7 @@ class DeepFMLayer:
                 else:
                     # hot rows (Zipf ids): long duplicate runs are pre-reduced per 64-position tile
                     pp = self._pp = self.k.segment_partials(groups, row_grad, row_grad.shape[1],
-                                                            out=getattr(self, "_pp", None))
+                                                            out=getattr(self, "_pp", None), **skw)
                     pp1 = self._pp1 = self.k.segment_partials(groups, dz, 1, grad_div=S, out=getattr(self, "_pp1", None))
                 if small:
                     pass
@@ -417,7 +453,7 @@ class DeepFMLayer:
                     # W, m, v and W1, m1, v1 of a row in ONE pass: W1 / m1 / v1 share the record line with W
                     D = self.sparse_feature_dim
                     self.k.sparse_adam_record(groups, row_grad, dz, S, self.fm.rec, st["mv"], D, t, lr,
-                                              v_offset=_round_up(D, 4), partials=pp, partials1=pp1)
+                                              v_offset=_round_up(D, 4), partials=pp, partials1=pp1, **skw)
                 else:
                     upd(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr, partials=pp)
                     upd(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr, partials=pp1)

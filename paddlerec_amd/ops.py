@@ -162,10 +162,12 @@ def deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, padding_idx=0, slot_o
     return y1, y2, feat, sum_emb, status
 
 
-def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, dense_w=None, compact=False):
+def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, dense_w=None, compact=False,
+                  row_rank=None):
     """-> row_grad [B*S,D], d_dense_w [Dn,D], d_dense_w_one [Dn].
     dense_w ([Dn,D] / [1,Dn,D], optional): recompute the dense part of feat instead of re-reading it.
-    compact: feat / d_feat_dnn are [B,S+1,D] and d_dense_w is the FM part only (see deepfm_fm_fwd)."""
+    compact: feat / d_feat_dnn are [B,S+1,D] and d_dense_w is the FM part only (see deepfm_fm_fwd).
+    row_rank [B*S] i32 (IdGroups.rank): row_grad is written in SORTED order (rec_deepfm_fm_bwd_sorted)."""
     B, F, D = feat.shape
     Dn = dense.shape[1] if compact else F - S
     dev = feat.device
@@ -188,6 +190,15 @@ def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, d
     nbytes = C.c_size_t(0)
     check(lib().rec_deepfm_fm_bwd_workspace_bytes(C.byref(desc), C.byref(nbytes)))
     w = ws.get(nbytes.value)
+    if row_rank is not None:
+        _chk(row_rank, torch.int32, "row_rank")
+        if row_rank.numel() < B * S:
+            raise RecError("row_rank shorter than B*S")
+        check(lib().rec_deepfm_fm_bwd_sorted(C.byref(desc), _p(dense), _p(feat), _p(sum_emb), _p(d_feat_dnn),
+                                             _p(dy1), _p(dy2), _p(dense_w), _p(row_rank), _p(row_grad),
+                                             _p(d_dense_w), _p(d_dense_w_one), _p(w), C.c_size_t(w.numel()),
+                                             _stream()), "rec_deepfm_fm_bwd_sorted")
+        return row_grad, d_dense_w, d_dense_w_one
     check(lib().rec_deepfm_fm_bwd(C.byref(desc), _p(dense), _p(feat), _p(sum_emb), _p(d_feat_dnn),
                                   _p(dy1), _p(dy2), _p(dense_w), _p(row_grad), _p(d_dense_w),
                                   _p(d_dense_w_one),
@@ -342,6 +353,12 @@ class IdGroups:
         self.uniq_rows = torch.empty(max(n, 1), dtype=torch.int64, device=device)
         self.seg_offset = torch.empty(n + 1, dtype=torch.int32, device=device)
         self.n_uniq = torch.zeros(4, dtype=torch.int32, device=device)
+        self.rank = None            # [n] i32, filled by ids_group_slots / ids_rank when asked for
+
+    def want_rank(self):
+        if self.rank is None:
+            self.rank = torch.empty(max(self.n, 1), dtype=torch.int32, device=self.sorted_pos.device)
+        return self.rank
 
     def host(self):
         """(sorted_pos[:n_valid], uniq_rows[:U], seg_offset[:U+1]) on the CPU — host sync."""
@@ -375,14 +392,52 @@ def ids_group(ids, num_rows, padding_idx, ws, slot_offset=None, status=None, gro
     return groups, status
 
 
-def _gl(div, group, group_stride, partials=None, index=None):
+def ids_group_slots(ids, slot_rows, padding_idx, ws, status=None, groups=None, want_rank=False):
+    """ids [B,S] whose slot s owns rows [s*slot_rows, (s+1)*slot_rows) (rec_ids_group_slots): the grouping of
+    ids_group(ids, S*slot_rows, ..., slot_offset = arange(S)*slot_rows), slot-local sort; want_rank: groups.rank[pos] =
+    sorted index of lookup pos (-1 = dropped)."""
+    _chk(ids, torch.int64, "ids")
+    if ids.dim() != 2:
+        raise RecError("ids must be [B, S]")
+    B, S = ids.shape
+    dev = ids.device
+    if groups is None:
+        groups = IdGroups(B * S, dev)
+    if status is None:
+        status = new_status(dev)
+    rank = groups.want_rank() if want_rank else None
+    nbytes = C.c_size_t(0)
+    check(lib().rec_ids_group_slots_workspace_bytes(B, S, int(slot_rows), C.byref(nbytes)))
+    w = ws.get(nbytes.value)
+    check(lib().rec_ids_group_slots(B, S, int(slot_rows), -1 if padding_idx is None else padding_idx, _p(ids),
+                                    _p(groups.sorted_pos), _p(groups.uniq_rows), _p(groups.seg_offset),
+                                    _p(groups.n_uniq), _p(rank), _p(status), _p(w), C.c_size_t(w.numel()), _stream()),
+          "rec_ids_group_slots")
+    return groups, status
+
+
+def group_slots_eligible(B, S, slot_rows):
+    """True when rec_ids_group_slots sorts slot by slot for this shape (csrc/ids_group_slots.hip sg::eligible)."""
+    return (B >= 8192 and 1 <= S <= 60 and 2 <= slot_rows <= (1 << 20) and B * S < 2 ** 31 - 1 and B <= 32 * 8192
+            and S * slot_rows < 2 ** 32 - 1 and os.environ.get("REC_GROUP_SLOTS", "1") != "0")
+
+
+def ids_rank(groups):
+    """groups.rank[pos] = k with sorted_pos[k] = pos (-1 for dropped lookups) for a grouping made without payload."""
+    rank = groups.want_rank()
+    check(lib().rec_ids_rank(groups.n, _p(groups.n_uniq), _p(groups.sorted_pos), _p(rank), _stream()), "rec_ids_rank")
+    return rank
+
+
+def _gl(div, group, group_stride, partials=None, index=None, sorted_=False):
     if index is not None:
         _chk(index, torch.int32, "grad index")
     return GradLayout(int(div), int(group), int(group_stride), partials.data_ptr() if partials is not None else None,
-                      index.data_ptr() if index is not None else None)
+                      index.data_ptr() if index is not None else None, int(bool(sorted_)))
 
 
-def segment_partials(groups, grad, D, grad_div=1, grad_group=0, grad_group_stride=0, out=None, grad_index=None):
+def segment_partials(groups, grad, D, grad_div=1, grad_group=0, grad_group_stride=0, out=None, grad_index=None,
+                     grad_sorted=False):
     """Tile partial sums of the long segments (hot rows) of `grad` under `groups` -> tensor to pass as
     `partials=` to the row-update ops together with the SAME grad and layout."""
     nbytes = C.c_size_t(0)
@@ -392,8 +447,8 @@ def segment_partials(groups, grad, D, grad_div=1, grad_group=0, grad_group_strid
         out = torch.empty(need, dtype=torch.float32, device=grad.device)
     check(lib().rec_segment_partials(groups.n, int(D), _p(groups.n_uniq), _p(groups.seg_offset),
                                      _p(groups.sorted_pos), _p(grad),
-                                     C.byref(_gl(grad_div, grad_group, grad_group_stride, None, grad_index)), _p(out),
-                                     _stream()),
+                                     C.byref(_gl(grad_div, grad_group, grad_group_stride, None, grad_index, grad_sorted)),
+                                     _p(out), _stream()),
           "rec_segment_partials")
     return out
 
@@ -424,7 +479,7 @@ def sparse_adam_rows(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, 
 
 
 def sparse_adam_record(groups, grad, grad1, grad1_div, rec, mv, D, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
-                       v_offset=None, grad_scale=None, partials=None, partials1=None):
+                       v_offset=None, grad_scale=None, partials=None, partials1=None, grad_sorted=False):
     """Lazy Adam on BOTH embeddings of a DeepFM row in one pass: rec [N, stride] = W(D) | W1 | m1 | v1 | pad,
     mv [N, sstride] = m(D) | v(D) at v_offset.  grad [n,D] row gradients, grad1 = dz with layout {grad1_div,0,0}."""
     _chk(grad, torch.float32, "grad")
@@ -439,7 +494,8 @@ def sparse_adam_record(groups, grad, grad1, grad1_div, rec, mv, D, step, lr=1e-3
     h = _hyper(lr, beta1, beta2, eps, step)
     check(lib().rec_sparse_adam_record(groups.n, int(D), rec.stride(0), mv.stride(0), int(v_offset),
                                        _p(groups.n_uniq), _p(groups.uniq_rows), _p(groups.seg_offset),
-                                       _p(groups.sorted_pos), _p(grad), C.byref(_gl(1, 0, 0, partials)), _p(grad1),
+                                       _p(groups.sorted_pos), _p(grad),
+                                       C.byref(_gl(1, 0, 0, partials, None, grad_sorted)), _p(grad1),
                                        C.byref(_gl(grad1_div, 0, 0, partials1)), _p(grad_scale), _p(rec), _p(mv),
                                        C.byref(h), _stream()), "rec_sparse_adam_record")
 
@@ -1418,6 +1474,19 @@ def cu_range_stream(device, cu_begin, cu_end):
         with torch.cuda.device(device):
             check(lib().rec_stream_create_cu_range(int(cu_begin), int(cu_end), C.byref(h)),
                   "rec_stream_create_cu_range")
+        _CU_STREAMS[key] = torch.cuda.ExternalStream(h.value, device=device)
+    return _CU_STREAMS[key]
+
+
+def cu_stride_stream(device, first, stride, cu_total=256):
+    """torch stream whose kernels only run on every `stride`-th compute unit (rec_stream_create_cu_stride)."""
+    device = torch.device(device)
+    key = (device.index, "stride", int(first), int(stride), int(cu_total))
+    if key not in _CU_STREAMS:
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            check(lib().rec_stream_create_cu_stride(int(first), int(stride), int(cu_total), C.byref(h)),
+                  "rec_stream_create_cu_stride")
         _CU_STREAMS[key] = torch.cuda.ExternalStream(h.value, device=device)
     return _CU_STREAMS[key]
 

@@ -35,7 +35,9 @@ for M, N, K in ((8192, 400, 416), (8192, 160, 16), (16384, 80, 48), (8192, 400, 
     Wt, act = rnd(N, K), rnd(M, N)                                         # dX = (dY W^T) * (act > 0), W given as [N, K]
     check(ops.gemm(A, Wt, ws, trans_b=True, epilogue="relu_mask", aux0=act),
           (A.double() @ Wt.double().t()) * (act > 0), ("relu_mask", M, N, K))
-for M, N, K in ((400, 400, 8192), (80, 160, 4096), (400, 80, 65536), (240, 400, 1600)):     # 80x80 tile, split-K, column sums
+# 80x80 tile, split-K, column sums; M = 432 / 144 / 1008: the 144x80 tile (9 waves: DeepFM's layer-0 weight gradient)
+for M, N, K in ((400, 400, 8192), (80, 160, 4096), (400, 80, 65536), (240, 400, 1600), (432, 400, 65536), (144, 80, 160),
+                (1008, 160, 4096)):
     X, dY = rnd(K, M), rnd(K, N)
     dW, db = torch.empty(M, N, device="cuda"), torch.empty(N, device="cuda")
     ops.gemm(X, dY, ws, trans_a=True, out=dW, b_colsum=db)

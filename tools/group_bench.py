@@ -34,10 +34,12 @@ ws = ops.Workspace(DEV)
 st = ops.new_status(DEV)
 grp = ops.IdGroups(B * S, DEV)
 print("ids_group uniform 26 x 1M rows, n = %d: %.1f us" % (B * S, timeit(lambda: ops.ids_group(ids, NT * S, 0, ws, so, st, grp))))
+print("ids_group_slots (slot-local, + rank):        %.1f us" % timeit(lambda: ops.ids_group_slots(ids, NT, 0, ws, st, grp, want_rank=True)))
 rng = np.random.default_rng(1)
 z = torch.as_tensor(np.minimum(rng.zipf(1.05, size=(B, S)), NT - 1)).to(DEV)
 print("ids_group zipf 1.05:                         %.1f us  (long segment flag %d)" %
       (timeit(lambda: ops.ids_group(z, NT * S, 0, ws, so, st, grp)), int(grp.n_uniq[2].item())))
+print("ids_group_slots zipf 1.05:                   %.1f us" % timeit(lambda: ops.ids_group_slots(z, NT, 0, ws, st, grp, want_rank=True)))
 big = torch.randint(1, 10_000_019, (40_000_000,), device=DEV, generator=g)
 grp2 = ops.IdGroups(big.numel(), DEV)
 print("ids_group slot_dnn 40 M ids, 10 M rows:      %.1f us" % timeit(lambda: ops.ids_group(big, 10_000_019, 0, ws, None, st, grp2), R=5))
