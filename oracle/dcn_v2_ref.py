@@ -140,11 +140,14 @@ def _mix64(k):
 
 def dropout_keep(shape, p, seed, stream):
     """The engine's counter-based keep mask (csrc/cross_ops.hip dropout_kernel): element e of a [rows, cols] matrix is
-    kept when bits 32.. of mix64(seed ^ mix64(stream << 40 | e)) >= p * 2^32.  (Paddle's own masks come from the
-    device generator and cannot be reproduced from the reference; the distribution is the same Bernoulli(1 - p).)"""
+    kept when bits 32.. of mix64(key + e) >= p * 2^32 with the per-stream key = mix64(seed ^ mix64(stream + golden
+    ratio)), all mod 2^64 — any stream id.  (Paddle's own masks come from the device generator and cannot be reproduced
+    from the reference; the distribution is the same Bernoulli(1 - p).)"""
     n = int(np.prod(shape))
-    e = np.arange(n, dtype=np.uint64) | (np.uint64(stream) << np.uint64(40))
-    h = _mix64(np.uint64(seed) ^ _mix64(e))
+    with np.errstate(over="ignore"):
+        key = _mix64(np.array([np.uint64(seed) ^ _mix64(np.array([np.uint64(stream) + np.uint64(0x9E3779B97F4A7C15)]))[0]]))[0]
+        e = np.arange(n, dtype=np.uint64) + key
+    h = _mix64(e)
     return ((h >> np.uint64(32)) >= np.uint64(int(float(p) * 4294967296.0))).reshape(shape)
 
 

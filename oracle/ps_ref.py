@@ -57,7 +57,8 @@ this restatement is anchored on the published source text above and on hand-comp
     sparse_sgd_rule.cc (heter_ps draws curand_uniform * range, i.e. (0, range]);
   * `slot` (an annotation for the save converter, no arithmetic) is not stored;
   * push_show = 0 (cannot happen: every occurrence carries show >= 1) divides by 1 instead of 0.
-Arithmetic: exactly the typed evaluation of the C++ text — `_initial_g2sum / (_initial_g2sum + g2sum)` and its sqrt in
+Arithmetic: the typed evaluation of the C++ text (round 4: `grad[i] / scale` is the float division the text has, on the
+float pushed gradient — round 3 divided in double) — `_initial_g2sum / (_initial_g2sum + g2sum)` and its sqrt in
 float (all operands are float), scaled_grad, the product with the learning rate and add_g2sum in double, `w[i] -=` and
 `g2sum +=` rounded to float on store.
 """
@@ -136,7 +137,9 @@ def update_value_work(w, g2sum, grad, scale, lr, g0, lo, hi):
     ratio = np.float64(np.sqrt(np.float32(g0) / (np.float32(g0) + np.float32(g2sum))))     # float expression
     add = np.float64(0.0)
     for i in range(len(w)):
-        sg = np.float64(grad[i]) / np.float64(scale)
+        # `double scaled_grad = grad[i] / scale;` with `const float* grad` and `float scale`: a FLOAT division, widened
+        # afterwards (a double division differs by up to one float ulp of the quotient)
+        sg = np.float64(np.float32(grad[i]) / np.float32(scale))
         w[i] = np.float32(np.float64(w[i]) - np.float64(lr) * sg * ratio)
         w[i] = min(max(w[i], lo), hi)
         add += sg * sg
@@ -173,13 +176,13 @@ def push_rows(rec, lay, uniq, g_embed, g_embedx, dshow, dclick, acc):
         st[CLICK] += push_click
         st[DELTA_SCORE] += (push_show - push_click) * f(acc["nonclk_coeff"]) + push_click * f(acc["click_coeff"])
         st[UNSEEN_DAYS] = f(0)
-        scale = np.float64(push_show) if (acc.get("show_scale", True) and push_show > 0) else np.float64(1.0)
-        # the pushed gradient = merged gradient x grad_scale (the batch size: gradient of the SUMMED loss), kept in
-        # double: scaled_grad = g * grad_scale / push_show
+        scale = f(push_show) if (acc.get("show_scale", True) and push_show > 0) else f(1.0)
+        # the pushed gradient = merged gradient x grad_scale (the batch size: gradient of the SUMMED loss) is a FLOAT
+        # in the push value (heter_ps PushCopy stores `g * -1. * bs` into a float field): one rounding of the product
         ew = r[eo:eo + 1]
-        st[G2SUM_W] = update_value_work(ew, st[G2SUM_W], [np.float64(g_embed[u]) * gs], scale, lr_w, g0_w, lo_w, hi_w)
+        st[G2SUM_W] = update_value_work(ew, st[G2SUM_W], [f(np.float64(g_embed[u]) * gs)], scale, lr_w, g0_w, lo_w, hi_w)
         if st[STATE] >= 2:
-            gx = np.asarray(g_embedx[u], np.float64) * gs
+            gx = (np.asarray(g_embedx[u], np.float64) * gs).astype(np.float32)
             xw = r[xo:xo + Dx]
             st[G2SUM_X] = update_value_work(xw, st[G2SUM_X], gx, scale, lr_x, g0_x, lo_x, hi_x)
         elif Dx > 0 and score(st[SHOW], st[CLICK], acc) >= f(acc["embedx_threshold"]):   # NeedExtendMF on the UPDATED value

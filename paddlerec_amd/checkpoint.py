@@ -245,6 +245,8 @@ def _load_sharded(net, model_prefix, shard_paths, load_optimizer):
                 raise ValueError("%s holds no PS table (written by a table='adam' run?)" % fn)
             _ps_import(net, sd, zero_first=first)
         else:
+            if "ps.rows" in sd or not any(key in sd for key in TABLE_KEYS):
+                raise ValueError("%s holds no embedding table of a table='adam' run (written by a PS-table run?)" % fn)
             for key in TABLE_KEYS:
                 if key not in sd:
                     continue

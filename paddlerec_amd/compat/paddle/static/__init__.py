@@ -257,7 +257,12 @@ class Executor:
             loss = program.loss.value
             opt.clear_grad()
             loss.backward()
-            label = feed.get("label")
+            # the click column of the pushed show / click pair: the label feed (dnn/static_model.py:86-94 casts `label`;
+            # slot_dnn names it `click`) — never a silent "0 clicks" when the program feeds neither
+            label = feed.get("label", feed.get("click"))
+            if label is None and program.tables:
+                raise RuntimeError("train_from_dataset: the program has a sparse table but feeds neither 'label' nor "
+                                   "'click' (the click counter of the pushed features)")
             for tab in program.tables.values():
                 tab.push(label)
             opt.step()

@@ -52,6 +52,8 @@ class SparseTable:
         self.pending = []
         if self.groups is None or self.groups.n != rows.numel():
             self.groups = K.IdGroups(rows.numel(), rows.device)
+        # padding_idx 0 is on the ROW: rec_feasign_rows maps feasign 0 — and only feasign 0 — to row 0 (every other key
+        # lands in [1, N)), so this drops exactly the padding key and never a real feature
         K.ids_group(rows, self.table.num_rows, 0, self.ws, None, self.status, self.groups)
         self.table.accessor.grad_scale = float(B)
         click = label.reshape(-1).to(_t.int64).contiguous() if label is not None else None

@@ -117,8 +117,10 @@ __global__ __launch_bounds__(kBlock) void dropout_kernel(int64_t rows, int cols,
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
     const int64_t r = e / cols;
     const int c = (int)(e - r * cols);
-    bool keep = (uint32_t)(mix64(seed ^ mix64((stream_a << 40) | (uint64_t)e)) >> 32) >= thresh;
-    if (nmask > 1) keep = keep && (uint32_t)(mix64(seed ^ mix64((stream_b << 40) | (uint64_t)e)) >> 32) >= thresh;
+    // stream_a / stream_b arrive as the per-stream keys mix64(seed ^ mix64(stream + golden)) (rec_dropout): any 64-bit
+    // stream id, any element index — no packing of the two into one word (ids above 2^24 failed)
+    bool keep = (uint32_t)(mix64(stream_a + (uint64_t)e) >> 32) >= thresh;
+    if (nmask > 1) keep = keep && (uint32_t)(mix64(stream_b + (uint64_t)e) >> 32) >= thresh;
     const float x = in[r * ld_in + c];
     out[r * ld_out + c] = keep ? x * scale : 0.f;
   }
@@ -270,16 +272,16 @@ extern "C" int rec_dropout(int64_t rows, int32_t cols, int64_t ld_in, int64_t ld
                            void* stream) {
   REC_REQUIRE(rows >= 0 && cols > 0 && ld_in >= cols && ld_out >= cols && in && out, REC_EINVAL, "bad arguments");
   REC_REQUIRE(p >= 0.f && p < 1.f && (nmask == 1 || nmask == 2), REC_EINVAL, "p must be in [0,1), nmask 1 or 2");
-  REC_REQUIRE(rows * (int64_t)cols < (1ll << 40) && stream_a < (1ull << 24) && stream_b < (1ull << 24), REC_ESHAPE,
-              "too many elements / stream id too large for the counter layout");
   if (rows == 0) return REC_OK;
+  const uint64_t key_a = mix64(seed ^ mix64(stream_a + 0x9E3779B97F4A7C15ull));
+  const uint64_t key_b = mix64(seed ^ mix64(stream_b + 0x9E3779B97F4A7C15ull));
   const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
   float scale = 1.f / (1.f - p);
   if (nmask == 2) scale *= scale;
   int64_t grid = (rows * cols + kBlock - 1) / kBlock;
   if (grid > kNumCU * 16) grid = kNumCU * 16;
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, rows, cols, ld_in,
-                     ld_out, in, out, thresh, scale, seed, stream_a, stream_b, nmask);
+                     ld_out, in, out, thresh, scale, seed, key_a, key_b, nmask);
   return check_launch("rec_dropout");
 }
 

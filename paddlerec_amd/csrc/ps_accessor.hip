@@ -67,13 +67,19 @@ __device__ __forceinline__ void ps_segment_sum(float (&g)[VEC], int beg, int end
   }
 }
 
-// SparseAdaGradSGDRule::UpdateValueWork on one element: typed evaluation of the C++ text (ratio in float, the
-// rest in double, float on store).  inv = grad_scale / scale (double).  Returns scaled_grad^2.
+// SparseAdaGradSGDRule::UpdateValueWork on one element: typed evaluation of the C++ text — `double scaled_grad =
+// grad[i] / scale;` is a FLOAT division (const float* grad, float scale) of the float pushed gradient g * grad_scale,
+// widened afterwards; ratio in float; the update and g2sum in double, float on store.  Returns scaled_grad^2.
 struct PsRule {
   float lr, g0, lo, hi;
 };
-__device__ __forceinline__ double ps_rule_elem(float& w, float g, double inv, float ratio, const PsRule& R) {
-  const double sg = (double)g * inv;
+struct PsScale {
+  float grad_scale, scale;   // the batch size the trainer multiplies the gradient by; the pushed show (or 1)
+};
+__device__ __forceinline__ double ps_rule_elem(float& w, float g, PsScale inv, float ratio, const PsRule& R) {
+#pragma clang fp contract(off)
+  const float pushed = g * inv.grad_scale;
+  const double sg = (double)(pushed / inv.scale);
   float nw = (float)((double)w - (double)R.lr * sg * (double)ratio);
   w = fminf(fmaxf(nw, R.lo), R.hi);
   return sg * sg;
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
   const bool has_x = state >= 2.f;
   const float show1 = show0 + dshow, click1 = click0 + dclick;
   const float score1 = (show1 - click1) * A.nonclk_coeff + click1 * A.click_coeff;
-  const double inv = (double)A.grad_scale / ((A.show_scale && dshow > 0.f) ? (double)dshow : 1.0);
+  const PsScale inv = {A.grad_scale, (A.show_scale && dshow > 0.f) ? dshow : 1.f};
 
   // ---- embedx part
   float w[VEC], g[VEC];
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_narrow_kernel(
   dclick = (float)lsum;
   const float show1 = show0 + dshow, click1 = click0 + dclick;
   const float score1 = (show1 - click1) * A.nonclk_coeff + click1 * A.click_coeff;
-  const double inv = (double)A.grad_scale / ((A.show_scale && dshow > 0.f) ? (double)dshow : 1.0);
+  const PsScale inv = {A.grad_scale, (A.show_scale && dshow > 0.f) ? dshow : 1.f};
 
   double sq = 0.0;
   if (has_x) {

@@ -273,14 +273,16 @@ class DCN_V2Layer:
         # launch-bound batches (the reference's own: dcn_v2 config_bigdata.yaml batch_size 512): from the third sight of
         # an input signature on the step is replayed from its recorded C-ABI call list (plan.py), the Adam step count and
         # the dropout mask streams re-derived per replay; bit-identical (tests/test_dcn_v2_gpu.py)
-        if (self.device.type == "cuda" and self.k is _ops and torch.is_tensor(sparse_inputs) and dlogit is None
+        if (self.device.type == "cuda" and self.k is _ops and torch.is_tensor(sparse_inputs)
+                and torch.is_tensor(dense_inputs) and torch.is_tensor(label) and dlogit is None
                 and self.timers is None and not self._recording and not self.use_low_rank_mixture
                 and sparse_inputs.numel() <= int(os.environ.get("REC_STEP_PLAN_MAX", "65536"))
                 and os.environ.get("REC_STEP_PLAN", "1") != "0"):
             from .plan import CallPlan
             inputs = [sparse_inputs, dense_inputs, label]
             key = (tuple(sparse_inputs.shape), float(clip_norm or 0.0),
-                   None if auc_stats is None else (auc_stats[0].data_ptr(), auc_stats[1].data_ptr()))
+                   None if auc_stats is None else (auc_stats[0].data_ptr(), auc_stats[1].data_ptr()),
+                   self.dropout_rate, self.dropout_seed, self.l2_dnn)       # baked into the recorded calls
             entry = self._plans.get(key)
             if entry is None:
                 self._plans[key] = "seen"

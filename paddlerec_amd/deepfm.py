@@ -293,7 +293,7 @@ class DeepFMLayer:
     # -- launch-bound batches: the step as a recorded call list (plan.py) ------------------------------------------
     def _plan_eligible(self, sparse_inputs, dense_inputs, label, auc_stats, allreduce):
         return (self.device.type == "cuda" and self.k is ops and torch.is_tensor(sparse_inputs)
-                and allreduce is None and self.timers is None and self.lazy_mode and not self._recording
+                and torch.is_tensor(dense_inputs) and torch.is_tensor(label) and allreduce is None and self.timers is None and self.lazy_mode and not self._recording
                 and sparse_inputs.numel() <= int(os.environ.get("REC_STEP_PLAN_MAX", "65536"))
                 and os.environ.get("REC_STEP_PLAN", "1") != "0")
 

@@ -172,7 +172,9 @@ class DINLayer:
         if (self.device.type == "cuda" and self.k is _ops and not self._recording and hist_item_seq.numel() <= small
                 and os.environ.get("REC_STEP_PLAN", "1") != "0"):
             from .plan import CallPlan
-            key = (tuple(hist_item_seq.shape), float(lr))
+            # the recorded calls hold the transposed copy of the attention weights made at record time: an in-place edit of
+            # attention_w (its torch version counter) gets a new plan, as set_attention does
+            key = (tuple(hist_item_seq.shape), float(lr), tuple(w._version for w in self.attention_w))
             entry = self._plans.get(key)
             if entry is None:
                 self._plans[key] = "seen"

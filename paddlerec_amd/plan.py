@@ -16,6 +16,8 @@ be replayed — tests compare planned and eager steps bit for bit over several s
 python control flow on device values; every tensor a call touches is kept alive by the plan."""
 import ctypes as C
 
+import torch
+
 from . import _lib, ops
 
 _HOST_ONLY = ("rec_last_error", "rec_gemm_plan_splits", "rec_din_saves_act1", "rec_comm_available")
@@ -34,6 +36,8 @@ class CallPlan:
         self.step0 = 0
         self.stream = None
         self.outputs = None
+        self.output_slots = []   # (c_void_p object, output index): where the recorded step wrote its returned tensors
+        self.output_fields = []  # (struct, field name, output index)
 
     # -- recording ---------------------------------------------------------------------------------
     def note_pointer(self, p, t):
@@ -82,6 +86,12 @@ class CallPlan:
         addr = {t.data_ptr(): i for i, t in enumerate(inputs)}
         self.input_slots = [(p, addr[a]) for p, a in self.pointers if a in addr]
         self.field_slots = [(o, f, addr[a]) for o, f, a in self.fields if a in addr]
+        # the tensors the step RETURNS (loss, pred): a replay writes them into fresh tensors, as the eager step does — a
+        # caller that keeps per-step predictions must not see every later step overwrite them
+        outs = self.outputs if isinstance(self.outputs, (tuple, list)) else (self.outputs,)
+        oaddr = {t.data_ptr(): i for i, t in enumerate(outs) if torch.is_tensor(t) and t.data_ptr() not in addr}
+        self.output_slots = [(p, oaddr[a]) for p, a in self.pointers if a in oaddr]
+        self.output_fields = [(o, f, oaddr[a]) for o, f, a in self.fields if a in oaddr]
         self.fields = None
         self.input_sig = [(tuple(t.shape), t.dtype, t.stride()) for t in inputs]
         self.pointers = None
@@ -102,8 +112,17 @@ class CallPlan:
             h.lr = lr
         for o, base, stride in self.step_args:
             o.value = base + (step - self.step0) * stride
+        outs = self.outputs
+        if self.output_slots or self.output_fields:
+            single = not isinstance(outs, (tuple, list))
+            fresh = [torch.empty_like(t) if torch.is_tensor(t) else t for t in ((outs,) if single else outs)]
+            for p, i in self.output_slots:
+                p.value = fresh[i].data_ptr()
+            for o, f, i in self.output_fields:
+                setattr(o, f, fresh[i].data_ptr())
+            outs = fresh[0] if single else tuple(fresh)
         for fn, args in self.calls:
             rc = fn(*args)
             if rc:
                 _lib.check(rc, "replayed call")
-        return self.outputs
+        return outs

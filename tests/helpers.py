@@ -251,3 +251,22 @@ def assert_sibling_moments(layer, st, rel=1e-5):
             assert_close_scaled(sp[vk].detach().cpu().numpy(), st[key][1], rel, err_msg="v of " + key)
             n += 1
     return n
+
+
+def assert_adam_weights_close(got, want, lr, steps, rel=1e-5, frac=0.98, err_msg=""):
+    """Weights after `steps` Adam steps against the oracle's.  Adam divides the gradient by its own magnitude, so an
+    element whose gradient is ~eps-sized (fp32 noise decides its sign) can end a whole step (~lr) away on the two sides
+    while every moment agrees to 1e-5 of its scale (assert_moments_close / assert_sibling_moments check those).  The
+    statement here has two parts instead of one loose rtol:
+      * at least `frac` of the elements are within `rel` of the tensor's scale — the stated bar;
+      * NO element is further away than Adam can move it: steps * lr * max(1, (1 - b1) / sqrt(1 - b2)) on each side."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64).reshape(np.asarray(got).shape)
+    err = np.abs(got - want)
+    scale = max(float(np.abs(want).max()), 1e-30)
+    tight = float(np.mean(err <= rel * scale))
+    assert tight >= frac, "%s only %.4f of the elements within %.0e of the scale %.3e (max err %.3e)" % (
+        err_msg, tight, rel, scale, float(err.max()))
+    cap = 2.0 * steps * lr * 3.17
+    assert float(err.max()) <= cap, "%s max err %.3e exceeds what %d Adam steps of lr %.3g can move (%.3e)" % (
+        err_msg, float(err.max()), steps, lr, cap)
+    return tight

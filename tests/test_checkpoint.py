@@ -156,3 +156,37 @@ def test_ps_table_checkpoint_keeps_whole_records_and_reshards(tmp_path, old_worl
             assert torch.equal(rec, want[row]), row
         else:
             assert not rec.any(), row
+
+
+def test_ps_shards_into_an_adam_table_net_are_refused(tmp_path, monkeypatch):
+    """_load_sharded used to skip every table key when an adam-table net was given PS shards (ps.rows /
+    ps.records, no fm.embedding.*) and return with the tables at their initial values.  Both directions raise now."""
+    from paddlerec_amd.deepfm import DeepFMLayer
+    monkeypatch.setattr(DeepFMLayer, "set_dict", lambda self, sd: self.set_dict(sd), raising=False)
+    old = [_PsNet(r, 2) for r in range(2)]
+    _fill(old)
+    for n in old:
+        d = ck.save_model(n, None, str(tmp_path), 0)
+
+    class _AdamNet:                                   # row-sharded Adam tables: no `ps`, dense embedding views
+        def __init__(self, rank, world, n_global=23, D=4):
+            self.comm, self.global_rows = _FakeComm(rank, world), n_global
+            rows = (n_global + world - 1) // world
+            self.W, self.W1, self.dense_w = torch.ones(rows, D), torch.ones(rows, 1), torch.zeros(3, 2)
+            self.step_count, self.sparse_state = 0, None
+
+        def state_dict(self):
+            return {"fm.embedding.weight": self.W, "fm.embedding_one.weight": self.W1, "dnn.linear_0.weight": self.dense_w}
+
+        def set_dict(self, sd):
+            for k, v in sd.items():
+                self.state_dict()[k].copy_(torch.as_tensor(v))
+
+        def _ensure_sparse_state(self):
+            pass
+
+    for world in (2, 3):
+        net = _AdamNet(0, world)
+        with pytest.raises(ValueError, match="PS-table run"):
+            ck.load_model(d, net)
+        assert bool((net.W == 1).all())               # nothing half-loaded into the tables

@@ -211,7 +211,7 @@ def test_dropout_kernel_matches_oracle_masks(engine_lib):
     x = rng.standard_normal((37, 50)).astype(np.float32)
     wide = torch.zeros(37, 64, device=DEV)
     wide[:, 3:53] = T(x)
-    for p, sa, sb in ((0.5, 7, None), (0.5, 7, 8), (0.3, 100000, 3), (0.0, 1, 2)):
+    for p, sa, sb in ((0.5, 7, None), (0.5, 7, 8), (0.3, 100000, 3), (0.0, 1, 2), (0.5, (1 << 24) + 5, (1 << 61) + 9)):
         y = ops.dropout(wide[:, 3:53].clone(), p, 99, sa, sb)
         keep = X.dropout_keep(x.shape, p, 99, sa)
         s = np.float32(1) / (np.float32(1) - np.float32(p))
@@ -242,6 +242,37 @@ def _check_train_mode(device, kernels, stacked, mix):
                 v.copy_(t((rng.standard_normal(tuple(v.shape)) * 0.05).astype(np.float32)))
     p = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
     tr = OracleDCNTrainer(p, lr=1e-2, clip_norm=0.05, dropout=(0.5, 4321), l2_dnn=1e-3)
+
+    def moments_vs_oracle():
+        want_m, want_v = dict(tr.m), dict(tr.v)
+        if mix:
+            for mv in (want_m, want_v):
+                mv[X.P + "gating.weight"] = np.concatenate([mv[X.P + "gating.%d.weight" % e] for e in range(4)], axis=1)
+                mv[X.P + "gating.bias"] = np.concatenate([mv[X.P + "gating.%d.bias" % e] for e in range(4)])
+        assert assert_moments_close(m, want_m, want_v) >= 8
+        assert_close_scaled(m.sparse_state["m"].cpu().numpy(), tr.m["embedding.weight"])
+
+    def oracle_takes_the_mirrors_state():
+        """Every step starts from ONE state on both sides (the mirror's parameters and moments): Adam turns the fp32 noise
+        of an ~eps-sized gradient into an lr-sized step, which would otherwise reach the next step's predictions (1e-4)
+        — each step's loss, predictions and moments are then held to the stated bar on their own."""
+        from helpers import layer_moments
+        sd = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+        mom = layer_moments(m)
+        for k in tr.p:
+            tr.p[k] = sd[k].reshape(tr.p[k].shape)
+            if k == "embedding.weight":
+                tr.m[k] = m.sparse_state["m"].cpu().numpy().copy()
+                tr.v[k] = m.sparse_state["v"].cpu().numpy().copy()
+                continue
+            if mix and ".gating." in k:
+                e, leaf = int(k.split(".gating.")[1].split(".")[0]), k.rsplit(".", 1)[1]
+                gm, gv = mom[X.P + "gating." + leaf]
+                tr.m[k] = (gm[:, e:e + 1] if leaf == "weight" else gm[e:e + 1]).copy().reshape(tr.p[k].shape)
+                tr.v[k] = (gv[:, e:e + 1] if leaf == "weight" else gv[e:e + 1]).copy().reshape(tr.p[k].shape)
+            else:
+                tr.m[k], tr.v[k] = mom[k][0].copy().reshape(tr.p[k].shape), mom[k][1].copy().reshape(tr.p[k].shape)
+
     for step in range(3):
         ids = rng.integers(0, N, (B, 26), dtype=np.int64)
         dense = np.log(rng.random((B, 13), dtype=np.float32) * 50 + 1).astype(np.float32)
@@ -250,14 +281,9 @@ def _check_train_mode(device, kernels, stacked, mix):
         oloss, opred, _ = tr.train_step(ids, dense, label)
         np.testing.assert_allclose(loss.cpu().numpy()[0], oloss, rtol=2e-5)
         np.testing.assert_allclose(pred.cpu().numpy(), opred, rtol=2e-5, atol=1e-6)
+        moments_vs_oracle()
+        oracle_takes_the_mirrors_state()
     # eval forward is untouched by the dropout settings
     ev = m.forward(t(ids), t(dense)).cpu().numpy()
     np.testing.assert_allclose(ev, X.forward(ids, dense, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}),
                                rtol=2e-5, atol=1e-6)
-    want_m, want_v = dict(tr.m), dict(tr.v)
-    if mix:
-        for mv in (want_m, want_v):
-            mv[X.P + "gating.weight"] = np.concatenate([mv[X.P + "gating.%d.weight" % e] for e in range(4)], axis=1)
-            mv[X.P + "gating.bias"] = np.concatenate([mv[X.P + "gating.%d.bias" % e] for e in range(4)])
-    assert assert_moments_close(m, want_m, want_v) >= 8
-    assert_close_scaled(m.sparse_state["m"].cpu().numpy(), tr.m["embedding.weight"])

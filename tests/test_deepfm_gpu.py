@@ -738,13 +738,19 @@ def test_planned_step_equals_eager_step(engine_lib, monkeypatch, B):
         m = DeepFMLayer(N, D, 13, 26, [64, 32], device=DEV)
         auc = (torch.zeros(4096, dtype=torch.int64, device=DEV), torch.zeros(4096, dtype=torch.int64, device=DEV))
         g = torch.Generator(device=DEV).manual_seed(11)
-        outs = []
+        outs, kept = [], []
         for step in range(6):
             ids = torch.randint(0, N, (B, 26), device=DEV, generator=g)
             dense = torch.rand(B, 13, device=DEV, generator=g)
             label = (torch.rand(B, 1, device=DEV, generator=g) < 0.3).to(torch.int64)
             loss, pred = m.train_step(ids, dense, label, lr=1e-2 * (1 + step), auc_stats=auc)
             outs.append((loss.cpu().numpy().copy(), pred.cpu().numpy().copy()))
+            kept.append((loss, pred))
+        # a caller that KEEPS the per-step tensors (host-side metrics after N steps) sees every step's own values: a
+        # replayed step writes its loss / predictions into fresh tensors, like the eager step
+        for (lk, pk), (lc, pc) in zip(kept, outs):
+            assert np.array_equal(lk.cpu().numpy(), lc) and np.array_equal(pk.cpu().numpy(), pc)
+        assert len({t[1].data_ptr() for t in kept}) == len(kept)
         runs[mode] = (outs, m.fm.rec.cpu().numpy(), m.sparse_state["mv"].cpu().numpy(), m.dense.data.cpu().numpy(),
                       m.dense.m.cpu().numpy(), m.dense.v.cpu().numpy(), auc[0].cpu().numpy(), auc[1].cpu().numpy(),
                       m.step_count, len(m._plans))

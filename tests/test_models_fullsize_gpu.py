@@ -125,3 +125,81 @@ def test_dygraph_model_mirrors_run(engine_lib):
     assert np.isfinite(float(loss.item()))
     dm.infer_forward(net, metrics, dbatch, cfg)
     assert int(metrics[0][0].sum() + metrics[0][1].sum()) == 2 * Bn
+
+
+def test_dcn_v2_full_width_step_vs_oracle(engine_lib):
+    """configs[2] at its real WIDTH against the oracle (the full-size tests checked properties only):
+    D 40 => d = 39 * 40 = 1560, CrossNetV2 depth 3 (three 1560 x 1560 cross weights), DNN 768-768, B 4096 — the 256x128 /
+    128x128 GEMM tiles, the 1560-wide cross epilogues and their backward at the shapes the benchmark runs.  The table is
+    cut to 30 001 rows so that the NumPy oracle's merge finishes in seconds.  One clipped step: loss, predictions,
+    Adam moments of every dense parameter and of the touched table rows."""
+    from helpers import OracleDCNTrainer, assert_close_scaled, assert_moments_close
+    from paddlerec_amd.dcn_v2 import DCN_V2Layer
+    rng = np.random.default_rng(40)
+    N, D, B, fc = 30001, 40, 4096, [768, 768]
+    m = DCN_V2Layer(N, D, 13, 26, fc, 3, is_Stacked=True, device=DEV)
+    with torch.no_grad():
+        for k, v in m.dense.p.items():
+            if k.endswith("bias"):
+                v.copy_(torch.as_tensor((rng.standard_normal(tuple(v.shape)) * 0.05).astype(np.float32)).to(DEV))
+    p = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    assert p["DeepCrossLayer_.crossNet.cross_layers.0.weight"].shape == (1560, 1560)
+    tr = OracleDCNTrainer(p, lr=1e-3, clip_norm=10.0)
+    ids = rng.integers(0, N, (B, 26), dtype=np.int64)
+    ids[rng.random((B, 26)) < 0.03] = 0
+    dense = np.log(rng.random((B, 13), dtype=np.float32) * 50 + 1).astype(np.float32)
+    label = (rng.random((B, 1)) < 0.3).astype(np.int64)
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    loss, pred = m.train_step(T(ids), T(dense), T(label), lr=1e-3, clip_norm=10.0)
+    oloss, opred, _ = tr.train_step(ids, dense, label)
+    assert int(m.status.item()) == 0
+    np.testing.assert_allclose(float(loss.item()), oloss, rtol=1e-5)
+    np.testing.assert_allclose(pred.cpu().numpy(), opred, rtol=2e-5, atol=1e-6)
+    assert assert_moments_close(m, tr.m, tr.v) >= 10
+    assert_close_scaled(m.sparse_state["m"].cpu().numpy(), tr.m["embedding.weight"])
+    assert_close_scaled(m.sparse_state["v"].cpu().numpy(), tr.v["embedding.weight"])
+
+
+def test_din_attention_long_history_vs_oracle(engine_lib):
+    """configs[3] shapes with the longest histories the benchmark runs (E 128, MLP 80-40-1, T 512, B 256): the compile-time-
+    shaped attention kernels (16 tiles of 32 positions per sample, online softmax across them) against oracle/din_ref.py —
+    output, softmax weights, and the backward's dh / dq."""
+    from oracle import din_ref as Dn
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(512)
+    B, Tn, Ei, Ec, ni, nc = 256, 512, 64, 64, 5000, 301
+    E = Ei + Ec
+    tabs = [rng.uniform(-0.3, 0.3, (n, d)).astype(np.float32) for n, d in ((ni, Ei), (nc, Ec), (ni, Ei), (nc, Ec))]
+    lens = rng.integers(1, Tn + 1, B)
+    lens[:4] = (Tn, 1, 33, 480)
+    hi = np.zeros((B, Tn), np.int64)
+    hc = np.zeros((B, Tn), np.int64)
+    for b in range(B):
+        hi[b, :lens[b]] = rng.integers(1, ni, lens[b])
+        hc[b, :lens[b]] = rng.integers(1, nc, lens[b])
+    mask = np.where(np.arange(Tn)[None] < lens[:, None], 0, -1000000000).astype(np.int64)
+    ti = np.repeat(rng.integers(1, ni, B)[:, None], Tn, 1)
+    tc = np.repeat(rng.integers(1, nc, B)[:, None], Tn, 1)
+    aw = [rng.uniform(-0.2, 0.2, s).astype(np.float32) for s in ((4 * E, 80), (80, 40), (40, 1))]
+    ab = [rng.uniform(-0.1, 0.1, s).astype(np.float32) for s in ((80,), (40,), (1,))]
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    tt = [T(t) for t in tabs]
+    out, attw, status = ops.din_attention_pool(T(hi), T(hc), T(ti), T(tc), T(mask), *tt, [T(w) for w in aw],
+                                               [T(b) for b in ab])
+    assert int(status.item()) == 0
+    h = np.concatenate([tabs[0][hi], tabs[1][hc]], 2)
+    q = np.concatenate([tabs[2][ti], tabs[3][tc]], 2)
+    want, wts = Dn.attention_pool(h, q, mask.astype(np.float32), aw, ab, return_weights=True)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(attw.cpu().numpy(), wts.reshape(B, Tn), rtol=2e-5, atol=1e-7)
+    dout = (rng.standard_normal((B, E)) * 0.1).astype(np.float32)
+    dh, dq = ops.din_attention_pool_bwd(T(hi), T(hc), T(ti), T(tc), *tt, [T(w) for w in aw], [T(b) for b in ab], attw,
+                                        T(dout))
+    ref = Dn.attention_pool_backward(h.astype(np.float64), q.astype(np.float64), mask.astype(np.float64),
+                                     [w.astype(np.float64) for w in aw], [b.astype(np.float64) for b in ab],
+                                     dout.astype(np.float64))
+    ref32 = Dn.attention_pool_backward(h, q, mask.astype(np.float32), aw, ab, dout)
+    from helpers import assert_close_floor
+    scale = max(np.abs(ref["dh"]).max(), np.abs(ref["dq"]).max())
+    assert_close_floor(dh.cpu().numpy(), ref["dh"], ref32["dh"], err_msg="dh", scale=scale)
+    assert_close_floor(dq.cpu().numpy(), ref["dq"], ref32["dq"], err_msg="dq", scale=scale)

@@ -128,3 +128,25 @@ def test_shrink_unseen_days_and_save_kinds():
     assert rec[0, S + 6] == 1 and rec[4, S + 6] == 3
     m0 = ps_ref.save_select(rec, LAY, ACC, 0)
     assert m0.tolist() == m3.tolist() and rec[0, S + 6] == 1
+
+
+def test_float_division_of_the_float_pushed_gradient():
+    """`double scaled_grad = grad[i] / scale;` divides a float by a float (round 3 divided in double and
+    carried g x grad_scale in double).  A vector on which the two typings end on different floats:
+      merged gradient g = 0.82f (= 0.819999992847...), grad_scale (batch size) 4, pushed show 6, embed_w 0.5, g2sum 0
+      pushed = float(0.82f * 4)       = 3.2799999713897705            (exact in float)
+      float division pushed / 6       = 0.5466666618982...  -> float 0.54666668176651      (the nearer neighbour)
+      w = float(0.5 - 0.05f * 0.54666668176651 * 1)  = 0.47266665     [the double quotient gives 0.47266668]
+      g2sum = float(0 + 0.54666668176651^2 / 1)      = 0.29884446     [the double quotient gives 0.29884443]"""
+    rec = np.zeros((3, 10), np.float32)
+    rec[1, 0] = 0.5
+    rec[1, S:S + 7] = [6, 0, 0.0, 0.0, 1, 0.0, 0]                            # a key without embedx
+    acc = dict(ACC, embedx_threshold=1e9, grad_scale=4.0)
+    ps_ref.push_rows(rec, LAY, [1], np.float32([0.82]), np.float32([[0.0, 0.0]]), [6], [0], acc)
+    assert rec[1, 0] == np.float32(0.47266665) and rec[1, 0] != np.float32(0.47266668)
+    assert rec[1, S + 2] == np.float32(0.29884446) and rec[1, S + 2] != np.float32(0.29884443)
+    # the same statement on the typed helper alone
+    w = np.float32([0.5])
+    g2 = ps_ref.update_value_work(w, np.float32(0), [np.float32(3.2799999713897705)], np.float32(6), np.float32(0.05),
+                                  np.float32(3.0), np.float32(-10), np.float32(10))
+    assert w[0] == np.float32(0.47266665) and g2 == np.float32(0.29884446)

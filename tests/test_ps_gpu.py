@@ -159,3 +159,39 @@ def test_kat_k_duplicates_move_like_one_deepfm_layout(engine_lib):
     ps_ref.push_rows(want, lay, [3], [4 * g1], [4 * g], [4], [0], dict(KAT, embedx_threshold=0.0))
     np.testing.assert_allclose(out["four"][:D + 1], want[3, :D + 1], rtol=2e-7, atol=0)
     np.testing.assert_allclose(out["four"][so:so + 7], want[3, so:so + 7], rtol=2e-7, atol=0)
+
+
+def test_kat_float_division_typing_on_the_device(engine_lib):
+    """tests/test_ps_accessor_kat.py::test_float_division_of_the_float_pushed_gradient through rec_ps_push_rows, both
+    kernels: six occurrences of the key (pushed show 6) whose gradients sum to 0.82f, grad_scale 4 — the float division
+    of the C++ text ends on 0.47266665 / 0.29884446, a double division on 0.47266668 / 0.29884443."""
+    from paddlerec_amd import ops
+    g = np.float32(0.82)
+    parts = np.float32([0.82, 0, 0, 0, 0, 0])                        # merged in ascending position: exactly 0.82f
+    # lane-per-feature kernel ('slot' layout, D 3)
+    t = ops.PsTable(3, 3, DEV, kind="slot", **dict(KAT, embedx_threshold=1e9))
+    so = t.layout.stat_off
+    t.rec[1, 0] = 0.5
+    t.rec[1, so:so + 7] = T(np.float32([6, 0, 0, 0, 1, 0, 0]))
+    t.accessor.grad_scale = 4.0
+    grad = np.zeros((6, 3), np.float32)
+    grad[:, 0] = parts
+    ids = T(np.full((6, 1), 1, np.int64))
+    groups, _ = ops.ids_group(ids, t.num_rows, 0, ops.Workspace(DEV))
+    ops.ps_push_rows(t, groups, T(grad), 1, click=T(np.zeros(6, np.int64)))
+    rec = t.rec.cpu().numpy()
+    assert rec[1, 0] == np.float32(0.47266665) and rec[1, so + 2] == np.float32(0.29884446)
+    assert rec[1, so] == 12 and g == np.float32(grad[:, 0].sum())
+    # row-group kernel ('deepfm' layout, D 16): embed_w = the first-order weight at column D
+    D = 16
+    t = ops.PsTable(4, D, DEV, kind="deepfm", **dict(KAT, embedx_threshold=1e9))
+    so = t.layout.stat_off
+    t.rec[2, D] = 0.5
+    t.rec[2, so:so + 7] = T(np.float32([6, 0, 0, 0, 1, 0, 0]))
+    t.accessor.grad_scale = 4.0
+    ids = T(np.full((6, 1), 2, np.int64))
+    groups, _ = ops.ids_group(ids, t.num_rows, 0, ops.Workspace(DEV))
+    ops.ps_push_rows(t, groups, T(np.zeros((6, D), np.float32)), 1, grad1=T(parts.reshape(6, 1)),
+                     click=T(np.zeros(6, np.int64)))
+    rec = t.rec.cpu().numpy()
+    assert rec[2, D] == np.float32(0.47266665) and rec[2, so + 2] == np.float32(0.29884446)

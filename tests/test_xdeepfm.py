@@ -135,7 +135,8 @@ def _check_layer(device, kernels, tol, chunk_bytes=None):
         sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
         want = _state_dict(tr.p)
         for k in want:
-            np.testing.assert_allclose(sd[k], want[k].reshape(sd[k].shape), rtol=1e-3, atol=p_atol, err_msg=k)
+            from helpers import assert_adam_weights_close
+            assert_adam_weights_close(sd[k], want[k], lr=1e-2, steps=3, err_msg=k)
         # ... and the optimizer state at the stated bar (Adam's moments within 1e-5 of their scale)
         from helpers import assert_sibling_moments
         assert assert_sibling_moments(m, tr.st) >= 3
