@@ -345,7 +345,8 @@ int rec_sparse_adagrad_rows(int64_t n_max, int32_t emb_dim, int32_t row_stride, 
  *   duplicate gradients fused in, ascending position order): a new key is created without embedx (embed_w = 0 when
  *   embed_zero_init, else uniform(+-initial_range)); show / click / delta_score / unseen_days; then
  *   SparseAdaGradSGDRule::UpdateValueWork on embed_w and (if it exists) embedx:
- *       double scaled = g * grad_scale / (show_scale ? pushed_show : 1);
+ *       float pushed = g * grad_scale;  double scaled = pushed / (show_scale ? pushed_show : 1)   [a FLOAT division, as
+ *       `double scaled_grad = grad[i] / scale;` over `const float* grad`, `float scale` is];
  *       w = clip(float(w - lr * scaled * sqrtf(g0 / (g0 + g2sum))));  g2sum = float(g2sum + sum(scaled^2) / n)
  *   a value without embedx drops its embedx gradient and is extended (uniform(+-x_initial_range), a pure function
  *   of (seed,row,element); embedx_g2sum = 0) at the end of the push after which

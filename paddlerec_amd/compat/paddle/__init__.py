@@ -188,6 +188,44 @@ def _ps_save(dirname, mode=0):
     _np.savez(_os.path.join(dirname, "rec_gpubox.npz"), **out)
 
 
+def _ps_save_shards():
+    """The pass checkpoint of an N-rank gpubox launch: the first worker's fleet.save_inference_model left a request
+    (directory, mode); in fleet.barrier_worker() — which every rank reaches — each rank writes the existing values of
+    ITS shard (global row ids + whole accessor records) and rank 0 merges the shards into the single rec_gpubox.npz a
+    one-GPU run writes (same keys, rows ascending)."""
+    import os as _os
+    import torch.distributed as dist
+    from . import _dist
+    from . import static as _s
+    c = _dist.comm()
+    req = [_dist._state["pending_save"] if c.rank == 0 else None]
+    dist.broadcast_object_list(req, src=dist.get_global_rank(c.group, 0), group=c.group)
+    _dist._state["pending_save"] = None
+    if req[0] is None:
+        return
+    dirname, mode = req[0]
+    _os.makedirs(dirname, exist_ok=True)
+    prog = _s.default_main_program()
+    K = _backend.kernels()
+    out = {}
+    for name, tab in prog.tables.items():
+        sel = K.ps_save_select(tab.table, int(mode))
+        rows = _t.nonzero(sel).reshape(-1)
+        out["table.%s.rows" % name] = (rows * c.world + c.rank).cpu().numpy()          # global row = local * G + rank
+        out["table.%s.records" % name] = tab.table.rec[rows].cpu().numpy()
+    _np.savez(_os.path.join(dirname, "rec_gpubox.shard%dof%d.npz" % (c.rank, c.world)), **out)
+    dist.barrier(group=c.group)
+    if c.rank == 0:
+        merged = {"dense.%d" % i: p.detach().cpu().numpy() for i, p in enumerate(prog.parameters())}
+        parts = [_np.load(_os.path.join(dirname, "rec_gpubox.shard%dof%d.npz" % (r, c.world))) for r in range(c.world)]
+        for name in prog.tables:
+            rows = _np.concatenate([p["table.%s.rows" % name] for p in parts])
+            recs = _np.concatenate([p["table.%s.records" % name] for p in parts])
+            order = _np.argsort(rows, kind="stable")
+            merged["table.%s.rows" % name], merged["table.%s.records" % name] = rows[order], recs[order]
+        _np.savez(_os.path.join(dirname, "rec_gpubox.npz"), **merged)
+
+
 def save(obj, path):
     """paddle.save(state_dict, path): a pickled {name -> ndarray} dict (nested dicts of tensors are converted)."""
     def conv(o):

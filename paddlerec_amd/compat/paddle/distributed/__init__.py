@@ -99,21 +99,39 @@ class _PipeDataset:
         pass
 
     def _batches(self, device):
-        """{feed name: tensor [B, width]} per batch, in file order (the last batch may be short, as Paddle feeds it)."""
+        """{feed name: tensor [B, width]} per batch, in file order (the last batch may be short, as Paddle feeds it).
+        N ranks (FLAGS_selected_gpus names N GPUs): a GLOBAL batch is N x batch_size consecutive samples — what the N
+        GPU worker threads of the reference's one trainer consume together — and rank r takes its r-th share of it, so a
+        step of the launch is one step on the global batch; a short last batch is split as evenly as it goes (a rank
+        may get none: it still takes part in the step's exchanges).  feed["__global_batch__"] = samples of the global
+        batch."""
         import numpy as np
         import torch
+        from .. import _dist
         if self.samples is None:
             self.load_into_memory()
         n = len(self.samples[0])
-        for lo in range(0, n, self.batch_size):
+        G, r = _dist.world(), _dist.rank()
+        step = self.batch_size * G
+        for lo in range(0, n, step):
+            m = min(step, n - lo)
+            base, extra = divmod(m, G)
+            a = lo + r * base + min(r, extra)
+            b = a + base + (1 if r < extra else 0)
             feed = {}
             for v, col in zip(self.use_var, self.samples):
-                part = col[lo:lo + self.batch_size]
+                part = col[a:b]
                 width = v.shape[-1] if len(v.shape) > 1 else 1
                 if any(len(x) != width for x in part):
                     raise ValueError("feed %r: a sample holds %s values, the variable is [*, %d] (LoD feeds are served "
                                      "by paddlerec_amd.gpubox)" % (v.name, sorted({len(x) for x in part}), width))
-                feed[v.name] = torch.as_tensor(np.stack(part)).to(device)
+                if part:
+                    feed[v.name] = torch.as_tensor(np.stack(part)).to(device)
+                else:
+                    dt = np.int64 if "int" in str(v.dtype) else np.float32
+                    feed[v.name] = torch.as_tensor(np.zeros((0, width), dt)).to(device)
+            if G > 1:
+                feed["__global_batch__"] = m
             yield feed
 
 

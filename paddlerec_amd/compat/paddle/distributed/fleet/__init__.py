@@ -2,10 +2,14 @@
 
 tools/trainer.py:113-119 (collective dygraph): distributed_optimizer / distributed_model are pass-through; the engine's
 own collective mode is the row-sharded trainer of paddlerec_amd.trainer (one process per GPU, torch.distributed.run).
-tools/static_gpubox_trainer.py:101-260 (parameter-server / gpubox mode): ONE worker process; the "servers" are the
-device tables of the main program (compat/paddle/static), so is_server() is False, init_worker / stop_worker /
-barrier_worker have nothing to contact, and DistributedStrategy is the attribute bag program_helper.get_strategy fills
-(its sparse_table_configs carry the accessor block of the YAML to the tables)."""
+tools/static_gpubox_trainer.py:101-260 (parameter-server / gpubox mode): the "servers" are the device tables of the main
+program (compat/paddle/static), so is_server() is False and init_worker / stop_worker have nothing to contact;
+DistributedStrategy is the attribute bag program_helper.get_strategy fills (its sparse_table_configs carry the accessor
+block of the YAML to the tables).  With FLAGS_selected_gpus naming N > 1 GPUs (tools/run_gpubox.sh:21) the launch is N
+ranks (paddlerec_amd.run_reference spawns them, one per GPU; compat/paddle/_dist.py): every rank is a worker
+(worker_index = rank), the tables are row-sharded over the ranks, util.all_reduce / barrier_worker are real
+collectives, and barrier_worker is also where a pass checkpoint requested by the first worker is written by ALL ranks
+(every rank holds a shard of the table; the reference only calls save_inference_model on the first worker)."""
 import os
 import sys
 
@@ -32,6 +36,8 @@ def init(role_maker=None, is_collective=False, strategy=None):  # noqa: A002
         raise NotImplementedError("runner.use_fleet (collective dygraph): run `python -m torch.distributed.run -m "
                                   "paddlerec_amd.trainer ...` (row-sharded collective mode) instead")
     _state.update(init=True, collective=False, strategy=strategy)
+    from ... import _dist
+    _dist.init()
 
 
 def is_server():
@@ -47,10 +53,16 @@ def is_first_worker():
 
 
 def worker_index():
+    from ... import _dist
+    if _dist.world() > 1:
+        return _dist.rank()
     return int(os.environ.get("PADDLE_TRAINER_ID", "0"))
 
 
 def worker_num():
+    from ... import _dist
+    if _dist.world() > 1:
+        return _dist.world()
     return int(os.environ.get("PADDLE_TRAINERS_NUM", "1"))
 
 
@@ -71,12 +83,18 @@ def stop_worker():
 
 
 def barrier_worker():
-    pass
+    from ... import _dist, _ps_save_shards
+    if _dist.world() > 1:
+        _ps_save_shards()           # a save the first worker asked for: every rank writes its shard (collective)
+        _dist.barrier()
 
 
 def save_inference_model(executor, dirname, feeded_var_names, target_vars, main_program=None, export_for_deployment=True,
                          mode=0):
-    from ... import _ps_save
+    from ... import _dist, _ps_save
+    if _dist.world() > 1:           # only the first worker gets here (static_gpubox_trainer.py:211-216): the table is
+        _dist._state["pending_save"] = (dirname, int(mode))   # sharded, so the write happens in barrier_worker()
+        return
     _ps_save(dirname, mode)
 
 
@@ -109,14 +127,19 @@ def distributed_model(model):
 
 class _Util:
     def all_reduce(self, x, mode="sum", comm_world="worker"):
-        return x              # one worker
+        from ... import _dist
+        return _dist.all_reduce_numpy(x, mode) if _dist.world() > 1 else x
 
     def get_file_shard(self, files):
+        from ... import _dist
+        if _dist.world() > 1:     # the ranks of one launch read ALL files and split every global batch between them
+            return sorted(files)  # (InMemoryDataset._batches): equal step counts on every rank, whatever the files hold
         n, i = worker_num(), worker_index()
         return [f for k, f in enumerate(sorted(files)) if k % n == i]
 
     def barrier(self, *a, **k):
-        pass
+        from ... import _dist
+        _dist.barrier()
 
 
 util = _Util()

@@ -24,6 +24,14 @@ class _PSGPU:
         if self.slots is None or self.slot_dims is None or len(self.slots) != len(self.slot_dims):
             raise ValueError("set_slot_vector / set_slot_dim_vector must be called first, with equal lengths")
         self.gpus = [int(g) for g in gpus]
+        from . import _dist
+        if len(self.gpus) > 1 and _dist.world() != len(self.gpus):
+            raise RuntimeError(
+                "init_gpu_ps(%s): %d GPUs, but this process is rank %d of %d.  The engine runs one process per GPU: start "
+                "the script with `python -m paddlerec_amd.run_reference tools/static_gpubox_trainer.py ...` — with "
+                "FLAGS_selected_gpus naming the GPUs it re-executes itself as one rank per GPU (torch.distributed.run) and "
+                "the tables of static.nn.sparse_embedding are row-sharded over the ranks" %
+                (self.gpus, len(self.gpus), _dist.rank(), _dist.world()))
 
     def begin_pass(self):
         if self.gpus is None:

@@ -12,6 +12,8 @@ under torch autograd — the Linear layers run rec_gemm_f32, `static.nn.sparse_e
 click = label: dnn/static_model.py:86-94), the dense parameters through the compat Adam, `static.auc` through
 rec_auc_histogram.  Layers are constructed once (at record time), so parameters persist across replays like Paddle's
 scope variables.  This is host glue around the same kernels as paddlerec_amd.gpubox, not a graph compiler."""
+import os as _os
+
 import numpy as _np
 import torch as _t
 
@@ -250,9 +252,50 @@ class Executor:
         if program.loss is None or program.optimizer is None:
             raise RuntimeError("train_from_dataset: optimizer.minimize(loss) was not called on this program")
         opt = program.optimizer
-        opt._bind(program.parameters())
+        params = program.parameters()
+        opt._bind(params)
+        from .. import _dist
+        comm = _dist.comm()
+        G = comm.world if comm is not None else 1
+        plan = self._lookup_plan(program) if G > 1 else {}
+        init_dump = _os.environ.get("REC_COMPAT_DUMP_INIT")
+        if init_dump and not getattr(program, "_init_dumped", False):     # tests: the parameters an oracle replay starts from
+            program._init_dumped = True
+            if _dist.rank() == 0:
+                _np.savez(init_dump, **{"dense.%d" % i: p.detach().cpu().numpy() for i, p in enumerate(params)})
         n = 0
         for feed in dataset._batches(_backend.device()):
+            global_batch = feed.pop("__global_batch__", None)
+            local_batch = int(next(iter(feed.values())).shape[0])
+            if G > 1:
+                # N ranks: ONE pull of the step's keys through the row-sharded tables (collective, also for a rank whose
+                # share of a short last batch is empty), the tape on the local share, the loss weighted so that the
+                # summed gradients are those of the mean over the GLOBAL batch
+                for name, tab in program.tables.items():
+                    tab.prefetch(_t.cat([feed[k].reshape(local_batch, -1)[:, :1] for k in plan[name]], dim=1))
+                opt.clear_grad()
+                if local_batch:
+                    self._forward(program, feed)
+                    loss = program.loss.value * (float(local_batch) / float(global_batch))
+                    loss.backward()
+                else:
+                    loss = _t.zeros((), device=_backend.device())
+                label = feed.get("label", feed.get("click"))
+                if label is None and program.tables:
+                    raise RuntimeError("train_from_dataset: the program has a sparse table but feeds neither 'label' "
+                                       "nor 'click' (the click counter of the pushed features)")
+                for tab in program.tables.values():
+                    tab.push(label, global_batch)
+                flat = _t.cat([(p.grad if p.grad is not None else _t.zeros_like(p)).reshape(-1) for p in params])
+                comm.all_reduce_sum(flat)                                  # ONE all-reduce of the dense gradients
+                o = 0
+                for p in params:
+                    k = p.numel()
+                    p.grad = flat[o:o + k].view_as(p).clone()
+                    o += k
+                opt.step()
+                n += 1
+                continue
             self._forward(program, feed)
             loss = program.loss.value
             opt.clear_grad()
@@ -271,6 +314,23 @@ class Executor:
                 print("batch %d loss %.6f" % (n, float(loss)))
         self.last_loss = float(loss.detach()) if n else None
         return n
+
+    @staticmethod
+    def _lookup_plan(program):
+        """{table name: feed variable names of its sparse_embedding calls, in tape order}: what lets N ranks pull all
+        keys of a step in ONE exchange.  Every lookup of a sharded table must read a feed variable directly."""
+        feeds = {id(v): v.name for v in program.feeds}
+        plan = {name: [] for name in program.tables}
+        for fn, args, _, _ in program.ops:
+            name = getattr(fn, "_rec_table", None)
+            if name is None:
+                continue
+            src = args[0] if args else None
+            if id(src) not in feeds:
+                raise NotImplementedError("multi-GPU gpubox: sparse_embedding[%s] reads a computed variable; the "
+                                          "row-sharded pull needs the feasigns of a step up front (feed variables)" % name)
+            plan[name].append(feeds[id(src)])
+        return plan
 
     def infer_from_dataset(self, program=None, dataset=None, **kw):
         program = program or _main

@@ -28,21 +28,60 @@ class _PsLookup(_t.autograd.Function):
         return None, None, None
 
 
+class _PsLookupPre(_t.autograd.Function):
+    """The j-th lookup of a step whose keys were pulled together (SparseTable.prefetch: ONE pull — on N ranks one
+    route + two all-to-alls — for all slots of the batch instead of one per sparse_embedding call)."""
+
+    @staticmethod
+    def forward(ctx, keys, anchor, table, j):
+        D = table.table.emb_dim
+        v = table.pre["vals"][:, j]                                     # [B, D + 2] = W(D) | show | click
+        ctx.table, ctx.j, ctx.D = table, j, D
+        return _t.cat([v[:, D:D + 2], v[:, :D]], dim=1).reshape(*keys.shape[:-1], D + 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.table.pending_slots[ctx.j] = g.reshape(-1, ctx.D + 2)[:, 2:].contiguous()
+        return None, None, None, None
+
+
 class SparseTable:
     """The GPU-PS table behind static.nn.sparse_embedding: an ops.PsTable (uint64 feasigns hashed to its rows on the
-    device) + the SelectedRows gradients of the lookups of the current step."""
+    device) + the SelectedRows gradients of the lookups of the current step.
+
+    N ranks (FLAGS_selected_gpus names N GPUs, compat/paddle/_dist.py): the table is ROW-SHARDED, owner(row) = row % N,
+    local row = row // N — `core.PSGPU` sharding the keys over the GPUs of tools/static_gpubox_trainer.py:152-160.  The
+    pull of a step (prefetch): feasigns -> global rows (rec_feasign_rows) -> rec_shard_route by owner -> all-to-all of
+    the local rows -> the owners gather W | show | click of the record (rec_emb_gather) -> all-to-all back in send
+    order; the push: one gradient row + show / click per lookup to its owner -> rec_ids_group -> rec_ps_push_rows with
+    grad_scale = the GLOBAL batch.  Rows arrive at an owner rank-major and in ascending position inside a rank, i.e. in
+    the order of the global batch: the merge sums in the same order as ONE unsharded step on the concatenated batch."""
 
     def __init__(self, name, num_rows, emb_dim, accessor=None):
+        from .. import _dist
         K = _backend.kernels()
         self.name = name
-        self.table = K.PsTable(int(num_rows), int(emb_dim), _backend.device(), kind="slot", **(accessor or {}))
+        self.comm = _dist.comm()
+        self.G = self.comm.world if self.comm is not None else 1
+        self.rank = self.comm.rank if self.comm is not None else 0
+        self.global_rows = int(num_rows)
+        acc = dict(accessor or {})
+        if self.G > 1:
+            acc.update(row_mul=self.G, row_add=self.rank)     # a key is created with the same values on any sharding
+        self.table = K.PsTable((self.global_rows + self.G - 1) // self.G, int(emb_dim), _backend.device(), kind="slot",
+                               **acc)
         self.status = K.new_status(_backend.device())
         self.anchor = _t.zeros(1, device=_backend.device(), requires_grad=True)   # gives the lookup a grad_fn
         self.pending, self.groups, self.ws = [], None, K.Workspace(_backend.device())
+        self.pre, self.pending_slots, self.cursor = None, {}, 0
+        self.ws_route, self.route = K.Workspace(_backend.device()), None
 
-    def push(self, label):
+    # -- single process: one gather per sparse_embedding call, merged at push ------------------------------------------
+    def push(self, label, global_batch=None):
         """After loss.backward(): merge the step's SelectedRows and apply the accessor's push (show = 1 per
         occurrence, click = the sample's label, gradient of the SUMMED loss)."""
+        if self.G > 1:
+            return self._push_sharded(label, global_batch)
         if not self.pending:
             return
         K = _backend.kernels()
@@ -59,6 +98,70 @@ class SparseTable:
         click = label.reshape(-1).to(_t.int64).contiguous() if label is not None else None
         K.ps_push_rows(self.table, self.groups, grad, S, click=click)
 
+    # -- N ranks: one pull and one push per step through the row-sharded table ------------------------------------------
+    def prefetch(self, keys):
+        """keys [B, S] int64 feasigns of ALL lookups of the step (slot-major columns in the order of the program's
+        sparse_embedding calls).  Collective: every rank calls it once per step, also with B = 0."""
+        K, G, comm = _backend.kernels(), self.G, self.comm
+        dev = _backend.device()
+        B, S = keys.shape
+        n, D = B * S, self.table.emb_dim
+        W2 = D + 2
+        if n:
+            rows_g = K.feasign_rows(keys.reshape(-1).contiguous(), self.global_rows)
+            if self.route is None or self.route.n != n:
+                self.route = K.ShardRoute(n, G, dev)
+            route = self.route
+            K.shard_route(rows_g.reshape(n, 1).contiguous(), self.global_rows, 0, G, self.ws_route, None, self.status, route)
+            send_splits = [int(x) for x in route.send_counts[:G].tolist()]              # host sync (G ints)
+        else:
+            route, send_splits = None, [0] * G
+        recv_splits = comm.exchange_counts(send_splits)
+        n_send, n_recv = sum(send_splits), sum(recv_splits)
+        recv_rows = _t.zeros(max(n_recv, 1), dtype=_t.int64, device=dev)[:n_recv]
+        send_rows = route.send_local_row[:n_send].contiguous() if n_send else _t.zeros(0, dtype=_t.int64, device=dev)
+        comm.all_to_all(recv_rows, send_rows, recv_splits, send_splits)
+        got = _t.zeros(max(n_recv, 1), W2, dtype=_t.float32, device=dev)[:n_recv]
+        if n_recv:      # the owners' lookup: W | show | click are the first D + 2 floats of a 'slot' record
+            K.emb_gather(recv_rows.contiguous(), self.table.rec[:, :W2], None, self.status, out=got)
+        reply = _t.zeros(n + 1, W2, dtype=_t.float32, device=dev)                        # row 0 = padding -> zeros
+        comm.all_to_all(reply[1:1 + n_send], got, send_splits, recv_splits)
+        vals = reply[route.slot_of_pos[:n]] if n else reply[:0]
+        self.pre = dict(B=B, S=S, vals=vals.reshape(B, S, W2), route=route, n_send=n_send, n_recv=n_recv,
+                        send_splits=send_splits, recv_splits=recv_splits, recv_rows=recv_rows)
+        self.pending_slots, self.cursor = {}, 0
+
+    def _push_sharded(self, label, global_batch):
+        K, comm, dev = _backend.kernels(), self.comm, _backend.device()
+        pre = self.pre
+        if pre is None:
+            raise RuntimeError("sparse table %r: push without the step's prefetch" % self.name)
+        B, S, D = pre["B"], pre["S"], self.table.emb_dim
+        n_send, n_recv = pre["n_send"], pre["n_recv"]
+        send_g = _t.zeros(max(n_send, 1), D, dtype=_t.float32, device=dev)[:n_send]
+        send_sc = _t.zeros(max(n_send, 1), 2, dtype=_t.int64, device=dev)[:n_send]
+        if n_send:
+            grad = _t.zeros(B, S, D, dtype=_t.float32, device=dev)
+            for j, g in self.pending_slots.items():
+                grad[:, j] = g
+            pos = pre["route"].send_pos[:n_send]                                         # b * S + s of every sent lookup
+            send_g.copy_(grad.reshape(B * S, D)[pos])
+            send_sc[:, 0] = 1
+            if label is not None:
+                send_sc[:, 1] = label.reshape(-1).to(_t.int64)[_t.div(pos, S, rounding_mode="floor")]
+        recv_g = _t.zeros(max(n_recv, 1), D, dtype=_t.float32, device=dev)[:n_recv]
+        recv_sc = _t.zeros(max(n_recv, 1), 2, dtype=_t.int64, device=dev)[:n_recv]
+        comm.all_to_all(recv_g, send_g.contiguous(), pre["recv_splits"], pre["send_splits"])
+        comm.all_to_all(recv_sc, send_sc.contiguous(), pre["recv_splits"], pre["send_splits"])
+        if n_recv:
+            if self.groups is None or self.groups.n < n_recv:
+                self.groups = K.IdGroups(int(n_recv * 1.25) + 1, dev)
+            K.ids_group(pre["recv_rows"].contiguous(), self.table.num_rows, None, self.ws, None, self.status, self.groups)
+            self.table.accessor.grad_scale = float(global_batch)
+            K.ps_push_rows(self.table, self.groups, recv_g.contiguous(), 1, show=recv_sc[:, 0].contiguous(),
+                           click=recv_sc[:, 1].contiguous())
+        self.pre, self.pending_slots = None, {}
+
 
 def sparse_embedding(input, size, padding_idx=None, is_test=False, entry=None, table_class="MemorySparseTable",  # noqa: A002
                      param_attr=None, dtype="float32", slot=None):
@@ -74,8 +177,13 @@ def sparse_embedding(input, size, padding_idx=None, is_test=False, entry=None, t
                                                accessor=getattr(_main, "accessor_kwargs", None))
 
     def lookup(keys):
+        if tab.pre is not None:                   # the step's keys were pulled together (Executor: N ranks)
+            j = tab.cursor
+            tab.cursor += 1
+            return _PsLookupPre.apply(keys, tab.anchor, tab, j)
         return _PsLookup.apply(keys, tab.anchor, tab)
     lookup.__qualname__ = "static.nn.sparse_embedding[%s]" % name
+    lookup._rec_table = name
     if isinstance(input, Var):
         return record(lookup, [input])
     return lookup(input)

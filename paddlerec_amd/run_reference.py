@@ -10,16 +10,49 @@ import runpy
 import sys
 
 
+def _selected_gpus():
+    return [g for g in os.environ.get("FLAGS_selected_gpus", "").split(",") if g.strip() != ""]
+
+
+def _spawn_ranks(argv):
+    """tools/static_gpubox_trainer.py with FLAGS_selected_gpus naming N > 1 GPUs (tools/run_gpubox.sh:21): the reference
+    drives them from one process; the engine runs one process per GPU — re-execute under torch.distributed.run, one rank
+    per GPU (what bench.py --gpus N does).  -> exit code, or None when this process should run the script itself."""
+    n = len(_selected_gpus())
+    if (n <= 1 or "WORLD_SIZE" in os.environ or os.environ.get("TRAINING_ROLE", "TRAINER") == "PSERVER"
+            or os.path.basename(argv[0]) != "static_gpubox_trainer.py" or os.environ.get("REC_COMPAT_SPAWN", "1") == "0"):
+        return None
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", "paddlerec_amd.run_reference"] + list(argv)
+    env = dict(os.environ)
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = os.pathsep.join([here, env.get("PYTHONPATH", "")])
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     if not argv:
         raise SystemExit(__doc__)
+    rc = _spawn_ranks(argv)
+    if rc is not None:
+        raise SystemExit(rc)
     script = os.path.abspath(argv[0])
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.dirname(here))                 # paddlerec_amd itself
     sys.path.insert(0, os.path.join(here, "compat"))          # `import paddle` -> the compat namespace
     sys.path.insert(0, os.path.dirname(script))               # what `python script.py` puts first
     sys.argv = [script] + argv[1:]
+    seed = os.environ.get("REC_COMPAT_SEED")        # tests: the same initial parameters in two runs of one script
+    if seed:
+        import torch
+        torch.manual_seed(int(seed))
     runpy.run_path(script, run_name="__main__")
 
 
