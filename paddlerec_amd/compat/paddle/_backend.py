@@ -30,6 +30,11 @@ def set_device(name):
     name = str(name)
     if name.startswith("gpu"):
         idx = name.split(":")[1] if ":" in name else "0"
+        if ":" not in name and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            # a rank of a multi-process launch asking for "the GPU": its own (all ranks on GPU 0 when there are fewer
+            # GPUs than ranks: the shared-GPU tests)
+            n = torch.cuda.device_count()
+            idx = os.environ.get("LOCAL_RANK", "0") if n >= int(os.environ["WORLD_SIZE"]) else "0"
         _state["device"] = torch.device("cuda", int(idx))
         torch.cuda.set_device(_state["device"])
     elif name.startswith("cpu"):

@@ -29,15 +29,15 @@ def init():
     import torch.distributed as dist
 
     from . import _backend
-    on_gpu = torch.cuda.is_available() and not os.environ.get("REC_COMPAT_KERNELS")
+    if _backend._state["device"] is None:          # the script has not chosen a device yet (gpubox: fleet.init() comes first)
+        if torch.cuda.is_available() and not os.environ.get("REC_COMPAT_KERNELS"):
+            _backend.set_device("gpu")             # -> this rank's GPU (all ranks on GPU 0 when there are fewer GPUs than ranks)
+        else:
+            _backend.set_device("cpu")
+    on_gpu = _backend.device().type == "cuda"
     ngpu = torch.cuda.device_count() if on_gpu else 0
     # one GPU per rank -> RCCL; fewer GPUs than ranks (tests: every rank on cuda:0) or no GPU -> gloo, host-staged
     backend = os.environ.get("REC_COMPAT_BACKEND") or ("nccl" if ngpu >= world() else "gloo")
-    if on_gpu:
-        local = int(os.environ.get("LOCAL_RANK", str(rank())))
-        _backend.set_device("gpu:%d" % (local if ngpu >= world() else 0))
-    else:
-        _backend.set_device("cpu")
     if not dist.is_initialized():
         dist.init_process_group(backend, rank=rank(), world_size=world())
     from paddlerec_amd.sharded import Comm

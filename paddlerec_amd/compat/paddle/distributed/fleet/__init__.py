@@ -32,10 +32,12 @@ _state = {"init": False, "collective": False, "strategy": None}
 
 
 def init(role_maker=None, is_collective=False, strategy=None):  # noqa: A002
-    if is_collective:
-        raise NotImplementedError("runner.use_fleet (collective dygraph): run `python -m torch.distributed.run -m "
-                                  "paddlerec_amd.trainer ...` (row-sharded collective mode) instead")
-    _state.update(init=True, collective=False, strategy=strategy)
+    """is_collective=True (tools/trainer.py:112-118, runner.use_fleet): dygraph data parallel over the ranks of the
+    launch (`python -m torch.distributed.run --nproc-per-node N -m paddlerec_amd.run_reference tools/trainer.py ...`):
+    replicated model, every rank reads its share of the files (the reference's readers split the file list by
+    paddle.distributed.get_rank()), gradients averaged before optimizer.step() — distributed_model /
+    distributed_optimizer below.  (The engine's own collective mode with ROW-SHARDED tables is paddlerec_amd.trainer.)"""
+    _state.update(init=True, collective=bool(is_collective), strategy=strategy)
     from ... import _dist
     _dist.init()
 
@@ -115,13 +117,72 @@ class _StrategyOptimizer:
         return getattr(self._opt, name)
 
 
+class _CollectiveOptimizer:
+    """fleet.distributed_optimizer in collective dygraph mode: step() first averages the gradients over the ranks
+    (Paddle's DataParallel scales the loss by 1 / nranks and all-reduces): ONE all-reduce of the flattened dense
+    gradients, an all-gather of the SelectedRows of every sparse=True embedding (ids + gradient rows, rank-major — the
+    order of the concatenated batch — scaled by 1 / nranks), then the wrapped optimizer's step on every rank."""
+
+    def __init__(self, optimizer):
+        self._opt = optimizer
+
+    def step(self):
+        import torch as _t
+        import torch.distributed as dist
+        from ... import _dist
+        c = _dist.comm()
+        if c is not None and c.world > 1:
+            G = c.world
+            params = list(self._opt._params)
+            dense = [p for p in params if not getattr(p, "_sparse_grads", None)]
+            if dense:
+                flat = _t.cat([(p.grad if p.grad is not None else _t.zeros_like(p)).reshape(-1) for p in dense])
+                c.all_reduce_sum(flat)
+                flat /= float(G)
+                o = 0
+                for p in dense:
+                    k = p.numel()
+                    p.grad = flat[o:o + k].view_as(p).clone()
+                    o += k
+            for p in params:
+                sg = getattr(p, "_sparse_grads", None)
+                if not sg:
+                    continue
+                ids = _t.cat([g[0] for g in sg]).contiguous()
+                rows = (_t.cat([g[1] for g in sg]) / float(G)).contiguous()
+                n = _t.tensor([ids.numel()], dtype=_t.int64, device="cpu" if c.staged else ids.device)
+                sizes = [_t.zeros_like(n) for _ in range(G)]
+                dist.all_gather(sizes, n, group=c.group)
+                sizes = [int(x.item()) for x in sizes]
+                all_ids = _t.zeros(sum(sizes), dtype=ids.dtype, device=ids.device)
+                all_rows = _t.zeros(sum(sizes), rows.shape[1], dtype=rows.dtype, device=rows.device)
+                # every rank sends its whole list to every rank: all-to-all with equal sends = all-gather(v)
+                c.all_to_all(all_ids, ids.repeat(G), sizes, [ids.numel()] * G)
+                c.all_to_all(all_rows, rows.repeat(G, 1), sizes, [ids.numel()] * G)
+                p._sparse_grads = [(all_ids, all_rows, sg[0][2])]
+        return self._opt.step()
+
+    def __getattr__(self, name):
+        return getattr(self._opt, name)
+
+
 def distributed_optimizer(optimizer, strategy=None):
+    if _state.get("collective"):
+        return _CollectiveOptimizer(optimizer)
     if strategy is None:
         return optimizer
     return _StrategyOptimizer(optimizer, strategy)
 
 
 def distributed_model(model):
+    """Collective dygraph: the replicas start from rank 0's parameters (Paddle's DataParallel broadcasts them)."""
+    from ... import _dist
+    c = _dist.comm()
+    if _state.get("collective") and c is not None and c.world > 1:
+        import torch as _t
+        with _t.no_grad():
+            for p in model.parameters():
+                c.broadcast(p.data, src=0)
     return model
 
 
