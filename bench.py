@@ -181,7 +181,15 @@ def other_configs(timeout_s=120):
                                                   "--opt", "ps"]),
             ("bench.py --force-sharded --table ps --hashed-rows 1250000000",
              [sys.executable, os.path.abspath(__file__), "--force-sharded", "--table", "ps", "--hashed-rows",
-              "1250000000", "--no-cpu-baseline", "--steps", "20", "--warmup", "5"])]
+              "1250000000", "--no-cpu-baseline", "--steps", "20", "--warmup", "5"]),
+            # BASELINE.md §2 config 2b — the reference's own layout: ONE shared [1 000 001, D] table, D 9
+            # (deepfm/config.yaml:48-50) and D 10 (benchmark.yaml:21); and the Zipf(1.05) ids of SURVEY §8(d) (hot rows)
+            ("bench.py --shared-table --dim 9", [sys.executable, os.path.abspath(__file__), "--shared-table", "--dim", "9",
+                                                 "--no-cpu-baseline", "--steps", "20", "--warmup", "5"]),
+            ("bench.py --shared-table --dim 10", [sys.executable, os.path.abspath(__file__), "--shared-table", "--dim", "10",
+                                                  "--no-cpu-baseline", "--steps", "20", "--warmup", "5"]),
+            ("bench.py --ids zipf", [sys.executable, os.path.abspath(__file__), "--ids", "zipf", "--no-cpu-baseline",
+                                     "--steps", "20", "--warmup", "5"])]
     keep = ("config", "workload", "ms", "ms_per_step", "samples_per_s", "value", "unit", "roofline", "pool_fwd_ms",
             "train_step_ms", "kernels_ms")
     out = []
@@ -198,14 +206,64 @@ def other_configs(timeout_s=120):
                 e = {k: d[k] for k in keep if k in d}
                 if "config" in d and isinstance(d["config"], dict):      # a bench.py line: its config object names the workload
                     e["workload"] = d["config"].get("workload")
-                    e["config"] = "configs[4] (one GPU's share, row-sharded path at world 1)"
-                    e["roofline"] = {k: d["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac")}
+                    e["config"] = ("configs[4] (one GPU's share, row-sharded path at world 1)" if "--table" in cmd else
+                                   "configs[1] layout 2b (one shared table)" if "--shared-table" in cmd else
+                                   "configs[1] with Zipf(1.05) ids")
+                    e["roofline"] = {k: d["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac",
+                                                                       "in_step_frac")}
                 e["command"] = name
                 out.append(e)
         except Exception as e:      # timeout, missing tool, bad JSON
             out.append({"command": name, "error": repr(e)[:300]})
         out[-1]["wall_s"] = round(time.time() - t0, 1)
     return out
+
+
+def reference_trainer_bs512(budget_s=90.0, lines=4096):
+    """the reference's unmodified tools/trainer.py once more at the batch size of its OWN
+    full-data config (models/rank/deepfm/config_bigdata.yaml: bs 512, D 10? fc 400x3) on a synthetic slot file of `lines`
+    lines in the reference's text format, so that `reference_trainer` is not only a bs-2 number.  Same caveat: the
+    reference's loop + reader over the NumPy oracle backend, not Paddle's kernels."""
+    import re
+    import subprocess
+    import tempfile
+    ref = next((d for d in (os.path.join(REPO, "oracle", "_ref", "PaddleRec"), "/root/reference")
+                if os.path.isdir(os.path.join(d, "tools"))), None)
+    cfg = os.path.join(ref or "", "models", "rank", "deepfm", "config_bigdata.yaml")
+    if ref is None or not os.path.isfile(cfg):
+        return {"error": "no staged config_bigdata.yaml (oracle/make_ref_tree.py)"}
+    threads = min(os.cpu_count() or 1, 32)
+    env = dict(os.environ, REC_COMPAT_KERNELS="cpu_kernels", OMP_NUM_THREADS=str(threads), PYTHONDONTWRITEBYTECODE="1")
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(REPO, "tests"), REPO, env.get("PYTHONPATH", "")])
+    rng = np.random.default_rng(7)
+    with tempfile.TemporaryDirectory() as tmp:
+        data = os.path.join(tmp, "train")
+        os.makedirs(data)
+        with open(os.path.join(data, "part-0"), "w") as f:
+            for _ in range(lines):
+                ids = rng.integers(1, 1000000, 26)
+                dense = rng.random(13)
+                f.write("click:%d " % (rng.random() < 0.25) + " ".join("dense_feature:%.6f" % x for x in dense) + " " +
+                        " ".join("%d:%d" % (i + 1, v) for i, v in enumerate(ids)) + "\n")
+        cmd = [sys.executable, "-m", "paddlerec_amd.run_reference", os.path.join(ref, "tools", "trainer.py"), "-m", cfg,
+               "-o", "runner.epochs=1", "runner.print_interval=2", "runner.use_gpu=False", "runner.train_data_dir=%s" % data,
+               "runner.model_save_path=%s" % os.path.join(tmp, "o")]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, cwd=ref, env=env, capture_output=True, text=True, timeout=budget_s)
+        except subprocess.TimeoutExpired:
+            return {"error": "did not finish in %.0f s" % budget_s}
+        dt = time.perf_counter() - t0
+    log = r.stdout + r.stderr
+    ips = [float(x) for x in re.findall(r"ips: ([0-9.]+) ins/s", log)]
+    bs = re.search(r"train_batch_size: (\d+)", log)
+    if r.returncode != 0 or len(ips) < 2:
+        return {"error": "failed (rc %d): %s" % (r.returncode, log[-300:])}
+    return {"value": sum(ips[1:]) / len(ips[1:]), "unit": "samples/s", "cores": threads, "host_cores": os.cpu_count(),
+            "kind": "reference-trainer-over-shim",
+            "sample": "the reference's unmodified tools/trainer.py, 1 epoch of config_bigdata.yaml (bs %s) on %d synthetic "
+                      "slot-text lines, NumPy oracle backend; its own ips lines (%d intervals), %.1f s wall"
+                      % (bs.group(1) if bs else "?", lines, len(ips) - 1, dt)}
 
 
 def reference_trainer_baseline(budget_s=60.0):
@@ -323,6 +381,7 @@ def main():
         args.table = "ps" if world > 1 else "adam"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rows_req = args.hashed_rows
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch as `python bench.py --gpus N` (spawns its own ranks) or "
                          "under torch.distributed.run --nproc-per-node N" % (args.gpus, world))
@@ -382,6 +441,20 @@ def main():
         parallelism = "single"
     elif args.table == "ps":
         from paddlerec_amd.sharded import ShardedDeepFMLayer
+        # Memory pre-flight (the first real --gpus 8 run must not die of OOM): one 128-B record per row + ~6 GB of
+        # activations / exchange buffers / workspaces of a batch-65536 step must fit what the device reports free.  The
+        # ranks agree on the smallest answer; a shrunk table is SAID in the line (config.table_rows_requested).
+        rows_req = args.hashed_rows
+        if not standin:
+            free_b, _tot = torch.cuda.mem_get_info(dev)
+            fit = int((free_b - 6 * 2 ** 30) * 0.92) // 128
+            fit_t = torch.tensor([max(fit, 1000)], dtype=torch.int64, device=dev)
+            if world > 1:
+                dist.all_reduce(fit_t, op=dist.ReduceOp.MIN)
+            if int(fit_t.item()) < args.hashed_rows:
+                args.hashed_rows = int(fit_t.item())
+                print("[bench] rank %d: %d rows per GPU do not fit (%.1f GB free): table shrunk to %d rows per GPU" %
+                      (rank, rows_req, free_b / 2 ** 30, args.hashed_rows), file=sys.stderr, flush=True)
         N = args.hashed_rows * world
         # embedx_threshold 0: a feature is created whole at its first pull (the full-work regime; the shipped
         # config_online.yaml gates embedx behind 10 shows)
@@ -440,9 +513,18 @@ def main():
     # per-region HIP-event timings (kernels_ms / host_issue_ms / in_step_event) come from a few MORE steps with the
     # event brackets switched on — outside the timed region, which therefore carries no measurement markers
     model.timers = None if standin else {}
-    for i in range(0 if standin else min(args.steps, 10)):
+    n_brk = 0 if standin else min(args.steps, 10)
+    if dist is not None:
+        model.comm.stats = {}
+        if standin:
+            n_brk = 1
+    for i in range(n_brk):
         step(first + args.steps + i)
     sync()
+    exch = None
+    if dist is not None:
+        exch = model.comm.stats_summary(max(n_brk, 1))
+        model.comm.stats = None
     if standin:
         model.timers = {}
     if dist is not None:
@@ -504,7 +586,11 @@ def main():
                    **({"exchange": "rec_alltoall_exchange (C-ABI, RCCL)" if model.comm.native is not None
                        else "torch.distributed (%s)" % ("RCCL" if backend == "nccl" else backend),
                        "rccl_ranks": model.comm.native_ranks} if dist is not None else {}),
-                   "table_rows_total": N, "loss": loss_v, "index_oob_flag": oob},
+                   "table_rows_total": N, "loss": loss_v, "index_oob_flag": oob,
+                   **({"table_rows_requested": rows_req * world} if args.table == "ps" and dist is not None
+                      and rows_req != args.hashed_rows else {}),
+                   **({"native_init_timed_out": True} if dist is not None and getattr(model.comm, "native_init_timed_out", False)
+                      else {})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": (tr_f + tr_b) if tr_f is not None else None,
@@ -528,8 +614,18 @@ def main():
                                        # not subtracted (profiles/*_bench_populations.txt holds rocprofv3's kernel clock)
                                        "empty_bracket_us": empty_bracket_us(dev) if not standin else None},
                      "frac_designed_bytes": ((dfwd_b + dbwd_b) / (fwd_s + bwd_s) / 1e9 / HBM_PEAK_GBS)
-                     if fwd_s + bwd_s > 0 else None},
+                     if fwd_s + bwd_s > 0 else None,
+                     # the honest in-step numbers as top-level scalars of this object (the driver's record keeps scalars,
+                     # not nested objects): the pair bracketed inside a step, and the MLP GEMMs of the same step
+                     "in_step_frac": in_step / HBM_PEAK_GBS, "in_step_us": t_step_pair * 1e6,
+                     "back_to_back_us": (fwd_s + bwd_s) * 1e6,
+                     "mlp_gemm_frac": gemm_tf / FP32_MFMA_PEAK_TF, "mlp_gemm_tflops": gemm_tf},
         "kernels_ms": k_ms, "host_issue_ms": host_ms,
+        **({"exchange": {"rccl_ranks": model.comm.native_ranks, "world": world,
+                         "xgmi_links_per_gpu": 7, "xgmi_link_GBs": 153.0,
+                         # per step and per GPU (rank 0's view): bytes handed to each collective, bytes that leave the
+                         # GPU, microseconds on the stream, egress GB/s = remote bytes / time (all 7 links together)
+                         "per_collective": exch}} if exch is not None else {}),
         "mlp_gemm": {"bound": "mfma", "achieved": gemm_tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": gemm_tf / FP32_MFMA_PEAK_TF, "flops_executed_per_step": 3 * mlp_flops(B, sizes)},
     }
@@ -543,6 +639,10 @@ def main():
                 out["cpu_baseline"]["reference_trainer"] = reference_trainer_baseline()
             except Exception as e:
                 out["cpu_baseline"]["reference_trainer"] = {"error": repr(e)}
+            try:    # ... and at the batch size of its full-data config (bs 512) on a synthetic slot file
+                out["cpu_baseline"]["reference_trainer_bs512"] = reference_trainer_bs512()
+            except Exception as e:
+                out["cpu_baseline"]["reference_trainer_bs512"] = {"error": repr(e)}
             if not args.no_other_configs and B == 65536 and not standin:
                 del model, batches          # the sub-benchmarks get the whole GPU
                 torch.cuda.empty_cache()

@@ -28,7 +28,7 @@ FILES = [
     "tools/utils/static_ps/config_fleet.py", "tools/utils/static_ps/flow_helper.py",
     "tools/utils/static_ps/time_helper.py", "tools/utils/static_ps/metric_helper.py",
     "tools/utils/static_ps/infer_args.py",
-    "models/rank/deepfm/config.yaml", "models/rank/deepfm/net.py", "models/rank/deepfm/dygraph_model.py",
+    "models/rank/deepfm/config.yaml", "models/rank/deepfm/config_bigdata.yaml", "models/rank/deepfm/net.py", "models/rank/deepfm/dygraph_model.py",
     "models/rank/deepfm/criteo_reader.py", "models/rank/deepfm/data/sample_data/train/sample_train.txt",
     "models/rank/dnn/config_gpubox.yaml", "models/rank/dnn/config.yaml", "models/rank/dnn/net.py",
     "models/rank/dnn/static_model.py", "models/rank/dnn/dygraph_model.py", "models/rank/dnn/criteo_reader.py",

@@ -492,9 +492,14 @@ class DeepFMLayer:
                                  self.dense.p["fm.dense_w"], self.dense.p["fm.dense_w_one"], self.fm.padding_idx,
                                  self.fm.slot_offset, self.status, (y1, y2, feat, sum_emb), compact=self.compact)
 
+        # the backward as the STEP runs it: with the slot-local grouping its row gradients go out in sorted order through
+        # the rank of the merge keys (rec_deepfm_fm_bwd_sorted) — the same variant is timed here
+        rank = getattr(getattr(self, "_groups", None), "rank", None)
+        rkw = dict(row_rank=rank) if rank is not None and rank.numel() >= B * S else {}
+
         def bwd(i):
             self.k.deepfm_fm_bwd(dense0, feat, sum_emb, dfeat, dz, dz, S, self.ws, out=out,
-                                 dense_w=self.dense.p["fm.dense_w"], compact=self.compact)
+                                 dense_w=self.dense.p["fm.dense_w"], compact=self.compact, **rkw)
 
         def run(fn):
             ts = []

@@ -37,10 +37,14 @@ class Comm:
         self.world = dist.get_world_size(self.group)
         self.staged = dist.get_backend(self.group) != "nccl"
         self.trace = None       # tests set this to a list: the sequence of collectives this rank issued
+        # bench.py switches this on for a few bracketed steps: {tag: [(bytes sent, bytes sent to OTHER ranks, start event,
+        # end event)]} of every data-path collective — per-step bytes and microseconds of each exchange, per-GPU egress
+        self.stats = None
         # backend nccl: the data-path collectives go through the engine's own C-ABI exchange layer
         # (rec_alltoall_exchange / rec_allreduce_sum_f32 over an RCCL communicator created here) — what a Paddle-side
         # binder gets; torch.distributed only carries the 128-byte communicator id and the small int64 metric sums.
         self.native = None
+        self.native_init_timed_out = False
         self.native_ranks = 0   # ncclCommCount of the C-ABI communicator (0: exchange carried by torch.distributed)
         if not self.staged and os.environ.get("REC_NATIVE_EXCHANGE", "1") != "0":
             self._init_native()
@@ -85,7 +89,27 @@ class Comm:
         raw = bytes(idbuf.cpu().numpy().tobytes())
         h = C.c_void_p()
         try:
-            check(lib().rec_comm_init(raw, self.world, self.rank, C.byref(h)), "rec_comm_init")
+            # ncclCommInitRank blocks until every peer has arrived: run it in a worker thread with a time limit
+            # (REC_NATIVE_INIT_TIMEOUT seconds), so that a rank that never comes back from it does not take the job
+            # down — the ranks then agree to carry the exchange over torch.distributed's communicator instead
+            import threading
+            res = {}
+
+            def work():
+                try:
+                    torch.cuda.set_device(dev)
+                    check(lib().rec_comm_init(raw, self.world, self.rank, C.byref(h)), "rec_comm_init")
+                    res["ok"] = True
+                except Exception as e:      # noqa: BLE001
+                    res["err"] = e
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("REC_NATIVE_INIT_TIMEOUT", "120")))
+            if th.is_alive():
+                self.native_init_timed_out = True
+                raise RuntimeError("rec_comm_init did not return within REC_NATIVE_INIT_TIMEOUT")
+            if "err" in res:
+                raise res["err"]
             self.native = h
             n = C.c_int32(0)
             check(lib().rec_comm_size(h, C.byref(n)), "rec_comm_size")
@@ -156,9 +180,32 @@ class Comm:
         self.dist.all_to_all_single(out, send_counts_dev.contiguous(), group=self.group)
         return out
 
-    def all_to_all(self, out, inp, out_splits, in_splits):
-        """Rows (dim 0) of `inp` split by in_splits go to the ranks; `out` receives out_splits rows."""
-        self._log("all_to_all:%s x%d" % (str(inp.dtype).replace("torch.", ""), inp.shape[1] if inp.dim() > 1 else 1))
+    def _stat_begin(self, tag, sent, remote, on_gpu):
+        if self.stats is None:
+            return None
+        ev = None
+        if on_gpu:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        self.stats.setdefault(tag, []).append([int(sent), int(remote), ev])
+        return ev
+
+    def all_to_all(self, out, inp, out_splits, in_splits, tag=None):
+        """Rows (dim 0) of `inp` split by in_splits go to the ranks; `out` receives out_splits rows.
+        tag: name of the exchange in Comm.stats (ids / rows / grads ...)."""
+        what = "all_to_all:%s x%d" % (str(inp.dtype).replace("torch.", ""), inp.shape[1] if inp.dim() > 1 else 1)
+        self._log(what)
+        ev = None
+        if self.stats is not None:
+            rb = inp.element_size() * (inp.shape[1] if inp.dim() > 1 else 1)
+            ev = self._stat_begin(tag or what, sum(in_splits) * rb, (sum(in_splits) - in_splits[self.rank]) * rb, out.is_cuda)
+        try:
+            return self._all_to_all(out, inp, out_splits, in_splits)
+        finally:
+            if ev is not None:
+                ev[1].record()
+
+    def _all_to_all(self, out, inp, out_splits, in_splits):
         if self.native is not None and out.is_cuda:
             if not (inp.is_contiguous() and out.is_contiguous()):
                 raise ops.RecError("exchange buffers must be contiguous")
@@ -187,8 +234,31 @@ class Comm:
             self.dist.broadcast(t, src=self.dist.get_global_rank(g, src), group=g)
         return t
 
-    def all_reduce_sum(self, t):
+    def all_reduce_sum(self, t, tag="all_reduce"):
         self._log("all_reduce")
+        ev = None
+        if self.stats is not None:     # ring all-reduce: every rank sends 2 (G-1)/G of the buffer
+            nb = t.numel() * t.element_size()
+            ev = self._stat_begin(tag, nb, int(2 * nb * (self.world - 1) / max(self.world, 1)), t.is_cuda)
+        try:
+            return self._all_reduce_sum(t)
+        finally:
+            if ev is not None:
+                ev[1].record()
+
+    def stats_summary(self, steps):
+        """{tag: {calls_per_step, bytes_per_step, remote_bytes_per_step, us_per_step, egress_GBs}} of the collectives
+        recorded since Comm.stats = {} (call after a device synchronize)."""
+        out = {}
+        for tag, recs in (self.stats or {}).items():
+            us = sum(e[0].elapsed_time(e[1]) * 1e3 for _, _, e in recs if e is not None)
+            sent, remote = sum(r[0] for r in recs), sum(r[1] for r in recs)
+            out[tag] = {"calls_per_step": len(recs) / steps, "bytes_per_step": sent / steps,
+                        "remote_bytes_per_step": remote / steps, "us_per_step": us / steps if us else None,
+                        "egress_GBs": (remote / 1e9) / (us * 1e-6) if us else None}
+        return out
+
+    def _all_reduce_sum(self, t):
         g = self.group
         if self.native is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
             import ctypes as C
@@ -351,7 +421,7 @@ class ShardedDeepFMLayer(DeepFMLayer):
         # exchange buffers are persistent (grown with slack, never allocated per step): no allocator traffic and
         # no cross-stream block recycling on the exchange path
         L.recv_rows = self._fit("recv_rows%d" % (self._reply_flip ^ 1), L.n_recv, 0, torch.int64)
-        self.comm.all_to_all(L.recv_rows, route.send_local_row[: L.n_send], L.recv_splits, L.send_splits)
+        self.comm.all_to_all(L.recv_rows, route.send_local_row[: L.n_send], L.recv_splits, L.send_splits, tag="a2a_ids")
         g_rows = self._fit("g_rows", L.n_recv, D)
         g_w1 = self._fit("g_w1", L.n_recv, 1)
         if L.n_recv:       # both embeddings of a row from its one record line (unborn PS rows: creation values)
@@ -362,8 +432,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
             rep = self._replies[self._reply_flip] = (torch.zeros(n + 1, D, **f32),
                                                      torch.zeros(n + 1, 1, **f32))  # row 0 stays 0
         L.reply, L.reply1 = rep
-        self.comm.all_to_all(L.reply[1:1 + L.n_send], g_rows, L.send_splits, L.recv_splits)
-        self.comm.all_to_all(L.reply1[1:1 + L.n_send], g_w1, L.send_splits, L.recv_splits)
+        self.comm.all_to_all(L.reply[1:1 + L.n_send], g_rows, L.send_splits, L.recv_splits, tag="a2a_rows")
+        self.comm.all_to_all(L.reply1[1:1 + L.n_send], g_w1, L.send_splits, L.recv_splits, tag="a2a_rows")
         return L
 
     def _fm_fwd_routed(self, L, B, S, dense_inputs):
@@ -475,8 +545,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
                                      out=send_g1[:, 1:], out_group=1, out_group_stride=C1)
                 recv_g = self._fit("recv_g", max(L.n_recv, 1), D)
                 recv_g1 = self._fit("recv_g1", max(L.n_recv, 1), C1)
-                self.comm.all_to_all(recv_g[: L.n_recv], send_g, L.recv_splits, L.send_splits)
-                self.comm.all_to_all(recv_g1[: L.n_recv], send_g1, L.recv_splits, L.send_splits)
+                self.comm.all_to_all(recv_g[: L.n_recv], send_g, L.recv_splits, L.send_splits, tag="a2a_grads")
+                self.comm.all_to_all(recv_g1[: L.n_recv], send_g1, L.recv_splits, L.send_splits, tag="a2a_grads")
             with self._timed("sparse_adam"):
                 if L.n_recv and self.ps is not None:
                     # the accessor's push: counters, AdaGrad rule per part, lazy birth / embedx creation
@@ -515,10 +585,10 @@ class ShardedDeepFMLayer(DeepFMLayer):
         if on_gpu:
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
-                self.comm.all_reduce_sum(self.dense.grad)
+                self.comm.all_reduce_sum(self.dense.grad, tag="allreduce_dense")
             cur.wait_stream(self._side)
         else:
-            self.comm.all_reduce_sum(self.dense.grad)
+            self.comm.all_reduce_sum(self.dense.grad, tag="allreduce_dense")
         loss = loss_slot.clone()
         loss_slot.zero_()                                         # not a parameter: keep Adam off it
         k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)

@@ -253,15 +253,18 @@ def train(config, model, device="cuda", kernels=None, comm=None):
         metric_list, metric_names = dy_model_class.create_metrics(dy_model.device)
         epoch_begin = time.time()
         reader_cost = run_cost = 0.0
+        reader_total = run_total = 0.0            # whole-epoch stage times (the interval ones are reset at every log line)
         interval_samples = total_samples = n_batches = 0
         loss = None
         reader_start = time.time()
         for batch_id, (batch, nxt) in enumerate(_lookahead(loader(), limit)):
             reader_cost += time.time() - reader_start
+            reader_total += time.time() - reader_start
             t0 = time.time()
             fkw = {"next_batch": nxt} if world > 1 else {}
             loss, metric_list, _ = dy_model_class.train_forward(dy_model, metric_list, batch, config, **fkw)
             run_cost += time.time() - t0
+            run_total += time.time() - t0
             bs = _batch_size(batch) * world
             interval_samples += bs
             total_samples += bs
@@ -280,16 +283,23 @@ def train(config, model, device="cuda", kernels=None, comm=None):
             reader_start = time.time()
         if n_batches == 0:                                # trainer.py:143-144
             raise ValueError("train_dataloader is null, please ensure batch size < dataset size!")
+        t_sync = time.time()
         if dy_model.device.type == "cuda":
             torch.cuda.synchronize(dy_model.device)
         elapsed = time.time() - epoch_begin
+        sync_s = time.time() - t_sync
         _check_status(dy_model, comm, "train")
         vals = _global_metric_values(dy_model_class, metric_list, metric_names, comm)
         if use_auc:
             _reset(metric_list)
-        model_dir = checkpoint.save_model(dy_model, None, save_path, epoch_id, prefix="rec")
+        t_ck = time.time()
+        model_dir = checkpoint.save_model(dy_model, None, save_path, epoch_id, prefix="rec") \
+            if config.get("runner.save_checkpoint", True) else None
+        # ips = samples / (first batch requested .. device idle): the checkpoint is NOT inside it; the stage times say
+        # where the host spent the epoch (waiting for the reader / issuing steps / draining the device at the end)
         s = dict(epoch=epoch_id, batches=n_batches, samples=total_samples, loss=float(loss.reshape(-1)[0].item()),
-                 ips=total_samples / max(elapsed, 1e-9), model_dir=model_dir, **vals)
+                 ips=total_samples / max(elapsed, 1e-9), model_dir=model_dir, epoch_s=elapsed, reader_wait_s=reader_total,
+                 step_issue_s=run_total, final_sync_s=sync_s, checkpoint_s=time.time() - t_ck, **vals)
         logger.info("epoch: %d done, %s epoch time: %.2f s", epoch_id,
                     "".join("%s: %.6f," % kv for kv in vals.items()), elapsed)
         summaries.append(s)

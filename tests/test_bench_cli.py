@@ -63,3 +63,24 @@ def test_world_size_mismatch_is_refused():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_eight_ranks_on_the_ps_table_print_the_exchange_fields():
+    """nothing had run with more than 2 ranks.  `python bench.py --gpus 8` as the driver starts it
+    (gloo stand-in): eight ranks rendezvous, shard the hashed table 8 ways, and rank 0's line carries the per-collective
+    exchange fields — the three all-to-alls (ids, rows, gradients) and the dense all-reduce with bytes per step."""
+    d = _run(["--gpus", "8"] + SMALL + ["--hashed-rows", "2000"], timeout=900)
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8 * 64 and d["config"]["table_rows_total"] == 16000
+    assert "rowshard8+dp8" in d["config"]["parallelism"] and d["config"]["index_oob_flag"] == 0
+    ex = d["exchange"]
+    assert ex["world"] == 8 and ex["rccl_ranks"] == 0                 # gloo here: the C-ABI communicator has no ranks
+    pc = ex["per_collective"]
+    for tag in ("a2a_ids", "a2a_rows", "a2a_grads", "allreduce_dense"):
+        assert tag in pc and pc[tag]["bytes_per_step"] > 0, tag
+    # 7/8 of the routed lookups leave the rank (uniform hash): ids 8 B, rows 16 + 1 floats, gradients 16 + 2 floats
+    n_lookups = 64 * 26 * 0.97
+    assert 0.7 * n_lookups * 8 < pc["a2a_ids"]["remote_bytes_per_step"] < n_lookups * 8
+    # (a rank sends its n_send ids / gradient rows out and the n_recv rows it OWNS back: equal only on average)
+    assert abs(pc["a2a_rows"]["bytes_per_step"] / pc["a2a_ids"]["bytes_per_step"] / ((17 * 4) / 8) - 1) < 0.2
+    assert abs(pc["a2a_grads"]["bytes_per_step"] / pc["a2a_ids"]["bytes_per_step"] / ((18 * 4) / 8) - 1) < 0.2
+    assert 0.0 < d["config"]["loss"] < 5.0

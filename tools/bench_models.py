@@ -31,11 +31,20 @@ JSON = []
 PEAK_TF, PEAK_GBS = 157.3, 8000.0
 
 
-def record(config, workload, ms, flops, samples, extra=None):
+def record(config, workload, ms, flops, samples, extra=None, hbm_bytes=None, bytes_formula=None):
+    """hbm_bytes: the line is NOT MFMA-bound (few rows per GEMM, BatchNorm / optimizer sweeps, a chain of small launches):
+    its roofline object is then the HBM one — algorithmic bytes of the step (bytes_formula says which) over the time —
+    and the GEMM rate is kept beside it as `mfma_tflops` for reference (a blanket "mfma" said nothing for
+    DLRM and for DIN at batch 32)."""
     tf = flops / ms / 1e9
+    if hbm_bytes is None:
+        roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_TF, "unit": "TFLOP/s", "frac": tf / PEAK_TF, "flops": flops}
+    else:
+        gbs = hbm_bytes / ms / 1e6
+        roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_GBS, "unit": "GB/s", "frac": gbs / PEAK_GBS,
+                "bytes": hbm_bytes, "bytes_formula": bytes_formula, "mfma_tflops": tf}
     d = {"config": config, "workload": workload, "ms": ms, "samples_per_s": samples / ms * 1e3, "dtype": "f32",
-         "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TF, "unit": "TFLOP/s", "frac": tf / PEAK_TF,
-                      "flops": flops}}
+         "roofline": roof}
     if extra:
         d.update(extra)
     JSON.append(d)
@@ -62,8 +71,13 @@ for B, mix, depth in ((65536, False, 3), (512, False, 3), (65536, True, 2)):
         t_s = timeit(lambda: m.train_step(ids, dense, label, lr=1e-3))
         print("DCN-v2 CrossNetV2 depth%d B=%d: forward %.2f ms (%.1f TF)  train step %.2f ms (%.1f TF, %.2f M samples/s)" %
               (depth, B, t_f, fl_f / t_f / 1e9, t_s, 3 * fl_f / t_s / 1e9, B / t_s / 1e3))
+        n_par = depth * (d * d + d) + d * 768 + 768 * 768 + 768 + 768 + 13 * 520 + 520 + 2 * 768
+        small = B < 4096      # the reference's own batch: every GEMM has 512 rows — the step streams parameters, not rows
         record("configs[2]", "DCN-v2 CrossNetV2 depth %d, d 1560, DNN 768-768, B %d: train step (fwd + bwd + clip + "
-               "Adam)" % (depth, B), t_s, 3 * fl_f, B, {"forward_ms": t_f, "forward_tflops": fl_f / t_f / 1e9})
+               "Adam)" % (depth, B), t_s, 3 * fl_f, B, {"forward_ms": t_f, "forward_tflops": fl_f / t_f / 1e9},
+               hbm_bytes=(n_par * 4 * (7 + 2 + 3) if small else None),
+               bytes_formula=("dense parameters P = %d: Adam 7 x 4P (read g, p, m, v; write p, m, v) + clip norm and L2 "
+                              "passes 2 x 4P + weights read by the forward / dX / dW GEMMs 3 x 4P" % n_par if small else None))
     del m
     torch.cuda.empty_cache()
 
@@ -86,7 +100,11 @@ for B, T in ((32, 152), (4096, 100), (4096, 512)):
            "T %d" % (B, T), t, fl, B,
            {"positions_per_s": B * T / t * 1e3,
             "gather_roofline": {"bound": "hbm", "achieved": by / t / 1e6, "peak": PEAK_GBS, "unit": "GB/s",
-                                "frac": by / t / 1e6 / PEAK_GBS, "bytes": by}})
+                                "frac": by / t / 1e6 / PEAK_GBS, "bytes": by}},
+           hbm_bytes=(by if B * T < 65536 else None),
+           bytes_formula=("B T (4 ids x 8 + mask 8 + 4 rows x 256 B): 32 samples = 32 blocks on 256 CUs, a dependent "
+                          "chain per block — neither roofline binds, the bytes are what the kernel must move"
+                          if B * T < 65536 else None))
 
 # ---- DIN full train step (din/dygraph_model.py:85-100): attention-pool fwd + bwd, the concat MLP, 7 row-merged SGDs
 from paddlerec_amd.din import DINLayer  # noqa: E402
@@ -105,14 +123,22 @@ for B, T in ((32, 152), (4096, 100), (4096, 512)):
     fl = 2.0 * B * T * (512 * 80 + 80 * 40 + 40 + 128) + 2.0 * B * T * (512 * 80 + 2 * 80 * 40 + 128)
     print("DIN train step B=%d T=%d: %.3f ms  (%.1f k samples/s, %.1f M positions/s, attention fwd+bwd %.1f TF executed)"
           % (B, T, t, B / t, B * T / t / 1e3, fl / t / 1e9))
+    # bytes of a step: history rows gathered by forward and backward (4 x 256 B per position each), act1 saved and re-read
+    # (80 floats), dh / dq written (2 x 128 floats), row gradients merged into 7 tables (read + write 128 floats), ids + mask
+    by_step = B * T * (2 * 4 * 256 + 2 * 80 * 4 + 2 * 128 * 4 + 2 * 128 * 4 + 5 * 8)
     record("configs[3]", "DIN train step (attention-pool fwd + bwd on saved activations, concat MLP, row-merged SGD on "
-           "7 tables), B %d, T %d" % (B, T), t, fl, B, {"positions_per_s": B * T / t * 1e3})
+           "7 tables), B %d, T %d" % (B, T), t, fl, B, {"positions_per_s": B * T / t * 1e3},
+           hbm_bytes=(by_step if B * T < 65536 else None),
+           bytes_formula=("B T (gathers fwd + bwd 2 x 4 x 256 + act1 2 x 320 + dh / dq 2 x 512 + row-gradient merge 2 x 512 "
+                          "+ ids / mask 40) B: ~34 dependent launches at the ~5 us floor each are the step time"
+                          if B * T < 65536 else None))
     if B == 32:     # the same step replayed from a hipGraph (paddlerec_amd/graph.py): the launch-bound shape
         tg = timeit(lambda: m.train_step_graphed(hi, hc, ti, tc, label, mask, tis, tcs))
         print("DIN train step B=%d T=%d, hipGraph replay: %.3f ms  (%.1f k samples/s; eager %.3f ms)"
               % (B, T, tg, B / tg, t))
         record("configs[3]", "DIN train step replayed from a hipGraph (same launches), B %d, T %d" % (B, T), tg, fl, B,
-               {"positions_per_s": B * T / tg * 1e3, "eager_ms": t})
+               {"positions_per_s": B * T / tg * 1e3, "eager_ms": t}, hbm_bytes=by_step,
+               bytes_formula="as the eager step above")
     del m
     torch.cuda.empty_cache()
 
@@ -139,8 +165,12 @@ for B in (4096, 65536):
     fl = 2.0 * B * (13 * 512 + 512 * 256 + 256 * 64 + 64 * 16 + 367 * 512 + 512 * 256 + 256 * 2 + 27 * 27 * 16)
     print("DLRM train step B=%d: %.2f ms  (%.2f M samples/s; non-lazy Adam sweeps the 1M x 16 table every step)"
           % (B, t, B / t / 1e3))
+    widths = 512 + 256 + 64 + 16 + 512 + 256 + 2
+    by_dlrm = 6 * 1000001 * 16 * 4 + 7 * B * widths * 4 + 3 * B * 26 * 16 * 4
     record("sibling net", "DLRM (bot 512-256-64-16, top 512-256-2, BatchNorm after every layer, 27 x 27 dot "
-           "interaction) train step with non-lazy Adam, B %d" % B, t, 3 * fl, B)
+           "interaction) train step with non-lazy Adam, B %d" % B, t, 3 * fl, B, hbm_bytes=by_dlrm,
+           bytes_formula="non-lazy Adam sweeps the table 6 N D 4 B (N 1000001, D 16) + BatchNorm after every Linear: 7 passes "
+                         "(3 forward, 4 backward) over B x %d activations x 4 B + lookup rows 3 B 26 D 4" % widths)
     del m
     torch.cuda.empty_cache()
 
