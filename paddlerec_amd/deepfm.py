@@ -354,14 +354,17 @@ class DeepFMLayer:
                  and hasattr(self.k, "sparse_adam_record_small")
                  and os.environ.get("REC_SMALL_MERGE", "1") != "0")
 
-        # slot-local grouping + row gradients in sorted order (round 4): the update kernel streams its gradient rows
-        # instead of chasing sorted_pos into a 109 MB buffer (REC_DEEPFM_SORTED=0: the general sort, position order)
+        # Slot-local grouping (round 4: rec_ids_group_slots, 7 launches instead of 13; REC_DEEPFM_GROUP=general: the one
+        # 25-bit sort) — and, optionally, row gradients written in SORTED order through the rank it emits
+        # (REC_DEEPFM_SORTED_GRAD=1: rec_deepfm_fm_bwd_sorted + rec_grad_layout.sorted).  Measured on MI355X
+        # (profiles/r04_sorted_grad_ab.txt): the update kernel's traffic drops 1151 -> 1002 MB per launch (the floor of the
+        # two-line record layout is ~985) and it runs 375 -> 340-358 us beside dW_0, but fm_bwd — on the critical path —
+        # pays 62 -> 75 us for scattering 64-byte rows, and the step time is the same (2.25 ms both ways).  Default off:
+        # the roofline kernels stay at their streaming speed.
         slot_sort = (not small and self.slot_rows is not None
                      and hasattr(self.k, "group_slots_eligible") and self.k.group_slots_eligible(B, S, self.slot_rows)
-                     and os.environ.get("REC_DEEPFM_SORTED", "1") != "0")
-        # REC_DEEPFM_SORTED=2 (measurement): the slot-local sort without the rank, gradients in position order
-        sorted_rg = slot_sort and self.lazy_mode and os.environ.get("REC_DEEPFM_SORTED", "1") != "2"
-
+                     and os.environ.get("REC_DEEPFM_GROUP", "slots") != "general")
+        sorted_rg = slot_sort and self.lazy_mode and os.environ.get("REC_DEEPFM_SORTED_GRAD", "0") == "1"
         # REC_DEEPFM_GROUP_CUS=<stride>[,range]: the grouping on its own stream confined to every stride-th CU ("k,r":
         # the first r CUs) — the 256x80 GEMM blocks fill the VGPR file (4 waves x 128 per SIMD), so a sort block can
         # only run where a GEMM block is not: confined to a few CUs it packs there instead of displacing GEMM blocks

@@ -208,8 +208,9 @@ def test_fm_bwd_sorted_and_record_update_match_position_order(ops, B, R_, zipf):
 
 def test_deepfm_layer_slot_path_equals_general_path(ops, monkeypatch):
     """DeepFMLayer with 26 tables as one (BASELINE configs[1] layout) at a batch the slot-local grouping takes: three train
-    steps through rec_ids_group_slots + rec_deepfm_fm_bwd_sorted + rec_grad_layout.sorted leave every parameter, moment
-    and prediction bit-identical to the general path (REC_DEEPFM_SORTED=0: one 25-bit sort, gradients in position order)
+    steps through rec_ids_group_slots (+ rec_deepfm_fm_bwd_sorted + rec_grad_layout.sorted with REC_DEEPFM_SORTED_GRAD=1)
+    leave every parameter, moment and prediction bit-identical to the general path (REC_DEEPFM_GROUP=general: one 25-bit
+    sort, gradients in position order)
     — and the first step's loss / dense gradient agree with the NumPy oracle."""
     from paddlerec_amd.deepfm import DeepFMLayer
     from helpers import make_deepfm_problem
@@ -224,7 +225,8 @@ def test_deepfm_layer_slot_path_equals_general_path(ops, monkeypatch):
     batches = [make_deepfm_problem(B=B, N=R_, D=D, fc=fc, seed=20 + i, tables=True, zipf=(i == 1)) for i in range(3)]
 
     def run(flag):
-        monkeypatch.setenv("REC_DEEPFM_SORTED", flag)
+        monkeypatch.setenv("REC_DEEPFM_GROUP", "slots" if flag != "0" else "general")
+        monkeypatch.setenv("REC_DEEPFM_SORTED_GRAD", "1" if flag == "1" else "0")
         monkeypatch.setenv("REC_STEP_PLAN", "0")
         m = DeepFMLayer(R_ * S, D, 13, S, fc, device=DEV, slot_offset=pr["slot_offsets"])
         assert m.slot_rows == R_
@@ -238,13 +240,16 @@ def test_deepfm_layer_slot_path_equals_general_path(ops, monkeypatch):
         return m, outs
 
     m1, o1 = run("1")
-    assert m1._groups.rank is not None                    # the sorted path ran
+    assert m1._groups.rank is not None                    # slot-local grouping + sorted row gradients
     m0, o0 = run("0")
-    assert m0._groups.rank is None
-    for (l1, p1), (l0, p0) in zip(o1, o0):
-        assert torch.equal(l1, l0) and torch.equal(p1, p0)
-    assert torch.equal(m1.fm.rec, m0.fm.rec) and torch.equal(m1.sparse_state["mv"], m0.sparse_state["mv"])
-    assert torch.equal(m1.dense.data, m0.dense.data) and torch.equal(m1.dense.m, m0.dense.m)
+    assert m0._groups.rank is None                        # the general 25-bit sort, gradients in position order
+    m2, o2 = run("2")
+    assert m2._groups.rank is None                        # the default: slot-local grouping, gradients in position order
+    for mx, ox in ((m0, o0), (m2, o2)):
+        for (l1, p1), (l0, p0) in zip(o1, ox):
+            assert torch.equal(l1, l0) and torch.equal(p1, p0)
+        assert torch.equal(m1.fm.rec, mx.fm.rec) and torch.equal(m1.sparse_state["mv"], mx.sparse_state["mv"])
+        assert torch.equal(m1.dense.data, mx.dense.data) and torch.equal(m1.dense.m, mx.dense.m)
     o = R.deepfm_loss_and_grads(batches[0]["ids"], batches[0]["dense"], batches[0]["label"], p,
                                 slot_offsets=pr["slot_offsets"])
     np.testing.assert_allclose(float(o1[0][0].item()), o["loss"], rtol=1e-5)

@@ -6,7 +6,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-CMD="python $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+CMD="python $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs"
 timeout 200 rocprofv3 --kernel-trace --stats -d $out/trace -o t --output-format csv -- $CMD > $out/bench_under_rocprof.log 2>&1
 echo "trace rc=$?"
 i=0
