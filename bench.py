@@ -649,6 +649,12 @@ def main():
                 out["other_configs"] = other_configs()
         print(json.dumps(out), flush=True)
     if dist is not None:
+        # leave together: a rank that tears its communicator down while a peer is still inside its last collective
+        # takes that peer down with it (seen with 8 gloo ranks: "terminate called without an active exception")
+        try:
+            dist.barrier()
+        except Exception as e:      # noqa: BLE001 - the line is out; a failed good-bye must not turn into a non-zero exit
+            print("[bench] rank %d: final barrier failed: %r" % (rank, e), file=sys.stderr)
         dist.destroy_process_group()
 
 
