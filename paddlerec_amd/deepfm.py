@@ -338,15 +338,13 @@ class DeepFMLayer:
         groups = getattr(self, "_groups", None)          # persistent: the wait_stream below orders reuse
         if groups is None or groups.n != B * S:
             groups = self._groups = self.k.IdGroups(B * S, self.device)
-        with self._timed("fm_fwd"):
-            y1, y2, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
         # SelectedRows merge keys only depend on ids: sort them on a side stream, hidden behind the MFMA-bound GEMMs.
         # REC_DEEPFM_GROUP_AT (measurement knob): "bwd" = under the dX chain (default: 2.83 ms/step), "fwd" = under
         # the forward GEMMs (2.875 ms; gpurun call 25) — the sort costs the GEMMs it runs beside about its own time
         # either way, the backward chain absorbs it slightly better
         # (round 3, weights aligned and the pipe kernels in the step: under the forward GEMMs is now the better place —
         # 2.311 against 2.32-2.34 ms in three A/B pairs on one box, profiles/r03_schedule_ab.txt)
-        group_at = os.environ.get("REC_DEEPFM_GROUP_AT", "fwd")
+        group_at = os.environ.get("REC_DEEPFM_GROUP_AT", "pre")
 
         # the reference's own batch sizes (config_bigdata.yaml: 512 x 26 = 13312 lookups): the merge happens inside the
         # ONE launch of the record update — no grouping sort, no hot-row partial passes (12 launches less per step)
@@ -389,6 +387,10 @@ class DeepFMLayer:
                 else:
                     self.k.ids_group(ids, self.sparse_feature_number, self.fm.padding_idx, self.ws_group,
                                      self.fm.slot_offset, self.status, groups)
+        if group_at == "pre":       # forked BEFORE fm_fwd: beside the HBM-bound lookup instead of under the forward GEMMs
+            issue_group()
+        with self._timed("fm_fwd"):
+            y1, y2, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
         if group_at == "fwd":
             issue_group()
         mlp_w, mlp_dw = self._mlp_weights()

@@ -13,6 +13,7 @@ import mmap
 import os
 import queue
 import threading
+import time
 
 import numpy as np
 import torch
@@ -180,6 +181,8 @@ def feasign_batches(file_list, batch_size, first_slot=1, num_slots=301, hash_row
 
 
 class _FileBatches:
+    last_trace = None
+
     def __init__(self, file_list, batch_size, device, parse, shard=None):
         self.file_list = list(file_list)
         if shard is not None:                      # criteo_reader.py:30-43: files split by worker
@@ -207,50 +210,72 @@ class _FileBatches:
                 _close_mmap(mm)
 
     def _files(self):
-        """Parsed files in order; the NEXT file is read and parsed by a background thread (the parser is a C call that
-        releases the GIL) while the caller trains on the current one."""
-        q = queue.Queue(maxsize=1)
+        """Parsed files in order; the NEXT files are read and parsed by background threads (the parser is a C call that
+        releases the GIL) while the caller trains on the current one — started NOW, not at the first next(): iter(reader)
+        begins the pass.  REC_READER_PRODUCERS (default 1) producers take the files round-robin (measured: the parser
+        already uses every core, two producers only slow each other — profiles/r04_trainer_level.txt) and the consumer
+        takes their results in file order."""
+        nprod = max(1, min(int(os.environ.get("REC_READER_PRODUCERS", "1")), len(self.file_list) or 1))
+        queues = [queue.Queue(maxsize=1) for _ in range(nprod)]
         stop = threading.Event()
+        # REC_READER_TRACE=1: (file, load seconds, seconds blocked on the queue) of the newest pass over the files
+        trace = _FileBatches.last_trace = [] if os.environ.get("REC_READER_TRACE") else None
 
-        def produce():
-            try:
-                for path in self.file_list:
-                    item = self._load(path)
-                    while not stop.is_set():
-                        try:
-                            q.put(item, timeout=0.1)
-                            break
-                        except queue.Full:
-                            pass
-                    if stop.is_set():
-                        return
-                item = None
-            except BaseException as e:           # surfaces in the consumer
-                item = e
+        def put(q, item):
             while not stop.is_set():
                 try:
                     q.put(item, timeout=0.1)
-                    break
+                    return True
                 except queue.Full:
                     pass
+            return False
 
-        th = threading.Thread(target=produce, daemon=True)
-        th.start()
+        def produce(k):
+            q = queues[k]
+            try:
+                for path in self.file_list[k::nprod]:
+                    t0 = time.perf_counter()
+                    item = self._load(path)
+                    t1 = time.perf_counter()
+                    if not put(q, item):
+                        return
+                    if trace is not None:
+                        trace.append([os.path.basename(path), t1 - t0, time.perf_counter() - t1])
+                item = None
+            except BaseException as e:           # surfaces in the consumer
+                item = e
+            put(q, item)
+
+        for k in range(nprod):
+            threading.Thread(target=produce, args=(k,), daemon=True).start()
+        return self._consume(queues, nprod, stop)
+
+    def _consume(self, queues, nprod, stop):
         try:
-            while True:
-                item = q.get()
-                if item is None:
-                    return
+            for i in range(len(self.file_list)):
+                item = queues[i % nprod].get()
                 if isinstance(item, BaseException):
                     raise item
+                if item is None:                 # a producer ran out early: cannot happen with a fixed file list
+                    return
                 yield item
+            for q in queues:                     # every producer ends with None or an exception
+                item = q.get()
+                if isinstance(item, BaseException):
+                    raise item
         finally:
             stop.set()
 
     def __iter__(self):
+        """iter(reader) starts reading and parsing the first files right away; the batches come from the returned
+        generator.  (The trainer creates the NEXT epoch's iterator before it drains the device and writes the checkpoint
+        of this one, so an epoch does not begin with an idle device waiting for its first file.)"""
+        return self._batches(self._files())
+
+    def _batches(self, files):
         B = self.batch_size
         carry = None
-        for label, ids, dense in self._files():
+        for label, ids, dense in files:
             if carry is not None:
                 label, ids, dense = (torch.cat([c, x]) for c, x in zip(carry, (label, ids, dense)))
             n = label.shape[0]

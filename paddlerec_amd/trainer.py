@@ -249,6 +249,7 @@ def train(config, model, device="cuda", kernels=None, comm=None):
         raise ValueError("train_dataloader is null on at least one rank, please ensure batch size < dataset size "
                          "of every rank's file split!")
     summaries = []
+    pending_iter = None
     for epoch_id in range(config.get("last_epoch", -1) + 1, epochs):
         metric_list, metric_names = dy_model_class.create_metrics(dy_model.device)
         epoch_begin = time.time()
@@ -257,7 +258,8 @@ def train(config, model, device="cuda", kernels=None, comm=None):
         interval_samples = total_samples = n_batches = 0
         loss = None
         reader_start = time.time()
-        for batch_id, (batch, nxt) in enumerate(_lookahead(loader(), limit)):
+        epoch_iter, pending_iter = (pending_iter if pending_iter is not None else loader()), None
+        for batch_id, (batch, nxt) in enumerate(_lookahead(epoch_iter, limit)):
             reader_cost += time.time() - reader_start
             reader_total += time.time() - reader_start
             t0 = time.time()
@@ -283,6 +285,8 @@ def train(config, model, device="cuda", kernels=None, comm=None):
             reader_start = time.time()
         if n_batches == 0:                                # trainer.py:143-144
             raise ValueError("train_dataloader is null, please ensure batch size < dataset size!")
+        if epoch_id + 1 < epochs:     # the next epoch's first files are read and parsed while the device drains and the
+            pending_iter = loader()   # checkpoint is written (the readers start their background parse at iter())
         t_sync = time.time()
         if dy_model.device.type == "cuda":
             torch.cuda.synchronize(dy_model.device)
@@ -300,6 +304,9 @@ def train(config, model, device="cuda", kernels=None, comm=None):
         s = dict(epoch=epoch_id, batches=n_batches, samples=total_samples, loss=float(loss.reshape(-1)[0].item()),
                  ips=total_samples / max(elapsed, 1e-9), model_dir=model_dir, epoch_s=elapsed, reader_wait_s=reader_total,
                  step_issue_s=run_total, final_sync_s=sync_s, checkpoint_s=time.time() - t_ck, **vals)
+        from .reader import _FileBatches
+        if _FileBatches.last_trace:                 # REC_READER_TRACE=1: per file (name, load s, s blocked on the queue)
+            s["reader_trace"] = [[a, round(b, 4), round(c, 4)] for a, b, c in _FileBatches.last_trace]
         logger.info("epoch: %d done, %s epoch time: %.2f s", epoch_id,
                     "".join("%s: %.6f," % kv for kv in vals.items()), elapsed)
         summaries.append(s)

@@ -79,6 +79,7 @@ def main():
     print(json.dumps({"metric": "trainer ips (text files -> host parser -> device -> DeepFM train step)",
                       "value": last["ips"], "unit": "samples/s", "epochs": [s["ips"] for s in summaries],
                       "batches_per_epoch": last["batches"], "stages_s_per_epoch": stages,
+                      "reader_trace_last_epoch": last.get("reader_trace"),
                       "lines": per * args.files, "text_bytes": size, "batch": args.batch, "dim": args.dim,
                       "backend": args.backend, "loss": last["loss"], "auc": last["auc"],
                       "generate_text_s": round(gen_s, 2),
