@@ -239,6 +239,32 @@ def test_gemm_glds_kernel(ops, M, N, K, tb, monkeypatch):
     _check(ops.gemm(wide[:, :K], Bt, ws, trans_b=tb).cpu().numpy(), want, bound)
 
 
+@pytest.mark.parametrize("M,N,K,tb", [(32768, 400, 400, False), (32768, 400, 432, False), (32768, 400, 400, True),
+                                      (32768, 432, 400, True), (65536 + 64 * 40, 400, 48, False)])
+def test_gemm_panel_kernel(ops, M, N, K, tb, monkeypatch):
+    """The row-panel kernel (csrc/gemm_panel.h: a block owns 64 rows x ALL N columns, persistent over panels, permuted
+    accumulator columns, float4 epilogue) is an opt-in experiment (REC_GEMM_PANEL=1; no faster on random data, see
+    profiles/r04_gemm_power.txt): against float64 and BIT-IDENTICAL to the tiled kernels (same order of additions), the
+    four epilogues, both B forms, a panel count that is not a multiple of the grid."""
+    rng = np.random.default_rng(M + N * 3 + K)
+    A, B = _mk(rng, M, K), _mk(rng, K, N)
+    bias, X0 = _mk(rng, N), _mk(rng, M, N)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    At, Bt = t(A), t(B.T if tb else B)
+    ws = ops.Workspace(DEV)
+    want = A.astype(np.float64) @ B.astype(np.float64)
+    bound = 4e-7 * (np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64))
+    for kw, ref, extra in ((dict(), want, 0.0), (dict(epilogue="bias", bias=t(bias)), want + bias, 1e-6),
+                           (dict(epilogue="bias_relu", bias=t(bias)), np.maximum(want + bias, 0), 1e-6),
+                           (dict(epilogue="relu_mask", aux0=t(X0)), np.where(X0 > 0, want, 0), 0.0)):
+        monkeypatch.setenv("REC_GEMM_PANEL", "1")
+        Cp = ops.gemm(At, Bt, ws, trans_b=tb, **kw).cpu().numpy()
+        monkeypatch.setenv("REC_GEMM_PANEL", "0")
+        Ct = ops.gemm(At, Bt, ws, trans_b=tb, **kw).cpu().numpy()
+        _check(Cp, ref, bound + extra)
+        assert np.array_equal(Cp, Ct), kw.get("epilogue", "none")
+
+
 @pytest.mark.parametrize("B,N,ld", [(64, 400, 400), (1000, 400, 400), (65536, 400, 400), (4099, 16, 16),
                                     (2048, 512, 512), (777, 128, 132)])
 def test_mlp_head_bwd(ops, B, N, ld):
