@@ -359,6 +359,9 @@ def main():
                     help="skip the CPU baselines AND the other-configs section (quick runs, profiling)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the BASELINE configs[2]/[3]/[4] + row-P measurements appended to the line at N = 1")
+    ap.add_argument("--c-step", action="store_true",
+                    help="issue every step through the one-call C entry point rec_deepfm_train_step (one stream; what a "
+                         "non-Python binder gets) instead of the Python mirror's step")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the row-sharded path (RCCL all-to-all) even with one rank")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -478,6 +481,8 @@ def main():
         ids, dense, label = batches[i % len(batches)]
         if dist is not None:      # the sharded layer routes the next batch's ids a step ahead
             return model.train_step(ids, dense, label, lr=1e-3, next_sparse_inputs=batches[(i + 1) % len(batches)][0])
+        if args.c_step:
+            return model.train_step_c(ids, dense, label, lr=1e-3)
         return model.train_step(ids, dense, label, lr=1e-3)
 
     def barrier():
@@ -587,6 +592,7 @@ def main():
                        else "torch.distributed (%s)" % ("RCCL" if backend == "nccl" else backend),
                        "rccl_ranks": model.comm.native_ranks} if dist is not None else {}),
                    "table_rows_total": N, "loss": loss_v, "index_oob_flag": oob,
+                   **({"step_entry": "rec_deepfm_train_step (one C-ABI call per step, one stream)"} if args.c_step else {}),
                    **({"table_rows_requested": rows_req * world} if args.table == "ps" and dist is not None
                       and rows_req != args.hashed_rows else {}),
                    **({"native_init_timed_out": True} if dist is not None and getattr(model.comm, "native_init_timed_out", False)

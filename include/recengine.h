@@ -902,6 +902,60 @@ int rec_stream_create_cu_range(int32_t cu_begin, int32_t cu_end, void** stream);
 int rec_stream_create_cu_stride(int32_t first, int32_t stride, int32_t cu_total, void** stream);
 int rec_stream_destroy(void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The WHOLE DeepFM train step behind one entry point: what `dy_model.train_forward` + `loss.backward()` +
+ * `optimizer.step()` do per batch in tools/trainer.py:148-152 for models/rank/deepfm (net.py:21-174,
+ * dygraph_model.py:76-88) — FM lookup and interactions, the top MLP forward, sigmoid + log-loss (+ the AUC buckets),
+ * the MLP backward, the FM backward, the merged lazy-Adam update of both embeddings and Adam on the dense parameters.
+ * It issues, on ONE stream, exactly the rec_* calls of this header that the Python mirror (paddlerec_amd/deepfm.py)
+ * issues for a step it records into a call list (paddlerec_amd/plan.py): same kernels, same arguments, same order —
+ * results are bit-identical to that path (tests/test_deepfm_step_c.py).  A binder that is not Python gets the
+ * launch-bound small-batch step (the reference's bigdata batch size 512: ~40 dependent launches) without paying a
+ * foreign-function round trip per launch.  At B * num_slots <= 15360 the SelectedRows merge happens inside the
+ * record update (rec_sparse_adam_record_small); larger batches group their ids first (rec_ids_group_slots when
+ * slot_rows > 0, else rec_ids_group_payload).  (The side-stream overlap of the mirror's large-batch step is NOT part
+ * of this entry point: one stream.)
+ *
+ * rec_deepfm_net describes the model the way the reference's state_dict does, as pointers into caller-owned device
+ * memory: the table as 128-B-line records rec [table_rows, rec_stride] = W(dim) | W1 | m1 | v1 | pad with the
+ * second-order moments in mv [table_rows, mv_stride] = m(dim) | v(dim) at v_offset, and the dense parameters as views
+ * into ONE flat buffer (flat_param, with flat_grad / flat_m / flat_v of the same length) that rec_adam_dense walks once.
+ * Linear i has weight w[i] [in_i, widths[i]] (Paddle layout) and bias b[i]; in_0 = (num_slots + dense_dim) * dim,
+ * widths[n_linear - 1] = 1.  With 0 < dense_dim <= dim the step runs layer 0 on folded weights (rec_deepfm_desc
+ * .compact_dense = 1): w0_folded [(num_slots + 1) * dim, widths[0]] is scratch that the CALLER zero-initialises once
+ * (its last dim - dense_dim rows stay zero). */
+#define REC_DEEPFM_MAX_LINEAR 8
+typedef struct {
+  int32_t num_slots, dim, dense_dim, n_linear;
+  int32_t widths[REC_DEEPFM_MAX_LINEAR];
+  int64_t table_rows;          /* rows of rec / mv */
+  int64_t num_rows;            /* logical rows of the id space after slot offsets (= table_rows unless sharded) */
+  int64_t padding_idx;         /* < 0: none */
+  int64_t slot_rows;           /* > 0: slot s owns rows [s * slot_rows, (s + 1) * slot_rows) (slot-local grouping) */
+  const int64_t* slot_offset;  /* device [num_slots] or NULL */
+  float* rec;
+  int32_t rec_stride;
+  float* mv;
+  int32_t mv_stride, v_offset;
+  float *dense_w, *dense_w_one;          /* [dense_dim, dim], [dense_dim] */
+  float *g_dense_w, *g_dense_w_one;      /* their gradient views */
+  float* w[REC_DEEPFM_MAX_LINEAR];
+  float* b[REC_DEEPFM_MAX_LINEAR];
+  float* gw[REC_DEEPFM_MAX_LINEAR];
+  float* gb[REC_DEEPFM_MAX_LINEAR];
+  float *flat_param, *flat_grad, *flat_m, *flat_v;
+  int64_t flat_numel;
+  float* w0_folded;            /* compact mode only, see above */
+} rec_deepfm_net;
+int rec_deepfm_train_step_workspace_bytes(const rec_deepfm_net* net, int64_t batch, size_t* bytes);
+/* ids [batch, num_slots] i64, dense [batch, dense_dim] f32, label [batch] i64 -> loss_out [1], pred_out [batch];
+ * hyper->step is Adam's 1-based step count.  auc_pos / auc_neg [num_thresholds + 1] i64 or NULL (no metric).
+ * status: the sticky out-of-range flag of the lookups (may be NULL). */
+int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, const int64_t* ids, const float* dense,
+                          const int64_t* label, const rec_adam_hyper* hyper, int64_t* auc_pos, int64_t* auc_neg,
+                          int32_t num_thresholds, float* loss_out, float* pred_out, int32_t* status, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

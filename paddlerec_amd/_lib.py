@@ -21,6 +21,19 @@ class DeepFMDesc(C.Structure):
                 ("padding_idx", C.c_int64), ("w1_stride", C.c_int32), ("compact_dense", C.c_int32)]
 
 
+class DeepFMNet(C.Structure):
+    """rec_deepfm_net (include/recengine.h): the model of rec_deepfm_train_step as pointers into caller-owned memory."""
+    MAX_LINEAR = 8
+    _fields_ = [("num_slots", C.c_int32), ("dim", C.c_int32), ("dense_dim", C.c_int32), ("n_linear", C.c_int32),
+                ("widths", C.c_int32 * 8), ("table_rows", C.c_int64), ("num_rows", C.c_int64),
+                ("padding_idx", C.c_int64), ("slot_rows", C.c_int64), ("slot_offset", C.c_void_p),
+                ("rec", C.c_void_p), ("rec_stride", C.c_int32), ("mv", C.c_void_p), ("mv_stride", C.c_int32),
+                ("v_offset", C.c_int32), ("dense_w", C.c_void_p), ("dense_w_one", C.c_void_p),
+                ("g_dense_w", C.c_void_p), ("g_dense_w_one", C.c_void_p), ("w", C.c_void_p * 8), ("b", C.c_void_p * 8),
+                ("gw", C.c_void_p * 8), ("gb", C.c_void_p * 8), ("flat_param", C.c_void_p), ("flat_grad", C.c_void_p),
+                ("flat_m", C.c_void_p), ("flat_v", C.c_void_p), ("flat_numel", C.c_int64), ("w0_folded", C.c_void_p)]
+
+
 class AdamHyper(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("step", C.c_int64)]
@@ -235,6 +248,9 @@ SIGNATURES = {
     "rec_copy_async": (C.c_int, [_P, _P, _SZ, _P]),
     "rec_stream_create_cu_range": (C.c_int, [_I32, _I32, C.POINTER(C.c_void_p)]),
     "rec_stream_create_cu_stride": (C.c_int, [_I32, _I32, _I32, C.POINTER(C.c_void_p)]),
+    "rec_deepfm_train_step_workspace_bytes": (C.c_int, [C.POINTER(DeepFMNet), _I64, C.POINTER(C.c_size_t)]),
+    "rec_deepfm_train_step": (C.c_int, [C.POINTER(DeepFMNet), _I64, _P, _P, _P, C.POINTER(AdamHyper), _P, _P, _I32, _P, _P,
+                                        _P, _P, _SZ, _P]),
     "rec_stream_destroy": (C.c_int, [_P]),
 }
 

@@ -1,0 +1,299 @@
+// rec_deepfm_train_step: the whole DeepFM train step issued from C (include/recengine.h, last section).
+//
+// Reference call site: tools/trainer.py:148-152 (train_forward / backward / optimizer.step per batch) for
+// models/rank/deepfm (net.py:21-174, dygraph_model.py:76-88).  The Python mirror (paddlerec_amd/deepfm.py:train_step)
+// issues ~40 rec_* calls per step through ctypes; at the reference's own batch size (config_bigdata.yaml: 512) the
+// step is a chain of dependent launches of a few microseconds each and the host's share per call sets the step time
+// (profiles/r03_small_batch.txt).  paddlerec_amd/plan.py removes that share for Python by replaying a recorded call
+// list; this file is the same list stated in C++ for every other binder.  Nothing here launches a kernel of its own:
+// every line below is a call of an entry point of this library, in the mirror's order with the mirror's arguments,
+// so the two paths are bit-identical by construction (tests/test_deepfm_step_c.py holds them to that).
+#include <stdlib.h>
+
+#include "rec_common.h"
+
+using namespace rec;
+
+namespace {
+
+struct Carve {
+  char* base;
+  size_t off = 0;
+  explicit Carve(void* p) : base((char*)p) {}
+  template <class T>
+  T* take(size_t count) {
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += align_up(count * sizeof(T), 256);
+    return p;
+  }
+  void* bytes(size_t n) { return take<char>(n); }
+};
+
+struct Shape {
+  int S, D, Dn, n;
+  bool compact;
+  int fp;             // fields per sample in feat
+  int in0;            // input width of layer 0 as the GEMM sees it (fp * D)
+  int in0_full;       // rows of w[0] as stored ((S + Dn) * D)
+  int max_w;          // widest activation / gradient row
+  bool small;         // merge inside the record update
+  bool head;          // fused one-logit head backward
+};
+
+int shape_of(const rec_deepfm_net* net, int64_t B, Shape* s) {
+  REC_REQUIRE(net, REC_EINVAL, "net is NULL");
+  REC_REQUIRE(net->num_slots > 0 && net->dim > 0 && net->dense_dim >= 0 && net->n_linear >= 1 &&
+                  net->n_linear <= REC_DEEPFM_MAX_LINEAR, REC_EINVAL, "bad net sizes");
+  REC_REQUIRE(B > 0 && B * net->num_slots < (1ll << 31), REC_EINVAL, "bad batch");
+  REC_REQUIRE(net->widths[net->n_linear - 1] == 1, REC_EINVAL, "the last Linear must have one output (net.py:150)");
+  s->S = net->num_slots; s->D = net->dim; s->Dn = net->dense_dim; s->n = net->n_linear;
+  s->compact = s->Dn > 0 && s->Dn <= s->D;
+  s->fp = s->compact ? s->S + 1 : s->S + s->Dn;
+  s->in0 = s->fp * s->D;
+  s->in0_full = (s->S + s->Dn) * s->D;
+  s->max_w = s->in0;
+  for (int i = 0; i < s->n; ++i) {
+    REC_REQUIRE(net->widths[i] > 0, REC_EINVAL, "bad layer width");
+    if (net->widths[i] > s->max_w) s->max_w = net->widths[i];
+  }
+  static const bool small_env = [] { const char* v = getenv("REC_SMALL_MERGE"); return !(v && *v == '0'); }();
+  s->small = small_env && B * s->S <= 15360;                      // ops.SMALL_MERGE_MAX
+  static const bool head_env = [] { const char* v = getenv("REC_MLP_HEAD_FUSED"); return !(v && *v == '0'); }();
+  const int nh = s->n > 1 ? net->widths[s->n - 2] : 0;            // input width of the head
+  s->head = head_env && s->n > 1 && nh % 4 == 0 && nh <= 512 && B >= 64 &&      // ops._head_ok
+            ((uintptr_t)net->w[s->n - 1]) % 16 == 0;
+  return REC_OK;
+}
+
+struct Buffers {
+  float *y1, *y2, *feat, *sum_emb, *act[REC_DEEPFM_MAX_LINEAR], *y_dnn, *dz, *g[2], *row_grad, *dm;
+  float *pp, *pp1;
+  int32_t *sorted_pos, *seg_offset, *n_uniq;
+  int64_t* uniq_rows;
+  void* ws;              // scratch of the individual calls (one at a time: a single region, the largest need)
+  size_t ws_bytes;
+};
+
+// the largest workspace any single call of the step asks for
+int call_workspace(const rec_deepfm_net* net, const Shape& s, int64_t B, size_t* out) {
+  size_t need = 0, b = 0;
+  auto up = [&](size_t x) { if (x > need) need = x; };
+  rec_gemm_desc d{};
+  auto gemm_ws = [&](int64_t m, int n, int k, int ta, int tb) {
+    d = rec_gemm_desc{m, n, k, 1, 1, n, ta, tb, REC_EPI_NONE, 0};
+    d.lda = ta ? (int)m : k; d.ldb = tb ? k : n; d.ldc = n;
+    if (rec_gemm_f32_workspace_bytes(&d, &b) == REC_OK) up(b);
+  };
+  int in = s.in0;
+  for (int i = 0; i < s.n; ++i) {
+    const int w = net->widths[i];
+    gemm_ws(B, w, in, 0, 0);          // forward
+    gemm_ws(B, in, w, 0, 1);          // dX
+    gemm_ws(in, w, (int)B, 1, 0);     // dW (K = batch)
+    in = w;
+  }
+  if (int rc = rec_logloss_workspace_bytes(B, &b)) return rc;
+  up(b);
+  rec_deepfm_desc fd{B, s.S, s.Dn, s.D, s.D, 1, -1, 1, s.compact ? 1 : 0};
+  if (int rc = rec_deepfm_fm_bwd_workspace_bytes(&fd, &b)) return rc;
+  up(b);
+  if (s.head) {
+    if (int rc = rec_mlp_head_bwd_workspace_bytes(B, net->widths[s.n - 2], &b)) return rc;
+    up(b);
+  }
+  if (!s.small) {
+    if (net->slot_rows > 0) {
+      if (int rc = rec_ids_group_slots_workspace_bytes(B, s.S, net->slot_rows, &b)) return rc;
+    } else {
+      if (int rc = rec_ids_group_workspace_bytes(B * s.S, net->num_rows, &b)) return rc;
+    }
+    up(b);
+  }
+  *out = align_up(need, 256);
+  return REC_OK;
+}
+
+int carve(const rec_deepfm_net* net, const Shape& s, int64_t B, void* workspace, Buffers* bf, size_t* total) {
+  Carve c(workspace);
+  const size_t n = (size_t)B * s.S;
+  bf->y1 = c.take<float>(B);
+  bf->y2 = c.take<float>(B);
+  bf->feat = c.take<float>((size_t)B * s.in0);
+  bf->sum_emb = c.take<float>((size_t)B * s.D);
+  bf->act[0] = bf->feat;
+  for (int i = 1; i < s.n; ++i) bf->act[i] = c.take<float>((size_t)B * net->widths[i - 1]);
+  bf->y_dnn = c.take<float>(B);
+  bf->dz = c.take<float>(B);
+  bf->g[0] = c.take<float>((size_t)B * s.max_w);
+  bf->g[1] = c.take<float>((size_t)B * s.max_w);
+  bf->row_grad = c.take<float>(n * s.D);
+  bf->dm = c.take<float>((size_t)(s.Dn > 0 ? s.Dn : 1) * net->widths[0]);
+  bf->pp = bf->pp1 = nullptr;
+  bf->sorted_pos = bf->seg_offset = bf->n_uniq = nullptr;
+  bf->uniq_rows = nullptr;
+  if (!s.small) {
+    size_t pb = 0, pb1 = 0;
+    if (int rc = rec_segment_partials_bytes((int64_t)n, s.D, &pb)) return rc;
+    if (int rc = rec_segment_partials_bytes((int64_t)n, 1, &pb1)) return rc;
+    bf->pp = (float*)c.bytes(pb > 4 ? pb : 4);
+    bf->pp1 = (float*)c.bytes(pb1 > 4 ? pb1 : 4);
+    bf->sorted_pos = c.take<int32_t>(n);
+    bf->uniq_rows = c.take<int64_t>(n);
+    bf->seg_offset = c.take<int32_t>(n + 1);
+    bf->n_uniq = c.take<int32_t>(4);
+  }
+  size_t cw = 0;
+  if (int rc = call_workspace(net, s, B, &cw)) return rc;
+  bf->ws = c.bytes(cw);
+  bf->ws_bytes = cw;
+  *total = c.off;
+  return REC_OK;
+}
+
+// C = epi(op(A) @ op(B)) on contiguous operands (the step's own buffers and parameter views)
+int gemm(int64_t m, int n, int k, bool ta, bool tb, int epi, const float* A, const float* Bm, float* C,
+         const float* bias, const float* aux0, int ld0, float* b_colsum, int split_k, const Buffers& bf, void* st) {
+  rec_gemm_desc d{};
+  d.m = m; d.n = n; d.k = k;
+  d.lda = ta ? (int)m : k;
+  d.ldb = tb ? k : n;
+  d.ldc = n;
+  d.trans_a = ta; d.trans_b = tb; d.epilogue = epi; d.split_k = split_k;
+  rec_gemm_epilogue_args x{};
+  x.bias = bias; x.aux0 = aux0; x.ld_aux0 = ld0; x.b_colsum = b_colsum;
+  return rec_gemm_f32(&d, A, Bm, C, &x, bf.ws, bf.ws_bytes, st);
+}
+
+}  // namespace
+
+extern "C" int rec_deepfm_train_step_workspace_bytes(const rec_deepfm_net* net, int64_t batch, size_t* bytes) {
+  REC_REQUIRE(bytes, REC_EINVAL, "bytes is NULL");
+  Shape s;
+  if (int rc = shape_of(net, batch, &s)) return rc;
+  Buffers bf;
+  return carve(net, s, batch, nullptr, &bf, bytes);
+}
+
+#define REC_TRY(call)            \
+  do {                           \
+    if (int rc_ = (call)) return rc_; \
+  } while (0)
+
+extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, const int64_t* ids, const float* dense,
+                                     const int64_t* label, const rec_adam_hyper* hyper, int64_t* auc_pos,
+                                     int64_t* auc_neg, int32_t num_thresholds, float* loss_out, float* pred_out,
+                                     int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+  Shape s;
+  if (int rc = shape_of(net, batch, &s)) return rc;
+  REC_REQUIRE(ids && label && hyper && loss_out && pred_out && (dense || s.Dn == 0), REC_EINVAL,
+              "null pointer argument");
+  REC_REQUIRE(net->rec && net->mv && net->flat_param && net->flat_grad && net->flat_m && net->flat_v, REC_EINVAL,
+              "net: null parameter pointer");
+  REC_REQUIRE(!s.compact || net->w0_folded, REC_EINVAL, "net: w0_folded is needed with 0 < dense_dim <= dim");
+  REC_REQUIRE((auc_pos == nullptr) == (auc_neg == nullptr), REC_EINVAL, "auc_pos / auc_neg: both or neither");
+  Buffers bf;
+  size_t need = 0;
+  if (int rc = carve(net, s, batch, workspace, &bf, &need)) return rc;
+  REC_REQUIRE(workspace && workspace_bytes >= need, REC_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
+  const int64_t B = batch;
+  const int S = s.S, D = s.D, Dn = s.Dn, n = s.n;
+  const size_t f4 = sizeof(float);
+
+  // -- layer 0 on folded weights (deepfm.py:_mlp_weights): W0' = [ W0[:S*D] ; M ; 0 ]
+  const float* w0 = net->w[0];
+  float* gw0 = net->gw[0];
+  if (s.compact) {
+    REC_TRY(rec_copy_async(net->w0_folded, net->w[0], (size_t)S * D * net->widths[0] * f4, stream));
+    REC_TRY(rec_dense_fold_fwd(S, Dn, D, net->widths[0], net->dense_w, net->w[0],
+                               net->w0_folded + (size_t)S * D * net->widths[0], stream));
+    w0 = net->w0_folded;
+  }
+  // -- FM: lookup + first / second order + the MLP's input (net.py:104-136)
+  rec_deepfm_desc fd{B, S, Dn, D, net->rec_stride, net->table_rows, net->padding_idx, net->rec_stride,
+                     s.compact ? 1 : 0};
+  REC_TRY(rec_deepfm_fm_fwd(&fd, ids, dense, net->rec, net->rec + D, net->dense_w, net->dense_w_one, net->slot_offset,
+                            bf.y1, bf.y2, bf.feat, bf.sum_emb, status, stream));
+  // -- top MLP forward (net.py:142-174): bias / ReLU in the GEMM epilogue
+  {
+    int in = s.in0;
+    for (int i = 0; i < n; ++i) {
+      const bool last = i == n - 1;
+      float* out = last ? bf.y_dnn : bf.act[i + 1];
+      REC_TRY(gemm(B, net->widths[i], in, false, false, last ? REC_EPI_BIAS : REC_EPI_BIAS_RELU, bf.act[i],
+                   i == 0 ? w0 : net->w[i], out, net->b[i], nullptr, 0, nullptr, 0, bf, stream));
+      in = net->widths[i];
+    }
+  }
+  // -- sigmoid + log_loss (dygraph_model.py:76-85), the AUC buckets (create_metrics)
+  REC_TRY(rec_sigmoid_logloss(B, 0, bf.y1, bf.y2, bf.y_dnn, label, 1e-4f, 0.f, 0.f, pred_out, bf.dz, loss_out, bf.ws,
+                              bf.ws_bytes, stream));
+  if (auc_pos) REC_TRY(rec_auc_histogram(B, pred_out, label, num_thresholds, auc_pos, auc_neg, stream));
+  // -- MLP backward (ops.mlp_backward, defer_first): dX of layer 0 before its dW
+  const float* g = bf.dz;       // gradient of the current layer's OUTPUT, [B, widths[i]]
+  int gi = 0;                   // next free ping-pong buffer
+  int n_run = n;
+  if (s.head) {
+    const int nh = net->widths[n - 2];
+    REC_TRY(rec_mlp_head_bwd(B, nh, bf.act[n - 1], nh, bf.dz, net->w[n - 1], 1, bf.g[gi], nh, net->gw[n - 1],
+                             net->gb[n - 1], bf.ws, bf.ws_bytes, stream));
+    g = bf.g[gi];
+    gi ^= 1;
+    n_run = n - 1;
+  }
+  const float* g0 = nullptr;
+  float* d_flat = nullptr;
+  for (int i = n_run - 1; i >= 0; --i) {
+    const int in = i == 0 ? s.in0 : net->widths[i - 1], w = net->widths[i];
+    if (i == 0) {
+      g0 = g;
+      d_flat = bf.g[gi];
+      REC_TRY(gemm(B, in, w, false, true, REC_EPI_NONE, g, w0, d_flat, nullptr, nullptr, 0, nullptr, 0, bf, stream));
+      break;
+    }
+    REC_TRY(gemm(in, w, (int)B, true, false, REC_EPI_NONE, bf.act[i], g, net->gw[i], nullptr, nullptr, 0, net->gb[i],
+                 0, bf, stream));
+    REC_TRY(gemm(B, in, w, false, true, REC_EPI_RELU_MASK, g, net->w[i], bf.g[gi], nullptr, bf.act[i], in, nullptr, 0,
+                 bf, stream));
+    g = bf.g[gi];
+    gi ^= 1;
+  }
+  // -- FM backward: row gradients of the S lookups + the dense FM parameters (net.py:104-136 backward)
+  rec_deepfm_desc bd{B, S, Dn, D, D, 1, -1, 1, s.compact ? 1 : 0};      // the backward reads no table
+  REC_TRY(rec_deepfm_fm_bwd(&bd, dense, bf.feat, bf.sum_emb, d_flat, bf.dz, bf.dz, net->dense_w, bf.row_grad,
+                            net->g_dense_w, net->g_dense_w_one, bf.ws, bf.ws_bytes, stream));
+  // -- merged lazy Adam on W / W1 of the touched rows (optimizer.step on the SelectedRows gradients)
+  const int64_t nlook = B * S;
+  rec_grad_layout gl{1, 0, 0, nullptr, nullptr, 0}, gl1{S, 0, 0, nullptr, nullptr, 0};
+  if (s.small) {
+    REC_TRY(rec_sparse_adam_record_small(nlook, S, D, net->rec_stride, net->mv_stride, net->v_offset, net->table_rows,
+                                         net->padding_idx, ids, net->slot_offset, bf.row_grad, &gl, bf.dz, &gl1,
+                                         nullptr, net->rec, net->mv, hyper, status, stream));
+  } else {
+    if (net->slot_rows > 0) {
+      REC_TRY(rec_ids_group_slots(B, S, net->slot_rows, net->padding_idx, ids, bf.sorted_pos, bf.uniq_rows,
+                                  bf.seg_offset, bf.n_uniq, nullptr, status, bf.ws, bf.ws_bytes, stream));
+    } else {
+      REC_TRY(rec_ids_group_payload(nlook, S, net->num_rows, net->padding_idx, ids, net->slot_offset, nullptr,
+                                    bf.sorted_pos, bf.uniq_rows, bf.seg_offset, bf.n_uniq, status, bf.ws, bf.ws_bytes,
+                                    stream));
+    }
+    REC_TRY(rec_segment_partials(nlook, D, bf.n_uniq, bf.seg_offset, bf.sorted_pos, bf.row_grad, &gl, bf.pp, stream));
+    REC_TRY(rec_segment_partials(nlook, 1, bf.n_uniq, bf.seg_offset, bf.sorted_pos, bf.dz, &gl1, bf.pp1, stream));
+    gl.partials = bf.pp;
+    gl1.partials = bf.pp1;
+    REC_TRY(rec_sparse_adam_record(nlook, D, net->rec_stride, net->mv_stride, net->v_offset, bf.n_uniq, bf.uniq_rows,
+                                   bf.seg_offset, bf.sorted_pos, bf.row_grad, &gl, bf.dz, &gl1, nullptr, net->rec,
+                                   net->mv, hyper, stream));
+  }
+  // -- dW_0 / db_0, then the folded rows back into the real parameters' gradients (deepfm.py:_fold_backward)
+  REC_TRY(gemm(s.in0, net->widths[0], (int)B, true, false, REC_EPI_NONE, bf.feat, g0, gw0, nullptr, nullptr, 0,
+               net->gb[0], 0, bf, stream));
+  if (s.compact) {
+    REC_TRY(rec_copy_async(bf.dm, gw0 + (size_t)S * D * net->widths[0], (size_t)Dn * net->widths[0] * f4, stream));
+    REC_TRY(rec_dense_fold_bwd(S, Dn, D, net->widths[0], net->dense_w, net->w[0], bf.dm, gw0, net->g_dense_w, 1,
+                               stream));
+  }
+  // -- Adam on every dense parameter (one pass over the flat buffer)
+  return rec_adam_dense(net->flat_numel, net->flat_param, net->flat_m, net->flat_v, net->flat_grad, nullptr, hyper,
+                        stream);
+}

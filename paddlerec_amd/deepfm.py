@@ -317,6 +317,49 @@ class DeepFMLayer:
         self.step_count += 1
         return entry.replay(inputs, self.step_count, float(lr))
 
+    # -- the step through the ONE-call C entry point (rec_deepfm_train_step) ---------------------------------------
+    def c_net(self):
+        """_lib.DeepFMNet over this layer's tensors (built once; the tensors live as long as the layer)."""
+        net = getattr(self, "_c_net", None)
+        if net is not None:
+            return net
+        from . import _lib
+        if self.n_linear > _lib.DeepFMNet.MAX_LINEAR:
+            raise ops.RecError("rec_deepfm_train_step takes at most %d Linear layers" % _lib.DeepFMNet.MAX_LINEAR)
+        self._ensure_sparse_state()
+        D, st = self.sparse_feature_dim, self.sparse_state
+        p, g = self.dense.p, self.dense.g
+        net = _lib.DeepFMNet()
+        net.num_slots, net.dim, net.dense_dim, net.n_linear = self.sparse_num_field, D, self.dense_feature_dim, self.n_linear
+        sizes = self.layer_sizes + [1]
+        for i in range(self.n_linear):
+            net.widths[i] = sizes[i]
+            net.w[i], net.b[i] = self.mlp_w[i].data_ptr(), self.mlp_b[i].data_ptr()
+            net.gw[i], net.gb[i] = self.mlp_dw[i].data_ptr(), self.mlp_db[i].data_ptr()
+        net.table_rows, net.num_rows = self.fm.rec.shape[0], self.sparse_feature_number
+        net.padding_idx = -1 if self.fm.padding_idx is None else self.fm.padding_idx
+        net.slot_rows = self.slot_rows or 0
+        net.slot_offset = None if self.fm.slot_offset is None else self.fm.slot_offset.data_ptr()
+        net.rec, net.rec_stride = self.fm.rec.data_ptr(), self.fm.rec.stride(0)
+        net.mv, net.mv_stride, net.v_offset = st["mv"].data_ptr(), st["mv"].stride(0), _round_up(D, 4)
+        net.dense_w, net.dense_w_one = p["fm.dense_w"].data_ptr(), p["fm.dense_w_one"].data_ptr()
+        net.g_dense_w, net.g_dense_w_one = g["fm.dense_w"].data_ptr(), g["fm.dense_w_one"].data_ptr()
+        net.flat_param, net.flat_grad = self.dense.data.data_ptr(), self.dense.grad.data_ptr()
+        net.flat_m, net.flat_v, net.flat_numel = self.dense.m.data_ptr(), self.dense.v.data_ptr(), self.dense.data.numel()
+        net.w0_folded = self._w0p.data_ptr() if self.compact else None
+        self._c_net = net
+        return net
+
+    def train_step_c(self, sparse_inputs, dense_inputs, label, lr=1e-3, auc_stats=None):
+        """train_step through rec_deepfm_train_step: ONE foreign call per step — what a non-Python binder of
+        include/recengine.h gets.  Same kernels, arguments and order as the recorded (one-stream) step: bit-identical."""
+        ids = self._concat_ids(sparse_inputs)
+        self.step_count += 1
+        if getattr(self, "_ws_c", None) is None:
+            self._ws_c = self.k.Workspace(self.device)
+        return self.k.deepfm_train_step(self.c_net(), ids, dense_inputs, label.reshape(-1), self.step_count, self._ws_c,
+                                        lr=lr, auc_stats=auc_stats, num_thresholds=NUM_THRESHOLDS, status=self.status)
+
     def train_step(self, sparse_inputs, dense_inputs, label, lr=1e-3, auc_stats=None,
                    allreduce=None):
         """dygraph_model.py:76-88 train_forward + tools/trainer.py:151-152 backward/step.

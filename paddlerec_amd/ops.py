@@ -122,6 +122,34 @@ class Workspace:
         return self.buf
 
 
+def deepfm_train_step(net, ids, dense, label, step, ws, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, auc_stats=None,
+                      num_thresholds=4095, status=None, out=None):
+    """The whole DeepFM train step through ONE C-ABI call (rec_deepfm_train_step).  net: a filled _lib.DeepFMNet (the
+    caller keeps the tensors it points into alive).  -> (loss [1], pred [B,1])."""
+    _chk(ids, torch.int64, "ids")
+    _chk(dense, torch.float32, "dense")
+    _chk(label, torch.int64, "label")
+    B = ids.shape[0]
+    if ids.shape[1] != net.num_slots or dense.shape[0] != B or label.numel() != B:
+        raise RecError("ids / dense / label shapes do not fit the net")
+    dev = ids.device
+    if out is None:
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        pred = torch.empty(B, 1, dtype=torch.float32, device=dev)
+    else:
+        loss, pred = out
+    nbytes = C.c_size_t(0)
+    check(lib().rec_deepfm_train_step_workspace_bytes(C.byref(net), B, C.byref(nbytes)),
+          "rec_deepfm_train_step_workspace_bytes")
+    w = ws.get(nbytes.value)
+    h = _hyper(lr, beta1, beta2, eps, step)
+    pos, neg = (auc_stats[0], auc_stats[1]) if auc_stats is not None else (None, None)
+    check(lib().rec_deepfm_train_step(C.byref(net), B, _p(ids), _p(dense), _p(label), C.byref(h), _p(pos), _p(neg),
+                                      int(num_thresholds), _p(loss), _p(pred), _p(status), _p(w),
+                                      C.c_size_t(w.numel()), _stream()), "rec_deepfm_train_step")
+    return loss, pred
+
+
 def make_desc(B, S, Dn, D, num_rows, padding_idx, row_stride=None, w1_stride=1, compact=False):
     return DeepFMDesc(int(B), int(S), int(Dn), int(D), int(row_stride or D), int(num_rows),
                       -1 if padding_idx is None else int(padding_idx), int(w1_stride), int(bool(compact)))
