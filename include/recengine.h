@@ -903,6 +903,23 @@ int rec_stream_create_cu_stride(int32_t first, int32_t stride, int32_t cu_total,
 int rec_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The tail of a CTR tower and its backward in ONE pass over the last hidden activation h [batch, n] (behind a ReLU):
+ *   y_dnn = h @ w + bias;  logit = y1 + y2 + y_dnn (y1 / y2 may be NULL);  pred = sigmoid(clip(logit));
+ *   loss = mean(log_loss(pred, label, eps));   dz = d loss / d logit;
+ *   dx[b,j] = (relu == 0 || h[b,j] > 0) ? dz[b] * w[j] : 0;   dw[j] = sum_b h[b,j] dz[b];   db = sum_b dz[b]
+ * = deepfm/net.py:169-174 (the last Linear(400, 1)) + dygraph_model.py:76-85 (sigmoid, log_loss, mean) forward, and
+ * the backward of both, i.e. what rec_gemm_f32 (one output column) + rec_sigmoid_logloss + rec_mlp_head_bwd do in five
+ * launches and two passes over h.  Same arithmetic per element as those entry points (eps, clip and mean_over as in
+ * rec_sigmoid_logloss); the reductions (loss, dw, db) run in a fixed order of their own.  n % 4 == 0, n <= 512, act / dx /
+ * w 16-byte aligned.  y_dnn may be NULL. */
+int rec_ctr_head_workspace_bytes(int64_t batch, int32_t n, size_t* bytes);
+int rec_ctr_head_fwd_bwd(int64_t batch, int32_t n, int64_t mean_over, const float* act, int64_t ld_act, const float* w,
+                         const float* bias, const float* y1, const float* y2, const int64_t* label, float eps,
+                         float clip_lo, float clip_hi, int32_t relu, float* y_dnn, float* pred, float* dz,
+                         float* loss_out, float* dx, int64_t ld_dx, float* dw, float* db, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * The WHOLE DeepFM train step behind one entry point: what `dy_model.train_forward` + `loss.backward()` +
  * `optimizer.step()` do per batch in tools/trainer.py:148-152 for models/rank/deepfm (net.py:21-174,
  * dygraph_model.py:76-88) — FM lookup and interactions, the top MLP forward, sigmoid + log-loss (+ the AUC buckets),

@@ -248,6 +248,9 @@ SIGNATURES = {
     "rec_copy_async": (C.c_int, [_P, _P, _SZ, _P]),
     "rec_stream_create_cu_range": (C.c_int, [_I32, _I32, C.POINTER(C.c_void_p)]),
     "rec_stream_create_cu_stride": (C.c_int, [_I32, _I32, _I32, C.POINTER(C.c_void_p)]),
+    "rec_ctr_head_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(C.c_size_t)]),
+    "rec_ctr_head_fwd_bwd": (C.c_int, [_I64, _I32, _I64, _P, _I64, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float,
+                                       _I32, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _SZ, _P]),
     "rec_deepfm_train_step_workspace_bytes": (C.c_int, [C.POINTER(DeepFMNet), _I64, C.POINTER(C.c_size_t)]),
     "rec_deepfm_train_step": (C.c_int, [C.POINTER(DeepFMNet), _I64, _P, _P, _P, C.POINTER(AdamHyper), _P, _P, _I32, _P, _P,
                                         _P, _P, _SZ, _P]),

@@ -38,6 +38,7 @@ struct Shape {
   int max_w;          // widest activation / gradient row
   bool small;         // merge inside the record update
   bool head;          // fused one-logit head backward
+  bool ctr_head;      // last Linear + loss + their backward in one pass (rec_ctr_head_fwd_bwd)
 };
 
 int shape_of(const rec_deepfm_net* net, int64_t B, Shape* s) {
@@ -62,6 +63,8 @@ int shape_of(const rec_deepfm_net* net, int64_t B, Shape* s) {
   const int nh = s->n > 1 ? net->widths[s->n - 2] : 0;            // input width of the head
   s->head = head_env && s->n > 1 && nh % 4 == 0 && nh <= 512 && B >= 64 &&      // ops._head_ok
             ((uintptr_t)net->w[s->n - 1]) % 16 == 0;
+  static const bool ctr_env = [] { const char* v = getenv("REC_CTR_HEAD_FUSED"); return !(v && *v == '0'); }();
+  s->ctr_head = ctr_env && s->n > 1 && nh % 4 == 0 && nh <= 512 && ((uintptr_t)net->w[s->n - 1]) % 16 == 0;   // ops.ctr_head_ok
   return REC_OK;
 }
 
@@ -99,6 +102,10 @@ int call_workspace(const rec_deepfm_net* net, const Shape& s, int64_t B, size_t*
   up(b);
   if (s.head) {
     if (int rc = rec_mlp_head_bwd_workspace_bytes(B, net->widths[s.n - 2], &b)) return rc;
+    up(b);
+  }
+  if (s.ctr_head) {
+    if (int rc = rec_ctr_head_workspace_bytes(B, net->widths[s.n - 2], &b)) return rc;
     up(b);
   }
   if (!s.small) {
@@ -213,10 +220,12 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
                      s.compact ? 1 : 0};
   REC_TRY(rec_deepfm_fm_fwd(&fd, ids, dense, net->rec, net->rec + D, net->dense_w, net->dense_w_one, net->slot_offset,
                             bf.y1, bf.y2, bf.feat, bf.sum_emb, status, stream));
-  // -- top MLP forward (net.py:142-174): bias / ReLU in the GEMM epilogue
+  // -- top MLP forward (net.py:142-174): bias / ReLU in the GEMM epilogue; with the fused head the last Linear, the loss
+  //    and the backward of both are ONE pass over the last hidden activation (deepfm.py: fused_head)
+  const int n_fwd = s.ctr_head ? n - 1 : n;
   {
     int in = s.in0;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n_fwd; ++i) {
       const bool last = i == n - 1;
       float* out = last ? bf.y_dnn : bf.act[i + 1];
       REC_TRY(gemm(B, net->widths[i], in, false, false, last ? REC_EPI_BIAS : REC_EPI_BIAS_RELU, bf.act[i],
@@ -224,15 +233,26 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
       in = net->widths[i];
     }
   }
-  // -- sigmoid + log_loss (dygraph_model.py:76-85), the AUC buckets (create_metrics)
-  REC_TRY(rec_sigmoid_logloss(B, 0, bf.y1, bf.y2, bf.y_dnn, label, 1e-4f, 0.f, 0.f, pred_out, bf.dz, loss_out, bf.ws,
-                              bf.ws_bytes, stream));
-  if (auc_pos) REC_TRY(rec_auc_histogram(B, pred_out, label, num_thresholds, auc_pos, auc_neg, stream));
-  // -- MLP backward (ops.mlp_backward, defer_first): dX of layer 0 before its dW
   const float* g = bf.dz;       // gradient of the current layer's OUTPUT, [B, widths[i]]
   int gi = 0;                   // next free ping-pong buffer
   int n_run = n;
-  if (s.head) {
+  if (s.ctr_head) {
+    const int nh = net->widths[n - 2];
+    REC_TRY(rec_ctr_head_fwd_bwd(B, nh, 0, bf.act[n - 1], nh, net->w[n - 1], net->b[n - 1], bf.y1, bf.y2, label, 1e-4f,
+                                 0.f, 0.f, 1, nullptr, pred_out, bf.dz, loss_out, bf.g[gi], nh, net->gw[n - 1],
+                                 net->gb[n - 1], bf.ws, bf.ws_bytes, stream));
+    g = bf.g[gi];
+    gi ^= 1;
+    n_run = n - 1;
+  } else {
+    // -- sigmoid + log_loss (dygraph_model.py:76-85)
+    REC_TRY(rec_sigmoid_logloss(B, 0, bf.y1, bf.y2, bf.y_dnn, label, 1e-4f, 0.f, 0.f, pred_out, bf.dz, loss_out, bf.ws,
+                                bf.ws_bytes, stream));
+  }
+  // -- the AUC buckets (create_metrics)
+  if (auc_pos) REC_TRY(rec_auc_histogram(B, pred_out, label, num_thresholds, auc_pos, auc_neg, stream));
+  // -- MLP backward (ops.mlp_backward, defer_first): dX of layer 0 before its dW
+  if (!s.ctr_head && s.head) {
     const int nh = net->widths[n - 2];
     REC_TRY(rec_mlp_head_bwd(B, nh, bf.act[n - 1], nh, bf.dz, net->w[n - 1], 1, bf.g[gi], nh, net->gw[n - 1],
                              net->gb[n - 1], bf.ws, bf.ws_bytes, stream));

@@ -122,6 +122,128 @@ __global__ __launch_bounds__(kBlock) void auc_hist_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------- the CTR head in one pass
+// The tail of every CTR tower here is  h [B,n] (behind a ReLU) -> Linear(n, 1) -> logit = y1 + y2 + y_dnn -> sigmoid ->
+// log_loss -> mean  (deepfm/net.py:169-174 + dygraph_model.py:76-85), and its backward needs h again: dx = dz w (under
+// the ReLU mask of h), dW = h^T dz, db = sum dz.  As separate calls that is a GEMV pass over h (26 us at B 65536), two
+// loss launches, and a second pass over h for the backward (35 us) — five launches on the step's critical path.  Here a
+// wave keeps a row of h in registers: dot product, loss and dz, dx written, dW accumulated per lane — ONE read of h.
+// Lane l owns columns 4l..4l+3 and 256+4l..+3 (n <= 512, n % 4 == 0); a wave walks rows wave, wave + W, ... in ascending
+// order, two rows in flight; per-wave partials fold in LDS in wave order, one partial row [n + 2] per block (dW | db |
+// sum of costs), folded across blocks by ctr_head_fold_kernel in ascending block order: deterministic.
+constexpr int kCtrHeadMaxBlocks = kNumCU * 4;
+__global__ __launch_bounds__(kBlock) void ctr_head_kernel(
+    int64_t B, int N, float invB, const float* __restrict__ act, int64_t ld_act, const float* __restrict__ w,
+    const float* __restrict__ bias, const float* __restrict__ y1, const float* __restrict__ y2,
+    const int64_t* __restrict__ label, float eps, float clip_lo, float clip_hi, int relu, float* __restrict__ y_out,
+    float* __restrict__ pred, float* __restrict__ dz_out, float* __restrict__ dx, int64_t ld_dx,
+    float* __restrict__ partial) {
+  extern __shared__ float ctr_red[];                       // [waves][N + 2]
+  constexpr int W = kBlock / kWave;
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+  const int c0 = lane * 4, c1 = 256 + lane * 4;
+  const bool ok0 = c0 < N, ok1 = c1 < N;
+  float w0[4] = {0.f, 0.f, 0.f, 0.f}, w1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ok0) vload<4>(w0, w + c0);
+  if (ok1) vload<4>(w1, w + c1);
+  const float b0 = bias ? bias[0] : 0.f;
+  const bool clipped = clip_lo < clip_hi;
+  float g0[4] = {0.f, 0.f, 0.f, 0.f}, g1[4] = {0.f, 0.f, 0.f, 0.f}, gb = 0.f, cost_sum = 0.f;
+  const int64_t nw = (int64_t)gridDim.x * W;
+  for (int64_t r = (int64_t)blockIdx.x * W + wave; r < B; r += 2 * nw) {
+    const int64_t rr[2] = {r, r + nw};
+    float a0[2][4], a1[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) a0[u][v] = a1[u][v] = 0.f;
+      if (rr[u] < B) {
+        if (ok0) vload_nt<4>(a0[u], act + rr[u] * ld_act + c0);
+        if (ok1) vload_nt<4>(a1[u], act + rr[u] * ld_act + c1);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (rr[u] >= B) continue;                             // wave-uniform
+      const int64_t i = rr[u];
+      float acc = 0.f;
+      acc += a0[u][0] * w0[0] + a0[u][1] * w0[1] + a0[u][2] * w0[2] + a0[u][3] * w0[3];
+      acc += a1[u][0] * w1[0] + a1[u][1] * w1[1] + a1[u][2] * w1[2] + a1[u][3] * w1[3];
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+      const float y = acc + b0;
+      float z = y1 ? y1[i] : 0.f;
+      if (y2) z += y2[i];
+      z = y1 ? z + y : y;
+      const float open = (!clipped || (z > clip_lo && z < clip_hi)) ? 1.f : 0.f;
+      if (clipped) z = fminf(fmaxf(z, clip_lo), clip_hi);
+      const float p = 1.f / (1.f + expf(-z));
+      const float t = (float)label[i];
+      cost_sum += -t * logf(p + eps) - (1.f - t) * logf(1.f - p + eps);
+      const float dz = (-t / (p + eps) + (1.f - t) / (1.f - p + eps)) * invB * (p * (1.f - p)) * open;
+      gb += dz;
+      if (lane == 0) {
+        if (y_out) y_out[i] = y;
+        pred[i] = p;
+        dz_out[i] = dz;
+      }
+      float o0[4], o1[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        g0[v] += a0[u][v] * dz;
+        g1[v] += a1[u][v] * dz;
+        o0[v] = (!relu || a0[u][v] > 0.f) ? dz * w0[v] : 0.f;
+        o1[v] = (!relu || a1[u][v] > 0.f) ? dz * w1[v] : 0.f;
+      }
+      if (ok0) vstore<4>(dx + i * ld_dx + c0, o0);
+      if (ok1) vstore<4>(dx + i * ld_dx + c1, o1);
+    }
+  }
+  float* mine = ctr_red + wave * (N + 2);
+  if (ok0) { mine[c0] = g0[0]; mine[c0 + 1] = g0[1]; mine[c0 + 2] = g0[2]; mine[c0 + 3] = g0[3]; }
+  if (ok1) { mine[c1] = g1[0]; mine[c1 + 1] = g1[1]; mine[c1 + 2] = g1[2]; mine[c1 + 3] = g1[3]; }
+  if (lane == 0) { mine[N] = gb; mine[N + 1] = cost_sum; }
+  __syncthreads();
+  float* prow = partial + (int64_t)blockIdx.x * (N + 2);
+  for (int j = threadIdx.x; j < N + 2; j += kBlock) {
+    float s = ctr_red[j];
+#pragma unroll
+    for (int q = 1; q < W; ++q) s += ctr_red[q * (N + 2) + j];
+    prow[j] = s;
+  }
+}
+
+// column j of the [nblk][n2] partial rows, blocks in ascending order.  A block owns 16 columns, thread (c, q) the rows
+// q, q + 16, ... of column c on four interleaved chains (loads in flight instead of one dependent chain per column: the
+// first version of this kernel summed 512 rows per thread one after the other and cost the step 130 us), then the 16
+// row groups fold in ascending q.  Columns < n2 - 2 -> dw, n2 - 2 -> db, n2 - 1 -> loss = sum of costs * invB.
+__global__ __launch_bounds__(kBlock) void ctr_head_fold_kernel(int nblk, int n2, const float* __restrict__ partial,
+                                                               float invB, float* __restrict__ dw,
+                                                               float* __restrict__ db, float* __restrict__ loss) {
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + c;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (j < n2) {
+    int r = q;
+    for (; r + 48 < nblk; r += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] += partial[(int64_t)(r + 16 * u) * n2 + j];
+    }
+    for (int u = 0; r < nblk; r += 16, ++u) a[u] += partial[(int64_t)r * n2 + j];
+  }
+  red[q][c] = (a[0] + a[1]) + (a[2] + a[3]);
+  __syncthreads();
+  if (q == 0 && j < n2) {
+    float t = red[0][c];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k][c];
+    if (j < n2 - 2) dw[j] = t;
+    else if (j == n2 - 2) db[0] = t;
+    else loss[0] = t * invB;
+  }
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -170,6 +292,44 @@ extern "C" int rec_sigmoid_logloss(int64_t batch, int64_t mean_over, const float
   hipLaunchKernelGGL(fold_loss_kernel, dim3(1), dim3(kBlock), 0, st, (const float*)workspace,
                      (int)grid, inv, loss_out);
   return check_launch("rec_sigmoid_logloss");
+}
+
+static int64_t ctr_head_grid(int64_t batch) {
+  int64_t grid = (batch + (kBlock / kWave) * 4 - 1) / ((kBlock / kWave) * 4);      // ~4 rows per wave at least
+  if (grid > kCtrHeadMaxBlocks) grid = kCtrHeadMaxBlocks;
+  return grid < 1 ? 1 : grid;
+}
+
+extern "C" int rec_ctr_head_workspace_bytes(int64_t batch, int32_t n, size_t* bytes) {
+  REC_REQUIRE(bytes && batch >= 0 && n > 0, REC_EINVAL, "bad arguments");
+  *bytes = align_up((size_t)ctr_head_grid(batch) * (n + 2) * sizeof(float), 256);
+  return REC_OK;
+}
+
+extern "C" int rec_ctr_head_fwd_bwd(int64_t batch, int32_t n, int64_t mean_over, const float* act, int64_t ld_act,
+                                    const float* w, const float* bias, const float* y1, const float* y2,
+                                    const int64_t* label, float eps, float clip_lo, float clip_hi, int32_t relu,
+                                    float* y_dnn, float* pred, float* dz, float* loss_out, float* dx, int64_t ld_dx,
+                                    float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+  REC_REQUIRE(batch > 0 && mean_over >= 0, REC_EINVAL, "bad batch");
+  REC_REQUIRE(n > 0 && n % 4 == 0 && n <= 512, REC_ESHAPE, "rec_ctr_head_fwd_bwd: n must be a multiple of 4 and <= 512");
+  REC_REQUIRE(act && w && label && pred && dz && loss_out && dx && dw && db, REC_EINVAL, "null pointer argument");
+  REC_REQUIRE(!y2 || y1, REC_EINVAL, "y2 without y1");
+  REC_REQUIRE(ld_act >= n && ld_dx >= n && ld_act % 4 == 0 && ld_dx % 4 == 0 && ((uintptr_t)act) % 16 == 0 &&
+                  ((uintptr_t)dx) % 16 == 0 && ((uintptr_t)w) % 16 == 0, REC_ESHAPE,
+              "rec_ctr_head_fwd_bwd: act / dx / w must be 16-byte aligned with row strides that are multiples of 4");
+  size_t need = 0;
+  rec_ctr_head_workspace_bytes(batch, n, &need);
+  REC_REQUIRE(workspace && workspace_bytes >= need, REC_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
+  const float inv = 1.f / (float)(mean_over > 0 ? mean_over : batch);
+  const int64_t grid = ctr_head_grid(batch);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t shmem = (size_t)(kBlock / kWave) * (n + 2) * sizeof(float);
+  hipLaunchKernelGGL(ctr_head_kernel, dim3((unsigned)grid), dim3(kBlock), shmem, st, batch, n, inv, act, ld_act, w, bias, y1,
+                     y2, label, eps, clip_lo, clip_hi, relu, y_dnn, pred, dz, dx, ld_dx, (float*)workspace);
+  hipLaunchKernelGGL(ctr_head_fold_kernel, dim3((unsigned)((n + 2 + 15) / 16)), dim3(kBlock), 0, st, (int)grid,
+                     n + 2, (const float*)workspace, inv, dw, db, loss_out);
+  return check_launch("rec_ctr_head_fwd_bwd");
 }
 
 extern "C" int rec_bce_with_logits(int64_t batch, int64_t mean_over, const float* logit,

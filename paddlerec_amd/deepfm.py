@@ -437,9 +437,18 @@ class DeepFMLayer:
         if group_at == "fwd":
             issue_group()
         mlp_w, mlp_dw = self._mlp_weights()
+        # the last Linear(-> 1), sigmoid + log_loss and the backward of both in ONE pass over the last hidden activation
+        # (rec_ctr_head_fwd_bwd: five launches and two passes less on the critical path; REC_CTR_HEAD_FUSED=0: the parts)
+        fused_head = self.n_linear > 1 and hasattr(self.k, "ctr_head") and self.k.ctr_head_ok(mlp_w[-1], mlp_dw[-1])
         with self._timed("mlp_fwd"):
-            y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), mlp_w, self.mlp_b, self.ws_mlp)
-        pred, dz, loss = self.k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws)
+            if fused_head:
+                h, acts = self.k.mlp_forward(feat.view(B, -1), mlp_w[:-1], self.mlp_b[:-1], self.ws_mlp, relu_last=True)
+                pred, dz, loss, g_head = self.k.ctr_head(h, mlp_w[-1], self.mlp_b[-1], y1, y2, label, self.ws,
+                                                         mlp_dw[-1], self.mlp_db[-1])
+            else:
+                y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), mlp_w, self.mlp_b, self.ws_mlp)
+        if not fused_head:
+            pred, dz, loss = self.k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws)
         if group_at == "bwd":
             issue_group()
         if auc_stats is not None:
@@ -461,7 +470,11 @@ class DeepFMLayer:
                 self._dw_stream, self._ws_dw = self.k.concurrent_stream(self.device), self.k.Workspace(self.device)
             kw.update(dw_stream=self._dw_stream, dw_ws=self._ws_dw)
         with self._timed("mlp_bwd"):
-            d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db, self.ws_mlp, **kw)
+            if fused_head:
+                d_flat, finish_dw0 = self.k.mlp_backward(g_head, acts, mlp_w[:-1], mlp_dw[:-1], self.mlp_db[:-1],
+                                                         self.ws_mlp, **kw)
+            else:
+                d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db, self.ws_mlp, **kw)
         if group_at == "tail":
             issue_group()
         if sorted_rg and side is not None:

@@ -1342,6 +1342,44 @@ def mlp_head_bwd(act, dz, w, ws, dw, db, relu=True, out=None):
     return out
 
 
+def ctr_head_ok(w, dw):
+    """The fused CTR head (rec_ctr_head_fwd_bwd) takes Linear(n -> 1) with n % 4 == 0, n <= 512 and an aligned contiguous
+    weight (its input is the previous GEMM's own output buffer: contiguous, aligned)."""
+    return (os.environ.get("REC_CTR_HEAD_FUSED", "1") != "0" and w.dim() == 2 and w.shape[1] == 1 and
+            w.shape[0] % 4 == 0 and w.shape[0] <= 512 and w.is_contiguous() and w.data_ptr() % 16 == 0 and
+            dw.is_contiguous())
+
+
+def ctr_head(act, w, bias, y1, y2, label, ws, dw, db, eps=1e-4, clip=None, mean_over=0, relu=True, out=None):
+    """Last Linear(n -> 1) + sigmoid + log_loss + mean AND their backward in one pass over act [B, n]
+    (rec_ctr_head_fwd_bwd).  -> (pred [B,1], dz [B,1], loss [1], dx [B,n]); dw [n(,1)] and db [1] are written."""
+    B, n = act.shape
+    dev = act.device
+    _chk(label, torch.int64, "label")
+    for t, nm in ((y1, "y1"), (y2, "y2"), (bias, "bias")):
+        _chk(t, torch.float32, nm)
+    if label.numel() != B or (y1 is not None and y1.numel() != B) or (y2 is not None and y2.numel() != B):
+        raise RecError("ctr_head: y1 / y2 / label must have one entry per row of act")
+    if clip is not None and not clip[0] < clip[1]:
+        raise RecError("clip must be (lo, hi) with lo < hi")
+    if out is None:
+        pred = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        dz = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dx = torch.empty(B, n, dtype=torch.float32, device=dev)
+    else:
+        pred, dz, loss, dx = out
+    nbytes = C.c_size_t(0)
+    check(lib().rec_ctr_head_workspace_bytes(B, n, C.byref(nbytes)))
+    wk = ws.get(nbytes.value)
+    lo, hi = (float(clip[0]), float(clip[1])) if clip is not None else (0.0, 0.0)
+    check(lib().rec_ctr_head_fwd_bwd(B, n, int(mean_over), _p(act), act.stride(0), _p(w), _p(bias), _p(y1), _p(y2),
+                                     _p(label), float(eps), lo, hi, 1 if relu else 0, None, _p(pred), _p(dz), _p(loss),
+                                     _p(dx), dx.stride(0), _p(dw), _p(db), _p(wk), C.c_size_t(wk.numel()), _stream()),
+          "rec_ctr_head_fwd_bwd")
+    return pred, dz, loss, dx
+
+
 def _head_ok(act, w, dw, db, dy):
     """A one-logit head the fused backward takes: Linear(n -> 1), n % 4 == 0, n <= 512, aligned contiguous operands."""
     return (os.environ.get("REC_MLP_HEAD_FUSED", "1") != "0" and w.dim() == 2 and w.shape[1] == 1 and
