@@ -14,6 +14,35 @@ def _selected_gpus():
     return [g for g in os.environ.get("FLAGS_selected_gpus", "").split(",") if g.strip() != ""]
 
 
+def _precreate_save_dir(argv):
+    """The script's `if not os.path.exists(p): os.makedirs(p)` on runner.model_save_path (static_gpubox_trainer.py:143-146)
+    is written for ONE process driving all GPUs; with one process per GPU two ranks can both find the directory missing and
+    the second makedirs raises.  The launcher creates it before any rank starts (-m <config.yaml>, -o overrides)."""
+    try:
+        import yaml
+        cfg_path, over = None, []
+        for i, a in enumerate(argv):
+            if a == "-m" and i + 1 < len(argv):
+                cfg_path = argv[i + 1]
+            if a == "-o":                                   # -o k=v [k=v ...]
+                j = i + 1
+                while j < len(argv) and not argv[j].startswith("-"):
+                    over.append(argv[j])
+                    j += 1
+        path = None
+        if cfg_path and os.path.exists(cfg_path):
+            with open(cfg_path) as f:
+                cfg = yaml.safe_load(f) or {}
+            path = (cfg.get("runner") or {}).get("model_save_path")
+        for o in over:
+            if o.startswith("runner.model_save_path="):
+                path = o.split("=", 1)[1]
+        if path:
+            os.makedirs(path, exist_ok=True)
+    except Exception:        # best effort: the script reports a bad config itself
+        pass
+
+
 def _spawn_ranks(argv):
     """tools/static_gpubox_trainer.py with FLAGS_selected_gpus naming N > 1 GPUs (tools/run_gpubox.sh:21): the reference
     drives them from one process; the engine runs one process per GPU — re-execute under torch.distributed.run, one rank
@@ -24,6 +53,7 @@ def _spawn_ranks(argv):
         return None
     import socket
     import subprocess
+    _precreate_save_dir(argv)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
