@@ -508,19 +508,33 @@ class ShardedDeepFMLayer(DeepFMLayer):
         with self._timed("fm_fwd"):
             y1, y2, feat, sum_emb, _ = self._fm_fwd_routed(L, B, S, dense_inputs)
         mlp_w, mlp_dw = self._mlp_weights()
-        with self._timed("mlp_fwd"):
-            y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), mlp_w, self.mlp_b, self.ws_mlp)
         loss_slot = self.dense.g["__loss__"]
-        pred, dz, _ = k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws, mean_over=G * B,
-                                        out=(self._buf("pred", (B, 1)), self._buf("dz", (B, 1)),
-                                             loss_slot))
+        # the tower's tail and its backward in one pass (rec_ctr_head_fwd_bwd), as the unsharded step does
+        fused_head = self.n_linear > 1 and hasattr(k, "ctr_head") and k.ctr_head_ok(mlp_w[-1], mlp_dw[-1])
+        with self._timed("mlp_fwd"):
+            if fused_head:
+                h, acts = k.mlp_forward(feat.view(B, -1), mlp_w[:-1], self.mlp_b[:-1], self.ws_mlp, relu_last=True)
+                pred, dz, _, g_head = k.ctr_head(h, mlp_w[-1], self.mlp_b[-1], y1, y2, label, self.ws, mlp_dw[-1],
+                                                 self.mlp_db[-1], mean_over=G * B,
+                                                 out=(self._buf("pred", (B, 1)), self._buf("dz", (B, 1)), loss_slot,
+                                                      self._buf("g_head", (B, mlp_w[-1].shape[0]))))
+            else:
+                y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), mlp_w, self.mlp_b, self.ws_mlp)
+        if not fused_head:
+            pred, dz, _ = k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws, mean_over=G * B,
+                                            out=(self._buf("pred", (B, 1)), self._buf("dz", (B, 1)),
+                                                 loss_slot))
         if auc_stats is not None:
             k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         with self._timed("mlp_bwd"):
             # dX chain only; every dW / db GEMM is deferred to the tail so that the exchange-bound work
             # (gradient all-to-all, sparse Adam, next batch's lookup) has ~1.2 ms of MFMA work to hide under
-            d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db,
-                                                     self.ws_mlp, defer_all=True)
+            if fused_head:
+                d_flat, finish_dw0 = self.k.mlp_backward(g_head, acts, mlp_w[:-1], mlp_dw[:-1], self.mlp_db[:-1],
+                                                         self.ws_mlp, defer_all=True)
+            else:
+                d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db,
+                                                         self.ws_mlp, defer_all=True)
         with self._timed("fm_bwd"):
             row_grad, _, _ = k.deepfm_fm_bwd(
                 dense_inputs, feat, sum_emb, d_flat.view(B, self.fp, -1), dz, dz, S, self.ws,

@@ -143,9 +143,17 @@ class BenchmarkDNNLayer:
             # value carries its (sample, slot) segment = its gradient row in dx through the sort (no index indirection)
             k.ids_group(rows[: mb.nnz], self.dict_dim, 0, self.ws_group, None, self.status, groups,
                         payload=seg[: mb.nnz])
+        # the tower's tail (last Linear, clip, sigmoid, log_loss) and its backward in one pass (rec_ctr_head_fwd_bwd)
+        fused_head = self.n_linear > 1 and hasattr(k, "ctr_head") and k.ctr_head_ok(self.mlp_w[-1], self.mlp_dw[-1])
         with self._timed("mlp_fwd"):
-            y, acts = k.mlp_forward(x, self.mlp_w, self.mlp_b, self.ws_mlp)
-        pred, dz, loss = k.sigmoid_logloss(y, None, None, label, self.ws, clip=CLIP)
+            if fused_head:
+                h, acts = k.mlp_forward(x, self.mlp_w[:-1], self.mlp_b[:-1], self.ws_mlp, relu_last=True)
+                pred, dz, loss, g_head = k.ctr_head(h, self.mlp_w[-1], self.mlp_b[-1], None, None, label, self.ws,
+                                                    self.mlp_dw[-1], self.mlp_db[-1], clip=CLIP)
+            else:
+                y, acts = k.mlp_forward(x, self.mlp_w, self.mlp_b, self.ws_mlp)
+        if not fused_head:
+            pred, dz, loss = k.sigmoid_logloss(y, None, None, label, self.ws, clip=CLIP)
         if auc_stats is not None:
             k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         with self._timed("mlp_bwd"):      # dX of layer 0 BEFORE its dW: the HBM-bound sparse update below runs on the
@@ -157,8 +165,12 @@ class BenchmarkDNNLayer:
             sk = int(os.environ.get("REC_SLOT_DW0_SPLIT", "4"))
             if on_gpu and sk > 0 and label.shape[0] >= 16384:
                 kw = dict(defer_split=sk)
-            dx, finish_dw0 = k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp,
-                                            defer_first=True, **kw)                               # [B, S*D]
+            if fused_head:
+                dx, finish_dw0 = k.mlp_backward(g_head, acts, self.mlp_w[:-1], self.mlp_dw[:-1], self.mlp_db[:-1],
+                                                self.ws_mlp, defer_first=True, **kw)              # [B, S*D]
+            else:
+                dx, finish_dw0 = k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp,
+                                                defer_first=True, **kw)                           # [B, S*D]
         with _OnSide(side, cur):
             with self._timed("sparse_update"):
                 if self.table is not None:
