@@ -930,8 +930,10 @@ int rec_ctr_head_fwd_bwd(int64_t batch, int32_t n, int64_t mean_over, const floa
  * launch-bound small-batch step (the reference's bigdata batch size 512: ~40 dependent launches) without paying a
  * foreign-function round trip per launch.  At B * num_slots <= 15360 the SelectedRows merge happens inside the
  * record update (rec_sparse_adam_record_small); larger batches group their ids first (rec_ids_group_slots when
- * slot_rows > 0, else rec_ids_group_payload).  (The side-stream overlap of the mirror's large-batch step is NOT part
- * of this entry point: one stream.)
+ * slot_rows > 0, else rec_ids_group_payload).  side_stream (may be NULL: everything on `stream`): a second stream of
+ * the caller's on which the entry point runs the mirror's large-batch schedule — the id grouping forked in front of the
+ * lookup, the sparse update underneath the dW_0 GEMM — ordered against `stream` with events; on return both streams'
+ * work is ordered before anything the caller issues on `stream` next.  One step at a time per process.
  *
  * rec_deepfm_net describes the model the way the reference's state_dict does, as pointers into caller-owned device
  * memory: the table as 128-B-line records rec [table_rows, rec_stride] = W(dim) | W1 | m1 | v1 | pad with the
@@ -971,7 +973,7 @@ int rec_deepfm_train_step_workspace_bytes(const rec_deepfm_net* net, int64_t bat
 int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, const int64_t* ids, const float* dense,
                           const int64_t* label, const rec_adam_hyper* hyper, int64_t* auc_pos, int64_t* auc_neg,
                           int32_t num_thresholds, float* loss_out, float* pred_out, int32_t* status, void* workspace,
-                          size_t workspace_bytes, void* stream);
+                          size_t workspace_bytes, void* stream, void* side_stream);
 
 #ifdef __cplusplus
 }

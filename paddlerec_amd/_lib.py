@@ -253,7 +253,7 @@ SIGNATURES = {
                                        _I32, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _SZ, _P]),
     "rec_deepfm_train_step_workspace_bytes": (C.c_int, [C.POINTER(DeepFMNet), _I64, C.POINTER(C.c_size_t)]),
     "rec_deepfm_train_step": (C.c_int, [C.POINTER(DeepFMNet), _I64, _P, _P, _P, C.POINTER(AdamHyper), _P, _P, _I32, _P, _P,
-                                        _P, _P, _SZ, _P]),
+                                        _P, _P, _SZ, _P, _P]),
     "rec_stream_destroy": (C.c_int, [_P]),
 }
 

@@ -75,6 +75,8 @@ struct Buffers {
   int64_t* uniq_rows;
   void* ws;              // scratch of the individual calls (one at a time: a single region, the largest need)
   size_t ws_bytes;
+  void* ws_side;         // the grouping's scratch: it may run on the side stream beside the main stream's calls
+  size_t ws_side_bytes;
 };
 
 // the largest workspace any single call of the step asks for
@@ -108,15 +110,18 @@ int call_workspace(const rec_deepfm_net* net, const Shape& s, int64_t B, size_t*
     if (int rc = rec_ctr_head_workspace_bytes(B, net->widths[s.n - 2], &b)) return rc;
     up(b);
   }
-  if (!s.small) {
-    if (net->slot_rows > 0) {
-      if (int rc = rec_ids_group_slots_workspace_bytes(B, s.S, net->slot_rows, &b)) return rc;
-    } else {
-      if (int rc = rec_ids_group_workspace_bytes(B * s.S, net->num_rows, &b)) return rc;
-    }
-    up(b);
-  }
   *out = align_up(need, 256);
+  return REC_OK;
+}
+
+int group_workspace(const rec_deepfm_net* net, const Shape& s, int64_t B, size_t* out) {
+  size_t b = 0;
+  if (net->slot_rows > 0) {
+    if (int rc = rec_ids_group_slots_workspace_bytes(B, s.S, net->slot_rows, &b)) return rc;
+  } else {
+    if (int rc = rec_ids_group_workspace_bytes(B * s.S, net->num_rows, &b)) return rc;
+  }
+  *out = align_up(b, 256);
   return REC_OK;
 }
 
@@ -138,6 +143,8 @@ int carve(const rec_deepfm_net* net, const Shape& s, int64_t B, void* workspace,
   bf->pp = bf->pp1 = nullptr;
   bf->sorted_pos = bf->seg_offset = bf->n_uniq = nullptr;
   bf->uniq_rows = nullptr;
+  bf->ws_side = nullptr;
+  bf->ws_side_bytes = 0;
   if (!s.small) {
     size_t pb = 0, pb1 = 0;
     if (int rc = rec_segment_partials_bytes((int64_t)n, s.D, &pb)) return rc;
@@ -148,6 +155,10 @@ int carve(const rec_deepfm_net* net, const Shape& s, int64_t B, void* workspace,
     bf->uniq_rows = c.take<int64_t>(n);
     bf->seg_offset = c.take<int32_t>(n + 1);
     bf->n_uniq = c.take<int32_t>(4);
+    size_t gw = 0;
+    if (int rc = group_workspace(net, s, B, &gw)) return rc;
+    bf->ws_side = c.bytes(gw);
+    bf->ws_side_bytes = gw;
   }
   size_t cw = 0;
   if (int rc = call_workspace(net, s, B, &cw)) return rc;
@@ -189,7 +200,8 @@ extern "C" int rec_deepfm_train_step_workspace_bytes(const rec_deepfm_net* net, 
 extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, const int64_t* ids, const float* dense,
                                      const int64_t* label, const rec_adam_hyper* hyper, int64_t* auc_pos,
                                      int64_t* auc_neg, int32_t num_thresholds, float* loss_out, float* pred_out,
-                                     int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+                                     int32_t* status, void* workspace, size_t workspace_bytes, void* stream,
+                                     void* side_stream) {
   Shape s;
   if (int rc = shape_of(net, batch, &s)) return rc;
   REC_REQUIRE(ids && label && hyper && loss_out && pred_out && (dense || s.Dn == 0), REC_EINVAL,
@@ -206,6 +218,38 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   const int S = s.S, D = s.D, Dn = s.Dn, n = s.n;
   const size_t f4 = sizeof(float);
 
+  // -- the mirror's large-batch schedule (deepfm.py:train_step, overlap): with a side stream the id grouping is forked
+  //    BEFORE the lookup and runs beside the HBM-bound FM kernels / under the forward GEMMs, and the sparse update runs
+  //    on it underneath the MFMA-bound dW_0 GEMM; without one (or when the merge happens inside the record update)
+  //    everything is issued on `stream` in the same order
+  const bool overlap = side_stream != nullptr && side_stream != stream && !s.small;
+  void* sst = overlap ? side_stream : stream;
+  static hipEvent_t ev[3] = {nullptr, nullptr, nullptr};     // fork, after fm_bwd, join: re-recorded every step
+  if (overlap && !ev[0])
+    for (auto& e : ev)
+      REC_REQUIRE(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, REC_EHIP, "hipEventCreate failed");
+  auto order = [&](int k, void* from, void* to) -> int {    // everything issued on `from` so far happens before `to` goes on
+    REC_REQUIRE(hipEventRecord(ev[k], (hipStream_t)from) == hipSuccess &&
+                    hipStreamWaitEvent((hipStream_t)to, ev[k], 0) == hipSuccess, REC_EHIP, "stream ordering failed");
+    return REC_OK;
+  };
+  const int64_t nlook = B * S;
+  if (!s.small) {                                            // SelectedRows merge keys: they only depend on the ids
+    if (overlap) REC_TRY(order(0, stream, sst));
+    if (net->slot_rows > 0) {
+      REC_TRY(rec_ids_group_slots(B, S, net->slot_rows, net->padding_idx, ids, bf.sorted_pos, bf.uniq_rows,
+                                  bf.seg_offset, bf.n_uniq, nullptr, status, bf.ws_side, bf.ws_side_bytes, sst));
+    } else {
+      REC_TRY(rec_ids_group_payload(nlook, S, net->num_rows, net->padding_idx, ids, net->slot_offset, nullptr,
+                                    bf.sorted_pos, bf.uniq_rows, bf.seg_offset, bf.n_uniq, status, bf.ws_side,
+                                    bf.ws_side_bytes, sst));
+    }
+  }
+  // -- FM: lookup + first / second order + the MLP's input (net.py:104-136)
+  rec_deepfm_desc fd{B, S, Dn, D, net->rec_stride, net->table_rows, net->padding_idx, net->rec_stride,
+                     s.compact ? 1 : 0};
+  REC_TRY(rec_deepfm_fm_fwd(&fd, ids, dense, net->rec, net->rec + D, net->dense_w, net->dense_w_one, net->slot_offset,
+                            bf.y1, bf.y2, bf.feat, bf.sum_emb, status, stream));
   // -- layer 0 on folded weights (deepfm.py:_mlp_weights): W0' = [ W0[:S*D] ; M ; 0 ]
   const float* w0 = net->w[0];
   float* gw0 = net->gw[0];
@@ -215,11 +259,6 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
                                net->w0_folded + (size_t)S * D * net->widths[0], stream));
     w0 = net->w0_folded;
   }
-  // -- FM: lookup + first / second order + the MLP's input (net.py:104-136)
-  rec_deepfm_desc fd{B, S, Dn, D, net->rec_stride, net->table_rows, net->padding_idx, net->rec_stride,
-                     s.compact ? 1 : 0};
-  REC_TRY(rec_deepfm_fm_fwd(&fd, ids, dense, net->rec, net->rec + D, net->dense_w, net->dense_w_one, net->slot_offset,
-                            bf.y1, bf.y2, bf.feat, bf.sum_emb, status, stream));
   // -- top MLP forward (net.py:142-174): bias / ReLU in the GEMM epilogue; with the fused head the last Linear, the loss
   //    and the backward of both are ONE pass over the last hidden activation (deepfm.py: fused_head)
   const int n_fwd = s.ctr_head ? n - 1 : n;
@@ -281,39 +320,36 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   rec_deepfm_desc bd{B, S, Dn, D, D, 1, -1, 1, s.compact ? 1 : 0};      // the backward reads no table
   REC_TRY(rec_deepfm_fm_bwd(&bd, dense, bf.feat, bf.sum_emb, d_flat, bf.dz, bf.dz, net->dense_w, bf.row_grad,
                             net->g_dense_w, net->g_dense_w_one, bf.ws, bf.ws_bytes, stream));
-  // -- merged lazy Adam on W / W1 of the touched rows (optimizer.step on the SelectedRows gradients)
-  const int64_t nlook = B * S;
+  // -- merged lazy Adam on W / W1 of the touched rows (optimizer.step on the SelectedRows gradients): on the side stream
+  //    when there is one, underneath dW_0
   rec_grad_layout gl{1, 0, 0, nullptr, nullptr, 0}, gl1{S, 0, 0, nullptr, nullptr, 0};
   if (s.small) {
     REC_TRY(rec_sparse_adam_record_small(nlook, S, D, net->rec_stride, net->mv_stride, net->v_offset, net->table_rows,
                                          net->padding_idx, ids, net->slot_offset, bf.row_grad, &gl, bf.dz, &gl1,
                                          nullptr, net->rec, net->mv, hyper, status, stream));
   } else {
-    if (net->slot_rows > 0) {
-      REC_TRY(rec_ids_group_slots(B, S, net->slot_rows, net->padding_idx, ids, bf.sorted_pos, bf.uniq_rows,
-                                  bf.seg_offset, bf.n_uniq, nullptr, status, bf.ws, bf.ws_bytes, stream));
-    } else {
-      REC_TRY(rec_ids_group_payload(nlook, S, net->num_rows, net->padding_idx, ids, net->slot_offset, nullptr,
-                                    bf.sorted_pos, bf.uniq_rows, bf.seg_offset, bf.n_uniq, status, bf.ws, bf.ws_bytes,
-                                    stream));
-    }
-    REC_TRY(rec_segment_partials(nlook, D, bf.n_uniq, bf.seg_offset, bf.sorted_pos, bf.row_grad, &gl, bf.pp, stream));
-    REC_TRY(rec_segment_partials(nlook, 1, bf.n_uniq, bf.seg_offset, bf.sorted_pos, bf.dz, &gl1, bf.pp1, stream));
+    if (overlap) REC_TRY(order(1, stream, sst));
+    REC_TRY(rec_segment_partials(nlook, D, bf.n_uniq, bf.seg_offset, bf.sorted_pos, bf.row_grad, &gl, bf.pp, sst));
+    REC_TRY(rec_segment_partials(nlook, 1, bf.n_uniq, bf.seg_offset, bf.sorted_pos, bf.dz, &gl1, bf.pp1, sst));
     gl.partials = bf.pp;
     gl1.partials = bf.pp1;
     REC_TRY(rec_sparse_adam_record(nlook, D, net->rec_stride, net->mv_stride, net->v_offset, bf.n_uniq, bf.uniq_rows,
                                    bf.seg_offset, bf.sorted_pos, bf.row_grad, &gl, bf.dz, &gl1, nullptr, net->rec,
-                                   net->mv, hyper, stream));
+                                   net->mv, hyper, sst));
   }
-  // -- dW_0 / db_0, then the folded rows back into the real parameters' gradients (deepfm.py:_fold_backward)
+  // -- dW_0 / db_0, then the folded rows back into the real parameters' gradients (deepfm.py:_fold_backward).  Beside the
+  //    HBM-bound update the mirror splits K 16 ways instead of the planner's 32: half a resident round of blocks
+  static const int dw0_split = [] { const char* v = getenv("REC_DW0_SPLIT"); return v && *v ? atoi(v) : 16; }();
   REC_TRY(gemm(s.in0, net->widths[0], (int)B, true, false, REC_EPI_NONE, bf.feat, g0, gw0, nullptr, nullptr, 0,
-               net->gb[0], 0, bf, stream));
+               net->gb[0], overlap && B >= 16384 ? dw0_split : 0, bf, stream));
   if (s.compact) {
     REC_TRY(rec_copy_async(bf.dm, gw0 + (size_t)S * D * net->widths[0], (size_t)Dn * net->widths[0] * f4, stream));
     REC_TRY(rec_dense_fold_bwd(S, Dn, D, net->widths[0], net->dense_w, net->w[0], bf.dm, gw0, net->g_dense_w, 1,
                                stream));
   }
   // -- Adam on every dense parameter (one pass over the flat buffer)
-  return rec_adam_dense(net->flat_numel, net->flat_param, net->flat_m, net->flat_v, net->flat_grad, nullptr, hyper,
-                        stream);
+  REC_TRY(rec_adam_dense(net->flat_numel, net->flat_param, net->flat_m, net->flat_v, net->flat_grad, nullptr, hyper,
+                         stream));
+  if (overlap) REC_TRY(order(2, sst, stream));
+  return REC_OK;
 }

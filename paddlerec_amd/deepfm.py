@@ -352,13 +352,20 @@ class DeepFMLayer:
 
     def train_step_c(self, sparse_inputs, dense_inputs, label, lr=1e-3, auc_stats=None):
         """train_step through rec_deepfm_train_step: ONE foreign call per step — what a non-Python binder of
-        include/recengine.h gets.  Same kernels, arguments and order as the recorded (one-stream) step: bit-identical."""
+        include/recengine.h gets.  Same kernels, arguments and order as train_step (with its side stream for the large
+        batches): bit-identical."""
         ids = self._concat_ids(sparse_inputs)
         self.step_count += 1
         if getattr(self, "_ws_c", None) is None:
             self._ws_c = self.k.Workspace(self.device)
+        side = None
+        if self.device.type == "cuda" and os.environ.get("REC_DEEPFM_OVERLAP", "1") != "0":
+            if self._side is None:
+                self._side = self.k.concurrent_stream(self.device)
+            side = self._side
         return self.k.deepfm_train_step(self.c_net(), ids, dense_inputs, label.reshape(-1), self.step_count, self._ws_c,
-                                        lr=lr, auc_stats=auc_stats, num_thresholds=NUM_THRESHOLDS, status=self.status)
+                                        lr=lr, auc_stats=auc_stats, num_thresholds=NUM_THRESHOLDS, status=self.status,
+                                        side_stream=side)
 
     def train_step(self, sparse_inputs, dense_inputs, label, lr=1e-3, auc_stats=None,
                    allreduce=None):

@@ -123,9 +123,10 @@ class Workspace:
 
 
 def deepfm_train_step(net, ids, dense, label, step, ws, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, auc_stats=None,
-                      num_thresholds=4095, status=None, out=None):
+                      num_thresholds=4095, status=None, out=None, side_stream=None):
     """The whole DeepFM train step through ONE C-ABI call (rec_deepfm_train_step).  net: a filled _lib.DeepFMNet (the
-    caller keeps the tensors it points into alive).  -> (loss [1], pred [B,1])."""
+    caller keeps the tensors it points into alive).  side_stream (torch stream or None): the large-batch schedule of the
+    mirror (grouping and sparse update beside the main stream's GEMMs).  -> (loss [1], pred [B,1])."""
     _chk(ids, torch.int64, "ids")
     _chk(dense, torch.float32, "dense")
     _chk(label, torch.int64, "label")
@@ -146,7 +147,9 @@ def deepfm_train_step(net, ids, dense, label, step, ws, lr=1e-3, beta1=0.9, beta
     pos, neg = (auc_stats[0], auc_stats[1]) if auc_stats is not None else (None, None)
     check(lib().rec_deepfm_train_step(C.byref(net), B, _p(ids), _p(dense), _p(label), C.byref(h), _p(pos), _p(neg),
                                       int(num_thresholds), _p(loss), _p(pred), _p(status), _p(w),
-                                      C.c_size_t(w.numel()), _stream()), "rec_deepfm_train_step")
+                                      C.c_size_t(w.numel()), _stream(),
+                                      C.c_void_p(side_stream.cuda_stream) if side_stream is not None else None),
+          "rec_deepfm_train_step")
     return loss, pred
 
 

@@ -11,10 +11,11 @@ DEV = "cuda"
 pytestmark = pytest.mark.gpu
 
 
-def _run(monkeypatch, which, B, N, D, Dn, fc, slot_rows=0, steps=4):
+def _run(monkeypatch, which, B, N, D, Dn, fc, slot_rows=0, steps=4, overlap=False):
     from paddlerec_amd.deepfm import DeepFMLayer
     monkeypatch.setenv("REC_STEP_PLAN", "0")
-    monkeypatch.setenv("REC_DEEPFM_OVERLAP", "0")            # the C entry point issues everything on ONE stream
+    # overlap: both paths fork the id grouping and the sparse update onto a side stream (the large-batch schedule)
+    monkeypatch.setenv("REC_DEEPFM_OVERLAP", "1" if overlap else "0")
     torch.manual_seed(3)
     S = 26
     so = torch.arange(S, dtype=torch.int64) * slot_rows if slot_rows else None
@@ -35,17 +36,20 @@ def _run(monkeypatch, which, B, N, D, Dn, fc, slot_rows=0, steps=4):
             m.dense.m.cpu().numpy(), m.dense.v.cpu().numpy(), auc[0].cpu().numpy(), auc[1].cpu().numpy(), m.step_count)
 
 
-@pytest.mark.parametrize("B,N,D,Dn,fc,slot_rows", [
-    (96, 5000, 16, 13, [64, 32], 0),             # one-launch merge, fused head
-    (512, 100000, 16, 13, [400, 400, 400], 0),   # the reference's bigdata batch and tower (config_bigdata.yaml)
-    (700, 5000, 16, 13, [64, 32], 0),            # 18200 lookups: grouping sort + partials + record update
-    (8192, 0, 16, 13, [80, 48], 3000),           # slot-local grouping (rec_ids_group_slots fast path)
-    (640, 4000, 9, 13, [48], 0),                 # dense_dim > dim: no folding, D not a multiple of 4
-    (48, 3000, 16, 13, [32, 16], 0),             # fewer than 64 samples: the head goes through the GEMM path
+@pytest.mark.parametrize("B,N,D,Dn,fc,slot_rows,overlap", [
+    (96, 5000, 16, 13, [64, 32], 0, False),             # one-launch merge, fused head
+    (512, 100000, 16, 13, [400, 400, 400], 0, False),   # the reference's bigdata batch and tower (config_bigdata.yaml)
+    (700, 5000, 16, 13, [64, 32], 0, False),            # 18200 lookups: grouping sort + partials + record update
+    (8192, 0, 16, 13, [80, 48], 3000, False),           # slot-local grouping (rec_ids_group_slots fast path)
+    (640, 4000, 9, 13, [48], 0, False),                 # dense_dim > dim: no folding, D not a multiple of 4
+    (48, 3000, 16, 13, [32, 16], 0, False),             # a handful of samples
+    (8192, 0, 16, 13, [80, 48], 3000, True),     # the large-batch schedule: side stream, slot-local grouping
+    (16384, 200000, 16, 13, [80, 80], 0, True),  # ... general grouping, dW_0 on the 16-way K split beside the update
+    (512, 100000, 16, 13, [400, 400, 400], 0, True),   # a side stream offered to a one-launch-merge step: unused
 ])
-def test_c_step_equals_the_mirrors_eager_step(engine_lib, monkeypatch, B, N, D, Dn, fc, slot_rows):
-    a = _run(monkeypatch, "c", B, N, D, Dn, fc, slot_rows)
-    b = _run(monkeypatch, "eager", B, N, D, Dn, fc, slot_rows)
+def test_c_step_equals_the_mirrors_eager_step(engine_lib, monkeypatch, B, N, D, Dn, fc, slot_rows, overlap):
+    a = _run(monkeypatch, "c", B, N, D, Dn, fc, slot_rows, overlap=overlap)
+    b = _run(monkeypatch, "eager", B, N, D, Dn, fc, slot_rows, overlap=overlap)
     assert a[-1] == b[-1] == 4
     for (la, pa), (lb, pb) in zip(a[0], b[0]):
         assert np.array_equal(la, lb) and np.array_equal(pa, pb)
