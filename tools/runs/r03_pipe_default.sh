@@ -1,6 +1,6 @@
 #!/bin/bash
 # First GPU call of the next round: decide whether gemm_f32_pipe_kernel becomes the default.
-#   gpurun --timeout 900 -- 'bash tools/r03_pipe_default.sh'
+#   gpurun --timeout 900 -- 'bash tools/runs/r03_pipe_default.sh'
 # Writes gpurun_out/r03/: the full GPU suite with REC_GEMM_PIPE=1, bench.py with and without it (two runs each,
 # alternating), and the kernel stats of the flagged bench.  Make it the default only if the suite is green and the
 # flagged bench is faster in both pairs.
