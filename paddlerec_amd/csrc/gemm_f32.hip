@@ -460,15 +460,37 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N +
   }
 }
 
-// C = epi(sum_z partial[z]) in ascending z (fixed order)
+// one column of the [splits][N] partial column sums, ascending z with eight loads in flight and a fixed fold order
+__device__ __forceinline__ float colsum_fold(int N, int splits, const float* __restrict__ partial, int j) {
+  float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int z = 0;
+  for (; z + 8 <= splits; z += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a8[u] += partial[(int64_t)(z + u) * N + j];
+  }
+  for (; z < splits; ++z) a8[z & 7] += partial[(int64_t)z * N + j];
+  return ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+}
+
+// C = epi(sum_z partial[z]) in ascending z (fixed order).  The LAST colsum_blocks blocks of the grid fold the partial
+// column sums of the same GEMM instead (the bias gradient of dW = X^T dY): one launch behind a split-K weight gradient
+// instead of two (round 4; the arithmetic of both folds is unchanged).
 template <int EPI>
 __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(int64_t M, int N, int64_t ldc,
                                                                int splits,
                                                                const float* __restrict__ partial,
-                                                               float* __restrict__ C, EpiArgs epi) {
+                                                               float* __restrict__ C, EpiArgs epi,
+                                                               const float* __restrict__ cpartial,
+                                                               float* __restrict__ colsum_out, int colsum_blocks) {
+  const int rblocks = (int)gridDim.x - colsum_blocks;
+  if ((int)blockIdx.x >= rblocks) {
+    const int j = ((int)blockIdx.x - rblocks) * kBlock + threadIdx.x;
+    if (j < N) colsum_out[j] = colsum_fold(N, splits, cpartial, j);
+    return;
+  }
   const int64_t total = M * N;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * kBlock) {
+       e += (int64_t)rblocks * kBlock) {
     const int64_t i = e / N;
     const int j = (int)(e % N);
     const float* pp = partial + i * ldc + j;
@@ -490,15 +512,7 @@ __global__ __launch_bounds__(kBlock) void colsum_reduce_kernel(int N, int splits
                                                                const float* __restrict__ partial,
                                                                float* __restrict__ out) {
   const int j = blockIdx.x * kBlock + threadIdx.x;
-  if (j >= N) return;
-  float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int z = 0;
-  for (; z + 8 <= splits; z += 8) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) a8[u] += partial[(int64_t)(z + u) * N + j];
-  }
-  for (; z < splits; ++z) a8[z & 7] += partial[(int64_t)z * N + j];
-  out[j] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  if (j < N) out[j] = colsum_fold(N, splits, partial, j);
 }
 
 // ------------------------------------------------------------------------------- skinny shapes (N <= 4)
@@ -970,11 +984,12 @@ static bool launch_glds(const rec_gemm_desc* d, const float* A, const float* B, 
 
 template <int EPI>
 static void launch_reduce(const rec_gemm_desc* d, const GemmPlan& p, const float* partial, float* C,
-                          const EpiArgs& e, hipStream_t st) {
+                          const EpiArgs& e, hipStream_t st, const float* cpart = nullptr, float* colsum_out = nullptr) {
   int64_t grid = (d->m * d->n + kBlock - 1) / kBlock;
   if (grid > kNumCU * 8) grid = kNumCU * 8;
-  hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)grid), dim3(kBlock), 0, st, d->m,
-                     d->n, (int64_t)d->ldc, p.splits, partial, C, e);
+  const int cblocks = cpart && colsum_out ? (d->n + kBlock - 1) / kBlock : 0;
+  hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)(grid + cblocks)), dim3(kBlock), 0, st, d->m,
+                     d->n, (int64_t)d->ldc, p.splits, partial, C, e, cpart, colsum_out, cblocks);
 }
 
 }  // namespace rec
@@ -1100,7 +1115,7 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
   case E:                                                                 \
     if (partial) {                                                        \
       launch_epi<REC_EPI_NONE>(desc, p, A, B, C, e, partial, cpart, st);  \
-      if (!skip_reduce) launch_reduce<E>(desc, p, partial, C, e, st);     \
+      if (!skip_reduce) launch_reduce<E>(desc, p, partial, C, e, st, cpart, b_colsum); \
     } else {                                                              \
       launch_epi<E>(desc, p, A, B, C, e, nullptr, cpart, st);             \
     }                                                                     \
@@ -1119,7 +1134,7 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
     REC_EPI_CASE(REC_EPI_DTANH)
   }
 #undef REC_EPI_CASE
-  if (b_colsum && !skip_reduce)
+  if (b_colsum && !partial && !skip_reduce)      // (with split-K the reduce launch above folded the column sums too)
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((desc->n + kBlock - 1) / kBlock), dim3(kBlock), 0,
                        st, desc->n, p.splits, (const float*)cpart, b_colsum);
   return check_launch("rec_gemm_f32");
