@@ -65,6 +65,10 @@ typedef struct {
                             (rec_dense_fold_fwd): feat'[B,(S+1)D] @ [W0_sparse; M; 0] == feat[B,(S+Dn)D] @ W0.
                             In this mode rec_deepfm_fm_bwd takes d_feat_dnn in the same [B,S+1,D] layout and
                             its d_dense_w holds the FM part only (the MLP part comes from rec_dense_fold_bwd). */
+  int64_t feat_stride;   /* floats between consecutive samples of feat (and of d_feat_dnn in the backward); 0 = dense
+                            (fields x emb_dim).  A caller whose first MLP layer wants an input width that is a multiple
+                            of its GEMM tiles (39 fields x 10 = 390 -> 400) keeps feat in a zero-initialised
+                            [B, feat_stride] buffer: the kernels never touch the padding columns. */
 } rec_deepfm_desc;
 
 /* ids [B,S] i64 (= paddle.concat(sparse_inputs,1), net.py:107); dense [B,Dn] f32;
@@ -964,7 +968,12 @@ typedef struct {
   float* gb[REC_DEEPFM_MAX_LINEAR];
   float *flat_param, *flat_grad, *flat_m, *flat_v;
   int64_t flat_numel;
-  float* w0_folded;            /* compact mode only, see above */
+  float* w0_folded;            /* compact mode (see above) and layer0_width > 0 */
+  int32_t layer0_width;        /* 0, or a padded input width of layer 0 >= (num_slots + dense_dim) * dim for nets without
+                                  the dense fold (dense_dim > dim): the step keeps feat at this sample stride
+                                  (rec_deepfm_desc.feat_stride) and runs layer 0 on w0_folded [layer0_width, widths[0]],
+                                  a zero-initialised buffer of the caller's whose leading rows it refreshes from w[0]
+                                  every step — 39 fields x D 10 = 390 columns become 400, whole GEMM tiles */
 } rec_deepfm_net;
 int rec_deepfm_train_step_workspace_bytes(const rec_deepfm_net* net, int64_t batch, size_t* bytes);
 /* ids [batch, num_slots] i64, dense [batch, dense_dim] f32, label [batch] i64 -> loss_out [1], pred_out [batch];

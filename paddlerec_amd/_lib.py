@@ -18,7 +18,8 @@ class RecError(RuntimeError):
 class DeepFMDesc(C.Structure):
     _fields_ = [("batch", C.c_int64), ("num_slots", C.c_int32), ("num_dense", C.c_int32),
                 ("emb_dim", C.c_int32), ("row_stride", C.c_int32), ("num_rows", C.c_int64),
-                ("padding_idx", C.c_int64), ("w1_stride", C.c_int32), ("compact_dense", C.c_int32)]
+                ("padding_idx", C.c_int64), ("w1_stride", C.c_int32), ("compact_dense", C.c_int32),
+                ("feat_stride", C.c_int64)]
 
 
 class DeepFMNet(C.Structure):
@@ -31,7 +32,8 @@ class DeepFMNet(C.Structure):
                 ("v_offset", C.c_int32), ("dense_w", C.c_void_p), ("dense_w_one", C.c_void_p),
                 ("g_dense_w", C.c_void_p), ("g_dense_w_one", C.c_void_p), ("w", C.c_void_p * 8), ("b", C.c_void_p * 8),
                 ("gw", C.c_void_p * 8), ("gb", C.c_void_p * 8), ("flat_param", C.c_void_p), ("flat_grad", C.c_void_p),
-                ("flat_m", C.c_void_p), ("flat_v", C.c_void_p), ("flat_numel", C.c_int64), ("w0_folded", C.c_void_p)]
+                ("flat_m", C.c_void_p), ("flat_v", C.c_void_p), ("flat_numel", C.c_int64), ("w0_folded", C.c_void_p),
+                ("layer0_width", C.c_int32)]
 
 
 class AdamHyper(C.Structure):

@@ -55,7 +55,7 @@ constexpr int kDenseCh = 2;  // ceil(SPW_max * kDnMax / 64) = 8*16/64
 
 template <int VEC, int LANES, int IDCH, bool NT>
 __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
-    int64_t B, int S, int Dn, int D, int FP, int stride, int w1_stride, int64_t N, int64_t pad,
+    int64_t B, int S, int Dn, int D, int FP, int64_t feat_ld, int stride, int w1_stride, int64_t N, int64_t pad,
     const int64_t* __restrict__ ids, const float* __restrict__ dense, const float* __restrict__ W,
     const float* __restrict__ W1, const float* __restrict__ dense_w,
     const float* __restrict__ dense_w_one, const int64_t* __restrict__ slot_off,
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
 #pragma unroll
     for (int v = 0; v < VEC; ++v) s[v] = q[v] = 0.f;
     float first = 0.f;
-    float* fb = feat + (b * FP) * (int64_t)D + d0;
+    float* fb = feat + b * feat_ld + d0;                         // feat_ld >= FP * D floats between samples
     const bool compact = FP != F;   // feat = S embedding rows + ONE row of raw dense values (see header)
 
     for (int it0 = 0; it0 < NIT; it0 += kFwdUnroll) {
@@ -245,7 +245,7 @@ constexpr int kMaxDenseIters = 8;   // wave iterations that may contain dense fi
 
 template <int VEC, int LANES, int NDI, bool NT>
 __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
-    int64_t B, int S, int Dn, int D, int FP, const float* __restrict__ dense,
+    int64_t B, int S, int Dn, int D, int FP, int64_t feat_ld, const float* __restrict__ dense,
     const float* __restrict__ feat, const float* __restrict__ sum_emb,
     const float* __restrict__ dfeat, const float* __restrict__ dy1, const float* __restrict__ dy2,
     const float* __restrict__ dense_w, float* __restrict__ row_grad, float* __restrict__ partial, int rg_nt,
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
       g1 = dy1[b];
       g2 = dy2[b];
     }
-    const float* fb = feat + (b * FP) * (int64_t)D + d0;
-    const float* gb = dfeat + (b * FP) * (int64_t)D + d0;
+    const float* fb = feat + b * feat_ld + d0;
+    const float* gb = dfeat + b * feat_ld + d0;
     const bool compact = FP != F;   // dense fields have no rows in feat / dfeat: their d_dnn part is handled
                                     // by the caller through the folded layer-0 weights (see header)
     float* rg = row_grad + (b * S) * (int64_t)D + d0;
@@ -487,6 +487,9 @@ extern "C" int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids
   REC_REQUIRE(!desc->compact_dense || (Dn > 0 && Dn <= D), REC_ESHAPE,
               "compact_dense needs 0 < num_dense <= emb_dim");
   const int FP = desc->compact_dense ? S + 1 : S + Dn;
+  const int64_t feat_ld = desc->feat_stride > 0 ? desc->feat_stride : (int64_t)FP * D;
+  REC_REQUIRE(feat_ld >= (int64_t)FP * D && (desc->feat_stride <= 0 || feat_ld % 4 == 0), REC_EINVAL,
+              "feat_stride %lld must be a multiple of 4 and >= %d fields x %d", (long long)feat_ld, FP, D);
   return dispatch_row_shape(D, desc->row_stride, [&](auto vec, auto lanes) -> int {
     constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
     constexpr int SPW = kWave / (LANES * fs_for<LANES>());
@@ -506,7 +509,7 @@ extern "C" int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids
     if (grid > want) grid = want;                                                                 \
     if (grid > kMaxBlocks) grid = kMaxBlocks;                                                     \
     hipLaunchKernelGGL((fm_fwd_kernel<VEC, LANES, IDCH, NT_>), dim3((unsigned)grid), dim3(kBlock), \
-                       shmem, st, desc->batch, S, Dn, D, FP, desc->row_stride, w1_stride,          \
+                       shmem, st, desc->batch, S, Dn, D, FP, feat_ld, desc->row_stride, w1_stride, \
                        desc->num_rows, desc->padding_idx, ids, dense, W, W1, dense_w, dense_w_one, \
                        slot_offset, y1, y2, feat, sum_emb, status);                                \
   }
@@ -572,6 +575,9 @@ static int fm_bwd_impl(const rec_deepfm_desc* desc, const float* dense, const fl
   REC_REQUIRE(!desc->compact_dense || (Dn > 0 && Dn <= D && dense_w), REC_ESHAPE,
               "compact_dense needs 0 < num_dense <= emb_dim and dense_w");
   const int FP = desc->compact_dense ? S + 1 : S + Dn;
+  const int64_t feat_ld = desc->feat_stride > 0 ? desc->feat_stride : (int64_t)FP * D;
+  REC_REQUIRE(feat_ld >= (int64_t)FP * D && (desc->feat_stride <= 0 || feat_ld % 4 == 0), REC_EINVAL,
+              "feat_stride %lld must be a multiple of 4 and >= %d fields x %d", (long long)feat_ld, FP, D);
   if (desc->batch == 0) {
     if (K) {
       (void)hipMemsetAsync(d_dense_w, 0, (size_t)Dn * D * sizeof(float), st);
@@ -601,7 +607,7 @@ static int fm_bwd_impl(const rec_deepfm_desc* desc, const float* dense, const fl
     if (g > kMaxBlocks) g = kMaxBlocks;                                                           \
     grid = (int)g;                                                                                \
     hipLaunchKernelGGL((fm_bwd_kernel<VEC, LANES, NDI, NT_>), dim3(grid), dim3(kBlock), shmem, st, \
-                       desc->batch, S, Dn, D, FP, dense, feat, sum_emb, d_feat_dnn, dy1, dy2,      \
+                       desc->batch, S, Dn, D, FP, feat_ld, dense, feat, sum_emb, d_feat_dnn, dy1, dy2, \
                        dense_w, row_grad, partial, tune().rg_nt, row_rank);                        \
   }
 #define REC_BWD_LAUNCH(NDI) if (tune().nt) REC_BWD_LAUNCH2(NDI, true) else REC_BWD_LAUNCH2(NDI, false)

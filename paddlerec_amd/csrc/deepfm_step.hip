@@ -33,7 +33,9 @@ struct Shape {
   int S, D, Dn, n;
   bool compact;
   int fp;             // fields per sample in feat
-  int in0;            // input width of layer 0 as the GEMM sees it (fp * D)
+  int in0;            // input width of layer 0 as the GEMM sees it (fp * D, or the padded width)
+  int in0_real;       // fp * D
+  bool pad;           // layer 0 on a zero-padded input width (net->layer0_width)
   int in0_full;       // rows of w[0] as stored ((S + Dn) * D)
   int max_w;          // widest activation / gradient row
   bool small;         // merge inside the record update
@@ -50,7 +52,13 @@ int shape_of(const rec_deepfm_net* net, int64_t B, Shape* s) {
   s->S = net->num_slots; s->D = net->dim; s->Dn = net->dense_dim; s->n = net->n_linear;
   s->compact = s->Dn > 0 && s->Dn <= s->D;
   s->fp = s->compact ? s->S + 1 : s->S + s->Dn;
-  s->in0 = s->fp * s->D;
+  s->in0_real = s->fp * s->D;
+  s->pad = !s->compact && net->layer0_width > s->in0_real;
+  REC_REQUIRE(net->layer0_width == 0 || s->pad || net->layer0_width == s->in0_real, REC_EINVAL,
+              "layer0_width %d: a padded width needs a net without the dense fold and >= %d", net->layer0_width,
+              s->in0_real);
+  REC_REQUIRE(!s->pad || net->layer0_width % 4 == 0, REC_EINVAL, "layer0_width must be a multiple of 4");
+  s->in0 = s->pad ? net->layer0_width : s->in0_real;
   s->in0_full = (s->S + s->Dn) * s->D;
   s->max_w = s->in0;
   for (int i = 0; i < s->n; ++i) {
@@ -70,7 +78,7 @@ int shape_of(const rec_deepfm_net* net, int64_t B, Shape* s) {
 
 struct Buffers {
   float *y1, *y2, *feat, *sum_emb, *act[REC_DEEPFM_MAX_LINEAR], *y_dnn, *dz, *g[2], *row_grad, *dm;
-  float *pp, *pp1;
+  float *pp, *pp1, *dw0p;
   int32_t *sorted_pos, *seg_offset, *n_uniq;
   int64_t* uniq_rows;
   void* ws;              // scratch of the individual calls (one at a time: a single region, the largest need)
@@ -140,6 +148,7 @@ int carve(const rec_deepfm_net* net, const Shape& s, int64_t B, void* workspace,
   bf->g[1] = c.take<float>((size_t)B * s.max_w);
   bf->row_grad = c.take<float>(n * s.D);
   bf->dm = c.take<float>((size_t)(s.Dn > 0 ? s.Dn : 1) * net->widths[0]);
+  bf->dw0p = s.pad ? c.take<float>((size_t)s.in0 * net->widths[0]) : nullptr;
   bf->pp = bf->pp1 = nullptr;
   bf->sorted_pos = bf->seg_offset = bf->n_uniq = nullptr;
   bf->uniq_rows = nullptr;
@@ -208,7 +217,8 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
               "null pointer argument");
   REC_REQUIRE(net->rec && net->mv && net->flat_param && net->flat_grad && net->flat_m && net->flat_v, REC_EINVAL,
               "net: null parameter pointer");
-  REC_REQUIRE(!s.compact || net->w0_folded, REC_EINVAL, "net: w0_folded is needed with 0 < dense_dim <= dim");
+  REC_REQUIRE(!(s.compact || s.pad) || net->w0_folded, REC_EINVAL,
+              "net: w0_folded is needed with 0 < dense_dim <= dim and with a padded layer0_width");
   REC_REQUIRE((auc_pos == nullptr) == (auc_neg == nullptr), REC_EINVAL, "auc_pos / auc_neg: both or neither");
   Buffers bf;
   size_t need = 0;
@@ -247,7 +257,10 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   }
   // -- FM: lookup + first / second order + the MLP's input (net.py:104-136)
   rec_deepfm_desc fd{B, S, Dn, D, net->rec_stride, net->table_rows, net->padding_idx, net->rec_stride,
-                     s.compact ? 1 : 0};
+                     s.compact ? 1 : 0, s.pad ? (int64_t)s.in0 : 0};
+  if (s.pad)        // the padding columns of feat (workspace memory) must be zero: they meet zero weight rows, but 0 x NaN
+    REC_REQUIRE(hipMemset2DAsync(bf.feat + s.in0_real, (size_t)s.in0 * f4, 0, (size_t)(s.in0 - s.in0_real) * f4,
+                                 (size_t)B, (hipStream_t)stream) == hipSuccess, REC_EHIP, "hipMemset2DAsync failed");
   REC_TRY(rec_deepfm_fm_fwd(&fd, ids, dense, net->rec, net->rec + D, net->dense_w, net->dense_w_one, net->slot_offset,
                             bf.y1, bf.y2, bf.feat, bf.sum_emb, status, stream));
   // -- layer 0 on folded weights (deepfm.py:_mlp_weights): W0' = [ W0[:S*D] ; M ; 0 ]
@@ -258,6 +271,11 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
     REC_TRY(rec_dense_fold_fwd(S, Dn, D, net->widths[0], net->dense_w, net->w[0],
                                net->w0_folded + (size_t)S * D * net->widths[0], stream));
     w0 = net->w0_folded;
+  }
+  if (s.pad) {      // layer 0 on the zero-padded copy of its weight (deepfm.py:_mlp_weights, padded)
+    REC_TRY(rec_copy_async(net->w0_folded, net->w[0], (size_t)s.in0_real * net->widths[0] * f4, stream));
+    w0 = net->w0_folded;
+    gw0 = bf.dw0p;
   }
   // -- top MLP forward (net.py:142-174): bias / ReLU in the GEMM epilogue; with the fused head the last Linear, the loss
   //    and the backward of both are ONE pass over the last hidden activation (deepfm.py: fused_head)
@@ -317,7 +335,7 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
     gi ^= 1;
   }
   // -- FM backward: row gradients of the S lookups + the dense FM parameters (net.py:104-136 backward)
-  rec_deepfm_desc bd{B, S, Dn, D, D, 1, -1, 1, s.compact ? 1 : 0};      // the backward reads no table
+  rec_deepfm_desc bd{B, S, Dn, D, D, 1, -1, 1, s.compact ? 1 : 0, s.pad ? (int64_t)s.in0 : 0};   // reads no table
   REC_TRY(rec_deepfm_fm_bwd(&bd, dense, bf.feat, bf.sum_emb, d_flat, bf.dz, bf.dz, net->dense_w, bf.row_grad,
                             net->g_dense_w, net->g_dense_w_one, bf.ws, bf.ws_bytes, stream));
   // -- merged lazy Adam on W / W1 of the touched rows (optimizer.step on the SelectedRows gradients): on the side stream
@@ -347,6 +365,7 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
     REC_TRY(rec_dense_fold_bwd(S, Dn, D, net->widths[0], net->dense_w, net->w[0], bf.dm, gw0, net->g_dense_w, 1,
                                stream));
   }
+  if (s.pad) REC_TRY(rec_copy_async(net->gw[0], gw0, (size_t)s.in0_real * net->widths[0] * f4, stream));
   // -- Adam on every dense parameter (one pass over the flat buffer)
   REC_TRY(rec_adam_dense(net->flat_numel, net->flat_param, net->flat_m, net->flat_v, net->flat_grad, nullptr, hyper,
                          stream));

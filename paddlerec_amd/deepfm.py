@@ -205,6 +205,18 @@ class DeepFMLayer:
         if self.compact:
             self._w0p = torch.zeros(self.fp * D, sizes[1], dtype=torch.float32, device=self.device)
             self._dm = torch.zeros(Dn, sizes[1], dtype=torch.float32, device=self.device)
+        # Layer-0 width that is no multiple of the GEMM tiles (the reference's own layout: 39 fields x D 9 / 10 = 351 /
+        # 390 columns put all three layer-0 GEMMs on the edge-handling kernels, 0.9 ms instead of 0.6 per step at B 65536):
+        # feat lives in a zero-initialised [B, ld0] buffer (rec_deepfm_desc.feat_stride), layer 0 runs on a zero-padded
+        # copy of its weight — whole tiles for forward, dX and dW; the padding columns / rows stay exactly zero
+        self.in0 = self.fp * D
+        self.ld0 = self._pad_width(self.in0) if (not self.compact and self.supports_padded_feat
+                                                 and getattr(self.k, "SUPPORTS_FEAT_LD", False)) else self.in0
+        self.padded = self.ld0 != self.in0
+        if self.padded:
+            self._w0p = torch.zeros(self.ld0, sizes[1], dtype=torch.float32, device=self.device)
+            self._dw0p = torch.zeros(self.ld0, sizes[1], dtype=torch.float32, device=self.device)
+            self._fm_bufs = {}
         self.ws = self.k.Workspace(self.device)
         self.ws_group = self.k.Workspace(self.device)
         self.ws_mlp = self.k.Workspace(self.device)
@@ -213,6 +225,16 @@ class DeepFMLayer:
         self._side = None
         self._plans, self._recording = {}, False      # recorded call lists of launch-bound steps (plan.py)
         self.timers = None      # bench.py: dict name -> list of (start,end) torch.cuda.Event pairs
+
+    supports_padded_feat = True      # (the row-sharded subclass keeps its own FM path: dense feat)
+
+    @staticmethod
+    def _pad_width(in0):
+        """Smallest multiple of the whole-tile widths (80, 144) >= in0, if that costs <= 20 % more layer-0 work."""
+        if os.environ.get("REC_DEEPFM_PAD0", "1") == "0" or in0 % 80 == 0 or in0 % 144 == 0:
+            return in0
+        c = min(-(-in0 // 80) * 80, -(-in0 // 144) * 144)
+        return c if (c - in0) * 5 <= in0 else in0
 
     # -- parameters under the reference's state_dict keys (Appendix C) -------------------------
     def state_dict(self):
@@ -236,6 +258,19 @@ class DeepFMLayer:
         return sparse_inputs
 
     def _fm_fwd(self, ids, dense_inputs):
+        if self.padded:
+            B, dev = ids.shape[0], self.device
+            bufs = self._fm_bufs.get(B)
+            if bufs is None:
+                if len(self._fm_bufs) > 4:
+                    self._fm_bufs.clear()
+                f32 = dict(dtype=torch.float32, device=dev)
+                bufs = self._fm_bufs[B] = (torch.empty(B, 1, **f32), torch.empty(B, 1, **f32),
+                                           torch.zeros(B, self.ld0, **f32), torch.empty(B, self.sparse_feature_dim, **f32))
+            return self.k.deepfm_fm_fwd(ids, dense_inputs, self.fm.embedding, self.fm.embedding_one,
+                                        self.dense.p["fm.dense_w"], self.dense.p["fm.dense_w_one"],
+                                        self.fm.padding_idx, self.fm.slot_offset, self.status, out=bufs,
+                                        compact=False, feat_ld=self.ld0)
         return self.k.deepfm_fm_fwd(ids, dense_inputs, self.fm.embedding, self.fm.embedding_one,
                                     self.dense.p["fm.dense_w"], self.dense.p["fm.dense_w_one"],
                                     self.fm.padding_idx, self.fm.slot_offset, self.status,
@@ -244,6 +279,9 @@ class DeepFMLayer:
     # -- layer 0 on folded weights ------------------------------------------------------------------
     def _mlp_weights(self):
         """(weights, weight-grad views) of the top MLP as the GEMMs see them this step."""
+        if self.padded:
+            self._copy(self._w0p[: self.in0], self.mlp_w[0])
+            return [self._w0p] + self.mlp_w[1:], [self._dw0p] + self.mlp_dw[1:]
         if not self.compact:
             return self.mlp_w, self.mlp_dw
         S, D, Dn = self.sparse_num_field, self.sparse_feature_dim, self.dense_feature_dim
@@ -263,6 +301,9 @@ class DeepFMLayer:
     def _fold_backward(self):
         """After dW0' = feat'^T dZ0 landed in the first (S+1)*D rows of the layer-0 gradient buffer: turn its
         dense rows (= dM) into the gradients of the real parameters (W0 dense rows, dense_w MLP part)."""
+        if self.padded:
+            self._copy(self.mlp_dw[0], self._dw0p[: self.in0])
+            return
         if not self.compact:
             return
         S, D, Dn = self.sparse_num_field, self.sparse_feature_dim, self.dense_feature_dim
@@ -346,7 +387,8 @@ class DeepFMLayer:
         net.g_dense_w, net.g_dense_w_one = g["fm.dense_w"].data_ptr(), g["fm.dense_w_one"].data_ptr()
         net.flat_param, net.flat_grad = self.dense.data.data_ptr(), self.dense.grad.data_ptr()
         net.flat_m, net.flat_v, net.flat_numel = self.dense.m.data_ptr(), self.dense.v.data_ptr(), self.dense.data.numel()
-        net.w0_folded = self._w0p.data_ptr() if self.compact else None
+        net.w0_folded = self._w0p.data_ptr() if (self.compact or self.padded) else None
+        net.layer0_width = self.ld0 if self.padded else 0
         self._c_net = net
         return net
 
@@ -488,12 +530,13 @@ class DeepFMLayer:
             cur.wait_stream(gside)          # fm_bwd scatters through the rank the grouping (side stream) produced
         with self._timed("fm_bwd"):
             row_grad, _, _ = self.k.deepfm_fm_bwd(
-                dense_inputs, feat, sum_emb, d_flat.view(B, self.fp, -1), dz, dz, S, self.ws,
+                dense_inputs, feat, sum_emb, d_flat if self.padded else d_flat.view(B, self.fp, -1), dz, dz, S, self.ws,
                 out=(self._row_grad_buf(B * S),
                      self.dense.g["fm.dense_w"].view(self.dense_feature_dim, -1),
                      self.dense.g["fm.dense_w_one"]),
                 dense_w=self.dense.p["fm.dense_w"], compact=self.compact,
-                **(dict(row_rank=groups.rank) if sorted_rg else {}))
+                **(dict(row_rank=groups.rank) if sorted_rg else {}),
+                **(dict(feat_ld=self.ld0) if self.padded else {}))
         # The lazy sparse optimizer (HBM-bound) runs on the side stream underneath the MFMA-bound
         # dW_0 GEMM; it needs row_grad / dz and the merge keys (sorted on that same stream earlier).
         t = self.step_count
@@ -549,7 +592,8 @@ class DeepFMLayer:
         B, S = ids0.shape
         D = self.sparse_feature_dim
         y1, y2, feat, sum_emb, _ = self._fm_fwd(ids0, dense0)
-        dfeat = torch.randn(B, self.fp, D, device=self.device) * 1e-3
+        dfeat = torch.randn(*((B, self.ld0) if self.padded else (B, self.fp, D)), device=self.device) * 1e-3
+        pkw = dict(feat_ld=self.ld0) if self.padded else {}
         dz = torch.randn(B, 1, device=self.device) * 1e-3
         out = (self._row_grad_buf(B * S), torch.empty(self.dense_feature_dim, D, device=self.device),
                torch.empty(self.dense_feature_dim, device=self.device))
@@ -558,7 +602,7 @@ class DeepFMLayer:
             ids, dense = batches[i % len(batches)]
             self.k.deepfm_fm_fwd(self._concat_ids(ids), dense, self.fm.embedding, self.fm.embedding_one,
                                  self.dense.p["fm.dense_w"], self.dense.p["fm.dense_w_one"], self.fm.padding_idx,
-                                 self.fm.slot_offset, self.status, (y1, y2, feat, sum_emb), compact=self.compact)
+                                 self.fm.slot_offset, self.status, (y1, y2, feat, sum_emb), compact=self.compact, **pkw)
 
         # the backward as the STEP runs it: with the slot-local grouping its row gradients go out in sorted order through
         # the rank of the merge keys (rec_deepfm_fm_bwd_sorted) — the same variant is timed here
@@ -567,7 +611,7 @@ class DeepFMLayer:
 
         def bwd(i):
             self.k.deepfm_fm_bwd(dense0, feat, sum_emb, dfeat, dz, dz, S, self.ws, out=out,
-                                 dense_w=self.dense.p["fm.dense_w"], compact=self.compact, **rkw)
+                                 dense_w=self.dense.p["fm.dense_w"], compact=self.compact, **rkw, **pkw)
 
         def run(fn):
             ts = []

@@ -153,14 +153,18 @@ def deepfm_train_step(net, ids, dense, label, step, ws, lr=1e-3, beta1=0.9, beta
     return loss, pred
 
 
-def make_desc(B, S, Dn, D, num_rows, padding_idx, row_stride=None, w1_stride=1, compact=False):
+SUPPORTS_FEAT_LD = True       # deepfm_fm_fwd / _bwd take feat_ld (a padded sample stride of feat)
+
+
+def make_desc(B, S, Dn, D, num_rows, padding_idx, row_stride=None, w1_stride=1, compact=False, feat_stride=0):
     return DeepFMDesc(int(B), int(S), int(Dn), int(D), int(row_stride or D), int(num_rows),
-                      -1 if padding_idx is None else int(padding_idx), int(w1_stride), int(bool(compact)))
+                      -1 if padding_idx is None else int(padding_idx), int(w1_stride), int(bool(compact)),
+                      int(feat_stride))
 
 
 # ------------------------------------------------------------------ DeepFM FM block
 def deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, padding_idx=0, slot_offset=None,
-                  status=None, out=None, compact=False):
+                  status=None, out=None, compact=False, feat_ld=0):
     """ids [B,S] i64, dense [B,Dn] f32, W [N,D], W1 [N,1]|[N], dense_w [Dn,D]|[1,Dn,D], dense_w_one [Dn]
     -> y1 [B,1], y2 [B,1], feat [B,S+Dn,D], sum_emb [B,D], status
     compact: feat is [B,S+1,D] — S embedding rows + one row of the raw dense values (rec_deepfm_desc.compact_dense)."""
@@ -186,7 +190,10 @@ def deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, padding_idx=0, slot_o
         y1, y2, feat, sum_emb = out
     if status is None:
         status = new_status(dev)
-    desc = make_desc(B, S, Dn, D, N, padding_idx, w_stride, w1_stride, compact)
+    if feat_ld:          # feat_ld: feat is a caller-kept zero-initialised [B, feat_ld] buffer (rec_deepfm_desc.feat_stride)
+        if out is None or feat.dim() != 2 or feat.shape[1] != feat_ld or not feat.is_contiguous():
+            raise RecError("feat_ld needs out=(y1, y2, feat [B, feat_ld], sum_emb)")
+    desc = make_desc(B, S, Dn, D, N, padding_idx, w_stride, w1_stride, compact, feat_ld)
     check(lib().rec_deepfm_fm_fwd(C.byref(desc), _p(ids), _p(dense), _p(W), _p(W1), _p(dense_w),
                                   _p(dense_w_one), _p(slot_offset), _p(y1), _p(y2), _p(feat),
                                   _p(sum_emb), _p(status), _stream()), "rec_deepfm_fm_fwd")
@@ -194,19 +201,28 @@ def deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, padding_idx=0, slot_o
 
 
 def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, dense_w=None, compact=False,
-                  row_rank=None):
+                  row_rank=None, feat_ld=0):
     """-> row_grad [B*S,D], d_dense_w [Dn,D], d_dense_w_one [Dn].
     dense_w ([Dn,D] / [1,Dn,D], optional): recompute the dense part of feat instead of re-reading it.
     compact: feat / d_feat_dnn are [B,S+1,D] and d_dense_w is the FM part only (see deepfm_fm_fwd).
     row_rank [B*S] i32 (IdGroups.rank): row_grad is written in SORTED order (rec_deepfm_fm_bwd_sorted)."""
-    B, F, D = feat.shape
-    Dn = dense.shape[1] if compact else F - S
+    if feat_ld:          # feat / d_feat_dnn are [B, feat_ld] (padded sample stride)
+        B, D = sum_emb.shape
+        Dn = dense.shape[1]
+        F = S + 1 if compact else S + Dn
+        if feat.shape != (B, feat_ld) or d_feat_dnn.shape != (B, feat_ld) or feat_ld < F * D:
+            raise RecError("feat / d_feat_dnn must be [B, feat_ld] with feat_ld >= fields x emb_dim")
+    else:
+        B, F, D = feat.shape
+        Dn = dense.shape[1] if compact else F - S
     dev = feat.device
     for t, n in ((dense, "dense"), (feat, "feat"), (sum_emb, "sum_emb"), (d_feat_dnn, "d_feat_dnn"),
                  (dy1, "dy1"), (dy2, "dy2")):
         _chk(t, torch.float32, n)
     if d_feat_dnn.numel() != feat.numel() or dy1.numel() != B or dy2.numel() != B:
         raise RecError("gradient shape mismatch")
+    if not (feat.is_contiguous() and d_feat_dnn.is_contiguous()):
+        raise RecError("feat / d_feat_dnn must be contiguous")
     if dense_w is not None:
         _chk(dense_w, torch.float32, "dense_w")
         if dense_w.numel() != Dn * D:
@@ -217,7 +233,7 @@ def deepfm_fm_bwd(dense, feat, sum_emb, d_feat_dnn, dy1, dy2, S, ws, out=None, d
         d_dense_w_one = torch.empty(Dn, dtype=torch.float32, device=dev)
     else:
         row_grad, d_dense_w, d_dense_w_one = out
-    desc = make_desc(B, S, Dn, D, 1, None, compact=compact)
+    desc = make_desc(B, S, Dn, D, 1, None, compact=compact, feat_stride=feat_ld)
     nbytes = C.c_size_t(0)
     check(lib().rec_deepfm_fm_bwd_workspace_bytes(C.byref(desc), C.byref(nbytes)))
     w = ws.get(nbytes.value)

@@ -286,6 +286,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
     """DeepFMLayer (deepfm/net.py:21-49) with both embedding tables row-sharded over `group`.
     sparse_feature_number is the GLOBAL row count (after slot offsets)."""
 
+    supports_padded_feat = False     # the routed FM path below writes a dense feat
+
     def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim,
                  sparse_num_field, layer_sizes, device="cuda", slot_offset=None, group=None,
                  comm=None, kernels=None, table="adam", accessor=None, hash_keys=False, scale_sparse_grad=True):

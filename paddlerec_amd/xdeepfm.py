@@ -33,6 +33,8 @@ Z_CHUNK_BYTES = int(os.environ.get("REC_CIN_CHUNK_MB", "4096")) << 20
 class xDeepFMLayer(DeepFMLayer):
     """xdeepfm/net.py:23-55.  forward(sparse_inputs, dense_inputs) -> predict [B,1]."""
 
+    supports_padded_feat = False     # the CIN reads feat as [B, fields, D]: dense layout
+
     def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim, sparse_num_field,
                  layer_sizes_cin, layer_sizes_dnn, device="cuda", kernels=None):
         F = dense_feature_dim + sparse_num_field

@@ -760,3 +760,42 @@ def test_planned_step_equals_eager_step(engine_lib, monkeypatch, B):
         assert np.array_equal(la, lb) and np.array_equal(pa, pb)
     for x, y in zip(a[1:8], b[1:8]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,B", [(9, 700), (10, 8192)])
+def test_padded_layer0_input_equals_the_dense_layout(engine_lib, monkeypatch, D, B):
+    """The reference's own layout (deepfm/config.yaml: 39 fields x D 9, D 10 in config_bigdata) gives layer 0 an input
+    width that is no multiple of the GEMM tiles (351 / 390); DeepFMLayer then keeps feat at a padded sample stride (400,
+    rec_deepfm_desc.feat_stride) and runs layer 0 on a zero-padded copy of its weight.  Same model, same numbers: against
+    the dense layout (REC_DEEPFM_PAD0=0) over several steps — predictions and loss at fp32 rounding of the GEMM's K order,
+    every parameter inside the Adam bar, the state_dict shapes unchanged."""
+    from helpers import assert_adam_weights_close
+    from paddlerec_amd.deepfm import DeepFMLayer
+    monkeypatch.setenv("REC_STEP_PLAN", "0")
+    N, lr, steps = 6000, 1e-2, 3
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("REC_DEEPFM_PAD0", mode)
+        torch.manual_seed(4)
+        m = DeepFMLayer(N, D, 13, 26, [80, 48], device=DEV)
+        assert m.padded == (mode == "1") and m.in0 == 39 * D and (m.ld0 == 400 if m.padded else m.ld0 == m.in0)
+        assert tuple(m.state_dict()["dnn.linear_0.weight"].shape) == (39 * D, 80)
+        g = torch.Generator(device=DEV).manual_seed(12)
+        outs = []
+        for step in range(steps):
+            ids = torch.randint(0, N, (B, 26), device=DEV, generator=g)
+            dense = torch.rand(B, 13, device=DEV, generator=g)
+            label = (torch.rand(B, 1, device=DEV, generator=g) < 0.3).to(torch.int64)
+            loss, pred = m.train_step(ids, dense, label, lr=lr)
+            outs.append((float(loss), pred.cpu().numpy().copy()))
+        ev = m(ids, dense).cpu().numpy()                     # the inference path takes the padded layout too
+        runs[mode] = (outs, {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}, ev)
+        assert int(m.status.item()) == 0
+    (oa, sa, ea), (ob, sb, eb) = runs["1"], runs["0"]
+    for (la, pa), (lb, pb) in zip(oa, ob):
+        assert abs(la - lb) <= 2e-6 * max(abs(lb), 1e-3)
+        np.testing.assert_allclose(pa, pb, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(ea, eb, rtol=0, atol=5e-6)
+    for k in sa:
+        assert_adam_weights_close(sa[k], sb[k], lr, steps, err_msg=k)
