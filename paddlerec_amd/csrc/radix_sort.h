@@ -12,6 +12,7 @@
 // The first pass reads its keys through a functor (ids -> row keys computed on the fly: no key materialisation
 // pass); passes ping-pong between two buffers so that the LAST pass writes the caller's destination.
 #pragma once
+#include <stdlib.h>
 #include "rec_common.h"
 
 namespace rec {
@@ -192,7 +193,12 @@ struct Plan {
 inline Plan make_plan(int64_t n, int key_bits_) {
   Plan p;
   if (key_bits_ < 1) key_bits_ = 1;
-  p.passes = key_bits_ <= kMaxBits ? 1 : (key_bits_ + 8) / 9;   // prefer 9-bit digits (512 bins)
+  // digit width: 9 bits (512 bins) unless wider digits save a whole pass AND the keys are few enough for the 4-wave
+  // blocks that take them (REC_RSORT_DIGIT=<9..11> forces one width: A/B runs)
+  static const int digit_env = [] { const char* v = getenv("REC_RSORT_DIGIT"); return v && *v ? atoi(v) : 0; }();
+  int digit = 9;
+  if (digit_env >= 9 && digit_env <= kMaxBits) digit = digit_env;
+  p.passes = key_bits_ <= kMaxBits ? 1 : (key_bits_ + digit - 1) / digit;
   int left = key_bits_, sh = 0, maxb = 0;
   for (int i = 0; i < p.passes; ++i) {
     const int b = (left + (p.passes - i) - 1) / (p.passes - i);
