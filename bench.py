@@ -596,7 +596,13 @@ def main():
                    **({"table_rows_requested": rows_req * world} if args.table == "ps" and dist is not None
                       and rows_req != args.hashed_rows else {}),
                    **({"native_init_timed_out": True} if dist is not None and getattr(model.comm, "native_init_timed_out", False)
-                      else {})},
+                      else {}),
+                   # the N = 1 headline line measures configs[1] (plain Adam table, no exchange); THIS workload at world 1
+                   # is the N = 1 line's other_configs entry named below — the like-for-like base of a scaling ratio
+                   **({"scaling_base": "other_configs entry \"configs[4] (one GPU's share, row-sharded path at world 1)\" of "
+                                       "the --gpus 1 line (same table, same step, exchange degenerated to copies); the "
+                                       "--gpus 1 headline value is configs[1] on the plain table"}
+                      if dist is not None and args.table == "ps" else {})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": (tr_f + tr_b) if tr_f is not None else None,
