@@ -32,6 +32,26 @@ struct BufSrc {
   __device__ __forceinline__ bool drop(KeyT) const { return false; }
 };
 
+// (key, value) pairs as ONE 8-byte element: what the intermediate passes of sort_pairs_packed read and write.  A
+// scattered 4-byte store stream costs a pass ~20 us per 1.7 M elements on top of the first one (write combining breaks:
+// profiles/r04_slot_group_probe.txt); a pass that scatters keys and values as two arrays pays that twice.
+struct PairSrc {
+  const uint2* pairs;
+  __device__ __forceinline__ uint32_t key(int64_t i) const { return pairs[i].x; }
+  __device__ __forceinline__ int32_t val(int64_t i) const { return (int32_t)pairs[i].y; }
+  __device__ __forceinline__ bool drop(uint32_t) const { return false; }
+};
+template <class Src, class KeyT>
+__device__ __forceinline__ void src_load(const Src& s, int64_t i, KeyT& k, int32_t& v) {
+  k = s.key(i);
+  v = s.val(i);
+}
+__device__ __forceinline__ void src_load(const PairSrc& s, int64_t i, uint32_t& k, int32_t& v) {
+  const uint2 p = s.pairs[i];
+  k = p.x;
+  v = (int32_t)p.y;
+}
+
 // WAVES waves per block, tile = WAVES * 512 consecutive elements (2048 for small jobs: enough blocks to fill the
 // chip at n ~ 10^6; 8192 for large ones: a smaller histogram matrix)
 template <class KeyT, class Src, int WAVES>
@@ -89,11 +109,11 @@ static __global__ __launch_bounds__(kThreads) void rowscan_kernel(int nblk, int3
   if (threadIdx.x == kThreads - 1) totals[blockIdx.x] = part[kThreads - 1];
 }
 
-template <class KeyT, class Src, int WAVES>
+template <class KeyT, class Src, int WAVES, bool PACK_OUT = false>
 __global__ __launch_bounds__(WAVES* kWave) void scatter_kernel(int64_t n, int shift, int bits, int nblk, Src src,
                                                                const int32_t* __restrict__ hist,
                                                                const int32_t* __restrict__ totals,
-                                                               KeyT* __restrict__ keys_out,
+                                                               KeyT* __restrict__ keys_out,   // PACK_OUT: a uint2 array
                                                                int32_t* __restrict__ vals_out,
                                                                const int32_t* __restrict__ n_dev,
                                                                int32_t* __restrict__ n_live_out) {
@@ -115,8 +135,9 @@ __global__ __launch_bounds__(WAVES* kWave) void scatter_kernel(int64_t n, int sh
   for (int c = 0; c < kChunks; ++c) {
     const int64_t i = wbase + c * kWave + lane;
     const bool in = i < n;
-    k[c] = in ? src.key(i) : (KeyT)0;
-    v[c] = in ? src.val(i) : 0;
+    k[c] = (KeyT)0;
+    v[c] = 0;
+    if (in) src_load(src, i, k[c], v[c]);
     d[c] = (in && !src.drop(k[c])) ? (int)((k[c] >> shift) & mask) : -1;
   }
   // bin bases: exclusive scan of the totals (serial per thread + block scan)
@@ -173,8 +194,12 @@ __global__ __launch_bounds__(WAVES* kWave) void scatter_kernel(int64_t n, int sh
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (in) {
-      keys_out[(int64_t)off + rank] = k[c];
-      vals_out[(int64_t)off + rank] = v[c];
+      if constexpr (PACK_OUT) {
+        reinterpret_cast<uint2*>(keys_out)[(int64_t)off + rank] = make_uint2((uint32_t)k[c], (uint32_t)v[c]);
+      } else {
+        keys_out[(int64_t)off + rank] = k[c];
+        vals_out[(int64_t)off + rank] = v[c];
+      }
       if (rank == __popcll(peers) - 1) wh[d[c]] = off + rank + 1;   // last peer advances the running offset
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -217,7 +242,7 @@ inline Plan make_plan(int64_t n, int key_bits_) {
   return p;
 }
 
-template <class KeyT, class Src, int WAVES>
+template <class KeyT, class Src, int WAVES, bool PACK_OUT = false>
 inline void run_pass(int64_t n, const Plan& p, int i, Src src, KeyT* ko, int32_t* vo, int32_t* hist,
                      int32_t* totals, hipStream_t st, const int32_t* n_dev = nullptr, int32_t* n_live_out = nullptr) {
   const int nb = 1 << p.bits[i];
@@ -225,7 +250,7 @@ inline void run_pass(int64_t n, const Plan& p, int i, Src src, KeyT* ko, int32_t
   hipLaunchKernelGGL((hist_kernel<KeyT, Src, WAVES>), dim3(p.nblk), dim3(WAVES * kWave), nb * sizeof(int), st, n,
                      p.shift[i], p.bits[i], p.nblk, src, hist, n_dev);
   hipLaunchKernelGGL(rowscan_kernel, dim3(nb), dim3(kThreads), 0, st, p.nblk, hist, totals);
-  hipLaunchKernelGGL((scatter_kernel<KeyT, Src, WAVES>), dim3(p.nblk), dim3(WAVES * kWave), sm_scatter, st, n,
+  hipLaunchKernelGGL((scatter_kernel<KeyT, Src, WAVES, PACK_OUT>), dim3(p.nblk), dim3(WAVES * kWave), sm_scatter, st, n,
                      p.shift[i], p.bits[i], p.nblk, src, hist, totals, ko, vo, n_dev, n_live_out);
 }
 
@@ -263,6 +288,39 @@ inline int sort_pairs(int64_t n, const Plan& p, FirstSrc first, KeyT* keys_tmp, 
   }
   if (n_live)
     hipLaunchKernelGGL(fill_tail_kernel<KeyT>, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, n,
+                       (const int32_t*)n_live, tail_key, keys_dst);
+  return check_launch("radix sort");
+}
+
+// sort_pairs for 32-bit keys and >= 2 passes with the intermediate results as packed (key, value) pairs: pass i < last
+// writes ONE scattered 8-byte stream into pairs_a / pairs_b (n uint2 each, ping-pong; the last pass reads pairs_b, so
+// keys_dst may alias pairs_a), the last pass writes keys_dst / vals_dst as before.  Same order, same results.
+template <class FirstSrc>
+inline int sort_pairs_packed(int64_t n, const Plan& p, FirstSrc first, uint2* pairs_a, uint2* pairs_b, uint32_t* keys_dst,
+                             int32_t* vals_dst, void* ws_hist, void* ws_totals, hipStream_t st, int32_t* n_live = nullptr,
+                             uint32_t tail_key = 0) {
+  int32_t* hist = (int32_t*)ws_hist;
+  int32_t* totals = (int32_t*)ws_totals;
+  const int last = p.passes - 1;
+  auto buf_of = [&](int i) { return ((last - 1 - i) % 2 == 0) ? pairs_b : pairs_a; };   // output of intermediate pass i
+  for (int i = 0; i < p.passes; ++i) {
+    if (i == 0) {          // first pass (never the last one here: passes >= 2)
+      uint32_t* ko = (uint32_t*)buf_of(0);
+      if (p.waves == 16) run_pass<uint32_t, FirstSrc, 16, true>(n, p, i, first, ko, nullptr, hist, totals, st, nullptr, n_live);
+      else run_pass<uint32_t, FirstSrc, 4, true>(n, p, i, first, ko, nullptr, hist, totals, st, nullptr, n_live);
+    } else if (i < last) {
+      PairSrc src{buf_of(i - 1)};
+      uint32_t* ko = (uint32_t*)buf_of(i);
+      if (p.waves == 16) run_pass<uint32_t, PairSrc, 16, true>(n, p, i, src, ko, nullptr, hist, totals, st, n_live);
+      else run_pass<uint32_t, PairSrc, 4, true>(n, p, i, src, ko, nullptr, hist, totals, st, n_live);
+    } else {
+      PairSrc src{buf_of(i - 1)};
+      if (p.waves == 16) run_pass<uint32_t, PairSrc, 16, false>(n, p, i, src, keys_dst, vals_dst, hist, totals, st, n_live);
+      else run_pass<uint32_t, PairSrc, 4, false>(n, p, i, src, keys_dst, vals_dst, hist, totals, st, n_live);
+    }
+  }
+  if (n_live)
+    hipLaunchKernelGGL(fill_tail_kernel<uint32_t>, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, n,
                        (const int32_t*)n_live, tail_key, keys_dst);
   return check_launch("radix sort");
 }

@@ -195,7 +195,9 @@ static int plan_group(int64_t n, int64_t N, GroupPlan<KeyT>* p) {
   size_t o = 0;
   p->off_keys_tmp = o; o += align_up((size_t)n * sizeof(KeyT), 256);
   p->off_keys_dst = o; o += align_up((size_t)n * sizeof(KeyT), 256);
-  p->off_vals_tmp = o; o += align_up((size_t)n * sizeof(int32_t), 256);
+  // (32-bit keys, >= 2 passes: the intermediate passes ping-pong PACKED pairs — pairs_a = the keys_tmp | keys_dst region,
+  // pairs_b = this region, n uint2 — see rsort::sort_pairs_packed)
+  p->off_vals_tmp = o; o += align_up((size_t)n * (sizeof(KeyT) == 4 ? 8 : sizeof(int32_t)), 256);
   p->off_hist = o;     o += p->sort.hist_bytes;
   p->off_totals = o;   o += p->sort.totals_bytes;
   p->off_nlive = o;    o += 256;
@@ -221,10 +223,25 @@ static int run_group(int64_t n, int S, int64_t N, int64_t pad, const int64_t* id
   static const bool drop = [] { const char* v = getenv("REC_GROUP_DROP"); return !(v && *v == '0'); }();
   const bool dr = drop && n < (1ll << 31);
   IdsSrc<KeyT> src{ids, slot_off, S, N, pad, status, payload, dr, slot_rows};
-  if (int rc = rsort::sort_pairs<KeyT>(n, p.sort, src, keys_tmp, vals_tmp, keys_dst, sorted_pos,
-                                       base + p.off_hist, base + p.off_totals, st,
-                                       dr ? (int32_t*)(base + p.off_nlive) : nullptr, (KeyT)N))
-    return rc;
+  // packed intermediate passes: measured on the gpubox model's 40 M lookups (sort alone 1.425 -> 1.361 ms, step -0.1 ms)
+  // and on the 1.7 M lookups of a DeepFM batch on one shared table (step +8 us): taken from 4 M lookups on
+  // (REC_RSORT_PACK=0 / 1: never / always)
+  static const int pack = [] { const char* v = getenv("REC_RSORT_PACK"); return v && *v ? atoi(v) : -1; }();
+  bool packed = false;
+  if constexpr (sizeof(KeyT) == 4) {
+    if (p.sort.passes >= 2 && (pack == 1 || (pack < 0 && n >= (4ll << 20)))) {
+      packed = true;
+      if (int rc = rsort::sort_pairs_packed(n, p.sort, src, (uint2*)keys_tmp, (uint2*)vals_tmp, (uint32_t*)keys_dst,
+                                            sorted_pos, base + p.off_hist, base + p.off_totals, st,
+                                            dr ? (int32_t*)(base + p.off_nlive) : nullptr, (uint32_t)N))
+        return rc;
+    }
+  }
+  if (!packed)
+    if (int rc = rsort::sort_pairs<KeyT>(n, p.sort, src, keys_tmp, vals_tmp, keys_dst, sorted_pos,
+                                         base + p.off_hist, base + p.off_totals, st,
+                                         dr ? (int32_t*)(base + p.off_nlive) : nullptr, (KeyT)N))
+      return rc;
   const int nblk = (int)((n + kHeadsTile - 1) / kHeadsTile);
   (void)hipMemsetAsync(n_uniq + 2, 0, 2 * sizeof(int32_t), st);
   hipLaunchKernelGGL(heads_count_kernel<KeyT>, dim3(nblk), dim3(rsort::kThreads), 0, st, n, (KeyT)N, keys_dst, cnt,
