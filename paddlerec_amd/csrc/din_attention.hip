@@ -37,6 +37,7 @@ struct DinArgs {
   float *out, *att_weight;
   float* act1;             // [B,T,H1] layer-1 activations, saved for the backward when non-null
   int32_t* status;
+  float* part;             // tile-split forward (few samples): [B * tiles][E + 2] = pooled sum / l, m, l of every tile
 };
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
@@ -471,13 +472,21 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
     }
   };
 
-  int64_t b = blockIdx.x;
-  if (b >= a.B) return;
-  int t0 = 0, buf = 0;
+  // Tile split (a.part != null: fewer samples than the chip has block slots — the reference's batch size 32): a work
+  // item is ONE 32-position tile of a sample, softmax-normalised over its own positions; the per-tile (pooled, m, l) go
+  // to a.part and din_combine_kernel rescales them to the softmax over the whole history.  Otherwise a block walks the
+  // tiles of a sample one after the other with a running (online) softmax, as at large batches.
+  const bool split = a.part != nullptr;
+  const int NTL = (T + kDinTP - 1) / kDinTP;
+  const int64_t W = split ? a.B * NTL : a.B;
+  int64_t w = blockIdx.x;
+  if (w >= W) return;
+  int64_t b = split ? w / NTL : w;
+  int t0 = split ? (int)(w % NTL) * kDinTP : 0, buf = 0;
   float4 ph[S::NIT], pq[S::NIT];
-  ids_store(0, ids_issue(b, 0));
+  ids_store(0, ids_issue(b, t0));
   __syncthreads();
-  rows_issue(0, 0, ph, pq);
+  rows_issue(0, t0, ph, pq);
   rows_store(ph, pq);
   __syncthreads();
   float m_run = -INFINITY, l_run = 0.f;     // live in wave 0
@@ -487,9 +496,11 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
   while (true) {
     int64_t nb = b;
     int nt0 = t0 + kDinTP;
-    const bool last_tile = nt0 >= T;
-    if (last_tile) { nb = b + gridDim.x; nt0 = 0; }
-    const bool has_next = nb < a.B;
+    const bool last_tile = split || nt0 >= T;
+    const int64_t nw = w + gridDim.x;
+    if (split) { nb = nw / NTL; nt0 = (int)(nw % NTL) * kDinTP; }
+    else if (last_tile) { nb = nw; nt0 = 0; }
+    const bool has_next = split ? nw < W : nb < a.B;
     int64_t idv = 0;
     if (has_next) idv = ids_issue(nb, nt0);
 
@@ -615,19 +626,53 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
         float o = 0.f;
 #pragma unroll
         for (int q = 0; q < S::NPART; ++q) o += red[q * E + tid];
-        a.out[b * E + tid] = o / l_fin;
+        if (split) a.part[w * (E + 2) + tid] = o / l_fin;
+        else a.out[b * E + tid] = o / l_fin;
       }
-      if (a.att_weight)
+      if (split) {
+        if (tid == 0) { a.part[w * (E + 2) + E] = m_fin; a.part[w * (E + 2) + E + 1] = l_fin; }
+        const int t = t0 + tid;
+        if (a.att_weight && tid < kDinTP && t < T) a.att_weight[b * T + t] = expf(sall[t] - m_fin) / l_fin;
+      } else if (a.att_weight) {
         for (int t = tid; t < T; t += kBlock) a.att_weight[b * T + t] = expf(sall[t] - m_fin) / l_fin;
+      }
     }
     if (!has_next) break;
     if (!PF) rows_issue(buf ^ 1, nt0, ph, pq);
     rows_store(ph, pq);
     __syncthreads();
+    if (last_tile) w = nw;
     b = nb; t0 = nt0; buf ^= 1;
   }
   if (oob) atomicOr(a.status, REC_FLAG_INDEX_OOB);
 }
+
+// softmax over the whole history from the per-tile pieces of the tile-split forward: with M = max_j m_j and
+// L = sum_j l_j e^(m_j - M), tile j weighs c_j = l_j e^(m_j - M) / L:  out[b] = sum_j c_j part_j (ascending j),
+// att_weight[b, t] *= c_(t / 32).  One block per sample.
+__global__ __launch_bounds__(kBlock) void din_combine_kernel(int64_t B, int T, int NTL, int E,
+                                                             const float* __restrict__ part, float* __restrict__ out,
+                                                             float* __restrict__ att_weight) {
+  __shared__ float cj[64];
+  const int64_t b = blockIdx.x;
+  const float* pb = part + b * NTL * (E + 2);
+  if (threadIdx.x == 0) {
+    float M = -INFINITY;
+    for (int j = 0; j < NTL; ++j) M = fmaxf(M, pb[j * (E + 2) + E]);
+    float L = 0.f;
+    for (int j = 0; j < NTL; ++j) L += pb[j * (E + 2) + E + 1] * expf(pb[j * (E + 2) + E] - M);
+    for (int j = 0; j < NTL; ++j) cj[j] = pb[j * (E + 2) + E + 1] * expf(pb[j * (E + 2) + E] - M) / L;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += kBlock) {
+    float o = 0.f;
+    for (int j = 0; j < NTL; ++j) o += cj[j] * pb[j * (E + 2) + e];
+    out[b * E + e] = o;
+  }
+  if (att_weight)
+    for (int t = threadIdx.x; t < T; t += kBlock) att_weight[b * T + t] *= cj[t / kDinTP];
+}
+
 
 // ------------------------------------------------------------------------------------------ backward
 // Gradient of the attention-pool w.r.t. the gathered rows: dh [B,T,E] (history item|cat), dq [B,T,E]
@@ -1007,24 +1052,32 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
     }
   };
 
-  int64_t b = blockIdx.x;
-  if (b >= a.B) return;
-  int t0 = 0, buf = 0;
+  // Work items are (sample, 32-position tile) pairs — with the saved softmax weights and sdp = dout . out no tile of a
+  // sample depends on another one — dealt to the blocks as contiguous ranges of the flattened list: a block still walks
+  // the tiles of one sample after the other at large batches, and at the reference's batch size (32 samples x 5 tiles
+  // on 256 CUs) every tile has a block of its own instead of 32 blocks walking five tiles each (68 -> ~20 us).
+  const int NTL = (T + kDinTP - 1) / kDinTP;
+  const int64_t W = a.B * NTL, per = (W + gridDim.x - 1) / gridDim.x;
+  int64_t w = (int64_t)blockIdx.x * per;
+  const int64_t w_end = (w + per < W) ? w + per : W;
+  if (w >= w_end) return;
+  int64_t b = w / NTL;
+  int t0 = (int)(w % NTL) * kDinTP, buf = 0;
   {
     int64_t idv; float pwv;
-    ids_issue(b, 0, idv, pwv);
+    ids_issue(b, t0, idv, pwv);
     ids_store(0, idv, pwv);
     sample_load(b);
   }
   __syncthreads();
-  tile_load(0, b, 0);
+  tile_load(0, b, t0);
   __syncthreads();
 
   while (true) {
-    int64_t nb = b;
-    int nt0 = t0 + kDinTP;
-    if (nt0 >= T) { nb = b + gridDim.x; nt0 = 0; }
-    const bool has_next = nb < a.B;
+    const int64_t nw = w + 1;
+    const int64_t nb = nw / NTL;
+    const int nt0 = (int)(nw % NTL) * kDinTP;
+    const bool has_next = nw < w_end;
     int64_t idv = 0;
     float pwv = 0.f;
     if (has_next) ids_issue(nb, nt0, idv, pwv);
@@ -1128,10 +1181,10 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
     }
     if (!has_next) break;
     __syncthreads();            // hs / qs / X / douts are rewritten for the next tile
-    if (nt0 == 0) sample_load(nb);
+    if (nb != b) sample_load(nb);
     tile_load(buf ^ 1, nb, nt0);
     __syncthreads();
-    b = nb; t0 = nt0; buf ^= 1;
+    w = nw; b = nb; t0 = nt0; buf ^= 1;
   }
 }
 
@@ -1147,7 +1200,17 @@ extern "C" int rec_din_saves_act1(const rec_din_desc* d) {
          Ct::lds_bytes(d->max_len) <= kDinCtLdsMax && getenv("REC_DIN_FWD_GENERIC") == nullptr;
 }
 
-extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* hist_item,
+// workspace of the tile-split forward: B * ceil(T / 32) pieces of (E + 2) floats; 0 = the shape never splits
+extern "C" int rec_din_attention_pool_fwd_workspace_bytes(const rec_din_desc* d, size_t* bytes) {
+  REC_REQUIRE(d && bytes, REC_EINVAL, "null argument");
+  const int64_t ntl = (d->max_len + kDinTP - 1) / kDinTP;
+  const int64_t tiles = d->batch * ntl;
+  *bytes = (ntl > 1 && ntl <= 64 && tiles <= 4096) ? align_up((size_t)tiles * (d->item_dim + d->cat_dim + 2) * sizeof(float), 256)
+                                                  : 0;
+  return REC_OK;
+}
+
+extern "C" int rec_din_attention_pool_fwd_ws(const rec_din_desc* d, const int64_t* hist_item,
                                           const int64_t* hist_cat, const int64_t* tgt_item_seq,
                                           const int64_t* tgt_cat_seq, const int64_t* mask,
                                           const float* w_hist_item, const float* w_hist_cat,
@@ -1155,7 +1218,8 @@ extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* 
                                           const float* att_w1, const float* att_b1,
                                           const float* att_w2, const float* att_b2,
                                           const float* att_w3, const float* att_b3, float* out,
-                                          float* att_weight, float* act1, int32_t* status, void* stream) {
+                                          float* att_weight, float* act1, int32_t* status, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
   REC_REQUIRE(d, REC_EINVAL, "desc is NULL");
   const int E = d->item_dim + d->cat_dim;
   REC_REQUIRE(d->batch >= 0 && d->max_len > 0 && d->item_dim > 0 && d->cat_dim > 0 && d->hidden1 > 0 &&
@@ -1190,6 +1254,7 @@ extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* 
   a.w_tgt_cat = w_tgt_cat_seq; a.w1 = att_w1; a.b1 = att_b1; a.w2 = att_w2; a.b2 = att_b2; a.w3 = att_w3;
   a.b3 = att_b3; a.out = out; a.att_weight = att_weight; a.status = status;
   a.act1 = ct ? act1 : nullptr;       // only the compile-time-shaped pair saves / consumes layer-1 activations
+  a.part = nullptr;
   if (ct) {
     // REC_DIN_FWD_VARIANT: measurement knob.  Measured at B 4096, T 512 (profiles/r02_din_variants.txt):
     //   nopf2 (default; rows fetched at the end of the tile, 2 blocks/CU, 36 spilled VGPRs)  2.74 ms  68.0 TF
@@ -1209,6 +1274,20 @@ extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* 
       attr_set[variant] = true;
     }
     int64_t grid = resident_blocks(kern, kBlock, shmem);
+    // few samples (the reference's batch size): one block per 32-position tile + a combine launch instead of one
+    // block per sample walking its tiles (REC_DIN_TILE_SPLIT=0: off)
+    const int ntl = (d->max_len + kDinTP - 1) / kDinTP;
+    const int64_t tiles = d->batch * ntl;
+    size_t need = 0;
+    rec_din_attention_pool_fwd_workspace_bytes(d, &need);
+    static const bool split_env = [] { const char* v = getenv("REC_DIN_TILE_SPLIT"); return !(v && *v == '0'); }();
+    if (split_env && need > 0 && workspace && workspace_bytes >= need && tiles <= grid) {
+      a.part = (float*)workspace;
+      hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kBlock), shmem, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(din_combine_kernel, dim3((unsigned)d->batch), dim3(kBlock), 0, (hipStream_t)stream, d->batch,
+                         d->max_len, ntl, E, (const float*)workspace, out, att_weight);
+      return check_launch("rec_din_attention_pool_fwd (tile split)");
+    }
     if (grid > d->batch) grid = d->batch;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), shmem, (hipStream_t)stream, a);
     return check_launch("rec_din_attention_pool_fwd");
@@ -1218,6 +1297,20 @@ extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* 
   hipLaunchKernelGGL(din_attention_fwd_kernel, dim3((unsigned)grid), dim3(kBlock), shmem,
                      (hipStream_t)stream, a);
   return check_launch("rec_din_attention_pool_fwd");
+}
+
+extern "C" int rec_din_attention_pool_fwd(const rec_din_desc* d, const int64_t* hist_item,
+                                          const int64_t* hist_cat, const int64_t* tgt_item_seq,
+                                          const int64_t* tgt_cat_seq, const int64_t* mask,
+                                          const float* w_hist_item, const float* w_hist_cat,
+                                          const float* w_tgt_item_seq, const float* w_tgt_cat_seq,
+                                          const float* att_w1, const float* att_b1,
+                                          const float* att_w2, const float* att_b2,
+                                          const float* att_w3, const float* att_b3, float* out,
+                                          float* att_weight, float* act1, int32_t* status, void* stream) {
+  return rec_din_attention_pool_fwd_ws(d, hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, mask, w_hist_item, w_hist_cat,
+                                       w_tgt_item_seq, w_tgt_cat_seq, att_w1, att_b1, att_w2, att_b2, att_w3, att_b3, out,
+                                       att_weight, act1, status, nullptr, 0, stream);
 }
 
 extern "C" int rec_din_attention_pool_bwd(const rec_din_desc* d, const int64_t* hist_item,
@@ -1266,7 +1359,10 @@ extern "C" int rec_din_attention_pool_bwd(const rec_din_desc* d, const int64_t* 
                                                        (int)kDinCtLdsMax);
     (void)attr;
     int64_t grid = resident_blocks(kern, kBlock, Ct::lds_bytes);
-    if (grid > d->batch) grid = d->batch;
+    const int64_t tiles = d->batch * ((d->max_len + kDinTP - 1) / kDinTP);
+    static const bool split_env = [] { const char* v = getenv("REC_DIN_TILE_SPLIT"); return !(v && *v == '0'); }();
+    const int64_t items = split_env ? tiles : d->batch;      // REC_DIN_TILE_SPLIT=0: at most one block per sample
+    if (grid > items) grid = items;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), Ct::lds_bytes, (hipStream_t)stream, g);
     return check_launch("rec_din_attention_pool_bwd");
   }

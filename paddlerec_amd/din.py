@@ -111,7 +111,8 @@ class DINLayer:
             p["hist_item_emb_attr.weight"], p["hist_cat_emb_attr.weight"],
             p["target_item_seq_emb_attr.weight"], p["target_cat_seq_emb_attr.weight"],
             self.attention_w, self.attention_b, self.status, want_weights=_keep is not None,
-            saved=att_saved if _keep is not None else None)                            # net.py:141-173
+            saved=att_saved if _keep is not None else None,
+            **(dict(ws=ws) if self.k is _ops else {}))                                 # net.py:141-173
         emb = torch.empty(B, 2 * E, dtype=torch.float32, device=self.device)           # net.py:178
         self.k.gemm(pooled, p["linearCon.weight"], ws, epilogue="bias", bias=p["linearCon.bias"],
                  out=emb[:, :E])                                                         # net.py:175-176

@@ -773,11 +773,13 @@ def clip_scale(sumsq_t, clip_norm, out):
 
 
 def din_attention_pool(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, mask, w_hist_item, w_hist_cat,
-                       w_tgt_item_seq, w_tgt_cat_seq, att_w, att_b, status=None, want_weights=True, saved=None):
+                       w_tgt_item_seq, w_tgt_cat_seq, att_w, att_b, status=None, want_weights=True, saved=None, ws=None):
     """Fused DIN attention-pool forward (din/net.py:141-173).  ids/mask [B,T] i64; att_w/att_b: the three
     attention Linear layers ([4E,H1],[H1,H2],[H2,1] / biases).  -> (out [B,E], att_weight [B,T] | None, status)
     saved: a dict the training caller hands in; it receives what the backward can reuse ("out", and "act1"
-    [B,T,H1] when the engine saves layer-1 activations for this shape) — pass it on to din_attention_pool_bwd."""
+    [B,T,H1] when the engine saves layer-1 activations for this shape) — pass it on to din_attention_pool_bwd.
+    ws (ops.Workspace, optional): lets a batch of few samples run one block per history tile
+    (rec_din_attention_pool_fwd_ws)."""
     B, T = hist_item.shape
     for t, n in ((hist_item, "hist_item"), (hist_cat, "hist_cat"), (tgt_item_seq, "tgt_item_seq"),
                  (tgt_cat_seq, "tgt_cat_seq"), (mask, "mask")):
@@ -802,11 +804,18 @@ def din_attention_pool(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, mask, w_h
         act1 = saved.get("act1")
         if act1 is None or act1.shape != (B, T, H1) or act1.device != dev:
             act1 = torch.empty(B, T, H1, dtype=torch.float32, device=dev)
-    check(lib().rec_din_attention_pool_fwd(
+    wk, nb = None, 0
+    if ws is not None:
+        nbytes = C.c_size_t(0)
+        check(lib().rec_din_attention_pool_fwd_workspace_bytes(C.byref(d), C.byref(nbytes)))
+        if nbytes.value:
+            wk = ws.get(nbytes.value)
+            nb = wk.numel()
+    check(lib().rec_din_attention_pool_fwd_ws(
         C.byref(d), _p(hist_item), _p(hist_cat), _p(tgt_item_seq), _p(tgt_cat_seq), _p(mask),
         _p(w_hist_item), _p(w_hist_cat), _p(w_tgt_item_seq), _p(w_tgt_cat_seq), _p(att_w[0]), _p(att_b[0]),
-        _p(att_w[1]), _p(att_b[1]), _p(att_w[2]), _p(att_b[2]), _p(out), _p(attw), _p(act1), _p(status), _stream()),
-        "rec_din_attention_pool_fwd")
+        _p(att_w[1]), _p(att_b[1]), _p(att_w[2]), _p(att_b[2]), _p(out), _p(attw), _p(act1), _p(status), _p(wk),
+        C.c_size_t(nb), _stream()), "rec_din_attention_pool_fwd_ws")
     if saved is not None:
         saved["out"], saved["act1"] = out, act1
     return out, attw, status

@@ -322,3 +322,42 @@ def test_sparse_sgd_small_equals_group_then_rows(engine_lib, n, D, N, hot):
         want2_32 = P0.copy()
         np.subtract.at(want2_32, ids2[keep], np.float32(0.37) * gfull[keep, 4:4 + D])
         assert_close_floor(N_(Pc), want2, want2_32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(32, 152), (3, 100), (7, 33), (40, 64)])
+def test_tile_split_forward_and_backward_equal_the_per_sample_walk(engine_lib, monkeypatch, B, T):
+    """Few samples (din/config.yaml batch size 32: fewer than the chip has block slots): the forward runs one block per
+    32-position history tile and a combine launch rescales the per-tile softmax pieces (rec_din_attention_pool_fwd_ws),
+    the backward deals (sample, tile) pairs to the blocks.  Against the same kernels walking a sample's tiles in one
+    block (REC_DIN_TILE_SPLIT=0): pooled output, attention weights and both gradients at fp32 rounding."""
+    from paddlerec_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + T)
+    Ei = Ec = 64
+    n_item, n_cat = 500, 60
+    tabs = [torch.randn(n, d, device=DEV, generator=g) * 0.3 for n, d in ((n_item, Ei), (n_cat, Ec), (n_item, Ei), (n_cat, Ec))]
+    hi = torch.randint(0, n_item, (B, T), device=DEV, generator=g)
+    hc = torch.randint(0, n_cat, (B, T), device=DEV, generator=g)
+    ti = torch.randint(0, n_item, (B, 1), device=DEV, generator=g).expand(B, T).contiguous()
+    tc = torch.randint(0, n_cat, (B, 1), device=DEV, generator=g).expand(B, T).contiguous()
+    lens = torch.randint(1, T + 1, (B, 1), device=DEV, generator=g)
+    mask = torch.where(torch.arange(T, device=DEV)[None, :] < lens, 0, -(2 ** 32) + 1).to(torch.int64)
+    E = Ei + Ec
+    aw = [torch.randn(4 * E, 80, device=DEV, generator=g) * 0.05, torch.randn(80, 40, device=DEV, generator=g) * 0.1,
+          torch.randn(40, 1, device=DEV, generator=g) * 0.1]
+    ab = [torch.randn(80, device=DEV, generator=g) * 0.1, torch.randn(40, device=DEV, generator=g) * 0.1,
+          torch.randn(1, device=DEV, generator=g) * 0.1]
+    dout = torch.randn(B, E, device=DEV, generator=g)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("REC_DIN_TILE_SPLIT", mode)
+        ws, saved = ops.Workspace(DEV), {}
+        out, attw, st = ops.din_attention_pool(hi, hc, ti, tc, mask, tabs[0], tabs[1], tabs[2], tabs[3], aw, ab,
+                                               saved=saved, ws=ws)
+        dh, dq = ops.din_attention_pool_bwd(hi, hc, ti, tc, tabs[0], tabs[1], tabs[2], tabs[3], aw, ab, attw, dout,
+                                            saved=saved)
+        res[mode] = [x.cpu().numpy() for x in (out, attw, dh, dq)]
+        assert int(st.item()) == 0
+    for a, b, name in zip(res["1"], res["0"], ("out", "att_weight", "d_hist", "d_tgt")):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-6 * max(float(np.abs(b).max()), 1e-6), err_msg=name)
+    np.testing.assert_allclose(res["1"][1].sum(1), 1.0, atol=1e-5)
