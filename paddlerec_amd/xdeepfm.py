@@ -68,6 +68,7 @@ class xDeepFMLayer(DeepFMLayer):
         self._decayed = ["cin.cnn_%d.weight" % i for i in range(len(self.layer_sizes_cin))] + ["cin.cnn_fc.weight"] + \
                         ["dnn.linear_%d.weight" % i for i in range(self.n_linear)]
         self._zbuf = None
+        self._keep_bufs, self._kept = {}, {}
         self._bias_sum = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._zeros = None
 
@@ -93,6 +94,15 @@ class xDeepFMLayer(DeepFMLayer):
         if self._zbuf is None or self._zbuf.numel() < rows * K:
             self._zbuf = torch.empty(rows * K, dtype=torch.float32, device=self.device)
         return self._zbuf[: rows * K].view(rows, K)
+
+    def _keep_buf(self, name, rows, K):
+        """Outer-product rows (Z) / the Y intermediate of a layer, KEPT from the forward for the backward when the whole
+        batch is one chunk: a few GB at B 65536 (Z 3.6 GB, Y 2.9 GB of 288) instead of recomputing them in the backward —
+        0.8 ms of HBM passes and a 1.7 ms GEMM per step (REC_CIN_KEEP=0: recompute, the round-3 behaviour)."""
+        b = self._keep_bufs.get(name)
+        if b is None or b.numel() < rows * K:
+            b = self._keep_bufs[name] = torch.empty(rows * K, dtype=torch.float32, device=self.device)
+        return b[: rows * K].view(rows, K)
 
     def _scratch(self, name, shape):
         b = self._pad_bufs.get(name)
@@ -125,25 +135,41 @@ class xDeepFMLayer(DeepFMLayer):
             return feat, (lambda t: k.cin_view(t, "bfd"))
         return xts[i - 1], (lambda t: k.cin_view((t, D), "xt"))
 
-    def _cin_forward(self, feat):
-        """-> (pooled [B, sum C], [XT_1 .. XT_L])   XT_k [B*D, C_k] d-major."""
+    def _cin_forward(self, feat, keep=False):
+        """-> (pooled [B, sum C], [XT_1 .. XT_L])   XT_k [B*D, C_k] d-major.  keep: a training forward — the Z / Y
+        intermediates of one-chunk layers stay in their own buffers for _cin_backward (self._kept)."""
         k, D = self.k, self.sparse_feature_dim
         B, F, _ = feat.shape
+        keep = keep and os.environ.get("REC_CIN_KEEP", "1") != "0"
+        self._kept = {}
         pooled = torch.empty(B, self.cin_total, dtype=torch.float32, device=self.device)
         xts, off, S = [], 0, F
         for i, Cn in enumerate(self.layer_sizes_cin):
             xk, mk = self._layer_inputs(feat, xts, i)
             xt = torch.empty(B * D, Cn, dtype=torch.float32, device=self.device)
             if self._use_y(i, S, Cn):       # C < S: Y = Xk @ W'^T [., C*F] is smaller than Z [., F*S] and better shaped
-                for b0, b1 in self._chunks(B, F * Cn):
+                chunks = self._chunks(B, F * Cn)
+                for b0, b1 in chunks:
                     n = b1 - b0
-                    y = self._z(n * D, Cn * F)
+                    if keep and len(chunks) == 1:
+                        y = self._keep_buf("y%d" % i, n * D, Cn * F)
+                        self._kept[i] = ("y", B, y)
+                    else:
+                        y = self._z(n * D, Cn * F)
                     k.gemm(xk[b0 * D:b1 * D], self.cin_w[i].view(Cn * F, S), self.ws, trans_b=True, out=y)
                     k.cin_contract_fwd(n, D, F, y, feat[b0:b1], k.cin_view(feat, "bfd"), xt[b0 * D:b1 * D])
             KP, wz = self._padded_weight(i, F * S)
-            for b0, b1 in ([] if self._use_y(i, S, Cn) else self._chunks(B, KP)):
+            zchunks = [] if self._use_y(i, S, Cn) else self._chunks(B, KP)
+            for b0, b1 in zchunks:
                 n = b1 - b0
-                zf, z = self._z_padded(n * D, F * S, KP)
+                if keep and len(zchunks) == 1:
+                    zf = self._keep_buf("z%d" % i, n * D, KP)
+                    if KP != F * S:
+                        zf[:, F * S:].zero_()
+                    z = zf[:, : F * S]
+                    self._kept[i] = ("z", B, zf)
+                else:
+                    zf, z = self._z_padded(n * D, F * S, KP)
                 xk_c = xk[b0:b1] if i == 0 else xk[b0 * D:b1 * D]
                 k.cin_outer_fwd(n, D, F, S, feat[b0:b1], k.cin_view(feat, "bfd"), xk_c, mk(xk_c), z)
                 k.gemm(zf, wz, self.ws, trans_b=True, out=xt[b0 * D:b1 * D])                   # net.py:190 (1x1 conv)
@@ -170,12 +196,17 @@ class xDeepFMLayer(DeepFMLayer):
                 w2 = self.cin_w[i].view(Cn * F, S)
                 dw2 = self.cin_dw[i].view(Cn * F, S)
                 k.cin_sumpool_bwd(B, D, dpooled[:, offs[i - 1]:offs[i - 1] + S], dxk)       # the pooled-feature gradient
-                for ci, (b0, b1) in enumerate(self._chunks(B, 2 * F * Cn)):
+                kept = self._kept.get(i)
+                kept = kept[2] if kept is not None and kept[0] == "y" and kept[1] == B else None
+                for ci, (b0, b1) in enumerate(self._chunks(B, (1 if kept is not None else 2) * F * Cn)):
                     n = b1 - b0
-                    both = self._z(2 * n * D, Cn * F)
-                    y, dy = both[: n * D], both[n * D:]
                     xk_c, g = xk[b0 * D:b1 * D], dxt[b0 * D:b1 * D]
-                    k.gemm(xk_c, w2, self.ws, trans_b=True, out=y)                            # Y recomputed
+                    if kept is not None:                                                      # Y kept by the forward
+                        y, dy = kept[b0 * D:b1 * D], self._z(n * D, Cn * F)
+                    else:
+                        both = self._z(2 * n * D, Cn * F)
+                        y, dy = both[: n * D], both[n * D:]
+                        k.gemm(xk_c, w2, self.ws, trans_b=True, out=y)                        # Y recomputed
                     k.cin_contract_bwd(n, D, F, y, g, feat[b0:b1], k.cin_view(feat, "bfd"), dy, dfeat[b0:b1],
                                        k.cin_view(dfeat, "bfd"), True)
                     k.gemm(dy, xk_c, self.ws, trans_a=True, out=dw2,
@@ -184,13 +215,18 @@ class xDeepFMLayer(DeepFMLayer):
                     k.gemm(dy, w2, self.ws, epilogue="add", aux1=dxk_c, out=dxk_c)            # dXk = dY W' + pooled grad
             KP, wz = (F * S, None) if use_y else self._padded_weight(i, F * S)
             dwz = self.cin_dw[i] if KP == F * S else self._scratch("cin_dwz%d" % i, (Cn, KP))
+            keptz = self._kept.get(i)
+            keptz = keptz[2] if keptz is not None and keptz[0] == "z" and keptz[1] == B else None
             for ci, (b0, b1) in enumerate([] if use_y else self._chunks(B, KP)):
                 n = b1 - b0
-                zf, z = self._z_padded(n * D, F * S, KP)
                 xk_c = xk[b0:b1] if i == 0 else xk[b0 * D:b1 * D]
                 dxk_c = dxk[b0:b1] if i == 0 else dxk[b0 * D:b1 * D]
                 g = dxt[b0 * D:b1 * D]
-                k.cin_outer_fwd(n, D, F, S, feat[b0:b1], k.cin_view(feat, "bfd"), xk_c, mk(xk_c), z)      # recomputed
+                if keptz is not None:                                                                     # Z kept by the forward
+                    zf, z = keptz, keptz[:, : F * S]
+                else:
+                    zf, z = self._z_padded(n * D, F * S, KP)
+                    k.cin_outer_fwd(n, D, F, S, feat[b0:b1], k.cin_view(feat, "bfd"), xk_c, mk(xk_c), z)  # recomputed
                 k.gemm(g, zf, self.ws, trans_a=True, out=dwz,
                        **(dict(epilogue="add", aux1=dwz) if ci > 0 else {}))                              # dWc
                 k.gemm(g, wz, self.ws, out=zf)                                                            # dZ (in place of Z)
@@ -205,7 +241,7 @@ class xDeepFMLayer(DeepFMLayer):
         k = self.k
         y1, _, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
         B = feat.shape[0]
-        pooled, xts = self._cin_forward(feat)
+        pooled, xts = self._cin_forward(feat, keep=keep is not None)
         p = self.dense.p
         self._bias_sum.copy_(p["cin.cnn_fc.bias"])
         k.sgd_dense(self._bias_sum, p["bias"], -1.0)                      # cnn_fc.bias + bias (net.py:54)
