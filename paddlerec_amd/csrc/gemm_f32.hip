@@ -1107,7 +1107,9 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
       partial = (float*)workspace;
       off = align_up((size_t)p.splits * desc->m * desc->ldc * sizeof(float), 256);
     }
-    if (b_colsum) cpart = (float*)((char*)workspace + off);
+    // one K slice: the blocks of the first M-tile write the column sums straight into b_colsum (the fold of a single
+    // partial row adds zeros to it: same bits, one launch less)
+    if (b_colsum) cpart = p.splits == 1 ? b_colsum : (float*)((char*)workspace + off);
   }
   // MEASUREMENT ONLY (REC_GEMM_SKIP_REDUCE=1: wrong results): what the split-K reduce launches cost a step
   static const bool skip_reduce = [] { const char* v = getenv("REC_GEMM_SKIP_REDUCE"); return v && *v == '1'; }();
@@ -1134,7 +1136,7 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
     REC_EPI_CASE(REC_EPI_DTANH)
   }
 #undef REC_EPI_CASE
-  if (b_colsum && !partial && !skip_reduce)      // (with split-K the reduce launch above folded the column sums too)
+  if (b_colsum && !partial && cpart != b_colsum && !skip_reduce)   // (split-K: the reduce launch above folded them too)
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((desc->n + kBlock - 1) / kBlock), dim3(kBlock), 0,
                        st, desc->n, p.splits, (const float*)cpart, b_colsum);
   return check_launch("rec_gemm_f32");
