@@ -38,12 +38,32 @@ __global__ __launch_bounds__(kBlock) void bn_colreduce_kernel(int64_t M, int N, 
   const int64_t r0 = (int64_t)blockIdx.y * per, r1 = r0 + per < M ? r0 + per : M;
   float a0 = 0.f, a1 = 0.f;
   if (on) {
-    for (int64_t r = r0 + rl; r < r1; r += kRowLanes) {
-      const float x = X[r * ldx + c];
-      if (MODE == 0) a0 += x;
-      if (MODE == 1) { const float d = x - mu; a0 += d * d; }
-      if (MODE == 2) { const float g = dY[r * lddy + c]; a0 += g; a1 += g * (x - mu) * is; }
+    // four rows in flight per thread on four interleaved chains, folded in a fixed order (one dependent load-add chain
+    // per thread made a [4096 x 512] reduce take 60 us: 23 + 19 + 9 % of a DLRM step at B 4096)
+    float p0[4] = {0.f, 0.f, 0.f, 0.f}, p1[4] = {0.f, 0.f, 0.f, 0.f};
+    int64_t r = r0 + rl;
+    for (; r + 3 * kRowLanes < r1; r += 4 * kRowLanes) {
+      float x[4], g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        x[u] = X[(r + u * kRowLanes) * ldx + c];
+        g[u] = MODE == 2 ? dY[(r + u * kRowLanes) * lddy + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (MODE == 0) p0[u] += x[u];
+        if (MODE == 1) { const float d = x[u] - mu; p0[u] += d * d; }
+        if (MODE == 2) { p0[u] += g[u]; p1[u] += g[u] * (x[u] - mu) * is; }
+      }
     }
+    for (int u = 0; r < r1; r += kRowLanes, ++u) {
+      const float x = X[r * ldx + c];
+      if (MODE == 0) p0[u] += x;
+      if (MODE == 1) { const float d = x - mu; p0[u] += d * d; }
+      if (MODE == 2) { const float g = dY[r * lddy + c]; p0[u] += g; p1[u] += g * (x - mu) * is; }
+    }
+    a0 = (p0[0] + p0[1]) + (p0[2] + p0[3]);
+    a1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
   }
   red[0][rl][threadIdx.x % kColTile] = a0;
   red[1][rl][threadIdx.x % kColTile] = a1;
@@ -189,8 +209,8 @@ __global__ __launch_bounds__(kBlock) void accuracy_kernel(int64_t n, const float
   if (i == 0) atomicAdd(counts + 1, (unsigned long long)n);
 }
 
-int row_blocks(int64_t M) {
-  int64_t g = (M + 1023) / 1024;
+int row_blocks(int64_t M) {     // 128 rows per block at small batches (enough blocks to fill the chip), up to 128 row blocks
+  int64_t g = (M + 127) / 128;
   return (int)(g < 1 ? 1 : g > kMaxRowBlocks ? kMaxRowBlocks : g);
 }
 
