@@ -243,7 +243,10 @@ __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
 constexpr int kBwdUnroll = 4;
 constexpr int kMaxDenseIters = 8;   // wave iterations that may contain dense fields
 
-template <int VEC, int LANES, int NDI, bool NT>
+// PADDED: feat / dfeat at a caller-chosen sample stride (rec_deepfm_desc.feat_stride).  A template flag, not a run-time
+// branch: with the stride as a plain kernel argument the dense-layout instantiation went from 164 to 180 VGPRs — 3 -> 2
+// waves per SIMD, fm_bwd 65 -> 77 us back to back (caught by bench.py's roofline line dropping from 0.656 to 0.597).
+template <int VEC, int LANES, int NDI, bool NT, bool PADDED = false>
 __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
     int64_t B, int S, int Dn, int D, int FP, int64_t feat_ld, const float* __restrict__ dense,
     const float* __restrict__ feat, const float* __restrict__ sum_emb,
@@ -294,8 +297,9 @@ __global__ __launch_bounds__(kBlock) void fm_bwd_kernel(
       g1 = dy1[b];
       g2 = dy2[b];
     }
-    const float* fb = feat + b * feat_ld + d0;
-    const float* gb = dfeat + b * feat_ld + d0;
+    const int64_t fo = PADDED ? b * feat_ld + d0 : (b * FP) * (int64_t)D + d0;
+    const float* fb = feat + fo;
+    const float* gb = dfeat + fo;
     const bool compact = FP != F;   // dense fields have no rows in feat / dfeat: their d_dnn part is handled
                                     // by the caller through the folded layer-0 weights (see header)
     float* rg = row_grad + (b * S) * (int64_t)D + d0;
@@ -600,13 +604,15 @@ static int fm_bwd_impl(const rec_deepfm_desc* desc, const float* dense, const fl
     float* partial = (float*)workspace;
     int grid = 1;
 #define REC_BWD_LAUNCH2(NDI, NT_)                                                                 \
+  if (desc->feat_stride > 0) REC_BWD_LAUNCH3(NDI, NT_, true) else REC_BWD_LAUNCH3(NDI, NT_, false)
+#define REC_BWD_LAUNCH3(NDI, NT_, PAD_)                                                           \
   {                                                                                               \
-    int64_t g = resident_blocks(fm_bwd_kernel<VEC, LANES, NDI, NT_>, kBlock, shmem);              \
+    int64_t g = resident_blocks(fm_bwd_kernel<VEC, LANES, NDI, NT_, PAD_>, kBlock, shmem);        \
     if (tune().bwd_bpc > 0 && g > (int64_t)tune().bwd_bpc * kNumCU) g = (int64_t)tune().bwd_bpc * kNumCU; \
     if (g > need_blocks) g = need_blocks;                                                         \
     if (g > kMaxBlocks) g = kMaxBlocks;                                                           \
     grid = (int)g;                                                                                \
-    hipLaunchKernelGGL((fm_bwd_kernel<VEC, LANES, NDI, NT_>), dim3(grid), dim3(kBlock), shmem, st, \
+    hipLaunchKernelGGL((fm_bwd_kernel<VEC, LANES, NDI, NT_, PAD_>), dim3(grid), dim3(kBlock), shmem, st, \
                        desc->batch, S, Dn, D, FP, feat_ld, dense, feat, sum_emb, d_feat_dnn, dy1, dy2, \
                        dense_w, row_grad, partial, tune().rg_nt, row_rank);                        \
   }
@@ -617,6 +623,7 @@ static int fm_bwd_impl(const rec_deepfm_desc* desc, const float* dense, const fl
     else { REC_BWD_LAUNCH(8); }
 #undef REC_BWD_LAUNCH
 #undef REC_BWD_LAUNCH2
+#undef REC_BWD_LAUNCH3
     if (K > 0) {
       hipLaunchKernelGGL(fold_partials_kernel, dim3(K), dim3(kBlock), 0, st, partial, grid, Dn * D,
                          d_dense_w, d_dense_w_one);
