@@ -206,7 +206,11 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
 // -> grad_index -> gradient row -> record one dependent round trip after the other (4.2 ms for 9 M features).
 // Here ONE LANE owns a feature: 64 features per wave in flight, the index chain coalesced across lanes, the 64-B
 // record the lane's private line.  Same rule, same ascending-position summation.
-template <int DX>   // embedx floats held in registers (>= embedx_dim)
+// WHOLE: the slot layout (row_stride 16 = one 64-byte record: embed_w at 0, embedx(8) at 1, the seven statistics at 9) —
+// the lane reads and writes its record as FOUR float4s instead of 17 + 17 scalar accesses to the same line (with 64
+// records per wave instruction and dozens of waves per CU the line does not stay in L1 between them: every scalar access
+// was an L2 round trip — 1.80 ms alone for 3.95 GB, half the chip's gather rate).
+template <int DX, bool WHOLE = false>   // DX: embedx floats held in registers (>= embedx_dim)
 __global__ __launch_bounds__(kBlock) void ps_push_rows_narrow_kernel(
     rec_ps_layout L, int S, const int32_t* __restrict__ n_uniq, const int64_t* __restrict__ uniq,
     const int32_t* __restrict__ seg_off, const int32_t* __restrict__ spos, GradSrc gx, GradSrc gw,
@@ -223,14 +227,24 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_narrow_kernel(
   float* r = rec + row * (int64_t)L.row_stride;
   float* st = r + L.stat_off;            // show, click, g2sum_w, g2sum_x, state, delta_score, unseen_days
   const int64_t grow = row * A.row_mul + A.row_add;
-  const float show0 = st[kStShow], click0 = st[kStClick], g2w = st[kStG2w], g2x = st[kStG2x], state = st[kStState],
-              delta0 = st[kStDelta];
+  float R[16];                           // WHOLE: the record in registers
+  if constexpr (WHOLE) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t = reinterpret_cast<const float4*>(r)[q];
+      R[4 * q] = t.x; R[4 * q + 1] = t.y; R[4 * q + 2] = t.z; R[4 * q + 3] = t.w;
+    }
+  }
+  const float show0 = WHOLE ? R[9 + kStShow] : st[kStShow], click0 = WHOLE ? R[9 + kStClick] : st[kStClick],
+              g2w = WHOLE ? R[9 + kStG2w] : st[kStG2w], g2x = WHOLE ? R[9 + kStG2x] : st[kStG2x],
+              state = WHOLE ? R[9 + kStState] : st[kStState], delta0 = WHOLE ? R[9 + kStDelta] : st[kStDelta];
   const bool unborn = state == 0.f;
   const bool has_x = state >= 2.f;
   float w[DX];
 #pragma unroll
-  for (int d = 0; d < DX; ++d) w[d] = (has_x && d < Dx) ? r[L.embedx_off + d] : 0.f;
-  float ew = unborn ? (A.embed_zero_init ? 0.f : ps_init_value(A.seed, grow, 0, A.initial_range)) : r[L.embed_off];
+  for (int d = 0; d < DX; ++d) w[d] = (has_x && d < Dx) ? (WHOLE ? R[1 + (d < 8 ? d : 0)] : r[L.embedx_off + d]) : 0.f;
+  float ew = unborn ? (A.embed_zero_init ? 0.f : ps_init_value(A.seed, grow, 0, A.initial_range))
+                    : (WHOLE ? R[0] : r[L.embed_off]);
 
   // ---- one walk over the feature's occurrences: counters, embed_w gradient, embedx gradient
   float dshow = show ? 0.f : (float)(end - beg), dclick = 0.f, gwv = 0.f;
@@ -272,21 +286,41 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_narrow_kernel(
     for (int d = 0; d < DX; ++d)
       w[d] = d < Dx ? fminf(fmaxf(ps_init_value(A.seed, grow, 1 + d, A.x_initial_range), RX.lo), RX.hi) : 0.f;
   }
-  if (has_x || create_x) {
-#pragma unroll
-    for (int d = 0; d < DX; ++d)
-      if (d < Dx) r[L.embedx_off + d] = w[d];
-  }
   const double sqw = ps_rule_elem(ew, gwv, inv, sqrtf(RW.g0 / (RW.g0 + g2w)), RW);
-  r[L.embed_off] = ew;
-  st[kStShow] = show1;
-  st[kStClick] = click1;
-  st[kStG2w] = (float)((double)g2w + sqw);
-  if (has_x) st[kStG2x] = (float)((double)g2x + sq / (double)Dx);
-  else if (create_x) st[kStG2x] = 0.f;
-  st[kStState] = (has_x || create_x) ? 2.f : 1.f;
-  st[kStDelta] = delta0 + ((dshow - dclick) * A.nonclk_coeff + dclick * A.click_coeff);
-  st[kStUnseen] = 0.f;
+  if constexpr (WHOLE) {
+    if (has_x || create_x) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+        if (d < DX) R[1 + d] = w[d];
+    }
+    R[0] = ew;
+    R[9 + kStShow] = show1;
+    R[9 + kStClick] = click1;
+    R[9 + kStG2w] = (float)((double)g2w + sqw);
+    if (has_x) R[9 + kStG2x] = (float)((double)g2x + sq / (double)Dx);
+    else if (create_x) R[9 + kStG2x] = 0.f;
+    R[9 + kStState] = (has_x || create_x) ? 2.f : 1.f;
+    R[9 + kStDelta] = delta0 + ((dshow - dclick) * A.nonclk_coeff + dclick * A.click_coeff);
+    R[9 + kStUnseen] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      reinterpret_cast<float4*>(r)[q] = make_float4(R[4 * q], R[4 * q + 1], R[4 * q + 2], R[4 * q + 3]);
+  } else {
+    if (has_x || create_x) {
+#pragma unroll
+      for (int d = 0; d < DX; ++d)
+        if (d < Dx) r[L.embedx_off + d] = w[d];
+    }
+    r[L.embed_off] = ew;
+    st[kStShow] = show1;
+    st[kStClick] = click1;
+    st[kStG2w] = (float)((double)g2w + sqw);
+    if (has_x) st[kStG2x] = (float)((double)g2x + sq / (double)Dx);
+    else if (create_x) st[kStG2x] = 0.f;
+    st[kStState] = (has_x || create_x) ? 2.f : 1.f;
+    st[kStDelta] = delta0 + ((dshow - dclick) * A.nonclk_coeff + dclick * A.click_coeff);
+    st[kStUnseen] = 0.f;
+  }
   }
 }
 
@@ -399,7 +433,13 @@ extern "C" int rec_ps_push_rows(int64_t n_max, int32_t num_slots, const rec_ps_l
 #define REC_PS_NARROW(DX_)                                                                               \
   hipLaunchKernelGGL((ps_push_rows_narrow_kernel<DX_>), dim3((unsigned)grid), dim3(kBlock), 0, st, *layout, \
                      num_slots, n_uniq, uniq_rows, seg_offset, sorted_pos, gx, gw, show, click, rec, *accessor)
-    if (Dx <= 4) REC_PS_NARROW(4); else if (Dx <= 8) REC_PS_NARROW(8);
+    static const bool whole_env = [] { const char* v = getenv("REC_PS_WHOLE_RECORD"); return !(v && *v == '0'); }();
+    const bool whole = whole_env && layout->row_stride == 16 && layout->embed_off == 0 && layout->embedx_off == 1 &&
+                       layout->embedx_dim == 8 && layout->stat_off == 9 && ((uintptr_t)rec) % 16 == 0;
+    if (whole)
+      hipLaunchKernelGGL((ps_push_rows_narrow_kernel<8, true>), dim3((unsigned)grid), dim3(kBlock), 0, st, *layout,
+                         num_slots, n_uniq, uniq_rows, seg_offset, sorted_pos, gx, gw, show, click, rec, *accessor);
+    else if (Dx <= 4) REC_PS_NARROW(4); else if (Dx <= 8) REC_PS_NARROW(8);
     else if (Dx <= 12) REC_PS_NARROW(12); else REC_PS_NARROW(16);
 #undef REC_PS_NARROW
     return check_launch("rec_ps_push_rows (narrow)");

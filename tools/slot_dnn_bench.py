@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--layers", default="512,256,128,128,128")
     ap.add_argument("--pool-bench", type=int, default=0, help="time only the pooling kernel and print its line")
     ap.add_argument("--pool-only", type=int, default=0, help="only loop the pooling kernel this many times (profiling)")
+    ap.add_argument("--push-alone", action="store_true", help="also time the accessor push of a step ALONE (no GEMM beside it)")
     args = ap.parse_args()
     B, S, D, N = args.batch, args.slots, args.dim, args.rows
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -100,6 +101,14 @@ def main():
     model.timers = {}
     ms_step = timeit(lambda i: model.train_step(batches[i % 2][0], label, 1e-3), R=5)
     ev = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in model.timers.items() if not k.endswith("@host")}
+    if args.push_alone and model.table is not None:      # the step's own groups / gradient buffers, the push by itself
+        dx = torch.randn(B, S * D, device=DEV) * 1e-3
+        model.table.accessor.grad_scale = float(B)
+        ms_push = timeit(lambda i: ops.ps_push_rows(model.table, model._groups, dx, S, show=None, click=label.reshape(-1)), R=5)
+        u = int(model._groups.n_uniq[0])
+        by = u * 256 + live * 64 + live * 4 + u * 12
+        print("ps_push_rows alone: %.3f ms  (%d features, %d live ids; records r/w + one 64-B gradient sector per id + index "
+              "arrays = %.2f GB -> %.2f TB/s)" % (ms_push, u, live, by / 1e9, by / ms_push / 1e9), file=sys.stderr)
     flops = 3 * sum(2 * B * a * b for a, b in zip([S * D] + model.layer_sizes, model.layer_sizes + [1]))
     print(json.dumps({
         "workload": "slot_dnn BenchmarkDNNLayer: %d slots x D %d, batch %d, %d ids (%d live), hashed table %d rows, %s"
