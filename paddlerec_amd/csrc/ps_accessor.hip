@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_narrow_kernel(
     rec_ps_layout L, int S, const int32_t* __restrict__ n_uniq, const int64_t* __restrict__ uniq,
     const int32_t* __restrict__ seg_off, const int32_t* __restrict__ spos, GradSrc gx, GradSrc gw,
     const int64_t* __restrict__ show, const int64_t* __restrict__ click, float* __restrict__ rec,
-    rec_ps_accessor A) {
+    rec_ps_accessor A, bool row9) {
   // n_max is a capacity (the number of touched features is only known on the device): capped grid, strided loop
   const int nu = n_uniq[0];
   const int Dx = L.embedx_dim;
@@ -259,11 +259,27 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_narrow_kernel(
       if (show) dshow += (float)show[smp];
       if (click) lsum += click[smp];
     }
-    gwv += gw.grad[ps_grad_offset(gw.gl, pos, gw.pitch) + gw.col];
-    if (has_x) {
-      const float* a = gx.grad + ps_grad_offset(gx.gl, pos, gx.pitch) + gx.col;
+    if (WHOLE && row9) {
+      // [g_embed_w | g_embedx(8)] are nine consecutive floats of one gradient row (4-byte aligned: 36-byte rows): two
+      // dwordx4 loads + one dword instead of nine dword loads (gfx950 global loads take any dword alignment)
+      typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+      const float* a = gx.grad + ps_grad_offset(gx.gl, pos, gx.pitch);
+      const f4u t0 = *reinterpret_cast<const f4u*>(a), t1 = *reinterpret_cast<const f4u*>(a + 4);
+      const float t2 = a[8];
+      gwv += t0.x;
+      if (has_x) {
+        const float v[8] = {t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2};
 #pragma unroll
-      for (int d = 0; d < DX; ++d) g[d] += d < Dx ? a[d] : 0.f;
+        for (int d = 0; d < 8; ++d)
+          if (d < DX) g[d] += v[d];
+      }
+    } else {
+      gwv += gw.grad[ps_grad_offset(gw.gl, pos, gw.pitch) + gw.col];
+      if (has_x) {
+        const float* a = gx.grad + ps_grad_offset(gx.gl, pos, gx.pitch) + gx.col;
+#pragma unroll
+        for (int d = 0; d < DX; ++d) g[d] += d < Dx ? a[d] : 0.f;
+      }
     }
   }
   // (the wide kernel adds the labels four at a time as integers, then to float: any grouping of integer partial
@@ -432,13 +448,17 @@ extern "C" int rec_ps_push_rows(int64_t n_max, int32_t num_slots, const rec_ps_l
     if (grid > (int64_t)kNumCU * 32) grid = (int64_t)kNumCU * 32;   // grid-stride loop in the kernel
 #define REC_PS_NARROW(DX_)                                                                               \
   hipLaunchKernelGGL((ps_push_rows_narrow_kernel<DX_>), dim3((unsigned)grid), dim3(kBlock), 0, st, *layout, \
-                     num_slots, n_uniq, uniq_rows, seg_offset, sorted_pos, gx, gw, show, click, rec, *accessor)
+                     num_slots, n_uniq, uniq_rows, seg_offset, sorted_pos, gx, gw, show, click, rec, *accessor, false)
     static const bool whole_env = [] { const char* v = getenv("REC_PS_WHOLE_RECORD"); return !(v && *v == '0'); }();
     const bool whole = whole_env && layout->row_stride == 16 && layout->embed_off == 0 && layout->embedx_off == 1 &&
                        layout->embedx_dim == 8 && layout->stat_off == 9 && ((uintptr_t)rec) % 16 == 0;
+    // both gradients from ONE 9-float row (slot_dnn: d(pooled)[sample, slot] = [g_embed_w | g_embedx(8)])
+    const bool row9 = gx.grad == gw.grad && gx.pitch == 9 && gw.pitch == 9 && gx.col == 1 && gw.col == 0 &&
+                      gx.gl.div == gw.gl.div && gx.gl.group == gw.gl.group && gx.gl.group_stride == gw.gl.group_stride &&
+                      gx.gl.index == gw.gl.index;
     if (whole)
       hipLaunchKernelGGL((ps_push_rows_narrow_kernel<8, true>), dim3((unsigned)grid), dim3(kBlock), 0, st, *layout,
-                         num_slots, n_uniq, uniq_rows, seg_offset, sorted_pos, gx, gw, show, click, rec, *accessor);
+                         num_slots, n_uniq, uniq_rows, seg_offset, sorted_pos, gx, gw, show, click, rec, *accessor, row9);
     else if (Dx <= 4) REC_PS_NARROW(4); else if (Dx <= 8) REC_PS_NARROW(8);
     else if (Dx <= 12) REC_PS_NARROW(12); else REC_PS_NARROW(16);
 #undef REC_PS_NARROW
