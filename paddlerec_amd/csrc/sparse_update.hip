@@ -469,6 +469,24 @@ __device__ __forceinline__ void narrow_store(float* __restrict__ p, const float 
   }
 }
 
+// x[0..D) = one narrow gradient row (zeros behind D).  Whole groups of four floats as ONE dwordx4 load at dword alignment
+// (gfx950 global loads take it; a 9-float row is two of them and a dword instead of nine dwords — every load instruction
+// of a lane-per-row kernel is an L2 round trip of its own: 64 different lines per wave instruction do not live in L1).
+template <int NV>
+__device__ __forceinline__ void narrow_row_load(float (&x)[NV * 4], const float* __restrict__ a, int D) {
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    if (4 * q + 4 <= D) {
+      const f4u t = *reinterpret_cast<const f4u*>(a + 4 * q);
+      x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+    } else {
+#pragma unroll
+      for (int d = 4 * q; d < 4 * q + 4; ++d) x[d] = d < D ? a[d] : 0.f;
+    }
+  }
+}
+
 // g[0..D) += the gradient rows of sorted positions [beg,end), ascending (two positions in flight); long segments
 // through the tile partials as segment_sum does
 template <int NV>
@@ -491,15 +509,16 @@ __device__ __forceinline__ void narrow_segment_sum(float (&g)[NV * 4], int beg, 
     const float* a = grad + grad_at(gl, spos, k, D);
     const float* b = grad + grad_at(gl, spos, k + 1, D);
     float x[NV * 4], y[NV * 4];
-#pragma unroll
-    for (int d = 0; d < NV * 4; ++d) { x[d] = d < D ? a[d] : 0.f; y[d] = d < D ? b[d] : 0.f; }
+    narrow_row_load<NV>(x, a, D);
+    narrow_row_load<NV>(y, b, D);
 #pragma unroll
     for (int d = 0; d < NV * 4; ++d) g[d] = (g[d] + x[d]) + y[d];
   }
   if (k < end) {
-    const float* a = grad + grad_at(gl, spos, k, D);
+    float x[NV * 4];
+    narrow_row_load<NV>(x, grad + grad_at(gl, spos, k, D), D);
 #pragma unroll
-    for (int d = 0; d < NV * 4; ++d) g[d] += d < D ? a[d] : 0.f;
+    for (int d = 0; d < NV * 4; ++d) g[d] += x[d];
   }
 }
 
