@@ -96,7 +96,10 @@ constexpr int kStShow = 0, kStClick = 1, kStG2w = 2, kStG2x = 3, kStState = 4, k
 
 // One row group of LANES lanes per touched feature: the lanes own VEC-float slices of the embedx part, lane 0 of
 // the group also owns embed_w and the statistics (same record line).
-template <int VEC, int LANES>
+// STATV: embed_w and the seven statistics are eight consecutive floats on a 16-byte boundary (the DeepFM layout: embed_w
+// at D, statistics at D + 1, D a multiple of 4) — read as two float4s by every lane of the group and written as two
+// float4s by lane 0 instead of 6 scalar loads per lane + 9 scalar stores (see the narrow kernel's WHOLE mode).
+template <int VEC, int LANES, bool STATV = false>
 __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
     rec_ps_layout L, int S, const int32_t* __restrict__ n_uniq, const int64_t* __restrict__ uniq,
     const int32_t* __restrict__ seg_off, const int32_t* __restrict__ spos, GradSrc gx, GradSrc gw,
@@ -138,10 +141,16 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
   dshow = __shfl(dshow, head, kWave);
   dclick = __shfl(dclick, head, kWave);
 
-  float show0 = 0.f, click0 = 0.f, g2w = 0.f, g2x = 0.f, state = 0.f, delta0 = 0.f;
+  float show0 = 0.f, click0 = 0.f, g2w = 0.f, g2x = 0.f, state = 0.f, delta0 = 0.f, ew0 = 0.f;
   if (rowok) {
-    show0 = st[kStShow]; click0 = st[kStClick]; g2w = st[kStG2w]; g2x = st[kStG2x]; state = st[kStState];
-    delta0 = st[kStDelta];
+    if constexpr (STATV) {
+      const float4 q0 = *reinterpret_cast<const float4*>(r + L.embed_off);
+      const float4 q1 = *reinterpret_cast<const float4*>(r + L.embed_off + 4);
+      ew0 = q0.x; show0 = q0.y; click0 = q0.z; g2w = q0.w; g2x = q1.x; state = q1.y; delta0 = q1.z;
+    } else {
+      show0 = st[kStShow]; click0 = st[kStClick]; g2w = st[kStG2w]; g2x = st[kStG2x]; state = st[kStState];
+      delta0 = st[kStDelta];
+    }
   }
   const bool unborn = state == 0.f;
   const bool has_x = state >= 2.f;
@@ -184,20 +193,29 @@ __global__ __launch_bounds__(kBlock) void ps_push_rows_kernel(
   }
   // ---- embed_w + statistics
   if (rowok && lg == 0) {
-    float ew = unborn ? (A.embed_zero_init ? 0.f : ps_init_value(A.seed, grow, 0, A.initial_range)) : r[L.embed_off];
+    float ew = unborn ? (A.embed_zero_init ? 0.f : ps_init_value(A.seed, grow, 0, A.initial_range))
+                      : (STATV ? ew0 : r[L.embed_off]);
     float gwv[1] = {0.f};
     ps_segment_sum<1>(gwv, beg, end, spos, gw, gw.col);
     const PsRule RW = {A.lr, A.initial_g2sum, A.min_bound, A.max_bound};
     const double sqw = ps_rule_elem(ew, gwv[0], inv, sqrtf(RW.g0 / (RW.g0 + g2w)), RW);
-    r[L.embed_off] = ew;
-    st[kStShow] = show1;
-    st[kStClick] = click1;
-    st[kStG2w] = (float)((double)g2w + sqw);
-    if (has_x) st[kStG2x] = (float)((double)g2x + sq / (double)Dx);
-    else if (create_x) st[kStG2x] = 0.f;
-    st[kStState] = (has_x || create_x) ? 2.f : 1.f;
-    st[kStDelta] = delta0 + ((dshow - dclick) * A.nonclk_coeff + dclick * A.click_coeff);
-    st[kStUnseen] = 0.f;
+    const float g2w1 = (float)((double)g2w + sqw);
+    const float g2x1 = has_x ? (float)((double)g2x + sq / (double)Dx) : (create_x ? 0.f : g2x);
+    const float state1 = (has_x || create_x) ? 2.f : 1.f;
+    const float delta1 = delta0 + ((dshow - dclick) * A.nonclk_coeff + dclick * A.click_coeff);
+    if constexpr (STATV) {
+      *reinterpret_cast<float4*>(r + L.embed_off) = make_float4(ew, show1, click1, g2w1);
+      *reinterpret_cast<float4*>(r + L.embed_off + 4) = make_float4(g2x1, state1, delta1, 0.f);
+    } else {
+      r[L.embed_off] = ew;
+      st[kStShow] = show1;
+      st[kStClick] = click1;
+      st[kStG2w] = g2w1;
+      if (has_x || create_x) st[kStG2x] = g2x1;
+      st[kStState] = state1;
+      st[kStDelta] = delta1;
+      st[kStUnseen] = 0.f;
+    }
   }
 }
 
@@ -464,13 +482,21 @@ extern "C" int rec_ps_push_rows(int64_t n_max, int32_t num_slots, const rec_ps_l
 #undef REC_PS_NARROW
     return check_launch("rec_ps_push_rows (narrow)");
   }
+  static const bool statv_env = [] { const char* v = getenv("REC_PS_WHOLE_RECORD"); return !(v && *v == '0'); }();
+  const bool statv = statv_env && layout->embed_off % 4 == 0 && layout->stat_off == layout->embed_off + 1 &&
+                     layout->row_stride % 4 == 0 && ((uintptr_t)rec) % 16 == 0;
 #define REC_PS_CASE(V, L_)                                                                             \
   if (lanes == L_) {                                                                                   \
     const int64_t grid = (n_max * L_ + kBlock - 1) / kBlock;                                           \
     REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");                                      \
-    hipLaunchKernelGGL((ps_push_rows_kernel<V, L_>), dim3((unsigned)grid), dim3(kBlock), 0, st,        \
-                       *layout, num_slots, n_uniq, uniq_rows, seg_offset, sorted_pos, gx, gw, show,    \
-                       click, rec, *accessor);                                                         \
+    if (statv)                                                                                         \
+      hipLaunchKernelGGL((ps_push_rows_kernel<V, L_, true>), dim3((unsigned)grid), dim3(kBlock), 0, st, \
+                         *layout, num_slots, n_uniq, uniq_rows, seg_offset, sorted_pos, gx, gw, show,  \
+                         click, rec, *accessor);                                                       \
+    else                                                                                               \
+      hipLaunchKernelGGL((ps_push_rows_kernel<V, L_>), dim3((unsigned)grid), dim3(kBlock), 0, st,      \
+                         *layout, num_slots, n_uniq, uniq_rows, seg_offset, sorted_pos, gx, gw, show,  \
+                         click, rec, *accessor);                                                       \
     return check_launch("rec_ps_push_rows");                                                           \
   }
   if (vec) {
