@@ -604,12 +604,17 @@ __global__ __launch_bounds__(kBlock) void sparse_adam_record_kernel(
     }
   }
   if (lg == 0) {   // first-order weight + its moments: rec[D], rec[D+1], rec[D+2]
-    float p1 = r[D], m1 = r[D + 1], v1 = r[D + 2];
+    // (VEC 4: D and the stride are multiples of 4 — the three floats and the pad float behind them are ONE aligned
+    // float4: one load and one store instead of three of each)
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (VEC == 4) vload<4>(q, r + D);
+    else { q[0] = r[D]; q[1] = r[D + 1]; q[2] = r[D + 2]; }
     float g1[1] = {0.f};
     segment_sum<1>(g1, beg, end, spos, grad1, gl1, 1, 0);
     const float g = grad_scale ? scale_grad(g1[0], sc) : g1[0];
-    adam_elem(p1, m1, v1, g, lr_t, eps_t, b1, b2);
-    r[D] = p1; r[D + 1] = m1; r[D + 2] = v1;
+    adam_elem(q[0], q[1], q[2], g, lr_t, eps_t, b1, b2);
+    if constexpr (VEC == 4) vstore<4>(r + D, q);
+    else { r[D] = q[0]; r[D + 1] = q[1]; r[D + 2] = q[2]; }
   }
 }
 
