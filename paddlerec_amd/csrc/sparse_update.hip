@@ -764,13 +764,17 @@ __device__ __forceinline__ void sparse_small_body(
   // logical index t of the list this lookup is compared with -> position in the id list
   const int ts = by_slot ? S : 1, t0 = by_slot ? pos % S : 0;
   const int tpos = by_slot ? pos / S : pos, tn = by_slot ? n / S : n;
-  // an earlier occurrence owns the row (four 64-id chunks per trip: the LDS reads of a trip are in flight together)
-  for (int c0 = 0; c0 < tpos; c0 += 4 * kWave) {
+  // an earlier occurrence owns the row (four 64-id chunks per trip: the LDS reads of a trip are in flight together).
+  // Searched from the NEAREST earlier lookups backwards: only existence matters, and where duplicates come in runs (DIN's
+  // target-seq tables: one row repeated over a sample's whole history) the first trip already finds one — searched from
+  // position 0 the lookups of the last sample walked the whole list first.
+  for (int c1 = tpos; c1 > 0; c1 -= 4 * kWave) {
+    const int c0 = c1 - 4 * kWave;
     bool hit = false;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = c0 + u * kWave + lane;
-      hit |= j < tpos && small_ids[t0 + j * ts] == my;
+      hit |= j >= 0 && j < tpos && small_ids[t0 + (j >= 0 ? j : 0) * ts] == my;
     }
     if (__ballot(hit) != 0) return;
   }
