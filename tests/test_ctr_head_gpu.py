@@ -64,6 +64,26 @@ def test_ctr_head_against_float64_and_the_separate_calls(ops, B, n, with_fm, cli
     assert torch.equal(dw, dw3) and torch.equal(loss, loss3) and torch.equal(dx, dx3) and torch.equal(db, db3)
 
 
+def test_ctr_head_on_strided_rows(ops):
+    """act and dx as column slices of wider buffers (row strides larger than n): the kernel addresses rows by their stride."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B, n = 1000, 400
+    wide = torch.relu(torch.randn(B, 416, device=DEV, generator=g))
+    act = wide[:, :n]
+    w = torch.randn(n, 1, device=DEV, generator=g) / 20
+    b = torch.zeros(1, device=DEV)
+    label = (torch.rand(B, 1, device=DEV, generator=g) < 0.3).to(torch.int64)
+    ws = ops.Workspace(DEV)
+    dw, db = torch.empty(n, 1, device=DEV), torch.empty(1, device=DEV)
+    dxw = torch.full((B, 432), 7.0, device=DEV)
+    out = (torch.empty(B, 1, device=DEV), torch.empty(B, 1, device=DEV), torch.empty(1, device=DEV), dxw[:, :n])
+    pred, dz, loss, dx = ops.ctr_head(act, w, b, None, None, label, ws, dw, db, out=out)
+    dw2, db2 = torch.empty(n, 1, device=DEV), torch.empty(1, device=DEV)
+    pred2, dz2, loss2, dx2 = ops.ctr_head(act.contiguous(), w, b, None, None, label, ws, dw2, db2)
+    assert torch.equal(pred, pred2) and torch.equal(dz, dz2) and torch.equal(loss, loss2) and torch.equal(dw, dw2)
+    assert torch.equal(dx, dx2) and bool((dxw[:, n:] == 7.0).all())          # nothing written behind column n
+
+
 def test_ctr_head_argument_errors(ops):
     act = torch.zeros(8, 400, device=DEV)
     w, b = torch.zeros(400, 1, device=DEV), torch.zeros(1, device=DEV)

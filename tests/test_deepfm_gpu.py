@@ -799,3 +799,33 @@ def test_padded_layer0_input_equals_the_dense_layout(engine_lib, monkeypatch, D,
     np.testing.assert_allclose(ea, eb, rtol=0, atol=5e-6)
     for k in sa:
         assert_adam_weights_close(sa[k], sb[k], lr, steps, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_planned_step_on_the_padded_layout_equals_its_eager_step(engine_lib, monkeypatch):
+    """The recorded call list on the padded layer-0 layout (D 10: 390 -> 400 columns; persistent zero-padded feat buffer,
+    weight copy and gradient copy-back are C-ABI calls like the rest): bit-identical to the eager step over six steps."""
+    from paddlerec_amd.deepfm import DeepFMLayer
+    N, D, B = 5000, 10, 512
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("REC_STEP_PLAN", mode)
+        torch.manual_seed(3)
+        m = DeepFMLayer(N, D, 13, 26, [64, 32], device=DEV)
+        assert m.padded and m.ld0 == 400
+        g = torch.Generator(device=DEV).manual_seed(11)
+        outs = []
+        for step in range(6):
+            ids = torch.randint(0, N, (B, 26), device=DEV, generator=g)
+            dense = torch.rand(B, 13, device=DEV, generator=g)
+            label = (torch.rand(B, 1, device=DEV, generator=g) < 0.3).to(torch.int64)
+            loss, pred = m.train_step(ids, dense, label, lr=1e-2 * (1 + step))
+            outs.append((loss.cpu().numpy().copy(), pred.cpu().numpy().copy()))
+        runs[mode] = (outs, m.fm.rec.cpu().numpy(), m.sparse_state["mv"].cpu().numpy(), m.dense.data.cpu().numpy(),
+                      m.dense.m.cpu().numpy(), len(m._plans))
+    a, b = runs["1"], runs["0"]
+    assert a[-1] == 1 and b[-1] == 0
+    for (la, pa), (lb, pb) in zip(a[0], b[0]):
+        assert np.array_equal(la, lb) and np.array_equal(pa, pb)
+    for x, y in zip(a[1:5], b[1:5]):
+        assert np.array_equal(x, y)
