@@ -243,10 +243,12 @@ class DINLayer:
             self.attention_w, self.attention_b, sv["attw"], dpooled, saved=bufs.att_saved)
         self._last = dict(dh=dh, dq=dq, de0=de0, dz=dz, dense=g)
         # ---- SGD (dygraph_model.py:64-73).  Embedding tables: merged rows; dense: in place.
-        jobs = [(hist_item_seq, dh, p["hist_item_emb_attr.weight"], E),
-                (hist_cat_seq, dh[:, :, Ei:], p["hist_cat_emb_attr.weight"], E),
-                (target_item_seq, dq, p["target_item_seq_emb_attr.weight"], E),
+        # (the target-seq tables first: one row per sample collects the gradients of all its history positions — the longest
+        # serial chains of the one-launch merge; their blocks should be the first to start, not the last)
+        jobs = [(target_item_seq, dq, p["target_item_seq_emb_attr.weight"], E),
                 (target_cat_seq, dq[:, :, Ei:], p["target_cat_seq_emb_attr.weight"], E),
+                (hist_item_seq, dh, p["hist_item_emb_attr.weight"], E),
+                (hist_cat_seq, dh[:, :, Ei:], p["hist_cat_emb_attr.weight"], E),
                 (sv["ti"], de0[:, E:], p["target_item_emb_attr.weight"], 2 * E),
                 (sv["tc"], de0[:, E + Ei:], p["target_cat_emb_attr.weight"], 2 * E),
                 (sv["ti"], dz, p["item_b_attr.weight"], 1)]
