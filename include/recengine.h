@@ -463,7 +463,10 @@ int rec_sparse_adam_record_small(int64_t n, int32_t num_slots, int32_t emb_dim, 
                                  const int64_t* ids, const int64_t* slot_offset, const float* grad,
                                  const rec_grad_layout* grad_layout, const float* grad1,
                                  const rec_grad_layout* grad1_layout, const float* grad_scale, float* rec, float* MV,
-                                 const rec_adam_hyper* hyper, int32_t* status, void* stream);
+                                 const rec_adam_hyper* hyper, int32_t* status, int32_t* scratch, void* stream);
+/* scratch: one device int32 of the caller's (may be NULL).  With it ONE block decides for the whole launch whether every
+ * id stays inside its slot's span of rows (then a lookup is only compared with the lookups of its own slot); without it
+ * every block of the launch reads the whole id list to take that decision itself. */
 
 /* lazy_mode=False Adam on a SelectedRows gradient — the dygraph default (deepfm/dygraph_model.py:61-65,
  * SURVEY.md App. B-3): every one of the num_rows rows is updated, rows absent from the merged gradient with

@@ -203,7 +203,7 @@ SIGNATURES = {
     "rec_sparse_sgd_small": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, C.POINTER(GradLayout), _P, _F, _P, _P]),
     "rec_sparse_sgd_small_multi": (C.c_int, [_I32, C.POINTER(SmallSgdJob), _F, _P, _P]),
     "rec_sparse_adam_record_small": (C.c_int, [_I64, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _P, _P, _P, C.POINTER(GradLayout),
-                                               _P, C.POINTER(GradLayout), _P, _P, _P, C.POINTER(AdamHyper), _P, _P]),
+                                               _P, C.POINTER(GradLayout), _P, _P, _P, C.POINTER(AdamHyper), _P, _P, _P]),
     "rec_bce_with_logits": (C.c_int, [_I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "rec_moe_bwd_prep": (C.c_int, [_I64, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _I32, _I32,
                                    _P, _I32, _P]),

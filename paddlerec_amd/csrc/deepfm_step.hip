@@ -79,6 +79,7 @@ int shape_of(const rec_deepfm_net* net, int64_t B, Shape* s) {
 struct Buffers {
   float *y1, *y2, *feat, *sum_emb, *act[REC_DEEPFM_MAX_LINEAR], *y_dnn, *dz, *g[2], *row_grad, *dm;
   float *pp, *pp1, *dw0p;
+  int32_t* small_scratch;
   int32_t *sorted_pos, *seg_offset, *n_uniq;
   int64_t* uniq_rows;
   void* ws;              // scratch of the individual calls (one at a time: a single region, the largest need)
@@ -149,6 +150,7 @@ int carve(const rec_deepfm_net* net, const Shape& s, int64_t B, void* workspace,
   bf->row_grad = c.take<float>(n * s.D);
   bf->dm = c.take<float>((size_t)(s.Dn > 0 ? s.Dn : 1) * net->widths[0]);
   bf->dw0p = s.pad ? c.take<float>((size_t)s.in0 * net->widths[0]) : nullptr;
+  bf->small_scratch = c.take<int32_t>(1);
   bf->pp = bf->pp1 = nullptr;
   bf->sorted_pos = bf->seg_offset = bf->n_uniq = nullptr;
   bf->uniq_rows = nullptr;
@@ -344,7 +346,7 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   if (s.small) {
     REC_TRY(rec_sparse_adam_record_small(nlook, S, D, net->rec_stride, net->mv_stride, net->v_offset, net->table_rows,
                                          net->padding_idx, ids, net->slot_offset, bf.row_grad, &gl, bf.dz, &gl1,
-                                         nullptr, net->rec, net->mv, hyper, status, stream));
+                                         nullptr, net->rec, net->mv, hyper, status, bf.small_scratch, stream));
   } else {
     if (overlap) REC_TRY(order(1, stream, sst));
     REC_TRY(rec_segment_partials(nlook, D, bf.n_uniq, bf.seg_offset, bf.sorted_pos, bf.row_grad, &gl, bf.pp, sst));

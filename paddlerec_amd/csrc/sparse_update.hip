@@ -733,37 +733,73 @@ template <int NACC, class Update>   // floats per lane: D <= 64 * NACC
 __device__ __forceinline__ void sparse_small_body(
     int blk, int n, int D, int S, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
     const int64_t* __restrict__ slot_off, const float* __restrict__ grad, rec_grad_layout gl, Update up,
-    int32_t* __restrict__ status) {
+    int32_t* __restrict__ status, const int32_t* __restrict__ span_flag = nullptr) {
   constexpr bool kRecord = std::is_same<Update, SmallAdamRecord>::value;
   constexpr int FLY = kSmallList / NACC;   // gradient rows in flight per wave (32 / 16 / 8 rows of 64 / 128 / 256 floats)
   extern __shared__ int small_lds[];
   int* wlists = small_lds;                               // [waves][kSmallList] positions of collected occurrences
   int* small_ids = small_lds + kSmallWaves * kSmallList; // [n] rows as int32, -1 = padding / out of range (never matches)
+  const int lane = threadIdx.x % kWave;
+  const bool slots = slot_off != nullptr && S > 1 && n % S == 0;
   int oob = 0, viol = 0;
-  for (int i = threadIdx.x; i < n; i += kSmallWaves * kWave) {
-    const int64_t id = ids[i];
-    const bool isp = pad >= 0 && id == pad;
-    const int s = slot_off ? i % S : 0;
-    const int64_t r = slot_off ? id + slot_off[s] : id;     // 26 tables as one: row = id + slot offset
-    const bool inr = r >= 0 && r < N;
-    oob |= (!isp && !inr) ? 1 : 0;
-    // slots whose ids stay inside their own span of rows cannot share a row with another slot
-    if (slot_off && (id < 0 || (s + 1 < S && id >= slot_off[s + 1] - slot_off[s]))) viol = 1;
-    small_ids[i] = (!isp && inr) ? (int)r : -1;
+  bool by_slot = false;
+  int pos = blk * kSmallWaves + threadIdx.x / kWave;       // the lookup of this wave (re-mapped below in slot mode)
+  int ts = 1, t0 = 0, tpos = pos, tn = n;                  // logical index in the compared list -> position t0 + j * ts
+  if (slots) {
+    // Slots whose ids stay inside their own span of rows cannot share a row with another slot: a lookup is then compared
+    // with the lookups of ITS slot only (n / S of them: 512 instead of 13312 at the reference's batch size).  Every
+    // block takes the decision on ALL ids — a plain scan, nothing staged: with the whole list staged per block the launch
+    // cost grew with n^2 (48 us at 512 x 26 lookups, 40 of them staging) — and stages only the ids of the ONE slot its 16
+    // waves belong to (blocks are dealt slot by slot).
+    if (span_flag) {        // small_span_check_kernel looked at every id once for the whole launch
+      by_slot = span_flag[0] == 0;
+    } else {
+      int sl = (int)(threadIdx.x % S);
+      const int step = (kSmallWaves * kWave) % S;
+      for (int i = threadIdx.x; i < n; i += kSmallWaves * kWave) {
+        const int64_t id = ids[i];
+        const bool isp = pad >= 0 && id == pad;
+        const int64_t r = id + slot_off[sl];
+        oob |= (!isp && !(r >= 0 && r < N)) ? 1 : 0;
+        if (id < 0 || (sl + 1 < S && id >= slot_off[sl + 1] - slot_off[sl])) viol = 1;
+        sl += step;
+        if (sl >= S) sl -= S;
+      }
+      by_slot = __syncthreads_or(viol) == 0;
+    }
+  }
+  if (by_slot) {
+    tn = n / S;
+    const int bps = (tn + kSmallWaves - 1) / kSmallWaves;   // blocks per slot
+    t0 = blk / bps;                                         // this block's slot
+    ts = S;
+    tpos = (blk % bps) * kSmallWaves + threadIdx.x / kWave;
+    pos = t0 + tpos * ts;
+    if (t0 >= S) return;                                    // (grid = max of the two mappings)
+    const int64_t off = slot_off[t0];
+    for (int j = threadIdx.x; j < tn; j += kSmallWaves * kWave) {
+      const int64_t id = ids[(int64_t)j * S + t0];
+      const int64_t r = id + off;
+      const bool isp = pad >= 0 && id == pad, inr = r >= 0 && r < N;
+      if (span_flag) oob |= (!isp && !inr) ? 1 : 0;       // (every slot's ids pass through its blocks' staging)
+      small_ids[j] = (!isp && inr) ? (int)r : -1;
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += kSmallWaves * kWave) {
+      const int64_t id = ids[i];
+      const bool isp = pad >= 0 && id == pad;
+      const int64_t r = slot_off ? id + slot_off[i % S] : id;     // 26 tables as one: row = id + slot offset
+      const bool inr = r >= 0 && r < N;
+      if (!slots || span_flag) oob |= (!isp && !inr) ? 1 : 0;
+      small_ids[i] = (!isp && inr) ? (int)r : -1;
+    }
+    if (blk >= (n + kSmallWaves - 1) / kSmallWaves) pos = n;   // a block of the slot mapping only: nothing to do
   }
   if (oob) atomicOr(status, REC_FLAG_INDEX_OOB);
-  // every block stages ALL ids, so every block takes the same decision: when no id leaves its slot's span, a lookup is
-  // compared with the lookups of ITS slot only (n / S of them: 512 instead of 13312 at the reference's batch size)
-  const bool by_slot = slot_off != nullptr && S > 1 && n % S == 0 && __syncthreads_or(viol) == 0;
-  if (!(slot_off != nullptr && S > 1 && n % S == 0)) __syncthreads();
-  const int lane = threadIdx.x % kWave;
-  const int pos = blk * kSmallWaves + threadIdx.x / kWave;
-  if (pos >= n) return;
-  const int my = small_ids[pos];
+  __syncthreads();
+  if (tpos >= tn || pos >= n) return;
+  const int my = small_ids[tpos];
   if (my < 0) return;
-  // logical index t of the list this lookup is compared with -> position in the id list
-  const int ts = by_slot ? S : 1, t0 = by_slot ? pos % S : 0;
-  const int tpos = by_slot ? pos / S : pos, tn = by_slot ? n / S : n;
   // an earlier occurrence owns the row (four 64-id chunks per trip: the LDS reads of a trip are in flight together).
   // Searched from the NEAREST earlier lookups backwards: only existence matters, and where duplicates come in runs (DIN's
   // target-seq tables: one row repeated over a sample's whole history) the first trip already finds one — searched from
@@ -774,7 +810,7 @@ __device__ __forceinline__ void sparse_small_body(
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = c0 + u * kWave + lane;
-      hit |= j >= 0 && j < tpos && small_ids[t0 + (j >= 0 ? j : 0) * ts] == my;
+      hit |= j >= 0 && j < tpos && small_ids[j >= 0 ? j : 0] == my;
     }
     if (__ballot(hit) != 0) return;
   }
@@ -826,7 +862,7 @@ __device__ __forceinline__ void sparse_small_body(
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = c0 + u * kWave + lane;
-      mk[u] = j >= tpos && j < tn && small_ids[t0 + (j < tn ? j : 0) * ts] == my;
+      mk[u] = j >= tpos && j < tn && small_ids[j < tn ? j : 0] == my;
     }
     if (__ballot(mk[0] || mk[1] || mk[2] || mk[3]) == 0) continue;
 #pragma unroll
@@ -880,8 +916,27 @@ template <int NACC, class Update>
 __global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_kernel(
     int n, int D, int S, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
     const int64_t* __restrict__ slot_off, const float* __restrict__ grad, rec_grad_layout gl, Update up,
-    int32_t* __restrict__ status) {
-  sparse_small_body<NACC, Update>(blockIdx.x, n, D, S, N, pad, ids, slot_off, grad, gl, up, status);
+    int32_t* __restrict__ status, const int32_t* __restrict__ span_flag) {
+  sparse_small_body<NACC, Update>(blockIdx.x, n, D, S, N, pad, ids, slot_off, grad, gl, up, status, span_flag);
+}
+
+// flag[0] = 1 when some id leaves its slot's span of rows (id < 0 or id >= slot_off[s + 1] - slot_off[s]): ONE block looks
+// at every id once, instead of every block of the merge launch doing so (832 blocks x 13312 ids at the reference's batch
+// size: 40 of the launch's 48 us).
+__global__ __launch_bounds__(kSmallWaves* kWave) void small_span_check_kernel(int n, int S, const int64_t* __restrict__ ids,
+                                                                             const int64_t* __restrict__ slot_off,
+                                                                             int32_t* __restrict__ flag) {
+  int viol = 0;
+  int sl = (int)(threadIdx.x % S);
+  const int step = (kSmallWaves * kWave) % S;
+  for (int i = threadIdx.x; i < n; i += kSmallWaves * kWave) {
+    const int64_t id = ids[i];
+    if (id < 0 || (sl + 1 < S && id >= slot_off[sl + 1] - slot_off[sl])) viol = 1;
+    sl += step;
+    if (sl >= S) sl -= S;
+  }
+  viol = __syncthreads_or(viol);
+  if (threadIdx.x == 0) flag[0] = viol ? 1 : 0;
 }
 
 // Several tables in ONE launch: DIN updates seven embedding tables per step (din/dygraph_model.py:64-73), independent of
@@ -1441,7 +1496,8 @@ extern "C" int rec_sparse_sgd_small(int64_t n, int32_t emb_dim, int32_t row_stri
   const SmallSgd up{P, row_stride, lr};
 #define REC_SMALL(NACC_)                                                                                        \
   hipLaunchKernelGGL((sparse_small_kernel<NACC_, SmallSgd>), dim3(grid), dim3(kSmallWaves * kWave), shmem, st,   \
-                     (int)n, emb_dim, 1, num_rows, padding_idx, ids, (const int64_t*)nullptr, grad, gl, up, status)
+                     (int)n, emb_dim, 1, num_rows, padding_idx, ids, (const int64_t*)nullptr, grad, gl, up, status,   \
+                     (const int32_t*)nullptr)
   if (emb_dim <= kWave) REC_SMALL(1); else if (emb_dim <= 2 * kWave) REC_SMALL(2); else REC_SMALL(4);
 #undef REC_SMALL
   return check_launch("rec_sparse_sgd_small");
@@ -1490,7 +1546,7 @@ extern "C" int rec_sparse_adam_record_small(int64_t n, int32_t num_slots, int32_
                                             const float* grad, const rec_grad_layout* grad_layout,
                                             const float* grad1, const rec_grad_layout* grad1_layout,
                                             const float* grad_scale, float* rec, float* MV,
-                                            const rec_adam_hyper* hyper, int32_t* status, void* stream) {
+                                            const rec_adam_hyper* hyper, int32_t* status, int32_t* scratch, void* stream) {
   rec_grad_layout gl = {1, 0, 0, nullptr, nullptr}, gl1 = {1, 0, 0, nullptr, nullptr};
   if (grad_layout) gl = *grad_layout;
   if (grad1_layout) gl1 = *grad1_layout;
@@ -1513,12 +1569,23 @@ extern "C" int rec_sparse_adam_record_small(int64_t n, int32_t num_slots, int32_
   adam_scalars(hyper, &up.lr_t, &up.eps_t);
   up.b1 = hyper->beta1; up.b2 = hyper->beta2;
   if (gl.group <= 0) { gl.group = 1; gl.group_stride = emb_dim; }   // one D-wide row per position
-  const unsigned grid = (unsigned)((n + kSmallWaves - 1) / kSmallWaves);
+  unsigned grid = (unsigned)((n + kSmallWaves - 1) / kSmallWaves);
+  if (slot_offset && num_slots > 1 && n % num_slots == 0) {        // slot-major block mapping (sparse_small_body)
+    const unsigned g2 = (unsigned)(num_slots * ((n / num_slots + kSmallWaves - 1) / kSmallWaves));
+    if (g2 > grid) grid = g2;
+  }
   const size_t shmem = ((size_t)n + kSmallWaves * kSmallList) * sizeof(int);
   hipStream_t st = (hipStream_t)stream;
+  int32_t* span_flag = nullptr;
+  if (scratch && slot_offset && num_slots > 1 && n % num_slots == 0 && n > 2048) {    // (small lists: the scan is cheap)
+    span_flag = scratch;
+    hipLaunchKernelGGL(small_span_check_kernel, dim3(1), dim3(kSmallWaves * kWave), 0, st, (int)n, num_slots, ids,
+                       slot_offset, span_flag);
+  }
 #define REC_SMALL(NACC_)                                                                                           \
   hipLaunchKernelGGL((sparse_small_kernel<NACC_, SmallAdamRecord>), dim3(grid), dim3(kSmallWaves * kWave), shmem,   \
-                     st, (int)n, emb_dim, num_slots, num_rows, padding_idx, ids, slot_offset, grad, gl, up, status)
+                     st, (int)n, emb_dim, num_slots, num_rows, padding_idx, ids, slot_offset, grad, gl, up, status,    \
+                     (const int32_t*)span_flag)
   if (emb_dim <= kWave) REC_SMALL(1); else if (emb_dim <= 2 * kWave) REC_SMALL(2); else REC_SMALL(4);
 #undef REC_SMALL
   return check_launch("rec_sparse_adam_record_small");

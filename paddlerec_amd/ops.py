@@ -1061,6 +1061,9 @@ def sparse_sgd_small_multi(jobs, lr, status):
     return status
 
 
+_SMALL_SCRATCH = {}
+
+
 def sparse_adam_record_small(ids, slot_offset, padding_idx, grad, grad1, grad1_div, rec, mv, D, step, lr=1e-3,
                              beta1=0.9, beta2=0.999, eps=1e-8, v_offset=None, grad_scale=None, status=None):
     """sparse_adam_record with the SelectedRows merge done inside the launch (ids.numel() <= SMALL_MERGE_MAX): ids
@@ -1074,11 +1077,15 @@ def sparse_adam_record_small(ids, slot_offset, padding_idx, grad, grad1, grad1_d
     if status is None:
         status = new_status(ids.device)
     h = _hyper(lr, beta1, beta2, eps, step)
+    scratch = _SMALL_SCRATCH.get(ids.device)
+    if scratch is None:         # one int per device: the launch's "every id stays in its slot's span" decision
+        scratch = _SMALL_SCRATCH[ids.device] = torch.zeros(1, dtype=torch.int32, device=ids.device)
     check(lib().rec_sparse_adam_record_small(ids.numel(), S, int(D), rec.stride(0), mv.stride(0), int(v_offset),
                                              rec.shape[0], -1 if padding_idx is None else int(padding_idx), _p(ids),
                                              _p(slot_offset), _p(grad), C.byref(_gl(1, 0, 0)), _p(grad1),
                                              C.byref(_gl(grad1_div, 0, 0)), _p(grad_scale), _p(rec), _p(mv),
-                                             C.byref(h), _p(status), _stream()), "rec_sparse_adam_record_small")
+                                             C.byref(h), _p(status), _p(scratch), _stream()),
+          "rec_sparse_adam_record_small")
     return status
 
 
