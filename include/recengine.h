@@ -112,6 +112,16 @@ int rec_deepfm_fm_bwd_sorted(const rec_deepfm_desc* desc, const float* dense, co
  * are written). */
 int rec_dense_fold_fwd(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out,
                        const float* dense_w, const float* W0, float* M, void* stream);
+/* The same folds with the row copies around them, ONE launch each way (what a training step issues):
+ *   fwd_full: W0_folded [(S+1)*D, n_out]: rows [0, S*D) = W0's, rows S*D + j = M[j,:] (the rest stays as the caller
+ *             left it: zero);
+ *   bwd_full: dW0_folded = feat'^T dZ0 [(S+1)*D, n_out] (a scratch of the caller's, NOT the gradient buffer): its sparse
+ *             rows are copied into dW0, its rows S*D.. are dM -> the dense rows of dW0 and d_dense_w as above. */
+int rec_dense_fold_fwd_full(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out, const float* dense_w,
+                            const float* W0, float* W0_folded, void* stream);
+int rec_dense_fold_bwd_full(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out, const float* dense_w,
+                            const float* W0, const float* dW0_folded, float* dW0, float* d_dense_w,
+                            int32_t accumulate_ddw, void* stream);
 int rec_dense_fold_bwd(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out,
                        const float* dense_w, const float* W0, const float* dM, float* dW0,
                        float* d_dense_w, int32_t accumulate_ddw, void* stream);
@@ -992,7 +1002,11 @@ typedef struct {
                                   the dense fold (dense_dim > dim): the step keeps feat at this sample stride
                                   (rec_deepfm_desc.feat_stride) and runs layer 0 on w0_folded [layer0_width, widths[0]],
                                   a zero-initialised buffer of the caller's whose leading rows it refreshes from w[0]
-                                  every step — 39 fields x D 10 = 390 columns become 400, whole GEMM tiles */
+                                  every step — 39 fields x D 10 = 390 columns become 400, whole GEMM tiles.
+                                  w0_folded == w[0] says the caller keeps layer0_width rows behind BOTH w[0] and gw[0]
+                                  (the extra rows zero, inside the flat buffers): the step then copies nothing and
+                                  writes dW_0 [layer0_width, widths[0]] straight into gw[0] (its extra rows come out
+                                  exactly zero, so they stay zero under rec_adam_dense) */
 } rec_deepfm_net;
 int rec_deepfm_train_step_workspace_bytes(const rec_deepfm_net* net, int64_t batch, size_t* bytes);
 /* ids [batch, num_slots] i64, dense [batch, dense_dim] f32, label [batch] i64 -> loss_out [1], pred_out [batch];

@@ -139,6 +139,8 @@ SIGNATURES = {
     "rec_deepfm_fm_bwd_sorted": (C.c_int, [C.POINTER(DeepFMDesc)] + [_P] * 12 + [_SZ, _P]),
     "rec_dense_fold_fwd": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "rec_dense_fold_bwd": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P]),
+    "rec_dense_fold_fwd_full": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "rec_dense_fold_bwd_full": (C.c_int, [_I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "rec_emb_gather": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, _P, _I32, _I64, _P, _P]),
     "rec_emb_gather_sumpool": (C.c_int, [_I64, _I32, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "rec_emb_sumpool_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _P]),

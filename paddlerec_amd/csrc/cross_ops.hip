@@ -241,7 +241,96 @@ __global__ __launch_bounds__(kBlock) void dense_fold_bwd_dw_kernel(int S, int D,
   }
   if (threadIdx.x == 0) ddw[jd] = (accumulate ? ddw[jd] : 0.f) + red[0];
 }
+// The whole fold of a step in ONE launch each way (the copy of the sparse rows was a hipMemcpyAsync of its own and the
+// backward two kernels behind a copy: five launches on the critical path of a step that is ~30 launches long at the
+// reference's batch size).  Block roles by index range; every element is computed exactly as by the kernels above.
+//   fwd:  W0f[r, :] = W0[r, :] for r < S*D;   W0f[S*D + j, :] = M[j, :]
+__global__ __launch_bounds__(kBlock) void dense_fold_fwd_full_kernel(int S, int Dn, int D, int NO, int copy_blocks,
+                                                                     const float* __restrict__ dw,
+                                                                     const float* __restrict__ W0,
+                                                                     float* __restrict__ W0f) {
+  if ((int)blockIdx.x < copy_blocks) {
+    const int64_t total = (int64_t)S * D * NO;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)copy_blocks * kBlock)
+      W0f[e] = W0[e];
+    return;
+  }
+  const int nb = (int)gridDim.x - copy_blocks;
+  float* M = W0f + (int64_t)S * D * NO;
+  for (int e = ((int)blockIdx.x - copy_blocks) * kBlock + threadIdx.x; e < Dn * NO; e += nb * kBlock) {
+    const int j = e / NO, n = e % NO;
+    float t = 0.f;
+    for (int d = 0; d < D; ++d) t += dw[j * D + d] * W0[(int64_t)((S + j) * D + d) * NO + n];
+    M[e] = t;
+  }
+}
+//   bwd:  dW0f [(S+1)*D, NO] = feat'^T dZ0 (its rows S*D.. hold dM):
+//         dW0[r, :] = dW0f[r, :] for r < S*D;   dW0[S*D + jd, n] = dw[jd] * dM[jd / D, n];
+//         d_dense_w[jd] (+)= sum_n dM[jd / D, n] * W0[S*D + jd, n]
+__global__ __launch_bounds__(kBlock) void dense_fold_bwd_full_kernel(int S, int Dn, int D, int NO, int copy_blocks,
+                                                                     int w_blocks, const float* __restrict__ dw,
+                                                                     const float* __restrict__ W0,
+                                                                     const float* __restrict__ dW0f,
+                                                                     float* __restrict__ dW0, float* __restrict__ ddw,
+                                                                     int accumulate) {
+  const float* dM = dW0f + (int64_t)S * D * NO;
+  int b = (int)blockIdx.x;
+  if (b < copy_blocks) {
+    const int64_t total = (int64_t)S * D * NO;
+    for (int64_t e = (int64_t)b * kBlock + threadIdx.x; e < total; e += (int64_t)copy_blocks * kBlock) dW0[e] = dW0f[e];
+    return;
+  }
+  b -= copy_blocks;
+  if (b < w_blocks) {
+    for (int e = b * kBlock + threadIdx.x; e < Dn * D * NO; e += w_blocks * kBlock) {
+      const int n = e % NO, jd = e / NO, j = jd / D;
+      dW0[(int64_t)(S * D + jd) * NO + n] = dw[jd] * dM[j * NO + n];
+    }
+    return;
+  }
+  b -= w_blocks;                                  // one block per (j, d): fixed-order tree, as dense_fold_bwd_dw_kernel
+  __shared__ float red[kBlock];
+  const int jd = b, j = jd / D;
+  float t = 0.f;
+  for (int n = threadIdx.x; n < NO; n += kBlock) t += dM[j * NO + n] * W0[(int64_t)(S * D + jd) * NO + n];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ddw[jd] = (accumulate ? ddw[jd] : 0.f) + red[0];
+}
 }  // namespace rec
+
+extern "C" int rec_dense_fold_fwd_full(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out,
+                                       const float* dense_w, const float* W0, float* W0_folded, void* stream) {
+  REC_REQUIRE(num_slots > 0 && num_dense > 0 && emb_dim > 0 && n_out > 0 && dense_w && W0 && W0_folded, REC_EINVAL,
+              "bad arguments");
+  const int64_t copy_elems = (int64_t)num_slots * emb_dim * n_out;
+  int copy_blocks = (int)((copy_elems + rec::kBlock * 4 - 1) / (rec::kBlock * 4));
+  if (copy_blocks > 512) copy_blocks = 512;
+  const int m_blocks = (num_dense * n_out + rec::kBlock - 1) / rec::kBlock;
+  hipLaunchKernelGGL(rec::dense_fold_fwd_full_kernel, dim3(copy_blocks + m_blocks), dim3(rec::kBlock), 0,
+                     (hipStream_t)stream, num_slots, num_dense, emb_dim, n_out, copy_blocks, dense_w, W0, W0_folded);
+  return rec::check_launch("rec_dense_fold_fwd_full");
+}
+
+extern "C" int rec_dense_fold_bwd_full(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out,
+                                       const float* dense_w, const float* W0, const float* dW0_folded, float* dW0,
+                                       float* d_dense_w, int32_t accumulate_ddw, void* stream) {
+  REC_REQUIRE(num_slots > 0 && num_dense > 0 && emb_dim > 0 && n_out > 0 && dense_w && W0 && dW0_folded && dW0 &&
+                  d_dense_w && dW0_folded != dW0, REC_EINVAL, "bad arguments");
+  const int64_t copy_elems = (int64_t)num_slots * emb_dim * n_out;
+  int copy_blocks = (int)((copy_elems + rec::kBlock * 4 - 1) / (rec::kBlock * 4));
+  if (copy_blocks > 512) copy_blocks = 512;
+  int w_blocks = (num_dense * emb_dim * n_out + rec::kBlock * 2 - 1) / (rec::kBlock * 2);
+  if (w_blocks > 512) w_blocks = 512;
+  hipLaunchKernelGGL(rec::dense_fold_bwd_full_kernel, dim3(copy_blocks + w_blocks + num_dense * emb_dim),
+                     dim3(rec::kBlock), 0, (hipStream_t)stream, num_slots, num_dense, emb_dim, n_out, copy_blocks,
+                     w_blocks, dense_w, W0, dW0_folded, dW0, d_dense_w, accumulate_ddw);
+  return rec::check_launch("rec_dense_fold_bwd_full");
+}
 
 extern "C" int rec_dense_fold_fwd(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out,
                                   const float* dense_w, const float* W0, float* M, void* stream) {

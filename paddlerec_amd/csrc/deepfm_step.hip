@@ -149,7 +149,7 @@ int carve(const rec_deepfm_net* net, const Shape& s, int64_t B, void* workspace,
   bf->g[1] = c.take<float>((size_t)B * s.max_w);
   bf->row_grad = c.take<float>(n * s.D);
   bf->dm = c.take<float>((size_t)(s.Dn > 0 ? s.Dn : 1) * net->widths[0]);
-  bf->dw0p = s.pad ? c.take<float>((size_t)s.in0 * net->widths[0]) : nullptr;
+  bf->dw0p = (s.pad || s.compact) ? c.take<float>((size_t)s.in0 * net->widths[0]) : nullptr;
   bf->small_scratch = c.take<int32_t>(1);
   bf->pp = bf->pp1 = nullptr;
   bf->sorted_pos = bf->seg_offset = bf->n_uniq = nullptr;
@@ -268,13 +268,15 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   // -- layer 0 on folded weights (deepfm.py:_mlp_weights): W0' = [ W0[:S*D] ; M ; 0 ]
   const float* w0 = net->w[0];
   float* gw0 = net->gw[0];
-  if (s.compact) {
-    REC_TRY(rec_copy_async(net->w0_folded, net->w[0], (size_t)S * D * net->widths[0] * f4, stream));
-    REC_TRY(rec_dense_fold_fwd(S, Dn, D, net->widths[0], net->dense_w, net->w[0],
-                               net->w0_folded + (size_t)S * D * net->widths[0], stream));
+  if (s.compact) {  // sparse rows + folded dense rows in one launch; dW_0' lands in scratch (bf.dw0p), not in gw[0]
+    REC_TRY(rec_dense_fold_fwd_full(S, Dn, D, net->widths[0], net->dense_w, net->w[0], net->w0_folded, stream));
     w0 = net->w0_folded;
+    gw0 = bf.dw0p;
   }
-  if (s.pad) {      // layer 0 on the zero-padded copy of its weight (deepfm.py:_mlp_weights, padded)
+  // layer 0 on its weight with zero rows behind it (deepfm.py:_mlp_weights, padded): in place when the caller's
+  // parameter and gradient buffers hold the rows (w0_folded == w[0]), else on a refreshed copy
+  const bool pad_copy = s.pad && net->w0_folded != net->w[0];
+  if (pad_copy) {
     REC_TRY(rec_copy_async(net->w0_folded, net->w[0], (size_t)s.in0_real * net->widths[0] * f4, stream));
     w0 = net->w0_folded;
     gw0 = bf.dw0p;
@@ -362,12 +364,10 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   static const int dw0_split = [] { const char* v = getenv("REC_DW0_SPLIT"); return v && *v ? atoi(v) : 16; }();
   REC_TRY(gemm(s.in0, net->widths[0], (int)B, true, false, REC_EPI_NONE, bf.feat, g0, gw0, nullptr, nullptr, 0,
                net->gb[0], overlap && B >= 16384 ? dw0_split : 0, bf, stream));
-  if (s.compact) {
-    REC_TRY(rec_copy_async(bf.dm, gw0 + (size_t)S * D * net->widths[0], (size_t)Dn * net->widths[0] * f4, stream));
-    REC_TRY(rec_dense_fold_bwd(S, Dn, D, net->widths[0], net->dense_w, net->w[0], bf.dm, gw0, net->g_dense_w, 1,
-                               stream));
-  }
-  if (s.pad) REC_TRY(rec_copy_async(net->gw[0], gw0, (size_t)s.in0_real * net->widths[0] * f4, stream));
+  if (s.compact)
+    REC_TRY(rec_dense_fold_bwd_full(S, Dn, D, net->widths[0], net->dense_w, net->w[0], gw0, net->gw[0],
+                                    net->g_dense_w, 1, stream));
+  if (pad_copy) REC_TRY(rec_copy_async(net->gw[0], gw0, (size_t)s.in0_real * net->widths[0] * f4, stream));
   // -- Adam on every dense parameter (one pass over the flat buffer)
   REC_TRY(rec_adam_dense(net->flat_numel, net->flat_param, net->flat_m, net->flat_v, net->flat_grad, nullptr, hyper,
                          stream));

@@ -30,13 +30,15 @@ class _FlatParams:
     checkpoints hold."""
     ALIGN = 64          # floats
 
-    def __init__(self, shapes, device):
+    def __init__(self, shapes, device, reserve=None):
+        """reserve: {name: floats}: room kept behind that tensor (zero like every gap, and it stays zero under the
+        optimizers: zero gradient on a zero parameter) — a zero-padded view of it then needs no copy."""
         self.names = [n for n, _ in shapes]
         self.shapes = dict(shapes)
         self.offsets, o = {}, 0
         for n, s in shapes:
             self.offsets[n] = o
-            o += -(-math.prod(s) // self.ALIGN) * self.ALIGN
+            o += -(-max(math.prod(s), (reserve or {}).get(n, 0)) // self.ALIGN) * self.ALIGN
         self.data = torch.zeros(max(o, 1), dtype=torch.float32, device=device)
         self.grad = torch.zeros_like(self.data)
         self.m = torch.zeros_like(self.data)
@@ -184,7 +186,23 @@ class DeepFMLayer:
                        ("dnn.linear_%d.bias" % i, (sizes[i + 1],))]
         shapes.append(("bias", (1,)))       # created, never used in forward (net.py:36-39; App. B-14)
         shapes += list(extra_dense)
-        self.dense = _FlatParams(shapes, self.device)
+        # Dense "embeddings" x_j * dense_w[j,:] are never materialised (DESIGN.md §3 "compact feat"): feat keeps
+        # the S embedding rows + one row of raw dense values, and layer 0 runs on folded weights
+        #   W0' = [ W0[:S*D] ; M ; 0 ],  M[j,:] = dense_w[j,:] @ W0[(S+j)*D:(S+j+1)*D, :]   (rebuilt every step)
+        self.compact = 0 < Dn <= D
+        self.fp = (sparse_num_field + 1) if self.compact else self.num_field      # fields per sample in feat
+        # Layer-0 width that is no multiple of the GEMM tiles (the reference's own layout: 39 fields x D 9 / 10 = 351 /
+        # 390 columns put all three layer-0 GEMMs on the edge-handling kernels, 0.9 ms instead of 0.6 per step at B 65536):
+        # feat lives in a zero-initialised [B, ld0] buffer (rec_deepfm_desc.feat_stride) and layer 0 runs on the weight
+        # with ld0 - in0 zero rows behind it — whole tiles for forward, dX and dW.  The rows are the gap the flat
+        # buffer keeps behind linear_0.weight (parameter AND gradient: the dW GEMM writes exact zeros there, feat's
+        # padding columns being zero), so neither direction copies anything
+        self.in0 = self.fp * D
+        self.ld0 = self._pad_width(self.in0) if (not self.compact and self.supports_padded_feat
+                                                 and getattr(self.k, "SUPPORTS_FEAT_LD", False)) else self.in0
+        self.padded = self.ld0 != self.in0
+        self.dense = _FlatParams(shapes, self.device,
+                                 reserve={"dnn.linear_0.weight": self.ld0 * sizes[1]} if self.padded else None)
         std = 0.1 / math.sqrt(float(D))
         for n in ("fm.dense_w_one", "fm.dense_w"):                          # net.py:89-103
             torch.nn.init.trunc_normal_(self.dense.p[n], 0.0, std, -2 * std, 2 * std)
@@ -197,25 +215,14 @@ class DeepFMLayer:
         self.mlp_db = [self.dense.g["dnn.linear_%d.bias" % i] for i in range(self.n_linear)]
         # sparse Adam state (lazy rows) + bookkeeping
         self.sparse_state = None
-        # Dense "embeddings" x_j * dense_w[j,:] are never materialised (DESIGN.md §3 "compact feat"): feat keeps
-        # the S embedding rows + one row of raw dense values, and layer 0 runs on folded weights
-        #   W0' = [ W0[:S*D] ; M ; 0 ],  M[j,:] = dense_w[j,:] @ W0[(S+j)*D:(S+j+1)*D, :]   (rebuilt every step)
-        self.compact = 0 < Dn <= D
-        self.fp = (sparse_num_field + 1) if self.compact else self.num_field      # fields per sample in feat
         if self.compact:
             self._w0p = torch.zeros(self.fp * D, sizes[1], dtype=torch.float32, device=self.device)
+            self._dw0f = torch.zeros(self.fp * D, sizes[1], dtype=torch.float32, device=self.device)
             self._dm = torch.zeros(Dn, sizes[1], dtype=torch.float32, device=self.device)
-        # Layer-0 width that is no multiple of the GEMM tiles (the reference's own layout: 39 fields x D 9 / 10 = 351 /
-        # 390 columns put all three layer-0 GEMMs on the edge-handling kernels, 0.9 ms instead of 0.6 per step at B 65536):
-        # feat lives in a zero-initialised [B, ld0] buffer (rec_deepfm_desc.feat_stride), layer 0 runs on a zero-padded
-        # copy of its weight — whole tiles for forward, dX and dW; the padding columns / rows stay exactly zero
-        self.in0 = self.fp * D
-        self.ld0 = self._pad_width(self.in0) if (not self.compact and self.supports_padded_feat
-                                                 and getattr(self.k, "SUPPORTS_FEAT_LD", False)) else self.in0
-        self.padded = self.ld0 != self.in0
         if self.padded:
-            self._w0p = torch.zeros(self.ld0, sizes[1], dtype=torch.float32, device=self.device)
-            self._dw0p = torch.zeros(self.ld0, sizes[1], dtype=torch.float32, device=self.device)
+            o, k = self.dense.offsets["dnn.linear_0.weight"], self.ld0 * sizes[1]
+            self._w0p = self.dense.data[o:o + k].view(self.ld0, sizes[1])
+            self._dw0p = self.dense.grad[o:o + k].view(self.ld0, sizes[1])
             self._fm_bufs = {}
         self.ws = self.k.Workspace(self.device)
         self.ws_group = self.k.Workspace(self.device)
@@ -280,15 +287,22 @@ class DeepFMLayer:
     def _mlp_weights(self):
         """(weights, weight-grad views) of the top MLP as the GEMMs see them this step."""
         if self.padded:
-            self._copy(self._w0p[: self.in0], self.mlp_w[0])
             return [self._w0p] + self.mlp_w[1:], [self._dw0p] + self.mlp_dw[1:]
         if not self.compact:
             return self.mlp_w, self.mlp_dw
         S, D, Dn = self.sparse_num_field, self.sparse_feature_dim, self.dense_feature_dim
         w0 = self.mlp_w[0]
+        if self._fold_full:
+            self.k.dense_fold_fwd_full(S, self.dense.p["fm.dense_w"].view(Dn, D), w0, self._w0p)
+            return [self._w0p] + self.mlp_w[1:], [self._dw0f] + self.mlp_dw[1:]
         self._copy(self._w0p[: S * D], w0[: S * D])
         self.k.dense_fold_fwd(S, self.dense.p["fm.dense_w"].view(Dn, D), w0, self._w0p[S * D: S * D + Dn])
         return [self._w0p] + self.mlp_w[1:], [self.mlp_dw[0][: self.fp * D]] + self.mlp_dw[1:]
+
+    @property
+    def _fold_full(self):
+        """One launch per direction for the dense fold (rec_dense_fold_*_full) where the backend has it."""
+        return hasattr(self.k, "dense_fold_fwd_full") and os.environ.get("REC_FOLD_FULL", "1") != "0"
 
     def _copy(self, dst, src):
         """Parameter-slice copy as a C-ABI call where the backend has one (a recorded step must not hide a torch kernel)."""
@@ -301,12 +315,13 @@ class DeepFMLayer:
     def _fold_backward(self):
         """After dW0' = feat'^T dZ0 landed in the first (S+1)*D rows of the layer-0 gradient buffer: turn its
         dense rows (= dM) into the gradients of the real parameters (W0 dense rows, dense_w MLP part)."""
-        if self.padded:
-            self._copy(self.mlp_dw[0], self._dw0p[: self.in0])
-            return
-        if not self.compact:
+        if self.padded or not self.compact:
             return
         S, D, Dn = self.sparse_num_field, self.sparse_feature_dim, self.dense_feature_dim
+        if self._fold_full:
+            self.k.dense_fold_bwd_full(S, self.dense.p["fm.dense_w"].view(Dn, D), self.mlp_w[0], self._dw0f,
+                                       self.mlp_dw[0], self.dense.g["fm.dense_w"].view(Dn, D), accumulate=True)
+            return
         self._copy(self._dm, self.mlp_dw[0][S * D: S * D + Dn])
         self.k.dense_fold_bwd(S, self.dense.p["fm.dense_w"].view(Dn, D), self.mlp_w[0], self._dm, self.mlp_dw[0],
                               self.dense.g["fm.dense_w"].view(Dn, D), accumulate=True)

@@ -274,6 +274,31 @@ def dense_fold_bwd(S, dense_w, W0, dM, dW0, d_dense_w, accumulate=True):
                                    _p(d_dense_w), int(accumulate), _stream()), "rec_dense_fold_bwd")
 
 
+def dense_fold_fwd_full(S, dense_w, W0, W0_folded):
+    """W0_folded [(S+1)*D, n_out]: sparse rows of W0 + the folded dense rows M, one launch."""
+    Dn, D = dense_w.shape[-2], dense_w.shape[-1]
+    for t, n in ((dense_w, "dense_w"), (W0, "W0"), (W0_folded, "W0_folded")):
+        _chk(t, torch.float32, n)
+    if tuple(W0_folded.shape) != ((S + 1) * D, W0.shape[1]) or W0.shape[0] != (S + Dn) * D or Dn > D:
+        raise RecError("W0 must be [(S+Dn)*D, n_out] and W0_folded [(S+1)*D, n_out] with Dn <= D")
+    check(lib().rec_dense_fold_fwd_full(int(S), Dn, D, W0.shape[1], _p(dense_w), _p(W0), _p(W0_folded), _stream()),
+          "rec_dense_fold_fwd_full")
+    return W0_folded
+
+
+def dense_fold_bwd_full(S, dense_w, W0, dW0_folded, dW0, d_dense_w, accumulate=True):
+    """dW0_folded = feat'^T dZ0 [(S+1)*D, n_out] (scratch) -> dW0 (sparse rows copied, dense rows = dense_w (x) dM) and
+    d_dense_w (+)= dM @ W0_dense^T, one launch."""
+    Dn, D = dense_w.shape[-2], dense_w.shape[-1]
+    for t, n in ((dense_w, "dense_w"), (W0, "W0"), (dW0_folded, "dW0_folded"), (dW0, "dW0"), (d_dense_w, "d_dense_w")):
+        _chk(t, torch.float32, n)
+    if (tuple(dW0_folded.shape) != ((S + 1) * D, W0.shape[1]) or tuple(dW0.shape) != tuple(W0.shape)
+            or W0.shape[0] != (S + Dn) * D or Dn > D):
+        raise RecError("dW0 must be [(S+Dn)*D, n_out] and dW0_folded [(S+1)*D, n_out] with Dn <= D")
+    check(lib().rec_dense_fold_bwd_full(int(S), Dn, D, W0.shape[1], _p(dense_w), _p(W0), _p(dW0_folded), _p(dW0),
+                                        _p(d_dense_w), int(accumulate), _stream()), "rec_dense_fold_bwd_full")
+
+
 # ------------------------------------------------------------------ lookups
 def emb_gather(ids, W, padding_idx=None, status=None, out=None, out_group=0, out_group_stride=0):
     """out[i,:] = W[ids[i],:] (zero row where ids[i]==padding_idx).  W [N,D] f32.

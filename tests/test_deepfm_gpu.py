@@ -210,6 +210,21 @@ def test_compact_dense_mode(ops, B, D, tables):
     assert float(dW0[:26 * D].abs().max()) == 0.0
     np.testing.assert_allclose(N_(gdw), 1 + np.einsum("jn,jdn->jd", dM, W0[26 * D:].reshape(13, D, n_out)),
                                rtol=1e-5, atol=1e-7)
+    # the one-launch forms: the same bits as the copy + the separate kernels
+    W0f = torch.zeros(27 * D, n_out, device=DEV)
+    ops.dense_fold_fwd_full(26, T(p["dense_w"]).view(13, D), T(W0), W0f)
+    assert torch.equal(W0f, T(W0p))
+    dW0f = T((rng.standard_normal((27 * D, n_out)) * 1e-2).astype(np.float32))
+    dW0f[26 * D + 13:] = 0
+    want_dw0 = torch.zeros(39 * D, n_out, device=DEV)
+    want_dw0[:26 * D] = dW0f[:26 * D]
+    want_gdw = torch.ones(13, D, device=DEV)
+    ops.dense_fold_bwd(26, T(p["dense_w"]).view(13, D), T(W0), dW0f[26 * D:26 * D + 13].clone(), want_dw0, want_gdw,
+                       accumulate=True)
+    got_dw0 = torch.full((39 * D, n_out), 7.0, device=DEV)
+    got_gdw = torch.ones(13, D, device=DEV)
+    ops.dense_fold_bwd_full(26, T(p["dense_w"]).view(13, D), T(W0), dW0f, got_dw0, got_gdw, accumulate=True)
+    assert torch.equal(got_dw0, want_dw0) and torch.equal(got_gdw, want_gdw)
 
 
 # ------------------------------------------------------------------------------ ids grouping
@@ -767,7 +782,7 @@ def test_planned_step_equals_eager_step(engine_lib, monkeypatch, B):
 def test_padded_layer0_input_equals_the_dense_layout(engine_lib, monkeypatch, D, B):
     """The reference's own layout (deepfm/config.yaml: 39 fields x D 9, D 10 in config_bigdata) gives layer 0 an input
     width that is no multiple of the GEMM tiles (351 / 390); DeepFMLayer then keeps feat at a padded sample stride (400,
-    rec_deepfm_desc.feat_stride) and runs layer 0 on a zero-padded copy of its weight.  Same model, same numbers: against
+    rec_deepfm_desc.feat_stride) and runs layer 0 on its weight with zero rows behind it.  Same model, same numbers: against
     the dense layout (REC_DEEPFM_PAD0=0) over several steps — predictions and loss at fp32 rounding of the GEMM's K order,
     every parameter inside the Adam bar, the state_dict shapes unchanged."""
     from helpers import assert_adam_weights_close
@@ -790,6 +805,13 @@ def test_padded_layer0_input_equals_the_dense_layout(engine_lib, monkeypatch, D,
             loss, pred = m.train_step(ids, dense, label, lr=lr)
             outs.append((float(loss), pred.cpu().numpy().copy()))
         ev = m(ids, dense).cpu().numpy()                     # the inference path takes the padded layout too
+        if m.padded:      # the zero rows behind W_0 live in the flat buffers: parameter, gradient, m and v all stay zero
+            o = m.dense.offsets["dnn.linear_0.weight"]
+            lo, hi = o + m.in0 * 80, o + m.ld0 * 80
+            assert m._w0p.data_ptr() == m.mlp_w[0].data_ptr() and m._dw0p.data_ptr() == m.mlp_dw[0].data_ptr()
+            for buf in (m.dense.data, m.dense.grad, m.dense.m, m.dense.v):
+                assert float(buf[lo:hi].abs().max()) == 0.0
+            assert hi <= m.dense.offsets["dnn.linear_0.bias"]
         runs[mode] = (outs, {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}, ev)
         assert int(m.status.item()) == 0
     (oa, sa, ea), (ob, sb, eb) = runs["1"], runs["0"]
@@ -802,9 +824,40 @@ def test_padded_layer0_input_equals_the_dense_layout(engine_lib, monkeypatch, D,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("plan", ["0", "1"])
+def test_one_launch_dense_fold_equals_the_separate_kernels(engine_lib, monkeypatch, plan):
+    """Compact feat (Dn 13 <= D 16): the fold of the dense rows as one launch per direction (rec_dense_fold_*_full, dW_0'
+    in scratch) against copy + rec_dense_fold_fwd / copy + rec_dense_fold_bwd on the gradient buffer: the same bits."""
+    from paddlerec_amd.deepfm import DeepFMLayer
+    monkeypatch.setenv("REC_STEP_PLAN", plan)
+    N, D, B = 5000, 16, 600
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("REC_FOLD_FULL", mode)
+        torch.manual_seed(5)
+        m = DeepFMLayer(N, D, 13, 26, [64, 32], device=DEV)
+        assert m.compact and not m.padded
+        g = torch.Generator(device=DEV).manual_seed(13)
+        outs = []
+        for step in range(4):
+            ids = torch.randint(0, N, (B, 26), device=DEV, generator=g)
+            dense = torch.rand(B, 13, device=DEV, generator=g)
+            label = (torch.rand(B, 1, device=DEV, generator=g) < 0.3).to(torch.int64)
+            loss, pred = m.train_step(ids, dense, label, lr=1e-2)
+            outs.append((loss.cpu().numpy().copy(), pred.cpu().numpy().copy()))
+        runs[mode] = (outs, m.fm.rec.cpu().numpy(), m.dense.data.cpu().numpy(), m.dense.grad.cpu().numpy(),
+                      m.dense.m.cpu().numpy(), m.dense.v.cpu().numpy())
+    a, b = runs["1"], runs["0"]
+    for (la, pa), (lb, pb) in zip(a[0], b[0]):
+        assert np.array_equal(la, lb) and np.array_equal(pa, pb)
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
 def test_planned_step_on_the_padded_layout_equals_its_eager_step(engine_lib, monkeypatch):
     """The recorded call list on the padded layer-0 layout (D 10: 390 -> 400 columns; persistent zero-padded feat buffer,
-    weight copy and gradient copy-back are C-ABI calls like the rest): bit-identical to the eager step over six steps."""
+    the weight's zero rows inside the flat buffers): bit-identical to the eager step over six steps."""
     from paddlerec_amd.deepfm import DeepFMLayer
     N, D, B = 5000, 10, 512
     runs = {}

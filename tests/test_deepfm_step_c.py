@@ -109,3 +109,35 @@ def test_c_step_padding_and_out_of_range_ids(engine_lib, monkeypatch, B):
     for x, y in zip(a[:5], b[:5]):
         assert np.array_equal(x, y)
     assert np.all(a[2][0, :17] == b[2][0, :17])                # the padding row itself never moves
+
+
+def test_c_step_padded_layer0_on_a_callers_separate_buffer(engine_lib, monkeypatch):
+    """layer0_width with w0_folded a buffer of its own (a binder whose parameters carry no spare rows): the step refreshes
+    it from w[0] and copies dW_0 back — the same bits as the in-place form (w0_folded == w[0]) the mirror uses."""
+    from paddlerec_amd import ops
+    from paddlerec_amd.deepfm import DeepFMLayer
+    monkeypatch.setenv("REC_STEP_PLAN", "0")
+    monkeypatch.setenv("REC_DEEPFM_OVERLAP", "0")
+    N, S, D, B = 4000, 26, 10, 640
+    res = {}
+    for which in ("separate", "inplace"):
+        torch.manual_seed(9)
+        m = DeepFMLayer(N, D, 13, S, [80, 48], device=DEV)
+        assert m.padded and m.ld0 == 400
+        scratch = torch.zeros(m.ld0, 80, device=DEV)
+        ws = ops.Workspace(DEV)
+        g = torch.Generator(device=DEV).manual_seed(23)
+        for step in range(3):
+            ids = torch.randint(0, N, (B, S), device=DEV, generator=g)
+            dense = torch.rand(B, 13, device=DEV, generator=g)
+            label = (torch.rand(B, device=DEV, generator=g) < 0.3).to(torch.int64)
+            net = m.c_net()
+            if which == "separate":
+                net.w0_folded = scratch.data_ptr()
+            loss, pred = ops.deepfm_train_step(net, ids, dense, label, step + 1, ws, lr=1e-2, status=m.status)
+        o = m.dense.offsets["dnn.linear_0.weight"]
+        assert float(m.dense.data[o + m.in0 * 80: o + m.ld0 * 80].abs().max()) == 0.0
+        res[which] = (loss.cpu().numpy(), pred.cpu().numpy(), m.fm.rec.cpu().numpy(), m.dense.data.cpu().numpy(),
+                      m.dense.m.cpu().numpy(), m.dense.v.cpu().numpy())
+    for x, y in zip(res["separate"], res["inplace"]):
+        assert np.array_equal(x, y)
