@@ -733,14 +733,22 @@ template <int NACC, class Update>   // floats per lane: D <= 64 * NACC
 __device__ __forceinline__ void sparse_small_body(
     int blk, int n, int D, int S, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
     const int64_t* __restrict__ slot_off, const float* __restrict__ grad, rec_grad_layout gl, Update up,
-    int32_t* __restrict__ status, const int32_t* __restrict__ span_flag = nullptr) {
+    int32_t* __restrict__ status, const int32_t* __restrict__ span_flag = nullptr, int fp_mode = 0) {
   constexpr bool kRecord = std::is_same<Update, SmallAdamRecord>::value;
   constexpr int FLY = kSmallList / NACC;   // gradient rows in flight per wave (32 / 16 / 8 rows of 64 / 128 / 256 floats)
-  extern __shared__ int small_lds[];
+  extern __shared__ __attribute__((aligned(16))) int small_lds[];
   int* wlists = small_lds;                               // [waves][kSmallList] positions of collected occurrences
   int* small_ids = small_lds + kSmallWaves * kSmallList; // [n] rows as int32, -1 = padding / out of range (never matches)
+  // fp_mode (plain tables, small_lds_bytes): 16-bit fingerprints of the rows behind the id list, 512 positions per chunk and
+  // position j of a chunk at half (j % 64) * 8 + j / 64 — one ds_read_b128 per lane then covers 512 positions (lane l holds
+  // positions l, 64 + l, ..., 448 + l), and a chunk without a fingerprint match costs that read, a dozen VALU ops and a
+  // ballot instead of eight reads and two ballots; candidates are confirmed against small_ids
+  unsigned short* fps = reinterpret_cast<unsigned short*>(small_ids + ((n + 3) & ~3));
   const int lane = threadIdx.x % kWave;
   const bool slots = slot_off != nullptr && S > 1 && n % S == 0;
+  const bool fp = fp_mode != 0 && !slots;
+  auto fp_of = [](int r) { return (unsigned short)((r ^ (r >> 16)) & 0xffff); };
+  auto fp_slot = [](int j) { return (j & ~511) | ((j & 63) << 3) | ((j >> 6) & 7); };
   int oob = 0, viol = 0;
   bool by_slot = false;
   int pos = blk * kSmallWaves + threadIdx.x / kWave;       // the lookup of this wave (re-mapped below in slot mode)
@@ -785,14 +793,43 @@ __device__ __forceinline__ void sparse_small_body(
       small_ids[j] = (!isp && inr) ? (int)r : -1;
     }
   } else {
-    for (int i = threadIdx.x; i < n; i += kSmallWaves * kWave) {
-      const int64_t id = ids[i];
+    auto stage = [&](int i, int64_t id) {
       const bool isp = pad >= 0 && id == pad;
       const int64_t r = slot_off ? id + slot_off[i % S] : id;     // 26 tables as one: row = id + slot offset
       const bool inr = r >= 0 && r < N;
       if (!slots || span_flag) oob |= (!isp && !inr) ? 1 : 0;
-      small_ids[i] = (!isp && inr) ? (int)r : -1;
+      const int row = (!isp && inr) ? (int)r : -1;
+      small_ids[i] = row;
+      if (fp) fps[fp_slot(i)] = fp_of(row);
+    };
+    constexpr int NT = kSmallWaves * kWave;
+    if (!slot_off && (reinterpret_cast<uintptr_t>(ids) & 15) == 0) {
+      // a plain table: two ids per 16-byte load and four loads in flight per thread (every block of the launch stages the
+      // whole list: one L2 round trip instead of one per 1024 ids)
+      const longlong2* ids2 = reinterpret_cast<const longlong2*>(ids);
+      const int np = n >> 1;
+      for (int b0 = 0; b0 < np; b0 += 4 * NT) {
+        longlong2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = b0 + u * NT + (int)threadIdx.x;
+          v[u] = ids2[q < np ? q : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = b0 + u * NT + (int)threadIdx.x;
+          if (q < np) {
+            stage(2 * q, v[u].x);
+            stage(2 * q + 1, v[u].y);
+          }
+        }
+      }
+      if ((n & 1) && threadIdx.x == 0) stage(n - 1, ids[n - 1]);
+    } else {
+      for (int i = threadIdx.x; i < n; i += NT) stage(i, ids[i]);
     }
+    if (fp)      // the rest of the last chunk: a fingerprint that is confirmed against nothing (positions >= n)
+      for (int j = n + (int)threadIdx.x; j < ((n + 511) & ~511); j += NT) fps[fp_slot(j)] = 0;
     if (blk >= (n + kSmallWaves - 1) / kSmallWaves) pos = n;   // a block of the slot mapping only: nothing to do
   }
   if (oob) atomicOr(status, REC_FLAG_INDEX_OOB);
@@ -804,15 +841,42 @@ __device__ __forceinline__ void sparse_small_body(
   // Searched from the NEAREST earlier lookups backwards: only existence matters, and where duplicates come in runs (DIN's
   // target-seq tables: one row repeated over a sample's whole history) the first trip already finds one — searched from
   // position 0 the lookups of the last sample walked the whole list first.
-  for (int c1 = tpos; c1 > 0; c1 -= 4 * kWave) {
-    const int c0 = c1 - 4 * kWave;
-    bool hit = false;
+  const unsigned myfp = fp_of(my), rep = myfp * 0x00010001u;
+  // does this lane's eight fingerprints of chunk ck hold myfp?  (zero-half test of w ^ rep, exact for "any")
+  auto chunk_any = [&](int ck, uint4& w) {
+    w = *reinterpret_cast<const uint4*>(fps + ck * 512 + lane * 8);
+    const unsigned x0 = w.x ^ rep, x1 = w.y ^ rep, x2 = w.z ^ rep, x3 = w.w ^ rep;
+    const unsigned z = ((x0 - 0x00010001u) & ~x0) | ((x1 - 0x00010001u) & ~x1) | ((x2 - 0x00010001u) & ~x2) |
+                       ((x3 - 0x00010001u) & ~x3);
+    return (z & 0x80008000u) != 0u;
+  };
+  auto half_of = [](const uint4& w, int h) {
+    const unsigned d = h < 2 ? w.x : h < 4 ? w.y : h < 6 ? w.z : w.w;
+    return (d >> (16 * (h & 1))) & 0xffffu;
+  };
+  if (fp) {
+    for (int ck = tpos >> 9; ck >= 0; --ck) {
+      uint4 w;
+      if (__ballot(chunk_any(ck, w)) == 0) continue;
+      bool hit = false;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = c0 + u * kWave + lane;
-      hit |= j >= 0 && j < tpos && small_ids[j >= 0 ? j : 0] == my;
+      for (int h = 0; h < 8; ++h) {
+        const int j = ck * 512 + h * kWave + lane;
+        if (half_of(w, h) == myfp && j < tpos) hit |= small_ids[j] == my;
+      }
+      if (__ballot(hit) != 0) return;
     }
-    if (__ballot(hit) != 0) return;
+  } else {
+    for (int c1 = tpos; c1 > 0; c1 -= 4 * kWave) {
+      const int c0 = c1 - 4 * kWave;
+      bool hit = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = c0 + u * kWave + lane;
+        hit |= j >= 0 && j < tpos && small_ids[j >= 0 ? j : 0] == my;
+      }
+      if (__ballot(hit) != 0) return;
+    }
   }
   // The occurrences (ascending) are collected FLY at a time across the 64-id chunks and their gradient rows fetched
   // together: a row with a handful of scattered duplicates costs one memory round trip, a hot row (the target item
@@ -857,28 +921,40 @@ __device__ __forceinline__ void sparse_small_body(
   };
   // (four chunks per trip, like the search above: most rows have no second occurrence, and a trip without a match
   // is four LDS reads in flight, one ballot)
-  for (int c0 = (tpos / kWave) * kWave; c0 < tn; c0 += 4 * kWave) {
-    bool mk[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = c0 + u * kWave + lane;
-      mk[u] = j >= tpos && j < tn && small_ids[j < tn ? j : 0] == my;
+  // the occurrences among 64 consecutive positions (lane = position j), appended in ascending order
+  auto emit = [&](bool mine, int j) {
+    unsigned long long m = __ballot(mine);
+    while (m) {
+      const int rank = __popcll(m & ((1ull << lane) - 1ull));
+      const int take = min((int)__popcll(m), FLY - cnt);
+      if (mine && rank < take) wl[cnt + rank] = t0 + j * ts;
+      cnt += take;
+      mine = mine && rank >= take;
+      m = __ballot(mine);
+      if (cnt == FLY) flush();
     }
-    if (__ballot(mk[0] || mk[1] || mk[2] || mk[3]) == 0) continue;
+  };
+  if (fp) {
+    for (int ck = tpos >> 9; ck * 512 < tn; ++ck) {
+      uint4 w;
+      if (__ballot(chunk_any(ck, w)) == 0) continue;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = c0 + u * kWave + lane;
-      bool mine = mk[u];
-      unsigned long long m = __ballot(mine);
-      while (m) {
-        const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        const int take = min((int)__popcll(m), FLY - cnt);
-        if (mine && rank < take) wl[cnt + rank] = t0 + j * ts;
-        cnt += take;
-        mine = mine && rank >= take;
-        m = __ballot(mine);
-        if (cnt == FLY) flush();
+      for (int h = 0; h < 8; ++h) {
+        const int j = ck * 512 + h * kWave + lane;
+        emit(half_of(w, h) == myfp && j >= tpos && j < tn && small_ids[j] == my, j);
       }
+    }
+  } else {
+    for (int c0 = (tpos / kWave) * kWave; c0 < tn; c0 += 4 * kWave) {
+      bool mk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = c0 + u * kWave + lane;
+        mk[u] = j >= tpos && j < tn && small_ids[j < tn ? j : 0] == my;
+      }
+      if (__ballot(mk[0] || mk[1] || mk[2] || mk[3]) == 0) continue;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) emit(mk[u], c0 + u * kWave + lane);
     }
   }
   if (cnt > 0) flush();
@@ -916,8 +992,18 @@ template <int NACC, class Update>
 __global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_kernel(
     int n, int D, int S, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
     const int64_t* __restrict__ slot_off, const float* __restrict__ grad, rec_grad_layout gl, Update up,
-    int32_t* __restrict__ status, const int32_t* __restrict__ span_flag) {
-  sparse_small_body<NACC, Update>(blockIdx.x, n, D, S, N, pad, ids, slot_off, grad, gl, up, status, span_flag);
+    int32_t* __restrict__ status, const int32_t* __restrict__ span_flag, int fp_mode) {
+  sparse_small_body<NACC, Update>(blockIdx.x, n, D, S, N, pad, ids, slot_off, grad, gl, up, status, span_flag, fp_mode);
+}
+
+// LDS bytes of a one-launch merge over n lookups; *fp_mode = 1 when the fingerprint array fits beside the id list in the
+// default 64 KB (plain tables only: the slot-local mode compares n / S lookups, a chunk or two)
+static size_t small_lds_bytes(size_t n, bool plain, int* fp_mode) {
+  static const bool on = [] { const char* v = getenv("REC_SMALL_FP"); return !(v && *v == '0'); }();
+  const size_t base = (n + kSmallWaves * kSmallList) * sizeof(int);
+  const size_t with_fp = (((n + 3) & ~(size_t)3) + kSmallWaves * kSmallList) * sizeof(int) + ((n + 511) & ~(size_t)511) * 2;
+  *fp_mode = on && plain && n >= 1024 && with_fp <= 64 * 1024 ? 1 : 0;
+  return *fp_mode ? with_fp : base;
 }
 
 // flag[0] = 1 when some id leaves its slot's span of rows (id < 0 or id >= slot_off[s + 1] - slot_off[s]): ONE block looks
@@ -953,7 +1039,7 @@ struct SmallJob {
   SmallSgd up;
 };
 struct SmallJobs {
-  int count;
+  int count, fp_mode;
   SmallJob j[kSmallJobsMax];
 };
 template <int NACC>
@@ -964,7 +1050,7 @@ __global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_multi_kernel(
     if (i < jobs.count && (int)blockIdx.x >= jobs.j[i].block0) k = i;
   const SmallJob& jb = jobs.j[k];
   sparse_small_body<NACC, SmallSgd>((int)blockIdx.x - jb.block0, jb.n, jb.D, 1, jb.N, jb.pad, jb.ids, nullptr, jb.grad, jb.gl,
-                                    jb.up, status);
+                                    jb.up, status, nullptr, jobs.fp_mode);
 }
 
 // sum over the merged rows of |g_row|^2 (global-norm clipping needs the norm of the MERGED sparse grad)
@@ -1491,13 +1577,14 @@ extern "C" int rec_sparse_sgd_small(int64_t n, int32_t emb_dim, int32_t row_stri
   REC_REQUIRE(ids && grad && P && status, REC_EINVAL, "null pointer argument");
   REC_REQUIRE(num_rows < (1ll << 31), REC_ESHAPE, "num_rows too large for the one-launch merge");
   const unsigned grid = (unsigned)((n + kSmallWaves - 1) / kSmallWaves);
-  const size_t shmem = ((size_t)n + kSmallWaves * kSmallList) * sizeof(int);       // <= 66 KB
+  int fp_mode = 0;
+  const size_t shmem = small_lds_bytes((size_t)n, true, &fp_mode);       // <= 64 KB
   hipStream_t st = (hipStream_t)stream;
   const SmallSgd up{P, row_stride, lr};
 #define REC_SMALL(NACC_)                                                                                        \
   hipLaunchKernelGGL((sparse_small_kernel<NACC_, SmallSgd>), dim3(grid), dim3(kSmallWaves * kWave), shmem, st,   \
                      (int)n, emb_dim, 1, num_rows, padding_idx, ids, (const int64_t*)nullptr, grad, gl, up, status,   \
-                     (const int32_t*)nullptr)
+                     (const int32_t*)nullptr, fp_mode)
   if (emb_dim <= kWave) REC_SMALL(1); else if (emb_dim <= 2 * kWave) REC_SMALL(2); else REC_SMALL(4);
 #undef REC_SMALL
   return check_launch("rec_sparse_sgd_small");
@@ -1530,7 +1617,7 @@ extern "C" int rec_sparse_sgd_small_multi(int32_t count, const rec_small_sgd_job
     nmax = (size_t)a.n > nmax ? (size_t)a.n : nmax;
   }
   if (js.count == 0) return REC_OK;
-  const size_t shmem = (nmax + kSmallWaves * kSmallList) * sizeof(int);
+  const size_t shmem = small_lds_bytes(nmax, true, &js.fp_mode);   // (the layout is per job: its own n)
   hipStream_t st = (hipStream_t)stream;
 #define REC_SMALLM(NACC_)                                                                                       \
   hipLaunchKernelGGL((sparse_small_multi_kernel<NACC_>), dim3((unsigned)blocks), dim3(kSmallWaves * kWave), shmem, st, \
@@ -1574,7 +1661,8 @@ extern "C" int rec_sparse_adam_record_small(int64_t n, int32_t num_slots, int32_
     const unsigned g2 = (unsigned)(num_slots * ((n / num_slots + kSmallWaves - 1) / kSmallWaves));
     if (g2 > grid) grid = g2;
   }
-  const size_t shmem = ((size_t)n + kSmallWaves * kSmallList) * sizeof(int);
+  int fp_mode = 0;
+  const size_t shmem = small_lds_bytes((size_t)n, !(slot_offset && num_slots > 1 && n % num_slots == 0), &fp_mode);
   hipStream_t st = (hipStream_t)stream;
   int32_t* span_flag = nullptr;
   if (scratch && slot_offset && num_slots > 1 && n % num_slots == 0 && n > 2048) {    // (small lists: the scan is cheap)
@@ -1585,7 +1673,7 @@ extern "C" int rec_sparse_adam_record_small(int64_t n, int32_t num_slots, int32_
 #define REC_SMALL(NACC_)                                                                                           \
   hipLaunchKernelGGL((sparse_small_kernel<NACC_, SmallAdamRecord>), dim3(grid), dim3(kSmallWaves * kWave), shmem,   \
                      st, (int)n, emb_dim, num_slots, num_rows, padding_idx, ids, slot_offset, grad, gl, up, status,    \
-                     (const int32_t*)span_flag)
+                     (const int32_t*)span_flag, fp_mode)
   if (emb_dim <= kWave) REC_SMALL(1); else if (emb_dim <= 2 * kWave) REC_SMALL(2); else REC_SMALL(4);
 #undef REC_SMALL
   return check_launch("rec_sparse_adam_record_small");
