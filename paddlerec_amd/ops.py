@@ -381,15 +381,17 @@ def multislot_sumpool(mb, W, num_rows=None, padding_idx=0, key_mode=0, status=No
         raise RecError("batch x slots must stay below 2^31")
     if out is None:
         out = torch.empty(B, S * D, dtype=torch.float32, device=dev)
-    else:
-        _chk(out, torch.float32, "out", (B, S * D))
+    else:       # [B, ld] with ld >= S * D: the kernel writes the first S * D columns of a row (rec_multislot_desc.out_stride)
+        _chk(out, torch.float32, "out")
+        if out.dim() != 2 or out.shape[0] != B or out.shape[1] < S * D:
+            raise RecError("out must be [batch, >= slots * emb_dim]")
     counts = torch.empty(B, S, dtype=torch.int32, device=dev) if want_counts else None
     seg = torch.empty(max(mb.nnz, 1), dtype=torch.int32, device=dev) if want_backward else None
     rows = torch.empty(max(mb.nnz, 1), dtype=torch.int64, device=dev) if want_backward else None
     if status is None:
         status = new_status(dev)
     d = MultislotDesc(B, S, D, stride, int(key_mode), N, -1 if padding_idx is None else int(padding_idx),
-                      mb.lod.stride(0), 0, *(lazy_init if lazy_init is not None else (0, 0, 0.0, 0)))
+                      mb.lod.stride(0), out.shape[1], *(lazy_init if lazy_init is not None else (0, 0, 0.0, 0)))
     check(lib().rec_multislot_sumpool_fwd(C.byref(d), _p(mb.values), _p(mb.lod), _p(mb.slot_base), _p(W), _p(out),
                                           _p(counts), _p(seg), _p(rows), _p(status), _stream()),
           "rec_multislot_sumpool_fwd")
@@ -681,14 +683,15 @@ def record_gather(rows, rec, D, out_w, out_w1, status, table=None):
 
 
 def ps_push_rows(table, groups, grad, num_slots, grad_pitch=None, grad_index=None, grad1=None, grad1_div=1,
-                 show=None, click=None, grad1_pitch=1):
+                 show=None, click=None, grad1_pitch=1, grad_group=0, grad_group_stride=0):
     """CtrCommonAccessor::Update on the touched rows of `table` (PsTable).  kind 'slot': grad rows [*, D] hold
-    [g_embed_w, g_embedx...]; kind 'deepfm': grad = the D-dim row gradients, grad1 = dz [B] (layout {grad1_div})."""
+    [g_embed_w, g_embedx...]; kind 'deepfm': grad = the D-dim row gradients, grad1 = dz [B] (layout {grad1_div}).
+    grad_group / grad_group_stride: rec_grad_layout (rows of `grad_group` segments at a padded stride)."""
     D = table.emb_dim
     pitch = int(grad_pitch or D)
     if table.kind == "slot":
-        gx = GradSrc(grad.data_ptr(), _gl(1, 0, 0, None, grad_index), pitch, 1)
-        gw = GradSrc(grad.data_ptr(), _gl(1, 0, 0, None, grad_index), pitch, 0)
+        gx = GradSrc(grad.data_ptr(), _gl(1, grad_group, grad_group_stride, None, grad_index), pitch, 1)
+        gw = GradSrc(grad.data_ptr(), _gl(1, grad_group, grad_group_stride, None, grad_index), pitch, 0)
     else:
         if grad1 is None:
             raise RecError("kind 'deepfm' needs grad1 (the first-order gradient)")

@@ -59,7 +59,19 @@ class BenchmarkDNNLayer:
         shapes = []
         for i in range(len(sizes) - 1):
             shapes += [("linear_%d.weight" % i, (sizes[i], sizes[i + 1])), ("linear_%d.bias" % i, (sizes[i + 1],))]
-        self.dense = _FlatParams(shapes, self.device)
+        # Layer 0's input width S x D (408 x 9 = 3672 on the gpubox benchmark) is no multiple of the GEMM tiles: dX_0, the
+        # largest GEMM of the step, then runs on the edge-handling kernel.  The pooled features live at a padded sample stride
+        # (rec_multislot_desc.out_stride; 3680 = 46 x 80: 8 % off dX_0, profiles/r04_gpubox_gemm_probe.txt) in a
+        # zero-initialised buffer, the weight has ld0 - in0 zero rows behind it inside the flat parameter buffers (as in
+        # deepfm.py: gradient, m and v stay exactly zero there), and the row-update kernels find a segment's gradient row
+        # through rec_grad_layout{group = S, group_stride = ld0}
+        self.in0 = sizes[0]
+        self.ld0 = self._pad_width(self.in0) if (self.supports_padded_input and
+                                                 getattr(self.k, "SUPPORTS_FEAT_LD", False)) else self.in0
+        self.padded = self.ld0 != self.in0
+        self.dense = _FlatParams(shapes, self.device,
+                                 reserve={"linear_0.weight": self.ld0 * sizes[1]} if self.padded else None)
+        self._x_bufs = {}
         self.n_linear = len(sizes) - 1
         for i in range(self.n_linear):                                              # net.py:38-46: Normal(std=0.2/sqrt(in))
             self.dense.p["linear_%d.weight" % i].normal_(0.0, 0.2 / math.sqrt(sizes[i]))
@@ -68,6 +80,11 @@ class BenchmarkDNNLayer:
         self.mlp_b = [p["linear_%d.bias" % i] for i in range(self.n_linear)]
         self.mlp_dw = [g["linear_%d.weight" % i] for i in range(self.n_linear)]
         self.mlp_db = [g["linear_%d.bias" % i] for i in range(self.n_linear)]
+        self.gemm_w, self.gemm_dw = self.mlp_w, self.mlp_dw
+        if self.padded:      # what the GEMMs see of layer 0: the weight / its gradient with the zero rows
+            o, k_ = self.dense.offsets["linear_0.weight"], self.ld0 * sizes[1]
+            self.gemm_w = [self.dense.data[o:o + k_].view(self.ld0, sizes[1])] + self.mlp_w[1:]
+            self.gemm_dw = [self.dense.grad[o:o + k_].view(self.ld0, sizes[1])] + self.mlp_dw[1:]
         self.sparse_state = None
         self.ws = self.k.Workspace(self.device)
         self.ws_group = self.k.Workspace(self.device)
@@ -77,6 +94,16 @@ class BenchmarkDNNLayer:
         self._side = None
         self._groups = None
         self.timers = None
+
+    supports_padded_input = True      # (the row-sharded subclass pools into its own buffers: dense layout)
+
+    @staticmethod
+    def _pad_width(in0):
+        """Smallest multiple of 80 >= in0 when that costs <= 2 % more layer-0 work (REC_SLOT_PAD0=0: dense layout)."""
+        if os.environ.get("REC_SLOT_PAD0", "1") == "0" or in0 % 80 == 0:
+            return in0
+        c = -(-in0 // 80) * 80
+        return c if (c - in0) * 50 <= in0 else in0
 
     # -- parameters ------------------------------------------------------------------------------
     def state_dict(self):
@@ -97,12 +124,19 @@ class BenchmarkDNNLayer:
     # -- forward ---------------------------------------------------------------------------------
     def _pool(self, mb, want_backward):
         lazy = self.table.lazy_init if self.table is not None else None
+        out = None
+        if self.padded:      # persistent: the padding columns are zero once and for all (the kernel never writes them)
+            out = self._x_bufs.get(mb.batch)
+            if out is None:
+                if len(self._x_bufs) > 2:
+                    self._x_bufs.clear()
+                out = self._x_bufs[mb.batch] = torch.zeros(mb.batch, self.ld0, dtype=torch.float32, device=self.device)
         return self.k.multislot_sumpool(mb, self.embedding, self.dict_dim, 0, self.key_mode, self.status,
-                                        want_backward=want_backward, lazy_init=lazy)
+                                        want_backward=want_backward, lazy_init=lazy, out=out)
 
     def forward(self, mb):
         x, _, _, _, _ = self._pool(mb, False)
-        y, _ = self.k.mlp_forward(x, self.mlp_w, self.mlp_b, self.ws_mlp)
+        y, _ = self.k.mlp_forward(x, self.gemm_w, self.mlp_b, self.ws_mlp)
         return torch.sigmoid(torch.clamp(y, CLIP[0], CLIP[1]))
 
     __call__ = forward
@@ -147,11 +181,11 @@ class BenchmarkDNNLayer:
         fused_head = self.n_linear > 1 and hasattr(k, "ctr_head") and k.ctr_head_ok(self.mlp_w[-1], self.mlp_dw[-1])
         with self._timed("mlp_fwd"):
             if fused_head:
-                h, acts = k.mlp_forward(x, self.mlp_w[:-1], self.mlp_b[:-1], self.ws_mlp, relu_last=True)
+                h, acts = k.mlp_forward(x, self.gemm_w[:-1], self.mlp_b[:-1], self.ws_mlp, relu_last=True)
                 pred, dz, loss, g_head = k.ctr_head(h, self.mlp_w[-1], self.mlp_b[-1], None, None, label, self.ws,
                                                     self.mlp_dw[-1], self.mlp_db[-1], clip=CLIP)
             else:
-                y, acts = k.mlp_forward(x, self.mlp_w, self.mlp_b, self.ws_mlp)
+                y, acts = k.mlp_forward(x, self.gemm_w, self.mlp_b, self.ws_mlp)
         if not fused_head:
             pred, dz, loss = k.sigmoid_logloss(y, None, None, label, self.ws, clip=CLIP)
         if auc_stats is not None:
@@ -166,11 +200,13 @@ class BenchmarkDNNLayer:
             if on_gpu and sk > 0 and label.shape[0] >= 16384:
                 kw = dict(defer_split=sk)
             if fused_head:
-                dx, finish_dw0 = k.mlp_backward(g_head, acts, self.mlp_w[:-1], self.mlp_dw[:-1], self.mlp_db[:-1],
+                dx, finish_dw0 = k.mlp_backward(g_head, acts, self.gemm_w[:-1], self.gemm_dw[:-1], self.mlp_db[:-1],
                                                 self.ws_mlp, defer_first=True, **kw)              # [B, S*D]
             else:
-                dx, finish_dw0 = k.mlp_backward(dz, acts, self.mlp_w, self.mlp_dw, self.mlp_db, self.ws_mlp,
+                dx, finish_dw0 = k.mlp_backward(dz, acts, self.gemm_w, self.gemm_dw, self.mlp_db, self.ws_mlp,
                                                 defer_first=True, **kw)                           # [B, S*D]
+        # gradient row of segment b * S + s inside dx [B, ld0]
+        lay = dict(grad_group=S, grad_group_stride=self.ld0) if self.padded else {}
         with _OnSide(side, cur):
             with self._timed("sparse_update"):
                 if self.table is not None:
@@ -178,11 +214,11 @@ class BenchmarkDNNLayer:
                     # heter_ps PushCopy `* bs`): the rule then divides it by the key's pushed show
                     if self.scale_sparse_grad:
                         self.table.accessor.grad_scale = float(label.shape[0])
-                    k.ps_push_rows(self.table, groups, dx, S, show=show, click=label.reshape(-1))
+                    k.ps_push_rows(self.table, groups, dx, S, show=show, click=label.reshape(-1), **lay)
                 else:
                     st = self.sparse_state
-                    pp = self._pp = k.segment_partials(groups, dx, D, out=getattr(self, "_pp", None))
-                    k.sparse_adam_rows(groups, dx, 1, self.embedding, st["m"], st["v"], t, lr, partials=pp)
+                    pp = self._pp = k.segment_partials(groups, dx, D, out=getattr(self, "_pp", None), **lay)
+                    k.sparse_adam_rows(groups, dx, 1, self.embedding, st["m"], st["v"], t, lr, partials=pp, **lay)
         with self._timed("mlp_bwd_dw0"):
             finish_dw0()
         k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)

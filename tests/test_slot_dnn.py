@@ -387,6 +387,58 @@ def test_layer_ps_accessor_gpu(engine_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("opt", ["ps", "adam"])
+def test_padded_pool_stride_equals_the_dense_layout(engine_lib, monkeypatch, opt):
+    """S x D = 88 x 9 = 792 inputs: the layer pools into a [B, 800] buffer (rec_multislot_desc.out_stride), runs layer 0 on
+    its weight with 8 zero rows behind it and hands the row updates rec_grad_layout{group S, stride 800} — against the dense
+    layout (REC_SLOT_PAD0=0) over three steps: same pooled values and counts bit for bit, predictions / losses at fp32
+    rounding of the GEMM's K order, the table and the dense parameters inside the optimizer's bar, shapes unchanged."""
+    from helpers import assert_adam_weights_close
+    from paddlerec_amd import ops
+    from paddlerec_amd.slot_dnn import BenchmarkDNNLayer
+    B, S, N, D, lr, steps = 200, 88, 5000, 9, 1e-2, 3
+    rng = np.random.default_rng(7)
+    batches = []
+    for _ in range(steps):
+        values, lod, base = M.csr_from_samples(_random_problem(rng, B, S, N, max_len=4), S)
+        batches.append((values, lod, base, (rng.random((B, 1)) < 0.3).astype(np.int64)))
+    accp = dict(lr=0.05, initial_g2sum=3.0, bounds=(-10.0, 10.0), initial_range=1e-2, embedx_threshold=1.5,
+                nonclk_coeff=0.1, click_coeff=1.0, seed=99)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("REC_SLOT_PAD0", mode)
+        torch.manual_seed(6)
+        m = BenchmarkDNNLayer(N, D, S, [64, 32], device=DEV, key_mode=0, sparse_optimizer=opt,
+                              accessor=accp if opt == "ps" else None)
+        assert m.padded == (mode == "1") and m.in0 == 792 and m.ld0 == (800 if m.padded else 792)
+        assert tuple(m.state_dict()["linear_0.weight"].shape) == (792, 64)
+        outs = []
+        for values, lod, base, label in batches:
+            mbatch = ops.MultislotBatch(T(values), T(lod), T(base))
+            loss, pred = m.train_step(mbatch, T(label), lr=lr)
+            outs.append((float(loss), pred.cpu().numpy().copy(), m.last_counts.cpu().numpy().copy()))
+        ev = m.forward(mbatch).cpu().numpy()
+        if m.padded:
+            o = m.dense.offsets["linear_0.weight"]
+            for buf in (m.dense.data, m.dense.grad, m.dense.m, m.dense.v):
+                assert float(buf[o + 792 * 64: o + 800 * 64].abs().max()) == 0.0
+        runs[mode] = (outs, m.rec.cpu().numpy().copy(), {k: v.cpu().numpy().copy() for k, v in m.dense.p.items()}, ev)
+        assert int(m.status.item()) == 0
+    (oa, ra, da, ea), (ob, rb, db_, eb) = runs["1"], runs["0"]
+    for (la, pa, ca), (lb, pb, cb) in zip(oa, ob):
+        assert abs(la - lb) <= 2e-6 * max(abs(lb), 1e-3) and np.array_equal(ca, cb)
+        np.testing.assert_allclose(pa, pb, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(ea, eb, rtol=0, atol=5e-6)
+    if opt == "ps":        # the whole record: counters and states exact, weights / g2sums at the merged gradient's rounding
+        wscale = float(np.abs(rb[:, :D]).max())
+        np.testing.assert_allclose(ra, rb, rtol=2e-5, atol=2e-5 * wscale)
+    else:
+        assert_adam_weights_close(ra[:, :D], rb[:, :D], lr, steps, err_msg="embedding")
+    for k in da:
+        assert_adam_weights_close(da[k], db_[k], lr, steps, err_msg=k)
+
+
+@pytest.mark.gpu
 def test_ps_shrink_rows(engine_lib):
     from oracle import ps_ref
     from paddlerec_amd import ops
