@@ -552,14 +552,21 @@ class DeepFMLayer:
                 dense_w=self.dense.p["fm.dense_w"], compact=self.compact,
                 **(dict(row_rank=groups.rank) if sorted_rg else {}),
                 **(dict(feat_ld=self.ld0) if self.padded else {}))
-        # The lazy sparse optimizer (HBM-bound) runs on the side stream underneath the MFMA-bound
-        # dW_0 GEMM; it needs row_grad / dz and the merge keys (sorted on that same stream earlier).
+        # The lazy sparse optimizer (HBM-bound) runs underneath the MFMA-bound dW_0 GEMM, one of the two on the side stream;
+        # it needs row_grad / dz and the merge keys (sorted on the side stream earlier).
         t = self.step_count
         st = self.sparse_state
         skw = dict(grad_sorted=True) if sorted_rg else {}
-        if gside is not side and not sorted_rg:
+        # Which of the two leaves the main stream: a kernel that waits for another QUEUE's event starts ~20 us after that
+        # event (fm_bwd ends -> the update's first kernel: 22-26 us in the kernel traces).  REC_DEEPFM_TAIL_SWAP=1 puts
+        # dW_0 + fold + dense Adam on the side stream instead, so that the wait sits in front of the shorter chain —
+        # measured: 2.193-2.201 ms against 2.188-2.196 (profiles/r04_tail_swap.txt); the update stays on the side stream
+        swap = (side is not None and allreduce is None and not small
+                and os.environ.get("REC_DEEPFM_TAIL_SWAP", "0") == "1")
+        if not sorted_rg and side is not None and (gside is not side or swap):
             cur.wait_stream(gside)
-        with _OnSide(side, cur):
+
+        def tail_sparse():
             with self._timed("sparse_adam"):
                 upd = self.k.sparse_adam_rows if self.lazy_mode else self.k.adam_rows_all
                 if small:
@@ -567,15 +574,12 @@ class DeepFMLayer:
                     self.k.sparse_adam_record_small(ids, self.fm.slot_offset, self.fm.padding_idx, row_grad, dz, S,
                                                     self.fm.rec, st["mv"], D, t, lr, v_offset=_round_up(D, 4),
                                                     status=self.status)
-                    pp = pp1 = None
-                else:
-                    # hot rows (Zipf ids): long duplicate runs are pre-reduced per 64-position tile
-                    pp = self._pp = self.k.segment_partials(groups, row_grad, row_grad.shape[1],
-                                                            out=getattr(self, "_pp", None), **skw)
-                    pp1 = self._pp1 = self.k.segment_partials(groups, dz, 1, grad_div=S, out=getattr(self, "_pp1", None))
-                if small:
-                    pass
-                elif self.lazy_mode:
+                    return
+                # hot rows (Zipf ids): long duplicate runs are pre-reduced per 64-position tile
+                pp = self._pp = self.k.segment_partials(groups, row_grad, row_grad.shape[1],
+                                                        out=getattr(self, "_pp", None), **skw)
+                pp1 = self._pp1 = self.k.segment_partials(groups, dz, 1, grad_div=S, out=getattr(self, "_pp1", None))
+                if self.lazy_mode:
                     # W, m, v and W1, m1, v1 of a row in ONE pass: W1 / m1 / v1 share the record line with W
                     D = self.sparse_feature_dim
                     self.k.sparse_adam_record(groups, row_grad, dz, S, self.fm.rec, st["mv"], D, t, lr,
@@ -583,12 +587,23 @@ class DeepFMLayer:
                 else:
                     upd(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr, partials=pp)
                     upd(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr, partials=pp1)
-        with self._timed("mlp_bwd_dw0"):
-            finish_dw0()
-            self._fold_backward()
-        if allreduce is not None:
-            allreduce(self.dense.grad)
-        self.k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
+
+        def tail_dense():
+            with self._timed("mlp_bwd_dw0"):
+                finish_dw0()
+                self._fold_backward()
+            if allreduce is not None:
+                allreduce(self.dense.grad)
+            self.k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
+
+        if swap:
+            with _OnSide(side, cur):        # ordered behind fm_bwd, not behind the update issued below
+                tail_dense()
+            tail_sparse()
+        else:
+            with _OnSide(side, cur):
+                tail_sparse()
+            tail_dense()
         if side is not None:
             cur.wait_stream(self._side)
         return loss, pred
