@@ -94,6 +94,7 @@ struct EpiArgs {
   const float* row_scale;  // [M] (stride rs_stride): MOE gate probability of this expert
   float* out2;             // [M,ldc] or null: CROSS also stores u = acc + bias (saved for backward)
   int ld0, ld1, rs_stride, ld2;
+  int nt_store;            // 1: the whole-tile kernel writes C with non-temporal stores (gemm_f32.hip: the dX + ReLU' form)
 };
 
 // which per-element operands an epilogue reads besides the accumulator

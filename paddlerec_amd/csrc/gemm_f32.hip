@@ -834,7 +834,11 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
   REC_REQUIRE(epi != REC_EPI_MOE || (x->row_scale && x->row_scale_stride >= 1), REC_EINVAL,
               "epilogue needs row_scale");
   hipStream_t st = (hipStream_t)stream;
-  EpiArgs e{bias, aux0, aux1, x->row_scale, x->out2, ld_aux0, ld_aux1, x->row_scale_stride, x->ld_out2};
+  // REC_GEMM_NT_STORE=1: non-temporal C stores for the dX + ReLU' form (alone 6 % faster, in the DeepFM step nothing:
+  // profiles/r04_gemm_variants.txt), 2: for every whole-tile GEMM; default off
+  static const int nt_env = [] { const char* v = getenv("REC_GEMM_NT_STORE"); return v && *v ? atoi(v) : 0; }();
+  const int nt_store = nt_env == 2 || (nt_env == 1 && epi == REC_EPI_RELU_MASK) ? 1 : 0;
+  EpiArgs e{bias, aux0, aux1, x->row_scale, x->out2, ld_aux0, ld_aux1, x->row_scale_stride, x->ld_out2, nt_store};
   REC_REQUIRE(!x->out2 || x->ld_out2 >= desc->n, REC_EINVAL, "bad ld_out2");
   if (skinny_rows(desc) && !b_colsum) {
     const bool vec_a = desc->lda % 4 == 0 && ((uintptr_t)A) % 16 == 0 && desc->k % 4 == 0;

@@ -207,6 +207,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N +
 
   // epilogue: as gemm_f32_kernel (every element is inside the matrix here)
   float* out = partial ? partial + (int64_t)kz * M * ldc : C;
+  // (dX + ReLU' — the epilogue READS a [M, N] operand while it writes C — runs 6 % faster alone with non-temporal writes,
+  // 187 against 199 us on 65536 x 400 x 400; the forward form does not care, the DeepFM step neither: an option)
+  const bool nt = epi.nt_store != 0 && !partial;
   float bj[NT];
 #pragma unroll
   for (int b = 0; b < NT; ++b) bj[b] = !partial ? load_bias<EPI>(n0 + wn * WTN + b * 16 + li, epi) : 0.f;
@@ -232,7 +235,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* kWave, (OCC * WAVES_M * WAVES_N +
       for (int b = 0; b < NT; ++b) {
         const int j = n0 + wn * WTN + b * 16 + li;
         const float v = acc[a][b][r];
-        out[i * ldc + j] = partial ? v : apply_epi<EPI>(v, x0[r][b], x1[r][b], bj[b], i, epi);
+        const float o = partial ? v : apply_epi<EPI>(v, x0[r][b], x1[r][b], bj[b], i, epi);
+        if (nt) __builtin_nontemporal_store(o, &out[i * ldc + j]); else out[i * ldc + j] = o;
       }
     }
   }

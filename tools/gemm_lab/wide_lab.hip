@@ -38,7 +38,8 @@ static void go_persist(int64_t M, int N, int K, const float* A, int64_t lda, con
 extern "C" int lab_wide(int variant, int64_t M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                         float* C, int64_t ldc, int tb, int epi, const float* bias, const float* aux0, int ld0, void* stream) {
   if (M % 256 || N % 80 || K % 16) return 1;
-  EpiArgs e{bias, aux0, nullptr, nullptr, nullptr, ld0, 0, 0, 0};
+  const char* nt = getenv("LAB_NT");
+  EpiArgs e{bias, aux0, nullptr, nullptr, nullptr, ld0, 0, 0, 0, nt && *nt == '1' ? 1 : 0};
   hipStream_t st = (hipStream_t)stream;
 #define GO(WM, OCC)                                                                                        \
   if (!tb && epi == REC_EPI_BIAS_RELU) go<WM, OCC, false, REC_EPI_BIAS_RELU>(M, N, K, A, lda, B, ldb, C, ldc, e, st); \
