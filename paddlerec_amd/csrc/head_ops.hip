@@ -295,7 +295,9 @@ extern "C" int rec_sigmoid_logloss(int64_t batch, int64_t mean_over, const float
 }
 
 static int64_t ctr_head_grid(int64_t batch) {
-  int64_t grid = (batch + (kBlock / kWave) * 4 - 1) / ((kBlock / kWave) * 4);      // ~4 rows per wave at least
+  // ~4 rows per wave at least; the launch-bound batches (the reference's 512) one pass of two rows per wave
+  const int per = (kBlock / kWave) * (batch <= 4096 ? 2 : 4);
+  int64_t grid = (batch + per - 1) / per;
   if (grid > kCtrHeadMaxBlocks) grid = kCtrHeadMaxBlocks;
   return grid < 1 ? 1 : grid;
 }

@@ -1012,14 +1012,25 @@ static size_t small_lds_bytes(size_t n, bool plain, int* fp_mode) {
 __global__ __launch_bounds__(kSmallWaves* kWave) void small_span_check_kernel(int n, int S, const int64_t* __restrict__ ids,
                                                                              const int64_t* __restrict__ slot_off,
                                                                              int32_t* __restrict__ flag) {
+  // eight ids in flight per thread: one block walking 13 312 ids one dependent load at a time took 9.5 us — on the critical
+  // path of a 190 us step
+  constexpr int NT = kSmallWaves * kWave, U = 8;
   int viol = 0;
-  int sl = (int)(threadIdx.x % S);
-  const int step = (kSmallWaves * kWave) % S;
-  for (int i = threadIdx.x; i < n; i += kSmallWaves * kWave) {
-    const int64_t id = ids[i];
-    if (id < 0 || (sl + 1 < S && id >= slot_off[sl + 1] - slot_off[sl])) viol = 1;
-    sl += step;
-    if (sl >= S) sl -= S;
+  for (int i0 = threadIdx.x; i0 < n; i0 += U * NT) {
+    int64_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * NT;
+      v[u] = ids[i < n ? i : i0];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * NT;
+      if (i < n) {
+        const int sl = i % S;
+        if (v[u] < 0 || (sl + 1 < S && v[u] >= slot_off[sl + 1] - slot_off[sl])) viol = 1;
+      }
+    }
   }
   viol = __syncthreads_or(viol);
   if (threadIdx.x == 0) flag[0] = viol ? 1 : 0;
