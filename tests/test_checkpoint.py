@@ -190,3 +190,29 @@ def test_ps_shards_into_an_adam_table_net_are_refused(tmp_path, monkeypatch):
         with pytest.raises(ValueError, match="PS-table run"):
             ck.load_model(d, net)
         assert bool((net.W == 1).all())               # nothing half-loaded into the tables
+
+
+def test_flat_params_reserved_rows_stay_out_of_the_packed_image():
+    """_FlatParams(reserve=...) keeps room behind a tensor (the zero rows of a padded layer-0 weight live there, in all four
+    buffers): offsets stay 256-byte aligned, the gap is zero, and the gap-free checkpoint image (packed / load_packed) is the
+    one of an unreserved layout."""
+    import torch
+    from paddlerec_amd.deepfm import _FlatParams
+    shapes = [("a", (13,)), ("w0", (390, 80)), ("b0", (80,)), ("w1", (80, 1))]
+    plain = _FlatParams(shapes, "cpu")
+    padded = _FlatParams(shapes, "cpu", reserve={"w0": 400 * 80})
+    assert padded.offsets["a"] == plain.offsets["a"] and padded.offsets["w0"] == plain.offsets["w0"]
+    assert padded.offsets["b0"] >= padded.offsets["w0"] + 400 * 80 and all(o % 64 == 0 for o in padded.offsets.values())
+    g = torch.Generator().manual_seed(0)
+    for n in plain.names:
+        v = torch.rand(plain.shapes[n], generator=g)
+        plain.p[n].copy_(v)
+        padded.p[n].copy_(v)
+    o = padded.offsets["w0"]
+    assert float(padded.data[o + 390 * 80: o + 400 * 80].abs().max()) == 0.0
+    view = padded.data[o: o + 400 * 80].view(400, 80)               # what the GEMMs see
+    assert torch.equal(view[:390], plain.p["w0"]) and float(view[390:].abs().max()) == 0.0
+    assert torch.equal(padded.packed(padded.data), plain.packed(plain.data))
+    fresh = _FlatParams(shapes, "cpu", reserve={"w0": 400 * 80})
+    fresh.load_packed(fresh.data, plain.packed(plain.data))
+    assert torch.equal(fresh.data, padded.data)
