@@ -916,6 +916,14 @@ int rec_fill_uniform(int64_t n, float* buf, float lo, float hi, uint64_t seed, v
  * layer-0 weights of DeepFM) so that a training step consists of C-ABI calls only and can be replayed from a recorded
  * call list (paddlerec_amd/plan.py). */
 int rec_copy_async(void* dst, const void* src, size_t bytes, void* stream);
+/* The same for a [rows, width_bytes] window of two pitched device buffers (hipMemcpy2DAsync): a binder that must hand
+ * a framework a CONTIGUOUS column block of an engine output (the item / category halves of DIN's d_hist [B,T,E] as the
+ * SelectedRows values of two separate embedding parameters, paddlerec_amd/paddle_ops/rec_paddle_ops.cc). */
+int rec_copy_2d_async(void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes, size_t width_bytes,
+                      size_t rows, void* stream);
+/* out [cols, rows] = in [rows, cols]^T (f32, both contiguous).  The DIN backward wants the first attention weight
+ * transposed (att_w1_t); a binder without a tensor library of its own materialises it with this. */
+int rec_transpose_f32(int64_t rows, int64_t cols, const float* in, float* out, void* stream);
 
 /* One wave busy-waits `micros` microseconds on `stream`.  Host-side stream probe: HIP maps streams onto a
  * few hardware queues and kernels of two streams that share a queue run strictly one after the other, so a

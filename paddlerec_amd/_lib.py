@@ -252,6 +252,8 @@ SIGNATURES = {
     "rec_fill_uniform": (C.c_int, [_I64, _P, _F, _F, C.c_uint64, _P]),
     "rec_stream_spin": (C.c_int, [_I32, _P]),
     "rec_copy_async": (C.c_int, [_P, _P, _SZ, _P]),
+    "rec_copy_2d_async": (C.c_int, [_P, _SZ, _P, _SZ, _SZ, _SZ, _P]),
+    "rec_transpose_f32": (C.c_int, [_I64, _I64, _P, _P, _P]),
     "rec_stream_create_cu_range": (C.c_int, [_I32, _I32, C.POINTER(C.c_void_p)]),
     "rec_stream_create_cu_stride": (C.c_int, [_I32, _I32, _I32, C.POINTER(C.c_void_p)]),
     "rec_ctr_head_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(C.c_size_t)]),

@@ -69,7 +69,31 @@ def build(force=False, verbose=True):
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
         if verbose:
             print("[build] linked", LIB, flush=True)
+    build_paddle_ops(force or bool(jobs), verbose)
     return LIB
+
+
+PADDLE_OPS = os.path.join(HERE, "paddle_ops")
+PADDLE_OPS_LIB = os.path.join(PADDLE_OPS, "librec_paddle_ops.so")
+
+
+def build_paddle_ops(force=False, verbose=True):
+    """The Paddle custom-op shim (paddle_ops/rec_paddle_ops.cc): host C++ only, compiled against the executable stand-in
+    of paddle/extension.h (paddle_ops/mock) because PaddlePaddle is not installable here, linked to librecengine.so."""
+    src = os.path.join(PADDLE_OPS, "rec_paddle_ops.cc")
+    deps = [src, os.path.join(PADDLE_OPS, "mock", "paddle", "extension.h"), os.path.join(REPO, "include", "recengine.h")]
+    if not (force or any(_newer(d, PADDLE_OPS_LIB) for d in deps)):
+        return PADDLE_OPS_LIB
+    cxx = os.environ.get("CXX", "g++")
+    cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wno-unused-parameter", "-fvisibility=hidden",
+           "-I" + os.path.join(PADDLE_OPS, "mock"), "-I" + os.path.join(REPO, "include"), src, "-o", PADDLE_OPS_LIB,
+           "-L" + HERE, "-lrecengine", "-Wl,-rpath,$ORIGIN/.."]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("custom-op shim failed to compile:\n" + r.stderr[-6000:])
+    if verbose:
+        print("[build] linked", PADDLE_OPS_LIB, flush=True)
+    return PADDLE_OPS_LIB
 
 
 if __name__ == "__main__":

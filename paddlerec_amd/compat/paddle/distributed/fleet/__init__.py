@@ -149,7 +149,8 @@ class _CollectiveOptimizer:
                 if not sg:
                     continue
                 ids = _t.cat([g[0] for g in sg]).contiguous()
-                rows = (_t.cat([g[1] for g in sg]) / float(G)).contiguous()
+                rows = (_t.cat([g[1] if g[3] == 1 else g[1].repeat_interleave(g[3], dim=0) for g in sg])
+                        / float(G)).contiguous()
                 n = _t.tensor([ids.numel()], dtype=_t.int64, device="cpu" if c.staged else ids.device)
                 sizes = [_t.zeros_like(n) for _ in range(G)]
                 dist.all_gather(sizes, n, group=c.group)
@@ -159,7 +160,7 @@ class _CollectiveOptimizer:
                 # every rank sends its whole list to every rank: all-to-all with equal sends = all-gather(v)
                 c.all_to_all(all_ids, ids.repeat(G), sizes, [ids.numel()] * G)
                 c.all_to_all(all_rows, rows.repeat(G, 1), sizes, [ids.numel()] * G)
-                p._sparse_grads = [(all_ids, all_rows, sg[0][2])]
+                p._sparse_grads = [(all_ids, all_rows, sg[0][2], 1)]
         return self._opt.step()
 
     def __getattr__(self, name):

@@ -77,7 +77,7 @@ class _EmbeddingFn(_t.autograd.Function):
         w = ctx.weight
         if not hasattr(w, "_sparse_grads"):
             w._sparse_grads = []
-        w._sparse_grads.append((flat, grad_out.reshape(flat.numel(), -1).contiguous(), ctx.padding_idx))
+        w._sparse_grads.append((flat, grad_out.reshape(flat.numel(), -1).contiguous(), ctx.padding_idx, 1))
         return None, None, None
 
 

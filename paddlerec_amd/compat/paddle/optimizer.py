@@ -56,11 +56,18 @@ class _Base:
     clear_gradients = clear_grad
 
     def _merged_keys(self, p):
-        """(groups, grad rows [n, D]) of the SelectedRows gradients stashed on an embedding parameter."""
+        """(groups, grad rows [n / div, D], div) of the SelectedRows gradients stashed on an embedding parameter: entries
+        (ids, value, padding_idx, div) — one value row serves `div` consecutive ids (nn.Embedding: 1; the first-order
+        table of the fused FM operator: one dy per sample for its S lookups)."""
         K = _backend.kernels()
-        ids = _t.cat([g[0] for g in p._sparse_grads])
-        rows = _t.cat([g[1] for g in p._sparse_grads]).contiguous()
-        pad = p._sparse_grads[0][2]
+        sg = p._sparse_grads
+        if len(sg) == 1:
+            ids, rows, div = sg[0][0], sg[0][1].contiguous(), sg[0][3]
+        else:
+            ids = _t.cat([g[0] for g in sg])
+            rows = _t.cat([g[1] if g[3] == 1 else g[1].repeat_interleave(g[3], dim=0) for g in sg]).contiguous()
+            div = 1
+        pad = sg[0][2]
         if self._ws is None:
             self._ws = K.Workspace(p.device)
         grp = self._groups.get(id(p))
@@ -68,7 +75,7 @@ class _Base:
             grp = self._groups[id(p)] = K.IdGroups(ids.numel(), p.device)
         status = getattr(p, "_rec_status", None)
         K.ids_group(ids.contiguous(), p.shape[0], pad, self._ws, None, status, grp)
-        return grp, rows
+        return grp, rows, div
 
     @staticmethod
     def _coeff(reg):
@@ -83,7 +90,7 @@ class _Base:
     def _prepare(self):
         """The global-norm clipping coefficient over the raw gradients, then the regulariser appended to the dense
         gradients (pre-divided by the coefficient, which the update kernels apply to the whole gradient).
-        -> (sparse: {id(p): (groups, rows)}, scale: device float[1] or None)"""
+        -> (sparse: {id(p): (groups, rows, div)}, scale: device float[1] or None)"""
         K = _backend.kernels()
         sparse = {}
         for p in self._params:
@@ -99,8 +106,8 @@ class _Base:
             ss = _t.zeros(1, dtype=_t.float32, device=dev)
             for p in self._params:
                 if id(p) in sparse:
-                    grp, rows = sparse[id(p)]
-                    K.sparse_rows_sumsq(grp, rows, rows.shape[1], ss, self._ws, accumulate=True)
+                    grp, rows, div = sparse[id(p)]
+                    K.sparse_rows_sumsq(grp, rows, rows.shape[1], ss, self._ws, accumulate=True, grad_div=div)
                 elif p.grad is not None:
                     K.sumsq(p.grad.contiguous().view(-1), ss, self._ws, accumulate=True)
             scale = K.clip_scale(ss, float(self._grad_clip.clip_norm), _t.empty_like(ss))
@@ -141,9 +148,9 @@ class Adam(_Base):
                     continue
                 st = self._state.setdefault(id(p), {"m": _t.zeros_like(p), "v": _t.zeros_like(p)})
                 if sparse:
-                    grp, rows = merged[id(p)]
+                    grp, rows, div = merged[id(p)]
                     upd = K.sparse_adam_rows if self._lazy else K.adam_rows_all
-                    upd(grp, rows, 1, p.data, st["m"], st["v"], t, **kw)
+                    upd(grp, rows, div, p.data, st["m"], st["v"], t, **kw)
                 else:
                     K.adam_dense(p.data.view(-1), st["m"].view(-1), st["v"].view(-1), p.grad.contiguous().view(-1), t, **kw)
 
@@ -157,8 +164,45 @@ class SGD(_Base):
             merged, scale = self._prepare()
             for p in self._params:
                 if id(p) in merged:
-                    grp, rows = merged[id(p)]
-                    K.sparse_sgd_rows(grp, rows if scale is None else rows * scale, p.data, lr)
+                    grp, rows, div = merged[id(p)]
+                    K.sparse_sgd_rows(grp, rows if scale is None else rows * scale, p.data, lr, grad_div=div)
                 elif p.grad is not None:
                     g = p.grad.contiguous().view(-1)
                     K.sgd_dense(p.data.view(-1), g if scale is None else g * scale, lr)
+
+
+class _LRScheduler:
+    """paddle.optimizer.lr.LRScheduler [EXT]: `last_lr` is what the optimizer reads; `step()` advances `last_epoch`.
+    (The reference's tools/trainer.py never calls scheduler.step(): DIN trains at values[0], din/dygraph_model.py:64-73.)"""
+
+    def __init__(self):
+        self.last_epoch = 0
+        self.last_lr = self.get_lr()
+
+    def __call__(self):
+        return self.last_lr
+
+    def step(self, epoch=None):
+        self.last_epoch = self.last_epoch + 1 if epoch is None else int(epoch)
+        self.last_lr = self.get_lr()
+
+
+class _PiecewiseDecay(_LRScheduler):
+    """lr = values[i] while boundaries[i-1] <= last_epoch < boundaries[i] [EXT]."""
+
+    def __init__(self, boundaries, values, last_epoch=-1, verbose=False):
+        if len(values) != len(boundaries) + 1:
+            raise ValueError("PiecewiseDecay: len(values) must be len(boundaries) + 1")
+        self.boundaries, self.values = list(boundaries), [float(v) for v in values]
+        super().__init__()
+
+    def get_lr(self):
+        for b, v in zip(self.boundaries, self.values):
+            if self.last_epoch < b:
+                return v
+        return self.values[-1]
+
+
+class lr:  # noqa: N801  (paddle.optimizer.lr namespace)
+    LRScheduler = _LRScheduler
+    PiecewiseDecay = _PiecewiseDecay

@@ -391,6 +391,45 @@ extern "C" int rec_copy_async(void* dst, const void* src, size_t bytes, void* st
   return REC_OK;
 }
 
+extern "C" int rec_copy_2d_async(void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes,
+                                 size_t width_bytes, size_t rows, void* stream) {
+  if (width_bytes == 0 || rows == 0) return REC_OK;
+  REC_REQUIRE(dst && src, REC_EINVAL, "null pointer argument");
+  REC_REQUIRE(dst_pitch_bytes >= width_bytes && src_pitch_bytes >= width_bytes, REC_ESHAPE, "pitch < width");
+  REC_REQUIRE(hipMemcpy2DAsync(dst, dst_pitch_bytes, src, src_pitch_bytes, width_bytes, rows, hipMemcpyDeviceToDevice,
+                               (hipStream_t)stream) == hipSuccess, REC_EHIP, "hipMemcpy2DAsync failed");
+  return REC_OK;
+}
+
+namespace rec {
+// 32 x 32 tile through LDS (+1 padding column: conflict-free column reads); 256 threads, 4 rows each.
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int64_t rows, int64_t cols) {
+  __shared__ float tile[32][33];
+  const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    int64_t r = r0 + k, c = c0 + tx;
+    if (r < rows && c < cols) tile[k][tx] = in[r * cols + c];
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    int64_t c = c0 + k, r = r0 + tx;
+    if (r < rows && c < cols) out[c * rows + r] = tile[tx][k];
+  }
+}
+}  // namespace rec
+
+extern "C" int rec_transpose_f32(int64_t rows, int64_t cols, const float* in, float* out, void* stream) {
+  REC_REQUIRE(rows >= 0 && cols >= 0, REC_ESHAPE, "negative shape");
+  if (rows == 0 || cols == 0) return REC_OK;
+  REC_REQUIRE(in && out, REC_EINVAL, "null pointer argument");
+  REC_REQUIRE((rows + 31) / 32 <= 65535, REC_ESHAPE, "rows too large for one launch");
+  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+  rec::transpose_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, out, rows, cols);
+  return rec::check_launch("rec_transpose_f32");
+}
+
 extern "C" int rec_stream_create_cu_range(int32_t cu_begin, int32_t cu_end, void** stream) {
   REC_REQUIRE(stream && cu_begin >= 0 && cu_end > cu_begin && cu_end <= 1024, REC_EINVAL, "bad CU range");
   uint32_t mask[32] = {0};

@@ -79,6 +79,8 @@ def main(argv=None):
     sys.path.insert(0, os.path.join(here, "compat"))          # `import paddle` -> the compat namespace
     sys.path.insert(0, os.path.dirname(script))               # what `python script.py` puts first
     sys.argv = [script] + argv[1:]
+    # a net.py patched by integration/*.patch names the custom-op source through this variable
+    os.environ.setdefault("REC_PADDLE_OPS_CC", os.path.join(here, "paddle_ops", "rec_paddle_ops.cc"))
     seed = os.environ.get("REC_COMPAT_SEED")        # tests: the same initial parameters in two runs of one script
     if seed:
         import torch

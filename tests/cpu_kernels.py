@@ -697,3 +697,80 @@ def crossnet_mix_layer_bwd(x0, xl, U, V, Cm, bias, gate_w, t1, t2, prob, dxnext,
         g_gate_b.copy_(gb)
     gemm(dgate, gate_w, ws, trans_b=True, epilogue="add", aux1=dxl, out=dxl, aux0=dx0_acc if fold_dx0 else None)
     return dxl
+
+
+# ------------------------------------------------------------------ custom operators (compat paddle.utils.cpp_extension)
+# CUSTOM_OPS[name] = (forward, gradient) with the calling convention of the shim's kernel functions
+# (paddlerec_amd/paddle_ops/rec_paddle_ops.cc): tensors in the op's declared input order + the attribute dict -> the
+# op's declared outputs.  GPU-less runs of the reference's trainer on a net.py patched by integration/*.patch use these.
+def _co_deepfm_fwd(x, attrs):
+    ids, dense, W, W1, dense_w, dense_w_one = x
+    y1, y2, feat, sum_emb, _ = deepfm_fm_fwd(ids, dense, W, W1, dense_w, dense_w_one, attrs["padding_idx"])
+    return [y1.reshape(-1, 1), y2.reshape(-1, 1), feat, sum_emb, torch.zeros(1, dtype=torch.int32)]
+
+
+def _co_deepfm_bwd(x, attrs):
+    ids, dense, feat, sum_emb, dense_w, d_feat, dy1, dy2 = x
+    B, S = ids.shape
+    D, Dn = feat.shape[2], dense.shape[1]
+    out = (torch.empty(B * S, D), torch.empty(Dn, D), torch.empty(Dn))
+    deepfm_fm_bwd(dense, feat, sum_emb, d_feat, dy1, dy2, S, None, out=out)
+    return [out[0], dy1.reshape(B, 1).clone(), out[1].reshape(1, Dn, D), out[2]]
+
+
+def _co_cross_v2_fwd(x, attrs):
+    x0, xl, W, b = x
+    u = torch.empty_like(xl)
+    out = crossnet_v2_layer_fwd(x0, xl, W, b, Workspace("cpu"), u=u)
+    return [out, u]
+
+
+def _co_cross_v2_bwd(x, attrs):
+    x0, xl, W, u, d_out = x
+    dx0, dW, db = torch.empty_like(xl), torch.empty_like(W), torch.empty(W.shape[1])
+    dxl = crossnet_v2_layer_bwd(x0, xl, W, u, d_out, dx0, False, False, dW, db, Workspace("cpu"))
+    return [dx0, dxl, dW, db]
+
+
+def _co_cross_mix_fwd(x, attrs):
+    x0, xl, U, V, Cm, bias, gate_w, gate_b = x
+    out, t1, t2, prob = crossnet_mix_layer_fwd(x0, xl, U, V, Cm, bias.reshape(-1), gate_w, gate_b, Workspace("cpu"))
+    return [out, t1, t2, prob]
+
+
+def _co_cross_mix_bwd(x, attrs):
+    x0, xl, U, V, Cm, bias, gate_w, t1, t2, prob, d_out = x
+    dx0 = torch.empty_like(xl)
+    gU, gV, gC = torch.empty_like(U), torch.empty_like(V), torch.empty_like(Cm)
+    gbias, ggw, ggb = torch.empty(bias.numel()), torch.empty_like(gate_w), torch.empty(gate_w.shape[1])
+    dxl = crossnet_mix_layer_bwd(x0, xl, U, V, Cm, bias.reshape(-1), gate_w, t1, t2, prob, d_out, dx0, False, False, gU, gV,
+                                 gC, gbias, ggw, ggb, False, Workspace("cpu"))
+    return [dx0, dxl, gU, gV, gC, gbias.reshape(bias.shape), ggw, ggb]
+
+
+def _co_din_fwd(x, attrs):
+    hi, hc, ti, tc, mask, w_hi, w_hc, w_ti, w_tc, w1, b1, w2, b2, w3, b3 = x
+    out, att, _ = din_attention_pool(hi, hc, ti, tc, mask, w_hi, w_hc, w_ti, w_tc, [w1, w2, w3], [b1, b2, b3])
+    import ctypes as C
+    from paddlerec_amd import _lib
+    d = _lib.DinDesc(hi.shape[0], hi.shape[1], w_hi.shape[1], w_hc.shape[1], w1.shape[1], w2.shape[1], w_hi.shape[0],
+                     w_hc.shape[0], w_hi.shape[1], w_hc.shape[1])
+    saves = _lib.lib().rec_din_saves_act1(C.byref(d)) == 1                   # host query: the shape the shim allocates
+    act1 = torch.zeros(hi.shape[0], hi.shape[1], w1.shape[1]) if saves else torch.zeros(1)
+    return [out, att, act1, torch.zeros(1, dtype=torch.int32)]
+
+
+def _co_din_bwd(x, attrs):
+    hi, hc, ti, tc, w_hi, w_hc, w_ti, w_tc, w1, b1, w2, b2, w3, out, att, act1, d_out = x
+    dh, dq = din_attention_pool_bwd(hi, hc, ti, tc, w_hi, w_hc, w_ti, w_tc, [w1, w2, w3], [b1, b2, None], att, d_out)
+    Ei, n = w_hi.shape[1], hi.numel()
+    dh, dq = dh.reshape(n, -1), dq.reshape(n, -1)
+    return [dh[:, :Ei].contiguous(), dh[:, Ei:].contiguous(), dq[:, :Ei].contiguous(), dq[:, Ei:].contiguous()]
+
+
+CUSTOM_OPS = {
+    "rec_deepfm_fm": (_co_deepfm_fwd, _co_deepfm_bwd),
+    "rec_crossnet_v2_layer": (_co_cross_v2_fwd, _co_cross_v2_bwd),
+    "rec_crossnet_mix_layer": (_co_cross_mix_fwd, _co_cross_mix_bwd),
+    "rec_din_attention_pool": (_co_din_fwd, _co_din_bwd),
+}

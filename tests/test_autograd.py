@@ -46,7 +46,6 @@ def test_autograd_adapter_plumbing_cpu_backend(name):
     _run(name, "cpu", cpu_kernels, 2e-6, 1e-8)
 
 
-@pytest.mark.first_hw_run
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["deepfm_D9", "deepfm_D16"])
 def test_autograd_adapter_gpu(name, engine_lib):

@@ -114,7 +114,6 @@ def test_fm_layer_host_logic_cpu_backend():
     _check_layer("cpu", cpu_kernels, (1e-6, 1e-6))
 
 
-@pytest.mark.first_hw_run
 @pytest.mark.gpu
 def test_fm_layer_gpu(engine_lib):
     _check_layer("cuda", None, (1e-5, 2e-4))

@@ -165,7 +165,6 @@ def test_gemm_argument_errors(ops):
         ops.gemm(torch.zeros(4, 5), torch.zeros(5, 3), ws)
 
 
-@pytest.mark.first_hw_run
 def test_stream_helpers(ops):
     """rec_stream_spin / concurrent_stream / cu_range_stream: the helpers the train steps place their side work with."""
     import ctypes as C

@@ -49,7 +49,6 @@ def test_cvm_lookup_and_adagrad_rule(engine_lib, D, B, N):
     assert np.all(np.abs(got[:, 4:4 + D]) <= 10.0)
 
 
-@pytest.mark.first_hw_run
 def test_multi_value_slots_file_to_sum_pool(engine_lib):
     """Row P end to end on the reference's own multi-value fixture (first lines of slot_dnn/data/demo_10):
     host parser (queuedataset_reader.py:56-82) -> hashed rows -> one rec_emb_gather_sumpool launch per slot

@@ -77,14 +77,17 @@ def test_reference_trainer_unmodified_on_the_hip_kernels(tmp_path, engine_lib):
     _run_trainer_and_check(tmp_path, gpu=True)
 
 
-def _run_trainer_and_check(tmp_path, gpu):
+def _run_trainer_and_check(tmp_path, gpu, tree=None):
+    """tree: the PaddleRec tree whose tools/trainer.py + deepfm plugin run (default: the unmodified one; the custom-op
+    tests pass the copy patched by integration/*.patch — initial parameters still come from the unmodified net.py)."""
     from oracle import deepfm_ref as R
     out_dir = tmp_path / "ckpt"
-    cmd = [sys.executable, "-m", "paddlerec_amd.run_reference", os.path.join(REF, "tools", "trainer.py"),
-           "-m", os.path.join(REF, "models", "rank", "deepfm", "config.yaml"),
+    tree = tree or REF
+    cmd = [sys.executable, "-m", "paddlerec_amd.run_reference", os.path.join(tree, "tools", "trainer.py"),
+           "-m", os.path.join(tree, "models", "rank", "deepfm", "config.yaml"),
            "-o", "runner.epochs=1", "runner.print_interval=5", "runner.model_save_path=%s" % out_dir,
            "runner.use_gpu=%s" % ("True" if gpu else "False")]
-    r = subprocess.run(cmd, cwd=REF, env=_env(gpu), capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, cwd=tree, env=_env(gpu), capture_output=True, text=True, timeout=900)
     log = r.stdout + r.stderr
     assert r.returncode == 0, log[-3000:]
     printed = [(int(m.group(1)), float(m.group(2))) for m in

@@ -165,7 +165,6 @@ def test_train_infer_resume_cpu_backend(workdir):
     _run(workdir, "cpu", cpu_kernels, (2e-5, 1e-12, 1e-4, 1e-6))
 
 
-@pytest.mark.first_hw_run
 @pytest.mark.gpu
 def test_train_infer_resume_gpu(workdir, engine_lib):
     # fp32 kernels vs the NumPy oracle over 10 optimizer steps: a prediction next to a bucket edge may move one
@@ -243,7 +242,6 @@ def test_other_mirrors_through_the_loops_cpu_backend(model, tmp_path):
     _other_mirrors(model, tmp_path, "cpu", cpu_kernels)
 
 
-@pytest.mark.first_hw_run
 @pytest.mark.gpu
 @pytest.mark.parametrize("model", ["dcn_v2", "din"])
 def test_other_mirrors_through_the_loops_gpu(model, tmp_path, engine_lib):
