@@ -179,6 +179,8 @@ def other_configs(timeout_s=120):
     jobs = [("tools/bench_models.py", [sys.executable, os.path.join(REPO, "tools", "bench_models.py")]),
             ("tools/slot_dnn_bench.py --opt ps", [sys.executable, os.path.join(REPO, "tools", "slot_dnn_bench.py"),
                                                   "--opt", "ps"]),
+            # L-trainer through the reference's own entry point: unpatched net.py / patched (custom op) / the engine's loop
+            ("tools/ref_entry_bench.py", [sys.executable, os.path.join(REPO, "tools", "ref_entry_bench.py")]),
             ("bench.py --force-sharded --table ps --hashed-rows 1250000000",
              [sys.executable, os.path.abspath(__file__), "--force-sharded", "--table", "ps", "--hashed-rows",
               "1250000000", "--no-cpu-baseline", "--steps", "20", "--warmup", "5"]),
@@ -191,7 +193,7 @@ def other_configs(timeout_s=120):
             ("bench.py --ids zipf", [sys.executable, os.path.abspath(__file__), "--ids", "zipf", "--no-cpu-baseline",
                                      "--steps", "20", "--warmup", "5"])]
     keep = ("config", "workload", "ms", "ms_per_step", "samples_per_s", "value", "unit", "roofline", "pool_fwd_ms",
-            "train_step_ms", "kernels_ms")
+            "train_step_ms", "kernels_ms", "entry", "reader_ms", "batch_ms", "error")
     out = []
     for name, cmd in jobs:
         t0 = time.time()

@@ -23,6 +23,10 @@ class DataLoader:
     def __init__(self, dataset, batch_size=1, places=None, drop_last=False, num_workers=0, shuffle=False,
                  return_list=True, collate_fn=None):
         self.dataset, self.batch_size, self.drop_last = dataset, int(batch_size), drop_last
+        # places = what paddle.set_device returned (tools/trainer.py:121-126): batches are delivered ON that device, as
+        # Paddle's loader does — din/dygraph_model.py:44-54 feeds them to the net without a to_tensor of its own
+        place = places[0] if isinstance(places, (list, tuple)) and places else places
+        self._device = place if isinstance(place, _t.device) and place.type == "cuda" else None
 
     def _batches(self):
         buf = []
@@ -35,10 +39,10 @@ class DataLoader:
         if buf and not self.drop_last:
             yield self._collate(buf)
 
-    @staticmethod
-    def _collate(samples):
+    def _collate(self, samples):
         n = len(samples[0])
-        return [_t.from_numpy(_np.stack([_np.asarray(s[i]) for s in samples])) for i in range(n)]
+        out = [_t.from_numpy(_np.stack([_np.asarray(s[i]) for s in samples])) for i in range(n)]
+        return out if self._device is None else [t.to(self._device, non_blocking=True) for t in out]
 
     def __iter__(self):
         return self._batches()
