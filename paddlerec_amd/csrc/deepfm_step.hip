@@ -10,6 +10,10 @@
 // so the two paths are bit-identical by construction (tests/test_deepfm_step_c.py holds them to that).
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "rec_common.h"
 
 using namespace rec;
@@ -208,6 +212,29 @@ extern "C" int rec_deepfm_train_step_workspace_bytes(const rec_deepfm_net* net, 
     if (int rc_ = (call)) return rc_; \
   } while (0)
 
+// Fork / join events of the two-stream schedule, one set per (device, stream, side stream): an event belongs to the
+// device it was created on, and two host threads stepping two nets (distinct streams, as the contract asks) must not
+// re-record each other's events between a record and its wait.  Created on first use under a lock, kept for the life of
+// the process (a handful of entries: one per stream pair a caller ever steps on).
+static int step_events(void* stream, void* side_stream, hipEvent_t** out) {
+  struct Set { hipEvent_t ev[3]; };
+  static std::mutex mu;
+  static std::map<std::tuple<int, void*, void*>, Set> cache;
+  int dev = 0;
+  REC_REQUIRE(hipGetDevice(&dev) == hipSuccess, REC_EHIP, "hipGetDevice failed");
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_tuple(dev, stream, side_stream);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    Set st{{nullptr, nullptr, nullptr}};
+    for (auto& e : st.ev)
+      REC_REQUIRE(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, REC_EHIP, "hipEventCreate failed");
+    it = cache.emplace(key, st).first;
+  }
+  *out = it->second.ev;                                      // std::map nodes do not move
+  return REC_OK;
+}
+
 extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, const int64_t* ids, const float* dense,
                                      const int64_t* label, const rec_adam_hyper* hyper, int64_t* auc_pos,
                                      int64_t* auc_neg, int32_t num_thresholds, float* loss_out, float* pred_out,
@@ -236,10 +263,8 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   //    everything is issued on `stream` in the same order
   const bool overlap = side_stream != nullptr && side_stream != stream && !s.small;
   void* sst = overlap ? side_stream : stream;
-  static hipEvent_t ev[3] = {nullptr, nullptr, nullptr};     // fork, after fm_bwd, join: re-recorded every step
-  if (overlap && !ev[0])
-    for (auto& e : ev)
-      REC_REQUIRE(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, REC_EHIP, "hipEventCreate failed");
+  hipEvent_t* ev = nullptr;                                  // fork, after fm_bwd, join: re-recorded every step
+  if (overlap) REC_TRY(step_events(stream, side_stream, &ev));
   auto order = [&](int k, void* from, void* to) -> int {    // everything issued on `from` so far happens before `to` goes on
     REC_REQUIRE(hipEventRecord(ev[k], (hipStream_t)from) == hipSuccess &&
                     hipStreamWaitEvent((hipStream_t)to, ev[k], 0) == hipSuccess, REC_EHIP, "stream ordering failed");

@@ -171,7 +171,12 @@ class DeepFMLayer:
         self.slot_rows = None
         if slot_offset is not None:
             so = [int(x) for x in torch.as_tensor(slot_offset).reshape(-1).tolist()]
-            if len(so) >= 2 and so[0] == 0 and so[1] > 0 and all(so[i] == i * so[1] for i in range(len(so))):
+            # ... and only when the table IS S equal spans: rec_ids_group_slots keeps a lookup iff 0 <= id < slot_rows,
+            # fm_fwd iff id + slot_offset[s] < num_rows — with a longer last span (or extra rows behind the spans) the
+            # forward would look a row up whose gradient the slot-local merge drops
+            rows_total = table_rows if table_rows is not None else sparse_feature_number
+            if (len(so) >= 2 and so[0] == 0 and so[1] > 0 and all(so[i] == i * so[1] for i in range(len(so)))
+                    and rows_total == len(so) * so[1]):
                 self.slot_rows = so[1]
             slot_offset = torch.as_tensor(slot_offset, dtype=torch.int64, device=self.device)
         self.fm = FM(table_rows if table_rows is not None else sparse_feature_number,

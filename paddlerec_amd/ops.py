@@ -1105,9 +1105,14 @@ def sparse_adam_record_small(ids, slot_offset, padding_idx, grad, grad1, grad1_d
     if status is None:
         status = new_status(ids.device)
     h = _hyper(lr, beta1, beta2, eps, step)
-    scratch = _SMALL_SCRATCH.get(ids.device)
-    if scratch is None:         # one int per device: the launch's "every id stays in its slot's span" decision
-        scratch = _SMALL_SCRATCH[ids.device] = torch.zeros(1, dtype=torch.int32, device=ids.device)
+    # one int per (device, stream): the launch's "every id stays in its slot's span" decision — written by one kernel
+    # of the call and read by the next on the SAME stream, so calls on different streams must not share it
+    key = (ids.device, _stream().value if ids.device.type == "cuda" else None)
+    scratch = _SMALL_SCRATCH.get(key)
+    if scratch is None:
+        if len(_SMALL_SCRATCH) > 256:
+            _SMALL_SCRATCH.clear()
+        scratch = _SMALL_SCRATCH[key] = torch.zeros(1, dtype=torch.int32, device=ids.device)
     check(lib().rec_sparse_adam_record_small(ids.numel(), S, int(D), rec.stride(0), mv.stride(0), int(v_offset),
                                              rec.shape[0], -1 if padding_idx is None else int(padding_idx), _p(ids),
                                              _p(slot_offset), _p(grad), C.byref(_gl(1, 0, 0)), _p(grad1),

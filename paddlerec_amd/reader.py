@@ -248,7 +248,7 @@ class _FileBatches:
 
         for k in range(nprod):
             threading.Thread(target=produce, args=(k,), daemon=True).start()
-        return self._consume(queues, nprod, stop)
+        return _StoppingIter(self._consume(queues, nprod, stop), stop)
 
     def _consume(self, queues, nprod, stop):
         try:
@@ -284,6 +284,31 @@ class _FileBatches:
                             (label.view(-1, 1), ids, dense))
             rem = n % B
             carry = (label[n - rem:], ids[n - rem:], dense[n - rem:]) if rem else None
+
+
+class _StoppingIter:
+    """The file iterator of _FileBatches: its producers are started eagerly, so the stop flag must follow the lifetime of
+    THIS object — an iterator that is dropped before (or between) next() calls stops them, where a bare generator's
+    `finally` only runs once the generator has been started."""
+
+    def __init__(self, gen, stop):
+        self._gen, self._stop = gen, stop
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return next(self._gen)
+
+    def close(self):
+        self._stop.set()
+        self._gen.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class SlotTextReader(_FileBatches):

@@ -119,8 +119,20 @@ class Comm:
         except Exception as e:
             warn("communicator init", e)
             ok = False
-        if not agree(ok):       # a rank whose ncclCommInitRank failed makes every rank fall back together
+        def drop():
+            """Fallback: release a communicator this rank did create (ranks where the init succeeded while a peer's
+            failed).  Best effort — while the init thread is still blocked inside ncclCommInitRank there is nothing to
+            destroy yet and the handle it may write later is abandoned (the thread is a daemon; documented limitation of
+            the timeout path)."""
+            if h.value and not th.is_alive():
+                try:
+                    lib().rec_comm_destroy(h)
+                except Exception:      # noqa: BLE001
+                    pass
             self.native = None
+
+        if not agree(ok):       # a rank whose ncclCommInitRank failed makes every rank fall back together
+            drop()
             return
         try:
             self._selftest_native(dev)
@@ -128,7 +140,7 @@ class Comm:
             warn("self-test", e)
             ok = False
         if not agree(ok):
-            self.native = None
+            drop()
 
     def _selftest_native(self, dev):
         """One all-to-all (one int64 per peer, value = 1000*src + dst) and one all-reduce over the new communicator,
