@@ -191,7 +191,11 @@ def other_configs(timeout_s=120):
             ("bench.py --shared-table --dim 10", [sys.executable, os.path.abspath(__file__), "--shared-table", "--dim", "10",
                                                   "--no-cpu-baseline", "--steps", "20", "--warmup", "5"]),
             ("bench.py --ids zipf", [sys.executable, os.path.abspath(__file__), "--ids", "zipf", "--no-cpu-baseline",
-                                     "--steps", "20", "--warmup", "5"])]
+                                     "--steps", "20", "--warmup", "5"]),
+            # the reference's dygraph-default optimizer on configs[1]: Adam lazy_mode=False, the whole table every step
+            # (~10 GB per step on 26 tables) next to the lazy headline
+            ("bench.py --non-lazy-adam", [sys.executable, os.path.abspath(__file__), "--non-lazy-adam", "--no-cpu-baseline",
+                                          "--steps", "10", "--warmup", "3"])]
     keep = ("config", "workload", "ms", "ms_per_step", "samples_per_s", "value", "unit", "roofline", "pool_fwd_ms",
             "train_step_ms", "kernels_ms", "entry", "reader_ms", "batch_ms", "error")
     out = []
@@ -210,6 +214,7 @@ def other_configs(timeout_s=120):
                     e["workload"] = d["config"].get("workload")
                     e["config"] = ("configs[4] (one GPU's share, row-sharded path at world 1)" if "--table" in cmd else
                                    "configs[1] layout 2b (one shared table)" if "--shared-table" in cmd else
+                                   "configs[1] with the dygraph-default NON-lazy Adam" if "--non-lazy-adam" in cmd else
                                    "configs[1] with Zipf(1.05) ids")
                     e["roofline"] = {k: d["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac",
                                                                        "in_step_frac")}
@@ -367,6 +372,9 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the row-sharded path (RCCL all-to-all) even with one rank")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--non-lazy-adam", action="store_true",
+                    help="single GPU: the reference's DYGRAPH optimizer (deepfm/dygraph_model.py:61-65, Adam lazy_mode=False"
+                         " — every row of both tables decays every step: 6 N (D+1) 4 B of extra traffic) instead of lazy Adam")
     ap.add_argument("--shared-table", action="store_true",
                     help="layout (2b) of SURVEY §8(d), the reference's own: ONE table of rows-per-table (+1) rows shared "
                          "by the 26 slots (deepfm/config.yaml:48-50 with --dim 9, benchmark.yaml:21 with --dim 10)")
@@ -443,6 +451,8 @@ def main():
     if dist is None:
         from paddlerec_amd.deepfm import DeepFMLayer
         model = DeepFMLayer(N, D, Dn, S, fc, device=dev, slot_offset=so, kernels=kernels)
+        if args.non_lazy_adam:
+            model.lazy_mode = False
         parallelism = "single"
     elif args.table == "ps":
         from paddlerec_amd.sharded import ShardedDeepFMLayer
@@ -583,7 +593,9 @@ def main():
         "data": "synthetic" if not standin else "cpu-standin (REC_BENCH_STANDIN=1: host-logic test of this file's "
                                                 "launch path on the tests' operator stand-in; NOT a measurement)",
         "config": {"workload": "DeepFM full Criteo: 26 sparse slots x %d rows x dim %d, 13 dense, "
-                               "MLP %s, batch %d per GPU, lazy Adam, %s ids" % (args.rows_per_table, D, args.fc, B, args.ids)
+                               "MLP %s, batch %d per GPU, %s Adam, %s ids" % (args.rows_per_table, D, args.fc, B,
+                                                                              "NON-lazy (dygraph default)" if args.non_lazy_adam
+                                                                              else "lazy", args.ids)
                    + (" [ONE shared table: the reference's layout]" if args.shared_table else "")
                    if args.table != "ps" else
                    "DeepFM on the hashed gpubox table (configs[4]): %d rows per GPU x %d GPUs x dim %d (one 128-B "

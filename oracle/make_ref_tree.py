@@ -33,6 +33,9 @@ FILES = [
     "models/rank/dnn/config_gpubox.yaml", "models/rank/dnn/config.yaml", "models/rank/dnn/net.py",
     "models/rank/dnn/static_model.py", "models/rank/dnn/dygraph_model.py", "models/rank/dnn/criteo_reader.py",
     "models/rank/dnn/queuedataset_reader.py", "models/rank/dnn/data/sample_data/train/sample_train.txt",
+    "models/rank/wide_deep/config_gpups.yaml", "models/rank/wide_deep/net.py", "models/rank/wide_deep/static_model.py",
+    "models/rank/wide_deep/queuedataset_reader.py", "models/rank/wide_deep/criteo_reader.py",
+    "models/rank/wide_deep/data/sample_data/train/sample_train.txt",
     "models/rank/slot_dnn/config_online.yaml", "models/rank/slot_dnn/net.py", "models/rank/slot_dnn/static_model.py",
     "models/rank/slot_dnn/queuedataset_reader.py", "models/rank/slot_dnn/data/demo_10",
     "models/rank/dcn_v2/config.yaml", "models/rank/dcn_v2/net.py", "models/rank/dcn_v2/dygraph_model.py",

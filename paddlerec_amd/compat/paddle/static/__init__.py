@@ -45,6 +45,33 @@ class Var:
     def __repr__(self):
         return "var %s : %s%s" % (self.name, str(self.dtype).replace("torch.", ""), self.shape)
 
+    # arithmetic on variables (wide_deep/static_model.py:99 `1 - pred`): one recorded elementwise op each
+    def _binary(self, other, fn, name):
+        fn.__name__ = fn.__qualname__ = name
+        return record(fn, (self, other))
+
+    def __add__(self, o):
+        return self._binary(o, lambda a, b: a + b, "elementwise_add")
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self._binary(o, lambda a, b: a - b, "elementwise_sub")
+
+    def __rsub__(self, o):
+        return self._binary(o, lambda a, b: b - a, "elementwise_sub")
+
+    def __mul__(self, o):
+        return self._binary(o, lambda a, b: a * b, "elementwise_mul")
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        return self._binary(o, lambda a, b: a / b, "elementwise_div")
+
+    def __neg__(self):
+        return self._binary(-1.0, lambda a, b: a * b, "scale")
+
 
 class Program:
     def __init__(self):

@@ -89,8 +89,8 @@ def test_v2_train_steps_vs_oracle(engine_lib, stacked, D, B):
         label = (rng.random((B, 1)) < 0.3).astype(np.int64)
         loss, pred = m.train_step(T(ids), T(dense), T(label), lr=1e-2, clip_norm=0.05)
         oloss, opred, og = tr.train_step(ids, dense, label)
-        np.testing.assert_allclose(N_(loss)[0], oloss, rtol=2e-5)
-        np.testing.assert_allclose(N_(pred), opred, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(N_(loss)[0], oloss, rtol=1e-5)
+        np.testing.assert_allclose(N_(pred), opred, rtol=1e-5, atol=1e-6)
     assert int(m.status.item()) == 0
     # the optimizer state after three clipped steps: Adam's moments at 1e-5 of their scale (weights would amplify
     # eps-sized gradient noise to lr-sized differences: helpers.assert_moments_close)
@@ -141,8 +141,8 @@ def test_mix_train_steps_vs_oracle(engine_lib, stacked):
         label = (rng.random((B, 1)) < 0.3).astype(np.int64)
         loss, pred = m.train_step(T(ids), T(dense), T(label), lr=1e-2, clip_norm=0.05)
         oloss, opred, _ = tr.train_step(ids, dense, label)
-        np.testing.assert_allclose(N_(loss)[0], oloss, rtol=2e-5)
-        np.testing.assert_allclose(N_(pred), opred, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(N_(loss)[0], oloss, rtol=1e-5)
+        np.testing.assert_allclose(N_(pred), opred, rtol=1e-5, atol=1e-6)
     # optimizer state: moments at 1e-5 of scale (the four gating Linear layers live in one [d, E] parameter here)
     want_m, want_v = dict(tr.m), dict(tr.v)
     for mv in (want_m, want_v):
@@ -279,11 +279,11 @@ def _check_train_mode(device, kernels, stacked, mix):
         label = (rng.random((B, 1)) < 0.3).astype(np.int64)
         loss, pred = m.train_step(t(ids), t(dense), t(label), lr=1e-2, clip_norm=0.05)
         oloss, opred, _ = tr.train_step(ids, dense, label)
-        np.testing.assert_allclose(loss.cpu().numpy()[0], oloss, rtol=2e-5)
-        np.testing.assert_allclose(pred.cpu().numpy(), opred, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(loss.cpu().numpy()[0], oloss, rtol=1e-5)
+        np.testing.assert_allclose(pred.cpu().numpy(), opred, rtol=1e-5, atol=1e-6)
         moments_vs_oracle()
         oracle_takes_the_mirrors_state()
     # eval forward is untouched by the dropout settings
     ev = m.forward(t(ids), t(dense)).cpu().numpy()
     np.testing.assert_allclose(ev, X.forward(ids, dense, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}),
-                               rtol=2e-5, atol=1e-6)
+                               rtol=1e-5, atol=1e-6)

@@ -169,10 +169,10 @@ def test_din_train_step_golden_grads_and_sgd(engine_lib):
     for k, v in g.items():
         if k.startswith("g."):
             # the UPDATE, not the weight (whose scale would hide it): p_new - p_old against -lr * golden gradient, to
-            # 2e-5 of the update's scale + the one fp32 rounding of the stored weight
+            # 1e-5 of the update's scale + the one fp32 rounding of the stored weight
             upd = -lr * v.astype(np.float64)
-            np.testing.assert_allclose(N_(sd[k[2:]]).astype(np.float64) - p[k[2:]], upd, rtol=2e-5, err_msg=k,
-                                       atol=2e-5 * np.abs(upd).max() + 1.2e-7 * np.abs(p[k[2:]]).max())
+            np.testing.assert_allclose(N_(sd[k[2:]]).astype(np.float64) - p[k[2:]], upd, rtol=1e-5, err_msg=k,
+                                       atol=1e-5 * np.abs(upd).max() + 1.2e-7 * np.abs(p[k[2:]]).max())
     assert int(m.status.item()) == 0
 
 
@@ -192,13 +192,13 @@ def test_din_train_steps_vs_oracle(engine_lib):
         tis, tcs = np.repeat(ti[:, None], Tn, 1), np.repeat(tc[:, None], Tn, 1)
         loss, pred = m.train_step(T(hi), T(hc), T(ti), T(tc), T(label), T(mask), T(tis), T(tcs), base_lr=lr)
         grads = Dn.backward(p, att, hi, hc, ti, tc, mask, label)
-        np.testing.assert_allclose(N_(loss)[0], Dn.bce_with_logits_mean(grads["_logit"], label), rtol=2e-5)
+        np.testing.assert_allclose(N_(loss)[0], Dn.bce_with_logits_mean(grads["_logit"], label), rtol=1e-5)
         for k in p:
             p[k] = (p[k] - lr * np.asarray(grads[k]).reshape(p[k].shape)).astype(np.float32)
     for k, v in m.state_dict().items():      # two SGD steps: the accumulated update against the oracle's
         d_got, d_want = N_(v).astype(np.float64) - p0[k], p[k].astype(np.float64) - p0[k]
-        np.testing.assert_allclose(d_got, d_want, rtol=2e-5, err_msg=k,      # + the fp32 rounding of two stored steps
-                                   atol=2e-5 * np.abs(d_want).max() + 2.4e-7 * np.abs(p0[k]).max())
+        np.testing.assert_allclose(d_got, d_want, rtol=1e-5, err_msg=k,      # + the fp32 rounding of two stored steps
+                                   atol=1e-5 * np.abs(d_want).max() + 2.4e-7 * np.abs(p0[k]).max())
 
 
 def test_din_train_step_graphed_equals_eager(engine_lib):

@@ -69,7 +69,7 @@ def test_gemm_epilogues(ops):
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
     ws = ops.Workspace(DEV)
     acc = A.astype(np.float64) @ B.astype(np.float64)
-    tol = dict(rtol=2e-5, atol=2e-5)
+    tol = dict(rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(ops.gemm(t(A), t(B), ws, epilogue="bias", bias=t(bias)).cpu().numpy(),
                                acc + bias, **tol)
     np.testing.assert_allclose(ops.gemm(t(A), t(B), ws, epilogue="bias_relu", bias=t(bias)).cpu().numpy(),
@@ -101,7 +101,7 @@ def test_gemm_skinny_paths(ops):
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
     ws = ops.Workspace(DEV)
     acc = A.astype(np.float64) @ w.astype(np.float64)
-    tol = dict(rtol=2e-5, atol=2e-5)
+    tol = dict(rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(ops.gemm(t(A), t(w), ws, epilogue="bias", bias=t(b)).cpu().numpy(), acc + b, **tol)
     np.testing.assert_allclose(ops.gemm(t(A), t(w), ws, epilogue="add", bias=t(b), aux1=t(item_b)).cpu().numpy(),
                                acc + b + item_b, **tol)
@@ -110,7 +110,7 @@ def test_gemm_skinny_paths(ops):
     G = _mk(rng, M, 1)
     db = torch.empty(1, device=DEV)
     dW = ops.gemm(t(A), t(G), ws, trans_a=True, b_colsum=db)
-    np.testing.assert_allclose(dW.cpu().numpy(), A.astype(np.float64).T @ G.astype(np.float64), rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(dW.cpu().numpy(), A.astype(np.float64).T @ G.astype(np.float64), rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(db.cpu().numpy(), G.astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
     dW2 = ops.gemm(t(A), t(G), ws, trans_a=True, b_colsum=db)
     assert torch.equal(dW, dW2)
@@ -127,7 +127,7 @@ def test_gemm_strided_views_and_inplace_out(ops):
     for a in (A, A1):
         C = ops.gemm(a, B, ws, out=outbuf[:, :48])
         want = a.double().cpu().numpy() @ B.double().cpu().numpy()
-        np.testing.assert_allclose(C.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(C.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
     assert float(outbuf[:, 48:].abs().max()) == 0.0   # nothing written outside the N columns
 
 
@@ -140,7 +140,7 @@ def test_gemm_fused_colsum(ops):
         db = torch.empty(nout, device=DEV)
         dW = ops.gemm(torch.as_tensor(X).to(DEV), torch.as_tensor(G).to(DEV), ws, trans_a=True, b_colsum=db)
         np.testing.assert_allclose(dW.cpu().numpy(), X.astype(np.float64).T @ G.astype(np.float64),
-                                   rtol=2e-5, atol=2e-4)
+                                   rtol=1e-5, atol=1e-4)
         np.testing.assert_allclose(db.cpu().numpy(), G.astype(np.float64).sum(0), rtol=1e-5,
                                    atol=1e-6 * np.abs(G).sum(0).max())
 

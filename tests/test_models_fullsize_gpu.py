@@ -154,7 +154,7 @@ def test_dcn_v2_full_width_step_vs_oracle(engine_lib):
     oloss, opred, _ = tr.train_step(ids, dense, label)
     assert int(m.status.item()) == 0
     np.testing.assert_allclose(float(loss.item()), oloss, rtol=1e-5)
-    np.testing.assert_allclose(pred.cpu().numpy(), opred, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(pred.cpu().numpy(), opred, rtol=1e-5, atol=1e-6)
     assert assert_moments_close(m, tr.m, tr.v) >= 10
     assert_close_scaled(m.sparse_state["m"].cpu().numpy(), tr.m["embedding.weight"])
     assert_close_scaled(m.sparse_state["v"].cpu().numpy(), tr.v["embedding.weight"])
@@ -191,7 +191,7 @@ def test_din_attention_long_history_vs_oracle(engine_lib):
     q = np.concatenate([tabs[2][ti], tabs[3][tc]], 2)
     want, wts = Dn.attention_pool(h, q, mask.astype(np.float32), aw, ab, return_weights=True)
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(attw.cpu().numpy(), wts.reshape(B, Tn), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(attw.cpu().numpy(), wts.reshape(B, Tn), rtol=1e-5, atol=1e-7)
     dout = (rng.standard_normal((B, E)) * 0.1).astype(np.float32)
     dh, dq = ops.din_attention_pool_bwd(T(hi), T(hc), T(ti), T(tc), *tt, [T(w) for w in aw], [T(b) for b in ab], attw,
                                         T(dout))

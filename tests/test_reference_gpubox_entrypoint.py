@@ -27,7 +27,14 @@ pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "tools", "s
                                 reason="staged reference tree not present (python oracle/make_ref_tree.py)")
 
 
-def _run(tmp_path, gpu, epochs=2, gpus="0", batch=None, name="out", extra_env=None):
+MODELS = {   # the two nets the reference wires for gpubox (dnn/net.py:71, wide_deep/net.py:80): config, data, dense tensors
+    "dnn": ("models/rank/dnn/config_gpubox.yaml", "models/rank/dnn/data/sample_data/train/sample_train.txt", 10),
+    "wide_deep": ("models/rank/wide_deep/config_gpups.yaml", "models/rank/wide_deep/data/sample_data/train/sample_train.txt",
+                  12),          # + the wide part's Linear(13, 1)
+}
+
+
+def _run(tmp_path, gpu, epochs=2, gpus="0", batch=None, name="out", extra_env=None, model="dnn", args=()):
     env = dict(os.environ, FLAGS_selected_gpus=gpus, TRAINING_ROLE="TRAINER", PADDLE_TRAINER_ID="0", OMP_NUM_THREADS="4",
                PYTHONDONTWRITEBYTECODE="1")
     env.pop("WORLD_SIZE", None)
@@ -39,7 +46,7 @@ def _run(tmp_path, gpu, epochs=2, gpus="0", batch=None, name="out", extra_env=No
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(REPO, "tests"), REPO, env.get("PYTHONPATH", "")])
     out = tmp_path / name
     cmd = [sys.executable, "-m", "paddlerec_amd.run_reference", os.path.join(REF, "tools", "static_gpubox_trainer.py"),
-           "-m", "models/rank/dnn/config_gpubox.yaml", "-o", "runner.epochs=%d" % epochs,
+           "-m", MODELS[model][0]] + list(args) + ["-o", "runner.epochs=%d" % epochs,
            "runner.use_gpu=%d" % (1 if gpu else 0), "runner.model_save_path=%s" % out]
     if batch:
         cmd.append("runner.train_batch_size=%d" % batch)
@@ -52,9 +59,9 @@ def _run(tmp_path, gpu, epochs=2, gpus="0", batch=None, name="out", extra_env=No
     return log, out
 
 
-def _check(tmp_path, gpu):
+def _check(tmp_path, gpu, model="dnn", args=()):
     epochs = 2
-    log, out = _run(tmp_path, gpu, epochs)
+    log, out = _run(tmp_path, gpu, epochs, model=model, args=args)
     assert "Run Success, Exit." in log
     ep = re.findall(r"Epoch: (\d+), using time: ([0-9.]+) second, ips: ([0-9.]+) example/sec. auc: ([0-9.]+)", log)
     assert [int(e[0]) for e in ep] == list(range(epochs)), log[-3000:]
@@ -63,7 +70,7 @@ def _check(tmp_path, gpu):
     assert log.count("self.reader.load_into_memory cost") == epochs and log.count("begin_pass cost") == epochs
     assert "sync_mode = gpubox" in log                                     # get_strategy took the gpubox branch
     # the data file: 80 lines of `click:L dense_feature:... 1:id ... 26:id`
-    data = open(os.path.join(REF, "models/rank/dnn/data/sample_data/train/sample_train.txt")).read().strip().split("\n")
+    data = open(os.path.join(REF, MODELS[model][1])).read().strip().split("\n")
     n_occ = sum(1 for ln in data for t in ln.split() if re.match(r"^\d+:", t) and int(t.split(":")[1]) != 0)
     n_click = sum(int(t.split(":")[1]) * 26 for ln in data for t in ln.split() if t.startswith("click:"))
     z = np.load(os.path.join(str(out), str(epochs - 1), "rec_gpubox.npz"))
@@ -74,11 +81,33 @@ def _check(tmp_path, gpu):
     assert float(rec[:, D + 1].sum()) == epochs * n_click, "click counters"
     assert np.all(rec[:, D + 4] >= 1) and np.abs(rec[:, 0]).max() > 0        # existing values, embed_w moved
     assert np.all(np.isfinite(rec))
-    assert sum(1 for k in z.files if k.startswith("dense.")) == 10         # 5 Linear layers: weight + bias
+    assert sum(1 for k in z.files if k.startswith("dense.")) == MODELS[model][2]      # Linear layers: weight + bias
+    return log
 
 
 def test_static_gpubox_trainer_runs_unmodified_cpu_backend(tmp_path):
     _check(tmp_path, gpu=False)
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REF, MODELS["wide_deep"][0])), reason="wide_deep not staged")
+def test_static_gpubox_trainer_wide_deep_config_gpups_cpu_backend(tmp_path):
+    """rank/wide_deep is the second net the reference wires for gpubox (wide_deep/net.py:73-100,
+    config_gpups.yaml) — same unmodified trainer, same checks."""
+    _check(tmp_path, gpu=False, model="wide_deep")
+
+
+@pytest.mark.gpu
+@pytest.mark.first_hw_run
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REF, MODELS["wide_deep"][0])), reason="wide_deep not staged")
+def test_static_gpubox_trainer_wide_deep_config_gpups_on_the_hip_kernels(tmp_path, engine_lib):
+    _check(tmp_path, gpu=True, model="wide_deep")
+
+
+def test_profiler_options_do_not_crash_the_unmodified_trainer(tmp_path):
+    """--profiler_options (static_gpubox_trainer.py:57,255 -> tools/profiler.py:82-110 -> paddle.utils.profiler.start /
+    stop_profiler): the compat hooks open / close a ROCTX range (no-op without libroctx) instead of raising."""
+    log = _check(tmp_path, gpu=False, args=("--profiler_options", "batch_range=[0,1];state=GPU;exit_on_finished=false;profile_path=%s" % tmp_path))
+    assert "profiler window closed" in log
 
 
 @pytest.mark.gpu
