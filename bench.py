@@ -156,6 +156,43 @@ def cpu_baseline(B, S, Dn, D, fc, rows_per_table, budget_s=20.0):
                       "NumPy/BLAS MLP fwd/bwd + dense Adam), %.1f s" % (steps, B, t_total)}
 
 
+XGMI_LINKS, XGMI_LINK_GBS = 7, 153.0          # 7 point-to-point links per GPU, ~153 GB/s each way
+
+
+def link_model_us(tag, remote_bytes, world, calls=1.0):
+    """Analytic time of one collective's REMOTE bytes over xGMI (microseconds per step), next to which the measured time
+    is printed so that the first real multi-GPU run diagnoses itself:
+      all-to-all : every peer is reached over its own link, min(world-1, 7) links busy at once
+      all-reduce : ring — per hop one link each way; remote_bytes already holds the 2 (G-1)/G factor
+    + ~8 us of launch / rendezvous per collective call (RCCL kernel launch + peer handshake, order of magnitude)."""
+    if world <= 1 or remote_bytes <= 0:
+        return 8.0 * calls
+    links = 1 if tag.startswith("allreduce") else min(world - 1, XGMI_LINKS)
+    return remote_bytes / (links * XGMI_LINK_GBS * 1e9) * 1e6 + 8.0 * calls
+
+
+def dry_links(B, S, D, table, worlds=(2, 4, 8)):
+    """bench.py --dry-links: the per-GPU, per-step exchange volumes of the row-sharded step (SURVEY §8(d) "all-to-all
+    bytes") and the link model's time for each collective, WITHOUT touching a GPU — what `exchange.per_collective`
+    should look like on real links.  Uniform ids: a fraction (G-1)/G of a rank's lookups is owned by a peer."""
+    rows = []
+    c1 = 2 if table == "ps" else 1                  # PS: the click label rides with dz
+    dense_params = 13 * (D + 1) + (S + 1) * D * 400 + 400 + 2 * (400 * 400 + 400) + 400 + 1 + 1
+    for G in worlds:
+        n, f = B * S, (G - 1) / G
+        per = {"a2a_counts": (2 * G * 8, 2 * G * 8 * f, 2), "a2a_ids": (n * 8, n * 8 * f, 1),
+               "a2a_rows": (n * (D + 1) * 4, n * (D + 1) * 4 * f, 2),
+               "a2a_grads": (n * (D + c1) * 4, n * (D + c1) * 4 * f, 2),
+               "allreduce_dense": (dense_params * 4, 2 * dense_params * 4 * f, 1)}
+        rows.append({"world": G, "per_collective": {
+            k: {"bytes_per_step": b, "remote_bytes_per_step": r, "calls_per_step": c,
+                "predicted_us": round(link_model_us(k, r, G, c), 1)} for k, (b, r, c) in per.items()},
+            "predicted_exchange_us_total": round(sum(link_model_us(k, r, G, c) for k, (b, r, c) in per.items()), 1)})
+    return {"workload": "row-sharded DeepFM step, batch %d per GPU, %d slots, dim %d, table %s" % (B, S, D, table),
+            "model": "remote bytes / (links x %.0f GB/s) + 8 us per call; all-to-all uses min(G-1, %d) links, ring "
+                     "all-reduce one" % (XGMI_LINK_GBS, XGMI_LINKS), "worlds": rows}
+
+
 def empty_bracket_us(dev, n=50):
     """Median elapsed time between two torch timing events recorded back to back on the current stream (microseconds)."""
     ts = []
@@ -375,6 +412,9 @@ def main():
     ap.add_argument("--non-lazy-adam", action="store_true",
                     help="single GPU: the reference's DYGRAPH optimizer (deepfm/dygraph_model.py:61-65, Adam lazy_mode=False"
                          " — every row of both tables decays every step: 6 N (D+1) 4 B of extra traffic) instead of lazy Adam")
+    ap.add_argument("--dry-links", action="store_true",
+                    help="print the analytic per-collective xGMI volumes / times of the row-sharded step for 2, 4, 8 GPUs "
+                         "(no GPU needed) and exit")
     ap.add_argument("--shared-table", action="store_true",
                     help="layout (2b) of SURVEY §8(d), the reference's own: ONE table of rows-per-table (+1) rows shared "
                          "by the 26 slots (deepfm/config.yaml:48-50 with --dim 9, benchmark.yaml:21 with --dim 10)")
@@ -387,6 +427,9 @@ def main():
                     help="--table ps: table rows PER GPU (10^10 / 8 = 1.25e9 = 160 GB of 128-B records)")
     args = ap.parse_args()
 
+    if args.dry_links:
+        print(json.dumps(dry_links(args.batch, 26, args.dim, "ps" if args.table in ("auto", "ps") else "adam")))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_spawn(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -542,6 +585,9 @@ def main():
     if dist is not None:
         exch = model.comm.stats_summary(max(n_brk, 1))
         model.comm.stats = None
+        for tag, e in exch.items():      # the link model next to the measurement (self-diagnosing first multi-GPU run)
+            e["measured_us"] = e.get("us_per_step")
+            e["predicted_us"] = round(link_model_us(tag, e["remote_bytes_per_step"], world, e["calls_per_step"]), 1)
     if standin:
         model.timers = {}
     if dist is not None:
@@ -651,7 +697,12 @@ def main():
                          "xgmi_links_per_gpu": 7, "xgmi_link_GBs": 153.0,
                          # per step and per GPU (rank 0's view): bytes handed to each collective, bytes that leave the
                          # GPU, microseconds on the stream, egress GB/s = remote bytes / time (all 7 links together)
-                         "per_collective": exch}} if exch is not None else {}),
+                         "per_collective": exch,
+                         "predicted_us": round(sum(e["predicted_us"] for e in exch.values()), 1),
+                         "measured_us": round(sum((e["measured_us"] or 0.0) for e in exch.values()), 1),
+                         "model": "remote bytes / (links x 153 GB/s) + 8 us per call: all-to-all on min(G-1, 7) links, "
+                                  "ring all-reduce on one (bench.py --dry-links prints it for 2 / 4 / 8 GPUs)"}}
+           if exch is not None else {}),
         "mlp_gemm": {"bound": "mfma", "achieved": gemm_tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": gemm_tf / FP32_MFMA_PEAK_TF, "flops_executed_per_step": 3 * mlp_flops(B, sizes)},
     }

@@ -84,3 +84,24 @@ def test_eight_ranks_on_the_ps_table_print_the_exchange_fields():
     assert abs(pc["a2a_rows"]["bytes_per_step"] / pc["a2a_ids"]["bytes_per_step"] / ((17 * 4) / 8) - 1) < 0.2
     assert abs(pc["a2a_grads"]["bytes_per_step"] / pc["a2a_ids"]["bytes_per_step"] / ((18 * 4) / 8) - 1) < 0.2
     assert 0.0 < d["config"]["loss"] < 5.0
+    # the link model next to every collective: predicted from the remote bytes, 7 links at 8 ranks
+    for tag, e in pc.items():
+        want = e["remote_bytes_per_step"] / ((1 if tag.startswith("allreduce") else 7) * 153e9) * 1e6 + 8.0 * e["calls_per_step"]
+        assert abs(e["predicted_us"] - want) < 0.06 and "measured_us" in e, tag
+    assert abs(ex["predicted_us"] - sum(e["predicted_us"] for e in pc.values())) < 0.3 and "measured_us" in ex
+
+
+
+def test_dry_links_prints_the_analytic_exchange_table():
+    """bench.py --dry-links: per-GPU, per-step exchange volumes and link-model times for 2 / 4 / 8 GPUs, no GPU, no ranks
+    — SURVEY §8(d): at G = 8 the rows coming back are B S D 4 (G-1)/G = 95.4 MB (+ the first-order column)."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--dry-links"], capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [w["world"] for w in d["worlds"]] == [2, 4, 8]
+    w8 = d["worlds"][2]["per_collective"]
+    assert abs(w8["a2a_ids"]["remote_bytes_per_step"] - 65536 * 26 * 8 * 7 / 8) < 1
+    assert abs(w8["a2a_rows"]["remote_bytes_per_step"] - 65536 * 26 * 17 * 4 * 7 / 8) < 1
+    assert 80 < w8["a2a_rows"]["predicted_us"] < 140          # ~101 MB over 7 x 153 GB/s
+    assert d["worlds"][0]["predicted_exchange_us_total"] > d["worlds"][2]["predicted_exchange_us_total"]
