@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include "rec_common.h"
+#include "fm_tile.h"
 
 namespace rec {
 
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void fold_partials_kernel(const float* __re
 // blocks per CU (0 = occupancy limit; 2 and 3 measured slower), REC_FM_NT = 1 streams feat / d_feat with
 // non-temporal accesses (fm_bwd 71.3 -> 64.5 us, fm_fwd 73.8 -> 72.9 us).
 struct FmTune {
-  int fwd_bpc, bwd_bpc, nt, fwd_nt, rg_nt;
+  int fwd_bpc, bwd_bpc, nt, fwd_nt, rg_nt, tile;
 };
 static const FmTune& tune() {
   static const FmTune t = [] {
@@ -453,8 +454,9 @@ static const FmTune& tune() {
     const int nt = geti("REC_FM_NT", 1);
     // REC_FM_FWD_NT: feat stores of the forward streamed (1) or cached (0); REC_FM_BWD_RG_NT: the backward's row
     // gradients streamed (1) or cached (0) — measured in-step, profiles/r03_fm_instep.txt
+    // REC_FM_TILE=0: narrow rows (D 9 / 10 / 11 ...) on the row-group kernels instead of the block-tile kernels (fm_tile.h)
     return FmTune{geti("REC_FM_FWD_BPC", 0), geti("REC_FM_BWD_BPC", 0), nt, geti("REC_FM_FWD_NT", nt),
-                  geti("REC_FM_BWD_RG_NT", 0)};
+                  geti("REC_FM_BWD_RG_NT", 0), geti("REC_FM_TILE", 1)};
   }();
   return t;
 }
@@ -469,6 +471,14 @@ static int check_desc(const rec_deepfm_desc* d) {
               d->row_stride, d->emb_dim);
   REC_REQUIRE(d->num_rows > 0, REC_EINVAL, "num_rows must be > 0");
   return REC_OK;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// narrow rows -> the block-tile kernels of fm_tile.h (everything they do not cover stays on the row-group kernels)
+static bool fm_tile_shape(const rec_deepfm_desc* d) {
+  return tune().tile && d->emb_dim <= kFmTileMaxD && d->emb_dim % 4 != 0 && !d->compact_dense &&
+         kFmTileS * d->num_slots <= kBlock * kFmTileLook && d->num_dense * d->emb_dim + d->num_dense <= kBlock;
 }
 
 }  // namespace rec
@@ -494,6 +504,26 @@ extern "C" int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids
   const int64_t feat_ld = desc->feat_stride > 0 ? desc->feat_stride : (int64_t)FP * D;
   REC_REQUIRE(feat_ld >= (int64_t)FP * D && (desc->feat_stride <= 0 || feat_ld % 4 == 0), REC_EINVAL,
               "feat_stride %lld must be a multiple of 4 and >= %d fields x %d", (long long)feat_ld, FP, D);
+  if (fm_tile_shape(desc) && aligned16(feat)) {
+    const int P = fm_tile_pitch(FP, D, feat_ld);
+    const size_t shmem = (size_t)fm_tile_fwd_lds(S, Dn, D, P).total_bytes;
+    if (shmem <= 64 * 1024) {
+      const bool v4 = desc->row_stride % 4 == 0 && desc->row_stride >= ((D + 3) & ~3) && aligned16(W);
+      const int64_t ntiles = (desc->batch + kFmTileS - 1) / kFmTileS;
+#define REC_FWD_TILE(V4_, NT_)                                                                                     \
+  {                                                                                                                \
+    int64_t grid = resident_blocks(fm_fwd_tile_kernel<V4_, NT_>, kBlock, shmem);                                   \
+    if (grid > ntiles) grid = ntiles;                                                                              \
+    hipLaunchKernelGGL((fm_fwd_tile_kernel<V4_, NT_>), dim3((unsigned)grid), dim3(kBlock), shmem, st, desc->batch, \
+                       S, Dn, D, feat_ld, desc->row_stride, w1_stride, desc->num_rows, desc->padding_idx, ids,     \
+                       dense, W, W1, dense_w, dense_w_one, slot_offset, y1, y2, feat, sum_emb, status);            \
+  }
+      if (v4) { if (tune().fwd_nt) REC_FWD_TILE(true, true) else REC_FWD_TILE(true, false) }
+      else { if (tune().fwd_nt) REC_FWD_TILE(false, true) else REC_FWD_TILE(false, false) }
+#undef REC_FWD_TILE
+      return check_launch("rec_deepfm_fm_fwd (tile)");
+    }
+  }
   return dispatch_row_shape(D, desc->row_stride, [&](auto vec, auto lanes) -> int {
     constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;
     constexpr int SPW = kWave / (LANES * fs_for<LANES>());
@@ -588,6 +618,28 @@ static int fm_bwd_impl(const rec_deepfm_desc* desc, const float* dense, const fl
       (void)hipMemsetAsync(d_dense_w_one, 0, (size_t)Dn * sizeof(float), st);
     }
     return REC_OK;
+  }
+  if (fm_tile_shape(desc) && !row_rank && aligned16(row_grad) && K > 0) {
+    const size_t shmem = (size_t)fm_tile_bwd_lds(S, Dn, D).total_floats * sizeof(float);
+    const bool v4 = feat_ld % 4 == 0 && aligned16(feat) && aligned16(d_feat_dnn);
+    const int64_t ntiles = (desc->batch + kFmTileS - 1) / kFmTileS;
+    float* partial = (float*)workspace;
+    int grid = 1;
+#define REC_BWD_TILE(V4_, NT_)                                                                                     \
+  {                                                                                                                \
+    /* persistent blocks (one block per tile was measured: fwd equal, bwd 59 -> 66 us — 4096 partial columns) */   \
+    int64_t g = resident_blocks(fm_bwd_tile_kernel<V4_, NT_>, kBlock, shmem);                                      \
+    if (g > ntiles) g = ntiles;                                                                                    \
+    if (g > kMaxBlocks) g = kMaxBlocks;                                                                            \
+    grid = (int)g;                                                                                                 \
+    hipLaunchKernelGGL((fm_bwd_tile_kernel<V4_, NT_>), dim3(grid), dim3(kBlock), shmem, st, desc->batch, S, Dn, D, \
+                       feat_ld, dense, feat, sum_emb, d_feat_dnn, dy1, dy2, dense_w, row_grad, partial);           \
+  }
+    if (v4) { if (tune().nt) REC_BWD_TILE(true, true) else REC_BWD_TILE(true, false) }
+    else { REC_BWD_TILE(false, false) }
+#undef REC_BWD_TILE
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(K), dim3(kBlock), 0, st, partial, grid, Dn * D, d_dense_w, d_dense_w_one);
+    return check_launch("rec_deepfm_fm_bwd (tile)");
   }
   return dispatch_row_shape(D, D, [&](auto vec, auto lanes) -> int {
     constexpr int VEC = decltype(vec)::value, LANES = decltype(lanes)::value;

@@ -139,7 +139,15 @@ class FM:
             self.embedding = self.rec[:, :D]
             self.embedding_one = self.rec[:, D:D + 1]
             return
-        self.rec_width = _round_up(D + 3, 32)
+        # D + 3 <= 16 (the reference's own D 9 / D 10): the record is ONE 64-byte half line — the fabric fetches 64-byte
+        # requests for it (TCC_EA0_RDREQ_64B), so a lookup moves half the bytes of a 128-byte record; wider rows keep
+        # whole lines.  REC_TABLE_RECORD_FLOATS overrides (a multiple of 4 >= D + 3).
+        self.rec_width = 16 if D + 3 <= 16 else _round_up(D + 3, 32)
+        forced = int(os.environ.get("REC_TABLE_RECORD_FLOATS", "0"))
+        if forced:
+            if forced % 4 or forced < D + 3:
+                raise ValueError("REC_TABLE_RECORD_FLOATS=%d: need a multiple of 4 >= D + 3 = %d" % (forced, D + 3))
+            self.rec_width = forced
         self.rec = torch.zeros(N, self.rec_width, dtype=torch.float32, device=device)
         self.embedding = self.rec[:, :D]
         self.embedding_one = self.rec[:, D:D + 1]

@@ -186,6 +186,10 @@ def test_din_train_steps_vs_oracle(engine_lib):
     p = {k: N_(v).copy() for k, v in m.state_dict().items()}
     p0 = {k: v.copy() for k, v in p.items()}
     att = ([N_(w).copy() for w in m.attention_w], [N_(b).copy() for b in m.attention_b])
+    # the same two steps in float64 (the oracle follows its inputs' dtype): the summation-order-independent truth, and
+    # with it THIS test's measured fp32 noise floor = |float32 oracle - float64 oracle| per tensor
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    att64 = ([w.astype(np.float64) for w in att[0]], [b.astype(np.float64) for b in att[1]])
     lr = 0.5
     for step in range(2):
         hi, hc, ti, tc, mask, label = _din_problem(rng, B, Tn, ni, nc)
@@ -195,10 +199,14 @@ def test_din_train_steps_vs_oracle(engine_lib):
         np.testing.assert_allclose(N_(loss)[0], Dn.bce_with_logits_mean(grads["_logit"], label), rtol=1e-5)
         for k in p:
             p[k] = (p[k] - lr * np.asarray(grads[k]).reshape(p[k].shape)).astype(np.float32)
-    for k, v in m.state_dict().items():      # two SGD steps: the accumulated update against the oracle's
-        d_got, d_want = N_(v).astype(np.float64) - p0[k], p[k].astype(np.float64) - p0[k]
-        np.testing.assert_allclose(d_got, d_want, rtol=1e-5, err_msg=k,      # + the fp32 rounding of two stored steps
-                                   atol=1e-5 * np.abs(d_want).max() + 2.4e-7 * np.abs(p0[k]).max())
+        g64 = Dn.backward(p64, att64, hi, hc, ti, tc, mask, label.astype(np.float64))
+        for k in p64:
+            p64[k] = p64[k] - lr * np.asarray(g64[k]).reshape(p64[k].shape)
+    for k, v in m.state_dict().items():      # two SGD steps: the accumulated update against the float64 trajectory's,
+        d_got, d_want = N_(v).astype(np.float64) - p0[k], p64[k] - p0[k]       # 1e-5 of its scale + the fp32 rounding of
+        floor = float(np.abs((p[k].astype(np.float64) - p0[k]) - d_want).max())  # two stored steps + the float32 oracle's
+        np.testing.assert_allclose(d_got, d_want, rtol=1e-5, err_msg=k,           # own distance from the truth
+                                   atol=1e-5 * np.abs(d_want).max() + 2.4e-7 * np.abs(p0[k]).max() + 2.0 * floor)
 
 
 def test_din_train_step_graphed_equals_eager(engine_lib):
