@@ -1025,6 +1025,40 @@ int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, const int64_
                           int32_t num_thresholds, float* loss_out, float* pred_out, int32_t* status, void* workspace,
                           size_t workspace_bytes, void* stream, void* side_stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The whole DIN train step behind one call — the per-batch body of tools/trainer.py:148-152 for models/rank/din:
+ * train_forward (din/dygraph_model.py:85-100 = net.py:139-184 + binary_cross_entropy_with_logits), loss.backward(),
+ * SGD step (din/dygraph_model.py:64-73; the learning rate of PiecewiseDecay is the caller's: `lr`).  Issues the ~25
+ * rec_* calls of paddlerec_amd/din.py:_step on `stream` (csrc/din_step.hip), bit-identical to it; at the reference's batch
+ * size (din/config.yaml: 32) the seven embedding updates are one rec_sparse_sgd_small_multi launch, larger batches sort.
+ * All pointers are device memory the caller owns: seven contiguous [rows, dim] tables (three item tables, three category
+ * tables, item_b [item_rows, 1]: independent parameters), the frozen attention MLP (att_w1 [4E, h1] AND
+ * its transpose att_w1_t [h1, 4E] — rec_transpose_f32 makes one —, b1, w2 [h1, h2], b2, w3 [h2], b3: not registered
+ * parameters in the reference's dygraph mode, App. B-9), the four registered Linear layers as [in, out] + bias with their
+ * gradient buffers, and the flat parameter / gradient buffers holding those eight tensors (rec_sgd_dense walks them).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t item_dim, cat_dim;            /* E = item_dim + cat_dim */
+  int64_t item_rows, cat_rows;
+  int32_t att_hidden1, att_hidden2;     /* attention MLP 4E -> h1 -> h2 -> 1 (80, 40) */
+  int32_t mlp_hidden1, mlp_hidden2;     /* top MLP 2E -> m1 -> m2 -> 1 (80, 40), sigmoid */
+  float *w_hist_item, *w_hist_cat, *w_tgt_item_seq, *w_tgt_cat_seq, *w_tgt_item, *w_tgt_cat, *w_item_b;
+  const float *att_w1, *att_w1_t, *att_b1, *att_w2, *att_b2, *att_w3, *att_b3;
+  float *w_con, *b_con, *w_l0, *b_l0, *w_l1, *b_l1, *w_l2, *b_l2;                  /* linearCon [E,E], linear_0..2 */
+  float *g_w_con, *g_b_con, *g_w_l0, *g_b_l0, *g_w_l1, *g_b_l1, *g_w_l2, *g_b_l2;  /* their gradients (written) */
+  float *flat_param, *flat_grad;
+  int64_t flat_numel;
+} rec_din_net;
+int rec_din_train_step_workspace_bytes(const rec_din_net* net, int64_t batch, int32_t max_len, size_t* bytes);
+/* hist_item / hist_cat / target_item_seq / target_cat_seq / mask [batch, max_len] i64 (mask 0 valid, -1e9 padding),
+ * target_item / target_cat [batch] i64, label [batch] f32 -> loss_out [1] (mean BCE), pred_out [batch] = sigmoid(logit).
+ * status: the sticky out-of-range flag of the lookups. */
+int rec_din_train_step(const rec_din_net* net, int64_t batch, int32_t max_len, const int64_t* hist_item,
+                       const int64_t* hist_cat, const int64_t* target_item, const int64_t* target_cat, const float* label,
+                       const int64_t* mask, const int64_t* target_item_seq, const int64_t* target_cat_seq, float lr,
+                       float* loss_out, float* pred_out, int32_t* status, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

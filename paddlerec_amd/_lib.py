@@ -36,6 +36,19 @@ class DeepFMNet(C.Structure):
                 ("layer0_width", C.c_int32)]
 
 
+class DinNet(C.Structure):
+    """rec_din_net (include/recengine.h): the model of rec_din_train_step as pointers into caller-owned memory."""
+    _fields_ = ([("item_dim", C.c_int32), ("cat_dim", C.c_int32), ("item_rows", C.c_int64), ("cat_rows", C.c_int64),
+                 ("att_hidden1", C.c_int32), ("att_hidden2", C.c_int32), ("mlp_hidden1", C.c_int32),
+                 ("mlp_hidden2", C.c_int32)] +
+                [(n, C.c_void_p) for n in (
+                    "w_hist_item", "w_hist_cat", "w_tgt_item_seq", "w_tgt_cat_seq", "w_tgt_item", "w_tgt_cat", "w_item_b",
+                    "att_w1", "att_w1_t", "att_b1", "att_w2", "att_b2", "att_w3", "att_b3",
+                    "w_con", "b_con", "w_l0", "b_l0", "w_l1", "b_l1", "w_l2", "b_l2",
+                    "g_w_con", "g_b_con", "g_w_l0", "g_b_l0", "g_w_l1", "g_b_l1", "g_w_l2", "g_b_l2",
+                    "flat_param", "flat_grad")] + [("flat_numel", C.c_int64)])
+
+
 class AdamHyper(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("step", C.c_int64)]
@@ -259,6 +272,9 @@ SIGNATURES = {
     "rec_ctr_head_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(C.c_size_t)]),
     "rec_ctr_head_fwd_bwd": (C.c_int, [_I64, _I32, _I64, _P, _I64, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float,
                                        _I32, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _SZ, _P]),
+    "rec_din_train_step_workspace_bytes": (C.c_int, [C.POINTER(DinNet), _I64, _I32, C.POINTER(C.c_size_t)]),
+    "rec_din_train_step": (C.c_int, [C.POINTER(DinNet), _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
+                                     _SZ, _P]),
     "rec_deepfm_train_step_workspace_bytes": (C.c_int, [C.POINTER(DeepFMNet), _I64, C.POINTER(C.c_size_t)]),
     "rec_deepfm_train_step": (C.c_int, [C.POINTER(DeepFMNet), _I64, _P, _P, _P, C.POINTER(AdamHyper), _P, _P, _I32, _P, _P,
                                         _P, _P, _SZ, _P, _P]),

@@ -195,6 +195,53 @@ class DINLayer:
                 return entry.replay(inputs, 0, float(lr))
         return run()
 
+    def c_net(self):
+        """rec_din_net over this layer's tensors (rebuilt when the attention weights changed: it holds their transpose)."""
+        from . import _lib
+        ver = tuple(w._version for w in self.attention_w)
+        cached = getattr(self, "_c_net", None)
+        if cached is not None and cached[0] == ver:
+            return cached[1]
+        p = self.params
+        net = _lib.DinNet()
+        net.item_dim, net.cat_dim = self.item_emb_size, self.cat_emb_size
+        net.item_rows, net.cat_rows = self.item_count, self.cat_count
+        net.att_hidden1, net.att_hidden2 = self.attention_w[0].shape[1], self.attention_w[1].shape[1]
+        net.mlp_hidden1, net.mlp_hidden2 = p["linear_0.weight"].shape[1], p["linear_1.weight"].shape[1]
+        for field, name in (("w_hist_item", "hist_item_emb_attr"), ("w_hist_cat", "hist_cat_emb_attr"),
+                            ("w_tgt_item_seq", "target_item_seq_emb_attr"), ("w_tgt_cat_seq", "target_cat_seq_emb_attr"),
+                            ("w_tgt_item", "target_item_emb_attr"), ("w_tgt_cat", "target_cat_emb_attr"),
+                            ("w_item_b", "item_b_attr")):
+            setattr(net, field, p[name + ".weight"].data_ptr())
+        w1t = self.attention_w[0].t().contiguous()
+        net.att_w1, net.att_w1_t = self.attention_w[0].data_ptr(), w1t.data_ptr()
+        net.att_b1, net.att_w2, net.att_b2 = (self.attention_b[0].data_ptr(), self.attention_w[1].data_ptr(),
+                                               self.attention_b[1].data_ptr())
+        net.att_w3, net.att_b3 = self.attention_w[2].data_ptr(), self.attention_b[2].data_ptr()
+        for tag, name in (("con", "linearCon"), ("l0", "linear_0"), ("l1", "linear_1"), ("l2", "linear_2")):
+            setattr(net, "w_" + tag, p[name + ".weight"].data_ptr())
+            setattr(net, "b_" + tag, p[name + ".bias"].data_ptr())
+            setattr(net, "g_w_" + tag, self._gb[name + ".weight"].data_ptr())
+            setattr(net, "g_b_" + tag, self._gb[name + ".bias"].data_ptr())
+        net.flat_param, net.flat_grad, net.flat_numel = (self._dense.data_ptr(), self._dense_grad.data_ptr(),
+                                                         self._dense.numel())
+        self._c_net = (ver, net, w1t)              # w1t: kept alive with the struct that points at it
+        return net
+
+    def train_step_c(self, hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq,
+                     target_cat_seq, base_lr=0.85):
+        """train_step through rec_din_train_step: ONE foreign call per step — what a non-Python binder of
+        include/recengine.h gets (csrc/din_step.hip).  Same entry points, arguments and order as _step: bit-identical."""
+        lr = self.learning_rate(self.step_count, base_lr)
+        self.step_count += 1
+        if getattr(self, "_ws_c", None) is None:
+            self._ws_c = self.k.Workspace(self.device)
+        B, T = hist_item_seq.shape
+        return self.k.din_train_step(self.c_net(), hist_item_seq, hist_cat_seq, target_item.reshape(-1).contiguous(),
+                                     target_cat.reshape(-1).contiguous(), label.reshape(-1).contiguous(),
+                                     mask.reshape(B, T).contiguous(), target_item_seq, target_cat_seq, lr, self._ws_c,
+                                     status=self.status)
+
     def train_step_graphed(self, hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq,
                            target_cat_seq, base_lr=0.85):
         """train_step replayed from a hipGraph per input signature (paddlerec_amd/graph.py): at the shipped batch size

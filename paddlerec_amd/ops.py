@@ -153,6 +153,38 @@ def deepfm_train_step(net, ids, dense, label, step, ws, lr=1e-3, beta1=0.9, beta
     return loss, pred
 
 
+def din_train_step(net, hist_item, hist_cat, target_item, target_cat, label, mask, target_item_seq, target_cat_seq, lr, ws,
+                   status=None, out=None):
+    """The whole DIN train step through ONE C-ABI call (rec_din_train_step).  net: a filled _lib.DinNet (the caller keeps
+    the tensors it points into alive).  ids / mask [B,T] i64, targets [B] i64, label [B] f32.  -> (loss [1], pred [B,1])."""
+    B, T = hist_item.shape
+    for t, n in ((hist_item, "hist_item"), (hist_cat, "hist_cat"), (target_item_seq, "target_item_seq"),
+                 (target_cat_seq, "target_cat_seq"), (mask, "mask")):
+        _chk(t, torch.int64, n, (B, T))
+    for t, n in ((target_item, "target_item"), (target_cat, "target_cat")):
+        _chk(t, torch.int64, n)
+        if t.numel() != B:
+            raise RecError("%s must have one id per sample" % n)
+    _chk(label, torch.float32, "label")
+    if label.numel() != B:
+        raise RecError("label must have one value per sample")
+    dev = hist_item.device
+    if out is None:
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        pred = torch.empty(B, 1, dtype=torch.float32, device=dev)
+    else:
+        loss, pred = out
+    if status is None:
+        status = new_status(dev)
+    nbytes = C.c_size_t(0)
+    check(lib().rec_din_train_step_workspace_bytes(C.byref(net), B, T, C.byref(nbytes)), "rec_din_train_step_workspace_bytes")
+    w = ws.get(nbytes.value)
+    check(lib().rec_din_train_step(C.byref(net), B, T, _p(hist_item), _p(hist_cat), _p(target_item), _p(target_cat),
+                                   _p(label), _p(mask), _p(target_item_seq), _p(target_cat_seq), float(lr), _p(loss),
+                                   _p(pred), _p(status), _p(w), C.c_size_t(w.numel()), _stream()), "rec_din_train_step")
+    return loss, pred
+
+
 SUPPORTS_FEAT_LD = True       # deepfm_fm_fwd / _bwd take feat_ld (a padded sample stride of feat)
 
 

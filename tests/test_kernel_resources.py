@@ -34,3 +34,9 @@ def test_fm_kernels_keep_their_occupancy(tmp_path):
     assert bwd and fwd, sorted(occ)[:10]
     assert min(bwd) >= 3, "fm_bwd_kernel<4,4,2,*,false> fell to %d waves per SIMD" % min(bwd)
     assert min(fwd) >= 4, "fm_fwd_kernel<4,4,1,*> fell to %d waves per SIMD" % min(fwd)
+    # the block-tile kernels for narrow rows (fm_tile.h): 6 blocks of 256 threads per CU is what their 16-sample tiles are
+    # sized for (round 5: 117 VGPRs = 4 waves per SIMD without the launch bound, 64 -> 52 us with it)
+    tile_f = [v for k, v in occ.items() if "fm_fwd_tile_kernel" in k]
+    tile_b = [v for k, v in occ.items() if "fm_bwd_tile_kernel" in k]
+    assert len(tile_f) == 4 and len(tile_b) >= 3, sorted(occ)
+    assert min(tile_f) >= 6 and min(tile_b) >= 6, (tile_f, tile_b)
