@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu, pytest.mark.first_hw_run]
+pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 

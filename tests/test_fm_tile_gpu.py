@@ -10,7 +10,7 @@ import torch
 from helpers import make_deepfm_problem
 from oracle import deepfm_ref as R
 
-pytestmark = [pytest.mark.gpu, pytest.mark.first_hw_run]
+pytestmark = pytest.mark.gpu
 DEV = "cuda"
 RTOL, ATOL = 1e-5, 2e-7
 

@@ -321,7 +321,6 @@ print("custom ops through the shim: ALL OK")
 
 
 @pytest.mark.gpu
-@pytest.mark.first_hw_run
 def test_custom_ops_through_the_shim_gpu(engine_lib):
     r = subprocess.run([sys.executable, "-c", GPU_SCRIPT % dict(repo=REPO)], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
@@ -330,7 +329,6 @@ def test_custom_ops_through_the_shim_gpu(engine_lib):
 
 @needs_trees
 @pytest.mark.gpu
-@pytest.mark.first_hw_run
 def test_reference_trainer_on_patched_deepfm_matches_oracle_gpu(tmp_path, engine_lib):
     """tools/trainer.py (unmodified) + the patched deepfm/net.py on the HIP kernels through the shim == the oracle's
     trajectory from the same initial parameters (the check the unpatched entry-point test applies)."""
@@ -340,7 +338,6 @@ def test_reference_trainer_on_patched_deepfm_matches_oracle_gpu(tmp_path, engine
 
 @needs_trees
 @pytest.mark.gpu
-@pytest.mark.first_hw_run
 def test_patched_net_files_train_like_the_unpatched_ones_gpu(tmp_path, engine_lib):
     # fp32 on the device: the fused kernels sum in a different order than the op-by-op graph
     _patched_equals_unpatched(tmp_path, ["deepfm", "dcn_v2", "dcn_mix", "din"], gpu=True, tol=2e-5)

@@ -97,7 +97,6 @@ def test_static_gpubox_trainer_wide_deep_config_gpups_cpu_backend(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.first_hw_run
 @pytest.mark.skipif(not os.path.isfile(os.path.join(REF, MODELS["wide_deep"][0])), reason="wide_deep not staged")
 def test_static_gpubox_trainer_wide_deep_config_gpups_on_the_hip_kernels(tmp_path, engine_lib):
     _check(tmp_path, gpu=True, model="wide_deep")

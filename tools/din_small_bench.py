@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """DIN train step at the shipped batch size (din/config.yaml: 32 samples, history up to 152): eager against the recorded
-call list (REC_STEP_PLAN) against the hipGraph replay.  Prints one line per mode."""
+call list (REC_STEP_PLAN) against the hipGraph replay against ONE C-ABI call per step (rec_din_train_step).  Prints one
+line per mode."""
 import os
 import sys
 
@@ -39,10 +40,11 @@ def problem():
 
 
 args = problem()
-for mode in ("plan", "eager", "graph", "plan"):       # plan twice: the first measurement of a process carries its warm-up
+for mode in ("plan", "eager", "graph", "c-abi", "plan", "c-abi"):   # twice: the first measurement of a process carries its warm-up
     os.environ["REC_STEP_PLAN"] = "0" if mode == "eager" else "1"
     m = DINLayer(64, 64, "sigmoid", False, True, 63001, 801, device=DEV)
-    fn = (lambda: m.train_step_graphed(*args)) if mode == "graph" else (lambda: m.train_step(*args))
+    fn = ((lambda: m.train_step_graphed(*args)) if mode == "graph" else
+          (lambda: m.train_step_c(*args)) if mode == "c-abi" else (lambda: m.train_step(*args)))   # c-abi: rec_din_train_step
     t = timeit(fn)
     print("DIN train step B=%d T=%d %-5s: %.3f ms  (%.1f k samples/s)" % (B, T, mode, t, B / t))
     del m
