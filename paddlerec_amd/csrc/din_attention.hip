@@ -38,6 +38,7 @@ struct DinArgs {
   float* act1;             // [B,T,H1] layer-1 activations, saved for the backward when non-null
   int32_t* status;
   float* part;             // tile-split forward (few samples): [B * tiles][E + 2] = pooled sum / l, m, l of every tile
+  unsigned int* ticket;    // large batches with a workspace: zeroed counter the blocks draw their next sample from
 };
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
@@ -343,7 +344,7 @@ struct DinCt {
   static constexpr int kB2 = kB1 + H1;
   static constexpr int kLp = kB2 + H2C;                  // [NT2][32] layer-3 partial dots
   static constexpr int kEs = kLp + NT2 * kDinTP;         // [32] exp weights of the tile, [32] f, [33] l_run, [34] m_run
-  static constexpr int kRed = kEs + 40;                  // [NPART][E] end-of-sample combine
+  static constexpr int kRed = kEs + 44;                  // (es[35] skip flag, [36..39] mask scan, [40..41] sample tickets)  [NPART][E] end-of-sample combine
   static constexpr int kIds = (kRed + NPART * E + 1) & ~1;   // int64 [2][5][32]: ids + mask of this / the next tile
   static constexpr int kSall = kIds + 2 * 2 * 5 * kDinTP;
   static size_t lds_bytes(int T) { return sizeof(float) * ((size_t)kSall + (size_t)T); }
@@ -479,7 +480,24 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
   const bool split = a.part != nullptr;
   const int NTL = (T + kDinTP - 1) / kDinTP;
   const int64_t W = split ? a.B * NTL : a.B;
-  int64_t w = blockIdx.x;
+  // Samples cost what their history holds (1 .. T/32 walked tiles): dealt round-robin, the slowest block of a B 4096
+  // batch of uniform lengths works on 26 tiles while the average works on 17.  With a ticket counter (a.ticket, zeroed by
+  // the launcher in the caller's workspace) a block draws its next sample when it finishes one — the draw is issued at
+  // the top of a sample's last tile, one sample ahead, so its latency never shows.  Which block computes a sample does
+  // not change the sample's arithmetic.  Without a workspace: round-robin as before.
+  const bool dyn = !split && a.ticket != nullptr;
+  int* ies = reinterpret_cast<int*>(es);
+  int64_t w = blockIdx.x, wn = w + gridDim.x;
+  if (dyn) {
+    if (tid == 0) {
+      ies[40] = (int)atomicAdd(a.ticket, 1u);
+      ies[41] = (int)atomicAdd(a.ticket, 1u);
+    }
+    __syncthreads();
+    w = ies[40];
+    wn = ies[41];
+    __syncthreads();
+  }
   if (w >= W) return;
   int64_t b = split ? w / NTL : w;
   int t0 = split ? (int)(w % NTL) * kDinTP : 0, buf = 0;
@@ -492,17 +510,70 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
   float m_run = -INFINITY, l_run = 0.f;     // live in wave 0
   float pool = 0.f;                         // thread (part, d): partial of out[b][d] over its positions
   const int pd = tid % E, part = tid / E;
+  // A tile whose 32 positions are ALL padding (mask <= -1e6: the reader's -1e9, din/dinReader.py:81-84) behind a tile that
+  // already produced a finite running maximum contributes exactly nothing: its logits are <= -8.8e4 + O(1), so its
+  // weights exp(s - m) underflow to 0.0f and the online-softmax state (m, l, pool) does not move.  Such tiles are not
+  // computed (block-uniform flag, decided by wave 0 for the NEXT tile of the same sample): their weights are written as
+  // 0, their layer-1 activations are not saved — the backward skips a tile whose 32 saved weights are all zero.  Padding
+  // in front of the first valid position, and a history that is padding only (uniform weights, App. B-11), are computed
+  // as before.  The batches the reference's reader builds (lengths 1..152 padded to the batch maximum) are mostly such
+  // tiles.
+  bool skip = false;
+  // ... and the block does not even walk the padded TAIL of a history: Teff = 1 + the last position with mask > -1e6 (T
+  // when there is none) ends the sample's tile loop.  The scan of the next sample's mask row is issued at the top of the
+  // current sample's last tile and folded at its end (es[36..39]: one partial per wave).
+  //  (walked: everything up to the last position with mask > -1e6; skipped only when some position has mask > -1e5 —
+  //   a gap of >= 9e5 * E^-0.5 between a kept logit and the dropped ones, far beyond the 104 at which expf underflows)
+  auto scan_issue = [&](int64_t bb) -> int {
+    int last = 0, any = 0;
+    for (int t = tid; t < T; t += kBlock) {
+      const int64_t mv = a.mask[bb * T + t];
+      if (mv > (int64_t)-1000000) last = t + 1;                   // ascending t: the last hit wins
+      if (mv > (int64_t)-100000) any = 1 << 20;
+    }
+    return last | any;
+  };
+  auto scan_fold = [&](int sc) {            // wave maximum of the position, OR of the flag -> es[36 + wave]
+    int last = sc & 0xFFFFF, any = sc >> 20;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+      last = max(last, __shfl_xor(last, o, kWave));
+      any |= __shfl_xor(any, o, kWave);
+    }
+    if (lane == 0) es[36 + seg] = (float)(last | (any << 20));
+  };
+  auto scan_read = [&]() -> int {
+    int last = 0, any = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int v = (int)es[36 + k];
+      last = max(last, v & 0xFFFFF);
+      any |= v >> 20;
+    }
+    return (any && last > 0) ? last : T;
+  };
+  int Teff = T;
+  if (!split) {
+    scan_fold(scan_issue(b));
+    for (int t = tid; t < T; t += kBlock) sall[t] = -INFINITY;
+    __syncthreads();
+    Teff = scan_read();
+  }
 
   while (true) {
     int64_t nb = b;
     int nt0 = t0 + kDinTP;
-    const bool last_tile = split || nt0 >= T;
-    const int64_t nw = w + gridDim.x;
+    const bool last_tile = split || nt0 >= Teff;
+    const int64_t nw = split ? w + gridDim.x : wn;
+    int tk = 0;
+    if (dyn && last_tile && tid == 0) tk = (int)atomicAdd(a.ticket, 1u);     // the sample after the next one
     if (split) { nb = nw / NTL; nt0 = (int)(nw % NTL) * kDinTP; }
     else if (last_tile) { nb = nw; nt0 = 0; }
     const bool has_next = split ? nw < W : nb < a.B;
     int64_t idv = 0;
     if (has_next) idv = ids_issue(nb, nt0);
+    int scan_next = 0;
+    if (!split && last_tile && has_next) scan_next = scan_issue(nb);
 
     // ---- layer 1: this wave's K segment of [h, q, h-q, h*q] @ W1 (net.py:155-164)
     f32x4_t acc[2][S::NT1];
@@ -510,16 +581,18 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < S::NT1; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (seg == 0) din_l1_segment<0, E, H1>(hs, qs, bf, acc, li, g);
-    else if (seg == 1) din_l1_segment<1, E, H1>(hs, qs, bf, acc, li, g);
-    else if (seg == 2) din_l1_segment<2, E, H1>(hs, qs, bf, acc, li, g);
-    else din_l1_segment<3, E, H1>(hs, qs, bf, acc, li, g);
+    if (!skip) {
+      if (seg == 0) din_l1_segment<0, E, H1>(hs, qs, bf, acc, li, g);
+      else if (seg == 1) din_l1_segment<1, E, H1>(hs, qs, bf, acc, li, g);
+      else if (seg == 2) din_l1_segment<2, E, H1>(hs, qs, bf, acc, li, g);
+      else din_l1_segment<3, E, H1>(hs, qs, bf, acc, li, g);
+    }
     if (has_next) ids_store(buf ^ 1, idv);
     // partial sums, two-level tree in a fixed order: X = (b1 + P0) + P2, Y = P1 + P3, z1 = X + Y.
     // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
     {
       float* dst = (seg & 1) ? Y : X;
-      if (seg < 2) {
+      if (seg < 2 && !skip) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -531,7 +604,7 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
             }
       }
       __syncthreads();
-      if (seg >= 2) {
+      if (seg >= 2 && !skip) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -546,7 +619,7 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
     }
     // embedding rows of the next tile: in flight during layers 2/3 and the softmax of this one
     if (PF && has_next) rows_issue(buf ^ 1, nt0, ph, pq);
-    for (int v = tid; v < kDinTP * (H1 / 4); v += kBlock) {
+    for (int v = tid; v < kDinTP * (H1 / 4) && !skip; v += kBlock) {
       const int p = v / (H1 / 4), c = (v % (H1 / 4)) * 4;
       const float4 x = *reinterpret_cast<const float4*>(X + p * S::H1P + c);
       const float4 y = *reinterpret_cast<const float4*>(Y + p * S::H1P + c);
@@ -557,7 +630,7 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
     }
     __syncthreads();
     // ---- layer 2 on the matrix cores, layer 3 folded into its epilogue: lp[n][p] = sum_{c in tile n} a2[p][c] w3[c]
-    for (int t = seg; t < 2 * S::NT2; t += kBlock / kWave) {
+    for (int t = seg; t < 2 * S::NT2 && !skip; t += kBlock / kWave) {
       const int m = t & 1, n = t >> 1;
       const int c = n * 16 + li;
       f32x4_t z = {0.f, 0.f, 0.f, 0.f};
@@ -583,40 +656,54 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
     // ---- logits + online softmax bookkeeping, wave 0 (net.py:166-170)
     if (seg == 0) {
       const int p = lane & 31, t = t0 + p;
-      float s = -INFINITY;
-      if (t < T) {
-        s = b3;
+      if (!skip) {
+        float s = -INFINITY;
+        if (t < T) {
+          s = b3;
 #pragma unroll
-        for (int n = 0; n < S::NT2; ++n) s += lp[n * kDinTP + p];
-        s = (s + (float)idbuf[(buf * 5 + 4) * kDinTP + p]) * scale;
-        if (lane < 32) sall[t] = s;
+          for (int n = 0; n < S::NT2; ++n) s += lp[n * kDinTP + p];
+          s = (s + (float)idbuf[(buf * 5 + 4) * kDinTP + p]) * scale;
+          if (lane < 32) sall[t] = s;
+        }
+        float mt = s;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) mt = fmaxf(mt, __shfl_xor(mt, o, kWave));
+        const float m_new = fmaxf(m_run, mt);
+        const float f = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+        const float e = (s == -INFINITY) ? 0.f : expf(s - m_new);
+        float lsum = e;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, kWave);
+        l_run = l_run * f + lsum;
+        m_run = m_new;
+        if (lane < 32) es[p] = e;
+        if (lane == 0) { es[32] = f; es[33] = l_run; es[34] = m_run; }
+      } else if (lane < 32 && t < T) {
+        sall[t] = -INFINITY;             // weight exp(-inf - m) / l = 0 at the end of the sample; es[33] / es[34] stand
       }
-      float mt = s;
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) mt = fmaxf(mt, __shfl_xor(mt, o, kWave));
-      const float m_new = fmaxf(m_run, mt);
-      const float f = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
-      const float e = (s == -INFINITY) ? 0.f : expf(s - m_new);
-      float lsum = e;
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, kWave);
-      l_run = l_run * f + lsum;
-      m_run = m_new;
-      if (lane < 32) es[p] = e;
-      if (lane == 0) { es[32] = f; es[33] = l_run; es[34] = m_run; }
+      // the NEXT tile of this sample: all padding behind a finite maximum -> skipped (see the top of the loop)
+      bool padn = true;
+      if (has_next && !last_tile) {
+        const int tn = nt0 + p;
+        padn = tn >= T || idbuf[((buf ^ 1) * 5 + 4) * kDinTP + p] <= (int64_t)-1000000;
+      }
+      const bool all_pad = __builtin_amdgcn_ballot_w64(padn) == ~0ull;
+      if (lane == 0) es[35] = (has_next && !last_tile && m_run > -1e5f && all_pad) ? 1.f : 0.f;
       if (last_tile) { m_run = -INFINITY; l_run = 0.f; }
     }
     __syncthreads();
     // ---- weighted sum of h (net.py:171): thread (part, d) covers PPART positions of column d
     {
-      const float f = es[32];
-      float asum = 0.f;
+      if (!skip) {
+        const float f = es[32];
+        float asum = 0.f;
 #pragma unroll
-      for (int i = 0; i < S::PPART; ++i) {
-        const int p = part * S::PPART + i;
-        asum += es[p] * hs[p * S::EP + pd];
+        for (int i = 0; i < S::PPART; ++i) {
+          const int p = part * S::PPART + i;
+          asum += es[p] * hs[p * S::EP + pd];
+        }
+        pool = pool * f + asum;
       }
-      pool = pool * f + asum;
       if (last_tile) { red[part * E + pd] = pool; pool = 0.f; }
     }
     __syncthreads();
@@ -633,14 +720,22 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
         if (tid == 0) { a.part[w * (E + 2) + E] = m_fin; a.part[w * (E + 2) + E + 1] = l_fin; }
         const int t = t0 + tid;
         if (a.att_weight && tid < kDinTP && t < T) a.att_weight[b * T + t] = expf(sall[t] - m_fin) / l_fin;
-      } else if (a.att_weight) {
-        for (int t = tid; t < T; t += kBlock) a.att_weight[b * T + t] = expf(sall[t] - m_fin) / l_fin;
+      } else {
+        for (int t = tid; t < T; t += kBlock) {
+          if (a.att_weight) a.att_weight[b * T + t] = expf(sall[t] - m_fin) / l_fin;   // never-walked tail: exp(-inf) = 0
+          sall[t] = -INFINITY;                                                          // for the next sample
+        }
       }
     }
     if (!has_next) break;
     if (!PF) rows_issue(buf ^ 1, nt0, ph, pq);
     rows_store(ph, pq);
+    if (!split && last_tile) scan_fold(scan_next);
+    if (dyn && last_tile && tid == 0) ies[40] = tk;
     __syncthreads();
+    if (!split && last_tile) Teff = scan_read();
+    skip = es[35] != 0.f && !split;
+    if (last_tile && !split) wn = dyn ? (int64_t)ies[40] : wn + gridDim.x;
     if (last_tile) w = nw;
     b = nb; t0 = nt0; buf ^= 1;
   }
@@ -1069,8 +1164,23 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
     ids_store(0, idv, pwv);
     sample_load(b);
   }
-  __syncthreads();
-  tile_load(0, b, t0);
+  // A tile whose 32 saved softmax weights are all 0.0f (padding behind the valid positions: the forward writes exact
+  // zeros there, and skips such tiles itself) has dl = p (..) = 0, hence dz2 = dz1 = dx = 0 and dh = p dout = 0: its
+  // gradient rows are written as zeros without gathering anything (block-uniform flag from a ballot over the weights).
+  // (a flag in the dynamic LDS block, not __syncthreads_and: its static LDS word would push the kernel past the
+  //  160 KB dynamic-LDS attribute the launcher sets)
+  auto tile_is_zero = [&](int bufi) -> bool {      // block-uniform; two barriers
+    __syncthreads();
+    if (wv == 0) {
+      const bool z = lane >= kDinTP || pws[bufi * kDinTP + lane] == 0.f;
+      const bool all = __builtin_amdgcn_ballot_w64(z) == ~0ull;
+      if (lane == 0) douts[E + 1] = all ? 1.f : 0.f;
+    }
+    __syncthreads();
+    return douts[E + 1] != 0.f;
+  };
+  bool skip = tile_is_zero(0);
+  if (!skip) tile_load(0, b, t0);
   __syncthreads();
 
   while (true) {
@@ -1081,6 +1191,23 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
     int64_t idv = 0;
     float pwv = 0.f;
     if (has_next) ids_issue(nb, nt0, idv, pwv);
+    if (skip) {
+      for (int v = tid; v < kDinTP * S::E4; v += kBlock) {
+        const int p = v / S::E4, c = (v % S::E4) * 4, t = t0 + p;
+        if (t < T) {
+          *reinterpret_cast<float4*>(gb.dh + (b * T + t) * (int64_t)E + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(gb.dq + (b * T + t) * (int64_t)E + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      if (!has_next) break;
+      ids_store(buf ^ 1, idv, pwv);
+      skip = tile_is_zero(buf ^ 1);
+      if (nb != b) sample_load(nb);
+      if (!skip) tile_load(buf ^ 1, nb, nt0);
+      __syncthreads();
+      w = nw; b = nb; t0 = nt0; buf ^= 1;
+      continue;
+    }
     // ---- dl_t = p_t (dout . h_t - sdp) E^-0.5 : 8 threads per position
     {
       const int p = tid >> 3, sub = tid & 7;
@@ -1180,9 +1307,10 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
       }
     }
     if (!has_next) break;
-    __syncthreads();            // hs / qs / X / douts are rewritten for the next tile
+    // hs / qs / X / douts are rewritten for the next tile (barrier); is the next tile all zero weights?
+    skip = tile_is_zero(buf ^ 1);
     if (nb != b) sample_load(nb);
-    tile_load(buf ^ 1, nb, nt0);
+    if (!skip) tile_load(buf ^ 1, nb, nt0);
     __syncthreads();
     w = nw; b = nb; t0 = nt0; buf ^= 1;
   }
@@ -1207,6 +1335,8 @@ extern "C" int rec_din_attention_pool_fwd_workspace_bytes(const rec_din_desc* d,
   const int64_t tiles = d->batch * ntl;
   *bytes = (ntl > 1 && ntl <= 64 && tiles <= 4096) ? align_up((size_t)tiles * (d->item_dim + d->cat_dim + 2) * sizeof(float), 256)
                                                   : 0;
+  // larger batches of the compile-time-shaped kernel: one 32-bit ticket counter (dynamic sample distribution)
+  if (*bytes == 0 && rec_din_saves_act1(d) == 1 && ntl > 1) *bytes = 256;
   return REC_OK;
 }
 
@@ -1255,6 +1385,7 @@ extern "C" int rec_din_attention_pool_fwd_ws(const rec_din_desc* d, const int64_
   a.b3 = att_b3; a.out = out; a.att_weight = att_weight; a.status = status;
   a.act1 = ct ? act1 : nullptr;       // only the compile-time-shaped pair saves / consumes layer-1 activations
   a.part = nullptr;
+  a.ticket = nullptr;
   if (ct) {
     // REC_DIN_FWD_VARIANT: measurement knob.  Measured at B 4096, T 512 (profiles/r02_din_variants.txt):
     //   nopf2 (default; rows fetched at the end of the tile, 2 blocks/CU, 36 spilled VGPRs)  2.74 ms  68.0 TF
@@ -1289,6 +1420,13 @@ extern "C" int rec_din_attention_pool_fwd_ws(const rec_din_desc* d, const int64_
       return check_launch("rec_din_attention_pool_fwd (tile split)");
     }
     if (grid > d->batch) grid = d->batch;
+    static const bool ticket_env = [] { const char* v = getenv("REC_DIN_TICKETS"); return !(v && *v == '0'); }();
+    if (ticket_env && workspace && workspace_bytes >= sizeof(unsigned int) && ntl > 1 && d->batch > grid &&
+        d->batch < (1ll << 31) - 4 * grid) {
+      a.ticket = (unsigned int*)workspace;
+      REC_REQUIRE(hipMemsetAsync(workspace, 0, sizeof(unsigned int), (hipStream_t)stream) == hipSuccess, REC_EHIP,
+                  "hipMemsetAsync failed");
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), shmem, (hipStream_t)stream, a);
     return check_launch("rec_din_attention_pool_fwd");
   }

@@ -64,6 +64,56 @@ def test_attention_pool_vs_oracle(engine_lib, B, Tn, Ei, Ec):
     np.testing.assert_allclose(N_(attw).sum(1), 1.0, rtol=1e-5)
 
 
+def test_attention_pool_skips_only_tiles_that_contribute_nothing(engine_lib):
+    """Round 5: the E 128 kernel pair does not compute a 32-position tile that is all padding behind a finite running
+    maximum (forward), nor one whose 32 saved weights are all zero (backward).  Masks that are NOT a valid prefix followed
+    by padding must still match the oracle: padding in front, a fully padded tile between valid stretches, an all-padding
+    history (uniform weights: nothing may be skipped), a full history, a single valid position at the very end."""
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(515)
+    B, Tn, Ei, Ec = 6, 160, 64, 64
+    E, ni, nc = Ei + Ec, 300, 41
+    valid = np.zeros((B, Tn), bool)
+    valid[0, :40] = True
+    valid[1, 64:100] = True
+    valid[2, :10] = True; valid[2, 96:130] = True
+    valid[4, :] = True
+    valid[5, 159] = True
+    mask = np.where(valid, 0, -1000000000).astype(np.int64)
+    tabs = [rng.uniform(-0.3, 0.3, (n, d)).astype(np.float32) for n, d in ((ni, Ei), (nc, Ec), (ni, Ei), (nc, Ec))]
+    hi = rng.integers(0, ni, (B, Tn)); hc = rng.integers(0, nc, (B, Tn))
+    tis = np.repeat(rng.integers(0, ni, B)[:, None], Tn, 1); tcs = np.repeat(rng.integers(0, nc, B)[:, None], Tn, 1)
+    aw = [rng.uniform(-0.3, 0.3, s).astype(np.float32) for s in ((4 * E, 80), (80, 40), (40, 1))]
+    ab = [rng.uniform(-0.1, 0.1, s).astype(np.float32) for s in ((80,), (40,), (1,))]
+    dout = rng.standard_normal((B, E)).astype(np.float32)
+    taw, tab, tt = [T(w) for w in aw], [T(b) for b in ab], [T(t) for t in tabs]
+    saved = {}
+    out, attw, status = ops.din_attention_pool(T(hi), T(hc), T(tis), T(tcs), T(mask), *tt, taw, tab, saved=saved)
+    assert int(status.item()) == 0 and saved["act1"] is not None
+    h = np.concatenate([tabs[0][hi], tabs[1][hc]], 2)
+    q = np.concatenate([tabs[2][tis], tabs[3][tcs]], 2)
+    want, wts = Dn.attention_pool(h, q, mask.astype(np.float32), aw, ab, return_weights=True)
+    np.testing.assert_allclose(N_(out), want, rtol=1e-5, atol=2e-6)
+    assert_close_scaled(N_(attw), wts, 1e-5)
+    got_w = N_(attw)
+    assert np.all(got_w[(mask != 0) & valid.any(1, keepdims=True)] == 0.0)          # padded, beside a valid position
+    np.testing.assert_allclose(got_w[3], 1.0 / Tn, rtol=1e-5)                       # all padding: uniform, computed
+    np.testing.assert_allclose(got_w.sum(1), 1.0, rtol=1e-5)
+    dh, dq = ops.din_attention_pool_bwd(T(hi), T(hc), T(tis), T(tcs), *tt, taw, tab, attw, T(dout), saved=saved)
+    ref = Dn.attention_pool_backward(h.astype(np.float64), q.astype(np.float64), mask.astype(np.float64),
+                                     [w.astype(np.float64) for w in aw], [b.astype(np.float64) for b in ab],
+                                     dout.astype(np.float64))
+    ref32 = Dn.attention_pool_backward(h, q, mask.astype(np.float32), aw, ab, dout)
+    scale = max(np.abs(ref["dh"]).max(), np.abs(ref["dq"]).max())
+    assert_close_floor(N_(dh), ref["dh"], ref32["dh"], err_msg="dh", scale=scale)
+    assert_close_floor(N_(dq), ref["dq"], ref32["dq"], err_msg="dq", scale=scale)
+    pad_beside_valid = (mask != 0) & valid.any(1, keepdims=True)
+    assert np.all(N_(dh)[pad_beside_valid] == 0.0) and np.all(N_(dq)[pad_beside_valid] == 0.0)
+    # the same through recomputed activations (no saved state): the generic backward, no tile skipping
+    dh2, dq2 = ops.din_attention_pool_bwd(T(hi), T(hc), T(tis), T(tcs), *tt, taw, tab, attw, T(dout), saved=None)
+    assert_close_floor(N_(dh2), ref["dh"], ref32["dh"], err_msg="dh (recomputed)", scale=scale)
+
+
 @pytest.mark.parametrize("Ei,Ec", [(8, 8), (64, 64)])      # runtime-shaped kernel / the compile-time-shaped one (E 128)
 def test_attention_pool_known_answers(engine_lib, Ei, Ec):
     from paddlerec_amd import ops

@@ -107,13 +107,14 @@ for B, T in ((32, 152), (4096, 100), (4096, 512)):
     aw = [torch.randn(s, device=DEV, generator=g) * 0.05 for s in ((512, 80), (80, 40), (40, 1))]
     ab = [torch.zeros(s, device=DEV) for s in (80, 40, 1)]
     st = ops.new_status(DEV)
-    t = timeit(lambda: ops.din_attention_pool(hi, hc, hi, hc, mask, *tabs, aw, ab, st))
-    fl = 2.0 * B * T * (512 * 80 + 80 * 40 + 40 + 128)
+    att_ws = ops.Workspace(DEV)            # as DINLayer.forward calls it: tile split (B 32) / sample tickets (B 4096)
+    t = timeit(lambda: ops.din_attention_pool(hi, hc, hi, hc, mask, *tabs, aw, ab, st, ws=att_ws))
+    fl = 2.0 * B * T * (512 * 80 + 80 * 40 + 40 + 128)     # what the reference computes: all B x T positions
     by = B * T * (4 * 8 + 8 + 4 * 256)          # ids + mask + 4 rows of 256 B (algorithmic, rows hit L2)
     print("DIN attention-pool B=%d T=%d: %.3f ms  (%.1f M positions/s, %.2f TF, %.0f GB/s algorithmic)" %
           (B, T, t, B * T / t / 1e3, fl / t / 1e9, by / t / 1e6))
     record("configs[3]", "DIN attention-pool forward (4 gathers + 512-80-40-1 MLP + masked softmax + pool), B %d, "
-           "T %d" % (B, T), t, fl, B,
+           "T %d, history lengths uniform in [1, T] (padded tail tiles are not walked)" % (B, T), t, fl, B,
            {"positions_per_s": B * T / t * 1e3,
             "gather_roofline": {"bound": "hbm", "achieved": by / t / 1e6, "peak": PEAK_GBS, "unit": "GB/s",
                                 "frac": by / t / 1e6 / PEAK_GBS, "bytes": by}},
