@@ -578,6 +578,22 @@ int rec_din_attention_pool_bwd(const rec_din_desc* desc, const int64_t* hist_ite
                                const float* out_saved, const float* act1_saved,
                                const float* d_out, float* d_hist, float* d_tgt_seq, void* stream);
 
+/* The same backward with a caller-owned workspace (rec_din_attention_pool_bwd_workspace_bytes; 0 bytes = the shape never
+ * needs one): at batches larger than the resident grid the blocks of the saved-activation kernel draw their next SAMPLE
+ * from a ticket counter in it instead of walking fixed ranges — samples cost between one and max_len / 32 tiles once
+ * tiles whose saved weights are all zero are skipped.  Same results: which block computes a tile changes nothing. */
+int rec_din_attention_pool_bwd_workspace_bytes(const rec_din_desc* desc, size_t* bytes);
+int rec_din_attention_pool_bwd_ws(const rec_din_desc* desc, const int64_t* hist_item,
+                                  const int64_t* hist_cat, const int64_t* tgt_item_seq,
+                                  const int64_t* tgt_cat_seq, const float* w_hist_item,
+                                  const float* w_hist_cat, const float* w_tgt_item_seq,
+                                  const float* w_tgt_cat_seq, const float* att_w1,
+                                  const float* att_w1_t, const float* att_b1, const float* att_w2,
+                                  const float* att_b2, const float* att_w3, const float* att_weight,
+                                  const float* out_saved, const float* act1_saved,
+                                  const float* d_out, float* d_hist, float* d_tgt_seq, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+
 /* CrossNetMix backward glue for one expert (dcn_v2/net.py:301-317), one pass over [m,n]:
  *   dU = dX*X0*p_e;  dX0_acc (+)= dX*p_e*U;  dp[i] = sum_j dX*X0*U      (p_e = prob[i*prob_stride])
  * and the softmax backward of the gate: dz = p * (dp - sum_e p_e dp_e) over n <= 64 columns. */

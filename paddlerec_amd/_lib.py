@@ -205,6 +205,8 @@ SIGNATURES = {
     "rec_din_attention_pool_fwd_workspace_bytes": (C.c_int, [C.POINTER(DinDesc), C.POINTER(C.c_size_t)]),
     "rec_din_attention_pool_fwd_ws": (C.c_int, [C.POINTER(DinDesc)] + [_P] * 20 + [_SZ, _P]),
     "rec_din_attention_pool_bwd": (C.c_int, [C.POINTER(DinDesc)] + [_P] * 21),
+    "rec_din_attention_pool_bwd_workspace_bytes": (C.c_int, [C.POINTER(DinDesc), C.POINTER(C.c_size_t)]),
+    "rec_din_attention_pool_bwd_ws": (C.c_int, [C.POINTER(DinDesc)] + [_P] * 21 + [_SZ, _P]),
     "rec_sparse_sgd_rows": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P, _F, _P]),
     "rec_sgd_dense": (C.c_int, [_I64, _P, _P, _F, _P]),
     "rec_crossnet_v2_layer_workspace_bytes": (C.c_int, [C.POINTER(CrossV2Desc), C.POINTER(_SZ), C.POINTER(_SZ)]),

@@ -787,6 +787,7 @@ struct DinBwdArgs {
   const float* out_saved;  // [B,E]    forward output        } both non-null: the compile-time-shaped kernel runs
   const float* act1;       // [B,T,H1] forward layer-1 acts  } on saved activations instead of recomputing them
   float *dh, *dq;          // [B,T,E]
+  unsigned int* ticket;    // zeroed counter in the caller's workspace (or null): blocks draw whole samples from it
 };
 
 __global__ __launch_bounds__(kBlock) void din_attention_bwd_kernel(DinBwdArgs g) {
@@ -1026,7 +1027,7 @@ struct DinBwdCt {
   static constexpr int kDl = kB2 + H2C;                  // [32] dl of the tile
   static constexpr int kPw = kDl + kDinTP;               // [2][32] softmax weights of this / the next tile
   static constexpr int kDout = kPw + 2 * kDinTP;         // [E] dout of the sample, [E] sdp
-  static constexpr int kIds = (kDout + E + 2 + 1) & ~1;  // int64 [4][32]: ids of the NEXT tile (this tile's are spent)
+  static constexpr int kIds = (kDout + E + 4 + 1) & ~1;  // (douts[E+1]: skip flag, [E+2..E+3]: sample tickets)  int64 [4][32]: ids of the NEXT tile (this tile's are spent)
   static constexpr int kEnd = kIds + 2 * 4 * kDinTP;
   static_assert(2 * sizeof(float) * kEnd <= 160 * 1024 || E > 128, "two blocks per CU no longer fit the LDS");
   static constexpr size_t lds_bytes = sizeof(float) * (size_t)kEnd;
@@ -1153,9 +1154,26 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
   // on 256 CUs) every tile has a block of its own instead of 32 blocks walking five tiles each (68 -> ~20 us).
   const int NTL = (T + kDinTP - 1) / kDinTP;
   const int64_t W = a.B * NTL, per = (W + gridDim.x - 1) / gridDim.x;
+  // With a ticket counter (gb.ticket: the _ws entry point at large batches) a block draws whole SAMPLES — skipped tiles
+  // make a sample cost anything between one and T / 32 tiles — one sample ahead, the draw after that issued while the
+  // current sample is worked on; otherwise contiguous ranges of the flattened list as before.
+  const bool dyn = gb.ticket != nullptr;
+  int* itk = reinterpret_cast<int*>(douts + E + 2);
   int64_t w = (int64_t)blockIdx.x * per;
-  const int64_t w_end = (w + per < W) ? w + per : W;
-  if (w >= w_end) return;
+  int64_t w_end = (w + per < W) ? w + per : W;
+  int64_t next_sample = a.B;
+  if (dyn) {
+    if (tid == 0) {
+      itk[0] = (int)atomicAdd(gb.ticket, 1u);
+      itk[1] = (int)atomicAdd(gb.ticket, 1u);
+    }
+    __syncthreads();
+    w = (int64_t)itk[0] * NTL;
+    w_end = w + NTL;
+    next_sample = itk[1];
+    __syncthreads();
+  }
+  if (w >= W || w >= w_end) return;
   int64_t b = w / NTL;
   int t0 = (int)(w % NTL) * kDinTP, buf = 0;
   {
@@ -1184,10 +1202,14 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
   __syncthreads();
 
   while (true) {
-    const int64_t nw = w + 1;
+    int64_t nw = w + 1;
+    const bool chunk_end = nw >= w_end;
+    if (chunk_end && dyn) nw = next_sample * NTL;          // the sample drawn a sample ago
+    const bool has_next = dyn ? (!chunk_end || next_sample < a.B) : !chunk_end;
     const int64_t nb = nw / NTL;
     const int nt0 = (int)(nw % NTL) * kDinTP;
-    const bool has_next = nw < w_end;
+    int tk = 0;
+    if (dyn && chunk_end && has_next && tid == 0) tk = (int)atomicAdd(gb.ticket, 1u);   // the sample after the next one
     int64_t idv = 0;
     float pwv = 0.f;
     if (has_next) ids_issue(nb, nt0, idv, pwv);
@@ -1201,7 +1223,9 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
       }
       if (!has_next) break;
       ids_store(buf ^ 1, idv, pwv);
+      if (dyn && chunk_end && tid == 0) itk[0] = tk;
       skip = tile_is_zero(buf ^ 1);
+      if (dyn && chunk_end) { w_end = nw + NTL; next_sample = itk[0]; }
       if (nb != b) sample_load(nb);
       if (!skip) tile_load(buf ^ 1, nb, nt0);
       __syncthreads();
@@ -1307,8 +1331,10 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
       }
     }
     if (!has_next) break;
+    if (dyn && chunk_end && tid == 0) itk[0] = tk;
     // hs / qs / X / douts are rewritten for the next tile (barrier); is the next tile all zero weights?
     skip = tile_is_zero(buf ^ 1);
+    if (dyn && chunk_end) { w_end = nw + NTL; next_sample = itk[0]; }
     if (nb != b) sample_load(nb);
     if (!skip) tile_load(buf ^ 1, nb, nt0);
     __syncthreads();
@@ -1462,6 +1488,29 @@ extern "C" int rec_din_attention_pool_bwd(const rec_din_desc* d, const int64_t* 
                                           const float* out_saved, const float* act1_saved,
                                           const float* d_out, float* d_hist, float* d_tgt_seq,
                                           void* stream) {
+  return rec_din_attention_pool_bwd_ws(d, hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_hist_item, w_hist_cat,
+                                       w_tgt_item_seq, w_tgt_cat_seq, att_w1, att_w1_t, att_b1, att_w2, att_b2, att_w3,
+                                       att_weight, out_saved, act1_saved, d_out, d_hist, d_tgt_seq, nullptr, 0, stream);
+}
+
+// one 32-bit ticket counter for the compile-time-shaped kernel at batches larger than the resident grid; else nothing
+extern "C" int rec_din_attention_pool_bwd_workspace_bytes(const rec_din_desc* d, size_t* bytes) {
+  REC_REQUIRE(d && bytes, REC_EINVAL, "null argument");
+  *bytes = (rec_din_saves_act1(d) == 1 && d->max_len > kDinTP) ? 256 : 0;
+  return REC_OK;
+}
+
+extern "C" int rec_din_attention_pool_bwd_ws(const rec_din_desc* d, const int64_t* hist_item,
+                                             const int64_t* hist_cat, const int64_t* tgt_item_seq,
+                                             const int64_t* tgt_cat_seq, const float* w_hist_item,
+                                             const float* w_hist_cat, const float* w_tgt_item_seq,
+                                             const float* w_tgt_cat_seq, const float* att_w1,
+                                             const float* att_w1_t, const float* att_b1,
+                                             const float* att_w2, const float* att_b2,
+                                             const float* att_w3, const float* att_weight,
+                                             const float* out_saved, const float* act1_saved,
+                                             const float* d_out, float* d_hist, float* d_tgt_seq,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
   REC_REQUIRE(d, REC_EINVAL, "desc is NULL");
   const int E = d->item_dim + d->cat_dim;
   REC_REQUIRE(d->batch >= 0 && d->max_len > 0 && d->item_dim > 0 && d->cat_dim > 0 && d->hidden1 > 0 &&
@@ -1489,6 +1538,7 @@ extern "C" int rec_din_attention_pool_bwd(const rec_din_desc* d, const int64_t* 
   a.b3 = nullptr; a.out = nullptr; a.att_weight = nullptr; a.status = nullptr; a.act1 = nullptr;
   g.w1t = att_w1_t; g.att_weight = att_weight; g.dout = d_out; g.dh = d_hist; g.dq = d_tgt_seq;
   g.out_saved = out_saved; g.act1 = act1_saved;
+  g.ticket = nullptr;
   static const bool force_generic = getenv("REC_DIN_BWD_GENERIC") != nullptr;
   if (!force_generic && out_saved && act1_saved && E == 128 && H1 == 80 && H2 == 40) {
     using Ct = DinBwdCt<128, 80, 40>;
@@ -1501,6 +1551,13 @@ extern "C" int rec_din_attention_pool_bwd(const rec_din_desc* d, const int64_t* 
     static const bool split_env = [] { const char* v = getenv("REC_DIN_TILE_SPLIT"); return !(v && *v == '0'); }();
     const int64_t items = split_env ? tiles : d->batch;      // REC_DIN_TILE_SPLIT=0: at most one block per sample
     if (grid > items) grid = items;
+    static const bool ticket_env = [] { const char* v = getenv("REC_DIN_TICKETS"); return !(v && *v == '0'); }();
+    if (ticket_env && split_env && workspace && workspace_bytes >= sizeof(unsigned int) && d->max_len > kDinTP &&
+        d->batch > grid && d->batch < (1ll << 31) - 4 * grid) {
+      g.ticket = (unsigned int*)workspace;
+      REC_REQUIRE(hipMemsetAsync(workspace, 0, sizeof(unsigned int), (hipStream_t)stream) == hipSuccess, REC_EHIP,
+                  "hipMemsetAsync failed");
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBlock), Ct::lds_bytes, (hipStream_t)stream, g);
     return check_launch("rec_din_attention_pool_bwd");
   }

@@ -67,8 +67,8 @@ struct Buffers {
   float *pooled, *attw, *act1, *emb, *item_b, *x1, *x2, *logit, *dz, *d2, *d1, *de0, *dpooled, *dh, *dq, *pp;
   int32_t *sorted_pos, *seg_offset, *n_uniq;
   int64_t* uniq_rows;
-  void *ws, *ws_group, *ws_att;
-  size_t ws_bytes, ws_group_bytes, ws_att_bytes;
+  void *ws, *ws_group, *ws_att, *ws_att_bwd;
+  size_t ws_bytes, ws_group_bytes, ws_att_bytes, ws_att_bwd_bytes;
 };
 
 int gemm_need(int64_t m, int n, int k, int lda, int ldb, int ldc, int ta, int tb, int epi, size_t* need) {
@@ -121,6 +121,9 @@ int carve(const rec_din_net* net, const Shape& s, void* workspace, Buffers* bf, 
   REC_TRY(rec_din_attention_pool_fwd_workspace_bytes(&d, &ab));
   bf->ws_att = ab ? c.bytes(ab) : nullptr;
   bf->ws_att_bytes = ab;
+  REC_TRY(rec_din_attention_pool_bwd_workspace_bytes(&d, &ab));
+  bf->ws_att_bwd = ab ? c.bytes(ab) : nullptr;
+  bf->ws_att_bwd_bytes = ab;
   size_t need = 0, lb = 0;
   const int E2 = 2 * s.E;
   REC_TRY(gemm_need(s.B, s.E, s.E, s.E, s.E, E2, 0, 0, REC_EPI_BIAS, &need));            // linearCon
@@ -224,11 +227,11 @@ extern "C" int rec_din_train_step(const rec_din_net* net, int64_t batch, int32_t
                nullptr, 0, net->g_b_con, bf, stream));
   REC_TRY(gemm(B, E, E, E2, E, E, false, true, REC_EPI_NONE, bf.de0, net->w_con, bf.dpooled, nullptr, nullptr, 0, nullptr,
                0, nullptr, bf, stream));
-  REC_TRY(rec_din_attention_pool_bwd(&d, hist_item, hist_cat, target_item_seq, target_cat_seq, net->w_hist_item,
-                                     net->w_hist_cat, net->w_tgt_item_seq, net->w_tgt_cat_seq, net->att_w1,
-                                     net->att_w1_t, net->att_b1, net->att_w2, net->att_b2, net->att_w3, bf.attw,
-                                     s.saves ? bf.pooled : nullptr, s.saves ? bf.act1 : nullptr, bf.dpooled, bf.dh,
-                                     bf.dq, stream));
+  REC_TRY(rec_din_attention_pool_bwd_ws(&d, hist_item, hist_cat, target_item_seq, target_cat_seq, net->w_hist_item,
+                                        net->w_hist_cat, net->w_tgt_item_seq, net->w_tgt_cat_seq, net->att_w1,
+                                        net->att_w1_t, net->att_b1, net->att_w2, net->att_b2, net->att_w3, bf.attw,
+                                        s.saves ? bf.pooled : nullptr, s.saves ? bf.act1 : nullptr, bf.dpooled, bf.dh,
+                                        bf.dq, bf.ws_att_bwd, bf.ws_att_bwd_bytes, stream));
 
   // ---- SGD (din/dygraph_model.py:64-73): merged rows of the seven tables, then the dense parameters in one launch.
   //      Order as din.py: the target-seq tables first (one row per sample collects all its history positions)

@@ -34,6 +34,7 @@ class _StepBuffers:
 
     def __init__(self, k, device):
         self.ws, self.ws_group = k.Workspace(device), k.Workspace(device)
+        self.ws_att_bwd = k.Workspace(device)      # the attention backward's ticket counter (its own: ws is the GEMMs')
         self.att_saved, self.groups, self.partials = {}, {}, {}
 
 
@@ -287,7 +288,8 @@ class DINLayer:
             hist_item_seq, hist_cat_seq, target_item_seq, target_cat_seq,
             p["hist_item_emb_attr.weight"], p["hist_cat_emb_attr.weight"],
             p["target_item_seq_emb_attr.weight"], p["target_cat_seq_emb_attr.weight"],
-            self.attention_w, self.attention_b, sv["attw"], dpooled, saved=bufs.att_saved)
+            self.attention_w, self.attention_b, sv["attw"], dpooled, saved=bufs.att_saved,
+            **(dict(ws=bufs.ws_att_bwd) if self.k is _ops else {}))
         self._last = dict(dh=dh, dq=dq, de0=de0, dz=dz, dense=g)
         # ---- SGD (dygraph_model.py:64-73).  Embedding tables: merged rows; dense: in place.
         # (the target-seq tables first: one row per sample collects the gradients of all its history positions — the longest

@@ -882,9 +882,11 @@ def din_attention_pool(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, mask, w_h
 
 
 def din_attention_pool_bwd(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_hist_item, w_hist_cat,
-                           w_tgt_item_seq, w_tgt_cat_seq, att_w, att_b, att_weight, d_out, saved=None):
+                           w_tgt_item_seq, w_tgt_cat_seq, att_w, att_b, att_weight, d_out, saved=None, ws=None):
     """-> (d_hist [B,T,E], d_tgt_seq [B,T,E]): per-position gradients of the gathered rows.
-    saved: the dict the forward filled (optional; without it the hidden activations are recomputed)."""
+    saved: the dict the forward filled (optional; without it the hidden activations are recomputed).
+    ws (ops.Workspace, optional): large batches draw their samples from a ticket counter in it
+    (rec_din_attention_pool_bwd_ws)."""
     B, T = hist_item.shape
     Ei, ldi = _chk_table(w_hist_item, "w_hist_item")
     Ec, ldc = _chk_table(w_hist_cat, "w_hist_cat")
@@ -901,11 +903,18 @@ def din_attention_pool_bwd(hist_item, hist_cat, tgt_item_seq, tgt_cat_seq, w_his
         out_s, act1_s = saved["out"], saved["act1"]
         _chk(out_s, torch.float32, "saved out", (B, E))
         _chk(act1_s, torch.float32, "saved act1", (B, T, H1))
-    check(lib().rec_din_attention_pool_bwd(
+    wk, nb = None, 0
+    if ws is not None:
+        nbytes = C.c_size_t(0)
+        check(lib().rec_din_attention_pool_bwd_workspace_bytes(C.byref(d), C.byref(nbytes)))
+        if nbytes.value:
+            wk = ws.get(nbytes.value)
+            nb = wk.numel()
+    check(lib().rec_din_attention_pool_bwd_ws(
         C.byref(d), _p(hist_item), _p(hist_cat), _p(tgt_item_seq), _p(tgt_cat_seq), _p(w_hist_item),
         _p(w_hist_cat), _p(w_tgt_item_seq), _p(w_tgt_cat_seq), _p(att_w[0]), _p(w1t), _p(att_b[0]),
         _p(att_w[1]), _p(att_b[1]), _p(att_w[2]), _p(att_weight), _p(out_s), _p(act1_s), _p(d_out), _p(dh), _p(dq),
-        _stream()), "rec_din_attention_pool_bwd")
+        _p(wk), C.c_size_t(nb), _stream()), "rec_din_attention_pool_bwd_ws")
     return dh, dq
 
 

@@ -320,12 +320,15 @@ std::vector<Tensor> RecDinAttBwd(const Tensor& hist_item, const Tensor& hist_cat
   void* st = att.stream();
   REC_CALL(rec_transpose_f32(4 * E, d.hidden1, a_w1.data<float>(), w1t.data<float>(), st));
   const bool saved = act1.numel() == n * d.hidden1 && rec_din_saves_act1(&d) == 1;
-  REC_CALL(rec_din_attention_pool_bwd(
+  size_t ws_bytes = 0;
+  REC_CALL(rec_din_attention_pool_bwd_workspace_bytes(&d, &ws_bytes));
+  auto ws = workspace(ws_bytes, att);
+  REC_CALL(rec_din_attention_pool_bwd_ws(
       &d, hist_item.data<int64_t>(), hist_cat.data<int64_t>(), tgt_item_seq.data<int64_t>(), tgt_cat_seq.data<int64_t>(),
       w_hi.data<float>(), w_hc.data<float>(), w_ti.data<float>(), w_tc.data<float>(), a_w1.data<float>(),
       w1t.data<float>(), a_b1.data<float>(), a_w2.data<float>(), a_b2.data<float>(), a_w3.data<float>(), att.data<float>(),
       saved ? out.data<float>() : nullptr, saved ? act1.data<float>() : nullptr, d_out.data<float>(),
-      d_hist.data<float>(), d_tgt.data<float>(), st));
+      d_hist.data<float>(), d_tgt.data<float>(), ws_bytes ? ws.data<uint8_t>() : nullptr, ws_bytes, st));
   // the engine writes [item | cat] columns side by side; the four parameters are separate tensors
   auto g_hi = f32({n, d.item_dim}), g_hc = f32({n, d.cat_dim}), g_ti = f32({n, d.item_dim}), g_tc = f32({n, d.cat_dim});
   const size_t f4 = sizeof(float), pitch = static_cast<size_t>(E) * f4;
