@@ -141,3 +141,64 @@ def test_c_step_padded_layer0_on_a_callers_separate_buffer(engine_lib, monkeypat
                       m.dense.m.cpu().numpy(), m.dense.v.cpu().numpy())
     for x, y in zip(res["separate"], res["inplace"]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.first_hw_run
+def test_two_host_threads_step_two_nets_on_their_own_streams(engine_lib, monkeypatch):
+    """the fork / join events of the two-stream schedule used to be one function-local static set shared by
+    every caller — two host threads stepping two nets could re-record each other's events between a record and its
+    wait.  They are kept per (device, stream, side stream) now: two threads, each with its own net, main stream and side
+    stream, stepping concurrently, leave exactly the bits of the same two nets stepped one after the other."""
+    import threading
+    from paddlerec_amd import ops
+    from paddlerec_amd.deepfm import DeepFMLayer
+    monkeypatch.setenv("REC_STEP_PLAN", "0")
+    B, S, slot_rows, steps = 8192, 26, 3000, 6
+    so = torch.arange(S, dtype=torch.int64) * slot_rows
+
+    def make(seed):
+        torch.manual_seed(seed)
+        m = DeepFMLayer(S * slot_rows, 16, 13, S, [80, 48], device=DEV, slot_offset=so)
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        data = [(torch.randint(0, slot_rows, (B, S), device=DEV, generator=g), torch.rand(B, 13, device=DEV, generator=g),
+                 (torch.rand(B, 1, device=DEV, generator=g) < 0.3).to(torch.int64)) for _ in range(steps)]
+        return m, data
+
+    def run(m, data, main, side, out):
+        try:
+            ws = ops.Workspace(DEV)
+            net = m.c_net()
+            with torch.cuda.stream(main):
+                for t, (ids, dense, label) in enumerate(data):
+                    loss, _ = ops.deepfm_train_step(net, ids, dense, label.reshape(-1), t + 1, ws, lr=1e-2, status=m.status,
+                                                    side_stream=side)
+                main.synchronize()
+            side.synchronize()
+            out.append((float(loss.item()), m.fm.rec.clone(), m.dense.data.clone()))
+        except Exception as e:      # noqa: BLE001
+            out.append(e)
+
+    def streams():
+        return torch.cuda.Stream(), torch.cuda.Stream()
+
+    torch.cuda.synchronize()
+    seq = []
+    for seed in (1, 2):
+        m, data = make(seed)
+        m._ensure_sparse_state()
+        torch.cuda.synchronize()
+        run(m, data, *streams(), seq)
+    par, nets = [[], []], [make(1), make(2)]
+    for m, _ in nets:
+        m._ensure_sparse_state()
+    torch.cuda.synchronize()
+    th = [threading.Thread(target=run, args=(nets[i][0], nets[i][1], *streams(), par[i])) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        assert not isinstance(par[i][0], Exception), par[i][0]
+        assert not isinstance(seq[i], Exception), seq[i]
+        assert par[i][0][0] == seq[i][0]
+        assert torch.equal(par[i][0][1], seq[i][1]) and torch.equal(par[i][0][2], seq[i][2])

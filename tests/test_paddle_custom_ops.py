@@ -45,7 +45,7 @@ def _shim():
     sys.path.insert(0, os.path.join(REPO, "paddlerec_amd", "compat"))
     try:
         from paddlerec_amd import build
-        build.build_paddle_ops(verbose=False)
+        build.build(verbose=False)              # incremental: librecengine.so first (the shim links it), then the shim
         from paddlerec_amd.compat.paddle.utils import cpp_extension as X
         return X, X.shim()
     finally:
