@@ -143,7 +143,6 @@ def test_c_step_padded_layer0_on_a_callers_separate_buffer(engine_lib, monkeypat
         assert np.array_equal(x, y)
 
 
-@pytest.mark.first_hw_run
 def test_two_host_threads_step_two_nets_on_their_own_streams(engine_lib, monkeypatch):
     """the fork / join events of the two-stream schedule used to be one function-local static set shared by
     every caller — two host threads stepping two nets could re-record each other's events between a record and its
