@@ -1075,6 +1075,51 @@ int rec_din_train_step(const rec_din_net* net, int64_t batch, int32_t max_len, c
                        float* loss_out, float* pred_out, int32_t* status, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The whole DCN-v2 train step behind one call — the per-batch body of tools/trainer.py:148-152 for models/rank/dcn_v2:
+ * train_forward (dcn_v2/dygraph_model.py:103-127 = net.py:89-137: lookup + dense_emb Linear, CrossNetV2 or CrossNetMix,
+ * the DNN tower with its train-mode Dropout pairs, the stacked or the parallel head, log_loss), loss.backward(), Adam with
+ * ClipGradByGlobalNorm and L2Decay on the DNN weights (dygraph_model.py:73-88, net.py:164-170).  Issues the rec_* calls of
+ * paddlerec_amd/dcn_v2.py:train_step on `stream` (csrc/dcn_v2_step.hip), bit-identical to it, for all four structures
+ * (is_stacked x low_rank_mix) with and without dropout.  All pointers are device memory the caller owns: the table as
+ * [num_rows, emb_stride] with its Adam moments [num_rows, state_stride], every dense parameter as Paddle's [in, out] with
+ * its gradient buffer, and the flat buffers holding all dense parameters / gradients / moments in one order
+ * (rec_adam_dense and rec_sumsq walk them).
+ * ---------------------------------------------------------------------------------------- */
+#define REC_DCN_MAX_LAYERS 8
+typedef struct {
+  int32_t num_slots, dim, dense_dim;    /* S, D, Dn: d = (S + Dn) * D */
+  int64_t num_rows, padding_idx;        /* padding_idx < 0: none (net.py:45-54 uses 0) */
+  int32_t emb_stride, state_stride;     /* row strides (floats) of emb and of emb_m / emb_v */
+  float *emb, *emb_m, *emb_v;
+  int32_t cross_num, n_dnn;             /* <= REC_DCN_MAX_LAYERS each */
+  int32_t widths[REC_DCN_MAX_LAYERS];   /* layer_sizes of the DNN tower */
+  int32_t is_stacked, low_rank_mix;     /* net.py:110-137 stacked / parallel; CrossNetV2 / CrossNetMix */
+  int32_t num_experts, low_rank;        /* CrossNetMix only */
+  float dropout_rate;                   /* 0: no dropout (eval-mode tower) */
+  float l2_dnn, clip_norm;              /* 0: off */
+  uint64_t dropout_seed;                /* mask streams of layer i at Adam step t: (t * n_dnn + i) * 2 and + 1 */
+  float *dense_emb_w, *dense_emb_b, *g_dense_emb_w, *g_dense_emb_b;   /* Linear(Dn -> D*Dn) */
+  float *cross_w[REC_DCN_MAX_LAYERS], *cross_b[REC_DCN_MAX_LAYERS];   /* CrossNetV2 [d,d], [d] */
+  float *g_cross_w[REC_DCN_MAX_LAYERS], *g_cross_b[REC_DCN_MAX_LAYERS];
+  float *mix_u[REC_DCN_MAX_LAYERS], *mix_v[REC_DCN_MAX_LAYERS], *mix_c[REC_DCN_MAX_LAYERS], *mix_bias[REC_DCN_MAX_LAYERS];
+  float *g_mix_u[REC_DCN_MAX_LAYERS], *g_mix_v[REC_DCN_MAX_LAYERS], *g_mix_c[REC_DCN_MAX_LAYERS],
+      *g_mix_bias[REC_DCN_MAX_LAYERS];                                /* CrossNetMix [E,d,r], [E,d,r], [E,r,r], [d] */
+  float *gate_w, *gate_b, *g_gate_w, *g_gate_b;                       /* the E gating Linear(d,1) stacked: [d,E], [E] */
+  float *dnn_w[REC_DCN_MAX_LAYERS], *dnn_b[REC_DCN_MAX_LAYERS], *g_dnn_w[REC_DCN_MAX_LAYERS], *g_dnn_b[REC_DCN_MAX_LAYERS];
+  float *fc_w, *fc_b, *g_fc_w, *g_fc_b;                               /* [widths[n-1] (+ d when parallel), 1], [1] */
+  float *flat_param, *flat_grad, *flat_m, *flat_v;
+  int64_t flat_numel;
+} rec_dcn_v2_net;
+int rec_dcn_v2_train_step_workspace_bytes(const rec_dcn_v2_net* net, int64_t batch, size_t* bytes);
+/* ids [batch, num_slots] i64, dense [batch, dense_dim] f32, label [batch] i64 -> loss_out [1], pred_out [batch];
+ * hyper->step = the Adam step count t (1-based; also keys the dropout masks); auc_pos / auc_neg i64
+ * [num_thresholds + 1] or NULL. */
+int rec_dcn_v2_train_step(const rec_dcn_v2_net* net, int64_t batch, const int64_t* ids, const float* dense,
+                          const int64_t* label, const rec_adam_hyper* hyper, int64_t* auc_pos, int64_t* auc_neg,
+                          int32_t num_thresholds, float* loss_out, float* pred_out, int32_t* status, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,27 @@ class DinNet(C.Structure):
                     "flat_param", "flat_grad")] + [("flat_numel", C.c_int64)])
 
 
+DCN_MAX_LAYERS = 8
+
+
+class DcnV2Net(C.Structure):
+    """rec_dcn_v2_net (include/recengine.h): the model of rec_dcn_v2_train_step as pointers into caller-owned memory."""
+    _fields_ = ([("num_slots", C.c_int32), ("dim", C.c_int32), ("dense_dim", C.c_int32), ("num_rows", C.c_int64),
+                 ("padding_idx", C.c_int64), ("emb_stride", C.c_int32), ("state_stride", C.c_int32),
+                 ("emb", C.c_void_p), ("emb_m", C.c_void_p), ("emb_v", C.c_void_p),
+                 ("cross_num", C.c_int32), ("n_dnn", C.c_int32), ("widths", C.c_int32 * DCN_MAX_LAYERS),
+                 ("is_stacked", C.c_int32), ("low_rank_mix", C.c_int32), ("num_experts", C.c_int32),
+                 ("low_rank", C.c_int32), ("dropout_rate", C.c_float), ("l2_dnn", C.c_float), ("clip_norm", C.c_float),
+                 ("dropout_seed", C.c_uint64)] +
+                [(n, C.c_void_p) for n in ("dense_emb_w", "dense_emb_b", "g_dense_emb_w", "g_dense_emb_b")] +
+                [(n, C.c_void_p * DCN_MAX_LAYERS) for n in ("cross_w", "cross_b", "g_cross_w", "g_cross_b", "mix_u", "mix_v", "mix_c",
+                                                "mix_bias", "g_mix_u", "g_mix_v", "g_mix_c", "g_mix_bias")] +
+                [(n, C.c_void_p) for n in ("gate_w", "gate_b", "g_gate_w", "g_gate_b")] +
+                [(n, C.c_void_p * DCN_MAX_LAYERS) for n in ("dnn_w", "dnn_b", "g_dnn_w", "g_dnn_b")] +
+                [(n, C.c_void_p) for n in ("fc_w", "fc_b", "g_fc_w", "g_fc_b", "flat_param", "flat_grad", "flat_m",
+                                           "flat_v")] + [("flat_numel", C.c_int64)])
+
+
 class AdamHyper(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("step", C.c_int64)]
@@ -277,6 +298,9 @@ SIGNATURES = {
     "rec_din_train_step_workspace_bytes": (C.c_int, [C.POINTER(DinNet), _I64, _I32, C.POINTER(C.c_size_t)]),
     "rec_din_train_step": (C.c_int, [C.POINTER(DinNet), _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                                      _SZ, _P]),
+    "rec_dcn_v2_train_step_workspace_bytes": (C.c_int, [C.POINTER(DcnV2Net), _I64, C.POINTER(C.c_size_t)]),
+    "rec_dcn_v2_train_step": (C.c_int, [C.POINTER(DcnV2Net), _I64, _P, _P, _P, C.POINTER(AdamHyper), _P, _P, _I32, _P, _P,
+                                        _P, _P, _SZ, _P]),
     "rec_deepfm_train_step_workspace_bytes": (C.c_int, [C.POINTER(DeepFMNet), _I64, C.POINTER(C.c_size_t)]),
     "rec_deepfm_train_step": (C.c_int, [C.POINTER(DeepFMNet), _I64, _P, _P, _P, C.POINTER(AdamHyper), _P, _P, _I32, _P, _P,
                                         _P, _P, _SZ, _P, _P]),

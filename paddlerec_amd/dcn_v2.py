@@ -405,6 +405,69 @@ class DCN_V2Layer:
             have_acc = True
         return dx
 
+    # ---------------------------------------------------------------- the step through ONE C-ABI call
+    def c_net(self, clip_norm=10.0):
+        """rec_dcn_v2_net over this layer's tensors (include/recengine.h)."""
+        from . import _lib
+        if len(self.layer_sizes) > _lib.DCN_MAX_LAYERS or self.cross_num > _lib.DCN_MAX_LAYERS:
+            raise ValueError("rec_dcn_v2_train_step takes at most %d cross layers / DNN layers" % _lib.DCN_MAX_LAYERS)
+        self._ensure_sparse_state()
+        p, g, st = self.dense.p, self.dense.g, self.sparse_state
+        net = _lib.DcnV2Net()
+        net.num_slots, net.dim, net.dense_dim = self.sparse_num_field, self.sparse_feature_dim, self.dense_feature_dim
+        net.num_rows, net.padding_idx = self.sparse_feature_number, self.padding_idx
+        net.emb_stride, net.state_stride = self.embedding.stride(0), st["m"].stride(0)
+        net.emb, net.emb_m, net.emb_v = self.embedding.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr()
+        net.cross_num, net.n_dnn = self.cross_num, len(self.layer_sizes)
+        for i, w in enumerate(self.layer_sizes):
+            net.widths[i] = w
+        net.is_stacked, net.low_rank_mix = int(self.is_Stacked), int(self.use_low_rank_mixture)
+        net.num_experts, net.low_rank = self.num_experts, self.low_rank
+        net.dropout_rate, net.dropout_seed, net.l2_dnn = self.dropout_rate, self.dropout_seed, self.l2_dnn
+        net.clip_norm = float(clip_norm or 0.0)
+
+        def both(field, name, i=None):
+            for prefix, src in (("", p), ("g_", g)):
+                if i is None:
+                    setattr(net, prefix + field, src[name].data_ptr())
+                else:
+                    getattr(net, prefix + field)[i] = src[name].data_ptr()
+        both("dense_emb_w", "dense_emb.weight")
+        both("dense_emb_b", "dense_emb.bias")
+        for i in range(self.cross_num):
+            if self.use_low_rank_mixture:
+                for field, nm in (("mix_u", "U_list"), ("mix_v", "V_list"), ("mix_c", "C_list"), ("mix_bias", "bias")):
+                    both(field, P + "%s.%d" % (nm, i), i)
+            else:
+                both("cross_w", P + "cross_layers.%d.weight" % i, i)
+                both("cross_b", P + "cross_layers.%d.bias" % i, i)
+        if self.use_low_rank_mixture:
+            both("gate_w", P + "gating.weight")
+            both("gate_b", P + "gating.bias")
+        for i in range(len(self.layer_sizes)):
+            both("dnn_w", "DNN_.linear_%d.weight" % i, i)
+            both("dnn_b", "DNN_.linear_%d.bias" % i, i)
+        both("fc_w", "fc.weight")
+        both("fc_b", "fc.bias")
+        net.flat_param, net.flat_grad = self.dense.data.data_ptr(), self.dense.grad.data_ptr()
+        net.flat_m, net.flat_v, net.flat_numel = self.dense.m.data_ptr(), self.dense.v.data_ptr(), self.dense.data.numel()
+        return net
+
+    def train_step_c(self, sparse_inputs, dense_inputs, label, lr=1e-3, clip_norm=10.0, auc_stats=None):
+        """train_step through rec_dcn_v2_train_step: ONE foreign call per step — what a non-Python binder of
+        include/recengine.h gets (csrc/dcn_v2_step.hip).  Same entry points, arguments and order as train_step:
+        bit-identical (tests/test_dcn_v2_step_c.py)."""
+        ids = self._concat_ids(sparse_inputs)
+        key = float(clip_norm or 0.0)
+        cached = getattr(self, "_c_net", None)
+        if cached is None or cached[0] != key:
+            cached = self._c_net = (key, self.c_net(clip_norm))
+        if getattr(self, "_ws_c", None) is None:
+            self._ws_c = self.k.Workspace(self.device)
+        self.step_count += 1
+        return self.k.dcn_v2_train_step(cached[1], ids, dense_inputs, label.reshape(-1), self.step_count, lr, self._ws_c,
+                                        auc_stats=auc_stats, num_thresholds=NUM_THRESHOLDS, status=self.status)
+
     def _scalar(self, name):
         b = getattr(self, "_s_" + name, None)
         if b is None:

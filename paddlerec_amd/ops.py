@@ -185,6 +185,43 @@ def din_train_step(net, hist_item, hist_cat, target_item, target_cat, label, mas
     return loss, pred
 
 
+def dcn_v2_train_step(net, ids, dense, label, step, lr, ws, auc_stats=None, num_thresholds=4095, status=None, out=None,
+                      beta1=0.9, beta2=0.999, eps=1e-8):
+    """The whole DCN-v2 train step through ONE C-ABI call (rec_dcn_v2_train_step).  net: a filled _lib.DcnV2Net (the
+    caller keeps the tensors it points into alive).  ids [B,S] i64, dense [B,Dn] f32, label [B(,1)] i64; step = Adam step
+    count (1-based).  -> (loss [1], pred [B,1])."""
+    _chk(ids, torch.int64, "ids")
+    if ids.dim() != 2 or ids.shape[1] != net.num_slots:
+        raise RecError("ids must be [batch, num_slots]")
+    B = ids.shape[0]
+    _chk(dense, torch.float32, "dense", (B, net.dense_dim))
+    _chk(label, torch.int64, "label")
+    if label.numel() != B:
+        raise RecError("label must have one value per sample")
+    dev = ids.device
+    if out is None:
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        pred = torch.empty(B, 1, dtype=torch.float32, device=dev)
+    else:
+        loss, pred = out
+    if status is None:
+        status = new_status(dev)
+    pos = neg = None
+    if auc_stats is not None:
+        pos, neg = auc_stats
+        _chk(pos, torch.int64, "stat_pos", (num_thresholds + 1,))
+        _chk(neg, torch.int64, "stat_neg", (num_thresholds + 1,))
+    h = _hyper(lr, beta1, beta2, eps, step)
+    nbytes = C.c_size_t(0)
+    check(lib().rec_dcn_v2_train_step_workspace_bytes(C.byref(net), B, C.byref(nbytes)),
+          "rec_dcn_v2_train_step_workspace_bytes")
+    w = ws.get(nbytes.value)
+    check(lib().rec_dcn_v2_train_step(C.byref(net), B, _p(ids), _p(dense), _p(label), C.byref(h), _p(pos), _p(neg),
+                                      int(num_thresholds), _p(loss), _p(pred), _p(status), _p(w), C.c_size_t(w.numel()),
+                                      _stream()), "rec_dcn_v2_train_step")
+    return loss, pred
+
+
 SUPPORTS_FEAT_LD = True       # deepfm_fm_fwd / _bwd take feat_ld (a padded sample stride of feat)
 
 
