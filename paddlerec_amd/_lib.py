@@ -297,7 +297,7 @@ SIGNATURES = {
                                        _I32, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _SZ, _P]),
     "rec_din_train_step_workspace_bytes": (C.c_int, [C.POINTER(DinNet), _I64, _I32, C.POINTER(C.c_size_t)]),
     "rec_din_train_step": (C.c_int, [C.POINTER(DinNet), _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
-                                     _SZ, _P]),
+                                     _SZ, _P, _P]),
     "rec_dcn_v2_train_step_workspace_bytes": (C.c_int, [C.POINTER(DcnV2Net), _I64, C.POINTER(C.c_size_t)]),
     "rec_dcn_v2_train_step": (C.c_int, [C.POINTER(DcnV2Net), _I64, _P, _P, _P, C.POINTER(AdamHyper), _P, _P, _I32, _P, _P,
                                         _P, _P, _SZ, _P]),

@@ -216,8 +216,8 @@ extern "C" int rec_deepfm_train_step_workspace_bytes(const rec_deepfm_net* net, 
 // device it was created on, and two host threads stepping two nets (distinct streams, as the contract asks) must not
 // re-record each other's events between a record and its wait.  Created on first use under a lock, kept for the life of
 // the process (a handful of entries: one per stream pair a caller ever steps on).
-static int step_events(void* stream, void* side_stream, hipEvent_t** out) {
-  struct Set { hipEvent_t ev[3]; };
+int rec::step_events(void* stream, void* side_stream, hipEvent_t** out) {
+  struct Set { hipEvent_t ev[kStepEvents]; };
   static std::mutex mu;
   static std::map<std::tuple<int, void*, void*>, Set> cache;
   int dev = 0;
@@ -226,7 +226,7 @@ static int step_events(void* stream, void* side_stream, hipEvent_t** out) {
   auto key = std::make_tuple(dev, stream, side_stream);
   auto it = cache.find(key);
   if (it == cache.end()) {
-    Set st{{nullptr, nullptr, nullptr}};
+    Set st{};
     for (auto& e : st.ev)
       REC_REQUIRE(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, REC_EHIP, "hipEventCreate failed");
     it = cache.emplace(key, st).first;

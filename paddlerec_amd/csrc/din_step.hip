@@ -64,10 +64,13 @@ int shape_of(const rec_din_net* net, int64_t B, int32_t T, Shape* s) {
 }
 
 struct Buffers {
-  float *pooled, *attw, *act1, *emb, *item_b, *x1, *x2, *logit, *dz, *d2, *d1, *de0, *dpooled, *dh, *dq, *pp;
-  int32_t *sorted_pos, *seg_offset, *n_uniq;
-  int64_t* uniq_rows;
-  void *ws, *ws_group, *ws_att, *ws_att_bwd;
+  float *pooled, *attw, *act1, *emb, *item_b, *x1, *x2, *logit, *dz, *d2, *d1, *de0, *dpooled, *dh, *dq;
+  // sort-based merge: one grouping buffer set and one hot-row partials buffer per [B, T] table (din.py: slot i), a fifth
+  // for the per-sample tables when the batch itself is above the one-launch merge
+  float* pp[5];
+  int32_t *sorted_pos[5], *seg_offset[5], *n_uniq[5];
+  int64_t* uniq_rows[5];
+  void *ws, *ws_group, *ws_group_side, *ws_att, *ws_att_bwd;
   size_t ws_bytes, ws_group_bytes, ws_att_bytes, ws_att_bwd_bytes;
 };
 
@@ -97,23 +100,28 @@ int carve(const rec_din_net* net, const Shape& s, void* workspace, Buffers* bf, 
   bf->dpooled = c.take<float>(B * E);
   bf->dh = c.take<float>(n * E);
   bf->dq = c.take<float>(n * E);
-  bf->pp = nullptr;
-  bf->sorted_pos = bf->seg_offset = bf->n_uniq = nullptr;
-  bf->uniq_rows = nullptr;
-  bf->ws_group = nullptr;
+  for (int i = 0; i < 5; ++i) {
+    bf->pp[i] = nullptr;
+    bf->sorted_pos[i] = bf->seg_offset[i] = bf->n_uniq[i] = nullptr;
+    bf->uniq_rows[i] = nullptr;
+  }
+  bf->ws_group = bf->ws_group_side = nullptr;
   bf->ws_group_bytes = 0;
-  if (!s.small) {                       // sort-based merge, one table after the other: one grouping buffer set
+  if (!s.small) {                       // sort-based merge of the four [B, T] tables
     size_t pb = 0, gb = 0, b = 0;
-    REC_TRY(rec_segment_partials_bytes((int64_t)n, s.Ei > s.Ec ? s.Ei : s.Ec, &pb));
-    bf->pp = (float*)c.bytes(pb > 4 ? pb : 4);
-    bf->sorted_pos = c.take<int32_t>(n);
-    bf->uniq_rows = c.take<int64_t>(n);
-    bf->seg_offset = c.take<int32_t>(n + 1);
-    bf->n_uniq = c.take<int32_t>(4);
+    for (int i = 0; i < 5; ++i) {
+      REC_TRY(rec_segment_partials_bytes((int64_t)n, i == 4 ? (s.Ei > s.Ec ? s.Ei : s.Ec) : i % 2 ? s.Ec : s.Ei, &pb));
+      bf->pp[i] = (float*)c.bytes(pb > 4 ? pb : 4);
+      bf->sorted_pos[i] = c.take<int32_t>(n);
+      bf->uniq_rows[i] = c.take<int64_t>(n);
+      bf->seg_offset[i] = c.take<int32_t>(n + 1);
+      bf->n_uniq[i] = c.take<int32_t>(4);
+    }
     REC_TRY(rec_ids_group_workspace_bytes((int64_t)n, net->item_rows, &gb));
     REC_TRY(rec_ids_group_workspace_bytes((int64_t)n, net->cat_rows, &b));
     if (b > gb) gb = b;
     bf->ws_group = c.bytes(gb);
+    bf->ws_group_side = c.bytes(gb);
     bf->ws_group_bytes = gb;
   }
   const rec_din_desc d = att_desc(net, s);
@@ -171,7 +179,7 @@ extern "C" int rec_din_train_step(const rec_din_net* net, int64_t batch, int32_t
                                   const int64_t* hist_cat, const int64_t* target_item, const int64_t* target_cat,
                                   const float* label, const int64_t* mask, const int64_t* target_item_seq,
                                   const int64_t* target_cat_seq, float lr, float* loss, float* pred, int32_t* status,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+                                  void* workspace, size_t workspace_bytes, void* stream, void* side_stream) {
   Shape s;
   REC_TRY(shape_of(net, batch, max_len, &s));
   REC_REQUIRE(hist_item && hist_cat && target_item && target_cat && label && mask && target_item_seq && target_cat_seq &&
@@ -189,6 +197,40 @@ extern "C" int rec_din_train_step(const rec_din_net* net, int64_t batch, int32_t
   const int64_t B = s.B;
   const int E = s.E, Ei = s.Ei, E2 = 2 * s.E, M1 = s.M1, M2 = s.M2;
   const rec_din_desc d = att_desc(net, s);
+
+  // ---- the SelectedRows merge and its two-stream schedule (din.py:_step).  Jobs in din.py's order: the target-seq
+  //      tables first (one row per sample collects all its history positions)
+  struct Job { int64_t n; const int64_t* ids; const float* grad; float* P; int dim; int64_t rows; int stride; };
+  const Job jobs[7] = {
+      {s.n, target_item_seq, bf.dq, net->w_tgt_item_seq, Ei, net->item_rows, E},
+      {s.n, target_cat_seq, bf.dq + Ei, net->w_tgt_cat_seq, s.Ec, net->cat_rows, E},
+      {s.n, hist_item, bf.dh, net->w_hist_item, Ei, net->item_rows, E},
+      {s.n, hist_cat, bf.dh + Ei, net->w_hist_cat, s.Ec, net->cat_rows, E},
+      {B, target_item, bf.de0 + E, net->w_tgt_item, Ei, net->item_rows, E2},
+      {B, target_cat, bf.de0 + E + Ei, net->w_tgt_cat, s.Ec, net->cat_rows, E2},
+      {B, target_item, bf.dz, net->w_item_b, 1, net->item_rows, 1}};
+  auto sorts = [&](const Job& j) { return !(j.n <= kSmallMergeMax && j.dim <= 256); };   // din.py:_sorts
+  // With a side stream and all four [B, T] tables on the sort-based merge: their merge keys (a function of the ids) are
+  // computed on the side stream from the start of the step, and behind the backward one item and one category table are
+  // updated on each stream.  Independent tables, same calls and arguments: the result does not depend on the schedule
+  const bool two = side_stream != nullptr && side_stream != stream && !s.small && sorts(jobs[0]) && sorts(jobs[1]) &&
+                   sorts(jobs[2]) && sorts(jobs[3]);
+  hipEvent_t* ev = nullptr;
+  if (two) REC_TRY(step_events(stream, side_stream, &ev));
+  auto order = [&](int k, void* from, void* to) -> int {    // everything issued on `from` so far happens before `to` goes on
+    REC_REQUIRE(hipEventRecord(ev[k], (hipStream_t)from) == hipSuccess &&
+                    hipStreamWaitEvent((hipStream_t)to, ev[k], 0) == hipSuccess, REC_EHIP, "stream ordering failed");
+    return REC_OK;
+  };
+  auto group = [&](int i, int b, void* ws, size_t ws_bytes, void* st) -> int {       // job i into buffer set b
+    const Job& j = jobs[i];
+    return rec_ids_group_payload(j.n, 1, j.rows, -1, j.ids, nullptr, nullptr, bf.sorted_pos[b], bf.uniq_rows[b],
+                                 bf.seg_offset[b], bf.n_uniq[b], status, ws, ws_bytes, st);
+  };
+  if (two) {
+    REC_TRY(order(0, stream, side_stream));
+    for (int i = 0; i < 4; ++i) REC_TRY(group(i, i, bf.ws_group_side, bf.ws_group_bytes, side_stream));
+  }
 
   // ---- forward (din.py:forward = net.py:139-184)
   REC_TRY(rec_din_attention_pool_fwd_ws(&d, hist_item, hist_cat, target_item_seq, target_cat_seq, mask, net->w_hist_item,
@@ -233,17 +275,7 @@ extern "C" int rec_din_train_step(const rec_din_net* net, int64_t batch, int32_t
                                         s.saves ? bf.pooled : nullptr, s.saves ? bf.act1 : nullptr, bf.dpooled, bf.dh,
                                         bf.dq, bf.ws_att_bwd, bf.ws_att_bwd_bytes, stream));
 
-  // ---- SGD (din/dygraph_model.py:64-73): merged rows of the seven tables, then the dense parameters in one launch.
-  //      Order as din.py: the target-seq tables first (one row per sample collects all its history positions)
-  struct Job { int64_t n; const int64_t* ids; const float* grad; float* P; int dim; int64_t rows; int stride; };
-  const Job jobs[7] = {
-      {s.n, target_item_seq, bf.dq, net->w_tgt_item_seq, Ei, net->item_rows, E},
-      {s.n, target_cat_seq, bf.dq + Ei, net->w_tgt_cat_seq, s.Ec, net->cat_rows, E},
-      {s.n, hist_item, bf.dh, net->w_hist_item, Ei, net->item_rows, E},
-      {s.n, hist_cat, bf.dh + Ei, net->w_hist_cat, s.Ec, net->cat_rows, E},
-      {B, target_item, bf.de0 + E, net->w_tgt_item, Ei, net->item_rows, E2},
-      {B, target_cat, bf.de0 + E + Ei, net->w_tgt_cat, s.Ec, net->cat_rows, E2},
-      {B, target_item, bf.dz, net->w_item_b, 1, net->item_rows, 1}};
+  // ---- SGD (din/dygraph_model.py:64-73): merged rows of the seven tables, then the dense parameters in one launch
   if (s.small) {
     rec_small_sgd_job sj[7];
     for (int i = 0; i < 7; ++i) {
@@ -254,21 +286,31 @@ extern "C" int rec_din_train_step(const rec_din_net* net, int64_t batch, int32_t
     }
     REC_TRY(rec_sparse_sgd_small_multi(7, sj, lr, status, stream));
   } else {
-    for (int i = 0; i < 7; ++i) {
+    auto update = [&](int i, bool grouped, void* st) -> int {
       const Job& j = jobs[i];
       const rec_grad_layout gl{1, 1, j.stride, nullptr, nullptr, 0};
-      if (j.n <= kSmallMergeMax && j.dim <= 256) {        // din.py:_sgd_rows: one launch per small table
-        REC_TRY(rec_sparse_sgd_small(j.n, j.dim, j.dim, j.rows, -1, j.ids, j.grad, &gl, j.P, lr, status, stream));
-        continue;
-      }
-      REC_TRY(rec_ids_group_payload(j.n, 1, j.rows, -1, j.ids, nullptr, nullptr, bf.sorted_pos, bf.uniq_rows,
-                                    bf.seg_offset, bf.n_uniq, status, bf.ws_group, bf.ws_group_bytes, stream));
-      REC_TRY(rec_segment_partials(j.n, j.dim, bf.n_uniq, bf.seg_offset, bf.sorted_pos, j.grad, &gl, bf.pp, stream));
+      if (!sorts(j))                                      // din.py:_sgd_rows: one launch per small table
+        return rec_sparse_sgd_small(j.n, j.dim, j.dim, j.rows, -1, j.ids, j.grad, &gl, j.P, lr, status, st);
+      const int b = i < 4 ? i : 4;
+      if (!grouped) REC_TRY(group(i, b, bf.ws_group, bf.ws_group_bytes, st));
+      REC_TRY(rec_segment_partials(j.n, j.dim, bf.n_uniq[b], bf.seg_offset[b], bf.sorted_pos[b], j.grad, &gl, bf.pp[b], st));
       rec_grad_layout glp = gl;
-      glp.partials = bf.pp;
-      REC_TRY(rec_sparse_sgd_rows(j.n, j.dim, j.dim, bf.n_uniq, bf.uniq_rows, bf.seg_offset, bf.sorted_pos, j.grad, &glp,
-                                  j.P, lr, stream));
+      glp.partials = bf.pp[b];
+      return rec_sparse_sgd_rows(j.n, j.dim, j.dim, bf.n_uniq[b], bf.uniq_rows[b], bf.seg_offset[b], bf.sorted_pos[b], j.grad,
+                                 &glp, j.P, lr, st);
+    };
+    if (two) {
+      REC_TRY(order(1, side_stream, stream));             // the merge keys
+      REC_TRY(order(2, stream, side_stream));             // the gradients
+      REC_TRY(update(0, true, side_stream));
+      REC_TRY(update(3, true, side_stream));
+      for (int i = 1; i < 7; ++i)
+        if (i != 3) REC_TRY(update(i, i < 4, stream));
+    } else {
+      for (int i = 0; i < 7; ++i) REC_TRY(update(i, false, stream));
     }
   }
-  return rec_sgd_dense(net->flat_numel, net->flat_param, net->flat_grad, lr, stream);
+  REC_TRY(rec_sgd_dense(net->flat_numel, net->flat_param, net->flat_grad, lr, stream));
+  if (two) REC_TRY(order(3, side_stream, stream));
+  return REC_OK;
 }

@@ -399,6 +399,58 @@ __global__ __launch_bounds__(kBlock) void skinny_dw_kernel(int M, int N, int64_t
   }
 }
 
+// The same partials for a NARROW A (M <= 128: the 40-wide head of DIN's top MLP): with one thread per column only M of the
+// 256 lanes would read, 128 dependent rows each (54 us at K 4096 x M 40).  Here 256 / M thread groups share the block's
+// k rows (group g takes rows g, g + G, ...), and group 0 folds the groups' sums through LDS in group order
+// (fixed order: deterministic).
+__global__ __launch_bounds__(kBlock) void skinny_dw_narrow_kernel(int M, int N, int64_t K, const float* __restrict__ A,
+                                                                  int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                                  int64_t ldc, float* __restrict__ partial,
+                                                                  float* __restrict__ colsum_partial) {
+  __shared__ float bs[kSkinnyKC * kSkinnyN];
+  __shared__ float red[kBlock * kSkinnyN];
+  const int64_t k0 = (int64_t)blockIdx.x * kSkinnyKC;
+  const int kc = (int)((K - k0 < kSkinnyKC) ? K - k0 : kSkinnyKC);
+  for (int i = threadIdx.x; i < kc * N; i += kBlock) bs[(i / N) * kSkinnyN + i % N] = B[(k0 + i / N) * ldb + i % N];
+  __syncthreads();
+  const int G = kBlock / M, g = (int)threadIdx.x / M, m = (int)threadIdx.x % M;
+  float acc[kSkinnyN] = {0.f, 0.f, 0.f, 0.f};
+  if (g < G) {
+    for (int kb = g; kb < kc; kb += 8 * G) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb + u * G;
+        x[u] = k < kc ? A[(k0 + k) * lda + m] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb + u * G;
+#pragma unroll
+        for (int n = 0; n < kSkinnyN; ++n)
+          if (n < N && k < kc) acc[n] += x[u] * bs[k * kSkinnyN + n];
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < kSkinnyN; ++n) red[threadIdx.x * kSkinnyN + n] = acc[n];
+  }
+  __syncthreads();
+  if (g == 0) {
+    for (int o = 1; o < G; ++o)
+#pragma unroll
+      for (int n = 0; n < kSkinnyN; ++n) acc[n] += red[(o * M + m) * kSkinnyN + n];
+    float* out = partial + (int64_t)blockIdx.x * M * ldc;
+#pragma unroll
+    for (int n = 0; n < kSkinnyN; ++n)
+      if (n < N) out[(int64_t)m * ldc + n] = acc[n];
+  }
+  if (colsum_partial && (int)threadIdx.x < N) {
+    float t = 0.f;
+    for (int k = 0; k < kc; ++k) t += bs[k * kSkinnyN + threadIdx.x];
+    colsum_partial[(int64_t)blockIdx.x * N + threadIdx.x] = t;
+  }
+}
+
 // column sums of G [M,N] (bias gradients): deterministic two-level reduction
 constexpr int kColsumRows = 64;
 __global__ __launch_bounds__(kBlock) void colsum_partial_kernel(int64_t M, int N, int64_t ld,
@@ -867,9 +919,9 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
     const int z = (int)((desc->k + kSkinnyKC - 1) / kSkinnyKC);
     float* part = (float*)workspace;
     float* cpart2 = (float*)((char*)workspace + align_up((size_t)z * desc->m * desc->ldc * sizeof(float), 256));
-    hipLaunchKernelGGL(skinny_dw_kernel, dim3(z), dim3(kBlock), 0, st, (int)desc->m, desc->n, (int64_t)desc->k, A,
-                       (int64_t)desc->lda, B, (int64_t)desc->ldb, (int64_t)desc->ldc, part,
-                       b_colsum ? cpart2 : nullptr);
+    hipLaunchKernelGGL(desc->m <= kBlock / 2 ? skinny_dw_narrow_kernel : skinny_dw_kernel, dim3(z), dim3(kBlock), 0, st,
+                       (int)desc->m, desc->n, (int64_t)desc->k, A, (int64_t)desc->lda, B, (int64_t)desc->ldb,
+                       (int64_t)desc->ldc, part, b_colsum ? cpart2 : nullptr);
     GemmPlan sp;
     sp.splits = z;
     launch_reduce<REC_EPI_NONE>(desc, sp, part, C, e, st);

@@ -163,4 +163,9 @@ inline int dispatch_row_shape(int D, int stride, F&& f) {
   return REC_ESHAPE;
 }
 
+// Fork / join events of a two-stream step schedule (csrc/deepfm_step.hip, csrc/din_step.hip): kStepEvents events per
+// (device, stream, side stream), created on first use and kept for the life of the process (defined in deepfm_step.hip).
+constexpr int kStepEvents = 4;
+int step_events(void* stream, void* side_stream, hipEvent_t** out);
+
 }  // namespace rec

@@ -35,6 +35,7 @@ class _StepBuffers:
     def __init__(self, k, device):
         self.ws, self.ws_group = k.Workspace(device), k.Workspace(device)
         self.ws_att_bwd = k.Workspace(device)      # the attention backward's ticket counter (its own: ws is the GEMMs')
+        self.ws_group_side = k.Workspace(device)   # the grouping workspace of the side stream (two-stream schedule)
         self.att_saved, self.groups, self.partials = {}, {}, {}
 
 
@@ -84,6 +85,7 @@ class DINLayer:
         self.status = self.k.new_status(self.device)
         self._att_saved = {}     # what the attention-pool forward keeps for its backward (buffers reused per step)
         self._bufs = None        # the eager train step's reusable buffers (_StepBuffers)
+        self._side = None        # side stream of the two-stream merge schedule (_step)
         self._graph = None       # StepGraph of train_step_graphed
         self._plans, self._recording = collections.OrderedDict(), False    # recorded call lists (plan.py), per signature
         self.step_count = 0
@@ -139,19 +141,32 @@ class DINLayer:
         """paddle.optimizer.lr.PiecewiseDecay(boundaries=[410000], values=[base_lr, 0.2]) (dygraph_model.py:65-70)."""
         return base_lr if step < 410000 else 0.2
 
-    def _sgd_rows(self, bufs, ids, grad_view, table, lr, row_stride_floats):
+    def _sorts(self, n, table):
+        """Does the row update of n lookups into `table` take the sort-based merge (else: one rec_sparse_sgd_small launch)."""
+        return not (n <= getattr(self.k, "SMALL_MERGE_MAX", 0) and table.shape[1] <= 256)
+
+    def _group(self, bufs, ids, table, slot=None, ws=None):
+        """SelectedRows merge keys of `ids` into the grouping buffers `slot` (None: the one set the tables share when they
+        are grouped one after the other)."""
+        key = (ids.numel(), slot)
+        grp = bufs.groups.get(key)
+        if grp is None:
+            grp = bufs.groups[key] = self.k.IdGroups(ids.numel(), self.device)
+        self.k.ids_group(ids.reshape(-1), table.shape[0], None, ws if ws is not None else bufs.ws_group, None, self.status,
+                         grp)
+        return grp
+
+    def _sgd_rows(self, bufs, ids, grad_view, table, lr, row_stride_floats, grp=None, slot=None):
         n = ids.numel()
-        if n <= getattr(self.k, "SMALL_MERGE_MAX", 0) and table.shape[1] <= 256:
+        if not self._sorts(n, table):
             # the shipped batch size (32 x ~150 positions): merge + update in ONE launch instead of the 12-13 of
             # sort + partials + row update — the launches, not the work, are the step time there
             self.k.sparse_sgd_small(ids.reshape(-1), grad_view, table, lr, None, self.status, grad_group=1,
                                     grad_group_stride=row_stride_floats)
             return
-        key = n
-        grp = bufs.groups.get(key)
         if grp is None:
-            grp = bufs.groups[key] = self.k.IdGroups(n, self.device)
-        self.k.ids_group(ids.reshape(-1), table.shape[0], None, bufs.ws_group, None, self.status, grp)
+            grp = self._group(bufs, ids, table)
+        key = (n, slot)
         pp = bufs.partials[key, table.shape[1]] = self.k.segment_partials(grp, grad_view, table.shape[1], grad_group=1,
                                                         grad_group_stride=row_stride_floats,
                                                         out=bufs.partials.get((key, table.shape[1])))   # popular items: hot rows
@@ -238,10 +253,16 @@ class DINLayer:
         if getattr(self, "_ws_c", None) is None:
             self._ws_c = self.k.Workspace(self.device)
         B, T = hist_item_seq.shape
+        side = None
+        if (self.device.type == "cuda" and self._sorts(B * T, self.params["hist_item_emb_attr.weight"])
+                and os.environ.get("REC_DIN_SIDE", "1") != "0"):
+            if self._side is None:
+                self._side = self.k.concurrent_stream(self.device)
+            side = self._side                   # the two-stream schedule of _step (large batches)
         return self.k.din_train_step(self.c_net(), hist_item_seq, hist_cat_seq, target_item.reshape(-1).contiguous(),
                                      target_cat.reshape(-1).contiguous(), label.reshape(-1).contiguous(),
                                      mask.reshape(B, T).contiguous(), target_item_seq, target_cat_seq, lr, self._ws_c,
-                                     status=self.status)
+                                     status=self.status, side_stream=side)
 
     def train_step_graphed(self, hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq,
                            target_cat_seq, base_lr=0.85):
@@ -265,6 +286,23 @@ class DINLayer:
         p, E, Ei = self.params, self.firInDim, self.item_emb_size
         B, T = hist_item_seq.shape
         sv = {}
+        # Two-stream schedule of the sort-based merge (batches above the one-launch merge): the merge keys of the four
+        # [B, T] tables depend on the ids only — grouped on a side stream from the start of the step —, and the four row
+        # updates, independent tables, go two per stream behind the backward.  Same calls, same arguments: bit-identical
+        # (B 4096: 1.72 -> 1.47 ms at T 100, 5.34 -> 5.04 ms at T 512; profiles/r05_din.txt)
+        seq = [(target_item_seq, p["target_item_seq_emb_attr.weight"]), (target_cat_seq, p["target_cat_seq_emb_attr.weight"]),
+               (hist_item_seq, p["hist_item_emb_attr.weight"]), (hist_cat_seq, p["hist_cat_emb_attr.weight"])]
+        two = (self.k is _ops and self.device.type == "cuda" and os.environ.get("REC_DIN_SIDE", "1") != "0"
+               and all(self._sorts(ids.numel(), tab) for ids, tab in seq) and not torch.cuda.is_current_stream_capturing())
+        pre = [None] * 7
+        if two:
+            if self._side is None:
+                self._side = self.k.concurrent_stream(self.device)
+            cur, side = torch.cuda.current_stream(), self._side
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for i, (ids, tab) in enumerate(seq):
+                    pre[i] = self._group(bufs, ids, tab, slot=i, ws=bufs.ws_group_side)
         logit = self.forward(hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask,
                              target_item_seq, target_cat_seq, _keep=sv, _bufs=bufs)
         pred, dz, loss = self.k.bce_with_logits(logit, label.reshape(B, 1).contiguous(), bufs.ws)
@@ -307,10 +345,23 @@ class DINLayer:
             # the shipped batch size: the seven independent merges share ONE launch (rec_sparse_sgd_small_multi)
             self.k.sparse_sgd_small_multi([(ids.reshape(-1), gv, tab, 1, rs) for ids, gv, tab, rs in jobs], lr,
                                           self.status)
+        elif two:
+            cur.wait_stream(side)                               # the merge keys
+            side.wait_stream(cur)                               # the gradients
+            on_side = (0, 3)            # one item and one category table per stream
+            with torch.cuda.stream(side):
+                for i in on_side:
+                    ids, gv, tab, rs = jobs[i]
+                    self._sgd_rows(bufs, ids, gv, tab, lr, rs, grp=pre[i], slot=i)
+            for i, (ids, gv, tab, rs) in enumerate(jobs):
+                if i not in on_side:
+                    self._sgd_rows(bufs, ids, gv, tab, lr, rs, grp=pre[i], slot=i)
         else:
             for ids, gv, tab, rs in jobs:
                 self._sgd_rows(bufs, ids, gv, tab, lr, rs)
         self.k.sgd_dense(self._dense, self._dense_grad, lr)      # all four Linear layers (every gradient was written above)
+        if two:
+            cur.wait_stream(side)
         return loss, pred
 
 

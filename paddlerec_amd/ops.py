@@ -154,7 +154,7 @@ def deepfm_train_step(net, ids, dense, label, step, ws, lr=1e-3, beta1=0.9, beta
 
 
 def din_train_step(net, hist_item, hist_cat, target_item, target_cat, label, mask, target_item_seq, target_cat_seq, lr, ws,
-                   status=None, out=None):
+                   status=None, out=None, side_stream=None):
     """The whole DIN train step through ONE C-ABI call (rec_din_train_step).  net: a filled _lib.DinNet (the caller keeps
     the tensors it points into alive).  ids / mask [B,T] i64, targets [B] i64, label [B] f32.  -> (loss [1], pred [B,1])."""
     B, T = hist_item.shape
@@ -181,7 +181,8 @@ def din_train_step(net, hist_item, hist_cat, target_item, target_cat, label, mas
     w = ws.get(nbytes.value)
     check(lib().rec_din_train_step(C.byref(net), B, T, _p(hist_item), _p(hist_cat), _p(target_item), _p(target_cat),
                                    _p(label), _p(mask), _p(target_item_seq), _p(target_cat_seq), float(lr), _p(loss),
-                                   _p(pred), _p(status), _p(w), C.c_size_t(w.numel()), _stream()), "rec_din_train_step")
+                                   _p(pred), _p(status), _p(w), C.c_size_t(w.numel()), _stream(),
+                                   None if side_stream is None else C.c_void_p(side_stream.cuda_stream)), "rec_din_train_step")
     return loss, pred
 
 

@@ -35,7 +35,8 @@ def _problem(rng, B, Tn, ni, nc):
     (32, (40, 152, 40), 64, 64),          # din/config.yaml: batch 32 — one rec_sparse_sgd_small_multi launch
     (7, (5, 1, 9), 8, 8),                 # a shape whose attention forward saves no layer-1 activations
     (200, (100, 60), 64, 64),             # 20 000 history lookups: sort-based merge for the history tables
-    (120, (120,), 32, 96)])               # 14 400 lookups: still the one-launch merge, uneven item / category widths
+    (120, (120,), 32, 96),                # 14 400 lookups: still the one-launch merge, uneven item / category widths
+    (16000, (2,), 16, 16)])               # the per-sample tables above the one-launch merge too (their own buffer set)
 def test_c_step_equals_the_mirror_bit_for_bit(engine_lib, B, lens, Ei, Ec):
     from paddlerec_amd.din import DINLayer
     rng = np.random.default_rng(B + Ei)
@@ -65,6 +66,30 @@ def test_c_step_equals_the_mirror_bit_for_bit(engine_lib, B, lens, Ei, Ec):
     assert int(a.status.item()) == 0 and int(b.status.item()) == 0
 
 
+def test_two_stream_schedule_changes_no_bit(engine_lib, monkeypatch):
+    """Batches on the sort-based merge group their keys on a side stream and update two tables per stream (REC_DIN_SIDE,
+    default on): mirror and C entry, one stream against two."""
+    from paddlerec_amd.din import DINLayer
+    ni, nc, B, Tn = 900, 60, 256, 80
+    runs = {}
+    for side in ("0", "1"):
+        monkeypatch.setenv("REC_DIN_SIDE", side)
+        for entry in ("train_step", "train_step_c"):
+            torch.manual_seed(11)
+            rng = np.random.default_rng(4)
+            m = DINLayer(64, 64, "sigmoid", False, True, ni, nc, device=DEV)
+            for _ in range(3):
+                loss, pred = getattr(m, entry)(*_problem(rng, B, Tn, ni, nc), base_lr=0.5)
+            torch.cuda.synchronize()
+            runs[side, entry] = (loss.clone(), pred.clone(), {k: v.clone() for k, v in m.state_dict().items()})
+            assert (m._side is not None) == (side == "1")
+    ref = runs["0", "train_step"]
+    for key, (loss, pred, sd) in runs.items():
+        assert torch.equal(loss, ref[0]) and torch.equal(pred, ref[1]), key
+        for k, v in sd.items():
+            assert torch.equal(v, ref[2][k]), (key, k)
+
+
 def test_c_step_argument_checks(engine_lib):
     import ctypes as C
     from paddlerec_amd import _lib
@@ -81,5 +106,6 @@ def test_c_step_argument_checks(engine_lib):
     rc = _lib.lib().rec_din_train_step(C.byref(net), 4, 6, *[C.c_void_p(t.data_ptr()) for t in
                                                              (bt[0], bt[1], bt[2], bt[3], bt[4], bt[5], bt[6], bt[7])],
                                        C.c_float(0.1), C.c_void_p(loss.data_ptr()), C.c_void_p(pred.data_ptr()),
-                                       C.c_void_p(m.status.data_ptr()), C.c_void_p(small.data_ptr()), C.c_size_t(16), None)
+                                       C.c_void_p(m.status.data_ptr()), C.c_void_p(small.data_ptr()), C.c_size_t(16), None,
+                                       None)
     assert rc != 0 and b"workspace" in _lib.lib().rec_last_error()

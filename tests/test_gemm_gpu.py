@@ -114,6 +114,14 @@ def test_gemm_skinny_paths(ops):
     np.testing.assert_allclose(db.cpu().numpy(), G.astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
     dW2 = ops.gemm(t(A), t(G), ws, trans_a=True, b_colsum=db)
     assert torch.equal(dW, dW2)
+    # narrow inputs (DIN's 40-wide head): thread groups share a block's k rows (skinny_dw_narrow_kernel)
+    for Kn, Mn, Nn in ((4096, 40, 1), (5001, 128, 3), (1024, 1, 1), (2500, 100, 4), (3000, 129, 2)):
+        A2, G2 = _mk(rng, Kn, Mn), _mk(rng, Kn, Nn)
+        db2 = torch.empty(Nn, device=DEV)
+        got = ops.gemm(t(A2), t(G2), ws, trans_a=True, b_colsum=db2)
+        np.testing.assert_allclose(got.cpu().numpy(), A2.astype(np.float64).T @ G2.astype(np.float64), rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(db2.cpu().numpy(), G2.astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
+        assert torch.equal(got, ops.gemm(t(A2), t(G2), ws, trans_a=True, b_colsum=db2))
 
 
 def test_gemm_strided_views_and_inplace_out(ops):
