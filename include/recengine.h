@@ -487,6 +487,16 @@ int rec_adam_rows_all(int64_t num_rows, int32_t emb_dim, int32_t row_stride, int
                       const float* grad_scale, float* P, float* M, float* V, const rec_adam_hyper* hyper,
                       void* stream);
 
+/* The same on the record layout of rec_sparse_adam_record (rec = W(D) | W1 | m1 | v1 | pad, MV = m(D) | v(D) at v_offset):
+ * both embeddings of every row in ONE pass — 512 B per row where two rec_adam_rows_all passes move 768 (the second
+ * one reads and writes the whole record line for W1 / m1 / v1).  Same arithmetic and summation order: bit-identical. */
+int rec_adam_record_all(int64_t num_rows, int32_t emb_dim, int32_t rec_stride, int32_t state_stride,
+                        int32_t v_offset, const int32_t* n_uniq, const int64_t* uniq_rows,
+                        const int32_t* seg_offset, const int32_t* sorted_pos, const float* grad,
+                        const rec_grad_layout* grad_layout, const float* grad1,
+                        const rec_grad_layout* grad1_layout, const float* grad_scale, float* rec, float* MV,
+                        const rec_adam_hyper* hyper, void* stream);
+
 /* dense Adam over a flat buffer (MLP + FM dense weights); grad_scale as above. */
 int rec_adam_dense(int64_t n, float* p, float* m, float* v, const float* g, const float* grad_scale,
                    const rec_adam_hyper* hyper, void* stream);

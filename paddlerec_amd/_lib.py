@@ -190,6 +190,8 @@ SIGNATURES = {
                                        _P, _P, _P, C.POINTER(AdamHyper), _P]),
     "rec_sparse_adam_record": (C.c_int, [_I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
                                          C.POINTER(GradLayout), _P, _P, _P, C.POINTER(AdamHyper), _P]),
+    "rec_adam_record_all": (C.c_int, [_I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
+                                      C.POINTER(GradLayout), _P, _P, _P, C.POINTER(AdamHyper), _P]),
     "rec_multislot_sumpool_fwd": (C.c_int, [C.POINTER(MultislotDesc)] + [_P] * 10),
     "rec_feasign_rows": (C.c_int, [_I64, _I64, _P, _P, _P]),
     "rec_feasign_rows_host": (C.c_int, [_I64, _I64, _P, _P]),

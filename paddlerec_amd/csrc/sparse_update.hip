@@ -674,6 +674,77 @@ __global__ __launch_bounds__(kBlock) void adam_rows_all_kernel(
   vstore<VEC>(V + so, v);
 }
 
+// The same on the record layout of sparse_adam_record_kernel — rec [N, stride] = W(D) | W1 | m1 | v1 | pad, MV [N, sstride] =
+// m(D) | v(D) at v_off — so that the dygraph-default optimizer touches a row's two lines once: two adam_rows_all passes
+// (W, then W1 / m1 / v1 as three strided 4-byte columns of the SAME record line) move 768 B per row, this one 512
+// (26 M rows x D 16: 20 GB -> 13.3 GB per step).  Same arithmetic and summation order as the two passes: bit-identical.
+template <int VEC, int LANES>
+__global__ __launch_bounds__(kBlock) void adam_record_all_kernel(
+    int64_t N, int D, int stride, int sstride, int v_off, const int32_t* __restrict__ n_uniq,
+    const int64_t* __restrict__ uniq, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ spos,
+    const float* __restrict__ grad, rec_grad_layout gl, const float* __restrict__ grad1, rec_grad_layout gl1,
+    const float* __restrict__ grad_scale, float* __restrict__ rec, float* __restrict__ MV, float lr_t, float eps_t,
+    float b1, float b2) {
+  constexpr int RB = kBlock / LANES;
+  __shared__ int slot[RB];
+  __shared__ int range[2];
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+  for (int i = threadIdx.x; i < RB; i += kBlock) slot[i] = -1;
+  if (threadIdx.x < 2) {
+    const int64_t key = r0 + (threadIdx.x ? RB : 0);
+    int lo = 0, hi = n_uniq[0];
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (uniq[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    range[threadIdx.x] = lo;
+  }
+  __syncthreads();
+  for (int u = range[0] + threadIdx.x; u < range[1]; u += kBlock) slot[(int)(uniq[u] - r0)] = u;
+  __syncthreads();
+  const int lr_ = threadIdx.x / LANES, lg = threadIdx.x % LANES;
+  const int64_t row = r0 + lr_;
+  const int d0 = lg * VEC;
+  if (row >= N) return;
+  const int u = slot[lr_];
+  const float sc = grad_scale ? grad_scale[0] : 1.f;
+  float* r = rec + row * stride;
+  if (d0 < D) {
+    float p[VEC], m[VEC], v[VEC], g[VEC];
+    float* mv = MV + row * sstride;
+    vload<VEC>(p, r + d0);
+    vload<VEC>(m, mv + d0);
+    vload<VEC>(v, mv + v_off + d0);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+    if (u >= 0) {
+      segment_sum<VEC>(g, seg_off[u], seg_off[u + 1], spos, grad, gl, D, d0);
+      if (grad_scale) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g[i] *= sc;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) adam_elem(p[i], m[i], v[i], g[i], lr_t, eps_t, b1, b2);
+    vstore_nt<VEC>(r + d0, p);                       // the whole table streams through: nothing of it is wanted in L2
+    vstore_nt<VEC>(mv + d0, m);
+    vstore_nt<VEC>(mv + v_off + d0, v);
+  }
+  if (lg == 0) {
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (VEC == 4) vload<4>(q, r + D);
+    else { q[0] = r[D]; q[1] = r[D + 1]; q[2] = r[D + 2]; }
+    float g1[1] = {0.f};
+    if (u >= 0) {
+      segment_sum<1>(g1, seg_off[u], seg_off[u + 1], spos, grad1, gl1, 1, 0);
+      if (grad_scale) g1[0] *= sc;
+    }
+    adam_elem(q[0], q[1], q[2], g1[0], lr_t, eps_t, b1, b2);
+    if constexpr (VEC == 4) vstore_nt<4>(r + D, q);
+    else { r[D] = q[0]; r[D + 1] = q[1]; r[D + 2] = q[2]; }
+  }
+}
+
 // paddle.optimizer.SGD on the touched rows (din/dygraph_model.py:64-73; rows with zero gradient do not move,
 // so updating only the merged rows IS dense SGD): p -= lr * sum of the row's duplicate gradients
 template <int VEC, int LANES>
@@ -1397,6 +1468,42 @@ extern "C" int rec_sparse_adam_record(int64_t n_max, int32_t emb_dim, int32_t re
                        seg_offset, sorted_pos, grad, gl, grad1, gl1, grad_scale, rec, MV, lr_t, eps_t,
                        hyper->beta1, hyper->beta2, sparse_nt);
     return check_launch("rec_sparse_adam_record");
+  });
+}
+
+extern "C" int rec_adam_record_all(int64_t num_rows, int32_t emb_dim, int32_t rec_stride, int32_t state_stride,
+                                   int32_t v_offset, const int32_t* n_uniq, const int64_t* uniq_rows,
+                                   const int32_t* seg_offset, const int32_t* sorted_pos, const float* grad,
+                                   const rec_grad_layout* grad_layout, const float* grad1,
+                                   const rec_grad_layout* grad1_layout, const float* grad_scale, float* rec, float* MV,
+                                   const rec_adam_hyper* hyper, void* stream) {
+  rec_grad_layout gl = {1, 0, 0, nullptr, nullptr}, gl1 = {1, 0, 0, nullptr, nullptr};
+  if (grad_layout) gl = *grad_layout;
+  if (grad1_layout) gl1 = *grad1_layout;
+  REC_REQUIRE(num_rows >= 0 && emb_dim > 0 && rec_stride >= emb_dim + 3 && gl.div >= 1 && gl1.div >= 1, REC_EINVAL,
+              "bad sizes (the record holds W(D) | W1 | m1 | v1)");
+  REC_REQUIRE(v_offset >= emb_dim && state_stride >= v_offset + emb_dim, REC_EINVAL,
+              "state line must hold m(D) at 0 and v(D) at v_offset");
+  REC_REQUIRE(gl.group <= 0 || gl.group_stride >= (int64_t)gl.group * emb_dim, REC_EINVAL, "grad group_stride too small");
+  REC_REQUIRE(((uintptr_t)gl.partials) % 16 == 0 && ((uintptr_t)gl1.partials) % 4 == 0, REC_EINVAL,
+              "grad_layout.partials must be 16-byte aligned");
+  REC_REQUIRE(n_uniq && uniq_rows && seg_offset && sorted_pos && grad && grad1 && rec && MV && hyper, REC_EINVAL,
+              "null pointer argument");
+  REC_REQUIRE(hyper->step >= 1, REC_EINVAL, "Adam step must be >= 1");
+  if (num_rows == 0) return REC_OK;
+  float lr_t, eps_t;
+  adam_scalars(hyper, &lr_t, &eps_t);
+  const bool vec = ((uintptr_t)grad) % 16 == 0 && (gl.group <= 0 || gl.group_stride % 4 == 0) && state_stride % 4 == 0 &&
+                   v_offset % 4 == 0 && ((uintptr_t)rec) % 16 == 0 && ((uintptr_t)MV) % 16 == 0;
+  return dispatch_row_shape(emb_dim, vec ? rec_stride : rec_stride | 1, [&](auto vec_, auto lanes) -> int {
+    constexpr int VEC = decltype(vec_)::value, LANES = decltype(lanes)::value;
+    constexpr int RB = kBlock / LANES;
+    const int64_t grid = (num_rows + RB - 1) / RB;
+    REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "too many rows");
+    hipLaunchKernelGGL((adam_record_all_kernel<VEC, LANES>), dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream,
+                       num_rows, emb_dim, rec_stride, state_stride, v_offset, n_uniq, uniq_rows, seg_offset, sorted_pos,
+                       grad, gl, grad1, gl1, grad_scale, rec, MV, lr_t, eps_t, hyper->beta1, hyper->beta2);
+    return check_launch("rec_adam_record_all");
   });
 }
 

@@ -597,6 +597,11 @@ class DeepFMLayer:
                     D = self.sparse_feature_dim
                     self.k.sparse_adam_record(groups, row_grad, dz, S, self.fm.rec, st["mv"], D, t, lr,
                                               v_offset=_round_up(D, 4), partials=pp, partials1=pp1, **skw)
+                elif hasattr(self.k, "adam_record_all") and os.environ.get("REC_NONLAZY_RECORD", "1") != "0":
+                    # the dygraph default: every row moves — both embeddings and their moments in ONE sweep of the table
+                    D = self.sparse_feature_dim
+                    self.k.adam_record_all(groups, row_grad, dz, S, self.fm.rec, st["mv"], D, t, lr,
+                                           v_offset=_round_up(D, 4), partials=pp, partials1=pp1)
                 else:
                     upd(groups, row_grad, 1, self.fm.embedding, st["m"], st["v"], t, lr, partials=pp)
                     upd(groups, dz, S, self.fm.embedding_one, st["m1"], st["v1"], t, lr, partials=pp1)

@@ -644,6 +644,27 @@ def sparse_adam_record(groups, grad, grad1, grad1_div, rec, mv, D, step, lr=1e-3
                                        C.byref(h), _stream()), "rec_sparse_adam_record")
 
 
+def adam_record_all(groups, grad, grad1, grad1_div, rec, mv, D, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                    v_offset=None, grad_scale=None, partials=None, partials1=None):
+    """lazy_mode=False Adam (dygraph default) on BOTH embeddings of every row of the record layout of sparse_adam_record in
+    one pass (rec_adam_record_all)."""
+    _chk(grad, torch.float32, "grad")
+    _chk(grad1, torch.float32, "grad1")
+    for t, n in ((rec, "rec"), (mv, "mv")):
+        if t.dim() != 2 or t.dtype != torch.float32 or not t.is_cuda or t.stride(1) != 1:
+            raise RecError("%s must be a 2-D float32 device tensor with unit column stride" % n)
+    if mv.shape[0] != rec.shape[0]:
+        raise RecError("rec and mv must have the same number of rows")
+    if v_offset is None:
+        v_offset = (D + 3) // 4 * 4
+    h = _hyper(lr, beta1, beta2, eps, step)
+    check(lib().rec_adam_record_all(rec.shape[0], int(D), rec.stride(0), mv.stride(0), int(v_offset),
+                                    _p(groups.n_uniq), _p(groups.uniq_rows), _p(groups.seg_offset),
+                                    _p(groups.sorted_pos), _p(grad), C.byref(_gl(1, 0, 0, partials)), _p(grad1),
+                                    C.byref(_gl(grad1_div, 0, 0, partials1)), _p(grad_scale), _p(rec), _p(mv),
+                                    C.byref(h), _stream()), "rec_adam_record_all")
+
+
 def adam_rows_all(groups, grad, grad_div, P, M, V, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
                   grad_group=0, grad_group_stride=0, grad_scale=None, partials=None):
     """lazy_mode=False Adam (dygraph default): every row of P/M/V moves, absent rows with g = 0."""

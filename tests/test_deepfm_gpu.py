@@ -416,6 +416,35 @@ def test_adam_rows_all_nonlazy_vs_oracle(ops, D):
     np.testing.assert_allclose(N_(tv), V, rtol=1e-5, atol=1e-12)
 
 
+@pytest.mark.parametrize("D,stride", [(16, 32), (9, 16), (10, 16), (40, 64)])
+def test_adam_record_all_equals_two_sweeps(ops, D, stride):
+    """rec_adam_record_all: the dygraph-default (non-lazy) Adam on both embeddings of every row of the record layout in ONE
+    sweep == rec_adam_rows_all on W and again on W1 / m1 / v1 (the oracle-checked path above), bit for bit; the pad floats
+    of the record stay untouched."""
+    rng = np.random.default_rng(D)
+    N, B, S = 1500, 200, 26
+    ids = rng.integers(0, N, (B, S)).astype(np.int64)
+    ids[rng.random((B, S)) < 0.1] = 0
+    ids[:, 0] = 7
+    grad = T((rng.standard_normal((B * S, D)) * 1e-2).astype(np.float32))
+    dz = T((rng.standard_normal(B) * 1e-2).astype(np.float32))
+    Dp = (D + 3) // 4 * 4
+    rec = T(rng.standard_normal((N, stride)).astype(np.float32))
+    rec[:, D + 1:D + 3] = rec[:, D + 1:D + 3].abs() * 1e-3
+    mv = T((rng.random((N, -(-2 * Dp // 32) * 32)) * 1e-3).astype(np.float32))
+    rec2, mv2 = rec.clone(), mv.clone()
+    ws = ops.Workspace(DEV)
+    groups, _ = ops.ids_group(T(ids), N, 0, ws)
+    pp = ops.segment_partials(groups, grad, D)
+    pp1 = ops.segment_partials(groups, dz, 1, grad_div=S)
+    for step in (1, 2):
+        ops.adam_record_all(groups, grad, dz, S, rec, mv, D, step, lr=1e-2, v_offset=Dp, partials=pp, partials1=pp1)
+        ops.adam_rows_all(groups, grad, 1, rec2[:, :D], mv2[:, :D], mv2[:, Dp:Dp + D], step, lr=1e-2, partials=pp)
+        ops.adam_rows_all(groups, dz, S, rec2[:, D:D + 1], rec2[:, D + 1:D + 2], rec2[:, D + 2:D + 3], step, lr=1e-2,
+                          partials=pp1)
+    assert torch.equal(rec, rec2) and torch.equal(mv, mv2)
+
+
 def test_adam_dense_vs_oracle(ops):
     rng = np.random.default_rng(0)
     n = 100003
