@@ -19,6 +19,7 @@ LIB = os.path.join(HERE, "librecengine.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"),
          "-I" + CSRC, "-Wno-unused-result"]
+FLAGS += os.environ.get("REC_HIPCC_DEFINES", "").split()      # measurement builds only (e.g. -DREC_DIN_PHASE_TIMING)
 
 
 def _hipcc():

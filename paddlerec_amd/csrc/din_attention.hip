@@ -41,7 +41,48 @@ struct DinArgs {
   unsigned int* ticket;    // large batches with a workspace: zeroed counter the blocks draw their next sample from
 };
 
+// -DREC_DIN_PHASE_TIMING: wave 0 of every block sums the shader cycles it spends in each phase of a tile into
+// din_phase_dbg (tools/din_phase_probe.py reads it through rec_din_debug_phases) — a measurement build, never shipped.
+#ifdef REC_DIN_PHASE_TIMING          // = 1: the forward kernel, = 2: the backward kernel
+__device__ unsigned long long din_phase_dbg[16];
+#define DIN_PH_DECL_ unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define DIN_PH_(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_acc[k] += n_ - ph_t; ph_t = n_; } while (0)
+#define DIN_PH_FLUSH_ do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 10; ++k_) atomicAdd(&din_phase_dbg[k_], ph_acc[k_]); } while (0)
+#endif
+#if defined(REC_DIN_PHASE_TIMING) && REC_DIN_PHASE_TIMING == 1
+#define DIN_PH_DECL DIN_PH_DECL_
+#define DIN_PH(k) DIN_PH_(k)
+#define DIN_PH_FLUSH DIN_PH_FLUSH_
+#else
+#define DIN_PH_DECL
+#define DIN_PH(k)
+#define DIN_PH_FLUSH
+#endif
+#if defined(REC_DIN_PHASE_TIMING) && REC_DIN_PHASE_TIMING == 2
+#define DIN_PHB_DECL DIN_PH_DECL_
+#define DIN_PHB(k) DIN_PH_(k)
+#define DIN_PHB_FLUSH DIN_PH_FLUSH_
+#else
+#define DIN_PHB_DECL
+#define DIN_PHB(k)
+#define DIN_PHB_FLUSH
+#endif
+
+// Block barrier that orders LDS traffic only: __syncthreads() also drains the wave's outstanding GLOBAL loads
+// (s_waitcnt vmcnt(0)), which would end a prefetch issued in front of it.  Use only where no wave of the block reads
+// global memory another wave of the block wrote before the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+// sum over the 16 lanes of a DPP row (lane & 15), every lane gets it: the pairs of the xor-8/4/2/1 butterfly (rotations by
+// 8 and 4 inside the row meet the same partner values), on the VALU instead of four ds_bpermute round trips
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  return v;
+}
 __device__ __forceinline__ float dout_k_of(const float* dout, int64_t b, int E, int k) { return dout[b * E + k]; }
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -369,6 +410,9 @@ __device__ __forceinline__ void din_l1_segment(const float* __restrict__ hs, con
       if (SEG == 3) { av[a][0] = hv.x * qv.x; av[a][1] = hv.y * qv.y; av[a][2] = hv.z * qv.z; av[a][3] = hv.w * qv.w; }
     }
   };
+  // The operands are SWAPPED (W1 fragment as A, activations as B): the tile comes out transposed — lane (li, g) holds
+  // columns b*16 + 4g .. + 3 of position a*16 + li — so a lane's four values are contiguous in the row-major [p][c]
+  // buffers and the partial sums move as 16-byte LDS accesses instead of four 4-byte ones (same products, same order).
   // one K block ahead in registers; the scheduling fences keep the compiler from hoisting all E/16 blocks' LDS
   // reads to the top (64 more live registers - the W1 fragments would spill)
   float av[2][2][4];
@@ -382,8 +426,47 @@ __device__ __forceinline__ void din_l1_segment(const float* __restrict__ hs, con
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < H1 / 16; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb & 1][a][s], bf[kb][b][s], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kb][b][s], av[kb & 1][a][s], acc[a][b], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Layer 2 (+ layer 3 in the epilogue) for J of a wave's (m, n) tiles n = n0, n0 + 2, ...: lp[n][p] = sum_c a2[p][c] w3[c].
+// J is a compile-time count so that the k loop has no branch in it (a wave-uniform `if` per MFMA compiled to one scalar
+// branch, one LDS read and one s_waitcnt per MFMA: 40 serial LDS round trips per tile).
+template <int J, class S>
+__device__ __forceinline__ void din_l2_tiles(const float* __restrict__ X, const float* __restrict__ w2s,
+                                             const float* __restrict__ b2s, const float* __restrict__ w3s,
+                                             float* __restrict__ lp, int m, int n0, int li, int g) {
+  if constexpr (J > 0) {
+    f32x4_t z[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) z[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < S::NT1; ++kb) {
+      const int k0 = kb * 16 + 4 * g;
+      const float4 av = *reinterpret_cast<const float4*>(X + (m * 16 + li) * S::H1P + k0);
+      const float a4[4] = {av.x, av.y, av.z, av.w};
+      float bv[4][J];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < J; ++j) bv[s][j] = w2s[(k0 + s) * S::W2P + (n0 + 2 * j) * 16 + li];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < J; ++j) z[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], bv[s][j], z[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int n = n0 + 2 * j, c = n * 16 + li;
+      const float bias = b2s[c], w3c = w3s[c];      // columns >= H2 carry w3 = 0
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = row16_sum(sigmoidf_(z[j][r] + bias) * w3c);
+        if (li == 0) lp[n * kDinTP + m * 16 + g * 4 + r] = v;
+      }
+    }
   }
 }
 
@@ -451,25 +534,37 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
   auto ids_store = [&](int buf, int64_t v) {
     if (id_arr < 5) idbuf[(buf * 5 + id_arr) * kDinTP + id_p] = v;
   };
-  auto rows_issue = [&](int buf, int t0, float4 (&ph)[S::NIT], float4 (&pq)[S::NIT]) {
+  // The gathered rows of the NEXT tile live in the registers of this tile's layer-1 accumulators (dead once the partial
+  // sums are in LDS): row it of h in acc[0][it], of q in acc[1][it].  Issued right behind the partial-sum tree, in flight
+  // through sigmoid / layer 2 / softmax / pool, stored to LDS at the end of the tile: the gather latency (10.6 k of a
+  // tile's 57 k cycles when issued at the end, tools/din_phase_probe.py) is hidden and costs no register.
+  static_assert(S::NIT <= S::NT1, "row prefetch aliases the accumulator tiles");
+  f32x4_t acc[2][S::NT1];
+  // Branch-free: a lookup that must read as zero (position >= T, id out of range) fetches row 0 and is zeroed when the
+  // rows are stored — a load inside a divergent branch is followed by s_waitcnt vmcnt(0) at the join, which serialised
+  // the eight row fetches of a thread into eight memory round trips (10.6 k of a tile's 57 k cycles).
+  unsigned rows_ok = 0;                                  // bit it: h row valid, bit 8 + it: q row valid
+  auto rows_issue = [&](int buf, int t0) {
+    rows_ok = 0;
 #pragma unroll
     for (int it = 0; it < S::NIT; ++it) {
       const int p = p0 + it * S::PSTEP;
-      ph[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      pq[it] = ph[it];
-      if (t0 + p < T) {
-        const int64_t hid = idbuf[(buf * 5 + ih) * kDinTP + p], qid = idbuf[(buf * 5 + iq) * kDinTP + p];
-        if (hid >= 0 && hid < nrow) ph[it] = *reinterpret_cast<const float4*>(wh + hid * ld + col); else oob = 1;
-        if (qid >= 0 && qid < nrow) pq[it] = *reinterpret_cast<const float4*>(wq + qid * ld + col); else oob = 1;
-      }
+      const bool inb = t0 + p < T;
+      const int64_t hid = idbuf[(buf * 5 + ih) * kDinTP + p], qid = idbuf[(buf * 5 + iq) * kDinTP + p];
+      const bool hok = hid >= 0 && hid < nrow, qok = qid >= 0 && qid < nrow;
+      if (inb && !(hok && qok)) oob = 1;
+      acc[0][it] = *reinterpret_cast<const f32x4_t*>(wh + (hok ? hid : 0) * ld + col);
+      acc[1][it] = *reinterpret_cast<const f32x4_t*>(wq + (qok ? qid : 0) * ld + col);
+      rows_ok |= (inb && hok ? 1u : 0u) << it | (inb && qok ? 1u : 0u) << (8 + it);
     }
   };
-  auto rows_store = [&](const float4 (&ph)[S::NIT], const float4 (&pq)[S::NIT]) {
+  auto rows_store = [&]() {
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < S::NIT; ++it) {
       const int p = p0 + it * S::PSTEP;
-      *reinterpret_cast<float4*>(hs + p * S::EP + c4) = ph[it];
-      *reinterpret_cast<float4*>(qs + p * S::EP + c4) = pq[it];
+      *reinterpret_cast<f32x4_t*>(hs + p * S::EP + c4) = (rows_ok >> it & 1u) ? acc[0][it] : zero;
+      *reinterpret_cast<f32x4_t*>(qs + p * S::EP + c4) = (rows_ok >> (8 + it) & 1u) ? acc[1][it] : zero;
     }
   };
 
@@ -501,11 +596,10 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
   if (w >= W) return;
   int64_t b = split ? w / NTL : w;
   int t0 = split ? (int)(w % NTL) * kDinTP : 0, buf = 0;
-  float4 ph[S::NIT], pq[S::NIT];
   ids_store(0, ids_issue(b, t0));
   __syncthreads();
-  rows_issue(0, t0, ph, pq);
-  rows_store(ph, pq);
+  rows_issue(0, t0);
+  rows_store();
   __syncthreads();
   float m_run = -INFINITY, l_run = 0.f;     // live in wave 0
   float pool = 0.f;                         // thread (part, d): partial of out[b][d] over its positions
@@ -560,7 +654,9 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
     Teff = scan_read();
   }
 
+  DIN_PH_DECL;
   while (true) {
+    DIN_PH(9);
     int64_t nb = b;
     int nt0 = t0 + kDinTP;
     const bool last_tile = split || nt0 >= Teff;
@@ -576,7 +672,6 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
     if (!split && last_tile && has_next) scan_next = scan_issue(nb);
 
     // ---- layer 1: this wave's K segment of [h, q, h-q, h*q] @ W1 (net.py:155-164)
-    f32x4_t acc[2][S::NT1];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -587,38 +682,43 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
       else if (seg == 2) din_l1_segment<2, E, H1>(hs, qs, bf, acc, li, g);
       else din_l1_segment<3, E, H1>(hs, qs, bf, acc, li, g);
     }
+    DIN_PH(0);
     if (has_next) ids_store(buf ^ 1, idv);
     // partial sums, two-level tree in a fixed order: X = (b1 + P0) + P2, Y = P1 + P3, z1 = X + Y.
-    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+    // C/D layout of the swapped product: position = a*16 + (lane & 15), columns = j*16 + (lane >> 4) * 4 + reg
     {
       float* dst = (seg & 1) ? Y : X;
       if (seg < 2 && !skip) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < S::NT1; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int p = i * 16 + g * 4 + r, c = j * 16 + li;
-              dst[p * S::H1P + c] = (seg == 0 ? b1s[c] : 0.f) + acc[i][j][r];
+          for (int j = 0; j < S::NT1; ++j) {
+            const int p = i * 16 + li, c = j * 16 + g * 4;
+            f32x4_t v = acc[i][j];
+            if (seg == 0) {
+              const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(b1s + c);
+              v = f32x4_t{bb[0] + v[0], bb[1] + v[1], bb[2] + v[2], bb[3] + v[3]};
             }
+            *reinterpret_cast<f32x4_t*>(dst + p * S::H1P + c) = v;
+          }
       }
       __syncthreads();
       if (seg >= 2 && !skip) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < S::NT1; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int p = i * 16 + g * 4 + r, c = j * 16 + li;
-              dst[p * S::H1P + c] += acc[i][j][r];
-            }
+          for (int j = 0; j < S::NT1; ++j) {
+            const int p = i * 16 + li, c = j * 16 + g * 4;
+            f32x4_t* q = reinterpret_cast<f32x4_t*>(dst + p * S::H1P + c);
+            const f32x4_t o = *q, v = acc[i][j];
+            *q = f32x4_t{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]};
+          }
       }
       __syncthreads();
     }
+    DIN_PH(1);
     // embedding rows of the next tile: in flight during layers 2/3 and the softmax of this one
-    if (PF && has_next) rows_issue(buf ^ 1, nt0, ph, pq);
+    if (PF && has_next) rows_issue(buf ^ 1, nt0);
     for (int v = tid; v < kDinTP * (H1 / 4) && !skip; v += kBlock) {
       const int p = v / (H1 / 4), c = (v % (H1 / 4)) * 4;
       const float4 x = *reinterpret_cast<const float4*>(X + p * S::H1P + c);
@@ -628,31 +728,19 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
       *reinterpret_cast<float4*>(X + p * S::H1P + c) = z;
       if (a.act1 && t0 + p < T) *reinterpret_cast<float4*>(a.act1 + ((int64_t)b * T + t0 + p) * H1 + c) = z;
     }
-    __syncthreads();
+    lds_barrier();     // the next tile's rows stay in flight
+    DIN_PH(2);
     // ---- layer 2 on the matrix cores, layer 3 folded into its epilogue: lp[n][p] = sum_{c in tile n} a2[p][c] w3[c]
-    for (int t = seg; t < 2 * S::NT2 && !skip; t += kBlock / kWave) {
-      const int m = t & 1, n = t >> 1;
-      const int c = n * 16 + li;
-      f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < S::NT1; ++kb) {
-        const int k0 = kb * 16 + 4 * g;
-        const float4 av = *reinterpret_cast<const float4*>(X + (m * 16 + li) * S::H1P + k0);
-        const float a4[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          z = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], w2s[(k0 + s) * S::W2P + c], z, 0, 0, 0);
-      }
-      const float bias = b2s[c], w3c = w3s[c];      // columns >= H2 carry w3 = 0
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = sigmoidf_(z[r] + bias) * w3c;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
-        if (li == 0) lp[n * kDinTP + m * 16 + g * 4 + r] = v;
-      }
+    // Wave `seg` owns the (m, n) tiles seg, seg + 4, ...: the same 16 rows m = seg & 1 for all of them, so the A fragments
+    // are read once and the tiles' accumulator chains (20 dependent MFMAs each) are issued interleaved.
+    if (!skip) {
+      constexpr int MAXJ = (2 * S::NT2 + 3) / 4;
+      const int m = seg & 1, n0 = seg >> 1;
+      if (n0 + 2 * (MAXJ - 1) < S::NT2) din_l2_tiles<MAXJ, S>(X, w2s, b2s, w3s, lp, m, n0, li, g);
+      else din_l2_tiles<MAXJ - 1, S>(X, w2s, b2s, w3s, lp, m, n0, li, g);
     }
-    __syncthreads();
+    lds_barrier();     // the next tile's rows stay in flight
+    DIN_PH(3);
     // ---- logits + online softmax bookkeeping, wave 0 (net.py:166-170)
     if (seg == 0) {
       const int p = lane & 31, t = t0 + p;
@@ -691,7 +779,8 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
       if (lane == 0) es[35] = (has_next && !last_tile && m_run > -1e5f && all_pad) ? 1.f : 0.f;
       if (last_tile) { m_run = -INFINITY; l_run = 0.f; }
     }
-    __syncthreads();
+    lds_barrier();     // the next tile's rows stay in flight
+    DIN_PH(4);
     // ---- weighted sum of h (net.py:171): thread (part, d) covers PPART positions of column d
     {
       if (!skip) {
@@ -706,7 +795,7 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
       }
       if (last_tile) { red[part * E + pd] = pool; pool = 0.f; }
     }
-    __syncthreads();
+    lds_barrier();     // the next tile's rows stay in flight
     if (last_tile) {
       const float l_fin = es[33], m_fin = es[34];
       if (tid < E) {
@@ -727,9 +816,11 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
         }
       }
     }
+    DIN_PH(5);
     if (!has_next) break;
-    if (!PF) rows_issue(buf ^ 1, nt0, ph, pq);
-    rows_store(ph, pq);
+    if (!PF) rows_issue(buf ^ 1, nt0);
+    DIN_PH(6);
+    rows_store();
     if (!split && last_tile) scan_fold(scan_next);
     if (dyn && last_tile && tid == 0) ies[40] = tk;
     __syncthreads();
@@ -738,7 +829,9 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
     if (last_tile && !split) wn = dyn ? (int64_t)ies[40] : wn + gridDim.x;
     if (last_tile) w = nw;
     b = nb; t0 = nt0; buf ^= 1;
+    DIN_PH(7);
   }
+  DIN_PH_FLUSH;
   if (oob) atomicOr(a.status, REC_FLAG_INDEX_OOB);
 }
 
@@ -1027,7 +1120,7 @@ struct DinBwdCt {
   static constexpr int kDl = kB2 + H2C;                  // [32] dl of the tile
   static constexpr int kPw = kDl + kDinTP;               // [2][32] softmax weights of this / the next tile
   static constexpr int kDout = kPw + 2 * kDinTP;         // [E] dout of the sample, [E] sdp
-  static constexpr int kIds = (kDout + E + 4 + 1) & ~1;  // (douts[E+1]: skip flag, [E+2..E+3]: sample tickets)  int64 [4][32]: ids of the NEXT tile (this tile's are spent)
+  static constexpr int kIds = (kDout + E + 8 + 1) & ~1;  // (douts[E+1]: skip flag, [E+2..E+3]: sample tickets, [E+4..E+7]: tail scan)  int64 [4][32]: ids of the NEXT tile (this tile's are spent)
   static constexpr int kEnd = kIds + 2 * 4 * kDinTP;
   static_assert(2 * sizeof(float) * kEnd <= 160 * 1024 || E > 128, "two blocks per CU no longer fit the LDS");
   static constexpr size_t lds_bytes = sizeof(float) * (size_t)kEnd;
@@ -1100,40 +1193,44 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
     if (id_arr < 4) idbuf[id_arr * kDinTP + id_p] = idv;
     else if (id_arr == 4) pws[buf * kDinTP + id_p] = pwv;
   };
-  // gathers h, q rows and the saved a1 rows of a tile into LDS
+  // gathers h, q rows and the saved a1 rows of a tile into LDS.  Branch-free (see the forward's rows_issue): every fetch
+  // is issued unconditionally on a clamped address and zeroed on the way into LDS, so the thread's loads are in flight
+  // together instead of one memory round trip per divergent branch.
   auto tile_load = [&](int buf, int64_t b, int t0) {
-    float4 ph[S::NIT], pq[S::NIT];
+    f32x4_t ph[S::NIT], pq[S::NIT];
+    unsigned ok = 0;
 #pragma unroll
     for (int it = 0; it < S::NIT; ++it) {
       const int p = p0 + it * S::PSTEP;
-      ph[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      pq[it] = ph[it];
-      if (t0 + p < T) {
-        const int64_t hid = idbuf[ih * kDinTP + p], qid = idbuf[iq * kDinTP + p];
-        if (hid >= 0 && hid < nrow) ph[it] = *reinterpret_cast<const float4*>(wh + hid * ld + col);
-        if (qid >= 0 && qid < nrow) pq[it] = *reinterpret_cast<const float4*>(wq + qid * ld + col);
-      }
+      const bool inb = t0 + p < T;
+      const int64_t hid = idbuf[ih * kDinTP + p], qid = idbuf[iq * kDinTP + p];
+      const bool hok = hid >= 0 && hid < nrow, qok = qid >= 0 && qid < nrow;
+      ph[it] = *reinterpret_cast<const f32x4_t*>(wh + (hok ? hid : 0) * ld + col);
+      pq[it] = *reinterpret_cast<const f32x4_t*>(wq + (qok ? qid : 0) * ld + col);
+      ok |= (inb && hok ? 1u : 0u) << it | (inb && qok ? 1u : 0u) << (8 + it);
     }
     constexpr int NV = kDinTP * (H1 / 4), NA = (NV + kBlock - 1) / kBlock;
-    float4 pa[NA];
+    f32x4_t pa[NA];
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int v = tid + it * kBlock;
       const int p = v / (H1 / 4), c = (v % (H1 / 4)) * 4;
-      pa[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v < NV && t0 + p < T) pa[it] = *reinterpret_cast<const float4*>(gb.act1 + (b * T + t0 + p) * H1 + c);
+      const bool live = v < NV && t0 + p < T;
+      pa[it] = *reinterpret_cast<const f32x4_t*>(gb.act1 + (b * T + (live ? t0 + p : 0)) * H1 + (live ? c : 0));
+      ok |= (live ? 1u : 0u) << (16 + it);
     }
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < S::NIT; ++it) {
       const int p = p0 + it * S::PSTEP;
-      *reinterpret_cast<float4*>(hs + p * S::EP + c4) = ph[it];
-      *reinterpret_cast<float4*>(qs + p * S::EP + c4) = pq[it];
+      *reinterpret_cast<f32x4_t*>(hs + p * S::EP + c4) = (ok >> it & 1u) ? ph[it] : zero;
+      *reinterpret_cast<f32x4_t*>(qs + p * S::EP + c4) = (ok >> (8 + it) & 1u) ? pq[it] : zero;
     }
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int v = tid + it * kBlock;
       const int p = v / (H1 / 4), c = (v % (H1 / 4)) * 4;
-      if (v < NV) *reinterpret_cast<float4*>(X + p * S::H1P + c) = pa[it];
+      if (v < NV) *reinterpret_cast<f32x4_t*>(X + p * S::H1P + c) = (ok >> (16 + it) & 1u) ? pa[it] : zero;
     }
   };
   // dout of a sample and sdp = dout . out (softmax backward), by wave 0 and threads < E
@@ -1162,6 +1259,31 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
   int64_t w = (int64_t)blockIdx.x * per;
   int64_t w_end = (w + per < W) ? w + per : W;
   int64_t next_sample = a.B;
+  // The padded TAIL of a sample (weights exactly 0.0f behind the last valid position: the forward does not even walk it)
+  // is not visited tile by tile — every skipped tile still cost the ids / weights round trip of the tile behind it, two
+  // block barriers and its share of the loop (17 k cycles each, as much as a computed tile's non-MFMA part): a block
+  // that owns a whole sample (ticket mode) scans the sample's weight row once, zero-fills the gradient rows behind the
+  // last non-zero weight in one streaming pass and walks only the tiles in front of it.  -> tiles to walk (>= 1)
+  auto tail_cut = [&](int64_t bs) -> int {          // block-uniform; two barriers
+    int last = 0;
+    for (int t = tid; t < T; t += kBlock)
+      if (gb.att_weight[bs * T + t] != 0.f) last = t + 1;             // ascending t: the last hit wins
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, kWave));
+    __syncthreads();
+    if (lane == 0) itk[2 + wv] = last;
+    __syncthreads();
+    last = max(max(itk[2], itk[3]), max(itk[4], itk[5]));
+    const int nt = last > 0 ? (last + kDinTP - 1) / kDinTP : 1;
+    const int tz = nt * kDinTP;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    for (int v = tid; v < (T - tz) * S::E4; v += kBlock) {
+      const int64_t o = (bs * T + tz + v / S::E4) * (int64_t)E + (v % S::E4) * 4;
+      __builtin_nontemporal_store(zero, reinterpret_cast<f32x4_t*>(gb.dh + o));
+      __builtin_nontemporal_store(zero, reinterpret_cast<f32x4_t*>(gb.dq + o));
+    }
+    return nt;
+  };
   if (dyn) {
     if (tid == 0) {
       itk[0] = (int)atomicAdd(gb.ticket, 1u);
@@ -1169,9 +1291,10 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
     }
     __syncthreads();
     w = (int64_t)itk[0] * NTL;
-    w_end = w + NTL;
     next_sample = itk[1];
     __syncthreads();
+    if (w >= W) return;
+    w_end = w + tail_cut(w / NTL);
   }
   if (w >= W || w >= w_end) return;
   int64_t b = w / NTL;
@@ -1201,7 +1324,9 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
   if (!skip) tile_load(0, b, t0);
   __syncthreads();
 
+  DIN_PHB_DECL;
   while (true) {
+    DIN_PHB(9);
     int64_t nw = w + 1;
     const bool chunk_end = nw >= w_end;
     if (chunk_end && dyn) nw = next_sample * NTL;          // the sample drawn a sample ago
@@ -1225,7 +1350,7 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
       ids_store(buf ^ 1, idv, pwv);
       if (dyn && chunk_end && tid == 0) itk[0] = tk;
       skip = tile_is_zero(buf ^ 1);
-      if (dyn && chunk_end) { w_end = nw + NTL; next_sample = itk[0]; }
+      if (dyn && chunk_end) { next_sample = itk[0]; w_end = nw + tail_cut(nb); }
       if (nb != b) sample_load(nb);
       if (!skip) tile_load(buf ^ 1, nb, nt0);
       __syncthreads();
@@ -1248,6 +1373,7 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
       if (sub == 0) dls[p] = pws[buf * kDinTP + p] * (dp - douts[E]) * scale;   // padded positions: p_t = 0
     }
     __syncthreads();
+    DIN_PHB(0);
     // ---- a2 = sigmoid(a1 W2 + b2) recomputed on the matrix cores; dz2 = dl w3 a2 (1 - a2) in the epilogue
     for (int t = wv; t < 2 * S::NCB; t += kBlock / kWave) {
       const int m = t & 1, n = t >> 1;
@@ -1271,6 +1397,7 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
       }
     }
     __syncthreads();
+    DIN_PHB(1);
     // ---- dz1 = (dz2 W2^T) a1 (1 - a1)
     for (int t = wv; t < 2 * S::NJB; t += kBlock / kWave) {
       const int m = t & 1, n = t >> 1;
@@ -1294,6 +1421,7 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
     }
     if (has_next) ids_store(buf ^ 1, idv, pwv);
     __syncthreads();
+    DIN_PHB(2);
     // ---- dx = dz1 W1^T for this wave's columns of the four segments, folded into dh / dq (16 positions a pass)
 #pragma unroll 1
     for (int m = 0; m < 2; ++m) {
@@ -1330,21 +1458,37 @@ __global__ __launch_bounds__(kBlock, 2) void din_attention_bwd_ct_kernel(DinBwdA
         }
       }
     }
+    DIN_PHB(3);
     if (!has_next) break;
     if (dyn && chunk_end && tid == 0) itk[0] = tk;
     // hs / qs / X / douts are rewritten for the next tile (barrier); is the next tile all zero weights?
     skip = tile_is_zero(buf ^ 1);
-    if (dyn && chunk_end) { w_end = nw + NTL; next_sample = itk[0]; }
+    DIN_PHB(4);
+    if (dyn && chunk_end) { next_sample = itk[0]; w_end = nw + tail_cut(nb); }
     if (nb != b) sample_load(nb);
     if (!skip) tile_load(buf ^ 1, nb, nt0);
+    DIN_PHB(5);
     __syncthreads();
     w = nw; b = nb; t0 = nt0; buf ^= 1;
+    DIN_PHB(6);
   }
+  DIN_PHB_FLUSH;
 }
 
 }  // namespace rec
 
 using namespace rec;
+
+#ifdef REC_DIN_PHASE_TIMING
+extern "C" __attribute__((visibility("default"))) int rec_din_debug_phases(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(din_phase_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(din_phase_dbg), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 // 1 when the forward for this shape writes `act1` (and the backward can consume it), else 0
 extern "C" int rec_din_saves_act1(const rec_din_desc* d) {
