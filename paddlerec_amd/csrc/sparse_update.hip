@@ -959,33 +959,54 @@ __device__ __forceinline__ void sparse_small_body(
   float acc1 = 0.f;                                      // first-order gradient of the row (record update)
   int cnt = 0;
   const bool plain = gl.group == 1 && gl.div == 1 && gl.index == nullptr;
+  // The gradient rows of the collected occurrences are fetched in straight-line code, in tiers of the count (1, 4, 16,
+  // FLY rows; slots behind the count re-read the first row and add nothing): with a wave-uniform
+  // `if (u < cnt)` around every fetch the compiler drained each load at the branch's join — a hot row's FLY fetches were
+  // FLY memory round trips (tools/isa_load_waits.py: 387 of the kernel's 774 loads).  Rows are added in ascending order.
+  bool no_index = gl.index == nullptr;
+  if constexpr (kRecord) no_index = no_index && up.gl1.index == nullptr;
+  auto fetch = [&](auto tier, auto noidx) {
+    constexpr int TR = decltype(tier)::value;
+    rec_grad_layout gq = gl;
+    if constexpr (decltype(noidx)::value) gq.index = nullptr;      // folds the position -> index load out of the tier
+    float x[TR][NACC], x1[TR];
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+      const int q = wl[u < cnt ? u : 0];
+      // (one gradient row per position at a fixed pitch is the common layout: no integer division)
+      const float* g = grad + (plain ? (int64_t)q * gq.group_stride : grad_offset(gq, q, D));
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        const int d = lane + a * kWave;
+        x[u][a] = g[d < D ? d : 0];
+      }
+      if constexpr (kRecord) {
+        rec_grad_layout g1 = up.gl1;
+        if constexpr (decltype(noidx)::value) g1.index = nullptr;
+        x1[u] = up.grad1[grad_offset(g1, q, 1)];
+      } else {
+        x1[u] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TR; ++u) {
+      const bool live = u < cnt;                       // wave-uniform
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) acc[a] += (live && lane + a * kWave < D) ? x[u][a] : 0.f;
+      acc1 += live ? x1[u] : 0.f;
+    }
+  };
   auto flush = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float x[FLY][NACC], x1[FLY];
-#pragma unroll
-    for (int u = 0; u < FLY; ++u) {
-#pragma unroll
-      for (int a = 0; a < NACC; ++a) x[u][a] = 0.f;
-      x1[u] = 0.f;
-      if (u < cnt) {                                   // wave-uniform: unused slots cost nothing
-        const int q = wl[u];
-        // (one gradient row per position at a fixed pitch is the common layout: no integer division)
-        const float* g = grad + (plain ? (int64_t)q * gl.group_stride : grad_offset(gl, q, D));
-#pragma unroll
-        for (int a = 0; a < NACC; ++a) {
-          const int d = lane + a * kWave;
-          if (d < D) x[u][a] = g[d];
-        }
-        if constexpr (kRecord) x1[u] = up.grad1[grad_offset(up.gl1, q, 1)];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < FLY; ++u) {
-#pragma unroll
-      for (int a = 0; a < NACC; ++a) acc[a] += x[u][a];
-      acc1 += x1[u];
+    if (no_index) {
+      if (cnt <= 1) fetch(std::integral_constant<int, 1>{}, std::true_type{});
+      else if (cnt <= 4) fetch(std::integral_constant<int, (FLY < 4 ? FLY : 4)>{}, std::true_type{});
+      else if (cnt <= 16) fetch(std::integral_constant<int, (FLY < 16 ? FLY : 16)>{}, std::true_type{});
+      else fetch(std::integral_constant<int, FLY>{}, std::true_type{});
+    } else {
+      fetch(std::integral_constant<int, FLY>{}, std::false_type{});      // (position -> index -> row: a dependent chain anyway)
     }
     cnt = 0;
     __builtin_amdgcn_wave_barrier();     // the list is rewritten only after every lane has read it
