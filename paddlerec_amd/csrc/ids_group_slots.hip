@@ -223,16 +223,17 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int64_t B, int S, int
 #pragma unroll
   for (int j = 0; j < kChunks; ++j) {
     const int64_t idx = wbase + j * kWave + lane;
-    k[j] = kNoKey;
-    v[j] = (int32_t)idx;
-    if (idx < lim) {
-      if (FIRST) {
-        k[j] = keys_in[(int64_t)s * B + idx];
-      } else {
-        const uint2 t = pairs_in[(int64_t)s * B + idx];
-        k[j] = t.x;
-        v[j] = (int32_t)t.y;
-      }
+    // (branch-free: a load inside `if (idx < lim)` is drained at the join — the wave's 16 fetches became 16 round trips)
+    const bool in = idx < lim;
+    const int64_t src = (int64_t)s * B + (in ? idx : 0);
+    if (FIRST) {
+      const uint32_t t = keys_in[src];
+      k[j] = in ? t : kNoKey;
+      v[j] = (int32_t)idx;
+    } else {
+      const uint2 t = pairs_in[src];
+      k[j] = in ? t.x : kNoKey;
+      v[j] = in ? (int32_t)t.y : (int32_t)idx;
     }
   }
 #pragma unroll
@@ -241,10 +242,16 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(int64_t B, int S, int
   for (int b = tid; b < nb; b += kThreads) {
     int tot = 0, p = 0;
     const int32_t* h = hist + (int64_t)s * C * nb + b;
-    for (int cc = 0; cc < C; ++cc) {
-      const int t = h[(int64_t)cc * nb];
-      tot += t;
-      if (cc < c) p += t;
+    for (int c0 = 0; c0 < C; c0 += 8) {                 // eight column entries in flight (C = 8 at batch 65536)
+      int t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = h[(int64_t)(c0 + u < C ? c0 + u : c0) * nb];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int x = c0 + u < C ? t[u] : 0;
+        tot += x;
+        if (c0 + u < c) p += x;
+      }
     }
     binbase[b] = tot;
     pre[b] = p;
@@ -315,15 +322,19 @@ __device__ __forceinline__ int total_valid(int nbv, const int32_t* __restrict__ 
   return *sh;
 }
 
-// sorted pair i = {position, global row}
-__device__ __forceinline__ unsigned long long head_mask(int n, const uint2* __restrict__ pairs, int64_t i, int lane,
-                                                        uint2* pair_out) {
+// sorted pair i = {position, global row}.  The fetches are branch-free (clamped index, every lane): a load inside a
+// divergent `if` is drained at the join, and the eight chunks of a block's tile were eight dependent round trips.
+__device__ __forceinline__ void head_fetch(int n, const uint2* __restrict__ pairs, int64_t i, uint2* pair, uint32_t* prev) {
+  const int64_t last = n > 0 ? n - 1 : 0;
+  *pair = pairs[i < n ? i : last];
+  *prev = pairs[(i > 0 && i < n) ? i - 1 : (i < n ? i : last)].y;
+}
+__device__ __forceinline__ unsigned long long head_eval(int n, int64_t i, int lane, uint2* pair, uint32_t prev) {
   const bool in = i < n;
-  const uint2 p = in ? pairs[i] : make_uint2(0u, kNoKey);
-  uint32_t left = __shfl_up(p.y, 1, kWave);
-  if (lane == 0) left = (i > 0 && in) ? pairs[i - 1].y : kNoKey;
-  *pair_out = p;
-  return __ballot(in && (i == 0 || p.y != left));
+  if (!in) *pair = make_uint2(0u, kNoKey);
+  uint32_t left = __shfl_up(pair->y, 1, kWave);
+  if (lane == 0) left = (i > 0 && in) ? prev : kNoKey;
+  return __ballot(in && (i == 0 || pair->y != left));
 }
 
 __global__ __launch_bounds__(kHeadThreads) void heads_count_kernel(int nbv, const int32_t* __restrict__ bvalid,
@@ -337,12 +348,19 @@ __global__ __launch_bounds__(kHeadThreads) void heads_count_kernel(int nbv, cons
   const int64_t base = (int64_t)blockIdx.x * kHeadTile;
   int heads = 0, has_long = 0;
   if (base < n) {
+    uint2 pp[kHeadChunks];
+    uint32_t prev[kHeadChunks], far[kHeadChunks];
 #pragma unroll
     for (int c = 0; c < kHeadChunks; ++c) {
       const int64_t i = base + (int64_t)(c * kHeadWaves + wave) * kWave + lane;
-      uint2 p;
-      heads += __popcll(head_mask(n, pairs, i, lane, &p));
-      if (i + kSegLong - 1 < n && pairs[i + kSegLong - 1].y == p.y) has_long = 1;
+      head_fetch(n, pairs, i, &pp[c], &prev[c]);
+      far[c] = pairs[i + kSegLong - 1 < n ? i + kSegLong - 1 : (n > 0 ? n - 1 : 0)].y;
+    }
+#pragma unroll
+    for (int c = 0; c < kHeadChunks; ++c) {
+      const int64_t i = base + (int64_t)(c * kHeadWaves + wave) * kWave + lane;
+      heads += __popcll(head_eval(n, i, lane, &pp[c], prev[c]));
+      if (i + kSegLong - 1 < n && far[c] == pp[c].y) has_long = 1;
     }
   }
   if (__ballot(has_long) != 0 && lane == 0) atomicOr(&n_uniq[2], 1);
@@ -381,10 +399,14 @@ __global__ __launch_bounds__(kHeadThreads) void heads_emit_kernel(int nbv, const
   if (lane == 0) red[wave] = t;
   unsigned long long hm[kHeadChunks];
   uint2 pp[kHeadChunks];
+  uint32_t prev[kHeadChunks];
+#pragma unroll
+  for (int c = 0; c < kHeadChunks; ++c)
+    head_fetch(n, pairs, base + (int64_t)(c * kHeadWaves + wave) * kWave + lane, &pp[c], &prev[c]);
 #pragma unroll
   for (int c = 0; c < kHeadChunks; ++c) {
     const int64_t i = base + (int64_t)(c * kHeadWaves + wave) * kWave + lane;
-    hm[c] = head_mask(n, pairs, i, lane, &pp[c]);
+    hm[c] = head_eval(n, i, lane, &pp[c], prev[c]);
     if (lane == 0) ccnt[c * kHeadWaves + wave] = __popcll(hm[c]);
     if (i < n) {
       sorted_pos[i] = (int32_t)pp[c].x;
