@@ -50,10 +50,12 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj, "-Rpass-analysis=kernel-resource-usage"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        with open(obj[:-2] + ".resources.txt", "w") as f:       # registers / occupancy / LDS of every kernel of this
+            f.write(r.stderr)                                   # object (tests/test_kernel_resources.py reads it)
         return src
 
     if jobs:
