@@ -1,0 +1,317 @@
+// f32 GEMM on the bf16 matrix pipe: every f32 operand is split into three bf16 terms (x = x0 + x1 + x2 to 2^-25 |x|, each
+// the round-to-nearest bf16 of the running remainder: 8 + 8 + 8 significand bits = the whole f32 significand) and the
+// product is accumulated in f32 from the six term products with i + j <= 2 (a0 b0, a0 b1, a1 b0, a0 b2, a1 b1, a2 b0) —
+// what is dropped (a1 b2, a2 b1, a2 b2) is below 2^-24 |a b| per product: the result is as close to the float64 product
+// as the exact-f32 kernels' (tests/test_gemm_gpu.py::test_gemm_bf16x3: the same 4e-7 of sum |a||b| bound).  Six v_mfma_f32_16x16x32_bf16 per K 32 are 96 matrix-pipe cycles where
+// eight v_mfma_f32_16x16x4_f32 are 256 (the "bf16 x 3" form).  OPT-IN (REC_GEMM_BF16X3): the results
+// are f32-grade but not the bit pattern of an f32 fma chain, so the exact-f32 kernels stay the default.
+//
+//   C[M,N] = epi(A[M,K] @ W'),   A f32 row-major (k contiguous, lda);   W' given as a pre-split IMAGE (x3_split_kernel)
+//
+// The weight (400 x 400: ~1 MB of planes, L2-resident) is split once per step by x3_split_kernel into the exact LDS
+// image of every k-step; the activation operand is split in registers by the wave that multiplies it:
+//   * block = 4 waves as 2 (M) x 2 (N), block tile 128 rows x 416 columns (N <= 416: ONE column block, so every A
+//     element is converted by the two waves that share its rows and by nobody else); wave tile 64 x 208 = 4 x 13 MFMA
+//     tiles, 208 accumulator registers: one wave per SIMD, one block per CU;
+//   * A: a lane's fragment of v_mfma_f32_16x16x32_bf16 is 8 consecutive k of one row = 32 contiguous bytes of f32:
+//     loaded global -> registers (a wave instruction covers 16 rows x one full 128-B line each), one k-step ahead, and
+//     split there (4.5 VALU instructions per element: v_cvt_pk_bf16_f32, shift / mask, v_pk_add_f32) — no LDS traffic for A;
+//   * W': k-step image [plane 3][n 416][4 chunks of 8 k] bf16, chunk c of row n stored at slot c ^ f(n % 16),
+//     f = {0,3,2,1}[i / 4] (the swizzle of gemm_glds.h: one conflict-free ds_read_b128 per fragment), 78 KB per k-step,
+//     two stages = 156 of the 160 KB; filled by LDS-DMA (global_load_lds_dwordx4: the global image IS the LDS image, so
+//     the copy is lane-linear), one k-step ahead, one barrier per k-step;
+//   * MFMAs with the operands swapped (W' fragment first) as in gemm_glds.h: lane (i, g) ends up with
+//     C[row i][columns 4g .. 4g+3] of a tile -> float4 stores, float4 bias / aux loads.
+// Shapes: K % 8 == 0 (a lane's 8-k chunk is inside or outside K as a whole), N % 4 == 0, N <= 416, rows 16-B aligned.
+#pragma once
+
+#include "gemm_epi.h"
+#include "gemm_glds.h"      // glb_void_t / lds_void_t, wait_vmcnt
+
+namespace rec {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kX3NT = 13;                       // MFMA column tiles per wave
+constexpr int kX3NP = 2 * kX3NT * 16;           // 416 columns per block (zero weight columns behind N)
+constexpr int kX3BM = 128;                      // rows per block
+constexpr int kX3MT = 4;                        // MFMA row tiles per wave (64 rows)
+constexpr int kX3PlaneBytes = kX3NP * 64;       // one plane of one k-step: 416 rows x 32 bf16
+constexpr int kX3Stage = 3 * kX3PlaneBytes;     // 79 872 B
+constexpr int kX3Pieces = kX3Stage / 1024;      // 78 LDS-DMA pieces per k-step
+
+__host__ __device__ inline size_t x3_image_bytes(int K) { return (size_t)((K + 31) / 32) * kX3Stage; }
+
+__device__ __forceinline__ int x3_swz(int i) { return (4 - (i >> 2)) & 3; }   // {0,3,2,1}[i / 4], i = n % 16
+
+// the three bf16 terms of an (even, odd) pair of floats, packed [even | odd << 16] per plane.  Each term is the
+// round-to-nearest bf16 of the running remainder (v_cvt_pk_bf16_f32); the remainders are exact f32 subtractions
+// (|x - x0| <= 2^-9 |x| fits 16 bits, |r1 - x1| <= 2^-17 |x| fits 8-9 bits), so x0 + x1 + x2 = x to 2^-25 |x| and the
+// dropped products a1 b2 + a2 b1 + a2 b2 stay below 2^-24 |a b| with either sign (a truncating split leaves them at
+// 2^-21 |a b| and all of one sign: a bias of ~1e-7 of sum |a||b| that showed against the float64 bound).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned x3_cvt_pk(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+__device__ __forceinline__ void x3_split_pair(float xe, float xo, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = x3_cvt_pk(xe, xo);
+  const float re = xe - __uint_as_float(p0 << 16), ro = xo - __uint_as_float(p0 & 0xffff0000u);   // exact
+  p1 = x3_cvt_pk(re, ro);
+  const float se = re - __uint_as_float(p1 << 16), so = ro - __uint_as_float(p1 & 0xffff0000u);   // exact
+  p2 = x3_cvt_pk(se, so);
+}
+
+// W [K,N] (trans 0: element (n, k) = W[k * ldw + n]) or W [N,K] (trans 1: W[n * ldw + k]) -> image; one thread per
+// (k-step, n, 8-k chunk).  Rows n >= N and chunks k >= K are zero.
+__global__ __launch_bounds__(kBlock) void x3_split_kernel(const float* __restrict__ W, int64_t ldw, int K, int N, int trans,
+                                                          char* __restrict__ img, int nkt) {
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (tid >= (int64_t)nkt * kX3NP * 4) return;
+  const int c = (int)(tid & 3), n = (int)((tid >> 2) % kX3NP), kt = (int)((tid >> 2) / kX3NP);
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kt * 32 + c * 8 + j;
+    x[j] = (n < N && k < K) ? (trans ? W[(int64_t)n * ldw + k] : W[(int64_t)k * ldw + n]) : 0.f;
+  }
+  u32x4_t p0, p1, p2;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    unsigned a, b, e;
+    x3_split_pair(x[2 * d], x[2 * d + 1], a, b, e);
+    p0[d] = a; p1[d] = b; p2[d] = e;
+  }
+  char* dst = img + (size_t)kt * kX3Stage + (size_t)n * 64 + ((c ^ x3_swz(n & 15)) * 16);
+  *reinterpret_cast<u32x4_t*>(dst) = p0;
+  *reinterpret_cast<u32x4_t*>(dst + kX3PlaneBytes) = p1;
+  *reinterpret_cast<u32x4_t*>(dst + 2 * kX3PlaneBytes) = p2;
+}
+
+// one tile's three plane fragments (ds_read_b128, offset = tile * 1024 + plane * kX3PlaneBytes; plane 2 through a second
+// base because 2 * 26 624 + 12 * 1024 does not fit the 16-bit offset field)
+template <int T>
+__device__ __forceinline__ void x3_read_frags(u32x4_t (&bf)[3], unsigned sb, unsigned sb2) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[0]) : "v"(sb), "n"(T * 1024));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[1]) : "v"(sb), "n"(T * 1024 + kX3PlaneBytes));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[2]) : "v"(sb2), "n"(T * 1024));
+}
+__device__ __forceinline__ void x3_read_frags_t(u32x4_t (&bf)[3], unsigned sb, unsigned sb2, int t) {
+  switch (t) {            // t is a compile-time constant at every call (fully unrolled tile loop)
+    case 1: x3_read_frags<1>(bf, sb, sb2); break;
+    case 2: x3_read_frags<2>(bf, sb, sb2); break;
+    case 3: x3_read_frags<3>(bf, sb, sb2); break;
+    case 4: x3_read_frags<4>(bf, sb, sb2); break;
+    case 5: x3_read_frags<5>(bf, sb, sb2); break;
+    case 6: x3_read_frags<6>(bf, sb, sb2); break;
+    case 7: x3_read_frags<7>(bf, sb, sb2); break;
+    case 8: x3_read_frags<8>(bf, sb, sb2); break;
+    case 9: x3_read_frags<9>(bf, sb, sb2); break;
+    case 10: x3_read_frags<10>(bf, sb, sb2); break;
+    case 11: x3_read_frags<11>(bf, sb, sb2); break;
+    default: x3_read_frags<12>(bf, sb, sb2); break;
+  }
+}
+
+#ifndef REC_X3_PRODUCTS
+#define REC_X3_PRODUCTS 6      // lab knob: 3 = a0 b0 + a0 b1 + a1 b0 only (~2^-14 of scale: NOT f32-grade), 1 = plain bf16
+#endif
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int64_t M, int N, int K, const float* __restrict__ A, int64_t lda,
+                                                          const char* __restrict__ Bimg, float* __restrict__ C,
+                                                          int64_t ldc, EpiArgs epi) {
+  extern __shared__ __attribute__((aligned(1024))) char x3_smem[];
+  const int lane = threadIdx.x % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int li = lane & 15, g = lane >> 4;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int nkt = (K + 31) / 32;
+  const int64_t m0 = (int64_t)blockIdx.x * kX3BM + wm * (kX3MT * 16);
+
+  // ---- A: per-lane row pointers (rows behind M re-read row M-1: finite data, never stored)
+  const float* ap[kX3MT];
+#pragma unroll
+  for (int a = 0; a < kX3MT; ++a) {
+    int64_t r = m0 + a * 16 + li;
+    r = r < M ? r : M - 1;
+    ap[a] = A + r * lda + g * 8;
+  }
+  float4 araw[kX3MT][2];
+  // a chunk behind K (only in the last k-step, K % 32 != 0) is read from the row's first chunk instead and zeroed when
+  // it is CONVERTED, a k-step later: a select right behind the load would park the wave until the load returns
+  auto load_a = [&](int kt) {
+    const int koff = kt * 32 + g * 8 < K ? kt * 32 : 0;      // K % 8 == 0: the lane's chunk is in or out as a whole
+#pragma unroll
+    for (int a = 0; a < kX3MT; ++a) {
+      araw[a][0] = *reinterpret_cast<const float4*>(ap[a] + koff);
+      araw[a][1] = *reinterpret_cast<const float4*>(ap[a] + koff + 4);
+    }
+  };
+  // ---- W': LDS-DMA of one k-step image; pieces dealt round-robin to the four waves
+  auto issue_b = [&](int kt, int stage) {
+    const char* src = Bimg + (size_t)kt * kX3Stage + lane * 16;
+    const char* dst = x3_smem + stage * kX3Stage;
+#pragma unroll
+    for (int j = 0; j < (kX3Pieces + 3) / 4; ++j) {
+      const int piece = wave + 4 * j;
+      if (piece < kX3Pieces)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + piece * 1024), (lds_void_t*)(dst + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[kX3MT][kX3NT];
+#pragma unroll
+  for (int a = 0; a < kX3MT; ++a)
+#pragma unroll
+    for (int t = 0; t < kX3NT; ++t) acc[a][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // byte address (LDS offset = low half of the flat address) of this lane's fragment slot in tile 0, plane 0, stage 0
+  const unsigned lds_base = (unsigned)(uintptr_t)x3_smem + (wn * kX3NT * 16 + li) * 64 + ((g ^ x3_swz(li)) * 16);
+
+  issue_b(0, 0);
+  load_a(0);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int stage = kt & 1;
+    // this k-step's A fragments: three planes per row tile
+    u32x4_t af[kX3MT][3];
+    if (kt == nkt - 1 && (K & 31) != 0 && kt * 32 + g * 8 >= K) {       // the K tail: this lane's chunk does not exist
+#pragma unroll
+      for (int a = 0; a < kX3MT; ++a) araw[a][0] = araw[a][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int a = 0; a < kX3MT; ++a) {
+      const float x[8] = {araw[a][0].x, araw[a][0].y, araw[a][0].z, araw[a][0].w,
+                          araw[a][1].x, araw[a][1].y, araw[a][1].z, araw[a][1].w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        unsigned p0, p1, p2;
+        x3_split_pair(x[2 * d], x[2 * d + 1], p0, p1, p2);
+        af[a][0][d] = p0; af[a][1][d] = p1; af[a][2][d] = p2;
+      }
+    }
+    if (kt + 1 < nkt) {                                      // next k-step: W' image into the other stage, A into registers
+      issue_b(kt + 1, stage ^ 1);
+      load_a(kt + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // W' fragments: ds_read_b128 as inline asm with COUNTED waits.  Through the builtin path the compiler waits
+    // lgkmcnt(0) before every tile while LDS-DMA loads are in flight (it cannot order them against LDS reads), i.e.
+    // also for the fragments it has just requested for the NEXT tile; here tile t's MFMAs wait for their own three
+    // reads only (lgkmcnt(3): LDS returns in order) and the next tile's reads stay in flight underneath them.
+    const unsigned sb = lds_base + stage * kX3Stage;
+    u32x4_t bf[2][3];
+    x3_read_frags<0>(bf[0], sb, sb + 2 * kX3PlaneBytes);
+#pragma unroll
+    for (int t = 0; t < kX3NT; ++t) {
+      if (t + 1 < kX3NT) {
+        x3_read_frags_t(bf[(t + 1) & 1], sb, sb + 2 * kX3PlaneBytes, t + 1);
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bf[t & 1][0]), "+v"(bf[t & 1][1]), "+v"(bf[t & 1][2]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[t & 1][0]), "+v"(bf[t & 1][1]), "+v"(bf[t & 1][2]));
+      }
+      const u32x4_t* b = bf[t & 1];
+      // smallest terms first; between two MFMAs on one accumulator sit the three other row tiles
+#define REC_X3_MFMA(PB, PA)                                                                                    \
+  _Pragma("unroll") for (int a = 0; a < kX3MT; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(         \
+      __builtin_bit_cast(bf16x8_t, b[PB]), __builtin_bit_cast(bf16x8_t, af[a][PA]), acc[a][t], 0, 0, 0);
+#if REC_X3_PRODUCTS >= 6
+      REC_X3_MFMA(2, 0)
+      REC_X3_MFMA(1, 1)
+      REC_X3_MFMA(0, 2)
+#endif
+#if REC_X3_PRODUCTS >= 3
+      REC_X3_MFMA(1, 0)
+      REC_X3_MFMA(0, 1)
+#endif
+      REC_X3_MFMA(0, 0)
+#undef REC_X3_MFMA
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kt + 1 < nkt) {
+      wait_vmcnt<0>();                     // my pieces of the next image (and my next A registers) have landed
+      __builtin_amdgcn_s_barrier();        // ... everybody's; everybody is done reading this stage
+    }
+  }
+
+  // ---- epilogue: float4 per lane and tile, aux / bias operands of a row tile loaded ahead of its stores
+  const int n_base = wn * kX3NT * 16 + g * 4;
+#pragma unroll
+  for (int a = 0; a < kX3MT; ++a) {
+    const int64_t i = m0 + a * 16 + li;
+    const bool row_ok = i < M;
+    const int64_t ic = row_ok ? i : M - 1;
+    f32x4_t x0[kX3NT], bj[kX3NT];
+#pragma unroll
+    for (int t = 0; t < kX3NT; ++t) {
+      const int j = n_base + t * 16;
+      const int jc = j < N ? j : 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bj[t][c] = load_bias<EPI>(jc + c, epi);
+      if constexpr (EpiUses<EPI>::aux0) x0[t] = *reinterpret_cast<const f32x4_t*>(epi.aux0 + ic * epi.ld0 + jc);
+      else x0[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int t = 0; t < kX3NT; ++t) {
+      const int j = n_base + t * 16;
+      f32x4_t v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = apply_epi<EPI>(acc[a][t][c], x0[t][c], 0.f, bj[t][c], ic, epi);
+#ifdef REC_X3_NT_STORE
+      if (row_ok && j < N) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(C + i * ldc + j));
+#else
+      if (row_ok && j < N) *reinterpret_cast<f32x4_t*>(C + i * ldc + j) = v;
+#endif
+    }
+  }
+}
+
+// host side -------------------------------------------------------------------------------------------------------
+inline int x3_launch_split(const float* W, int64_t ldw, int K, int N, int trans, char* img, hipStream_t st) {
+  const int nkt = (K + 31) / 32;
+  const int64_t thr = (int64_t)nkt * kX3NP * 4;
+  hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)((thr + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, W, ldw, K, N,
+                     trans, img, nkt);
+  return check_launch("x3_split_kernel");
+}
+
+inline bool x3_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldc, const void* A, const void* C) {
+  return M > 0 && N > 0 && N <= kX3NP && N % 4 == 0 && K > 0 && K % 8 == 0 && lda % 4 == 0 && ldc % 4 == 0 &&
+         ((uintptr_t)A % 16) == 0 && ((uintptr_t)C % 16) == 0;
+}
+
+template <int EPI>
+inline int x3_launch_gemm_epi(int64_t M, int N, int K, const float* A, int64_t lda, const char* img, float* C, int64_t ldc,
+                              const EpiArgs& e, hipStream_t st) {
+  static bool attr_set = false;             // > 64 KB of dynamic LDS needs the attribute once per kernel
+  constexpr int lds = 2 * kX3Stage;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("gemm_bf16x3: %d B of dynamic LDS refused", lds);
+      return REC_EHIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI>), dim3((unsigned)((M + kX3BM - 1) / kX3BM)), dim3(256), lds, st, M, N, K, A,
+                     lda, img, C, ldc, e);
+  return check_launch("gemm_bf16x3_kernel");
+}
+
+inline int x3_launch_gemm(int epi, int64_t M, int N, int K, const float* A, int64_t lda, const char* img, float* C,
+                          int64_t ldc, const EpiArgs& e, hipStream_t st) {
+  switch (epi) {
+    case REC_EPI_NONE: return x3_launch_gemm_epi<REC_EPI_NONE>(M, N, K, A, lda, img, C, ldc, e, st);
+    case REC_EPI_BIAS: return x3_launch_gemm_epi<REC_EPI_BIAS>(M, N, K, A, lda, img, C, ldc, e, st);
+    case REC_EPI_BIAS_RELU: return x3_launch_gemm_epi<REC_EPI_BIAS_RELU>(M, N, K, A, lda, img, C, ldc, e, st);
+    case REC_EPI_RELU_MASK: return x3_launch_gemm_epi<REC_EPI_RELU_MASK>(M, N, K, A, lda, img, C, ldc, e, st);
+    default: set_error("gemm_bf16x3: epilogue %d not built", epi); return REC_EINVAL;
+  }
+}
+
+}  // namespace rec

@@ -36,6 +36,7 @@
 #include "gemm_glds.h"
 #include "gemm_panel.h"
 #include "gemm_pipe.h"
+#include "gemm_bf16x3.h"
 namespace rec {
 
 // --------------------------------------------------------------------------------------- kernel
@@ -821,6 +822,34 @@ static bool launch_glds(const rec_gemm_desc* d, const float* A, const float* B, 
   return false;
 }
 
+// The bf16 x 3 form (gemm_bf16x3.h) for the tall problems of the MLP path: C = epi(A @ op(B)) with A row-major, 336 to
+// 416 output columns (one column block of 416: fewer columns waste its MFMAs), the four epilogues of the forward / dX chain.  B is split into its plane image
+// in the caller's workspace by a ~4 us launch in front of the GEMM.  REC_GEMM_BF16X3 = 1 / 0 (read per call: tests flip
+// it inside one process); results are f32-grade (error against float64 no larger than the exact-f32 kernels',
+// profiles/r05_bf16x3.txt) but not the bits of an f32 fma chain.
+constexpr bool kX3Default = false;
+static bool x3_enabled() {
+  const char* v = getenv("REC_GEMM_BF16X3");
+  return v && *v ? *v != '0' : kX3Default;
+}
+static bool x3_eligible(const rec_gemm_desc* d) {
+  if (!x3_enabled() || d->trans_a || d->split_k > 1 || d->m < 8192 || d->n > kX3NP || d->n < 336 || d->n % 4 || d->k % 8 ||
+      d->k < 64)
+    return false;
+  const int e_ = d->epilogue;
+  return e_ == REC_EPI_NONE || e_ == REC_EPI_BIAS || e_ == REC_EPI_BIAS_RELU || e_ == REC_EPI_RELU_MASK;
+}
+static bool launch_x3(const rec_gemm_desc* d, const float* A, const float* B, float* C, const EpiArgs& e, void* workspace,
+                      size_t workspace_bytes, hipStream_t st) {
+  if (!x3_eligible(d)) return false;
+  if (!x3_shape_ok(d->m, d->n, d->k, d->lda, d->ldc, A, C)) return false;
+  if (d->epilogue == REC_EPI_RELU_MASK && (e.ld0 % 4 || ((uintptr_t)e.aux0) % 16)) return false;
+  if (!workspace || ((uintptr_t)workspace) % 16 || workspace_bytes < x3_image_bytes(d->k)) return false;   // sized without it
+  char* img = (char*)workspace;
+  if (x3_launch_split(B, d->ldb, d->k, d->n, d->trans_b ? 1 : 0, img, st) != REC_OK) return false;
+  return x3_launch_gemm(d->epilogue, d->m, d->n, d->k, A, d->lda, img, C, d->ldc, e, st) == REC_OK;
+}
+
 template <int EPI>
 static void launch_reduce(const rec_gemm_desc* d, const GemmPlan& p, const float* partial, float* C,
                           const EpiArgs& e, hipStream_t st, const float* cpart = nullptr, float* colsum_out = nullptr) {
@@ -847,6 +876,7 @@ extern "C" int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* b
   // [splits][M][ldc] partial tiles (split-K only) + [splits][N] partial column sums
   *bytes = (p.splits > 1 ? align_up((size_t)p.splits * desc->m * desc->ldc * sizeof(float), 256) : 0) +
            align_up((size_t)p.splits * desc->n * sizeof(float), 256);
+  if (x3_eligible(desc) && *bytes < x3_image_bytes(desc->k)) *bytes = align_up(x3_image_bytes(desc->k), 256);   // B's plane image
   return REC_OK;
 }
 
@@ -931,6 +961,7 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
     return check_launch("rec_gemm_f32 (skinny dW)");
   }
   // tall problems of the towers' own widths: whole row panels, one resident round (gemm_panel.h)
+  if (!b_colsum && launch_x3(desc, A, B, C, e, workspace, workspace_bytes, st)) return check_launch("rec_gemm_f32 (bf16x3)");
   if (!b_colsum && launch_panel(desc, A, B, C, e, st, device_cus())) return check_launch("rec_gemm_f32 (panel)");
   if (!b_colsum && launch_glds(desc, A, B, C, e, st)) return check_launch("rec_gemm_f32 (glds)");
   const GemmPlan p = plan_gemm(desc);

@@ -322,3 +322,43 @@ def test_mlp_backward_head_path_matches_gemm_path(ops, monkeypatch):
         outs.append([dx.cpu().numpy()] + [t.cpu().numpy() for t in dws + dbs])
     for a, b in zip(*outs):
         assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
+
+
+@pytest.mark.parametrize("M,N,K,tb,epi", [
+    (8192, 400, 400, False, "bias_relu"), (8192, 400, 432, False, "bias_relu"), (8192, 400, 400, True, "relu_mask"),
+    (8200, 396, 104, False, "bias"), (9000, 416, 72, True, "none"), (8192, 336, 400, False, "none")])
+def test_gemm_bf16x3(ops, monkeypatch, M, N, K, tb, epi):
+    """gemm_bf16x3.h (REC_GEMM_BF16X3=1): f32 operands split exactly into three bf16 terms, six bf16 MFMAs per product,
+    f32 accumulate.  Same float64 bar as the exact-f32 kernels (4e-7 of sum |a||b| per output), rows behind a multiple of
+    128, a K tail behind a multiple of 32, both weight orientations, the four epilogues; and the switch really switches
+    (the results differ from the exact-f32 kernels' in the last bits, both inside the bound)."""
+    rng = np.random.default_rng(M + N + K)
+    A, B, bias, X0 = _mk(rng, M, K), _mk(rng, K, N), _mk(rng, N), _mk(rng, M, N)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    At, Bt = t(A), t(B.T if tb else B)
+    kw = dict(trans_b=tb, epilogue=epi, bias=t(bias) if epi.startswith("bias") else None,
+              aux0=t(X0) if epi == "relu_mask" else None)
+    monkeypatch.setenv("REC_GEMM_BF16X3", "0")
+    C0 = ops.gemm(At, Bt, ops.Workspace(DEV), **kw).cpu().numpy()
+    monkeypatch.setenv("REC_GEMM_BF16X3", "1")
+    ws = ops.Workspace(DEV)
+    C1 = ops.gemm(At, Bt, ws, **kw).cpu().numpy()
+    acc = A.astype(np.float64) @ B.astype(np.float64)
+    bound = 4e-7 * (np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64))
+    if epi.startswith("bias"):
+        acc = acc + bias
+        bound = bound + 1.2e-7 * np.abs(acc)                 # the f32 add of the bias
+    if epi == "bias_relu":
+        acc = np.maximum(acc, 0)
+    if epi == "relu_mask":
+        acc = np.where(X0 > 0, acc, 0)
+    _check(C1, acc, bound)
+    _check(C0, acc, bound)
+    assert not np.array_equal(C0, C1), "REC_GEMM_BF16X3=1 did not select the bf16 x 3 kernel"
+    assert np.array_equal(C1, ops.gemm(At, Bt, ws, **kw).cpu().numpy())          # deterministic
+    # an operand with a wide dynamic range (products of very different magnitude in one sum): the split is exact per
+    # element whatever its exponent, so the bound still holds
+    A2 = (A * np.exp(6 * rng.standard_normal(A.shape))).astype(np.float32)
+    C2 = ops.gemm(t(A2), Bt, ws, trans_b=tb).cpu().numpy()
+    _check(C2, A2.astype(np.float64) @ B.astype(np.float64),
+           4e-7 * (np.abs(A2).astype(np.float64) @ np.abs(B).astype(np.float64)))

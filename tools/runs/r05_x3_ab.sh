@@ -1,0 +1,11 @@
+#!/bin/bash
+# bf16 x 3 GEMM (csrc/gemm_bf16x3.h, REC_GEMM_BF16X3): GEMM tests, then the bench step with the switch off / on (A/B/A/B)
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/x3; mkdir -p "$O"; cd "$R"
+timeout 300 python -m pytest tests/test_gemm_gpu.py -x -q 2>&1 | tail -5 | tee "$O/test_gemm.txt"
+for v in 0 1 0 1; do
+  echo "REC_GEMM_BF16X3=$v" | tee -a "$O/ab.txt"
+  REC_GEMM_BF16X3=$v timeout 200 python bench.py --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('ms_per_step %.4f  value %.3fM  kernels_ms %s  mlp_gemm_tflops %.1f loss %s' % (d['ms_per_step'], d['value']/1e6, {k: round(v,3) for k,v in d['kernels_ms'].items()}, r.get('mlp_gemm_tflops',0), d['config'].get('loss')))" | tee -a "$O/ab.txt"
+done
