@@ -270,6 +270,233 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int64_t M, int N, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------ weight gradient (TN form)
+//   P[z][Kin,Nout] = X[rows of slice z, Kin]^T @ G[rows of slice z, Nout]       (dW = X^T G, K = the batch, split over z)
+// Both operands are activations: f32, row-major, the contraction index (the batch row m) is the STRIDED one.  A thread
+// loads an 8 (m) x 4 (columns) patch as eight coalesced float4s, splits it in registers into the three bf16 planes with
+// the pairs packed ALONG m, and writes each column's 8 m as one 16-B chunk into LDS — the transpose happens in that
+// write, and the fragment of v_mfma_f32_16x16x32_bf16 (8 consecutive contraction indices of one column) is again one
+// ds_read_b128.  LDS stage = [X planes 3 x 208 columns x 64 B][G planes the same] = 79 872 B, two stages.
+// Slot of (column c, m-group g) inside a plane: g * 208 + 16 a + q, a = c / 16, i = c % 16,
+// q = i / 4 + 4 ((i % 4 + a) % 4): conflict-free for the fragment read (16 lanes = 16 columns of one tile: q is a
+// bijection of i) AND for the patch write (16 lanes = columns 4 L + e: q = L % 4 + 4 ((e + L / 4) % 4)).
+// Block = 4 waves as 2 x 2 over an output block of up to 13 x 13 MFMA tiles (208 x 208), a wave up to 7 x 7 tiles; output
+// blocks x slices = grid, block b on XCD b % 8 takes slice (j / nob) * 8 + b % 8, j = b / 8, output block j % nob: the
+// output blocks of a slice run on ONE XCD, so X and G rows come from HBM once and from that L2 the other times.
+// Partial sums go to P (float4 along Nout), the column sums of G's slice (the bias gradient) to cpart[z][Nout] from the
+// blocks of the first Kin block; the engine's split-K reduce folds both in ascending z.
+constexpr int kX3DwCols = 208;                         // columns of one operand per block (13 MFMA tiles)
+constexpr int kX3DwPlane = kX3DwCols * 64;             // 13 312 B
+constexpr int kX3DwOperand = 3 * kX3DwPlane;           // 39 936 B
+constexpr int kX3DwWT = 7;                             // MFMA tiles per wave along Nout (and, at most, along Kin)
+
+__device__ __forceinline__ int x3_dw_q(int i, int a) { return (i >> 2) + 4 * (((i & 3) + a) & 3); }
+
+template <int T>
+__device__ __forceinline__ void x3_dw_read(u32x4_t (&f)[3], unsigned base) {     // tile T of this lane's operand region
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[0]) : "v"(base), "n"(T * 256));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[1]) : "v"(base), "n"(T * 256 + kX3DwPlane));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[2]) : "v"(base), "n"(T * 256 + 2 * kX3DwPlane));
+}
+
+__device__ __forceinline__ void x3_dw_read_u(u32x4_t (&f)[3], unsigned base, int u) {   // u: constant after unrolling
+  switch (u) {
+    case 0: x3_dw_read<0>(f, base); break;
+    case 1: x3_dw_read<1>(f, base); break;
+    case 2: x3_dw_read<2>(f, base); break;
+    case 3: x3_dw_read<3>(f, base); break;
+    case 4: x3_dw_read<4>(f, base); break;
+    case 5: x3_dw_read<5>(f, base); break;
+    default: x3_dw_read<6>(f, base); break;
+  }
+}
+
+struct X3DwArgs {
+  const float* X; int64_t ldx;      // [rows, Kin]
+  const float* G; int64_t ldg;      // [rows, Nout]
+  int64_t rows;                     // the batch (contraction length), % 32 == 0
+  int kin, nout;
+  int kb_tiles, nb_tiles;           // MFMA tiles per output block along Kin / Nout (<= 13)
+  int kblocks, nblocks;             // output blocks along Kin / Nout
+  int slices, steps_per_slice;      // slices % 8 == 0; 32-row k-steps per slice
+  float* P; int64_t ldp;            // [slices][Kin][ldp]
+  float* cpart;                     // [slices][Nout] or null
+};
+
+// PW = MFMA tiles per wave along Kin (7: blocks of 13 / 12 tiles, 5: blocks of 9 / 10).  A wave always computes its whole
+// PW x 7 tile set: the tiles behind its share (the smaller half of an odd split, the block's edge) multiply whatever
+// those LDS slots hold and are never stored — the block waits for its largest wave anyway, and a branch per MFMA costs
+// more than the MFMA (measured in the ISA: 674 branches and 725 accumulator moves with guards, none without).
+template <int PW>
+__global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
+  extern __shared__ __attribute__((aligned(1024))) char x3_smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int li = lane & 15, g = lane >> 4;
+  const int wk = wave & 1, wn = wave >> 1;
+  // which output block, which slice (see the header)
+  const int nob = w.kblocks * w.nblocks;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int ob = j % nob, slice = (j / nob) * 8 + xcd;
+  const int kb = ob / w.nblocks, nb = ob % w.nblocks;
+  const int k_tile0 = kb * w.kb_tiles, n_tile0 = nb * w.nb_tiles;                       // first MFMA tile of the block
+  const int kt_blk = min(w.kb_tiles, (w.kin + 15) / 16 - k_tile0);                       // tiles of this block
+  const int nt_blk = min(w.nb_tiles, (w.nout + 15) / 16 - n_tile0);
+  const int k_split = (kt_blk + 1) / 2, n_split = (nt_blk + 1) / 2;                      // wave 0 takes the larger half
+  const int my_k0 = wk ? k_split : 0, my_p = __builtin_amdgcn_readfirstlane(wk ? kt_blk - k_split : k_split);
+  const int my_n0 = wn ? n_split : 0, my_q = __builtin_amdgcn_readfirstlane(wn ? nt_blk - n_split : n_split);
+  const int64_t row0 = (int64_t)slice * w.steps_per_slice * 32;
+  int nsteps = (int)min((int64_t)w.steps_per_slice, (w.rows - row0) / 32);
+  if (nsteps < 0) nsteps = 0;
+
+  // ---- staging: thread t < 208 owns patch (m-group t / 52, column group t % 52) of BOTH operands
+  const bool stager = tid < 4 * (kX3DwCols / 4);
+  const int mg = stager ? tid / (kX3DwCols / 4) : 0, cg = tid % (kX3DwCols / 4);     // (the idle threads re-read m-group 0)
+  const int xc = k_tile0 * 16 + cg * 4, gc = n_tile0 * 16 + cg * 4;                      // first global column of the patch
+  const bool x_ok = stager && cg * 4 < kt_blk * 16 && xc < w.kin;                        // kin, nout % 4 == 0
+  const bool g_ok = stager && cg * 4 < nt_blk * 16 && gc < w.nout;
+  const float* xp = w.X + (row0 + mg * 8) * w.ldx + (x_ok ? xc : 0);
+  const float* gp = w.G + (row0 + mg * 8) * w.ldg + (g_ok ? gc : 0);
+  float4 xr[8], gr[8];
+  auto load_patches = [&](int kt) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      xr[r] = *reinterpret_cast<const float4*>(xp + ((int64_t)kt * 32 + r) * w.ldx);
+      gr[r] = *reinterpret_cast<const float4*>(gp + ((int64_t)kt * 32 + r) * w.ldg);
+    }
+  };
+  // LDS byte offsets of the patch's four columns (chunk mg): column c = cg * 4 + e -> a = cg / 4, i = 4 (cg % 4) + e
+  unsigned wr_off[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int a = cg >> 2, i = 4 * (cg & 3) + e;
+    wr_off[e] = (unsigned)((mg * kX3DwCols + 16 * a + x3_dw_q(i, a)) * 16);
+  }
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto convert_store = [&](int stage) {
+    char* sx = x3_smem + stage * kX3Stage;
+    char* sg = sx + kX3DwOperand;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      u32x4_t p0, p1, p2;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const float v0 = e == 0 ? xr[2 * d].x : e == 1 ? xr[2 * d].y : e == 2 ? xr[2 * d].z : xr[2 * d].w;
+        const float v1 = e == 0 ? xr[2 * d + 1].x : e == 1 ? xr[2 * d + 1].y : e == 2 ? xr[2 * d + 1].z : xr[2 * d + 1].w;
+        unsigned a, b, c;
+        x3_split_pair(x_ok ? v0 : 0.f, x_ok ? v1 : 0.f, a, b, c);
+        p0[d] = a; p1[d] = b; p2[d] = c;
+      }
+      if (stager) {
+        *reinterpret_cast<u32x4_t*>(sx + wr_off[e]) = p0;
+        *reinterpret_cast<u32x4_t*>(sx + kX3DwPlane + wr_off[e]) = p1;
+        *reinterpret_cast<u32x4_t*>(sx + 2 * kX3DwPlane + wr_off[e]) = p2;
+      }
+      float cs = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const float v0 = e == 0 ? gr[2 * d].x : e == 1 ? gr[2 * d].y : e == 2 ? gr[2 * d].z : gr[2 * d].w;
+        const float v1 = e == 0 ? gr[2 * d + 1].x : e == 1 ? gr[2 * d + 1].y : e == 2 ? gr[2 * d + 1].z : gr[2 * d + 1].w;
+        const float u0 = g_ok ? v0 : 0.f, u1 = g_ok ? v1 : 0.f;
+        cs += u0 + u1;
+        unsigned a, b, c;
+        x3_split_pair(u0, u1, a, b, c);
+        p0[d] = a; p1[d] = b; p2[d] = c;
+      }
+      if (e == 0) csum.x += cs; else if (e == 1) csum.y += cs; else if (e == 2) csum.z += cs; else csum.w += cs;
+      if (stager) {
+        *reinterpret_cast<u32x4_t*>(sg + wr_off[e]) = p0;
+        *reinterpret_cast<u32x4_t*>(sg + kX3DwPlane + wr_off[e]) = p1;
+        *reinterpret_cast<u32x4_t*>(sg + 2 * kX3DwPlane + wr_off[e]) = p2;
+      }
+    }
+  };
+
+  f32x4_t acc[PW][kX3DwWT];
+#pragma unroll
+  for (int a = 0; a < PW; ++a)
+#pragma unroll
+    for (int t = 0; t < kX3DwWT; ++t) acc[a][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read bases: tile (first tile of the wave + u) lives at 256 B x tile + the lane's slot, whose q depends on
+  // tile % 4 -> four bases per operand, indexed by u % 4 (the unrolled loops pick them statically)
+  const unsigned lds0 = (unsigned)(uintptr_t)x3_smem;
+  unsigned xb[4], gb[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int ax = my_k0 + u, an = my_n0 + u;
+    xb[u] = lds0 + (unsigned)((g * kX3DwCols + 16 * my_k0 + x3_dw_q(li, ax)) * 16);
+    gb[u] = lds0 + kX3DwOperand + (unsigned)((g * kX3DwCols + 16 * my_n0 + x3_dw_q(li, an)) * 16);
+  }
+
+  if (nsteps > 0) {
+    load_patches(0);
+    convert_store(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nsteps; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < nsteps) load_patches(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned so = stage * kX3Stage;
+    // this wave's X fragments (the MFMA's second operand: Kin becomes the accumulator's lane index)
+    u32x4_t af[PW][3];
+#pragma unroll
+    for (int u = 0; u < PW; ++u) x3_dw_read_u(af[u], xb[u & 3] + so, u);
+    u32x4_t bf[2][3];
+    x3_dw_read_u(bf[0], gb[0] + so, 0);
+#pragma unroll
+    for (int t = 0; t < kX3DwWT; ++t) {
+      if (t + 1 < kX3DwWT) {
+        x3_dw_read_u(bf[(t + 1) & 1], gb[(t + 1) & 3] + so, t + 1);
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bf[t & 1][0]), "+v"(bf[t & 1][1]), "+v"(bf[t & 1][2]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[t & 1][0]), "+v"(bf[t & 1][1]), "+v"(bf[t & 1][2]));
+      }
+      const u32x4_t* b = bf[t & 1];
+#define REC_X3_DW_MFMA(PB, PA)                                                                                 \
+  _Pragma("unroll") for (int a = 0; a < PW; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(            \
+      __builtin_bit_cast(bf16x8_t, b[PB]), __builtin_bit_cast(bf16x8_t, af[a][PA]), acc[a][t], 0, 0, 0);
+      REC_X3_DW_MFMA(2, 0) REC_X3_DW_MFMA(1, 1) REC_X3_DW_MFMA(0, 2)
+      REC_X3_DW_MFMA(1, 0) REC_X3_DW_MFMA(0, 1) REC_X3_DW_MFMA(0, 0)
+#undef REC_X3_DW_MFMA
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kt + 1 < nsteps) convert_store(stage ^ 1);      // the other stage: nobody reads it since the last barrier
+    __syncthreads();
+  }
+
+  // ---- partial tile: lane (i, g) holds P[Kin = tile a, row i][Nout = tile t, columns 4g .. 4g+3]
+  float* P = w.P + (int64_t)slice * w.kin * w.ldp;
+#pragma unroll
+  for (int a = 0; a < PW; ++a) {
+    if (a >= my_p) continue;
+    const int ki = (k_tile0 + my_k0 + a) * 16 + li;
+#pragma unroll
+    for (int t = 0; t < kX3DwWT; ++t) {
+      if (t >= my_q) continue;
+      const int nj = (n_tile0 + my_n0 + t) * 16 + g * 4;
+      if (ki < w.kin && nj < w.nout) *reinterpret_cast<f32x4_t*>(P + (int64_t)ki * w.ldp + nj) = acc[a][t];
+    }
+  }
+  // ---- column sums of G's slice: the four m-groups of a column group meet in LDS (every stage is free now)
+  if (w.cpart && kb == 0) {
+    float4* red = reinterpret_cast<float4*>(x3_smem);
+    if (stager) red[mg * (kX3DwCols / 4) + cg] = csum;
+    __syncthreads();
+    if (tid < kX3DwCols / 4 && tid * 4 < nt_blk * 16 && n_tile0 * 16 + tid * 4 < w.nout) {
+      const float4 s0 = red[tid], s1 = red[kX3DwCols / 4 + tid], s2 = red[2 * (kX3DwCols / 4) + tid],
+                   s3 = red[3 * (kX3DwCols / 4) + tid];
+      float4 o;
+      o.x = (s0.x + s1.x) + (s2.x + s3.x); o.y = (s0.y + s1.y) + (s2.y + s3.y);
+      o.z = (s0.z + s1.z) + (s2.z + s3.z); o.w = (s0.w + s1.w) + (s2.w + s3.w);
+      *reinterpret_cast<float4*>(w.cpart + (int64_t)slice * w.nout + n_tile0 * 16 + tid * 4) = o;
+    }
+  }
+}
+
 // host side -------------------------------------------------------------------------------------------------------
 inline int x3_launch_split(const float* W, int64_t ldw, int K, int N, int trans, char* img, hipStream_t st) {
   const int nkt = (K + 31) / 32;
@@ -312,6 +539,50 @@ inline int x3_launch_gemm(int epi, int64_t M, int N, int K, const float* A, int6
     case REC_EPI_RELU_MASK: return x3_launch_gemm_epi<REC_EPI_RELU_MASK>(M, N, K, A, lda, img, C, ldc, e, st);
     default: set_error("gemm_bf16x3: epilogue %d not built", epi); return REC_EINVAL;
   }
+}
+
+
+// dW plan: output blocks of <= 13 x 13 tiles, as equal as they come; slices = one resident round of blocks
+struct X3DwPlan { int kb_tiles, nb_tiles, kblocks, nblocks, slices, steps_per_slice; };
+inline bool x3_dw_plan(int kin, int nout, int64_t rows, int cus, X3DwPlan* p) {
+  if (kin % 4 || nout % 4 || rows % 32 || kin < 16 || nout < 16) return false;
+  const int kt = (kin + 15) / 16, nt = (nout + 15) / 16;
+  p->kblocks = (kt + 12) / 13; p->nblocks = (nt + 12) / 13;
+  p->kb_tiles = (kt + p->kblocks - 1) / p->kblocks; p->nb_tiles = (nt + p->nblocks - 1) / p->nblocks;
+  const int nob = p->kblocks * p->nblocks;
+  int slices = cus / nob;
+  slices -= slices % 8;
+  if (slices < 8) return false;
+  const int64_t steps = rows / 32;
+  p->steps_per_slice = (int)((steps + slices - 1) / slices);
+  if (p->steps_per_slice < 4) return false;
+  p->slices = (int)((steps + p->steps_per_slice - 1) / p->steps_per_slice);
+  p->slices = (p->slices + 7) / 8 * 8;             // whole groups of 8 (slices behind the rows write zeros)
+  return true;
+}
+inline int x3_launch_dw(const X3DwPlan& pl, int kin, int nout, int64_t rows, const float* X, int64_t ldx, const float* G,
+                        int64_t ldg, float* P, int64_t ldp, float* cpart, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr int lds = 2 * kX3Stage;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dw_kernel<7>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dw_kernel<5>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("gemm_bf16x3_dw: %d B of dynamic LDS refused", lds);
+      return REC_EHIP;
+    }
+    attr_set = true;
+  }
+  X3DwArgs w{X, ldx, G, ldg, rows, kin, nout, pl.kb_tiles, pl.nb_tiles, pl.kblocks, pl.nblocks, pl.slices,
+             pl.steps_per_slice, P, ldp, cpart};
+  const unsigned grid = (unsigned)(pl.slices * pl.kblocks * pl.nblocks);
+  if ((pl.kb_tiles + 1) / 2 <= 5)
+    hipLaunchKernelGGL(gemm_bf16x3_dw_kernel<5>, dim3(grid), dim3(256), lds, st, w);
+  else
+    hipLaunchKernelGGL(gemm_bf16x3_dw_kernel<7>, dim3(grid), dim3(256), lds, st, w);
+  return check_launch("gemm_bf16x3_dw_kernel");
 }
 
 }  // namespace rec

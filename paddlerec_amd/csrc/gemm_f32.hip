@@ -860,9 +860,56 @@ static void launch_reduce(const rec_gemm_desc* d, const GemmPlan& p, const float
                      d->n, (int64_t)d->ldc, p.splits, partial, C, e, cpart, colsum_out, cblocks);
 }
 
+// dW = X^T G of the towers' own widths on the same bf16 x 3 arithmetic (gemm_bf16x3_dw_kernel): trans_a form, no
+// epilogue, the planner's own K split; partial tiles and partial column sums in the caller's workspace, folded by the
+// engine's split-K reduce in ascending slice order (deterministic).
+static bool x3_dw_eligible(const rec_gemm_desc* d, X3DwPlan* pl) {
+  // an explicit K split is a caller's request for few, long blocks that leave wave slots to a kernel running beside the
+  // GEMM (the deferred dW_0 under the sparse update): this kernel owns every SIMD's register file, so it only takes those
+  // calls on request (REC_GEMM_BF16X3=2)
+  const char* v = getenv("REC_GEMM_BF16X3");
+  const bool forced = v && *v == '2';
+  const char* vd = getenv("REC_GEMM_BF16X3_DW");           // 0: forward / dX only (A/B runs)
+  if (vd && *vd == '0') return false;
+  if (!x3_enabled() || !d->trans_a || d->trans_b || (d->split_k != 0 && !forced) || d->epilogue != REC_EPI_NONE) return false;
+  if (d->k < 8192 || d->m < 336 || d->m > 448 || d->n < 336 || d->n > 416) return false;
+  if (d->lda % 4 || d->ldb % 4 || d->ldc % 4) return false;
+  return x3_dw_plan((int)d->m, d->n, d->k, device_cus(), pl);
+}
+static size_t x3_dw_bytes(const rec_gemm_desc* d, const X3DwPlan& pl) {
+  return align_up((size_t)pl.slices * d->m * d->ldc * sizeof(float), 256) + align_up((size_t)pl.slices * d->n * sizeof(float), 256);
+}
+static bool launch_x3_dw(const rec_gemm_desc* d, const float* A, const float* B, float* C, const EpiArgs& e, float* b_colsum,
+                         void* workspace, size_t workspace_bytes, hipStream_t st) {
+  X3DwPlan pl;
+  if (!x3_dw_eligible(d, &pl)) return false;
+  if (((uintptr_t)A) % 16 || ((uintptr_t)B) % 16 || ((uintptr_t)C) % 16) return false;
+  if (!workspace || ((uintptr_t)workspace) % 16 || workspace_bytes < x3_dw_bytes(d, pl)) return false;
+  float* partial = (float*)workspace;
+  float* cpart = (float*)((char*)workspace + align_up((size_t)pl.slices * d->m * d->ldc * sizeof(float), 256));
+  if (x3_launch_dw(pl, (int)d->m, d->n, d->k, A, d->lda, B, d->ldb, partial, d->ldc, b_colsum ? cpart : nullptr, st) != REC_OK)
+    return false;
+  GemmPlan sp{};
+  sp.splits = pl.slices;
+  launch_reduce<REC_EPI_NONE>(d, sp, partial, C, e, st, b_colsum ? cpart : nullptr, b_colsum);
+  return true;
+}
+
 }  // namespace rec
 
 using namespace rec;
+
+// what the exact-f32 kernels need (the bf16 x 3 forms ask for more; a caller that sized its workspace with the switch off
+// gets the exact-f32 kernels when it is flipped on, not an error)
+static size_t plain_workspace_bytes(const rec_gemm_desc* desc) {
+  if (skinny_dw(desc)) {
+    const size_t z = (size_t)((desc->k + kSkinnyKC - 1) / kSkinnyKC);
+    return align_up(z * desc->m * desc->ldc * sizeof(float), 256) + align_up(z * desc->n * sizeof(float), 256);
+  }
+  const GemmPlan p = plan_gemm(desc);
+  return (p.splits > 1 ? align_up((size_t)p.splits * desc->m * desc->ldc * sizeof(float), 256) : 0) +
+         align_up((size_t)p.splits * desc->n * sizeof(float), 256);
+}
 
 extern "C" int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* bytes) {
   if (int rc = check_gemm(desc)) return rc;
@@ -877,6 +924,8 @@ extern "C" int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* b
   *bytes = (p.splits > 1 ? align_up((size_t)p.splits * desc->m * desc->ldc * sizeof(float), 256) : 0) +
            align_up((size_t)p.splits * desc->n * sizeof(float), 256);
   if (x3_eligible(desc) && *bytes < x3_image_bytes(desc->k)) *bytes = align_up(x3_image_bytes(desc->k), 256);   // B's plane image
+  X3DwPlan dwp;
+  if (x3_dw_eligible(desc, &dwp) && *bytes < x3_dw_bytes(desc, dwp)) *bytes = x3_dw_bytes(desc, dwp);
   return REC_OK;
 }
 
@@ -943,8 +992,7 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
     return check_launch("rec_gemm_f32 (skinny rows)");
   }
   if (skinny_dw(desc) && epi == REC_EPI_NONE) {
-    size_t need = 0;
-    rec_gemm_f32_workspace_bytes(desc, &need);
+    const size_t need = plain_workspace_bytes(desc);
     REC_REQUIRE(workspace && workspace_bytes >= need, REC_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, need);
     const int z = (int)((desc->k + kSkinnyKC - 1) / kSkinnyKC);
     float* part = (float*)workspace;
@@ -960,6 +1008,7 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
                          desc->n, z, (const float*)cpart2, b_colsum);
     return check_launch("rec_gemm_f32 (skinny dW)");
   }
+  if (launch_x3_dw(desc, A, B, C, e, b_colsum, workspace, workspace_bytes, st)) return check_launch("rec_gemm_f32 (bf16x3 dW)");
   // tall problems of the towers' own widths: whole row panels, one resident round (gemm_panel.h)
   if (!b_colsum && launch_x3(desc, A, B, C, e, workspace, workspace_bytes, st)) return check_launch("rec_gemm_f32 (bf16x3)");
   if (!b_colsum && launch_panel(desc, A, B, C, e, st, device_cus())) return check_launch("rec_gemm_f32 (panel)");
@@ -972,8 +1021,7 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
   float* partial = nullptr;
   float* cpart = nullptr;
   if (p.splits > 1 || b_colsum) {
-    size_t need = 0;
-    rec_gemm_f32_workspace_bytes(desc, &need);
+    const size_t need = plain_workspace_bytes(desc);
     REC_REQUIRE(workspace && workspace_bytes >= need, REC_EWORKSPACE, "workspace %zu < %zu",
                 workspace_bytes, need);
     size_t off = 0;

@@ -1455,7 +1455,7 @@ def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux
                          ld2, pv(b_colsum))
     if _recorder is not None:      # a recorded step holds these addresses too
         _recorder.keep.extend(t for t in (bias, aux0, aux1, row_scale, out2, b_colsum) if t is not None)
-    key = (M, N, K, lda, ldb, ldc, d.trans_a, d.trans_b, d.epilogue, d.split_k)
+    key = (M, N, K, lda, ldb, ldc, d.trans_a, d.trans_b, d.epilogue, d.split_k, os.environ.get("REC_GEMM_BF16X3"))
     need = _gemm_ws_cache.get(key)
     if need is None:       # a pure function of the descriptor: one C call per distinct GEMM, not per launch
         nbytes = C.c_size_t(0)

@@ -356,9 +356,42 @@ def test_gemm_bf16x3(ops, monkeypatch, M, N, K, tb, epi):
     _check(C0, acc, bound)
     assert not np.array_equal(C0, C1), "REC_GEMM_BF16X3=1 did not select the bf16 x 3 kernel"
     assert np.array_equal(C1, ops.gemm(At, Bt, ws, **kw).cpu().numpy())          # deterministic
-    # an operand with a wide dynamic range (products of very different magnitude in one sum): the split is exact per
-    # element whatever its exponent, so the bound still holds
+    # an operand with a wide dynamic range (products of very different magnitude in one sum): every element is split to
+    # 2^-25 of ITS OWN magnitude whatever its exponent, so the result is as close to float64 as the exact-f32 kernel's
+    # (whose own error on such sums is ~1.5e-6 of sum |a||b|: f32 accumulation, not the operands)
     A2 = (A * np.exp(6 * rng.standard_normal(A.shape))).astype(np.float32)
+    want2 = A2.astype(np.float64) @ B.astype(np.float64)
+    mag2 = np.abs(A2).astype(np.float64) @ np.abs(B).astype(np.float64)
     C2 = ops.gemm(t(A2), Bt, ws, trans_b=tb).cpu().numpy()
-    _check(C2, A2.astype(np.float64) @ B.astype(np.float64),
-           4e-7 * (np.abs(A2).astype(np.float64) @ np.abs(B).astype(np.float64)))
+    monkeypatch.setenv("REC_GEMM_BF16X3", "0")
+    C2f = ops.gemm(t(A2), Bt, ops.Workspace(DEV), trans_b=tb).cpu().numpy()
+    e3, ef = (np.abs(C2 - want2) / mag2).max(), (np.abs(C2f - want2) / mag2).max()
+    assert e3 <= 2.0 * ef + 1e-7 and e3 < 4e-6, (e3, ef)      # both ~1e-6: sqrt(K) roundings of a sum one product dominates
+
+
+@pytest.mark.parametrize("rows,kin,nout", [(8192 + 64, 400, 400), (16384, 432, 400), (8192, 336, 416), (12000 - 32, 448, 340)])
+def test_gemm_bf16x3_weight_gradient(ops, monkeypatch, rows, kin, nout):
+    """dW = X^T G and db = colsum(G) on the bf16 x 3 kernel (gemm_bf16x3_dw_kernel: both operands split and transposed
+    on their way into LDS, K split over the chip, the engine's fixed-order reduce): float64 bound of the exact-f32 form,
+    rows that do not fill the last slice, output blocks of 13 / 12 / 9 tiles, deterministic."""
+    rng = np.random.default_rng(rows + kin)
+    X, G = _mk(rng, rows, kin), _mk(rng, rows, nout)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    Xt, Gt = t(X), t(G)
+    res = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("REC_GEMM_BF16X3", v)
+        ws = ops.Workspace(DEV)
+        C_, b_ = torch.zeros(kin, nout, device=DEV), torch.zeros(nout, device=DEV)
+        ops.gemm(Xt, Gt, ws, trans_a=True, out=C_, b_colsum=b_)
+        C2, b2 = torch.zeros(kin, nout, device=DEV), torch.zeros(nout, device=DEV)
+        ops.gemm(Xt, Gt, ws, trans_a=True, out=C2, b_colsum=b2)
+        assert torch.equal(C_, C2) and torch.equal(b_, b2)
+        res[v] = (C_.cpu().numpy(), b_.cpu().numpy())
+    want = X.astype(np.float64).T @ G.astype(np.float64)
+    bound = 4e-7 * (np.abs(X).astype(np.float64).T @ np.abs(G).astype(np.float64))
+    cwant, cbound = G.astype(np.float64).sum(0), 4e-7 * np.abs(G).astype(np.float64).sum(0)
+    for v in ("0", "1"):
+        _check(res[v][0], want, bound)
+        _check(res[v][1], cwant, cbound)
+    assert not np.array_equal(res["0"][0], res["1"][0]), "REC_GEMM_BF16X3=1 did not select the bf16 x 3 weight-gradient kernel"

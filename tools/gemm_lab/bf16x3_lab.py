@@ -93,5 +93,48 @@ def main():
                  float((e0 / mag).max()), float((e1 / mag).max())), flush=True)
 
 
+def dw_main(args):
+    """the weight-gradient form through the engine (rec_gemm_f32, trans_a, b_colsum): switch off / on"""
+    g = torch.Generator(device="cuda").manual_seed(2)
+    rnd = lambda *s: torch.rand(*s, device="cuda", generator=g) - 0.5
+    for name, rows, kin, nout in (("dw1", 65536, 400, 400), ("dw0", 65536, 432, 400), ("dwr", 8192 + 64, 400, 336)):
+        X, G = rnd(rows, kin), rnd(rows, nout)
+        out, cs = {}, {}
+        best = {}
+        for v in ("0", "1"):
+            os.environ["REC_GEMM_BF16X3"] = v
+            ws = ops.Workspace("cuda")
+            C_, b_ = torch.zeros(kin, nout, device="cuda"), torch.zeros(nout, device="cuda")
+            fn = lambda: ops.gemm(X, G, ws, trans_a=True, out=C_, b_colsum=b_)
+            for _ in range(args.rounds):
+                fn()
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _i in range(args.iters):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                best[v] = min(best.get(v, 1e9), a.elapsed_time(b) / args.iters * 1e3)
+            out[v], cs[v] = C_.double(), b_.double()
+        ref = X.double().t() @ G.double()
+        mag = X.double().abs().t() @ G.double().abs()
+        cref = G.double().sum(0)
+        fl = 2.0 * rows * kin * nout
+        print("%-4s rows=%d kin=%d nout=%d  f32 %6.1f us %6.1f TF | x3 %6.1f us %6.1f TF-equiv (x%.2f) | max err / sum|a||b|: "
+              "f32 %.2e x3 %.2e | colsum max err / sum|g|: f32 %.2e x3 %.2e | differ=%s"
+              % (name, rows, kin, nout, best["0"], fl / best["0"] / 1e6, best["1"], fl / best["1"] / 1e6, best["0"] / best["1"],
+                 float(((out["0"] - ref).abs() / mag).max()), float(((out["1"] - ref).abs() / mag).max()),
+                 float(((cs["0"] - cref).abs() / G.double().abs().sum(0)).max()),
+                 float(((cs["1"] - cref).abs() / G.double().abs().sum(0)).max()), not torch.equal(out["0"], out["1"])), flush=True)
+
+
 if __name__ == "__main__":
+    if "--dw" in sys.argv:
+        sys.argv.remove("--dw")
+        ap = argparse.ArgumentParser()
+        ap.add_argument("--iters", type=int, default=20)
+        ap.add_argument("--rounds", type=int, default=2)
+        dw_main(ap.parse_args())
+        sys.exit(0)
     main()
