@@ -37,6 +37,8 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FP32_MFMA_PEAK_TF = 157.3   # dense f32 MFMA peak
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md); the bf16 x 3 GEMMs spend six bf16 MFMAs per f32 product
+X3_ON = os.environ.get("REC_GEMM_BF16X3", "1") != "0"      # csrc/gemm_bf16x3.h (the library's default: on)
 
 
 def algorithmic_bytes(B, S, Dn, D):
@@ -232,14 +234,20 @@ def other_configs(timeout_s=120):
             # the reference's dygraph-default optimizer on configs[1]: Adam lazy_mode=False, the whole table every step
             # (~10 GB per step on 26 tables) next to the lazy headline
             ("bench.py --non-lazy-adam", [sys.executable, os.path.abspath(__file__), "--non-lazy-adam", "--no-cpu-baseline",
-                                          "--steps", "10", "--warmup", "3"])]
+                                          "--steps", "10", "--warmup", "3"]),
+            # the headline workload with every GEMM on the exact-f32 MFMA kernels (v_mfma_f32_16x16x4_f32): what the
+            # bf16 x 3 split of the tall MLP GEMMs buys, same run, same box
+            ("REC_GEMM_BF16X3=0 bench.py", [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--steps", "20",
+                                            "--warmup", "5"])]
     keep = ("config", "workload", "ms", "ms_per_step", "samples_per_s", "value", "unit", "roofline", "pool_fwd_ms",
             "train_step_ms", "kernels_ms", "entry", "reader_ms", "batch_ms", "error")
     out = []
     for name, cmd in jobs:
         t0 = time.time()
         try:
-            r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout_s)
+            job_env = dict(env, REC_GEMM_BF16X3="0") if name.startswith("REC_GEMM_BF16X3=0") else env
+            r = subprocess.run(cmd + (["--no-other-configs"] if name.startswith("REC_GEMM_BF16X3=0") else []), cwd=REPO,
+                               env=job_env, capture_output=True, text=True, timeout=timeout_s)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not lines:
                 out.append({"command": name, "error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])})
@@ -252,7 +260,10 @@ def other_configs(timeout_s=120):
                     e["config"] = ("configs[4] (one GPU's share, row-sharded path at world 1)" if "--table" in cmd else
                                    "configs[1] layout 2b (one shared table)" if "--shared-table" in cmd else
                                    "configs[1] with the dygraph-default NON-lazy Adam" if "--non-lazy-adam" in cmd else
-                                   "configs[1] with Zipf(1.05) ids")
+                                   "configs[1] with every GEMM on the exact-f32 MFMA kernels (REC_GEMM_BF16X3=0)"
+                                   if name.startswith("REC_GEMM_BF16X3=0") else "configs[1] with Zipf(1.05) ids")
+                    if name.startswith("REC_GEMM_BF16X3=0"):
+                        e["dtype"] = d.get("dtype")
                     e["roofline"] = {k: d["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac",
                                                                        "in_step_frac")}
                 e["command"] = name
@@ -635,7 +646,13 @@ def main():
         "metric": "CTR samples/sec, Criteo DeepFM bs=65536 (train step: fwd+bwd+optimizer)",
         "value": world * B * args.steps / dt, "unit": "samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "scaling": "weak", "vs_baseline": None,
+        # f32 storage, f32 accumulation everywhere.  The tall MLP GEMMs (forward, dX, dW of the 400-wide layers) multiply
+        # on the bf16 matrix pipe: each f32 operand is split into three bf16 terms (x = x0 + x1 + x2 to 2^-25 |x|) and six
+        # of the nine term products are accumulated in f32 — error against float64 no larger than the exact-f32 MFMA
+        # kernels' (tests/test_gemm_gpu.py::test_gemm_bf16x3*); REC_GEMM_BF16X3=0 = those kernels (other_configs)
+        "dtype": "f32 (MLP GEMMs: f32 operands as 3 bf16 terms, 6 bf16 MFMAs per product, f32 accumulate)" if X3_ON
+        else "f32",
         "data": "synthetic" if not standin else "cpu-standin (REC_BENCH_STANDIN=1: host-logic test of this file's "
                                                 "launch path on the tests' operator stand-in; NOT a measurement)",
         "config": {"workload": "DeepFM full Criteo: 26 sparse slots x %d rows x dim %d, 13 dense, "
@@ -703,8 +720,15 @@ def main():
                          "model": "remote bytes / (links x 153 GB/s) + 8 us per call: all-to-all on min(G-1, 7) links, "
                                   "ring all-reduce on one (bench.py --dry-links prints it for 2 / 4 / 8 GPUs)"}}
            if exch is not None else {}),
-        "mlp_gemm": {"bound": "mfma", "achieved": gemm_tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": gemm_tf / FP32_MFMA_PEAK_TF, "flops_executed_per_step": 3 * mlp_flops(B, sizes)},
+        # f32-equivalent flops of the MLP / their time in the step.  With the bf16 x 3 kernels the pipe that bounds them is
+        # the bf16 MFMA at six instructions per f32 product: peak = 2500 / 6; the exact-f32 figure stays beside it
+        "mlp_gemm": {"bound": "mfma", "achieved": gemm_tf,
+                     "peak": BF16_MFMA_PEAK_TF / 6 if X3_ON else FP32_MFMA_PEAK_TF, "unit": "TFLOP/s (f32-equivalent)",
+                     "frac": gemm_tf / (BF16_MFMA_PEAK_TF / 6 if X3_ON else FP32_MFMA_PEAK_TF),
+                     "arithmetic": "bf16x3 (fwd, dX, dW of the 400-wide layers; dW_0 beside the sparse update stays exact f32)"
+                     if X3_ON else "exact f32 MFMA",
+                     "f32_mfma_peak": FP32_MFMA_PEAK_TF, "vs_f32_mfma_peak": gemm_tf / FP32_MFMA_PEAK_TF,
+                     "flops_executed_per_step": 3 * mlp_flops(B, sizes)},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -33,15 +33,38 @@ namespace rec {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int kX3NT = 13;                       // MFMA column tiles per wave
-constexpr int kX3NP = 2 * kX3NT * 16;           // 416 columns per block (zero weight columns behind N)
+constexpr int kX3NT = 13;                       // MFMA column tiles per wave of the widest column block
+constexpr int kX3NP = 2 * kX3NT * 16;           // 416 columns per block
 constexpr int kX3BM = 128;                      // rows per block
 constexpr int kX3MT = 4;                        // MFMA row tiles per wave (64 rows)
-constexpr int kX3PlaneBytes = kX3NP * 64;       // one plane of one k-step: 416 rows x 32 bf16
-constexpr int kX3Stage = 3 * kX3PlaneBytes;     // 79 872 B
-constexpr int kX3Pieces = kX3Stage / 1024;      // 78 LDS-DMA pieces per k-step
-
-__host__ __device__ inline size_t x3_image_bytes(int K) { return (size_t)((K + 31) / 32) * kX3Stage; }
+constexpr int kX3Stage = 3 * kX3NP * 64;        // the largest k-step stage: 79 872 B (two stages = 156 of the 160 KB)
+// Column blocks: a block covers 2 NT MFMA column tiles (NT per wave), NT in {13, 8, 7}: 400 -> one block of 26 tiles,
+// 432 -> two of 14, 512 -> two of 16, 1560 -> four of 26; the weight image is [column block][k-step][plane][NP rows][64 B].
+template <int NT>
+struct X3Geo {
+  static constexpr int NP = 2 * NT * 16;        // columns per block (zero weight columns behind N)
+  static constexpr int Plane = NP * 64;         // one plane of one k-step: NP rows x 32 bf16
+  static constexpr int Stage = 3 * Plane;
+  static constexpr int Pieces = Stage / 1024;   // LDS-DMA pieces per k-step (Stage % 1024 == 0 for every NT: 3 * NT * 2)
+};
+struct X3Cols { int nt, ncb; };                 // tiles per wave, column blocks
+inline X3Cols x3_cols(int N) {                  // least padded choice; nt = 0: none within 15 % of N
+  const int tiles = (N + 15) / 16;
+  X3Cols best{0, 0};
+  int best_pad = 1 << 30;
+  const int cand[3] = {13, 8, 7};
+  for (int c = 0; c < 3; ++c) {
+    const int ncb = (tiles + 2 * cand[c] - 1) / (2 * cand[c]);
+    const int pad = ncb * 2 * cand[c] - tiles;
+    if (pad < best_pad) { best_pad = pad; best = X3Cols{cand[c], ncb}; }
+  }
+  if (best_pad * 100 > tiles * 15) best.nt = 0;
+  return best;
+}
+inline size_t x3_image_bytes(int K, int N) {
+  const X3Cols c = x3_cols(N);
+  return (size_t)c.ncb * ((K + 31) / 32) * 3 * (2 * c.nt * 16) * 64;
+}
 
 __device__ __forceinline__ int x3_swz(int i) { return (4 - (i >> 2)) & 3; }   // {0,3,2,1}[i / 4], i = n % 16
 
@@ -64,12 +87,14 @@ __device__ __forceinline__ void x3_split_pair(float xe, float xo, unsigned& p0, 
 }
 
 // W [K,N] (trans 0: element (n, k) = W[k * ldw + n]) or W [N,K] (trans 1: W[n * ldw + k]) -> image; one thread per
-// (k-step, n, 8-k chunk).  Rows n >= N and chunks k >= K are zero.
+// (column block, k-step, row of the block, 8-k chunk).  Rows n >= N and chunks k >= K are zero.
 __global__ __launch_bounds__(kBlock) void x3_split_kernel(const float* __restrict__ W, int64_t ldw, int K, int N, int trans,
-                                                          char* __restrict__ img, int nkt) {
+                                                          char* __restrict__ img, int nkt, int np, int ncb) {
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (tid >= (int64_t)nkt * kX3NP * 4) return;
-  const int c = (int)(tid & 3), n = (int)((tid >> 2) % kX3NP), kt = (int)((tid >> 2) / kX3NP);
+  if (tid >= (int64_t)ncb * nkt * np * 4) return;
+  const int c = (int)(tid & 3), nl = (int)((tid >> 2) % np);
+  const int kt = (int)(((tid >> 2) / np) % nkt), cb = (int)((tid >> 2) / np / nkt);
+  const int n = cb * np + nl;
   float x[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -83,34 +108,37 @@ __global__ __launch_bounds__(kBlock) void x3_split_kernel(const float* __restric
     x3_split_pair(x[2 * d], x[2 * d + 1], a, b, e);
     p0[d] = a; p1[d] = b; p2[d] = e;
   }
-  char* dst = img + (size_t)kt * kX3Stage + (size_t)n * 64 + ((c ^ x3_swz(n & 15)) * 16);
+  const size_t plane = (size_t)np * 64;
+  char* dst = img + ((size_t)cb * nkt + kt) * 3 * plane + (size_t)nl * 64 + ((c ^ x3_swz(nl & 15)) * 16);
   *reinterpret_cast<u32x4_t*>(dst) = p0;
-  *reinterpret_cast<u32x4_t*>(dst + kX3PlaneBytes) = p1;
-  *reinterpret_cast<u32x4_t*>(dst + 2 * kX3PlaneBytes) = p2;
+  *reinterpret_cast<u32x4_t*>(dst + plane) = p1;
+  *reinterpret_cast<u32x4_t*>(dst + 2 * plane) = p2;
 }
 
 // one tile's three plane fragments (ds_read_b128, offset = tile * 1024 + plane * kX3PlaneBytes; plane 2 through a second
 // base because 2 * 26 624 + 12 * 1024 does not fit the 16-bit offset field)
-template <int T>
+template <int T, int PLANE>
 __device__ __forceinline__ void x3_read_frags(u32x4_t (&bf)[3], unsigned sb, unsigned sb2) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[0]) : "v"(sb), "n"(T * 1024));
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[1]) : "v"(sb), "n"(T * 1024 + kX3PlaneBytes));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[1]) : "v"(sb), "n"(T * 1024 + PLANE));
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[2]) : "v"(sb2), "n"(T * 1024));
 }
+template <int PLANE>
 __device__ __forceinline__ void x3_read_frags_t(u32x4_t (&bf)[3], unsigned sb, unsigned sb2, int t) {
   switch (t) {            // t is a compile-time constant at every call (fully unrolled tile loop)
-    case 1: x3_read_frags<1>(bf, sb, sb2); break;
-    case 2: x3_read_frags<2>(bf, sb, sb2); break;
-    case 3: x3_read_frags<3>(bf, sb, sb2); break;
-    case 4: x3_read_frags<4>(bf, sb, sb2); break;
-    case 5: x3_read_frags<5>(bf, sb, sb2); break;
-    case 6: x3_read_frags<6>(bf, sb, sb2); break;
-    case 7: x3_read_frags<7>(bf, sb, sb2); break;
-    case 8: x3_read_frags<8>(bf, sb, sb2); break;
-    case 9: x3_read_frags<9>(bf, sb, sb2); break;
-    case 10: x3_read_frags<10>(bf, sb, sb2); break;
-    case 11: x3_read_frags<11>(bf, sb, sb2); break;
-    default: x3_read_frags<12>(bf, sb, sb2); break;
+    case 0: x3_read_frags<0, PLANE>(bf, sb, sb2); break;
+    case 1: x3_read_frags<1, PLANE>(bf, sb, sb2); break;
+    case 2: x3_read_frags<2, PLANE>(bf, sb, sb2); break;
+    case 3: x3_read_frags<3, PLANE>(bf, sb, sb2); break;
+    case 4: x3_read_frags<4, PLANE>(bf, sb, sb2); break;
+    case 5: x3_read_frags<5, PLANE>(bf, sb, sb2); break;
+    case 6: x3_read_frags<6, PLANE>(bf, sb, sb2); break;
+    case 7: x3_read_frags<7, PLANE>(bf, sb, sb2); break;
+    case 8: x3_read_frags<8, PLANE>(bf, sb, sb2); break;
+    case 9: x3_read_frags<9, PLANE>(bf, sb, sb2); break;
+    case 10: x3_read_frags<10, PLANE>(bf, sb, sb2); break;
+    case 11: x3_read_frags<11, PLANE>(bf, sb, sb2); break;
+    default: x3_read_frags<12, PLANE>(bf, sb, sb2); break;
   }
 }
 
@@ -118,10 +146,11 @@ __device__ __forceinline__ void x3_read_frags_t(u32x4_t (&bf)[3], unsigned sb, u
 #define REC_X3_PRODUCTS 6      // lab knob: 3 = a0 b0 + a0 b1 + a1 b0 only (~2^-14 of scale: NOT f32-grade), 1 = plain bf16
 #endif
 
-template <int EPI>
+template <int NT, int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int64_t M, int N, int K, const float* __restrict__ A, int64_t lda,
-                                                          const char* __restrict__ Bimg, float* __restrict__ C,
+                                                          const char* __restrict__ Bimg_all, float* __restrict__ C,
                                                           int64_t ldc, EpiArgs epi) {
+  using Geo = X3Geo<NT>;
   extern __shared__ __attribute__((aligned(1024))) char x3_smem[];
   const int lane = threadIdx.x % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -129,6 +158,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int64_t M, int N, int 
   const int wm = wave & 1, wn = wave >> 1;
   const int nkt = (K + 31) / 32;
   const int64_t m0 = (int64_t)blockIdx.x * kX3BM + wm * (kX3MT * 16);
+  const int cb = blockIdx.y;                                  // column block: columns cb * NP ..
+  const char* Bimg = Bimg_all + (size_t)cb * nkt * Geo::Stage;
 
   // ---- A: per-lane row pointers (rows behind M re-read row M-1: finite data, never stored)
   const float* ap[kX3MT];
@@ -151,24 +182,24 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int64_t M, int N, int 
   };
   // ---- W': LDS-DMA of one k-step image; pieces dealt round-robin to the four waves
   auto issue_b = [&](int kt, int stage) {
-    const char* src = Bimg + (size_t)kt * kX3Stage + lane * 16;
-    const char* dst = x3_smem + stage * kX3Stage;
+    const char* src = Bimg + (size_t)kt * Geo::Stage + lane * 16;
+    const char* dst = x3_smem + stage * Geo::Stage;
 #pragma unroll
-    for (int j = 0; j < (kX3Pieces + 3) / 4; ++j) {
+    for (int j = 0; j < (Geo::Pieces + 3) / 4; ++j) {
       const int piece = wave + 4 * j;
-      if (piece < kX3Pieces)
+      if (piece < Geo::Pieces)
         __builtin_amdgcn_global_load_lds((glb_void_t*)(src + piece * 1024), (lds_void_t*)(dst + piece * 1024), 16, 0, 0);
     }
   };
 
-  f32x4_t acc[kX3MT][kX3NT];
+  f32x4_t acc[kX3MT][NT];
 #pragma unroll
   for (int a = 0; a < kX3MT; ++a)
 #pragma unroll
-    for (int t = 0; t < kX3NT; ++t) acc[a][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) acc[a][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   // byte address (LDS offset = low half of the flat address) of this lane's fragment slot in tile 0, plane 0, stage 0
-  const unsigned lds_base = (unsigned)(uintptr_t)x3_smem + (wn * kX3NT * 16 + li) * 64 + ((g ^ x3_swz(li)) * 16);
+  const unsigned lds_base = (unsigned)(uintptr_t)x3_smem + (wn * NT * 16 + li) * 64 + ((g ^ x3_swz(li)) * 16);
 
   issue_b(0, 0);
   load_a(0);
@@ -203,13 +234,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int64_t M, int N, int 
     // lgkmcnt(0) before every tile while LDS-DMA loads are in flight (it cannot order them against LDS reads), i.e.
     // also for the fragments it has just requested for the NEXT tile; here tile t's MFMAs wait for their own three
     // reads only (lgkmcnt(3): LDS returns in order) and the next tile's reads stay in flight underneath them.
-    const unsigned sb = lds_base + stage * kX3Stage;
+    const unsigned sb = lds_base + stage * Geo::Stage;
     u32x4_t bf[2][3];
-    x3_read_frags<0>(bf[0], sb, sb + 2 * kX3PlaneBytes);
+    x3_read_frags<0, Geo::Plane>(bf[0], sb, sb + 2 * Geo::Plane);
 #pragma unroll
-    for (int t = 0; t < kX3NT; ++t) {
-      if (t + 1 < kX3NT) {
-        x3_read_frags_t(bf[(t + 1) & 1], sb, sb + 2 * kX3PlaneBytes, t + 1);
+    for (int t = 0; t < NT; ++t) {
+      if (t + 1 < NT) {
+        x3_read_frags_t<Geo::Plane>(bf[(t + 1) & 1], sb, sb + 2 * Geo::Plane, t + 1);
         asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bf[t & 1][0]), "+v"(bf[t & 1][1]), "+v"(bf[t & 1][2]));
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[t & 1][0]), "+v"(bf[t & 1][1]), "+v"(bf[t & 1][2]));
@@ -239,33 +270,44 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int64_t M, int N, int 
   }
 
   // ---- epilogue: float4 per lane and tile, aux / bias operands of a row tile loaded ahead of its stores
-  const int n_base = wn * kX3NT * 16 + g * 4;
+  const int n_base = cb * Geo::NP + wn * NT * 16 + g * 4;
 #pragma unroll
   for (int a = 0; a < kX3MT; ++a) {
     const int64_t i = m0 + a * 16 + li;
     const bool row_ok = i < M;
     const int64_t ic = row_ok ? i : M - 1;
-    f32x4_t x0[kX3NT], bj[kX3NT];
+    f32x4_t x0[NT], x1[EpiUses<EPI>::aux1 ? NT : 1], bj[NT];
 #pragma unroll
-    for (int t = 0; t < kX3NT; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const int j = n_base + t * 16;
       const int jc = j < N ? j : 0;
 #pragma unroll
       for (int c = 0; c < 4; ++c) bj[t][c] = load_bias<EPI>(jc + c, epi);
-      if constexpr (EpiUses<EPI>::aux0) x0[t] = *reinterpret_cast<const f32x4_t*>(epi.aux0 + ic * epi.ld0 + jc);
-      else x0[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if constexpr (EPI == REC_EPI_ADD) {                    // aux0 may be absent (gemm_epi.h load_aux0)
+        x0[t] = epi.aux0 ? *reinterpret_cast<const f32x4_t*>(epi.aux0 + ic * epi.ld0 + jc) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      } else if constexpr (EpiUses<EPI>::aux0) {
+        x0[t] = *reinterpret_cast<const f32x4_t*>(epi.aux0 + ic * epi.ld0 + jc);
+      } else {
+        x0[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      if constexpr (EpiUses<EPI>::aux1) x1[t] = *reinterpret_cast<const f32x4_t*>(epi.aux1 + ic * epi.ld1 + jc);
     }
 #pragma unroll
-    for (int t = 0; t < kX3NT; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const int j = n_base + t * 16;
-      f32x4_t v;
+      f32x4_t v, u;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = apply_epi<EPI>(acc[a][t][c], x0[t][c], 0.f, bj[t][c], ic, epi);
-#ifdef REC_X3_NT_STORE
-      if (row_ok && j < N) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(C + i * ldc + j));
-#else
-      if (row_ok && j < N) *reinterpret_cast<f32x4_t*>(C + i * ldc + j) = v;
-#endif
+      for (int c = 0; c < 4; ++c) {
+        const float xx1 = EpiUses<EPI>::aux1 ? x1[EpiUses<EPI>::aux1 ? t : 0][c] : 0.f;
+        v[c] = apply_epi<EPI>(acc[a][t][c], x0[t][c], xx1, bj[t][c], ic, epi);
+        u[c] = acc[a][t][c] + bj[t][c];
+      }
+      if (row_ok && j < N) {
+        *reinterpret_cast<f32x4_t*>(C + i * ldc + j) = v;
+        if constexpr (EPI == REC_EPI_CROSS) {                // CROSS also stores u = acc + bias (saved for the backward)
+          if (epi.out2) *reinterpret_cast<f32x4_t*>(epi.out2 + i * epi.ld2 + j) = u;
+        }
+      }
     }
   }
 }
@@ -499,25 +541,26 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
 
 // host side -------------------------------------------------------------------------------------------------------
 inline int x3_launch_split(const float* W, int64_t ldw, int K, int N, int trans, char* img, hipStream_t st) {
-  const int nkt = (K + 31) / 32;
-  const int64_t thr = (int64_t)nkt * kX3NP * 4;
+  const X3Cols c = x3_cols(N);
+  const int nkt = (K + 31) / 32, np = 2 * c.nt * 16;
+  const int64_t thr = (int64_t)c.ncb * nkt * np * 4;
   hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)((thr + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, W, ldw, K, N,
-                     trans, img, nkt);
+                     trans, img, nkt, np, c.ncb);
   return check_launch("x3_split_kernel");
 }
 
 inline bool x3_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldc, const void* A, const void* C) {
-  return M > 0 && N > 0 && N <= kX3NP && N % 4 == 0 && K > 0 && K % 8 == 0 && lda % 4 == 0 && ldc % 4 == 0 &&
+  return M > 0 && N > 0 && x3_cols(N).nt > 0 && N % 4 == 0 && K > 0 && K % 8 == 0 && lda % 4 == 0 && ldc % 4 == 0 &&
          ((uintptr_t)A % 16) == 0 && ((uintptr_t)C % 16) == 0;
 }
 
-template <int EPI>
-inline int x3_launch_gemm_epi(int64_t M, int N, int K, const float* A, int64_t lda, const char* img, float* C, int64_t ldc,
-                              const EpiArgs& e, hipStream_t st) {
+template <int NT, int EPI>
+inline int x3_launch_gemm_cfg(int64_t M, int N, int K, const float* A, int64_t lda, const char* img, float* C, int64_t ldc,
+                              const EpiArgs& e, int ncb, hipStream_t st) {
   static bool attr_set = false;             // > 64 KB of dynamic LDS needs the attribute once per kernel
-  constexpr int lds = 2 * kX3Stage;
+  constexpr int lds = 2 * X3Geo<NT>::Stage;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<EPI>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<NT, EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       (void)hipGetLastError();
       set_error("gemm_bf16x3: %d B of dynamic LDS refused", lds);
@@ -525,9 +568,26 @@ inline int x3_launch_gemm_epi(int64_t M, int N, int K, const float* A, int64_t l
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI>), dim3((unsigned)((M + kX3BM - 1) / kX3BM)), dim3(256), lds, st, M, N, K, A,
-                     lda, img, C, ldc, e);
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<NT, EPI>), dim3((unsigned)((M + kX3BM - 1) / kX3BM), (unsigned)ncb), dim3(256), lds,
+                     st, M, N, K, A, lda, img, C, ldc, e);
   return check_launch("gemm_bf16x3_kernel");
+}
+
+template <int EPI>
+inline int x3_launch_gemm_epi(int64_t M, int N, int K, const float* A, int64_t lda, const char* img, float* C, int64_t ldc,
+                              const EpiArgs& e, hipStream_t st) {
+  const X3Cols c = x3_cols(N);
+  switch (c.nt) {
+    case 13: return x3_launch_gemm_cfg<13, EPI>(M, N, K, A, lda, img, C, ldc, e, c.ncb, st);
+    case 8: return x3_launch_gemm_cfg<8, EPI>(M, N, K, A, lda, img, C, ldc, e, c.ncb, st);
+    case 7: return x3_launch_gemm_cfg<7, EPI>(M, N, K, A, lda, img, C, ldc, e, c.ncb, st);
+    default: set_error("gemm_bf16x3: no column blocking for N = %d", N); return REC_ESHAPE;
+  }
+}
+
+inline bool x3_epilogue_ok(int epi) {
+  return epi == REC_EPI_NONE || epi == REC_EPI_BIAS || epi == REC_EPI_BIAS_RELU || epi == REC_EPI_RELU_MASK ||
+         epi == REC_EPI_CROSS || epi == REC_EPI_ADD;
 }
 
 inline int x3_launch_gemm(int epi, int64_t M, int N, int K, const float* A, int64_t lda, const char* img, float* C,
@@ -537,10 +597,11 @@ inline int x3_launch_gemm(int epi, int64_t M, int N, int K, const float* A, int6
     case REC_EPI_BIAS: return x3_launch_gemm_epi<REC_EPI_BIAS>(M, N, K, A, lda, img, C, ldc, e, st);
     case REC_EPI_BIAS_RELU: return x3_launch_gemm_epi<REC_EPI_BIAS_RELU>(M, N, K, A, lda, img, C, ldc, e, st);
     case REC_EPI_RELU_MASK: return x3_launch_gemm_epi<REC_EPI_RELU_MASK>(M, N, K, A, lda, img, C, ldc, e, st);
+    case REC_EPI_CROSS: return x3_launch_gemm_epi<REC_EPI_CROSS>(M, N, K, A, lda, img, C, ldc, e, st);
+    case REC_EPI_ADD: return x3_launch_gemm_epi<REC_EPI_ADD>(M, N, K, A, lda, img, C, ldc, e, st);
     default: set_error("gemm_bf16x3: epilogue %d not built", epi); return REC_EINVAL;
   }
 }
-
 
 // dW plan: output blocks of <= 13 x 13 tiles, as equal as they come; slices = one resident round of blocks
 struct X3DwPlan { int kb_tiles, nb_tiles, kblocks, nblocks, slices, steps_per_slice; };

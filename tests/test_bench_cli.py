@@ -55,7 +55,7 @@ def test_single_rank_line_and_contract_keys():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"].startswith("f32")
 
 
 def test_world_size_mismatch_is_refused():

@@ -326,7 +326,10 @@ def test_mlp_backward_head_path_matches_gemm_path(ops, monkeypatch):
 
 @pytest.mark.parametrize("M,N,K,tb,epi", [
     (8192, 400, 400, False, "bias_relu"), (8192, 400, 432, False, "bias_relu"), (8192, 400, 400, True, "relu_mask"),
-    (8200, 396, 104, False, "bias"), (9000, 416, 72, True, "none"), (8192, 336, 400, False, "none")])
+    (8200, 396, 104, False, "bias"), (9000, 416, 72, True, "none"), (8192, 368, 400, False, "none"),
+    # column blocks: 432 = two blocks of 14 tiles, 512 = two of 16, 1560 = four of 26; the CrossNet epilogues
+    (8192, 432, 400, True, "none"), (8192, 512, 200, False, "bias_relu"), (8192, 1560, 136, False, "cross"),
+    (8192, 1560, 72, True, "add"), (8320, 768, 1560, False, "bias_relu")])
 def test_gemm_bf16x3(ops, monkeypatch, M, N, K, tb, epi):
     """gemm_bf16x3.h (REC_GEMM_BF16X3=1): f32 operands split exactly into three bf16 terms, six bf16 MFMAs per product,
     f32 accumulate.  Same float64 bar as the exact-f32 kernels (4e-7 of sum |a||b| per output), rows behind a multiple of
@@ -336,8 +339,9 @@ def test_gemm_bf16x3(ops, monkeypatch, M, N, K, tb, epi):
     A, B, bias, X0 = _mk(rng, M, K), _mk(rng, K, N), _mk(rng, N), _mk(rng, M, N)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
     At, Bt = t(A), t(B.T if tb else B)
-    kw = dict(trans_b=tb, epilogue=epi, bias=t(bias) if epi.startswith("bias") else None,
-              aux0=t(X0) if epi == "relu_mask" else None)
+    X1 = _mk(rng, M, N)
+    kw = dict(trans_b=tb, epilogue=epi, bias=t(bias) if epi.startswith("bias") or epi in ("cross", "add") else None,
+              aux0=t(X0) if epi in ("relu_mask", "cross", "add") else None, aux1=t(X1) if epi in ("cross", "add") else None)
     monkeypatch.setenv("REC_GEMM_BF16X3", "0")
     C0 = ops.gemm(At, Bt, ops.Workspace(DEV), **kw).cpu().numpy()
     monkeypatch.setenv("REC_GEMM_BF16X3", "1")
@@ -352,6 +356,12 @@ def test_gemm_bf16x3(ops, monkeypatch, M, N, K, tb, epi):
         acc = np.maximum(acc, 0)
     if epi == "relu_mask":
         acc = np.where(X0 > 0, acc, 0)
+    if epi == "cross":                                       # dcn_v2/net.py:225: X_l + X_0 * (X_l W + b)
+        acc = X1 + X0.astype(np.float64) * (acc + bias)
+        bound = bound * np.abs(X0) + 2.4e-7 * (np.abs(acc) + np.abs(X1)) + 1e-7
+    if epi == "add":
+        acc = acc + bias + X1.astype(np.float64) + X0
+        bound = bound + 3.6e-7 * (np.abs(acc) + np.abs(X1) + np.abs(X0)) + 1e-7
     _check(C1, acc, bound)
     _check(C0, acc, bound)
     assert not np.array_equal(C0, C1), "REC_GEMM_BF16X3=1 did not select the bf16 x 3 kernel"

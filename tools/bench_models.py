@@ -55,6 +55,9 @@ def record(config, workload, ms, flops, samples, extra=None, hbm_bytes=None, byt
     tf = flops / ms / 1e9
     if hbm_bytes is None:
         roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_TF, "unit": "TFLOP/s", "frac": tf / PEAK_TF, "flops": flops}
+        if os.environ.get("REC_GEMM_BF16X3", "1") != "0":     # f32-equivalent flops against the exact-f32 MFMA peak
+            roof["note"] = ("tall GEMMs with N >= 368 run as bf16 x 3 (csrc/gemm_bf16x3.h: 6 bf16 MFMAs per f32 product, "
+                            "own peak 2500 / 6 = 417 TF-equivalent); peak here is the exact-f32 MFMA figure")
     else:
         gbs = hbm_bytes / ms / 1e6
         roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_GBS, "unit": "GB/s", "frac": gbs / PEAK_GBS,

@@ -10,7 +10,7 @@ namespace rec {
 void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 }
 #endif
-extern "C" size_t lab_x3_image_bytes(int K) { return x3_image_bytes(K); }
+extern "C" size_t lab_x3_image_bytes(int K, int N) { return x3_image_bytes(K, N); }
 extern "C" int lab_x3_split(const float* W, int64_t ldw, int K, int N, int trans, char* img, void* stream) {
   return x3_launch_split(W, ldw, K, N, trans, img, (hipStream_t)stream);
 }

@@ -17,7 +17,9 @@ from paddlerec_amd import ops  # noqa: E402
 EPI = {"none": 0, "bias": 1, "bias_relu": 2, "relu_mask": 3}
 SHAPES = [("fwd0", 65536, 400, 432, False, "bias_relu"), ("fwd1", 65536, 400, 400, False, "bias_relu"),
           ("dx1", 65536, 400, 400, True, "relu_mask"), ("dx0'", 65536, 400, 400, True, "none"),
-          ("edge", 1000, 396, 104, False, "bias"), ("small", 512, 400, 400, False, "bias_relu")]
+          ("dx0", 65536, 432, 400, True, "none"), ("dcn", 65536, 1560, 1560, False, "bias_relu"),
+          ("slot", 65536, 512, 3680, False, "bias_relu"), ("edge", 1000, 396, 104, False, "bias"),
+          ("small", 512, 400, 400, False, "bias_relu")]
 
 
 def main():
@@ -47,7 +49,7 @@ def main():
         C0, C1 = torch.zeros(M, N, device="cuda"), torch.full((M, N), 7.0, device="cuda")
         bias_ = bias if epi.startswith("bias") else None
         aux_ = X0 if epi == "relu_mask" else None
-        img = torch.zeros(lab.lab_x3_image_bytes(K), dtype=torch.uint8, device="cuda")
+        img = torch.zeros(lab.lab_x3_image_bytes(K, N), dtype=torch.uint8, device="cuda")
 
         def split():
             rc = lab.lab_x3_split(p(B), C.c_int64(B.stride(0)), K, N, int(tb), p(img), C.c_void_p(st))

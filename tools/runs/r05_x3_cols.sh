@@ -1,0 +1,16 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/x3; mkdir -p "$O"; cd "$R"
+timeout 500 python tools/gemm_lab/bf16x3_lab.py --rounds 2 --only "fwd1,dx0,dcn,slot" 2>&1 | grep -v amdgpu.ids | tee "$O/call7_cols_lab.txt"
+timeout 400 python -m pytest tests/test_gemm_gpu.py -q 2>&1 | tail -12 | tee "$O/test_gemm.txt"
+REC_GEMM_BF16X3=1 timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -12 | tee "$O/suite_x3_on.txt"
+for v in 1 0; do
+  echo "REC_GEMM_BF16X3=$v" | tee -a "$O/ab4.txt"
+  REC_GEMM_BF16X3=$v timeout 300 python bench.py --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('ms_per_step %.4f  value %.3fM  kernels_ms %s  mlp_gemm_tflops %.1f loss %s' % (d['ms_per_step'], d['value']/1e6, {k: round(v,3) for k,v in d['kernels_ms'].items()}, r.get('mlp_gemm_tflops',0), d['config'].get('loss')))" | tee -a "$O/ab4.txt"
+  REC_GEMM_BF16X3=$v timeout 400 python tools/bench_models.py 2>/dev/null | grep -E "^\{" | python -c "
+import json,sys
+for l in sys.stdin:
+    d=json.loads(l); print('   %-110s %8.3f ms' % (d.get('workload','')[:110], d.get('ms',0)))" | tee -a "$O/ab4.txt"
+done
