@@ -142,6 +142,10 @@ __device__ __forceinline__ void x3_read_frags_t(u32x4_t (&bf)[3], unsigned sb, u
   }
 }
 
+#ifndef REC_X3_DW_VALU_PER_MFMA
+#define REC_X3_DW_VALU_PER_MFMA 2      // conversion instructions laid behind every MFMA of the tiles that carry a patch column
+                                       // (a 16-cycle MFMA leaves one wave ~2 issue slots: 3 measured 162 us against 159)
+#endif
 #ifndef REC_X3_PRODUCTS
 #define REC_X3_PRODUCTS 6      // lab knob: 3 = a0 b0 + a0 b1 + a1 b0 only (~2^-14 of scale: NOT f32-grade), 1 = plain bf16
 #endif
@@ -353,6 +357,19 @@ __device__ __forceinline__ void x3_dw_read_u(u32x4_t (&f)[3], unsigned base, int
   }
 }
 
+// wait until at most `left` LDS reads are outstanding (a compile-time constant after unrolling), tied to the fragments
+// that must have landed
+__device__ __forceinline__ void x3_dw_wait_frags(u32x4_t (&f)[3], int left) {
+#define REC_X3_WAIT_CASE(N) case N: asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2])); break;
+  switch (left) {
+    REC_X3_WAIT_CASE(0) REC_X3_WAIT_CASE(1) REC_X3_WAIT_CASE(2) REC_X3_WAIT_CASE(3) REC_X3_WAIT_CASE(4) REC_X3_WAIT_CASE(5)
+    REC_X3_WAIT_CASE(6) REC_X3_WAIT_CASE(7) REC_X3_WAIT_CASE(8) REC_X3_WAIT_CASE(9) REC_X3_WAIT_CASE(10) REC_X3_WAIT_CASE(11)
+    REC_X3_WAIT_CASE(12) REC_X3_WAIT_CASE(13) REC_X3_WAIT_CASE(14) REC_X3_WAIT_CASE(15)
+    default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2])); break;
+  }
+#undef REC_X3_WAIT_CASE
+}
+
 struct X3DwArgs {
   const float* X; int64_t ldx;      // [rows, Kin]
   const float* G; int64_t ldg;      // [rows, Nout]
@@ -402,6 +419,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
   const float* gp = w.G + (row0 + mg * 8) * w.ldg + (g_ok ? gc : 0);
   float4 xr[8], gr[8];
   auto load_patches = [&](int kt) {
+#ifdef REC_X3_DW_NO_LOADS      // lab: the k-loop without its global loads (the step-0 registers are converted every step)
+    if (kt > 0) return;
+#endif
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       xr[r] = *reinterpret_cast<const float4*>(xp + ((int64_t)kt * 32 + r) * w.ldx);
@@ -416,43 +436,54 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
     wr_off[e] = (unsigned)((mg * kX3DwCols + 16 * a + x3_dw_q(i, a)) * 16);
   }
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto convert_store = [&](int stage) {
-    char* sx = x3_smem + stage * kX3Stage;
-    char* sg = sx + kX3DwOperand;
+  // Branch-free stores: a thread without a patch (tid >= 208) writes its chunks to a 16-B slot of its own behind the
+  // two stages (the 4 KB that are left of the 160), so that the conversion is straight-line code the scheduler can lay
+  // between the MFMAs of a tile.
+  const unsigned w_stage = stager ? (unsigned)kX3Stage : 0u, w_oper = stager ? (unsigned)kX3DwOperand : 0u,
+                 w_plane = stager ? (unsigned)kX3DwPlane : 0u;
+  char* const w_base = stager ? x3_smem : x3_smem + 2 * kX3Stage + tid * 16;
+  if (!stager) { wr_off[0] = wr_off[1] = wr_off[2] = wr_off[3] = 0u; }
+  auto convert_part = [&](int stage, int e) {                 // column e of this thread's X and G patches
+    char* sx = w_base + stage * w_stage + wr_off[e];
+    char* sg = sx + w_oper;
+    float xv[8], gv[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      u32x4_t p0, p1, p2;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const float v0 = e == 0 ? xr[2 * d].x : e == 1 ? xr[2 * d].y : e == 2 ? xr[2 * d].z : xr[2 * d].w;
-        const float v1 = e == 0 ? xr[2 * d + 1].x : e == 1 ? xr[2 * d + 1].y : e == 2 ? xr[2 * d + 1].z : xr[2 * d + 1].w;
-        unsigned a, b, c;
-        x3_split_pair(x_ok ? v0 : 0.f, x_ok ? v1 : 0.f, a, b, c);
-        p0[d] = a; p1[d] = b; p2[d] = c;
-      }
-      if (stager) {
-        *reinterpret_cast<u32x4_t*>(sx + wr_off[e]) = p0;
-        *reinterpret_cast<u32x4_t*>(sx + kX3DwPlane + wr_off[e]) = p1;
-        *reinterpret_cast<u32x4_t*>(sx + 2 * kX3DwPlane + wr_off[e]) = p2;
-      }
-      float cs = 0.f;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const float v0 = e == 0 ? gr[2 * d].x : e == 1 ? gr[2 * d].y : e == 2 ? gr[2 * d].z : gr[2 * d].w;
-        const float v1 = e == 0 ? gr[2 * d + 1].x : e == 1 ? gr[2 * d + 1].y : e == 2 ? gr[2 * d + 1].z : gr[2 * d + 1].w;
-        const float u0 = g_ok ? v0 : 0.f, u1 = g_ok ? v1 : 0.f;
-        cs += u0 + u1;
-        unsigned a, b, c;
-        x3_split_pair(u0, u1, a, b, c);
-        p0[d] = a; p1[d] = b; p2[d] = c;
-      }
-      if (e == 0) csum.x += cs; else if (e == 1) csum.y += cs; else if (e == 2) csum.z += cs; else csum.w += cs;
-      if (stager) {
-        *reinterpret_cast<u32x4_t*>(sg + wr_off[e]) = p0;
-        *reinterpret_cast<u32x4_t*>(sg + kX3DwPlane + wr_off[e]) = p1;
-        *reinterpret_cast<u32x4_t*>(sg + 2 * kX3DwPlane + wr_off[e]) = p2;
-      }
+    for (int r = 0; r < 8; ++r) {
+      xv[r] = e == 0 ? xr[r].x : e == 1 ? xr[r].y : e == 2 ? xr[r].z : xr[r].w;
+      gv[r] = e == 0 ? gr[r].x : e == 1 ? gr[r].y : e == 2 ? gr[r].z : gr[r].w;
     }
+    // the values pass through an empty volatile asm: pure arithmetic on registers loaded at the top of the k-step is
+    // otherwise scheduled right behind those loads (in front of every MFMA of the step, waiting for the loads) whatever
+    // the source order says
+    asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]),
+                      "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]), "+v"(gv[4]), "+v"(gv[5]), "+v"(gv[6]), "+v"(gv[7]));
+    u32x4_t p0, p1, p2;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      unsigned a, b, c;
+      x3_split_pair(x_ok ? xv[2 * d] : 0.f, x_ok ? xv[2 * d + 1] : 0.f, a, b, c);
+      p0[d] = a; p1[d] = b; p2[d] = c;
+    }
+    *reinterpret_cast<u32x4_t*>(sx) = p0;
+    *reinterpret_cast<u32x4_t*>(sx + w_plane) = p1;
+    *reinterpret_cast<u32x4_t*>(sx + 2 * w_plane) = p2;
+    float cs = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const float u0 = g_ok ? gv[2 * d] : 0.f, u1 = g_ok ? gv[2 * d + 1] : 0.f;
+      cs += u0 + u1;
+      unsigned a, b, c;
+      x3_split_pair(u0, u1, a, b, c);
+      p0[d] = a; p1[d] = b; p2[d] = c;
+    }
+    if (e == 0) csum.x += cs; else if (e == 1) csum.y += cs; else if (e == 2) csum.z += cs; else csum.w += cs;
+    *reinterpret_cast<u32x4_t*>(sg) = p0;
+    *reinterpret_cast<u32x4_t*>(sg + w_plane) = p1;
+    *reinterpret_cast<u32x4_t*>(sg + 2 * w_plane) = p2;
+  };
+  auto convert_store = [&](int stage) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) convert_part(stage, e);
   };
 
   f32x4_t acc[PW][kX3DwWT];
@@ -478,19 +509,45 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
   }
   __syncthreads();
 
-  for (int kt = 0; kt < nsteps; ++kt) {
+  // One k-step.  MORE: there is a next step — its patches are loaded at the top and converted / written to the other stage
+  // IN the MFMA stream of tiles 3 .. 6, one patch column per tile (sched_group_barrier: one MFMA, two VALU, ... — the
+  // conversion's ~85 VALU instructions per column ride in the shadow of the tile's 6 PW MFMAs instead of following them).
+  auto step = [&](int kt, auto more_c) {
+    constexpr bool MORE = decltype(more_c)::value;
     const int stage = kt & 1;
-    if (kt + 1 < nsteps) load_patches(kt + 1);
+    if (MORE) load_patches(kt + 1);
     __builtin_amdgcn_sched_barrier(0);
     const unsigned so = stage * kX3Stage;
     // this wave's X fragments (the MFMA's second operand: Kin becomes the accumulator's lane index)
+    // Fragment reads in the order of their first use: G tile 0, then the X tiles one by one, then G tile 1.  Tile 0 runs
+    // row tile by row tile behind counted waits (its first MFMAs need 6 of the 3 PW + 6 reads, not all of them);
+    // from tile 1 on the products run across the row tiles as in the forward kernel.
     u32x4_t af[PW][3];
-#pragma unroll
-    for (int u = 0; u < PW; ++u) x3_dw_read_u(af[u], xb[u & 3] + so, u);
     u32x4_t bf[2][3];
     x3_dw_read_u(bf[0], gb[0] + so, 0);
 #pragma unroll
-    for (int t = 0; t < kX3DwWT; ++t) {
+    for (int u = 0; u < PW; ++u) x3_dw_read_u(af[u], xb[u & 3] + so, u);
+    x3_dw_read_u(bf[1], gb[1] + so, 1);
+#pragma unroll
+    for (int a = 0; a < PW; ++a) {                          // tile 0: reads still outstanding behind X tile a: 3 (PW - 1 - a) + 3
+      x3_dw_wait_frags(af[a], 3 * (PW - 1 - a) + 3);
+      const u32x4_t* b0 = bf[0];
+#define REC_X3_DW_MFMA0(PB, PA)                                                                                \
+  acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b0[PB]),                      \
+                                                      __builtin_bit_cast(bf16x8_t, af[a][PA]), acc[a][0], 0, 0, 0);
+#if REC_X3_PRODUCTS >= 6
+      REC_X3_DW_MFMA0(2, 0) REC_X3_DW_MFMA0(1, 1) REC_X3_DW_MFMA0(0, 2)
+#endif
+#if REC_X3_PRODUCTS >= 3
+      REC_X3_DW_MFMA0(1, 0) REC_X3_DW_MFMA0(0, 1)
+#endif
+      REC_X3_DW_MFMA0(0, 0)
+#undef REC_X3_DW_MFMA0
+      __builtin_amdgcn_sched_barrier(0);                    // (the MFMAs of row tile a stay in front of the next wait)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < kX3DwWT; ++t) {
       if (t + 1 < kX3DwWT) {
         x3_dw_read_u(bf[(t + 1) & 1], gb[(t + 1) & 3] + so, t + 1);
         asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bf[t & 1][0]), "+v"(bf[t & 1][1]), "+v"(bf[t & 1][2]));
@@ -501,14 +558,35 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
 #define REC_X3_DW_MFMA(PB, PA)                                                                                 \
   _Pragma("unroll") for (int a = 0; a < PW; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(            \
       __builtin_bit_cast(bf16x8_t, b[PB]), __builtin_bit_cast(bf16x8_t, af[a][PA]), acc[a][t], 0, 0, 0);
+#if REC_X3_PRODUCTS >= 6
       REC_X3_DW_MFMA(2, 0) REC_X3_DW_MFMA(1, 1) REC_X3_DW_MFMA(0, 2)
-      REC_X3_DW_MFMA(1, 0) REC_X3_DW_MFMA(0, 1) REC_X3_DW_MFMA(0, 0)
+#endif
+#if REC_X3_PRODUCTS >= 3
+      REC_X3_DW_MFMA(1, 0) REC_X3_DW_MFMA(0, 1)
+#endif
+      REC_X3_DW_MFMA(0, 0)
 #undef REC_X3_DW_MFMA
+#ifndef REC_X3_DW_SERIAL_CONVERT
+      if (MORE && t >= kX3DwWT - 4) {
+        convert_part(stage ^ 1, t - (kX3DwWT - 4));
+#pragma unroll
+        for (int i = 0; i < 6 * PW; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, REC_X3_DW_VALU_PER_MFMA, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);       // what is left of the conversion
+        __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);        // the column's six ds_write_b128
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (kt + 1 < nsteps) convert_store(stage ^ 1);      // the other stage: nobody reads it since the last barrier
+#ifdef REC_X3_DW_SERIAL_CONVERT
+    if (MORE) convert_store(stage ^ 1);                 // the other stage: nobody reads it since the last barrier
+#endif
     __syncthreads();
-  }
+  };
+  for (int kt = 0; kt + 1 < nsteps; ++kt) step(kt, std::true_type{});
+  if (nsteps > 0) step(nsteps - 1, std::false_type{});
 
   // ---- partial tile: lane (i, g) holds P[Kin = tile a, row i][Nout = tile t, columns 4g .. 4g+3]
   float* P = w.P + (int64_t)slice * w.kin * w.ldp;
@@ -526,7 +604,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
   // ---- column sums of G's slice: the four m-groups of a column group meet in LDS (every stage is free now)
   if (w.cpart && kb == 0) {
     float4* red = reinterpret_cast<float4*>(x3_smem);
-    if (stager) red[mg * (kX3DwCols / 4) + cg] = csum;
+    if (stager) red[(tid / (kX3DwCols / 4)) * (kX3DwCols / 4) + cg] = csum;
     __syncthreads();
     if (tid < kX3DwCols / 4 && tid * 4 < nt_blk * 16 && n_tile0 * 16 + tid * 4 < w.nout) {
       const float4 s0 = red[tid], s1 = red[kX3DwCols / 4 + tid], s2 = red[2 * (kX3DwCols / 4) + tid],
@@ -624,7 +702,7 @@ inline bool x3_dw_plan(int kin, int nout, int64_t rows, int cus, X3DwPlan* p) {
 inline int x3_launch_dw(const X3DwPlan& pl, int kin, int nout, int64_t rows, const float* X, int64_t ldx, const float* G,
                         int64_t ldg, float* P, int64_t ldp, float* cpart, hipStream_t st) {
   static bool attr_set = false;
-  constexpr int lds = 2 * kX3Stage;
+  constexpr int lds = 2 * kX3Stage + 4096;        // + a 16-B slot per thread for the patch-less threads' stores
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dw_kernel<7>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||

@@ -865,10 +865,11 @@ static void launch_reduce(const rec_gemm_desc* d, const GemmPlan& p, const float
 // engine's split-K reduce in ascending slice order (deterministic).
 static bool x3_dw_eligible(const rec_gemm_desc* d, X3DwPlan* pl) {
   // an explicit K split is a caller's request for few, long blocks that leave wave slots to a kernel running beside the
-  // GEMM (the deferred dW_0 under the sparse update): this kernel owns every SIMD's register file, so it only takes those
-  // calls on request (REC_GEMM_BF16X3=2)
+  // GEMM (the deferred dW_0 under the sparse update).  This kernel owns every SIMD's register file, so the two take turns
+  // instead — and the step is still 30 us shorter (1.76 -> 1.73 ms, profiles/r05_bf16x3.txt); REC_GEMM_BF16X3=1 leaves
+  // those calls on the exact-f32 kernel
   const char* v = getenv("REC_GEMM_BF16X3");
-  const bool forced = v && *v == '2';
+  const bool forced = !(v && *v == '1');
   const char* vd = getenv("REC_GEMM_BF16X3_DW");           // 0: forward / dX only (A/B runs)
   if (vd && *vd == '0') return false;
   if (!x3_enabled() || !d->trans_a || d->trans_b || (d->split_k != 0 && !forced) || d->epilogue != REC_EPI_NONE) return false;

@@ -20,3 +20,12 @@ extern "C" int lab_x3_gemm(int64_t M, int N, int K, const float* A, int64_t lda,
   EpiArgs e{bias, aux0, nullptr, nullptr, nullptr, ld0, 0, 0, 0, 0};
   return x3_launch_gemm(epi, M, N, K, A, lda, img, C, ldc, e, (hipStream_t)stream);
 }
+
+// the weight-gradient kernel alone (no reduce): partial tiles into `P` ([slices][kin][ldp]), column sums into cpart
+extern "C" int lab_x3_dw(int kin, int nout, int64_t rows, const float* X, int64_t ldx, const float* G, int64_t ldg, float* P,
+                         int64_t ldp, float* cpart, int* slices_out, void* stream) {
+  X3DwPlan pl;
+  if (!x3_dw_plan(kin, nout, rows, 256, &pl)) return -1;
+  if (slices_out) *slices_out = pl.slices;
+  return x3_launch_dw(pl, kin, nout, rows, X, ldx, G, ldg, P, ldp, cpart, (hipStream_t)stream);
+}

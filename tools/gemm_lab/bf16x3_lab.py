@@ -131,7 +131,47 @@ def dw_main(args):
                  float(((cs["1"] - cref).abs() / G.double().abs().sum(0)).max()), not torch.equal(out["0"], out["1"])), flush=True)
 
 
+def dwk_main(args):
+    """the weight-gradient KERNEL alone in a lab build (--lib): where its time goes (products 1, no loads)"""
+    lab = C.CDLL(args.lib)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    rnd = lambda *s: torch.rand(*s, device="cuda", generator=g) - 0.5
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for name, rows, kin, nout in (("dw1", 65536, 400, 400), ("dw0", 65536, 432, 400)):
+        X, G = rnd(rows, kin), rnd(rows, nout)
+        P = torch.zeros(64, kin, nout, device="cuda")
+        cp = torch.zeros(64, nout, device="cuda")
+        sl = C.c_int(0)
+        fn = lambda: lab.lab_x3_dw(kin, nout, C.c_int64(rows), p(X), C.c_int64(kin), p(G), C.c_int64(nout), p(P), C.c_int64(nout),
+                                   p(cp), C.byref(sl), C.c_void_p(st))
+        assert fn() == 0
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(args.rounds):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _i in range(args.iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b) / args.iters * 1e3)
+        ref = X.double().t() @ G.double()
+        got = P[: sl.value].double().sum(0)
+        err = float(((got - ref).abs() / (X.double().abs().t() @ G.double().abs())).max())
+        print("%-4s kernel alone %6.1f us  (%d slices)  max err / sum|a||b| %.2e   [%s]" % (name, best, sl.value, err, os.path.basename(args.lib)),
+              flush=True)
+
+
 if __name__ == "__main__":
+    if "--dwk" in sys.argv:
+        sys.argv.remove("--dwk")
+        ap = argparse.ArgumentParser()
+        ap.add_argument("--iters", type=int, default=20)
+        ap.add_argument("--rounds", type=int, default=2)
+        ap.add_argument("--lib", default=os.path.join(HERE, "_build", "libx3lab.so"))
+        dwk_main(ap.parse_args())
+        sys.exit(0)
     if "--dw" in sys.argv:
         sys.argv.remove("--dw")
         ap = argparse.ArgumentParser()
