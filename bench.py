@@ -104,6 +104,33 @@ def make_batches(n, B, S, Dn, rows_per_table, device, seed, dist="uniform"):
     return out
 
 
+def gemm_accuracy(dev):
+    """The bf16 x 3 GEMM and the exact-f32 MFMA GEMM on ONE MLP-layer problem of the bench's shape (8192 rows of it),
+    both against a float64 product of the same f32 inputs — measured in this run so that the line carries the evidence for
+    its `dtype`: max |C - C64| / sum_k |a||b| per output (the scale f32 round-off lives on).  Not part of the timed region."""
+    from paddlerec_amd import ops
+    g = torch.Generator(device=dev).manual_seed(7)
+    M, K, N = 8192, 400, 400
+    A = torch.rand(M, K, device=dev, generator=g) - 0.5
+    W = (torch.rand(K, N, device=dev, generator=g) - 0.5) * 0.1
+    bias = torch.rand(N, device=dev, generator=g) - 0.5
+    ref = torch.relu(A.double() @ W.double() + bias.double())
+    mag = A.double().abs() @ W.double().abs() + bias.double().abs()
+    out, keep = {}, os.environ.get("REC_GEMM_BF16X3")
+    try:
+        for name, v in (("bf16x3", "1"), ("exact_f32", "0")):
+            os.environ["REC_GEMM_BF16X3"] = v
+            C_ = ops.gemm(A, W, ops.Workspace(dev), epilogue="bias_relu", bias=bias)
+            out[name] = float(((C_.double() - ref).abs() / mag).max())
+    finally:
+        if keep is None:
+            os.environ.pop("REC_GEMM_BF16X3", None)
+        else:
+            os.environ["REC_GEMM_BF16X3"] = keep
+    out["problem"] = "relu(A[8192,400] @ W[400,400] + b), uniform operands; max |C - C_float64| / (sum_k |a||w| + |b|)"
+    return out
+
+
 def cpu_baseline(B, S, Dn, D, fc, rows_per_table, budget_s=20.0):
     """Times the ORACLE (C restatement for embedding+FM+sparse Adam, NumPy GEMMs for the MLP) on this
     host's cores, on a bounded sample of the same workload: whole steps of batch B until ~budget_s."""
@@ -730,6 +757,11 @@ def main():
                      "f32_mfma_peak": FP32_MFMA_PEAK_TF, "vs_f32_mfma_peak": gemm_tf / FP32_MFMA_PEAK_TF,
                      "flops_executed_per_step": 3 * mlp_flops(B, sizes)},
     }
+    if rank == 0 and not standin and dev.type == "cuda":
+        try:
+            out["mlp_gemm"]["error_vs_float64"] = gemm_accuracy(dev)
+        except Exception as e:
+            out["mlp_gemm"]["error_vs_float64"] = {"error": repr(e)[:200]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
