@@ -676,8 +676,9 @@ def main():
         "scaling": "weak", "vs_baseline": None,
         # f32 storage, f32 accumulation everywhere.  The tall MLP GEMMs (forward, dX, dW of the 400-wide layers) multiply
         # on the bf16 matrix pipe: each f32 operand is split into three bf16 terms (x = x0 + x1 + x2 to 2^-25 |x|) and six
-        # of the nine term products are accumulated in f32 — error against float64 no larger than the exact-f32 MFMA
-        # kernels' (tests/test_gemm_gpu.py::test_gemm_bf16x3*); REC_GEMM_BF16X3=0 = those kernels (other_configs)
+        # of the nine term products are accumulated in f32 — error against float64 of the order of the exact-f32 MFMA
+        # kernels' (1-4e-7 of sum |a||b| either way: mlp_gemm.error_vs_float64 of this line, tests/test_gemm_gpu.py::
+        # test_gemm_bf16x3*); REC_GEMM_BF16X3=0 = those kernels (other_configs)
         "dtype": "f32 (MLP GEMMs: f32 operands as 3 bf16 terms, 6 bf16 MFMAs per product, f32 accumulate)" if X3_ON
         else "f32",
         "data": "synthetic" if not standin else "cpu-standin (REC_BENCH_STANDIN=1: host-logic test of this file's "
@@ -752,7 +753,7 @@ def main():
         "mlp_gemm": {"bound": "mfma", "achieved": gemm_tf,
                      "peak": BF16_MFMA_PEAK_TF / 6 if X3_ON else FP32_MFMA_PEAK_TF, "unit": "TFLOP/s (f32-equivalent)",
                      "frac": gemm_tf / (BF16_MFMA_PEAK_TF / 6 if X3_ON else FP32_MFMA_PEAK_TF),
-                     "arithmetic": "bf16x3 (fwd, dX, dW of the 400-wide layers; dW_0 beside the sparse update stays exact f32)"
+                     "arithmetic": "bf16x3 (forward, dX and dW GEMMs of the tower; REC_GEMM_BF16X3=0: exact f32 MFMA)"
                      if X3_ON else "exact f32 MFMA",
                      "f32_mfma_peak": FP32_MFMA_PEAK_TF, "vs_f32_mfma_peak": gemm_tf / FP32_MFMA_PEAK_TF,
                      "flops_executed_per_step": 3 * mlp_flops(B, sizes)},
