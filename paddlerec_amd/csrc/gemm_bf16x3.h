@@ -1,28 +1,32 @@
-// f32 GEMM on the bf16 matrix pipe: every f32 operand is split into three bf16 terms (x = x0 + x1 + x2 to 2^-25 |x|, each
-// the round-to-nearest bf16 of the running remainder: 8 + 8 + 8 significand bits = the whole f32 significand) and the
-// product is accumulated in f32 from the six term products with i + j <= 2 (a0 b0, a0 b1, a1 b0, a0 b2, a1 b1, a2 b0) —
-// what is dropped (a1 b2, a2 b1, a2 b2) is below 2^-24 |a b| per product: the result is as close to the float64 product
-// as the exact-f32 kernels' (tests/test_gemm_gpu.py::test_gemm_bf16x3: the same 4e-7 of sum |a||b| bound).  Six v_mfma_f32_16x16x32_bf16 per K 32 are 96 matrix-pipe cycles where
-// eight v_mfma_f32_16x16x4_f32 are 256 (the "bf16 x 3" form).  OPT-IN (REC_GEMM_BF16X3): the results
-// are f32-grade but not the bit pattern of an f32 fma chain, so the exact-f32 kernels stay the default.
+// f32 GEMM on the bf16 matrix pipe (the towers' tall GEMMs: deepfm/net.py:142-174, dcn_v2/net.py:140-184,214-226,
+// slot_dnn/net.py:77-84 and their backward).  Every f32 operand is split into three bf16 terms (x = x0 + x1 + x2 to
+// 2^-25 |x|, each the round-to-nearest bf16 of the running remainder: 8 + 8 + 8 significand bits = the whole f32
+// significand) and the product is accumulated in f32 from the six term products with i + j <= 2 (a0 b0, a0 b1, a1 b0,
+// a0 b2, a1 b1, a2 b0) — what is dropped (a1 b2, a2 b1, a2 b2) is below 2^-24 |a b| per product.  Against float64 the
+// results carry the error of the exact-f32 kernels (1-4e-7 of sum |a||b| either way: the MFMA's f32 accumulation sets
+// it, tests/test_gemm_gpu.py::test_gemm_bf16x3*, tests/test_bf16x3_split.py, profiles/r05_bf16x3.txt); they are f32-grade
+// but not the bit pattern of an f32 fma chain, hence the switch: REC_GEMM_BF16X3=0 selects the exact-f32 MFMA kernels.
+// Six v_mfma_f32_16x16x32_bf16 per K 32 are 96 matrix-pipe cycles where eight v_mfma_f32_16x16x4_f32 are 256
+// (the "bf16 x 3" form): 1.4-1.5x in time on the 65 536 x 400 x 400 problems.
 //
-//   C[M,N] = epi(A[M,K] @ W'),   A f32 row-major (k contiguous, lda);   W' given as a pre-split IMAGE (x3_split_kernel)
-//
-// The weight (400 x 400: ~1 MB of planes, L2-resident) is split once per step by x3_split_kernel into the exact LDS
+// (1) forward / dX form:  C[M,N] = epi(A[M,K] @ W'),  A f32 row-major (k contiguous, lda), W' a pre-split IMAGE
+// The weight (400 x 400: ~1 MB of planes, L2-resident) is split once per call by x3_split_kernel into the exact LDS
 // image of every k-step; the activation operand is split in registers by the wave that multiplies it:
-//   * block = 4 waves as 2 (M) x 2 (N), block tile 128 rows x 416 columns (N <= 416: ONE column block, so every A
-//     element is converted by the two waves that share its rows and by nobody else); wave tile 64 x 208 = 4 x 13 MFMA
-//     tiles, 208 accumulator registers: one wave per SIMD, one block per CU;
+//   * block = 4 waves as 2 (M) x 2 (N), block tile 128 rows x one COLUMN BLOCK of 2 NT MFMA tiles (NT 13 / 8 / 7 per
+//     wave: N 400 -> one block of 416 columns, 432 -> two of 224, 512 -> two of 256, 1560 -> four of 416); at NT 13 the
+//     wave tile is 64 x 208 = 4 x 13 MFMA tiles, 208 accumulator registers: one wave per SIMD, one block per CU;
 //   * A: a lane's fragment of v_mfma_f32_16x16x32_bf16 is 8 consecutive k of one row = 32 contiguous bytes of f32:
 //     loaded global -> registers (a wave instruction covers 16 rows x one full 128-B line each), one k-step ahead, and
 //     split there (4.5 VALU instructions per element: v_cvt_pk_bf16_f32, shift / mask, v_pk_add_f32) — no LDS traffic for A;
-//   * W': k-step image [plane 3][n 416][4 chunks of 8 k] bf16, chunk c of row n stored at slot c ^ f(n % 16),
-//     f = {0,3,2,1}[i / 4] (the swizzle of gemm_glds.h: one conflict-free ds_read_b128 per fragment), 78 KB per k-step,
-//     two stages = 156 of the 160 KB; filled by LDS-DMA (global_load_lds_dwordx4: the global image IS the LDS image, so
-//     the copy is lane-linear), one k-step ahead, one barrier per k-step;
+//   * W': k-step image [plane 3][n NP][4 chunks of 8 k] bf16, chunk c of row n stored at slot c ^ f(n % 16),
+//     f = {0,3,2,1}[i / 4] (the swizzle of gemm_glds.h: one conflict-free ds_read_b128 per fragment), 78 KB per k-step
+//     at NT 13, two stages = 156 of the 160 KB; filled by LDS-DMA (global_load_lds_dwordx4: the global image IS the LDS
+//     image, so the copy is lane-linear), one k-step ahead, one barrier per k-step;
 //   * MFMAs with the operands swapped (W' fragment first) as in gemm_glds.h: lane (i, g) ends up with
 //     C[row i][columns 4g .. 4g+3] of a tile -> float4 stores, float4 bias / aux loads.
-// Shapes: K % 8 == 0 (a lane's 8-k chunk is inside or outside K as a whole), N % 4 == 0, N <= 416, rows 16-B aligned.
+// Shapes: K % 8 == 0 (a lane's 8-k chunk is inside or outside K as a whole), N % 4 == 0, rows 16-B aligned, M >= 8192
+// (the caller's rule: short problems do not fill the chip with 128-row blocks).
+// (2) weight-gradient form (gemm_bf16x3_dw_kernel): further down.
 #pragma once
 
 #include "gemm_epi.h"
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void x3_split_kernel(const float* __restric
   *reinterpret_cast<u32x4_t*>(dst + 2 * plane) = p2;
 }
 
-// one tile's three plane fragments (ds_read_b128, offset = tile * 1024 + plane * kX3PlaneBytes; plane 2 through a second
+// one tile's three plane fragments (ds_read_b128, offset = tile * 1024 + plane * PLANE; plane 2 through a second
 // base because 2 * 26 624 + 12 * 1024 does not fit the 16-bit offset field)
 template <int T, int PLANE>
 __device__ __forceinline__ void x3_read_frags(u32x4_t (&bf)[3], unsigned sb, unsigned sb2) {
