@@ -12,9 +12,11 @@
 // (1) forward / dX form:  C[M,N] = epi(A[M,K] @ W'),  A f32 row-major (k contiguous, lda), W' a pre-split IMAGE
 // The weight (400 x 400: ~1 MB of planes, L2-resident) is split once per call by x3_split_kernel into the exact LDS
 // image of every k-step; the activation operand is split in registers by the wave that multiplies it:
-//   * block = 4 waves as 2 (M) x 2 (N), block tile 128 rows x one COLUMN BLOCK of 2 NT MFMA tiles (NT 13 / 8 / 7 per
-//     wave: N 400 -> one block of 416 columns, 432 -> two of 224, 512 -> two of 256, 1560 -> four of 416); at NT 13 the
-//     wave tile is 64 x 208 = 4 x 13 MFMA tiles, 208 accumulator registers: one wave per SIMD, one block per CU;
+//   * block tile 128 rows x one COLUMN BLOCK of 2 NT MFMA tiles (NT 13 / 8 / 7 per wave: N 400 -> one block of 416
+//     columns, 432 -> two of 224, 512 -> two of 256, 1560 -> four of 416), one block per CU (LDS); 8 waves as 4 (M) x 2 (N),
+//     wave tile 32 x 208 = 2 x 13 MFMA tiles, 104 accumulator registers, TWO waves per SIMD (a wave's conversion and
+//     waits run beside its partner's MFMAs: 7-8 % over the four-wave form with 64-row wave tiles, which the CrossNet
+//     epilogues keep for their registers);
 //   * A: a lane's fragment of v_mfma_f32_16x16x32_bf16 is 8 consecutive k of one row = 32 contiguous bytes of f32:
 //     loaded global -> registers (a wave instruction covers 16 rows x one full 128-B line each), one k-step ahead, and
 //     split there (4.5 VALU instructions per element: v_cvt_pk_bf16_f32, shift / mask, v_pk_add_f32) — no LDS traffic for A;
@@ -154,36 +156,40 @@ __device__ __forceinline__ void x3_read_frags_t(u32x4_t (&bf)[3], unsigned sb, u
 #define REC_X3_PRODUCTS 6      // lab knob: 3 = a0 b0 + a0 b1 + a1 b0 only (~2^-14 of scale: NOT f32-grade), 1 = plain bf16
 #endif
 
-template <int NT, int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int64_t M, int N, int K, const float* __restrict__ A, int64_t lda,
+// WM = waves along M (2: four waves, one per SIMD, 64-row wave tiles; 4: EIGHT waves, two per SIMD, 32-row wave tiles —
+// a wave's conversion / waits sit beside its SIMD partner's MFMAs, at twice the W' fragment reads per MFMA).
+template <int NT, int EPI, int WM>
+__global__ __launch_bounds__(WM * 2 * 64) void gemm_bf16x3_kernel(int64_t M, int N, int K, const float* __restrict__ A, int64_t lda,
                                                           const char* __restrict__ Bimg_all, float* __restrict__ C,
                                                           int64_t ldc, EpiArgs epi) {
   using Geo = X3Geo<NT>;
+  constexpr int MT = kX3BM / 16 / WM;                         // MFMA row tiles per wave
+  constexpr int NW = WM * 2;                                  // waves per block
   extern __shared__ __attribute__((aligned(1024))) char x3_smem[];
   const int lane = threadIdx.x % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int li = lane & 15, g = lane >> 4;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WM, wn = wave / WM;
   const int nkt = (K + 31) / 32;
-  const int64_t m0 = (int64_t)blockIdx.x * kX3BM + wm * (kX3MT * 16);
+  const int64_t m0 = (int64_t)blockIdx.x * kX3BM + wm * (MT * 16);
   const int cb = blockIdx.y;                                  // column block: columns cb * NP ..
   const char* Bimg = Bimg_all + (size_t)cb * nkt * Geo::Stage;
 
   // ---- A: per-lane row pointers (rows behind M re-read row M-1: finite data, never stored)
-  const float* ap[kX3MT];
+  const float* ap[MT];
 #pragma unroll
-  for (int a = 0; a < kX3MT; ++a) {
+  for (int a = 0; a < MT; ++a) {
     int64_t r = m0 + a * 16 + li;
     r = r < M ? r : M - 1;
     ap[a] = A + r * lda + g * 8;
   }
-  float4 araw[kX3MT][2];
+  float4 araw[MT][2];
   // a chunk behind K (only in the last k-step, K % 32 != 0) is read from the row's first chunk instead and zeroed when
   // it is CONVERTED, a k-step later: a select right behind the load would park the wave until the load returns
   auto load_a = [&](int kt) {
     const int koff = kt * 32 + g * 8 < K ? kt * 32 : 0;      // K % 8 == 0: the lane's chunk is in or out as a whole
 #pragma unroll
-    for (int a = 0; a < kX3MT; ++a) {
+    for (int a = 0; a < MT; ++a) {
       araw[a][0] = *reinterpret_cast<const float4*>(ap[a] + koff);
       araw[a][1] = *reinterpret_cast<const float4*>(ap[a] + koff + 4);
     }
@@ -193,16 +199,16 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int64_t M, int N, int 
     const char* src = Bimg + (size_t)kt * Geo::Stage + lane * 16;
     const char* dst = x3_smem + stage * Geo::Stage;
 #pragma unroll
-    for (int j = 0; j < (Geo::Pieces + 3) / 4; ++j) {
-      const int piece = wave + 4 * j;
+    for (int j = 0; j < (Geo::Pieces + NW - 1) / NW; ++j) {
+      const int piece = wave + NW * j;
       if (piece < Geo::Pieces)
         __builtin_amdgcn_global_load_lds((glb_void_t*)(src + piece * 1024), (lds_void_t*)(dst + piece * 1024), 16, 0, 0);
     }
   };
 
-  f32x4_t acc[kX3MT][NT];
+  f32x4_t acc[MT][NT];
 #pragma unroll
-  for (int a = 0; a < kX3MT; ++a)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[a][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -217,13 +223,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int64_t M, int N, int 
   for (int kt = 0; kt < nkt; ++kt) {
     const int stage = kt & 1;
     // this k-step's A fragments: three planes per row tile
-    u32x4_t af[kX3MT][3];
+    u32x4_t af[MT][3];
     if (kt == nkt - 1 && (K & 31) != 0 && kt * 32 + g * 8 >= K) {       // the K tail: this lane's chunk does not exist
 #pragma unroll
-      for (int a = 0; a < kX3MT; ++a) araw[a][0] = araw[a][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int a = 0; a < MT; ++a) araw[a][0] = araw[a][1] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int a = 0; a < kX3MT; ++a) {
+    for (int a = 0; a < MT; ++a) {
       const float x[8] = {araw[a][0].x, araw[a][0].y, araw[a][0].z, araw[a][0].w,
                           araw[a][1].x, araw[a][1].y, araw[a][1].z, araw[a][1].w};
 #pragma unroll
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int64_t M, int N, int 
       const u32x4_t* b = bf[t & 1];
       // smallest terms first; between two MFMAs on one accumulator sit the three other row tiles
 #define REC_X3_MFMA(PB, PA)                                                                                    \
-  _Pragma("unroll") for (int a = 0; a < kX3MT; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(         \
+  _Pragma("unroll") for (int a = 0; a < MT; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(         \
       __builtin_bit_cast(bf16x8_t, b[PB]), __builtin_bit_cast(bf16x8_t, af[a][PA]), acc[a][t], 0, 0, 0);
 #if REC_X3_PRODUCTS >= 6
       REC_X3_MFMA(2, 0)
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(int64_t M, int N, int 
   // ---- epilogue: float4 per lane and tile, aux / bias operands of a row tile loaded ahead of its stores
   const int n_base = cb * Geo::NP + wn * NT * 16 + g * 4;
 #pragma unroll
-  for (int a = 0; a < kX3MT; ++a) {
+  for (int a = 0; a < MT; ++a) {
     const int64_t i = m0 + a * 16 + li;
     const bool row_ok = i < M;
     const int64_t ic = row_ok ? i : M - 1;
@@ -636,13 +642,13 @@ inline bool x3_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldc, const
          ((uintptr_t)A % 16) == 0 && ((uintptr_t)C % 16) == 0;
 }
 
-template <int NT, int EPI>
-inline int x3_launch_gemm_cfg(int64_t M, int N, int K, const float* A, int64_t lda, const char* img, float* C, int64_t ldc,
-                              const EpiArgs& e, int ncb, hipStream_t st) {
+template <int NT, int EPI, int WM>
+inline int x3_launch_gemm_wm(int64_t M, int N, int K, const float* A, int64_t lda, const char* img, float* C, int64_t ldc,
+                             const EpiArgs& e, int ncb, hipStream_t st) {
   static bool attr_set = false;             // > 64 KB of dynamic LDS needs the attribute once per kernel
   constexpr int lds = 2 * X3Geo<NT>::Stage;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<NT, EPI>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<NT, EPI, WM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       (void)hipGetLastError();
       set_error("gemm_bf16x3: %d B of dynamic LDS refused", lds);
@@ -650,9 +656,22 @@ inline int x3_launch_gemm_cfg(int64_t M, int N, int K, const float* A, int64_t l
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<NT, EPI>), dim3((unsigned)((M + kX3BM - 1) / kX3BM), (unsigned)ncb), dim3(256), lds,
-                     st, M, N, K, A, lda, img, C, ldc, e);
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<NT, EPI, WM>), dim3((unsigned)((M + kX3BM - 1) / kX3BM), (unsigned)ncb),
+                     dim3(WM * 2 * 64), lds, st, M, N, K, A, lda, img, C, ldc, e);
   return check_launch("gemm_bf16x3_kernel");
+}
+
+// Eight waves (two per SIMD, 32-row wave tiles) for the four MLP epilogues: 129 -> 119 us at 65 536 x 400 x 400, 1808 ->
+// 1716 us at 1560^2, 1305 -> 1199 us at 512 x 3680, bit-identical (profiles/r05_bf16x3.txt section 9); the CrossNet
+// epilogues hold two more operand tiles in registers and spill at the 256-register budget of that shape: four waves.
+#ifndef REC_X3_WM
+#define REC_X3_WM 4            // lab knob (tools/gemm_lab): 2 = four waves per block for every epilogue
+#endif
+template <int NT, int EPI>
+inline int x3_launch_gemm_cfg(int64_t M, int N, int K, const float* A, int64_t lda, const char* img, float* C, int64_t ldc,
+                              const EpiArgs& e, int ncb, hipStream_t st) {
+  constexpr int WM = (EPI == REC_EPI_CROSS || EPI == REC_EPI_ADD) ? 2 : REC_X3_WM;
+  return x3_launch_gemm_wm<NT, EPI, WM>(M, N, K, A, lda, img, C, ldc, e, ncb, st);
 }
 
 template <int EPI>
