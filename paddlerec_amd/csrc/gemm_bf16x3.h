@@ -670,7 +670,7 @@ inline int x3_launch_gemm_wm(int64_t M, int N, int K, const float* A, int64_t ld
 template <int NT, int EPI>
 inline int x3_launch_gemm_cfg(int64_t M, int N, int K, const float* A, int64_t lda, const char* img, float* C, int64_t ldc,
                               const EpiArgs& e, int ncb, hipStream_t st) {
-  constexpr int WM = (EPI == REC_EPI_CROSS || EPI == REC_EPI_ADD) ? 2 : REC_X3_WM;
+  constexpr int WM = EpiUses<EPI>::aux1 ? 2 : REC_X3_WM;        // CROSS / ADD / MOE
   return x3_launch_gemm_wm<NT, EPI, WM>(M, N, K, A, lda, img, C, ldc, e, ncb, st);
 }
 
@@ -686,10 +686,7 @@ inline int x3_launch_gemm_epi(int64_t M, int N, int K, const float* A, int64_t l
   }
 }
 
-inline bool x3_epilogue_ok(int epi) {
-  return epi == REC_EPI_NONE || epi == REC_EPI_BIAS || epi == REC_EPI_BIAS_RELU || epi == REC_EPI_RELU_MASK ||
-         epi == REC_EPI_CROSS || epi == REC_EPI_ADD;
-}
+inline bool x3_epilogue_ok(int epi) { return epi >= REC_EPI_NONE && epi <= REC_EPI_DTANH; }     // every rec_gemm_f32 epilogue
 
 inline int x3_launch_gemm(int epi, int64_t M, int N, int K, const float* A, int64_t lda, const char* img, float* C,
                           int64_t ldc, const EpiArgs& e, hipStream_t st) {
@@ -699,7 +696,12 @@ inline int x3_launch_gemm(int epi, int64_t M, int N, int K, const float* A, int6
     case REC_EPI_BIAS_RELU: return x3_launch_gemm_epi<REC_EPI_BIAS_RELU>(M, N, K, A, lda, img, C, ldc, e, st);
     case REC_EPI_RELU_MASK: return x3_launch_gemm_epi<REC_EPI_RELU_MASK>(M, N, K, A, lda, img, C, ldc, e, st);
     case REC_EPI_CROSS: return x3_launch_gemm_epi<REC_EPI_CROSS>(M, N, K, A, lda, img, C, ldc, e, st);
+    case REC_EPI_BIAS_SIGMOID: return x3_launch_gemm_epi<REC_EPI_BIAS_SIGMOID>(M, N, K, A, lda, img, C, ldc, e, st);
+    case REC_EPI_BIAS_TANH: return x3_launch_gemm_epi<REC_EPI_BIAS_TANH>(M, N, K, A, lda, img, C, ldc, e, st);
     case REC_EPI_ADD: return x3_launch_gemm_epi<REC_EPI_ADD>(M, N, K, A, lda, img, C, ldc, e, st);
+    case REC_EPI_MOE: return x3_launch_gemm_epi<REC_EPI_MOE>(M, N, K, A, lda, img, C, ldc, e, st);
+    case REC_EPI_DSIGMOID: return x3_launch_gemm_epi<REC_EPI_DSIGMOID>(M, N, K, A, lda, img, C, ldc, e, st);
+    case REC_EPI_DTANH: return x3_launch_gemm_epi<REC_EPI_DTANH>(M, N, K, A, lda, img, C, ldc, e, st);
     default: set_error("gemm_bf16x3: epilogue %d not built", epi); return REC_EINVAL;
   }
 }
