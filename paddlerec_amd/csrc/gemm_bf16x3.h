@@ -27,7 +27,9 @@
 //   * MFMAs with the operands swapped (W' fragment first) as in gemm_glds.h: lane (i, g) ends up with
 //     C[row i][columns 4g .. 4g+3] of a tile -> float4 stores, float4 bias / aux loads.
 // Shapes: K % 8 == 0 (a lane's 8-k chunk is inside or outside K as a whole), N % 4 == 0, rows 16-B aligned, M >= 8192
-// (the caller's rule: short problems do not fill the chip with 128-row blocks).
+// (the caller's rule: short problems do not fill the chip with 128-row blocks).  Non-finite operands: an Inf (or a finite
+// |x| > 3.39e38, which rounds to the bf16 Inf) leaves Inf - Inf in its remainder and the output is NaN where the f32 fma
+// chain gives Inf — both mean the same for a training step.
 // (2) weight-gradient form (gemm_bf16x3_dw_kernel): further down.
 #pragma once
 
