@@ -50,3 +50,29 @@ def _check_occupancy(remarks):
     tile_b = [v for k, v in occ.items() if "fm_bwd_tile_kernel" in k]
     assert len(tile_f) == 4 and len(tile_b) >= 3, sorted(occ)
     assert min(tile_f) >= 6 and min(tile_b) >= 6, (tile_f, tile_b)
+
+
+def test_bf16x3_gemm_kernels_keep_their_registers():
+    """csrc/gemm_bf16x3.h: the eight-wave forward / dX kernel lives on TWO waves per SIMD (<= 256 registers; it is 7-8 %
+    slower with one), none of the kernels may spill (the weight-gradient kernel sits at 440 of 512 registers)."""
+    saved = os.path.join(REPO, "paddlerec_amd", "_obj", "gemm_f32.resources.txt")
+    src = [os.path.join(REPO, "paddlerec_amd", "csrc", f) for f in ("gemm_f32.hip", "gemm_bf16x3.h", "gemm_epi.h")]
+    if not (os.path.exists(saved) and all(os.path.getmtime(d) <= os.path.getmtime(saved) for d in src)):
+        pytest.skip("no resource remarks newer than the sources (python -m paddlerec_amd.build writes them)")
+    occ, scratch, name = {}, {}, None
+    for line in open(saved):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", line)
+        if m and name:
+            occ[name] = int(m.group(1))
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name:
+            scratch[name] = int(m.group(1))
+    x3 = {k: v for k, v in occ.items() if "gemm_bf16x3" in k}
+    assert len(x3) >= 30, sorted(x3)[:5]
+    # gemm_bf16x3_kernel<NT, EPI, WM 4>: the four MLP epilogues at every column-block width
+    eight = [k for k in x3 if re.search(r"gemm_bf16x3_kernelILi(13|8|7)ELi[0-3]ELi4E", k)]
+    assert len(eight) == 12 and all(x3[k] >= 2 for k in eight), {k: x3[k] for k in eight}
+    assert all(scratch[k] == 0 for k in x3 if "dw_kernel" in k or k in eight), {k: scratch[k] for k in x3 if scratch[k]}
