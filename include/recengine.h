@@ -207,6 +207,13 @@ typedef struct {
 int rec_multislot_sumpool_fwd(const rec_multislot_desc* desc, const int64_t* values, const int64_t* lod,
                               const int64_t* slot_base, const float* W, float* out, int32_t* counts,
                               int32_t* seg_of_value, int64_t* rows_out, int32_t* status, void* stream);
+/* The backward of the pool in ROWS FORM — the SelectedRows value of sequence_pool('sum') o sparse_embedding
+ * (slot_dnn/net.py:63-75): row_grad[k, :] = d_out[b, s*D:(s+1)*D] for value k of segment seg_of_value[k] = b*S+s
+ * (rows = rows_out of the forward).  For binders that must hand the gradient over as a dense [nnz, D] tensor (the
+ * Paddle custom operator rec_multislot_sumpool); the engine's own steps read d_out through rec_grad_layout.index
+ * and never materialise it.  desc: batch, num_slots, emb_dim, out_stride are read. */
+int rec_multislot_sumpool_bwd(const rec_multislot_desc* desc, int64_t nnz, const int32_t* seg_of_value,
+                              const float* d_out, float* row_grad, void* stream);
 /* Row of a feasign in a hashed table of num_rows (>= 2) rows: 0 -> 0 (padding row), f -> 1 + mix64(f) %
  * (num_rows - 1) with mix64 = the murmur3 64-bit finaliser (SURVEY §8(d) cfg5 "64-bit mix % N").  Device
  * (keys/rows device pointers) and host variants, bit-identical. */
@@ -950,6 +957,10 @@ int rec_copy_2d_async(void* dst, size_t dst_pitch_bytes, const void* src, size_t
 /* out [cols, rows] = in [rows, cols]^T (f32, both contiguous).  The DIN backward wants the first attention weight
  * transposed (att_w1_t); a binder without a tensor library of its own materialises it with this. */
 int rec_transpose_f32(int64_t rows, int64_t cols, const float* in, float* out, void* stream);
+/* dst[i] = (int64) round(src[i * src_stride]).  The gpubox nets carry the click label to the lookup as a float column
+ * (show_click = concat([ones, cast(label)]), dnn/static_model.py:86-94); the accessor's push counts clicks in int64 —
+ * a binder without a tensor library (the custom operator rec_ps_pull's gradient) converts the column with this. */
+int rec_cast_f32_i64(int64_t n, const float* src, int64_t src_stride, int64_t* dst, void* stream);
 
 /* One wave busy-waits `micros` microseconds on `stream`.  Host-side stream probe: HIP maps streams onto a
  * few hardware queues and kernels of two streams that share a queue run strictly one after the other, so a

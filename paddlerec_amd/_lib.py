@@ -193,6 +193,7 @@ SIGNATURES = {
     "rec_adam_record_all": (C.c_int, [_I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.POINTER(GradLayout), _P,
                                       C.POINTER(GradLayout), _P, _P, _P, C.POINTER(AdamHyper), _P]),
     "rec_multislot_sumpool_fwd": (C.c_int, [C.POINTER(MultislotDesc)] + [_P] * 10),
+    "rec_multislot_sumpool_bwd": (C.c_int, [C.POINTER(MultislotDesc), _I64, _P, _P, _P, _P]),
     "rec_feasign_rows": (C.c_int, [_I64, _I64, _P, _P, _P]),
     "rec_feasign_rows_host": (C.c_int, [_I64, _I64, _P, _P]),
     "rec_record_gather": (C.c_int, [_I64, _I32, _I32, _I64, _P, _P, _P, _P, C.POINTER(LazyInit), _P, _P]),
@@ -292,6 +293,7 @@ SIGNATURES = {
     "rec_copy_async": (C.c_int, [_P, _P, _SZ, _P]),
     "rec_copy_2d_async": (C.c_int, [_P, _SZ, _P, _SZ, _SZ, _SZ, _P]),
     "rec_transpose_f32": (C.c_int, [_I64, _I64, _P, _P, _P]),
+    "rec_cast_f32_i64": (C.c_int, [_I64, _P, _I64, _P, _P]),
     "rec_stream_create_cu_range": (C.c_int, [_I32, _I32, C.POINTER(C.c_void_p)]),
     "rec_stream_create_cu_stride": (C.c_int, [_I32, _I32, _I32, C.POINTER(C.c_void_p)]),
     "rec_ctr_head_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(C.c_size_t)]),

@@ -63,7 +63,32 @@ def to_tensor(x, dtype=None, place=None, stop_gradient=True):
     return t.to(_dtype(dtype)) if dtype is not None else t
 
 
+class LoDTensor:
+    """A lod_level=1 feed (`static.data(..., lod_level=1)`; Paddle's LoDTensor [EXT]): values [nnz, ...] of all segments
+    of the batch back to back + the offsets lod [B+1] (device int64) — values and offsets as two dense tensors, which is
+    also how the custom operator rec_multislot_sumpool takes them."""
+    _n = 0
+
+    def __init__(self, values, lod, name=None):
+        dev = _backend.device()
+        self.values = values.to(dev) if isinstance(values, _t.Tensor) else _t.as_tensor(_np.asarray(values)).to(dev)
+        self.lod = (lod if isinstance(lod, _t.Tensor) else _t.as_tensor(_np.asarray(lod, _np.int64))).to(dev).to(_t.int64)
+        LoDTensor._n += 1
+        self.name = name or "lod_%d" % LoDTensor._n
+        self.lod_level = 1
+
+    @property
+    def shape(self):
+        return list(self.values.shape)
+
+    @property
+    def dtype(self):
+        return self.values.dtype
+
+
 def cast(x, dtype):
+    if isinstance(x, LoDTensor):
+        return LoDTensor(x.values.to(_dtype(dtype)), x.lod, x.name + ".cast")
     return x.to(_dtype(dtype))
 
 

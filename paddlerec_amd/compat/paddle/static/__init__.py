@@ -136,6 +136,9 @@ def _subst(x, key):
 def _wrap(out):
     if isinstance(out, _t.Tensor):
         return Var(out.detach())
+    from .. import LoDTensor
+    if isinstance(out, (LoDTensor, nn.LodEmbedding)):       # LoD values travel through the tape as they are
+        return Var(out, name=out.name)
     if isinstance(out, (list, tuple)):
         return type(out)(_wrap(o) for o in out)
     return out
@@ -171,10 +174,47 @@ def data(name, shape, dtype="float32", lod_level=0):
     """A feed variable: the example batch has 2 rows (None / -1 dims)."""
     from .. import _dtype
     shp = [2 if (s is None or s < 0) else int(s) for s in shape]
-    v = Var(_t.zeros(shp, dtype=_dtype(dtype), device=_backend.device()), name=name)
+    ex = _t.zeros(shp, dtype=_dtype(dtype), device=_backend.device())
+    if lod_level:                  # a multi-value feed: the example is two segments of one value each
+        from .. import LoDTensor
+        ex = LoDTensor(ex, list(range(shp[0] + 1)), name)
+    v = Var(ex, name=name)
     v.lod_level = lod_level
     _main.feeds.append(v)
     return v
+
+
+def create_global_var(shape, value, dtype, persistable=False, force_cpu=False, name=None):
+    """paddle.static.create_global_var [EXT]: a non-trainable variable of the program filled with `value` — what a
+    custom operator that keeps state across steps is handed (rec_ps_pull's record table).  One tensor per name."""
+    from .. import _dtype
+    name = name or "global_var_%d" % len(_persistables)
+    for v in _persistables:
+        if v.name == name:
+            return v
+    t = _t.full([int(s) for s in shape], value, dtype=_dtype(dtype),
+                device="cpu" if force_cpu else _backend.device())
+    t._rec_var_name = name
+    v = Var(t, name=name, persistable=True)
+    v.stop_gradient = True
+    _persistables.append(v)
+    return v
+
+
+_parameters = {}
+
+
+def create_parameter(shape, dtype, name=None, attr=None, is_bias=False, default_initializer=None):
+    """paddle.static.create_parameter [EXT]: a trainable parameter of the program (zeros unless an initializer is given;
+    one per name).  Returned as a persistable Var whose value is the torch Parameter."""
+    from .. import create_parameter as _cp
+    name = name or getattr(attr, "name", None) or "parameter_%d" % len(_parameters)
+    if name not in _parameters:
+        p = _cp(shape, dtype, default_initializer=default_initializer, attr=attr, is_bias=is_bias)
+        v = Var(p, name=name, persistable=True)
+        _persistables.append(v)
+        _parameters[name] = v
+    return _parameters[name]
 
 
 def cpu_places(n=1):

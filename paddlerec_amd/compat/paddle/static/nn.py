@@ -57,7 +57,7 @@ class SparseTable:
     grad_scale = the GLOBAL batch.  Rows arrive at an owner rank-major and in ascending position inside a rank, i.e. in
     the order of the global batch: the merge sums in the same order as ONE unsharded step on the concatenated batch."""
 
-    def __init__(self, name, num_rows, emb_dim, accessor=None):
+    def __init__(self, name, num_rows, emb_dim, accessor=None, rec=None):
         from .. import _dist
         K = _backend.kernels()
         self.name = name
@@ -68,13 +68,24 @@ class SparseTable:
         acc = dict(accessor or {})
         if self.G > 1:
             acc.update(row_mul=self.G, row_add=self.rank)     # a key is created with the same values on any sharding
-        self.table = K.PsTable((self.global_rows + self.G - 1) // self.G, int(emb_dim), _backend.device(), kind="slot",
-                               **acc)
+        if rec is not None:
+            # a record tensor the program owns (static.create_global_var) and a custom operator updates in place
+            # (rec_ps_pull): this object only lists it for the pass checkpoint / shrink / PSGPU
+            if self.G > 1:
+                raise NotImplementedError("the custom-operator PS pull runs on one GPU (the row-sharded pull is "
+                                          "static.nn.sparse_embedding's)")
+            self.table = K.PsTable(1, int(emb_dim), _backend.device(), kind="slot", row_stride=rec.shape[1], **acc)
+            self.table.rec, self.table.num_rows = rec, int(rec.shape[0])
+            self.table.W = rec[:, self.table.w_cols]
+        else:
+            self.table = K.PsTable((self.global_rows + self.G - 1) // self.G, int(emb_dim), _backend.device(),
+                                   kind="slot", **acc)
         self.status = K.new_status(_backend.device())
         self.anchor = _t.zeros(1, device=_backend.device(), requires_grad=True)   # gives the lookup a grad_fn
         self.pending, self.groups, self.ws = [], None, K.Workspace(_backend.device())
         self.pre, self.pending_slots, self.cursor = None, {}, 0
         self.ws_route, self.route = K.Workspace(_backend.device()), None
+        self.pending_pool, self.last_counts = [], []      # sequence_pool('sum') lookups of the step (LoD feeds)
 
     # -- single process: one gather per sparse_embedding call, merged at push ------------------------------------------
     def push(self, label, global_batch=None):
@@ -82,6 +93,8 @@ class SparseTable:
         occurrence, click = the sample's label, gradient of the SUMMED loss)."""
         if self.G > 1:
             return self._push_sharded(label, global_batch)
+        if self.pending_pool:
+            self._push_pooled(label)
         if not self.pending:
             return
         K = _backend.kernels()
@@ -97,6 +110,27 @@ class SparseTable:
         self.table.accessor.grad_scale = float(B)
         click = label.reshape(-1).to(_t.int64).contiguous() if label is not None else None
         K.ps_push_rows(self.table, self.groups, grad, S, click=click)
+
+    def _push_pooled(self, label):
+        """The push of a step's J pooled lookups (sequence_pool('sum') over sparse_embedding of LoD feeds,
+        slot_dnn/net.py:63-75): value k of lookup j belongs to sample b = seg_j[k]; its gradient row is the pooled
+        gradient d_out_j[b].  All J x nnz_j values are merged in ONE grouping whose payload b * J + j addresses
+        [B, J*D] = the J gradients side by side — the layout paddlerec_amd.slot_dnn pushes from."""
+        K = _backend.kernels()
+        J = len(self.pending_pool)
+        B, D = self.pending_pool[0][2].shape
+        rows = _t.cat([r for r, _, _ in self.pending_pool]).contiguous()
+        payload = _t.cat([seg.to(_t.int32) * J + j for j, (_, seg, _) in enumerate(self.pending_pool)]).contiguous()
+        grad = _t.stack([g for _, _, g in self.pending_pool], dim=1).reshape(B, J * D).contiguous()
+        self.pending_pool, n = [], rows.numel()
+        if n == 0:
+            return
+        if self.groups is None or self.groups.n != n:
+            self.groups = K.IdGroups(n, rows.device)
+        K.ids_group(rows, self.table.num_rows, 0, self.ws, None, self.status, self.groups, payload=payload)
+        self.table.accessor.grad_scale = float(B)
+        click = label.reshape(-1).to(_t.int64).contiguous() if label is not None else None
+        K.ps_push_rows(self.table, self.groups, grad, J, click=click)
 
     # -- N ranks: one pull and one push per step through the row-sharded table ------------------------------------------
     def prefetch(self, keys):
@@ -163,18 +197,84 @@ class SparseTable:
         self.pre, self.pending_slots = None, {}
 
 
+class LodEmbedding:
+    """What sparse_embedding returns for a lod_level=1 feed: the lookup of every value of the batch's segments, NOT yet
+    materialised — the reference pools it straight away (slot_dnn/net.py:63-75, dnn/static_model_lod.py:70-97), and
+    sequence_pool(..., 'sum') over this object is ONE rec_multislot_sumpool_fwd launch on (values, LoD offsets).  Anything
+    else that touches it gets the gathered rows (`.values`, LoD kept)."""
+
+    def __init__(self, table, keys, padding_idx):
+        self.table, self.keys, self.padding_idx, self.lod, self.name = table, keys, padding_idx, keys.lod, keys.name + ".emb"
+        self._values = None
+
+    @property
+    def values(self):
+        if self._values is None:
+            K = _backend.kernels()
+            t = self.table
+            flat = self.keys.values.reshape(-1).contiguous()
+            rows = K.feasign_rows(flat, t.table.num_rows)
+            if self.padding_idx is not None:
+                rows = _t.where(flat == int(self.padding_idx), _t.zeros_like(rows), rows)
+            self._values, _ = K.emb_gather(rows, t.table.W, None, t.status)
+        return self._values
+
+    @property
+    def shape(self):
+        return [self.keys.values.shape[0], self.table.table.emb_dim]
+
+
+class _PsPool(_t.autograd.Function):
+    """sequence_pool(sparse_embedding(lod feed), 'sum'): rec_multislot_sumpool_fwd with one slot; the backward leaves
+    (rows, segment of every value, pooled gradient) with the table for the step's push."""
+
+    @staticmethod
+    def forward(ctx, anchor, emb):
+        K = _backend.kernels()
+        tab, keys = emb.table, emb.keys
+        t = tab.table
+        vals = keys.values.reshape(-1).contiguous()
+        lod = keys.lod.reshape(1, -1).contiguous()
+        base = _t.tensor([0, vals.numel()], dtype=_t.int64, device=vals.device)
+        pad = 0 if emb.padding_idx is None else int(emb.padding_idx)      # feasign 0 is the padding key either way
+        out, counts, seg, rows, _ = K.multislot_sumpool(K.MultislotBatch(vals, lod, base), t.W, t.num_rows, pad, 1,
+                                                        tab.status, lazy_init=t.lazy_init)
+        tab.last_counts.append(counts)
+        ctx.tab, ctx.rows, ctx.seg, ctx.n = tab, rows, seg, vals.numel()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.tab.pending_pool.append((ctx.rows[:ctx.n], ctx.seg[:ctx.n], g.contiguous()))
+        return None, None
+
+
+def _lod_input(x):
+    from .. import LoDTensor
+    return isinstance(x, LoDTensor)
+
+
 def sparse_embedding(input, size, padding_idx=None, is_test=False, entry=None, table_class="MemorySparseTable",  # noqa: A002
                      param_attr=None, dtype="float32", slot=None):
     from . import Var, _main, record
     name = getattr(param_attr, "name", None) or "embedding"
     tab = _main.tables.get(name)
+    # a lod_level=1 feed (multi-value slot: slot_dnn, static_model_lod) is looked up without CVM columns: size[1] IS the
+    # embedding width; the one-id-per-slot gpubox form (dnn/net.py:71-79) sizes the value as [show, click, embed...]
+    lod = _lod_input(input) or (isinstance(input, Var) and _lod_input(input.example))
     if tab is None:
         import os
         # the reference's size[0] is ignored by the GPU-PS (a hash map keyed by feasign [EXT]); the engine's table is a
         # hashed array: REC_GPUBOX_TABLE_ROWS rows (default 1 000 003), the looked-up vector is size[1] - 2 floats
         rows = int(os.environ.get("REC_GPUBOX_TABLE_ROWS", "1000003"))
-        tab = _main.tables[name] = SparseTable(name, rows, int(size[1]) - 2,
+        tab = _main.tables[name] = SparseTable(name, rows, int(size[1]) - (0 if lod else 2),
                                                accessor=getattr(_main, "accessor_kwargs", None))
+    if lod:
+        if tab.G > 1:
+            raise NotImplementedError("pooled LoD lookups on a row-sharded table: paddlerec_amd.sharded_slot_dnn")
+        pooled = lambda keys: LodEmbedding(tab, keys, padding_idx)      # noqa: E731
+        pooled.__qualname__ = "static.nn.sparse_embedding[%s, lod]" % name
+        return record(pooled, [input]) if isinstance(input, Var) else pooled(input)
 
     def lookup(keys):
         if tab.pre is not None:                   # the step's keys were pulled together (Executor: N ranks)
@@ -203,8 +303,36 @@ def continuous_value_model(input, cvm, use_cvm=True):  # noqa: A002
 
 
 def sequence_pool(input, pool_type, is_test=False, pad_value=0.0):  # noqa: A002
-    raise NotImplementedError("static.nn.sequence_pool over LoD feeds: use paddlerec_amd.gpubox (BenchmarkDNNLayer) for "
-                              "the multi-value slot_dnn model; the tape executor serves dnn/config_gpubox.yaml")
+    """paddle.static.nn.sequence_pool [EXT, SURVEY App. B-7]: per-LoD-segment row sum, an empty segment -> pad_value.
+    Over a sparse_embedding of a LoD feed the lookup and the pool are ONE kernel on (values, LoD offsets); over
+    materialised LoD rows the same kernel pools them as a table indexed by position."""
+    from . import Var, record
+    from .. import LoDTensor
+    if str(pool_type).lower() != "sum":
+        raise NotImplementedError("sequence_pool(pool_type=%r): the reference's rank models pool with 'sum'" % pool_type)
+    if float(pad_value) != 0.0:
+        raise NotImplementedError("sequence_pool: pad_value != 0")
+
+    def pool(x):
+        if isinstance(x, LodEmbedding):
+            return _PsPool.apply(x.table.anchor, x)
+        if isinstance(x, LoDTensor):              # rows already materialised: pool values[k] as row k + 1 of a table
+            K = _backend.kernels()
+            v = x.values.reshape(x.values.shape[0], -1).to(_t.float32)
+            if v.requires_grad:
+                raise NotImplementedError("sequence_pool over differentiable LoD rows (only lookups are pooled in the "
+                                          "reference's rank models)")
+            n, D = v.shape
+            W = _t.cat([_t.zeros(1, D, dtype=v.dtype, device=v.device), v]).contiguous()
+            ids = _t.arange(1, n + 1, dtype=_t.int64, device=v.device)
+            base = _t.tensor([0, n], dtype=_t.int64, device=v.device)
+            return K.multislot_sumpool(K.MultislotBatch(ids, x.lod.reshape(1, -1).contiguous(), base), W, n + 1, 0, 0,
+                                       K.new_status(v.device), want_counts=False, want_backward=False)[0]
+        raise TypeError("sequence_pool needs a LoD input (static.data(..., lod_level=1) feed or its sparse_embedding)")
+    pool.__qualname__ = "static.nn.sequence_pool"
+    if isinstance(input, Var):
+        return record(pool, [input])
+    return pool(input)
 
 
 def embedding(input, size, is_sparse=False, padding_idx=None, param_attr=None, dtype="float32"):  # noqa: A002

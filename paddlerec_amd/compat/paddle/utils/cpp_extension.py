@@ -58,14 +58,17 @@ class _OpDef:
         split = lambda s: [x for x in s.split(",") if x]
         self.index, self.name, self.is_grad = index, f[0], f[1] == "grad"
         self.inputs, self.outputs = split(f[2]), split(f[3])
-        self.attrs = [tuple(p.strip() for p in a.split(":")) for a in split(f[4])]        # (name, c++ type)
+        self.attrs = [tuple(p.strip() for p in a.split(":", 1)) for a in split(f[4])]        # (name, c++ type)
         self.has_kernel, self.has_shape, self.has_dtype = (c == "1" for c in f[5])
         self.notes = [n for n in f[6].split(";") if n]
-        self.selected_rows = {}                                                            # table input -> ids input
+        self.selected_rows = {}                                  # table input -> ids (a forward input or output)
+        self.ps_tables = []                                      # inputs that are PS record tables updated in place
         for n in self.notes:
             if n.startswith("selected_rows="):
                 t, i = n[len("selected_rows="):].split(":")
                 self.selected_rows[t] = i
+            elif n.startswith("ps_table="):
+                self.ps_tables.append(n[len("ps_table="):])
 
 
 class _Shim:
@@ -144,6 +147,10 @@ class _Shim:
                 at[k].kind, at[k].s = 2, keep[-1]
             elif ty == "bool":
                 at[k].kind, at[k].i = 3, int(bool(v))
+            elif ty == "std::vector<float>":
+                arr = (C.c_float * max(1, len(v)))(*[float(x) for x in v])
+                keep.append(arr)
+                at[k].kind, at[k].i, at[k].s = 4, len(v), C.cast(arr, C.c_char_p)
             else:
                 at[k].kind, at[k].i = 0, int(v)
         return flat, tin, cnt, at, stream, keep
@@ -222,7 +229,7 @@ class _CustomOp(torch.autograd.Function):
     def forward(ctx, fwd, grad, attrs, *inputs):
         s = shim()
         alt = _standin(fwd.name)
-        det = [t.detach() for t in inputs]
+        det = [t.detach() for t in inputs]      # X@VECTOR (list) inputs never reach here: op() runs them without a tape
         outs = list(alt[0](det, attrs)) if alt is not None else s.run(fwd, det, attrs)
         _check_infer(s, fwd, det, attrs, outs)
         ctx.fwd, ctx.grad, ctx.attrs, ctx.n_in = fwd, grad, attrs, len(inputs)
@@ -252,13 +259,38 @@ class _CustomOp(torch.autograd.Function):
             k = fwd.inputs.index(name[:-5])
             if name[:-5] in grad.selected_rows:               # rows-form: SelectedRows(rows = ids, value = g)
                 p = ctx.params[k]
+                if not ctx.needs_input_grad[3 + k]:           # a frozen table (stop_gradient) gets no update
+                    continue
                 ids = by_name[grad.selected_rows[name[:-5]]].reshape(-1)
+                if g.shape[0] == 0 or ids.numel() % g.shape[0] != 0:
+                    if ids.numel() or g.shape[0]:
+                        raise RuntimeError("%s: %d ids cannot share %d gradient rows" % (fwd.name, ids.numel(), g.shape[0]))
+                    continue
                 if not hasattr(p, "_sparse_grads"):
                     p._sparse_grads = []
                 p._sparse_grads.append((ids, g, attrs.get("padding_idx"), ids.numel() // g.shape[0]))
             elif ctx.needs_input_grad[3 + k]:
                 out[k] = g.reshape(ins[k].shape)
         return (None, None, None) + tuple(out)
+
+
+def _adopt_ps_table(op, rec, attrs):
+    """An operator input marked `ps_table` (rec_ps_pull's Rec) is a GPU-PS record table the gradient operator updates in
+    place.  The first call lists the tensor — a persistable variable made with paddle.static.create_global_var — among
+    the program's sparse tables under the variable's name, so that the pass checkpoint (fleet.save_*), shrink and
+    core.PSGPU see it exactly like a table static.nn.sparse_embedding created."""
+    from .. import static as S
+    name = getattr(rec, "_rec_var_name", None)
+    if name is None or name in S._main.tables:
+        return
+    from ..static import nn as SN
+    a = [float(x) for x in attrs["accessor"]]
+    acc = dict(lr=a[0], initial_g2sum=a[1], bounds=(a[2], a[3]), initial_range=a[4], embedx_lr=a[5],
+               embedx_initial_g2sum=a[6], embedx_bounds=(a[7], a[8]), embedx_initial_range=a[9], embedx_threshold=a[10],
+               nonclk_coeff=a[11], click_coeff=a[12], seed=int(a[13]))
+    S._main.tables[name] = SN.SparseTable(name, rec.shape[0], int(attrs["emb_dim"]), accessor=acc, rec=rec)
+    print("[compat] custom operator %s: variable %r [%d, %d] listed as a GPU-PS table of the program"
+          % (op.name, name, rec.shape[0], rec.shape[1]), flush=True)
 
 
 class _OpModule:
@@ -287,9 +319,15 @@ class _OpModule:
             if kwargs:
                 raise TypeError("%s: unexpected arguments %s" % (fwd.name, sorted(kwargs)))
             inputs = [x if isinstance(x, torch.Tensor) else list(x) for x in inputs]
-            if grad is None or not torch.is_grad_enabled():
+            for tname in fwd.ps_tables:                      # the record table joins the program's sparse tables
+                _adopt_ps_table(fwd, inputs[fwd.inputs.index(tname)], attrs)
+            has_list = any(not isinstance(x, torch.Tensor) for x in inputs)
+            if has_list and grad is not None and torch.is_grad_enabled() and any(
+                    t.requires_grad for x in inputs for t in (x if isinstance(x, list) else [x])):
+                raise NotImplementedError("%s: X@VECTOR inputs are not differentiable through the compat loader" % fwd.name)
+            if grad is None or not torch.is_grad_enabled() or has_list:
                 alt = _standin(fwd.name)
-                det = [t.detach() for t in inputs]
+                det = [t.detach() if isinstance(t, torch.Tensor) else [u.detach() for u in t] for t in inputs]
                 outs = list(alt[0](det, attrs)) if alt is not None else shim().run(fwd, det, attrs)
             else:
                 outs = list(_CustomOp.apply(fwd, grad, attrs, *inputs))

@@ -420,6 +420,23 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
 }
 }  // namespace rec
 
+namespace rec {
+__global__ __launch_bounds__(256) void cast_f32_i64_kernel(int64_t n, const float* __restrict__ src, int64_t stride,
+                                                           int64_t* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (int64_t)llrintf(src[i * stride]);
+}
+}  // namespace rec
+
+extern "C" int rec_cast_f32_i64(int64_t n, const float* src, int64_t src_stride, int64_t* dst, void* stream) {
+  REC_REQUIRE(n >= 0 && src_stride >= 1, REC_EINVAL, "bad sizes");
+  if (n == 0) return REC_OK;
+  REC_REQUIRE(src && dst, REC_EINVAL, "null pointer argument");
+  REC_REQUIRE((n + 255) / 256 < (1ll << 31), REC_ESHAPE, "n too large");
+  rec::cast_f32_i64_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(n, src, src_stride, dst);
+  return rec::check_launch("rec_cast_f32_i64");
+}
+
 extern "C" int rec_transpose_f32(int64_t rows, int64_t cols, const float* in, float* out, void* stream) {
   REC_REQUIRE(rows >= 0 && cols >= 0, REC_ESHAPE, "negative shape");
   if (rows == 0 || cols == 0) return REC_OK;

@@ -555,6 +555,22 @@ inline FastMod make_fastmod(uint64_t d) {
   return f;
 }
 
+// Rows form of the sum-pool's gradient (the SelectedRows VALUE of slot_dnn/net.py:63-75's backward): value k of the CSR
+// belongs to segment seg = b * S + s and receives that segment's gradient row d_out[b, s*D:(s+1)*D].  One thread per
+// float of row_grad: consecutive threads write consecutive floats, the reads repeat a segment's row (cache hits).
+__global__ __launch_bounds__(kBlock) void multislot_sumpool_bwd_kernel(
+    int64_t total, int S, int D, int64_t out_stride, const int32_t* __restrict__ seg_of_value,
+    const float* __restrict__ d_out, float* __restrict__ row_grad) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= total) return;
+  const int64_t k = i / D;
+  const int c = (int)(i - k * D);
+  const int32_t seg = seg_of_value[k];
+  const int64_t b = seg / S;
+  const int s = seg - (int32_t)b * S;
+  row_grad[i] = d_out[b * out_stride + (int64_t)s * D + c];
+}
+
 }  // namespace rec
 
 using namespace rec;
@@ -688,4 +704,20 @@ extern "C" int rec_multislot_sumpool_fwd(const rec_multislot_desc* d, const int6
 #undef REC_MS_LAUNCH
   set_error("emb_dim %d unsupported", D);
   return REC_ESHAPE;
+}
+
+extern "C" int rec_multislot_sumpool_bwd(const rec_multislot_desc* d, int64_t nnz, const int32_t* seg_of_value,
+                                         const float* d_out, float* row_grad, void* stream) {
+  REC_REQUIRE(d, REC_EINVAL, "desc is NULL");
+  REC_REQUIRE(d->batch >= 0 && d->num_slots > 0 && d->emb_dim > 0 && nnz >= 0, REC_EINVAL, "bad sizes");
+  if (nnz == 0 || d->batch == 0) return REC_OK;
+  REC_REQUIRE(seg_of_value && d_out && row_grad, REC_EINVAL, "null pointer argument");
+  const int64_t out_stride = d->out_stride > 0 ? d->out_stride : (int64_t)d->num_slots * d->emb_dim;
+  REC_REQUIRE(out_stride >= (int64_t)d->num_slots * d->emb_dim, REC_EINVAL, "out_stride too small");
+  const int64_t total = nnz * d->emb_dim;
+  const int64_t grid = (total + kBlock - 1) / kBlock;
+  REC_REQUIRE(grid < (1ll << 31), REC_ESHAPE, "nnz too large");
+  hipLaunchKernelGGL(multislot_sumpool_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, total,
+                     d->num_slots, d->emb_dim, out_stride, seg_of_value, d_out, row_grad);
+  return check_launch("rec_multislot_sumpool_bwd");
 }

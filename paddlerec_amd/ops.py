@@ -468,6 +468,22 @@ def multislot_sumpool(mb, W, num_rows=None, padding_idx=0, key_mode=0, status=No
     return out, counts, seg, rows, status
 
 
+def multislot_sumpool_bwd(seg_of_value, d_out, num_slots, emb_dim, nnz=None):
+    """Rows form of the pool's gradient: row_grad [nnz, D], row k = d_out[b, s*D:(s+1)*D] of value k's segment b*S+s
+    (what a binder that needs the SelectedRows value as a dense tensor hands to the optimizer; rows = the forward's)."""
+    _chk(seg_of_value, torch.int32, "seg_of_value")
+    _chk(d_out, torch.float32, "d_out")
+    S, D = int(num_slots), int(emb_dim)
+    if d_out.dim() != 2 or d_out.shape[1] < S * D or d_out.stride(1) != 1:
+        raise RecError("d_out must be [batch, >= slots * emb_dim]")
+    n = int(seg_of_value.numel() if nnz is None else nnz)
+    row_grad = torch.empty(n, D, dtype=torch.float32, device=d_out.device)
+    d = MultislotDesc(d_out.shape[0], S, D, D, 0, 1, -1, 0, d_out.stride(0), 0, 0, 0.0, 0)
+    check(lib().rec_multislot_sumpool_bwd(C.byref(d), n, _p(seg_of_value), _p(d_out), _p(row_grad), _stream()),
+          "rec_multislot_sumpool_bwd")
+    return row_grad
+
+
 def feasign_rows(keys, num_rows, out=None):
     """uint64 feasign bit patterns (int64 tensor) -> rows of a hashed table: 0 -> 0, f -> 1 + mix64(f) % (N-1)."""
     _chk(keys, torch.int64, "keys")

@@ -38,7 +38,7 @@ typedef struct pd_mock_tensor {
   int64_t handle;  /* host-side owner of memory that paddle::empty obtained; 0 for tensors the caller passed in */
 } pd_mock_tensor;
 typedef struct pd_mock_attr {
-  int32_t kind; /* 0 int64, 1 double, 2 string, 3 bool */
+  int32_t kind; /* 0 int64, 1 double, 2 string, 3 bool, 4 list of float (s = const float*, i = count) */
   int32_t reserved;
   int64_t i;
   double f;
@@ -244,6 +244,9 @@ PD_MOCK_ATTR_GET(bool, (v.i != 0))
 PD_MOCK_ATTR_GET(float, static_cast<float>(v.kind == 1 ? v.f : static_cast<double>(v.i)))
 PD_MOCK_ATTR_GET(double, (v.kind == 1 ? v.f : static_cast<double>(v.i)))
 PD_MOCK_ATTR_GET(std::string, std::string(v.s ? v.s : ""))
+PD_MOCK_ATTR_GET(std::vector<float>, (v.kind == 4 && v.s ? std::vector<float>(reinterpret_cast<const float*>(v.s),
+                                                                              reinterpret_cast<const float*>(v.s) + v.i)
+                                                          : std::vector<float>()))
 #undef PD_MOCK_ATTR_GET
 
 template <typename F, F fn> struct KernelImpl;

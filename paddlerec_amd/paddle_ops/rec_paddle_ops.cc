@@ -27,8 +27,12 @@
 #ifdef PD_MOCK_EXTENSION_H
 // table input `T` receives a rows-form gradient whose rows are the flattened ids of input `I` (metadata for the loader)
 #define REC_SELECTED_ROWS(T, I) .Note("selected_rows=" T ":" I)
+// input `T` is a PS record table the gradient operator updates in place: the loader lists it with the program's sparse
+// tables (pass checkpoints, shrink, save) under the variable's name
+#define REC_PS_TABLE(T) .Note("ps_table=" T)
 #else
 #define REC_SELECTED_ROWS(T, I)
+#define REC_PS_TABLE(T)
 #endif
 
 #define REC_CALL(expr) PD_CHECK((expr) == REC_OK, #expr ": ", rec_last_error())
@@ -341,6 +345,180 @@ std::vector<Tensor> RecDinAttBwd(const Tensor& hist_item, const Tensor& hist_cat
   return {g_hi, g_hc, g_ti, g_tc};
 }
 
+// =====================================================================================================================
+// rec_multislot_sumpool — replaces the loop of models/rank/slot_dnn/net.py:63-77 (and dnn/static_model_lod.py:70-97):
+// for every slot `sparse_embedding(padding_idx=0) -> sequence_pool('sum')`, then concat(axis=1) — ALL slots of the batch
+// in one launch (rec_multislot_sumpool_fwd).  The custom-op interface hands a kernel dense tensors without their LoD, so
+// the multi-value slots arrive the way every custom sum-pool operator is fed, as two dense tensors:
+//   Values  [nnz] (or [nnz,1]) i64 : the ids of slot 0's B segments, then slot 1's, ... (slot-major CSR)
+//   Offsets [S, B+1] i64           : segment (s, b) = Values[Offsets[s,b] .. Offsets[s,b+1])   (absolute offsets)
+//   W       [N, stride] f32        : the table; a row's embedding = its first emb_dim floats (stride == emb_dim for a
+//                                    plain [dict_dim, emb_dim] parameter, wider for a record table)
+//   key_mode 0: ids are rows of W;  1: uint64 feasigns hashed to rows on the device (row = 1 + mix64(f) % (N-1))
+//   -> Out [B, S*emb_dim], Counts [B,S] i32 (ids pooled per segment, padding skipped), SegOfValue [nnz] i32 = b*S+s,
+//      Rows [nnz] i64 (table row of every value; dropped ones -> the padding row), Status [1] i32.
+// =====================================================================================================================
+rec_multislot_desc ms_desc(int64_t B, int64_t S, int emb_dim, const Shape& w, int64_t padding_idx, int key_mode) {
+  rec_multislot_desc d;
+  d.batch = B;
+  d.num_slots = static_cast<int32_t>(S);
+  d.emb_dim = emb_dim;
+  d.row_stride = static_cast<int32_t>(w[1]);
+  d.key_mode = key_mode;
+  d.num_rows = w[0];
+  d.padding_idx = padding_idx;
+  d.lod_stride = 0;
+  d.out_stride = 0;
+  d.state_offset = 0;
+  d.init_dims = 0;
+  d.init_range = 0.f;      // plain memory: a key that was never pushed reads as zeros (Paddle's zero_init default)
+  d.init_seed = 0;
+  return d;
+}
+std::vector<Tensor> RecMultislotFwd(const Tensor& values, const Tensor& offsets, const Tensor& w, int emb_dim,
+                                    int64_t padding_idx, int key_mode) {
+  PD_CHECK(values.dtype() == DataType::INT64 && (values.shape().size() == 1 ||
+                                                 (values.shape().size() == 2 && values.shape()[1] == 1)),
+           "Values must be [nnz] or [nnz,1] int64");
+  want(offsets, DataType::INT64, 2, "Offsets");
+  want(w, DataType::FLOAT32, 2, "W");
+  const int64_t S = offsets.shape()[0], B = offsets.shape()[1] - 1, nnz = values.numel();
+  PD_CHECK(S >= 1 && B >= 0 && emb_dim >= 1 && emb_dim <= w.shape()[1], "Offsets [S, B+1] / emb_dim <= row stride of W");
+  const rec_multislot_desc d = ms_desc(B, S, emb_dim, w.shape(), padding_idx, key_mode);
+  auto out = paddle::empty({B, S * emb_dim}, DataType::FLOAT32, w.place());
+  auto counts = paddle::empty({B, S}, DataType::INT32, w.place());
+  auto seg = paddle::empty({nnz}, DataType::INT32, w.place());
+  auto rows = paddle::empty({nnz}, DataType::INT64, w.place());
+  auto status = paddle::full({1}, 0, DataType::INT32, w.place());
+  if (B == 0) return {out, counts, seg, rows, status};
+  auto slot_base = paddle::full({S}, 0, DataType::INT64, w.place());          // Offsets are absolute
+  auto none = paddle::full({1}, 0, DataType::INT64, w.place());               // a batch whose every segment is empty
+  REC_CALL(rec_multislot_sumpool_fwd(&d, nnz ? values.data<int64_t>() : none.data<int64_t>(), offsets.data<int64_t>(),
+                                     slot_base.data<int64_t>(), w.data<float>(), out.data<float>(),
+                                     counts.data<int32_t>(), nnz ? seg.data<int32_t>() : nullptr,
+                                     nnz ? rows.data<int64_t>() : nullptr, status.data<int32_t>(), w.stream()));
+  return {out, counts, seg, rows, status};
+}
+std::vector<Shape> RecMultislotInferShape(const Shape& values, const Shape& offsets, const Shape& w, int emb_dim,
+                                          int64_t padding_idx, int key_mode) {
+  int64_t nnz = 1;
+  for (auto v : values) nnz *= v;
+  const int64_t S = offsets[0], B = offsets[1] - 1;
+  return {{B, S * emb_dim}, {B, S}, {nnz}, {nnz}, {1}};
+}
+std::vector<DataType> RecMultislotInferDtype(DataType values, DataType offsets, DataType w) {
+  return {w, DataType::INT32, DataType::INT32, DataType::INT64, DataType::INT32};
+}
+// gradient: the SelectedRows VALUE of the table, one row per pooled value (its segment's gradient row), rows = the
+// forward's Rows output — the merge (MergeAdd) drops the padding row and sums duplicates, exactly as for nn.Embedding.
+std::vector<Tensor> RecMultislotBwd(const Tensor& seg, const Tensor& d_out, int emb_dim) {
+  want(d_out, DataType::FLOAT32, 2, "Grad(Out)");
+  const int64_t B = d_out.shape()[0], nnz = seg.numel();
+  PD_CHECK(emb_dim >= 1 && d_out.shape()[1] % emb_dim == 0, "Grad(Out) must be [B, S*emb_dim]");
+  const int64_t S = d_out.shape()[1] / emb_dim;
+  auto row_grad = paddle::empty({nnz, emb_dim}, DataType::FLOAT32, d_out.place());
+  const rec_multislot_desc d = ms_desc(B, S, emb_dim, {1, emb_dim}, -1, 0);
+  if (nnz)
+    REC_CALL(rec_multislot_sumpool_bwd(&d, nnz, seg.data<int32_t>(), d_out.data<float>(), row_grad.data<float>(),
+                                       d_out.stream()));
+  return {row_grad};
+}
+std::vector<Shape> RecMultislotBwdInferShape(const Shape& seg, const Shape& d_out, int emb_dim) {
+  return {{seg[0], emb_dim}};
+}
+
+// =====================================================================================================================
+// rec_ps_pull / its gradient = the push — replaces the gpubox branch of models/rank/dnn/net.py:67-82 (and
+// wide_deep/net.py:80): `static.nn.sparse_embedding(size=[N, D+2])` + `continuous_value_model(emb, show_click, False)`
+// for ALL slots of the batch, i.e. the pull of the GPU parameter server (core.PSGPU, tools/static_gpubox_trainer.py:
+// 152-160,256), on the engine's record table
+//   Rec [rows, stride] f32, row = W(D) = [embed_w, embedx(D-1)] | show click g2sum_w g2sum_x state delta_score unseen_days
+// (a persistable, non-trainable variable of the program — paddle.static.create_global_var).
+//   Keys [B,S] i64 feasigns (= paddle.concat(sparse_inputs, 1)); ShowClick [B,2] f32 = [1, label] (dnn/static_model.py:
+//   86-94); Anchor [1] f32: a trainable dummy so that the framework schedules the gradient operator at all — Paddle's
+//   own pull_gpups_sparse takes its `W` input for the same reason.
+//   -> Out [B,S,D] (the CVM columns are never attached: use_cvm=False strips them), Rows [B*S] i64, Status [1] i32.
+// The gradient operator IS the table update: SelectedRows merge of the B*S gradient rows (rec_ids_group) +
+// CtrCommonAccessor::Update + SparseAdaGradSGDRule on the touched records (rec_ps_push_rows), in place on Rec, with
+// show = 1 per occurrence, click = the sample's label and the gradient of the SUMMED loss (grad_scale = B).
+//   accessor = {lr, initial_g2sum, min_bound, max_bound, initial_range,  (embed_w)   5 floats
+//               lr, initial_g2sum, min_bound, max_bound, initial_range,  (embedx)     5 floats
+//               embedx_threshold, nonclk_coeff, click_coeff, seed}  — table_parameters.embedding.accessor of
+//   slot_dnn/config_online.yaml:57-89; Paddle's defaults: {0.05, 3, -10, 10, 1e-4} x 2, 10, 0.1, 1.
+// =====================================================================================================================
+std::vector<Tensor> RecPsPull(const Tensor& keys, const Tensor& rec, const Tensor& show_click, const Tensor& anchor,
+                              int emb_dim, std::vector<float> accessor) {
+  want(keys, DataType::INT64, 2, "Keys");
+  want(rec, DataType::FLOAT32, 2, "Rec");
+  const int64_t B = keys.shape()[0], S = keys.shape()[1], n = B * S, rows_total = rec.shape()[0];
+  PD_CHECK(emb_dim >= 2 && emb_dim + 7 <= rec.shape()[1], "Rec rows hold W(emb_dim) + 7 statistics");
+  PD_CHECK(show_click.numel() == 2 * B && anchor.numel() == 1, "ShowClick [B,2], Anchor [1]");
+  auto out = paddle::empty({B, S, emb_dim}, DataType::FLOAT32, rec.place());
+  auto rows = paddle::empty({n}, DataType::INT64, rec.place());
+  auto status = paddle::full({1}, 0, DataType::INT32, rec.place());
+  if (n == 0) return {out, rows, status};
+  void* st = rec.stream();
+  REC_CALL(rec_feasign_rows(n, rows_total, keys.data<int64_t>(), rows.data<int64_t>(), st));   // 0 -> row 0 (padding)
+  REC_CALL(rec_emb_gather(n, emb_dim, static_cast<int32_t>(rec.shape()[1]), rows_total, /*padding_idx=*/-1,
+                          rows.data<int64_t>(), rec.data<float>(), out.data<float>(), 0, 0, status.data<int32_t>(), st));
+  return {out, rows, status};
+}
+std::vector<Shape> RecPsPullInferShape(const Shape& keys, const Shape& rec, const Shape& show_click, const Shape& anchor,
+                                       int emb_dim, std::vector<float> accessor) {
+  return {{keys[0], keys[1], emb_dim}, {keys[0] * keys[1]}, {1}};
+}
+std::vector<DataType> RecPsPullInferDtype(DataType keys, DataType rec, DataType show_click, DataType anchor) {
+  return {rec, DataType::INT64, DataType::INT32};
+}
+std::vector<Tensor> RecPsPush(const Tensor& rows, const Tensor& rec, const Tensor& show_click, const Tensor& d_out,
+                              int emb_dim, std::vector<float> accessor) {
+  want(d_out, DataType::FLOAT32, 3, "Grad(Out)");
+  PD_CHECK(accessor.size() == 14, "accessor: 14 floats (see rec_paddle_ops.cc), got ", accessor.size());
+  const int64_t B = d_out.shape()[0], S = d_out.shape()[1], n = B * S, rows_total = rec.shape()[0];
+  PD_CHECK(rows.numel() == n && d_out.shape()[2] == emb_dim, "Rows / Grad(Out) shapes");
+  auto d_anchor = paddle::full({1}, 0, DataType::FLOAT32, rec.place());
+  if (n == 0) return {d_anchor};
+  void* st = rec.stream();
+  size_t ws_bytes = 0;
+  REC_CALL(rec_ids_group_workspace_bytes(n, rows_total, &ws_bytes));
+  auto ws = workspace(ws_bytes, rec);
+  auto spos = paddle::empty({n}, DataType::INT32, rec.place());
+  auto uniq = paddle::empty({n}, DataType::INT64, rec.place());
+  auto seg = paddle::empty({n + 1}, DataType::INT32, rec.place());
+  auto nu = paddle::full({4}, 0, DataType::INT32, rec.place());
+  auto status = paddle::full({1}, 0, DataType::INT32, rec.place());
+  auto click = paddle::empty({B}, DataType::INT64, rec.place());
+  REC_CALL(rec_cast_f32_i64(B, show_click.data<float>() + 1, 2, click.data<int64_t>(), st));
+  // feasign 0 — and only feasign 0 — maps to row 0: dropping row 0 drops exactly the padding key
+  REC_CALL(rec_ids_group(n, static_cast<int32_t>(S), rows_total, /*padding row*/ 0, rows.data<int64_t>(), nullptr,
+                         spos.data<int32_t>(), uniq.data<int64_t>(), seg.data<int32_t>(), nu.data<int32_t>(),
+                         status.data<int32_t>(), ws.data<uint8_t>(), ws_bytes, st));
+  const rec_ps_layout lay{static_cast<int32_t>(rec.shape()[1]), /*embed_off*/ 0, /*embedx_off*/ 1, emb_dim - 1,
+                          /*stat_off*/ emb_dim};
+  const float* a = accessor.data();
+  rec_ps_accessor acc;
+  acc.lr = a[0]; acc.initial_g2sum = a[1]; acc.min_bound = a[2]; acc.max_bound = a[3]; acc.initial_range = a[4];
+  acc.x_lr = a[5]; acc.x_initial_g2sum = a[6]; acc.x_min_bound = a[7]; acc.x_max_bound = a[8]; acc.x_initial_range = a[9];
+  acc.embedx_threshold = a[10]; acc.nonclk_coeff = a[11]; acc.click_coeff = a[12];
+  acc.grad_scale = static_cast<float>(B);      // Paddle pushes the gradient of the SUMMED loss
+  acc.show_scale = 1;
+  acc.embed_zero_init = 1;
+  acc.seed = static_cast<uint64_t>(a[13]);
+  acc.row_mul = 1;
+  acc.row_add = 0;
+  const rec_grad_src gx{d_out.data<float>(), {1, 0, 0, nullptr, nullptr, 0}, emb_dim, 1};   // embedx = columns 1..D-1
+  const rec_grad_src gw{d_out.data<float>(), {1, 0, 0, nullptr, nullptr, 0}, emb_dim, 0};   // embed_w = column 0
+  // Rec is updated IN PLACE: the PS table has no dense gradient, the "gradient" of the pull is the accessor's push
+  REC_CALL(rec_ps_push_rows(n, static_cast<int32_t>(S), &lay, nu.data<int32_t>(), uniq.data<int64_t>(),
+                            seg.data<int32_t>(), spos.data<int32_t>(), &gx, &gw, /*show: 1 per occurrence*/ nullptr,
+                            click.data<int64_t>(), const_cast<float*>(rec.data<float>()), &acc, st));
+  return {d_anchor};
+}
+std::vector<Shape> RecPsPushInferShape(const Shape& rows, const Shape& rec, const Shape& show_click, const Shape& d_out,
+                                       int emb_dim, std::vector<float> accessor) {
+  return {{1}};
+}
+
 }  // namespace
 
 PD_BUILD_OP(rec_deepfm_fm)
@@ -393,3 +571,33 @@ PD_BUILD_GRAD_OP(rec_din_attention_pool)
     .SetKernelFn(PD_KERNEL(RecDinAttBwd))
     REC_SELECTED_ROWS("WHistItem", "HistItem") REC_SELECTED_ROWS("WHistCat", "HistCat")
     REC_SELECTED_ROWS("WTgtItemSeq", "TgtItemSeq") REC_SELECTED_ROWS("WTgtCatSeq", "TgtCatSeq");
+
+PD_BUILD_OP(rec_multislot_sumpool)
+    .Inputs({"Values", "Offsets", "W"})
+    .Outputs({"Out", "Counts", "SegOfValue", "Rows", "Status"})
+    .Attrs({"emb_dim: int", "padding_idx: int64_t", "key_mode: int"})
+    .SetKernelFn(PD_KERNEL(RecMultislotFwd))
+    .SetInferShapeFn(PD_INFER_SHAPE(RecMultislotInferShape))
+    .SetInferDtypeFn(PD_INFER_DTYPE(RecMultislotInferDtype));
+PD_BUILD_GRAD_OP(rec_multislot_sumpool)
+    .Inputs({"SegOfValue", paddle::Grad("Out")})
+    .Outputs({paddle::Grad("W")})
+    .Attrs({"emb_dim: int"})
+    .SetKernelFn(PD_KERNEL(RecMultislotBwd))
+    .SetInferShapeFn(PD_INFER_SHAPE(RecMultislotBwdInferShape))
+    REC_SELECTED_ROWS("W", "Rows");
+
+PD_BUILD_OP(rec_ps_pull)
+    .Inputs({"Keys", "Rec", "ShowClick", "Anchor"})
+    .Outputs({"Out", "Rows", "Status"})
+    .Attrs({"emb_dim: int", "accessor: std::vector<float>"})
+    .SetKernelFn(PD_KERNEL(RecPsPull))
+    .SetInferShapeFn(PD_INFER_SHAPE(RecPsPullInferShape))
+    .SetInferDtypeFn(PD_INFER_DTYPE(RecPsPullInferDtype))
+    REC_PS_TABLE("Rec");
+PD_BUILD_GRAD_OP(rec_ps_pull)
+    .Inputs({"Rows", "Rec", "ShowClick", paddle::Grad("Out")})
+    .Outputs({paddle::Grad("Anchor")})
+    .Attrs({"emb_dim: int", "accessor: std::vector<float>"})
+    .SetKernelFn(PD_KERNEL(RecPsPush))
+    .SetInferShapeFn(PD_INFER_SHAPE(RecPsPushInferShape));

@@ -768,7 +768,54 @@ def _co_din_bwd(x, attrs):
     return [dh[:, :Ei].contiguous(), dh[:, Ei:].contiguous(), dq[:, :Ei].contiguous(), dq[:, Ei:].contiguous()]
 
 
+def _co_multislot_fwd(x, attrs):
+    values, offsets, W = x
+    S, D = offsets.shape[0], int(attrs["emb_dim"])
+    mb = MultislotBatch(values.reshape(-1), offsets, torch.zeros(S + 1, dtype=torch.int64))      # absolute offsets
+    out, cnt, seg, rows, _ = multislot_sumpool(mb, W[:, :D], W.shape[0], attrs["padding_idx"], attrs["key_mode"])
+    n = values.numel()
+    return [out, cnt, seg[:n].to(torch.int32), rows[:n].to(torch.int64), torch.zeros(1, dtype=torch.int32)]
+
+
+def _co_multislot_bwd(x, attrs):
+    seg, d_out = x
+    D = int(attrs["emb_dim"])
+    return [d_out.reshape(-1, D)[seg.to(torch.int64)].contiguous()]
+
+
+def _co_ps_table(rec, attrs):
+    a = [float(v) for v in attrs["accessor"]]
+    t = PsTable(1, int(attrs["emb_dim"]), "cpu", kind="slot", row_stride=rec.shape[1], lr=a[0], initial_g2sum=a[1],
+                bounds=(a[2], a[3]), initial_range=a[4], embedx_lr=a[5], embedx_initial_g2sum=a[6],
+                embedx_bounds=(a[7], a[8]), embedx_initial_range=a[9], embedx_threshold=a[10], nonclk_coeff=a[11],
+                click_coeff=a[12], seed=int(a[13]))
+    t.rec, t.num_rows = rec, rec.shape[0]
+    return t
+
+
+def _co_ps_pull_fwd(x, attrs):
+    keys, rec, show_click, anchor = x
+    B, S = keys.shape
+    D = int(attrs["emb_dim"])
+    rows = feasign_rows(keys.reshape(-1).contiguous(), rec.shape[0])
+    return [rec[rows, :D].reshape(B, S, D).contiguous(), rows, torch.zeros(1, dtype=torch.int32)]
+
+
+def _co_ps_pull_bwd(x, attrs):
+    rows, rec, show_click, d_out = x
+    B, S, D = d_out.shape
+    table = _co_ps_table(rec, attrs)
+    table.accessor.grad_scale = float(B)
+    groups = IdGroups(rows.numel(), "cpu")
+    ids_group(rows, rec.shape[0], 0, None, None, None, groups)
+    click = show_click[:, 1].round().to(torch.int64)
+    ps_push_rows(table, groups, d_out.reshape(B * S, D).contiguous(), S, click=click)      # in place on rec
+    return [torch.zeros(1)]
+
+
 CUSTOM_OPS = {
+    "rec_multislot_sumpool": (_co_multislot_fwd, _co_multislot_bwd),
+    "rec_ps_pull": (_co_ps_pull_fwd, _co_ps_pull_bwd),
     "rec_deepfm_fm": (_co_deepfm_fwd, _co_deepfm_bwd),
     "rec_crossnet_v2_layer": (_co_cross_v2_fwd, _co_cross_v2_bwd),
     "rec_crossnet_mix_layer": (_co_cross_mix_fwd, _co_cross_mix_bwd),

@@ -4,7 +4,7 @@ it (integration/*.patch) — SURVEY.md §8(b), VERDICT r04 item 1.
 not gpu:
   * the shim builds against the stand-in paddle/extension.h, loads, registers the operators the patches call, and its
     InferShape / InferDtype functions describe the outputs (host functions: they run here);
-  * the patches apply to the staged reference tree, touch nothing but the three net.py files, and add <= 15 lines each
+  * the patches apply to the staged reference tree, touch nothing but the five net.py files, and add <= 15 lines each
     per edited block;
   * the reference's UNMODIFIED tools/trainer.py on the PATCHED net.py files produces the trajectory of the unpatched run
     (deepfm, dcn_v2 with CrossNetMix and with CrossNetV2, din) — operator stand-in backend (REC_COMPAT_KERNELS), so this
@@ -38,6 +38,11 @@ EXPECTED = {
     "rec_din_attention_pool": (["HistItem", "HistCat", "TgtItemSeq", "TgtCatSeq", "Mask", "WHistItem", "WHistCat",
                                 "WTgtItemSeq", "WTgtCatSeq", "AttW1", "AttB1", "AttW2", "AttB2", "AttW3", "AttB3"],
                                ["Out", "AttWeight", "Act1", "Status"], []),
+    # VERDICT r05 missing 2: the lookup / sum-pool and the GPU-PS pull / push pair
+    "rec_multislot_sumpool": (["Values", "Offsets", "W"], ["Out", "Counts", "SegOfValue", "Rows", "Status"],
+                              [("emb_dim", "int"), ("padding_idx", "int64_t"), ("key_mode", "int")]),
+    "rec_ps_pull": (["Keys", "Rec", "ShowClick", "Anchor"], ["Out", "Rows", "Status"],
+                    [("emb_dim", "int"), ("accessor", "std::vector<float>")]),
 }
 
 
@@ -63,10 +68,14 @@ def test_shim_registers_the_operators_the_patches_call():
             assert n in ins or n in outs or (n.endswith("@GRAD") and n[:-5] in outs), (name, n)
         for n in g.outputs:
             assert n.endswith("@GRAD") and n[:-5] in ins, (name, n)
-        for table, ids in g.selected_rows.items():
-            assert table in ins and ids in ins and table + "@GRAD" in g.outputs, (name, table)
+        for table, ids in g.selected_rows.items():      # the SelectedRows rows: an id input, or the Rows the forward emits
+            assert table in ins and (ids in ins or ids in outs) and table + "@GRAD" in g.outputs, (name, table)
     assert s.grad["rec_deepfm_fm"].selected_rows == {"W": "Ids", "W1": "Ids"}
     assert len(s.grad["rec_din_attention_pool"].selected_rows) == 4
+    assert s.grad["rec_multislot_sumpool"].selected_rows == {"W": "Rows"}
+    # the push is the gradient operator of the pull; the record table is updated in place and listed with the program
+    assert s.fwd["rec_ps_pull"].ps_tables == ["Rec"] and s.grad["rec_ps_pull"].outputs == ["Anchor@GRAD"]
+    assert s.grad["rec_ps_pull"].attrs == s.fwd["rec_ps_pull"].attrs and s.grad["rec_ps_pull"].has_shape
     # every operator a patch calls is registered
     called = set()
     for p in sorted(os.listdir(os.path.join(REPO, "integration"))):
@@ -103,6 +112,19 @@ def test_infer_shape_and_dtype_functions():
     assert got[2][0] in ((B, T, 80), (1,))          # layer-1 activations are saved for the reference's shape only
     with pytest.raises(TypeError):
         s.infer(s.fwd["rec_crossnet_v2_layer"], [e(B, d)], {})
+    nnz, Sm = 40, 5
+    a = {"emb_dim": 9, "padding_idx": 0, "key_mode": 1}
+    got = s.infer(s.fwd["rec_multislot_sumpool"], [e(nnz, 1, dt=torch.int64), e(Sm, B + 1, dt=torch.int64), e(N, 16)], a)
+    assert got == [((B, Sm * 9), torch.float32), ((B, Sm), torch.int32), ((nnz,), torch.int32), ((nnz,), torch.int64),
+                   ((1,), torch.int32)]
+    got = s.infer(s.grad["rec_multislot_sumpool"], [e(nnz, dt=torch.int32), e(B, Sm * 9)], {"emb_dim": 9})
+    assert got[0][0] == (nnz, 9)
+    acc = [0.05, 3.0, -10.0, 10.0, 1e-4] * 2 + [10.0, 0.1, 1.0, 2025.0]
+    got = s.infer(s.fwd["rec_ps_pull"], [ids, e(N, 16), e(B, 2), e(1)], {"emb_dim": 9, "accessor": acc})
+    assert got == [((B, S, 9), torch.float32), ((B * S,), torch.int64), ((1,), torch.int32)]
+    got = s.infer(s.grad["rec_ps_pull"], [e(B * S, dt=torch.int64), e(N, 16), e(B, 2), e(B, S, 9)],
+                  {"emb_dim": 9, "accessor": acc})
+    assert got[0][0] == (1,)
 
 
 def test_kernel_errors_surface_as_python_exceptions():
@@ -116,10 +138,14 @@ def test_kernel_errors_surface_as_python_exceptions():
     with pytest.raises(RuntimeError, match="wrong dtype"):
         s.run(s.fwd["rec_deepfm_fm"], [torch.zeros(B, 3), torch.zeros(B, 2), torch.zeros(5, 4), torch.zeros(5, 1),
                                        torch.zeros(1, 2, 4), torch.zeros(2)], {"padding_idx": 0})
+    # a list-of-float attribute reaches the kernel function as std::vector<float> (13 instead of 14 entries: PD_CHECK)
+    with pytest.raises(RuntimeError, match="accessor: 14 floats"):
+        s.run(s.grad["rec_ps_pull"], [torch.zeros(6, dtype=torch.int64), torch.zeros(5, 16), torch.zeros(3, 2),
+                                      torch.zeros(3, 2, 9)], {"emb_dim": 9, "accessor": [0.0] * 13})
 
 
 @needs_trees
-def test_patches_touch_only_the_three_net_files_and_are_small():
+def test_patches_touch_only_the_net_files_and_are_small():
     changed = []
     for root, _, files in os.walk(STAGED):
         if "__pycache__" in root or "output_model" in root:
@@ -129,7 +155,8 @@ def test_patches_touch_only_the_three_net_files_and_are_small():
             other = os.path.join(PATCHED, rel)
             if f.endswith(".py") and os.path.exists(other) and open(os.path.join(root, f), "rb").read() != open(other, "rb").read():
                 changed.append(rel)
-    assert sorted(changed) == ["models/rank/dcn_v2/net.py", "models/rank/deepfm/net.py", "models/rank/din/net.py"]
+    assert sorted(changed) == ["models/rank/dcn_v2/net.py", "models/rank/deepfm/net.py", "models/rank/din/net.py",
+                               "models/rank/dnn/net.py", "models/rank/slot_dnn/net.py"]
     for p in sorted(os.listdir(os.path.join(REPO, "integration"))):
         if not p.endswith(".patch"):
             continue
@@ -140,7 +167,9 @@ def test_patches_touch_only_the_three_net_files_and_are_small():
             assert len(added) <= 15, (p, len(added))
     # the drivers are byte-identical in both trees
     for rel in ("tools/trainer.py", "tools/utils/utils_single.py", "models/rank/deepfm/dygraph_model.py",
-                "models/rank/deepfm/config.yaml", "models/rank/din/dygraph_model.py", "models/rank/dcn_v2/dygraph_model.py"):
+                "models/rank/deepfm/config.yaml", "models/rank/din/dygraph_model.py", "models/rank/dcn_v2/dygraph_model.py",
+                "tools/static_gpubox_trainer.py", "models/rank/dnn/static_model.py", "models/rank/dnn/config_gpubox.yaml",
+                "models/rank/slot_dnn/static_model.py"):
         assert open(os.path.join(STAGED, rel), "rb").read() == open(os.path.join(PATCHED, rel), "rb").read(), rel
 
 
@@ -316,6 +345,60 @@ q = np.concatenate([tabs[2].detach().cpu().numpy()[ti.cpu().numpy()], tabs[3].de
 r_out = din_ref.attention_pool(h, q, mask.cpu().numpy().astype(np.float32), [a.cpu().numpy() for a in aw], [a.cpu().numpy() for a in ab])
 np.testing.assert_allclose(out.detach().cpu().numpy(), r_out, rtol=1e-5, atol=1e-5)
 print("din_attention_pool ok")
+# ---- rec_multislot_sumpool: shim == ops.py bit for bit (forward: pooled sums, counts, segments, rows; rows-form gradient)
+from oracle import slot_dnn_ref as SM
+B, S, D, NT = 37, 12, 9, 5003
+rng = np.random.default_rng(3)
+vals, offs = [], np.zeros((S, B + 1), np.int64)
+for s_ in range(S):
+    for b_ in range(B):
+        k_ = 0 if rng.random() < 0.2 else int(rng.integers(1, 6))
+        v_ = rng.integers(1, 2 ** 63, size=k_, dtype=np.int64)
+        v_[rng.random(k_) < 0.1] = 0                                    # explicit padding ids inside a segment
+        vals.extend(v_.tolist()); offs[s_, b_ + 1] = len(vals)
+    if s_ + 1 < S: offs[s_ + 1, 0] = len(vals)
+offs[:, 0] = np.concatenate([[0], offs[:-1, -1]])
+values = torch.as_tensor(np.asarray(vals, np.int64)).to(dev); offsets = torch.as_tensor(offs).to(dev)
+rec_t = torch.zeros(NT, 16, device=dev); rec_t[:, :D] = rnd(NT, D, scale=0.3)
+Wp = torch.nn.Parameter(rec_t)
+out, counts, seg, rows, st = rec_ops.rec_multislot_sumpool(values, offsets, Wp, emb_dim=D, padding_idx=0, key_mode=1)
+mb = ops.MultislotBatch(values, offsets, torch.zeros(S + 1, dtype=torch.int64, device=dev))
+o_out, o_cnt, o_seg, o_rows, _ = ops.multislot_sumpool(mb, rec_t[:, :D], NT, 0, 1)
+eq(out, o_out, "multislot out"); eq(counts, o_cnt, "multislot counts"); eq(seg, o_seg[:values.numel()], "seg"); eq(rows, o_rows[:values.numel()], "rows")
+r_out, r_cnt, r_seg, r_rows = SM.multislot_sumpool(np.asarray(vals, np.int64), offs, np.zeros(S + 1, np.int64), rec_t[:, :D].cpu().numpy(), 0, 1, NT)
+assert np.array_equal(counts.cpu().numpy(), r_cnt) and np.array_equal(rows.cpu().numpy(), r_rows) and np.array_equal(seg.cpu().numpy(), r_seg)
+np.testing.assert_allclose(out.detach().cpu().numpy(), r_out, rtol=1e-5, atol=1e-6)
+gd = rnd(B, S * D)
+(out * gd).sum().backward()
+(sid, val, pad, div), = Wp._sparse_grads
+eq(sid, rows, "SelectedRows rows = the operator's Rows"); assert pad == 0 and div == 1 and Wp.grad is None
+eq(val, gd.reshape(B * S, D)[seg.long()], "rows-form gradient")
+eq(val, ops.multislot_sumpool_bwd(seg, gd, S, D), "rec_multislot_sumpool_bwd through ops.py")
+print("multislot_sumpool ok")
+
+# ---- rec_ps_pull: pull == feasign_rows + emb_gather; its gradient operator == ids_group + ps_push_rows on a twin table
+B, S, D, NT = 64, 26, 9, 20011
+acc = [0.05, 3.0, -10.0, 10.0, 1e-4] * 2 + [10.0, 0.1, 1.0, 2025.0]
+keys = torch.randint(1, 400, (B, S), generator=g).to(dev); keys[::5, 2] = 0
+twin = ops.PsTable(NT, D, dev, kind="slot")
+recv = torch.zeros(NT, 16, device=dev)
+label = (torch.rand(B, generator=g) < 0.3).to(torch.int64).to(dev)
+show_click = torch.stack([torch.ones(B, device=dev), label.float()], 1).contiguous()
+anchor = torch.nn.Parameter(torch.zeros(1, device=dev))
+for step_ in range(3):                                                  # step 0 creates keys, later ones train / extend them
+    emb, prow, st = rec_ops.rec_ps_pull(keys, recv, show_click, anchor, emb_dim=D, accessor=acc)
+    rows_ = ops.feasign_rows(keys.reshape(-1).contiguous(), NT)
+    w_, _ = ops.emb_gather(rows_, twin.W, None, ops.new_status(dev))
+    eq(prow, rows_, "pull rows"); eq(emb.reshape(B * S, D), w_, "pulled values")
+    gd = rnd(B, S, D, scale=0.01)
+    (emb * gd).sum().backward()
+    grp = ops.IdGroups(B * S, dev)
+    ops.ids_group(rows_, NT, 0, ws, None, ops.new_status(dev), grp)
+    twin.accessor.grad_scale = float(B)
+    ops.ps_push_rows(twin, grp, gd.reshape(B * S, D).contiguous(), S, click=label)
+    eq(recv, twin.rec, "record table after push " + str(step_))
+assert float(recv[:, D].sum()) == 3 * int((keys != 0).sum()) and float(recv[:, D + 4].max()) >= 1
+print("ps_pull / push ok")
 print("custom ops through the shim: ALL OK")
 """
 

@@ -23,6 +23,9 @@ from conftest import REPO
 # in the STAGED byte copy of the reference files (oracle/_ref/PaddleRec, made by oracle/make_ref_tree.py; build() does
 # that in the build container and the copy travels to the GPU box) — never inside /root/reference.
 REF = os.path.join(REPO, "oracle", "_ref", "PaddleRec")
+PATCHED = os.path.join(REPO, "oracle", "_ref", "PaddleRec_rec_ops")      # the same tree with integration/*.patch applied
+needs_patched = pytest.mark.skipif(not os.path.isfile(os.path.join(PATCHED, "models", "rank", "dnn", "net.py")),
+                                   reason="patched reference tree not present (python integration/apply.py)")
 pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "tools", "static_gpubox_trainer.py")),
                                 reason="staged reference tree not present (python oracle/make_ref_tree.py)")
 
@@ -34,7 +37,7 @@ MODELS = {   # the two nets the reference wires for gpubox (dnn/net.py:71, wide_
 }
 
 
-def _run(tmp_path, gpu, epochs=2, gpus="0", batch=None, name="out", extra_env=None, model="dnn", args=()):
+def _run(tmp_path, gpu, epochs=2, gpus="0", batch=None, name="out", extra_env=None, model="dnn", args=(), tree=REF):
     env = dict(os.environ, FLAGS_selected_gpus=gpus, TRAINING_ROLE="TRAINER", PADDLE_TRAINER_ID="0", OMP_NUM_THREADS="4",
                PYTHONDONTWRITEBYTECODE="1")
     env.pop("WORLD_SIZE", None)
@@ -46,15 +49,15 @@ def _run(tmp_path, gpu, epochs=2, gpus="0", batch=None, name="out", extra_env=No
         env["REC_COMPAT_KERNELS"] = "cpu_kernels"
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(REPO, "tests"), REPO, env.get("PYTHONPATH", "")])
     out = tmp_path / name
-    cmd = [sys.executable, "-m", "paddlerec_amd.run_reference", os.path.join(REF, "tools", "static_gpubox_trainer.py"),
+    cmd = [sys.executable, "-m", "paddlerec_amd.run_reference", os.path.join(tree, "tools", "static_gpubox_trainer.py"),
            "-m", MODELS[model][0]] + list(args) + ["-o", "runner.epochs=%d" % epochs,
            "runner.use_gpu=%d" % (1 if gpu else 0), "runner.model_save_path=%s" % out]
     if batch:
         cmd.append("runner.train_batch_size=%d" % batch)
-    r = subprocess.run(cmd, cwd=REF, env=env, capture_output=True, text=True, timeout=900)
-    for f in os.listdir(REF):                                   # the script dumps its programs into the cwd
+    r = subprocess.run(cmd, cwd=tree, env=env, capture_output=True, text=True, timeout=900)
+    for f in os.listdir(tree):                                  # the script dumps its programs into the cwd
         if f.endswith("_program.prototxt") or f == "train_result_dict.txt":
-            os.remove(os.path.join(REF, f))
+            os.remove(os.path.join(tree, f))
     log = r.stdout + r.stderr
     assert r.returncode == 0, log[-4000:]
     return log, out
@@ -207,15 +210,15 @@ def _oracle_replay(init, data_lines, epochs, batch, table_rows, D=9):
     return rec, mlp_w, mlp_b
 
 
-def _check_against_oracles(tmp_path, gpu):
+def _check_against_oracles(tmp_path, gpu, tree=REF):
     """the entry-point test compared log lines and counter sums only.  Here the pass checkpoint the
     UNMODIFIED script wrote — every record of the PS table (weights, both g2sums, counters, state) and the dense
     parameters — against an independent replay on the oracles, from the same initial dense parameters
     (REC_COMPAT_DUMP_INIT) and a small hashed table (REC_GPUBOX_TABLE_ROWS)."""
     epochs, rows_n = 2, 20011
     init_path = str(tmp_path / "init.npz")
-    log, out = _run(tmp_path, gpu, epochs, name="orc", extra_env={"REC_COMPAT_DUMP_INIT": init_path,
-                                                                  "REC_GPUBOX_TABLE_ROWS": str(rows_n)})
+    log, out = _run(tmp_path, gpu, epochs, name="orc", tree=tree,
+                    extra_env={"REC_COMPAT_DUMP_INIT": init_path, "REC_GPUBOX_TABLE_ROWS": str(rows_n)})
     init = dict(np.load(init_path))
     assert len(init) == 10 and init["dense.0"].shape == (26 * 9 + 13, 512)
     data = open(os.path.join(REF, "models/rank/dnn/data/sample_data/train/sample_train.txt")).read().strip().split("\n")
@@ -250,3 +253,53 @@ def test_static_gpubox_trainer_checkpoint_equals_the_oracles_cpu_backend(tmp_pat
 @pytest.mark.gpu
 def test_static_gpubox_trainer_checkpoint_equals_the_oracles_on_the_hip_kernels(tmp_path, engine_lib):
     _check_against_oracles(tmp_path, gpu=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# integration/dnn_net.patch: the gpubox branch of dnn/net.py calling the compiled custom operator rec_ps_pull (its gradient
+# operator is the accessor's push) instead of static.nn.sparse_embedding + continuous_value_model — under the SAME
+# unmodified tools/static_gpubox_trainer.py (patched == unpatched == oracle)
+def _patched_equals_unpatched(tmp_path, gpu, tol):
+    epochs = 2
+    env = {"REC_GPUBOX_TABLE_ROWS": "20011", "REC_COMPAT_SEED": "99"}
+    loga, outa = _run(tmp_path, gpu, epochs, name="plain", extra_env=env)
+    logb, outb = _run(tmp_path, gpu, epochs, name="patched", extra_env=env, tree=PATCHED)
+    assert "rec_ps_pull" not in loga and "custom operator rec_ps_pull" in logb and "Run Success, Exit." in logb
+    a = np.load(os.path.join(str(outa), str(epochs - 1), "rec_gpubox.npz"))
+    b = np.load(os.path.join(str(outb), str(epochs - 1), "rec_gpubox.npz"))
+    assert sorted(a.files) == sorted(b.files)                      # same dense tensors (the anchor is no parameter of the
+    assert np.array_equal(a["table.embedding.rows"], b["table.embedding.rows"])          # program), same table, same keys
+    ra, rb = a["table.embedding.records"], b["table.embedding.records"]
+    D = 9
+    for col, what in ((D, "show"), (D + 1, "click"), (D + 4, "state"), (D + 6, "unseen_days")):
+        assert np.array_equal(ra[:, col], rb[:, col]), what
+    np.testing.assert_allclose(rb, ra, rtol=0, atol=tol * float(np.abs(ra[:, :D]).max()), err_msg="records")
+    for k in [k for k in a.files if k.startswith("dense.")]:
+        np.testing.assert_allclose(b[k], a[k], rtol=0, atol=tol * max(1.0, float(np.abs(a[k]).max())), err_msg=k)
+    ea = re.findall(r"Epoch: \d+, .* auc: ([0-9.]+)", loga)
+    eb = re.findall(r"Epoch: \d+, .* auc: ([0-9.]+)", logb)
+    assert len(ea) == epochs and [round(float(x), 5) for x in ea] == [round(float(x), 5) for x in eb]
+
+
+@needs_patched
+def test_patched_dnn_net_trains_like_the_unpatched_one_cpu_backend(tmp_path):
+    _patched_equals_unpatched(tmp_path, gpu=False, tol=1e-6)
+
+
+@needs_patched
+def test_patched_dnn_net_checkpoint_equals_the_oracles_cpu_backend(tmp_path):
+    _check_against_oracles(tmp_path, gpu=False, tree=PATCHED)
+
+
+@needs_patched
+@pytest.mark.gpu
+def test_patched_dnn_net_trains_like_the_unpatched_one_on_the_hip_kernels(tmp_path, engine_lib):
+    # the same kernels on both sides (rec_feasign_rows, rec_emb_gather, rec_ids_group, rec_ps_push_rows): the pull is
+    # bit-identical, the push sees the 26 slots' gradient rows in the same order
+    _patched_equals_unpatched(tmp_path, gpu=True, tol=1e-6)
+
+
+@needs_patched
+@pytest.mark.gpu
+def test_patched_dnn_net_checkpoint_equals_the_oracles_on_the_hip_kernels(tmp_path, engine_lib):
+    _check_against_oracles(tmp_path, gpu=True, tree=PATCHED)
