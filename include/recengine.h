@@ -706,8 +706,31 @@ int rec_accuracy_count(int64_t n, const float* pred, const int64_t* label, int64
  *   CrossNetMix      dcn_v2/net.py:278-320 : REC_EPI_BIAS_TANH for the low-rank projections
  * Row-major everywhere; Paddle's Linear.weight is [in,out] = B[K,N].
  *   trans_a: A is stored [K,M] (dW = X^T G);  trans_b: B is stored [N,K] (dX = G W^T).
- * Exact f32 (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain).  split_k: 0 = automatic, partial
- * sums are reduced in a fixed order (deterministic).
+ * split_k: 0 = automatic, partial sums are reduced in a fixed order (deterministic).
+ *
+ * ARITHMETIC — two kernel families, chosen per call:
+ *   (a) exact f32: v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain per output element.  Every call with M < 8192 rows, every
+ *       shape (b) does not cover, and EVERY call when the process environment holds REC_GEMM_BF16X3=0.
+ *   (b) bf16 x 3 (the DEFAULT for the tall GEMMs of the towers; csrc/gemm_bf16x3.h): each f32 operand is split into three
+ *       bf16 terms (8 + 8 + 8 significand bits, round-to-nearest remainders) and the six term products with i + j <= 2
+ *       are accumulated in f32 by v_mfma_f32_16x16x32_bf16.  Taken by   forward / dX calls (trans_a = 0): M >= 8192,
+ *       N % 4 == 0, N within 15 % of a column-block multiple (336 <= N: 400, 432, 512, 768, 1560 ...), K % 8 == 0, K >= 64,
+ *       16-byte aligned rows, split_k <= 1, no b_colsum;   weight-gradient calls (trans_a = 1, no epilogue): K >= 8192,
+ *       336 <= M <= 448, 336 <= N <= 416 (REC_GEMM_BF16X3_DW=0: never).  Results are f32-GRADE — the error against
+ *       float64 is that of (a), <= 4e-7 of sum |a||b| (tests/test_gemm_gpu.py) — but NOT the bit pattern of (a):
+ *         - a step sharded so that a rank holds fewer than 8192 rows runs (a) and does not match the unsharded step's
+ *           bits (it matches to the bound above);
+ *         - non-finite operands: NaN propagates in both; an operand that is +-Inf, or finite with |x| > 3.39e38 (it
+ *           rounds to the bf16 Inf), leaves Inf - Inf in its second term, so (b) returns NaN where (a) returns +-Inf —
+ *           also behind REC_EPI_RELU_MASK / BIAS_RELU, where relu(-Inf) = 0 under (a) continues and NaN under (b) does
+ *           not; operands whose third term falls below 2^-133 lose it (bf16 subnormals flush): the product of such an
+ *           operand carries 16 instead of 24 significand bits, i.e. an absolute error below 2^-126 * |b| — not
+ *           observable behind an f32 accumulation of normal numbers (tests/test_gemm_gpu.py::test_gemm_nonfinite_*).
+ *       REC_GEMM_BF16X3 (read per call): unset = (b) as above; 1 = (b), but a weight-gradient call with an explicit
+ *       split_k stays on (a) (the caller asked for few long blocks beside another kernel); 0 = (a) everywhere.
+ *   WORKSPACE: under (b) a forward / dX call WRITES op(B)'s three-plane image into the workspace (unless
+ *   rec_gemm_epilogue_args.b_image hands one in) and a weight-gradient call its partial tiles — so, unlike (a) without
+ *   split-K, concurrent calls on two streams need one workspace each.  rec_gemm_f32_workspace_bytes covers both families.
  * ---------------------------------------------------------------------------------------- */
 typedef enum {
   REC_EPI_NONE = 0,
@@ -746,6 +769,9 @@ typedef struct {
   int32_t ld_out2;
   float* b_colsum;          /* [N] or NULL (trans_a calls only): also return the column sums of B over K — the
                                bias gradient when the call computes dW = X^T dY (B = dY), at no extra pass */
+  const void* b_image;      /* NULL, or the bf16 x 3 image of THIS call's op(B) made by rec_gemm_b_images (same k, n,
+                               trans_b, current values of B): the call then skips its own split launch and does not
+                               write the workspace.  Ignored by calls that do not take the bf16 x 3 forward / dX kernel */
 } rec_gemm_epilogue_args;
 
 int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* bytes);
@@ -756,6 +782,19 @@ int rec_gemm_plan_splits(const rec_gemm_desc* desc, int32_t num_cus, int32_t* sp
 int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const float* B, float* C,
                  const rec_gemm_epilogue_args* args /* may be NULL */, void* workspace,
                  size_t workspace_bytes, void* stream);
+/* Weight images ahead of time.  Under the bf16 x 3 family every forward / dX call splits op(B) [k, n] into its plane image
+ * first (a ~5 us launch per call); the weights of a tower change once per step, so a trainer makes ALL images of the step
+ * in one launch right after its optimizer (rec_adam_dense) and passes them as rec_gemm_epilogue_args.b_image.
+ *   rec_gemm_b_image_bytes : *eligible = 1 and the image size if an op(B) of k x n has an image form, else 0 / 0
+ *   rec_gemm_b_images      : items[i].image <- image of op(B_i) (B_i as rec_gemm_f32 takes it: [k,n] row-major with ldb,
+ *                            or [n,k] when trans_b); any count (8 images per launch).  items is a HOST array. */
+typedef struct {
+  const float* B;
+  int32_t ldb, k, n, trans_b;
+  void* image;     /* device, 16-byte aligned, rec_gemm_b_image_bytes(k, n) bytes */
+} rec_gemm_b_image;
+int rec_gemm_b_image_bytes(int32_t k, int32_t n, int32_t* eligible, size_t* bytes);
+int rec_gemm_b_images(int32_t count, const rec_gemm_b_image* items, void* stream);
 
 /* out[j] = sum_i G[i,j] (bias gradient of a Linear), fixed reduction order. */
 int rec_colsum_workspace_bytes(int64_t m, int32_t n, size_t* bytes);

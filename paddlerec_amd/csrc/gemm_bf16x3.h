@@ -33,6 +33,8 @@
 // (2) weight-gradient form (gemm_bf16x3_dw_kernel): further down.
 #pragma once
 
+#include <atomic>
+
 #include "gemm_epi.h"
 #include "gemm_glds.h"      // glb_void_t / lds_void_t, wait_vmcnt
 
@@ -46,16 +48,17 @@ constexpr int kX3NP = 2 * kX3NT * 16;           // 416 columns per block
 constexpr int kX3BM = 128;                      // rows per block
 constexpr int kX3MT = 4;                        // MFMA row tiles per wave (64 rows)
 constexpr int kX3Stage = 3 * kX3NP * 64;        // the largest k-step stage: 79 872 B (two stages = 156 of the 160 KB)
-// Column blocks: a block covers 2 NT MFMA column tiles (NT per wave), NT in {13, 8, 7}: 400 -> one block of 26 tiles,
-// 432 -> two of 14, 512 -> two of 16, 1560 -> four of 26; the weight image is [column block][k-step][plane][NP rows][64 B].
+// Column blocks: ONE wave's NT MFMA column tiles (NT in {13, 8, 7}), always an even number of them: 400 -> 2 x 13 tiles,
+// 432 -> 4 x 7, 512 -> 4 x 8, 1560 -> 8 x 13; the weight image is [column block][k-step][plane][NP rows][64 B].  A
+// workgroup covers WN = 1 or 2 adjacent column blocks (its waves are WM along M x WN along N).
 template <int NT>
 struct X3Geo {
-  static constexpr int NP = 2 * NT * 16;        // columns per block (zero weight columns behind N)
+  static constexpr int NP = NT * 16;            // columns per column block (zero weight columns behind N)
   static constexpr int Plane = NP * 64;         // one plane of one k-step: NP rows x 32 bf16
-  static constexpr int Stage = 3 * Plane;
-  static constexpr int Pieces = Stage / 1024;   // LDS-DMA pieces per k-step (Stage % 1024 == 0 for every NT: 3 * NT * 2)
+  static constexpr int Stage = 3 * Plane;       // one column block's k-step image
+  static constexpr int Pieces = Stage / 1024;   // LDS-DMA pieces per column block and k-step (3 * NT)
 };
-struct X3Cols { int nt, ncb; };                 // tiles per wave, column blocks
+struct X3Cols { int nt, ncb; };                 // tiles per wave, PAIRS of column blocks
 inline X3Cols x3_cols(int N) {                  // least padded choice; nt = 0: none within 15 % of N
   const int tiles = (N + 15) / 16;
   X3Cols best{0, 0};
@@ -96,9 +99,8 @@ __device__ __forceinline__ void x3_split_pair(float xe, float xo, unsigned& p0, 
 
 // W [K,N] (trans 0: element (n, k) = W[k * ldw + n]) or W [N,K] (trans 1: W[n * ldw + k]) -> image; one thread per
 // (column block, k-step, row of the block, 8-k chunk).  Rows n >= N and chunks k >= K are zero.
-__global__ __launch_bounds__(kBlock) void x3_split_kernel(const float* __restrict__ W, int64_t ldw, int K, int N, int trans,
-                                                          char* __restrict__ img, int nkt, int np, int ncb) {
-  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ void x3_split_one(const float* __restrict__ W, int64_t ldw, int K, int N, int trans,
+                                             char* __restrict__ img, int nkt, int np, int ncb, int64_t tid) {
   if (tid >= (int64_t)ncb * nkt * np * 4) return;
   const int c = (int)(tid & 3), nl = (int)((tid >> 2) % np);
   const int kt = (int)(((tid >> 2) / np) % nkt), cb = (int)((tid >> 2) / np / nkt);
@@ -121,6 +123,28 @@ __global__ __launch_bounds__(kBlock) void x3_split_kernel(const float* __restric
   *reinterpret_cast<u32x4_t*>(dst) = p0;
   *reinterpret_cast<u32x4_t*>(dst + plane) = p1;
   *reinterpret_cast<u32x4_t*>(dst + 2 * plane) = p2;
+}
+__global__ __launch_bounds__(kBlock) void x3_split_kernel(const float* __restrict__ W, int64_t ldw, int K, int N, int trans,
+                                                          char* __restrict__ img, int nkt, int np, int ncb) {
+  x3_split_one(W, ldw, K, N, trans, img, nkt, np, ncb, (int64_t)blockIdx.x * kBlock + threadIdx.x);
+}
+// every weight image of a step in ONE launch (rec_gemm_b_images): item i owns blocks [first[i], first[i + 1])
+constexpr int kX3BatchMax = 8;
+struct X3SplitBatch {
+  const float* W[kX3BatchMax];
+  char* img[kX3BatchMax];
+  int64_t ldw[kX3BatchMax];
+  int K[kX3BatchMax], N[kX3BatchMax], trans[kX3BatchMax], nkt[kX3BatchMax], np[kX3BatchMax], ncb[kX3BatchMax];
+  unsigned first[kX3BatchMax + 1];
+  int count;
+};
+__global__ __launch_bounds__(kBlock) void x3_split_batch_kernel(const X3SplitBatch b) {
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < kX3BatchMax; ++j)
+    if (j < b.count && blockIdx.x >= b.first[j]) i = j;
+  x3_split_one(b.W[i], b.ldw[i], b.K[i], b.N[i], b.trans[i], b.img[i], b.nkt[i], b.np[i], b.ncb[i],
+               (int64_t)(blockIdx.x - b.first[i]) * kBlock + threadIdx.x);
 }
 
 // one tile's three plane fragments (ds_read_b128, offset = tile * 1024 + plane * PLANE; plane 2 through a second
@@ -150,6 +174,25 @@ __device__ __forceinline__ void x3_read_frags_t(u32x4_t (&bf)[3], unsigned sb, u
   }
 }
 
+#ifndef REC_X3_TG
+#define REC_X3_TG 2            // column tiles per MFMA group of the forward / dX kernel (lab knob: 1 = tile by tile)
+#endif
+// wait until at most `left` LDS reads are outstanding (a constant after unrolling: 0, 3, 6 or 9), tied to the TG x 3
+// fragments that must have landed (LDS returns in order)
+template <int TG>
+__device__ __forceinline__ void x3_wait_group(u32x4_t (&f)[TG][3], int left) {
+#define REC_X3_TIE(U) if constexpr (TG > U) asm volatile("" : "+v"(f[U][0]), "+v"(f[U][1]), "+v"(f[U][2]));
+  switch (left) {
+    case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+  }
+  REC_X3_TIE(0) REC_X3_TIE(1) REC_X3_TIE(2) REC_X3_TIE(3)
+#undef REC_X3_TIE
+}
+
 #ifndef REC_X3_DW_VALU_PER_MFMA
 #define REC_X3_DW_VALU_PER_MFMA 2      // conversion instructions laid behind every MFMA of the tiles that carry a patch column
                                        // (a 16-cycle MFMA leaves one wave ~2 issue slots: 3 measured 162 us against 159)
@@ -160,22 +203,39 @@ __device__ __forceinline__ void x3_read_frags_t(u32x4_t (&bf)[3], unsigned sb, u
 
 // WM = waves along M (2: four waves, one per SIMD, 64-row wave tiles; 4: EIGHT waves, two per SIMD, 32-row wave tiles —
 // a wave's conversion / waits sit beside its SIMD partner's MFMAs, at twice the W' fragment reads per MFMA).
-template <int NT, int EPI, int WM>
-__global__ __launch_bounds__(WM * 2 * 64) void gemm_bf16x3_kernel(int64_t M, int N, int K, const float* __restrict__ A, int64_t lda,
-                                                          const char* __restrict__ Bimg_all, float* __restrict__ C,
-                                                          int64_t ldc, EpiArgs epi) {
+// WN = 1 (four waves, WM = 4): a workgroup is 128 rows x ONE column block, 80 KB of LDS, 256 registers per wave — TWO
+// workgroups share a CU, each SIMD holds one wave of either.  Unlike the two waves of one 8-wave workgroup, which the
+// k-step barrier keeps in lockstep (both convert, both wait, both store their C tiles at the same time: the matrix pipe
+// idles), the two workgroups drift apart and one's prologue / conversion / C stores run beside the other's MFMAs.
+// Grid: 1-D; workgroup b runs on XCD b % 8 (round-robin dispatch), and the column blocks of one row tile are CONSECUTIVE
+// on that XCD (j = b / 8: cb = j % ncb, row tile = (j / ncb) * 8 + b % 8): the second reader of an A tile finds it in L2.
+template <int NT, int EPI, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, WN == 1 ? 2 : 1) void gemm_bf16x3_kernel(
+    int64_t M, int N, int K, const float* __restrict__ A, int64_t lda, const char* __restrict__ Bimg_all,
+    float* __restrict__ C, int64_t ldc, EpiArgs epi, int ncb) {
   using Geo = X3Geo<NT>;
   constexpr int MT = kX3BM / 16 / WM;                         // MFMA row tiles per wave
-  constexpr int NW = WM * 2;                                  // waves per block
+  constexpr int NW = WM * WN;                                 // waves per block
+  constexpr int BStage = WN * Geo::Stage;                     // LDS bytes of one k-step stage
   extern __shared__ __attribute__((aligned(1024))) char x3_smem[];
   const int lane = threadIdx.x % kWave;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int li = lane & 15, g = lane >> 4;
   const int wm = wave % WM, wn = wave / WM;
   const int nkt = (K + 31) / 32;
-  const int64_t m0 = (int64_t)blockIdx.x * kX3BM + wm * (MT * 16);
-  const int cb = blockIdx.y;                                  // column block: columns cb * NP ..
-  const char* Bimg = Bimg_all + (size_t)cb * nkt * Geo::Stage;
+  int64_t row_tile;
+  int cb0;                                                    // first column block of this workgroup
+  if constexpr (WN == 1) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    cb0 = j % ncb;
+    row_tile = (int64_t)(j / ncb) * 8 + xcd;
+    if (row_tile * kX3BM >= M) return;                        // the grid is padded to whole groups of 8 row tiles
+  } else {
+    row_tile = blockIdx.x;
+    cb0 = blockIdx.y * WN;
+  }
+  const int64_t m0 = row_tile * kX3BM + wm * (MT * 16);
+  const char* Bimg = Bimg_all + (size_t)cb0 * nkt * Geo::Stage;
 
   // ---- A: per-lane row pointers (rows behind M re-read row M-1: finite data, never stored)
   const float* ap[MT];
@@ -199,12 +259,15 @@ __global__ __launch_bounds__(WM * 2 * 64) void gemm_bf16x3_kernel(int64_t M, int
   // ---- W': LDS-DMA of one k-step image; pieces dealt round-robin to the four waves
   auto issue_b = [&](int kt, int stage) {
     const char* src = Bimg + (size_t)kt * Geo::Stage + lane * 16;
-    const char* dst = x3_smem + stage * Geo::Stage;
+    const char* dst = x3_smem + stage * BStage;
 #pragma unroll
-    for (int j = 0; j < (Geo::Pieces + NW - 1) / NW; ++j) {
-      const int piece = wave + NW * j;
-      if (piece < Geo::Pieces)
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + piece * 1024), (lds_void_t*)(dst + piece * 1024), 16, 0, 0);
+    for (int j = 0; j < (WN * Geo::Pieces + NW - 1) / NW; ++j) {
+      const int piece = wave + NW * j;                        // column block w = piece / Pieces, piece q of its image
+      if (piece < WN * Geo::Pieces) {
+        const int w = WN == 1 ? 0 : piece / Geo::Pieces, q = piece - w * Geo::Pieces;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + (size_t)w * nkt * Geo::Stage + q * 1024),
+                                         (lds_void_t*)(dst + w * Geo::Stage + q * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -215,7 +278,7 @@ __global__ __launch_bounds__(WM * 2 * 64) void gemm_bf16x3_kernel(int64_t M, int
     for (int t = 0; t < NT; ++t) acc[a][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   // byte address (LDS offset = low half of the flat address) of this lane's fragment slot in tile 0, plane 0, stage 0
-  const unsigned lds_base = (unsigned)(uintptr_t)x3_smem + (wn * NT * 16 + li) * 64 + ((g ^ x3_swz(li)) * 16);
+  const unsigned lds_base = (unsigned)(uintptr_t)x3_smem + wn * Geo::Stage + li * 64 + ((g ^ x3_swz(li)) * 16);
 
   issue_b(0, 0);
   load_a(0);
@@ -250,22 +313,34 @@ __global__ __launch_bounds__(WM * 2 * 64) void gemm_bf16x3_kernel(int64_t M, int
     // lgkmcnt(0) before every tile while LDS-DMA loads are in flight (it cannot order them against LDS reads), i.e.
     // also for the fragments it has just requested for the NEXT tile; here tile t's MFMAs wait for their own three
     // reads only (lgkmcnt(3): LDS returns in order) and the next tile's reads stay in flight underneath them.
-    const unsigned sb = lds_base + stage * Geo::Stage;
-    u32x4_t bf[2][3];
-    x3_read_frags<0, Geo::Plane>(bf[0], sb, sb + 2 * Geo::Plane);
+    const unsigned sb = lds_base + stage * BStage;
+    // Column tiles are multiplied in GROUPS of TG: the six term products of a group go product by product over all
+    // TG x MT accumulators, so that two MFMAs on ONE accumulator are TG x MT instructions apart (TG = 1: every other
+    // instruction waits for its predecessor's result — the issue stalls of profiles/r05_bf16x3.txt section 8).
+    constexpr int TG = REC_X3_TG, NG = (NT + TG - 1) / TG;
+    u32x4_t bf[2][TG][3];
+    auto read_group = [&](int gi, int slot) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t + 1 < NT) {
-        x3_read_frags_t<Geo::Plane>(bf[(t + 1) & 1], sb, sb + 2 * Geo::Plane, t + 1);
-        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bf[t & 1][0]), "+v"(bf[t & 1][1]), "+v"(bf[t & 1][2]));
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[t & 1][0]), "+v"(bf[t & 1][1]), "+v"(bf[t & 1][2]));
+      for (int u = 0; u < TG; ++u)
+        if (gi * TG + u < NT) x3_read_frags_t<Geo::Plane>(bf[slot][u], sb, sb + 2 * Geo::Plane, gi * TG + u);
+    };
+    read_group(0, 0);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int slot = gi & 1;
+      const int n_cur = NT - gi * TG < TG ? NT - gi * TG : TG;
+      int left = 0;                                            // reads that may stay in flight: the next group's
+      if (gi + 1 < NG) {
+        read_group(gi + 1, slot ^ 1);
+        left = 3 * (NT - (gi + 1) * TG < TG ? NT - (gi + 1) * TG : TG);
       }
-      const u32x4_t* b = bf[t & 1];
-      // smallest terms first; between two MFMAs on one accumulator sit the three other row tiles
-#define REC_X3_MFMA(PB, PA)                                                                                    \
-  _Pragma("unroll") for (int a = 0; a < MT; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(         \
-      __builtin_bit_cast(bf16x8_t, b[PB]), __builtin_bit_cast(bf16x8_t, af[a][PA]), acc[a][t], 0, 0, 0);
+      x3_wait_group<TG>(bf[slot], left);
+      // smallest terms first
+#define REC_X3_MFMA(PB, PA)                                                                                          \
+  _Pragma("unroll") for (int u = 0; u < TG; ++u) if (u < n_cur) {                                                    \
+    _Pragma("unroll") for (int a = 0; a < MT; ++a) acc[a][gi * TG + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(    \
+        __builtin_bit_cast(bf16x8_t, bf[slot][u][PB]), __builtin_bit_cast(bf16x8_t, af[a][PA]), acc[a][gi * TG + u], 0, 0, 0); \
+  }
 #if REC_X3_PRODUCTS >= 6
       REC_X3_MFMA(2, 0)
       REC_X3_MFMA(1, 1)
@@ -286,7 +361,7 @@ __global__ __launch_bounds__(WM * 2 * 64) void gemm_bf16x3_kernel(int64_t M, int
   }
 
   // ---- epilogue: float4 per lane and tile, aux / bias operands of a row tile loaded ahead of its stores
-  const int n_base = cb * Geo::NP + wn * NT * 16 + g * 4;
+  const int n_base = (cb0 + wn) * Geo::NP + g * 4;
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
     const int64_t i = m0 + a * 16 + li;
@@ -632,10 +707,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
 // host side -------------------------------------------------------------------------------------------------------
 inline int x3_launch_split(const float* W, int64_t ldw, int K, int N, int trans, char* img, hipStream_t st) {
   const X3Cols c = x3_cols(N);
-  const int nkt = (K + 31) / 32, np = 2 * c.nt * 16;
-  const int64_t thr = (int64_t)c.ncb * nkt * np * 4;
+  const int nkt = (K + 31) / 32, np = c.nt * 16, ncb = 2 * c.ncb;
+  const int64_t thr = (int64_t)ncb * nkt * np * 4;
   hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)((thr + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, W, ldw, K, N,
-                     trans, img, nkt, np, c.ncb);
+                     trans, img, nkt, np, ncb);
   return check_launch("x3_split_kernel");
 }
 
@@ -644,36 +719,56 @@ inline bool x3_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldc, const
          ((uintptr_t)A % 16) == 0 && ((uintptr_t)C % 16) == 0;
 }
 
-template <int NT, int EPI, int WM>
+template <int NT, int EPI, int WM, int WN>
 inline int x3_launch_gemm_wm(int64_t M, int N, int K, const float* A, int64_t lda, const char* img, float* C, int64_t ldc,
                              const EpiArgs& e, int ncb, hipStream_t st) {
-  static bool attr_set = false;             // > 64 KB of dynamic LDS needs the attribute once per kernel
-  constexpr int lds = 2 * X3Geo<NT>::Stage;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<NT, EPI, WM>),
+  static std::atomic<bool> attr_set{false};          // > 64 KB of dynamic LDS needs the attribute once per kernel
+  constexpr int lds = 2 * WN * X3Geo<NT>::Stage;
+  if (!attr_set.load(std::memory_order_acquire)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<NT, EPI, WM, WN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       (void)hipGetLastError();
       set_error("gemm_bf16x3: %d B of dynamic LDS refused", lds);
       return REC_EHIP;
     }
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<NT, EPI, WM>), dim3((unsigned)((M + kX3BM - 1) / kX3BM), (unsigned)ncb),
-                     dim3(WM * 2 * 64), lds, st, M, N, K, A, lda, img, C, ldc, e);
+  const int64_t row_tiles = (M + kX3BM - 1) / kX3BM;
+  if constexpr (WN == 1) {         // 1-D grid, column blocks of a row tile consecutive on one XCD (see the kernel)
+    const int64_t grid = (row_tiles + 7) / 8 * 8 * ncb;
+    if (grid >= (1ll << 31)) { set_error("gemm_bf16x3: too many workgroups"); return REC_ESHAPE; }
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<NT, EPI, WM, WN>), dim3((unsigned)grid), dim3(WM * WN * 64), lds, st, M, N, K, A,
+                       lda, img, C, ldc, e, ncb);
+  } else {
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<NT, EPI, WM, WN>), dim3((unsigned)row_tiles, (unsigned)(ncb / WN)),
+                       dim3(WM * WN * 64), lds, st, M, N, K, A, lda, img, C, ldc, e, ncb);
+  }
   return check_launch("gemm_bf16x3_kernel");
 }
 
-// Eight waves (two per SIMD, 32-row wave tiles) for the four MLP epilogues: 129 -> 119 us at 65 536 x 400 x 400, 1808 ->
-// 1716 us at 1560^2, 1305 -> 1199 us at 512 x 3680, bit-identical (profiles/r05_bf16x3.txt section 9); the CrossNet
-// epilogues hold two more operand tiles in registers and spill at the 256-register budget of that shape: four waves.
+// Workgroup shapes (WM waves along M x WN along N, wave tile 128 / WM rows x NT column tiles):
+//   4 x 1 (round 6, the MLP epilogues): four waves, 80 KB of LDS, two workgroups per CU that run out of phase — see
+//         the kernel; REC_X3_WN=2 selects the round-5 shape for A/B runs;
+//   4 x 2 (round 5): eight waves in one workgroup, two per SIMD in lockstep: 129 -> 119 us at 65 536 x 400 x 400 against
+//   2 x 2: four waves with 64-row wave tiles, one per SIMD (512 registers) — kept for the CrossNet epilogues, which hold
+//         two more operand tiles in registers and spill at a 256-register budget.
 #ifndef REC_X3_WM
 #define REC_X3_WM 4            // lab knob (tools/gemm_lab): 2 = four waves per block for every epilogue
 #endif
+inline int x3_wn_default() {
+  static const int v = [] { const char* e = getenv("REC_X3_WN"); return e && *e == '2' ? 2 : 1; }();
+  return v;
+}
 template <int NT, int EPI>
 inline int x3_launch_gemm_cfg(int64_t M, int N, int K, const float* A, int64_t lda, const char* img, float* C, int64_t ldc,
                               const EpiArgs& e, int ncb, hipStream_t st) {
-  constexpr int WM = EpiUses<EPI>::aux1 ? 2 : REC_X3_WM;        // CROSS / ADD / MOE
-  return x3_launch_gemm_wm<NT, EPI, WM>(M, N, K, A, lda, img, C, ldc, e, ncb, st);
+  if constexpr (EpiUses<EPI>::aux1) {                           // CROSS / ADD / MOE
+    return x3_launch_gemm_wm<NT, EPI, 2, 2>(M, N, K, A, lda, img, C, ldc, e, ncb, st);
+  } else {
+    if (REC_X3_WM == 4 && x3_wn_default() == 1)
+      return x3_launch_gemm_wm<NT, EPI, 4, 1>(M, N, K, A, lda, img, C, ldc, e, ncb, st);
+    return x3_launch_gemm_wm<NT, EPI, REC_X3_WM, 2>(M, N, K, A, lda, img, C, ldc, e, ncb, st);
+  }
 }
 
 template <int EPI>
@@ -681,9 +776,9 @@ inline int x3_launch_gemm_epi(int64_t M, int N, int K, const float* A, int64_t l
                               const EpiArgs& e, hipStream_t st) {
   const X3Cols c = x3_cols(N);
   switch (c.nt) {
-    case 13: return x3_launch_gemm_cfg<13, EPI>(M, N, K, A, lda, img, C, ldc, e, c.ncb, st);
-    case 8: return x3_launch_gemm_cfg<8, EPI>(M, N, K, A, lda, img, C, ldc, e, c.ncb, st);
-    case 7: return x3_launch_gemm_cfg<7, EPI>(M, N, K, A, lda, img, C, ldc, e, c.ncb, st);
+    case 13: return x3_launch_gemm_cfg<13, EPI>(M, N, K, A, lda, img, C, ldc, e, 2 * c.ncb, st);
+    case 8: return x3_launch_gemm_cfg<8, EPI>(M, N, K, A, lda, img, C, ldc, e, 2 * c.ncb, st);
+    case 7: return x3_launch_gemm_cfg<7, EPI>(M, N, K, A, lda, img, C, ldc, e, 2 * c.ncb, st);
     default: set_error("gemm_bf16x3: no column blocking for N = %d", N); return REC_ESHAPE;
   }
 }
@@ -728,9 +823,9 @@ inline bool x3_dw_plan(int kin, int nout, int64_t rows, int cus, X3DwPlan* p) {
 }
 inline int x3_launch_dw(const X3DwPlan& pl, int kin, int nout, int64_t rows, const float* X, int64_t ldx, const float* G,
                         int64_t ldg, float* P, int64_t ldp, float* cpart, hipStream_t st) {
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   constexpr int lds = 2 * kX3Stage + 4096;        // + a 16-B slot per thread for the patch-less threads' stores
-  if (!attr_set) {
+  if (!attr_set.load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dw_kernel<7>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dw_kernel<5>),
@@ -739,7 +834,7 @@ inline int x3_launch_dw(const X3DwPlan& pl, int kin, int nout, int64_t rows, con
       set_error("gemm_bf16x3_dw: %d B of dynamic LDS refused", lds);
       return REC_EHIP;
     }
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   X3DwArgs w{X, ldx, G, ldg, rows, kin, nout, pl.kb_tiles, pl.nb_tiles, pl.kblocks, pl.nblocks, pl.slices,
              pl.steps_per_slice, P, ldp, cpart};

@@ -837,13 +837,15 @@ static bool x3_eligible(const rec_gemm_desc* d) {
     return false;
   return x3_cols(d->n).nt > 0 && x3_epilogue_ok(d->epilogue);
 }
-static bool launch_x3(const rec_gemm_desc* d, const float* A, const float* B, float* C, const EpiArgs& e, void* workspace,
-                      size_t workspace_bytes, hipStream_t st) {
+static bool launch_x3(const rec_gemm_desc* d, const float* A, const float* B, float* C, const EpiArgs& e,
+                      const void* b_image, void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (!x3_eligible(d)) return false;
   if (!x3_shape_ok(d->m, d->n, d->k, d->lda, d->ldc, A, C)) return false;
   if (e.aux0 && (e.ld0 % 4 || ((uintptr_t)e.aux0) % 16)) return false;                 // float4 aux operands
   if (e.aux1 && (e.ld1 % 4 || ((uintptr_t)e.aux1) % 16)) return false;
   if (e.out2 && (e.ld2 % 4 || ((uintptr_t)e.out2) % 16)) return false;
+  if (b_image && ((uintptr_t)b_image) % 16 == 0)       // the caller split B ahead of time (rec_gemm_b_images)
+    return x3_launch_gemm(d->epilogue, d->m, d->n, d->k, A, d->lda, (const char*)b_image, C, d->ldc, e, st) == REC_OK;
   if (!workspace || ((uintptr_t)workspace) % 16 || workspace_bytes < x3_image_bytes(d->k, d->n)) return false;   // sized without it
   char* img = (char*)workspace;
   if (x3_launch_split(B, d->ldb, d->k, d->n, d->trans_b ? 1 : 0, img, st) != REC_OK) return false;
@@ -930,6 +932,42 @@ extern "C" int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* b
   return REC_OK;
 }
 
+// ---- weight images made ahead of the GEMMs that consume them (rec_gemm_epilogue_args.b_image) ---------------------------
+extern "C" int rec_gemm_b_image_bytes(int32_t k, int32_t n, int32_t* eligible, size_t* bytes) {
+  REC_REQUIRE(k > 0 && n > 0 && bytes, REC_EINVAL, "bad arguments");
+  const bool ok = n % 4 == 0 && k % 8 == 0 && k >= 64 && x3_cols(n).nt > 0;
+  if (eligible) *eligible = ok ? 1 : 0;
+  *bytes = ok ? align_up(x3_image_bytes(k, n), 256) : 0;
+  return REC_OK;
+}
+
+extern "C" int rec_gemm_b_images(int32_t count, const rec_gemm_b_image* items, void* stream) {
+  REC_REQUIRE(count >= 0 && (count == 0 || items), REC_EINVAL, "bad arguments");
+  for (int32_t at = 0; at < count; at += kX3BatchMax) {
+    X3SplitBatch b{};
+    b.count = count - at < kX3BatchMax ? count - at : kX3BatchMax;
+    int64_t blocks = 0;
+    for (int i = 0; i < b.count; ++i) {
+      const rec_gemm_b_image& it = items[at + i];
+      REC_REQUIRE(it.B && it.image && ((uintptr_t)it.image) % 16 == 0, REC_EINVAL, "item %d: null / unaligned pointer", at + i);
+      REC_REQUIRE(it.k > 0 && it.n > 0 && it.n % 4 == 0 && it.k % 8 == 0 && it.k >= 64 && x3_cols(it.n).nt > 0, REC_ESHAPE,
+                  "item %d: k %d x n %d has no image form (rec_gemm_b_image_bytes)", at + i, it.k, it.n);
+      REC_REQUIRE(it.ldb >= (it.trans_b ? it.k : it.n), REC_EINVAL, "item %d: ldb too small", at + i);
+      const X3Cols c = x3_cols(it.n);
+      b.W[i] = it.B; b.img[i] = (char*)it.image; b.ldw[i] = it.ldb; b.K[i] = it.k; b.N[i] = it.n;
+      b.trans[i] = it.trans_b ? 1 : 0;
+      b.nkt[i] = (it.k + 31) / 32; b.np[i] = c.nt * 16; b.ncb[i] = 2 * c.ncb;
+      b.first[i] = (unsigned)blocks;
+      blocks += ((int64_t)b.ncb[i] * b.nkt[i] * b.np[i] * 4 + kBlock - 1) / kBlock;
+    }
+    b.first[b.count] = (unsigned)blocks;
+    REC_REQUIRE(blocks < (1ll << 31), REC_ESHAPE, "too many blocks");
+    hipLaunchKernelGGL(x3_split_batch_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, b);
+    if (int rc = check_launch("rec_gemm_b_images")) return rc;
+  }
+  return REC_OK;
+}
+
 extern "C" int rec_gemm_plan_splits(const rec_gemm_desc* desc, int32_t num_cus, int32_t* splits) {
   if (int rc = check_gemm(desc)) return rc;
   REC_REQUIRE(splits && num_cus <= kNumCU, REC_EINVAL, "bad arguments");
@@ -1011,7 +1049,8 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
   }
   if (launch_x3_dw(desc, A, B, C, e, b_colsum, workspace, workspace_bytes, st)) return check_launch("rec_gemm_f32 (bf16x3 dW)");
   // tall problems of the towers' own widths: whole row panels, one resident round (gemm_panel.h)
-  if (!b_colsum && launch_x3(desc, A, B, C, e, workspace, workspace_bytes, st)) return check_launch("rec_gemm_f32 (bf16x3)");
+  if (!b_colsum && launch_x3(desc, A, B, C, e, x->b_image, workspace, workspace_bytes, st))
+    return check_launch("rec_gemm_f32 (bf16x3)");
   if (!b_colsum && launch_panel(desc, A, B, C, e, st, device_cus())) return check_launch("rec_gemm_f32 (panel)");
   if (!b_colsum && launch_glds(desc, A, B, C, e, st)) return check_launch("rec_gemm_f32 (glds)");
   const GemmPlan p = plan_gemm(desc);

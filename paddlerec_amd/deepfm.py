@@ -243,6 +243,14 @@ class DeepFMLayer:
         self.status = self.k.new_status(self.device)
         self.step_count = 0
         self._side = None
+        # Pipelined steps (round 6; bench.py and the trainer loops switch it on): the step's critical chain
+        # fm_bwd -> sparse update -> the NEXT step's lookup stays on ONE stream (no cross-queue event latency), the dense
+        # tail (dW_0, fold, dense Adam, the next step's folded layer-0 weight and every GEMM weight image) runs on the side
+        # stream and is joined only where the next step's first GEMM needs it.  Between steps the dense parameters /
+        # gradients are therefore still being written: read them after sync().  Same kernels, same arguments: bit-identical.
+        self.pipelined = os.environ.get("REC_DEEPFM_PIPELINED", "0") == "1"
+        self._side_pending, self._pending_refs, self._gside, self._adam_done = False, None, None, None
+        self._w_key, self._images = None, None        # (param version, step, images?) the folded weight / images belong to
         self._plans, self._recording = {}, False      # recorded call lists of launch-bound steps (plan.py)
         self.timers = None      # bench.py: dict name -> list of (start,end) torch.cuda.Event pairs
 
@@ -258,6 +266,7 @@ class DeepFMLayer:
 
     # -- parameters under the reference's state_dict keys (Appendix C) -------------------------
     def state_dict(self):
+        self.sync()
         sd = {"fm.embedding_one.weight": self.fm.embedding_one, "fm.embedding.weight": self.fm.embedding}
         sd.update({k: v for k, v in self.dense.p.items() if not k.startswith("__")})
         return sd
@@ -297,20 +306,56 @@ class DeepFMLayer:
                                     compact=self.compact)
 
     # -- layer 0 on folded weights ------------------------------------------------------------------
-    def _mlp_weights(self):
-        """(weights, weight-grad views) of the top MLP as the GEMMs see them this step."""
+    def _weight_lists(self):
         if self.padded:
             return [self._w0p] + self.mlp_w[1:], [self._dw0p] + self.mlp_dw[1:]
         if not self.compact:
             return self.mlp_w, self.mlp_dw
-        S, D, Dn = self.sparse_num_field, self.sparse_feature_dim, self.dense_feature_dim
-        w0 = self.mlp_w[0]
         if self._fold_full:
-            self.k.dense_fold_fwd_full(S, self.dense.p["fm.dense_w"].view(Dn, D), w0, self._w0p)
             return [self._w0p] + self.mlp_w[1:], [self._dw0f] + self.mlp_dw[1:]
-        self._copy(self._w0p[: S * D], w0[: S * D])
-        self.k.dense_fold_fwd(S, self.dense.p["fm.dense_w"].view(Dn, D), w0, self._w0p[S * D: S * D + Dn])
-        return [self._w0p] + self.mlp_w[1:], [self.mlp_dw[0][: self.fp * D]] + self.mlp_dw[1:]
+        return [self._w0p] + self.mlp_w[1:], [self.mlp_dw[0][: self.fp * self.sparse_feature_dim]] + self.mlp_dw[1:]
+
+    def _refresh_weights(self, images=False):
+        """What the GEMMs of a step read besides the parameters themselves, on the current stream: layer 0's folded
+        weight (compact feat) and — images=True — the bf16 x 3 image of every Linear's weight in both orientations
+        (forward: W, dX: W^T), ALL in one launch (rec_gemm_b_images) instead of one split launch in front of each GEMM."""
+        if self.compact and not self.padded:
+            S, D, Dn = self.sparse_num_field, self.sparse_feature_dim, self.dense_feature_dim
+            w0 = self.mlp_w[0]
+            if self._fold_full:
+                self.k.dense_fold_fwd_full(S, self.dense.p["fm.dense_w"].view(Dn, D), w0, self._w0p)
+            else:
+                self._copy(self._w0p[: S * D], w0[: S * D])
+                self.k.dense_fold_fwd(S, self.dense.p["fm.dense_w"].view(Dn, D), w0, self._w0p[S * D: S * D + Dn])
+        if images:
+            if self._images is None:
+                ws_ = self._weight_lists()[0]
+                self._images = self.k.GemmImages([(w, False) for w in ws_] + [(w, True) for w in ws_], self.device)
+            self._images.refresh()
+
+    def _mlp_weights(self, images=False):
+        """(weights, weight-grad views) of the top MLP as the GEMMs see them this step.  The folded weight / the images
+        are rebuilt unless they were made for exactly these parameter values and this step (the pipelined step makes
+        them at the end of the previous one, behind its dense Adam)."""
+        key = (self.dense.data._version, self.step_count)
+        if self._w_key is None or self._w_key[:2] != key or (images and not self._w_key[2]):
+            self._refresh_weights(images)
+            self._w_key = key + (bool(images),)
+        return self._weight_lists()
+
+    def _image_lists(self):
+        """(images of the weights, images of their transposes) for mlp_forward / mlp_backward, or (None, None)."""
+        if self._images is None or self._w_key is None or not self._w_key[2]:
+            return None, None
+        n = self.n_linear
+        return [self._images.get(i) for i in range(n)], [self._images.get(n + i) for i in range(n)]
+
+    def sync(self):
+        """Joins the side stream of a pipelined step into the current stream: after it, parameters, gradients and
+        optimizer state are ordered behind everything the last step issued (checkpoints, eval, tests)."""
+        if self._side_pending:
+            torch.cuda.current_stream().wait_event(self._side_pending)       # recorded behind the tail's last kernel
+            self._side_pending, self._pending_refs, self._adam_done = False, None, None
 
     @property
     def _fold_full(self):
@@ -340,6 +385,7 @@ class DeepFMLayer:
                               self.dense.g["fm.dense_w"].view(Dn, D), accumulate=True)
 
     def forward(self, sparse_inputs, dense_inputs):
+        self.sync()
         ids = self._concat_ids(sparse_inputs)
         y1, y2, feat, _, _ = self._fm_fwd(ids, dense_inputs)
         y_dnn, _ = self.k.mlp_forward(feat.view(feat.shape[0], -1), self._mlp_weights()[0], self.mlp_b, self.ws_mlp)
@@ -384,6 +430,7 @@ class DeepFMLayer:
             self._plans[key] = plan
             return out
         self.step_count += 1
+        self._w_key = None
         return entry.replay(inputs, self.step_count, float(lr))
 
     # -- the step through the ONE-call C entry point (rec_deepfm_train_step) ---------------------------------------
@@ -424,6 +471,7 @@ class DeepFMLayer:
         """train_step through rec_deepfm_train_step: ONE foreign call per step — what a non-Python binder of
         include/recengine.h gets.  Same kernels, arguments and order as train_step (with its side stream for the large
         batches): bit-identical."""
+        self.sync()
         ids = self._concat_ids(sparse_inputs)
         self.step_count += 1
         if getattr(self, "_ws_c", None) is None:
@@ -433,6 +481,7 @@ class DeepFMLayer:
             if self._side is None:
                 self._side = self.k.concurrent_stream(self.device)
             side = self._side
+        self._w_key = None
         return self.k.deepfm_train_step(self.c_net(), ids, dense_inputs, label.reshape(-1), self.step_count, self._ws_c,
                                         lr=lr, auc_stats=auc_stats, num_thresholds=NUM_THRESHOLDS, status=self.status,
                                         side_stream=side)
@@ -442,6 +491,7 @@ class DeepFMLayer:
         """dygraph_model.py:76-88 train_forward + tools/trainer.py:151-152 backward/step.
         label [B,1] int64.  Returns (loss [1] device tensor, pred [B,1])."""
         if self._plan_eligible(sparse_inputs, dense_inputs, label, auc_stats, allreduce):
+            self.sync()
             out = self._train_step_planned(sparse_inputs, dense_inputs, label, lr, auc_stats)
             if out is not None:
                 return out
@@ -455,6 +505,10 @@ class DeepFMLayer:
         if overlap and self._side is None:
             self._side = self.k.concurrent_stream(self.device)   # verified to overlap with the main stream
         side = self._side if overlap else None
+        # one launch for every weight image of the step (bf16 x 3 GEMMs: M >= 8192 rows; REC_GEMM_IMAGES=0: each GEMM
+        # splits its own weight as before)
+        use_images = (on_gpu and B >= 8192 and hasattr(self.k, "GemmImages") and not self._recording
+                      and os.environ.get("REC_GEMM_IMAGES", "1") != "0")
         groups = getattr(self, "_groups", None)          # persistent: the wait_stream below orders reuse
         if groups is None or groups.n != B * S:
             groups = self._groups = self.k.IdGroups(B * S, self.device)
@@ -489,6 +543,15 @@ class DeepFMLayer:
         # all over the chip
         gspec = os.environ.get("REC_DEEPFM_GROUP_CUS", "")
         gside = side
+        # pipelined: lazy Adam, sort-based merge, two streams, no collective in the tail
+        pipe = (self.pipelined and side is not None and self.lazy_mode and not small and allreduce is None
+                and B >= 16384 and os.environ.get("REC_DEEPFM_DEFER_ALL", "0") != "1")
+        if pipe:                      # the side stream carries the previous step's dense tail: the grouping gets its own
+            if self._gside is None:
+                self._gside = self.k.concurrent_stream(self.device, index=1)
+            gside = self._gside
+        elif self._side_pending:
+            self.sync()
         if gspec and side is not None and hasattr(self.k, "cu_stride_stream"):
             if "," in gspec:
                 gside = self.k.cu_range_stream(self.device, 0, int(gspec.split(",")[1]))
@@ -509,21 +572,32 @@ class DeepFMLayer:
                                      self.fm.slot_offset, self.status, groups)
         if group_at == "pre":       # forked BEFORE fm_fwd: beside the HBM-bound lookup instead of under the forward GEMMs
             issue_group()
+        if self._adam_done is not None and "adam" in os.environ.get("REC_PIPE_SKIP", ""):
+            self._adam_done = None              # MEASUREMENT ONLY
+        if self._adam_done is not None:     # pipelined: the lookup reads fm.dense_w / dense_w_one, which the previous step's
+            cur.wait_event(self._adam_done)     # dense Adam (side stream) wrote — long done when the update in front of
+            self._adam_done = None              # this point has finished, so the wait costs nothing
         with self._timed("fm_fwd"):
             y1, y2, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
+        self.sync()     # pipelined: the previous step's dense tail (side stream) is needed from the first GEMM on
         if group_at == "fwd":
             issue_group()
-        mlp_w, mlp_dw = self._mlp_weights()
+        mlp_w, mlp_dw = self._mlp_weights(use_images)
+        img_f, img_t = self._image_lists() if use_images else (None, None)
+        nl = self.n_linear
+        ikw_f = lambda n_: dict(images=img_f[:n_]) if img_f is not None else {}       # noqa: E731
+        ikw_t = lambda n_: dict(images_t=img_t[:n_]) if img_t is not None else {}     # noqa: E731
         # the last Linear(-> 1), sigmoid + log_loss and the backward of both in ONE pass over the last hidden activation
         # (rec_ctr_head_fwd_bwd: five launches and two passes less on the critical path; REC_CTR_HEAD_FUSED=0: the parts)
         fused_head = self.n_linear > 1 and hasattr(self.k, "ctr_head") and self.k.ctr_head_ok(mlp_w[-1], mlp_dw[-1])
         with self._timed("mlp_fwd"):
             if fused_head:
-                h, acts = self.k.mlp_forward(feat.view(B, -1), mlp_w[:-1], self.mlp_b[:-1], self.ws_mlp, relu_last=True)
+                h, acts = self.k.mlp_forward(feat.view(B, -1), mlp_w[:-1], self.mlp_b[:-1], self.ws_mlp, relu_last=True,
+                                             **ikw_f(nl - 1))
                 pred, dz, loss, g_head = self.k.ctr_head(h, mlp_w[-1], self.mlp_b[-1], y1, y2, label, self.ws,
                                                          mlp_dw[-1], self.mlp_db[-1])
             else:
-                y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), mlp_w, self.mlp_b, self.ws_mlp)
+                y_dnn, acts = self.k.mlp_forward(feat.view(B, -1), mlp_w, self.mlp_b, self.ws_mlp, **ikw_f(nl))
         if not fused_head:
             pred, dz, loss = self.k.sigmoid_logloss(y1, y2, y_dnn, label, self.ws)
         if group_at == "bwd":
@@ -549,9 +623,10 @@ class DeepFMLayer:
         with self._timed("mlp_bwd"):
             if fused_head:
                 d_flat, finish_dw0 = self.k.mlp_backward(g_head, acts, mlp_w[:-1], mlp_dw[:-1], self.mlp_db[:-1],
-                                                         self.ws_mlp, **kw)
+                                                         self.ws_mlp, **kw, **ikw_t(nl - 1))
             else:
-                d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db, self.ws_mlp, **kw)
+                d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db, self.ws_mlp, **kw,
+                                                         **ikw_t(nl))
         if group_at == "tail":
             issue_group()
         if sorted_rg and side is not None:
@@ -613,7 +688,30 @@ class DeepFMLayer:
             if allreduce is not None:
                 allreduce(self.dense.grad)
             self.k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
+            self._w_key = None          # the folded layer-0 weight / the weight images belong to the old parameters
 
+        if pipe:
+            # main: merge + update, then — next call — the lookup; side: dW_0 -> fold -> dense Adam -> the NEXT step's
+            # folded layer-0 weight and weight images, ordered behind fm_bwd by an event and ISSUED behind the update: the
+            # kernel that reaches the chip first takes the wave slots — the HBM-bound update must be the resident one
+            # that dW_0's blocks fill in beside (dW_0 first: 215 + 252 us one after the other; forked in front of
+            # fm_bwd: the lookup's backward waits for the GEMM's blocks, 70 -> 248 us)
+            after_bwd = torch.cuda.Event()
+            after_bwd.record(cur)
+            if "gwait" not in os.environ.get("REC_PIPE_SKIP", ""):       # MEASUREMENT ONLY (unordered: wrong results)
+                cur.wait_stream(gside)
+            tail_sparse()
+            with torch.cuda.stream(side):
+                side.wait_event(after_bwd)
+                tail_dense()
+                self._adam_done = torch.cuda.Event()
+                self._adam_done.record()
+                self._refresh_weights(use_images)
+                self._w_key = (self.dense.data._version, self.step_count + 1, bool(use_images))
+                self._side_pending = torch.cuda.Event()
+                self._side_pending.record()
+            self._pending_refs = (acts, finish_dw0, d_flat, feat)     # the side stream still reads them: freed at the join
+            return loss, pred
         if swap:
             with _OnSide(side, cur):        # ordered behind fm_bwd, not behind the update issued below
                 tail_dense()

@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (EPI, AdagradHyper, AdamHyper, CinView, DeepFMDesc, DinDesc, GemmDesc, GemmEpilogueArgs, GradLayout,
+from ._lib import (EPI, AdagradHyper, AdamHyper, CinView, DeepFMDesc, DinDesc, GemmBImage, GemmDesc, GemmEpilogueArgs, GradLayout,
                    GradSrc, LazyInit, MultislotDesc, PsAccessor, PsLayout, RecError, check)
 
 _recorder = None        # paddlerec_amd.plan.CallPlan while a step is being recorded
@@ -1422,12 +1422,41 @@ def _chk_mat(t, name):
 _gemm_ws_cache = {}
 
 
+class GemmImages:
+    """bf16 x 3 images of a set of GEMM weights, made in ONE launch (rec_gemm_b_images) ahead of the GEMMs that consume
+    them: entries (B, trans_b) in the orientation the consuming call passes.  get(i) -> the image tensor (or None where
+    the shape has no image form: the call then splits for itself, or runs the exact-f32 kernel)."""
+
+    def __init__(self, specs, device):
+        self.specs, self.images = list(specs), []
+        for B, trans_b in self.specs:
+            n, k = (B.shape if trans_b else B.shape[::-1])
+            ok, nb = C.c_int32(0), C.c_size_t(0)
+            check(lib().rec_gemm_b_image_bytes(int(k), int(n), C.byref(ok), C.byref(nb)), "rec_gemm_b_image_bytes")
+            self.images.append(torch.empty(nb.value, dtype=torch.uint8, device=device) if ok.value else None)
+        live = [(B, t, img) for (B, t), img in zip(self.specs, self.images) if img is not None]
+        self._items = (GemmBImage * max(1, len(live)))()
+        self._n = len(live)
+        for it, (B, t, img) in zip(self._items, live):
+            n, k = (B.shape if t else B.shape[::-1])
+            it.B, it.ldb, it.k, it.n, it.trans_b, it.image = B.data_ptr(), _chk_mat(B, "B"), int(k), int(n), int(t), img.data_ptr()
+
+    def refresh(self):
+        """Re-split every weight from its current values on the current stream."""
+        if self._n:
+            check(lib().rec_gemm_b_images(self._n, self._items, _stream()), "rec_gemm_b_images")
+
+    def get(self, i):
+        return self.images[i]
+
+
 def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux0=None, aux1=None,
-         out=None, split_k=0, b_colsum=None, row_scale=None, out2=None, num_cus=0):
+         out=None, split_k=0, b_colsum=None, row_scale=None, out2=None, num_cus=0, b_image=None):
     """out[M,N] = epi(op(A) @ op(B)); A/B/out row-major (row strides allowed).
     trans_a: A is given as [K,M]; trans_b: B is given as [N,K] (a torch Linear.weight, or W for dX).
     num_cus > 0: the current stream is confined to that many compute units (cu_range_stream) — size the
-    split-K for them instead of the whole chip."""
+    split-K for them instead of the whole chip.
+    b_image: op(B)'s bf16 x 3 image from GemmImages (current values of B): the call skips its own split launch."""
     lda, ldb = _chk_mat(A, "A"), _chk_mat(B, "B")
     K, M = (A.shape if trans_a else A.shape[::-1])
     N, K2 = (B.shape if trans_b else B.shape[::-1])
@@ -1468,10 +1497,11 @@ def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux
         d.split_k = sp.value
     pv = lambda t: None if t is None else t.data_ptr()
     x = GemmEpilogueArgs(pv(bias), pv(aux0), ld0, pv(aux1), ld1, pv(row_scale), rs_stride, pv(out2),
-                         ld2, pv(b_colsum))
+                         ld2, pv(b_colsum), pv(b_image))
     if _recorder is not None:      # a recorded step holds these addresses too
-        _recorder.keep.extend(t for t in (bias, aux0, aux1, row_scale, out2, b_colsum) if t is not None)
-    key = (M, N, K, lda, ldb, ldc, d.trans_a, d.trans_b, d.epilogue, d.split_k, os.environ.get("REC_GEMM_BF16X3"))
+        _recorder.keep.extend(t for t in (bias, aux0, aux1, row_scale, out2, b_colsum, b_image) if t is not None)
+    key = (M, N, K, lda, ldb, ldc, d.trans_a, d.trans_b, d.epilogue, d.split_k, os.environ.get("REC_GEMM_BF16X3"),
+           os.environ.get("REC_GEMM_BF16X3_DW"))
     need = _gemm_ws_cache.get(key)
     if need is None:       # a pure function of the descriptor: one C call per distinct GEMM, not per launch
         nbytes = C.c_size_t(0)
@@ -1497,10 +1527,11 @@ def colsum(G, ws, out=None):
 
 
 # ------------------------------------------------------------------ top MLP on the GEMM above
-def mlp_forward(x, weights, biases, ws, relu_last=False, out_last=None):
+def mlp_forward(x, weights, biases, ws, relu_last=False, out_last=None, images=None):
     """Linear(+bias)->ReLU ... ->Linear (deepfm/net.py:142-174) with Paddle-layout weights [in,out];
     bias and ReLU run in the GEMM epilogue.  relu_last: ReLU after the last layer too (the DNN tower of
     dcn_v2/net.py:161-184); out_last: buffer (view) for the last layer's output.
+    images[i]: the bf16 x 3 image of weights[i] (GemmImages, current values) or None.
     Returns (y, acts): acts[i] = input of layer i."""
     acts = []
     n = len(weights)
@@ -1508,7 +1539,7 @@ def mlp_forward(x, weights, biases, ws, relu_last=False, out_last=None):
         acts.append(x)
         last = i == n - 1
         x = gemm(x, weights[i], ws, epilogue="bias_relu" if (not last or relu_last) else "bias",
-                 bias=biases[i], out=out_last if last else None)
+                 bias=biases[i], out=out_last if last else None, b_image=images[i] if images is not None else None)
     return x, acts + [x]
 
 
@@ -1573,7 +1604,7 @@ def _head_ok(act, w, dw, db, dy):
 
 
 def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=False, dw_stream=None, dw_ws=None,
-                 defer_split=0):
+                 defer_split=0, images_t=None):
     """Backward of mlp_forward: dW_i -> dws[i], db_i -> dbs[i] (preallocated views); returns d(input).
     ReLU' is applied in the epilogue of the dX GEMM (mask = layer input > 0).
     defer_first: compute d(input) BEFORE dW_0 and return (d_input, finish) where finish() launches the
@@ -1583,6 +1614,7 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
     — the row-sharded step hides its gradient exchange, sparse optimizer and the next batch's lookup under them."""
     n = len(weights)
     g = dy
+    imt = (lambda i: images_t[i]) if images_t is not None else (lambda i: None)   # images of weights[i]^T (the dX GEMMs)
     head = n > 1 and _head_ok(acts[n - 1], weights[n - 1], dws[n - 1], dbs[n - 1], dy)
     if head:
         # the one-logit head: dX (with the ReLU mask of the layer in front), dW and db in ONE pass over its input
@@ -1594,7 +1626,8 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
         gs = [None] * n_run
         for i in reversed(range(n_run)):
             gs[i] = g
-            g = gemm(g, weights[i], ws, trans_b=True, **(dict(epilogue="relu_mask", aux0=acts[i]) if i > 0 else {}))
+            g = gemm(g, weights[i], ws, trans_b=True, b_image=imt(i),
+                     **(dict(epilogue="relu_mask", aux0=acts[i]) if i > 0 else {}))
 
         def finish(num_cus=0):
             for i in reversed(range(n_run)):
@@ -1610,7 +1643,7 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
     for i in reversed(range(n_run)):
         if i == 0 and defer_first:
             g0 = g
-            d_in = gemm(g0, weights[0], ws, trans_b=True)
+            d_in = gemm(g0, weights[0], ws, trans_b=True, b_image=imt(0))
             join()
             # defer_split: K split of the deferred dW_0 GEMM (0 = the planner's: one resident round of blocks) — the
             # caller that runs an HBM-bound kernel beside it asks for fewer, longer blocks, which leave it wave slots
@@ -1625,9 +1658,9 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
         else:
             gemm(acts[i], g, ws, trans_a=True, out=dws[i], b_colsum=dbs[i])    # dW = X^T G, db = colsum(G)
         if i > 0:
-            g = gemm(g, weights[i], ws, trans_b=True, epilogue="relu_mask", aux0=acts[i])
+            g = gemm(g, weights[i], ws, trans_b=True, epilogue="relu_mask", aux0=acts[i], b_image=imt(i))
         else:
-            g = gemm(g, weights[i], ws, trans_b=True)
+            g = gemm(g, weights[i], ws, trans_b=True, b_image=imt(i))
     join()
     return g
 
@@ -1679,33 +1712,39 @@ def fill_uniform(buf, lo, hi, seed):
 _SIDE_STREAMS = {}
 
 
-def concurrent_stream(device, tries=8, micros=200, priority=None):
+def concurrent_stream(device, tries=8, micros=200, priority=None, index=0):
     """A side stream whose kernels really run CONCURRENTLY with the current stream's.  HIP multiplexes streams
     onto a few hardware queues (4 by default, shared with the streams RCCL and rocPRIM create); two streams on
     one queue execute strictly in submission order, which silently turns 'sparse optimizer underneath the dW
     GEMM' into 'after it'.  Probe: spin `micros` on a candidate, then on the current stream, and accept the
-    candidate if the second spin did not have to wait for the first (events).  Cached per (device, main stream)."""
+    candidate if the second spin did not have to wait for the first (events).  Cached per (device, main stream).
+    index > 0: a further stream that also overlaps with the side streams of the lower indices (its own hardware queue)."""
     device = torch.device(device)
     main = torch.cuda.current_stream(device)
     if priority is None:
         priority = int(os.environ.get("REC_SIDE_PRIORITY", "0"))      # -1 = high priority queue (measured: no effect)
-    key = (device.index, main.cuda_stream, priority)
+    key = (device.index, main.cuda_stream, priority, int(index))
     if key in _SIDE_STREAMS:
         return _SIDE_STREAMS[key]
-    s = None
+    others = [main] + [concurrent_stream(device, tries, micros, priority, j) for j in range(int(index))]
+
+    def overlaps(s, o):
+        for st in (s, o):                                         # first use of a stream binds its queue
+            check(lib().rec_stream_spin(1, C.c_void_p(st.cuda_stream)), "rec_stream_spin")
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(o)
+        check(lib().rec_stream_spin(micros, C.c_void_p(s.cuda_stream)), "rec_stream_spin")
+        check(lib().rec_stream_spin(micros, C.c_void_p(o.cuda_stream)), "rec_stream_spin")
+        e1.record(o)
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1) * 1e3 < 1.5 * micros
+    s, keep = None, []
     with torch.cuda.device(device):
         for _ in range(tries):
             s = torch.cuda.Stream(device=device, priority=priority)
-            for st in (s, main):                                  # first use of a stream binds its queue
-                check(lib().rec_stream_spin(1, C.c_void_p(st.cuda_stream)), "rec_stream_spin")
-            torch.cuda.synchronize(device)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(main)
-            check(lib().rec_stream_spin(micros, C.c_void_p(s.cuda_stream)), "rec_stream_spin")
-            check(lib().rec_stream_spin(micros, C.c_void_p(main.cuda_stream)), "rec_stream_spin")
-            e1.record(main)
-            torch.cuda.synchronize(device)
-            if e0.elapsed_time(e1) * 1e3 < 1.5 * micros:
+            keep.append(s)          # rejected candidates stay alive until the search ends: a freed stream's queue slot
+            if all(overlaps(s, o) for o in others):               # would be handed to the next candidate again
                 break
     _SIDE_STREAMS[key] = s
     return s

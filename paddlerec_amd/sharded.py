@@ -620,6 +620,7 @@ class ShardedDeepFMLayer(DeepFMLayer):
         loss = loss_slot.clone()
         loss_slot.zero_()                                         # not a parameter: keep Adam off it
         k.adam_dense(self.dense.data, self.dense.m, self.dense.v, self.dense.grad, t, lr)
+        self._w_key = None          # the folded layer-0 weight belongs to the old parameters
         if on_gpu:
             cur.wait_stream(self._side)
         return loss, pred
