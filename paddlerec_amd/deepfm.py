@@ -577,6 +577,9 @@ class DeepFMLayer:
         if self._adam_done is not None:     # pipelined: the lookup reads fm.dense_w / dense_w_one, which the previous step's
             cur.wait_event(self._adam_done)     # dense Adam (side stream) wrote — long done when the update in front of
             self._adam_done = None              # this point has finished, so the wait costs nothing
+        if os.environ.get("REC_PIPE_JOIN", "early") == "early":
+            self.sync()     # ONE cross-queue wait in front of the lookup instead of two (every such wait costs the main
+            #                 stream ~20 us in the step, fired or not): the side chain ends when the update does
         with self._timed("fm_fwd"):
             y1, y2, feat, sum_emb, _ = self._fm_fwd(ids, dense_inputs)
         self.sync()     # pipelined: the previous step's dense tail (side stream) is needed from the first GEMM on

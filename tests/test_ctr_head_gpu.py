@@ -14,16 +14,17 @@ def ops(engine_lib):
     return o
 
 
-def _ref(act, w, b, y1, y2, label, eps, clip):
-    a = act.double().requires_grad_(True)
-    wd = w.double().requires_grad_(True)
-    bd = b.double().requires_grad_(True)
+def _ref(act, w, b, y1, y2, label, eps, clip, dtype=torch.float64):
+    """float64: the reference; float32: the same graph in the kernel's own precision — the measured fp32 floor."""
+    a = act.to(dtype).requires_grad_(True)
+    wd = w.to(dtype).requires_grad_(True)
+    bd = b.to(dtype).requires_grad_(True)
     y = a @ wd + bd
-    z = y if y1 is None else (y1.double() + (y2.double() if y2 is not None else 0) + y)
+    z = y if y1 is None else (y1.to(dtype) + (y2.to(dtype) if y2 is not None else 0) + y)
     z.retain_grad()
     zc = z.clamp(clip[0], clip[1]) if clip else z
     p = torch.sigmoid(zc)
-    t = label.double().reshape(-1, 1)
+    t = label.to(dtype).reshape(-1, 1)
     loss = (-t * torch.log(p + eps) - (1 - t) * torch.log(1 - p + eps)).mean()
     loss.backward()
     return p.detach(), z.grad, loss.detach(), a.grad, wd.grad, bd.grad
@@ -48,7 +49,14 @@ def test_ctr_head_against_float64_and_the_separate_calls(ops, B, n, with_fm, cli
     dx_r = torch.where(act > 0, dx_r, torch.zeros_like(dx_r))
     close = lambda x, r, tol: float((x.double() - r).abs().max()) <= tol * max(float(r.abs().max()), 1e-30)
     assert close(pred, p_r, 2e-6) and close(dz, dz_r, 1e-5) and close(loss, loss_r, 2e-6)
-    assert close(dx, dx_r, 1e-5) and close(dw, dw_r, 2e-5) and close(db, db_r.reshape(1), 2e-5)
+    assert close(dx, dx_r, 1e-5)
+    # dw / db are sums over the batch of O(1/B) terms of either sign: 1e-5 of the result, or 4 x the distance of the SAME
+    # graph in float32 (torch, its own summation order) from the float64 one — the measured fp32 floor
+    from helpers import assert_close_floor
+    _, _, _, _, dw32, db32 = _ref(act, w, b, y1, y2, label, 1e-4, clip, dtype=torch.float32)
+    n64 = lambda x: x.detach().double().cpu().numpy()
+    assert_close_floor(n64(dw), n64(dw_r), n64(dw32), rel=1e-5, err_msg="dw")
+    assert_close_floor(n64(db).reshape(1), n64(db_r).reshape(1), n64(db32).reshape(1), rel=1e-5, err_msg="db")
     # ... and against the five launches it replaces: same arithmetic per element
     y = ops.gemm(act, w, ws, epilogue="bias", bias=b)
     a1, a2, a3 = (y1, y2, y) if with_fm else (y, None, None)

@@ -424,3 +424,53 @@ def test_gemm_bf16x3_weight_gradient(ops, monkeypatch, rows, kin, nout):
         _check(res[v][0], want, bound)
         _check(res[v][1], cwant, cbound)
     assert not np.array_equal(res["0"][0], res["1"][0]), "REC_GEMM_BF16X3=1 did not select the bf16 x 3 weight-gradient kernel"
+
+
+def test_gemm_nonfinite_operands(ops, monkeypatch):
+    """Non-finite and extreme operands on both GEMM families (include/recengine.h "ARITHMETIC"):
+      exact f32 (REC_GEMM_BF16X3=0): IEEE — an Inf operand gives +-Inf, relu(-Inf) = 0, relu(+Inf) = +Inf;
+      bf16 x 3: the second term of an Inf (or of a finite |x| > 3.39e38, which rounds to the bf16 Inf) is Inf - Inf, so the
+      row comes out NaN; behind BIAS_RELU the epilogue's fmaxf(NaN, 0) turns that into 0 — also where the exact kernel
+      returns +Inf.  NaN operands give NaN in both (0 behind BIAS_RELU in both: fmaxf).  Rows without such an operand are
+      untouched: finite and inside the float64 bound in both families.  Operands so small that their third bf16 term is
+      subnormal (|x| < 2^-110) lose that term: an absolute error below 2^-126 per product, invisible at the bound."""
+    rng = np.random.default_rng(11)
+    M, N, K = 8192, 400, 400
+    A, B, bias = _mk(rng, M, K), _mk(rng, K, N), _mk(rng, N)
+    B[7, :] = np.abs(B[7, :]) + 0.1                       # a column-independent sign for the special operands' products
+    A[100, 7] = np.inf
+    A[200, 7] = -np.inf
+    A[300, 7] = np.nan
+    A[400, 7] = 3.4e38                                    # finite in f32, Inf as a bf16 first term
+    A[500, :] = (A[500, :] * 2.0 ** -118).astype(np.float32)          # third terms below the bf16 normal range
+    special = [100, 200, 300, 400]
+    plain = np.ones(M, bool)
+    plain[special] = False
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    out = {}
+    for fam in ("0", "1"):
+        monkeypatch.setenv("REC_GEMM_BF16X3", fam)
+        ws = ops.Workspace(DEV)
+        out[fam, "none"] = ops.gemm(t(A), t(B), ws).cpu().numpy()
+        out[fam, "relu"] = ops.gemm(t(A), t(B), ws, epilogue="bias_relu", bias=t(bias)).cpu().numpy()
+    Af = np.where(np.isfinite(A), A, 0).astype(np.float64)
+    Af[400, 7] = 0
+    want = Af @ B.astype(np.float64)
+    bound = 4e-7 * (np.abs(Af) @ np.abs(B).astype(np.float64)) + 1e-37
+    for fam in ("0", "1"):                                # rows without a special operand: finite, inside the bound
+        C = out[fam, "none"]
+        assert np.all(np.isfinite(C[plain]))
+        _check(C[plain], want[plain], bound[plain])
+        R = out[fam, "relu"]
+        assert np.all(np.isfinite(R[plain])) and np.all(R[plain] >= 0)
+    # exact f32: IEEE
+    e, er = out["0", "none"], out["0", "relu"]
+    assert np.all(np.isposinf(e[100])) and np.all(np.isneginf(e[200])) and np.all(np.isnan(e[300]))
+    assert np.all(np.isfinite(e[400]) | np.isposinf(e[400]))                     # 3.4e38 x b (|b| <= 1.1): finite or overflow
+    assert np.all(np.isposinf(er[100])) and np.all(er[200] == 0) and np.all(er[300] == 0)      # fmaxf(NaN, 0) = 0
+    # bf16 x 3: the row of a non-finite / overflowing operand is NaN, and 0 behind the ReLU
+    x, xr = out["1", "none"], out["1", "relu"]
+    for r in special:
+        assert np.all(np.isnan(x[r])), r
+        assert np.all(xr[r] == 0), r
+    assert not np.array_equal(out["0", "none"][plain], out["1", "none"][plain])     # the switch really switched

@@ -233,11 +233,23 @@ def _check_against_oracles(tmp_path, gpu, tree=REF):
         assert np.array_equal(got[:, col], want[:, col]), what
     assert (want[:, D + 4] == 2).any() and (want[:, D + 4] == 1).any()         # embedx created for some keys, not for all
     np.testing.assert_allclose(got[:, D + 5], want[:, D + 5], rtol=1e-6, err_msg="delta_score")
+    # Weights and g2sums: 1e-5 of the tensor's scale, or 4 x the MEASURED sensitivity of this two-pass trajectory to fp32
+    # round-off — the same oracle replay from initial dense parameters moved by ONE ulp (the dense Adam turns the sign
+    # noise of ~eps-sized gradients into lr-sized steps, which reach the embedding gradients of later steps): what the
+    # oracle cannot reproduce of itself, the kernels are not asked to reproduce of it
+    init_ulp = {k: np.nextafter(v, np.float32(np.inf)) for k, v in init.items()}
+    rec_ulp, _, _ = _oracle_replay(init_ulp, data, epochs, 32, rows_n)
+    want_ulp = rec_ulp[want_rows]
     wscale = float(np.abs(want[:, :D]).max())
+    wfloor = float(np.abs(want_ulp[:, :D] - want[:, :D]).max())
     werr = np.abs(got[:, :D] - want[:, :D])
-    assert float(np.mean(werr <= 1e-5 * wscale)) >= 0.98 and float(werr.max()) <= 1e-4 * wscale, (werr.max(), wscale)
+    assert float(werr.max()) <= max(1e-5 * wscale, 4.0 * wfloor), (float(werr.max()), wscale, wfloor)
     g2 = want[:, D + 2:D + 4]
-    np.testing.assert_allclose(got[:, D + 2:D + 4], g2, rtol=1e-4, atol=1e-5 * float(g2.max()))
+    gfloor = float(np.abs(want_ulp[:, D + 2:D + 4] - g2).max())
+    gerr = float(np.abs(got[:, D + 2:D + 4] - g2).max())
+    assert gerr <= max(1e-5 * float(g2.max()), 4.0 * gfloor), (gerr, float(g2.max()), gfloor)
+    print("gpubox checkpoint vs oracles: weights err %.3e (1e-5 of scale %.3e, measured floor %.3e); g2sum err %.3e (floor %.3e)"
+          % (float(werr.max()), 1e-5 * wscale, wfloor, gerr, gfloor))
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from helpers import assert_adam_weights_close
     steps = epochs * 3                                                          # 80 samples at batch 32: 3 steps per pass

@@ -112,13 +112,21 @@ for B, T in ((32, 152), (4096, 100), (4096, 512)):
     st = ops.new_status(DEV)
     att_ws = ops.Workspace(DEV)            # as DINLayer.forward calls it: tile split (B 32) / sample tickets (B 4096)
     t = timeit(lambda: ops.din_attention_pool(hi, hc, hi, hc, mask, *tabs, aw, ab, st, ws=att_ws))
-    fl = 2.0 * B * T * (512 * 80 + 80 * 40 + 40 + 128)     # what the reference computes: all B x T positions
+    per_pos = 2.0 * (512 * 80 + 80 * 40 + 40 + 128)
+    fl_dense = B * T * per_pos                  # what the reference computes: all B x T positions (padding included)
+    # what the KERNEL computes: the 32-position tiles that hold at least one valid position (the padded
+    # tail is not walked, so a rate on all B x T positions is a dense-equivalent figure, not a fraction of the pipe)
+    pos_exec = int(((lens.reshape(-1) + 31) // 32 * 32).clamp(max=(T + 31) // 32 * 32).sum().item())
+    fl = pos_exec * per_pos
     by = B * T * (4 * 8 + 8 + 4 * 256)          # ids + mask + 4 rows of 256 B (algorithmic, rows hit L2)
-    print("DIN attention-pool B=%d T=%d: %.3f ms  (%.1f M positions/s, %.2f TF, %.0f GB/s algorithmic)" %
-          (B, T, t, B * T / t / 1e3, fl / t / 1e9, by / t / 1e6))
+    print("DIN attention-pool B=%d T=%d: %.3f ms  (%.1f M positions/s dense-equivalent, %.2f TF executed = %.3f of the f32 "
+          "MFMA peak on %d of %d positions; %.2f TF dense-equivalent; %.0f GB/s algorithmic)" %
+          (B, T, t, B * T / t / 1e3, fl / t / 1e9, fl / t / 1e9 / PEAK_TF, pos_exec, B * T, fl_dense / t / 1e9, by / t / 1e6))
     record("configs[3]", "DIN attention-pool forward (4 gathers + 512-80-40-1 MLP + masked softmax + pool), B %d, "
-           "T %d, history lengths uniform in [1, T] (padded tail tiles are not walked)" % (B, T), t, fl, B,
-           {"positions_per_s": B * T / t * 1e3,
+           "T %d, history lengths uniform in [1, T] (padded tail tiles are not walked: roofline on EXECUTED flops)" % (B, T),
+           t, fl, B,
+           {"positions_per_s": B * T / t * 1e3, "positions_executed": pos_exec, "positions_dense": B * T,
+            "frac_executed": fl / t / 1e9 / PEAK_TF, "dense_equivalent_tflops": fl_dense / t / 1e9,
             "gather_roofline": {"bound": "hbm", "achieved": by / t / 1e6, "peak": PEAK_GBS, "unit": "GB/s",
                                 "frac": by / t / 1e6 / PEAK_GBS, "bytes": by}},
            hbm_bytes=(by if B * T < 65536 else None),
@@ -141,14 +149,20 @@ for B, T in ((32, 152), (4096, 100), (4096, 512)):
     tis, tcs = ti.expand(B, T).contiguous(), tc.expand(B, T).contiguous()
     tm = timeit_stream if B * T <= 15360 else timeit
     t = tm(lambda: m.train_step(hi, hc, ti, tc, label, mask, tis, tcs))
-    fl = 2.0 * B * T * (512 * 80 + 80 * 40 + 40 + 128) + 2.0 * B * T * (512 * 80 + 2 * 80 * 40 + 128)
-    print("DIN train step B=%d T=%d: %.3f ms  (%.1f k samples/s, %.1f M positions/s, attention fwd+bwd %.1f TF executed)"
-          % (B, T, t, B / t, B * T / t / 1e3, fl / t / 1e9))
+    per_pos = 2.0 * (512 * 80 + 80 * 40 + 40 + 128) + 2.0 * (512 * 80 + 2 * 80 * 40 + 128)
+    fl_dense = B * T * per_pos
+    pos_exec = int(((lens.reshape(-1) + 31) // 32 * 32).clamp(max=(T + 31) // 32 * 32).sum().item())
+    fl = pos_exec * per_pos                     # the 32-position tiles the forward and the backward walk
+    print("DIN train step B=%d T=%d: %.3f ms  (%.1f k samples/s, %.1f M positions/s dense-equivalent, attention fwd+bwd "
+          "%.1f TF executed = %.3f of the f32 MFMA peak; %.1f TF dense-equivalent)"
+          % (B, T, t, B / t, B * T / t / 1e3, fl / t / 1e9, fl / t / 1e9 / PEAK_TF, fl_dense / t / 1e9))
     # bytes of a step: history rows gathered by forward and backward (4 x 256 B per position each), act1 saved and re-read
     # (80 floats), dh / dq written (2 x 128 floats), row gradients merged into 7 tables (read + write 128 floats), ids + mask
     by_step = B * T * (2 * 4 * 256 + 2 * 80 * 4 + 2 * 128 * 4 + 2 * 128 * 4 + 5 * 8)
     record("configs[3]", "DIN train step (attention-pool fwd + bwd on saved activations, concat MLP, row-merged SGD on "
-           "7 tables), B %d, T %d" % (B, T), t, fl, B, {"positions_per_s": B * T / t * 1e3},
+           "7 tables), B %d, T %d (roofline on EXECUTED flops)" % (B, T), t, fl, B,
+           {"positions_per_s": B * T / t * 1e3, "positions_executed": pos_exec, "positions_dense": B * T,
+            "frac_executed": fl / t / 1e9 / PEAK_TF, "dense_equivalent_tflops": fl_dense / t / 1e9},
            hbm_bytes=(by_step if B * T < 65536 else None),
            bytes_formula=("B T (gathers fwd + bwd 2 x 4 x 256 + act1 2 x 320 + dh / dq 2 x 512 + row-gradient merge 2 x 512 "
                           "+ ids / mask 40) B: ~25 dependent launches at the ~5 us floor each are the step time"
