@@ -200,26 +200,50 @@ def link_model_us(tag, remote_bytes, world, calls=1.0):
     return remote_bytes / (links * XGMI_LINK_GBS * 1e9) * 1e6 + 8.0 * calls
 
 
-def dry_links(B, S, D, table, worlds=(2, 4, 8)):
+def _distinct_share(n, rows, zipf_alpha=None, seed=20250404):
+    """Expected fraction of a rank's n lookups that are DISTINCT rows (what the deduplicated exchange moves), for uniform
+    ids over `rows` rows (closed form) or Zipf(alpha) ids (one sampled batch; the ids of SURVEY section 8(d): alpha 1.05)."""
+    import numpy as np
+    if zipf_alpha is None:
+        return float(rows * (1.0 - np.exp(-n / rows)) / n) if rows < 1e12 else 1.0
+    r = np.random.default_rng(seed).zipf(zipf_alpha, size=min(n, 1 << 21))
+    return float(len(np.unique(np.minimum(r, int(rows) - 1))) / len(r))
+
+
+def dry_links(B, S, D, table, worlds=(2, 4, 8), rows=None, dedup_cap=1.25):
     """bench.py --dry-links: the per-GPU, per-step exchange volumes of the row-sharded step (SURVEY §8(d) "all-to-all
     bytes") and the link model's time for each collective, WITHOUT touching a GPU — what `exchange.per_collective`
-    should look like on real links.  Uniform ids: a fraction (G-1)/G of a rank's lookups is owned by a peer."""
-    rows = []
+    should look like on real links.  Uniform ids: a fraction (G-1)/G of a rank's lookups is owned by a peer.
+    Both exchanges are priced: the plain one (every lookup crosses, exact sizes one step ahead through pinned memory) and
+    the DEDUPLICATED one (REC_SHARD_DEDUP=1: distinct rows only, fixed capacity dedup_cap x n / G slots per owner — the
+    slots travel whether filled or not, so uniform ids pay the slack and Zipf ids save what they repeat)."""
+    out = []
     c1 = 2 if table == "ps" else 1                  # PS: the click label rides with dz
+    c1d = 3 if table == "ps" else 1                 # deduplicated PS: dz | occurrences | clicks of the distinct row
     dense_params = 13 * (D + 1) + (S + 1) * D * 400 + 400 + 2 * (400 * 400 + 400) + 400 + 1 + 1
+    rows = float(rows or 26e6)
     for G in worlds:
         n, f = B * S, (G - 1) / G
         per = {"a2a_counts": (2 * G * 8, 2 * G * 8 * f, 2), "a2a_ids": (n * 8, n * 8 * f, 1),
                "a2a_rows": (n * (D + 1) * 4, n * (D + 1) * 4 * f, 2),
                "a2a_grads": (n * (D + c1) * 4, n * (D + c1) * 4 * f, 2),
                "allreduce_dense": (dense_params * 4, 2 * dense_params * 4 * f, 1)}
-        rows.append({"world": G, "per_collective": {
-            k: {"bytes_per_step": b, "remote_bytes_per_step": r, "calls_per_step": c,
-                "predicted_us": round(link_model_us(k, r, G, c), 1)} for k, (b, r, c) in per.items()},
-            "predicted_exchange_us_total": round(sum(link_model_us(k, r, G, c) for k, (b, r, c) in per.items()), 1)})
-    return {"workload": "row-sharded DeepFM step, batch %d per GPU, %d slots, dim %d, table %s" % (B, S, D, table),
+        slots = G * (int(dedup_cap * n / G) + 64)              # ShardedDeepFMLayer.dedup_capacity
+        ded = {"a2a_ids": (slots * 8, slots * 8 * f, 1), "a2a_rows": (slots * (D + 1) * 4, slots * (D + 1) * 4 * f, 2),
+               "a2a_grads": (slots * (D + c1d) * 4, slots * (D + c1d) * 4 * f, 2),
+               "allreduce_dense": per["allreduce_dense"]}
+        fmt = lambda d_: {k: {"bytes_per_step": b, "remote_bytes_per_step": r, "calls_per_step": c,
+                              "predicted_us": round(link_model_us(k, r, G, c), 1)} for k, (b, r, c) in d_.items()}
+        tot = lambda d_: round(sum(link_model_us(k, r, G, c) for k, (b, r, c) in d_.items()), 1)
+        out.append({"world": G, "per_collective": fmt(per), "predicted_exchange_us_total": tot(per),
+                    "dedup": {"slots_per_step": slots, "per_collective": fmt(ded), "predicted_exchange_us_total": tot(ded),
+                              "distinct_share_uniform": round(_distinct_share(n, rows), 4),
+                              "distinct_share_zipf_1p05": round(_distinct_share(n, rows, 1.05), 4),
+                              "note": "slots = G x (%.2f n / G + 64): the fixed capacity travels; with exact sizes the "
+                                      "payload would be distinct_share x the plain exchange's bytes" % dedup_cap}})
+    return {"workload": "row-sharded DeepFM step, batch %d per GPU, %d slots, dim %d, table %s, %.3g rows" % (B, S, D, table, rows),
             "model": "remote bytes / (links x %.0f GB/s) + 8 us per call; all-to-all uses min(G-1, %d) links, ring "
-                     "all-reduce one" % (XGMI_LINK_GBS, XGMI_LINKS), "worlds": rows}
+                     "all-reduce one" % (XGMI_LINK_GBS, XGMI_LINKS), "worlds": out}
 
 
 def empty_bracket_us(dev, n=50):

@@ -36,6 +36,9 @@ typedef enum {
 
 /* bits OR-ed into a device status word */
 #define REC_FLAG_INDEX_OOB 1 /* an id was < 0 or >= num_rows (Paddle raises on OOB [EXT]) */
+#define REC_FLAG_EXCHANGE_OVERFLOW 2 /* host binders (paddlerec_amd/sharded.py, deduplicated exchange): a rank needed more
+                                        distinct rows of one owner than the fixed exchange capacity; the rows behind it
+                                        read as zeros and their gradients are dropped — raise the capacity */
 
 const char* rec_last_error(void); /* host; thread-local */
 int rec_version(void);            /* host */

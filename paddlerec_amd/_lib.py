@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librecengine.so")
 
 REC_FLAG_INDEX_OOB = 1
+REC_FLAG_EXCHANGE_OVERFLOW = 2
 
 
 class RecError(RuntimeError):

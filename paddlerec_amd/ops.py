@@ -107,6 +107,9 @@ def raise_on_status(status, what="lookup"):
     s = int(status.item())
     if s & _lib.REC_FLAG_INDEX_OOB:
         raise RecError("%s: index out of range [0, num_rows)" % what)
+    if s & _lib.REC_FLAG_EXCHANGE_OVERFLOW:
+        raise RecError("%s: a rank needed more distinct rows of one owner than the deduplicated exchange's capacity "
+                       "(REC_SHARD_DEDUP_CAP)" % what)
 
 
 class Workspace:
@@ -1384,6 +1387,91 @@ class ShardRoute:
         self.send_sample = torch.empty(max(n, 1), **i64)
         self.slot_of_pos = torch.empty(max(n, 1), **i64)
         self.send_counts = torch.zeros(num_shards + 1, **i64)
+
+
+class DedupPlan:
+    """One deduplicated lookup of a row-sharded table (paddlerec_amd/sharded.py, REC_SHARD_DEDUP): the DISTINCT rows this
+    rank needs of every owner, in fixed-capacity send slots (owner o owns slots [o * cap, (o + 1) * cap)), and the maps
+    between lookup positions, distinct rows and slots.  Everything lives on the device; nothing here reads it back."""
+
+    def __init__(self, n, num_shards, cap, device):
+        self.n, self.num_shards, self.cap = n, num_shards, cap
+        self.groups = IdGroups(n, device)                  # grouping of the lookups by (owner, local row)
+        i64 = dict(dtype=torch.int64, device=device)
+        self.send_rows = torch.empty(num_shards * cap, **i64)       # local row per slot; empty slots hold `sentinel`
+        self.slot_of_pos = torch.empty(max(n, 1), **i64)            # 1 + slot of the position's row; 0: padding / dropped
+        self.slot_of_uniq = torch.empty(max(n, 1), **i64)           # slot of distinct row u; num_shards * cap: none
+        self.counts = torch.zeros(num_shards, **i64)                # distinct rows per owner (before the capacity cut)
+        self.sentinel = None
+
+
+def dedup_plan(ids, num_rows, padding_idx, num_shards, local_rows, cap, ws, slot_offset=None, status=None, plan=None):
+    """Distinct (owner, local row) pairs of a batch of lookups, owner-major and ascending — HeterPS dedups a pass's keys
+    before it builds the per-GPU tables (tools/static_gpubox_trainer.py:237-246).  ids [B,S] int64; row = id +
+    slot_offset[s]; owner = row % num_shards, local row = row // num_shards.  Device only (rec_ids_group + index
+    arithmetic), no host read: sizes are the fixed capacity `cap` rows per owner; a rank that needs more of one owner sets
+    REC_FLAG_EXCHANGE_OVERFLOW and loses the rows behind the capacity."""
+    _chk(ids, torch.int64, "ids")
+    n, G, dev = ids.numel(), int(num_shards), ids.device
+    if plan is None or plan.n != n or plan.cap != cap or plan.num_shards != G:
+        plan = DedupPlan(n, G, cap, dev)
+    if status is None:
+        status = new_status(dev)
+    rows = ids if slot_offset is None else ids + slot_offset.reshape(1, -1)
+    pad = (ids == int(padding_idx)) if padding_idx is not None else torch.zeros_like(ids, dtype=torch.bool)
+    oob = ((rows < 0) | (rows >= int(num_rows))) & ~pad
+    status.bitwise_or_(oob.any().to(torch.int32) * _lib.REC_FLAG_INDEX_OOB)
+    kpad = G * int(local_rows)                      # the shard-major key space is [0, G * local_rows); kpad = "no lookup"
+    key = torch.where(pad | oob, torch.full_like(rows, kpad), (rows % G) * int(local_rows) + rows // G).reshape(-1)
+    g = plan.groups
+    ids_group(key.contiguous(), kpad + 1, kpad, ws, None, status, g)
+    U, nv = g.n_uniq[0].to(torch.int64), g.n_uniq[1].to(torch.int64)
+    ar = torch.arange(n, dtype=torch.int64, device=dev)
+    uvalid = ar < U
+    owner = torch.where(uvalid, g.uniq_rows[:n] // int(local_rows), torch.full_like(ar, G))
+    counts = torch.zeros(G + 1, dtype=torch.int64, device=dev).scatter_add_(0, owner, torch.ones_like(ar))[:G]
+    plan.counts.copy_(counts)
+    offs = torch.cumsum(counts, 0) - counts
+    oc = owner.clamp(max=G - 1)
+    j = ar - offs[oc]
+    fits = uvalid & (j < cap)
+    status.bitwise_or_((uvalid & ~fits).any().to(torch.int32) * _lib.REC_FLAG_EXCHANGE_OVERFLOW)
+    none = G * cap
+    plan.slot_of_uniq[:n] = torch.where(fits, oc * cap + j, torch.full_like(ar, none))
+    plan.sentinel = int(local_rows)
+    buf = torch.full((none + 1,), int(local_rows), dtype=torch.int64, device=dev)
+    buf[plan.slot_of_uniq[:n]] = torch.where(fits, g.uniq_rows[:n] - oc * int(local_rows), torch.full_like(ar, int(local_rows)))
+    plan.send_rows.copy_(buf[:none])
+    # position -> slot: sorted index k belongs to distinct row u = #{u' : seg_offset[u' + 1] <= k}
+    seg_hi = torch.where(torch.arange(1, n + 1, dtype=torch.int64, device=dev) <= U, g.seg_offset[1:n + 1].to(torch.int64),
+                         torch.full_like(ar, 1 << 62))
+    u_of_k = torch.searchsorted(seg_hi, ar, right=True).clamp(max=max(n - 1, 0))
+    kvalid = ar < nv
+    su = plan.slot_of_uniq[u_of_k]
+    slot_k = torch.where(kvalid & (su < none), su + 1, torch.zeros_like(ar))
+    pos = torch.where(kvalid, g.sorted_pos[:n].to(torch.int64), torch.full_like(ar, n))
+    out = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    out[pos] = slot_k
+    plan.slot_of_pos[:n] = out[:n]
+    return plan, status
+
+
+def dedup_merge(plan, grad, emb_dim, grad_div=1, out=None):
+    """The gradient rows of a deduplicated lookup merged per distinct row (duplicates summed in ascending position
+    order, as every merge of the engine) and laid into the plan's send slots: out [num_shards * cap, emb_dim], zeros in
+    the empty slots.  grad: [n / grad_div, emb_dim] (grad_div = S: one row per sample serving its S lookups)."""
+    G, cap, D = plan.num_shards, plan.cap, int(emb_dim)
+    none = G * cap
+    if out is None or out.shape[0] != none + 1:
+        out = torch.empty(none + 1, D, dtype=torch.float32, device=grad.device)      # + one row the unplaced rows land in
+    out.zero_()
+
+    class _G:                                   # the plan's grouping with the send slot in the place of the table row
+        pass
+    g, f = plan.groups, _G()
+    f.n, f.n_uniq, f.seg_offset, f.sorted_pos, f.uniq_rows = g.n, g.n_uniq, g.seg_offset, g.sorted_pos, plan.slot_of_uniq
+    sparse_sgd_rows(f, grad, out, -1.0, grad_div=grad_div)          # 0 - (-1) * sum = sum, exactly
+    return out
 
 
 def shard_route(ids, num_rows, padding_idx, num_shards, ws, slot_offset=None, status=None,

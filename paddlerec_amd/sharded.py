@@ -290,8 +290,8 @@ class Comm:
 
 class _Lookup:
     """Everything one routed lookup leaves behind for the backward exchange."""
-    __slots__ = ("route", "send_splits", "recv_splits", "n_send", "n_recv", "recv_rows", "reply",
-                 "reply1")
+    __slots__ = ("route", "plan", "slot_of_pos", "send_splits", "recv_splits", "n_send", "n_recv", "recv_rows",
+                 "reply", "reply1")
 
 
 class ShardedDeepFMLayer(DeepFMLayer):
@@ -302,7 +302,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
 
     def __init__(self, sparse_feature_number, sparse_feature_dim, dense_feature_dim,
                  sparse_num_field, layer_sizes, device="cuda", slot_offset=None, group=None,
-                 comm=None, kernels=None, table="adam", accessor=None, hash_keys=False, scale_sparse_grad=True):
+                 comm=None, kernels=None, table="adam", accessor=None, hash_keys=False, scale_sparse_grad=True,
+                 dedup=None, dedup_cap=None):
         """table 'adam': the record layout + lazy Adam of the unsharded layer.  table 'ps': the gpubox feature value
         (tools/static_gpubox_trainer.py:152-160; accessor = slot_dnn/config_online.yaml:57-89) — ONE 128-B record
         line per row [W(16) | W1 | show | click | g2sum_w | g2sum_x | state | delta_score | unseen_days], no second
@@ -352,6 +353,14 @@ class ShardedDeepFMLayer(DeepFMLayer):
         self._gemm_stream, self._gemm_cus = None, 0
         self._xbuf, self._pinned = {}, [None, None]
         self._next_lookup = None
+        # Deduplicated exchange (REC_SHARD_DEDUP=1 / dedup=True): a rank asks every owner for its DISTINCT rows only,
+        # expands the reply locally and merges its row gradients locally before they travel — what HeterPS does per pass
+        # (tools/static_gpubox_trainer.py:237-259: load_into_memory -> begin_pass builds the pass's key set).  The
+        # exchange sizes are a fixed capacity per owner (dedup_cap x the mean, REC_SHARD_DEDUP_CAP, default 1.25; capped
+        # by the lookups of a batch and the rows of a shard), so nothing on the step path reads the device back.
+        self.dedup = (os.environ.get("REC_SHARD_DEDUP", "0") == "1") if dedup is None else bool(dedup)
+        self.dedup_cap = float(os.environ.get("REC_SHARD_DEDUP_CAP", "1.25")) if dedup_cap is None else float(dedup_cap)
+        self._plans_d, self._plan_flip = [None, None], 0
 
     # -- parameters: global <-> shard --------------------------------------------------------------
     def set_dict(self, sd):
@@ -412,7 +421,52 @@ class ShardedDeepFMLayer(DeepFMLayer):
             pend.update(host=host, ev=ev, keep=recv_dev)
         return pend
 
+    def dedup_capacity(self, n):
+        """Send slots per owner of a deduplicated lookup of n positions."""
+        G = self.comm.world
+        cap = min(n, self.local_rows)
+        if self.dedup_cap > 0:
+            cap = min(cap, int(self.dedup_cap * n / G) + 64)
+        return max(cap, 1)
+
+    def _lookup_dedup(self, ids):
+        """The deduplicated lookup: plan (distinct rows per owner, fixed-capacity slots) -> all-to-all of the local
+        rows -> the owners gather -> all-to-all back; the forward reads the reply through slot_of_pos.  No host read."""
+        B, S = ids.shape
+        n, G, D = B * S, self.comm.world, self.sparse_feature_dim
+        k = self.k
+        cap = self.dedup_capacity(n)
+        if self.hash_keys:
+            ids = k.feasign_rows(ids, self.global_rows, out=self._fit("hashed_ids_d", n, 0, torch.int64).view(B, S))
+        self._plan_flip ^= 1                         # double-buffered like the routes: the next batch's lookup may be
+        plan, _ = k.dedup_plan(ids, self.global_rows, self.fm.padding_idx, G, self.local_rows, cap, self.ws_route,
+                               self.fm.slot_offset, self.status, self._plans_d[self._plan_flip])     # issued during this step
+        self._plans_d[self._plan_flip] = plan
+        L = _Lookup()
+        L.route, L.plan = None, plan
+        L.send_splits = L.recv_splits = [cap] * G
+        L.n_send = L.n_recv = G * cap
+        L.recv_rows = self._fit("recv_rows_d%d" % self._plan_flip, G * cap, 0, torch.int64)
+        self.comm.all_to_all(L.recv_rows, plan.send_rows, L.recv_splits, L.send_splits, tag="a2a_ids")
+        g_rows = self._fit("g_rows", G * cap, D)
+        g_w1 = self._fit("g_w1", G * cap, 1)
+        # empty slots carry the sentinel local_rows: they gather row 0, which nobody reads (no position maps to them)
+        rows_g = torch.where(L.recv_rows == plan.sentinel, torch.zeros_like(L.recv_rows), L.recv_rows)
+        k.record_gather(rows_g, self.fm.rec, D, g_rows, g_w1, self.status, table=self.ps)
+        self._reply_flip ^= 1
+        rep = self._replies[self._reply_flip]
+        if rep is None or rep[0].shape[0] != G * cap + 1:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            rep = self._replies[self._reply_flip] = (torch.zeros(G * cap + 1, D, **f32), torch.zeros(G * cap + 1, 1, **f32))
+        L.reply, L.reply1 = rep
+        self.comm.all_to_all(L.reply[1:], g_rows, L.send_splits, L.recv_splits, tag="a2a_rows")
+        self.comm.all_to_all(L.reply1[1:], g_w1, L.send_splits, L.recv_splits, tag="a2a_rows")
+        L.slot_of_pos = plan.slot_of_pos[:n]
+        return L
+
     def _lookup(self, ids):
+        if self.dedup:
+            return self._lookup_dedup(ids)
         B, S = ids.shape
         n, G, D = B * S, self.comm.world, self.sparse_feature_dim
         k = self.k
@@ -422,7 +476,8 @@ class ShardedDeepFMLayer(DeepFMLayer):
             pend = self._route_async(ids)
         route = pend["route"]
         L = _Lookup()
-        L.route = route
+        L.route, L.plan = route, None
+        L.slot_of_pos = route.slot_of_pos
         if pend["ev"] is not None:
             pend["ev"].synchronize()                  # normally long since complete (issued a step ahead)
             L.send_splits = [int(x) for x in pend["host"][0].tolist()]
@@ -452,7 +507,7 @@ class ShardedDeepFMLayer(DeepFMLayer):
 
     def _fm_fwd_routed(self, L, B, S, dense_inputs):
         # the reply buffer is a (n+1)-row table read through slot_of_pos; 0 = padding -> zero row
-        return self.k.deepfm_fm_fwd(L.route.slot_of_pos.view(B, S), dense_inputs, L.reply, L.reply1,
+        return self.k.deepfm_fm_fwd(L.slot_of_pos.view(B, S), dense_inputs, L.reply, L.reply1,
                                     self.dense.p["fm.dense_w"], self.dense.p["fm.dense_w_one"], 0, None,
                                     self.status, compact=self.compact)
 
@@ -514,9 +569,13 @@ class ShardedDeepFMLayer(DeepFMLayer):
             if self._groups is None or self._groups.n < L.n_recv:
                 self._groups = k.IdGroups(L.n_recv + L.n_recv // 8, self.device)
             with _Side():
-                groups, _ = k.ids_group(L.recv_rows, self.local_rows, None, self.ws_group, None,
-                                        self.status, self._groups)
-        if next_sparse_inputs is not None:
+                if L.plan is not None:        # empty slots hold the sentinel local_rows: dropped as the padding key
+                    groups, _ = k.ids_group(L.recv_rows, self.local_rows + 1, self.local_rows, self.ws_group, None,
+                                            self.status, self._groups)
+                else:
+                    groups, _ = k.ids_group(L.recv_rows, self.local_rows, None, self.ws_group, None,
+                                            self.status, self._groups)
+        if next_sparse_inputs is not None and not self.dedup:
             with _Side():
                 self._pending = self._route_async(self._concat_ids(next_sparse_inputs))
         with self._timed("fm_fwd"):
@@ -562,15 +621,33 @@ class ShardedDeepFMLayer(DeepFMLayer):
             with self._timed("grad_exchange"):
                 f32 = dict(dtype=torch.float32, device=self.device)
                 C1 = 2 if self.ps is not None else 1     # PS: the label rides with dz (click counter of the accessor)
-                send_g = self._fit("send_g", L.n_send, D)
-                send_g1 = self._fit("send_g1", L.n_send, C1)
-                if L.n_send:
-                    k.emb_gather(L.route.send_pos[: L.n_send], row_grad, None, self.status, out=send_g)
-                    k.emb_gather(L.route.send_sample[: L.n_send], dz, None, self.status, out=send_g1,
-                                 out_group=1, out_group_stride=C1)
-                    if C1 == 2:
-                        k.emb_gather(L.route.send_sample[: L.n_send], label.to(torch.float32), None, self.status,
-                                     out=send_g1[:, 1:], out_group=1, out_group_stride=C1)
+                if L.plan is not None:
+                    # merged per distinct row on THIS rank (ascending position order), laid into the plan's send slots;
+                    # PS: the occurrence and click counts of a distinct row travel as exact small floats beside dz
+                    send_g = k.dedup_merge(L.plan, row_grad, D, out=self._xbuf.get("send_g_d"))
+                    self._xbuf["send_g_d"] = send_g
+                    send_g = send_g[: L.n_send]
+                    if C1 == 1:
+                        send_g1 = k.dedup_merge(L.plan, dz, 1, grad_div=S, out=self._xbuf.get("send_g1_d"))
+                        self._xbuf["send_g1_d"] = send_g1
+                        send_g1 = send_g1[: L.n_send]
+                    else:
+                        trip = torch.cat([dz.reshape(-1, 1), torch.ones_like(dz).reshape(-1, 1),
+                                          label.to(torch.float32).reshape(-1, 1)], dim=1).contiguous()
+                        send_g1 = k.dedup_merge(L.plan, trip, 3, grad_div=S, out=self._xbuf.get("send_g3_d"))
+                        self._xbuf["send_g3_d"] = send_g1
+                        send_g1 = send_g1[: L.n_send]
+                        C1 = 3                       # dz | occurrences | clicks of the distinct row
+                else:
+                    send_g = self._fit("send_g", L.n_send, D)
+                    send_g1 = self._fit("send_g1", L.n_send, C1)
+                    if L.n_send:
+                        k.emb_gather(L.route.send_pos[: L.n_send], row_grad, None, self.status, out=send_g)
+                        k.emb_gather(L.route.send_sample[: L.n_send], dz, None, self.status, out=send_g1,
+                                     out_group=1, out_group_stride=C1)
+                        if C1 == 2:
+                            k.emb_gather(L.route.send_sample[: L.n_send], label.to(torch.float32), None, self.status,
+                                         out=send_g1[:, 1:], out_group=1, out_group_stride=C1)
                 recv_g = self._fit("recv_g", max(L.n_recv, 1), D)
                 recv_g1 = self._fit("recv_g1", max(L.n_recv, 1), C1)
                 self.comm.all_to_all(recv_g[: L.n_recv], send_g, L.recv_splits, L.send_splits, tag="a2a_grads")
@@ -578,10 +655,15 @@ class ShardedDeepFMLayer(DeepFMLayer):
             with self._timed("sparse_adam"):
                 if L.n_recv and self.ps is not None:
                     # the accessor's push: counters, AdaGrad rule per part, lazy birth / embedx creation
-                    click = recv_g1[: L.n_recv, 1].contiguous().to(torch.int64)
                     if self.scale_sparse_grad:      # the loss is the mean over the GLOBAL batch
                         self.ps.accessor.grad_scale = float(label.shape[0] * self.comm.world)
-                    k.ps_push_rows(self.ps, groups, recv_g, 1, grad1=recv_g1, grad1_pitch=2, click=click)
+                    if C1 == 3:                     # deduplicated: a received row carries its rank's merged counters
+                        show = recv_g1[: L.n_recv, 1].round().contiguous().to(torch.int64)
+                        click = recv_g1[: L.n_recv, 2].round().contiguous().to(torch.int64)
+                        k.ps_push_rows(self.ps, groups, recv_g, 1, grad1=recv_g1, grad1_pitch=3, show=show, click=click)
+                    else:
+                        click = recv_g1[: L.n_recv, 1].contiguous().to(torch.int64)
+                        k.ps_push_rows(self.ps, groups, recv_g, 1, grad1=recv_g1, grad1_pitch=2, click=click)
                 elif L.n_recv:
                     st = self.sparse_state
                     pp = self._pp = k.segment_partials(groups, recv_g, D, out=getattr(self, "_pp", None))
@@ -594,6 +676,10 @@ class ShardedDeepFMLayer(DeepFMLayer):
             if self._pending is not None and next_sparse_inputs is not None:
                 with self._timed("next_lookup"):
                     nids = self._pending["ids"]
+                    self._next_lookup = (nids, self._lookup(nids))
+            elif self.dedup and next_sparse_inputs is not None:      # no routing a step ahead: the plan needs no host sizes
+                with self._timed("next_lookup"):
+                    nids = self._concat_ids(next_sparse_inputs)
                     self._next_lookup = (nids, self._lookup(nids))
         if mode == "serial":
             cur.wait_stream(self._side)                          # exchange chain first, GEMMs after it

@@ -20,6 +20,14 @@ import torch.distributed as dist  # noqa: E402
 from helpers import deepfm_state_dict, make_deepfm_problem  # noqa: E402
 
 CFG = dict(B=48, N=257, D=16, fc=(32, 16), seed=77, pad_frac=0.08, steps=2, lr=1e-2)
+ZIPF = os.environ.get("REC_TEST_ZIPF", "0") == "1"       # hot rows: one row owning a large share of a batch's lookups
+
+
+def later_ids(rng, c, world, zipf=ZIPF):
+    """ids of the steps after the first (the same global batch on every rank and in the oracle run)."""
+    if zipf:
+        return np.minimum(rng.zipf(1.3, size=(c["B"] * world, 26)), c["N"] - 1).astype(np.int64)
+    return rng.integers(0, c["N"], (c["B"] * world, 26), dtype=np.int64)
 
 
 def main():
@@ -35,7 +43,7 @@ def main():
         dev, kernels = "cuda:0", None
     c = CFG
     pr = make_deepfm_problem(B=c["B"] * world, N=c["N"], D=c["D"], fc=c["fc"], seed=c["seed"],
-                             pad_frac=c["pad_frac"], tables=tables)
+                             pad_frac=c["pad_frac"], tables=tables, zipf=ZIPF)
     so = pr["slot_offsets"]
     comm = Comm()
     comm.trace = []
@@ -58,13 +66,24 @@ def main():
         if step == 0:
             ids, dense, label = pr["ids"], pr["dense"], pr["label"]
         else:      # later steps: fresh global batch, same on every rank
-            ids = rng.integers(0, c["N"], (c["B"] * world, 26), dtype=np.int64)
+            ids = later_ids(rng, c, world)
             dense = rng.random((c["B"] * world, 13), dtype=np.float32)
             label = (rng.random((c["B"] * world, 1)) < 0.3).astype(np.int64)
         batches.append((t(ids[lo:hi]), t(dense[lo:hi]), t(label[lo:hi])))
+    no_reads = os.environ.get("REC_TEST_NO_HOST_READS", "0") == "1"
     for step, (ids_t, dense_t, label_t) in enumerate(batches):
         nxt = batches[step + 1][0] if step + 1 < len(batches) else None     # routed a step ahead
-        loss, pred = m.train_step(ids_t, dense_t, label_t, lr=c["lr"], next_sparse_inputs=nxt)
+        if no_reads:       # the deduplicated exchange: nothing on the step path reads a device value back to size anything
+            def boom(*a, **k):
+                raise AssertionError("host read (.item() / .tolist()) on the step path")
+            saved = torch.Tensor.item, torch.Tensor.tolist
+            torch.Tensor.item = torch.Tensor.tolist = boom
+            try:
+                loss, pred = m.train_step(ids_t, dense_t, label_t, lr=c["lr"], next_sparse_inputs=nxt)
+            finally:
+                torch.Tensor.item, torch.Tensor.tolist = saved
+        else:
+            loss, pred = m.train_step(ids_t, dense_t, label_t, lr=c["lr"], next_sparse_inputs=nxt)
         out["loss%d" % step] = loss.cpu().numpy().copy()
         out["pred%d" % step] = pred.cpu().numpy().copy()   # pred is a reused buffer
     pred_eval = m.forward(t(pr["ids"][lo:hi]), t(pr["dense"][lo:hi]))

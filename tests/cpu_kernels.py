@@ -45,6 +45,66 @@ def shard_route(ids, num_rows, padding_idx, num_shards, ws, slot_offset=None, st
     return route, status
 
 
+class DedupPlan:
+    def __init__(self, n, num_shards, cap, device):
+        self.n, self.num_shards, self.cap = n, num_shards, cap
+        self.groups = IdGroups(n, device)
+        self.send_rows = torch.empty(num_shards * cap, dtype=torch.int64)
+        self.slot_of_pos = torch.zeros(max(n, 1), dtype=torch.int64)
+        self.slot_of_uniq = torch.zeros(max(n, 1), dtype=torch.int64)
+        self.counts = torch.zeros(num_shards, dtype=torch.int64)
+        self.sentinel = None
+
+
+def dedup_plan(ids, num_rows, padding_idx, num_shards, local_rows, cap, ws, slot_offset=None, status=None, plan=None):
+    """Oracle-side statement of ops.dedup_plan (the distinct (owner, local row) pairs of a batch, owner-major ascending,
+    in fixed-capacity slots)."""
+    idn = _n(ids).astype(np.int64)
+    n, G = idn.size, int(num_shards)
+    S = idn.shape[-1]
+    if plan is None or plan.n != n or plan.cap != cap:
+        plan = DedupPlan(n, G, cap, "cpu")
+    rows = idn if slot_offset is None else idn + _n(slot_offset).reshape(1, -1)
+    pad = (idn == padding_idx) if padding_idx is not None else np.zeros_like(idn, bool)
+    oob = ((rows < 0) | (rows >= num_rows)) & ~pad
+    if oob.any() and status is not None:
+        status |= 1
+    valid = ~(pad | oob).reshape(-1)
+    key = ((rows % G) * local_rows + rows // G).reshape(-1)
+    g = plan.groups
+    g.spos, g.uniq, g.offs = R.group_ids(np.where(valid, key, 0), valid)
+    none = G * cap
+    plan.sentinel = int(local_rows)
+    send = np.full(none, local_rows, np.int64)
+    slot_u = np.full(max(n, 1), none, np.int64)
+    slot_p = np.zeros(max(n, 1), np.int64)
+    fill = np.zeros(G, np.int64)
+    for u, k in enumerate(g.uniq):
+        o = int(k // local_rows)
+        j = fill[o]
+        fill[o] += 1
+        if j < cap:
+            slot_u[u] = o * cap + j
+            send[o * cap + j] = k - o * local_rows
+            for kk in range(g.offs[u], g.offs[u + 1]):
+                slot_p[int(g.spos[kk])] = 1 + o * cap + j
+        elif status is not None:
+            status |= 2
+    plan.counts = torch.from_numpy(fill.copy())
+    plan.send_rows, plan.slot_of_uniq, plan.slot_of_pos = torch.from_numpy(send), torch.from_numpy(slot_u), torch.from_numpy(slot_p)
+    return plan, status
+
+
+def dedup_merge(plan, grad, emb_dim, grad_div=1, out=None):
+    none = plan.num_shards * plan.cap
+    merged = _merged_rows(plan.groups, grad, int(emb_dim), grad_div)
+    o = np.zeros((none + 1, int(emb_dim)), np.float32)
+    su = _n(plan.slot_of_uniq)
+    for u in range(len(plan.groups.uniq)):
+        o[su[u]] = merged[u]
+    return torch.from_numpy(o)
+
+
 def emb_gather(ids, W, padding_idx=None, status=None, out=None, out_group=0, out_group_stride=0):
     res = torch.from_numpy(R.embedding_lookup(_n(W), _n(ids).reshape(-1, 1), padding_idx)[:, 0, :])
     if out is None:

@@ -30,9 +30,9 @@ def _free_port():
     return str(p)
 
 
-def _run_world(world, mode, outdir, tables=False, worker=None):
+def _run_world(world, mode, outdir, tables=False, worker=None, extra_env=None):
     port = _free_port()
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2", **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, worker or WORKER, str(r), str(world), port, mode, str(outdir)]
                               + (["tables"] if tables else []), env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
@@ -50,11 +50,11 @@ def _run_world(world, mode, outdir, tables=False, worker=None):
     return [dict(np.load(os.path.join(outdir, "rank%d.npz" % r))) for r in range(world)]
 
 
-def _expected(world, tables):
+def _expected(world, tables, zipf=False):
     sys.path.insert(0, os.path.join(REPO, "tests"))
-    from _sharded_worker import CFG as c
+    from _sharded_worker import CFG as c, later_ids
     pr = make_deepfm_problem(B=c["B"] * world, N=c["N"], D=c["D"], fc=c["fc"], seed=c["seed"],
-                             pad_frac=c["pad_frac"], tables=tables)
+                             pad_frac=c["pad_frac"], tables=tables, zipf=zipf)
     tr = OracleTrainer(pr["params"], pr["slot_offsets"], lr=c["lr"])
     rng = np.random.default_rng(c["seed"] + 1)
     res = []
@@ -62,7 +62,7 @@ def _expected(world, tables):
         if step == 0:
             ids, dense, label = pr["ids"], pr["dense"], pr["label"]
         else:
-            ids = rng.integers(0, c["N"], (c["B"] * world, 26), dtype=np.int64)
+            ids = later_ids(rng, c, world, zipf)
             dense = rng.random((c["B"] * world, 13), dtype=np.float32)
             label = (rng.random((c["B"] * world, 1)) < 0.3).astype(np.int64)
         res.append(tr.train_step(ids, dense, label))
@@ -71,8 +71,8 @@ def _expected(world, tables):
     return c, tr, res, pred_eval
 
 
-def _check(world, ranks, tables):
-    c, tr, res, pred_eval = _expected(world, tables)
+def _check(world, ranks, tables, zipf=False):
+    c, tr, res, pred_eval = _expected(world, tables, zipf)
     B = c["B"]
     for r, out in enumerate(ranks):
         assert int(out["status"][0]) == 0
@@ -130,6 +130,97 @@ def test_sharded_orchestration_cpu(tmp_path, tables):
 
 def test_sharded_orchestration_cpu_world3(tmp_path):
     _check(3, _run_world(3, "cpu", tmp_path), False)
+
+
+# ---- the deduplicated exchange (REC_SHARD_DEDUP=1): distinct rows per owner in fixed-capacity slots, replies expanded and
+# gradients merged locally, no host read on the step path — the same checks as above must hold with the switch on
+DEDUP = {"REC_SHARD_DEDUP": "1"}
+
+
+@pytest.mark.parametrize("world,tables", [(2, False), (2, True), (3, False)])
+def test_sharded_dedup_exchange_cpu(tmp_path, world, tables):
+    _check(world, _run_world(world, "cpu", tmp_path, tables, extra_env=DEDUP), tables)
+
+
+def test_sharded_dedup_exchange_zipf_ids_cpu(tmp_path):
+    """Zipf ids (one row owning a large share of a batch's lookups): the case fixed-capacity buckets could not take without
+    deduplication — a hot row is ONE slot here, whatever its share."""
+    env = dict(DEDUP, REC_TEST_ZIPF="1")
+    _check(2, _run_world(2, "cpu", tmp_path, extra_env=env), False, zipf=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,tables", [(2, False), (2, True), (1, False)])
+def test_sharded_dedup_exchange_ranks_share_one_gpu(engine_lib, tmp_path, world, tables):
+    """The HIP kernels + the device-side plan (ops.dedup_plan / dedup_merge), and no .item() / .tolist() on the step path."""
+    env = dict(DEDUP, REC_TEST_NO_HOST_READS="1")
+    _check(world, _run_world(world, "gpu", tmp_path, tables, extra_env=env), tables)
+
+
+@pytest.mark.gpu
+def test_dedup_plan_device_equals_the_oracle_statement(engine_lib):
+    """ops.dedup_plan (rec_ids_group + device index arithmetic) == tests/cpu_kernels.dedup_plan on every integer it emits;
+    ops.dedup_merge == the position-ordered merge, bit for bit."""
+    import torch
+    import cpu_kernels as K
+    from paddlerec_amd import ops
+    rng = np.random.default_rng(8)
+    for B, S, N, G, cap, so in ((300, 26, 5003, 8, 2000, False), (64, 26, 100, 3, 30, False), (128, 4, 997, 2, 512, True)):
+        local = ((N * S if so else N) + G - 1) // G
+        ids = np.minimum(rng.zipf(1.2, size=(B, S)), N - 1).astype(np.int64)
+        ids[rng.random((B, S)) < 0.05] = 0
+        slot_off = (np.arange(S, dtype=np.int64) * N) if so else None
+        rows_total = N * S if so else N
+        st_d, st_h = ops.new_status("cuda"), K.new_status("cpu")
+        ws = ops.Workspace("cuda")
+        pd, _ = ops.dedup_plan(torch.from_numpy(ids).cuda(), rows_total, 0, G, local, cap, ws,
+                               None if slot_off is None else torch.from_numpy(slot_off).cuda(), st_d)
+        ph, _ = K.dedup_plan(torch.from_numpy(ids), rows_total, 0, G, local, cap, None,
+                             None if slot_off is None else torch.from_numpy(slot_off), st_h)
+        assert np.array_equal(pd.send_rows.cpu().numpy(), ph.send_rows.numpy())
+        assert np.array_equal(pd.slot_of_pos[: B * S].cpu().numpy(), ph.slot_of_pos.numpy()[: B * S])
+        assert np.array_equal(pd.counts.cpu().numpy(), ph.counts.numpy())
+        assert int(st_d.item()) == int(st_h.item())
+        grad = rng.standard_normal((B * S, 16)).astype(np.float32)
+        md = ops.dedup_merge(pd, torch.from_numpy(grad).cuda(), 16)[: G * cap].cpu().numpy()
+        mh = K.dedup_merge(ph, torch.from_numpy(grad), 16)[: G * cap].numpy()
+        assert np.array_equal(md, mh)
+        dz = rng.standard_normal((B, 1)).astype(np.float32)
+        m1d = ops.dedup_merge(pd, torch.from_numpy(dz).cuda(), 1, grad_div=S)[: G * cap].cpu().numpy()
+        m1h = K.dedup_merge(ph, torch.from_numpy(dz), 1, grad_div=S)[: G * cap].numpy()
+        assert np.array_equal(m1d, m1h)
+
+
+def test_dedup_plan_properties():
+    """ops.dedup_plan's contract on the oracle-side statement (tests/cpu_kernels.py; the GPU test compares the device
+    implementation with it): owner-major ascending distinct rows, slots inside the capacity, padding -> slot 0, every
+    position's slot holds its row, overflow flagged."""
+    import torch
+    import cpu_kernels as K
+    rng = np.random.default_rng(4)
+    B, S, N, G = 40, 26, 997, 3
+    local = (N + G - 1) // G
+    ids = rng.integers(0, N, (B, S), dtype=np.int64)
+    ids[rng.random((B, S)) < 0.1] = 0
+    ids[:, 3] = 17                                             # a hot row
+    st = K.new_status("cpu")
+    plan, _ = K.dedup_plan(torch.from_numpy(ids), N, 0, G, local, B * S, None, None, st)
+    send = plan.send_rows.numpy().reshape(G, -1)
+    sop = plan.slot_of_pos.numpy()
+    assert int(st.item()) == 0
+    for o in range(G):
+        live = send[o][send[o] != local]
+        want = np.unique(ids[(ids != 0) & (ids % G == o)] // G)
+        assert np.array_equal(live, want)                      # distinct, ascending, nothing else
+        assert np.array_equal(send[o][: len(live)], live) and int(plan.counts[o]) == len(want)
+    flat = ids.reshape(-1)
+    assert np.array_equal(sop == 0, flat == 0)
+    slot = sop[flat != 0] - 1
+    assert np.array_equal(send.reshape(-1)[slot], flat[flat != 0] // G) and np.array_equal(slot // send.shape[1], flat[flat != 0] % G)
+    # a capacity below the need: flagged, the rows behind it read slot 0
+    st2 = K.new_status("cpu")
+    plan2, _ = K.dedup_plan(torch.from_numpy(ids), N, 0, G, local, 8, None, None, st2)
+    assert int(st2.item()) & 2 and (plan2.slot_of_pos.numpy()[flat != 0] == 0).any()
 
 
 # ------------------------------------------------------------------------------ GPU
@@ -245,3 +336,16 @@ def test_sharded_ps_table_world2_cpu(tmp_path):
 def test_sharded_ps_table_two_ranks_one_gpu(tmp_path):
     worker = os.path.join(REPO, "tests", "_sharded_ps_worker.py")
     _check_ps(2, _run_world(2, "gpu", tmp_path, worker=worker))
+
+
+def test_sharded_ps_table_dedup_world2_cpu(tmp_path):
+    """The accessor table behind the deduplicated exchange: a distinct row's occurrence and click counts travel with its
+    merged gradient; counters stay exact."""
+    worker = os.path.join(REPO, "tests", "_sharded_ps_worker.py")
+    _check_ps(2, _run_world(2, "cpu", tmp_path, worker=worker, extra_env=DEDUP))
+
+
+@pytest.mark.gpu
+def test_sharded_ps_table_dedup_two_ranks_one_gpu(tmp_path):
+    worker = os.path.join(REPO, "tests", "_sharded_ps_worker.py")
+    _check_ps(2, _run_world(2, "gpu", tmp_path, worker=worker, extra_env=DEDUP))
