@@ -289,7 +289,15 @@ def other_configs(timeout_s=120):
             # the headline workload with every GEMM on the exact-f32 MFMA kernels (v_mfma_f32_16x16x4_f32): what the
             # bf16 x 3 split of the tall MLP GEMMs buys, same run, same box
             ("REC_GEMM_BF16X3=0 bench.py", [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--steps", "20",
-                                            "--warmup", "5"])]
+                                            "--warmup", "5"]),
+            # configs[4] share with the exchanges of an 8-GPU step emulated by paced link kernels (rec_link_emulate:
+            # profiles/r06_links.txt) — the one-GPU evidence for "the exchange fits beside the dW GEMMs"
+            ("REC_EMULATE_LINKS=8 bench.py --force-sharded --table ps --hashed-rows 1250000000",
+             [sys.executable, os.path.abspath(__file__), "--force-sharded", "--table", "ps", "--hashed-rows",
+              "1250000000", "--no-cpu-baseline", "--steps", "20", "--warmup", "5"]),
+            # the pipelined step schedule (DeepFMLayer.pipelined: fm_bwd -> update -> next lookup on one stream)
+            ("REC_DEEPFM_PIPELINED=1 bench.py", [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--steps",
+                                                 "20", "--warmup", "5", "--no-other-configs"])]
     keep = ("config", "workload", "ms", "ms_per_step", "samples_per_s", "value", "unit", "roofline", "pool_fwd_ms",
             "train_step_ms", "kernels_ms", "entry", "reader_ms", "batch_ms", "error")
     out = []
@@ -297,6 +305,10 @@ def other_configs(timeout_s=120):
         t0 = time.time()
         try:
             job_env = dict(env, REC_GEMM_BF16X3="0") if name.startswith("REC_GEMM_BF16X3=0") else env
+            if name.startswith("REC_EMULATE_LINKS=8"):
+                job_env = dict(env, REC_EMULATE_LINKS="8")
+            if name.startswith("REC_DEEPFM_PIPELINED=1"):
+                job_env = dict(env, REC_DEEPFM_PIPELINED="1")
             r = subprocess.run(cmd + (["--no-other-configs"] if name.startswith("REC_GEMM_BF16X3=0") else []), cwd=REPO,
                                env=job_env, capture_output=True, text=True, timeout=timeout_s)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -308,7 +320,10 @@ def other_configs(timeout_s=120):
                 e = {k: d[k] for k in keep if k in d}
                 if "config" in d and isinstance(d["config"], dict):      # a bench.py line: its config object names the workload
                     e["workload"] = d["config"].get("workload")
-                    e["config"] = ("configs[4] (one GPU's share, row-sharded path at world 1)" if "--table" in cmd else
+                    e["config"] = ("configs[4] share + emulated links of an 8-GPU step (rec_link_emulate: 8 workgroups per "
+                                   "collective for remote bytes / (7 x 153 GB/s) + 8 us)" if name.startswith("REC_EMULATE_LINKS")
+                                   else "configs[1], pipelined step schedule" if name.startswith("REC_DEEPFM_PIPELINED") else
+                                   "configs[4] (one GPU's share, row-sharded path at world 1)" if "--table" in cmd else
                                    "configs[1] layout 2b (one shared table)" if "--shared-table" in cmd else
                                    "configs[1] with the dygraph-default NON-lazy Adam" if "--non-lazy-adam" in cmd else
                                    "configs[1] with every GEMM on the exact-f32 MFMA kernels (REC_GEMM_BF16X3=0)"

@@ -758,6 +758,9 @@ typedef struct {
   int32_t trans_a, trans_b;
   int32_t epilogue;      /* rec_epilogue */
   int32_t split_k;       /* 0 = automatic */
+  int32_t num_cus;       /* 0 = the whole chip; > 0: the stream the call is issued on is confined to this many compute
+                            units (rec_stream_create_cu_range): split-K and the bf16 x 3 weight-gradient grid are sized
+                            for one resident round on THOSE, not on the chip */
 } rec_gemm_desc;
 
 typedef struct {
@@ -1003,6 +1006,14 @@ int rec_transpose_f32(int64_t rows, int64_t cols, const float* in, float* out, v
  * (show_click = concat([ones, cast(label)]), dnn/static_model.py:86-94); the accessor's push counts clicks in int64 —
  * a binder without a tensor library (the custom operator rec_ps_pull's gradient) converts the column with this. */
 int rec_cast_f32_i64(int64_t n, const float* src, int64_t src_stride, int64_t* dst, void* stream);
+
+/* MEASUREMENT AID, no reference counterpart: a stand-in link.  `blocks` (<= 64) workgroups copy `bytes` between two device
+ * rings (ring_bytes each, a power of two; the copy wraps) and pace themselves so that the launch lasts bytes / gbytes_per_s + fixed_us
+ * — what an RCCL all-to-all over xGMI is to the rest of the chip: a few resident workgroups moving bytes at the links'
+ * rate.  paddlerec_amd/sharded.py issues it where the collectives of a world-1 run sit (REC_EMULATE_LINKS=<G>), so that
+ * ONE GPU can show whether the exchange of a G-GPU step fits beside the dW GEMMs. */
+int rec_link_emulate(size_t bytes, float gbytes_per_s, float fixed_us, int32_t blocks, const void* src, void* dst,
+                     size_t ring_bytes, void* stream);
 
 /* One wave busy-waits `micros` microseconds on `stream`.  Host-side stream probe: HIP maps streams onto a
  * few hardware queues and kernels of two streams that share a queue run strictly one after the other, so a

@@ -148,7 +148,7 @@ class CrossMixDesc(C.Structure):
 class GemmDesc(C.Structure):
     _fields_ = [("m", C.c_int64), ("n", C.c_int32), ("k", C.c_int32), ("lda", C.c_int32),
                 ("ldb", C.c_int32), ("ldc", C.c_int32), ("trans_a", C.c_int32),
-                ("trans_b", C.c_int32), ("epilogue", C.c_int32), ("split_k", C.c_int32)]
+                ("trans_b", C.c_int32), ("epilogue", C.c_int32), ("split_k", C.c_int32), ("num_cus", C.c_int32)]
 
 
 class GemmEpilogueArgs(C.Structure):
@@ -203,6 +203,7 @@ SIGNATURES = {
     "rec_feasign_rows": (C.c_int, [_I64, _I64, _P, _P, _P]),
     "rec_feasign_rows_host": (C.c_int, [_I64, _I64, _P, _P]),
     "rec_record_gather": (C.c_int, [_I64, _I32, _I32, _I64, _P, _P, _P, _P, C.POINTER(LazyInit), _P, _P]),
+    "rec_link_emulate": (C.c_int, [_SZ, _F, _F, _I32, _P, _P, _SZ, _P]),
     "rec_comm_unique_id": (C.c_int, [_P]),
     "rec_comm_init": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),
     "rec_comm_destroy": (C.c_int, [_P]),

@@ -160,3 +160,60 @@ extern "C" int rec_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* st
     return nccl_fail("ncclAllReduce", rc);
   return REC_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A stand-in link for ONE-GPU measurements of the row-sharded step: what an RCCL all-to-all looks
+// like to the rest of the chip — a handful of resident workgroups (RCCL's channels) that move bytes at the LINK's rate,
+// not HBM's.  `blocks` workgroups of 256 threads copy `bytes` from src to dst (both device; may alias rings of any
+// size >= ring_bytes: the copy wraps) in 64 KB slices and pace themselves with the 100 MHz wall clock so that the launch
+// lasts bytes / gbytes_per_s + fixed_us.  It holds its wave slots for that long, as the real collective would.
+namespace rec {
+__global__ __launch_bounds__(256) void link_emulate_kernel(const char* __restrict__ src, char* __restrict__ dst,
+                                                           size_t bytes, unsigned ring_mask, double ticks_per_byte,
+                                                           long long fixed_ticks) {
+  const long long t0 = wall_clock64();
+  const long long end = t0 + fixed_ticks + (long long)((double)bytes * ticks_per_byte);
+  const size_t share = bytes / gridDim.x;
+  const unsigned base = (unsigned)(((size_t)blockIdx.x * share) & ring_mask);
+  constexpr unsigned kIter = 4 * 256 * 16;              // four 16-byte loads per thread in flight: 16 KB per iteration
+  size_t moved = 0;
+  // The launch lasts bytes / rate + fixed whatever the copy manages: a workgroup moves its share while it is ahead of
+  // the link's schedule and sleeps otherwise (a few workgroups cannot outrun seven xGMI links; they hold their wave
+  // slots and touch memory as the collective's channels would)
+  while (true) {
+    const long long now = wall_clock64();
+    if (now >= end) break;
+    const double sched = (double)(now - t0 - fixed_ticks) / ticks_per_byte / gridDim.x;      // bytes the link has taken
+    if (moved < share && (double)moved <= sched) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        v[u] = *reinterpret_cast<const uint4*>(src + ((base + (unsigned)moved + (u * 256 + threadIdx.x) * 16) & ring_mask));
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        *reinterpret_cast<uint4*>(dst + ((base + (unsigned)moved + (u * 256 + threadIdx.x) * 16) & ring_mask)) = v[u];
+      moved += kIter;
+    } else {
+      __builtin_amdgcn_s_sleep(16);
+    }
+  }
+}
+}  // namespace rec
+
+extern "C" int rec_link_emulate(size_t bytes, float gbytes_per_s, float fixed_us, int32_t blocks, const void* src,
+                                void* dst, size_t ring_bytes, void* stream) {
+  REC_REQUIRE(gbytes_per_s > 0.f && fixed_us >= 0.f && blocks >= 1 && blocks <= 64, REC_EINVAL, "bad arguments");
+  REC_REQUIRE(src && dst && ring_bytes >= 65536 && ring_bytes <= (1u << 31) && (ring_bytes & (ring_bytes - 1)) == 0 &&
+                  ((uintptr_t)src) % 16 == 0 && ((uintptr_t)dst) % 16 == 0, REC_EINVAL,
+              "src / dst: 16-byte aligned rings of a power of two >= 64 KB");
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+    khz = 100000;   // gfx9: a constant 100 MHz counter
+  const double ticks_per_us = khz / 1000.0;
+  const double ticks_per_byte = ticks_per_us / ((double)gbytes_per_s * 1e3);      // GB/s = 1e3 bytes per us
+  hipLaunchKernelGGL(link_emulate_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const char*)src,
+                     (char*)dst, bytes, (unsigned)(ring_bytes - 1) & ~15u, ticks_per_byte, (long long)(fixed_us * ticks_per_us));
+  return check_launch("rec_link_emulate");
+}

@@ -874,10 +874,14 @@ static bool x3_dw_eligible(const rec_gemm_desc* d, X3DwPlan* pl) {
   const bool forced = !(v && *v == '1');
   const char* vd = getenv("REC_GEMM_BF16X3_DW");           // 0: forward / dX only (A/B runs)
   if (vd && *vd == '0') return false;
-  if (!x3_enabled() || !d->trans_a || d->trans_b || (d->split_k != 0 && !forced) || d->epilogue != REC_EPI_NONE) return false;
+  if (!x3_enabled() || !d->trans_a || d->trans_b || (d->split_k != 0 && !forced && d->num_cus <= 0) ||
+      d->epilogue != REC_EPI_NONE)
+    return false;
   if (d->k < 8192 || d->m < 336 || d->m > 448 || d->n < 336 || d->n > 416) return false;
   if (d->lda % 4 || d->ldb % 4 || d->ldc % 4) return false;
-  return x3_dw_plan((int)d->m, d->n, d->k, device_cus(), pl);
+  // a caller on a CU-restricted stream (the row-sharded step's partitioned tail) gets one resident round on ITS units
+  const int cus = d->num_cus > 0 && d->num_cus < device_cus() ? d->num_cus : device_cus();
+  return x3_dw_plan((int)d->m, d->n, d->k, cus, pl);
 }
 static size_t x3_dw_bytes(const rec_gemm_desc* d, const X3DwPlan& pl) {
   return align_up((size_t)pl.slices * d->m * d->ldc * sizeof(float), 256) + align_up((size_t)pl.slices * d->n * sizeof(float), 256);

@@ -1578,7 +1578,7 @@ def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux
         ld2 = _chk_mat(out2, "out2")
         if tuple(out2.shape) != (M, N):
             raise RecError("out2 must have the shape of out")
-    d = GemmDesc(M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), EPI[epilogue], int(split_k))
+    d = GemmDesc(M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), EPI[epilogue], int(split_k), int(max(num_cus, 0)))
     if num_cus > 0 and split_k <= 0:
         sp = C.c_int32(0)
         check(lib().rec_gemm_plan_splits(C.byref(d), int(num_cus), C.byref(sp)), "rec_gemm_plan_splits")
@@ -1588,8 +1588,8 @@ def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux
                          ld2, pv(b_colsum), pv(b_image))
     if _recorder is not None:      # a recorded step holds these addresses too
         _recorder.keep.extend(t for t in (bias, aux0, aux1, row_scale, out2, b_colsum, b_image) if t is not None)
-    key = (M, N, K, lda, ldb, ldc, d.trans_a, d.trans_b, d.epilogue, d.split_k, os.environ.get("REC_GEMM_BF16X3"),
-           os.environ.get("REC_GEMM_BF16X3_DW"))
+    key = (M, N, K, lda, ldb, ldc, d.trans_a, d.trans_b, d.epilogue, d.split_k, d.num_cus,
+           os.environ.get("REC_GEMM_BF16X3"), os.environ.get("REC_GEMM_BF16X3_DW"))
     need = _gemm_ws_cache.get(key)
     if need is None:       # a pure function of the descriptor: one C call per distinct GEMM, not per launch
         nbytes = C.c_size_t(0)

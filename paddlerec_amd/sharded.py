@@ -43,6 +43,11 @@ class Comm:
         # backend nccl: the data-path collectives go through the engine's own C-ABI exchange layer
         # (rec_alltoall_exchange / rec_allreduce_sum_f32 over an RCCL communicator created here) — what a Paddle-side
         # binder gets; torch.distributed only carries the 128-byte communicator id and the small int64 metric sums.
+        # REC_EMULATE_LINKS=<G> at world 1: every data-path collective is followed by a stand-in link launch
+        # (rec_link_emulate) that holds REC_EMULATE_LINK_BLOCKS workgroups (default 8: RCCL's channels) for the time the
+        # remote bytes of a G-GPU run would need on xGMI — does the exchange fit beside the dW GEMMs? (one-GPU evidence)
+        self.emulate = int(os.environ.get("REC_EMULATE_LINKS", "0")) if dist.get_world_size(self.group) == 1 else 0
+        self._emu_ring = None
         self.native = None
         self.native_init_timed_out = False
         self.native_ranks = 0   # ncclCommCount of the C-ABI communicator (0: exchange carried by torch.distributed)
@@ -212,7 +217,12 @@ class Comm:
             rb = inp.element_size() * (inp.shape[1] if inp.dim() > 1 else 1)
             ev = self._stat_begin(tag or what, sum(in_splits) * rb, (sum(in_splits) - in_splits[self.rank]) * rb, out.is_cuda)
         try:
-            return self._all_to_all(out, inp, out_splits, in_splits)
+            r = self._all_to_all(out, inp, out_splits, in_splits)
+            if self.emulate > 1 and out.is_cuda:
+                rb = inp.element_size() * (inp.shape[1] if inp.dim() > 1 else 1)
+                G = self.emulate
+                self._emulate_link(sum(in_splits) * rb * (G - 1) // G, min(G - 1, 7) * 153.0)
+            return r
         finally:
             if ev is not None:
                 ev[1].record()
@@ -253,10 +263,27 @@ class Comm:
             nb = t.numel() * t.element_size()
             ev = self._stat_begin(tag, nb, int(2 * nb * (self.world - 1) / max(self.world, 1)), t.is_cuda)
         try:
-            return self._all_reduce_sum(t)
+            r = self._all_reduce_sum(t)
+            if self.emulate > 1 and t.is_cuda:         # ring all-reduce: 2 (G-1)/G of the buffer over ONE link
+                G = self.emulate
+                self._emulate_link(int(2 * t.numel() * t.element_size() * (G - 1) / G), 153.0)
+            return r
         finally:
             if ev is not None:
                 ev[1].record()
+
+    def _emulate_link(self, remote_bytes, gbs):
+        import ctypes as C
+        from ._lib import check, lib
+        if remote_bytes <= 0:
+            return
+        if self._emu_ring is None:
+            self._emu_ring = (torch.empty(32 << 20, dtype=torch.uint8, device="cuda"),
+                              torch.empty(32 << 20, dtype=torch.uint8, device="cuda"))
+        a, b = self._emu_ring
+        check(lib().rec_link_emulate(int(remote_bytes), float(gbs), 8.0, int(os.environ.get("REC_EMULATE_LINK_BLOCKS", "8")),
+                                     C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), a.numel(),
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rec_link_emulate")
 
     def stats_summary(self, steps):
         """{tag: {calls_per_step, bytes_per_step, remote_bytes_per_step, us_per_step, egress_GBs}} of the collectives
