@@ -174,6 +174,9 @@ __device__ __forceinline__ void x3_read_frags_t(u32x4_t (&bf)[3], unsigned sb, u
   }
 }
 
+#ifndef REC_X3_LAB
+#define REC_X3_LAB 0           // measurement builds: 1 no C stores, 2 no A loads in the k-loop, 3 no LDS-DMA in the k-loop, 4 no conversion
+#endif
 #ifndef REC_X3_TG
 #define REC_X3_TG 2            // column tiles per MFMA group of the forward / dX kernel (lab knob: 1 = tile by tile)
 #endif
@@ -249,6 +252,9 @@ __global__ __launch_bounds__(WM * WN * 64, WN == 1 ? 2 : 1) void gemm_bf16x3_ker
   // a chunk behind K (only in the last k-step, K % 32 != 0) is read from the row's first chunk instead and zeroed when
   // it is CONVERTED, a k-step later: a select right behind the load would park the wave until the load returns
   auto load_a = [&](int kt) {
+#if REC_X3_LAB == 2      // lab: no A loads in the k-loop (the first k-step's registers are converted every step)
+    if (kt > 0) return;
+#endif
     const int koff = kt * 32 + g * 8 < K ? kt * 32 : 0;      // K % 8 == 0: the lane's chunk is in or out as a whole
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
@@ -258,6 +264,9 @@ __global__ __launch_bounds__(WM * WN * 64, WN == 1 ? 2 : 1) void gemm_bf16x3_ker
   };
   // ---- W': LDS-DMA of one k-step image; pieces dealt round-robin to the four waves
   auto issue_b = [&](int kt, int stage) {
+#if REC_X3_LAB == 3      // lab: no LDS-DMA in the k-loop (every k-step multiplies the first image)
+    if (kt > 0) return;
+#endif
     const char* src = Bimg + (size_t)kt * Geo::Stage + lane * 16;
     const char* dst = x3_smem + stage * BStage;
 #pragma unroll
@@ -299,9 +308,13 @@ __global__ __launch_bounds__(WM * WN * 64, WN == 1 ? 2 : 1) void gemm_bf16x3_ker
                           araw[a][1].x, araw[a][1].y, araw[a][1].z, araw[a][1].w};
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
+#if REC_X3_LAB == 4      // lab: no conversion (the raw bits as planes)
+        af[a][0][d] = __float_as_uint(x[2 * d]); af[a][1][d] = __float_as_uint(x[2 * d + 1]); af[a][2][d] = __float_as_uint(x[2 * d]) ^ 1u;
+#else
         unsigned p0, p1, p2;
         x3_split_pair(x[2 * d], x[2 * d + 1], p0, p1, p2);
         af[a][0][d] = p0; af[a][1][d] = p1; af[a][2][d] = p2;
+#endif
       }
     }
     if (kt + 1 < nkt) {                                      // next k-step: W' image into the other stage, A into registers
@@ -313,7 +326,11 @@ __global__ __launch_bounds__(WM * WN * 64, WN == 1 ? 2 : 1) void gemm_bf16x3_ker
     // lgkmcnt(0) before every tile while LDS-DMA loads are in flight (it cannot order them against LDS reads), i.e.
     // also for the fragments it has just requested for the NEXT tile; here tile t's MFMAs wait for their own three
     // reads only (lgkmcnt(3): LDS returns in order) and the next tile's reads stay in flight underneath them.
+#if REC_X3_LAB == 3
+    const unsigned sb = lds_base;
+#else
     const unsigned sb = lds_base + stage * BStage;
+#endif
     // Column tiles are multiplied in GROUPS of TG: the six term products of a group go product by product over all
     // TG x MT accumulators, so that two MFMAs on ONE accumulator are TG x MT instructions apart (TG = 1: every other
     // instruction waits for its predecessor's result — the issue stalls of profiles/r05_bf16x3.txt section 8).
@@ -393,7 +410,11 @@ __global__ __launch_bounds__(WM * WN * 64, WN == 1 ? 2 : 1) void gemm_bf16x3_ker
         v[c] = apply_epi<EPI>(acc[a][t][c], x0[t][c], xx1, bj[t][c], ic, epi);
         u[c] = acc[a][t][c] + bj[t][c];
       }
+#if REC_X3_LAB == 1      // lab: the kernel without its C stores (the compare keeps the epilogue arithmetic alive)
+      if (row_ok && j < N && v[0] == 1.2345678e33f) {
+#else
       if (row_ok && j < N) {
+#endif
         *reinterpret_cast<f32x4_t*>(C + i * ldc + j) = v;
         if constexpr (EPI == REC_EPI_CROSS) {                // CROSS also stores u = acc + bias (saved for the backward)
           if (epi.out2) *reinterpret_cast<f32x4_t*>(epi.out2 + i * epi.ld2 + j) = u;
