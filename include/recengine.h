@@ -909,6 +909,25 @@ int rec_shard_route(int64_t n, int32_t num_slots, int64_t num_rows, int64_t padd
                     int64_t* slot_of_pos, int64_t* send_counts, int32_t* status, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* Deduplicated lookup plan: the DISTINCT rows a rank needs of every owner, in fixed-capacity send slots (owner o owns
+ * slots [o * cap, (o + 1) * cap)) — what HeterPS does per pass before it builds the per-GPU tables
+ * (tools/static_gpubox_trainer.py:237-246 load_into_memory -> PSGPU.begin_pass [EXT]).  rec_ids_group over the shard-major
+ * key (row % G) * local_rows + row / G, then four small kernels; no host read, sizes are the capacity:
+ *   sorted_pos / uniq_rows / seg_offset / n_uniq : the grouping (uniq_rows = shard-major keys), as rec_ids_group emits it —
+ *                  the merge keys of rec_sparse_sgd_rows & co. for the local pre-merge of the row gradients
+ *   send_rows    [G * cap] i64 : local row per slot; empty slots hold `local_rows` (the owner groups them away by
+ *                  rec_ids_group(num_rows = local_rows + 1, padding_idx = local_rows))
+ *   slot_of_pos  [n] i64 : 1 + slot of a position's row, 0 = padding / out of range / behind the capacity — the `ids`
+ *                  rec_deepfm_fm_fwd reads the (G * cap + 1)-row reply table with (row 0 = zero row)
+ *   slot_of_uniq [n] i64 : slot of distinct row u, G * cap = none;   counts [G] i64 : distinct rows per owner
+ * An owner that needs more than cap distinct rows sets REC_FLAG_EXCHANGE_OVERFLOW.  All outputs are bit-exact targets. */
+int rec_dedup_plan_workspace_bytes(int64_t n, int32_t num_shards, int64_t local_rows, size_t* bytes);
+int rec_dedup_plan(int64_t n, int32_t num_slots, int64_t num_rows, int64_t padding_idx, int32_t num_shards,
+                   int64_t local_rows, int32_t cap, const int64_t* ids, const int64_t* slot_offset, int32_t* sorted_pos,
+                   int64_t* uniq_rows, int32_t* seg_offset, int32_t* n_uniq, int64_t* send_rows, int64_t* slot_of_pos,
+                   int64_t* slot_of_uniq, int64_t* counts, int32_t* status, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Exchange layer of the row-sharded table (reference: the inter-GPU pull / push of
  * core.PSGPU, tools/static_gpubox_trainer.py:152-160,256 [EXT HeterPS]).  `comm` is an RCCL ncclComm_t — created

@@ -203,6 +203,8 @@ SIGNATURES = {
     "rec_feasign_rows": (C.c_int, [_I64, _I64, _P, _P, _P]),
     "rec_feasign_rows_host": (C.c_int, [_I64, _I64, _P, _P]),
     "rec_record_gather": (C.c_int, [_I64, _I32, _I32, _I64, _P, _P, _P, _P, C.POINTER(LazyInit), _P, _P]),
+    "rec_dedup_plan_workspace_bytes": (C.c_int, [_I64, _I32, _I64, C.POINTER(_SZ)]),
+    "rec_dedup_plan": (C.c_int, [_I64, _I32, _I64, _I64, _I32, _I64, _I32] + [_P] * 11 + [_P, _SZ, _P]),
     "rec_link_emulate": (C.c_int, [_SZ, _F, _F, _I32, _P, _P, _SZ, _P]),
     "rec_comm_unique_id": (C.c_int, [_P]),
     "rec_comm_init": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),

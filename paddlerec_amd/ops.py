@@ -1408,51 +1408,25 @@ class DedupPlan:
 def dedup_plan(ids, num_rows, padding_idx, num_shards, local_rows, cap, ws, slot_offset=None, status=None, plan=None):
     """Distinct (owner, local row) pairs of a batch of lookups, owner-major and ascending — HeterPS dedups a pass's keys
     before it builds the per-GPU tables (tools/static_gpubox_trainer.py:237-246).  ids [B,S] int64; row = id +
-    slot_offset[s]; owner = row % num_shards, local row = row // num_shards.  Device only (rec_ids_group + index
-    arithmetic), no host read: sizes are the fixed capacity `cap` rows per owner; a rank that needs more of one owner sets
-    REC_FLAG_EXCHANGE_OVERFLOW and loses the rows behind the capacity."""
+    slot_offset[s]; owner = row % num_shards, local row = row // num_shards.  rec_dedup_plan: device only, no host read:
+    sizes are the fixed capacity `cap` rows per owner; a rank that needs more of one owner sets REC_FLAG_EXCHANGE_OVERFLOW
+    and loses the rows behind the capacity."""
     _chk(ids, torch.int64, "ids")
     n, G, dev = ids.numel(), int(num_shards), ids.device
     if plan is None or plan.n != n or plan.cap != cap or plan.num_shards != G:
         plan = DedupPlan(n, G, cap, dev)
     if status is None:
         status = new_status(dev)
-    rows = ids if slot_offset is None else ids + slot_offset.reshape(1, -1)
-    pad = (ids == int(padding_idx)) if padding_idx is not None else torch.zeros_like(ids, dtype=torch.bool)
-    oob = ((rows < 0) | (rows >= int(num_rows))) & ~pad
-    status.bitwise_or_(oob.any().to(torch.int32) * _lib.REC_FLAG_INDEX_OOB)
-    kpad = G * int(local_rows)                      # the shard-major key space is [0, G * local_rows); kpad = "no lookup"
-    key = torch.where(pad | oob, torch.full_like(rows, kpad), (rows % G) * int(local_rows) + rows // G).reshape(-1)
+    S = ids.shape[-1] if ids.dim() > 1 else 1
+    nbytes = C.c_size_t(0)
+    check(lib().rec_dedup_plan_workspace_bytes(n, G, int(local_rows), C.byref(nbytes)), "rec_dedup_plan_workspace_bytes")
+    w = ws.get(nbytes.value)
     g = plan.groups
-    ids_group(key.contiguous(), kpad + 1, kpad, ws, None, status, g)
-    U, nv = g.n_uniq[0].to(torch.int64), g.n_uniq[1].to(torch.int64)
-    ar = torch.arange(n, dtype=torch.int64, device=dev)
-    uvalid = ar < U
-    owner = torch.where(uvalid, g.uniq_rows[:n] // int(local_rows), torch.full_like(ar, G))
-    counts = torch.zeros(G + 1, dtype=torch.int64, device=dev).scatter_add_(0, owner, torch.ones_like(ar))[:G]
-    plan.counts.copy_(counts)
-    offs = torch.cumsum(counts, 0) - counts
-    oc = owner.clamp(max=G - 1)
-    j = ar - offs[oc]
-    fits = uvalid & (j < cap)
-    status.bitwise_or_((uvalid & ~fits).any().to(torch.int32) * _lib.REC_FLAG_EXCHANGE_OVERFLOW)
-    none = G * cap
-    plan.slot_of_uniq[:n] = torch.where(fits, oc * cap + j, torch.full_like(ar, none))
     plan.sentinel = int(local_rows)
-    buf = torch.full((none + 1,), int(local_rows), dtype=torch.int64, device=dev)
-    buf[plan.slot_of_uniq[:n]] = torch.where(fits, g.uniq_rows[:n] - oc * int(local_rows), torch.full_like(ar, int(local_rows)))
-    plan.send_rows.copy_(buf[:none])
-    # position -> slot: sorted index k belongs to distinct row u = #{u' : seg_offset[u' + 1] <= k}
-    seg_hi = torch.where(torch.arange(1, n + 1, dtype=torch.int64, device=dev) <= U, g.seg_offset[1:n + 1].to(torch.int64),
-                         torch.full_like(ar, 1 << 62))
-    u_of_k = torch.searchsorted(seg_hi, ar, right=True).clamp(max=max(n - 1, 0))
-    kvalid = ar < nv
-    su = plan.slot_of_uniq[u_of_k]
-    slot_k = torch.where(kvalid & (su < none), su + 1, torch.zeros_like(ar))
-    pos = torch.where(kvalid, g.sorted_pos[:n].to(torch.int64), torch.full_like(ar, n))
-    out = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-    out[pos] = slot_k
-    plan.slot_of_pos[:n] = out[:n]
+    check(lib().rec_dedup_plan(n, S, int(num_rows), -1 if padding_idx is None else int(padding_idx), G, int(local_rows),
+                               int(cap), _p(ids), _p(slot_offset), _p(g.sorted_pos), _p(g.uniq_rows), _p(g.seg_offset),
+                               _p(g.n_uniq), _p(plan.send_rows), _p(plan.slot_of_pos), _p(plan.slot_of_uniq),
+                               _p(plan.counts), _p(status), _p(w), C.c_size_t(w.numel()), _stream()), "rec_dedup_plan")
     return plan, status
 
 
