@@ -90,6 +90,10 @@ struct Buffers {
   size_t ws_bytes;
   void* ws_side;         // the grouping's scratch: it may run on the side stream beside the main stream's calls
   size_t ws_side_bytes;
+  // bf16 x 3 images of the Linear weights, forward (W) and dX (W^T) orientation, made by ONE rec_gemm_b_images launch
+  // at the top of the step (deepfm.py:_refresh_weights); NULL where the shape has no image form or the batch is short
+  void* img_f[REC_DEEPFM_MAX_LINEAR];
+  void* img_t[REC_DEEPFM_MAX_LINEAR];
 };
 
 // the largest workspace any single call of the step asks for
@@ -175,6 +179,21 @@ int carve(const rec_deepfm_net* net, const Shape& s, int64_t B, void* workspace,
     bf->ws_side = c.bytes(gw);
     bf->ws_side_bytes = gw;
   }
+  static const bool img_env = [] { const char* v = getenv("REC_GEMM_IMAGES"); return !(v && *v == '0'); }();
+  {
+    int in = s.in0;
+    for (int i = 0; i < s.n; ++i) {
+      bf->img_f[i] = bf->img_t[i] = nullptr;
+      const int w = net->widths[i];
+      if (img_env && B >= 8192) {                              // deepfm.py: use_images
+        int32_t ok = 0;
+        size_t ib = 0;
+        if (rec_gemm_b_image_bytes(in, w, &ok, &ib) == REC_OK && ok) bf->img_f[i] = c.bytes(ib);
+        if (rec_gemm_b_image_bytes(w, in, &ok, &ib) == REC_OK && ok) bf->img_t[i] = c.bytes(ib);
+      }
+      in = w;
+    }
+  }
   size_t cw = 0;
   if (int rc = call_workspace(net, s, B, &cw)) return rc;
   bf->ws = c.bytes(cw);
@@ -185,7 +204,8 @@ int carve(const rec_deepfm_net* net, const Shape& s, int64_t B, void* workspace,
 
 // C = epi(op(A) @ op(B)) on contiguous operands (the step's own buffers and parameter views)
 int gemm(int64_t m, int n, int k, bool ta, bool tb, int epi, const float* A, const float* Bm, float* C,
-         const float* bias, const float* aux0, int ld0, float* b_colsum, int split_k, const Buffers& bf, void* st) {
+         const float* bias, const float* aux0, int ld0, float* b_colsum, int split_k, const Buffers& bf, void* st,
+         const void* b_image = nullptr) {
   rec_gemm_desc d{};
   d.m = m; d.n = n; d.k = k;
   d.lda = ta ? (int)m : k;
@@ -193,7 +213,7 @@ int gemm(int64_t m, int n, int k, bool ta, bool tb, int epi, const float* A, con
   d.ldc = n;
   d.trans_a = ta; d.trans_b = tb; d.epilogue = epi; d.split_k = split_k;
   rec_gemm_epilogue_args x{};
-  x.bias = bias; x.aux0 = aux0; x.ld_aux0 = ld0; x.b_colsum = b_colsum;
+  x.bias = bias; x.aux0 = aux0; x.ld_aux0 = ld0; x.b_colsum = b_colsum; x.b_image = b_image;
   return rec_gemm_f32(&d, A, Bm, C, &x, bf.ws, bf.ws_bytes, st);
 }
 
@@ -309,13 +329,26 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   // -- top MLP forward (net.py:142-174): bias / ReLU in the GEMM epilogue; with the fused head the last Linear, the loss
   //    and the backward of both are ONE pass over the last hidden activation (deepfm.py: fused_head)
   const int n_fwd = s.ctr_head ? n - 1 : n;
+  {   // every weight image of the step in one launch (the mirror's _refresh_weights(images)): the GEMMs below skip their
+      // own split launches
+    rec_gemm_b_image items[2 * REC_DEEPFM_MAX_LINEAR];
+    int cnt = 0, in = s.in0;
+    for (int i = 0; i < n; ++i) {
+      const int w = net->widths[i];
+      const float* wi = i == 0 ? w0 : net->w[i];
+      if (bf.img_f[i]) items[cnt++] = rec_gemm_b_image{wi, w, in, w, 0, bf.img_f[i]};
+      if (bf.img_t[i]) items[cnt++] = rec_gemm_b_image{wi, w, w, in, 1, bf.img_t[i]};
+      in = w;
+    }
+    if (cnt) REC_TRY(rec_gemm_b_images(cnt, items, stream));
+  }
   {
     int in = s.in0;
     for (int i = 0; i < n_fwd; ++i) {
       const bool last = i == n - 1;
       float* out = last ? bf.y_dnn : bf.act[i + 1];
       REC_TRY(gemm(B, net->widths[i], in, false, false, last ? REC_EPI_BIAS : REC_EPI_BIAS_RELU, bf.act[i],
-                   i == 0 ? w0 : net->w[i], out, net->b[i], nullptr, 0, nullptr, 0, bf, stream));
+                   i == 0 ? w0 : net->w[i], out, net->b[i], nullptr, 0, nullptr, 0, bf, stream, bf.img_f[i]));
       in = net->widths[i];
     }
   }
@@ -353,13 +386,14 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
     if (i == 0) {
       g0 = g;
       d_flat = bf.g[gi];
-      REC_TRY(gemm(B, in, w, false, true, REC_EPI_NONE, g, w0, d_flat, nullptr, nullptr, 0, nullptr, 0, bf, stream));
+      REC_TRY(gemm(B, in, w, false, true, REC_EPI_NONE, g, w0, d_flat, nullptr, nullptr, 0, nullptr, 0, bf, stream,
+                   bf.img_t[0]));
       break;
     }
     REC_TRY(gemm(in, w, (int)B, true, false, REC_EPI_NONE, bf.act[i], g, net->gw[i], nullptr, nullptr, 0, net->gb[i],
                  0, bf, stream));
     REC_TRY(gemm(B, in, w, false, true, REC_EPI_RELU_MASK, g, net->w[i], bf.g[gi], nullptr, bf.act[i], in, nullptr, 0,
-                 bf, stream));
+                 bf, stream, bf.img_t[i]));
     g = bf.g[gi];
     gi ^= 1;
   }
