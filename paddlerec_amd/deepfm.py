@@ -723,6 +723,12 @@ class DeepFMLayer:
             with _OnSide(side, cur):
                 tail_sparse()
             tail_dense()
+            if side is not None and use_images and os.environ.get("REC_DEEPFM_REFRESH_TAIL", "1") != "0":
+                # the NEXT step's folded layer-0 weight and weight images now, behind the dense Adam: the main stream
+                # waits ~90 us for the side stream's table update at this point anyway (profiles/r06_step_timeline.txt),
+                # and the next step's first GEMM then follows its lookup without the fold and split launches in between
+                self._refresh_weights(use_images)
+                self._w_key = (self.dense.data._version, self.step_count + 1, bool(use_images))
         if side is not None:
             cur.wait_stream(self._side)
         return loss, pred
