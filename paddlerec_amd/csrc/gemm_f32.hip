@@ -33,6 +33,7 @@
 #include "rec_common.h"
 
 #include "gemm_epi.h"
+#include "gemm_direct.h"
 #include "gemm_glds.h"
 #include "gemm_panel.h"
 #include "gemm_pipe.h"
@@ -1057,6 +1058,8 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
     return check_launch("rec_gemm_f32 (bf16x3)");
   if (!b_colsum && launch_panel(desc, A, B, C, e, st, device_cus())) return check_launch("rec_gemm_f32 (panel)");
   if (!b_colsum && launch_glds(desc, A, B, C, e, st)) return check_launch("rec_gemm_f32 (glds)");
+  // the launch-bound sizes (the reference's own batches): one launch, a wave per 16 x 16 tile over the whole K (gemm_direct.h)
+  if (launch_direct(desc, A, B, C, e, b_colsum, st)) return check_launch("rec_gemm_f32 (direct)");
   const GemmPlan p = plan_gemm(desc);
   // (The half-empty last round of blocks — 65536 x 400 on 256x80 tiles is 2.5 rounds of the 512 resident blocks and
   // costs three — was attacked in round 3 by giving the rows behind the whole rounds to a second launch on 64x80 tiles:

@@ -91,6 +91,42 @@ def test_gemm_epilogues(ops):
         np.maximum(acc + bias, 0), **tol)
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb", [
+    (512, 400, 432, False, False),      # deepfm/config_bigdata.yaml bs 512: layer 0 forward
+    (512, 432, 400, False, True),       # ... its dX
+    (432, 400, 512, True, False),       # ... its dW (K = the batch), with the bias gradient
+    (32, 80, 512, False, False),        # din/config.yaml bs 32: attention MLP
+    (80, 40, 32, True, False), (513, 401, 37, False, True), (17, 6, 1000, True, True), (1, 400, 400, False, False)])
+def test_gemm_direct_kernel(ops, M, N, K, ta, tb):
+    """csrc/gemm_direct.h: the launch-bound sizes in ONE launch, a wave per 16 x 16 tile over the whole K — against float64
+    with the same bound as every other exact-f32 path, bit-reproducible, and (trans_a) the fused column sums."""
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A, B = _mk(rng, M, K), _mk(rng, K, N)
+    At = torch.as_tensor(np.ascontiguousarray(A.T if ta else A)).to(DEV)
+    Bt = torch.as_tensor(np.ascontiguousarray(B.T if tb else B)).to(DEV)
+    ws = ops.Workspace(DEV)
+    kw = {}
+    if ta and not tb:
+        kw["b_colsum"] = torch.empty(N, device=DEV)
+    C = ops.gemm(At, Bt, ws, trans_a=ta, trans_b=tb, **kw).cpu().numpy()
+    want = A.astype(np.float64) @ B.astype(np.float64)
+    bound = 4e-7 * (np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64))
+    _check(C, want, bound)
+    if kw:
+        np.testing.assert_allclose(kw["b_colsum"].cpu().numpy(), B.astype(np.float64).sum(0), rtol=1e-5,
+                                   atol=1e-6 * np.abs(B).sum(0).max())
+    assert np.array_equal(C, ops.gemm(At, Bt, ws, trans_a=ta, trans_b=tb, **kw).cpu().numpy())
+    # an explicit K split takes the tiled kernels + the reduce launch: same result to the bound of both
+    C2 = ops.gemm(At, Bt, ws, trans_a=ta, trans_b=tb, split_k=2).cpu().numpy()
+    _check(C2, want, bound)
+    # strided operands (a column slice of a wider buffer): the float4 path must not be taken on unaligned rows
+    if not ta and not tb and K % 4 == 0 and M > 1:
+        wide = torch.zeros(M, K + 3, device=DEV)
+        wide[:, 1:K + 1] = At
+        C3 = ops.gemm(wide[:, 1:K + 1], Bt, ws).cpu().numpy()
+        assert np.array_equal(C3, C)
+
+
 def test_gemm_skinny_paths(ops):
     """One-output Linear layers (N <= 4) take the streaming kernels: forward with epilogues, dW with the fused
     bias gradient."""

@@ -72,7 +72,8 @@ def test_bf16x3_gemm_kernels_keep_their_registers():
             scratch[name] = int(m.group(1))
     x3 = {k: v for k, v in occ.items() if "gemm_bf16x3" in k}
     assert len(x3) >= 30, sorted(x3)[:5]
-    # gemm_bf16x3_kernel<NT, EPI, WM 4>: the four MLP epilogues at every column-block width
-    eight = [k for k in x3 if re.search(r"gemm_bf16x3_kernelILi(13|8|7)ELi[0-3]ELi4E", k)]
-    assert len(eight) == 12 and all(x3[k] >= 2 for k in eight), {k: x3[k] for k in eight}
+    # gemm_bf16x3_kernel<NT, EPI, WM 4, WN>: the four MLP epilogues at every column-block width, in both workgroup shapes
+    # (WN 1, round 6: four waves, two workgroups per CU; WN 2, round 5: eight waves in one) — two waves per SIMD either way
+    eight = [k for k in x3 if re.search(r"gemm_bf16x3_kernelILi(13|8|7)ELi[0-3]ELi4ELi[12]E", k)]
+    assert len(eight) == 24 and all(x3[k] >= 2 for k in eight), {k: x3[k] for k in eight}
     assert all(scratch[k] == 0 for k in x3 if "dw_kernel" in k or k in eight), {k: scratch[k] for k in x3 if scratch[k]}
