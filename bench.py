@@ -295,6 +295,15 @@ def other_configs(timeout_s=120):
             ("REC_EMULATE_LINKS=8 bench.py --force-sharded --table ps --hashed-rows 1250000000",
              [sys.executable, os.path.abspath(__file__), "--force-sharded", "--table", "ps", "--hashed-rows",
               "1250000000", "--no-cpu-baseline", "--steps", "20", "--warmup", "5"]),
+            # the reference's OWN batch size (deepfm/config_bigdata.yaml:23: 512) on its own table layout (one shared table,
+            # D 9): launch-bound — with the one-launch GEMMs of csrc/gemm_direct.h and (REC_GEMM_DIRECT=0) with the tiled
+            # kernels + split-K reduce launches they replace
+            ("bench.py --batch 512 --shared-table --dim 9",
+             [sys.executable, os.path.abspath(__file__), "--batch", "512", "--shared-table", "--dim", "9", "--no-cpu-baseline",
+              "--steps", "300", "--warmup", "30", "--no-other-configs"]),
+            ("REC_GEMM_DIRECT=0 bench.py --batch 512 --shared-table --dim 9",
+             [sys.executable, os.path.abspath(__file__), "--batch", "512", "--shared-table", "--dim", "9", "--no-cpu-baseline",
+              "--steps", "300", "--warmup", "30", "--no-other-configs"]),
             # the pipelined step schedule (DeepFMLayer.pipelined: fm_bwd -> update -> next lookup on one stream)
             ("REC_DEEPFM_PIPELINED=1 bench.py", [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--steps",
                                                  "20", "--warmup", "5", "--no-other-configs"])]
@@ -309,6 +318,8 @@ def other_configs(timeout_s=120):
                 job_env = dict(env, REC_EMULATE_LINKS="8")
             if name.startswith("REC_DEEPFM_PIPELINED=1"):
                 job_env = dict(env, REC_DEEPFM_PIPELINED="1")
+            if name.startswith("REC_GEMM_DIRECT=0"):
+                job_env = dict(env, REC_GEMM_DIRECT="0")
             r = subprocess.run(cmd + (["--no-other-configs"] if name.startswith("REC_GEMM_BF16X3=0") else []), cwd=REPO,
                                env=job_env, capture_output=True, text=True, timeout=timeout_s)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -323,6 +334,9 @@ def other_configs(timeout_s=120):
                     e["config"] = ("configs[4] share + emulated links of an 8-GPU step (rec_link_emulate: 8 workgroups per "
                                    "collective for remote bytes / (7 x 153 GB/s) + 8 us)" if name.startswith("REC_EMULATE_LINKS")
                                    else "configs[1], pipelined step schedule" if name.startswith("REC_DEEPFM_PIPELINED") else
+                                   "configs[0] shape at the reference's batch size 512 (launch-bound), tiled GEMMs + split-K "
+                                   "reduce launches (REC_GEMM_DIRECT=0)" if name.startswith("REC_GEMM_DIRECT=0") else
+                                   "configs[0] shape at the reference's batch size 512 (launch-bound)" if "512" in cmd else
                                    "configs[4] (one GPU's share, row-sharded path at world 1)" if "--table" in cmd else
                                    "configs[1] layout 2b (one shared table)" if "--shared-table" in cmd else
                                    "configs[1] with the dygraph-default NON-lazy Adam" if "--non-lazy-adam" in cmd else
