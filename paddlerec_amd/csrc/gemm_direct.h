@@ -3,109 +3,155 @@
 //
 // The tiled kernels fill the chip for such a problem by splitting K and folding the partial tiles in a second launch
 // (profiles/r04_b512_trace.txt: 9-11 us + 4 us, nine times per DeepFM step at batch 512 — 28 launches, 0.18 ms).  Here a
-// WAVE owns one 16 x 16 tile of C and walks the whole K alone: 512 x 400 is 800 waves, three per CU; nothing is shared
-// between waves, so there is no LDS, no barrier and no second launch, and C[i][j] is ONE k-ordered chain of
-// v_mfma_f32_16x16x4_f32 (the exact-f32 contract of recengine.h "ARITHMETIC").  Operand fragments go global -> registers:
-// in k-block kb (16 contraction indices) lane (r = lane % 16, g = lane / 16) holds k = 16 kb + 4 g + s for the block's four
-// MFMAs s = 0 .. 3 — the same permutation of the contraction index on both operands — so that an operand whose memory
-// is contiguous along k (A row-major, B given transposed) is ONE float4 per lane and block; the other form is four
-// 4-byte loads whose 16 lanes read 64 contiguous bytes.  kDirectPF blocks (8 registers each) are in flight ahead of the
-// MFMAs: ~1000 cycles of prefetch for 128 cycles of matrix work per block.  A workgroup is four waves = a 16 x 64 strip
-// (the A rows come from L1 for three of them).
+// WAVE owns one 16 x 16 tile of C (512 x 400 is 800 waves, three per CU); nothing is shared between tiles, so there is no
+// second launch, and C[i][j] is a k-ordered chain of v_mfma_f32_16x16x4_f32 (the exact-f32 contract of recengine.h
+// "ARITHMETIC"; with few tiles four such chains over a quarter of K each, added in a fixed order — KS below).  Operand
+// fragments go global -> registers: in k-block kb (16 contraction indices) lane (r = lane % 16, g = lane / 16) holds
+// k = 16 kb + 4 g + s for the block's four MFMAs s = 0 .. 3 — the same permutation of the contraction index on both
+// operands — so that an operand whose memory is contiguous along k (A row-major, B given transposed) is ONE float4 per
+// lane and block; the other form is four 4-byte loads whose 16 lanes read 64 contiguous bytes.  kDirectPF blocks (8
+// registers each) are in flight ahead of the MFMAs.
+// Measured (tools/gemm_lab/direct_lab.py, back-to-back launches): 4.2 us for any problem with K 16 — the launch floor —
+// and 8.4 ns per k on top for a wave walking K alone: 6.0 / 6.7 / 7.1 us for the forward / dX / dW problems of a DeepFM
+// step at batch 512, 7.3 -> 4.7 us for DIN's 32 x 80 x 512 with the K split over the workgroup's four waves.
 #pragma once
 
 #include "gemm_epi.h"
 
 namespace rec {
 
-constexpr int kDirectPF = 8;          // k-blocks in flight per wave
+#ifndef REC_DIRECT_PF
+#define REC_DIRECT_PF 8
+#endif
+constexpr int kDirectPF = REC_DIRECT_PF;          // k-blocks in flight per wave
 
-template <bool TA, bool TB, int EPI, bool VEC>
+template <bool TA, bool TB, int EPI, bool VEC, int KS>
 __global__ __launch_bounds__(256) void gemm_f32_direct_kernel(int64_t M, int N, int K, const float* __restrict__ A,
                                                               int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                               float* __restrict__ C, int64_t ldc, EpiArgs epi,
                                                               float* __restrict__ colsum_out, int strips_n) {
+  // KS 1: the four waves of a workgroup own four column tiles of a 16 x 64 strip, each the whole K.
+  // KS 4: the four waves own ONE tile and a quarter of K each; the partial tiles meet in LDS and wave 0 adds them in a
+  //       fixed order ((w0 + w1) + (w2 + w3)) and writes C.  The chain of dependent MFMAs a wave walks is what a problem
+  //       of few tiles costs (8.4 ns per k measured: 4.3 us of a 7.3 us launch at K 512) — a quarter of it each, side by side.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int64_t m0 = (int64_t)(blockIdx.x / strips_n) * 16;
-  const int n0 = (int)(blockIdx.x % strips_n) * 64 + wave * 16;
-  if (n0 >= N) return;                                     // a wave behind the last column tile (no barrier in this kernel)
+  const int n0 = KS == 1 ? (int)(blockIdx.x % strips_n) * 64 + wave * 16 : (int)(blockIdx.x % strips_n) * 16;
+  if (KS == 1 && n0 >= N) return;                          // a wave behind the last column tile (no barrier in this form)
   // the lane's row of A / column of B, clamped into the matrix (rows / columns behind the edge are computed and dropped)
   const int64_t ar = m0 + r < M ? m0 + r : M - 1;
   const int bc = n0 + r < N ? n0 + r : N - 1;
-  // memory is contiguous along k for A when !TA, for B when TB
-  const float* ap = TA ? A + ar : A + ar * lda;
-  const float* bp = TB ? B + (int64_t)bc * ldb : B + bc;
-  const int64_t ak = TA ? lda : 1, bk = TB ? 1 : ldb;      // element stride of one step in k
-
-  struct Frag { float a[4], b[4]; bool ok; };
+  // Addresses: element (row, k) of A is A[row * lda + k] (TA: A[k * lda + row]).  Everything that depends on the k-block
+  // is wave-uniform and stays in scalar registers (the block's base pointer); the lane's part — its row / column and its
+  // k-group, plus s for the strided form — is four loop-invariant 32-bit offsets per operand (direct_eligible keeps the
+  // operands below 2^30 elements).  A load is then one instruction with no vector arithmetic in front of it; with 64-bit
+  // per-load address arithmetic the k-block took ~300 cycles for 128 cycles of matrix work.
+  const int a_step = TA ? (int)lda : 1, b_step = TB ? 1 : (int)ldb;           // elements per step in k
+  int a_off[4], b_off[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    a_off[s] = (int)(TA ? ar : ar * lda) + (4 * g + s) * a_step;
+    b_off[s] = (int)(TB ? (int64_t)bc * ldb : bc) + (4 * g + s) * b_step;
+  }
+  struct Frag { float a[4], b[4]; };
   const int nfull = K / 16, ktail = K % 16;
-  // k-block kb of the full ones; a block behind them re-reads the last one and contributes zeros (0 x 0: the loop below
-  // is branch-free — a load under a branch makes the compiler drain every load in flight at the join)
-  auto load_sel = [&](Frag& f, int kb) {
-    const bool ok = kb < nfull;
-    const int64_t k = (int64_t)(ok ? kb : nfull - 1) * 16 + 4 * g;
+  auto load_blk = [&](Frag& f, int kb) {                   // k-block kb (wave-uniform; the caller keeps it inside K)
+    const float* pa = A + (int64_t)kb * 16 * a_step;
+    const float* pb = B + (int64_t)kb * 16 * b_step;
     if (VEC && !TA) {
-      const float4 t = *reinterpret_cast<const float4*>(ap + k);
+      const float4 t = *reinterpret_cast<const float4*>(pa + a_off[0]);
       f.a[0] = t.x; f.a[1] = t.y; f.a[2] = t.z; f.a[3] = t.w;
     } else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) f.a[s] = ap[(k + s) * ak];
+      for (int s = 0; s < 4; ++s) f.a[s] = pa[a_off[s]];
     }
     if (VEC && TB) {
-      const float4 t = *reinterpret_cast<const float4*>(bp + k);
+      const float4 t = *reinterpret_cast<const float4*>(pb + b_off[0]);
       f.b[0] = t.x; f.b[1] = t.y; f.b[2] = t.z; f.b[3] = t.w;
     } else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) f.b[s] = bp[(k + s) * bk];
+      for (int s = 0; s < 4; ++s) f.b[s] = pb[b_off[s]];
     }
-    f.ok = ok;                                             // the zeroing happens where the block is USED (mma): a select
-  };                                                       // here would wait for the load it follows
+  };
   auto load_tail = [&](Frag& f, int kb) {                  // the last, partial k-block: indices behind K contribute zeros
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int64_t k = (int64_t)kb * 16 + 4 * g + s;
-      const int64_t kc = k < K ? k : K - 1;
-      const float a = ap[kc * ak], b = bp[kc * bk];
+      const int k = kb * 16 + 4 * g + s;
+      const int kc = (k < K ? k : K - 1) - (4 * g + s);    // (the lane offsets already hold 4 g + s)
+      const float a = A[(int64_t)kc * a_step + a_off[s]], b = B[(int64_t)kc * b_step + b_off[s]];
       f.a[s] = k < K ? a : 0.f;
       f.b[s] = k < K ? b : 0.f;
     }
-    f.ok = true;
   };
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   float csum = 0.f;                                        // this lane's share of the column sum of B (TA form: the bias gradient)
+#ifdef REC_DIRECT_ACC2      // lab: two accumulator chains (even / odd MFMAs of a block), summed at the end
+  f32x4_t acc2 = {0.f, 0.f, 0.f, 0.f};
+#endif
   auto mma = [&](const Frag& f) {
-    float a[4], b[4];
+#ifdef REC_DIRECT_ACC2
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[0], f.b[0], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[1], f.b[1], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[2], f.b[2], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[3], f.b[3], acc2, 0, 0, 0);
+#else
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      a[s] = f.ok ? f.a[s] : 0.f;
-      b[s] = f.ok ? f.b[s] : 0.f;
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
-    csum += (b[0] + b[1]) + (b[2] + b[3]);
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s], f.b[s], acc, 0, 0, 0);
+#endif
+    csum += (f.b[0] + f.b[1]) + (f.b[2] + f.b[3]);
   };
 
-  if (nfull > 0) {
+  // this wave's k-blocks [kb0, kb1) and whether the partial block behind them is its own
+  const int kq = KS == 1 ? nfull : (nfull + KS - 1) / KS;
+  const int kb0 = KS == 1 ? 0 : min(wave * kq, nfull), kb1 = KS == 1 ? nfull : min(kb0 + kq, nfull);
+  const bool my_tail = ktail != 0 && (KS == 1 || wave == KS - 1);
+  if (kb1 > kb0) {
+    // kDirectPF blocks in flight.  Whole groups run branch-free (a load under a branch makes the compiler drain every load
+    // in flight at the join); a prefetch behind the last full block re-reads that block and is never used.  The blocks
+    // behind the last whole group were fetched by it: their MFMAs sit under wave-uniform branches, which cost nothing.
     Frag f[kDirectPF];
+    const int last = kb1 - 1;
 #pragma unroll
-    for (int j = 0; j < kDirectPF; ++j) load_sel(f[j], j);
+    for (int j = 0; j < kDirectPF; ++j) load_blk(f[j], kb0 + j < last ? kb0 + j : last);
     __builtin_amdgcn_sched_barrier(0);
-    for (int kb = 0; kb < nfull; kb += kDirectPF) {
+    int kb = kb0;
+    for (; kb + kDirectPF <= kb1; kb += kDirectPF) {
 #pragma unroll
       for (int j = 0; j < kDirectPF; ++j) {
         mma(f[j]);
-        load_sel(f[j], kb + j + kDirectPF);
+        const int nx = kb + j + kDirectPF;
+        load_blk(f[j], nx < last ? nx : last);
         __builtin_amdgcn_sched_barrier(0);                 // the scheduler otherwise sinks a block's loads down to their use,
       }                                                    // kDirectPF steps later: nothing would be in flight
     }
+#pragma unroll
+    for (int j = 0; j < kDirectPF - 1; ++j)
+      if (kb + j < kb1) mma(f[j]);
   }
-  if (ktail) {
+  if (my_tail) {
     Frag t;
     load_tail(t, nfull);
     mma(t);
   }
 
+#ifdef REC_DIRECT_ACC2
+  acc += acc2;
+#endif
+  if constexpr (KS > 1) {
+    __shared__ float red[KS - 1][5][64];
+    if (wave > 0) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[wave - 1][v][lane] = acc[v];
+      red[wave - 1][4][lane] = csum;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    static_assert(KS == 4, "the fold below is written for four partial tiles");
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[v] = (acc[v] + red[0][v][lane]) + (red[1][v][lane] + red[2][v][lane]);
+    csum = (csum + red[0][4][lane]) + (red[1][4][lane] + red[2][4][lane]);
+  }
   // ---- C: lane (r, g) holds rows m0 + 4 g + v, column n0 + r
   const int j = n0 + r;
   if (j < N) {
@@ -133,6 +179,9 @@ inline bool direct_eligible(const rec_gemm_desc* d) {
   static const bool on = [] { const char* v = getenv("REC_GEMM_DIRECT"); return !(v && *v == '0'); }();
   if (!on || d->split_k > 1) return false;                 // an explicit K split is the caller's choice of schedule
   if ((double)d->m * d->n * d->k >= 1.5e8 || d->k > 1024 || d->n <= 4) return false;
+  // 32-bit lane offsets: both operands below 2^30 elements, leading dimensions included
+  const int64_t a_rows = d->trans_a ? d->k : d->m, b_rows = d->trans_b ? d->n : d->k;
+  if (a_rows * (int64_t)d->lda >= (1ll << 30) || b_rows * (int64_t)d->ldb >= (1ll << 30)) return false;
   const int64_t strips = ((d->m + 15) / 16) * ((d->n + 63) / 64);
   return strips < (1ll << 31);
 }
@@ -140,17 +189,26 @@ inline bool direct_eligible(const rec_gemm_desc* d) {
 template <bool TA, bool TB, int EPI>
 inline void launch_direct_epi(const rec_gemm_desc* d, const float* A, const float* B, float* C, const EpiArgs& e,
                               float* colsum_out, hipStream_t st) {
-  const int strips_n = (d->n + 63) / 64;
-  const unsigned grid = (unsigned)(((d->m + 15) / 16) * strips_n);
   // float4 loads along k: 16-B aligned rows of the operand(s) that are contiguous along k
   const bool vec = (TA || (d->lda % 4 == 0 && ((uintptr_t)A) % 16 == 0)) &&
                    (!TB || (d->ldb % 4 == 0 && ((uintptr_t)B) % 16 == 0)) && (!TA || TB);
-  if (vec)
-    hipLaunchKernelGGL((gemm_f32_direct_kernel<TA, TB, EPI, true>), dim3(grid), dim3(256), 0, st, d->m, d->n, d->k, A,
-                       (int64_t)d->lda, B, (int64_t)d->ldb, C, (int64_t)d->ldc, e, colsum_out, strips_n);
-  else
-    hipLaunchKernelGGL((gemm_f32_direct_kernel<TA, TB, EPI, false>), dim3(grid), dim3(256), 0, st, d->m, d->n, d->k, A,
-                       (int64_t)d->lda, B, (int64_t)d->ldb, C, (int64_t)d->ldc, e, colsum_out, strips_n);
+  // few tiles and a K worth splitting: four waves per tile (see the kernel); REC_GEMM_DIRECT_KS=1 / 4 forces a form
+  static const int ks_env = [] { const char* v = getenv("REC_GEMM_DIRECT_KS"); return v && *v ? atoi(v) : 0; }();
+  const int64_t tiles = ((d->m + 15) / 16) * ((d->n + 15) / 16);
+  const bool split = ks_env == 4 || (ks_env != 1 && tiles <= 256 && d->k >= 128);      // at most one wave per SIMD
+#define REC_DIRECT_LAUNCH(VEC_, KS_)                                                                                  \
+  hipLaunchKernelGGL((gemm_f32_direct_kernel<TA, TB, EPI, VEC_, KS_>), dim3(grid), dim3(256), 0, st, d->m, d->n, d->k, A, \
+                     (int64_t)d->lda, B, (int64_t)d->ldb, C, (int64_t)d->ldc, e, colsum_out, strips_n)
+  if (split) {
+    const int strips_n = (d->n + 15) / 16;                 // (tiles along N: a workgroup is one tile)
+    const unsigned grid = (unsigned)tiles;
+    if (vec) REC_DIRECT_LAUNCH(true, 4); else REC_DIRECT_LAUNCH(false, 4);
+  } else {
+    const int strips_n = (d->n + 63) / 64;
+    const unsigned grid = (unsigned)(((d->m + 15) / 16) * strips_n);
+    if (vec) REC_DIRECT_LAUNCH(true, 1); else REC_DIRECT_LAUNCH(false, 1);
+  }
+#undef REC_DIRECT_LAUNCH
 }
 
 template <int EPI>
