@@ -788,6 +788,18 @@ int rec_gemm_plan_splits(const rec_gemm_desc* desc, int32_t num_cus, int32_t* sp
 int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const float* B, float* C,
                  const rec_gemm_epilogue_args* args /* may be NULL */, void* workspace,
                  size_t workspace_bytes, void* stream);
+/* Two INDEPENDENT GEMMs — neither reads what the other writes — in one call: the backward of one Linear,
+ * dW = X^T G (+ db = colsum(G): desc0, trans_a, no epilogue) and dX = G W^T (+ ReLU' of the layer in front: desc1,
+ * trans_b, REC_EPI_NONE / REC_EPI_RELU_MASK / REC_EPI_DSIGMOID), both consume G and nothing of each other (ops.mlp_backward; the
+ * reference's Linear backward is two matmul_grad kernels, `paddle.nn.Linear` in deepfm/net.py:142-174).  At the
+ * reference's own batch sizes both are launch-bound (M N K < 1.5e8, K <= 1024: csrc/gemm_direct.h) and go out as ONE
+ * launch whose workgroups run exactly the code of the single launches — bit-identical to two rec_gemm_f32 calls, one
+ * ~4 us launch less; any other pair IS two rec_gemm_f32 calls, desc0 first (workspace: the larger of the two needs).
+ * REC_GEMM_PAIR=0: always two calls. */
+int rec_gemm_f32_pair(const rec_gemm_desc* desc0, const float* A0, const float* B0, float* C0,
+                      const rec_gemm_epilogue_args* args0 /* may be NULL */, const rec_gemm_desc* desc1, const float* A1,
+                      const float* B1, float* C1, const rec_gemm_epilogue_args* args1 /* may be NULL */, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* Weight images ahead of time.  Under the bf16 x 3 family every forward / dX call splits op(B) [k, n] into its plane image
  * first (a ~5 us launch per call); the weights of a tower change once per step, so a trainer makes ALL images of the step
  * in one launch right after its optimizer (rec_adam_dense) and passes them as rec_gemm_epilogue_args.b_image.

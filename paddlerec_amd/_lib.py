@@ -284,6 +284,8 @@ SIGNATURES = {
     "rec_gemm_b_image_bytes": (C.c_int, [_I32, _I32, C.POINTER(_I32), C.POINTER(_SZ)]),
     "rec_gemm_b_images": (C.c_int, [_I32, C.POINTER(GemmBImage), _P]),
     "rec_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, C.POINTER(GemmEpilogueArgs), _P, _SZ, _P]),
+    "rec_gemm_f32_pair": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, C.POINTER(GemmEpilogueArgs), C.POINTER(GemmDesc), _P, _P,
+                                    _P, C.POINTER(GemmEpilogueArgs), _P, _SZ, _P]),
     "rec_colsum_workspace_bytes": (C.c_int, [_I64, _I32, C.POINTER(_SZ)]),
     "rec_colsum": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, _SZ, _P]),
     "rec_xxh32": (C.c_uint32, [C.c_char_p, _SZ, C.c_uint32]),

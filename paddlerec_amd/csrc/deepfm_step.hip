@@ -217,6 +217,19 @@ int gemm(int64_t m, int n, int k, bool ta, bool tb, int epi, const float* A, con
   return rec_gemm_f32(&d, A, Bm, C, &x, bf.ws, bf.ws_bytes, st);
 }
 
+// the backward of one Linear in one call (ops.linear_backward): dW = X^T G + db, and dX = G W^T (+ ReLU' by `mask`)
+int linear_backward(int64_t B, int in, int w, const float* X, const float* G, const float* W, float* dW, float* db,
+                    float* dX, const float* mask, const Buffers& bf, void* st, const void* b_image_t) {
+  rec_gemm_desc d0{}, d1{};
+  d0.m = in; d0.n = w; d0.k = (int)B; d0.lda = in; d0.ldb = w; d0.ldc = w; d0.trans_a = 1; d0.epilogue = REC_EPI_NONE;
+  d1.m = B; d1.n = in; d1.k = w; d1.lda = w; d1.ldb = w; d1.ldc = in; d1.trans_b = 1;
+  d1.epilogue = mask ? REC_EPI_RELU_MASK : REC_EPI_NONE;
+  rec_gemm_epilogue_args x0{}, x1{};
+  x0.b_colsum = db;
+  x1.aux0 = mask; x1.ld_aux0 = mask ? in : 0; x1.b_image = b_image_t;
+  return rec_gemm_f32_pair(&d0, X, G, dW, &x0, &d1, G, W, dX, &x1, bf.ws, bf.ws_bytes, st);
+}
+
 }  // namespace
 
 extern "C" int rec_deepfm_train_step_workspace_bytes(const rec_deepfm_net* net, int64_t batch, size_t* bytes) {
@@ -381,19 +394,23 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   }
   const float* g0 = nullptr;
   float* d_flat = nullptr;
+  bool dw0_done = false;
   for (int i = n_run - 1; i >= 0; --i) {
     const int in = i == 0 ? s.in0 : net->widths[i - 1], w = net->widths[i];
     if (i == 0) {
       g0 = g;
       d_flat = bf.g[gi];
+      if (s.small) {          // no second stream at these sizes: dW_0 beside dX_0 instead of behind fm_bwd (the mirror's
+        dw0_done = true;      // mlp_backward without defer_first)
+        REC_TRY(linear_backward(B, in, w, bf.feat, g, w0, gw0, net->gb[0], d_flat, nullptr, bf, stream, bf.img_t[0]));
+        break;
+      }
       REC_TRY(gemm(B, in, w, false, true, REC_EPI_NONE, g, w0, d_flat, nullptr, nullptr, 0, nullptr, 0, bf, stream,
                    bf.img_t[0]));
       break;
     }
-    REC_TRY(gemm(in, w, (int)B, true, false, REC_EPI_NONE, bf.act[i], g, net->gw[i], nullptr, nullptr, 0, net->gb[i],
-                 0, bf, stream));
-    REC_TRY(gemm(B, in, w, false, true, REC_EPI_RELU_MASK, g, net->w[i], bf.g[gi], nullptr, bf.act[i], in, nullptr, 0,
-                 bf, stream, bf.img_t[i]));
+    REC_TRY(linear_backward(B, in, w, bf.act[i], g, net->w[i], net->gw[i], net->gb[i], bf.g[gi], bf.act[i], bf, stream,
+                            bf.img_t[i]));
     g = bf.g[gi];
     gi ^= 1;
   }
@@ -421,8 +438,9 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   // -- dW_0 / db_0, then the folded rows back into the real parameters' gradients (deepfm.py:_fold_backward).  Beside the
   //    HBM-bound update the mirror splits K 16 ways instead of the planner's 32: half a resident round of blocks
   static const int dw0_split = [] { const char* v = getenv("REC_DW0_SPLIT"); return v && *v ? atoi(v) : 16; }();
-  REC_TRY(gemm(s.in0, net->widths[0], (int)B, true, false, REC_EPI_NONE, bf.feat, g0, gw0, nullptr, nullptr, 0,
-               net->gb[0], overlap && B >= 16384 ? dw0_split : 0, bf, stream));
+  if (!dw0_done)
+    REC_TRY(gemm(s.in0, net->widths[0], (int)B, true, false, REC_EPI_NONE, bf.feat, g0, gw0, nullptr, nullptr, 0,
+                 net->gb[0], overlap && B >= 16384 ? dw0_split : 0, bf, stream));
   if (s.compact)
     REC_TRY(rec_dense_fold_bwd_full(S, Dn, D, net->widths[0], net->dense_w, net->w[0], gw0, net->gw[0],
                                     net->g_dense_w, 1, stream));

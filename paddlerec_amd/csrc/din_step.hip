@@ -165,6 +165,17 @@ int gemm(int64_t m, int n, int k, int lda, int ldb, int ldc, bool ta, bool tb, i
   return rec_gemm_f32(&d, A, Bm, C, &x, bf.ws, bf.ws_bytes, st);
 }
 
+// dW (+ db) and dX of one Linear in one call (din.py:lin_bwd -> ops.linear_backward): one launch at the shipped batch size
+int lin_bwd(int64_t B, int in, int out, int ldx, int ldg, int ldw, int lddx, const float* X, const float* G, const float* W,
+            float* dW, float* db, float* dX, int epi, const float* aux0, int ld0, const Buffers& bf, void* st) {
+  rec_gemm_desc d0{in, out, (int)B, ldx, ldg, out, 1, 0, REC_EPI_NONE, 0};
+  rec_gemm_desc d1{B, in, out, ldg, ldw, lddx, 0, 1, epi, 0};
+  rec_gemm_epilogue_args x0{}, x1{};
+  x0.b_colsum = db;
+  x1.aux0 = aux0; x1.ld_aux0 = ld0;
+  return rec_gemm_f32_pair(&d0, X, G, dW, &x0, &d1, G, W, dX, &x1, bf.ws, bf.ws_bytes, st);
+}
+
 }  // namespace
 
 extern "C" int rec_din_train_step_workspace_bytes(const rec_din_net* net, int64_t batch, int32_t max_len, size_t* bytes) {
@@ -257,18 +268,12 @@ extern "C" int rec_din_train_step(const rec_din_net* net, int64_t batch, int32_t
                nullptr, 0, net->g_b_l2, bf, stream));
   REC_TRY(gemm(B, M2, 1, 1, 1, M2, false, true, REC_EPI_DSIGMOID, bf.dz, net->w_l2, bf.d2, nullptr, bf.x2, M2, nullptr, 0,
                nullptr, bf, stream));
-  REC_TRY(gemm(M1, M2, (int)B, M1, M2, M2, true, false, REC_EPI_NONE, bf.x1, bf.d2, net->g_w_l1, nullptr, nullptr, 0,
-               nullptr, 0, net->g_b_l1, bf, stream));
-  REC_TRY(gemm(B, M1, M2, M2, M2, M1, false, true, REC_EPI_DSIGMOID, bf.d2, net->w_l1, bf.d1, nullptr, bf.x1, M1, nullptr,
-               0, nullptr, bf, stream));
-  REC_TRY(gemm(E2, M1, (int)B, E2, M1, M1, true, false, REC_EPI_NONE, bf.emb, bf.d1, net->g_w_l0, nullptr, nullptr, 0,
-               nullptr, 0, net->g_b_l0, bf, stream));
-  REC_TRY(gemm(B, E2, M1, M1, M1, E2, false, true, REC_EPI_NONE, bf.d1, net->w_l0, bf.de0, nullptr, nullptr, 0, nullptr, 0,
-               nullptr, bf, stream));                    // [d linearCon out | d target_concat]
-  REC_TRY(gemm(E, E, (int)B, E, E2, E, true, false, REC_EPI_NONE, bf.pooled, bf.de0, net->g_w_con, nullptr, nullptr, 0,
-               nullptr, 0, net->g_b_con, bf, stream));
-  REC_TRY(gemm(B, E, E, E2, E, E, false, true, REC_EPI_NONE, bf.de0, net->w_con, bf.dpooled, nullptr, nullptr, 0, nullptr,
-               0, nullptr, bf, stream));
+  REC_TRY(lin_bwd(B, M1, M2, M1, M2, M2, M1, bf.x1, bf.d2, net->w_l1, net->g_w_l1, net->g_b_l1, bf.d1, REC_EPI_DSIGMOID,
+                  bf.x1, M1, bf, stream));
+  REC_TRY(lin_bwd(B, E2, M1, E2, M1, M1, E2, bf.emb, bf.d1, net->w_l0, net->g_w_l0, net->g_b_l0, bf.de0, REC_EPI_NONE,
+                  nullptr, 0, bf, stream));                    // [d linearCon out | d target_concat]
+  REC_TRY(lin_bwd(B, E, E, E, E2, E, E, bf.pooled, bf.de0, net->w_con, net->g_w_con, net->g_b_con, bf.dpooled, REC_EPI_NONE,
+                  nullptr, 0, bf, stream));
   REC_TRY(rec_din_attention_pool_bwd_ws(&d, hist_item, hist_cat, target_item_seq, target_cat_seq, net->w_hist_item,
                                         net->w_hist_cat, net->w_tgt_item_seq, net->w_tgt_cat_seq, net->att_w1,
                                         net->att_w1_t, net->att_b1, net->att_w2, net->att_b2, net->att_w3, bf.attw,

@@ -25,19 +25,35 @@ namespace rec {
 #endif
 constexpr int kDirectPF = REC_DIRECT_PF;          // k-blocks in flight per wave
 
+struct DirectArgs {
+  int64_t M; int N, K;
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  float* C; int64_t ldc;
+  EpiArgs epi;
+  float* colsum_out;
+  int strips_n;                 // KS 1: 64-column strips along N; KS 4: 16-column tiles along N
+};
+
+// the work of workgroup `block` of one problem (gemm_f32_direct_kernel: block = blockIdx.x; the pair kernel below deals the
+// blocks of one launch to two problems)
 template <bool TA, bool TB, int EPI, bool VEC, int KS>
-__global__ __launch_bounds__(256) void gemm_f32_direct_kernel(int64_t M, int N, int K, const float* __restrict__ A,
-                                                              int64_t lda, const float* __restrict__ B, int64_t ldb,
-                                                              float* __restrict__ C, int64_t ldc, EpiArgs epi,
-                                                              float* __restrict__ colsum_out, int strips_n) {
+__device__ __forceinline__ void direct_body(const DirectArgs& w, unsigned block) {
+  const int64_t M = w.M, lda = w.lda, ldb = w.ldb, ldc = w.ldc;
+  const int N = w.N, K = w.K, strips_n = w.strips_n;
+  const float* __restrict__ A = w.A;
+  const float* __restrict__ B = w.B;
+  float* __restrict__ C = w.C;
+  float* __restrict__ colsum_out = w.colsum_out;
+  const EpiArgs& epi = w.epi;
   // KS 1: the four waves of a workgroup own four column tiles of a 16 x 64 strip, each the whole K.
   // KS 4: the four waves own ONE tile and a quarter of K each; the partial tiles meet in LDS and wave 0 adds them in a
   //       fixed order ((w0 + w1) + (w2 + w3)) and writes C.  The chain of dependent MFMAs a wave walks is what a problem
   //       of few tiles costs (8.4 ns per k measured: 4.3 us of a 7.3 us launch at K 512) — a quarter of it each, side by side.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int64_t m0 = (int64_t)(blockIdx.x / strips_n) * 16;
-  const int n0 = KS == 1 ? (int)(blockIdx.x % strips_n) * 64 + wave * 16 : (int)(blockIdx.x % strips_n) * 16;
+  const int64_t m0 = (int64_t)(block / strips_n) * 16;
+  const int n0 = KS == 1 ? (int)(block % strips_n) * 64 + wave * 16 : (int)(block % strips_n) * 16;
   if (KS == 1 && n0 >= N) return;                          // a wave behind the last column tile (no barrier in this form)
   // the lane's row of A / column of B, clamped into the matrix (rows / columns behind the edge are computed and dropped)
   const int64_t ar = m0 + r < M ? m0 + r : M - 1;
@@ -174,6 +190,21 @@ __global__ __launch_bounds__(256) void gemm_f32_direct_kernel(int64_t M, int N, 
   }
 }
 
+template <bool TA, bool TB, int EPI, bool VEC, int KS>
+__global__ __launch_bounds__(256) void gemm_f32_direct_kernel(DirectArgs w) {
+  direct_body<TA, TB, EPI, VEC, KS>(w, blockIdx.x);
+}
+
+// Two INDEPENDENT launch-bound problems in one launch (rec_gemm_f32_pair): the weight gradient dW = X^T G (+ the bias
+// gradient) and the input gradient dX = G W^T (+ ReLU') of one Linear's backward both consume G and nothing of each
+// other; at the reference's batch sizes each is a 6-7 us launch of which 4.2 us is the launch itself.  The first g0
+// workgroups work on problem 0, the others on problem 1; every workgroup runs exactly the code of the single launch.
+template <int EPI1, int KS0, int KS1>
+__global__ __launch_bounds__(256) void gemm_f32_direct_pair_kernel(DirectArgs w0, DirectArgs w1, unsigned g0) {
+  if (blockIdx.x < g0) direct_body<true, false, REC_EPI_NONE, false, KS0>(w0, blockIdx.x);
+  else direct_body<false, true, EPI1, true, KS1>(w1, blockIdx.x - g0);
+}
+
 // M N K below which a GEMM is a few microseconds whichever way it runs (gemm_f32.hip: plan_gemm `tiny`)
 inline bool direct_eligible(const rec_gemm_desc* d) {
   static const bool on = [] { const char* v = getenv("REC_GEMM_DIRECT"); return !(v && *v == '0'); }();
@@ -186,26 +217,36 @@ inline bool direct_eligible(const rec_gemm_desc* d) {
   return strips < (1ll << 31);
 }
 
+// float4 loads along k: 16-B aligned rows of the operand(s) that are contiguous along k
+inline bool direct_vec(const rec_gemm_desc* d, const float* A, const float* B) {
+  const bool ta = d->trans_a != 0, tb = d->trans_b != 0;
+  return (ta || (d->lda % 4 == 0 && ((uintptr_t)A) % 16 == 0)) && (!tb || (d->ldb % 4 == 0 && ((uintptr_t)B) % 16 == 0)) &&
+         (!ta || tb);
+}
+// few tiles and a K worth splitting: four waves per tile (see the kernel); REC_GEMM_DIRECT_KS=1 / 4 forces a form
+inline bool direct_split(const rec_gemm_desc* d) {
+  static const int ks_env = [] { const char* v = getenv("REC_GEMM_DIRECT_KS"); return v && *v ? atoi(v) : 0; }();
+  const int64_t tiles = ((d->m + 15) / 16) * ((d->n + 15) / 16);
+  return ks_env == 4 || (ks_env != 1 && tiles <= 256 && d->k >= 128);      // at most one wave per SIMD
+}
+inline DirectArgs direct_args(const rec_gemm_desc* d, const float* A, const float* B, float* C, const EpiArgs& e,
+                              float* colsum_out, bool split, unsigned* grid) {
+  const int strips_n = split ? (d->n + 15) / 16 : (d->n + 63) / 64;
+  *grid = (unsigned)(((d->m + 15) / 16) * strips_n);
+  return DirectArgs{d->m, d->n, d->k, A, (int64_t)d->lda, B, (int64_t)d->ldb, C, (int64_t)d->ldc, e, colsum_out, strips_n};
+}
+
 template <bool TA, bool TB, int EPI>
 inline void launch_direct_epi(const rec_gemm_desc* d, const float* A, const float* B, float* C, const EpiArgs& e,
                               float* colsum_out, hipStream_t st) {
-  // float4 loads along k: 16-B aligned rows of the operand(s) that are contiguous along k
-  const bool vec = (TA || (d->lda % 4 == 0 && ((uintptr_t)A) % 16 == 0)) &&
-                   (!TB || (d->ldb % 4 == 0 && ((uintptr_t)B) % 16 == 0)) && (!TA || TB);
-  // few tiles and a K worth splitting: four waves per tile (see the kernel); REC_GEMM_DIRECT_KS=1 / 4 forces a form
-  static const int ks_env = [] { const char* v = getenv("REC_GEMM_DIRECT_KS"); return v && *v ? atoi(v) : 0; }();
-  const int64_t tiles = ((d->m + 15) / 16) * ((d->n + 15) / 16);
-  const bool split = ks_env == 4 || (ks_env != 1 && tiles <= 256 && d->k >= 128);      // at most one wave per SIMD
-#define REC_DIRECT_LAUNCH(VEC_, KS_)                                                                                  \
-  hipLaunchKernelGGL((gemm_f32_direct_kernel<TA, TB, EPI, VEC_, KS_>), dim3(grid), dim3(256), 0, st, d->m, d->n, d->k, A, \
-                     (int64_t)d->lda, B, (int64_t)d->ldb, C, (int64_t)d->ldc, e, colsum_out, strips_n)
+  const bool vec = direct_vec(d, A, B), split = direct_split(d);
+  unsigned grid = 0;
+  const DirectArgs w = direct_args(d, A, B, C, e, colsum_out, split, &grid);
+#define REC_DIRECT_LAUNCH(VEC_, KS_) \
+  hipLaunchKernelGGL((gemm_f32_direct_kernel<TA, TB, EPI, VEC_, KS_>), dim3(grid), dim3(256), 0, st, w)
   if (split) {
-    const int strips_n = (d->n + 15) / 16;                 // (tiles along N: a workgroup is one tile)
-    const unsigned grid = (unsigned)tiles;
     if (vec) REC_DIRECT_LAUNCH(true, 4); else REC_DIRECT_LAUNCH(false, 4);
   } else {
-    const int strips_n = (d->n + 63) / 64;
-    const unsigned grid = (unsigned)(((d->m + 15) / 16) * strips_n);
     if (vec) REC_DIRECT_LAUNCH(true, 1); else REC_DIRECT_LAUNCH(false, 1);
   }
 #undef REC_DIRECT_LAUNCH
@@ -232,6 +273,39 @@ inline bool launch_direct(const rec_gemm_desc* d, const float* A, const float* B
 #undef REC_DIRECT_CASE
   }
   return false;
+}
+
+// the dW / dX pair of a Linear's backward as ONE launch: d0 = the trans_a form without an epilogue (dW, b_colsum allowed),
+// d1 = the trans_b form with no epilogue, the ReLU mask or sigmoid' (dX), float4-loadable; both launch-bound.  -> false: not this
+// shape of pair, the caller issues the two GEMMs one after the other.
+inline bool launch_direct_pair(const rec_gemm_desc* d0, const float* A0, const float* B0, float* C0, const EpiArgs& e0,
+                               float* colsum0, const rec_gemm_desc* d1, const float* A1, const float* B1, float* C1,
+                               const EpiArgs& e1, hipStream_t st) {
+  static const bool on = [] { const char* v = getenv("REC_GEMM_PAIR"); return !(v && *v == '0'); }();
+  if (!on || !direct_eligible(d0) || !direct_eligible(d1)) return false;
+  if (!d0->trans_a || d0->trans_b || d0->epilogue != REC_EPI_NONE) return false;
+  if (d1->trans_a || !d1->trans_b || (d1->epilogue != REC_EPI_NONE && d1->epilogue != REC_EPI_RELU_MASK &&
+                                        d1->epilogue != REC_EPI_DSIGMOID))
+    return false;
+  if (!direct_vec(d1, A1, B1)) return false;
+  const bool s0 = direct_split(d0), s1 = direct_split(d1);
+  unsigned g0 = 0, g1 = 0;
+  const DirectArgs w0 = direct_args(d0, A0, B0, C0, e0, colsum0, s0, &g0);
+  const DirectArgs w1 = direct_args(d1, A1, B1, C1, e1, nullptr, s1, &g1);
+  if ((uint64_t)g0 + g1 >= (1ull << 31)) return false;
+#define REC_PAIR_LAUNCH(E_, K0_, K1_) \
+  hipLaunchKernelGGL((gemm_f32_direct_pair_kernel<E_, K0_, K1_>), dim3(g0 + g1), dim3(256), 0, st, w0, w1, g0)
+#define REC_PAIR_KS(E_)                                        \
+  if (s0 && s1) REC_PAIR_LAUNCH(E_, 4, 4);                     \
+  else if (s0) REC_PAIR_LAUNCH(E_, 4, 1);                      \
+  else if (s1) REC_PAIR_LAUNCH(E_, 1, 4);                      \
+  else REC_PAIR_LAUNCH(E_, 1, 1)
+  if (d1->epilogue == REC_EPI_RELU_MASK) { REC_PAIR_KS(REC_EPI_RELU_MASK); }
+  else if (d1->epilogue == REC_EPI_DSIGMOID) { REC_PAIR_KS(REC_EPI_DSIGMOID); }
+  else { REC_PAIR_KS(REC_EPI_NONE); }
+#undef REC_PAIR_KS
+#undef REC_PAIR_LAUNCH
+  return true;
 }
 
 }  // namespace rec

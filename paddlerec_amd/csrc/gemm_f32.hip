@@ -982,6 +982,36 @@ extern "C" int rec_gemm_plan_splits(const rec_gemm_desc* desc, int32_t num_cus, 
   return REC_OK;
 }
 
+// Two independent GEMMs (neither reads what the other writes).  The dW / dX pair of one Linear's backward at the
+// reference's batch sizes — both launch-bound, both reading the same gradient — goes out as ONE launch (gemm_direct.h:
+// gemm_f32_direct_pair_kernel; every workgroup runs the code of the single launch: bit-identical to two calls); every
+// other pair is two rec_gemm_f32 calls, desc0 first.
+extern "C" int rec_gemm_f32_pair(const rec_gemm_desc* desc0, const float* A0, const float* B0, float* C0,
+                                 const rec_gemm_epilogue_args* x0, const rec_gemm_desc* desc1, const float* A1,
+                                 const float* B1, float* C1, const rec_gemm_epilogue_args* x1, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  if (int rc = check_gemm(desc0)) return rc;
+  if (int rc = check_gemm(desc1)) return rc;
+  static const rec_gemm_epilogue_args kNoArgs = {};
+  const rec_gemm_epilogue_args* y0 = x0 ? x0 : &kNoArgs;
+  const rec_gemm_epilogue_args* y1 = x1 ? x1 : &kNoArgs;
+  const bool shape = desc0->m > 0 && desc1->m > 0 && A0 && B0 && C0 && A1 && B1 && C1 && desc0->trans_a &&
+                     desc0->epilogue == REC_EPI_NONE && !desc1->trans_a &&
+                     (desc1->epilogue == REC_EPI_NONE ||
+                      ((desc1->epilogue == REC_EPI_RELU_MASK || desc1->epilogue == REC_EPI_DSIGMOID) && y1->aux0 &&
+                       y1->ld_aux0 >= desc1->n)) &&
+                     !y1->b_colsum;
+  if (shape) {
+    EpiArgs e0{}, e1{};
+    e1.aux0 = y1->aux0;
+    e1.ld0 = y1->ld_aux0;
+    if (launch_direct_pair(desc0, A0, B0, C0, e0, y0->b_colsum, desc1, A1, B1, C1, e1, (hipStream_t)stream))
+      return check_launch("rec_gemm_f32_pair");
+  }
+  if (int rc = rec_gemm_f32(desc0, A0, B0, C0, x0, workspace, workspace_bytes, stream)) return rc;
+  return rec_gemm_f32(desc1, A1, B1, C1, x1, workspace, workspace_bytes, stream);
+}
+
 extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const float* B, float* C,
                             const rec_gemm_epilogue_args* x, void* workspace,
                             size_t workspace_bytes, void* stream) {

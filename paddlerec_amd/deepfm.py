@@ -608,7 +608,8 @@ class DeepFMLayer:
         if auc_stats is not None:
             self.k.auc_histogram(pred, label, auc_stats[0], auc_stats[1], NUM_THRESHOLDS)
         defer_all = os.environ.get("REC_DEEPFM_DEFER_ALL", "0") == "1"   # measurement knob: every dW GEMM in the tail
-        kw = dict(defer_all=True) if defer_all else dict(defer_first=True)
+        # small: one stream, nothing to run dW_0 beside — it goes out WITH dX_0 (ops.linear_backward: one launch at these sizes)
+        kw = dict(defer_all=True) if defer_all else dict(defer_first=True) if not small else {}
         if overlap and not defer_all and not small and B >= 16384:
             # dW_0 runs beside the sparse update: half a resident round of blocks (K split 16 instead of 32) leaves the
             # HBM-bound kernel its wave slots — sparse_adam 404 -> 336 us, dW_0 unchanged (REC_DW0_SPLIT: 0 = planner's)
@@ -625,11 +626,11 @@ class DeepFMLayer:
             kw.update(dw_stream=self._dw_stream, dw_ws=self._ws_dw)
         with self._timed("mlp_bwd"):
             if fused_head:
-                d_flat, finish_dw0 = self.k.mlp_backward(g_head, acts, mlp_w[:-1], mlp_dw[:-1], self.mlp_db[:-1],
-                                                         self.ws_mlp, **kw, **ikw_t(nl - 1))
+                res = self.k.mlp_backward(g_head, acts, mlp_w[:-1], mlp_dw[:-1], self.mlp_db[:-1], self.ws_mlp, **kw,
+                                          **ikw_t(nl - 1))
             else:
-                d_flat, finish_dw0 = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db, self.ws_mlp, **kw,
-                                                         **ikw_t(nl))
+                res = self.k.mlp_backward(dz, acts, mlp_w, mlp_dw, self.mlp_db, self.ws_mlp, **kw, **ikw_t(nl))
+            d_flat, finish_dw0 = res if kw else (res, (lambda: None))
         if group_at == "tail":
             issue_group()
         if sorted_rg and side is not None:

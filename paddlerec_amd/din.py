@@ -311,6 +311,10 @@ class DINLayer:
 
         def lin_bwd(name, x, dy, act=None):
             """dW, db of Linear `name` (input x, output-gradient dy); returns d x (sigmoid' of x fused when act)."""
+            if hasattr(self.k, "linear_backward"):      # both GEMMs in one call: one launch at the shipped batch size
+                g[name + ".weight"], g[name + ".bias"] = self._gb[name + ".weight"], self._gb[name + ".bias"]
+                return self.k.linear_backward(x, dy, p[name + ".weight"], ws, g[name + ".weight"], g[name + ".bias"],
+                                              **(dict(epilogue="dsigmoid", aux0=act) if act is not None else {}))
             g[name + ".weight"] = self.k.gemm(x, dy, ws, trans_a=True, out=self._gb[name + ".weight"],
                                               b_colsum=self._gb[name + ".bias"])
             g[name + ".bias"] = self._gb[name + ".bias"]

@@ -1519,6 +1519,32 @@ def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux
     num_cus > 0: the current stream is confined to that many compute units (cu_range_stream) — size the
     split-K for them instead of the whole chip.
     b_image: op(B)'s bf16 x 3 image from GemmImages (current values of B): the call skips its own split launch."""
+    d, x, out, need = _gemm_prepare(A, B, trans_a, trans_b, epilogue, bias, aux0, aux1, out, split_k, b_colsum, row_scale,
+                                    out2, num_cus, b_image)
+    w = ws.get(need)
+    check(lib().rec_gemm_f32(C.byref(d), _p(A), _p(B), _p(out), C.byref(x), _p(w),
+                             C.c_size_t(w.numel()), _stream()), "rec_gemm_f32")
+    return out
+
+
+def linear_backward(X, G, W, ws, dW, db, relu_src=None, b_image=None, epilogue=None, aux0=None):
+    """The backward of one Linear in ONE call (rec_gemm_f32_pair): dW = X^T G, db = colsum(G) and
+    dX = G W^T (masked by relu_src > 0 — the layer's own input — when given; or any dX epilogue of gemm(): epilogue=
+    "dsigmoid", aux0=the layer's input).  -> dX.  At launch-bound sizes the two GEMMs are one launch; otherwise exactly the
+    two gemm() calls of mlp_backward, dW first."""
+    if epilogue is None:
+        epilogue, aux0 = ("relu_mask", relu_src) if relu_src is not None else ("none", None)
+    d0, x0, _, need0 = _gemm_prepare(X, G, True, False, "none", None, None, None, dW, 0, db, None, None, 0, None)
+    d1, x1, dX, need1 = _gemm_prepare(G, W, False, True, epilogue, None, aux0, None, None, 0, None, None, None, 0, b_image)
+    w = ws.get(max(need0, need1))
+    check(lib().rec_gemm_f32_pair(C.byref(d0), _p(X), _p(G), _p(dW), C.byref(x0), C.byref(d1), _p(G), _p(W), _p(dX),
+                                  C.byref(x1), _p(w), C.c_size_t(w.numel()), _stream()), "rec_gemm_f32_pair")
+    return dX
+
+
+def _gemm_prepare(A, B, trans_a, trans_b, epilogue, bias, aux0, aux1, out, split_k, b_colsum, row_scale, out2, num_cus,
+                  b_image):
+    """Checks of one rec_gemm_f32 call -> (descriptor, epilogue arguments, out, workspace bytes)."""
     lda, ldb = _chk_mat(A, "A"), _chk_mat(B, "B")
     K, M = (A.shape if trans_a else A.shape[::-1])
     N, K2 = (B.shape if trans_b else B.shape[::-1])
@@ -1569,10 +1595,7 @@ def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux
         nbytes = C.c_size_t(0)
         check(lib().rec_gemm_f32_workspace_bytes(C.byref(d), C.byref(nbytes)))
         need = _gemm_ws_cache[key] = nbytes.value
-    w = ws.get(need)
-    check(lib().rec_gemm_f32(C.byref(d), _p(A), _p(B), _p(out), C.byref(x), _p(w),
-                             C.c_size_t(w.numel()), _stream()), "rec_gemm_f32")
-    return out
+    return d, x, out, need
 
 
 def colsum(G, ws, out=None):
@@ -1718,7 +1741,10 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
             with torch.cuda.stream(dw_stream):
                 gemm(acts[i], g, dw_ws if dw_ws is not None else ws, trans_a=True, out=dws[i], b_colsum=dbs[i])
         else:
-            gemm(acts[i], g, ws, trans_a=True, out=dws[i], b_colsum=dbs[i])    # dW = X^T G, db = colsum(G)
+            # dW = X^T G, db = colsum(G) and dX = G W^T (+ ReLU') in one call: one launch at launch-bound sizes
+            g = linear_backward(acts[i], g, weights[i], ws, dws[i], dbs[i], relu_src=acts[i] if i > 0 else None,
+                                b_image=imt(i))
+            continue
         if i > 0:
             g = gemm(g, weights[i], ws, trans_b=True, epilogue="relu_mask", aux0=acts[i], b_image=imt(i))
         else:

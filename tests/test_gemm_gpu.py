@@ -127,6 +127,33 @@ def test_gemm_direct_kernel(ops, M, N, K, ta, tb):
         assert np.array_equal(C3, C)
 
 
+@pytest.mark.parametrize("B,nin,nout,epi", [
+    (512, 400, 400, "relu_mask"), (512, 432, 400, "none"),      # deepfm bs 512: hidden layer, layer 0 (one launch for both)
+    (32, 80, 40, "dsigmoid"), (32, 256, 80, "none"),            # din bs 32 (K split over the workgroup)
+    (512, 1560, 1560, "relu_mask"),                             # not launch-bound: two rec_gemm_f32 calls
+    (300, 130, 77, "relu_mask")])                               # odd sizes, unaligned rows of W: falls back as well
+def test_linear_backward_pair(ops, B, nin, nout, epi):
+    """rec_gemm_f32_pair (ops.linear_backward): dW = X^T G + db and dX = G W^T (+ activation') of one Linear in one call —
+    bit-identical to the two rec_gemm_f32 calls whether it goes out as one launch or two, and right against float64."""
+    rng = np.random.default_rng(B + nin + nout)
+    X, G, W = _mk(rng, B, nin), _mk(rng, B, nout), _mk(rng, nin, nout)
+    Xt, Gt, Wt = (torch.as_tensor(a).to(DEV) for a in (X, G, W))
+    ws = ops.Workspace(DEV)
+    dW, db = torch.empty(nin, nout, device=DEV), torch.empty(nout, device=DEV)
+    aux = Xt if epi != "none" else None
+    dX = ops.linear_backward(Xt, Gt, Wt, ws, dW, db, epilogue=epi, aux0=aux)
+    dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+    ops.gemm(Xt, Gt, ws, trans_a=True, out=dW2, b_colsum=db2)
+    dX2 = ops.gemm(Gt, Wt, ws, trans_b=True, epilogue=epi, **(dict(aux0=aux) if aux is not None else {}))
+    assert torch.equal(dW, dW2) and torch.equal(db, db2) and torch.equal(dX, dX2)
+    acc = G.astype(np.float64) @ W.astype(np.float64).T
+    want = np.where(X > 0, acc, 0) if epi == "relu_mask" else acc * X * (1 - X) if epi == "dsigmoid" else acc
+    scale = 2.5 if epi == "dsigmoid" else 1.0          # |x (1 - x)| <= 2 on [-1, 1], plus the rounding of the product
+    _check(dX.cpu().numpy(), want, scale * 4e-7 * (np.abs(G).astype(np.float64) @ np.abs(W).astype(np.float64).T) + 1e-12)
+    _check(dW.cpu().numpy(), X.astype(np.float64).T @ G.astype(np.float64),
+           4e-7 * (np.abs(X).astype(np.float64).T @ np.abs(G).astype(np.float64)))
+
+
 def test_gemm_skinny_paths(ops):
     """One-output Linear layers (N <= 4) take the streaming kernels: forward with epilogues, dW with the fused
     bias gradient."""
