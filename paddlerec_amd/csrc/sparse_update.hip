@@ -1088,6 +1088,249 @@ __global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_kernel(
   sparse_small_body<NACC, Update>(blockIdx.x, n, D, S, N, pad, ids, slot_off, grad, gl, up, status, span_flag, fp_mode);
 }
 
+// ------------------------------------------------------------------ one-launch merge by ROW BUCKETS (n > kBucketMin)
+// The merge above compares a lookup with every other lookup of its list: O(n^2 / 64) wave steps and, worse, every block
+// staging the whole id list — 22 us + a 6 us span-check launch for the 13 312 lookups of a DeepFM batch of 512 on 26 slot
+// tables (compared slot by slot), 98 us on the reference's own ONE shared table, where every lookup meets every other.
+// Here block b owns the rows that HASH to bucket b: every block still reads all n ids once (8 n bytes from L2, no
+// staging), but keeps only its own ~n / P lookups — (row, position) pairs in ascending position, built in two steps so
+// that the list is dense and ordered without atomics: each wave counts the members of its contiguous range of positions
+// (the ballots stay in registers), the counts meet in LDS, and the wave writes its members behind the waves in front of
+// it.  All occurrences of a row are in ONE bucket whatever the slots are, so nothing depends on ids staying inside
+// their slot's span (no span check), and the duplicate search runs over ~16 entries instead of 512 or 13 312.  The wave
+// of a row's first occurrence adds the gradient rows of every occurrence in ascending position (the SelectedRows merge
+// order: bit-identical to the kernels above) and applies the update; its record and moment lines are requested BEFORE
+// the gradient rows, so the two fetches overlap.  A bucket with more than kBucketCap members (a row that owns a quarter
+// of the batch) does not fit its LDS list: that block walks the positions in global memory instead — same arithmetic,
+// same order, slower.
+constexpr int kBucketMin = 2048;       // below: sparse_small_kernel (few blocks, cheap staging)
+constexpr int kBucketWaves = 16;
+constexpr int kBucketCap = 4096;       // (row, position) pairs of one bucket in LDS: 32 KB
+constexpr int kBucketIts = (kSmallMergeMax + kBucketWaves * kWave - 1) / (kBucketWaves * kWave);   // positions per lane: 15
+
+__device__ __forceinline__ unsigned bucket_of(int row, unsigned P) {
+  const unsigned h = (unsigned)row * 0x9E3779B1u;
+  return (unsigned)(((unsigned long long)(h ^ (h >> 15)) * P) >> 32);
+}
+
+template <int NACC, class Update>
+__global__ __launch_bounds__(kBucketWaves* kWave) void sparse_bucket_kernel(
+    int n, int D, int S, int64_t N, int64_t pad, const int64_t* __restrict__ ids, const int64_t* __restrict__ slot_off,
+    const float* __restrict__ grad, rec_grad_layout gl, Update up, int32_t* __restrict__ status) {
+  constexpr bool kRecord = std::is_same<Update, SmallAdamRecord>::value;
+  constexpr int FLY = kSmallList / NACC;
+  __shared__ int b_rows[kBucketCap];
+  __shared__ int b_pos[kBucketCap];
+  __shared__ int b_wl[kBucketWaves][kSmallList];
+  __shared__ int b_cnt[kBucketWaves + 1];
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+  const unsigned P = gridDim.x, me = blockIdx.x;
+  auto row_of = [&](int p) -> int {                  // table row of position p, -1 = padding / out of range
+    const int64_t id = ids[p];
+    const bool isp = pad >= 0 && id == pad;
+    const int64_t r = slot_off ? id + slot_off[p % S] : id;
+    return (!isp && r >= 0 && r < N) ? (int)r : -1;
+  };
+  // ---- step 1: this wave's range of positions, members counted (ballots and rows stay in registers)
+  const int per_wave = ((n + kBucketWaves - 1) / kBucketWaves + kWave - 1) / kWave * kWave;
+  const int p0 = wave * per_wave;
+  unsigned long long mask[kBucketIts];
+  int rowv[kBucketIts];
+  int mine_cnt = 0, oob = 0;
+#pragma unroll
+  for (int it = 0; it < kBucketIts; ++it) {
+    const int p = p0 + it * kWave + lane;
+    const bool in = it * kWave < per_wave && p < n;
+    int r = -1;
+    if (in) {
+      const int64_t id = ids[p];
+      const bool isp = pad >= 0 && id == pad;
+      const int64_t rr = slot_off ? id + slot_off[p % S] : id;
+      const bool inr = rr >= 0 && rr < N;
+      oob |= (!isp && !inr) ? 1 : 0;
+      r = (!isp && inr) ? (int)rr : -1;
+    }
+    rowv[it] = r;
+    mask[it] = __ballot(r >= 0 && bucket_of(r, P) == me);
+    mine_cnt += (int)__popcll(mask[it]);
+  }
+  if (me == 0 && oob) atomicOr(status, REC_FLAG_INDEX_OOB);      // (every block sees every id: one of them reports)
+  if (lane == 0) b_cnt[wave] = mine_cnt;
+  __syncthreads();
+  int my_off = 0, m = 0;
+#pragma unroll
+  for (int w = 0; w < kBucketWaves; ++w) {
+    const int c = b_cnt[w];
+    my_off += w < wave ? c : 0;
+    m += c;
+  }
+  const bool in_lds = m <= kBucketCap;
+  if (in_lds) {
+    int at = my_off;
+#pragma unroll
+    for (int it = 0; it < kBucketIts; ++it) {
+      const unsigned long long mk = mask[it];
+      if ((mk >> lane) & 1ull) {
+        const int idx = at + (int)__popcll(mk & ((1ull << lane) - 1ull));
+        b_rows[idx] = rowv[it];
+        b_pos[idx] = p0 + it * kWave + lane;
+      }
+      at += (int)__popcll(mk);
+    }
+  }
+  __syncthreads();
+  // ---- step 2: the entries of the compared list.  LDS list: entry j = (b_rows[j], b_pos[j]), j < m, every entry a member.
+  //      Overflow: the list is the n positions themselves, a candidate is a member of this bucket.
+  const int tn = in_lds ? m : n;
+  auto row_at = [&](int j) { return in_lds ? b_rows[j] : row_of(j); };
+  auto pos_at = [&](int j) { return in_lds ? b_pos[j] : j; };
+  const bool plain = gl.group == 1 && gl.div == 1 && gl.index == nullptr;
+  bool no_index = gl.index == nullptr;
+  if constexpr (kRecord) no_index = no_index && up.gl1.index == nullptr;
+  int* wl = b_wl[wave];
+  for (int j = wave; j < tn; j += kBucketWaves) {
+    const int my = row_at(j);                                    // wave-uniform
+    if (my < 0 || (!in_lds && bucket_of(my, P) != me)) continue;
+    // an earlier occurrence owns the row: searched from the nearest earlier entries backwards (only existence matters)
+    bool owned = false;
+    for (int c1 = j; c1 > 0 && !owned; c1 -= 4 * kWave) {
+      const int c0 = c1 - 4 * kWave;
+      bool hit = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = c0 + u * kWave + lane;
+        hit |= k >= 0 && k < j && row_at(k >= 0 ? k : 0) == my;
+      }
+      owned = __ballot(hit) != 0;
+    }
+    if (owned) continue;
+    // the row's lines first, its gradient rows behind them (two fetches in flight together)
+    float pw[NACC], pm[NACC], pv[NACC], q1 = 0.f, q2 = 0.f, q3 = 0.f;
+    if constexpr (kRecord) {
+      const float* r = up.rec + (int64_t)my * up.stride;
+      const float* mv = up.MV + (int64_t)my * up.sstride;
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        const int d = lane + a * kWave;
+        const int dc = d < D ? d : 0;
+        pw[a] = r[dc]; pm[a] = mv[dc]; pv[a] = mv[up.v_off + dc];
+      }
+      if (lane == 0) { q1 = r[D]; q2 = r[D + 1]; q3 = r[D + 2]; }
+    } else {
+      const float* r = up.P + (int64_t)my * up.stride;
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        const int d = lane + a * kWave;
+        pw[a] = r[d < D ? d : 0];
+        pm[a] = pv[a] = 0.f;
+      }
+    }
+    float acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = 0.f;
+    float acc1 = 0.f;
+    int cnt = 0;
+    // (the fetch tiers, flush and emit are those of sparse_small_body: rows are added in ascending position)
+    auto fetch = [&](auto tier, auto noidx) {
+      constexpr int TR = decltype(tier)::value;
+      rec_grad_layout gq = gl;
+      if constexpr (decltype(noidx)::value) gq.index = nullptr;
+      float x[TR][NACC], x1[TR];
+#pragma unroll
+      for (int u = 0; u < TR; ++u) {
+        const int q = wl[u < cnt ? u : 0];
+        const float* g = grad + (plain ? (int64_t)q * gq.group_stride : grad_offset(gq, q, D));
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+          const int d = lane + a * kWave;
+          x[u][a] = g[d < D ? d : 0];
+        }
+        if constexpr (kRecord) {
+          rec_grad_layout g1 = up.gl1;
+          if constexpr (decltype(noidx)::value) g1.index = nullptr;
+          x1[u] = up.grad1[grad_offset(g1, q, 1)];
+        } else {
+          x1[u] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TR; ++u) {
+        const bool live = u < cnt;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] += (live && lane + a * kWave < D) ? x[u][a] : 0.f;
+        acc1 += live ? x1[u] : 0.f;
+      }
+    };
+    auto flush = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (no_index) {
+        if (cnt <= 1) fetch(std::integral_constant<int, 1>{}, std::true_type{});
+        else if (cnt <= 4) fetch(std::integral_constant<int, (FLY < 4 ? FLY : 4)>{}, std::true_type{});
+        else if (cnt <= 16) fetch(std::integral_constant<int, (FLY < 16 ? FLY : 16)>{}, std::true_type{});
+        else fetch(std::integral_constant<int, FLY>{}, std::true_type{});
+      } else {
+        fetch(std::integral_constant<int, FLY>{}, std::false_type{});
+      }
+      cnt = 0;
+      __builtin_amdgcn_wave_barrier();
+    };
+    auto emit = [&](bool mine, int k) {
+      unsigned long long mk = __ballot(mine);
+      while (mk) {
+        const int rank = __popcll(mk & ((1ull << lane) - 1ull));
+        const int take = min((int)__popcll(mk), FLY - cnt);
+        if (mine && rank < take) wl[cnt + rank] = pos_at(k);
+        cnt += take;
+        mine = mine && rank >= take;
+        mk = __ballot(mine);
+        if (cnt == FLY) flush();
+      }
+    };
+    for (int c0 = (j / kWave) * kWave; c0 < tn; c0 += 4 * kWave) {
+      bool mk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = c0 + u * kWave + lane;
+        mk[u] = k >= j && k < tn && row_at(k < tn ? k : 0) == my;
+      }
+      if (__ballot(mk[0] || mk[1] || mk[2] || mk[3]) == 0) continue;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) emit(mk[u], c0 + u * kWave + lane);
+    }
+    if (cnt > 0) flush();
+    if constexpr (!kRecord) {
+      float* r = up.P + (int64_t)my * up.stride;
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        const int d = lane + a * kWave;
+        if (d < D) r[d] = pw[a] - up.lr * acc[a];
+      }
+    } else {
+      float* r = up.rec + (int64_t)my * up.stride;
+      float* mv = up.MV + (int64_t)my * up.sstride;
+      const float sc = up.grad_scale ? up.grad_scale[0] : 1.f;
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        const int d = lane + a * kWave;
+        if (d < D) {
+          float p_ = pw[a], m_ = pm[a], v_ = pv[a];
+          const float g = up.grad_scale ? scale_grad(acc[a], sc) : acc[a];
+          adam_elem(p_, m_, v_, g, up.lr_t, up.eps_t, up.b1, up.b2);
+          r[d] = p_; mv[d] = m_; mv[up.v_off + d] = v_;
+        }
+      }
+      if (lane == 0) {
+        const float g = up.grad_scale ? scale_grad(acc1, sc) : acc1;
+        adam_elem(q1, q2, q3, g, up.lr_t, up.eps_t, up.b1, up.b2);
+        r[D] = q1; r[D + 1] = q2; r[D + 2] = q3;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();       // the wave's occurrence list is reused by its next entry
+  }
+}
+
 // LDS bytes of a one-launch merge over n lookups; *fp_mode = 1 when the fingerprint array fits beside the id list in the
 // default 64 KB (plain tables only: the slot-local mode compares n / S lookups, a chunk or two)
 static size_t small_lds_bytes(size_t n, bool plain, int* fp_mode) {
@@ -1795,6 +2038,20 @@ extern "C" int rec_sparse_adam_record_small(int64_t n, int32_t num_slots, int32_
   adam_scalars(hyper, &up.lr_t, &up.eps_t);
   up.b1 = hyper->beta1; up.b2 = hyper->beta2;
   if (gl.group <= 0) { gl.group = 1; gl.group_stride = emb_dim; }   // one D-wide row per position
+  static const int bucket_on = [] { const char* v = getenv("REC_SMALL_BUCKET"); return v ? atoi(v) : 1; }();   // 2 (lab): slot tables too
+  // by row buckets (sparse_bucket_kernel): ONE table whose lookups all meet each other.  Slot tables keep the slot-major
+  // merge below — a lookup is compared with its slot's n / S lookups only (26 x 512: 0.114 ms per step against 0.149 here)
+  if (bucket_on && n > kBucketMin && (!slot_offset || num_slots <= 1 || bucket_on == 2)) {
+    static const int per_bucket = [] { const char* v = getenv("REC_SMALL_BUCKET_ROWS"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 64; }();
+    const unsigned buckets = (unsigned)((n + per_bucket - 1) / per_bucket);
+#define REC_BUCKET(NACC_)                                                                                             \
+  hipLaunchKernelGGL((sparse_bucket_kernel<NACC_, SmallAdamRecord>), dim3(buckets), dim3(kBucketWaves * kWave), 0,      \
+                     (hipStream_t)stream, (int)n, emb_dim, num_slots, num_rows, padding_idx, ids, slot_offset, grad, gl, \
+                     up, status)
+    if (emb_dim <= kWave) REC_BUCKET(1); else if (emb_dim <= 2 * kWave) REC_BUCKET(2); else REC_BUCKET(4);
+#undef REC_BUCKET
+    return check_launch("rec_sparse_adam_record_small (buckets)");
+  }
   unsigned grid = (unsigned)((n + kSmallWaves - 1) / kSmallWaves);
   if (slot_offset && num_slots > 1 && n % num_slots == 0) {        // slot-major block mapping (sparse_small_body)
     const unsigned g2 = (unsigned)(num_slots * ((n / num_slots + kSmallWaves - 1) / kSmallWaves));
