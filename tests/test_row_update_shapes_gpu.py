@@ -190,3 +190,47 @@ def test_ps_push_narrow_shape_sweep(engine_lib, seed):
     untouched = np.setdiff1d(np.arange(N), uniq)
     assert np.array_equal(got[untouched], rec[untouched])
     assert int(status.item()) == 0
+
+
+@pytest.mark.parametrize("case", ["uniform", "zipf", "one_row_owns_most", "all_padding_but_one", "oob"])
+@pytest.mark.parametrize("D", [9, 16])
+def test_bucket_merge_equals_sorted_merge_bitwise(engine_lib, case, D):
+    """One shared table, more than 2048 lookups: rec_sparse_adam_record_small merges by ROW BUCKETS
+    (sparse_bucket_kernel).  A row's gradients are added in ascending position, as the sort-based merge
+    (rec_ids_group + rec_sparse_adam_record without partials) adds them: records and moments bit-identical — also
+    when one row owns most of the batch (its bucket does not fit the LDS list: the block walks global memory), with
+    padding ids and with ids outside the table (flagged, not applied)."""
+    from paddlerec_amd import ops
+    from paddlerec_amd import _lib as L
+    rng = np.random.default_rng(77)
+    B, S, N = 512, 26, 3000
+    n = B * S
+    if case == "zipf":
+        ids_np = np.minimum(rng.zipf(1.2, size=n), N - 1).astype(np.int64)
+    else:
+        ids_np = rng.integers(0, N, size=n)
+    if case == "one_row_owns_most":
+        ids_np[rng.random(n) < 0.8] = 1234
+    if case == "all_padding_but_one":
+        ids_np[:] = 0
+        ids_np[n // 2] = 17
+    if case == "oob":
+        ids_np[rng.random(n) < 0.01] = N + 5
+        ids_np[7] = -3
+    ids = torch.from_numpy(ids_np).to(DEV).reshape(B, S)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    stride = 16 if D == 9 else 32
+    Dp = (D + 3) // 4 * 4
+    rec = torch.randn(N, stride, device=DEV, generator=g) * 0.1
+    mv = torch.rand(N, 32, device=DEV, generator=g) * 1e-3
+    rec[:, D + 2].abs_()
+    rec_b, mv_b = rec.clone(), mv.clone()
+    rg = torch.randn(n, D, device=DEV, generator=g) * 1e-2
+    dz = torch.randn(B, device=DEV, generator=g) * 1e-2
+    st = ops.sparse_adam_record_small(ids, None, 0, rg, dz, S, rec, mv, D, 5, lr=1e-2, v_offset=Dp)
+    ws = ops.Workspace(DEV)
+    groups, st_b = ops.ids_group(ids.reshape(-1), N, 0, ws)
+    ops.sparse_adam_record(groups, rg, dz, S, rec_b, mv_b, D, 5, lr=1e-2, v_offset=Dp)
+    assert torch.equal(rec, rec_b) and torch.equal(mv, mv_b)
+    want = L.REC_FLAG_INDEX_OOB if case == "oob" else 0
+    assert int(st.item()) == want and int(st_b.item()) == want
