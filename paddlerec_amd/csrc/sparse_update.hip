@@ -1107,6 +1107,8 @@ constexpr int kBucketMin = 2048;       // below: sparse_small_kernel (few blocks
 constexpr int kBucketWaves = 16;
 constexpr int kBucketCap = 4096;       // (row, position) pairs of one bucket in LDS: 32 KB
 constexpr int kBucketIts = (kSmallMergeMax + kBucketWaves * kWave - 1) / (kBucketWaves * kWave);   // positions per lane: 15
+constexpr int kQuadCap = kBucketWaves * kWave;   // a list of at most one entry per thread ...
+constexpr int kQuadLanes = 16;                   // ... of rows at most this wide: a row per 16 lanes (step 2Q below)
 
 __device__ __forceinline__ unsigned bucket_of(int row, unsigned P) {
   const unsigned h = (unsigned)row * 0x9E3779B1u;
@@ -1123,8 +1125,12 @@ __global__ __launch_bounds__(kBucketWaves* kWave) void sparse_bucket_kernel(
   __shared__ int b_pos[kBucketCap];
   __shared__ int b_wl[kBucketWaves][kSmallList];
   __shared__ int b_cnt[kBucketWaves + 1];
+  __shared__ int b_next[kQuadCap];     // step 2Q: the next entry of the same row, -1 = none
+  __shared__ int b_own[kQuadCap];      // step 2Q: the entries that are their row's first occurrence (any order)
+  __shared__ int b_nown;
   const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
   const unsigned P = gridDim.x, me = blockIdx.x;
+  if (threadIdx.x == 0) b_nown = 0;
   auto row_of = [&](int p) -> int {                  // table row of position p, -1 = padding / out of range
     const int64_t id = ids[p];
     const bool isp = pad >= 0 && id == pad;
@@ -1177,8 +1183,84 @@ __global__ __launch_bounds__(kBucketWaves* kWave) void sparse_bucket_kernel(
       }
       at += (int)__popcll(mk);
     }
+    if (threadIdx.x < 4 && m + (int)threadIdx.x < kBucketCap) b_rows[m + threadIdx.x] = -2;   // (step 2Q reads whole int4s)
   }
   __syncthreads();
+  // ---- step 2Q: narrow rows (D <= 16) and a list of at most one entry per thread — the DeepFM record at the reference's
+  // batch size: ~64 entries per bucket.  Step 2 below gives a wave ONE entry at a time — search, record lines, gradient
+  // rows, stores: four dependent round trips per entry, four entries per wave, nine of 64 lanes carrying a D 9 row.  Here
+  // thread j looks at entry j: one pass over the list tells it whether an earlier entry holds its row (then it is not
+  // the row's owner) and which entry is the next of the same row; the owners are then dealt to groups of 16 lanes, which
+  // walk their row's chain — ascending position, the same order of additions as step 2 — with four gradient rows in
+  // flight.  Every row of the bucket is in flight at once: one round of latencies per block instead of four per wave.
+  if constexpr (NACC == 1 && kRecord) {
+    if (in_lds && m <= kQuadCap && D <= kQuadLanes) {
+      const int j = threadIdx.x;
+      if (j < m) {
+        const int my = b_rows[j];
+        bool first = true;
+        int nxt = -1;
+        const int4* r4 = reinterpret_cast<const int4*>(b_rows);
+        for (int k4 = 0; k4 * 4 < m; ++k4) {                    // (every lane reads the same address: a broadcast)
+          const int4 v = r4[k4];
+          const int k = k4 * 4;
+          const bool e0 = v.x == my, e1 = v.y == my, e2 = v.z == my, e3 = v.w == my;
+          first = first && !((e0 && k < j) || (e1 && k + 1 < j) || (e2 && k + 2 < j) || (e3 && k + 3 < j));
+          if (nxt < 0) nxt = (e0 && k > j) ? k : (e1 && k + 1 > j) ? k + 1 : (e2 && k + 2 > j) ? k + 2 : (e3 && k + 3 > j) ? k + 3 : -1;
+        }
+        b_next[j] = nxt;
+        if (first) b_own[atomicAdd(&b_nown, 1)] = j;
+      }
+      __syncthreads();
+      const int nown = b_nown;
+      const int l = threadIdx.x % kQuadLanes, grp = threadIdx.x / kQuadLanes;
+      const bool on = l < D;
+      const int dc = on ? l : 0;
+      const bool plain = gl.group == 1 && gl.div == 1 && gl.index == nullptr;
+      const float sc = up.grad_scale ? up.grad_scale[0] : 1.f;
+      for (int o = grp; o < nown; o += kQuadCap / kQuadLanes) {
+        int k = b_own[o];
+        const int my = b_rows[k];
+        float* r = up.rec + (int64_t)my * up.stride;
+        float* mv = up.MV + (int64_t)my * up.sstride;
+        float pw = r[dc], pm = mv[dc], pv = mv[up.v_off + dc];
+        float q1 = 0.f, q2 = 0.f, q3 = 0.f;
+        if (l == 0) { q1 = r[D]; q2 = r[D + 1]; q3 = r[D + 2]; }
+        float acc = 0.f, acc1 = 0.f;
+        while (k >= 0) {
+          int q[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            q[u] = k >= 0 ? b_pos[k] : -1;
+            k = k >= 0 ? b_next[k] : -1;
+          }
+          float x[4], x1[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int qq = q[u] >= 0 ? q[u] : q[0];
+            x[u] = grad[(plain ? (int64_t)qq * gl.group_stride : grad_offset(gl, qq, D)) + dc];
+            x1[u] = up.grad1[grad_offset(up.gl1, qq, 1)];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            acc += (q[u] >= 0 && on) ? x[u] : 0.f;
+            acc1 += q[u] >= 0 ? x1[u] : 0.f;
+          }
+        }
+        if (on) {
+          const float g = up.grad_scale ? scale_grad(acc, sc) : acc;
+          adam_elem(pw, pm, pv, g, up.lr_t, up.eps_t, up.b1, up.b2);
+          r[l] = pw; mv[l] = pm; mv[up.v_off + l] = pv;
+        }
+        if (l == 0) {
+          const float g = up.grad_scale ? scale_grad(acc1, sc) : acc1;
+          adam_elem(q1, q2, q3, g, up.lr_t, up.eps_t, up.b1, up.b2);
+          r[D] = q1; r[D + 1] = q2; r[D + 2] = q3;
+        }
+      }
+      return;
+    }
+  }
   // ---- step 2: the entries of the compared list.  LDS list: entry j = (b_rows[j], b_pos[j]), j < m, every entry a member.
   //      Overflow: the list is the n positions themselves, a candidate is a member of this bucket.
   const int tn = in_lds ? m : n;
@@ -2039,9 +2121,11 @@ extern "C" int rec_sparse_adam_record_small(int64_t n, int32_t num_slots, int32_
   up.b1 = hyper->beta1; up.b2 = hyper->beta2;
   if (gl.group <= 0) { gl.group = 1; gl.group_stride = emb_dim; }   // one D-wide row per position
   static const int bucket_on = [] { const char* v = getenv("REC_SMALL_BUCKET"); return v ? atoi(v) : 1; }();   // 2 (lab): slot tables too
-  // by row buckets (sparse_bucket_kernel): ONE table whose lookups all meet each other.  Slot tables keep the slot-major
-  // merge below — a lookup is compared with its slot's n / S lookups only (26 x 512: 0.114 ms per step against 0.149 here)
-  if (bucket_on && n > kBucketMin && (!slot_offset || num_slots <= 1 || bucket_on == 2)) {
+  // by row buckets (sparse_bucket_kernel): ONE table whose lookups all meet each other, and slot tables of narrow rows
+  // (the 16-lane form of the kernel's step 2: 26 x 512 lookups 0.115 -> 0.109 ms per step, and no span check — a row's
+  // occurrences meet in its bucket whatever slot they come from).  Slot tables of wider rows keep the slot-major merge
+  // below: a lookup is compared with its slot's n / S lookups only.
+  if (bucket_on && n > kBucketMin && (!slot_offset || num_slots <= 1 || emb_dim <= kQuadLanes || bucket_on == 2)) {
     static const int per_bucket = [] { const char* v = getenv("REC_SMALL_BUCKET_ROWS"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 64; }();
     const unsigned buckets = (unsigned)((n + per_bucket - 1) / per_bucket);
 #define REC_BUCKET(NACC_)                                                                                             \
