@@ -7,6 +7,7 @@
 //     dX0_acc += dX * U_l            (gradient reaching X_0 through the Hadamard product)
 // One streaming pass reads dX, X_0, U_l once and writes both results (HBM-bound, float4 per lane).
 #include "rec_common.h"
+#include "tail_roles.h"
 
 namespace rec {
 
@@ -245,24 +246,8 @@ __global__ __launch_bounds__(kBlock) void dense_fold_bwd_dw_kernel(int S, int D,
 // backward two kernels behind a copy: five launches on the critical path of a step that is ~30 launches long at the
 // reference's batch size).  Block roles by index range; every element is computed exactly as by the kernels above.
 //   fwd:  W0f[r, :] = W0[r, :] for r < S*D;   W0f[S*D + j, :] = M[j, :]
-__global__ __launch_bounds__(kBlock) void dense_fold_fwd_full_kernel(int S, int Dn, int D, int NO, int copy_blocks,
-                                                                     const float* __restrict__ dw,
-                                                                     const float* __restrict__ W0,
-                                                                     float* __restrict__ W0f) {
-  if ((int)blockIdx.x < copy_blocks) {
-    const int64_t total = (int64_t)S * D * NO;
-    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)copy_blocks * kBlock)
-      W0f[e] = W0[e];
-    return;
-  }
-  const int nb = (int)gridDim.x - copy_blocks;
-  float* M = W0f + (int64_t)S * D * NO;
-  for (int e = ((int)blockIdx.x - copy_blocks) * kBlock + threadIdx.x; e < Dn * NO; e += nb * kBlock) {
-    const int j = e / NO, n = e % NO;
-    float t = 0.f;
-    for (int d = 0; d < D; ++d) t += dw[j * D + d] * W0[(int64_t)((S + j) * D + d) * NO + n];
-    M[e] = t;
-  }
+__global__ __launch_bounds__(kBlock) void dense_fold_fwd_full_kernel(FoldFwd r) {
+  dense_fold_fwd_role(blockIdx.x, threadIdx.x, r);      // tail_roles.h
 }
 //   bwd:  dW0f [(S+1)*D, NO] = feat'^T dZ0 (its rows S*D.. hold dM):
 //         dW0[r, :] = dW0f[r, :] for r < S*D;   dW0[S*D + jd, n] = dw[jd] * dM[jd / D, n];
@@ -303,16 +288,21 @@ __global__ __launch_bounds__(kBlock) void dense_fold_bwd_full_kernel(int S, int 
 }
 }  // namespace rec
 
-extern "C" int rec_dense_fold_fwd_full(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out,
-                                       const float* dense_w, const float* W0, float* W0_folded, void* stream) {
-  REC_REQUIRE(num_slots > 0 && num_dense > 0 && emb_dim > 0 && n_out > 0 && dense_w && W0 && W0_folded, REC_EINVAL,
-              "bad arguments");
+rec::FoldFwd rec::dense_fold_fwd_plan(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out,
+                                      const float* dense_w, const float* W0, float* W0_folded) {
   const int64_t copy_elems = (int64_t)num_slots * emb_dim * n_out;
   int copy_blocks = (int)((copy_elems + rec::kBlock * 4 - 1) / (rec::kBlock * 4));
   if (copy_blocks > 512) copy_blocks = 512;
   const int m_blocks = (num_dense * n_out + rec::kBlock - 1) / rec::kBlock;
-  hipLaunchKernelGGL(rec::dense_fold_fwd_full_kernel, dim3(copy_blocks + m_blocks), dim3(rec::kBlock), 0,
-                     (hipStream_t)stream, num_slots, num_dense, emb_dim, n_out, copy_blocks, dense_w, W0, W0_folded);
+  return rec::FoldFwd{copy_blocks + m_blocks, num_slots, num_dense, emb_dim, n_out, copy_blocks, dense_w, W0, W0_folded};
+}
+
+extern "C" int rec_dense_fold_fwd_full(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out,
+                                       const float* dense_w, const float* W0, float* W0_folded, void* stream) {
+  REC_REQUIRE(num_slots > 0 && num_dense > 0 && emb_dim > 0 && n_out > 0 && dense_w && W0 && W0_folded, REC_EINVAL,
+              "bad arguments");
+  const rec::FoldFwd r = rec::dense_fold_fwd_plan(num_slots, num_dense, emb_dim, n_out, dense_w, W0, W0_folded);
+  hipLaunchKernelGGL(rec::dense_fold_fwd_full_kernel, dim3(r.blocks), dim3(rec::kBlock), 0, (hipStream_t)stream, r);
   return rec::check_launch("rec_dense_fold_fwd_full");
 }
 

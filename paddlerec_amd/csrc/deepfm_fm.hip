@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include "rec_common.h"
+#include "tail_roles.h"
 #include "fm_tile.h"
 
 namespace rec {
@@ -61,7 +62,12 @@ __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
     const float* __restrict__ W1, const float* __restrict__ dense_w,
     const float* __restrict__ dense_w_one, const int64_t* __restrict__ slot_off,
     float* __restrict__ y1, float* __restrict__ y2, float* __restrict__ feat,
-    float* __restrict__ sum_emb, int32_t* __restrict__ status) {
+    float* __restrict__ sum_emb, int32_t* __restrict__ status, int main_blocks, FoldFwd fold) {
+  // blocks behind the lookup's own: layer 0's weight fold of a launch-bound step (tail_roles.h, FoldFwd)
+  if ((int)blockIdx.x >= main_blocks) {
+    dense_fold_fwd_role((int)blockIdx.x - main_blocks, threadIdx.x, fold);
+    return;
+  }
   constexpr int FS = fs_for<LANES>();
   constexpr int SPW = kWave / (LANES * FS);  // samples per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void fm_fwd_kernel(
   const int F = S + Dn;
   const int NIT = (F + FS - 1) / FS;
   const int64_t ntiles = (B + SPW - 1) / SPW;
-  const int64_t tstride = (int64_t)gridDim.x * kWavesPerBlock;
+  const int64_t tstride = (int64_t)main_blocks * kWavesPerBlock;
   const int64_t n_ids = B * S, n_dense = B * Dn;
   int oob = 0;
 
@@ -423,19 +429,8 @@ __global__ __launch_bounds__(kBlock) void fold_partials_kernel(const float* __re
                                                                int nblk, int split,
                                                                float* __restrict__ out0,
                                                                float* __restrict__ out1) {
-  __shared__ float red[kBlock];
-  const int k = blockIdx.x;
-  float t = 0.f;
-  for (int i = threadIdx.x; i < nblk; i += kBlock) t += partial[(int64_t)k * nblk + i];
-  red[threadIdx.x] = t;
-  __syncthreads();
-  for (int o = kBlock / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    if (k < split) out0[k] = red[0]; else out1[k - split] = red[0];
-  }
+  fm_fold_role<false>(blockIdx.x, threadIdx.x, kBlock, partial, nblk, split, out0, out1, FoldedLayer0{}, DenseAdam{}, 0, 0,
+                      0);   // tail_roles.h
 }
 
 // Launch-geometry knobs, read once from the environment (tools/fm_sweep.py measures them; the defaults below are
@@ -485,11 +480,32 @@ static bool fm_tile_shape(const rec_deepfm_desc* d) {
 
 using namespace rec;
 
+static int fm_fwd_impl(const rec_deepfm_desc* desc, const int64_t* ids, const float* dense, const float* W, const float* W1,
+                       const float* dense_w, const float* dense_w_one, const int64_t* slot_offset, float* y1, float* y2,
+                       float* feat, float* sum_emb, int32_t* status, void* stream, const FoldFwd& fold, bool* rode);
+
 extern "C" int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids,
                                  const float* dense, const float* W, const float* W1,
                                  const float* dense_w, const float* dense_w_one,
                                  const int64_t* slot_offset, float* y1, float* y2, float* feat,
                                  float* sum_emb, int32_t* status, void* stream) {
+  return fm_fwd_impl(desc, ids, dense, W, W1, dense_w, dense_w_one, slot_offset, y1, y2, feat, sum_emb, status, stream,
+                     FoldFwd{}, nullptr);
+}
+
+// *rode = the fold went out with the lookup (the wide-row kernel); false: the caller issues rec_dense_fold_fwd_full
+int rec::deepfm_fm_fwd_fold(const rec_deepfm_desc* desc, const int64_t* ids, const float* dense, const float* W,
+                            const float* W1, const float* dense_w, const float* dense_w_one, const int64_t* slot_offset,
+                            float* y1, float* y2, float* feat, float* sum_emb, int32_t* status, void* stream, FoldFwd fold,
+                            bool* rode) {
+  return fm_fwd_impl(desc, ids, dense, W, W1, dense_w, dense_w_one, slot_offset, y1, y2, feat, sum_emb, status, stream,
+                     fold, rode);
+}
+
+static int fm_fwd_impl(const rec_deepfm_desc* desc, const int64_t* ids, const float* dense, const float* W, const float* W1,
+                       const float* dense_w, const float* dense_w_one, const int64_t* slot_offset, float* y1, float* y2,
+                       float* feat, float* sum_emb, int32_t* status, void* stream, const FoldFwd& fold, bool* rode) {
+  if (rode) *rode = false;
   if (int rc = check_desc(desc)) return rc;
   if (desc->batch == 0) return REC_OK;
   REC_REQUIRE(ids && W && W1 && y1 && y2 && feat && status, REC_EINVAL, "null pointer argument");
@@ -542,10 +558,11 @@ extern "C" int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids
     if (tune().fwd_bpc > 0 && grid > (int64_t)tune().fwd_bpc * kNumCU) grid = (int64_t)tune().fwd_bpc * kNumCU; \
     if (grid > want) grid = want;                                                                 \
     if (grid > kMaxBlocks) grid = kMaxBlocks;                                                     \
-    hipLaunchKernelGGL((fm_fwd_kernel<VEC, LANES, IDCH, NT_>), dim3((unsigned)grid), dim3(kBlock), \
+    hipLaunchKernelGGL((fm_fwd_kernel<VEC, LANES, IDCH, NT_>), dim3((unsigned)(grid + fold.blocks)), dim3(kBlock), \
                        shmem, st, desc->batch, S, Dn, D, FP, feat_ld, desc->row_stride, w1_stride, \
                        desc->num_rows, desc->padding_idx, ids, dense, W, W1, dense_w, dense_w_one, \
-                       slot_offset, y1, y2, feat, sum_emb, status);                                \
+                       slot_offset, y1, y2, feat, sum_emb, status, (int)grid, fold);               \
+    if (rode) *rode = fold.blocks > 0;                                                            \
   }
 #define REC_FWD_LAUNCH(IDCH) if (tune().fwd_nt) REC_FWD_LAUNCH2(IDCH, true) else REC_FWD_LAUNCH2(IDCH, false)
     if (idch <= 1) { REC_FWD_LAUNCH(1); }
@@ -569,7 +586,7 @@ extern "C" int rec_deepfm_fm_bwd_workspace_bytes(const rec_deepfm_desc* desc, si
 static int fm_bwd_impl(const rec_deepfm_desc* desc, const float* dense, const float* feat, const float* sum_emb,
                        const float* d_feat_dnn, const float* dy1, const float* dy2, const float* dense_w,
                        const int32_t* row_rank, float* row_grad, float* d_dense_w, float* d_dense_w_one,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       void* workspace, size_t workspace_bytes, void* stream, int* defer_fold = nullptr);
 
 extern "C" int rec_deepfm_fm_bwd(const rec_deepfm_desc* desc, const float* dense,
                                  const float* feat, const float* sum_emb, const float* d_feat_dnn,
@@ -590,13 +607,22 @@ extern "C" int rec_deepfm_fm_bwd_sorted(const rec_deepfm_desc* desc, const float
                      d_dense_w_one, workspace, workspace_bytes, stream);
 }
 
+int rec::deepfm_fm_bwd_partial(const rec_deepfm_desc* desc, const float* dense, const float* feat, const float* sum_emb,
+                               const float* d_feat_dnn, const float* dy1, const float* dy2, const float* dense_w,
+                               float* row_grad, void* workspace, size_t workspace_bytes, void* stream, int* nblk) {
+  REC_REQUIRE(nblk && desc && desc->batch > 0, REC_EINVAL, "bad arguments");
+  return fm_bwd_impl(desc, dense, feat, sum_emb, d_feat_dnn, dy1, dy2, dense_w, nullptr, row_grad, nullptr, nullptr,
+                     workspace, workspace_bytes, stream, nblk);
+}
+
 static int fm_bwd_impl(const rec_deepfm_desc* desc, const float* dense, const float* feat, const float* sum_emb,
                        const float* d_feat_dnn, const float* dy1, const float* dy2, const float* dense_w,
                        const int32_t* row_rank, float* row_grad, float* d_dense_w, float* d_dense_w_one,
-                       void* workspace, size_t workspace_bytes, void* stream) {
+                       void* workspace, size_t workspace_bytes, void* stream, int* defer_fold) {
+  // defer_fold: the fold launch is left to the caller (tail_roles.h); *defer_fold = blocks that wrote partial columns
   if (int rc = check_desc(desc)) return rc;
   const int S = desc->num_slots, Dn = desc->num_dense, D = desc->emb_dim;
-  REC_REQUIRE(Dn == 0 || (d_dense_w && d_dense_w_one), REC_EINVAL, "dense args missing");
+  REC_REQUIRE(Dn == 0 || defer_fold || (d_dense_w && d_dense_w_one), REC_EINVAL, "dense args missing");
   REC_REQUIRE(desc->batch == 0 || (feat && sum_emb && d_feat_dnn && dy1 && dy2 && row_grad &&
                                    (Dn == 0 || dense)),
               REC_EINVAL, "null pointer argument");
@@ -638,7 +664,8 @@ static int fm_bwd_impl(const rec_deepfm_desc* desc, const float* dense, const fl
     if (v4) { if (tune().nt) REC_BWD_TILE(true, true) else REC_BWD_TILE(true, false) }
     else { REC_BWD_TILE(false, false) }
 #undef REC_BWD_TILE
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(K), dim3(kBlock), 0, st, partial, grid, Dn * D, d_dense_w, d_dense_w_one);
+    if (defer_fold) *defer_fold = grid;
+    else hipLaunchKernelGGL(fold_partials_kernel, dim3(K), dim3(kBlock), 0, st, partial, grid, Dn * D, d_dense_w, d_dense_w_one);
     return check_launch("rec_deepfm_fm_bwd (tile)");
   }
   return dispatch_row_shape(D, D, [&](auto vec, auto lanes) -> int {
@@ -676,7 +703,9 @@ static int fm_bwd_impl(const rec_deepfm_desc* desc, const float* dense, const fl
 #undef REC_BWD_LAUNCH
 #undef REC_BWD_LAUNCH2
 #undef REC_BWD_LAUNCH3
-    if (K > 0) {
+    if (defer_fold) {
+      *defer_fold = grid;
+    } else if (K > 0) {
       hipLaunchKernelGGL(fold_partials_kernel, dim3(K), dim3(kBlock), 0, st, partial, grid, Dn * D,
                          d_dense_w, d_dense_w_one);
     }

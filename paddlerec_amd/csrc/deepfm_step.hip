@@ -8,6 +8,10 @@
 // list; this file is the same list stated in C++ for every other binder.  Nothing here launches a kernel of its own:
 // every line below is a call of an entry point of this library, in the mirror's order with the mirror's arguments,
 // so the two paths are bit-identical by construction (tests/test_deepfm_step_c.py holds them to that).
+// One exception, at the launch-bound sizes only (tail_roles.h): the folds of the head's and the FM backward's partial sums,
+// the folded layer 0's backward and the dense Adam do not go out as launches of their own but as roles of the launch that
+// merges and updates the table rows — the same statements per value, four launches less per step (REC_SMALL_TAIL=0: the
+// mirror's list).
 #include <stdlib.h>
 
 #include <map>
@@ -15,6 +19,7 @@
 #include <tuple>
 
 #include "rec_common.h"
+#include "tail_roles.h"
 
 using namespace rec;
 
@@ -88,6 +93,8 @@ struct Buffers {
   int64_t* uniq_rows;
   void* ws;              // scratch of the individual calls (one at a time: a single region, the largest need)
   size_t ws_bytes;
+  void* ws_head;         // the fused head's partial rows when their fold waits for the tail launch (tail_roles.h)
+  size_t ws_head_bytes;
   void* ws_side;         // the grouping's scratch: it may run on the side stream beside the main stream's calls
   size_t ws_side_bytes;
   // bf16 x 3 images of the Linear weights, forward (W) and dX (W^T) orientation, made by ONE rec_gemm_b_images launch
@@ -198,6 +205,14 @@ int carve(const rec_deepfm_net* net, const Shape& s, int64_t B, void* workspace,
   if (int rc = call_workspace(net, s, B, &cw)) return rc;
   bf->ws = c.bytes(cw);
   bf->ws_bytes = cw;
+  bf->ws_head = nullptr;
+  bf->ws_head_bytes = 0;
+  if (s.small && s.ctr_head) {
+    size_t hb = 0;
+    if (int rc = rec_ctr_head_workspace_bytes(B, net->widths[s.n - 2], &hb)) return rc;
+    bf->ws_head = c.bytes(hb);
+    bf->ws_head_bytes = hb;
+  }
   *total = c.off;
   return REC_OK;
 }
@@ -321,13 +336,21 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   if (s.pad)        // the padding columns of feat (workspace memory) must be zero: they meet zero weight rows, but 0 x NaN
     REC_REQUIRE(hipMemset2DAsync(bf.feat + s.in0_real, (size_t)s.in0 * f4, 0, (size_t)(s.in0 - s.in0_real) * f4,
                                  (size_t)B, (hipStream_t)stream) == hipSuccess, REC_EHIP, "hipMemset2DAsync failed");
-  REC_TRY(rec_deepfm_fm_fwd(&fd, ids, dense, net->rec, net->rec + D, net->dense_w, net->dense_w_one, net->slot_offset,
-                            bf.y1, bf.y2, bf.feat, bf.sum_emb, status, stream));
+  // (launch-bound sizes: layer 0's weight fold rides behind the lookup's blocks — tail_roles.h, FoldFwd)
+  static const bool fold_ride = [] { const char* v = getenv("REC_SMALL_TAIL"); return !(v && *v == '0'); }();
+  bool fold_rode = false;
+  REC_TRY(deepfm_fm_fwd_fold(&fd, ids, dense, net->rec, net->rec + D, net->dense_w, net->dense_w_one, net->slot_offset,
+                             bf.y1, bf.y2, bf.feat, bf.sum_emb, status, stream,
+                             s.compact && s.small && fold_ride
+                                 ? dense_fold_fwd_plan(S, Dn, D, net->widths[0], net->dense_w, net->w[0], net->w0_folded)
+                                 : FoldFwd{},
+                             &fold_rode));
   // -- layer 0 on folded weights (deepfm.py:_mlp_weights): W0' = [ W0[:S*D] ; M ; 0 ]
   const float* w0 = net->w[0];
   float* gw0 = net->gw[0];
   if (s.compact) {  // sparse rows + folded dense rows in one launch; dW_0' lands in scratch (bf.dw0p), not in gw[0]
-    REC_TRY(rec_dense_fold_fwd_full(S, Dn, D, net->widths[0], net->dense_w, net->w[0], net->w0_folded, stream));
+    if (!fold_rode)
+      REC_TRY(rec_dense_fold_fwd_full(S, Dn, D, net->widths[0], net->dense_w, net->w[0], net->w0_folded, stream));
     w0 = net->w0_folded;
     gw0 = bf.dw0p;
   }
@@ -368,8 +391,29 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   const float* g = bf.dz;       // gradient of the current layer's OUTPUT, [B, widths[i]]
   int gi = 0;                   // next free ping-pong buffer
   int n_run = n;
+  // -- launch-bound sizes: the step's folds and its dense Adam as roles of the row update's launch (tail_roles.h).  The
+  //    roles address parameters by their offset in the flat buffer: every parameter a role owns must sit at the same
+  //    offset in flat_param and flat_grad (the mirror's FlatParams does), else the mirror's list of launches is issued
+  const float* P0 = net->flat_param;
+  const float* G0 = net->flat_grad;
+  auto flat_pair = [&](const float* pp, const float* gg, int64_t cnt) {
+    return pp && gg && pp >= P0 && pp + cnt <= P0 + net->flat_numel && pp - P0 == gg - G0;
+  };
+  const bool pad_copy_ = s.pad && net->w0_folded != net->w[0];
+  bool tail = s.small && s.ctr_head && !pad_copy_ && small_tail_eligible(nlook, D, net->slot_offset, S) &&
+              flat_pair(net->w[n - 1], net->gw[n - 1], net->widths[n - 2]) && flat_pair(net->b[n - 1], net->gb[n - 1], 1) &&
+              flat_pair(net->w[0], net->gw[0], (int64_t)s.in0_full * net->widths[0]) &&
+              (Dn == 0 || (flat_pair(net->dense_w, net->g_dense_w, (int64_t)Dn * D) &&
+                           flat_pair(net->dense_w_one, net->g_dense_w_one, Dn)));
+  int head_nblk = 0;
+  float head_inv = 0.f;
   if (s.ctr_head) {
     const int nh = net->widths[n - 2];
+    if (tail)
+      REC_TRY(ctr_head_fwd_bwd_partial(B, nh, 0, bf.act[n - 1], nh, net->w[n - 1], net->b[n - 1], bf.y1, bf.y2, label, 1e-4f,
+                                       0.f, 0.f, 1, nullptr, pred_out, bf.dz, bf.g[gi], nh, bf.ws_head, bf.ws_head_bytes,
+                                       stream, &head_nblk, &head_inv));
+    else
     REC_TRY(rec_ctr_head_fwd_bwd(B, nh, 0, bf.act[n - 1], nh, net->w[n - 1], net->b[n - 1], bf.y1, bf.y2, label, 1e-4f,
                                  0.f, 0.f, 1, nullptr, pred_out, bf.dz, loss_out, bf.g[gi], nh, net->gw[n - 1],
                                  net->gb[n - 1], bf.ws, bf.ws_bytes, stream));
@@ -416,11 +460,53 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   }
   // -- FM backward: row gradients of the S lookups + the dense FM parameters (net.py:104-136 backward)
   rec_deepfm_desc bd{B, S, Dn, D, D, 1, -1, 1, s.compact ? 1 : 0, s.pad ? (int64_t)s.in0 : 0};   // reads no table
+  int fm_nblk = 0;
+  if (tail)
+    REC_TRY(deepfm_fm_bwd_partial(&bd, dense, bf.feat, bf.sum_emb, d_flat, bf.dz, bf.dz, net->dense_w, bf.row_grad, bf.ws,
+                                  bf.ws_bytes, stream, &fm_nblk));
+  else
   REC_TRY(rec_deepfm_fm_bwd(&bd, dense, bf.feat, bf.sum_emb, d_flat, bf.dz, bf.dz, net->dense_w, bf.row_grad,
                             net->g_dense_w, net->g_dense_w_one, bf.ws, bf.ws_bytes, stream));
   // -- merged lazy Adam on W / W1 of the touched rows (optimizer.step on the SelectedRows gradients): on the side stream
   //    when there is one, underneath dW_0
   rec_grad_layout gl{1, 0, 0, nullptr, nullptr, 0}, gl1{S, 0, 0, nullptr, nullptr, 0};
+  if (tail) {     // ... and, behind its row-bucket blocks, both folds, the folded layer 0's backward and the dense Adam
+    TailRoles t{};
+    const int nh = net->widths[n - 2], NO = net->widths[0];
+    t.head_blocks = (nh + 2 + 15) / 16;
+    t.head_nblk = head_nblk; t.head_n2 = nh + 2; t.head_partial = (const float*)bf.ws_head; t.head_invB = head_inv;
+    t.head_dw = net->gw[n - 1]; t.head_db = net->gb[n - 1]; t.loss = loss_out;
+    t.head_w_off = net->w[n - 1] - P0; t.head_b_off = net->b[n - 1] - P0;
+    t.n_skip = 0;
+    auto skip = [&](int64_t lo, int64_t cnt) { t.skip_lo[t.n_skip] = lo; t.skip_hi[t.n_skip] = lo + cnt; ++t.n_skip; };
+    skip(t.head_w_off, nh);
+    skip(t.head_b_off, 1);
+    t.fm_blocks = Dn * D + Dn;
+    t.fm_nblk = fm_nblk; t.fm_split = Dn * D; t.fm_partial = (const float*)bf.ws;
+    t.ddw = net->g_dense_w; t.ddw1 = net->g_dense_w_one;
+    if (Dn > 0) {
+      t.dw_off = net->dense_w - P0; t.dw1_off = net->dense_w_one - P0;
+      skip(t.dw_off, (int64_t)Dn * D);
+      skip(t.dw1_off, Dn);
+    }
+    t.w0_off = net->w[0] - P0;
+    t.f = FoldedLayer0{S, Dn, D, NO, nullptr, nullptr, nullptr, nullptr};
+    t.w0_blocks = 0;
+    if (s.compact) {
+      t.f.dW0f = gw0; t.f.dW0 = net->gw[0]; t.f.W0 = net->w[0]; t.f.dense_w = net->dense_w;
+      skip(t.w0_off, (int64_t)s.in0_full * NO);
+      const int64_t we = (int64_t)S * D * NO;
+      t.w0_blocks = (int)((we + 4 * 1024 - 1) / (4 * 1024));
+    }
+    t.flat_numel = net->flat_numel; t.flat_grad = net->flat_grad;
+    t.adam.p = net->flat_param; t.adam.m = net->flat_m; t.adam.v = net->flat_v;
+    t.rest_blocks = (int)((net->flat_numel + 4 * 1024 - 1) / (4 * 1024));
+    if (t.rest_blocks > 256) t.rest_blocks = 256;
+    REC_TRY(sparse_adam_record_small_tail(nlook, S, D, net->rec_stride, net->mv_stride, net->v_offset, net->table_rows,
+                                          net->padding_idx, ids, net->slot_offset, bf.row_grad, &gl, bf.dz, &gl1, net->rec,
+                                          net->mv, hyper, status, t, stream));
+    return REC_OK;
+  }
   if (s.small) {
     REC_TRY(rec_sparse_adam_record_small(nlook, S, D, net->rec_stride, net->mv_stride, net->v_offset, net->table_rows,
                                          net->padding_idx, ids, net->slot_offset, bf.row_grad, &gl, bf.dz, &gl1,

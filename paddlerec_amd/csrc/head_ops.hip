@@ -12,6 +12,7 @@
 #include <string>
 
 #include "rec_common.h"
+#include "tail_roles.h"
 
 namespace rec {
 
@@ -220,28 +221,7 @@ __global__ __launch_bounds__(kBlock) void ctr_head_kernel(
 __global__ __launch_bounds__(kBlock) void ctr_head_fold_kernel(int nblk, int n2, const float* __restrict__ partial,
                                                                float invB, float* __restrict__ dw,
                                                                float* __restrict__ db, float* __restrict__ loss) {
-  __shared__ float red[16][17];
-  const int c = threadIdx.x & 15, q = threadIdx.x >> 4;
-  const int j = blockIdx.x * 16 + c;
-  float a[4] = {0.f, 0.f, 0.f, 0.f};
-  if (j < n2) {
-    int r = q;
-    for (; r + 48 < nblk; r += 64) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] += partial[(int64_t)(r + 16 * u) * n2 + j];
-    }
-    for (int u = 0; r < nblk; r += 16, ++u) a[u] += partial[(int64_t)r * n2 + j];
-  }
-  red[q][c] = (a[0] + a[1]) + (a[2] + a[3]);
-  __syncthreads();
-  if (q == 0 && j < n2) {
-    float t = red[0][c];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) t += red[k][c];
-    if (j < n2 - 2) dw[j] = t;
-    else if (j == n2 - 2) db[0] = t;
-    else loss[0] = t * invB;
-  }
+  ctr_head_fold_role<false>(blockIdx.x, threadIdx.x, nblk, n2, partial, invB, dw, db, loss, DenseAdam{}, 0, 0);   // tail_roles.h
 }
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
@@ -308,14 +288,15 @@ extern "C" int rec_ctr_head_workspace_bytes(int64_t batch, int32_t n, size_t* by
   return REC_OK;
 }
 
-extern "C" int rec_ctr_head_fwd_bwd(int64_t batch, int32_t n, int64_t mean_over, const float* act, int64_t ld_act,
-                                    const float* w, const float* bias, const float* y1, const float* y2,
-                                    const int64_t* label, float eps, float clip_lo, float clip_hi, int32_t relu,
-                                    float* y_dnn, float* pred, float* dz, float* loss_out, float* dx, int64_t ld_dx,
-                                    float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+static int ctr_head_impl(int64_t batch, int32_t n, int64_t mean_over, const float* act, int64_t ld_act, const float* w,
+                         const float* bias, const float* y1, const float* y2, const int64_t* label, float eps,
+                         float clip_lo, float clip_hi, int32_t relu, float* y_dnn, float* pred, float* dz,
+                         float* loss_out, float* dx, int64_t ld_dx, float* dw, float* db, void* workspace,
+                         size_t workspace_bytes, void* stream, bool fold, int* nblk, float* invB) {
   REC_REQUIRE(batch > 0 && mean_over >= 0, REC_EINVAL, "bad batch");
   REC_REQUIRE(n > 0 && n % 4 == 0 && n <= 512, REC_ESHAPE, "rec_ctr_head_fwd_bwd: n must be a multiple of 4 and <= 512");
-  REC_REQUIRE(act && w && label && pred && dz && loss_out && dx && dw && db, REC_EINVAL, "null pointer argument");
+  REC_REQUIRE(act && w && label && pred && dz && dx && (!fold || (loss_out && dw && db)), REC_EINVAL,
+              "null pointer argument");
   REC_REQUIRE(!y2 || y1, REC_EINVAL, "y2 without y1");
   REC_REQUIRE(ld_act >= n && ld_dx >= n && ld_act % 4 == 0 && ld_dx % 4 == 0 && ((uintptr_t)act) % 16 == 0 &&
                   ((uintptr_t)dx) % 16 == 0 && ((uintptr_t)w) % 16 == 0, REC_ESHAPE,
@@ -329,9 +310,31 @@ extern "C" int rec_ctr_head_fwd_bwd(int64_t batch, int32_t n, int64_t mean_over,
   const size_t shmem = (size_t)(kBlock / kWave) * (n + 2) * sizeof(float);
   hipLaunchKernelGGL(ctr_head_kernel, dim3((unsigned)grid), dim3(kBlock), shmem, st, batch, n, inv, act, ld_act, w, bias, y1,
                      y2, label, eps, clip_lo, clip_hi, relu, y_dnn, pred, dz, dx, ld_dx, (float*)workspace);
-  hipLaunchKernelGGL(ctr_head_fold_kernel, dim3((unsigned)((n + 2 + 15) / 16)), dim3(kBlock), 0, st, (int)grid,
-                     n + 2, (const float*)workspace, inv, dw, db, loss_out);
+  if (fold)
+    hipLaunchKernelGGL(ctr_head_fold_kernel, dim3((unsigned)((n + 2 + 15) / 16)), dim3(kBlock), 0, st, (int)grid,
+                       n + 2, (const float*)workspace, inv, dw, db, loss_out);
+  if (nblk) *nblk = (int)grid;
+  if (invB) *invB = inv;
   return check_launch("rec_ctr_head_fwd_bwd");
+}
+
+extern "C" int rec_ctr_head_fwd_bwd(int64_t batch, int32_t n, int64_t mean_over, const float* act, int64_t ld_act,
+                                    const float* w, const float* bias, const float* y1, const float* y2,
+                                    const int64_t* label, float eps, float clip_lo, float clip_hi, int32_t relu,
+                                    float* y_dnn, float* pred, float* dz, float* loss_out, float* dx, int64_t ld_dx,
+                                    float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+  return ctr_head_impl(batch, n, mean_over, act, ld_act, w, bias, y1, y2, label, eps, clip_lo, clip_hi, relu, y_dnn, pred,
+                       dz, loss_out, dx, ld_dx, dw, db, workspace, workspace_bytes, stream, true, nullptr, nullptr);
+}
+
+// the head without its fold launch (tail_roles.h: the fold rides in the step's tail launch)
+int rec::ctr_head_fwd_bwd_partial(int64_t batch, int32_t n, int64_t mean_over, const float* act, int64_t ld_act,
+                                  const float* w, const float* bias, const float* y1, const float* y2,
+                                  const int64_t* label, float eps, float clip_lo, float clip_hi, int32_t relu,
+                                  float* y_dnn, float* pred, float* dz, float* dx, int64_t ld_dx, void* workspace,
+                                  size_t workspace_bytes, void* stream, int* nblk, float* invB) {
+  return ctr_head_impl(batch, n, mean_over, act, ld_act, w, bias, y1, y2, label, eps, clip_lo, clip_hi, relu, y_dnn, pred,
+                       dz, nullptr, dx, ld_dx, nullptr, nullptr, workspace, workspace_bytes, stream, false, nblk, invB);
 }
 
 extern "C" int rec_bce_with_logits(int64_t batch, int64_t mean_over, const float* logit,

@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "rec_common.h"
+#include "tail_roles.h"
 
 namespace rec {
 
@@ -1116,9 +1117,10 @@ __device__ __forceinline__ unsigned bucket_of(int row, unsigned P) {
 }
 
 template <int NACC, class Update>
-__global__ __launch_bounds__(kBucketWaves* kWave) void sparse_bucket_kernel(
-    int n, int D, int S, int64_t N, int64_t pad, const int64_t* __restrict__ ids, const int64_t* __restrict__ slot_off,
-    const float* __restrict__ grad, rec_grad_layout gl, Update up, int32_t* __restrict__ status) {
+__device__ __forceinline__ void sparse_bucket_body(
+    const unsigned me, const unsigned P, int n, int D, int S, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
+    const int64_t* __restrict__ slot_off, const float* __restrict__ grad, rec_grad_layout gl, Update up,
+    int32_t* __restrict__ status) {
   constexpr bool kRecord = std::is_same<Update, SmallAdamRecord>::value;
   constexpr int FLY = kSmallList / NACC;
   __shared__ int b_rows[kBucketCap];
@@ -1129,7 +1131,6 @@ __global__ __launch_bounds__(kBucketWaves* kWave) void sparse_bucket_kernel(
   __shared__ int b_own[kQuadCap];      // step 2Q: the entries that are their row's first occurrence (any order)
   __shared__ int b_nown;
   const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
-  const unsigned P = gridDim.x, me = blockIdx.x;
   if (threadIdx.x == 0) b_nown = 0;
   auto row_of = [&](int p) -> int {                  // table row of position p, -1 = padding / out of range
     const int64_t id = ids[p];
@@ -1413,6 +1414,62 @@ __global__ __launch_bounds__(kBucketWaves* kWave) void sparse_bucket_kernel(
   }
 }
 
+template <int NACC, class Update>
+__global__ __launch_bounds__(kBucketWaves* kWave) void sparse_bucket_kernel(
+    int n, int D, int S, int64_t N, int64_t pad, const int64_t* __restrict__ ids, const int64_t* __restrict__ slot_off,
+    const float* __restrict__ grad, rec_grad_layout gl, Update up, int32_t* __restrict__ status) {
+  sparse_bucket_body<NACC, Update>(blockIdx.x, gridDim.x, n, D, S, N, pad, ids, slot_off, grad, gl, up, status);
+}
+
+// ------------------------------------------------------------------ the whole tail of a launch-bound step in ONE launch
+// Blocks [0, buckets): the row-bucket merge + update above.  Behind them the roles of tail_roles.h: the fused head's
+// partial rows folded (+ Adam on the last Linear), the FM backward's partial rows folded (+ the folded layer 0's share,
+// Adam on dense_w / dense_w_one and on the dense rows of W_0), and two elementwise roles — the sparse rows of a folded W_0
+// (gradient: dW_0' as it is) and every other dense parameter (gradient: the flat gradient buffer, the ranges owned by the
+// roles above skipped).  Four launches of the step (ctr_head_fold, fold_partials, dense_fold_bwd_full, adam_dense) ride
+// in the fifth: 16 -> 12 launches at the reference's batch size.
+__global__ __launch_bounds__(kBucketWaves* kWave) void small_tail_kernel(
+    unsigned buckets, int n, int D, int S, int64_t N, int64_t pad, const int64_t* __restrict__ ids,
+    const int64_t* __restrict__ slot_off, const float* __restrict__ grad, rec_grad_layout gl, SmallAdamRecord up,
+    int32_t* __restrict__ status, TailRoles t) {
+  constexpr int NT = kBucketWaves * kWave;
+  int b = (int)blockIdx.x;
+  if ((unsigned)b < buckets) {
+    sparse_bucket_body<1, SmallAdamRecord>((unsigned)b, buckets, n, D, S, N, pad, ids, slot_off, grad, gl, up, status);
+    return;
+  }
+  b -= (int)buckets;
+  const int tid = (int)threadIdx.x;
+  if (b < t.head_blocks) {
+    ctr_head_fold_role<true>(b, tid, t.head_nblk, t.head_n2, t.head_partial, t.head_invB, t.head_dw, t.head_db, t.loss,
+                             t.adam, t.head_w_off, t.head_b_off);
+    return;
+  }
+  b -= t.head_blocks;
+  if (b < t.fm_blocks) {
+    fm_fold_role<true>(b, tid, NT, t.fm_partial, t.fm_nblk, t.fm_split, t.ddw, t.ddw1, t.f, t.adam, t.dw_off, t.dw1_off,
+                       t.w0_off);
+    return;
+  }
+  b -= t.fm_blocks;
+  if (b < t.w0_blocks) {                      // the sparse rows of a folded W_0: dW_0[e] = dW_0'[e], Adam
+    const int64_t total = (int64_t)t.f.S * t.f.D * t.f.NO;
+    for (int64_t e = (int64_t)b * NT + tid; e < total; e += (int64_t)t.w0_blocks * NT) {
+      const float g = t.f.dW0f[e];
+      t.f.dW0[e] = g;
+      adam_dense_at(t.adam, t.w0_off + e, g);
+    }
+    return;
+  }
+  b -= t.w0_blocks;
+  for (int64_t e = (int64_t)b * NT + tid; e < t.flat_numel; e += (int64_t)t.rest_blocks * NT) {
+    bool owned = false;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) owned = owned || (r < t.n_skip && e >= t.skip_lo[r] && e < t.skip_hi[r]);
+    if (!owned) adam_dense_at(t.adam, e, t.flat_grad[e]);
+  }
+}
+
 // LDS bytes of a one-launch merge over n lookups; *fp_mode = 1 when the fingerprint array fits beside the id list in the
 // default 64 KB (plain tables only: the slot-local mode compares n / S lookups, a chunk or two)
 static size_t small_lds_bytes(size_t n, bool plain, int* fp_mode) {
@@ -1555,11 +1612,11 @@ __global__ void adam_dense_kernel(int64_t n, float* __restrict__ p, float* __res
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * sc;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_dense_elem(pi, mi, vi, gi, lr_t, eps_t, b1, b2);
     m[i] = mi;
     v[i] = vi;
-    p[i] = p[i] - lr_t * (mi / (sqrtf(vi) + eps_t));
+    p[i] = pi;
   }
 }
 
@@ -2091,6 +2148,51 @@ extern "C" int rec_sparse_sgd_small_multi(int32_t count, const rec_small_sgd_job
   return check_launch("rec_sparse_sgd_small_multi");
 }
 
+// REC_SMALL_BUCKET=0: the wave-per-lookup merge for every shape, =2 (lab): row buckets for slot tables of wide rows too;
+// REC_SMALL_BUCKET_ROWS: lookups per bucket (64: 13 312 lookups = 208 blocks, one round on 256 CUs)
+static bool bucket_path(int64_t n, int32_t emb_dim, const int64_t* slot_offset, int32_t num_slots) {
+  static const int bucket_on = [] { const char* v = getenv("REC_SMALL_BUCKET"); return v ? atoi(v) : 1; }();
+  return bucket_on && n > kBucketMin && (!slot_offset || num_slots <= 1 || emb_dim <= kQuadLanes || bucket_on == 2);
+}
+static unsigned bucket_count(int64_t n) {
+  static const int per_bucket = [] { const char* v = getenv("REC_SMALL_BUCKET_ROWS"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 64; }();
+  return (unsigned)((n + per_bucket - 1) / per_bucket);
+}
+
+bool rec::small_tail_eligible(int64_t n, int32_t emb_dim, const int64_t* slot_offset, int32_t num_slots) {
+  static const bool on = [] { const char* v = getenv("REC_SMALL_TAIL"); return !(v && *v == '0'); }();
+  return on && n <= kSmallMergeMax && emb_dim <= kWave && bucket_path(n, emb_dim, slot_offset, num_slots);
+}
+
+int rec::sparse_adam_record_small_tail(int64_t n, int32_t num_slots, int32_t emb_dim, int32_t rec_stride,
+                                       int32_t state_stride, int32_t v_offset, int64_t num_rows, int64_t padding_idx,
+                                       const int64_t* ids, const int64_t* slot_offset, const float* grad,
+                                       const rec_grad_layout* grad_layout, const float* grad1,
+                                       const rec_grad_layout* grad1_layout, float* rec, float* MV,
+                                       const rec_adam_hyper* hyper, int32_t* status, TailRoles roles, void* stream) {
+  rec_grad_layout gl = {1, 0, 0, nullptr, nullptr}, gl1 = {1, 0, 0, nullptr, nullptr};
+  if (grad_layout) gl = *grad_layout;
+  if (grad1_layout) gl1 = *grad1_layout;
+  gl.partials = gl1.partials = nullptr;
+  REC_REQUIRE(small_tail_eligible(n, emb_dim, slot_offset, num_slots), REC_ESHAPE, "not a row-bucket shape");
+  REC_REQUIRE(n > 0 && num_slots > 0 && emb_dim > 0 && rec_stride >= emb_dim + 3 && num_rows > 0 &&
+                  num_rows < (1ll << 31) && gl.div >= 1 && gl1.div >= 1 && v_offset >= emb_dim &&
+                  state_stride >= v_offset + emb_dim, REC_EINVAL, "bad sizes");
+  REC_REQUIRE(ids && grad && grad1 && rec && MV && hyper && status && hyper->step >= 1, REC_EINVAL, "bad arguments");
+  SmallAdamRecord up;
+  up.rec = rec; up.MV = MV; up.stride = rec_stride; up.sstride = state_stride; up.v_off = v_offset;
+  up.grad1 = grad1; up.gl1 = gl1; up.grad_scale = nullptr;
+  adam_scalars(hyper, &up.lr_t, &up.eps_t);
+  up.b1 = hyper->beta1; up.b2 = hyper->beta2;
+  if (gl.group <= 0) { gl.group = 1; gl.group_stride = emb_dim; }
+  roles.adam.lr_t = up.lr_t; roles.adam.eps_t = up.eps_t; roles.adam.b1 = up.b1; roles.adam.b2 = up.b2;
+  const unsigned buckets = bucket_count(n);
+  const unsigned grid = buckets + (unsigned)(roles.head_blocks + roles.fm_blocks + roles.w0_blocks + roles.rest_blocks);
+  hipLaunchKernelGGL(small_tail_kernel, dim3(grid), dim3(kBucketWaves * kWave), 0, (hipStream_t)stream, buckets, (int)n,
+                     emb_dim, num_slots, num_rows, padding_idx, ids, slot_offset, grad, gl, up, status, roles);
+  return check_launch("small_tail_kernel");
+}
+
 extern "C" int rec_sparse_adam_record_small(int64_t n, int32_t num_slots, int32_t emb_dim, int32_t rec_stride,
                                             int32_t state_stride, int32_t v_offset, int64_t num_rows,
                                             int64_t padding_idx, const int64_t* ids, const int64_t* slot_offset,
@@ -2120,14 +2222,12 @@ extern "C" int rec_sparse_adam_record_small(int64_t n, int32_t num_slots, int32_
   adam_scalars(hyper, &up.lr_t, &up.eps_t);
   up.b1 = hyper->beta1; up.b2 = hyper->beta2;
   if (gl.group <= 0) { gl.group = 1; gl.group_stride = emb_dim; }   // one D-wide row per position
-  static const int bucket_on = [] { const char* v = getenv("REC_SMALL_BUCKET"); return v ? atoi(v) : 1; }();   // 2 (lab): slot tables too
   // by row buckets (sparse_bucket_kernel): ONE table whose lookups all meet each other, and slot tables of narrow rows
   // (the 16-lane form of the kernel's step 2: 26 x 512 lookups 0.115 -> 0.109 ms per step, and no span check — a row's
   // occurrences meet in its bucket whatever slot they come from).  Slot tables of wider rows keep the slot-major merge
   // below: a lookup is compared with its slot's n / S lookups only.
-  if (bucket_on && n > kBucketMin && (!slot_offset || num_slots <= 1 || emb_dim <= kQuadLanes || bucket_on == 2)) {
-    static const int per_bucket = [] { const char* v = getenv("REC_SMALL_BUCKET_ROWS"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 64; }();
-    const unsigned buckets = (unsigned)((n + per_bucket - 1) / per_bucket);
+  if (bucket_path(n, emb_dim, slot_offset, num_slots)) {
+    const unsigned buckets = bucket_count(n);
 #define REC_BUCKET(NACC_)                                                                                             \
   hipLaunchKernelGGL((sparse_bucket_kernel<NACC_, SmallAdamRecord>), dim3(buckets), dim3(kBucketWaves * kWave), 0,      \
                      (hipStream_t)stream, (int)n, emb_dim, num_slots, num_rows, padding_idx, ids, slot_offset, grad, gl, \

@@ -412,6 +412,12 @@ class DeepFMLayer:
                 and sparse_inputs.numel() <= int(os.environ.get("REC_STEP_PLAN_MAX", "65536"))
                 and os.environ.get("REC_STEP_PLAN", "1") != "0")
 
+    def _c_step_small(self, ids):
+        from . import _lib
+        return (ids.dim() == 2 and ids.numel() <= getattr(self.k, "SMALL_MERGE_MAX", 0)
+                and self.n_linear <= _lib.DeepFMNet.MAX_LINEAR and hasattr(self.k, "deepfm_train_step")
+                and os.environ.get("REC_SMALL_MERGE", "1") != "0" and os.environ.get("REC_SMALL_C_STEP", "1") != "0")
+
     def _train_step_planned(self, ids, dense_inputs, label, lr, auc_stats):
         from .plan import CallPlan
         inputs = [ids, dense_inputs, label]
@@ -491,6 +497,11 @@ class DeepFMLayer:
         """dygraph_model.py:76-88 train_forward + tools/trainer.py:151-152 backward/step.
         label [B,1] int64.  Returns (loss [1] device tensor, pred [B,1])."""
         if self._plan_eligible(sparse_inputs, dense_inputs, label, auc_stats, allreduce):
+            if self._c_step_small(sparse_inputs):
+                # launch-bound sizes: the step through rec_deepfm_train_step, where the folds and the dense Adam ride
+                # in the row update's launch and layer 0's weight fold in the lookup's (csrc/tail_roles.h: 16 -> 10
+                # launches; bit-identical to the list below, tests/test_deepfm_step_c.py; REC_SMALL_C_STEP=0: the list)
+                return self.train_step_c(sparse_inputs, dense_inputs, label, lr=lr, auc_stats=auc_stats)
             self.sync()
             out = self._train_step_planned(sparse_inputs, dense_inputs, label, lr, auc_stats)
             if out is not None:

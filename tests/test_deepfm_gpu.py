@@ -784,8 +784,11 @@ def test_planned_step_equals_eager_step(engine_lib, monkeypatch, B):
     from paddlerec_amd.deepfm import DeepFMLayer
     N, D = 5000, 16
     runs = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("REC_STEP_PLAN", mode)
+    for mode in ("1", "0", "default"):
+        # "1": the recorded call list; "0": eager; "default": launch-bound sizes go through rec_deepfm_train_step (the
+        # one-launch tail of csrc/tail_roles.h), the others through the call list — all three leave the same bits
+        monkeypatch.setenv("REC_STEP_PLAN", "0" if mode == "0" else "1")
+        monkeypatch.setenv("REC_SMALL_C_STEP", "1" if mode == "default" else "0")
         torch.manual_seed(3)
         m = DeepFMLayer(N, D, 13, 26, [64, 32], device=DEV)
         auc = (torch.zeros(4096, dtype=torch.int64, device=DEV), torch.zeros(4096, dtype=torch.int64, device=DEV))
@@ -806,12 +809,14 @@ def test_planned_step_equals_eager_step(engine_lib, monkeypatch, B):
         runs[mode] = (outs, m.fm.rec.cpu().numpy(), m.sparse_state["mv"].cpu().numpy(), m.dense.data.cpu().numpy(),
                       m.dense.m.cpu().numpy(), m.dense.v.cpu().numpy(), auc[0].cpu().numpy(), auc[1].cpu().numpy(),
                       m.step_count, len(m._plans))
-    a, b = runs["1"], runs["0"]
-    assert a[-1] == 1 and b[-1] == 0 and a[-2] == b[-2] == 6          # the planned run really recorded a plan
-    for (la, pa), (lb, pb) in zip(a[0], b[0]):
-        assert np.array_equal(la, lb) and np.array_equal(pa, pb)
-    for x, y in zip(a[1:8], b[1:8]):
-        assert np.array_equal(x, y)
+    a, b, c = runs["1"], runs["0"], runs["default"]
+    assert a[-1] == 1 and b[-1] == 0 and a[-2] == b[-2] == c[-2] == 6     # the planned run really recorded a plan
+    assert c[-1] == (0 if B * 26 <= 15360 else 1)                         # ... and the small batch went through the C step
+    for other in (b, c):
+        for (la, pa), (lb, pb) in zip(a[0], other[0]):
+            assert np.array_equal(la, lb) and np.array_equal(pa, pb)
+        for x, y in zip(a[1:8], other[1:8]):
+            assert np.array_equal(x, y)
 
 
 @pytest.mark.gpu
@@ -898,8 +903,11 @@ def test_planned_step_on_the_padded_layout_equals_its_eager_step(engine_lib, mon
     from paddlerec_amd.deepfm import DeepFMLayer
     N, D, B = 5000, 10, 512
     runs = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("REC_STEP_PLAN", mode)
+    for mode in ("1", "0", "default"):
+        # "1": the recorded call list; "0": eager; "default": launch-bound sizes go through rec_deepfm_train_step (the
+        # one-launch tail of csrc/tail_roles.h), the others through the call list — all three leave the same bits
+        monkeypatch.setenv("REC_STEP_PLAN", "0" if mode == "0" else "1")
+        monkeypatch.setenv("REC_SMALL_C_STEP", "1" if mode == "default" else "0")
         torch.manual_seed(3)
         m = DeepFMLayer(N, D, 13, 26, [64, 32], device=DEV)
         assert m.padded and m.ld0 == 400

@@ -43,6 +43,8 @@ def _run(monkeypatch, which, B, N, D, Dn, fc, slot_rows=0, steps=4, overlap=Fals
     (8192, 0, 16, 13, [80, 48], 3000, False),           # slot-local grouping (rec_ids_group_slots fast path)
     (640, 4000, 9, 13, [48], 0, False),                 # dense_dim > dim: no folding, D not a multiple of 4
     (48, 3000, 16, 13, [32, 16], 0, False),             # a handful of samples
+    (512, 4000, 9, 13, [48], 0, False),                 # the tail launch (tail_roles.h) without a folded layer 0 (D 9)
+    (512, 0, 16, 13, [64, 32], 3000, False),            # ... on 26 slot tables
     (8192, 0, 16, 13, [80, 48], 3000, True),     # the large-batch schedule: side stream, slot-local grouping
     (16384, 200000, 16, 13, [80, 80], 0, True),  # ... general grouping, dW_0 on the 16-way K split beside the update
     (512, 100000, 16, 13, [400, 400, 400], 0, True),   # a side stream offered to a one-launch-merge step: unused
