@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include "rec_common.h"
+#include "tail_roles.h"
 
 using namespace rec;
 
@@ -250,11 +251,22 @@ extern "C" int rec_din_train_step(const rec_din_net* net, int64_t batch, int32_t
                                         bf.attw, bf.act1, status, bf.ws_att, bf.ws_att_bytes, stream));   // net.py:141-173
   REC_TRY(gemm(B, E, E, E, E, E2, false, false, REC_EPI_BIAS, bf.pooled, net->w_con, bf.emb, net->b_con, nullptr, 0,
                nullptr, 0, nullptr, bf, stream));                                                        // net.py:175-176
+  // launch-bound sizes (din/config.yaml:20, bs 32): the three gathers as ONE launch, the dense SGD in the merges' launch
+  // (tail_roles.h; REC_SMALL_TAIL=0: the mirror's list of launches) — same values, three launches less
+  static const bool ride = [] { const char* v = getenv("REC_SMALL_TAIL"); return !(v && *v == '0'); }();
+  if (s.small && ride) {
+    const GatherJob gj[3] = {
+        {B, Ei, Ei, net->item_rows, -1, target_item, net->w_tgt_item, bf.emb + E, 1, E2},             // net.py:143,152
+        {B, s.Ec, s.Ec, net->cat_rows, -1, target_cat, net->w_tgt_cat, bf.emb + E + Ei, 1, E2},
+        {B, 1, 1, net->item_rows, -1, target_item, net->w_item_b, bf.item_b, 0, 0}};
+    REC_TRY(emb_gather_multi(3, gj, status, stream));
+  } else {
   REC_TRY(rec_emb_gather(B, Ei, Ei, net->item_rows, -1, target_item, net->w_tgt_item, bf.emb + E, 1, E2, status,
                          stream));                                                                        // net.py:143,152
   REC_TRY(rec_emb_gather(B, s.Ec, s.Ec, net->cat_rows, -1, target_cat, net->w_tgt_cat, bf.emb + E + Ei, 1, E2, status,
                          stream));
   REC_TRY(rec_emb_gather(B, 1, 1, net->item_rows, -1, target_item, net->w_item_b, bf.item_b, 0, 0, status, stream));
+  }
   REC_TRY(gemm(B, M1, E2, E2, M1, M1, false, false, REC_EPI_BIAS_SIGMOID, bf.emb, net->w_l0, bf.x1, net->b_l0, nullptr, 0,
                nullptr, 0, nullptr, bf, stream));
   REC_TRY(gemm(B, M2, M1, M1, M2, M2, false, false, REC_EPI_BIAS_SIGMOID, bf.x1, net->w_l1, bf.x2, net->b_l1, nullptr, 0,
@@ -288,6 +300,10 @@ extern "C" int rec_din_train_step(const rec_din_net* net, int64_t batch, int32_t
       sj[i].num_rows = jobs[i].rows; sj[i].padding_idx = -1; sj[i].ids = jobs[i].ids; sj[i].grad = jobs[i].grad;
       sj[i].grad_layout = rec_grad_layout{1, 1, jobs[i].stride, nullptr, nullptr, 0};
       sj[i].P = jobs[i].P;
+    }
+    if (ride) {
+      REC_TRY(sparse_sgd_small_multi_dense(7, sj, lr, status, stream, net->flat_numel, net->flat_param, net->flat_grad));
+      return REC_OK;        // (small: one stream, nothing to join)
     }
     REC_TRY(rec_sparse_sgd_small_multi(7, sj, lr, status, stream));
   } else {

@@ -10,6 +10,7 @@
 // sample's LoD segment CH ids at a time so CH row gathers are in flight per group; the pooled
 // count of non-padding ids is an integer output (bit-exact target).
 #include "rec_common.h"
+#include "tail_roles.h"
 
 namespace rec {
 
@@ -32,6 +33,36 @@ __global__ __launch_bounds__(kBlock) void emb_gather_kernel(
   }
   const int64_t o = group > 0 ? (i / group) * group_stride + (i % group) * D : i * D;
   vstore<VEC>(out + o + d0, e);
+}
+
+// Several gathers in ONE launch (tail_roles.h, GatherJob): a launch-bound step pays per launch, not per byte — DIN at batch 32
+// looks up 32 target items, 32 target categories and 32 item biases as three launches of one block each.  One float per
+// thread; the values, the padding rule and the out-of-range flag are emb_gather_kernel's.
+constexpr int kGatherJobsMax = 4;
+struct GatherJobs {
+  int count;
+  int block0[kGatherJobsMax + 1];
+  GatherJob j[kGatherJobsMax];
+};
+__global__ __launch_bounds__(kBlock) void emb_gather_multi_kernel(GatherJobs js, int32_t* __restrict__ status) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < kGatherJobsMax; ++i)
+    if (i < js.count && (int)blockIdx.x >= js.block0[i]) k = i;
+  const GatherJob& g = js.j[k];
+  const int D = g.emb_dim;
+  const int64_t e = (int64_t)((int)blockIdx.x - js.block0[k]) * kBlock + threadIdx.x;
+  const int64_t i = e / D;
+  const int d = (int)(e % D);
+  if (i >= g.n) return;
+  const int64_t id = g.ids[i];
+  float v = 0.f;
+  if (id != g.padding_idx || g.padding_idx < 0) {
+    if (id >= 0 && id < g.num_rows) v = g.W[id * g.row_stride + d];
+    else if (d == 0) atomicOr(status, REC_FLAG_INDEX_OOB);
+  }
+  const int64_t o = g.out_group > 0 ? (i / g.out_group) * g.out_group_stride + (i % g.out_group) * D : i * D;
+  g.out[o + d] = v;
 }
 
 // Owner-side lookup of a row-sharded DeepFM table: BOTH embeddings of a row from its ONE record line
@@ -216,4 +247,23 @@ extern "C" int rec_record_gather(int64_t n, int32_t emb_dim, int32_t rec_stride,
                        status);
     return check_launch("rec_record_gather");
   });
+}
+
+int rec::emb_gather_multi(int32_t count, const GatherJob* jobs, int32_t* status, void* stream) {
+  REC_REQUIRE(count >= 0 && count <= kGatherJobsMax && (count == 0 || jobs) && status, REC_EINVAL, "bad arguments");
+  GatherJobs js;
+  js.count = 0;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const GatherJob& a = jobs[i];
+    REC_REQUIRE(a.n >= 0 && a.emb_dim > 0 && a.row_stride >= a.emb_dim && a.num_rows > 0, REC_EINVAL, "job %d: bad sizes", i);
+    if (a.n == 0) continue;
+    REC_REQUIRE(a.ids && a.W && a.out, REC_EINVAL, "job %d: null pointer argument", i);
+    js.block0[js.count] = blocks;
+    js.j[js.count++] = a;
+    blocks += (int)((a.n * a.emb_dim + kBlock - 1) / kBlock);
+  }
+  if (js.count == 0) return REC_OK;
+  hipLaunchKernelGGL(emb_gather_multi_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, js, status);
+  return check_launch("emb_gather_multi");
 }

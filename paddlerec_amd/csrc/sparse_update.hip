@@ -1526,9 +1526,21 @@ struct SmallJob {
 struct SmallJobs {
   int count, fp_mode;
   SmallJob j[kSmallJobsMax];
+  int merge_blocks;          // blocks of the merges; the blocks behind them: the dense parameters' SGD (tail_roles.h)
+  int dense_blocks;
+  int64_t dense_n;
+  float* dense_p;
+  const float* dense_g;
+  float dense_lr;
 };
 template <int NACC>
 __global__ __launch_bounds__(kSmallWaves* kWave) void sparse_small_multi_kernel(SmallJobs jobs, int32_t* __restrict__ status) {
+  if ((int)blockIdx.x >= jobs.merge_blocks) {            // rec_sgd_dense's statement, in this launch
+    const int64_t nt = (int64_t)jobs.dense_blocks * blockDim.x;
+    for (int64_t i = (int64_t)((int)blockIdx.x - jobs.merge_blocks) * blockDim.x + threadIdx.x; i < jobs.dense_n; i += nt)
+      jobs.dense_p[i] -= jobs.dense_lr * jobs.dense_g[i];
+    return;
+  }
   int k = 0;
 #pragma unroll
   for (int i = 1; i < kSmallJobsMax; ++i)
@@ -2111,8 +2123,8 @@ extern "C" int rec_sparse_sgd_small(int64_t n, int32_t emb_dim, int32_t row_stri
   return check_launch("rec_sparse_sgd_small");
 }
 
-extern "C" int rec_sparse_sgd_small_multi(int32_t count, const rec_small_sgd_job* jobs, float lr, int32_t* status,
-                                          void* stream) {
+static int small_multi_impl(int32_t count, const rec_small_sgd_job* jobs, float lr, int32_t* status, void* stream,
+                            int64_t dense_n, float* dense_p, const float* dense_g) {
   REC_REQUIRE(count >= 0 && count <= kSmallJobsMax && (count == 0 || jobs) && status, REC_EINVAL,
               "bad arguments (at most %d tables per call)", kSmallJobsMax);
   SmallJobs js;
@@ -2137,15 +2149,33 @@ extern "C" int rec_sparse_sgd_small_multi(int32_t count, const rec_small_sgd_job
     dmax = a.emb_dim > dmax ? a.emb_dim : dmax;
     nmax = (size_t)a.n > nmax ? (size_t)a.n : nmax;
   }
-  if (js.count == 0) return REC_OK;
+  if (js.count == 0) return dense_n > 0 ? rec_sgd_dense(dense_n, dense_p, dense_g, lr, stream) : REC_OK;
+  js.merge_blocks = blocks;
+  js.dense_blocks = 0;
+  js.dense_n = dense_n; js.dense_p = dense_p; js.dense_g = dense_g; js.dense_lr = lr;
+  if (dense_n > 0) {
+    const int64_t db = (dense_n + 4 * kSmallWaves * kWave - 1) / (4 * kSmallWaves * kWave);
+    js.dense_blocks = (int)(db > 64 ? 64 : db);
+  }
   const size_t shmem = small_lds_bytes(nmax, true, &js.fp_mode);   // (the layout is per job: its own n)
   hipStream_t st = (hipStream_t)stream;
 #define REC_SMALLM(NACC_)                                                                                       \
-  hipLaunchKernelGGL((sparse_small_multi_kernel<NACC_>), dim3((unsigned)blocks), dim3(kSmallWaves * kWave), shmem, st, \
+  hipLaunchKernelGGL((sparse_small_multi_kernel<NACC_>), dim3((unsigned)(blocks + js.dense_blocks)), dim3(kSmallWaves * kWave), shmem, st, \
                      js, status)
   if (dmax <= kWave) REC_SMALLM(1); else if (dmax <= 2 * kWave) REC_SMALLM(2); else REC_SMALLM(4);
 #undef REC_SMALLM
   return check_launch("rec_sparse_sgd_small_multi");
+}
+
+extern "C" int rec_sparse_sgd_small_multi(int32_t count, const rec_small_sgd_job* jobs, float lr, int32_t* status,
+                                          void* stream) {
+  return small_multi_impl(count, jobs, lr, status, stream, 0, nullptr, nullptr);
+}
+
+int rec::sparse_sgd_small_multi_dense(int32_t count, const rec_small_sgd_job* jobs, float lr, int32_t* status, void* stream,
+                                      int64_t dense_n, float* dense_p, const float* dense_g) {
+  REC_REQUIRE(dense_n >= 0 && (dense_n == 0 || (dense_p && dense_g)), REC_EINVAL, "bad dense arguments");
+  return small_multi_impl(count, jobs, lr, status, stream, dense_n, dense_p, dense_g);
 }
 
 // REC_SMALL_BUCKET=0: the wave-per-lookup merge for every shape, =2 (lab): row buckets for slot tables of wide rows too;

@@ -234,6 +234,23 @@ int deepfm_fm_fwd_fold(const rec_deepfm_desc* desc, const int64_t* ids, const fl
 // the FoldFwd of rec_dense_fold_fwd_full's arguments (cross_ops.hip)
 FoldFwd dense_fold_fwd_plan(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out, const float* dense_w,
                             const float* W0, float* W0_folded);
+// DIN at its shipped batch size (din/config.yaml:20, bs 32) -------------------------------------------------------------
+// rec_sparse_sgd_small_multi with the dense parameters' SGD (rec_sgd_dense: p -= lr g) in blocks behind the merges' —
+// the tables and the flat dense buffer are disjoint, both only wait for the backward (sparse_update.hip)
+int sparse_sgd_small_multi_dense(int32_t count, const rec_small_sgd_job* jobs, float lr, int32_t* status, void* stream,
+                                 int64_t dense_n, float* dense_p, const float* dense_g);
+// up to 4 rec_emb_gather calls in ONE launch (emb_ops.hip): DIN's target item / target category / item bias rows
+struct GatherJob {
+  int64_t n;
+  int32_t emb_dim, row_stride;
+  int64_t num_rows, padding_idx;
+  const int64_t* ids;
+  const float* W;
+  float* out;
+  int32_t out_group;
+  int64_t out_group_stride;
+};
+int emb_gather_multi(int32_t count, const GatherJob* jobs, int32_t* status, void* stream);
 // rec_deepfm_fm_bwd without its fold launch: the partial columns [K][*nblk] stay in workspace (deepfm_fm.hip)
 int deepfm_fm_bwd_partial(const rec_deepfm_desc* desc, const float* dense, const float* feat, const float* sum_emb,
                           const float* d_feat_dnn, const float* dy1, const float* dy2, const float* dense_w,

@@ -177,6 +177,13 @@ class DINLayer:
                    target_cat_seq, base_lr=0.85):
         """din/dygraph_model.py:85-100 train_forward + backward + SGD step.  label float32 [B,1].
         Returns (loss [1], pred [B,1])."""
+        if (self.device.type == "cuda" and self.k is _ops and not self._recording
+                and hist_item_seq.numel() <= getattr(self.k, "SMALL_MERGE_MAX", 0) and hasattr(self.k, "din_train_step")
+                and os.environ.get("REC_STEP_PLAN", "1") != "0" and os.environ.get("REC_SMALL_C_STEP", "1") != "0"):
+            # the shipped batch size: the step through rec_din_train_step, where the three target gathers are one launch
+            # and the dense SGD rides in the merges' launch (csrc/tail_roles.h; bit-identical to the list below)
+            return self.train_step_c(hist_item_seq, hist_cat_seq, target_item, target_cat, label, mask, target_item_seq,
+                                     target_cat_seq, base_lr=base_lr)
         if self._bufs is None:
             self._bufs = _StepBuffers(self.k, self.device)
         lr = self.learning_rate(self.step_count, base_lr)

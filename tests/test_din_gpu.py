@@ -196,9 +196,13 @@ def test_attention_pool_bwd_vs_oracle(engine_lib, B, Tn, Ei, Ec, use_saved):
     assert np.all(N_(dh)[mask != 0] == 0.0) and np.all(N_(dq)[mask != 0] == 0.0)   # padding: exactly zero
 
 
-def test_din_train_step_golden_grads_and_sgd(engine_lib):
-    """Gradients of every registered parameter vs the reference's autograd (golden), then the SGD step."""
+@pytest.mark.parametrize("c_step", [False, True])
+def test_din_train_step_golden_grads_and_sgd(engine_lib, monkeypatch, c_step):
+    """Gradients of every registered parameter vs the reference's autograd (golden), then the SGD step — through the
+    eager mirror (which keeps its gradients for inspection) and through the default of a launch-bound batch, the one-call
+    C step (rec_din_train_step: loss and the updated parameters)."""
     from paddlerec_amd.din import DINLayer
+    monkeypatch.setenv("REC_SMALL_C_STEP", "1" if c_step else "0")
     g = load_golden("din")
     p = {k[2:]: v for k, v in g.items() if k.startswith("p.")}
     m = DINLayer(8, 8, "sigmoid", False, True, 301, 41, device=DEV)
@@ -213,7 +217,8 @@ def test_din_train_step_golden_grads_and_sgd(engine_lib):
     for name in ("linear_0", "linear_1", "linear_2", "linearCon"):
         for part in ("weight", "bias"):
             k = "%s.%s" % (name, part)
-            assert_close_scaled(N_(m._last["dense"][k]), g["g." + k], 1e-5, err_msg=k)
+            if not c_step:
+                assert_close_scaled(N_(m._last["dense"][k]), g["g." + k], 1e-5, err_msg=k)
     # after one SGD step every registered parameter equals p - lr * golden gradient
     sd = m.state_dict()
     for k, v in g.items():
@@ -259,7 +264,7 @@ def test_din_train_steps_vs_oracle(engine_lib):
                                    atol=1e-5 * np.abs(d_want).max() + 2.4e-7 * np.abs(p0[k]).max() + 2.0 * floor)
 
 
-def test_din_train_step_graphed_equals_eager(engine_lib):
+def test_din_train_step_graphed_equals_eager(engine_lib, monkeypatch):
     """train_step_graphed (hipGraph replay per input signature, paddlerec_amd/graph.py) runs the same launches in the
     same order as train_step: after a sequence of batches with TWO padded lengths (two signatures, first sight eager,
     second sight captured, then replays) every parameter and every loss is bit-identical, and no step ran twice."""
@@ -275,6 +280,7 @@ def test_din_train_step_graphed_equals_eager(engine_lib):
         hi, hc, ti, tc, mask, label = _din_problem(rng, B, Tn, ni, nc)
         tis, tcs = np.repeat(ti[:, None], Tn, 1), np.repeat(tc[:, None], Tn, 1)
         batches.append([T(x) for x in (hi, hc, ti, tc, label, mask, tis, tcs)])
+    monkeypatch.setenv("REC_STEP_PLAN", "0")        # a: the eager mirror
     for bt in batches:
         la, _ = a.train_step(*bt, base_lr=0.5)
         lb, _ = b.train_step_graphed(*bt, base_lr=0.5)
@@ -325,8 +331,10 @@ def test_din_planned_step_equals_eager(engine_lib, monkeypatch):
     ni, nc, B = 150, 30, 32
     a = DINLayer(64, 64, "sigmoid", False, True, ni, nc, device=DEV)
     b = DINLayer(64, 64, "sigmoid", False, True, ni, nc, device=DEV)
-    b.set_dict({k: v.clone() for k, v in a.state_dict().items()})
-    b.set_attention([w.clone() for w in a.attention_w], [x.clone() for x in a.attention_b])
+    c = DINLayer(64, 64, "sigmoid", False, True, ni, nc, device=DEV)
+    for other in (b, c):
+        other.set_dict({k: v.clone() for k, v in a.state_dict().items()})
+        other.set_attention([w.clone() for w in a.attention_w], [x.clone() for x in a.attention_b])
     for Tn in (40, 24, 40, 40, 24, 40, 24, 24, 40):
         hi, hc, ti, tc, mask, label = _din_problem(rng, B, Tn, ni, nc)
         tis, tcs = np.repeat(ti[:, None], Tn, 1), np.repeat(tc[:, None], Tn, 1)
@@ -334,12 +342,16 @@ def test_din_planned_step_equals_eager(engine_lib, monkeypatch):
         monkeypatch.setenv("REC_STEP_PLAN", "0")
         la, pa = a.train_step(*bt, base_lr=0.5)
         monkeypatch.setenv("REC_STEP_PLAN", "1")
+        monkeypatch.setenv("REC_SMALL_C_STEP", "0")          # the recorded call list
         lb, pb = b.train_step(*bt, base_lr=0.5)
-        assert torch.equal(la, lb) and torch.equal(pa, pb)
+        monkeypatch.setenv("REC_SMALL_C_STEP", "1")          # the default: rec_din_train_step (csrc/tail_roles.h)
+        lc, pc = c.train_step(*bt, base_lr=0.5)
+        assert torch.equal(la, lb) and torch.equal(pa, pb) and torch.equal(la, lc) and torch.equal(pa, pc)
     assert not a._plans and len(b._plans) == 2 and all(isinstance(p, CallPlan) for p in b._plans.values())
+    assert not c._plans and c.step_count == a.step_count
     for k, v in a.state_dict().items():
-        assert torch.equal(v, b.state_dict()[k]), k
-    assert int(a.status.item()) == 0 and int(b.status.item()) == 0
+        assert torch.equal(v, b.state_dict()[k]) and torch.equal(v, c.state_dict()[k]), k
+    assert int(a.status.item()) == 0 and int(b.status.item()) == 0 and int(c.status.item()) == 0
 
 
 @pytest.mark.parametrize("n,D,N,hot", [(4864, 128, 63001, True), (32, 64, 801, False), (1, 1, 5, False),
