@@ -477,7 +477,10 @@ int rec_sparse_sgd_small_multi(int32_t count, const rec_small_sgd_job* jobs, flo
  * (deepfm/config_bigdata.yaml: 512 x 26 slots = 13312 lookups) replaces grouping sort + two partial passes + record
  * update, 12 launches, by one.  ids [n] (n = B * num_slots, row = id + slot_offset[pos % num_slots] when
  * slot_offset is given); grad: one emb_dim-wide row per position (grad_layout as rec_sparse_adam_record), grad1:
- * the first-order gradient source with its layout (dz with {div = num_slots}). */
+ * the first-order gradient source with its layout (dz with {div = num_slots}).
+ * Above 2048 lookups, ONE table (or slot tables of rows <= 16 floats) is merged by ROW BUCKETS: block b owns the rows
+ * hashing to bucket b and keeps their (row, position) pairs in ascending position — the same order of additions, the
+ * same bits, without comparing every lookup with every other (the reference's one shared table: 98 -> 21 us). */
 int rec_sparse_adam_record_small(int64_t n, int32_t num_slots, int32_t emb_dim, int32_t rec_stride,
                                  int32_t state_stride, int32_t v_offset, int64_t num_rows, int64_t padding_idx,
                                  const int64_t* ids, const int64_t* slot_offset, const float* grad,
@@ -1092,7 +1095,11 @@ int rec_ctr_head_fwd_bwd(int64_t batch, int32_t n, int64_t mean_over, const floa
  * launch-bound small-batch step (the reference's bigdata batch size 512: ~40 dependent launches) without paying a
  * foreign-function round trip per launch.  At B * num_slots <= 15360 the SelectedRows merge happens inside the
  * record update (rec_sparse_adam_record_small); larger batches group their ids first (rec_ids_group_slots when
- * slot_rows > 0, else rec_ids_group_payload).  side_stream (may be NULL: everything on `stream`): a second stream of
+ * slot_rows > 0, else rec_ids_group_payload).  At those launch-bound sizes, when the merge runs by row buckets, the
+ * entry point goes one step further than the call list: the folds of the head's and the FM backward's partial sums,
+ * the folded layer 0's backward and rec_adam_dense run as ROLES of the row update's launch, layer 0's weight fold
+ * behind the lookup's blocks (csrc/tail_roles.h: every value by the statements of the stand-alone kernel, the
+ * parameters dealt out by owner) — 10 launches instead of 16, the same bits (REC_SMALL_TAIL=0: the call list).  side_stream (may be NULL: everything on `stream`): a second stream of
  * the caller's on which the entry point runs the mirror's large-batch schedule — the id grouping forked in front of the
  * lookup, the sparse update underneath the dW_0 GEMM — ordered against `stream` with events; on return both streams'
  * work is ordered before anything the caller issues on `stream` next.  One step at a time per process.
