@@ -295,13 +295,18 @@ def other_configs(timeout_s=120):
             ("REC_EMULATE_LINKS=8 bench.py --force-sharded --table ps --hashed-rows 1250000000",
              [sys.executable, os.path.abspath(__file__), "--force-sharded", "--table", "ps", "--hashed-rows",
               "1250000000", "--no-cpu-baseline", "--steps", "20", "--warmup", "5"]),
-            # the reference's OWN batch size (deepfm/config_bigdata.yaml:23: 512) on its own table layout (one shared table,
-            # D 9): launch-bound — with the one-launch GEMMs of csrc/gemm_direct.h and (REC_GEMM_DIRECT=0) with the tiled
-            # kernels + split-K reduce launches they replace
+            # the reference's OWN batch size (deepfm/config_bigdata.yaml:23: 512): launch-bound.  On its own table layout (one
+            # shared table, D 9) and on 26 slot tables (D 16) as round 6 leaves it — one-launch GEMMs (csrc/gemm_direct.h),
+            # merge + update by row buckets, folds + dense Adam as roles of that launch (csrc/tail_roles.h), issued by
+            # rec_deepfm_train_step — and with those three switched off (the round-5 step: tiled GEMMs + split-K reduces,
+            # wave-per-lookup merge, every fold a launch, the recorded call list)
             ("bench.py --batch 512 --shared-table --dim 9",
              [sys.executable, os.path.abspath(__file__), "--batch", "512", "--shared-table", "--dim", "9", "--no-cpu-baseline",
               "--steps", "300", "--warmup", "30", "--no-other-configs"]),
-            ("REC_GEMM_DIRECT=0 bench.py --batch 512 --shared-table --dim 9",
+            ("bench.py --batch 512",
+             [sys.executable, os.path.abspath(__file__), "--batch", "512", "--no-cpu-baseline",
+              "--steps", "300", "--warmup", "30", "--no-other-configs"]),
+            ("REC_GEMM_DIRECT=0 REC_SMALL_BUCKET=0 REC_SMALL_C_STEP=0 bench.py --batch 512 --shared-table --dim 9",
              [sys.executable, os.path.abspath(__file__), "--batch", "512", "--shared-table", "--dim", "9", "--no-cpu-baseline",
               "--steps", "300", "--warmup", "30", "--no-other-configs"]),
             # the pipelined step schedule (DeepFMLayer.pipelined: fm_bwd -> update -> next lookup on one stream)
@@ -318,8 +323,8 @@ def other_configs(timeout_s=120):
                 job_env = dict(env, REC_EMULATE_LINKS="8")
             if name.startswith("REC_DEEPFM_PIPELINED=1"):
                 job_env = dict(env, REC_DEEPFM_PIPELINED="1")
-            if name.startswith("REC_GEMM_DIRECT=0"):
-                job_env = dict(env, REC_GEMM_DIRECT="0")
+            if name.startswith("REC_GEMM_DIRECT=0"):      # every leading VAR=value of the name
+                job_env = dict(env, **dict(t.split("=", 1) for t in name.split(" bench.py")[0].split()))
             r = subprocess.run(cmd + (["--no-other-configs"] if name.startswith("REC_GEMM_BF16X3=0") else []), cwd=REPO,
                                env=job_env, capture_output=True, text=True, timeout=timeout_s)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -334,8 +339,9 @@ def other_configs(timeout_s=120):
                     e["config"] = ("configs[4] share + emulated links of an 8-GPU step (rec_link_emulate: 8 workgroups per "
                                    "collective for remote bytes / (7 x 153 GB/s) + 8 us)" if name.startswith("REC_EMULATE_LINKS")
                                    else "configs[1], pipelined step schedule" if name.startswith("REC_DEEPFM_PIPELINED") else
-                                   "configs[0] shape at the reference's batch size 512 (launch-bound), tiled GEMMs + split-K "
-                                   "reduce launches (REC_GEMM_DIRECT=0)" if name.startswith("REC_GEMM_DIRECT=0") else
+                                   "configs[0] shape at the reference's batch size 512 (launch-bound), the round-5 step: tiled "
+                                   "GEMMs + split-K reduce launches, wave-per-lookup merge, every fold a launch of its own"
+                                   if name.startswith("REC_GEMM_DIRECT=0") else
                                    "configs[0] shape at the reference's batch size 512 (launch-bound)" if "512" in cmd else
                                    "configs[4] (one GPU's share, row-sharded path at world 1)" if "--table" in cmd else
                                    "configs[1] layout 2b (one shared table)" if "--shared-table" in cmd else
@@ -750,7 +756,8 @@ def main():
                        else "torch.distributed (%s)" % ("RCCL" if backend == "nccl" else backend),
                        "rccl_ranks": model.comm.native_ranks} if dist is not None else {}),
                    "table_rows_total": N, "loss": loss_v, "index_oob_flag": oob,
-                   **({"step_entry": "rec_deepfm_train_step (one C-ABI call per step, one stream)"} if args.c_step else {}),
+                   **({"step_entry": "rec_deepfm_train_step (one C-ABI call per step, one stream)"}
+                      if args.c_step or getattr(model, "_ws_c", None) is not None else {}),
                    **({"table_rows_requested": rows_req * world} if args.table == "ps" and dist is not None
                       and rows_req != args.hashed_rows else {}),
                    **({"native_init_timed_out": True} if dist is not None and getattr(model.comm, "native_init_timed_out", False)
