@@ -220,8 +220,9 @@ int carve(const rec_deepfm_net* net, const Shape& s, int64_t B, void* workspace,
 // C = epi(op(A) @ op(B)) on contiguous operands (the step's own buffers and parameter views)
 int gemm(int64_t m, int n, int k, bool ta, bool tb, int epi, const float* A, const float* Bm, float* C,
          const float* bias, const float* aux0, int ld0, float* b_colsum, int split_k, const Buffers& bf, void* st,
-         const void* b_image = nullptr) {
+         const void* b_image = nullptr, int num_cus = 0) {
   rec_gemm_desc d{};
+  d.num_cus = num_cus;
   d.m = m; d.n = n; d.k = k;
   d.lda = ta ? (int)m : k;
   d.ldb = tb ? k : n;
@@ -524,9 +525,11 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   // -- dW_0 / db_0, then the folded rows back into the real parameters' gradients (deepfm.py:_fold_backward).  Beside the
   //    HBM-bound update the mirror splits K 16 ways instead of the planner's 32: half a resident round of blocks
   static const int dw0_split = [] { const char* v = getenv("REC_DW0_SPLIT"); return v && *v ? atoi(v) : 16; }();
+  static const int dw0_cus = [] { const char* v = getenv("REC_DW0_CUS"); return v && *v ? atoi(v) : 192; }();   // deepfm.py
   if (!dw0_done)
     REC_TRY(gemm(s.in0, net->widths[0], (int)B, true, false, REC_EPI_NONE, bf.feat, g0, gw0, nullptr, nullptr, 0,
-                 net->gb[0], overlap && B >= 16384 ? dw0_split : 0, bf, stream));
+                 net->gb[0], overlap && B >= 16384 ? dw0_split : 0, bf, stream, nullptr,
+                 overlap && B >= 16384 ? dw0_cus : 0));
   if (s.compact)
     REC_TRY(rec_dense_fold_bwd_full(S, Dn, D, net->widths[0], net->dense_w, net->w[0], gw0, net->gw[0],
                                     net->g_dense_w, 1, stream));

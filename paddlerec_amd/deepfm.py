@@ -625,6 +625,9 @@ class DeepFMLayer:
             # dW_0 runs beside the sparse update: half a resident round of blocks (K split 16 instead of 32) leaves the
             # HBM-bound kernel its wave slots — sparse_adam 404 -> 336 us, dW_0 unchanged (REC_DW0_SPLIT: 0 = planner's)
             kw.update(defer_split=int(os.environ.get("REC_DW0_SPLIT", "16")))
+            # ... and, on the bf16 x 3 kernel (one 512-register block per CU), a grid for 192 of the 256 CUs: dW_0 248 ->
+            # 292 us, the update 337 -> 324, the step 1.567-1.576 -> 1.548-1.557 ms (REC_DW0_CUS=0: every CU)
+            kw.update(defer_cus=int(os.environ.get("REC_DW0_CUS", "192")))
         # dW_i on a third stream beside dX_i (both consume g_i, neither the other): the half-empty last round of
         # blocks of one GEMM is filled by the other — 2.77-2.84 -> 2.70-2.81 ms per step in five A/B pairs on two boxes
         # (profiles/r02f_dw_stream_ab.txt); REC_MLP_DW_STREAM=0 puts them back on one stream

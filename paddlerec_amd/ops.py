@@ -1689,7 +1689,7 @@ def _head_ok(act, w, dw, db, dy):
 
 
 def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=False, dw_stream=None, dw_ws=None,
-                 defer_split=0, images_t=None):
+                 defer_split=0, images_t=None, defer_cus=0):
     """Backward of mlp_forward: dW_i -> dws[i], db_i -> dbs[i] (preallocated views); returns d(input).
     ReLU' is applied in the epilogue of the dX GEMM (mask = layer input > 0).
     defer_first: compute d(input) BEFORE dW_0 and return (d_input, finish) where finish() launches the
@@ -1730,9 +1730,11 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
             g0 = g
             d_in = gemm(g0, weights[0], ws, trans_b=True, b_image=imt(0))
             join()
+            # defer_cus: the deferred dW_0's grid sized for that many CUs (the bf16 x 3 kernel: one block per CU)
             # defer_split: K split of the deferred dW_0 GEMM (0 = the planner's: one resident round of blocks) — the
             # caller that runs an HBM-bound kernel beside it asks for fewer, longer blocks, which leave it wave slots
-            return d_in, (lambda: gemm(acts[0], g0, ws, trans_a=True, out=dws[0], b_colsum=dbs[0], split_k=defer_split))
+            return d_in, (lambda: gemm(acts[0], g0, ws, trans_a=True, out=dws[0], b_colsum=dbs[0], split_k=defer_split,
+                                    num_cus=defer_cus))
         if dw_stream is not None:
             # dW_i and dX_i both consume g_i and nothing of each other: two streams, so that the half-empty last
             # round of blocks of one GEMM is filled by the other

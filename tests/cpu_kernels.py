@@ -433,7 +433,7 @@ def copy_f32(dst, src):
 
 
 def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=False, dw_stream=None, dw_ws=None,
-                 defer_split=0):
+                 defer_split=0, defer_cus=0):
     if defer_first or defer_all:
         return mlp_backward(dy, acts, weights, dws, dbs, ws), (lambda: None)
     n = len(weights)
