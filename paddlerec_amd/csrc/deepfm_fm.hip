@@ -482,7 +482,8 @@ using namespace rec;
 
 static int fm_fwd_impl(const rec_deepfm_desc* desc, const int64_t* ids, const float* dense, const float* W, const float* W1,
                        const float* dense_w, const float* dense_w_one, const int64_t* slot_offset, float* y1, float* y2,
-                       float* feat, float* sum_emb, int32_t* status, void* stream, const FoldFwd& fold, bool* rode);
+                       float* feat, float* sum_emb, int32_t* status, void* stream, const FoldFwd& fold, bool* rode,
+                       bool* pad_zeroed);
 
 extern "C" int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids,
                                  const float* dense, const float* W, const float* W1,
@@ -490,22 +491,24 @@ extern "C" int rec_deepfm_fm_fwd(const rec_deepfm_desc* desc, const int64_t* ids
                                  const int64_t* slot_offset, float* y1, float* y2, float* feat,
                                  float* sum_emb, int32_t* status, void* stream) {
   return fm_fwd_impl(desc, ids, dense, W, W1, dense_w, dense_w_one, slot_offset, y1, y2, feat, sum_emb, status, stream,
-                     FoldFwd{}, nullptr);
+                     FoldFwd{}, nullptr, nullptr);
 }
 
 // *rode = the fold went out with the lookup (the wide-row kernel); false: the caller issues rec_dense_fold_fwd_full
 int rec::deepfm_fm_fwd_fold(const rec_deepfm_desc* desc, const int64_t* ids, const float* dense, const float* W,
                             const float* W1, const float* dense_w, const float* dense_w_one, const int64_t* slot_offset,
                             float* y1, float* y2, float* feat, float* sum_emb, int32_t* status, void* stream, FoldFwd fold,
-                            bool* rode) {
+                            bool* rode, bool* pad_zeroed) {
   return fm_fwd_impl(desc, ids, dense, W, W1, dense_w, dense_w_one, slot_offset, y1, y2, feat, sum_emb, status, stream,
-                     fold, rode);
+                     fold, rode, pad_zeroed);
 }
 
 static int fm_fwd_impl(const rec_deepfm_desc* desc, const int64_t* ids, const float* dense, const float* W, const float* W1,
                        const float* dense_w, const float* dense_w_one, const int64_t* slot_offset, float* y1, float* y2,
-                       float* feat, float* sum_emb, int32_t* status, void* stream, const FoldFwd& fold, bool* rode) {
+                       float* feat, float* sum_emb, int32_t* status, void* stream, const FoldFwd& fold, bool* rode,
+                       bool* pad_zeroed) {
   if (rode) *rode = false;
+  if (pad_zeroed) *pad_zeroed = false;
   if (int rc = check_desc(desc)) return rc;
   if (desc->batch == 0) return REC_OK;
   REC_REQUIRE(ids && W && W1 && y1 && y2 && feat && status, REC_EINVAL, "null pointer argument");
@@ -526,13 +529,16 @@ static int fm_fwd_impl(const rec_deepfm_desc* desc, const int64_t* ids, const fl
     if (shmem <= 64 * 1024) {
       const bool v4 = desc->row_stride % 4 == 0 && desc->row_stride >= ((D + 3) & ~3) && aligned16(W);
       const int64_t ntiles = (desc->batch + kFmTileS - 1) / kFmTileS;
+      const int zero_to = fold.zero_feat_pad && feat_ld > P && feat_ld != (int64_t)FP * D ? (int)feat_ld : 0;
+      if (pad_zeroed) *pad_zeroed = zero_to > 0;
 #define REC_FWD_TILE(V4_, NT_)                                                                                     \
   {                                                                                                                \
     int64_t grid = resident_blocks(fm_fwd_tile_kernel<V4_, NT_>, kBlock, shmem);                                   \
     if (grid > ntiles) grid = ntiles;                                                                              \
     hipLaunchKernelGGL((fm_fwd_tile_kernel<V4_, NT_>), dim3((unsigned)grid), dim3(kBlock), shmem, st, desc->batch, \
                        S, Dn, D, feat_ld, desc->row_stride, w1_stride, desc->num_rows, desc->padding_idx, ids,     \
-                       dense, W, W1, dense_w, dense_w_one, slot_offset, y1, y2, feat, sum_emb, status);            \
+                       dense, W, W1, dense_w, dense_w_one, slot_offset, y1, y2, feat, sum_emb, status,             \
+                       zero_to);                                                                                   \
   }
       if (v4) { if (tune().fwd_nt) REC_FWD_TILE(true, true) else REC_FWD_TILE(true, false) }
       else { if (tune().fwd_nt) REC_FWD_TILE(false, true) else REC_FWD_TILE(false, false) }

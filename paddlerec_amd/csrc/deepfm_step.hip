@@ -334,18 +334,19 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
   // -- FM: lookup + first / second order + the MLP's input (net.py:104-136)
   rec_deepfm_desc fd{B, S, Dn, D, net->rec_stride, net->table_rows, net->padding_idx, net->rec_stride,
                      s.compact ? 1 : 0, s.pad ? (int64_t)s.in0 : 0};
-  if (s.pad)        // the padding columns of feat (workspace memory) must be zero: they meet zero weight rows, but 0 x NaN
+  // (launch-bound sizes: layer 0's weight fold rides behind the lookup's blocks — tail_roles.h, FoldFwd — and the
+  //  narrow-row lookup zeroes the padding columns of its samples itself)
+  static const bool fold_ride = [] { const char* v = getenv("REC_SMALL_TAIL"); return !(v && *v == '0'); }();
+  bool fold_rode = false, pad_zeroed = false;
+  FoldFwd ff{};
+  if (s.compact && s.small && fold_ride)
+    ff = dense_fold_fwd_plan(S, Dn, D, net->widths[0], net->dense_w, net->w[0], net->w0_folded);
+  ff.zero_feat_pad = s.pad && s.small && fold_ride ? 1 : 0;
+  REC_TRY(deepfm_fm_fwd_fold(&fd, ids, dense, net->rec, net->rec + D, net->dense_w, net->dense_w_one, net->slot_offset,
+                             bf.y1, bf.y2, bf.feat, bf.sum_emb, status, stream, ff, &fold_rode, &pad_zeroed));
+  if (s.pad && !pad_zeroed)   // the padding columns of feat (workspace memory) must be zero: they meet zero weight rows, but 0 x NaN
     REC_REQUIRE(hipMemset2DAsync(bf.feat + s.in0_real, (size_t)s.in0 * f4, 0, (size_t)(s.in0 - s.in0_real) * f4,
                                  (size_t)B, (hipStream_t)stream) == hipSuccess, REC_EHIP, "hipMemset2DAsync failed");
-  // (launch-bound sizes: layer 0's weight fold rides behind the lookup's blocks — tail_roles.h, FoldFwd)
-  static const bool fold_ride = [] { const char* v = getenv("REC_SMALL_TAIL"); return !(v && *v == '0'); }();
-  bool fold_rode = false;
-  REC_TRY(deepfm_fm_fwd_fold(&fd, ids, dense, net->rec, net->rec + D, net->dense_w, net->dense_w_one, net->slot_offset,
-                             bf.y1, bf.y2, bf.feat, bf.sum_emb, status, stream,
-                             s.compact && s.small && fold_ride
-                                 ? dense_fold_fwd_plan(S, Dn, D, net->widths[0], net->dense_w, net->w[0], net->w0_folded)
-                                 : FoldFwd{},
-                             &fold_rode));
   // -- layer 0 on folded weights (deepfm.py:_mlp_weights): W0' = [ W0[:S*D] ; M ; 0 ]
   const float* w0 = net->w[0];
   float* gw0 = net->gw[0];

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "rec_common.h"
+#include "tail_roles.h"
 
 namespace rec {
 
@@ -838,9 +839,16 @@ __global__ __launch_bounds__(kBlock, OCC) void din_attention_fwd_ct_kernel(DinAr
 // softmax over the whole history from the per-tile pieces of the tile-split forward: with M = max_j m_j and
 // L = sum_j l_j e^(m_j - M), tile j weighs c_j = l_j e^(m_j - M) / L:  out[b] = sum_j c_j part_j (ascending j),
 // att_weight[b, t] *= c_(t / 32).  One block per sample.
+// Blocks behind the B samples': gathers that only wait for the step's inputs (tail_roles.h, GatherJobs: DIN's target rows at
+// the shipped batch size — one launch less on a launch-bound step).
 __global__ __launch_bounds__(kBlock) void din_combine_kernel(int64_t B, int T, int NTL, int E,
                                                              const float* __restrict__ part, float* __restrict__ out,
-                                                             float* __restrict__ att_weight) {
+                                                             float* __restrict__ att_weight, GatherJobs riders,
+                                                             int32_t* __restrict__ rider_status) {
+  if ((int64_t)blockIdx.x >= B) {
+    gather_role((int)((int64_t)blockIdx.x - B), threadIdx.x, riders, rider_status);
+    return;
+  }
   __shared__ float cj[64];
   const int64_t b = blockIdx.x;
   const float* pb = part + b * NTL * (E + 2);
@@ -1510,6 +1518,26 @@ extern "C" int rec_din_attention_pool_fwd_workspace_bytes(const rec_din_desc* d,
   return REC_OK;
 }
 
+static thread_local rec::GatherJobs t_combine_rider_jobs;
+static thread_local const rec::GatherJobs* t_combine_rider = nullptr;
+static thread_local int32_t* t_combine_rider_status = nullptr;
+static thread_local bool t_combine_rider_taken = false;
+void rec::din_combine_rider_set(const GatherJobs* jobs, int32_t* status) {
+  t_combine_rider = nullptr;
+  if (jobs && status && jobs->count > 0) {
+    t_combine_rider_jobs = *jobs;
+    t_combine_rider = &t_combine_rider_jobs;
+  }
+  t_combine_rider_status = status;
+  t_combine_rider_taken = false;
+}
+bool rec::din_combine_rider_take() {
+  const bool taken = t_combine_rider_taken;
+  t_combine_rider = nullptr;
+  t_combine_rider_taken = false;
+  return taken;
+}
+
 extern "C" int rec_din_attention_pool_fwd_ws(const rec_din_desc* d, const int64_t* hist_item,
                                           const int64_t* hist_cat, const int64_t* tgt_item_seq,
                                           const int64_t* tgt_cat_seq, const int64_t* mask,
@@ -1585,8 +1613,18 @@ extern "C" int rec_din_attention_pool_fwd_ws(const rec_din_desc* d, const int64_
     if (split_env && need > 0 && workspace && workspace_bytes >= need && tiles <= grid) {
       a.part = (float*)workspace;
       hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kBlock), shmem, (hipStream_t)stream, a);
-      hipLaunchKernelGGL(din_combine_kernel, dim3((unsigned)d->batch), dim3(kBlock), 0, (hipStream_t)stream, d->batch,
-                         d->max_len, ntl, E, (const float*)workspace, out, att_weight);
+      GatherJobs riders;
+      riders.count = riders.blocks = 0;
+      int32_t* rider_status = nullptr;
+      if (t_combine_rider) {                              // (din_combine_rider_set: this thread's next combine launch)
+        riders = *t_combine_rider;
+        rider_status = t_combine_rider_status;
+        t_combine_rider = nullptr;
+        t_combine_rider_taken = true;
+      }
+      hipLaunchKernelGGL(din_combine_kernel, dim3((unsigned)(d->batch + riders.blocks)), dim3(kBlock), 0,
+                         (hipStream_t)stream, d->batch, d->max_len, ntl, E, (const float*)workspace, out, att_weight, riders,
+                         rider_status);
       return check_launch("rec_din_attention_pool_fwd (tile split)");
     }
     if (grid > d->batch) grid = d->batch;

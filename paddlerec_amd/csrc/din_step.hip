@@ -245,21 +245,36 @@ extern "C" int rec_din_train_step(const rec_din_net* net, int64_t batch, int32_t
   }
 
   // ---- forward (din.py:forward = net.py:139-184)
-  REC_TRY(rec_din_attention_pool_fwd_ws(&d, hist_item, hist_cat, target_item_seq, target_cat_seq, mask, net->w_hist_item,
-                                        net->w_hist_cat, net->w_tgt_item_seq, net->w_tgt_cat_seq, net->att_w1,
-                                        net->att_b1, net->att_w2, net->att_b2, net->att_w3, net->att_b3, bf.pooled,
-                                        bf.attw, bf.act1, status, bf.ws_att, bf.ws_att_bytes, stream));   // net.py:141-173
-  REC_TRY(gemm(B, E, E, E, E, E2, false, false, REC_EPI_BIAS, bf.pooled, net->w_con, bf.emb, net->b_con, nullptr, 0,
-               nullptr, 0, nullptr, bf, stream));                                                        // net.py:175-176
-  // launch-bound sizes (din/config.yaml:20, bs 32): the three gathers as ONE launch, the dense SGD in the merges' launch
-  // (tail_roles.h; REC_SMALL_TAIL=0: the mirror's list of launches) — same values, three launches less
+  // launch-bound sizes (din/config.yaml:20, bs 32): the three target gathers ride behind the blocks of the attention's
+  // combine launch (or go out as ONE launch of their own), the dense SGD in the merges' launch (tail_roles.h;
+  // REC_SMALL_TAIL=0: the mirror's list of launches) — same values, four launches less
   static const bool ride = [] { const char* v = getenv("REC_SMALL_TAIL"); return !(v && *v == '0'); }();
+  GatherJobs gjs;
   if (s.small && ride) {
     const GatherJob gj[3] = {
         {B, Ei, Ei, net->item_rows, -1, target_item, net->w_tgt_item, bf.emb + E, 1, E2},             // net.py:143,152
         {B, s.Ec, s.Ec, net->cat_rows, -1, target_cat, net->w_tgt_cat, bf.emb + E + Ei, 1, E2},
         {B, 1, 1, net->item_rows, -1, target_item, net->w_item_b, bf.item_b, 0, 0}};
-    REC_TRY(emb_gather_multi(3, gj, status, stream));
+    REC_TRY(gather_jobs_make(3, gj, &gjs));
+    din_combine_rider_set(&gjs, status);
+  }
+  const int att_rc = rec_din_attention_pool_fwd_ws(&d, hist_item, hist_cat, target_item_seq, target_cat_seq, mask,
+                                                   net->w_hist_item, net->w_hist_cat, net->w_tgt_item_seq,
+                                                   net->w_tgt_cat_seq, net->att_w1, net->att_b1, net->att_w2, net->att_b2,
+                                                   net->att_w3, net->att_b3, bf.pooled, bf.attw, bf.act1, status, bf.ws_att,
+                                                   bf.ws_att_bytes, stream);                              // net.py:141-173
+  const bool gathers_rode = din_combine_rider_take();    // (always: an unconsumed rider must not wait for a later call)
+  if (att_rc) return att_rc;
+  REC_TRY(gemm(B, E, E, E, E, E2, false, false, REC_EPI_BIAS, bf.pooled, net->w_con, bf.emb, net->b_con, nullptr, 0,
+               nullptr, 0, nullptr, bf, stream));                                                        // net.py:175-176
+  if (s.small && ride) {
+    if (!gathers_rode) {                                // (the attention did not split by tiles: no combine launch)
+      const GatherJob gj[3] = {
+          {B, Ei, Ei, net->item_rows, -1, target_item, net->w_tgt_item, bf.emb + E, 1, E2},
+          {B, s.Ec, s.Ec, net->cat_rows, -1, target_cat, net->w_tgt_cat, bf.emb + E + Ei, 1, E2},
+          {B, 1, 1, net->item_rows, -1, target_item, net->w_item_b, bf.item_b, 0, 0}};
+      REC_TRY(emb_gather_multi(3, gj, status, stream));
+    }
   } else {
   REC_TRY(rec_emb_gather(B, Ei, Ei, net->item_rows, -1, target_item, net->w_tgt_item, bf.emb + E, 1, E2, status,
                          stream));                                                                        // net.py:143,152

@@ -35,34 +35,10 @@ __global__ __launch_bounds__(kBlock) void emb_gather_kernel(
   vstore<VEC>(out + o + d0, e);
 }
 
-// Several gathers in ONE launch (tail_roles.h, GatherJob): a launch-bound step pays per launch, not per byte — DIN at batch 32
-// looks up 32 target items, 32 target categories and 32 item biases as three launches of one block each.  One float per
-// thread; the values, the padding rule and the out-of-range flag are emb_gather_kernel's.
-constexpr int kGatherJobsMax = 4;
-struct GatherJobs {
-  int count;
-  int block0[kGatherJobsMax + 1];
-  GatherJob j[kGatherJobsMax];
-};
+// Several gathers in ONE launch (tail_roles.h, GatherJobs): a launch-bound step pays per launch, not per byte — DIN at batch 32
+// looks up 32 target items, 32 target categories and 32 item biases as three launches of one block each.
 __global__ __launch_bounds__(kBlock) void emb_gather_multi_kernel(GatherJobs js, int32_t* __restrict__ status) {
-  int k = 0;
-#pragma unroll
-  for (int i = 1; i < kGatherJobsMax; ++i)
-    if (i < js.count && (int)blockIdx.x >= js.block0[i]) k = i;
-  const GatherJob& g = js.j[k];
-  const int D = g.emb_dim;
-  const int64_t e = (int64_t)((int)blockIdx.x - js.block0[k]) * kBlock + threadIdx.x;
-  const int64_t i = e / D;
-  const int d = (int)(e % D);
-  if (i >= g.n) return;
-  const int64_t id = g.ids[i];
-  float v = 0.f;
-  if (id != g.padding_idx || g.padding_idx < 0) {
-    if (id >= 0 && id < g.num_rows) v = g.W[id * g.row_stride + d];
-    else if (d == 0) atomicOr(status, REC_FLAG_INDEX_OOB);
-  }
-  const int64_t o = g.out_group > 0 ? (i / g.out_group) * g.out_group_stride + (i % g.out_group) * D : i * D;
-  g.out[o + d] = v;
+  gather_role((int)blockIdx.x, threadIdx.x, js, status);
 }
 
 // Owner-side lookup of a row-sharded DeepFM table: BOTH embeddings of a row from its ONE record line
@@ -249,21 +225,28 @@ extern "C" int rec_record_gather(int64_t n, int32_t emb_dim, int32_t rec_stride,
   });
 }
 
-int rec::emb_gather_multi(int32_t count, const GatherJob* jobs, int32_t* status, void* stream) {
-  REC_REQUIRE(count >= 0 && count <= kGatherJobsMax && (count == 0 || jobs) && status, REC_EINVAL, "bad arguments");
-  GatherJobs js;
-  js.count = 0;
+int rec::gather_jobs_make(int32_t count, const GatherJob* jobs, GatherJobs* out) {
+  REC_REQUIRE(count >= 0 && count <= kGatherJobsMax && (count == 0 || jobs) && out, REC_EINVAL, "bad arguments");
+  out->count = 0;
   int blocks = 0;
   for (int i = 0; i < count; ++i) {
     const GatherJob& a = jobs[i];
     REC_REQUIRE(a.n >= 0 && a.emb_dim > 0 && a.row_stride >= a.emb_dim && a.num_rows > 0, REC_EINVAL, "job %d: bad sizes", i);
     if (a.n == 0) continue;
     REC_REQUIRE(a.ids && a.W && a.out, REC_EINVAL, "job %d: null pointer argument", i);
-    js.block0[js.count] = blocks;
-    js.j[js.count++] = a;
+    out->block0[out->count] = blocks;
+    out->j[out->count++] = a;
     blocks += (int)((a.n * a.emb_dim + kBlock - 1) / kBlock);
   }
+  out->blocks = blocks;
+  return REC_OK;
+}
+
+int rec::emb_gather_multi(int32_t count, const GatherJob* jobs, int32_t* status, void* stream) {
+  REC_REQUIRE(status, REC_EINVAL, "status is NULL");
+  GatherJobs js;
+  if (int rc = gather_jobs_make(count, jobs, &js)) return rc;
   if (js.count == 0) return REC_OK;
-  hipLaunchKernelGGL(emb_gather_multi_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, js, status);
+  hipLaunchKernelGGL(emb_gather_multi_kernel, dim3((unsigned)js.blocks), dim3(kBlock), 0, (hipStream_t)stream, js, status);
   return check_launch("emb_gather_multi");
 }

@@ -54,7 +54,9 @@ __global__ __launch_bounds__(kBlock, 6) void fm_fwd_tile_kernel(
     const int64_t* __restrict__ ids, const float* __restrict__ dense, const float* __restrict__ W,
     const float* __restrict__ W1, const float* __restrict__ dense_w, const float* __restrict__ dense_w_one,
     const int64_t* __restrict__ slot_off, float* __restrict__ y1, float* __restrict__ y2, float* __restrict__ feat,
-    float* __restrict__ sum_emb, int32_t* __restrict__ status) {
+    float* __restrict__ sum_emb, int32_t* __restrict__ status, int zero_to) {
+  // zero_to > pitch (padded sample stride only): the columns [pitch, zero_to) of every sample are written as zeros too —
+  // a caller whose feat buffer is scratch (rec_deepfm_train_step at launch-bound sizes) then needs no memset launch
   extern __shared__ __attribute__((aligned(16))) unsigned char fm_tile_smem[];
   const int F = S + Dn, FD = F * D;
   const int P = fm_tile_pitch(F, D, feat_ld);
@@ -177,6 +179,14 @@ __global__ __launch_bounds__(kBlock, 6) void fm_fwd_tile_kernel(
         float* dst = feat + (b0 + sample) * feat_ld + c4 * 4;
         if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
         else *reinterpret_cast<f32x4*>(dst) = v;
+      }
+      if (zero_to > P) {
+        const int z4 = (zero_to - P) / 4;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < nvalid * z4; i += kBlock) {
+          const int sample = i / z4, c4 = i - sample * z4;
+          *reinterpret_cast<f32x4*>(feat + (b0 + sample) * feat_ld + P + c4 * 4) = zero;
+        }
       }
     }
     __syncthreads();                                        // the tile is rewritten by the next round's phase A

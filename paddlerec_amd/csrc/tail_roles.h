@@ -171,6 +171,8 @@ struct FoldFwd {
   const float* dw;          // dense_w [Dn, D]
   const float* W0;          // [(S + Dn) D, NO]
   float* W0f;               // [(S + 1) D, NO]
+  int zero_feat_pad;        // narrow-row lookup (fm_tile.h) on a padded sample stride: the kernel also zeroes the columns
+                            // behind its float4 rows up to feat_stride (a caller's scratch buffer needs no memset launch)
 };
 __device__ __forceinline__ void dense_fold_fwd_role(int b, int tid, const FoldFwd& r) {
   const int S = r.S, Dn = r.Dn, D = r.D, NO = r.NO;
@@ -230,7 +232,8 @@ int ctr_head_fwd_bwd_partial(int64_t batch, int32_t n, int64_t mean_over, const 
 // rec_deepfm_fm_fwd with layer 0's weight fold riding behind the lookup's blocks (fold.blocks == 0: the plain lookup)
 int deepfm_fm_fwd_fold(const rec_deepfm_desc* desc, const int64_t* ids, const float* dense, const float* W, const float* W1,
                        const float* dense_w, const float* dense_w_one, const int64_t* slot_offset, float* y1, float* y2,
-                       float* feat, float* sum_emb, int32_t* status, void* stream, FoldFwd fold, bool* rode);
+                       float* feat, float* sum_emb, int32_t* status, void* stream, FoldFwd fold, bool* rode,
+                       bool* pad_zeroed);
 // the FoldFwd of rec_dense_fold_fwd_full's arguments (cross_ops.hip)
 FoldFwd dense_fold_fwd_plan(int32_t num_slots, int32_t num_dense, int32_t emb_dim, int32_t n_out, const float* dense_w,
                             const float* W0, float* W0_folded);
@@ -250,6 +253,38 @@ struct GatherJob {
   int32_t out_group;
   int64_t out_group_stride;
 };
+constexpr int kGatherJobsMax = 4;
+struct GatherJobs {         // what the kernel gets: the jobs and the first block of each (256 threads, one float per thread)
+  int count, blocks;
+  int block0[kGatherJobsMax + 1];
+  GatherJob j[kGatherJobsMax];
+};
+// block b (of js.blocks) of the gathers: the values, the padding rule and the out-of-range flag of emb_gather_kernel
+__device__ __forceinline__ void gather_role(int b, int tid, const GatherJobs& js, int32_t* __restrict__ status) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < kGatherJobsMax; ++i)
+    if (i < js.count && b >= js.block0[i]) k = i;
+  const GatherJob& g = js.j[k];
+  const int D = g.emb_dim;
+  const int64_t e = (int64_t)(b - js.block0[k]) * kBlock + tid;
+  const int64_t i = e / D;
+  const int d = (int)(e % D);
+  if (tid >= kBlock || i >= g.n) return;
+  const int64_t id = g.ids[i];
+  float v = 0.f;
+  if (id != g.padding_idx || g.padding_idx < 0) {
+    if (id >= 0 && id < g.num_rows) v = g.W[id * g.row_stride + d];
+    else if (d == 0) atomicOr(status, REC_FLAG_INDEX_OOB);
+  }
+  const int64_t o = g.out_group > 0 ? (i / g.out_group) * g.out_group_stride + (i % g.out_group) * D : i * D;
+  g.out[o + d] = v;
+}
+int gather_jobs_make(int32_t count, const GatherJob* jobs, GatherJobs* out);       // emb_ops.hip (checks + block ranges)
+// the gathers riding behind the blocks of the NEXT tile-split rec_din_attention_pool_fwd_ws's combine launch issued by this
+// thread (din_attention.hip); din_combine_rider_take() -> true when that launch carried them (else: emb_gather_multi)
+void din_combine_rider_set(const GatherJobs* jobs, int32_t* status);
+bool din_combine_rider_take();
 int emb_gather_multi(int32_t count, const GatherJob* jobs, int32_t* status, void* stream);
 // rec_deepfm_fm_bwd without its fold launch: the partial columns [K][*nblk] stay in workspace (deepfm_fm.hip)
 int deepfm_fm_bwd_partial(const rec_deepfm_desc* desc, const float* dense, const float* feat, const float* sum_emb,
