@@ -1,3 +1,7 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -x -q -n 4 2>&1 | tail -4
-bash tools/runs/r06_small_final.sh 2>&1 | grep -v "^+"
+ms() { python -c "import sys,json; [print('$1 %.4f ms' % json.loads(l)['ms_per_step']) for l in sys.stdin if l.startswith('{')]"; }
+for rep in 1 2; do
+for k in 0 4; do
+REC_GEMM_DIRECT_KS=$k python bench.py --batch 512 --steps 300 --warmup 30 --no-cpu-baseline --no-other-configs 2>/dev/null | ms "KS=$k 26 tables"
+REC_GEMM_DIRECT_KS=$k python bench.py --batch 512 --shared-table --dim 9 --steps 300 --warmup 30 --no-cpu-baseline --no-other-configs 2>/dev/null | ms "KS=$k shared"
+done; done
