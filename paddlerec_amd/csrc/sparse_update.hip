@@ -1122,7 +1122,7 @@ __device__ __forceinline__ void sparse_bucket_body(
     const int64_t* __restrict__ slot_off, const float* __restrict__ grad, rec_grad_layout gl, Update up,
     int32_t* __restrict__ status) {
   constexpr bool kRecord = std::is_same<Update, SmallAdamRecord>::value;
-  constexpr int FLY = kSmallList / NACC;
+  constexpr int FLY = NACC == 1 ? kSmallList / 2 : kSmallList / NACC;   // (16 rows in flight at most: 32 spilled beside step 1's registers)
   __shared__ int b_rows[kBucketCap];
   __shared__ int b_pos[kBucketCap];
   __shared__ int b_wl[kBucketWaves][kSmallList];
