@@ -12,7 +12,7 @@ tail -5 "$O/profile.log"
 f=$(find gpurun_out/prof_r06/trace -name "*kernel_stats.csv" | head -1); cp "$f" "$O/kernel_stats.csv"
 t=$(find gpurun_out/prof_r06/trace -name "*kernel_trace.csv" | head -1); gzip -c "$t" > "$O/kernel_trace.csv.gz"
 python tools/kernel_populations.py "$t" > "$O/populations.txt" 2>&1 || true
-python tools/trace_timeline.py "$t" ctr_head > "$O/step_timeline.txt" 2>&1 || true
+python tools/trace_timeline.py "$t" ctr_head_fold mid > "$O/step_timeline.txt" 2>&1 || true
 cp gpurun_out/prof_r06/pmc_traffic.json "$O/pmc_traffic.json"
 rm -rf gpurun_out/prof_r06/trace gpurun_out/prof_r06/pmc?
 echo "== trainer level"; timeout 300 python tools/trainer_bench.py --lines 1048576 2>/dev/null | tail -1 > "$O/trainer_bench.json"; cut -c1-400 "$O/trainer_bench.json"

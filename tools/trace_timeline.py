@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Prints the per-queue kernel timeline of the LAST step found in a rocprofv3 --kernel-trace csv
 (kernel name, queue, start offset, duration, gap to the previous kernel on the same queue) — used to see what
-overlaps with what and where a stream idles.  Usage: trace_timeline.py <kernel_trace.csv> [anchor-substring]"""
+overlaps with what and where a stream idles.  Usage: trace_timeline.py <kernel_trace.csv> [anchor-substring] [mid]
+(mid: the step in the MIDDLE of the trace instead of one of the last — bench.py's last steps carry event brackets whose
+markers show up as 7-16 us gaps; its timed region sits in the middle of the run)"""
 import csv
 import sys
 
@@ -12,7 +14,10 @@ ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name
 starts = [i for i, k in enumerate(ks) if anchor in k[2]]
 if len(starts) < 3:
     sys.exit("anchor kernel not found often enough")
-a, b = starts[-3], starts[-2]          # one full step between two anchors, not the last (teardown) one
+if len(sys.argv) > 3 and sys.argv[3] == "mid":
+    a, b = starts[len(starts) // 2], starts[len(starts) // 2 + 1]
+else:
+    a, b = starts[-3], starts[-2]      # one full step between two anchors, not the last (teardown) one
 t0 = ks[a][0]
 last_end = {}
 print("step length %.3f ms" % ((ks[b][0] - t0) / 1e6))
