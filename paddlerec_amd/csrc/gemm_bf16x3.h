@@ -569,25 +569,41 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       unsigned a, b, c;
+#ifdef REC_X3_DW_NOCVT      /* lab (timing only): the k-loop without the f32 -> 3 x bf16 arithmetic */
+      a = __float_as_uint(xv[2 * d]); b = __float_as_uint(xv[2 * d + 1]); c = a ^ b;
+#else
       x3_split_pair(x_ok ? xv[2 * d] : 0.f, x_ok ? xv[2 * d + 1] : 0.f, a, b, c);
+#endif
       p0[d] = a; p1[d] = b; p2[d] = c;
     }
+#ifdef REC_X3_DW_NOWRITE    /* lab (timing only): one LDS store per patch column and operand instead of three */
+    *reinterpret_cast<u32x4_t*>(sx) = p0 ^ p1 ^ p2;
+#else
     *reinterpret_cast<u32x4_t*>(sx) = p0;
     *reinterpret_cast<u32x4_t*>(sx + w_plane) = p1;
     *reinterpret_cast<u32x4_t*>(sx + 2 * w_plane) = p2;
+#endif
     float cs = 0.f;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const float u0 = g_ok ? gv[2 * d] : 0.f, u1 = g_ok ? gv[2 * d + 1] : 0.f;
       cs += u0 + u1;
       unsigned a, b, c;
+#ifdef REC_X3_DW_NOCVT
+      a = __float_as_uint(u0); b = __float_as_uint(u1); c = a ^ b;
+#else
       x3_split_pair(u0, u1, a, b, c);
+#endif
       p0[d] = a; p1[d] = b; p2[d] = c;
     }
     if (e == 0) csum.x += cs; else if (e == 1) csum.y += cs; else if (e == 2) csum.z += cs; else csum.w += cs;
+#ifdef REC_X3_DW_NOWRITE
+    *reinterpret_cast<u32x4_t*>(sg) = p0 ^ p1 ^ p2;
+#else
     *reinterpret_cast<u32x4_t*>(sg) = p0;
     *reinterpret_cast<u32x4_t*>(sg + w_plane) = p1;
     *reinterpret_cast<u32x4_t*>(sg + 2 * w_plane) = p2;
+#endif
   };
   auto convert_store = [&](int stage) {
 #pragma unroll
