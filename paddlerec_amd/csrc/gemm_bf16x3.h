@@ -196,6 +196,9 @@ __device__ __forceinline__ void x3_wait_group(u32x4_t (&f)[TG][3], int left) {
 #undef REC_X3_TIE
 }
 
+#ifndef REC_X3_DW_PIPE_STORES
+#define REC_X3_DW_PIPE_STORES 1      // default schedule of the weight-gradient kernel's LDS stores (REC_X3_DW_PIPE=0 / 1 at run time)
+#endif
 #ifndef REC_X3_DW_VALU_PER_MFMA
 #define REC_X3_DW_VALU_PER_MFMA 2      // conversion instructions laid behind every MFMA of the tiles that carry a patch column
                                        // (a 16-cycle MFMA leaves one wave ~2 issue slots: 3 measured 162 us against 159)
@@ -494,7 +497,7 @@ struct X3DwArgs {
 // PW x 7 tile set: the tiles behind its share (the smaller half of an odd split, the block's edge) multiply whatever
 // those LDS slots hold and are never stored — the block waits for its largest wave anyway, and a branch per MFMA costs
 // more than the MFMA (measured in the ISA: 674 branches and 725 accumulator moves with guards, none without).
-template <int PW>
+template <int PW, bool PIPE>
 __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
   extern __shared__ __attribute__((aligned(1024))) char x3_smem[];
   const int tid = threadIdx.x;
@@ -551,9 +554,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
                  w_plane = stager ? (unsigned)kX3DwPlane : 0u;
   char* const w_base = stager ? x3_smem : x3_smem + 2 * kX3Stage + tid * 16;
   if (!stager) { wr_off[0] = wr_off[1] = wr_off[2] = wr_off[3] = 0u; }
-  auto convert_part = [&](int stage, int e) {                 // column e of this thread's X and G patches
-    char* sx = w_base + stage * w_stage + wr_off[e];
-    char* sg = sx + w_oper;
+  // column e of this thread's X and G patches -> six 16-B chunks (X planes 0..2, G planes 0..2) ...
+  auto convert_compute = [&](int e, u32x4_t (&ch)[6]) {
     float xv[8], gv[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -565,7 +567,6 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
     // the source order says
     asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]),
                       "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]), "+v"(gv[4]), "+v"(gv[5]), "+v"(gv[6]), "+v"(gv[7]));
-    u32x4_t p0, p1, p2;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       unsigned a, b, c;
@@ -574,15 +575,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
 #else
       x3_split_pair(x_ok ? xv[2 * d] : 0.f, x_ok ? xv[2 * d + 1] : 0.f, a, b, c);
 #endif
-      p0[d] = a; p1[d] = b; p2[d] = c;
+      ch[0][d] = a; ch[1][d] = b; ch[2][d] = c;
     }
-#ifdef REC_X3_DW_NOWRITE    /* lab (timing only): one LDS store per patch column and operand instead of three */
-    *reinterpret_cast<u32x4_t*>(sx) = p0 ^ p1 ^ p2;
-#else
-    *reinterpret_cast<u32x4_t*>(sx) = p0;
-    *reinterpret_cast<u32x4_t*>(sx + w_plane) = p1;
-    *reinterpret_cast<u32x4_t*>(sx + 2 * w_plane) = p2;
-#endif
     float cs = 0.f;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -594,16 +588,30 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
 #else
       x3_split_pair(u0, u1, a, b, c);
 #endif
-      p0[d] = a; p1[d] = b; p2[d] = c;
+      ch[3][d] = a; ch[4][d] = b; ch[5][d] = c;
     }
     if (e == 0) csum.x += cs; else if (e == 1) csum.y += cs; else if (e == 2) csum.z += cs; else csum.w += cs;
-#ifdef REC_X3_DW_NOWRITE
-    *reinterpret_cast<u32x4_t*>(sg) = p0 ^ p1 ^ p2;
+  };
+  // ... and the chunks into the stage: the transpose happens in this write
+  auto convert_write = [&](int stage, int e, const u32x4_t (&ch)[6]) {
+    char* sx = w_base + stage * w_stage + wr_off[e];
+    char* sg = sx + w_oper;
+#ifdef REC_X3_DW_NOWRITE    /* lab (timing only): one LDS store per patch column and operand instead of three */
+    *reinterpret_cast<u32x4_t*>(sx) = ch[0] ^ ch[1] ^ ch[2];
+    *reinterpret_cast<u32x4_t*>(sg) = ch[3] ^ ch[4] ^ ch[5];
 #else
-    *reinterpret_cast<u32x4_t*>(sg) = p0;
-    *reinterpret_cast<u32x4_t*>(sg + w_plane) = p1;
-    *reinterpret_cast<u32x4_t*>(sg + 2 * w_plane) = p2;
+    *reinterpret_cast<u32x4_t*>(sx) = ch[0];
+    *reinterpret_cast<u32x4_t*>(sx + w_plane) = ch[1];
+    *reinterpret_cast<u32x4_t*>(sx + 2 * w_plane) = ch[2];
+    *reinterpret_cast<u32x4_t*>(sg) = ch[3];
+    *reinterpret_cast<u32x4_t*>(sg + w_plane) = ch[4];
+    *reinterpret_cast<u32x4_t*>(sg + 2 * w_plane) = ch[5];
 #endif
+  };
+  auto convert_part = [&](int stage, int e) {
+    u32x4_t ch[6];
+    convert_compute(e, ch);
+    convert_write(stage, e, ch);
   };
   auto convert_store = [&](int stage) {
 #pragma unroll
@@ -648,6 +656,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
     // from tile 1 on the products run across the row tiles as in the forward kernel.
     u32x4_t af[PW][3];
     u32x4_t bf[2][3];
+    u32x4_t pend[6];                                      // (REC_X3_DW_PIPE_STORES: a converted column waiting for its stores)
     x3_dw_read_u(bf[0], gb[0] + so, 0);
 #pragma unroll
     for (int u = 0; u < PW; ++u) x3_dw_read_u(af[u], xb[u & 3] + so, u);
@@ -691,7 +700,24 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_dw_kernel(X3DwArgs w) {
       REC_X3_DW_MFMA(0, 0)
 #undef REC_X3_DW_MFMA
 #ifndef REC_X3_DW_SERIAL_CONVERT
-      if (MORE && t >= kX3DwWT - 4) {
+      if constexpr (PIPE) {
+      // the chunks of a patch column are converted under one tile's MFMAs and STORED under the next tile's, one
+      // ds_write_b128 per 6 PW / 6 MFMAs (a burst of six stores from each of the four waves at the end of a tile had the
+      // waves queue for the LDS store port with the matrix pipe idle): columns 0..3 converted in tiles WT-5..WT-2,
+      // stored in tiles WT-4..WT-1
+      if (MORE && t >= kX3DwWT - 5) {
+        const bool wr = t >= kX3DwWT - 4, cv = t <= kX3DwWT - 2;
+        if (wr) convert_write(stage ^ 1, t - (kX3DwWT - 4), pend);
+        if (cv) convert_compute(t - (kX3DwWT - 5), pend);
+#pragma unroll
+        for (int i = 0; i < 6 * PW; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+          if (cv) __builtin_amdgcn_sched_group_barrier(0x002, REC_X3_DW_VALU_PER_MFMA, 0);
+          if (wr && i % PW == PW / 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // one ds_write_b128
+        }
+        if (cv) __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);       // what is left of the conversion
+      }
+      } else if (MORE && t >= kX3DwWT - 4) {
         convert_part(stage ^ 1, t - (kX3DwWT - 4));
 #pragma unroll
         for (int i = 0; i < 6 * PW; ++i) {
@@ -863,9 +889,13 @@ inline int x3_launch_dw(const X3DwPlan& pl, int kin, int nout, int64_t rows, con
   static std::atomic<bool> attr_set{false};
   constexpr int lds = 2 * kX3Stage + 4096;        // + a 16-B slot per thread for the patch-less threads' stores
   if (!attr_set.load(std::memory_order_acquire)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dw_kernel<7>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dw_kernel<7, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dw_kernel<5>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dw_kernel<5, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dw_kernel<7, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dw_kernel<5, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       (void)hipGetLastError();
       set_error("gemm_bf16x3_dw: %d B of dynamic LDS refused", lds);
@@ -876,10 +906,13 @@ inline int x3_launch_dw(const X3DwPlan& pl, int kin, int nout, int64_t rows, con
   X3DwArgs w{X, ldx, G, ldg, rows, kin, nout, pl.kb_tiles, pl.nb_tiles, pl.kblocks, pl.nblocks, pl.slices,
              pl.steps_per_slice, P, ldp, cpart};
   const unsigned grid = (unsigned)(pl.slices * pl.kblocks * pl.nblocks);
-  if ((pl.kb_tiles + 1) / 2 <= 5)
-    hipLaunchKernelGGL(gemm_bf16x3_dw_kernel<5>, dim3(grid), dim3(256), lds, st, w);
-  else
-    hipLaunchKernelGGL(gemm_bf16x3_dw_kernel<7>, dim3(grid), dim3(256), lds, st, w);
+  // REC_X3_DW_PIPE=0: the round-5 schedule (a column's six LDS stores in one burst behind its conversion) for A/B runs
+  static const bool pipe = [] { const char* v = getenv("REC_X3_DW_PIPE"); return v && *v ? *v != '0' : REC_X3_DW_PIPE_STORES != 0; }();
+  const bool p5 = (pl.kb_tiles + 1) / 2 <= 5;
+  if (p5 && pipe) hipLaunchKernelGGL((gemm_bf16x3_dw_kernel<5, true>), dim3(grid), dim3(256), lds, st, w);
+  else if (p5) hipLaunchKernelGGL((gemm_bf16x3_dw_kernel<5, false>), dim3(grid), dim3(256), lds, st, w);
+  else if (pipe) hipLaunchKernelGGL((gemm_bf16x3_dw_kernel<7, true>), dim3(grid), dim3(256), lds, st, w);
+  else hipLaunchKernelGGL((gemm_bf16x3_dw_kernel<7, false>), dim3(grid), dim3(256), lds, st, w);
   return check_launch("gemm_bf16x3_dw_kernel");
 }
 
