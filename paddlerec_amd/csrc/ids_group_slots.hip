@@ -97,16 +97,31 @@ __global__ __launch_bounds__(kKeyRows) void keys_kernel(int64_t B, int S, int64_
   int r = tid / S, s = tid % S;
   const int dr = kKeyRows / S, ds = kKeyRows % S;
   int oob = 0;
-  for (int i = tid; i < total; i += kKeyRows) {
-    const int64_t id = src[i];
-    uint32_t key = kNoKey;
-    if (id != pad || pad < 0) {
-      if (id >= 0 && id < R) key = (uint32_t)id; else oob = 1;
+  // eight ids in flight per thread (one dependent load per trip took 26 trips of a memory latency that is several
+  // microseconds beside the lookup kernel this one runs next to)
+  constexpr int U = 8;
+  for (int i0 = tid; i0 < total; i0 += U * kKeyRows) {
+    int64_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * kKeyRows;
+      v[u] = src[i < total ? i : tid];
     }
-    key_tile[r * pitch + s] = key;
-    if (rank && key == kNoKey) rank[b0 * S + i] = -1;
-    r += dr; s += ds;
-    if (s >= S) { s -= S; ++r; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * kKeyRows;
+      if (i < total) {
+        const int64_t id = v[u];
+        uint32_t key = kNoKey;
+        if (id != pad || pad < 0) {
+          if (id >= 0 && id < R) key = (uint32_t)id; else oob = 1;
+        }
+        key_tile[r * pitch + s] = key;
+        if (rank && key == kNoKey) rank[b0 * S + i] = -1;
+        r += dr; s += ds;
+        if (s >= S) { s -= S; ++r; }
+      }
+    }
   }
   if (oob) atomicOr(status, REC_FLAG_INDEX_OOB);
   __syncthreads();
