@@ -781,9 +781,21 @@ typedef struct {
   const void* b_image;      /* NULL, or the bf16 x 3 image of THIS call's op(B) made by rec_gemm_b_images (same k, n,
                                trans_b, current values of B): the call then skips its own split launch and does not
                                write the workspace.  Ignored by calls that do not take the bf16 x 3 forward / dX kernel */
+  void* relu_bits;          /* NULL, or rec_gemm_relu_bits_bytes(desc) bytes of device memory (8-byte aligned): the ReLU
+                               mask of an activation as BITS.  A REC_EPI_BIAS_RELU call WRITES it beside C (one 64-bit word
+                               per row, column block and lane group of the bf16 x 3 kernel); a REC_EPI_RELU_MASK call with
+                               the same m and n READS it instead of aux0 (which may then be NULL): the dX GEMM of a tower
+                               fetches 4 MB of bits where it fetched the 105 MB activation.  Same results bit for bit.
+                               Only calls for which rec_gemm_relu_bits_bytes reports eligible = 1 (both sides take the
+                               bf16 x 3 forward / dX kernel); any other call given relu_bits fails with REC_EINVAL */
 } rec_gemm_epilogue_args;
 
 int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* bytes);
+/* Host query: *eligible = 1 and the size of rec_gemm_epilogue_args.relu_bits for this call (REC_EPI_BIAS_RELU or
+ * REC_EPI_RELU_MASK on the bf16 x 3 forward / dX kernel), else 0 / 0.  The layout depends on m and n only: the mask a
+ * forward call with (m, n) wrote is the one a dX call with the same (m, n) reads
+ * (deepfm/net.py:142-174: Linear -> ReLU, and the ReLU' of its backward). */
+int rec_gemm_relu_bits_bytes(const rec_gemm_desc* desc, int32_t* eligible, size_t* bytes);
 /* Host query: the split-K factor the planner picks for `desc` (its split_k ignored) when the GEMM may use
  * num_cus compute units (<= 0: the whole chip) — one resident round of blocks.  A caller that runs the GEMM on
  * a CU-restricted stream (rec_stream_create_cu_range) passes the result as desc->split_k. */

@@ -155,7 +155,7 @@ class GemmEpilogueArgs(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("aux0", C.c_void_p), ("ld_aux0", C.c_int32),
                 ("aux1", C.c_void_p), ("ld_aux1", C.c_int32), ("row_scale", C.c_void_p),
                 ("row_scale_stride", C.c_int32), ("out2", C.c_void_p), ("ld_out2", C.c_int32),
-                ("b_colsum", C.c_void_p), ("b_image", C.c_void_p)]
+                ("b_colsum", C.c_void_p), ("b_image", C.c_void_p), ("relu_bits", C.c_void_p)]
 
 
 class GemmBImage(C.Structure):
@@ -281,6 +281,7 @@ SIGNATURES = {
     "rec_shard_route": (C.c_int, [_I64, _I32, _I64, _I64, _I32] + [_P] * 9 + [_SZ, _P]),
     "rec_gemm_f32_workspace_bytes": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(_SZ)]),
     "rec_gemm_plan_splits": (C.c_int, [C.POINTER(GemmDesc), _I32, C.POINTER(_I32)]),
+    "rec_gemm_relu_bits_bytes": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(_I32), C.POINTER(_SZ)]),
     "rec_gemm_b_image_bytes": (C.c_int, [_I32, _I32, C.POINTER(_I32), C.POINTER(_SZ)]),
     "rec_gemm_b_images": (C.c_int, [_I32, C.POINTER(GemmBImage), _P]),
     "rec_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, C.POINTER(GemmEpilogueArgs), _P, _SZ, _P]),

@@ -388,6 +388,15 @@ __global__ __launch_bounds__(WM * WN * 64, WN == 1 ? 2 : 1) void gemm_bf16x3_ker
     const bool row_ok = i < M;
     const int64_t ic = row_ok ? i : M - 1;
     f32x4_t x0[NT], x1[EpiUses<EPI>::aux1 ? NT : 1], bj[NT];
+    // ReLU mask as BITS (rec_gemm_epilogue_args.relu_bits): the forward of a layer (BIAS_RELU) leaves one 64-bit word per
+    // (row, column block, lane group g) — bit 4 t + c = "column n_base + 16 t + c of the output is > 0" — and the dX GEMM
+    // that needs the layer's ReLU' (RELU_MASK: same N, hence the same column blocks and the same lane <-> element map)
+    // reads ITS OWN word back instead of the whole activation: 8 B per lane and row tile for NT float4 loads
+    unsigned long long* bits_at = epi.relu_bits ? epi.relu_bits + ((ic * ncb + (cb0 + wn)) * 4 + g) : nullptr;
+    unsigned long long mbits = 0ull;
+    if constexpr (EPI == REC_EPI_RELU_MASK) {
+      if (bits_at) mbits = *bits_at;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int j = n_base + t * 16;
@@ -396,6 +405,13 @@ __global__ __launch_bounds__(WM * WN * 64, WN == 1 ? 2 : 1) void gemm_bf16x3_ker
       for (int c = 0; c < 4; ++c) bj[t][c] = load_bias<EPI>(jc + c, epi);
       if constexpr (EPI == REC_EPI_ADD) {                    // aux0 may be absent (gemm_epi.h load_aux0)
         x0[t] = epi.aux0 ? *reinterpret_cast<const f32x4_t*>(epi.aux0 + ic * epi.ld0 + jc) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      } else if constexpr (EPI == REC_EPI_RELU_MASK) {
+        if (bits_at) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) x0[t][c] = ((mbits >> (4 * t + c)) & 1ull) ? 1.f : 0.f;
+        } else {
+          x0[t] = *reinterpret_cast<const f32x4_t*>(epi.aux0 + ic * epi.ld0 + jc);
+        }
       } else if constexpr (EpiUses<EPI>::aux0) {
         x0[t] = *reinterpret_cast<const f32x4_t*>(epi.aux0 + ic * epi.ld0 + jc);
       } else {
@@ -412,6 +428,7 @@ __global__ __launch_bounds__(WM * WN * 64, WN == 1 ? 2 : 1) void gemm_bf16x3_ker
         const float xx1 = EpiUses<EPI>::aux1 ? x1[EpiUses<EPI>::aux1 ? t : 0][c] : 0.f;
         v[c] = apply_epi<EPI>(acc[a][t][c], x0[t][c], xx1, bj[t][c], ic, epi);
         u[c] = acc[a][t][c] + bj[t][c];
+        if constexpr (EPI == REC_EPI_BIAS_RELU) mbits |= (unsigned long long)(v[c] > 0.f ? 1 : 0) << (4 * t + c);
       }
 #if REC_X3_LAB == 1      // lab: the kernel without its C stores (the compare keeps the epilogue arithmetic alive)
       if (row_ok && j < N && v[0] == 1.2345678e33f) {
@@ -423,6 +440,9 @@ __global__ __launch_bounds__(WM * WN * 64, WN == 1 ? 2 : 1) void gemm_bf16x3_ker
           if (epi.out2) *reinterpret_cast<f32x4_t*>(epi.out2 + i * epi.ld2 + j) = u;
         }
       }
+    }
+    if constexpr (EPI == REC_EPI_BIAS_RELU) {
+      if (bits_at && row_ok) *bits_at = mbits;
     }
   }
 }
@@ -776,6 +796,9 @@ inline int x3_launch_split(const float* W, int64_t ldw, int K, int N, int trans,
                      trans, img, nkt, np, ncb);
   return check_launch("x3_split_kernel");
 }
+
+// bytes of the ReLU bit mask of an [M, N] activation (one 64-bit word per row, column block and lane group)
+inline size_t x3_relu_bits_bytes(int64_t M, int N) { return (size_t)M * (2 * x3_cols(N).ncb) * 4 * sizeof(unsigned long long); }
 
 inline bool x3_shape_ok(int64_t M, int N, int K, int64_t lda, int64_t ldc, const void* A, const void* C) {
   return M > 0 && N > 0 && x3_cols(N).nt > 0 && N % 4 == 0 && K > 0 && K % 8 == 0 && lda % 4 == 0 && ldc % 4 == 0 &&

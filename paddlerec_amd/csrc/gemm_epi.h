@@ -95,6 +95,7 @@ struct EpiArgs {
   float* out2;             // [M,ldc] or null: CROSS also stores u = acc + bias (saved for backward)
   int ld0, ld1, rs_stride, ld2;
   int nt_store;            // 1: the whole-tile kernel writes C with non-temporal stores (gemm_f32.hip: the dX + ReLU' form)
+  unsigned long long* relu_bits;   // bf16 x 3 forward / dX kernel only (gemm_bf16x3.h): BIAS_RELU writes, RELU_MASK reads the mask bits
 };
 
 // which per-element operands an epilogue reads besides the accumulator

@@ -919,6 +919,20 @@ static size_t plain_workspace_bytes(const rec_gemm_desc* desc) {
          align_up((size_t)p.splits * desc->n * sizeof(float), 256);
 }
 
+// a forward / dX call whose ReLU mask may travel as bits: it takes the bf16 x 3 forward / dX kernel
+static bool relu_bits_ok(const rec_gemm_desc* d) {
+  return (d->epilogue == REC_EPI_BIAS_RELU || d->epilogue == REC_EPI_RELU_MASK) && x3_eligible(d) && d->lda % 4 == 0 &&
+         d->ldc % 4 == 0;
+}
+extern "C" int rec_gemm_relu_bits_bytes(const rec_gemm_desc* desc, int32_t* eligible, size_t* bytes) {
+  if (int rc = check_gemm(desc)) return rc;
+  REC_REQUIRE(bytes, REC_EINVAL, "bytes is NULL");
+  const bool ok = relu_bits_ok(desc);
+  if (eligible) *eligible = ok ? 1 : 0;
+  *bytes = ok ? align_up(x3_relu_bits_bytes(desc->m, desc->n), 256) : 0;
+  return REC_OK;
+}
+
 extern "C" int rec_gemm_f32_workspace_bytes(const rec_gemm_desc* desc, size_t* bytes) {
   if (int rc = check_gemm(desc)) return rc;
   REC_REQUIRE(bytes, REC_EINVAL, "bytes is NULL");
@@ -1030,8 +1044,13 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
   REC_REQUIRE(!(epi == REC_EPI_BIAS || epi == REC_EPI_BIAS_RELU || epi == REC_EPI_CROSS ||
                 epi == REC_EPI_BIAS_SIGMOID || epi == REC_EPI_MOE) || bias, REC_EINVAL,
               "epilogue needs bias");
+  unsigned long long* relu_bits = (unsigned long long*)x->relu_bits;
+  REC_REQUIRE(!relu_bits || ((epi == REC_EPI_BIAS_RELU || epi == REC_EPI_RELU_MASK) && relu_bits_ok(desc) &&
+                             ((uintptr_t)relu_bits) % 8 == 0), REC_EINVAL,
+              "relu_bits: only a BIAS_RELU / RELU_MASK call that takes the bf16 x 3 forward / dX kernel "
+              "(rec_gemm_relu_bits_bytes says which)");
   REC_REQUIRE(!(epi == REC_EPI_RELU_MASK || epi == REC_EPI_CROSS || epi == REC_EPI_MOE ||
-                epi == REC_EPI_DSIGMOID || epi == REC_EPI_DTANH) ||
+                epi == REC_EPI_DSIGMOID || epi == REC_EPI_DTANH) || (epi == REC_EPI_RELU_MASK && relu_bits) ||
                   (aux0 && ld_aux0 >= desc->n), REC_EINVAL, "epilogue needs aux0");
   REC_REQUIRE(!(epi == REC_EPI_CROSS || epi == REC_EPI_ADD || epi == REC_EPI_MOE) ||
                   (aux1 && ld_aux1 >= desc->n), REC_EINVAL, "epilogue needs aux1");
@@ -1043,7 +1062,7 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
   // profiles/r04_gemm_variants.txt), 2: for every whole-tile GEMM; default off
   static const int nt_env = [] { const char* v = getenv("REC_GEMM_NT_STORE"); return v && *v ? atoi(v) : 0; }();
   const int nt_store = nt_env == 2 || (nt_env == 1 && epi == REC_EPI_RELU_MASK) ? 1 : 0;
-  EpiArgs e{bias, aux0, aux1, x->row_scale, x->out2, ld_aux0, ld_aux1, x->row_scale_stride, x->ld_out2, nt_store};
+  EpiArgs e{bias, aux0, aux1, x->row_scale, x->out2, ld_aux0, ld_aux1, x->row_scale_stride, x->ld_out2, nt_store, relu_bits};
   REC_REQUIRE(!x->out2 || x->ld_out2 >= desc->n, REC_EINVAL, "bad ld_out2");
   if (skinny_rows(desc) && !b_colsum) {
     const bool vec_a = desc->lda % 4 == 0 && ((uintptr_t)A) % 16 == 0 && desc->k % 4 == 0;
@@ -1086,6 +1105,8 @@ extern "C" int rec_gemm_f32(const rec_gemm_desc* desc, const float* A, const flo
   // tall problems of the towers' own widths: whole row panels, one resident round (gemm_panel.h)
   if (!b_colsum && launch_x3(desc, A, B, C, e, x->b_image, workspace, workspace_bytes, st))
     return check_launch("rec_gemm_f32 (bf16x3)");
+  // (no other kernel knows the bit mask: a call that asked for it never continues on one that would ignore it)
+  REC_REQUIRE(!relu_bits, REC_EINVAL, "relu_bits: the call did not take the bf16 x 3 kernel (alignment / workspace)");
   if (!b_colsum && launch_panel(desc, A, B, C, e, st, device_cus())) return check_launch("rec_gemm_f32 (panel)");
   if (!b_colsum && launch_glds(desc, A, B, C, e, st)) return check_launch("rec_gemm_f32 (glds)");
   // the launch-bound sizes (the reference's own batches): one launch, a wave per 16 x 16 tile over the whole K (gemm_direct.h)

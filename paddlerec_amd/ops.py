@@ -1513,21 +1513,36 @@ class GemmImages:
 
 
 def gemm(A, B, ws, trans_a=False, trans_b=False, epilogue="none", bias=None, aux0=None, aux1=None,
-         out=None, split_k=0, b_colsum=None, row_scale=None, out2=None, num_cus=0, b_image=None):
+         out=None, split_k=0, b_colsum=None, row_scale=None, out2=None, num_cus=0, b_image=None, relu_bits=None):
     """out[M,N] = epi(op(A) @ op(B)); A/B/out row-major (row strides allowed).
     trans_a: A is given as [K,M]; trans_b: B is given as [N,K] (a torch Linear.weight, or W for dX).
     num_cus > 0: the current stream is confined to that many compute units (cu_range_stream) — size the
     split-K for them instead of the whole chip.
-    b_image: op(B)'s bf16 x 3 image from GemmImages (current values of B): the call skips its own split launch."""
+    b_image: op(B)'s bf16 x 3 image from GemmImages (current values of B): the call skips its own split launch.
+    relu_bits: the ReLU mask as bits (rec_gemm_epilogue_args.relu_bits).  epilogue "bias_relu": a LIST — the call appends
+    the mask tensor it wrote beside `out` (or None when this call has no bit form); "relu_mask": such a tensor (or None):
+    read instead of aux0 when this call has the bit form."""
     d, x, out, need = _gemm_prepare(A, B, trans_a, trans_b, epilogue, bias, aux0, aux1, out, split_k, b_colsum, row_scale,
                                     out2, num_cus, b_image)
+    if relu_bits is not None:
+        nb = _relu_bits_bytes(d)
+        if epilogue == "bias_relu":
+            t = torch.empty(nb // 8, dtype=torch.int64, device=A.device) if nb else None
+            relu_bits.append(t)
+            relu_bits = t
+        elif nb == 0 or relu_bits.numel() * 8 < nb:
+            relu_bits = None
+        if relu_bits is not None:
+            x.relu_bits = relu_bits.data_ptr()
+            if _recorder is not None:
+                _recorder.keep.append(relu_bits)
     w = ws.get(need)
     check(lib().rec_gemm_f32(C.byref(d), _p(A), _p(B), _p(out), C.byref(x), _p(w),
                              C.c_size_t(w.numel()), _stream()), "rec_gemm_f32")
     return out
 
 
-def linear_backward(X, G, W, ws, dW, db, relu_src=None, b_image=None, epilogue=None, aux0=None):
+def linear_backward(X, G, W, ws, dW, db, relu_src=None, b_image=None, epilogue=None, aux0=None, relu_bits=None):
     """The backward of one Linear in ONE call (rec_gemm_f32_pair): dW = X^T G, db = colsum(G) and
     dX = G W^T (masked by relu_src > 0 — the layer's own input — when given; or any dX epilogue of gemm(): epilogue=
     "dsigmoid", aux0=the layer's input).  -> dX.  At launch-bound sizes the two GEMMs are one launch; otherwise exactly the
@@ -1536,10 +1551,32 @@ def linear_backward(X, G, W, ws, dW, db, relu_src=None, b_image=None, epilogue=N
         epilogue, aux0 = ("relu_mask", relu_src) if relu_src is not None else ("none", None)
     d0, x0, _, need0 = _gemm_prepare(X, G, True, False, "none", None, None, None, dW, 0, db, None, None, 0, None)
     d1, x1, dX, need1 = _gemm_prepare(G, W, False, True, epilogue, None, aux0, None, None, 0, None, None, None, 0, b_image)
+    if relu_bits is not None and epilogue == "relu_mask":      # relu_src's mask as bits (mlp_forward), where dX has the bit form
+        nb = _relu_bits_bytes(d1)
+        if nb and relu_bits.numel() * 8 >= nb:
+            x1.relu_bits = relu_bits.data_ptr()
+            if _recorder is not None:
+                _recorder.keep.append(relu_bits)
     w = ws.get(max(need0, need1))
     check(lib().rec_gemm_f32_pair(C.byref(d0), _p(X), _p(G), _p(dW), C.byref(x0), C.byref(d1), _p(G), _p(W), _p(dX),
                                   C.byref(x1), _p(w), C.c_size_t(w.numel()), _stream()), "rec_gemm_f32_pair")
     return dX
+
+
+_relu_bits_cache = {}
+
+
+def _relu_bits_bytes(d):
+    """Bytes of the ReLU bit mask of this call, 0 when it has no bit form (or REC_RELU_BITS=0)."""
+    if os.environ.get("REC_RELU_BITS") == "0":
+        return 0
+    key = (d.m, d.n, d.k, d.lda, d.ldb, d.ldc, d.trans_a, d.trans_b, d.epilogue, d.split_k, os.environ.get("REC_GEMM_BF16X3"))
+    nb = _relu_bits_cache.get(key)
+    if nb is None:
+        ok, nbytes = C.c_int32(0), C.c_size_t(0)
+        check(lib().rec_gemm_relu_bits_bytes(C.byref(d), C.byref(ok), C.byref(nbytes)), "rec_gemm_relu_bits_bytes")
+        nb = _relu_bits_cache[key] = nbytes.value if ok.value else 0
+    return nb
 
 
 def _gemm_prepare(A, B, trans_a, trans_b, epilogue, bias, aux0, aux1, out, split_k, b_colsum, row_scale, out2, num_cus,
@@ -1612,20 +1649,32 @@ def colsum(G, ws, out=None):
 
 
 # ------------------------------------------------------------------ top MLP on the GEMM above
+class _Acts(list):
+    """mlp_forward's list of layer inputs; relu_bits[j] = the ReLU mask of acts[j] as bits, for mlp_backward's dX GEMMs."""
+    relu_bits = None
+
+
 def mlp_forward(x, weights, biases, ws, relu_last=False, out_last=None, images=None):
     """Linear(+bias)->ReLU ... ->Linear (deepfm/net.py:142-174) with Paddle-layout weights [in,out];
     bias and ReLU run in the GEMM epilogue.  relu_last: ReLU after the last layer too (the DNN tower of
     dcn_v2/net.py:161-184); out_last: buffer (view) for the last layer's output.
     images[i]: the bf16 x 3 image of weights[i] (GemmImages, current values) or None.
     Returns (y, acts): acts[i] = input of layer i."""
-    acts = []
+    acts = _Acts()
+    bits = [None]                      # bits[j]: the ReLU mask of acts[j] as bits (gemm(relu_bits=)), or None
     n = len(weights)
     for i in range(n):
         acts.append(x)
         last = i == n - 1
-        x = gemm(x, weights[i], ws, epilogue="bias_relu" if (not last or relu_last) else "bias",
-                 bias=biases[i], out=out_last if last else None, b_image=images[i] if images is not None else None)
-    return x, acts + [x]
+        relu = not last or relu_last
+        x = gemm(x, weights[i], ws, epilogue="bias_relu" if relu else "bias",
+                 bias=biases[i], out=out_last if last else None, b_image=images[i] if images is not None else None,
+                 relu_bits=bits if relu else None)
+        if not relu:
+            bits.append(None)
+    acts.append(x)
+    acts.relu_bits = bits
+    return x, acts
 
 
 def mlp_head_bwd(act, dz, w, ws, dw, db, relu=True, out=None):
@@ -1700,6 +1749,8 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
     n = len(weights)
     g = dy
     imt = (lambda i: images_t[i]) if images_t is not None else (lambda i: None)   # images of weights[i]^T (the dX GEMMs)
+    rbl = getattr(acts, "relu_bits", None)
+    rb = (lambda i: rbl[i]) if rbl is not None else (lambda i: None)              # ReLU mask of acts[i] as bits
     head = n > 1 and _head_ok(acts[n - 1], weights[n - 1], dws[n - 1], dbs[n - 1], dy)
     if head:
         # the one-logit head: dX (with the ReLU mask of the layer in front), dW and db in ONE pass over its input
@@ -1712,7 +1763,7 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
         for i in reversed(range(n_run)):
             gs[i] = g
             g = gemm(g, weights[i], ws, trans_b=True, b_image=imt(i),
-                     **(dict(epilogue="relu_mask", aux0=acts[i]) if i > 0 else {}))
+                     **(dict(epilogue="relu_mask", aux0=acts[i], relu_bits=rb(i)) if i > 0 else {}))
 
         def finish(num_cus=0):
             for i in reversed(range(n_run)):
@@ -1745,10 +1796,10 @@ def mlp_backward(dy, acts, weights, dws, dbs, ws, defer_first=False, defer_all=F
         else:
             # dW = X^T G, db = colsum(G) and dX = G W^T (+ ReLU') in one call: one launch at launch-bound sizes
             g = linear_backward(acts[i], g, weights[i], ws, dws[i], dbs[i], relu_src=acts[i] if i > 0 else None,
-                                b_image=imt(i))
+                                b_image=imt(i), relu_bits=rb(i) if i > 0 else None)
             continue
         if i > 0:
-            g = gemm(g, weights[i], ws, trans_b=True, epilogue="relu_mask", aux0=acts[i], b_image=imt(i))
+            g = gemm(g, weights[i], ws, trans_b=True, epilogue="relu_mask", aux0=acts[i], b_image=imt(i), relu_bits=rb(i))
         else:
             g = gemm(g, weights[i], ws, trans_b=True, b_image=imt(i))
     join()

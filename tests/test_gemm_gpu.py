@@ -537,3 +537,50 @@ def test_gemm_nonfinite_operands(ops, monkeypatch):
         assert np.all(np.isnan(x[r])), r
         assert np.all(xr[r] == 0), r
     assert not np.array_equal(out["0", "none"][plain], out["1", "none"][plain])     # the switch really switched
+
+
+@pytest.mark.parametrize("M,N,K", [(8192 + 64, 400, 400), (16384 - 16, 400, 432), (8192, 512, 256), (9000, 368, 400)])
+def test_gemm_relu_bits(ops, monkeypatch, M, N, K):
+    """rec_gemm_epilogue_args.relu_bits: the BIAS_RELU forward leaves the ReLU mask of its output as bits, the RELU_MASK dX
+    GEMM with the same (m, n) reads them instead of the activation — the same result bit for bit (deepfm/net.py:142-174:
+    Linear -> ReLU and the ReLU' of its backward); calls without the bit form say so instead of ignoring the argument."""
+    monkeypatch.setenv("REC_GEMM_BF16X3", "1")
+    rng = np.random.default_rng(M + N)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+    X, W, b = t(_mk(rng, M, K)), t(_mk(rng, K, N)), t(_mk(rng, N))
+    ws = ops.Workspace(DEV)
+    holder = []
+    Y = ops.gemm(X, W, ws, epilogue="bias_relu", bias=b, relu_bits=holder)
+    assert len(holder) == 1 and holder[0] is not None, "no bit form for a tall forward call"
+    assert torch.equal(Y, ops.gemm(X, W, ws, epilogue="bias_relu", bias=b))             # the output itself is unchanged
+    assert 0.2 < float((Y > 0).float().mean()) < 0.8
+    # the backward of the NEXT layer: dY_in [M, N2] @ W2^T [N2, N] masked by Y > 0
+    N2 = 400
+    G, W2 = t(_mk(rng, M, N2)), t(_mk(rng, N, N2))
+    want = ops.gemm(G, W2, ws, trans_b=True, epilogue="relu_mask", aux0=Y)
+    got = ops.gemm(G, W2, ws, trans_b=True, epilogue="relu_mask", aux0=Y, relu_bits=holder[0])
+    assert torch.equal(want, got)
+    # aux0 may be absent when the bits are given
+    d, x, out, need = ops._gemm_prepare(G, W2, False, True, "relu_mask", None, None, None, None, 0, None, None, None, 0, None)
+    x.relu_bits = holder[0].data_ptr()
+    w = ws.get(need)
+    import ctypes as C
+    ops.check(ops.lib().rec_gemm_f32(C.byref(d), ops._p(G), ops._p(W2), ops._p(out), C.byref(x), ops._p(w),
+                                     C.c_size_t(w.numel()), ops._stream()), "rec_gemm_f32")
+    assert torch.equal(want, out)
+    # a call without the bit form (a short batch runs on the exact-f32 kernels): Python says None, the C entry refuses
+    Xs = X[:512].contiguous()
+    h2 = []
+    ops.gemm(Xs, W, ws, epilogue="bias_relu", bias=b, relu_bits=h2)
+    assert h2 == [None]
+    d, x, out, need = ops._gemm_prepare(Xs, W, False, False, "bias_relu", b, None, None, None, 0, None, None, None, 0, None)
+    x.relu_bits = holder[0].data_ptr()
+    w = ws.get(need)
+    rc = ops.lib().rec_gemm_f32(C.byref(d), ops._p(Xs), ops._p(W), ops._p(out), C.byref(x), ops._p(w),
+                                C.c_size_t(w.numel()), ops._stream())
+    assert rc != 0
+    # the switch: REC_RELU_BITS=0 keeps every mask on the activation
+    monkeypatch.setenv("REC_RELU_BITS", "0")
+    h3 = []
+    ops.gemm(X, W, ws, epilogue="bias_relu", bias=b, relu_bits=h3)
+    assert h3 == [None]
