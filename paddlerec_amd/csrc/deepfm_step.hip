@@ -101,6 +101,9 @@ struct Buffers {
   // at the top of the step (deepfm.py:_refresh_weights); NULL where the shape has no image form or the batch is short
   void* img_f[REC_DEEPFM_MAX_LINEAR];
   void* img_t[REC_DEEPFM_MAX_LINEAR];
+  // relu_bits[i]: the ReLU mask of act[i] as bits (rec_gemm_epilogue_args.relu_bits: written by the forward GEMM of layer
+  // i - 1, read by the dX GEMM of layer i), NULL where either call has no bit form (ops.mlp_forward / mlp_backward)
+  void* relu_bits[REC_DEEPFM_MAX_LINEAR];
 };
 
 // the largest workspace any single call of the step asks for
@@ -201,6 +204,20 @@ int carve(const rec_deepfm_net* net, const Shape& s, int64_t B, void* workspace,
       in = w;
     }
   }
+  static const bool bits_env = [] { const char* v = getenv("REC_RELU_BITS"); return !(v && *v == '0'); }();
+  for (int i = 0; i < s.n; ++i) {
+    bf->relu_bits[i] = nullptr;
+    if (i == 0 || !bits_env) continue;
+    // act[i] = ReLU output of layer i - 1 ([B, widths[i-1]], K = its input width) and mask of the dX GEMM of layer i
+    const int wi = net->widths[i - 1], kin = i == 1 ? s.in0 : net->widths[i - 2];
+    rec_gemm_desc df{B, wi, kin, kin, wi, wi, 0, 0, REC_EPI_BIAS_RELU, 0, 0};
+    rec_gemm_desc db{B, wi, net->widths[i], net->widths[i], net->widths[i], wi, 0, 1, REC_EPI_RELU_MASK, 0, 0};
+    int32_t okf = 0, okb = 0;
+    size_t nf = 0, nb = 0;
+    if (rec_gemm_relu_bits_bytes(&df, &okf, &nf) == REC_OK && rec_gemm_relu_bits_bytes(&db, &okb, &nb) == REC_OK && okf && okb &&
+        nf == nb)
+      bf->relu_bits[i] = c.bytes(nf);
+  }
   size_t cw = 0;
   if (int rc = call_workspace(net, s, B, &cw)) return rc;
   bf->ws = c.bytes(cw);
@@ -220,7 +237,7 @@ int carve(const rec_deepfm_net* net, const Shape& s, int64_t B, void* workspace,
 // C = epi(op(A) @ op(B)) on contiguous operands (the step's own buffers and parameter views)
 int gemm(int64_t m, int n, int k, bool ta, bool tb, int epi, const float* A, const float* Bm, float* C,
          const float* bias, const float* aux0, int ld0, float* b_colsum, int split_k, const Buffers& bf, void* st,
-         const void* b_image = nullptr, int num_cus = 0) {
+         const void* b_image = nullptr, int num_cus = 0, void* relu_bits = nullptr) {
   rec_gemm_desc d{};
   d.num_cus = num_cus;
   d.m = m; d.n = n; d.k = k;
@@ -229,20 +246,21 @@ int gemm(int64_t m, int n, int k, bool ta, bool tb, int epi, const float* A, con
   d.ldc = n;
   d.trans_a = ta; d.trans_b = tb; d.epilogue = epi; d.split_k = split_k;
   rec_gemm_epilogue_args x{};
-  x.bias = bias; x.aux0 = aux0; x.ld_aux0 = ld0; x.b_colsum = b_colsum; x.b_image = b_image;
+  x.bias = bias; x.aux0 = aux0; x.ld_aux0 = ld0; x.b_colsum = b_colsum; x.b_image = b_image; x.relu_bits = relu_bits;
   return rec_gemm_f32(&d, A, Bm, C, &x, bf.ws, bf.ws_bytes, st);
 }
 
 // the backward of one Linear in one call (ops.linear_backward): dW = X^T G + db, and dX = G W^T (+ ReLU' by `mask`)
 int linear_backward(int64_t B, int in, int w, const float* X, const float* G, const float* W, float* dW, float* db,
-                    float* dX, const float* mask, const Buffers& bf, void* st, const void* b_image_t) {
+                    float* dX, const float* mask, const Buffers& bf, void* st, const void* b_image_t,
+                    void* mask_bits = nullptr) {
   rec_gemm_desc d0{}, d1{};
   d0.m = in; d0.n = w; d0.k = (int)B; d0.lda = in; d0.ldb = w; d0.ldc = w; d0.trans_a = 1; d0.epilogue = REC_EPI_NONE;
   d1.m = B; d1.n = in; d1.k = w; d1.lda = w; d1.ldb = w; d1.ldc = in; d1.trans_b = 1;
   d1.epilogue = mask ? REC_EPI_RELU_MASK : REC_EPI_NONE;
   rec_gemm_epilogue_args x0{}, x1{};
   x0.b_colsum = db;
-  x1.aux0 = mask; x1.ld_aux0 = mask ? in : 0; x1.b_image = b_image_t;
+  x1.aux0 = mask; x1.ld_aux0 = mask ? in : 0; x1.b_image = b_image_t; x1.relu_bits = mask ? mask_bits : nullptr;
   return rec_gemm_f32_pair(&d0, X, G, dW, &x0, &d1, G, W, dX, &x1, bf.ws, bf.ws_bytes, st);
 }
 
@@ -386,7 +404,8 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
       const bool last = i == n - 1;
       float* out = last ? bf.y_dnn : bf.act[i + 1];
       REC_TRY(gemm(B, net->widths[i], in, false, false, last ? REC_EPI_BIAS : REC_EPI_BIAS_RELU, bf.act[i],
-                   i == 0 ? w0 : net->w[i], out, net->b[i], nullptr, 0, nullptr, 0, bf, stream, bf.img_f[i]));
+                   i == 0 ? w0 : net->w[i], out, net->b[i], nullptr, 0, nullptr, 0, bf, stream, bf.img_f[i], 0,
+                   last ? nullptr : bf.relu_bits[i + 1]));
       in = net->widths[i];
     }
   }
@@ -456,7 +475,7 @@ extern "C" int rec_deepfm_train_step(const rec_deepfm_net* net, int64_t batch, c
       break;
     }
     REC_TRY(linear_backward(B, in, w, bf.act[i], g, net->w[i], net->gw[i], net->gb[i], bf.g[gi], bf.act[i], bf, stream,
-                            bf.img_t[i]));
+                            bf.img_t[i], bf.relu_bits[i]));
     g = bf.g[gi];
     gi ^= 1;
   }
